@@ -1,0 +1,331 @@
+"""ctypes binding for the CPU oracle (TEST INFRASTRUCTURE).
+
+Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg import
+this module. The product package (zolt_amd/) must never import it.
+
+Arrays are numpy uint64: field elements are (..., 4) Montgomery limbs, affine
+points (..., 8) (x limbs, y limbs) plus a uint8 infinity flag array.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+FR, FP = 0, 1
+
+
+def _cpu_has(*flags):
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    have = set(line.split(":", 1)[1].split())
+                    return all(fl in have for fl in flags)
+    except OSError:
+        pass
+    return False
+
+
+def build():
+    subprocess.check_call(["make", "-C", _HERE, "all"], stdout=subprocess.DEVNULL)
+
+
+def _load():
+    v3 = os.path.join(_HERE, "libzolt_oracle_v3.so")
+    v2 = os.path.join(_HERE, "libzolt_oracle.so")
+    if not os.path.exists(v2):
+        build()
+    path = v3 if (os.path.exists(v3) and _cpu_has("bmi2", "adx", "avx2")) else v2
+    return C.CDLL(path), path
+
+
+lib, LIB_PATH = _load()
+
+_u64p = C.POINTER(C.c_uint64)
+_u8p = C.POINTER(C.c_uint8)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_u64p)
+
+
+def _b(a):
+    return None if a is None else a.ctypes.data_as(_u8p)
+
+
+def _c(a, dtype=np.uint64):
+    return None if a is None else np.ascontiguousarray(a, dtype=dtype)
+
+
+for _name in ("zo_optimal_window_size", "zo_get_window", "zo_f_inv"):
+    getattr(lib, _name).restype = C.c_size_t
+lib.zo_run_sumcheck.restype = C.c_int
+lib.zo_g1_is_on_curve.restype = C.c_int
+
+
+# ---- field
+def _binop(name, f, a, b):
+    a, b = _c(a), _c(b)
+    o = np.empty_like(a)
+    getattr(lib, name)(C.c_int(f), _p(a), _p(b), _p(o), C.c_size_t(a.size // 4))
+    return o
+
+
+def _unop(name, f, a):
+    a = _c(a)
+    o = np.empty_like(a)
+    getattr(lib, name)(C.c_int(f), _p(a), _p(o), C.c_size_t(a.size // 4))
+    return o
+
+
+def f_mul(f, a, b): return _binop("zo_f_mul", f, a, b)
+def f_add(f, a, b): return _binop("zo_f_add", f, a, b)
+def f_sub(f, a, b): return _binop("zo_f_sub", f, a, b)
+def f_neg(f, a): return _unop("zo_f_neg", f, a)
+def f_sqr(f, a): return _unop("zo_f_sqr", f, a)
+def f_inv(f, a): return _unop("zo_f_inv", f, a)
+def f_from_mont(f, a): return _unop("zo_f_from_mont", f, a)
+def f_to_mont(f, a): return _unop("zo_f_to_mont", f, a)
+
+
+def f_from_u64(f, v):
+    v = _c(v)
+    o = np.empty(v.shape + (4,), dtype=np.uint64)
+    lib.zo_f_from_u64(C.c_int(f), _p(v), _p(o), C.c_size_t(v.size))
+    return o
+
+
+def f_to_bytes_be(f, a):
+    a = _c(a)
+    out = np.empty(32, dtype=np.uint8)
+    lib.zo_f_to_bytes_be(C.c_int(f), _p(a), _b(out))
+    return out.tobytes()
+
+
+# ---- G1 / MSM
+def optimal_window_size(n): return int(lib.zo_optimal_window_size(C.c_size_t(n)))
+
+
+def get_window(scalar, w, c):
+    s = _c(scalar)
+    return int(lib.zo_get_window(_p(s), C.c_size_t(w), C.c_size_t(c)))
+
+
+def msm_g1(xy, inf, scalars):
+    xy, inf, scalars = _c(xy), _c(inf, np.uint8), _c(scalars)
+    n = scalars.size // 4
+    out = np.empty(8, dtype=np.uint64)
+    oinf = np.zeros(1, dtype=np.uint8)
+    lib.zo_msm_g1(_p(xy), _b(inf), _p(scalars), C.c_size_t(n), _p(out), _b(oinf))
+    return out, int(oinf[0])
+
+
+def msm_g1_parallel(xy, inf, scalars, threads):
+    xy, inf, scalars = _c(xy), _c(inf, np.uint8), _c(scalars)
+    n = scalars.size // 4
+    out = np.empty(8, dtype=np.uint64)
+    oinf = np.zeros(1, dtype=np.uint8)
+    lib.zo_msm_g1_parallel(_p(xy), _b(inf), _p(scalars), C.c_size_t(n), C.c_size_t(threads), _p(out), _b(oinf))
+    return out, int(oinf[0])
+
+
+def msm_g1_batch(xy, inf, batches):
+    xy, inf = _c(xy), _c(inf, np.uint8)
+    batches = [_c(b) for b in batches]
+    n = batches[0].size // 4 if batches else 0
+    k = len(batches)
+    arr = (_u64p * k)(*[_p(b) for b in batches])
+    out = np.empty((k, 8), dtype=np.uint64)
+    oinf = np.zeros(k, dtype=np.uint8)
+    lib.zo_msm_g1_batch(_p(xy), _b(inf), C.c_size_t(n), arr, C.c_size_t(k), _p(out), _b(oinf))
+    return out, oinf
+
+
+def g1_scalar_mul(xy, inf, scalar):
+    xy, scalar = _c(xy), _c(scalar)
+    out = np.empty(8, dtype=np.uint64)
+    oinf = np.zeros(1, dtype=np.uint8)
+    lib.zo_g1_scalar_mul(_p(xy), C.c_uint8(inf), _p(scalar), _p(out), _b(oinf))
+    return out, int(oinf[0])
+
+
+def g1_add_affine(a, ainf, b, binf):
+    a, b = _c(a), _c(b)
+    out = np.empty(8, dtype=np.uint64)
+    oinf = np.zeros(1, dtype=np.uint8)
+    lib.zo_g1_add_affine(_p(a), C.c_uint8(ainf), _p(b), C.c_uint8(binf), _p(out), _b(oinf))
+    return out, int(oinf[0])
+
+
+def g1_double_affine(a, ainf):
+    a = _c(a)
+    out = np.empty(8, dtype=np.uint64)
+    oinf = np.zeros(1, dtype=np.uint8)
+    lib.zo_g1_double_affine(_p(a), C.c_uint8(ainf), _p(out), _b(oinf))
+    return out, int(oinf[0])
+
+
+def g1_jac_add(a, b):
+    a, b = _c(a), _c(b)
+    o = np.empty(12, dtype=np.uint64)
+    lib.zo_g1_jac_add(_p(a), _p(b), _p(o))
+    return o
+
+
+def g1_jac_double(a):
+    a = _c(a)
+    o = np.empty(12, dtype=np.uint64)
+    lib.zo_g1_jac_double(_p(a), _p(o))
+    return o
+
+
+def g1_jac_add_affine(a, b, binf=0):
+    a, b = _c(a), _c(b)
+    o = np.empty(12, dtype=np.uint64)
+    lib.zo_g1_jac_add_affine(_p(a), _p(b), C.c_uint8(binf), _p(o))
+    return o
+
+
+def g1_jac_to_affine(a):
+    a = _c(a)
+    out = np.empty(8, dtype=np.uint64)
+    oinf = np.zeros(1, dtype=np.uint8)
+    lib.zo_g1_jac_to_affine(_p(a), _p(out), _b(oinf))
+    return out, int(oinf[0])
+
+
+def g1_is_on_curve(xy, inf=0):
+    xy = _c(xy)
+    return bool(lib.zo_g1_is_on_curve(_p(xy), C.c_uint8(inf)))
+
+
+def g1_gen_multiples(n):
+    out = np.empty((n, 8), dtype=np.uint64)
+    lib.zo_g1_gen_multiples(C.c_size_t(n), _p(out))
+    return out
+
+
+# ---- HyperKZG
+def hyperkzg_setup(n):
+    out = np.empty((n, 8), dtype=np.uint64)
+    inf = np.zeros(n, dtype=np.uint8)
+    lib.zo_hyperkzg_setup(C.c_size_t(n), _p(out), _b(inf))
+    return out, inf
+
+
+def hyperkzg_commit(srs_xy, srs_inf, evals):
+    srs_xy, srs_inf, evals = _c(srs_xy), _c(srs_inf, np.uint8), _c(evals)
+    out = np.empty(8, dtype=np.uint64)
+    oinf = np.zeros(1, dtype=np.uint8)
+    lib.zo_hyperkzg_commit(_p(srs_xy), _b(srs_inf), C.c_size_t(srs_xy.size // 8), _p(evals),
+                           C.c_size_t(evals.size // 4), _p(out), _b(oinf))
+    return out, int(oinf[0])
+
+
+def hyperkzg_open(srs_xy, srs_inf, evals, point, value):
+    srs_xy, srs_inf, evals, point, value = _c(srs_xy), _c(srs_inf, np.uint8), _c(evals), _c(point), _c(value)
+    v = point.size // 4
+    q = np.zeros((v, 8), dtype=np.uint64)
+    qinf = np.zeros(v, dtype=np.uint8)
+    fin = np.empty(4, dtype=np.uint64)
+    lib.zo_hyperkzg_open(_p(srs_xy), _b(srs_inf), C.c_size_t(srs_xy.size // 8), _p(evals),
+                         C.c_size_t(evals.size // 4), _p(point), C.c_size_t(v), _p(value), _p(q), _b(qinf), _p(fin))
+    return q, qinf, fin
+
+
+def commitment_to_bytes(xy):
+    xy = _c(xy)
+    out = np.empty(64, dtype=np.uint8)
+    lib.zo_commitment_to_bytes(_p(xy), _b(out))
+    return out.tobytes()
+
+
+# ---- poly / sumcheck
+def fr_eq_table(r, scale=None):
+    r = _c(r)
+    v = r.size // 4
+    out = np.empty((1 << v, 4), dtype=np.uint64)
+    lib.zo_fr_eq_table(_p(r), C.c_size_t(v), _p(_c(scale)), _p(out))
+    return out
+
+
+def fr_eq_table_append_lsb(tau):
+    tau = _c(tau)
+    v = tau.size // 4
+    out = np.empty((1 << v, 4), dtype=np.uint64)
+    lib.zo_fr_eq_table_append_lsb(_p(tau), C.c_size_t(v), _p(out))
+    return out
+
+
+def fr_bind_low(table, r):
+    t = np.array(table, dtype=np.uint64, copy=True)
+    n = t.size // 4
+    lib.zo_fr_bind_low(_p(t), C.c_size_t(n), _p(_c(r)))
+    return t.reshape(-1, 4)[: n // 2].copy()
+
+
+def fr_bind_high(table, r):
+    t = _c(table)
+    n = t.size // 4
+    out = np.empty((n // 2, 4), dtype=np.uint64)
+    lib.zo_fr_bind_high(_p(t), C.c_size_t(n), _p(_c(r)), _p(out))
+    return out
+
+
+def fr_bind_low_2mul(table, r):
+    t = _c(table)
+    n = t.size // 4
+    out = np.empty((n // 2, 4), dtype=np.uint64)
+    lib.zo_fr_bind_low_2mul(_p(t), C.c_size_t(n), _p(_c(r)), _p(out))
+    return out
+
+
+def fr_dense_evaluate(evals, point):
+    e, p = _c(evals), _c(point)
+    out = np.empty(4, dtype=np.uint64)
+    lib.zo_fr_dense_evaluate(_p(e), C.c_size_t(p.size // 4), _p(p), _p(out))
+    return out
+
+
+def fr_sum_halves(table):
+    t = _c(table)
+    g0 = np.empty(4, dtype=np.uint64)
+    g1 = np.empty(4, dtype=np.uint64)
+    lib.zo_fr_sum_halves(_p(t), C.c_size_t(t.size // 4), _p(g0), _p(g1))
+    return g0, g1
+
+
+def fr_sum_even_odd(table):
+    t = _c(table)
+    g0 = np.empty(4, dtype=np.uint64)
+    g1 = np.empty(4, dtype=np.uint64)
+    lib.zo_fr_sum_even_odd(_p(t), C.c_size_t(t.size // 4), _p(g0), _p(g1))
+    return g0, g1
+
+
+def fr_spartan_combine(eq, az, bz, cz):
+    eq, az, bz, cz = _c(eq), _c(az), _c(bz), _c(cz)
+    out = np.empty_like(eq)
+    lib.zo_fr_spartan_combine(_p(eq), _p(az), _p(bz), _p(cz), C.c_size_t(eq.size // 4), _p(out))
+    return out
+
+
+def sumcheck_derive_challenge(rnd, claim, coeffs):
+    claim, coeffs = _c(claim), _c(coeffs)
+    out = np.empty(4, dtype=np.uint64)
+    lib.zo_sumcheck_derive_challenge(C.c_size_t(rnd), _p(claim), _p(coeffs), C.c_size_t(coeffs.size // 4), _p(out))
+    return out
+
+
+def run_sumcheck(evals):
+    e = _c(evals)
+    n = e.size // 4
+    v = n.bit_length() - 1
+    claim = np.empty(4, dtype=np.uint64)
+    rounds = np.empty((v, 2, 4), dtype=np.uint64)
+    chals = np.empty((v, 4), dtype=np.uint64)
+    fin = np.empty(4, dtype=np.uint64)
+    ok = lib.zo_run_sumcheck(_p(e), C.c_size_t(v), _p(claim), _p(rounds), _p(chals), _p(fin))
+    return claim, rounds, chals, fin, int(ok)

@@ -1,0 +1,791 @@
+/*
+ * zolt_oracle.c — CPU restatement of the Zolt hot path (TEST INFRASTRUCTURE).
+ *
+ * This file is the parity ORACLE for the gfx950 backend. It restates, in plain
+ * C with `unsigned __int128`, the algorithms of the reference's Zig CPU path
+ * (MatteoMer/zolt, mounted at /root/reference) function by function; every
+ * function cites the reference file:line it follows.
+ *
+ *   ONLY tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ *   load this library. The product (libzolt_gpu.so, zolt_amd/) never links,
+ *   imports or calls it.
+ *
+ * Pinning: the reference is Zig-only and cannot be compiled here (no zig
+ * toolchain). This restatement is pinned against the reference's own golden
+ * data instead — see tests/test_oracle_golden.py:
+ *   - the 64-byte bytecode commitment inside logs/zolt_proof_regular.bin
+ *     (a real MSM(Fr,Fp).compute output of the reference), regenerated from
+ *     examples/fibonacci.elf;
+ *   - the KATs embedded in the reference's inline tests (field, msm, poly,
+ *     sumcheck), and an independent Python big-int model (oracle/pymodel.py).
+ *
+ * Element format everywhere: 4 x u64 little-endian limbs, Montgomery form with
+ * R = 2^256, canonical (< modulus) — src/field/mod.zig:131,583-584.
+ * Points at this ABI: xy = 8 x u64 (x limbs then y limbs) + separate u8
+ * infinity flag (the Zig struct layout is not ABI-stable, src/msm/mod.zig:19-21).
+ */
+#include <stdint.h>
+#include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
+#include <pthread.h>
+
+typedef unsigned __int128 u128;
+typedef struct { uint64_t l[4]; } fe;
+
+typedef struct {
+    uint64_t mod[4], r[4], r2[4], inv;
+} fparams;
+
+/* src/field/mod.zig:16-41 (Fr) */
+static const fparams FR = {
+    {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL},
+    {0xac96341c4ffffffbULL, 0x36fc76959f60cd29ULL, 0x666ea36f7879462eULL, 0x0e0a77c19a07df2fULL},
+    {0x1bb8e645ae216da7ULL, 0x53fe3ab1e35c59e3ULL, 0x8c49833d53bb8085ULL, 0x0216d0b17f4e44a5ULL},
+    0xc2e1f593efffffffULL};
+/* src/field/mod.zig:51-75 (Fp) */
+static const fparams FP = {
+    {0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL},
+    {0xd35d438dc58f0d9dULL, 0x0a78eb28f5c70b3dULL, 0x666ea36f7879462cULL, 0x0e0a77c19a07df2fULL},
+    {0xf32cfc5b538afa89ULL, 0xb5e71911d44501fbULL, 0x47ab1eff0a417ff6ULL, 0x06d89f71cab8351fULL},
+    0x87d20782e4866389ULL};
+
+/* ------------------------------------------------------------------ field */
+
+/* lessThanModulus — src/field/mod.zig:520-528 / :1005-1013 */
+static inline int f_lt_mod(const fparams *P, const fe *a) {
+    for (int i = 3; i >= 0; i--) {
+        if (a->l[i] < P->mod[i]) return 1;
+        if (a->l[i] > P->mod[i]) return 0;
+    }
+    return 0;
+}
+/* subtractModulus — :530-541 / :1015-1026 */
+static inline void f_sub_mod(const fparams *P, fe *a) {
+    uint64_t borrow = 0;
+    for (int i = 0; i < 4; i++) {
+        u128 d = (u128)a->l[i] - P->mod[i] - borrow;
+        a->l[i] = (uint64_t)d;
+        borrow = (uint64_t)(d >> 64) & 1;
+    }
+}
+/* addModulus — :543-554 / :1028-1039 */
+static inline void f_add_mod(const fparams *P, fe *a) {
+    uint64_t carry = 0;
+    for (int i = 0; i < 4; i++) {
+        u128 s = (u128)a->l[i] + P->mod[i] + carry;
+        a->l[i] = (uint64_t)s;
+        carry = (uint64_t)(s >> 64);
+    }
+}
+
+/* montgomeryMul (CIOS) — src/field/mod.zig:269-308 (generic) ≡ :735-779 (Fr) */
+static inline fe f_mul(const fparams *P, const fe *a, const fe *b) {
+    uint64_t t[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) {
+        uint64_t carry = 0;
+        for (int j = 0; j < 4; j++) {
+            u128 s = (u128)t[j] + (u128)a->l[i] * b->l[j] + carry;
+            t[j] = (uint64_t)s;
+            carry = (uint64_t)(s >> 64);
+        }
+        t[4] = t[4] + carry; /* :280-281 truncating add */
+        uint64_t m = t[0] * P->inv;
+        u128 s0 = (u128)t[0] + (u128)m * P->mod[0];
+        carry = (uint64_t)(s0 >> 64);
+        for (int j = 1; j < 4; j++) {
+            u128 s = (u128)t[j] + (u128)m * P->mod[j] + carry;
+            t[j - 1] = (uint64_t)s;
+            carry = (uint64_t)(s >> 64);
+        }
+        u128 fs = (u128)t[4] + carry;
+        t[3] = (uint64_t)fs;
+        t[4] = (uint64_t)(fs >> 64);
+    }
+    fe r = {{t[0], t[1], t[2], t[3]}};
+    if (t[4] != 0 || !f_lt_mod(P, &r)) f_sub_mod(P, &r);
+    return r;
+}
+/* add — :402-417 / :782-798 */
+static inline fe f_add(const fparams *P, const fe *a, const fe *b) {
+    fe r; uint64_t carry = 0;
+    for (int i = 0; i < 4; i++) {
+        u128 s = (u128)a->l[i] + b->l[i] + carry;
+        r.l[i] = (uint64_t)s; carry = (uint64_t)(s >> 64);
+    }
+    if (carry != 0 || !f_lt_mod(P, &r)) f_sub_mod(P, &r);
+    return r;
+}
+/* sub — :420-435 / :801-816 */
+static inline fe f_sub(const fparams *P, const fe *a, const fe *b) {
+    fe r; uint64_t borrow = 0;
+    for (int i = 0; i < 4; i++) {
+        u128 d = (u128)a->l[i] - b->l[i] - borrow;
+        r.l[i] = (uint64_t)d; borrow = (uint64_t)(d >> 64) & 1;
+    }
+    if (borrow) f_add_mod(P, &r);
+    return r;
+}
+static inline int f_is_zero(const fe *a) { return (a->l[0] | a->l[1] | a->l[2] | a->l[3]) == 0; }
+static inline int f_eq(const fe *a, const fe *b) {
+    return a->l[0] == b->l[0] && a->l[1] == b->l[1] && a->l[2] == b->l[2] && a->l[3] == b->l[3];
+}
+/* neg — :494-497 / :944-947 (neg(0) = 0) */
+static inline fe f_neg(const fparams *P, const fe *a) {
+    if (f_is_zero(a)) return *a;
+    fe m = {{P->mod[0], P->mod[1], P->mod[2], P->mod[3]}};
+    return f_sub(P, &m, a);
+}
+/* square — Fp: :443-445 (= mul(self,self)). Fr: :866-941 is a hand-rolled SOS
+ * squaring whose `+%=` at :886/:908 drops a carry with probability ~2^-64; the
+ * mathematically intended value a^2·R^-1 is restated here. */
+static inline fe f_sqr(const fparams *P, const fe *a) { return f_mul(P, a, a); }
+static inline fe f_one(const fparams *P) { fe r = {{P->r[0], P->r[1], P->r[2], P->r[3]}}; return r; }
+static inline fe f_zero(void) { fe r = {{0, 0, 0, 0}}; return r; }
+/* fromU64 — :164-168 / :617-622 */
+static inline fe f_from_u64(const fparams *P, uint64_t n) {
+    fe a = {{n, 0, 0, 0}}, r2 = {{P->r2[0], P->r2[1], P->r2[2], P->r2[3]}};
+    return f_mul(P, &a, &r2);
+}
+/* fromMontgomery — :187-189 / :642-645 */
+static inline fe f_from_mont(const fparams *P, const fe *a) {
+    fe one = {{1, 0, 0, 0}};
+    return f_mul(P, a, &one);
+}
+/* toMontgomery / fromBytes (LE; input may be >= modulus) — :171-184,192-200 / :625-652 */
+static inline fe f_to_mont(const fparams *P, const fe *a) {
+    fe r2 = {{P->r2[0], P->r2[1], P->r2[2], P->r2[3]}};
+    return f_mul(P, a, &r2);
+}
+/* inverse (Fermat, LSB-first square-and-multiply) — :500-518 / :955-983.
+ * returns 0 for input 0 (Zig: null). */
+static int f_inv(const fparams *P, const fe *a, fe *out) {
+    if (f_is_zero(a)) return 0;
+    uint64_t e[4] = {P->mod[0] - 2, P->mod[1], P->mod[2], P->mod[3]};
+    fe result = f_one(P), base = *a;
+    for (int i = 0; i < 256; i++) {
+        if ((e[i / 64] >> (i % 64)) & 1) result = f_mul(P, &result, &base);
+        base = f_sqr(P, &base);
+    }
+    *out = result;
+    return 1;
+}
+
+/* ---------------------------------------------------------- exported field */
+#define EXPORT __attribute__((visibility("default")))
+static const fparams *sel(int which) { return which ? &FP : &FR; } /* 0 = Fr, 1 = Fp */
+
+EXPORT void zo_f_mul(int f, const uint64_t *a, const uint64_t *b, uint64_t *o, size_t n) {
+    for (size_t i = 0; i < n; i++) { fe r = f_mul(sel(f), (const fe *)(a + 4 * i), (const fe *)(b + 4 * i)); memcpy(o + 4 * i, &r, 32); }
+}
+EXPORT void zo_f_add(int f, const uint64_t *a, const uint64_t *b, uint64_t *o, size_t n) {
+    for (size_t i = 0; i < n; i++) { fe r = f_add(sel(f), (const fe *)(a + 4 * i), (const fe *)(b + 4 * i)); memcpy(o + 4 * i, &r, 32); }
+}
+EXPORT void zo_f_sub(int f, const uint64_t *a, const uint64_t *b, uint64_t *o, size_t n) {
+    for (size_t i = 0; i < n; i++) { fe r = f_sub(sel(f), (const fe *)(a + 4 * i), (const fe *)(b + 4 * i)); memcpy(o + 4 * i, &r, 32); }
+}
+EXPORT void zo_f_neg(int f, const uint64_t *a, uint64_t *o, size_t n) {
+    for (size_t i = 0; i < n; i++) { fe r = f_neg(sel(f), (const fe *)(a + 4 * i)); memcpy(o + 4 * i, &r, 32); }
+}
+EXPORT void zo_f_sqr(int f, const uint64_t *a, uint64_t *o, size_t n) {
+    for (size_t i = 0; i < n; i++) { fe r = f_sqr(sel(f), (const fe *)(a + 4 * i)); memcpy(o + 4 * i, &r, 32); }
+}
+/* returns number of zero inputs (their outputs are set to 0) */
+EXPORT size_t zo_f_inv(int f, const uint64_t *a, uint64_t *o, size_t n) {
+    size_t z = 0;
+    for (size_t i = 0; i < n; i++) {
+        fe r = f_zero();
+        if (!f_inv(sel(f), (const fe *)(a + 4 * i), &r)) z++;
+        memcpy(o + 4 * i, &r, 32);
+    }
+    return z;
+}
+EXPORT void zo_f_from_u64(int f, const uint64_t *v, uint64_t *o, size_t n) {
+    for (size_t i = 0; i < n; i++) { fe r = f_from_u64(sel(f), v[i]); memcpy(o + 4 * i, &r, 32); }
+}
+EXPORT void zo_f_from_mont(int f, const uint64_t *a, uint64_t *o, size_t n) {
+    for (size_t i = 0; i < n; i++) { fe r = f_from_mont(sel(f), (const fe *)(a + 4 * i)); memcpy(o + 4 * i, &r, 32); }
+}
+/* raw 256-bit LE integers (possibly >= modulus) -> Montgomery; = fromBytes :171-184 */
+EXPORT void zo_f_to_mont(int f, const uint64_t *a, uint64_t *o, size_t n) {
+    for (size_t i = 0; i < n; i++) { fe r = f_to_mont(sel(f), (const fe *)(a + 4 * i)); memcpy(o + 4 * i, &r, 32); }
+}
+/* toBytesBE — :213-237 / :665-681 */
+EXPORT void zo_f_to_bytes_be(int f, const uint64_t *a, uint8_t *out32) {
+    fe s = f_from_mont(sel(f), (const fe *)a);
+    for (int i = 0; i < 4; i++)
+        for (int b = 0; b < 8; b++) out32[31 - (i * 8 + b)] = (uint8_t)(s.l[i] >> (8 * b));
+}
+
+/* --------------------------------------------------------------------- G1 */
+typedef struct { fe x, y; int inf; } aff;
+typedef struct { fe x, y, z; } jac;
+
+/* AffinePoint.identity — src/msm/mod.zig:24-30 */
+static aff a_identity(void) { aff p; p.x = f_zero(); p.y = f_zero(); p.inf = 1; return p; }
+/* ProjectivePoint.identity = (1,1,0) — :154-160 */
+static jac j_identity(void) { jac p; p.x = f_one(&FP); p.y = f_one(&FP); p.z = f_zero(); return p; }
+/* fromAffine — :163-170 */
+static jac j_from_affine(const aff *p) {
+    if (p->inf) return j_identity();
+    jac r; r.x = p->x; r.y = p->y; r.z = f_one(&FP); return r;
+}
+/* toAffine — :178-189 */
+static aff j_to_affine(const jac *p) {
+    if (f_is_zero(&p->z)) return a_identity();
+    fe zi;
+    if (!f_inv(&FP, &p->z, &zi)) return a_identity();
+    fe zi2 = f_sqr(&FP, &zi), zi3 = f_mul(&FP, &zi2, &zi);
+    aff r; r.inf = 0;
+    r.x = f_mul(&FP, &p->x, &zi2);
+    r.y = f_mul(&FP, &p->y, &zi3);
+    return r;
+}
+/* double (dbl-2009-l) — :195-226 */
+static jac j_double(const jac *p) {
+    if (f_is_zero(&p->z)) return *p;
+    const fparams *F = &FP;
+    fe A = f_sqr(F, &p->x), B = f_sqr(F, &p->y), C = f_sqr(F, &B);
+    fe xpb = f_add(F, &p->x, &B);
+    fe t = f_sqr(F, &xpb); t = f_sub(F, &t, &A); fe halfD = f_sub(F, &t, &C);
+    fe D = f_add(F, &halfD, &halfD);
+    fe E = f_add(F, &A, &A); E = f_add(F, &E, &A);
+    fe FF = f_sqr(F, &E);
+    fe twoD = f_add(F, &D, &D);
+    fe X3 = f_sub(F, &FF, &twoD);
+    fe c8 = f_add(F, &C, &C); for (int i = 0; i < 6; i++) c8 = f_add(F, &c8, &C); /* 8*C, :216 */
+    fe dmx = f_sub(F, &D, &X3);
+    fe Y3 = f_mul(F, &E, &dmx); Y3 = f_sub(F, &Y3, &c8);
+    fe yz = f_mul(F, &p->y, &p->z);
+    fe Z3 = f_add(F, &yz, &yz);
+    jac r = {X3, Y3, Z3};
+    return r;
+}
+/* addAffine (madd-2007-bl shape) — :229-274; edge-case order as in the reference */
+static jac j_add_affine(const jac *s, const aff *o) {
+    if (o->inf) return *s;
+    if (f_is_zero(&s->z)) return j_from_affine(o);
+    const fparams *F = &FP;
+    fe z1z1 = f_sqr(F, &s->z);
+    fe U2 = f_mul(F, &o->x, &z1z1);
+    fe S2 = f_mul(F, &o->y, &s->z); S2 = f_mul(F, &S2, &z1z1);
+    fe H = f_sub(F, &U2, &s->x);
+    fe HH = f_sqr(F, &H);
+    fe I = f_add(F, &HH, &HH); I = f_add(F, &I, &HH); I = f_add(F, &I, &HH);
+    fe J = f_mul(F, &H, &I);
+    fe d = f_sub(F, &S2, &s->y);
+    fe r = f_add(F, &d, &d);
+    fe V = f_mul(F, &s->x, &I);
+    fe X3 = f_sqr(F, &r); X3 = f_sub(F, &X3, &J); X3 = f_sub(F, &X3, &V); X3 = f_sub(F, &X3, &V);
+    fe vmx = f_sub(F, &V, &X3);
+    fe y1j = f_mul(F, &s->y, &J);
+    fe Y3 = f_mul(F, &r, &vmx); Y3 = f_sub(F, &Y3, &y1j); Y3 = f_sub(F, &Y3, &y1j);
+    fe zph = f_add(F, &s->z, &H);
+    fe Z3 = f_sqr(F, &zph); Z3 = f_sub(F, &Z3, &z1z1); Z3 = f_sub(F, &Z3, &HH);
+    if (f_is_zero(&H)) {
+        if (f_is_zero(&r)) return j_double(s);
+        return j_identity();
+    }
+    jac out = {X3, Y3, Z3};
+    return out;
+}
+/* add (add-2007-bl) — :277-327 */
+static jac j_add(const jac *s, const jac *o) {
+    if (f_is_zero(&s->z)) return *o;
+    if (f_is_zero(&o->z)) return *s;
+    const fparams *F = &FP;
+    fe z1z1 = f_sqr(F, &s->z), z2z2 = f_sqr(F, &o->z);
+    fe U1 = f_mul(F, &s->x, &z2z2), U2 = f_mul(F, &o->x, &z1z1);
+    fe S1 = f_mul(F, &s->y, &o->z); S1 = f_mul(F, &S1, &z2z2);
+    fe S2 = f_mul(F, &o->y, &s->z); S2 = f_mul(F, &S2, &z1z1);
+    fe H = f_sub(F, &U2, &U1);
+    fe twoH = f_add(F, &H, &H);
+    fe I = f_sqr(F, &twoH);
+    fe J = f_mul(F, &H, &I);
+    fe d = f_sub(F, &S2, &S1);
+    fe r = f_add(F, &d, &d);
+    fe V = f_mul(F, &U1, &I);
+    fe X3 = f_sqr(F, &r); X3 = f_sub(F, &X3, &J); X3 = f_sub(F, &X3, &V); X3 = f_sub(F, &X3, &V);
+    fe vmx = f_sub(F, &V, &X3);
+    fe s1j = f_mul(F, &S1, &J);
+    fe Y3 = f_mul(F, &r, &vmx); Y3 = f_sub(F, &Y3, &s1j); Y3 = f_sub(F, &Y3, &s1j);
+    fe zz = f_add(F, &s->z, &o->z);
+    fe Z3 = f_sqr(F, &zz); Z3 = f_sub(F, &Z3, &z1z1); Z3 = f_sub(F, &Z3, &z2z2); Z3 = f_mul(F, &Z3, &H);
+    if (f_is_zero(&H)) {
+        if (f_is_zero(&r)) return j_double(s);
+        return j_identity();
+    }
+    jac out = {X3, Y3, Z3};
+    return out;
+}
+/* AffinePoint.double — :118-138 */
+static aff a_double(const aff *p) {
+    if (p->inf) return *p;
+    if (f_is_zero(&p->y)) return a_identity();
+    const fparams *F = &FP;
+    fe xs = f_sqr(F, &p->x);
+    fe t3 = f_add(F, &xs, &xs); t3 = f_add(F, &t3, &xs);
+    fe ty = f_add(F, &p->y, &p->y), tyi;
+    if (!f_inv(F, &ty, &tyi)) return a_identity();
+    fe lam = f_mul(F, &t3, &tyi);
+    fe x3 = f_sqr(F, &lam); x3 = f_sub(F, &x3, &p->x); x3 = f_sub(F, &x3, &p->x);
+    fe d = f_sub(F, &p->x, &x3);
+    fe y3 = f_mul(F, &lam, &d); y3 = f_sub(F, &y3, &p->y);
+    aff r; r.x = x3; r.y = y3; r.inf = 0; return r;
+}
+/* AffinePoint.add — :74-103 */
+static aff a_add(const aff *s, const aff *o) {
+    if (s->inf) return *o;
+    if (o->inf) return *s;
+    const fparams *F = &FP;
+    if (f_eq(&s->x, &o->x)) {
+        fe ny = f_neg(F, &o->y);
+        if (f_eq(&s->y, &ny)) return a_identity();
+        if (f_eq(&s->y, &o->y)) return a_double(s);
+    }
+    fe dy = f_sub(F, &o->y, &s->y), dx = f_sub(F, &o->x, &s->x), dxi;
+    if (!f_inv(F, &dx, &dxi)) return a_identity();
+    fe lam = f_mul(F, &dy, &dxi);
+    fe x3 = f_sqr(F, &lam); x3 = f_sub(F, &x3, &s->x); x3 = f_sub(F, &x3, &o->x);
+    fe d = f_sub(F, &s->x, &x3);
+    fe y3 = f_mul(F, &lam, &d); y3 = f_sub(F, &y3, &s->y);
+    aff r; r.x = x3; r.y = y3; r.inf = 0; return r;
+}
+/* isOnCurve y^2 = x^3 + 3 — :106-115 */
+static int a_on_curve(const aff *p) {
+    if (p->inf) return 1;
+    const fparams *F = &FP;
+    fe y2 = f_sqr(F, &p->y), x3 = f_sqr(F, &p->x); x3 = f_mul(F, &x3, &p->x);
+    fe b = f_from_u64(F, 3), rhs = f_add(F, &x3, &b);
+    return f_eq(&y2, &rhs);
+}
+
+static aff load_aff(const uint64_t *xy, const uint8_t *inf, size_t i) {
+    aff p;
+    memcpy(&p.x, xy + 8 * i, 32); memcpy(&p.y, xy + 8 * i + 4, 32);
+    p.inf = inf ? (inf[i] != 0) : 0;
+    return p;
+}
+static void store_aff(const aff *p, uint64_t *xy, uint8_t *inf) {
+    memcpy(xy, &p->x, 32); memcpy(xy + 4, &p->y, 32);
+    if (inf) *inf = (uint8_t)p->inf;
+}
+
+/* --------------------------------------------------------------------- MSM */
+
+/* optimalWindowSize — src/msm/mod.zig:475-484 */
+EXPORT size_t zo_optimal_window_size(size_t n) {
+    if (n < 8) return 1;
+    if (n < 32) return 2;
+    if (n < 128) return 3;
+    if (n < 512) return 4;
+    if (n < 2048) return 5;
+    if (n < 8192) return 6;
+    if (n < 32768) return 7;
+    return 8;
+}
+/* getWindow — :441-471 (fromMontgomery per call kept, as in the reference) */
+static size_t get_window(const fe *scalar, size_t window_idx, size_t c) {
+    fe ns = f_from_mont(&FR, scalar);
+    size_t bit_offset = window_idx * c;
+    size_t limb_idx = bit_offset / 64, bit_in_limb = bit_offset % 64;
+    if (limb_idx >= 4) return 0;
+    uint64_t mask = (1ULL << c) - 1;
+    uint64_t value = (ns.l[limb_idx] >> bit_in_limb) & mask;
+    if (bit_in_limb + c > 64 && limb_idx + 1 < 4) {
+        size_t remaining = bit_in_limb + c - 64;
+        if (remaining > 0 && remaining <= 63 && bit_in_limb > 0) {
+            uint64_t next_mask = (1ULL << remaining) - 1;
+            value |= (ns.l[limb_idx + 1] & next_mask) << (64 - bit_in_limb);
+        }
+    }
+    return (size_t)(value & mask);
+}
+EXPORT size_t zo_get_window(const uint64_t *scalar_mont, size_t window_idx, size_t c) {
+    return get_window((const fe *)scalar_mont, window_idx, c);
+}
+/* scalarMul (MSB-first double-and-add) — :503-540 */
+static jac scalar_mul(const aff *base, const fe *scalar) {
+    if (base->inf) return j_identity();
+    if (f_is_zero(scalar)) return j_identity();
+    jac result = j_identity();
+    fe ns = f_from_mont(&FR, scalar);
+    for (int li = 3; li >= 0; li--) {
+        uint64_t limb = ns.l[li];
+        for (int b = 63; b >= 0; b--) {
+            if (!f_is_zero(&result.z)) result = j_double(&result);
+            if ((limb >> b) & 1) {
+                if (f_is_zero(&result.z)) result = j_from_affine(base);
+                else result = j_add_affine(&result, base);
+            }
+        }
+    }
+    return result;
+}
+/* naiveMSM — :487-499 */
+static aff naive_msm(const uint64_t *xy, const uint8_t *inf, const uint64_t *sc, size_t n) {
+    jac result = j_identity();
+    for (size_t i = 0; i < n; i++) {
+        aff b = load_aff(xy, inf, i);
+        jac term = scalar_mul(&b, (const fe *)(sc + 4 * i));
+        result = j_add(&result, &term);
+    }
+    return j_to_affine(&result);
+}
+/* pippengerMSM — :375-438 */
+static aff pippenger_msm(const uint64_t *xy, const uint8_t *inf, const uint64_t *sc, size_t n) {
+    size_t c = zo_optimal_window_size(n);
+    size_t num_windows = (256 + c - 1) / c;
+    size_t num_buckets = ((size_t)1 << c) - 1;
+    jac final_result = j_identity();
+    jac buckets[256];
+    for (size_t w = num_windows; w-- > 0;) {
+        if (!f_is_zero(&final_result.z))
+            for (size_t i = 0; i < c; i++) final_result = j_double(&final_result);
+        for (size_t j = 0; j < num_buckets && j < 256; j++) buckets[j] = j_identity();
+        for (size_t i = 0; i < n; i++) {
+            if (inf && inf[i]) continue;
+            size_t bidx = get_window((const fe *)(sc + 4 * i), w, c);
+            if (bidx == 0) continue;
+            size_t idx = bidx - 1;
+            if (idx < num_buckets) {
+                aff b = load_aff(xy, inf, i);
+                buckets[idx] = j_add_affine(&buckets[idx], &b);
+            }
+        }
+        jac running = j_identity(), wsum = j_identity();
+        for (size_t b = num_buckets; b-- > 0;) {
+            running = j_add(&running, &buckets[b]);
+            wsum = j_add(&wsum, &running);
+        }
+        final_result = j_add(&final_result, &wsum);
+    }
+    return j_to_affine(&final_result);
+}
+/* MSM.compute — :355-372 */
+static aff msm_compute(const uint64_t *xy, const uint8_t *inf, const uint64_t *sc, size_t n) {
+    if (n == 0) return a_identity();
+    if (n < 8) return naive_msm(xy, inf, sc, n);
+    return pippenger_msm(xy, inf, sc, n);
+}
+EXPORT void zo_msm_g1(const uint64_t *xy, const uint8_t *inf, const uint64_t *scalars, size_t n,
+                      uint64_t out_xy[8], uint8_t *out_inf) {
+    aff r = msm_compute(xy, inf, scalars, n);
+    store_aff(&r, out_xy, out_inf);
+}
+/* BatchMSM.compute — :545-565 */
+EXPORT void zo_msm_g1_batch(const uint64_t *xy, const uint8_t *inf, size_t n,
+                            const uint64_t *const *batches, size_t k, uint64_t *out_xy, uint8_t *out_inf) {
+    for (size_t b = 0; b < k; b++) {
+        aff r = msm_compute(xy, inf, batches[b], n);
+        store_aff(&r, out_xy + 8 * b, out_inf ? out_inf + b : NULL);
+    }
+}
+
+/* ParallelMSM.compute — :572-680: contiguous chunks of ceil(n/T), each
+ * SingleMSM.compute -> fromAffine, serial Jacobian combine, toAffine. */
+typedef struct { const uint64_t *xy; const uint8_t *inf; const uint64_t *sc; size_t n; jac result; } pm_ctx;
+static void *pm_worker(void *p) {
+    pm_ctx *c = (pm_ctx *)p;
+    if (c->n == 0) { c->result = j_identity(); return NULL; }
+    aff a = msm_compute(c->xy, c->inf, c->sc, c->n);
+    c->result = j_from_affine(&a);
+    return NULL;
+}
+EXPORT void zo_msm_g1_parallel(const uint64_t *xy, const uint8_t *inf, const uint64_t *scalars, size_t n,
+                               size_t num_threads, uint64_t out_xy[8], uint8_t *out_inf) {
+    if (n == 0) { aff r = a_identity(); store_aff(&r, out_xy, out_inf); return; }
+    size_t by_size = n / 1024; if (by_size < 1) by_size = 1;
+    size_t T = num_threads < by_size ? num_threads : by_size;
+    if (T <= 1) { zo_msm_g1(xy, inf, scalars, n, out_xy, out_inf); return; }
+    size_t chunk = (n + T - 1) / T;
+    pm_ctx *ctx = (pm_ctx *)calloc(T, sizeof(pm_ctx));
+    pthread_t *th = (pthread_t *)calloc(T, sizeof(pthread_t));
+    for (size_t i = 0; i < T; i++) {
+        size_t start = i * chunk, end = start + chunk; if (end > n) end = n;
+        if (start >= n) { ctx[i].n = 0; }
+        else { ctx[i].xy = xy + 8 * start; ctx[i].inf = inf ? inf + start : NULL; ctx[i].sc = scalars + 4 * start; ctx[i].n = end - start; }
+        pthread_create(&th[i], NULL, pm_worker, &ctx[i]);
+    }
+    for (size_t i = 0; i < T; i++) pthread_join(th[i], NULL);
+    jac fin = j_identity();
+    for (size_t i = 0; i < T; i++) fin = j_add(&fin, &ctx[i].result);
+    aff r = j_to_affine(&fin);
+    store_aff(&r, out_xy, out_inf);
+    free(ctx); free(th);
+}
+/* MSM.scalarMul(base, scalar).toAffine() */
+EXPORT void zo_g1_scalar_mul(const uint64_t xy[8], uint8_t inf, const uint64_t scalar[4], uint64_t out_xy[8], uint8_t *out_inf) {
+    aff b = load_aff(xy, &inf, 0);
+    jac j = scalar_mul(&b, (const fe *)scalar);
+    aff r = j_to_affine(&j);
+    store_aff(&r, out_xy, out_inf);
+}
+EXPORT void zo_g1_add_affine(const uint64_t a[8], uint8_t ainf, const uint64_t b[8], uint8_t binf, uint64_t out_xy[8], uint8_t *out_inf) {
+    aff pa = load_aff(a, &ainf, 0), pb = load_aff(b, &binf, 0);
+    aff r = a_add(&pa, &pb);
+    store_aff(&r, out_xy, out_inf);
+}
+EXPORT void zo_g1_double_affine(const uint64_t a[8], uint8_t ainf, uint64_t out_xy[8], uint8_t *out_inf) {
+    aff pa = load_aff(a, &ainf, 0);
+    aff r = a_double(&pa);
+    store_aff(&r, out_xy, out_inf);
+}
+/* Jacobian ops on raw 12-limb records, for unit-testing device formulas */
+EXPORT void zo_g1_jac_add(const uint64_t a[12], const uint64_t b[12], uint64_t o[12]) {
+    jac r = j_add((const jac *)a, (const jac *)b); memcpy(o, &r, 96);
+}
+EXPORT void zo_g1_jac_double(const uint64_t a[12], uint64_t o[12]) {
+    jac r = j_double((const jac *)a); memcpy(o, &r, 96);
+}
+EXPORT void zo_g1_jac_add_affine(const uint64_t a[12], const uint64_t b[8], uint8_t binf, uint64_t o[12]) {
+    aff pb = load_aff(b, &binf, 0);
+    jac r = j_add_affine((const jac *)a, &pb); memcpy(o, &r, 96);
+}
+EXPORT void zo_g1_jac_to_affine(const uint64_t a[12], uint64_t out_xy[8], uint8_t *out_inf) {
+    aff r = j_to_affine((const jac *)a); store_aff(&r, out_xy, out_inf);
+}
+EXPORT int zo_g1_is_on_curve(const uint64_t xy[8], uint8_t inf) {
+    aff p = load_aff(xy, &inf, 0); return a_on_curve(&p);
+}
+/* Bench point family P_i = (i+1)·G, G=(1,2) — src/bench.zig:261-268. Built by
+ * a running Jacobian sum + per-point toAffine replaced with batch inversion
+ * (values identical: affine coordinates are unique). */
+EXPORT void zo_g1_gen_multiples(size_t n, uint64_t *out_xy) {
+    if (n == 0) return;
+    const fparams *F = &FP;
+    aff g; g.x = f_one(F); g.y = f_from_u64(F, 2); g.inf = 0;
+    jac *pts = (jac *)malloc(n * sizeof(jac));
+    fe *pre = (fe *)malloc(n * sizeof(fe));
+    jac acc = j_from_affine(&g);
+    for (size_t i = 0; i < n; i++) { pts[i] = acc; acc = j_add_affine(&acc, &g); }
+    fe run = f_one(F);
+    for (size_t i = 0; i < n; i++) { pre[i] = run; run = f_mul(F, &run, &pts[i].z); }
+    fe inv; f_inv(F, &run, &inv);
+    for (size_t i = n; i-- > 0;) {
+        fe zi = f_mul(F, &inv, &pre[i]);
+        inv = f_mul(F, &inv, &pts[i].z);
+        fe zi2 = f_sqr(F, &zi), zi3 = f_mul(F, &zi2, &zi);
+        fe x = f_mul(F, &pts[i].x, &zi2), y = f_mul(F, &pts[i].y, &zi3);
+        memcpy(out_xy + 8 * i, &x, 32); memcpy(out_xy + 8 * i + 4, &y, 32);
+    }
+    free(pts); free(pre);
+}
+
+/* ---------------------------------------------------------------- HyperKZG */
+/* HyperKZG.setup mock SRS: powers[i] = scalarMul(G, tau^i).toAffine(), tau = 0x12345678
+ * — src/poly/commitment/mod.zig:174-213 */
+EXPORT void zo_hyperkzg_setup(size_t max_degree, uint64_t *out_xy, uint8_t *out_inf) {
+    aff g; g.x = f_one(&FP); g.y = f_from_u64(&FP, 2); g.inf = 0;
+    fe tau = f_from_u64(&FR, 0x12345678ULL), tp = f_one(&FR);
+    for (size_t i = 0; i < max_degree; i++) {
+        jac j = scalar_mul(&g, &tp);
+        aff a = j_to_affine(&j);
+        store_aff(&a, out_xy + 8 * i, out_inf ? out_inf + i : NULL);
+        tp = f_mul(&FR, &tp, &tau);
+    }
+}
+/* HyperKZG.commit — :239-255 */
+EXPORT void zo_hyperkzg_commit(const uint64_t *srs_xy, const uint8_t *srs_inf, size_t srs_len,
+                               const uint64_t *evals, size_t n_evals, uint64_t out_xy[8], uint8_t *out_inf) {
+    if (n_evals == 0) { aff r = a_identity(); store_aff(&r, out_xy, out_inf); return; }
+    size_t n = n_evals < srs_len ? n_evals : srs_len;
+    zo_msm_g1(srs_xy, srs_inf, evals, n, out_xy, out_inf);
+}
+/* PolyCommitment.toBytes: x||y big-endian canonical; identity -> 64 zero bytes
+ * — src/zkvm/commitment_types.zig:49-54 */
+EXPORT void zo_commitment_to_bytes(const uint64_t xy[8], uint8_t out64[64]) {
+    zo_f_to_bytes_be(1, xy, out64);
+    zo_f_to_bytes_be(1, xy + 4, out64 + 32);
+}
+/* HyperKZG.open — :261-324. quotient commitments (num_vars x 8 limbs + inf) + final eval */
+EXPORT void zo_hyperkzg_open(const uint64_t *srs_xy, const uint8_t *srs_inf, size_t srs_len,
+                             const uint64_t *evals, size_t n_evals, const uint64_t *point, size_t num_vars,
+                             const uint64_t value[4], uint64_t *q_xy, uint8_t *q_inf, uint64_t final_eval[4]) {
+    if (num_vars == 0) { memcpy(final_eval, value, 32); return; }
+    size_t len = n_evals;
+    fe *cur = (fe *)malloc((len ? len : 1) * sizeof(fe));
+    memcpy(cur, evals, len * 32);
+    for (size_t i = 0; i < num_vars; i++) {
+        size_t half = len / 2;
+        if (half == 0) break;
+        fe *q = (fe *)malloc(half * sizeof(fe));
+        for (size_t j = 0; j < half; j++) q[j] = f_sub(&FR, &cur[j + half], &cur[j]);
+        zo_hyperkzg_commit(srs_xy, srs_inf, srs_len, (const uint64_t *)q, half, q_xy + 8 * i, q_inf ? q_inf + i : NULL);
+        free(q);
+        fe *nw = (fe *)malloc(half * sizeof(fe));
+        fe one = f_one(&FR), r = *(const fe *)(point + 4 * i), omr = f_sub(&FR, &one, &r);
+        for (size_t j = 0; j < half; j++) {
+            fe lo = f_mul(&FR, &cur[j], &omr), hi = f_mul(&FR, &cur[j + half], &r);
+            nw[j] = f_add(&FR, &lo, &hi);
+        }
+        free(cur); cur = nw; len = half;
+    }
+    fe fin = len > 0 ? cur[0] : f_zero();
+    memcpy(final_eval, &fin, 32);
+    free(cur);
+}
+
+/* -------------------------------------------------------------------- poly */
+/* EqPolynomial.evalsSliceWithScaling — src/poly/mod.zig:252-290 (big-endian index) */
+EXPORT void zo_fr_eq_table(const uint64_t *r, size_t v, const uint64_t *scale, uint64_t *out) {
+    fe *res = (fe *)out;
+    size_t final_size = (size_t)1 << v;
+    for (size_t i = 0; i < final_size; i++) res[i] = f_zero();
+    res[0] = scale ? *(const fe *)scale : f_one(&FR);
+    size_t size = 1;
+    for (size_t j = v; j-- > 0;) {
+        const fe *rj = (const fe *)(r + 4 * j);
+        for (size_t i = 0; i < size; i++) {
+            fe x = res[i], y = f_mul(&FR, &x, rj);
+            res[i + size] = y;
+            res[i] = f_sub(&FR, &x, &y);
+        }
+        size *= 2;
+    }
+}
+/* GruenSplitEqPolynomial prefix-table step ("append LSB") — src/poly/split_eq.zig:122-147:
+ * next[2i] = prev[i]*(1-tau_k), next[2i+1] = prev[i]*tau_k; full table for tau[0..v) */
+EXPORT void zo_fr_eq_table_append_lsb(const uint64_t *tau, size_t v, uint64_t *out) {
+    size_t total = (size_t)1 << v;
+    fe *a = (fe *)malloc(total * sizeof(fe)), *b = (fe *)malloc(total * sizeof(fe));
+    a[0] = f_one(&FR);
+    for (size_t k = 0; k < v; k++) {
+        size_t prev = (size_t)1 << k;
+        fe one = f_one(&FR), tk = *(const fe *)(tau + 4 * k), omt = f_sub(&FR, &one, &tk);
+        for (size_t i = 0; i < prev; i++) {
+            b[2 * i] = f_mul(&FR, &a[i], &omt);
+            b[2 * i + 1] = f_mul(&FR, &a[i], &tk);
+        }
+        fe *t = a; a = b; b = t;
+    }
+    memcpy(out, a, total * 32);
+    free(a); free(b);
+}
+/* DensePolynomial.bindLow (in place) — src/poly/mod.zig:160-175 */
+EXPORT void zo_fr_bind_low(uint64_t *table, size_t len, const uint64_t r[4]) {
+    fe *t = (fe *)table; const fe *rv = (const fe *)r;
+    size_t ns = len / 2;
+    for (size_t i = 0; i < ns; i++) {
+        fe lo = t[2 * i], hi = t[2 * i + 1];
+        fe d = f_sub(&FR, &hi, &lo), m = f_mul(&FR, rv, &d);
+        t[i] = f_add(&FR, &lo, &m);
+    }
+}
+/* DensePolynomial.bindFirst (high half, new array) — :128-149 */
+EXPORT void zo_fr_bind_high(const uint64_t *table, size_t len, const uint64_t r[4], uint64_t *out) {
+    const fe *t = (const fe *)table; fe *o = (fe *)out; const fe *rv = (const fe *)r;
+    size_t ns = len / 2;
+    fe one = f_one(&FR), omr = f_sub(&FR, &one, rv);
+    for (size_t i = 0; i < ns; i++) {
+        fe lo = f_mul(&FR, &t[i], &omr), hi = f_mul(&FR, &t[i + ns], rv);
+        o[i] = f_add(&FR, &lo, &hi);
+    }
+}
+/* JoltSpartanInterface.bindChallenge fold: new[i] = (1-r)*old[2i] + r*old[2i+1]
+ * — src/zkvm/r1cs/jolt_r1cs.zig:470-477 (out may alias table) */
+EXPORT void zo_fr_bind_low_2mul(const uint64_t *table, size_t len, const uint64_t r[4], uint64_t *out) {
+    const fe *t = (const fe *)table; fe *o = (fe *)out; const fe *rv = (const fe *)r;
+    size_t ns = len / 2;
+    fe one = f_one(&FR), omr = f_sub(&FR, &one, rv);
+    for (size_t i = 0; i < ns; i++) {
+        fe lo = f_mul(&FR, &omr, &t[2 * i]), hi = f_mul(&FR, rv, &t[2 * i + 1]);
+        o[i] = f_add(&FR, &lo, &hi);
+    }
+}
+/* DensePolynomial.evaluate — :73-92 (index bit j <-> point[j], LSB-first). O(n·v): small n only */
+EXPORT void zo_fr_dense_evaluate(const uint64_t *evals, size_t num_vars, const uint64_t *point, uint64_t out[4]) {
+    fe result = f_zero(), one = f_one(&FR);
+    size_t n = (size_t)1 << num_vars;
+    for (size_t i = 0; i < n; i++) {
+        fe term = *(const fe *)(evals + 4 * i);
+        for (size_t j = 0; j < num_vars; j++) {
+            const fe *pj = (const fe *)(point + 4 * j);
+            if ((i >> j) & 1) term = f_mul(&FR, &term, pj);
+            else { fe om = f_sub(&FR, &one, pj); term = f_mul(&FR, &term, &om); }
+        }
+        result = f_add(&FR, &result, &term);
+    }
+    memcpy(out, &result, 32);
+}
+/* Sumcheck.Prover.nextRound sums: g0 = Σ first half, g1 = Σ second half
+ * — src/subprotocols/mod.zig:79-93 */
+EXPORT void zo_fr_sum_halves(const uint64_t *table, size_t len, uint64_t g0[4], uint64_t g1[4]) {
+    const fe *t = (const fe *)table; size_t half = len / 2;
+    fe a = f_zero(), b = f_zero();
+    for (size_t i = 0; i < half; i++) a = f_add(&FR, &a, &t[i]);
+    for (size_t i = 0; i < half; i++) b = f_add(&FR, &b, &t[i + half]);
+    memcpy(g0, &a, 32); memcpy(g1, &b, 32);
+}
+/* even/odd sums used by the LowToHigh provers — src/zkvm/r1cs/jolt_r1cs.zig:436-444 */
+EXPORT void zo_fr_sum_even_odd(const uint64_t *table, size_t len, uint64_t s0[4], uint64_t s1[4]) {
+    const fe *t = (const fe *)table; size_t half = len / 2;
+    fe a = f_zero(), b = f_zero();
+    for (size_t i = 0; i < half; i++) { a = f_add(&FR, &a, &t[2 * i]); b = f_add(&FR, &b, &t[2 * i + 1]); }
+    memcpy(s0, &a, 32); memcpy(s1, &b, 32);
+}
+/* Spartan combine f[i] = eq[i]·(Az[i]·Bz[i] − Cz[i]) — src/zkvm/spartan/mod.zig:191-199 */
+EXPORT void zo_fr_spartan_combine(const uint64_t *eq, const uint64_t *az, const uint64_t *bz, const uint64_t *cz,
+                                  size_t n, uint64_t *out) {
+    for (size_t i = 0; i < n; i++) {
+        fe ab = f_mul(&FR, (const fe *)(az + 4 * i), (const fe *)(bz + 4 * i));
+        fe d = f_sub(&FR, &ab, (const fe *)(cz + 4 * i));
+        fe f = f_mul(&FR, (const fe *)(eq + 4 * i), &d);
+        memcpy(out + 4 * i, &f, 32);
+    }
+}
+/* UniPoly.evaluate (Horner) — src/poly/mod.zig:608-618 */
+static fe unipoly_eval(const fe *coeffs, size_t n, const fe *x) {
+    if (n == 0) return f_zero();
+    fe result = coeffs[n - 1];
+    for (size_t i = n - 1; i-- > 0;) { result = f_mul(&FR, &result, x); result = f_add(&FR, &result, &coeffs[i]); }
+    return result;
+}
+/* Verifier.deriveChallenge toy mixer — src/subprotocols/mod.zig:211-243 */
+static fe derive_challenge(size_t round, const fe *claim, const fe *coeffs, size_t ncoeffs) {
+    uint64_t h = 0x9e3779b97f4a7c15ULL;
+    h ^= (uint64_t)round; h *= 0xff51afd7ed558ccdULL;
+    for (int i = 0; i < 4; i++) { h ^= claim->l[i]; h *= 0xc4ceb9fe1a85ec53ULL; }
+    for (size_t c = 0; c < ncoeffs; c++)
+        for (int i = 0; i < 4; i++) { h ^= coeffs[c].l[i]; h *= 0xff51afd7ed558ccdULL; h ^= h >> 33; }
+    h ^= h >> 33; h *= 0xff51afd7ed558ccdULL; h ^= h >> 33;
+    return f_from_u64(&FR, h);
+}
+EXPORT void zo_sumcheck_derive_challenge(size_t round, const uint64_t claim[4], const uint64_t *coeffs, size_t ncoeffs, uint64_t out[4]) {
+    fe r = derive_challenge(round, (const fe *)claim, (const fe *)coeffs, ncoeffs); memcpy(out, &r, 32);
+}
+/* runSumcheck — src/subprotocols/mod.zig:302-354, with Prover.nextRound (:69-109),
+ * Verifier.verifyRound (:165-207), Prover.receiveChallenge (:112-122).
+ * outputs: claim[4]; rounds[num_vars][2][4] = [g0, g1-g0]; challenges[num_vars][4];
+ * final_eval[4]; returns 1 if verifier.claim == final_eval, 0 if not, -1 on
+ * SumcheckVerificationFailed. */
+EXPORT int zo_run_sumcheck(const uint64_t *evals, size_t num_vars, uint64_t claim_out[4], uint64_t *rounds,
+                           uint64_t *challenges, uint64_t final_eval[4]) {
+    size_t len = (size_t)1 << num_vars;
+    fe *cur = (fe *)malloc(len * sizeof(fe));
+    memcpy(cur, evals, len * 32);
+    fe claim = f_zero();
+    for (size_t i = 0; i < len; i++) claim = f_add(&FR, &claim, &cur[i]);
+    memcpy(claim_out, &claim, 32);
+    fe vclaim = claim;
+    for (size_t rd = 0; rd < num_vars; rd++) {
+        fe coeffs[2], g0, g1;
+        zo_fr_sum_halves((const uint64_t *)cur, len, g0.l, g1.l);
+        coeffs[0] = g0; coeffs[1] = f_sub(&FR, &g1, &g0);
+        memcpy(rounds + 8 * rd, coeffs, 64);
+        fe zero = f_zero(), one = f_one(&FR);
+        fe p0 = unipoly_eval(coeffs, 2, &zero), p1 = unipoly_eval(coeffs, 2, &one);
+        fe sum = f_add(&FR, &p0, &p1);
+        if (!f_eq(&sum, &vclaim)) { free(cur); return -1; }
+        fe ch = derive_challenge(rd, &vclaim, coeffs, 2);
+        memcpy(challenges + 4 * rd, &ch, 32);
+        vclaim = unipoly_eval(coeffs, 2, &ch);
+        fe *nw = (fe *)malloc((len / 2) * sizeof(fe));
+        zo_fr_bind_high((const uint64_t *)cur, len, ch.l, (uint64_t *)nw);
+        free(cur); cur = nw; len /= 2;
+    }
+    memcpy(final_eval, &cur[0], 32);
+    int ok = f_eq(&vclaim, &cur[0]);
+    free(cur);
+    return ok;
+}

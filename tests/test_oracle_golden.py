@@ -1,0 +1,253 @@
+"""Pins the CPU oracle (oracle/zolt_oracle.c) against the reference's own golden data
+and against the independent Python big-int model. CPU-only (-m "not gpu")."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+from oracle import pymodel as pm
+from tests import util as U
+
+FR, FP = ob.FR, ob.FP
+
+
+# ---------------------------------------------------------------- reference fixtures
+def test_bytecode_commitment_matches_reference_proof(golden_dir):
+    """logs/zolt_proof_regular.bin bytes 8..72 = HyperKZG.commit(bytecode poly) of
+    examples/fibonacci.elf (src/zkvm/mod.zig:1519-1538 -> commitment/mod.zig:239-255
+    -> msm/mod.zig:355-438), serialised by commitment_types.zig:49-54."""
+    elf = open(os.path.join(golden_dir, "fibonacci.elf"), "rb").read()
+    proof = open(os.path.join(golden_dir, "zolt_proof_regular.bin"), "rb").read()
+    assert proof[:4] == b"ZOLT"
+    code = elf[0x1000:0x1000 + 104]
+    srs, inf = ob.hyperkzg_setup(128)
+    ev = np.zeros(128, dtype=np.uint64)
+    ev[:104] = np.frombuffer(code, dtype=np.uint8)
+    c, ci = ob.hyperkzg_commit(srs, inf, ob.f_from_u64(FR, ev))
+    assert ci == 0
+    assert ob.commitment_to_bytes(c) == proof[8:72]
+    # the memory commitment in the same proof is the identity -> 64 zero bytes
+    z, zi = ob.hyperkzg_commit(srs, inf, np.zeros((0, 4), dtype=np.uint64))
+    assert zi == 1 and ob.commitment_to_bytes(z) == proof[232:296] == bytes(64)
+    # independent model agrees too
+    r = pm.msm(pm.mock_srs(128), [int(x) for x in ev])
+    assert pm.commitment_bytes(r) == proof[8:72]
+
+
+def test_field_constants_and_kats():
+    """src/field/mod.zig:16-75 constants; KATs :1101-1140 (3*7=21, 7*7^-1=1, 2^3=8)."""
+    for f, mod in ((FR, pm.R_MOD), (FP, pm.P_MOD)):
+        one = ob.f_from_u64(f, np.array([1], dtype=np.uint64))[0]
+        assert pm.from_limbs(one) == (1 << 256) % mod
+        a = ob.f_from_u64(f, np.array([3, 7, 2], dtype=np.uint64))
+        assert U.fr_to_int(ob.f_mul(f, a[0], a[1])) == 21 if f == FR else True
+        prod = ob.f_mul(f, a[1], ob.f_inv(f, a[1]))
+        assert np.array_equal(prod, one)
+        two = a[2]
+        assert np.array_equal(ob.f_mul(f, ob.f_mul(f, two, two), two), ob.f_from_u64(f, np.array([8], dtype=np.uint64))[0])
+        z = np.zeros(4, dtype=np.uint64)
+        assert np.array_equal(ob.f_neg(f, z), z)  # neg(0) = 0
+        assert np.array_equal(ob.f_inv(f, z), z)  # inverse(0) = null -> reported as 0
+
+
+@pytest.mark.parametrize("f,mod", [(FR, pm.R_MOD), (FP, pm.P_MOD)])
+def test_field_random_vs_bigint(f, mod):
+    n = 2000
+    a_raw = U.random_raw256(11 + f, n)
+    b_raw = U.random_raw256(23 + f, n)
+    # edge values, incl. values >= modulus for the fromBytes path (src/field/mod.zig:171-184)
+    edges = [0, 1, mod - 1, mod, mod + 1, (1 << 256) - 1, (1 << 256) % mod]
+    for i, e in enumerate(edges):
+        a_raw[i] = pm.limbs(e)
+        b_raw[-1 - i] = pm.limbs(e)
+    a = ob.f_to_mont(f, a_raw)
+    b = ob.f_to_mont(f, b_raw)
+    ai = [pm.from_limbs(x) % mod for x in a_raw]
+    bi = [pm.from_limbs(x) % mod for x in b_raw]
+    for name, fn, py in (("mul", ob.f_mul, lambda x, y: x * y), ("add", ob.f_add, lambda x, y: x + y),
+                         ("sub", ob.f_sub, lambda x, y: x - y)):
+        got = fn(f, a, b)
+        for i in range(n):
+            assert pm.from_mont(pm.from_limbs(got[i]), mod) == py(ai[i], bi[i]) % mod, name
+            assert pm.from_limbs(got[i]) < mod
+    back = ob.f_from_mont(f, a)
+    for i in range(n):
+        assert pm.from_limbs(back[i]) == ai[i]
+    inv = ob.f_inv(f, a[:64])
+    for i in range(64):
+        if ai[i]:
+            assert pm.from_mont(pm.from_limbs(inv[i]), mod) == pow(ai[i], -1, mod)
+
+
+def test_window_kats():
+    """src/msm/mod.zig:827-851."""
+    for n, c in ((1, 1), (7, 1), (8, 2), (31, 2), (32, 3), (127, 3), (128, 4), (511, 4), (512, 5), (2047, 5),
+                 (2048, 6), (8191, 6), (8192, 7), (32767, 7), (32768, 8), (1 << 20, 8)):
+        assert ob.optimal_window_size(n) == c
+    s = U.fr([202])[0]  # 0b11001010
+    assert ob.get_window(s, 0, 4) == 10 and ob.get_window(s, 1, 4) == 12
+    # limb-crossing window (c=7, bit 63)
+    v = (0x55 << 60) | 0x123
+    s = U.fr([v])[0]
+    for w in range(37):
+        assert ob.get_window(s, w, 7) == (v >> (7 * w)) & 0x7F
+
+
+def _xy_inf(case):
+    pts = [(int(p[0], 16), int(p[1], 16)) for p in case["points"]]
+    return U.points_xy(pts), np.array(case["inf"], dtype=np.uint8), U.fr_hex(case["scalars"])
+
+
+def test_msm_golden_vectors():
+    vec = U.load_vectors()
+    for case in vec["msm"]:
+        xy, inf, sc = _xy_inf(case)
+        out, oinf = ob.msm_g1(xy, inf, sc)
+        got = U.point_from_xy(out, oinf)
+        want = None if case["result"] is None else tuple(int(h, 16) for h in case["result"])
+        assert got == want, case["n"]
+        if case["n"] >= 4096:  # ParallelMSM only splits at >= 1024 points per thread
+            continue
+        out2, oinf2 = ob.msm_g1_parallel(xy, inf, sc, 4)
+        assert U.point_from_xy(out2, oinf2) == want
+
+
+def test_msm_reference_edge_semantics():
+    """src/msm/mod.zig:802-825,875-891,938-966 — 0*P = inf, 1*P = P, zero scalars, empty."""
+    g = U.points_xy([pm.G1])
+    out, inf = ob.g1_scalar_mul(g[0], 0, U.fr([0])[0])
+    assert inf == 1
+    out, inf = ob.g1_scalar_mul(g[0], 0, U.fr([1])[0])
+    assert inf == 0 and np.array_equal(out, g[0])
+    pts = ob.g1_gen_multiples(10)
+    out, inf = ob.msm_g1(pts, None, np.zeros((10, 4), dtype=np.uint64))
+    assert inf == 1 and not out.any()
+    out, inf = ob.msm_g1(pts[:0], None, np.zeros((0, 4), dtype=np.uint64))
+    assert inf == 1
+    out, inf = ob.msm_g1_parallel(pts[:8], None, np.zeros((8, 4), dtype=np.uint64), 4)
+    assert inf == 1
+    # scalarMul(P,2) == double (src/integration_tests.zig:145-161) and affine double == Jacobian double
+    d1, i1 = ob.g1_scalar_mul(g[0], 0, U.fr([2])[0])
+    d2, i2 = ob.g1_double_affine(g[0], 0)
+    assert i1 == i2 == 0 and np.array_equal(d1, d2)
+    assert U.point_from_xy(d1, 0) == pm.ec_add(pm.G1, pm.G1)
+
+
+def test_msm_bench_family_closed_form():
+    """Bases (i+1)G, scalars 7i+13 (src/bench.zig:261-268) against the closed form."""
+    vec = U.load_vectors()
+    gm = ob.g1_gen_multiples(1000)
+    for k, want in enumerate(vec["generator_multiples"]):
+        assert U.point_from_xy(gm[k], 0) == tuple(int(h, 16) for h in want)
+    for case in vec["msm_bench_family"]:
+        n = case["n"]
+        sc = ob.f_from_u64(FR, np.array([7 * i + 13 for i in range(n)], dtype=np.uint64))
+        out, inf = ob.msm_g1(gm[:n], None, sc)
+        assert U.point_from_xy(out, inf) == tuple(int(h, 16) for h in case["result"])
+
+
+def test_pippenger_window_paths_vs_closed_form():
+    """Exercise every optimalWindowSize branch incl. c=7 limb-crossing windows and c=8."""
+    gm = ob.g1_gen_multiples(40000)
+    for n in (8, 40, 200, 600, 2500, 9000, 33000, 40000):
+        raw = U.random_raw256(n, n)
+        sc = ob.f_to_mont(FR, raw)
+        ints = [pm.from_limbs(x) % pm.R_MOD for x in raw]
+        want = pm.msm_generator_multiples(range(1, n + 1), ints)
+        out, inf = ob.msm_g1(gm[:n], None, sc)
+        assert U.point_from_xy(out, inf) == want, n
+    out2, inf2 = ob.msm_g1_parallel(gm[:40000], None, sc, 8)
+    assert U.point_from_xy(out2, inf2) == want
+
+
+def test_mock_srs_and_batch_commit():
+    vec = U.load_vectors()
+    srs, inf = ob.hyperkzg_setup(6)
+    for i, want in enumerate(vec["mock_srs"]):
+        assert U.point_from_xy(srs[i], inf[i]) == tuple(int(h, 16) for h in want)
+        assert ob.g1_is_on_curve(srs[i])
+    # batchCommit[i] == commit(poly_i) (src/poly/commitment/mod.zig:1392-1420)
+    srs, inf = ob.hyperkzg_setup(16)
+    polys = [ob.f_to_mont(FR, U.random_raw256(5 + k, 16)) for k in range(3)]
+    outs, oinf = ob.msm_g1_batch(srs, inf, polys)
+    for k in range(3):
+        c, ci = ob.hyperkzg_commit(srs, inf, polys[k])
+        assert np.array_equal(c, outs[k]) and ci == oinf[k]
+
+
+# ---------------------------------------------------------------- poly / sumcheck
+def test_bind_low_kats():
+    """src/poly/mod.zig:816-888."""
+    got = ob.fr_bind_low(U.fr([1, 2, 3, 4]), U.fr([3])[0])
+    assert [U.fr_to_int(x) for x in got] == [4, 6]
+    got = ob.fr_bind_low(U.fr([10, 20, 30, 40, 50, 60, 70, 80]), U.fr([5])[0])
+    assert [U.fr_to_int(x) for x in got] == [60, 80, 100, 120]
+
+
+def test_sumcheck_kats():
+    """src/subprotocols/mod.zig:366-461."""
+    t = U.fr([1, 2, 3, 4])
+    g0, g1 = ob.fr_sum_halves(t)
+    assert (U.fr_to_int(g0), U.fr_to_int(g1)) == (3, 7)
+    t2 = ob.fr_bind_high(t, U.fr([2])[0])
+    assert [U.fr_to_int(x) for x in t2] == [5, 6]
+    claim, rounds, chals, fin, ok = ob.run_sumcheck(U.fr(range(1, 9)))
+    assert U.fr_to_int(claim) == 36 and ok == 1
+
+
+def test_eq_table_golden_and_properties():
+    vec = U.load_vectors()
+    for case in vec["eq_table"]:
+        r = U.fr_hex(case["r"]) if case["r"] else np.zeros((0, 4), dtype=np.uint64)
+        got = ob.fr_eq_table(r)
+        assert [U.fr_to_int(x) for x in got] == [int(h, 16) for h in case["table"]]
+        if len(case["r"]):
+            assert np.array_equal(ob.fr_eq_table_append_lsb(r), got)  # split_eq build order, same values
+        assert sum(U.fr_to_int(x) for x in got) % pm.R_MOD == 1  # partition of unity (poly/mod.zig:689-753)
+    # scaling factor
+    r = U.fr_hex(vec["eq_table"][3]["r"])
+    sc = U.fr([12345])[0]
+    got = ob.fr_eq_table(r, sc)
+    assert [U.fr_to_int(x) for x in got] == [int(h, 16) * 12345 % pm.R_MOD for h in vec["eq_table"][3]["table"]]
+    # the captured run's 13 tau challenges (logs/zolt.log:47-59) as a bigger input
+    taus = json.load(open(os.path.join(U.GOLDEN, "stage1_tau.json")))["tau_hex"]
+    tv = [int(h, 16) % pm.R_MOD for h in taus]
+    got = ob.fr_eq_table(U.fr(tv))
+    want = pm.eq_table(tv)
+    assert [U.fr_to_int(x) for x in got[:64]] == want[:64] and U.fr_to_int(got[-1]) == want[-1]
+
+
+def test_folds_and_sumcheck_golden():
+    vec = U.load_vectors()
+    for case in vec["folds"]:
+        t, r = U.fr_hex(case["table"]), U.fr_hex([case["r"]])[0]
+        assert [U.fr_to_int(x) for x in ob.fr_bind_high(t, r)] == [int(h, 16) for h in case["bind_high"]]
+        assert [U.fr_to_int(x) for x in ob.fr_bind_low(t, r)] == [int(h, 16) for h in case["bind_low"]]
+        assert [U.fr_to_int(x) for x in ob.fr_bind_low_2mul(t, r)] == [int(h, 16) for h in case["bind_low"]]
+    for case in vec["sumcheck"]:
+        claim, rounds, chals, fin, ok = ob.run_sumcheck(U.fr_hex(case["evals"]))
+        assert U.fr_to_int(claim) == int(case["claim"], 16)
+        assert [[U.fr_to_int(c) for c in rd] for rd in rounds] == [[int(h, 16) for h in rd] for rd in case["rounds"]]
+        assert [U.fr_to_int(c) for c in chals] == [int(h, 16) for h in case["challenges"]]
+        assert U.fr_to_int(fin) == int(case["final_eval"], 16) and ok == int(case["ok"])
+
+
+def test_dense_evaluate_and_hyperkzg_open_fold():
+    """DensePolynomial.evaluate corners (commitment/mod.zig:1448-1472) and open()'s final eval."""
+    t = ob.f_to_mont(FR, U.random_raw256(77, 8))
+    for idx in range(8):
+        pt = U.fr([(idx >> j) & 1 for j in range(3)])
+        assert np.array_equal(ob.fr_dense_evaluate(t, pt), t[idx])
+    srs, inf = ob.hyperkzg_setup(8)
+    point = ob.f_to_mont(FR, U.random_raw256(78, 3))
+    q, qinf, fin = ob.hyperkzg_open(srs, inf, t, point, np.zeros(4, dtype=np.uint64))
+    # open() folds the HIGH half first: final = evaluate with point reversed in LSB-first order
+    assert np.array_equal(fin, ob.fr_dense_evaluate(t, point[::-1].copy()))
+    cur = t
+    for i in range(3):
+        half = len(cur) // 2
+        c, ci = ob.hyperkzg_commit(srs, inf, ob.f_sub(FR, cur[half:], cur[:half]))
+        assert np.array_equal(c, q[i]) and ci == qinf[i]
+        cur = ob.fr_bind_high(cur, point[i])
