@@ -1,0 +1,176 @@
+/*
+ * zolt_gpu.h — C ABI of libzolt_gpu.so, the MI355X (gfx950) backend for Zolt's
+ * data-parallel prover inner loops.
+ *
+ * The reference (MatteoMer/zolt) has no FFI boundary; the seam is a set of Zig
+ * generic functions. Each entry point below names the reference
+ * function it replaces (paths relative to the reference root). A Zig shim keeps the
+ * `src/msm`, `src/poly`, `src/subprotocols` module APIs and forwards here — see
+ * INTEGRATION.md for the `extern fn` declarations.
+ *
+ * Conventions
+ *   - field element  : uint64_t[4], little-endian limbs, Montgomery form (R = 2^256),
+ *                      canonical (< modulus) — src/field/mod.zig:131,583-584.
+ *                      "fr" = BN254 scalar field (:16-41), "fp" = base field (:51-75).
+ *   - affine G1 point: uint64_t[8] = x limbs then y limbs (Fp), plus an out-of-band
+ *                      uint8_t infinity flag (the Zig struct layout {x,y,infinity} is not
+ *                      ABI-stable, src/msm/mod.zig:19-21). Identity is written as
+ *                      x = y = 0, inf = 1 like AffinePoint.identity() (:24-30).
+ *   - Jacobian record: uint64_t[12] = X,Y,Z (Fp); identity = (1,1,0) (:154-160).
+ *   - every function returns 0 on success or a ZG_ERR_* code, never throws, and is
+ *     re-entrant (MSM.compute is called from std.Thread workers, src/msm/mod.zig:637,732).
+ *     zg_last_error() gives the calling thread's last message.
+ *   - "_dev" variants take DEVICE pointers (hipMalloc'ed / torch tensors' data_ptr) and a
+ *     hipStream_t passed as void* (NULL = the library's stream); work is enqueued
+ *     asynchronously unless the function returns a host value.
+ *   - No CPU fallback exists: without a usable gfx950 device every compute entry point
+ *     fails with ZG_ERR_NO_DEVICE.
+ */
+#ifndef ZOLT_GPU_H
+#define ZOLT_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__GNUC__)
+#define ZG_API __attribute__((visibility("default")))
+#else
+#define ZG_API
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZG_OK 0
+#define ZG_ERR_INVALID 1   /* bad argument */
+#define ZG_ERR_HIP 2       /* HIP runtime error (see zg_last_error) */
+#define ZG_ERR_NOMEM 3
+#define ZG_ERR_NO_DEVICE 4
+
+#define ZG_FIELD_FR 0
+#define ZG_FIELD_FP 1
+
+/* elementwise ops for zg_field_op */
+#define ZG_OP_MUL 0        /* montgomeryMul, src/field/mod.zig:269-308 / :735-779 */
+#define ZG_OP_ADD 1        /* :402-417 / :782-798 */
+#define ZG_OP_SUB 2        /* :420-435 / :801-816 */
+#define ZG_OP_NEG 3        /* :494-497 / :944-947 (b ignored) */
+#define ZG_OP_SQR 4        /* :443-445 / :866-941 (b ignored) */
+#define ZG_OP_INV 5        /* :500-518 / :955-983; inverse(0) -> 0 (b ignored) */
+#define ZG_OP_FROM_MONT 6  /* :187-189 / :642-645 (b ignored) */
+#define ZG_OP_TO_MONT 7    /* fromBytes' reduction :171-184 / :625-639: raw 256-bit LE -> Montgomery (b ignored) */
+
+/* ------------------------------------------------------------------ lifecycle */
+/* Binds the calling process to one GPU (device < 0: keep the current HIP device) and
+ * creates the library stream. Idempotent. */
+ZG_API int zg_init(int device);
+ZG_API void zg_shutdown(void);
+ZG_API const char *zg_last_error(void);
+ZG_API const char *zg_version(void);
+ZG_API int zg_device_count(void);
+
+/* raw device memory, for hosts without their own HIP binding (the Zig shim) */
+ZG_API int zg_dev_alloc(size_t bytes, void **dptr);
+ZG_API int zg_dev_free(void *dptr);
+ZG_API int zg_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
+ZG_API int zg_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
+ZG_API int zg_sync(void);
+
+/* ------------------------------------------------------------------ field vectors */
+/* out[i] = op(a[i], b[i]) over n elements; host pointers. Replaces the scalar loops of
+ * field.BatchOps (src/field/mod.zig:1164-1280) and backs the device-arithmetic unit tests. */
+ZG_API int zg_field_op(int field, int op, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
+
+/* ------------------------------------------------------------------ G1 bases (SRS) */
+typedef struct zg_bases_s *zg_bases_t;
+
+/* MSM tuning. window_bits 0 = auto from n; precompute_levels: 1 = none, 0 = auto,
+ * k>1 = store 2^(c*G*l)*P for l<k at upload so k windows share one bucket set
+ * (HBM cost k*64 B per base). Results do not depend on these. */
+typedef struct {
+    int window_bits;
+    int precompute_levels;
+} zg_msm_config;
+
+/* Upload n affine bases once and keep them resident in HBM for any number of MSMs —
+ * the device-side image of HyperKZG SetupParams.powers_of_tau_g1
+ * (src/poly/commitment/mod.zig:122-140), which lives for the whole prover run.
+ * inf may be NULL (no infinity bases). cfg may be NULL (auto). Bases must be on the
+ * curve y^2 = x^3 + 3 (src/msm/mod.zig:106-115). */
+ZG_API int zg_g1_bases_upload(const uint64_t *xy, const uint8_t *inf, size_t n, const zg_msm_config *cfg, zg_bases_t *out);
+ZG_API int zg_g1_bases_upload_dev(const uint64_t *d_xy, const uint8_t *d_inf, size_t n, const zg_msm_config *cfg, void *stream,
+                           zg_bases_t *out);
+ZG_API int zg_g1_bases_free(zg_bases_t b);
+ZG_API size_t zg_g1_bases_len(zg_bases_t b);
+
+/* ------------------------------------------------------------------ MSM */
+/* MSM(F,G).compute(bases[off..off+n], scalars) -> Affine   (src/msm/mod.zig:355-438)
+ * = HyperKZG.commit when bases is the SRS (src/poly/commitment/mod.zig:239-255).
+ * n = 0 -> identity (:361-363). Scalars: n x 4 Montgomery Fr limbs on the host. */
+ZG_API int zg_msm_g1(zg_bases_t b, size_t off, size_t n, const uint64_t *scalars_mont, uint64_t out_xy[8], uint8_t *out_inf);
+/* same, scalars already resident in HBM */
+ZG_API int zg_msm_g1_dev(zg_bases_t b, size_t off, size_t n, const uint64_t *d_scalars_mont, void *stream, uint64_t out_xy[8],
+                  uint8_t *out_inf);
+/* asynchronous form: the affine result (8 limbs) and the flag are written to DEVICE memory */
+ZG_API int zg_msm_g1_dev_async(zg_bases_t b, size_t off, size_t n, const uint64_t *d_scalars_mont, void *stream,
+                        uint64_t *d_out_xy, uint8_t *d_out_inf);
+/* BatchMSM / ParallelBatchMSM.compute (src/msm/mod.zig:545-565,683-748) = HyperKZG.batchCommit
+ * (src/poly/commitment/mod.zig:558-570): k scalar vectors of length n over bases[0..n]. */
+ZG_API int zg_msm_g1_batch(zg_bases_t b, size_t n, const uint64_t *const *scalar_batches, size_t k, uint64_t *out_xy /* k*8 */,
+                    uint8_t *out_inf /* k */);
+/* ParallelMSM's per-chunk result (src/msm/mod.zig:656-665): this GPU's partial sum as the
+ * reference's Jacobian record fromAffine(SingleMSM.compute(chunk)) = (x,y,1) or (1,1,0),
+ * written to DEVICE memory so it can be all-gathered over RCCL without a host round trip. */
+ZG_API int zg_msm_g1_partial_dev(zg_bases_t b, size_t off, size_t n, const uint64_t *d_scalars_mont, void *stream,
+                          uint64_t *d_out_jac /* 12 */);
+/* ParallelMSM's serial combine + toAffine (src/msm/mod.zig:647-652) over k gathered
+ * Jacobian partials resident on the device. */
+ZG_API int zg_g1_combine_partials_dev(const uint64_t *d_partials_jac /* k*12 */, size_t k, void *stream, uint64_t out_xy[8],
+                               uint8_t *out_inf);
+/* MSM(F,G).scalarMul(base, scalar).toAffine() for n independent (base, scalar) pairs
+ * (src/msm/mod.zig:503-540) — the primitive of HyperKZG.setup (commitment/mod.zig:194-199). */
+ZG_API int zg_g1_scalar_mul_batch(const uint64_t *xy, const uint8_t *inf, const uint64_t *scalars_mont, size_t n,
+                           uint64_t *out_xy, uint8_t *out_inf);
+
+/* ------------------------------------------------------------------ poly tables */
+/* EqPolynomial.evals / evalsSliceWithScaling (src/poly/mod.zig:240-290): out[2^v], index MSB <-> r[0];
+ * scale may be NULL (= one). Identical values to GruenSplitEqPolynomial's tables
+ * (src/poly/split_eq.zig:122-171). */
+ZG_API int zg_fr_eq_table(const uint64_t *r, size_t v, const uint64_t *scale, uint64_t *out);
+ZG_API int zg_fr_eq_table_dev(const uint64_t *r_host, size_t v, const uint64_t *scale_host, uint64_t *d_out, void *stream);
+/* DensePolynomial.bindLow, in place: t[i] = t[2i] + r*(t[2i+1]-t[2i]), len -> len/2 (src/poly/mod.zig:160-175) */
+ZG_API int zg_fr_bind_low(uint64_t *table, size_t len, const uint64_t r[4]);
+/* DensePolynomial.bindFirst: out[i] = (1-r)*t[i] + r*t[i+len/2] (src/poly/mod.zig:128-149) */
+ZG_API int zg_fr_bind_high(const uint64_t *table, size_t len, const uint64_t r[4], uint64_t *out);
+/* Spartan combine f[i] = eq[i]*(Az[i]*Bz[i] - Cz[i]) (src/zkvm/spartan/mod.zig:191-199) */
+ZG_API int zg_fr_spartan_combine(const uint64_t *eq, const uint64_t *az, const uint64_t *bz, const uint64_t *cz, size_t n,
+                          uint64_t *out);
+ZG_API int zg_fr_spartan_combine_dev(const uint64_t *d_eq, const uint64_t *d_az, const uint64_t *d_bz, const uint64_t *d_cz,
+                              size_t n, uint64_t *d_out, void *stream);
+
+/* ------------------------------------------------------------------ sumcheck session */
+/* A device-resident Sumcheck(F).Prover (src/subprotocols/mod.zig:50-134): the table stays in
+ * HBM across rounds; per round only two field elements come back and one goes in.
+ * layout ZG_SC_HIGH_HALF = bindFirst order (the generic prover, :112-122);
+ *        ZG_SC_LOW_PAIR  = bindLow order (src/poly/mod.zig:160-175; zkvm/r1cs/jolt_r1cs.zig:470-477). */
+#define ZG_SC_HIGH_HALF 0
+#define ZG_SC_LOW_PAIR 1
+typedef struct zg_sc_s *zg_sc_t;
+ZG_API int zg_sumcheck_open(const uint64_t *evals, size_t len, int layout, zg_sc_t *s);
+ZG_API int zg_sumcheck_open_dev(const uint64_t *d_evals, size_t len, int layout, void *stream, zg_sc_t *s); /* copies */
+/* Prover.nextRound's two sums (:79-93): HIGH_HALF g0 = sum first half, g1 = sum second half;
+ * LOW_PAIR g0 = sum even, g1 = sum odd (jolt_r1cs.zig:436-444). */
+ZG_API int zg_sumcheck_round_sums(zg_sc_t s, uint64_t g0[4], uint64_t g1[4]);
+/* Prover.receiveChallenge (:112-122): fold by r. The next round's sums are produced by the
+ * same kernel and returned by the following zg_sumcheck_round_sums without another pass. */
+ZG_API int zg_sumcheck_bind(zg_sc_t s, const uint64_t r[4]);
+ZG_API size_t zg_sumcheck_len(zg_sc_t s);
+ZG_API int zg_sumcheck_final(zg_sc_t s, uint64_t out[4]); /* getFinalEval (:130-133), needs len == 1 */
+ZG_API int zg_sumcheck_read(zg_sc_t s, uint64_t *out_table); /* copy the current table to the host (tests) */
+ZG_API int zg_sumcheck_close(zg_sc_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZOLT_GPU_H */

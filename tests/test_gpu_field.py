@@ -1,0 +1,66 @@
+"""Device field arithmetic (zolt_amd/csrc/field.hip.h) vs the CPU oracle, through the C ABI."""
+import numpy as np
+import pytest
+
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def zl():
+    from zolt_amd import lib
+    lib.init()
+    return lib
+
+
+def _edge_raw(mod):
+    from oracle import pymodel as pm
+    vals = [0, 1, 2, mod - 1, mod - 2, mod, mod + 1, (1 << 256) - 1, (1 << 256) % mod, (1 << 255), (1 << 64) - 1, 1 << 64,
+            (1 << 128) - 1, ((1 << 256) % mod) - 1, mod >> 1]
+    return np.array([pm.limbs(v) for v in vals], dtype=np.uint64)
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_field_ops_match_oracle(zl, field):
+    from oracle import binding as ob
+    from oracle import pymodel as pm
+    mod = pm.R_MOD if field == 0 else pm.P_MOD
+    n = 1 << 20  # >= 10^6 random pairs
+    a_raw = U.random_raw256(101 + field, n)
+    b_raw = U.random_raw256(202 + field, n)
+    e = _edge_raw(mod)
+    a_raw[: len(e)] = e
+    b_raw[: len(e)] = e[::-1]
+    b_raw[len(e): 2 * len(e)] = e  # edge x edge on the diagonal too
+    a_raw[len(e): 2 * len(e)] = e
+    # TO_MONT accepts raw values >= modulus (fromBytes, src/field/mod.zig:171-184)
+    a = zl.field_op(field, zl.OP_TO_MONT, a_raw)
+    b = zl.field_op(field, zl.OP_TO_MONT, b_raw)
+    assert np.array_equal(a, ob.f_to_mont(field, a_raw))
+    assert np.array_equal(b, ob.f_to_mont(field, b_raw))
+    assert np.array_equal(zl.field_op(field, zl.OP_MUL, a, b), ob.f_mul(field, a, b))
+    assert np.array_equal(zl.field_op(field, zl.OP_ADD, a, b), ob.f_add(field, a, b))
+    assert np.array_equal(zl.field_op(field, zl.OP_SUB, a, b), ob.f_sub(field, a, b))
+    assert np.array_equal(zl.field_op(field, zl.OP_NEG, a), ob.f_neg(field, a))
+    assert np.array_equal(zl.field_op(field, zl.OP_SQR, a), ob.f_sqr(field, a))
+    assert np.array_equal(zl.field_op(field, zl.OP_FROM_MONT, a), ob.f_from_mont(field, a))
+    k = 4096
+    assert np.array_equal(zl.field_op(field, zl.OP_INV, a[:k]), ob.f_inv(field, a[:k]))
+
+
+def test_field_kats(zl):
+    """src/field/mod.zig:1101-1140: 3*7 = 21, 7*7^-1 = 1, 2^3 = 8."""
+    f = U.fr([3, 7, 2, 21, 8, 1])
+    assert np.array_equal(zl.field_op(0, zl.OP_MUL, f[0:1], f[1:2])[0], f[3])
+    inv7 = zl.field_op(0, zl.OP_INV, f[1:2])
+    assert np.array_equal(zl.field_op(0, zl.OP_MUL, f[1:2], inv7)[0], f[5])
+    sq = zl.field_op(0, zl.OP_SQR, f[2:3])
+    assert np.array_equal(zl.field_op(0, zl.OP_MUL, sq, f[2:3])[0], f[4])
+    z = np.zeros((1, 4), dtype=np.uint64)
+    assert not zl.field_op(0, zl.OP_NEG, z).any() and not zl.field_op(0, zl.OP_INV, z).any()
+
+
+def test_invalid_arguments(zl):
+    with pytest.raises(zl.ZgError):
+        zl.field_op(7, zl.OP_MUL, np.zeros((1, 4), dtype=np.uint64), np.zeros((1, 4), dtype=np.uint64))

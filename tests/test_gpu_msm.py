@@ -1,0 +1,232 @@
+"""MSM parity: zg_msm_g1* (HIP) vs the CPU oracle (restated pippengerMSM), the golden
+fixtures and the closed form. Everything goes through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def zl():
+    from zolt_amd import lib
+    lib.init()
+    return lib
+
+
+@pytest.fixture(scope="module")
+def ob():
+    from oracle import binding
+    return binding
+
+
+@pytest.fixture(scope="module")
+def gm(ob):
+    return ob.g1_gen_multiples((1 << 16) + 1)  # P_i = (i+1)G, src/bench.zig:261-268
+
+
+def _scalars(ob, seed, n):
+    return ob.f_to_mont(ob.FR, U.random_raw256(seed, n))
+
+
+def _check(zl, ob, xy, inf, sc, **cfg):
+    b = zl.Bases.upload(xy, inf, **cfg)
+    got, ginf = b.msm(sc)
+    b.free()
+    want, winf = ob.msm_g1(xy, inf, sc)
+    assert ginf == winf
+    assert np.array_equal(got, want), (got, want)
+
+
+def test_golden_vectors(zl, ob):
+    """tests/golden/vectors.json: duplicates, P/-P pairs, infinity bases, scalars 0/1/r-1."""
+    from oracle import pymodel as pm
+    for case in U.load_vectors()["msm"]:
+        pts = [(int(p[0], 16), int(p[1], 16)) for p in case["points"]]
+        xy, inf, sc = U.points_xy(pts), np.array(case["inf"], dtype=np.uint8), U.fr_hex(case["scalars"])
+        for cfg in ({}, {"window_bits": 8, "precompute_levels": 1}, {"window_bits": 5, "precompute_levels": 3}):
+            b = zl.Bases.upload(xy, inf, **cfg)
+            got, ginf = b.msm(sc)
+            b.free()
+            want = None if case["result"] is None else tuple(int(h, 16) for h in case["result"])
+            assert U.point_from_xy(got, ginf) == want, (case["n"], cfg)
+            if want is None:
+                assert not got.any()  # identity is {0,0,inf}, src/msm/mod.zig:24-30
+
+
+@pytest.mark.parametrize("n", [0, 1, 7, 8, 9, 31, 32, 100, 1000, (1 << 15) - 1, 1 << 15, (1 << 16) + 1])
+def test_sizes_vs_oracle(zl, ob, gm, n):
+    """SURVEY §8(d) adversarial size set (the reference switches algorithm at n=8 and window size at 32/128/.../32768)."""
+    _check(zl, ob, gm[:n], None, _scalars(ob, 1000 + n, n))
+
+
+@pytest.mark.parametrize("cfg", [dict(window_bits=8, precompute_levels=1), dict(window_bits=13, precompute_levels=1),
+                                 dict(window_bits=16, precompute_levels=1), dict(window_bits=11, precompute_levels=4),
+                                 dict(window_bits=16, precompute_levels=16), dict(window_bits=7, precompute_levels=0)])
+def test_window_and_precompute_configs(zl, ob, gm, cfg):
+    """The result must not depend on the window size or the precompute depth."""
+    n = 5000
+    _check(zl, ob, gm[:n], None, _scalars(ob, 77, n), **cfg)
+
+
+def test_adversarial_inputs(zl, ob, gm):
+    from oracle import pymodel as pm
+    n = 4096
+    rng = np.random.default_rng(5)
+    # all-equal points: every bucket add after the first is P+P or kP+P (forces the doubling branch)
+    same = np.repeat(gm[3:4], n, axis=0)
+    _check(zl, ob, same, None, _scalars(ob, 5, n))
+    # all scalars equal: single-bucket pile-up per window
+    one_scalar = np.repeat(_scalars(ob, 6, 1), n, axis=0)
+    _check(zl, ob, gm[:n], None, one_scalar)
+    _check(zl, ob, same, None, one_scalar)
+    # P / -P pairs with equal scalars cancel to the identity
+    neg = gm[:n].copy()
+    neg[:, 4:] = ob.f_neg(ob.FP, gm[:n, 4:])
+    xy = np.concatenate([gm[:n], neg])
+    sc = _scalars(ob, 7, n)
+    b = zl.Bases.upload(xy)
+    got, ginf = b.msm(np.concatenate([sc, sc]))
+    b.free()
+    assert ginf == 1 and not got.any()
+    # scalars 0, 1, r-1 and duplicates of the same (P, s)
+    special = U.fr([0, 1, pm.R_MOD - 1, 2, pm.R_MOD - 2])
+    sc = special[rng.integers(0, 5, size=n)]
+    _check(zl, ob, gm[:n], None, sc)
+    dup_idx = rng.integers(0, 16, size=n)
+    _check(zl, ob, gm[dup_idx], None, _scalars(ob, 8, 16)[dup_idx])
+    # infinity bases are skipped (src/msm/mod.zig:407), zero scalars -> identity (:875-891)
+    inf = (rng.integers(0, 3, size=n) == 0).astype(np.uint8)
+    _check(zl, ob, gm[:n], inf, _scalars(ob, 9, n))
+    b = zl.Bases.upload(gm[:10])
+    got, ginf = b.msm(np.zeros((10, 4), dtype=np.uint64))
+    assert ginf == 1 and not got.any()
+    got, ginf = b.msm(np.zeros((0, 4), dtype=np.uint64), n=0)  # empty -> identity (:938-947)
+    assert ginf == 1 and not got.any()
+    b.free()
+
+
+def test_bench_family_closed_form(zl, ob, gm):
+    """Bases (i+1)G, scalars 7i+13 (src/bench.zig:261-268): GPU == oracle == (sum s_i (i+1))·G."""
+    from oracle import pymodel as pm
+    for n in (16, 64, 256, 1 << 16):
+        sc = ob.f_from_u64(ob.FR, np.arange(n, dtype=np.uint64) * np.uint64(7) + np.uint64(13))
+        b = zl.Bases.upload(gm[:n])
+        got, ginf = b.msm(sc)
+        b.free()
+        want = pm.msm_generator_multiples(range(1, n + 1), [7 * i + 13 for i in range(n)])
+        assert U.point_from_xy(got, ginf) == want
+    for case in U.load_vectors()["msm_bench_family"]:
+        n = case["n"]
+        sc = ob.f_from_u64(ob.FR, np.arange(n, dtype=np.uint64) * np.uint64(7) + np.uint64(13))
+        b = zl.Bases.upload(gm[:n])
+        got, ginf = b.msm(sc)
+        b.free()
+        assert U.point_from_xy(got, ginf) == tuple(int(h, 16) for h in case["result"])
+
+
+def test_subrange_batch_and_partials(zl, ob, gm):
+    n = 3000
+    b = zl.Bases.upload(gm[:n])
+    sc = _scalars(ob, 31, n)
+    # MSM over bases[off..off+m) — HyperKZG.open commits to halving prefixes (commitment/mod.zig:287-315)
+    for off, m in ((0, 1500), (100, 900), (2999, 1), (0, 0)):
+        got, ginf = b.msm(sc[:m], off=off, n=m)
+        want, winf = ob.msm_g1(gm[off:off + m], None, sc[:m])
+        assert ginf == winf and np.array_equal(got, want)
+    # BatchMSM.compute / batchCommit[i] == commit(poly_i) (commitment/mod.zig:1392-1420)
+    batches = [_scalars(ob, 40 + k, n) for k in range(3)]
+    outs, infs = b.msm_batch(batches)
+    wouts, winfs = ob.msm_g1_batch(gm[:n], None, batches)
+    assert np.array_equal(outs, wouts) and np.array_equal(infs, winfs)
+    b.free()
+
+
+def test_parallel_msm_partials_combine(zl, ob, gm):
+    """ParallelMSM (src/msm/mod.zig:572-680): contiguous chunks -> Jacobian partials -> serial combine.
+    Partials must equal fromAffine(SingleMSM.compute(chunk)) exactly, the combined point the full MSM."""
+    import ctypes as C
+    n, T = 8192, 4
+    sc = _scalars(ob, 55, n)
+    chunk = (n + T - 1) // T
+    d_sc = C.c_void_p()
+    d_part = C.c_void_p()
+    assert zl._lib.zg_dev_alloc(C.c_size_t(n * 32), C.byref(d_sc)) == 0
+    assert zl._lib.zg_dev_alloc(C.c_size_t(T * 96), C.byref(d_part)) == 0
+    assert zl._lib.zg_memcpy_h2d(d_sc, sc.ctypes.data_as(C.c_void_p), C.c_size_t(n * 32)) == 0
+    b = zl.Bases.upload(gm[:n])
+    for t in range(T):
+        b.msm_partial_dev(d_sc.value + t * chunk * 32, chunk, d_part.value + t * 96, off=t * chunk)
+    zl.sync()
+    parts = np.empty((T, 12), dtype=np.uint64)
+    assert zl._lib.zg_memcpy_d2h(parts.ctypes.data_as(C.c_void_p), d_part, C.c_size_t(T * 96)) == 0
+    one = ob.f_from_u64(ob.FP, np.array([1], dtype=np.uint64))[0]
+    for t in range(T):
+        want, winf = ob.msm_g1(gm[t * chunk:(t + 1) * chunk], None, sc[t * chunk:(t + 1) * chunk])
+        assert winf == 0 and np.array_equal(parts[t, :8], want) and np.array_equal(parts[t, 8:], one)
+    got, ginf = zl.combine_partials_dev(d_part.value, T)
+    want, winf = ob.msm_g1_parallel(gm[:n], None, sc, T)
+    assert ginf == winf and np.array_equal(got, want)
+    full, finf = b.msm(sc)
+    assert np.array_equal(full, got)
+    # an empty shard contributes the reference's identity record (1,1,0)
+    b.msm_partial_dev(d_sc.value, 0, d_part.value)
+    zl.sync()
+    assert zl._lib.zg_memcpy_d2h(parts.ctypes.data_as(C.c_void_p), d_part, C.c_size_t(96)) == 0
+    assert np.array_equal(parts[0, :4], one) and np.array_equal(parts[0, 4:8], one) and not parts[0, 8:].any()
+    b.free()
+    zl._lib.zg_dev_free(d_sc)
+    zl._lib.zg_dev_free(d_part)
+
+
+def test_srs_and_reference_proof_commitment(zl, ob, golden_dir):
+    """HyperKZG.setup (mock SRS) + commit of fibonacci.elf's bytecode polynomial reproduce the
+    bytes stored in the reference's captured proof (logs/zolt_proof_regular.bin @8..72)."""
+    from oracle import pymodel as pm
+    elf = open(os.path.join(golden_dir, "fibonacci.elf"), "rb").read()
+    proof = open(os.path.join(golden_dir, "zolt_proof_regular.bin"), "rb").read()
+    n = 128
+    g = U.points_xy([pm.G1])
+    taus = U.fr([pow(pm.TAU, i, pm.R_MOD) for i in range(n)])
+    srs, sinf = zl.g1_scalar_mul_batch(np.repeat(g, n, axis=0), np.zeros(n, dtype=np.uint8), taus)
+    wsrs, winf = ob.hyperkzg_setup(n)
+    assert np.array_equal(srs, wsrs) and np.array_equal(sinf, winf)
+    ev = np.zeros(n, dtype=np.uint64)
+    ev[:104] = np.frombuffer(elf[0x1000:0x1000 + 104], dtype=np.uint8)
+    b = zl.Bases.upload(srs, sinf)
+    got, ginf = b.msm(U.fr(ev))
+    b.free()
+    assert ginf == 0
+    x = U.fp_to_int(got[:4]).to_bytes(32, "big")
+    y = U.fp_to_int(got[4:]).to_bytes(32, "big")
+    assert x + y == proof[8:72]
+    # scalarMul edge cases: 0*P = inf, 1*P = P, k*inf = inf (src/msm/mod.zig:503-505,802-825)
+    out, oinf = zl.g1_scalar_mul_batch(np.repeat(g, 3, axis=0), np.array([0, 0, 1], dtype=np.uint8), U.fr([0, 1, 5]))
+    assert list(oinf) == [1, 0, 1] and np.array_equal(out[1], g[0]) and not out[0].any() and not out[2].any()
+
+
+@pytest.mark.parametrize("logn", [20])
+def test_full_size_closed_form(zl, ob, logn):
+    """BASELINE config 2 (2^20 points, one GPU): uniform scalars; the result must equal the
+    size-independent closed form (sum s_i (i+1) mod r)·G and the oracle's ParallelMSM."""
+    from oracle import pymodel as pm
+    n = 1 << logn
+    gm = ob.g1_gen_multiples(n)
+    raw = U.random_raw256(0x5A4F4C54, n)
+    sc = ob.f_to_mont(ob.FR, raw)
+    b = zl.Bases.upload(gm)
+    got, ginf = b.msm(sc)
+    got2, ginf2 = b.msm(sc)  # idempotent: same handle, same answer
+    b.free()
+    assert np.array_equal(got, got2) and ginf == ginf2 == 0
+    # closed form in Python big ints, vectorised per limb to keep it O(seconds)
+    k = np.arange(1, n + 1, dtype=object)
+    tot = 0
+    for limb in range(4):
+        tot += int((raw[:, limb].astype(object) * k).sum()) << (64 * limb)
+    # raw values may exceed r: the scalar is raw mod r
+    want = pm.ec_mul(tot % pm.R_MOD, pm.G1)
+    assert U.point_from_xy(got, ginf) == want

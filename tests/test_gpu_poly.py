@@ -1,0 +1,176 @@
+"""eq-table / fold / sumcheck parity: HIP kernels vs the CPU oracle through the C ABI."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def zl():
+    from zolt_amd import lib
+    lib.init()
+    return lib
+
+
+@pytest.fixture(scope="module")
+def ob():
+    from oracle import binding
+    return binding
+
+
+def _rand(ob, seed, n):
+    return ob.f_to_mont(ob.FR, U.random_raw256(seed, n))
+
+
+@pytest.mark.parametrize("v", [0, 1, 2, 3, 7, 8, 9, 13, 16])
+def test_eq_table_vs_oracle(zl, ob, v):
+    r = _rand(ob, 300 + v, v)
+    assert np.array_equal(zl.fr_eq_table(r), ob.fr_eq_table(r))
+    scale = _rand(ob, 400 + v, 1)[0]
+    assert np.array_equal(zl.fr_eq_table(r, scale), ob.fr_eq_table(r, scale))
+
+
+def test_eq_table_golden(zl, ob):
+    vec = U.load_vectors()
+    for case in vec["eq_table"]:
+        r = U.fr_hex(case["r"]) if case["r"] else np.zeros((0, 4), dtype=np.uint64)
+        got = zl.fr_eq_table(r)
+        assert [U.fr_to_int(x) for x in got] == [int(h, 16) for h in case["table"]]
+    # the captured run's 13 Stage-1 tau challenges (reference logs/zolt.log:47-59)
+    taus = json.load(open(os.path.join(U.GOLDEN, "stage1_tau.json")))["tau_hex"]
+    from oracle import pymodel as pm
+    r = U.fr([int(h, 16) % pm.R_MOD for h in taus])
+    got = zl.fr_eq_table(r)
+    assert np.array_equal(got, ob.fr_eq_table(r))
+    assert np.array_equal(got, ob.fr_eq_table_append_lsb(r))  # GruenSplitEq build order, same table
+
+
+def test_bind_kats_and_golden(zl, ob):
+    """src/poly/mod.zig:816-888 and tests/golden folds."""
+    got = zl.fr_bind_low(U.fr([1, 2, 3, 4]), U.fr([3])[0])
+    assert [U.fr_to_int(x) for x in got] == [4, 6]
+    got = zl.fr_bind_low(U.fr([10, 20, 30, 40, 50, 60, 70, 80]), U.fr([5])[0])
+    assert [U.fr_to_int(x) for x in got] == [60, 80, 100, 120]
+    got = zl.fr_bind_high(U.fr([1, 2, 3, 4]), U.fr([2])[0])  # src/subprotocols/mod.zig:426-432
+    assert [U.fr_to_int(x) for x in got] == [5, 6]
+    for case in U.load_vectors()["folds"]:
+        t, r = U.fr_hex(case["table"]), U.fr_hex([case["r"]])[0]
+        assert [U.fr_to_int(x) for x in zl.fr_bind_high(t, r)] == [int(h, 16) for h in case["bind_high"]]
+        assert [U.fr_to_int(x) for x in zl.fr_bind_low(t, r)] == [int(h, 16) for h in case["bind_low"]]
+
+
+@pytest.mark.parametrize("logn", [1, 2, 5, 9, 14, 18])
+def test_binds_vs_oracle(zl, ob, logn):
+    t = _rand(ob, 500 + logn, 1 << logn)
+    r = _rand(ob, 600 + logn, 1)[0]
+    assert np.array_equal(zl.fr_bind_high(t, r), ob.fr_bind_high(t, r))
+    assert np.array_equal(zl.fr_bind_low(t, r), ob.fr_bind_low(t, r))
+    assert np.array_equal(zl.fr_bind_low(t, r), ob.fr_bind_low_2mul(t, r))  # jolt_r1cs.zig:470-477 form
+
+
+def test_spartan_combine(zl, ob):
+    n = 5000
+    eq, az, bz, cz = (_rand(ob, 700 + k, n) for k in range(4))
+    cz[n // 2:] = 0  # zero-padded past num_constraints (src/zkvm/spartan/mod.zig:191-199)
+    assert np.array_equal(zl.fr_spartan_combine(eq, az, bz, cz), ob.fr_spartan_combine(eq, az, bz, cz))
+
+
+def _run_sumcheck_gpu(zl, ob, evals):
+    """runSumcheck (src/subprotocols/mod.zig:302-354) with the table resident on the GPU; the toy
+    verifier's challenge derivation stays on the host exactly like the reference."""
+    from oracle import pymodel as pm
+    s = zl.SumcheckSession.open(evals, zl.SC_HIGH_HALF)
+    g0, g1 = s.round_sums()
+    claim = ob.f_add(ob.FR, g0, g1)
+    vclaim = claim
+    rounds, chals = [], []
+    rd = 0
+    while len(s) > 1:
+        g0, g1 = s.round_sums()
+        coeffs = np.stack([g0, ob.f_sub(ob.FR, g1, g0)])
+        assert np.array_equal(ob.f_add(ob.FR, ob.f_add(ob.FR, coeffs[0], coeffs[0]), coeffs[1]), vclaim)
+        ch = ob.sumcheck_derive_challenge(rd, vclaim, coeffs)
+        vclaim = ob.f_add(ob.FR, ob.f_mul(ob.FR, coeffs[1], ch), coeffs[0])
+        s.bind(ch)
+        rounds.append(coeffs)
+        chals.append(ch)
+        rd += 1
+    fin = s.final()
+    s.close()
+    return claim, np.array(rounds), np.array(chals), fin, int(np.array_equal(vclaim, fin))
+
+
+@pytest.mark.parametrize("logn", [1, 3, 6, 12, 16])
+def test_run_sumcheck_vs_oracle(zl, ob, logn):
+    evals = _rand(ob, 800 + logn, 1 << logn)
+    c, rds, chs, fin, ok = _run_sumcheck_gpu(zl, ob, evals)
+    wc, wr, wch, wfin, wok = ob.run_sumcheck(evals)
+    assert np.array_equal(c, wc) and np.array_equal(rds, wr) and np.array_equal(chs, wch)
+    assert np.array_equal(fin, wfin) and ok == wok == 1
+
+
+def test_sumcheck_kats(zl, ob):
+    """src/subprotocols/mod.zig:366-461: [1,2,3,4] -> g(0)=3, g(1)=7, r=2 -> [5,6]; [1..8] -> claim 36."""
+    s = zl.SumcheckSession.open(U.fr([1, 2, 3, 4]))
+    g0, g1 = s.round_sums()
+    assert (U.fr_to_int(g0), U.fr_to_int(g1)) == (3, 7)
+    s.bind(U.fr([2])[0])
+    assert [U.fr_to_int(x) for x in s.read()] == [5, 6]
+    g0, g1 = s.round_sums()
+    assert (U.fr_to_int(g0), U.fr_to_int(g1)) == (5, 6)
+    s.close()
+    c, rds, chs, fin, ok = _run_sumcheck_gpu(zl, ob, U.fr(range(1, 9)))
+    assert U.fr_to_int(c) == 36 and ok == 1
+    for case in U.load_vectors()["sumcheck"]:
+        c, rds, chs, fin, ok = _run_sumcheck_gpu(zl, ob, U.fr_hex(case["evals"]))
+        assert U.fr_to_int(c) == int(case["claim"], 16)
+        assert [[U.fr_to_int(x) for x in rd] for rd in rds] == [[int(h, 16) for h in rd] for rd in case["rounds"]]
+        assert U.fr_to_int(fin) == int(case["final_eval"], 16) and ok == int(case["ok"])
+
+
+def test_low_pair_session_every_table(zl, ob):
+    """BASELINE config 3 mode (ii) at a CPU-checkable size: eq-table -> combine -> LowToHigh folds with given
+    challenges; SHA-256 of every intermediate table and every round's (even, odd) sums equal the oracle's."""
+    v = 14
+    r = _rand(ob, 900, v)
+    eq = zl.fr_eq_table(r)
+    az, bz, cz = (_rand(ob, 901 + k, 1 << v) for k in range(3))
+    f_gpu = zl.fr_spartan_combine(eq, az, bz, cz)
+    f_cpu = ob.fr_spartan_combine(ob.fr_eq_table(r), az, bz, cz)
+    assert np.array_equal(f_gpu, f_cpu)
+    chals = _rand(ob, 905, v)
+    s = zl.SumcheckSession.open(f_gpu, zl.SC_LOW_PAIR)
+    cur = f_cpu
+    for k in range(v):
+        g0, g1 = s.round_sums()
+        w0, w1 = ob.fr_sum_even_odd(cur)
+        assert np.array_equal(g0, w0) and np.array_equal(g1, w1), k
+        s.bind(chals[k])
+        cur = ob.fr_bind_low(cur, chals[k])
+        assert hashlib.sha256(s.read().tobytes()).digest() == hashlib.sha256(cur.tobytes()).digest(), k
+    assert np.array_equal(s.final(), cur[0])
+    s.close()
+
+
+def test_full_size_sumcheck_properties(zl, ob):
+    """BASELINE config 3 at full size (v = 20): size-independent checks — every round satisfies
+    g0 + g1 == previous claim evaluated at the challenge, and the final evaluation equals the
+    multilinear extension evaluated at the challenge point (computed on the GPU by an eq-table inner
+    product is avoided: we use the verifier identity instead), plus oracle equality on the round messages."""
+    v = 20
+    evals = _rand(ob, 0x53554D43, 1 << v)
+    c, rds, chs, fin, ok = _run_sumcheck_gpu(zl, ob, evals)
+    assert ok == 1
+    wc, wr, wch, wfin, wok = ob.run_sumcheck(evals)  # ~1 s on the CPU
+    assert np.array_equal(c, wc) and np.array_equal(rds, wr) and np.array_equal(chs, wch) and np.array_equal(fin, wfin)
+    # eq table at v = 20: partition of unity and spot rows against the oracle
+    r = _rand(ob, 0x45515F54, v)
+    got = zl.fr_eq_table(r)
+    want = ob.fr_eq_table(r)
+    assert hashlib.sha256(got.tobytes()).digest() == hashlib.sha256(want.tobytes()).digest()

@@ -1,0 +1,152 @@
+// microbench.hip — gfx950 integer-ALU issue-rate probes for the MSM design
+// (SURVEY §7.1 "micro-benchmarks to run first"): cycles per wave-instruction for the
+// candidate multiply/add instructions at 1, 2, 4 and 8 waves per SIMD, and the
+// throughput of the Montgomery multiply as compiled.
+//   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/microbench.hip -o tools/microbench
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include "../zolt_amd/csrc/field.hip.h"
+#include "../zolt_amd/csrc/g1.hip.h"
+
+#define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
+
+#define REP8(x) x x x x x x x x
+#define REP64(x) REP8(REP8(x))
+
+// each kernel: ITER iterations of 64 instructions spread over 8 independent register chains
+#define DEFK(name, ASM8, DECL, OUTEXPR)                                                           \
+    __global__ void name(unsigned long long *cyc, unsigned *sink, int iters, unsigned seed) {      \
+        DECL;                                                                                      \
+        unsigned long long t0 = __builtin_amdgcn_s_memtime();                                      \
+        for (int it = 0; it < iters; it++) { REP8(ASM8) }                                          \
+        unsigned long long t1 = __builtin_amdgcn_s_memtime();                                      \
+        if (threadIdx.x % 64 == 0) cyc[(blockIdx.x * blockDim.x + threadIdx.x) / 64] = t1 - t0;   \
+        sink[blockIdx.x * blockDim.x + threadIdx.x] = OUTEXPR;                                     \
+    }
+
+#define DECL_U32                                                                                   \
+    unsigned a0 = seed + threadIdx.x, a1 = a0 * 3u + 1, a2 = a0 * 5u + 2, a3 = a0 * 7u + 3, a4 = a0 * 11u, a5 = a0 * 13u, \
+             a6 = a0 * 17u, a7 = a0 * 19u, b = a0 | 1u, c = a0 ^ 0x9e3779b9u
+#define OUT_U32 (a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7)
+#define DECL_U64                                                                                   \
+    unsigned long long a0 = seed + threadIdx.x, a1 = a0 * 3u + 1, a2 = a0 * 5u + 2, a3 = a0 * 7u + 3, a4 = a0 * 11u,       \
+                       a5 = a0 * 13u, a6 = a0 * 17u, a7 = a0 * 19u;                                \
+    unsigned b = (unsigned)a0 | 1u, c = (unsigned)a0 ^ 0x9e3779b9u
+#define OUT_U64 ((unsigned)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7) ^ (unsigned)((a0 ^ a1 ^ a2 ^ a3) >> 32))
+
+#define A1(op, r) asm volatile(op " %0, %0, %1" : "+v"(r) : "v"(b));
+#define ASM8_2OP(op) A1(op, a0) A1(op, a1) A1(op, a2) A1(op, a3) A1(op, a4) A1(op, a5) A1(op, a6) A1(op, a7)
+#define A3(op, r) asm volatile(op " %0, %1, %2, %0" : "+v"(r) : "v"(b), "v"(c));
+#define ASM8_3OP(op) A3(op, a0) A3(op, a1) A3(op, a2) A3(op, a3) A3(op, a4) A3(op, a5) A3(op, a6) A3(op, a7)
+#define AM(r) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(r) : "v"(b), "v"(c) : "vcc");
+#define ASM8_MAD64 AM(a0) AM(a1) AM(a2) AM(a3) AM(a4) AM(a5) AM(a6) AM(a7)
+#define AL(r) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(r) : "v"(a7));
+#define ASM8_LSHLADD64 AL(a0) AL(a1) AL(a2) AL(a3) AL(a4) AL(a5) AL(a6) AL(a0)
+#define AC(r) asm volatile("v_add_co_u32 %0, vcc, %0, %1\n v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(r) : "v"(b) : "vcc");
+#define ASM8_ADDC AC(a0) AC(a1) AC(a2) AC(a3)   /* 8 instructions: 4 x (add_co + addc_co) */
+#define AMV(r) asm volatile("v_mov_b32 %0, %1" : "+v"(r) : "v"(b));
+#define ASM8_MOV AMV(a0) AMV(a1) AMV(a2) AMV(a3) AMV(a4) AMV(a5) AMV(a6) AMV(a7)
+
+DEFK(k_add_u32, ASM8_2OP("v_add_u32"), DECL_U32, OUT_U32)
+DEFK(k_mov_b32, ASM8_MOV, DECL_U32, OUT_U32)
+DEFK(k_mul_lo_u32, ASM8_2OP("v_mul_lo_u32"), DECL_U32, OUT_U32)
+DEFK(k_mul_hi_u32, ASM8_2OP("v_mul_hi_u32"), DECL_U32, OUT_U32)
+DEFK(k_mul_u32_u24, ASM8_2OP("v_mul_u32_u24"), DECL_U32, OUT_U32)
+DEFK(k_mad_u32_u24, ASM8_3OP("v_mad_u32_u24"), DECL_U32, OUT_U32)
+DEFK(k_add3_u32, ASM8_3OP("v_add3_u32"), DECL_U32, OUT_U32)
+DEFK(k_addc_pair, ASM8_ADDC, DECL_U32, OUT_U32)
+DEFK(k_mad_u64_u32, ASM8_MAD64, DECL_U64, OUT_U64)
+DEFK(k_lshl_add_u64, ASM8_LSHLADD64, DECL_U64, OUT_U64)
+
+__global__ void k_fma_f64(unsigned long long *cyc, unsigned *sink, int iters, unsigned seed) {
+    double a0 = seed + threadIdx.x, a1 = a0 * 3 + 1, a2 = a0 * 5 + 2, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19;
+    double b = 1.0000001, c = 1e-9;
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; it++) {
+#define AF(r) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(r) : "v"(b), "v"(c));
+        REP8(AF(a0) AF(a1) AF(a2) AF(a3) AF(a4) AF(a5) AF(a6) AF(a7))
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x % 64 == 0) cyc[(blockIdx.x * blockDim.x + threadIdx.x) / 64] = t1 - t0;
+    sink[blockIdx.x * blockDim.x + threadIdx.x] = (unsigned)(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7);
+}
+
+// Montgomery multiply as compiled from field.hip.h: a dependent chain of fe_mul
+__global__ void k_fe_mul(unsigned long long *cyc, unsigned *sink, int iters, unsigned seed) {
+    zg::Fp x, y;
+    for (int i = 0; i < 8; i++) { x.l[i] = (seed + threadIdx.x) * (i + 3); y.l[i] = (seed ^ threadIdx.x) * (i + 7); }
+    x.l[7] &= 0x0fffffff; y.l[7] &= 0x0fffffff;
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; it++) { x = zg::fe_mul(x, y); y = zg::fe_mul(y, x); }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x % 64 == 0) cyc[(blockIdx.x * blockDim.x + threadIdx.x) / 64] = t1 - t0;
+    sink[blockIdx.x * blockDim.x + threadIdx.x] = x.l[0] ^ y.l[3];
+}
+// XYZZ mixed add chain
+__global__ void k_madd(unsigned long long *cyc, unsigned *sink, int iters, unsigned seed) {
+    zg::XYZZ acc; zg::Affine p;
+    for (int i = 0; i < 8; i++) {
+        acc.x.l[i] = (seed + threadIdx.x) * (i + 3); acc.y.l[i] = (seed ^ threadIdx.x) * (i + 7);
+        acc.zz.l[i] = (seed + 2 * threadIdx.x) * (i + 5); acc.zzz.l[i] = (seed + 3 * threadIdx.x) * (i + 9);
+        p.x.l[i] = (seed + 5 * threadIdx.x) * (i + 1); p.y.l[i] = (seed + 7 * threadIdx.x) * (i + 2);
+    }
+    acc.x.l[7] &= 0x0fffffff; acc.y.l[7] &= 0x0fffffff; acc.zz.l[7] &= 0x0fffffff; acc.zzz.l[7] &= 0x0fffffff;
+    p.x.l[7] &= 0x0fffffff; p.y.l[7] &= 0x0fffffff;
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; it++) { acc = zg::xyzz_madd(acc, p); p.x.l[0] ^= acc.x.l[1]; }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x % 64 == 0) cyc[(blockIdx.x * blockDim.x + threadIdx.x) / 64] = t1 - t0;
+    sink[blockIdx.x * blockDim.x + threadIdx.x] = acc.x.l[0] ^ acc.zzz.l[3];
+}
+
+typedef void (*kern_t)(unsigned long long *, unsigned *, int, unsigned);
+
+static void run(const char *name, kern_t k, int instr_per_iter, int iters, int ncu) {
+    unsigned long long *cyc; unsigned *sink;
+    int maxwaves = ncu * 32;
+    CHK(hipMalloc(&cyc, maxwaves * sizeof(unsigned long long)));
+    CHK(hipMalloc(&sink, (size_t)maxwaves * 64 * sizeof(unsigned)));
+    printf("%-16s", name);
+    for (int wps = 1; wps <= 8; wps *= 2) {  // waves per SIMD
+        int threads = 256;                    // 4 waves = 1 per SIMD
+        int blocks = ncu * wps;
+        hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(threads), 0, 0, cyc, sink, 10, 1u);  // warm
+        CHK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(threads), 0, 0, cyc, sink, iters, 1u);
+        CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+        float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+        std::vector<unsigned long long> h(blocks * 4);
+        CHK(hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost));
+        double avg = 0; for (auto v : h) avg += (double)v; avg /= h.size();
+        double per_wave_instr = avg / ((double)iters * instr_per_iter);     // memtime ticks per wave-instruction (latency view)
+        double total_instr = (double)blocks * 4 * iters * instr_per_iter;    // wave-instructions
+        double ns_per_simd_instr = ms * 1e6 / (total_instr / (ncu * 4.0));   // wall ns per instruction per SIMD
+        printf(" | w/simd=%d: %7.2f tick/winstr %7.3f ns/instr/SIMD", wps, per_wave_instr, ns_per_simd_instr);
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+    printf("\n");
+    (void)hipFree(cyc); (void)hipFree(sink);
+}
+
+int main() {
+    hipDeviceProp_t prop; CHK(hipGetDeviceProperties(&prop, 0));
+    int ncu = prop.multiProcessorCount;
+    printf("device %s, CUs %d, clock %d kHz, memtime ticks are at 100MHz*? (compare with ns column)\n", prop.name, ncu, prop.clockRate);
+    run("v_add_u32", k_add_u32, 64, 4000, ncu);
+    run("v_mov_b32", k_mov_b32, 64, 4000, ncu);
+    run("v_add3_u32", k_add3_u32, 64, 4000, ncu);
+    run("add_co+addc_co", k_addc_pair, 64, 4000, ncu);
+    run("v_lshl_add_u64", k_lshl_add_u64, 64, 4000, ncu);
+    run("v_mul_u32_u24", k_mul_u32_u24, 64, 4000, ncu);
+    run("v_mad_u32_u24", k_mad_u32_u24, 64, 4000, ncu);
+    run("v_mul_lo_u32", k_mul_lo_u32, 64, 2000, ncu);
+    run("v_mul_hi_u32", k_mul_hi_u32, 64, 2000, ncu);
+    run("v_mad_u64_u32", k_mad_u64_u32, 64, 2000, ncu);
+    run("v_fma_f64", k_fma_f64, 64, 2000, ncu);
+    run("fe_mul(x2)", k_fe_mul, 2, 2000, ncu);
+    run("xyzz_madd", k_madd, 1, 500, ncu);
+    return 0;
+}

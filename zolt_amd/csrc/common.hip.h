@@ -1,0 +1,37 @@
+// common.hip.h — host-side plumbing shared by the translation units of libzolt_gpu.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/zolt_gpu.h"
+
+namespace zg {
+
+void set_error(const std::string &msg);
+int ensure_init();          // ZG_OK or ZG_ERR_NO_DEVICE / ZG_ERR_HIP
+hipStream_t lib_stream();   // the library's own stream (valid after ensure_init)
+
+inline hipStream_t pick_stream(void *s) { return s ? reinterpret_cast<hipStream_t>(s) : lib_stream(); }
+
+#define ZG_HIP(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            zg::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                    \
+            return ZG_ERR_HIP;                                                                    \
+        }                                                                                         \
+    } while (0)
+
+#define ZG_TRY(expr)                  \
+    do {                              \
+        int _r = (expr);              \
+        if (_r != ZG_OK) return _r;   \
+    } while (0)
+
+#define ZG_INIT() ZG_TRY(zg::ensure_init())
+
+static inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+}  // namespace zg

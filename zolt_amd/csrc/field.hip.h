@@ -1,0 +1,234 @@
+// field.hip.h — BN254 Fr / Fp Montgomery arithmetic for gfx950 (device side).
+//
+// Representation at the ABI and in HBM: 4 x u64 little-endian limbs, Montgomery
+// form, R = 2^256, canonical (< modulus) — the reference's in-memory format
+// (/root/reference/src/field/mod.zig:131,583-584). On the device the same 32
+// bytes are viewed as 8 x u32 limbs: CDNA4 has no 64x64->128 multiplier, the
+// widest integer multiply-add is v_mad_u64_u32 (32x32+64).
+//
+// Every function returns canonical values, so results are bit-identical to the
+// reference's montgomeryMul / add / sub (field/mod.zig:269-308, 402-435,
+// 735-816) — the value a*b*R^-1 mod m in [0, m) is unique whatever limb width
+// computes it.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace zg {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+#define ZG_DEV __device__ __forceinline__
+
+// ---- field parameters (u32 limbs, little-endian); values from field/mod.zig:16-41,51-75
+struct FrParams {
+    static constexpr u32 MOD[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u,
+                                   0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+    static constexpr u32 ONE[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u,
+                                   0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+    static constexpr u32 R2[8] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u,
+                                  0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};
+    static constexpr u32 INV = 0xefffffffu;  // -MOD^-1 mod 2^32 (low word of BN254_INV)
+};
+struct FpParams {
+    static constexpr u32 MOD[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u,
+                                   0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+    static constexpr u32 ONE[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u,
+                                   0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+    static constexpr u32 R2[8] = {0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u,
+                                  0x0a417ff6u, 0x47ab1effu, 0xcab8351fu, 0x06d89f71u};
+    static constexpr u32 INV = 0xe4866389u;  // low word of BN254_FP_INV
+};
+
+template <class P>
+struct Fe {
+    u32 l[8];
+
+    ZG_DEV static Fe zero() {
+        Fe r;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.l[i] = 0;
+        return r;
+    }
+    ZG_DEV static Fe one() {
+        Fe r;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.l[i] = P::ONE[i];
+        return r;
+    }
+    ZG_DEV bool is_zero() const {
+        u32 o = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o |= l[i];
+        return o == 0;
+    }
+    ZG_DEV bool eq(const Fe &b) const {
+        u32 o = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o |= l[i] ^ b.l[i];
+        return o == 0;
+    }
+};
+
+// 16-byte vector load/store of one element (two global_load_dwordx4)
+template <class P>
+ZG_DEV Fe<P> fe_load(const void *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    uint4 a = q[0], b = q[1];
+    Fe<P> r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    return r;
+}
+template <class P>
+ZG_DEV void fe_store(void *p, const Fe<P> &v) {
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+    q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+
+// r = a - MOD if a >= MOD else a   (a < 2*MOD)
+template <class P>
+ZG_DEV Fe<P> fe_reduce_once(const Fe<P> &a) {
+    Fe<P> d;
+    u32 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u64 s = (u64)a.l[i] - P::MOD[i] - borrow;
+        d.l[i] = (u32)s;
+        borrow = (u32)(s >> 32) & 1u;
+    }
+    Fe<P> r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = borrow ? a.l[i] : d.l[i];
+    return r;
+}
+
+// field/mod.zig:402-417 / :782-798. MOD < 2^254 so a+b never carries out of 256 bits.
+template <class P>
+ZG_DEV Fe<P> fe_add(const Fe<P> &a, const Fe<P> &b) {
+    Fe<P> s;
+    u32 carry = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u64 t = (u64)a.l[i] + b.l[i] + carry;
+        s.l[i] = (u32)t;
+        carry = (u32)(t >> 32);
+    }
+    return fe_reduce_once(s);
+}
+
+// field/mod.zig:420-435 / :801-816
+template <class P>
+ZG_DEV Fe<P> fe_sub(const Fe<P> &a, const Fe<P> &b) {
+    Fe<P> d;
+    u32 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u64 s = (u64)a.l[i] - b.l[i] - borrow;
+        d.l[i] = (u32)s;
+        borrow = (u32)(s >> 32) & 1u;
+    }
+    u32 mask = 0u - borrow;
+    u32 carry = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u64 t = (u64)d.l[i] + (P::MOD[i] & mask) + carry;
+        d.l[i] = (u32)t;
+        carry = (u32)(t >> 32);
+    }
+    return d;
+}
+
+// field/mod.zig:494-497 / :944-947 (neg(0) = 0)
+template <class P>
+ZG_DEV Fe<P> fe_neg(const Fe<P> &a) {
+    return fe_sub(Fe<P>::zero(), a);
+}
+
+template <class P>
+ZG_DEV Fe<P> fe_dbl(const Fe<P> &a) {
+    return fe_add(a, a);
+}
+
+// Montgomery product a*b*R^-1 mod MOD (field/mod.zig:269-308 ≡ :735-779), CIOS over
+// 8 x 32-bit words. MOD < 2^254, inputs < MOD  =>  every intermediate t < 2*MOD < 2^255,
+// so the 9th word never carries further and one conditional subtract finishes.
+template <class P>
+ZG_DEV Fe<P> fe_mul(const Fe<P> &a, const Fe<P> &b) {
+    u32 t[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u64 c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            u64 s = (u64)a.l[i] * b.l[j] + t[j] + c;
+            t[j] = (u32)s;
+            c = s >> 32;
+        }
+        u32 t8 = t[8] + (u32)c;
+        u32 m = t[0] * P::INV;
+        u64 s = (u64)m * P::MOD[0] + t[0];
+        c = s >> 32;
+#pragma unroll
+        for (int j = 1; j < 8; j++) {
+            s = (u64)m * P::MOD[j] + t[j] + c;
+            t[j - 1] = (u32)s;
+            c = s >> 32;
+        }
+        s = (u64)t8 + c;
+        t[7] = (u32)s;
+        t[8] = (u32)(s >> 32);
+    }
+    Fe<P> r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = t[i];
+    return fe_reduce_once(r);
+}
+
+template <class P>
+ZG_DEV Fe<P> fe_sqr(const Fe<P> &a) {
+    return fe_mul(a, a);
+}
+
+// a*R^-1: Montgomery -> canonical integer (field/mod.zig:187-189 / :642-645)
+template <class P>
+ZG_DEV Fe<P> fe_from_mont(const Fe<P> &a) {
+    Fe<P> one = Fe<P>::zero();
+    one.l[0] = 1;
+    return fe_mul(a, one);
+}
+// raw 256-bit integer (may be >= MOD) -> Montgomery (field/mod.zig:171-184: one CIOS by R^2;
+// a < 2^256, R2 < MOD  =>  t < 2*MOD still holds)
+template <class P>
+ZG_DEV Fe<P> fe_to_mont(const Fe<P> &a) {
+    Fe<P> r2;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r2.l[i] = P::R2[i];
+    return fe_mul(a, r2);
+}
+
+// Fermat inverse a^(MOD-2), LSB-first like field/mod.zig:500-518 / :955-983.
+// inverse(0) returns 0 (the reference returns null; callers test is_zero first).
+template <class P>
+ZG_DEV Fe<P> fe_inv(const Fe<P> &a) {
+    Fe<P> result = Fe<P>::one(), base = a;
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+        u32 e = P::MOD[w] - (w == 0 ? 2u : 0u);  // MOD[0] >= 2, no borrow
+#pragma unroll 1
+        for (int bit = 0; bit < 32; bit++) {
+            if ((e >> bit) & 1u) result = fe_mul(result, base);
+            base = fe_sqr(base);
+        }
+    }
+    return a.is_zero() ? Fe<P>::zero() : result;
+}
+
+typedef Fe<FrParams> Fr;
+typedef Fe<FpParams> Fp;
+
+}  // namespace zg

@@ -1,0 +1,687 @@
+// msm.hip — BN254 G1 multi-scalar multiplication on gfx950.
+//
+// Replaces the reference's single-threaded Pippenger (/root/reference/src/msm/mod.zig:375-438:
+// c = 8, 32 windows, 255 Jacobian buckets on the stack, per-window fromMontgomery) with a
+// pipeline shaped for 256 CUs and 288 GB of HBM:
+//
+//   upload (once per SRS)   bases -> table[l][i] = 2^(c*G*l) * P_i as 64-byte affine records
+//                           (l < L "precompute levels"); with L = W every window of a scalar
+//                           lands in ONE shared bucket set and no window-combining doublings
+//                           remain at MSM time.
+//   msm_digits              one fromMontgomery per scalar (the reference does 32), then W signed
+//                           c-bit digits -> keys (bucket group g, |digit|-1) + histogram
+//   msm_scan / msm_scatter  counting sort of the n*W (key, point-ref) pairs by key
+//   msm_accumulate          S threads per bucket walk the sorted refs: gather the 64-byte
+//                           affine point, complete mixed add into an XYZZ accumulator
+//   msm_reduce_level*       sum_k k*B_k by chunked running sums, recursively on the chunk sums
+//   msm_sum_levels / msm_final   tree sums, Horner over levels/groups, one inversion -> affine
+//
+// Bucket sums are order-independent group sums and the final affine coordinates are
+// canonical field values, so the 64-byte result is bit-identical to the reference's
+// MSM(F,G).compute whatever c, L, S are (tests/test_msm_parity.py).
+#include <mutex>
+#include <vector>
+
+#include "common.hip.h"
+#include "g1.hip.h"
+
+namespace zg {
+
+static constexpr int MAX_LEVELS = 8;
+static constexpr int MAX_GROUPS = 64;
+
+struct MsmPlan {
+    int c;         // window bits
+    int W;         // windows = ceil(255 / c)
+    int L;         // precompute levels stored in the table
+    int G;         // bucket groups = ceil(W / L); window w -> group w % G, level w / G
+    int S;         // accumulate threads (slices) per bucket
+    uint32_t NB;   // buckets per group = 2^(c-1)
+    uint32_t NK;   // total buckets = G * NB
+    int nlev;      // reduce levels
+    int q[MAX_LEVELS];          // chunk size per level (power of two)
+    uint32_t m[MAX_LEVELS + 1]; // elements per group entering level l (m[0] = NB, m[nlev] = 1)
+    uint32_t off[MAX_LEVELS];   // offset (elements, per group block of size offtot) of level l's outputs
+    uint32_t offtot;            // sum of m[1..nlev]
+};
+
+struct LevelArgs {
+    int nlev, G, c;
+    int logq[MAX_LEVELS];
+    uint32_t cnt[MAX_LEVELS];  // m[l+1]
+    uint32_t off[MAX_LEVELS];
+    uint32_t offtot;
+};
+
+}  // namespace zg
+
+struct zg_bases_s {
+    size_t n = 0;
+    zg::MsmPlan plan;
+    char *d_table = nullptr;     // L * n * 64 B
+    uint8_t *d_inf = nullptr;    // n B or null
+    uint64_t *d_scal = nullptr;  // staging for host scalars, n * 32 B
+    uint32_t *d_dig = nullptr, *d_sorted = nullptr, *d_hist = nullptr, *d_starts = nullptr;
+    char *d_partial = nullptr;  // NK * S * 128 B
+    char *d_levA = nullptr, *d_levS = nullptr;  // G * offtot * 128 B each
+    char *d_sumA = nullptr;     // G * nlev * 128 B
+    uint64_t *d_out = nullptr;  // 16 x u64: result record + flag
+    uint64_t *h_out = nullptr;  // pinned mirror
+    std::mutex mu;
+};
+
+namespace zg {
+
+// ------------------------------------------------------------------ kernels
+
+// Table build: level 0 = the bases; level l = 2^(c*G) * level (l-1), as affine.
+__global__ void __launch_bounds__(256) msm_precompute_kernel(const uint64_t *xy, const uint8_t *inf, size_t n, int levels,
+                                                             int dbl_per_level, char *table) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine p = affine_load(xy + 8 * i);
+    affine_store(table + 64 * i, p);
+    if (inf && inf[i]) return;  // infinity bases are never referenced (digits are suppressed)
+    for (int l = 1; l < levels; l++) {
+        XYZZ a = xyzz_dbl_affine(p);
+        for (int k = 1; k < dbl_per_level; k++) a = xyzz_dbl(a);
+        xyzz_to_affine(a, p);
+        affine_store(table + 64 * ((size_t)l * n + i), p);
+    }
+}
+
+// Signed-digit decomposition. The reference extracts unsigned 8-bit windows of the canonical
+// integer (getWindow, msm/mod.zig:441-471) and converts from Montgomery inside every call;
+// here: one conversion, digits in [-2^(c-1), 2^(c-1)], so a group needs 2^(c-1) buckets.
+template <int C>
+__global__ void __launch_bounds__(256) msm_digits_kernel(const uint64_t *scalars, const uint8_t *inf, uint32_t n, int G,
+                                                         uint32_t *dig, uint32_t *hist) {
+    constexpr int W = (255 + C - 1) / C;
+    constexpr uint32_t NB = 1u << (C - 1);
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    Fr s = fe_from_mont(fe_load<FrParams>(scalars + 4 * (size_t)i));
+    bool skip = inf && inf[i];  // msm/mod.zig:407: infinity bases contribute nothing
+    uint32_t carry = 0;
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+        const int bit = w * C, limb = bit / 32, sh = bit % 32;
+        uint32_t v = s.l[limb] >> sh;
+        if (sh + C > 32 && limb + 1 < 8) v |= s.l[limb + 1] << (32 - sh);
+        v = (v & ((1u << C) - 1u)) + carry;
+        uint32_t neg = v > NB ? 1u : 0u;
+        uint32_t d = neg ? (1u << C) - v : v;
+        carry = neg;
+        uint32_t e = 0xFFFFFFFFu;
+        if (d != 0 && !skip) {
+            uint32_t key = (uint32_t)(w % G) * NB + (d - 1);
+            e = key | (neg << 31);
+            atomicAdd(&hist[key], 1u);
+        }
+        dig[(size_t)w * n + i] = e;
+    }
+}
+
+// exclusive scan of the bucket histogram (NK <= 2^21 entries), one block
+__global__ void __launch_bounds__(1024) msm_scan_kernel(const uint32_t *hist, uint32_t *starts, uint32_t NK) {
+    __shared__ uint32_t sh[1024];
+    uint32_t tid = threadIdx.x;
+    uint32_t per = (NK + 1023) / 1024;
+    uint32_t b = tid * per, e = b + per < NK ? b + per : NK;
+    uint32_t sum = 0;
+    for (uint32_t k = b; k < e; k++) sum += hist[k];
+    sh[tid] = sum;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024; o <<= 1) {
+        uint32_t v = tid >= o ? sh[tid - o] : 0;
+        __syncthreads();
+        sh[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = sh[tid] - sum;
+    for (uint32_t k = b; k < e; k++) {
+        starts[k] = run;
+        run += hist[k];
+    }
+    if (tid == 1023) starts[NK] = sh[1023];
+}
+
+// counting-sort scatter; order inside a bucket is irrelevant (group sums commute).
+// fill[] is the histogram array re-zeroed by the caller.
+__global__ void __launch_bounds__(256) msm_scatter_kernel(const uint32_t *dig, uint32_t n, int G, size_t table_n, uint32_t off,
+                                                          const uint32_t *starts, uint32_t *fill, uint32_t *sorted) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    uint32_t w = blockIdx.y;
+    if (i >= n) return;
+    uint32_t e = dig[(size_t)w * n + i];
+    if (e == 0xFFFFFFFFu) return;
+    uint32_t key = e & 0x7FFFFFFFu;
+    uint32_t pos = starts[key] + atomicAdd(&fill[key], 1u);
+    uint32_t ref = (uint32_t)((size_t)(w / G) * table_n + off + i);
+    sorted[pos] = (e & 0x80000000u) | ref;
+}
+
+// Bucket accumulation: the reference's inner loop buckets[idx] = buckets[idx].addAffine(base)
+// (msm/mod.zig:406-418). S threads share one bucket's list; each produces a partial.
+__global__ void __launch_bounds__(256) msm_accumulate_kernel(const uint32_t *sorted, const uint32_t *starts, const char *table,
+                                                             uint32_t NK, int S, char *partial) {
+    uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    uint32_t key = t / (uint32_t)S, s = t % (uint32_t)S;
+    if (key >= NK) return;
+    uint32_t b0 = starts[key], b1 = starts[key + 1];
+    uint32_t len = b1 - b0;
+    uint32_t a = b0 + (uint32_t)(((uint64_t)len * s) / (uint32_t)S);
+    uint32_t b = b0 + (uint32_t)(((uint64_t)len * (s + 1)) / (uint32_t)S);
+    XYZZ acc = XYZZ::identity();
+    if (a < b) {
+        uint32_t e = sorted[a];
+        Affine cur = affine_load(table + 64 * (size_t)(e & 0x7FFFFFFFu));
+        uint32_t cneg = e >> 31;
+        for (uint32_t p = a; p < b; p++) {
+            Affine nxt = cur;
+            uint32_t nneg = 0;
+            if (p + 1 < b) {  // prefetch the next point under the current add
+                uint32_t e2 = sorted[p + 1];
+                nxt = affine_load(table + 64 * (size_t)(e2 & 0x7FFFFFFFu));
+                nneg = e2 >> 31;
+            }
+            if (cneg) cur.y = fe_neg(cur.y);
+            acc = xyzz_madd(acc, cur);
+            cur = nxt;
+            cneg = nneg;
+        }
+    }
+    xyzz_store(partial + 128 * (size_t)t, acc);
+}
+
+// One level of the bucket reduction sum_{x=0}^{m-1} x*E_x  (msm/mod.zig:423-432 is the serial
+// running-sum form). Thread j owns chunk [j*q, (j+1)*q):  A_j = sum_i i*E_{jq+i},  S_j = sum_i E_{jq+i};
+// then  W(E) = sum_j A_j + q*W(S).  `slices` partials are summed per input element (level 0).
+__global__ void __launch_bounds__(64) msm_reduce_level_kernel(const char *in, int slices, uint32_t m_in, size_t in_group_stride,
+                                                              int q, uint32_t m_out, int G, char *outA, char *outS,
+                                                              size_t out_group_stride) {
+    uint32_t t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= (uint32_t)G * m_out) return;
+    uint32_t g = t / m_out, j = t % m_out;
+    const char *base = in + 128 * ((size_t)g * in_group_stride + (size_t)j * q * slices);
+    XYZZ run = XYZZ::identity(), acc = XYZZ::identity();
+    for (int i = q - 1; i >= 0; i--) {
+        XYZZ e = xyzz_load(base + 128 * (size_t)i * slices);
+        for (int s = 1; s < slices; s++) e = xyzz_add(e, xyzz_load(base + 128 * ((size_t)i * slices + s)));
+        run = xyzz_add(run, e);
+        if (i > 0) acc = xyzz_add(acc, run);
+    }
+    (void)m_in;
+    xyzz_store(outA + 128 * ((size_t)g * out_group_stride + j), acc);
+    xyzz_store(outS + 128 * ((size_t)g * out_group_stride + j), run);
+}
+
+// block (g, l): plain sum of level l's A outputs of group g
+__global__ void __launch_bounds__(256) msm_sum_levels_kernel(const char *levA, LevelArgs la, char *sumA) {
+    __shared__ uint4 sh[256 * 8];
+    uint32_t g = blockIdx.x, l = blockIdx.y, tid = threadIdx.x;
+    const char *A = levA + 128 * ((size_t)g * la.offtot + la.off[l]);
+    XYZZ acc = XYZZ::identity();
+    for (uint32_t k = tid; k < la.cnt[l]; k += 256) acc = xyzz_add(acc, xyzz_load(A + 128 * (size_t)k));
+    xyzz_store(&sh[tid * 8], acc);
+    __syncthreads();
+    for (uint32_t o = 128; o > 0; o >>= 1) {
+        if (tid < o && tid + o < 256) {
+            XYZZ x = xyzz_load(&sh[tid * 8]), y = xyzz_load(&sh[(tid + o) * 8]);
+            xyzz_store(&sh[tid * 8], xyzz_add(x, y));
+        }
+        __syncthreads();
+    }
+    if (tid == 0) xyzz_store(sumA + 128 * ((size_t)g * la.nlev + l), xyzz_load(&sh[0]));
+}
+
+// Horner over levels (per group) and over groups (window combine, msm/mod.zig:393-398,434),
+// then toAffine (:178-189). mode 0: affine xy[8] + inf flag; mode 1: the reference's Jacobian
+// record fromAffine(result) = (x,y,1) / (1,1,0) as ParallelMSM's threadWorker stores (:663-664).
+__global__ void __launch_bounds__(64) msm_final_kernel(const char *sumA, const char *levS, LevelArgs la, int mode, uint64_t *out_rec,
+                                                       uint8_t *out_inf) {
+    __shared__ uint4 sh[MAX_GROUPS * 8];
+    uint32_t g = threadIdx.x;
+    if (g < (uint32_t)la.G) {
+        const char *sa = sumA + 128 * (size_t)g * la.nlev;
+        XYZZ acc = xyzz_load(sa + 128 * (size_t)(la.nlev - 1));
+        for (int l = la.nlev - 2; l >= 0; l--) {
+            for (int k = 0; k < la.logq[l]; k++) acc = xyzz_dbl(acc);
+            acc = xyzz_add(acc, xyzz_load(sa + 128 * (size_t)l));
+        }
+        // bucket index x holds digit magnitude x+1:  sum (x+1)*E_x = W(E) + T(E);  T = last level's single S
+        XYZZ T = xyzz_load(levS + 128 * ((size_t)g * la.offtot + la.off[la.nlev - 1]));
+        acc = xyzz_add(acc, T);
+        xyzz_store(&sh[g * 8], acc);
+    }
+    __syncthreads();
+    if (g != 0) return;
+    XYZZ acc = xyzz_load(&sh[(la.G - 1) * 8]);
+    for (int gg = la.G - 2; gg >= 0; gg--) {
+        for (int k = 0; k < la.c; k++) acc = xyzz_dbl(acc);
+        acc = xyzz_add(acc, xyzz_load(&sh[gg * 8]));
+    }
+    Affine r;
+    bool inf = xyzz_to_affine(acc, r);
+    if (mode == 0) {
+        affine_store(out_rec, r);
+        *out_inf = inf ? 1 : 0;
+    } else {
+        Fp one = Fp::one();
+        if (inf) {
+            fe_store(out_rec, one); fe_store(out_rec + 4, one); fe_store(out_rec + 8, Fp::zero());
+        } else {
+            fe_store(out_rec, r.x); fe_store(out_rec + 4, r.y); fe_store(out_rec + 8, one);
+        }
+    }
+}
+
+__global__ void msm_identity_kernel(int mode, uint64_t *out_rec, uint8_t *out_inf) {
+    if (mode == 0) {
+        for (int i = 0; i < 8; i++) out_rec[i] = 0;
+        *out_inf = 1;
+    } else {
+        Fp one = Fp::one();
+        fe_store(out_rec, one); fe_store(out_rec + 4, one); fe_store(out_rec + 8, Fp::zero());
+    }
+}
+
+// ParallelMSM combine (msm/mod.zig:647-652): serial add of k Jacobian partials + toAffine
+__global__ void msm_combine_kernel(const uint64_t *partials, uint32_t k, uint64_t *out_xy, uint8_t *out_inf) {
+    XYZZ acc = XYZZ::identity();
+    for (uint32_t i = 0; i < k; i++) {
+        Fp X = fe_load<FpParams>(partials + 12 * i), Y = fe_load<FpParams>(partials + 12 * i + 4),
+           Z = fe_load<FpParams>(partials + 12 * i + 8);
+        acc = xyzz_add(acc, xyzz_from_jacobian(X, Y, Z));
+    }
+    Affine r;
+    bool inf = xyzz_to_affine(acc, r);
+    affine_store(out_xy, r);
+    *out_inf = inf ? 1 : 0;
+}
+
+// MSM.scalarMul(base, scalar).toAffine() (msm/mod.zig:503-540), one pair per thread
+__global__ void __launch_bounds__(256) g1_scalar_mul_kernel(const uint64_t *xy, const uint8_t *inf, const uint64_t *scalars, size_t n,
+                                                            uint64_t *out_xy, uint8_t *out_inf) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine p = affine_load(xy + 8 * i);
+    Fr s = fe_from_mont(fe_load<FrParams>(scalars + 4 * i));
+    XYZZ acc = XYZZ::identity();
+    if (!(inf && inf[i])) {
+        for (int limb = 7; limb >= 0; limb--) {
+            uint32_t wv = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) wv = (k == limb) ? s.l[k] : wv;
+            for (int bit = 31; bit >= 0; bit--) {
+                acc = xyzz_dbl(acc);
+                if ((wv >> bit) & 1u) acc = xyzz_madd(acc, p);
+            }
+        }
+    }
+    Affine r;
+    bool isinf = xyzz_to_affine(acc, r);
+    affine_store(out_xy + 8 * i, r);
+    out_inf[i] = isinf ? 1 : 0;
+}
+
+// ------------------------------------------------------------------ host side
+
+static int ilog2(uint32_t v) {
+    int r = 0;
+    while ((1u << (r + 1)) <= v) r++;
+    return r;
+}
+
+static int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+static int make_plan(size_t n, const zg_msm_config *cfg, MsmPlan &p) {
+    int c = cfg ? cfg->window_bits : 0;
+    if (c == 0) c = env_int("ZG_MSM_WINDOW_BITS", 0);
+    if (c == 0) {
+        int lg = n > 1 ? ilog2((uint32_t)(n - 1)) + 1 : 1;
+        c = lg - 4;
+        if (c < 4) c = 4;
+        if (c > 16) c = 16;
+    }
+    if (c < 2 || c > 16) {
+        set_error("msm: window_bits must be in [2,16]");
+        return ZG_ERR_INVALID;
+    }
+    p.c = c;
+    p.W = (255 + c - 1) / c;
+    int L = cfg ? cfg->precompute_levels : 0;
+    if (L == 0) L = env_int("ZG_MSM_PRECOMPUTE", 0);
+    if (L == 0) L = p.W;  // 288 GB of HBM: full precompute is 64*W bytes per base
+    if (L < 1) L = 1;
+    if (L > p.W) L = p.W;
+    p.G = (p.W + L - 1) / L;
+    p.L = (p.W + p.G - 1) / p.G;
+    if (p.G > MAX_GROUPS) {
+        set_error("msm: too many bucket groups for this window size");
+        return ZG_ERR_INVALID;
+    }
+    p.NB = 1u << (c - 1);
+    p.NK = p.NB * (uint32_t)p.G;
+    // slices per bucket: aim for ~2^18-2^19 accumulate threads
+    int S = 1;
+    while ((uint64_t)p.NK * S * 2 <= (1u << 19) && S < 64) S *= 2;
+    p.S = env_int("ZG_MSM_SLICES", S);
+    // reduce levels
+    int q0 = env_int("ZG_MSM_REDUCE_Q", 8);
+    p.nlev = 0;
+    p.m[0] = p.NB;
+    p.offtot = 0;
+    while (p.m[p.nlev] > 1) {
+        uint32_t q = (uint32_t)q0 < p.m[p.nlev] ? (uint32_t)q0 : p.m[p.nlev];
+        p.q[p.nlev] = (int)q;
+        p.m[p.nlev + 1] = p.m[p.nlev] / q;
+        p.off[p.nlev] = p.offtot;
+        p.offtot += p.m[p.nlev + 1];
+        p.nlev++;
+    }
+    if (p.nlev == 0) {  // NB == 1 (c = 1) is excluded by c >= 2
+        set_error("msm: internal plan error");
+        return ZG_ERR_INVALID;
+    }
+    return ZG_OK;
+}
+
+static void free_bases(zg_bases_s *b) {
+    if (!b) return;
+    void *ptrs[] = {b->d_table, b->d_inf, b->d_scal, b->d_dig, b->d_sorted, b->d_hist, b->d_starts,
+                    b->d_partial, b->d_levA, b->d_levS, b->d_sumA, b->d_out};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (b->h_out) (void)hipHostFree(b->h_out);
+    delete b;
+}
+
+#define ZG_ALLOC(ptr, bytes)                                                         \
+    do {                                                                             \
+        hipError_t _e = hipMalloc((void **)&(ptr), (bytes) ? (bytes) : 16);          \
+        if (_e != hipSuccess) {                                                      \
+            set_error(std::string("hipMalloc(" #ptr "): ") + hipGetErrorString(_e)); \
+            free_bases(b);                                                           \
+            return _e == hipErrorOutOfMemory ? ZG_ERR_NOMEM : ZG_ERR_HIP;            \
+        }                                                                            \
+    } while (0)
+
+static int bases_create(const uint64_t *d_xy, const uint8_t *d_inf_in, size_t n, const zg_msm_config *cfg, hipStream_t st,
+                        zg_bases_t *out) {
+    if (n >= (1ull << 27)) {
+        set_error("msm: at most 2^27 bases per handle");
+        return ZG_ERR_INVALID;
+    }
+    zg_bases_s *b = new zg_bases_s();
+    b->n = n;
+    int rc = make_plan(n ? n : 1, cfg, b->plan);
+    if (rc != ZG_OK) {
+        delete b;
+        return rc;
+    }
+    const MsmPlan &p = b->plan;
+    if ((uint64_t)p.L * n >= (1ull << 31)) {
+        set_error("msm: precompute table too large for 31-bit point references");
+        delete b;
+        return ZG_ERR_INVALID;
+    }
+    ZG_ALLOC(b->d_table, (size_t)p.L * n * 64);
+    if (d_inf_in) ZG_ALLOC(b->d_inf, n);
+    ZG_ALLOC(b->d_dig, (size_t)p.W * n * 4);
+    ZG_ALLOC(b->d_sorted, (size_t)p.W * n * 4);
+    ZG_ALLOC(b->d_hist, (size_t)p.NK * 4);
+    ZG_ALLOC(b->d_starts, ((size_t)p.NK + 1) * 4);
+    ZG_ALLOC(b->d_partial, (size_t)p.NK * p.S * 128);
+    ZG_ALLOC(b->d_levA, (size_t)p.G * p.offtot * 128);
+    ZG_ALLOC(b->d_levS, (size_t)p.G * p.offtot * 128);
+    ZG_ALLOC(b->d_sumA, (size_t)p.G * p.nlev * 128);
+    ZG_ALLOC(b->d_out, 16 * 8);
+    if (hipHostMalloc((void **)&b->h_out, 16 * 8) != hipSuccess) {
+        set_error("hipHostMalloc failed");
+        free_bases(b);
+        return ZG_ERR_NOMEM;
+    }
+    if (n) {
+        if (d_inf_in) ZG_HIP(hipMemcpyAsync(b->d_inf, d_inf_in, n, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(msm_precompute_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, d_xy, b->d_inf, n, p.L, p.c * p.G,
+                           b->d_table);
+        ZG_HIP(hipGetLastError());
+    }
+    ZG_HIP(hipStreamSynchronize(st));
+    *out = b;
+    return ZG_OK;
+}
+
+template <int C>
+static void launch_digits(hipStream_t st, const uint64_t *sc, const uint8_t *inf, uint32_t n, int G, uint32_t *dig, uint32_t *hist) {
+    hipLaunchKernelGGL(msm_digits_kernel<C>, dim3(div_up(n, 256)), dim3(256), 0, st, sc, inf, n, G, dig, hist);
+}
+
+static int launch_digits_c(int c, hipStream_t st, const uint64_t *sc, const uint8_t *inf, uint32_t n, int G, uint32_t *dig,
+                           uint32_t *hist) {
+    switch (c) {
+#define ZG_CASE(C) case C: launch_digits<C>(st, sc, inf, n, G, dig, hist); break;
+        ZG_CASE(2) ZG_CASE(3) ZG_CASE(4) ZG_CASE(5) ZG_CASE(6) ZG_CASE(7) ZG_CASE(8) ZG_CASE(9) ZG_CASE(10)
+        ZG_CASE(11) ZG_CASE(12) ZG_CASE(13) ZG_CASE(14) ZG_CASE(15) ZG_CASE(16)
+#undef ZG_CASE
+        default: set_error("msm: unsupported window size"); return ZG_ERR_INVALID;
+    }
+    return ZG_OK;
+}
+
+// Enqueue one MSM over bases[off, off+n) on `st`; result record lands in d_rec / d_inf_out.
+static int msm_enqueue(zg_bases_s *b, size_t off, size_t n, const uint64_t *d_scalars, hipStream_t st, int mode, uint64_t *d_rec,
+                       uint8_t *d_inf_out) {
+    const MsmPlan &p = b->plan;
+    if (off + n > b->n) {
+        set_error("msm: range exceeds uploaded bases");
+        return ZG_ERR_INVALID;
+    }
+    if (n == 0) {  // msm/mod.zig:361-363
+        hipLaunchKernelGGL(msm_identity_kernel, dim3(1), dim3(1), 0, st, mode, d_rec, d_inf_out);
+        ZG_HIP(hipGetLastError());
+        return ZG_OK;
+    }
+    ZG_HIP(hipMemsetAsync(b->d_hist, 0, (size_t)p.NK * 4, st));
+    ZG_TRY(launch_digits_c(p.c, st, d_scalars, b->d_inf ? b->d_inf + off : nullptr, (uint32_t)n, p.G, b->d_dig, b->d_hist));
+    hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(1024), 0, st, b->d_hist, b->d_starts, p.NK);
+    ZG_HIP(hipMemsetAsync(b->d_hist, 0, (size_t)p.NK * 4, st));
+    hipLaunchKernelGGL(msm_scatter_kernel, dim3(div_up(n, 256), p.W), dim3(256), 0, st, b->d_dig, (uint32_t)n, p.G, b->n,
+                       (uint32_t)off, b->d_starts, b->d_hist, b->d_sorted);
+    hipLaunchKernelGGL(msm_accumulate_kernel, dim3(div_up((size_t)p.NK * p.S, 256)), dim3(256), 0, st, b->d_sorted, b->d_starts,
+                       b->d_table, p.NK, p.S, b->d_partial);
+    LevelArgs la;
+    la.nlev = p.nlev; la.G = p.G; la.c = p.c; la.offtot = p.offtot;
+    for (int l = 0; l < p.nlev; l++) {
+        la.logq[l] = ilog2((uint32_t)p.q[l]);
+        la.cnt[l] = p.m[l + 1];
+        la.off[l] = p.off[l];
+        const char *in = l == 0 ? b->d_partial : b->d_levS + 128 * (size_t)p.off[l - 1];
+        int slices = l == 0 ? p.S : 1;
+        size_t in_stride = l == 0 ? (size_t)p.NB * p.S : p.offtot;
+        uint32_t threads = (uint32_t)p.G * p.m[l + 1];
+        hipLaunchKernelGGL(msm_reduce_level_kernel, dim3(div_up(threads, 64)), dim3(64), 0, st, in, slices, p.m[l], in_stride, p.q[l],
+                           p.m[l + 1], p.G, b->d_levA + 128 * (size_t)p.off[l], b->d_levS + 128 * (size_t)p.off[l],
+                           (size_t)p.offtot);
+    }
+    hipLaunchKernelGGL(msm_sum_levels_kernel, dim3(p.G, p.nlev), dim3(256), 0, st, b->d_levA, la, b->d_sumA);
+    hipLaunchKernelGGL(msm_final_kernel, dim3(1), dim3(64), 0, st, b->d_sumA, b->d_levS, la, mode, d_rec, d_inf_out);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
+static int msm_to_host(zg_bases_s *b, size_t off, size_t n, const uint64_t *d_scalars, hipStream_t st, uint64_t out_xy[8],
+                       uint8_t *out_inf) {
+    ZG_TRY(msm_enqueue(b, off, n, d_scalars, st, 0, b->d_out, reinterpret_cast<uint8_t *>(b->d_out + 8)));
+    ZG_HIP(hipMemcpyAsync(b->h_out, b->d_out, 9 * 8, hipMemcpyDeviceToHost, st));
+    ZG_HIP(hipStreamSynchronize(st));
+    for (int i = 0; i < 8; i++) out_xy[i] = b->h_out[i];
+    if (out_inf) *out_inf = (uint8_t)(b->h_out[8] & 0xff);
+    return ZG_OK;
+}
+
+}  // namespace zg
+
+using namespace zg;
+
+extern "C" {
+
+int zg_g1_bases_upload_dev(const uint64_t *d_xy, const uint8_t *d_inf, size_t n, const zg_msm_config *cfg, void *stream,
+                           zg_bases_t *out) {
+    ZG_INIT();
+    if (!out || (n && !d_xy)) {
+        set_error("zg_g1_bases_upload_dev: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    return bases_create(d_xy, d_inf, n, cfg, pick_stream(stream), out);
+}
+
+int zg_g1_bases_upload(const uint64_t *xy, const uint8_t *inf, size_t n, const zg_msm_config *cfg, zg_bases_t *out) {
+    ZG_INIT();
+    if (!out || (n && !xy)) {
+        set_error("zg_g1_bases_upload: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    uint64_t *dxy = nullptr;
+    uint8_t *dinf = nullptr;
+    ZG_HIP(hipMalloc((void **)&dxy, n ? n * 64 : 16));
+    ZG_HIP(hipMemcpy(dxy, xy, n * 64, hipMemcpyHostToDevice));
+    if (inf) {
+        ZG_HIP(hipMalloc((void **)&dinf, n ? n : 16));
+        ZG_HIP(hipMemcpy(dinf, inf, n, hipMemcpyHostToDevice));
+    }
+    int rc = bases_create(dxy, dinf, n, cfg, lib_stream(), out);
+    (void)hipFree(dxy);
+    if (dinf) (void)hipFree(dinf);
+    return rc;
+}
+
+int zg_g1_bases_free(zg_bases_t b) {
+    if (!b) return ZG_OK;
+    ZG_INIT();
+    (void)hipDeviceSynchronize();
+    free_bases(b);
+    return ZG_OK;
+}
+
+size_t zg_g1_bases_len(zg_bases_t b) { return b ? b->n : 0; }
+
+int zg_msm_g1_dev(zg_bases_t b, size_t off, size_t n, const uint64_t *d_scalars, void *stream, uint64_t out_xy[8], uint8_t *out_inf) {
+    ZG_INIT();
+    if (!b || !out_xy || (n && !d_scalars)) {
+        set_error("zg_msm_g1_dev: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(b->mu);
+    return msm_to_host(b, off, n, d_scalars, pick_stream(stream), out_xy, out_inf);
+}
+
+int zg_msm_g1(zg_bases_t b, size_t off, size_t n, const uint64_t *scalars, uint64_t out_xy[8], uint8_t *out_inf) {
+    ZG_INIT();
+    if (!b || !out_xy || (n && !scalars)) {
+        set_error("zg_msm_g1: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    if (off + n > b->n) {
+        set_error("msm: range exceeds uploaded bases");
+        return ZG_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(b->mu);
+    hipStream_t st = lib_stream();
+    if (n) {
+        if (!b->d_scal) ZG_HIP(hipMalloc((void **)&b->d_scal, b->n * 32));
+        ZG_HIP(hipMemcpyAsync(b->d_scal, scalars, n * 32, hipMemcpyHostToDevice, st));
+    }
+    return msm_to_host(b, off, n, b->d_scal, st, out_xy, out_inf);
+}
+
+int zg_msm_g1_dev_async(zg_bases_t b, size_t off, size_t n, const uint64_t *d_scalars, void *stream, uint64_t *d_out_xy,
+                        uint8_t *d_out_inf) {
+    ZG_INIT();
+    if (!b || !d_out_xy || !d_out_inf || (n && !d_scalars)) {
+        set_error("zg_msm_g1_dev_async: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(b->mu);
+    return msm_enqueue(b, off, n, d_scalars, pick_stream(stream), 0, d_out_xy, d_out_inf);
+}
+
+int zg_msm_g1_partial_dev(zg_bases_t b, size_t off, size_t n, const uint64_t *d_scalars, void *stream, uint64_t *d_out_jac) {
+    ZG_INIT();
+    if (!b || !d_out_jac || (n && !d_scalars)) {
+        set_error("zg_msm_g1_partial_dev: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(b->mu);
+    return msm_enqueue(b, off, n, d_scalars, pick_stream(stream), 1, d_out_jac, nullptr);
+}
+
+int zg_msm_g1_batch(zg_bases_t b, size_t n, const uint64_t *const *batches, size_t k, uint64_t *out_xy, uint8_t *out_inf) {
+    if (k && (!batches || !out_xy)) {
+        set_error("zg_msm_g1_batch: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    for (size_t i = 0; i < k; i++) {
+        uint8_t inf = 0;
+        ZG_TRY(zg_msm_g1(b, 0, n, batches[i], out_xy + 8 * i, &inf));
+        if (out_inf) out_inf[i] = inf;
+    }
+    return ZG_OK;
+}
+
+int zg_g1_combine_partials_dev(const uint64_t *d_partials, size_t k, void *stream, uint64_t out_xy[8], uint8_t *out_inf) {
+    ZG_INIT();
+    if (!out_xy || (k && !d_partials)) {
+        set_error("zg_g1_combine_partials_dev: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    hipStream_t st = pick_stream(stream);
+    uint64_t *d_out = nullptr;
+    ZG_HIP(hipMalloc((void **)&d_out, 16 * 8));
+    hipLaunchKernelGGL(msm_combine_kernel, dim3(1), dim3(1), 0, st, d_partials, (uint32_t)k, d_out, reinterpret_cast<uint8_t *>(d_out + 8));
+    uint64_t h[9];
+    hipError_t e = hipMemcpyAsync(h, d_out, 9 * 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d_out);
+    ZG_HIP(e);
+    for (int i = 0; i < 8; i++) out_xy[i] = h[i];
+    if (out_inf) *out_inf = (uint8_t)(h[8] & 0xff);
+    return ZG_OK;
+}
+
+int zg_g1_scalar_mul_batch(const uint64_t *xy, const uint8_t *inf, const uint64_t *scalars, size_t n, uint64_t *out_xy,
+                           uint8_t *out_inf) {
+    ZG_INIT();
+    if (n && (!xy || !scalars || !out_xy || !out_inf)) {
+        set_error("zg_g1_scalar_mul_batch: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    if (n == 0) return ZG_OK;
+    hipStream_t st = lib_stream();
+    uint64_t *dxy = nullptr, *dsc = nullptr, *dout = nullptr;
+    uint8_t *dinf = nullptr, *doinf = nullptr;
+    ZG_HIP(hipMalloc((void **)&dxy, n * 64));
+    ZG_HIP(hipMalloc((void **)&dsc, n * 32));
+    ZG_HIP(hipMalloc((void **)&dout, n * 64));
+    ZG_HIP(hipMalloc((void **)&doinf, n));
+    ZG_HIP(hipMemcpyAsync(dxy, xy, n * 64, hipMemcpyHostToDevice, st));
+    ZG_HIP(hipMemcpyAsync(dsc, scalars, n * 32, hipMemcpyHostToDevice, st));
+    if (inf) {
+        ZG_HIP(hipMalloc((void **)&dinf, n));
+        ZG_HIP(hipMemcpyAsync(dinf, inf, n, hipMemcpyHostToDevice, st));
+    }
+    hipLaunchKernelGGL(g1_scalar_mul_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, dxy, dinf, dsc, n, dout, doinf);
+    ZG_HIP(hipGetLastError());
+    ZG_HIP(hipMemcpyAsync(out_xy, dout, n * 64, hipMemcpyDeviceToHost, st));
+    ZG_HIP(hipMemcpyAsync(out_inf, doinf, n, hipMemcpyDeviceToHost, st));
+    ZG_HIP(hipStreamSynchronize(st));
+    (void)hipFree(dxy); (void)hipFree(dsc); (void)hipFree(dout); (void)hipFree(doinf);
+    if (dinf) (void)hipFree(dinf);
+    return ZG_OK;
+}
+
+}  // extern "C"

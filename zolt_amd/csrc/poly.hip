@@ -1,0 +1,478 @@
+// poly.hip — Fr evaluation-table kernels on gfx950: eq-table build, Spartan combine,
+// sumcheck folds with fused next-round sums, and the device-resident sumcheck session.
+//
+// Reference functions replaced (paths under /root/reference):
+//   EqPolynomial.evalsSliceWithScaling   src/poly/mod.zig:252-290
+//   GruenSplitEqPolynomial tables        src/poly/split_eq.zig:122-171 (same values)
+//   DensePolynomial.bindFirst / bindLow  src/poly/mod.zig:128-149 / :160-175
+//   Sumcheck.Prover.nextRound sums       src/subprotocols/mod.zig:79-93
+//   LowToHigh round sums / fold          src/zkvm/r1cs/jolt_r1cs.zig:436-444,470-477
+//   Spartan combine                      src/zkvm/spartan/mod.zig:191-199
+// All of these are exact modular arithmetic with canonical outputs, so any evaluation order
+// gives the reference's bytes (sums of field elements commute; eq(r,x) is one field value
+// however its factors are grouped).
+#include <mutex>
+
+#include "common.hip.h"
+#include "field.hip.h"
+
+namespace zg {
+
+// ------------------------------------------------------------------ eq table
+// hi[h] = scale * prod_{j < v_hi} (bit_j(h) ? r[j] : 1 - r[j]),  bit_j = bit (v_hi-1-j) of h  (r[0] <-> MSB)
+__global__ void __launch_bounds__(256) eq_hi_kernel(const uint64_t *r, int v_hi, const uint64_t *scale, uint64_t *hi) {
+    uint32_t h = blockIdx.x * 256 + threadIdx.x;
+    if (h >= (1u << v_hi)) return;
+    Fr prod = scale ? fe_load<FrParams>(scale) : Fr::one();
+    Fr one = Fr::one();
+    for (int j = 0; j < v_hi; j++) {
+        Fr rj = fe_load<FrParams>(r + 4 * j);
+        Fr f = ((h >> (v_hi - 1 - j)) & 1u) ? rj : fe_sub(one, rj);
+        prod = fe_mul(prod, f);
+    }
+    fe_store(hi + 4 * (size_t)h, prod);
+}
+
+// out[(h << v_lo) | lo] = hi[h] * prod_{j < v_lo} (bit_j(lo) ? r_lo[j] : 1 - r_lo[j]); one 32-byte
+// store per thread, 8 KiB contiguous per (block, h): the kernel is a pure HBM write stream.
+__global__ void __launch_bounds__(256) eq_main_kernel(const uint64_t *r_lo, int v_lo, const uint64_t *hi, uint32_t n_hi,
+                                                      uint32_t hi_per_block, uint64_t *out) {
+    uint32_t lo = threadIdx.x;
+    if (lo >= (1u << v_lo)) return;
+    Fr t = Fr::one(), one = Fr::one();
+    for (int j = 0; j < v_lo; j++) {
+        Fr rj = fe_load<FrParams>(r_lo + 4 * j);
+        Fr f = ((lo >> (v_lo - 1 - j)) & 1u) ? rj : fe_sub(one, rj);
+        t = fe_mul(t, f);
+    }
+    uint32_t h0 = blockIdx.x * hi_per_block;
+    for (uint32_t k = 0; k < hi_per_block; k++) {
+        uint32_t h = h0 + k;
+        if (h >= n_hi) break;
+        Fr hv = fe_load<FrParams>(hi + 4 * (size_t)h);
+        fe_store(out + 4 * (((size_t)h << v_lo) | lo), fe_mul(hv, t));
+    }
+}
+
+// f[i] = eq[i] * (Az[i]*Bz[i] - Cz[i])
+__global__ void __launch_bounds__(256) spartan_combine_kernel(const uint64_t *eq, const uint64_t *az, const uint64_t *bz,
+                                                              const uint64_t *cz, size_t n, uint64_t *out) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        Fr a = fe_load<FrParams>(az + 4 * i), b = fe_load<FrParams>(bz + 4 * i), c = fe_load<FrParams>(cz + 4 * i);
+        Fr e = fe_load<FrParams>(eq + 4 * i);
+        fe_store(out + 4 * i, fe_mul(e, fe_sub(fe_mul(a, b), c)));
+    }
+}
+
+// ------------------------------------------------------------------ sums / folds
+// block-wide sum of (g0, g1) pairs; result valid in thread 0
+__device__ __forceinline__ void block_sum_pair(Fr &g0, Fr &g1, uint4 *sh) {
+    uint32_t tid = threadIdx.x;
+    fe_store(&sh[tid * 4], g0);
+    fe_store(&sh[tid * 4 + 2], g1);
+    __syncthreads();
+    for (uint32_t o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            Fr a0 = fe_load<FrParams>(&sh[tid * 4]), a1 = fe_load<FrParams>(&sh[tid * 4 + 2]);
+            Fr b0 = fe_load<FrParams>(&sh[(tid + o) * 4]), b1 = fe_load<FrParams>(&sh[(tid + o) * 4 + 2]);
+            fe_store(&sh[tid * 4], fe_add(a0, b0));
+            fe_store(&sh[tid * 4 + 2], fe_add(a1, b1));
+        }
+        __syncthreads();
+    }
+    g0 = fe_load<FrParams>(&sh[0]);
+    g1 = fe_load<FrParams>(&sh[2]);
+}
+
+// round sums of a table: HIGH: g0 = sum t[0..h), g1 = sum t[h..2h);  LOW: g0 = sum t[2i], g1 = sum t[2i+1]
+template <int LAYOUT>
+__global__ void __launch_bounds__(256) sc_sums_kernel(const uint64_t *t, size_t half, uint64_t *partials) {
+    __shared__ uint4 sh[256 * 4];
+    Fr g0 = Fr::zero(), g1 = Fr::zero();
+    size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < half; i += stride) {
+        size_t i0 = LAYOUT == ZG_SC_HIGH_HALF ? i : 2 * i, i1 = LAYOUT == ZG_SC_HIGH_HALF ? i + half : 2 * i + 1;
+        g0 = fe_add(g0, fe_load<FrParams>(t + 4 * i0));
+        g1 = fe_add(g1, fe_load<FrParams>(t + 4 * i1));
+    }
+    block_sum_pair(g0, g1, sh);
+    if (threadIdx.x == 0) {
+        fe_store(partials + 8 * (size_t)blockIdx.x, g0);
+        fe_store(partials + 8 * (size_t)blockIdx.x + 4, g1);
+    }
+}
+
+// fold by r and produce the NEXT round's two sums from the values just written:
+//   HIGH: out[i] = (1-r)*t[i] + r*t[i+half]     next g0 over i < half/2, g1 over i >= half/2
+//   LOW : out[i] = t[2i] + r*(t[2i+1]-t[2i])    next g0 over even i,     g1 over odd i
+template <int LAYOUT>
+__global__ void __launch_bounds__(256) sc_fold_kernel(const uint64_t *t, size_t half, const uint64_t *r, uint64_t *out,
+                                                      uint64_t *partials) {
+    __shared__ uint4 sh[256 * 4];
+    Fr rv = fe_load<FrParams>(r);
+    Fr omr = fe_sub(Fr::one(), rv);
+    Fr g0 = Fr::zero(), g1 = Fr::zero();
+    size_t stride = (size_t)gridDim.x * 256;
+    size_t quarter = half / 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < half; i += stride) {
+        Fr v;
+        if (LAYOUT == ZG_SC_HIGH_HALF) {
+            Fr lo = fe_load<FrParams>(t + 4 * i), hi = fe_load<FrParams>(t + 4 * (i + half));
+            v = fe_add(fe_mul(lo, omr), fe_mul(hi, rv));
+        } else {
+            Fr lo = fe_load<FrParams>(t + 8 * i), hi = fe_load<FrParams>(t + 8 * i + 4);
+            v = fe_add(lo, fe_mul(rv, fe_sub(hi, lo)));
+        }
+        fe_store(out + 4 * i, v);
+        bool second = LAYOUT == ZG_SC_HIGH_HALF ? (i >= quarter) : (i & 1);
+        if (second) g1 = fe_add(g1, v);
+        else g0 = fe_add(g0, v);
+    }
+    block_sum_pair(g0, g1, sh);
+    if (threadIdx.x == 0) {
+        fe_store(partials + 8 * (size_t)blockIdx.x, g0);
+        fe_store(partials + 8 * (size_t)blockIdx.x + 4, g1);
+    }
+}
+
+// reduce the per-block partial pairs to sums[0..8)
+__global__ void __launch_bounds__(256) sc_finish_kernel(const uint64_t *partials, uint32_t nblocks, uint64_t *sums) {
+    __shared__ uint4 sh[256 * 4];
+    Fr g0 = Fr::zero(), g1 = Fr::zero();
+    for (uint32_t k = threadIdx.x; k < nblocks; k += 256) {
+        g0 = fe_add(g0, fe_load<FrParams>(partials + 8 * (size_t)k));
+        g1 = fe_add(g1, fe_load<FrParams>(partials + 8 * (size_t)k + 4));
+    }
+    block_sum_pair(g0, g1, sh);
+    if (threadIdx.x == 0) {
+        fe_store(sums, g0);
+        fe_store(sums + 4, g1);
+    }
+}
+
+static unsigned sc_blocks(size_t half) {
+    unsigned b = div_up(half ? half : 1, 256);
+    return b > 2048 ? 2048 : b;  // grid-stride beyond 8 blocks per CU
+}
+
+static int launch_sums(int layout, const uint64_t *t, size_t len, uint64_t *partials, uint64_t *sums, hipStream_t st) {
+    size_t half = len / 2;
+    unsigned nb = sc_blocks(half);
+    if (layout == ZG_SC_HIGH_HALF)
+        hipLaunchKernelGGL(sc_sums_kernel<ZG_SC_HIGH_HALF>, dim3(nb), dim3(256), 0, st, t, half, partials);
+    else
+        hipLaunchKernelGGL(sc_sums_kernel<ZG_SC_LOW_PAIR>, dim3(nb), dim3(256), 0, st, t, half, partials);
+    hipLaunchKernelGGL(sc_finish_kernel, dim3(1), dim3(256), 0, st, partials, nb, sums);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
+static int launch_fold(int layout, const uint64_t *t, size_t len, const uint64_t *d_r, uint64_t *out, uint64_t *partials,
+                       uint64_t *sums, hipStream_t st) {
+    size_t half = len / 2;
+    unsigned nb = sc_blocks(half);
+    if (layout == ZG_SC_HIGH_HALF)
+        hipLaunchKernelGGL(sc_fold_kernel<ZG_SC_HIGH_HALF>, dim3(nb), dim3(256), 0, st, t, half, d_r, out, partials);
+    else
+        hipLaunchKernelGGL(sc_fold_kernel<ZG_SC_LOW_PAIR>, dim3(nb), dim3(256), 0, st, t, half, d_r, out, partials);
+    hipLaunchKernelGGL(sc_finish_kernel, dim3(1), dim3(256), 0, st, partials, nb, sums);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
+static int eq_table_enqueue(const uint64_t *r_host, size_t v, const uint64_t *scale_host, uint64_t *d_out, hipStream_t st) {
+    if (v > 34) {
+        set_error("zg_fr_eq_table: v too large");
+        return ZG_ERR_INVALID;
+    }
+    int v_lo = v < 8 ? (int)v : 8, v_hi = (int)v - v_lo;
+    uint32_t n_hi = 1u << v_hi;
+    uint64_t *d_r = nullptr, *d_hi = nullptr;
+    ZG_HIP(hipMalloc((void **)&d_r, (v + 1) * 32 + 32));
+    ZG_HIP(hipMalloc((void **)&d_hi, (size_t)n_hi * 32));
+    if (v) ZG_HIP(hipMemcpyAsync(d_r + 4, r_host, v * 32, hipMemcpyHostToDevice, st));
+    if (scale_host) ZG_HIP(hipMemcpyAsync(d_r, scale_host, 32, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(eq_hi_kernel, dim3(div_up(n_hi, 256)), dim3(256), 0, st, d_r + 4, v_hi, scale_host ? d_r : nullptr, d_hi);
+    uint32_t hpb = n_hi / 2048 ? n_hi / 2048 : 1;
+    hipLaunchKernelGGL(eq_main_kernel, dim3(div_up(n_hi, hpb)), dim3(256), 0, st, d_r + 4 + 4 * (size_t)v_hi, v_lo, d_hi, n_hi, hpb,
+                       d_out);
+    ZG_HIP(hipGetLastError());
+    ZG_HIP(hipStreamSynchronize(st));  // r_host / temporaries are released on return
+    (void)hipFree(d_r);
+    (void)hipFree(d_hi);
+    return ZG_OK;
+}
+
+}  // namespace zg
+
+struct zg_sc_s {
+    int layout = 0;
+    size_t len = 0;
+    uint64_t *buf[2] = {nullptr, nullptr};  // ping-pong tables (a fold cannot run in place across threads)
+    int cur = 0;
+    uint64_t *d_partials = nullptr, *d_sums = nullptr, *d_r = nullptr;
+    uint64_t *h_pin = nullptr;  // 8 limbs out, 4 limbs in
+    bool sums_valid = false;
+    hipStream_t st = nullptr;
+    std::mutex mu;
+};
+
+using namespace zg;
+
+static void sc_free(zg_sc_s *s) {
+    if (!s) return;
+    void *ptrs[] = {s->buf[0], s->buf[1], s->d_partials, s->d_sums, s->d_r};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (s->h_pin) (void)hipHostFree(s->h_pin);
+    delete s;
+}
+
+static int sc_create(size_t len, int layout, hipStream_t st, zg_sc_s **out) {
+    if (len == 0 || (len & (len - 1)) || (layout != ZG_SC_HIGH_HALF && layout != ZG_SC_LOW_PAIR)) {
+        set_error("zg_sumcheck_open: len must be a power of two and layout valid");
+        return ZG_ERR_INVALID;
+    }
+    zg_sc_s *s = new zg_sc_s();
+    s->layout = layout;
+    s->len = len;
+    s->st = st;
+    hipError_t e = hipMalloc((void **)&s->buf[0], len * 32);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->buf[1], (len / 2 ? len / 2 : 1) * 32);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_partials, 2048 * 64);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_sums, 64);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_r, 32);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_pin, 128);
+    if (e != hipSuccess) {
+        set_error(std::string("zg_sumcheck_open: ") + hipGetErrorString(e));
+        sc_free(s);
+        return e == hipErrorOutOfMemory ? ZG_ERR_NOMEM : ZG_ERR_HIP;
+    }
+    *out = s;
+    return ZG_OK;
+}
+
+extern "C" {
+
+int zg_fr_eq_table_dev(const uint64_t *r_host, size_t v, const uint64_t *scale_host, uint64_t *d_out, void *stream) {
+    ZG_INIT();
+    if (!d_out || (v && !r_host)) {
+        set_error("zg_fr_eq_table_dev: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    return eq_table_enqueue(r_host, v, scale_host, d_out, pick_stream(stream));
+}
+
+int zg_fr_eq_table(const uint64_t *r, size_t v, const uint64_t *scale, uint64_t *out) {
+    ZG_INIT();
+    if (!out || (v && !r) || v > 30) {
+        set_error("zg_fr_eq_table: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    size_t bytes = ((size_t)1 << v) * 32;
+    uint64_t *d_out = nullptr;
+    ZG_HIP(hipMalloc((void **)&d_out, bytes));
+    int rc = eq_table_enqueue(r, v, scale, d_out, lib_stream());
+    if (rc == ZG_OK) {
+        hipError_t e = hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            set_error(hipGetErrorString(e));
+            rc = ZG_ERR_HIP;
+        }
+    }
+    (void)hipFree(d_out);
+    return rc;
+}
+
+static int bind_host(int layout, const uint64_t *table, size_t len, const uint64_t r[4], uint64_t *out) {
+    if (!table || !r || !out || len < 2 || (len & (len - 1))) {
+        set_error("zg_fr_bind_*: len must be a power of two >= 2");
+        return ZG_ERR_INVALID;
+    }
+    hipStream_t st = lib_stream();
+    uint64_t *d_t = nullptr, *d_o = nullptr, *d_misc = nullptr;
+    ZG_HIP(hipMalloc((void **)&d_t, len * 32));
+    ZG_HIP(hipMalloc((void **)&d_o, len / 2 * 32));
+    ZG_HIP(hipMalloc((void **)&d_misc, 2048 * 64 + 64 + 32));
+    uint64_t *d_sums = d_misc + 2048 * 8, *d_r = d_sums + 8;
+    ZG_HIP(hipMemcpyAsync(d_t, table, len * 32, hipMemcpyHostToDevice, st));
+    ZG_HIP(hipMemcpyAsync(d_r, r, 32, hipMemcpyHostToDevice, st));
+    int rc = launch_fold(layout, d_t, len, d_r, d_o, d_misc, d_sums, st);
+    if (rc == ZG_OK) {
+        hipError_t e = hipMemcpyAsync(out, d_o, len / 2 * 32, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) {
+            set_error(hipGetErrorString(e));
+            rc = ZG_ERR_HIP;
+        }
+    }
+    (void)hipFree(d_t); (void)hipFree(d_o); (void)hipFree(d_misc);
+    return rc;
+}
+
+int zg_fr_bind_low(uint64_t *table, size_t len, const uint64_t r[4]) {
+    ZG_INIT();
+    return bind_host(ZG_SC_LOW_PAIR, table, len, r, table);
+}
+
+int zg_fr_bind_high(const uint64_t *table, size_t len, const uint64_t r[4], uint64_t *out) {
+    ZG_INIT();
+    return bind_host(ZG_SC_HIGH_HALF, table, len, r, out);
+}
+
+int zg_fr_spartan_combine_dev(const uint64_t *d_eq, const uint64_t *d_az, const uint64_t *d_bz, const uint64_t *d_cz, size_t n,
+                              uint64_t *d_out, void *stream) {
+    ZG_INIT();
+    if (n && (!d_eq || !d_az || !d_bz || !d_cz || !d_out)) {
+        set_error("zg_fr_spartan_combine_dev: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    if (n == 0) return ZG_OK;
+    unsigned nb = div_up(n, 256);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(spartan_combine_kernel, dim3(nb), dim3(256), 0, pick_stream(stream), d_eq, d_az, d_bz, d_cz, n, d_out);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
+int zg_fr_spartan_combine(const uint64_t *eq, const uint64_t *az, const uint64_t *bz, const uint64_t *cz, size_t n, uint64_t *out) {
+    ZG_INIT();
+    if (n && (!eq || !az || !bz || !cz || !out)) {
+        set_error("zg_fr_spartan_combine: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    if (n == 0) return ZG_OK;
+    hipStream_t st = lib_stream();
+    uint64_t *d = nullptr;
+    size_t bytes = n * 32;
+    ZG_HIP(hipMalloc((void **)&d, bytes * 5));
+    const uint64_t *src[4] = {eq, az, bz, cz};
+    for (int k = 0; k < 4; k++) ZG_HIP(hipMemcpyAsync(d + 4 * n * k, src[k], bytes, hipMemcpyHostToDevice, st));
+    int rc = zg_fr_spartan_combine_dev(d, d + 4 * n, d + 8 * n, d + 12 * n, n, d + 16 * n, st);
+    if (rc == ZG_OK) {
+        hipError_t e = hipMemcpyAsync(out, d + 16 * n, bytes, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) {
+            set_error(hipGetErrorString(e));
+            rc = ZG_ERR_HIP;
+        }
+    }
+    (void)hipFree(d);
+    return rc;
+}
+
+// ---------------------------------------------------------------- sumcheck session
+int zg_sumcheck_open(const uint64_t *evals, size_t len, int layout, zg_sc_t *out) {
+    ZG_INIT();
+    if (!evals || !out) {
+        set_error("zg_sumcheck_open: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    zg_sc_s *s = nullptr;
+    ZG_TRY(sc_create(len, layout, lib_stream(), &s));
+    hipError_t e = hipMemcpyAsync(s->buf[0], evals, len * 32, hipMemcpyHostToDevice, s->st);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->st);
+    if (e != hipSuccess) {
+        set_error(hipGetErrorString(e));
+        sc_free(s);
+        return ZG_ERR_HIP;
+    }
+    *out = s;
+    return ZG_OK;
+}
+
+int zg_sumcheck_open_dev(const uint64_t *d_evals, size_t len, int layout, void *stream, zg_sc_t *out) {
+    ZG_INIT();
+    if (!d_evals || !out) {
+        set_error("zg_sumcheck_open_dev: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    zg_sc_s *s = nullptr;
+    ZG_TRY(sc_create(len, layout, pick_stream(stream), &s));
+    hipError_t e = hipMemcpyAsync(s->buf[0], d_evals, len * 32, hipMemcpyDeviceToDevice, s->st);
+    if (e != hipSuccess) {
+        set_error(hipGetErrorString(e));
+        sc_free(s);
+        return ZG_ERR_HIP;
+    }
+    *out = s;
+    return ZG_OK;
+}
+
+int zg_sumcheck_round_sums(zg_sc_t s, uint64_t g0[4], uint64_t g1[4]) {
+    ZG_INIT();
+    if (!s || !g0 || !g1 || s->len < 2) {
+        set_error("zg_sumcheck_round_sums: invalid session or protocol already complete");
+        return ZG_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (!s->sums_valid) {
+        ZG_TRY(launch_sums(s->layout, s->buf[s->cur], s->len, s->d_partials, s->d_sums, s->st));
+        s->sums_valid = true;
+    }
+    ZG_HIP(hipMemcpyAsync(s->h_pin, s->d_sums, 64, hipMemcpyDeviceToHost, s->st));
+    ZG_HIP(hipStreamSynchronize(s->st));
+    for (int i = 0; i < 4; i++) {
+        g0[i] = s->h_pin[i];
+        g1[i] = s->h_pin[4 + i];
+    }
+    return ZG_OK;
+}
+
+int zg_sumcheck_bind(zg_sc_t s, const uint64_t r[4]) {
+    ZG_INIT();
+    if (!s || !r || s->len < 2) {
+        set_error("zg_sumcheck_bind: invalid session or protocol already complete");
+        return ZG_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(s->mu);
+    for (int i = 0; i < 4; i++) s->h_pin[8 + i] = r[i];
+    ZG_HIP(hipMemcpyAsync(s->d_r, s->h_pin + 8, 32, hipMemcpyHostToDevice, s->st));
+    // buf[1] holds len/2 elements at most; after the first fold both buffers are large enough
+    int nxt = s->cur ^ 1;
+    ZG_TRY(launch_fold(s->layout, s->buf[s->cur], s->len, s->d_r, s->buf[nxt], s->d_partials, s->d_sums, s->st));
+    // the pinned r buffer is reused by the next call: drain the copy before returning
+    ZG_HIP(hipStreamSynchronize(s->st));
+    s->cur = nxt;
+    s->len /= 2;
+    s->sums_valid = s->len >= 2;
+    return ZG_OK;
+}
+
+size_t zg_sumcheck_len(zg_sc_t s) { return s ? s->len : 0; }
+
+int zg_sumcheck_final(zg_sc_t s, uint64_t out[4]) {
+    ZG_INIT();
+    if (!s || !out || s->len != 1) {
+        set_error("zg_sumcheck_final: protocol not complete");
+        return ZG_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(s->mu);
+    ZG_HIP(hipMemcpyAsync(s->h_pin, s->buf[s->cur], 32, hipMemcpyDeviceToHost, s->st));
+    ZG_HIP(hipStreamSynchronize(s->st));
+    for (int i = 0; i < 4; i++) out[i] = s->h_pin[i];
+    return ZG_OK;
+}
+
+int zg_sumcheck_read(zg_sc_t s, uint64_t *out_table) {
+    ZG_INIT();
+    if (!s || !out_table) {
+        set_error("zg_sumcheck_read: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(s->mu);
+    ZG_HIP(hipMemcpyAsync(out_table, s->buf[s->cur], s->len * 32, hipMemcpyDeviceToHost, s->st));
+    ZG_HIP(hipStreamSynchronize(s->st));
+    return ZG_OK;
+}
+
+int zg_sumcheck_close(zg_sc_t s) {
+    if (!s) return ZG_OK;
+    ZG_INIT();
+    (void)hipStreamSynchronize(s->st);
+    sc_free(s);
+    return ZG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,157 @@
+// runtime.hip — lifecycle, error reporting, raw device memory and the elementwise field
+// kernels of libzolt_gpu.so (C ABI: include/zolt_gpu.h).
+#include <mutex>
+
+#include "common.hip.h"
+#include "field.hip.h"
+
+namespace zg {
+
+static thread_local std::string t_err;
+static std::mutex g_mu;
+static bool g_inited = false;
+static hipStream_t g_stream = nullptr;
+
+void set_error(const std::string &msg) { t_err = msg; }
+hipStream_t lib_stream() { return g_stream; }
+
+static int do_init(int device) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_inited) return ZG_OK;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) {
+        set_error("no HIP device available (libzolt_gpu has no CPU fallback)");
+        return ZG_ERR_NO_DEVICE;
+    }
+    if (device >= 0) {
+        if (device >= count) {
+            set_error("zg_init: device ordinal out of range");
+            return ZG_ERR_INVALID;
+        }
+        ZG_HIP(hipSetDevice(device));
+    }
+    ZG_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    g_inited = true;
+    return ZG_OK;
+}
+
+int ensure_init() {
+    if (g_inited) return ZG_OK;
+    return do_init(-1);
+}
+
+// ------------------------------------------------------------------ field op kernel
+template <class P>
+__global__ void __launch_bounds__(256) field_op_kernel(int op, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        Fe<P> x = fe_load<P>(a + 4 * i);
+        Fe<P> y = Fe<P>::zero();
+        if (op <= ZG_OP_SUB) y = fe_load<P>(b + 4 * i);
+        Fe<P> r;
+        switch (op) {
+            case ZG_OP_MUL: r = fe_mul(x, y); break;
+            case ZG_OP_ADD: r = fe_add(x, y); break;
+            case ZG_OP_SUB: r = fe_sub(x, y); break;
+            case ZG_OP_NEG: r = fe_neg(x); break;
+            case ZG_OP_SQR: r = fe_sqr(x); break;
+            case ZG_OP_INV: r = fe_inv(x); break;
+            case ZG_OP_FROM_MONT: r = fe_from_mont(x); break;
+            default: r = fe_to_mont(x); break;
+        }
+        fe_store(out + 4 * i, r);
+    }
+}
+
+}  // namespace zg
+
+using namespace zg;
+
+extern "C" {
+
+int zg_init(int device) { return do_init(device); }
+
+void zg_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_inited) return;
+    (void)hipStreamSynchronize(g_stream);
+    (void)hipStreamDestroy(g_stream);
+    g_stream = nullptr;
+    g_inited = false;
+}
+
+const char *zg_last_error(void) { return t_err.c_str(); }
+const char *zg_version(void) { return "zolt-gfx950 0.1 (BN254 G1 MSM / eq-table / sumcheck fold; gfx950 HIP)"; }
+
+int zg_device_count(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+    return count;
+}
+
+int zg_dev_alloc(size_t bytes, void **dptr) {
+    ZG_INIT();
+    if (!dptr) return ZG_ERR_INVALID;
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
+    if (e == hipErrorOutOfMemory) {
+        set_error("hipMalloc: out of memory");
+        return ZG_ERR_NOMEM;
+    }
+    ZG_HIP(e);
+    return ZG_OK;
+}
+int zg_dev_free(void *dptr) {
+    ZG_INIT();
+    ZG_HIP(hipFree(dptr));
+    return ZG_OK;
+}
+int zg_memcpy_h2d(void *dst, const void *src, size_t bytes) {
+    ZG_INIT();
+    ZG_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return ZG_OK;
+}
+int zg_memcpy_d2h(void *dst, const void *src, size_t bytes) {
+    ZG_INIT();
+    ZG_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return ZG_OK;
+}
+int zg_sync(void) {
+    ZG_INIT();
+    ZG_HIP(hipStreamSynchronize(g_stream));
+    return ZG_OK;
+}
+
+int zg_field_op(int field, int op, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n) {
+    ZG_INIT();
+    if (op < 0 || op > ZG_OP_TO_MONT || (field != ZG_FIELD_FR && field != ZG_FIELD_FP) || !a || !out ||
+        (op <= ZG_OP_SUB && !b)) {
+        set_error("zg_field_op: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    if (n == 0) return ZG_OK;
+    size_t bytes = n * 32;
+    uint64_t *da = nullptr, *db = nullptr, *dout = nullptr;
+    ZG_HIP(hipMalloc(&da, bytes));
+    ZG_HIP(hipMalloc(&dout, bytes));
+    ZG_HIP(hipMemcpyAsync(da, a, bytes, hipMemcpyHostToDevice, g_stream));
+    if (op <= ZG_OP_SUB) {
+        ZG_HIP(hipMalloc(&db, bytes));
+        ZG_HIP(hipMemcpyAsync(db, b, bytes, hipMemcpyHostToDevice, g_stream));
+    }
+    unsigned blocks = div_up(n, 256);
+    if (blocks > 4096) blocks = 4096;
+    if (field == ZG_FIELD_FR)
+        hipLaunchKernelGGL(field_op_kernel<FrParams>, dim3(blocks), dim3(256), 0, g_stream, op, da, db, dout, n);
+    else
+        hipLaunchKernelGGL(field_op_kernel<FpParams>, dim3(blocks), dim3(256), 0, g_stream, op, da, db, dout, n);
+    ZG_HIP(hipGetLastError());
+    ZG_HIP(hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, g_stream));
+    ZG_HIP(hipStreamSynchronize(g_stream));
+    (void)hipFree(da);
+    (void)hipFree(dout);
+    if (db) (void)hipFree(db);
+    return ZG_OK;
+}
+
+}  // extern "C"

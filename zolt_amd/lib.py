@@ -1,0 +1,294 @@
+"""ctypes binding of include/zolt_gpu.h. Arrays are numpy uint64 (host) or raw device
+pointers (ints, e.g. torch.Tensor.data_ptr()). No torch import here."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzolt_gpu.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `make -C zolt_amd/csrc` (or __graft_entry__.build()). "
+        "zolt_amd has no CPU fallback."
+    )
+_lib = C.CDLL(LIB_PATH)
+
+OK, ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_NO_DEVICE = 0, 1, 2, 3, 4
+FR, FP = 0, 1
+OP_MUL, OP_ADD, OP_SUB, OP_NEG, OP_SQR, OP_INV, OP_FROM_MONT, OP_TO_MONT = range(8)
+SC_HIGH_HALF, SC_LOW_PAIR = 0, 1
+
+# every symbol include/zolt_gpu.h declares (tests check that the .so exports all of them)
+SYMBOLS = [
+    "zg_init", "zg_shutdown", "zg_last_error", "zg_version", "zg_device_count",
+    "zg_dev_alloc", "zg_dev_free", "zg_memcpy_h2d", "zg_memcpy_d2h", "zg_sync",
+    "zg_field_op",
+    "zg_g1_bases_upload", "zg_g1_bases_upload_dev", "zg_g1_bases_free", "zg_g1_bases_len",
+    "zg_msm_g1", "zg_msm_g1_dev", "zg_msm_g1_dev_async", "zg_msm_g1_batch", "zg_msm_g1_partial_dev",
+    "zg_g1_combine_partials_dev", "zg_g1_scalar_mul_batch",
+    "zg_fr_eq_table", "zg_fr_eq_table_dev", "zg_fr_bind_low", "zg_fr_bind_high",
+    "zg_fr_spartan_combine", "zg_fr_spartan_combine_dev",
+    "zg_sumcheck_open", "zg_sumcheck_open_dev", "zg_sumcheck_round_sums", "zg_sumcheck_bind",
+    "zg_sumcheck_len", "zg_sumcheck_final", "zg_sumcheck_read", "zg_sumcheck_close",
+]
+
+
+class MsmConfig(C.Structure):
+    _fields_ = [("window_bits", C.c_int), ("precompute_levels", C.c_int)]
+
+
+_lib.zg_last_error.restype = C.c_char_p
+_lib.zg_version.restype = C.c_char_p
+_lib.zg_g1_bases_len.restype = C.c_size_t
+_lib.zg_sumcheck_len.restype = C.c_size_t
+
+_u64p = C.POINTER(C.c_uint64)
+_u8p = C.POINTER(C.c_uint8)
+
+
+class ZgError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        msg = _lib.zg_last_error()
+        super().__init__(f"{where}: error {code}: {msg.decode() if msg else ''}")
+
+
+def _chk(rc, where):
+    if rc != OK:
+        raise ZgError(rc, where)
+
+
+def _h(a):
+    """host numpy array -> uint64* (None passes NULL)"""
+    return None if a is None else a.ctypes.data_as(_u64p)
+
+
+def _hb(a):
+    return None if a is None else a.ctypes.data_as(_u8p)
+
+
+def _d(ptr):
+    """device address (int) -> void*"""
+    return C.c_void_p(int(ptr) if ptr else None)
+
+
+def _c(a, dtype=np.uint64):
+    return None if a is None else np.ascontiguousarray(a, dtype=dtype)
+
+
+def version():
+    return _lib.zg_version().decode()
+
+
+def device_count():
+    return int(_lib.zg_device_count())
+
+
+def init(device=-1):
+    _chk(_lib.zg_init(C.c_int(device)), "zg_init")
+
+
+def shutdown():
+    _lib.zg_shutdown()
+
+
+def sync():
+    _chk(_lib.zg_sync(), "zg_sync")
+
+
+def last_error():
+    m = _lib.zg_last_error()
+    return m.decode() if m else ""
+
+
+# ---- field vectors
+def field_op(field, op, a, b=None):
+    a = _c(a)
+    b = _c(b)
+    out = np.empty_like(a)
+    _chk(_lib.zg_field_op(C.c_int(field), C.c_int(op), _h(a), _h(b), _h(out), C.c_size_t(a.size // 4)), "zg_field_op")
+    return out
+
+
+# ---- bases / MSM
+class Bases:
+    """Device-resident bases (the SRS). Mirrors HyperKZG SetupParams.powers_of_tau_g1."""
+
+    def __init__(self, handle, n):
+        self._h = handle
+        self.n = n
+
+    @classmethod
+    def upload(cls, xy, inf=None, window_bits=0, precompute_levels=0):
+        xy = _c(xy)
+        inf = _c(inf, np.uint8)
+        n = xy.size // 8
+        cfg = MsmConfig(window_bits, precompute_levels)
+        h = C.c_void_p()
+        _chk(_lib.zg_g1_bases_upload(_h(xy), _hb(inf), C.c_size_t(n), C.byref(cfg), C.byref(h)), "zg_g1_bases_upload")
+        return cls(h, n)
+
+    @classmethod
+    def upload_dev(cls, d_xy, d_inf, n, stream=0, window_bits=0, precompute_levels=0):
+        cfg = MsmConfig(window_bits, precompute_levels)
+        h = C.c_void_p()
+        _chk(_lib.zg_g1_bases_upload_dev(_d(d_xy), _d(d_inf), C.c_size_t(n), C.byref(cfg), _d(stream), C.byref(h)),
+             "zg_g1_bases_upload_dev")
+        return cls(h, n)
+
+    def free(self):
+        if self._h:
+            _chk(_lib.zg_g1_bases_free(self._h), "zg_g1_bases_free")
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def msm(self, scalars, off=0, n=None):
+        scalars = _c(scalars)
+        n = scalars.size // 4 if n is None else n
+        out = np.empty(8, dtype=np.uint64)
+        inf = C.c_uint8(0)
+        _chk(_lib.zg_msm_g1(self._h, C.c_size_t(off), C.c_size_t(n), _h(scalars), _h(out), C.byref(inf)), "zg_msm_g1")
+        return out, int(inf.value)
+
+    def msm_dev(self, d_scalars, n, off=0, stream=0):
+        out = np.empty(8, dtype=np.uint64)
+        inf = C.c_uint8(0)
+        _chk(_lib.zg_msm_g1_dev(self._h, C.c_size_t(off), C.c_size_t(n), _d(d_scalars), _d(stream), _h(out), C.byref(inf)),
+             "zg_msm_g1_dev")
+        return out, int(inf.value)
+
+    def msm_dev_async(self, d_scalars, n, d_out_xy, d_out_inf, off=0, stream=0):
+        _chk(_lib.zg_msm_g1_dev_async(self._h, C.c_size_t(off), C.c_size_t(n), _d(d_scalars), _d(stream), _d(d_out_xy),
+                                      _d(d_out_inf)), "zg_msm_g1_dev_async")
+
+    def msm_partial_dev(self, d_scalars, n, d_out_jac, off=0, stream=0):
+        _chk(_lib.zg_msm_g1_partial_dev(self._h, C.c_size_t(off), C.c_size_t(n), _d(d_scalars), _d(stream), _d(d_out_jac)),
+             "zg_msm_g1_partial_dev")
+
+    def msm_batch(self, batches, n=None):
+        batches = [_c(b) for b in batches]
+        k = len(batches)
+        n = (batches[0].size // 4 if k else 0) if n is None else n
+        arr = (_u64p * max(k, 1))(*[_h(b) for b in batches])
+        out = np.empty((k, 8), dtype=np.uint64)
+        inf = np.zeros(k, dtype=np.uint8)
+        _chk(_lib.zg_msm_g1_batch(self._h, C.c_size_t(n), arr, C.c_size_t(k), _h(out), _hb(inf)), "zg_msm_g1_batch")
+        return out, inf
+
+
+def combine_partials_dev(d_partials, k, stream=0):
+    out = np.empty(8, dtype=np.uint64)
+    inf = C.c_uint8(0)
+    _chk(_lib.zg_g1_combine_partials_dev(_d(d_partials), C.c_size_t(k), _d(stream), _h(out), C.byref(inf)),
+         "zg_g1_combine_partials_dev")
+    return out, int(inf.value)
+
+
+def g1_scalar_mul_batch(xy, inf, scalars):
+    xy, inf, scalars = _c(xy), _c(inf, np.uint8), _c(scalars)
+    n = scalars.size // 4
+    out = np.empty((n, 8), dtype=np.uint64)
+    oinf = np.zeros(n, dtype=np.uint8)
+    _chk(_lib.zg_g1_scalar_mul_batch(_h(xy), _hb(inf), _h(scalars), C.c_size_t(n), _h(out), _hb(oinf)), "zg_g1_scalar_mul_batch")
+    return out, oinf
+
+
+# ---- poly
+def fr_eq_table(r, scale=None):
+    r = _c(r)
+    v = r.size // 4
+    out = np.empty((1 << v, 4), dtype=np.uint64)
+    _chk(_lib.zg_fr_eq_table(_h(r), C.c_size_t(v), _h(_c(scale)), _h(out)), "zg_fr_eq_table")
+    return out
+
+
+def fr_eq_table_dev(r, d_out, scale=None, stream=0):
+    r = _c(r)
+    _chk(_lib.zg_fr_eq_table_dev(_h(r), C.c_size_t(r.size // 4), _h(_c(scale)), _d(d_out), _d(stream)), "zg_fr_eq_table_dev")
+
+
+def fr_bind_low(table, r):
+    t = np.array(table, dtype=np.uint64, copy=True).reshape(-1, 4)
+    n = t.shape[0]
+    _chk(_lib.zg_fr_bind_low(_h(t), C.c_size_t(n), _h(_c(r))), "zg_fr_bind_low")
+    return t[: n // 2].copy()
+
+
+def fr_bind_high(table, r):
+    t = _c(table).reshape(-1, 4)
+    n = t.shape[0]
+    out = np.empty((n // 2, 4), dtype=np.uint64)
+    _chk(_lib.zg_fr_bind_high(_h(t), C.c_size_t(n), _h(_c(r)), _h(out)), "zg_fr_bind_high")
+    return out
+
+
+def fr_spartan_combine(eq, az, bz, cz):
+    eq, az, bz, cz = _c(eq), _c(az), _c(bz), _c(cz)
+    out = np.empty_like(eq)
+    _chk(_lib.zg_fr_spartan_combine(_h(eq), _h(az), _h(bz), _h(cz), C.c_size_t(eq.size // 4), _h(out)), "zg_fr_spartan_combine")
+    return out
+
+
+def fr_spartan_combine_dev(d_eq, d_az, d_bz, d_cz, n, d_out, stream=0):
+    _chk(_lib.zg_fr_spartan_combine_dev(_d(d_eq), _d(d_az), _d(d_bz), _d(d_cz), C.c_size_t(n), _d(d_out), _d(stream)),
+         "zg_fr_spartan_combine_dev")
+
+
+class SumcheckSession:
+    """Device-resident Sumcheck(F).Prover table (src/subprotocols/mod.zig:50-134)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def open(cls, evals, layout=SC_HIGH_HALF):
+        e = _c(evals)
+        h = C.c_void_p()
+        _chk(_lib.zg_sumcheck_open(_h(e), C.c_size_t(e.size // 4), C.c_int(layout), C.byref(h)), "zg_sumcheck_open")
+        return cls(h)
+
+    @classmethod
+    def open_dev(cls, d_evals, n, layout=SC_HIGH_HALF, stream=0):
+        h = C.c_void_p()
+        _chk(_lib.zg_sumcheck_open_dev(_d(d_evals), C.c_size_t(n), C.c_int(layout), _d(stream), C.byref(h)), "zg_sumcheck_open_dev")
+        return cls(h)
+
+    def round_sums(self):
+        g0 = np.empty(4, dtype=np.uint64)
+        g1 = np.empty(4, dtype=np.uint64)
+        _chk(_lib.zg_sumcheck_round_sums(self._h, _h(g0), _h(g1)), "zg_sumcheck_round_sums")
+        return g0, g1
+
+    def bind(self, r):
+        _chk(_lib.zg_sumcheck_bind(self._h, _h(_c(r))), "zg_sumcheck_bind")
+
+    def __len__(self):
+        return int(_lib.zg_sumcheck_len(self._h))
+
+    def final(self):
+        out = np.empty(4, dtype=np.uint64)
+        _chk(_lib.zg_sumcheck_final(self._h, _h(out)), "zg_sumcheck_final")
+        return out
+
+    def read(self):
+        out = np.empty((len(self), 4), dtype=np.uint64)
+        _chk(_lib.zg_sumcheck_read(self._h, _h(out)), "zg_sumcheck_read")
+        return out
+
+    def close(self):
+        if self._h:
+            _chk(_lib.zg_sumcheck_close(self._h), "zg_sumcheck_close")
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
