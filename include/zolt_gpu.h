@@ -77,6 +77,23 @@ ZG_API int zg_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
 ZG_API int zg_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
 ZG_API int zg_sync(void);
 
+/* ------------------------------------------------------------------ profiling */
+/* Per-kernel timing with HIP events recorded on the stream each kernel is launched on
+ * (bench.py's roofline figure). zg_profile_begin enables recording of up to max_records
+ * kernel intervals; zg_profile_end synchronises, adds the elapsed times up per kernel id
+ * (milliseconds, launch counts) and disables recording. Not thread-safe; bench use only. */
+#define ZG_PROF_MSM_DIGITS 0
+#define ZG_PROF_MSM_SORT 1       /* scan + scatter */
+#define ZG_PROF_MSM_ACCUMULATE 2 /* bucket accumulation: the dominant MSM kernel */
+#define ZG_PROF_MSM_REDUCE 3     /* bucket reduction levels + final */
+#define ZG_PROF_EQ_TABLE 4
+#define ZG_PROF_SC_FOLD 5        /* fold + fused next-round sums */
+#define ZG_PROF_SC_SUMS 6
+#define ZG_PROF_COMBINE 7        /* Spartan combine */
+#define ZG_PROF_NKERNELS 8
+ZG_API int zg_profile_begin(int max_records);
+ZG_API int zg_profile_end(double ms_out[ZG_PROF_NKERNELS], uint64_t count_out[ZG_PROF_NKERNELS]);
+
 /* ------------------------------------------------------------------ field vectors */
 /* out[i] = op(a[i], b[i]) over n elements; host pointers. Replaces the scalar loops of
  * field.BatchOps (src/field/mod.zig:1164-1280) and backs the device-arithmetic unit tests. */

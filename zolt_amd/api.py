@@ -1,0 +1,344 @@
+"""Host-side mirror of the reference's module API for the hot path, over libzolt_gpu.so.
+
+Names, argument meaning and error behaviour follow the Zig modules so the parity tests
+read like the reference's own tests (paths under /root/reference):
+
+  MSM.compute / BatchMSM / ParallelMSM        src/msm/mod.zig:345-748
+  HyperKZG.setup / commit / batchCommit / open src/poly/commitment/mod.zig:174-324,558-570
+  EqPolynomial.evals, DensePolynomial          src/poly/mod.zig:23-323
+  Sumcheck.Prover / Verifier, runSumcheck      src/subprotocols/mod.zig:18-354
+
+All heavy arithmetic runs in the HIP kernels. What stays on the host is exactly what
+stays on the host in the reference integration: the toy verifier's 64-bit challenge mixer
+and a handful of scalar field operations per round (Python ints below), i.e. the role the
+unchanged Zig `field` module plays above the FFI seam.
+
+Field elements are numpy uint64[4] Montgomery limbs; points numpy uint64[8] + inf flag.
+"""
+import numpy as np
+
+from . import lib
+
+R_MOD = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+P_MOD = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+_M64 = (1 << 64) - 1
+_MONT_R = 1 << 256
+
+
+# ---- host scalar helpers (representation only)
+def _limbs(v):
+    return np.array([(v >> (64 * i)) & _M64 for i in range(4)], dtype=np.uint64)
+
+
+def _int(l):
+    return sum(int(x) << (64 * i) for i, x in enumerate(l))
+
+
+def fr_from_int(v):
+    """F.fromU64 / canonical integer -> Montgomery limbs (src/field/mod.zig:617-622)."""
+    return _limbs((v % R_MOD) * _MONT_R % R_MOD)
+
+
+def fr_to_int(l):
+    return _int(l) * pow(_MONT_R, -1, R_MOD) % R_MOD
+
+
+def fp_from_int(v):
+    return _limbs((v % P_MOD) * _MONT_R % P_MOD)
+
+
+def fp_to_int(l):
+    return _int(l) * pow(_MONT_R, -1, P_MOD) % P_MOD
+
+
+def generator():
+    """AffinePoint.generator() = (1, 2) (src/msm/mod.zig:43-49)."""
+    return np.concatenate([fp_from_int(1), fp_from_int(2)])
+
+
+def commitment_to_bytes(xy, inf):
+    """PolyCommitment.toBytes: x || y big-endian canonical (src/zkvm/commitment_types.zig:49-54)."""
+    if inf:
+        return bytes(64)
+    return fp_to_int(xy[:4]).to_bytes(32, "big") + fp_to_int(xy[4:]).to_bytes(32, "big")
+
+
+# ---- MSM
+class MSM:
+    """MSM(F, G) with F = Fr, G = Fp."""
+
+    @staticmethod
+    def compute(bases_xy, scalars, bases_inf=None):
+        """MSM.compute(bases, scalars) -> (xy, inf)   (src/msm/mod.zig:355-372)."""
+        bases_xy = np.ascontiguousarray(bases_xy, dtype=np.uint64).reshape(-1, 8)
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        assert bases_xy.shape[0] == scalars.shape[0]  # std.debug.assert(bases.len == scalars.len), :359
+        b = lib.Bases.upload(bases_xy, bases_inf)
+        try:
+            return b.msm(scalars)
+        finally:
+            b.free()
+
+    @staticmethod
+    def scalarMul(base_xy, scalar, base_inf=0):
+        """MSM.scalarMul(base, scalar).toAffine() (src/msm/mod.zig:503-540)."""
+        out, inf = lib.g1_scalar_mul_batch(np.asarray(base_xy).reshape(1, 8), np.array([base_inf], dtype=np.uint8),
+                                           np.asarray(scalar).reshape(1, 4))
+        return out[0], int(inf[0])
+
+
+class BatchMSM:
+    @staticmethod
+    def compute(bases_xy, scalar_batches, bases_inf=None):
+        """BatchMSM.compute / ParallelBatchMSM.compute (src/msm/mod.zig:545-565,683-748)."""
+        b = lib.Bases.upload(bases_xy, bases_inf)
+        try:
+            return b.msm_batch(scalar_batches)
+        finally:
+            b.free()
+
+
+def shard_bounds(n, parts):
+    """ParallelMSM's partition: contiguous chunks of ceil(n/T) (src/msm/mod.zig:609,619-639).
+    Returns [(start, end)] of length `parts`; trailing shards may be empty."""
+    chunk = (n + parts - 1) // parts if parts else 0
+    out = []
+    for i in range(parts):
+        s = min(i * chunk, n)
+        out.append((s, min(s + chunk, n)))
+    return out
+
+
+class ShardedMSM:
+    """ParallelMSM across GPUs: rank r owns bases/scalars [start_r, end_r), computes its
+    Jacobian partial on its GPU, the partials are all-gathered (RCCL via torch.distributed: one
+    96-byte record per rank), and the serial combine + toAffine runs on the device.
+
+    `backend` supplies the two device operations so the orchestration can be exercised on CPU
+    with gloo in the tests:
+        backend.partial(rank_scalars_tensor) -> torch int64[12] tensor (device of the backend)
+        backend.combine(gathered int64[world,12]) -> (xy, inf)
+    """
+
+    def __init__(self, backend, world_size, rank, group=None):
+        self.backend, self.world, self.rank, self.group = backend, world_size, rank, group
+
+    def compute(self, local_scalars):
+        import torch
+        import torch.distributed as dist
+        part = self.backend.partial(local_scalars)
+        if self.world == 1:
+            gathered = part.reshape(1, 12)
+        else:
+            gathered = torch.empty((self.world, 12), dtype=torch.int64, device=part.device)
+            dist.all_gather_into_tensor(gathered, part.reshape(1, 12), group=self.group)
+        return self.backend.combine(gathered)
+
+
+class GpuShardBackend:
+    """ShardedMSM backend over libzolt_gpu.so; tensors are torch CUDA tensors (device memory plumbing)."""
+
+    def __init__(self, bases, n_local, stream_ptr=0):
+        self.bases, self.n, self.stream = bases, n_local, stream_ptr
+
+    def partial(self, d_scalars):
+        import torch
+        out = torch.empty(12, dtype=torch.int64, device=d_scalars.device)
+        self.bases.msm_partial_dev(d_scalars.data_ptr(), self.n, out.data_ptr(), stream=self.stream)
+        return out
+
+    def combine(self, gathered):
+        return lib.combine_partials_dev(gathered.data_ptr(), gathered.shape[0], stream=self.stream)
+
+
+# ---- HyperKZG (commit side)
+class HyperKZG:
+    TAU = 0x12345678  # src/poly/commitment/mod.zig:189 (mock SRS, INSECURE by design)
+
+    class SetupParams:
+        def __init__(self, xy, inf):
+            self.powers_of_tau_g1 = xy
+            self.infinity = inf
+            self.max_degree = xy.shape[0]
+            self._dev = lib.Bases.upload(xy, inf)  # device-resident for the whole run (:122-140)
+
+        def deinit(self):
+            self._dev.free()
+
+    @staticmethod
+    def setup(max_degree):
+        """powers[i] = scalarMul(G1, tau^i).toAffine() (src/poly/commitment/mod.zig:174-213)."""
+        g = generator()
+        taus = np.stack([fr_from_int(pow(HyperKZG.TAU, i, R_MOD)) for i in range(max_degree)]) if max_degree else \
+            np.zeros((0, 4), dtype=np.uint64)
+        xy, inf = lib.g1_scalar_mul_batch(np.repeat(g[None, :], max_degree, axis=0), np.zeros(max_degree, dtype=np.uint8), taus)
+        return HyperKZG.SetupParams(xy, inf)
+
+    @staticmethod
+    def commit(params, evals):
+        """commit(params, evals) (src/poly/commitment/mod.zig:239-255): empty -> identity; n = min(len, srs)."""
+        evals = np.ascontiguousarray(evals, dtype=np.uint64).reshape(-1, 4)
+        if evals.shape[0] == 0:
+            return np.zeros(8, dtype=np.uint64), 1
+        n = min(evals.shape[0], params.max_degree)
+        return params._dev.msm(evals[:n], off=0, n=n)
+
+    @staticmethod
+    def batchCommit(params, polys):
+        """batchCommit (src/poly/commitment/mod.zig:558-570)."""
+        return [HyperKZG.commit(params, p) for p in polys]
+
+    @staticmethod
+    def open(params, evals, point, value):
+        """open (src/poly/commitment/mod.zig:261-324): per variable commit(q = hi - lo), fold high half.
+        Returns (quotient commitments [(xy, inf)], final_eval)."""
+        point = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1, 4)
+        if point.shape[0] == 0:
+            return [], np.asarray(value, dtype=np.uint64)
+        cur = np.ascontiguousarray(evals, dtype=np.uint64).reshape(-1, 4)
+        quotients = []
+        for i in range(point.shape[0]):
+            half = cur.shape[0] // 2
+            if half == 0:
+                break
+            q = lib.field_op(lib.FR, lib.OP_SUB, cur[half:2 * half], cur[:half])
+            quotients.append(HyperKZG.commit(params, q))
+            cur = lib.fr_bind_high(cur[:2 * half], point[i])
+        final = cur[0] if cur.shape[0] else np.zeros(4, dtype=np.uint64)
+        return quotients, final
+
+
+# ---- polynomials
+class EqPolynomial:
+    def __init__(self, r):
+        self.r = np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4).copy()
+
+    def evals(self):
+        """EqPolynomial.evals (src/poly/mod.zig:240-242): 2^n table, index MSB <-> r[0]."""
+        return lib.fr_eq_table(self.r)
+
+    @staticmethod
+    def evalsSliceWithScaling(r, scaling_factor=None):
+        return lib.fr_eq_table(np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4), scaling_factor)
+
+
+class DensePolynomial:
+    def __init__(self, evaluations):
+        ev = np.ascontiguousarray(evaluations, dtype=np.uint64).reshape(-1, 4)
+        n = ev.shape[0]
+        assert n and n & (n - 1) == 0  # src/poly/mod.zig:36-37
+        self.evaluations = ev.copy()
+        self.num_vars = n.bit_length() - 1
+
+    def len(self):
+        return self.evaluations.shape[0]
+
+    def bindFirst(self, value):
+        """high-half fold into a NEW polynomial (src/poly/mod.zig:128-149)."""
+        assert self.num_vars > 0
+        return DensePolynomial(lib.fr_bind_high(self.evaluations, value))
+
+    def bindLow(self, value):
+        """adjacent-pair fold IN PLACE (src/poly/mod.zig:160-175)."""
+        assert self.num_vars > 0
+        self.evaluations = lib.fr_bind_low(self.evaluations, value)
+        self.num_vars -= 1
+
+
+# ---- sumcheck
+class SumcheckVerificationFailed(Exception):
+    pass
+
+
+class Sumcheck:
+    class Prover:
+        """Sumcheck(F).Prover with the polynomial resident on the GPU (src/subprotocols/mod.zig:50-134)."""
+
+        def __init__(self, polynomial):
+            self._s = lib.SumcheckSession.open(polynomial.evaluations, lib.SC_HIGH_HALF)
+            self.round = 0
+
+        def nextRound(self):
+            """-> coeffs [g(0), g(1) - g(0)] (src/subprotocols/mod.zig:69-109)."""
+            g0, g1 = self._s.round_sums()
+            c1 = _limbs((_int(g1) - _int(g0)) % R_MOD)  # Montgomery form is linear: sub on limbs mod r
+            return np.stack([g0, c1])
+
+        def receiveChallenge(self, challenge):
+            self._s.bind(challenge)
+            self.round += 1
+
+        def isComplete(self):
+            return len(self._s) == 1
+
+        def getFinalEval(self):
+            assert self.isComplete()
+            return self._s.final()
+
+        def deinit(self):
+            self._s.close()
+
+    class Verifier:
+        """Toy verifier with the deterministic 64-bit mixer (src/subprotocols/mod.zig:137-244)."""
+
+        def __init__(self, claim):
+            self.claim = np.asarray(claim, dtype=np.uint64)
+            self.round = 0
+            self.challenges = []
+
+        @staticmethod
+        def _eval(coeffs, x_int):
+            """UniPoly.evaluate by Horner (src/poly/mod.zig:608-618) on canonical ints."""
+            res = 0
+            for c in reversed(coeffs):
+                res = (res * x_int + c) % R_MOD
+            return res
+
+        def deriveChallenge(self, coeffs):
+            h = 0x9E3779B97F4A7C15
+            h ^= self.round
+            h = (h * 0xFF51AFD7ED558CCD) & _M64
+            for limb in self.claim:
+                h ^= int(limb)
+                h = (h * 0xC4CEB9FE1A85EC53) & _M64
+            for c in coeffs:
+                for limb in c:
+                    h ^= int(limb)
+                    h = (h * 0xFF51AFD7ED558CCD) & _M64
+                    h ^= h >> 33
+            h ^= h >> 33
+            h = (h * 0xFF51AFD7ED558CCD) & _M64
+            h ^= h >> 33
+            return h
+
+        def verifyRound(self, coeffs):
+            ci = [fr_to_int(c) for c in coeffs]
+            p0, p1 = self._eval(ci, 0), self._eval(ci, 1)
+            if (p0 + p1) % R_MOD != fr_to_int(self.claim):
+                raise SumcheckVerificationFailed()
+            h = self.deriveChallenge(coeffs)
+            challenge = fr_from_int(h)
+            self.challenges.append(challenge)
+            self.claim = fr_from_int(self._eval(ci, h))
+            self.round += 1
+            return challenge
+
+
+def runSumcheck(polynomial):
+    """runSumcheck (src/subprotocols/mod.zig:302-354) -> dict(claim, rounds, final_point, final_eval, result)."""
+    s = lib.SumcheckSession.open(polynomial.evaluations, lib.SC_HIGH_HALF)
+    g0, g1 = s.round_sums() if polynomial.num_vars else (polynomial.evaluations[0], np.zeros(4, dtype=np.uint64))
+    s.close()
+    claim = _limbs((_int(g0) + _int(g1)) % R_MOD)
+    prover = Sumcheck.Prover(polynomial)
+    verifier = Sumcheck.Verifier(claim)
+    rounds = []
+    for _ in range(polynomial.num_vars):
+        coeffs = prover.nextRound()
+        ch = verifier.verifyRound(coeffs)
+        prover.receiveChallenge(ch)
+        rounds.append(coeffs)
+    final_eval = prover.getFinalEval()
+    prover.deinit()
+    return {"claim": claim, "rounds": rounds, "final_point": list(verifier.challenges), "final_eval": final_eval,
+            "result": bool(np.array_equal(verifier.claim, final_eval))}

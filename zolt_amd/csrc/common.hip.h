@@ -32,6 +32,16 @@ inline hipStream_t pick_stream(void *s) { return s ? reinterpret_cast<hipStream_
 
 #define ZG_INIT() ZG_TRY(zg::ensure_init())
 
+// optional per-kernel HIP-event timing (bench.py's roofline leg); ids are ZG_PROF_*
+void prof_begin(int id, hipStream_t st);
+void prof_end(int id, hipStream_t st);
+struct ProfScope {
+    int id;
+    hipStream_t st;
+    ProfScope(int i, hipStream_t s) : id(i), st(s) { prof_begin(id, st); }
+    ~ProfScope() { prof_end(id, st); }
+};
+
 static inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
 }  // namespace zg

@@ -486,14 +486,21 @@ static int msm_enqueue(zg_bases_s *b, size_t off, size_t n, const uint64_t *d_sc
         ZG_HIP(hipGetLastError());
         return ZG_OK;
     }
+    prof_begin(ZG_PROF_MSM_DIGITS, st);
     ZG_HIP(hipMemsetAsync(b->d_hist, 0, (size_t)p.NK * 4, st));
     ZG_TRY(launch_digits_c(p.c, st, d_scalars, b->d_inf ? b->d_inf + off : nullptr, (uint32_t)n, p.G, b->d_dig, b->d_hist));
+    prof_end(ZG_PROF_MSM_DIGITS, st);
+    prof_begin(ZG_PROF_MSM_SORT, st);
     hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(1024), 0, st, b->d_hist, b->d_starts, p.NK);
     ZG_HIP(hipMemsetAsync(b->d_hist, 0, (size_t)p.NK * 4, st));
     hipLaunchKernelGGL(msm_scatter_kernel, dim3(div_up(n, 256), p.W), dim3(256), 0, st, b->d_dig, (uint32_t)n, p.G, b->n,
                        (uint32_t)off, b->d_starts, b->d_hist, b->d_sorted);
+    prof_end(ZG_PROF_MSM_SORT, st);
+    prof_begin(ZG_PROF_MSM_ACCUMULATE, st);
     hipLaunchKernelGGL(msm_accumulate_kernel, dim3(div_up((size_t)p.NK * p.S, 256)), dim3(256), 0, st, b->d_sorted, b->d_starts,
                        b->d_table, p.NK, p.S, b->d_partial);
+    prof_end(ZG_PROF_MSM_ACCUMULATE, st);
+    prof_begin(ZG_PROF_MSM_REDUCE, st);
     LevelArgs la;
     la.nlev = p.nlev; la.G = p.G; la.c = p.c; la.offtot = p.offtot;
     for (int l = 0; l < p.nlev; l++) {
@@ -510,6 +517,7 @@ static int msm_enqueue(zg_bases_s *b, size_t off, size_t n, const uint64_t *d_sc
     }
     hipLaunchKernelGGL(msm_sum_levels_kernel, dim3(p.G, p.nlev), dim3(256), 0, st, b->d_levA, la, b->d_sumA);
     hipLaunchKernelGGL(msm_final_kernel, dim3(1), dim3(64), 0, st, b->d_sumA, b->d_levS, la, mode, d_rec, d_inf_out);
+    prof_end(ZG_PROF_MSM_REDUCE, st);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }

@@ -159,11 +159,13 @@ static unsigned sc_blocks(size_t half) {
 static int launch_sums(int layout, const uint64_t *t, size_t len, uint64_t *partials, uint64_t *sums, hipStream_t st) {
     size_t half = len / 2;
     unsigned nb = sc_blocks(half);
+    prof_begin(ZG_PROF_SC_SUMS, st);
     if (layout == ZG_SC_HIGH_HALF)
         hipLaunchKernelGGL(sc_sums_kernel<ZG_SC_HIGH_HALF>, dim3(nb), dim3(256), 0, st, t, half, partials);
     else
         hipLaunchKernelGGL(sc_sums_kernel<ZG_SC_LOW_PAIR>, dim3(nb), dim3(256), 0, st, t, half, partials);
     hipLaunchKernelGGL(sc_finish_kernel, dim3(1), dim3(256), 0, st, partials, nb, sums);
+    prof_end(ZG_PROF_SC_SUMS, st);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
@@ -172,11 +174,13 @@ static int launch_fold(int layout, const uint64_t *t, size_t len, const uint64_t
                        uint64_t *sums, hipStream_t st) {
     size_t half = len / 2;
     unsigned nb = sc_blocks(half);
+    prof_begin(ZG_PROF_SC_FOLD, st);
     if (layout == ZG_SC_HIGH_HALF)
         hipLaunchKernelGGL(sc_fold_kernel<ZG_SC_HIGH_HALF>, dim3(nb), dim3(256), 0, st, t, half, d_r, out, partials);
     else
         hipLaunchKernelGGL(sc_fold_kernel<ZG_SC_LOW_PAIR>, dim3(nb), dim3(256), 0, st, t, half, d_r, out, partials);
     hipLaunchKernelGGL(sc_finish_kernel, dim3(1), dim3(256), 0, st, partials, nb, sums);
+    prof_end(ZG_PROF_SC_FOLD, st);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
@@ -193,10 +197,12 @@ static int eq_table_enqueue(const uint64_t *r_host, size_t v, const uint64_t *sc
     ZG_HIP(hipMalloc((void **)&d_hi, (size_t)n_hi * 32));
     if (v) ZG_HIP(hipMemcpyAsync(d_r + 4, r_host, v * 32, hipMemcpyHostToDevice, st));
     if (scale_host) ZG_HIP(hipMemcpyAsync(d_r, scale_host, 32, hipMemcpyHostToDevice, st));
+    prof_begin(ZG_PROF_EQ_TABLE, st);
     hipLaunchKernelGGL(eq_hi_kernel, dim3(div_up(n_hi, 256)), dim3(256), 0, st, d_r + 4, v_hi, scale_host ? d_r : nullptr, d_hi);
     uint32_t hpb = n_hi / 2048 ? n_hi / 2048 : 1;
     hipLaunchKernelGGL(eq_main_kernel, dim3(div_up(n_hi, hpb)), dim3(256), 0, st, d_r + 4 + 4 * (size_t)v_hi, v_lo, d_hi, n_hi, hpb,
                        d_out);
+    prof_end(ZG_PROF_EQ_TABLE, st);
     ZG_HIP(hipGetLastError());
     ZG_HIP(hipStreamSynchronize(st));  // r_host / temporaries are released on return
     (void)hipFree(d_r);
@@ -331,7 +337,9 @@ int zg_fr_spartan_combine_dev(const uint64_t *d_eq, const uint64_t *d_az, const 
     if (n == 0) return ZG_OK;
     unsigned nb = div_up(n, 256);
     if (nb > 4096) nb = 4096;
+    prof_begin(ZG_PROF_COMBINE, pick_stream(stream));
     hipLaunchKernelGGL(spartan_combine_kernel, dim3(nb), dim3(256), 0, pick_stream(stream), d_eq, d_az, d_bz, d_cz, n, d_out);
+    prof_end(ZG_PROF_COMBINE, pick_stream(stream));
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }

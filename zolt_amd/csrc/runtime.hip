@@ -1,6 +1,7 @@
 // runtime.hip — lifecycle, error reporting, raw device memory and the elementwise field
 // kernels of libzolt_gpu.so (C ABI: include/zolt_gpu.h).
 #include <mutex>
+#include <vector>
 
 #include "common.hip.h"
 #include "field.hip.h"
@@ -39,6 +40,26 @@ static int do_init(int device) {
 int ensure_init() {
     if (g_inited) return ZG_OK;
     return do_init(-1);
+}
+
+// ------------------------------------------------------------------ profiling
+struct ProfRec { int id; hipEvent_t e0, e1; };
+static std::vector<ProfRec> g_prof;
+static size_t g_prof_used = 0;
+static bool g_prof_on = false;
+static int g_prof_open[ZG_PROF_NKERNELS];
+
+void prof_begin(int id, hipStream_t st) {
+    if (!g_prof_on || g_prof_used >= g_prof.size()) { g_prof_open[id] = -1; return; }
+    ProfRec &r = g_prof[g_prof_used];
+    r.id = id;
+    g_prof_open[id] = (int)g_prof_used++;
+    (void)hipEventRecord(r.e0, st);
+}
+void prof_end(int id, hipStream_t st) {
+    if (!g_prof_on || g_prof_open[id] < 0) return;
+    (void)hipEventRecord(g_prof[g_prof_open[id]].e1, st);
+    g_prof_open[id] = -1;
 }
 
 // ------------------------------------------------------------------ field op kernel
@@ -119,6 +140,38 @@ int zg_memcpy_d2h(void *dst, const void *src, size_t bytes) {
 int zg_sync(void) {
     ZG_INIT();
     ZG_HIP(hipStreamSynchronize(g_stream));
+    return ZG_OK;
+}
+
+int zg_profile_begin(int max_records) {
+    ZG_INIT();
+    if (max_records < 1) return ZG_ERR_INVALID;
+    while ((int)g_prof.size() < max_records) {
+        ProfRec r;
+        r.id = -1;
+        ZG_HIP(hipEventCreate(&r.e0));
+        ZG_HIP(hipEventCreate(&r.e1));
+        g_prof.push_back(r);
+    }
+    for (int i = 0; i < ZG_PROF_NKERNELS; i++) g_prof_open[i] = -1;
+    g_prof_used = 0;
+    g_prof_on = true;
+    return ZG_OK;
+}
+
+int zg_profile_end(double ms_out[ZG_PROF_NKERNELS], uint64_t count_out[ZG_PROF_NKERNELS]) {
+    ZG_INIT();
+    g_prof_on = false;
+    for (int i = 0; i < ZG_PROF_NKERNELS; i++) { ms_out[i] = 0.0; count_out[i] = 0; }
+    ZG_HIP(hipDeviceSynchronize());
+    for (size_t k = 0; k < g_prof_used; k++) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g_prof[k].e0, g_prof[k].e1) == hipSuccess) {
+            ms_out[g_prof[k].id] += ms;
+            count_out[g_prof[k].id] += 1;
+        }
+    }
+    g_prof_used = 0;
     return ZG_OK;
 }
 

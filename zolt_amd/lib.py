@@ -24,6 +24,7 @@ SC_HIGH_HALF, SC_LOW_PAIR = 0, 1
 SYMBOLS = [
     "zg_init", "zg_shutdown", "zg_last_error", "zg_version", "zg_device_count",
     "zg_dev_alloc", "zg_dev_free", "zg_memcpy_h2d", "zg_memcpy_d2h", "zg_sync",
+    "zg_profile_begin", "zg_profile_end",
     "zg_field_op",
     "zg_g1_bases_upload", "zg_g1_bases_upload_dev", "zg_g1_bases_free", "zg_g1_bases_len",
     "zg_msm_g1", "zg_msm_g1_dev", "zg_msm_g1_dev_async", "zg_msm_g1_batch", "zg_msm_g1_partial_dev",
@@ -101,6 +102,21 @@ def sync():
 def last_error():
     m = _lib.zg_last_error()
     return m.decode() if m else ""
+
+
+PROF_NAMES = ["msm_digits", "msm_sort", "msm_accumulate", "msm_reduce", "eq_table", "sc_fold", "sc_sums", "combine"]
+
+
+def profile_begin(max_records=4096):
+    _chk(_lib.zg_profile_begin(C.c_int(max_records)), "zg_profile_begin")
+
+
+def profile_end():
+    """-> {kernel name: (total ms, launches)} measured with HIP events on the launch stream"""
+    ms = (C.c_double * len(PROF_NAMES))()
+    cnt = (C.c_uint64 * len(PROF_NAMES))()
+    _chk(_lib.zg_profile_end(ms, cnt), "zg_profile_end")
+    return {n: (float(ms[i]), int(cnt[i])) for i, n in enumerate(PROF_NAMES)}
 
 
 # ---- field vectors
