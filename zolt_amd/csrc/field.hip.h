@@ -29,6 +29,8 @@ struct FrParams {
                                    0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
     static constexpr u32 R2[8] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u,
                                   0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};
+    static constexpr u32 R3[8] = {0xb4bf0040u, 0x5e94d8e1u, 0x1cfbb6b8u, 0x2a489cbeu,
+                                  0xa19fcfedu, 0x893cc664u, 0x7fcc657cu, 0x0cf8594bu};  // 2^768 mod MOD
     static constexpr u32 INV = 0xefffffffu;  // -MOD^-1 mod 2^32 (low word of BN254_INV)
 };
 struct FpParams {
@@ -38,6 +40,8 @@ struct FpParams {
                                    0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
     static constexpr u32 R2[8] = {0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u,
                                   0x0a417ff6u, 0x47ab1effu, 0xcab8351fu, 0x06d89f71u};
+    static constexpr u32 R3[8] = {0xda1530dfu, 0xb1cd6dafu, 0xa7283db6u, 0x62f210e6u,
+                                  0x0ada0afbu, 0xef7f0b0cu, 0x2d592544u, 0x20fd6e90u};  // 2^768 mod MOD
     static constexpr u32 INV = 0xe4866389u;  // low word of BN254_FP_INV
 };
 
@@ -226,6 +230,76 @@ ZG_DEV Fe<P> fe_inv(const Fe<P> &a) {
         }
     }
     return a.is_zero() ? Fe<P>::zero() : result;
+}
+
+// ---- fast inversion: binary extended Euclid on the raw limbs, then one Montgomery fix-up.
+// The reference inverts by Fermat (381 multiplications, fe_inv above). A GPU lane runs one
+// multiplication in ~1 us when it is alone on its SIMD, so the inversion that ends every MSM
+// (toAffine) would cost ~0.4 ms; the shift/subtract Euclid below needs ~1/6 of the instructions.
+// Same value: for Montgomery input aR it returns a^-1 R = (aR)^-1 * R^2 = montmul((aR)^-1, R^3).
+template <class P>
+ZG_DEV bool limbs_ge(const u32 *a, const u32 *b) {  // a >= b
+    bool ge = true;
+#pragma unroll
+    for (int i = 0; i < 8; i++) ge = (a[i] > b[i]) || (a[i] == b[i] && ge);
+    return ge;
+}
+ZG_DEV void limbs_sub(u32 *a, const u32 *b) {  // a -= b (no borrow out expected)
+    u32 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u64 s = (u64)a[i] - b[i] - borrow;
+        a[i] = (u32)s;
+        borrow = (u32)(s >> 32) & 1u;
+    }
+}
+// x = x/2 mod MOD for x in [0, MOD): if odd add MOD first (x + MOD < 2^255 fits)
+template <class P>
+ZG_DEV void limbs_half_mod(u32 *x) {
+    u32 mask = 0u - (x[0] & 1u);
+    u32 carry = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u64 t = (u64)x[i] + (P::MOD[i] & mask) + carry;
+        x[i] = (u32)t;
+        carry = (u32)(t >> 32);
+    }
+#pragma unroll
+    for (int i = 0; i < 7; i++) x[i] = (x[i] >> 1) | (x[i + 1] << 31);
+    x[7] = (x[7] >> 1) | (carry << 31);
+}
+ZG_DEV void limbs_shr1(u32 *x) {
+#pragma unroll
+    for (int i = 0; i < 7; i++) x[i] = (x[i] >> 1) | (x[i + 1] << 31);
+    x[7] >>= 1;
+}
+ZG_DEV bool limbs_is_one(const u32 *x) {
+    u32 o = x[0] ^ 1u;
+#pragma unroll
+    for (int i = 1; i < 8; i++) o |= x[i];
+    return o == 0;
+}
+
+template <class P>
+ZG_DEV Fe<P> fe_inv_fast(const Fe<P> &a) {
+    if (a.is_zero()) return Fe<P>::zero();
+    u32 u[8], v[8];
+    Fe<P> x1 = Fe<P>::zero(), x2 = Fe<P>::zero();
+    x1.l[0] = 1;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { u[i] = a.l[i]; v[i] = P::MOD[i]; }
+    // invariants: x1*a == u, x2*a == v (mod MOD); gcd(a, MOD) = 1
+    while (!limbs_is_one(u) && !limbs_is_one(v)) {
+        while (!(u[0] & 1u)) { limbs_shr1(u); limbs_half_mod<P>(x1.l); }
+        while (!(v[0] & 1u)) { limbs_shr1(v); limbs_half_mod<P>(x2.l); }
+        if (limbs_ge<P>(u, v)) { limbs_sub(u, v); x1 = fe_sub(x1, x2); }
+        else { limbs_sub(v, u); x2 = fe_sub(x2, x1); }
+    }
+    Fe<P> x = limbs_is_one(u) ? x1 : x2;
+    Fe<P> r3;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r3.l[i] = P::R3[i];
+    return fe_mul(x, r3);
 }
 
 typedef Fe<FrParams> Fr;

@@ -13,8 +13,12 @@
 //   msm_scan / msm_scatter  counting sort of the n*W (key, point-ref) pairs by key
 //   msm_accumulate          S threads per bucket walk the sorted refs: gather the 64-byte
 //                           affine point, complete mixed add into an XYZZ accumulator
-//   msm_reduce_level*       sum_k k*B_k by chunked running sums, recursively on the chunk sums
-//   msm_sum_levels / msm_final   tree sums, Horner over levels/groups, one inversion -> affine
+//                           (S lanes per bucket, then a segmented wave shuffle reduction)
+//   msm_bitsum              sum_k k*B_k = sum_b 2^b * T_b,  T_b = sum of the buckets whose index has
+//                           bit b set: c plain tree sums (log depth) instead of the reference's
+//                           serial running sum (a lone GPU lane needs ~10 us per point add)
+//   msm_final               b doublings of T_b in parallel lanes, tree sum, window Horner if G > 1,
+//                           one binary-Euclid inversion -> affine
 //
 // Bucket sums are order-independent group sums and the final affine coordinates are
 // canonical field values, so the 64-byte result is bit-identical to the reference's
@@ -27,7 +31,6 @@
 
 namespace zg {
 
-static constexpr int MAX_LEVELS = 8;
 static constexpr int MAX_GROUPS = 64;
 
 struct MsmPlan {
@@ -38,19 +41,7 @@ struct MsmPlan {
     int S;         // accumulate threads (slices) per bucket
     uint32_t NB;   // buckets per group = 2^(c-1)
     uint32_t NK;   // total buckets = G * NB
-    int nlev;      // reduce levels
-    int q[MAX_LEVELS];          // chunk size per level (power of two)
-    uint32_t m[MAX_LEVELS + 1]; // elements per group entering level l (m[0] = NB, m[nlev] = 1)
-    uint32_t off[MAX_LEVELS];   // offset (elements, per group block of size offtot) of level l's outputs
-    uint32_t offtot;            // sum of m[1..nlev]
-};
-
-struct LevelArgs {
-    int nlev, G, c;
-    int logq[MAX_LEVELS];
-    uint32_t cnt[MAX_LEVELS];  // m[l+1]
-    uint32_t off[MAX_LEVELS];
-    uint32_t offtot;
+    int PB;        // bit-sum partial blocks per (group, bit)
 };
 
 }  // namespace zg
@@ -62,9 +53,9 @@ struct zg_bases_s {
     uint8_t *d_inf = nullptr;    // n B or null
     uint64_t *d_scal = nullptr;  // staging for host scalars, n * 32 B
     uint32_t *d_dig = nullptr, *d_sorted = nullptr, *d_hist = nullptr, *d_starts = nullptr;
-    char *d_partial = nullptr;  // NK * S * 128 B
-    char *d_levA = nullptr, *d_levS = nullptr;  // G * offtot * 128 B each
-    char *d_sumA = nullptr;     // G * nlev * 128 B
+    char *d_partial = nullptr;  // NK * 128 B: bucket sums
+    char *d_bits = nullptr;     // G * c * PB * 128 B: per-bit partial sums
+    char *d_rg = nullptr;       // G * 128 B: per-group results
     uint64_t *d_out = nullptr;  // 16 x u64: result record + flag
     uint64_t *h_out = nullptr;  // pinned mirror
     std::mutex mu;
@@ -161,17 +152,31 @@ __global__ void __launch_bounds__(256) msm_scatter_kernel(const uint32_t *dig, u
     sorted[pos] = (e & 0x80000000u) | ref;
 }
 
+ZG_DEV XYZZ xyzz_shfl_down(const XYZZ &v, int delta) {
+    XYZZ r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        r.x.l[i] = __shfl_down(v.x.l[i], delta, 64);
+        r.y.l[i] = __shfl_down(v.y.l[i], delta, 64);
+        r.zz.l[i] = __shfl_down(v.zz.l[i], delta, 64);
+        r.zzz.l[i] = __shfl_down(v.zzz.l[i], delta, 64);
+    }
+    return r;
+}
+
 // Bucket accumulation: the reference's inner loop buckets[idx] = buckets[idx].addAffine(base)
-// (msm/mod.zig:406-418). S threads share one bucket's list; each produces a partial.
+// (msm/mod.zig:406-418). S adjacent lanes share one bucket's list (S | 64); their partial sums
+// are combined by a segmented shuffle tree and lane 0 of the segment stores the bucket.
 __global__ void __launch_bounds__(256) msm_accumulate_kernel(const uint32_t *sorted, const uint32_t *starts, const char *table,
-                                                             uint32_t NK, int S, char *partial) {
+                                                             uint32_t NK, int S, char *buckets) {
     uint32_t t = blockIdx.x * 256 + threadIdx.x;
     uint32_t key = t / (uint32_t)S, s = t % (uint32_t)S;
-    if (key >= NK) return;
-    uint32_t b0 = starts[key], b1 = starts[key + 1];
-    uint32_t len = b1 - b0;
-    uint32_t a = b0 + (uint32_t)(((uint64_t)len * s) / (uint32_t)S);
-    uint32_t b = b0 + (uint32_t)(((uint64_t)len * (s + 1)) / (uint32_t)S);
+    uint32_t a = 0, b = 0;
+    if (key < NK) {
+        uint32_t b0 = starts[key], len = starts[key + 1] - b0;
+        a = b0 + (uint32_t)(((uint64_t)len * s) / (uint32_t)S);
+        b = b0 + (uint32_t)(((uint64_t)len * (s + 1)) / (uint32_t)S);
+    }
     XYZZ acc = XYZZ::identity();
     if (a < b) {
         uint32_t e = sorted[a];
@@ -191,82 +196,51 @@ __global__ void __launch_bounds__(256) msm_accumulate_kernel(const uint32_t *sor
             cneg = nneg;
         }
     }
-    xyzz_store(partial + 128 * (size_t)t, acc);
-}
-
-// One level of the bucket reduction sum_{x=0}^{m-1} x*E_x  (msm/mod.zig:423-432 is the serial
-// running-sum form). Thread j owns chunk [j*q, (j+1)*q):  A_j = sum_i i*E_{jq+i},  S_j = sum_i E_{jq+i};
-// then  W(E) = sum_j A_j + q*W(S).  `slices` partials are summed per input element (level 0).
-__global__ void __launch_bounds__(64) msm_reduce_level_kernel(const char *in, int slices, uint32_t m_in, size_t in_group_stride,
-                                                              int q, uint32_t m_out, int G, char *outA, char *outS,
-                                                              size_t out_group_stride) {
-    uint32_t t = blockIdx.x * 64 + threadIdx.x;
-    if (t >= (uint32_t)G * m_out) return;
-    uint32_t g = t / m_out, j = t % m_out;
-    const char *base = in + 128 * ((size_t)g * in_group_stride + (size_t)j * q * slices);
-    XYZZ run = XYZZ::identity(), acc = XYZZ::identity();
-    for (int i = q - 1; i >= 0; i--) {
-        XYZZ e = xyzz_load(base + 128 * (size_t)i * slices);
-        for (int s = 1; s < slices; s++) e = xyzz_add(e, xyzz_load(base + 128 * ((size_t)i * slices + s)));
-        run = xyzz_add(run, e);
-        if (i > 0) acc = xyzz_add(acc, run);
+    for (int d = 1; d < S; d <<= 1) {
+        XYZZ o = xyzz_shfl_down(acc, d);
+        if ((s & (uint32_t)(2 * d - 1)) == 0) acc = xyzz_add(acc, o);
     }
-    (void)m_in;
-    xyzz_store(outA + 128 * ((size_t)g * out_group_stride + j), acc);
-    xyzz_store(outS + 128 * ((size_t)g * out_group_stride + j), run);
+    if (key < NK && s == 0) xyzz_store(buckets + 128 * (size_t)key, acc);
 }
 
-// block (g, l): plain sum of level l's A outputs of group g
-__global__ void __launch_bounds__(256) msm_sum_levels_kernel(const char *levA, LevelArgs la, char *sumA) {
-    __shared__ uint4 sh[256 * 8];
-    uint32_t g = blockIdx.x, l = blockIdx.y, tid = threadIdx.x;
-    const char *A = levA + 128 * ((size_t)g * la.offtot + la.off[l]);
-    XYZZ acc = XYZZ::identity();
-    for (uint32_t k = tid; k < la.cnt[l]; k += 256) acc = xyzz_add(acc, xyzz_load(A + 128 * (size_t)k));
+// block-wide XYZZ sum through LDS (256 threads); result returned to thread 0
+__device__ __forceinline__ XYZZ block_sum_xyzz(XYZZ acc, uint4 *sh) {
+    uint32_t tid = threadIdx.x;
     xyzz_store(&sh[tid * 8], acc);
     __syncthreads();
     for (uint32_t o = 128; o > 0; o >>= 1) {
-        if (tid < o && tid + o < 256) {
+        if (tid < o) {
             XYZZ x = xyzz_load(&sh[tid * 8]), y = xyzz_load(&sh[(tid + o) * 8]);
             xyzz_store(&sh[tid * 8], xyzz_add(x, y));
         }
         __syncthreads();
     }
-    if (tid == 0) xyzz_store(sumA + 128 * ((size_t)g * la.nlev + l), xyzz_load(&sh[0]));
+    return xyzz_load(&sh[0]);
 }
 
-// Horner over levels (per group) and over groups (window combine, msm/mod.zig:393-398,434),
-// then toAffine (:178-189). mode 0: affine xy[8] + inf flag; mode 1: the reference's Jacobian
-// record fromAffine(result) = (x,y,1) / (1,1,0) as ParallelMSM's threadWorker stores (:663-664).
-__global__ void __launch_bounds__(64) msm_final_kernel(const char *sumA, const char *levS, LevelArgs la, int mode, uint64_t *out_rec,
-                                                       uint8_t *out_inf) {
-    __shared__ uint4 sh[MAX_GROUPS * 8];
-    uint32_t g = threadIdx.x;
-    if (g < (uint32_t)la.G) {
-        const char *sa = sumA + 128 * (size_t)g * la.nlev;
-        XYZZ acc = xyzz_load(sa + 128 * (size_t)(la.nlev - 1));
-        for (int l = la.nlev - 2; l >= 0; l--) {
-            for (int k = 0; k < la.logq[l]; k++) acc = xyzz_dbl(acc);
-            acc = xyzz_add(acc, xyzz_load(sa + 128 * (size_t)l));
-        }
-        // bucket index x holds digit magnitude x+1:  sum (x+1)*E_x = W(E) + T(E);  T = last level's single S
-        XYZZ T = xyzz_load(levS + 128 * ((size_t)g * la.offtot + la.off[la.nlev - 1]));
-        acc = xyzz_add(acc, T);
-        xyzz_store(&sh[g * 8], acc);
+// Bucket reduction, step 1. The reference computes sum_k k*B_k with a serial running sum
+// (msm/mod.zig:423-432). Here  sum_k k*B_k = sum_b 2^b * T_b  with  T_b = sum_{k: bit b of k set} B_k;
+// block (x, b, g) tree-sums a slice of T_b of group g. Bucket index idx holds digit magnitude k = idx+1.
+__global__ void __launch_bounds__(256) msm_bitsum_kernel(const char *buckets, uint32_t NB, int c, char *out) {
+    __shared__ uint4 sh[256 * 8];
+    uint32_t b = blockIdx.y, g = blockIdx.z, PB = gridDim.x;
+    uint32_t total = (b == (uint32_t)(c - 1)) ? 1u : NB / 2;
+    XYZZ acc = XYZZ::identity();
+    for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < total; j += PB * 256) {
+        uint32_t k = (b == (uint32_t)(c - 1)) ? NB : ((((j >> b) << 1) | 1u) << b) | (j & ((1u << b) - 1u));
+        acc = xyzz_add(acc, xyzz_load(buckets + 128 * ((size_t)g * NB + (k - 1))));
     }
-    __syncthreads();
-    if (g != 0) return;
-    XYZZ acc = xyzz_load(&sh[(la.G - 1) * 8]);
-    for (int gg = la.G - 2; gg >= 0; gg--) {
-        for (int k = 0; k < la.c; k++) acc = xyzz_dbl(acc);
-        acc = xyzz_add(acc, xyzz_load(&sh[gg * 8]));
-    }
+    XYZZ r = block_sum_xyzz(acc, sh);
+    if (threadIdx.x == 0) xyzz_store(out + 128 * (((size_t)g * c + b) * PB + blockIdx.x), r);
+}
+
+ZG_DEV void write_result(const XYZZ &acc, int mode, uint64_t *out_rec, uint8_t *out_inf) {
     Affine r;
     bool inf = xyzz_to_affine(acc, r);
-    if (mode == 0) {
+    if (mode == 0) {  // affine xy[8] + inf flag (AffinePoint, msm/mod.zig:15-30)
         affine_store(out_rec, r);
         *out_inf = inf ? 1 : 0;
-    } else {
+    } else {  // ParallelMSM's threadWorker record fromAffine(result) = (x,y,1) / (1,1,0) (msm/mod.zig:663-664)
         Fp one = Fp::one();
         if (inf) {
             fe_store(out_rec, one); fe_store(out_rec + 4, one); fe_store(out_rec + 8, Fp::zero());
@@ -274,6 +248,48 @@ __global__ void __launch_bounds__(64) msm_final_kernel(const char *sumA, const c
             fe_store(out_rec, r.x); fe_store(out_rec + 4, r.y); fe_store(out_rec + 8, one);
         }
     }
+}
+
+// Bucket reduction, step 2 (block g): lane (b, j) loads partial j of T_b; 16-lane shuffle tree over j;
+// lane (b, 0) doubles b times; LDS tree over b  ->  R_g = sum_k k*B_k of group g.
+// With a single group (full precompute) thread 0 goes straight on to toAffine (msm/mod.zig:178-189).
+__global__ void __launch_bounds__(256) msm_final_kernel(const char *bits, int c, int PB, int G, char *rg, int mode, uint64_t *out_rec,
+                                                       uint8_t *out_inf) {
+    __shared__ uint4 sh[16 * 8];
+    uint32_t tid = threadIdx.x, g = blockIdx.x;
+    uint32_t b = tid / 16, j = tid % 16;
+    XYZZ v = XYZZ::identity();
+    if (b < (uint32_t)c && j < (uint32_t)PB) v = xyzz_load(bits + 128 * (((size_t)g * c + b) * PB + j));
+    for (int d = 1; d < 16; d <<= 1) {
+        XYZZ o = xyzz_shfl_down(v, d);
+        if ((j & (uint32_t)(2 * d - 1)) == 0) v = xyzz_add(v, o);
+    }
+    if (j == 0) {
+        for (uint32_t i = 0; i < b; i++) v = xyzz_dbl(v);
+        xyzz_store(&sh[b * 8], v);
+    }
+    __syncthreads();
+    for (uint32_t o = 8; o > 0; o >>= 1) {
+        if (tid < o) {
+            XYZZ x = xyzz_load(&sh[tid * 8]), y = xyzz_load(&sh[(tid + o) * 8]);
+            xyzz_store(&sh[tid * 8], xyzz_add(x, y));
+        }
+        __syncthreads();
+    }
+    if (tid != 0) return;
+    XYZZ r = xyzz_load(&sh[0]);
+    if (G == 1) write_result(r, mode, out_rec, out_inf);
+    else xyzz_store(rg + 128 * (size_t)g, r);
+}
+
+// window combine for G > 1 (msm/mod.zig:393-398,434): Horner from the top group with c doublings per step
+__global__ void msm_groups_kernel(const char *rg, int G, int c, int mode, uint64_t *out_rec, uint8_t *out_inf) {
+    XYZZ acc = xyzz_load(rg + 128 * (size_t)(G - 1));
+    for (int g = G - 2; g >= 0; g--) {
+        for (int k = 0; k < c; k++) acc = xyzz_dbl(acc);
+        acc = xyzz_add(acc, xyzz_load(rg + 128 * (size_t)g));
+    }
+    write_result(acc, mode, out_rec, out_inf);
 }
 
 __global__ void msm_identity_kernel(int mode, uint64_t *out_rec, uint8_t *out_inf) {
@@ -368,32 +384,22 @@ static int make_plan(size_t n, const zg_msm_config *cfg, MsmPlan &p) {
     p.NK = p.NB * (uint32_t)p.G;
     // slices per bucket: aim for ~2^18-2^19 accumulate threads
     int S = 1;
-    while ((uint64_t)p.NK * S * 2 <= (1u << 19) && S < 64) S *= 2;
+    while ((uint64_t)p.NK * S * 2 <= (1u << 18) && S < 64) S *= 2;
     p.S = env_int("ZG_MSM_SLICES", S);
-    // reduce levels
-    int q0 = env_int("ZG_MSM_REDUCE_Q", 8);
-    p.nlev = 0;
-    p.m[0] = p.NB;
-    p.offtot = 0;
-    while (p.m[p.nlev] > 1) {
-        uint32_t q = (uint32_t)q0 < p.m[p.nlev] ? (uint32_t)q0 : p.m[p.nlev];
-        p.q[p.nlev] = (int)q;
-        p.m[p.nlev + 1] = p.m[p.nlev] / q;
-        p.off[p.nlev] = p.offtot;
-        p.offtot += p.m[p.nlev + 1];
-        p.nlev++;
-    }
-    if (p.nlev == 0) {  // NB == 1 (c = 1) is excluded by c >= 2
-        set_error("msm: internal plan error");
+    if (p.S < 1 || p.S > 64 || (p.S & (p.S - 1))) {
+        set_error("msm: slices per bucket must be a power of two <= 64");
         return ZG_ERR_INVALID;
     }
+    // bit-sum partial blocks: ~4 buckets per thread, at most 16 (the final kernel reduces 16 lanes per bit)
+    int pb = (int)(p.NB / 2 / (256 * 4));
+    p.PB = pb < 1 ? 1 : (pb > 16 ? 16 : pb);
     return ZG_OK;
 }
 
 static void free_bases(zg_bases_s *b) {
     if (!b) return;
     void *ptrs[] = {b->d_table, b->d_inf, b->d_scal, b->d_dig, b->d_sorted, b->d_hist, b->d_starts,
-                    b->d_partial, b->d_levA, b->d_levS, b->d_sumA, b->d_out};
+                    b->d_partial, b->d_bits, b->d_rg, b->d_out};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (b->h_out) (void)hipHostFree(b->h_out);
@@ -435,10 +441,9 @@ static int bases_create(const uint64_t *d_xy, const uint8_t *d_inf_in, size_t n,
     ZG_ALLOC(b->d_sorted, (size_t)p.W * n * 4);
     ZG_ALLOC(b->d_hist, (size_t)p.NK * 4);
     ZG_ALLOC(b->d_starts, ((size_t)p.NK + 1) * 4);
-    ZG_ALLOC(b->d_partial, (size_t)p.NK * p.S * 128);
-    ZG_ALLOC(b->d_levA, (size_t)p.G * p.offtot * 128);
-    ZG_ALLOC(b->d_levS, (size_t)p.G * p.offtot * 128);
-    ZG_ALLOC(b->d_sumA, (size_t)p.G * p.nlev * 128);
+    ZG_ALLOC(b->d_partial, (size_t)p.NK * 128);
+    ZG_ALLOC(b->d_bits, (size_t)p.G * p.c * p.PB * 128);
+    ZG_ALLOC(b->d_rg, (size_t)p.G * 128);
     ZG_ALLOC(b->d_out, 16 * 8);
     if (hipHostMalloc((void **)&b->h_out, 16 * 8) != hipSuccess) {
         set_error("hipHostMalloc failed");
@@ -501,22 +506,9 @@ static int msm_enqueue(zg_bases_s *b, size_t off, size_t n, const uint64_t *d_sc
                        b->d_table, p.NK, p.S, b->d_partial);
     prof_end(ZG_PROF_MSM_ACCUMULATE, st);
     prof_begin(ZG_PROF_MSM_REDUCE, st);
-    LevelArgs la;
-    la.nlev = p.nlev; la.G = p.G; la.c = p.c; la.offtot = p.offtot;
-    for (int l = 0; l < p.nlev; l++) {
-        la.logq[l] = ilog2((uint32_t)p.q[l]);
-        la.cnt[l] = p.m[l + 1];
-        la.off[l] = p.off[l];
-        const char *in = l == 0 ? b->d_partial : b->d_levS + 128 * (size_t)p.off[l - 1];
-        int slices = l == 0 ? p.S : 1;
-        size_t in_stride = l == 0 ? (size_t)p.NB * p.S : p.offtot;
-        uint32_t threads = (uint32_t)p.G * p.m[l + 1];
-        hipLaunchKernelGGL(msm_reduce_level_kernel, dim3(div_up(threads, 64)), dim3(64), 0, st, in, slices, p.m[l], in_stride, p.q[l],
-                           p.m[l + 1], p.G, b->d_levA + 128 * (size_t)p.off[l], b->d_levS + 128 * (size_t)p.off[l],
-                           (size_t)p.offtot);
-    }
-    hipLaunchKernelGGL(msm_sum_levels_kernel, dim3(p.G, p.nlev), dim3(256), 0, st, b->d_levA, la, b->d_sumA);
-    hipLaunchKernelGGL(msm_final_kernel, dim3(1), dim3(64), 0, st, b->d_sumA, b->d_levS, la, mode, d_rec, d_inf_out);
+    hipLaunchKernelGGL(msm_bitsum_kernel, dim3(p.PB, p.c, p.G), dim3(256), 0, st, b->d_partial, p.NB, p.c, b->d_bits);
+    hipLaunchKernelGGL(msm_final_kernel, dim3(p.G), dim3(256), 0, st, b->d_bits, p.c, p.PB, p.G, b->d_rg, mode, d_rec, d_inf_out);
+    if (p.G > 1) hipLaunchKernelGGL(msm_groups_kernel, dim3(1), dim3(1), 0, st, b->d_rg, p.G, p.c, mode, d_rec, d_inf_out);
     prof_end(ZG_PROF_MSM_REDUCE, st);
     ZG_HIP(hipGetLastError());
     return ZG_OK;

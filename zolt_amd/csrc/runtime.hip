@@ -79,6 +79,7 @@ __global__ void __launch_bounds__(256) field_op_kernel(int op, const uint64_t *a
             case ZG_OP_SQR: r = fe_sqr(x); break;
             case ZG_OP_INV: r = fe_inv(x); break;
             case ZG_OP_FROM_MONT: r = fe_from_mont(x); break;
+            case ZG_OP_INV_FAST: r = fe_inv_fast(x); break;
             default: r = fe_to_mont(x); break;
         }
         fe_store(out + 4 * i, r);
@@ -177,7 +178,7 @@ int zg_profile_end(double ms_out[ZG_PROF_NKERNELS], uint64_t count_out[ZG_PROF_N
 
 int zg_field_op(int field, int op, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n) {
     ZG_INIT();
-    if (op < 0 || op > ZG_OP_TO_MONT || (field != ZG_FIELD_FR && field != ZG_FIELD_FP) || !a || !out ||
+    if (op < 0 || op > ZG_OP_INV_FAST || (field != ZG_FIELD_FR && field != ZG_FIELD_FP) || !a || !out ||
         (op <= ZG_OP_SUB && !b)) {
         set_error("zg_field_op: invalid argument");
         return ZG_ERR_INVALID;
