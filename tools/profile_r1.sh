@@ -1,0 +1,21 @@
+#!/bin/bash
+# rocprofv3 recipe for the round's committed profiles (run on the GPU box from the repo root):
+#   bash tools/profile_r1.sh <tag> [bench args]
+# pass 1: kernel trace + stats; passes 2..4: PMC counters alone (never combined with tracing domains).
+TAG=${1:-r1}
+shift
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/prof_$TAG
+export TMPDIR=/tmp
+mkdir -p $OUT
+cd /tmp
+BENCH="python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra $@"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH > $OUT/pmc_write.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $OUT/pmc_sq -- $BENCH > $OUT/pmc_sq.log 2>&1
+cd $OUT
+python3 $ROOT/tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
+find $OUT -name "*.csv" -size +2M -delete
+ls -R $OUT | head -50
+tail -3 $OUT/trace.log
