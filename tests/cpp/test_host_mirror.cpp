@@ -1,0 +1,146 @@
+// test_host_mirror.cpp — the reference's inline tests for the hot path, restated against the C++ host
+// mirror (zolt_amd/host/zolt_host.hpp) over libzolt_gpu.so. Each TEST names the Zig test it follows.
+// Runs on the GPU box (tests/test_gpu_cpp_host.py); exit code 0 = all passed.
+#include <cstdio>
+#include <cstdlib>
+
+#include "../../zolt_amd/host/zolt_host.hpp"
+
+using namespace zolt;
+
+static int g_failed = 0, g_run = 0;
+#define EXPECT(cond)                                                                  \
+    do {                                                                              \
+        if (!(cond)) { std::printf("  FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond); g_failed++; } \
+    } while (0)
+#define TEST(name) static void name(); static struct Reg_##name { Reg_##name() { tests().push_back({#name, name}); } } reg_##name; static void name()
+struct T { const char *n; void (*f)(); };
+static std::vector<T> &tests() { static std::vector<T> v; return v; }
+
+static std::vector<AffinePoint> generator_multiples(size_t n) {  // points (i+1)G as in src/bench.zig:261-268
+    std::vector<AffinePoint> pts;
+    for (size_t i = 0; i < n; i++) pts.push_back(MSM::scalarMul(AffinePoint::generator(), Fr::fromU64(i + 1)));
+    return pts;
+}
+
+// src/msm/mod.zig:802-825 "scalar mul by zero/one"
+TEST(scalar_mul_by_zero_and_one) {
+    AffinePoint g = AffinePoint::generator();
+    EXPECT(MSM::scalarMul(g, Fr::zero()).isIdentity());
+    EXPECT(MSM::scalarMul(g, Fr::one()).eql(g));
+    EXPECT(MSM::scalarMul(AffinePoint::identity(), Fr::fromU64(5)).isIdentity());
+}
+
+// src/msm/mod.zig:875-891 "msm with zero scalars", :938-947 "parallel msm empty"
+TEST(msm_zero_scalars_and_empty) {
+    auto pts = generator_multiples(10);
+    std::vector<Fr> zeros(10, Fr::zero());
+    EXPECT(MSM::compute(pts, zeros).isIdentity());
+    EXPECT(MSM::compute({}, {}).isIdentity());
+    EXPECT(ParallelMSM::compute(pts, zeros, 4).isIdentity());
+}
+
+// src/integration_tests.zig:145-161 "msm scalar multiply consistency": 2*P == P + P
+TEST(msm_scalar_multiply_consistency) {
+    AffinePoint g = AffinePoint::generator();
+    AffinePoint twice = MSM::scalarMul(g, Fr::fromU64(2));
+    AffinePoint sum = MSM::compute({g, g}, {Fr::one(), Fr::one()});
+    EXPECT(twice.eql(sum) && !twice.isIdentity());
+    // identity bases are skipped (src/msm/mod.zig:407; src/integration_tests.zig:124-143)
+    AffinePoint r = MSM::compute({AffinePoint::identity(), g, AffinePoint::identity()}, {Fr::fromU64(5), Fr::fromU64(3), Fr::fromU64(7)});
+    EXPECT(r.eql(MSM::scalarMul(g, Fr::fromU64(3))));
+}
+
+// src/bench.zig:243-287 benchMSM inputs: points (i+1)G, scalars 7i+13, n = 16, 64, 256 — closed form
+TEST(bench_msm_family_closed_form) {
+    for (size_t n : {16u, 64u, 256u}) {
+        auto pts = generator_multiples(n);
+        std::vector<Fr> sc;
+        uint64_t k = 0;
+        for (size_t i = 0; i < n; i++) { sc.push_back(Fr::fromU64(7 * i + 13)); k += (7 * i + 13) * (i + 1); }
+        AffinePoint got = MSM::compute(pts, sc);
+        EXPECT(got.eql(MSM::scalarMul(AffinePoint::generator(), Fr::fromU64(k))));
+    }
+}
+
+// src/poly/commitment/mod.zig:1392-1420 "hyperkzg batch commit", :239-243 empty -> identity
+TEST(hyperkzg_batch_commit) {
+    auto params = HyperKZG::setup(16);
+    EXPECT(params.powers_of_tau_g1[0].eql(AffinePoint::generator()));
+    std::vector<std::vector<Fr>> polys(3);
+    for (int p = 0; p < 3; p++)
+        for (int i = 0; i < 16; i++) polys[p].push_back(Fr::fromU64((uint64_t)(p * 100 + i * 7 + 1)));
+    auto batch = HyperKZG::batchCommit(params, polys);
+    for (int p = 0; p < 3; p++) EXPECT(batch[p].eql(HyperKZG::commit(params, polys[p])));
+    EXPECT(HyperKZG::commit(params, {}).point.isIdentity());
+    // commit(e_1) = tau*G = powers[1]
+    std::vector<Fr> e1(16, Fr::zero());
+    e1[1] = Fr::one();
+    EXPECT(HyperKZG::commit(params, e1).point.eql(params.powers_of_tau_g1[1]));
+}
+
+// src/poly/mod.zig:816-888 "dense polynomial bindLow"
+TEST(dense_polynomial_bind_low) {
+    DensePolynomial p({Fr::fromU64(1), Fr::fromU64(2), Fr::fromU64(3), Fr::fromU64(4)});
+    p.bindLow(Fr::fromU64(3));
+    EXPECT(p.num_vars == 1 && p.evaluations[0].eql(Fr::fromU64(4)) && p.evaluations[1].eql(Fr::fromU64(6)));
+    std::vector<Fr> e;
+    for (int i = 1; i <= 8; i++) e.push_back(Fr::fromU64(10 * i));
+    DensePolynomial q(e);
+    q.bindLow(Fr::fromU64(5));
+    uint64_t want[4] = {60, 80, 100, 120};
+    for (int i = 0; i < 4; i++) EXPECT(q.evaluations[i].eql(Fr::fromU64(want[i])));
+}
+
+// src/poly/mod.zig:689-753 "EqPolynomial partition of unity"
+TEST(eq_polynomial_partition_of_unity) {
+    std::vector<Fr> r = {Fr::fromU64(12345), Fr::fromU64(67890), Fr::fromU64(0x123456789abcdefULL)};
+    auto ev = EqPolynomial(r).evals();
+    EXPECT(ev.size() == 8);
+    Fr sum = Fr::zero();
+    for (auto &x : ev) sum = sum.add(x);
+    EXPECT(sum.eql(Fr::one()));
+    // index 0 = prod (1 - r_i); index 2^n - 1 = prod r_i; MSB <-> r[0]
+    Fr one = Fr::one();
+    EXPECT(ev[0].eql(one.sub(r[0]).mul(one.sub(r[1])).mul(one.sub(r[2]))));
+    EXPECT(ev[7].eql(r[0].mul(r[1]).mul(r[2])));
+    EXPECT(ev[4].eql(r[0].mul(one.sub(r[1])).mul(one.sub(r[2]))));
+}
+
+// src/subprotocols/mod.zig:366-439 "sumcheck prover round generation"
+TEST(sumcheck_prover_round_generation) {
+    DensePolynomial poly({Fr::fromU64(1), Fr::fromU64(2), Fr::fromU64(3), Fr::fromU64(4)});
+    Sumcheck::Prover prover(poly);
+    auto round1 = prover.nextRound();
+    EXPECT(round1.poly.evaluate(Fr::zero()).eql(Fr::fromU64(3)));
+    EXPECT(round1.poly.evaluate(Fr::one()).eql(Fr::fromU64(7)));
+    Fr r0 = Fr::fromU64(2);
+    prover.receiveChallenge(r0);
+    auto round2 = prover.nextRound();
+    Fr a = round2.poly.evaluate(Fr::zero()), b = round2.poly.evaluate(Fr::one());
+    EXPECT(a.eql(Fr::fromU64(5)) && b.eql(Fr::fromU64(6)));
+    EXPECT(a.add(b).eql(round1.poly.evaluate(r0)));
+}
+
+// src/subprotocols/mod.zig:441-461 "sumcheck complete protocol"
+TEST(sumcheck_complete_protocol) {
+    std::vector<Fr> e;
+    for (int i = 1; i <= 8; i++) e.push_back(Fr::fromU64(i));
+    auto res = runSumcheck(DensePolynomial(e));
+    EXPECT(res.result);
+    EXPECT(res.proof.claim.eql(Fr::fromU64(36)));
+    EXPECT(res.proof.rounds.size() == 3 && res.proof.final_point.size() == 3);
+}
+
+int main() {
+    if (zg_init(0) != ZG_OK) { std::printf("zg_init failed: %s\n", zg_last_error()); return 2; }
+    for (auto &t : tests()) {
+        int before = g_failed;
+        try { t.f(); } catch (const std::exception &e) { std::printf("  EXCEPTION in %s: %s\n", t.n, e.what()); g_failed++; }
+        std::printf("[%s] %s\n", g_failed == before ? " OK " : "FAIL", t.n);
+        g_run++;
+    }
+    std::printf("%d tests, %d failures\n", g_run, g_failed);
+    zg_shutdown();
+    return g_failed ? 1 : 0;
+}

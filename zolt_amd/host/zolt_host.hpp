@@ -1,0 +1,425 @@
+// zolt_host.hpp — C++ host-side mirror of the reference's module API for the hot path, layered
+// on the C ABI (include/zolt_gpu.h). The reference is Zig and no Zig toolchain exists in this
+// image, so this header plays the role the patched Zig modules play in the real integration
+// (INTEGRATION.md): same names, argument meaning and error behaviour as
+//
+//   zolt.msm.{AffinePoint, MSM, BatchMSM, ParallelMSM}          src/msm/mod.zig
+//   zolt.poly.{DensePolynomial, EqPolynomial, UniPoly}          src/poly/mod.zig
+//   zolt.poly.commitment.HyperKZG.{setup, commit, batchCommit}  src/poly/commitment/mod.zig
+//   zolt.subprotocols.{Sumcheck, runSumcheck}                   src/subprotocols/mod.zig
+//
+// All heavy arithmetic runs in libzolt_gpu.so. The host keeps what the Zig host keeps: a few
+// scalar Fr operations per sumcheck round for the toy verifier (the unchanged `field` module's
+// job above the FFI seam) — implemented below with unsigned __int128 CIOS.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/zolt_gpu.h"
+
+namespace zolt {
+
+struct GpuError : std::runtime_error {
+    int code;
+    GpuError(int c, const std::string &where) : std::runtime_error(where + ": " + zg_last_error()), code(c) {}
+};
+inline void check(int rc, const char *where) {
+    if (rc != ZG_OK) throw GpuError(rc, where);
+}
+
+// ---------------------------------------------------------------- host Fr (scalar use only)
+struct Fr {
+    uint64_t limbs[4];
+
+    static constexpr uint64_t MOD[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+    static constexpr uint64_t R[4] = {0xac96341c4ffffffbULL, 0x36fc76959f60cd29ULL, 0x666ea36f7879462eULL, 0x0e0a77c19a07df2fULL};
+    static constexpr uint64_t R2[4] = {0x1bb8e645ae216da7ULL, 0x53fe3ab1e35c59e3ULL, 0x8c49833d53bb8085ULL, 0x0216d0b17f4e44a5ULL};
+    static constexpr uint64_t INV = 0xc2e1f593efffffffULL;
+
+    static Fr zero() { return Fr{{0, 0, 0, 0}}; }
+    static Fr one() { return Fr{{R[0], R[1], R[2], R[3]}}; }
+    bool isZero() const { return (limbs[0] | limbs[1] | limbs[2] | limbs[3]) == 0; }
+    bool eql(const Fr &o) const { return std::memcmp(limbs, o.limbs, 32) == 0; }
+
+    static bool geMod(const uint64_t *a) {
+        for (int i = 3; i >= 0; i--) {
+            if (a[i] < MOD[i]) return false;
+            if (a[i] > MOD[i]) return true;
+        }
+        return true;
+    }
+    static void subMod(uint64_t *a) {
+        unsigned __int128 borrow = 0;
+        for (int i = 0; i < 4; i++) {
+            unsigned __int128 d = (unsigned __int128)a[i] - MOD[i] - borrow;
+            a[i] = (uint64_t)d;
+            borrow = (d >> 64) & 1;
+        }
+    }
+    Fr mul(const Fr &o) const {  // src/field/mod.zig:735-779
+        uint64_t t[5] = {0, 0, 0, 0, 0};
+        for (int i = 0; i < 4; i++) {
+            uint64_t carry = 0;
+            for (int j = 0; j < 4; j++) {
+                unsigned __int128 s = (unsigned __int128)t[j] + (unsigned __int128)limbs[i] * o.limbs[j] + carry;
+                t[j] = (uint64_t)s;
+                carry = (uint64_t)(s >> 64);
+            }
+            t[4] += carry;
+            uint64_t m = t[0] * INV;
+            unsigned __int128 s0 = (unsigned __int128)t[0] + (unsigned __int128)m * MOD[0];
+            carry = (uint64_t)(s0 >> 64);
+            for (int j = 1; j < 4; j++) {
+                unsigned __int128 s = (unsigned __int128)t[j] + (unsigned __int128)m * MOD[j] + carry;
+                t[j - 1] = (uint64_t)s;
+                carry = (uint64_t)(s >> 64);
+            }
+            unsigned __int128 fs = (unsigned __int128)t[4] + carry;
+            t[3] = (uint64_t)fs;
+            t[4] = (uint64_t)(fs >> 64);
+        }
+        Fr r{{t[0], t[1], t[2], t[3]}};
+        if (t[4] != 0 || geMod(r.limbs)) subMod(r.limbs);
+        return r;
+    }
+    Fr add(const Fr &o) const {  // :782-798
+        Fr r;
+        unsigned __int128 carry = 0;
+        for (int i = 0; i < 4; i++) {
+            unsigned __int128 s = (unsigned __int128)limbs[i] + o.limbs[i] + carry;
+            r.limbs[i] = (uint64_t)s;
+            carry = s >> 64;
+        }
+        if (carry || geMod(r.limbs)) subMod(r.limbs);
+        return r;
+    }
+    Fr sub(const Fr &o) const {  // :801-816
+        Fr r;
+        unsigned __int128 borrow = 0;
+        for (int i = 0; i < 4; i++) {
+            unsigned __int128 d = (unsigned __int128)limbs[i] - o.limbs[i] - borrow;
+            r.limbs[i] = (uint64_t)d;
+            borrow = (d >> 64) & 1;
+        }
+        if (borrow) {
+            unsigned __int128 carry = 0;
+            for (int i = 0; i < 4; i++) {
+                unsigned __int128 s = (unsigned __int128)r.limbs[i] + MOD[i] + carry;
+                r.limbs[i] = (uint64_t)s;
+                carry = s >> 64;
+            }
+        }
+        return r;
+    }
+    static Fr fromU64(uint64_t n) {  // :617-622
+        Fr a{{n, 0, 0, 0}}, r2{{R2[0], R2[1], R2[2], R2[3]}};
+        return a.mul(r2);
+    }
+};
+
+// Fp values cross the host only as opaque limbs (coordinates of points)
+struct Fp {
+    uint64_t limbs[4];
+    static constexpr uint64_t ONE[4] = {0xd35d438dc58f0d9dULL, 0x0a78eb28f5c70b3dULL, 0x666ea36f7879462cULL, 0x0e0a77c19a07df2fULL};
+    static constexpr uint64_t TWO[4] = {0xa6ba871b8b1e1b3aULL, 0x14f1d651eb8e167bULL, 0xccdd46def0f28c58ULL, 0x1c14ef83340fbe5eULL};
+};
+
+// ---------------------------------------------------------------- msm
+struct AffinePoint {  // src/msm/mod.zig:15-49
+    Fp x, y;
+    bool infinity;
+    static AffinePoint identity() { return AffinePoint{{{0, 0, 0, 0}}, {{0, 0, 0, 0}}, true}; }
+    static AffinePoint generator() {
+        AffinePoint g;
+        std::memcpy(g.x.limbs, Fp::ONE, 32);
+        std::memcpy(g.y.limbs, Fp::TWO, 32);
+        g.infinity = false;
+        return g;
+    }
+    bool isIdentity() const { return infinity; }
+    bool eql(const AffinePoint &o) const {
+        if (infinity && o.infinity) return true;
+        if (infinity || o.infinity) return false;
+        return std::memcmp(x.limbs, o.x.limbs, 32) == 0 && std::memcmp(y.limbs, o.y.limbs, 32) == 0;
+    }
+};
+
+inline void pack_points(const std::vector<AffinePoint> &pts, std::vector<uint64_t> &xy, std::vector<uint8_t> &inf) {
+    xy.resize(pts.size() * 8);
+    inf.resize(pts.size());
+    for (size_t i = 0; i < pts.size(); i++) {
+        std::memcpy(&xy[8 * i], pts[i].x.limbs, 32);
+        std::memcpy(&xy[8 * i + 4], pts[i].y.limbs, 32);
+        inf[i] = pts[i].infinity ? 1 : 0;
+    }
+}
+inline AffinePoint unpack_point(const uint64_t *xy, uint8_t inf) {
+    AffinePoint p;
+    std::memcpy(p.x.limbs, xy, 32);
+    std::memcpy(p.y.limbs, xy + 4, 32);
+    p.infinity = inf != 0;
+    return p;
+}
+
+// device-resident bases: the GPU image of SetupParams.powers_of_tau_g1
+class DeviceBases {
+public:
+    explicit DeviceBases(const std::vector<AffinePoint> &pts, const zg_msm_config *cfg = nullptr) : n_(pts.size()) {
+        std::vector<uint64_t> xy;
+        std::vector<uint8_t> inf;
+        pack_points(pts, xy, inf);
+        check(zg_g1_bases_upload(xy.data(), inf.data(), n_, cfg, &h_), "zg_g1_bases_upload");
+    }
+    ~DeviceBases() { zg_g1_bases_free(h_); }
+    DeviceBases(const DeviceBases &) = delete;
+    DeviceBases &operator=(const DeviceBases &) = delete;
+    size_t len() const { return n_; }
+    AffinePoint msm(const Fr *scalars, size_t n, size_t off = 0) const {
+        uint64_t out[8];
+        uint8_t inf = 0;
+        check(zg_msm_g1(h_, off, n, reinterpret_cast<const uint64_t *>(scalars), out, &inf), "zg_msm_g1");
+        return unpack_point(out, inf);
+    }
+    zg_bases_t handle() const { return h_; }
+
+private:
+    zg_bases_t h_ = nullptr;
+    size_t n_;
+};
+
+struct MSM {  // MSM(Fr, Fp), src/msm/mod.zig:345-542
+    // compute(bases, scalars) — :355-372. Lengths must match (std.debug.assert :359).
+    static AffinePoint compute(const std::vector<AffinePoint> &bases, const std::vector<Fr> &scalars) {
+        if (bases.size() != scalars.size()) throw std::invalid_argument("MSM.compute: bases.len != scalars.len");
+        if (bases.empty()) return AffinePoint::identity();
+        DeviceBases d(bases);
+        return d.msm(scalars.data(), scalars.size());
+    }
+    // scalarMul(base, scalar).toAffine() — :503-540
+    static AffinePoint scalarMul(const AffinePoint &base, const Fr &scalar) {
+        uint64_t xy[8], out[8];
+        uint8_t inf = base.infinity ? 1 : 0, oinf = 0;
+        std::memcpy(xy, base.x.limbs, 32);
+        std::memcpy(xy + 4, base.y.limbs, 32);
+        check(zg_g1_scalar_mul_batch(xy, &inf, scalar.limbs, 1, out, &oinf), "zg_g1_scalar_mul_batch");
+        return unpack_point(out, oinf);
+    }
+};
+
+struct BatchMSM {  // :545-565 (ParallelBatchMSM :683-748 returns the same values)
+    static std::vector<AffinePoint> compute(const std::vector<AffinePoint> &bases, const std::vector<std::vector<Fr>> &batches) {
+        std::vector<AffinePoint> out;
+        if (batches.empty()) return out;
+        DeviceBases d(bases);
+        for (const auto &b : batches) out.push_back(d.msm(b.data(), b.size()));
+        return out;
+    }
+};
+
+struct ParallelMSM {  // :572-680 — on one GPU the chunking is internal to the kernels; the value is MSM.compute's
+    static AffinePoint compute(const std::vector<AffinePoint> &bases, const std::vector<Fr> &scalars, size_t /*num_threads*/) {
+        return MSM::compute(bases, scalars);
+    }
+};
+
+// ---------------------------------------------------------------- poly
+struct UniPoly {  // src/poly/mod.zig:584-624
+    std::vector<Fr> coeffs;
+    Fr evaluate(const Fr &x) const {
+        if (coeffs.empty()) return Fr::zero();
+        Fr r = coeffs.back();
+        for (size_t i = coeffs.size() - 1; i-- > 0;) r = r.mul(x).add(coeffs[i]);
+        return r;
+    }
+};
+
+struct DensePolynomial {  // src/poly/mod.zig:23-182
+    std::vector<Fr> evaluations;
+    size_t num_vars;
+    explicit DensePolynomial(const std::vector<Fr> &evals) : evaluations(evals), num_vars(0) {
+        size_t n = evals.size();
+        if (n == 0 || (n & (n - 1))) throw std::invalid_argument("DensePolynomial.init: length must be a power of two");
+        while ((size_t(1) << num_vars) < n) num_vars++;
+    }
+    size_t len() const { return evaluations.size(); }
+    DensePolynomial bindFirst(const Fr &value) const {  // :128-149
+        if (num_vars == 0) throw std::invalid_argument("bindFirst: num_vars == 0");
+        std::vector<Fr> out(evaluations.size() / 2);
+        check(zg_fr_bind_high(reinterpret_cast<const uint64_t *>(evaluations.data()), evaluations.size(), value.limbs,
+                              reinterpret_cast<uint64_t *>(out.data())), "zg_fr_bind_high");
+        return DensePolynomial(out);
+    }
+    void bindLow(const Fr &value) {  // :160-175, in place
+        if (num_vars == 0) throw std::invalid_argument("bindLow: num_vars == 0");
+        check(zg_fr_bind_low(reinterpret_cast<uint64_t *>(evaluations.data()), evaluations.size(), value.limbs), "zg_fr_bind_low");
+        evaluations.resize(evaluations.size() / 2);
+        num_vars -= 1;
+    }
+};
+
+struct EqPolynomial {  // src/poly/mod.zig:190-323
+    std::vector<Fr> r;
+    explicit EqPolynomial(const std::vector<Fr> &point) : r(point) {}
+    std::vector<Fr> evals() const { return evalsSliceWithScaling(r, nullptr); }
+    static std::vector<Fr> evalsSliceWithScaling(const std::vector<Fr> &r, const Fr *scaling_factor) {  // :252-290
+        std::vector<Fr> out(size_t(1) << r.size());
+        check(zg_fr_eq_table(reinterpret_cast<const uint64_t *>(r.data()), r.size(), scaling_factor ? scaling_factor->limbs : nullptr,
+                             reinterpret_cast<uint64_t *>(out.data())), "zg_fr_eq_table");
+        return out;
+    }
+};
+
+// ---------------------------------------------------------------- HyperKZG (commit side)
+struct HyperKZG {
+    struct SetupParams {  // src/poly/commitment/mod.zig:122-140
+        std::vector<AffinePoint> powers_of_tau_g1;
+        AffinePoint g1;
+        size_t max_degree;
+        std::unique_ptr<DeviceBases> device;  // uploaded once, reused by every commit
+    };
+    struct Commitment {
+        AffinePoint point;
+        bool eql(const Commitment &o) const { return point.eql(o.point) && point.infinity == o.point.infinity; }
+    };
+    static SetupParams setup(size_t max_degree) {  // :174-213, tau = 0x12345678
+        SetupParams p;
+        p.g1 = AffinePoint::generator();
+        p.max_degree = max_degree;
+        std::vector<uint64_t> xy(max_degree * 8), sc(max_degree * 4), out(max_degree * 8);
+        std::vector<uint8_t> inf(max_degree, 0), oinf(max_degree, 0);
+        Fr tau = Fr::fromU64(0x12345678), tp = Fr::one();
+        for (size_t i = 0; i < max_degree; i++) {
+            std::memcpy(&xy[8 * i], p.g1.x.limbs, 32);
+            std::memcpy(&xy[8 * i + 4], p.g1.y.limbs, 32);
+            std::memcpy(&sc[4 * i], tp.limbs, 32);
+            tp = tp.mul(tau);
+        }
+        check(zg_g1_scalar_mul_batch(xy.data(), inf.data(), sc.data(), max_degree, out.data(), oinf.data()), "zg_g1_scalar_mul_batch");
+        for (size_t i = 0; i < max_degree; i++) p.powers_of_tau_g1.push_back(unpack_point(&out[8 * i], oinf[i]));
+        p.device.reset(new DeviceBases(p.powers_of_tau_g1));
+        return p;
+    }
+    static Commitment commit(const SetupParams &params, const std::vector<Fr> &evals) {  // :239-255
+        if (evals.empty()) return Commitment{AffinePoint::identity()};
+        size_t n = evals.size() < params.powers_of_tau_g1.size() ? evals.size() : params.powers_of_tau_g1.size();
+        return Commitment{params.device->msm(evals.data(), n)};
+    }
+    static std::vector<Commitment> batchCommit(const SetupParams &params, const std::vector<std::vector<Fr>> &polys) {  // :558-570
+        std::vector<Commitment> out;
+        for (const auto &p : polys) out.push_back(commit(params, p));
+        return out;
+    }
+};
+
+// ---------------------------------------------------------------- sumcheck
+struct SumcheckVerificationFailed : std::runtime_error {
+    SumcheckVerificationFailed() : std::runtime_error("SumcheckVerificationFailed") {}
+};
+
+struct Sumcheck {
+    struct Round {
+        UniPoly poly;
+    };
+    class Prover {  // src/subprotocols/mod.zig:50-134 — the polynomial lives on the GPU
+    public:
+        explicit Prover(const DensePolynomial &p) : round(0) {
+            check(zg_sumcheck_open(reinterpret_cast<const uint64_t *>(p.evaluations.data()), p.evaluations.size(), ZG_SC_HIGH_HALF, &s_),
+                  "zg_sumcheck_open");
+        }
+        ~Prover() { zg_sumcheck_close(s_); }
+        Prover(const Prover &) = delete;
+        Round nextRound() {  // :69-109 -> coefficients [g(0), g(1) - g(0)]
+            Fr g0, g1;
+            check(zg_sumcheck_round_sums(s_, g0.limbs, g1.limbs), "zg_sumcheck_round_sums");
+            Round r;
+            r.poly.coeffs = {g0, g1.sub(g0)};
+            return r;
+        }
+        void receiveChallenge(const Fr &c) {  // :112-122
+            check(zg_sumcheck_bind(s_, c.limbs), "zg_sumcheck_bind");
+            round++;
+        }
+        bool isComplete() const { return zg_sumcheck_len(s_) == 1; }
+        Fr getFinalEval() const {  // :130-133
+            Fr f;
+            check(zg_sumcheck_final(s_, f.limbs), "zg_sumcheck_final");
+            return f;
+        }
+        size_t round;
+
+    private:
+        zg_sc_t s_ = nullptr;
+    };
+    struct Verifier {  // :137-244 (toy Fiat-Shamir mixer, host side as in the reference)
+        Fr claim;
+        size_t round = 0;
+        std::vector<Fr> challenges;
+        explicit Verifier(const Fr &c) : claim(c) {}
+        Fr deriveChallenge(const Round &rd) const {  // :211-243
+            uint64_t h = 0x9e3779b97f4a7c15ULL;
+            h ^= (uint64_t)round;
+            h *= 0xff51afd7ed558ccdULL;
+            for (uint64_t limb : claim.limbs) { h ^= limb; h *= 0xc4ceb9fe1a85ec53ULL; }
+            for (const Fr &c : rd.poly.coeffs)
+                for (uint64_t limb : c.limbs) { h ^= limb; h *= 0xff51afd7ed558ccdULL; h ^= h >> 33; }
+            h ^= h >> 33; h *= 0xff51afd7ed558ccdULL; h ^= h >> 33;
+            return Fr::fromU64(h);
+        }
+        Fr verifyRound(const Round &rd) {  // :165-207
+            Fr sum = rd.poly.evaluate(Fr::zero()).add(rd.poly.evaluate(Fr::one()));
+            if (!sum.eql(claim)) throw SumcheckVerificationFailed();
+            Fr ch = deriveChallenge(rd);
+            challenges.push_back(ch);
+            claim = rd.poly.evaluate(ch);
+            round++;
+            return ch;
+        }
+    };
+    struct Proof {
+        Fr claim;
+        std::vector<Round> rounds;
+        std::vector<Fr> final_point;
+        Fr final_eval;
+    };
+};
+
+struct SumcheckResult {
+    Sumcheck::Proof proof;
+    bool result;
+};
+
+inline SumcheckResult runSumcheck(const DensePolynomial &polynomial) {  // src/subprotocols/mod.zig:302-354
+    SumcheckResult out;
+    Fr claim = Fr::zero();
+    if (polynomial.num_vars == 0) {
+        claim = polynomial.evaluations[0];
+    } else {  // claim = sum of all evaluations (:306-309) = g0 + g1 of round 0
+        zg_sc_t s = nullptr;
+        check(zg_sumcheck_open(reinterpret_cast<const uint64_t *>(polynomial.evaluations.data()), polynomial.evaluations.size(),
+                               ZG_SC_HIGH_HALF, &s), "zg_sumcheck_open");
+        Fr g0, g1;
+        int rc = zg_sumcheck_round_sums(s, g0.limbs, g1.limbs);
+        zg_sumcheck_close(s);
+        check(rc, "zg_sumcheck_round_sums");
+        claim = g0.add(g1);
+    }
+    Sumcheck::Prover prover(polynomial);
+    Sumcheck::Verifier verifier(claim);
+    for (size_t i = 0; i < polynomial.num_vars; i++) {
+        Sumcheck::Round rd = prover.nextRound();
+        Fr ch = verifier.verifyRound(rd);
+        prover.receiveChallenge(ch);
+        out.proof.rounds.push_back(rd);
+    }
+    out.proof.claim = claim;
+    out.proof.final_point = verifier.challenges;
+    out.proof.final_eval = prover.getFinalEval();
+    out.result = verifier.claim.eql(out.proof.final_eval);
+    return out;
+}
+
+}  // namespace zolt
