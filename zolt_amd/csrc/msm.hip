@@ -53,6 +53,8 @@ struct zg_bases_s {
     uint8_t *d_inf = nullptr;    // n B or null
     uint64_t *d_scal = nullptr;  // staging for host scalars, n * 32 B
     uint32_t *d_dig = nullptr, *d_sorted = nullptr, *d_hist = nullptr, *d_starts = nullptr;
+    uint32_t *d_blockhist = nullptr;  // LDS sort path: nblk * NK per-block histograms / offsets
+    uint32_t nblk = 0;
     char *d_partial = nullptr;  // NK * 128 B: bucket sums
     char *d_bits = nullptr;     // G * c * PB * 128 B: per-bit partial sums
     char *d_rg = nullptr;       // G * 128 B: per-group results
@@ -150,6 +152,78 @@ __global__ void __launch_bounds__(256) msm_scatter_kernel(const uint32_t *dig, u
     uint32_t pos = starts[key] + atomicAdd(&fill[key], 1u);
     uint32_t ref = (uint32_t)((size_t)(w / G) * table_n + off + i);
     sorted[pos] = (e & 0x80000000u) | ref;
+}
+
+// ---- LDS-staged counting sort (used when the whole bucket histogram fits in LDS: NK*4 <= 128 KiB).
+// One 1024-thread block per CU owns a contiguous slice of the scalars; its histogram and, later, its
+// scatter cursors live in LDS (ds_add_rtn_u32), so the sort issues no global atomics at all. The global
+// path above costs one device-scope atomic per digit, twice (histogram + scatter).
+template <int C>
+__global__ void __launch_bounds__(1024) msm_digits_lds_kernel(const uint64_t *scalars, const uint8_t *inf, uint32_t n, int G,
+                                                              uint32_t per_block, uint32_t NK, uint32_t *dig, uint32_t *blockhist) {
+    extern __shared__ uint32_t lds_hist[];
+    constexpr int W = (255 + C - 1) / C;
+    constexpr uint32_t NB = 1u << (C - 1);
+    for (uint32_t k = threadIdx.x; k < NK; k += 1024) lds_hist[k] = 0;
+    __syncthreads();
+    uint32_t i0 = blockIdx.x * per_block, i1 = i0 + per_block < n ? i0 + per_block : n;
+    for (uint32_t i = i0 + threadIdx.x; i < i1; i += 1024) {
+        Fr s = fe_from_mont(fe_load<FrParams>(scalars + 4 * (size_t)i));
+        bool skip = inf && inf[i];
+        uint32_t carry = 0;
+#pragma unroll
+        for (int w = 0; w < W; w++) {
+            const int bit = w * C, limb = bit / 32, sh = bit % 32;
+            uint32_t v = s.l[limb] >> sh;
+            if (sh + C > 32 && limb + 1 < 8) v |= s.l[limb + 1] << (32 - sh);
+            v = (v & ((1u << C) - 1u)) + carry;
+            uint32_t neg = v > NB ? 1u : 0u;
+            uint32_t d = neg ? (1u << C) - v : v;
+            carry = neg;
+            uint32_t e = 0xFFFFFFFFu;
+            if (d != 0 && !skip) {
+                uint32_t key = (uint32_t)(w % G) * NB + (d - 1);
+                e = key | (neg << 31);
+                atomicAdd(&lds_hist[key], 1u);
+            }
+            dig[(size_t)w * n + i] = e;
+        }
+    }
+    __syncthreads();
+    uint32_t *row = blockhist + (size_t)blockIdx.x * NK;
+    for (uint32_t k = threadIdx.x; k < NK; k += 1024) row[k] = lds_hist[k];
+}
+
+// per key: exclusive prefix over the blocks (in place) and the key's total
+__global__ void __launch_bounds__(256) msm_colscan_kernel(uint32_t *blockhist, uint32_t nblk, uint32_t NK, uint32_t *total) {
+    uint32_t key = blockIdx.x * 256 + threadIdx.x;
+    if (key >= NK) return;
+    uint32_t run = 0;
+    for (uint32_t b = 0; b < nblk; b++) {
+        uint32_t v = blockhist[(size_t)b * NK + key];
+        blockhist[(size_t)b * NK + key] = run;
+        run += v;
+    }
+    total[key] = run;
+}
+
+__global__ void __launch_bounds__(1024) msm_scatter_lds_kernel(const uint32_t *dig, uint32_t n, int W, int G, size_t table_n, uint32_t off,
+                                                               uint32_t per_block, uint32_t NK, const uint32_t *starts,
+                                                               const uint32_t *blockhist, uint32_t *sorted) {
+    extern __shared__ uint32_t lds_cur[];
+    const uint32_t *row = blockhist + (size_t)blockIdx.x * NK;
+    for (uint32_t k = threadIdx.x; k < NK; k += 1024) lds_cur[k] = starts[k] + row[k];
+    __syncthreads();
+    uint32_t i0 = blockIdx.x * per_block, i1 = i0 + per_block < n ? i0 + per_block : n;
+    for (int w = 0; w < W; w++) {
+        uint32_t lvl = (uint32_t)(w / G);
+        for (uint32_t i = i0 + threadIdx.x; i < i1; i += 1024) {
+            uint32_t e = dig[(size_t)w * n + i];
+            if (e == 0xFFFFFFFFu) continue;
+            uint32_t pos = atomicAdd(&lds_cur[e & 0x7FFFFFFFu], 1u);
+            sorted[pos] = (e & 0x80000000u) | (uint32_t)((size_t)lvl * table_n + off + i);
+        }
+    }
 }
 
 ZG_DEV XYZZ xyzz_shfl_down(const XYZZ &v, int delta) {
@@ -399,7 +473,7 @@ static int make_plan(size_t n, const zg_msm_config *cfg, MsmPlan &p) {
 static void free_bases(zg_bases_s *b) {
     if (!b) return;
     void *ptrs[] = {b->d_table, b->d_inf, b->d_scal, b->d_dig, b->d_sorted, b->d_hist, b->d_starts,
-                    b->d_partial, b->d_bits, b->d_rg, b->d_out};
+                    b->d_partial, b->d_bits, b->d_rg, b->d_out, b->d_blockhist};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (b->h_out) (void)hipHostFree(b->h_out);
@@ -441,6 +515,11 @@ static int bases_create(const uint64_t *d_xy, const uint8_t *d_inf_in, size_t n,
     ZG_ALLOC(b->d_sorted, (size_t)p.W * n * 4);
     ZG_ALLOC(b->d_hist, (size_t)p.NK * 4);
     ZG_ALLOC(b->d_starts, ((size_t)p.NK + 1) * 4);
+    if ((size_t)p.NK * 4 <= 128 * 1024 && env_int("ZG_MSM_LDS_SORT", 1)) {
+        uint32_t nblk = (uint32_t)(n / 2048);
+        b->nblk = nblk < 1 ? 1 : (nblk > 256 ? 256 : nblk);
+        ZG_ALLOC(b->d_blockhist, (size_t)b->nblk * p.NK * 4);
+    }
     ZG_ALLOC(b->d_partial, (size_t)p.NK * 128);
     ZG_ALLOC(b->d_bits, (size_t)p.G * p.c * p.PB * 128);
     ZG_ALLOC(b->d_rg, (size_t)p.G * 128);
@@ -464,6 +543,26 @@ static int bases_create(const uint64_t *d_xy, const uint8_t *d_inf_in, size_t n,
 template <int C>
 static void launch_digits(hipStream_t st, const uint64_t *sc, const uint8_t *inf, uint32_t n, int G, uint32_t *dig, uint32_t *hist) {
     hipLaunchKernelGGL(msm_digits_kernel<C>, dim3(div_up(n, 256)), dim3(256), 0, st, sc, inf, n, G, dig, hist);
+}
+
+template <int C>
+static int launch_digits_lds(hipStream_t st, const uint64_t *sc, const uint8_t *inf, uint32_t n, int G, uint32_t per_block,
+                             uint32_t NK, uint32_t nblk, uint32_t *dig, uint32_t *blockhist) {
+    ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_digits_lds_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(NK * 4)));
+    hipLaunchKernelGGL(msm_digits_lds_kernel<C>, dim3(nblk), dim3(1024), NK * 4, st, sc, inf, n, G, per_block, NK, dig, blockhist);
+    return ZG_OK;
+}
+
+static int launch_digits_lds_c(int c, hipStream_t st, const uint64_t *sc, const uint8_t *inf, uint32_t n, int G, uint32_t per_block,
+                               uint32_t NK, uint32_t nblk, uint32_t *dig, uint32_t *blockhist) {
+    switch (c) {
+#define ZG_CASE(C) case C: return launch_digits_lds<C>(st, sc, inf, n, G, per_block, NK, nblk, dig, blockhist);
+        ZG_CASE(2) ZG_CASE(3) ZG_CASE(4) ZG_CASE(5) ZG_CASE(6) ZG_CASE(7) ZG_CASE(8) ZG_CASE(9) ZG_CASE(10)
+        ZG_CASE(11) ZG_CASE(12) ZG_CASE(13) ZG_CASE(14) ZG_CASE(15) ZG_CASE(16)
+#undef ZG_CASE
+        default: set_error("msm: unsupported window size"); return ZG_ERR_INVALID;
+    }
 }
 
 static int launch_digits_c(int c, hipStream_t st, const uint64_t *sc, const uint8_t *inf, uint32_t n, int G, uint32_t *dig,
@@ -491,15 +590,32 @@ static int msm_enqueue(zg_bases_s *b, size_t off, size_t n, const uint64_t *d_sc
         ZG_HIP(hipGetLastError());
         return ZG_OK;
     }
-    prof_begin(ZG_PROF_MSM_DIGITS, st);
-    ZG_HIP(hipMemsetAsync(b->d_hist, 0, (size_t)p.NK * 4, st));
-    ZG_TRY(launch_digits_c(p.c, st, d_scalars, b->d_inf ? b->d_inf + off : nullptr, (uint32_t)n, p.G, b->d_dig, b->d_hist));
-    prof_end(ZG_PROF_MSM_DIGITS, st);
-    prof_begin(ZG_PROF_MSM_SORT, st);
-    hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(1024), 0, st, b->d_hist, b->d_starts, p.NK);
-    ZG_HIP(hipMemsetAsync(b->d_hist, 0, (size_t)p.NK * 4, st));
-    hipLaunchKernelGGL(msm_scatter_kernel, dim3(div_up(n, 256), p.W), dim3(256), 0, st, b->d_dig, (uint32_t)n, p.G, b->n,
-                       (uint32_t)off, b->d_starts, b->d_hist, b->d_sorted);
+    const uint8_t *infp = b->d_inf ? b->d_inf + off : nullptr;
+    if (b->d_blockhist) {
+        uint32_t nblk = b->nblk;
+        while (nblk > 1 && (size_t)(nblk - 1) * 1024 >= n) nblk--;  // no empty blocks for short sub-range MSMs
+        uint32_t per_block = (uint32_t)((n + nblk - 1) / nblk);
+        prof_begin(ZG_PROF_MSM_DIGITS, st);
+        ZG_TRY(launch_digits_lds_c(p.c, st, d_scalars, infp, (uint32_t)n, p.G, per_block, p.NK, nblk, b->d_dig, b->d_blockhist));
+        prof_end(ZG_PROF_MSM_DIGITS, st);
+        prof_begin(ZG_PROF_MSM_SORT, st);
+        hipLaunchKernelGGL(msm_colscan_kernel, dim3(div_up(p.NK, 256)), dim3(256), 0, st, b->d_blockhist, nblk, p.NK, b->d_hist);
+        hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(1024), 0, st, b->d_hist, b->d_starts, p.NK);
+        ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_scatter_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(p.NK * 4)));
+        hipLaunchKernelGGL(msm_scatter_lds_kernel, dim3(nblk), dim3(1024), p.NK * 4, st, b->d_dig, (uint32_t)n, p.W, p.G, b->n,
+                           (uint32_t)off, per_block, p.NK, b->d_starts, b->d_blockhist, b->d_sorted);
+    } else {
+        prof_begin(ZG_PROF_MSM_DIGITS, st);
+        ZG_HIP(hipMemsetAsync(b->d_hist, 0, (size_t)p.NK * 4, st));
+        ZG_TRY(launch_digits_c(p.c, st, d_scalars, infp, (uint32_t)n, p.G, b->d_dig, b->d_hist));
+        prof_end(ZG_PROF_MSM_DIGITS, st);
+        prof_begin(ZG_PROF_MSM_SORT, st);
+        hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(1024), 0, st, b->d_hist, b->d_starts, p.NK);
+        ZG_HIP(hipMemsetAsync(b->d_hist, 0, (size_t)p.NK * 4, st));
+        hipLaunchKernelGGL(msm_scatter_kernel, dim3(div_up(n, 256), p.W), dim3(256), 0, st, b->d_dig, (uint32_t)n, p.G, b->n,
+                           (uint32_t)off, b->d_starts, b->d_hist, b->d_sorted);
+    }
     prof_end(ZG_PROF_MSM_SORT, st);
     prof_begin(ZG_PROF_MSM_ACCUMULATE, st);
     hipLaunchKernelGGL(msm_accumulate_kernel, dim3(div_up((size_t)p.NK * p.S, 256)), dim3(256), 0, st, b->d_sorted, b->d_starts,
