@@ -1,0 +1,236 @@
+// fp29.hip.h — BN254 Fp in 9 x 29-bit redundant limbs, for the MSM bucket-accumulation inner loop.
+//
+// Why a second representation. field.hip.h multiplies 8 x 32-bit limbs; every 32x32 product then
+// needs carry handling, and on gfx950 v_add_co/v_addc_co and 64-bit adds cost as much as a
+// v_mad_u64_u32 (4 cycles per wave-instruction, tools/microbench.hip). With 29-bit limbs a column of
+// the schoolbook product holds at most 9 + 9 products of < 2^58, which fits a 64-bit accumulator, so
+// the whole multiplication is a stream of v_mad_u64_u32 with NO carry instructions until one
+// shift-and-add per column at the end: ~225 VALU instructions instead of ~560.
+//
+// Values are in Montgomery form with R' = 2^261 and are kept LAZILY reduced: a value is any
+// representative in [0, k*p) for a small k tracked per formula (see xyzz29_madd); p < 2^254 leaves
+// 7 spare bits, so a Montgomery product of inputs < A*p and < B*p is < (A*B/168.9 + 1)*p with no final
+// subtraction. Limbs are "near-normalised" (< 2^29 + 8) except the top limb. Nothing in this format
+// ever leaves the MSM: bucket sums are converted back to canonical 8 x 32-bit Montgomery-2^256
+// (field.hip.h) before they are stored, so results stay bit-identical to the reference.
+#pragma once
+#include "field.hip.h"
+
+namespace zg {
+
+struct F29 {
+    u32 l[9];
+};
+
+struct Fp29 {
+    static constexpr u32 MASK = 0x1fffffffu;
+    static constexpr u32 P[9] = {0x187cfd47u, 0x010460b6u, 0x1c72a34fu, 0x02d522d0u, 0x1585d978u,
+                                 0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
+    static constexpr u32 NINV = 0x04866389u;   // -p^-1 mod 2^29
+    static constexpr u32 PINV0 = 0x1b799c77u;  //  p^-1 mod 2^29
+    static constexpr u32 ONE[9] = {0x157ccc21u, 0x141c2758u, 0x185230d3u, 0x014c0419u, 0x0aa36fb9u,
+                                   0x1d4240ceu, 0x11d54c07u, 0x052ac7a8u, 0x000dc836u};  // 2^261 mod p
+    // ext (x*2^256) -> int (x*2^261): mont29(ext, K_IN), K_IN = 2^266 mod p
+    static constexpr u32 K_IN[9] = {0x13349ca1u, 0x1a5d84a8u, 0x0a3e5cacu, 0x100249e0u, 0x12b951e8u,
+                                    0x0e92d304u, 0x14cb95b3u, 0x041b9d3du, 0x00058003u};
+    // int -> ext: mont29(int, K_OUT), K_OUT = 2^256 mod p
+    static constexpr u32 K_OUT[9] = {0x058f0d9du, 0x1aea1c6eu, 0x11c2cf74u, 0x11d651ebu, 0x1462c0a7u,
+                                     0x11b7bc3cu, 0x1cbd99bau, 0x183340fbu, 0x000e0a77u};
+    // k*p with limbs 0..7 raised by 2^30 (2^31 for 5p) and the excess borrowed from the next limb, so
+    // that (bias - b) never underflows limb-wise for near-normalised b (3 of them for 5p)
+    static constexpr u32 BIAS2P[9] = {0x50f9fa8eu, 0x4208c16bu, 0x58e5469cu, 0x45aa459fu, 0x4b0bb2eeu,
+                                      0x45b6817fu, 0x414dc280u, 0x5cb84c66u, 0x0060c89au};
+    static constexpr u32 BIAS4P[9] = {0x41f3f51cu, 0x441182d9u, 0x51ca8d3au, 0x4b548b41u, 0x561765deu,
+                                      0x4b6d0300u, 0x429b8502u, 0x597098ceu, 0x00c19137u};
+    static constexpr u32 BIAS5P[9] = {0x9a70f263u, 0x8515e38du, 0x8e3d3087u, 0x8e29ae10u, 0x8b9d3f54u,
+                                      0x8e4843bfu, 0x83426641u, 0x87ccbf00u, 0x00f1f584u};
+    static constexpr u32 BIAS7P[9] = {0x4b6aecf1u, 0x471ea4fdu, 0x47227727u, 0x53d3f3b4u, 0x56a8f246u,
+                                      0x53fec542u, 0x449028c5u, 0x44850b6au, 0x0152be23u};
+};
+
+// one parallel carry step: limbs < 2^32 in, limbs < 2^29 + 8 out (top limb keeps the rest)
+ZG_DEV F29 f29_carry(const F29 &x) {
+    F29 r;
+    r.l[0] = x.l[0] & Fp29::MASK;
+#pragma unroll
+    for (int i = 1; i < 8; i++) r.l[i] = (x.l[i] & Fp29::MASK) + (x.l[i - 1] >> 29);
+    r.l[8] = x.l[8] + (x.l[7] >> 29);
+    return r;
+}
+
+// Montgomery product a*b*2^-261 mod p (lazy): limbs of a, b < 2^30; output limbs exactly < 2^29,
+// value < (A*B/168.9 + 1)*p for a < A*p, b < B*p.
+ZG_DEV F29 f29_mul(const F29 &a, const F29 &b) {
+    u64 c[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) c[k] = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+#pragma unroll
+        for (int j = 0; j < 9; j++) c[i + j] += (u64)a.l[i] * b.l[j];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        u32 m = ((u32)c[i] * Fp29::NINV) & Fp29::MASK;
+#pragma unroll
+        for (int j = 0; j < 9; j++) c[i + j] += (u64)m * Fp29::P[j];
+        c[i + 1] += c[i] >> 29;
+    }
+    F29 r;
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+        r.l[k - 9] = (u32)c[k] & Fp29::MASK;
+        c[k + 1] += c[k] >> 29;
+    }
+    r.l[8] = (u32)c[17];
+    return r;
+}
+
+ZG_DEV F29 f29_sqr(const F29 &a) {
+    u64 c[18];
+    u32 d[9];
+#pragma unroll
+    for (int k = 0; k < 18; k++) c[k] = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) d[i] = a.l[i] << 1;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        c[2 * i] += (u64)a.l[i] * a.l[i];
+#pragma unroll
+        for (int j = i + 1; j < 9; j++) c[i + j] += (u64)d[i] * a.l[j];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        u32 m = ((u32)c[i] * Fp29::NINV) & Fp29::MASK;
+#pragma unroll
+        for (int j = 0; j < 9; j++) c[i + j] += (u64)m * Fp29::P[j];
+        c[i + 1] += c[i] >> 29;
+    }
+    F29 r;
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+        r.l[k - 9] = (u32)c[k] & Fp29::MASK;
+        c[k + 1] += c[k] >> 29;
+    }
+    r.l[8] = (u32)c[17];
+    return r;
+}
+
+// a + K*p - b, near-normalised; needs b < K*p (with margin) and near-normalised limbs
+#define ZG_F29_SUB(NAME, BIAS)                                        \
+    ZG_DEV F29 NAME(const F29 &a, const F29 &b) {                     \
+        F29 t;                                                        \
+        _Pragma("unroll") for (int i = 0; i < 9; i++) t.l[i] = a.l[i] + Fp29::BIAS[i] - b.l[i]; \
+        return f29_carry(t);                                          \
+    }
+ZG_F29_SUB(f29_sub2, BIAS2P)
+ZG_F29_SUB(f29_sub4, BIAS4P)
+ZG_F29_SUB(f29_sub7, BIAS7P)
+#undef ZG_F29_SUB
+
+// 2p - y (negation of an affine y < 2p)
+ZG_DEV F29 f29_neg2(const F29 &y) {
+    F29 t;
+#pragma unroll
+    for (int i = 0; i < 9; i++) t.l[i] = Fp29::BIAS2P[i] - y.l[i];
+    return f29_carry(t);
+}
+
+// a + 5p - b - 2c  (b, c exactly normalised mul outputs)
+ZG_DEV F29 f29_x3(const F29 &a, const F29 &b, const F29 &c) {
+    F29 t;
+#pragma unroll
+    for (int i = 0; i < 9; i++) t.l[i] = a.l[i] + Fp29::BIAS5P[i] - b.l[i] - 2u * c.l[i];
+    return f29_carry(t);
+}
+
+// x == 0 (mod p) for a near-normalised x < 16p whose limb 0 is exact (< 2^29: any f29_carry output).
+// If x = k*p then k = x_0 * p^-1 mod 2^29; anything else passes this filter with probability 2^-25.
+ZG_DEV bool f29_is_zero_modp(const F29 &x) {
+    u32 k = (x.l[0] * Fp29::PINV0) & Fp29::MASK;
+    if (k > 16u) return false;
+    u32 carry = 0;
+    u64 kp = 0;
+    bool eq = true;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        u32 v = x.l[i] + carry;
+        kp += (u64)k * Fp29::P[i];
+        if (i < 8) {
+            eq = eq && ((v & Fp29::MASK) == ((u32)kp & Fp29::MASK));
+            carry = v >> 29;
+            kp >>= 29;
+        } else {
+            eq = eq && (v == (u32)kp);
+        }
+    }
+    return eq;
+}
+
+// 256-bit little-endian words (value < 2^256) <-> 9 x 29-bit limbs
+ZG_DEV F29 f29_unpack(const u32 *w) {
+    F29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const int o = 29 * i, wi = o / 32, sh = o % 32;
+        u32 v = w[wi] >> sh;
+        if (sh > 3 && wi + 1 < 8) v |= w[wi + 1] << (32 - sh);
+        r.l[i] = (i < 8) ? (v & Fp29::MASK) : v;
+    }
+    return r;
+}
+// limbs must be exactly normalised and the value < 2^256
+ZG_DEV void f29_pack(const F29 &x, u32 *w) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int o = 32 * j, li = o / 29, sh = o % 29;  // word j starts at bit `sh` of limb li
+        u32 v = x.l[li] >> sh;
+        if (li + 1 < 9) v |= x.l[li + 1] << (29 - sh);
+        if (sh > 26 && li + 2 < 9) v |= x.l[li + 2] << (58 - sh);
+        w[j] = v;
+    }
+}
+
+// canonical Montgomery-2^256 element (field.hip.h) -> lazy Montgomery-2^261
+ZG_DEV F29 f29_from_fp(const Fp &a) {
+    F29 k;
+#pragma unroll
+    for (int i = 0; i < 9; i++) k.l[i] = Fp29::K_IN[i];
+    return f29_mul(f29_unpack(a.l), k);
+}
+// lazy (value < 16p) -> canonical Montgomery-2^256 element
+ZG_DEV Fp f29_to_fp(const F29 &x) {
+    F29 k;
+#pragma unroll
+    for (int i = 0; i < 9; i++) k.l[i] = Fp29::K_OUT[i];
+    F29 t = f29_mul(x, k);  // < 1.1p, limbs exact
+    // conditional subtract of p (29-bit borrow chain)
+    F29 d;
+    u32 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        u32 v = t.l[i] - Fp29::P[i] - borrow;
+        if (i < 8) {
+            borrow = v >> 31;
+            d.l[i] = v & Fp29::MASK;
+        } else {
+            borrow = v >> 31;
+            d.l[i] = v;
+        }
+    }
+    F29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = borrow ? t.l[i] : d.l[i];
+    Fp out;
+    f29_pack(r, out.l);
+    return out;
+}
+
+// table row (64 B): x, y as packed Montgomery-2^261 values (< 2^256, not necessarily < p)
+ZG_DEV void f29_store_packed(void *p, const F29 &x) {
+    Fp t;
+    f29_pack(x, t.l);
+    fe_store(p, t);
+}
+
+}  // namespace zg

@@ -28,6 +28,7 @@
 
 #include "common.hip.h"
 #include "g1.hip.h"
+#include "g1_29.hip.h"
 
 namespace zg {
 
@@ -73,13 +74,17 @@ __global__ void __launch_bounds__(256) msm_precompute_kernel(const uint64_t *xy,
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Affine p = affine_load(xy + 8 * i);
-    affine_store(table + 64 * i, p);
+    // rows are stored in the accumulate kernel's format: x, y as packed Montgomery-2^261 values (fp29.hip.h)
+    f29_store_packed(table + 64 * i, f29_from_fp(p.x));
+    f29_store_packed(table + 64 * i + 32, f29_from_fp(p.y));
     if (inf && inf[i]) return;  // infinity bases are never referenced (digits are suppressed)
     for (int l = 1; l < levels; l++) {
         XYZZ a = xyzz_dbl_affine(p);
         for (int k = 1; k < dbl_per_level; k++) a = xyzz_dbl(a);
         xyzz_to_affine(a, p);
-        affine_store(table + 64 * ((size_t)l * n + i), p);
+        char *row = table + 64 * ((size_t)l * n + i);
+        f29_store_packed(row, f29_from_fp(p.x));
+        f29_store_packed(row + 32, f29_from_fp(p.y));
     }
 }
 
@@ -251,25 +256,28 @@ __global__ void __launch_bounds__(256) msm_accumulate_kernel(const uint32_t *sor
         a = b0 + (uint32_t)(((uint64_t)len * s) / (uint32_t)S);
         b = b0 + (uint32_t)(((uint64_t)len * (s + 1)) / (uint32_t)S);
     }
-    XYZZ acc = XYZZ::identity();
+    XYZZ29 acc29;
+    bool acc_inf = true;
     if (a < b) {
         uint32_t e = sorted[a];
-        Affine cur = affine_load(table + 64 * (size_t)(e & 0x7FFFFFFFu));
+        Affine cur = affine_load(table + 64 * (size_t)(e & 0x7FFFFFFFu));  // packed lazy-form row
         uint32_t cneg = e >> 31;
         for (uint32_t p = a; p < b; p++) {
             Affine nxt = cur;
             uint32_t nneg = 0;
-            if (p + 1 < b) {  // prefetch the next point under the current add
+            if (p + 1 < b) {  // prefetch the next row under the current add
                 uint32_t e2 = sorted[p + 1];
                 nxt = affine_load(table + 64 * (size_t)(e2 & 0x7FFFFFFFu));
                 nneg = e2 >> 31;
             }
-            if (cneg) cur.y = fe_neg(cur.y);
-            acc = xyzz_madd(acc, cur);
+            F29 px = f29_unpack(cur.x.l), py = f29_unpack(cur.y.l);
+            if (cneg) py = f29_neg2(py);
+            xyzz29_madd(acc29, acc_inf, px, py);
             cur = nxt;
             cneg = nneg;
         }
     }
+    XYZZ acc = xyzz29_to_std(acc29, acc_inf);  // canonical from here on
     for (int d = 1; d < S; d <<= 1) {
         XYZZ o = xyzz_shfl_down(acc, d);
         if ((s & (uint32_t)(2 * d - 1)) == 0) acc = xyzz_add(acc, o);
