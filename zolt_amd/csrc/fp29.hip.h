@@ -144,6 +144,33 @@ ZG_DEV F29 f29_x3(const F29 &a, const F29 &b, const F29 &c) {
     return f29_carry(t);
 }
 
+// a + 4p - 2c (c an exactly normalised mul output < 1.6p)
+ZG_DEV F29 f29_sub4_2c(const F29 &a, const F29 &c) {
+    F29 t;
+#pragma unroll
+    for (int i = 0; i < 9; i++) t.l[i] = a.l[i] + Fp29::BIAS4P[i] - 2u * c.l[i];
+    return f29_carry(t);
+}
+// small multiples, carried: inputs near-normalised
+ZG_DEV F29 f29_times2(const F29 &a) {
+    F29 t;
+#pragma unroll
+    for (int i = 0; i < 9; i++) t.l[i] = a.l[i] << 1;
+    return f29_carry(t);
+}
+ZG_DEV F29 f29_times3(const F29 &a) {
+    F29 t;
+#pragma unroll
+    for (int i = 0; i < 9; i++) t.l[i] = a.l[i] * 3u;
+    return f29_carry(t);
+}
+ZG_DEV bool f29_all_zero(const F29 &a) {
+    u32 o = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o |= a.l[i];
+    return o == 0;
+}
+
 // x == 0 (mod p) for a near-normalised x < 16p whose limb 0 is exact (< 2^29: any f29_carry output).
 // If x = k*p then k = x_0 * p^-1 mod 2^29; anything else passes this filter with probability 2^-25.
 ZG_DEV bool f29_is_zero_modp(const F29 &x) {

@@ -64,4 +64,98 @@ ZG_DEV void xyzz29_madd(XYZZ29 &a, bool &inf, const F29 &px, const F29 &py) {
     a.y = Y3;
 }
 
+// ---- full group law on lazy elements, for the bucket-reduction kernels.
+// Identity is encoded as zz = all-zero limbs (a non-identity ZZ is a non-zero field element, whose lazy
+// representative cannot be 0). Classes as above: X < 6.6p, Y < 3.6p, ZZ, ZZZ < 1.6p.
+ZG_DEV XYZZ29 xyzz29_identity() {
+    XYZZ29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { r.x.l[i] = 0; r.y.l[i] = 0; r.zz.l[i] = 0; r.zzz.l[i] = 0; }
+    return r;
+}
+ZG_DEV bool xyzz29_is_identity(const XYZZ29 &a) { return f29_all_zero(a.zz); }
+
+ZG_DEV XYZZ29 xyzz29_from_std_val(const XYZZ &s) {
+    if (s.is_identity()) return xyzz29_identity();
+    XYZZ29 a;
+    a.x = f29_from_fp(s.x); a.y = f29_from_fp(s.y); a.zz = f29_from_fp(s.zz); a.zzz = f29_from_fp(s.zzz);
+    return a;
+}
+ZG_DEV XYZZ xyzz29_to_std_val(const XYZZ29 &a) { return xyzz29_to_std(a, xyzz29_is_identity(a)); }
+
+// 2*P (dbl-2008-s-1)
+ZG_DEV XYZZ29 xyzz29_dbl(const XYZZ29 &p) {
+    if (xyzz29_is_identity(p)) return p;
+    F29 U = f29_times2(p.y);            // < 7.2p
+    F29 V = f29_sqr(U);
+    F29 W = f29_mul(U, V);
+    F29 S = f29_mul(p.x, V);
+    F29 M = f29_times3(f29_sqr(p.x));   // < 4.8p
+    XYZZ29 r;
+    r.x = f29_sub4_2c(f29_sqr(M), S);   // < 5.6p
+    r.y = f29_sub2(f29_mul(M, f29_sub7(S, r.x)), f29_mul(W, p.y));
+    r.zz = f29_mul(V, p.zz);
+    r.zzz = f29_mul(W, p.zzz);
+    return r;
+}
+
+// a + b (add-2008-s), complete
+ZG_DEV XYZZ29 xyzz29_add(const XYZZ29 &a, const XYZZ29 &b) {
+    if (xyzz29_is_identity(a)) return b;
+    if (xyzz29_is_identity(b)) return a;
+    F29 U1 = f29_mul(a.x, b.zz);
+    F29 U2 = f29_mul(b.x, a.zz);
+    F29 S1 = f29_mul(a.y, b.zzz);
+    F29 S2 = f29_mul(b.y, a.zzz);
+    F29 Pp = f29_sub2(U2, U1);
+    F29 R = f29_sub2(S2, S1);
+    if (f29_is_zero_modp(Pp)) {
+        if (f29_is_zero_modp(R)) return xyzz29_dbl(a);
+        return xyzz29_identity();
+    }
+    F29 PP = f29_sqr(Pp);
+    F29 PPP = f29_mul(Pp, PP);
+    F29 Q = f29_mul(U1, PP);
+    XYZZ29 r;
+    r.x = f29_x3(f29_sqr(R), PPP, Q);
+    r.y = f29_sub2(f29_mul(R, f29_sub7(Q, r.x)), f29_mul(S1, PPP));
+    r.zz = f29_mul(f29_mul(a.zz, b.zz), PP);
+    r.zzz = f29_mul(f29_mul(a.zzz, b.zzz), PPP);
+    return r;
+}
+
+// 144-byte records (4 x 9 u32), 16-byte aligned
+ZG_DEV XYZZ29 xyzz29_load(const void *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    u32 w[36];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        uint4 v = q[i];
+        w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+    }
+    XYZZ29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { r.x.l[i] = w[i]; r.y.l[i] = w[9 + i]; r.zz.l[i] = w[18 + i]; r.zzz.l[i] = w[27 + i]; }
+    return r;
+}
+ZG_DEV void xyzz29_store(void *p, const XYZZ29 &v) {
+    u32 w[36];
+#pragma unroll
+    for (int i = 0; i < 9; i++) { w[i] = v.x.l[i]; w[9 + i] = v.y.l[i]; w[18 + i] = v.zz.l[i]; w[27 + i] = v.zzz.l[i]; }
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+#pragma unroll
+    for (int i = 0; i < 9; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+ZG_DEV XYZZ29 xyzz29_shfl_down(const XYZZ29 &v, int delta) {
+    XYZZ29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        r.x.l[i] = __shfl_down(v.x.l[i], delta, 64);
+        r.y.l[i] = __shfl_down(v.y.l[i], delta, 64);
+        r.zz.l[i] = __shfl_down(v.zz.l[i], delta, 64);
+        r.zzz.l[i] = __shfl_down(v.zzz.l[i], delta, 64);
+    }
+    return r;
+}
+
 }  // namespace zg

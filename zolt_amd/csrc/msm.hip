@@ -56,8 +56,8 @@ struct zg_bases_s {
     uint32_t *d_dig = nullptr, *d_sorted = nullptr, *d_hist = nullptr, *d_starts = nullptr;
     uint32_t *d_blockhist = nullptr;  // LDS sort path: nblk * NK per-block histograms / offsets
     uint32_t nblk = 0;
-    char *d_partial = nullptr;  // NK * 128 B: bucket sums
-    char *d_bits = nullptr;     // G * c * PB * 128 B: per-bit partial sums
+    char *d_partial = nullptr;  // NK * 144 B: bucket sums (lazy 29-bit-limb XYZZ records)
+    char *d_bits = nullptr;     // G * c * PB * 144 B: per-bit partial sums
     char *d_rg = nullptr;       // G * 128 B: per-group results
     uint64_t *d_out = nullptr;  // 16 x u64: result record + flag
     uint64_t *h_out = nullptr;  // pinned mirror
@@ -277,43 +277,43 @@ __global__ void __launch_bounds__(256) msm_accumulate_kernel(const uint32_t *sor
             cneg = nneg;
         }
     }
-    XYZZ acc = xyzz29_to_std(acc29, acc_inf);  // canonical from here on
+    XYZZ29 acc = acc_inf ? xyzz29_identity() : acc29;
     for (int d = 1; d < S; d <<= 1) {
-        XYZZ o = xyzz_shfl_down(acc, d);
-        if ((s & (uint32_t)(2 * d - 1)) == 0) acc = xyzz_add(acc, o);
+        XYZZ29 o = xyzz29_shfl_down(acc, d);
+        if ((s & (uint32_t)(2 * d - 1)) == 0) acc = xyzz29_add(acc, o);
     }
-    if (key < NK && s == 0) xyzz_store(buckets + 128 * (size_t)key, acc);
+    if (key < NK && s == 0) xyzz29_store(buckets + 144 * (size_t)key, acc);
 }
 
-// block-wide XYZZ sum through LDS (256 threads); result returned to thread 0
-__device__ __forceinline__ XYZZ block_sum_xyzz(XYZZ acc, uint4 *sh) {
+// block-wide sum of lazy XYZZ points through LDS (256 threads x 144 B); result returned to every thread
+__device__ __forceinline__ XYZZ29 block_sum_xyzz29(const XYZZ29 &acc, uint4 *sh) {
     uint32_t tid = threadIdx.x;
-    xyzz_store(&sh[tid * 8], acc);
+    xyzz29_store(&sh[tid * 9], acc);
     __syncthreads();
     for (uint32_t o = 128; o > 0; o >>= 1) {
         if (tid < o) {
-            XYZZ x = xyzz_load(&sh[tid * 8]), y = xyzz_load(&sh[(tid + o) * 8]);
-            xyzz_store(&sh[tid * 8], xyzz_add(x, y));
+            XYZZ29 x = xyzz29_load(&sh[tid * 9]), y = xyzz29_load(&sh[(tid + o) * 9]);
+            xyzz29_store(&sh[tid * 9], xyzz29_add(x, y));
         }
         __syncthreads();
     }
-    return xyzz_load(&sh[0]);
+    return xyzz29_load(&sh[0]);
 }
 
 // Bucket reduction, step 1. The reference computes sum_k k*B_k with a serial running sum
 // (msm/mod.zig:423-432). Here  sum_k k*B_k = sum_b 2^b * T_b  with  T_b = sum_{k: bit b of k set} B_k;
 // block (x, b, g) tree-sums a slice of T_b of group g. Bucket index idx holds digit magnitude k = idx+1.
 __global__ void __launch_bounds__(256) msm_bitsum_kernel(const char *buckets, uint32_t NB, int c, char *out) {
-    __shared__ uint4 sh[256 * 8];
+    __shared__ uint4 sh[256 * 9];
     uint32_t b = blockIdx.y, g = blockIdx.z, PB = gridDim.x;
     uint32_t total = (b == (uint32_t)(c - 1)) ? 1u : NB / 2;
-    XYZZ acc = XYZZ::identity();
+    XYZZ29 acc = xyzz29_identity();
     for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < total; j += PB * 256) {
         uint32_t k = (b == (uint32_t)(c - 1)) ? NB : ((((j >> b) << 1) | 1u) << b) | (j & ((1u << b) - 1u));
-        acc = xyzz_add(acc, xyzz_load(buckets + 128 * ((size_t)g * NB + (k - 1))));
+        acc = xyzz29_add(acc, xyzz29_load(buckets + 144 * ((size_t)g * NB + (k - 1))));
     }
-    XYZZ r = block_sum_xyzz(acc, sh);
-    if (threadIdx.x == 0) xyzz_store(out + 128 * (((size_t)g * c + b) * PB + blockIdx.x), r);
+    XYZZ29 r = block_sum_xyzz29(acc, sh);
+    if (threadIdx.x == 0) xyzz29_store(out + 144 * (((size_t)g * c + b) * PB + blockIdx.x), r);
 }
 
 ZG_DEV void write_result(const XYZZ &acc, int mode, uint64_t *out_rec, uint8_t *out_inf) {
@@ -337,29 +337,29 @@ ZG_DEV void write_result(const XYZZ &acc, int mode, uint64_t *out_rec, uint8_t *
 // With a single group (full precompute) thread 0 goes straight on to toAffine (msm/mod.zig:178-189).
 __global__ void __launch_bounds__(256) msm_final_kernel(const char *bits, int c, int PB, int G, char *rg, int mode, uint64_t *out_rec,
                                                        uint8_t *out_inf) {
-    __shared__ uint4 sh[16 * 8];
+    __shared__ uint4 sh[16 * 9];
     uint32_t tid = threadIdx.x, g = blockIdx.x;
     uint32_t b = tid / 16, j = tid % 16;
-    XYZZ v = XYZZ::identity();
-    if (b < (uint32_t)c && j < (uint32_t)PB) v = xyzz_load(bits + 128 * (((size_t)g * c + b) * PB + j));
+    XYZZ29 v = xyzz29_identity();
+    if (b < (uint32_t)c && j < (uint32_t)PB) v = xyzz29_load(bits + 144 * (((size_t)g * c + b) * PB + j));
     for (int d = 1; d < 16; d <<= 1) {
-        XYZZ o = xyzz_shfl_down(v, d);
-        if ((j & (uint32_t)(2 * d - 1)) == 0) v = xyzz_add(v, o);
+        XYZZ29 o = xyzz29_shfl_down(v, d);
+        if ((j & (uint32_t)(2 * d - 1)) == 0) v = xyzz29_add(v, o);
     }
     if (j == 0) {
-        for (uint32_t i = 0; i < b; i++) v = xyzz_dbl(v);
-        xyzz_store(&sh[b * 8], v);
+        for (uint32_t i = 0; i < b; i++) v = xyzz29_dbl(v);
+        xyzz29_store(&sh[b * 9], v);
     }
     __syncthreads();
     for (uint32_t o = 8; o > 0; o >>= 1) {
         if (tid < o) {
-            XYZZ x = xyzz_load(&sh[tid * 8]), y = xyzz_load(&sh[(tid + o) * 8]);
-            xyzz_store(&sh[tid * 8], xyzz_add(x, y));
+            XYZZ29 x = xyzz29_load(&sh[tid * 9]), y = xyzz29_load(&sh[(tid + o) * 9]);
+            xyzz29_store(&sh[tid * 9], xyzz29_add(x, y));
         }
         __syncthreads();
     }
     if (tid != 0) return;
-    XYZZ r = xyzz_load(&sh[0]);
+    XYZZ r = xyzz29_to_std_val(xyzz29_load(&sh[0]));  // canonical Montgomery-2^256 from here on
     if (G == 1) write_result(r, mode, out_rec, out_inf);
     else xyzz_store(rg + 128 * (size_t)g, r);
 }
@@ -528,8 +528,8 @@ static int bases_create(const uint64_t *d_xy, const uint8_t *d_inf_in, size_t n,
         b->nblk = nblk < 1 ? 1 : (nblk > 256 ? 256 : nblk);
         ZG_ALLOC(b->d_blockhist, (size_t)b->nblk * p.NK * 4);
     }
-    ZG_ALLOC(b->d_partial, (size_t)p.NK * 128);
-    ZG_ALLOC(b->d_bits, (size_t)p.G * p.c * p.PB * 128);
+    ZG_ALLOC(b->d_partial, (size_t)p.NK * 144);
+    ZG_ALLOC(b->d_bits, (size_t)p.G * p.c * p.PB * 144);
     ZG_ALLOC(b->d_rg, (size_t)p.G * 128);
     ZG_ALLOC(b->d_out, 16 * 8);
     if (hipHostMalloc((void **)&b->h_out, 16 * 8) != hipSuccess) {
