@@ -53,12 +53,20 @@ struct zg_bases_s {
     char *d_table = nullptr;     // L * n * 64 B
     uint8_t *d_inf = nullptr;    // n B or null
     uint64_t *d_scal = nullptr;  // staging for host scalars, n * 32 B
-    uint32_t *d_dig = nullptr, *d_sorted = nullptr, *d_hist = nullptr, *d_starts = nullptr;
-    uint32_t *d_blockhist = nullptr;  // LDS sort path: nblk * NK per-block histograms / offsets
+    // One MSM in flight needs one workspace ("lane"). Several lanes let independent MSMs issued on different
+    // streams overlap: the latency-bound tail of one runs under the ALU-bound accumulation of the next.
+    struct Lane {
+        uint32_t *d_dig = nullptr, *d_sorted = nullptr, *d_hist = nullptr, *d_starts = nullptr;
+        uint32_t *d_blockhist = nullptr;  // LDS sort path: nblk * NK per-block histograms / offsets
+        char *d_partial = nullptr;        // NK * 144 B: bucket sums (lazy 29-bit-limb XYZZ records)
+        char *d_bits = nullptr;           // G * c * PB * 144 B: per-bit partial sums
+        char *d_rg = nullptr;             // G * 128 B: per-group results
+        hipEvent_t done = nullptr;        // recorded after the lane's last MSM; the next user waits on it
+        bool used = false;
+    };
+    std::vector<Lane> lanes;
+    size_t next_lane = 0;
     uint32_t nblk = 0;
-    char *d_partial = nullptr;  // NK * 144 B: bucket sums (lazy 29-bit-limb XYZZ records)
-    char *d_bits = nullptr;     // G * c * PB * 144 B: per-bit partial sums
-    char *d_rg = nullptr;       // G * 128 B: per-group results
     uint64_t *d_out = nullptr;  // 16 x u64: result record + flag
     uint64_t *h_out = nullptr;  // pinned mirror
     std::mutex mu;
@@ -480,10 +488,15 @@ static int make_plan(size_t n, const zg_msm_config *cfg, MsmPlan &p) {
 
 static void free_bases(zg_bases_s *b) {
     if (!b) return;
-    void *ptrs[] = {b->d_table, b->d_inf, b->d_scal, b->d_dig, b->d_sorted, b->d_hist, b->d_starts,
-                    b->d_partial, b->d_bits, b->d_rg, b->d_out, b->d_blockhist};
+    void *ptrs[] = {b->d_table, b->d_inf, b->d_scal, b->d_out};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    for (auto &ln : b->lanes) {
+        void *lp[] = {ln.d_dig, ln.d_sorted, ln.d_hist, ln.d_starts, ln.d_blockhist, ln.d_partial, ln.d_bits, ln.d_rg};
+        for (void *p : lp)
+            if (p) (void)hipFree(p);
+        if (ln.done) (void)hipEventDestroy(ln.done);
+    }
     if (b->h_out) (void)hipHostFree(b->h_out);
     delete b;
 }
@@ -519,18 +532,30 @@ static int bases_create(const uint64_t *d_xy, const uint8_t *d_inf_in, size_t n,
     }
     ZG_ALLOC(b->d_table, (size_t)p.L * n * 64);
     if (d_inf_in) ZG_ALLOC(b->d_inf, n);
-    ZG_ALLOC(b->d_dig, (size_t)p.W * n * 4);
-    ZG_ALLOC(b->d_sorted, (size_t)p.W * n * 4);
-    ZG_ALLOC(b->d_hist, (size_t)p.NK * 4);
-    ZG_ALLOC(b->d_starts, ((size_t)p.NK + 1) * 4);
-    if ((size_t)p.NK * 4 <= 128 * 1024 && env_int("ZG_MSM_LDS_SORT", 1)) {
+    int nlanes = env_int("ZG_MSM_LANES", 2);
+    if (nlanes < 1) nlanes = 1;
+    if (nlanes > 8) nlanes = 8;
+    bool lds_sort = (size_t)p.NK * 4 <= 128 * 1024 && env_int("ZG_MSM_LDS_SORT", 1);
+    if (lds_sort) {
         uint32_t nblk = (uint32_t)(n / 2048);
         b->nblk = nblk < 1 ? 1 : (nblk > 256 ? 256 : nblk);
-        ZG_ALLOC(b->d_blockhist, (size_t)b->nblk * p.NK * 4);
     }
-    ZG_ALLOC(b->d_partial, (size_t)p.NK * 144);
-    ZG_ALLOC(b->d_bits, (size_t)p.G * p.c * p.PB * 144);
-    ZG_ALLOC(b->d_rg, (size_t)p.G * 128);
+    b->lanes.resize(nlanes);
+    for (auto &ln : b->lanes) {
+        ZG_ALLOC(ln.d_dig, (size_t)p.W * n * 4);
+        ZG_ALLOC(ln.d_sorted, (size_t)p.W * n * 4);
+        ZG_ALLOC(ln.d_hist, (size_t)p.NK * 4);
+        ZG_ALLOC(ln.d_starts, ((size_t)p.NK + 1) * 4);
+        if (lds_sort) ZG_ALLOC(ln.d_blockhist, (size_t)b->nblk * p.NK * 4);
+        ZG_ALLOC(ln.d_partial, (size_t)p.NK * 144);
+        ZG_ALLOC(ln.d_bits, (size_t)p.G * p.c * p.PB * 144);
+        ZG_ALLOC(ln.d_rg, (size_t)p.G * 128);
+        if (hipEventCreateWithFlags(&ln.done, hipEventDisableTiming) != hipSuccess) {
+            set_error("hipEventCreate failed");
+            free_bases(b);
+            return ZG_ERR_HIP;
+        }
+    }
     ZG_ALLOC(b->d_out, 16 * 8);
     if (hipHostMalloc((void **)&b->h_out, 16 * 8) != hipSuccess) {
         set_error("hipHostMalloc failed");
@@ -599,42 +624,47 @@ static int msm_enqueue(zg_bases_s *b, size_t off, size_t n, const uint64_t *d_sc
         return ZG_OK;
     }
     const uint8_t *infp = b->d_inf ? b->d_inf + off : nullptr;
-    if (b->d_blockhist) {
+    zg_bases_s::Lane &ln = b->lanes[b->next_lane];
+    b->next_lane = (b->next_lane + 1) % b->lanes.size();
+    if (ln.used) ZG_HIP(hipStreamWaitEvent(st, ln.done, 0));  // the lane's previous MSM may be on another stream
+    ln.used = true;
+    if (ln.d_blockhist) {
         uint32_t nblk = b->nblk;
         while (nblk > 1 && (size_t)(nblk - 1) * 1024 >= n) nblk--;  // no empty blocks for short sub-range MSMs
         uint32_t per_block = (uint32_t)((n + nblk - 1) / nblk);
         prof_begin(ZG_PROF_MSM_DIGITS, st);
-        ZG_TRY(launch_digits_lds_c(p.c, st, d_scalars, infp, (uint32_t)n, p.G, per_block, p.NK, nblk, b->d_dig, b->d_blockhist));
+        ZG_TRY(launch_digits_lds_c(p.c, st, d_scalars, infp, (uint32_t)n, p.G, per_block, p.NK, nblk, ln.d_dig, ln.d_blockhist));
         prof_end(ZG_PROF_MSM_DIGITS, st);
         prof_begin(ZG_PROF_MSM_SORT, st);
-        hipLaunchKernelGGL(msm_colscan_kernel, dim3(div_up(p.NK, 256)), dim3(256), 0, st, b->d_blockhist, nblk, p.NK, b->d_hist);
-        hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(1024), 0, st, b->d_hist, b->d_starts, p.NK);
+        hipLaunchKernelGGL(msm_colscan_kernel, dim3(div_up(p.NK, 256)), dim3(256), 0, st, ln.d_blockhist, nblk, p.NK, ln.d_hist);
+        hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(1024), 0, st, ln.d_hist, ln.d_starts, p.NK);
         ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_scatter_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)(p.NK * 4)));
-        hipLaunchKernelGGL(msm_scatter_lds_kernel, dim3(nblk), dim3(1024), p.NK * 4, st, b->d_dig, (uint32_t)n, p.W, p.G, b->n,
-                           (uint32_t)off, per_block, p.NK, b->d_starts, b->d_blockhist, b->d_sorted);
+        hipLaunchKernelGGL(msm_scatter_lds_kernel, dim3(nblk), dim3(1024), p.NK * 4, st, ln.d_dig, (uint32_t)n, p.W, p.G, b->n,
+                           (uint32_t)off, per_block, p.NK, ln.d_starts, ln.d_blockhist, ln.d_sorted);
     } else {
         prof_begin(ZG_PROF_MSM_DIGITS, st);
-        ZG_HIP(hipMemsetAsync(b->d_hist, 0, (size_t)p.NK * 4, st));
-        ZG_TRY(launch_digits_c(p.c, st, d_scalars, infp, (uint32_t)n, p.G, b->d_dig, b->d_hist));
+        ZG_HIP(hipMemsetAsync(ln.d_hist, 0, (size_t)p.NK * 4, st));
+        ZG_TRY(launch_digits_c(p.c, st, d_scalars, infp, (uint32_t)n, p.G, ln.d_dig, ln.d_hist));
         prof_end(ZG_PROF_MSM_DIGITS, st);
         prof_begin(ZG_PROF_MSM_SORT, st);
-        hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(1024), 0, st, b->d_hist, b->d_starts, p.NK);
-        ZG_HIP(hipMemsetAsync(b->d_hist, 0, (size_t)p.NK * 4, st));
-        hipLaunchKernelGGL(msm_scatter_kernel, dim3(div_up(n, 256), p.W), dim3(256), 0, st, b->d_dig, (uint32_t)n, p.G, b->n,
-                           (uint32_t)off, b->d_starts, b->d_hist, b->d_sorted);
+        hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(1024), 0, st, ln.d_hist, ln.d_starts, p.NK);
+        ZG_HIP(hipMemsetAsync(ln.d_hist, 0, (size_t)p.NK * 4, st));
+        hipLaunchKernelGGL(msm_scatter_kernel, dim3(div_up(n, 256), p.W), dim3(256), 0, st, ln.d_dig, (uint32_t)n, p.G, b->n,
+                           (uint32_t)off, ln.d_starts, ln.d_hist, ln.d_sorted);
     }
     prof_end(ZG_PROF_MSM_SORT, st);
     prof_begin(ZG_PROF_MSM_ACCUMULATE, st);
-    hipLaunchKernelGGL(msm_accumulate_kernel, dim3(div_up((size_t)p.NK * p.S, 256)), dim3(256), 0, st, b->d_sorted, b->d_starts,
-                       b->d_table, p.NK, p.S, b->d_partial);
+    hipLaunchKernelGGL(msm_accumulate_kernel, dim3(div_up((size_t)p.NK * p.S, 256)), dim3(256), 0, st, ln.d_sorted, ln.d_starts,
+                       b->d_table, p.NK, p.S, ln.d_partial);
     prof_end(ZG_PROF_MSM_ACCUMULATE, st);
     prof_begin(ZG_PROF_MSM_REDUCE, st);
-    hipLaunchKernelGGL(msm_bitsum_kernel, dim3(p.PB, p.c, p.G), dim3(256), 0, st, b->d_partial, p.NB, p.c, b->d_bits);
-    hipLaunchKernelGGL(msm_final_kernel, dim3(p.G), dim3(256), 0, st, b->d_bits, p.c, p.PB, p.G, b->d_rg, mode, d_rec, d_inf_out);
-    if (p.G > 1) hipLaunchKernelGGL(msm_groups_kernel, dim3(1), dim3(1), 0, st, b->d_rg, p.G, p.c, mode, d_rec, d_inf_out);
+    hipLaunchKernelGGL(msm_bitsum_kernel, dim3(p.PB, p.c, p.G), dim3(256), 0, st, ln.d_partial, p.NB, p.c, ln.d_bits);
+    hipLaunchKernelGGL(msm_final_kernel, dim3(p.G), dim3(256), 0, st, ln.d_bits, p.c, p.PB, p.G, ln.d_rg, mode, d_rec, d_inf_out);
+    if (p.G > 1) hipLaunchKernelGGL(msm_groups_kernel, dim3(1), dim3(1), 0, st, ln.d_rg, p.G, p.c, mode, d_rec, d_inf_out);
     prof_end(ZG_PROF_MSM_REDUCE, st);
     ZG_HIP(hipGetLastError());
+    ZG_HIP(hipEventRecord(ln.done, st));
     return ZG_OK;
 }
 
