@@ -66,3 +66,32 @@ def test_field_kats(zl):
 def test_invalid_arguments(zl):
     with pytest.raises(zl.ZgError):
         zl.field_op(7, zl.OP_MUL, np.zeros((1, 4), dtype=np.uint64), np.zeros((1, 4), dtype=np.uint64))
+
+
+def test_lazy_29bit_limb_arithmetic(zl):
+    """csrc/fp29.hip.h (the MSM inner loop's representation): products, squares and a chain through every
+    biased subtraction and the exact zero test, on 2^20 random pairs plus edge values, against big ints."""
+    from oracle import binding as ob
+    from oracle import pymodel as pm
+    p = pm.P_MOD
+    n = 1 << 20
+    a_raw = U.random_raw256(909, n)
+    b_raw = U.random_raw256(910, n)
+    e = _edge_raw(p)
+    a_raw[: len(e)] = e
+    b_raw[: len(e)] = e[::-1]
+    a_raw[len(e): 2 * len(e)] = e
+    b_raw[len(e): 2 * len(e)] = e
+    a = ob.f_to_mont(ob.FP, a_raw)
+    b = ob.f_to_mont(ob.FP, b_raw)
+    assert np.array_equal(zl.field_op(1, zl.OP_MUL29, a, b), ob.f_mul(ob.FP, a, b))
+    assert np.array_equal(zl.field_op(1, zl.OP_SQR29, a, b), ob.f_sqr(ob.FP, a))
+    # chain: b^2 + b^3 - 8ab (see fp29_op_kernel)
+    b2 = ob.f_sqr(ob.FP, b)
+    b3 = ob.f_mul(ob.FP, b2, b)
+    ab = ob.f_mul(ob.FP, a, b)
+    eight = ob.f_from_u64(ob.FP, np.full(n, 8, dtype=np.uint64))
+    want = ob.f_sub(ob.FP, ob.f_add(ob.FP, b2, b3), ob.f_mul(ob.FP, eight, ab))
+    assert np.array_equal(zl.field_op(1, zl.OP_X3_29, a, b), want)
+    with pytest.raises(zl.ZgError):
+        zl.field_op(0, zl.OP_MUL29, a[:4], b[:4])  # Fp only

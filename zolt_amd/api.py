@@ -23,6 +23,8 @@ R_MOD = 218882428718392752222464057452572750885483644004160343436982041865758084
 P_MOD = 21888242871839275222246405745257275088696311157297823662689037894645226208583
 _M64 = (1 << 64) - 1
 _MONT_R = 1 << 256
+_RINV_R = pow(_MONT_R, -1, R_MOD)
+_RINV_P = pow(_MONT_R, -1, P_MOD)
 
 
 # ---- host scalar helpers (representation only)
@@ -40,7 +42,7 @@ def fr_from_int(v):
 
 
 def fr_to_int(l):
-    return _int(l) * pow(_MONT_R, -1, R_MOD) % R_MOD
+    return _int(l) * _RINV_R % R_MOD
 
 
 def fp_from_int(v):
@@ -48,7 +50,7 @@ def fp_from_int(v):
 
 
 def fp_to_int(l):
-    return _int(l) * pow(_MONT_R, -1, P_MOD) % P_MOD
+    return _int(l) * _RINV_P % P_MOD
 
 
 def generator():

@@ -106,11 +106,17 @@ __global__ void __launch_bounds__(256) sc_sums_kernel(const uint64_t *t, size_t 
 // fold by r and produce the NEXT round's two sums from the values just written:
 //   HIGH: out[i] = (1-r)*t[i] + r*t[i+half]     next g0 over i < half/2, g1 over i >= half/2
 //   LOW : out[i] = t[2i] + r*(t[2i+1]-t[2i])    next g0 over even i,     g1 over odd i
+struct FrArg {  // a challenge travels as a kernel argument: no H2D copy, no staging buffer to recycle
+    uint32_t l[8];
+};
+
 template <int LAYOUT>
-__global__ void __launch_bounds__(256) sc_fold_kernel(const uint64_t *t, size_t half, const uint64_t *r, uint64_t *out,
+__global__ void __launch_bounds__(256) sc_fold_kernel(const uint64_t *t, size_t half, FrArg r, uint64_t *out,
                                                       uint64_t *partials) {
     __shared__ uint4 sh[256 * 4];
-    Fr rv = fe_load<FrParams>(r);
+    Fr rv;
+#pragma unroll
+    for (int i = 0; i < 8; i++) rv.l[i] = r.l[i];
     Fr omr = fe_sub(Fr::one(), rv);
     Fr g0 = Fr::zero(), g1 = Fr::zero();
     size_t stride = (size_t)gridDim.x * 256;
@@ -160,26 +166,33 @@ static int launch_sums(int layout, const uint64_t *t, size_t len, uint64_t *part
     size_t half = len / 2;
     unsigned nb = sc_blocks(half);
     prof_begin(ZG_PROF_SC_SUMS, st);
+    uint64_t *dst = nb == 1 ? sums : partials;  // one block: its pair IS the result
     if (layout == ZG_SC_HIGH_HALF)
-        hipLaunchKernelGGL(sc_sums_kernel<ZG_SC_HIGH_HALF>, dim3(nb), dim3(256), 0, st, t, half, partials);
+        hipLaunchKernelGGL(sc_sums_kernel<ZG_SC_HIGH_HALF>, dim3(nb), dim3(256), 0, st, t, half, dst);
     else
-        hipLaunchKernelGGL(sc_sums_kernel<ZG_SC_LOW_PAIR>, dim3(nb), dim3(256), 0, st, t, half, partials);
-    hipLaunchKernelGGL(sc_finish_kernel, dim3(1), dim3(256), 0, st, partials, nb, sums);
+        hipLaunchKernelGGL(sc_sums_kernel<ZG_SC_LOW_PAIR>, dim3(nb), dim3(256), 0, st, t, half, dst);
+    if (nb > 1) hipLaunchKernelGGL(sc_finish_kernel, dim3(1), dim3(256), 0, st, partials, nb, sums);
     prof_end(ZG_PROF_SC_SUMS, st);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
 
-static int launch_fold(int layout, const uint64_t *t, size_t len, const uint64_t *d_r, uint64_t *out, uint64_t *partials,
+static int launch_fold(int layout, const uint64_t *t, size_t len, const uint64_t r[4], uint64_t *out, uint64_t *partials,
                        uint64_t *sums, hipStream_t st) {
     size_t half = len / 2;
     unsigned nb = sc_blocks(half);
+    FrArg ra;
+    for (int i = 0; i < 4; i++) {
+        ra.l[2 * i] = (uint32_t)r[i];
+        ra.l[2 * i + 1] = (uint32_t)(r[i] >> 32);
+    }
+    uint64_t *dst = nb == 1 ? sums : partials;
     prof_begin(ZG_PROF_SC_FOLD, st);
     if (layout == ZG_SC_HIGH_HALF)
-        hipLaunchKernelGGL(sc_fold_kernel<ZG_SC_HIGH_HALF>, dim3(nb), dim3(256), 0, st, t, half, d_r, out, partials);
+        hipLaunchKernelGGL(sc_fold_kernel<ZG_SC_HIGH_HALF>, dim3(nb), dim3(256), 0, st, t, half, ra, out, dst);
     else
-        hipLaunchKernelGGL(sc_fold_kernel<ZG_SC_LOW_PAIR>, dim3(nb), dim3(256), 0, st, t, half, d_r, out, partials);
-    hipLaunchKernelGGL(sc_finish_kernel, dim3(1), dim3(256), 0, st, partials, nb, sums);
+        hipLaunchKernelGGL(sc_fold_kernel<ZG_SC_LOW_PAIR>, dim3(nb), dim3(256), 0, st, t, half, ra, out, dst);
+    if (nb > 1) hipLaunchKernelGGL(sc_finish_kernel, dim3(1), dim3(256), 0, st, partials, nb, sums);
     prof_end(ZG_PROF_SC_FOLD, st);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
@@ -199,7 +212,7 @@ static int eq_table_enqueue(const uint64_t *r_host, size_t v, const uint64_t *sc
     if (scale_host) ZG_HIP(hipMemcpyAsync(d_r, scale_host, 32, hipMemcpyHostToDevice, st));
     prof_begin(ZG_PROF_EQ_TABLE, st);
     hipLaunchKernelGGL(eq_hi_kernel, dim3(div_up(n_hi, 256)), dim3(256), 0, st, d_r + 4, v_hi, scale_host ? d_r : nullptr, d_hi);
-    uint32_t hpb = n_hi / 2048 ? n_hi / 2048 : 1;
+    uint32_t hpb = n_hi / 512 ? n_hi / 512 : 1;  // rows per block: amortises the 8-mul low-table product of each thread
     hipLaunchKernelGGL(eq_main_kernel, dim3(div_up(n_hi, hpb)), dim3(256), 0, st, d_r + 4 + 4 * (size_t)v_hi, v_lo, d_hi, n_hi, hpb,
                        d_out);
     prof_end(ZG_PROF_EQ_TABLE, st);
@@ -217,8 +230,8 @@ struct zg_sc_s {
     size_t len = 0;
     uint64_t *buf[2] = {nullptr, nullptr};  // ping-pong tables (a fold cannot run in place across threads)
     int cur = 0;
-    uint64_t *d_partials = nullptr, *d_sums = nullptr, *d_r = nullptr;
-    uint64_t *h_pin = nullptr;  // 8 limbs out, 4 limbs in
+    uint64_t *d_partials = nullptr;
+    uint64_t *h_pin = nullptr;  // pinned, device-visible: the kernels write the round sums (8 limbs) straight to the host
     bool sums_valid = false;
     hipStream_t st = nullptr;
     std::mutex mu;
@@ -228,7 +241,7 @@ using namespace zg;
 
 static void sc_free(zg_sc_s *s) {
     if (!s) return;
-    void *ptrs[] = {s->buf[0], s->buf[1], s->d_partials, s->d_sums, s->d_r};
+    void *ptrs[] = {s->buf[0], s->buf[1], s->d_partials};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (s->h_pin) (void)hipHostFree(s->h_pin);
@@ -247,8 +260,6 @@ static int sc_create(size_t len, int layout, hipStream_t st, zg_sc_s **out) {
     hipError_t e = hipMalloc((void **)&s->buf[0], len * 32);
     if (e == hipSuccess) e = hipMalloc((void **)&s->buf[1], (len / 2 ? len / 2 : 1) * 32);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_partials, 2048 * 64);
-    if (e == hipSuccess) e = hipMalloc((void **)&s->d_sums, 64);
-    if (e == hipSuccess) e = hipMalloc((void **)&s->d_r, 32);
     if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_pin, 128);
     if (e != hipSuccess) {
         set_error(std::string("zg_sumcheck_open: ") + hipGetErrorString(e));
@@ -300,11 +311,10 @@ static int bind_host(int layout, const uint64_t *table, size_t len, const uint64
     uint64_t *d_t = nullptr, *d_o = nullptr, *d_misc = nullptr;
     ZG_HIP(hipMalloc((void **)&d_t, len * 32));
     ZG_HIP(hipMalloc((void **)&d_o, len / 2 * 32));
-    ZG_HIP(hipMalloc((void **)&d_misc, 2048 * 64 + 64 + 32));
-    uint64_t *d_sums = d_misc + 2048 * 8, *d_r = d_sums + 8;
+    ZG_HIP(hipMalloc((void **)&d_misc, 2048 * 64 + 64));
+    uint64_t *d_sums = d_misc + 2048 * 8;
     ZG_HIP(hipMemcpyAsync(d_t, table, len * 32, hipMemcpyHostToDevice, st));
-    ZG_HIP(hipMemcpyAsync(d_r, r, 32, hipMemcpyHostToDevice, st));
-    int rc = launch_fold(layout, d_t, len, d_r, d_o, d_misc, d_sums, st);
+    int rc = launch_fold(layout, d_t, len, r, d_o, d_misc, d_sums, st);
     if (rc == ZG_OK) {
         hipError_t e = hipMemcpyAsync(out, d_o, len / 2 * 32, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -416,11 +426,10 @@ int zg_sumcheck_round_sums(zg_sc_t s, uint64_t g0[4], uint64_t g1[4]) {
     }
     std::lock_guard<std::mutex> lk(s->mu);
     if (!s->sums_valid) {
-        ZG_TRY(launch_sums(s->layout, s->buf[s->cur], s->len, s->d_partials, s->d_sums, s->st));
+        ZG_TRY(launch_sums(s->layout, s->buf[s->cur], s->len, s->d_partials, s->h_pin, s->st));
         s->sums_valid = true;
     }
-    ZG_HIP(hipMemcpyAsync(s->h_pin, s->d_sums, 64, hipMemcpyDeviceToHost, s->st));
-    ZG_HIP(hipStreamSynchronize(s->st));
+    ZG_HIP(hipStreamSynchronize(s->st));  // the only host<->device rendezvous of a round
     for (int i = 0; i < 4; i++) {
         g0[i] = s->h_pin[i];
         g1[i] = s->h_pin[4 + i];
@@ -435,13 +444,9 @@ int zg_sumcheck_bind(zg_sc_t s, const uint64_t r[4]) {
         return ZG_ERR_INVALID;
     }
     std::lock_guard<std::mutex> lk(s->mu);
-    for (int i = 0; i < 4; i++) s->h_pin[8 + i] = r[i];
-    ZG_HIP(hipMemcpyAsync(s->d_r, s->h_pin + 8, 32, hipMemcpyHostToDevice, s->st));
     // buf[1] holds len/2 elements at most; after the first fold both buffers are large enough
     int nxt = s->cur ^ 1;
-    ZG_TRY(launch_fold(s->layout, s->buf[s->cur], s->len, s->d_r, s->buf[nxt], s->d_partials, s->d_sums, s->st));
-    // the pinned r buffer is reused by the next call: drain the copy before returning
-    ZG_HIP(hipStreamSynchronize(s->st));
+    ZG_TRY(launch_fold(s->layout, s->buf[s->cur], s->len, r, s->buf[nxt], s->d_partials, s->h_pin, s->st));  // asynchronous
     s->cur = nxt;
     s->len /= 2;
     s->sums_valid = s->len >= 2;
@@ -457,9 +462,9 @@ int zg_sumcheck_final(zg_sc_t s, uint64_t out[4]) {
         return ZG_ERR_INVALID;
     }
     std::lock_guard<std::mutex> lk(s->mu);
-    ZG_HIP(hipMemcpyAsync(s->h_pin, s->buf[s->cur], 32, hipMemcpyDeviceToHost, s->st));
+    ZG_HIP(hipMemcpyAsync(s->h_pin + 8, s->buf[s->cur], 32, hipMemcpyDeviceToHost, s->st));
     ZG_HIP(hipStreamSynchronize(s->st));
-    for (int i = 0; i < 4; i++) out[i] = s->h_pin[i];
+    for (int i = 0; i < 4; i++) out[i] = s->h_pin[8 + i];
     return ZG_OK;
 }
 

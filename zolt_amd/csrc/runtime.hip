@@ -5,6 +5,7 @@
 
 #include "common.hip.h"
 #include "field.hip.h"
+#include "fp29.hip.h"
 
 namespace zg {
 
@@ -63,6 +64,30 @@ void prof_end(int id, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------ field op kernel
+// self-test hooks for the lazy 29-bit-limb arithmetic: results come back in canonical form
+__global__ void __launch_bounds__(256) fp29_op_kernel(int op, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        F29 x = f29_from_fp(fe_load<FpParams>(a + 4 * i));
+        F29 y = f29_from_fp(fe_load<FpParams>(b + 4 * i));
+        F29 r;
+        if (op == ZG_OP_MUL29) r = f29_mul(x, y);
+        else if (op == ZG_OP_SQR29) r = f29_sqr(x);
+        else {
+            // ((x - y) [bias 2p] ... ) chain touching every biased subtraction and the zero test:
+            //   t = x^2 + 5p - y - 2*(x*y);  u = (t + 7p - t') with t' = sub4(x, y);  r = u * (2p - y) , zeroed if y == 0 mod p
+            F29 xy = f29_mul(x, y);
+            F29 t = f29_x3(f29_sqr(x), y, xy);
+            F29 t2 = f29_sub4(x, y);
+            F29 u = f29_sub7(t, f29_mul(t2, t2));
+            r = f29_mul(u, f29_neg2(y));
+            r = f29_sub2(r, f29_mul(f29_times2(x), f29_times3(y)));
+            if (f29_is_zero_modp(f29_sub2(y, f29_mul(y, f29_from_fp(Fp::one()))))) r = f29_sub4_2c(r, xy);
+        }
+        fe_store(out + 4 * i, f29_to_fp(r));
+    }
+}
+
 template <class P>
 __global__ void __launch_bounds__(256) field_op_kernel(int op, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n) {
     size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -178,8 +203,8 @@ int zg_profile_end(double ms_out[ZG_PROF_NKERNELS], uint64_t count_out[ZG_PROF_N
 
 int zg_field_op(int field, int op, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n) {
     ZG_INIT();
-    if (op < 0 || op > ZG_OP_INV_FAST || (field != ZG_FIELD_FR && field != ZG_FIELD_FP) || !a || !out ||
-        (op <= ZG_OP_SUB && !b)) {
+    if (op < 0 || op > ZG_OP_X3_29 || (op >= ZG_OP_MUL29 && field != ZG_FIELD_FP) || (field != ZG_FIELD_FR && field != ZG_FIELD_FP) || !a || !out ||
+        ((op <= ZG_OP_SUB || op >= ZG_OP_MUL29) && !b)) {
         set_error("zg_field_op: invalid argument");
         return ZG_ERR_INVALID;
     }
@@ -189,13 +214,15 @@ int zg_field_op(int field, int op, const uint64_t *a, const uint64_t *b, uint64_
     ZG_HIP(hipMalloc(&da, bytes));
     ZG_HIP(hipMalloc(&dout, bytes));
     ZG_HIP(hipMemcpyAsync(da, a, bytes, hipMemcpyHostToDevice, g_stream));
-    if (op <= ZG_OP_SUB) {
+    if (op <= ZG_OP_SUB || op >= ZG_OP_MUL29) {
         ZG_HIP(hipMalloc(&db, bytes));
         ZG_HIP(hipMemcpyAsync(db, b, bytes, hipMemcpyHostToDevice, g_stream));
     }
     unsigned blocks = div_up(n, 256);
     if (blocks > 4096) blocks = 4096;
-    if (field == ZG_FIELD_FR)
+    if (op >= ZG_OP_MUL29)
+        hipLaunchKernelGGL(fp29_op_kernel, dim3(blocks), dim3(256), 0, g_stream, op, da, db, dout, n);
+    else if (field == ZG_FIELD_FR)
         hipLaunchKernelGGL(field_op_kernel<FrParams>, dim3(blocks), dim3(256), 0, g_stream, op, da, db, dout, n);
     else
         hipLaunchKernelGGL(field_op_kernel<FpParams>, dim3(blocks), dim3(256), 0, g_stream, op, da, db, dout, n);
