@@ -15,7 +15,8 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > $OU
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $OUT/pmc_sq -- $BENCH > $OUT/pmc_sq.log 2>&1
 cd $OUT
-python3 $ROOT/tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
+echo "# bench command: $BENCH" > $OUT/summary.txt
+grep -h '^{' $OUT/trace.log | tail -1 >> $OUT/summary.txt
+python3 $ROOT/tools/summarize_prof.py $OUT >> $OUT/summary.txt 2>&1
 find $OUT -name "*.csv" -size +2M -delete
-ls -R $OUT | head -50
-tail -3 $OUT/trace.log
+tail -3 $OUT/trace.log | cut -c1-300

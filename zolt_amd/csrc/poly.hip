@@ -12,6 +12,7 @@
 // gives the reference's bytes (sums of field elements commute; eq(r,x) is one field value
 // however its factors are grouped).
 #include <mutex>
+#include <vector>
 
 #include "common.hip.h"
 #include "field.hip.h"
@@ -234,6 +235,7 @@ struct zg_sc_s {
     uint64_t *h_pin = nullptr;  // pinned, device-visible: the kernels write the round sums (8 limbs) straight to the host
     bool sums_valid = false;
     hipStream_t st = nullptr;
+    size_t cap = 0;  // elements buf[0] can hold (sessions are pooled: hipMalloc/hipFree cost more than a round)
     std::mutex mu;
 };
 
@@ -248,12 +250,28 @@ static void sc_free(zg_sc_s *s) {
     delete s;
 }
 
+static std::mutex g_pool_mu;
+static std::vector<zg_sc_s *> g_pool;  // closed sessions kept for reuse (at most 4)
+
 static int sc_create(size_t len, int layout, hipStream_t st, zg_sc_s **out) {
     if (len == 0 || (len & (len - 1)) || (layout != ZG_SC_HIGH_HALF && layout != ZG_SC_LOW_PAIR)) {
         set_error("zg_sumcheck_open: len must be a power of two and layout valid");
         return ZG_ERR_INVALID;
     }
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (size_t i = 0; i < g_pool.size(); i++) {
+            if (g_pool[i]->cap >= len && g_pool[i]->cap <= 4 * len) {
+                zg_sc_s *s = g_pool[i];
+                g_pool.erase(g_pool.begin() + i);
+                s->layout = layout; s->len = len; s->st = st; s->cur = 0; s->sums_valid = false;
+                *out = s;
+                return ZG_OK;
+            }
+        }
+    }
     zg_sc_s *s = new zg_sc_s();
+    s->cap = len;
     s->layout = layout;
     s->len = len;
     s->st = st;
@@ -484,6 +502,13 @@ int zg_sumcheck_close(zg_sc_t s) {
     if (!s) return ZG_OK;
     ZG_INIT();
     (void)hipStreamSynchronize(s->st);
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if (g_pool.size() < 4) {
+            g_pool.push_back(s);
+            return ZG_OK;
+        }
+    }
     sc_free(s);
     return ZG_OK;
 }
