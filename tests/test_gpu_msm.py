@@ -230,3 +230,27 @@ def test_full_size_closed_form(zl, ob, logn):
     # raw values may exceed r: the scalar is raw mod r
     want = pm.ec_mul(tot % pm.R_MOD, pm.G1)
     assert U.point_from_xy(got, ginf) == want
+
+
+@pytest.mark.parametrize("kind", ["boolean", "bytes", "all_equal", "one_hot_bucket", "mixed"])
+def test_skewed_scalar_distributions(zl, ob, gm, kind):
+    """Real witness columns are not uniform: 0/1 flags, bytes, constants. The chunk-scheduled accumulate must
+    give the oracle's bytes whatever the bucket-size skew (heavy buckets go through the block-tree stages)."""
+    n = 1 << 16
+    rng = np.random.default_rng(77)
+    if kind == "boolean":
+        vals = rng.integers(0, 2, size=n)
+    elif kind == "bytes":
+        vals = rng.integers(0, 256, size=n)
+    elif kind == "all_equal":
+        vals = np.full(n, 0x1234)
+    elif kind == "one_hot_bucket":
+        vals = np.where(rng.integers(0, 10, size=n) == 0, rng.integers(0, 1 << 30, size=n), 7)
+    else:
+        vals = rng.integers(0, 1 << 62, size=n)
+    sc = ob.f_from_u64(ob.FR, vals.astype(np.uint64))
+    if kind == "mixed":  # a few full-width scalars and negated small ones on top
+        sc[::17] = _scalars(ob, 99, len(sc[::17]))
+        sc[5::29] = ob.f_neg(ob.FR, sc[5::29])
+    _check(zl, ob, gm[:n], None, sc)
+    _check(zl, ob, gm[:n], None, sc, window_bits=13, precompute_levels=1)

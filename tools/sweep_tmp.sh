@@ -1,8 +1,5 @@
-export TMPDIR=/tmp
-ROOT=$(pwd)
-mkdir -p $ROOT/gpurun_out/prof_sc
-cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_sc/trace -- python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $ROOT/gpurun_out/prof_sc/trace.log 2>&1
-cd $ROOT
-python3 tools/summarize_prof.py gpurun_out/prof_sc | cut -c1-160 | head -40
-find gpurun_out/prof_sc -name "*.csv" -size +2M -delete
+python -m pytest tests/test_gpu_msm.py -m gpu -x -q 2>&1 | tail -5
+for SCHED in 1 0; do
+  echo "chunk_sched=$SCHED: $(ZG_MSM_CHUNK_SCHED=$SCHED python bench.py --steps 10 --warmup 2 --streams 1 --no-cpu-baseline --no-extra 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value'],1), round(d['ms_per_step'],3), d['extra']['kernel_ms_per_msm'])")"
+done
+echo "streams2: $(python bench.py --steps 20 --warmup 3 --streams 2 --no-cpu-baseline --no-extra 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value'],1), round(d['ms_per_step'],3), d['extra']['kernel_ms_per_msm'])")"

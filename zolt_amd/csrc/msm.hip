@@ -43,6 +43,7 @@ struct MsmPlan {
     uint32_t NB;   // buckets per group = 2^(c-1)
     uint32_t NK;   // total buckets = G * NB
     int PB;        // bit-sum partial blocks per (group, bit)
+    uint32_t NT;   // chunk-scheduled accumulate: threads (0 = per-bucket scheduling)
 };
 
 }  // namespace zg
@@ -61,6 +62,11 @@ struct zg_bases_s {
         char *d_partial = nullptr;        // NK * 144 B: bucket sums (lazy 29-bit-limb XYZZ records)
         char *d_bits = nullptr;           // G * c * PB * 144 B: per-bit partial sums
         char *d_rg = nullptr;             // G * 128 B: per-group results
+        uint32_t *d_nzrank = nullptr;     // NK + 1: non-empty buckets before k
+        char *d_part = nullptr;           // (NT + NK) * 144 B: per-(chunk, bucket-run) partial sums
+        char *d_part2 = nullptr;          // heavy-bucket stage-A partials
+        uint32_t *d_heavy = nullptr;      // NK: heavy bucket list
+        void *d_state = nullptr;          // MsmState
         hipEvent_t done = nullptr;        // recorded after the lane's last MSM; the next user waits on it
         bool used = false;
     };
@@ -129,27 +135,39 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint64_t *scalars
 }
 
 // exclusive scan of the bucket histogram (NK <= 2^21 entries), one block
-__global__ void __launch_bounds__(1024) msm_scan_kernel(const uint32_t *hist, uint32_t *starts, uint32_t NK) {
-    __shared__ uint32_t sh[1024];
+__global__ void __launch_bounds__(1024) msm_scan_kernel(const uint32_t *hist, uint32_t *starts, uint32_t *nzrank, uint32_t NK) {
+    __shared__ uint32_t sh[1024], shz[1024];
     uint32_t tid = threadIdx.x;
     uint32_t per = (NK + 1023) / 1024;
     uint32_t b = tid * per, e = b + per < NK ? b + per : NK;
-    uint32_t sum = 0;
-    for (uint32_t k = b; k < e; k++) sum += hist[k];
+    uint32_t sum = 0, nz = 0;
+    for (uint32_t k = b; k < e; k++) {
+        uint32_t h = hist[k];
+        sum += h;
+        nz += h ? 1u : 0u;
+    }
     sh[tid] = sum;
+    shz[tid] = nz;
     __syncthreads();
     for (uint32_t o = 1; o < 1024; o <<= 1) {
-        uint32_t v = tid >= o ? sh[tid - o] : 0;
+        uint32_t v = tid >= o ? sh[tid - o] : 0, z = tid >= o ? shz[tid - o] : 0;
         __syncthreads();
         sh[tid] += v;
+        shz[tid] += z;
         __syncthreads();
     }
-    uint32_t run = sh[tid] - sum;
+    uint32_t run = sh[tid] - sum, runz = shz[tid] - nz;
     for (uint32_t k = b; k < e; k++) {
+        uint32_t h = hist[k];
         starts[k] = run;
-        run += hist[k];
+        nzrank[k] = runz;  // number of non-empty buckets before k
+        run += h;
+        runz += h ? 1u : 0u;
     }
-    if (tid == 1023) starts[NK] = sh[1023];
+    if (tid == 1023) {
+        starts[NK] = sh[1023];
+        nzrank[NK] = shz[1023];
+    }
 }
 
 // counting-sort scatter; order inside a bucket is irrelevant (group sums commute).
@@ -293,6 +311,87 @@ __global__ void __launch_bounds__(256) msm_accumulate_kernel(const uint32_t *sor
     if (key < NK && s == 0) xyzz29_store(buckets + 144 * (size_t)key, acc);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Skew-robust scheduling of the bucket accumulation. The kernel above gives every bucket S lanes, which
+// is perfectly balanced for uniform scalars and pathological for real witness columns (a 0/1 column puts
+// half of all points into ONE bucket). Here the sorted reference list is cut into NT equal chunks
+// instead, one per thread, whatever the bucket sizes; a thread emits one partial sum per bucket run it
+// crosses, at slot  chunk + (number of non-empty buckets before the run's bucket)  — unique and, for one
+// bucket, contiguous. Buckets with few partials are finished by one thread each; "heavy" buckets
+// (more than 8 partials) go through two block-level tree stages.
+struct MsmState {
+    uint32_t nheavy;
+    uint32_t pad[3];
+};
+
+ZG_DEV uint32_t chunk_len(uint32_t total, uint32_t NT) {
+    uint32_t C = (total + NT - 1) / NT;
+    return C ? C : 1;
+}
+
+__global__ void __launch_bounds__(256) msm_accumulate_chunk_kernel(const uint32_t *sorted, const uint32_t *starts, const uint32_t *nzrank,
+                                                                   const char *table, uint32_t NK, uint32_t NT, char *part) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    uint32_t total = starts[NK];
+    uint32_t C = chunk_len(total, NT);
+    uint64_t a64 = (uint64_t)i * C;
+    if (i >= NT || a64 >= total) return;
+    uint32_t a = (uint32_t)a64, b = a + C < total ? a + C : total;
+    // bucket of entry a: starts[k] <= a < starts[k+1]
+    uint32_t lo = 0, hi = NK;  // invariant: starts[lo] <= a < starts[hi]
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (starts[mid] <= a) lo = mid; else hi = mid;
+    }
+    uint32_t k = lo, kend = starts[k + 1];
+    XYZZ29 acc;
+    bool acc_inf = true;
+    uint32_t e = sorted[a];
+    Affine cur = affine_load(table + 64 * (size_t)(e & 0x7FFFFFFFu));  // packed lazy-form row
+    uint32_t cneg = e >> 31;
+    for (uint32_t p = a; p < b; p++) {
+        Affine nxt = cur;
+        uint32_t nneg = 0;
+        if (p + 1 < b) {  // prefetch the next row under the current add
+            uint32_t e2 = sorted[p + 1];
+            nxt = affine_load(table + 64 * (size_t)(e2 & 0x7FFFFFFFu));
+            nneg = e2 >> 31;
+        }
+        if (p == kend) {  // the run of bucket k ended inside this chunk: emit its partial, move on
+            xyzz29_store(part + 144 * (size_t)(i + nzrank[k]), acc_inf ? xyzz29_identity() : acc);
+            acc_inf = true;
+            do { k++; kend = starts[k + 1]; } while (kend <= p);
+        }
+        F29 px = f29_unpack(cur.x.l), py = f29_unpack(cur.y.l);
+        if (cneg) py = f29_neg2(py);
+        xyzz29_madd(acc, acc_inf, px, py);
+        cur = nxt;
+        cneg = nneg;
+    }
+    xyzz29_store(part + 144 * (size_t)(i + nzrank[k]), acc_inf ? xyzz29_identity() : acc);
+}
+
+// one thread per bucket: sum its (few) partials; queue heavy buckets
+__global__ void __launch_bounds__(64) msm_bucket_combine_kernel(const char *part, const uint32_t *starts, const uint32_t *nzrank, uint32_t NK,
+                                                                uint32_t NT, char *buckets, uint32_t *heavy_list, MsmState *st) {
+    uint32_t k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= NK) return;
+    uint32_t C = chunk_len(starts[NK], NT);
+    uint32_t s0 = starts[k], s1 = starts[k + 1];
+    if (s1 == s0) {
+        xyzz29_store(buckets + 144 * (size_t)k, xyzz29_identity());
+        return;
+    }
+    uint32_t q0 = s0 / C, q1 = (s1 - 1) / C, cnt = q1 - q0 + 1, base = q0 + nzrank[k];
+    if (cnt > 8) {
+        heavy_list[atomicAdd(&st->nheavy, 1u)] = k;
+        return;
+    }
+    XYZZ29 acc = xyzz29_load(part + 144 * (size_t)base);
+    for (uint32_t j = 1; j < cnt; j++) acc = xyzz29_add(acc, xyzz29_load(part + 144 * (size_t)(base + j)));
+    xyzz29_store(buckets + 144 * (size_t)k, acc);
+}
+
 // block-wide sum of lazy XYZZ points through LDS (256 threads x 144 B); result returned to every thread
 __device__ __forceinline__ XYZZ29 block_sum_xyzz29(const XYZZ29 &acc, uint4 *sh) {
     uint32_t tid = threadIdx.x;
@@ -306,6 +405,56 @@ __device__ __forceinline__ XYZZ29 block_sum_xyzz29(const XYZZ29 &acc, uint4 *sh)
         __syncthreads();
     }
     return xyzz29_load(&sh[0]);
+}
+
+static constexpr uint32_t HEAVY_BLOCK_ITEMS = 2048;
+
+// heavy stage A: block b owns partial slots [2048 b, 2048 (b+1)); every run of a heavy bucket inside is
+// tree-summed by the whole block into part2[b + nzrank[k]]
+__global__ void __launch_bounds__(256) msm_heavy_a_kernel(const char *part, const uint32_t *starts, const uint32_t *nzrank, uint32_t NK,
+                                                         uint32_t NT, char *part2, const MsmState *st) {
+    __shared__ uint4 sh[256 * 9];
+    if (st->nheavy == 0) return;
+    uint32_t C = chunk_len(starts[NK], NT);
+    uint32_t lo_slot = blockIdx.x * HEAVY_BLOCK_ITEMS, hi_slot = lo_slot + HEAVY_BLOCK_ITEMS;
+    // first bucket whose slot range can reach lo_slot: base(k) = starts[k]/C + nzrank[k] is non-decreasing in k
+    uint32_t lo = 0, hi = NK;
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (starts[mid] / C + nzrank[mid] <= lo_slot) lo = mid; else hi = mid;
+    }
+    for (uint32_t k = lo; k < NK; k++) {
+        uint32_t s0 = starts[k], s1 = starts[k + 1];
+        if (s1 == s0) continue;
+        uint32_t q0 = s0 / C, q1 = (s1 - 1) / C, cnt = q1 - q0 + 1, base = q0 + nzrank[k];
+        if (base >= hi_slot) break;
+        if (cnt <= 8 || base + cnt <= lo_slot) continue;
+        uint32_t r0 = base > lo_slot ? base : lo_slot, r1 = base + cnt < hi_slot ? base + cnt : hi_slot;
+        XYZZ29 acc = xyzz29_identity();
+        for (uint32_t j = r0 + threadIdx.x; j < r1; j += 256) acc = xyzz29_add(acc, xyzz29_load(part + 144 * (size_t)j));
+        XYZZ29 r = block_sum_xyzz29(acc, sh);
+        if (threadIdx.x == 0) xyzz29_store(part2 + 144 * (size_t)(blockIdx.x + nzrank[k]), r);
+        __syncthreads();
+    }
+}
+
+// heavy stage B: one block per heavy bucket sums its stage-A partials (at most a few dozen)
+__global__ void __launch_bounds__(256) msm_heavy_b_kernel(const char *part2, const uint32_t *starts, const uint32_t *nzrank, uint32_t NK,
+                                                         uint32_t NT, const uint32_t *heavy_list, const MsmState *st, char *buckets) {
+    __shared__ uint4 sh[256 * 9];
+    uint32_t nheavy = st->nheavy;
+    uint32_t C = chunk_len(starts[NK], NT);
+    for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
+        uint32_t k = heavy_list[h];
+        uint32_t s0 = starts[k], s1 = starts[k + 1];
+        uint32_t q0 = s0 / C, q1 = (s1 - 1) / C, cnt = q1 - q0 + 1, base = q0 + nzrank[k];
+        uint32_t b0 = base / HEAVY_BLOCK_ITEMS, b1 = (base + cnt - 1) / HEAVY_BLOCK_ITEMS;
+        XYZZ29 acc = xyzz29_identity();
+        for (uint32_t bb = b0 + threadIdx.x; bb <= b1; bb += 256) acc = xyzz29_add(acc, xyzz29_load(part2 + 144 * (size_t)(bb + nzrank[k])));
+        XYZZ29 r = block_sum_xyzz29(acc, sh);
+        if (threadIdx.x == 0) xyzz29_store(buckets + 144 * (size_t)k, r);
+        __syncthreads();
+    }
 }
 
 // Bucket reduction, step 1. The reference computes sum_k k*B_k with a serial running sum
@@ -480,6 +629,14 @@ static int make_plan(size_t n, const zg_msm_config *cfg, MsmPlan &p) {
         set_error("msm: slices per bucket must be a power of two <= 64");
         return ZG_ERR_INVALID;
     }
+    // chunk-scheduled accumulate: enough threads to fill 2 waves per SIMD on 256 CUs, fewer for small inputs
+    p.NT = 0;
+    if (env_int("ZG_MSM_CHUNK_SCHED", 1)) {
+        uint64_t want = ((uint64_t)n * p.W) / 16;
+        uint32_t nt = 1024;
+        while (nt < want && nt < 131072u) nt <<= 1;
+        p.NT = (uint32_t)env_int("ZG_MSM_CHUNK_THREADS", (int)nt);
+    }
     // bit-sum partial blocks: ~4 buckets per thread, at most 16 (the final kernel reduces 16 lanes per bit)
     int pb = (int)(p.NB / 2 / (256 * 4));
     p.PB = pb < 1 ? 1 : (pb > 16 ? 16 : pb);
@@ -492,7 +649,8 @@ static void free_bases(zg_bases_s *b) {
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &ln : b->lanes) {
-        void *lp[] = {ln.d_dig, ln.d_sorted, ln.d_hist, ln.d_starts, ln.d_blockhist, ln.d_partial, ln.d_bits, ln.d_rg};
+        void *lp[] = {ln.d_dig, ln.d_sorted, ln.d_hist, ln.d_starts, ln.d_blockhist, ln.d_partial, ln.d_bits, ln.d_rg,
+                      ln.d_nzrank, ln.d_part, ln.d_part2, ln.d_heavy, ln.d_state};
         for (void *p : lp)
             if (p) (void)hipFree(p);
         if (ln.done) (void)hipEventDestroy(ln.done);
@@ -550,6 +708,14 @@ static int bases_create(const uint64_t *d_xy, const uint8_t *d_inf_in, size_t n,
         ZG_ALLOC(ln.d_partial, (size_t)p.NK * 144);
         ZG_ALLOC(ln.d_bits, (size_t)p.G * p.c * p.PB * 144);
         ZG_ALLOC(ln.d_rg, (size_t)p.G * 128);
+        ZG_ALLOC(ln.d_nzrank, ((size_t)p.NK + 1) * 4);
+        if (p.NT) {
+            size_t slots = (size_t)p.NT + p.NK;
+            ZG_ALLOC(ln.d_part, slots * 144);
+            ZG_ALLOC(ln.d_part2, (slots / HEAVY_BLOCK_ITEMS + 1 + p.NK) * 144);
+            ZG_ALLOC(ln.d_heavy, (size_t)p.NK * 4);
+            ZG_ALLOC(ln.d_state, sizeof(MsmState));
+        }
         if (hipEventCreateWithFlags(&ln.done, hipEventDisableTiming) != hipSuccess) {
             set_error("hipEventCreate failed");
             free_bases(b);
@@ -637,7 +803,7 @@ static int msm_enqueue(zg_bases_s *b, size_t off, size_t n, const uint64_t *d_sc
         prof_end(ZG_PROF_MSM_DIGITS, st);
         prof_begin(ZG_PROF_MSM_SORT, st);
         hipLaunchKernelGGL(msm_colscan_kernel, dim3(div_up(p.NK, 256)), dim3(256), 0, st, ln.d_blockhist, nblk, p.NK, ln.d_hist);
-        hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(1024), 0, st, ln.d_hist, ln.d_starts, p.NK);
+        hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(1024), 0, st, ln.d_hist, ln.d_starts, ln.d_nzrank, p.NK);
         ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_scatter_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)(p.NK * 4)));
         hipLaunchKernelGGL(msm_scatter_lds_kernel, dim3(nblk), dim3(1024), p.NK * 4, st, ln.d_dig, (uint32_t)n, p.W, p.G, b->n,
@@ -648,15 +814,28 @@ static int msm_enqueue(zg_bases_s *b, size_t off, size_t n, const uint64_t *d_sc
         ZG_TRY(launch_digits_c(p.c, st, d_scalars, infp, (uint32_t)n, p.G, ln.d_dig, ln.d_hist));
         prof_end(ZG_PROF_MSM_DIGITS, st);
         prof_begin(ZG_PROF_MSM_SORT, st);
-        hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(1024), 0, st, ln.d_hist, ln.d_starts, p.NK);
+        hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(1024), 0, st, ln.d_hist, ln.d_starts, ln.d_nzrank, p.NK);
         ZG_HIP(hipMemsetAsync(ln.d_hist, 0, (size_t)p.NK * 4, st));
         hipLaunchKernelGGL(msm_scatter_kernel, dim3(div_up(n, 256), p.W), dim3(256), 0, st, ln.d_dig, (uint32_t)n, p.G, b->n,
                            (uint32_t)off, ln.d_starts, ln.d_hist, ln.d_sorted);
     }
     prof_end(ZG_PROF_MSM_SORT, st);
     prof_begin(ZG_PROF_MSM_ACCUMULATE, st);
-    hipLaunchKernelGGL(msm_accumulate_kernel, dim3(div_up((size_t)p.NK * p.S, 256)), dim3(256), 0, st, ln.d_sorted, ln.d_starts,
-                       b->d_table, p.NK, p.S, ln.d_partial);
+    if (p.NT) {
+        ZG_HIP(hipMemsetAsync(ln.d_state, 0, sizeof(MsmState), st));
+        hipLaunchKernelGGL(msm_accumulate_chunk_kernel, dim3(div_up(p.NT, 256)), dim3(256), 0, st, ln.d_sorted, ln.d_starts, ln.d_nzrank,
+                           b->d_table, p.NK, p.NT, ln.d_part);
+        hipLaunchKernelGGL(msm_bucket_combine_kernel, dim3(div_up(p.NK, 64)), dim3(64), 0, st, ln.d_part, ln.d_starts, ln.d_nzrank, p.NK,
+                           p.NT, ln.d_partial, ln.d_heavy, reinterpret_cast<MsmState *>(ln.d_state));
+        uint32_t nblk_a = (p.NT + p.NK) / HEAVY_BLOCK_ITEMS + 1;
+        hipLaunchKernelGGL(msm_heavy_a_kernel, dim3(nblk_a), dim3(256), 0, st, ln.d_part, ln.d_starts, ln.d_nzrank, p.NK, p.NT, ln.d_part2,
+                           reinterpret_cast<const MsmState *>(ln.d_state));
+        hipLaunchKernelGGL(msm_heavy_b_kernel, dim3(64), dim3(256), 0, st, ln.d_part2, ln.d_starts, ln.d_nzrank, p.NK, p.NT, ln.d_heavy,
+                           reinterpret_cast<const MsmState *>(ln.d_state), ln.d_partial);
+    } else {
+        hipLaunchKernelGGL(msm_accumulate_kernel, dim3(div_up((size_t)p.NK * p.S, 256)), dim3(256), 0, st, ln.d_sorted, ln.d_starts,
+                           b->d_table, p.NK, p.S, ln.d_partial);
+    }
     prof_end(ZG_PROF_MSM_ACCUMULATE, st);
     prof_begin(ZG_PROF_MSM_REDUCE, st);
     hipLaunchKernelGGL(msm_bitsum_kernel, dim3(p.PB, p.c, p.G), dim3(256), 0, st, ln.d_partial, p.NB, p.c, ln.d_bits);
