@@ -63,6 +63,7 @@ struct zg_bases_s {
         char *d_bits = nullptr;           // G * c * PB * 144 B: per-bit partial sums
         char *d_rg = nullptr;             // G * 128 B: per-group results
         uint32_t *d_nzrank = nullptr;     // NK + 1: non-empty buckets before k
+        uint32_t *d_nzlist = nullptr;     // NK: the non-empty buckets, compacted
         char *d_part = nullptr;           // (NT + NK) * 144 B: per-(chunk, bucket-run) partial sums
         char *d_part2 = nullptr;          // heavy-bucket stage-A partials
         uint32_t *d_heavy = nullptr;      // NK: heavy bucket list
@@ -135,7 +136,8 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint64_t *scalars
 }
 
 // exclusive scan of the bucket histogram (NK <= 2^21 entries), one block
-__global__ void __launch_bounds__(1024) msm_scan_kernel(const uint32_t *hist, uint32_t *starts, uint32_t *nzrank, uint32_t NK) {
+__global__ void __launch_bounds__(1024) msm_scan_kernel(const uint32_t *hist, uint32_t *starts, uint32_t *nzrank, uint32_t *nzlist,
+                                                        uint32_t NK) {
     __shared__ uint32_t sh[1024], shz[1024];
     uint32_t tid = threadIdx.x;
     uint32_t per = (NK + 1023) / 1024;
@@ -161,6 +163,7 @@ __global__ void __launch_bounds__(1024) msm_scan_kernel(const uint32_t *hist, ui
         uint32_t h = hist[k];
         starts[k] = run;
         nzrank[k] = runz;  // number of non-empty buckets before k
+        if (h) nzlist[runz] = k;  // compacted list of the non-empty buckets
         run += h;
         runz += h ? 1u : 0u;
     }
@@ -330,7 +333,8 @@ ZG_DEV uint32_t chunk_len(uint32_t total, uint32_t NT) {
 }
 
 __global__ void __launch_bounds__(256) msm_accumulate_chunk_kernel(const uint32_t *sorted, const uint32_t *starts, const uint32_t *nzrank,
-                                                                   const char *table, uint32_t NK, uint32_t NT, char *part) {
+                                                                   const uint32_t *nzlist, const char *table, uint32_t NK, uint32_t NT,
+                                                                   char *part) {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     uint32_t total = starts[NK];
     uint32_t C = chunk_len(total, NT);
@@ -343,7 +347,7 @@ __global__ void __launch_bounds__(256) msm_accumulate_chunk_kernel(const uint32_
         uint32_t mid = (lo + hi) >> 1;
         if (starts[mid] <= a) lo = mid; else hi = mid;
     }
-    uint32_t k = lo, kend = starts[k + 1];
+    uint32_t r = nzrank[lo], kend = starts[lo + 1];  // r-th non-empty bucket; nzlist[r] == lo
     XYZZ29 acc;
     bool acc_inf = true;
     uint32_t e = sorted[a];
@@ -358,9 +362,10 @@ __global__ void __launch_bounds__(256) msm_accumulate_chunk_kernel(const uint32_
             nneg = e2 >> 31;
         }
         if (p == kend) {  // the run of bucket k ended inside this chunk: emit its partial, move on
-            xyzz29_store(part + 144 * (size_t)(i + nzrank[k]), acc_inf ? xyzz29_identity() : acc);
+            xyzz29_store(part + 144 * (size_t)(i + r), acc_inf ? xyzz29_identity() : acc);
             acc_inf = true;
-            do { k++; kend = starts[k + 1]; } while (kend <= p);
+            r++;  // next non-empty bucket (p < total, so it exists); empty buckets are never walked
+            kend = starts[nzlist[r] + 1];
         }
         F29 px = f29_unpack(cur.x.l), py = f29_unpack(cur.y.l);
         if (cneg) py = f29_neg2(py);
@@ -368,7 +373,7 @@ __global__ void __launch_bounds__(256) msm_accumulate_chunk_kernel(const uint32_
         cur = nxt;
         cneg = nneg;
     }
-    xyzz29_store(part + 144 * (size_t)(i + nzrank[k]), acc_inf ? xyzz29_identity() : acc);
+    xyzz29_store(part + 144 * (size_t)(i + r), acc_inf ? xyzz29_identity() : acc);
 }
 
 // one thread per bucket: sum its (few) partials; queue heavy buckets
@@ -411,29 +416,29 @@ static constexpr uint32_t HEAVY_BLOCK_ITEMS = 2048;
 
 // heavy stage A: block b owns partial slots [2048 b, 2048 (b+1)); every run of a heavy bucket inside is
 // tree-summed by the whole block into part2[b + nzrank[k]]
-__global__ void __launch_bounds__(256) msm_heavy_a_kernel(const char *part, const uint32_t *starts, const uint32_t *nzrank, uint32_t NK,
-                                                         uint32_t NT, char *part2, const MsmState *st) {
+__global__ void __launch_bounds__(256) msm_heavy_a_kernel(const char *part, const uint32_t *starts, const uint32_t *nzrank,
+                                                         const uint32_t *nzlist, uint32_t NK, uint32_t NT, char *part2, const MsmState *st) {
     __shared__ uint4 sh[256 * 9];
     if (st->nheavy == 0) return;
     uint32_t C = chunk_len(starts[NK], NT);
+    uint32_t NZ = nzrank[NK];  // non-empty buckets; the r-th one, k = nzlist[r], owns slots [starts[k]/C + r, ...)
     uint32_t lo_slot = blockIdx.x * HEAVY_BLOCK_ITEMS, hi_slot = lo_slot + HEAVY_BLOCK_ITEMS;
-    // first bucket whose slot range can reach lo_slot: base(k) = starts[k]/C + nzrank[k] is non-decreasing in k
-    uint32_t lo = 0, hi = NK;
+    uint32_t lo = 0, hi = NZ;  // last r whose first slot is <= lo_slot (first slots increase strictly with r)
     while (hi - lo > 1) {
         uint32_t mid = (lo + hi) >> 1;
-        if (starts[mid] / C + nzrank[mid] <= lo_slot) lo = mid; else hi = mid;
+        if (starts[nzlist[mid]] / C + mid <= lo_slot) lo = mid; else hi = mid;
     }
-    for (uint32_t k = lo; k < NK; k++) {
+    for (uint32_t r = lo; r < NZ; r++) {
+        uint32_t k = nzlist[r];
         uint32_t s0 = starts[k], s1 = starts[k + 1];
-        if (s1 == s0) continue;
-        uint32_t q0 = s0 / C, q1 = (s1 - 1) / C, cnt = q1 - q0 + 1, base = q0 + nzrank[k];
+        uint32_t q0 = s0 / C, q1 = (s1 - 1) / C, cnt = q1 - q0 + 1, base = q0 + r;
         if (base >= hi_slot) break;
         if (cnt <= 8 || base + cnt <= lo_slot) continue;
         uint32_t r0 = base > lo_slot ? base : lo_slot, r1 = base + cnt < hi_slot ? base + cnt : hi_slot;
         XYZZ29 acc = xyzz29_identity();
         for (uint32_t j = r0 + threadIdx.x; j < r1; j += 256) acc = xyzz29_add(acc, xyzz29_load(part + 144 * (size_t)j));
-        XYZZ29 r = block_sum_xyzz29(acc, sh);
-        if (threadIdx.x == 0) xyzz29_store(part2 + 144 * (size_t)(blockIdx.x + nzrank[k]), r);
+        XYZZ29 res = block_sum_xyzz29(acc, sh);
+        if (threadIdx.x == 0) xyzz29_store(part2 + 144 * (size_t)(blockIdx.x + r), res);
         __syncthreads();
     }
 }
@@ -650,7 +655,7 @@ static void free_bases(zg_bases_s *b) {
         if (p) (void)hipFree(p);
     for (auto &ln : b->lanes) {
         void *lp[] = {ln.d_dig, ln.d_sorted, ln.d_hist, ln.d_starts, ln.d_blockhist, ln.d_partial, ln.d_bits, ln.d_rg,
-                      ln.d_nzrank, ln.d_part, ln.d_part2, ln.d_heavy, ln.d_state};
+                      ln.d_nzrank, ln.d_nzlist, ln.d_part, ln.d_part2, ln.d_heavy, ln.d_state};
         for (void *p : lp)
             if (p) (void)hipFree(p);
         if (ln.done) (void)hipEventDestroy(ln.done);
@@ -709,6 +714,7 @@ static int bases_create(const uint64_t *d_xy, const uint8_t *d_inf_in, size_t n,
         ZG_ALLOC(ln.d_bits, (size_t)p.G * p.c * p.PB * 144);
         ZG_ALLOC(ln.d_rg, (size_t)p.G * 128);
         ZG_ALLOC(ln.d_nzrank, ((size_t)p.NK + 1) * 4);
+        ZG_ALLOC(ln.d_nzlist, (size_t)p.NK * 4);
         if (p.NT) {
             size_t slots = (size_t)p.NT + p.NK;
             ZG_ALLOC(ln.d_part, slots * 144);
@@ -803,7 +809,7 @@ static int msm_enqueue(zg_bases_s *b, size_t off, size_t n, const uint64_t *d_sc
         prof_end(ZG_PROF_MSM_DIGITS, st);
         prof_begin(ZG_PROF_MSM_SORT, st);
         hipLaunchKernelGGL(msm_colscan_kernel, dim3(div_up(p.NK, 256)), dim3(256), 0, st, ln.d_blockhist, nblk, p.NK, ln.d_hist);
-        hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(1024), 0, st, ln.d_hist, ln.d_starts, ln.d_nzrank, p.NK);
+        hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(1024), 0, st, ln.d_hist, ln.d_starts, ln.d_nzrank, ln.d_nzlist, p.NK);
         ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_scatter_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)(p.NK * 4)));
         hipLaunchKernelGGL(msm_scatter_lds_kernel, dim3(nblk), dim3(1024), p.NK * 4, st, ln.d_dig, (uint32_t)n, p.W, p.G, b->n,
@@ -814,7 +820,7 @@ static int msm_enqueue(zg_bases_s *b, size_t off, size_t n, const uint64_t *d_sc
         ZG_TRY(launch_digits_c(p.c, st, d_scalars, infp, (uint32_t)n, p.G, ln.d_dig, ln.d_hist));
         prof_end(ZG_PROF_MSM_DIGITS, st);
         prof_begin(ZG_PROF_MSM_SORT, st);
-        hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(1024), 0, st, ln.d_hist, ln.d_starts, ln.d_nzrank, p.NK);
+        hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(1024), 0, st, ln.d_hist, ln.d_starts, ln.d_nzrank, ln.d_nzlist, p.NK);
         ZG_HIP(hipMemsetAsync(ln.d_hist, 0, (size_t)p.NK * 4, st));
         hipLaunchKernelGGL(msm_scatter_kernel, dim3(div_up(n, 256), p.W), dim3(256), 0, st, ln.d_dig, (uint32_t)n, p.G, b->n,
                            (uint32_t)off, ln.d_starts, ln.d_hist, ln.d_sorted);
@@ -824,11 +830,12 @@ static int msm_enqueue(zg_bases_s *b, size_t off, size_t n, const uint64_t *d_sc
     if (p.NT) {
         ZG_HIP(hipMemsetAsync(ln.d_state, 0, sizeof(MsmState), st));
         hipLaunchKernelGGL(msm_accumulate_chunk_kernel, dim3(div_up(p.NT, 256)), dim3(256), 0, st, ln.d_sorted, ln.d_starts, ln.d_nzrank,
-                           b->d_table, p.NK, p.NT, ln.d_part);
+                           ln.d_nzlist, b->d_table, p.NK, p.NT, ln.d_part);
         hipLaunchKernelGGL(msm_bucket_combine_kernel, dim3(div_up(p.NK, 64)), dim3(64), 0, st, ln.d_part, ln.d_starts, ln.d_nzrank, p.NK,
                            p.NT, ln.d_partial, ln.d_heavy, reinterpret_cast<MsmState *>(ln.d_state));
         uint32_t nblk_a = (p.NT + p.NK) / HEAVY_BLOCK_ITEMS + 1;
-        hipLaunchKernelGGL(msm_heavy_a_kernel, dim3(nblk_a), dim3(256), 0, st, ln.d_part, ln.d_starts, ln.d_nzrank, p.NK, p.NT, ln.d_part2,
+        hipLaunchKernelGGL(msm_heavy_a_kernel, dim3(nblk_a), dim3(256), 0, st, ln.d_part, ln.d_starts, ln.d_nzrank, ln.d_nzlist, p.NK, p.NT,
+                           ln.d_part2,
                            reinterpret_cast<const MsmState *>(ln.d_state));
         hipLaunchKernelGGL(msm_heavy_b_kernel, dim3(64), dim3(256), 0, st, ln.d_part2, ln.d_starts, ln.d_nzrank, p.NK, p.NT, ln.d_heavy,
                            reinterpret_cast<const MsmState *>(ln.d_state), ln.d_partial);
