@@ -92,10 +92,18 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libzolt_gpu has no CPU fallback)")
+    # one process per GPU; ZOLT_BENCH_DIST_BACKEND=gloo lets several ranks share one GPU to exercise the
+    # sharded path on a 1-GPU box (RCCL refuses two ranks on one device) — never used for reported numbers
+    dist_backend = os.environ.get("ZOLT_BENCH_DIST_BACKEND", "nccl")
+    if dist_backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(dist_backend)
 
     from zolt_amd import api, lib
     lib.init(local_rank)
@@ -104,7 +112,12 @@ def main():
     bounds = api.shard_bounds(n, world)
     start, end = bounds[rank]
     n_loc = end - start
-    stream = torch.cuda.current_stream().cuda_stream
+    # all work runs on an explicit (non-default) torch stream: the C ABI treats a NULL stream as "the library's own
+    # stream", which is not ordered with torch's legacy default stream (handle 0)
+    work_stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(work_stream)
+    stream = work_stream.cuda_stream
+    assert stream != 0
     nstreams = max(1, args.streams) if world == 1 else 1
     tstreams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(nstreams - 1)]
 
@@ -138,7 +151,7 @@ def main():
             st = tstreams[i % nstreams].cuda_stream
             bases.msm_dev_async(sc.data_ptr(), n_loc, d_res[slot].data_ptr(), d_res[slot, 8:].data_ptr(), stream=st)
             return None
-        return sharded.compute(sc)
+        return sharded.compute(sc, out=d_res[slot])
 
     def barrier():
         if world > 1:
@@ -159,7 +172,7 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = lib.profile_end()
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist_backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -171,14 +184,10 @@ def main():
         dist.all_gather_object(gathered, expect_k)
         all_k = [sum(gk[s] for gk in gathered) % api.R_MOD for s in range(N_SCALAR_SETS)]
     want = [api.MSM.scalarMul(g, api.fr_from_int(k)) for k in all_k]
-    if world == 1:
-        res = d_res.cpu().numpy().view(np.uint64)
-        for i in range(args.steps):
-            wxy, winf = want[i % N_SCALAR_SETS]
-            assert int(res[i, 8] & 0xFF) == winf and np.array_equal(res[i, :8], wxy), f"MSM result mismatch at step {i}"
-    else:
-        wxy, winf = want[(args.steps - 1) % N_SCALAR_SETS]
-        assert last[1] == winf and np.array_equal(last[0], wxy), "sharded MSM result mismatch"
+    res = d_res.cpu().numpy().view(np.uint64)
+    for i in range(args.steps):
+        wxy, winf = want[i % N_SCALAR_SETS]
+        assert int(res[i, 8] & 0xFF) == winf and np.array_equal(res[i, :8], wxy), f"MSM result mismatch at step {i}"
 
     if rank != 0:
         if world > 1:
@@ -197,7 +206,7 @@ def main():
         "vs_baseline": None, "dtype": "u32 limbs (256-bit Montgomery, integer)", "data": "synthetic",
         "config": {"workload": f"msm_g1_2^{args.logn}", "points": n, "points_per_gpu": n_loc,
                    "bases": "(i+1)*G resident in HBM", "scalars": "uniform mod r, splitmix64 seed 0x5A4F4C54, resident in HBM",
-                   "sharding": "contiguous chunks + RCCL all-gather of 96-byte Jacobian partials" if world > 1 else "single GPU",
+                   "sharding": f"contiguous chunks + {dist_backend} all-gather of 96-byte Jacobian partials" if world > 1 else "single GPU",
                    "streams": nstreams,
                    "bit_exact_check": "closed form (sum s_i*(i+1))*G via scalarMul kernel, every timed step"},
         "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,

@@ -21,8 +21,9 @@
  *     re-entrant (MSM.compute is called from std.Thread workers, src/msm/mod.zig:637,732).
  *     zg_last_error() gives the calling thread's last message.
  *   - "_dev" variants take DEVICE pointers (hipMalloc'ed / torch tensors' data_ptr) and a
- *     hipStream_t passed as void* (NULL = the library's stream); work is enqueued
- *     asynchronously unless the function returns a host value.
+ *     hipStream_t passed as void* (NULL = the library's own non-blocking stream, which is NOT ordered
+ *     with the legacy default stream: pass your stream explicitly when other work consumes the
+ *     result); work is enqueued asynchronously unless the function returns a host value.
  *   - No CPU fallback exists: without a usable gfx950 device every compute entry point
  *     fails with ZG_ERR_NO_DEVICE.
  */
@@ -149,6 +150,9 @@ ZG_API int zg_msm_g1_partial_dev(zg_bases_t b, size_t off, size_t n, const uint6
  * Jacobian partials resident on the device. */
 ZG_API int zg_g1_combine_partials_dev(const uint64_t *d_partials_jac /* k*12 */, size_t k, void *stream, uint64_t out_xy[8],
                                uint8_t *out_inf);
+/* asynchronous form: result (8 limbs) and flag land in DEVICE memory, ordered on `stream` */
+ZG_API int zg_g1_combine_partials_dev_async(const uint64_t *d_partials_jac /* k*12 */, size_t k, void *stream, uint64_t *d_out_xy,
+                                     uint8_t *d_out_inf);
 /* MSM(F,G).scalarMul(base, scalar).toAffine() for n independent (base, scalar) pairs
  * (src/msm/mod.zig:503-540) — the primitive of HyperKZG.setup (commitment/mod.zig:194-199). */
 ZG_API int zg_g1_scalar_mul_batch(const uint64_t *xy, const uint8_t *inf, const uint64_t *scalars_mont, size_t n,

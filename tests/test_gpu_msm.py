@@ -254,3 +254,26 @@ def test_skewed_scalar_distributions(zl, ob, gm, kind):
         sc[5::29] = ob.f_neg(ob.FR, sc[5::29])
     _check(zl, ob, gm[:n], None, sc)
     _check(zl, ob, gm[:n], None, sc, window_bits=13, precompute_levels=1)
+
+
+@pytest.mark.parametrize("c", list(range(2, 17)))
+def test_every_window_size(zl, ob, gm, c):
+    """every digit-kernel instantiation (window_bits 2..16), full precompute and none"""
+    n = 2000
+    sc = _scalars(ob, 4000 + c, n)
+    _check(zl, ob, gm[:n], None, sc, window_bits=c, precompute_levels=0)
+    if (255 + c - 1) // c <= 64:
+        _check(zl, ob, gm[:n], None, sc, window_bits=c, precompute_levels=1)
+
+
+@pytest.mark.parametrize("logn", [17, 18, 19])
+def test_auto_plan_sizes(zl, ob, logn):
+    """the automatic plan picks c = 13..15 for these sizes (the per-rank shard sizes of a sharded 2^20..2^22 MSM)"""
+    n = 1 << logn
+    gmn = ob.g1_gen_multiples(n)
+    sc = _scalars(ob, 5000 + logn, n)
+    b = zl.Bases.upload(gmn)
+    got, ginf = b.msm(sc)
+    b.free()
+    want, winf = ob.msm_g1_parallel(gmn, None, sc, 8)
+    assert ginf == winf and np.array_equal(got, want)

@@ -125,15 +125,24 @@ class ShardedMSM:
     def __init__(self, backend, world_size, rank, group=None):
         self.backend, self.world, self.rank, self.group = backend, world_size, rank, group
 
-    def compute(self, local_scalars):
+    def compute(self, local_scalars, out=None):
+        """-> (xy, inf) on the host, or, with `out` (a device int64[9] slot: xy[8] + flag word), fully
+        asynchronous: partial MSM, all-gather and combine are only stream-ordered."""
         import torch
         import torch.distributed as dist
         part = self.backend.partial(local_scalars)
         if self.world == 1:
             gathered = part.reshape(1, 12)
+        elif dist.get_backend(self.group) == "gloo" and part.is_cuda:
+            # debugging aid (several ranks on one GPU): stage the 96-byte records through the host
+            parts = [torch.empty(12, dtype=torch.int64) for _ in range(self.world)]
+            dist.all_gather(parts, part.cpu(), group=self.group)
+            gathered = torch.stack(parts).to(part.device)
         else:
             gathered = torch.empty((self.world, 12), dtype=torch.int64, device=part.device)
             dist.all_gather_into_tensor(gathered, part.reshape(1, 12), group=self.group)
+        if out is not None:
+            return self.backend.combine_async(gathered, out)
         return self.backend.combine(gathered)
 
 
@@ -151,6 +160,11 @@ class GpuShardBackend:
 
     def combine(self, gathered):
         return lib.combine_partials_dev(gathered.data_ptr(), gathered.shape[0], stream=self.stream)
+
+    def combine_async(self, gathered, out):
+        self._keep = gathered  # the kernel reads it after this call returns
+        lib.combine_partials_dev_async(gathered.data_ptr(), gathered.shape[0], out.data_ptr(), out[8:].data_ptr(), stream=self.stream)
+        return None
 
 
 # ---- HyperKZG (commit side)

@@ -993,6 +993,17 @@ int zg_g1_combine_partials_dev(const uint64_t *d_partials, size_t k, void *strea
     return ZG_OK;
 }
 
+int zg_g1_combine_partials_dev_async(const uint64_t *d_partials, size_t k, void *stream, uint64_t *d_out_xy, uint8_t *d_out_inf) {
+    ZG_INIT();
+    if (!d_out_xy || !d_out_inf || (k && !d_partials)) {
+        set_error("zg_g1_combine_partials_dev_async: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    hipLaunchKernelGGL(msm_combine_kernel, dim3(1), dim3(1), 0, pick_stream(stream), d_partials, (uint32_t)k, d_out_xy, d_out_inf);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
 int zg_g1_scalar_mul_batch(const uint64_t *xy, const uint8_t *inf, const uint64_t *scalars, size_t n, uint64_t *out_xy,
                            uint8_t *out_inf) {
     ZG_INIT();

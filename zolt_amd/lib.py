@@ -28,7 +28,7 @@ SYMBOLS = [
     "zg_field_op",
     "zg_g1_bases_upload", "zg_g1_bases_upload_dev", "zg_g1_bases_free", "zg_g1_bases_len",
     "zg_msm_g1", "zg_msm_g1_dev", "zg_msm_g1_dev_async", "zg_msm_g1_batch", "zg_msm_g1_partial_dev",
-    "zg_g1_combine_partials_dev", "zg_g1_scalar_mul_batch",
+    "zg_g1_combine_partials_dev", "zg_g1_combine_partials_dev_async", "zg_g1_scalar_mul_batch",
     "zg_fr_eq_table", "zg_fr_eq_table_dev", "zg_fr_bind_low", "zg_fr_bind_high",
     "zg_fr_spartan_combine", "zg_fr_spartan_combine_dev",
     "zg_sumcheck_open", "zg_sumcheck_open_dev", "zg_sumcheck_round_sums", "zg_sumcheck_bind",
@@ -205,6 +205,11 @@ def combine_partials_dev(d_partials, k, stream=0):
     _chk(_lib.zg_g1_combine_partials_dev(_d(d_partials), C.c_size_t(k), _d(stream), _h(out), C.byref(inf)),
          "zg_g1_combine_partials_dev")
     return out, int(inf.value)
+
+
+def combine_partials_dev_async(d_partials, k, d_out_xy, d_out_inf, stream=0):
+    _chk(_lib.zg_g1_combine_partials_dev_async(_d(d_partials), C.c_size_t(k), _d(stream), _d(d_out_xy), _d(d_out_inf)),
+         "zg_g1_combine_partials_dev_async")
 
 
 def g1_scalar_mul_batch(xy, inf, scalars):
