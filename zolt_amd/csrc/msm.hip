@@ -44,6 +44,7 @@ struct MsmPlan {
     uint32_t NK;   // total buckets = G * NB
     int PB;        // bit-sum partial blocks per (group, bit)
     uint32_t NT;   // chunk-scheduled accumulate: threads (0 = per-bucket scheduling)
+    int GS;        // lanes per bucket in the combine pass
 };
 
 }  // namespace zg
@@ -376,25 +377,34 @@ __global__ void __launch_bounds__(256) msm_accumulate_chunk_kernel(const uint32_
     xyzz29_store(part + 144 * (size_t)(i + r), acc_inf ? xyzz29_identity() : acc);
 }
 
-// one thread per bucket: sum its (few) partials; queue heavy buckets
+// GS adjacent lanes per bucket (GS | 64, chosen from the expected partials per bucket) sum its partials:
+// strided serial adds, then a segmented shuffle tree; buckets with more than 8*GS partials are queued as heavy
 __global__ void __launch_bounds__(64) msm_bucket_combine_kernel(const char *part, const uint32_t *starts, const uint32_t *nzrank, uint32_t NK,
-                                                                uint32_t NT, char *buckets, uint32_t *heavy_list, MsmState *st) {
-    uint32_t k = blockIdx.x * 64 + threadIdx.x;
-    if (k >= NK) return;
-    uint32_t C = chunk_len(starts[NK], NT);
-    uint32_t s0 = starts[k], s1 = starts[k + 1];
-    if (s1 == s0) {
-        xyzz29_store(buckets + 144 * (size_t)k, xyzz29_identity());
-        return;
+                                                                uint32_t NT, int GS, char *buckets, uint32_t *heavy_list, MsmState *st) {
+    uint32_t t = blockIdx.x * 64 + threadIdx.x;
+    uint32_t k = t / (uint32_t)GS, g = t % (uint32_t)GS;
+    XYZZ29 acc = xyzz29_identity();
+    bool light = false;
+    if (k < NK) {
+        uint32_t C = chunk_len(starts[NK], NT);
+        uint32_t s0 = starts[k], s1 = starts[k + 1];
+        if (s1 == s0) {
+            light = true;  // empty bucket: identity
+        } else {
+            uint32_t q0 = s0 / C, q1 = (s1 - 1) / C, cnt = q1 - q0 + 1, base = q0 + nzrank[k];
+            if (cnt > 8u * (uint32_t)GS) {
+                if (g == 0) heavy_list[atomicAdd(&st->nheavy, 1u)] = k;
+            } else {
+                light = true;
+                for (uint32_t j = g; j < cnt; j += (uint32_t)GS) acc = xyzz29_add(acc, xyzz29_load(part + 144 * (size_t)(base + j)));
+            }
+        }
     }
-    uint32_t q0 = s0 / C, q1 = (s1 - 1) / C, cnt = q1 - q0 + 1, base = q0 + nzrank[k];
-    if (cnt > 8) {
-        heavy_list[atomicAdd(&st->nheavy, 1u)] = k;
-        return;
+    for (int d = 1; d < GS; d <<= 1) {
+        XYZZ29 o = xyzz29_shfl_down(acc, d);
+        if ((g & (uint32_t)(2 * d - 1)) == 0) acc = xyzz29_add(acc, o);
     }
-    XYZZ29 acc = xyzz29_load(part + 144 * (size_t)base);
-    for (uint32_t j = 1; j < cnt; j++) acc = xyzz29_add(acc, xyzz29_load(part + 144 * (size_t)(base + j)));
-    xyzz29_store(buckets + 144 * (size_t)k, acc);
+    if (light && g == 0) xyzz29_store(buckets + 144 * (size_t)k, acc);
 }
 
 // block-wide sum of lazy XYZZ points through LDS (256 threads x 144 B); result returned to every thread
@@ -417,7 +427,8 @@ static constexpr uint32_t HEAVY_BLOCK_ITEMS = 2048;
 // heavy stage A: block b owns partial slots [2048 b, 2048 (b+1)); every run of a heavy bucket inside is
 // tree-summed by the whole block into part2[b + nzrank[k]]
 __global__ void __launch_bounds__(256) msm_heavy_a_kernel(const char *part, const uint32_t *starts, const uint32_t *nzrank,
-                                                         const uint32_t *nzlist, uint32_t NK, uint32_t NT, char *part2, const MsmState *st) {
+                                                         const uint32_t *nzlist, uint32_t NK, uint32_t NT, int GS, char *part2,
+                                                         const MsmState *st) {
     __shared__ uint4 sh[256 * 9];
     if (st->nheavy == 0) return;
     uint32_t C = chunk_len(starts[NK], NT);
@@ -433,7 +444,7 @@ __global__ void __launch_bounds__(256) msm_heavy_a_kernel(const char *part, cons
         uint32_t s0 = starts[k], s1 = starts[k + 1];
         uint32_t q0 = s0 / C, q1 = (s1 - 1) / C, cnt = q1 - q0 + 1, base = q0 + r;
         if (base >= hi_slot) break;
-        if (cnt <= 8 || base + cnt <= lo_slot) continue;
+        if (cnt <= 8u * (uint32_t)GS || base + cnt <= lo_slot) continue;
         uint32_t r0 = base > lo_slot ? base : lo_slot, r1 = base + cnt < hi_slot ? base + cnt : hi_slot;
         XYZZ29 acc = xyzz29_identity();
         for (uint32_t j = r0 + threadIdx.x; j < r1; j += 256) acc = xyzz29_add(acc, xyzz29_load(part + 144 * (size_t)j));
@@ -642,6 +653,9 @@ static int make_plan(size_t n, const zg_msm_config *cfg, MsmPlan &p) {
         while (nt < want && nt < 131072u) nt <<= 1;
         p.NT = (uint32_t)env_int("ZG_MSM_CHUNK_THREADS", (int)nt);
     }
+    // combine lanes per bucket: a bucket expects about NT/NK + 1 partials; keep ~4 per lane
+    p.GS = 1;
+    while (p.GS < 64 && (uint64_t)p.GS * 4 < (uint64_t)p.NT / p.NK + 1) p.GS <<= 1;
     // bit-sum partial blocks: ~4 buckets per thread, at most 16 (the final kernel reduces 16 lanes per bit)
     int pb = (int)(p.NB / 2 / (256 * 4));
     p.PB = pb < 1 ? 1 : (pb > 16 ? 16 : pb);
@@ -831,11 +845,11 @@ static int msm_enqueue(zg_bases_s *b, size_t off, size_t n, const uint64_t *d_sc
         ZG_HIP(hipMemsetAsync(ln.d_state, 0, sizeof(MsmState), st));
         hipLaunchKernelGGL(msm_accumulate_chunk_kernel, dim3(div_up(p.NT, 256)), dim3(256), 0, st, ln.d_sorted, ln.d_starts, ln.d_nzrank,
                            ln.d_nzlist, b->d_table, p.NK, p.NT, ln.d_part);
-        hipLaunchKernelGGL(msm_bucket_combine_kernel, dim3(div_up(p.NK, 64)), dim3(64), 0, st, ln.d_part, ln.d_starts, ln.d_nzrank, p.NK,
-                           p.NT, ln.d_partial, ln.d_heavy, reinterpret_cast<MsmState *>(ln.d_state));
+        hipLaunchKernelGGL(msm_bucket_combine_kernel, dim3(div_up((size_t)p.NK * p.GS, 64)), dim3(64), 0, st, ln.d_part, ln.d_starts,
+                           ln.d_nzrank, p.NK, p.NT, p.GS, ln.d_partial, ln.d_heavy, reinterpret_cast<MsmState *>(ln.d_state));
         uint32_t nblk_a = (p.NT + p.NK) / HEAVY_BLOCK_ITEMS + 1;
         hipLaunchKernelGGL(msm_heavy_a_kernel, dim3(nblk_a), dim3(256), 0, st, ln.d_part, ln.d_starts, ln.d_nzrank, ln.d_nzlist, p.NK, p.NT,
-                           ln.d_part2,
+                           p.GS, ln.d_part2,
                            reinterpret_cast<const MsmState *>(ln.d_state));
         hipLaunchKernelGGL(msm_heavy_b_kernel, dim3(64), dim3(256), 0, st, ln.d_part2, ln.d_starts, ln.d_nzrank, p.NK, p.NT, ln.d_heavy,
                            reinterpret_cast<const MsmState *>(ln.d_state), ln.d_partial);
