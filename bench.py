@@ -266,6 +266,17 @@ def extra_measurements(lib, api, torch, dev, stream, args):
         "kernel_ms": {k: (val[0] / max(val[1], 1)) for k, val in prof.items() if val[1]},
         "fold_round0_GBps": (48.0 * n) / ((prof["sc_fold"][0] / max(prof["sc_fold"][1], 1)) * 1e-3) / 1e9 if prof["sc_fold"][1] else None,
     }
+    # the metric's second size, 2^22 points on this one GPU (same code path, fresh process)
+    try:
+        import subprocess
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--logn", "22", "--steps", "8", "--warmup", "2",
+                              "--no-cpu-baseline", "--no-extra", "--streams", str(args.streams)],
+                             capture_output=True, text=True, timeout=600)
+        d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        extra["msm_2^22_single_gpu"] = {"value": d["value"], "unit": "MSM/s", "ms_per_step": d["ms_per_step"],
+                                        "kernel_ms_per_msm": d["extra"]["kernel_ms_per_msm"], "roofline": d["roofline"]}
+    except Exception as e:  # noqa: BLE001
+        extra["msm_2^22_single_gpu"] = {"error": str(e)}
     # the same pipeline driven by a compiled host loop (tools/bench_sumcheck.cpp over zolt_host.hpp): what a
     # Zig/C++ prover would see, without the Python interpreter between rounds
     exe = os.path.join(ROOT, "tools", "bench_sumcheck")

@@ -1,0 +1,114 @@
+"""The Python host mirror (zolt_amd/api.py) against the oracle: HyperKZG setup/commit/batchCommit/open, the
+polynomial classes, runSumcheck; plus re-entrancy of the C ABI from several host threads."""
+import threading
+
+import numpy as np
+import pytest
+
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    from oracle import binding as ob
+    from zolt_amd import api, lib
+    lib.init()
+    return api, lib, ob
+
+
+def _rand(ob, seed, n):
+    return ob.f_to_mont(ob.FR, U.random_raw256(seed, n))
+
+
+def test_hyperkzg_setup_commit_open(env):
+    """src/poly/commitment/mod.zig:174-324: mock SRS, commit, batchCommit, open (quotient commitments + final eval)."""
+    api, lib, ob = env
+    params = api.HyperKZG.setup(64)
+    wsrs, winf = ob.hyperkzg_setup(64)
+    assert np.array_equal(params.powers_of_tau_g1, wsrs) and np.array_equal(params.infinity, winf)
+    evals = _rand(ob, 1, 64)
+    c, ci = api.HyperKZG.commit(params, evals)
+    wc, wci = ob.hyperkzg_commit(wsrs, winf, evals)
+    assert ci == wci and np.array_equal(c, wc)
+    # evals longer than the SRS are truncated to n = min(len, srs) (:246); empty -> identity (:240-242)
+    c2, _ = api.HyperKZG.commit(params, _rand(ob, 2, 100))
+    w2, _ = ob.hyperkzg_commit(wsrs, winf, _rand(ob, 2, 100))
+    assert np.array_equal(c2, w2)
+    z, zi = api.HyperKZG.commit(params, np.zeros((0, 4), dtype=np.uint64))
+    assert zi == 1 and not z.any() and api.commitment_to_bytes(z, zi) == bytes(64)
+    polys = [_rand(ob, 10 + k, 64) for k in range(3)]
+    for (bc, bi), p in zip(api.HyperKZG.batchCommit(params, polys), polys):
+        w, wi = ob.hyperkzg_commit(wsrs, winf, p)
+        assert bi == wi and np.array_equal(bc, w)
+    point = _rand(ob, 3, 6)
+    quotients, final = api.HyperKZG.open(params, evals, point, np.zeros(4, dtype=np.uint64))
+    wq, wqi, wfin = ob.hyperkzg_open(wsrs, winf, evals, point, np.zeros(4, dtype=np.uint64))
+    assert np.array_equal(final, wfin) and len(quotients) == 6
+    for i, (q, qi) in enumerate(quotients):
+        assert qi == wqi[i] and np.array_equal(q, wq[i])
+    params.deinit()
+
+
+def test_poly_classes_and_run_sumcheck(env):
+    api, lib, ob = env
+    ev = _rand(ob, 20, 256)
+    r = _rand(ob, 21, 1)[0]
+    p = api.DensePolynomial(ev)
+    assert p.num_vars == 8 and p.len() == 256
+    assert np.array_equal(p.bindFirst(r).evaluations, ob.fr_bind_high(ev, r))
+    p.bindLow(r)
+    assert p.num_vars == 7 and np.array_equal(p.evaluations, ob.fr_bind_low(ev, r))
+    pt = _rand(ob, 22, 9)
+    assert np.array_equal(api.EqPolynomial(pt).evals(), ob.fr_eq_table(pt))
+    sc = _rand(ob, 23, 1)[0]
+    assert np.array_equal(api.EqPolynomial.evalsSliceWithScaling(pt, sc), ob.fr_eq_table(pt, sc))
+    res = api.runSumcheck(api.DensePolynomial(ev))
+    wc, wr, wch, wfin, wok = ob.run_sumcheck(ev)
+    assert res["result"] and wok == 1
+    assert np.array_equal(res["claim"], wc) and np.array_equal(np.array(res["rounds"]), wr)
+    assert np.array_equal(np.array(res["final_point"]), wch) and np.array_equal(res["final_eval"], wfin)
+    with pytest.raises(AssertionError):
+        api.DensePolynomial(ev[:100])  # length must be a power of two (src/poly/mod.zig:36-37)
+
+
+def test_c_abi_is_reentrant(env):
+    """MSM.compute is called from std.Thread workers in the reference (src/msm/mod.zig:637,732): several host
+    threads hammer one handle and their own handles concurrently; every result must be the oracle's."""
+    api, lib, ob = env
+    n = 3000
+    gm = ob.g1_gen_multiples(n)
+    shared = lib.Bases.upload(gm)
+    scs = [_rand(ob, 100 + t, n) for t in range(6)]
+    want = [ob.msm_g1(gm, None, s) for s in scs]
+    errors = []
+
+    def worker(t):
+        try:
+            own = lib.Bases.upload(gm[: 1000 + 100 * t])
+            for _ in range(4):
+                got, inf = shared.msm(scs[t])
+                if inf != want[t][1] or not np.array_equal(got, want[t][0]):
+                    errors.append(("shared", t))
+                g2, i2 = own.msm(scs[t][: 1000 + 100 * t])
+                w2, wi2 = ob.msm_g1(gm[: 1000 + 100 * t], None, scs[t][: 1000 + 100 * t])
+                if i2 != wi2 or not np.array_equal(g2, w2):
+                    errors.append(("own", t))
+                s = lib.SumcheckSession.open(scs[t][:1024])
+                g0, g1 = s.round_sums()
+                w0, w1 = ob.fr_sum_halves(scs[t][:1024])
+                if not (np.array_equal(g0, w0) and np.array_equal(g1, w1)):
+                    errors.append(("sums", t))
+                s.close()
+            own.free()
+        except Exception as e:  # noqa: BLE001
+            errors.append((repr(e), t))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    shared.free()
+    assert not errors, errors

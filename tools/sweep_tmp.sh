@@ -1,3 +1,8 @@
-for NT in 131072 196608 262144; do
-  echo "NT=$NT: $(ZG_MSM_CHUNK_THREADS=$NT python bench.py --steps 10 --warmup 2 --streams 1 --no-cpu-baseline --no-extra 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value'],1), round(d['ms_per_step'],3), d['extra']['kernel_ms_per_msm'])")"
-done
+export TMPDIR=/tmp
+ROOT=$(pwd)
+mkdir -p $ROOT/gpurun_out/prof_22
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_22/trace -- python3 $ROOT/bench.py --logn 22 --steps 6 --warmup 2 --streams 1 --no-cpu-baseline --no-extra > $ROOT/gpurun_out/prof_22/trace.log 2>&1
+cd $ROOT
+python3 tools/summarize_prof.py gpurun_out/prof_22 | cut -c1-150 | head -22
+find gpurun_out/prof_22 -name "*.csv" -size +2M -delete
