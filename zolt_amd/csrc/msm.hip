@@ -65,6 +65,7 @@ struct zg_bases_s {
         char *d_rg = nullptr;             // G * 128 B: per-group results
         uint32_t *d_nzrank = nullptr;     // NK + 1: non-empty buckets before k
         uint32_t *d_nzlist = nullptr;     // NK: the non-empty buckets, compacted
+        uint32_t *d_scan_tmp = nullptr;   // 2*NK + 2*tiles: tile-local scans and tile totals
         char *d_part = nullptr;           // (NT + NK) * 144 B: per-(chunk, bucket-run) partial sums
         char *d_part2 = nullptr;          // heavy-bucket stage-A partials
         uint32_t *d_heavy = nullptr;      // NK: heavy bucket list
@@ -137,40 +138,67 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint64_t *scalars
 }
 
 // exclusive scan of the bucket histogram (NK <= 2^21 entries), one block
-__global__ void __launch_bounds__(1024) msm_scan_kernel(const uint32_t *hist, uint32_t *starts, uint32_t *nzrank, uint32_t *nzlist,
-                                                        uint32_t NK) {
+// Exclusive scan of the bucket histogram in two coalesced passes (a one-block scan with strided slices was
+// L2-latency-bound: 83 us for 32768 buckets). Pass A: each 1024-bucket tile is scanned in LDS (bucket sizes and
+// non-empty flags) and its totals are published. Pass B: every tile adds the totals of the tiles before it and
+// writes starts / nzrank / the compacted list of non-empty buckets.
+__global__ void __launch_bounds__(1024) msm_scan_a_kernel(const uint32_t *__restrict__ hist, uint32_t NK, uint32_t *__restrict__ loc,
+                                                          uint32_t *__restrict__ locz, uint32_t *__restrict__ tile_tot) {
     __shared__ uint32_t sh[1024], shz[1024];
-    uint32_t tid = threadIdx.x;
-    uint32_t per = (NK + 1023) / 1024;
-    uint32_t b = tid * per, e = b + per < NK ? b + per : NK;
-    uint32_t sum = 0, nz = 0;
-    for (uint32_t k = b; k < e; k++) {
-        uint32_t h = hist[k];
-        sum += h;
-        nz += h ? 1u : 0u;
-    }
-    sh[tid] = sum;
-    shz[tid] = nz;
+    uint32_t tid = threadIdx.x, k = blockIdx.x * 1024 + tid;
+    uint32_t h = k < NK ? hist[k] : 0u, z = h ? 1u : 0u;
+    sh[tid] = h;
+    shz[tid] = z;
     __syncthreads();
     for (uint32_t o = 1; o < 1024; o <<= 1) {
-        uint32_t v = tid >= o ? sh[tid - o] : 0, z = tid >= o ? shz[tid - o] : 0;
+        uint32_t v = tid >= o ? sh[tid - o] : 0, vz = tid >= o ? shz[tid - o] : 0;
         __syncthreads();
         sh[tid] += v;
-        shz[tid] += z;
+        shz[tid] += vz;
         __syncthreads();
     }
-    uint32_t run = sh[tid] - sum, runz = shz[tid] - nz;
-    for (uint32_t k = b; k < e; k++) {
-        uint32_t h = hist[k];
-        starts[k] = run;
-        nzrank[k] = runz;  // number of non-empty buckets before k
-        if (h) nzlist[runz] = k;  // compacted list of the non-empty buckets
-        run += h;
-        runz += h ? 1u : 0u;
+    if (k < NK) {
+        loc[k] = sh[tid] - h;    // exclusive within the tile
+        locz[k] = shz[tid] - z;
     }
     if (tid == 1023) {
-        starts[NK] = sh[1023];
-        nzrank[NK] = shz[1023];
+        tile_tot[2 * blockIdx.x] = sh[1023];
+        tile_tot[2 * blockIdx.x + 1] = shz[1023];
+    }
+}
+
+__global__ void __launch_bounds__(1024) msm_scan_b_kernel(const uint32_t *__restrict__ hist, uint32_t NK, const uint32_t *__restrict__ loc,
+                                                          const uint32_t *__restrict__ locz, const uint32_t *__restrict__ tile_tot,
+                                                          uint32_t *__restrict__ starts, uint32_t *__restrict__ nzrank,
+                                                          uint32_t *__restrict__ nzlist) {
+    __shared__ uint32_t pre[2];
+    uint32_t tid = threadIdx.x, k = blockIdx.x * 1024 + tid;
+    if (tid < 64) {  // one wave sums the totals of the preceding tiles (at most 2048 tiles)
+        uint32_t a = 0, az = 0;
+        for (uint32_t t = tid; t < blockIdx.x; t += 64) {
+            a += tile_tot[2 * t];
+            az += tile_tot[2 * t + 1];
+        }
+        for (int d = 32; d > 0; d >>= 1) {
+            a += __shfl_down(a, d, 64);
+            az += __shfl_down(az, d, 64);
+        }
+        if (tid == 0) {
+            pre[0] = a;
+            pre[1] = az;
+        }
+    }
+    __syncthreads();
+    if (k < NK) {
+        uint32_t s = pre[0] + loc[k], r = pre[1] + locz[k];
+        starts[k] = s;
+        nzrank[k] = r;  // number of non-empty buckets before k
+        uint32_t h = hist[k];
+        if (h) nzlist[r] = k;  // compacted list of the non-empty buckets
+        if (k == NK - 1) {
+            starts[NK] = s + h;
+            nzrank[NK] = r + (h ? 1u : 0u);
+        }
     }
 }
 
@@ -234,10 +262,15 @@ __global__ void __launch_bounds__(256) msm_colscan_kernel(uint32_t *blockhist, u
     uint32_t key = blockIdx.x * 256 + threadIdx.x;
     if (key >= NK) return;
     uint32_t run = 0;
-    for (uint32_t b = 0; b < nblk; b++) {
-        uint32_t v = blockhist[(size_t)b * NK + key];
-        blockhist[(size_t)b * NK + key] = run;
-        run += v;
+    for (uint32_t b0 = 0; b0 < nblk; b0 += 16) {  // 16 independent loads in flight, then the in-place prefix
+        uint32_t v[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) v[u] = (b0 + u < nblk) ? blockhist[(size_t)(b0 + u) * NK + key] : 0u;
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            if (b0 + u < nblk) blockhist[(size_t)(b0 + u) * NK + key] = run;
+            run += v[u];
+        }
     }
     total[key] = run;
 }
@@ -669,7 +702,7 @@ static void free_bases(zg_bases_s *b) {
         if (p) (void)hipFree(p);
     for (auto &ln : b->lanes) {
         void *lp[] = {ln.d_dig, ln.d_sorted, ln.d_hist, ln.d_starts, ln.d_blockhist, ln.d_partial, ln.d_bits, ln.d_rg,
-                      ln.d_nzrank, ln.d_nzlist, ln.d_part, ln.d_part2, ln.d_heavy, ln.d_state};
+                      ln.d_nzrank, ln.d_nzlist, ln.d_scan_tmp, ln.d_part, ln.d_part2, ln.d_heavy, ln.d_state};
         for (void *p : lp)
             if (p) (void)hipFree(p);
         if (ln.done) (void)hipEventDestroy(ln.done);
@@ -729,6 +762,7 @@ static int bases_create(const uint64_t *d_xy, const uint8_t *d_inf_in, size_t n,
         ZG_ALLOC(ln.d_rg, (size_t)p.G * 128);
         ZG_ALLOC(ln.d_nzrank, ((size_t)p.NK + 1) * 4);
         ZG_ALLOC(ln.d_nzlist, (size_t)p.NK * 4);
+        ZG_ALLOC(ln.d_scan_tmp, (2 * (size_t)p.NK + 2 * (p.NK / 1024 + 1)) * 4);
         if (p.NT) {
             size_t slots = (size_t)p.NT + p.NK;
             ZG_ALLOC(ln.d_part, slots * 144);
@@ -823,7 +857,13 @@ static int msm_enqueue(zg_bases_s *b, size_t off, size_t n, const uint64_t *d_sc
         prof_end(ZG_PROF_MSM_DIGITS, st);
         prof_begin(ZG_PROF_MSM_SORT, st);
         hipLaunchKernelGGL(msm_colscan_kernel, dim3(div_up(p.NK, 256)), dim3(256), 0, st, ln.d_blockhist, nblk, p.NK, ln.d_hist);
-        hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(1024), 0, st, ln.d_hist, ln.d_starts, ln.d_nzrank, ln.d_nzlist, p.NK);
+        {
+            uint32_t tiles = div_up(p.NK, 1024);
+            hipLaunchKernelGGL(msm_scan_a_kernel, dim3(tiles), dim3(1024), 0, st, ln.d_hist, p.NK, ln.d_scan_tmp, ln.d_scan_tmp + p.NK,
+                               ln.d_scan_tmp + 2 * (size_t)p.NK);
+            hipLaunchKernelGGL(msm_scan_b_kernel, dim3(tiles), dim3(1024), 0, st, ln.d_hist, p.NK, ln.d_scan_tmp, ln.d_scan_tmp + p.NK,
+                               ln.d_scan_tmp + 2 * (size_t)p.NK, ln.d_starts, ln.d_nzrank, ln.d_nzlist);
+        }
         ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_scatter_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)(p.NK * 4)));
         hipLaunchKernelGGL(msm_scatter_lds_kernel, dim3(nblk), dim3(1024), p.NK * 4, st, ln.d_dig, (uint32_t)n, p.W, p.G, b->n,
@@ -834,7 +874,13 @@ static int msm_enqueue(zg_bases_s *b, size_t off, size_t n, const uint64_t *d_sc
         ZG_TRY(launch_digits_c(p.c, st, d_scalars, infp, (uint32_t)n, p.G, ln.d_dig, ln.d_hist));
         prof_end(ZG_PROF_MSM_DIGITS, st);
         prof_begin(ZG_PROF_MSM_SORT, st);
-        hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(1024), 0, st, ln.d_hist, ln.d_starts, ln.d_nzrank, ln.d_nzlist, p.NK);
+        {
+            uint32_t tiles = div_up(p.NK, 1024);
+            hipLaunchKernelGGL(msm_scan_a_kernel, dim3(tiles), dim3(1024), 0, st, ln.d_hist, p.NK, ln.d_scan_tmp, ln.d_scan_tmp + p.NK,
+                               ln.d_scan_tmp + 2 * (size_t)p.NK);
+            hipLaunchKernelGGL(msm_scan_b_kernel, dim3(tiles), dim3(1024), 0, st, ln.d_hist, p.NK, ln.d_scan_tmp, ln.d_scan_tmp + p.NK,
+                               ln.d_scan_tmp + 2 * (size_t)p.NK, ln.d_starts, ln.d_nzrank, ln.d_nzlist);
+        }
         ZG_HIP(hipMemsetAsync(ln.d_hist, 0, (size_t)p.NK * 4, st));
         hipLaunchKernelGGL(msm_scatter_kernel, dim3(div_up(n, 256), p.W), dim3(256), 0, st, ln.d_dig, (uint32_t)n, p.G, b->n,
                            (uint32_t)off, ln.d_starts, ln.d_hist, ln.d_sorted);
