@@ -1021,14 +1021,55 @@ int zg_msm_g1_partial_dev(zg_bases_t b, size_t off, size_t n, const uint64_t *d_
 }
 
 int zg_msm_g1_batch(zg_bases_t b, size_t n, const uint64_t *const *batches, size_t k, uint64_t *out_xy, uint8_t *out_inf) {
-    if (k && (!batches || !out_xy)) {
+    ZG_INIT();
+    if (!b || (k && (!batches || !out_xy))) {
         set_error("zg_msm_g1_batch: invalid argument");
         return ZG_ERR_INVALID;
     }
+    if (n > b->n) {
+        set_error("msm: range exceeds uploaded bases");
+        return ZG_ERR_INVALID;
+    }
+    if (k == 0) return ZG_OK;
+    // Pipelined: MSM i runs on stream i % 2 with its own scalar staging buffer and workspace lane, so the
+    // H2D copy and the latency-bound tail of one commitment overlap the accumulation of the next; all results
+    // stay on the device until one final copy.
+    std::lock_guard<std::mutex> lk(b->mu);
+    hipStream_t st[2] = {nullptr, nullptr};
+    uint64_t *d_sc[2] = {nullptr, nullptr}, *d_res = nullptr;
+    std::vector<uint64_t> h_res(9 * k);
+    int rc = ZG_OK;
+    hipError_t e = hipMalloc((void **)&d_res, 9 * 8 * k);
+    for (int i = 0; i < 2 && e == hipSuccess; i++) {
+        e = hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMalloc((void **)&d_sc[i], n ? n * 32 : 16);
+    }
+    if (e == hipSuccess) e = hipMemsetAsync(d_res, 0, 9 * 8 * k, st[0]);
+    if (e == hipSuccess) e = hipStreamSynchronize(st[0]);
+    hipEvent_t free_ev[2] = {nullptr, nullptr};
+    for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&free_ev[i], hipEventDisableTiming);
+    for (size_t i = 0; i < k && e == hipSuccess && rc == ZG_OK; i++) {
+        int s = (int)(i & 1);
+        if (n) e = hipMemcpyAsync(d_sc[s], batches[i], n * 32, hipMemcpyHostToDevice, st[s]);  // stream-ordered after MSM i-2
+        if (e != hipSuccess) break;
+        rc = msm_enqueue(b, 0, n, d_sc[s], st[s], 0, d_res + 9 * i, reinterpret_cast<uint8_t *>(d_res + 9 * i + 8));
+    }
+    for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipStreamSynchronize(st[i]);
+    if (e == hipSuccess && rc == ZG_OK) e = hipMemcpy(h_res.data(), d_res, 9 * 8 * k, hipMemcpyDeviceToHost);
+    for (int i = 0; i < 2; i++) {
+        if (free_ev[i]) (void)hipEventDestroy(free_ev[i]);
+        if (d_sc[i]) (void)hipFree(d_sc[i]);
+        if (st[i]) (void)hipStreamDestroy(st[i]);
+    }
+    if (d_res) (void)hipFree(d_res);
+    if (e != hipSuccess) {
+        set_error(std::string("zg_msm_g1_batch: ") + hipGetErrorString(e));
+        return ZG_ERR_HIP;
+    }
+    if (rc != ZG_OK) return rc;
     for (size_t i = 0; i < k; i++) {
-        uint8_t inf = 0;
-        ZG_TRY(zg_msm_g1(b, 0, n, batches[i], out_xy + 8 * i, &inf));
-        if (out_inf) out_inf[i] = inf;
+        for (int j = 0; j < 8; j++) out_xy[8 * i + j] = h_res[9 * i + j];
+        if (out_inf) out_inf[i] = (uint8_t)(h_res[9 * i + 8] & 0xff);
     }
     return ZG_OK;
 }

@@ -87,8 +87,18 @@ __device__ __forceinline__ void block_sum_pair(Fr &g0, Fr &g1, uint4 *sh) {
 }
 
 // round sums of a table: HIGH: g0 = sum t[0..h), g1 = sum t[h..2h);  LOW: g0 = sum t[2i], g1 = sum t[2i+1]
+// A kernel that produces the final pair of a round publishes it to the pinned host mailbox: sums first, then
+// (after a system-scope fence) the round's sequence number, so the host can spin on the mailbox instead of
+// paying a stream synchronisation per round. flag == nullptr: this launch only writes block partials.
+ZG_DEV void publish_seq(uint64_t *flag, uint64_t seq) {
+    if (flag) {
+        __threadfence_system();
+        __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 template <int LAYOUT>
-__global__ void __launch_bounds__(256) sc_sums_kernel(const uint64_t *t, size_t half, uint64_t *partials) {
+__global__ void __launch_bounds__(256) sc_sums_kernel(const uint64_t *t, size_t half, uint64_t *partials, uint64_t *flag, uint64_t seq) {
     __shared__ uint4 sh[256 * 4];
     Fr g0 = Fr::zero(), g1 = Fr::zero();
     size_t stride = (size_t)gridDim.x * 256;
@@ -101,6 +111,7 @@ __global__ void __launch_bounds__(256) sc_sums_kernel(const uint64_t *t, size_t 
     if (threadIdx.x == 0) {
         fe_store(partials + 8 * (size_t)blockIdx.x, g0);
         fe_store(partials + 8 * (size_t)blockIdx.x + 4, g1);
+        publish_seq(flag, seq);
     }
 }
 
@@ -113,7 +124,7 @@ struct FrArg {  // a challenge travels as a kernel argument: no H2D copy, no sta
 
 template <int LAYOUT>
 __global__ void __launch_bounds__(256) sc_fold_kernel(const uint64_t *t, size_t half, FrArg r, uint64_t *out,
-                                                      uint64_t *partials) {
+                                                      uint64_t *partials, uint64_t *flag, uint64_t seq) {
     __shared__ uint4 sh[256 * 4];
     Fr rv;
 #pragma unroll
@@ -140,11 +151,13 @@ __global__ void __launch_bounds__(256) sc_fold_kernel(const uint64_t *t, size_t 
     if (threadIdx.x == 0) {
         fe_store(partials + 8 * (size_t)blockIdx.x, g0);
         fe_store(partials + 8 * (size_t)blockIdx.x + 4, g1);
+        publish_seq(flag, seq);
     }
 }
 
 // reduce the per-block partial pairs to sums[0..8)
-__global__ void __launch_bounds__(256) sc_finish_kernel(const uint64_t *partials, uint32_t nblocks, uint64_t *sums) {
+__global__ void __launch_bounds__(256) sc_finish_kernel(const uint64_t *partials, uint32_t nblocks, uint64_t *sums, uint64_t *flag,
+                                                        uint64_t seq) {
     __shared__ uint4 sh[256 * 4];
     Fr g0 = Fr::zero(), g1 = Fr::zero();
     for (uint32_t k = threadIdx.x; k < nblocks; k += 256) {
@@ -155,6 +168,7 @@ __global__ void __launch_bounds__(256) sc_finish_kernel(const uint64_t *partials
     if (threadIdx.x == 0) {
         fe_store(sums, g0);
         fe_store(sums + 4, g1);
+        publish_seq(flag, seq);
     }
 }
 
@@ -163,23 +177,24 @@ static unsigned sc_blocks(size_t half) {
     return b > 2048 ? 2048 : b;  // grid-stride beyond 8 blocks per CU
 }
 
-static int launch_sums(int layout, const uint64_t *t, size_t len, uint64_t *partials, uint64_t *sums, hipStream_t st) {
+static int launch_sums(int layout, const uint64_t *t, size_t len, uint64_t *partials, uint64_t *sums, hipStream_t st,
+                       uint64_t *flag = nullptr, uint64_t seq = 0) {
     size_t half = len / 2;
     unsigned nb = sc_blocks(half);
     prof_begin(ZG_PROF_SC_SUMS, st);
     uint64_t *dst = nb == 1 ? sums : partials;  // one block: its pair IS the result
     if (layout == ZG_SC_HIGH_HALF)
-        hipLaunchKernelGGL(sc_sums_kernel<ZG_SC_HIGH_HALF>, dim3(nb), dim3(256), 0, st, t, half, dst);
+        hipLaunchKernelGGL(sc_sums_kernel<ZG_SC_HIGH_HALF>, dim3(nb), dim3(256), 0, st, t, half, dst, nb == 1 ? flag : nullptr, seq);
     else
-        hipLaunchKernelGGL(sc_sums_kernel<ZG_SC_LOW_PAIR>, dim3(nb), dim3(256), 0, st, t, half, dst);
-    if (nb > 1) hipLaunchKernelGGL(sc_finish_kernel, dim3(1), dim3(256), 0, st, partials, nb, sums);
+        hipLaunchKernelGGL(sc_sums_kernel<ZG_SC_LOW_PAIR>, dim3(nb), dim3(256), 0, st, t, half, dst, nb == 1 ? flag : nullptr, seq);
+    if (nb > 1) hipLaunchKernelGGL(sc_finish_kernel, dim3(1), dim3(256), 0, st, partials, nb, sums, flag, seq);
     prof_end(ZG_PROF_SC_SUMS, st);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
 
 static int launch_fold(int layout, const uint64_t *t, size_t len, const uint64_t r[4], uint64_t *out, uint64_t *partials,
-                       uint64_t *sums, hipStream_t st) {
+                       uint64_t *sums, hipStream_t st, uint64_t *flag = nullptr, uint64_t seq = 0) {
     size_t half = len / 2;
     unsigned nb = sc_blocks(half);
     FrArg ra;
@@ -190,10 +205,10 @@ static int launch_fold(int layout, const uint64_t *t, size_t len, const uint64_t
     uint64_t *dst = nb == 1 ? sums : partials;
     prof_begin(ZG_PROF_SC_FOLD, st);
     if (layout == ZG_SC_HIGH_HALF)
-        hipLaunchKernelGGL(sc_fold_kernel<ZG_SC_HIGH_HALF>, dim3(nb), dim3(256), 0, st, t, half, ra, out, dst);
+        hipLaunchKernelGGL(sc_fold_kernel<ZG_SC_HIGH_HALF>, dim3(nb), dim3(256), 0, st, t, half, ra, out, dst, nb == 1 ? flag : nullptr, seq);
     else
-        hipLaunchKernelGGL(sc_fold_kernel<ZG_SC_LOW_PAIR>, dim3(nb), dim3(256), 0, st, t, half, ra, out, dst);
-    if (nb > 1) hipLaunchKernelGGL(sc_finish_kernel, dim3(1), dim3(256), 0, st, partials, nb, sums);
+        hipLaunchKernelGGL(sc_fold_kernel<ZG_SC_LOW_PAIR>, dim3(nb), dim3(256), 0, st, t, half, ra, out, dst, nb == 1 ? flag : nullptr, seq);
+    if (nb > 1) hipLaunchKernelGGL(sc_finish_kernel, dim3(1), dim3(256), 0, st, partials, nb, sums, flag, seq);
     prof_end(ZG_PROF_SC_FOLD, st);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
@@ -235,6 +250,7 @@ struct zg_sc_s {
     uint64_t *h_pin = nullptr;  // pinned, device-visible: the kernels write the round sums (8 limbs) straight to the host
     bool sums_valid = false;
     hipStream_t st = nullptr;
+    uint64_t seq = 0;  // number of (sums) publications requested so far; h_pin[12] holds the last one completed
     size_t cap = 0;  // elements buf[0] can hold (sessions are pooled: hipMalloc/hipFree cost more than a round)
     std::mutex mu;
 };
@@ -265,6 +281,7 @@ static int sc_create(size_t len, int layout, hipStream_t st, zg_sc_s **out) {
                 zg_sc_s *s = g_pool[i];
                 g_pool.erase(g_pool.begin() + i);
                 s->layout = layout; s->len = len; s->st = st; s->cur = 0; s->sums_valid = false;
+                s->seq = 0; s->h_pin[12] = 0;
                 *out = s;
                 return ZG_OK;
             }
@@ -278,7 +295,8 @@ static int sc_create(size_t len, int layout, hipStream_t st, zg_sc_s **out) {
     hipError_t e = hipMalloc((void **)&s->buf[0], len * 32);
     if (e == hipSuccess) e = hipMalloc((void **)&s->buf[1], (len / 2 ? len / 2 : 1) * 32);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_partials, 2048 * 64);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_pin, 128);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_pin, 128, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) s->h_pin[12] = 0;
     if (e != hipSuccess) {
         set_error(std::string("zg_sumcheck_open: ") + hipGetErrorString(e));
         sc_free(s);
@@ -444,10 +462,23 @@ int zg_sumcheck_round_sums(zg_sc_t s, uint64_t g0[4], uint64_t g1[4]) {
     }
     std::lock_guard<std::mutex> lk(s->mu);
     if (!s->sums_valid) {
-        ZG_TRY(launch_sums(s->layout, s->buf[s->cur], s->len, s->d_partials, s->h_pin, s->st));
+        s->seq++;
+        ZG_TRY(launch_sums(s->layout, s->buf[s->cur], s->len, s->d_partials, s->h_pin, s->st, s->h_pin + 12, s->seq));
         s->sums_valid = true;
     }
-    ZG_HIP(hipStreamSynchronize(s->st));  // the only host<->device rendezvous of a round
+    // the only host<->device rendezvous of a round: spin on the mailbox's sequence word (written by the GPU after
+    // the sums, system-scope release); fall back to a stream synchronisation if it does not arrive promptly
+    {
+        volatile uint64_t *flag = s->h_pin + 12;
+        bool got = false;
+        for (uint64_t spin = 0; spin < (1ull << 22); spin++) {
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == s->seq) { got = true; break; }
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        if (!got) ZG_HIP(hipStreamSynchronize(s->st));
+    }
     for (int i = 0; i < 4; i++) {
         g0[i] = s->h_pin[i];
         g1[i] = s->h_pin[4 + i];
@@ -464,7 +495,9 @@ int zg_sumcheck_bind(zg_sc_t s, const uint64_t r[4]) {
     std::lock_guard<std::mutex> lk(s->mu);
     // buf[1] holds len/2 elements at most; after the first fold both buffers are large enough
     int nxt = s->cur ^ 1;
-    ZG_TRY(launch_fold(s->layout, s->buf[s->cur], s->len, r, s->buf[nxt], s->d_partials, s->h_pin, s->st));  // asynchronous
+    s->seq++;
+    ZG_TRY(launch_fold(s->layout, s->buf[s->cur], s->len, r, s->buf[nxt], s->d_partials, s->h_pin, s->st, s->h_pin + 12,
+                       s->seq));  // asynchronous
     s->cur = nxt;
     s->len /= 2;
     s->sums_valid = s->len >= 2;
