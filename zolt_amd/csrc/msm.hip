@@ -891,6 +891,8 @@ static int msm_enqueue(zg_bases_s *b, size_t off, size_t n, const uint64_t *d_sc
         ZG_HIP(hipMemsetAsync(ln.d_state, 0, sizeof(MsmState), st));
         hipLaunchKernelGGL(msm_accumulate_chunk_kernel, dim3(div_up(p.NT, 256)), dim3(256), 0, st, ln.d_sorted, ln.d_starts, ln.d_nzrank,
                            ln.d_nzlist, b->d_table, p.NK, p.NT, ln.d_part);
+        prof_end(ZG_PROF_MSM_ACCUMULATE, st);  // the dominant kernel alone; combine/heavy stages count as reduction
+        prof_begin(ZG_PROF_MSM_REDUCE, st);
         hipLaunchKernelGGL(msm_bucket_combine_kernel, dim3(div_up((size_t)p.NK * p.GS, 64)), dim3(64), 0, st, ln.d_part, ln.d_starts,
                            ln.d_nzrank, p.NK, p.NT, p.GS, ln.d_partial, ln.d_heavy, reinterpret_cast<MsmState *>(ln.d_state));
         uint32_t nblk_a = (p.NT + p.NK) / HEAVY_BLOCK_ITEMS + 1;
@@ -902,9 +904,9 @@ static int msm_enqueue(zg_bases_s *b, size_t off, size_t n, const uint64_t *d_sc
     } else {
         hipLaunchKernelGGL(msm_accumulate_kernel, dim3(div_up((size_t)p.NK * p.S, 256)), dim3(256), 0, st, ln.d_sorted, ln.d_starts,
                            b->d_table, p.NK, p.S, ln.d_partial);
+        prof_end(ZG_PROF_MSM_ACCUMULATE, st);
+        prof_begin(ZG_PROF_MSM_REDUCE, st);
     }
-    prof_end(ZG_PROF_MSM_ACCUMULATE, st);
-    prof_begin(ZG_PROF_MSM_REDUCE, st);
     hipLaunchKernelGGL(msm_bitsum_kernel, dim3(p.PB, p.c, p.G), dim3(256), 0, st, ln.d_partial, p.NB, p.c, ln.d_bits);
     hipLaunchKernelGGL(msm_final_kernel, dim3(p.G), dim3(256), 0, st, ln.d_bits, p.c, p.PB, p.G, ln.d_rg, mode, d_rec, d_inf_out);
     if (p.G > 1) hipLaunchKernelGGL(msm_groups_kernel, dim3(1), dim3(1), 0, st, ln.d_rg, p.G, p.c, mode, d_rec, d_inf_out);
