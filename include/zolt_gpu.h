@@ -158,6 +158,14 @@ ZG_API int zg_g1_combine_partials_dev_async(const uint64_t *d_partials_jac /* k*
 ZG_API int zg_g1_scalar_mul_batch(const uint64_t *xy, const uint8_t *inf, const uint64_t *scalars_mont, size_t n,
                            uint64_t *out_xy, uint8_t *out_inf);
 
+/* HyperKZG.open (src/poly/commitment/mod.zig:261-324), resident on the device: per variable i the quotient
+ * q[j] = cur[j+half] - cur[j] is committed (MSM over srs[0..min(half, srs_len))), then cur is folded by point[i]
+ * (high half). Writes num_vars quotient commitments (rounds that the reference skips when the table runs out are
+ * reported as the identity) and the final evaluation; num_vars == 0 returns `value` like the reference. */
+ZG_API int zg_hyperkzg_open(zg_bases_t srs, const uint64_t *evals, size_t n_evals, const uint64_t *point, size_t num_vars,
+                     const uint64_t value[4], uint64_t *q_xy /* num_vars*8 */, uint8_t *q_inf /* num_vars */,
+                     uint64_t final_eval[4]);
+
 /* ------------------------------------------------------------------ poly tables */
 /* EqPolynomial.evals / evalsSliceWithScaling (src/poly/mod.zig:240-290): out[2^v], index MSB <-> r[0];
  * scale may be NULL (= one). Identical values to GruenSplitEqPolynomial's tables

@@ -79,6 +79,25 @@ TEST(hyperkzg_batch_commit) {
     EXPECT(HyperKZG::commit(params, e1).point.eql(params.powers_of_tau_g1[1]));
 }
 
+// src/poly/commitment/mod.zig:1448-1472 "hyperkzg multilinear evaluation" + open(): the final evaluation of open() at a
+// boolean point is the table entry it selects (high variable first), and quotient 0 is commit(hi - lo)
+TEST(hyperkzg_open_corner_points) {
+    auto params = HyperKZG::setup(8);
+    std::vector<Fr> evals;
+    for (int i = 0; i < 8; i++) evals.push_back(Fr::fromU64(100 + 7 * i));
+    for (int idx = 0; idx < 8; idx++) {
+        std::vector<Fr> pt = {Fr::fromU64((idx >> 2) & 1), Fr::fromU64((idx >> 1) & 1), Fr::fromU64(idx & 1)};
+        auto pr = HyperKZG::open(params, evals, pt, Fr::zero());
+        EXPECT(pr.final_eval.eql(evals[idx]));
+        EXPECT(pr.quotient_commitments.size() == 3);
+    }
+    std::vector<Fr> q0;
+    for (int j = 0; j < 4; j++) q0.push_back(evals[j + 4].sub(evals[j]));
+    auto pr = HyperKZG::open(params, evals, {Fr::fromU64(3), Fr::fromU64(5), Fr::fromU64(9)}, Fr::zero());
+    EXPECT(pr.quotient_commitments[0].eql(HyperKZG::commit(params, q0)));
+    EXPECT(HyperKZG::open(params, evals, {}, Fr::fromU64(42)).final_eval.eql(Fr::fromU64(42)));
+}
+
 // src/poly/mod.zig:816-888 "dense polynomial bindLow"
 TEST(dense_polynomial_bind_low) {
     DensePolynomial p({Fr::fromU64(1), Fr::fromU64(2), Fr::fromU64(3), Fr::fromU64(4)});

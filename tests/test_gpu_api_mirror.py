@@ -48,6 +48,22 @@ def test_hyperkzg_setup_commit_open(env):
     assert np.array_equal(final, wfin) and len(quotients) == 6
     for i, (q, qi) in enumerate(quotients):
         assert qi == wqi[i] and np.array_equal(q, wq[i])
+    # table shorter than 2^num_vars (folding stops, :289), odd length, SRS shorter than the quotient
+    for n_ev, v, n_srs in ((5, 4, 64), (37, 5, 64), (64, 6, 20), (1, 3, 64), (128, 7, 64)):
+        ev = _rand(ob, 40 + n_ev, n_ev)
+        pt = _rand(ob, 50 + v, v)
+        pr = api.HyperKZG.setup(n_srs)
+        ws, wi = ob.hyperkzg_setup(n_srs)
+        qs, fin = api.HyperKZG.open(pr, ev, pt, np.zeros(4, dtype=np.uint64))
+        wq, wqi, wfin = ob.hyperkzg_open(ws, wi, ev, pt, np.zeros(4, dtype=np.uint64))
+        assert np.array_equal(fin, wfin), (n_ev, v)
+        done = 0
+        ln = n_ev
+        while done < v and ln // 2 > 0:   # rounds the reference actually executes
+            assert qs[done][1] == wqi[done] and np.array_equal(qs[done][0], wq[done]), (n_ev, v, done)
+            ln //= 2
+            done += 1
+        pr.deinit()
     params.deinit()
 
 

@@ -211,17 +211,8 @@ class HyperKZG:
         point = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1, 4)
         if point.shape[0] == 0:
             return [], np.asarray(value, dtype=np.uint64)
-        cur = np.ascontiguousarray(evals, dtype=np.uint64).reshape(-1, 4)
-        quotients = []
-        for i in range(point.shape[0]):
-            half = cur.shape[0] // 2
-            if half == 0:
-                break
-            q = lib.field_op(lib.FR, lib.OP_SUB, cur[half:2 * half], cur[:half])
-            quotients.append(HyperKZG.commit(params, q))
-            cur = lib.fr_bind_high(cur[:2 * half], point[i])
-        final = cur[0] if cur.shape[0] else np.zeros(4, dtype=np.uint64)
-        return quotients, final
+        q, qinf, final = lib.hyperkzg_open(params._dev, evals, point, value)  # whole loop resident on the device
+        return [(q[i], int(qinf[i])) for i in range(point.shape[0])], final
 
 
 # ---- polynomials

@@ -55,6 +55,13 @@ __global__ void __launch_bounds__(256) eq_main_kernel(const uint64_t *r_lo, int 
     }
 }
 
+// q[j] = t[j + half] - t[j]   (HyperKZG.open's quotient, src/poly/commitment/mod.zig:296-299)
+__global__ void __launch_bounds__(256) fr_sub_halves_kernel(const uint64_t *t, size_t half, uint64_t *q) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < half; j += stride)
+        fe_store(q + 4 * j, fe_sub(fe_load<FrParams>(t + 4 * (j + half)), fe_load<FrParams>(t + 4 * j)));
+}
+
 // f[i] = eq[i] * (Az[i]*Bz[i] - Cz[i])
 __global__ void __launch_bounds__(256) spartan_combine_kernel(const uint64_t *eq, const uint64_t *az, const uint64_t *bz,
                                                               const uint64_t *cz, size_t n, uint64_t *out) {
@@ -414,6 +421,70 @@ int zg_fr_spartan_combine(const uint64_t *eq, const uint64_t *az, const uint64_t
     }
     (void)hipFree(d);
     return rc;
+}
+
+int zg_hyperkzg_open(zg_bases_t srs, const uint64_t *evals, size_t n_evals, const uint64_t *point, size_t num_vars,
+                     const uint64_t value[4], uint64_t *q_xy, uint8_t *q_inf, uint64_t final_eval[4]) {
+    ZG_INIT();
+    if (!final_eval || (num_vars && (!point || !q_xy)) || (n_evals && !evals) || (num_vars == 0 && !value)) {
+        set_error("zg_hyperkzg_open: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    if (num_vars == 0) {  // :270-276
+        for (int i = 0; i < 4; i++) final_eval[i] = value[i];
+        return ZG_OK;
+    }
+    hipStream_t st = lib_stream();
+    size_t srs_len = zg_g1_bases_len(srs);
+    size_t cap = n_evals ? n_evals : 1;
+    uint64_t *d_a = nullptr, *d_b = nullptr, *d_q = nullptr, *d_res = nullptr, *d_misc = nullptr;
+    std::vector<uint64_t> h_res(9 * num_vars + 4, 0);
+    hipError_t e = hipMalloc((void **)&d_a, cap * 32);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_b, (cap / 2 + 1) * 32);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_q, (cap / 2 + 1) * 32);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_res, (9 * num_vars + 4) * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_misc, 2048 * 64 + 64);
+    if (e == hipSuccess) e = hipMemsetAsync(d_res, 0, (9 * num_vars + 4) * 8, st);
+    if (e == hipSuccess && n_evals) e = hipMemcpyAsync(d_a, evals, n_evals * 32, hipMemcpyHostToDevice, st);
+    int rc = ZG_OK;
+    size_t len = n_evals;
+    uint64_t *cur = d_a, *nxt = d_b;
+    for (size_t i = 0; i < num_vars && e == hipSuccess && rc == ZG_OK; i++) {
+        size_t half = len / 2;
+        if (half == 0) {  // :289: the reference stops folding; remaining quotients stay unset -> identity here
+            for (size_t r = i; r < num_vars; r++) h_res[9 * r + 8] = 0x100;  // marker: identity
+            break;
+        }
+        unsigned nb = div_up(half, 256);
+        if (nb > 4096) nb = 4096;
+        hipLaunchKernelGGL(fr_sub_halves_kernel, dim3(nb), dim3(256), 0, st, cur, half, d_q);
+        size_t nc = half < srs_len ? half : srs_len;  // commit(): n = min(evals.len, srs.len), :246
+        rc = zg_msm_g1_dev_async(srs, 0, nc, d_q, st, d_res + 9 * i, reinterpret_cast<uint8_t *>(d_res + 9 * i + 8));
+        if (rc != ZG_OK) break;
+        rc = launch_fold(ZG_SC_HIGH_HALF, cur, 2 * half, point + 4 * i, nxt, d_misc, d_misc + 2048 * 8, st);
+        uint64_t *t = cur; cur = nxt; nxt = t;
+        len = half;
+    }
+    if (e == hipSuccess && rc == ZG_OK && len > 0)
+        e = hipMemcpyAsync(d_res + 9 * num_vars, cur, 32, hipMemcpyDeviceToDevice, st);  // final = current[0], :317
+    std::vector<uint64_t> dev_res(9 * num_vars + 4);
+    if (e == hipSuccess && rc == ZG_OK) e = hipMemcpyAsync(dev_res.data(), d_res, (9 * num_vars + 4) * 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    void *ptrs[] = {d_a, d_b, d_q, d_res, d_misc};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (e != hipSuccess) {
+        set_error(std::string("zg_hyperkzg_open: ") + hipGetErrorString(e));
+        return ZG_ERR_HIP;
+    }
+    if (rc != ZG_OK) return rc;
+    for (size_t i = 0; i < num_vars; i++) {
+        bool skipped = h_res[9 * i + 8] == 0x100;
+        for (int j = 0; j < 8; j++) q_xy[8 * i + j] = skipped ? 0 : dev_res[9 * i + j];
+        if (q_inf) q_inf[i] = skipped ? 1 : (uint8_t)(dev_res[9 * i + 8] & 0xff);
+    }
+    for (int j = 0; j < 4; j++) final_eval[j] = len > 0 ? dev_res[9 * num_vars + j] : 0;
+    return ZG_OK;
 }
 
 // ---------------------------------------------------------------- sumcheck session

@@ -308,6 +308,22 @@ struct HyperKZG {
         size_t n = evals.size() < params.powers_of_tau_g1.size() ? evals.size() : params.powers_of_tau_g1.size();
         return Commitment{params.device->msm(evals.data(), n)};
     }
+    struct Proof {  // :155-167
+        std::vector<Commitment> quotient_commitments;
+        Fr final_eval;
+    };
+    // open(params, evals, point, value) — :261-324, the whole fold/commit loop stays on the device
+    static Proof open(const SetupParams &params, const std::vector<Fr> &evals, const std::vector<Fr> &point, const Fr &value) {
+        Proof pr;
+        size_t v = point.size();
+        std::vector<uint64_t> q(8 * v);
+        std::vector<uint8_t> qi(v);
+        check(zg_hyperkzg_open(params.device->handle(), reinterpret_cast<const uint64_t *>(evals.data()), evals.size(),
+                               reinterpret_cast<const uint64_t *>(point.data()), v, value.limbs, q.data(), qi.data(), pr.final_eval.limbs),
+              "zg_hyperkzg_open");
+        for (size_t i = 0; i < v; i++) pr.quotient_commitments.push_back(Commitment{unpack_point(&q[8 * i], qi[i])});
+        return pr;
+    }
     static std::vector<Commitment> batchCommit(const SetupParams &params, const std::vector<std::vector<Fr>> &polys) {  // :558-570
         std::vector<Commitment> out;
         for (const auto &p : polys) out.push_back(commit(params, p));

@@ -29,6 +29,7 @@ SYMBOLS = [
     "zg_g1_bases_upload", "zg_g1_bases_upload_dev", "zg_g1_bases_free", "zg_g1_bases_len",
     "zg_msm_g1", "zg_msm_g1_dev", "zg_msm_g1_dev_async", "zg_msm_g1_batch", "zg_msm_g1_partial_dev",
     "zg_g1_combine_partials_dev", "zg_g1_combine_partials_dev_async", "zg_g1_scalar_mul_batch",
+    "zg_hyperkzg_open",
     "zg_fr_eq_table", "zg_fr_eq_table_dev", "zg_fr_bind_low", "zg_fr_bind_high",
     "zg_fr_spartan_combine", "zg_fr_spartan_combine_dev",
     "zg_sumcheck_open", "zg_sumcheck_open_dev", "zg_sumcheck_round_sums", "zg_sumcheck_bind",
@@ -219,6 +220,18 @@ def g1_scalar_mul_batch(xy, inf, scalars):
     oinf = np.zeros(n, dtype=np.uint8)
     _chk(_lib.zg_g1_scalar_mul_batch(_h(xy), _hb(inf), _h(scalars), C.c_size_t(n), _h(out), _hb(oinf)), "zg_g1_scalar_mul_batch")
     return out, oinf
+
+
+def hyperkzg_open(bases, evals, point, value):
+    """HyperKZG.open on the device -> (quotient commitments (v,8), inf flags (v,), final_eval)."""
+    evals, point, value = _c(evals), _c(point), _c(value)
+    v = point.size // 4
+    q = np.zeros((v, 8), dtype=np.uint64)
+    qinf = np.zeros(v, dtype=np.uint8)
+    fin = np.zeros(4, dtype=np.uint64)
+    _chk(_lib.zg_hyperkzg_open(bases._h, _h(evals), C.c_size_t(evals.size // 4), _h(point), C.c_size_t(v), _h(value), _h(q),
+                               _hb(qinf), _h(fin)), "zg_hyperkzg_open")
+    return q, qinf, fin
 
 
 # ---- poly
