@@ -128,3 +128,31 @@ def test_c_abi_is_reentrant(env):
         th.join()
     shared.free()
     assert not errors, errors
+
+
+def test_srs_raw_binary_g1_round_trip(env):
+    """SRS raw binary wire format, G1 section (src/poly/commitment/srs.zig:256-306,358-408): bytes written from
+    the oracle's mock SRS parse back to the same Montgomery limbs, commit through them matches, infinity is all-zero."""
+    api, lib, ob = env
+    from oracle import pymodel as pm
+    n = 33
+    srs, inf = ob.hyperkzg_setup(n)
+    pts = pm.mock_srs(n)
+    want_bytes = n.to_bytes(4, "little") + b"".join(pm.commitment_bytes(p) for p in pts) + bytes(320)
+    assert api.srs_g1_to_raw(srs, inf) == want_bytes
+    xy, pinf, trailer = api.srs_g1_from_raw(want_bytes)
+    assert np.array_equal(xy, srs) and not pinf.any() and trailer == bytes(320)
+    blob = bytearray(want_bytes)
+    blob[4 + 64 * 5: 4 + 64 * 6] = bytes(64)  # point 5 := infinity
+    xy2, pinf2, _ = api.srs_g1_from_raw(bytes(blob))
+    assert pinf2[5] == 1 and pinf2.sum() == 1 and not xy2[5].any()
+    ev = _rand(ob, 60, n)
+    b = lib.Bases.upload(xy2, pinf2)
+    got, ginf = b.msm(ev)
+    b.free()
+    winf = inf.copy()
+    winf[5] = 1
+    want, wi = ob.msm_g1(srs, winf, ev)
+    assert ginf == wi and np.array_equal(got, want)
+    with pytest.raises(api.SRSError):
+        api.srs_g1_from_raw(want_bytes[:100])

@@ -215,6 +215,38 @@ class HyperKZG:
         return [(q[i], int(qinf[i])) for i in range(point.shape[0])], final
 
 
+# ---- SRS wire format (G1 section)
+class SRSError(Exception):
+    pass
+
+
+def srs_g1_from_raw(data):
+    """G1 part of loadFromRawBinary (src/poly/commitment/srs.zig:256-306): u32 n (LE) | n x (x BE 32 B | y BE 32 B).
+    All-zero 64 bytes = point at infinity (parseG1Uncompressed, :65-99). Coordinates are reduced and converted to
+    Montgomery form on the GPU (Fp.fromBytesBE -> fromBytes, src/field/mod.zig:171-210). The G2 / generator trailer
+    (pairing side, out of scope) is returned untouched. -> (xy (n,8) uint64, inf (n,) uint8, trailer bytes)"""
+    if len(data) < 4:
+        raise SRSError("TruncatedData")
+    n = int.from_bytes(data[:4], "little")
+    if len(data) < 4 + 64 * n + 128 + 64 + 128:
+        raise SRSError("TruncatedData")
+    body = np.frombuffer(data, dtype=np.uint8, count=64 * n, offset=4).reshape(n, 2, 32)
+    inf = (~body.reshape(n, 64).any(axis=1)).astype(np.uint8)
+    raw = np.ascontiguousarray(body[:, :, ::-1]).view(np.uint64).reshape(n, 8)  # BE bytes -> LE limbs
+    xy = lib.field_op(lib.FP, lib.OP_TO_MONT, raw.reshape(2 * n, 4)).reshape(n, 8) if n else np.zeros((0, 8), dtype=np.uint64)
+    xy[inf == 1] = 0
+    return xy, inf, bytes(data[4 + 64 * n:])
+
+
+def srs_g1_to_raw(xy, inf, trailer=bytes(128 + 64 + 128)):
+    """serializeToRawBinary's G1 section (src/poly/commitment/srs.zig:358-408): toBytesBE of x and y."""
+    xy = np.ascontiguousarray(xy, dtype=np.uint64).reshape(-1, 8)
+    n = xy.shape[0]
+    canon = lib.field_op(lib.FP, lib.OP_FROM_MONT, xy.reshape(2 * n, 4)) if n else np.zeros((0, 4), dtype=np.uint64)
+    be = np.ascontiguousarray(canon).view(np.uint8).reshape(n, 2, 32)[:, :, ::-1]
+    return n.to_bytes(4, "little") + np.ascontiguousarray(be).tobytes() + bytes(trailer)
+
+
 # ---- polynomials
 class EqPolynomial:
     def __init__(self, r):
