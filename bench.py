@@ -99,7 +99,11 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # ZOLT_BENCH_FORCE_SHARDED=1 (with torchrun --nproc-per-node 1) drives the sharded code path — partial MSM,
+    # RCCL all-gather, device combine — on a single GPU, so it can be exercised on a 1-GPU box
+    force_sharded = bool(os.environ.get("ZOLT_BENCH_FORCE_SHARDED")) and "WORLD_SIZE" in os.environ
+    use_dist = world > 1 or force_sharded
+    if use_dist:
         if dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -118,7 +122,9 @@ def main():
     torch.cuda.set_stream(work_stream)
     stream = work_stream.cuda_stream
     assert stream != 0
-    nstreams = max(1, args.streams) if world == 1 else 1
+    nstreams = max(1, args.streams)
+    if world > 1 and dist_backend != "nccl":
+        nstreams = 1  # the gloo debugging path stages through the host and is synchronous anyway
     tstreams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(nstreams - 1)]
 
     # ---- synthetic inputs, generated with the product's own kernels (untimed)
@@ -141,20 +147,21 @@ def main():
         expect_k.append(closed_form_scalar(raw, start))
     setup_s = time.time() - t0
 
-    backend = api.GpuShardBackend(bases, n_loc, stream)
+    backend = api.GpuShardBackend(bases, n_loc)
     sharded = api.ShardedMSM(backend, world, rank)
     d_res = torch.zeros((max(args.steps, args.warmup, 1), 9), dtype=torch.int64, device=dev)  # xy[8] + flag word
 
     def step(i, slot):
         sc = d_scalars[i % N_SCALAR_SETS]
-        if world == 1:
+        if not use_dist:
             st = tstreams[i % nstreams].cuda_stream
             bases.msm_dev_async(sc.data_ptr(), n_loc, d_res[slot].data_ptr(), d_res[slot, 8:].data_ptr(), stream=st)
             return None
-        return sharded.compute(sc, out=d_res[slot])
+        with torch.cuda.stream(tstreams[i % nstreams]):
+            return sharded.compute(sc, out=d_res[slot])
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -190,8 +197,7 @@ def main():
         assert int(res[i, 8] & 0xFF) == winf and np.array_equal(res[i, :8], wxy), f"MSM result mismatch at step {i}"
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     ms_per_step = elapsed / args.steps * 1e3
@@ -224,7 +230,7 @@ def main():
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(bases_xy, d_scalars[0].cpu().numpy().view(np.uint64), want[0], args.logn)
     print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

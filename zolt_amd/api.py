@@ -147,23 +147,32 @@ class ShardedMSM:
 
 
 class GpuShardBackend:
-    """ShardedMSM backend over libzolt_gpu.so; tensors are torch CUDA tensors (device memory plumbing)."""
+    """ShardedMSM backend over libzolt_gpu.so; tensors are torch CUDA tensors (device memory plumbing). All work is
+    enqueued on torch's CURRENT stream, so the caller can rotate streams (`with torch.cuda.stream(s)`) to overlap
+    consecutive sharded MSMs; the collective is ordered against that stream by torch.distributed."""
 
-    def __init__(self, bases, n_local, stream_ptr=0):
-        self.bases, self.n, self.stream = bases, n_local, stream_ptr
+    def __init__(self, bases, n_local):
+        self.bases, self.n = bases, n_local
+
+    @staticmethod
+    def _stream():
+        import torch
+        s = torch.cuda.current_stream().cuda_stream
+        assert s != 0, "run under an explicit torch stream: a NULL stream means the library's own stream"
+        return s
 
     def partial(self, d_scalars):
         import torch
         out = torch.empty(12, dtype=torch.int64, device=d_scalars.device)
-        self.bases.msm_partial_dev(d_scalars.data_ptr(), self.n, out.data_ptr(), stream=self.stream)
+        self.bases.msm_partial_dev(d_scalars.data_ptr(), self.n, out.data_ptr(), stream=self._stream())
         return out
 
     def combine(self, gathered):
-        return lib.combine_partials_dev(gathered.data_ptr(), gathered.shape[0], stream=self.stream)
+        return lib.combine_partials_dev(gathered.data_ptr(), gathered.shape[0], stream=self._stream())
 
     def combine_async(self, gathered, out):
-        self._keep = gathered  # the kernel reads it after this call returns
-        lib.combine_partials_dev_async(gathered.data_ptr(), gathered.shape[0], out.data_ptr(), out[8:].data_ptr(), stream=self.stream)
+        gathered.record_stream(__import__("torch").cuda.current_stream())
+        lib.combine_partials_dev_async(gathered.data_ptr(), gathered.shape[0], out.data_ptr(), out[8:].data_ptr(), stream=self._stream())
         return None
 
 
