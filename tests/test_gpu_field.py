@@ -49,6 +49,7 @@ def test_field_ops_match_oracle(zl, field):
     assert np.array_equal(zl.field_op(field, zl.OP_INV, a[:k]), ob.f_inv(field, a[:k]))
     k = 1 << 16  # binary-Euclid inversion used by the device toAffine
     assert np.array_equal(zl.field_op(field, zl.OP_INV_FAST, a[:k]), ob.f_inv(field, a[:k]))
+    assert np.array_equal(zl.field_op(field, zl.OP_INV_XGCD, a[:k]), ob.f_inv(field, a[:k]))
 
 
 def test_field_kats(zl):

@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "inv_table.hip.h"
+
 namespace zg {
 
 typedef uint32_t u32;
@@ -23,6 +25,7 @@ typedef uint64_t u64;
 
 // ---- field parameters (u32 limbs, little-endian); values from field/mod.zig:16-41,51-75
 struct FrParams {
+    static __device__ __forceinline__ const uint32_t *kaliski_tab() { return KALISKI_TAB_FR; }
     static constexpr u32 MOD[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u,
                                    0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
     static constexpr u32 ONE[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u,
@@ -34,6 +37,7 @@ struct FrParams {
     static constexpr u32 INV = 0xefffffffu;  // -MOD^-1 mod 2^32 (low word of BN254_INV)
 };
 struct FpParams {
+    static __device__ __forceinline__ const uint32_t *kaliski_tab() { return KALISKI_TAB_FP; }
     static constexpr u32 MOD[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u,
                                    0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
     static constexpr u32 ONE[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u,
@@ -300,6 +304,64 @@ ZG_DEV Fe<P> fe_inv_fast(const Fe<P> &a) {
 #pragma unroll
     for (int i = 0; i < 8; i++) r3.l[i] = P::R3[i];
     return fe_mul(x, r3);
+}
+
+// ---- Kaliski almost-inverse: the same shift/subtract loop without modular halvings (r and s only grow by
+// shifts and adds, < 2*MOD), about half the instructions of fe_inv_fast; the 2^k it leaves behind
+// (254 <= k <= 508) is removed together with the Montgomery factors by one product with a tabulated constant.
+ZG_DEV void limbs_shl1(u32 *x) {
+#pragma unroll
+    for (int i = 7; i > 0; i--) x[i] = (x[i] << 1) | (x[i - 1] >> 31);
+    x[0] <<= 1;
+}
+ZG_DEV void limbs_add(u32 *a, const u32 *b) {
+    u32 carry = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u64 t = (u64)a[i] + b[i] + carry;
+        a[i] = (u32)t;
+        carry = (u32)(t >> 32);
+    }
+}
+ZG_DEV bool limbs_gt(const u32 *a, const u32 *b) {  // a > b
+    bool gt = false;
+#pragma unroll
+    for (int i = 0; i < 8; i++) gt = (a[i] > b[i]) || (a[i] == b[i] && gt);
+    return gt;
+}
+ZG_DEV bool limbs_nonzero(const u32 *a) {
+    u32 o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o |= a[i];
+    return o != 0;
+}
+
+template <class P>
+ZG_DEV Fe<P> fe_inv_kaliski(const Fe<P> &a) {
+    if (a.is_zero()) return Fe<P>::zero();
+    u32 u[8], v[8], r[8], s[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { u[i] = P::MOD[i]; v[i] = a.l[i]; r[i] = 0; s[i] = 0; }
+    s[0] = 1;
+    u32 k = 0;
+    while (limbs_nonzero(v)) {
+        if (!(u[0] & 1u)) { limbs_shr1(u); limbs_shl1(s); }
+        else if (!(v[0] & 1u)) { limbs_shr1(v); limbs_shl1(r); }
+        else if (limbs_gt(u, v)) { limbs_sub(u, v); limbs_shr1(u); limbs_add(r, s); limbs_shl1(s); }
+        else { limbs_sub(v, u); limbs_shr1(v); limbs_add(s, r); limbs_shl1(r); }
+        k++;
+    }
+    // r = -(a^-1) 2^k mod MOD with r < 2 MOD
+    Fe<P> x;
+#pragma unroll
+    for (int i = 0; i < 8; i++) x.l[i] = r[i];
+    x = fe_reduce_once(x);
+    x = fe_neg(x);
+    const u32 *c = P::kaliski_tab() + 8 * (size_t)(k - 254u);
+    Fe<P> ck;
+#pragma unroll
+    for (int i = 0; i < 8; i++) ck.l[i] = c[i];
+    return fe_mul(x, ck);
 }
 
 typedef Fe<FrParams> Fr;

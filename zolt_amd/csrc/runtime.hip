@@ -104,7 +104,8 @@ __global__ void __launch_bounds__(256) field_op_kernel(int op, const uint64_t *a
             case ZG_OP_SQR: r = fe_sqr(x); break;
             case ZG_OP_INV: r = fe_inv(x); break;
             case ZG_OP_FROM_MONT: r = fe_from_mont(x); break;
-            case ZG_OP_INV_FAST: r = fe_inv_fast(x); break;
+            case ZG_OP_INV_FAST: r = fe_inv_kaliski(x); break;
+            case ZG_OP_INV_XGCD: r = fe_inv_fast(x); break;
             default: r = fe_to_mont(x); break;
         }
         fe_store(out + 4 * i, r);
@@ -203,8 +204,8 @@ int zg_profile_end(double ms_out[ZG_PROF_NKERNELS], uint64_t count_out[ZG_PROF_N
 
 int zg_field_op(int field, int op, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n) {
     ZG_INIT();
-    if (op < 0 || op > ZG_OP_X3_29 || (op >= ZG_OP_MUL29 && field != ZG_FIELD_FP) || (field != ZG_FIELD_FR && field != ZG_FIELD_FP) || !a || !out ||
-        ((op <= ZG_OP_SUB || op >= ZG_OP_MUL29) && !b)) {
+    if (op < 0 || op > ZG_OP_INV_XGCD || (op >= ZG_OP_MUL29 && op <= ZG_OP_X3_29 && field != ZG_FIELD_FP) || (field != ZG_FIELD_FR && field != ZG_FIELD_FP) || !a || !out ||
+        ((op <= ZG_OP_SUB || (op >= ZG_OP_MUL29 && op <= ZG_OP_X3_29)) && !b)) {
         set_error("zg_field_op: invalid argument");
         return ZG_ERR_INVALID;
     }
@@ -214,13 +215,13 @@ int zg_field_op(int field, int op, const uint64_t *a, const uint64_t *b, uint64_
     ZG_HIP(hipMalloc(&da, bytes));
     ZG_HIP(hipMalloc(&dout, bytes));
     ZG_HIP(hipMemcpyAsync(da, a, bytes, hipMemcpyHostToDevice, g_stream));
-    if (op <= ZG_OP_SUB || op >= ZG_OP_MUL29) {
+    if (op <= ZG_OP_SUB || (op >= ZG_OP_MUL29 && op <= ZG_OP_X3_29)) {
         ZG_HIP(hipMalloc(&db, bytes));
         ZG_HIP(hipMemcpyAsync(db, b, bytes, hipMemcpyHostToDevice, g_stream));
     }
     unsigned blocks = div_up(n, 256);
     if (blocks > 4096) blocks = 4096;
-    if (op >= ZG_OP_MUL29)
+    if (op >= ZG_OP_MUL29 && op <= ZG_OP_X3_29)
         hipLaunchKernelGGL(fp29_op_kernel, dim3(blocks), dim3(256), 0, g_stream, op, da, db, dout, n);
     else if (field == ZG_FIELD_FR)
         hipLaunchKernelGGL(field_op_kernel<FrParams>, dim3(blocks), dim3(256), 0, g_stream, op, da, db, dout, n);
