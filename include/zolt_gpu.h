@@ -154,6 +154,9 @@ ZG_API int zg_g1_combine_partials_dev(const uint64_t *d_partials_jac /* k*12 */,
 /* asynchronous form: result (8 limbs) and flag land in DEVICE memory, ordered on `stream` */
 ZG_API int zg_g1_combine_partials_dev_async(const uint64_t *d_partials_jac /* k*12 */, size_t k, void *stream, uint64_t *d_out_xy,
                                      uint8_t *d_out_inf);
+/* AffinePoint.isOnCurve (src/msm/mod.zig:106-115) for n points: out[i] = 1 iff infinity or y^2 == x^3 + 3
+ * (what parseG1Uncompressed checks per SRS point, src/poly/commitment/srs.zig:93-96). */
+ZG_API int zg_g1_is_on_curve_batch(const uint64_t *xy, const uint8_t *inf, size_t n, uint8_t *out);
 /* MSM(F,G).scalarMul(base, scalar).toAffine() for n independent (base, scalar) pairs
  * (src/msm/mod.zig:503-540) — the primitive of HyperKZG.setup (commitment/mod.zig:194-199). */
 ZG_API int zg_g1_scalar_mul_batch(const uint64_t *xy, const uint8_t *inf, const uint64_t *scalars_mont, size_t n,
@@ -173,6 +176,10 @@ ZG_API int zg_hyperkzg_open(zg_bases_t srs, const uint64_t *evals, size_t n_eval
  * (src/poly/split_eq.zig:122-171). */
 ZG_API int zg_fr_eq_table(const uint64_t *r, size_t v, const uint64_t *scale, uint64_t *out);
 ZG_API int zg_fr_eq_table_dev(const uint64_t *r_host, size_t v, const uint64_t *scale_host, uint64_t *d_out, void *stream);
+/* DensePolynomial.evaluate (src/poly/mod.zig:73-92): sum_i evals[i] * prod_j (bit_j(i) ? point[j] : 1 - point[j]),
+ * index bit j <-> point[j] (LSB first). The reference expands every term (O(n*v) multiplications); here the
+ * weights are one eq table (point reversed) and the sum is a device dot product — same field value. */
+ZG_API int zg_fr_dense_evaluate(const uint64_t *evals, size_t num_vars, const uint64_t *point, uint64_t out[4]);
 /* DensePolynomial.bindLow, in place: t[i] = t[2i] + r*(t[2i+1]-t[2i]), len -> len/2 (src/poly/mod.zig:160-175) */
 ZG_API int zg_fr_bind_low(uint64_t *table, size_t len, const uint64_t r[4]);
 /* DensePolynomial.bindFirst: out[i] = (1-r)*t[i] + r*t[i+len/2] (src/poly/mod.zig:128-149) */

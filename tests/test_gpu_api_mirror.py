@@ -156,3 +156,23 @@ def test_srs_raw_binary_g1_round_trip(env):
     assert ginf == wi and np.array_equal(got, want)
     with pytest.raises(api.SRSError):
         api.srs_g1_from_raw(want_bytes[:100])
+    bad = bytearray(want_bytes)
+    bad[4 + 64 * 3 + 63] ^= 1  # y of point 3 off the curve -> PointNotOnCurve (srs.zig:93-96)
+    with pytest.raises(api.SRSError):
+        api.srs_g1_from_raw(bytes(bad))
+    oc = lib.g1_is_on_curve_batch(np.concatenate([srs, srs[:1] ^ np.uint64(2)]), None)
+    assert oc[:n].all() and oc[n] == 0
+
+
+def test_dense_evaluate(env):
+    """DensePolynomial.evaluate (src/poly/mod.zig:73-92): boolean corners select entries (commitment/mod.zig:1448-1472),
+    random points match the oracle's term-by-term expansion; open()'s final evaluation is evaluate(reversed point)."""
+    api, lib, ob = env
+    for v in (0, 1, 3, 6, 10):
+        ev = _rand(ob, 70 + v, 1 << v)
+        p = api.DensePolynomial(ev)
+        pt = _rand(ob, 80 + v, v)
+        assert np.array_equal(p.evaluate(pt), ob.fr_dense_evaluate(ev, pt)), v
+    ev = _rand(ob, 90, 8)
+    for idx in range(8):
+        assert np.array_equal(api.DensePolynomial(ev).evaluate(U.fr([(idx >> j) & 1 for j in range(3)])), ev[idx])

@@ -244,6 +244,8 @@ def srs_g1_from_raw(data):
     raw = np.ascontiguousarray(body[:, :, ::-1]).view(np.uint64).reshape(n, 8)  # BE bytes -> LE limbs
     xy = lib.field_op(lib.FP, lib.OP_TO_MONT, raw.reshape(2 * n, 4)).reshape(n, 8) if n else np.zeros((0, 8), dtype=np.uint64)
     xy[inf == 1] = 0
+    if n and not lib.g1_is_on_curve_batch(xy, inf).all():  # parseG1Uncompressed, :93-96
+        raise SRSError("PointNotOnCurve")
     return xy, inf, bytes(data[4 + 64 * n:])
 
 
@@ -280,6 +282,12 @@ class DensePolynomial:
 
     def len(self):
         return self.evaluations.shape[0]
+
+    def evaluate(self, point):
+        """DensePolynomial.evaluate (src/poly/mod.zig:73-92), index bit j <-> point[j]."""
+        point = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1, 4)
+        assert point.shape[0] == self.num_vars
+        return lib.fr_dense_evaluate(self.evaluations, point)
 
     def bindFirst(self, value):
         """high-half fold into a NEW polynomial (src/poly/mod.zig:128-149)."""

@@ -629,6 +629,20 @@ __global__ void __launch_bounds__(256) g1_scalar_mul_kernel(const uint64_t *xy, 
     out_inf[i] = isinf ? 1 : 0;
 }
 
+// AffinePoint.isOnCurve (msm/mod.zig:106-115)
+__global__ void __launch_bounds__(256) g1_on_curve_kernel(const uint64_t *xy, const uint8_t *inf, size_t n, uint8_t *out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (inf && inf[i]) {
+        out[i] = 1;
+        return;
+    }
+    Affine p = affine_load(xy + 8 * i);
+    Fp three = fe_add(fe_dbl(Fp::one()), Fp::one());
+    Fp rhs = fe_add(fe_mul(fe_sqr(p.x), p.x), three);
+    out[i] = fe_sqr(p.y).eq(rhs) ? 1 : 0;
+}
+
 // ------------------------------------------------------------------ host side
 
 static int ilog2(uint32_t v) {
@@ -1104,6 +1118,32 @@ int zg_g1_combine_partials_dev_async(const uint64_t *d_partials, size_t k, void 
     }
     hipLaunchKernelGGL(msm_combine_kernel, dim3(1), dim3(1), 0, pick_stream(stream), d_partials, (uint32_t)k, d_out_xy, d_out_inf);
     ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
+int zg_g1_is_on_curve_batch(const uint64_t *xy, const uint8_t *inf, size_t n, uint8_t *out) {
+    ZG_INIT();
+    if (n && (!xy || !out)) {
+        set_error("zg_g1_is_on_curve_batch: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    if (n == 0) return ZG_OK;
+    hipStream_t st = lib_stream();
+    uint64_t *dxy = nullptr;
+    uint8_t *dinf = nullptr, *dout = nullptr;
+    ZG_HIP(hipMalloc((void **)&dxy, n * 64));
+    ZG_HIP(hipMalloc((void **)&dout, n));
+    ZG_HIP(hipMemcpyAsync(dxy, xy, n * 64, hipMemcpyHostToDevice, st));
+    if (inf) {
+        ZG_HIP(hipMalloc((void **)&dinf, n));
+        ZG_HIP(hipMemcpyAsync(dinf, inf, n, hipMemcpyHostToDevice, st));
+    }
+    hipLaunchKernelGGL(g1_on_curve_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, dxy, dinf, n, dout);
+    ZG_HIP(hipGetLastError());
+    ZG_HIP(hipMemcpyAsync(out, dout, n, hipMemcpyDeviceToHost, st));
+    ZG_HIP(hipStreamSynchronize(st));
+    (void)hipFree(dxy); (void)hipFree(dout);
+    if (dinf) (void)hipFree(dinf);
     return ZG_OK;
 }
 

@@ -73,6 +73,9 @@ __global__ void __launch_bounds__(256) spartan_combine_kernel(const uint64_t *eq
     }
 }
 
+// dot product sum_i a[i]*b[i] over Fr: per-block partials, finished by sc_finish_kernel's first slot
+__global__ void __launch_bounds__(256) fr_dot_kernel(const uint64_t *a, const uint64_t *b, size_t n, uint64_t *partials);
+
 // ------------------------------------------------------------------ sums / folds
 // block-wide sum of (g0, g1) pairs; result valid in thread 0
 __device__ __forceinline__ void block_sum_pair(Fr &g0, Fr &g1, uint4 *sh) {
@@ -91,6 +94,19 @@ __device__ __forceinline__ void block_sum_pair(Fr &g0, Fr &g1, uint4 *sh) {
     }
     g0 = fe_load<FrParams>(&sh[0]);
     g1 = fe_load<FrParams>(&sh[2]);
+}
+
+__global__ void __launch_bounds__(256) fr_dot_kernel(const uint64_t *a, const uint64_t *b, size_t n, uint64_t *partials) {
+    __shared__ uint4 sh[256 * 4];
+    Fr g0 = Fr::zero(), g1 = Fr::zero();
+    size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+        g0 = fe_add(g0, fe_mul(fe_load<FrParams>(a + 4 * i), fe_load<FrParams>(b + 4 * i)));
+    block_sum_pair(g0, g1, sh);
+    if (threadIdx.x == 0) {
+        fe_store(partials + 8 * (size_t)blockIdx.x, g0);
+        fe_store(partials + 8 * (size_t)blockIdx.x + 4, g1);
+    }
 }
 
 // round sums of a table: HIGH: g0 = sum t[0..h), g1 = sum t[h..2h);  LOW: g0 = sum t[2i], g1 = sum t[2i+1]
@@ -378,6 +394,42 @@ int zg_fr_bind_low(uint64_t *table, size_t len, const uint64_t r[4]) {
 int zg_fr_bind_high(const uint64_t *table, size_t len, const uint64_t r[4], uint64_t *out) {
     ZG_INIT();
     return bind_host(ZG_SC_HIGH_HALF, table, len, r, out);
+}
+
+int zg_fr_dense_evaluate(const uint64_t *evals, size_t num_vars, const uint64_t *point, uint64_t out[4]) {
+    ZG_INIT();
+    if (!evals || !out || (num_vars && !point) || num_vars > 30) {
+        set_error("zg_fr_dense_evaluate: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    size_t n = (size_t)1 << num_vars;
+    hipStream_t st = lib_stream();
+    // the eq table's index MSB pairs with r[0]; evaluate() pairs index bit j with point[j]: reverse the point
+    std::vector<uint64_t> rev(4 * (num_vars ? num_vars : 1));
+    for (size_t j = 0; j < num_vars; j++)
+        for (int l = 0; l < 4; l++) rev[4 * j + l] = point[4 * (num_vars - 1 - j) + l];
+    uint64_t *d_ev = nullptr, *d_eq = nullptr, *d_misc = nullptr;
+    ZG_HIP(hipMalloc((void **)&d_ev, n * 32));
+    ZG_HIP(hipMalloc((void **)&d_eq, n * 32));
+    ZG_HIP(hipMalloc((void **)&d_misc, 2048 * 64 + 64));
+    ZG_HIP(hipMemcpyAsync(d_ev, evals, n * 32, hipMemcpyHostToDevice, st));
+    int rc = eq_table_enqueue(rev.data(), num_vars, nullptr, d_eq, st);
+    if (rc == ZG_OK) {
+        unsigned nb = sc_blocks(n);
+        hipLaunchKernelGGL(fr_dot_kernel, dim3(nb), dim3(256), 0, st, d_ev, d_eq, n, d_misc);
+        hipLaunchKernelGGL(sc_finish_kernel, dim3(1), dim3(256), 0, st, d_misc, nb, d_misc + 2048 * 8, (uint64_t *)nullptr, (uint64_t)0);
+        uint64_t h[4];
+        hipError_t e = hipMemcpyAsync(h, d_misc + 2048 * 8, 32, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) {
+            set_error(hipGetErrorString(e));
+            rc = ZG_ERR_HIP;
+        } else {
+            for (int l = 0; l < 4; l++) out[l] = h[l];
+        }
+    }
+    (void)hipFree(d_ev); (void)hipFree(d_eq); (void)hipFree(d_misc);
+    return rc;
 }
 
 int zg_fr_spartan_combine_dev(const uint64_t *d_eq, const uint64_t *d_az, const uint64_t *d_bz, const uint64_t *d_cz, size_t n,

@@ -28,9 +28,9 @@ SYMBOLS = [
     "zg_field_op",
     "zg_g1_bases_upload", "zg_g1_bases_upload_dev", "zg_g1_bases_free", "zg_g1_bases_len",
     "zg_msm_g1", "zg_msm_g1_dev", "zg_msm_g1_dev_async", "zg_msm_g1_batch", "zg_msm_g1_partial_dev",
-    "zg_g1_combine_partials_dev", "zg_g1_combine_partials_dev_async", "zg_g1_scalar_mul_batch",
+    "zg_g1_combine_partials_dev", "zg_g1_combine_partials_dev_async", "zg_g1_is_on_curve_batch", "zg_g1_scalar_mul_batch",
     "zg_hyperkzg_open",
-    "zg_fr_eq_table", "zg_fr_eq_table_dev", "zg_fr_bind_low", "zg_fr_bind_high",
+    "zg_fr_dense_evaluate", "zg_fr_eq_table", "zg_fr_eq_table_dev", "zg_fr_bind_low", "zg_fr_bind_high",
     "zg_fr_spartan_combine", "zg_fr_spartan_combine_dev",
     "zg_sumcheck_open", "zg_sumcheck_open_dev", "zg_sumcheck_round_sums", "zg_sumcheck_bind",
     "zg_sumcheck_len", "zg_sumcheck_final", "zg_sumcheck_read", "zg_sumcheck_close",
@@ -220,6 +220,21 @@ def g1_scalar_mul_batch(xy, inf, scalars):
     oinf = np.zeros(n, dtype=np.uint8)
     _chk(_lib.zg_g1_scalar_mul_batch(_h(xy), _hb(inf), _h(scalars), C.c_size_t(n), _h(out), _hb(oinf)), "zg_g1_scalar_mul_batch")
     return out, oinf
+
+
+def g1_is_on_curve_batch(xy, inf=None):
+    xy, inf = _c(xy), _c(inf, np.uint8)
+    n = xy.size // 8
+    out = np.zeros(n, dtype=np.uint8)
+    _chk(_lib.zg_g1_is_on_curve_batch(_h(xy), _hb(inf), C.c_size_t(n), _hb(out)), "zg_g1_is_on_curve_batch")
+    return out
+
+
+def fr_dense_evaluate(evals, point):
+    evals, point = _c(evals), _c(point)
+    out = np.empty(4, dtype=np.uint64)
+    _chk(_lib.zg_fr_dense_evaluate(_h(evals), C.c_size_t(point.size // 4), _h(point), _h(out)), "zg_fr_dense_evaluate")
+    return out
 
 
 def hyperkzg_open(bases, evals, point, value):
