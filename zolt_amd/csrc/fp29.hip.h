@@ -58,9 +58,18 @@ ZG_DEV F29 f29_carry(const F29 &x) {
     return r;
 }
 
+// 29-bit-limb constants of the scalar field, for the poly kernels' mixed-format multiply (fr_mul29)
+struct Fr29 {
+    static constexpr u32 MASK = 0x1fffffffu;
+    static constexpr u32 P[9] = {0x10000001u, 0x1f0fac9fu, 0x0e5c2450u, 0x07d090f3u, 0x1585d283u,
+                                 0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
+    static constexpr u32 NINV = 0x0fffffffu;  // -r^-1 mod 2^29
+};
+
 // Montgomery product a*b*2^-261 mod p (lazy): limbs of a, b < 2^30; output limbs exactly < 2^29,
 // value < (A*B/168.9 + 1)*p for a < A*p, b < B*p.
-ZG_DEV F29 f29_mul(const F29 &a, const F29 &b) {
+template <class C29>
+ZG_DEV F29 f29t_mul(const F29 &a, const F29 &b) {
     u64 c[18];
 #pragma unroll
     for (int k = 0; k < 18; k++) c[k] = 0;
@@ -71,20 +80,22 @@ ZG_DEV F29 f29_mul(const F29 &a, const F29 &b) {
     }
 #pragma unroll
     for (int i = 0; i < 9; i++) {
-        u32 m = ((u32)c[i] * Fp29::NINV) & Fp29::MASK;
+        u32 m = ((u32)c[i] * C29::NINV) & C29::MASK;
 #pragma unroll
-        for (int j = 0; j < 9; j++) c[i + j] += (u64)m * Fp29::P[j];
+        for (int j = 0; j < 9; j++) c[i + j] += (u64)m * C29::P[j];
         c[i + 1] += c[i] >> 29;
     }
     F29 r;
 #pragma unroll
     for (int k = 9; k < 17; k++) {
-        r.l[k - 9] = (u32)c[k] & Fp29::MASK;
+        r.l[k - 9] = (u32)c[k] & C29::MASK;
         c[k + 1] += c[k] >> 29;
     }
     r.l[8] = (u32)c[17];
     return r;
 }
+
+ZG_DEV F29 f29_mul(const F29 &a, const F29 &b) { return f29t_mul<Fp29>(a, b); }
 
 ZG_DEV F29 f29_sqr(const F29 &a) {
     u64 c[18];
@@ -249,6 +260,36 @@ ZG_DEV Fp f29_to_fp(const F29 &x) {
 #pragma unroll
     for (int i = 0; i < 9; i++) r.l[i] = borrow ? t.l[i] : d.l[i];
     Fp out;
+    f29_pack(r, out.l);
+    return out;
+}
+
+// ---- mixed-format product for the poly kernels. Table entries live in HBM in the ABI format (canonical
+// Montgomery-2^256). When one factor is shared by many products (a sumcheck challenge, an eq-table row factor)
+// it is pre-scaled ONCE:  y' = 32*y mod r  as 29-bit limbs; then for any canonical x
+//     mont261(x, y') = x*y*2^5*2^-261 = x*y*2^-256 (mod r)
+// is exactly the reference's montgomeryMul(x, y) — computed with the carry-free 29-bit columns (~300
+// instructions incl. unpack, one conditional subtraction and repack, instead of ~560).
+ZG_DEV F29 fr29_prescale(const Fr &y) {
+    Fr t = y;
+#pragma unroll
+    for (int i = 0; i < 5; i++) t = fe_dbl(t);  // 32*y mod r, canonical
+    return f29_unpack(t.l);
+}
+ZG_DEV Fr fr_mul29(const Fr &x, const F29 &y_pre) {
+    F29 t = f29t_mul<Fr29>(f29_unpack(x.l), y_pre);  // < (1/168.9 + 1) r, limbs exact
+    F29 d;
+    u32 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        u32 v = t.l[i] - Fr29::P[i] - borrow;
+        borrow = v >> 31;
+        d.l[i] = (i < 8) ? (v & Fr29::MASK) : v;
+    }
+    F29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = borrow ? t.l[i] : d.l[i];
+    Fr out;
     f29_pack(r, out.l);
     return out;
 }

@@ -16,6 +16,7 @@
 
 #include "common.hip.h"
 #include "field.hip.h"
+#include "fp29.hip.h"
 
 namespace zg {
 
@@ -46,12 +47,13 @@ __global__ void __launch_bounds__(256) eq_main_kernel(const uint64_t *r_lo, int 
         Fr f = ((lo >> (v_lo - 1 - j)) & 1u) ? rj : fe_sub(one, rj);
         t = fe_mul(t, f);
     }
+    F29 tp = fr29_prescale(t);  // shared factor of this thread's products: pre-scaled once
     uint32_t h0 = blockIdx.x * hi_per_block;
     for (uint32_t k = 0; k < hi_per_block; k++) {
         uint32_t h = h0 + k;
         if (h >= n_hi) break;
         Fr hv = fe_load<FrParams>(hi + 4 * (size_t)h);
-        fe_store(out + 4 * (((size_t)h << v_lo) | lo), fe_mul(hv, t));
+        fe_store(out + 4 * (((size_t)h << v_lo) | lo), fr_mul29(hv, tp));
     }
 }
 
@@ -152,7 +154,7 @@ __global__ void __launch_bounds__(256) sc_fold_kernel(const uint64_t *t, size_t 
     Fr rv;
 #pragma unroll
     for (int i = 0; i < 8; i++) rv.l[i] = r.l[i];
-    Fr omr = fe_sub(Fr::one(), rv);
+    F29 rp = fr29_prescale(rv);  // the challenge is the shared factor of every product of this launch
     Fr g0 = Fr::zero(), g1 = Fr::zero();
     size_t stride = (size_t)gridDim.x * 256;
     size_t quarter = half / 2;
@@ -160,10 +162,10 @@ __global__ void __launch_bounds__(256) sc_fold_kernel(const uint64_t *t, size_t 
         Fr v;
         if (LAYOUT == ZG_SC_HIGH_HALF) {
             Fr lo = fe_load<FrParams>(t + 4 * i), hi = fe_load<FrParams>(t + 4 * (i + half));
-            v = fe_add(fe_mul(lo, omr), fe_mul(hi, rv));
+            v = fe_add(lo, fr_mul29(fe_sub(hi, lo), rp));  // (1-r)*lo + r*hi = lo + r*(hi - lo): one product, same value
         } else {
             Fr lo = fe_load<FrParams>(t + 8 * i), hi = fe_load<FrParams>(t + 8 * i + 4);
-            v = fe_add(lo, fe_mul(rv, fe_sub(hi, lo)));
+            v = fe_add(lo, fr_mul29(fe_sub(hi, lo), rp));
         }
         fe_store(out + 4 * i, v);
         bool second = LAYOUT == ZG_SC_HIGH_HALF ? (i >= quarter) : (i & 1);
