@@ -77,7 +77,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--precompute", type=int, default=0)
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="independent MSMs are issued round-robin on this many HIP streams (1 = strictly serial)")
     args = ap.parse_args()
 

@@ -1,13 +1,5 @@
-export TMPDIR=/tmp
-ROOT=$(pwd)
-mkdir -p $ROOT/gpurun_out/prof_sc
-cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_sc/trace -- $ROOT/tools/bench_sumcheck 20 10 > $ROOT/gpurun_out/prof_sc/trace.log 2>&1
-cd $ROOT
-python3 - <<'PY'
-import csv,glob
-f=glob.glob('gpurun_out/prof_sc/trace/**/*kernel_stats.csv',recursive=True)[0]
-for r in csv.DictReader(open(f)):
-    print(r['Name'].split('(')[0][:44].ljust(46), r['Calls'].rjust(5), ("%.1f"%(float(r['AverageNs'])/1e3)).rjust(9),'us avg', ("%.1f"%(float(r['MaxNs'])/1e3)).rjust(9),'us max')
-PY
-find gpurun_out/prof_sc -name "*.csv" -size +2M -delete
+for NT in 131072 122880 114688 98304; do
+ for ST in 2 3; do
+  echo "NT=$NT streams=$ST: $(ZG_MSM_LANES=$ST ZG_MSM_CHUNK_THREADS=$NT python bench.py --steps 30 --warmup 4 --streams $ST --no-cpu-baseline --no-extra 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value'],1), round(d['ms_per_step'],3))")"
+ done
+done
