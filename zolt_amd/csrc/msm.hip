@@ -92,16 +92,25 @@ __global__ void __launch_bounds__(256) msm_precompute_kernel(const uint64_t *xy,
     if (i >= n) return;
     Affine p = affine_load(xy + 8 * i);
     // rows are stored in the accumulate kernel's format: x, y as packed Montgomery-2^261 values (fp29.hip.h)
-    f29_store_packed(table + 64 * i, f29_from_fp(p.x));
-    f29_store_packed(table + 64 * i + 32, f29_from_fp(p.y));
+    F29 px = f29_from_fp(p.x), py = f29_from_fp(p.y);
+    f29_store_packed(table + 64 * i, px);
+    f29_store_packed(table + 64 * i + 32, py);
     if (inf && inf[i]) return;  // infinity bases are never referenced (digits are suppressed)
+    F29 one29;
+#pragma unroll
+    for (int k = 0; k < 9; k++) one29.l[k] = Fp29::ONE[k];
     for (int l = 1; l < levels; l++) {
-        XYZZ a = xyzz_dbl_affine(p);
-        for (int k = 1; k < dbl_per_level; k++) a = xyzz_dbl(a);
-        xyzz_to_affine(a, p);
+        XYZZ29 a;
+        a.x = px; a.y = py; a.zz = one29; a.zzz = one29;
+        for (int k = 0; k < dbl_per_level; k++) a = xyzz29_dbl(a);  // never the identity: the group has odd prime order
+        // back to affine in the lazy domain: 1/Z = ZZ/ZZZ, x = X/Z^2, y = Y/ZZZ (one canonical-form inversion)
+        F29 izzz = f29_from_fp(fe_inv_kaliski(f29_to_fp(a.zzz)));
+        F29 iz = f29_mul(izzz, a.zz);
+        px = f29_mul(a.x, f29_sqr(iz));
+        py = f29_mul(a.y, izzz);
         char *row = table + 64 * ((size_t)l * n + i);
-        f29_store_packed(row, f29_from_fp(p.x));
-        f29_store_packed(row + 32, f29_from_fp(p.y));
+        f29_store_packed(row, px);
+        f29_store_packed(row + 32, py);
     }
 }
 
