@@ -42,6 +42,22 @@ struct ProfScope {
     ~ProfScope() { prof_end(id, st); }
 };
 
+// Cached device scratch for the host-pointer entry points: hipMalloc/hipFree per call cost more than the
+// kernels they serve (hipFree also synchronises the device, which would stall other streams' work).
+// A buffer is returned to the cache only after the work using it has been synchronised.
+void *scratch_get(size_t bytes);  // nullptr on allocation failure (error set)
+void scratch_put(void *p);
+struct Scratch {
+    void *p = nullptr;
+    Scratch() = default;
+    explicit Scratch(size_t bytes) : p(scratch_get(bytes)) {}
+    Scratch(const Scratch &) = delete;
+    Scratch &operator=(const Scratch &) = delete;
+    ~Scratch() { if (p) scratch_put(p); }
+    bool alloc(size_t bytes) { p = scratch_get(bytes); return p != nullptr; }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
 static inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
 }  // namespace zg

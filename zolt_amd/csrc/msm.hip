@@ -827,8 +827,12 @@ static void launch_digits(hipStream_t st, const uint64_t *sc, const uint8_t *inf
 template <int C>
 static int launch_digits_lds(hipStream_t st, const uint64_t *sc, const uint8_t *inf, uint32_t n, int G, uint32_t per_block,
                              uint32_t NK, uint32_t nblk, uint32_t *dig, uint32_t *blockhist) {
-    ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_digits_lds_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)(NK * 4)));
+    static uint32_t attr_set = 0;  // per instantiation: largest dynamic-LDS size configured so far
+    if (attr_set < NK * 4) {
+        ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_digits_lds_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   128 * 1024));
+        attr_set = 128 * 1024;
+    }
     hipLaunchKernelGGL(msm_digits_lds_kernel<C>, dim3(nblk), dim3(1024), NK * 4, st, sc, inf, n, G, per_block, NK, dig, blockhist);
     return ZG_OK;
 }
@@ -890,8 +894,12 @@ static int msm_enqueue(zg_bases_s *b, size_t off, size_t n, const uint64_t *d_sc
             hipLaunchKernelGGL(msm_scan_b_kernel, dim3(tiles), dim3(1024), 0, st, ln.d_hist, p.NK, ln.d_scan_tmp, ln.d_scan_tmp + p.NK,
                                ln.d_scan_tmp + 2 * (size_t)p.NK, ln.d_starts, ln.d_nzrank, ln.d_nzlist);
         }
-        ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_scatter_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)(p.NK * 4)));
+        static bool scatter_attr_set = false;
+        if (!scatter_attr_set) {
+            ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_scatter_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       128 * 1024));
+            scatter_attr_set = true;
+        }
         hipLaunchKernelGGL(msm_scatter_lds_kernel, dim3(nblk), dim3(1024), p.NK * 4, st, ln.d_dig, (uint32_t)n, p.W, p.G, b->n,
                            (uint32_t)off, per_block, p.NK, ln.d_starts, ln.d_blockhist, ln.d_sorted);
     } else {
@@ -1074,8 +1082,6 @@ int zg_msm_g1_batch(zg_bases_t b, size_t n, const uint64_t *const *batches, size
     }
     if (e == hipSuccess) e = hipMemsetAsync(d_res, 0, 9 * 8 * k, st[0]);
     if (e == hipSuccess) e = hipStreamSynchronize(st[0]);
-    hipEvent_t free_ev[2] = {nullptr, nullptr};
-    for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&free_ev[i], hipEventDisableTiming);
     for (size_t i = 0; i < k && e == hipSuccess && rc == ZG_OK; i++) {
         int s = (int)(i & 1);
         if (n) e = hipMemcpyAsync(d_sc[s], batches[i], n * 32, hipMemcpyHostToDevice, st[s]);  // stream-ordered after MSM i-2
@@ -1085,7 +1091,6 @@ int zg_msm_g1_batch(zg_bases_t b, size_t n, const uint64_t *const *batches, size
     for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipStreamSynchronize(st[i]);
     if (e == hipSuccess && rc == ZG_OK) e = hipMemcpy(h_res.data(), d_res, 9 * 8 * k, hipMemcpyDeviceToHost);
     for (int i = 0; i < 2; i++) {
-        if (free_ev[i]) (void)hipEventDestroy(free_ev[i]);
         if (d_sc[i]) (void)hipFree(d_sc[i]);
         if (st[i]) (void)hipStreamDestroy(st[i]);
     }

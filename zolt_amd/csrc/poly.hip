@@ -246,9 +246,9 @@ static int eq_table_enqueue(const uint64_t *r_host, size_t v, const uint64_t *sc
     }
     int v_lo = v < 8 ? (int)v : 8, v_hi = (int)v - v_lo;
     uint32_t n_hi = 1u << v_hi;
-    uint64_t *d_r = nullptr, *d_hi = nullptr;
-    ZG_HIP(hipMalloc((void **)&d_r, (v + 1) * 32 + 32));
-    ZG_HIP(hipMalloc((void **)&d_hi, (size_t)n_hi * 32));
+    Scratch s_r((v + 1) * 32 + 32), s_hi((size_t)n_hi * 32);
+    if (!s_r.p || !s_hi.p) return ZG_ERR_NOMEM;
+    uint64_t *d_r = s_r.as<uint64_t>(), *d_hi = s_hi.as<uint64_t>();
     if (v) ZG_HIP(hipMemcpyAsync(d_r + 4, r_host, v * 32, hipMemcpyHostToDevice, st));
     if (scale_host) ZG_HIP(hipMemcpyAsync(d_r, scale_host, 32, hipMemcpyHostToDevice, st));
     prof_begin(ZG_PROF_EQ_TABLE, st);
@@ -259,8 +259,6 @@ static int eq_table_enqueue(const uint64_t *r_host, size_t v, const uint64_t *sc
     prof_end(ZG_PROF_EQ_TABLE, st);
     ZG_HIP(hipGetLastError());
     ZG_HIP(hipStreamSynchronize(st));  // r_host / temporaries are released on return
-    (void)hipFree(d_r);
-    (void)hipFree(d_hi);
     return ZG_OK;
 }
 
@@ -349,8 +347,9 @@ int zg_fr_eq_table(const uint64_t *r, size_t v, const uint64_t *scale, uint64_t 
         return ZG_ERR_INVALID;
     }
     size_t bytes = ((size_t)1 << v) * 32;
-    uint64_t *d_out = nullptr;
-    ZG_HIP(hipMalloc((void **)&d_out, bytes));
+    Scratch s_out(bytes);
+    if (!s_out.p) return ZG_ERR_NOMEM;
+    uint64_t *d_out = s_out.as<uint64_t>();
     int rc = eq_table_enqueue(r, v, scale, d_out, lib_stream());
     if (rc == ZG_OK) {
         hipError_t e = hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost);
@@ -359,7 +358,6 @@ int zg_fr_eq_table(const uint64_t *r, size_t v, const uint64_t *scale, uint64_t 
             rc = ZG_ERR_HIP;
         }
     }
-    (void)hipFree(d_out);
     return rc;
 }
 
@@ -369,10 +367,9 @@ static int bind_host(int layout, const uint64_t *table, size_t len, const uint64
         return ZG_ERR_INVALID;
     }
     hipStream_t st = lib_stream();
-    uint64_t *d_t = nullptr, *d_o = nullptr, *d_misc = nullptr;
-    ZG_HIP(hipMalloc((void **)&d_t, len * 32));
-    ZG_HIP(hipMalloc((void **)&d_o, len / 2 * 32));
-    ZG_HIP(hipMalloc((void **)&d_misc, 2048 * 64 + 64));
+    Scratch s_t(len * 32), s_o(len / 2 * 32), s_misc(2048 * 64 + 64);
+    if (!s_t.p || !s_o.p || !s_misc.p) return ZG_ERR_NOMEM;
+    uint64_t *d_t = s_t.as<uint64_t>(), *d_o = s_o.as<uint64_t>(), *d_misc = s_misc.as<uint64_t>();
     uint64_t *d_sums = d_misc + 2048 * 8;
     ZG_HIP(hipMemcpyAsync(d_t, table, len * 32, hipMemcpyHostToDevice, st));
     int rc = launch_fold(layout, d_t, len, r, d_o, d_misc, d_sums, st);
@@ -384,7 +381,6 @@ static int bind_host(int layout, const uint64_t *table, size_t len, const uint64
             rc = ZG_ERR_HIP;
         }
     }
-    (void)hipFree(d_t); (void)hipFree(d_o); (void)hipFree(d_misc);
     return rc;
 }
 
@@ -410,10 +406,9 @@ int zg_fr_dense_evaluate(const uint64_t *evals, size_t num_vars, const uint64_t 
     std::vector<uint64_t> rev(4 * (num_vars ? num_vars : 1));
     for (size_t j = 0; j < num_vars; j++)
         for (int l = 0; l < 4; l++) rev[4 * j + l] = point[4 * (num_vars - 1 - j) + l];
-    uint64_t *d_ev = nullptr, *d_eq = nullptr, *d_misc = nullptr;
-    ZG_HIP(hipMalloc((void **)&d_ev, n * 32));
-    ZG_HIP(hipMalloc((void **)&d_eq, n * 32));
-    ZG_HIP(hipMalloc((void **)&d_misc, 2048 * 64 + 64));
+    Scratch s_ev(n * 32), s_eq(n * 32), s_misc(2048 * 64 + 64);
+    if (!s_ev.p || !s_eq.p || !s_misc.p) return ZG_ERR_NOMEM;
+    uint64_t *d_ev = s_ev.as<uint64_t>(), *d_eq = s_eq.as<uint64_t>(), *d_misc = s_misc.as<uint64_t>();
     ZG_HIP(hipMemcpyAsync(d_ev, evals, n * 32, hipMemcpyHostToDevice, st));
     int rc = eq_table_enqueue(rev.data(), num_vars, nullptr, d_eq, st);
     if (rc == ZG_OK) {
@@ -430,7 +425,7 @@ int zg_fr_dense_evaluate(const uint64_t *evals, size_t num_vars, const uint64_t 
             for (int l = 0; l < 4; l++) out[l] = h[l];
         }
     }
-    (void)hipFree(d_ev); (void)hipFree(d_eq); (void)hipFree(d_misc);
+    if (rc != ZG_OK) (void)hipStreamSynchronize(st);
     return rc;
 }
 
@@ -459,9 +454,10 @@ int zg_fr_spartan_combine(const uint64_t *eq, const uint64_t *az, const uint64_t
     }
     if (n == 0) return ZG_OK;
     hipStream_t st = lib_stream();
-    uint64_t *d = nullptr;
     size_t bytes = n * 32;
-    ZG_HIP(hipMalloc((void **)&d, bytes * 5));
+    Scratch s_d(bytes * 5);
+    if (!s_d.p) return ZG_ERR_NOMEM;
+    uint64_t *d = s_d.as<uint64_t>();
     const uint64_t *src[4] = {eq, az, bz, cz};
     for (int k = 0; k < 4; k++) ZG_HIP(hipMemcpyAsync(d + 4 * n * k, src[k], bytes, hipMemcpyHostToDevice, st));
     int rc = zg_fr_spartan_combine_dev(d, d + 4 * n, d + 8 * n, d + 12 * n, n, d + 16 * n, st);
@@ -473,7 +469,6 @@ int zg_fr_spartan_combine(const uint64_t *eq, const uint64_t *az, const uint64_t
             rc = ZG_ERR_HIP;
         }
     }
-    (void)hipFree(d);
     return rc;
 }
 
@@ -491,13 +486,12 @@ int zg_hyperkzg_open(zg_bases_t srs, const uint64_t *evals, size_t n_evals, cons
     hipStream_t st = lib_stream();
     size_t srs_len = zg_g1_bases_len(srs);
     size_t cap = n_evals ? n_evals : 1;
-    uint64_t *d_a = nullptr, *d_b = nullptr, *d_q = nullptr, *d_res = nullptr, *d_misc = nullptr;
     std::vector<uint64_t> h_res(9 * num_vars + 4, 0);
-    hipError_t e = hipMalloc((void **)&d_a, cap * 32);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_b, (cap / 2 + 1) * 32);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_q, (cap / 2 + 1) * 32);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_res, (9 * num_vars + 4) * 8);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_misc, 2048 * 64 + 64);
+    Scratch s_a(cap * 32), s_b((cap / 2 + 1) * 32), s_q((cap / 2 + 1) * 32), s_res((9 * num_vars + 4) * 8), s_misc(2048 * 64 + 64);
+    if (!s_a.p || !s_b.p || !s_q.p || !s_res.p || !s_misc.p) return ZG_ERR_NOMEM;
+    uint64_t *d_a = s_a.as<uint64_t>(), *d_b = s_b.as<uint64_t>(), *d_q = s_q.as<uint64_t>(), *d_res = s_res.as<uint64_t>(),
+             *d_misc = s_misc.as<uint64_t>();
+    hipError_t e = hipSuccess;
     if (e == hipSuccess) e = hipMemsetAsync(d_res, 0, (9 * num_vars + 4) * 8, st);
     if (e == hipSuccess && n_evals) e = hipMemcpyAsync(d_a, evals, n_evals * 32, hipMemcpyHostToDevice, st);
     int rc = ZG_OK;
@@ -524,9 +518,7 @@ int zg_hyperkzg_open(zg_bases_t srs, const uint64_t *evals, size_t n_evals, cons
     std::vector<uint64_t> dev_res(9 * num_vars + 4);
     if (e == hipSuccess && rc == ZG_OK) e = hipMemcpyAsync(dev_res.data(), d_res, (9 * num_vars + 4) * 8, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    void *ptrs[] = {d_a, d_b, d_q, d_res, d_misc};
-    for (void *p : ptrs)
-        if (p) (void)hipFree(p);
+    else (void)hipStreamSynchronize(st);
     if (e != hipSuccess) {
         set_error(std::string("zg_hyperkzg_open: ") + hipGetErrorString(e));
         return ZG_ERR_HIP;

@@ -43,6 +43,64 @@ int ensure_init() {
     return do_init(-1);
 }
 
+// ------------------------------------------------------------------ scratch cache
+struct ScratchBuf { void *p; size_t bytes; bool used; };
+static std::mutex g_scratch_mu;
+static std::vector<ScratchBuf> g_scratch;
+static size_t g_scratch_total = 0;
+static constexpr size_t SCRATCH_CAP = (size_t)4 << 30;  // cached bytes kept at most
+
+void *scratch_get(size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    {
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        size_t best = (size_t)-1;
+        for (size_t i = 0; i < g_scratch.size(); i++)
+            if (!g_scratch[i].used && g_scratch[i].bytes >= bytes && g_scratch[i].bytes <= 4 * bytes + 4096 &&
+                (best == (size_t)-1 || g_scratch[i].bytes < g_scratch[best].bytes))
+                best = i;
+        if (best != (size_t)-1) {
+            g_scratch[best].used = true;
+            return g_scratch[best].p;
+        }
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        set_error(std::string("hipMalloc(scratch): ") + hipGetErrorString(e));
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    g_scratch.push_back({p, bytes, true});
+    g_scratch_total += bytes;
+    return p;
+}
+
+void scratch_put(void *p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    for (size_t i = 0; i < g_scratch.size(); i++) {
+        if (g_scratch[i].p == p) {
+            if (g_scratch_total > SCRATCH_CAP) {  // over the cap: really free it
+                g_scratch_total -= g_scratch[i].bytes;
+                (void)hipFree(p);
+                g_scratch.erase(g_scratch.begin() + i);
+            } else {
+                g_scratch[i].used = false;
+            }
+            return;
+        }
+    }
+    (void)hipFree(p);
+}
+
+static void scratch_trim() {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    for (auto &b : g_scratch) (void)hipFree(b.p);
+    g_scratch.clear();
+    g_scratch_total = 0;
+}
+
 // ------------------------------------------------------------------ profiling
 struct ProfRec { int id; hipEvent_t e0, e1; };
 static std::vector<ProfRec> g_prof;
@@ -124,6 +182,7 @@ void zg_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_inited) return;
     (void)hipStreamSynchronize(g_stream);
+    scratch_trim();
     (void)hipStreamDestroy(g_stream);
     g_stream = nullptr;
     g_inited = false;
@@ -211,14 +270,12 @@ int zg_field_op(int field, int op, const uint64_t *a, const uint64_t *b, uint64_
     }
     if (n == 0) return ZG_OK;
     size_t bytes = n * 32;
-    uint64_t *da = nullptr, *db = nullptr, *dout = nullptr;
-    ZG_HIP(hipMalloc(&da, bytes));
-    ZG_HIP(hipMalloc(&dout, bytes));
+    bool two = op <= ZG_OP_SUB || (op >= ZG_OP_MUL29 && op <= ZG_OP_X3_29);
+    Scratch sa(bytes), sout(bytes), sb;
+    if (!sa.p || !sout.p || (two && !sb.alloc(bytes))) return ZG_ERR_NOMEM;
+    uint64_t *da = sa.as<uint64_t>(), *db = sb.as<uint64_t>(), *dout = sout.as<uint64_t>();
     ZG_HIP(hipMemcpyAsync(da, a, bytes, hipMemcpyHostToDevice, g_stream));
-    if (op <= ZG_OP_SUB || (op >= ZG_OP_MUL29 && op <= ZG_OP_X3_29)) {
-        ZG_HIP(hipMalloc(&db, bytes));
-        ZG_HIP(hipMemcpyAsync(db, b, bytes, hipMemcpyHostToDevice, g_stream));
-    }
+    if (two) ZG_HIP(hipMemcpyAsync(db, b, bytes, hipMemcpyHostToDevice, g_stream));
     unsigned blocks = div_up(n, 256);
     if (blocks > 4096) blocks = 4096;
     if (op >= ZG_OP_MUL29 && op <= ZG_OP_X3_29)
@@ -230,9 +287,6 @@ int zg_field_op(int field, int op, const uint64_t *a, const uint64_t *b, uint64_
     ZG_HIP(hipGetLastError());
     ZG_HIP(hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, g_stream));
     ZG_HIP(hipStreamSynchronize(g_stream));
-    (void)hipFree(da);
-    (void)hipFree(dout);
-    if (db) (void)hipFree(db);
     return ZG_OK;
 }
 
