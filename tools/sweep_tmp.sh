@@ -9,7 +9,7 @@ from zolt_amd import api, lib
 lib.init(0)
 dev = torch.device("cuda", 0)
 st = torch.cuda.Stream(device=dev); torch.cuda.set_stream(st)
-n = 1 << 10
+n = 1 << 17
 g = api.generator()
 ks = np.zeros((n, 4), dtype=np.uint64); ks[:, 0] = np.arange(1, n + 1, dtype=np.uint64)
 bases_xy, _ = lib.g1_scalar_mul_batch(np.repeat(g[None, :], n, axis=0), np.zeros(n, dtype=np.uint8), lib.field_op(lib.FR, lib.OP_TO_MONT, ks))

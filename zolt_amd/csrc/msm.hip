@@ -68,7 +68,7 @@ struct zg_bases_s {
         uint32_t *d_scan_tmp = nullptr;   // 2*NK + 2*tiles: tile-local scans and tile totals
         char *d_part = nullptr;           // (NT + NK) * 144 B: per-(chunk, bucket-run) partial sums
         char *d_part2 = nullptr;          // heavy-bucket stage-A partials
-        uint32_t *d_heavy = nullptr;      // NK: heavy bucket list
+        uint32_t *d_heavy = nullptr;      // 2*NK: heavy bucket list, then huge bucket list
         void *d_state = nullptr;          // MsmState
         hipEvent_t done = nullptr;        // recorded after the lane's last MSM; the next user waits on it
         bool used = false;
@@ -366,9 +366,11 @@ __global__ void __launch_bounds__(256) msm_accumulate_kernel(const uint32_t *sor
 // bucket, contiguous. Buckets with few partials are finished by one thread each; "heavy" buckets
 // (more than 8 partials) go through two block-level tree stages.
 struct MsmState {
-    uint32_t nheavy;
-    uint32_t pad[3];
+    uint32_t nheavy;  // buckets with more than 8*GS partials (queued by msm_bucket_combine)
+    uint32_t nhuge;   // of those, buckets with more than HUGE_PARTIALS (queued by msm_heavy_wave)
+    uint32_t pad[2];
 };
+static constexpr uint32_t HUGE_PARTIALS = 2048;
 
 ZG_DEV uint32_t chunk_len(uint32_t total, uint32_t NT) {
     uint32_t C = (total + NT - 1) / NT;
@@ -464,6 +466,33 @@ __device__ __forceinline__ XYZZ29 block_sum_xyzz29(const XYZZ29 &acc, uint4 *sh)
     return xyzz29_load(&sh[0]);
 }
 
+// heavy buckets, first stage: one wave per bucket — strided serial sums (<= 32 per lane) and a shuffle tree.
+// (Typical source: the top window of a c-bit decomposition covers only a few bits, so its digits pile into a
+// small set of buckets.) Only "huge" buckets (a 0/1 column: one bucket holds everything) go on to the block stages.
+__global__ void __launch_bounds__(64) msm_heavy_wave_kernel(const char *part, const uint32_t *starts, const uint32_t *nzrank, uint32_t NK,
+                                                            uint32_t NT, const uint32_t *heavy_list, uint32_t *huge_list, MsmState *st,
+                                                            char *buckets) {
+    uint32_t nheavy = st->nheavy;
+    uint32_t C = chunk_len(starts[NK], NT);
+    uint32_t lane = threadIdx.x;
+    for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
+        uint32_t k = heavy_list[h];
+        uint32_t s0 = starts[k], s1 = starts[k + 1];
+        uint32_t q0 = s0 / C, q1 = (s1 - 1) / C, cnt = q1 - q0 + 1, base = q0 + nzrank[k];
+        if (cnt > HUGE_PARTIALS) {
+            if (lane == 0) huge_list[atomicAdd(&st->nhuge, 1u)] = k;
+            continue;
+        }
+        XYZZ29 acc = xyzz29_identity();
+        for (uint32_t j = lane; j < cnt; j += 64) acc = xyzz29_add(acc, xyzz29_load(part + 144 * (size_t)(base + j)));
+        for (int d = 1; d < 64; d <<= 1) {
+            XYZZ29 o = xyzz29_shfl_down(acc, d);
+            if ((lane & (uint32_t)(2 * d - 1)) == 0) acc = xyzz29_add(acc, o);
+        }
+        if (lane == 0) xyzz29_store(buckets + 144 * (size_t)k, acc);
+    }
+}
+
 static constexpr uint32_t HEAVY_BLOCK_ITEMS = 2048;
 
 // heavy stage A: block b owns partial slots [2048 b, 2048 (b+1)); every run of a heavy bucket inside is
@@ -472,7 +501,7 @@ __global__ void __launch_bounds__(256) msm_heavy_a_kernel(const char *part, cons
                                                          const uint32_t *nzlist, uint32_t NK, uint32_t NT, int GS, char *part2,
                                                          const MsmState *st) {
     __shared__ uint4 sh[256 * 9];
-    if (st->nheavy == 0) return;
+    if (st->nhuge == 0) return;
     uint32_t C = chunk_len(starts[NK], NT);
     uint32_t NZ = nzrank[NK];  // non-empty buckets; the r-th one, k = nzlist[r], owns slots [starts[k]/C + r, ...)
     uint32_t lo_slot = blockIdx.x * HEAVY_BLOCK_ITEMS, hi_slot = lo_slot + HEAVY_BLOCK_ITEMS;
@@ -486,7 +515,7 @@ __global__ void __launch_bounds__(256) msm_heavy_a_kernel(const char *part, cons
         uint32_t s0 = starts[k], s1 = starts[k + 1];
         uint32_t q0 = s0 / C, q1 = (s1 - 1) / C, cnt = q1 - q0 + 1, base = q0 + r;
         if (base >= hi_slot) break;
-        if (cnt <= 8u * (uint32_t)GS || base + cnt <= lo_slot) continue;
+        if (cnt <= HUGE_PARTIALS || base + cnt <= lo_slot) continue;
         uint32_t r0 = base > lo_slot ? base : lo_slot, r1 = base + cnt < hi_slot ? base + cnt : hi_slot;
         XYZZ29 acc = xyzz29_identity();
         for (uint32_t j = r0 + threadIdx.x; j < r1; j += 256) acc = xyzz29_add(acc, xyzz29_load(part + 144 * (size_t)j));
@@ -500,7 +529,7 @@ __global__ void __launch_bounds__(256) msm_heavy_a_kernel(const char *part, cons
 __global__ void __launch_bounds__(256) msm_heavy_b_kernel(const char *part2, const uint32_t *starts, const uint32_t *nzrank, uint32_t NK,
                                                          uint32_t NT, const uint32_t *heavy_list, const MsmState *st, char *buckets) {
     __shared__ uint4 sh[256 * 9];
-    uint32_t nheavy = st->nheavy;
+    uint32_t nheavy = st->nhuge;  // heavy_list is the huge list here
     uint32_t C = chunk_len(starts[NK], NT);
     for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
         uint32_t k = heavy_list[h];
@@ -793,7 +822,7 @@ static int bases_create(const uint64_t *d_xy, const uint8_t *d_inf_in, size_t n,
             size_t slots = (size_t)p.NT + p.NK;
             ZG_ALLOC(ln.d_part, slots * 144);
             ZG_ALLOC(ln.d_part2, (slots / HEAVY_BLOCK_ITEMS + 1 + p.NK) * 144);
-            ZG_ALLOC(ln.d_heavy, (size_t)p.NK * 4);
+            ZG_ALLOC(ln.d_heavy, (size_t)p.NK * 8);
             ZG_ALLOC(ln.d_state, sizeof(MsmState));
         }
         if (hipEventCreateWithFlags(&ln.done, hipEventDisableTiming) != hipSuccess) {
@@ -929,11 +958,13 @@ static int msm_enqueue(zg_bases_s *b, size_t off, size_t n, const uint64_t *d_sc
         prof_begin(ZG_PROF_MSM_REDUCE, st);
         hipLaunchKernelGGL(msm_bucket_combine_kernel, dim3(div_up((size_t)p.NK * p.GS, 64)), dim3(64), 0, st, ln.d_part, ln.d_starts,
                            ln.d_nzrank, p.NK, p.NT, p.GS, ln.d_partial, ln.d_heavy, reinterpret_cast<MsmState *>(ln.d_state));
+        hipLaunchKernelGGL(msm_heavy_wave_kernel, dim3(1024), dim3(64), 0, st, ln.d_part, ln.d_starts, ln.d_nzrank, p.NK, p.NT, ln.d_heavy,
+                           ln.d_heavy + p.NK, reinterpret_cast<MsmState *>(ln.d_state), ln.d_partial);
         uint32_t nblk_a = (p.NT + p.NK) / HEAVY_BLOCK_ITEMS + 1;
         hipLaunchKernelGGL(msm_heavy_a_kernel, dim3(nblk_a), dim3(256), 0, st, ln.d_part, ln.d_starts, ln.d_nzrank, ln.d_nzlist, p.NK, p.NT,
                            p.GS, ln.d_part2,
                            reinterpret_cast<const MsmState *>(ln.d_state));
-        hipLaunchKernelGGL(msm_heavy_b_kernel, dim3(64), dim3(256), 0, st, ln.d_part2, ln.d_starts, ln.d_nzrank, p.NK, p.NT, ln.d_heavy,
+        hipLaunchKernelGGL(msm_heavy_b_kernel, dim3(64), dim3(256), 0, st, ln.d_part2, ln.d_starts, ln.d_nzrank, p.NK, p.NT, ln.d_heavy + p.NK,
                            reinterpret_cast<const MsmState *>(ln.d_state), ln.d_partial);
     } else {
         hipLaunchKernelGGL(msm_accumulate_kernel, dim3(div_up((size_t)p.NK * p.S, 256)), dim3(256), 0, st, ln.d_sorted, ln.d_starts,
