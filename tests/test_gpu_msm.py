@@ -268,7 +268,7 @@ def test_every_window_size(zl, ob, gm, c):
 
 @pytest.mark.parametrize("logn", [17, 18, 19])
 def test_auto_plan_sizes(zl, ob, logn):
-    """the automatic plan picks c = 13..15 for these sizes (the per-rank shard sizes of a sharded 2^20..2^22 MSM)"""
+    """the per-rank shard sizes of a sharded 2^20..2^22 MSM under the automatic plan"""
     n = 1 << logn
     gmn = ob.g1_gen_multiples(n)
     sc = _scalars(ob, 5000 + logn, n)

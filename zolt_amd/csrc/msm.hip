@@ -698,10 +698,10 @@ static int make_plan(size_t n, const zg_msm_config *cfg, MsmPlan &p) {
     int c = cfg ? cfg->window_bits : 0;
     if (c == 0) c = env_int("ZG_MSM_WINDOW_BITS", 0);
     if (c == 0) {
-        int lg = n > 1 ? ilog2((uint32_t)(n - 1)) + 1 : 1;
-        c = lg - 4;
-        if (c < 4) c = 4;
-        if (c > 16) c = 16;
+        // measured on MI355X (tools/bench_window.py): window sizes whose last window covers only a couple of the 254
+        // scalar bits (c = 9, 12, 14) waste a window and pile its digits into a handful of buckets; 16 wins from
+        // 2^15 points up (fewest windows; the rest of the pipeline is latency), 8 / 7 below.
+        c = n >= 32768 ? 16 : (n >= 2048 ? 8 : (n >= 64 ? 7 : 5));
     }
     if (c < 2 || c > 16) {
         set_error("msm: window_bits must be in [2,16]");
