@@ -277,3 +277,17 @@ def test_auto_plan_sizes(zl, ob, logn):
     b.free()
     want, winf = ob.msm_g1_parallel(gmn, None, sc, 8)
     assert ginf == winf and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("env", [{"ZG_MSM_CHUNK_SCHED": "0"}, {"ZG_MSM_LDS_SORT": "0"}, {"ZG_MSM_LANES": "1"},
+                                 {"ZG_MSM_CHUNK_THREADS": "1000"}, {"ZG_MSM_CHUNK_SCHED": "0", "ZG_MSM_LDS_SORT": "0", "ZG_MSM_SLICES": "4"}])
+def test_alternate_code_paths(zl, ob, gm, env, monkeypatch):
+    """the fallback schedulers (per-bucket lanes, global-atomic counting sort) and odd tuning values stay bit-exact"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    n = 6000
+    rng = np.random.default_rng(11)
+    sc = _scalars(ob, 777, n)
+    sc[rng.integers(0, n, size=500)] = U.fr([3])[0]  # some skew
+    _check(zl, ob, gm[:n], None, sc)
+    _check(zl, ob, gm[:n], None, sc, window_bits=16, precompute_levels=2)
