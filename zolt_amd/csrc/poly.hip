@@ -79,23 +79,33 @@ __global__ void __launch_bounds__(256) spartan_combine_kernel(const uint64_t *eq
 __global__ void __launch_bounds__(256) fr_dot_kernel(const uint64_t *a, const uint64_t *b, size_t n, uint64_t *partials);
 
 // ------------------------------------------------------------------ sums / folds
-// block-wide sum of (g0, g1) pairs; result valid in thread 0
+// block-wide sum of (g0, g1) pairs (256 threads); result valid in thread 0. Wave-level shuffle tree first
+// (no barriers, no LDS round trips), then one LDS hop across the four waves: the latency of this reduction is
+// what a small sumcheck round mostly consists of.
+ZG_DEV Fr fr_shfl_down(const Fr &v, int d) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = __shfl_down(v.l[i], d, 64);
+    return r;
+}
 __device__ __forceinline__ void block_sum_pair(Fr &g0, Fr &g1, uint4 *sh) {
     uint32_t tid = threadIdx.x;
-    fe_store(&sh[tid * 4], g0);
-    fe_store(&sh[tid * 4 + 2], g1);
-    __syncthreads();
-    for (uint32_t o = 128; o > 0; o >>= 1) {
-        if (tid < o) {
-            Fr a0 = fe_load<FrParams>(&sh[tid * 4]), a1 = fe_load<FrParams>(&sh[tid * 4 + 2]);
-            Fr b0 = fe_load<FrParams>(&sh[(tid + o) * 4]), b1 = fe_load<FrParams>(&sh[(tid + o) * 4 + 2]);
-            fe_store(&sh[tid * 4], fe_add(a0, b0));
-            fe_store(&sh[tid * 4 + 2], fe_add(a1, b1));
-        }
-        __syncthreads();
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        g0 = fe_add(g0, fr_shfl_down(g0, d));
+        g1 = fe_add(g1, fr_shfl_down(g1, d));
     }
-    g0 = fe_load<FrParams>(&sh[0]);
-    g1 = fe_load<FrParams>(&sh[2]);
+    if ((tid & 63) == 0) {
+        fe_store(&sh[(tid >> 6) * 4], g0);
+        fe_store(&sh[(tid >> 6) * 4 + 2], g1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (uint32_t w = 1; w < 4; w++) {
+            g0 = fe_add(g0, fe_load<FrParams>(&sh[w * 4]));
+            g1 = fe_add(g1, fe_load<FrParams>(&sh[w * 4 + 2]));
+        }
+    }
 }
 
 __global__ void __launch_bounds__(256) fr_dot_kernel(const uint64_t *a, const uint64_t *b, size_t n, uint64_t *partials) {
