@@ -4,25 +4,28 @@
 // c = 8, 32 windows, 255 Jacobian buckets on the stack, per-window fromMontgomery) with a
 // pipeline shaped for 256 CUs and 288 GB of HBM:
 //
-//   upload (once per SRS)   bases -> table[l][i] = 2^(c*G*l) * P_i as 64-byte affine records
-//                           (l < L "precompute levels"); with L = W every window of a scalar
-//                           lands in ONE shared bucket set and no window-combining doublings
-//                           remain at MSM time.
-//   msm_digits              one fromMontgomery per scalar (the reference does 32), then W signed
-//                           c-bit digits -> keys (bucket group g, |digit|-1) + histogram
-//   msm_scan / msm_scatter  counting sort of the n*W (key, point-ref) pairs by key
-//   msm_accumulate          S threads per bucket walk the sorted refs: gather the 64-byte
-//                           affine point, complete mixed add into an XYZZ accumulator
-//                           (S lanes per bucket, then a segmented wave shuffle reduction)
+//   upload (once per SRS)   bases -> table[l][i] = 2^(c*G*l) * P_i as 64-byte rows (l < L "precompute
+//                           levels", stored in the accumulate kernel's lazy 29-bit-limb format); with L = W
+//                           every window of a scalar lands in ONE shared bucket set and no window-combining
+//                           doublings remain at MSM time.
+//   msm_digits_lds          one fromMontgomery per scalar (the reference does 32), then W signed c-bit
+//                           digits -> keys (bucket group g, |digit|-1); per-block histogram in LDS
+//   msm_colscan / scan_a/b / scatter_lds   counting sort of the n*W (key, point-ref) pairs: per-block
+//                           offsets, two-pass coalesced scan, scatter with LDS cursors (no global atomics)
+//   msm_accumulate_chunk    the sorted list is cut into equal chunks, one per thread, whatever the bucket
+//                           sizes (skew-robust); complete XYZZ mixed adds on lazy limbs; one partial per
+//                           bucket run
+//   msm_bucket_combine / heavy_wave / heavy_a/b   per-bucket sums of the partials: GS lanes, a wave, or
+//                           block trees depending on how many partials a bucket has
 //   msm_bitsum              sum_k k*B_k = sum_b 2^b * T_b,  T_b = sum of the buckets whose index has
 //                           bit b set: c plain tree sums (log depth) instead of the reference's
 //                           serial running sum (a lone GPU lane needs ~10 us per point add)
 //   msm_final               b doublings of T_b in parallel lanes, tree sum, window Horner if G > 1,
-//                           one binary-Euclid inversion -> affine
+//                           one Kaliski inversion -> affine
 //
 // Bucket sums are order-independent group sums and the final affine coordinates are
 // canonical field values, so the 64-byte result is bit-identical to the reference's
-// MSM(F,G).compute whatever c, L, S are (tests/test_msm_parity.py).
+// MSM(F,G).compute whatever c, L and the scheduling are (tests/test_gpu_msm.py).
 #include <mutex>
 #include <vector>
 
