@@ -212,7 +212,7 @@ def main():
         "vs_baseline": None, "dtype": "u32", "data": "synthetic",
         "config": {"workload": f"msm_g1_2^{args.logn}", "points": n, "points_per_gpu": n_loc,
                    "arithmetic": "256-bit Montgomery field elements as 32-bit limbs (9x29-bit lazy limbs in the MSM), integer only",
-                   "bases": "(i+1)*G resident in HBM", "scalars": "uniform mod r, splitmix64 seed 0x5A4F4C54, resident in HBM",
+                   "bases": "(i+1)*G resident in HBM (table of 2^(16l)*P_i built once at upload, like an SRS)", "scalars": "uniform mod r, splitmix64 seed 0x5A4F4C54, resident in HBM",
                    "sharding": f"contiguous chunks + {dist_backend} all-gather of 96-byte Jacobian partials" if world > 1 else "single GPU",
                    "streams": nstreams,
                    "bit_exact_check": "closed form (sum s_i*(i+1))*G via scalarMul kernel, every timed step"},
@@ -292,6 +292,18 @@ def extra_measurements(lib, api, torch, dev, stream, args):
                                         "kernel_ms_per_msm": d["extra"]["kernel_ms_per_msm"], "roofline": d["roofline"]}
     except Exception as e:  # noqa: BLE001
         extra["msm_2^22_single_gpu"] = {"error": str(e)}
+    # transparency: the same 2^20 MSM with NO table of precomputed multiples (precompute_levels = 1: classical
+    # per-window bucket sets, window combine by doublings on the device) — what a one-shot caller would see
+    try:
+        import subprocess
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--logn", str(args.logn), "--steps", "10", "--warmup", "2",
+                              "--precompute", "1", "--no-cpu-baseline", "--no-extra", "--streams", str(args.streams)],
+                             capture_output=True, text=True, timeout=600)
+        d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        extra["msm_no_precompute"] = {"value": d["value"], "unit": "MSM/s", "ms_per_step": d["ms_per_step"],
+                                      "kernel_ms_per_msm": d["extra"]["kernel_ms_per_msm"]}
+    except Exception as e:  # noqa: BLE001
+        extra["msm_no_precompute"] = {"error": str(e)}
     # the same pipeline driven by a compiled host loop (tools/bench_sumcheck.cpp over zolt_host.hpp): what a
     # Zig/C++ prover would see, without the Python interpreter between rounds
     exe = os.path.join(ROOT, "tools", "bench_sumcheck")
