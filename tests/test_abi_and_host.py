@@ -102,3 +102,17 @@ def test_host_scalar_helpers_and_toy_verifier():
     bad = api.Sumcheck.Verifier(api.fr_from_int(35))
     with pytest.raises(api.SumcheckVerificationFailed):
         bad.verifyRound(coeffs)
+
+
+def test_parse_zolt_proof_commitments(golden_dir):
+    """the captured reference proof (logs/zolt_proof_regular.bin): container layout of src/zkvm/serialization.zig:283-306"""
+    from zolt_amd import api
+    data = open(os.path.join(golden_dir, "zolt_proof_regular.bin"), "rb").read()
+    c = api.parse_zolt_proof_commitments(data)
+    assert len(c) == 11
+    assert c["bytecode.commitment"].hex().startswith("048184e5b9afa827")  # SURVEY §8(c): reproduced from fibonacci.elf
+    assert c["memory.commitment"] == bytes(64)                              # identity
+    assert c["register.commitment"].hex().startswith("1a5d881d")
+    assert c["bytecode.read_ts_commitment"] == bytes(64)
+    with pytest.raises(ValueError):
+        api.parse_zolt_proof_commitments(b"JOLT" + data[4:])

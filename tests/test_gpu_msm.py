@@ -200,9 +200,8 @@ def test_srs_and_reference_proof_commitment(zl, ob, golden_dir):
     got, ginf = b.msm(U.fr(ev))
     b.free()
     assert ginf == 0
-    x = U.fp_to_int(got[:4]).to_bytes(32, "big")
-    y = U.fp_to_int(got[4:]).to_bytes(32, "big")
-    assert x + y == proof[8:72]
+    from zolt_amd import api
+    assert api.commitment_to_bytes(got, ginf) == api.parse_zolt_proof_commitments(proof)["bytecode.commitment"] == proof[8:72]
     # scalarMul edge cases: 0*P = inf, 1*P = P, k*inf = inf (src/msm/mod.zig:503-505,802-825)
     out, oinf = zl.g1_scalar_mul_batch(np.repeat(g, 3, axis=0), np.array([0, 0, 1], dtype=np.uint8), U.fr([0, 1, 5]))
     assert list(oinf) == [1, 0, 1] and np.array_equal(out[1], g[0]) and not out[0].any() and not out[2].any()

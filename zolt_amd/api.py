@@ -224,6 +224,29 @@ class HyperKZG:
         return [(q[i], int(qinf[i])) for i in range(point.shape[0])], final
 
 
+# ---- ZOLT v1 proof container: the commitments this backend produces
+def parse_zolt_proof_commitments(data):
+    """Header of serializeProof (src/zkvm/serialization.zig:283-306): "ZOLT" | u32 version | bytecode proof
+    {commitment, read_ts, write_ts (64 B each, x||y big-endian, identity = 64 zero bytes,
+    src/zkvm/commitment_types.zig:49-54), legacy field element 32 B} | memory proof {4 x 64 B} | register proof
+    {4 x 64 B}. Returns {name: 64 raw bytes}; the rest of the proof (R1CS / stage proofs) is not parsed."""
+    if len(data) < 8 + 3 * 64 + 32 + 8 * 64 or data[:4] != b"ZOLT":
+        raise ValueError("not a ZOLT proof")
+    version = int.from_bytes(data[4:8], "little")
+    if version != 1:
+        raise ValueError(f"unsupported ZOLT proof version {version}")
+    out, off = {}, 8
+    for name in ("bytecode.commitment", "bytecode.read_ts_commitment", "bytecode.write_ts_commitment"):
+        out[name] = bytes(data[off:off + 64])
+        off += 64
+    off += 32  # bytecode._legacy_commitment
+    for group in ("memory", "register"):
+        for name in ("commitment", "final_state_commitment", "read_ts_commitment", "write_ts_commitment"):
+            out[f"{group}.{name}"] = bytes(data[off:off + 64])
+            off += 64
+    return out
+
+
 # ---- SRS wire format (G1 section)
 class SRSError(Exception):
     pass
