@@ -207,12 +207,11 @@ def test_srs_and_reference_proof_commitment(zl, ob, golden_dir):
     assert list(oinf) == [1, 0, 1] and np.array_equal(out[1], g[0]) and not out[0].any() and not out[2].any()
 
 
-@pytest.mark.parametrize("logn", [20])
-def test_full_size_closed_form(zl, ob, logn):
-    """BASELINE config 2 (2^20 points, one GPU): uniform scalars; the result must equal the
-    size-independent closed form (sum s_i (i+1) mod r)·G and the oracle's ParallelMSM."""
+@pytest.mark.parametrize("n", [1 << 20, (1 << 20) + 1])
+def test_full_size_closed_form(zl, ob, n):
+    """BASELINE config 2 (2^20 points, one GPU) and the 2^20 + 1 member of SURVEY §8(d)'s adversarial size set:
+    uniform scalars; the result must equal the size-independent closed form (sum s_i (i+1) mod r)·G."""
     from oracle import pymodel as pm
-    n = 1 << logn
     gm = ob.g1_gen_multiples(n)
     raw = U.random_raw256(0x5A4F4C54, n)
     sc = ob.f_to_mont(ob.FR, raw)
