@@ -147,6 +147,11 @@ ZG_API int zg_msm_g1_batch(zg_bases_t b, size_t n, const uint64_t *const *scalar
  * written to DEVICE memory so it can be all-gathered over RCCL without a host round trip. */
 ZG_API int zg_msm_g1_partial_dev(zg_bases_t b, size_t off, size_t n, const uint64_t *d_scalars_mont, void *stream,
                           uint64_t *d_out_jac /* 12 */);
+/* Same partial without the normalisation: some Jacobian representative (X, Y, Z) of the shard's sum (identity:
+ * Z = 0). It exists only to be fed to zg_g1_combine_partials_dev*, whose result is identical; skipping the
+ * per-GPU inversion shortens every rank's step in a sharded MSM. */
+ZG_API int zg_msm_g1_partial_fast_dev(zg_bases_t b, size_t off, size_t n, const uint64_t *d_scalars_mont, void *stream,
+                               uint64_t *d_out_jac /* 12 */);
 /* ParallelMSM's serial combine + toAffine (src/msm/mod.zig:647-652) over k gathered
  * Jacobian partials resident on the device. */
 ZG_API int zg_g1_combine_partials_dev(const uint64_t *d_partials_jac /* k*12 */, size_t k, void *stream, uint64_t out_xy[8],

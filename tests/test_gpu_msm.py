@@ -172,6 +172,33 @@ def test_parallel_msm_partials_combine(zl, ob, gm):
     assert ginf == winf and np.array_equal(got, want)
     full, finf = b.msm(sc)
     assert np.array_equal(full, got)
+    # the un-normalised partials (no per-GPU inversion) are other Jacobian representatives of the same points,
+    # and combine to the same bytes
+    for t in range(T):
+        b.msm_partial_fast_dev(d_sc.value + t * chunk * 32, chunk, d_part.value + t * 96, off=t * chunk)
+    zl.sync()
+    fast = np.empty((T, 12), dtype=np.uint64)
+    assert zl._lib.zg_memcpy_d2h(fast.ctypes.data_as(C.c_void_p), d_part, C.c_size_t(T * 96)) == 0
+    for t in range(T):
+        a_xy, a_inf = ob.g1_jac_to_affine(fast[t])
+        assert a_inf == 0 and np.array_equal(a_xy, parts[t, :8])
+    got2, ginf2 = zl.combine_partials_dev(d_part.value, T)
+    assert ginf2 == ginf and np.array_equal(got2, got)
+    # more partials than lanes in the combine wave, with identities mixed in
+    many = np.concatenate([np.tile(fast, (20, 1)), np.tile(parts, (3, 1))])  # 92 records
+    ident = np.concatenate([one, one, np.zeros(4, dtype=np.uint64)])
+    many[5] = ident
+    many[77] = ident
+    d_many = C.c_void_p()
+    assert zl._lib.zg_dev_alloc(C.c_size_t(many.size * 8), C.byref(d_many)) == 0
+    assert zl._lib.zg_memcpy_h2d(d_many, many.ctypes.data_as(C.c_void_p), C.c_size_t(many.size * 8)) == 0
+    gm_xy, gm_inf = zl.combine_partials_dev(d_many.value, many.shape[0])
+    acc = ident.copy()
+    for rec in many:
+        acc = ob.g1_jac_add(acc, rec)
+    w_xy, w_inf = ob.g1_jac_to_affine(acc)
+    assert gm_inf == w_inf and np.array_equal(gm_xy, w_xy)
+    zl._lib.zg_dev_free(d_many)
     # an empty shard contributes the reference's identity record (1,1,0)
     b.msm_partial_dev(d_sc.value, 0, d_part.value)
     zl.sync()

@@ -164,7 +164,8 @@ class GpuShardBackend:
     def partial(self, d_scalars):
         import torch
         out = torch.empty(12, dtype=torch.int64, device=d_scalars.device)
-        self.bases.msm_partial_dev(d_scalars.data_ptr(), self.n, out.data_ptr(), stream=self._stream())
+        # un-normalised Jacobian partial: the combine result is identical and the rank skips an inversion
+        self.bases.msm_partial_fast_dev(d_scalars.data_ptr(), self.n, out.data_ptr(), stream=self._stream())
         return out
 
     def combine(self, gathered):

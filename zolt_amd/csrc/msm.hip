@@ -579,6 +579,15 @@ ZG_DEV void write_result(const XYZZ &acc, int mode, uint64_t *out_rec, uint8_t *
     }
 }
 
+// mode 2: a per-GPU partial that is only ever fed to the combine step. Any Jacobian representative of the shard's
+// sum works there, so the inversion (the longest single piece of a small MSM's tail) is skipped:
+// (X*ZZ, Y*ZZZ, ZZ) has the same affine image as the XYZZ point; identity = (1,1,0).
+ZG_DEV void write_partial_unnormalised(const XYZZ &acc, uint64_t *out_rec) {
+    Fp X, Y, Z;
+    xyzz_to_jacobian(acc, X, Y, Z);
+    fe_store(out_rec, X); fe_store(out_rec + 4, Y); fe_store(out_rec + 8, Z);
+}
+
 // Bucket reduction, step 2 (block g): lane (b, j) loads partial j of T_b; 16-lane shuffle tree over j;
 // lane (b, 0) doubles b times; LDS tree over b  ->  R_g = sum_k k*B_k of group g.
 // With a single group (full precompute) thread 0 goes straight on to toAffine (msm/mod.zig:178-189).
@@ -607,8 +616,12 @@ __global__ void __launch_bounds__(256) msm_final_kernel(const char *bits, int c,
     }
     if (tid != 0) return;
     XYZZ r = xyzz29_to_std_val(xyzz29_load(&sh[0]));  // canonical Montgomery-2^256 from here on
-    if (G == 1) write_result(r, mode, out_rec, out_inf);
-    else xyzz_store(rg + 128 * (size_t)g, r);
+    if (G == 1) {
+        if (mode == 2) write_partial_unnormalised(r, out_rec);
+        else write_result(r, mode, out_rec, out_inf);
+    } else {
+        xyzz_store(rg + 128 * (size_t)g, r);
+    }
 }
 
 // window combine for G > 1 (msm/mod.zig:393-398,434): Horner from the top group with c doublings per step
@@ -618,7 +631,8 @@ __global__ void msm_groups_kernel(const char *rg, int G, int c, int mode, uint64
         for (int k = 0; k < c; k++) acc = xyzz_dbl(acc);
         acc = xyzz_add(acc, xyzz_load(rg + 128 * (size_t)g));
     }
-    write_result(acc, mode, out_rec, out_inf);
+    if (mode == 2) write_partial_unnormalised(acc, out_rec);
+    else write_result(acc, mode, out_rec, out_inf);
 }
 
 __global__ void msm_identity_kernel(int mode, uint64_t *out_rec, uint8_t *out_inf) {
@@ -632,15 +646,30 @@ __global__ void msm_identity_kernel(int mode, uint64_t *out_rec, uint8_t *out_in
 }
 
 // ParallelMSM combine (msm/mod.zig:647-652): serial add of k Jacobian partials + toAffine
-__global__ void msm_combine_kernel(const uint64_t *partials, uint32_t k, uint64_t *out_xy, uint8_t *out_inf) {
-    XYZZ acc = XYZZ::identity();
-    for (uint32_t i = 0; i < k; i++) {
+__global__ void __launch_bounds__(64) msm_combine_kernel(const uint64_t *partials, uint32_t k, uint64_t *out_xy, uint8_t *out_inf) {
+    // one wave: lane i folds partials i, i+64, ... (Jacobian -> lazy XYZZ), then a shuffle tree; the group sum does not
+    // depend on the association order, and the affine result is canonical
+    uint32_t lane = threadIdx.x;
+    XYZZ29 acc = xyzz29_identity();
+    for (uint32_t i = lane; i < k; i += 64) {
         Fp X = fe_load<FpParams>(partials + 12 * i), Y = fe_load<FpParams>(partials + 12 * i + 4),
            Z = fe_load<FpParams>(partials + 12 * i + 8);
-        acc = xyzz_add(acc, xyzz_from_jacobian(X, Y, Z));
+        if (!Z.is_zero()) {
+            XYZZ29 p;
+            F29 z = f29_from_fp(Z);
+            p.x = f29_from_fp(X); p.y = f29_from_fp(Y);
+            p.zz = f29_sqr(z);
+            p.zzz = f29_mul(p.zz, z);
+            acc = xyzz29_add(acc, p);
+        }
     }
+    for (int d = 1; d < 64; d <<= 1) {
+        XYZZ29 o = xyzz29_shfl_down(acc, d);
+        if ((lane & (uint32_t)(2 * d - 1)) == 0 && (uint32_t)d < k) acc = xyzz29_add(acc, o);
+    }
+    if (lane != 0) return;
     Affine r;
-    bool inf = xyzz_to_affine(acc, r);
+    bool inf = xyzz_to_affine(xyzz29_to_std_val(acc), r);
     affine_store(out_xy, r);
     *out_inf = inf ? 1 : 0;
 }
@@ -1090,6 +1119,16 @@ int zg_msm_g1_partial_dev(zg_bases_t b, size_t off, size_t n, const uint64_t *d_
     return msm_enqueue(b, off, n, d_scalars, pick_stream(stream), 1, d_out_jac, nullptr);
 }
 
+int zg_msm_g1_partial_fast_dev(zg_bases_t b, size_t off, size_t n, const uint64_t *d_scalars, void *stream, uint64_t *d_out_jac) {
+    ZG_INIT();
+    if (!b || !d_out_jac || (n && !d_scalars)) {
+        set_error("zg_msm_g1_partial_fast_dev: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(b->mu);
+    return msm_enqueue(b, off, n, d_scalars, pick_stream(stream), 2, d_out_jac, nullptr);
+}
+
 int zg_msm_g1_batch(zg_bases_t b, size_t n, const uint64_t *const *batches, size_t k, uint64_t *out_xy, uint8_t *out_inf) {
     ZG_INIT();
     if (!b || (k && (!batches || !out_xy))) {
@@ -1150,7 +1189,7 @@ int zg_g1_combine_partials_dev(const uint64_t *d_partials, size_t k, void *strea
     hipStream_t st = pick_stream(stream);
     uint64_t *d_out = nullptr;
     ZG_HIP(hipMalloc((void **)&d_out, 16 * 8));
-    hipLaunchKernelGGL(msm_combine_kernel, dim3(1), dim3(1), 0, st, d_partials, (uint32_t)k, d_out, reinterpret_cast<uint8_t *>(d_out + 8));
+    hipLaunchKernelGGL(msm_combine_kernel, dim3(1), dim3(64), 0, st, d_partials, (uint32_t)k, d_out, reinterpret_cast<uint8_t *>(d_out + 8));
     uint64_t h[9];
     hipError_t e = hipMemcpyAsync(h, d_out, 9 * 8, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -1167,7 +1206,7 @@ int zg_g1_combine_partials_dev_async(const uint64_t *d_partials, size_t k, void 
         set_error("zg_g1_combine_partials_dev_async: invalid argument");
         return ZG_ERR_INVALID;
     }
-    hipLaunchKernelGGL(msm_combine_kernel, dim3(1), dim3(1), 0, pick_stream(stream), d_partials, (uint32_t)k, d_out_xy, d_out_inf);
+    hipLaunchKernelGGL(msm_combine_kernel, dim3(1), dim3(64), 0, pick_stream(stream), d_partials, (uint32_t)k, d_out_xy, d_out_inf);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
