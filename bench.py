@@ -196,6 +196,10 @@ def main():
         wxy, winf = want[i % N_SCALAR_SETS]
         assert int(res[i, 8] & 0xFF) == winf and np.array_equal(res[i, :8], wxy), f"MSM result mismatch at step {i}"
 
+    sharded_sc = None
+    if use_dist and not args.no_extra and world & (world - 1) == 0:
+        sharded_sc = sharded_sumcheck_measurement(lib, api, torch, dist, dev, stream, world, rank, dist_backend)
+
     if rank != 0:
         dist.destroy_process_group()
         return
@@ -226,6 +230,8 @@ def main():
                   "setup_seconds": setup_s},
     }
 
+    if sharded_sc is not None:
+        out["extra"]["sumcheck_v20_sharded"] = sharded_sc
     if not args.no_extra and world == 1:
         # the host-buffer entry point (what an unmodified MSM.compute call site pays): scalars cross PCIe every call
         h_sc = d_scalars[0].cpu().numpy().view(np.uint64)
@@ -241,6 +247,51 @@ def main():
     print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
+
+
+def sharded_sumcheck_measurement(lib, api, torch, dist, dev, stream, world, rank, dist_backend):
+    """BASELINE config 3 with the 2^20-entry table sharded over the ranks: every rank builds ITS shard of
+    the eq table (shared-prefix scalar), combines it with its shards of Az/Bz/Cz, then 20 rounds of
+    (local sums -> 64-byte all-gather -> host toy challenge -> local fold); the last log2(world) rounds run on the
+    gathered residuals. Every rank checks final_eval == the verifier's last claim. rounds/s = 20 / max-over-ranks time."""
+    v, layout = 20, lib.SC_LOW_PAIR
+    n_loc = (1 << v) // world
+    r = lib.field_op(lib.FR, lib.OP_TO_MONT, raw_scalars(0x45515F54, 0, v))
+    tabs = [torch.from_numpy(lib.field_op(lib.FR, lib.OP_TO_MONT, raw_scalars(0x53554D43 + k, rank * n_loc, n_loc)).view(np.int64)).to(dev)
+            for k in range(3)]
+    d_eq = torch.empty((n_loc, 4), dtype=torch.int64, device=dev)
+    d_f = torch.empty((n_loc, 4), dtype=torch.int64, device=dev)
+    r_loc, sc_loc = api.sharded_eq_args(r, world, rank, layout)
+    reps = 3
+    times = []
+    for rep in range(reps + 1):
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        lib.fr_eq_table_dev(r_loc, d_eq.data_ptr(), scale=sc_loc, stream=stream)
+        lib.fr_spartan_combine_dev(d_eq.data_ptr(), tabs[0].data_ptr(), tabs[1].data_ptr(), tabs[2].data_ptr(), n_loc,
+                                   d_f.data_ptr(), stream=stream)
+        sh = api.ShardedSumcheck(api.GpuSumcheckShardBackend(d_f, layout), world, rank)
+        c0 = sh.nextRound()  # round 0 message also yields the claim g0 + g1
+        claim = api._limbs((2 * api._int(c0[0]) + api._int(c0[1])) % api.R_MOD)
+        ver = api.Sumcheck.Verifier(claim)
+        coeffs = c0
+        for rd in range(v):
+            if rd:
+                coeffs = sh.nextRound()
+            sh.receiveChallenge(ver.verifyRound(coeffs))
+        assert sh.isComplete() and np.array_equal(sh.getFinalEval(), ver.claim), "sharded sumcheck: final evaluation mismatch"
+        sh.deinit()
+        torch.cuda.synchronize()
+        if rep:  # first repetition warms the session pool and the collective
+            times.append(time.perf_counter() - t0)
+    t = torch.tensor([sum(times) / len(times)], dtype=torch.float64, device=dev if dist_backend == "nccl" else "cpu")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t.item())
+    return {"rounds_per_s": v / el, "ms_per_sumcheck": el * 1e3, "ranks": world, "entries_per_rank": n_loc,
+            "pipeline": "per-rank eq-table shard + spartan_combine + 20 x (local sums, 64 B all-gather, host toy challenge, local fold)",
+            "layout": "LOW_PAIR, contiguous shards"}
 
 
 def extra_measurements(lib, api, torch, dev, stream, args):

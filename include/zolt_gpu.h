@@ -214,6 +214,11 @@ ZG_API int zg_sumcheck_bind(zg_sc_t s, const uint64_t r[4]);
 ZG_API size_t zg_sumcheck_len(zg_sc_t s);
 ZG_API int zg_sumcheck_final(zg_sc_t s, uint64_t out[4]); /* getFinalEval (:130-133), needs len == 1 */
 ZG_API int zg_sumcheck_read(zg_sc_t s, uint64_t *out_table); /* copy the current table to the host (tests) */
+/* Sharded tables: the LOCAL pair g0||g1 (8 limbs) / the current local table, written to device
+ * memory in stream order on the session's stream (the one given to zg_sumcheck_open_dev) with no host
+ * synchronisation, so an RCCL all-gather enqueued on that stream can follow directly. */
+ZG_API int zg_sumcheck_round_sums_dev(zg_sc_t s, uint64_t *d_out8);
+ZG_API int zg_sumcheck_read_dev(zg_sc_t s, uint64_t *d_out_table);
 ZG_API int zg_sumcheck_close(zg_sc_t s);
 
 #ifdef __cplusplus

@@ -658,6 +658,36 @@ int zg_sumcheck_read(zg_sc_t s, uint64_t *out_table) {
     return ZG_OK;
 }
 
+// Stream-ordered variants for a table sharded over several GPUs: the local pair of round sums /
+// the current table land in DEVICE memory on the session's stream, ready for an RCCL all-gather enqueued on
+// the same stream; nothing is synchronised here.
+int zg_sumcheck_round_sums_dev(zg_sc_t s, uint64_t *d_out) {
+    ZG_INIT();
+    if (!s || !d_out || s->len < 2) {
+        set_error("zg_sumcheck_round_sums_dev: invalid session or protocol already complete");
+        return ZG_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (!s->sums_valid) {
+        s->seq++;
+        ZG_TRY(launch_sums(s->layout, s->buf[s->cur], s->len, s->d_partials, s->h_pin, s->st, s->h_pin + 12, s->seq));
+        s->sums_valid = true;
+    }
+    ZG_HIP(hipMemcpyAsync(d_out, s->h_pin, 64, hipMemcpyHostToDevice, s->st));  // ordered before the next fold's write
+    return ZG_OK;
+}
+
+int zg_sumcheck_read_dev(zg_sc_t s, uint64_t *d_out_table) {
+    ZG_INIT();
+    if (!s || !d_out_table) {
+        set_error("zg_sumcheck_read_dev: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(s->mu);
+    ZG_HIP(hipMemcpyAsync(d_out_table, s->buf[s->cur], s->len * 32, hipMemcpyDeviceToDevice, s->st));
+    return ZG_OK;
+}
+
 int zg_sumcheck_close(zg_sc_t s) {
     if (!s) return ZG_OK;
     ZG_INIT();

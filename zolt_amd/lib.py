@@ -34,6 +34,7 @@ SYMBOLS = [
     "zg_fr_spartan_combine", "zg_fr_spartan_combine_dev",
     "zg_sumcheck_open", "zg_sumcheck_open_dev", "zg_sumcheck_round_sums", "zg_sumcheck_bind",
     "zg_sumcheck_len", "zg_sumcheck_final", "zg_sumcheck_read", "zg_sumcheck_close",
+    "zg_sumcheck_round_sums_dev", "zg_sumcheck_read_dev",
 ]
 
 
@@ -334,6 +335,12 @@ class SumcheckSession:
         out = np.empty((len(self), 4), dtype=np.uint64)
         _chk(_lib.zg_sumcheck_read(self._h, _h(out)), "zg_sumcheck_read")
         return out
+
+    def round_sums_dev(self, d_out8):
+        _chk(_lib.zg_sumcheck_round_sums_dev(self._h, _d(d_out8)), "zg_sumcheck_round_sums_dev")
+
+    def read_dev(self, d_out):
+        _chk(_lib.zg_sumcheck_read_dev(self._h, _d(d_out)), "zg_sumcheck_read_dev")
 
     def close(self):
         if self._h:
