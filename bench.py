@@ -332,6 +332,16 @@ def extra_measurements(lib, api, torch, dev, stream, args):
         "kernel_ms": {k: (val[0] / max(val[1], 1)) for k, val in prof.items() if val[1]},
         "fold_round0_GBps": (48.0 * n) / ((prof["sc_fold"][0] / max(prof["sc_fold"][1], 1)) * 1e-3) / 1e9 if prof["sc_fold"][1] else None,
     }
+    # runSumcheck with the toy verifier on the device as well (zg_run_sumcheck_dev): no PCIe crossing per round
+    res = lib.run_sumcheck_dev(d_f.data_ptr(), n, stream=stream)
+    assert res["result"] and np.array_equal(res["final_eval"], fin)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        lib.run_sumcheck_dev(d_f.data_ptr(), n, stream=stream)
+    el = time.perf_counter() - t0
+    extra["sumcheck_v20_device_resident"] = {"rounds_per_s": 20 * v / el, "ms_per_runSumcheck": el / 20 * 1e3,
+                                             "note": "prover + toy verifier on the device; transcript equals the host-verifier run"}
     # the metric's second size, 2^22 points on this one GPU (same code path, fresh process)
     try:
         import subprocess

@@ -48,6 +48,7 @@ extern "C" {
 #define ZG_ERR_HIP 2       /* HIP runtime error (see zg_last_error) */
 #define ZG_ERR_NOMEM 3
 #define ZG_ERR_NO_DEVICE 4
+#define ZG_ERR_VERIFY 5    /* error.SumcheckVerificationFailed (src/subprotocols/mod.zig:175-178) */
 
 #define ZG_FIELD_FR 0
 #define ZG_FIELD_FP 1
@@ -220,6 +221,18 @@ ZG_API int zg_sumcheck_read(zg_sc_t s, uint64_t *out_table); /* copy the current
 ZG_API int zg_sumcheck_round_sums_dev(zg_sc_t s, uint64_t *d_out8);
 ZG_API int zg_sumcheck_read_dev(zg_sc_t s, uint64_t *d_out_table);
 ZG_API int zg_sumcheck_close(zg_sc_t s);
+
+/* runSumcheck (src/subprotocols/mod.zig:302-354) with the WHOLE protocol on the device: the prover's sums and folds
+ * (bindFirst order) and the reference's toy verifier (verifyRound / deriveChallenge, :165-243: the deterministic
+ * 64-bit mixer, F.fromU64, claim <- p(challenge)) — the verifier step runs at the end of the kernel that produced the
+ * round's sums, so no round crosses PCIe. len = 2^v (v >= 0). Outputs (host): claim[4]; rounds: v x (c0 || c1) =
+ * Round.poly.coeffs [g(0), g(1) - g(0)]; challenges: v x 4 (= Proof.final_point); final_eval[4]; *result =
+ * verifier.claim == final_eval. Returns ZG_ERR_VERIFY where the reference returns error.SumcheckVerificationFailed.
+ * The input table is not modified. Provers driven by a host transcript (Keccak/Blake2b) use the session API above. */
+ZG_API int zg_run_sumcheck_dev(const uint64_t *d_evals, size_t len, void *stream, uint64_t claim[4], uint64_t *rounds,
+                               uint64_t *challenges, uint64_t final_eval[4], uint8_t *result);
+ZG_API int zg_run_sumcheck(const uint64_t *evals, size_t len, uint64_t claim[4], uint64_t *rounds, uint64_t *challenges,
+                           uint64_t final_eval[4], uint8_t *result);
 
 #ifdef __cplusplus
 }

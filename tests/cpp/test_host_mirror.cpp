@@ -149,6 +149,14 @@ TEST(sumcheck_complete_protocol) {
     EXPECT(res.result);
     EXPECT(res.proof.claim.eql(Fr::fromU64(36)));
     EXPECT(res.proof.rounds.size() == 3 && res.proof.final_point.size() == 3);
+    // the host-verifier form (one device round trip per round) produces the same transcript
+    auto inter = runSumcheckInteractive(DensePolynomial(e));
+    EXPECT(inter.result && inter.proof.claim.eql(res.proof.claim) && inter.proof.final_eval.eql(res.proof.final_eval));
+    for (size_t i = 0; i < 3; i++) {
+        EXPECT(inter.proof.final_point[i].eql(res.proof.final_point[i]));
+        EXPECT(inter.proof.rounds[i].poly.coeffs[0].eql(res.proof.rounds[i].poly.coeffs[0]));
+        EXPECT(inter.proof.rounds[i].poly.coeffs[1].eql(res.proof.rounds[i].poly.coeffs[1]));
+    }
 }
 
 int main() {

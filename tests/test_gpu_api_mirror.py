@@ -85,6 +85,9 @@ def test_poly_classes_and_run_sumcheck(env):
     assert res["result"] and wok == 1
     assert np.array_equal(res["claim"], wc) and np.array_equal(np.array(res["rounds"]), wr)
     assert np.array_equal(np.array(res["final_point"]), wch) and np.array_equal(res["final_eval"], wfin)
+    inter = api.runSumcheckInteractive(api.DensePolynomial(ev))  # host verifier, one round trip per round: same transcript
+    assert inter["result"] and np.array_equal(inter["claim"], wc) and np.array_equal(np.array(inter["rounds"]), wr)
+    assert np.array_equal(np.array(inter["final_point"]), wch) and np.array_equal(inter["final_eval"], wfin)
     with pytest.raises(AssertionError):
         api.DensePolynomial(ev[:100])  # length must be a power of two (src/poly/mod.zig:36-37)
 

@@ -115,6 +115,46 @@ def test_run_sumcheck_vs_oracle(zl, ob, logn):
     assert np.array_equal(fin, wfin) and ok == wok == 1
 
 
+@pytest.mark.parametrize("logn", [0, 1, 2, 3, 6, 9, 10, 12, 13, 16, 18])
+def test_device_resident_run_sumcheck_vs_oracle(zl, ob, logn):
+    """zg_run_sumcheck: prover and toy verifier both on the device (src/subprotocols/mod.zig:302-354, :165-243) —
+    claim, every round polynomial, every challenge, the final evaluation and the result flag equal the oracle's."""
+    evals = _rand(ob, 1800 + logn, 1 << logn)
+    res = zl.run_sumcheck(evals)
+    wc, wr, wch, wfin, wok = ob.run_sumcheck(evals)
+    assert np.array_equal(res["claim"], wc) and np.array_equal(res["final_eval"], wfin) and res["result"] == bool(wok)
+    assert np.array_equal(res["rounds"].reshape(-1, 2, 4), np.asarray(wr).reshape(-1, 2, 4))
+    assert np.array_equal(res["final_point"].reshape(-1, 4), np.asarray(wch).reshape(-1, 4))
+    # the input table is left untouched by the device path; the other launch shapes (every round its own launch;
+    # the LDS-resident tail taking over at 64 entries) give the same transcript
+    import os
+    for tail in ("1", "64"):
+        os.environ["ZG_SC_TAIL_MAX"] = tail
+        try:
+            again = zl.run_sumcheck(evals)
+        finally:
+            del os.environ["ZG_SC_TAIL_MAX"]
+        assert all(np.array_equal(res[k], again[k]) for k in ("claim", "rounds", "final_point", "final_eval")) and again["result"]
+
+
+def test_device_resident_run_sumcheck_kats_and_full_size(zl, ob):
+    res = zl.run_sumcheck(U.fr(range(1, 9)))  # src/subprotocols/mod.zig:441-461
+    assert U.fr_to_int(res["claim"]) == 36 and res["result"] and res["rounds"].shape == (3, 2, 4)
+    for case in U.load_vectors()["sumcheck"]:
+        res = zl.run_sumcheck(U.fr_hex(case["evals"]))
+        assert U.fr_to_int(res["claim"]) == int(case["claim"], 16)
+        assert [[U.fr_to_int(x) for x in rd] for rd in res["rounds"]] == [[int(h, 16) for h in rd] for rd in case["rounds"]]
+        assert U.fr_to_int(res["final_eval"]) == int(case["final_eval"], 16) and res["result"] == bool(int(case["ok"]))
+    evals = _rand(ob, 0x53554D43, 1 << 20)  # BASELINE config 3 size
+    res = zl.run_sumcheck(evals)
+    wc, wr, wch, wfin, wok = ob.run_sumcheck(evals)
+    assert res["result"] and wok == 1 and np.array_equal(res["claim"], wc) and np.array_equal(res["final_eval"], wfin)
+    assert np.array_equal(res["rounds"].reshape(-1, 2, 4), np.asarray(wr).reshape(-1, 2, 4))
+    assert np.array_equal(res["final_point"].reshape(-1, 4), np.asarray(wch).reshape(-1, 4))
+    with pytest.raises(zl.ZgError):
+        zl.run_sumcheck(evals[:100])  # length must be a power of two
+
+
 def test_sumcheck_kats(zl, ob):
     """src/subprotocols/mod.zig:366-461: [1,2,3,4] -> g(0)=3, g(1)=7, r=2 -> [5,6]; [1..8] -> claim 36."""
     s = zl.SumcheckSession.open(U.fr([1, 2, 3, 4]))

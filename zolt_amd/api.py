@@ -548,7 +548,21 @@ class GpuSumcheckShardBackend:
 
 
 def runSumcheck(polynomial):
-    """runSumcheck (src/subprotocols/mod.zig:302-354) -> dict(claim, rounds, final_point, final_eval, result)."""
+    """runSumcheck (src/subprotocols/mod.zig:302-354) -> dict(claim, rounds, final_point, final_eval, result), with the
+    prover AND the toy verifier on the device (zg_run_sumcheck): no PCIe crossing between rounds. Raises
+    SumcheckVerificationFailed where the reference returns that error."""
+    try:
+        out = lib.run_sumcheck(polynomial.evaluations)
+    except lib.SumcheckVerificationFailed as e:
+        raise SumcheckVerificationFailed(str(e)) from None
+    out["rounds"] = list(out["rounds"])
+    out["final_point"] = list(out["final_point"])
+    return out
+
+
+def runSumcheckInteractive(polynomial):
+    """The same protocol with the verifier on the host and one device round trip per round — the shape a prover with
+    a real (Keccak/Blake2b) transcript has. Same outputs as runSumcheck."""
     s = lib.SumcheckSession.open(polynomial.evaluations, lib.SC_HIGH_HALF)
     g0, g1 = s.round_sums() if polynomial.num_vars else (polynomial.evaluations[0], np.zeros(4, dtype=np.uint64))
     s.close()

@@ -68,6 +68,86 @@ struct Fr29 {
 
 // Montgomery product a*b*2^-261 mod p (lazy): limbs of a, b < 2^30; output limbs exactly < 2^29,
 // value < (A*B/168.9 + 1)*p for a < A*p, b < B*p.
+// Column-serial (Comba) order: column k collects its product terms and the reduction terms of the earlier
+// quotient digits in ONE 64-bit accumulator whose initial value is the carry out of column k-1, so the
+// carry propagation costs a shift only (no 64-bit add): every v_mad_u64_u32 takes its addend for free.
+// A column holds <= 9 + 9 products of < 2^58 plus a carry < 2^36 (27 for the two-product form): < 2^63.
+// c + a*b as one v_mad_u64_u32. ZG_F29_ASM pins the instruction (and with it the accumulation order) with inline
+// assembly; the default leaves instruction selection to the compiler.
+#ifdef ZG_F29_ASM
+ZG_DEV u64 mad64(u32 a, u32 b, u64 c) {
+    u64 d;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c) : "vcc");
+    return d;
+}
+ZG_DEV u64 mad64k(u32 a, u32 k, u64 c) {  // k: a compile-time constant, kept in an SGPR
+    u64 d;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "s"(k), "v"(c) : "vcc");
+    return d;
+}
+#else
+ZG_DEV u64 mad64(u32 a, u32 b, u64 c) { return c + (u64)a * b; }
+ZG_DEV u64 mad64k(u32 a, u32 k, u64 c) { return c + (u64)a * k; }
+#endif
+
+#ifndef ZG_F29_ROWWISE
+template <class C29, int NPROD>
+ZG_DEV F29 f29t_mulsum(const F29 &a, const F29 &b, const F29 &c, const F29 &d) {
+    u32 m[9];
+    F29 r;
+    u64 acc = 0;
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+#pragma unroll
+        for (int i = (k > 8 ? k - 8 : 0); i <= (k < 8 ? k : 8); i++) {
+            acc = mad64(a.l[i], b.l[k - i], acc);
+            if (NPROD == 2) acc = mad64(c.l[i], d.l[k - i], acc);
+        }
+#pragma unroll
+        for (int i = (k > 8 ? k - 8 : 0); i <= (k < 9 ? k - 1 : 8); i++) acc = mad64k(m[i], C29::P[k - i], acc);
+        if (k < 9) {
+            m[k] = ((u32)acc * C29::NINV) & C29::MASK;
+            acc = mad64k(m[k], C29::P[0], acc);
+        } else {
+            r.l[k - 9] = (u32)acc & C29::MASK;
+        }
+        acc >>= 29;
+    }
+    r.l[8] = (u32)acc;
+    return r;
+}
+template <class C29>
+ZG_DEV F29 f29t_mul(const F29 &a, const F29 &b) { return f29t_mulsum<C29, 1>(a, b, a, b); }
+
+ZG_DEV F29 f29_mul(const F29 &a, const F29 &b) { return f29t_mul<Fp29>(a, b); }
+// (a*b + c*d) * 2^-261 with ONE reduction: value < ((A*B + C*D)/168.9 + 1)*p
+ZG_DEV F29 f29_mul2(const F29 &a, const F29 &b, const F29 &c, const F29 &d) { return f29t_mulsum<Fp29, 2>(a, b, c, d); }
+
+ZG_DEV F29 f29_sqr(const F29 &a) {
+    u32 m[9], d2[9];
+    F29 r;
+    u64 acc = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) d2[i] = a.l[i] << 1;
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+#pragma unroll
+        for (int i = (k > 8 ? k - 8 : 0); 2 * i < k; i++) acc = mad64(d2[i], a.l[k - i], acc);
+        if ((k & 1) == 0) acc = mad64(a.l[k / 2], a.l[k / 2], acc);
+#pragma unroll
+        for (int i = (k > 8 ? k - 8 : 0); i <= (k < 9 ? k - 1 : 8); i++) acc = mad64k(m[i], Fp29::P[k - i], acc);
+        if (k < 9) {
+            m[k] = ((u32)acc * Fp29::NINV) & Fp29::MASK;
+            acc = mad64k(m[k], Fp29::P[0], acc);
+        } else {
+            r.l[k - 9] = (u32)acc & Fp29::MASK;
+        }
+        acc >>= 29;
+    }
+    r.l[8] = (u32)acc;
+    return r;
+}
+#else
 template <class C29>
 ZG_DEV F29 f29t_mul(const F29 &a, const F29 &b) {
     u64 c[18];
@@ -127,6 +207,33 @@ ZG_DEV F29 f29_sqr(const F29 &a) {
     return r;
 }
 
+ZG_DEV F29 f29_mul2(const F29 &a, const F29 &b, const F29 &c, const F29 &d) {
+    u64 t[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) t[k] = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+#pragma unroll
+        for (int j = 0; j < 9; j++) t[i + j] += (u64)a.l[i] * b.l[j] + (u64)c.l[i] * d.l[j];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        u32 m = ((u32)t[i] * Fp29::NINV) & Fp29::MASK;
+#pragma unroll
+        for (int j = 0; j < 9; j++) t[i + j] += (u64)m * Fp29::P[j];
+        t[i + 1] += t[i] >> 29;
+    }
+    F29 r;
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+        r.l[k - 9] = (u32)t[k] & Fp29::MASK;
+        t[k + 1] += t[k] >> 29;
+    }
+    r.l[8] = (u32)t[17];
+    return r;
+}
+#endif
+
 // a + K*p - b, near-normalised; needs b < K*p (with margin) and near-normalised limbs
 #define ZG_F29_SUB(NAME, BIAS)                                        \
     ZG_DEV F29 NAME(const F29 &a, const F29 &b) {                     \
@@ -144,6 +251,14 @@ ZG_DEV F29 f29_neg2(const F29 &y) {
     F29 t;
 #pragma unroll
     for (int i = 0; i < 9; i++) t.l[i] = Fp29::BIAS2P[i] - y.l[i];
+    return f29_carry(t);
+}
+
+// 4p - y (y < 4p, near-normalised)
+ZG_DEV F29 f29_neg4(const F29 &y) {
+    F29 t;
+#pragma unroll
+    for (int i = 0; i < 9; i++) t.l[i] = Fp29::BIAS4P[i] - y.l[i];
     return f29_carry(t);
 }
 

@@ -20,34 +20,61 @@
 
 namespace zg {
 
-// ------------------------------------------------------------------ eq table
-// hi[h] = scale * prod_{j < v_hi} (bit_j(h) ? r[j] : 1 - r[j]),  bit_j = bit (v_hi-1-j) of h  (r[0] <-> MSB)
-__global__ void __launch_bounds__(256) eq_hi_kernel(const uint64_t *r, int v_hi, const uint64_t *scale, uint64_t *hi) {
-    uint32_t h = blockIdx.x * 256 + threadIdx.x;
-    if (h >= (1u << v_hi)) return;
-    Fr prod = scale ? fe_load<FrParams>(scale) : Fr::one();
-    Fr one = Fr::one();
-    for (int j = 0; j < v_hi; j++) {
-        Fr rj = fe_load<FrParams>(r + 4 * j);
-        Fr f = ((h >> (v_hi - 1 - j)) & 1u) ? rj : fe_sub(one, rj);
-        prod = fe_mul(prod, f);
-    }
-    fe_store(hi + 4 * (size_t)h, prod);
+ZG_DEV Fr fr_shfl_down(const Fr &v, int d) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = __shfl_down(v.l[i], d, 64);
+    return r;
 }
 
-// out[(h << v_lo) | lo] = hi[h] * prod_{j < v_lo} (bit_j(lo) ? r_lo[j] : 1 - r_lo[j]); one 32-byte
-// store per thread, 8 KiB contiguous per (block, h): the kernel is a pure HBM write stream.
-__global__ void __launch_bounds__(256) eq_main_kernel(const uint64_t *r_lo, int v_lo, const uint64_t *hi, uint32_t n_hi,
+// ------------------------------------------------------------------ eq table
+// Factor tables of eq(r, .) (r[0] <-> MSB of the index), one launch:
+//   blocks [0, nb_hi):  hi[h]   = scale * prod_{j < v_hi} (bit_j(h) ? r[j] : 1 - r[j]),        bit_j = bit (v_hi-1-j) of h
+//   the other blocks:   lo[t]   =         prod_{j < v_lo} (bit_j(t) ? r[v_hi+j] : 1 - r[v_hi+j])   (256 entries at most)
+// The kernel is pure dependency latency (a few thousand outputs), so FOUR adjacent lanes share one output: lane q
+// multiplies the factors j = q (mod 4), then two shuffle steps combine the four partial products — a chain of
+// ceil(v/4) + 2 products instead of v.
+ZG_DEV Fr eq_factor_product4(const uint64_t *r, int v, uint32_t idx, uint32_t q, const Fr *init) {
+    Fr one = Fr::one();
+    Fr c = (q == 0 && init) ? *init : one;
+    bool used = q == 0 && init;
+    for (int j = (int)q; j < v; j += 4) {
+        Fr rj = fe_load<FrParams>(r + 4 * j);
+        Fr f = ((idx >> (v - 1 - j)) & 1u) ? rj : fe_sub(one, rj);
+        c = used ? fe_mul(c, f) : f;
+        used = true;
+    }
+    // lanes q and q+1, then q and q+2 (all four lanes of a group execute the same products; lane 0 holds the result)
+    Fr o = fr_shfl_down(c, 1);
+    c = fe_mul(c, o);
+    o = fr_shfl_down(c, 2);
+    return fe_mul(c, o);
+}
+
+__global__ void __launch_bounds__(256) eq_tables_kernel(const uint64_t *r, int v_hi, int v_lo, const uint64_t *scale, uint64_t *hi,
+                                                        uint32_t nb_hi, uint64_t *lo) {
+    uint32_t q = threadIdx.x & 3;
+    if (blockIdx.x < nb_hi) {
+        uint32_t h = blockIdx.x * 64 + (threadIdx.x >> 2);
+        bool live = h < (1u << v_hi);
+        Fr sc = scale ? fe_load<FrParams>(scale) : Fr::one();
+        Fr p = eq_factor_product4(r, v_hi, live ? h : 0, q, scale ? &sc : nullptr);
+        if (live && q == 0) fe_store(hi + 4 * (size_t)h, p);
+    } else {
+        uint32_t t = (blockIdx.x - nb_hi) * 64 + (threadIdx.x >> 2);
+        bool live = t < (1u << v_lo);
+        Fr p = eq_factor_product4(r + 4 * (size_t)v_hi, v_lo, live ? t : 0, q, nullptr);
+        if (live && q == 0) fe_store(lo + 4 * (size_t)t, p);
+    }
+}
+
+// out[(h << v_lo) | t] = hi[h] * lo[t]; one 32-byte store per thread and row, 8 KiB contiguous per (block, h): the
+// kernel is an HBM write stream with one mixed-format product (fr_mul29) per element.
+__global__ void __launch_bounds__(256) eq_main_kernel(const uint64_t *lo_tab, int v_lo, const uint64_t *hi, uint32_t n_hi,
                                                       uint32_t hi_per_block, uint64_t *out) {
     uint32_t lo = threadIdx.x;
     if (lo >= (1u << v_lo)) return;
-    Fr t = Fr::one(), one = Fr::one();
-    for (int j = 0; j < v_lo; j++) {
-        Fr rj = fe_load<FrParams>(r_lo + 4 * j);
-        Fr f = ((lo >> (v_lo - 1 - j)) & 1u) ? rj : fe_sub(one, rj);
-        t = fe_mul(t, f);
-    }
-    F29 tp = fr29_prescale(t);  // shared factor of this thread's products: pre-scaled once
+    F29 tp = fr29_prescale(fe_load<FrParams>(lo_tab + 4 * (size_t)lo));  // shared factor of this thread's products
     uint32_t h0 = blockIdx.x * hi_per_block;
     for (uint32_t k = 0; k < hi_per_block; k++) {
         uint32_t h = h0 + k;
@@ -82,12 +109,6 @@ __global__ void __launch_bounds__(256) fr_dot_kernel(const uint64_t *a, const ui
 // block-wide sum of (g0, g1) pairs (256 threads); result valid in thread 0. Wave-level shuffle tree first
 // (no barriers, no LDS round trips), then one LDS hop across the four waves: the latency of this reduction is
 // what a small sumcheck round mostly consists of.
-ZG_DEV Fr fr_shfl_down(const Fr &v, int d) {
-    Fr r;
-#pragma unroll
-    for (int i = 0; i < 8; i++) r.l[i] = __shfl_down(v.l[i], d, 64);
-    return r;
-}
 __device__ __forceinline__ void block_sum_pair(Fr &g0, Fr &g1, uint4 *sh) {
     uint32_t tid = threadIdx.x;
 #pragma unroll
@@ -132,8 +153,134 @@ ZG_DEV void publish_seq(uint64_t *flag, uint64_t seq) {
     }
 }
 
+// ---- runSumcheck resident on the device (src/subprotocols/mod.zig:302-354): the toy verifier (:165-243) runs as the
+// last step of the kernel that produced a round's sums, so no round needs the host. `res` (u64 words):
+//   [0,4) claim | [4, 4+8v) rounds: c0 || c1 | [.., +4v) challenges | +4 final_eval | +1 status | +4 running claim |
+//   +4 running challenge.   status: bit 0 = result (verifier.claim == final_eval), bits 8.. = 1 + first failed round
+struct ScRunArg {
+    uint64_t *res;  // nullptr: an ordinary session launch (sums go to `sums`, sequence word published)
+    uint32_t v, round, init;
+};
+ZG_DEV size_t run_off_chal(uint32_t v) { return 4 + 8 * (size_t)v; }
+ZG_DEV size_t run_off_final(uint32_t v) { return 4 + 12 * (size_t)v; }
+ZG_DEV size_t run_off_status(uint32_t v) { return 8 + 12 * (size_t)v; }
+ZG_DEV size_t run_off_claim(uint32_t v) { return 9 + 12 * (size_t)v; }
+ZG_DEV size_t run_off_cur(uint32_t v) { return 13 + 12 * (size_t)v; }
+ZG_DEV uint64_t fr_limb64(const Fr &a, int i) { return (uint64_t)a.l[2 * i] | ((uint64_t)a.l[2 * i + 1] << 32); }
+ZG_DEV bool fr_eq(const Fr &a, const Fr &b) {
+    uint32_t d = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) d |= a.l[i] ^ b.l[i];
+    return d == 0;
+}
+
+// Verifier.verifyRound for the round polynomial [g0, g1 - g0]: check, derive the challenge, update the claim.
+// One thread. With `init` the claim is first set to g0 + g1 (runSumcheck's initial sum over the hypercube).
+ZG_DEV Fr sc_verifier_step(const ScRunArg &a, const Fr &g0, const Fr &g1) {
+    uint64_t *res = a.res;
+    Fr sum = fe_add(g0, g1);
+    Fr claim;
+    if (a.init) {
+        claim = sum;
+        fe_store(res, claim);
+        res[run_off_status(a.v)] = 0;
+    } else {
+        claim = fe_load<FrParams>(res + run_off_claim(a.v));
+    }
+    Fr c1 = fe_sub(g1, g0);
+    if (!fr_eq(sum, claim) && (res[run_off_status(a.v)] >> 8) == 0) res[run_off_status(a.v)] = ((uint64_t)(a.round + 1)) << 8;
+    uint64_t h = 0x9e3779b97f4a7c15ull;
+    h ^= (uint64_t)a.round;
+    h *= 0xff51afd7ed558ccdull;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        h ^= fr_limb64(claim, i);
+        h *= 0xc4ceb9fe1a85ec53ull;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        h ^= i < 4 ? fr_limb64(g0, i) : fr_limb64(c1, i - 4);
+        h *= 0xff51afd7ed558ccdull;
+        h ^= h >> 33;
+    }
+    h ^= h >> 33;
+    h *= 0xff51afd7ed558ccdull;
+    h ^= h >> 33;
+    Fr hv = Fr::zero();
+    hv.l[0] = (uint32_t)h;
+    hv.l[1] = (uint32_t)(h >> 32);
+    Fr ch = fe_to_mont(hv);                      // F.fromU64
+    Fr next = fe_add(fe_mul(c1, ch), g0);        // UniPoly.evaluate by Horner: c1 * x + c0
+    fe_store(res + 4 + 8 * (size_t)a.round, g0);
+    fe_store(res + 8 + 8 * (size_t)a.round, c1);
+    fe_store(res + run_off_chal(a.v) + 4 * (size_t)a.round, ch);
+    fe_store(res + run_off_claim(a.v), next);
+    fe_store(res + run_off_cur(a.v), ch);
+    return ch;
+}
+
+// End of a round inside the producing kernel (no second launch): every block leaves its pair in `partials`; the block
+// that arrives last at the device-scope counter adds all of them up, writes the round's pair to `sums` (the pinned
+// host mailbox), publishes the sequence word and re-arms the counter. g0/g1: the block's pair, valid in thread 0.
+__device__ __forceinline__ void finish_round(Fr &g0, Fr &g1, uint4 *sh, uint64_t *partials, uint64_t *sums, uint32_t *counter,
+                                             uint64_t *flag, uint64_t seq, const ScRunArg &run) {
+    uint32_t tid = threadIdx.x, nb = gridDim.x;
+    if (nb == 1) {
+        if (tid == 0) {
+            if (run.res) {
+                sc_verifier_step(run, g0, g1);
+            } else {
+                fe_store(sums, g0);
+                fe_store(sums + 4, g1);
+                publish_seq(flag, seq);
+            }
+        }
+        return;
+    }
+    __shared__ uint32_t last;
+    if (tid == 0) {
+        uint64_t *dst = partials + 8 * (size_t)blockIdx.x;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            __hip_atomic_store(dst + i, (uint64_t)g0.l[2 * i] | ((uint64_t)g0.l[2 * i + 1] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dst + 4 + i, (uint64_t)g1.l[2 * i] | ((uint64_t)g1.l[2 * i + 1] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        uint32_t arrived = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last = arrived == nb - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!last) return;
+    Fr a0 = Fr::zero(), a1 = Fr::zero();
+    for (uint32_t k = tid; k < nb; k += 256) {
+        const uint64_t *src = partials + 8 * (size_t)k;
+        Fr p0, p1;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint64_t x = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint64_t y = __hip_atomic_load(src + 4 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            p0.l[2 * i] = (uint32_t)x; p0.l[2 * i + 1] = (uint32_t)(x >> 32);
+            p1.l[2 * i] = (uint32_t)y; p1.l[2 * i + 1] = (uint32_t)(y >> 32);
+        }
+        a0 = fe_add(a0, p0);
+        a1 = fe_add(a1, p1);
+    }
+    __syncthreads();  // sh is reused
+    block_sum_pair(a0, a1, sh);
+    if (tid == 0) {
+        __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch (stream order)
+        if (run.res) {
+            sc_verifier_step(run, a0, a1);
+        } else {
+            fe_store(sums, a0);
+            fe_store(sums + 4, a1);
+            publish_seq(flag, seq);
+        }
+    }
+}
+
 template <int LAYOUT>
-__global__ void __launch_bounds__(256) sc_sums_kernel(const uint64_t *t, size_t half, uint64_t *partials, uint64_t *flag, uint64_t seq) {
+__global__ void __launch_bounds__(256) sc_sums_kernel(const uint64_t *t, size_t half, uint64_t *partials, uint64_t *sums,
+                                                      uint32_t *counter, uint64_t *flag, uint64_t seq, ScRunArg run) {
     __shared__ uint4 sh[256 * 4];
     Fr g0 = Fr::zero(), g1 = Fr::zero();
     size_t stride = (size_t)gridDim.x * 256;
@@ -143,11 +290,7 @@ __global__ void __launch_bounds__(256) sc_sums_kernel(const uint64_t *t, size_t 
         g1 = fe_add(g1, fe_load<FrParams>(t + 4 * i1));
     }
     block_sum_pair(g0, g1, sh);
-    if (threadIdx.x == 0) {
-        fe_store(partials + 8 * (size_t)blockIdx.x, g0);
-        fe_store(partials + 8 * (size_t)blockIdx.x + 4, g1);
-        publish_seq(flag, seq);
-    }
+    finish_round(g0, g1, sh, partials, sums, counter, flag, seq, run);
 }
 
 // fold by r and produce the NEXT round's two sums from the values just written:
@@ -159,11 +302,16 @@ struct FrArg {  // a challenge travels as a kernel argument: no H2D copy, no sta
 
 template <int LAYOUT>
 __global__ void __launch_bounds__(256) sc_fold_kernel(const uint64_t *t, size_t half, FrArg r, uint64_t *out,
-                                                      uint64_t *partials, uint64_t *flag, uint64_t seq) {
+                                                      uint64_t *partials, uint64_t *sums, uint32_t *counter, uint64_t *flag,
+                                                      uint64_t seq, ScRunArg run) {
     __shared__ uint4 sh[256 * 4];
     Fr rv;
+    if (run.res) {  // device-resident protocol: the challenge was left in device memory by the previous kernel's verifier step
+        rv = fe_load<FrParams>(run.res + run_off_cur(run.v));
+    } else {
 #pragma unroll
-    for (int i = 0; i < 8; i++) rv.l[i] = r.l[i];
+        for (int i = 0; i < 8; i++) rv.l[i] = r.l[i];
+    }
     F29 rp = fr29_prescale(rv);  // the challenge is the shared factor of every product of this launch
     Fr g0 = Fr::zero(), g1 = Fr::zero();
     size_t stride = (size_t)gridDim.x * 256;
@@ -183,10 +331,56 @@ __global__ void __launch_bounds__(256) sc_fold_kernel(const uint64_t *t, size_t 
         else g0 = fe_add(g0, v);
     }
     block_sum_pair(g0, g1, sh);
-    if (threadIdx.x == 0) {
-        fe_store(partials + 8 * (size_t)blockIdx.x, g0);
-        fe_store(partials + 8 * (size_t)blockIdx.x + 4, g1);
-        publish_seq(flag, seq);
+    if (run.res && half == 1) {  // the table is down to one element: getFinalEval + the verifier's last comparison
+        if (threadIdx.x == 0 && blockIdx.x == 0) {
+            Fr fin = fe_load<FrParams>(out);
+            fe_store(run.res + run_off_final(run.v), fin);
+            if (fr_eq(fin, fe_load<FrParams>(run.res + run_off_claim(run.v)))) run.res[run_off_status(run.v)] |= 1;
+        }
+        return;
+    }
+    finish_round(g0, g1, sh, partials, sums, counter, flag, seq, run);
+}
+
+// Last rounds of the device-resident protocol in ONE single-block launch: once the table fits in LDS (<= 4096
+// entries = 128 KiB) every remaining round — fold by the challenge the previous verifier step left, sums of the folded
+// table, verifier step, next challenge — stays inside the workgroup; a round costs a block reduction and two
+// dependent field products instead of a kernel launch. run.round = index of the next verifier step.
+constexpr uint32_t SC_TAIL_MAX = 4096;
+__global__ void __launch_bounds__(256) sc_tail_run_kernel(const uint64_t *t, uint32_t len, ScRunArg run) {
+    extern __shared__ uint4 lds_tab[];          // len entries of 2 x uint4, then 16 uint4 of reduction scratch + 2 for the challenge
+    uint4 *sh = lds_tab + 2 * (size_t)len;
+    uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < len; i += 256) fe_store(&lds_tab[2 * i], fe_load<FrParams>(t + 4 * (size_t)i));
+    Fr ch = fe_load<FrParams>(run.res + run_off_cur(run.v));
+    __syncthreads();
+    while (len > 1) {
+        uint32_t half = len / 2, quarter = half / 2;
+        F29 rp = fr29_prescale(ch);
+        Fr g0 = Fr::zero(), g1 = Fr::zero();
+        for (uint32_t i = tid; i < half; i += 256) {
+            Fr lo = fe_load<FrParams>(&lds_tab[2 * i]), hi = fe_load<FrParams>(&lds_tab[2 * (i + half)]);
+            Fr v = fe_add(lo, fr_mul29(fe_sub(hi, lo), rp));
+            fe_store(&lds_tab[2 * i], v);  // in place: entry i is read and written by this thread only
+            if (i >= quarter) g1 = fe_add(g1, v);
+            else g0 = fe_add(g0, v);
+        }
+        len = half;
+        if (len == 1) break;
+        block_sum_pair(g0, g1, sh);
+        if (tid == 0) {
+            Fr c = sc_verifier_step(run, g0, g1);
+            fe_store(&sh[16], c);
+        }
+        run.round++;
+        __syncthreads();
+        ch = fe_load<FrParams>(&sh[16]);
+        __syncthreads();  // sh is rewritten by the next round's reduction
+    }
+    if (tid == 0) {
+        Fr fin = fe_load<FrParams>(&lds_tab[0]);
+        fe_store(run.res + run_off_final(run.v), fin);
+        if (fr_eq(fin, fe_load<FrParams>(run.res + run_off_claim(run.v)))) run.res[run_off_status(run.v)] |= 1;
     }
 }
 
@@ -207,43 +401,52 @@ __global__ void __launch_bounds__(256) sc_finish_kernel(const uint64_t *partials
     }
 }
 
+// scratch layout of a fold/sums launch (u64 words): [0, 8*SC_MAX_BLOCKS) block pairs | 16 words: arrival counter
+// (must be 0 before a launch; the kernels re-arm it) | 8 words: the round's pair when it is not sent to a host mailbox
+constexpr unsigned SC_MAX_BLOCKS = 2048;
+constexpr size_t SC_SUMS_OFF = 8 * (size_t)SC_MAX_BLOCKS + 16;
+constexpr size_t SC_MISC_BYTES = (SC_SUMS_OFF + 8) * 8;
 static unsigned sc_blocks(size_t half) {
+    static const unsigned cap = [] {
+        const char *e = getenv("ZG_SC_MAX_BLOCKS");
+        unsigned v = e && *e ? (unsigned)atoi(e) : 256u;  // one block per CU: every extra block is one more same-address atomic
+        return v < 1 ? 1u : (v > SC_MAX_BLOCKS ? SC_MAX_BLOCKS : v);
+    }();
     unsigned b = div_up(half ? half : 1, 256);
-    return b > 2048 ? 2048 : b;  // grid-stride beyond 8 blocks per CU
+    return b > cap ? cap : b;  // grid-stride beyond that
 }
 
 static int launch_sums(int layout, const uint64_t *t, size_t len, uint64_t *partials, uint64_t *sums, hipStream_t st,
-                       uint64_t *flag = nullptr, uint64_t seq = 0) {
+                       uint64_t *flag = nullptr, uint64_t seq = 0, ScRunArg run = ScRunArg{nullptr, 0, 0, 0}) {
     size_t half = len / 2;
     unsigned nb = sc_blocks(half);
+    uint32_t *counter = reinterpret_cast<uint32_t *>(partials + 8 * (size_t)SC_MAX_BLOCKS);  // zeroed at session creation
     prof_begin(ZG_PROF_SC_SUMS, st);
-    uint64_t *dst = nb == 1 ? sums : partials;  // one block: its pair IS the result
     if (layout == ZG_SC_HIGH_HALF)
-        hipLaunchKernelGGL(sc_sums_kernel<ZG_SC_HIGH_HALF>, dim3(nb), dim3(256), 0, st, t, half, dst, nb == 1 ? flag : nullptr, seq);
+        hipLaunchKernelGGL(sc_sums_kernel<ZG_SC_HIGH_HALF>, dim3(nb), dim3(256), 0, st, t, half, partials, sums, counter, flag, seq, run);
     else
-        hipLaunchKernelGGL(sc_sums_kernel<ZG_SC_LOW_PAIR>, dim3(nb), dim3(256), 0, st, t, half, dst, nb == 1 ? flag : nullptr, seq);
-    if (nb > 1) hipLaunchKernelGGL(sc_finish_kernel, dim3(1), dim3(256), 0, st, partials, nb, sums, flag, seq);
+        hipLaunchKernelGGL(sc_sums_kernel<ZG_SC_LOW_PAIR>, dim3(nb), dim3(256), 0, st, t, half, partials, sums, counter, flag, seq, run);
     prof_end(ZG_PROF_SC_SUMS, st);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
 
 static int launch_fold(int layout, const uint64_t *t, size_t len, const uint64_t r[4], uint64_t *out, uint64_t *partials,
-                       uint64_t *sums, hipStream_t st, uint64_t *flag = nullptr, uint64_t seq = 0) {
+                       uint64_t *sums, hipStream_t st, uint64_t *flag = nullptr, uint64_t seq = 0,
+                       ScRunArg run = ScRunArg{nullptr, 0, 0, 0}) {
     size_t half = len / 2;
     unsigned nb = sc_blocks(half);
     FrArg ra;
     for (int i = 0; i < 4; i++) {
-        ra.l[2 * i] = (uint32_t)r[i];
-        ra.l[2 * i + 1] = (uint32_t)(r[i] >> 32);
+        ra.l[2 * i] = r ? (uint32_t)r[i] : 0;
+        ra.l[2 * i + 1] = r ? (uint32_t)(r[i] >> 32) : 0;
     }
-    uint64_t *dst = nb == 1 ? sums : partials;
+    uint32_t *counter = reinterpret_cast<uint32_t *>(partials + 8 * (size_t)SC_MAX_BLOCKS);
     prof_begin(ZG_PROF_SC_FOLD, st);
     if (layout == ZG_SC_HIGH_HALF)
-        hipLaunchKernelGGL(sc_fold_kernel<ZG_SC_HIGH_HALF>, dim3(nb), dim3(256), 0, st, t, half, ra, out, dst, nb == 1 ? flag : nullptr, seq);
+        hipLaunchKernelGGL(sc_fold_kernel<ZG_SC_HIGH_HALF>, dim3(nb), dim3(256), 0, st, t, half, ra, out, partials, sums, counter, flag, seq, run);
     else
-        hipLaunchKernelGGL(sc_fold_kernel<ZG_SC_LOW_PAIR>, dim3(nb), dim3(256), 0, st, t, half, ra, out, dst, nb == 1 ? flag : nullptr, seq);
-    if (nb > 1) hipLaunchKernelGGL(sc_finish_kernel, dim3(1), dim3(256), 0, st, partials, nb, sums, flag, seq);
+        hipLaunchKernelGGL(sc_fold_kernel<ZG_SC_LOW_PAIR>, dim3(nb), dim3(256), 0, st, t, half, ra, out, partials, sums, counter, flag, seq, run);
     prof_end(ZG_PROF_SC_FOLD, st);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
@@ -256,16 +459,17 @@ static int eq_table_enqueue(const uint64_t *r_host, size_t v, const uint64_t *sc
     }
     int v_lo = v < 8 ? (int)v : 8, v_hi = (int)v - v_lo;
     uint32_t n_hi = 1u << v_hi;
-    Scratch s_r((v + 1) * 32 + 32), s_hi((size_t)n_hi * 32);
+    Scratch s_r((v + 1) * 32 + 32), s_hi((size_t)n_hi * 32 + 256 * 32);
     if (!s_r.p || !s_hi.p) return ZG_ERR_NOMEM;
-    uint64_t *d_r = s_r.as<uint64_t>(), *d_hi = s_hi.as<uint64_t>();
+    uint64_t *d_r = s_r.as<uint64_t>(), *d_hi = s_hi.as<uint64_t>(), *d_lo = d_hi + 4 * (size_t)n_hi;
     if (v) ZG_HIP(hipMemcpyAsync(d_r + 4, r_host, v * 32, hipMemcpyHostToDevice, st));
     if (scale_host) ZG_HIP(hipMemcpyAsync(d_r, scale_host, 32, hipMemcpyHostToDevice, st));
     prof_begin(ZG_PROF_EQ_TABLE, st);
-    hipLaunchKernelGGL(eq_hi_kernel, dim3(div_up(n_hi, 256)), dim3(256), 0, st, d_r + 4, v_hi, scale_host ? d_r : nullptr, d_hi);
-    uint32_t hpb = n_hi / 512 ? n_hi / 512 : 1;  // rows per block: amortises the 8-mul low-table product of each thread
-    hipLaunchKernelGGL(eq_main_kernel, dim3(div_up(n_hi, hpb)), dim3(256), 0, st, d_r + 4 + 4 * (size_t)v_hi, v_lo, d_hi, n_hi, hpb,
-                       d_out);
+    uint32_t nb_hi = div_up(n_hi, 64), nb_lo = div_up(1u << v_lo, 64);
+    hipLaunchKernelGGL(eq_tables_kernel, dim3(nb_hi + nb_lo), dim3(256), 0, st, d_r + 4, v_hi, v_lo, scale_host ? d_r : nullptr, d_hi, nb_hi,
+                       d_lo);
+    uint32_t hpb = n_hi / 1024 ? n_hi / 1024 : 1;  // rows per block: amortises the per-thread prescale, keeps >= 4 blocks per CU
+    hipLaunchKernelGGL(eq_main_kernel, dim3(div_up(n_hi, hpb)), dim3(256), 0, st, d_lo, v_lo, d_hi, n_hi, hpb, d_out);
     prof_end(ZG_PROF_EQ_TABLE, st);
     ZG_HIP(hipGetLastError());
     ZG_HIP(hipStreamSynchronize(st));  // r_host / temporaries are released on return
@@ -327,7 +531,8 @@ static int sc_create(size_t len, int layout, hipStream_t st, zg_sc_s **out) {
     s->st = st;
     hipError_t e = hipMalloc((void **)&s->buf[0], len * 32);
     if (e == hipSuccess) e = hipMalloc((void **)&s->buf[1], (len / 2 ? len / 2 : 1) * 32);
-    if (e == hipSuccess) e = hipMalloc((void **)&s->d_partials, 2048 * 64);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_partials, SC_MISC_BYTES);
+    if (e == hipSuccess) e = hipMemset(s->d_partials, 0, SC_MISC_BYTES);
     if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_pin, 128, hipHostMallocMapped | hipHostMallocCoherent);
     if (e == hipSuccess) s->h_pin[12] = 0;
     if (e != hipSuccess) {
@@ -377,10 +582,11 @@ static int bind_host(int layout, const uint64_t *table, size_t len, const uint64
         return ZG_ERR_INVALID;
     }
     hipStream_t st = lib_stream();
-    Scratch s_t(len * 32), s_o(len / 2 * 32), s_misc(2048 * 64 + 64);
+    Scratch s_t(len * 32), s_o(len / 2 * 32), s_misc(SC_MISC_BYTES);
     if (!s_t.p || !s_o.p || !s_misc.p) return ZG_ERR_NOMEM;
     uint64_t *d_t = s_t.as<uint64_t>(), *d_o = s_o.as<uint64_t>(), *d_misc = s_misc.as<uint64_t>();
-    uint64_t *d_sums = d_misc + 2048 * 8;
+    uint64_t *d_sums = d_misc + SC_SUMS_OFF;
+    ZG_HIP(hipMemsetAsync(d_misc + 8 * (size_t)SC_MAX_BLOCKS, 0, 128, st));
     ZG_HIP(hipMemcpyAsync(d_t, table, len * 32, hipMemcpyHostToDevice, st));
     int rc = launch_fold(layout, d_t, len, r, d_o, d_misc, d_sums, st);
     if (rc == ZG_OK) {
@@ -416,7 +622,7 @@ int zg_fr_dense_evaluate(const uint64_t *evals, size_t num_vars, const uint64_t 
     std::vector<uint64_t> rev(4 * (num_vars ? num_vars : 1));
     for (size_t j = 0; j < num_vars; j++)
         for (int l = 0; l < 4; l++) rev[4 * j + l] = point[4 * (num_vars - 1 - j) + l];
-    Scratch s_ev(n * 32), s_eq(n * 32), s_misc(2048 * 64 + 64);
+    Scratch s_ev(n * 32), s_eq(n * 32), s_misc(SC_MISC_BYTES);
     if (!s_ev.p || !s_eq.p || !s_misc.p) return ZG_ERR_NOMEM;
     uint64_t *d_ev = s_ev.as<uint64_t>(), *d_eq = s_eq.as<uint64_t>(), *d_misc = s_misc.as<uint64_t>();
     ZG_HIP(hipMemcpyAsync(d_ev, evals, n * 32, hipMemcpyHostToDevice, st));
@@ -424,9 +630,9 @@ int zg_fr_dense_evaluate(const uint64_t *evals, size_t num_vars, const uint64_t 
     if (rc == ZG_OK) {
         unsigned nb = sc_blocks(n);
         hipLaunchKernelGGL(fr_dot_kernel, dim3(nb), dim3(256), 0, st, d_ev, d_eq, n, d_misc);
-        hipLaunchKernelGGL(sc_finish_kernel, dim3(1), dim3(256), 0, st, d_misc, nb, d_misc + 2048 * 8, (uint64_t *)nullptr, (uint64_t)0);
+        hipLaunchKernelGGL(sc_finish_kernel, dim3(1), dim3(256), 0, st, d_misc, nb, d_misc + SC_SUMS_OFF, (uint64_t *)nullptr, (uint64_t)0);
         uint64_t h[4];
-        hipError_t e = hipMemcpyAsync(h, d_misc + 2048 * 8, 32, hipMemcpyDeviceToHost, st);
+        hipError_t e = hipMemcpyAsync(h, d_misc + SC_SUMS_OFF, 32, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) {
             set_error(hipGetErrorString(e));
@@ -497,12 +703,13 @@ int zg_hyperkzg_open(zg_bases_t srs, const uint64_t *evals, size_t n_evals, cons
     size_t srs_len = zg_g1_bases_len(srs);
     size_t cap = n_evals ? n_evals : 1;
     std::vector<uint64_t> h_res(9 * num_vars + 4, 0);
-    Scratch s_a(cap * 32), s_b((cap / 2 + 1) * 32), s_q((cap / 2 + 1) * 32), s_res((9 * num_vars + 4) * 8), s_misc(2048 * 64 + 64);
+    Scratch s_a(cap * 32), s_b((cap / 2 + 1) * 32), s_q((cap / 2 + 1) * 32), s_res((9 * num_vars + 4) * 8), s_misc(SC_MISC_BYTES);
     if (!s_a.p || !s_b.p || !s_q.p || !s_res.p || !s_misc.p) return ZG_ERR_NOMEM;
     uint64_t *d_a = s_a.as<uint64_t>(), *d_b = s_b.as<uint64_t>(), *d_q = s_q.as<uint64_t>(), *d_res = s_res.as<uint64_t>(),
              *d_misc = s_misc.as<uint64_t>();
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = hipMemsetAsync(d_res, 0, (9 * num_vars + 4) * 8, st);
+    if (e == hipSuccess) e = hipMemsetAsync(d_misc + 8 * (size_t)SC_MAX_BLOCKS, 0, 128, st);
     if (e == hipSuccess && n_evals) e = hipMemcpyAsync(d_a, evals, n_evals * 32, hipMemcpyHostToDevice, st);
     int rc = ZG_OK;
     size_t len = n_evals;
@@ -519,7 +726,7 @@ int zg_hyperkzg_open(zg_bases_t srs, const uint64_t *evals, size_t n_evals, cons
         size_t nc = half < srs_len ? half : srs_len;  // commit(): n = min(evals.len, srs.len), :246
         rc = zg_msm_g1_dev_async(srs, 0, nc, d_q, st, d_res + 9 * i, reinterpret_cast<uint8_t *>(d_res + 9 * i + 8));
         if (rc != ZG_OK) break;
-        rc = launch_fold(ZG_SC_HIGH_HALF, cur, 2 * half, point + 4 * i, nxt, d_misc, d_misc + 2048 * 8, st);
+        rc = launch_fold(ZG_SC_HIGH_HALF, cur, 2 * half, point + 4 * i, nxt, d_misc, d_misc + SC_SUMS_OFF, st);
         uint64_t *t = cur; cur = nxt; nxt = t;
         len = half;
     }
@@ -541,6 +748,106 @@ int zg_hyperkzg_open(zg_bases_t srs, const uint64_t *evals, size_t n_evals, cons
     }
     for (int j = 0; j < 4; j++) final_eval[j] = len > 0 ? dev_res[9 * num_vars + j] : 0;
     return ZG_OK;
+}
+
+// ---------------------------------------------------------------- runSumcheck, device-resident
+static unsigned env_uint(const char *name, unsigned dflt, unsigned lo, unsigned hi) {
+    const char *e = getenv(name);
+    unsigned v = e && *e ? (unsigned)atoi(e) : dflt;
+    return v < lo ? lo : (v > hi ? hi : v);
+}
+
+static uint32_t ilog2_sz(size_t x) {
+    uint32_t r = 0;
+    while (((size_t)1 << (r + 1)) <= x) r++;
+    return r;
+}
+
+static int run_sumcheck_enqueue(const uint64_t *d_evals, size_t len, hipStream_t st, uint64_t claim[4], uint64_t *rounds,
+                                uint64_t *challenges, uint64_t final_eval[4], uint8_t *result) {
+    if (!d_evals || len == 0 || (len & (len - 1)) || !claim || !final_eval || !result) {
+        set_error("zg_run_sumcheck: len must be a power of two >= 1 and outputs non-null");
+        return ZG_ERR_INVALID;
+    }
+    uint32_t v = ilog2_sz(len);
+    if (v && (!rounds || !challenges)) {
+        set_error("zg_run_sumcheck: rounds / challenges buffers missing");
+        return ZG_ERR_INVALID;
+    }
+    size_t res_words = 17 + 12 * (size_t)v;
+    if (v == 0) {  // no rounds: claim = final_eval = the single evaluation
+        uint64_t h[4];
+        ZG_HIP(hipMemcpyAsync(h, d_evals, 32, hipMemcpyDeviceToHost, st));
+        ZG_HIP(hipStreamSynchronize(st));
+        for (int i = 0; i < 4; i++) claim[i] = final_eval[i] = h[i];
+        *result = 1;
+        return ZG_OK;
+    }
+    Scratch s_a(len / 2 * 32), s_b((len / 4 ? len / 4 : 1) * 32), s_res(res_words * 8), s_misc(SC_MISC_BYTES);
+    if (!s_a.p || !s_b.p || !s_res.p || !s_misc.p) return ZG_ERR_NOMEM;
+    uint64_t *d_res = s_res.as<uint64_t>(), *d_misc = s_misc.as<uint64_t>();
+    uint64_t *buf[2] = {s_a.as<uint64_t>(), s_b.as<uint64_t>()};
+    ZG_HIP(hipMemsetAsync(d_misc + 8 * (size_t)SC_MAX_BLOCKS, 0, 128, st));
+    // round 0's sums: also fixes the claim; every later round's sums come out of the fold that precedes it
+    ZG_TRY(launch_sums(ZG_SC_HIGH_HALF, d_evals, len, d_misc, d_misc + SC_SUMS_OFF, st, nullptr, 0, ScRunArg{d_res, v, 0, 1}));
+    const uint64_t *cur = d_evals;
+    size_t cl = len;
+    const uint32_t tail_max = (uint32_t)env_uint("ZG_SC_TAIL_MAX", SC_TAIL_MAX, 1, SC_TAIL_MAX);  // 1: every round as its own launch
+    uint32_t k = 0;
+    for (; k < v && cl > tail_max; k++) {
+        uint64_t *nxt = buf[k & 1];
+        ZG_TRY(launch_fold(ZG_SC_HIGH_HALF, cur, cl, nullptr, nxt, d_misc, d_misc + SC_SUMS_OFF, st, nullptr, 0,
+                           ScRunArg{d_res, v, k + 1, 0}));
+        cur = nxt;
+        cl /= 2;
+    }
+    if (cl > 1) {  // the remaining rounds in one launch, table in LDS
+        static std::once_flag once;
+        static hipError_t attr_err = hipSuccess;
+        std::call_once(once, [] {
+            attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(sc_tail_run_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(SC_TAIL_MAX * 32 + 18 * 16));
+        });
+        ZG_HIP(attr_err);
+        hipLaunchKernelGGL(sc_tail_run_kernel, dim3(1), dim3(256), cl * 32 + 18 * 16, st, cur, (uint32_t)cl, ScRunArg{d_res, v, k + 1, 0});
+        ZG_HIP(hipGetLastError());
+    }
+    std::vector<uint64_t> h(res_words);
+    ZG_HIP(hipMemcpyAsync(h.data(), d_res, res_words * 8, hipMemcpyDeviceToHost, st));
+    ZG_HIP(hipStreamSynchronize(st));
+    for (int i = 0; i < 4; i++) {
+        claim[i] = h[i];
+        final_eval[i] = h[4 + 12 * (size_t)v + i];
+    }
+    for (size_t i = 0; i < 8 * (size_t)v; i++) rounds[i] = h[4 + i];
+    for (size_t i = 0; i < 4 * (size_t)v; i++) challenges[i] = h[4 + 8 * (size_t)v + i];
+    uint64_t status = h[8 + 12 * (size_t)v];
+    *result = (uint8_t)(status & 1);
+    if (status >> 8) {
+        set_error("zg_run_sumcheck: SumcheckVerificationFailed in round " + std::to_string((status >> 8) - 1));
+        return ZG_ERR_VERIFY;
+    }
+    return ZG_OK;
+}
+
+int zg_run_sumcheck_dev(const uint64_t *d_evals, size_t len, void *stream, uint64_t claim[4], uint64_t *rounds, uint64_t *challenges,
+                        uint64_t final_eval[4], uint8_t *result) {
+    ZG_INIT();
+    return run_sumcheck_enqueue(d_evals, len, pick_stream(stream), claim, rounds, challenges, final_eval, result);
+}
+
+int zg_run_sumcheck(const uint64_t *evals, size_t len, uint64_t claim[4], uint64_t *rounds, uint64_t *challenges, uint64_t final_eval[4],
+                    uint8_t *result) {
+    ZG_INIT();
+    if (!evals || len == 0 || (len & (len - 1))) {
+        set_error("zg_run_sumcheck: len must be a power of two >= 1");
+        return ZG_ERR_INVALID;
+    }
+    hipStream_t st = lib_stream();
+    Scratch s_t(len * 32);
+    if (!s_t.p) return ZG_ERR_NOMEM;
+    ZG_HIP(hipMemcpyAsync(s_t.p, evals, len * 32, hipMemcpyHostToDevice, st));
+    return run_sumcheck_enqueue(s_t.as<uint64_t>(), len, st, claim, rounds, challenges, final_eval, result);
 }
 
 // ---------------------------------------------------------------- sumcheck session

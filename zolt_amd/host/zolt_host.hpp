@@ -408,7 +408,9 @@ struct SumcheckResult {
     bool result;
 };
 
-inline SumcheckResult runSumcheck(const DensePolynomial &polynomial) {  // src/subprotocols/mod.zig:302-354
+// runSumcheck with the verifier on the host, one device round trip per round: the shape every prover with a real
+// (Keccak/Blake2b) transcript has. Same outputs as runSumcheck below.
+inline SumcheckResult runSumcheckInteractive(const DensePolynomial &polynomial) {  // src/subprotocols/mod.zig:302-354
     SumcheckResult out;
     Fr claim = Fr::zero();
     if (polynomial.num_vars == 0) {
@@ -435,6 +437,31 @@ inline SumcheckResult runSumcheck(const DensePolynomial &polynomial) {  // src/s
     out.proof.final_point = verifier.challenges;
     out.proof.final_eval = prover.getFinalEval();
     out.result = verifier.claim.eql(out.proof.final_eval);
+    return out;
+}
+
+// runSumcheck (src/subprotocols/mod.zig:302-354): prover AND toy verifier on the device (zg_run_sumcheck), no PCIe
+// crossing between rounds.
+inline SumcheckResult runSumcheck(const DensePolynomial &polynomial) {
+    SumcheckResult out;
+    size_t v = polynomial.num_vars;
+    std::vector<uint64_t> rounds(8 * v + 1), chal(4 * v + 1);
+    uint8_t result = 0;
+    int rc = zg_run_sumcheck(reinterpret_cast<const uint64_t *>(polynomial.evaluations.data()), polynomial.evaluations.size(),
+                             out.proof.claim.limbs, rounds.data(), chal.data(), out.proof.final_eval.limbs, &result);
+    if (rc == ZG_ERR_VERIFY) throw SumcheckVerificationFailed();
+    check(rc, "zg_run_sumcheck");
+    for (size_t i = 0; i < v; i++) {
+        Sumcheck::Round rd;
+        Fr c0, c1, ch;
+        std::memcpy(c0.limbs, &rounds[8 * i], 32);
+        std::memcpy(c1.limbs, &rounds[8 * i + 4], 32);
+        std::memcpy(ch.limbs, &chal[4 * i], 32);
+        rd.poly.coeffs = {c0, c1};
+        out.proof.rounds.push_back(rd);
+        out.proof.final_point.push_back(ch);
+    }
+    out.result = result != 0;
     return out;
 }
 

@@ -6,7 +6,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzolt_gpu.so")
+# ZOLT_GPU_LIB: load another build of the same library (A/B experiments on kernel variants); never a fallback
+LIB_PATH = os.environ.get("ZOLT_GPU_LIB") or os.path.join(_HERE, "libzolt_gpu.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -15,7 +16,7 @@ if not os.path.exists(LIB_PATH):
     )
 _lib = C.CDLL(LIB_PATH)
 
-OK, ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_NO_DEVICE = 0, 1, 2, 3, 4
+OK, ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_NO_DEVICE, ERR_VERIFY = 0, 1, 2, 3, 4, 5
 FR, FP = 0, 1
 OP_MUL, OP_ADD, OP_SUB, OP_NEG, OP_SQR, OP_INV, OP_FROM_MONT, OP_TO_MONT, OP_INV_FAST, OP_MUL29, OP_SQR29, OP_X3_29, OP_INV_XGCD = range(13)
 SC_HIGH_HALF, SC_LOW_PAIR = 0, 1
@@ -35,6 +36,7 @@ SYMBOLS = [
     "zg_sumcheck_open", "zg_sumcheck_open_dev", "zg_sumcheck_round_sums", "zg_sumcheck_bind",
     "zg_sumcheck_len", "zg_sumcheck_final", "zg_sumcheck_read", "zg_sumcheck_close",
     "zg_sumcheck_round_sums_dev", "zg_sumcheck_read_dev",
+    "zg_run_sumcheck", "zg_run_sumcheck_dev",
 ]
 
 
@@ -293,6 +295,34 @@ def fr_spartan_combine(eq, az, bz, cz):
 def fr_spartan_combine_dev(d_eq, d_az, d_bz, d_cz, n, d_out, stream=0):
     _chk(_lib.zg_fr_spartan_combine_dev(_d(d_eq), _d(d_az), _d(d_bz), _d(d_cz), C.c_size_t(n), _d(d_out), _d(stream)),
          "zg_fr_spartan_combine_dev")
+
+
+class SumcheckVerificationFailed(RuntimeError):
+    """error.SumcheckVerificationFailed (src/subprotocols/mod.zig:175-178)."""
+
+
+def _run_sumcheck_call(fn, ptr, n, extra, where):
+    v = max(n.bit_length() - 1, 0)
+    claim = np.empty(4, dtype=np.uint64)
+    rounds = np.empty((v, 2, 4), dtype=np.uint64)
+    chal = np.empty((v, 4), dtype=np.uint64)
+    fin = np.empty(4, dtype=np.uint64)
+    res = C.c_uint8(0)
+    rc = fn(ptr, C.c_size_t(n), *extra, _h(claim), _h(rounds) if v else None, _h(chal) if v else None, _h(fin), C.byref(res))
+    if rc == ERR_VERIFY:
+        raise SumcheckVerificationFailed(last_error())
+    _chk(rc, where)
+    return {"claim": claim, "rounds": rounds, "final_point": chal, "final_eval": fin, "result": bool(res.value)}
+
+
+def run_sumcheck(evals):
+    """runSumcheck (src/subprotocols/mod.zig:302-354), prover and toy verifier both on the device."""
+    e = _c(evals)
+    return _run_sumcheck_call(_lib.zg_run_sumcheck, _h(e), e.size // 4, (), "zg_run_sumcheck")
+
+
+def run_sumcheck_dev(d_evals, n, stream=0):
+    return _run_sumcheck_call(_lib.zg_run_sumcheck_dev, _d(d_evals), n, (_d(stream),), "zg_run_sumcheck_dev")
 
 
 class SumcheckSession:
