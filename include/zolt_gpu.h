@@ -143,6 +143,12 @@ ZG_API int zg_msm_g1_dev_async(zg_bases_t b, size_t off, size_t n, const uint64_
  * (src/poly/commitment/mod.zig:558-570): k scalar vectors of length n over bases[0..n]. */
 ZG_API int zg_msm_g1_batch(zg_bases_t b, size_t n, const uint64_t *const *scalar_batches, size_t k, uint64_t *out_xy /* k*8 */,
                     uint8_t *out_inf /* k */);
+/* same with the k vectors resident in HBM back to back (k*n*4 limbs); asynchronous: record i = d_out9[9*i .. 9*i+9) =
+ * affine xy[8] followed by a flag word (low byte 1 = identity). Short vectors (Dory row commitments,
+ * src/poly/commitment/dory.zig:646-670; commitments of <= 2^14-entry polynomials) are FUSED: the k MSMs run as one
+ * sort / accumulate / reduce pass with k times the bucket groups, instead of k latency-bound launch sets; long vectors
+ * rotate over three streams so their tails overlap. Results are identical to k separate zg_msm_g1 calls. */
+ZG_API int zg_msm_g1_batch_dev(zg_bases_t b, size_t n, const uint64_t *d_scalars_mont, size_t k, void *stream, uint64_t *d_out9);
 /* ParallelMSM's per-chunk result (src/msm/mod.zig:656-665): this GPU's partial sum as the
  * reference's Jacobian record fromAffine(SingleMSM.compute(chunk)) = (x,y,1) or (1,1,0),
  * written to DEVICE memory so it can be all-gathered over RCCL without a host round trip. */

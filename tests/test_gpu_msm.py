@@ -145,6 +145,60 @@ def test_subrange_batch_and_partials(zl, ob, gm):
     b.free()
 
 
+@pytest.mark.parametrize("n,k,cfg", [(8, 5, {}), (200, 7, {}), (1024, 33, {}), (3000, 12, {}), (4096, 9, {"window_bits": 6}),
+                                      (700, 4, {"window_bits": 8, "precompute_levels": 5}), (64, 300, {}),
+                                      (5000, 3, {"window_bits": 16})])
+def test_fused_batch_equals_separate_msms(zl, ob, gm, n, k, cfg):
+    """zg_msm_g1_batch with short vectors runs ONE launch set with k times the bucket groups (BatchMSM.compute,
+    src/msm/mod.zig:545-565; Dory rows, src/poly/commitment/dory.zig:646-670): every result must be the oracle's MSM
+    of that vector — including all-zero vectors, vectors of ones, repeated vectors, infinity bases, a batch larger than
+    one launch set takes (split), and the unfused rotation used for wide windows."""
+    inf = np.zeros(n, dtype=np.uint8)
+    inf[::7] = 1
+    b = zl.Bases.upload(gm[:n], inf, **cfg)
+    batches = [_scalars(ob, 7000 + 31 * n + j, n) for j in range(k)]
+    batches[0] = np.zeros((n, 4), dtype=np.uint64)                       # identity result
+    if k > 2:
+        batches[2] = ob.f_from_u64(ob.FR, np.ones(n, dtype=np.uint64))   # one bucket per window takes every point
+    if k > 3:
+        batches[3] = batches[1].copy()                                  # equal vectors give equal commitments
+    outs, infs = b.msm_batch(batches)
+    for j in range(k):
+        want, winf = ob.msm_g1(gm[:n], inf, batches[j])
+        assert infs[j] == winf and np.array_equal(outs[j], want), (n, k, j)
+    assert infs[0] == 1
+    # a second call reuses the cached fused workspace; a call with fewer vectors fits the same workspace
+    outs2, infs2 = b.msm_batch(batches[:max(2, k // 2)])
+    assert np.array_equal(outs2, outs[:max(2, k // 2)]) and np.array_equal(infs2, infs[:max(2, k // 2)])
+    # a plain MSM on the same handle afterwards is unaffected
+    got, ginf = b.msm(batches[1])
+    assert ginf == infs[1] and np.array_equal(got, outs[1])
+    b.free()
+
+
+def test_fused_batch_dev_and_prefix(zl, ob, gm):
+    """Device-resident form: vectors back to back in HBM, records (xy[8], flag word) written to HBM; vectors shorter than
+    the handle commit to the prefix bases[0..n) (HyperKZG.commit: n = min(evals.len, srs.len), commitment/mod.zig:246)."""
+    import ctypes as C
+    N, n, k = 2048, 500, 6
+    b = zl.Bases.upload(gm[:N])
+    sc = np.concatenate([_scalars(ob, 7700 + j, n) for j in range(k)])
+    d_sc, d_out = C.c_void_p(), C.c_void_p()
+    assert zl._lib.zg_dev_alloc(C.c_size_t(sc.size * 8), C.byref(d_sc)) == 0
+    assert zl._lib.zg_dev_alloc(C.c_size_t(k * 72), C.byref(d_out)) == 0
+    assert zl._lib.zg_memcpy_h2d(d_sc, sc.ctypes.data_as(C.c_void_p), C.c_size_t(sc.size * 8)) == 0
+    b.msm_batch_dev(d_sc.value, n, k, d_out.value)
+    zl.sync()
+    rec = np.empty((k, 9), dtype=np.uint64)
+    assert zl._lib.zg_memcpy_d2h(rec.ctypes.data_as(C.c_void_p), d_out, C.c_size_t(k * 72)) == 0
+    for j in range(k):
+        want, winf = ob.msm_g1(gm[:n], None, sc[j * n:(j + 1) * n])
+        assert int(rec[j, 8]) & 0xFF == winf and np.array_equal(rec[j, :8], want)
+    zl._lib.zg_dev_free(d_sc)
+    zl._lib.zg_dev_free(d_out)
+    b.free()
+
+
 def test_parallel_msm_partials_combine(zl, ob, gm):
     """ParallelMSM (src/msm/mod.zig:572-680): contiguous chunks -> Jacobian partials -> serial combine.
     Partials must equal fromAffine(SingleMSM.compute(chunk)) exactly, the combined point the full MSM."""

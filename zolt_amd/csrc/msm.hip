@@ -44,7 +44,8 @@ struct MsmPlan {
     int G;         // bucket groups = ceil(W / L); window w -> group w % G, level w / G
     int S;         // accumulate threads (slices) per bucket
     uint32_t NB;   // buckets per group = 2^(c-1)
-    uint32_t NK;   // total buckets = G * NB
+    uint32_t NK;   // total buckets = K * G * NB
+    int K;         // MSMs sharing one launch set (scalar vectors over the same bases); bucket group = batch * G + w % G
     int PB;        // bit-sum partial blocks per (group, bit)
     uint32_t NT;   // chunk-scheduled accumulate: threads (0 = per-bucket scheduling)
     int GS;        // lanes per bucket in the combine pass
@@ -79,6 +80,15 @@ struct zg_bases_s {
     std::vector<Lane> lanes;
     size_t next_lane = 0;
     uint32_t nblk = 0;
+    // zg_msm_g1_batch: k short scalar vectors over the same bases run as ONE launch set (k times the bucket groups);
+    // its workspace is built on first use and kept while (k, n) fit
+    Lane batch_lane;
+    zg::MsmPlan batch_plan;
+    size_t batch_n = 0;
+    uint32_t batch_nblk = 0;
+    // long vectors are not fused: they rotate over the caller's stream and two forked helper streams instead
+    hipStream_t aux[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     uint64_t *d_out = nullptr;  // 16 x u64: result record + flag
     uint64_t *h_out = nullptr;  // pinned mirror
     std::mutex mu;
@@ -121,14 +131,15 @@ __global__ void __launch_bounds__(256) msm_precompute_kernel(const uint64_t *xy,
 // integer (getWindow, msm/mod.zig:441-471) and converts from Montgomery inside every call;
 // here: one conversion, digits in [-2^(c-1), 2^(c-1)], so a group needs 2^(c-1) buckets.
 template <int C>
-__global__ void __launch_bounds__(256) msm_digits_kernel(const uint64_t *scalars, const uint8_t *inf, uint32_t n, int G,
+__global__ void __launch_bounds__(256) msm_digits_kernel(const uint64_t *scalars, const uint8_t *inf, uint32_t n, uint32_t n_pts, int G,
                                                          uint32_t *dig, uint32_t *hist) {
     constexpr int W = (255 + C - 1) / C;
     constexpr uint32_t NB = 1u << (C - 1);
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     Fr s = fe_from_mont(fe_load<FrParams>(scalars + 4 * (size_t)i));
-    bool skip = inf && inf[i];  // msm/mod.zig:407: infinity bases contribute nothing
+    uint32_t batch = i / n_pts, pt = i - batch * n_pts;  // scalar vector `batch`, base `pt` (n == n_pts: one MSM)
+    bool skip = inf && inf[pt];  // msm/mod.zig:407: infinity bases contribute nothing
     uint32_t carry = 0;
 #pragma unroll
     for (int w = 0; w < W; w++) {
@@ -141,7 +152,7 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint64_t *scalars
         carry = neg;
         uint32_t e = 0xFFFFFFFFu;
         if (d != 0 && !skip) {
-            uint32_t key = (uint32_t)(w % G) * NB + (d - 1);
+            uint32_t key = (batch * (uint32_t)G + (uint32_t)(w % G)) * NB + (d - 1);
             e = key | (neg << 31);
             atomicAdd(&hist[key], 1u);
         }
@@ -216,8 +227,8 @@ __global__ void __launch_bounds__(1024) msm_scan_b_kernel(const uint32_t *__rest
 
 // counting-sort scatter; order inside a bucket is irrelevant (group sums commute).
 // fill[] is the histogram array re-zeroed by the caller.
-__global__ void __launch_bounds__(256) msm_scatter_kernel(const uint32_t *dig, uint32_t n, int G, size_t table_n, uint32_t off,
-                                                          const uint32_t *starts, uint32_t *fill, uint32_t *sorted) {
+__global__ void __launch_bounds__(256) msm_scatter_kernel(const uint32_t *dig, uint32_t n, uint32_t n_pts, int G, size_t table_n,
+                                                          uint32_t off, const uint32_t *starts, uint32_t *fill, uint32_t *sorted) {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     uint32_t w = blockIdx.y;
     if (i >= n) return;
@@ -225,7 +236,7 @@ __global__ void __launch_bounds__(256) msm_scatter_kernel(const uint32_t *dig, u
     if (e == 0xFFFFFFFFu) return;
     uint32_t key = e & 0x7FFFFFFFu;
     uint32_t pos = starts[key] + atomicAdd(&fill[key], 1u);
-    uint32_t ref = (uint32_t)((size_t)(w / G) * table_n + off + i);
+    uint32_t ref = (uint32_t)((size_t)(w / G) * table_n + off + i % n_pts);
     sorted[pos] = (e & 0x80000000u) | ref;
 }
 
@@ -234,8 +245,9 @@ __global__ void __launch_bounds__(256) msm_scatter_kernel(const uint32_t *dig, u
 // scatter cursors live in LDS (ds_add_rtn_u32), so the sort issues no global atomics at all. The global
 // path above costs one device-scope atomic per digit, twice (histogram + scatter).
 template <int C>
-__global__ void __launch_bounds__(1024) msm_digits_lds_kernel(const uint64_t *scalars, const uint8_t *inf, uint32_t n, int G,
-                                                              uint32_t per_block, uint32_t NK, uint32_t *dig, uint32_t *blockhist) {
+__global__ void __launch_bounds__(1024) msm_digits_lds_kernel(const uint64_t *scalars, const uint8_t *inf, uint32_t n, uint32_t n_pts,
+                                                              int G, uint32_t per_block, uint32_t NK, uint32_t *dig,
+                                                              uint32_t *blockhist) {
     extern __shared__ uint32_t lds_hist[];
     constexpr int W = (255 + C - 1) / C;
     constexpr uint32_t NB = 1u << (C - 1);
@@ -244,7 +256,8 @@ __global__ void __launch_bounds__(1024) msm_digits_lds_kernel(const uint64_t *sc
     uint32_t i0 = blockIdx.x * per_block, i1 = i0 + per_block < n ? i0 + per_block : n;
     for (uint32_t i = i0 + threadIdx.x; i < i1; i += 1024) {
         Fr s = fe_from_mont(fe_load<FrParams>(scalars + 4 * (size_t)i));
-        bool skip = inf && inf[i];
+        uint32_t batch = i / n_pts, pt = i - batch * n_pts;
+        bool skip = inf && inf[pt];
         uint32_t carry = 0;
 #pragma unroll
         for (int w = 0; w < W; w++) {
@@ -257,7 +270,7 @@ __global__ void __launch_bounds__(1024) msm_digits_lds_kernel(const uint64_t *sc
             carry = neg;
             uint32_t e = 0xFFFFFFFFu;
             if (d != 0 && !skip) {
-                uint32_t key = (uint32_t)(w % G) * NB + (d - 1);
+                uint32_t key = (batch * (uint32_t)G + (uint32_t)(w % G)) * NB + (d - 1);
                 e = key | (neg << 31);
                 atomicAdd(&lds_hist[key], 1u);
             }
@@ -287,9 +300,9 @@ __global__ void __launch_bounds__(256) msm_colscan_kernel(uint32_t *blockhist, u
     total[key] = run;
 }
 
-__global__ void __launch_bounds__(1024) msm_scatter_lds_kernel(const uint32_t *dig, uint32_t n, int W, int G, size_t table_n, uint32_t off,
-                                                               uint32_t per_block, uint32_t NK, const uint32_t *starts,
-                                                               const uint32_t *blockhist, uint32_t *sorted) {
+__global__ void __launch_bounds__(1024) msm_scatter_lds_kernel(const uint32_t *dig, uint32_t n, uint32_t n_pts, int W, int G,
+                                                               size_t table_n, uint32_t off, uint32_t per_block, uint32_t NK,
+                                                               const uint32_t *starts, const uint32_t *blockhist, uint32_t *sorted) {
     extern __shared__ uint32_t lds_cur[];
     const uint32_t *row = blockhist + (size_t)blockIdx.x * NK;
     for (uint32_t k = threadIdx.x; k < NK; k += 1024) lds_cur[k] = starts[k] + row[k];
@@ -301,7 +314,7 @@ __global__ void __launch_bounds__(1024) msm_scatter_lds_kernel(const uint32_t *d
             uint32_t e = dig[(size_t)w * n + i];
             if (e == 0xFFFFFFFFu) continue;
             uint32_t pos = atomicAdd(&lds_cur[e & 0x7FFFFFFFu], 1u);
-            sorted[pos] = (e & 0x80000000u) | (uint32_t)((size_t)lvl * table_n + off + i);
+            sorted[pos] = (e & 0x80000000u) | (uint32_t)((size_t)lvl * table_n + off + i % n_pts);
         }
     }
 }
@@ -592,7 +605,7 @@ ZG_DEV void write_partial_unnormalised(const XYZZ &acc, uint64_t *out_rec) {
 // lane (b, 0) doubles b times; LDS tree over b  ->  R_g = sum_k k*B_k of group g.
 // With a single group (full precompute) thread 0 goes straight on to toAffine (msm/mod.zig:178-189).
 __global__ void __launch_bounds__(256) msm_final_kernel(const char *bits, int c, int PB, int G, char *rg, int mode, uint64_t *out_rec,
-                                                       uint8_t *out_inf) {
+                                                       uint8_t *out_inf, uint32_t rec_stride, uint32_t inf_stride) {
     __shared__ uint4 sh[16 * 9];
     uint32_t tid = threadIdx.x, g = blockIdx.x;
     uint32_t b = tid / 16, j = tid % 16;
@@ -616,7 +629,9 @@ __global__ void __launch_bounds__(256) msm_final_kernel(const char *bits, int c,
     }
     if (tid != 0) return;
     XYZZ r = xyzz29_to_std_val(xyzz29_load(&sh[0]));  // canonical Montgomery-2^256 from here on
-    if (G == 1) {
+    if (G == 1) {  // block g is scalar vector g of a batched launch (g == 0 for a single MSM)
+        out_rec += (size_t)rec_stride * g;
+        out_inf += (size_t)inf_stride * g;
         if (mode == 2) write_partial_unnormalised(r, out_rec);
         else write_result(r, mode, out_rec, out_inf);
     } else {
@@ -625,7 +640,11 @@ __global__ void __launch_bounds__(256) msm_final_kernel(const char *bits, int c,
 }
 
 // window combine for G > 1 (msm/mod.zig:393-398,434): Horner from the top group with c doublings per step
-__global__ void msm_groups_kernel(const char *rg, int G, int c, int mode, uint64_t *out_rec, uint8_t *out_inf) {
+__global__ void msm_groups_kernel(const char *rg, int G, int c, int mode, uint64_t *out_rec, uint8_t *out_inf, uint32_t rec_stride,
+                                  uint32_t inf_stride) {
+    rg += 128 * (size_t)G * blockIdx.x;  // one single-thread block per scalar vector
+    out_rec += (size_t)rec_stride * blockIdx.x;
+    out_inf += (size_t)inf_stride * blockIdx.x;
     XYZZ acc = xyzz_load(rg + 128 * (size_t)(G - 1));
     for (int g = G - 2; g >= 0; g--) {
         for (int k = 0; k < c; k++) acc = xyzz_dbl(acc);
@@ -726,7 +745,7 @@ static int env_int(const char *name, int dflt) {
     return v && *v ? atoi(v) : dflt;
 }
 
-static int make_plan(size_t n, const zg_msm_config *cfg, MsmPlan &p) {
+static int make_plan(size_t n, const zg_msm_config *cfg, MsmPlan &p, size_t batch = 1) {
     int c = cfg ? cfg->window_bits : 0;
     if (c == 0) c = env_int("ZG_MSM_WINDOW_BITS", 0);
     if (c == 0) {
@@ -753,7 +772,12 @@ static int make_plan(size_t n, const zg_msm_config *cfg, MsmPlan &p) {
         return ZG_ERR_INVALID;
     }
     p.NB = 1u << (c - 1);
-    p.NK = p.NB * (uint32_t)p.G;
+    p.K = (int)batch;
+    if ((uint64_t)p.NB * p.G * batch > (1u << 21)) {
+        set_error("msm: too many buckets");
+        return ZG_ERR_INVALID;
+    }
+    p.NK = p.NB * (uint32_t)p.G * (uint32_t)batch;
     // slices per bucket: aim for ~2^18-2^19 accumulate threads
     int S = 1;
     while ((uint64_t)p.NK * S * 2 <= (1u << 18) && S < 64) S *= 2;
@@ -765,7 +789,7 @@ static int make_plan(size_t n, const zg_msm_config *cfg, MsmPlan &p) {
     // chunk-scheduled accumulate: enough threads to fill 2 waves per SIMD on 256 CUs, fewer for small inputs
     p.NT = 0;
     if (env_int("ZG_MSM_CHUNK_SCHED", 1)) {
-        uint64_t want = ((uint64_t)n * p.W) / 16;
+        uint64_t want = ((uint64_t)n * batch * p.W) / 16;
         uint32_t nt = 1024;
         while (nt < want && nt < 131072u) nt <<= 1;
         // full size = 2 waves per SIMD on 256 CUs; 15/16 of it leaves a few CUs with spare registers so that
@@ -782,18 +806,55 @@ static int make_plan(size_t n, const zg_msm_config *cfg, MsmPlan &p) {
     return ZG_OK;
 }
 
+static void lane_free(zg_bases_s::Lane &ln) {
+    void *lp[] = {ln.d_dig, ln.d_sorted, ln.d_hist, ln.d_starts, ln.d_blockhist, ln.d_partial, ln.d_bits, ln.d_rg,
+                  ln.d_nzrank, ln.d_nzlist, ln.d_scan_tmp, ln.d_part, ln.d_part2, ln.d_heavy, ln.d_state};
+    for (void *p : lp)
+        if (p) (void)hipFree(p);
+    if (ln.done) (void)hipEventDestroy(ln.done);
+    ln = zg_bases_s::Lane();
+}
+
+// workspace of one MSM launch set: n_total scalars (all scalar vectors of a batched launch together) under plan p
+static hipError_t lane_alloc(zg_bases_s::Lane &ln, const MsmPlan &p, size_t n_total, uint32_t nblk_lds) {
+    hipError_t e = hipSuccess;
+    auto A = [&](auto &ptr, size_t bytes) {
+        if (e == hipSuccess) e = hipMalloc((void **)&ptr, bytes ? bytes : 16);
+    };
+    A(ln.d_dig, (size_t)p.W * n_total * 4);
+    A(ln.d_sorted, (size_t)p.W * n_total * 4);
+    A(ln.d_hist, (size_t)p.NK * 4);
+    A(ln.d_starts, ((size_t)p.NK + 1) * 4);
+    if (nblk_lds) A(ln.d_blockhist, (size_t)nblk_lds * p.NK * 4);
+    A(ln.d_partial, (size_t)p.NK * 144);
+    A(ln.d_bits, (size_t)p.G * p.K * p.c * p.PB * 144);
+    A(ln.d_rg, (size_t)p.G * p.K * 128);
+    A(ln.d_nzrank, ((size_t)p.NK + 1) * 4);
+    A(ln.d_nzlist, (size_t)p.NK * 4);
+    A(ln.d_scan_tmp, (2 * (size_t)p.NK + 2 * (p.NK / 1024 + 1)) * 4);
+    if (p.NT) {
+        size_t slots = (size_t)p.NT + p.NK;
+        A(ln.d_part, slots * 144);
+        A(ln.d_part2, (slots / HEAVY_BLOCK_ITEMS + 1 + p.NK) * 144);
+        A(ln.d_heavy, (size_t)p.NK * 8);
+        A(ln.d_state, sizeof(MsmState));
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ln.done, hipEventDisableTiming);
+    return e;
+}
+
 static void free_bases(zg_bases_s *b) {
     if (!b) return;
     void *ptrs[] = {b->d_table, b->d_inf, b->d_scal, b->d_out};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
-    for (auto &ln : b->lanes) {
-        void *lp[] = {ln.d_dig, ln.d_sorted, ln.d_hist, ln.d_starts, ln.d_blockhist, ln.d_partial, ln.d_bits, ln.d_rg,
-                      ln.d_nzrank, ln.d_nzlist, ln.d_scan_tmp, ln.d_part, ln.d_part2, ln.d_heavy, ln.d_state};
-        for (void *p : lp)
-            if (p) (void)hipFree(p);
-        if (ln.done) (void)hipEventDestroy(ln.done);
+    for (auto &ln : b->lanes) lane_free(ln);
+    lane_free(b->batch_lane);
+    for (int i = 0; i < 2; i++) {
+        if (b->aux[i]) (void)hipStreamDestroy(b->aux[i]);
+        if (b->ev_join[i]) (void)hipEventDestroy(b->ev_join[i]);
     }
+    if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
     if (b->h_out) (void)hipHostFree(b->h_out);
     delete b;
 }
@@ -834,33 +895,16 @@ static int bases_create(const uint64_t *d_xy, const uint8_t *d_inf_in, size_t n,
     if (nlanes > 8) nlanes = 8;
     bool lds_sort = (size_t)p.NK * 4 <= 128 * 1024 && env_int("ZG_MSM_LDS_SORT", 1);
     if (lds_sort) {
-        uint32_t nblk = (uint32_t)(n / 2048);
+        uint32_t nblk = (uint32_t)(n / (size_t)env_int("ZG_MSM_SORT_SPAN", 2048));
         b->nblk = nblk < 1 ? 1 : (nblk > 256 ? 256 : nblk);
     }
     b->lanes.resize(nlanes);
     for (auto &ln : b->lanes) {
-        ZG_ALLOC(ln.d_dig, (size_t)p.W * n * 4);
-        ZG_ALLOC(ln.d_sorted, (size_t)p.W * n * 4);
-        ZG_ALLOC(ln.d_hist, (size_t)p.NK * 4);
-        ZG_ALLOC(ln.d_starts, ((size_t)p.NK + 1) * 4);
-        if (lds_sort) ZG_ALLOC(ln.d_blockhist, (size_t)b->nblk * p.NK * 4);
-        ZG_ALLOC(ln.d_partial, (size_t)p.NK * 144);
-        ZG_ALLOC(ln.d_bits, (size_t)p.G * p.c * p.PB * 144);
-        ZG_ALLOC(ln.d_rg, (size_t)p.G * 128);
-        ZG_ALLOC(ln.d_nzrank, ((size_t)p.NK + 1) * 4);
-        ZG_ALLOC(ln.d_nzlist, (size_t)p.NK * 4);
-        ZG_ALLOC(ln.d_scan_tmp, (2 * (size_t)p.NK + 2 * (p.NK / 1024 + 1)) * 4);
-        if (p.NT) {
-            size_t slots = (size_t)p.NT + p.NK;
-            ZG_ALLOC(ln.d_part, slots * 144);
-            ZG_ALLOC(ln.d_part2, (slots / HEAVY_BLOCK_ITEMS + 1 + p.NK) * 144);
-            ZG_ALLOC(ln.d_heavy, (size_t)p.NK * 8);
-            ZG_ALLOC(ln.d_state, sizeof(MsmState));
-        }
-        if (hipEventCreateWithFlags(&ln.done, hipEventDisableTiming) != hipSuccess) {
-            set_error("hipEventCreate failed");
+        hipError_t le = lane_alloc(ln, p, n, lds_sort ? b->nblk : 0);
+        if (le != hipSuccess) {
+            set_error(std::string("msm workspace: ") + hipGetErrorString(le));
             free_bases(b);
-            return ZG_ERR_HIP;
+            return le == hipErrorOutOfMemory ? ZG_ERR_NOMEM : ZG_ERR_HIP;
         }
     }
     ZG_ALLOC(b->d_out, 16 * 8);
@@ -881,12 +925,13 @@ static int bases_create(const uint64_t *d_xy, const uint8_t *d_inf_in, size_t n,
 }
 
 template <int C>
-static void launch_digits(hipStream_t st, const uint64_t *sc, const uint8_t *inf, uint32_t n, int G, uint32_t *dig, uint32_t *hist) {
-    hipLaunchKernelGGL(msm_digits_kernel<C>, dim3(div_up(n, 256)), dim3(256), 0, st, sc, inf, n, G, dig, hist);
+static void launch_digits(hipStream_t st, const uint64_t *sc, const uint8_t *inf, uint32_t n, uint32_t n_pts, int G, uint32_t *dig,
+                          uint32_t *hist) {
+    hipLaunchKernelGGL(msm_digits_kernel<C>, dim3(div_up(n, 256)), dim3(256), 0, st, sc, inf, n, n_pts, G, dig, hist);
 }
 
 template <int C>
-static int launch_digits_lds(hipStream_t st, const uint64_t *sc, const uint8_t *inf, uint32_t n, int G, uint32_t per_block,
+static int launch_digits_lds(hipStream_t st, const uint64_t *sc, const uint8_t *inf, uint32_t n, uint32_t n_pts, int G, uint32_t per_block,
                              uint32_t NK, uint32_t nblk, uint32_t *dig, uint32_t *blockhist) {
     static uint32_t attr_set = 0;  // per instantiation: largest dynamic-LDS size configured so far
     if (attr_set < NK * 4) {
@@ -894,14 +939,14 @@ static int launch_digits_lds(hipStream_t st, const uint64_t *sc, const uint8_t *
                                    128 * 1024));
         attr_set = 128 * 1024;
     }
-    hipLaunchKernelGGL(msm_digits_lds_kernel<C>, dim3(nblk), dim3(1024), NK * 4, st, sc, inf, n, G, per_block, NK, dig, blockhist);
+    hipLaunchKernelGGL(msm_digits_lds_kernel<C>, dim3(nblk), dim3(1024), NK * 4, st, sc, inf, n, n_pts, G, per_block, NK, dig, blockhist);
     return ZG_OK;
 }
 
-static int launch_digits_lds_c(int c, hipStream_t st, const uint64_t *sc, const uint8_t *inf, uint32_t n, int G, uint32_t per_block,
-                               uint32_t NK, uint32_t nblk, uint32_t *dig, uint32_t *blockhist) {
+static int launch_digits_lds_c(int c, hipStream_t st, const uint64_t *sc, const uint8_t *inf, uint32_t n, uint32_t n_pts, int G,
+                               uint32_t per_block, uint32_t NK, uint32_t nblk, uint32_t *dig, uint32_t *blockhist) {
     switch (c) {
-#define ZG_CASE(C) case C: return launch_digits_lds<C>(st, sc, inf, n, G, per_block, NK, nblk, dig, blockhist);
+#define ZG_CASE(C) case C: return launch_digits_lds<C>(st, sc, inf, n, n_pts, G, per_block, NK, nblk, dig, blockhist);
         ZG_CASE(2) ZG_CASE(3) ZG_CASE(4) ZG_CASE(5) ZG_CASE(6) ZG_CASE(7) ZG_CASE(8) ZG_CASE(9) ZG_CASE(10)
         ZG_CASE(11) ZG_CASE(12) ZG_CASE(13) ZG_CASE(14) ZG_CASE(15) ZG_CASE(16)
 #undef ZG_CASE
@@ -909,10 +954,10 @@ static int launch_digits_lds_c(int c, hipStream_t st, const uint64_t *sc, const 
     }
 }
 
-static int launch_digits_c(int c, hipStream_t st, const uint64_t *sc, const uint8_t *inf, uint32_t n, int G, uint32_t *dig,
+static int launch_digits_c(int c, hipStream_t st, const uint64_t *sc, const uint8_t *inf, uint32_t n, uint32_t n_pts, int G, uint32_t *dig,
                            uint32_t *hist) {
     switch (c) {
-#define ZG_CASE(C) case C: launch_digits<C>(st, sc, inf, n, G, dig, hist); break;
+#define ZG_CASE(C) case C: launch_digits<C>(st, sc, inf, n, n_pts, G, dig, hist); break;
         ZG_CASE(2) ZG_CASE(3) ZG_CASE(4) ZG_CASE(5) ZG_CASE(6) ZG_CASE(7) ZG_CASE(8) ZG_CASE(9) ZG_CASE(10)
         ZG_CASE(11) ZG_CASE(12) ZG_CASE(13) ZG_CASE(14) ZG_CASE(15) ZG_CASE(16)
 #undef ZG_CASE
@@ -920,11 +965,14 @@ static int launch_digits_c(int c, hipStream_t st, const uint64_t *sc, const uint
     }
     return ZG_OK;
 }
+
+static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &ln, uint32_t nblk_cap, size_t off, size_t n_pts,
+                            const uint64_t *d_scalars, hipStream_t st, int mode, uint64_t *d_rec, uint8_t *d_inf_out,
+                            uint32_t rec_stride, uint32_t inf_stride);
 
 // Enqueue one MSM over bases[off, off+n) on `st`; result record lands in d_rec / d_inf_out.
 static int msm_enqueue(zg_bases_s *b, size_t off, size_t n, const uint64_t *d_scalars, hipStream_t st, int mode, uint64_t *d_rec,
                        uint8_t *d_inf_out) {
-    const MsmPlan &p = b->plan;
     if (off + n > b->n) {
         set_error("msm: range exceeds uploaded bases");
         return ZG_ERR_INVALID;
@@ -934,17 +982,27 @@ static int msm_enqueue(zg_bases_s *b, size_t off, size_t n, const uint64_t *d_sc
         ZG_HIP(hipGetLastError());
         return ZG_OK;
     }
-    const uint8_t *infp = b->d_inf ? b->d_inf + off : nullptr;
     zg_bases_s::Lane &ln = b->lanes[b->next_lane];
     b->next_lane = (b->next_lane + 1) % b->lanes.size();
+    return msm_enqueue_lane(b, b->plan, ln, b->nblk, off, n, d_scalars, st, mode, d_rec, d_inf_out, 0, 0);
+}
+
+// One launch set on workspace `ln` under plan `p`: p.K scalar vectors of n_pts scalars each, stored back to back at
+// d_scalars, all over bases[off, off+n_pts); vector i's record lands at d_rec + i*rec_stride / d_inf_out + i*inf_stride.
+static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &ln, uint32_t nblk_cap, size_t off, size_t n_pts,
+                            const uint64_t *d_scalars, hipStream_t st, int mode, uint64_t *d_rec, uint8_t *d_inf_out,
+                            uint32_t rec_stride, uint32_t inf_stride) {
+    const size_t n = n_pts * (size_t)p.K;  // scalars in this launch set
+    const uint8_t *infp = b->d_inf ? b->d_inf + off : nullptr;
     if (ln.used) ZG_HIP(hipStreamWaitEvent(st, ln.done, 0));  // the lane's previous MSM may be on another stream
     ln.used = true;
     if (ln.d_blockhist) {
-        uint32_t nblk = b->nblk;
+        uint32_t nblk = nblk_cap;
         while (nblk > 1 && (size_t)(nblk - 1) * 1024 >= n) nblk--;  // no empty blocks for short sub-range MSMs
         uint32_t per_block = (uint32_t)((n + nblk - 1) / nblk);
         prof_begin(ZG_PROF_MSM_DIGITS, st);
-        ZG_TRY(launch_digits_lds_c(p.c, st, d_scalars, infp, (uint32_t)n, p.G, per_block, p.NK, nblk, ln.d_dig, ln.d_blockhist));
+        ZG_TRY(launch_digits_lds_c(p.c, st, d_scalars, infp, (uint32_t)n, (uint32_t)n_pts, p.G, per_block, p.NK, nblk, ln.d_dig,
+                                   ln.d_blockhist));
         prof_end(ZG_PROF_MSM_DIGITS, st);
         prof_begin(ZG_PROF_MSM_SORT, st);
         hipLaunchKernelGGL(msm_colscan_kernel, dim3(div_up(p.NK, 256)), dim3(256), 0, st, ln.d_blockhist, nblk, p.NK, ln.d_hist);
@@ -961,12 +1019,12 @@ static int msm_enqueue(zg_bases_s *b, size_t off, size_t n, const uint64_t *d_sc
                                        128 * 1024));
             scatter_attr_set = true;
         }
-        hipLaunchKernelGGL(msm_scatter_lds_kernel, dim3(nblk), dim3(1024), p.NK * 4, st, ln.d_dig, (uint32_t)n, p.W, p.G, b->n,
-                           (uint32_t)off, per_block, p.NK, ln.d_starts, ln.d_blockhist, ln.d_sorted);
+        hipLaunchKernelGGL(msm_scatter_lds_kernel, dim3(nblk), dim3(1024), p.NK * 4, st, ln.d_dig, (uint32_t)n, (uint32_t)n_pts, p.W, p.G,
+                           b->n, (uint32_t)off, per_block, p.NK, ln.d_starts, ln.d_blockhist, ln.d_sorted);
     } else {
         prof_begin(ZG_PROF_MSM_DIGITS, st);
         ZG_HIP(hipMemsetAsync(ln.d_hist, 0, (size_t)p.NK * 4, st));
-        ZG_TRY(launch_digits_c(p.c, st, d_scalars, infp, (uint32_t)n, p.G, ln.d_dig, ln.d_hist));
+        ZG_TRY(launch_digits_c(p.c, st, d_scalars, infp, (uint32_t)n, (uint32_t)n_pts, p.G, ln.d_dig, ln.d_hist));
         prof_end(ZG_PROF_MSM_DIGITS, st);
         prof_begin(ZG_PROF_MSM_SORT, st);
         {
@@ -977,8 +1035,8 @@ static int msm_enqueue(zg_bases_s *b, size_t off, size_t n, const uint64_t *d_sc
                                ln.d_scan_tmp + 2 * (size_t)p.NK, ln.d_starts, ln.d_nzrank, ln.d_nzlist);
         }
         ZG_HIP(hipMemsetAsync(ln.d_hist, 0, (size_t)p.NK * 4, st));
-        hipLaunchKernelGGL(msm_scatter_kernel, dim3(div_up(n, 256), p.W), dim3(256), 0, st, ln.d_dig, (uint32_t)n, p.G, b->n,
-                           (uint32_t)off, ln.d_starts, ln.d_hist, ln.d_sorted);
+        hipLaunchKernelGGL(msm_scatter_kernel, dim3(div_up(n, 256), p.W), dim3(256), 0, st, ln.d_dig, (uint32_t)n, (uint32_t)n_pts, p.G,
+                           b->n, (uint32_t)off, ln.d_starts, ln.d_hist, ln.d_sorted);
     }
     prof_end(ZG_PROF_MSM_SORT, st);
     prof_begin(ZG_PROF_MSM_ACCUMULATE, st);
@@ -1004,9 +1062,11 @@ static int msm_enqueue(zg_bases_s *b, size_t off, size_t n, const uint64_t *d_sc
         prof_end(ZG_PROF_MSM_ACCUMULATE, st);
         prof_begin(ZG_PROF_MSM_REDUCE, st);
     }
-    hipLaunchKernelGGL(msm_bitsum_kernel, dim3(p.PB, p.c, p.G), dim3(256), 0, st, ln.d_partial, p.NB, p.c, ln.d_bits);
-    hipLaunchKernelGGL(msm_final_kernel, dim3(p.G), dim3(256), 0, st, ln.d_bits, p.c, p.PB, p.G, ln.d_rg, mode, d_rec, d_inf_out);
-    if (p.G > 1) hipLaunchKernelGGL(msm_groups_kernel, dim3(1), dim3(1), 0, st, ln.d_rg, p.G, p.c, mode, d_rec, d_inf_out);
+    hipLaunchKernelGGL(msm_bitsum_kernel, dim3(p.PB, p.c, p.G * p.K), dim3(256), 0, st, ln.d_partial, p.NB, p.c, ln.d_bits);
+    hipLaunchKernelGGL(msm_final_kernel, dim3(p.G * p.K), dim3(256), 0, st, ln.d_bits, p.c, p.PB, p.G, ln.d_rg, mode, d_rec, d_inf_out,
+                       rec_stride, inf_stride);
+    if (p.G > 1)
+        hipLaunchKernelGGL(msm_groups_kernel, dim3(p.K), dim3(1), 0, st, ln.d_rg, p.G, p.c, mode, d_rec, d_inf_out, rec_stride, inf_stride);
     prof_end(ZG_PROF_MSM_REDUCE, st);
     ZG_HIP(hipGetLastError());
     ZG_HIP(hipEventRecord(ln.done, st));
@@ -1129,6 +1189,97 @@ int zg_msm_g1_partial_fast_dev(zg_bases_t b, size_t off, size_t n, const uint64_
     return msm_enqueue(b, off, n, d_scalars, pick_stream(stream), 2, d_out_jac, nullptr);
 }
 
+// Largest number of scalar vectors one fused launch set can take for this handle and vector length (0: do not fuse).
+// Fusing pays when the MSMs are short (a lone short MSM is pure launch/dependency latency, ~0.4 ms whatever its size):
+// the k vectors become k times the bucket groups of ONE sort / accumulate / reduce pass. It needs the LDS counting sort
+// (all bucket counters of the launch in 128 KiB), i.e. handles with a small window.
+static size_t batch_fuse_limit(const zg_bases_s *b, size_t n) {
+    const MsmPlan &p = b->plan;
+    if (n == 0 || !env_int("ZG_MSM_BATCH_FUSE", 1)) return 0;
+    size_t by_lds = (128 * 1024 / 4) / ((size_t)p.NB * p.G);
+    size_t by_size = ((size_t)1 << 22) / n;  // keep a launch set at or below 2^22 scalars
+    size_t lim = by_lds < by_size ? by_lds : by_size;
+    return lim >= 2 ? lim : 0;
+}
+
+// enqueue k scalar vectors (device, back to back) over bases[0, n) on st; record i = d_out9[9*i .. 9*i+8] (xy[8], flag word)
+static int msm_batch_enqueue(zg_bases_s *b, size_t n, const uint64_t *d_scalars, size_t k, hipStream_t st, uint64_t *d_out9) {
+    if (n > b->n) {
+        set_error("msm: range exceeds uploaded bases");
+        return ZG_ERR_INVALID;
+    }
+    size_t lim = batch_fuse_limit(b, n);
+    if (lim == 0 || k < 2) {
+        // one launch set per vector, rotating through the handle's workspaces AND through three streams (the caller's
+        // plus two forked helpers), so the latency-bound tail of one MSM runs under the accumulation of the next
+        bool fork = k >= 2 && n > 0 && b->lanes.size() >= 2;
+        if (fork && !b->aux[0]) {
+            hipError_t e = hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming);
+            for (int i = 0; i < 2 && e == hipSuccess; i++) {
+                e = hipStreamCreateWithFlags(&b->aux[i], hipStreamNonBlocking);
+                if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_join[i], hipEventDisableTiming);
+            }
+            if (e != hipSuccess) {
+                set_error(std::string("msm batch streams: ") + hipGetErrorString(e));
+                return ZG_ERR_HIP;
+            }
+        }
+        if (fork) {
+            ZG_HIP(hipEventRecord(b->ev_fork, st));
+            for (int i = 0; i < 2; i++) ZG_HIP(hipStreamWaitEvent(b->aux[i], b->ev_fork, 0));
+        }
+        int rc = ZG_OK;
+        for (size_t i = 0; i < k && rc == ZG_OK; i++) {
+            hipStream_t si = !fork || i % 3 == 0 ? st : b->aux[i % 3 - 1];
+            rc = msm_enqueue(b, 0, n, d_scalars + 4 * n * i, si, 0, d_out9 + 9 * i, reinterpret_cast<uint8_t *>(d_out9 + 9 * i + 8));
+        }
+        if (fork) {  // join even after an error so the helpers never run ahead of the caller's next work
+            for (int i = 0; i < 2; i++) {
+                ZG_HIP(hipEventRecord(b->ev_join[i], b->aux[i]));
+                ZG_HIP(hipStreamWaitEvent(st, b->ev_join[i], 0));
+            }
+        }
+        return rc;
+    }
+    zg_msm_config cfg{b->plan.c, b->plan.L};
+    size_t kc = k < lim ? k : lim;
+    if (b->batch_n != n || (size_t)b->batch_plan.K < kc) {  // (re)build the fused workspace for kc vectors of n scalars
+        if (b->batch_lane.done) {
+            (void)hipEventSynchronize(b->batch_lane.done);
+            lane_free(b->batch_lane);
+        }
+        b->batch_n = 0;
+        ZG_TRY(make_plan(n, &cfg, b->batch_plan, kc));
+        uint32_t nblk = (uint32_t)(n * kc / (size_t)env_int("ZG_MSM_SORT_SPAN", 2048));
+        b->batch_nblk = nblk < 1 ? 1 : (nblk > 256 ? 256 : nblk);
+        hipError_t e = lane_alloc(b->batch_lane, b->batch_plan, n * kc, b->batch_nblk);
+        if (e != hipSuccess) {
+            lane_free(b->batch_lane);
+            set_error(std::string("msm batch workspace: ") + hipGetErrorString(e));
+            return e == hipErrorOutOfMemory ? ZG_ERR_NOMEM : ZG_ERR_HIP;
+        }
+        b->batch_n = n;
+    }
+    for (size_t i0 = 0; i0 < k; i0 += kc) {
+        size_t kk = k - i0 < kc ? k - i0 : kc;
+        MsmPlan pl = b->batch_plan;
+        if (kk != (size_t)pl.K) ZG_TRY(make_plan(n, &cfg, pl, kk));  // a shorter last set fits the same workspace
+        ZG_TRY(msm_enqueue_lane(b, pl, b->batch_lane, b->batch_nblk, 0, n, d_scalars + 4 * n * i0, st, 0, d_out9 + 9 * i0,
+                                reinterpret_cast<uint8_t *>(d_out9 + 9 * i0 + 8), 9, 72));
+    }
+    return ZG_OK;
+}
+
+int zg_msm_g1_batch_dev(zg_bases_t b, size_t n, const uint64_t *d_scalars, size_t k, void *stream, uint64_t *d_out9) {
+    ZG_INIT();
+    if (!b || (k && (!d_out9 || (n && !d_scalars)))) {
+        set_error("zg_msm_g1_batch_dev: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(b->mu);
+    return msm_batch_enqueue(b, n, d_scalars, k, pick_stream(stream), d_out9);
+}
+
 int zg_msm_g1_batch(zg_bases_t b, size_t n, const uint64_t *const *batches, size_t k, uint64_t *out_xy, uint8_t *out_inf) {
     ZG_INIT();
     if (!b || (k && (!batches || !out_xy))) {
@@ -1140,39 +1291,25 @@ int zg_msm_g1_batch(zg_bases_t b, size_t n, const uint64_t *const *batches, size
         return ZG_ERR_INVALID;
     }
     if (k == 0) return ZG_OK;
-    // Pipelined: MSM i runs on stream i % 2 with its own scalar staging buffer and workspace lane, so the
-    // H2D copy and the latency-bound tail of one commitment overlap the accumulation of the next; all results
-    // stay on the device until one final copy.
     std::lock_guard<std::mutex> lk(b->mu);
-    hipStream_t st[2] = {nullptr, nullptr};
-    uint64_t *d_sc[2] = {nullptr, nullptr}, *d_res = nullptr;
+    hipStream_t st = lib_stream();
+    // the k vectors are staged back to back on the device; all results stay there until one final copy
+    Scratch s_sc((n ? n : 1) * 32 * k), s_res(9 * 8 * k);
+    if (!s_sc.p || !s_res.p) return ZG_ERR_NOMEM;
+    uint64_t *d_sc = s_sc.as<uint64_t>(), *d_res = s_res.as<uint64_t>();
+    ZG_HIP(hipMemsetAsync(d_res, 0, 9 * 8 * k, st));
+    for (size_t i = 0; i < k && n; i++) ZG_HIP(hipMemcpyAsync(d_sc + 4 * n * i, batches[i], n * 32, hipMemcpyHostToDevice, st));
+    int rc = msm_batch_enqueue(b, n, d_sc, k, st, d_res);
     std::vector<uint64_t> h_res(9 * k);
-    int rc = ZG_OK;
-    hipError_t e = hipMalloc((void **)&d_res, 9 * 8 * k);
-    for (int i = 0; i < 2 && e == hipSuccess; i++) {
-        e = hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipMalloc((void **)&d_sc[i], n ? n * 32 : 16);
-    }
-    if (e == hipSuccess) e = hipMemsetAsync(d_res, 0, 9 * 8 * k, st[0]);
-    if (e == hipSuccess) e = hipStreamSynchronize(st[0]);
-    for (size_t i = 0; i < k && e == hipSuccess && rc == ZG_OK; i++) {
-        int s = (int)(i & 1);
-        if (n) e = hipMemcpyAsync(d_sc[s], batches[i], n * 32, hipMemcpyHostToDevice, st[s]);  // stream-ordered after MSM i-2
-        if (e != hipSuccess) break;
-        rc = msm_enqueue(b, 0, n, d_sc[s], st[s], 0, d_res + 9 * i, reinterpret_cast<uint8_t *>(d_res + 9 * i + 8));
-    }
-    for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipStreamSynchronize(st[i]);
-    if (e == hipSuccess && rc == ZG_OK) e = hipMemcpy(h_res.data(), d_res, 9 * 8 * k, hipMemcpyDeviceToHost);
-    for (int i = 0; i < 2; i++) {
-        if (d_sc[i]) (void)hipFree(d_sc[i]);
-        if (st[i]) (void)hipStreamDestroy(st[i]);
-    }
-    if (d_res) (void)hipFree(d_res);
+    hipError_t e = hipSuccess;
+    if (rc == ZG_OK) e = hipMemcpyAsync(h_res.data(), d_res, 9 * 8 * k, hipMemcpyDeviceToHost, st);
+    hipError_t e2 = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = e2;
+    if (rc != ZG_OK) return rc;
     if (e != hipSuccess) {
         set_error(std::string("zg_msm_g1_batch: ") + hipGetErrorString(e));
         return ZG_ERR_HIP;
     }
-    if (rc != ZG_OK) return rc;
     for (size_t i = 0; i < k; i++) {
         for (int j = 0; j < 8; j++) out_xy[8 * i + j] = h_res[9 * i + j];
         if (out_inf) out_inf[i] = (uint8_t)(h_res[9 * i + 8] & 0xff);

@@ -28,7 +28,7 @@ SYMBOLS = [
     "zg_profile_begin", "zg_profile_end",
     "zg_field_op",
     "zg_g1_bases_upload", "zg_g1_bases_upload_dev", "zg_g1_bases_free", "zg_g1_bases_len",
-    "zg_msm_g1", "zg_msm_g1_dev", "zg_msm_g1_dev_async", "zg_msm_g1_batch", "zg_msm_g1_partial_dev", "zg_msm_g1_partial_fast_dev",
+    "zg_msm_g1", "zg_msm_g1_dev", "zg_msm_g1_dev_async", "zg_msm_g1_batch", "zg_msm_g1_batch_dev", "zg_msm_g1_partial_dev", "zg_msm_g1_partial_fast_dev",
     "zg_g1_combine_partials_dev", "zg_g1_combine_partials_dev_async", "zg_g1_is_on_curve_batch", "zg_g1_scalar_mul_batch",
     "zg_hyperkzg_open",
     "zg_fr_dense_evaluate", "zg_fr_eq_table", "zg_fr_eq_table_dev", "zg_fr_bind_low", "zg_fr_bind_high",
@@ -195,6 +195,10 @@ class Bases:
     def msm_partial_fast_dev(self, d_scalars, n, d_out_jac, off=0, stream=0):
         _chk(_lib.zg_msm_g1_partial_fast_dev(self._h, C.c_size_t(off), C.c_size_t(n), _d(d_scalars), _d(stream), _d(d_out_jac)),
              "zg_msm_g1_partial_fast_dev")
+
+    def msm_batch_dev(self, d_scalars, n, k, d_out9, stream=0):
+        """k vectors of n scalars back to back in HBM -> k records of 9 u64 (xy[8] + flag word) in HBM, asynchronous."""
+        _chk(_lib.zg_msm_g1_batch_dev(self._h, C.c_size_t(n), _d(d_scalars), C.c_size_t(k), _d(stream), _d(d_out9)), "zg_msm_g1_batch_dev")
 
     def msm_batch(self, batches, n=None):
         batches = [_c(b) for b in batches]
