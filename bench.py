@@ -27,10 +27,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # HBM traffic of one msm_accumulate launch at 2^20 points (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
-# passes, profiles/r1d_rocprofv3_summary_streams1.txt): 1,281,617 KB fetched + 22,849 KB written. The launch
+# passes, profiles/r1e_rocprofv3_summary_streams1.txt): 1,293,143 KB fetched + 22,848 KB written. The launch
 # gathers 16.7M random 64-byte rows (1.07 GB) + 67 MB of sorted refs: FETCH_SIZE is taken uncorrected because
 # the gfx950 x2 under-count applies to wide streaming reads tallied as 128-byte requests, not to 64-byte rows.
-MEASURED_TRAFFIC = {20: (1281617.0 + 22849.3) * 1024.0}
+MEASURED_TRAFFIC = {20: (1293143.4 + 22848.4) * 1024.0}
+# static instruction mix of one lazy-limb XYZZ mixed add (hipcc --save-temps of the accumulate fast path): 1467
+# v_mad_u64_u32 + 146 v_lshl_add_u64 + 144 v_lshrrev_b64 + 81 v_mul_lo_u32 at 4 issue cycles per wave, 382 32-bit
+# add/and/shift/sub at 2 (tools/microbench.hip rates)
+MADD_ISSUE_CYCLES = (1467 + 146 + 144 + 81) * 4 + 382 * 2
+VALU_PEAK_GCYC = 1024 * 2.4  # 256 CUs x 4 SIMDs x 2.4 GHz
+W_WINDOWS = 16
 SEED = 0x5A4F4C54
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 N_SCALAR_SETS = 3
@@ -70,8 +76,8 @@ def closed_form_scalar(raw, start):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--logn", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
@@ -112,10 +118,6 @@ def main():
     from zolt_amd import api, lib
     lib.init(local_rank)
 
-    n = 1 << args.logn
-    bounds = api.shard_bounds(n, world)
-    start, end = bounds[rank]
-    n_loc = end - start
     # all work runs on an explicit (non-default) torch stream: the C ABI treats a NULL stream as "the library's own
     # stream", which is not ordered with torch's legacy default stream (handle 0)
     work_stream = torch.cuda.Stream(device=dev)
@@ -126,75 +128,111 @@ def main():
     if world > 1 and dist_backend != "nccl":
         nstreams = 1  # the gloo debugging path stages through the host and is synchronous anyway
     tstreams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(nstreams - 1)]
-
-    # ---- synthetic inputs, generated with the product's own kernels (untimed)
-    t0 = time.time()
     g = api.generator()
-    ks = np.zeros((n_loc, 4), dtype=np.uint64)
-    ks[:, 0] = np.arange(start + 1, end + 1, dtype=np.uint64)
-    ks_m = lib.field_op(lib.FR, lib.OP_TO_MONT, ks)
-    bases_xy, bases_inf = lib.g1_scalar_mul_batch(np.repeat(g[None, :], n_loc, axis=0), np.zeros(n_loc, dtype=np.uint8), ks_m)
-    assert not bases_inf.any()
-    d_bases = torch.from_numpy(bases_xy.view(np.int64)).to(dev)
-    bases = lib.Bases.upload_dev(d_bases.data_ptr(), 0, n_loc, stream=stream, window_bits=args.window_bits,
-                                 precompute_levels=args.precompute)
-    raws, d_scalars, expect_k = [], [], []
-    for s in range(N_SCALAR_SETS):
-        raw = raw_scalars(SEED + s, start, n_loc)
-        sm = lib.field_op(lib.FR, lib.OP_TO_MONT, raw)  # reduces mod r and converts, like F.fromBytes
-        raws.append(raw)
-        d_scalars.append(torch.from_numpy(sm.view(np.int64)).to(dev))
-        expect_k.append(closed_form_scalar(raw, start))
-    setup_s = time.time() - t0
-
-    backend = api.GpuShardBackend(bases, n_loc)
-    sharded = api.ShardedMSM(backend, world, rank)
-    d_res = torch.zeros((max(args.steps, args.warmup, 1), 9), dtype=torch.int64, device=dev)  # xy[8] + flag word
-
-    def step(i, slot):
-        sc = d_scalars[i % N_SCALAR_SETS]
-        if not use_dist:
-            st = tstreams[i % nstreams].cuda_stream
-            bases.msm_dev_async(sc.data_ptr(), n_loc, d_res[slot].data_ptr(), d_res[slot, 8:].data_ptr(), stream=st)
-            return None
-        with torch.cuda.stream(tstreams[i % nstreams]):
-            return sharded.compute(sc, out=d_res[slot])
 
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i, i)
-    barrier()
+    def run_size(logn, steps, warmup):
+        """time `steps` MSMs of 2^logn points (sharded over the ranks), every result checked against the closed form"""
+        n = 1 << logn
+        bounds = api.shard_bounds(n, world)
+        start, end = bounds[rank]
+        n_loc = end - start
 
-    lib.profile_begin(8 * args.steps + 64)
-    last = None
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        last = step(i, i)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prof = lib.profile_end()
+        # ---- synthetic inputs, generated with the product's own kernels (untimed)
+        t0 = time.time()
+        ks = np.zeros((n_loc, 4), dtype=np.uint64)
+        ks[:, 0] = np.arange(start + 1, end + 1, dtype=np.uint64)
+        ks_m = lib.field_op(lib.FR, lib.OP_TO_MONT, ks)
+        bases_xy, bases_inf = lib.g1_scalar_mul_batch(np.repeat(g[None, :], n_loc, axis=0), np.zeros(n_loc, dtype=np.uint8), ks_m)
+        assert not bases_inf.any()
+        d_bases = torch.from_numpy(bases_xy.view(np.int64)).to(dev)
+        bases = lib.Bases.upload_dev(d_bases.data_ptr(), 0, n_loc, stream=stream, window_bits=args.window_bits,
+                                     precompute_levels=args.precompute)
+        raws, d_scalars, expect_k = [], [], []
+        for s in range(N_SCALAR_SETS):
+            raw = raw_scalars(SEED + s, start, n_loc)
+            sm = lib.field_op(lib.FR, lib.OP_TO_MONT, raw)  # reduces mod r and converts, like F.fromBytes
+            raws.append(raw)
+            d_scalars.append(torch.from_numpy(sm.view(np.int64)).to(dev))
+            expect_k.append(closed_form_scalar(raw, start))
+        setup_s = time.time() - t0
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist_backend == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+        backend = api.GpuShardBackend(bases, n_loc)
+        sharded = api.ShardedMSM(backend, world, rank)
+        d_res = torch.zeros((max(steps, warmup, 1), 9), dtype=torch.int64, device=dev)  # xy[8] + flag word
 
-    # ---- correctness of what was timed: closed form via an independent kernel path (scalarMul)
-    all_k = expect_k
-    if world > 1:
-        gathered = [None] * world
-        dist.all_gather_object(gathered, expect_k)
-        all_k = [sum(gk[s] for gk in gathered) % api.R_MOD for s in range(N_SCALAR_SETS)]
-    want = [api.MSM.scalarMul(g, api.fr_from_int(k)) for k in all_k]
-    res = d_res.cpu().numpy().view(np.uint64)
-    for i in range(args.steps):
-        wxy, winf = want[i % N_SCALAR_SETS]
-        assert int(res[i, 8] & 0xFF) == winf and np.array_equal(res[i, :8], wxy), f"MSM result mismatch at step {i}"
+        def step(i, slot):
+            sc = d_scalars[i % N_SCALAR_SETS]
+            if not use_dist:
+                st = tstreams[i % nstreams].cuda_stream
+                bases.msm_dev_async(sc.data_ptr(), n_loc, d_res[slot].data_ptr(), d_res[slot, 8:].data_ptr(), stream=st)
+                return None
+            with torch.cuda.stream(tstreams[i % nstreams]):
+                return sharded.compute(sc, out=d_res[slot])
+
+        for i in range(warmup):
+            step(i, i)
+        barrier()
+
+        lib.profile_begin(8 * steps + 64)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i, i)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        prof = lib.profile_end()
+
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist_backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+        # outside the timed region: the same MSM strictly serial on one stream, so that each kernel's duration is its own
+        # (in the timed region kernels of different streams share the GPU and their HIP-event durations stretch)
+        d_tmp = torch.zeros(9, dtype=torch.int64, device=dev)
+        lib.profile_begin(8 * 6 + 64)
+        for i in range(6):
+            bases.msm_dev_async(d_scalars[i % N_SCALAR_SETS].data_ptr(), n_loc, d_tmp.data_ptr(), d_tmp[8:].data_ptr(), stream=stream)
+            torch.cuda.synchronize()
+        prof_alone = lib.profile_end()
+
+        # ---- correctness of what was timed: closed form via an independent kernel path (scalarMul)
+        all_k = expect_k
+        if world > 1:
+            gathered = [None] * world
+            dist.all_gather_object(gathered, expect_k)
+            all_k = [sum(gk[s] for gk in gathered) % api.R_MOD for s in range(N_SCALAR_SETS)]
+        want = [api.MSM.scalarMul(g, api.fr_from_int(k)) for k in all_k]
+        res = d_res.cpu().numpy().view(np.uint64)
+        for i in range(steps):
+            wxy, winf = want[i % N_SCALAR_SETS]
+            assert int(res[i, 8] & 0xFF) == winf and np.array_equal(res[i, :8], wxy), f"MSM result mismatch at step {i}"
+
+        return {"n": n, "n_loc": n_loc, "elapsed": elapsed, "prof": prof, "prof_alone": prof_alone, "setup_s": setup_s, "bases_xy": bases_xy,
+                "d_scalars": d_scalars, "want": want, "bases": bases}
+
+    m = run_size(args.logn, args.steps, args.warmup)
+    n, n_loc, elapsed, prof, setup_s = m["n"], m["n_loc"], m["elapsed"], m["prof"], m["setup_s"]
+    prof_alone = m["prof_alone"]
+    bases_xy, d_scalars, want, bases = m["bases_xy"], m["d_scalars"], m["want"], m["bases"]
+
+    # BASELINE config 4: the 2^22-point MSM sharded over the ranks (same code path, untimed setup), reported beside the
+    # headline workload so that the strong-scaling curve exists at both sizes of the metric
+    sharded_22 = None
+    if world > 1 and not args.no_extra and args.logn != 22:
+        del m
+        bases.free()
+        m22 = run_size(22, 12, 3)
+        sharded_22 = {"value": 12 / m22["elapsed"], "unit": "MSM/s", "ms_per_step": m22["elapsed"] / 12 * 1e3,
+                      "points": m22["n"], "points_per_gpu": m22["n_loc"], "n_gpus": world}
+        m22["bases"].free()
+        bases = None
+        del m22
 
     sharded_sc = None
     if use_dist and not args.no_extra and world & (world - 1) == 0:
@@ -223,15 +261,28 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "msm_accumulate_chunk_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                      "traffic": MEASURED_TRAFFIC.get(args.logn) if world == 1 else None,
-                     "traffic_source": "rocprofv3 PMC FETCH_SIZE+WRITE_SIZE, profiles/r1d_rocprofv3_summary_streams1.txt",
+                     "traffic_source": "rocprofv3 PMC FETCH_SIZE+WRITE_SIZE, profiles/r1e_rocprofv3_summary_streams1.txt",
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": acc_avg_ms,
                      "note": "MSM is integer-ALU-bound (10 Fp mul per mixed add x windows per point); see DESIGN.md"},
         "extra": {"kernel_ms_per_msm": {k: (v[0] / max(v[1], 1)) for k, v in prof.items() if v[1]},
+                  "kernel_ms_per_msm_alone": {k: (v[0] / max(v[1], 1)) for k, v in prof_alone.items() if v[1]},
                   "setup_seconds": setup_s},
     }
 
+    # the ceiling that actually binds msm_accumulate: VALU issue. One mixed add compiles to MADD_ISSUE_CYCLES issue cycles
+    # per wave (static instruction mix of the kernel's fast path); peak = 1024 SIMDs x 2.4 GHz.
+    adds = float(n_loc) * W_WINDOWS * (1.0 - 2.0 ** -16)  # one table row per non-zero signed 16-bit digit
+    alone_ms = prof_alone["msm_accumulate"][0] / max(prof_alone["msm_accumulate"][1], 1)
+    issue = adds / 64.0 * MADD_ISSUE_CYCLES / (alone_ms * 1e-3) / 1e9 if alone_ms and args.window_bits in (0, 16) and args.logn >= 15 else None
+    out["roofline"]["avg_launch_ms_alone"] = alone_ms
+    out["roofline"]["valu_issue"] = {"achieved": issue, "peak": VALU_PEAK_GCYC, "unit": "G issue-cycles/s",
+                                     "frac": issue / VALU_PEAK_GCYC if issue else None,
+                                     "duration": "avg_launch_ms_alone (the kernel running by itself, outside the timed region)",
+                                     "model": "1467 v_mad_u64_u32 + 371 other quarter-rate + 382 half-rate VALU instructions per mixed add"}
     if sharded_sc is not None:
         out["extra"]["sumcheck_v20_sharded"] = sharded_sc
+    if sharded_22 is not None:
+        out["extra"]["msm_2^22_sharded"] = sharded_22
     if not args.no_extra and world == 1:
         # the host-buffer entry point (what an unmodified MSM.compute call site pays): scalars cross PCIe every call
         h_sc = d_scalars[0].cpu().numpy().view(np.uint64)

@@ -38,7 +38,9 @@ def test_hyperkzg_setup_commit_open(env):
     assert np.array_equal(c2, w2)
     z, zi = api.HyperKZG.commit(params, np.zeros((0, 4), dtype=np.uint64))
     assert zi == 1 and not z.any() and api.commitment_to_bytes(z, zi) == bytes(64)
-    polys = [_rand(ob, 10 + k, 64) for k in range(3)]
+    # equal lengths are fused into one launch set; mixed lengths (short, empty, longer than the SRS) keep their order
+    polys = [_rand(ob, 10 + k, 64) for k in range(3)] + [_rand(ob, 20, 10), np.zeros((0, 4), dtype=np.uint64), _rand(ob, 21, 100),
+                                                         _rand(ob, 22, 10)]
     for (bc, bi), p in zip(api.HyperKZG.batchCommit(params, polys), polys):
         w, wi = ob.hyperkzg_commit(wsrs, winf, p)
         assert bi == wi and np.array_equal(bc, w)

@@ -9,11 +9,11 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 export TMPDIR=/tmp
 mkdir -p $OUT
 cd /tmp
-BENCH="python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra $@"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH > $OUT/pmc_write.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $OUT/pmc_sq -- $BENCH > $OUT/pmc_sq.log 2>&1
+BENCH="python3 $ROOT/bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-extra $@"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH </dev/null > $OUT/trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH </dev/null > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH </dev/null > $OUT/pmc_write.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $OUT/pmc_sq -- $BENCH </dev/null > $OUT/pmc_sq.log 2>&1
 cd $OUT
 echo "# bench command: $BENCH" > $OUT/summary.txt
 grep -h '^{' $OUT/trace.log | tail -1 >> $OUT/summary.txt

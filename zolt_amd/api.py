@@ -211,8 +211,22 @@ class HyperKZG:
 
     @staticmethod
     def batchCommit(params, polys):
-        """batchCommit (src/poly/commitment/mod.zig:558-570)."""
-        return [HyperKZG.commit(params, p) for p in polys]
+        """batchCommit (src/poly/commitment/mod.zig:558-570): out[i] = commit(poly_i). Polynomials of equal (clamped)
+        length share one zg_msm_g1_batch call, which fuses short vectors into a single launch set."""
+        polys = [np.ascontiguousarray(p, dtype=np.uint64).reshape(-1, 4) for p in polys]
+        out = [None] * len(polys)
+        groups = {}
+        for i, p in enumerate(polys):
+            groups.setdefault(min(p.shape[0], params.max_degree), []).append(i)
+        for n, idx in groups.items():
+            if n == 0 or len(idx) == 1:
+                for i in idx:
+                    out[i] = HyperKZG.commit(params, polys[i])
+            else:
+                xy, inf = params._dev.msm_batch([polys[i][:n] for i in idx], n=n)
+                for j, i in enumerate(idx):
+                    out[i] = (xy[j], int(inf[j]))
+        return out
 
     @staticmethod
     def open(params, evals, point, value):

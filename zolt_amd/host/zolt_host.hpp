@@ -325,8 +325,28 @@ struct HyperKZG {
         return pr;
     }
     static std::vector<Commitment> batchCommit(const SetupParams &params, const std::vector<std::vector<Fr>> &polys) {  // :558-570
-        std::vector<Commitment> out;
-        for (const auto &p : polys) out.push_back(commit(params, p));
+        // polynomials of equal (clamped) length share one zg_msm_g1_batch call: short vectors are fused into one launch set
+        std::vector<Commitment> out(polys.size(), Commitment{AffinePoint::identity()});
+        std::vector<bool> done(polys.size(), false);
+        size_t srs = params.powers_of_tau_g1.size();
+        for (size_t i = 0; i < polys.size(); i++) {
+            if (done[i]) continue;
+            size_t n = polys[i].size() < srs ? polys[i].size() : srs;
+            std::vector<size_t> idx;
+            for (size_t j = i; j < polys.size(); j++)
+                if (!done[j] && (polys[j].size() < srs ? polys[j].size() : srs) == n) idx.push_back(j);
+            for (size_t j : idx) done[j] = true;
+            if (n == 0 || idx.size() == 1) {
+                for (size_t j : idx) out[j] = commit(params, polys[j]);
+                continue;
+            }
+            std::vector<const uint64_t *> ptrs;
+            for (size_t j : idx) ptrs.push_back(reinterpret_cast<const uint64_t *>(polys[j].data()));
+            std::vector<uint64_t> xy(8 * idx.size());
+            std::vector<uint8_t> inf(idx.size());
+            check(zg_msm_g1_batch(params.device->handle(), n, ptrs.data(), idx.size(), xy.data(), inf.data()), "zg_msm_g1_batch");
+            for (size_t t = 0; t < idx.size(); t++) out[idx[t]] = Commitment{unpack_point(&xy[8 * t], inf[t])};
+        }
         return out;
     }
 };
