@@ -181,6 +181,16 @@ ZG_API int zg_g1_scalar_mul_batch(const uint64_t *xy, const uint8_t *inf, const 
 ZG_API int zg_hyperkzg_open(zg_bases_t srs, const uint64_t *evals, size_t n_evals, const uint64_t *point, size_t num_vars,
                      const uint64_t value[4], uint64_t *q_xy /* num_vars*8 */, uint8_t *q_inf /* num_vars */,
                      uint64_t final_eval[4]);
+/* HyperKZG.batchOpen (src/poly/commitment/mod.zig:607-732): k polynomials opened at one point through the random linear
+ * combination P = sum_i gamma^i p_i, gamma = fromU64(0x9a8b7c6d) * prod_j (point[j] + 11) (the reference's deterministic
+ * stand-in for a transcript challenge, :633-640). Outputs: evaluations[k] = evaluateMultilinear(p_i, point) EXACTLY as the
+ * reference computes it (:788-817 — the direct sum for point.len <= 10 and len <= 1024, evals[0] otherwise); the quotient
+ * commitments of P (*n_quot of them; fewer than num_vars when the fold runs out of elements, :686,714-720; the unused
+ * slots are reported as identity); final_eval (combined_eval when num_vars == 0, :665-673) and gamma. Polynomials shorter
+ * than polys[0] are zero-extended, longer ones truncated (:649-651). */
+ZG_API int zg_hyperkzg_batch_open(zg_bases_t srs, const uint64_t *const *polys, const size_t *lens, size_t k, const uint64_t *point,
+                           size_t num_vars, uint64_t *q_xy /* num_vars*8 */, uint8_t *q_inf /* num_vars */, size_t *n_quot,
+                           uint64_t *evaluations /* k*4 */, uint64_t final_eval[4], uint64_t gamma[4]);
 
 /* ------------------------------------------------------------------ poly tables */
 /* EqPolynomial.evals / evalsSliceWithScaling (src/poly/mod.zig:240-290): out[2^v], index MSB <-> r[0];

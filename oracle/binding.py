@@ -235,6 +235,24 @@ def hyperkzg_open(srs_xy, srs_inf, evals, point, value):
     return q, qinf, fin
 
 
+def hyperkzg_batch_open(srs_xy, srs_inf, polys, point):
+    """-> (q_xy[nq,8], q_inf[nq], evaluations[k,4], final_eval, gamma)"""
+    srs_xy, srs_inf, point = _c(srs_xy), _c(srs_inf, np.uint8), _c(point)
+    polys = [_c(p) for p in polys]
+    k, v = len(polys), point.size // 4
+    ptrs = (C.c_void_p * max(k, 1))(*[p.ctypes.data for p in polys])
+    lens = (C.c_size_t * max(k, 1))(*[p.size // 4 for p in polys])
+    q = np.zeros((max(v, 1), 8), dtype=np.uint64)
+    qi = np.zeros(max(v, 1), dtype=np.uint8)
+    nq = C.c_size_t(0)
+    ev = np.zeros((max(k, 1), 4), dtype=np.uint64)
+    fin = np.zeros(4, dtype=np.uint64)
+    gam = np.zeros(4, dtype=np.uint64)
+    lib.zo_hyperkzg_batch_open(_p(srs_xy), _b(srs_inf), C.c_size_t(srs_xy.size // 8), ptrs, lens, C.c_size_t(k), _p(point),
+                               C.c_size_t(v), _p(q), _b(qi), C.byref(nq), _p(ev), _p(fin), _p(gam))
+    return q[:nq.value], qi[:nq.value], ev[:k], fin, gam
+
+
 def commitment_to_bytes(xy):
     xy = _c(xy)
     out = np.empty(64, dtype=np.uint8)

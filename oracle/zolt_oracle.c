@@ -626,6 +626,103 @@ EXPORT void zo_hyperkzg_open(const uint64_t *srs_xy, const uint8_t *srs_inf, siz
     free(cur);
 }
 
+/* HyperKZG.evaluateMultilinear — src/poly/commitment/mod.zig:788-817: index bit j <-> point[j] (LSB first); direct
+ * monomial sum only when point.len <= 10 and evals.len <= 1024, otherwise the reference's "fallback" returns evals[0]. */
+static fe hk_eval_multilinear(const fe *evals, size_t n, const fe *point, size_t v) {
+    if (n == 0) return f_zero();
+    if (v == 0) return evals[0];
+    if (v <= 10 && n <= 1024) {
+        fe sum = f_zero(), one = f_one(&FR);
+        for (size_t idx = 0; idx < n; idx++) {
+            fe term = evals[idx];
+            size_t bits = idx;
+            for (size_t j = 0; j < v; j++) {
+                fe f = (bits & 1) ? point[j] : f_sub(&FR, &one, &point[j]);
+                term = f_mul(&FR, &term, &f);
+                bits >>= 1;
+            }
+            sum = f_add(&FR, &sum, &term);
+        }
+        return sum;
+    }
+    return evals[0];
+}
+
+/* HyperKZG.batchOpen — src/poly/commitment/mod.zig:607-732. polys[i] has lens[i] elements; outputs: up to num_vars
+ * quotient commitments (*n_quot computed before the fold runs out of elements, :677-680,714-720), evaluations[k],
+ * final_eval, gamma. */
+EXPORT void zo_hyperkzg_batch_open(const uint64_t *srs_xy, const uint8_t *srs_inf, size_t srs_len, const uint64_t *const *polys,
+                                   const size_t *lens, size_t k, const uint64_t *point, size_t num_vars, uint64_t *q_xy,
+                                   uint8_t *q_inf, size_t *n_quot, uint64_t *evaluations, uint64_t final_eval[4], uint64_t gamma_out[4]) {
+    *n_quot = 0;
+    if (k == 0) {  /* :613-621 */
+        fe z = f_zero(), one = f_one(&FR);
+        memcpy(final_eval, &z, 32);
+        memcpy(gamma_out, &one, 32);
+        return;
+    }
+    const fe *pt = (const fe *)point;
+    size_t poly_size = lens[0];
+    fe *ev = (fe *)evaluations;
+    for (size_t i = 0; i < k; i++) ev[i] = hk_eval_multilinear((const fe *)polys[i], lens[i], pt, num_vars);  /* :628-631 */
+    uint64_t g0[4] = {0x9a8b7c6dULL, 0, 0, 0}, e11[4] = {11, 0, 0, 0};
+    fe gamma, eleven;
+    zo_f_to_mont(0, g0, (uint64_t *)&gamma, 1);   /* F.fromU64 */
+    zo_f_to_mont(0, e11, (uint64_t *)&eleven, 1);
+    for (size_t j = 0; j < num_vars; j++) {     /* :634-637 */
+        fe t = f_add(&FR, &pt[j], &eleven);
+        gamma = f_mul(&FR, &gamma, &t);
+    }
+    fe zero = f_zero();
+    if (memcmp(&gamma, &zero, 32) == 0) gamma = f_one(&FR);
+    fe *combined = (fe *)malloc((poly_size ? poly_size : 1) * sizeof(fe));
+    for (size_t j = 0; j < poly_size; j++) combined[j] = f_zero();
+    fe gp = f_one(&FR);
+    for (size_t i = 0; i < k; i++) {            /* :646-654 */
+        const fe *p = (const fe *)polys[i];
+        for (size_t j = 0; j < poly_size; j++)
+            if (j < lens[i]) {
+                fe t = f_mul(&FR, &gp, &p[j]);
+                combined[j] = f_add(&FR, &combined[j], &t);
+            }
+        gp = f_mul(&FR, &gp, &gamma);
+    }
+    fe ce = f_zero();
+    gp = f_one(&FR);
+    for (size_t i = 0; i < k; i++) {            /* :657-662 */
+        fe t = f_mul(&FR, &gp, &ev[i]);
+        ce = f_add(&FR, &ce, &t);
+        gp = f_mul(&FR, &gp, &gamma);
+    }
+    memcpy(gamma_out, &gamma, 32);
+    if (num_vars == 0) {                        /* :665-673 */
+        memcpy(final_eval, &ce, 32);
+        free(combined);
+        return;
+    }
+    size_t len = poly_size;
+    fe *cur = combined;
+    for (size_t i = 0; i < num_vars; i++) {     /* :684-712 */
+        size_t half = len / 2;
+        if (half == 0) break;
+        fe *q = (fe *)malloc(half * sizeof(fe));
+        for (size_t j = 0; j < half; j++) q[j] = f_sub(&FR, &cur[j + half], &cur[j]);
+        zo_hyperkzg_commit(srs_xy, srs_inf, srs_len, (const uint64_t *)q, half, q_xy + 8 * i, q_inf ? q_inf + i : NULL);
+        (*n_quot)++;
+        free(q);
+        fe *nw = (fe *)malloc(half * sizeof(fe));
+        fe one = f_one(&FR), r = pt[i], omr = f_sub(&FR, &one, &r);
+        for (size_t j = 0; j < half; j++) {
+            fe lo = f_mul(&FR, &cur[j], &omr), hi = f_mul(&FR, &cur[j + half], &r);
+            nw[j] = f_add(&FR, &lo, &hi);
+        }
+        free(cur); cur = nw; len = half;
+    }
+    fe fin = len > 0 ? cur[0] : f_zero();       /* :714 */
+    memcpy(final_eval, &fin, 32);
+    free(cur);
+}
+
 /* -------------------------------------------------------------------- poly */
 /* EqPolynomial.evalsSliceWithScaling — src/poly/mod.zig:252-290 (big-endian index) */
 EXPORT void zo_fr_eq_table(const uint64_t *r, size_t v, const uint64_t *scale, uint64_t *out) {

@@ -79,6 +79,24 @@ TEST(hyperkzg_batch_commit) {
     EXPECT(HyperKZG::commit(params, e1).point.eql(params.powers_of_tau_g1[1]));
 }
 
+// batchOpen of ONE polynomial is open() of that polynomial (gamma^0 = 1); evaluations are the multilinear evaluations;
+// the batching challenge follows :633-640
+TEST(hyperkzg_batch_open_single_equals_open) {
+    auto params = HyperKZG::setup(8);
+    std::vector<Fr> e, pt;
+    for (int i = 0; i < 8; i++) e.push_back(Fr::fromU64((uint64_t)(3 * i + 2)));
+    for (int j = 0; j < 3; j++) pt.push_back(Fr::fromU64((uint64_t)(5 + j)));
+    auto single = HyperKZG::open(params, e, pt, Fr::zero());
+    auto batch = HyperKZG::batchOpen(params, {e}, pt);
+    EXPECT(batch.quotient_commitments.size() == 3 && batch.evaluations.size() == 1);
+    for (size_t i = 0; i < 3; i++) EXPECT(batch.quotient_commitments[i].eql(single.quotient_commitments[i]));
+    EXPECT(batch.final_eval.eql(single.final_eval));
+    EXPECT(batch.evaluations[0].eql(DensePolynomial(e).evaluate(pt)));
+    Fr g = Fr::fromU64(0x9a8b7c6dULL);
+    for (auto &r : pt) g = g.mul(r.add(Fr::fromU64(11)));
+    EXPECT(batch.batching_challenge.eql(g));
+}
+
 // src/poly/commitment/mod.zig:1448-1472 "hyperkzg multilinear evaluation" + open(): the final evaluation of open() at a
 // boolean point is the table entry it selects (high variable first), and quotient 0 is commit(hi - lo)
 TEST(hyperkzg_open_corner_points) {

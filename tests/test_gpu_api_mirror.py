@@ -69,6 +69,26 @@ def test_hyperkzg_setup_commit_open(env):
     params.deinit()
 
 
+@pytest.mark.parametrize("srs_n,lens,v", [(64, [64, 64, 64], 6), (64, [32, 16, 40, 0], 5), (16, [8], 3), (64, [64, 64], 0),
+                                          (2048, [2048, 2048, 1000], 11), (64, [4, 4], 5), (64, [], 3), (2048, [1024, 1024], 10)])
+def test_hyperkzg_batch_open(env, srs_n, lens, v):
+    """HyperKZG.batchOpen (src/poly/commitment/mod.zig:607-732) incl. the reference's evaluateMultilinear (:788-817: direct sum
+    only for point.len <= 10 and len <= 1024, evals[0] otherwise), shorter / longer / empty polynomials, zero variables,
+    a fold that runs out of elements (fewer quotients than variables) and the empty batch."""
+    api, lib, ob = env
+    params = api.HyperKZG.setup(srs_n)
+    polys = [_rand(ob, 300 + i, n) if n else np.zeros((0, 4), dtype=np.uint64) for i, n in enumerate(lens)]
+    point = _rand(ob, 350, v) if v else np.zeros((0, 4), dtype=np.uint64)
+    got = api.HyperKZG.batchOpen(params, polys, point)
+    wq, wqi, wev, wfin, wgam = ob.hyperkzg_batch_open(params.powers_of_tau_g1, params.infinity, polys, point)
+    assert len(got["quotient_commitments"]) == wq.shape[0]
+    for i, (q, qi) in enumerate(got["quotient_commitments"]):
+        assert qi == wqi[i] and np.array_equal(q, wq[i])
+    assert np.array_equal(got["evaluations"], wev) and np.array_equal(got["final_eval"], wfin)
+    assert np.array_equal(got["batching_challenge"], wgam)
+    params.deinit()
+
+
 def test_poly_classes_and_run_sumcheck(env):
     api, lib, ob = env
     ev = _rand(ob, 20, 256)

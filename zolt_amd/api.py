@@ -239,6 +239,16 @@ class HyperKZG:
         return [(q[i], int(qinf[i])) for i in range(point.shape[0])], final
 
 
+    @staticmethod
+    def batchOpen(params, polys, point):
+        """batchOpen (src/poly/commitment/mod.zig:607-732) -> dict(quotient_commitments [(xy, inf)], evaluations,
+        final_eval, batching_challenge); the combination, the evaluations and the fold/commit loop run on the device."""
+        point = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1, 4)
+        q, qinf, ev, fin, gam = lib.hyperkzg_batch_open(params._dev, polys, point)
+        return {"quotient_commitments": [(q[i], int(qinf[i])) for i in range(q.shape[0])], "evaluations": ev, "final_eval": fin,
+                "batching_challenge": gam}
+
+
 # ---- ZOLT v1 proof container: the commitments this backend produces
 def parse_zolt_proof_commitments(data):
     """Header of serializeProof (src/zkvm/serialization.zig:283-306): "ZOLT" | u32 version | bytecode proof

@@ -688,6 +688,61 @@ int zg_fr_spartan_combine(const uint64_t *eq, const uint64_t *az, const uint64_t
     return rc;
 }
 
+// The fold / quotient / commit loop of HyperKZG.open and batchOpen (src/poly/commitment/mod.zig:283-317, :684-712) on a table
+// already resident at d_a (n_evals entries; d_a, d_b: ping-pong buffers of >= n_evals and n_evals/2 entries, d_q: n_evals/2).
+// Quotient i is commit(cur[half..] - cur[..half]); levels the fold cannot reach (half == 0, :289 / :686) are reported as
+// identity and not counted in *n_quot.
+static int hk_open_device(zg_bases_t srs, uint64_t *d_a, uint64_t *d_b, uint64_t *d_q, size_t n_evals, const uint64_t *point,
+                          size_t num_vars, hipStream_t st, uint64_t *q_xy, uint8_t *q_inf, uint64_t final_eval[4], size_t *n_quot) {
+    size_t srs_len = zg_g1_bases_len(srs);
+    std::vector<uint64_t> h_res(9 * num_vars + 4, 0);
+    Scratch s_res((9 * num_vars + 4) * 8), s_misc(SC_MISC_BYTES);
+    if (!s_res.p || !s_misc.p) return ZG_ERR_NOMEM;
+    uint64_t *d_res = s_res.as<uint64_t>(), *d_misc = s_misc.as<uint64_t>();
+    hipError_t e = hipSuccess;
+    if (e == hipSuccess) e = hipMemsetAsync(d_res, 0, (9 * num_vars + 4) * 8, st);
+    if (e == hipSuccess) e = hipMemsetAsync(d_misc + 8 * (size_t)SC_MAX_BLOCKS, 0, 128, st);
+    int rc = ZG_OK;
+    size_t len = n_evals, computed = 0;
+    uint64_t *cur = d_a, *nxt = d_b;
+    for (size_t i = 0; i < num_vars && e == hipSuccess && rc == ZG_OK; i++) {
+        size_t half = len / 2;
+        if (half == 0) {  // the reference stops folding; remaining quotients stay unset -> identity here
+            for (size_t r = i; r < num_vars; r++) h_res[9 * r + 8] = 0x100;  // marker: identity
+            break;
+        }
+        unsigned nb = div_up(half, 256);
+        if (nb > 4096) nb = 4096;
+        hipLaunchKernelGGL(fr_sub_halves_kernel, dim3(nb), dim3(256), 0, st, cur, half, d_q);
+        size_t nc = half < srs_len ? half : srs_len;  // commit(): n = min(evals.len, srs.len), :246
+        rc = zg_msm_g1_dev_async(srs, 0, nc, d_q, st, d_res + 9 * i, reinterpret_cast<uint8_t *>(d_res + 9 * i + 8));
+        if (rc != ZG_OK) break;
+        computed++;
+        rc = launch_fold(ZG_SC_HIGH_HALF, cur, 2 * half, point + 4 * i, nxt, d_misc, d_misc + SC_SUMS_OFF, st);
+        uint64_t *t = cur; cur = nxt; nxt = t;
+        len = half;
+    }
+    if (e == hipSuccess && rc == ZG_OK && len > 0)
+        e = hipMemcpyAsync(d_res + 9 * num_vars, cur, 32, hipMemcpyDeviceToDevice, st);  // final = current[0], :317
+    std::vector<uint64_t> dev_res(9 * num_vars + 4);
+    if (e == hipSuccess && rc == ZG_OK) e = hipMemcpyAsync(dev_res.data(), d_res, (9 * num_vars + 4) * 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    else (void)hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        set_error(std::string("hyperkzg open: ") + hipGetErrorString(e));
+        return ZG_ERR_HIP;
+    }
+    if (rc != ZG_OK) return rc;
+    for (size_t i = 0; i < num_vars; i++) {
+        bool skipped = h_res[9 * i + 8] == 0x100;
+        for (int j = 0; j < 8; j++) q_xy[8 * i + j] = skipped ? 0 : dev_res[9 * i + j];
+        if (q_inf) q_inf[i] = skipped ? 1 : (uint8_t)(dev_res[9 * i + 8] & 0xff);
+    }
+    for (int j = 0; j < 4; j++) final_eval[j] = len > 0 ? dev_res[9 * num_vars + j] : 0;
+    if (n_quot) *n_quot = computed;
+    return ZG_OK;
+}
+
 int zg_hyperkzg_open(zg_bases_t srs, const uint64_t *evals, size_t n_evals, const uint64_t *point, size_t num_vars,
                      const uint64_t value[4], uint64_t *q_xy, uint8_t *q_inf, uint64_t final_eval[4]) {
     ZG_INIT();
@@ -700,54 +755,139 @@ int zg_hyperkzg_open(zg_bases_t srs, const uint64_t *evals, size_t n_evals, cons
         return ZG_OK;
     }
     hipStream_t st = lib_stream();
-    size_t srs_len = zg_g1_bases_len(srs);
     size_t cap = n_evals ? n_evals : 1;
-    std::vector<uint64_t> h_res(9 * num_vars + 4, 0);
-    Scratch s_a(cap * 32), s_b((cap / 2 + 1) * 32), s_q((cap / 2 + 1) * 32), s_res((9 * num_vars + 4) * 8), s_misc(SC_MISC_BYTES);
-    if (!s_a.p || !s_b.p || !s_q.p || !s_res.p || !s_misc.p) return ZG_ERR_NOMEM;
-    uint64_t *d_a = s_a.as<uint64_t>(), *d_b = s_b.as<uint64_t>(), *d_q = s_q.as<uint64_t>(), *d_res = s_res.as<uint64_t>(),
-             *d_misc = s_misc.as<uint64_t>();
-    hipError_t e = hipSuccess;
-    if (e == hipSuccess) e = hipMemsetAsync(d_res, 0, (9 * num_vars + 4) * 8, st);
-    if (e == hipSuccess) e = hipMemsetAsync(d_misc + 8 * (size_t)SC_MAX_BLOCKS, 0, 128, st);
-    if (e == hipSuccess && n_evals) e = hipMemcpyAsync(d_a, evals, n_evals * 32, hipMemcpyHostToDevice, st);
-    int rc = ZG_OK;
-    size_t len = n_evals;
-    uint64_t *cur = d_a, *nxt = d_b;
-    for (size_t i = 0; i < num_vars && e == hipSuccess && rc == ZG_OK; i++) {
-        size_t half = len / 2;
-        if (half == 0) {  // :289: the reference stops folding; remaining quotients stay unset -> identity here
-            for (size_t r = i; r < num_vars; r++) h_res[9 * r + 8] = 0x100;  // marker: identity
-            break;
+    Scratch s_a(cap * 32), s_b((cap / 2 + 1) * 32), s_q((cap / 2 + 1) * 32);
+    if (!s_a.p || !s_b.p || !s_q.p) return ZG_ERR_NOMEM;
+    if (n_evals) ZG_HIP(hipMemcpyAsync(s_a.p, evals, n_evals * 32, hipMemcpyHostToDevice, st));
+    return hk_open_device(srs, s_a.as<uint64_t>(), s_b.as<uint64_t>(), s_q.as<uint64_t>(), n_evals, point, num_vars, st, q_xy, q_inf,
+                          final_eval, nullptr);
+}
+
+// ---- HyperKZG.batchOpen (src/poly/commitment/mod.zig:607-732)
+// gpow[i] = gamma^i for i < k, gpow[k] = gamma;  gamma = fromU64(0x9a8b7c6d) * prod_j (point[j] + fromU64(11)), 0 -> 1 (:633-640)
+__global__ void hk_gamma_kernel(const uint64_t *point, uint32_t v, uint32_t k, uint64_t *gpow) {
+    Fr g = Fr::zero(), e11 = Fr::zero();
+    g.l[0] = 0x9a8b7c6du;
+    e11.l[0] = 11u;
+    g = fe_to_mont(g);
+    e11 = fe_to_mont(e11);
+    for (uint32_t j = 0; j < v; j++) g = fe_mul(g, fe_add(fe_load<FrParams>(point + 4 * j), e11));
+    if (fr_eq(g, Fr::zero())) g = Fr::one();
+    Fr pw = Fr::one();
+    for (uint32_t i = 0; i < k; i++) {
+        fe_store(gpow + 4 * (size_t)i, pw);
+        pw = fe_mul(pw, g);
+    }
+    fe_store(gpow + 4 * (size_t)k, g);
+}
+
+// out[j] (+)= g * p[j] for j < n_p; entries of out beyond n_p keep their value (zero on the first pass)  (:646-654)
+__global__ void __launch_bounds__(256) hk_axpy_kernel(uint64_t *out, size_t n_out, const uint64_t *p, size_t n_p, const uint64_t *g, int first) {
+    F29 gp = fr29_prescale(fe_load<FrParams>(g));
+    size_t stride = (size_t)gridDim.x * 256;
+    for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < n_out; j += stride) {
+        Fr acc = first ? Fr::zero() : fe_load<FrParams>(out + 4 * j);
+        if (j < n_p) acc = fe_add(acc, fr_mul29(fe_load<FrParams>(p + 4 * j), gp));
+        fe_store(out + 4 * j, acc);
+    }
+}
+
+// evaluateMultilinear's monomial sum (:796-813): sum_idx a[idx] * eq[idx & mask] (eq indexed LSB-first via the reversed point)
+__global__ void __launch_bounds__(256) hk_dot_mask_kernel(const uint64_t *a, size_t n, const uint64_t *eq, size_t mask, uint64_t *partials) {
+    __shared__ uint4 sh[256 * 4];
+    Fr g0 = Fr::zero(), g1 = Fr::zero();
+    size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+        g0 = fe_add(g0, fe_mul(fe_load<FrParams>(a + 4 * i), fe_load<FrParams>(eq + 4 * (i & mask))));
+    block_sum_pair(g0, g1, sh);
+    if (threadIdx.x == 0) {
+        fe_store(partials + 8 * (size_t)blockIdx.x, g0);
+        fe_store(partials + 8 * (size_t)blockIdx.x + 4, g1);
+    }
+}
+
+// combined_eval = sum_i gamma^i * evaluations[i] (:657-662)
+__global__ void hk_combined_eval_kernel(const uint64_t *evals, const uint64_t *gpow, uint32_t k, uint64_t *out) {
+    Fr acc = Fr::zero();
+    for (uint32_t i = 0; i < k; i++) acc = fe_add(acc, fe_mul(fe_load<FrParams>(gpow + 4 * (size_t)i), fe_load<FrParams>(evals + 4 * (size_t)i)));
+    fe_store(out, acc);
+}
+
+int zg_hyperkzg_batch_open(zg_bases_t srs, const uint64_t *const *polys, const size_t *lens, size_t k, const uint64_t *point,
+                           size_t num_vars, uint64_t *q_xy, uint8_t *q_inf, size_t *n_quot, uint64_t *evaluations,
+                           uint64_t final_eval[4], uint64_t gamma[4]) {
+    ZG_INIT();
+    if (!final_eval || !gamma || !n_quot || (k && (!polys || !lens || !evaluations)) || (num_vars && (!point || !q_xy)) || num_vars > 34) {
+        set_error("zg_hyperkzg_batch_open: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    *n_quot = 0;
+    if (k == 0) {  // :613-621
+        for (int i = 0; i < 4; i++) {
+            final_eval[i] = 0;
+            gamma[i] = (uint64_t)FrParams::ONE[2 * i] | ((uint64_t)FrParams::ONE[2 * i + 1] << 32);
         }
-        unsigned nb = div_up(half, 256);
+        return ZG_OK;
+    }
+    for (size_t i = 0; i < k; i++)
+        if (lens[i] && !polys[i]) {
+            set_error("zg_hyperkzg_batch_open: null polynomial");
+            return ZG_ERR_INVALID;
+        }
+    hipStream_t st = lib_stream();
+    size_t poly_size = lens[0], max_len = 1;
+    for (size_t i = 0; i < k; i++) max_len = lens[i] > max_len ? lens[i] : max_len;
+    size_t cap = poly_size ? poly_size : 1;
+    Scratch s_pt((num_vars + 1) * 32), s_g((k + 1) * 32), s_p(max_len * 32), s_a(cap * 32), s_b((cap / 2 + 1) * 32), s_q((cap / 2 + 1) * 32),
+        s_ev((k + 1) * 32), s_misc(SC_MISC_BYTES), s_eq(((size_t)1 << (num_vars <= 10 ? num_vars : 0)) * 32);
+    if (!s_pt.p || !s_g.p || !s_p.p || !s_a.p || !s_b.p || !s_q.p || !s_ev.p || !s_misc.p || !s_eq.p) return ZG_ERR_NOMEM;
+    uint64_t *d_pt = s_pt.as<uint64_t>(), *d_g = s_g.as<uint64_t>(), *d_p = s_p.as<uint64_t>(), *d_a = s_a.as<uint64_t>(),
+             *d_ev = s_ev.as<uint64_t>(), *d_misc = s_misc.as<uint64_t>(), *d_eq = s_eq.as<uint64_t>();
+    if (num_vars) ZG_HIP(hipMemcpyAsync(d_pt, point, num_vars * 32, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(hk_gamma_kernel, dim3(1), dim3(1), 0, st, d_pt, (uint32_t)num_vars, (uint32_t)k, d_g);
+    // evaluateMultilinear (:788-817): the direct sum only for point.len <= 10 and len <= 1024, else evals[0]; empty -> 0
+    bool any_small = false;
+    for (size_t i = 0; i < k; i++) any_small = any_small || (lens[i] && num_vars && num_vars <= 10 && lens[i] <= 1024);
+    if (any_small) {  // eq(point, .) with index bit j <-> point[j]: the big-endian table of the reversed point
+        std::vector<uint64_t> rev(4 * num_vars);
+        for (size_t j = 0; j < num_vars; j++)
+            for (int l = 0; l < 4; l++) rev[4 * j + l] = point[4 * (num_vars - 1 - j) + l];
+        ZG_TRY(eq_table_enqueue(rev.data(), num_vars, nullptr, d_eq, st));
+    }
+    std::vector<uint64_t> h_ev(4 * k, 0);
+    std::vector<char> on_dev(k, 0);
+    for (size_t i = 0; i < k; i++) {
+        if (lens[i]) ZG_HIP(hipMemcpyAsync(d_p, polys[i], lens[i] * 32, hipMemcpyHostToDevice, st));
+        unsigned nb = div_up(cap, 256);
         if (nb > 4096) nb = 4096;
-        hipLaunchKernelGGL(fr_sub_halves_kernel, dim3(nb), dim3(256), 0, st, cur, half, d_q);
-        size_t nc = half < srs_len ? half : srs_len;  // commit(): n = min(evals.len, srs.len), :246
-        rc = zg_msm_g1_dev_async(srs, 0, nc, d_q, st, d_res + 9 * i, reinterpret_cast<uint8_t *>(d_res + 9 * i + 8));
-        if (rc != ZG_OK) break;
-        rc = launch_fold(ZG_SC_HIGH_HALF, cur, 2 * half, point + 4 * i, nxt, d_misc, d_misc + SC_SUMS_OFF, st);
-        uint64_t *t = cur; cur = nxt; nxt = t;
-        len = half;
+        hipLaunchKernelGGL(hk_axpy_kernel, dim3(nb), dim3(256), 0, st, d_a, poly_size, d_p, lens[i] < poly_size ? lens[i] : poly_size,
+                           d_g + 4 * i, i == 0 ? 1 : 0);
+        if (lens[i] && num_vars && num_vars <= 10 && lens[i] <= 1024) {
+            unsigned nd = sc_blocks(lens[i]);
+            hipLaunchKernelGGL(hk_dot_mask_kernel, dim3(nd), dim3(256), 0, st, d_p, lens[i], d_eq, ((size_t)1 << num_vars) - 1, d_misc);
+            hipLaunchKernelGGL(sc_finish_kernel, dim3(1), dim3(256), 0, st, d_misc, nd, d_misc + SC_SUMS_OFF, (uint64_t *)nullptr, (uint64_t)0);
+            ZG_HIP(hipMemcpyAsync(d_ev + 4 * i, d_misc + SC_SUMS_OFF, 32, hipMemcpyDeviceToDevice, st));
+            on_dev[i] = 1;
+        } else if (lens[i]) {
+            for (int l = 0; l < 4; l++) h_ev[4 * i + l] = polys[i][l];  // point.len == 0 or the large-polynomial fallback: evals[0]
+        }
+        ZG_HIP(hipGetLastError());
+        ZG_HIP(hipStreamSynchronize(st));  // d_p is reused by the next polynomial
     }
-    if (e == hipSuccess && rc == ZG_OK && len > 0)
-        e = hipMemcpyAsync(d_res + 9 * num_vars, cur, 32, hipMemcpyDeviceToDevice, st);  // final = current[0], :317
-    std::vector<uint64_t> dev_res(9 * num_vars + 4);
-    if (e == hipSuccess && rc == ZG_OK) e = hipMemcpyAsync(dev_res.data(), d_res, (9 * num_vars + 4) * 8, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    else (void)hipStreamSynchronize(st);
-    if (e != hipSuccess) {
-        set_error(std::string("zg_hyperkzg_open: ") + hipGetErrorString(e));
-        return ZG_ERR_HIP;
+    std::vector<uint64_t> d2h(4 * (k + 1));
+    ZG_HIP(hipMemcpyAsync(d2h.data(), d_ev, 4 * 8 * k, hipMemcpyDeviceToHost, st));
+    ZG_HIP(hipMemcpyAsync(gamma, d_g + 4 * k, 32, hipMemcpyDeviceToHost, st));
+    ZG_HIP(hipStreamSynchronize(st));
+    for (size_t i = 0; i < k; i++)
+        for (int l = 0; l < 4; l++) evaluations[4 * i + l] = on_dev[i] ? d2h[4 * i + l] : h_ev[4 * i + l];
+    if (num_vars == 0) {  // :665-673: no quotients, final_eval = combined_eval
+        ZG_HIP(hipMemcpyAsync(d_ev, evaluations, 4 * 8 * k, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(hk_combined_eval_kernel, dim3(1), dim3(1), 0, st, d_ev, d_g, (uint32_t)k, d_ev + 4 * k);
+        ZG_HIP(hipMemcpyAsync(final_eval, d_ev + 4 * k, 32, hipMemcpyDeviceToHost, st));
+        ZG_HIP(hipStreamSynchronize(st));
+        return ZG_OK;
     }
-    if (rc != ZG_OK) return rc;
-    for (size_t i = 0; i < num_vars; i++) {
-        bool skipped = h_res[9 * i + 8] == 0x100;
-        for (int j = 0; j < 8; j++) q_xy[8 * i + j] = skipped ? 0 : dev_res[9 * i + j];
-        if (q_inf) q_inf[i] = skipped ? 1 : (uint8_t)(dev_res[9 * i + 8] & 0xff);
-    }
-    for (int j = 0; j < 4; j++) final_eval[j] = len > 0 ? dev_res[9 * num_vars + j] : 0;
-    return ZG_OK;
+    return hk_open_device(srs, d_a, s_b.as<uint64_t>(), s_q.as<uint64_t>(), poly_size, point, num_vars, st, q_xy, q_inf, final_eval, n_quot);
 }
 
 // ---------------------------------------------------------------- runSumcheck, device-resident

@@ -246,6 +246,13 @@ struct DensePolynomial {  // src/poly/mod.zig:23-182
         while ((size_t(1) << num_vars) < n) num_vars++;
     }
     size_t len() const { return evaluations.size(); }
+    Fr evaluate(const std::vector<Fr> &point) const {  // :73-92, index bit j <-> point[j]
+        if (point.size() != num_vars) throw std::invalid_argument("evaluate: point length != num_vars");
+        Fr out;
+        check(zg_fr_dense_evaluate(reinterpret_cast<const uint64_t *>(evaluations.data()), num_vars,
+                                   reinterpret_cast<const uint64_t *>(point.data()), out.limbs), "zg_fr_dense_evaluate");
+        return out;
+    }
     DensePolynomial bindFirst(const Fr &value) const {  // :128-149
         if (num_vars == 0) throw std::invalid_argument("bindFirst: num_vars == 0");
         std::vector<Fr> out(evaluations.size() / 2);
@@ -322,6 +329,35 @@ struct HyperKZG {
                                reinterpret_cast<const uint64_t *>(point.data()), v, value.limbs, q.data(), qi.data(), pr.final_eval.limbs),
               "zg_hyperkzg_open");
         for (size_t i = 0; i < v; i++) pr.quotient_commitments.push_back(Commitment{unpack_point(&q[8 * i], qi[i])});
+        return pr;
+    }
+    struct BatchProof {  // :577-596
+        std::vector<Commitment> quotient_commitments;
+        std::vector<Fr> evaluations;
+        Fr final_eval;
+        Fr batching_challenge;
+    };
+    // batchOpen(params, polys, point) — :607-732: combination, evaluations and the fold/commit loop on the device
+    static BatchProof batchOpen(const SetupParams &params, const std::vector<std::vector<Fr>> &polys, const std::vector<Fr> &point) {
+        BatchProof pr;
+        size_t k = polys.size(), v = point.size(), nq = 0;
+        std::vector<const uint64_t *> ptrs(k ? k : 1, nullptr);
+        std::vector<size_t> lens(k ? k : 1, 0);
+        for (size_t i = 0; i < k; i++) {
+            ptrs[i] = reinterpret_cast<const uint64_t *>(polys[i].data());
+            lens[i] = polys[i].size();
+        }
+        std::vector<uint64_t> q(8 * (v ? v : 1)), ev(4 * (k ? k : 1));
+        std::vector<uint8_t> qi(v ? v : 1);
+        check(zg_hyperkzg_batch_open(params.device->handle(), ptrs.data(), lens.data(), k, reinterpret_cast<const uint64_t *>(point.data()), v,
+                                     q.data(), qi.data(), &nq, ev.data(), pr.final_eval.limbs, pr.batching_challenge.limbs),
+              "zg_hyperkzg_batch_open");
+        for (size_t i = 0; i < nq; i++) pr.quotient_commitments.push_back(Commitment{unpack_point(&q[8 * i], qi[i])});
+        for (size_t i = 0; i < k; i++) {
+            Fr e;
+            std::memcpy(e.limbs, &ev[4 * i], 32);
+            pr.evaluations.push_back(e);
+        }
         return pr;
     }
     static std::vector<Commitment> batchCommit(const SetupParams &params, const std::vector<std::vector<Fr>> &polys) {  // :558-570

@@ -30,7 +30,7 @@ SYMBOLS = [
     "zg_g1_bases_upload", "zg_g1_bases_upload_dev", "zg_g1_bases_free", "zg_g1_bases_len",
     "zg_msm_g1", "zg_msm_g1_dev", "zg_msm_g1_dev_async", "zg_msm_g1_batch", "zg_msm_g1_batch_dev", "zg_msm_g1_partial_dev", "zg_msm_g1_partial_fast_dev",
     "zg_g1_combine_partials_dev", "zg_g1_combine_partials_dev_async", "zg_g1_is_on_curve_batch", "zg_g1_scalar_mul_batch",
-    "zg_hyperkzg_open",
+    "zg_hyperkzg_open", "zg_hyperkzg_batch_open",
     "zg_fr_dense_evaluate", "zg_fr_eq_table", "zg_fr_eq_table_dev", "zg_fr_bind_low", "zg_fr_bind_high",
     "zg_fr_spartan_combine", "zg_fr_spartan_combine_dev",
     "zg_sumcheck_open", "zg_sumcheck_open_dev", "zg_sumcheck_round_sums", "zg_sumcheck_bind",
@@ -258,6 +258,24 @@ def hyperkzg_open(bases, evals, point, value):
     _chk(_lib.zg_hyperkzg_open(bases._h, _h(evals), C.c_size_t(evals.size // 4), _h(point), C.c_size_t(v), _h(value), _h(q),
                                _hb(qinf), _h(fin)), "zg_hyperkzg_open")
     return q, qinf, fin
+
+
+def hyperkzg_batch_open(bases, polys, point):
+    """HyperKZG.batchOpen -> (quotient xy[nq,8], inf[nq], evaluations[k,4], final_eval, gamma)."""
+    polys = [_c(p) for p in polys]
+    point = _c(point)
+    k, v = len(polys), point.size // 4
+    ptrs = (C.c_void_p * max(k, 1))(*[p.ctypes.data if p.size else None for p in polys])
+    lens = (C.c_size_t * max(k, 1))(*[p.size // 4 for p in polys])
+    q = np.zeros((max(v, 1), 8), dtype=np.uint64)
+    qi = np.zeros(max(v, 1), dtype=np.uint8)
+    nq = C.c_size_t(0)
+    ev = np.zeros((max(k, 1), 4), dtype=np.uint64)
+    fin = np.zeros(4, dtype=np.uint64)
+    gam = np.zeros(4, dtype=np.uint64)
+    _chk(_lib.zg_hyperkzg_batch_open(bases._h, ptrs, lens, C.c_size_t(k), _h(point), C.c_size_t(v), _h(q), _hb(qi), C.byref(nq), _h(ev),
+                                     _h(fin), _h(gam)), "zg_hyperkzg_batch_open")
+    return q[:nq.value], qi[:nq.value], ev[:k], fin, gam
 
 
 # ---- poly
