@@ -89,6 +89,55 @@ def test_hyperkzg_batch_open(env, srs_n, lens, v):
     params.deinit()
 
 
+def _ptau(sections):
+    out = b"ptau" + (1).to_bytes(4, "little") + len(sections).to_bytes(4, "little")
+    for typ, payload in sections:
+        out += typ.to_bytes(4, "little") + len(payload).to_bytes(8, "little") + payload
+    return out
+
+
+def test_srs_ptau_loader(env):
+    """loadFromPtau's G1 side (src/poly/commitment/srs.zig:733-900) with the reference's own test shapes (:935-1000): header-only
+    file -> power / ceremony power; bad magic -> InvalidFileFormat; 4 bytes -> TruncatedData; a G1 record is x | y little-endian;
+    plus TauG1 / AlphaTauG1 sections of real points, an infinity record, a count capped by the power, and a point off the curve."""
+    api, lib, ob = env
+    hdr = (32).to_bytes(4, "little") + bytes(32) + (2).to_bytes(4, "little") + (2).to_bytes(4, "little")
+    got = api.srs_g1_from_ptau(_ptau([(1, hdr)]))
+    assert got["power"] == 2 and got["ceremony_power"] == 2 and got["powers_of_tau_g1"][0].shape == (0, 8)
+    with pytest.raises(api.SRSError, match="InvalidFileFormat"):
+        api.srs_g1_from_ptau(bytes(24))
+    with pytest.raises(api.SRSError, match="TruncatedData"):
+        api.srs_g1_from_ptau(b"ptau")
+    with pytest.raises(api.SRSError, match="UnsupportedFormat"):
+        api.srs_g1_from_ptau(b"ptau" + (2).to_bytes(4, "little") + bytes(8))
+    # points: canonical little-endian coordinates of (i+1)G; record 3 is the identity
+    gm = ob.g1_gen_multiples(9)
+    canon = ob.f_from_mont(ob.FP, gm.reshape(-1, 4)).reshape(9, 8)
+    recs = [canon[i].tobytes() for i in range(9)]
+    recs[3] = bytes(64)
+    tau = b"".join(recs)
+    got = api.srs_g1_from_ptau(_ptau([(1, hdr), (2, tau), (4, b"".join(recs[:4])), (3, bytes(128 * 5)), (6, bytes(128))]))
+    xy, inf = got["powers_of_tau_g1"]
+    assert xy.shape == (7, 8)  # min(2*2^2 - 1, 9)
+    want = gm[:7].copy()
+    want[3] = 0
+    assert np.array_equal(xy, want) and list(inf) == [0, 0, 0, 1, 0, 0, 0]
+    axy, ainf = got["alpha_tau_g1"]
+    assert axy.shape == (4, 8) and np.array_equal(axy[:3], gm[:3]) and ainf[3] == 1 and got["beta_tau_g1"] is None
+    assert len(got["tau_g2_raw"]) == 640 and len(got["beta_g2_raw"]) == 128
+    # the loaded points are a usable SRS: commit with them
+    params = api.HyperKZG.SetupParams(xy, inf)
+    ev = _rand(ob, 77, 7)
+    c, ci = api.HyperKZG.commit(params, ev)
+    w, wi = ob.hyperkzg_commit(xy, inf, ev)
+    assert ci == wi and np.array_equal(c, w)
+    params.deinit()
+    bad = bytearray(tau)
+    bad[64] ^= 1  # x of the second point
+    with pytest.raises(api.SRSError, match="PointNotOnCurve"):
+        api.srs_g1_from_ptau(_ptau([(1, hdr), (2, bytes(bad))]))
+
+
 def test_poly_classes_and_run_sumcheck(env):
     api, lib, ob = env
     ev = _rand(ob, 20, 256)

@@ -297,6 +297,71 @@ def srs_g1_from_raw(data):
     return xy, inf, bytes(data[4 + 64 * n:])
 
 
+PTAU_MAGIC = b"ptau"
+_PTAU_HEADER, _PTAU_TAU_G1, _PTAU_TAU_G2, _PTAU_ALPHA_G1, _PTAU_BETA_G1, _PTAU_BETA_G2 = 1, 2, 3, 4, 5, 6
+
+
+def _g1_from_le(sec, count):
+    """parseG1LE (src/poly/commitment/srs.zig:616-660) over `count` 64-byte records: x | y as little-endian integers
+    (reduced like Fp.fromBytesBE of the reversed bytes), all-zero = infinity, every other point checked on the curve.
+    Conversion to Montgomery form and the curve check run on the GPU."""
+    body = np.frombuffer(sec, dtype=np.uint8, count=64 * count).reshape(count, 64)
+    inf = (~body.any(axis=1)).astype(np.uint8)
+    raw = np.ascontiguousarray(body).view(np.uint64).reshape(count, 8)  # LE bytes are already LE limbs
+    xy = lib.field_op(lib.FP, lib.OP_TO_MONT, raw.reshape(2 * count, 4)).reshape(count, 8) if count else np.zeros((0, 8), dtype=np.uint64)
+    xy[inf == 1] = 0
+    if count and not lib.g1_is_on_curve_batch(xy, inf).all():
+        raise SRSError("PointNotOnCurve")
+    return xy, inf
+
+
+def srs_g1_from_ptau(data):
+    """G1 side of loadFromPtau (src/poly/commitment/srs.zig:733-900, snarkjs powers-of-tau container): "ptau" | u32 version
+    (= 1) | u32 sections | sections (u32 type, u64 size, payload). Header payload: u32 field size (= 32) | 32-byte prime |
+    u32 power | u32 ceremony power. TauG1 holds min(2*2^power - 1, size/64) points, AlphaTauG1 / BetaTauG1 min(2^power,
+    size/64). The G2 sections (pairing side, out of scope) are returned as raw bytes.
+    -> dict(power, ceremony_power, powers_of_tau_g1=(xy, inf), alpha_tau_g1, beta_tau_g1 (or None), tau_g2_raw, beta_g2_raw)"""
+    if len(data) < 12:
+        raise SRSError("TruncatedData")
+    if data[:4] != PTAU_MAGIC:
+        raise SRSError("InvalidFileFormat")
+    if int.from_bytes(data[4:8], "little") != 1:
+        raise SRSError("UnsupportedFormat")
+    nsec = int.from_bytes(data[8:12], "little")
+    off, secs = 12, {}
+    for _ in range(nsec):
+        if off + 12 > len(data):
+            raise SRSError("TruncatedData")
+        typ = int.from_bytes(data[off:off + 4], "little")
+        size = int.from_bytes(data[off + 4:off + 12], "little")
+        off += 12
+        if off + size > len(data):
+            raise SRSError("TruncatedData")
+        secs[typ] = data[off:off + size]  # a later section of the same type wins, as in the reference's scan
+        off += size
+    if _PTAU_HEADER not in secs:
+        raise SRSError("InvalidFileFormat")
+    hdr = secs[_PTAU_HEADER]
+    if len(hdr) < 8:
+        raise SRSError("TruncatedData")
+    if int.from_bytes(hdr[:4], "little") != 32:
+        raise SRSError("UnsupportedFormat")
+    if len(hdr) < 44:
+        raise SRSError("TruncatedData")
+    power = int.from_bytes(hdr[36:40], "little")
+    out = {"power": power, "ceremony_power": int.from_bytes(hdr[40:44], "little"),
+           "powers_of_tau_g1": (np.zeros((0, 8), dtype=np.uint64), np.zeros(0, dtype=np.uint8)),
+           "alpha_tau_g1": None, "beta_tau_g1": None,
+           "tau_g2_raw": bytes(secs.get(_PTAU_TAU_G2, b"")), "beta_g2_raw": bytes(secs.get(_PTAU_BETA_G2, b""))}
+    if _PTAU_TAU_G1 in secs:
+        sec = secs[_PTAU_TAU_G1]
+        out["powers_of_tau_g1"] = _g1_from_le(sec, min((1 << power) * 2 - 1, len(sec) // 64))
+    for key, typ in (("alpha_tau_g1", _PTAU_ALPHA_G1), ("beta_tau_g1", _PTAU_BETA_G1)):
+        if typ in secs:
+            out[key] = _g1_from_le(secs[typ], min(1 << power, len(secs[typ]) // 64))
+    return out
+
+
 def srs_g1_to_raw(xy, inf, trailer=bytes(128 + 64 + 128)):
     """serializeToRawBinary's G1 section (src/poly/commitment/srs.zig:358-408): toBytesBE of x and y."""
     xy = np.ascontiguousarray(xy, dtype=np.uint64).reshape(-1, 8)
