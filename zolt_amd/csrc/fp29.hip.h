@@ -64,6 +64,9 @@ struct Fr29 {
     static constexpr u32 P[9] = {0x10000001u, 0x1f0fac9fu, 0x0e5c2450u, 0x07d090f3u, 0x1585d283u,
                                  0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
     static constexpr u32 NINV = 0x0fffffffu;  // -r^-1 mod 2^29
+    // fr29_prescale(R^2 mod r): fr_mul29(x, R2PRE) = x * R^2 * 2^-256 = toMontgomery(x)
+    static constexpr u32 R2PRE[9] = {0x142db4dfu, 0x19d6990eu, 0x1472f48cu, 0x06dbe7e3u, 0x0b84d579u,
+                                     0x10f9faf7u, 0x121f4380u, 0x17a112deu, 0x001275c7u};
 };
 
 // Montgomery product a*b*2^-261 mod p (lazy): limbs of a, b < 2^30; output limbs exactly < 2^29,

@@ -176,7 +176,7 @@ ZG_DEV bool fr_eq(const Fr &a, const Fr &b) {
 
 // Verifier.verifyRound for the round polynomial [g0, g1 - g0]: check, derive the challenge, update the claim.
 // One thread. With `init` the claim is first set to g0 + g1 (runSumcheck's initial sum over the hypercube).
-ZG_DEV Fr sc_verifier_step(const ScRunArg &a, const Fr &g0, const Fr &g1) {
+ZG_DEV Fr sc_verifier_step(const ScRunArg &a, const Fr &g0, const Fr &g1, F29 *ch_pre = nullptr) {
     uint64_t *res = a.res;
     Fr sum = fe_add(g0, g1);
     Fr claim;
@@ -209,8 +209,14 @@ ZG_DEV Fr sc_verifier_step(const ScRunArg &a, const Fr &g0, const Fr &g1) {
     Fr hv = Fr::zero();
     hv.l[0] = (uint32_t)h;
     hv.l[1] = (uint32_t)(h >> 32);
-    Fr ch = fe_to_mont(hv);                      // F.fromU64
-    Fr next = fe_add(fe_mul(c1, ch), g0);        // UniPoly.evaluate by Horner: c1 * x + c0
+    // both products through the carry-free 29-bit-limb multiplier (this single-lane chain is the floor of a small round)
+    F29 r2p;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r2p.l[i] = Fr29::R2PRE[i];
+    Fr ch = fr_mul29(hv, r2p);                   // F.fromU64: h * R^2 * R^-1
+    F29 chp = fr29_prescale(ch);                 // also the shared factor of the fold that follows
+    Fr next = fe_add(fr_mul29(c1, chp), g0);     // UniPoly.evaluate by Horner: c1 * x + c0
+    if (ch_pre) *ch_pre = chp;
     fe_store(res + 4 + 8 * (size_t)a.round, g0);
     fe_store(res + 8 + 8 * (size_t)a.round, c1);
     fe_store(res + run_off_chal(a.v) + 4 * (size_t)a.round, ch);
@@ -350,13 +356,13 @@ constexpr uint32_t SC_TAIL_MAX = 4096;
 __global__ void __launch_bounds__(256) sc_tail_run_kernel(const uint64_t *t, uint32_t len, ScRunArg run) {
     extern __shared__ uint4 lds_tab[];          // len entries of 2 x uint4, then 16 uint4 of reduction scratch + 2 for the challenge
     uint4 *sh = lds_tab + 2 * (size_t)len;
+    uint32_t *sh_rp = reinterpret_cast<uint32_t *>(sh + 16);  // the prescaled challenge (9 limbs), written by lane 0
     uint32_t tid = threadIdx.x;
     for (uint32_t i = tid; i < len; i += 256) fe_store(&lds_tab[2 * i], fe_load<FrParams>(t + 4 * (size_t)i));
-    Fr ch = fe_load<FrParams>(run.res + run_off_cur(run.v));
+    F29 rp = fr29_prescale(fe_load<FrParams>(run.res + run_off_cur(run.v)));
     __syncthreads();
     while (len > 1) {
         uint32_t half = len / 2, quarter = half / 2;
-        F29 rp = fr29_prescale(ch);
         Fr g0 = Fr::zero(), g1 = Fr::zero();
         for (uint32_t i = tid; i < half; i += 256) {
             Fr lo = fe_load<FrParams>(&lds_tab[2 * i]), hi = fe_load<FrParams>(&lds_tab[2 * (i + half)]);
@@ -369,12 +375,15 @@ __global__ void __launch_bounds__(256) sc_tail_run_kernel(const uint64_t *t, uin
         if (len == 1) break;
         block_sum_pair(g0, g1, sh);
         if (tid == 0) {
-            Fr c = sc_verifier_step(run, g0, g1);
-            fe_store(&sh[16], c);
+            F29 cp;
+            (void)sc_verifier_step(run, g0, g1, &cp);
+#pragma unroll
+            for (int i = 0; i < 9; i++) sh_rp[i] = cp.l[i];
         }
         run.round++;
         __syncthreads();
-        ch = fe_load<FrParams>(&sh[16]);
+#pragma unroll
+        for (int i = 0; i < 9; i++) rp.l[i] = sh_rp[i];
         __syncthreads();  // sh is rewritten by the next round's reduction
     }
     if (tid == 0) {
@@ -946,10 +955,10 @@ static int run_sumcheck_enqueue(const uint64_t *d_evals, size_t len, hipStream_t
         static hipError_t attr_err = hipSuccess;
         std::call_once(once, [] {
             attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(sc_tail_run_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)(SC_TAIL_MAX * 32 + 18 * 16));
+                                           (int)(SC_TAIL_MAX * 32 + 20 * 16));
         });
         ZG_HIP(attr_err);
-        hipLaunchKernelGGL(sc_tail_run_kernel, dim3(1), dim3(256), cl * 32 + 18 * 16, st, cur, (uint32_t)cl, ScRunArg{d_res, v, k + 1, 0});
+        hipLaunchKernelGGL(sc_tail_run_kernel, dim3(1), dim3(256), cl * 32 + 20 * 16, st, cur, (uint32_t)cl, ScRunArg{d_res, v, k + 1, 0});
         ZG_HIP(hipGetLastError());
     }
     std::vector<uint64_t> h(res_words);
