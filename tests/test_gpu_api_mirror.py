@@ -89,6 +89,25 @@ def test_hyperkzg_batch_open(env, srs_n, lens, v):
     params.deinit()
 
 
+@pytest.mark.parametrize("v,srs_n", [(13, 8192), (15, 32768), (12, 1000), (14, 16384)])
+def test_hyperkzg_open_mid_sizes(env, v, srs_n):
+    """open() at sizes where the short quotient commits are batched: a small-window SRS handle fuses them into one launch set
+    (v = 13, 14), a 2^15-point handle (16-bit windows) takes the unfused rotation, and an SRS shorter than the table clamps
+    every commit to its length (src/poly/commitment/mod.zig:246). Quotients and final evaluation equal the oracle's."""
+    api, lib, ob = env
+    gm = ob.g1_gen_multiples(srs_n)
+    inf = np.zeros(srs_n, dtype=np.uint8)
+    params = api.HyperKZG.SetupParams(gm, inf)
+    ev = _rand(ob, 600 + v, 1 << v)
+    pt = _rand(ob, 650 + v, v)
+    quotients, final = api.HyperKZG.open(params, ev, pt, np.zeros(4, dtype=np.uint64))
+    wq, wqi, wfin = ob.hyperkzg_open(gm, inf, ev, pt, np.zeros(4, dtype=np.uint64))
+    assert np.array_equal(final, wfin) and len(quotients) == v
+    for i, (q, qi) in enumerate(quotients):
+        assert qi == wqi[i] and np.array_equal(q, wq[i]), i
+    params.deinit()
+
+
 def _ptau(sections):
     out = b"ptau" + (1).to_bytes(4, "little") + len(sections).to_bytes(4, "little")
     for typ, payload in sections:

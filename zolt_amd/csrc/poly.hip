@@ -85,9 +85,9 @@ __global__ void __launch_bounds__(256) eq_main_kernel(const uint64_t *lo_tab, in
 }
 
 // q[j] = t[j + half] - t[j]   (HyperKZG.open's quotient, src/poly/commitment/mod.zig:296-299)
-__global__ void __launch_bounds__(256) fr_sub_halves_kernel(const uint64_t *t, size_t half, uint64_t *q) {
+__global__ void __launch_bounds__(256) fr_sub_halves_kernel(const uint64_t *t, size_t half, uint64_t *q, size_t count) {
     size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < half; j += stride)
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < count; j += stride)
         fe_store(q + 4 * j, fe_sub(fe_load<FrParams>(t + 4 * (j + half)), fe_load<FrParams>(t + 4 * j)));
 }
 
@@ -705,14 +705,35 @@ static int hk_open_device(zg_bases_t srs, uint64_t *d_a, uint64_t *d_b, uint64_t
                           size_t num_vars, hipStream_t st, uint64_t *q_xy, uint8_t *q_inf, uint64_t final_eval[4], size_t *n_quot) {
     size_t srs_len = zg_g1_bases_len(srs);
     std::vector<uint64_t> h_res(9 * num_vars + 4, 0);
-    Scratch s_res((9 * num_vars + 4) * 8), s_misc(SC_MISC_BYTES);
-    if (!s_res.p || !s_misc.p) return ZG_ERR_NOMEM;
-    uint64_t *d_res = s_res.as<uint64_t>(), *d_misc = s_misc.as<uint64_t>();
+    // Levels whose quotient has at most HK_SMALL entries are committed TOGETHER at the end: their quotients are written
+    // into rows of one zero-padded matrix (a zero scalar contributes no digit, so commit(q) over bases[0..row length) is
+    // unchanged) and handed to zg_msm_g1_batch_dev, which fuses short vectors into one launch set — a lone short MSM is
+    // ~0.4 ms of launch latency, and there are log2(HK_SMALL) + 1 of them.
+    const size_t HK_SMALL = 4096;
+    size_t small_rows = 0, small_len = 0;
+    {
+        size_t len = n_evals;
+        for (size_t i = 0; i < num_vars; i++) {
+            size_t half = len / 2;
+            if (half == 0) break;
+            size_t nc = half < srs_len ? half : srs_len;
+            if (nc <= HK_SMALL) {
+                if (small_rows == 0) small_len = nc;
+                small_rows++;
+            }
+            len = half;
+        }
+        if (small_rows < 2) small_rows = 0;  // nothing to fuse
+    }
+    Scratch s_res((9 * num_vars + 4) * 8), s_misc(SC_MISC_BYTES), s_small((small_rows * small_len + 1) * 32);
+    if (!s_res.p || !s_misc.p || !s_small.p) return ZG_ERR_NOMEM;
+    uint64_t *d_res = s_res.as<uint64_t>(), *d_misc = s_misc.as<uint64_t>(), *d_small = s_small.as<uint64_t>();
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = hipMemsetAsync(d_res, 0, (9 * num_vars + 4) * 8, st);
     if (e == hipSuccess) e = hipMemsetAsync(d_misc + 8 * (size_t)SC_MAX_BLOCKS, 0, 128, st);
+    if (e == hipSuccess && small_rows) e = hipMemsetAsync(d_small, 0, small_rows * small_len * 32, st);
     int rc = ZG_OK;
-    size_t len = n_evals, computed = 0;
+    size_t len = n_evals, computed = 0, first_small = num_vars, row = 0;
     uint64_t *cur = d_a, *nxt = d_b;
     for (size_t i = 0; i < num_vars && e == hipSuccess && rc == ZG_OK; i++) {
         size_t half = len / 2;
@@ -722,15 +743,24 @@ static int hk_open_device(zg_bases_t srs, uint64_t *d_a, uint64_t *d_b, uint64_t
         }
         unsigned nb = div_up(half, 256);
         if (nb > 4096) nb = 4096;
-        hipLaunchKernelGGL(fr_sub_halves_kernel, dim3(nb), dim3(256), 0, st, cur, half, d_q);
         size_t nc = half < srs_len ? half : srs_len;  // commit(): n = min(evals.len, srs.len), :246
-        rc = zg_msm_g1_dev_async(srs, 0, nc, d_q, st, d_res + 9 * i, reinterpret_cast<uint8_t *>(d_res + 9 * i + 8));
-        if (rc != ZG_OK) break;
+        if (small_rows && nc <= HK_SMALL) {
+            if (first_small == num_vars) first_small = i;
+            // only the first nc entries are committed; the row keeps zeros beyond them
+            hipLaunchKernelGGL(fr_sub_halves_kernel, dim3(div_up(nc, 256)), dim3(256), 0, st, cur, half, d_small + 4 * small_len * row, nc);
+            row++;
+        } else {
+            hipLaunchKernelGGL(fr_sub_halves_kernel, dim3(nb), dim3(256), 0, st, cur, half, d_q, half);
+            rc = zg_msm_g1_dev_async(srs, 0, nc, d_q, st, d_res + 9 * i, reinterpret_cast<uint8_t *>(d_res + 9 * i + 8));
+            if (rc != ZG_OK) break;
+        }
         computed++;
         rc = launch_fold(ZG_SC_HIGH_HALF, cur, 2 * half, point + 4 * i, nxt, d_misc, d_misc + SC_SUMS_OFF, st);
         uint64_t *t = cur; cur = nxt; nxt = t;
         len = half;
     }
+    if (e == hipSuccess && rc == ZG_OK && row)  // rows are consecutive levels first_small, first_small + 1, ...
+        rc = zg_msm_g1_batch_dev(srs, small_len, d_small, row, st, d_res + 9 * first_small);
     if (e == hipSuccess && rc == ZG_OK && len > 0)
         e = hipMemcpyAsync(d_res + 9 * num_vars, cur, 32, hipMemcpyDeviceToDevice, st);  // final = current[0], :317
     std::vector<uint64_t> dev_res(9 * num_vars + 4);
