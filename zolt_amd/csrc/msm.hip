@@ -89,6 +89,10 @@ struct zg_bases_s {
     // long vectors are not fused: they rotate over the caller's stream and two forked helper streams instead
     hipStream_t aux[2] = {nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    // Wide-window handles (2^15 buckets) also keep a narrow-window table of their first SIDE_TABLE_POINTS bases: MSMs over a
+    // short prefix (HyperKZG.commit of a short polynomial on a long SRS, HyperKZG.open's last levels) then sort into 2^7
+    // buckets instead of 2^15, and batches of them can be fused into one launch set. Same results, by construction.
+    zg_bases_s *small = nullptr;
     uint64_t *d_out = nullptr;  // 16 x u64: result record + flag
     uint64_t *h_out = nullptr;  // pinned mirror
     std::mutex mu;
@@ -845,6 +849,7 @@ static hipError_t lane_alloc(zg_bases_s::Lane &ln, const MsmPlan &p, size_t n_to
 
 static void free_bases(zg_bases_s *b) {
     if (!b) return;
+    free_bases(b->small);
     void *ptrs[] = {b->d_table, b->d_inf, b->d_scal, b->d_out};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -868,6 +873,8 @@ static void free_bases(zg_bases_s *b) {
             return _e == hipErrorOutOfMemory ? ZG_ERR_NOMEM : ZG_ERR_HIP;            \
         }                                                                            \
     } while (0)
+
+static constexpr size_t SIDE_TABLE_POINTS = 16384;
 
 static int bases_create(const uint64_t *d_xy, const uint8_t *d_inf_in, size_t n, const zg_msm_config *cfg, hipStream_t st,
                         zg_bases_t *out) {
@@ -920,6 +927,14 @@ static int bases_create(const uint64_t *d_xy, const uint8_t *d_inf_in, size_t n,
         ZG_HIP(hipGetLastError());
     }
     ZG_HIP(hipStreamSynchronize(st));
+    if ((size_t)p.NB * p.G > 4096 && n > SIDE_TABLE_POINTS && env_int("ZG_MSM_SIDE_TABLE", 1)) {
+        zg_msm_config small_cfg{8, 0};
+        int src = bases_create(d_xy, d_inf_in, SIDE_TABLE_POINTS, &small_cfg, st, &b->small);
+        if (src != ZG_OK) {
+            free_bases(b);
+            return src;
+        }
+    }
     *out = b;
     return ZG_OK;
 }
@@ -982,6 +997,7 @@ static int msm_enqueue(zg_bases_s *b, size_t off, size_t n, const uint64_t *d_sc
         ZG_HIP(hipGetLastError());
         return ZG_OK;
     }
+    if (b->small && off + n <= b->small->n) return msm_enqueue(b->small, off, n, d_scalars, st, mode, d_rec, d_inf_out);  // short prefix
     zg_bases_s::Lane &ln = b->lanes[b->next_lane];
     b->next_lane = (b->next_lane + 1) % b->lanes.size();
     return msm_enqueue_lane(b, b->plan, ln, b->nblk, off, n, d_scalars, st, mode, d_rec, d_inf_out, 0, 0);
@@ -1208,6 +1224,7 @@ static int msm_batch_enqueue(zg_bases_s *b, size_t n, const uint64_t *d_scalars,
         set_error("msm: range exceeds uploaded bases");
         return ZG_ERR_INVALID;
     }
+    if (b->small && n <= b->small->n) return msm_batch_enqueue(b->small, n, d_scalars, k, st, d_out9);  // narrow-window side table
     size_t lim = batch_fuse_limit(b, n);
     if (lim == 0 || k < 2) {
         // one launch set per vector, rotating through the handle's workspaces AND through three streams (the caller's

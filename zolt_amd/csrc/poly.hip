@@ -709,7 +709,7 @@ static int hk_open_device(zg_bases_t srs, uint64_t *d_a, uint64_t *d_b, uint64_t
     // into rows of one zero-padded matrix (a zero scalar contributes no digit, so commit(q) over bases[0..row length) is
     // unchanged) and handed to zg_msm_g1_batch_dev, which fuses short vectors into one launch set — a lone short MSM is
     // ~0.4 ms of launch latency, and there are log2(HK_SMALL) + 1 of them.
-    const size_t HK_SMALL = 4096;
+    const size_t HK_SMALL = 8192;
     size_t small_rows = 0, small_len = 0;
     {
         size_t len = n_evals;
