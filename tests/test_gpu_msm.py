@@ -288,10 +288,12 @@ def test_srs_and_reference_proof_commitment(zl, ob, golden_dir):
     assert list(oinf) == [1, 0, 1] and np.array_equal(out[1], g[0]) and not out[0].any() and not out[2].any()
 
 
-@pytest.mark.parametrize("n", [1 << 20, (1 << 20) + 1])
+@pytest.mark.parametrize("n", [1 << 20, (1 << 20) + 1, 1 << 22])
 def test_full_size_closed_form(zl, ob, n):
-    """BASELINE config 2 (2^20 points, one GPU) and the 2^20 + 1 member of SURVEY §8(d)'s adversarial size set:
-    uniform scalars; the result must equal the size-independent closed form (sum s_i (i+1) mod r)·G."""
+    """BASELINE config 2 (2^20 points, one GPU), the 2^20 + 1 member of SURVEY §8(d)'s adversarial size set and the metric's
+    second size 2^22: uniform scalars; the result must equal the size-independent closed form (sum s_i (i+1) mod r)·G.
+    At 2^22 the same inputs are also run as BASELINE config 4's shards (ParallelMSM's contiguous chunks for G = 2 and 8 ranks,
+    one handle per shard, un-normalised Jacobian partials, device combine) — identical bytes for every G."""
     from oracle import pymodel as pm
     gm = ob.g1_gen_multiples(n)
     raw = U.random_raw256(0x5A4F4C54, n)
@@ -309,6 +311,23 @@ def test_full_size_closed_form(zl, ob, n):
     # raw values may exceed r: the scalar is raw mod r
     want = pm.ec_mul(tot % pm.R_MOD, pm.G1)
     assert U.point_from_xy(got, ginf) == want
+    if n == 1 << 22:
+        import ctypes as C
+        from zolt_amd import api
+        d_sc, d_part = C.c_void_p(), C.c_void_p()
+        assert zl._lib.zg_dev_alloc(C.c_size_t(n * 32), C.byref(d_sc)) == 0
+        assert zl._lib.zg_dev_alloc(C.c_size_t(8 * 96), C.byref(d_part)) == 0
+        assert zl._lib.zg_memcpy_h2d(d_sc, sc.ctypes.data_as(C.c_void_p), C.c_size_t(n * 32)) == 0
+        for G in (2, 8):
+            for rank, (s0, s1) in enumerate(api.shard_bounds(n, G)):
+                shard = zl.Bases.upload(gm[s0:s1])
+                shard.msm_partial_fast_dev(d_sc.value + s0 * 32, s1 - s0, d_part.value + rank * 96)
+                zl.sync()
+                shard.free()
+            cxy, cinf = zl.combine_partials_dev(d_part.value, G)
+            assert cinf == ginf and np.array_equal(cxy, got), G
+        zl._lib.zg_dev_free(d_sc)
+        zl._lib.zg_dev_free(d_part)
 
 
 @pytest.mark.parametrize("kind", ["boolean", "bytes", "all_equal", "one_hot_bucket", "mixed"])
