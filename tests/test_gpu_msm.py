@@ -377,6 +377,30 @@ def test_auto_plan_sizes(zl, ob, logn):
     assert ginf == winf and np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("env", [{}, {"ZG_MSM_SIDE_TABLE": "0"}, {"ZG_MSM_BATCH_FUSE": "0"}])
+def test_side_table_routing(zl, ob, gm, env, monkeypatch):
+    """A wide-window handle (n >= 32768) answers MSMs over a short prefix, and batches of them, from its narrow-window side
+    table of the first 16384 bases; ranges that leave the prefix use the main table. Same bytes either way, and with the
+    side table or the fusing switched off."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    n = 40000
+    inf = np.zeros(n, dtype=np.uint8)
+    inf[5::11] = 1
+    b = zl.Bases.upload(gm[:n], inf)
+    sc = _scalars(ob, 4321, n)
+    for off, m in ((0, 16384), (0, 1000), (384, 16000), (1, 16384), (16000, 500), (0, 16385), (0, n)):
+        got, ginf = b.msm(sc[:m], off=off, n=m)
+        want, winf = ob.msm_g1(gm[off:off + m], inf[off:off + m], sc[:m])
+        assert ginf == winf and np.array_equal(got, want), (off, m)
+    batches = [_scalars(ob, 4400 + j, 3000) for j in range(5)]
+    outs, infs = b.msm_batch(batches)
+    for j in range(5):
+        want, winf = ob.msm_g1(gm[:3000], inf[:3000], batches[j])
+        assert infs[j] == winf and np.array_equal(outs[j], want)
+    b.free()
+
+
 @pytest.mark.parametrize("env", [{"ZG_MSM_CHUNK_SCHED": "0"}, {"ZG_MSM_LDS_SORT": "0"}, {"ZG_MSM_LANES": "1"},
                                  {"ZG_MSM_CHUNK_THREADS": "1000"}, {"ZG_MSM_CHUNK_SCHED": "0", "ZG_MSM_LDS_SORT": "0", "ZG_MSM_SLICES": "4"}])
 def test_alternate_code_paths(zl, ob, gm, env, monkeypatch):
