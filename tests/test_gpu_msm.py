@@ -377,6 +377,32 @@ def test_auto_plan_sizes(zl, ob, logn):
     assert ginf == winf and np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("env", [{}, {"ZG_MSM_TWO_PASS_SORT": "0"}, {"ZG_MSM_FINE_BITS": "5", "ZG_MSM_FINE_BITS_MIN": "2"},
+                                 {"ZG_MSM_FINE_BITS": "3", "ZG_MSM_FINE_BITS_MIN": "2", "ZG_MSM_TWO_PASS_SPAN": "256"},
+                                 {"ZG_MSM_TWO_PASS_SPAN": "8192"}])
+def test_two_pass_sort_variants(zl, ob, gm, env, monkeypatch):
+    """The two-pass counting sort used for 2^15 buckets (coarse partition, then per-bin slices) against the single-pass sort and
+    with other bin / block shapes — uniform scalars, a 0/1 column (half of all entries in ONE coarse bin, split over many
+    slices), a constant column and infinity bases. Same bytes as the oracle every time."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    n = 40000
+    rng = np.random.default_rng(5)
+    inf = np.zeros(n, dtype=np.uint8)
+    inf[3::13] = 1
+    b = zl.Bases.upload(gm[:n], inf, window_bits=16)
+    cases = [_scalars(ob, 31337, n), ob.f_from_u64(ob.FR, rng.integers(0, 2, size=n).astype(np.uint64)),
+             ob.f_from_u64(ob.FR, np.full(n, 0xABCDEF, dtype=np.uint64))]
+    for sc in cases:
+        got, ginf = b.msm(sc)
+        want, winf = ob.msm_g1(gm[:n], inf, sc)
+        assert ginf == winf and np.array_equal(got, want)
+    got, ginf = b.msm(cases[0][:17000], off=16500, n=17000)  # a sub-range that does not fit the side table
+    want, winf = ob.msm_g1(gm[16500:33500], inf[16500:33500], cases[0][:17000])
+    assert ginf == winf and np.array_equal(got, want)
+    b.free()
+
+
 @pytest.mark.parametrize("env", [{}, {"ZG_MSM_SIDE_TABLE": "0"}, {"ZG_MSM_BATCH_FUSE": "0"}])
 def test_side_table_routing(zl, ob, gm, env, monkeypatch):
     """A wide-window handle (n >= 32768) answers MSMs over a short prefix, and batches of them, from its narrow-window side

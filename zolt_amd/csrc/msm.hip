@@ -49,6 +49,9 @@ struct MsmPlan {
     int PB;        // bit-sum partial blocks per (group, bit)
     uint32_t NT;   // chunk-scheduled accumulate: threads (0 = per-bucket scheduling)
     int GS;        // lanes per bucket in the combine pass
+    int fb;        // two-pass sort: low key bits resolved by the second pass (0 = single-pass LDS / atomic sort)
+    int rb;        // two-pass sort: bits of a table-row reference inside an intermediate entry (= 31 - fb)
+    uint32_t NCB;  // two-pass sort: coarse bins = ceil(NK / 2^fb)
 };
 
 }  // namespace zg
@@ -63,7 +66,10 @@ struct zg_bases_s {
     // streams overlap: the latency-bound tail of one runs under the ALU-bound accumulation of the next.
     struct Lane {
         uint32_t *d_dig = nullptr, *d_sorted = nullptr, *d_hist = nullptr, *d_starts = nullptr;
-        uint32_t *d_blockhist = nullptr;  // LDS sort path: nblk * NK per-block histograms / offsets
+        uint32_t *d_blockhist = nullptr;  // LDS sort path: nblk * NK per-block histograms / offsets (two-pass: nblk2 * NCB)
+        uint32_t *d_tmp = nullptr;        // two-pass sort: entries partitioned by coarse bin, W * n
+        uint32_t *d_cstarts = nullptr;    // two-pass sort: cstarts | totals | tstarts | istarts, NCB + 1 each
+        uint32_t *d_fine = nullptr;       // two-pass sort: slicecnt[max items][2^fb] then fbase[NCB][2^fb]
         char *d_partial = nullptr;        // NK * 144 B: bucket sums (lazy 29-bit-limb XYZZ records)
         char *d_bits = nullptr;           // G * c * PB * 144 B: per-bit partial sums
         char *d_rg = nullptr;             // G * 128 B: per-group results
@@ -250,7 +256,7 @@ __global__ void __launch_bounds__(256) msm_scatter_kernel(const uint32_t *dig, u
 // path above costs one device-scope atomic per digit, twice (histogram + scatter).
 template <int C>
 __global__ void __launch_bounds__(1024) msm_digits_lds_kernel(const uint64_t *scalars, const uint8_t *inf, uint32_t n, uint32_t n_pts,
-                                                              int G, uint32_t per_block, uint32_t NK, uint32_t *dig,
+                                                              int G, uint32_t per_block, uint32_t NK, int shift, uint32_t *dig,
                                                               uint32_t *blockhist) {
     extern __shared__ uint32_t lds_hist[];
     constexpr int W = (255 + C - 1) / C;
@@ -276,7 +282,7 @@ __global__ void __launch_bounds__(1024) msm_digits_lds_kernel(const uint64_t *sc
             if (d != 0 && !skip) {
                 uint32_t key = (batch * (uint32_t)G + (uint32_t)(w % G)) * NB + (d - 1);
                 e = key | (neg << 31);
-                atomicAdd(&lds_hist[key], 1u);
+                atomicAdd(&lds_hist[key >> shift], 1u);  // shift > 0: coarse bins of the two-pass sort (NK = their number)
             }
             dig[(size_t)w * n + i] = e;
         }
@@ -321,6 +327,205 @@ __global__ void __launch_bounds__(1024) msm_scatter_lds_kernel(const uint32_t *d
             sorted[pos] = (e & 0x80000000u) | (uint32_t)((size_t)lvl * table_n + off + i % n_pts);
         }
     }
+}
+
+// ---- two-pass counting sort for many buckets (NK >= 8192). The single-pass scatter above writes runs of only
+// n*W / (blocks * NK) entries per (block, bucket) — 2 entries = 8 bytes at 2^20 points — and rocprofv3 shows the price:
+// WRITE_SIZE 514 MB for 64 MB of sorted references (every 64-byte line leaves L2 eight times, partially filled).
+// Pass 1 (msm_scatter_lds_kernel with shift = fb) partitions by the HIGH key bits only: <= 8192 coarse bins, so a block
+// writes runs of hundreds of bytes. Pass 2 (below) gives each coarse bin to one block: its entries are contiguous
+// (~256 KiB, L2-resident), it counts the 2^fb fine keys in LDS, publishes the per-bucket histogram the accumulate
+// scheduler needs, and places the entries — scattered 4-byte stores again, but confined to a region that is complete
+// before it leaves L2.
+// cstarts[b] = entries before coarse bin b (positions in the sorted list); tstarts[b] = the same with every bin rounded up to
+// a multiple of 4 entries (positions in the intermediate buffer, so that pass 2 can use 16-byte loads); istarts[b] = work items
+// before bin b, an item being a slice of at most FINE_SLICE entries of one bin (a skewed witness column can put half of all
+// entries into one bin: it is then spread over many blocks instead of one).
+static constexpr uint32_t FINE_SLICE = 32768;
+__global__ void __launch_bounds__(1024) msm_coarse_base_kernel(const uint32_t *totals, uint32_t NCB, uint32_t *cstarts, uint32_t *tstarts,
+                                                               uint32_t *istarts) {
+    __shared__ uint32_t sh[1024], sh4[1024], shi[1024];
+    uint32_t tid = threadIdx.x, per = (NCB + 1023) / 1024, a = tid * per, b = a + per < NCB ? a + per : NCB;
+    uint32_t s = 0, s4 = 0, si = 0;
+    for (uint32_t k = a; k < b; k++) {
+        s += totals[k];
+        s4 += (totals[k] + 3u) & ~3u;
+        si += (totals[k] + FINE_SLICE - 1) / FINE_SLICE;
+    }
+    sh[tid] = s;
+    sh4[tid] = s4;
+    shi[tid] = si;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024; o <<= 1) {
+        uint32_t v = tid >= o ? sh[tid - o] : 0, v4 = tid >= o ? sh4[tid - o] : 0, vi = tid >= o ? shi[tid - o] : 0;
+        __syncthreads();
+        sh[tid] += v;
+        sh4[tid] += v4;
+        shi[tid] += vi;
+        __syncthreads();
+    }
+    uint32_t run = sh[tid] - s, run4 = sh4[tid] - s4, runi = shi[tid] - si;  // exclusive
+    for (uint32_t k = a; k < b; k++) {
+        cstarts[k] = run;
+        tstarts[k] = run4;
+        istarts[k] = runi;
+        run += totals[k];
+        run4 += (totals[k] + 3u) & ~3u;
+        runi += (totals[k] + FINE_SLICE - 1) / FINE_SLICE;
+    }
+    if (tid == 1023) {
+        cstarts[NCB] = sh[1023];
+        tstarts[NCB] = sh4[1023];
+        istarts[NCB] = shi[1023];
+    }
+}
+
+// pass 1: partition the digit entries by coarse bin (key >> fb). An intermediate entry keeps the fine key bits above the rb bits
+// of the table-row reference: sign | fine << rb | ref. Loads are issued four at a time (the loop body is load -> LDS atomic ->
+// store, a dependent chain).
+__global__ void __launch_bounds__(256) msm_partition_kernel(const uint32_t *dig, uint32_t n, uint32_t n_pts, int W, int G, size_t table_n,
+                                                            uint32_t off, uint32_t per_block, uint32_t NCB, int fb, int rb,
+                                                            const uint32_t *tstarts, const uint32_t *blockoff, uint32_t *tmp) {
+    extern __shared__ uint32_t lds_cur[];
+    const uint32_t *row = blockoff + (size_t)blockIdx.x * NCB;
+    for (uint32_t k = threadIdx.x; k < NCB; k += blockDim.x) lds_cur[k] = tstarts[k] + row[k];
+    __syncthreads();
+    const uint32_t T = blockDim.x, fmask = (1u << fb) - 1u;
+    uint32_t i0 = blockIdx.x * per_block, i1 = i0 + per_block < n ? i0 + per_block : n;
+    for (int w = 0; w < W; w++) {
+        uint32_t lvl = (uint32_t)(w / G);
+        const uint32_t *dw = dig + (size_t)w * n;
+        for (uint32_t ib = i0; ib < i1; ib += 4 * T) {
+            uint32_t e[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                uint32_t i = ib + u * T + threadIdx.x;
+                e[u] = i < i1 ? dw[i] : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (e[u] == 0xFFFFFFFFu) continue;
+                uint32_t i = ib + u * T + threadIdx.x, key = e[u] & 0x7FFFFFFFu;
+                uint32_t pos = atomicAdd(&lds_cur[key >> fb], 1u);
+                tmp[pos] = (e[u] & 0x80000000u) | ((key & fmask) << rb) | (uint32_t)((size_t)lvl * table_n + off + i % n_pts);
+            }
+        }
+    }
+}
+
+// pass 2, three launches over the work items (slices of coarse bins; the grid is an upper bound, surplus blocks exit):
+//   count : fine-key histogram of the slice (LDS) -> slicecnt[item][f]
+//   offsets (one block per bin): per fine key, exclusive prefix over the bin's slices (in place) and the bucket's size ->
+//           hist[key]; exclusive prefix over the fine keys -> fbase[bin][f]
+//   place : cursor[f] = cstarts[bin] + fbase[bin][f] + slicecnt[item][f]; scattered 4-byte stores confined to the bin's region
+// Entries are read with 16-byte loads (bins are 16-byte aligned in tmp and FINE_SLICE is a multiple of 4).
+ZG_DEV bool fine_item(uint32_t item, const uint32_t *istarts, uint32_t NCB, uint32_t &bin, uint32_t &q0) {
+    if (item >= istarts[NCB]) return false;
+    uint32_t lo = 0, hi = NCB;  // istarts[lo] <= item < istarts[hi]
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (istarts[mid] <= item) lo = mid; else hi = mid;
+    }
+    // bins without entries have no items: skip back over equal istarts values is not needed (istarts[lo] <= item < istarts[lo+1])
+    bin = lo;
+    q0 = (item - istarts[lo]) * FINE_SLICE;
+    return true;
+}
+
+template <bool PLACE>
+__global__ void __launch_bounds__(1024) msm_fine_kernel(const uint32_t *tmp, const uint32_t *cstarts, const uint32_t *tstarts,
+                                                        const uint32_t *istarts, uint32_t NCB, int fb, int rb, uint32_t *slicecnt,
+                                                        const uint32_t *fbase, uint32_t *sorted) {
+    __shared__ uint32_t cnt[128];
+    __shared__ uint32_t sh_bin, sh_q0, sh_ok;
+    uint32_t tid = threadIdx.x, nf = 1u << fb, fmask = nf - 1u, rmask = (1u << rb) - 1u;
+    if (tid == 0) {
+        uint32_t bb = 0, qq = 0;
+        sh_ok = fine_item(blockIdx.x, istarts, NCB, bb, qq) ? 1u : 0u;
+        sh_bin = bb;
+        sh_q0 = qq;
+    }
+    __syncthreads();
+    if (!sh_ok) return;
+    uint32_t bin = sh_bin, q0 = sh_q0;
+    uint32_t total = cstarts[bin + 1] - cstarts[bin];
+    uint32_t count = total - q0 < FINE_SLICE ? total - q0 : FINE_SLICE;
+    const uint4 *src = reinterpret_cast<const uint4 *>(tmp + tstarts[bin] + q0);
+    const uint32_t T = blockDim.x, quads = (count + 3) / 4;
+    if (tid < nf) cnt[tid] = PLACE ? cstarts[bin] + fbase[(size_t)bin * nf + tid] + slicecnt[(size_t)blockIdx.x * nf + tid] : 0u;
+    __syncthreads();
+    for (uint32_t qb = 0; qb < quads; qb += 2 * T) {
+        uint4 v[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            uint32_t q = qb + u * T + tid;
+            v[u] = q < quads ? src[q] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            uint32_t q = qb + u * T + tid, e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (4 * q + j < count) {
+                    uint32_t pos = atomicAdd(&cnt[(e[j] >> rb) & fmask], 1u);
+                    if (PLACE) sorted[pos] = (e[j] & 0x80000000u) | (e[j] & rmask);
+                }
+        }
+    }
+    if (!PLACE) {
+        __syncthreads();
+        if (tid < nf) slicecnt[(size_t)blockIdx.x * nf + tid] = cnt[tid];
+    }
+}
+
+__global__ void __launch_bounds__(128) msm_fine_offsets_kernel(const uint32_t *istarts, int fb, uint32_t NK, uint32_t *slicecnt, uint32_t *fbase,
+                                                               uint32_t *hist) {
+    __shared__ uint32_t sh[128];
+    uint32_t bin = blockIdx.x, f = threadIdx.x, nf = 1u << fb;
+    uint32_t i0 = istarts[bin], i1 = istarts[bin + 1], run = 0;
+    if (f < nf)
+        for (uint32_t it = i0; it < i1; it++) {
+            uint32_t v = slicecnt[(size_t)it * nf + f];
+            slicecnt[(size_t)it * nf + f] = run;
+            run += v;
+        }
+    sh[f] = f < nf ? run : 0;
+    __syncthreads();
+    for (uint32_t o = 1; o < 128; o <<= 1) {
+        uint32_t v = f >= o ? sh[f - o] : 0;
+        __syncthreads();
+        sh[f] += v;
+        __syncthreads();
+    }
+    if (f < nf) {
+        fbase[(size_t)bin * nf + f] = sh[f] - run;
+        uint32_t key = (bin << fb) | f;
+        if (key < NK) hist[key] = run;
+    }
+}
+
+// per coarse bin (one block each): exclusive prefix over the blocks' counts, in place, and the bin's total. The layout is
+// chist[blk][bin]; a thread owns a contiguous run of blocks.
+__global__ void __launch_bounds__(256) msm_colscan_bins_kernel(uint32_t *chist, uint32_t nblk, uint32_t NCB, uint32_t *total) {
+    __shared__ uint32_t sh[256];
+    uint32_t bin = blockIdx.x, tid = threadIdx.x, per = (nblk + 255) / 256, a = tid * per, b = a + per < nblk ? a + per : nblk;
+    uint32_t s = 0;
+    for (uint32_t k = a; k < b; k++) s += chist[(size_t)k * NCB + bin];
+    sh[tid] = s;
+    __syncthreads();
+    for (uint32_t o = 1; o < 256; o <<= 1) {
+        uint32_t v = tid >= o ? sh[tid - o] : 0;
+        __syncthreads();
+        sh[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = sh[tid] - s;
+    for (uint32_t k = a; k < b; k++) {
+        uint32_t v = chist[(size_t)k * NCB + bin];
+        chist[(size_t)k * NCB + bin] = run;
+        run += v;
+    }
+    if (tid == 255) total[bin] = sh[255];
 }
 
 ZG_DEV XYZZ xyzz_shfl_down(const XYZZ &v, int delta) {
@@ -750,6 +955,9 @@ static int env_int(const char *name, int dflt) {
 }
 
 static int make_plan(size_t n, const zg_msm_config *cfg, MsmPlan &p, size_t batch = 1) {
+    p.fb = 0;  // sort mode is decided afterwards (plan_two_pass)
+    p.rb = 0;
+    p.NCB = 0;
     int c = cfg ? cfg->window_bits : 0;
     if (c == 0) c = env_int("ZG_MSM_WINDOW_BITS", 0);
     if (c == 0) {
@@ -810,8 +1018,37 @@ static int make_plan(size_t n, const zg_msm_config *cfg, MsmPlan &p, size_t batc
     return ZG_OK;
 }
 
+// Decide whether a launch set of n_total scalars under plan p sorts in two passes (see msm_finesort_kernel): worth it when
+// the per-(block, bucket) runs of the single-pass scatter are a few bytes, i.e. many buckets. table_rows = L * (bases in the
+// handle) bounds a row reference, which shares a 32-bit intermediate entry with the sign and the fine key bits.
+static uint32_t two_pass_span() {
+    static const uint32_t v = (uint32_t)env_int("ZG_MSM_TWO_PASS_SPAN", 2048);
+    return v < 256 ? 256 : v;
+}
+static void plan_two_pass(MsmPlan &p, size_t table_rows, size_t n_total) {
+    p.fb = 0;
+    p.rb = 0;
+    p.NCB = 0;
+    if (!env_int("ZG_MSM_TWO_PASS_SORT", 1) || p.NK < 8192 || (uint64_t)n_total * p.W < (1u << 17)) return;
+    int need = 1;
+    while (((size_t)1 << need) < table_rows) need++;
+    int fb = 31 - need, fb_max = env_int("ZG_MSM_FINE_BITS", 7);
+    if (fb_max > 7) fb_max = 7;
+    if (fb > fb_max) fb = fb_max;
+    // with fewer than 7 fine bits there are >= 512 coarse bins and pass 1's open 64-byte lines (blocks x bins) no longer fit in
+    // L2: measured slower than the single-pass sort at 2^22 points (partition 1.03 ms), so only the 7-bit split is used
+    if (fb < env_int("ZG_MSM_FINE_BITS_MIN", 7)) return;
+    uint32_t ncb = (p.NK + (1u << fb) - 1) >> fb;
+    if (ncb > 8192) return;
+    p.fb = fb;
+    p.rb = 31 - fb;
+    p.NCB = ncb;
+}
+
+static size_t fine_max_items(const MsmPlan &p, size_t n_total) { return (size_t)p.NCB + (size_t)p.W * n_total / FINE_SLICE + 1; }
+
 static void lane_free(zg_bases_s::Lane &ln) {
-    void *lp[] = {ln.d_dig, ln.d_sorted, ln.d_hist, ln.d_starts, ln.d_blockhist, ln.d_partial, ln.d_bits, ln.d_rg,
+    void *lp[] = {ln.d_dig, ln.d_sorted, ln.d_hist, ln.d_starts, ln.d_blockhist, ln.d_tmp, ln.d_cstarts, ln.d_fine, ln.d_partial, ln.d_bits, ln.d_rg,
                   ln.d_nzrank, ln.d_nzlist, ln.d_scan_tmp, ln.d_part, ln.d_part2, ln.d_heavy, ln.d_state};
     for (void *p : lp)
         if (p) (void)hipFree(p);
@@ -829,7 +1066,14 @@ static hipError_t lane_alloc(zg_bases_s::Lane &ln, const MsmPlan &p, size_t n_to
     A(ln.d_sorted, (size_t)p.W * n_total * 4);
     A(ln.d_hist, (size_t)p.NK * 4);
     A(ln.d_starts, ((size_t)p.NK + 1) * 4);
-    if (nblk_lds) A(ln.d_blockhist, (size_t)nblk_lds * p.NK * 4);
+    if (p.fb) {
+        A(ln.d_blockhist, (size_t)nblk_lds * p.NCB * 4);
+        A(ln.d_tmp, ((size_t)p.W * n_total + 4 * (size_t)p.NCB + 4) * 4);
+        A(ln.d_cstarts, (4 * (size_t)p.NCB + 8) * 4);
+        A(ln.d_fine, (fine_max_items(p, n_total) + (size_t)p.NCB) * ((size_t)1 << p.fb) * 4);
+    } else if (nblk_lds) {
+        A(ln.d_blockhist, (size_t)nblk_lds * p.NK * 4);
+    }
     A(ln.d_partial, (size_t)p.NK * 144);
     A(ln.d_bits, (size_t)p.G * p.K * p.c * p.PB * 144);
     A(ln.d_rg, (size_t)p.G * p.K * 128);
@@ -901,13 +1145,17 @@ static int bases_create(const uint64_t *d_xy, const uint8_t *d_inf_in, size_t n,
     if (nlanes < 1) nlanes = 1;
     if (nlanes > 8) nlanes = 8;
     bool lds_sort = (size_t)p.NK * 4 <= 128 * 1024 && env_int("ZG_MSM_LDS_SORT", 1);
-    if (lds_sort) {
+    plan_two_pass(b->plan, (size_t)p.L * n, n);
+    if (p.fb) {
+        uint32_t nblk = (uint32_t)(n / two_pass_span());
+        b->nblk = nblk < 1 ? 1 : (nblk > 8192 ? 8192 : nblk);
+    } else if (lds_sort) {
         uint32_t nblk = (uint32_t)(n / (size_t)env_int("ZG_MSM_SORT_SPAN", 2048));
         b->nblk = nblk < 1 ? 1 : (nblk > 256 ? 256 : nblk);
     }
     b->lanes.resize(nlanes);
     for (auto &ln : b->lanes) {
-        hipError_t le = lane_alloc(ln, p, n, lds_sort ? b->nblk : 0);
+        hipError_t le = lane_alloc(ln, p, n, (p.fb || lds_sort) ? b->nblk : 0);
         if (le != hipSuccess) {
             set_error(std::string("msm workspace: ") + hipGetErrorString(le));
             free_bases(b);
@@ -956,21 +1204,23 @@ static unsigned sort_threads() {
 
 template <int C>
 static int launch_digits_lds(hipStream_t st, const uint64_t *sc, const uint8_t *inf, uint32_t n, uint32_t n_pts, int G, uint32_t per_block,
-                             uint32_t NK, uint32_t nblk, uint32_t *dig, uint32_t *blockhist) {
+                             uint32_t NK, uint32_t nblk, uint32_t *dig, uint32_t *blockhist, int shift, unsigned threads) {
     static uint32_t attr_set = 0;  // per instantiation: largest dynamic-LDS size configured so far
     if (attr_set < NK * 4) {
         ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_digits_lds_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    128 * 1024));
         attr_set = 128 * 1024;
     }
-    hipLaunchKernelGGL(msm_digits_lds_kernel<C>, dim3(nblk), dim3(sort_threads()), NK * 4, st, sc, inf, n, n_pts, G, per_block, NK, dig, blockhist);
+    hipLaunchKernelGGL(msm_digits_lds_kernel<C>, dim3(nblk), dim3(threads), NK * 4, st, sc, inf, n, n_pts, G, per_block, NK, shift, dig, blockhist);
     return ZG_OK;
 }
 
 static int launch_digits_lds_c(int c, hipStream_t st, const uint64_t *sc, const uint8_t *inf, uint32_t n, uint32_t n_pts, int G,
-                               uint32_t per_block, uint32_t NK, uint32_t nblk, uint32_t *dig, uint32_t *blockhist) {
+                               uint32_t per_block, uint32_t NK, uint32_t nblk, uint32_t *dig, uint32_t *blockhist, int shift = 0,
+                               unsigned threads = 0) {
+    if (!threads) threads = sort_threads();
     switch (c) {
-#define ZG_CASE(C) case C: return launch_digits_lds<C>(st, sc, inf, n, n_pts, G, per_block, NK, nblk, dig, blockhist);
+#define ZG_CASE(C) case C: return launch_digits_lds<C>(st, sc, inf, n, n_pts, G, per_block, NK, nblk, dig, blockhist, shift, threads);
         ZG_CASE(2) ZG_CASE(3) ZG_CASE(4) ZG_CASE(5) ZG_CASE(6) ZG_CASE(7) ZG_CASE(8) ZG_CASE(9) ZG_CASE(10)
         ZG_CASE(11) ZG_CASE(12) ZG_CASE(13) ZG_CASE(14) ZG_CASE(15) ZG_CASE(16)
 #undef ZG_CASE
@@ -1021,7 +1271,36 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
     const uint8_t *infp = b->d_inf ? b->d_inf + off : nullptr;
     if (ln.used) ZG_HIP(hipStreamWaitEvent(st, ln.done, 0));  // the lane's previous MSM may be on another stream
     ln.used = true;
-    if (ln.d_blockhist) {
+    if (p.fb) {
+        // two-pass sort: blocks of 256 threads over TWO_PASS_SPAN scalars each (coarse counters are a few KiB of LDS)
+        uint32_t nblk = nblk_cap;
+        while (nblk > 1 && (size_t)(nblk - 1) * 256 >= n) nblk--;
+        uint32_t per_block = (uint32_t)((n + nblk - 1) / nblk);
+        prof_begin(ZG_PROF_MSM_DIGITS, st);
+        ZG_TRY(launch_digits_lds_c(p.c, st, d_scalars, infp, (uint32_t)n, (uint32_t)n_pts, p.G, per_block, p.NCB, nblk, ln.d_dig,
+                                   ln.d_blockhist, p.fb, 256));
+        prof_end(ZG_PROF_MSM_DIGITS, st);
+        prof_begin(ZG_PROF_MSM_SORT, st);
+        uint32_t *d_tot = ln.d_cstarts + p.NCB + 1, *d_tst = ln.d_cstarts + 2 * (size_t)p.NCB + 2, *d_ist = ln.d_cstarts + 3 * (size_t)p.NCB + 3;
+        hipLaunchKernelGGL(msm_colscan_bins_kernel, dim3(p.NCB), dim3(256), 0, st, ln.d_blockhist, nblk, p.NCB, d_tot);
+        hipLaunchKernelGGL(msm_coarse_base_kernel, dim3(1), dim3(1024), 0, st, d_tot, p.NCB, ln.d_cstarts, d_tst, d_ist);
+        hipLaunchKernelGGL(msm_partition_kernel, dim3(nblk), dim3(256), p.NCB * 4, st, ln.d_dig, (uint32_t)n, (uint32_t)n_pts, p.W, p.G, b->n,
+                           (uint32_t)off, per_block, p.NCB, p.fb, p.rb, d_tst, ln.d_blockhist, ln.d_tmp);
+        {
+            uint32_t items = (uint32_t)fine_max_items(p, n);
+            uint32_t *d_fbase = ln.d_fine + (size_t)items * ((size_t)1 << p.fb);
+            hipLaunchKernelGGL(msm_fine_kernel<false>, dim3(items), dim3(1024), 0, st, ln.d_tmp, ln.d_cstarts, d_tst, d_ist, p.NCB, p.fb, p.rb,
+                               ln.d_fine, d_fbase, ln.d_sorted);
+            hipLaunchKernelGGL(msm_fine_offsets_kernel, dim3(p.NCB), dim3(128), 0, st, d_ist, p.fb, p.NK, ln.d_fine, d_fbase, ln.d_hist);
+            hipLaunchKernelGGL(msm_fine_kernel<true>, dim3(items), dim3(1024), 0, st, ln.d_tmp, ln.d_cstarts, d_tst, d_ist, p.NCB, p.fb, p.rb,
+                               ln.d_fine, d_fbase, ln.d_sorted);
+        }
+        uint32_t tiles = div_up(p.NK, 1024);
+        hipLaunchKernelGGL(msm_scan_a_kernel, dim3(tiles), dim3(1024), 0, st, ln.d_hist, p.NK, ln.d_scan_tmp, ln.d_scan_tmp + p.NK,
+                           ln.d_scan_tmp + 2 * (size_t)p.NK);
+        hipLaunchKernelGGL(msm_scan_b_kernel, dim3(tiles), dim3(1024), 0, st, ln.d_hist, p.NK, ln.d_scan_tmp, ln.d_scan_tmp + p.NK,
+                           ln.d_scan_tmp + 2 * (size_t)p.NK, ln.d_starts, ln.d_nzrank, ln.d_nzlist);
+    } else if (ln.d_blockhist) {
         uint32_t nblk = nblk_cap;
         while (nblk > 1 && (size_t)(nblk - 1) * 1024 >= n) nblk--;  // no empty blocks for short sub-range MSMs
         uint32_t per_block = (uint32_t)((n + nblk - 1) / nblk);
@@ -1276,8 +1555,10 @@ static int msm_batch_enqueue(zg_bases_s *b, size_t n, const uint64_t *d_scalars,
         }
         b->batch_n = 0;
         ZG_TRY(make_plan(n, &cfg, b->batch_plan, kc));
-        uint32_t nblk = (uint32_t)(n * kc / (size_t)env_int("ZG_MSM_SORT_SPAN", 2048));
-        b->batch_nblk = nblk < 1 ? 1 : (nblk > 256 ? 256 : nblk);
+        plan_two_pass(b->batch_plan, (size_t)b->plan.L * b->n, n * kc);
+        uint32_t nblk = (uint32_t)(n * kc / (size_t)(b->batch_plan.fb ? two_pass_span() : (uint32_t)env_int("ZG_MSM_SORT_SPAN", 2048)));
+        uint32_t cap = b->batch_plan.fb ? 4096u : 256u;
+        b->batch_nblk = nblk < 1 ? 1 : (nblk > cap ? cap : nblk);
         hipError_t e = lane_alloc(b->batch_lane, b->batch_plan, n * kc, b->batch_nblk);
         if (e != hipSuccess) {
             lane_free(b->batch_lane);
@@ -1289,7 +1570,12 @@ static int msm_batch_enqueue(zg_bases_s *b, size_t n, const uint64_t *d_scalars,
     for (size_t i0 = 0; i0 < k; i0 += kc) {
         size_t kk = k - i0 < kc ? k - i0 : kc;
         MsmPlan pl = b->batch_plan;
-        if (kk != (size_t)pl.K) ZG_TRY(make_plan(n, &cfg, pl, kk));  // a shorter last set fits the same workspace
+        if (kk != (size_t)pl.K) {  // a shorter last set fits the same workspace (and keeps its sort mode)
+            ZG_TRY(make_plan(n, &cfg, pl, kk));
+            pl.fb = b->batch_plan.fb;
+            pl.rb = b->batch_plan.rb;
+            pl.NCB = pl.fb ? (pl.NK + (1u << pl.fb) - 1) >> pl.fb : 0;
+        }
         ZG_TRY(msm_enqueue_lane(b, pl, b->batch_lane, b->batch_nblk, 0, n, d_scalars + 4 * n * i0, st, 0, d_out9 + 9 * i0,
                                 reinterpret_cast<uint8_t *>(d_out9 + 9 * i0 + 8), 9, 72));
     }
