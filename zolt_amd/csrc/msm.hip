@@ -381,35 +381,72 @@ __global__ void __launch_bounds__(1024) msm_coarse_base_kernel(const uint32_t *t
 }
 
 // pass 1: partition the digit entries by coarse bin (key >> fb). An intermediate entry keeps the fine key bits above the rb bits
-// of the table-row reference: sign | fine << rb | ref. Loads are issued four at a time (the loop body is load -> LDS atomic ->
-// store, a dependent chain).
-__global__ void __launch_bounds__(256) msm_partition_kernel(const uint32_t *dig, uint32_t n, uint32_t n_pts, int W, int G, size_t table_n,
-                                                            uint32_t off, uint32_t per_block, uint32_t NCB, int fb, int rb,
-                                                            const uint32_t *tstarts, const uint32_t *blockoff, uint32_t *tmp) {
-    extern __shared__ uint32_t lds_cur[];
-    const uint32_t *row = blockoff + (size_t)blockIdx.x * NCB;
-    for (uint32_t k = threadIdx.x; k < NCB; k += blockDim.x) lds_cur[k] = tstarts[k] + row[k];
+// of the table-row reference: sign | fine << rb | ref. A block owns <= STAGE_ENTRIES entries (its scalars x W windows), sorts
+// them by coarse bin INSIDE LDS (count, scan, place — LDS handles divergent addresses at full rate, the global store path
+// handles about one divergent lane per two cycles per CU), and then copies every bin's run to its place in `tmp` with
+// consecutive lanes on consecutive addresses: all HBM traffic of the pass is coalesced.
+static constexpr uint32_t STAGE_ENTRIES = 32768;  // 128 KiB of LDS
+__global__ void __launch_bounds__(1024) msm_partition_kernel(const uint32_t *dig, uint32_t n, uint32_t n_pts, int W, int G, size_t table_n,
+                                                             uint32_t off, uint32_t per_block, uint32_t NCB, int fb, int rb,
+                                                             const uint32_t *tstarts, const uint32_t *blockoff, uint32_t *tmp) {
+    extern __shared__ uint32_t lds[];
+    uint32_t *buf = lds, *cnt = lds + STAGE_ENTRIES, *lbase = cnt + NCB, *sums = lbase + NCB + 1;  // sums: 1024 scan partials
+    const uint32_t tid = threadIdx.x, T = 1024, fmask = (1u << fb) - 1u;
+    uint32_t i0 = blockIdx.x * per_block, cntl = i0 < n ? (n - i0 < per_block ? n - i0 : per_block) : 0;
+    uint32_t total = cntl * (uint32_t)W;
+    for (uint32_t k = tid; k < NCB; k += T) cnt[k] = 0;
     __syncthreads();
-    const uint32_t T = blockDim.x, fmask = (1u << fb) - 1u;
-    uint32_t i0 = blockIdx.x * per_block, i1 = i0 + per_block < n ? i0 + per_block : n;
-    for (int w = 0; w < W; w++) {
-        uint32_t lvl = (uint32_t)(w / G);
-        const uint32_t *dw = dig + (size_t)w * n;
-        for (uint32_t ib = i0; ib < i1; ib += 4 * T) {
-            uint32_t e[4];
+    // the block's entries stay in registers between the counting and the placing pass (<= 32 per thread)
+    uint32_t e[STAGE_ENTRIES / 1024];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                uint32_t i = ib + u * T + threadIdx.x;
-                e[u] = i < i1 ? dw[i] : 0xFFFFFFFFu;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                if (e[u] == 0xFFFFFFFFu) continue;
-                uint32_t i = ib + u * T + threadIdx.x, key = e[u] & 0x7FFFFFFFu;
-                uint32_t pos = atomicAdd(&lds_cur[key >> fb], 1u);
-                tmp[pos] = (e[u] & 0x80000000u) | ((key & fmask) << rb) | (uint32_t)((size_t)lvl * table_n + off + i % n_pts);
-            }
+    for (int r = 0; r < (int)(STAGE_ENTRIES / 1024); r++) {
+        uint32_t x = (uint32_t)r * T + tid;
+        e[r] = 0xFFFFFFFFu;
+        if (x < total) {
+            uint32_t w = x / cntl, i = i0 + (x - w * cntl);
+            uint32_t d = dig[(size_t)w * n + i];
+            e[r] = d;  // key | sign, or 0xFFFFFFFF for a dropped digit
+            if (d != 0xFFFFFFFFu) atomicAdd(&cnt[(d & 0x7FFFFFFFu) >> fb], 1u);
         }
+    }
+    __syncthreads();
+    // exclusive scan of cnt[0..NCB) -> lbase (each thread owns a contiguous run of bins)
+    {
+        uint32_t per = (NCB + T - 1) / T, a = tid * per, b = a + per < NCB ? a + per : NCB, sacc = 0;
+        for (uint32_t k = a; k < b && k < NCB; k++) sacc += cnt[k];
+        sums[tid] = sacc;
+        __syncthreads();
+        for (uint32_t o = 1; o < T; o <<= 1) {
+            uint32_t v = tid >= o ? sums[tid - o] : 0;
+            __syncthreads();
+            sums[tid] += v;
+            __syncthreads();
+        }
+        uint32_t run = sums[tid] - sacc;
+        for (uint32_t k = a; k < b && k < NCB; k++) {
+            lbase[k] = run;
+            run += cnt[k];
+            cnt[k] = 0;  // becomes the placing cursor
+        }
+        if (tid == T - 1) lbase[NCB] = sums[T - 1];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < (int)(STAGE_ENTRIES / 1024); r++) {
+        if (e[r] != 0xFFFFFFFFu) {
+            uint32_t x = (uint32_t)r * T + tid, w = x / cntl, i = i0 + (x - w * cntl);
+            uint32_t key = e[r] & 0x7FFFFFFFu, bin = key >> fb, lvl = w / (uint32_t)G;
+            uint32_t packed = (e[r] & 0x80000000u) | ((key & fmask) << rb) | (uint32_t)((size_t)lvl * table_n + off + i % n_pts);
+            buf[lbase[bin] + atomicAdd(&cnt[bin], 1u)] = packed;
+        }
+    }
+    __syncthreads();
+    // copy-out: wave v takes bins v, v + 16, ...; lanes walk the bin's run
+    const uint32_t *row = blockoff + (size_t)blockIdx.x * NCB;
+    for (uint32_t bin = tid >> 6; bin < NCB; bin += T >> 6) {
+        uint32_t a = lbase[bin], b = lbase[bin + 1];
+        uint32_t dst = tstarts[bin] + row[bin];
+        for (uint32_t j = a + (tid & 63); j < b; j += 64) tmp[dst + (j - a)] = buf[j];
     }
 }
 
@@ -432,19 +469,18 @@ ZG_DEV bool fine_item(uint32_t item, const uint32_t *istarts, uint32_t NCB, uint
     return true;
 }
 
-template <bool PLACE>
-__global__ void __launch_bounds__(1024) msm_fine_kernel(const uint32_t *tmp, const uint32_t *cstarts, const uint32_t *tstarts,
-                                                        const uint32_t *istarts, uint32_t NCB, int fb, int rb, uint32_t *slicecnt,
-                                                        const uint32_t *fbase, uint32_t *sorted) {
+__global__ void __launch_bounds__(1024) msm_fine_count_kernel(const uint32_t *tmp, const uint32_t *cstarts, const uint32_t *tstarts,
+                                                              const uint32_t *istarts, uint32_t NCB, int fb, int rb, uint32_t *slicecnt) {
     __shared__ uint32_t cnt[128];
     __shared__ uint32_t sh_bin, sh_q0, sh_ok;
-    uint32_t tid = threadIdx.x, nf = 1u << fb, fmask = nf - 1u, rmask = (1u << rb) - 1u;
+    uint32_t tid = threadIdx.x, nf = 1u << fb, fmask = nf - 1u;
     if (tid == 0) {
         uint32_t bb = 0, qq = 0;
         sh_ok = fine_item(blockIdx.x, istarts, NCB, bb, qq) ? 1u : 0u;
         sh_bin = bb;
         sh_q0 = qq;
     }
+    if (tid < nf) cnt[tid] = 0;
     __syncthreads();
     if (!sh_ok) return;
     uint32_t bin = sh_bin, q0 = sh_q0;
@@ -452,8 +488,6 @@ __global__ void __launch_bounds__(1024) msm_fine_kernel(const uint32_t *tmp, con
     uint32_t count = total - q0 < FINE_SLICE ? total - q0 : FINE_SLICE;
     const uint4 *src = reinterpret_cast<const uint4 *>(tmp + tstarts[bin] + q0);
     const uint32_t T = blockDim.x, quads = (count + 3) / 4;
-    if (tid < nf) cnt[tid] = PLACE ? cstarts[bin] + fbase[(size_t)bin * nf + tid] + slicecnt[(size_t)blockIdx.x * nf + tid] : 0u;
-    __syncthreads();
     for (uint32_t qb = 0; qb < quads; qb += 2 * T) {
         uint4 v[2];
 #pragma unroll
@@ -466,15 +500,76 @@ __global__ void __launch_bounds__(1024) msm_fine_kernel(const uint32_t *tmp, con
             uint32_t q = qb + u * T + tid, e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
             for (int j = 0; j < 4; j++)
-                if (4 * q + j < count) {
-                    uint32_t pos = atomicAdd(&cnt[(e[j] >> rb) & fmask], 1u);
-                    if (PLACE) sorted[pos] = (e[j] & 0x80000000u) | (e[j] & rmask);
-                }
+                if (4 * q + j < count) atomicAdd(&cnt[(e[j] >> rb) & fmask], 1u);
         }
     }
-    if (!PLACE) {
-        __syncthreads();
-        if (tid < nf) slicecnt[(size_t)blockIdx.x * nf + tid] = cnt[tid];
+    __syncthreads();
+    if (tid < nf) slicecnt[(size_t)blockIdx.x * nf + tid] = cnt[tid];
+}
+
+// place: the slice (<= FINE_SLICE = STAGE_ENTRIES entries, held in registers) is sorted by fine key inside LDS, then every
+// fine key's run is copied to  cstarts[bin] + fbase[bin][f] + (prefix over the earlier slices)  with coalesced stores.
+__global__ void __launch_bounds__(1024) msm_fine_place_kernel(const uint32_t *tmp, const uint32_t *cstarts, const uint32_t *tstarts,
+                                                              const uint32_t *istarts, uint32_t NCB, int fb, int rb, const uint32_t *slicecnt,
+                                                              const uint32_t *fbase, uint32_t *sorted) {
+    extern __shared__ uint32_t lds[];
+    uint32_t *buf = lds, *cnt = lds + STAGE_ENTRIES, *lbase = cnt + 128;  // lbase: 129 entries
+    __shared__ uint32_t sh_bin, sh_q0, sh_ok;
+    uint32_t tid = threadIdx.x, nf = 1u << fb, fmask = nf - 1u, rmask = (1u << rb) - 1u;
+    if (tid == 0) {
+        uint32_t bb = 0, qq = 0;
+        sh_ok = fine_item(blockIdx.x, istarts, NCB, bb, qq) ? 1u : 0u;
+        sh_bin = bb;
+        sh_q0 = qq;
+    }
+    if (tid < nf) cnt[tid] = 0;
+    __syncthreads();
+    if (!sh_ok) return;
+    uint32_t bin = sh_bin, q0 = sh_q0;
+    uint32_t total = cstarts[bin + 1] - cstarts[bin];
+    uint32_t count = total - q0 < FINE_SLICE ? total - q0 : FINE_SLICE;
+    const uint4 *src = reinterpret_cast<const uint4 *>(tmp + tstarts[bin] + q0);
+    const uint32_t T = 1024, quads = (count + 3) / 4;
+    uint4 v[FINE_SLICE / 4 / 1024];
+#pragma unroll
+    for (int u = 0; u < (int)(FINE_SLICE / 4 / 1024); u++) {
+        uint32_t q = (uint32_t)u * T + tid;
+        v[u] = q < quads ? src[q] : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < (int)(FINE_SLICE / 4 / 1024); u++) {
+        uint32_t q = (uint32_t)u * T + tid, e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (4 * q + j < count) atomicAdd(&cnt[(e[j] >> rb) & fmask], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (uint32_t f = 0; f < nf; f++) {
+            lbase[f] = run;
+            run += cnt[f];
+            cnt[f] = 0;
+        }
+        lbase[nf] = run;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < (int)(FINE_SLICE / 4 / 1024); u++) {
+        uint32_t q = (uint32_t)u * T + tid, e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (4 * q + j < count) {
+                uint32_t f = (e[j] >> rb) & fmask;
+                buf[lbase[f] + atomicAdd(&cnt[f], 1u)] = (e[j] & 0x80000000u) | (e[j] & rmask);
+            }
+    }
+    __syncthreads();
+    uint32_t base = cstarts[bin];
+    for (uint32_t f = tid >> 6; f < nf; f += T >> 6) {
+        uint32_t a = lbase[f], b = lbase[f + 1];
+        uint32_t dst = base + fbase[(size_t)bin * nf + f] + slicecnt[(size_t)blockIdx.x * nf + f];
+        for (uint32_t j = a + (tid & 63); j < b; j += 64) sorted[dst + (j - a)] = buf[j];
     }
 }
 
@@ -1021,9 +1116,11 @@ static int make_plan(size_t n, const zg_msm_config *cfg, MsmPlan &p, size_t batc
 // Decide whether a launch set of n_total scalars under plan p sorts in two passes (see msm_finesort_kernel): worth it when
 // the per-(block, bucket) runs of the single-pass scatter are a few bytes, i.e. many buckets. table_rows = L * (bases in the
 // handle) bounds a row reference, which shares a 32-bit intermediate entry with the sign and the fine key bits.
-static uint32_t two_pass_span() {
-    static const uint32_t v = (uint32_t)env_int("ZG_MSM_TWO_PASS_SPAN", 2048);
-    return v < 256 ? 256 : v;
+static uint32_t two_pass_span(int W) {
+    uint32_t cap = (STAGE_ENTRIES / (uint32_t)W) & ~255u;  // a partition block stages per_block * W entries in LDS
+    uint32_t v = (uint32_t)env_int("ZG_MSM_TWO_PASS_SPAN", 2048);
+    v = v < 256 ? 256 : v;
+    return v > cap ? cap : v;
 }
 static void plan_two_pass(MsmPlan &p, size_t table_rows, size_t n_total) {
     p.fb = 0;
@@ -1039,7 +1136,7 @@ static void plan_two_pass(MsmPlan &p, size_t table_rows, size_t n_total) {
     // L2: measured slower than the single-pass sort at 2^22 points (partition 1.03 ms), so only the 7-bit split is used
     if (fb < env_int("ZG_MSM_FINE_BITS_MIN", 7)) return;
     uint32_t ncb = (p.NK + (1u << fb) - 1) >> fb;
-    if (ncb > 8192) return;
+    if (ncb > 2048) return;  // pass 1 keeps 2 * NCB counters next to 128 KiB of staged entries in LDS
     p.fb = fb;
     p.rb = 31 - fb;
     p.NCB = ncb;
@@ -1147,8 +1244,8 @@ static int bases_create(const uint64_t *d_xy, const uint8_t *d_inf_in, size_t n,
     bool lds_sort = (size_t)p.NK * 4 <= 128 * 1024 && env_int("ZG_MSM_LDS_SORT", 1);
     plan_two_pass(b->plan, (size_t)p.L * n, n);
     if (p.fb) {
-        uint32_t nblk = (uint32_t)(n / two_pass_span());
-        b->nblk = nblk < 1 ? 1 : (nblk > 8192 ? 8192 : nblk);
+        uint32_t nblk = (uint32_t)div_up(n, two_pass_span(p.W));
+        b->nblk = nblk < 1 ? 1 : nblk;
     } else if (lds_sort) {
         uint32_t nblk = (uint32_t)(n / (size_t)env_int("ZG_MSM_SORT_SPAN", 2048));
         b->nblk = nblk < 1 ? 1 : (nblk > 256 ? 256 : nblk);
@@ -1240,6 +1337,18 @@ static int launch_digits_c(int c, hipStream_t st, const uint64_t *sc, const uint
     return ZG_OK;
 }
 
+static int two_pass_attrs() {
+    static std::once_flag once;
+    static hipError_t err = hipSuccess;
+    std::call_once(once, [] {
+        err = hipFuncSetAttribute(reinterpret_cast<const void *>(msm_partition_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+        if (err == hipSuccess)
+            err = hipFuncSetAttribute(reinterpret_cast<const void *>(msm_fine_place_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    });
+    ZG_HIP(err);
+    return ZG_OK;
+}
+
 static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &ln, uint32_t nblk_cap, size_t off, size_t n_pts,
                             const uint64_t *d_scalars, hipStream_t st, int mode, uint64_t *d_rec, uint8_t *d_inf_out,
                             uint32_t rec_stride, uint32_t inf_stride);
@@ -1273,8 +1382,11 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
     ln.used = true;
     if (p.fb) {
         // two-pass sort: blocks of 256 threads over TWO_PASS_SPAN scalars each (coarse counters are a few KiB of LDS)
-        uint32_t nblk = nblk_cap;
-        while (nblk > 1 && (size_t)(nblk - 1) * 256 >= n) nblk--;
+        uint32_t nblk = (uint32_t)div_up(n, two_pass_span(p.W));  // per_block * W <= STAGE_ENTRIES
+        if (nblk > nblk_cap) {
+            set_error("msm: two-pass workspace too small for this launch");
+            return ZG_ERR_INVALID;
+        }
         uint32_t per_block = (uint32_t)((n + nblk - 1) / nblk);
         prof_begin(ZG_PROF_MSM_DIGITS, st);
         ZG_TRY(launch_digits_lds_c(p.c, st, d_scalars, infp, (uint32_t)n, (uint32_t)n_pts, p.G, per_block, p.NCB, nblk, ln.d_dig,
@@ -1284,16 +1396,18 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
         uint32_t *d_tot = ln.d_cstarts + p.NCB + 1, *d_tst = ln.d_cstarts + 2 * (size_t)p.NCB + 2, *d_ist = ln.d_cstarts + 3 * (size_t)p.NCB + 3;
         hipLaunchKernelGGL(msm_colscan_bins_kernel, dim3(p.NCB), dim3(256), 0, st, ln.d_blockhist, nblk, p.NCB, d_tot);
         hipLaunchKernelGGL(msm_coarse_base_kernel, dim3(1), dim3(1024), 0, st, d_tot, p.NCB, ln.d_cstarts, d_tst, d_ist);
-        hipLaunchKernelGGL(msm_partition_kernel, dim3(nblk), dim3(256), p.NCB * 4, st, ln.d_dig, (uint32_t)n, (uint32_t)n_pts, p.W, p.G, b->n,
-                           (uint32_t)off, per_block, p.NCB, p.fb, p.rb, d_tst, ln.d_blockhist, ln.d_tmp);
+        ZG_TRY(two_pass_attrs());
+        hipLaunchKernelGGL(msm_partition_kernel, dim3(nblk), dim3(1024), (STAGE_ENTRIES + 2 * (size_t)p.NCB + 1 + 1024) * 4, st, ln.d_dig,
+                           (uint32_t)n, (uint32_t)n_pts, p.W, p.G, b->n, (uint32_t)off, per_block, p.NCB, p.fb, p.rb, d_tst, ln.d_blockhist,
+                           ln.d_tmp);
         {
             uint32_t items = (uint32_t)fine_max_items(p, n);
             uint32_t *d_fbase = ln.d_fine + (size_t)items * ((size_t)1 << p.fb);
-            hipLaunchKernelGGL(msm_fine_kernel<false>, dim3(items), dim3(1024), 0, st, ln.d_tmp, ln.d_cstarts, d_tst, d_ist, p.NCB, p.fb, p.rb,
-                               ln.d_fine, d_fbase, ln.d_sorted);
+            hipLaunchKernelGGL(msm_fine_count_kernel, dim3(items), dim3(1024), 0, st, ln.d_tmp, ln.d_cstarts, d_tst, d_ist, p.NCB, p.fb, p.rb,
+                               ln.d_fine);
             hipLaunchKernelGGL(msm_fine_offsets_kernel, dim3(p.NCB), dim3(128), 0, st, d_ist, p.fb, p.NK, ln.d_fine, d_fbase, ln.d_hist);
-            hipLaunchKernelGGL(msm_fine_kernel<true>, dim3(items), dim3(1024), 0, st, ln.d_tmp, ln.d_cstarts, d_tst, d_ist, p.NCB, p.fb, p.rb,
-                               ln.d_fine, d_fbase, ln.d_sorted);
+            hipLaunchKernelGGL(msm_fine_place_kernel, dim3(items), dim3(1024), (STAGE_ENTRIES + 128 + 132) * 4, st, ln.d_tmp, ln.d_cstarts, d_tst,
+                               d_ist, p.NCB, p.fb, p.rb, ln.d_fine, d_fbase, ln.d_sorted);
         }
         uint32_t tiles = div_up(p.NK, 1024);
         hipLaunchKernelGGL(msm_scan_a_kernel, dim3(tiles), dim3(1024), 0, st, ln.d_hist, p.NK, ln.d_scan_tmp, ln.d_scan_tmp + p.NK,
@@ -1556,9 +1670,12 @@ static int msm_batch_enqueue(zg_bases_s *b, size_t n, const uint64_t *d_scalars,
         b->batch_n = 0;
         ZG_TRY(make_plan(n, &cfg, b->batch_plan, kc));
         plan_two_pass(b->batch_plan, (size_t)b->plan.L * b->n, n * kc);
-        uint32_t nblk = (uint32_t)(n * kc / (size_t)(b->batch_plan.fb ? two_pass_span() : (uint32_t)env_int("ZG_MSM_SORT_SPAN", 2048)));
-        uint32_t cap = b->batch_plan.fb ? 4096u : 256u;
-        b->batch_nblk = nblk < 1 ? 1 : (nblk > cap ? cap : nblk);
+        if (b->batch_plan.fb) {
+            b->batch_nblk = (uint32_t)div_up(n * kc, two_pass_span(b->batch_plan.W));
+        } else {
+            uint32_t nblk = (uint32_t)(n * kc / (size_t)env_int("ZG_MSM_SORT_SPAN", 2048));
+            b->batch_nblk = nblk < 1 ? 1 : (nblk > 256 ? 256 : nblk);
+        }
         hipError_t e = lane_alloc(b->batch_lane, b->batch_plan, n * kc, b->batch_nblk);
         if (e != hipSuccess) {
             lane_free(b->batch_lane);
