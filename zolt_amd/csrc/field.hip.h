@@ -336,6 +336,23 @@ ZG_DEV bool limbs_nonzero(const u32 *a) {
     return o != 0;
 }
 
+// multi-limb shifts by 1 <= t <= 31
+ZG_DEV void limbs_shr(u32 *x, u32 t) {
+#pragma unroll
+    for (int i = 0; i < 7; i++) x[i] = (x[i] >> t) | (x[i + 1] << (32 - t));
+    x[7] >>= t;
+}
+ZG_DEV void limbs_shl(u32 *x, u32 t) {
+#pragma unroll
+    for (int i = 7; i > 0; i--) x[i] = (x[i] << t) | (x[i - 1] >> (32 - t));
+    x[0] <<= t;
+}
+
+// Phase 1 of Kaliski's almost-inverse with the steps regrouped so that one loop iteration is one subtraction: u and v are
+// kept ODD (after a subtraction the difference is shifted right by ALL its trailing zeros at once, the partner
+// coefficient left by as many), so the original's "halve u" / "halve v" iterations disappear and ~180 iterations remain
+// instead of ~380; the u > v / v >= u cases share one straight-line body (difference, sum, selects) instead of four
+// branches. Same r and k as the textbook loop, step for step.
 template <class P>
 ZG_DEV Fe<P> fe_inv_kaliski(const Fe<P> &a) {
     if (a.is_zero()) return Fe<P>::zero();
@@ -344,12 +361,61 @@ ZG_DEV Fe<P> fe_inv_kaliski(const Fe<P> &a) {
     for (int i = 0; i < 8; i++) { u[i] = P::MOD[i]; v[i] = a.l[i]; r[i] = 0; s[i] = 0; }
     s[0] = 1;
     u32 k = 0;
-    while (limbs_nonzero(v)) {
-        if (!(u[0] & 1u)) { limbs_shr1(u); limbs_shl1(s); }
-        else if (!(v[0] & 1u)) { limbs_shr1(v); limbs_shl1(r); }
-        else if (limbs_gt(u, v)) { limbs_sub(u, v); limbs_shr1(u); limbs_add(r, s); limbs_shl1(s); }
-        else { limbs_sub(v, u); limbs_shr1(v); limbs_add(s, r); limbs_shl1(r); }
-        k++;
+    // make v odd (r = 0 doubles to 0): the textbook loop would spend one iteration per trailing zero here
+    while (!(v[0] & 1u)) {
+        u32 t = v[0] ? (u32)__builtin_ctz(v[0]) : 31u;
+        limbs_shr(v, t);
+        k += t;
+    }
+    for (;;) {
+        // d = u - v with borrow; both odd, so d is even
+        u32 d[8], borrow = 0, nz = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            u64 t = (u64)u[i] - v[i] - borrow;
+            d[i] = (u32)t;
+            borrow = (u32)(t >> 32) & 1u;
+            nz |= d[i];
+        }
+        if (nz == 0) {  // u == v (== gcd == 1): the textbook's last step  v = 0, s += r, r = 2r, k++
+            limbs_shl(r, 1);
+            k++;
+            break;
+        }
+        const bool ub = borrow == 0;  // u > v: the u-branch (u = (u-v)/2, r += s, s = 2s); else the mirrored v-branch
+        if (!ub) {                    // magnitude v - u = -(d)
+            u32 c = 1;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                u64 t = (u64)(~d[i]) + c;
+                d[i] = (u32)t;
+                c = (u32)(t >> 32);
+            }
+        }
+        u32 sum[8], carry = 0;  // r + s: the new r (u-branch) or the new s (v-branch)
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            u64 t = (u64)r[i] + s[i] + carry;
+            sum[i] = (u32)t;
+            carry = (u32)(t >> 32);
+        }
+        // the other coefficient doubles once per halving of the difference
+        u32 oth[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) oth[i] = ub ? s[i] : r[i];
+        do {  // all trailing zeros of the difference (a second pass only if its low limb is zero)
+            u32 t = d[0] ? (u32)__builtin_ctz(d[0]) : 31u;
+            limbs_shr(d, t);
+            limbs_shl(oth, t);
+            k += t;
+        } while (!(d[0] & 1u));
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            u[i] = ub ? d[i] : u[i];
+            v[i] = ub ? v[i] : d[i];
+            r[i] = ub ? sum[i] : oth[i];
+            s[i] = ub ? oth[i] : sum[i];
+        }
     }
     // r = -(a^-1) 2^k mod MOD with r < 2 MOD
     Fe<P> x;

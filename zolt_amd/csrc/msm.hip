@@ -32,6 +32,7 @@
 #include "common.hip.h"
 #include "g1.hip.h"
 #include "g1_29.hip.h"
+#include "g1_29x4.hip.h"
 
 namespace zg {
 
@@ -771,15 +772,24 @@ __global__ void __launch_bounds__(64) msm_bucket_combine_kernel(const char *part
     if (light && g == 0) xyzz29_store(buckets + 144 * (size_t)k, acc);
 }
 
-// block-wide sum of lazy XYZZ points through LDS (256 threads x 144 B); result returned to every thread
+// block-wide sum of lazy XYZZ points through LDS (256 threads x 144 B); result returned to every thread. After the first level
+// (128 additions, one lane each) every addition of a level is done by a quad of lanes (g1_29x4.hip.h): the chain is one
+// single-lane addition plus seven quad additions instead of eight single-lane ones.
 __device__ __forceinline__ XYZZ29 block_sum_xyzz29(const XYZZ29 &acc, uint4 *sh) {
     uint32_t tid = threadIdx.x;
     xyzz29_store(&sh[tid * 9], acc);
     __syncthreads();
-    for (uint32_t o = 128; o > 0; o >>= 1) {
-        if (tid < o) {
-            XYZZ29 x = xyzz29_load(&sh[tid * 9]), y = xyzz29_load(&sh[(tid + o) * 9]);
-            xyzz29_store(&sh[tid * 9], xyzz29_add(x, y));
+    if (tid < 128) {
+        XYZZ29 x = xyzz29_load(&sh[tid * 9]), y = xyzz29_load(&sh[(tid + 128) * 9]);
+        xyzz29_store(&sh[tid * 9], xyzz29_add(x, y));
+    }
+    __syncthreads();
+    uint32_t g = tid >> 2, q = tid & 3;
+    for (uint32_t o = 64; o > 0; o >>= 1) {
+        if (g < o) {  // slot g is read and written by quad g only, slot g + o read by quad g only: no hazard inside a level
+            XYZZ29 x = xyzz29_load(&sh[g * 9]), y = xyzz29_load(&sh[(g + o) * 9]);
+            XYZZ29 r = xyzz29_add4(x, y, q);
+            if (q == 0) xyzz29_store(&sh[g * 9], r);
         }
         __syncthreads();
     }
@@ -905,34 +915,52 @@ ZG_DEV void write_partial_unnormalised(const XYZZ &acc, uint64_t *out_rec) {
     fe_store(out_rec, X); fe_store(out_rec + 4, Y); fe_store(out_rec + 8, Z);
 }
 
-// Bucket reduction, step 2 (block g): lane (b, j) loads partial j of T_b; 16-lane shuffle tree over j;
-// lane (b, 0) doubles b times; LDS tree over b  ->  R_g = sum_k k*B_k of group g.
-// With a single group (full precompute) thread 0 goes straight on to toAffine (msm/mod.zig:178-189).
-__global__ void __launch_bounds__(256) msm_final_kernel(const char *bits, int c, int PB, int G, char *rg, int mode, uint64_t *out_rec,
-                                                       uint8_t *out_inf, uint32_t rec_stride, uint32_t inf_stride) {
-    __shared__ uint4 sh[16 * 9];
-    uint32_t tid = threadIdx.x, g = blockIdx.x;
-    uint32_t b = tid / 16, j = tid % 16;
-    XYZZ29 v = xyzz29_identity();
-    if (b < (uint32_t)c && j < (uint32_t)PB) v = xyzz29_load(bits + 144 * (((size_t)g * c + b) * PB + j));
-    for (int d = 1; d < 16; d <<= 1) {
-        XYZZ29 o = xyzz29_shfl_down(v, d);
-        if ((j & (uint32_t)(2 * d - 1)) == 0) v = xyzz29_add(v, o);
+// Bucket reduction, step 2 (block g, 512 threads = 128 quads): the c x PB partial sums of group g go to LDS; a tree over the
+// partials of each bit, then quad b doubles T_b b times, then a tree over the bits  ->  R_g = sum_k k*B_k of group g.
+// Every point operation is done by a quad of lanes (g1_29x4.hip.h). With a single group (full precompute) thread 0 goes
+// straight on to toAffine (msm/mod.zig:178-189).
+__global__ void __launch_bounds__(512) msm_final_kernel(const char *bits, int c, int PB, int G, char *rg, int mode, uint64_t *out_rec,
+                                                        uint8_t *out_inf, uint32_t rec_stride, uint32_t inf_stride) {
+    __shared__ uint4 pts[256 * 9];  // slot b * 16 + j
+    uint32_t tid = threadIdx.x, g = blockIdx.x, quad = tid >> 2, q = tid & 3;
+    if (tid < 256) {
+        uint32_t b = tid / 16, j = tid % 16;
+        XYZZ29 v = xyzz29_identity();
+        if (b < (uint32_t)c && j < (uint32_t)PB) v = xyzz29_load(bits + 144 * (((size_t)g * c + b) * PB + j));
+        xyzz29_store(&pts[tid * 9], v);
     }
-    if (j == 0) {
-        for (uint32_t i = 0; i < b; i++) v = xyzz29_dbl(v);
-        xyzz29_store(&sh[b * 9], v);
+    __syncthreads();
+    for (uint32_t d = 1; d < 16; d <<= 1) {  // per bit: partial j += partial j + d, for j a multiple of 2d
+        uint32_t per_bit = 8 / d;            // additions per bit at this level
+        if (quad < 16 * per_bit) {
+            uint32_t b = quad / per_bit, j = (quad % per_bit) * 2 * d;
+            XYZZ29 x = xyzz29_load(&pts[(b * 16 + j) * 9]), y = xyzz29_load(&pts[(b * 16 + j + d) * 9]);
+            XYZZ29 r = xyzz29_add4(x, y, q);
+            if (q == 0) xyzz29_store(&pts[(b * 16 + j) * 9], r);
+        }
+        __syncthreads();
+    }
+    if (quad < 16) {  // 2^b * T_b
+        XYZZ29 v = xyzz29_load(&pts[(quad * 16) * 9]);
+#if !(defined(ZG_EXP_SKIP) && (ZG_EXP_SKIP & 1))
+        for (uint32_t i = 0; i < quad; i++) v = xyzz29_dbl4(v, q);
+#endif
+        if (q == 0) xyzz29_store(&pts[(quad * 16) * 9], v);
     }
     __syncthreads();
     for (uint32_t o = 8; o > 0; o >>= 1) {
-        if (tid < o) {
-            XYZZ29 x = xyzz29_load(&sh[tid * 9]), y = xyzz29_load(&sh[(tid + o) * 9]);
-            xyzz29_store(&sh[tid * 9], xyzz29_add(x, y));
+        if (quad < o) {
+            XYZZ29 x = xyzz29_load(&pts[(quad * 16) * 9]), y = xyzz29_load(&pts[((quad + o) * 16) * 9]);
+            XYZZ29 r = xyzz29_add4(x, y, q);
+            if (q == 0) xyzz29_store(&pts[(quad * 16) * 9], r);
         }
         __syncthreads();
     }
     if (tid != 0) return;
-    XYZZ r = xyzz29_to_std_val(xyzz29_load(&sh[0]));  // canonical Montgomery-2^256 from here on
+#if defined(ZG_EXP_SKIP) && (ZG_EXP_SKIP & 4)
+    if (G == 1) { xyzz29_store(rg, xyzz29_load(&pts[0])); return; }
+#endif
+    XYZZ r = xyzz29_to_std_val(xyzz29_load(&pts[0]));  // canonical Montgomery-2^256 from here on
     if (G == 1) {  // block g is scalar vector g of a batched launch (g == 0 for a single MSM)
         out_rec += (size_t)rec_stride * g;
         out_inf += (size_t)inf_stride * g;
@@ -1481,7 +1509,7 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
         prof_begin(ZG_PROF_MSM_REDUCE, st);
     }
     hipLaunchKernelGGL(msm_bitsum_kernel, dim3(p.PB, p.c, p.G * p.K), dim3(256), 0, st, ln.d_partial, p.NB, p.c, ln.d_bits);
-    hipLaunchKernelGGL(msm_final_kernel, dim3(p.G * p.K), dim3(256), 0, st, ln.d_bits, p.c, p.PB, p.G, ln.d_rg, mode, d_rec, d_inf_out,
+    hipLaunchKernelGGL(msm_final_kernel, dim3(p.G * p.K), dim3(512), 0, st, ln.d_bits, p.c, p.PB, p.G, ln.d_rg, mode, d_rec, d_inf_out,
                        rec_stride, inf_stride);
     if (p.G > 1)
         hipLaunchKernelGGL(msm_groups_kernel, dim3(p.K), dim3(1), 0, st, ln.d_rg, p.G, p.c, mode, d_rec, d_inf_out, rec_stride, inf_stride);
