@@ -64,8 +64,9 @@ extern "C" {
 #define ZG_OP_MUL29 9      /* Fp only: a*b through the MSM's 9x29-bit lazy representation (csrc/fp29.hip.h) */
 #define ZG_OP_SQR29 10     /* Fp only: a^2 through the lazy representation (b ignored) */
 #define ZG_OP_X3_29 11     /* Fp only: a*a - b - 2*b*b... see tests: exercises the biased lazy subtractions */
-#define ZG_OP_INV_FAST 8   /* same value as ZG_OP_INV via Kaliski's almost-inverse (the device's toAffine path) */
+#define ZG_OP_INV_FAST 8   /* same value as ZG_OP_INV via Kaliski's almost-inverse (kept for cross-checking) */
 #define ZG_OP_INV_XGCD 12   /* same value via plain binary extended Euclid (kept for cross-checking) */
+#define ZG_OP_INV_SAFEGCD 13 /* same value via batched Bernstein-Yang division steps (the device's toAffine path) */
 #define ZG_OP_TO_MONT 7    /* fromBytes' reduction :171-184 / :625-639: raw 256-bit LE -> Montgomery (b ignored) */
 
 /* ------------------------------------------------------------------ lifecycle */

@@ -50,6 +50,32 @@ def test_field_ops_match_oracle(zl, field):
     k = 1 << 16  # binary-Euclid inversion used by the device toAffine
     assert np.array_equal(zl.field_op(field, zl.OP_INV_FAST, a[:k]), ob.f_inv(field, a[:k]))
     assert np.array_equal(zl.field_op(field, zl.OP_INV_XGCD, a[:k]), ob.f_inv(field, a[:k]))
+    assert np.array_equal(zl.field_op(field, zl.OP_INV_SAFEGCD, a[:k]), ob.f_inv(field, a[:k]))
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_inversion_variants_on_structured_values(zl, field):
+    """The three device inversions (Kaliski almost-inverse, binary Euclid, batched division steps — the last is what toAffine
+    uses) against the oracle's Fermat inverse on values that stress their control flow: 0 (-> 0, src/field/mod.zig:500-503),
+    small integers, powers of two and their neighbours (long runs of trailing zeros), modulus - small, all-ones limbs, and
+    the Montgomery images of the same."""
+    from oracle import binding as ob
+    mod = 21888242871839275222246405745257275088548364400416034343698204186575808495617 if field == 0 else \
+        21888242871839275222246405745257275088696311157297823662689037894645226208583
+    vals = [0, 1, 2, 3, 4, 7, 255, 256, mod - 1, mod - 2, mod - 3, (mod - 1) // 2, (mod + 1) // 2, (1 << 253) % mod, (1 << 253) - 1,
+            (1 << 254) % mod, (1 << 255) % mod, (1 << 128), (1 << 128) - 1, (1 << 192) + 1, (1 << 64), (1 << 32), (1 << 30),
+            (1 << 60) - 1, 0xFFFFFFFF, 0xFFFFFFFFFFFFFFFF, ((1 << 256) - 1) % mod]
+    vals += [(1 << k) % mod for k in range(1, 254, 7)] + [((1 << k) + 1) % mod for k in range(29, 254, 30)]
+    raw = np.array([[(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)] for v in vals], dtype=np.uint64)
+    for a in (raw, ob.f_to_mont(field, raw)):   # every 256-bit pattern below the modulus is a valid Montgomery value
+        want = ob.f_inv(field, a)
+        for op in (zl.OP_INV, zl.OP_INV_FAST, zl.OP_INV_XGCD, zl.OP_INV_SAFEGCD):
+            assert np.array_equal(zl.field_op(field, op, a), want), op
+        # x * x^-1 == 1 (Montgomery one) wherever x != 0
+        one = ob.f_from_u64(field, np.array([1], dtype=np.uint64))[0]
+        prod = ob.f_mul(field, a, want)
+        for i, v in enumerate(a):
+            assert np.array_equal(prod[i], one) or not v.any()
 
 
 def test_field_kats(zl):

@@ -35,6 +35,7 @@ struct FrParams {
     static constexpr u32 R3[8] = {0xb4bf0040u, 0x5e94d8e1u, 0x1cfbb6b8u, 0x2a489cbeu,
                                   0xa19fcfedu, 0x893cc664u, 0x7fcc657cu, 0x0cf8594bu};  // 2^768 mod MOD
     static constexpr u32 INV = 0xefffffffu;  // -MOD^-1 mod 2^32 (low word of BN254_INV)
+    static constexpr u32 MINV30 = 0x10000001u;  // MOD^-1 mod 2^30 (fe_inv_safegcd)
 };
 struct FpParams {
     static __device__ __forceinline__ const uint32_t *kaliski_tab() { return KALISKI_TAB_FP; }
@@ -47,6 +48,7 @@ struct FpParams {
     static constexpr u32 R3[8] = {0xda1530dfu, 0xb1cd6dafu, 0xa7283db6u, 0x62f210e6u,
                                   0x0ada0afbu, 0xef7f0b0cu, 0x2d592544u, 0x20fd6e90u};  // 2^768 mod MOD
     static constexpr u32 INV = 0xe4866389u;  // low word of BN254_FP_INV
+    static constexpr u32 MINV30 = 0x1b799c77u;  // MOD^-1 mod 2^30 (fe_inv_safegcd)
 };
 
 template <class P>
@@ -428,6 +430,170 @@ ZG_DEV Fe<P> fe_inv_kaliski(const Fe<P> &a) {
 #pragma unroll
     for (int i = 0; i < 8; i++) ck.l[i] = c[i];
     return fe_mul(x, ck);
+}
+
+// ---- Inversion by Bernstein-Yang division steps ("safegcd"), in the batched variable-time form popularised by libsecp256k1's
+// modinv32: the state (f, g) = (MOD, x) and the Bezout coefficients (d, e) are 9 signed 30-bit limbs; 30 division steps at a
+// time are run on the low 32 bits of f and g only and collected in a 2x2 matrix of 31-bit entries, which is then applied to
+// the four big numbers with 32x32->64 multiply-adds. ~20 batches of ~300 instructions replace Kaliski's ~180 iterations of
+// ~130 carry-chained instructions: on one GPU lane (where a dependent instruction costs 4-8 cycles) that is ~4x faster, and
+// the single inversion at the end of an MSM was the longest item of a short MSM's tail. Value: x^-1 for the integer x;
+// Montgomery form is restored with one product by R^3.
+struct S30 {
+    int32_t v[9];
+};
+template <class P>
+ZG_DEV S30 s30_modulus() {
+    S30 m;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const int o = 30 * i, wi = o / 32, sh = o % 32;
+        u32 x = P::MOD[wi] >> sh;
+        if (sh > 2 && wi + 1 < 8) x |= P::MOD[wi + 1] << (32 - sh);
+        m.v[i] = (int32_t)(i < 8 ? (x & 0x3fffffffu) : x);
+    }
+    return m;
+}
+ZG_DEV S30 s30_from_words(const u32 *w) {
+    S30 m;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const int o = 30 * i, wi = o / 32, sh = o % 32;
+        u32 x = w[wi] >> sh;
+        if (sh > 2 && wi + 1 < 8) x |= w[wi + 1] << (32 - sh);
+        m.v[i] = (int32_t)(i < 8 ? (x & 0x3fffffffu) : x);
+    }
+    return m;
+}
+// limbs in [0, 2^30), value < 2^256
+ZG_DEV void s30_to_words(const S30 &a, u32 *w) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int o = 32 * j, li = o / 30, sh = o % 30;
+        u32 x = (u32)a.v[li] >> sh;
+        if (li + 1 < 9) x |= (u32)a.v[li + 1] << (30 - sh);
+        if (sh > 28 && li + 2 < 9) x |= (u32)a.v[li + 2] << (60 - sh);
+        w[j] = x;
+    }
+}
+
+template <class P>
+ZG_DEV Fe<P> fe_inv_safegcd(const Fe<P> &a) {
+    if (a.is_zero()) return Fe<P>::zero();
+    const int32_t M30 = 0x3fffffff;
+    const S30 mod = s30_modulus<P>();
+    S30 f = mod, g = s30_from_words(a.l), d, e;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { d.v[i] = 0; e.v[i] = 0; }
+    e.v[0] = 1;
+    int32_t eta = -1;
+    for (int batch = 0; batch < 40; batch++) {  // 590 steps bound the loop for 256-bit inputs; it ends when g == 0
+        // ---- 30 division steps on the low words -> transition matrix [u v; q r]
+        u32 u = 1, v = 0, q = 0, r = 1;
+        u32 fl = (u32)f.v[0] | ((u32)f.v[1] << 30), gl = (u32)g.v[0] | ((u32)g.v[1] << 30);
+        int i = 30;
+        for (;;) {
+            int zeros = __builtin_ctz(gl | (0xffffffffu << i));  // trailing zeros of g, at most i
+            gl >>= zeros;
+            u <<= zeros;
+            v <<= zeros;
+            eta -= zeros;
+            i -= zeros;
+            if (i == 0) break;
+            if (eta < 0) {  // swap f and g (with a sign), and the matrix rows with them
+                u32 t;
+                eta = -eta;
+                t = fl; fl = gl; gl = 0u - t;
+                t = u; u = q; q = 0u - t;
+                t = v; v = r; r = 0u - t;
+            }
+            // eta >= 0: cancel min(eta + 1, i, 6) low bits of g with a multiple of f; -g/f mod 2^6 = g*f*(f^2 - 2)
+            int limit = (eta + 1) > i ? i : (eta + 1);
+            u32 m = (0xffffffffu >> (32 - limit)) & 63u;
+            u32 w = (fl * gl * (fl * fl - 2u)) & m;
+            gl += fl * w;
+            q += u * w;
+            r += v * w;
+        }
+        const int32_t tu = (int32_t)u, tv = (int32_t)v, tq = (int32_t)q, tr = (int32_t)r;
+        // ---- (d, e) <- t * (d, e) / 2^30 mod MOD: multiples md, me of MOD make the low 30 bits vanish
+        {
+            int32_t sd = d.v[8] >> 31, se = e.v[8] >> 31;
+            int32_t md = (tu & sd) + (tv & se), me = (tq & sd) + (tr & se);
+            int64_t cd = (int64_t)tu * d.v[0] + (int64_t)tv * e.v[0];
+            int64_t ce = (int64_t)tq * d.v[0] + (int64_t)tr * e.v[0];
+            md -= (int32_t)((P::MINV30 * (u32)cd + (u32)md) & (u32)M30);
+            me -= (int32_t)((P::MINV30 * (u32)ce + (u32)me) & (u32)M30);
+            cd += (int64_t)mod.v[0] * md;
+            ce += (int64_t)mod.v[0] * me;
+            cd >>= 30;
+            ce >>= 30;
+            int32_t d0 = d.v[0], e0 = e.v[0];
+            (void)d0; (void)e0;
+#pragma unroll
+            for (int k = 1; k < 9; k++) {
+                int32_t di = d.v[k], ei = e.v[k];
+                cd += (int64_t)tu * di + (int64_t)tv * ei + (int64_t)mod.v[k] * md;
+                ce += (int64_t)tq * di + (int64_t)tr * ei + (int64_t)mod.v[k] * me;
+                d.v[k - 1] = (int32_t)cd & M30;
+                cd >>= 30;
+                e.v[k - 1] = (int32_t)ce & M30;
+                ce >>= 30;
+            }
+            d.v[8] = (int32_t)cd;
+            e.v[8] = (int32_t)ce;
+        }
+        // ---- (f, g) <- t * (f, g) / 2^30 (exact)
+        u32 gnz = 0;
+        {
+            int64_t cf = (int64_t)tu * f.v[0] + (int64_t)tv * g.v[0];
+            int64_t cg = (int64_t)tq * f.v[0] + (int64_t)tr * g.v[0];
+            cf >>= 30;
+            cg >>= 30;
+#pragma unroll
+            for (int k = 1; k < 9; k++) {
+                int32_t fi = f.v[k], gi = g.v[k];
+                cf += (int64_t)tu * fi + (int64_t)tv * gi;
+                cg += (int64_t)tq * fi + (int64_t)tr * gi;
+                f.v[k - 1] = (int32_t)cf & M30;
+                cf >>= 30;
+                g.v[k - 1] = (int32_t)cg & M30;
+                cg >>= 30;
+                gnz |= (u32)g.v[k - 1];
+            }
+            f.v[8] = (int32_t)cf;
+            g.v[8] = (int32_t)cg;
+            gnz |= (u32)g.v[8];
+        }
+        if (gnz == 0) break;
+    }
+    // f = +-1 and d * x = f (mod MOD): bring d from (-2 MOD, MOD) to [0, MOD), negated when f = -1
+    {
+        int32_t cond_add = d.v[8] >> 31, cond_neg = f.v[8] >> 31;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            d.v[k] += mod.v[k] & cond_add;
+            d.v[k] = (d.v[k] ^ cond_neg) - cond_neg;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            d.v[k + 1] += d.v[k] >> 30;
+            d.v[k] &= M30;
+        }
+        cond_add = d.v[8] >> 31;
+#pragma unroll
+        for (int k = 0; k < 9; k++) d.v[k] += mod.v[k] & cond_add;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            d.v[k + 1] += d.v[k] >> 30;
+            d.v[k] &= M30;
+        }
+    }
+    Fe<P> x, r3;
+    s30_to_words(d, x.l);
+#pragma unroll
+    for (int i = 0; i < 8; i++) r3.l[i] = P::R3[i];
+    return fe_mul(x, r3);  // (aR)^-1 * R^3 * R^-1 = a^-1 R
 }
 
 typedef Fe<FrParams> Fr;

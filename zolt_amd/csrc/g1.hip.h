@@ -153,7 +153,7 @@ ZG_DEV bool xyzz_to_affine(const XYZZ &p, Affine &out) {
         out.x = Fp::zero(); out.y = Fp::zero();
         return true;  // infinity
     }
-    Fp izzz = fe_inv_kaliski(p.zzz);
+    Fp izzz = fe_inv_safegcd(p.zzz);
     Fp iz = fe_mul(izzz, p.zz);
     Fp izz = fe_sqr(iz);
     out.x = fe_mul(p.x, izz);

@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(256) msm_precompute_kernel(const uint64_t *xy,
         a.x = px; a.y = py; a.zz = one29; a.zzz = one29;
         for (int k = 0; k < dbl_per_level; k++) a = xyzz29_dbl(a);  // never the identity: the group has odd prime order
         // back to affine in the lazy domain: 1/Z = ZZ/ZZZ, x = X/Z^2, y = Y/ZZZ (one canonical-form inversion)
-        F29 izzz = f29_from_fp(fe_inv_kaliski(f29_to_fp(a.zzz)));
+        F29 izzz = f29_from_fp(fe_inv_safegcd(f29_to_fp(a.zzz)));
         F29 iz = f29_mul(izzz, a.zz);
         px = f29_mul(a.x, f29_sqr(iz));
         py = f29_mul(a.y, izzz);
@@ -742,11 +742,12 @@ __global__ void __launch_bounds__(256) msm_accumulate_chunk_kernel(const uint32_
     xyzz29_store(part + 144 * (size_t)(i + r), acc_inf ? xyzz29_identity() : acc);
 }
 
-// GS adjacent lanes per bucket (GS | 64, chosen from the expected partials per bucket) sum its partials:
-// strided serial adds, then a segmented shuffle tree; buckets with more than 8*GS partials are queued as heavy
+// GS adjacent QUADS of lanes per bucket (4*GS | 64, GS chosen from the expected partials per bucket) sum its partials: strided
+// serial adds, then a segmented shuffle tree, every addition by a quad (g1_29x4.hip.h); buckets with more than 8*GS partials
+// are queued as heavy
 __global__ void __launch_bounds__(64) msm_bucket_combine_kernel(const char *part, const uint32_t *starts, const uint32_t *nzrank, uint32_t NK,
                                                                 uint32_t NT, int GS, char *buckets, uint32_t *heavy_list, MsmState *st) {
-    uint32_t t = blockIdx.x * 64 + threadIdx.x;
+    uint32_t t = (blockIdx.x * 64 + threadIdx.x) >> 2, q = threadIdx.x & 3;
     uint32_t k = t / (uint32_t)GS, g = t % (uint32_t)GS;
     XYZZ29 acc = xyzz29_identity();
     bool light = false;
@@ -758,18 +759,18 @@ __global__ void __launch_bounds__(64) msm_bucket_combine_kernel(const char *part
         } else {
             uint32_t q0 = s0 / C, q1 = (s1 - 1) / C, cnt = q1 - q0 + 1, base = q0 + nzrank[k];
             if (cnt > 8u * (uint32_t)GS) {
-                if (g == 0) heavy_list[atomicAdd(&st->nheavy, 1u)] = k;
+                if (g == 0 && q == 0) heavy_list[atomicAdd(&st->nheavy, 1u)] = k;
             } else {
                 light = true;
-                for (uint32_t j = g; j < cnt; j += (uint32_t)GS) acc = xyzz29_add(acc, xyzz29_load(part + 144 * (size_t)(base + j)));
+                for (uint32_t j = g; j < cnt; j += (uint32_t)GS) acc = xyzz29_add4(acc, xyzz29_load(part + 144 * (size_t)(base + j)), q);
             }
         }
     }
     for (int d = 1; d < GS; d <<= 1) {
-        XYZZ29 o = xyzz29_shfl_down(acc, d);
-        if ((g & (uint32_t)(2 * d - 1)) == 0) acc = xyzz29_add(acc, o);
+        XYZZ29 o = xyzz29_shfl_down(acc, 4 * d);  // the same lane of the quad d quads further
+        if ((g & (uint32_t)(2 * d - 1)) == 0) acc = xyzz29_add4(acc, o, q);
     }
-    if (light && g == 0) xyzz29_store(buckets + 144 * (size_t)k, acc);
+    if (light && g == 0 && q == 0) xyzz29_store(buckets + 144 * (size_t)k, acc);
 }
 
 // block-wide sum of lazy XYZZ points through LDS (256 threads x 144 B); result returned to every thread. After the first level
@@ -1134,7 +1135,7 @@ static int make_plan(size_t n, const zg_msm_config *cfg, MsmPlan &p, size_t batc
     }
     // combine lanes per bucket: a bucket expects about NT/NK + 1 partials; keep ~4 per lane
     p.GS = 1;
-    while (p.GS < 64 && (uint64_t)p.GS * 4 < (uint64_t)p.NT / p.NK + 1) p.GS <<= 1;
+    while (p.GS < 16 && (uint64_t)p.GS * 4 < (uint64_t)p.NT / p.NK + 1) p.GS <<= 1;  // GS quads of lanes per bucket: 4 * GS <= 64
     // bit-sum partial blocks: ~4 buckets per thread, at most 16 (the final kernel reduces 16 lanes per bit)
     int pb = (int)(p.NB / 2 / (256 * 4));
     p.PB = pb < 1 ? 1 : (pb > 16 ? 16 : pb);
@@ -1492,7 +1493,7 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
                            ln.d_nzlist, b->d_table, p.NK, p.NT, ln.d_part);
         prof_end(ZG_PROF_MSM_ACCUMULATE, st);  // the dominant kernel alone; combine/heavy stages count as reduction
         prof_begin(ZG_PROF_MSM_REDUCE, st);
-        hipLaunchKernelGGL(msm_bucket_combine_kernel, dim3(div_up((size_t)p.NK * p.GS, 64)), dim3(64), 0, st, ln.d_part, ln.d_starts,
+        hipLaunchKernelGGL(msm_bucket_combine_kernel, dim3(div_up((size_t)p.NK * p.GS * 4, 64)), dim3(64), 0, st, ln.d_part, ln.d_starts,
                            ln.d_nzrank, p.NK, p.NT, p.GS, ln.d_partial, ln.d_heavy, reinterpret_cast<MsmState *>(ln.d_state));
         hipLaunchKernelGGL(msm_heavy_wave_kernel, dim3(1024), dim3(64), 0, st, ln.d_part, ln.d_starts, ln.d_nzrank, p.NK, p.NT, ln.d_heavy,
                            ln.d_heavy + p.NK, reinterpret_cast<MsmState *>(ln.d_state), ln.d_partial);

@@ -164,6 +164,7 @@ __global__ void __launch_bounds__(256) field_op_kernel(int op, const uint64_t *a
             case ZG_OP_FROM_MONT: r = fe_from_mont(x); break;
             case ZG_OP_INV_FAST: r = fe_inv_kaliski(x); break;
             case ZG_OP_INV_XGCD: r = fe_inv_fast(x); break;
+            case ZG_OP_INV_SAFEGCD: r = fe_inv_safegcd(x); break;
             default: r = fe_to_mont(x); break;
         }
         fe_store(out + 4 * i, r);
@@ -263,7 +264,7 @@ int zg_profile_end(double ms_out[ZG_PROF_NKERNELS], uint64_t count_out[ZG_PROF_N
 
 int zg_field_op(int field, int op, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n) {
     ZG_INIT();
-    if (op < 0 || op > ZG_OP_INV_XGCD || (op >= ZG_OP_MUL29 && op <= ZG_OP_X3_29 && field != ZG_FIELD_FP) || (field != ZG_FIELD_FR && field != ZG_FIELD_FP) || !a || !out ||
+    if (op < 0 || op > ZG_OP_INV_SAFEGCD || (op >= ZG_OP_MUL29 && op <= ZG_OP_X3_29 && field != ZG_FIELD_FP) || (field != ZG_FIELD_FR && field != ZG_FIELD_FP) || !a || !out ||
         ((op <= ZG_OP_SUB || (op >= ZG_OP_MUL29 && op <= ZG_OP_X3_29)) && !b)) {
         set_error("zg_field_op: invalid argument");
         return ZG_ERR_INVALID;

@@ -18,7 +18,7 @@ _lib = C.CDLL(LIB_PATH)
 
 OK, ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_NO_DEVICE, ERR_VERIFY = 0, 1, 2, 3, 4, 5
 FR, FP = 0, 1
-OP_MUL, OP_ADD, OP_SUB, OP_NEG, OP_SQR, OP_INV, OP_FROM_MONT, OP_TO_MONT, OP_INV_FAST, OP_MUL29, OP_SQR29, OP_X3_29, OP_INV_XGCD = range(13)
+OP_MUL, OP_ADD, OP_SUB, OP_NEG, OP_SQR, OP_INV, OP_FROM_MONT, OP_TO_MONT, OP_INV_FAST, OP_MUL29, OP_SQR29, OP_X3_29, OP_INV_XGCD, OP_INV_SAFEGCD = range(14)
 SC_HIGH_HALF, SC_LOW_PAIR = 0, 1
 
 # every symbol include/zolt_gpu.h declares (tests check that the .so exports all of them)
