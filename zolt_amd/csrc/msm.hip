@@ -999,11 +999,12 @@ __global__ void msm_identity_kernel(int mode, uint64_t *out_rec, uint8_t *out_in
 
 // ParallelMSM combine (msm/mod.zig:647-652): serial add of k Jacobian partials + toAffine
 __global__ void __launch_bounds__(64) msm_combine_kernel(const uint64_t *partials, uint32_t k, uint64_t *out_xy, uint8_t *out_inf) {
-    // one wave: lane i folds partials i, i+64, ... (Jacobian -> lazy XYZZ), then a shuffle tree; the group sum does not
-    // depend on the association order, and the affine result is canonical
-    uint32_t lane = threadIdx.x;
+    // one wave = 16 quads of lanes: quad i folds partials i, i+16, ... (Jacobian -> lazy XYZZ), then a shuffle tree over the
+    // quads, every addition by a quad (g1_29x4.hip.h); the group sum does not depend on the association order, and the
+    // affine result is canonical
+    uint32_t lane = threadIdx.x, quad = lane >> 2, q = lane & 3;
     XYZZ29 acc = xyzz29_identity();
-    for (uint32_t i = lane; i < k; i += 64) {
+    for (uint32_t i = quad; i < k; i += 16) {
         Fp X = fe_load<FpParams>(partials + 12 * i), Y = fe_load<FpParams>(partials + 12 * i + 4),
            Z = fe_load<FpParams>(partials + 12 * i + 8);
         if (!Z.is_zero()) {
@@ -1012,12 +1013,12 @@ __global__ void __launch_bounds__(64) msm_combine_kernel(const uint64_t *partial
             p.x = f29_from_fp(X); p.y = f29_from_fp(Y);
             p.zz = f29_sqr(z);
             p.zzz = f29_mul(p.zz, z);
-            acc = xyzz29_add(acc, p);
+            acc = xyzz29_add4(acc, p, q);
         }
     }
-    for (int d = 1; d < 64; d <<= 1) {
-        XYZZ29 o = xyzz29_shfl_down(acc, d);
-        if ((lane & (uint32_t)(2 * d - 1)) == 0 && (uint32_t)d < k) acc = xyzz29_add(acc, o);
+    for (int d = 1; d < 16; d <<= 1) {
+        XYZZ29 o = xyzz29_shfl_down(acc, 4 * d);
+        if ((quad & (uint32_t)(2 * d - 1)) == 0 && (uint32_t)d < k) acc = xyzz29_add4(acc, o, q);
     }
     if (lane != 0) return;
     Affine r;
