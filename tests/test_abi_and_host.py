@@ -53,6 +53,13 @@ def test_no_gpu_fails_loudly_never_falls_back():
         lib.fr_eq_table(np.zeros((2, 4), dtype=np.uint64))
     with pytest.raises(lib.ZgError):
         lib.SumcheckSession.open(np.zeros((2, 4), dtype=np.uint64))
+    with pytest.raises(lib.ZgError) as e:
+        lib.run_sumcheck(np.zeros((4, 4), dtype=np.uint64))
+    assert e.value.code == lib.ERR_NO_DEVICE
+    with pytest.raises(lib.ZgError):
+        lib.fr_spartan_combine(*[np.zeros((2, 4), dtype=np.uint64)] * 4)
+    with pytest.raises(lib.ZgError):
+        lib.g1_scalar_mul_batch(np.zeros((1, 8), dtype=np.uint64), np.zeros(1, dtype=np.uint8), np.zeros((1, 4), dtype=np.uint64))
 
 
 def test_product_never_imports_oracle():
