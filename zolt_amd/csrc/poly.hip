@@ -725,8 +725,26 @@ static int hk_open_device(zg_bases_t srs, uint64_t *d_a, uint64_t *d_b, uint64_t
         }
         if (small_rows < 2) small_rows = 0;  // nothing to fuse
     }
-    Scratch s_res((9 * num_vars + 4) * 8), s_misc(SC_MISC_BYTES), s_small((small_rows * small_len + 1) * 32);
-    if (!s_res.p || !s_misc.p || !s_small.p) return ZG_ERR_NOMEM;
+    // The long levels' commits are independent of the folds that follow them: each gets its own quotient buffer and its MSM is
+    // issued on one of three streams in turn (the caller's and two helpers forked / joined by events), so the latency-bound tail
+    // of one commit runs under the accumulation of the next.
+    static hipStream_t aux[2] = {nullptr, nullptr};
+    static std::once_flag aux_once;
+    std::call_once(aux_once, [] {
+        for (int i = 0; i < 2; i++)
+            if (hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking) != hipSuccess) aux[i] = nullptr;
+    });
+    const bool fork = aux[0] && aux[1];
+    std::vector<hipEvent_t> events;
+    struct EventGuard {
+        std::vector<hipEvent_t> &ev;
+        ~EventGuard() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
+    } guard{events};
+    Scratch s_res((9 * num_vars + 4) * 8), s_misc(SC_MISC_BYTES), s_small((small_rows * small_len + 1) * 32), s_qall((n_evals + 1) * 32);
+    if (!s_res.p || !s_misc.p || !s_small.p || !s_qall.p) return ZG_ERR_NOMEM;
+    uint64_t *d_qall = s_qall.as<uint64_t>();
+    size_t q_used = 0, big = 0;
+    bool aux_used[2] = {false, false};
     uint64_t *d_res = s_res.as<uint64_t>(), *d_misc = s_misc.as<uint64_t>(), *d_small = s_small.as<uint64_t>();
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = hipMemsetAsync(d_res, 0, (9 * num_vars + 4) * 8, st);
@@ -750,8 +768,23 @@ static int hk_open_device(zg_bases_t srs, uint64_t *d_a, uint64_t *d_b, uint64_t
             hipLaunchKernelGGL(fr_sub_halves_kernel, dim3(div_up(nc, 256)), dim3(256), 0, st, cur, half, d_small + 4 * small_len * row, nc);
             row++;
         } else {
-            hipLaunchKernelGGL(fr_sub_halves_kernel, dim3(nb), dim3(256), 0, st, cur, half, d_q, half);
-            rc = zg_msm_g1_dev_async(srs, 0, nc, d_q, st, d_res + 9 * i, reinterpret_cast<uint8_t *>(d_res + 9 * i + 8));
+            uint64_t *qi = fork ? d_qall + 4 * q_used : d_q;
+            q_used += half;
+            hipLaunchKernelGGL(fr_sub_halves_kernel, dim3(nb), dim3(256), 0, st, cur, half, qi, half);
+            hipStream_t si = st;
+            if (fork && big % 3 != 0) {
+                hipEvent_t ev = nullptr;
+                if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
+                    events.push_back(ev);
+                    si = aux[big % 3 - 1];
+                    aux_used[big % 3 - 1] = true;
+                    e = hipEventRecord(ev, st);
+                    if (e == hipSuccess) e = hipStreamWaitEvent(si, ev, 0);
+                    if (e != hipSuccess) break;
+                }
+            }
+            big++;
+            rc = zg_msm_g1_dev_async(srs, 0, nc, qi, si, d_res + 9 * i, reinterpret_cast<uint8_t *>(d_res + 9 * i + 8));
             if (rc != ZG_OK) break;
         }
         computed++;
@@ -759,6 +792,16 @@ static int hk_open_device(zg_bases_t srs, uint64_t *d_a, uint64_t *d_b, uint64_t
         uint64_t *t = cur; cur = nxt; nxt = t;
         len = half;
     }
+    for (int a = 0; a < 2; a++)  // join the helper streams (also after an error, so that they never run ahead of later work)
+        if (aux_used[a]) {
+            hipEvent_t ev = nullptr;
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
+                events.push_back(ev);
+                if (hipEventRecord(ev, aux[a]) == hipSuccess) (void)hipStreamWaitEvent(st, ev, 0);
+            } else {
+                (void)hipStreamSynchronize(aux[a]);
+            }
+        }
     if (e == hipSuccess && rc == ZG_OK && row)  // rows are consecutive levels first_small, first_small + 1, ...
         rc = zg_msm_g1_batch_dev(srs, small_len, d_small, row, st, d_res + 9 * first_small);
     if (e == hipSuccess && rc == ZG_OK && len > 0)
