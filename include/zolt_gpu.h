@@ -223,6 +223,12 @@ ZG_API int zg_fr_spartan_combine_dev(const uint64_t *d_eq, const uint64_t *d_az,
 typedef struct zg_sc_s *zg_sc_t;
 ZG_API int zg_sumcheck_open(const uint64_t *evals, size_t len, int layout, zg_sc_t *s);
 ZG_API int zg_sumcheck_open_dev(const uint64_t *d_evals, size_t len, int layout, void *stream, zg_sc_t *s); /* copies */
+/* Spartan's first sumcheck instance in ONE pass (src/zkvm/spartan/mod.zig:182-206, then Sumcheck.Prover.init): opens a session
+ * whose table is f[i] = eq(r, i) * (Az[i]*Bz[i] - Cz[i]) (eq as zg_fr_eq_table: r[0] <-> MSB, optional scale; Az, Bz, Cz: 2^v
+ * device-resident elements) with round 0's sums already computed; the eq table is never materialised, nothing is copied. */
+ZG_API int zg_sumcheck_open_spartan_dev(const uint64_t *r /* host, v*4 */, size_t v, const uint64_t *scale /* host 4 or NULL */,
+                                 const uint64_t *d_az, const uint64_t *d_bz, const uint64_t *d_cz, int layout, void *stream,
+                                 zg_sc_t *s);
 /* Prover.nextRound's two sums (:79-93): HIGH_HALF g0 = sum first half, g1 = sum second half;
  * LOW_PAIR g0 = sum even, g1 = sum odd (jolt_r1cs.zig:436-444). */
 ZG_API int zg_sumcheck_round_sums(zg_sc_t s, uint64_t g0[4], uint64_t g1[4]);

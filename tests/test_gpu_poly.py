@@ -155,6 +155,39 @@ def test_device_resident_run_sumcheck_kats_and_full_size(zl, ob):
         zl.run_sumcheck(evals[:100])  # length must be a power of two
 
 
+@pytest.mark.parametrize("v,layout", [(0, 0), (1, 0), (3, 1), (8, 0), (9, 1), (12, 0), (14, 1), (16, 0)])
+def test_session_opened_from_spartan_inputs(zl, ob, v, layout):
+    """zg_sumcheck_open_spartan_dev: f = eq(r,.)*(Az*Bz - Cz) built straight into the session with round 0's sums
+    (src/zkvm/spartan/mod.zig:182-206 + Sumcheck.Prover.init) equals eq table -> combine -> open -> round_sums done separately
+    with the oracle, including the scaled eq table, both fold layouts, and the rounds that follow."""
+    import ctypes as C
+    n = 1 << v
+    r = _rand(ob, 3000 + v, v) if v else np.zeros((0, 4), dtype=np.uint64)
+    scale = _rand(ob, 3100 + v, 1)[0] if v % 2 else None
+    az, bz, cz = (_rand(ob, 3200 + 3 * v + k, n) for k in range(3))
+    want = ob.fr_spartan_combine(ob.fr_eq_table(r, scale), az, bz, cz)
+    d = []
+    for t in (az, bz, cz):
+        p = C.c_void_p()
+        assert zl._lib.zg_dev_alloc(C.c_size_t(n * 32), C.byref(p)) == 0
+        assert zl._lib.zg_memcpy_h2d(p, np.ascontiguousarray(t).ctypes.data_as(C.c_void_p), C.c_size_t(n * 32)) == 0
+        d.append(p)
+    s = zl.SumcheckSession.open_spartan_dev(r, d[0].value, d[1].value, d[2].value, layout=layout, scale=scale)
+    assert len(s) == n and np.array_equal(s.read(), want)
+    cur = want
+    chals = _rand(ob, 3300 + v, max(v, 1))
+    for k in range(v):
+        g0, g1 = s.round_sums()
+        w0, w1 = ob.fr_sum_halves(cur) if layout == 0 else ob.fr_sum_even_odd(cur)
+        assert np.array_equal(g0, w0) and np.array_equal(g1, w1), k
+        s.bind(chals[k])
+        cur = ob.fr_bind_high(cur, chals[k]) if layout == 0 else ob.fr_bind_low(cur, chals[k])
+    assert np.array_equal(s.final(), cur[0])
+    s.close()
+    for p in d:
+        zl._lib.zg_dev_free(p)
+
+
 def test_sumcheck_kats(zl, ob):
     """src/subprotocols/mod.zig:366-461: [1,2,3,4] -> g(0)=3, g(1)=7, r=2 -> [5,6]; [1..8] -> claim 36."""
     s = zl.SumcheckSession.open(U.fr([1, 2, 3, 4]))

@@ -410,6 +410,45 @@ __global__ void __launch_bounds__(256) sc_finish_kernel(const uint64_t *partials
     }
 }
 
+// Spartan's first sumcheck instance in one pass (src/zkvm/spartan/mod.zig:182-206 followed by Sumcheck.Prover.init): the table
+//   f[i] = eq(r, i) * (Az[i]*Bz[i] - Cz[i]),   eq(r, i) = hi[i >> v_lo] * lo[i & (2^v_lo - 1)]
+// is written straight into the session's buffer and round 0's pair of sums is accumulated on the way (finished by the last
+// block to arrive, like every other round): the eq table is never materialised, the 2^v-entry copy into the session and the
+// separate first sums pass disappear.
+template <int LAYOUT>
+__global__ void __launch_bounds__(256) eq_spartan_kernel(const uint64_t *lo_tab, int v_lo, const uint64_t *hi, uint32_t n_hi,
+                                                         uint32_t hi_per_block, const uint64_t *az, const uint64_t *bz, const uint64_t *cz,
+                                                         uint64_t *out, uint64_t *partials, uint64_t *sums, uint32_t *counter, uint64_t *flag,
+                                                         uint64_t seq) {
+    __shared__ uint4 sh[256 * 4];
+    uint32_t lo = threadIdx.x;
+    Fr g0 = Fr::zero(), g1 = Fr::zero();
+    if (lo < (1u << v_lo)) {
+        F29 tp = fr29_prescale(fe_load<FrParams>(lo_tab + 4 * (size_t)lo));
+        uint32_t h0 = blockIdx.x * hi_per_block;
+        for (uint32_t k = 0; k < hi_per_block; k++) {
+            uint32_t h = h0 + k;
+            if (h >= n_hi) break;
+            size_t i = ((size_t)h << v_lo) | lo;
+            Fr e = fr_mul29(fe_load<FrParams>(hi + 4 * (size_t)h), tp);
+            Fr a = fe_load<FrParams>(az + 4 * i), b = fe_load<FrParams>(bz + 4 * i), c = fe_load<FrParams>(cz + 4 * i);
+            Fr f = fe_mul(e, fe_sub(fe_mul(a, b), c));
+            fe_store(out + 4 * i, f);
+            bool second = LAYOUT == ZG_SC_HIGH_HALF ? (n_hi > 1 ? h >= n_hi / 2 : lo >= (1u << v_lo) / 2) : (lo & 1u);
+            if (second) g1 = fe_add(g1, f);
+            else g0 = fe_add(g0, f);
+        }
+    }
+    block_sum_pair(g0, g1, sh);
+    finish_round(g0, g1, sh, partials, sums, counter, flag, seq, ScRunArg{nullptr, 0, 0, 0});
+}
+
+static unsigned env_uint(const char *name, unsigned dflt, unsigned lo, unsigned hi) {
+    const char *e = getenv(name);
+    unsigned v = e && *e ? (unsigned)atoi(e) : dflt;
+    return v < lo ? lo : (v > hi ? hi : v);
+}
+
 // scratch layout of a fold/sums launch (u64 words): [0, 8*SC_MAX_BLOCKS) block pairs | 16 words: arrival counter
 // (must be 0 before a launch; the kernels re-arm it) | 8 words: the round's pair when it is not sent to a host mailbox
 constexpr unsigned SC_MAX_BLOCKS = 2048;
@@ -480,6 +519,40 @@ static int eq_table_enqueue(const uint64_t *r_host, size_t v, const uint64_t *sc
     uint32_t hpb = n_hi / 1024 ? n_hi / 1024 : 1;  // rows per block: amortises the per-thread prescale, keeps >= 4 blocks per CU
     hipLaunchKernelGGL(eq_main_kernel, dim3(div_up(n_hi, hpb)), dim3(256), 0, st, d_lo, v_lo, d_hi, n_hi, hpb, d_out);
     prof_end(ZG_PROF_EQ_TABLE, st);
+    ZG_HIP(hipGetLastError());
+    ZG_HIP(hipStreamSynchronize(st));  // r_host / temporaries are released on return
+    return ZG_OK;
+}
+
+// factor tables + fused table/sums kernel of zg_sumcheck_open_spartan_dev
+static int eq_spartan_enqueue(const uint64_t *r_host, size_t v, const uint64_t *scale_host, const uint64_t *d_az, const uint64_t *d_bz,
+                              const uint64_t *d_cz, int layout, uint64_t *d_out, uint64_t *partials, uint64_t *sums, uint64_t *flag,
+                              uint64_t seq, hipStream_t st) {
+    int v_lo = v < 8 ? (int)v : 8, v_hi = (int)v - v_lo;
+    uint32_t n_hi = 1u << v_hi;
+    Scratch s_r((v + 1) * 32 + 32), s_hi((size_t)n_hi * 32 + 256 * 32);
+    if (!s_r.p || !s_hi.p) return ZG_ERR_NOMEM;
+    uint64_t *d_r = s_r.as<uint64_t>(), *d_hi = s_hi.as<uint64_t>(), *d_lo = d_hi + 4 * (size_t)n_hi;
+    if (v) ZG_HIP(hipMemcpyAsync(d_r + 4, r_host, v * 32, hipMemcpyHostToDevice, st));
+    if (scale_host) ZG_HIP(hipMemcpyAsync(d_r, scale_host, 32, hipMemcpyHostToDevice, st));
+    prof_begin(ZG_PROF_EQ_TABLE, st);
+    uint32_t nb_hi = div_up(n_hi, 64), nb_lo = div_up(1u << v_lo, 64);
+    hipLaunchKernelGGL(eq_tables_kernel, dim3(nb_hi + nb_lo), dim3(256), 0, st, d_r + 4, v_hi, v_lo, scale_host ? d_r : nullptr, d_hi, nb_hi,
+                       d_lo);
+    prof_end(ZG_PROF_EQ_TABLE, st);
+    static const uint32_t nb_cap = env_uint("ZG_SC_SPARTAN_BLOCKS", 512, 1, SC_MAX_BLOCKS);
+    uint32_t nb = n_hi < nb_cap ? n_hi : nb_cap;  // enough waves per SIMD for three products per element; each block is one more atomic
+    uint32_t hpb = div_up(n_hi, nb);
+    nb = div_up(n_hi, hpb);
+    uint32_t *counter = reinterpret_cast<uint32_t *>(partials + 8 * (size_t)SC_MAX_BLOCKS);
+    prof_begin(ZG_PROF_COMBINE, st);
+    if (layout == ZG_SC_HIGH_HALF)
+        hipLaunchKernelGGL(eq_spartan_kernel<ZG_SC_HIGH_HALF>, dim3(nb), dim3(256), 0, st, d_lo, v_lo, d_hi, n_hi, hpb, d_az, d_bz, d_cz, d_out,
+                           partials, sums, counter, flag, seq);
+    else
+        hipLaunchKernelGGL(eq_spartan_kernel<ZG_SC_LOW_PAIR>, dim3(nb), dim3(256), 0, st, d_lo, v_lo, d_hi, n_hi, hpb, d_az, d_bz, d_cz, d_out,
+                           partials, sums, counter, flag, seq);
+    prof_end(ZG_PROF_COMBINE, st);
     ZG_HIP(hipGetLastError());
     ZG_HIP(hipStreamSynchronize(st));  // r_host / temporaries are released on return
     return ZG_OK;
@@ -973,11 +1046,6 @@ int zg_hyperkzg_batch_open(zg_bases_t srs, const uint64_t *const *polys, const s
 }
 
 // ---------------------------------------------------------------- runSumcheck, device-resident
-static unsigned env_uint(const char *name, unsigned dflt, unsigned lo, unsigned hi) {
-    const char *e = getenv(name);
-    unsigned v = e && *e ? (unsigned)atoi(e) : dflt;
-    return v < lo ? lo : (v > hi ? hi : v);
-}
 
 static uint32_t ilog2_sz(size_t x) {
     uint32_t r = 0;
@@ -1106,6 +1174,26 @@ int zg_sumcheck_open_dev(const uint64_t *d_evals, size_t len, int layout, void *
         sc_free(s);
         return ZG_ERR_HIP;
     }
+    *out = s;
+    return ZG_OK;
+}
+
+int zg_sumcheck_open_spartan_dev(const uint64_t *r, size_t v, const uint64_t *scale, const uint64_t *d_az, const uint64_t *d_bz,
+                                 const uint64_t *d_cz, int layout, void *stream, zg_sc_t *out) {
+    ZG_INIT();
+    if (!out || (v && !r) || !d_az || !d_bz || !d_cz || v > 30) {
+        set_error("zg_sumcheck_open_spartan_dev: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    zg_sc_s *s = nullptr;
+    ZG_TRY(sc_create((size_t)1 << v, layout, pick_stream(stream), &s));
+    s->seq = 1;  // the fused kernel publishes round 0's pair
+    int rc = eq_spartan_enqueue(r, v, scale, d_az, d_bz, d_cz, layout, s->buf[0], s->d_partials, s->h_pin, s->h_pin + 12, s->seq, s->st);
+    if (rc != ZG_OK) {
+        sc_free(s);
+        return rc;
+    }
+    s->sums_valid = s->len >= 2;
     *out = s;
     return ZG_OK;
 }

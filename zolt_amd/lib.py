@@ -36,7 +36,7 @@ SYMBOLS = [
     "zg_sumcheck_open", "zg_sumcheck_open_dev", "zg_sumcheck_round_sums", "zg_sumcheck_bind",
     "zg_sumcheck_len", "zg_sumcheck_final", "zg_sumcheck_read", "zg_sumcheck_close",
     "zg_sumcheck_round_sums_dev", "zg_sumcheck_read_dev",
-    "zg_run_sumcheck", "zg_run_sumcheck_dev",
+    "zg_run_sumcheck", "zg_run_sumcheck_dev", "zg_sumcheck_open_spartan_dev",
 ]
 
 
@@ -364,6 +364,15 @@ class SumcheckSession:
     def open_dev(cls, d_evals, n, layout=SC_HIGH_HALF, stream=0):
         h = C.c_void_p()
         _chk(_lib.zg_sumcheck_open_dev(_d(d_evals), C.c_size_t(n), C.c_int(layout), _d(stream), C.byref(h)), "zg_sumcheck_open_dev")
+        return cls(h)
+
+    @classmethod
+    def open_spartan_dev(cls, r, d_az, d_bz, d_cz, layout=SC_HIGH_HALF, scale=None, stream=0):
+        """f = eq(r, .) * (Az*Bz - Cz) built straight into a new session (round 0's sums included), zg_sumcheck_open_spartan_dev."""
+        r = _c(r)
+        h = C.c_void_p()
+        _chk(_lib.zg_sumcheck_open_spartan_dev(_h(r), C.c_size_t(r.size // 4), _h(_c(scale)), _d(d_az), _d(d_bz), _d(d_cz), C.c_int(layout),
+                                               _d(stream), C.byref(h)), "zg_sumcheck_open_spartan_dev")
         return cls(h)
 
     def round_sums(self):
