@@ -978,11 +978,15 @@ __global__ void msm_groups_kernel(const char *rg, int G, int c, int mode, uint64
     rg += 128 * (size_t)G * blockIdx.x;  // one single-thread block per scalar vector
     out_rec += (size_t)rec_stride * blockIdx.x;
     out_inf += (size_t)inf_stride * blockIdx.x;
-    XYZZ acc = xyzz_load(rg + 128 * (size_t)(G - 1));
+    // one quad of lanes per scalar vector (g1_29x4.hip.h): the (G-1)*c doublings are a serial chain
+    uint32_t q = threadIdx.x & 3;
+    XYZZ29 acc29 = xyzz29_from_std_val(xyzz_load(rg + 128 * (size_t)(G - 1)));
     for (int g = G - 2; g >= 0; g--) {
-        for (int k = 0; k < c; k++) acc = xyzz_dbl(acc);
-        acc = xyzz_add(acc, xyzz_load(rg + 128 * (size_t)g));
+        for (int k = 0; k < c; k++) acc29 = xyzz29_dbl4(acc29, q);
+        acc29 = xyzz29_add4(acc29, xyzz29_from_std_val(xyzz_load(rg + 128 * (size_t)g)), q);
     }
+    if (threadIdx.x != 0) return;
+    XYZZ acc = xyzz29_to_std_val(acc29);
     if (mode == 2) write_partial_unnormalised(acc, out_rec);
     else write_result(acc, mode, out_rec, out_inf);
 }
@@ -1514,7 +1518,7 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
     hipLaunchKernelGGL(msm_final_kernel, dim3(p.G * p.K), dim3(512), 0, st, ln.d_bits, p.c, p.PB, p.G, ln.d_rg, mode, d_rec, d_inf_out,
                        rec_stride, inf_stride);
     if (p.G > 1)
-        hipLaunchKernelGGL(msm_groups_kernel, dim3(p.K), dim3(1), 0, st, ln.d_rg, p.G, p.c, mode, d_rec, d_inf_out, rec_stride, inf_stride);
+        hipLaunchKernelGGL(msm_groups_kernel, dim3(p.K), dim3(4), 0, st, ln.d_rg, p.G, p.c, mode, d_rec, d_inf_out, rec_stride, inf_stride);
     prof_end(ZG_PROF_MSM_REDUCE, st);
     ZG_HIP(hipGetLastError());
     ZG_HIP(hipEventRecord(ln.done, st));
