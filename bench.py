@@ -27,7 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # HBM traffic of one msm_accumulate launch at 2^20 points (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
-# passes, profiles/r1g_rocprofv3_summary_streams1.txt): 1,292,897 KB fetched + 22,848 KB written. The launch
+# passes, profiles/r1h_rocprofv3_summary_streams1.txt): 1,292,897 KB fetched + 22,848 KB written. The launch
 # gathers 16.7M random 64-byte rows (1.07 GB) + 67 MB of sorted refs: FETCH_SIZE is taken uncorrected because
 # the gfx950 x2 under-count applies to wide streaming reads tallied as 128-byte requests, not to 64-byte rows.
 MEASURED_TRAFFIC = {20: (1292897.0 + 22848.1) * 1024.0}
@@ -261,7 +261,7 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "msm_accumulate_chunk_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                      "traffic": MEASURED_TRAFFIC.get(args.logn) if world == 1 else None,
-                     "traffic_source": "rocprofv3 PMC FETCH_SIZE+WRITE_SIZE, profiles/r1g_rocprofv3_summary_streams1.txt",
+                     "traffic_source": "rocprofv3 PMC FETCH_SIZE+WRITE_SIZE, profiles/r1h_rocprofv3_summary_streams1.txt",
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": acc_avg_ms,
                      "note": "MSM is integer-ALU-bound (10 Fp mul per mixed add x windows per point); see DESIGN.md"},
         "extra": {"kernel_ms_per_msm": {k: (v[0] / max(v[1], 1)) for k, v in prof.items() if v[1]},
