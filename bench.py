@@ -27,10 +27,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # HBM traffic of one msm_accumulate launch at 2^20 points (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
-# passes, profiles/r1h_rocprofv3_summary_streams1.txt): 1,292,897 KB fetched + 22,848 KB written. The launch
+# passes, profiles/r1h_rocprofv3_summary_streams1.txt): 1,293,680 KB fetched + 22,848 KB written. The launch
 # gathers 16.7M random 64-byte rows (1.07 GB) + 67 MB of sorted refs: FETCH_SIZE is taken uncorrected because
 # the gfx950 x2 under-count applies to wide streaming reads tallied as 128-byte requests, not to 64-byte rows.
-MEASURED_TRAFFIC = {20: (1292897.0 + 22848.1) * 1024.0}
+MEASURED_TRAFFIC = {20: (1293679.8 + 22848.1) * 1024.0}
 # static instruction mix of one lazy-limb XYZZ mixed add (hipcc --save-temps of the accumulate fast path): 1467
 # v_mad_u64_u32 + 146 v_lshl_add_u64 + 144 v_lshrrev_b64 + 81 v_mul_lo_u32 at 4 issue cycles per wave, 382 32-bit
 # add/and/shift/sub at 2 (tools/microbench.hip rates)
