@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Randomised differential test of the MSM entry points against the CPU oracle (not part of the pytest suite: run it for as
+long as you like).  usage: fuzz_msm.py [seconds=60] [seed=1]"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import binding as ob  # checker
+from zolt_amd import lib
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+lib.init(0)
+NMAX = 70000
+gm = ob.g1_gen_multiples(NMAX)
+R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+
+def scalars(n, kind):
+    if kind == 0:
+        raw = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(n, 4), dtype=np.uint64)
+        return ob.f_to_mont(ob.FR, raw)
+    if kind == 1:
+        return ob.f_from_u64(ob.FR, rng.integers(0, 2, size=n).astype(np.uint64))
+    if kind == 2:
+        return ob.f_from_u64(ob.FR, rng.integers(0, 1 << 16, size=n).astype(np.uint64))
+    if kind == 3:
+        return ob.f_from_u64(ob.FR, np.full(n, int(rng.integers(1, 1 << 40)), dtype=np.uint64))
+    sc = scalars(n, 0)
+    if n == 0:
+        return sc
+    k = max(1, n // 7)
+    idx = rng.integers(0, n, size=k)
+    vals = [0, 1, R - 1, R - 2, (1 << 15), (1 << 16) - 1, (1 << 16), (1 << 255) % R, ((1 << 240) - 1)]
+    raw = np.array([[(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)] for v in vals], dtype=np.uint64)
+    sc[idx] = ob.f_to_mont(ob.FR, raw)[rng.integers(0, len(vals), size=k)]
+    return sc
+
+
+t0 = time.time()
+cases = 0
+while time.time() - t0 < budget:
+    big = rng.random() < 0.25
+    n = int(rng.integers(32768, NMAX)) if big else int(rng.choice([0, 1, 2, 7, 8, 9, 31, 33, 100, 511, 1000, 2048, 4097, 9000, 20000]))
+    perm_dup = rng.random() < 0.3
+    xy = gm[:n].copy()
+    if perm_dup and n > 4:  # repeated and negated points in the same bucket sets
+        xy[n // 2:] = xy[:n - n // 2]
+        if rng.random() < 0.5:
+            neg = xy[n // 2:].copy()
+            neg[:, 4:] = ob.f_neg(ob.FP, neg[:, 4:])
+            xy[n // 2:] = neg
+    inf = (rng.random(n) < 0.05).astype(np.uint8) if rng.random() < 0.5 else None
+    cfg = {}
+    if rng.random() < 0.5:
+        cfg["window_bits"] = int(rng.choice([2, 3, 5, 7, 8, 10, 13, 15, 16]))
+    if rng.random() < 0.4:
+        cfg["precompute_levels"] = int(rng.integers(1, 20))
+    try:
+        b = lib.Bases.upload(xy, inf, **cfg)
+    except lib.ZgError as e:  # e.g. too many groups for a tiny window with few levels: a documented refusal, not a mismatch
+        continue
+    for _ in range(2):
+        sc = scalars(n, int(rng.integers(0, 5)))
+        off = int(rng.integers(0, n + 1)) if rng.random() < 0.3 else 0
+        m = int(rng.integers(0, n - off + 1)) if off or rng.random() < 0.3 else n
+        got, ginf = b.msm(sc[:m], off=off, n=m)
+        want, winf = ob.msm_g1(xy[off:off + m], None if inf is None else inf[off:off + m], sc[:m])
+        assert ginf == winf and np.array_equal(got, want), ("msm", n, cfg, off, m)
+        cases += 1
+    if n and rng.random() < 0.5:
+        k = int(rng.integers(2, 12))
+        nb = int(rng.integers(1, min(n, 6000) + 1))
+        batches = [scalars(nb, int(rng.integers(0, 5))) for _ in range(k)]
+        outs, infs = b.msm_batch(batches, n=nb)
+        for j in range(k):
+            want, winf = ob.msm_g1(xy[:nb], None if inf is None else inf[:nb], batches[j])
+            assert infs[j] == winf and np.array_equal(outs[j], want), ("batch", n, cfg, nb, k, j)
+        cases += k
+    b.free()
+print(f"fuzz ok: {cases} MSMs checked in {time.time() - t0:.1f} s")

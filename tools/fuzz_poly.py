@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Randomised differential test of the poly / sumcheck entry points against the CPU oracle.  usage: fuzz_poly.py [seconds=60] [seed=1]"""
+import ctypes as C
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import binding as ob  # checker
+from zolt_amd import lib
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+lib.init(0)
+
+
+def rand_fr(n, sparse=False):
+    raw = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(n, 4), dtype=np.uint64)
+    a = ob.f_to_mont(ob.FR, raw)
+    if sparse and n:
+        a[rng.random(n) < 0.5] = 0
+    return a
+
+
+def dev(a):
+    p = C.c_void_p()
+    assert lib._lib.zg_dev_alloc(C.c_size_t(max(a.size, 1) * 8), C.byref(p)) == 0
+    if a.size:
+        assert lib._lib.zg_memcpy_h2d(p, np.ascontiguousarray(a).ctypes.data_as(C.c_void_p), C.c_size_t(a.size * 8)) == 0
+    return p
+
+
+t0 = time.time()
+cases = 0
+while time.time() - t0 < budget:
+    v = int(rng.integers(0, 15))
+    n = 1 << v
+    sparse = rng.random() < 0.3
+    tab = rand_fr(n, sparse)
+    # device-resident runSumcheck vs oracle
+    res = lib.run_sumcheck(tab)
+    wc, wr, wch, wfin, wok = ob.run_sumcheck(tab)
+    assert np.array_equal(res["claim"], wc) and np.array_equal(res["final_eval"], wfin) and res["result"] == bool(wok)
+    assert np.array_equal(res["rounds"].reshape(-1, 2, 4), np.asarray(wr).reshape(-1, 2, 4))
+    # sessions in both layouts with arbitrary challenges
+    for layout in (0, 1):
+        s = lib.SumcheckSession.open(tab, layout)
+        cur = tab
+        for k in range(v):
+            g0, g1 = s.round_sums()
+            w0, w1 = ob.fr_sum_halves(cur) if layout == 0 else ob.fr_sum_even_odd(cur)
+            assert np.array_equal(g0, w0) and np.array_equal(g1, w1)
+            ch = rand_fr(1)[0]
+            s.bind(ch)
+            cur = ob.fr_bind_high(cur, ch) if layout == 0 else ob.fr_bind_low(cur, ch)
+        assert np.array_equal(s.final(), cur[0])
+        s.close()
+    # eq table (scaled or not), Spartan combine, fused opening
+    r = rand_fr(v)
+    scale = rand_fr(1)[0] if rng.random() < 0.5 else None
+    eq = lib.fr_eq_table(r, scale)
+    assert np.array_equal(eq, ob.fr_eq_table(r, scale))
+    az, bz, cz = rand_fr(n, sparse), rand_fr(n), rand_fr(n, sparse)
+    f = lib.fr_spartan_combine(eq, az, bz, cz)
+    assert np.array_equal(f, ob.fr_spartan_combine(eq, az, bz, cz))
+    d = [dev(x) for x in (az, bz, cz)]
+    layout = int(rng.integers(0, 2))
+    s = lib.SumcheckSession.open_spartan_dev(r, d[0].value, d[1].value, d[2].value, layout=layout, scale=scale)
+    assert np.array_equal(s.read(), f)
+    if v:
+        g0, g1 = s.round_sums()
+        w0, w1 = ob.fr_sum_halves(f) if layout == 0 else ob.fr_sum_even_odd(f)
+        assert np.array_equal(g0, w0) and np.array_equal(g1, w1)
+    s.close()
+    for p in d:
+        lib._lib.zg_dev_free(p)
+    if v <= 12:
+        pt = rand_fr(v)
+        assert np.array_equal(lib.fr_dense_evaluate(tab, pt), ob.fr_dense_evaluate(tab, pt))
+    cases += 1
+print(f"fuzz ok: {cases} random instances (all entry points) in {time.time() - t0:.1f} s")
