@@ -73,6 +73,44 @@ ZG_DEV XYZZ29 xyzz29_dbl4(const XYZZ29 &p, uint32_t q) {
     return r;
 }
 
+// acc += (px, py) by a quad; (px, py) an affine point in lazy form, never infinity (xyzz29_madd)
+ZG_DEV void xyzz29_madd4(XYZZ29 &a, bool &inf, const F29 &px, const F29 &py, uint32_t q) {
+    if (inf) {
+        a.x = px; a.y = py;
+#pragma unroll
+        for (int i = 0; i < 9; i++) { a.zz.l[i] = Fp29::ONE[i]; a.zzz.l[i] = Fp29::ONE[i]; }
+        inf = false;
+        return;
+    }
+    // level 1: q0: U2 = px*ZZ, q1: S2 = py*ZZZ (q2, q3 mirror them)
+    F29 t1 = f29_mul(f29_pick((q & 1) == 0, px, py), f29_pick((q & 1) == 0, a.zz, a.zzz));
+    F29 U2 = quad_bcast<0>(t1), S2 = quad_bcast<1>(t1);
+    F29 Pp = f29_sub7(U2, a.x);
+    F29 R = f29_sub4(S2, a.y);
+    if (f29_is_zero_modp(Pp)) {  // same x: P == acc (double) or P == -acc (infinity) — rare; every lane takes the complete single-lane path
+        XYZZ s = xyzz29_to_std(a, false);
+        Affine pt;
+        pt.x = f29_to_fp(px); pt.y = f29_to_fp(py);
+        xyzz29_from_std(xyzz_madd(s, pt), a, inf);
+        return;
+    }
+    // level 2: q0: PP = P^2, q1: RR = R^2
+    F29 s2 = f29_pick((q & 1) == 0, Pp, R);
+    F29 t2 = f29_mul(s2, s2);
+    F29 PP = quad_bcast<0>(t2), RR = quad_bcast<1>(t2);
+    // level 3: q0: PPP = P*PP, q1: Q = X1*PP, q2: ZZ3 = ZZ*PP
+    F29 t3 = f29_mul(quad_sel(q, Pp, a.x, a.zz, a.zz), PP);
+    F29 PPP = quad_bcast<0>(t3), Q = quad_bcast<1>(t3);
+    a.zz = quad_bcast<2>(t3);
+    F29 X3 = f29_x3(RR, PPP, Q);
+    // level 4: q0: Y3 = R*(Q - X3) + (4p - Y1)*PPP; q1: ZZZ3 = ZZZ*PPP
+    F29 z = f29_zero();
+    F29 t4 = f29_mul2(f29_pick(q == 0, R, a.zzz), f29_pick(q == 0, f29_sub7(Q, X3), PPP), f29_pick(q == 0, f29_neg4(a.y), z), f29_pick(q == 0, PPP, z));
+    a.y = quad_bcast<0>(t4);
+    a.zzz = quad_bcast<1>(t4);
+    a.x = X3;
+}
+
 // a + b by a quad (complete, as xyzz29_add)
 ZG_DEV XYZZ29 xyzz29_add4(const XYZZ29 &a, const XYZZ29 &b, uint32_t q) {
     if (xyzz29_is_identity(a)) return b;

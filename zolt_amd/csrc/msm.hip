@@ -698,10 +698,17 @@ ZG_DEV uint32_t chunk_len(uint32_t total, uint32_t NT) {
     return C ? C : 1;
 }
 
+// QUAD = true: one chunk per quad of lanes, every mixed add by xyzz29_madd4 — for launch sets too short to fill the GPU, where
+// the kernel is a latency chain of a few adds per chunk rather than a throughput problem (4 * NT lanes are launched).
+template <bool QUAD>
 __global__ void __launch_bounds__(256) msm_accumulate_chunk_kernel(const uint32_t *sorted, const uint32_t *starts, const uint32_t *nzrank,
                                                                    const uint32_t *nzlist, const char *table, uint32_t NK, uint32_t NT,
                                                                    char *part) {
-    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    uint32_t i = blockIdx.x * 256 + threadIdx.x, q = 0;
+    if (QUAD) {
+        q = i & 3;
+        i >>= 2;
+    }
     uint32_t total = starts[NK];
     uint32_t C = chunk_len(total, NT);
     uint64_t a64 = (uint64_t)i * C;
@@ -728,18 +735,19 @@ __global__ void __launch_bounds__(256) msm_accumulate_chunk_kernel(const uint32_
             nneg = e2 >> 31;
         }
         if (p == kend) {  // the run of bucket k ended inside this chunk: emit its partial, move on
-            xyzz29_store(part + 144 * (size_t)(i + r), acc_inf ? xyzz29_identity() : acc);
+            if (q == 0) xyzz29_store(part + 144 * (size_t)(i + r), acc_inf ? xyzz29_identity() : acc);
             acc_inf = true;
             r++;  // next non-empty bucket (p < total, so it exists); empty buckets are never walked
             kend = starts[nzlist[r] + 1];
         }
         F29 px = f29_unpack(cur.x.l), py = f29_unpack(cur.y.l);
         if (cneg) py = f29_neg2(py);
-        xyzz29_madd(acc, acc_inf, px, py);
+        if (QUAD) xyzz29_madd4(acc, acc_inf, px, py, q);
+        else xyzz29_madd(acc, acc_inf, px, py);
         cur = nxt;
         cneg = nneg;
     }
-    xyzz29_store(part + 144 * (size_t)(i + r), acc_inf ? xyzz29_identity() : acc);
+    if (q == 0) xyzz29_store(part + 144 * (size_t)(i + r), acc_inf ? xyzz29_identity() : acc);
 }
 
 // GS adjacent QUADS of lanes per bucket (4*GS | 64, GS chosen from the expected partials per bucket) sum its partials: strided
@@ -1091,6 +1099,16 @@ static uint32_t sort_span(uint32_t NK) {
     return NK <= 4096 ? 256u : 2048u;
 }
 
+// chunks (threads, or quads of lanes) of the chunk-scheduled accumulate for a launch set of `digits` entries
+static uint32_t chunk_threads(uint64_t digits) {
+    uint64_t want = digits / 16;
+    uint32_t nt = 1024;
+    while (nt < want && nt < 131072u) nt <<= 1;
+    // full size = 2 waves per SIMD on 256 CUs; 15/16 of it leaves a few CUs with spare registers so that
+    // another stream's latency-bound kernels (bit sums, final) can run under this kernel (measured +4-6 % MSM/s)
+    return nt == 131072u ? 122880u : nt;
+}
+
 static int make_plan(size_t n, const zg_msm_config *cfg, MsmPlan &p, size_t batch = 1) {
     p.fb = 0;  // sort mode is decided afterwards (plan_two_pass)
     p.rb = 0;
@@ -1137,15 +1155,7 @@ static int make_plan(size_t n, const zg_msm_config *cfg, MsmPlan &p, size_t batc
     }
     // chunk-scheduled accumulate: enough threads to fill 2 waves per SIMD on 256 CUs, fewer for small inputs
     p.NT = 0;
-    if (env_int("ZG_MSM_CHUNK_SCHED", 1)) {
-        uint64_t want = ((uint64_t)n * batch * p.W) / 16;
-        uint32_t nt = 1024;
-        while (nt < want && nt < 131072u) nt <<= 1;
-        // full size = 2 waves per SIMD on 256 CUs; 15/16 of it leaves a few CUs with spare registers so that
-        // another stream's latency-bound kernels (bit sums, final) can run under this kernel (measured +4-6 % MSM/s)
-        if (nt == 131072u) nt = 122880u;
-        p.NT = (uint32_t)env_int("ZG_MSM_CHUNK_THREADS", (int)nt);
-    }
+    if (env_int("ZG_MSM_CHUNK_SCHED", 1)) p.NT = (uint32_t)env_int("ZG_MSM_CHUNK_THREADS", (int)chunk_threads((uint64_t)n * batch * p.W));
     // combine lanes per bucket: a bucket expects about NT/NK + 1 partials; keep ~4 per lane
     p.GS = 1;
     while (p.GS < 16 && (uint64_t)p.GS * 4 < (uint64_t)p.NT / p.NK + 1) p.GS <<= 1;  // GS quads of lanes per bucket: 4 * GS <= 64
@@ -1501,20 +1511,28 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
     prof_end(ZG_PROF_MSM_SORT, st);
     prof_begin(ZG_PROF_MSM_ACCUMULATE, st);
     if (p.NT) {
+        // a launch over a sub-range of the handle (a short prefix, the last set of a batch) gets as many chunks as ITS digits
+        // warrant, never more than the workspace was sized for
+        uint32_t NT = chunk_threads((uint64_t)n * p.W);
+        if (NT > p.NT || getenv("ZG_MSM_CHUNK_THREADS")) NT = p.NT;
         ZG_HIP(hipMemsetAsync(ln.d_state, 0, sizeof(MsmState), st));
-        hipLaunchKernelGGL(msm_accumulate_chunk_kernel, dim3(div_up(p.NT, 256)), dim3(256), 0, st, ln.d_sorted, ln.d_starts, ln.d_nzrank,
-                           ln.d_nzlist, b->d_table, p.NK, p.NT, ln.d_part);
+        if (NT <= (uint32_t)env_int("ZG_MSM_QUAD_ACC_MAX_CHUNKS", 32768))
+            hipLaunchKernelGGL(msm_accumulate_chunk_kernel<true>, dim3(div_up((size_t)NT * 4, 256)), dim3(256), 0, st, ln.d_sorted, ln.d_starts,
+                               ln.d_nzrank, ln.d_nzlist, b->d_table, p.NK, NT, ln.d_part);
+        else
+            hipLaunchKernelGGL(msm_accumulate_chunk_kernel<false>, dim3(div_up(NT, 256)), dim3(256), 0, st, ln.d_sorted, ln.d_starts,
+                               ln.d_nzrank, ln.d_nzlist, b->d_table, p.NK, NT, ln.d_part);
         prof_end(ZG_PROF_MSM_ACCUMULATE, st);  // the dominant kernel alone; combine/heavy stages count as reduction
         prof_begin(ZG_PROF_MSM_REDUCE, st);
         hipLaunchKernelGGL(msm_bucket_combine_kernel, dim3(div_up((size_t)p.NK * p.GS * 4, 64)), dim3(64), 0, st, ln.d_part, ln.d_starts,
-                           ln.d_nzrank, p.NK, p.NT, p.GS, ln.d_partial, ln.d_heavy, reinterpret_cast<MsmState *>(ln.d_state));
-        hipLaunchKernelGGL(msm_heavy_wave_kernel, dim3(1024), dim3(64), 0, st, ln.d_part, ln.d_starts, ln.d_nzrank, p.NK, p.NT, ln.d_heavy,
+                           ln.d_nzrank, p.NK, NT, p.GS, ln.d_partial, ln.d_heavy, reinterpret_cast<MsmState *>(ln.d_state));
+        hipLaunchKernelGGL(msm_heavy_wave_kernel, dim3(1024), dim3(64), 0, st, ln.d_part, ln.d_starts, ln.d_nzrank, p.NK, NT, ln.d_heavy,
                            ln.d_heavy + p.NK, reinterpret_cast<MsmState *>(ln.d_state), ln.d_partial);
-        uint32_t nblk_a = (p.NT + p.NK) / HEAVY_BLOCK_ITEMS + 1;
-        hipLaunchKernelGGL(msm_heavy_a_kernel, dim3(nblk_a), dim3(256), 0, st, ln.d_part, ln.d_starts, ln.d_nzrank, ln.d_nzlist, p.NK, p.NT,
+        uint32_t nblk_a = (NT + p.NK) / HEAVY_BLOCK_ITEMS + 1;
+        hipLaunchKernelGGL(msm_heavy_a_kernel, dim3(nblk_a), dim3(256), 0, st, ln.d_part, ln.d_starts, ln.d_nzrank, ln.d_nzlist, p.NK, NT,
                            p.GS, ln.d_part2,
                            reinterpret_cast<const MsmState *>(ln.d_state));
-        hipLaunchKernelGGL(msm_heavy_b_kernel, dim3(64), dim3(256), 0, st, ln.d_part2, ln.d_starts, ln.d_nzrank, p.NK, p.NT, ln.d_heavy + p.NK,
+        hipLaunchKernelGGL(msm_heavy_b_kernel, dim3(64), dim3(256), 0, st, ln.d_part2, ln.d_starts, ln.d_nzrank, p.NK, NT, ln.d_heavy + p.NK,
                            reinterpret_cast<const MsmState *>(ln.d_state), ln.d_partial);
     } else {
         hipLaunchKernelGGL(msm_accumulate_kernel, dim3(div_up((size_t)p.NK * p.S, 256)), dim3(256), 0, st, ln.d_sorted, ln.d_starts,
