@@ -394,18 +394,19 @@ __global__ void __launch_bounds__(1024) msm_partition_kernel(const uint32_t *dig
     uint32_t *buf = lds, *cnt = lds + STAGE_ENTRIES, *lbase = cnt + NCB, *sums = lbase + NCB + 1;  // sums: 1024 scan partials
     const uint32_t tid = threadIdx.x, T = 1024, fmask = (1u << fb) - 1u;
     uint32_t i0 = blockIdx.x * per_block, cntl = i0 < n ? (n - i0 < per_block ? n - i0 : per_block) : 0;
-    uint32_t total = cntl * (uint32_t)W;
     for (uint32_t k = tid; k < NCB; k += T) cnt[k] = 0;
     __syncthreads();
-    // the block's entries stay in registers between the counting and the placing pass (<= 32 per thread)
+    // the block's entries stay in registers between the counting and the placing pass (<= 32 per thread). Register r holds
+    // window w = r / JW, scalar (r % JW) * T + tid of the block, JW = ceil(cntl / T) in {1, 2} (two_pass_span keeps JW * W <= 32):
+    // w and the row base are wave-uniform, so no per-entry division is needed to find them.
+    const uint32_t jw2 = cntl > T ? 1u : 0u;
     uint32_t e[STAGE_ENTRIES / 1024];
 #pragma unroll
     for (int r = 0; r < (int)(STAGE_ENTRIES / 1024); r++) {
-        uint32_t x = (uint32_t)r * T + tid;
+        uint32_t w = (uint32_t)r >> jw2, j = ((uint32_t)r & jw2) * T + tid;
         e[r] = 0xFFFFFFFFu;
-        if (x < total) {
-            uint32_t w = x / cntl, i = i0 + (x - w * cntl);
-            uint32_t d = dig[(size_t)w * n + i];
+        if (w < (uint32_t)W && j < cntl) {
+            uint32_t d = dig[(size_t)w * n + i0 + j];
             e[r] = d;  // key | sign, or 0xFFFFFFFF for a dropped digit
             if (d != 0xFFFFFFFFu) atomicAdd(&cnt[(d & 0x7FFFFFFFu) >> fb], 1u);
         }
@@ -432,12 +433,14 @@ __global__ void __launch_bounds__(1024) msm_partition_kernel(const uint32_t *dig
         if (tid == T - 1) lbase[NCB] = sums[T - 1];
     }
     __syncthreads();
+    const bool batched = n != n_pts;  // several scalar vectors back to back over the same bases
 #pragma unroll
     for (int r = 0; r < (int)(STAGE_ENTRIES / 1024); r++) {
         if (e[r] != 0xFFFFFFFFu) {
-            uint32_t x = (uint32_t)r * T + tid, w = x / cntl, i = i0 + (x - w * cntl);
-            uint32_t key = e[r] & 0x7FFFFFFFu, bin = key >> fb, lvl = w / (uint32_t)G;
-            uint32_t packed = (e[r] & 0x80000000u) | ((key & fmask) << rb) | (uint32_t)((size_t)lvl * table_n + off + i % n_pts);
+            uint32_t w = (uint32_t)r >> jw2, i = i0 + ((uint32_t)r & jw2) * T + tid;
+            uint32_t key = e[r] & 0x7FFFFFFFu, bin = key >> fb, lvl = G == 1 ? w : w / (uint32_t)G;
+            uint32_t pt = batched ? i % n_pts : i;
+            uint32_t packed = (e[r] & 0x80000000u) | ((key & fmask) << rb) | (uint32_t)((size_t)lvl * table_n + off + pt);
             buf[lbase[bin] + atomicAdd(&cnt[bin], 1u)] = packed;
         }
     }
@@ -1169,7 +1172,9 @@ static int make_plan(size_t n, const zg_msm_config *cfg, MsmPlan &p, size_t batc
 // the per-(block, bucket) runs of the single-pass scatter are a few bytes, i.e. many buckets. table_rows = L * (bases in the
 // handle) bounds a row reference, which shares a 32-bit intermediate entry with the sign and the fine key bits.
 static uint32_t two_pass_span(int W) {
-    uint32_t cap = (STAGE_ENTRIES / (uint32_t)W) & ~255u;  // a partition block stages per_block * W entries in LDS
+    // a partition block stages per_block * W entries in LDS and keeps them in 32 registers per thread as ceil(per_block / 1024)
+    // rows per window (msm_partition_kernel): <= 2048 scalars for W <= 16 windows, <= 1024 up to 32 windows
+    uint32_t cap = W <= 16 ? 2048u : 1024u;
     uint32_t v = (uint32_t)env_int("ZG_MSM_TWO_PASS_SPAN", 2048);
     v = v < 256 ? 256 : v;
     return v > cap ? cap : v;
@@ -1178,7 +1183,7 @@ static void plan_two_pass(MsmPlan &p, size_t table_rows, size_t n_total) {
     p.fb = 0;
     p.rb = 0;
     p.NCB = 0;
-    if (!env_int("ZG_MSM_TWO_PASS_SORT", 1) || p.NK < 8192 || (uint64_t)n_total * p.W < (1u << 17)) return;
+    if (!env_int("ZG_MSM_TWO_PASS_SORT", 1) || p.NK < 8192 || p.W > 32 || (uint64_t)n_total * p.W < (1u << 17)) return;  // W: see two_pass_span
     int need = 1;
     while (((size_t)1 << need) < table_rows) need++;
     int fb = 31 - need, fb_max = env_int("ZG_MSM_FINE_BITS", 7);
