@@ -48,6 +48,7 @@ struct MsmPlan {
     uint32_t NK;   // total buckets = K * G * NB
     int K;         // MSMs sharing one launch set (scalar vectors over the same bases); bucket group = batch * G + w % G
     int PB;        // bit-sum partial blocks per (group, bit)
+    int lb, hb;    // two-dimensional bucket reduction: low / high bits of a digit magnitude (0 = one-dimensional bit sums)
     uint32_t NT;   // chunk-scheduled accumulate: threads (0 = per-bucket scheduling)
     int GS;        // lanes per bucket in the combine pass
     int fb;        // two-pass sort: low key bits resolved by the second pass (0 = single-pass LDS / atomic sort)
@@ -773,7 +774,8 @@ __global__ void __launch_bounds__(64) msm_bucket_combine_kernel(const char *part
                 if (g == 0 && q == 0) heavy_list[atomicAdd(&st->nheavy, 1u)] = k;
             } else {
                 light = true;
-                for (uint32_t j = g; j < cnt; j += (uint32_t)GS) acc = xyzz29_add4(acc, xyzz29_load(part + 144 * (size_t)(base + j)), q);
+                if (g < cnt) acc = xyzz29_load(part + 144 * (size_t)(base + g));  // the first partial is taken as it is
+                for (uint32_t j = g + (uint32_t)GS; j < cnt; j += (uint32_t)GS) acc = xyzz29_add4(acc, xyzz29_load(part + 144 * (size_t)(base + j)), q);
             }
         }
     }
@@ -902,6 +904,45 @@ __global__ void __launch_bounds__(256) msm_bitsum_kernel(const char *buckets, ui
     if (threadIdx.x == 0) xyzz29_store(out + 144 * (((size_t)g * c + b) * PB + blockIdx.x), r);
 }
 
+// Bucket reduction, step 1, two-dimensional form for wide windows (c >= 11). The bit sums above touch every bucket (c-1)/2 times
+// on average: 2^(c-2) * (c-1) additions per group — for c = 16 a quarter of a million, 16 M VALU wave-instructions, a fixed cost
+// that does not shrink with the number of points. Write a digit magnitude k < NB = 2^(c-1) as k = h * 2^lb + l: then
+//     sum_k k * B_k = 2^lb * sum_h h * R_h + sum_l l * C_l,    R_h = sum_l B_(h,l),  C_l = sum_h B_(h,l),
+// i.e. every bucket is added twice (one row sum, one column sum: 2^c additions), and the weighted sums run over 2^hb rows and
+// 2^lb columns only. msm_rowcol_kernel: block x < 2^hb sums row x, block 2^hb + l sums column l (<= 256 elements each, one
+// block tree). msm_bits2d_kernel then forms the same T_b the one-dimensional kernel produces — for b < lb from the columns whose
+// index has bit b, for lb <= b < c-1 from the rows whose index has bit b - lb, T_(c-1) = B_NB — so msm_final_kernel is unchanged.
+__global__ void __launch_bounds__(256) msm_rowcol_kernel(const char *buckets, uint32_t NB, int lb, int hb, char *rc) {
+    __shared__ uint4 sh[256 * 9];
+    const uint32_t x = blockIdx.x, g = blockIdx.y, nrow = 1u << hb, ncol = 1u << lb, t = threadIdx.x;
+    XYZZ29 acc = xyzz29_identity();
+    uint32_t k = 0;  // digit magnitude of this thread's element; 0 = none
+    if (x < nrow) {
+        if (t < ncol) k = (x << lb) | t;
+    } else {
+        if (t < nrow) k = (t << lb) | (x - nrow);
+    }
+    if (k != 0) acc = xyzz29_load(buckets + 144 * ((size_t)g * NB + (k - 1)));
+    XYZZ29 r = block_sum_xyzz29(acc, sh);
+    if (t == 0) xyzz29_store(rc + 144 * ((size_t)g * (nrow + ncol) + x), r);
+}
+
+__global__ void __launch_bounds__(256) msm_bits2d_kernel(const char *buckets, const char *rc, uint32_t NB, int c, int lb, int hb, char *out) {
+    __shared__ uint4 sh[256 * 9];
+    const uint32_t b = blockIdx.x, g = blockIdx.y, nrow = 1u << hb, ncol = 1u << lb, t = threadIdx.x;
+    const char *rcg = rc + 144 * (size_t)g * (nrow + ncol);
+    XYZZ29 acc = xyzz29_identity();
+    if (b == (uint32_t)(c - 1)) {
+        if (t == 0) acc = xyzz29_load(buckets + 144 * ((size_t)g * NB + (NB - 1)));
+    } else if (b < (uint32_t)lb) {
+        if (t < ncol && ((t >> b) & 1u)) acc = xyzz29_load(rcg + 144 * (size_t)(nrow + t));
+    } else {
+        if (t < nrow && ((t >> (b - (uint32_t)lb)) & 1u)) acc = xyzz29_load(rcg + 144 * (size_t)t);
+    }
+    XYZZ29 r = block_sum_xyzz29(acc, sh);
+    if (t == 0) xyzz29_store(out + 144 * ((size_t)g * c + b), r);
+}
+
 ZG_DEV void write_result(const XYZZ &acc, int mode, uint64_t *out_rec, uint8_t *out_inf) {
     Affine r;
     bool inf = xyzz_to_affine(acc, r);
@@ -942,7 +983,7 @@ __global__ void __launch_bounds__(512) msm_final_kernel(const char *bits, int c,
         xyzz29_store(&pts[tid * 9], v);
     }
     __syncthreads();
-    for (uint32_t d = 1; d < 16; d <<= 1) {  // per bit: partial j += partial j + d, for j a multiple of 2d
+    for (uint32_t d = 1; d < 16 && d < (uint32_t)PB; d <<= 1) {  // per bit: partial j += partial j + d, for j a multiple of 2d (slots >= PB hold the identity)
         uint32_t per_bit = 8 / d;            // additions per bit at this level
         if (quad < 16 * per_bit) {
             uint32_t b = quad / per_bit, j = (quad % per_bit) * 2 * d;
@@ -1159,12 +1200,19 @@ static int make_plan(size_t n, const zg_msm_config *cfg, MsmPlan &p, size_t batc
     // chunk-scheduled accumulate: enough threads to fill 2 waves per SIMD on 256 CUs, fewer for small inputs
     p.NT = 0;
     if (env_int("ZG_MSM_CHUNK_SCHED", 1)) p.NT = (uint32_t)env_int("ZG_MSM_CHUNK_THREADS", (int)chunk_threads((uint64_t)n * batch * p.W));
-    // combine lanes per bucket: a bucket expects about NT/NK + 1 partials; keep ~4 per lane
+    // combine lanes per bucket: a bucket expects about NT/NK + 1 partials; about 4 per quad (every tree level costs the whole
+    // wave one more addition; ZG_MSM_COMBINE_PER_QUAD = 8 halves the quads, measured equal)
     p.GS = 1;
-    while (p.GS < 16 && (uint64_t)p.GS * 4 < (uint64_t)p.NT / p.NK + 1) p.GS <<= 1;  // GS quads of lanes per bucket: 4 * GS <= 64
+    while (p.GS < 16 && (uint64_t)p.GS * (uint64_t)env_int("ZG_MSM_COMBINE_PER_QUAD", 4) < (uint64_t)p.NT / p.NK + 1) p.GS <<= 1;  // GS quads of lanes per bucket: 4 * GS <= 64
     // bit-sum partial blocks: ~4 buckets per thread, at most 16 (the final kernel reduces 16 lanes per bit)
     int pb = (int)(p.NB / 2 / (256 * 4));
     p.PB = pb < 1 ? 1 : (pb > 16 ? 16 : pb);
+    // wide windows: row / column sums first (msm_rowcol_kernel); rows and columns of at most 256 buckets
+    p.lb = p.hb = 0;
+    if (c >= 11 && env_int("ZG_MSM_REDUCE_2D", 1)) {
+        p.lb = c / 2;  // c - 1 = lb + hb, lb >= hb
+        p.hb = c - 1 - p.lb;
+    }
     return ZG_OK;
 }
 
@@ -1229,7 +1277,11 @@ static hipError_t lane_alloc(zg_bases_s::Lane &ln, const MsmPlan &p, size_t n_to
         A(ln.d_blockhist, (size_t)nblk_lds * p.NK * 4);
     }
     A(ln.d_partial, (size_t)p.NK * 144);
-    A(ln.d_bits, (size_t)p.G * p.K * p.c * p.PB * 144);
+    {
+        size_t per_group = (size_t)p.c * p.PB;  // one-dimensional bit sums; the two-dimensional form keeps rows + columns + c sums
+        if (p.lb && ((size_t)1 << p.lb) + ((size_t)1 << p.hb) + p.c > per_group) per_group = ((size_t)1 << p.lb) + ((size_t)1 << p.hb) + p.c;
+        A(ln.d_bits, (size_t)p.G * p.K * per_group * 144);
+    }
     A(ln.d_rg, (size_t)p.G * p.K * 128);
     A(ln.d_nzrank, ((size_t)p.NK + 1) * 4);
     A(ln.d_nzlist, (size_t)p.NK * 4);
@@ -1545,8 +1597,14 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
         prof_end(ZG_PROF_MSM_ACCUMULATE, st);
         prof_begin(ZG_PROF_MSM_REDUCE, st);
     }
-    hipLaunchKernelGGL(msm_bitsum_kernel, dim3(p.PB, p.c, p.G * p.K), dim3(256), 0, st, ln.d_partial, p.NB, p.c, ln.d_bits);
-    hipLaunchKernelGGL(msm_final_kernel, dim3(p.G * p.K), dim3(512), 0, st, ln.d_bits, p.c, p.PB, p.G, ln.d_rg, mode, d_rec, d_inf_out,
+    if (p.lb) {
+        char *d_rc = ln.d_bits + 144 * (size_t)p.G * p.K * p.c;  // rows and columns behind the c bit sums of every group
+        hipLaunchKernelGGL(msm_rowcol_kernel, dim3((1u << p.hb) + (1u << p.lb), p.G * p.K), dim3(256), 0, st, ln.d_partial, p.NB, p.lb, p.hb, d_rc);
+        hipLaunchKernelGGL(msm_bits2d_kernel, dim3(p.c, p.G * p.K), dim3(256), 0, st, ln.d_partial, d_rc, p.NB, p.c, p.lb, p.hb, ln.d_bits);
+    } else {
+        hipLaunchKernelGGL(msm_bitsum_kernel, dim3(p.PB, p.c, p.G * p.K), dim3(256), 0, st, ln.d_partial, p.NB, p.c, ln.d_bits);
+    }
+    hipLaunchKernelGGL(msm_final_kernel, dim3(p.G * p.K), dim3(512), 0, st, ln.d_bits, p.c, p.lb ? 1 : p.PB, p.G, ln.d_rg, mode, d_rec, d_inf_out,
                        rec_stride, inf_stride);
     if (p.G > 1)
         hipLaunchKernelGGL(msm_groups_kernel, dim3(p.K), dim3(4), 0, st, ln.d_rg, p.G, p.c, mode, d_rec, d_inf_out, rec_stride, inf_stride);
