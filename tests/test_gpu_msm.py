@@ -427,7 +427,39 @@ def test_side_table_routing(zl, ob, gm, env, monkeypatch):
     b.free()
 
 
-@pytest.mark.parametrize("env", [{"ZG_MSM_CHUNK_SCHED": "0"}, {"ZG_MSM_LDS_SORT": "0"}, {"ZG_MSM_LANES": "1"},
+@pytest.mark.parametrize("c", [11, 12, 13, 16])
+@pytest.mark.parametrize("env", [{}, {"ZG_MSM_REDUCE_2D": "0"}])
+def test_bucket_reduction_rows_and_columns(zl, ob, gm, c, env, monkeypatch):
+    """The two-dimensional bucket reduction (row / column sums of the 2^hb x 2^lb bucket matrix, then bit sums over rows and
+    columns) against the oracle with digit magnitudes chosen to sit on the matrix edges: every magnitude 1..2^(c-1) for the
+    narrow windows, and for c = 16 all multiples of 2^lb, their neighbours, the first row, the first column and the top
+    bucket NB itself (the only one outside the matrix) — each in the lowest window, plus one uniform vector."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    NB, lb = 1 << (c - 1), c // 2
+    if c <= 13:
+        mags = np.arange(1, NB + 1, dtype=np.uint64)
+    else:
+        edge = np.arange(0, NB + 1, 1 << lb, dtype=np.int64)
+        mags = np.unique(np.concatenate([edge, edge - 1, edge + 1, np.arange(1, (1 << lb) + 2), [NB - 1, NB]]))
+        mags = mags[(mags >= 1) & (mags <= NB)].astype(np.uint64)
+    n = len(mags)
+    assert n <= len(gm)
+    b = zl.Bases.upload(gm[:n], None, window_bits=c)
+    # magnitude m as a positive digit (scalar m) and as a negative one (scalar 2^c - m: digit -m with a carry into window 1)
+    for vals in (mags, (np.uint64(1 << c) - mags)):
+        sc = ob.f_from_u64(ob.FR, vals)
+        got, ginf = b.msm(sc)
+        want, winf = ob.msm_g1(gm[:n], None, sc)
+        assert ginf == winf and np.array_equal(got, want)
+    sc = _scalars(ob, 9100 + c, n)
+    got, ginf = b.msm(sc)
+    want, winf = ob.msm_g1(gm[:n], None, sc)
+    assert ginf == winf and np.array_equal(got, want)
+    b.free()
+
+
+@pytest.mark.parametrize("env", [{"ZG_MSM_CHUNK_SCHED": "0"}, {"ZG_MSM_LDS_SORT": "0"}, {"ZG_MSM_LANES": "1"}, {"ZG_MSM_COMBINE_PER_QUAD": "8"},
                                  {"ZG_MSM_CHUNK_THREADS": "1000"}, {"ZG_MSM_CHUNK_SCHED": "0", "ZG_MSM_LDS_SORT": "0", "ZG_MSM_SLICES": "4"}])
 def test_alternate_code_paths(zl, ob, gm, env, monkeypatch):
     """the fallback schedulers (per-bucket lanes, global-atomic counting sort) and odd tuning values stay bit-exact"""
