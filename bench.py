@@ -36,7 +36,6 @@ MEASURED_TRAFFIC = {20: (1263916.7 + 22846.8) * 1024.0}
 # add/and/shift/sub at 2 (tools/microbench.hip rates)
 MADD_ISSUE_CYCLES = (1467 + 146 + 144 + 81) * 4 + 382 * 2
 VALU_PEAK_GCYC = 1024 * 2.4  # 256 CUs x 4 SIMDs x 2.4 GHz
-W_WINDOWS = 16
 SEED = 0x5A4F4C54
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 N_SCALAR_SETS = 3
@@ -220,6 +219,7 @@ def main():
     n, n_loc, elapsed, prof, setup_s = m["n"], m["n_loc"], m["elapsed"], m["prof"], m["setup_s"]
     prof_alone = m["prof_alone"]
     bases_xy, d_scalars, want, bases = m["bases_xy"], m["d_scalars"], m["want"], m["bases"]
+    m_plan = bases.plan()
 
     # BASELINE config 4: the 2^22-point MSM sharded over the ranks (same code path, untimed setup), reported beside the
     # headline workload so that the strong-scaling curve exists at both sizes of the metric
@@ -254,7 +254,7 @@ def main():
         "vs_baseline": None, "dtype": "u32", "data": "synthetic",
         "config": {"workload": f"msm_g1_2^{args.logn}", "points": n, "points_per_gpu": n_loc,
                    "arithmetic": "256-bit Montgomery field elements as 32-bit limbs (9x29-bit lazy limbs in the MSM), integer only",
-                   "bases": "(i+1)*G resident in HBM (table of 2^(16l)*P_i built once at upload, like an SRS)", "scalars": "uniform mod r, splitmix64 seed 0x5A4F4C54, resident in HBM",
+                   "bases": "(i+1)*G resident in HBM (table of 2^(c*l)*P_i built once at upload, like an SRS)", "scalars": "uniform mod r, splitmix64 seed 0x5A4F4C54, resident in HBM",
                    "sharding": f"contiguous chunks + {dist_backend} all-gather of 96-byte Jacobian partials" if world > 1 else "single GPU",
                    "streams": nstreams,
                    "bit_exact_check": "closed form (sum s_i*(i+1))*G via scalarMul kernel, every timed step"},
@@ -271,9 +271,11 @@ def main():
 
     # the ceiling that actually binds msm_accumulate: VALU issue. One mixed add compiles to MADD_ISSUE_CYCLES issue cycles
     # per wave (static instruction mix of the kernel's fast path); peak = 1024 SIMDs x 2.4 GHz.
-    adds = float(n_loc) * W_WINDOWS * (1.0 - 2.0 ** -16)  # one table row per non-zero signed 16-bit digit
+    plan_c, plan_w, plan_l = m_plan
+    adds = float(n_loc) * plan_w * (1.0 - 2.0 ** -plan_c)  # one table row per non-zero signed c-bit digit
     alone_ms = prof_alone["msm_accumulate"][0] / max(prof_alone["msm_accumulate"][1], 1)
-    issue = adds / 64.0 * MADD_ISSUE_CYCLES / (alone_ms * 1e-3) / 1e9 if alone_ms and args.window_bits in (0, 16) and args.logn >= 15 else None
+    issue = adds / 64.0 * MADD_ISSUE_CYCLES / (alone_ms * 1e-3) / 1e9 if alone_ms and args.logn >= 15 else None
+    out["config"]["window_bits"], out["config"]["windows"], out["config"]["table_levels"] = plan_c, plan_w, plan_l
     out["roofline"]["avg_launch_ms_alone"] = alone_ms
     out["roofline"]["valu_issue"] = {"achieved": issue, "peak": VALU_PEAK_GCYC, "unit": "G issue-cycles/s",
                                      "frac": issue / VALU_PEAK_GCYC if issue else None,

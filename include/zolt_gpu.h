@@ -128,6 +128,9 @@ ZG_API int zg_g1_bases_upload_dev(const uint64_t *d_xy, const uint8_t *d_inf, si
                            zg_bases_t *out);
 ZG_API int zg_g1_bases_free(zg_bases_t b);
 ZG_API size_t zg_g1_bases_len(zg_bases_t b);
+/* the plan the handle was built with: window bits c (optimalWindowSize's role, src/msm/mod.zig:475-484, chosen for the GPU),
+ * windows per scalar ceil(255 / c), table levels stored per base. Any pointer may be NULL. */
+ZG_API int zg_g1_bases_plan(zg_bases_t b, int *window_bits, int *windows, int *precompute_levels);
 
 /* ------------------------------------------------------------------ MSM */
 /* MSM(F,G).compute(bases[off..off+n], scalars) -> Affine   (src/msm/mod.zig:355-438)

@@ -354,9 +354,9 @@ def test_skewed_scalar_distributions(zl, ob, gm, kind):
     _check(zl, ob, gm[:n], None, sc, window_bits=13, precompute_levels=1)
 
 
-@pytest.mark.parametrize("c", list(range(2, 17)))
+@pytest.mark.parametrize("c", list(range(2, 18)))
 def test_every_window_size(zl, ob, gm, c):
-    """every digit-kernel instantiation (window_bits 2..16), full precompute and none"""
+    """every digit-kernel instantiation (window_bits 2..17), full precompute and none"""
     n = 2000
     sc = _scalars(ob, 4000 + c, n)
     _check(zl, ob, gm[:n], None, sc, window_bits=c, precompute_levels=0)
@@ -380,7 +380,8 @@ def test_auto_plan_sizes(zl, ob, logn):
 @pytest.mark.parametrize("env", [{}, {"ZG_MSM_TWO_PASS_SORT": "0"}, {"ZG_MSM_FINE_BITS": "5", "ZG_MSM_FINE_BITS_MIN": "2"},
                                  {"ZG_MSM_FINE_BITS": "3", "ZG_MSM_FINE_BITS_MIN": "2", "ZG_MSM_TWO_PASS_SPAN": "256"},
                                  {"ZG_MSM_TWO_PASS_SPAN": "8192"}])
-def test_two_pass_sort_variants(zl, ob, gm, env, monkeypatch):
+@pytest.mark.parametrize("wb", [16, 17])
+def test_two_pass_sort_variants(zl, ob, gm, env, wb, monkeypatch):
     """The two-pass counting sort used for 2^15 buckets (coarse partition, then per-bin slices) against the single-pass sort and
     with other bin / block shapes — uniform scalars, a 0/1 column (half of all entries in ONE coarse bin, split over many
     slices), a constant column and infinity bases. Same bytes as the oracle every time."""
@@ -390,7 +391,7 @@ def test_two_pass_sort_variants(zl, ob, gm, env, monkeypatch):
     rng = np.random.default_rng(5)
     inf = np.zeros(n, dtype=np.uint8)
     inf[3::13] = 1
-    b = zl.Bases.upload(gm[:n], inf, window_bits=16)
+    b = zl.Bases.upload(gm[:n], inf, window_bits=wb)  # 2^15 / 2^16 buckets
     cases = [_scalars(ob, 31337, n), ob.f_from_u64(ob.FR, rng.integers(0, 2, size=n).astype(np.uint64)),
              ob.f_from_u64(ob.FR, np.full(n, 0xABCDEF, dtype=np.uint64))]
     for sc in cases:
@@ -427,7 +428,7 @@ def test_side_table_routing(zl, ob, gm, env, monkeypatch):
     b.free()
 
 
-@pytest.mark.parametrize("c", [11, 12, 13, 16])
+@pytest.mark.parametrize("c", [11, 12, 13, 16, 17])
 @pytest.mark.parametrize("env", [{}, {"ZG_MSM_REDUCE_2D": "0"}])
 def test_bucket_reduction_rows_and_columns(zl, ob, gm, c, env, monkeypatch):
     """The two-dimensional bucket reduction (row / column sums of the 2^hb x 2^lb bucket matrix, then bit sums over rows and

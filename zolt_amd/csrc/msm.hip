@@ -974,38 +974,42 @@ ZG_DEV void write_partial_unnormalised(const XYZZ &acc, uint64_t *out_rec) {
 // straight on to toAffine (msm/mod.zig:178-189).
 __global__ void __launch_bounds__(512) msm_final_kernel(const char *bits, int c, int PB, int G, char *rg, int mode, uint64_t *out_rec,
                                                         uint8_t *out_inf, uint32_t rec_stride, uint32_t inf_stride) {
-    __shared__ uint4 pts[256 * 9];  // slot b * 16 + j
+    __shared__ uint4 pts[256 * 9];  // slot b * S + j, S = PB rounded up to a power of two: 256 / S bit rows (c <= 16 for S = 16, c <= 32 below)
     uint32_t tid = threadIdx.x, g = blockIdx.x, quad = tid >> 2, q = tid & 3;
+    uint32_t S = 1;
+    while (S < (uint32_t)PB) S <<= 1;
     if (tid < 256) {
-        uint32_t b = tid / 16, j = tid % 16;
+        uint32_t b = tid / S, j = tid % S;
         XYZZ29 v = xyzz29_identity();
         if (b < (uint32_t)c && j < (uint32_t)PB) v = xyzz29_load(bits + 144 * (((size_t)g * c + b) * PB + j));
         xyzz29_store(&pts[tid * 9], v);
     }
     __syncthreads();
-    for (uint32_t d = 1; d < 16 && d < (uint32_t)PB; d <<= 1) {  // per bit: partial j += partial j + d, for j a multiple of 2d (slots >= PB hold the identity)
-        uint32_t per_bit = 8 / d;            // additions per bit at this level
-        if (quad < 16 * per_bit) {
+    for (uint32_t d = 1; d < S; d <<= 1) {   // per bit: partial j += partial j + d, for j a multiple of 2d
+        uint32_t per_bit = S / (2 * d);      // additions per bit at this level; (256 / S) * per_bit <= 128 quads
+        if (quad < (256 / S) * per_bit) {
             uint32_t b = quad / per_bit, j = (quad % per_bit) * 2 * d;
-            XYZZ29 x = xyzz29_load(&pts[(b * 16 + j) * 9]), y = xyzz29_load(&pts[(b * 16 + j + d) * 9]);
+            XYZZ29 x = xyzz29_load(&pts[(b * S + j) * 9]), y = xyzz29_load(&pts[(b * S + j + d) * 9]);
             XYZZ29 r = xyzz29_add4(x, y, q);
-            if (q == 0) xyzz29_store(&pts[(b * 16 + j) * 9], r);
+            if (q == 0) xyzz29_store(&pts[(b * S + j) * 9], r);
         }
         __syncthreads();
     }
-    if (quad < 16) {  // 2^b * T_b
-        XYZZ29 v = xyzz29_load(&pts[(quad * 16) * 9]);
+    if (quad < (uint32_t)c) {  // 2^b * T_b
+        XYZZ29 v = xyzz29_load(&pts[(quad * S) * 9]);
 #if !(defined(ZG_EXP_SKIP) && (ZG_EXP_SKIP & 1))
         for (uint32_t i = 0; i < quad; i++) v = xyzz29_dbl4(v, q);
 #endif
-        if (q == 0) xyzz29_store(&pts[(quad * 16) * 9], v);
+        if (q == 0) xyzz29_store(&pts[(quad * S) * 9], v);
     }
     __syncthreads();
-    for (uint32_t o = 8; o > 0; o >>= 1) {
+    uint32_t top = 1;  // bit rows c .. top-1 hold the identity (top <= 256 / S)
+    while (top < (uint32_t)c) top <<= 1;
+    for (uint32_t o = top >> 1; o > 0; o >>= 1) {
         if (quad < o) {
-            XYZZ29 x = xyzz29_load(&pts[(quad * 16) * 9]), y = xyzz29_load(&pts[((quad + o) * 16) * 9]);
+            XYZZ29 x = xyzz29_load(&pts[(quad * S) * 9]), y = xyzz29_load(&pts[((quad + o) * S) * 9]);
             XYZZ29 r = xyzz29_add4(x, y, q);
-            if (q == 0) xyzz29_store(&pts[(quad * 16) * 9], r);
+            if (q == 0) xyzz29_store(&pts[(quad * S) * 9], r);
         }
         __syncthreads();
     }
@@ -1164,9 +1168,12 @@ static int make_plan(size_t n, const zg_msm_config *cfg, MsmPlan &p, size_t batc
         // scalar bits (c = 9, 12, 14) waste a window and pile its digits into a handful of buckets; 16 wins from
         // 2^15 points up (fewest windows; the rest of the pipeline is latency), 8 / 7 below.
         c = n >= 32768 ? 16 : (n >= 2048 ? 8 : (n >= 64 ? 7 : 5));
+        // 17 bits = 15 windows instead of 16 (6 % fewer bucket additions) for twice the buckets: pays from about 2^20 points,
+        // as long as the 15 n table rows still fit the 24-bit references of the two-pass sort (n <= 1.1 M)
+        if (batch == 1 && n >= (size_t)env_int("ZG_MSM_C17_MIN", 900000) && (uint64_t)n * 15 <= (1u << 24)) c = 17;
     }
-    if (c < 2 || c > 16) {
-        set_error("msm: window_bits must be in [2,16]");
+    if (c < 2 || c > 17) {
+        set_error("msm: window_bits must be in [2,17]");
         return ZG_ERR_INVALID;
     }
     p.c = c;
@@ -1207,6 +1214,7 @@ static int make_plan(size_t n, const zg_msm_config *cfg, MsmPlan &p, size_t batc
     // bit-sum partial blocks: ~4 buckets per thread, at most 16 (the final kernel reduces 16 lanes per bit)
     int pb = (int)(p.NB / 2 / (256 * 4));
     p.PB = pb < 1 ? 1 : (pb > 16 ? 16 : pb);
+    if (c > 16 && p.PB > 8) p.PB = 8;  // msm_final_kernel holds 256 partial sums: 17 bit rows need a stride of at most 8
     // wide windows: row / column sums first (msm_rowcol_kernel); rows and columns of at most 256 buckets
     p.lb = p.hb = 0;
     if (c >= 11 && env_int("ZG_MSM_REDUCE_2D", 1)) {
@@ -1428,7 +1436,7 @@ static int launch_digits_lds_c(int c, hipStream_t st, const uint64_t *sc, const 
     switch (c) {
 #define ZG_CASE(C) case C: return launch_digits_lds<C>(st, sc, inf, n, n_pts, G, per_block, NK, nblk, dig, blockhist, shift, threads);
         ZG_CASE(2) ZG_CASE(3) ZG_CASE(4) ZG_CASE(5) ZG_CASE(6) ZG_CASE(7) ZG_CASE(8) ZG_CASE(9) ZG_CASE(10)
-        ZG_CASE(11) ZG_CASE(12) ZG_CASE(13) ZG_CASE(14) ZG_CASE(15) ZG_CASE(16)
+        ZG_CASE(11) ZG_CASE(12) ZG_CASE(13) ZG_CASE(14) ZG_CASE(15) ZG_CASE(16) ZG_CASE(17)
 #undef ZG_CASE
         default: set_error("msm: unsupported window size"); return ZG_ERR_INVALID;
     }
@@ -1439,7 +1447,7 @@ static int launch_digits_c(int c, hipStream_t st, const uint64_t *sc, const uint
     switch (c) {
 #define ZG_CASE(C) case C: launch_digits<C>(st, sc, inf, n, n_pts, G, dig, hist); break;
         ZG_CASE(2) ZG_CASE(3) ZG_CASE(4) ZG_CASE(5) ZG_CASE(6) ZG_CASE(7) ZG_CASE(8) ZG_CASE(9) ZG_CASE(10)
-        ZG_CASE(11) ZG_CASE(12) ZG_CASE(13) ZG_CASE(14) ZG_CASE(15) ZG_CASE(16)
+        ZG_CASE(11) ZG_CASE(12) ZG_CASE(13) ZG_CASE(14) ZG_CASE(15) ZG_CASE(16) ZG_CASE(17)
 #undef ZG_CASE
         default: set_error("msm: unsupported window size"); return ZG_ERR_INVALID;
     }
@@ -1669,6 +1677,17 @@ int zg_g1_bases_free(zg_bases_t b) {
 }
 
 size_t zg_g1_bases_len(zg_bases_t b) { return b ? b->n : 0; }
+
+int zg_g1_bases_plan(zg_bases_t b, int *window_bits, int *windows, int *precompute_levels) {
+    if (!b) {
+        set_error("zg_g1_bases_plan: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    if (window_bits) *window_bits = b->plan.c;
+    if (windows) *windows = b->plan.W;
+    if (precompute_levels) *precompute_levels = b->plan.L;
+    return ZG_OK;
+}
 
 int zg_msm_g1_dev(zg_bases_t b, size_t off, size_t n, const uint64_t *d_scalars, void *stream, uint64_t out_xy[8], uint8_t *out_inf) {
     ZG_INIT();

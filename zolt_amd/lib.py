@@ -27,7 +27,7 @@ SYMBOLS = [
     "zg_dev_alloc", "zg_dev_free", "zg_memcpy_h2d", "zg_memcpy_d2h", "zg_sync",
     "zg_profile_begin", "zg_profile_end",
     "zg_field_op",
-    "zg_g1_bases_upload", "zg_g1_bases_upload_dev", "zg_g1_bases_free", "zg_g1_bases_len",
+    "zg_g1_bases_upload", "zg_g1_bases_upload_dev", "zg_g1_bases_free", "zg_g1_bases_len", "zg_g1_bases_plan",
     "zg_msm_g1", "zg_msm_g1_dev", "zg_msm_g1_dev_async", "zg_msm_g1_batch", "zg_msm_g1_batch_dev", "zg_msm_g1_partial_dev", "zg_msm_g1_partial_fast_dev",
     "zg_g1_combine_partials_dev", "zg_g1_combine_partials_dev_async", "zg_g1_is_on_curve_batch", "zg_g1_scalar_mul_batch",
     "zg_hyperkzg_open", "zg_hyperkzg_batch_open",
@@ -157,6 +157,12 @@ class Bases:
         _chk(_lib.zg_g1_bases_upload_dev(_d(d_xy), _d(d_inf), C.c_size_t(n), C.byref(cfg), _d(stream), C.byref(h)),
              "zg_g1_bases_upload_dev")
         return cls(h, n)
+
+    def plan(self):
+        """(window bits c, windows per scalar, table levels per base) the handle was built with"""
+        c, w, l = C.c_int(), C.c_int(), C.c_int()
+        _chk(_lib.zg_g1_bases_plan(self._h, C.byref(c), C.byref(w), C.byref(l)), "zg_g1_bases_plan")
+        return c.value, w.value, l.value
 
     def free(self):
         if self._h:
