@@ -1245,9 +1245,9 @@ static void plan_two_pass(MsmPlan &p, size_t table_rows, size_t n_total) {
     int fb = 31 - need, fb_max = env_int("ZG_MSM_FINE_BITS", 7);
     if (fb_max > 7) fb_max = 7;
     if (fb > fb_max) fb = fb_max;
-    // with fewer than 7 fine bits there are >= 512 coarse bins and pass 1's open 64-byte lines (blocks x bins) no longer fit in
-    // L2: measured slower than the single-pass sort at 2^22 points (partition 1.03 ms), so only the 7-bit split is used
-    if (fb < env_int("ZG_MSM_FINE_BITS_MIN", 7)) return;
+    // fewer than 7 fine bits mean >= 512 coarse bins; down to 5 bits (2^22 points, 1024 bins) the two passes still beat the
+    // single-pass sort there (0.67 vs 1.3 ms alone, +2-3 % pipelined); below that the single pass is used
+    if (fb < env_int("ZG_MSM_FINE_BITS_MIN", 5)) return;
     uint32_t ncb = (p.NK + (1u << fb) - 1) >> fb;
     if (ncb > 2048) return;  // pass 1 keeps 2 * NCB counters next to 128 KiB of staged entries in LDS
     p.fb = fb;
