@@ -322,19 +322,29 @@ __global__ void __launch_bounds__(256) sc_fold_kernel(const uint64_t *t, size_t 
     Fr g0 = Fr::zero(), g1 = Fr::zero();
     size_t stride = (size_t)gridDim.x * 256;
     size_t quarter = half / 2;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < half; i += stride) {
-        Fr v;
-        if (LAYOUT == ZG_SC_HIGH_HALF) {
-            Fr lo = fe_load<FrParams>(t + 4 * i), hi = fe_load<FrParams>(t + 4 * (i + half));
-            v = fe_add(lo, fr_mul29(fe_sub(hi, lo), rp));  // (1-r)*lo + r*hi = lo + r*(hi - lo): one product, same value
-        } else {
-            Fr lo = fe_load<FrParams>(t + 8 * i), hi = fe_load<FrParams>(t + 8 * i + 4);
-            v = fe_add(lo, fr_mul29(fe_sub(hi, lo), rp));
+    // the pair of the next iteration is requested before the current product is computed: with one block per CU (4 waves) the
+    // loads in flight, not the arithmetic, bound a long table (Little's law: 64 B per thread x 65536 threads per ~2 us)
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    Fr lo = Fr::zero(), hi = Fr::zero();
+    if (i < half) {
+        lo = fe_load<FrParams>(LAYOUT == ZG_SC_HIGH_HALF ? t + 4 * i : t + 8 * i);
+        hi = fe_load<FrParams>(LAYOUT == ZG_SC_HIGH_HALF ? t + 4 * (i + half) : t + 8 * i + 4);
+    }
+    while (i < half) {
+        size_t ni = i + stride;
+        Fr nlo = lo, nhi = hi;
+        if (ni < half) {
+            nlo = fe_load<FrParams>(LAYOUT == ZG_SC_HIGH_HALF ? t + 4 * ni : t + 8 * ni);
+            nhi = fe_load<FrParams>(LAYOUT == ZG_SC_HIGH_HALF ? t + 4 * (ni + half) : t + 8 * ni + 4);
         }
+        Fr v = fe_add(lo, fr_mul29(fe_sub(hi, lo), rp));  // (1-r)*lo + r*hi = lo + r*(hi - lo): one product, same value
         fe_store(out + 4 * i, v);
         bool second = LAYOUT == ZG_SC_HIGH_HALF ? (i >= quarter) : (i & 1);
         if (second) g1 = fe_add(g1, v);
         else g0 = fe_add(g0, v);
+        lo = nlo;
+        hi = nhi;
+        i = ni;
     }
     block_sum_pair(g0, g1, sh);
     if (run.res && half == 1) {  // the table is down to one element: getFinalEval + the verifier's last comparison
