@@ -384,6 +384,9 @@ def extra_measurements(lib, api, torch, dev, stream, args):
         "pipeline": "eq_table + spartan_combine + 20 x (sums, host toy challenge, fold)",
         "kernel_ms": {k: (val[0] / max(val[1], 1)) for k, val in prof.items() if val[1]},
         "fold_round0_GBps": (48.0 * n) / ((prof["sc_fold"][0] / max(prof["sc_fold"][1], 1)) * 1e-3) / 1e9 if prof["sc_fold"][1] else None,
+        "kernel_ms_note": "HIP-event brackets on the launch stream; eq_table's opens right behind the pageable H2D copy of r and includes "
+                          "its completion — the two kernels alone take 24 us (profiles/*_sumcheck_kernel_stats.csv); sc_fold / sc_sums "
+                          "are averages over the 20 rounds",
     }
     # runSumcheck with the toy verifier on the device as well (zg_run_sumcheck_dev): no PCIe crossing per round
     res = lib.run_sumcheck_dev(d_f.data_ptr(), n, stream=stream)
