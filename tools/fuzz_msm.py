@@ -30,7 +30,8 @@ def scalars(n, kind):
         return sc
     k = max(1, n // 7)
     idx = rng.integers(0, n, size=k)
-    vals = [0, 1, R - 1, R - 2, (1 << 15), (1 << 16) - 1, (1 << 16), (1 << 255) % R, ((1 << 240) - 1)]
+    vals = [0, 1, R - 1, R - 2, (1 << 15), (1 << 16) - 1, (1 << 16), (1 << 16) + 1, (1 << 17) - 1, (1 << 17), (1 << 255) % R, ((1 << 240) - 1),
+            (1 << 238) - 1, (1 << 253) + (1 << 16)]
     raw = np.array([[(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)] for v in vals], dtype=np.uint64)
     sc[idx] = ob.f_to_mont(ob.FR, raw)[rng.integers(0, len(vals), size=k)]
     return sc
@@ -52,7 +53,7 @@ while time.time() - t0 < budget:
     inf = (rng.random(n) < 0.05).astype(np.uint8) if rng.random() < 0.5 else None
     cfg = {}
     if rng.random() < 0.5:
-        cfg["window_bits"] = int(rng.choice([2, 3, 5, 7, 8, 10, 13, 15, 16]))
+        cfg["window_bits"] = int(rng.choice([2, 3, 5, 7, 8, 10, 11, 12, 13, 14, 15, 16, 17]))
     if rng.random() < 0.4:
         cfg["precompute_levels"] = int(rng.integers(1, 20))
     try:
