@@ -34,6 +34,15 @@
 #include "g1_29.hip.h"
 #include "g1_29x4.hip.h"
 
+// Every MSM kernel except the bucket accumulation is short and mostly a chain of dependent operations; when it shares a SIMD with
+// two accumulate waves of another stream the arbiter gives it a third of the issue slots and its latency triples, which
+// stretches the per-stream chain digits -> sort -> accumulate -> reduce. Raised wave priority lets these kernels issue first;
+// the accumulation fills the remaining slots (its total work is unchanged).
+#ifndef ZG_TAIL_PRIO
+#define ZG_TAIL_PRIO 3
+#endif
+#define ZG_HIPRIO() __builtin_amdgcn_s_setprio(ZG_TAIL_PRIO)
+
 namespace zg {
 
 static constexpr int MAX_GROUPS = 64;
@@ -179,6 +188,7 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint64_t *scalars
 // writes starts / nzrank / the compacted list of non-empty buckets.
 __global__ void __launch_bounds__(1024) msm_scan_a_kernel(const uint32_t *__restrict__ hist, uint32_t NK, uint32_t *__restrict__ loc,
                                                           uint32_t *__restrict__ locz, uint32_t *__restrict__ tile_tot) {
+    ZG_HIPRIO();
     __shared__ uint32_t sh[1024], shz[1024];
     uint32_t tid = threadIdx.x, k = blockIdx.x * 1024 + tid;
     uint32_t h = k < NK ? hist[k] : 0u, z = h ? 1u : 0u;
@@ -206,6 +216,7 @@ __global__ void __launch_bounds__(1024) msm_scan_b_kernel(const uint32_t *__rest
                                                           const uint32_t *__restrict__ locz, const uint32_t *__restrict__ tile_tot,
                                                           uint32_t *__restrict__ starts, uint32_t *__restrict__ nzrank,
                                                           uint32_t *__restrict__ nzlist) {
+    ZG_HIPRIO();
     __shared__ uint32_t pre[2];
     uint32_t tid = threadIdx.x, k = blockIdx.x * 1024 + tid;
     if (tid < 64) {  // one wave sums the totals of the preceding tiles (at most 2048 tiles)
@@ -260,6 +271,7 @@ template <int C>
 __global__ void __launch_bounds__(1024) msm_digits_lds_kernel(const uint64_t *scalars, const uint8_t *inf, uint32_t n, uint32_t n_pts,
                                                               int G, uint32_t per_block, uint32_t NK, int shift, uint32_t *dig,
                                                               uint32_t *blockhist) {
+    ZG_HIPRIO();
     extern __shared__ uint32_t lds_hist[];
     constexpr int W = (255 + C - 1) / C;
     constexpr uint32_t NB = 1u << (C - 1);
@@ -296,6 +308,7 @@ __global__ void __launch_bounds__(1024) msm_digits_lds_kernel(const uint64_t *sc
 
 // per key: exclusive prefix over the blocks (in place) and the key's total
 __global__ void __launch_bounds__(256) msm_colscan_kernel(uint32_t *blockhist, uint32_t nblk, uint32_t NK, uint32_t *total) {
+    ZG_HIPRIO();
     uint32_t key = blockIdx.x * 256 + threadIdx.x;
     if (key >= NK) return;
     uint32_t run = 0;
@@ -315,6 +328,7 @@ __global__ void __launch_bounds__(256) msm_colscan_kernel(uint32_t *blockhist, u
 __global__ void __launch_bounds__(1024) msm_scatter_lds_kernel(const uint32_t *dig, uint32_t n, uint32_t n_pts, int W, int G,
                                                                size_t table_n, uint32_t off, uint32_t per_block, uint32_t NK,
                                                                const uint32_t *starts, const uint32_t *blockhist, uint32_t *sorted) {
+    ZG_HIPRIO();
     extern __shared__ uint32_t lds_cur[];
     const uint32_t *row = blockhist + (size_t)blockIdx.x * NK;
     for (uint32_t k = threadIdx.x; k < NK; k += blockDim.x) lds_cur[k] = starts[k] + row[k];
@@ -346,6 +360,7 @@ __global__ void __launch_bounds__(1024) msm_scatter_lds_kernel(const uint32_t *d
 static constexpr uint32_t FINE_SLICE = 32768;
 __global__ void __launch_bounds__(1024) msm_coarse_base_kernel(const uint32_t *totals, uint32_t NCB, uint32_t *cstarts, uint32_t *tstarts,
                                                                uint32_t *istarts) {
+    ZG_HIPRIO();
     __shared__ uint32_t sh[1024], sh4[1024], shi[1024];
     uint32_t tid = threadIdx.x, per = (NCB + 1023) / 1024, a = tid * per, b = a + per < NCB ? a + per : NCB;
     uint32_t s = 0, s4 = 0, si = 0;
@@ -391,6 +406,7 @@ static constexpr uint32_t STAGE_ENTRIES = 32768;  // 128 KiB of LDS
 __global__ void __launch_bounds__(1024) msm_partition_kernel(const uint32_t *dig, uint32_t n, uint32_t n_pts, int W, int G, size_t table_n,
                                                              uint32_t off, uint32_t per_block, uint32_t NCB, int fb, int rb,
                                                              const uint32_t *tstarts, const uint32_t *blockoff, uint32_t *tmp) {
+    ZG_HIPRIO();
     extern __shared__ uint32_t lds[];
     uint32_t *buf = lds, *cnt = lds + STAGE_ENTRIES, *lbase = cnt + NCB, *sums = lbase + NCB + 1;  // sums: 1024 scan partials
     const uint32_t tid = threadIdx.x, T = 1024, fmask = (1u << fb) - 1u;
@@ -476,6 +492,7 @@ ZG_DEV bool fine_item(uint32_t item, const uint32_t *istarts, uint32_t NCB, uint
 
 __global__ void __launch_bounds__(1024) msm_fine_count_kernel(const uint32_t *tmp, const uint32_t *cstarts, const uint32_t *tstarts,
                                                               const uint32_t *istarts, uint32_t NCB, int fb, int rb, uint32_t *slicecnt) {
+    ZG_HIPRIO();
     __shared__ uint32_t cnt[128];
     __shared__ uint32_t sh_bin, sh_q0, sh_ok;
     uint32_t tid = threadIdx.x, nf = 1u << fb, fmask = nf - 1u;
@@ -517,6 +534,7 @@ __global__ void __launch_bounds__(1024) msm_fine_count_kernel(const uint32_t *tm
 __global__ void __launch_bounds__(1024) msm_fine_place_kernel(const uint32_t *tmp, const uint32_t *cstarts, const uint32_t *tstarts,
                                                               const uint32_t *istarts, uint32_t NCB, int fb, int rb, const uint32_t *slicecnt,
                                                               const uint32_t *fbase, uint32_t *sorted) {
+    ZG_HIPRIO();
     extern __shared__ uint32_t lds[];
     uint32_t *buf = lds, *cnt = lds + STAGE_ENTRIES, *lbase = cnt + 128;  // lbase: 129 entries
     __shared__ uint32_t sh_bin, sh_q0, sh_ok;
@@ -580,6 +598,7 @@ __global__ void __launch_bounds__(1024) msm_fine_place_kernel(const uint32_t *tm
 
 __global__ void __launch_bounds__(128) msm_fine_offsets_kernel(const uint32_t *istarts, int fb, uint32_t NK, uint32_t *slicecnt, uint32_t *fbase,
                                                                uint32_t *hist) {
+    ZG_HIPRIO();
     __shared__ uint32_t sh[128];
     uint32_t bin = blockIdx.x, f = threadIdx.x, nf = 1u << fb;
     uint32_t i0 = istarts[bin], i1 = istarts[bin + 1], run = 0;
@@ -607,6 +626,7 @@ __global__ void __launch_bounds__(128) msm_fine_offsets_kernel(const uint32_t *i
 // per coarse bin (one block each): exclusive prefix over the blocks' counts, in place, and the bin's total. The layout is
 // chist[blk][bin]; a thread owns a contiguous run of blocks.
 __global__ void __launch_bounds__(256) msm_colscan_bins_kernel(uint32_t *chist, uint32_t nblk, uint32_t NCB, uint32_t *total) {
+    ZG_HIPRIO();
     __shared__ uint32_t sh[256];
     uint32_t bin = blockIdx.x, tid = threadIdx.x, per = (nblk + 255) / 256, a = tid * per, b = a + per < nblk ? a + per : nblk;
     uint32_t s = 0;
@@ -759,6 +779,7 @@ __global__ void __launch_bounds__(256) msm_accumulate_chunk_kernel(const uint32_
 // are queued as heavy
 __global__ void __launch_bounds__(64) msm_bucket_combine_kernel(const char *part, const uint32_t *starts, const uint32_t *nzrank, uint32_t NK,
                                                                 uint32_t NT, int GS, char *buckets, uint32_t *heavy_list, MsmState *st) {
+    ZG_HIPRIO();
     uint32_t t = (blockIdx.x * 64 + threadIdx.x) >> 2, q = threadIdx.x & 3;
     uint32_t k = t / (uint32_t)GS, g = t % (uint32_t)GS;
     XYZZ29 acc = xyzz29_identity();
@@ -816,6 +837,7 @@ __device__ __forceinline__ XYZZ29 block_sum_xyzz29(const XYZZ29 &acc, uint4 *sh)
 __global__ void __launch_bounds__(64) msm_heavy_wave_kernel(const char *part, const uint32_t *starts, const uint32_t *nzrank, uint32_t NK,
                                                             uint32_t NT, const uint32_t *heavy_list, uint32_t *huge_list, MsmState *st,
                                                             char *buckets) {
+    ZG_HIPRIO();
     uint32_t nheavy = st->nheavy;
     uint32_t C = chunk_len(starts[NK], NT);
     uint32_t lane = threadIdx.x;
@@ -844,6 +866,7 @@ static constexpr uint32_t HEAVY_BLOCK_ITEMS = 2048;
 __global__ void __launch_bounds__(256) msm_heavy_a_kernel(const char *part, const uint32_t *starts, const uint32_t *nzrank,
                                                          const uint32_t *nzlist, uint32_t NK, uint32_t NT, int GS, char *part2,
                                                          const MsmState *st) {
+    ZG_HIPRIO();
     __shared__ uint4 sh[256 * 9];
     if (st->nhuge == 0) return;
     uint32_t C = chunk_len(starts[NK], NT);
@@ -872,6 +895,7 @@ __global__ void __launch_bounds__(256) msm_heavy_a_kernel(const char *part, cons
 // heavy stage B: one block per heavy bucket sums its stage-A partials (at most a few dozen)
 __global__ void __launch_bounds__(256) msm_heavy_b_kernel(const char *part2, const uint32_t *starts, const uint32_t *nzrank, uint32_t NK,
                                                          uint32_t NT, const uint32_t *heavy_list, const MsmState *st, char *buckets) {
+    ZG_HIPRIO();
     __shared__ uint4 sh[256 * 9];
     uint32_t nheavy = st->nhuge;  // heavy_list is the huge list here
     uint32_t C = chunk_len(starts[NK], NT);
@@ -892,6 +916,7 @@ __global__ void __launch_bounds__(256) msm_heavy_b_kernel(const char *part2, con
 // (msm/mod.zig:423-432). Here  sum_k k*B_k = sum_b 2^b * T_b  with  T_b = sum_{k: bit b of k set} B_k;
 // block (x, b, g) tree-sums a slice of T_b of group g. Bucket index idx holds digit magnitude k = idx+1.
 __global__ void __launch_bounds__(256) msm_bitsum_kernel(const char *buckets, uint32_t NB, int c, char *out) {
+    ZG_HIPRIO();
     __shared__ uint4 sh[256 * 9];
     uint32_t b = blockIdx.y, g = blockIdx.z, PB = gridDim.x;
     uint32_t total = (b == (uint32_t)(c - 1)) ? 1u : NB / 2;
@@ -913,6 +938,7 @@ __global__ void __launch_bounds__(256) msm_bitsum_kernel(const char *buckets, ui
 // block tree). msm_bits2d_kernel then forms the same T_b the one-dimensional kernel produces — for b < lb from the columns whose
 // index has bit b, for lb <= b < c-1 from the rows whose index has bit b - lb, T_(c-1) = B_NB — so msm_final_kernel is unchanged.
 __global__ void __launch_bounds__(256) msm_rowcol_kernel(const char *buckets, uint32_t NB, int lb, int hb, char *rc) {
+    ZG_HIPRIO();
     __shared__ uint4 sh[256 * 9];
     const uint32_t x = blockIdx.x, g = blockIdx.y, nrow = 1u << hb, ncol = 1u << lb, t = threadIdx.x;
     XYZZ29 acc = xyzz29_identity();
@@ -928,6 +954,7 @@ __global__ void __launch_bounds__(256) msm_rowcol_kernel(const char *buckets, ui
 }
 
 __global__ void __launch_bounds__(256) msm_bits2d_kernel(const char *buckets, const char *rc, uint32_t NB, int c, int lb, int hb, char *out) {
+    ZG_HIPRIO();
     __shared__ uint4 sh[256 * 9];
     const uint32_t b = blockIdx.x, g = blockIdx.y, nrow = 1u << hb, ncol = 1u << lb, t = threadIdx.x;
     const char *rcg = rc + 144 * (size_t)g * (nrow + ncol);
@@ -974,6 +1001,7 @@ ZG_DEV void write_partial_unnormalised(const XYZZ &acc, uint64_t *out_rec) {
 // straight on to toAffine (msm/mod.zig:178-189).
 __global__ void __launch_bounds__(512) msm_final_kernel(const char *bits, int c, int PB, int G, char *rg, int mode, uint64_t *out_rec,
                                                         uint8_t *out_inf, uint32_t rec_stride, uint32_t inf_stride) {
+    ZG_HIPRIO();
     __shared__ uint4 pts[256 * 9];  // slot b * S + j, S = PB rounded up to a power of two: 256 / S bit rows (c <= 16 for S = 16, c <= 32 below)
     uint32_t tid = threadIdx.x, g = blockIdx.x, quad = tid >> 2, q = tid & 3;
     uint32_t S = 1;
@@ -1031,6 +1059,7 @@ __global__ void __launch_bounds__(512) msm_final_kernel(const char *bits, int c,
 // window combine for G > 1 (msm/mod.zig:393-398,434): Horner from the top group with c doublings per step
 __global__ void msm_groups_kernel(const char *rg, int G, int c, int mode, uint64_t *out_rec, uint8_t *out_inf, uint32_t rec_stride,
                                   uint32_t inf_stride) {
+    ZG_HIPRIO();
     rg += 128 * (size_t)G * blockIdx.x;  // one single-thread block per scalar vector
     out_rec += (size_t)rec_stride * blockIdx.x;
     out_inf += (size_t)inf_stride * blockIdx.x;
