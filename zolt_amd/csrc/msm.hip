@@ -1448,12 +1448,13 @@ static unsigned sort_threads() {
 template <int C>
 static int launch_digits_lds(hipStream_t st, const uint64_t *sc, const uint8_t *inf, uint32_t n, uint32_t n_pts, int G, uint32_t per_block,
                              uint32_t NK, uint32_t nblk, uint32_t *dig, uint32_t *blockhist, int shift, unsigned threads) {
-    static uint32_t attr_set = 0;  // per instantiation: largest dynamic-LDS size configured so far
-    if (attr_set < NK * 4) {
-        ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_digits_lds_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   128 * 1024));
-        attr_set = 128 * 1024;
-    }
+    static std::once_flag once;  // per instantiation; MSM entry points are re-entrant (std.Thread workers call MSM.compute)
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(msm_digits_lds_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       128 * 1024);
+    });
+    ZG_HIP(attr_err);
     hipLaunchKernelGGL(msm_digits_lds_kernel<C>, dim3(nblk), dim3(threads), NK * 4, st, sc, inf, n, n_pts, G, per_block, NK, shift, dig, blockhist);
     return ZG_OK;
 }
@@ -1577,12 +1578,13 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
             hipLaunchKernelGGL(msm_scan_b_kernel, dim3(tiles), dim3(1024), 0, st, ln.d_hist, p.NK, ln.d_scan_tmp, ln.d_scan_tmp + p.NK,
                                ln.d_scan_tmp + 2 * (size_t)p.NK, ln.d_starts, ln.d_nzrank, ln.d_nzlist);
         }
-        static bool scatter_attr_set = false;
-        if (!scatter_attr_set) {
-            ZG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_scatter_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       128 * 1024));
-            scatter_attr_set = true;
-        }
+        static std::once_flag scatter_once;
+        static hipError_t scatter_err = hipSuccess;
+        std::call_once(scatter_once, [] {
+            scatter_err = hipFuncSetAttribute(reinterpret_cast<const void *>(msm_scatter_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              128 * 1024);
+        });
+        ZG_HIP(scatter_err);
         hipLaunchKernelGGL(msm_scatter_lds_kernel, dim3(nblk), dim3(sort_threads()), p.NK * 4, st, ln.d_dig, (uint32_t)n, (uint32_t)n_pts, p.W, p.G,
                            b->n, (uint32_t)off, per_block, p.NK, ln.d_starts, ln.d_blockhist, ln.d_sorted);
     } else {

@@ -1,5 +1,6 @@
 // runtime.hip — lifecycle, error reporting, raw device memory and the elementwise field
 // kernels of libzolt_gpu.so (C ABI: include/zolt_gpu.h).
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -11,7 +12,7 @@ namespace zg {
 
 static thread_local std::string t_err;
 static std::mutex g_mu;
-static bool g_inited = false;
+static std::atomic<bool> g_inited{false};  // read without the mutex on every entry point
 static hipStream_t g_stream = nullptr;
 
 void set_error(const std::string &msg) { t_err = msg; }
@@ -105,20 +106,28 @@ static void scratch_trim() {
 struct ProfRec { int id; hipEvent_t e0, e1; };
 static std::vector<ProfRec> g_prof;
 static size_t g_prof_used = 0;
-static bool g_prof_on = false;
-static int g_prof_open[ZG_PROF_NKERNELS];
+static std::atomic<bool> g_prof_on{false};
+static std::mutex g_prof_mu;                            // record allocation; entry points may run on several host threads
+static thread_local int t_prof_open[ZG_PROF_NKERNELS];  // record index + 1 of this thread's open bracket per kernel id (0 = none)
 
 void prof_begin(int id, hipStream_t st) {
-    if (!g_prof_on || g_prof_used >= g_prof.size()) { g_prof_open[id] = -1; return; }
-    ProfRec &r = g_prof[g_prof_used];
-    r.id = id;
-    g_prof_open[id] = (int)g_prof_used++;
-    (void)hipEventRecord(r.e0, st);
+    t_prof_open[id] = 0;
+    if (!g_prof_on.load(std::memory_order_acquire)) return;
+    ProfRec *r = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        if (!g_prof_on.load(std::memory_order_relaxed) || g_prof_used >= g_prof.size()) return;
+        r = &g_prof[g_prof_used];
+        r->id = id;
+        t_prof_open[id] = (int)++g_prof_used;
+    }
+    (void)hipEventRecord(r->e0, st);
 }
 void prof_end(int id, hipStream_t st) {
-    if (!g_prof_on || g_prof_open[id] < 0) return;
-    (void)hipEventRecord(g_prof[g_prof_open[id]].e1, st);
-    g_prof_open[id] = -1;
+    int k = t_prof_open[id];
+    if (k == 0 || !g_prof_on.load(std::memory_order_acquire)) return;
+    t_prof_open[id] = 0;
+    (void)hipEventRecord(g_prof[k - 1].e1, st);
 }
 
 // ------------------------------------------------------------------ field op kernel
@@ -233,6 +242,7 @@ int zg_sync(void) {
 int zg_profile_begin(int max_records) {
     ZG_INIT();
     if (max_records < 1) return ZG_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     while ((int)g_prof.size() < max_records) {
         ProfRec r;
         r.id = -1;
@@ -240,7 +250,6 @@ int zg_profile_begin(int max_records) {
         ZG_HIP(hipEventCreate(&r.e1));
         g_prof.push_back(r);
     }
-    for (int i = 0; i < ZG_PROF_NKERNELS; i++) g_prof_open[i] = -1;
     g_prof_used = 0;
     g_prof_on = true;
     return ZG_OK;
@@ -251,6 +260,7 @@ int zg_profile_end(double ms_out[ZG_PROF_NKERNELS], uint64_t count_out[ZG_PROF_N
     g_prof_on = false;
     for (int i = 0; i < ZG_PROF_NKERNELS; i++) { ms_out[i] = 0.0; count_out[i] = 0; }
     ZG_HIP(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     for (size_t k = 0; k < g_prof_used; k++) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, g_prof[k].e0, g_prof[k].e1) == hipSuccess) {
