@@ -36,6 +36,10 @@ MEASURED_TRAFFIC = {20: (1270353.1 + 28524.6) * 1024.0}
 # add/and/shift/sub at 2 (tools/microbench.hip rates)
 MADD_ISSUE_CYCLES = (1467 + 146 + 144 + 81) * 4 + 382 * 2
 VALU_PEAK_GCYC = 1024 * 2.4  # 256 CUs x 4 SIMDs x 2.4 GHz
+# the same mix priced with the issue times MEASURED on MI355X at 2 waves per SIMD (profiles/r1_microbench_instruction_rates.txt,
+# ns per wave-instruction per SIMD under load: v_mad_u64_u32 2.034, v_lshl_add_u64 2.181 (v_lshrrev_b64 taken equal), v_mul_lo_u32
+# 2.113, 32-bit add 1.183): the least time one SIMD needs for one wave-wide mixed add, clocks as they really are under this load
+MADD_MIN_NS_PER_SIMD = 1467 * 2.034 + (146 + 144) * 2.181 + 81 * 2.113 + 382 * 1.183
 SEED = 0x5A4F4C54
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 N_SCALAR_SETS = 3
@@ -281,6 +285,11 @@ def main():
                                      "frac": issue / VALU_PEAK_GCYC if issue else None,
                                      "duration": "avg_launch_ms_alone (the kernel running by itself, outside the timed region)",
                                      "model": "1467 v_mad_u64_u32 + 371 other quarter-rate + 382 half-rate VALU instructions per mixed add"}
+    floor_ms = adds / 64.0 / 1024.0 * MADD_MIN_NS_PER_SIMD * 1e-6 if args.logn >= 15 else None
+    out["roofline"]["valu_issue_measured_rates"] = {
+        "floor_ms": floor_ms, "frac": floor_ms / alone_ms if floor_ms and alone_ms else None,
+        "model": "adds / (64 lanes x 1024 SIMDs) x least ns per wave-wide mixed add at the issue times measured by tools/microbench.hip "
+                 "(profiles/r1_microbench_instruction_rates.txt); frac = floor / avg_launch_ms_alone"}
     if sharded_sc is not None:
         out["extra"]["sumcheck_v20_sharded"] = sharded_sc
     if sharded_22 is not None:
