@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint64_t *scalars
     constexpr uint32_t NB = 1u << (C - 1);
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    Fr s = fe_from_mont(fe_load<FrParams>(scalars + 4 * (size_t)i));
+    Fr s = fr_from_mont29(fe_load<FrParams>(scalars + 4 * (size_t)i));
     uint32_t batch = i / n_pts, pt = i - batch * n_pts;  // scalar vector `batch`, base `pt` (n == n_pts: one MSM)
     bool skip = inf && inf[pt];  // msm/mod.zig:407: infinity bases contribute nothing
     uint32_t carry = 0;
@@ -279,7 +279,7 @@ __global__ void __launch_bounds__(1024) msm_digits_lds_kernel(const uint64_t *sc
     __syncthreads();
     uint32_t i0 = blockIdx.x * per_block, i1 = i0 + per_block < n ? i0 + per_block : n;
     for (uint32_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-        Fr s = fe_from_mont(fe_load<FrParams>(scalars + 4 * (size_t)i));
+        Fr s = fr_from_mont29(fe_load<FrParams>(scalars + 4 * (size_t)i));
         uint32_t batch = i / n_pts, pt = i - batch * n_pts;
         bool skip = inf && inf[pt];
         uint32_t carry = 0;
