@@ -403,6 +403,9 @@ __global__ void __launch_bounds__(1024) msm_coarse_base_kernel(const uint32_t *t
 // handles about one divergent lane per two cycles per CU), and then copies every bin's run to its place in `tmp` with
 // consecutive lanes on consecutive addresses: all HBM traffic of the pass is coalesced.
 static constexpr uint32_t STAGE_ENTRIES = 32768;  // 128 KiB of LDS
+// PLAIN: one bucket group and one scalar vector (the full-precompute single MSM) — level = window, point = scalar index; the
+// general form divides by G and reduces modulo n_pts per entry (a select would evaluate both: 50 instructions per entry)
+template <bool PLAIN>
 __global__ void __launch_bounds__(1024) msm_partition_kernel(const uint32_t *dig, uint32_t n, uint32_t n_pts, int W, int G, size_t table_n,
                                                              uint32_t off, uint32_t per_block, uint32_t NCB, int fb, int rb,
                                                              const uint32_t *tstarts, const uint32_t *blockoff, uint32_t *tmp) {
@@ -450,13 +453,12 @@ __global__ void __launch_bounds__(1024) msm_partition_kernel(const uint32_t *dig
         if (tid == T - 1) lbase[NCB] = sums[T - 1];
     }
     __syncthreads();
-    const bool batched = n != n_pts;  // several scalar vectors back to back over the same bases
 #pragma unroll
     for (int r = 0; r < (int)(STAGE_ENTRIES / 1024); r++) {
         if (e[r] != 0xFFFFFFFFu) {
             uint32_t w = (uint32_t)r >> jw2, i = i0 + ((uint32_t)r & jw2) * T + tid;
-            uint32_t key = e[r] & 0x7FFFFFFFu, bin = key >> fb, lvl = G == 1 ? w : w / (uint32_t)G;
-            uint32_t pt = batched ? i % n_pts : i;
+            uint32_t key = e[r] & 0x7FFFFFFFu, bin = key >> fb, lvl = PLAIN ? w : w / (uint32_t)G;
+            uint32_t pt = PLAIN ? i : i % n_pts;  // several scalar vectors back to back over the same bases
             uint32_t packed = (e[r] & 0x80000000u) | ((key & fmask) << rb) | (uint32_t)((size_t)lvl * table_n + off + pt);
             buf[lbase[bin] + atomicAdd(&cnt[bin], 1u)] = packed;
         }
@@ -1488,7 +1490,9 @@ static int two_pass_attrs() {
     static std::once_flag once;
     static hipError_t err = hipSuccess;
     std::call_once(once, [] {
-        err = hipFuncSetAttribute(reinterpret_cast<const void *>(msm_partition_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+        err = hipFuncSetAttribute(reinterpret_cast<const void *>(msm_partition_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+        if (err == hipSuccess)
+            err = hipFuncSetAttribute(reinterpret_cast<const void *>(msm_partition_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
         if (err == hipSuccess)
             err = hipFuncSetAttribute(reinterpret_cast<const void *>(msm_fine_place_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     });
@@ -1544,9 +1548,14 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
         hipLaunchKernelGGL(msm_colscan_bins_kernel, dim3(p.NCB), dim3(256), 0, st, ln.d_blockhist, nblk, p.NCB, d_tot);
         hipLaunchKernelGGL(msm_coarse_base_kernel, dim3(1), dim3(1024), 0, st, d_tot, p.NCB, ln.d_cstarts, d_tst, d_ist);
         ZG_TRY(two_pass_attrs());
-        hipLaunchKernelGGL(msm_partition_kernel, dim3(nblk), dim3(1024), (STAGE_ENTRIES + 2 * (size_t)p.NCB + 1 + 1024) * 4, st, ln.d_dig,
-                           (uint32_t)n, (uint32_t)n_pts, p.W, p.G, b->n, (uint32_t)off, per_block, p.NCB, p.fb, p.rb, d_tst, ln.d_blockhist,
-                           ln.d_tmp);
+        if (p.G == 1 && n == n_pts)
+            hipLaunchKernelGGL(msm_partition_kernel<true>, dim3(nblk), dim3(1024), (STAGE_ENTRIES + 2 * (size_t)p.NCB + 1 + 1024) * 4, st, ln.d_dig,
+                               (uint32_t)n, (uint32_t)n_pts, p.W, p.G, b->n, (uint32_t)off, per_block, p.NCB, p.fb, p.rb, d_tst, ln.d_blockhist,
+                               ln.d_tmp);
+        else
+            hipLaunchKernelGGL(msm_partition_kernel<false>, dim3(nblk), dim3(1024), (STAGE_ENTRIES + 2 * (size_t)p.NCB + 1 + 1024) * 4, st, ln.d_dig,
+                               (uint32_t)n, (uint32_t)n_pts, p.W, p.G, b->n, (uint32_t)off, per_block, p.NCB, p.fb, p.rb, d_tst, ln.d_blockhist,
+                               ln.d_tmp);
         {
             uint32_t items = (uint32_t)fine_max_items(p, n);
             uint32_t *d_fbase = ln.d_fine + (size_t)items * ((size_t)1 << p.fb);
