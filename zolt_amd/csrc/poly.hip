@@ -306,6 +306,27 @@ struct FrArg {  // a challenge travels as a kernel argument: no H2D copy, no sta
     uint32_t l[8];
 };
 
+// One level of HyperKZG.open (src/poly/commitment/mod.zig:296-310) in one pass over the table: the quotient
+// q[j] = t[j + half] - t[j] (the first q_count entries are kept: commit() uses min(half, srs_len) of them) and the fold
+// out[j] = (1 - r) t[j] + r t[j + half] = t[j] + r q[j]. It replaces a quotient launch plus a fold launch that also produced round
+// sums nobody reads, and stays below the 112 registers per SIMD that a resident bucket accumulation leaves free: the open's serial
+// quotient -> fold chain then runs beside the commits of the earlier levels instead of waiting for their workgroups to retire.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(56))) hk_quot_fold_kernel(const uint64_t *t, size_t half, FrArg r, uint64_t *q,
+                                                                                               size_t q_count, uint64_t *out) {
+    __builtin_amdgcn_s_setprio(3);
+    Fr rv;
+#pragma unroll
+    for (int i = 0; i < 8; i++) rv.l[i] = r.l[i];
+    F29 rp = fr29_prescale(rv);
+    size_t stride = (size_t)gridDim.x * 256;
+    for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < half; j += stride) {
+        Fr lo = fe_load<FrParams>(t + 4 * j), hi = fe_load<FrParams>(t + 4 * (j + half));
+        Fr d = fe_sub(hi, lo);
+        if (j < q_count) fe_store(q + 4 * j, d);
+        fe_store(out + 4 * j, fe_add(lo, fr_mul29(d, rp)));
+    }
+}
+
 template <int LAYOUT>
 __global__ void __launch_bounds__(256) sc_fold_kernel(const uint64_t *t, size_t half, FrArg r, uint64_t *out,
                                                       uint64_t *partials, uint64_t *sums, uint32_t *counter, uint64_t *flag,
@@ -809,15 +830,16 @@ static int hk_open_device(zg_bases_t srs, uint64_t *d_a, uint64_t *d_b, uint64_t
         if (small_rows < 2) small_rows = 0;  // nothing to fuse
     }
     // The long levels' commits are independent of the folds that follow them: each gets its own quotient buffer and its MSM is
-    // issued on one of three streams in turn (the caller's and two helpers forked / joined by events), so the latency-bound tail
-    // of one commit runs under the accumulation of the next.
-    static hipStream_t aux[2] = {nullptr, nullptr};
+    // issued on one of three helper streams in turn (forked / joined by events), never on the caller's stream, so the
+    // latency-bound tail of one commit runs under the accumulation of the next.
+    constexpr int NAUX = 3;
+    static hipStream_t aux[NAUX] = {nullptr, nullptr, nullptr};
     static std::once_flag aux_once;
     std::call_once(aux_once, [] {
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < NAUX; i++)
             if (hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking) != hipSuccess) aux[i] = nullptr;
     });
-    const bool fork = aux[0] && aux[1];
+    const bool fork = aux[0] && aux[1] && aux[2];
     std::vector<hipEvent_t> events;
     struct EventGuard {
         std::vector<hipEvent_t> &ev;
@@ -826,8 +848,10 @@ static int hk_open_device(zg_bases_t srs, uint64_t *d_a, uint64_t *d_b, uint64_t
     Scratch s_res((9 * num_vars + 4) * 8), s_misc(SC_MISC_BYTES), s_small((small_rows * small_len + 1) * 32), s_qall((n_evals + 1) * 32);
     if (!s_res.p || !s_misc.p || !s_small.p || !s_qall.p) return ZG_ERR_NOMEM;
     uint64_t *d_qall = s_qall.as<uint64_t>();
-    size_t q_used = 0, big = 0;
-    bool aux_used[2] = {false, false};
+    size_t q_used = 0;
+    struct PendingCommit { size_t level, nc; const uint64_t *q; };
+    std::vector<PendingCommit> pending;
+    bool aux_used[NAUX] = {false, false, false};
     uint64_t *d_res = s_res.as<uint64_t>(), *d_misc = s_misc.as<uint64_t>(), *d_small = s_small.as<uint64_t>();
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = hipMemsetAsync(d_res, 0, (9 * num_vars + 4) * 8, st);
@@ -845,37 +869,59 @@ static int hk_open_device(zg_bases_t srs, uint64_t *d_a, uint64_t *d_b, uint64_t
         unsigned nb = div_up(half, 256);
         if (nb > 4096) nb = 4096;
         size_t nc = half < srs_len ? half : srs_len;  // commit(): n = min(evals.len, srs.len), :246
+        FrArg ra;
+        for (int k = 0; k < 4; k++) {
+            ra.l[2 * k] = (uint32_t)point[4 * i + k];
+            ra.l[2 * k + 1] = (uint32_t)(point[4 * i + k] >> 32);
+        }
+        if (nb > 1024) nb = 1024;
         if (small_rows && nc <= HK_SMALL) {
             if (first_small == num_vars) first_small = i;
             // only the first nc entries are committed; the row keeps zeros beyond them
-            hipLaunchKernelGGL(fr_sub_halves_kernel, dim3(div_up(nc, 256)), dim3(256), 0, st, cur, half, d_small + 4 * small_len * row, nc);
+            hipLaunchKernelGGL(hk_quot_fold_kernel, dim3(nb), dim3(256), 0, st, cur, half, ra, d_small + 4 * small_len * row, nc, nxt);
             row++;
         } else {
             uint64_t *qi = fork ? d_qall + 4 * q_used : d_q;
             q_used += half;
-            hipLaunchKernelGGL(fr_sub_halves_kernel, dim3(nb), dim3(256), 0, st, cur, half, qi, half);
-            hipStream_t si = st;
-            if (fork && big % 3 != 0) {
-                hipEvent_t ev = nullptr;
-                if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
-                    events.push_back(ev);
-                    si = aux[big % 3 - 1];
-                    aux_used[big % 3 - 1] = true;
-                    e = hipEventRecord(ev, st);
-                    if (e == hipSuccess) e = hipStreamWaitEvent(si, ev, 0);
-                    if (e != hipSuccess) break;
-                }
+            hipLaunchKernelGGL(hk_quot_fold_kernel, dim3(nb), dim3(256), 0, st, cur, half, ra, qi, half, nxt);
+            if (fork) {
+                pending.push_back(PendingCommit{i, nc, qi});  // issued after the chain, see below
+            } else {
+                rc = zg_msm_g1_dev_async(srs, 0, nc, qi, st, d_res + 9 * i, reinterpret_cast<uint8_t *>(d_res + 9 * i + 8));
+                if (rc != ZG_OK) break;
             }
-            big++;
-            rc = zg_msm_g1_dev_async(srs, 0, nc, qi, si, d_res + 9 * i, reinterpret_cast<uint8_t *>(d_res + 9 * i + 8));
-            if (rc != ZG_OK) break;
         }
         computed++;
-        rc = launch_fold(ZG_SC_HIGH_HALF, cur, 2 * half, point + 4 * i, nxt, d_misc, d_misc + SC_SUMS_OFF, st);
         uint64_t *t = cur; cur = nxt; nxt = t;
         len = half;
     }
-    for (int a = 0; a < 2; a++)  // join the helper streams (also after an error, so that they never run ahead of later work)
+    // The whole chain is enqueued (and, being a few short kernels, finished) before the first commit starts: kernels of different
+    // streams share the dispatch pipes, and a commit's sort kernels (whole-CU workgroups that launch as accumulate workgroups
+    // retire) held the chain's next link back by 0.5-1 ms per level when both were in flight. Commits then go out on the three
+    // helper streams in turn, largest first.
+    if (fork && e == hipSuccess && rc == ZG_OK && !pending.empty()) {
+        hipEvent_t ev = nullptr;
+        e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e == hipSuccess) {
+            events.push_back(ev);
+            e = hipEventRecord(ev, st);
+        }
+        for (size_t k = 0; k < pending.size() && e == hipSuccess && rc == ZG_OK; k++) {
+            hipStream_t si = aux[k % NAUX];
+            if (!aux_used[k % NAUX]) {
+                e = hipStreamWaitEvent(si, ev, 0);
+                if (e != hipSuccess) break;
+                aux_used[k % NAUX] = true;
+            }
+            const PendingCommit &pc = pending[k];
+            rc = zg_msm_g1_dev_async(srs, 0, pc.nc, pc.q, si, d_res + 9 * pc.level, reinterpret_cast<uint8_t *>(d_res + 9 * pc.level + 8));
+        }
+    }
+    // the short levels' fused commit depends on the chain only: it goes on the caller's stream before the joins and runs beside
+    // the long commits
+    if (e == hipSuccess && rc == ZG_OK && row)  // rows are consecutive levels first_small, first_small + 1, ...
+        rc = zg_msm_g1_batch_dev(srs, small_len, d_small, row, st, d_res + 9 * first_small);
+    for (int a = 0; a < NAUX; a++)  // join the helper streams (also after an error, so that they never run ahead of later work)
         if (aux_used[a]) {
             hipEvent_t ev = nullptr;
             if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
@@ -885,8 +931,6 @@ static int hk_open_device(zg_bases_t srs, uint64_t *d_a, uint64_t *d_b, uint64_t
                 (void)hipStreamSynchronize(aux[a]);
             }
         }
-    if (e == hipSuccess && rc == ZG_OK && row)  // rows are consecutive levels first_small, first_small + 1, ...
-        rc = zg_msm_g1_batch_dev(srs, small_len, d_small, row, st, d_res + 9 * first_small);
     if (e == hipSuccess && rc == ZG_OK && len > 0)
         e = hipMemcpyAsync(d_res + 9 * num_vars, cur, 32, hipMemcpyDeviceToDevice, st);  // final = current[0], :317
     std::vector<uint64_t> dev_res(9 * num_vars + 4);
