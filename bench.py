@@ -27,10 +27,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # HBM traffic of one msm_accumulate launch at 2^20 points (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
-# passes, profiles/r1k_rocprofv3_summary_streams1.txt; 17-bit windows, 15.7M rows): 1,270,353 KB fetched + 28,525 KB written. The launch
+# passes, profiles/r1l_rocprofv3_summary_streams1.txt; 17-bit windows, 15.7M rows): 1,412,487 KB fetched + 28,525 KB written
+# (1.25-1.41 GB over the boxes of profiles/r1j..r1l: how much of the 1 GiB table the 256 MB memory-side cache still holds). The launch
 # gathers 15.7M random 64-byte rows (1.01 GB) + 63 MB of sorted refs: FETCH_SIZE is taken uncorrected because
 # the gfx950 x2 under-count applies to wide streaming reads tallied as 128-byte requests, not to 64-byte rows.
-MEASURED_TRAFFIC = {20: (1270353.1 + 28524.6) * 1024.0}
+MEASURED_TRAFFIC = {20: (1412487.0 + 28524.7) * 1024.0}
 # static instruction mix of one lazy-limb XYZZ mixed add (hipcc --save-temps of the accumulate fast path): 1467
 # v_mad_u64_u32 + 146 v_lshl_add_u64 + 144 v_lshrrev_b64 + 81 v_mul_lo_u32 at 4 issue cycles per wave, 382 32-bit
 # add/and/shift/sub at 2 (tools/microbench.hip rates)
@@ -265,7 +266,7 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "msm_accumulate_chunk_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                      "traffic": MEASURED_TRAFFIC.get(args.logn) if world == 1 and args.window_bits == 0 and args.precompute == 0 else None,
-                     "traffic_source": "rocprofv3 PMC FETCH_SIZE+WRITE_SIZE, profiles/r1k_rocprofv3_summary_streams1.txt",
+                     "traffic_source": "rocprofv3 PMC FETCH_SIZE+WRITE_SIZE, profiles/r1l_rocprofv3_summary_streams1.txt",
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": acc_avg_ms,
                      "note": "MSM is integer-ALU-bound (10 Fp mul per mixed add x windows per point); see DESIGN.md"},
         "extra": {"kernel_ms_per_msm": {k: (v[0] / max(v[1], 1)) for k, v in prof.items() if v[1]},
