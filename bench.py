@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 
 # HBM traffic of one msm_accumulate launch at 2^20 points (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
 # passes, profiles/r1l_rocprofv3_summary_streams1.txt; 17-bit windows, 15.7M rows): 1,412,487 KB fetched + 28,525 KB written
-# (1.25-1.41 GB over the boxes of profiles/r1j..r1l: how much of the 1 GiB table the 256 MB memory-side cache still holds). The launch
+# (1.25-1.41 GB over the runs profiles/r1j..r1l on different boxes). The launch
 # gathers 15.7M random 64-byte rows (1.01 GB) + 63 MB of sorted refs: FETCH_SIZE is taken uncorrected because
 # the gfx950 x2 under-count applies to wide streaming reads tallied as 128-byte requests, not to 64-byte rows.
 MEASURED_TRAFFIC = {20: (1412487.0 + 28524.7) * 1024.0}
