@@ -12,6 +12,8 @@
 //                           digits -> keys (bucket group g, |digit|-1); per-block histogram in LDS
 //   msm_colscan / scan_a/b / scatter_lds   counting sort of the n*W (key, point-ref) pairs: per-block
 //                           offsets, two-pass coalesced scan, scatter with LDS cursors (no global atomics)
+//   msm_partition / fine_count / fine_offsets / fine_place   the same sort in two LDS-staged passes (coarse bins,
+//                           then slices of a bin by fine key) for >= 8192 buckets: all HBM traffic coalesced
 //   msm_accumulate_chunk    the sorted list is cut into equal chunks, one per thread, whatever the bucket
 //                           sizes (skew-robust); complete XYZZ mixed adds on lazy limbs; one partial per
 //                           bucket run
@@ -20,8 +22,12 @@
 //   msm_bitsum              sum_k k*B_k = sum_b 2^b * T_b,  T_b = sum of the buckets whose index has
 //                           bit b set: c plain tree sums (log depth) instead of the reference's
 //                           serial running sum (a lone GPU lane needs ~10 us per point add)
-//   msm_final               b doublings of T_b in parallel lanes, tree sum, window Horner if G > 1,
-//                           one Kaliski inversion -> affine
+//   msm_rowcol / bits2d     the same T_b for c >= 11 from row and column sums of the bucket matrix (every bucket
+//                           added twice instead of (c-1)/2 times)
+//   msm_final               b doublings of T_b in parallel quads, tree sum, window Horner if G > 1,
+//                           one inversion (safegcd) -> affine
+// Every kernel but the accumulation raises its wave priority: they are short dependent chains that would otherwise
+// get a third of the issue slots beside another stream's accumulate waves.
 //
 // Bucket sums are order-independent group sums and the final affine coordinates are
 // canonical field values, so the 64-byte result is bit-identical to the reference's
