@@ -221,9 +221,11 @@ __global__ void __launch_bounds__(1024) msm_scan_a_kernel(const uint32_t *__rest
 __global__ void __launch_bounds__(1024) msm_scan_b_kernel(const uint32_t *__restrict__ hist, uint32_t NK, const uint32_t *__restrict__ loc,
                                                           const uint32_t *__restrict__ locz, const uint32_t *__restrict__ tile_tot,
                                                           uint32_t *__restrict__ starts, uint32_t *__restrict__ nzrank,
-                                                          uint32_t *__restrict__ nzlist) {
+                                                          uint32_t *__restrict__ nzlist, uint32_t *__restrict__ state) {
     ZG_HIPRIO();
     __shared__ uint32_t pre[2];
+    // the launch set's MsmState (heavy / huge bucket counters of the reduction) is cleared here: one launch less than a memset
+    if (state && blockIdx.x == 0 && threadIdx.x < 4) state[threadIdx.x] = 0;
     uint32_t tid = threadIdx.x, k = blockIdx.x * 1024 + tid;
     if (tid < 64) {  // one wave sums the totals of the preceding tiles (at most 2048 tiles)
         uint32_t a = 0, az = 0;
@@ -1575,7 +1577,7 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
         hipLaunchKernelGGL(msm_scan_a_kernel, dim3(tiles), dim3(1024), 0, st, ln.d_hist, p.NK, ln.d_scan_tmp, ln.d_scan_tmp + p.NK,
                            ln.d_scan_tmp + 2 * (size_t)p.NK);
         hipLaunchKernelGGL(msm_scan_b_kernel, dim3(tiles), dim3(1024), 0, st, ln.d_hist, p.NK, ln.d_scan_tmp, ln.d_scan_tmp + p.NK,
-                           ln.d_scan_tmp + 2 * (size_t)p.NK, ln.d_starts, ln.d_nzrank, ln.d_nzlist);
+                           ln.d_scan_tmp + 2 * (size_t)p.NK, ln.d_starts, ln.d_nzrank, ln.d_nzlist, reinterpret_cast<uint32_t *>(ln.d_state));
     } else if (ln.d_blockhist) {
         uint32_t nblk = nblk_cap;
         while (nblk > 1 && (size_t)(nblk - 1) * 1024 >= n) nblk--;  // no empty blocks for short sub-range MSMs
@@ -1591,7 +1593,7 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
             hipLaunchKernelGGL(msm_scan_a_kernel, dim3(tiles), dim3(1024), 0, st, ln.d_hist, p.NK, ln.d_scan_tmp, ln.d_scan_tmp + p.NK,
                                ln.d_scan_tmp + 2 * (size_t)p.NK);
             hipLaunchKernelGGL(msm_scan_b_kernel, dim3(tiles), dim3(1024), 0, st, ln.d_hist, p.NK, ln.d_scan_tmp, ln.d_scan_tmp + p.NK,
-                               ln.d_scan_tmp + 2 * (size_t)p.NK, ln.d_starts, ln.d_nzrank, ln.d_nzlist);
+                               ln.d_scan_tmp + 2 * (size_t)p.NK, ln.d_starts, ln.d_nzrank, ln.d_nzlist, reinterpret_cast<uint32_t *>(ln.d_state));
         }
         static std::once_flag scatter_once;
         static hipError_t scatter_err = hipSuccess;
@@ -1613,7 +1615,7 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
             hipLaunchKernelGGL(msm_scan_a_kernel, dim3(tiles), dim3(1024), 0, st, ln.d_hist, p.NK, ln.d_scan_tmp, ln.d_scan_tmp + p.NK,
                                ln.d_scan_tmp + 2 * (size_t)p.NK);
             hipLaunchKernelGGL(msm_scan_b_kernel, dim3(tiles), dim3(1024), 0, st, ln.d_hist, p.NK, ln.d_scan_tmp, ln.d_scan_tmp + p.NK,
-                               ln.d_scan_tmp + 2 * (size_t)p.NK, ln.d_starts, ln.d_nzrank, ln.d_nzlist);
+                               ln.d_scan_tmp + 2 * (size_t)p.NK, ln.d_starts, ln.d_nzrank, ln.d_nzlist, reinterpret_cast<uint32_t *>(ln.d_state));
         }
         ZG_HIP(hipMemsetAsync(ln.d_hist, 0, (size_t)p.NK * 4, st));
         hipLaunchKernelGGL(msm_scatter_kernel, dim3(div_up(n, 256), p.W), dim3(256), 0, st, ln.d_dig, (uint32_t)n, (uint32_t)n_pts, p.G,
@@ -1626,7 +1628,6 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
         // warrant, never more than the workspace was sized for
         uint32_t NT = chunk_threads((uint64_t)n * p.W);
         if (NT > p.NT || getenv("ZG_MSM_CHUNK_THREADS")) NT = p.NT;
-        ZG_HIP(hipMemsetAsync(ln.d_state, 0, sizeof(MsmState), st));
         if (NT <= (uint32_t)env_int("ZG_MSM_QUAD_ACC_MAX_CHUNKS", 32768))
             hipLaunchKernelGGL(msm_accumulate_chunk_kernel<true>, dim3(div_up((size_t)NT * 4, 256)), dim3(256), 0, st, ln.d_sorted, ln.d_starts,
                                ln.d_nzrank, ln.d_nzlist, b->d_table, p.NK, NT, ln.d_part);
