@@ -1206,7 +1206,7 @@ static int make_plan(size_t n, const zg_msm_config *cfg, MsmPlan &p, size_t batc
         // measured on MI355X (tools/bench_window.py): window sizes whose last window covers only a couple of the 254
         // scalar bits (c = 9, 12, 14) waste a window and pile its digits into a handful of buckets; 16 wins from
         // 2^15 points up (fewest windows; the rest of the pipeline is latency), 8 / 7 below.
-        c = n >= 32768 ? 16 : (n >= 2048 ? 8 : (n >= 64 ? 7 : 5));
+        c = n >= 32768 ? 16 : (n >= 8192 ? 10 : (n >= 2048 ? 8 : (n >= 64 ? 7 : 5)));  // 2^13 points: 0.40 ms with c = 8, 0.32 with 10
         // 17 bits = 15 windows instead of 16 (6 % fewer bucket additions) for twice the buckets: pays from about 2^20 points,
         // as long as the 15 n table rows still fit the 24-bit references of the two-pass sort (n <= 1.1 M)
         if (batch == 1 && n >= (size_t)env_int("ZG_MSM_C17_MIN", 900000) && (uint64_t)n * 15 <= (1u << 24)) c = 17;
