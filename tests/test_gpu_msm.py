@@ -57,9 +57,10 @@ def test_golden_vectors(zl, ob):
                 assert not got.any()  # identity is {0,0,inf}, src/msm/mod.zig:24-30
 
 
-@pytest.mark.parametrize("n", [0, 1, 7, 8, 9, 31, 32, 100, 1000, (1 << 15) - 1, 1 << 15, (1 << 16) + 1])
+@pytest.mark.parametrize("n", [0, 1, 7, 8, 9, 31, 32, 100, 1000, 2047, 2048, (1 << 13) - 1, 1 << 13, (1 << 15) - 1, 1 << 15, (1 << 16) + 1])
 def test_sizes_vs_oracle(zl, ob, gm, n):
-    """SURVEY §8(d) adversarial size set (the reference switches algorithm at n=8 and window size at 32/128/.../32768)."""
+    """SURVEY §8(d) adversarial size set (the reference switches algorithm at n=8 and window size at 32/128/.../32768), plus the
+    sizes at which the automatic plan here changes its window (64, 2048, 8192, 32768)."""
     _check(zl, ob, gm[:n], None, _scalars(ob, 1000 + n, n))
 
 
@@ -299,6 +300,8 @@ def test_full_size_closed_form(zl, ob, n):
     raw = U.random_raw256(0x5A4F4C54, n)
     sc = ob.f_to_mont(ob.FR, raw)
     b = zl.Bases.upload(gm)
+    # the automatic plan (the GPU's optimalWindowSize): 17-bit windows while 15 n table rows fit 24-bit references, else 16
+    assert b.plan() == ((17, 15, 15) if n * 15 <= 1 << 24 else (16, 16, 16))
     got, ginf = b.msm(sc)
     got2, ginf2 = b.msm(sc)  # idempotent: same handle, same answer
     b.free()
@@ -371,6 +374,7 @@ def test_auto_plan_sizes(zl, ob, logn):
     gmn = ob.g1_gen_multiples(n)
     sc = _scalars(ob, 5000 + logn, n)
     b = zl.Bases.upload(gmn)
+    assert b.plan() == (16, 16, 16)
     got, ginf = b.msm(sc)
     b.free()
     want, winf = ob.msm_g1_parallel(gmn, None, sc, 8)
