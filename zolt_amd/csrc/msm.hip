@@ -461,12 +461,15 @@ __global__ void __launch_bounds__(1024) msm_partition_kernel(const uint32_t *dig
         if (tid == T - 1) lbase[NCB] = sums[T - 1];
     }
     __syncthreads();
+    // a thread's entries belong to at most two scalars (rows 0 and 1 of every window): their point indices are found once
+    // (several scalar vectors lie back to back over the same bases: index modulo n_pts)
+    const uint32_t pt_row0 = PLAIN ? i0 + tid : (i0 + tid) % n_pts, pt_row1 = PLAIN ? i0 + T + tid : (i0 + T + tid) % n_pts;
 #pragma unroll
     for (int r = 0; r < (int)(STAGE_ENTRIES / 1024); r++) {
         if (e[r] != 0xFFFFFFFFu) {
-            uint32_t w = (uint32_t)r >> jw2, i = i0 + ((uint32_t)r & jw2) * T + tid;
-            uint32_t key = e[r] & 0x7FFFFFFFu, bin = key >> fb, lvl = PLAIN ? w : w / (uint32_t)G;
-            uint32_t pt = PLAIN ? i : i % n_pts;  // several scalar vectors back to back over the same bases
+            uint32_t w = (uint32_t)r >> jw2;
+            uint32_t key = e[r] & 0x7FFFFFFFu, bin = key >> fb, lvl = (PLAIN || G == 1) ? w : w / (uint32_t)G;
+            uint32_t pt = ((uint32_t)r & jw2) ? pt_row1 : pt_row0;
             uint32_t packed = (e[r] & 0x80000000u) | ((key & fmask) << rb) | (uint32_t)((size_t)lvl * table_n + off + pt);
             buf[lbase[bin] + atomicAdd(&cnt[bin], 1u)] = packed;
         }
@@ -1288,7 +1291,7 @@ static void plan_two_pass(MsmPlan &p, size_t table_rows, size_t n_total) {
     // single-pass sort there (0.67 vs 1.3 ms alone, +2-3 % pipelined); below that the single pass is used
     if (fb < env_int("ZG_MSM_FINE_BITS_MIN", 5)) return;
     uint32_t ncb = (p.NK + (1u << fb) - 1) >> fb;
-    if (ncb > 2048) return;  // pass 1 keeps 2 * NCB counters next to 128 KiB of staged entries in LDS
+    if (ncb > 3000) return;  // pass 1 keeps 2 * NCB counters + 1024 scan partials next to 128 KiB of staged entries in 156 KiB of LDS
     p.fb = fb;
     p.rb = 31 - fb;
     p.NCB = ncb;
@@ -1800,23 +1803,33 @@ int zg_msm_g1_partial_fast_dev(zg_bases_t b, size_t off, size_t n, const uint64_
 // Fusing pays when the MSMs are short (a lone short MSM is pure launch/dependency latency, ~0.4 ms whatever its size):
 // the k vectors become k times the bucket groups of ONE sort / accumulate / reduce pass. It needs the LDS counting sort
 // (all bucket counters of the launch in 128 KiB), i.e. handles with a small window.
-static size_t batch_fuse_limit(const zg_bases_s *b, size_t n) {
+// How many scalar vectors of n scalars one launch set may hold. Narrow windows: all bucket counters of the set must fit the
+// single-pass sort's LDS histogram. wide_ok (HyperKZG.open's long levels, zero-padded rows): wide-window handles too, as many
+// vectors as the two-pass sort has coarse bins for (plan_two_pass: <= 3000 bins of 2^7 buckets when the table rows fit 24 bits).
+static size_t batch_fuse_limit(const zg_bases_s *b, size_t n, bool wide_ok = false) {
     const MsmPlan &p = b->plan;
     if (n == 0 || !env_int("ZG_MSM_BATCH_FUSE", 1)) return 0;
     size_t by_lds = (128 * 1024 / 4) / ((size_t)p.NB * p.G);
+    if (by_lds < 2 && wide_ok) {
+        int need = 1;
+        while (((size_t)1 << need) < (size_t)p.L * b->n) need++;
+        int fb = 31 - need > 7 ? 7 : 31 - need;
+        if (fb >= 5) by_lds = ((size_t)3000 << fb) / ((size_t)p.NB * p.G);
+    }
     size_t by_size = ((size_t)1 << 22) / n;  // keep a launch set at or below 2^22 scalars
     size_t lim = by_lds < by_size ? by_lds : by_size;
     return lim >= 2 ? lim : 0;
 }
 
 // enqueue k scalar vectors (device, back to back) over bases[0, n) on st; record i = d_out9[9*i .. 9*i+8] (xy[8], flag word)
-static int msm_batch_enqueue(zg_bases_s *b, size_t n, const uint64_t *d_scalars, size_t k, hipStream_t st, uint64_t *d_out9) {
+static int msm_batch_enqueue(zg_bases_s *b, size_t n, const uint64_t *d_scalars, size_t k, hipStream_t st, uint64_t *d_out9,
+                             bool wide_ok = false) {
     if (n > b->n) {
         set_error("msm: range exceeds uploaded bases");
         return ZG_ERR_INVALID;
     }
     if (b->small && n <= b->small->n) return msm_batch_enqueue(b->small, n, d_scalars, k, st, d_out9);  // narrow-window side table
-    size_t lim = batch_fuse_limit(b, n);
+    size_t lim = batch_fuse_limit(b, n, wide_ok);
     if (lim == 0 || k < 2) {
         // one launch set per vector, rotating through the handle's workspaces AND through three streams (the caller's
         // plus two forked helpers), so the latency-bound tail of one MSM runs under the accumulation of the next
@@ -1887,6 +1900,19 @@ static int msm_batch_enqueue(zg_bases_s *b, size_t n, const uint64_t *d_scalars,
     }
     return ZG_OK;
 }
+
+}  // extern "C"
+
+namespace zg {
+// zg_msm_g1_batch_dev for zero-padded rows of different live lengths (HyperKZG.open's long levels): also fuses on wide-window
+// handles. Not exported: a general batch of full-length vectors on such a handle is better served by the stream rotation.
+int msm_batch_dev_wide(zg_bases_t b, size_t n, const uint64_t *d_scalars, size_t k, hipStream_t st, uint64_t *d_out9) {
+    std::lock_guard<std::mutex> lk(b->mu);
+    return msm_batch_enqueue(b, n, d_scalars, k, st, d_out9, true);
+}
+}  // namespace zg
+
+extern "C" {
 
 int zg_msm_g1_batch_dev(zg_bases_t b, size_t n, const uint64_t *d_scalars, size_t k, void *stream, uint64_t *d_out9) {
     ZG_INIT();
