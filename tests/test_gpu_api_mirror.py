@@ -108,6 +108,28 @@ def test_hyperkzg_open_mid_sizes(env, v, srs_n):
     params.deinit()
 
 
+@pytest.mark.parametrize("v,srs_n,fuse", [(17, 1 << 17, "1"), (18, 1 << 17, "1"), (17, 1 << 17, "0")])
+def test_hyperkzg_open_long_levels(env, v, srs_n, fuse, monkeypatch):
+    """open() with several long levels (quotients of more than 16384 entries) on a wide-window SRS handle: they are committed as
+    the rows of one zero-padded matrix by ONE fused launch set (two-pass sort over several vectors' bucket sets), the short
+    levels by another; v = 18 on a 2^17-point SRS clamps the first commit to the SRS length. ZG_HK_FUSE_LONG=0: one launch set
+    per long level on the helper streams. Same quotient commitments and final evaluation as the oracle either way."""
+    api, lib, ob = env
+    monkeypatch.setenv("ZG_HK_FUSE_LONG", fuse)
+    gm = ob.g1_gen_multiples(srs_n)
+    inf = np.zeros(srs_n, dtype=np.uint8)
+    inf[7::1000] = 1
+    params = api.HyperKZG.SetupParams(gm, inf)
+    ev = _rand(ob, 700 + v, 1 << v)
+    pt = _rand(ob, 750 + v, v)
+    quotients, final = api.HyperKZG.open(params, ev, pt, np.zeros(4, dtype=np.uint64))
+    wq, wqi, wfin = ob.hyperkzg_open(gm, inf, ev, pt, np.zeros(4, dtype=np.uint64))
+    assert np.array_equal(final, wfin) and len(quotients) == v
+    for i, (q, qi) in enumerate(quotients):
+        assert qi == wqi[i] and np.array_equal(q, wq[i]), i
+    params.deinit()
+
+
 def _ptau(sections):
     out = b"ptau" + (1).to_bytes(4, "little") + len(sections).to_bytes(4, "little")
     for typ, payload in sections:

@@ -836,7 +836,7 @@ static int hk_open_device(zg_bases_t srs, uint64_t *d_a, uint64_t *d_b, uint64_t
     // by ONE fused launch set on a helper stream (msm_batch_dev_wide) — one sort, one accumulation over all levels' digits (as many
     // as a single MSM of twice the first level's size has) and one reduction, instead of five or six launch sets that overlap
     // badly. ZG_HK_FUSE_LONG=0 keeps one launch set per long level.
-    static const bool fuse_long_env = env_uint("ZG_HK_FUSE_LONG", 1, 0, 1) != 0;
+    const bool fuse_long_env = env_uint("ZG_HK_FUSE_LONG", 1, 0, 1) != 0;  // read per call: tests switch it
     // The long levels' commits are independent of the folds that follow them: each gets its own quotient buffer and its MSM is
     // issued on one of three helper streams in turn (forked / joined by events), never on the caller's stream, so the
     // latency-bound tail of one commit runs under the accumulation of the next.
