@@ -29,6 +29,37 @@ def test_header_symbols_all_exported():
     assert all(s.startswith("zg_") for s in re.findall(r" T (\w+)", nm) if not s.startswith("_"))
 
 
+def _split_params(arglist):
+    """top-level comma split of a C / Zig parameter list (no nested parentheses in either header)"""
+    arglist = re.sub(r"/\*.*?\*/", "", arglist, flags=re.S).strip()
+    if arglist in ("", "void"):
+        return []
+    return [a.strip() for a in arglist.split(",")]
+
+
+def test_zig_extern_declarations_match_the_header():
+    """zig/gpu/ffi.zig cannot be compiled here (no Zig toolchain), so at least its extern list is held against include/zolt_gpu.h:
+    every declared function exists in the header with the same number of parameters, pointer parameters are pointers on both
+    sides, and the constants it copies (error codes, sumcheck layouts) have the header's values."""
+    hdr = open(os.path.join(ROOT, "include", "zolt_gpu.h")).read()
+    zig = open(os.path.join(ROOT, "zig", "gpu", "ffi.zig")).read()
+    protos = {m.group(1): _split_params(m.group(2)) for m in re.finditer(r"ZG_API[^;(]*?\b(zg_\w+)\s*\(([^;]*?)\)\s*;", hdr, flags=re.S)}
+    externs = re.findall(r"pub extern fn (zg_\w+)\((.*?)\) [\w\[\]:*?. ]+;", zig)
+    assert len(externs) >= 25
+    for name, args in externs:
+        assert name in protos, name
+        zargs, cargs = _split_params(args), protos[name]
+        assert len(zargs) == len(cargs), (name, zargs, cargs)
+        for za, ca in zip(zargs, cargs):
+            c_ptr = "*" in ca or "[" in ca or "zg_bases_t" in ca or "zg_sc_t" in ca
+            z_ptr = "*" in za or "Bases" in za or "Session" in za
+            assert c_ptr == z_ptr, (name, za, ca)
+    for zname, cname in (("ERR_VERIFY", "ZG_ERR_VERIFY"), ("SC_HIGH_HALF", "ZG_SC_HIGH_HALF"), ("SC_LOW_PAIR", "ZG_SC_LOW_PAIR"), ("OK", "ZG_OK")):
+        zv = int(re.search(r"pub const %s: c_int = (\d+);" % zname, zig).group(1))
+        cv = int(re.search(r"#define %s (\d+)" % cname, hdr).group(1))
+        assert zv == cv, (zname, zv, cv)
+
+
 def test_header_compiles_as_c_and_cpp(tmp_path):
     src = tmp_path / "t.c"
     src.write_text('#include "zolt_gpu.h"\nint main(void){ zg_msm_config c = {0,0}; (void)c; return ZG_OK; }\n')
