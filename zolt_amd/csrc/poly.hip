@@ -84,13 +84,6 @@ __global__ void __launch_bounds__(256) eq_main_kernel(const uint64_t *lo_tab, in
     }
 }
 
-// q[j] = t[j + half] - t[j]   (HyperKZG.open's quotient, src/poly/commitment/mod.zig:296-299)
-__global__ void __launch_bounds__(256) fr_sub_halves_kernel(const uint64_t *t, size_t half, uint64_t *q, size_t count) {
-    size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < count; j += stride)
-        fe_store(q + 4 * j, fe_sub(fe_load<FrParams>(t + 4 * (j + half)), fe_load<FrParams>(t + 4 * j)));
-}
-
 // f[i] = eq[i] * (Az[i]*Bz[i] - Cz[i])
 __global__ void __launch_bounds__(256) spartan_combine_kernel(const uint64_t *eq, const uint64_t *az, const uint64_t *bz,
                                                               const uint64_t *cz, size_t n, uint64_t *out) {
