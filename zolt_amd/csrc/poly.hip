@@ -807,7 +807,7 @@ static int hk_open_device(zg_bases_t srs, uint64_t *d_a, uint64_t *d_b, uint64_t
     // unchanged) and handed to zg_msm_g1_batch_dev, which fuses short vectors into one launch set — a lone short MSM is
     // ~0.4 ms of launch latency, and there are log2(HK_SMALL) + 1 of them.
     const size_t HK_SMALL = 16384;  // = the narrow-window side table of a wide-window handle (msm.hip)
-    size_t small_rows = 0, small_len = 0, long_rows = 0, long_len = 0;
+    size_t small_rows = 0, small_len = 0, long_rows = 0, long_len = 0, long_len2 = 0;
     {
         size_t len = n_evals;
         for (size_t i = 0; i < num_vars; i++) {
@@ -819,6 +819,7 @@ static int hk_open_device(zg_bases_t srs, uint64_t *d_a, uint64_t *d_b, uint64_t
                 small_rows++;
             } else {
                 if (long_rows == 0) long_len = nc;
+                if (long_rows == 1) long_len2 = nc;
                 long_rows++;
             }
             len = half;
@@ -829,7 +830,11 @@ static int hk_open_device(zg_bases_t srs, uint64_t *d_a, uint64_t *d_b, uint64_t
     // by ONE fused launch set on a helper stream (msm_batch_dev_wide) — one sort, one accumulation over all levels' digits (as many
     // as a single MSM of twice the first level's size has) and one reduction, instead of five or six launch sets that overlap
     // badly. ZG_HK_FUSE_LONG=0 keeps one launch set per long level.
-    const bool fuse_long_env = env_uint("ZG_HK_FUSE_LONG", 1, 0, 1) != 0;  // read per call: tests switch it
+    // Mode 2 (default): the first long level — half of all live scalars — keeps a launch set of its own on another helper stream,
+    // and the matrix holds the remaining long levels at the SECOND level's row length: the padding that the digit and sort kernels
+    // walk shrinks from 2.6 M to 1.5 M scalars at 2^20 evaluations, and the two sets run side by side. Mode 1: all long levels in
+    // one matrix.
+    const unsigned fuse_long_env = env_uint("ZG_HK_FUSE_LONG", 2, 0, 2);  // read per call: tests switch it
     // The long levels' commits are independent of the folds that follow them: each gets its own quotient buffer and its MSM is
     // issued on one of three helper streams in turn (forked / joined by events), never on the caller's stream, so the
     // latency-bound tail of one commit runs under the accumulation of the next.
@@ -842,16 +847,20 @@ static int hk_open_device(zg_bases_t srs, uint64_t *d_a, uint64_t *d_b, uint64_t
     });
     const bool fork = aux[0] && aux[1] && aux[2];
     const bool fuse_long = fork && fuse_long_env && long_rows >= 2;
+    const bool split_first = fuse_long && fuse_long_env == 2 && long_rows >= 3;
+    const size_t fl_len = split_first ? long_len2 : long_len, fl_rows = split_first ? long_rows - 1 : long_rows,
+                 fl_off = split_first ? long_len : 0;  // matrix geometry inside d_qall (the lone first level's quotient sits before it)
     std::vector<hipEvent_t> events;
     struct EventGuard {
         std::vector<hipEvent_t> &ev;
         ~EventGuard() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
     } guard{events};
     Scratch s_res((9 * num_vars + 4) * 8), s_misc(SC_MISC_BYTES), s_small((small_rows * small_len + 1) * 32),
-        s_qall(((fuse_long ? long_rows * long_len : n_evals) + 1) * 32);
+        s_qall(((fuse_long ? fl_off + fl_rows * fl_len : 0) + n_evals + 1) * 32);  // matrix, then one buffer per unfused level
     if (!s_res.p || !s_misc.p || !s_small.p || !s_qall.p) return ZG_ERR_NOMEM;
     uint64_t *d_qall = s_qall.as<uint64_t>();
     size_t q_used = 0, long_used = 0, first_long = num_vars;
+    bool first_split_done = false;
     struct PendingCommit { size_t level, nc; const uint64_t *q; };
     std::vector<PendingCommit> pending;
     bool aux_used[NAUX] = {false, false, false};
@@ -860,7 +869,7 @@ static int hk_open_device(zg_bases_t srs, uint64_t *d_a, uint64_t *d_b, uint64_t
     if (e == hipSuccess) e = hipMemsetAsync(d_res, 0, (9 * num_vars + 4) * 8, st);
     if (e == hipSuccess) e = hipMemsetAsync(d_misc + 8 * (size_t)SC_MAX_BLOCKS, 0, 128, st);
     if (e == hipSuccess && small_rows) e = hipMemsetAsync(d_small, 0, small_rows * small_len * 32, st);
-    if (e == hipSuccess && fuse_long) e = hipMemsetAsync(d_qall, 0, long_rows * long_len * 32, st);
+    if (e == hipSuccess && fuse_long) e = hipMemsetAsync(d_qall + 4 * fl_off, 0, fl_rows * fl_len * 32, st);
     int rc = ZG_OK;
     size_t len = n_evals, computed = 0, first_small = num_vars, row = 0;
     uint64_t *cur = d_a, *nxt = d_b;
@@ -885,16 +894,23 @@ static int hk_open_device(zg_bases_t srs, uint64_t *d_a, uint64_t *d_b, uint64_t
             hipLaunchKernelGGL(hk_quot_fold_kernel, dim3(nb), dim3(256), 0, st, cur, half, ra, d_small + 4 * small_len * row, nc, nxt);
             row++;
         } else {
-            if (fuse_long) {  // row long_used of the padded matrix; only the nc committed entries are kept
-                if (first_long == num_vars) first_long = i;
-                hipLaunchKernelGGL(hk_quot_fold_kernel, dim3(nb), dim3(256), 0, st, cur, half, ra, d_qall + 4 * long_len * long_used, nc, nxt);
-                long_used++;
+            if (fuse_long && nc > HK_SMALL) {  // row long_used of the padded matrix; only the nc committed entries are kept
+                if (split_first && !first_split_done) {
+                    first_split_done = true;
+                    hipLaunchKernelGGL(hk_quot_fold_kernel, dim3(nb), dim3(256), 0, st, cur, half, ra, d_qall, nc, nxt);
+                    pending.push_back(PendingCommit{i, nc, d_qall});
+                } else {
+                    if (first_long == num_vars) first_long = i;
+                    hipLaunchKernelGGL(hk_quot_fold_kernel, dim3(nb), dim3(256), 0, st, cur, half, ra, d_qall + 4 * (fl_off + fl_len * long_used), nc,
+                                       nxt);
+                    long_used++;
+                }
                 computed++;
                 uint64_t *t2 = cur; cur = nxt; nxt = t2;
                 len = half;
                 continue;
             }
-            uint64_t *qi = fork ? d_qall + 4 * q_used : d_q;
+            uint64_t *qi = fork ? d_qall + 4 * ((fuse_long ? fl_off + fl_rows * fl_len : 0) + q_used) : d_q;
             q_used += half;
             hipLaunchKernelGGL(hk_quot_fold_kernel, dim3(nb), dim3(256), 0, st, cur, half, ra, qi, half, nxt);
             if (fork) {
@@ -912,19 +928,6 @@ static int hk_open_device(zg_bases_t srs, uint64_t *d_a, uint64_t *d_b, uint64_t
     // streams share the dispatch pipes, and a commit's sort kernels (whole-CU workgroups that launch as accumulate workgroups
     // retire) held the chain's next link back by 0.5-1 ms per level when both were in flight. Commits then go out on the three
     // helper streams in turn, largest first.
-    if (fuse_long && e == hipSuccess && rc == ZG_OK && long_used) {
-        hipEvent_t ev = nullptr;
-        e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-        if (e == hipSuccess) {
-            events.push_back(ev);
-            e = hipEventRecord(ev, st);
-        }
-        if (e == hipSuccess) e = hipStreamWaitEvent(aux[0], ev, 0);
-        if (e == hipSuccess) {
-            aux_used[0] = true;
-            rc = msm_batch_dev_wide(srs, long_len, d_qall, long_used, aux[0], d_res + 9 * first_long);
-        }
-    }
     if (fork && e == hipSuccess && rc == ZG_OK && !pending.empty()) {
         hipEvent_t ev = nullptr;
         e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
@@ -941,6 +944,20 @@ static int hk_open_device(zg_bases_t srs, uint64_t *d_a, uint64_t *d_b, uint64_t
             }
             const PendingCommit &pc = pending[k];
             rc = zg_msm_g1_dev_async(srs, 0, pc.nc, pc.q, si, d_res + 9 * pc.level, reinterpret_cast<uint8_t *>(d_res + 9 * pc.level + 8));
+        }
+    }
+    if (fuse_long && e == hipSuccess && rc == ZG_OK && long_used) {
+        hipEvent_t ev = nullptr;
+        e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e == hipSuccess) {
+            events.push_back(ev);
+            e = hipEventRecord(ev, st);
+        }
+        const int fa = split_first ? 1 : 0;  // the lone first level took helper 0
+        if (e == hipSuccess && !aux_used[fa]) e = hipStreamWaitEvent(aux[fa], ev, 0);
+        if (e == hipSuccess) {
+            aux_used[fa] = true;
+            rc = msm_batch_dev_wide(srs, fl_len, d_qall + 4 * fl_off, long_used, aux[fa], d_res + 9 * first_long);
         }
     }
     // the short levels' fused commit depends on the chain only: it goes on the caller's stream before the joins and runs beside
