@@ -304,7 +304,7 @@ def main():
             hxy, hinf = bases.msm(h_sc)
         out["extra"]["msm_host_scalars_ms"] = (time.perf_counter() - t0) / 3 * 1e3
         assert hinf == want[0][1] and np.array_equal(hxy, want[0][0])
-        out["extra"].update(extra_measurements(lib, api, torch, dev, stream, args))
+        out["extra"].update(extra_measurements(lib, api, torch, dev, stream, args, bases_xy if args.logn == 20 else None))
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(bases_xy, d_scalars[0].cpu().numpy().view(np.uint64), want[0], args.logn)
     print(json.dumps(out))
@@ -357,7 +357,7 @@ def sharded_sumcheck_measurement(lib, api, torch, dist, dev, stream, world, rank
             "layout": "LOW_PAIR, contiguous shards"}
 
 
-def extra_measurements(lib, api, torch, dev, stream, args):
+def extra_measurements(lib, api, torch, dev, stream, args, srs_xy=None):
     """sumcheck rounds/s at v = 20 (BASELINE config 3): eq-table build + Spartan combine + 20 x (round sums,
     host toy challenge, fold) with the table resident in HBM."""
     extra = {}
@@ -408,6 +408,25 @@ def extra_measurements(lib, api, torch, dev, stream, args):
     el = time.perf_counter() - t0
     extra["sumcheck_v20_device_resident"] = {"rounds_per_s": 20 * v / el, "ms_per_runSumcheck": el / 20 * 1e3,
                                              "note": "prover + toy verifier on the device; transcript equals the host-verifier run"}
+    # HyperKZG.open over the same 2^20 bases as an SRS: host table in, v quotient commitments + final value out
+    if srs_xy is not None:
+        try:
+            params = api.HyperKZG.SetupParams(srs_xy, np.zeros(srs_xy.shape[0], dtype=np.uint8))
+            res = {}
+            for vv in (16, 20):
+                ev = lib.field_op(lib.FR, lib.OP_TO_MONT, raw_scalars(0x4F50454E + vv, 0, 1 << vv))
+                pt = lib.field_op(lib.FR, lib.OP_TO_MONT, raw_scalars(0x50543030 + vv, 0, vv))
+                q0, f0 = api.HyperKZG.open(params, ev, pt, np.zeros(4, dtype=np.uint64))
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    q1, f1 = api.HyperKZG.open(params, ev, pt, np.zeros(4, dtype=np.uint64))
+                res[f"v{vv}_ms"] = (time.perf_counter() - t0) / 3 * 1e3
+                assert np.array_equal(f0, f1) and all(np.array_equal(a[0], b[0]) for a, b in zip(q0, q1))
+            res["note"] = "host table in (pageable H2D included), proof out; parity with the oracle is tests/test_gpu_api_mirror.py"
+            extra["hyperkzg_open"] = res
+            params.deinit()
+        except Exception as exc:  # an extra: never take the headline line down with it
+            extra["hyperkzg_open"] = {"error": repr(exc)}
     # the metric's second size, 2^22 points on this one GPU (same code path, fresh process)
     try:
         import subprocess
