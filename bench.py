@@ -3,8 +3,10 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--logn 20]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    (without a launcher, `python bench.py --gpus N` starts its N ranks itself, before anything touches a GPU)
 
-A step = one 2^logn-point MSM over device-resident bases P_i = (i+1)·G (the reference bench's
+A step = one pass of the hot path over one batch of synthetic input: --msms-per-step (default 32) independent 2^logn-point MSMs
+(value = MSMs per second = steps x msms_per_step / time), each over device-resident bases P_i = (i+1)·G (the reference bench's
 point family, src/bench.zig:261-268) and device-resident uniform scalars (splitmix64, seed
 0x5A4F4C54; several scalar vectors rotate across steps). N > 1: the point/scalar arrays are
 sharded in ParallelMSM's contiguous chunks (src/msm/mod.zig:609), each rank computes its Jacobian
@@ -32,6 +34,7 @@ sys.path.insert(0, ROOT)
 # gathers 15.7M random 64-byte rows (1.01 GB) + 63 MB of sorted refs: FETCH_SIZE is taken uncorrected because
 # the gfx950 x2 under-count applies to wide streaming reads tallied as 128-byte requests, not to 64-byte rows.
 MEASURED_TRAFFIC = {20: (1412487.0 + 28524.7) * 1024.0}
+TRAFFIC_SOURCE = "rocprofv3 PMC FETCH_SIZE+WRITE_SIZE, profiles/r1l_rocprofv3_summary_streams1.txt"
 # static instruction mix of one lazy-limb XYZZ mixed add (hipcc --save-temps of the accumulate fast path): 1467
 # v_mad_u64_u32 + 146 v_lshl_add_u64 + 144 v_lshrrev_b64 + 81 v_mul_lo_u32 at 4 issue cycles per wave, 382 32-bit
 # add/and/shift/sub at 2 (tools/microbench.hip rates)
@@ -77,12 +80,83 @@ def closed_form_scalar(raw, start):
     return tot % R_MOD
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU, the env torch.distributed.run would
+    set, rendezvous on 127.0.0.1) and relay rank 0's output. Nothing in this parent process has touched a GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for pr in procs:
+        rc = max(rc, pr.wait())
+    return rc
+
+
+def single_process_mode(args):
+    """The reference's own process model: ONE process drives --single-process GPUs through the C ABI (zg_init_devices,
+    zg_g1_bases_upload_sharded, zg_msm_g1_sharded_dev: per-device Pippenger on worker threads, ONE ncclAllGather of 96 B per
+    device, combine on device 0). Prints one JSON object; called by the main bench as a child process."""
+    import torch
+    from zolt_amd import api, lib
+    nd = args.single_process
+    lib.init(0)
+    lib.init_devices(nd)
+    n = 1 << args.logn
+    g = api.generator()
+    ks = np.zeros((n, 4), dtype=np.uint64)
+    ks[:, 0] = np.arange(1, n + 1, dtype=np.uint64)
+    bases_xy, _ = lib.g1_scalar_mul_batch(np.repeat(g[None, :], n, axis=0), np.zeros(n, dtype=np.uint8), lib.field_op(lib.FR, lib.OP_TO_MONT, ks))
+    res = {"devices": nd, "points": n}
+    for mode in (["auto"] if nd > 1 else ["auto", "rccl"]):
+        if mode != "auto":
+            os.environ["ZG_SHARD_EXCHANGE"] = mode
+        sb = lib.ShardedBases.upload(bases_xy)
+        shards = sb.shards()
+        raw = raw_scalars(SEED, 0, n)
+        sm = lib.field_op(lib.FR, lib.OP_TO_MONT, raw)
+        parts = [torch.from_numpy(sm[s:s + l].view(np.int64).copy()).to(torch.device("cuda", d)) for d, s, l in shards]
+        ptrs = [t.data_ptr() for t in parts]
+        want = api.MSM.scalarMul(g, api.fr_from_int(closed_form_scalar(raw, 0)))
+        for _ in range(3):
+            got = sb.msm_dev(ptrs, n)
+        assert got[1] == want[1] and np.array_equal(got[0], want[0]), "sharded MSM result mismatch"
+        reps = 30
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            sb.msm_dev(ptrs, n)
+        el = (time.perf_counter() - t0) / reps
+        res[sb.exchange()] = {"ms_per_msm": el * 1e3, "msm_per_s": 1.0 / el, "shards": len(shards),
+                              "note": "synchronous calls (host result per MSM), scalars resident per device"}
+        h = sb.msm(sm)  # host-scalar entry point: per-device H2D of the shard on the worker threads
+        assert h[1] == want[1] and np.array_equal(h[0], want[0])
+        t0 = time.perf_counter()
+        for _ in range(5):
+            sb.msm(sm)
+        res[sb.exchange()]["host_scalars_ms_per_msm"] = (time.perf_counter() - t0) / 5 * 1e3
+        sb.free()
+    print(json.dumps(res))
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--logn", type=int, default=20)
+    ap.add_argument("--msms-per-step", type=int, default=32,
+                    help="independent MSMs (scalar vectors) per step; 20 steps x 32 MSMs keep the timed region near a second")
+    ap.add_argument("--single-process", type=int, default=0,
+                    help="internal: measure the one-process / several-GPU C ABI (zg_init_devices + zg_msm_g1_sharded_dev) on this many devices")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--window-bits", type=int, default=0)
@@ -91,6 +165,11 @@ def main():
                     help="independent MSMs are issued round-robin on this many HIP streams (1 = strictly serial)")
     args = ap.parse_args()
 
+    if args.single_process:
+        return single_process_mode(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)  # no launcher: become the launcher (nothing has touched a GPU yet)
+
     import torch
     import torch.distributed as dist
 
@@ -98,8 +177,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or without a launcher)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libzolt_gpu has no CPU fallback)")
     # one process per GPU; ZOLT_BENCH_DIST_BACKEND=gloo lets several ranks share one GPU to exercise the
@@ -139,8 +217,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_size(logn, steps, warmup):
-        """time `steps` MSMs of 2^logn points (sharded over the ranks), every result checked against the closed form"""
+    def run_size(logn, steps, warmup, per_step):
+        """time `steps` steps of `per_step` MSMs of 2^logn points (sharded over the ranks), every result checked against the closed form"""
         n = 1 << logn
         bounds = api.shard_bounds(n, world)
         start, end = bounds[rank]
@@ -167,26 +245,29 @@ def main():
 
         backend = api.GpuShardBackend(bases, n_loc)
         sharded = api.ShardedMSM(backend, world, rank)
-        d_res = torch.zeros((max(steps, warmup, 1), 9), dtype=torch.int64, device=dev)  # xy[8] + flag word
+        d_res = torch.zeros((max(steps, warmup, 1) * per_step, 9), dtype=torch.int64, device=dev)  # xy[8] + flag word
 
-        def step(i, slot):
-            sc = d_scalars[i % N_SCALAR_SETS]
-            if not use_dist:
-                st = tstreams[i % nstreams].cuda_stream
-                bases.msm_dev_async(sc.data_ptr(), n_loc, d_res[slot].data_ptr(), d_res[slot, 8:].data_ptr(), stream=st)
-                return None
-            with torch.cuda.stream(tstreams[i % nstreams]):
-                return sharded.compute(sc, out=d_res[slot])
+        def step(i):
+            """one step = per_step independent MSMs (scalar vectors rotate), issued round-robin on the work streams"""
+            for b in range(per_step):
+                j = i * per_step + b
+                sc = d_scalars[j % N_SCALAR_SETS]
+                if not use_dist:
+                    st = tstreams[j % nstreams].cuda_stream
+                    bases.msm_dev_async(sc.data_ptr(), n_loc, d_res[j].data_ptr(), d_res[j, 8:].data_ptr(), stream=st)
+                else:
+                    with torch.cuda.stream(tstreams[j % nstreams]):
+                        sharded.compute(sc, out=d_res[j])
 
         for i in range(warmup):
-            step(i, i)
+            step(i)
         barrier()
 
-        lib.profile_begin(8 * steps + 64)
+        lib.profile_begin(8 * 64 + 64)  # HIP-event brackets on the first 64 MSMs of the timed region (recording stops when they run out)
         barrier()
         t0 = time.perf_counter()
         for i in range(steps):
-            step(i, i)
+            step(i)
         barrier()
         elapsed = time.perf_counter() - t0
         prof = lib.profile_end()
@@ -213,14 +294,15 @@ def main():
             all_k = [sum(gk[s] for gk in gathered) % api.R_MOD for s in range(N_SCALAR_SETS)]
         want = [api.MSM.scalarMul(g, api.fr_from_int(k)) for k in all_k]
         res = d_res.cpu().numpy().view(np.uint64)
-        for i in range(steps):
-            wxy, winf = want[i % N_SCALAR_SETS]
-            assert int(res[i, 8] & 0xFF) == winf and np.array_equal(res[i, :8], wxy), f"MSM result mismatch at step {i}"
+        for j in range(steps * per_step):
+            wxy, winf = want[j % N_SCALAR_SETS]
+            assert int(res[j, 8] & 0xFF) == winf and np.array_equal(res[j, :8], wxy), f"MSM result mismatch at MSM {j}"
 
         return {"n": n, "n_loc": n_loc, "elapsed": elapsed, "prof": prof, "prof_alone": prof_alone, "setup_s": setup_s, "bases_xy": bases_xy,
                 "d_scalars": d_scalars, "want": want, "bases": bases}
 
-    m = run_size(args.logn, args.steps, args.warmup)
+    per_step = max(1, args.msms_per_step)
+    m = run_size(args.logn, args.steps, args.warmup, per_step)
     n, n_loc, elapsed, prof, setup_s = m["n"], m["n_loc"], m["elapsed"], m["prof"], m["setup_s"]
     prof_alone = m["prof_alone"]
     bases_xy, d_scalars, want, bases = m["bases_xy"], m["d_scalars"], m["want"], m["bases"]
@@ -232,8 +314,8 @@ def main():
     if world > 1 and not args.no_extra and args.logn != 22:
         del m
         bases.free()
-        m22 = run_size(22, 12, 3)
-        sharded_22 = {"value": 12 / m22["elapsed"], "unit": "MSM/s", "ms_per_step": m22["elapsed"] / 12 * 1e3,
+        m22 = run_size(22, 12, 3, 1)
+        sharded_22 = {"value": 12 / m22["elapsed"], "unit": "MSM/s", "ms_per_msm": m22["elapsed"] / 12 * 1e3,
                       "points": m22["n"], "points_per_gpu": m22["n_loc"], "n_gpus": world}
         m22["bases"].free()
         bases = None
@@ -243,45 +325,68 @@ def main():
     if use_dist and not args.no_extra and world & (world - 1) == 0:
         sharded_sc = sharded_sumcheck_measurement(lib, api, torch, dist, dev, stream, world, rank, dist_backend)
 
+    # the one-process / several-GPU C ABI on the same devices (extra, never the headline): rank 0 runs it as a child process while
+    # the other ranks wait on a HOST barrier (gloo), their GPUs idle and their tables freed
+    single_proc = None
+    if not args.no_extra and args.logn == 20:
+        if world > 1 and bases is not None:  # N = 1 keeps its handle for the extras below (288 GB: the child's table fits beside it)
+            bases.free()
+            bases = None
+        torch.cuda.empty_cache()
+        host_pg = dist.new_group(backend="gloo") if use_dist and world > 1 else None
+        if rank == 0:
+            single_proc = single_process_child(world)
+        if host_pg is not None:
+            dist.barrier(group=host_pg)
+
     if rank != 0:
         dist.destroy_process_group()
         return
 
     ms_per_step = elapsed / args.steps * 1e3
-    value = args.steps / elapsed
+    value = args.steps * per_step / elapsed
+    ms_per_msm = ms_per_step / per_step
+    # roofline of the dominant kernel from its duration running BY ITSELF (one stream, outside the timed region): this is the
+    # figure rocprofv3 --kernel-trace --stats reports for the serial run (profiles/r2*_kernel_stats_streams1.csv). Inside the timed
+    # region kernels of three streams share the GPU and a HIP-event bracket stretches beyond the per-MSM step time; that
+    # overlapped figure is kept beside it for transparency only.
     acc_ms, acc_cnt = prof["msm_accumulate"]
-    acc_avg_ms = acc_ms / max(acc_cnt, 1)
+    acc_overlapped_ms = acc_ms / max(acc_cnt, 1)
+    alone_ms = prof_alone["msm_accumulate"][0] / max(prof_alone["msm_accumulate"][1], 1)
     alg_bytes = 96.0 * n_loc  # 64 B affine point + 32 B scalar per point on this rank
-    achieved = alg_bytes / (acc_avg_ms * 1e-3) / 1e9 if acc_cnt else 0.0
+    achieved = alg_bytes / (alone_ms * 1e-3) / 1e9 if alone_ms else 0.0
     out = {
         "metric": "BN254 G1 MSM/sec", "value": value, "unit": "MSM/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-        "config": {"workload": f"msm_g1_2^{args.logn}", "points": n, "points_per_gpu": n_loc,
+        "config": {"workload": f"msm_g1_2^{args.logn}", "points": n, "points_per_gpu": n_loc, "msms_per_step": per_step,
+                   "ms_per_msm": ms_per_msm,
                    "arithmetic": "256-bit Montgomery field elements as 32-bit limbs (9x29-bit lazy limbs in the MSM), integer only",
                    "bases": "(i+1)*G resident in HBM (table of 2^(c*l)*P_i built once at upload, like an SRS)", "scalars": "uniform mod r, splitmix64 seed 0x5A4F4C54, resident in HBM",
                    "sharding": f"contiguous chunks + {dist_backend} all-gather of 96-byte Jacobian partials" if world > 1 else "single GPU",
                    "streams": nstreams,
-                   "bit_exact_check": "closed form (sum s_i*(i+1))*G via scalarMul kernel, every timed step"},
+                   "bit_exact_check": "closed form (sum s_i*(i+1))*G via scalarMul kernel, every timed MSM"},
         "roofline": {"bound": "hbm", "kernel": "msm_accumulate_chunk_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                      "traffic": MEASURED_TRAFFIC.get(args.logn) if world == 1 and args.window_bits == 0 and args.precompute == 0 else None,
-                     "traffic_source": "rocprofv3 PMC FETCH_SIZE+WRITE_SIZE, profiles/r1l_rocprofv3_summary_streams1.txt",
-                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": acc_avg_ms,
-                     "note": "MSM is integer-ALU-bound (10 Fp mul per mixed add x windows per point); see DESIGN.md"},
-        "extra": {"kernel_ms_per_msm": {k: (v[0] / max(v[1], 1)) for k, v in prof.items() if v[1]},
+                     "traffic_source": TRAFFIC_SOURCE,
+                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": alone_ms,
+                     "avg_launch_ms_source": "HIP events around the kernel, one stream in flight (6 serial MSMs right after the timed region)",
+                     "avg_launch_ms_overlapped": acc_overlapped_ms,
+                     "note": "MSM is integer-ALU-bound (Fp products per bucket addition x windows per point); see DESIGN.md"},
+        "extra": {"kernel_ms_per_msm_overlapped": {k: (v[0] / max(v[1], 1)) for k, v in prof.items() if v[1]},
                   "kernel_ms_per_msm_alone": {k: (v[0] / max(v[1], 1)) for k, v in prof_alone.items() if v[1]},
                   "setup_seconds": setup_s},
     }
+    assert alone_ms <= ms_per_msm * 1.5 or world > 1 or nstreams == 1, "kernel-alone duration inconsistent with the step time"
 
     # the ceiling that actually binds msm_accumulate: VALU issue. One mixed add compiles to MADD_ISSUE_CYCLES issue cycles
     # per wave (static instruction mix of the kernel's fast path); peak = 1024 SIMDs x 2.4 GHz.
     plan_c, plan_w, plan_l = m_plan
     adds = float(n_loc) * plan_w * (1.0 - 2.0 ** -plan_c)  # one table row per non-zero signed c-bit digit
-    alone_ms = prof_alone["msm_accumulate"][0] / max(prof_alone["msm_accumulate"][1], 1)
     issue = adds / 64.0 * MADD_ISSUE_CYCLES / (alone_ms * 1e-3) / 1e9 if alone_ms and args.logn >= 15 else None
     out["config"]["window_bits"], out["config"]["windows"], out["config"]["table_levels"] = plan_c, plan_w, plan_l
-    out["roofline"]["avg_launch_ms_alone"] = alone_ms
+    out["roofline"]["avg_launch_ms_alone"] = alone_ms  # same number as avg_launch_ms (kept under its round-1 name)
     out["roofline"]["valu_issue"] = {"achieved": issue, "peak": VALU_PEAK_GCYC, "unit": "G issue-cycles/s",
                                      "frac": issue / VALU_PEAK_GCYC if issue else None,
                                      "duration": "avg_launch_ms_alone (the kernel running by itself, outside the timed region)",
@@ -291,6 +396,8 @@ def main():
         "floor_ms": floor_ms, "frac": floor_ms / alone_ms if floor_ms and alone_ms else None,
         "model": "adds / (64 lanes x 1024 SIMDs) x least ns per wave-wide mixed add at the issue times measured by tools/microbench.hip "
                  "(profiles/r1_microbench_instruction_rates.txt); frac = floor / avg_launch_ms_alone"}
+    if single_proc is not None:
+        out["extra"]["single_process_c_abi"] = single_proc
     if sharded_sc is not None:
         out["extra"]["sumcheck_v20_sharded"] = sharded_sc
     if sharded_22 is not None:
@@ -310,6 +417,21 @@ def main():
     print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
+
+
+def single_process_child(n_devices):
+    import subprocess
+    try:
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                                 "ZG_SHARDS", "ZG_SHARD_EXCHANGE")}
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--single-process", str(n_devices), "--logn", "20"],
+                             capture_output=True, text=True, timeout=420, env=env)
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        if out.returncode != 0 or not lines:
+            return {"error": (out.stderr or out.stdout)[-600:], "returncode": out.returncode}
+        return json.loads(lines[-1])
+    except Exception as e:  # noqa: BLE001  (an extra: never take the headline line down with it)
+        return {"error": repr(e)}
 
 
 def sharded_sumcheck_measurement(lib, api, torch, dist, dev, stream, world, rank, dist_backend):
@@ -430,24 +552,24 @@ def extra_measurements(lib, api, torch, dev, stream, args, srs_xy=None):
     # the metric's second size, 2^22 points on this one GPU (same code path, fresh process)
     try:
         import subprocess
-        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--logn", "22", "--steps", "8", "--warmup", "2",
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--logn", "22", "--steps", "4", "--warmup", "1", "--msms-per-step", "4",
                               "--no-cpu-baseline", "--no-extra", "--streams", str(args.streams)],
                              capture_output=True, text=True, timeout=600)
         d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-        extra["msm_2^22_single_gpu"] = {"value": d["value"], "unit": "MSM/s", "ms_per_step": d["ms_per_step"],
-                                        "kernel_ms_per_msm": d["extra"]["kernel_ms_per_msm"], "roofline": d["roofline"]}
+        extra["msm_2^22_single_gpu"] = {"value": d["value"], "unit": "MSM/s", "ms_per_msm": d["config"]["ms_per_msm"],
+                                        "kernel_ms_per_msm_alone": d["extra"]["kernel_ms_per_msm_alone"], "roofline": d["roofline"]}
     except Exception as e:  # noqa: BLE001
         extra["msm_2^22_single_gpu"] = {"error": str(e)}
     # transparency: the same 2^20 MSM with NO table of precomputed multiples (precompute_levels = 1: classical
     # per-window bucket sets, window combine by doublings on the device) — what a one-shot caller would see
     try:
         import subprocess
-        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--logn", str(args.logn), "--steps", "10", "--warmup", "2",
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--logn", str(args.logn), "--steps", "4", "--warmup", "1", "--msms-per-step", "8",
                               "--precompute", "1", "--no-cpu-baseline", "--no-extra", "--streams", str(args.streams)],
                              capture_output=True, text=True, timeout=600)
         d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-        extra["msm_no_precompute"] = {"value": d["value"], "unit": "MSM/s", "ms_per_step": d["ms_per_step"],
-                                      "kernel_ms_per_msm": d["extra"]["kernel_ms_per_msm"]}
+        extra["msm_no_precompute"] = {"value": d["value"], "unit": "MSM/s", "ms_per_msm": d["config"]["ms_per_msm"],
+                                      "kernel_ms_per_msm_alone": d["extra"]["kernel_ms_per_msm_alone"]}
     except Exception as e:  # noqa: BLE001
         extra["msm_no_precompute"] = {"error": str(e)}
     # the same pipeline driven by a compiled host loop (tools/bench_sumcheck.cpp over zolt_host.hpp): what a
@@ -486,7 +608,22 @@ def cpu_baseline(bases_xy, scalars, want, logn):
         checked = True
     secs_full = el * (n / sample)
     ncores = os.cpu_count() or 1
-    res = {"value": 1.0 / secs_full, "unit": "MSM/s", "cores": 1, "kind": "port",
+    # the metric's other sizes (2^16 = config 1, 2^20, 2^22), same single thread, same point family: 2^16 in full
+    # (also the c = 8 branch: n >= 32768); 2^22 scaled from the largest size measured (cost is linear in n at fixed c = 8)
+    sizes = {}
+    n16 = min(n, 1 << 16)
+    t0 = time.perf_counter()
+    g16, i16 = ob.msm_g1(bases_xy[:n16], None, scalars[:n16])
+    el16 = time.perf_counter() - t0
+    sizes["2^16"] = {"value": 1.0 / (el16 * ((1 << 16) / n16)), "unit": "MSM/s", "seconds_per_msm": el16 * ((1 << 16) / n16),
+                     "sample": f"full {n16}-point MSM, single thread", "window_bits": ob.optimal_window_size(n16)}
+    sizes[f"2^{logn}"] = {"value": 1.0 / secs_full, "unit": "MSM/s", "seconds_per_msm": secs_full,
+                          "sample": f"{sample} of {n} points" if sample != n else "full MSM, result checked == GPU result"}
+    if logn < 22:
+        s22 = secs_full * ((1 << 22) / n)
+        sizes["2^22"] = {"value": 1.0 / s22, "unit": "MSM/s", "seconds_per_msm": s22,
+                         "sample": f"{sample} of {1 << 22} points, scaled linearly (c = 8 fixed for n >= 32768: 32 windows x n mixed adds)"}
+    res = {"value": 1.0 / secs_full, "unit": "MSM/s", "cores": 1, "kind": "port", "sizes": sizes,
            "sample": f"{sample} of {n} points, single thread, scaled linearly to 2^{logn} (c=8 fixed for n>=32768)"
                      if sample != n else f"full 2^{logn}-point MSM, single thread, result checked == GPU result",
            "seconds_per_msm": secs_full, "oracle_lib": os.path.basename(ob.LIB_PATH), "host_cores_available": ncores,

@@ -61,18 +61,19 @@ extern "C" {
 #define ZG_OP_SQR 4        /* :443-445 / :866-941 (b ignored) */
 #define ZG_OP_INV 5        /* :500-518 / :955-983; inverse(0) -> 0 (b ignored) */
 #define ZG_OP_FROM_MONT 6  /* :187-189 / :642-645 (b ignored) */
-#define ZG_OP_MUL29 9      /* Fp only: a*b through the MSM's 9x29-bit lazy representation (csrc/fp29.hip.h) */
-#define ZG_OP_SQR29 10     /* Fp only: a^2 through the lazy representation (b ignored) */
-#define ZG_OP_X3_29 11     /* Fp only: a*a - b - 2*b*b... see tests: exercises the biased lazy subtractions */
-#define ZG_OP_INV_FAST 8   /* same value as ZG_OP_INV via Kaliski's almost-inverse (kept for cross-checking) */
-#define ZG_OP_INV_XGCD 12   /* same value via plain binary extended Euclid (kept for cross-checking) */
-#define ZG_OP_INV_SAFEGCD 13 /* same value via batched Bernstein-Yang division steps (the device's toAffine path) */
 #define ZG_OP_TO_MONT 7    /* fromBytes' reduction :171-184 / :625-639: raw 256-bit LE -> Montgomery (b ignored) */
+/* op codes 9..13 are self-test hooks for the device arithmetic: include/zolt_gpu_internal.h */
 
 /* ------------------------------------------------------------------ lifecycle */
 /* Binds the calling process to one GPU (device < 0: keep the current HIP device) and
  * creates the library stream. Idempotent. */
 ZG_API int zg_init(int device);
+/* ONE process driving several GPUs — the reference's own process model: `zolt prove` is a single process (src/main.zig:271-696)
+ * and ParallelMSM.compute runs threads inside it (src/msm/mod.zig:588-653). Binds devices 0..n_devices-1 (n_devices <= 0: every
+ * visible device); device 0 stays the primary for the single-device entry points. May follow zg_init(0) / zg_init(-1) on
+ * device 0. The sharded entry points below ("several GPUs in one process") then spread their work over the bound devices. */
+ZG_API int zg_init_devices(int n_devices);
+ZG_API int zg_n_devices(void); /* devices bound: 1 after zg_init, n after zg_init_devices(n), 0 before either */
 ZG_API void zg_shutdown(void);
 ZG_API const char *zg_last_error(void);
 ZG_API const char *zg_version(void);
@@ -85,37 +86,26 @@ ZG_API int zg_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
 ZG_API int zg_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
 ZG_API int zg_sync(void);
 
-/* ------------------------------------------------------------------ profiling */
-/* Per-kernel timing with HIP events recorded on the stream each kernel is launched on
- * (bench.py's roofline figure). zg_profile_begin enables recording of up to max_records
- * kernel intervals; zg_profile_end synchronises, adds the elapsed times up per kernel id
- * (milliseconds, launch counts) and disables recording. Not thread-safe; bench use only. */
-#define ZG_PROF_MSM_DIGITS 0
-#define ZG_PROF_MSM_SORT 1       /* scan + scatter */
-#define ZG_PROF_MSM_ACCUMULATE 2 /* bucket accumulation: the dominant MSM kernel */
-#define ZG_PROF_MSM_REDUCE 3     /* bucket reduction levels + final */
-#define ZG_PROF_EQ_TABLE 4
-#define ZG_PROF_SC_FOLD 5        /* fold + fused next-round sums */
-#define ZG_PROF_SC_SUMS 6
-#define ZG_PROF_COMBINE 7        /* Spartan combine */
-#define ZG_PROF_NKERNELS 8
-ZG_API int zg_profile_begin(int max_records);
-ZG_API int zg_profile_end(double ms_out[ZG_PROF_NKERNELS], uint64_t count_out[ZG_PROF_NKERNELS]);
-
 /* ------------------------------------------------------------------ field vectors */
 /* out[i] = op(a[i], b[i]) over n elements; host pointers. Replaces the scalar loops of
  * field.BatchOps (src/field/mod.zig:1164-1280) and backs the device-arithmetic unit tests. */
 ZG_API int zg_field_op(int field, int op, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
+
+/* DensePolynomial.scale (src/poly/mod.zig:112-126): out[i] = a[i] * s. (DensePolynomial.add, :94-110, is zg_field_op ZG_OP_ADD.) */
+ZG_API int zg_fr_scale(const uint64_t *a, size_t n, const uint64_t s[4], uint64_t *out);
 
 /* ------------------------------------------------------------------ G1 bases (SRS) */
 typedef struct zg_bases_s *zg_bases_t;
 
 /* MSM tuning. window_bits 0 = auto from n; precompute_levels: 1 = none, 0 = auto,
  * k>1 = store 2^(c*G*l)*P for l<k at upload so k windows share one bucket set
- * (HBM cost k*64 B per base). Results do not depend on these. */
+ * (HBM cost k*64 B per base). expected_uses: how many MSMs the handle is expected to serve — 0 = many (an SRS that lives for
+ * the whole run: the full table, 64*W bytes per base and a one-time build, pays back after ~20 MSMs); 1..15 = an ad-hoc
+ * bases slice (MSM.compute on a temporary): auto picks precompute_levels = 1, no table build. Results do not depend on these. */
 typedef struct {
     int window_bits;
     int precompute_levels;
+    int expected_uses;
 } zg_msm_config;
 
 /* Upload n affine bases once and keep them resident in HBM for any number of MSMs —
@@ -173,6 +163,11 @@ ZG_API int zg_g1_combine_partials_dev_async(const uint64_t *d_partials_jac /* k*
 /* AffinePoint.isOnCurve (src/msm/mod.zig:106-115) for n points: out[i] = 1 iff infinity or y^2 == x^3 + 3
  * (what parseG1Uncompressed checks per SRS point, src/poly/commitment/srs.zig:93-96). */
 ZG_API int zg_g1_is_on_curve_batch(const uint64_t *xy, const uint8_t *inf, size_t n, uint8_t *out);
+/* AffinePoint.add for n independent pairs (src/msm/mod.zig:74-103): the lambda formulas with one field inversion per pair,
+ * x1 == x2 resolved as the reference does (:79-88: y1 == -y2 -> identity, y1 == y2 -> double, :118-138); identity operands pass
+ * the other point through. AffinePoint.double(p) = add(p, p). Flags may be NULL (no identity inputs / flags not wanted). */
+ZG_API int zg_g1_affine_add_batch(const uint64_t *a_xy, const uint8_t *a_inf, const uint64_t *b_xy, const uint8_t *b_inf, size_t n,
+                           uint64_t *out_xy, uint8_t *out_inf);
 /* MSM(F,G).scalarMul(base, scalar).toAffine() for n independent (base, scalar) pairs
  * (src/msm/mod.zig:503-540) — the primitive of HyperKZG.setup (commitment/mod.zig:194-199). */
 ZG_API int zg_g1_scalar_mul_batch(const uint64_t *xy, const uint8_t *inf, const uint64_t *scalars_mont, size_t n,
@@ -259,6 +254,47 @@ ZG_API int zg_run_sumcheck_dev(const uint64_t *d_evals, size_t len, void *stream
                                uint64_t *challenges, uint64_t final_eval[4], uint8_t *result);
 ZG_API int zg_run_sumcheck(const uint64_t *evals, size_t len, uint64_t claim[4], uint64_t *rounds, uint64_t *challenges,
                            uint64_t final_eval[4], uint8_t *result);
+
+/* ------------------------------------------------------------------ several GPUs in one process */
+/* The bases (SRS) sharded over the bound devices in ParallelMSM's contiguous chunks of ceil(n / S) points
+ * (src/msm/mod.zig:609,619-639), one resident table per device. */
+typedef struct zg_sbases_s *zg_sbases_t;
+/* the partition itself — chunk `shard` of `shards` over n points: start = min(shard * ceil(n / shards), n), end = min(start +
+ * ceil(n / shards), n) (src/msm/mod.zig:609,619-621). Pure host arithmetic, needs no device. */
+ZG_API int zg_shard_bounds(size_t n, int shards, int shard, size_t *start, size_t *len);
+ZG_API int zg_g1_bases_upload_sharded(const uint64_t *xy, const uint8_t *inf, size_t n, const zg_msm_config *cfg, zg_sbases_t *out);
+ZG_API int zg_g1_sbases_free(zg_sbases_t sb);
+ZG_API size_t zg_g1_sbases_len(zg_sbases_t sb);
+ZG_API int zg_g1_sbases_shards(zg_sbases_t sb);   /* number of shards S */
+ZG_API int zg_g1_sbases_exchange(zg_sbases_t sb); /* how partials meet: 0 = single shard, 1 = RCCL all-gather, 2 = peer copies */
+ZG_API int zg_g1_sbases_shard(zg_sbases_t sb, int shard, int *device, size_t *start, size_t *len);
+/* ParallelMSM.compute(bases[0..n), scalars) (src/msm/mod.zig:588-653) over the devices: every device runs the Pippenger pipeline
+ * on its chunk (one host worker thread per device issues its launches), the S Jacobian partials (96 B each, un-normalised) are
+ * exchanged with ONE ncclAllGather over xGMI (RCCL has no user-defined reduction for group elements) and device 0 performs the
+ * serial combine + the single toAffine (:647-652). Result bytes equal zg_msm_g1's. Scalars: n x 4 limbs on the host. */
+ZG_API int zg_msm_g1_sharded(zg_sbases_t sb, size_t n, const uint64_t *scalars_mont, uint64_t out_xy[8], uint8_t *out_inf);
+/* same with the scalars resident: d_scalars_per_shard[i] points into device memory of shard i's device and holds the scalars of
+ * that shard's chunk (zg_g1_sbases_shard tells which) */
+ZG_API int zg_msm_g1_sharded_dev(zg_sbases_t sb, size_t n, const uint64_t *const *d_scalars_per_shard, uint64_t out_xy[8],
+                          uint8_t *out_inf);
+/* ParallelBatchMSM.compute / HyperKZG.batchCommit (src/msm/mod.zig:683-748, src/poly/commitment/mod.zig:558-570) sharded: k scalar
+ * vectors over bases[0..n) -> k partials per device, ONE all-gather of k x 96 B per device, k combines. */
+ZG_API int zg_msm_g1_batch_sharded(zg_sbases_t sb, size_t n, const uint64_t *const *scalar_batches, size_t k, uint64_t *out_xy /* k*8 */,
+                            uint8_t *out_inf /* k */);
+
+/* Sumcheck(F).Prover over a table sharded across the bound devices (S = the largest power of two <= devices and <= len):
+ * LOW_PAIR tables by contiguous chunks, HIGH_HALF tables by residue class i mod S, so that every fold of the first
+ * log2(len / S) rounds is local to a device; a round's sums are the modular sum of the per-device pairs (64 B per device, read
+ * from each session's pinned mailbox); the last log2(S) rounds run on the S gathered residuals on device 0. Same messages as
+ * the single-device session, bit for bit. */
+typedef struct zg_ssc_s *zg_ssc_t;
+ZG_API int zg_sumcheck_open_sharded(const uint64_t *evals, size_t len, int layout, zg_ssc_t *s);
+ZG_API int zg_sumcheck_shards(zg_ssc_t s);
+ZG_API size_t zg_sumcheck_len_sharded(zg_ssc_t s);
+ZG_API int zg_sumcheck_round_sums_sharded(zg_ssc_t s, uint64_t g0[4], uint64_t g1[4]);
+ZG_API int zg_sumcheck_bind_sharded(zg_ssc_t s, const uint64_t r[4]);
+ZG_API int zg_sumcheck_final_sharded(zg_ssc_t s, uint64_t out[4]);
+ZG_API int zg_sumcheck_close_sharded(zg_ssc_t s);
 
 #ifdef __cplusplus
 }

@@ -269,6 +269,22 @@ def fr_eq_table(r, scale=None):
     return out
 
 
+def fr_eq_mle(r, x):
+    """EqPolynomial.mle / evaluate (src/poly/mod.zig:214-227,311-321)"""
+    r, x = _c(r), _c(x)
+    out = np.empty(4, dtype=np.uint64)
+    lib.zo_fr_eq_mle(_p(r), _p(x), C.c_size_t(r.size // 4), _p(out))
+    return out
+
+
+def fr_poly_scale(a, s):
+    """DensePolynomial.scale (src/poly/mod.zig:112-126)"""
+    a = _c(a)
+    out = np.empty_like(a)
+    lib.zo_fr_poly_scale(_p(a), C.c_size_t(a.size // 4), _p(_c(s)), _p(out))
+    return out
+
+
 def fr_eq_table_append_lsb(tau):
     tau = _c(tau)
     v = tau.size // 4

@@ -741,6 +741,28 @@ EXPORT void zo_fr_eq_table(const uint64_t *r, size_t v, const uint64_t *scale, u
         size *= 2;
     }
 }
+/* EqPolynomial.mle / EqPolynomial.evaluate — src/poly/mod.zig:311-321 (and :214-227, the same product):
+ * prod_i (r_i*x_i + (1-r_i)*(1-x_i)) */
+EXPORT void zo_fr_eq_mle(const uint64_t *r, const uint64_t *x, size_t v, uint64_t out[4]) {
+    fe one = f_one(&FR), result = one;
+    for (size_t i = 0; i < v; i++) {
+        const fe *ri = (const fe *)(r + 4 * i), *xi = (const fe *)(x + 4 * i);
+        fe ri_xi = f_mul(&FR, ri, xi);
+        fe one_minus_ri = f_sub(&FR, &one, ri), one_minus_xi = f_sub(&FR, &one, xi);
+        fe prod = f_mul(&FR, &one_minus_ri, &one_minus_xi);
+        fe term = f_add(&FR, &ri_xi, &prod);
+        result = f_mul(&FR, &result, &term);
+    }
+    memcpy(out, &result, 32);
+}
+/* DensePolynomial.add / scale — src/poly/mod.zig:94-126 */
+EXPORT void zo_fr_poly_scale(const uint64_t *a, size_t n, const uint64_t s[4], uint64_t *out) {
+    const fe *sv = (const fe *)s;
+    for (size_t i = 0; i < n; i++) {
+        fe v = f_mul(&FR, (const fe *)(a + 4 * i), sv);
+        memcpy(out + 4 * i, &v, 32);
+    }
+}
 /* GruenSplitEqPolynomial prefix-table step ("append LSB") — src/poly/split_eq.zig:122-147:
  * next[2i] = prev[i]*(1-tau_k), next[2i+1] = prev[i]*tau_k; full table for tau[0..v) */
 EXPORT void zo_fr_eq_table_append_lsb(const uint64_t *tau, size_t v, uint64_t *out) {

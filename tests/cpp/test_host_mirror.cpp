@@ -177,6 +177,53 @@ TEST(sumcheck_complete_protocol) {
     }
 }
 
+// src/poly/commitment/mod.zig:1240-1258 "generator affine double == jacobian double"; AffinePoint.add (src/msm/mod.zig:74-103):
+// P + P takes the doubling branch, P + (-P) is the identity, identity operands pass the other point through
+TEST(affine_point_add_and_double) {
+    AffinePoint g = AffinePoint::generator();
+    AffinePoint two = MSM::scalarMul(g, Fr::fromU64(2)), three = MSM::scalarMul(g, Fr::fromU64(3));
+    EXPECT(g.dbl().eql(two));
+    EXPECT(g.add(g).eql(two));
+    EXPECT(g.add(two).eql(three) && two.add(g).eql(three));
+    AffinePoint neg = MSM::scalarMul(g, Fr::zero().sub(Fr::one()));  // (r - 1) G = -G
+    EXPECT(g.add(neg).isIdentity());
+    EXPECT(g.add(AffinePoint::identity()).eql(g) && AffinePoint::identity().add(g).eql(g));
+    EXPECT(AffinePoint::identity().dbl().isIdentity());
+}
+
+// src/poly/mod.zig:94-126 DensePolynomial.add / scale; :214-227,311-321 EqPolynomial.evaluate / mle
+TEST(dense_polynomial_add_scale_and_eq_mle) {
+    DensePolynomial a({Fr::fromU64(1), Fr::fromU64(2), Fr::fromU64(3), Fr::fromU64(4)});
+    DensePolynomial b({Fr::fromU64(10), Fr::fromU64(20), Fr::fromU64(30), Fr::fromU64(40)});
+    auto s = a.add(b);
+    auto t = a.scale(Fr::fromU64(7));
+    for (int i = 0; i < 4; i++) {
+        EXPECT(s.evaluations[i].eql(Fr::fromU64(11 * (i + 1))));
+        EXPECT(t.evaluations[i].eql(Fr::fromU64(7 * (i + 1))));
+    }
+    std::vector<Fr> r = {Fr::fromU64(12345), Fr::fromU64(67890), Fr::fromU64(0x123456789abcdefULL)};
+    auto ev = EqPolynomial(r).evals();
+    for (int idx = 0; idx < 8; idx++) {  // mle at a boolean point = the table entry (index MSB <-> r[0])
+        std::vector<Fr> x = {Fr::fromU64((idx >> 2) & 1), Fr::fromU64((idx >> 1) & 1), Fr::fromU64(idx & 1)};
+        EXPECT(EqPolynomial::mle(r, x).eql(ev[idx]));
+        EXPECT(EqPolynomial(r).evaluate(x).eql(ev[idx]));
+    }
+    EXPECT(EqPolynomial::mle({}, {}).eql(Fr::one()));
+}
+
+// src/msm/mod.zig:949-966 "parallel msm" through the several-GPU entry points (one shard per bound device); :683-748 batch form
+TEST(parallel_msm_equals_msm) {
+    auto pts = generator_multiples(64);
+    std::vector<Fr> sc;
+    for (size_t i = 0; i < 64; i++) sc.push_back(Fr::fromU64(1000003 * i + 17));
+    EXPECT(ParallelMSM::compute(pts, sc, 8).eql(MSM::compute(pts, sc)));
+    std::vector<std::vector<Fr>> batches(3, sc);
+    batches[1][5] = Fr::fromU64(99);
+    auto out = ParallelBatchMSM::compute(pts, batches);
+    EXPECT(out.size() == 3);
+    for (size_t j = 0; j < 3; j++) EXPECT(out[j].eql(MSM::compute(pts, batches[j])));
+}
+
 int main() {
     if (zg_init(0) != ZG_OK) { std::printf("zg_init failed: %s\n", zg_last_error()); return 2; }
     for (auto &t : tests()) {

@@ -11,22 +11,27 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    hdr = open(os.path.join(ROOT, "include", "zolt_gpu.h")).read()
+def _declared_symbols(header="zolt_gpu.h"):
+    hdr = open(os.path.join(ROOT, "include", header)).read()
     return sorted(set(re.findall(r"ZG_API[^;(]*?\b(zg_\w+)\s*\(", hdr)))
 
 
 def test_header_symbols_all_exported():
     from zolt_amd import lib
     declared = _declared_symbols()
-    assert len(declared) >= 36
+    internal = _declared_symbols("zolt_gpu_internal.h")
+    assert len(declared) >= 70 and internal == ["zg_profile_begin", "zg_profile_end"]
     nm = subprocess.check_output(["nm", "-D", "--defined-only", lib.LIB_PATH], text=True)
     exported = set(re.findall(r" T (zg_\w+)", nm))
-    missing = [s for s in declared if s not in exported]
-    assert not missing, missing
-    assert sorted(lib.SYMBOLS) == declared  # the Python binding covers the whole header
+    assert exported == set(declared) | set(internal)  # the library exports exactly the two headers, nothing more, nothing less
+    assert sorted(lib.SYMBOLS) == declared  # the Python binding covers the whole public header
+    assert sorted(lib.INTERNAL_SYMBOLS) == internal
     # nothing else leaks out of the library
     assert all(s.startswith("zg_") for s in re.findall(r" T (\w+)", nm) if not s.startswith("_"))
+    # the public header carries no test / bench scaffolding (self-test op codes and the profiler live in the internal one)
+    pub = open(os.path.join(ROOT, "include", "zolt_gpu.h")).read()
+    for name in ("zg_profile", "ZG_OP_MUL29", "ZG_OP_X3_29", "ZG_OP_INV_XGCD", "ZG_OP_INV_SAFEGCD", "ZG_PROF_"):
+        assert name not in pub, name
 
 
 def _split_params(arglist):
@@ -37,32 +42,60 @@ def _split_params(arglist):
     return [a.strip() for a in arglist.split(",")]
 
 
-def test_zig_extern_declarations_match_the_header():
-    """zig/gpu/ffi.zig cannot be compiled here (no Zig toolchain), so at least its extern list is held against include/zolt_gpu.h:
-    every declared function exists in the header with the same number of parameters, pointer parameters are pointers on both
-    sides, and the constants it copies (error codes, sumcheck layouts) have the header's values."""
-    hdr = open(os.path.join(ROOT, "include", "zolt_gpu.h")).read()
+def test_zig_ffi_is_generated_from_the_header():
+    """zig/gpu/ffi.zig cannot be compiled here (no Zig toolchain): it is GENERATED from include/zolt_gpu.h by tools/gen_zig_ffi.py,
+    and this test re-runs the generator, so the file can neither go stale nor miss an export. Every public export must have an
+    extern with the same number of parameters, pointers where the header has pointers, and the header's constants."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_zig_ffi
     zig = open(os.path.join(ROOT, "zig", "gpu", "ffi.zig")).read()
+    assert zig == gen_zig_ffi.generate(), "zig/gpu/ffi.zig is stale: run python tools/gen_zig_ffi.py"
+    hdr = open(os.path.join(ROOT, "include", "zolt_gpu.h")).read()
     protos = {m.group(1): _split_params(m.group(2)) for m in re.finditer(r"ZG_API[^;(]*?\b(zg_\w+)\s*\(([^;]*?)\)\s*;", hdr, flags=re.S)}
-    externs = re.findall(r"pub extern fn (zg_\w+)\((.*?)\) [\w\[\]:*?. ]+;", zig)
-    assert len(externs) >= 25
-    for name, args in externs:
-        assert name in protos, name
+    externs = dict(re.findall(r"pub extern fn (zg_\w+)\((.*?)\) [\w\[\]:*?. ]+;", zig))
+    assert sorted(externs) == sorted(protos) == _declared_symbols()  # EVERY export, no extras
+    for name, args in externs.items():
         zargs, cargs = _split_params(args), protos[name]
         assert len(zargs) == len(cargs), (name, zargs, cargs)
         for za, ca in zip(zargs, cargs):
-            c_ptr = "*" in ca or "[" in ca or "zg_bases_t" in ca or "zg_sc_t" in ca
-            z_ptr = "*" in za or "Bases" in za or "Session" in za
+            c_ptr = "*" in ca or "[" in ca or any(h in ca for h in ("zg_bases_t", "zg_sc_t", "zg_sbases_t", "zg_ssc_t"))
+            z_ptr = "*" in za or any(h in za for h in ("Bases", "Session"))
             assert c_ptr == z_ptr, (name, za, ca)
-    for zname, cname in (("ERR_VERIFY", "ZG_ERR_VERIFY"), ("SC_HIGH_HALF", "ZG_SC_HIGH_HALF"), ("SC_LOW_PAIR", "ZG_SC_LOW_PAIR"), ("OK", "ZG_OK")):
-        zv = int(re.search(r"pub const %s: c_int = (\d+);" % zname, zig).group(1))
-        cv = int(re.search(r"#define %s (\d+)" % cname, hdr).group(1))
-        assert zv == cv, (zname, zv, cv)
+    for cname, cval in re.findall(r"#define (ZG_(?:OK|ERR_\w+|SC_\w+|FIELD_\w+)) (\d+)", hdr):
+        assert re.search(r"pub const %s: c_int = %s;" % (cname[3:], cval), zig), cname
+    assert "expected_uses" in zig  # zg_msm_config's third field
+
+
+def test_zig_backend_rules_out_the_stale_table_and_wrong_field_hazards():
+    """zig/gpu/backend.zig (compile-unverified) is at least held to the three rules INTEGRATION.md states: a comptime type gate in
+    front of every MSM path (the reference instantiates MSM(Fr, Fr), src/msm/mod.zig:853-873,911-936), no (ptr, len)-keyed
+    handle cache (stale tables / use-after-evict), and one-shot uploads for ad-hoc slices that are freed before returning.
+    Every ffi symbol it uses must exist in the generated ffi.zig."""
+    be = open(os.path.join(ROOT, "zig", "gpu", "backend.zig")).read()
+    code = "\n".join(l for l in be.splitlines() if not l.lstrip().startswith("//"))
+    zig = open(os.path.join(ROOT, "zig", "gpu", "ffi.zig")).read()
+    externs = set(re.findall(r"pub extern fn (zg_\w+)\(", zig))
+    used = set(re.findall(r"ffi\.(zg_\w+)\(", code))
+    assert used and used <= externs, used - externs
+    for wrapper in ("zg_g1_scalar_mul_batch", "zg_hyperkzg_open", "zg_hyperkzg_batch_open", "zg_msm_g1_sharded", "zg_msm_g1_batch_sharded",
+                    "zg_sumcheck_open_sharded", "zg_init_devices"):
+        assert wrapper in used, wrapper  # setup / open / batchOpen / the multi-GPU entry points all have a wrapper now
+    # rule 1: both one-shot MSM entry points start with the comptime gate
+    for fn in ("msmComputeOneShot", "parallelMsmOneShot"):
+        body = code[code.index("pub fn " + fn):]
+        body = body[:body.index("\npub fn ", 10)] if "\npub fn " in body[10:] else body
+        assert "if (comptime !isBn254Pair(F, G)) return null;" in body, fn
+    assert "0xac96341c4ffffffb" in code and "0xd35d438dc58f0d9d" in code  # Fr / Fp Montgomery R: what the gate compares
+    # rule 2: no address-keyed cache anywhere
+    assert "@intFromPtr" not in code and "CacheEntry" not in code and "cache" not in code.lower()
+    # rule 3: the one-shot handle is freed in the function that created it, and it skips the precompute table
+    body = code[code.index("pub fn msmComputeOneShot"):code.index("pub fn parallelMsmOneShot")]
+    assert "defer _ = ffi.zg_g1_bases_free(h);" in body and ".expected_uses = 1" in body
 
 
 def test_header_compiles_as_c_and_cpp(tmp_path):
     src = tmp_path / "t.c"
-    src.write_text('#include "zolt_gpu.h"\nint main(void){ zg_msm_config c = {0,0}; (void)c; return ZG_OK; }\n')
+    src.write_text('#include "zolt_gpu.h"\nint main(void){ zg_msm_config c = {0,0,0}; (void)c; return ZG_OK; }\n')
     inc = os.path.join(ROOT, "include")
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", inc, "-c", str(src), "-o", str(tmp_path / "t.o")])
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-x", "c++", "-I", inc, "-c", str(src), "-o", str(tmp_path / "t2.o")])
@@ -154,3 +187,51 @@ def test_parse_zolt_proof_commitments(golden_dir):
     assert c["bytecode.read_ts_commitment"] == bytes(64)
     with pytest.raises(ValueError):
         api.parse_zolt_proof_commitments(b"JOLT" + data[4:])
+
+
+def test_shard_bounds_is_parallel_msm_partition():
+    """zg_shard_bounds (host arithmetic, no device) = ParallelMSM's chunks (src/msm/mod.zig:609,619-621): chunk_size =
+    ceil(n / T), start = i * chunk_size, end = min(start + chunk_size, n), empty chunk when start >= n. The chunks tile [0, n)
+    in shard order — the order in which the gathered partials are combined — and agree with api.shard_bounds (the
+    one-process-per-GPU path)."""
+    from zolt_amd import api, lib
+    for n in (0, 1, 7, 8, 1000, 1024, (1 << 20) + 1, 1 << 22):
+        for shards in (1, 2, 3, 4, 7, 8, 16):
+            chunk = (n + shards - 1) // shards
+            pos = 0
+            for i in range(shards):
+                st, ln = lib.shard_bounds(n, shards, i)
+                ref_start = i * chunk
+                want = (min(ref_start, n), 0) if ref_start >= n else (ref_start, min(ref_start + chunk, n) - ref_start)
+                assert (st, ln) == want, (n, shards, i)
+                assert st == pos or ln == 0
+                pos += ln
+            assert pos == n
+            assert [(a, b - a) for a, b in api.shard_bounds(n, shards)] == [lib.shard_bounds(n, shards, i) for i in range(shards)]
+    with pytest.raises(lib.ZgError):
+        lib.shard_bounds(10, 0, 0)
+    with pytest.raises(lib.ZgError):
+        lib.shard_bounds(10, 4, 4)
+
+
+def test_eq_mle_host_mirror_matches_oracle_and_bigint():
+    """EqPolynomial.mle / evaluate (src/poly/mod.zig:214-227,311-321) is host scalar code in the reference and in the mirror
+    (zolt_amd/api.py): checked here, without a GPU, against the C oracle and the big-int model."""
+    from oracle import binding as ob
+    from oracle import pymodel as pm
+    from tests import util as U
+    from zolt_amd import api
+    for v in (0, 1, 3, 13):
+        r = ob.f_to_mont(ob.FR, U.random_raw256(70 + v, v))
+        x = ob.f_to_mont(ob.FR, U.random_raw256(80 + v, v))
+        want = ob.fr_eq_mle(r, x)
+        assert np.array_equal(api.EqPolynomial.mle(r, x), want)
+        assert np.array_equal(api.EqPolynomial(r).evaluate(x), want)
+        acc = 1
+        for a, b in zip([U.fr_to_int(t) for t in r], [U.fr_to_int(t) for t in x]):
+            acc = acc * ((a * b + (1 - a) * (1 - b)) % pm.R_MOD) % pm.R_MOD
+        assert U.fr_to_int(want) == acc
+    r = ob.f_to_mont(ob.FR, U.random_raw256(90, 4))
+    tab = ob.fr_eq_table(r)
+    for idx in range(16):  # at a boolean point mle is the table entry, index MSB <-> r[0]
+        assert np.array_equal(api.EqPolynomial.mle(r, U.fr([(idx >> (3 - j)) & 1 for j in range(4)])), tab[idx])

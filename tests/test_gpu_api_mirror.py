@@ -139,6 +139,43 @@ def test_hyperkzg_open_long_levels(env, v, srs_n, fuse, monkeypatch):
     params.deinit()
 
 
+def test_hyperkzg_open_at_the_bench_size(env):
+    """open() of 2^20 evaluations on a 2^20-point SRS — the size bench.py times — quotient by quotient against the oracle
+    (the CPU side is ~2^20 points of Pippenger: tens of seconds)."""
+    api, lib, ob = env
+    v = 20
+    gm = ob.g1_gen_multiples(1 << v)
+    inf = np.zeros(1 << v, dtype=np.uint8)
+    params = api.HyperKZG.SetupParams(gm, inf)
+    ev = _rand(ob, 820, 1 << v)
+    pt = _rand(ob, 821, v)
+    quotients, final = api.HyperKZG.open(params, ev, pt, np.zeros(4, dtype=np.uint64))
+    wq, wqi, wfin = ob.hyperkzg_open(gm, inf, ev, pt, np.zeros(4, dtype=np.uint64))
+    assert np.array_equal(final, wfin) and len(quotients) == v
+    for i, (q, qi) in enumerate(quotients):
+        assert qi == wqi[i] and np.array_equal(q, wq[i]), i
+    params.deinit()
+
+
+def test_hyperkzg_batch_open_2_16(env):
+    """batchOpen of three 2^16-entry polynomials (one shorter) on a 2^16-point SRS against the oracle."""
+    api, lib, ob = env
+    v = 16
+    gm = ob.g1_gen_multiples(1 << v)
+    inf = np.zeros(1 << v, dtype=np.uint8)
+    params = api.HyperKZG.SetupParams(gm, inf)
+    polys = [_rand(ob, 830, 1 << v), _rand(ob, 831, 1 << v), _rand(ob, 832, 40000)]
+    point = _rand(ob, 833, v)
+    got = api.HyperKZG.batchOpen(params, polys, point)
+    wq, wqi, wev, wfin, wgam = ob.hyperkzg_batch_open(gm, inf, polys, point)
+    assert len(got["quotient_commitments"]) == wq.shape[0] == v
+    for i, (q, qi) in enumerate(got["quotient_commitments"]):
+        assert qi == wqi[i] and np.array_equal(q, wq[i]), i
+    assert np.array_equal(got["evaluations"], wev) and np.array_equal(got["final_eval"], wfin)
+    assert np.array_equal(got["batching_challenge"], wgam)
+    params.deinit()
+
+
 def _ptau(sections):
     out = b"ptau" + (1).to_bytes(4, "little") + len(sections).to_bytes(4, "little")
     for typ, payload in sections:

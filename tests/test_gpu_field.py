@@ -48,14 +48,13 @@ def test_field_ops_match_oracle(zl, field):
     k = 4096
     assert np.array_equal(zl.field_op(field, zl.OP_INV, a[:k]), ob.f_inv(field, a[:k]))
     k = 1 << 16  # binary-Euclid inversion used by the device toAffine
-    assert np.array_equal(zl.field_op(field, zl.OP_INV_FAST, a[:k]), ob.f_inv(field, a[:k]))
     assert np.array_equal(zl.field_op(field, zl.OP_INV_XGCD, a[:k]), ob.f_inv(field, a[:k]))
     assert np.array_equal(zl.field_op(field, zl.OP_INV_SAFEGCD, a[:k]), ob.f_inv(field, a[:k]))
 
 
 @pytest.mark.parametrize("field", [0, 1])
 def test_inversion_variants_on_structured_values(zl, field):
-    """The three device inversions (Kaliski almost-inverse, binary Euclid, batched division steps — the last is what toAffine
+    """The three device inversions (Fermat, binary Euclid, batched division steps — the last is what toAffine
     uses) against the oracle's Fermat inverse on values that stress their control flow: 0 (-> 0, src/field/mod.zig:500-503),
     small integers, powers of two and their neighbours (long runs of trailing zeros), modulus - small, all-ones limbs, and
     the Montgomery images of the same."""
@@ -69,7 +68,7 @@ def test_inversion_variants_on_structured_values(zl, field):
     raw = np.array([[(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)] for v in vals], dtype=np.uint64)
     for a in (raw, ob.f_to_mont(field, raw)):   # every 256-bit pattern below the modulus is a valid Montgomery value
         want = ob.f_inv(field, a)
-        for op in (zl.OP_INV, zl.OP_INV_FAST, zl.OP_INV_XGCD, zl.OP_INV_SAFEGCD):
+        for op in (zl.OP_INV, zl.OP_INV_XGCD, zl.OP_INV_SAFEGCD):
             assert np.array_equal(zl.field_op(field, op, a), want), op
         # x * x^-1 == 1 (Montgomery one) wherever x != 0
         one = ob.f_from_u64(field, np.array([1], dtype=np.uint64))[0]

@@ -476,3 +476,50 @@ def test_alternate_code_paths(zl, ob, gm, env, monkeypatch):
     sc[rng.integers(0, n, size=500)] = U.fr([3])[0]  # some skew
     _check(zl, ob, gm[:n], None, sc)
     _check(zl, ob, gm[:n], None, sc, window_bits=16, precompute_levels=2)
+
+
+def test_affine_point_add_and_double(zl, ob, gm):
+    """AffinePoint.add / double (src/msm/mod.zig:74-138) as zg_g1_affine_add_batch: generic pairs, P + P (the doubling branch),
+    P + (-P) (identity), identity operands, and the reference's KAT 'generator affine-double == Jacobian-double'
+    (src/poly/commitment/mod.zig:1240-1258), all against the oracle's restatement of the same functions."""
+    from zolt_amd import api
+    n = 512
+    a = gm[:n].copy()
+    b = gm[n:2 * n].copy()
+    b[:8] = a[:8]  # P + P
+    neg = a[8:16].copy()
+    pm_p = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+    for i in range(8):  # P + (-P): y -> p - y (Montgomery form is linear)
+        y = sum(int(v) << (64 * k) for k, v in enumerate(neg[i, 4:]))
+        neg[i, 4:] = [((pm_p - y) >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(4)]
+    b[8:16] = neg
+    ai = np.zeros(n, dtype=np.uint8)
+    bi = np.zeros(n, dtype=np.uint8)
+    ai[16:20] = 1
+    bi[18:24] = 1
+    out, oinf = zl.g1_affine_add_batch(a, ai, b, bi)
+    for i in range(n):
+        w, wi = ob.g1_add_affine(a[i], int(ai[i]), b[i], int(bi[i]))
+        assert oinf[i] == wi and (wi or np.array_equal(out[i], w)), i
+    assert oinf[8:16].all() and not out[8:16].any()  # identity is written as x = y = 0, inf = 1
+    d, di = api.AffinePoint.double(api.generator())
+    w, wi = ob.g1_double_affine(api.generator(), 0)
+    assert di == wi == 0 and np.array_equal(d, w)
+    jd = ob.g1_jac_to_affine(ob.g1_jac_double(np.concatenate([api.generator(), api.fp_from_int(1)])))
+    assert np.array_equal(d, jd[0])
+    s2, s2i = api.AffinePoint.add(api.generator(), 0, api.generator(), 0)
+    assert s2i == 0 and np.array_equal(s2, d) and api.AffinePoint.isOnCurve(d)
+    z, zi = api.AffinePoint.double(np.zeros(8, dtype=np.uint64), 1)
+    assert zi == 1
+
+
+def test_mock_srs_and_scalar_mul_at_reference_default_size(zl, ob):
+    """HyperKZG.setup at the reference's default srs_size = 1280 (logs/zolt.log:10-12; src/poly/commitment/mod.zig:174-213):
+    the device batch scalar multiplication equals the oracle's mock SRS point for point."""
+    from zolt_amd import api
+    n = 1280
+    params = api.HyperKZG.setup(n)
+    wsrs, winf = ob.hyperkzg_setup(n)
+    assert np.array_equal(params.powers_of_tau_g1, wsrs) and np.array_equal(params.infinity, winf)
+    assert zl.g1_is_on_curve_batch(params.powers_of_tau_g1, params.infinity).all()
+    params.deinit()

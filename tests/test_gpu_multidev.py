@@ -1,0 +1,158 @@
+"""Several GPUs in ONE process behind the C ABI (include/zolt_gpu.h "several GPUs in one process"; csrc/sharded.hip): the
+reference's own process model — ParallelMSM.compute runs threads inside `zolt prove` (src/msm/mod.zig:588-653),
+ParallelBatchMSM (:683-748) / HyperKZG.batchCommit (src/poly/commitment/mod.zig:558-570) likewise.
+
+The test box has ONE GPU, so the shard logic (partition, per-shard launch sets on worker threads, exchange, gather order,
+combine) runs with several LOGICAL shards on that device (ZG_SHARDS, exchange by peer copies), and the RCCL exchange itself
+(ncclCommInitAll + ncclAllGather through the dlopen'ed library) runs with the one shard RCCL accepts per device
+(ZG_SHARD_EXCHANGE=rccl). Results must be byte-identical to the oracle's MSM(F,G).compute for every shard count."""
+import numpy as np
+import pytest
+
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+
+N = 5000
+
+
+@pytest.fixture(scope="module")
+def env():
+    from oracle import binding as ob
+    from zolt_amd import api, lib
+    lib.init()
+    lib.init_devices(1)  # widen nothing on a 1-GPU box; on a multi-GPU box the tests still pin ZG_SHARDS explicitly
+    gm = ob.g1_gen_multiples(N)
+    return api, lib, ob, gm
+
+
+def _rand(ob, seed, n):
+    return ob.f_to_mont(ob.FR, U.random_raw256(seed, n))
+
+
+@pytest.mark.parametrize("shards", [1, 2, 3, 8])
+def test_sharded_msm_equals_oracle(env, shards, monkeypatch):
+    api, lib, ob, gm = env
+    monkeypatch.setenv("ZG_SHARDS", str(shards))
+    inf = np.zeros(N, dtype=np.uint8)
+    inf[11::97] = 1
+    sb = lib.ShardedBases.upload(gm, inf)
+    try:
+        assert len(sb.shards()) == shards and sb.exchange() == ("none" if shards == 1 else "p2p")
+        # the partition is ParallelMSM's: contiguous chunks of ceil(n / S) (src/msm/mod.zig:609,619-621)
+        per = -(-N // shards)
+        assert [(s, l) for _, s, l in sb.shards()] == [(min(i * per, N), max(0, min(per, N - i * per))) for i in range(shards)]
+        sc = _rand(ob, 900 + shards, N)
+        want = ob.msm_g1(gm, inf, sc)
+        got = sb.msm(sc)
+        assert got[1] == want[1] and np.array_equal(got[0], want[0])
+        # equals the reference's ParallelMSM partition + serial combine, restated in the oracle
+        wp = ob.msm_g1_parallel(gm, inf, sc, shards)
+        assert got[1] == wp[1] and np.array_equal(got[0], wp[0])
+        # a prefix (HyperKZG.commit of a shorter polynomial): trailing shards contribute the identity
+        for n in (0, 1, per, per + 1, N - 1):
+            w = ob.msm_g1(gm[:n], inf[:n], sc[:n])
+            g = sb.msm(sc[:n], n)
+            assert g[1] == w[1] and np.array_equal(g[0], w[0]), n
+        # all-zero scalars -> identity from every shard (src/msm/mod.zig:949-966)
+        z = sb.msm(np.zeros((N, 4), dtype=np.uint64))
+        assert z[1] == 1 and not z[0].any()
+    finally:
+        sb.free()
+
+
+@pytest.mark.parametrize("shards", [1, 2, 5])
+@pytest.mark.parametrize("k,n", [(1, N), (4, N), (7, 1000), (3, 0)])
+def test_sharded_batch_commit_equals_oracle(env, shards, k, n, monkeypatch):
+    """E2: HyperKZG.batchCommit / ParallelBatchMSM sharded — k partials per shard in ONE exchange, k combines."""
+    api, lib, ob, gm = env
+    monkeypatch.setenv("ZG_SHARDS", str(shards))
+    sb = lib.ShardedBases.upload(gm)
+    try:
+        batches = [_rand(ob, 1000 + 10 * k + j, n) for j in range(k)]
+        out, inf = sb.msm_batch(batches, n)
+        for j in range(k):
+            w, wi = ob.msm_g1(gm[:n], None, batches[j])
+            assert inf[j] == wi and np.array_equal(out[j], w), (shards, k, n, j)
+    finally:
+        sb.free()
+
+
+def test_rccl_exchange_at_one_device(env, monkeypatch):
+    """The RCCL leg itself: communicator creation (ncclCommInitAll via dlopen) and the grouped ncclAllGather, with the one rank
+    per device RCCL accepts. Batch of 3 -> 288-byte gather."""
+    api, lib, ob, gm = env
+    monkeypatch.setenv("ZG_SHARDS", "1")
+    monkeypatch.setenv("ZG_SHARD_EXCHANGE", "rccl")
+    sb = lib.ShardedBases.upload(gm)
+    try:
+        assert sb.exchange() == "rccl"
+        sc = _rand(ob, 1200, N)
+        want = ob.msm_g1(gm, None, sc)
+        got = sb.msm(sc)
+        assert got[1] == want[1] and np.array_equal(got[0], want[0])
+        batches = [_rand(ob, 1210 + j, N) for j in range(3)]
+        out, inf = sb.msm_batch(batches)
+        for j in range(3):
+            w, wi = ob.msm_g1(gm, None, batches[j])
+            assert inf[j] == wi and np.array_equal(out[j], w)
+    finally:
+        sb.free()
+
+
+def test_sharded_msm_resident_scalars(env, monkeypatch):
+    import torch
+    api, lib, ob, gm = env
+    monkeypatch.setenv("ZG_SHARDS", "4")
+    sb = lib.ShardedBases.upload(gm)
+    try:
+        sc = _rand(ob, 1300, N)
+        d_parts = [torch.from_numpy(sc[s:s + l].view(np.int64).copy()).cuda() for _, s, l in sb.shards()]
+        got = sb.msm_dev([t.data_ptr() for t in d_parts], N)
+        want = ob.msm_g1(gm, None, sc)
+        assert got[1] == want[1] and np.array_equal(got[0], want[0])
+    finally:
+        sb.free()
+
+
+def test_api_parallel_msm_mirrors(env, monkeypatch):
+    api, lib, ob, gm = env
+    monkeypatch.setenv("ZG_SHARDS", "3")
+    sc = _rand(ob, 1400, 3000)
+    got = api.ParallelMSM.compute(gm[:3000], sc)
+    want = ob.msm_g1(gm[:3000], None, sc)
+    assert got[1] == want[1] and np.array_equal(got[0], want[0])
+    batches = [_rand(ob, 1410 + j, 3000) for j in range(2)]
+    out, inf = api.ParallelBatchMSM.compute(gm[:3000], batches)
+    for j in range(2):
+        w, wi = ob.msm_g1(gm[:3000], None, batches[j])
+        assert inf[j] == wi and np.array_equal(out[j], w)
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("shards,v", [(1, 6), (2, 6), (4, 9), (8, 3), (8, 12), (3, 7)])
+def test_sharded_sumcheck_session_equals_single_device(env, layout, shards, v, monkeypatch):
+    """zg_sumcheck_*_sharded: every round message, and the final evaluation, equal the oracle's for the whole table — LOW_PAIR
+    shards by contiguous chunks, HIGH_HALF by residue class; 8 shards of a 2^3 table start directly in the tail; 3 devices
+    use 2 shards (largest power of two)."""
+    api, lib, ob, gm = env
+    monkeypatch.setenv("ZG_SHARDS", str(shards))
+    table = _rand(ob, 1500 + 16 * shards + v, 1 << v)
+    s = lib.ShardedSumcheckSession.open(table, layout)
+    try:
+        want_shards = 1
+        while want_shards * 2 <= min(shards, 1 << v):
+            want_shards *= 2
+        assert s.shards() == want_shards
+        cur = table
+        for rd in range(v):
+            g0, g1 = s.round_sums()
+            w0, w1 = (ob.fr_sum_halves(cur) if layout == lib.SC_HIGH_HALF else ob.fr_sum_even_odd(cur))
+            assert np.array_equal(g0, w0) and np.array_equal(g1, w1), rd
+            r = _rand(ob, 1600 + rd, 1)[0]
+            s.bind(r)
+            cur = ob.fr_bind_high(cur, r) if layout == lib.SC_HIGH_HALF else ob.fr_bind_low(cur, r)
+            assert len(s) == len(cur)
+        assert np.array_equal(s.final(), cur[0])
+    finally:
+        s.close()

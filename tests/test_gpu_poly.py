@@ -51,6 +51,20 @@ def test_eq_table_golden(zl, ob):
     assert np.array_equal(got, ob.fr_eq_table_append_lsb(r))  # GruenSplitEq build order, same table
 
 
+def test_eq_table_matches_reference_log(zl, ob):
+    """zg_fr_eq_table against the E_out / E_in entries the reference printed for a real GruenSplitEqPolynomial
+    (logs/zolt.log [STAGE4_GRUEN_INIT]; fixture tests/golden/stage4_gruen_eq.json, src/poly/split_eq.zig:91-171)."""
+    d = json.load(open(os.path.join(U.GOLDEN, "stage4_gruen_eq.json")))
+    tau = np.array([[int(x) for x in row] for row in d["r_cycle_be_mont_limbs"]], dtype=np.uint64)
+    n, m = d["n"], d["m"]
+    for name, sl, ln in (("E_out", slice(0, m), d["E_out_len"]), ("E_in", slice(m, n - 1), d["E_in_len"])):
+        t = zl.fr_eq_table(tau[sl])
+        assert len(t) == ln
+        tc = zl.field_op(zl.FR, zl.OP_FROM_MONT, t)  # canonical limbs (F.toBytes = LE bytes of these)
+        assert [tc[i].tobytes().hex() for i in range(4)] == d[name + "_first4_canonical_le_hex"], name
+        assert np.array_equal(t, ob.fr_eq_table(tau[sl]))
+
+
 def test_bind_kats_and_golden(zl, ob):
     """src/poly/mod.zig:816-888 and tests/golden folds."""
     got = zl.fr_bind_low(U.fr([1, 2, 3, 4]), U.fr([3])[0])
@@ -247,3 +261,24 @@ def test_full_size_sumcheck_properties(zl, ob):
     got = zl.fr_eq_table(r)
     want = ob.fr_eq_table(r)
     assert hashlib.sha256(got.tobytes()).digest() == hashlib.sha256(want.tobytes()).digest()
+
+
+def test_dense_polynomial_add_scale_and_eq_mle(zl, ob):
+    """DensePolynomial.add / scale (src/poly/mod.zig:94-126) and EqPolynomial.mle / evaluate (:214-227,311-321) through the host
+    mirror, against the oracle. mle at a boolean point is the eq table's entry (big-endian index)."""
+    from zolt_amd import api
+    a, b = _rand(ob, 2000, 1 << 10), _rand(ob, 2001, 1 << 10)
+    s = _rand(ob, 2002, 1)[0]
+    pa, pb = api.DensePolynomial(a), api.DensePolynomial(b)
+    assert np.array_equal(pa.add(pb).evaluations, ob.f_add(ob.FR, a, b))
+    assert np.array_equal(pa.scale(s).evaluations, ob.fr_poly_scale(a, s))
+    assert np.array_equal(pa.scale(s).evaluations, ob.f_mul(ob.FR, a, np.repeat(s[None, :], 1 << 10, axis=0)))
+    for v in (0, 1, 5, 20):
+        r, x = _rand(ob, 2010 + v, v), _rand(ob, 2020 + v, v)
+        assert np.array_equal(api.EqPolynomial.mle(r, x), ob.fr_eq_mle(r, x))
+        assert np.array_equal(api.EqPolynomial(r).evaluate(x), ob.fr_eq_mle(r, x))
+    r = _rand(ob, 2030, 6)
+    tab = zl.fr_eq_table(r)
+    for idx in (0, 1, 37, 63):
+        bits = U.fr([(idx >> (5 - j)) & 1 for j in range(6)])
+        assert np.array_equal(api.EqPolynomial.mle(r, bits), tab[idx])

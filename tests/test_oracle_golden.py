@@ -251,3 +251,34 @@ def test_dense_evaluate_and_hyperkzg_open_fold():
         c, ci = ob.hyperkzg_commit(srs, inf, ob.f_sub(FR, cur[half:], cur[:half]))
         assert np.array_equal(c, q[i]) and ci == qinf[i]
         cur = ob.fr_bind_high(cur, point[i])
+
+
+def _gruen_fixture(golden_dir):
+    d = json.load(open(os.path.join(golden_dir, "stage4_gruen_eq.json")))
+    tau = np.array([[int(x) for x in row] for row in d["r_cycle_be_mont_limbs"]], dtype=np.uint64)  # raw Montgomery limbs
+    return d, tau
+
+
+def test_gruen_split_eq_tables_match_reference_log(golden_dir):
+    """The only eq-table values the reference itself produced and kept: logs/zolt.log [STAGE4_GRUEN_INIT]
+    (stage4_gruen_prover.zig:266-312): E_out = eq table over w_out = tau[0..m], E_in over w_in = tau[m..n-1]
+    (src/poly/split_eq.zig:91-171), entries printed as canonical little-endian bytes (F.toBytes, field/mod.zig:685-695).
+    Pins EqPolynomial.evalsSliceWithScaling (A17) and the split-eq append-LSB build (A19) of the oracle AND of the
+    independent big-int model against reference-produced numbers."""
+    d, tau = _gruen_fixture(golden_dir)
+    n, m = d["n"], d["m"]
+    can = ob.f_from_mont(FR, tau)
+    assert can[n - 1].tobytes().hex() == d["current_w_canonical_le_hex"]  # decoding of the Montgomery limbs is right
+    assert ob.f_from_mont(FR, ob.f_from_u64(FR, np.array([1], dtype=np.uint64)))[0].tobytes().hex() == d["current_scalar_canonical_le_hex"]
+    for name, sl, ln in (("E_out", slice(0, m), d["E_out_len"]), ("E_in", slice(m, n - 1), d["E_in_len"])):
+        want = d[name + "_first4_canonical_le_hex"]
+        for build in (ob.fr_eq_table, ob.fr_eq_table_append_lsb):
+            t = build(tau[sl])
+            assert len(t) == ln
+            tc = ob.f_from_mont(FR, t)
+            assert [tc[i].tobytes().hex() for i in range(4)] == want, (name, build.__name__)
+        # independent model: canonical ints in, canonical ints out
+        r_int = [pm.from_mont(pm.from_limbs(x), pm.R_MOD) for x in tau[sl]]
+        tp = pm.eq_table(r_int)
+        assert len(tp) == ln
+        assert [int(v).to_bytes(32, "little").hex() for v in tp[:4]] == want, name

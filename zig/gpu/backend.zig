@@ -5,18 +5,62 @@
 //! Everything here is generic over the reference's own types, so this file imports nothing from Zolt: `F` is
 //! BN254Scalar, `G` is BN254BaseField, `Affine` is msm.AffinePoint(G) — any struct with `.x.limbs`, `.y.limbs`,
 //! `.infinity`, `identity()` and `fromCoords(x, y)` (src/msm/mod.zig:15-49).
+//!
+//! Three rules this file enforces (each was a hazard in the first version of the shim):
+//!  1. TYPE GATE. The GPU kernels are BN254 G1 only. The reference also instantiates MSM(Fr, Fr) with off-curve "points"
+//!     (src/msm/mod.zig:853-873,911-936; commitment/mod.zig:930,1000). `isBn254Pair` decides at comptime from the fields'
+//!     Montgomery constants; every other instantiation keeps the original Zig body (`msmCompute*` return null).
+//!  2. OWNERSHIP, NOT A CACHE. A device table belongs to an `SrsHandle` stored IN SetupParams: created by setup()/load(), freed by
+//!     deinit(). Nothing is keyed by (ptr, len), so a re-used stack or heap address can never meet a stale table, and no
+//!     other thread can free a handle that is in use (the owner outlives its commits).
+//!  3. AD-HOC SLICES ARE ONE-SHOT. MSM.compute on a temporary slice (dory.zig row commitments, folded G vectors, tests,
+//!     src/bench.zig:261-268) uploads with `expected_uses = 1` (no precompute table: the build would cost more than it
+//!     saves), computes, and frees before returning; below `one_shot_min_points` the CPU body is faster and is kept.
 const std = @import("std");
 pub const ffi = @import("ffi.zig");
 
 pub const Error = error{ GpuFailure, OutOfMemory, SumcheckVerificationFailed };
 
+/// BN254 Montgomery R = 2^256 mod r / mod q (src/field/mod.zig:23-28, 60-65): what F.one() / G.one() hold.
+const FR_ONE = [4]u64{ 0xac96341c4ffffffb, 0x36fc76959f60cd29, 0x666ea36f7879462e, 0x0e0a77c19a07df2f };
+const FP_ONE = [4]u64{ 0xd35d438dc58f0d9d, 0x0a78eb28f5c70b3d, 0x666ea36f7879462c, 0x0e0a77c19a07df2f };
+
+/// comptime: is (F, G) = (BN254 scalar field, BN254 base field), both 4x64-bit Montgomery? Anything else must not reach the GPU.
+pub fn isBn254Pair(comptime F: type, comptime G: type) bool {
+    comptime {
+        if (@sizeOf(F) != 32 or @sizeOf(G) != 32) return false;
+        if (!@hasDecl(F, "one") or !@hasDecl(G, "one")) return false;
+        if (!@hasField(F, "limbs") or !@hasField(G, "limbs")) return false;
+        const f1 = F.one();
+        const g1 = G.one();
+        return std.mem.eql(u64, &f1.limbs, &FR_ONE) and std.mem.eql(u64, &g1.limbs, &FP_ONE);
+    }
+}
+
+/// comptime: is F the BN254 scalar field (poly / sumcheck kernels are Fr only)
+pub fn isBn254Scalar(comptime F: type) bool {
+    comptime {
+        if (@sizeOf(F) != 32 or !@hasDecl(F, "one") or !@hasField(F, "limbs")) return false;
+        const f1 = F.one();
+        return std.mem.eql(u64, &f1.limbs, &FR_ONE);
+    }
+}
+
 var init_once = std.once(initDevice);
 var available: bool = false;
+var n_devices: c_int = 1;
 
 fn initDevice() void {
-    // ZOLT_GPU=0 keeps the original Zig bodies; ZOLT_GPU_DEVICE selects the GPU of this process (one process per GPU)
+    // ZOLT_GPU=0 keeps the original Zig bodies. ZOLT_GPU_DEVICES=n (or "all") lets this ONE process drive n GPUs through the
+    // sharded entry points (ParallelMSM / batchCommit); otherwise ZOLT_GPU_DEVICE selects the single GPU of this process.
     if (std.posix.getenv("ZOLT_GPU")) |v| {
         if (v.len > 0 and v[0] == '0') return;
+    }
+    if (std.posix.getenv("ZOLT_GPU_DEVICES")) |v| {
+        const n: c_int = if (std.mem.eql(u8, v, "all")) 0 else (std.fmt.parseInt(c_int, v, 10) catch 1);
+        available = ffi.zg_init_devices(n) == ffi.OK;
+        if (available) n_devices = ffi.zg_n_devices();
+        return;
     }
     var dev: c_int = 0;
     if (std.posix.getenv("ZOLT_GPU_DEVICE")) |v| dev = std.fmt.parseInt(c_int, v, 10) catch 0;
@@ -28,6 +72,11 @@ pub fn enabled() bool {
     return available;
 }
 
+pub fn deviceCount() usize {
+    _ = enabled();
+    return @intCast(n_devices);
+}
+
 pub fn lastError() []const u8 {
     return std.mem.span(ffi.zg_last_error());
 }
@@ -37,101 +86,234 @@ fn limbsOf(comptime F: type, s: []const F) [*]const u64 {
     return @ptrCast(s.ptr);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Bases: `[]const Affine` -> device handle, cached by (ptr, len). HyperKZG.commit is called three times per proof with the
-// same SetupParams.powers_of_tau_g1 (src/zkvm/mod.zig:1538,1572,1607): the SRS is packed and uploaded once.
-// MSM.compute is reached from std.Thread workers (src/msm/mod.zig:637,732), hence the mutex.
-// ---------------------------------------------------------------------------------------------------------------
-const CacheEntry = struct { ptr: usize, len: usize, handle: ffi.Bases };
-var cache_mutex: std.Thread.Mutex = .{};
-var cache: [8]CacheEntry = [_]CacheEntry{.{ .ptr = 0, .len = 0, .handle = null }} ** 8;
-var cache_next: usize = 0;
-
-/// AffinePoint is an auto-layout struct (field order not ABI-stable, src/msm/mod.zig:19-21): pack x‖y into n×8 u64 + n flags.
-pub fn basesHandleFor(comptime Affine: type, bases: []const Affine) Error!ffi.Bases {
-    const key_ptr = @intFromPtr(bases.ptr);
-    cache_mutex.lock();
-    defer cache_mutex.unlock();
-    for (cache) |e| {
-        if (e.handle != null and e.ptr == key_ptr and e.len == bases.len) return e.handle;
-    }
-    const a = std.heap.page_allocator;
-    const xy = a.alloc(u64, bases.len * 8) catch return Error.OutOfMemory;
-    defer a.free(xy);
-    const inf = a.alloc(u8, bases.len) catch return Error.OutOfMemory;
-    defer a.free(inf);
-    for (bases, 0..) |p, i| {
-        @memcpy(xy[8 * i .. 8 * i + 4], &p.x.limbs);
-        @memcpy(xy[8 * i + 4 .. 8 * i + 8], &p.y.limbs);
-        inf[i] = @intFromBool(p.infinity);
-    }
-    var h: ffi.Bases = null;
-    if (ffi.zg_g1_bases_upload(xy.ptr, inf.ptr, bases.len, null, &h) != ffi.OK) return Error.GpuFailure;
-    const slot = &cache[cache_next % cache.len];
-    if (slot.handle != null) _ = ffi.zg_g1_bases_free(slot.handle); // evict the oldest
-    slot.* = .{ .ptr = key_ptr, .len = bases.len, .handle = h };
-    cache_next += 1;
-    return h;
-}
-
-/// Call from SetupParams.deinit (src/poly/commitment/mod.zig:136-140) before the powers are freed.
-pub fn forgetBases(ptr: *const anyopaque, len: usize) void {
-    cache_mutex.lock();
-    defer cache_mutex.unlock();
-    for (&cache) |*e| {
-        if (e.handle != null and e.ptr == @intFromPtr(ptr) and e.len == len) {
-            _ = ffi.zg_g1_bases_free(e.handle);
-            e.* = .{ .ptr = 0, .len = 0, .handle = null };
-        }
-    }
-}
-
 fn affineFrom(comptime Affine: type, xy: *const [8]u64, inf: u8) Affine {
     if (inf != 0) return Affine.identity();
     return Affine.fromCoords(.{ .limbs = xy[0..4].* }, .{ .limbs = xy[4..8].* });
 }
 
-/// Body of MSM(F, G).compute (src/msm/mod.zig:355-372) on the GPU. `compute` has no error channel: a device failure panics,
-/// exactly like an assertion failure of the original would (the caller can still run with ZOLT_GPU=0).
-pub fn msmCompute(comptime F: type, comptime Affine: type, bases: []const Affine, scalars: []const F) Affine {
-    std.debug.assert(bases.len == scalars.len);
-    if (bases.len == 0) return Affine.identity();
-    const h = basesHandleFor(Affine, bases) catch @panic("zolt-gpu: bases upload failed");
-    var xy: [8]u64 = undefined;
-    var inf: u8 = 0;
-    if (ffi.zg_msm_g1(h, 0, bases.len, limbsOf(F, scalars), &xy, &inf) != ffi.OK) @panic("zolt-gpu: zg_msm_g1 failed");
-    return affineFrom(Affine, &xy, inf);
-}
+/// AffinePoint is an auto-layout struct (field order not ABI-stable, src/msm/mod.zig:19-21): pack x‖y into n×8 u64 + n flags.
+const Packed = struct {
+    xy: []u64,
+    inf: []u8,
+    fn init(comptime Affine: type, a: std.mem.Allocator, bases: []const Affine) Error!Packed {
+        const xy = a.alloc(u64, @max(bases.len, 1) * 8) catch return Error.OutOfMemory;
+        errdefer a.free(xy);
+        const inf = a.alloc(u8, @max(bases.len, 1)) catch return Error.OutOfMemory;
+        for (bases, 0..) |p, i| {
+            @memcpy(xy[8 * i .. 8 * i + 4], &p.x.limbs);
+            @memcpy(xy[8 * i + 4 .. 8 * i + 8], &p.y.limbs);
+            inf[i] = @intFromBool(p.infinity);
+        }
+        return .{ .xy = xy, .inf = inf };
+    }
+    fn deinit(self: Packed, a: std.mem.Allocator) void {
+        a.free(self.xy);
+        a.free(self.inf);
+    }
+};
 
-/// Body of BatchMSM.compute / ParallelBatchMSM.compute (src/msm/mod.zig:545-565, 683-748): k scalar vectors over the same
-/// bases; short vectors run as ONE fused launch set. The result slice is owned by the caller's allocator, as before.
-pub fn msmBatch(comptime F: type, comptime Affine: type, bases: []const Affine, scalar_batches: []const []const F, allocator: std.mem.Allocator) ![]Affine {
-    const k = scalar_batches.len;
-    const results = try allocator.alloc(Affine, k);
-    errdefer allocator.free(results);
-    if (k == 0) return results;
-    const n = scalar_batches[0].len;
-    for (scalar_batches) |b| std.debug.assert(b.len == n and n <= bases.len);
-    const h = try basesHandleFor(Affine, bases);
-    const ptrs = try allocator.alloc([*]const u64, k);
-    defer allocator.free(ptrs);
-    for (scalar_batches, 0..) |b, i| ptrs[i] = limbsOf(F, b);
-    const xy = try allocator.alloc(u64, 8 * k);
+// ---------------------------------------------------------------------------------------------------------------
+// SrsHandle: the device image of SetupParams.powers_of_tau_g1 (src/poly/commitment/mod.zig:122-140). A FIELD of SetupParams
+// (`gpu: gpu.SrsHandle = .{}`): HyperKZG.setup / SRS loaders call init(), SetupParams.deinit calls deinit(). One table on one
+// GPU, or — when the process drives several (ZOLT_GPU_DEVICES) — one shard per GPU.
+// ---------------------------------------------------------------------------------------------------------------
+pub const SrsHandle = struct {
+    bases: ffi.Bases = null,
+    sharded: ffi.ShardedBases = null,
+    len: usize = 0,
+
+    /// Upload `powers` (kept resident until deinit). On any failure the handle stays empty and every caller keeps its CPU body.
+    pub fn init(comptime Affine: type, powers: []const Affine) SrsHandle {
+        var h: SrsHandle = .{};
+        if (!enabled() or powers.len == 0) return h;
+        const a = std.heap.page_allocator;
+        const pk = Packed.init(Affine, a, powers) catch return h;
+        defer pk.deinit(a);
+        if (n_devices > 1) {
+            if (ffi.zg_g1_bases_upload_sharded(pk.xy.ptr, pk.inf.ptr, powers.len, null, &h.sharded) != ffi.OK) h.sharded = null;
+        } else {
+            if (ffi.zg_g1_bases_upload(pk.xy.ptr, pk.inf.ptr, powers.len, null, &h.bases) != ffi.OK) h.bases = null;
+        }
+        if (h.ready()) h.len = powers.len;
+        return h;
+    }
+
+    pub fn ready(self: *const SrsHandle) bool {
+        return self.bases != null or self.sharded != null;
+    }
+
+    pub fn deinit(self: *SrsHandle) void {
+        if (self.bases != null) _ = ffi.zg_g1_bases_free(self.bases);
+        if (self.sharded != null) _ = ffi.zg_g1_sbases_free(self.sharded);
+        self.* = .{};
+    }
+
+    /// HyperKZG.commit (src/poly/commitment/mod.zig:239-255): MSM over powers[0..n). null = not on the GPU, run the Zig body.
+    pub fn commit(self: *const SrsHandle, comptime F: type, comptime Affine: type, evals: []const F) ?Affine {
+        if (!self.ready()) return null;
+        const n = @min(evals.len, self.len);
+        if (n == 0) return Affine.identity();
+        var xy: [8]u64 = undefined;
+        var inf: u8 = 0;
+        const rc = if (self.sharded != null)
+            ffi.zg_msm_g1_sharded(self.sharded, n, limbsOf(F, evals), &xy, @ptrCast(&inf))
+        else
+            ffi.zg_msm_g1(self.bases, 0, n, limbsOf(F, evals), &xy, @ptrCast(&inf));
+        if (rc != ffi.OK) return null; // the caller falls back to the CPU body; lastError() says why
+        return affineFrom(Affine, &xy, inf);
+    }
+
+    /// HyperKZG.batchCommit (:558-570) / BatchMSM / ParallelBatchMSM (src/msm/mod.zig:545-565,683-748): k vectors of one length n
+    /// over powers[0..n); short vectors run as ONE fused launch set, several GPUs exchange k partials in one all-gather.
+    pub fn batchCommit(self: *const SrsHandle, comptime F: type, comptime Affine: type, polys: []const []const F, allocator: std.mem.Allocator) !?[]Affine {
+        if (!self.ready() or polys.len == 0) return null;
+        const n = @min(polys[0].len, self.len);
+        for (polys) |p| if (@min(p.len, self.len) != n) return null; // ragged batch: keep the per-polynomial loop
+        const k = polys.len;
+        const results = try allocator.alloc(Affine, k);
+        errdefer allocator.free(results);
+        const ptrs = try allocator.alloc(?[*]const u64, k);
+        defer allocator.free(ptrs);
+        for (polys, 0..) |p, i| ptrs[i] = limbsOf(F, p);
+        const xy = try allocator.alloc(u64, 8 * k);
+        defer allocator.free(xy);
+        const inf = try allocator.alloc(u8, k);
+        defer allocator.free(inf);
+        const rc = if (self.sharded != null)
+            ffi.zg_msm_g1_batch_sharded(self.sharded, n, ptrs.ptr, k, xy.ptr, inf.ptr)
+        else
+            ffi.zg_msm_g1_batch(self.bases, n, ptrs.ptr, k, xy.ptr, inf.ptr);
+        if (rc != ffi.OK) {
+            allocator.free(results);
+            return null;
+        }
+        for (results, 0..) |*r, i| r.* = affineFrom(Affine, xy[8 * i ..][0..8], inf[i]);
+        return results;
+    }
+
+    /// HyperKZG.open (:261-324) on the device: the quotient -> commit -> fold loop never leaves HBM. Returns the quotient
+    /// commitments (one per variable the fold reaches) and the final evaluation; null = run the Zig body.
+    pub fn open(self: *const SrsHandle, comptime F: type, comptime Affine: type, evals: []const F, point: []const F, value: F, allocator: std.mem.Allocator) !?struct { quotients: []Affine, final_eval: F } {
+        if (self.bases == null) return null; // single-device handle only (the sharded form commits level by level: not offered)
+        const v = point.len;
+        const q = try allocator.alloc(Affine, v);
+        errdefer allocator.free(q);
+        const xy = try allocator.alloc(u64, 8 * @max(v, 1));
+        defer allocator.free(xy);
+        const inf = try allocator.alloc(u8, @max(v, 1));
+        defer allocator.free(inf);
+        var fin: F = undefined;
+        if (ffi.zg_hyperkzg_open(self.bases, limbsOf(F, evals), evals.len, limbsOf(F, point), v, &value.limbs, xy.ptr, inf.ptr, &fin.limbs) != ffi.OK) {
+            allocator.free(q);
+            return null;
+        }
+        for (q, 0..) |*r, i| r.* = affineFrom(Affine, xy[8 * i ..][0..8], inf[i]);
+        return .{ .quotients = q, .final_eval = fin };
+    }
+
+    /// HyperKZG.batchOpen (:607-732): gamma, the combined polynomial, per-polynomial evaluations and the same loop, one call.
+    pub fn batchOpen(self: *const SrsHandle, comptime F: type, comptime Affine: type, polys: []const []const F, point: []const F, allocator: std.mem.Allocator) !?struct { quotients: []Affine, evaluations: []F, final_eval: F, gamma: F } {
+        if (self.bases == null) return null;
+        const k = polys.len;
+        const v = point.len;
+        const ptrs = try allocator.alloc(?[*]const u64, @max(k, 1));
+        defer allocator.free(ptrs);
+        const lens = try allocator.alloc(usize, @max(k, 1));
+        defer allocator.free(lens);
+        for (polys, 0..) |p, i| {
+            ptrs[i] = if (p.len > 0) limbsOf(F, p) else null;
+            lens[i] = p.len;
+        }
+        const xy = try allocator.alloc(u64, 8 * @max(v, 1));
+        defer allocator.free(xy);
+        const inf = try allocator.alloc(u8, @max(v, 1));
+        defer allocator.free(inf);
+        const evaluations = try allocator.alloc(F, k);
+        errdefer allocator.free(evaluations);
+        var nq: usize = 0;
+        var fin: F = undefined;
+        var gamma: F = undefined;
+        if (ffi.zg_hyperkzg_batch_open(self.bases, ptrs.ptr, lens.ptr, k, limbsOf(F, point), v, xy.ptr, inf.ptr, &nq, @ptrCast(evaluations.ptr), &fin.limbs, &gamma.limbs) != ffi.OK) {
+            allocator.free(evaluations);
+            return null;
+        }
+        const q = try allocator.alloc(Affine, nq);
+        for (q, 0..) |*r, i| r.* = affineFrom(Affine, xy[8 * i ..][0..8], inf[i]);
+        return .{ .quotients = q, .evaluations = evaluations, .final_eval = fin, .gamma = gamma };
+    }
+};
+
+/// HyperKZG.setup's loop `powers[i] = MSM.scalarMul(g1, tau^i).toAffine()` (src/poly/commitment/mod.zig:194-199) as one batch:
+/// `scalars[i]` = tau^i (Montgomery Fr), all over the same base point. Returns false -> run the Zig loop.
+pub fn setupPowers(comptime F: type, comptime Affine: type, g1: Affine, scalars: []const F, out: []Affine, allocator: std.mem.Allocator) !bool {
+    if (!enabled() or scalars.len == 0) return false;
+    const n = scalars.len;
+    const xy = try allocator.alloc(u64, 8 * n);
     defer allocator.free(xy);
-    const inf = try allocator.alloc(u8, k);
-    defer allocator.free(inf);
-    if (ffi.zg_msm_g1_batch(h, n, ptrs.ptr, k, xy.ptr, inf.ptr) != ffi.OK) return Error.GpuFailure;
-    for (results, 0..) |*r, i| r.* = affineFrom(Affine, xy[8 * i ..][0..8], inf[i]);
-    return results;
+    for (0..n) |i| {
+        @memcpy(xy[8 * i .. 8 * i + 4], &g1.x.limbs);
+        @memcpy(xy[8 * i + 4 .. 8 * i + 8], &g1.y.limbs);
+    }
+    const oxy = try allocator.alloc(u64, 8 * n);
+    defer allocator.free(oxy);
+    const oinf = try allocator.alloc(u8, n);
+    defer allocator.free(oinf);
+    if (ffi.zg_g1_scalar_mul_batch(xy.ptr, null, limbsOf(F, scalars), n, oxy.ptr, oinf.ptr) != ffi.OK) return false;
+    for (out, 0..) |*r, i| r.* = affineFrom(Affine, oxy[8 * i ..][0..8], oinf[i]);
+    return true;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// poly: EqPolynomial.evalsSliceWithScaling, DensePolynomial.bindLow / bindFirst / evaluate (src/poly/mod.zig)
+// MSM(F, G).compute on an arbitrary slice (src/msm/mod.zig:355-372): ONE-SHOT. No table outlives the call.
+// ---------------------------------------------------------------------------------------------------------------
+/// below this many points the upload + launch latency (~0.5 ms) loses to the CPU body
+pub const one_shot_min_points: usize = 4096;
+
+/// null = not handled here (wrong field types, GPU disabled, too small, or a device failure): run the original body.
+pub fn msmComputeOneShot(comptime F: type, comptime G: type, comptime Affine: type, bases: []const Affine, scalars: []const F) ?Affine {
+    if (comptime !isBn254Pair(F, G)) return null; // rule 1: MSM(Fr, Fr) and friends never reach the G1 kernels
+    std.debug.assert(bases.len == scalars.len);
+    if (bases.len < one_shot_min_points or !enabled()) return null;
+    const a = std.heap.page_allocator;
+    const pk = Packed.init(Affine, a, bases) catch return null;
+    defer pk.deinit(a);
+    const cfg = ffi.MsmConfig{ .expected_uses = 1 }; // no precompute table for a slice that is used once
+    var h: ffi.Bases = null;
+    if (ffi.zg_g1_bases_upload(pk.xy.ptr, pk.inf.ptr, bases.len, &cfg, &h) != ffi.OK) return null;
+    defer _ = ffi.zg_g1_bases_free(h); // rule 2: the handle dies with the call — nothing to go stale
+    var xy: [8]u64 = undefined;
+    var inf: u8 = 0;
+    if (ffi.zg_msm_g1(h, 0, bases.len, limbsOf(F, scalars), &xy, @ptrCast(&inf)) != ffi.OK) return null;
+    return affineFrom(Affine, &xy, inf);
+}
+
+/// ParallelMSM.compute (src/msm/mod.zig:588-653) on an arbitrary slice with several GPUs bound: one-shot sharded upload, one
+/// all-gather of 96-byte partials, device combine. null = run the Zig body.
+pub fn parallelMsmOneShot(comptime F: type, comptime G: type, comptime Affine: type, bases: []const Affine, scalars: []const F) ?Affine {
+    if (comptime !isBn254Pair(F, G)) return null;
+    if (!enabled() or n_devices < 2) return msmComputeOneShot(F, G, Affine, bases, scalars);
+    if (bases.len < one_shot_min_points * @as(usize, @intCast(n_devices))) return msmComputeOneShot(F, G, Affine, bases, scalars);
+    const a = std.heap.page_allocator;
+    const pk = Packed.init(Affine, a, bases) catch return null;
+    defer pk.deinit(a);
+    const cfg = ffi.MsmConfig{ .expected_uses = 1 };
+    var h: ffi.ShardedBases = null;
+    if (ffi.zg_g1_bases_upload_sharded(pk.xy.ptr, pk.inf.ptr, bases.len, &cfg, &h) != ffi.OK) return null;
+    defer _ = ffi.zg_g1_sbases_free(h);
+    var xy: [8]u64 = undefined;
+    var inf: u8 = 0;
+    if (ffi.zg_msm_g1_sharded(h, bases.len, limbsOf(F, scalars), &xy, @ptrCast(&inf)) != ffi.OK) return null;
+    return affineFrom(Affine, &xy, inf);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// poly: EqPolynomial.evalsSliceWithScaling, DensePolynomial.bindLow / bindFirst / evaluate (src/poly/mod.zig). Fr only:
+// callers gate with `comptime gpu.isBn254Scalar(F)`.
 // ---------------------------------------------------------------------------------------------------------------
 pub fn eqTable(comptime F: type, allocator: std.mem.Allocator, r: []const F, scaling_factor: ?F) ![]F {
     const result = try allocator.alloc(F, @as(usize, 1) << @intCast(r.len));
     errdefer allocator.free(result);
-    const sc: ?*const [4]u64 = if (scaling_factor) |*s| &s.limbs else null;
+    const sc: ?[*]const u64 = if (scaling_factor) |*s| &s.limbs else null;
     if (ffi.zg_fr_eq_table(limbsOf(F, r), r.len, sc, @ptrCast(result.ptr)) != ffi.OK) return Error.GpuFailure;
     return result;
 }
@@ -155,48 +337,77 @@ pub fn denseEvaluate(comptime F: type, evaluations: []const F, point: []const F)
     return out;
 }
 
+/// DensePolynomial.scale (:112-126)
+pub fn scale(comptime F: type, allocator: std.mem.Allocator, evaluations: []const F, scalar: F) ![]F {
+    const out = try allocator.alloc(F, evaluations.len);
+    errdefer allocator.free(out);
+    if (ffi.zg_fr_scale(limbsOf(F, evaluations), evaluations.len, &scalar.limbs, @ptrCast(out.ptr)) != ffi.OK) return Error.GpuFailure;
+    return out;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Sumcheck(F).Prover as a device-resident session (src/subprotocols/mod.zig:55-133). The table stays in HBM; per round two
 // field elements come back and one challenge goes in, so any host transcript (src/transcripts) keeps working unchanged.
+// With several GPUs bound the table is sharded over them (zg_sumcheck_*_sharded): same messages, bit for bit.
 // ---------------------------------------------------------------------------------------------------------------
 pub fn SumcheckSession(comptime F: type) type {
     return struct {
         const Self = @This();
-        handle: ffi.Session,
+        handle: ffi.Session = null,
+        sharded: ffi.ShardedSession = null,
 
         pub fn open(evaluations: []const F, layout: c_int) Error!Self {
-            var s: ffi.Session = null;
-            if (ffi.zg_sumcheck_open(limbsOf(F, evaluations), evaluations.len, layout, &s) != ffi.OK) return Error.GpuFailure;
-            return .{ .handle = s };
+            var self: Self = .{};
+            if (!enabled()) return Error.GpuFailure;
+            if (n_devices > 1) {
+                if (ffi.zg_sumcheck_open_sharded(limbsOf(F, evaluations), evaluations.len, layout, &self.sharded) != ffi.OK) return Error.GpuFailure;
+            } else {
+                if (ffi.zg_sumcheck_open(limbsOf(F, evaluations), evaluations.len, layout, &self.handle) != ffi.OK) return Error.GpuFailure;
+            }
+            return self;
         }
         /// nextRound (:69-109): coefficients [g(0), g(1) - g(0)]
         pub fn roundCoeffs(self: *Self) Error![2]F {
             var g0: F = undefined;
             var g1: F = undefined;
-            if (ffi.zg_sumcheck_round_sums(self.handle, &g0.limbs, &g1.limbs) != ffi.OK) return Error.GpuFailure;
+            const rc = if (self.sharded != null)
+                ffi.zg_sumcheck_round_sums_sharded(self.sharded, &g0.limbs, &g1.limbs)
+            else
+                ffi.zg_sumcheck_round_sums(self.handle, &g0.limbs, &g1.limbs);
+            if (rc != ffi.OK) return Error.GpuFailure;
             return .{ g0, g1.sub(g0) };
         }
         /// receiveChallenge (:112-122)
         pub fn bind(self: *Self, challenge: F) Error!void {
-            if (ffi.zg_sumcheck_bind(self.handle, &challenge.limbs) != ffi.OK) return Error.GpuFailure;
+            const rc = if (self.sharded != null)
+                ffi.zg_sumcheck_bind_sharded(self.sharded, &challenge.limbs)
+            else
+                ffi.zg_sumcheck_bind(self.handle, &challenge.limbs);
+            if (rc != ffi.OK) return Error.GpuFailure;
         }
         pub fn len(self: *const Self) usize {
-            return ffi.zg_sumcheck_len(self.handle);
+            return if (self.sharded != null) ffi.zg_sumcheck_len_sharded(self.sharded) else ffi.zg_sumcheck_len(self.handle);
         }
         /// getFinalEval (:130-133)
         pub fn finalEval(self: *Self) Error!F {
             var out: F = undefined;
-            if (ffi.zg_sumcheck_final(self.handle, &out.limbs) != ffi.OK) return Error.GpuFailure;
+            const rc = if (self.sharded != null)
+                ffi.zg_sumcheck_final_sharded(self.sharded, &out.limbs)
+            else
+                ffi.zg_sumcheck_final(self.handle, &out.limbs);
+            if (rc != ffi.OK) return Error.GpuFailure;
             return out;
         }
-        /// materialise the current table for callers that index prover.polynomial.evaluations directly (:79-92,126,132)
+        /// materialise the current table for callers that index prover.polynomial.evaluations directly (:79-92,126,132);
+        /// single-device sessions only
         pub fn read(self: *Self, out: []F) Error!void {
             std.debug.assert(out.len == self.len());
-            if (ffi.zg_sumcheck_read(self.handle, @ptrCast(out.ptr)) != ffi.OK) return Error.GpuFailure;
+            if (self.handle == null or ffi.zg_sumcheck_read(self.handle, @ptrCast(out.ptr)) != ffi.OK) return Error.GpuFailure;
         }
         pub fn close(self: *Self) void {
-            _ = ffi.zg_sumcheck_close(self.handle);
-            self.handle = null;
+            if (self.handle != null) _ = ffi.zg_sumcheck_close(self.handle);
+            if (self.sharded != null) _ = ffi.zg_sumcheck_close_sharded(self.sharded);
+            self.* = .{};
         }
     };
 }
@@ -211,7 +422,7 @@ pub fn runSumcheck(comptime F: type, allocator: std.mem.Allocator, evaluations: 
     var claim: F = undefined;
     var final_eval: F = undefined;
     var result: u8 = 0;
-    const rc = ffi.zg_run_sumcheck(limbsOf(F, evaluations), evaluations.len, &claim.limbs, @ptrCast(rounds.ptr), @ptrCast(challenges.ptr), &final_eval.limbs, &result);
+    const rc = ffi.zg_run_sumcheck(limbsOf(F, evaluations), evaluations.len, &claim.limbs, @ptrCast(rounds.ptr), @ptrCast(challenges.ptr), &final_eval.limbs, @ptrCast(&result));
     if (rc == ffi.ERR_VERIFY) return Error.SumcheckVerificationFailed;
     if (rc != ffi.OK) return Error.GpuFailure;
     return .{ .claim = claim, .rounds = rounds, .challenges = challenges, .final_eval = final_eval, .result = result != 0 };

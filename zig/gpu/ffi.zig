@@ -1,53 +1,104 @@
-//! extern declarations of libzolt_gpu.so (include/zolt_gpu.h), for Zolt's src/gpu/ffi.zig.
+//! extern declarations of libzolt_gpu.so, for Zolt's src/gpu/ffi.zig.
+//! GENERATED from include/zolt_gpu.h by tools/gen_zig_ffi.py — do not edit; tests/test_abi_and_host.py holds the two together.
 //! COMPILE-UNVERIFIED: the build image has no Zig toolchain (Zig >= 0.14 syntax, build.zig.zon:5 of the reference).
 //! The same ABI is exercised for real by zolt_amd/host/zolt_host.hpp (C++) and zolt_amd/lib.py (ctypes).
 //!
 //! Field elements cross the boundary as they are: BN254Scalar / BN254BaseField are `struct { limbs: [4]u64 }`
 //! (src/field/mod.zig:131,583-584), Montgomery form, so `[]const F` is passed as `[*]const u64` via @ptrCast.
 
-pub const Bases = ?*opaque {};
-pub const Session = ?*opaque {};
+pub const Bases = ?*opaque {}; // zg_bases_t
+pub const Session = ?*opaque {}; // zg_sc_t
+pub const ShardedBases = ?*opaque {}; // zg_sbases_t
+pub const ShardedSession = ?*opaque {}; // zg_ssc_t
 
-pub const MsmConfig = extern struct { window_bits: c_int = 0, precompute_levels: c_int = 0 };
+pub const MsmConfig = extern struct { window_bits: c_int = 0, precompute_levels: c_int = 0, expected_uses: c_int = 0 };
 
 pub const OK: c_int = 0;
-pub const ERR_VERIFY: c_int = 5; // zg_run_sumcheck: the toy verifier rejected (error.SumcheckVerificationFailed)
-pub const SC_HIGH_HALF: c_int = 0; // DensePolynomial.bindFirst layout (src/poly/mod.zig:128-149)
-pub const SC_LOW_PAIR: c_int = 1; // DensePolynomial.bindLow layout (src/poly/mod.zig:160-175)
+pub const ERR_INVALID: c_int = 1;
+pub const ERR_HIP: c_int = 2;
+pub const ERR_NOMEM: c_int = 3;
+pub const ERR_NO_DEVICE: c_int = 4;
+pub const ERR_VERIFY: c_int = 5;
+pub const FIELD_FR: c_int = 0;
+pub const FIELD_FP: c_int = 1;
+pub const OP_MUL: c_int = 0;
+pub const OP_ADD: c_int = 1;
+pub const OP_SUB: c_int = 2;
+pub const OP_NEG: c_int = 3;
+pub const OP_SQR: c_int = 4;
+pub const OP_INV: c_int = 5;
+pub const OP_FROM_MONT: c_int = 6;
+pub const OP_TO_MONT: c_int = 7;
+pub const SC_HIGH_HALF: c_int = 0;
+pub const SC_LOW_PAIR: c_int = 1;
 
 pub extern fn zg_init(device: c_int) c_int;
+pub extern fn zg_init_devices(n_devices: c_int) c_int;
+pub extern fn zg_n_devices() c_int;
 pub extern fn zg_shutdown() void;
 pub extern fn zg_last_error() [*:0]const u8;
+pub extern fn zg_version() [*:0]const u8;
 pub extern fn zg_device_count() c_int;
-
-// bases (the SRS): uploaded once, resident for the run (SetupParams.powers_of_tau_g1, src/poly/commitment/mod.zig:122-140)
-pub extern fn zg_g1_bases_upload(xy: [*]const u64, inf: ?[*]const u8, n: usize, cfg: ?*const MsmConfig, out: *Bases) c_int;
+pub extern fn zg_dev_alloc(bytes: usize, dptr: *?*anyopaque) c_int;
+pub extern fn zg_dev_free(dptr: ?*anyopaque) c_int;
+pub extern fn zg_memcpy_h2d(dst_dev: ?*anyopaque, src_host: ?*const anyopaque, bytes: usize) c_int;
+pub extern fn zg_memcpy_d2h(dst_host: ?*anyopaque, src_dev: ?*const anyopaque, bytes: usize) c_int;
+pub extern fn zg_sync() c_int;
+pub extern fn zg_field_op(field: c_int, op: c_int, a: ?[*]const u64, b: ?[*]const u64, out: ?[*]u64, n: usize) c_int;
+pub extern fn zg_fr_scale(a: ?[*]const u64, n: usize, s: *const [4]u64, out: ?[*]u64) c_int;
+pub extern fn zg_g1_bases_upload(xy: ?[*]const u64, inf: ?[*]const u8, n: usize, cfg: ?*const MsmConfig, out: *Bases) c_int;
+pub extern fn zg_g1_bases_upload_dev(d_xy: ?[*]const u64, d_inf: ?[*]const u8, n: usize, cfg: ?*const MsmConfig, stream: ?*anyopaque, out: *Bases) c_int;
 pub extern fn zg_g1_bases_free(b: Bases) c_int;
 pub extern fn zg_g1_bases_len(b: Bases) usize;
 pub extern fn zg_g1_bases_plan(b: Bases, window_bits: ?*c_int, windows: ?*c_int, precompute_levels: ?*c_int) c_int;
-
-// MSM(F,G).compute / BatchMSM.compute / scalarMul loops / curve checks (src/msm/mod.zig:355-565)
-pub extern fn zg_msm_g1(b: Bases, off: usize, n: usize, scalars: [*]const u64, out_xy: *[8]u64, out_inf: *u8) c_int;
-pub extern fn zg_msm_g1_batch(b: Bases, n: usize, batches: [*]const [*]const u64, k: usize, out_xy: [*]u64, out_inf: [*]u8) c_int;
-pub extern fn zg_g1_scalar_mul_batch(xy: [*]const u64, inf: ?[*]const u8, scalars: [*]const u64, n: usize, out_xy: [*]u64, out_inf: [*]u8) c_int;
-pub extern fn zg_g1_is_on_curve_batch(xy: [*]const u64, inf: ?[*]const u8, n: usize, out: [*]u8) c_int;
-
-// HyperKZG.open / batchOpen (src/poly/commitment/mod.zig:261-324, 607-732)
-pub extern fn zg_hyperkzg_open(srs: Bases, evals: [*]const u64, n: usize, point: [*]const u64, num_vars: usize, value: *const [4]u64, q_xy: [*]u64, q_inf: [*]u8, final_eval: *[4]u64) c_int;
-
-// poly (src/poly/mod.zig:73-92, 128-175, 252-290) and Spartan's combine (src/zkvm/spartan/mod.zig:191-199)
-pub extern fn zg_fr_dense_evaluate(evals: [*]const u64, num_vars: usize, point: [*]const u64, out: *[4]u64) c_int;
-pub extern fn zg_fr_eq_table(r: [*]const u64, v: usize, scale: ?*const [4]u64, out: [*]u64) c_int;
-pub extern fn zg_fr_bind_low(table: [*]u64, len: usize, r: *const [4]u64) c_int;
-pub extern fn zg_fr_bind_high(table: [*]const u64, len: usize, r: *const [4]u64, out: [*]u64) c_int;
-pub extern fn zg_fr_spartan_combine(eq: [*]const u64, az: [*]const u64, bz: [*]const u64, cz: [*]const u64, n: usize, out: [*]u64) c_int;
-
-// Sumcheck(F).Prover as a device-resident session; runSumcheck with the toy verifier (src/subprotocols/mod.zig:55-133, 302-354)
-pub extern fn zg_sumcheck_open(evals: [*]const u64, len: usize, layout: c_int, s: *Session) c_int;
+pub extern fn zg_msm_g1(b: Bases, off: usize, n: usize, scalars_mont: ?[*]const u64, out_xy: *[8]u64, out_inf: ?[*]u8) c_int;
+pub extern fn zg_msm_g1_dev(b: Bases, off: usize, n: usize, d_scalars_mont: ?[*]const u64, stream: ?*anyopaque, out_xy: *[8]u64, out_inf: ?[*]u8) c_int;
+pub extern fn zg_msm_g1_dev_async(b: Bases, off: usize, n: usize, d_scalars_mont: ?[*]const u64, stream: ?*anyopaque, d_out_xy: ?[*]u64, d_out_inf: ?[*]u8) c_int;
+pub extern fn zg_msm_g1_batch(b: Bases, n: usize, scalar_batches: ?[*]const ?[*]const u64, k: usize, out_xy: ?[*]u64, out_inf: ?[*]u8) c_int;
+pub extern fn zg_msm_g1_batch_dev(b: Bases, n: usize, d_scalars_mont: ?[*]const u64, k: usize, stream: ?*anyopaque, d_out9: ?[*]u64) c_int;
+pub extern fn zg_msm_g1_partial_dev(b: Bases, off: usize, n: usize, d_scalars_mont: ?[*]const u64, stream: ?*anyopaque, d_out_jac: ?[*]u64) c_int;
+pub extern fn zg_msm_g1_partial_fast_dev(b: Bases, off: usize, n: usize, d_scalars_mont: ?[*]const u64, stream: ?*anyopaque, d_out_jac: ?[*]u64) c_int;
+pub extern fn zg_g1_combine_partials_dev(d_partials_jac: ?[*]const u64, k: usize, stream: ?*anyopaque, out_xy: *[8]u64, out_inf: ?[*]u8) c_int;
+pub extern fn zg_g1_combine_partials_dev_async(d_partials_jac: ?[*]const u64, k: usize, stream: ?*anyopaque, d_out_xy: ?[*]u64, d_out_inf: ?[*]u8) c_int;
+pub extern fn zg_g1_is_on_curve_batch(xy: ?[*]const u64, inf: ?[*]const u8, n: usize, out: ?[*]u8) c_int;
+pub extern fn zg_g1_affine_add_batch(a_xy: ?[*]const u64, a_inf: ?[*]const u8, b_xy: ?[*]const u64, b_inf: ?[*]const u8, n: usize, out_xy: ?[*]u64, out_inf: ?[*]u8) c_int;
+pub extern fn zg_g1_scalar_mul_batch(xy: ?[*]const u64, inf: ?[*]const u8, scalars_mont: ?[*]const u64, n: usize, out_xy: ?[*]u64, out_inf: ?[*]u8) c_int;
+pub extern fn zg_hyperkzg_open(srs: Bases, evals: ?[*]const u64, n_evals: usize, point: ?[*]const u64, num_vars: usize, value: *const [4]u64, q_xy: ?[*]u64, q_inf: ?[*]u8, final_eval: *[4]u64) c_int;
+pub extern fn zg_hyperkzg_batch_open(srs: Bases, polys: ?[*]const ?[*]const u64, lens: ?[*]const usize, k: usize, point: ?[*]const u64, num_vars: usize, q_xy: ?[*]u64, q_inf: ?[*]u8, n_quot: ?*usize, evaluations: ?[*]u64, final_eval: *[4]u64, gamma: *[4]u64) c_int;
+pub extern fn zg_fr_eq_table(r: ?[*]const u64, v: usize, scale: ?[*]const u64, out: ?[*]u64) c_int;
+pub extern fn zg_fr_eq_table_dev(r_host: ?[*]const u64, v: usize, scale_host: ?[*]const u64, d_out: ?[*]u64, stream: ?*anyopaque) c_int;
+pub extern fn zg_fr_dense_evaluate(evals: ?[*]const u64, num_vars: usize, point: ?[*]const u64, out: *[4]u64) c_int;
+pub extern fn zg_fr_bind_low(table: ?[*]u64, len: usize, r: *const [4]u64) c_int;
+pub extern fn zg_fr_bind_high(table: ?[*]const u64, len: usize, r: *const [4]u64, out: ?[*]u64) c_int;
+pub extern fn zg_fr_spartan_combine(eq: ?[*]const u64, az: ?[*]const u64, bz: ?[*]const u64, cz: ?[*]const u64, n: usize, out: ?[*]u64) c_int;
+pub extern fn zg_fr_spartan_combine_dev(d_eq: ?[*]const u64, d_az: ?[*]const u64, d_bz: ?[*]const u64, d_cz: ?[*]const u64, n: usize, d_out: ?[*]u64, stream: ?*anyopaque) c_int;
+pub extern fn zg_sumcheck_open(evals: ?[*]const u64, len: usize, layout: c_int, s: *Session) c_int;
+pub extern fn zg_sumcheck_open_dev(d_evals: ?[*]const u64, len: usize, layout: c_int, stream: ?*anyopaque, s: *Session) c_int;
+pub extern fn zg_sumcheck_open_spartan_dev(r: ?[*]const u64, v: usize, scale: ?[*]const u64, d_az: ?[*]const u64, d_bz: ?[*]const u64, d_cz: ?[*]const u64, layout: c_int, stream: ?*anyopaque, s: *Session) c_int;
 pub extern fn zg_sumcheck_round_sums(s: Session, g0: *[4]u64, g1: *[4]u64) c_int;
 pub extern fn zg_sumcheck_bind(s: Session, r: *const [4]u64) c_int;
 pub extern fn zg_sumcheck_len(s: Session) usize;
 pub extern fn zg_sumcheck_final(s: Session, out: *[4]u64) c_int;
-pub extern fn zg_sumcheck_read(s: Session, out_table: [*]u64) c_int;
+pub extern fn zg_sumcheck_read(s: Session, out_table: ?[*]u64) c_int;
+pub extern fn zg_sumcheck_round_sums_dev(s: Session, d_out8: ?[*]u64) c_int;
+pub extern fn zg_sumcheck_read_dev(s: Session, d_out_table: ?[*]u64) c_int;
 pub extern fn zg_sumcheck_close(s: Session) c_int;
-pub extern fn zg_run_sumcheck(evals: [*]const u64, len: usize, claim: *[4]u64, rounds: [*]u64, challenges: [*]u64, final_eval: *[4]u64, result: *u8) c_int;
+pub extern fn zg_run_sumcheck_dev(d_evals: ?[*]const u64, len: usize, stream: ?*anyopaque, claim: *[4]u64, rounds: ?[*]u64, challenges: ?[*]u64, final_eval: *[4]u64, result: ?[*]u8) c_int;
+pub extern fn zg_run_sumcheck(evals: ?[*]const u64, len: usize, claim: *[4]u64, rounds: ?[*]u64, challenges: ?[*]u64, final_eval: *[4]u64, result: ?[*]u8) c_int;
+pub extern fn zg_shard_bounds(n: usize, shards: c_int, shard: c_int, start: ?*usize, len: ?*usize) c_int;
+pub extern fn zg_g1_bases_upload_sharded(xy: ?[*]const u64, inf: ?[*]const u8, n: usize, cfg: ?*const MsmConfig, out: *ShardedBases) c_int;
+pub extern fn zg_g1_sbases_free(sb: ShardedBases) c_int;
+pub extern fn zg_g1_sbases_len(sb: ShardedBases) usize;
+pub extern fn zg_g1_sbases_shards(sb: ShardedBases) c_int;
+pub extern fn zg_g1_sbases_exchange(sb: ShardedBases) c_int;
+pub extern fn zg_g1_sbases_shard(sb: ShardedBases, shard: c_int, device: ?*c_int, start: ?*usize, len: ?*usize) c_int;
+pub extern fn zg_msm_g1_sharded(sb: ShardedBases, n: usize, scalars_mont: ?[*]const u64, out_xy: *[8]u64, out_inf: ?[*]u8) c_int;
+pub extern fn zg_msm_g1_sharded_dev(sb: ShardedBases, n: usize, d_scalars_per_shard: ?[*]const ?[*]const u64, out_xy: *[8]u64, out_inf: ?[*]u8) c_int;
+pub extern fn zg_msm_g1_batch_sharded(sb: ShardedBases, n: usize, scalar_batches: ?[*]const ?[*]const u64, k: usize, out_xy: ?[*]u64, out_inf: ?[*]u8) c_int;
+pub extern fn zg_sumcheck_open_sharded(evals: ?[*]const u64, len: usize, layout: c_int, s: *ShardedSession) c_int;
+pub extern fn zg_sumcheck_shards(s: ShardedSession) c_int;
+pub extern fn zg_sumcheck_len_sharded(s: ShardedSession) usize;
+pub extern fn zg_sumcheck_round_sums_sharded(s: ShardedSession, g0: *[4]u64, g1: *[4]u64) c_int;
+pub extern fn zg_sumcheck_bind_sharded(s: ShardedSession, r: *const [4]u64) c_int;
+pub extern fn zg_sumcheck_final_sharded(s: ShardedSession, out: *[4]u64) c_int;
+pub extern fn zg_sumcheck_close_sharded(s: ShardedSession) c_int;

@@ -75,7 +75,7 @@ class MSM:
         bases_xy = np.ascontiguousarray(bases_xy, dtype=np.uint64).reshape(-1, 8)
         scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
         assert bases_xy.shape[0] == scalars.shape[0]  # std.debug.assert(bases.len == scalars.len), :359
-        b = lib.Bases.upload(bases_xy, bases_inf)
+        b = lib.Bases.upload(bases_xy, bases_inf, expected_uses=1)  # a one-shot slice: no precompute table
         try:
             return b.msm(scalars)
         finally:
@@ -87,6 +87,54 @@ class MSM:
         out, inf = lib.g1_scalar_mul_batch(np.asarray(base_xy).reshape(1, 8), np.array([base_inf], dtype=np.uint8),
                                            np.asarray(scalar).reshape(1, 4))
         return out[0], int(inf[0])
+
+
+class AffinePoint:
+    """AffinePoint(G) group law (src/msm/mod.zig:15-140) on (xy[8], inf) pairs."""
+
+    @staticmethod
+    def add(a_xy, a_inf, b_xy, b_inf):
+        """AffinePoint.add (:74-103) -> (xy, inf)"""
+        out, inf = lib.g1_affine_add_batch(np.asarray(a_xy).reshape(1, 8), np.array([a_inf], dtype=np.uint8),
+                                           np.asarray(b_xy).reshape(1, 8), np.array([b_inf], dtype=np.uint8))
+        return out[0], int(inf[0])
+
+    @staticmethod
+    def double(xy, inf=0):
+        """AffinePoint.double (:118-138) = add(p, p)"""
+        return AffinePoint.add(xy, inf, xy, inf)
+
+    @staticmethod
+    def isOnCurve(xy, inf=0):
+        return bool(lib.g1_is_on_curve_batch(np.asarray(xy).reshape(1, 8), np.array([inf], dtype=np.uint8))[0])
+
+
+class ParallelMSM:
+    """ParallelMSM.compute (src/msm/mod.zig:588-653) in the reference's process model: ONE process, its workers = the GPUs bound
+    by lib.init_devices (contiguous chunks of ceil(n / S), one partial per GPU, RCCL all-gather, serial combine on device 0)."""
+
+    @staticmethod
+    def compute(bases_xy, scalars, bases_inf=None, num_threads=None):
+        bases_xy = np.ascontiguousarray(bases_xy, dtype=np.uint64).reshape(-1, 8)
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        assert bases_xy.shape[0] == scalars.shape[0]
+        sb = lib.ShardedBases.upload(bases_xy, bases_inf, precompute_levels=1)
+        try:
+            return sb.msm(scalars)
+        finally:
+            sb.free()
+
+
+class ParallelBatchMSM:
+    """ParallelBatchMSM.compute (src/msm/mod.zig:683-748) / HyperKZG.batchCommit sharded: k partials per GPU, one exchange."""
+
+    @staticmethod
+    def compute(bases_xy, scalar_batches, bases_inf=None):
+        sb = lib.ShardedBases.upload(bases_xy, bases_inf, precompute_levels=1)
+        try:
+            return sb.msm_batch(scalar_batches)
+        finally:
+            sb.free()
 
 
 class BatchMSM:
@@ -380,6 +428,22 @@ class EqPolynomial:
         """EqPolynomial.evals (src/poly/mod.zig:240-242): 2^n table, index MSB <-> r[0]."""
         return lib.fr_eq_table(self.r)
 
+    def evaluate(self, x):
+        """EqPolynomial.evaluate (src/poly/mod.zig:214-227): eq(x, r) — host scalar code, like the reference's."""
+        return EqPolynomial.mle(self.r, x)
+
+    @staticmethod
+    def mle(r, x):
+        """EqPolynomial.mle (src/poly/mod.zig:311-321): prod_i (r_i x_i + (1 - r_i)(1 - x_i))."""
+        r = np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4)
+        x = np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, 4)
+        assert r.shape[0] == x.shape[0]  # std.debug.assert(r.len == x.len)
+        acc = 1
+        for ri, xi in zip(r, x):
+            a, b = fr_to_int(ri), fr_to_int(xi)
+            acc = acc * ((a * b + (1 - a) * (1 - b)) % R_MOD) % R_MOD
+        return fr_from_int(acc)
+
     @staticmethod
     def evalsSliceWithScaling(r, scaling_factor=None):
         return lib.fr_eq_table(np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4), scaling_factor)
@@ -401,6 +465,15 @@ class DensePolynomial:
         point = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1, 4)
         assert point.shape[0] == self.num_vars
         return lib.fr_dense_evaluate(self.evaluations, point)
+
+    def add(self, other):
+        """DensePolynomial.add (src/poly/mod.zig:94-110) -> new polynomial"""
+        assert self.num_vars == other.num_vars
+        return DensePolynomial(lib.field_op(lib.FR, lib.OP_ADD, self.evaluations, other.evaluations))
+
+    def scale(self, scalar):
+        """DensePolynomial.scale (src/poly/mod.zig:112-126) -> new polynomial"""
+        return DensePolynomial(lib.fr_scale(self.evaluations, scalar))
 
     def bindFirst(self, value):
         """high-half fold into a NEW polynomial (src/poly/mod.zig:128-149)."""

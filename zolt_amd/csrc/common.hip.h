@@ -3,15 +3,36 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <mutex>
 #include <string>
 
-#include "../../include/zolt_gpu.h"
+#include "../../include/zolt_gpu_internal.h"
 
 namespace zg {
 
+static constexpr int ZG_MAX_DEVICES = 16;
+
 void set_error(const std::string &msg);
 int ensure_init();          // ZG_OK or ZG_ERR_NO_DEVICE / ZG_ERR_HIP
-hipStream_t lib_stream();   // the library's own stream (valid after ensure_init)
+int primary_device();       // the device zg_init / zg_init_devices bound this process to (valid after ensure_init)
+int current_device();       // the calling thread's HIP device
+hipStream_t lib_stream();   // the library's own stream on the calling thread's CURRENT device (created on first use)
+
+// HIP's current device is per host thread (a fresh std.Thread worker starts on device 0) and a handle's memory lives on
+// the device it was created on: every entry point pins the calling thread to the right device for its duration.
+struct DeviceGuard {
+    int prev = -1, dev = -1;
+    explicit DeviceGuard(int d) : dev(d) {
+        if (d < 0) return;
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != d) (void)hipSetDevice(d);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+    ~DeviceGuard() {
+        if (dev >= 0 && prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+    }
+};
 
 inline hipStream_t pick_stream(void *s) { return s ? reinterpret_cast<hipStream_t>(s) : lib_stream(); }
 
@@ -30,7 +51,33 @@ inline hipStream_t pick_stream(void *s) { return s ? reinterpret_cast<hipStream_
         if (_r != ZG_OK) return _r;   \
     } while (0)
 
-#define ZG_INIT() ZG_TRY(zg::ensure_init())
+// Multi-device code (sharded.hip) runs whole public entry points on another device: inside a DeviceScope the calling thread
+// sits on `dev` AND primary_device() reports `dev`, so the ZG_INIT() of every nested entry point keeps it there.
+void set_device_override(int dev);  // thread-local; -1 = none
+int device_override();
+struct DeviceScope {
+    int prev_override;
+    DeviceGuard guard;
+    explicit DeviceScope(int d) : prev_override(device_override()), guard(d) { set_device_override(d); }
+    ~DeviceScope() { set_device_override(prev_override); }
+};
+
+// every extern "C" compute entry point starts with this: library initialised, thread on the primary device
+#define ZG_INIT()                \
+    ZG_TRY(zg::ensure_init());   \
+    zg::DeviceGuard _zg_primary_guard(zg::primary_device())
+
+// a function attribute (dynamic LDS limit) belongs to the kernel's code object on ONE device: set it once per device
+struct PerDeviceOnce {
+    std::once_flag flag[ZG_MAX_DEVICES];
+    hipError_t err[ZG_MAX_DEVICES];
+    template <class F> hipError_t run(F f) {
+        int d = current_device();
+        if (d < 0 || d >= ZG_MAX_DEVICES) return hipErrorInvalidDevice;
+        std::call_once(flag[d], [&] { err[d] = f(); });
+        return err[d];
+    }
+};
 
 // optional per-kernel HIP-event timing (bench.py's roofline leg); ids are ZG_PROF_*
 void prof_begin(int id, hipStream_t st);
@@ -58,9 +105,28 @@ struct Scratch {
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// Declared AFTER the Scratch objects of a host-pointer entry point (so it is destroyed BEFORE them): an early error return
+// then waits for the work already enqueued on `st` before the scratch buffers go back to the shared cache.
+struct SyncGuard {
+    hipStream_t st;
+    bool armed = true;
+    explicit SyncGuard(hipStream_t s) : st(s) {}
+    SyncGuard(const SyncGuard &) = delete;
+    SyncGuard &operator=(const SyncGuard &) = delete;
+    ~SyncGuard() { if (armed) (void)hipStreamSynchronize(st); }
+    void dismiss() { armed = false; }
+};
+
 static inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+int bound_devices();      // devices 0..n-1 bound by zg_init_devices (1 in the one-GPU-per-process model)
+void sharded_shutdown();  // sharded.hip: drop communicators / exchange buffers (called by zg_shutdown)
 
 // msm.hip: zg_msm_g1_batch_dev that also fuses zero-padded rows on wide-window handles (HyperKZG.open's long levels)
 int msm_batch_dev_wide(zg_bases_t b, size_t n, const uint64_t *d_scalars, size_t k, hipStream_t st, uint64_t *d_out9);
+// msm.hip, for sharded.hip: k un-normalised Jacobian partials of this device's shard; the combine of gathered partials
+int msm_batch_partials_dev(zg_bases_t b, size_t n, const uint64_t *d_scalars, size_t k, hipStream_t st, uint64_t *d_out12);
+int msm_combine_batch_enqueue(const uint64_t *d_partials, size_t ranks, size_t rank_stride, size_t k, hipStream_t st, uint64_t *d_out9);
+int bases_device(zg_bases_t b);
 
 }  // namespace zg

@@ -14,7 +14,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "inv_table.hip.h"
 
 namespace zg {
 
@@ -25,7 +24,6 @@ typedef uint64_t u64;
 
 // ---- field parameters (u32 limbs, little-endian); values from field/mod.zig:16-41,51-75
 struct FrParams {
-    static __device__ __forceinline__ const uint32_t *kaliski_tab() { return KALISKI_TAB_FR; }
     static constexpr u32 MOD[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u,
                                    0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
     static constexpr u32 ONE[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u,
@@ -38,7 +36,6 @@ struct FrParams {
     static constexpr u32 MINV30 = 0x10000001u;  // MOD^-1 mod 2^30 (fe_inv_safegcd)
 };
 struct FpParams {
-    static __device__ __forceinline__ const uint32_t *kaliski_tab() { return KALISKI_TAB_FP; }
     static constexpr u32 MOD[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u,
                                    0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
     static constexpr u32 ONE[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u,
@@ -306,130 +303,6 @@ ZG_DEV Fe<P> fe_inv_fast(const Fe<P> &a) {
 #pragma unroll
     for (int i = 0; i < 8; i++) r3.l[i] = P::R3[i];
     return fe_mul(x, r3);
-}
-
-// ---- Kaliski almost-inverse: the same shift/subtract loop without modular halvings (r and s only grow by
-// shifts and adds, < 2*MOD), about half the instructions of fe_inv_fast; the 2^k it leaves behind
-// (254 <= k <= 508) is removed together with the Montgomery factors by one product with a tabulated constant.
-ZG_DEV void limbs_shl1(u32 *x) {
-#pragma unroll
-    for (int i = 7; i > 0; i--) x[i] = (x[i] << 1) | (x[i - 1] >> 31);
-    x[0] <<= 1;
-}
-ZG_DEV void limbs_add(u32 *a, const u32 *b) {
-    u32 carry = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        u64 t = (u64)a[i] + b[i] + carry;
-        a[i] = (u32)t;
-        carry = (u32)(t >> 32);
-    }
-}
-ZG_DEV bool limbs_gt(const u32 *a, const u32 *b) {  // a > b
-    bool gt = false;
-#pragma unroll
-    for (int i = 0; i < 8; i++) gt = (a[i] > b[i]) || (a[i] == b[i] && gt);
-    return gt;
-}
-ZG_DEV bool limbs_nonzero(const u32 *a) {
-    u32 o = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) o |= a[i];
-    return o != 0;
-}
-
-// multi-limb shifts by 1 <= t <= 31
-ZG_DEV void limbs_shr(u32 *x, u32 t) {
-#pragma unroll
-    for (int i = 0; i < 7; i++) x[i] = (x[i] >> t) | (x[i + 1] << (32 - t));
-    x[7] >>= t;
-}
-ZG_DEV void limbs_shl(u32 *x, u32 t) {
-#pragma unroll
-    for (int i = 7; i > 0; i--) x[i] = (x[i] << t) | (x[i - 1] >> (32 - t));
-    x[0] <<= t;
-}
-
-// Phase 1 of Kaliski's almost-inverse with the steps regrouped so that one loop iteration is one subtraction: u and v are
-// kept ODD (after a subtraction the difference is shifted right by ALL its trailing zeros at once, the partner
-// coefficient left by as many), so the original's "halve u" / "halve v" iterations disappear and ~180 iterations remain
-// instead of ~380; the u > v / v >= u cases share one straight-line body (difference, sum, selects) instead of four
-// branches. Same r and k as the textbook loop, step for step.
-template <class P>
-ZG_DEV Fe<P> fe_inv_kaliski(const Fe<P> &a) {
-    if (a.is_zero()) return Fe<P>::zero();
-    u32 u[8], v[8], r[8], s[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) { u[i] = P::MOD[i]; v[i] = a.l[i]; r[i] = 0; s[i] = 0; }
-    s[0] = 1;
-    u32 k = 0;
-    // make v odd (r = 0 doubles to 0): the textbook loop would spend one iteration per trailing zero here
-    while (!(v[0] & 1u)) {
-        u32 t = v[0] ? (u32)__builtin_ctz(v[0]) : 31u;
-        limbs_shr(v, t);
-        k += t;
-    }
-    for (;;) {
-        // d = u - v with borrow; both odd, so d is even
-        u32 d[8], borrow = 0, nz = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            u64 t = (u64)u[i] - v[i] - borrow;
-            d[i] = (u32)t;
-            borrow = (u32)(t >> 32) & 1u;
-            nz |= d[i];
-        }
-        if (nz == 0) {  // u == v (== gcd == 1): the textbook's last step  v = 0, s += r, r = 2r, k++
-            limbs_shl(r, 1);
-            k++;
-            break;
-        }
-        const bool ub = borrow == 0;  // u > v: the u-branch (u = (u-v)/2, r += s, s = 2s); else the mirrored v-branch
-        if (!ub) {                    // magnitude v - u = -(d)
-            u32 c = 1;
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                u64 t = (u64)(~d[i]) + c;
-                d[i] = (u32)t;
-                c = (u32)(t >> 32);
-            }
-        }
-        u32 sum[8], carry = 0;  // r + s: the new r (u-branch) or the new s (v-branch)
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            u64 t = (u64)r[i] + s[i] + carry;
-            sum[i] = (u32)t;
-            carry = (u32)(t >> 32);
-        }
-        // the other coefficient doubles once per halving of the difference
-        u32 oth[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) oth[i] = ub ? s[i] : r[i];
-        do {  // all trailing zeros of the difference (a second pass only if its low limb is zero)
-            u32 t = d[0] ? (u32)__builtin_ctz(d[0]) : 31u;
-            limbs_shr(d, t);
-            limbs_shl(oth, t);
-            k += t;
-        } while (!(d[0] & 1u));
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            u[i] = ub ? d[i] : u[i];
-            v[i] = ub ? v[i] : d[i];
-            r[i] = ub ? sum[i] : oth[i];
-            s[i] = ub ? oth[i] : sum[i];
-        }
-    }
-    // r = -(a^-1) 2^k mod MOD with r < 2 MOD
-    Fe<P> x;
-#pragma unroll
-    for (int i = 0; i < 8; i++) x.l[i] = r[i];
-    x = fe_reduce_once(x);
-    x = fe_neg(x);
-    const u32 *c = P::kaliski_tab() + 8 * (size_t)(k - 254u);
-    Fe<P> ck;
-#pragma unroll
-    for (int i = 0; i < 8; i++) ck.l[i] = c[i];
-    return fe_mul(x, ck);
 }
 
 // ---- Inversion by Bernstein-Yang division steps ("safegcd"), in the batched variable-time form popularised by libsecp256k1's

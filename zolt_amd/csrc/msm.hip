@@ -75,6 +75,7 @@ struct MsmPlan {
 
 struct zg_bases_s {
     size_t n = 0;
+    int device = -1;  // the HIP device the table and the workspaces live on
     zg::MsmPlan plan;
     char *d_table = nullptr;     // L * n * 64 B
     uint8_t *d_inf = nullptr;    // n B or null
@@ -1099,16 +1100,22 @@ __global__ void msm_identity_kernel(int mode, uint64_t *out_rec, uint8_t *out_in
     }
 }
 
-// ParallelMSM combine (msm/mod.zig:647-652): serial add of k Jacobian partials + toAffine
-__global__ void __launch_bounds__(64) msm_combine_kernel(const uint64_t *partials, uint32_t k, uint64_t *out_xy, uint8_t *out_inf) {
+// ParallelMSM combine (msm/mod.zig:647-652): serial add of k Jacobian partials + toAffine. Block j combines scalar vector j of
+// a sharded batch: rank i's record for it sits at partials + i * rank_stride + 12 * j (u64 units); its result record goes to
+// out_xy + j * rec_stride / out_inf + j * inf_stride.
+__global__ void __launch_bounds__(64) msm_combine_kernel(const uint64_t *partials, uint32_t k, uint32_t rank_stride, uint64_t *out_xy,
+                                                         uint8_t *out_inf, uint32_t rec_stride, uint32_t inf_stride) {
     // one wave = 16 quads of lanes: quad i folds partials i, i+16, ... (Jacobian -> lazy XYZZ), then a shuffle tree over the
     // quads, every addition by a quad (g1_29x4.hip.h); the group sum does not depend on the association order, and the
     // affine result is canonical
+    partials += 12 * (size_t)blockIdx.x;
+    out_xy += (size_t)rec_stride * blockIdx.x;
+    out_inf += (size_t)inf_stride * blockIdx.x;
     uint32_t lane = threadIdx.x, quad = lane >> 2, q = lane & 3;
     XYZZ29 acc = xyzz29_identity();
     for (uint32_t i = quad; i < k; i += 16) {
-        Fp X = fe_load<FpParams>(partials + 12 * i), Y = fe_load<FpParams>(partials + 12 * i + 4),
-           Z = fe_load<FpParams>(partials + 12 * i + 8);
+        const uint64_t *rec = partials + (size_t)rank_stride * i;
+        Fp X = fe_load<FpParams>(rec), Y = fe_load<FpParams>(rec + 4), Z = fe_load<FpParams>(rec + 8);
         if (!Z.is_zero()) {
             XYZZ29 p;
             F29 z = f29_from_fp(Z);
@@ -1152,6 +1159,53 @@ __global__ void __launch_bounds__(256) g1_scalar_mul_kernel(const uint64_t *xy, 
     bool isinf = xyzz_to_affine(acc, r);
     affine_store(out_xy + 8 * i, r);
     out_inf[i] = isinf ? 1 : 0;
+}
+
+// AffinePoint.add (msm/mod.zig:74-103) and, through add(p, p), AffinePoint.double (:118-138): the lambda formulas on canonical
+// Montgomery values, one inversion per pair (safegcd, the value of the reference's Fermat inverse)
+__global__ void __launch_bounds__(256) g1_affine_add_kernel(const uint64_t *a_xy, const uint8_t *a_inf, const uint64_t *b_xy,
+                                                            const uint8_t *b_inf, size_t n, uint64_t *out_xy, uint8_t *out_inf) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine a = affine_load(a_xy + 8 * i), b = affine_load(b_xy + 8 * i), r;
+    bool ai = a_inf && a_inf[i], bi = b_inf && b_inf[i], ri = false;
+    if (ai) {  // :75-76
+        r = b;
+        ri = bi;
+    } else if (bi) {
+        r = a;
+    } else {
+        Fp num, den;
+        bool dbl = false;
+        if (a.x.eq(b.x)) {  // :79-88
+            if (a.y.eq(fe_neg(b.y))) ri = true;
+            else if (a.y.eq(b.y)) dbl = true;
+        }
+        if (!ri) {
+            if (dbl) {  // :118-138: lambda = 3 x^2 / 2 y; y == 0 -> identity
+                Fp xx = fe_sqr(a.x);
+                num = fe_add(fe_add(xx, xx), xx);
+                den = fe_add(a.y, a.y);
+                if (a.y.is_zero()) ri = true;
+            } else {  // :90-93: lambda = (y2 - y1) / (x2 - x1)
+                num = fe_sub(b.y, a.y);
+                den = fe_sub(b.x, a.x);
+            }
+        }
+        if (!ri && den.is_zero()) ri = true;  // dx.inverse() orelse return identity() (:93,:129)
+        if (!ri) {
+            Fp lam = fe_mul(num, fe_inv_safegcd(den));
+            Fp x2 = dbl ? a.x : b.x;
+            r.x = fe_sub(fe_sub(fe_sqr(lam), a.x), x2);
+            r.y = fe_sub(fe_mul(lam, fe_sub(a.x, r.x)), a.y);
+        }
+    }
+    if (ri) {  // AffinePoint.identity(): x = y = 0, infinity = true (:24-30)
+        r.x = Fp::zero();
+        r.y = Fp::zero();
+    }
+    affine_store(out_xy + 8 * i, r);
+    if (out_inf) out_inf[i] = ri ? 1 : 0;
 }
 
 // AffinePoint.isOnCurve (msm/mod.zig:106-115)
@@ -1222,6 +1276,9 @@ static int make_plan(size_t n, const zg_msm_config *cfg, MsmPlan &p, size_t batc
     p.W = (255 + c - 1) / c;
     int L = cfg ? cfg->precompute_levels : 0;
     if (L == 0) L = env_int("ZG_MSM_PRECOMPUTE", 0);
+    // a handle that will serve only a few MSMs (MSM.compute on a temporary slice) skips the table: its build costs about as
+    // much as twenty MSMs save (2^20 points: 41 ms against 2 ms per MSM)
+    if (L == 0 && cfg && cfg->expected_uses > 0 && cfg->expected_uses < 16) L = 1;
     if (L == 0) L = p.W;  // 288 GB of HBM: full precompute is 64*W bytes per base
     if (L < 1) L = 1;
     if (L > p.W) L = p.W;
@@ -1384,6 +1441,7 @@ static int bases_create(const uint64_t *d_xy, const uint8_t *d_inf_in, size_t n,
     }
     zg_bases_s *b = new zg_bases_s();
     b->n = n;
+    b->device = current_device();
     int rc = make_plan(n ? n : 1, cfg, b->plan);
     if (rc != ZG_OK) {
         delete b;
@@ -1424,15 +1482,26 @@ static int bases_create(const uint64_t *d_xy, const uint8_t *d_inf_in, size_t n,
         free_bases(b);
         return ZG_ERR_NOMEM;
     }
-    if (n) {
-        if (d_inf_in) ZG_HIP(hipMemcpyAsync(b->d_inf, d_inf_in, n, hipMemcpyDeviceToDevice, st));
-        hipLaunchKernelGGL(msm_precompute_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, d_xy, b->d_inf, n, p.L, p.c * p.G,
-                           b->d_table);
-        ZG_HIP(hipGetLastError());
+    {
+        hipError_t e = hipSuccess;
+        if (n) {
+            if (d_inf_in) e = hipMemcpyAsync(b->d_inf, d_inf_in, n, hipMemcpyDeviceToDevice, st);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(msm_precompute_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, d_xy, b->d_inf, n, p.L, p.c * p.G,
+                                   b->d_table);
+                e = hipGetLastError();
+            }
+        }
+        hipError_t e2 = hipStreamSynchronize(st);  // also on failure: nothing of this handle may still be in flight when it is freed
+        if (e == hipSuccess) e = e2;
+        if (e != hipSuccess) {
+            set_error(std::string("msm table build: ") + hipGetErrorString(e));
+            free_bases(b);
+            return ZG_ERR_HIP;
+        }
     }
-    ZG_HIP(hipStreamSynchronize(st));
     if ((size_t)p.NB * p.G > 4096 && n > SIDE_TABLE_POINTS && env_int("ZG_MSM_SIDE_TABLE", 1)) {
-        zg_msm_config small_cfg{8, 0};
+        zg_msm_config small_cfg{8, 0, 0};
         int src = bases_create(d_xy, d_inf_in, SIDE_TABLE_POINTS, &small_cfg, st, &b->small);
         if (src != ZG_OK) {
             free_bases(b);
@@ -1461,13 +1530,10 @@ static unsigned sort_threads() {
 template <int C>
 static int launch_digits_lds(hipStream_t st, const uint64_t *sc, const uint8_t *inf, uint32_t n, uint32_t n_pts, int G, uint32_t per_block,
                              uint32_t NK, uint32_t nblk, uint32_t *dig, uint32_t *blockhist, int shift, unsigned threads) {
-    static std::once_flag once;  // per instantiation; MSM entry points are re-entrant (std.Thread workers call MSM.compute)
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(msm_digits_lds_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       128 * 1024);
-    });
-    ZG_HIP(attr_err);
+    static PerDeviceOnce once;  // per instantiation and device; MSM entry points are re-entrant (std.Thread workers call MSM.compute)
+    ZG_HIP(once.run([] {
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(msm_digits_lds_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    }));
     hipLaunchKernelGGL(msm_digits_lds_kernel<C>, dim3(nblk), dim3(threads), NK * 4, st, sc, inf, n, n_pts, G, per_block, NK, shift, dig, blockhist);
     return ZG_OK;
 }
@@ -1498,16 +1564,15 @@ static int launch_digits_c(int c, hipStream_t st, const uint64_t *sc, const uint
 }
 
 static int two_pass_attrs() {
-    static std::once_flag once;
-    static hipError_t err = hipSuccess;
-    std::call_once(once, [] {
-        err = hipFuncSetAttribute(reinterpret_cast<const void *>(msm_partition_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    static PerDeviceOnce once;
+    ZG_HIP(once.run([] {
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(msm_partition_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
         if (err == hipSuccess)
             err = hipFuncSetAttribute(reinterpret_cast<const void *>(msm_partition_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
         if (err == hipSuccess)
             err = hipFuncSetAttribute(reinterpret_cast<const void *>(msm_fine_place_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-    });
-    ZG_HIP(err);
+        return err;
+    }));
     return ZG_OK;
 }
 
@@ -1598,13 +1663,10 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
             hipLaunchKernelGGL(msm_scan_b_kernel, dim3(tiles), dim3(1024), 0, st, ln.d_hist, p.NK, ln.d_scan_tmp, ln.d_scan_tmp + p.NK,
                                ln.d_scan_tmp + 2 * (size_t)p.NK, ln.d_starts, ln.d_nzrank, ln.d_nzlist, reinterpret_cast<uint32_t *>(ln.d_state));
         }
-        static std::once_flag scatter_once;
-        static hipError_t scatter_err = hipSuccess;
-        std::call_once(scatter_once, [] {
-            scatter_err = hipFuncSetAttribute(reinterpret_cast<const void *>(msm_scatter_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              128 * 1024);
-        });
-        ZG_HIP(scatter_err);
+        static PerDeviceOnce scatter_once;
+        ZG_HIP(scatter_once.run([] {
+            return hipFuncSetAttribute(reinterpret_cast<const void *>(msm_scatter_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        }));
         hipLaunchKernelGGL(msm_scatter_lds_kernel, dim3(nblk), dim3(sort_threads()), p.NK * 4, st, ln.d_dig, (uint32_t)n, (uint32_t)n_pts, p.W, p.G,
                            b->n, (uint32_t)off, per_block, p.NK, ln.d_starts, ln.d_blockhist, ln.d_sorted);
     } else {
@@ -1706,14 +1768,20 @@ int zg_g1_bases_upload(const uint64_t *xy, const uint8_t *inf, size_t n, const z
     }
     uint64_t *dxy = nullptr;
     uint8_t *dinf = nullptr;
-    ZG_HIP(hipMalloc((void **)&dxy, n ? n * 64 : 16));
-    ZG_HIP(hipMemcpy(dxy, xy, n * 64, hipMemcpyHostToDevice));
-    if (inf) {
-        ZG_HIP(hipMalloc((void **)&dinf, n ? n : 16));
-        ZG_HIP(hipMemcpy(dinf, inf, n, hipMemcpyHostToDevice));
+    hipError_t e = hipMalloc((void **)&dxy, n ? n * 64 : 16);
+    if (e == hipSuccess && n) e = hipMemcpy(dxy, xy, n * 64, hipMemcpyHostToDevice);
+    if (e == hipSuccess && inf) {
+        e = hipMalloc((void **)&dinf, n ? n : 16);
+        if (e == hipSuccess && n) e = hipMemcpy(dinf, inf, n, hipMemcpyHostToDevice);
     }
-    int rc = bases_create(dxy, dinf, n, cfg, lib_stream(), out);
-    (void)hipFree(dxy);
+    int rc;
+    if (e != hipSuccess) {
+        set_error(std::string("zg_g1_bases_upload: ") + hipGetErrorString(e));
+        rc = e == hipErrorOutOfMemory ? ZG_ERR_NOMEM : ZG_ERR_HIP;
+    } else {
+        rc = bases_create(dxy, dinf, n, cfg, lib_stream(), out);
+    }
+    if (dxy) (void)hipFree(dxy);
     if (dinf) (void)hipFree(dinf);
     return rc;
 }
@@ -1721,6 +1789,7 @@ int zg_g1_bases_upload(const uint64_t *xy, const uint8_t *inf, size_t n, const z
 int zg_g1_bases_free(zg_bases_t b) {
     if (!b) return ZG_OK;
     ZG_INIT();
+    DeviceGuard dg(b->device);
     (void)hipDeviceSynchronize();
     free_bases(b);
     return ZG_OK;
@@ -1745,6 +1814,7 @@ int zg_msm_g1_dev(zg_bases_t b, size_t off, size_t n, const uint64_t *d_scalars,
         set_error("zg_msm_g1_dev: invalid argument");
         return ZG_ERR_INVALID;
     }
+    DeviceGuard dg(b->device);
     std::lock_guard<std::mutex> lk(b->mu);
     return msm_to_host(b, off, n, d_scalars, pick_stream(stream), out_xy, out_inf);
 }
@@ -1759,6 +1829,7 @@ int zg_msm_g1(zg_bases_t b, size_t off, size_t n, const uint64_t *scalars, uint6
         set_error("msm: range exceeds uploaded bases");
         return ZG_ERR_INVALID;
     }
+    DeviceGuard dg(b->device);
     std::lock_guard<std::mutex> lk(b->mu);
     hipStream_t st = lib_stream();
     if (n) {
@@ -1775,6 +1846,7 @@ int zg_msm_g1_dev_async(zg_bases_t b, size_t off, size_t n, const uint64_t *d_sc
         set_error("zg_msm_g1_dev_async: invalid argument");
         return ZG_ERR_INVALID;
     }
+    DeviceGuard dg(b->device);
     std::lock_guard<std::mutex> lk(b->mu);
     return msm_enqueue(b, off, n, d_scalars, pick_stream(stream), 0, d_out_xy, d_out_inf);
 }
@@ -1785,6 +1857,7 @@ int zg_msm_g1_partial_dev(zg_bases_t b, size_t off, size_t n, const uint64_t *d_
         set_error("zg_msm_g1_partial_dev: invalid argument");
         return ZG_ERR_INVALID;
     }
+    DeviceGuard dg(b->device);
     std::lock_guard<std::mutex> lk(b->mu);
     return msm_enqueue(b, off, n, d_scalars, pick_stream(stream), 1, d_out_jac, nullptr);
 }
@@ -1795,6 +1868,7 @@ int zg_msm_g1_partial_fast_dev(zg_bases_t b, size_t off, size_t n, const uint64_
         set_error("zg_msm_g1_partial_fast_dev: invalid argument");
         return ZG_ERR_INVALID;
     }
+    DeviceGuard dg(b->device);
     std::lock_guard<std::mutex> lk(b->mu);
     return msm_enqueue(b, off, n, d_scalars, pick_stream(stream), 2, d_out_jac, nullptr);
 }
@@ -1821,14 +1895,17 @@ static size_t batch_fuse_limit(const zg_bases_s *b, size_t n, bool wide_ok = fal
     return lim >= 2 ? lim : 0;
 }
 
-// enqueue k scalar vectors (device, back to back) over bases[0, n) on st; record i = d_out9[9*i .. 9*i+8] (xy[8], flag word)
+// enqueue k scalar vectors (device, back to back) over bases[0, n) on st. mode 0: record i = d_out9[9*i .. 9*i+8] (xy[8], flag
+// word); mode 1 / 2: record i = 12 limbs at d_out9 + 12*i (Jacobian partial, normalised / any representative — see write_result)
 static int msm_batch_enqueue(zg_bases_s *b, size_t n, const uint64_t *d_scalars, size_t k, hipStream_t st, uint64_t *d_out9,
-                             bool wide_ok = false) {
+                             bool wide_ok = false, int mode = 0) {
+    const uint32_t RS = mode == 0 ? 9u : 12u;  // record stride in u64
+    auto inf_of = [&](size_t i) { return mode == 0 ? reinterpret_cast<uint8_t *>(d_out9 + RS * i + 8) : (uint8_t *)nullptr; };
     if (n > b->n) {
         set_error("msm: range exceeds uploaded bases");
         return ZG_ERR_INVALID;
     }
-    if (b->small && n <= b->small->n) return msm_batch_enqueue(b->small, n, d_scalars, k, st, d_out9);  // narrow-window side table
+    if (b->small && n <= b->small->n) return msm_batch_enqueue(b->small, n, d_scalars, k, st, d_out9, false, mode);  // narrow-window side table
     size_t lim = batch_fuse_limit(b, n, wide_ok);
     if (lim == 0 || k < 2) {
         // one launch set per vector, rotating through the handle's workspaces AND through three streams (the caller's
@@ -1852,7 +1929,7 @@ static int msm_batch_enqueue(zg_bases_s *b, size_t n, const uint64_t *d_scalars,
         int rc = ZG_OK;
         for (size_t i = 0; i < k && rc == ZG_OK; i++) {
             hipStream_t si = !fork || i % 3 == 0 ? st : b->aux[i % 3 - 1];
-            rc = msm_enqueue(b, 0, n, d_scalars + 4 * n * i, si, 0, d_out9 + 9 * i, reinterpret_cast<uint8_t *>(d_out9 + 9 * i + 8));
+            rc = msm_enqueue(b, 0, n, d_scalars + 4 * n * i, si, mode, d_out9 + RS * i, inf_of(i));
         }
         if (fork) {  // join even after an error so the helpers never run ahead of the caller's next work
             for (int i = 0; i < 2; i++) {
@@ -1862,7 +1939,7 @@ static int msm_batch_enqueue(zg_bases_s *b, size_t n, const uint64_t *d_scalars,
         }
         return rc;
     }
-    zg_msm_config cfg{b->plan.c, b->plan.L};
+    zg_msm_config cfg{b->plan.c, b->plan.L, 0};
     size_t kc = k < lim ? k : lim;
     if (b->batch_n != n || (size_t)b->batch_plan.K < kc) {  // (re)build the fused workspace for kc vectors of n scalars
         if (b->batch_lane.done) {
@@ -1895,8 +1972,8 @@ static int msm_batch_enqueue(zg_bases_s *b, size_t n, const uint64_t *d_scalars,
             pl.rb = b->batch_plan.rb;
             pl.NCB = pl.fb ? (pl.NK + (1u << pl.fb) - 1) >> pl.fb : 0;
         }
-        ZG_TRY(msm_enqueue_lane(b, pl, b->batch_lane, b->batch_nblk, 0, n, d_scalars + 4 * n * i0, st, 0, d_out9 + 9 * i0,
-                                reinterpret_cast<uint8_t *>(d_out9 + 9 * i0 + 8), 9, 72));
+        ZG_TRY(msm_enqueue_lane(b, pl, b->batch_lane, b->batch_nblk, 0, n, d_scalars + 4 * n * i0, st, mode, d_out9 + RS * i0, inf_of(i0), RS,
+                                mode == 0 ? 72 : 0));
     }
     return ZG_OK;
 }
@@ -1907,9 +1984,30 @@ namespace zg {
 // zg_msm_g1_batch_dev for zero-padded rows of different live lengths (HyperKZG.open's long levels): also fuses on wide-window
 // handles. Not exported: a general batch of full-length vectors on such a handle is better served by the stream rotation.
 int msm_batch_dev_wide(zg_bases_t b, size_t n, const uint64_t *d_scalars, size_t k, hipStream_t st, uint64_t *d_out9) {
+    DeviceGuard dg(b->device);
     std::lock_guard<std::mutex> lk(b->mu);
     return msm_batch_enqueue(b, n, d_scalars, k, st, d_out9, true);
 }
+
+// sharded.hip: this device's k partial sums of a sharded batch (BatchMSM over one shard of the bases), as un-normalised
+// Jacobian records back to back (12 limbs each) — the batch form of zg_msm_g1_partial_fast_dev
+int msm_batch_partials_dev(zg_bases_t b, size_t n, const uint64_t *d_scalars, size_t k, hipStream_t st, uint64_t *d_out12) {
+    DeviceGuard dg(b->device);
+    std::lock_guard<std::mutex> lk(b->mu);
+    return msm_batch_enqueue(b, n, d_scalars, k, st, d_out12, false, 2);
+}
+
+// sharded.hip: combine `ranks` gathered partial records per scalar vector (rank r's k records back to back at
+// d_partials + r * rank_stride) into k affine result records of 9 words (xy[8], flag)
+int msm_combine_batch_enqueue(const uint64_t *d_partials, size_t ranks, size_t rank_stride, size_t k, hipStream_t st, uint64_t *d_out9) {
+    if (k == 0) return ZG_OK;
+    hipLaunchKernelGGL(msm_combine_kernel, dim3((unsigned)k), dim3(64), 0, st, d_partials, (uint32_t)ranks, (uint32_t)rank_stride, d_out9,
+                       reinterpret_cast<uint8_t *>(d_out9 + 8), 9u, 72u);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
+int bases_device(zg_bases_t b) { return b ? b->device : -1; }
 }  // namespace zg
 
 extern "C" {
@@ -1920,6 +2018,7 @@ int zg_msm_g1_batch_dev(zg_bases_t b, size_t n, const uint64_t *d_scalars, size_
         set_error("zg_msm_g1_batch_dev: invalid argument");
         return ZG_ERR_INVALID;
     }
+    DeviceGuard dg(b->device);
     std::lock_guard<std::mutex> lk(b->mu);
     return msm_batch_enqueue(b, n, d_scalars, k, pick_stream(stream), d_out9);
 }
@@ -1935,6 +2034,7 @@ int zg_msm_g1_batch(zg_bases_t b, size_t n, const uint64_t *const *batches, size
         return ZG_ERR_INVALID;
     }
     if (k == 0) return ZG_OK;
+    DeviceGuard dg(b->device);
     std::lock_guard<std::mutex> lk(b->mu);
     hipStream_t st = lib_stream();
     // the k vectors are staged back to back on the device; all results stay there until one final copy
@@ -1970,7 +2070,7 @@ int zg_g1_combine_partials_dev(const uint64_t *d_partials, size_t k, void *strea
     hipStream_t st = pick_stream(stream);
     uint64_t *d_out = nullptr;
     ZG_HIP(hipMalloc((void **)&d_out, 16 * 8));
-    hipLaunchKernelGGL(msm_combine_kernel, dim3(1), dim3(64), 0, st, d_partials, (uint32_t)k, d_out, reinterpret_cast<uint8_t *>(d_out + 8));
+    hipLaunchKernelGGL(msm_combine_kernel, dim3(1), dim3(64), 0, st, d_partials, (uint32_t)k, 12u, d_out, reinterpret_cast<uint8_t *>(d_out + 8), 0u, 0u);
     uint64_t h[9];
     hipError_t e = hipMemcpyAsync(h, d_out, 9 * 8, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -1987,7 +2087,7 @@ int zg_g1_combine_partials_dev_async(const uint64_t *d_partials, size_t k, void 
         set_error("zg_g1_combine_partials_dev_async: invalid argument");
         return ZG_ERR_INVALID;
     }
-    hipLaunchKernelGGL(msm_combine_kernel, dim3(1), dim3(64), 0, pick_stream(stream), d_partials, (uint32_t)k, d_out_xy, d_out_inf);
+    hipLaunchKernelGGL(msm_combine_kernel, dim3(1), dim3(64), 0, pick_stream(stream), d_partials, (uint32_t)k, 12u, d_out_xy, d_out_inf, 0u, 0u);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
@@ -2015,6 +2115,33 @@ int zg_g1_is_on_curve_batch(const uint64_t *xy, const uint8_t *inf, size_t n, ui
     ZG_HIP(hipStreamSynchronize(st));
     (void)hipFree(dxy); (void)hipFree(dout);
     if (dinf) (void)hipFree(dinf);
+    return ZG_OK;
+}
+
+int zg_g1_affine_add_batch(const uint64_t *a_xy, const uint8_t *a_inf, const uint64_t *b_xy, const uint8_t *b_inf, size_t n,
+                           uint64_t *out_xy, uint8_t *out_inf) {
+    ZG_INIT();
+    if (n && (!a_xy || !b_xy || !out_xy)) {
+        set_error("zg_g1_affine_add_batch: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    if (n == 0) return ZG_OK;
+    hipStream_t st = lib_stream();
+    Scratch s_a(n * 64), s_b(n * 64), s_o(n * 64), s_f(3 * n);
+    if (!s_a.p || !s_b.p || !s_o.p || !s_f.p) return ZG_ERR_NOMEM;
+    SyncGuard sync(st);
+    uint8_t *d_ai = s_f.as<uint8_t>(), *d_bi = d_ai + n, *d_oi = d_bi + n;
+    ZG_HIP(hipMemcpyAsync(s_a.p, a_xy, n * 64, hipMemcpyHostToDevice, st));
+    ZG_HIP(hipMemcpyAsync(s_b.p, b_xy, n * 64, hipMemcpyHostToDevice, st));
+    if (a_inf) ZG_HIP(hipMemcpyAsync(d_ai, a_inf, n, hipMemcpyHostToDevice, st));
+    if (b_inf) ZG_HIP(hipMemcpyAsync(d_bi, b_inf, n, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(g1_affine_add_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, s_a.as<uint64_t>(), a_inf ? d_ai : nullptr,
+                       s_b.as<uint64_t>(), b_inf ? d_bi : nullptr, n, s_o.as<uint64_t>(), d_oi);
+    ZG_HIP(hipGetLastError());
+    ZG_HIP(hipMemcpyAsync(out_xy, s_o.p, n * 64, hipMemcpyDeviceToHost, st));
+    if (out_inf) ZG_HIP(hipMemcpyAsync(out_inf, d_oi, n, hipMemcpyDeviceToHost, st));
+    ZG_HIP(hipStreamSynchronize(st));
+    sync.dismiss();
     return ZG_OK;
 }
 

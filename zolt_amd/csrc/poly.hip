@@ -533,6 +533,7 @@ static int eq_table_enqueue(const uint64_t *r_host, size_t v, const uint64_t *sc
     uint32_t n_hi = 1u << v_hi;
     Scratch s_r((v + 1) * 32 + 32), s_hi((size_t)n_hi * 32 + 256 * 32);
     if (!s_r.p || !s_hi.p) return ZG_ERR_NOMEM;
+    SyncGuard sync(st);  // the temporaries go back to the shared cache on return, also on an error path
     uint64_t *d_r = s_r.as<uint64_t>(), *d_hi = s_hi.as<uint64_t>(), *d_lo = d_hi + 4 * (size_t)n_hi;
     if (v) ZG_HIP(hipMemcpyAsync(d_r + 4, r_host, v * 32, hipMemcpyHostToDevice, st));
     if (scale_host) ZG_HIP(hipMemcpyAsync(d_r, scale_host, 32, hipMemcpyHostToDevice, st));
@@ -556,6 +557,7 @@ static int eq_spartan_enqueue(const uint64_t *r_host, size_t v, const uint64_t *
     uint32_t n_hi = 1u << v_hi;
     Scratch s_r((v + 1) * 32 + 32), s_hi((size_t)n_hi * 32 + 256 * 32);
     if (!s_r.p || !s_hi.p) return ZG_ERR_NOMEM;
+    SyncGuard sync(st);  // the temporaries go back to the shared cache on return, also on an error path
     uint64_t *d_r = s_r.as<uint64_t>(), *d_hi = s_hi.as<uint64_t>(), *d_lo = d_hi + 4 * (size_t)n_hi;
     if (v) ZG_HIP(hipMemcpyAsync(d_r + 4, r_host, v * 32, hipMemcpyHostToDevice, st));
     if (scale_host) ZG_HIP(hipMemcpyAsync(d_r, scale_host, 32, hipMemcpyHostToDevice, st));
@@ -585,6 +587,7 @@ static int eq_spartan_enqueue(const uint64_t *r_host, size_t v, const uint64_t *
 }  // namespace zg
 
 struct zg_sc_s {
+    int device = -1;  // the HIP device the tables live on
     int layout = 0;
     size_t len = 0;
     uint64_t *buf[2] = {nullptr, nullptr};  // ping-pong tables (a fold cannot run in place across threads)
@@ -620,7 +623,7 @@ static int sc_create(size_t len, int layout, hipStream_t st, zg_sc_s **out) {
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
         for (size_t i = 0; i < g_pool.size(); i++) {
-            if (g_pool[i]->cap >= len && g_pool[i]->cap <= 4 * len) {
+            if (g_pool[i]->device == current_device() && g_pool[i]->cap >= len && g_pool[i]->cap <= 4 * len) {
                 zg_sc_s *s = g_pool[i];
                 g_pool.erase(g_pool.begin() + i);
                 s->layout = layout; s->len = len; s->st = st; s->cur = 0; s->sums_valid = false;
@@ -631,6 +634,7 @@ static int sc_create(size_t len, int layout, hipStream_t st, zg_sc_s **out) {
         }
     }
     zg_sc_s *s = new zg_sc_s();
+    s->device = current_device();
     s->cap = len;
     s->layout = layout;
     s->len = len;
@@ -839,12 +843,15 @@ static int hk_open_device(zg_bases_t srs, uint64_t *d_a, uint64_t *d_b, uint64_t
     // issued on one of three helper streams in turn (forked / joined by events), never on the caller's stream, so the
     // latency-bound tail of one commit runs under the accumulation of the next.
     constexpr int NAUX = 3;
-    static hipStream_t aux[NAUX] = {nullptr, nullptr, nullptr};
-    static std::once_flag aux_once;
-    std::call_once(aux_once, [] {
+    static hipStream_t aux_all[ZG_MAX_DEVICES][NAUX] = {};  // helper streams belong to a device (created on its first open, kept)
+    static PerDeviceOnce aux_once;
+    const int aux_dev = current_device();
+    (void)aux_once.run([aux_dev] {
         for (int i = 0; i < NAUX; i++)
-            if (hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking) != hipSuccess) aux[i] = nullptr;
+            if (hipStreamCreateWithFlags(&aux_all[aux_dev][i], hipStreamNonBlocking) != hipSuccess) aux_all[aux_dev][i] = nullptr;
+        return hipSuccess;
     });
+    hipStream_t *aux = aux_all[aux_dev];
     const bool fork = aux[0] && aux[1] && aux[2];
     const bool fuse_long = fork && fuse_long_env && long_rows >= 2;
     const bool split_first = fuse_long && fuse_long_env == 2 && long_rows >= 3;
@@ -1006,10 +1013,16 @@ int zg_hyperkzg_open(zg_bases_t srs, const uint64_t *evals, size_t n_evals, cons
         for (int i = 0; i < 4; i++) final_eval[i] = value[i];
         return ZG_OK;
     }
+    if (!srs) {
+        set_error("zg_hyperkzg_open: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    DeviceGuard dg(bases_device(srs));
     hipStream_t st = lib_stream();
     size_t cap = n_evals ? n_evals : 1;
     Scratch s_a(cap * 32), s_b((cap / 2 + 1) * 32), s_q((cap / 2 + 1) * 32);
     if (!s_a.p || !s_b.p || !s_q.p) return ZG_ERR_NOMEM;
+    SyncGuard sync(st);  // whatever happens below, the scratch tables are idle when they return to the cache
     if (n_evals) ZG_HIP(hipMemcpyAsync(s_a.p, evals, n_evals * 32, hipMemcpyHostToDevice, st));
     return hk_open_device(srs, s_a.as<uint64_t>(), s_b.as<uint64_t>(), s_q.as<uint64_t>(), n_evals, point, num_vars, st, q_xy, q_inf,
                           final_eval, nullptr);
@@ -1065,6 +1078,30 @@ __global__ void hk_combined_eval_kernel(const uint64_t *evals, const uint64_t *g
     fe_store(out, acc);
 }
 
+int zg_fr_scale(const uint64_t *a, size_t n, const uint64_t sc[4], uint64_t *out) {
+    ZG_INIT();
+    if (n && (!a || !sc || !out)) {
+        set_error("zg_fr_scale: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    if (n == 0) return ZG_OK;
+    hipStream_t st = lib_stream();
+    Scratch s_a(n * 32), s_o(n * 32), s_s(32);
+    if (!s_a.p || !s_o.p || !s_s.p) return ZG_ERR_NOMEM;
+    SyncGuard sync(st);
+    ZG_HIP(hipMemcpyAsync(s_a.p, a, n * 32, hipMemcpyHostToDevice, st));
+    ZG_HIP(hipMemcpyAsync(s_s.p, sc, 32, hipMemcpyHostToDevice, st));
+    unsigned nb = div_up(n, 256);
+    if (nb > 4096) nb = 4096;
+    // out = 0 + a * s: the axpy kernel of HyperKZG.batchOpen's random linear combination with an empty accumulator
+    hipLaunchKernelGGL(hk_axpy_kernel, dim3(nb), dim3(256), 0, st, s_o.as<uint64_t>(), n, s_a.as<uint64_t>(), n, s_s.as<uint64_t>(), 1);
+    ZG_HIP(hipGetLastError());
+    ZG_HIP(hipMemcpyAsync(out, s_o.p, n * 32, hipMemcpyDeviceToHost, st));
+    ZG_HIP(hipStreamSynchronize(st));
+    sync.dismiss();
+    return ZG_OK;
+}
+
 int zg_hyperkzg_batch_open(zg_bases_t srs, const uint64_t *const *polys, const size_t *lens, size_t k, const uint64_t *point,
                            size_t num_vars, uint64_t *q_xy, uint8_t *q_inf, size_t *n_quot, uint64_t *evaluations,
                            uint64_t final_eval[4], uint64_t gamma[4]) {
@@ -1086,6 +1123,11 @@ int zg_hyperkzg_batch_open(zg_bases_t srs, const uint64_t *const *polys, const s
             set_error("zg_hyperkzg_batch_open: null polynomial");
             return ZG_ERR_INVALID;
         }
+    if (!srs) {
+        set_error("zg_hyperkzg_batch_open: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    DeviceGuard dg(bases_device(srs));
     hipStream_t st = lib_stream();
     size_t poly_size = lens[0], max_len = 1;
     for (size_t i = 0; i < k; i++) max_len = lens[i] > max_len ? lens[i] : max_len;
@@ -1093,6 +1135,7 @@ int zg_hyperkzg_batch_open(zg_bases_t srs, const uint64_t *const *polys, const s
     Scratch s_pt((num_vars + 1) * 32), s_g((k + 1) * 32), s_p(max_len * 32), s_a(cap * 32), s_b((cap / 2 + 1) * 32), s_q((cap / 2 + 1) * 32),
         s_ev((k + 1) * 32), s_misc(SC_MISC_BYTES), s_eq(((size_t)1 << (num_vars <= 10 ? num_vars : 0)) * 32);
     if (!s_pt.p || !s_g.p || !s_p.p || !s_a.p || !s_b.p || !s_q.p || !s_ev.p || !s_misc.p || !s_eq.p) return ZG_ERR_NOMEM;
+    SyncGuard sync(st);  // an early error return waits for the enqueued work before the scratch buffers are recycled
     uint64_t *d_pt = s_pt.as<uint64_t>(), *d_g = s_g.as<uint64_t>(), *d_p = s_p.as<uint64_t>(), *d_a = s_a.as<uint64_t>(),
              *d_ev = s_ev.as<uint64_t>(), *d_misc = s_misc.as<uint64_t>(), *d_eq = s_eq.as<uint64_t>();
     if (num_vars) ZG_HIP(hipMemcpyAsync(d_pt, point, num_vars * 32, hipMemcpyHostToDevice, st));
@@ -1123,8 +1166,7 @@ int zg_hyperkzg_batch_open(zg_bases_t srs, const uint64_t *const *polys, const s
         } else if (lens[i]) {
             for (int l = 0; l < 4; l++) h_ev[4 * i + l] = polys[i][l];  // point.len == 0 or the large-polynomial fallback: evals[0]
         }
-        ZG_HIP(hipGetLastError());
-        ZG_HIP(hipStreamSynchronize(st));  // d_p is reused by the next polynomial
+        ZG_HIP(hipGetLastError());  // d_p is reused by the next polynomial: its upload is ordered behind these kernels on the same stream
     }
     std::vector<uint64_t> d2h(4 * (k + 1));
     ZG_HIP(hipMemcpyAsync(d2h.data(), d_ev, 4 * 8 * k, hipMemcpyDeviceToHost, st));
@@ -1189,13 +1231,11 @@ static int run_sumcheck_enqueue(const uint64_t *d_evals, size_t len, hipStream_t
         cl /= 2;
     }
     if (cl > 1) {  // the remaining rounds in one launch, table in LDS
-        static std::once_flag once;
-        static hipError_t attr_err = hipSuccess;
-        std::call_once(once, [] {
-            attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(sc_tail_run_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)(SC_TAIL_MAX * 32 + 20 * 16));
-        });
-        ZG_HIP(attr_err);
+        static PerDeviceOnce once;
+        ZG_HIP(once.run([] {
+            return hipFuncSetAttribute(reinterpret_cast<const void *>(sc_tail_run_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(SC_TAIL_MAX * 32 + 20 * 16));
+        }));
         hipLaunchKernelGGL(sc_tail_run_kernel, dim3(1), dim3(256), cl * 32 + 20 * 16, st, cur, (uint32_t)cl, ScRunArg{d_res, v, k + 1, 0});
         ZG_HIP(hipGetLastError());
     }
@@ -1301,6 +1341,7 @@ int zg_sumcheck_round_sums(zg_sc_t s, uint64_t g0[4], uint64_t g1[4]) {
         set_error("zg_sumcheck_round_sums: invalid session or protocol already complete");
         return ZG_ERR_INVALID;
     }
+    DeviceGuard dg(s->device);
     std::lock_guard<std::mutex> lk(s->mu);
     if (!s->sums_valid) {
         s->seq++;
@@ -1333,6 +1374,7 @@ int zg_sumcheck_bind(zg_sc_t s, const uint64_t r[4]) {
         set_error("zg_sumcheck_bind: invalid session or protocol already complete");
         return ZG_ERR_INVALID;
     }
+    DeviceGuard dg(s->device);
     std::lock_guard<std::mutex> lk(s->mu);
     // buf[1] holds len/2 elements at most; after the first fold both buffers are large enough
     int nxt = s->cur ^ 1;
@@ -1353,6 +1395,7 @@ int zg_sumcheck_final(zg_sc_t s, uint64_t out[4]) {
         set_error("zg_sumcheck_final: protocol not complete");
         return ZG_ERR_INVALID;
     }
+    DeviceGuard dg(s->device);
     std::lock_guard<std::mutex> lk(s->mu);
     ZG_HIP(hipMemcpyAsync(s->h_pin + 8, s->buf[s->cur], 32, hipMemcpyDeviceToHost, s->st));
     ZG_HIP(hipStreamSynchronize(s->st));
@@ -1366,6 +1409,7 @@ int zg_sumcheck_read(zg_sc_t s, uint64_t *out_table) {
         set_error("zg_sumcheck_read: invalid argument");
         return ZG_ERR_INVALID;
     }
+    DeviceGuard dg(s->device);
     std::lock_guard<std::mutex> lk(s->mu);
     ZG_HIP(hipMemcpyAsync(out_table, s->buf[s->cur], s->len * 32, hipMemcpyDeviceToHost, s->st));
     ZG_HIP(hipStreamSynchronize(s->st));
@@ -1381,6 +1425,7 @@ int zg_sumcheck_round_sums_dev(zg_sc_t s, uint64_t *d_out) {
         set_error("zg_sumcheck_round_sums_dev: invalid session or protocol already complete");
         return ZG_ERR_INVALID;
     }
+    DeviceGuard dg(s->device);
     std::lock_guard<std::mutex> lk(s->mu);
     if (!s->sums_valid) {
         s->seq++;
@@ -1397,6 +1442,7 @@ int zg_sumcheck_read_dev(zg_sc_t s, uint64_t *d_out_table) {
         set_error("zg_sumcheck_read_dev: invalid argument");
         return ZG_ERR_INVALID;
     }
+    DeviceGuard dg(s->device);
     std::lock_guard<std::mutex> lk(s->mu);
     ZG_HIP(hipMemcpyAsync(d_out_table, s->buf[s->cur], s->len * 32, hipMemcpyDeviceToDevice, s->st));
     return ZG_OK;
@@ -1405,6 +1451,7 @@ int zg_sumcheck_read_dev(zg_sc_t s, uint64_t *d_out_table) {
 int zg_sumcheck_close(zg_sc_t s) {
     if (!s) return ZG_OK;
     ZG_INIT();
+    DeviceGuard dg(s->device);
     (void)hipStreamSynchronize(s->st);
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);

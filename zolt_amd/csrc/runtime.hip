@@ -13,39 +13,81 @@ namespace zg {
 static thread_local std::string t_err;
 static std::mutex g_mu;
 static std::atomic<bool> g_inited{false};  // read without the mutex on every entry point
-static hipStream_t g_stream = nullptr;
+static std::atomic<int> g_primary{-1};     // device bound by zg_init / zg_init_devices
+static std::atomic<int> g_ndev{0};         // devices bound (1 after zg_init, n after zg_init_devices(n)); they are 0..n-1 then
+static hipStream_t g_streams[ZG_MAX_DEVICES] = {};  // the library's own stream per device, created on first use
 
 void set_error(const std::string &msg) { t_err = msg; }
-hipStream_t lib_stream() { return g_stream; }
+static thread_local int t_dev_override = -1;
+void set_device_override(int dev) { t_dev_override = dev; }
+int device_override() { return t_dev_override; }
+int primary_device() { return t_dev_override >= 0 ? t_dev_override : g_primary.load(std::memory_order_acquire); }
+int bound_devices() { return g_ndev.load(std::memory_order_acquire); }
+int current_device() {
+    int d = -1;
+    if (hipGetDevice(&d) != hipSuccess) return -1;
+    return d;
+}
 
-static int do_init(int device) {
+hipStream_t lib_stream() {
+    int d = current_device();
+    if (d < 0 || d >= ZG_MAX_DEVICES) return nullptr;
     std::lock_guard<std::mutex> lk(g_mu);
-    if (g_inited) return ZG_OK;
+    if (!g_streams[d] && hipStreamCreateWithFlags(&g_streams[d], hipStreamNonBlocking) != hipSuccess) g_streams[d] = nullptr;
+    return g_streams[d];
+}
+
+// device >= 0: bind that device as the primary; -1: keep the calling thread's current device. ndev: devices 0..ndev-1 are bound
+// (zg_init_devices), 1 for the one-GPU-per-process model.
+static int do_init(int device, int ndev) {
+    std::lock_guard<std::mutex> lk(g_mu);
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count == 0) {
         set_error("no HIP device available (libzolt_gpu has no CPU fallback)");
         return ZG_ERR_NO_DEVICE;
     }
-    if (device >= 0) {
-        if (device >= count) {
-            set_error("zg_init: device ordinal out of range");
+    if (count > ZG_MAX_DEVICES) count = ZG_MAX_DEVICES;
+    if (g_inited) {
+        // idempotent; a later zg_init_devices may widen the set of bound devices but never moves the primary
+        if (ndev > count) {
+            set_error("zg_init_devices: more devices requested than are visible");
             return ZG_ERR_INVALID;
         }
-        ZG_HIP(hipSetDevice(device));
+        if (ndev > g_ndev) {
+            if (g_primary != 0) {
+                set_error("zg_init_devices: the process is already bound to a device other than 0 (one-GPU-per-process model)");
+                return ZG_ERR_INVALID;
+            }
+            g_ndev = ndev;
+        }
+        return ZG_OK;
     }
-    ZG_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    if (device >= count || ndev > count) {
+        set_error("zg_init: device ordinal out of range");
+        return ZG_ERR_INVALID;
+    }
+    if (device >= 0) ZG_HIP(hipSetDevice(device));
+    int cur = 0;
+    ZG_HIP(hipGetDevice(&cur));
+    if (cur >= ZG_MAX_DEVICES) {
+        set_error("zg_init: device ordinal beyond ZG_MAX_DEVICES");
+        return ZG_ERR_INVALID;
+    }
+    ZG_HIP(hipStreamCreateWithFlags(&g_streams[cur], hipStreamNonBlocking));
+    g_primary = cur;
+    g_ndev = ndev;
     g_inited = true;
     return ZG_OK;
 }
 
 int ensure_init() {
     if (g_inited) return ZG_OK;
-    return do_init(-1);
+    return do_init(-1, 1);
 }
 
 // ------------------------------------------------------------------ scratch cache
-struct ScratchBuf { void *p; size_t bytes; bool used; };
+struct ScratchBuf { void *p; size_t bytes; bool used; int dev; };
 static std::mutex g_scratch_mu;
 static std::vector<ScratchBuf> g_scratch;
 static size_t g_scratch_total = 0;
@@ -53,11 +95,12 @@ static constexpr size_t SCRATCH_CAP = (size_t)4 << 30;  // cached bytes kept at 
 
 void *scratch_get(size_t bytes) {
     if (bytes == 0) bytes = 16;
+    const int dev = current_device();
     {
         std::lock_guard<std::mutex> lk(g_scratch_mu);
         size_t best = (size_t)-1;
         for (size_t i = 0; i < g_scratch.size(); i++)
-            if (!g_scratch[i].used && g_scratch[i].bytes >= bytes && g_scratch[i].bytes <= 4 * bytes + 4096 &&
+            if (!g_scratch[i].used && g_scratch[i].dev == dev && g_scratch[i].bytes >= bytes && g_scratch[i].bytes <= 4 * bytes + 4096 &&
                 (best == (size_t)-1 || g_scratch[i].bytes < g_scratch[best].bytes))
                 best = i;
         if (best != (size_t)-1) {
@@ -72,7 +115,7 @@ void *scratch_get(size_t bytes) {
         return nullptr;
     }
     std::lock_guard<std::mutex> lk(g_scratch_mu);
-    g_scratch.push_back({p, bytes, true});
+    g_scratch.push_back({p, bytes, true, dev});
     g_scratch_total += bytes;
     return p;
 }
@@ -171,7 +214,6 @@ __global__ void __launch_bounds__(256) field_op_kernel(int op, const uint64_t *a
             case ZG_OP_SQR: r = fe_sqr(x); break;
             case ZG_OP_INV: r = fe_inv(x); break;
             case ZG_OP_FROM_MONT: r = fe_from_mont(x); break;
-            case ZG_OP_INV_FAST: r = fe_inv_kaliski(x); break;
             case ZG_OP_INV_XGCD: r = fe_inv_fast(x); break;
             case ZG_OP_INV_SAFEGCD: r = fe_inv_safegcd(x); break;
             default: r = fe_to_mont(x); break;
@@ -186,15 +228,37 @@ using namespace zg;
 
 extern "C" {
 
-int zg_init(int device) { return do_init(device); }
+int zg_init(int device) { return do_init(device, 1); }
+
+int zg_init_devices(int n_devices) {
+    int count = zg_device_count();
+    if (count > ZG_MAX_DEVICES) count = ZG_MAX_DEVICES;
+    if (n_devices <= 0) n_devices = count;
+    if (count == 0) {
+        set_error("no HIP device available (libzolt_gpu has no CPU fallback)");
+        return ZG_ERR_NO_DEVICE;
+    }
+    return do_init(0, n_devices);
+}
+
+int zg_n_devices(void) { return bound_devices(); }
 
 void zg_shutdown(void) {
+    sharded_shutdown();  // communicators and per-device exchange buffers (sharded.hip)
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_inited) return;
-    (void)hipStreamSynchronize(g_stream);
+    int prev = current_device();
+    for (int d = 0; d < ZG_MAX_DEVICES; d++) {
+        if (!g_streams[d]) continue;
+        (void)hipSetDevice(d);
+        (void)hipStreamSynchronize(g_streams[d]);
+        (void)hipStreamDestroy(g_streams[d]);
+        g_streams[d] = nullptr;
+    }
+    if (prev >= 0) (void)hipSetDevice(prev);
     scratch_trim();
-    (void)hipStreamDestroy(g_stream);
-    g_stream = nullptr;
+    g_primary = -1;
+    g_ndev = 0;
     g_inited = false;
 }
 
@@ -235,7 +299,7 @@ int zg_memcpy_d2h(void *dst, const void *src, size_t bytes) {
 }
 int zg_sync(void) {
     ZG_INIT();
-    ZG_HIP(hipStreamSynchronize(g_stream));
+    ZG_HIP(hipStreamSynchronize(lib_stream()));
     return ZG_OK;
 }
 
@@ -257,6 +321,10 @@ int zg_profile_begin(int max_records) {
 
 int zg_profile_end(double ms_out[ZG_PROF_NKERNELS], uint64_t count_out[ZG_PROF_NKERNELS]) {
     ZG_INIT();
+    if (!ms_out || !count_out) {
+        set_error("zg_profile_end: invalid argument");
+        return ZG_ERR_INVALID;
+    }
     g_prof_on = false;
     for (int i = 0; i < ZG_PROF_NKERNELS; i++) { ms_out[i] = 0.0; count_out[i] = 0; }
     ZG_HIP(hipDeviceSynchronize());
@@ -274,7 +342,7 @@ int zg_profile_end(double ms_out[ZG_PROF_NKERNELS], uint64_t count_out[ZG_PROF_N
 
 int zg_field_op(int field, int op, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n) {
     ZG_INIT();
-    if (op < 0 || op > ZG_OP_INV_SAFEGCD || (op >= ZG_OP_MUL29 && op <= ZG_OP_X3_29 && field != ZG_FIELD_FP) || (field != ZG_FIELD_FR && field != ZG_FIELD_FP) || !a || !out ||
+    if (op < 0 || op > ZG_OP_INV_SAFEGCD || op == 8 /* retired */ || (op >= ZG_OP_MUL29 && op <= ZG_OP_X3_29 && field != ZG_FIELD_FP) || (field != ZG_FIELD_FR && field != ZG_FIELD_FP) || !a || !out ||
         ((op <= ZG_OP_SUB || (op >= ZG_OP_MUL29 && op <= ZG_OP_X3_29)) && !b)) {
         set_error("zg_field_op: invalid argument");
         return ZG_ERR_INVALID;
@@ -282,22 +350,25 @@ int zg_field_op(int field, int op, const uint64_t *a, const uint64_t *b, uint64_
     if (n == 0) return ZG_OK;
     size_t bytes = n * 32;
     bool two = op <= ZG_OP_SUB || (op >= ZG_OP_MUL29 && op <= ZG_OP_X3_29);
+    hipStream_t st = lib_stream();
     Scratch sa(bytes), sout(bytes), sb;
     if (!sa.p || !sout.p || (two && !sb.alloc(bytes))) return ZG_ERR_NOMEM;
+    SyncGuard sync(st);
     uint64_t *da = sa.as<uint64_t>(), *db = sb.as<uint64_t>(), *dout = sout.as<uint64_t>();
-    ZG_HIP(hipMemcpyAsync(da, a, bytes, hipMemcpyHostToDevice, g_stream));
-    if (two) ZG_HIP(hipMemcpyAsync(db, b, bytes, hipMemcpyHostToDevice, g_stream));
+    ZG_HIP(hipMemcpyAsync(da, a, bytes, hipMemcpyHostToDevice, st));
+    if (two) ZG_HIP(hipMemcpyAsync(db, b, bytes, hipMemcpyHostToDevice, st));
     unsigned blocks = div_up(n, 256);
     if (blocks > 4096) blocks = 4096;
     if (op >= ZG_OP_MUL29 && op <= ZG_OP_X3_29)
-        hipLaunchKernelGGL(fp29_op_kernel, dim3(blocks), dim3(256), 0, g_stream, op, da, db, dout, n);
+        hipLaunchKernelGGL(fp29_op_kernel, dim3(blocks), dim3(256), 0, st, op, da, db, dout, n);
     else if (field == ZG_FIELD_FR)
-        hipLaunchKernelGGL(field_op_kernel<FrParams>, dim3(blocks), dim3(256), 0, g_stream, op, da, db, dout, n);
+        hipLaunchKernelGGL(field_op_kernel<FrParams>, dim3(blocks), dim3(256), 0, st, op, da, db, dout, n);
     else
-        hipLaunchKernelGGL(field_op_kernel<FpParams>, dim3(blocks), dim3(256), 0, g_stream, op, da, db, dout, n);
+        hipLaunchKernelGGL(field_op_kernel<FpParams>, dim3(blocks), dim3(256), 0, st, op, da, db, dout, n);
     ZG_HIP(hipGetLastError());
-    ZG_HIP(hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, g_stream));
-    ZG_HIP(hipStreamSynchronize(g_stream));
+    ZG_HIP(hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, st));
+    ZG_HIP(hipStreamSynchronize(st));
+    sync.dismiss();
     return ZG_OK;
 }
 

@@ -146,6 +146,19 @@ struct AffinePoint {  // src/msm/mod.zig:15-49
         if (infinity || o.infinity) return false;
         return std::memcmp(x.limbs, o.x.limbs, 32) == 0 && std::memcmp(y.limbs, o.y.limbs, 32) == 0;
     }
+    // add (:74-103) / double (:118-138): lambda formulas, one inversion; on the device (zg_g1_affine_add_batch)
+    AffinePoint add(const AffinePoint &o) const {
+        uint64_t a[8], b[8], out[8];
+        uint8_t ai = infinity ? 1 : 0, bi = o.infinity ? 1 : 0, oi = 0;
+        std::memcpy(a, x.limbs, 32); std::memcpy(a + 4, y.limbs, 32);
+        std::memcpy(b, o.x.limbs, 32); std::memcpy(b + 4, o.y.limbs, 32);
+        check(zg_g1_affine_add_batch(a, &ai, b, &bi, 1, out, &oi), "zg_g1_affine_add_batch");
+        AffinePoint r;
+        std::memcpy(r.x.limbs, out, 32); std::memcpy(r.y.limbs, out + 4, 32);
+        r.infinity = oi != 0;
+        return r;
+    }
+    AffinePoint dbl() const { return add(*this); }  // `double` is a C++ keyword
 };
 
 inline void pack_points(const std::vector<AffinePoint> &pts, std::vector<uint64_t> &xy, std::vector<uint8_t> &inf) {
@@ -220,9 +233,58 @@ struct BatchMSM {  // :545-565 (ParallelBatchMSM :683-748 returns the same value
     }
 };
 
-struct ParallelMSM {  // :572-680 — on one GPU the chunking is internal to the kernels; the value is MSM.compute's
+// the SRS sharded over the devices bound by zg_init_devices (one resident table per GPU)
+class ShardedDeviceBases {
+public:
+    explicit ShardedDeviceBases(const std::vector<AffinePoint> &pts, const zg_msm_config *cfg = nullptr) : n_(pts.size()) {
+        std::vector<uint64_t> xy;
+        std::vector<uint8_t> inf;
+        pack_points(pts, xy, inf);
+        check(zg_g1_bases_upload_sharded(xy.data(), inf.data(), n_, cfg, &h_), "zg_g1_bases_upload_sharded");
+    }
+    ~ShardedDeviceBases() { zg_g1_sbases_free(h_); }
+    ShardedDeviceBases(const ShardedDeviceBases &) = delete;
+    ShardedDeviceBases &operator=(const ShardedDeviceBases &) = delete;
+    size_t len() const { return n_; }
+    int shards() const { return zg_g1_sbases_shards(h_); }
+    AffinePoint msm(const Fr *scalars, size_t n) const {
+        uint64_t out[8];
+        uint8_t inf = 0;
+        check(zg_msm_g1_sharded(h_, n, reinterpret_cast<const uint64_t *>(scalars), out, &inf), "zg_msm_g1_sharded");
+        return unpack_point(out, inf);
+    }
+    std::vector<AffinePoint> msmBatch(const std::vector<std::vector<Fr>> &batches, size_t n) const {
+        std::vector<const uint64_t *> ptrs;
+        for (const auto &b : batches) ptrs.push_back(reinterpret_cast<const uint64_t *>(b.data()));
+        std::vector<uint64_t> xy(8 * batches.size());
+        std::vector<uint8_t> inf(batches.size());
+        check(zg_msm_g1_batch_sharded(h_, n, ptrs.data(), batches.size(), xy.data(), inf.data()), "zg_msm_g1_batch_sharded");
+        std::vector<AffinePoint> out;
+        for (size_t i = 0; i < batches.size(); i++) out.push_back(unpack_point(&xy[8 * i], inf[i]));
+        return out;
+    }
+
+private:
+    zg_sbases_t h_ = nullptr;
+    size_t n_;
+};
+
+struct ParallelMSM {  // :572-680 — contiguous chunks of ceil(n / T), one partial per worker, serial combine: one worker = one GPU
     static AffinePoint compute(const std::vector<AffinePoint> &bases, const std::vector<Fr> &scalars, size_t /*num_threads*/) {
-        return MSM::compute(bases, scalars);
+        if (bases.size() != scalars.size()) throw std::invalid_argument("ParallelMSM.compute: bases.len != scalars.len");
+        if (bases.empty()) return AffinePoint::identity();
+        zg_msm_config cfg{0, 0, 1};  // a one-shot slice: no precompute table
+        ShardedDeviceBases d(bases, &cfg);
+        return d.msm(scalars.data(), scalars.size());
+    }
+};
+
+struct ParallelBatchMSM {  // :683-748 — k vectors, k partials per GPU, one exchange
+    static std::vector<AffinePoint> compute(const std::vector<AffinePoint> &bases, const std::vector<std::vector<Fr>> &batches) {
+        if (batches.empty()) return {};
+        zg_msm_config cfg{0, 0, 1};
+        ShardedDeviceBases d(bases, &cfg);
+        return d.msmBatch(batches, batches[0].size());
     }
 };
 
@@ -260,6 +322,20 @@ struct DensePolynomial {  // src/poly/mod.zig:23-182
                               reinterpret_cast<uint64_t *>(out.data())), "zg_fr_bind_high");
         return DensePolynomial(out);
     }
+    DensePolynomial add(const DensePolynomial &other) const {  // :94-110
+        if (num_vars != other.num_vars) throw std::invalid_argument("add: num_vars differ");
+        std::vector<Fr> out(evaluations.size());
+        check(zg_field_op(ZG_FIELD_FR, ZG_OP_ADD, reinterpret_cast<const uint64_t *>(evaluations.data()),
+                          reinterpret_cast<const uint64_t *>(other.evaluations.data()), reinterpret_cast<uint64_t *>(out.data()), out.size()),
+              "zg_field_op");
+        return DensePolynomial(out);
+    }
+    DensePolynomial scale(const Fr &scalar) const {  // :112-126
+        std::vector<Fr> out(evaluations.size());
+        check(zg_fr_scale(reinterpret_cast<const uint64_t *>(evaluations.data()), out.size(), scalar.limbs, reinterpret_cast<uint64_t *>(out.data())),
+              "zg_fr_scale");
+        return DensePolynomial(out);
+    }
     void bindLow(const Fr &value) {  // :160-175, in place
         if (num_vars == 0) throw std::invalid_argument("bindLow: num_vars == 0");
         check(zg_fr_bind_low(reinterpret_cast<uint64_t *>(evaluations.data()), evaluations.size(), value.limbs), "zg_fr_bind_low");
@@ -272,6 +348,18 @@ struct EqPolynomial {  // src/poly/mod.zig:190-323
     std::vector<Fr> r;
     explicit EqPolynomial(const std::vector<Fr> &point) : r(point) {}
     std::vector<Fr> evals() const { return evalsSliceWithScaling(r, nullptr); }
+    // evaluate (:214-227) / mle (:311-321): prod_i (r_i x_i + (1 - r_i)(1 - x_i)) — host scalar code, v products
+    Fr evaluate(const std::vector<Fr> &x) const { return mle(r, x); }
+    static Fr mle(const std::vector<Fr> &r, const std::vector<Fr> &x) {
+        if (r.size() != x.size()) throw std::invalid_argument("EqPolynomial.mle: r.len != x.len");
+        Fr result = Fr::one();
+        for (size_t i = 0; i < r.size(); i++) {
+            Fr ri_xi = r[i].mul(x[i]);
+            Fr one_minus_ri = Fr::one().sub(r[i]), one_minus_xi = Fr::one().sub(x[i]);
+            result = result.mul(ri_xi.add(one_minus_ri.mul(one_minus_xi)));
+        }
+        return result;
+    }
     static std::vector<Fr> evalsSliceWithScaling(const std::vector<Fr> &r, const Fr *scaling_factor) {  // :252-290
         std::vector<Fr> out(size_t(1) << r.size());
         check(zg_fr_eq_table(reinterpret_cast<const uint64_t *>(r.data()), r.size(), scaling_factor ? scaling_factor->limbs : nullptr,

@@ -18,15 +18,20 @@ _lib = C.CDLL(LIB_PATH)
 
 OK, ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_NO_DEVICE, ERR_VERIFY = 0, 1, 2, 3, 4, 5
 FR, FP = 0, 1
-OP_MUL, OP_ADD, OP_SUB, OP_NEG, OP_SQR, OP_INV, OP_FROM_MONT, OP_TO_MONT, OP_INV_FAST, OP_MUL29, OP_SQR29, OP_X3_29, OP_INV_XGCD, OP_INV_SAFEGCD = range(14)
+OP_MUL, OP_ADD, OP_SUB, OP_NEG, OP_SQR, OP_INV, OP_FROM_MONT, OP_TO_MONT = range(8)
+# self-test hooks (include/zolt_gpu_internal.h)
+OP_MUL29, OP_SQR29, OP_X3_29, OP_INV_XGCD, OP_INV_SAFEGCD = 9, 10, 11, 12, 13
 SC_HIGH_HALF, SC_LOW_PAIR = 0, 1
 
-# every symbol include/zolt_gpu.h declares (tests check that the .so exports all of them)
+# every symbol include/zolt_gpu.h declares (tests check that the .so exports all of them, and that the header declares no more)
 SYMBOLS = [
-    "zg_init", "zg_shutdown", "zg_last_error", "zg_version", "zg_device_count",
+    "zg_init", "zg_init_devices", "zg_n_devices", "zg_shutdown", "zg_last_error", "zg_version", "zg_device_count",
     "zg_dev_alloc", "zg_dev_free", "zg_memcpy_h2d", "zg_memcpy_d2h", "zg_sync",
-    "zg_profile_begin", "zg_profile_end",
-    "zg_field_op",
+    "zg_field_op", "zg_fr_scale", "zg_g1_affine_add_batch",
+    "zg_shard_bounds", "zg_g1_bases_upload_sharded", "zg_g1_sbases_free", "zg_g1_sbases_len", "zg_g1_sbases_shards", "zg_g1_sbases_exchange", "zg_g1_sbases_shard",
+    "zg_msm_g1_sharded", "zg_msm_g1_sharded_dev", "zg_msm_g1_batch_sharded",
+    "zg_sumcheck_open_sharded", "zg_sumcheck_shards", "zg_sumcheck_len_sharded", "zg_sumcheck_round_sums_sharded",
+    "zg_sumcheck_bind_sharded", "zg_sumcheck_final_sharded", "zg_sumcheck_close_sharded",
     "zg_g1_bases_upload", "zg_g1_bases_upload_dev", "zg_g1_bases_free", "zg_g1_bases_len", "zg_g1_bases_plan",
     "zg_msm_g1", "zg_msm_g1_dev", "zg_msm_g1_dev_async", "zg_msm_g1_batch", "zg_msm_g1_batch_dev", "zg_msm_g1_partial_dev", "zg_msm_g1_partial_fast_dev",
     "zg_g1_combine_partials_dev", "zg_g1_combine_partials_dev_async", "zg_g1_is_on_curve_batch", "zg_g1_scalar_mul_batch",
@@ -38,15 +43,19 @@ SYMBOLS = [
     "zg_sumcheck_round_sums_dev", "zg_sumcheck_read_dev",
     "zg_run_sumcheck", "zg_run_sumcheck_dev", "zg_sumcheck_open_spartan_dev",
 ]
+# test / bench scaffolding of include/zolt_gpu_internal.h (not part of the drop-in boundary)
+INTERNAL_SYMBOLS = ["zg_profile_begin", "zg_profile_end"]
 
 
 class MsmConfig(C.Structure):
-    _fields_ = [("window_bits", C.c_int), ("precompute_levels", C.c_int)]
+    _fields_ = [("window_bits", C.c_int), ("precompute_levels", C.c_int), ("expected_uses", C.c_int)]
 
 
 _lib.zg_last_error.restype = C.c_char_p
 _lib.zg_version.restype = C.c_char_p
 _lib.zg_g1_bases_len.restype = C.c_size_t
+_lib.zg_g1_sbases_len.restype = C.c_size_t
+_lib.zg_sumcheck_len_sharded.restype = C.c_size_t
 _lib.zg_sumcheck_len.restype = C.c_size_t
 
 _u64p = C.POINTER(C.c_uint64)
@@ -95,6 +104,15 @@ def init(device=-1):
     _chk(_lib.zg_init(C.c_int(device)), "zg_init")
 
 
+def init_devices(n=0):
+    """one process, several GPUs (devices 0..n-1; n <= 0: all visible)"""
+    _chk(_lib.zg_init_devices(C.c_int(n)), "zg_init_devices")
+
+
+def n_devices():
+    return int(_lib.zg_n_devices())
+
+
 def shutdown():
     _lib.zg_shutdown()
 
@@ -141,18 +159,18 @@ class Bases:
         self.n = n
 
     @classmethod
-    def upload(cls, xy, inf=None, window_bits=0, precompute_levels=0):
+    def upload(cls, xy, inf=None, window_bits=0, precompute_levels=0, expected_uses=0):
         xy = _c(xy)
         inf = _c(inf, np.uint8)
         n = xy.size // 8
-        cfg = MsmConfig(window_bits, precompute_levels)
+        cfg = MsmConfig(window_bits, precompute_levels, expected_uses)
         h = C.c_void_p()
         _chk(_lib.zg_g1_bases_upload(_h(xy), _hb(inf), C.c_size_t(n), C.byref(cfg), C.byref(h)), "zg_g1_bases_upload")
         return cls(h, n)
 
     @classmethod
     def upload_dev(cls, d_xy, d_inf, n, stream=0, window_bits=0, precompute_levels=0):
-        cfg = MsmConfig(window_bits, precompute_levels)
+        cfg = MsmConfig(window_bits, precompute_levels, 0)
         h = C.c_void_p()
         _chk(_lib.zg_g1_bases_upload_dev(_d(d_xy), _d(d_inf), C.c_size_t(n), C.byref(cfg), _d(stream), C.byref(h)),
              "zg_g1_bases_upload_dev")
@@ -215,6 +233,98 @@ class Bases:
         inf = np.zeros(k, dtype=np.uint8)
         _chk(_lib.zg_msm_g1_batch(self._h, C.c_size_t(n), arr, C.c_size_t(k), _h(out), _hb(inf)), "zg_msm_g1_batch")
         return out, inf
+
+
+def shard_bounds(n, shards, shard):
+    """ParallelMSM's chunk `shard` of `shards` over n points -> (start, len); host arithmetic only (works without a GPU)"""
+    st, ln = C.c_size_t(), C.c_size_t()
+    _chk(_lib.zg_shard_bounds(C.c_size_t(n), C.c_int(shards), C.c_int(shard), C.byref(st), C.byref(ln)), "zg_shard_bounds")
+    return st.value, ln.value
+
+
+class ShardedBases:
+    """The SRS sharded over the devices bound by init_devices (ParallelMSM's contiguous chunks, src/msm/mod.zig:609)."""
+    EXCHANGE = {0: "none", 1: "rccl", 2: "p2p"}
+
+    def __init__(self, handle, n):
+        self._h = handle
+        self.n = n
+
+    @classmethod
+    def upload(cls, xy, inf=None, window_bits=0, precompute_levels=0):
+        xy = _c(xy)
+        inf = _c(inf, np.uint8)
+        n = xy.size // 8
+        cfg = MsmConfig(window_bits, precompute_levels, 0)
+        h = C.c_void_p()
+        _chk(_lib.zg_g1_bases_upload_sharded(_h(xy), _hb(inf), C.c_size_t(n), C.byref(cfg), C.byref(h)), "zg_g1_bases_upload_sharded")
+        return cls(h, n)
+
+    def shards(self):
+        """[(device, start, len)] per shard"""
+        out = []
+        for i in range(int(_lib.zg_g1_sbases_shards(self._h))):
+            d, st, ln = C.c_int(), C.c_size_t(), C.c_size_t()
+            _chk(_lib.zg_g1_sbases_shard(self._h, C.c_int(i), C.byref(d), C.byref(st), C.byref(ln)), "zg_g1_sbases_shard")
+            out.append((d.value, st.value, ln.value))
+        return out
+
+    def exchange(self):
+        return self.EXCHANGE[int(_lib.zg_g1_sbases_exchange(self._h))]
+
+    def msm(self, scalars, n=None):
+        scalars = _c(scalars)
+        n = scalars.size // 4 if n is None else n
+        out = np.empty(8, dtype=np.uint64)
+        inf = C.c_uint8(0)
+        _chk(_lib.zg_msm_g1_sharded(self._h, C.c_size_t(n), _h(scalars), _h(out), C.byref(inf)), "zg_msm_g1_sharded")
+        return out, int(inf.value)
+
+    def msm_dev(self, d_scalars_per_shard, n):
+        arr = (C.c_void_p * len(d_scalars_per_shard))(*[int(p) if p else None for p in d_scalars_per_shard])
+        out = np.empty(8, dtype=np.uint64)
+        inf = C.c_uint8(0)
+        _chk(_lib.zg_msm_g1_sharded_dev(self._h, C.c_size_t(n), arr, _h(out), C.byref(inf)), "zg_msm_g1_sharded_dev")
+        return out, int(inf.value)
+
+    def msm_batch(self, batches, n=None):
+        batches = [_c(b) for b in batches]
+        k = len(batches)
+        n = (batches[0].size // 4 if k else 0) if n is None else n
+        arr = (_u64p * max(k, 1))(*[_h(b) for b in batches])
+        out = np.empty((k, 8), dtype=np.uint64)
+        inf = np.zeros(k, dtype=np.uint8)
+        _chk(_lib.zg_msm_g1_batch_sharded(self._h, C.c_size_t(n), arr, C.c_size_t(k), _h(out), _hb(inf)), "zg_msm_g1_batch_sharded")
+        return out, inf
+
+    def free(self):
+        if self._h:
+            _chk(_lib.zg_g1_sbases_free(self._h), "zg_g1_sbases_free")
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def g1_affine_add_batch(a_xy, a_inf, b_xy, b_inf):
+    """AffinePoint.add per pair (src/msm/mod.zig:74-103) -> (xy (n,8), inf (n,))"""
+    a_xy, b_xy = _c(a_xy), _c(b_xy)
+    a_inf, b_inf = _c(a_inf, np.uint8), _c(b_inf, np.uint8)
+    n = a_xy.size // 8
+    out = np.empty((n, 8), dtype=np.uint64)
+    oinf = np.zeros(n, dtype=np.uint8)
+    _chk(_lib.zg_g1_affine_add_batch(_h(a_xy), _hb(a_inf), _h(b_xy), _hb(b_inf), C.c_size_t(n), _h(out), _hb(oinf)), "zg_g1_affine_add_batch")
+    return out, oinf
+
+
+def fr_scale(a, s):
+    a = _c(a)
+    out = np.empty_like(a)
+    _chk(_lib.zg_fr_scale(_h(a), C.c_size_t(a.size // 4), _h(_c(s)), _h(out)), "zg_fr_scale")
+    return out
 
 
 def combine_partials_dev(d_partials, k, stream=0):
@@ -412,6 +522,51 @@ class SumcheckSession:
     def close(self):
         if self._h:
             _chk(_lib.zg_sumcheck_close(self._h), "zg_sumcheck_close")
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ShardedSumcheckSession:
+    """Sumcheck(F).Prover over a table sharded across the devices bound by init_devices (zg_sumcheck_*_sharded)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def open(cls, evals, layout=SC_HIGH_HALF):
+        e = _c(evals)
+        h = C.c_void_p()
+        _chk(_lib.zg_sumcheck_open_sharded(_h(e), C.c_size_t(e.size // 4), C.c_int(layout), C.byref(h)), "zg_sumcheck_open_sharded")
+        return cls(h)
+
+    def shards(self):
+        return int(_lib.zg_sumcheck_shards(self._h))
+
+    def round_sums(self):
+        g0 = np.empty(4, dtype=np.uint64)
+        g1 = np.empty(4, dtype=np.uint64)
+        _chk(_lib.zg_sumcheck_round_sums_sharded(self._h, _h(g0), _h(g1)), "zg_sumcheck_round_sums_sharded")
+        return g0, g1
+
+    def bind(self, r):
+        _chk(_lib.zg_sumcheck_bind_sharded(self._h, _h(_c(r))), "zg_sumcheck_bind_sharded")
+
+    def __len__(self):
+        return int(_lib.zg_sumcheck_len_sharded(self._h))
+
+    def final(self):
+        out = np.empty(4, dtype=np.uint64)
+        _chk(_lib.zg_sumcheck_final_sharded(self._h, _h(out)), "zg_sumcheck_final_sharded")
+        return out
+
+    def close(self):
+        if self._h:
+            _chk(_lib.zg_sumcheck_close_sharded(self._h), "zg_sumcheck_close_sharded")
             self._h = None
 
     def __del__(self):
