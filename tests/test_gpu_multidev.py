@@ -50,7 +50,7 @@ def test_sharded_msm_equals_oracle(env, shards, monkeypatch):
         wp = ob.msm_g1_parallel(gm, inf, sc, shards)
         assert got[1] == wp[1] and np.array_equal(got[0], wp[0])
         # a prefix (HyperKZG.commit of a shorter polynomial): trailing shards contribute the identity
-        for n in (0, 1, per, per + 1, N - 1):
+        for n in sorted({0, 1, min(per, N), min(per + 1, N), N - 1}):
             w = ob.msm_g1(gm[:n], inf[:n], sc[:n])
             g = sb.msm(sc[:n], n)
             assert g[1] == w[1] and np.array_equal(g[0], w[0]), n

@@ -119,6 +119,7 @@ struct zg_bases_s {
     zg_bases_s *small = nullptr;
     uint64_t *d_out = nullptr;  // 16 x u64: result record + flag
     uint64_t *h_out = nullptr;  // pinned mirror
+    uint64_t *d_slice_parts = nullptr;  // zg_msm_g1 (host scalars, sliced): one Jacobian partial per slice
     std::mutex mu;
 };
 
@@ -1407,7 +1408,7 @@ static hipError_t lane_alloc(zg_bases_s::Lane &ln, const MsmPlan &p, size_t n_to
 static void free_bases(zg_bases_s *b) {
     if (!b) return;
     free_bases(b->small);
-    void *ptrs[] = {b->d_table, b->d_inf, b->d_scal, b->d_out};
+    void *ptrs[] = {b->d_table, b->d_inf, b->d_scal, b->d_out, b->d_slice_parts};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &ln : b->lanes) lane_free(ln);
@@ -1819,6 +1820,54 @@ int zg_msm_g1_dev(zg_bases_t b, size_t off, size_t n, const uint64_t *d_scalars,
     return msm_to_host(b, off, n, d_scalars, pick_stream(stream), out_xy, out_inf);
 }
 
+// The host-scalar entry point — what an unmodified MSM.compute / HyperKZG.commit call site reaches — pays a 32*n-byte H2D copy
+// (0.7 ms at 2^20 over PCIe Gen5) before anything can run. Long vectors are therefore cut into slices: slice i's copy runs
+// while slice i-1's launch set computes (three streams, the handle's workspaces rotate), every slice ends in an un-normalised
+// Jacobian partial, and one combine launch adds them up (the group sum does not depend on how the points were grouped, so
+// the bytes are those of the unsliced MSM).
+static int ensure_aux_streams(zg_bases_s *b);
+static constexpr size_t HOST_SLICE_MIN_POINTS = (size_t)1 << 18;
+static constexpr int HOST_SLICES_MAX = 8;
+
+static int msm_host_sliced(zg_bases_s *b, size_t off, size_t n, const uint64_t *scalars, int slices, uint64_t out_xy[8], uint8_t *out_inf) {
+    hipStream_t st = lib_stream();
+    ZG_TRY(ensure_aux_streams(b));
+    if (!b->d_slice_parts) ZG_HIP(hipMalloc((void **)&b->d_slice_parts, HOST_SLICES_MAX * 12 * 8));
+    hipStream_t ss[3] = {st, b->aux[0], b->aux[1]};
+    ZG_HIP(hipEventRecord(b->ev_fork, st));
+    for (int i = 0; i < 2; i++) ZG_HIP(hipStreamWaitEvent(b->aux[i], b->ev_fork, 0));
+    const size_t per = (n + (size_t)slices - 1) / (size_t)slices;
+    int rc = ZG_OK;
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < slices && rc == ZG_OK && e == hipSuccess; i++) {
+        size_t a = (size_t)i * per, cnt = a >= n ? 0 : (n - a < per ? n - a : per);
+        hipStream_t si = ss[i % 3];
+        if (cnt) e = hipMemcpyAsync(b->d_scal + 4 * a, scalars + 4 * a, cnt * 32, hipMemcpyHostToDevice, si);
+        if (e == hipSuccess) rc = msm_enqueue(b, off + a, cnt, b->d_scal + 4 * a, si, 2, b->d_slice_parts + 12 * (size_t)i, nullptr);
+    }
+    for (int i = 0; i < 2; i++) {  // join even after an error so the helpers never run ahead of the caller's next work
+        hipError_t e1 = hipEventRecord(b->ev_join[i], b->aux[i]);
+        if (e1 == hipSuccess) e1 = hipStreamWaitEvent(st, b->ev_join[i], 0);
+        if (e == hipSuccess) e = e1;
+    }
+    if (rc == ZG_OK && e == hipSuccess) {
+        hipLaunchKernelGGL(msm_combine_kernel, dim3(1), dim3(64), 0, st, b->d_slice_parts, (uint32_t)slices, 12u, b->d_out,
+                           reinterpret_cast<uint8_t *>(b->d_out + 8), 0u, 0u);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(b->h_out, b->d_out, 9 * 8, hipMemcpyDeviceToHost, st);
+    }
+    hipError_t e2 = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = e2;
+    if (rc != ZG_OK) return rc;
+    if (e != hipSuccess) {
+        set_error(std::string("zg_msm_g1 (sliced): ") + hipGetErrorString(e));
+        return ZG_ERR_HIP;
+    }
+    for (int i = 0; i < 8; i++) out_xy[i] = b->h_out[i];
+    if (out_inf) *out_inf = (uint8_t)(b->h_out[8] & 0xff);
+    return ZG_OK;
+}
+
 int zg_msm_g1(zg_bases_t b, size_t off, size_t n, const uint64_t *scalars, uint64_t out_xy[8], uint8_t *out_inf) {
     ZG_INIT();
     if (!b || !out_xy || (n && !scalars)) {
@@ -1832,10 +1881,11 @@ int zg_msm_g1(zg_bases_t b, size_t off, size_t n, const uint64_t *scalars, uint6
     DeviceGuard dg(b->device);
     std::lock_guard<std::mutex> lk(b->mu);
     hipStream_t st = lib_stream();
-    if (n) {
-        if (!b->d_scal) ZG_HIP(hipMalloc((void **)&b->d_scal, b->n * 32));
-        ZG_HIP(hipMemcpyAsync(b->d_scal, scalars, n * 32, hipMemcpyHostToDevice, st));
-    }
+    if (n && !b->d_scal) ZG_HIP(hipMalloc((void **)&b->d_scal, b->n * 32));
+    int slices = env_int("ZG_MSM_HOST_SLICES", 4);
+    if (slices > HOST_SLICES_MAX) slices = HOST_SLICES_MAX;
+    if (slices >= 2 && n >= HOST_SLICE_MIN_POINTS && b->lanes.size() >= 2) return msm_host_sliced(b, off, n, scalars, slices, out_xy, out_inf);
+    if (n) ZG_HIP(hipMemcpyAsync(b->d_scal, scalars, n * 32, hipMemcpyHostToDevice, st));
     return msm_to_host(b, off, n, b->d_scal, st, out_xy, out_inf);
 }
 
@@ -1895,6 +1945,21 @@ static size_t batch_fuse_limit(const zg_bases_s *b, size_t n, bool wide_ok = fal
     return lim >= 2 ? lim : 0;
 }
 
+// the handle's two helper streams (+ fork / join events): independent launch sets rotate over the caller's stream and these
+static int ensure_aux_streams(zg_bases_s *b) {
+    if (b->aux[0]) return ZG_OK;
+    hipError_t e = hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming);
+    for (int i = 0; i < 2 && e == hipSuccess; i++) {
+        e = hipStreamCreateWithFlags(&b->aux[i], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_join[i], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) {
+        set_error(std::string("msm helper streams: ") + hipGetErrorString(e));
+        return ZG_ERR_HIP;
+    }
+    return ZG_OK;
+}
+
 // enqueue k scalar vectors (device, back to back) over bases[0, n) on st. mode 0: record i = d_out9[9*i .. 9*i+8] (xy[8], flag
 // word); mode 1 / 2: record i = 12 limbs at d_out9 + 12*i (Jacobian partial, normalised / any representative — see write_result)
 static int msm_batch_enqueue(zg_bases_s *b, size_t n, const uint64_t *d_scalars, size_t k, hipStream_t st, uint64_t *d_out9,
@@ -1911,17 +1976,7 @@ static int msm_batch_enqueue(zg_bases_s *b, size_t n, const uint64_t *d_scalars,
         // one launch set per vector, rotating through the handle's workspaces AND through three streams (the caller's
         // plus two forked helpers), so the latency-bound tail of one MSM runs under the accumulation of the next
         bool fork = k >= 2 && n > 0 && b->lanes.size() >= 2;
-        if (fork && !b->aux[0]) {
-            hipError_t e = hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming);
-            for (int i = 0; i < 2 && e == hipSuccess; i++) {
-                e = hipStreamCreateWithFlags(&b->aux[i], hipStreamNonBlocking);
-                if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_join[i], hipEventDisableTiming);
-            }
-            if (e != hipSuccess) {
-                set_error(std::string("msm batch streams: ") + hipGetErrorString(e));
-                return ZG_ERR_HIP;
-            }
-        }
+        if (fork) ZG_TRY(ensure_aux_streams(b));
         if (fork) {
             ZG_HIP(hipEventRecord(b->ev_fork, st));
             for (int i = 0; i < 2; i++) ZG_HIP(hipStreamWaitEvent(b->aux[i], b->ev_fork, 0));
