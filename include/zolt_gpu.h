@@ -242,6 +242,19 @@ ZG_API int zg_sumcheck_read(zg_sc_t s, uint64_t *out_table); /* copy the current
 ZG_API int zg_sumcheck_round_sums_dev(zg_sc_t s, uint64_t *d_out8);
 ZG_API int zg_sumcheck_read_dev(zg_sc_t s, uint64_t *d_out_table);
 ZG_API int zg_sumcheck_close(zg_sc_t s);
+/* Prover fold sites beyond the generic Sumcheck.Prover. On a LOW_PAIR session holding RaPolynomial's table:
+ * RafEvaluationProver.computeRoundPolynomialCubic's two sums (src/zkvm/ram/raf_checking.zig:335-410)
+ *   s(0) = sum_i ra[2i] * u0(i),  s(2) = sum_i (2 ra[2i+1] - ra[2i]) * (u0(i) + 2 * current_power),
+ *   u0(i) = base + 2 * current_power * i   (as field elements; `base` = start_address + 8 * sum_j bound_j 2^j, Montgomery),
+ * in one pass over the table; s(1) = claim - s(0) and s(3) = s(0) - 3 s(1) + 3 s(2) are host scalar code, the fold of the round
+ * (RaPolynomial.bind, :162-174) is zg_sumcheck_bind. */
+ZG_API int zg_sumcheck_raf_round(zg_sc_t s, const uint64_t base[4], uint64_t current_power, uint64_t s0[4], uint64_t s2[4]);
+/* LassoProver.computeAddressRoundPoly's two sums (src/zkvm/lasso/prover.zig:283-293): sum0 / sum1 = the sum of vals[j] over the
+ * entries whose u128 lookup index (idx128: n x 2 little-endian u64 words) has bit `bit` clear / set. The _dev form keeps eq_evals
+ * and the indices resident across the LOG_K address rounds. */
+ZG_API int zg_fr_bit_split_sums(const uint64_t *vals, const uint64_t *idx128, size_t n, unsigned bit, uint64_t sum0[4], uint64_t sum1[4]);
+ZG_API int zg_fr_bit_split_sums_dev(const uint64_t *d_vals, const uint64_t *d_idx128, size_t n, unsigned bit, void *stream, uint64_t sum0[4],
+                             uint64_t sum1[4]);
 
 /* runSumcheck (src/subprotocols/mod.zig:302-354) with the WHOLE protocol on the device: the prover's sums and folds
  * (bindFirst order) and the reference's toy verifier (verifyRound / deriveChallenge, :165-243: the deterministic

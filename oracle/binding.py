@@ -363,3 +363,70 @@ def run_sumcheck(evals):
     fin = np.empty(4, dtype=np.uint64)
     ok = lib.zo_run_sumcheck(_p(e), C.c_size_t(v), _p(claim), _p(rounds), _p(chals), _p(fin))
     return claim, rounds, chals, fin, int(ok)
+
+
+# ---- prover fold sites + host transcript
+def keccak_f1600(lanes):
+    st = np.array(lanes, dtype=np.uint64).copy()
+    lib.zo_keccak_f1600(_p(st))
+    return st
+
+
+class Transcript:
+    """Keccak Transcript(F) of the reference (src/transcripts/mod.zig:49-161), state held in a 208-byte buffer."""
+
+    def __init__(self, domain=b"Jolt"):
+        self._buf = C.create_string_buffer(208)
+        lib.zo_transcript_init(self._buf, C.c_char_p(bytes(domain)), C.c_size_t(len(domain)))
+
+    def append_bytes(self, data):
+        data = bytes(data)
+        lib.zo_transcript_append_bytes(self._buf, C.c_char_p(data), C.c_size_t(len(data)))
+
+    def append_scalar(self, label, scalar):
+        label = bytes(label)
+        lib.zo_transcript_append_scalar(self._buf, C.c_char_p(label), C.c_size_t(len(label)), _p(_c(scalar)))
+
+    def challenge_scalar(self, label):
+        label = bytes(label)
+        out = np.empty(4, dtype=np.uint64)
+        lib.zo_transcript_challenge_scalar(self._buf, C.c_char_p(label), C.c_size_t(len(label)), _p(out))
+        return out
+
+    def state_bytes(self):
+        return bytes(self._buf.raw[:200]), int.from_bytes(self._buf.raw[200:208], "little")
+
+
+def stage1_prove(combined_poly, num_rounds, transcript):
+    """prover.zig:397-432 -> (round_polys (rounds,3,4), challenges (rounds,4), final_eval)"""
+    poly = np.array(combined_poly, dtype=np.uint64, copy=True).reshape(-1, 4)
+    rp = np.zeros((num_rounds, 3, 4), dtype=np.uint64)
+    ch = np.zeros((num_rounds, 4), dtype=np.uint64)
+    fin = np.zeros(4, dtype=np.uint64)
+    lib.zo_stage1_prove(_p(poly), C.c_size_t(poly.shape[0]), C.c_size_t(num_rounds), transcript._buf, _p(rp), _p(ch), _p(fin))
+    return rp, ch, fin
+
+
+def raf_round_cubic(ra, start_address, bound, unmap_num_vars, current_claim):
+    """RafEvaluationProver.computeRoundPolynomialCubic (raf_checking.zig:335-410) -> (4,4): s(0..3)"""
+    ra = _c(ra).reshape(-1, 4)
+    bound = _c(bound).reshape(-1, 4) if bound is not None and len(bound) else np.zeros((0, 4), dtype=np.uint64)
+    nv = ra.shape[0].bit_length() - 1
+    out = np.zeros((4, 4), dtype=np.uint64)
+    lib.zo_raf_round_cubic(_p(ra), C.c_size_t(nv), C.c_uint64(start_address), _p(bound), C.c_size_t(bound.shape[0]), C.c_size_t(unmap_num_vars),
+                           _p(_c(current_claim)), _p(out))
+    return out
+
+
+def raf_update_claim(evals, challenge):
+    out = np.zeros(4, dtype=np.uint64)
+    lib.zo_raf_update_claim(_p(_c(evals)), _p(_c(challenge)), _p(out))
+    return out
+
+
+def lasso_address_sums(eq_evals, idx128, round_bit):
+    """LassoProver.computeAddressRoundPoly's sums (lasso/prover.zig:283-293); idx128: (n,2) uint64 little-endian halves"""
+    eq_evals, idx128 = _c(eq_evals), _c(idx128)
+    s0, s1 = np.zeros(4, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
+    lib.zo_lasso_address_sums(_p(eq_evals), _p(idx128), C.c_size_t(eq_evals.size // 4), C.c_uint(round_bit), _p(s0), _p(s1))
+    return s0, s1

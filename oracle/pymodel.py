@@ -154,3 +154,72 @@ def run_sumcheck(evals):
         chals.append(c)
         rnd += 1
     return claim, rounds, chals, t[0], vclaim == t[0]
+
+
+# ---- Keccak Fiat-Shamir transcript (src/transcripts/mod.zig:19-221), independent big-int / byte model
+_KECCAK_RC = [0x0000000000000001, 0x0000000000008082, 0x800000000000808a, 0x8000000080008000, 0x000000000000808b, 0x0000000080000001,
+              0x8000000080008081, 0x8000000000008009, 0x000000000000008a, 0x0000000000000088, 0x0000000080008009, 0x000000008000000a,
+              0x000000008000808b, 0x800000000000008b, 0x8000000000008089, 0x8000000000008003, 0x8000000000008002, 0x8000000000000080,
+              0x000000000000800a, 0x800000008000000a, 0x8000000080008081, 0x8000000000008080, 0x0000000080000001, 0x8000000080008008]
+_KECCAK_ROTC = [1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44]
+_KECCAK_PILN = [10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1]
+_M64 = (1 << 64) - 1
+
+
+def keccak_f1600(st):
+    """st: list of 25 u64 lanes -> permuted lanes (24 rounds, src/transcripts/mod.zig:163-213)."""
+    st = list(st)
+    rotl = lambda x, n: ((x << n) | (x >> (64 - n))) & _M64
+    for rnd in range(24):
+        bc = [st[i] ^ st[i + 5] ^ st[i + 10] ^ st[i + 15] ^ st[i + 20] for i in range(5)]
+        for i in range(5):
+            t = bc[(i + 4) % 5] ^ rotl(bc[(i + 1) % 5], 1)
+            for j in range(i, 25, 5):
+                st[j] ^= t
+        t = st[1]
+        for i in range(24):
+            j = _KECCAK_PILN[i]
+            st[j], t = rotl(t, _KECCAK_ROTC[i]), st[j]
+        for row in range(0, 25, 5):
+            b = st[row:row + 5]
+            for i in range(5):
+                st[row + i] = b[i] ^ (~b[(i + 1) % 5] & _M64 & b[(i + 2) % 5])
+        st[0] ^= _KECCAK_RC[rnd]
+    return st
+
+
+class KeccakTranscript:
+    """Transcript(F) of the reference: bytes are XORed into a 200-byte state at `position`, a Keccak-f every 136 bytes (no
+    padding, no squeeze offset); challengeScalar = append label, one Keccak-f, F.fromBytes(state[0..32]) (little-endian, reduced
+    mod r). Field elements are absorbed as their raw MONTGOMERY limbs, little-endian (appendScalar, :100-110)."""
+    RATE = 136
+
+    def __init__(self, domain=b"Jolt"):
+        self.state = bytearray(200)
+        self.position = 0
+        self.append_bytes(domain)
+
+    def _permute(self):
+        lanes = [int.from_bytes(self.state[8 * i:8 * i + 8], "little") for i in range(25)]
+        lanes = keccak_f1600(lanes)
+        for i, v in enumerate(lanes):
+            self.state[8 * i:8 * i + 8] = v.to_bytes(8, "little")
+
+    def append_bytes(self, data):
+        for byte in bytes(data):
+            self.state[self.position] ^= byte
+            self.position += 1
+            if self.position >= self.RATE:
+                self._permute()
+                self.position = 0
+
+    def append_scalar_mont(self, label, mont_value):
+        """mont_value: the element's Montgomery representative as an int (what scalar.limbs hold)"""
+        self.append_bytes(label)
+        self.append_bytes(int(mont_value).to_bytes(32, "little"))
+
+    def challenge_scalar(self, label, mod=R_MOD):
+        """-> canonical int value of the challenge (F.fromBytes reduces the 256-bit little-endian integer mod r)"""
+        self.append_bytes(label)
+        self._permute()
+        return int.from_bytes(self.state[:32], "little") % mod

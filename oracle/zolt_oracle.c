@@ -908,3 +908,194 @@ EXPORT int zo_run_sumcheck(const uint64_t *evals, size_t num_vars, uint64_t clai
     free(cur);
     return ok;
 }
+
+/* ================================================================== prover fold sites + host transcript
+ * Keccak Fiat-Shamir transcript — src/transcripts/mod.zig:19-221. State = 200 bytes + a position; bytes are XORed in at
+ * `position`, a Keccak-f[1600] every 136 bytes (no padding); challengeScalar = append label, one Keccak-f,
+ * F.fromBytes(state[0..32]) (:116-130). appendScalar absorbs the element's raw Montgomery limbs, little-endian (:100-110). */
+static const uint64_t KECCAK_RC[24] = {
+    0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL, 0x0000000080000001ULL,
+    0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+    0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL,
+    0x000000000000800aULL, 0x800000008000000aULL, 0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+static const unsigned KECCAK_ROTC[24] = {1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44};
+static const unsigned KECCAK_PILN[24] = {10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1};
+static inline uint64_t rotl64(uint64_t x, unsigned n) { return (x << n) | (x >> (64 - n)); }
+
+/* keccakF — :163-213, on 25 little-endian lanes */
+EXPORT void zo_keccak_f1600(uint64_t st[25]) {
+    for (int round = 0; round < 24; round++) {
+        uint64_t bc[5];
+        for (int i = 0; i < 5; i++) bc[i] = st[i] ^ st[i + 5] ^ st[i + 10] ^ st[i + 15] ^ st[i + 20];
+        for (int i = 0; i < 5; i++) {
+            uint64_t t = bc[(i + 4) % 5] ^ rotl64(bc[(i + 1) % 5], 1);
+            for (int j = i; j < 25; j += 5) st[j] ^= t;
+        }
+        uint64_t t = st[1];
+        for (int i = 0; i < 24; i++) {
+            unsigned j = KECCAK_PILN[i];
+            uint64_t tmp = st[j];
+            st[j] = rotl64(t, KECCAK_ROTC[i]);
+            t = tmp;
+        }
+        for (int j = 0; j < 5; j++) {
+            int row = j * 5;
+            for (int i = 0; i < 5; i++) bc[i] = st[row + i];
+            for (int i = 0; i < 5; i++) st[row + i] = bc[i] ^ (~bc[(i + 1) % 5] & bc[(i + 2) % 5]);
+        }
+        st[0] ^= KECCAK_RC[round];
+    }
+}
+
+typedef struct { uint8_t state[200]; uint64_t position; } zo_transcript;  /* 208 bytes, plain data: callers keep it in a byte buffer */
+
+static void tr_permute(zo_transcript *t) {
+    uint64_t st[25];
+    for (int i = 0; i < 25; i++) { uint64_t v = 0; for (int b = 7; b >= 0; b--) v = (v << 8) | t->state[8 * i + b]; st[i] = v; }
+    zo_keccak_f1600(st);
+    for (int i = 0; i < 25; i++) for (int b = 0; b < 8; b++) t->state[8 * i + b] = (uint8_t)(st[i] >> (8 * b));
+}
+/* appendBytes — :88-98 */
+EXPORT void zo_transcript_append_bytes(zo_transcript *t, const uint8_t *data, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        t->state[t->position] ^= data[i];
+        t->position += 1;
+        if (t->position >= 136) { tr_permute(t); t->position = 0; }
+    }
+}
+/* init — :61-74 */
+EXPORT void zo_transcript_init(zo_transcript *t, const uint8_t *domain, size_t n) {
+    memset(t, 0, sizeof(*t));
+    zo_transcript_append_bytes(t, domain, n);
+}
+/* appendScalar — :100-110 */
+EXPORT void zo_transcript_append_scalar(zo_transcript *t, const uint8_t *label, size_t label_len, const uint64_t scalar[4]) {
+    zo_transcript_append_bytes(t, label, label_len);
+    uint8_t buf[32];
+    for (int i = 0; i < 4; i++) for (int b = 0; b < 8; b++) buf[8 * i + b] = (uint8_t)(scalar[i] >> (8 * b));
+    zo_transcript_append_bytes(t, buf, 32);
+}
+/* challengeScalar — :116-130; F.fromBytes — src/field/mod.zig:625-639 (raw little-endian limbs times R^2) */
+EXPORT void zo_transcript_challenge_scalar(zo_transcript *t, const uint8_t *label, size_t label_len, uint64_t out[4]) {
+    zo_transcript_append_bytes(t, label, label_len);
+    tr_permute(t);
+    fe raw;
+    for (int i = 0; i < 4; i++) { uint64_t v = 0; for (int b = 7; b >= 0; b--) v = (v << 8) | t->state[8 * i + b]; raw.l[i] = v; }
+    fe r = f_to_mont(&FR, &raw);
+    memcpy(out, &r, 32);
+}
+
+/* Stage 1 (outer Spartan sumcheck) round loop — src/zkvm/prover.zig:397-432 over JoltSpartanInterface.computeRoundPolynomial /
+ * bindChallenge (src/zkvm/r1cs/jolt_r1cs.zig:413-486): per round [p0, p1, p2 = 2 p1 - p0] with p0 / p1 the sums over even /
+ * odd indices (current_len <= 1: [poly[0] or 0, 0, 0] and no fold); the three values are absorbed as "round_poly_0/1/2", the
+ * challenge is challengeScalar("spartan_round"), the fold is new[i] = (1-r) old[2i] + r old[2i+1]. combined: len entries
+ * (modified in place); outputs: round_polys num_rounds x 3 x 4, challenges num_rounds x 4, final_eval = combined_poly[0]. */
+EXPORT void zo_stage1_prove(uint64_t *combined, size_t len, size_t num_rounds, zo_transcript *t, uint64_t *round_polys,
+                            uint64_t *challenges, uint64_t final_eval[4]) {
+    fe *poly = (fe *)combined;
+    size_t cur = len;
+    for (size_t round = 0; round < num_rounds; round++) {
+        fe p0 = f_zero(), p1 = f_zero(), p2 = f_zero();
+        if (cur <= 1) {
+            if (cur == 1) p0 = poly[0];
+        } else {
+            size_t half = cur / 2;
+            for (size_t i = 0; i < half; i++) { p0 = f_add(&FR, &p0, &poly[2 * i]); p1 = f_add(&FR, &p1, &poly[2 * i + 1]); }
+            fe d = f_add(&FR, &p1, &p1);
+            p2 = f_sub(&FR, &d, &p0);
+        }
+        memcpy(round_polys + 12 * round, &p0, 32); memcpy(round_polys + 12 * round + 4, &p1, 32); memcpy(round_polys + 12 * round + 8, &p2, 32);
+        zo_transcript_append_scalar(t, (const uint8_t *)"round_poly_0", 12, p0.l);
+        zo_transcript_append_scalar(t, (const uint8_t *)"round_poly_1", 12, p1.l);
+        zo_transcript_append_scalar(t, (const uint8_t *)"round_poly_2", 12, p2.l);
+        fe ch;
+        zo_transcript_challenge_scalar(t, (const uint8_t *)"spartan_round", 13, ch.l);
+        memcpy(challenges + 4 * round, &ch, 32);
+        if (cur > 1) {
+            size_t half = cur / 2;
+            fe one = f_one(&FR), omr = f_sub(&FR, &one, &ch);
+            for (size_t i = 0; i < half; i++) {
+                fe a = f_mul(&FR, &omr, &poly[2 * i]), b = f_mul(&FR, &ch, &poly[2 * i + 1]);
+                poly[i] = f_add(&FR, &a, &b);
+            }
+            cur = half;
+        }
+    }
+    fe fin = len ? poly[0] : f_zero();
+    memcpy(final_eval, &fin, 32);
+}
+
+/* RafEvaluationProver.computeRoundPolynomialCubic — src/zkvm/ram/raf_checking.zig:335-410. ra: the 2^num_vars active entries
+ * (LowToHigh pairs 2i, 2i+1); bound: the `round` challenges bound so far; unmap_num_vars = UnmapPolynomial.num_vars.
+ * out: s(0), s(1), s(2), s(3). */
+EXPORT void zo_raf_round_cubic(const uint64_t *ra, size_t ra_num_vars, uint64_t start_address, const uint64_t *bound, size_t round,
+                               size_t unmap_num_vars, const uint64_t current_claim[4], uint64_t out[16]) {
+    const fe *evals = (const fe *)ra;
+    size_t active_len = (size_t)1 << ra_num_vars, half = active_len / 2;
+    fe s0 = f_zero(), s2 = f_zero();
+    fe base = f_from_u64(&FR, start_address);
+    uint64_t power = 8;
+    for (size_t j = 0; j < round; j++) {
+        fe pw = f_from_u64(&FR, power), term = f_mul(&FR, (const fe *)(bound + 4 * j), &pw);
+        base = f_add(&FR, &base, &term);
+        power *= 2;
+    }
+    const uint64_t current_power = power;
+    for (size_t i = 0; i < half; i++) {
+        fe ra_lo = evals[2 * i], ra_hi = evals[2 * i + 1];
+        fe dbl = f_add(&FR, &ra_hi, &ra_hi), ra_at_2 = f_sub(&FR, &dbl, &ra_lo);
+        fe remaining = f_zero();
+        uint64_t remaining_power = current_power * 2;
+        size_t remaining_vars = unmap_num_vars - round - 1, idx = i;
+        for (size_t k = 0; k < remaining_vars; k++) {
+            if (idx & 1) { fe rp = f_from_u64(&FR, remaining_power); remaining = f_add(&FR, &remaining, &rp); }
+            idx >>= 1;
+            remaining_power *= 2;
+        }
+        fe u0 = f_add(&FR, &base, &remaining);
+        fe cp2 = f_from_u64(&FR, current_power * 2), u2 = f_add(&FR, &base, &cp2);
+        u2 = f_add(&FR, &u2, &remaining);
+        fe t0 = f_mul(&FR, &ra_lo, &u0), t2 = f_mul(&FR, &ra_at_2, &u2);
+        s0 = f_add(&FR, &s0, &t0);
+        s2 = f_add(&FR, &s2, &t2);
+    }
+    fe s1 = f_sub(&FR, (const fe *)current_claim, &s0);
+    fe three = f_from_u64(&FR, 3), a = f_mul(&FR, &s1, &three), b = f_mul(&FR, &s2, &three);
+    fe s3 = f_sub(&FR, &s0, &a);
+    s3 = f_add(&FR, &s3, &b);
+    memcpy(out, &s0, 32); memcpy(out + 4, &s1, 32); memcpy(out + 8, &s2, 32); memcpy(out + 12, &s3, 32);
+}
+
+/* RafEvaluationProver.updateClaim — :420-445: Lagrange interpolation of evals at 0,1,2,3 at the challenge */
+EXPORT void zo_raf_update_claim(const uint64_t evals[16], const uint64_t challenge[4], uint64_t out[4]) {
+    const fe *e = (const fe *)evals;
+    fe c = *(const fe *)challenge, one = f_one(&FR), zero = f_zero();
+    fe two = f_from_u64(&FR, 2), three = f_from_u64(&FR, 3), six = f_from_u64(&FR, 6);
+    fe cm1 = f_sub(&FR, &c, &one), cm2 = f_sub(&FR, &c, &two), cm3 = f_sub(&FR, &c, &three);
+    fe neg6 = f_sub(&FR, &zero, &six), neg2 = f_sub(&FR, &zero, &two);
+    fe i_neg6, i_2, i_neg2, i_6;  /* .inverse().? — none of -6, 2, -2, 6 is zero */
+    (void)f_inv(&FR, &neg6, &i_neg6); (void)f_inv(&FR, &two, &i_2); (void)f_inv(&FR, &neg2, &i_neg2); (void)f_inv(&FR, &six, &i_6);
+    fe L0 = f_mul(&FR, &cm1, &cm2); L0 = f_mul(&FR, &L0, &cm3); L0 = f_mul(&FR, &L0, &i_neg6);
+    fe L1 = f_mul(&FR, &c, &cm2); L1 = f_mul(&FR, &L1, &cm3); L1 = f_mul(&FR, &L1, &i_2);
+    fe L2 = f_mul(&FR, &c, &cm1); L2 = f_mul(&FR, &L2, &cm3); L2 = f_mul(&FR, &L2, &i_neg2);
+    fe L3 = f_mul(&FR, &c, &cm1); L3 = f_mul(&FR, &L3, &cm2); L3 = f_mul(&FR, &L3, &i_6);
+    fe r = f_mul(&FR, &e[0], &L0), t = f_mul(&FR, &e[1], &L1);
+    r = f_add(&FR, &r, &t);
+    t = f_mul(&FR, &e[2], &L2); r = f_add(&FR, &r, &t);
+    t = f_mul(&FR, &e[3], &L3); r = f_add(&FR, &r, &t);
+    memcpy(out, &r, 32);
+}
+
+/* LassoProver.computeAddressRoundPoly's two sums — src/zkvm/lasso/prover.zig:283-293: eq_evals split by bit `round` of the
+ * u128 lookup index (idx: n x 2 u64, little-endian halves). */
+EXPORT void zo_lasso_address_sums(const uint64_t *eq_evals, const uint64_t *idx, size_t n, unsigned round_bit, uint64_t sum0[4],
+                                  uint64_t sum1[4]) {
+    fe s0 = f_zero(), s1 = f_zero();
+    for (size_t j = 0; j < n; j++) {
+        uint64_t word = round_bit < 64 ? idx[2 * j] : idx[2 * j + 1];
+        unsigned bit = (unsigned)((word >> (round_bit & 63)) & 1);
+        const fe *v = (const fe *)(eq_evals + 4 * j);
+        if (bit == 0) s0 = f_add(&FR, &s0, v); else s1 = f_add(&FR, &s1, v);
+    }
+    memcpy(sum0, &s0, 32); memcpy(sum1, &s1, 32);
+}

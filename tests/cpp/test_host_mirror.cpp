@@ -224,6 +224,21 @@ TEST(parallel_msm_equals_msm) {
     for (size_t j = 0; j < 3; j++) EXPECT(out[j].eql(MSM::compute(pts, batches[j])));
 }
 
+// src/transcripts/mod.zig:49-161 — the host Keccak transcript. Expected limbs generated with the C oracle's restatement
+// (oracle.binding.Transcript: init "Jolt", appendScalar("round_poly_0", fromU64(7)), challengeScalar("spartan_round"); then
+// 200 bytes 'q' and challengeScalar("x")), itself pinned against hashlib.sha3_256 (tests/test_transcript_host.py).
+TEST(keccak_transcript_kat) {
+    Transcript t("Jolt");
+    t.appendScalar("round_poly_0", Fr::fromU64(7));
+    Fr c = t.challengeScalar("spartan_round");
+    Fr want{{0x1719faabca06f284ULL, 0x61cd547aaa4e2a6fULL, 0xee71ee5ce38605c0ULL, 0x01db5fa4e23c262bULL}};
+    EXPECT(c.eql(want));
+    t.appendBytes(std::string(200, 'q'));
+    Fr c2 = t.challengeScalar("x");
+    Fr want2{{0x769c3385e142fb3cULL, 0x9a870a5588cbfe6eULL, 0x201d82b576506a20ULL, 0x16cd0b4530a610dfULL}};
+    EXPECT(c2.eql(want2));
+}
+
 int main() {
     if (zg_init(0) != ZG_OK) { std::printf("zg_init failed: %s\n", zg_last_error()); return 2; }
     for (auto &t : tests()) {

@@ -523,3 +523,27 @@ def test_mock_srs_and_scalar_mul_at_reference_default_size(zl, ob):
     assert np.array_equal(params.powers_of_tau_g1, wsrs) and np.array_equal(params.infinity, winf)
     assert zl.g1_is_on_curve_batch(params.powers_of_tau_g1, params.infinity).all()
     params.deinit()
+
+
+@pytest.mark.parametrize("slices", [2, 3, 8])
+def test_host_scalar_path_sliced(zl, ob, gm, slices, monkeypatch):
+    """zg_msm_g1 with host scalars cuts long vectors into slices (copy of slice i under the launch set of slice i-1, partials
+    combined on the device): same bytes as the unsliced call and the oracle, including a sub-range and infinity bases."""
+    monkeypatch.setenv("ZG_MSM_HOST_SLICES", str(slices))
+    monkeypatch.setenv("ZG_MSM_HOST_SLICE_MIN", "1000")
+    n = 5003
+    inf = np.zeros(n, dtype=np.uint8)
+    inf[3::50] = 1
+    sc = ob.f_to_mont(ob.FR, U.random_raw256(4000 + slices, n))
+    b = zl.Bases.upload(gm[:n], inf)
+    try:
+        want = ob.msm_g1(gm[:n], inf, sc)
+        got = b.msm(sc)
+        assert got[1] == want[1] and np.array_equal(got[0], want[0])
+        w2 = ob.msm_g1(gm[100:4100], inf[100:4100], sc[:4000])
+        g2 = b.msm(sc[:4000], off=100, n=4000)
+        assert g2[1] == w2[1] and np.array_equal(g2[0], w2[0])
+        z = b.msm(np.zeros((n, 4), dtype=np.uint64))
+        assert z[1] == 1
+    finally:
+        b.free()

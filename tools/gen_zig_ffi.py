@@ -15,7 +15,7 @@ HDR = os.path.join(ROOT, "include", "zolt_gpu.h")
 OUT = os.path.join(ROOT, "zig", "gpu", "ffi.zig")
 
 HANDLES = {"zg_bases_t": "Bases", "zg_sc_t": "Session", "zg_sbases_t": "ShardedBases", "zg_ssc_t": "ShardedSession"}
-SCALARS = {"int": "c_int", "size_t": "usize", "uint64_t": "u64", "uint8_t": "u8", "double": "f64"}
+SCALARS = {"int": "c_int", "unsigned": "c_uint", "size_t": "usize", "uint64_t": "u64", "uint8_t": "u8", "double": "f64"}
 
 
 def split_params(arglist):

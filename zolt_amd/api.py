@@ -741,3 +741,210 @@ def runSumcheckInteractive(polynomial):
     prover.deinit()
     return {"claim": claim, "rounds": rounds, "final_point": list(verifier.challenges), "final_eval": final_eval,
             "result": bool(np.array_equal(verifier.claim, final_eval))}
+
+
+# ---- host Fiat-Shamir transcript + the prover fold sites driven by it
+_KECCAK_RC = [0x0000000000000001, 0x0000000000008082, 0x800000000000808a, 0x8000000080008000, 0x000000000000808b, 0x0000000080000001,
+              0x8000000080008081, 0x8000000000008009, 0x000000000000008a, 0x0000000000000088, 0x0000000080008009, 0x000000008000000a,
+              0x000000008000808b, 0x800000000000008b, 0x8000000000008089, 0x8000000000008003, 0x8000000000008002, 0x8000000000000080,
+              0x000000000000800a, 0x800000008000000a, 0x8000000080008081, 0x8000000000008080, 0x0000000080000001, 0x8000000080008008]
+_KECCAK_ROTC = [1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44]
+_KECCAK_PILN = [10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1]
+
+
+class Transcript:
+    """Transcript(F) — the reference's Keccak Fiat-Shamir transcript (src/transcripts/mod.zig:49-221), on the host, where it stays
+    in the reference integration too: a sequential hash between rounds. Field elements go in as their raw Montgomery limbs
+    (appendScalar, :100-110) and challenges come out through F.fromBytes (:116-130), so it plugs straight onto the C ABI's limbs."""
+    KECCAK_RATE = 136
+
+    def __init__(self, domain=b"Jolt"):
+        self.state = bytearray(200)
+        self.position = 0
+        self.appendBytes(domain)
+
+    def _keccakF(self):
+        st = [int.from_bytes(self.state[8 * i:8 * i + 8], "little") for i in range(25)]
+        for rc in _KECCAK_RC:
+            bc = [st[i] ^ st[i + 5] ^ st[i + 10] ^ st[i + 15] ^ st[i + 20] for i in range(5)]
+            for i in range(5):
+                b1 = bc[(i + 1) % 5]
+                t = bc[(i + 4) % 5] ^ (((b1 << 1) | (b1 >> 63)) & _M64)
+                for j in range(i, 25, 5):
+                    st[j] ^= t
+            t = st[1]
+            for i in range(24):
+                j, n = _KECCAK_PILN[i], _KECCAK_ROTC[i]
+                st[j], t = ((t << n) | (t >> (64 - n))) & _M64, st[j]
+            for row in range(0, 25, 5):
+                b = st[row:row + 5]
+                for i in range(5):
+                    st[row + i] = b[i] ^ ((~b[(i + 1) % 5]) & _M64 & b[(i + 2) % 5])
+            st[0] ^= rc
+        for i, v in enumerate(st):
+            self.state[8 * i:8 * i + 8] = v.to_bytes(8, "little")
+
+    def appendBytes(self, data):
+        for byte in bytes(data):
+            self.state[self.position] ^= byte
+            self.position += 1
+            if self.position >= self.KECCAK_RATE:
+                self._keccakF()
+                self.position = 0
+
+    def appendMessage(self, label, message):
+        self.appendBytes(label)
+        self.appendBytes(message)
+
+    def appendScalar(self, label, scalar):
+        self.appendBytes(label)
+        self.appendBytes(np.ascontiguousarray(scalar, dtype="<u8").tobytes())
+
+    def appendScalars(self, label, scalars):
+        self.appendBytes(label)
+        for s in np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4):
+            self.appendScalar(b"", s)
+
+    def challengeScalar(self, label):
+        self.appendBytes(label)
+        self._keccakF()
+        raw = np.frombuffer(bytes(self.state[:32]), dtype="<u8").astype(np.uint64)
+        return _limbs((_int(raw) % R_MOD) * _MONT_R % R_MOD)  # F.fromBytes: the 256-bit little-endian integer, reduced, Montgomery
+
+    def challengeScalars(self, label, count):
+        self.appendBytes(label)
+        return np.stack([self.challengeScalar(b"") for _ in range(count)]) if count else np.zeros((0, 4), dtype=np.uint64)
+
+
+def _fr_add(a, b):
+    return _limbs((_int(a) + _int(b)) % R_MOD)
+
+
+def _fr_sub(a, b):
+    return _limbs((_int(a) - _int(b)) % R_MOD)
+
+
+def proveStage1(combined_poly, num_rounds, transcript):
+    """The Stage-1 (outer Spartan) round loop of MultiStageProver.proveStage1 (src/zkvm/prover.zig:397-432) over
+    JoltSpartanInterface.computeRoundPolynomial / bindChallenge (src/zkvm/r1cs/jolt_r1cs.zig:413-486): the combined polynomial
+    lives in a LOW_PAIR device session; per round [p0, p1, 2 p1 - p0] comes back (64 bytes), is absorbed as round_poly_0/1/2,
+    the challenge is challengeScalar("spartan_round") and goes back in for the fold. -> dict(round_polys, challenges, final_eval)."""
+    poly = np.ascontiguousarray(combined_poly, dtype=np.uint64).reshape(-1, 4)
+    n = poly.shape[0]
+    sess = lib.SumcheckSession.open(poly, lib.SC_LOW_PAIR) if n >= 1 else None
+    zero = np.zeros(4, dtype=np.uint64)
+    round_polys, challenges = [], []
+    try:
+        for _ in range(num_rounds):
+            cur = len(sess) if sess is not None else 0
+            if cur <= 1:  # :421-430: single element -> [poly[0] or 0, 0, 0], bindChallenge does not fold (:462-465)
+                p0 = sess.final() if cur == 1 else zero
+                p1 = p2 = zero
+            else:
+                p0, p1 = sess.round_sums()  # even / odd sums (:436-444)
+                p2 = _fr_sub(_fr_add(p1, p1), p0)  # :449
+            round_polys.append(np.stack([p0, p1, p2]))
+            transcript.appendScalar(b"round_poly_0", p0)
+            transcript.appendScalar(b"round_poly_1", p1)
+            transcript.appendScalar(b"round_poly_2", p2)
+            ch = transcript.challengeScalar(b"spartan_round")
+            challenges.append(ch)
+            if cur > 1:
+                sess.bind(ch)
+        if sess is None:
+            final = zero
+        else:
+            final = sess.final() if len(sess) == 1 else sess.read()[0]  # getFinalEval = combined_poly[0] (:492-497)
+        return {"round_polys": np.array(round_polys).reshape(-1, 3, 4), "challenges": np.array(challenges).reshape(-1, 4), "final_eval": final}
+    finally:
+        if sess is not None:
+            sess.close()
+
+
+class RafEvaluationProver:
+    """RafEvaluationProver (src/zkvm/ram/raf_checking.zig:262-470) with RaPolynomial's table in a LOW_PAIR device session: the
+    cubic round polynomial's two sums are one kernel pass (zg_sumcheck_raf_round), the bind is the session's fold; the handful of
+    scalar operations around them (base contribution, s(1), s(3), the Lagrange update of the claim) are host code as in the reference."""
+
+    def __init__(self, ra_evals, start_address, log_k, initial_claim):
+        ra = np.ascontiguousarray(ra_evals, dtype=np.uint64).reshape(-1, 4)
+        assert ra.shape[0] == 1 << log_k
+        self.sess = lib.SumcheckSession.open(ra, lib.SC_LOW_PAIR)
+        self.start_address, self.log_k = int(start_address), log_k
+        self.current_claim = np.array(initial_claim, dtype=np.uint64)
+        self.bound_values = []
+        self.round = 0
+        self._final = ra[0].copy() if log_k == 0 else None
+
+    def computeRoundPolynomialCubic(self):
+        """-> (4,4): s(0), s(1), s(2), s(3)   (:335-410)"""
+        base = self.start_address % R_MOD
+        power = 8
+        for v in self.bound_values:
+            base = (base + fr_to_int(v) * power) % R_MOD
+            power *= 2
+        s0, s2 = self.sess.raf_round(fr_from_int(base), power)
+        a0, a2, claim = fr_to_int(s0), fr_to_int(s2), fr_to_int(self.current_claim)
+        a1 = (claim - a0) % R_MOD
+        a3 = (a0 - 3 * a1 + 3 * a2) % R_MOD
+        return np.stack([s0, fr_from_int(a1), s2, fr_from_int(a3)])
+
+    def updateClaim(self, evals, challenge):
+        """Lagrange interpolation through evals at 0,1,2,3 evaluated at the challenge (:420-445)"""
+        c = fr_to_int(challenge)
+        e = [fr_to_int(x) for x in evals]
+        inv = lambda x: pow(x % R_MOD, -1, R_MOD)
+        L0 = (c - 1) * (c - 2) * (c - 3) * inv(-6)
+        L1 = c * (c - 2) * (c - 3) * inv(2)
+        L2 = c * (c - 1) * (c - 3) * inv(-2)
+        L3 = c * (c - 1) * (c - 2) * inv(6)
+        self.current_claim = fr_from_int((e[0] * L0 + e[1] * L1 + e[2] * L2 + e[3] * L3) % R_MOD)
+
+    def bindChallenge(self, challenge):
+        """RaPolynomial.bind (:162-174) + bookkeeping (:413-417)"""
+        self.sess.bind(challenge)
+        self.bound_values.append(np.array(challenge, dtype=np.uint64))
+        self.round += 1
+
+    def getFinalClaim(self):
+        return self.sess.final() if len(self.sess) == 1 else self.sess.read()[0]
+
+    def isComplete(self):
+        return self.round >= self.log_k
+
+    def deinit(self):
+        self.sess.close()
+
+
+def proveStage2(raf_prover, transcript):
+    """The Stage-2 round loop (src/zkvm/prover.zig:523-548): cubic round polynomial, challengeScalar("raf_round"), claim
+    update, bind. -> dict(round_polys [(s0, s2)], challenges, final_claim)."""
+    polys, chals = [], []
+    for _ in range(raf_prover.log_k):
+        rp = raf_prover.computeRoundPolynomialCubic()
+        polys.append(np.stack([rp[0], rp[2]]))  # the proof keeps s(0) and s(2) (:531-535)
+        ch = transcript.challengeScalar(b"raf_round")
+        chals.append(ch)
+        raf_prover.updateClaim(rp, ch)
+        raf_prover.bindChallenge(ch)
+    return {"round_polys": np.array(polys).reshape(-1, 2, 4), "challenges": np.array(chals).reshape(-1, 4),
+            "final_claim": raf_prover.getFinalClaim()}
+
+
+class LassoAddressRounds:
+    """The address phase of LassoProver.computeRoundPolynomial (src/zkvm/lasso/prover.zig:262-313): per round the eq values are
+    summed by bit `round` of the u128 lookup index — eq_evals and indices stay resident in HBM for all LOG_K rounds."""
+
+    def __init__(self, eq_evals, lookup_indices_u128):
+        import torch
+        eq = np.ascontiguousarray(eq_evals, dtype=np.uint64).reshape(-1, 4)
+        idx = np.ascontiguousarray(lookup_indices_u128, dtype=np.uint64).reshape(-1, 2)
+        assert eq.shape[0] == idx.shape[0]
+        self.n = eq.shape[0]
+        self._eq = torch.from_numpy(eq.view(np.int64)).cuda()
+        self._idx = torch.from_numpy(idx.view(np.int64)).cuda()
+
+    def computeAddressRoundPoly(self, round_bit):
+        """-> coeffs [sum_0, sum_1 - sum_0, 0] (:304-306)"""
+        s0, s1 = lib.fr_bit_split_sums_dev(self._eq.data_ptr(), self._idx.data_ptr(), self.n, round_bit)
+        return np.stack([s0, _fr_sub(s1, s0), np.zeros(4, dtype=np.uint64)])

@@ -1884,7 +1884,7 @@ int zg_msm_g1(zg_bases_t b, size_t off, size_t n, const uint64_t *scalars, uint6
     if (n && !b->d_scal) ZG_HIP(hipMalloc((void **)&b->d_scal, b->n * 32));
     int slices = env_int("ZG_MSM_HOST_SLICES", 4);
     if (slices > HOST_SLICES_MAX) slices = HOST_SLICES_MAX;
-    if (slices >= 2 && n >= HOST_SLICE_MIN_POINTS && b->lanes.size() >= 2) return msm_host_sliced(b, off, n, scalars, slices, out_xy, out_inf);
+    if (slices >= 2 && n >= (size_t)env_int("ZG_MSM_HOST_SLICE_MIN", (int)HOST_SLICE_MIN_POINTS) && b->lanes.size() >= 2) return msm_host_sliced(b, off, n, scalars, slices, out_xy, out_inf);
     if (n) ZG_HIP(hipMemcpyAsync(b->d_scal, scalars, n * 32, hipMemcpyHostToDevice, st));
     return msm_to_host(b, off, n, b->d_scal, st, out_xy, out_inf);
 }

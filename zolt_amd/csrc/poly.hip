@@ -467,6 +467,64 @@ __global__ void __launch_bounds__(256) eq_spartan_kernel(const uint64_t *lo_tab,
     finish_round(g0, g1, sh, partials, sums, counter, flag, seq, ScRunArg{nullptr, 0, 0, 0});
 }
 
+// RafEvaluationProver.computeRoundPolynomialCubic's two sums (src/zkvm/ram/raf_checking.zig:335-410) over a LowToHigh table:
+//   s(0) = sum_i ra[2i] * u0(i),   s(2) = sum_i (2 ra[2i+1] - ra[2i]) * u2(i),
+//   u0(i) = base + F(rem(i)),  u2(i) = u0(i) + F(2 * current_power),  rem(i) = sum_j bit_j(i) * current_power * 2^(j+1) = step * i
+// (`base` = start_address + 8 * sum_j bound_j 2^j, a handful of host scalar operations; step = 2 * current_power; the host has
+// checked that step * half fits 64 bits, so F.fromU64 of the sum equals the reference's sum of F.fromU64 terms).
+__global__ void __launch_bounds__(256) raf_round_kernel(const uint64_t *t, size_t half, FrArg base, uint64_t step, uint64_t *partials) {
+    __shared__ uint4 sh[256 * 4];
+    Fr bv;
+#pragma unroll
+    for (int i = 0; i < 8; i++) bv.l[i] = base.l[i];
+    F29 r2p;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r2p.l[i] = Fr29::R2PRE[i];
+    Fr cp2 = Fr::zero();  // F.fromU64(2 * current_power)
+    cp2.l[0] = (uint32_t)step;
+    cp2.l[1] = (uint32_t)(step >> 32);
+    cp2 = fr_mul29(cp2, r2p);
+    Fr g0 = Fr::zero(), g1 = Fr::zero();
+    size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < half; i += stride) {
+        Fr lo = fe_load<FrParams>(t + 8 * i), hi = fe_load<FrParams>(t + 8 * i + 4);
+        uint64_t rem = step * (uint64_t)i;
+        Fr rv = Fr::zero();
+        rv.l[0] = (uint32_t)rem;
+        rv.l[1] = (uint32_t)(rem >> 32);
+        Fr u0 = fe_add(bv, fr_mul29(rv, r2p));  // F.fromU64(rem) = rem * R^2 * R^-1
+        Fr u2 = fe_add(u0, cp2);
+        Fr ra2 = fe_sub(fe_add(hi, hi), lo);
+        g0 = fe_add(g0, fe_mul(lo, u0));
+        g1 = fe_add(g1, fe_mul(ra2, u2));
+    }
+    block_sum_pair(g0, g1, sh);
+    if (threadIdx.x == 0) {
+        fe_store(partials + 8 * (size_t)blockIdx.x, g0);
+        fe_store(partials + 8 * (size_t)blockIdx.x + 4, g1);
+    }
+}
+
+// LassoProver.computeAddressRoundPoly's two sums (src/zkvm/lasso/prover.zig:283-293): the eq values split by bit `bit` of the
+// u128 lookup index (two little-endian u64 words per entry)
+__global__ void __launch_bounds__(256) bit_split_sums_kernel(const uint64_t *vals, const uint64_t *idx, size_t n, uint32_t bit,
+                                                             uint64_t *partials) {
+    __shared__ uint4 sh[256 * 4];
+    Fr g0 = Fr::zero(), g1 = Fr::zero();
+    size_t stride = (size_t)gridDim.x * 256;
+    const uint32_t word = bit >> 6, sh_bits = bit & 63u;
+    for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < n; j += stride) {
+        Fr v = fe_load<FrParams>(vals + 4 * j);
+        if ((idx[2 * j + word] >> sh_bits) & 1ull) g1 = fe_add(g1, v);
+        else g0 = fe_add(g0, v);
+    }
+    block_sum_pair(g0, g1, sh);
+    if (threadIdx.x == 0) {
+        fe_store(partials + 8 * (size_t)blockIdx.x, g0);
+        fe_store(partials + 8 * (size_t)blockIdx.x + 4, g1);
+    }
+}
+
 static unsigned env_uint(const char *name, unsigned dflt, unsigned lo, unsigned hi) {
     const char *e = getenv(name);
     unsigned v = e && *e ? (unsigned)atoi(e) : dflt;
@@ -1446,6 +1504,87 @@ int zg_sumcheck_read_dev(zg_sc_t s, uint64_t *d_out_table) {
     std::lock_guard<std::mutex> lk(s->mu);
     ZG_HIP(hipMemcpyAsync(d_out_table, s->buf[s->cur], s->len * 32, hipMemcpyDeviceToDevice, s->st));
     return ZG_OK;
+}
+
+int zg_sumcheck_raf_round(zg_sc_t s, const uint64_t base[4], uint64_t current_power, uint64_t s0[4], uint64_t s2[4]) {
+    ZG_INIT();
+    if (!s || !base || !s0 || !s2 || s->layout != ZG_SC_LOW_PAIR || s->len < 2) {
+        set_error("zg_sumcheck_raf_round: needs a LOW_PAIR session with at least two entries");
+        return ZG_ERR_INVALID;
+    }
+    DeviceGuard dg(s->device);
+    std::lock_guard<std::mutex> lk(s->mu);
+    const size_t half = s->len / 2;
+    // rem(i) = 2 * current_power * i must fit 64 bits for every i < half (the reference's u64 `remaining_power *= 2` would
+    // overflow otherwise, :377-386)
+    unsigned __int128 top = (unsigned __int128)current_power * 2 * (half ? half : 1);
+    if (current_power == 0 || (top >> 64) != 0) {
+        set_error("zg_sumcheck_raf_round: current_power * table length overflows 64 bits");
+        return ZG_ERR_INVALID;
+    }
+    const uint64_t step = current_power * 2;
+    FrArg ba;
+    for (int i = 0; i < 4; i++) {
+        ba.l[2 * i] = (uint32_t)base[i];
+        ba.l[2 * i + 1] = (uint32_t)(base[i] >> 32);
+    }
+    unsigned nb = sc_blocks(half);
+    uint64_t *d_part = s->d_partials, *d_sums = s->d_partials + SC_SUMS_OFF;
+    hipLaunchKernelGGL(raf_round_kernel, dim3(nb), dim3(256), 0, s->st, s->buf[s->cur], half, ba, step, d_part);
+    hipLaunchKernelGGL(sc_finish_kernel, dim3(1), dim3(256), 0, s->st, d_part, nb, d_sums, (uint64_t *)nullptr, (uint64_t)0);
+    ZG_HIP(hipGetLastError());
+    uint64_t h[8];
+    ZG_HIP(hipMemcpyAsync(h, d_sums, 64, hipMemcpyDeviceToHost, s->st));
+    ZG_HIP(hipStreamSynchronize(s->st));
+    for (int i = 0; i < 4; i++) {
+        s0[i] = h[i];
+        s2[i] = h[4 + i];
+    }
+    return ZG_OK;
+}
+
+int zg_fr_bit_split_sums_dev(const uint64_t *d_vals, const uint64_t *d_idx128, size_t n, unsigned bit, void *stream, uint64_t sum0[4],
+                             uint64_t sum1[4]) {
+    ZG_INIT();
+    if (!sum0 || !sum1 || bit > 127 || (n && (!d_vals || !d_idx128))) {
+        set_error("zg_fr_bit_split_sums_dev: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    hipStream_t st = pick_stream(stream);
+    Scratch s_misc(SC_MISC_BYTES);
+    if (!s_misc.p) return ZG_ERR_NOMEM;
+    SyncGuard sync(st);
+    uint64_t *d_misc = s_misc.as<uint64_t>();
+    unsigned nb = sc_blocks(n ? n : 1);
+    hipLaunchKernelGGL(bit_split_sums_kernel, dim3(nb), dim3(256), 0, st, d_vals, d_idx128, n, (uint32_t)bit, d_misc);
+    hipLaunchKernelGGL(sc_finish_kernel, dim3(1), dim3(256), 0, st, d_misc, nb, d_misc + SC_SUMS_OFF, (uint64_t *)nullptr, (uint64_t)0);
+    ZG_HIP(hipGetLastError());
+    uint64_t h[8];
+    ZG_HIP(hipMemcpyAsync(h, d_misc + SC_SUMS_OFF, 64, hipMemcpyDeviceToHost, st));
+    ZG_HIP(hipStreamSynchronize(st));
+    sync.dismiss();
+    for (int i = 0; i < 4; i++) {
+        sum0[i] = h[i];
+        sum1[i] = h[4 + i];
+    }
+    return ZG_OK;
+}
+
+int zg_fr_bit_split_sums(const uint64_t *vals, const uint64_t *idx128, size_t n, unsigned bit, uint64_t sum0[4], uint64_t sum1[4]) {
+    ZG_INIT();
+    if (!sum0 || !sum1 || bit > 127 || (n && (!vals || !idx128))) {
+        set_error("zg_fr_bit_split_sums: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    hipStream_t st = lib_stream();
+    Scratch s_v((n ? n : 1) * 32), s_i((n ? n : 1) * 16);
+    if (!s_v.p || !s_i.p) return ZG_ERR_NOMEM;
+    SyncGuard sync(st);
+    if (n) {
+        ZG_HIP(hipMemcpyAsync(s_v.p, vals, n * 32, hipMemcpyHostToDevice, st));
+        ZG_HIP(hipMemcpyAsync(s_i.p, idx128, n * 16, hipMemcpyHostToDevice, st));
+    }
+    return zg_fr_bit_split_sums_dev(s_v.as<uint64_t>(), s_i.as<uint64_t>(), n, bit, st, sum0, sum1);
 }
 
 int zg_sumcheck_close(zg_sc_t s) {

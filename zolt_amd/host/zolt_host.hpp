@@ -119,6 +119,15 @@ struct Fr {
         Fr a{{n, 0, 0, 0}}, r2{{R2[0], R2[1], R2[2], R2[3]}};
         return a.mul(r2);
     }
+    static Fr fromBytes(const uint8_t *bytes) {  // :625-639: 32 little-endian bytes (may exceed the modulus), times R^2
+        Fr a, r2{{R2[0], R2[1], R2[2], R2[3]}};
+        for (int i = 0; i < 4; i++) {
+            uint64_t v = 0;
+            for (int b = 7; b >= 0; b--) v = (v << 8) | bytes[8 * i + b];
+            a.limbs[i] = v;
+        }
+        return a.mul(r2);
+    }
 };
 
 // Fp values cross the host only as opaque limbs (coordinates of points)
@@ -476,6 +485,80 @@ struct HyperKZG {
 };
 
 // ---------------------------------------------------------------- sumcheck
+// ---------------------------------------------------------------- transcript (host side, between rounds)
+// Transcript(F) — the reference's Keccak Fiat-Shamir transcript, src/transcripts/mod.zig:49-221: bytes XORed into a 200-byte
+// state at `position`, Keccak-f[1600] every 136 bytes, challengeScalar = label, one Keccak-f, F.fromBytes(state[0..32]).
+class Transcript {
+public:
+    explicit Transcript(const std::string &domain = "Jolt") { appendBytes(reinterpret_cast<const uint8_t *>(domain.data()), domain.size()); }
+    void appendBytes(const uint8_t *data, size_t n) {  // :88-98
+        for (size_t i = 0; i < n; i++) {
+            state_[position_] ^= data[i];
+            position_ += 1;
+            if (position_ >= 136) {
+                keccakF();
+                position_ = 0;
+            }
+        }
+    }
+    void appendBytes(const std::string &s) { appendBytes(reinterpret_cast<const uint8_t *>(s.data()), s.size()); }
+    void appendScalar(const std::string &label, const Fr &scalar) {  // :100-110: raw Montgomery limbs, little-endian
+        appendBytes(label);
+        uint8_t buf[32];
+        for (int i = 0; i < 4; i++)
+            for (int b = 0; b < 8; b++) buf[8 * i + b] = (uint8_t)(scalar.limbs[i] >> (8 * b));
+        appendBytes(buf, 32);
+    }
+    Fr challengeScalar(const std::string &label) {  // :116-130
+        appendBytes(label);
+        keccakF();
+        return Fr::fromBytes(state_);
+    }
+    const uint8_t *state() const { return state_; }
+
+private:
+    uint8_t state_[200] = {0};
+    size_t position_ = 0;
+    static uint64_t rotl(uint64_t x, unsigned n) { return (x << n) | (x >> (64 - n)); }
+    void keccakF() {  // :163-213
+        static const uint64_t RC[24] = {
+            0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL, 0x0000000080000001ULL,
+            0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+            0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL,
+            0x000000000000800aULL, 0x800000008000000aULL, 0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+        static const unsigned ROTC[24] = {1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44};
+        static const unsigned PILN[24] = {10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1};
+        uint64_t st[25];
+        for (int i = 0; i < 25; i++) {
+            uint64_t v = 0;
+            for (int b = 7; b >= 0; b--) v = (v << 8) | state_[8 * i + b];
+            st[i] = v;
+        }
+        for (int round = 0; round < 24; round++) {
+            uint64_t bc[5];
+            for (int i = 0; i < 5; i++) bc[i] = st[i] ^ st[i + 5] ^ st[i + 10] ^ st[i + 15] ^ st[i + 20];
+            for (int i = 0; i < 5; i++) {
+                uint64_t t = bc[(i + 4) % 5] ^ rotl(bc[(i + 1) % 5], 1);
+                for (int j = i; j < 25; j += 5) st[j] ^= t;
+            }
+            uint64_t t = st[1];
+            for (int i = 0; i < 24; i++) {
+                unsigned j = PILN[i];
+                uint64_t tmp = st[j];
+                st[j] = rotl(t, ROTC[i]);
+                t = tmp;
+            }
+            for (int row = 0; row < 25; row += 5) {
+                for (int i = 0; i < 5; i++) bc[i] = st[row + i];
+                for (int i = 0; i < 5; i++) st[row + i] = bc[i] ^ (~bc[(i + 1) % 5] & bc[(i + 2) % 5]);
+            }
+            st[0] ^= RC[round];
+        }
+        for (int i = 0; i < 25; i++)
+            for (int b = 0; b < 8; b++) state_[8 * i + b] = (uint8_t)(st[i] >> (8 * b));
+    }
+};
+
 struct SumcheckVerificationFailed : std::runtime_error {
     SumcheckVerificationFailed() : std::runtime_error("SumcheckVerificationFailed") {}
 };

@@ -40,7 +40,7 @@ SYMBOLS = [
     "zg_fr_spartan_combine", "zg_fr_spartan_combine_dev",
     "zg_sumcheck_open", "zg_sumcheck_open_dev", "zg_sumcheck_round_sums", "zg_sumcheck_bind",
     "zg_sumcheck_len", "zg_sumcheck_final", "zg_sumcheck_read", "zg_sumcheck_close",
-    "zg_sumcheck_round_sums_dev", "zg_sumcheck_read_dev",
+    "zg_sumcheck_round_sums_dev", "zg_sumcheck_read_dev", "zg_sumcheck_raf_round", "zg_fr_bit_split_sums", "zg_fr_bit_split_sums_dev",
     "zg_run_sumcheck", "zg_run_sumcheck_dev", "zg_sumcheck_open_spartan_dev",
 ]
 # test / bench scaffolding of include/zolt_gpu_internal.h (not part of the drop-in boundary)
@@ -435,6 +435,23 @@ def fr_spartan_combine_dev(d_eq, d_az, d_bz, d_cz, n, d_out, stream=0):
          "zg_fr_spartan_combine_dev")
 
 
+def fr_bit_split_sums(vals, idx128, bit):
+    """sums of vals[j] split by bit `bit` of the u128 index (n,2) -> (sum0, sum1)"""
+    vals, idx128 = _c(vals), _c(idx128)
+    s0 = np.empty(4, dtype=np.uint64)
+    s1 = np.empty(4, dtype=np.uint64)
+    _chk(_lib.zg_fr_bit_split_sums(_h(vals), _h(idx128), C.c_size_t(vals.size // 4), C.c_uint(bit), _h(s0), _h(s1)), "zg_fr_bit_split_sums")
+    return s0, s1
+
+
+def fr_bit_split_sums_dev(d_vals, d_idx128, n, bit, stream=0):
+    s0 = np.empty(4, dtype=np.uint64)
+    s1 = np.empty(4, dtype=np.uint64)
+    _chk(_lib.zg_fr_bit_split_sums_dev(_d(d_vals), _d(d_idx128), C.c_size_t(n), C.c_uint(bit), _d(stream), _h(s0), _h(s1)),
+         "zg_fr_bit_split_sums_dev")
+    return s0, s1
+
+
 class SumcheckVerificationFailed(RuntimeError):
     """error.SumcheckVerificationFailed (src/subprotocols/mod.zig:175-178)."""
 
@@ -512,6 +529,13 @@ class SumcheckSession:
         out = np.empty((len(self), 4), dtype=np.uint64)
         _chk(_lib.zg_sumcheck_read(self._h, _h(out)), "zg_sumcheck_read")
         return out
+
+    def raf_round(self, base, current_power):
+        """RAF cubic round sums s(0), s(2) over this LOW_PAIR session's table (zg_sumcheck_raf_round)"""
+        s0 = np.empty(4, dtype=np.uint64)
+        s2 = np.empty(4, dtype=np.uint64)
+        _chk(_lib.zg_sumcheck_raf_round(self._h, _h(_c(base)), C.c_uint64(current_power), _h(s0), _h(s2)), "zg_sumcheck_raf_round")
+        return s0, s2
 
     def round_sums_dev(self, d_out8):
         _chk(_lib.zg_sumcheck_round_sums_dev(self._h, _d(d_out8)), "zg_sumcheck_round_sums_dev")
