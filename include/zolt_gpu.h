@@ -173,6 +173,12 @@ ZG_API int zg_g1_affine_add_batch(const uint64_t *a_xy, const uint8_t *a_inf, co
 ZG_API int zg_g1_scalar_mul_batch(const uint64_t *xy, const uint8_t *inf, const uint64_t *scalars_mont, size_t n,
                            uint64_t *out_xy, uint8_t *out_inf);
 
+/* The same for n scalars over ONE base — HyperKZG.setup's loop powers[i] = MSM.scalarMul(g1, tau^i).toAffine()
+ * (src/poly/commitment/mod.zig:194-199; generateMockSRS, srs.zig:326-355): a shared table of the 255 multiples of 2^(8w) * base
+ * per 8-bit window, so an output is at most 32 mixed additions and one toAffine instead of 254 doublings + ~127 additions. */
+ZG_API int zg_g1_fixed_base_mul_batch(const uint64_t base_xy[8], uint8_t base_inf, const uint64_t *scalars_mont, size_t n, uint64_t *out_xy,
+                               uint8_t *out_inf);
+
 /* HyperKZG.open (src/poly/commitment/mod.zig:261-324), resident on the device: per variable i the quotient
  * q[j] = cur[j+half] - cur[j] is committed (MSM over srs[0..min(half, srs_len))), then cur is folded by point[i]
  * (high half). Writes num_vars quotient commitments (rounds that the reference skips when the table runs out are

@@ -77,7 +77,7 @@ def test_zig_backend_rules_out_the_stale_table_and_wrong_field_hazards():
     externs = set(re.findall(r"pub extern fn (zg_\w+)\(", zig))
     used = set(re.findall(r"ffi\.(zg_\w+)\(", code))
     assert used and used <= externs, used - externs
-    for wrapper in ("zg_g1_scalar_mul_batch", "zg_hyperkzg_open", "zg_hyperkzg_batch_open", "zg_msm_g1_sharded", "zg_msm_g1_batch_sharded",
+    for wrapper in ("zg_g1_fixed_base_mul_batch", "zg_hyperkzg_open", "zg_hyperkzg_batch_open", "zg_msm_g1_sharded", "zg_msm_g1_batch_sharded",
                     "zg_sumcheck_open_sharded", "zg_init_devices"):
         assert wrapper in used, wrapper  # setup / open / batchOpen / the multi-GPU entry points all have a wrapper now
     # rule 1: both one-shot MSM entry points start with the comptime gate

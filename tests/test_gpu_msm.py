@@ -547,3 +547,28 @@ def test_host_scalar_path_sliced(zl, ob, gm, slices, monkeypatch):
         assert z[1] == 1
     finally:
         b.free()
+
+
+def test_fixed_base_batch_equals_scalar_mul(zl, ob):
+    """zg_g1_fixed_base_mul_batch (HyperKZG.setup's primitive) against the generic per-pair scalarMul kernel and the oracle:
+    random scalars, 0, 1, r - 1, small values, single-window values, a base other than the generator, an infinity base."""
+    from zolt_amd import api
+    g = api.generator()
+    n = 3000
+    sc = ob.f_to_mont(ob.FR, U.random_raw256(4100, n))
+    special = [0, 1, 2, 255, 256, 257, (1 << 248), (1 << 253), api.R_MOD - 1, api.R_MOD - 2, 0xFF << 64, 0x12345678]
+    for i, v in enumerate(special):
+        sc[i] = api.fr_from_int(v)
+    out, inf = zl.g1_fixed_base_mul_batch(g, sc)
+    w, wi = zl.g1_scalar_mul_batch(np.repeat(g[None, :], n, axis=0), np.zeros(n, dtype=np.uint8), sc)
+    assert np.array_equal(inf, wi) and np.array_equal(out, w)
+    assert inf[0] == 1 and not out[0].any()
+    for i in list(range(len(special))) + [100, 2999]:
+        o, oi = ob.g1_scalar_mul(g, 0, sc[i])
+        assert inf[i] == oi and (oi or np.array_equal(out[i], o)), i
+    base = w[50]  # some other point of the group
+    out2, inf2 = zl.g1_fixed_base_mul_batch(base, sc[:64])
+    w2, wi2 = zl.g1_scalar_mul_batch(np.repeat(base[None, :], 64, axis=0), np.zeros(64, dtype=np.uint8), sc[:64])
+    assert np.array_equal(inf2, wi2) and np.array_equal(out2, w2)
+    out3, inf3 = zl.g1_fixed_base_mul_batch(g, sc[:8], base_inf=1)
+    assert inf3.all() and not out3.any()

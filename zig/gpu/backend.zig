@@ -248,17 +248,15 @@ pub const SrsHandle = struct {
 pub fn setupPowers(comptime F: type, comptime Affine: type, g1: Affine, scalars: []const F, out: []Affine, allocator: std.mem.Allocator) !bool {
     if (!enabled() or scalars.len == 0) return false;
     const n = scalars.len;
-    const xy = try allocator.alloc(u64, 8 * n);
-    defer allocator.free(xy);
-    for (0..n) |i| {
-        @memcpy(xy[8 * i .. 8 * i + 4], &g1.x.limbs);
-        @memcpy(xy[8 * i + 4 .. 8 * i + 8], &g1.y.limbs);
-    }
+    var g: [8]u64 = undefined;
+    @memcpy(g[0..4], &g1.x.limbs);
+    @memcpy(g[4..8], &g1.y.limbs);
     const oxy = try allocator.alloc(u64, 8 * n);
     defer allocator.free(oxy);
     const oinf = try allocator.alloc(u8, n);
     defer allocator.free(oinf);
-    if (ffi.zg_g1_scalar_mul_batch(xy.ptr, null, limbsOf(F, scalars), n, oxy.ptr, oinf.ptr) != ffi.OK) return false;
+    // one shared base: the fixed-base kernel (a 255 x 32 table of multiples, at most 32 additions per output)
+    if (ffi.zg_g1_fixed_base_mul_batch(&g, @intFromBool(g1.infinity), limbsOf(F, scalars), n, oxy.ptr, oinf.ptr) != ffi.OK) return false;
     for (out, 0..) |*r, i| r.* = affineFrom(Affine, oxy[8 * i ..][0..8], oinf[i]);
     return true;
 }

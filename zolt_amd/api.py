@@ -243,9 +243,13 @@ class HyperKZG:
     def setup(max_degree):
         """powers[i] = scalarMul(G1, tau^i).toAffine() (src/poly/commitment/mod.zig:174-213)."""
         g = generator()
-        taus = np.stack([fr_from_int(pow(HyperKZG.TAU, i, R_MOD)) for i in range(max_degree)]) if max_degree else \
-            np.zeros((0, 4), dtype=np.uint64)
-        xy, inf = lib.g1_scalar_mul_batch(np.repeat(g[None, :], max_degree, axis=0), np.zeros(max_degree, dtype=np.uint8), taus)
+        taus = np.zeros((max_degree, 4), dtype=np.uint64)
+        t = 1
+        for i in range(max_degree):  # tau_power = tau_power.mul(tau) (:196-198)
+            taus[i] = fr_from_int(t)
+            t = t * HyperKZG.TAU % R_MOD
+        # every product has the same base: the fixed-base batch kernel (32 table additions per point instead of double-and-add)
+        xy, inf = lib.g1_fixed_base_mul_batch(g, taus)
         return HyperKZG.SetupParams(xy, inf)
 
     @staticmethod

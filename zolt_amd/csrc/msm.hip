@@ -32,6 +32,8 @@
 // Bucket sums are order-independent group sums and the final affine coordinates are
 // canonical field values, so the 64-byte result is bit-identical to the reference's
 // MSM(F,G).compute whatever c, L and the scheduling are (tests/test_gpu_msm.py).
+#include <string.h>
+
 #include <mutex>
 #include <vector>
 
@@ -1162,6 +1164,66 @@ __global__ void __launch_bounds__(256) g1_scalar_mul_kernel(const uint64_t *xy, 
     out_inf[i] = isinf ? 1 : 0;
 }
 
+// ---- fixed-base batch scalar multiplication: HyperKZG.setup's loop powers[i] = scalarMul(g1, tau^i).toAffine()
+// (src/poly/commitment/mod.zig:194-199; generateMockSRS, srs.zig:326-355) — every product has the SAME base. The reference's
+// scalarMul is double-and-add (254 doublings + ~127 additions per output, msm/mod.zig:503-540); with one shared table
+// T[w][d-1] = d * 2^(8w) * G (32 windows x 255 multiples, 510 KiB, L2-resident) an output is at most 32 mixed additions
+// and one toAffine, no doubling at all.
+static constexpr int FB_C = 8, FB_W = 32, FB_ROWS = 255;
+
+// one thread per window: 8w doublings of G, then the 255 multiples by repeated addition; rows left in lazy XYZZ form
+__global__ void __launch_bounds__(32) fb_table_build_kernel(const uint64_t *base_xy, char *xyzz_rows /* FB_W * FB_ROWS * 144 */) {
+    uint32_t w = threadIdx.x;
+    if (w >= (uint32_t)FB_W) return;
+    Affine g = affine_load(base_xy);
+    F29 one29;
+#pragma unroll
+    for (int k = 0; k < 9; k++) one29.l[k] = Fp29::ONE[k];
+    XYZZ29 step;
+    step.x = f29_from_fp(g.x); step.y = f29_from_fp(g.y); step.zz = one29; step.zzz = one29;
+    for (uint32_t k = 0; k < (uint32_t)FB_C * w; k++) step = xyzz29_dbl(step);  // 2^(8w) * G (odd prime order: never the identity)
+    XYZZ29 acc = step;
+    for (int d = 1; d <= FB_ROWS; d++) {
+        xyzz29_store(xyzz_rows + 144 * ((size_t)w * FB_ROWS + (d - 1)), acc);
+        if (d < FB_ROWS) acc = xyzz29_add(acc, step);  // complete addition: d = 1 -> doubling is handled
+    }
+}
+
+// lazy XYZZ rows -> packed affine rows (the accumulate kernel's 64-byte row format), one inversion per row
+__global__ void __launch_bounds__(256) fb_table_affine_kernel(const char *xyzz_rows, uint32_t n_rows, char *table) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_rows) return;
+    XYZZ29 a = xyzz29_load(xyzz_rows + 144 * (size_t)i);
+    F29 izzz = f29_from_fp(fe_inv_safegcd(f29_to_fp(a.zzz)));
+    F29 iz = f29_mul(izzz, a.zz);  // 1/Z = ZZ / ZZZ
+    f29_store_packed(table + 64 * (size_t)i, f29_mul(a.x, f29_sqr(iz)));
+    f29_store_packed(table + 64 * (size_t)i + 32, f29_mul(a.y, izzz));
+}
+
+__global__ void __launch_bounds__(256) fb_mul_kernel(const char *table, const uint64_t *scalars, size_t n, uint64_t *out_xy, uint8_t *out_inf) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr s = fr_from_mont29(fe_load<FrParams>(scalars + 4 * i));  // canonical integer, 8 x 32-bit words
+    XYZZ29 acc;
+    bool acc_inf = true;
+#pragma unroll 1
+    for (int w = 0; w < FB_W; w++) {
+        uint32_t d = (s.l[w >> 2] >> (8 * (w & 3))) & 0xffu;
+        if (d == 0) continue;
+        Affine row = affine_load(table + 64 * ((size_t)w * FB_ROWS + (d - 1)));
+        xyzz29_madd(acc, acc_inf, f29_unpack(row.x.l), f29_unpack(row.y.l));
+    }
+    Affine r;
+    bool isinf = acc_inf;
+    if (!isinf) isinf = xyzz_to_affine(xyzz29_to_std_val(acc), r);
+    if (isinf) {
+        r.x = Fp::zero();
+        r.y = Fp::zero();
+    }
+    affine_store(out_xy + 8 * i, r);
+    out_inf[i] = isinf ? 1 : 0;
+}
+
 // AffinePoint.add (msm/mod.zig:74-103) and, through add(p, p), AffinePoint.double (:118-138): the lambda formulas on canonical
 // Montgomery values, one inversion per pair (safegcd, the value of the reference's Fermat inverse)
 __global__ void __launch_bounds__(256) g1_affine_add_kernel(const uint64_t *a_xy, const uint8_t *a_inf, const uint64_t *b_xy,
@@ -2195,6 +2257,38 @@ int zg_g1_affine_add_batch(const uint64_t *a_xy, const uint8_t *a_inf, const uin
     ZG_HIP(hipGetLastError());
     ZG_HIP(hipMemcpyAsync(out_xy, s_o.p, n * 64, hipMemcpyDeviceToHost, st));
     if (out_inf) ZG_HIP(hipMemcpyAsync(out_inf, d_oi, n, hipMemcpyDeviceToHost, st));
+    ZG_HIP(hipStreamSynchronize(st));
+    sync.dismiss();
+    return ZG_OK;
+}
+
+int zg_g1_fixed_base_mul_batch(const uint64_t base_xy[8], uint8_t base_inf, const uint64_t *scalars, size_t n, uint64_t *out_xy,
+                               uint8_t *out_inf) {
+    ZG_INIT();
+    if (!base_xy || (n && (!scalars || !out_xy || !out_inf))) {
+        set_error("zg_g1_fixed_base_mul_batch: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    if (n == 0) return ZG_OK;
+    if (base_inf) {  // k * infinity = infinity (src/msm/mod.zig:504-506)
+        memset(out_xy, 0, n * 64);
+        memset(out_inf, 1, n);
+        return ZG_OK;
+    }
+    hipStream_t st = lib_stream();
+    const uint32_t n_rows = FB_W * FB_ROWS;
+    Scratch s_base(64), s_rows((size_t)n_rows * 144), s_tab((size_t)n_rows * 64), s_sc(n * 32), s_out(n * 64), s_inf(n);
+    if (!s_base.p || !s_rows.p || !s_tab.p || !s_sc.p || !s_out.p || !s_inf.p) return ZG_ERR_NOMEM;
+    SyncGuard sync(st);
+    ZG_HIP(hipMemcpyAsync(s_base.p, base_xy, 64, hipMemcpyHostToDevice, st));
+    ZG_HIP(hipMemcpyAsync(s_sc.p, scalars, n * 32, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(fb_table_build_kernel, dim3(1), dim3(32), 0, st, s_base.as<uint64_t>(), s_rows.as<char>());
+    hipLaunchKernelGGL(fb_table_affine_kernel, dim3(div_up(n_rows, 256)), dim3(256), 0, st, s_rows.as<char>(), n_rows, s_tab.as<char>());
+    hipLaunchKernelGGL(fb_mul_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, s_tab.as<char>(), s_sc.as<uint64_t>(), n, s_out.as<uint64_t>(),
+                       s_inf.as<uint8_t>());
+    ZG_HIP(hipGetLastError());
+    ZG_HIP(hipMemcpyAsync(out_xy, s_out.p, n * 64, hipMemcpyDeviceToHost, st));
+    ZG_HIP(hipMemcpyAsync(out_inf, s_inf.p, n, hipMemcpyDeviceToHost, st));
     ZG_HIP(hipStreamSynchronize(st));
     sync.dismiss();
     return ZG_OK;

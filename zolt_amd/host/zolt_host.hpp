@@ -393,16 +393,18 @@ struct HyperKZG {
         SetupParams p;
         p.g1 = AffinePoint::generator();
         p.max_degree = max_degree;
-        std::vector<uint64_t> xy(max_degree * 8), sc(max_degree * 4), out(max_degree * 8);
-        std::vector<uint8_t> inf(max_degree, 0), oinf(max_degree, 0);
+        std::vector<uint64_t> sc(max_degree * 4), out(max_degree * 8);
+        std::vector<uint8_t> oinf(max_degree, 0);
+        uint64_t g[8];
+        std::memcpy(g, p.g1.x.limbs, 32);
+        std::memcpy(g + 4, p.g1.y.limbs, 32);
         Fr tau = Fr::fromU64(0x12345678), tp = Fr::one();
         for (size_t i = 0; i < max_degree; i++) {
-            std::memcpy(&xy[8 * i], p.g1.x.limbs, 32);
-            std::memcpy(&xy[8 * i + 4], p.g1.y.limbs, 32);
             std::memcpy(&sc[4 * i], tp.limbs, 32);
             tp = tp.mul(tau);
         }
-        check(zg_g1_scalar_mul_batch(xy.data(), inf.data(), sc.data(), max_degree, out.data(), oinf.data()), "zg_g1_scalar_mul_batch");
+        // :194-199: every product has the same base -> the fixed-base batch kernel
+        check(zg_g1_fixed_base_mul_batch(g, 0, sc.data(), max_degree, out.data(), oinf.data()), "zg_g1_fixed_base_mul_batch");
         for (size_t i = 0; i < max_degree; i++) p.powers_of_tau_g1.push_back(unpack_point(&out[8 * i], oinf[i]));
         p.device.reset(new DeviceBases(p.powers_of_tau_g1));
         return p;

@@ -34,7 +34,7 @@ SYMBOLS = [
     "zg_sumcheck_bind_sharded", "zg_sumcheck_final_sharded", "zg_sumcheck_close_sharded",
     "zg_g1_bases_upload", "zg_g1_bases_upload_dev", "zg_g1_bases_free", "zg_g1_bases_len", "zg_g1_bases_plan",
     "zg_msm_g1", "zg_msm_g1_dev", "zg_msm_g1_dev_async", "zg_msm_g1_batch", "zg_msm_g1_batch_dev", "zg_msm_g1_partial_dev", "zg_msm_g1_partial_fast_dev",
-    "zg_g1_combine_partials_dev", "zg_g1_combine_partials_dev_async", "zg_g1_is_on_curve_batch", "zg_g1_scalar_mul_batch",
+    "zg_g1_combine_partials_dev", "zg_g1_combine_partials_dev_async", "zg_g1_is_on_curve_batch", "zg_g1_scalar_mul_batch", "zg_g1_fixed_base_mul_batch",
     "zg_hyperkzg_open", "zg_hyperkzg_batch_open",
     "zg_fr_dense_evaluate", "zg_fr_eq_table", "zg_fr_eq_table_dev", "zg_fr_bind_low", "zg_fr_bind_high",
     "zg_fr_spartan_combine", "zg_fr_spartan_combine_dev",
@@ -346,6 +346,17 @@ def g1_scalar_mul_batch(xy, inf, scalars):
     out = np.empty((n, 8), dtype=np.uint64)
     oinf = np.zeros(n, dtype=np.uint8)
     _chk(_lib.zg_g1_scalar_mul_batch(_h(xy), _hb(inf), _h(scalars), C.c_size_t(n), _h(out), _hb(oinf)), "zg_g1_scalar_mul_batch")
+    return out, oinf
+
+
+def g1_fixed_base_mul_batch(base_xy, scalars, base_inf=0):
+    """scalars[i] * base for one shared base (HyperKZG.setup) -> (xy (n,8), inf (n,))"""
+    base_xy, scalars = _c(base_xy), _c(scalars)
+    n = scalars.size // 4
+    out = np.empty((n, 8), dtype=np.uint64)
+    oinf = np.zeros(n, dtype=np.uint8)
+    _chk(_lib.zg_g1_fixed_base_mul_batch(_h(base_xy), C.c_uint8(base_inf), _h(scalars), C.c_size_t(n), _h(out), _hb(oinf)),
+         "zg_g1_fixed_base_mul_batch")
     return out, oinf
 
 
