@@ -8,6 +8,15 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# torch bundles its own HIP runtime: when a test process is going to use both torch and libzolt_gpu.so, torch has to be
+# imported FIRST (afterwards it fails with "No HIP GPUs are available"). Test modules that need torch import it at module level,
+# which pytest's collection runs before any test body; importing it here as well makes that independent of which files are selected.
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover - torch is optional for the CPU suite
+    torch = None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

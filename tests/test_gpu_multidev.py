@@ -101,14 +101,13 @@ def test_rccl_exchange_at_one_device(env, monkeypatch):
 
 
 def test_sharded_msm_resident_scalars(env, monkeypatch):
-    import torch
     api, lib, ob, gm = env
     monkeypatch.setenv("ZG_SHARDS", "4")
     sb = lib.ShardedBases.upload(gm)
     try:
         sc = _rand(ob, 1300, N)
-        d_parts = [torch.from_numpy(sc[s:s + l].view(np.int64).copy()).cuda() for _, s, l in sb.shards()]
-        got = sb.msm_dev([t.data_ptr() for t in d_parts], N)
+        d_parts = [lib.DeviceBuffer.from_host(sc[s:s + l]) for _, s, l in sb.shards()]
+        got = sb.msm_dev([t.ptr for t in d_parts], N)
         want = ob.msm_g1(gm, None, sc)
         assert got[1] == want[1] and np.array_equal(got[0], want[0])
     finally:

@@ -9,6 +9,7 @@
 #include <vector>
 #include "../zolt_amd/csrc/field.hip.h"
 #include "../zolt_amd/csrc/g1.hip.h"
+#include "../zolt_amd/csrc/g1_29.hip.h"
 
 #define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -101,6 +102,61 @@ __global__ void k_madd(unsigned long long *cyc, unsigned *sink, int iters, unsig
     sink[blockIdx.x * blockDim.x + threadIdx.x] = acc.x.l[0] ^ acc.zzz.l[3];
 }
 
+// ---- the numbers behind DESIGN.md's batched-affine analysis: what a field inversion costs a wave (all 64 lanes invert their
+// own value: SIMD executes 64 inversions for the price of one), the lazy-limb XYZZ mixed addition the accumulate kernel runs,
+// and the arithmetic of one batched-affine addition (2M + 1S for the group law + 3M for Montgomery's trick) WITHOUT its share of
+// the inversion
+__global__ void k_inv_safegcd(unsigned long long *cyc, unsigned *sink, int iters, unsigned seed) {
+    zg::Fp x;
+    for (int i = 0; i < 8; i++) x.l[i] = (seed + threadIdx.x + blockIdx.x * 977u) * (i + 3) + 12345u;
+    x.l[7] &= 0x0fffffff;
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; it++) { x = zg::fe_inv_safegcd(x); x.l[0] ^= (unsigned)it * 2654435761u; x.l[7] &= 0x0fffffff; }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x % 64 == 0) cyc[(blockIdx.x * blockDim.x + threadIdx.x) / 64] = t1 - t0;
+    sink[blockIdx.x * blockDim.x + threadIdx.x] = x.l[0] ^ x.l[5];
+}
+__global__ void k_madd29(unsigned long long *cyc, unsigned *sink, int iters, unsigned seed) {
+    zg::XYZZ29 acc; zg::F29 px, py;
+    for (int i = 0; i < 9; i++) {
+        unsigned b = (seed + threadIdx.x) * (i + 3);
+        acc.x.l[i] = b & 0x1fffffff; acc.y.l[i] = (b * 7) & 0x1fffffff; acc.zz.l[i] = (b * 11) & 0x1fffffff; acc.zzz.l[i] = (b * 13) & 0x1fffffff;
+        px.l[i] = (b * 17) & 0x1fffffff; py.l[i] = (b * 19) & 0x1fffffff;
+    }
+    acc.x.l[8] &= 0x3fffff; acc.y.l[8] &= 0x3fffff; acc.zz.l[8] &= 0x3fffff; acc.zzz.l[8] &= 0x3fffff; px.l[8] &= 0x3fffff; py.l[8] &= 0x3fffff;
+    bool acc_inf = false;
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; it++) { zg::xyzz29_madd(acc, acc_inf, px, py); px.l[0] ^= acc.x.l[1] & 0xff; }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x % 64 == 0) cyc[(blockIdx.x * blockDim.x + threadIdx.x) / 64] = t1 - t0;
+    sink[blockIdx.x * blockDim.x + threadIdx.x] = acc.x.l[0] ^ acc.zzz.l[3];
+}
+__global__ void k_affine_add_body29(unsigned long long *cyc, unsigned *sink, int iters, unsigned seed) {
+    zg::F29 x1, y1, x2, y2, pre, inv;
+    for (int i = 0; i < 9; i++) {
+        unsigned b = (seed + threadIdx.x) * (i + 3);
+        x1.l[i] = b & 0x1fffffff; y1.l[i] = (b * 7) & 0x1fffffff; x2.l[i] = (b * 11) & 0x1fffffff; y2.l[i] = (b * 13) & 0x1fffffff;
+        pre.l[i] = (b * 17) & 0x1fffffff; inv.l[i] = (b * 19) & 0x1fffffff;
+    }
+    x1.l[8] &= 0x3fffff; y1.l[8] &= 0x3fffff; x2.l[8] &= 0x3fffff; y2.l[8] &= 0x3fffff; pre.l[8] &= 0x3fffff; inv.l[8] &= 0x3fffff;
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; it++) {
+        // Montgomery's trick around the pair: prefix product forward (1M), then backward inv_d = inv * prefix (1M), inv *= d (1M)
+        zg::F29 d = zg::f29_sub2(x2, x1);
+        zg::F29 prefix = zg::f29_mul(pre, d);
+        zg::F29 inv_d = zg::f29_mul(inv, pre);
+        inv = zg::f29_mul(inv, d);
+        // the affine group law: lambda = (y2 - y1) / (x2 - x1), x3 = lambda^2 - x1 - x2, y3 = lambda (x1 - x3) - y1  (2M + 1S)
+        zg::F29 lam = zg::f29_mul(zg::f29_sub2(y2, y1), inv_d);
+        zg::F29 x3 = zg::f29_sub4(zg::f29_sub2(zg::f29_sqr(lam), x1), x2);
+        zg::F29 y3 = zg::f29_sub2(zg::f29_mul(lam, zg::f29_sub4(x1, x3)), y1);
+        x1 = zg::f29_carry(x3); y1 = zg::f29_carry(y3); pre = prefix;
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x % 64 == 0) cyc[(blockIdx.x * blockDim.x + threadIdx.x) / 64] = t1 - t0;
+    sink[blockIdx.x * blockDim.x + threadIdx.x] = x1.l[0] ^ y1.l[3] ^ inv.l[2];
+}
+
 typedef void (*kern_t)(unsigned long long *, unsigned *, int, unsigned);
 
 static void run(const char *name, kern_t k, int instr_per_iter, int iters, int ncu) {
@@ -131,10 +187,69 @@ static void run(const char *name, kern_t k, int instr_per_iter, int iters, int n
     (void)hipFree(cyc); (void)hipFree(sink);
 }
 
-int main() {
+// ---- HBM access-pattern calibration for the PMC figures (MI355X_MICROARCH.md: "calibrate on a known byte count in your own access
+// pattern"): `microbench gather` reads N random 64-byte rows of a 2 GiB table with the accumulate kernel's load shape (one row per
+// lane: four 16-byte loads of consecutive addresses), `microbench stream` reads the same number of bytes sequentially. Run each
+// under rocprofv3 --pmc FETCH_SIZE: FETCH_SIZE / known bytes is the correction factor of that pattern; the printed rows/s also
+// bounds the request width (rows/s x 64 B vs x 128 B against the 8 TB/s peak).
+__global__ void k_gather64(const uint4 *table, size_t n_rows_table, size_t rows_per_thread, unsigned *sink) {
+    size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long h = tid * 0x9E3779B97F4A7C15ull + 0x1234567ull;
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    for (size_t k = 0; k < rows_per_thread; k++) {
+        h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+        size_t row = (size_t)(h % n_rows_table);
+        const uint4 *p = table + 4 * row;
+        uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+        acc.x ^= a.x ^ b.y ^ c.z ^ d.w; acc.y += a.y + d.x;
+    }
+    sink[tid] = acc.x ^ acc.y;
+}
+__global__ void k_stream64(const uint4 *table, size_t n_rows_table, size_t rows_per_thread, unsigned *sink) {
+    size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (size_t)gridDim.x * blockDim.x;
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    for (size_t k = 0; k < 4 * rows_per_thread; k++) {  // 16 B per lane per load, consecutive lanes on consecutive addresses
+        size_t i = (k * nthreads + tid) % (4 * n_rows_table);
+        uint4 a = table[i];
+        acc.x ^= a.x; acc.y += a.w;
+    }
+    sink[tid] = acc.x ^ acc.y;
+}
+static int run_mem(const char *mode) {
+    const size_t table_bytes = (size_t)2 << 30, n_rows = table_bytes / 64;
+    const int blocks = 256 * 8, threads = 256;
+    const size_t rows_per_thread = 64;  // 2048 * 256 * 64 rows = 33.5 M rows = 2.1 GB
+    uint4 *table; unsigned *sink;
+    CHK(hipMalloc(&table, table_bytes));
+    CHK(hipMemset(table, 1, table_bytes));
+    CHK(hipMalloc(&sink, (size_t)blocks * threads * 4));
+    bool gather = mode[0] == 'g';
+    hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    for (int rep = 0; rep < 3; rep++) {
+        CHK(hipEventRecord(e0));
+        if (gather) hipLaunchKernelGGL(k_gather64, dim3(blocks), dim3(threads), 0, 0, table, n_rows, rows_per_thread, sink);
+        else hipLaunchKernelGGL(k_stream64, dim3(blocks), dim3(threads), 0, 0, table, n_rows, rows_per_thread, sink);
+        CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+        float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+        double rows = (double)blocks * threads * rows_per_thread;
+        printf("%s: %.0f rows of 64 B = %.1f MB per launch, %.3f ms, %.2f G rows/s, %.2f TB/s of row bytes\n", gather ? "gather64" : "stream64", rows,
+               rows * 64 / 1e6, ms, rows / ms / 1e6, rows * 64 / ms / 1e9);
+    }
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    if (argc > 1 && (argv[1][0] == 'g' || argv[1][0] == 's')) return run_mem(argv[1]);
+    bool only_ec = argc > 1 && argv[1][0] == 'e';
     hipDeviceProp_t prop; CHK(hipGetDeviceProperties(&prop, 0));
     int ncu = prop.multiProcessorCount;
     printf("device %s, CUs %d, clock %d kHz, memtime ticks are at 100MHz*? (compare with ns column)\n", prop.name, ncu, prop.clockRate);
+    if (only_ec) {
+        run("xyzz29_madd", k_madd29, 1, 500, ncu);
+        run("affine_add_body", k_affine_add_body29, 1, 500, ncu);
+        run("fe_inv_safegcd", k_inv_safegcd, 1, 40, ncu);
+        return 0;
+    }
     run("v_add_u32", k_add_u32, 64, 4000, ncu);
     run("v_mov_b32", k_mov_b32, 64, 4000, ncu);
     run("v_add3_u32", k_add3_u32, 64, 4000, ncu);
@@ -148,5 +263,8 @@ int main() {
     run("v_fma_f64", k_fma_f64, 64, 2000, ncu);
     run("fe_mul(x2)", k_fe_mul, 2, 2000, ncu);
     run("xyzz_madd", k_madd, 1, 500, ncu);
+    run("xyzz29_madd", k_madd29, 1, 500, ncu);
+    run("affine_add_body", k_affine_add_body29, 1, 500, ncu);
+    run("fe_inv_safegcd", k_inv_safegcd, 1, 40, ncu);
     return 0;
 }

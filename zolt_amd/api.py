@@ -940,15 +940,18 @@ class LassoAddressRounds:
     summed by bit `round` of the u128 lookup index — eq_evals and indices stay resident in HBM for all LOG_K rounds."""
 
     def __init__(self, eq_evals, lookup_indices_u128):
-        import torch
         eq = np.ascontiguousarray(eq_evals, dtype=np.uint64).reshape(-1, 4)
         idx = np.ascontiguousarray(lookup_indices_u128, dtype=np.uint64).reshape(-1, 2)
         assert eq.shape[0] == idx.shape[0]
         self.n = eq.shape[0]
-        self._eq = torch.from_numpy(eq.view(np.int64)).cuda()
-        self._idx = torch.from_numpy(idx.view(np.int64)).cuda()
+        self._eq = lib.DeviceBuffer.from_host(eq)
+        self._idx = lib.DeviceBuffer.from_host(idx)
 
     def computeAddressRoundPoly(self, round_bit):
         """-> coeffs [sum_0, sum_1 - sum_0, 0] (:304-306)"""
-        s0, s1 = lib.fr_bit_split_sums_dev(self._eq.data_ptr(), self._idx.data_ptr(), self.n, round_bit)
+        s0, s1 = lib.fr_bit_split_sums_dev(self._eq.ptr, self._idx.ptr, self.n, round_bit)
         return np.stack([s0, _fr_sub(s1, s0), np.zeros(4, dtype=np.uint64)])
+
+    def deinit(self):
+        self._eq.free()
+        self._idx.free()

@@ -412,6 +412,20 @@ ZG_DEV Fr fr_mul29(const Fr &x, const F29 &y_pre) {
     return out;
 }
 
+// The same product for two VARIABLE canonical factors (no shared one to pre-scale): the factor 2^5 is applied to y as a
+// 5-bit left shift across its 29-bit limbs — 32*y < 2^259 still fits the nine limbs, and the lazy multiplier accepts an
+// operand < 32 r: the product is < (32/168.9 + 1) r < 2 r, so one conditional subtraction restores the canonical value.
+// ~330 instructions against ~560 for the 32-bit-limb CIOS (fe_mul); bit-identical result.
+ZG_DEV Fr fr_mul29v(const Fr &x, const Fr &y) {
+    F29 yu = f29_unpack(y.l), ys;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        u32 lo = i ? (yu.l[i - 1] >> 24) : 0u;
+        ys.l[i] = (i < 8) ? (((yu.l[i] << 5) & Fr29::MASK) | lo) : ((yu.l[i] << 5) | lo);
+    }
+    return fr_mul29(x, ys);
+}
+
 // Montgomery -> canonical integer of a scalar (fromMontgomery, src/field/mod.zig:642-645) = montgomeryMul(x, 1): the
 // prescaled 1 is the constant 32, so the product half of the multiplication folds to nine shifts and only the reduction
 // remains (~260 instructions instead of ~500 for the 32-bit-limb CIOS by one). Canonical output.

@@ -1171,29 +1171,31 @@ __global__ void __launch_bounds__(256) g1_scalar_mul_kernel(const uint64_t *xy, 
 // and one toAffine, no doubling at all.
 static constexpr int FB_C = 8, FB_W = 32, FB_ROWS = 255;
 
-// one thread per window: 8w doublings of G, then the 255 multiples by repeated addition; rows left in lazy XYZZ form
-__global__ void __launch_bounds__(32) fb_table_build_kernel(const uint64_t *base_xy, char *xyzz_rows /* FB_W * FB_ROWS * 144 */) {
-    uint32_t w = threadIdx.x;
-    if (w >= (uint32_t)FB_W) return;
+// step 1 (one block, quad w of lanes per window): B_w = 2^(8w) * G by 8w doublings, every doubling by a quad (g1_29x4.hip.h) —
+// the only serial chain of the build (248 doublings for the top window)
+__global__ void __launch_bounds__(128) fb_window_bases_kernel(const uint64_t *base_xy, char *bw /* FB_W * 144 */) {
+    uint32_t w = threadIdx.x >> 2, q = threadIdx.x & 3;
     Affine g = affine_load(base_xy);
     F29 one29;
 #pragma unroll
     for (int k = 0; k < 9; k++) one29.l[k] = Fp29::ONE[k];
     XYZZ29 step;
     step.x = f29_from_fp(g.x); step.y = f29_from_fp(g.y); step.zz = one29; step.zzz = one29;
-    for (uint32_t k = 0; k < (uint32_t)FB_C * w; k++) step = xyzz29_dbl(step);  // 2^(8w) * G (odd prime order: never the identity)
-    XYZZ29 acc = step;
-    for (int d = 1; d <= FB_ROWS; d++) {
-        xyzz29_store(xyzz_rows + 144 * ((size_t)w * FB_ROWS + (d - 1)), acc);
-        if (d < FB_ROWS) acc = xyzz29_add(acc, step);  // complete addition: d = 1 -> doubling is handled
-    }
+    for (uint32_t k = 0; k < (uint32_t)FB_C * w; k++) step = xyzz29_dbl4(step, q);  // odd prime order: never the identity
+    if (q == 0) xyzz29_store(bw + 144 * (size_t)w, step);
 }
 
-// lazy XYZZ rows -> packed affine rows (the accumulate kernel's 64-byte row format), one inversion per row
-__global__ void __launch_bounds__(256) fb_table_affine_kernel(const char *xyzz_rows, uint32_t n_rows, char *table) {
+// step 2 (one thread per table row): d * B_w by double-and-add over the 8 bits of d, then to affine — the packed 64-byte row
+// format of the accumulate kernel (x, y as lazy Montgomery-2^261 values)
+__global__ void __launch_bounds__(256) fb_table_rows_kernel(const char *bw, uint32_t n_rows, char *table) {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_rows) return;
-    XYZZ29 a = xyzz29_load(xyzz_rows + 144 * (size_t)i);
+    uint32_t w = i / FB_ROWS, d = i % FB_ROWS + 1;
+    XYZZ29 b = xyzz29_load(bw + 144 * (size_t)w), a = xyzz29_identity();
+    for (int bit = FB_C - 1; bit >= 0; bit--) {
+        a = xyzz29_dbl(a);
+        if ((d >> bit) & 1u) a = xyzz29_add(a, b);
+    }
     F29 izzz = f29_from_fp(fe_inv_safegcd(f29_to_fp(a.zzz)));
     F29 iz = f29_mul(izzz, a.zz);  // 1/Z = ZZ / ZZZ
     f29_store_packed(table + 64 * (size_t)i, f29_mul(a.x, f29_sqr(iz)));
@@ -2277,13 +2279,13 @@ int zg_g1_fixed_base_mul_batch(const uint64_t base_xy[8], uint8_t base_inf, cons
     }
     hipStream_t st = lib_stream();
     const uint32_t n_rows = FB_W * FB_ROWS;
-    Scratch s_base(64), s_rows((size_t)n_rows * 144), s_tab((size_t)n_rows * 64), s_sc(n * 32), s_out(n * 64), s_inf(n);
+    Scratch s_base(64), s_rows((size_t)FB_W * 144), s_tab((size_t)n_rows * 64), s_sc(n * 32), s_out(n * 64), s_inf(n);
     if (!s_base.p || !s_rows.p || !s_tab.p || !s_sc.p || !s_out.p || !s_inf.p) return ZG_ERR_NOMEM;
     SyncGuard sync(st);
     ZG_HIP(hipMemcpyAsync(s_base.p, base_xy, 64, hipMemcpyHostToDevice, st));
     ZG_HIP(hipMemcpyAsync(s_sc.p, scalars, n * 32, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(fb_table_build_kernel, dim3(1), dim3(32), 0, st, s_base.as<uint64_t>(), s_rows.as<char>());
-    hipLaunchKernelGGL(fb_table_affine_kernel, dim3(div_up(n_rows, 256)), dim3(256), 0, st, s_rows.as<char>(), n_rows, s_tab.as<char>());
+    hipLaunchKernelGGL(fb_window_bases_kernel, dim3(1), dim3(4 * FB_W), 0, st, s_base.as<uint64_t>(), s_rows.as<char>());
+    hipLaunchKernelGGL(fb_table_rows_kernel, dim3(div_up(n_rows, 256)), dim3(256), 0, st, s_rows.as<char>(), n_rows, s_tab.as<char>());
     hipLaunchKernelGGL(fb_mul_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, s_tab.as<char>(), s_sc.as<uint64_t>(), n, s_out.as<uint64_t>(),
                        s_inf.as<uint8_t>());
     ZG_HIP(hipGetLastError());

@@ -41,14 +41,14 @@ ZG_DEV Fr eq_factor_product4(const uint64_t *r, int v, uint32_t idx, uint32_t q,
     for (int j = (int)q; j < v; j += 4) {
         Fr rj = fe_load<FrParams>(r + 4 * j);
         Fr f = ((idx >> (v - 1 - j)) & 1u) ? rj : fe_sub(one, rj);
-        c = used ? fe_mul(c, f) : f;
+        c = used ? fr_mul29v(c, f) : f;
         used = true;
     }
     // lanes q and q+1, then q and q+2 (all four lanes of a group execute the same products; lane 0 holds the result)
     Fr o = fr_shfl_down(c, 1);
-    c = fe_mul(c, o);
+    c = fr_mul29v(c, o);
     o = fr_shfl_down(c, 2);
-    return fe_mul(c, o);
+    return fr_mul29v(c, o);
 }
 
 __global__ void __launch_bounds__(256) eq_tables_kernel(const uint64_t *r, int v_hi, int v_lo, const uint64_t *scale, uint64_t *hi,
@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(256) spartan_combine_kernel(const uint64_t *eq
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         Fr a = fe_load<FrParams>(az + 4 * i), b = fe_load<FrParams>(bz + 4 * i), c = fe_load<FrParams>(cz + 4 * i);
         Fr e = fe_load<FrParams>(eq + 4 * i);
-        fe_store(out + 4 * i, fe_mul(e, fe_sub(fe_mul(a, b), c)));
+        fe_store(out + 4 * i, fr_mul29v(e, fe_sub(fr_mul29v(a, b), c)));
     }
 }
 
@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(256) fr_dot_kernel(const uint64_t *a, const ui
     Fr g0 = Fr::zero(), g1 = Fr::zero();
     size_t stride = (size_t)gridDim.x * 256;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
-        g0 = fe_add(g0, fe_mul(fe_load<FrParams>(a + 4 * i), fe_load<FrParams>(b + 4 * i)));
+        g0 = fe_add(g0, fr_mul29v(fe_load<FrParams>(a + 4 * i), fe_load<FrParams>(b + 4 * i)));
     block_sum_pair(g0, g1, sh);
     if (threadIdx.x == 0) {
         fe_store(partials + 8 * (size_t)blockIdx.x, g0);
@@ -456,7 +456,7 @@ __global__ void __launch_bounds__(256) eq_spartan_kernel(const uint64_t *lo_tab,
             size_t i = ((size_t)h << v_lo) | lo;
             Fr e = fr_mul29(fe_load<FrParams>(hi + 4 * (size_t)h), tp);
             Fr a = fe_load<FrParams>(az + 4 * i), b = fe_load<FrParams>(bz + 4 * i), c = fe_load<FrParams>(cz + 4 * i);
-            Fr f = fe_mul(e, fe_sub(fe_mul(a, b), c));
+            Fr f = fr_mul29v(e, fe_sub(fr_mul29v(a, b), c));
             fe_store(out + 4 * i, f);
             bool second = LAYOUT == ZG_SC_HIGH_HALF ? (n_hi > 1 ? h >= n_hi / 2 : lo >= (1u << v_lo) / 2) : (lo & 1u);
             if (second) g1 = fe_add(g1, f);
@@ -495,8 +495,8 @@ __global__ void __launch_bounds__(256) raf_round_kernel(const uint64_t *t, size_
         Fr u0 = fe_add(bv, fr_mul29(rv, r2p));  // F.fromU64(rem) = rem * R^2 * R^-1
         Fr u2 = fe_add(u0, cp2);
         Fr ra2 = fe_sub(fe_add(hi, hi), lo);
-        g0 = fe_add(g0, fe_mul(lo, u0));
-        g1 = fe_add(g1, fe_mul(ra2, u2));
+        g0 = fe_add(g0, fr_mul29v(lo, u0));
+        g1 = fe_add(g1, fr_mul29v(ra2, u2));
     }
     block_sum_pair(g0, g1, sh);
     if (threadIdx.x == 0) {
@@ -1121,7 +1121,7 @@ __global__ void __launch_bounds__(256) hk_dot_mask_kernel(const uint64_t *a, siz
     Fr g0 = Fr::zero(), g1 = Fr::zero();
     size_t stride = (size_t)gridDim.x * 256;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
-        g0 = fe_add(g0, fe_mul(fe_load<FrParams>(a + 4 * i), fe_load<FrParams>(eq + 4 * (i & mask))));
+        g0 = fe_add(g0, fr_mul29v(fe_load<FrParams>(a + 4 * i), fe_load<FrParams>(eq + 4 * (i & mask))));
     block_sum_pair(g0, g1, sh);
     if (threadIdx.x == 0) {
         fe_store(partials + 8 * (size_t)blockIdx.x, g0);

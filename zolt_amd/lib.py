@@ -126,6 +126,40 @@ def last_error():
     return m.decode() if m else ""
 
 
+class DeviceBuffer:
+    """Raw device memory through the C ABI itself (zg_dev_alloc / zg_memcpy_*): what a host without its own HIP binding uses
+    (the Zig shim), and what keeps this module free of torch."""
+
+    def __init__(self, nbytes):
+        p = C.c_void_p()
+        _chk(_lib.zg_dev_alloc(C.c_size_t(nbytes), C.byref(p)), "zg_dev_alloc")
+        self.ptr, self.nbytes = p.value, nbytes
+
+    @classmethod
+    def from_host(cls, arr):
+        a = np.ascontiguousarray(arr)
+        b = cls(max(a.nbytes, 1))
+        if a.nbytes:
+            _chk(_lib.zg_memcpy_h2d(C.c_void_p(b.ptr), a.ctypes.data_as(C.c_void_p), C.c_size_t(a.nbytes)), "zg_memcpy_h2d")
+        return b
+
+    def to_host(self, dtype=np.uint64):
+        out = np.empty(self.nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        _chk(_lib.zg_memcpy_d2h(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr), C.c_size_t(out.nbytes)), "zg_memcpy_d2h")
+        return out
+
+    def free(self):
+        if self.ptr:
+            _chk(_lib.zg_dev_free(C.c_void_p(self.ptr)), "zg_dev_free")
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 PROF_NAMES = ["msm_digits", "msm_sort", "msm_accumulate", "msm_reduce", "eq_table", "sc_fold", "sc_sums", "combine"]
 
 
