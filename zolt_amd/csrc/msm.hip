@@ -1330,8 +1330,9 @@ static int make_plan(size_t n, const zg_msm_config *cfg, MsmPlan &p, size_t batc
         // 2^15 points up (fewest windows; the rest of the pipeline is latency), 8 / 7 below.
         c = n >= 32768 ? 16 : (n >= 8192 ? 10 : (n >= 2048 ? 8 : (n >= 64 ? 7 : 5)));  // 2^13 points: 0.40 ms with c = 8, 0.32 with 10
         // 17 bits = 15 windows instead of 16 (6 % fewer bucket additions) for twice the buckets: pays from about 2^20 points,
-        // as long as the 15 n table rows still fit the 24-bit references of the two-pass sort (n <= 1.1 M)
-        if (batch == 1 && n >= (size_t)env_int("ZG_MSM_C17_MIN", 900000) && (uint64_t)n * 15 <= (1u << 24)) c = 17;
+        // as long as the 15 n table rows leave the two-pass sort at least 5 fine key bits beside the 26-bit reference of an
+        // intermediate entry (n <= 4.4 M: 2^22 points run 177 instead of 172 MSM/s, accumulate 5.98 -> 5.61 ms)
+        if (batch == 1 && n >= (size_t)env_int("ZG_MSM_C17_MIN", 900000) && (uint64_t)n * 15 <= (1u << 26)) c = 17;
     }
     if (c < 2 || c > 17) {
         set_error("msm: window_bits must be in [2,17]");
