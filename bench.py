@@ -647,4 +647,4 @@ def cpu_baseline(bases_xy, scalars, want, logn):
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -235,3 +235,12 @@ def test_eq_mle_host_mirror_matches_oracle_and_bigint():
     tab = ob.fr_eq_table(r)
     for idx in range(16):  # at a boolean point mle is the table entry, index MSB <-> r[0]
         assert np.array_equal(api.EqPolynomial.mle(r, U.fr([(idx >> (3 - j)) & 1 for j in range(4)])), tab[idx])
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="GPU present: the no-device path cannot be observed")
+def test_bench_self_launch_without_gpu_fails_fast_and_loudly():
+    """`python bench.py --gpus N` without a launcher starts its N ranks itself (before anything touches a GPU); without a device
+    every rank must refuse (no CPU fallback) and the launcher must hand the failure back as its exit code, not hang."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0
+    assert res.stderr.count("bench.py needs a GPU") == 2 and "{" not in res.stdout

@@ -74,3 +74,54 @@ def test_stage1_oracle_kat_tiny():
     # more rounds than variables: [poly[0], 0, 0] rounds, no further folding (jolt_r1cs.zig:421-430,462-465)
     rp3, ch3, fin3 = ob.stage1_prove(poly, 4, ob.Transcript(b"Jolt"))
     assert np.array_equal(rp3[:2], rp) and np.array_equal(rp3[2][0], fin) and not rp3[2][1:].any() and np.array_equal(fin3, fin)
+
+
+def test_blake2b_transcript_matches_reference_log(golden_dir):
+    """The Jolt-compatible transcript of the reference's proving path (src/transcripts/blake2b.zig) against the states the
+    reference printed in its captured run (logs/zolt.log:28-30,1165-1187; fixture tests/golden/blake2b_transcript_preamble.json):
+    the full 32-byte state after init("Jolt"), then six appendU64 and two empty appendBytes whose 8-byte state prefixes the log
+    shows, up to the state the first appendGT saw."""
+    import json
+    import os
+    from zolt_amd import api
+    d = json.load(open(os.path.join(golden_dir, "blake2b_transcript_preamble.json")))
+    t = api.Blake2bTranscript(d["label"].encode())
+    assert t.state.hex() == d["initial_state_hex"] and t.n_rounds == 0
+    for op in d["ops"]:
+        if op["op"] == "appendU64":
+            t.appendU64(op["value"])
+        else:
+            assert t.state.hex().startswith(op["state_before_prefix"])
+            t.appendBytes(bytes.fromhex(op["hex"]))
+            assert t.state.hex().startswith(op["state_after_prefix"])
+    assert t.state.hex().startswith(d["state_prefix_after_all_ops"]) and t.n_rounds == len(d["ops"])
+
+
+def test_blake2b_transcript_challenge_shapes():
+    """challengeScalar = MontU128Challenge: raw limbs [0, 0, low, high] of a 125-bit value (the layout the reference's
+    r_cycle_be fixture shows); challengeScalarFull = the unmasked 128-bit value in Montgomery form; both advance the state."""
+    from zolt_amd import api
+    t = api.Blake2bTranscript(b"Jolt")
+    t.appendScalar(api.fr_from_int(12345))
+    t.appendScalars([api.fr_from_int(1), api.fr_from_int(2)])
+    t2 = api.Blake2bTranscript(b"Jolt")
+    t2.appendBytes((12345).to_bytes(32, "big"))
+    t2.appendMessage(b"begin_append_vector")
+    t2.appendBytes((1).to_bytes(32, "big"))
+    t2.appendBytes((2).to_bytes(32, "big"))
+    t2.appendMessage(b"end_append_vector")
+    assert t.state == t2.state and t.n_rounds == 5
+    t3 = api.Blake2bTranscript(b"Jolt")
+    t3.state, t3.n_rounds = t.state, t.n_rounds
+    raw = t3.challengeBytes(16)  # the 16 bytes all three draw from the same state
+    c = t.challengeScalar()
+    # challengeScalar128Bits (:332-390): bytes reversed, read big-endian (= the raw bytes little-endian), 125-bit mask, limbs UNCONVERTED
+    want = int.from_bytes(raw, "little") & ((1 << 125) - 1)
+    assert c[0] == 0 and c[1] == 0 and int(c[2]) | (int(c[3]) << 64) == want and int(c[3]) < (1 << 61)
+    # challengeScalarFull (:279-312): bytes reversed, read little-endian (= the raw bytes big-endian), no mask, proper Montgomery form
+    full = t2.challengeScalarFull()
+    assert api.fr_to_int(full) == int.from_bytes(raw, "big")
+    assert t.state == t2.state == t3.state
+    assert len(t.challengeBytes(70)) == 70 and t.n_rounds == t2.n_rounds + 3
+    v = t2.challengeVector(3)  # :392-399: challengeScalar each
+    assert v.shape == (3, 4) and not v[:, :2].any()
