@@ -128,6 +128,28 @@ def test_api_parallel_msm_mirrors(env, monkeypatch):
         assert inf[j] == wi and np.array_equal(out[j], w)
 
 
+def test_hyperkzg_commit_and_batch_commit_on_a_sharded_srs(env, monkeypatch):
+    """north_star's "HyperKZG batch-commit shard ... across the GPUs" at the mirror level: SetupParams(sharded=True) keeps one
+    shard of the SRS per device; commit / batchCommit (equal lengths fused into one sharded batch call, others one by one)
+    equal the oracle's HyperKZG.commit (src/poly/commitment/mod.zig:239-255,558-570)."""
+    api, lib, ob, gm = env
+    monkeypatch.setenv("ZG_SHARDS", "4")
+    n = 2048
+    inf = np.zeros(n, dtype=np.uint8)
+    params = api.HyperKZG.SetupParams(gm[:n], inf, sharded=True)
+    try:
+        polys = [_rand(ob, 1800 + k, n) for k in range(3)] + [_rand(ob, 1810, 700), np.zeros((0, 4), dtype=np.uint64), _rand(ob, 1811, 3000)]
+        got = api.HyperKZG.batchCommit(params, polys)
+        for (xy, fl), p in zip(got, polys):
+            w, wi = ob.hyperkzg_commit(gm[:n], inf, p)
+            assert fl == wi and np.array_equal(xy, w)
+        c, ci = api.HyperKZG.commit(params, polys[0])
+        w, wi = ob.hyperkzg_commit(gm[:n], inf, polys[0])
+        assert ci == wi and np.array_equal(c, w)
+    finally:
+        params.deinit()
+
+
 @pytest.mark.parametrize("layout", [0, 1])
 @pytest.mark.parametrize("shards,v", [(1, 6), (2, 6), (4, 9), (8, 3), (8, 12), (3, 7)])
 def test_sharded_sumcheck_session_equals_single_device(env, layout, shards, v, monkeypatch):
@@ -155,3 +177,52 @@ def test_sharded_sumcheck_session_equals_single_device(env, layout, shards, v, m
         assert np.array_equal(s.final(), cur[0])
     finally:
         s.close()
+
+
+def _n_gpus():
+    from zolt_amd import lib
+    return lib.device_count()
+
+
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs at least two GPUs in this box (the real RCCL all-gather over xGMI)")
+def test_real_devices_rccl_all_gather(env, monkeypatch):
+    """On a multi-GPU box: one shard per physical device, partials exchanged by the grouped ncclAllGather, combined on device 0 —
+    single MSM, prefix, batch, and the sharded sumcheck session across the devices. Skipped on the one-GPU test box."""
+    api, lib, ob, gm = env
+    monkeypatch.delenv("ZG_SHARDS", raising=False)
+    monkeypatch.delenv("ZG_SHARD_EXCHANGE", raising=False)
+    nd = min(_n_gpus(), 8)
+    lib.init_devices(nd)
+    assert lib.n_devices() >= nd
+    sb = lib.ShardedBases.upload(gm)
+    try:
+        assert len(sb.shards()) == lib.n_devices() and sb.exchange() == "rccl"
+        assert sorted(d for d, _, _ in sb.shards()) == list(range(lib.n_devices()))
+        sc = _rand(ob, 1700, N)
+        for n in (N, N // 2 + 1, 3):
+            want = ob.msm_g1(gm[:n], None, sc[:n])
+            got = sb.msm(sc[:n], n)
+            assert got[1] == want[1] and np.array_equal(got[0], want[0]), n
+        batches = [_rand(ob, 1710 + j, N) for j in range(5)]
+        out, inf = sb.msm_batch(batches)
+        for j in range(5):
+            w, wi = ob.msm_g1(gm, None, batches[j])
+            assert inf[j] == wi and np.array_equal(out[j], w)
+    finally:
+        sb.free()
+    for layout in (lib.SC_HIGH_HALF, lib.SC_LOW_PAIR):
+        table = _rand(ob, 1720 + layout, 1 << 12)
+        s = lib.ShardedSumcheckSession.open(table, layout)
+        try:
+            assert s.shards() > 1
+            cur = table
+            for rd in range(12):
+                g0, g1 = s.round_sums()
+                w0, w1 = (ob.fr_sum_halves(cur) if layout == lib.SC_HIGH_HALF else ob.fr_sum_even_odd(cur))
+                assert np.array_equal(g0, w0) and np.array_equal(g1, w1), rd
+                r = _rand(ob, 1730 + rd, 1)[0]
+                s.bind(r)
+                cur = ob.fr_bind_high(cur, r) if layout == lib.SC_HIGH_HALF else ob.fr_bind_low(cur, r)
+            assert np.array_equal(s.final(), cur[0])
+        finally:
+            s.close()

@@ -230,11 +230,14 @@ class HyperKZG:
     TAU = 0x12345678  # src/poly/commitment/mod.zig:189 (mock SRS, INSECURE by design)
 
     class SetupParams:
-        def __init__(self, xy, inf):
+        def __init__(self, xy, inf, sharded=False):
             self.powers_of_tau_g1 = xy
             self.infinity = inf
             self.max_degree = xy.shape[0]
-            self._dev = lib.Bases.upload(xy, inf)  # device-resident for the whole run (:122-140)
+            # device-resident for the whole run (:122-140); sharded=True: one shard per GPU bound by lib.init_devices — commit and
+            # batchCommit then go through the one-process multi-GPU entry points (zg_msm_g1_sharded / zg_msm_g1_batch_sharded)
+            self.sharded = bool(sharded)
+            self._dev = lib.ShardedBases.upload(xy, inf) if sharded else lib.Bases.upload(xy, inf)
 
         def deinit(self):
             self._dev.free()
@@ -259,6 +262,8 @@ class HyperKZG:
         if evals.shape[0] == 0:
             return np.zeros(8, dtype=np.uint64), 1
         n = min(evals.shape[0], params.max_degree)
+        if params.sharded:
+            return params._dev.msm(evals[:n], n=n)
         return params._dev.msm(evals[:n], off=0, n=n)
 
     @staticmethod
