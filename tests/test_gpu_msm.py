@@ -300,8 +300,9 @@ def test_full_size_closed_form(zl, ob, n):
     raw = U.random_raw256(0x5A4F4C54, n)
     sc = ob.f_to_mont(ob.FR, raw)
     b = zl.Bases.upload(gm)
-    # the automatic plan (the GPU's optimalWindowSize): 17-bit windows while 15 n table rows fit 24-bit references, else 16
-    assert b.plan() == ((17, 15, 15) if n * 15 <= 1 << 24 else (16, 16, 16))
+    # the automatic plan (the GPU's optimalWindowSize): 17-bit windows while the 15 n table rows fit the 26-bit reference that
+    # leaves the two-pass sort 5 fine key bits (2^22 points included), else 16
+    assert b.plan() == ((17, 15, 15) if n * 15 <= 1 << 26 else (16, 16, 16))
     got, ginf = b.msm(sc)
     got2, ginf2 = b.msm(sc)  # idempotent: same handle, same answer
     b.free()
