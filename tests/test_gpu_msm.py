@@ -289,6 +289,32 @@ def test_srs_and_reference_proof_commitment(zl, ob, golden_dir):
     assert list(oinf) == [1, 0, 1] and np.array_equal(out[1], g[0]) and not out[0].any() and not out[2].any()
 
 
+def test_all_commitments_of_the_reference_proof_header(zl, ob, golden_dir):
+    """BASELINE config 5 as far as it goes without a Zig toolchain: the three commitments a `zolt prove examples/fibonacci.elf` run
+    stores in the ZOLT v1 proof header (src/zkvm/serialization.zig:283-306) — bytecode @8, memory @232 (identity: empty RAM
+    trace), registers @488 — produced by the GPU path (HyperKZG.setup with the fixed-base kernel at the reference's srs_size =
+    1280, HyperKZG.commit on the resident SRS) and compared with the reference's own captured bytes."""
+    from zolt_amd import api
+    elf = open(os.path.join(golden_dir, "fibonacci.elf"), "rb").read()
+    proof = open(os.path.join(golden_dir, "zolt_proof_regular.bin"), "rb").read()
+    hdr = api.parse_zolt_proof_commitments(proof)
+    params = api.HyperKZG.setup(1280)  # logs/zolt.log:10
+    try:
+        bc = np.zeros(128, dtype=np.uint64)
+        bc[:104] = np.frombuffer(elf[0x1000:0x1000 + 104], dtype=np.uint8)  # commitBytecode, src/zkvm/mod.zig:1519-1547
+        reg = np.zeros(256, dtype=np.uint64)
+        reg[:54] = np.array(U.fibonacci_rd_values(elf), dtype=np.uint64)    # commitRegisters, :1585-1617
+        polys = [U.fr(bc), np.zeros((0, 4), dtype=np.uint64), U.fr(reg)]
+        got = api.HyperKZG.batchCommit(params, polys)
+        for (xy, fl), name in zip(got, ("bytecode.commitment", "memory.commitment", "register.commitment")):
+            assert api.commitment_to_bytes(xy, fl) == hdr[name], name
+        assert hdr["register.commitment"] == proof[488:552] and hdr["register.commitment"] != bytes(64)
+        one = api.HyperKZG.commit(params, polys[2])
+        assert api.commitment_to_bytes(*one) == proof[488:552]
+    finally:
+        params.deinit()
+
+
 @pytest.mark.parametrize("n", [1 << 20, (1 << 20) + 1, 1 << 22])
 def test_full_size_closed_form(zl, ob, n):
     """BASELINE config 2 (2^20 points, one GPU), the 2^20 + 1 member of SURVEY §8(d)'s adversarial size set and the metric's

@@ -36,6 +36,23 @@ def test_bytecode_commitment_matches_reference_proof(golden_dir):
     assert pm.commitment_bytes(r) == proof[8:72]
 
 
+def test_register_commitment_matches_reference_proof(golden_dir):
+    """logs/zolt_proof_regular.bin bytes 488..552 = HyperKZG.commit of the register polynomial poly[i] = rd_value of trace step i
+    (src/zkvm/mod.zig:1585-1617), 54 executed steps of examples/fibonacci.elf padded to 256 (logs/zolt.log:23-27): a second
+    commitment the reference itself produced, regenerated from the ELF through a minimal RV64 interpreter (tests/util.py)."""
+    elf = open(os.path.join(golden_dir, "fibonacci.elf"), "rb").read()
+    proof = open(os.path.join(golden_dir, "zolt_proof_regular.bin"), "rb").read()
+    vals = U.fibonacci_rd_values(elf)
+    assert len(vals) == 54 and vals[:4] == [0x8000, 0x8001, 0x80010000, 0x80000010] and vals[-1] == 0x80000014
+    ev = np.zeros(256, dtype=np.uint64)
+    ev[:54] = np.array(vals, dtype=np.uint64)
+    srs, inf = ob.hyperkzg_setup(256)
+    c, ci = ob.hyperkzg_commit(srs, inf, ob.f_from_u64(FR, ev))
+    assert ci == 0 and ob.commitment_to_bytes(c) == proof[488:552]
+    r = pm.msm(pm.mock_srs(256), [int(x) for x in ev])
+    assert pm.commitment_bytes(r) == proof[488:552]
+
+
 def test_field_constants_and_kats():
     """src/field/mod.zig:16-75 constants; KATs :1101-1140 (3*7=21, 7*7^-1=1, 2^3=8)."""
     for f, mod in ((FR, pm.R_MOD), (FP, pm.P_MOD)):

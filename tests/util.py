@@ -73,3 +73,52 @@ def splitmix64(seed, n):
 def random_raw256(seed, n):
     """(n,4) uint64 raw 256-bit integers (may exceed the modulus)."""
     return splitmix64(seed, 4 * n).reshape(n, 4)
+
+
+def fibonacci_rd_values(elf_bytes, steps=54):
+    """rd_value of every step of the reference's captured fibonacci run (logs/zolt.log:23-27: 54 cycles, terminated by the
+    `j .` at 0x80000010), from a minimal RV64 interpreter of the ten instruction forms the 104-byte program uses — the semantics
+    of the reference's tracer (src/tracer/mod.zig:429-816: rd_value = the value computed for rd, 0 for branches; JAL / JALR
+    record pc + 4 even when rd = x0). Test infrastructure for the register-commitment fixture (src/zkvm/mod.zig:1585-1617)."""
+    import struct
+    code = elf_bytes[0x1000:0x1000 + 104]
+    mask = (1 << 64) - 1
+
+    def sx(v, b):
+        return v - (1 << b) if v >> (b - 1) else v
+
+    regs, pc, vals = [0] * 32, 0x80000000, []
+    for _ in range(steps):
+        w = struct.unpack("<I", code[pc - 0x80000000:pc - 0x80000000 + 4])[0]
+        op, rd, f3, rs1, rs2, f7 = w & 0x7F, (w >> 7) & 31, (w >> 12) & 7, (w >> 15) & 31, (w >> 20) & 31, w >> 25
+        imm_i, npc, rv = sx(w >> 20, 12), pc + 4, 0
+        a, b = regs[rs1], regs[rs2]
+        if op == 0x37:  # LUI
+            rv = sx(w & 0xFFFFF000, 32) & mask
+        elif op == 0x1B and f3 == 0:  # ADDIW
+            rv = sx((a + imm_i) & 0xFFFFFFFF, 32) & mask
+        elif op == 0x13 and f3 == 0:  # ADDI
+            rv = (a + imm_i) & mask
+        elif op == 0x13 and f3 == 1:  # SLLI
+            rv = (a << ((w >> 20) & 0x3F)) & mask
+        elif op == 0x6F:  # JAL
+            imm = sx(((w >> 31) << 20) | (((w >> 12) & 0xFF) << 12) | (((w >> 20) & 1) << 11) | (((w >> 21) & 0x3FF) << 1), 21)
+            rv, npc = pc + 4, pc + imm
+        elif op == 0x67:  # JALR
+            rv, npc = pc + 4, (a + imm_i) & ~1
+        elif op == 0x63:  # BRANCH: no rd, rd_value stays 0
+            imm = sx(((w >> 31) << 12) | (((w >> 7) & 1) << 11) | (((w >> 25) & 0x3F) << 5) | (((w >> 8) & 0xF) << 1), 13)
+            sa, sb = sx(a, 64), sx(b, 64)
+            if {0: a == b, 1: a != b, 4: sa < sb, 5: sa >= sb, 6: a < b, 7: a >= b}[f3]:
+                npc = pc + imm
+            rd = 0
+        elif op == 0x3B and f3 == 0:  # ADDW / SUBW
+            rv = sx(((a - b) if f7 & 0x20 else (a + b)) & 0xFFFFFFFF, 32) & mask
+        else:
+            raise ValueError(f"unexpected instruction {w:08x} at {pc:x}")
+        if rd:
+            regs[rd] = rv
+        vals.append(rv)
+        pc = npc
+    assert pc == 0x80000010 and regs[10] == 55  # back in the `j .` loop with fib = 55 in a0
+    return vals
