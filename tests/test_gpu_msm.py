@@ -599,3 +599,21 @@ def test_fixed_base_batch_equals_scalar_mul(zl, ob):
     assert np.array_equal(inf2, wi2) and np.array_equal(out2, w2)
     out3, inf3 = zl.g1_fixed_base_mul_batch(g, sc[:8], base_inf=1)
     assert inf3.all() and not out3.any()
+
+
+def test_host_batch_of_long_vectors_interleaves_copies(zl, ob, gm, monkeypatch):
+    """zg_msm_g1_batch with vectors too long to fuse: vector i's upload and launch set share stream i mod 3 (the copy of the next
+    vector runs under the MSM of the previous one). Same results as k separate calls and as the oracle; k = 5 exercises the
+    workspace rotation (3 lanes) and the join."""
+    monkeypatch.setenv("ZG_MSM_HOST_SLICE_MIN", "1000")
+    monkeypatch.setenv("ZG_MSM_BATCH_FUSE", "0")  # force the unfused path at a size the oracle finishes quickly
+    n, k = 5003, 5
+    b = zl.Bases.upload(gm[:n])
+    try:
+        batches = [ob.f_to_mont(ob.FR, U.random_raw256(4200 + j, n)) for j in range(k)]
+        out, inf = b.msm_batch(batches)
+        for j in range(k):
+            w, wi = ob.msm_g1(gm[:n], None, batches[j])
+            assert inf[j] == wi and np.array_equal(out[j], w), j
+    finally:
+        b.free()

@@ -1892,6 +1892,7 @@ int zg_msm_g1_dev(zg_bases_t b, size_t off, size_t n, const uint64_t *d_scalars,
 // the bytes are those of the unsliced MSM).
 static int ensure_aux_streams(zg_bases_s *b);
 static constexpr size_t HOST_SLICE_MIN_POINTS = (size_t)1 << 18;
+static size_t host_slice_min() { return (size_t)env_int("ZG_MSM_HOST_SLICE_MIN", (int)HOST_SLICE_MIN_POINTS); }  // tests lower it
 static constexpr int HOST_SLICES_MAX = 8;
 
 static int msm_host_sliced(zg_bases_s *b, size_t off, size_t n, const uint64_t *scalars, int slices, uint64_t out_xy[8], uint8_t *out_inf) {
@@ -1949,7 +1950,7 @@ int zg_msm_g1(zg_bases_t b, size_t off, size_t n, const uint64_t *scalars, uint6
     if (n && !b->d_scal) ZG_HIP(hipMalloc((void **)&b->d_scal, b->n * 32));
     int slices = env_int("ZG_MSM_HOST_SLICES", 4);
     if (slices > HOST_SLICES_MAX) slices = HOST_SLICES_MAX;
-    if (slices >= 2 && n >= (size_t)env_int("ZG_MSM_HOST_SLICE_MIN", (int)HOST_SLICE_MIN_POINTS) && b->lanes.size() >= 2) return msm_host_sliced(b, off, n, scalars, slices, out_xy, out_inf);
+    if (slices >= 2 && n >= host_slice_min() && b->lanes.size() >= 2) return msm_host_sliced(b, off, n, scalars, slices, out_xy, out_inf);
     if (n) ZG_HIP(hipMemcpyAsync(b->d_scal, scalars, n * 32, hipMemcpyHostToDevice, st));
     return msm_to_host(b, off, n, b->d_scal, st, out_xy, out_inf);
 }
@@ -2162,8 +2163,41 @@ int zg_msm_g1_batch(zg_bases_t b, size_t n, const uint64_t *const *batches, size
     if (!s_sc.p || !s_res.p) return ZG_ERR_NOMEM;
     uint64_t *d_sc = s_sc.as<uint64_t>(), *d_res = s_res.as<uint64_t>();
     ZG_HIP(hipMemsetAsync(d_res, 0, 9 * 8 * k, st));
-    for (size_t i = 0; i < k && n; i++) ZG_HIP(hipMemcpyAsync(d_sc + 4 * n * i, batches[i], n * 32, hipMemcpyHostToDevice, st));
-    int rc = msm_batch_enqueue(b, n, d_sc, k, st, d_res);
+    int rc = ZG_OK;
+    const bool routed_small = b->small && n <= b->small->n;
+    if (!routed_small && k >= 2 && n >= host_slice_min() && batch_fuse_limit(b, n) == 0 && b->lanes.size() >= 2) {
+        // long vectors (HyperKZG.batchCommit of full-size polynomials): vector i's copy and launch set go on stream i mod 3, so the
+        // 32n-byte copy of the next vector runs under the MSM of the previous one instead of all k copies preceding all k MSMs
+        rc = ensure_aux_streams(b);
+        if (rc == ZG_OK) {
+            hipStream_t ss[3] = {st, b->aux[0], b->aux[1]};
+            hipError_t e = hipEventRecord(b->ev_fork, st);
+            for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipStreamWaitEvent(b->aux[i], b->ev_fork, 0);
+            for (size_t i = 0; i < k && rc == ZG_OK && e == hipSuccess; i++) {
+                hipStream_t si = ss[i % 3];
+                e = hipMemcpyAsync(d_sc + 4 * n * i, batches[i], n * 32, hipMemcpyHostToDevice, si);
+                if (e == hipSuccess) rc = msm_enqueue(b, 0, n, d_sc + 4 * n * i, si, 0, d_res + 9 * i, reinterpret_cast<uint8_t *>(d_res + 9 * i + 8));
+            }
+            for (int i = 0; i < 2; i++) {  // join even after an error
+                hipError_t e1 = hipEventRecord(b->ev_join[i], b->aux[i]);
+                if (e1 == hipSuccess) e1 = hipStreamWaitEvent(st, b->ev_join[i], 0);
+                if (e == hipSuccess) e = e1;
+            }
+            if (e != hipSuccess && rc == ZG_OK) {
+                set_error(std::string("zg_msm_g1_batch: ") + hipGetErrorString(e));
+                rc = ZG_ERR_HIP;
+            }
+        }
+    } else {
+        hipError_t e = hipSuccess;
+        for (size_t i = 0; i < k && n && e == hipSuccess; i++) e = hipMemcpyAsync(d_sc + 4 * n * i, batches[i], n * 32, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) {
+            set_error(std::string("zg_msm_g1_batch: ") + hipGetErrorString(e));
+            rc = ZG_ERR_HIP;
+        } else {
+            rc = msm_batch_enqueue(b, n, d_sc, k, st, d_res);
+        }
+    }
     std::vector<uint64_t> h_res(9 * k);
     hipError_t e = hipSuccess;
     if (rc == ZG_OK) e = hipMemcpyAsync(h_res.data(), d_res, 9 * 8 * k, hipMemcpyDeviceToHost, st);
