@@ -308,8 +308,8 @@ ZG_DEV Fe<P> fe_inv_fast(const Fe<P> &a) {
 // ---- Inversion by Bernstein-Yang division steps ("safegcd"), in the batched variable-time form popularised by libsecp256k1's
 // modinv32: the state (f, g) = (MOD, x) and the Bezout coefficients (d, e) are 9 signed 30-bit limbs; 30 division steps at a
 // time are run on the low 32 bits of f and g only and collected in a 2x2 matrix of 31-bit entries, which is then applied to
-// the four big numbers with 32x32->64 multiply-adds. ~20 batches of ~300 instructions replace Kaliski's ~180 iterations of
-// ~130 carry-chained instructions: on one GPU lane (where a dependent instruction costs 4-8 cycles) that is ~4x faster, and
+// the four big numbers with 32x32->64 multiply-adds. ~20 batches of ~300 instructions replace the ~500 carry-chained iterations of
+// a binary Euclid: on one GPU lane (where a dependent instruction costs 4-8 cycles) that is ~4x faster, and
 // the single inversion at the end of an MSM was the longest item of a short MSM's tail. Value: x^-1 for the integer x;
 // Montgomery form is restored with one product by R^3.
 struct S30 {
