@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Launches the round-2 kernels at sizes where their bound shows (run under `rocprofv3 --kernel-trace --stats` for the per-kernel
+durations in DESIGN.md's table): RAF cubic round sums + LowToHigh fold at 2^22 entries, Lasso bit-split sums over 2^22 lookups,
+fixed-base batch at 2^20 scalars, affine add at 2^20 pairs, eq table + Spartan combine at 2^22."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    from bench import raw_scalars
+    from zolt_amd import api, lib
+    lib.init(0)
+    v = 22
+    n = 1 << v
+    tab = lib.field_op(lib.FR, lib.OP_TO_MONT, raw_scalars(0x52414631, 0, n))
+    for _ in range(3):
+        s = lib.SumcheckSession.open(tab, lib.SC_LOW_PAIR)
+        s.raf_round(api.fr_from_int(0x7FFF8000), 8)
+        s.bind(tab[5])
+        s.raf_round(api.fr_from_int(0x7FFF8000 + 8 * 12345), 16)
+        s.close()
+    idx = raw_scalars(0x4C415353, 0, n // 2).reshape(n, 2)
+    d_eq, d_idx = lib.DeviceBuffer.from_host(tab), lib.DeviceBuffer.from_host(idx)
+    for bit in (0, 17, 70):
+        lib.fr_bit_split_sums_dev(d_eq.ptr, d_idx.ptr, n, bit)
+    d_eq.free(); d_idx.free()
+    m = 1 << 20
+    g = api.generator()
+    sc = tab[:m]
+    for _ in range(2):
+        xy, inf = lib.g1_fixed_base_mul_batch(g, sc)
+    for _ in range(2):
+        lib.g1_affine_add_batch(xy[:m // 2], None, xy[m // 2:], None)
+    r = tab[:v]
+    d_out = lib.DeviceBuffer(n * 32)
+    d_a = lib.DeviceBuffer.from_host(tab)
+    for _ in range(3):
+        lib.fr_eq_table_dev(r, d_out.ptr)
+        lib.sync()
+        lib.fr_spartan_combine_dev(d_out.ptr, d_a.ptr, d_a.ptr, d_a.ptr, n, d_out.ptr)
+        lib.sync()
+    print("ok")
+
+
+if __name__ == "__main__":
+    main()
