@@ -396,6 +396,15 @@ pub fn SumcheckSession(comptime F: type) type {
             if (rc != ffi.OK) return Error.GpuFailure;
             return out;
         }
+        /// RafEvaluationProver.computeRoundPolynomialCubic's two sums s(0), s(2) over this LOW_PAIR session's table
+        /// (src/zkvm/ram/raf_checking.zig:335-410); `base` = start_address + 8 * sum_j bound_j 2^j, `current_power` = 8 * 2^round.
+        /// s(1) = claim - s(0) and s(3) = s(0) - 3 s(1) + 3 s(2) stay host code; the bind of the round is `bind`.
+        pub fn rafRoundSums(self: *Self, base: F, current_power: u64) Error![2]F {
+            var s0: F = undefined;
+            var s2: F = undefined;
+            if (self.handle == null or ffi.zg_sumcheck_raf_round(self.handle, &base.limbs, current_power, &s0.limbs, &s2.limbs) != ffi.OK) return Error.GpuFailure;
+            return .{ s0, s2 };
+        }
         /// materialise the current table for callers that index prover.polynomial.evaluations directly (:79-92,126,132);
         /// single-device sessions only
         pub fn read(self: *Self, out: []F) Error!void {
@@ -424,4 +433,15 @@ pub fn runSumcheck(comptime F: type, allocator: std.mem.Allocator, evaluations: 
     if (rc == ffi.ERR_VERIFY) return Error.SumcheckVerificationFailed;
     if (rc != ffi.OK) return Error.GpuFailure;
     return .{ .claim = claim, .rounds = rounds, .challenges = challenges, .final_eval = final_eval, .result = result != 0 };
+}
+
+/// LassoProver.computeAddressRoundPoly's two sums (src/zkvm/lasso/prover.zig:283-293): eq_evals split by bit `round_bit` of the
+/// u128 lookup indices. Host slices in; provers that run all LOG_K address rounds keep both arrays resident and call
+/// ffi.zg_fr_bit_split_sums_dev instead.
+pub fn lassoAddressSums(comptime F: type, eq_evals: []const F, lookup_indices: []const u128, round_bit: u32) Error![2]F {
+    std.debug.assert(eq_evals.len == lookup_indices.len);
+    var s0: F = undefined;
+    var s1: F = undefined;
+    if (ffi.zg_fr_bit_split_sums(limbsOf(F, eq_evals), @ptrCast(lookup_indices.ptr), eq_evals.len, round_bit, &s0.limbs, &s1.limbs) != ffi.OK) return Error.GpuFailure;
+    return .{ s0, s1 };
 }
