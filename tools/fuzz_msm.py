@@ -10,6 +10,7 @@ from zolt_amd import lib
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 lib.init(0)
+lib.init_devices(1)
 NMAX = 70000
 gm = ob.g1_gen_multiples(NMAX)
 R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
@@ -78,4 +79,52 @@ while time.time() - t0 < budget:
             assert infs[j] == winf and np.array_equal(outs[j], want), ("batch", n, cfg, nb, k, j)
         cases += k
     b.free()
+    # round-2 entry points: the one-process multi-GPU path with a random number of logical shards (peer-copy exchange on this box),
+    # the sliced host-scalar path, the fixed-base batch and the affine group law
+    if n and rng.random() < 0.5:
+        os.environ["ZG_SHARDS"] = str(int(rng.integers(1, 9)))
+        os.environ["ZG_MSM_HOST_SLICES"] = str(int(rng.integers(1, 9)))
+        os.environ["ZG_MSM_HOST_SLICE_MIN"] = str(int(rng.integers(1, 5000)))
+        sb = lib.ShardedBases.upload(xy, inf)
+        sc = scalars(n, int(rng.integers(0, 5)))
+        m = int(rng.integers(0, n + 1)) if rng.random() < 0.4 else n
+        got, ginf = sb.msm(sc[:m], m)
+        want, winf = ob.msm_g1(xy[:m], None if inf is None else inf[:m], sc[:m])
+        assert ginf == winf and np.array_equal(got, want), ("sharded", n, m, os.environ["ZG_SHARDS"])
+        k = int(rng.integers(1, 5))
+        nb = int(rng.integers(0, min(n, 4000) + 1))
+        batches = [scalars(nb, int(rng.integers(0, 5))) for _ in range(k)]
+        outs, infs = sb.msm_batch(batches, nb)
+        for j in range(k):
+            want, winf = ob.msm_g1(xy[:nb], None if inf is None else inf[:nb], batches[j])
+            assert infs[j] == winf and np.array_equal(outs[j], want), ("sharded batch", n, nb, k, j)
+        sb.free()
+        b2 = lib.Bases.upload(xy, inf)
+        got, ginf = b2.msm(sc)  # host scalars: sliced when n >= the random minimum
+        want, winf = ob.msm_g1(xy, inf, sc)
+        assert ginf == winf and np.array_equal(got, want), ("sliced host path", n, os.environ["ZG_MSM_HOST_SLICES"])
+        b2.free()
+        cases += 2 + k
+    if rng.random() < 0.3:
+        m = int(rng.integers(1, 300))
+        sc = scalars(m, int(rng.integers(0, 5)))
+        base = gm[int(rng.integers(0, NMAX))]
+        fx, fi = lib.g1_fixed_base_mul_batch(base, sc)
+        gx, gi = lib.g1_scalar_mul_batch(np.repeat(base[None, :], m, axis=0), np.zeros(m, dtype=np.uint8), sc)
+        assert np.array_equal(fi, gi) and np.array_equal(fx, gx), "fixed base"
+        for j in range(min(m, 3)):
+            o, oi = ob.g1_scalar_mul(base, 0, sc[j])
+            assert fi[j] == oi and (oi or np.array_equal(fx[j], o))
+        a_i, b_i = rng.integers(0, NMAX, size=m), rng.integers(0, NMAX, size=m)
+        b_i[: m // 4] = a_i[: m // 4]  # P + P
+        pa, pb = gm[a_i].copy(), gm[b_i].copy()
+        neg = slice(m // 4, m // 2)
+        pb[neg] = pa[neg]
+        pb[neg, 4:] = ob.f_neg(ob.FP, pa[neg, 4:])  # P + (-P)
+        ia, ib = (rng.random(m) < 0.1).astype(np.uint8), (rng.random(m) < 0.1).astype(np.uint8)
+        ox, oi = lib.g1_affine_add_batch(pa, ia, pb, ib)
+        for j in range(m):
+            w, wi = ob.g1_add_affine(pa[j], int(ia[j]), pb[j], int(ib[j]))
+            assert oi[j] == wi and (wi or np.array_equal(ox[j], w)), ("affine add", j)
+        cases += 2
 print(f"fuzz ok: {cases} MSMs checked in {time.time() - t0:.1f} s")

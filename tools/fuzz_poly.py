@@ -10,6 +10,7 @@ from zolt_amd import lib
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 lib.init(0)
+lib.init_devices(1)
 
 
 def rand_fr(n, sparse=False):
@@ -75,5 +76,53 @@ while time.time() - t0 < budget:
     if v <= 12:
         pt = rand_fr(v)
         assert np.array_equal(lib.fr_dense_evaluate(tab, pt), ob.fr_dense_evaluate(tab, pt))
+    # round-2 prover sites: RAF cubic round sums on a LOW_PAIR session, Lasso bit-split sums, a transcript-driven Stage-1 loop,
+    # DensePolynomial.scale, and the sharded session with a random number of logical shards
+    if v >= 1:
+        s = lib.SumcheckSession.open(tab, lib.SC_LOW_PAIR)
+        start = int(rng.integers(0, 1 << 40))
+        claim = rand_fr(1)[0]
+        bound = np.zeros((0, 4), dtype=np.uint64)
+        cur = tab
+        for k in range(min(v, 4)):
+            from zolt_amd import api
+            base = start % api.R_MOD
+            power = 8
+            for bv in bound:
+                base = (base + api.fr_to_int(bv) * power) % api.R_MOD
+                power *= 2
+            s0, s2 = s.raf_round(api.fr_from_int(base), power)
+            want = ob.raf_round_cubic(cur, start, bound, v, claim)
+            assert np.array_equal(s0, want[0]) and np.array_equal(s2, want[2]), ("raf", v, k)
+            ch = rand_fr(1)[0]
+            s.bind(ch)
+            cur = ob.fr_bind_low(cur, ch)
+            bound = np.concatenate([bound, ch[None, :]])
+        s.close()
+    idx = rng.integers(0, 1 << 63, size=(n, 2), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(n, 2), dtype=np.uint64)
+    bit = int(rng.integers(0, 128))
+    h0, h1 = lib.fr_bit_split_sums(tab, idx, bit)
+    w0, w1 = ob.lasso_address_sums(tab, idx, bit)
+    assert np.array_equal(h0, w0) and np.array_equal(h1, w1), ("bit split", v, bit)
+    from zolt_amd import api
+    rounds = v + int(rng.integers(0, 2))
+    got = api.proveStage1(tab, rounds, api.Transcript(b"Jolt"))
+    wrp, wch, wfin = ob.stage1_prove(tab, rounds, ob.Transcript(b"Jolt"))
+    assert np.array_equal(got["round_polys"], wrp) and np.array_equal(got["challenges"], wch) and np.array_equal(got["final_eval"], wfin), ("stage1", v)
+    sc1 = rand_fr(1)[0]
+    assert np.array_equal(lib.fr_scale(tab, sc1), ob.fr_poly_scale(tab, sc1))
+    os.environ["ZG_SHARDS"] = str(int(rng.integers(1, 9)))
+    layout = int(rng.integers(0, 2))
+    ss = lib.ShardedSumcheckSession.open(tab, layout)
+    cur = tab
+    for k in range(v):
+        g0, g1 = ss.round_sums()
+        w0, w1 = ob.fr_sum_halves(cur) if layout == 0 else ob.fr_sum_even_odd(cur)
+        assert np.array_equal(g0, w0) and np.array_equal(g1, w1), ("sharded session", v, k)
+        ch = rand_fr(1)[0]
+        ss.bind(ch)
+        cur = ob.fr_bind_high(cur, ch) if layout == 0 else ob.fr_bind_low(cur, ch)
+    assert np.array_equal(ss.final(), cur[0])
+    ss.close()
     cases += 1
 print(f"fuzz ok: {cases} random instances (all entry points) in {time.time() - t0:.1f} s")
