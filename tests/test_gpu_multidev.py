@@ -226,3 +226,36 @@ def test_real_devices_rccl_all_gather(env, monkeypatch):
             assert np.array_equal(s.final(), cur[0])
         finally:
             s.close()
+
+
+def test_sharded_entry_points_reject_bad_arguments(env, monkeypatch):
+    """Error behaviour of the several-GPU entry points: same codes and messages as their single-device counterparts
+    (ZG_ERR_INVALID, never a crash, never a silent wrong answer)."""
+    api, lib, ob, gm = env
+    monkeypatch.setenv("ZG_SHARDS", "3")
+    sb = lib.ShardedBases.upload(gm[:100])
+    try:
+        with pytest.raises(lib.ZgError) as e:
+            sb.msm(_rand(ob, 1, 101), 101)  # range exceeds the uploaded bases
+        assert e.value.code == lib.ERR_INVALID and "exceeds" in str(e.value)
+        with pytest.raises(lib.ZgError):
+            sb.msm_batch([_rand(ob, 2, 101)], 101)
+        out, inf = sb.msm_batch([], 0)
+        assert out.shape == (0, 8)
+        z = sb.msm(np.zeros((0, 4), dtype=np.uint64), 0)  # n = 0 -> identity (src/msm/mod.zig:361-363)
+        assert z[1] == 1 and not z[0].any()
+    finally:
+        sb.free()
+    with pytest.raises(lib.ZgError) as e:
+        lib.ShardedSumcheckSession.open(_rand(ob, 3, 12), lib.SC_LOW_PAIR)  # length not a power of two
+    assert e.value.code == lib.ERR_INVALID
+    s = lib.ShardedSumcheckSession.open(_rand(ob, 4, 1), lib.SC_LOW_PAIR)  # a single element: already complete
+    assert len(s) == 1 and s.shards() == 1
+    with pytest.raises(lib.ZgError):
+        s.bind(_rand(ob, 5, 1)[0])
+    assert np.array_equal(s.final(), _rand(ob, 4, 1)[0])
+    s.close()
+    monkeypatch.setenv("ZG_SHARD_EXCHANGE", "rccl")  # RCCL needs exactly one shard per bound device
+    with pytest.raises(lib.ZgError) as e:
+        lib.ShardedBases.upload(gm[:100])
+    assert e.value.code == lib.ERR_INVALID and "one shard per bound device" in str(e.value)
