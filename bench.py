@@ -546,6 +546,13 @@ def extra_measurements(lib, api, torch, dev, stream, args, srs_xy=None):
                     q1, f1 = api.HyperKZG.open(params, ev, pt, np.zeros(4, dtype=np.uint64))
                 res[f"v{vv}_ms"] = (time.perf_counter() - t0) / 3 * 1e3
                 assert np.array_equal(f0, f1) and all(np.array_equal(a[0], b[0]) for a, b in zip(q0, q1))
+                d_ev = torch.from_numpy(ev.view(np.int64)).to(dev)  # the same opening with the table already resident (no upload)
+                lib.hyperkzg_open_dev(params._dev, d_ev.data_ptr(), 1 << vv, pt, np.zeros(4, dtype=np.uint64))
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    q2, qi2, f2 = lib.hyperkzg_open_dev(params._dev, d_ev.data_ptr(), 1 << vv, pt, np.zeros(4, dtype=np.uint64))
+                res[f"v{vv}_resident_ms"] = (time.perf_counter() - t0) / 3 * 1e3
+                assert np.array_equal(f2, f0) and np.array_equal(q2[0], q0[0][0])
             res["note"] = "host table in (pageable H2D included), proof out; parity with the oracle is tests/test_gpu_api_mirror.py"
             extra["hyperkzg_open"] = res
             params.deinit()

@@ -186,6 +186,11 @@ ZG_API int zg_g1_fixed_base_mul_batch(const uint64_t base_xy[8], uint8_t base_in
 ZG_API int zg_hyperkzg_open(zg_bases_t srs, const uint64_t *evals, size_t n_evals, const uint64_t *point, size_t num_vars,
                      const uint64_t value[4], uint64_t *q_xy /* num_vars*8 */, uint8_t *q_inf /* num_vars */,
                      uint64_t final_eval[4]);
+/* same with the evaluation table already resident in HBM (a prover that has just committed the polynomial from device memory):
+ * no 32*n-byte upload; the table is copied on the device (the loop folds in place, the caller's polynomial stays intact) */
+ZG_API int zg_hyperkzg_open_dev(zg_bases_t srs, const uint64_t *d_evals, size_t n_evals, const uint64_t *point, size_t num_vars,
+                         const uint64_t value[4], void *stream, uint64_t *q_xy /* num_vars*8 */, uint8_t *q_inf /* num_vars */,
+                         uint64_t final_eval[4]);
 /* HyperKZG.batchOpen (src/poly/commitment/mod.zig:607-732): k polynomials opened at one point through the random linear
  * combination P = sum_i gamma^i p_i, gamma = fromU64(0x9a8b7c6d) * prod_j (point[j] + 11) (the reference's deterministic
  * stand-in for a transcript challenge, :633-640). Outputs: evaluations[k] = evaluateMultilinear(p_i, point) EXACTLY as the

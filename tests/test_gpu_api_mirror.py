@@ -157,6 +157,23 @@ def test_hyperkzg_open_at_the_bench_size(env):
     params.deinit()
 
 
+def test_hyperkzg_open_resident_table(env):
+    """zg_hyperkzg_open_dev: same proof as the host-table entry point, and the caller's device table is left intact."""
+    api, lib, ob = env
+    v = 15
+    gm = ob.g1_gen_multiples(1 << v)
+    params = api.HyperKZG.SetupParams(gm, np.zeros(1 << v, dtype=np.uint8))
+    ev = _rand(ob, 840, 1 << v)
+    pt = _rand(ob, 841, v)
+    d_ev = lib.DeviceBuffer.from_host(ev)
+    q, qi, fin = lib.hyperkzg_open_dev(params._dev, d_ev.ptr, 1 << v, pt, np.zeros(4, dtype=np.uint64))
+    wq, wqi, wfin = ob.hyperkzg_open(gm, np.zeros(1 << v, dtype=np.uint8), ev, pt, np.zeros(4, dtype=np.uint64))
+    assert np.array_equal(fin, wfin) and np.array_equal(qi, wqi) and np.array_equal(q, wq)
+    assert np.array_equal(d_ev.to_host().reshape(-1, 4), ev)
+    d_ev.free()
+    params.deinit()
+
+
 def test_hyperkzg_batch_open_2_16(env):
     """batchOpen of three 2^16-entry polynomials (one shorter) on a 2^16-point SRS against the oracle."""
     api, lib, ob = env

@@ -1136,6 +1136,29 @@ __global__ void hk_combined_eval_kernel(const uint64_t *evals, const uint64_t *g
     fe_store(out, acc);
 }
 
+int zg_hyperkzg_open_dev(zg_bases_t srs, const uint64_t *d_evals, size_t n_evals, const uint64_t *point, size_t num_vars,
+                         const uint64_t value[4], void *stream, uint64_t *q_xy, uint8_t *q_inf, uint64_t final_eval[4]) {
+    ZG_INIT();
+    if (!srs || !final_eval || (num_vars && (!point || !q_xy)) || (n_evals && !d_evals) || (num_vars == 0 && !value)) {
+        set_error("zg_hyperkzg_open_dev: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    if (num_vars == 0) {  // :270-276
+        for (int i = 0; i < 4; i++) final_eval[i] = value[i];
+        return ZG_OK;
+    }
+    DeviceGuard dg(bases_device(srs));
+    hipStream_t st = pick_stream(stream);
+    size_t cap = n_evals ? n_evals : 1;
+    Scratch s_a(cap * 32), s_b((cap / 2 + 1) * 32), s_q((cap / 2 + 1) * 32);
+    if (!s_a.p || !s_b.p || !s_q.p) return ZG_ERR_NOMEM;
+    SyncGuard sync(st);
+    // the loop folds its table in place: work on a copy, the caller's polynomial stays intact (open() takes evals by const slice)
+    if (n_evals) ZG_HIP(hipMemcpyAsync(s_a.p, d_evals, n_evals * 32, hipMemcpyDeviceToDevice, st));
+    return hk_open_device(srs, s_a.as<uint64_t>(), s_b.as<uint64_t>(), s_q.as<uint64_t>(), n_evals, point, num_vars, st, q_xy, q_inf,
+                          final_eval, nullptr);
+}
+
 int zg_fr_scale(const uint64_t *a, size_t n, const uint64_t sc[4], uint64_t *out) {
     ZG_INIT();
     if (n && (!a || !sc || !out)) {

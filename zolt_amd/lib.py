@@ -35,7 +35,7 @@ SYMBOLS = [
     "zg_g1_bases_upload", "zg_g1_bases_upload_dev", "zg_g1_bases_free", "zg_g1_bases_len", "zg_g1_bases_plan",
     "zg_msm_g1", "zg_msm_g1_dev", "zg_msm_g1_dev_async", "zg_msm_g1_batch", "zg_msm_g1_batch_dev", "zg_msm_g1_partial_dev", "zg_msm_g1_partial_fast_dev",
     "zg_g1_combine_partials_dev", "zg_g1_combine_partials_dev_async", "zg_g1_is_on_curve_batch", "zg_g1_scalar_mul_batch", "zg_g1_fixed_base_mul_batch",
-    "zg_hyperkzg_open", "zg_hyperkzg_batch_open",
+    "zg_hyperkzg_open", "zg_hyperkzg_open_dev", "zg_hyperkzg_batch_open",
     "zg_fr_dense_evaluate", "zg_fr_eq_table", "zg_fr_eq_table_dev", "zg_fr_bind_low", "zg_fr_bind_high",
     "zg_fr_spartan_combine", "zg_fr_spartan_combine_dev",
     "zg_sumcheck_open", "zg_sumcheck_open_dev", "zg_sumcheck_round_sums", "zg_sumcheck_bind",
@@ -418,6 +418,18 @@ def hyperkzg_open(bases, evals, point, value):
     fin = np.zeros(4, dtype=np.uint64)
     _chk(_lib.zg_hyperkzg_open(bases._h, _h(evals), C.c_size_t(evals.size // 4), _h(point), C.c_size_t(v), _h(value), _h(q),
                                _hb(qinf), _h(fin)), "zg_hyperkzg_open")
+    return q, qinf, fin
+
+
+def hyperkzg_open_dev(bases, d_evals, n_evals, point, value, stream=0):
+    """HyperKZG.open with the table resident in HBM -> (quotient commitments (v,8), inf flags (v,), final_eval)."""
+    point, value = _c(point), _c(value)
+    v = point.size // 4
+    q = np.zeros((v, 8), dtype=np.uint64)
+    qinf = np.zeros(v, dtype=np.uint8)
+    fin = np.zeros(4, dtype=np.uint64)
+    _chk(_lib.zg_hyperkzg_open_dev(bases._h, _d(d_evals), C.c_size_t(n_evals), _h(point), C.c_size_t(v), _h(value), _d(stream), _h(q),
+                                   _hb(qinf), _h(fin)), "zg_hyperkzg_open_dev")
     return q, qinf, fin
 
 
