@@ -25,25 +25,23 @@ pub const Error = error{ GpuFailure, OutOfMemory, SumcheckVerificationFailed };
 const FR_ONE = [4]u64{ 0xac96341c4ffffffb, 0x36fc76959f60cd29, 0x666ea36f7879462e, 0x0e0a77c19a07df2f };
 const FP_ONE = [4]u64{ 0xd35d438dc58f0d9d, 0x0a78eb28f5c70b3d, 0x666ea36f7879462c, 0x0e0a77c19a07df2f };
 
-/// comptime: is (F, G) = (BN254 scalar field, BN254 base field), both 4x64-bit Montgomery? Anything else must not reach the GPU.
+/// Is (F, G) = (BN254 scalar field, BN254 base field), both 4x64-bit Montgomery? Anything else must not reach the GPU. Every
+/// input is a comptime type, so a call site writes `if (comptime gpu.isBn254Pair(F, G))` and the other branch is never analysed
+/// (the usual `if (comptime cond) return ...;` idiom: statements behind a comptime-known return are dead code).
 pub fn isBn254Pair(comptime F: type, comptime G: type) bool {
-    comptime {
-        if (@sizeOf(F) != 32 or @sizeOf(G) != 32) return false;
-        if (!@hasDecl(F, "one") or !@hasDecl(G, "one")) return false;
-        if (!@hasField(F, "limbs") or !@hasField(G, "limbs")) return false;
-        const f1 = F.one();
-        const g1 = G.one();
-        return std.mem.eql(u64, &f1.limbs, &FR_ONE) and std.mem.eql(u64, &g1.limbs, &FP_ONE);
-    }
+    if (@sizeOf(F) != 32 or @sizeOf(G) != 32) return false;
+    if (!@hasDecl(F, "one") or !@hasDecl(G, "one")) return false;
+    if (!@hasField(F, "limbs") or !@hasField(G, "limbs")) return false;
+    const f1 = F.one();
+    const g1 = G.one();
+    return std.mem.eql(u64, &f1.limbs, &FR_ONE) and std.mem.eql(u64, &g1.limbs, &FP_ONE);
 }
 
-/// comptime: is F the BN254 scalar field (poly / sumcheck kernels are Fr only)
+/// Is F the BN254 scalar field (the poly / sumcheck kernels are Fr only)?
 pub fn isBn254Scalar(comptime F: type) bool {
-    comptime {
-        if (@sizeOf(F) != 32 or !@hasDecl(F, "one") or !@hasField(F, "limbs")) return false;
-        const f1 = F.one();
-        return std.mem.eql(u64, &f1.limbs, &FR_ONE);
-    }
+    if (@sizeOf(F) != 32 or !@hasDecl(F, "one") or !@hasField(F, "limbs")) return false;
+    const f1 = F.one();
+    return std.mem.eql(u64, &f1.limbs, &FR_ONE);
 }
 
 var init_once = std.once(initDevice);
