@@ -311,6 +311,9 @@ def test_all_commitments_of_the_reference_proof_header(zl, ob, golden_dir):
         assert hdr["register.commitment"] == proof[488:552] and hdr["register.commitment"] != bytes(64)
         one = api.HyperKZG.commit(params, polys[2])
         assert api.commitment_to_bytes(*one) == proof[488:552]
+        # the proof header a `zolt prove` run would write from these commitments: byte-identical to the captured file's first 744 bytes
+        header = api.serialize_zolt_proof_header({"bytecode.commitment": got[0], "memory.commitment": got[1], "register.commitment": got[2]})
+        assert len(header) == 744 and header == proof[:744]
     finally:
         params.deinit()
 

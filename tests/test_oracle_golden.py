@@ -53,6 +53,26 @@ def test_register_commitment_matches_reference_proof(golden_dir):
     assert pm.commitment_bytes(r) == proof[488:552]
 
 
+def test_proof_header_bytes_match_reference_proof(golden_dir):
+    """The first 744 bytes of the reference's captured proof (ZOLT v1 header: magic, version, the bytecode / memory / register
+    proofs' twelve commitment slots and the legacy field element, src/zkvm/serialization.zig:283-306) re-serialised by the host
+    mirror from commitments computed by the oracle: byte-identical."""
+    from zolt_amd import api
+    elf = open(os.path.join(golden_dir, "fibonacci.elf"), "rb").read()
+    proof = open(os.path.join(golden_dir, "zolt_proof_regular.bin"), "rb").read()
+    srs, inf = ob.hyperkzg_setup(256)
+    bc = np.zeros(128, dtype=np.uint64)
+    bc[:104] = np.frombuffer(elf[0x1000:0x1000 + 104], dtype=np.uint8)
+    reg = np.zeros(256, dtype=np.uint64)
+    reg[:54] = np.array(U.fibonacci_rd_values(elf), dtype=np.uint64)
+    hdr = api.serialize_zolt_proof_header({
+        "bytecode.commitment": ob.hyperkzg_commit(srs, inf, ob.f_from_u64(FR, bc)),
+        "memory.commitment": ob.hyperkzg_commit(srs, inf, np.zeros((0, 4), dtype=np.uint64)),
+        "register.commitment": ob.hyperkzg_commit(srs, inf, ob.f_from_u64(FR, reg))})
+    assert hdr == proof[:744]
+    assert api.parse_zolt_proof_commitments(hdr + bytes(64))["register.commitment"] == proof[488:552]
+
+
 def test_field_constants_and_kats():
     """src/field/mod.zig:16-75 constants; KATs :1101-1140 (3*7=21, 7*7^-1=1, 2^3=8)."""
     for f, mod in ((FR, pm.R_MOD), (FP, pm.P_MOD)):

@@ -329,6 +329,25 @@ def parse_zolt_proof_commitments(data):
     return out
 
 
+def serialize_zolt_proof_header(commitments):
+    """The part of serializeProof (src/zkvm/serialization.zig:283-306) this backend produces: "ZOLT" | u32 version 1 | bytecode
+    proof {commitment, read_ts, write_ts, 32-byte legacy field element} | memory proof {commitment, final_state, read_ts, write_ts}
+    | register proof {same four}. `commitments`: {name: (xy, inf)} with the names of parse_zolt_proof_commitments; missing names are
+    the identity (64 zero bytes, PolyCommitment.zero()) — what commitBytecode / commitMemory / commitRegisters leave in the
+    timestamp and final-state slots (src/zkvm/mod.zig:1540-1546,1574-1581,1609-1616). Returns the first 744 bytes of the proof."""
+    def enc(name):
+        c = commitments.get(name)
+        return bytes(64) if c is None else commitment_to_bytes(c[0], c[1])
+    out = b"ZOLT" + (1).to_bytes(4, "little")
+    for name in ("bytecode.commitment", "bytecode.read_ts_commitment", "bytecode.write_ts_commitment"):
+        out += enc(name)
+    out += bytes(32)  # bytecode._legacy_commitment = F.zero()
+    for group in ("memory", "register"):
+        for name in ("commitment", "final_state_commitment", "read_ts_commitment", "write_ts_commitment"):
+            out += enc(f"{group}.{name}")
+    return out
+
+
 # ---- SRS wire format (G1 section)
 class SRSError(Exception):
     pass
