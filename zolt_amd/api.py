@@ -843,6 +843,15 @@ class Transcript:
         self.appendBytes(label)
         return np.stack([self.challengeScalar(b"") for _ in range(count)]) if count else np.zeros((0, 4), dtype=np.uint64)
 
+    def challengeBytes(self, label, n):
+        """challengeBytes (:143-160): one Keccak-f per 136 output bytes, each block read from the start of the state"""
+        self.appendBytes(label)
+        out = b""
+        while len(out) < n:
+            self._keccakF()
+            out += bytes(self.state[:min(n - len(out), self.KECCAK_RATE)])
+        return out
+
 
 def _fr_add(a, b):
     return _limbs((_int(a) + _int(b)) % R_MOD)
