@@ -208,6 +208,12 @@ ZG_API int zg_hyperkzg_batch_open(zg_bases_t srs, const uint64_t *const *polys, 
  * (src/poly/split_eq.zig:122-171). */
 ZG_API int zg_fr_eq_table(const uint64_t *r, size_t v, const uint64_t *scale, uint64_t *out);
 ZG_API int zg_fr_eq_table_dev(const uint64_t *r_host, size_t v, const uint64_t *scale_host, uint64_t *d_out, void *stream);
+/* GruenSplitEqPolynomial.initWithScaling's prefix-table set in one launch (src/poly/split_eq.zig:122-171: E_out_vec / E_in_vec,
+ * "append the new variable as LSB" and KEEP every level): out holds the v+1 tables eq(tau[0..k), .), k = 0..v, back to back —
+ * table k has 2^k entries and starts at element 2^k - 1 (so out has 2^(v+1) - 1 elements; table 0 is [1]); within a table
+ * tau[0] <-> MSB of the index. The caller passes tau[0..m) for E_out_vec and tau[m..n-1) for E_in_vec (:91-93). v <= 24. */
+ZG_API int zg_fr_eq_prefix_tables(const uint64_t *tau, size_t v, uint64_t *out /* (2^(v+1)-1)*4 */);
+ZG_API int zg_fr_eq_prefix_tables_dev(const uint64_t *tau_host, size_t v, uint64_t *d_out, void *stream);
 /* DensePolynomial.evaluate (src/poly/mod.zig:73-92): sum_i evals[i] * prod_j (bit_j(i) ? point[j] : 1 - point[j]),
  * index bit j <-> point[j] (LSB first). The reference expands every term (O(n*v) multiplications); here the
  * weights are one eq table (point reversed) and the sum is a device dot product — same field value. */

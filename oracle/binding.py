@@ -293,6 +293,82 @@ def fr_eq_table_append_lsb(tau):
     return out
 
 
+def fr_eq_prefix_tables(tau):
+    """list of the v+1 prefix tables eq(tau[0..k), .) — GruenSplitEqPolynomial E_out_vec / E_in_vec (split_eq.zig:122-171)"""
+    tau = _c(np.asarray(tau, dtype=np.uint64).reshape(-1, 4))
+    v = tau.shape[0]
+    out = np.empty(((2 << v) - 1, 4), dtype=np.uint64)
+    lib.zo_fr_eq_prefix_tables(_p(tau), C.c_size_t(v), _p(out))
+    return [out[(1 << k) - 1:(2 << k) - 1].copy() for k in range(v + 1)]
+
+
+class GruenSplitEq:
+    """CPU restatement of GruenSplitEqPolynomial's state machine (src/poly/split_eq.zig:63-514); field arithmetic in the C oracle."""
+
+    def __init__(self, tau, scaling_factor=None):
+        self.tau = _c(np.asarray(tau, dtype=np.uint64).reshape(-1, 4)).copy()
+        n = self.tau.shape[0]
+        self.current_index = n
+        self.current_scalar = f_from_u64(FR, np.array([1], dtype=np.uint64))[0] if scaling_factor is None else _c(scaling_factor).copy()
+        m = n // 2
+        self.num_x_out = m if n else 0
+        self.num_x_in = (n - 1 - m) if n > 1 else 0
+        if n == 0:  # :75-86: no tables at all
+            self.E_out_vec, self.E_in_vec = [], []
+        else:
+            self.E_out_vec = fr_eq_prefix_tables(self.tau[:m])
+            self.E_in_vec = fr_eq_prefix_tables(self.tau[m:m + self.num_x_in])
+
+    def bind(self, r):  # :213-248
+        if self.current_index == 0:
+            return
+        out = np.empty(4, dtype=np.uint64)
+        lib.zo_gruen_bind_scalar(_p(_c(self.current_scalar)), _p(_c(self.tau[self.current_index - 1])), _p(_c(r)), _p(out))
+        self.current_scalar = out
+        self.current_index -= 1
+        m = self.tau.shape[0] // 2
+        if m < self.current_index:
+            if len(self.E_in_vec) > 1:
+                self.E_in_vec.pop()
+        elif self.current_index > 0:
+            if len(self.E_out_vec) > 1:
+                self.E_out_vec.pop()
+
+    def getFullEqTable(self):  # :254-285 (same values as the append-LSB build scaled by current_scalar)
+        t = fr_eq_table_append_lsb(self.tau[:self.current_index])
+        return fr_poly_scale(t, self.current_scalar)
+
+    def getTauHigh(self):  # :291-294
+        return self.tau[-1] if self.tau.shape[0] else np.zeros(4, dtype=np.uint64)
+
+    def getWindowEqTables(self, window_size):  # :312-343
+        num_unbound = self.current_index
+        head_len = max(num_unbound - min(window_size, num_unbound), 0)
+        m = self.tau.shape[0] // 2
+        head_out_bits = min(head_len, m)
+        head_in_bits = max(head_len - head_out_bits, 0)
+        e_out = self.E_out_vec[head_out_bits] if head_out_bits < len(self.E_out_vec) else self.E_out_vec[-1]
+        e_in = self.E_in_vec[head_in_bits] if head_in_bits < len(self.E_in_vec) else self.E_in_vec[-1]
+        return e_out, e_in, head_in_bits
+
+    def computeCubicRoundPoly(self, q_constant, q_quadratic_coeff, previous_claim):  # :353-434
+        if self.current_index == 0:
+            out = np.zeros((4, 4), dtype=np.uint64)
+            out[0] = previous_claim
+            return out
+        out = np.empty((4, 4), dtype=np.uint64)
+        lib.zo_gruen_cubic_round_poly(_p(_c(self.current_scalar)), _p(_c(self.tau[self.current_index - 1])), _p(_c(q_constant)),
+                                      _p(_c(q_quadratic_coeff)), _p(_c(previous_claim)), _p(out))
+        return out
+
+    def getEActiveForWindow(self, window_size):  # :466-514
+        one = f_from_u64(FR, np.array([1], dtype=np.uint64))
+        if window_size <= 1 or window_size > self.current_index:
+            return one
+        ws = self.current_index - window_size
+        return fr_eq_table_append_lsb(self.tau[ws:ws + window_size - 1])
+
+
 def fr_bind_low(table, r):
     t = np.array(table, dtype=np.uint64, copy=True)
     n = t.size // 4

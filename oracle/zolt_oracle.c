@@ -781,6 +781,46 @@ EXPORT void zo_fr_eq_table_append_lsb(const uint64_t *tau, size_t v, uint64_t *o
     memcpy(out, a, total * 32);
     free(a); free(b);
 }
+/* GruenSplitEqPolynomial.initWithScaling's table set — src/poly/split_eq.zig:122-171: E_vec[0] = [1], E_vec[k+1] built from
+ * E_vec[k] by the append-LSB step above, every level kept. out: the v+1 tables back to back, table k at element 2^k - 1. */
+EXPORT void zo_fr_eq_prefix_tables(const uint64_t *tau, size_t v, uint64_t *out) {
+    fe *o = (fe *)out;
+    o[0] = f_one(&FR);
+    for (size_t k = 0; k < v; k++) {
+        size_t prev_size = (size_t)1 << k;
+        const fe *prev = o + (prev_size - 1);
+        fe *next = o + (2 * prev_size - 1);
+        fe one = f_one(&FR), tk = *(const fe *)(tau + 4 * k), omt = f_sub(&FR, &one, &tk);
+        for (size_t i = 0; i < prev_size; i++) {
+            next[2 * i] = f_mul(&FR, &prev[i], &omt);
+            next[2 * i + 1] = f_mul(&FR, &prev[i], &tk);
+        }
+    }
+}
+/* GruenSplitEqPolynomial.bind's scalar update — :213-219: current_scalar *= tau_i*r + (1-tau_i)*(1-r) */
+EXPORT void zo_gruen_bind_scalar(const uint64_t cur[4], const uint64_t tau_i[4], const uint64_t r[4], uint64_t out[4]) {
+    fe one = f_one(&FR), t = *(const fe *)tau_i, rv = *(const fe *)r;
+    fe a = f_mul(&FR, &t, &rv), omt = f_sub(&FR, &one, &t), omr = f_sub(&FR, &one, &rv), b = f_mul(&FR, &omt, &omr);
+    fe e = f_add(&FR, &a, &b), res = f_mul(&FR, (const fe *)cur, &e);
+    memcpy(out, &res, 32);
+}
+/* GruenSplitEqPolynomial.computeCubicRoundPoly — :353-434 (current_index > 0): l(X) from (current_scalar, tau_curr),
+ * q(1) = (claim - l(0) q(0)) / l(1) (zero when l(1) = 0), q(2), q(3) by the recurrences, s = l*q at 0..3 */
+EXPORT void zo_gruen_cubic_round_poly(const uint64_t current_scalar[4], const uint64_t tau_curr[4], const uint64_t q_constant[4],
+                                      const uint64_t q_quadratic[4], const uint64_t previous_claim[4], uint64_t out[16]) {
+    fe one = f_one(&FR), cs = *(const fe *)current_scalar, tc = *(const fe *)tau_curr;
+    fe c = *(const fe *)q_constant, e = *(const fe *)q_quadratic, claim = *(const fe *)previous_claim;
+    fe omt = f_sub(&FR, &one, &tc), eq0 = f_mul(&FR, &cs, &omt), eq1 = f_mul(&FR, &cs, &tc), slope = f_sub(&FR, &eq1, &eq0);
+    fe two = f_from_u64(&FR, 2), three = f_from_u64(&FR, 3);
+    fe t2 = f_mul(&FR, &slope, &two), t3 = f_mul(&FR, &slope, &three), l2 = f_add(&FR, &eq0, &t2), l3 = f_add(&FR, &eq0, &t3);
+    fe l0q0 = f_mul(&FR, &eq0, &c), q1 = f_zero(), inv;
+    if (f_inv(&FR, &eq1, &inv)) { fe d = f_sub(&FR, &claim, &l0q0); q1 = f_mul(&FR, &d, &inv); }
+    fe e2 = f_add(&FR, &e, &e);
+    fe q2 = f_add(&FR, &q1, &q1); q2 = f_sub(&FR, &q2, &c); q2 = f_add(&FR, &q2, &e2);
+    fe q3 = f_add(&FR, &q2, &q1); q3 = f_sub(&FR, &q3, &c); q3 = f_add(&FR, &q3, &e2); q3 = f_add(&FR, &q3, &e2);
+    fe s[4] = {l0q0, f_mul(&FR, &eq1, &q1), f_mul(&FR, &l2, &q2), f_mul(&FR, &l3, &q3)};
+    memcpy(out, s, 128);
+}
 /* DensePolynomial.bindLow (in place) — src/poly/mod.zig:160-175 */
 EXPORT void zo_fr_bind_low(uint64_t *table, size_t len, const uint64_t r[4]) {
     fe *t = (fe *)table; const fe *rv = (const fe *)r;

@@ -239,6 +239,43 @@ TEST(keccak_transcript_kat) {
     EXPECT(c2.eql(want2));
 }
 
+// src/poly/split_eq.zig:525-733 — the reference's six GruenSplitEqPolynomial tests, restated
+TEST(gruen_split_eq_polynomial) {
+    auto F = [](uint64_t v) { return Fr::fromU64(v); };
+    {  // "initialization" (:525-553) and "prefix tables correctness" (:578-611)
+        GruenSplitEqPolynomial p({F(2), F(3), F(5)});
+        EXPECT(p.current_index == 3 && p.current_scalar.eql(Fr::one()));
+        EXPECT(p.num_x_in == 1 && p.num_x_out == 1 && p.E_in_vec.size() == 2 && p.E_out_vec.size() == 2);
+        EXPECT(p.E_out_vec[1].size() == 2 && p.E_out_vec[1][0].eql(Fr::one().sub(F(2))) && p.E_out_vec[1][1].eql(F(2)));
+        EXPECT(p.E_in_vec[1].size() == 2 && p.E_in_vec[1][0].eql(Fr::one().sub(F(3))) && p.E_in_vec[1][1].eql(F(3)));
+        EXPECT(p.E_out_vec[0].size() == 1 && p.E_out_vec[0][0].eql(Fr::one()));
+    }
+    {  // "bind updates scalar" (:555-576): eq(3, 5) = 15 + (-2)(-4) = 23
+        GruenSplitEqPolynomial p({F(2), F(3)});
+        p.bind(F(5));
+        EXPECT(p.current_index == 1 && p.current_scalar.eql(F(23)));
+    }
+    {  // "cubic round poly basic" (:613-633)
+        GruenSplitEqPolynomial p({F(1), F(2)});
+        auto rp = p.computeCubicRoundPoly(F(10), F(3), F(100));
+        EXPECT(rp[0].add(rp[1]).eql(F(100)));
+    }
+    {  // "big-endian eq table correctness" (:635-681) and "getEActiveForWindow" (:683-733)
+        GruenSplitEqPolynomial p({F(3), F(5), F(7), F(11)});
+        auto t = p.getFullEqTable();
+        Fr o = Fr::one(), m3 = o.sub(F(3)), m5 = o.sub(F(5)), m7 = o.sub(F(7)), m11 = o.sub(F(11));
+        EXPECT(t.size() == 16);
+        EXPECT(t[0].eql(m3.mul(m5).mul(m7).mul(m11)) && t[15].eql(F(3 * 5 * 7 * 11)));
+        EXPECT(t[5].eql(m3.mul(F(5)).mul(m7).mul(F(11))) && t[10].eql(F(3).mul(m5).mul(F(7)).mul(m11)));
+        auto a1 = p.getEActiveForWindow(1), a2 = p.getEActiveForWindow(2), a3 = p.getEActiveForWindow(3);
+        EXPECT(a1.size() == 1 && a1[0].eql(o));
+        EXPECT(a2.size() == 2 && a2[0].eql(m7) && a2[1].eql(F(7)));
+        EXPECT(a3.size() == 4 && a3[0].eql(m5.mul(m7)) && a3[1].eql(m5.mul(F(7))) && a3[2].eql(F(5).mul(m7)) && a3[3].eql(F(35)));
+        auto w = p.getWindowEqTables(0, 1);  // head_len 3, m 2: E_out over 2 bits, E_in over 1
+        EXPECT(w.E_out->size() == 4 && w.E_in->size() == 2 && w.head_in_bits == 1);
+    }
+}
+
 int main() {
     if (zg_init(0) != ZG_OK) { std::printf("zg_init failed: %s\n", zg_last_error()); return 2; }
     for (auto &t : tests()) {

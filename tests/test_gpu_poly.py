@@ -65,6 +65,79 @@ def test_eq_table_matches_reference_log(zl, ob):
         assert np.array_equal(t, ob.fr_eq_table(tau[sl]))
 
 
+@pytest.mark.parametrize("v", [0, 1, 2, 5, 8, 9, 12, 15])
+def test_eq_prefix_tables_vs_oracle(zl, ob, v):
+    """zg_fr_eq_prefix_tables[_dev]: GruenSplitEqPolynomial's E_vec (src/poly/split_eq.zig:122-171), every level, one launch"""
+    tau = _rand(ob, 900 + v, v)
+    got, want = zl.fr_eq_prefix_tables(tau), ob.fr_eq_prefix_tables(tau)
+    assert len(got) == len(want) == v + 1
+    for k in range(v + 1):
+        assert got[k].shape == (1 << k, 4) and np.array_equal(got[k], want[k]), k
+    buf = zl.DeviceBuffer(((2 << v) - 1) * 32)
+    zl.fr_eq_prefix_tables_dev(tau, buf.ptr)
+    flat = buf.to_host(np.uint64).reshape(-1, 4)
+    assert np.array_equal(flat, np.concatenate(want))
+    buf.free()
+
+
+def test_gruen_split_eq_mirror_reference_inline_tests(zl, ob):
+    """src/poly/split_eq.zig:525-733 restated against zolt_amd.api.GruenSplitEqPolynomial (tables from the device)."""
+    from zolt_amd import api
+    F = api.fr_from_int
+    P = api.R_MOD
+    p = api.GruenSplitEqPolynomial.init(np.stack([F(2), F(3), F(5)]))
+    assert p.current_index == 3 and np.array_equal(p.current_scalar, F(1))
+    assert (p.num_x_in, p.num_x_out, len(p.E_in_vec), len(p.E_out_vec)) == (1, 1, 2, 2)
+    assert np.array_equal(p.E_out_vec[1], np.stack([F(P - 1), F(2)])) and np.array_equal(p.E_in_vec[1], np.stack([F(P - 2), F(3)]))
+    p = api.GruenSplitEqPolynomial.init(np.stack([F(2), F(3)]))
+    p.bind(F(5))
+    assert p.current_index == 1 and np.array_equal(p.current_scalar, F(23))
+    p = api.GruenSplitEqPolynomial.init(np.stack([F(1), F(2)]))
+    rp = p.computeCubicRoundPoly(F(10), F(3), F(100))
+    assert (api.fr_to_int(rp[0]) + api.fr_to_int(rp[1])) % P == 100
+    p = api.GruenSplitEqPolynomial.init(np.stack([F(3), F(5), F(7), F(11)]))
+    t = [api.fr_to_int(x) for x in p.getFullEqTable()]
+    assert len(t) == 16 and t[0] == (-2 * -4 * -6 * -10) % P and t[15] == 3 * 5 * 7 * 11
+    assert t[5] == (-2 * 5 * -6 * 11) % P and t[10] == (3 * -4 * 7 * -10) % P
+    assert [api.fr_to_int(x) for x in p.getEActiveForWindow(1)] == [1]
+    assert [api.fr_to_int(x) for x in p.getEActiveForWindow(2)] == [(-6) % P, 7]
+    assert [api.fr_to_int(x) for x in p.getEActiveForWindow(3)] == [24, (-28) % P, (-30) % P, 35]
+    assert [api.fr_to_int(x) for x in p.getEActiveForWindow(5)] == [1]  # wider than the unbound variables (:476-481)
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 7, 8, 13, 24])
+def test_gruen_split_eq_mirror_vs_oracle_through_all_rounds(zl, ob, n):
+    """The mirror against the oracle's restatement of the struct across a whole LowToHigh binding: tables, window views,
+    scalar, cubic round polynomial, active-window and full tables at every round; n = 8 is the captured run's shape (fixture)."""
+    from zolt_amd import api
+    if n == 8:
+        d = json.load(open(os.path.join(U.GOLDEN, "stage4_gruen_eq.json")))
+        tau = np.array([[int(x) for x in row] for row in d["r_cycle_be_mont_limbs"]], dtype=np.uint64)
+    else:
+        tau = _rand(ob, 950 + n, n)
+    scale = _rand(ob, 980 + n, 1)[0] if n % 2 else None
+    g, w = api.GruenSplitEqPolynomial(tau, scale), ob.GruenSplitEq(tau, scale)
+    rs = _rand(ob, 990 + n, 3 * n + 3)
+    for rnd in range(n + 1):
+        assert g.current_index == w.current_index and np.array_equal(g.current_scalar, w.current_scalar)
+        assert len(g.E_out_vec) == len(w.E_out_vec) and len(g.E_in_vec) == len(w.E_in_vec)
+        for a, b in zip(g.E_out_vec + g.E_in_vec, w.E_out_vec + w.E_in_vec):
+            assert np.array_equal(a, b)
+        if n:
+            for ws in (1, 2, 3):
+                eo, ei, hib = g.getWindowEqTables(0, ws)
+                weo, wei, whib = w.getWindowEqTables(ws)
+                assert hib == whib and np.array_equal(eo, weo) and np.array_equal(ei, wei)
+                assert np.array_equal(g.getEActiveForWindow(ws), w.getEActiveForWindow(ws))
+        q0, q2, claim = rs[3 * rnd], rs[3 * rnd + 1], rs[3 * rnd + 2]
+        assert np.array_equal(g.computeCubicRoundPoly(q0, q2, claim), w.computeCubicRoundPoly(q0, q2, claim))
+        if g.current_index <= 16:
+            assert np.array_equal(g.getFullEqTable(), w.getFullEqTable())
+        assert np.array_equal(g.getTauHigh(), w.getTauHigh())
+        g.bind(rs[rnd])
+        w.bind(rs[rnd])
+
+
 def test_bind_kats_and_golden(zl, ob):
     """src/poly/mod.zig:816-888 and tests/golden folds."""
     got = zl.fr_bind_low(U.fr([1, 2, 3, 4]), U.fr([3])[0])

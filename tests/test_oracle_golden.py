@@ -319,3 +319,55 @@ def test_gruen_split_eq_tables_match_reference_log(golden_dir):
         tp = pm.eq_table(r_int)
         assert len(tp) == ln
         assert [int(v).to_bytes(32, "little").hex() for v in tp[:4]] == want, name
+
+
+def test_gruen_split_eq_state_machine_reference_inline_tests(golden_dir):
+    """src/poly/split_eq.zig:525-733 — the reference's six GruenSplitEqPolynomial tests restated against the oracle's
+    restatement of the struct (oracle.binding.GruenSplitEq), plus the prefix tables of the captured run (fixture)."""
+    F = lambda v: ob.f_from_u64(FR, np.array([v], dtype=np.uint64))[0]
+    one = F(1)
+    sub = lambda a, b: ob.f_sub(FR, a[None, :], b[None, :])[0]
+    mul = lambda a, b: ob.f_mul(FR, a[None, :], b[None, :])[0]
+    add = lambda a, b: ob.f_add(FR, a[None, :], b[None, :])[0]
+    tau = np.stack([F(2), F(3), F(5)])
+    p = ob.GruenSplitEq(tau)
+    assert p.current_index == 3 and np.array_equal(p.current_scalar, one)
+    assert (p.num_x_in, p.num_x_out, len(p.E_in_vec), len(p.E_out_vec)) == (1, 1, 2, 2)
+    assert np.array_equal(p.E_out_vec[1], np.stack([sub(one, F(2)), F(2)]))
+    assert np.array_equal(p.E_in_vec[1], np.stack([sub(one, F(3)), F(3)]))
+    p = ob.GruenSplitEq(np.stack([F(2), F(3)]))
+    p.bind(F(5))
+    assert p.current_index == 1 and np.array_equal(p.current_scalar, F(23))
+    p = ob.GruenSplitEq(np.stack([F(1), F(2)]))
+    rp = p.computeCubicRoundPoly(F(10), F(3), F(100))
+    assert np.array_equal(add(rp[0], rp[1]), F(100))
+    p = ob.GruenSplitEq(np.stack([F(3), F(5), F(7), F(11)]))
+    t = p.getFullEqTable()
+    m3, m5, m7, m11 = (sub(one, F(v)) for v in (3, 5, 7, 11))
+    assert len(t) == 16
+    assert np.array_equal(t[0], mul(mul(m3, m5), mul(m7, m11))) and np.array_equal(t[15], F(3 * 5 * 7 * 11))
+    assert np.array_equal(t[5], mul(mul(m3, F(5)), mul(m7, F(11)))) and np.array_equal(t[10], mul(mul(F(3), m5), mul(F(7), m11)))
+    assert np.array_equal(p.getEActiveForWindow(1), one[None, :])
+    assert np.array_equal(p.getEActiveForWindow(2), np.stack([m7, F(7)]))
+    assert np.array_equal(p.getEActiveForWindow(3), np.stack([mul(m5, m7), mul(m5, F(7)), mul(F(5), m7), F(35)]))
+    # every prefix table is the eq table of the prefix (A17 build), and the captured run's E_out / E_in are the last ones
+    d, tau = _gruen_fixture(golden_dir)
+    n, m = d["n"], d["m"]
+    g = ob.GruenSplitEq(tau)
+    assert len(g.E_out_vec) == m + 1 and len(g.E_in_vec) == n - 1 - m + 1
+    for k, tab in enumerate(g.E_out_vec):
+        assert np.array_equal(tab, ob.fr_eq_table(tau[:k]))
+    for k, tab in enumerate(g.E_in_vec):
+        assert np.array_equal(tab, ob.fr_eq_table(tau[m:m + k]))
+    for name, tab in (("E_out", g.E_out_vec[-1]), ("E_in", g.E_in_vec[-1])):
+        tc = ob.f_from_mont(FR, tab)
+        assert len(tab) == d[name + "_len"] and [tc[i].tobytes().hex() for i in range(4)] == d[name + "_first4_canonical_le_hex"]
+    # bind pops E_in first, then E_out, never table 0 (:213-248); the window tables shrink with it (:312-343)
+    sizes = []
+    for r in range(n):
+        e_out, e_in, hib = g.getWindowEqTables(1)
+        sizes.append((len(e_out), len(e_in), hib))
+        assert len(e_out).bit_length() - 1 + len(e_in).bit_length() - 1 + 1 == g.current_index
+        g.bind(F(1000 + r))
+    assert sizes[0] == (1 << m, 1 << (n - 1 - m), n - 1 - m) and sizes[-1] == (1, 1, 0)
+    assert len(g.E_out_vec) == 1 and len(g.E_in_vec) == 1 and g.current_index == 0

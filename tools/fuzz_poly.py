@@ -59,6 +59,9 @@ while time.time() - t0 < budget:
     scale = rand_fr(1)[0] if rng.random() < 0.5 else None
     eq = lib.fr_eq_table(r, scale)
     assert np.array_equal(eq, ob.fr_eq_table(r, scale))
+    if v <= 12:  # GruenSplitEqPolynomial's prefix-table set of the same point
+        for a, b in zip(lib.fr_eq_prefix_tables(r), ob.fr_eq_prefix_tables(r)):
+            assert np.array_equal(a, b), ("prefix tables", v)
     az, bz, cz = rand_fr(n, sparse), rand_fr(n), rand_fr(n, sparse)
     f = lib.fr_spartan_combine(eq, az, bz, cz)
     assert np.array_equal(f, ob.fr_spartan_combine(eq, az, bz, cz))

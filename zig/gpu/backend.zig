@@ -314,6 +314,24 @@ pub fn eqTable(comptime F: type, allocator: std.mem.Allocator, r: []const F, sca
     return result;
 }
 
+/// GruenSplitEqPolynomial.initWithScaling's E_vec for one half of tau (src/poly/split_eq.zig:122-171), all levels from one
+/// launch: appends w.len + 1 tables (table k = eq(w[0..k), .), 2^k entries) to `vec`, each its own allocation so that
+/// bind()'s pop + free (:230-246) and deinit (:185-197) stay as they are.
+pub fn gruenPrefixTables(comptime F: type, allocator: std.mem.Allocator, w: []const F, vec: *std.ArrayListUnmanaged([]F)) !void {
+    const total = (@as(usize, 2) << @intCast(w.len)) - 1;
+    const flat = try allocator.alloc(F, total);
+    defer allocator.free(flat);
+    if (ffi.zg_fr_eq_prefix_tables(limbsOf(F, w), w.len, @ptrCast(flat.ptr)) != ffi.OK) return Error.GpuFailure;
+    var k: usize = 0;
+    while (k <= w.len) : (k += 1) {
+        const size = @as(usize, 1) << @intCast(k);
+        const table = try allocator.alloc(F, size);
+        errdefer allocator.free(table);
+        @memcpy(table, flat[size - 1 .. 2 * size - 1]);
+        try vec.append(allocator, table);
+    }
+}
+
 /// in place; the caller then halves its live length / decrements num_vars as the original does (:160-175)
 pub fn bindLow(comptime F: type, evaluations: []F, value: F) Error!void {
     if (ffi.zg_fr_bind_low(@ptrCast(evaluations.ptr), evaluations.len, &value.limbs) != ffi.OK) return Error.GpuFailure;

@@ -477,6 +477,94 @@ class EqPolynomial:
         return lib.fr_eq_table(np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4), scaling_factor)
 
 
+class GruenSplitEqPolynomial:
+    """GruenSplitEqPolynomial (src/poly/split_eq.zig:22-514). The prefix-table set is built on the device in one launch per
+    half (zg_fr_eq_prefix_tables); bind / computeCubicRoundPoly are the reference's host scalar algebra; getFullEqTable and
+    getEActiveForWindow are eq-table builds on the device."""
+
+    def __init__(self, tau, scaling_factor=None):
+        """init / initWithScaling (:51-183): m = len/2, w_out = tau[0..m), w_in = tau[m..len-1), tau[len-1] stays out of the tables"""
+        self.tau = np.ascontiguousarray(tau, dtype=np.uint64).reshape(-1, 4).copy()
+        n = self.tau.shape[0]
+        self.current_index = n
+        self.current_scalar = fr_from_int(1) if scaling_factor is None else np.ascontiguousarray(scaling_factor, dtype=np.uint64).copy()
+        if n == 0:  # :75-86
+            self.E_out_vec, self.E_in_vec, self.num_x_out, self.num_x_in = [], [], 0, 0
+            return
+        m = n // 2
+        self.num_x_out = m
+        self.num_x_in = min(n - 1 - m, n - 1) if n > 1 else 0
+        self.E_out_vec = list(lib.fr_eq_prefix_tables(self.tau[:m]))
+        self.E_in_vec = list(lib.fr_eq_prefix_tables(self.tau[m:m + self.num_x_in]))
+
+    init = classmethod(lambda cls, tau: cls(tau))
+    initWithScaling = classmethod(lambda cls, tau, scaling_factor: cls(tau, scaling_factor))
+
+    def bind(self, r):
+        """bind (:213-248): current_scalar *= eq(tau[current_index-1], r); pops the largest E_in (then E_out) table, never table 0"""
+        if self.current_index == 0:
+            return
+        t, rv = fr_to_int(self.tau[self.current_index - 1]), fr_to_int(r)
+        eq_val = (t * rv + (1 - t) * (1 - rv)) % R_MOD
+        self.current_scalar = fr_from_int(fr_to_int(self.current_scalar) * eq_val % R_MOD)
+        self.current_index -= 1
+        m = self.tau.shape[0] // 2
+        if m < self.current_index:
+            if len(self.E_in_vec) > 1:
+                self.E_in_vec.pop()
+        elif self.current_index > 0:
+            if len(self.E_out_vec) > 1:
+                self.E_out_vec.pop()
+
+    def getFullEqTable(self):
+        """getFullEqTable (:254-285): eq(tau[0..current_index), .) scaled by current_scalar, tau[0] <-> MSB"""
+        return lib.fr_eq_table(self.tau[:self.current_index], self.current_scalar)
+
+    def getTauHigh(self):
+        """getTauHigh (:291-294)"""
+        return self.tau[-1].copy() if self.tau.shape[0] else fr_from_int(0)
+
+    def getWindowEqTables(self, num_unbound_vars, window_size):
+        """getWindowEqTables (:312-343); the first argument is ignored, as in the reference. -> (E_out, E_in, head_in_bits)"""
+        num_unbound = self.current_index
+        head_len = max(num_unbound - min(window_size, num_unbound), 0)
+        m = self.tau.shape[0] // 2
+        head_out_bits = min(head_len, m)
+        head_in_bits = max(head_len - head_out_bits, 0)
+        e_out = self.E_out_vec[head_out_bits] if head_out_bits < len(self.E_out_vec) else self.E_out_vec[-1]
+        e_in = self.E_in_vec[head_in_bits] if head_in_bits < len(self.E_in_vec) else self.E_in_vec[-1]
+        return e_out, e_in, head_in_bits
+
+    def getCurrentEqFactors(self):
+        """getCurrentEqFactors (:441-452) -> (eq_0, eq_1)"""
+        if self.current_index == 0:
+            return self.current_scalar.copy(), self.current_scalar.copy()
+        cs, t = fr_to_int(self.current_scalar), fr_to_int(self.tau[self.current_index - 1])
+        return fr_from_int(cs * (1 - t) % R_MOD), fr_from_int(cs * t % R_MOD)
+
+    def computeCubicRoundPoly(self, q_constant, q_quadratic_coeff, previous_claim):
+        """computeCubicRoundPoly (:353-434): [s(0), s(1), s(2), s(3)] with s = l*q, q(1) recovered from the claim"""
+        claim = fr_to_int(previous_claim)
+        if self.current_index == 0:
+            return np.stack([fr_from_int(claim), fr_from_int(0), fr_from_int(0), fr_from_int(0)])
+        cs, t = fr_to_int(self.current_scalar), fr_to_int(self.tau[self.current_index - 1])
+        c, e = fr_to_int(q_constant), fr_to_int(q_quadratic_coeff)
+        l0, l1 = cs * (1 - t) % R_MOD, cs * t % R_MOD
+        slope = (l1 - l0) % R_MOD
+        l2, l3 = (l0 + 2 * slope) % R_MOD, (l0 + 3 * slope) % R_MOD
+        q1 = 0 if l1 == 0 else (claim - l0 * c) * pow(l1, R_MOD - 2, R_MOD) % R_MOD
+        q2 = (2 * q1 - c + 2 * e) % R_MOD
+        q3 = (q2 + q1 - c + 4 * e) % R_MOD
+        return np.stack([fr_from_int(l0 * c % R_MOD), fr_from_int(l1 * q1 % R_MOD), fr_from_int(l2 * q2 % R_MOD), fr_from_int(l3 * q3 % R_MOD)])
+
+    def getEActiveForWindow(self, window_size):
+        """getEActiveForWindow (:466-514): eq over the window's bits except the current one; [1] for windows of 0/1 or too wide"""
+        if window_size <= 1 or window_size > self.current_index:
+            return fr_from_int(1).reshape(1, 4)
+        ws = self.current_index - window_size
+        return lib.fr_eq_table(self.tau[ws:ws + window_size - 1])
+
+
 class DensePolynomial:
     def __init__(self, evaluations):
         ev = np.ascontiguousarray(evaluations, dtype=np.uint64).reshape(-1, 4)

@@ -68,6 +68,20 @@ __global__ void __launch_bounds__(256) eq_tables_kernel(const uint64_t *r, int v
     }
 }
 
+// GruenSplitEqPolynomial's prefix tables: entry idx of table k = prod_{j<k} (bit_j(idx) ? tau[j] : 1 - tau[j]) at element
+// 2^k - 1 + idx of out. Element p-1 (p = 1 .. 2^(v+1)-1) therefore has k = floor(log2 p), idx = p - 2^k: one launch, four
+// lanes per output as above (the chain is at most ceil(v/4) + 2 products; Montgomery products are exact, so the product
+// order does not change the value the reference's level-by-level build produces).
+__global__ void __launch_bounds__(256) eq_prefix_kernel(const uint64_t *tau, int v, uint64_t *out) {
+    uint32_t q = threadIdx.x & 3;
+    uint64_t p = (uint64_t)blockIdx.x * 64 + (threadIdx.x >> 2) + 1;
+    bool live = p < (2ull << v);
+    uint32_t pp = live ? (uint32_t)p : 1u;
+    int k = 31 - __clz(pp);
+    Fr e = eq_factor_product4(tau, k, pp - (1u << k), q, nullptr);
+    if (live && q == 0) fe_store(out + 4 * (size_t)(p - 1), e);
+}
+
 // out[(h << v_lo) | t] = hi[h] * lo[t]; one 32-byte store per thread and row, 8 KiB contiguous per (block, h): the
 // kernel is an HBM write stream with one mixed-format product (fr_mul29) per element.
 __global__ void __launch_bounds__(256) eq_main_kernel(const uint64_t *lo_tab, int v_lo, const uint64_t *hi, uint32_t n_hi,
@@ -607,6 +621,25 @@ static int eq_table_enqueue(const uint64_t *r_host, size_t v, const uint64_t *sc
     return ZG_OK;
 }
 
+static int eq_prefix_enqueue(const uint64_t *tau_host, size_t v, uint64_t *d_out, hipStream_t st) {
+    if (v > 24) {
+        set_error("zg_fr_eq_prefix_tables: v too large");
+        return ZG_ERR_INVALID;
+    }
+    Scratch s_r((v + 1) * 32);
+    if (!s_r.p) return ZG_ERR_NOMEM;
+    SyncGuard sync(st);
+    uint64_t *d_r = s_r.as<uint64_t>();
+    if (v) ZG_HIP(hipMemcpyAsync(d_r, tau_host, v * 32, hipMemcpyHostToDevice, st));
+    uint64_t total = (2ull << v) - 1;
+    prof_begin(ZG_PROF_EQ_TABLE, st);
+    hipLaunchKernelGGL(eq_prefix_kernel, dim3((uint32_t)div_up(total, (uint64_t)64)), dim3(256), 0, st, d_r, (int)v, d_out);
+    prof_end(ZG_PROF_EQ_TABLE, st);
+    ZG_HIP(hipGetLastError());
+    ZG_HIP(hipStreamSynchronize(st));  // tau_host / the temporary are released on return
+    return ZG_OK;
+}
+
 // factor tables + fused table/sums kernel of zg_sumcheck_open_spartan_dev
 static int eq_spartan_enqueue(const uint64_t *r_host, size_t v, const uint64_t *scale_host, const uint64_t *d_az, const uint64_t *d_bz,
                               const uint64_t *d_cz, int layout, uint64_t *d_out, uint64_t *partials, uint64_t *sums, uint64_t *flag,
@@ -734,6 +767,36 @@ int zg_fr_eq_table(const uint64_t *r, size_t v, const uint64_t *scale, uint64_t 
     if (!s_out.p) return ZG_ERR_NOMEM;
     uint64_t *d_out = s_out.as<uint64_t>();
     int rc = eq_table_enqueue(r, v, scale, d_out, lib_stream());
+    if (rc == ZG_OK) {
+        hipError_t e = hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            set_error(hipGetErrorString(e));
+            rc = ZG_ERR_HIP;
+        }
+    }
+    return rc;
+}
+
+int zg_fr_eq_prefix_tables_dev(const uint64_t *tau_host, size_t v, uint64_t *d_out, void *stream) {
+    ZG_INIT();
+    if (!d_out || (v && !tau_host)) {
+        set_error("zg_fr_eq_prefix_tables_dev: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    return eq_prefix_enqueue(tau_host, v, d_out, pick_stream(stream));
+}
+
+int zg_fr_eq_prefix_tables(const uint64_t *tau, size_t v, uint64_t *out) {
+    ZG_INIT();
+    if (!out || (v && !tau) || v > 24) {
+        set_error("zg_fr_eq_prefix_tables: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    size_t bytes = (((size_t)2 << v) - 1) * 32;
+    Scratch s_out(bytes);
+    if (!s_out.p) return ZG_ERR_NOMEM;
+    uint64_t *d_out = s_out.as<uint64_t>();
+    int rc = eq_prefix_enqueue(tau, v, d_out, lib_stream());
     if (rc == ZG_OK) {
         hipError_t e = hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost);
         if (e != hipSuccess) {

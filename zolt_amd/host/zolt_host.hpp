@@ -12,6 +12,8 @@
 // scalar Fr operations per sumcheck round for the toy verifier (the unchanged `field` module's
 // job above the FFI seam) — implemented below with unsigned __int128 CIOS.
 #pragma once
+#include <algorithm>
+#include <array>
 #include <cstdint>
 #include <cstring>
 #include <memory>
@@ -114,6 +116,17 @@ struct Fr {
             }
         }
         return r;
+    }
+    bool inverse(Fr &out) const {  // :955-983 — Fermat, a^(p-2); false for zero (Zig: null)
+        if (isZero()) return false;
+        uint64_t e[4] = {MOD[0] - 2, MOD[1], MOD[2], MOD[3]};
+        Fr result = one(), base = *this;
+        for (int i = 0; i < 256; i++) {
+            if ((e[i / 64] >> (i % 64)) & 1) result = result.mul(base);
+            base = base.mul(base);
+        }
+        out = result;
+        return true;
     }
     static Fr fromU64(uint64_t n) {  // :617-622
         Fr a{{n, 0, 0, 0}}, r2{{R2[0], R2[1], R2[2], R2[3]}};
@@ -374,6 +387,83 @@ struct EqPolynomial {  // src/poly/mod.zig:190-323
         check(zg_fr_eq_table(reinterpret_cast<const uint64_t *>(r.data()), r.size(), scaling_factor ? scaling_factor->limbs : nullptr,
                              reinterpret_cast<uint64_t *>(out.data())), "zg_fr_eq_table");
         return out;
+    }
+};
+
+// GruenSplitEqPolynomial (src/poly/split_eq.zig:22-514): the prefix-table set comes from the device in one launch per half;
+// bind / computeCubicRoundPoly are the reference's host scalar algebra.
+struct GruenSplitEqPolynomial {
+    size_t current_index = 0;
+    Fr current_scalar = Fr::one();
+    std::vector<Fr> tau;
+    std::vector<std::vector<Fr>> E_out_vec, E_in_vec;
+    size_t num_x_out = 0, num_x_in = 0;
+
+    static std::vector<std::vector<Fr>> prefixTables(const Fr *w, size_t v) {  // :122-171, every level kept
+        std::vector<Fr> flat((size_t(2) << v) - 1);
+        check(zg_fr_eq_prefix_tables(reinterpret_cast<const uint64_t *>(w), v, reinterpret_cast<uint64_t *>(flat.data())), "zg_fr_eq_prefix_tables");
+        std::vector<std::vector<Fr>> tabs(v + 1);
+        for (size_t k = 0; k <= v; k++) tabs[k].assign(flat.begin() + ((size_t(1) << k) - 1), flat.begin() + ((size_t(2) << k) - 1));
+        return tabs;
+    }
+    explicit GruenSplitEqPolynomial(const std::vector<Fr> &t, const Fr *scaling_factor = nullptr) : tau(t) {  // init / initWithScaling :51-183
+        current_index = tau.size();
+        if (scaling_factor) current_scalar = *scaling_factor;
+        if (tau.empty()) return;
+        size_t m = tau.size() / 2;
+        num_x_out = m;
+        num_x_in = tau.size() > 1 ? std::min(tau.size() - 1 - m, tau.size() - 1) : 0;
+        E_out_vec = prefixTables(tau.data(), m);
+        E_in_vec = prefixTables(tau.data() + m, num_x_in);
+    }
+    void bind(const Fr &r) {  // :213-248
+        if (current_index == 0) return;
+        const Fr &tau_i = tau[current_index - 1];
+        Fr eq_val = tau_i.mul(r).add(Fr::one().sub(tau_i).mul(Fr::one().sub(r)));
+        current_scalar = current_scalar.mul(eq_val);
+        current_index -= 1;
+        size_t m = tau.size() / 2;
+        if (m < current_index) {
+            if (E_in_vec.size() > 1) E_in_vec.pop_back();
+        } else if (current_index > 0) {
+            if (E_out_vec.size() > 1) E_out_vec.pop_back();
+        }
+    }
+    std::vector<Fr> getFullEqTable() const {  // :254-285
+        std::vector<Fr> head(tau.begin(), tau.begin() + current_index);
+        return EqPolynomial::evalsSliceWithScaling(head, &current_scalar);
+    }
+    Fr getTauHigh() const { return tau.empty() ? Fr::zero() : tau.back(); }  // :291-294
+    struct Window { const std::vector<Fr> *E_out, *E_in; size_t head_in_bits; };
+    Window getWindowEqTables(size_t /* num_unbound_vars: ignored, as in the reference */, size_t window_size) const {  // :312-343
+        size_t num_unbound = current_index, actual = std::min(window_size, num_unbound), head_len = num_unbound - actual;
+        size_t m = tau.size() / 2, head_out_bits = std::min(head_len, m), head_in_bits = head_len - head_out_bits;
+        const std::vector<Fr> &eo = head_out_bits < E_out_vec.size() ? E_out_vec[head_out_bits] : E_out_vec.back();
+        const std::vector<Fr> &ei = head_in_bits < E_in_vec.size() ? E_in_vec[head_in_bits] : E_in_vec.back();
+        return Window{&eo, &ei, head_in_bits};
+    }
+    std::array<Fr, 2> getCurrentEqFactors() const {  // :441-452
+        if (current_index == 0) return {current_scalar, current_scalar};
+        const Fr &tc = tau[current_index - 1];
+        return {current_scalar.mul(Fr::one().sub(tc)), current_scalar.mul(tc)};
+    }
+    std::array<Fr, 4> computeCubicRoundPoly(const Fr &q_constant, const Fr &q_quadratic_coeff, const Fr &previous_claim) const {  // :353-434
+        if (current_index == 0) return {previous_claim, Fr::zero(), Fr::zero(), Fr::zero()};
+        auto f = getCurrentEqFactors();
+        Fr l_slope = f[1].sub(f[0]);
+        Fr l_2 = f[0].add(l_slope.mul(Fr::fromU64(2))), l_3 = f[0].add(l_slope.mul(Fr::fromU64(3)));
+        Fr l0_q0 = f[0].mul(q_constant), inv, q_1 = Fr::zero();
+        if (f[1].inverse(inv)) q_1 = previous_claim.sub(l0_q0).mul(inv);
+        Fr e2 = q_quadratic_coeff.add(q_quadratic_coeff);
+        Fr q_2 = q_1.add(q_1).sub(q_constant).add(e2);
+        Fr q_3 = q_2.add(q_1).sub(q_constant).add(e2).add(e2);
+        return {l0_q0, f[1].mul(q_1), l_2.mul(q_2), l_3.mul(q_3)};
+    }
+    std::vector<Fr> getEActiveForWindow(size_t window_size) const {  // :466-514
+        if (window_size <= 1 || window_size > current_index) return {Fr::one()};
+        size_t ws = current_index - window_size;
+        std::vector<Fr> w(tau.begin() + ws, tau.begin() + ws + window_size - 1);
+        return EqPolynomial::evalsSliceWithScaling(w, nullptr);
     }
 };
 

@@ -36,7 +36,7 @@ SYMBOLS = [
     "zg_msm_g1", "zg_msm_g1_dev", "zg_msm_g1_dev_async", "zg_msm_g1_batch", "zg_msm_g1_batch_dev", "zg_msm_g1_partial_dev", "zg_msm_g1_partial_fast_dev",
     "zg_g1_combine_partials_dev", "zg_g1_combine_partials_dev_async", "zg_g1_is_on_curve_batch", "zg_g1_scalar_mul_batch", "zg_g1_fixed_base_mul_batch",
     "zg_hyperkzg_open", "zg_hyperkzg_open_dev", "zg_hyperkzg_batch_open",
-    "zg_fr_dense_evaluate", "zg_fr_eq_table", "zg_fr_eq_table_dev", "zg_fr_bind_low", "zg_fr_bind_high",
+    "zg_fr_dense_evaluate", "zg_fr_eq_table", "zg_fr_eq_table_dev", "zg_fr_eq_prefix_tables", "zg_fr_eq_prefix_tables_dev", "zg_fr_bind_low", "zg_fr_bind_high",
     "zg_fr_spartan_combine", "zg_fr_spartan_combine_dev",
     "zg_sumcheck_open", "zg_sumcheck_open_dev", "zg_sumcheck_round_sums", "zg_sumcheck_bind",
     "zg_sumcheck_len", "zg_sumcheck_final", "zg_sumcheck_read", "zg_sumcheck_close",
@@ -463,6 +463,20 @@ def fr_eq_table(r, scale=None):
 def fr_eq_table_dev(r, d_out, scale=None, stream=0):
     r = _c(r)
     _chk(_lib.zg_fr_eq_table_dev(_h(r), C.c_size_t(r.size // 4), _h(_c(scale)), _d(d_out), _d(stream)), "zg_fr_eq_table_dev")
+
+
+def fr_eq_prefix_tables(tau):
+    """GruenSplitEqPolynomial's prefix tables (split_eq.zig:122-171) of tau[0..v): list of v+1 arrays, table k = eq(tau[0..k), .)"""
+    tau = _c(np.asarray(tau, dtype=np.uint64).reshape(-1, 4))
+    v = tau.shape[0]
+    out = np.empty(((2 << v) - 1, 4), dtype=np.uint64)
+    _chk(_lib.zg_fr_eq_prefix_tables(_h(tau), C.c_size_t(v), _h(out)), "zg_fr_eq_prefix_tables")
+    return [out[(1 << k) - 1:(2 << k) - 1] for k in range(v + 1)]
+
+
+def fr_eq_prefix_tables_dev(tau, d_out, stream=0):
+    tau = _c(np.asarray(tau, dtype=np.uint64).reshape(-1, 4))
+    _chk(_lib.zg_fr_eq_prefix_tables_dev(_h(tau), C.c_size_t(tau.shape[0]), _d(d_out), _d(stream)), "zg_fr_eq_prefix_tables_dev")
 
 
 def fr_bind_low(table, r):
