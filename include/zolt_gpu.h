@@ -266,6 +266,15 @@ ZG_API int zg_sumcheck_close(zg_sc_t s);
  * in one pass over the table; s(1) = claim - s(0) and s(3) = s(0) - 3 s(1) + 3 s(2) are host scalar code, the fold of the round
  * (RaPolynomial.bind, :162-174) is zg_sumcheck_bind. */
 ZG_API int zg_sumcheck_raf_round(zg_sc_t s, const uint64_t base[4], uint64_t current_power, uint64_t s0[4], uint64_t s2[4]);
+/* LassoProver's eq_evals path on ONE session (src/zkvm/lasso/prover.zig:262-453): open the session with layout ZG_SC_HIGH_HALF over
+ * the padded eq_evals (:153-171); the log_K address rounds use the two calls below, the log_T cycle rounds are the session's
+ * ordinary round_sums / bind (:313-340,411-441). d_idx128: the u128 lookup indices in DEVICE memory (two little-endian u64 words
+ * each; zg_dev_alloc + zg_memcpy_h2d), n_idx <= the session's length.
+ *   bit_round = computeAddressRoundPoly's sum_0 / sum_1 (:283-293) over the first n_idx entries;
+ *   bit_bind  = receiveChallenge's address branch (:375-399): entry j *= (bit of idx[j]) ? r : 1 - r, claim = sum of ALL entries.
+ * bit_bind also leaves the next round's sums (bit + 1) behind, so the following bit_round costs no pass over the table. */
+ZG_API int zg_sumcheck_bit_round(zg_sc_t s, const uint64_t *d_idx128, size_t n_idx, unsigned bit, uint64_t sum0[4], uint64_t sum1[4]);
+ZG_API int zg_sumcheck_bit_bind(zg_sc_t s, const uint64_t *d_idx128, size_t n_idx, unsigned bit, const uint64_t r[4], uint64_t claim[4]);
 /* LassoProver.computeAddressRoundPoly's two sums (src/zkvm/lasso/prover.zig:283-293): sum0 / sum1 = the sum of vals[j] over the
  * entries whose u128 lookup index (idx128: n x 2 little-endian u64 words) has bit `bit` clear / set. The _dev form keeps eq_evals
  * and the indices resident across the LOG_K address rounds. */

@@ -506,3 +506,89 @@ def lasso_address_sums(eq_evals, idx128, round_bit):
     s0, s1 = np.zeros(4, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
     lib.zo_lasso_address_sums(_p(eq_evals), _p(idx128), C.c_size_t(eq_evals.size // 4), C.c_uint(round_bit), _p(s0), _p(s1))
     return s0, s1
+
+
+class LassoProver:
+    """CPU restatement of LassoProver's eq_evals path (src/zkvm/lasso/prover.zig:113-453): init, computeRoundPolynomial and
+    receiveChallenge in both phases. The prefix-suffix structures the reference also binds do not enter the round polynomials."""
+
+    def __init__(self, lookup_indices_u128, log_T, log_K, r_reduction):
+        self.idx = _c(np.asarray(lookup_indices_u128, dtype=np.uint64).reshape(-1, 2))
+        self.log_T, self.log_K = log_T, log_K
+        w = _c(np.asarray(r_reduction, dtype=np.uint64).reshape(-1, 4))
+        assert w.shape[0] == log_T
+        outer = log_T // 2
+        self.eq_evals = np.zeros((1 << log_T, 4), dtype=np.uint64)
+        self.current_claim = np.zeros(4, dtype=np.uint64)
+        lib.zo_lasso_init_eq_evals(_p(w), C.c_size_t(outer), C.c_size_t(log_T - outer), C.c_size_t(self.idx.shape[0]),
+                                   _p(self.eq_evals), _p(self.current_claim))
+        self.eq_evals_len = 1 << log_T
+        self.round = 0
+        self.challenges = []
+
+    def isAddressPhase(self):
+        return self.round < self.log_K
+
+    def isComplete(self):
+        return self.round >= self.log_K + self.log_T
+
+    def computeRoundPolynomial(self):
+        """-> coeffs [c0, c1, c2] (:262-345)"""
+        zero = np.zeros(4, dtype=np.uint64)
+        if self.isAddressPhase():
+            s0, s1 = lasso_address_sums(self.eq_evals[:self.idx.shape[0]], self.idx, self.round)
+        else:
+            n = self.eq_evals_len
+            if n <= 1:
+                return np.stack([self.eq_evals[0] if n else zero, zero, zero])
+            s0, s1 = fr_sum_halves(self.eq_evals[:n])
+        return np.stack([s0, f_sub(FR, s1[None, :], s0[None, :])[0], zero])
+
+    def receiveChallenge(self, challenge):
+        """:352-453"""
+        challenge = _c(challenge)
+        self.challenges.append(challenge.copy())
+        if self.isAddressPhase():
+            claim = np.zeros(4, dtype=np.uint64)
+            lib.zo_lasso_receive_address(_p(self.eq_evals), C.c_size_t(self.eq_evals.shape[0]), _p(self.idx), C.c_size_t(self.idx.shape[0]),
+                                         C.c_uint(self.round), _p(challenge), _p(claim))
+            self.current_claim = claim
+        else:
+            n = self.eq_evals_len
+            if n > 1:
+                folded = fr_bind_high(self.eq_evals[:n], challenge)
+                self.eq_evals[:n // 2] = folded
+                self.eq_evals_len = n // 2
+                if len(folded) >= 2:  # :431-435: the sum of the folded array (a modular sum: any grouping gives the same value)
+                    h0, h1 = fr_sum_halves(folded)
+                    self.current_claim = f_add(FR, h0[None, :], h1[None, :])[0]
+                else:
+                    self.current_claim = folded[0].copy()
+        self.round += 1
+
+    def getFinalEval(self):
+        """:458-462: expanding_v.get(0) after log_K binds = prod (1 - r_i) (expanding_table.zig:83-99: new[0] = old[0] * (1 - r))"""
+        acc = f_from_u64(FR, np.array([1], dtype=np.uint64))
+        one = acc.copy()
+        for c in self.challenges[:self.log_K]:
+            acc = f_mul(FR, acc, f_sub(FR, one, c[None, :]))
+        return acc[0]
+
+
+def lasso_derive_challenge(coeffs, round_index):
+    coeffs = _c(coeffs)
+    out = np.empty(4, dtype=np.uint64)
+    lib.zo_lasso_derive_challenge(_p(coeffs), C.c_size_t(coeffs.size // 4), C.c_uint64(round_index), _p(out))
+    return out
+
+
+def run_lasso_prover(lookup_indices_u128, log_T, log_K, r_reduction):
+    """runLassoProver (lasso/prover.zig:495-530)"""
+    p = LassoProver(lookup_indices_u128, log_T, log_K, r_reduction)
+    polys, rnd = [], 0
+    while not p.isComplete():
+        polys.append(p.computeRoundPolynomial())
+        p.receiveChallenge(lasso_derive_challenge(polys[-1], rnd))
+        rnd += 1
+    return {"round_polys": np.stack(polys) if polys else np.zeros((0, 3, 4), dtype=np.uint64), "final_eval": p.getFinalEval(),
+            "challenges": np.stack(p.challenges) if p.challenges else np.zeros((0, 4), dtype=np.uint64)}

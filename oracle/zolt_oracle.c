@@ -1139,3 +1139,57 @@ EXPORT void zo_lasso_address_sums(const uint64_t *eq_evals, const uint64_t *idx,
     }
     memcpy(sum0, &s0, 32); memcpy(sum1, &s1, 32);
 }
+
+/* SplitEqPolynomial.buildTables + getEq (src/zkvm/lasso/split_eq.zig:113-142,157-168) and LassoProver.init's eq_evals
+ * (src/zkvm/lasso/prover.zig:153-171): E_out / E_in built LSB-first (w[i] <-> bit i of the half's index),
+ * eq_evals[j] = E_out[j >> num_inner] * E_in[j & mask] for j < num_cycles, zero up to 2^(num_outer + num_inner);
+ * *claim = sum of all entries (:166-171). */
+EXPORT void zo_lasso_init_eq_evals(const uint64_t *w, size_t num_outer, size_t num_inner, size_t num_cycles, uint64_t *eq_evals,
+                                   uint64_t claim[4]) {
+    size_t so = (size_t)1 << num_outer, si = (size_t)1 << num_inner, padded = so * si;
+    fe *eo = (fe *)malloc(so * sizeof(fe)), *ei = (fe *)malloc(si * sizeof(fe));
+    fe one = f_one(&FR);
+    eo[0] = one;
+    for (size_t i = 0; i < num_outer; i++) {
+        size_t half = (size_t)1 << i;
+        fe val = *(const fe *)(w + 4 * i), om = f_sub(&FR, &one, &val);
+        for (size_t j = 0; j < half; j++) { eo[j + half] = f_mul(&FR, &eo[j], &val); eo[j] = f_mul(&FR, &eo[j], &om); }
+    }
+    ei[0] = one;
+    for (size_t i = 0; i < num_inner; i++) {
+        size_t half = (size_t)1 << i;
+        fe val = *(const fe *)(w + 4 * (num_outer + i)), om = f_sub(&FR, &one, &val);
+        for (size_t j = 0; j < half; j++) { ei[j + half] = f_mul(&FR, &ei[j], &val); ei[j] = f_mul(&FR, &ei[j], &om); }
+    }
+    fe sum = f_zero(), *out = (fe *)eq_evals;
+    for (size_t j = 0; j < padded; j++) {
+        out[j] = j < num_cycles ? f_mul(&FR, &eo[j >> num_inner], &ei[j & (si - 1)]) : f_zero();
+        sum = f_add(&FR, &sum, &out[j]);
+    }
+    memcpy(claim, &sum, 32);
+    free(eo); free(ei);
+}
+/* LassoProver.receiveChallenge, address branch — src/zkvm/lasso/prover.zig:375-399: the n lookups' eq values are multiplied by
+ * the challenge or its complement by bit `round_bit` of the index; the new claim sums the whole (padded) array. */
+EXPORT void zo_lasso_receive_address(uint64_t *eq_evals, size_t padded, const uint64_t *idx, size_t n, unsigned round_bit,
+                                     const uint64_t challenge[4], uint64_t claim[4]) {
+    fe *e = (fe *)eq_evals, c = *(const fe *)challenge, one = f_one(&FR), omr = f_sub(&FR, &one, &c);
+    for (size_t j = 0; j < n; j++) {
+        uint64_t word = round_bit < 64 ? idx[2 * j] : idx[2 * j + 1];
+        e[j] = ((word >> (round_bit & 63)) & 1) ? f_mul(&FR, &e[j], &c) : f_mul(&FR, &e[j], &omr);
+    }
+    fe sum = f_zero();
+    for (size_t j = 0; j < padded; j++) sum = f_add(&FR, &sum, &e[j]);
+    memcpy(claim, &sum, 32);
+}
+/* deriveChallenge — src/zkvm/lasso/prover.zig:533-551 */
+EXPORT void zo_lasso_derive_challenge(const uint64_t *coeffs, size_t ncoeffs, uint64_t round, uint64_t out[4]) {
+    uint64_t hash = 0x9e3779b97f4a7c15ULL;
+    hash ^= round;
+    hash *= 0xff51afd7ed558ccdULL;
+    for (size_t i = 0; i < ncoeffs; i++)
+        for (int l = 0; l < 4; l++) { hash ^= coeffs[4 * i + l]; hash *= 0xc4ceb9fe1a85ec53ULL; }
+    hash ^= hash >> 33;
+    fe r = f_from_u64(&FR, hash);
+    memcpy(out, &r, 32);
+}

@@ -103,3 +103,104 @@ def test_lasso_address_round_sums(env, n):
     tot = ob.fr_sum_halves(np.concatenate([eq, np.zeros_like(eq)]))[0]
     w0, w1 = lib.fr_bit_split_sums(eq, idx, 5)
     assert np.array_equal(ob.f_add(ob.FR, w0, w1), tot)
+
+
+def _lasso_case(ob, seed, log_T, log_K, n):
+    w = _rand(ob, seed, log_T)
+    idx = U.splitmix64(seed + 1, 2 * max(n, 1)).reshape(-1, 2)[:n].copy()
+    if log_K < 128:  # indices below 2^log_K, as the reference's callers produce them
+        mask = (1 << log_K) - 1
+        idx[:, 0] &= np.uint64(mask & (2**64 - 1))
+        idx[:, 1] &= np.uint64(mask >> 64)
+    return w, idx
+
+
+def test_lasso_prover_reference_inline_tests(env):
+    """src/zkvm/lasso/prover.zig:553-688 restated against api.LassoProver (one device session for both phases)."""
+    api, lib, ob = env
+    F, P = api.fr_from_int, api.R_MOD
+    idx = np.array([[0, 0], [1, 0], [2, 0], [3, 0]], dtype=np.uint64)
+    p = api.LassoProver(idx, 2, 3, np.stack([F(2), F(3)]))
+    assert p.round == 0 and p.isAddressPhase() and not p.isComplete()
+    assert len(p.computeRoundPolynomial()) > 0
+    p.receiveChallenge(F(7))
+    assert p.round == 1
+    p.deinit()
+    p = api.LassoProver(idx, 2, 3, np.stack([F(2), F(3)]))
+    for rnd in range(5):
+        claim = api.fr_to_int(p.current_claim)
+        c0, c1, c2 = (api.fr_to_int(c) for c in p.computeRoundPolynomial())
+        assert (c0 + c0 + c1 + c2) % P == claim
+        ch = rnd + 10
+        p.receiveChallenge(F(ch))
+        assert api.fr_to_int(p.current_claim) == (c0 + c1 * ch + c2 * ch * ch) % P
+    assert p.isComplete()
+    p.deinit()
+
+
+@pytest.mark.parametrize("log_T,log_K,n", [(0, 3, 1), (1, 1, 2), (2, 3, 4), (5, 16, 21), (8, 64, 256), (10, 128, 1000), (14, 32, 16384), (16, 16, 40000)])
+def test_lasso_prover_vs_oracle(env, log_T, log_K, n):
+    """every round polynomial, claim and the live eq_evals array of both phases against the oracle's restatement; random challenges"""
+    api, lib, ob = env
+    w, idx = _lasso_case(ob, 5100 + log_T, log_T, log_K, n)
+    g, o = api.LassoProver(idx, log_T, log_K, w), ob.LassoProver(idx, log_T, log_K, w)
+    assert np.array_equal(g.eq_evals(), o.eq_evals) and np.array_equal(g.computeInitialClaim(), o.current_claim)
+    chal = _rand(ob, 5200 + log_T, log_T + log_K)
+    for rnd in range(log_T + log_K):
+        assert g.isAddressPhase() == o.isAddressPhase()
+        assert np.array_equal(g.computeRoundPolynomial(), o.computeRoundPolynomial()), rnd
+        g.receiveChallenge(chal[rnd])
+        o.receiveChallenge(chal[rnd])
+        assert np.array_equal(g.current_claim, o.current_claim), rnd
+        if rnd % 7 == 0 or rnd >= log_K:
+            assert np.array_equal(g.eq_evals(), o.eq_evals[:o.eq_evals_len]), rnd
+    assert g.isComplete() and o.isComplete()
+    assert np.array_equal(g.computeRoundPolynomial(), o.computeRoundPolynomial())  # the num_cycles <= 1 branch (:325-333)
+    assert np.array_equal(g.getFinalEval(), o.getFinalEval())
+    g.deinit()
+
+
+@pytest.mark.parametrize("log_T,log_K,n", [(2, 3, 4), (6, 16, 50), (12, 24, 4096)])
+def test_run_lasso_prover_vs_oracle(env, log_T, log_K, n):
+    """runLassoProver (:495-530) with the reference's own 64-bit challenge mixer (:533-551)"""
+    api, lib, ob = env
+    w, idx = _lasso_case(ob, 5300 + log_T, log_T, log_K, n)
+    got, want = api.runLassoProver(idx, log_T, log_K, w), ob.run_lasso_prover(idx, log_T, log_K, w)
+    for k in ("round_polys", "final_eval", "challenges"):
+        assert np.array_equal(got[k], want[k]), k
+
+
+def test_lasso_session_bit_ops_edge_cases(env):
+    """zg_sumcheck_bit_round / bit_bind directly: non-zero padding past the lookups stays untouched and is part of the claim; a
+    bit_round on a different bit than the one bit_bind prepared recomputes; invalid arguments are refused; the ordinary
+    HIGH_HALF rounds continue on the same session afterwards."""
+    api, lib, ob = env
+    n, n_idx = 1 << 10, 700
+    tab = _rand(ob, 5400, n)
+    idx = U.splitmix64(5401, 2 * n_idx).reshape(n_idx, 2)
+    d_idx = lib.DeviceBuffer.from_host(idx)
+    s = lib.SumcheckSession.open(tab, lib.SC_HIGH_HALF)
+    cur = tab.copy()
+    for bit in (3, 4, 64, 127, 9):
+        w0, w1 = ob.lasso_address_sums(cur[:n_idx], idx, bit)
+        g0, g1 = s.bit_round(d_idx.ptr, n_idx, bit)
+        assert np.array_equal(g0, w0) and np.array_equal(g1, w1), bit
+        r = _rand(ob, 5410 + bit, 1)[0]
+        claim = np.zeros(4, dtype=np.uint64)
+        ob.lib.zo_lasso_receive_address(ob._p(cur), n, ob._p(idx), n_idx, bit, ob._p(r), ob._p(claim))
+        assert np.array_equal(s.bit_bind(d_idx.ptr, n_idx, bit, r), claim), bit
+        assert np.array_equal(s.read(), cur)
+    g0, g1 = s.round_sums()
+    w0, w1 = ob.fr_sum_halves(cur)
+    assert np.array_equal(g0, w0) and np.array_equal(g1, w1)
+    r = _rand(ob, 5420, 1)[0]
+    s.bind(r)
+    assert np.array_equal(s.read(), ob.fr_bind_high(cur, r))
+    with pytest.raises(RuntimeError):
+        s.bit_round(d_idx.ptr, n, 0)  # n_idx beyond the (folded) table
+    with pytest.raises(RuntimeError):
+        s.bit_round(d_idx.ptr, 10, 128)
+    with pytest.raises(RuntimeError):
+        s.bit_bind(0, 10, 1, r)
+    s.close()
+    d_idx.free()

@@ -371,3 +371,74 @@ def test_gruen_split_eq_state_machine_reference_inline_tests(golden_dir):
         g.bind(F(1000 + r))
     assert sizes[0] == (1 << m, 1 << (n - 1 - m), n - 1 - m) and sizes[-1] == (1, 1, 0)
     assert len(g.E_out_vec) == 1 and len(g.E_in_vec) == 1 and g.current_index == 0
+
+
+def test_lasso_prover_oracle_reference_inline_tests_and_bigint_model():
+    """src/zkvm/lasso/prover.zig:553-688 — "basic", "rounds" and "claim tracking" restated against the oracle's LassoProver
+    (the claim after every challenge is p(r) of the round polynomial just sent), then the whole protocol against an independent
+    big-int model (eq by the product formula, sums and folds with plain ints)."""
+    F = lambda v: ob.f_from_u64(FR, np.array([v], dtype=np.uint64))[0]
+    idx = np.array([[0, 0], [1, 0], [2, 0], [3, 0]], dtype=np.uint64)
+    p = ob.LassoProver(idx, 2, 3, np.stack([F(2), F(3)]))
+    assert p.round == 0 and p.isAddressPhase() and not p.isComplete()
+    uni = p.computeRoundPolynomial()
+    assert len(uni) > 0
+    p.receiveChallenge(F(7))
+    assert p.round == 1
+    p = ob.LassoProver(idx, 2, 3, np.stack([F(2), F(3)]))
+    to_int = lambda a: pm.from_mont(pm.from_limbs(a), pm.R_MOD)
+    for rnd in range(5):
+        claim = to_int(p.current_claim)
+        c0, c1, c2 = (to_int(c) for c in p.computeRoundPolynomial())
+        assert (c0 + (c0 + c1 + c2)) % pm.R_MOD == claim
+        ch = rnd + 10
+        p.receiveChallenge(F(ch))
+        assert to_int(p.current_claim) == (c0 + c1 * ch + c2 * ch * ch) % pm.R_MOD
+    assert p.isComplete()
+    # independent model, ragged cycle count, indices above 64 bits
+    rng = np.random.default_rng(5)
+    log_T, log_K, n = 5, 70, 21
+    P = pm.R_MOD
+    w = [int(rng.integers(1, 1 << 62)) for _ in range(log_T)]
+    lk = [(int(rng.integers(0, 1 << 62)) << 40) ^ int(rng.integers(0, 1 << 62)) for _ in range(n)]
+    lk = [x & ((1 << log_K) - 1) for x in lk]
+    wm = ob.f_to_mont(FR, np.array([[x, 0, 0, 0] for x in w], dtype=np.uint64))
+    idxa = np.array([[x & (2**64 - 1), x >> 64] for x in lk], dtype=np.uint64)
+    lp = ob.LassoProver(idxa, log_T, log_K, wm)
+    outer, inner = log_T // 2, log_T - log_T // 2
+
+    def eq(j):
+        o, i, v = j >> inner, j & ((1 << inner) - 1), 1
+        for b in range(outer):
+            v = v * (w[b] if (o >> b) & 1 else 1 - w[b]) % P
+        for b in range(inner):
+            v = v * (w[outer + b] if (i >> b) & 1 else 1 - w[outer + b]) % P
+        return v
+
+    ev = [eq(j) if j < n else 0 for j in range(1 << log_T)]
+    assert [to_int(x) for x in lp.eq_evals] == ev and to_int(lp.current_claim) == sum(ev) % P
+    chal = [int(rng.integers(1, 1 << 62)) for _ in range(log_T + log_K)]
+    cm = ob.f_to_mont(FR, np.array([[x, 0, 0, 0] for x in chal], dtype=np.uint64))
+    ln = len(ev)
+    for r in range(log_T + log_K):
+        c = [to_int(x) for x in lp.computeRoundPolynomial()]
+        if r < log_K:
+            s0 = sum(ev[j] for j in range(n) if not (lk[j] >> r) & 1) % P
+            s1 = sum(ev[j] for j in range(n) if (lk[j] >> r) & 1) % P
+        else:
+            s0, s1 = sum(ev[:ln // 2]) % P, sum(ev[ln // 2:ln]) % P
+        assert c == [s0, (s1 - s0) % P, 0], r
+        assert (s0 + s1) % P == to_int(lp.current_claim)
+        lp.receiveChallenge(cm[r])
+        ch = chal[r]
+        if r < log_K:
+            for j in range(n):
+                ev[j] = ev[j] * (ch if (lk[j] >> r) & 1 else 1 - ch) % P
+        else:
+            ev[:ln // 2] = [((1 - ch) * ev[j] + ch * ev[j + ln // 2]) % P for j in range(ln // 2)]
+            ln //= 2
+    assert lp.isComplete() and to_int(lp.current_claim) == ev[0]
+    fin = 1
+    for ch in chal[:log_K]:
+        fin = fin * (1 - ch) % P
+    assert to_int(lp.getFinalEval()) == fin

@@ -1078,6 +1078,123 @@ class LassoAddressRounds:
         self._idx.free()
 
 
+class LassoProver:
+    """LassoProver's sumcheck over eq_evals (src/zkvm/lasso/prover.zig:80-467) on ONE device session: the padded eq_evals array is
+    built on the device (SplitEqPolynomial.getEq, src/zkvm/lasso/split_eq.zig:113-168 = the eq table with each half's variables
+    reversed), the log_K address rounds split / scale it by index bits, the log_T cycle rounds are HIGH_HALF sums and folds.
+    The prefix-suffix structures the reference binds alongside (:402-404) do not enter the round polynomials and are not mirrored."""
+
+    def __init__(self, lookup_indices_u128, log_T, log_K, r_reduction):
+        idx = np.ascontiguousarray(lookup_indices_u128, dtype=np.uint64).reshape(-1, 2)
+        w = np.ascontiguousarray(r_reduction, dtype=np.uint64).reshape(-1, 4)
+        assert w.shape[0] == log_T  # SplitEqPolynomial.init: w.len == num_outer + num_inner
+        self.log_T, self.log_K = log_T, log_K
+        self.num_cycles = idx.shape[0]
+        padded = 1 << log_T
+        assert self.num_cycles <= padded
+        outer = log_T // 2  # :129-131
+        # E_out / E_in are built LSB-first (w[i] <-> bit i of the half's index): MSB-first order = each half reversed
+        point = np.concatenate([w[:outer][::-1], w[outer:][::-1]]) if log_T else w
+        buf = lib.DeviceBuffer(padded * 32)
+        lib.fr_eq_table_dev(point, buf.ptr)
+        if self.num_cycles < padded:  # :160-164: cycles without lookups are zero
+            tail = np.zeros((padded - self.num_cycles, 4), dtype=np.uint64)
+            lib._chk(lib._lib.zg_memcpy_h2d(lib._d(buf.ptr + self.num_cycles * 32), lib._h(tail), tail.nbytes), "zg_memcpy_h2d")
+        self._s = lib.SumcheckSession.open_dev(buf.ptr, padded, lib.SC_HIGH_HALF)
+        lib.sync()
+        buf.free()
+        self._idx = lib.DeviceBuffer.from_host(idx) if self.num_cycles else lib.DeviceBuffer(16)
+        self.eq_evals_len = padded
+        self.round = 0
+        self.challenges = []
+        self.current_claim = self._total()  # :166-171
+
+    def _total(self):
+        if len(self._s) >= 2:
+            g0, g1 = self._s.round_sums()
+            return _fr_add(g0, g1)
+        return self._s.final()
+
+    def computeInitialClaim(self):
+        return self.current_claim.copy()
+
+    def isAddressPhase(self):
+        return self.round < self.log_K
+
+    def isComplete(self):
+        return self.round >= self.log_K + self.log_T
+
+    def computeRoundPolynomial(self):
+        """-> coeffs [c0, c1, c2] = [sum_0, sum_1 - sum_0, 0] (:262-345)"""
+        zero = np.zeros(4, dtype=np.uint64)
+        if self.isAddressPhase():
+            s0, s1 = self._s.bit_round(self._idx.ptr, self.num_cycles, self.round)
+        else:
+            if self.eq_evals_len <= 1:  # :325-333
+                return np.stack([self._s.final(), zero, zero])
+            s0, s1 = self._s.round_sums()
+        return np.stack([s0, _fr_sub(s1, s0), zero])
+
+    def receiveChallenge(self, challenge):
+        """:352-453 — address phase: scale by the index bit, claim = sum; cycle phase: high-half fold, claim = sum of the folded array"""
+        challenge = np.ascontiguousarray(challenge, dtype=np.uint64)
+        self.challenges.append(challenge.copy())
+        if self.isAddressPhase():
+            self.current_claim = self._s.bit_bind(self._idx.ptr, self.num_cycles, self.round, challenge)
+        elif self.eq_evals_len > 1:
+            self._s.bind(challenge)
+            self.eq_evals_len //= 2
+            self.current_claim = self._total()
+        self.round += 1
+
+    def getFinalEval(self):
+        """getFinalEval (:458-462) = expanding_v.get(0) = prod over the address challenges of (1 - r) (expanding_table.zig:83-99)"""
+        assert self.isComplete()
+        acc = 1
+        for c in self.challenges[:self.log_K]:
+            acc = acc * (1 - fr_to_int(c)) % R_MOD
+        return fr_from_int(acc)
+
+    def getChallenges(self):
+        return np.stack(self.challenges) if self.challenges else np.zeros((0, 4), dtype=np.uint64)
+
+    def eq_evals(self):
+        """the live prefix of eq_evals, read back (tests)"""
+        return self._s.read()
+
+    def deinit(self):
+        self._s.close()
+        self._idx.free()
+
+
+def lassoDeriveChallenge(coeffs, round_index):
+    """deriveChallenge (src/zkvm/lasso/prover.zig:533-551): a 64-bit mix of the round index and the coefficients' Montgomery limbs"""
+    M = (1 << 64) - 1
+    h = 0x9E3779B97F4A7C15 ^ round_index
+    h = h * 0xFF51AFD7ED558CCD & M
+    for c in np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4):
+        for limb in c:
+            h ^= int(limb)
+            h = h * 0xC4CEB9FE1A85EC53 & M
+    h ^= h >> 33
+    return fr_from_int(h)
+
+
+def runLassoProver(lookup_indices_u128, log_T, log_K, r_reduction):
+    """runLassoProver (:495-530) -> {round_polys (rounds,3,4), final_eval, challenges}"""
+    p = LassoProver(lookup_indices_u128, log_T, log_K, r_reduction)
+    polys = []
+    rnd = 0
+    while not p.isComplete():
+        polys.append(p.computeRoundPolynomial())
+        p.receiveChallenge(lassoDeriveChallenge(polys[-1], rnd))
+        rnd += 1
+    out = {"round_polys": np.stack(polys) if polys else np.zeros((0, 3, 4), dtype=np.uint64), "final_eval": p.getFinalEval(),
+           "challenges": p.getChallenges()}
+    p.deinit()
+    return out
+
+
 class Blake2bTranscript:
     """Blake2bTranscript(F) — the Jolt-compatible transcript the reference's proving path uses (src/transcripts/blake2b.zig:25-545):
     a 32-byte running state and a round counter; every operation hashes state || [0u8; 28] || n_rounds_be32 || payload with

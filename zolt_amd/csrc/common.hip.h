@@ -119,6 +119,27 @@ struct SyncGuard {
 
 static inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
+// r = a + b mod the BN254 scalar modulus on the host, canonical inputs (src/field/mod.zig:782-798)
+static inline void fr_add_host(uint64_t r[4], const uint64_t a[4], const uint64_t b[4]) {
+    static const uint64_t M[4] = {0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
+    uint64_t t[4];
+    unsigned __int128 c = 0;
+    for (int i = 0; i < 4; i++) {
+        c += (unsigned __int128)a[i] + b[i];
+        t[i] = (uint64_t)c;
+        c >>= 64;
+    }
+    uint64_t carry = (uint64_t)c, d[4];
+    unsigned __int128 br = 0;
+    for (int i = 0; i < 4; i++) {
+        unsigned __int128 x = (unsigned __int128)t[i] - M[i] - (uint64_t)br;
+        d[i] = (uint64_t)x;
+        br = (x >> 64) & 1;
+    }
+    bool ge = carry || !br;
+    for (int i = 0; i < 4; i++) r[i] = ge ? d[i] : t[i];
+}
+
 int bound_devices();      // devices 0..n-1 bound by zg_init_devices (1 in the one-GPU-per-process model)
 void sharded_shutdown();  // sharded.hip: drop communicators / exchange buffers (called by zg_shutdown)
 

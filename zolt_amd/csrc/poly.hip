@@ -539,6 +539,47 @@ __global__ void __launch_bounds__(256) bit_split_sums_kernel(const uint64_t *val
     }
 }
 
+// LassoProver.receiveChallenge, address phase (src/zkvm/lasso/prover.zig:375-399): t[j] *= (bit `bit` of idx[j]) ? r : 1 - r for the
+// n lookups, in place, and — in the same pass — the NEXT address round's two sums (the scaled values split by bit `next_bit`,
+// :283-293); their total is the new current_claim (:394-399; entries past the lookups are not touched by the reference either).
+__global__ void __launch_bounds__(256) bit_bind_kernel(uint64_t *t, const uint64_t *idx, size_t n, uint32_t bit, uint32_t next_bit,
+                                                       FrArg r, uint64_t *partials) {
+    __shared__ uint4 sh[256 * 4];
+    Fr rv;
+#pragma unroll
+    for (int i = 0; i < 8; i++) rv.l[i] = r.l[i];
+    F29 rp = fr29_prescale(rv), omrp = fr29_prescale(fe_sub(Fr::one(), rv));
+    Fr g0 = Fr::zero(), g1 = Fr::zero();
+    size_t stride = (size_t)gridDim.x * 256;
+    const uint32_t w0 = bit >> 6, s0 = bit & 63u, w1 = next_bit >> 6, s1 = next_bit & 63u;
+    for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < n; j += stride) {
+        Fr v = fe_load<FrParams>(t + 4 * j);
+        uint64_t a = idx[2 * j + w0], b = w1 == w0 ? a : idx[2 * j + w1];
+        v = ((a >> s0) & 1ull) ? fr_mul29(v, rp) : fr_mul29(v, omrp);
+        fe_store(t + 4 * j, v);
+        if ((b >> s1) & 1ull) g1 = fe_add(g1, v);
+        else g0 = fe_add(g0, v);
+    }
+    block_sum_pair(g0, g1, sh);
+    if (threadIdx.x == 0) {
+        fe_store(partials + 8 * (size_t)blockIdx.x, g0);
+        fe_store(partials + 8 * (size_t)blockIdx.x + 4, g1);
+    }
+}
+
+// sum of t[from, to) as the pair (sum, 0): the padding entries of LassoProver.eq_evals (:164-171) that `current_claim` includes
+__global__ void __launch_bounds__(256) range_sum_kernel(const uint64_t *t, size_t from, size_t to, uint64_t *partials) {
+    __shared__ uint4 sh[256 * 4];
+    Fr g0 = Fr::zero(), g1 = Fr::zero();
+    size_t stride = (size_t)gridDim.x * 256;
+    for (size_t j = from + (size_t)blockIdx.x * 256 + threadIdx.x; j < to; j += stride) g0 = fe_add(g0, fe_load<FrParams>(t + 4 * j));
+    block_sum_pair(g0, g1, sh);
+    if (threadIdx.x == 0) {
+        fe_store(partials + 8 * (size_t)blockIdx.x, g0);
+        fe_store(partials + 8 * (size_t)blockIdx.x + 4, g1);
+    }
+}
+
 static unsigned env_uint(const char *name, unsigned dflt, unsigned lo, unsigned hi) {
     const char *e = getenv(name);
     unsigned v = e && *e ? (unsigned)atoi(e) : dflt;
@@ -689,6 +730,15 @@ struct zg_sc_s {
     hipStream_t st = nullptr;
     uint64_t seq = 0;  // number of (sums) publications requested so far; h_pin[12] holds the last one completed
     size_t cap = 0;  // elements buf[0] can hold (sessions are pooled: hipMalloc/hipFree cost more than a round)
+    // address-phase state of a Lasso session (zg_sumcheck_bit_round / bit_bind)
+    bool bit_valid = false;     // bit_sums = the split of the first bit_n entries by bit bit_cached (left by the last bit_bind)
+    unsigned bit_cached = 0;
+    size_t bit_n = 0;
+    const uint64_t *bit_idx = nullptr;
+    uint64_t bit_sums[8] = {0};
+    bool pad_valid = false;     // pad = sum of the entries [pad_from, len) — they do not change during the address phase
+    size_t pad_from = 0;
+    uint64_t pad[4] = {0};
     std::mutex mu;
 };
 
@@ -719,6 +769,7 @@ static int sc_create(size_t len, int layout, hipStream_t st, zg_sc_s **out) {
                 g_pool.erase(g_pool.begin() + i);
                 s->layout = layout; s->len = len; s->st = st; s->cur = 0; s->sums_valid = false;
                 s->seq = 0; s->h_pin[12] = 0;
+                s->bit_valid = false; s->pad_valid = false;
                 *out = s;
                 return ZG_OK;
             }
@@ -1528,6 +1579,7 @@ int zg_sumcheck_bind(zg_sc_t s, const uint64_t r[4]) {
     s->cur = nxt;
     s->len /= 2;
     s->sums_valid = s->len >= 2;
+    s->bit_valid = s->pad_valid = false;
     return ZG_OK;
 }
 
@@ -1626,6 +1678,84 @@ int zg_sumcheck_raf_round(zg_sc_t s, const uint64_t base[4], uint64_t current_po
         s0[i] = h[i];
         s2[i] = h[4 + i];
     }
+    return ZG_OK;
+}
+
+// pair of sums left at d_sums by `launch` + sc_finish_kernel, read back synchronously (the caller holds the session's mutex)
+static int sc_read_pair(zg_sc_s *s, unsigned nb, uint64_t out[8]) {
+    uint64_t *d_part = s->d_partials, *d_sums = s->d_partials + SC_SUMS_OFF;
+    hipLaunchKernelGGL(sc_finish_kernel, dim3(1), dim3(256), 0, s->st, d_part, nb, d_sums, (uint64_t *)nullptr, (uint64_t)0);
+    ZG_HIP(hipGetLastError());
+    ZG_HIP(hipMemcpyAsync(out, d_sums, 64, hipMemcpyDeviceToHost, s->st));
+    ZG_HIP(hipStreamSynchronize(s->st));
+    return ZG_OK;
+}
+
+int zg_sumcheck_bit_round(zg_sc_t s, const uint64_t *d_idx128, size_t n_idx, unsigned bit, uint64_t sum0[4], uint64_t sum1[4]) {
+    ZG_INIT();
+    if (!s || !sum0 || !sum1 || bit > 127 || n_idx > s->len || (n_idx && !d_idx128)) {
+        set_error("zg_sumcheck_bit_round: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    DeviceGuard dg(s->device);
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (!(s->bit_valid && s->bit_cached == bit && s->bit_n == n_idx && s->bit_idx == d_idx128)) {
+        unsigned nb = sc_blocks(n_idx ? n_idx : 1);
+        hipLaunchKernelGGL(bit_split_sums_kernel, dim3(nb), dim3(256), 0, s->st, s->buf[s->cur], d_idx128, n_idx, (uint32_t)bit, s->d_partials);
+        ZG_TRY(sc_read_pair(s, nb, s->bit_sums));
+        s->bit_valid = true;
+        s->bit_cached = bit;
+        s->bit_n = n_idx;
+        s->bit_idx = d_idx128;
+    }
+    for (int i = 0; i < 4; i++) {
+        sum0[i] = s->bit_sums[i];
+        sum1[i] = s->bit_sums[4 + i];
+    }
+    return ZG_OK;
+}
+
+int zg_sumcheck_bit_bind(zg_sc_t s, const uint64_t *d_idx128, size_t n_idx, unsigned bit, const uint64_t r[4], uint64_t claim[4]) {
+    ZG_INIT();
+    if (!s || !r || !claim || bit > 127 || n_idx > s->len || (n_idx && !d_idx128)) {
+        set_error("zg_sumcheck_bit_bind: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    DeviceGuard dg(s->device);
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (!(s->pad_valid && s->pad_from == n_idx)) {  // once per session: the entries past the lookups stay as they are
+        for (int i = 0; i < 4; i++) s->pad[i] = 0;
+        if (n_idx < s->len) {
+            unsigned nb = sc_blocks(s->len - n_idx);
+            uint64_t h[8];
+            hipLaunchKernelGGL(range_sum_kernel, dim3(nb), dim3(256), 0, s->st, s->buf[s->cur], n_idx, s->len, s->d_partials);
+            ZG_TRY(sc_read_pair(s, nb, h));
+            for (int i = 0; i < 4; i++) s->pad[i] = h[i];
+        }
+        s->pad_valid = true;
+        s->pad_from = n_idx;
+    }
+    FrArg ra;
+    for (int i = 0; i < 4; i++) {
+        ra.l[2 * i] = (uint32_t)r[i];
+        ra.l[2 * i + 1] = (uint32_t)(r[i] >> 32);
+    }
+    const unsigned next_bit = bit < 127 ? bit + 1 : bit;
+    unsigned nb = sc_blocks(n_idx ? n_idx : 1);
+    s->sums_valid = false;  // the HIGH_HALF / LOW_PAIR sums of the table are stale now
+    s->bit_valid = false;
+    hipLaunchKernelGGL(bit_bind_kernel, dim3(nb), dim3(256), 0, s->st, s->buf[s->cur], d_idx128, n_idx, (uint32_t)bit, (uint32_t)next_bit, ra,
+                       s->d_partials);
+    ZG_TRY(sc_read_pair(s, nb, s->bit_sums));
+    if (next_bit != bit) {
+        s->bit_valid = true;
+        s->bit_cached = next_bit;
+        s->bit_n = n_idx;
+        s->bit_idx = d_idx128;
+    }
+    uint64_t t[4];
+    fr_add_host(t, s->bit_sums, s->bit_sums + 4);
+    fr_add_host(claim, t, s->pad);
     return ZG_OK;
 }
 

@@ -40,7 +40,7 @@ SYMBOLS = [
     "zg_fr_spartan_combine", "zg_fr_spartan_combine_dev",
     "zg_sumcheck_open", "zg_sumcheck_open_dev", "zg_sumcheck_round_sums", "zg_sumcheck_bind",
     "zg_sumcheck_len", "zg_sumcheck_final", "zg_sumcheck_read", "zg_sumcheck_close",
-    "zg_sumcheck_round_sums_dev", "zg_sumcheck_read_dev", "zg_sumcheck_raf_round", "zg_fr_bit_split_sums", "zg_fr_bit_split_sums_dev",
+    "zg_sumcheck_round_sums_dev", "zg_sumcheck_read_dev", "zg_sumcheck_raf_round", "zg_sumcheck_bit_round", "zg_sumcheck_bit_bind", "zg_fr_bit_split_sums", "zg_fr_bit_split_sums_dev",
     "zg_run_sumcheck", "zg_run_sumcheck_dev", "zg_sumcheck_open_spartan_dev",
 ]
 # test / bench scaffolding of include/zolt_gpu_internal.h (not part of the drop-in boundary)
@@ -607,6 +607,19 @@ class SumcheckSession:
         s2 = np.empty(4, dtype=np.uint64)
         _chk(_lib.zg_sumcheck_raf_round(self._h, _h(_c(base)), C.c_uint64(current_power), _h(s0), _h(s2)), "zg_sumcheck_raf_round")
         return s0, s2
+
+    def bit_round(self, d_idx128, n_idx, bit):
+        """LassoProver.computeAddressRoundPoly's sum_0 / sum_1 over the session's first n_idx entries (zg_sumcheck_bit_round)"""
+        s0 = np.empty(4, dtype=np.uint64)
+        s1 = np.empty(4, dtype=np.uint64)
+        _chk(_lib.zg_sumcheck_bit_round(self._h, _d(d_idx128), C.c_size_t(n_idx), C.c_uint(bit), _h(s0), _h(s1)), "zg_sumcheck_bit_round")
+        return s0, s1
+
+    def bit_bind(self, d_idx128, n_idx, bit, r):
+        """LassoProver.receiveChallenge's address branch in place; -> the new claim (zg_sumcheck_bit_bind)"""
+        claim = np.empty(4, dtype=np.uint64)
+        _chk(_lib.zg_sumcheck_bit_bind(self._h, _d(d_idx128), C.c_size_t(n_idx), C.c_uint(bit), _h(_c(r)), _h(claim)), "zg_sumcheck_bit_bind")
+        return claim
 
     def round_sums_dev(self, d_out8):
         _chk(_lib.zg_sumcheck_round_sums_dev(self._h, _d(d_out8)), "zg_sumcheck_round_sums_dev")
