@@ -276,6 +276,42 @@ TEST(gruen_split_eq_polynomial) {
     }
 }
 
+// src/zkvm/lasso/prover.zig:553-688 — "lasso prover basic" / "rounds" / "claim tracking": p(0) + p(1) = current_claim before every
+// round, current_claim = p(challenge) after it; then runLassoProver's invariants over a ragged lookup set
+TEST(lasso_prover_claim_tracking) {
+    std::vector<unsigned __int128> idx = {0, 1, 2, 3};
+    std::vector<Fr> r_reduction = {Fr::fromU64(2), Fr::fromU64(3)};
+    {
+        LassoProver p(idx, 2, 3, r_reduction);
+        EXPECT(p.round == 0 && p.isAddressPhase() && !p.isComplete());
+        EXPECT(!p.computeRoundPolynomial().coeffs.empty());
+        p.receiveChallenge(Fr::fromU64(7));
+        EXPECT(p.round == 1);
+    }
+    LassoProver p(idx, 2, 3, r_reduction);
+    for (size_t round = 0; round < 5; round++) {
+        Fr claim = p.current_claim;
+        UniPoly rp = p.computeRoundPolynomial();
+        Fr p1 = rp.coeffs[0].add(rp.coeffs[1]).add(rp.coeffs[2]);
+        EXPECT(rp.coeffs[0].add(p1).eql(claim));
+        Fr ch = Fr::fromU64(round + 10);
+        p.receiveChallenge(ch);
+        EXPECT(p.current_claim.eql(rp.evaluate(ch)));
+    }
+    EXPECT(p.isComplete());
+    std::vector<unsigned __int128> big;
+    for (unsigned i = 0; i < 37; i++) big.push_back(((unsigned __int128)(i * 0x9e3779b97f4a7c15ULL) << 17) ^ (i * 77u));
+    std::vector<Fr> w;
+    for (unsigned i = 0; i < 6; i++) w.push_back(Fr::fromU64(1000003 * i + 5));
+    LassoProof proof = runLassoProver(big, 6, 81, w);
+    EXPECT(proof.round_polys.size() == 87 && proof.challenges.size() == 87);
+    for (size_t i = 0; i + 1 < proof.round_polys.size(); i++) {  // p_i(r_i) = p_{i+1}(0) + p_{i+1}(1)
+        const UniPoly &a = proof.round_polys[i], &b = proof.round_polys[i + 1];
+        Fr next = b.coeffs[0].add(b.coeffs[0].add(b.coeffs[1]).add(b.coeffs[2]));
+        EXPECT(a.evaluate(proof.challenges[i]).eql(next));
+    }
+}
+
 int main() {
     if (zg_init(0) != ZG_OK) { std::printf("zg_init failed: %s\n", zg_last_error()); return 2; }
     for (auto &t : tests()) {

@@ -43,6 +43,28 @@ def main():
         lib.sync()
         lib.fr_spartan_combine_dev(d_out.ptr, d_a.ptr, d_a.ptr, d_a.ptr, n, d_out.ptr)
         lib.sync()
+    # LassoProver: 2^22 cycles, 16 address rounds (scale by index bit + next round's sums in one pass), then 22 cycle rounds
+    import time
+    w = tab[100:100 + v]
+    idx16 = idx.copy()
+    idx16[:, 0] &= np.uint64(0xFFFF)
+    idx16[:, 1] = 0
+    lp = api.LassoProver(idx16, v, 16, w)
+    lib.sync()
+    t = []
+    for rnd in range(16 + v):
+        t0 = time.perf_counter()
+        lp.computeRoundPolynomial()
+        lp.receiveChallenge(tab[200 + rnd])
+        t.append(time.perf_counter() - t0)
+    lp.deinit()
+    print(f"lasso 2^{v} cycles: address round {1e6 * np.median(t[1:16]):.1f} us (first, unfused sums: {1e6 * t[0]:.1f}), "
+          f"cycle rounds {1e6 * np.sum(t[16:]):.0f} us for all {v}, whole protocol {1e3 * np.sum(t):.2f} ms")
+    # GruenSplitEqPolynomial init: both halves' prefix-table sets for a 24-variable tau (m = 12)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        api.GruenSplitEqPolynomial(tab[300:324])
+    print(f"GruenSplitEqPolynomial.init, 24 variables: {1e6 * (time.perf_counter() - t0) / 20:.1f} us")
     print("ok")
 
 

@@ -421,6 +421,21 @@ pub fn SumcheckSession(comptime F: type) type {
             if (self.handle == null or ffi.zg_sumcheck_raf_round(self.handle, &base.limbs, current_power, &s0.limbs, &s2.limbs) != ffi.OK) return Error.GpuFailure;
             return .{ s0, s2 };
         }
+        /// LassoProver's address rounds on this session (opened SC_HIGH_HALF over the padded eq_evals, src/zkvm/lasso/prover.zig:153-171).
+        /// `d_idx`: the u128 lookup indices uploaded once with `uploadLookupIndices`. computeAddressRoundPoly's sum_0 / sum_1 (:283-293):
+        pub fn bitRoundSums(self: *Self, d_idx: DeviceIndices, round_bit: u32) Error![2]F {
+            var s0: F = undefined;
+            var s1: F = undefined;
+            if (self.handle == null or ffi.zg_sumcheck_bit_round(self.handle, @ptrCast(d_idx.ptr), d_idx.len, round_bit, &s0.limbs, &s1.limbs) != ffi.OK) return Error.GpuFailure;
+            return .{ s0, s1 };
+        }
+        /// receiveChallenge's address branch (:375-399): eq_evals[j] *= bit ? r : 1 - r in place; returns the new current_claim.
+        /// The next round's bitRoundSums is then already computed (fused into this pass).
+        pub fn bitBind(self: *Self, d_idx: DeviceIndices, round_bit: u32, challenge: F) Error!F {
+            var claim: F = undefined;
+            if (self.handle == null or ffi.zg_sumcheck_bit_bind(self.handle, @ptrCast(d_idx.ptr), d_idx.len, round_bit, &challenge.limbs, &claim.limbs) != ffi.OK) return Error.GpuFailure;
+            return claim;
+        }
         /// materialise the current table for callers that index prover.polynomial.evaluations directly (:79-92,126,132);
         /// single-device sessions only
         pub fn read(self: *Self, out: []F) Error!void {
@@ -449,6 +464,27 @@ pub fn runSumcheck(comptime F: type, allocator: std.mem.Allocator, evaluations: 
     if (rc == ffi.ERR_VERIFY) return Error.SumcheckVerificationFailed;
     if (rc != ffi.OK) return Error.GpuFailure;
     return .{ .claim = claim, .rounds = rounds, .challenges = challenges, .final_eval = final_eval, .result = result != 0 };
+}
+
+/// The u128 lookup indices of a LassoProver in device memory (little-endian u128 = two u64 words, the layout zg_sumcheck_bit_* reads).
+/// Owned by the prover struct: `uploadLookupIndices` in init, `free` in deinit.
+pub const DeviceIndices = struct {
+    ptr: ?*anyopaque = null,
+    len: usize = 0,
+    pub fn free(self: *DeviceIndices) void {
+        if (self.ptr != null) _ = ffi.zg_dev_free(self.ptr);
+        self.* = .{};
+    }
+};
+pub fn uploadLookupIndices(lookup_indices: []const u128) Error!DeviceIndices {
+    var d: DeviceIndices = .{ .len = lookup_indices.len };
+    const bytes = @max(lookup_indices.len, 1) * @sizeOf(u128);
+    if (ffi.zg_dev_alloc(bytes, &d.ptr) != ffi.OK) return Error.GpuFailure;
+    if (lookup_indices.len != 0 and ffi.zg_memcpy_h2d(d.ptr, @ptrCast(lookup_indices.ptr), lookup_indices.len * @sizeOf(u128)) != ffi.OK) {
+        d.free();
+        return Error.GpuFailure;
+    }
+    return d;
 }
 
 /// LassoProver.computeAddressRoundPoly's two sums (src/zkvm/lasso/prover.zig:283-293): eq_evals split by bit `round_bit` of the
