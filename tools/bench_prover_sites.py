@@ -60,6 +60,16 @@ def main():
     lp.deinit()
     print(f"lasso 2^{v} cycles: address round {1e6 * np.median(t[1:16]):.1f} us (first, unfused sums: {1e6 * t[0]:.1f}), "
           f"cycle rounds {1e6 * np.sum(t[16:]):.0f} us for all {v}, whole protocol {1e3 * np.sum(t):.2f} ms")
+    # the size the reference's own run has (log_T = 13, logs/zolt.log): latency per round, not bandwidth
+    lp = api.LassoProver(idx16[:1 << 13], 13, 16, tab[100:113])
+    t = []
+    for rnd in range(16 + 13):
+        t0 = time.perf_counter()
+        lp.computeRoundPolynomial()
+        lp.receiveChallenge(tab[200 + rnd])
+        t.append(time.perf_counter() - t0)
+    lp.deinit()
+    print(f"lasso 2^13 cycles: address round {1e6 * np.median(t[1:16]):.1f} us, cycle round {1e6 * np.median(t[16:]):.1f} us")
     # GruenSplitEqPolynomial init: both halves' prefix-table sets for a 24-variable tau (m = 12)
     t0 = time.perf_counter()
     for _ in range(20):

@@ -152,7 +152,27 @@ int main(int argc, char **argv) {
             if (rep >= 0) t_raf += std::chrono::duration<double>(clk::now() - t1).count();
         }
     }
-    std::printf("{\"v\": %d, \"reps\": %d, \"verified\": %s, \"stage1_keccak_rounds_per_s\": %.1f, \"stage1_ms\": %.4f, "
+    // runLassoProver (src/zkvm/lasso/prover.zig:495-551): 2^v cycles, log_K = 16 address rounds + v cycle rounds on one session,
+    // the reference's 64-bit challenge mixer between rounds
+    double t_lasso = 0;
+    {
+        std::vector<unsigned __int128> lk(n);
+        uint64_t x = 0x4c4153534fULL;
+        for (size_t j = 0; j < n; j++) {
+            x = x * 6364136223846793005ULL + 1442695040888963407ULL;
+            lk[j] = (x >> 33) & 0xffff;
+        }
+        std::vector<Fr> w;
+        for (int i = 0; i < v; i++) w.push_back(Fr::fromU64(1000003ULL * i + 17));
+        for (int rep = -1; rep < reps; rep++) {
+            auto t0 = clk::now();
+            LassoProof pr = runLassoProver(lk, v, 16, w);
+            if (rep >= 0) t_lasso += std::chrono::duration<double>(clk::now() - t0).count();
+            ok = ok && pr.round_polys.size() == (size_t)(16 + v);
+        }
+    }
+    std::printf("{\"lasso_log_K16_rounds_per_s\": %.1f, \"lasso_ms_whole_protocol_incl_setup\": %.4f, ", reps * (16 + v) / t_lasso, t_lasso / reps * 1e3);
+    std::printf("\"v\": %d, \"reps\": %d, \"verified\": %s, \"stage1_keccak_rounds_per_s\": %.1f, \"stage1_ms\": %.4f, "
                 "\"raf_cubic_rounds_per_s\": %.1f, \"raf_ms\": %.4f, \"device_resident_rounds_per_s\": %.1f, "
                 "\"device_resident_ms_runSumcheck\": %.4f, ", v, reps, ok ? "true" : "false", reps * v / t_s1, t_s1 / reps * 1e3, reps * v / t_raf,
                 t_raf / reps * 1e3, reps * v / t_dev, t_dev / reps * 1e3);

@@ -521,8 +521,11 @@ __global__ void __launch_bounds__(256) raf_round_kernel(const uint64_t *t, size_
 
 // LassoProver.computeAddressRoundPoly's two sums (src/zkvm/lasso/prover.zig:283-293): the eq values split by bit `bit` of the
 // u128 lookup index (two little-endian u64 words per entry)
+// `sums` == nullptr: the block pairs stay in `partials` (finished by sc_finish_kernel); otherwise the round ends inside this launch
+// (finish_round: pinned mailbox + sequence word), as in the fold kernels.
 __global__ void __launch_bounds__(256) bit_split_sums_kernel(const uint64_t *vals, const uint64_t *idx, size_t n, uint32_t bit,
-                                                             uint64_t *partials) {
+                                                             uint64_t *partials, uint64_t *sums, uint32_t *counter, uint64_t *flag,
+                                                             uint64_t seq) {
     __shared__ uint4 sh[256 * 4];
     Fr g0 = Fr::zero(), g1 = Fr::zero();
     size_t stride = (size_t)gridDim.x * 256;
@@ -533,7 +536,9 @@ __global__ void __launch_bounds__(256) bit_split_sums_kernel(const uint64_t *val
         else g0 = fe_add(g0, v);
     }
     block_sum_pair(g0, g1, sh);
-    if (threadIdx.x == 0) {
+    if (sums) {
+        finish_round(g0, g1, sh, partials, sums, counter, flag, seq, ScRunArg{nullptr, 0, 0, 0});
+    } else if (threadIdx.x == 0) {
         fe_store(partials + 8 * (size_t)blockIdx.x, g0);
         fe_store(partials + 8 * (size_t)blockIdx.x + 4, g1);
     }
@@ -543,7 +548,8 @@ __global__ void __launch_bounds__(256) bit_split_sums_kernel(const uint64_t *val
 // n lookups, in place, and — in the same pass — the NEXT address round's two sums (the scaled values split by bit `next_bit`,
 // :283-293); their total is the new current_claim (:394-399; entries past the lookups are not touched by the reference either).
 __global__ void __launch_bounds__(256) bit_bind_kernel(uint64_t *t, const uint64_t *idx, size_t n, uint32_t bit, uint32_t next_bit,
-                                                       FrArg r, uint64_t *partials) {
+                                                       FrArg r, uint64_t *partials, uint64_t *sums, uint32_t *counter, uint64_t *flag,
+                                                       uint64_t seq) {
     __shared__ uint4 sh[256 * 4];
     Fr rv;
 #pragma unroll
@@ -561,20 +567,25 @@ __global__ void __launch_bounds__(256) bit_bind_kernel(uint64_t *t, const uint64
         else g0 = fe_add(g0, v);
     }
     block_sum_pair(g0, g1, sh);
-    if (threadIdx.x == 0) {
+    if (sums) {
+        finish_round(g0, g1, sh, partials, sums, counter, flag, seq, ScRunArg{nullptr, 0, 0, 0});
+    } else if (threadIdx.x == 0) {
         fe_store(partials + 8 * (size_t)blockIdx.x, g0);
         fe_store(partials + 8 * (size_t)blockIdx.x + 4, g1);
     }
 }
 
 // sum of t[from, to) as the pair (sum, 0): the padding entries of LassoProver.eq_evals (:164-171) that `current_claim` includes
-__global__ void __launch_bounds__(256) range_sum_kernel(const uint64_t *t, size_t from, size_t to, uint64_t *partials) {
+__global__ void __launch_bounds__(256) range_sum_kernel(const uint64_t *t, size_t from, size_t to, uint64_t *partials, uint64_t *sums,
+                                                        uint32_t *counter, uint64_t *flag, uint64_t seq) {
     __shared__ uint4 sh[256 * 4];
     Fr g0 = Fr::zero(), g1 = Fr::zero();
     size_t stride = (size_t)gridDim.x * 256;
     for (size_t j = from + (size_t)blockIdx.x * 256 + threadIdx.x; j < to; j += stride) g0 = fe_add(g0, fe_load<FrParams>(t + 4 * j));
     block_sum_pair(g0, g1, sh);
-    if (threadIdx.x == 0) {
+    if (sums) {
+        finish_round(g0, g1, sh, partials, sums, counter, flag, seq, ScRunArg{nullptr, 0, 0, 0});
+    } else if (threadIdx.x == 0) {
         fe_store(partials + 8 * (size_t)blockIdx.x, g0);
         fe_store(partials + 8 * (size_t)blockIdx.x + 4, g1);
     }
@@ -793,6 +804,23 @@ static int sc_create(size_t len, int layout, hipStream_t st, zg_sc_s **out) {
         return e == hipErrorOutOfMemory ? ZG_ERR_NOMEM : ZG_ERR_HIP;
     }
     *out = s;
+    return ZG_OK;
+}
+
+// the host side of a round that ended inside its kernel: spin on the mailbox's sequence word (written by the GPU after the sums,
+// system-scope release); fall back to a stream synchronisation if it does not arrive promptly. The caller holds the session's mutex.
+static int sc_wait_mailbox(zg_sc_s *s, uint64_t out[8]) {
+    ZG_HIP(hipGetLastError());
+    volatile uint64_t *flag = s->h_pin + 12;
+    bool got = false;
+    for (uint64_t spin = 0; spin < (1ull << 22); spin++) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == s->seq) { got = true; break; }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    if (!got) ZG_HIP(hipStreamSynchronize(s->st));
+    for (int i = 0; i < 8; i++) out[i] = s->h_pin[i];
     return ZG_OK;
 }
 
@@ -1543,22 +1571,11 @@ int zg_sumcheck_round_sums(zg_sc_t s, uint64_t g0[4], uint64_t g1[4]) {
         ZG_TRY(launch_sums(s->layout, s->buf[s->cur], s->len, s->d_partials, s->h_pin, s->st, s->h_pin + 12, s->seq));
         s->sums_valid = true;
     }
-    // the only host<->device rendezvous of a round: spin on the mailbox's sequence word (written by the GPU after
-    // the sums, system-scope release); fall back to a stream synchronisation if it does not arrive promptly
-    {
-        volatile uint64_t *flag = s->h_pin + 12;
-        bool got = false;
-        for (uint64_t spin = 0; spin < (1ull << 22); spin++) {
-            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == s->seq) { got = true; break; }
-#if defined(__x86_64__)
-            __builtin_ia32_pause();
-#endif
-        }
-        if (!got) ZG_HIP(hipStreamSynchronize(s->st));
-    }
+    uint64_t h[8];
+    ZG_TRY(sc_wait_mailbox(s, h));  // the only host<->device rendezvous of a round
     for (int i = 0; i < 4; i++) {
-        g0[i] = s->h_pin[i];
-        g1[i] = s->h_pin[4 + i];
+        g0[i] = h[i];
+        g1[i] = h[4 + i];
     }
     return ZG_OK;
 }
@@ -1681,16 +1698,6 @@ int zg_sumcheck_raf_round(zg_sc_t s, const uint64_t base[4], uint64_t current_po
     return ZG_OK;
 }
 
-// pair of sums left at d_sums by `launch` + sc_finish_kernel, read back synchronously (the caller holds the session's mutex)
-static int sc_read_pair(zg_sc_s *s, unsigned nb, uint64_t out[8]) {
-    uint64_t *d_part = s->d_partials, *d_sums = s->d_partials + SC_SUMS_OFF;
-    hipLaunchKernelGGL(sc_finish_kernel, dim3(1), dim3(256), 0, s->st, d_part, nb, d_sums, (uint64_t *)nullptr, (uint64_t)0);
-    ZG_HIP(hipGetLastError());
-    ZG_HIP(hipMemcpyAsync(out, d_sums, 64, hipMemcpyDeviceToHost, s->st));
-    ZG_HIP(hipStreamSynchronize(s->st));
-    return ZG_OK;
-}
-
 int zg_sumcheck_bit_round(zg_sc_t s, const uint64_t *d_idx128, size_t n_idx, unsigned bit, uint64_t sum0[4], uint64_t sum1[4]) {
     ZG_INIT();
     if (!s || !sum0 || !sum1 || bit > 127 || n_idx > s->len || (n_idx && !d_idx128)) {
@@ -1701,8 +1708,12 @@ int zg_sumcheck_bit_round(zg_sc_t s, const uint64_t *d_idx128, size_t n_idx, uns
     std::lock_guard<std::mutex> lk(s->mu);
     if (!(s->bit_valid && s->bit_cached == bit && s->bit_n == n_idx && s->bit_idx == d_idx128)) {
         unsigned nb = sc_blocks(n_idx ? n_idx : 1);
-        hipLaunchKernelGGL(bit_split_sums_kernel, dim3(nb), dim3(256), 0, s->st, s->buf[s->cur], d_idx128, n_idx, (uint32_t)bit, s->d_partials);
-        ZG_TRY(sc_read_pair(s, nb, s->bit_sums));
+        uint32_t *counter = reinterpret_cast<uint32_t *>(s->d_partials + 8 * (size_t)SC_MAX_BLOCKS);
+        s->sums_valid = false;  // the mailbox now holds this pair
+        s->seq++;
+        hipLaunchKernelGGL(bit_split_sums_kernel, dim3(nb), dim3(256), 0, s->st, s->buf[s->cur], d_idx128, n_idx, (uint32_t)bit, s->d_partials,
+                           s->h_pin, counter, s->h_pin + 12, s->seq);
+        ZG_TRY(sc_wait_mailbox(s, s->bit_sums));
         s->bit_valid = true;
         s->bit_cached = bit;
         s->bit_n = n_idx;
@@ -1723,13 +1734,17 @@ int zg_sumcheck_bit_bind(zg_sc_t s, const uint64_t *d_idx128, size_t n_idx, unsi
     }
     DeviceGuard dg(s->device);
     std::lock_guard<std::mutex> lk(s->mu);
+    uint32_t *counter = reinterpret_cast<uint32_t *>(s->d_partials + 8 * (size_t)SC_MAX_BLOCKS);
+    s->sums_valid = false;  // the table changes and the mailbox is reused: the HIGH_HALF / LOW_PAIR sums are stale
     if (!(s->pad_valid && s->pad_from == n_idx)) {  // once per session: the entries past the lookups stay as they are
         for (int i = 0; i < 4; i++) s->pad[i] = 0;
         if (n_idx < s->len) {
             unsigned nb = sc_blocks(s->len - n_idx);
             uint64_t h[8];
-            hipLaunchKernelGGL(range_sum_kernel, dim3(nb), dim3(256), 0, s->st, s->buf[s->cur], n_idx, s->len, s->d_partials);
-            ZG_TRY(sc_read_pair(s, nb, h));
+            s->seq++;
+            hipLaunchKernelGGL(range_sum_kernel, dim3(nb), dim3(256), 0, s->st, s->buf[s->cur], n_idx, s->len, s->d_partials, s->h_pin, counter,
+                               s->h_pin + 12, s->seq);
+            ZG_TRY(sc_wait_mailbox(s, h));
             for (int i = 0; i < 4; i++) s->pad[i] = h[i];
         }
         s->pad_valid = true;
@@ -1742,11 +1757,11 @@ int zg_sumcheck_bit_bind(zg_sc_t s, const uint64_t *d_idx128, size_t n_idx, unsi
     }
     const unsigned next_bit = bit < 127 ? bit + 1 : bit;
     unsigned nb = sc_blocks(n_idx ? n_idx : 1);
-    s->sums_valid = false;  // the HIGH_HALF / LOW_PAIR sums of the table are stale now
     s->bit_valid = false;
+    s->seq++;
     hipLaunchKernelGGL(bit_bind_kernel, dim3(nb), dim3(256), 0, s->st, s->buf[s->cur], d_idx128, n_idx, (uint32_t)bit, (uint32_t)next_bit, ra,
-                       s->d_partials);
-    ZG_TRY(sc_read_pair(s, nb, s->bit_sums));
+                       s->d_partials, s->h_pin, counter, s->h_pin + 12, s->seq);
+    ZG_TRY(sc_wait_mailbox(s, s->bit_sums));
     if (next_bit != bit) {
         s->bit_valid = true;
         s->bit_cached = next_bit;
@@ -1772,7 +1787,8 @@ int zg_fr_bit_split_sums_dev(const uint64_t *d_vals, const uint64_t *d_idx128, s
     SyncGuard sync(st);
     uint64_t *d_misc = s_misc.as<uint64_t>();
     unsigned nb = sc_blocks(n ? n : 1);
-    hipLaunchKernelGGL(bit_split_sums_kernel, dim3(nb), dim3(256), 0, st, d_vals, d_idx128, n, (uint32_t)bit, d_misc);
+    hipLaunchKernelGGL(bit_split_sums_kernel, dim3(nb), dim3(256), 0, st, d_vals, d_idx128, n, (uint32_t)bit, d_misc, (uint64_t *)nullptr,
+                       (uint32_t *)nullptr, (uint64_t *)nullptr, (uint64_t)0);
     hipLaunchKernelGGL(sc_finish_kernel, dim3(1), dim3(256), 0, st, d_misc, nb, d_misc + SC_SUMS_OFF, (uint64_t *)nullptr, (uint64_t)0);
     ZG_HIP(hipGetLastError());
     uint64_t h[8];
