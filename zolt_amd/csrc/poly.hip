@@ -486,7 +486,8 @@ __global__ void __launch_bounds__(256) eq_spartan_kernel(const uint64_t *lo_tab,
 //   u0(i) = base + F(rem(i)),  u2(i) = u0(i) + F(2 * current_power),  rem(i) = sum_j bit_j(i) * current_power * 2^(j+1) = step * i
 // (`base` = start_address + 8 * sum_j bound_j 2^j, a handful of host scalar operations; step = 2 * current_power; the host has
 // checked that step * half fits 64 bits, so F.fromU64 of the sum equals the reference's sum of F.fromU64 terms).
-__global__ void __launch_bounds__(256) raf_round_kernel(const uint64_t *t, size_t half, FrArg base, uint64_t step, uint64_t *partials) {
+__global__ void __launch_bounds__(256) raf_round_kernel(const uint64_t *t, size_t half, FrArg base, uint64_t step, uint64_t *partials,
+                                                        uint64_t *sums, uint32_t *counter, uint64_t *flag, uint64_t seq) {
     __shared__ uint4 sh[256 * 4];
     Fr bv;
 #pragma unroll
@@ -513,10 +514,7 @@ __global__ void __launch_bounds__(256) raf_round_kernel(const uint64_t *t, size_
         g1 = fe_add(g1, fr_mul29v(ra2, u2));
     }
     block_sum_pair(g0, g1, sh);
-    if (threadIdx.x == 0) {
-        fe_store(partials + 8 * (size_t)blockIdx.x, g0);
-        fe_store(partials + 8 * (size_t)blockIdx.x + 4, g1);
-    }
+    finish_round(g0, g1, sh, partials, sums, counter, flag, seq, ScRunArg{nullptr, 0, 0, 0});  // the round ends inside this launch
 }
 
 // LassoProver.computeAddressRoundPoly's two sums (src/zkvm/lasso/prover.zig:283-293): the eq values split by bit `bit` of the
@@ -1684,13 +1682,14 @@ int zg_sumcheck_raf_round(zg_sc_t s, const uint64_t base[4], uint64_t current_po
         ba.l[2 * i + 1] = (uint32_t)(base[i] >> 32);
     }
     unsigned nb = sc_blocks(half);
-    uint64_t *d_part = s->d_partials, *d_sums = s->d_partials + SC_SUMS_OFF;
-    hipLaunchKernelGGL(raf_round_kernel, dim3(nb), dim3(256), 0, s->st, s->buf[s->cur], half, ba, step, d_part);
-    hipLaunchKernelGGL(sc_finish_kernel, dim3(1), dim3(256), 0, s->st, d_part, nb, d_sums, (uint64_t *)nullptr, (uint64_t)0);
-    ZG_HIP(hipGetLastError());
+    uint32_t *counter = reinterpret_cast<uint32_t *>(s->d_partials + 8 * (size_t)SC_MAX_BLOCKS);
+    s->sums_valid = false;  // the mailbox now carries s(0), s(2)
+    s->bit_valid = false;
+    s->seq++;
+    hipLaunchKernelGGL(raf_round_kernel, dim3(nb), dim3(256), 0, s->st, s->buf[s->cur], half, ba, step, s->d_partials, s->h_pin, counter,
+                       s->h_pin + 12, s->seq);
     uint64_t h[8];
-    ZG_HIP(hipMemcpyAsync(h, d_sums, 64, hipMemcpyDeviceToHost, s->st));
-    ZG_HIP(hipStreamSynchronize(s->st));
+    ZG_TRY(sc_wait_mailbox(s, h));
     for (int i = 0; i < 4; i++) {
         s0[i] = h[i];
         s2[i] = h[4 + i];
