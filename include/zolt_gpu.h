@@ -294,6 +294,36 @@ ZG_API int zg_run_sumcheck_dev(const uint64_t *d_evals, size_t len, void *stream
 ZG_API int zg_run_sumcheck(const uint64_t *evals, size_t len, uint64_t claim[4], uint64_t *rounds, uint64_t *challenges,
                            uint64_t final_eval[4], uint8_t *result);
 
+/* ------------------------------------------------------------------ product-form sumcheck sessions */
+/* The zkVM provers whose round polynomial is a sum over adjacent pairs of a PRODUCT of multilinear tables, all folded LowToHigh by
+ * the same challenge — ValEvaluationProver (src/zkvm/ram/val_evaluation.zig:554-628: inc * wa * lt), ValFinalProver
+ * (ram/val_final.zig:149-200: inc * wa), OutputSumcheckProver (ram/output_check.zig:375-470: eq * io * (vf - vio)),
+ * InstructionLookupsClaimReduction (claim_reductions/instruction_lookups.zig:146-240: eq * (out + gamma left + gamma^2 right)) and the
+ * Gruen-form ProductVirtualRemainderProver (spartan/product_remainder.zig:269-420: left * right under split-eq weights). A session keeps
+ * k <= 8 tables of `len` entries (a power of two) resident in HBM; the transcript, the claim update and the Gruen scalar algebra stay
+ * on the host. */
+typedef struct zg_psc_s *zg_psc_t;
+ZG_API int zg_psc_open(const uint64_t *const *tables /* k host pointers, len*4 words each */, size_t k, size_t len, zg_psc_t *s);
+ZG_API int zg_psc_open_dev(const uint64_t *const *d_tables /* host array of k device pointers */, size_t k, size_t len, void *stream,
+                    zg_psc_t *s); /* copies */
+ZG_API size_t zg_psc_len(zg_psc_t s);
+ZG_API size_t zg_psc_tables(zg_psc_t s);
+/* out[t] (t = 0..3, 4 words each) = sum over the pairs g of  prod_{j<p} T[prod_idx[j]](t) * L(t), where T(t) = T[2g] + t (T[2g+1] - T[2g])
+ * and L(t) = sum_{m<q} lin_coeff[m] * T[lin_idx[m]](t) (q = 0: L = 1). p, q <= 4, p + q >= 1. These are the reference's
+ * [p(0), p(1), p(2), p(3)] (val_evaluation.zig:554-603); provers that send fewer values drop the rest. */
+ZG_API int zg_psc_round_evals(zg_psc_t s, const int *prod_idx, size_t p, const int *lin_idx, const uint64_t *lin_coeff /* q*4 */, size_t q,
+                       uint64_t out[16]);
+/* Gruen's pair (product_remainder.zig:281-330): t0 = sum_g w(g) prod_j T_j[2g], t_inf = sum_g w(g) prod_j (T_j[2g+1] - T_j[2g]),
+ * w(g) = E_out[g >> log2|E_in|] * E_in[g & (|E_in| - 1)], pairs with g >> log2|E_in| >= |E_out| skipped. d_e_out / d_e_in: DEVICE
+ * pointers (e.g. into the buffer zg_fr_eq_prefix_tables_dev filled: table k starts at element 2^k - 1). */
+ZG_API int zg_psc_round_gruen(zg_psc_t s, const int *prod_idx, size_t p, const uint64_t *d_e_out, size_t n_out, const uint64_t *d_e_in,
+                       size_t n_in, uint64_t t0[4], uint64_t t_inf[4]);
+/* every table folded: T'[i] = (1 - r) T[2i] + r T[2i+1]; len -> len / 2 (val_evaluation.zig:609-628) */
+ZG_API int zg_psc_bind(zg_psc_t s, const uint64_t r[4]);
+ZG_API int zg_psc_read(zg_psc_t s, size_t table, uint64_t *out /* len*4 */);
+ZG_API int zg_psc_final(zg_psc_t s, uint64_t *out /* k*4: each table's single remaining entry */);
+ZG_API int zg_psc_close(zg_psc_t s);
+
 /* ------------------------------------------------------------------ several GPUs in one process */
 /* The bases (SRS) sharded over the bound devices in ParallelMSM's contiguous chunks of ceil(n / S) points
  * (src/msm/mod.zig:609,619-639), one resident table per device. */

@@ -592,3 +592,139 @@ def run_lasso_prover(lookup_indices_u128, log_T, log_K, r_reduction):
         rnd += 1
     return {"round_polys": np.stack(polys) if polys else np.zeros((0, 3, 4), dtype=np.uint64), "final_eval": p.getFinalEval(),
             "challenges": np.stack(p.challenges) if p.challenges else np.zeros((0, 4), dtype=np.uint64)}
+
+
+# ---- product-form zkVM provers (sumcheck loops only: tables in, round polynomials / claims / final values out)
+def interpolate_degree3(evals):
+    out = np.empty((4, 4), dtype=np.uint64)
+    lib.zo_interpolate_degree3(_p(_c(evals)), _p(out))
+    return out
+
+
+def evals_to_compressed(evals):
+    """UniPoly.evalsToCompressed (poly/mod.zig:682-685): [c0, c2, c3]"""
+    c = interpolate_degree3(evals)
+    return np.stack([c[0], c[2], c[3]])
+
+
+class ValEvaluationProver:
+    """ValEvaluationProver (src/zkvm/ram/val_evaluation.zig:545-660); lt=None: ValFinalProver (src/zkvm/ram/val_final.zig:144-230)"""
+
+    def __init__(self, inc, wa, lt, claim):
+        self.t = [_c(x).reshape(-1, 4).copy() for x in ((inc, wa) if lt is None else (inc, wa, lt))]
+        self.n = self.t[0].shape[0]
+        self.current_claim = _c(claim).copy()
+        self.round = 0
+
+    def computeRoundPolynomial(self):
+        out = np.empty((4, 4), dtype=np.uint64)
+        lt = self.t[2] if len(self.t) == 3 else None
+        lib.zo_val_evaluation_round(_p(self.t[0]), _p(self.t[1]), _p(lt), C.c_size_t(self.n), _p(out))
+        return out
+
+    def bindChallengeWithPoly(self, r, round_poly):
+        if self.n // 2 == 0:
+            self.round += 1
+            return
+        self.t = [fr_bind_low_2mul(x[:self.n], r) for x in self.t]  # (1-r)*lo + r*hi (:609-620)
+        self.n //= 2
+        self.current_claim = raf_update_claim(round_poly, r)  # the same cubic Lagrange step (:630-660)
+        self.round += 1
+
+    def getFinalClaims(self):
+        return [x[0].copy() for x in self.t]
+
+
+class OutputSumcheckProver:
+    """OutputSumcheckProver's loop (src/zkvm/ram/output_check.zig:375-499)"""
+
+    def __init__(self, eq_r_address, io_mask, val_final, val_io, val_init, claim):
+        self.t = [_c(x).reshape(-1, 4).copy() for x in (eq_r_address, io_mask, val_final, val_io, val_init)]
+        self.current_size = self.t[0].shape[0]
+        self.current_claim = _c(claim).copy()
+
+    def roundEvals(self):
+        out = np.empty((4, 4), dtype=np.uint64)
+        lib.zo_output_check_round(_p(self.t[0]), _p(self.t[1]), _p(self.t[2]), _p(self.t[3]), C.c_size_t(self.current_size), _p(out))
+        return out
+
+    def computeRoundPolynomial(self):
+        return evals_to_compressed(self.roundEvals())
+
+    def bindChallenge(self, r):
+        self.t = [fr_bind_low(x[:self.current_size], r) for x in self.t]
+        self.current_size //= 2
+
+    def updateClaim(self, evals, challenge):
+        out = np.empty(4, dtype=np.uint64)
+        lib.zo_output_check_update_claim(_p(_c(evals)), _p(_c(challenge)), _p(out))
+        self.current_claim = out
+
+    def getFinalClaims(self):
+        return {"val_final": self.t[2][0], "val_init": self.t[4][0], "val_io": self.t[3][0], "eq_r_address": self.t[0][0], "io_mask": self.t[1][0]}
+
+
+class InstructionLookupsClaimReduction:
+    """InstructionLookupsClaimReductionProver's loop (src/zkvm/claim_reductions/instruction_lookups.zig:146-284)"""
+
+    def __init__(self, eq_evals, lookup_outputs, left_operands, right_operands, gamma, claim):
+        self.t = [_c(x).reshape(-1, 4).copy() for x in (eq_evals, lookup_outputs, left_operands, right_operands)]
+        self.gamma = _c(gamma).copy()
+        self.current_claim = _c(claim).copy()
+        self.round = 0
+
+    def computeRoundPolynomialCubic(self):
+        out = np.empty((4, 4), dtype=np.uint64)
+        lib.zo_instruction_lookups_round(_p(self.t[0]), _p(self.t[1]), _p(self.t[2]), _p(self.t[3]), C.c_size_t(self.t[0].shape[0]),
+                                         _p(self.gamma), _p(self.current_claim), _p(out))
+        return out
+
+    def bindChallenge(self, challenge):
+        self.t = [fr_bind_low(x, challenge) for x in self.t]
+        self.round += 1
+
+    def updateClaim(self, evals, challenge):
+        self.current_claim = raf_update_claim(evals, challenge)
+
+    def getOpeningClaims(self):
+        return {"lookup_output": self.t[1][0], "left_operand": self.t[2][0], "right_operand": self.t[3][0]}
+
+
+class ProductRemainderProver:
+    """ProductVirtualRemainderProver's loop (src/zkvm/spartan/product_remainder.zig:269-394) over given fused left / right tables"""
+
+    def __init__(self, left_evals, right_evals, tau_low, lagrange_kernel, uni_skip_claim):
+        self.left = _c(left_evals).reshape(-1, 4).copy()
+        self.right = _c(right_evals).reshape(-1, 4).copy()
+        self.split_eq = GruenSplitEq(tau_low, lagrange_kernel)
+        self.current_claim = _c(uni_skip_claim).copy()
+        self.current_round = 0
+
+    def roundEvals(self):
+        n = self.left.shape[0]
+        if n // 2 == 0:
+            return None
+        e_out, e_in, _ = self.split_eq.getWindowEqTables(1)
+        t0, ti = np.empty(4, dtype=np.uint64), np.empty(4, dtype=np.uint64)
+        lib.zo_product_remainder_sums(_p(self.left), _p(self.right), C.c_size_t(n), _p(_c(e_out)), C.c_size_t(len(e_out)), _p(_c(e_in)),
+                                      C.c_size_t(len(e_in)), _p(t0), _p(ti))
+        return self.split_eq.computeCubicRoundPoly(t0, ti, self.current_claim)
+
+    def computeRoundPolynomial(self):
+        ev = self.roundEvals()
+        if ev is None:
+            z = np.zeros(4, dtype=np.uint64)
+            return np.stack([self.current_claim, z, z])
+        return evals_to_compressed(ev)
+
+    def bindChallenge(self, challenge):
+        self.left = fr_bind_low(self.left, challenge)
+        self.right = fr_bind_low(self.right, challenge)
+        self.split_eq.bind(challenge)
+        self.current_round += 1
+
+    def updateClaim(self, round_evals, challenge):
+        self.current_claim = raf_update_claim(round_evals, challenge)
+
+    def getFinalClaim(self):
+        return f_mul(FR, self.left[:1], self.right[:1])[0]

@@ -1193,3 +1193,145 @@ EXPORT void zo_lasso_derive_challenge(const uint64_t *coeffs, size_t ncoeffs, ui
     fe r = f_from_u64(&FR, hash);
     memcpy(out, &r, 32);
 }
+
+/* ---------------------------------------------------------- product-form prover rounds (zkvm) */
+/* UniPoly.interpolateDegree3 / evalsToCompressed — src/poly/mod.zig:632-685: [c0, c1, c2, c3] from p(0..3); compressed = [c0, c2, c3] */
+EXPORT void zo_interpolate_degree3(const uint64_t evals[16], uint64_t coeffs[16]) {
+    const fe *p = (const fe *)evals;
+    fe six = f_from_u64(&FR, 6), two = f_from_u64(&FR, 2), inv6, inv2, zero = f_zero();
+    (void)f_inv(&FR, &six, &inv6); (void)f_inv(&FR, &two, &inv2);
+    fe k11 = f_from_u64(&FR, 11), k18 = f_from_u64(&FR, 18), k9 = f_from_u64(&FR, 9), k5 = f_from_u64(&FR, 5), k4 = f_from_u64(&FR, 4),
+       k3 = f_from_u64(&FR, 3);
+    fe t, c1 = zero, c2, c3;
+    t = f_mul(&FR, &k11, &p[0]); c1 = f_sub(&FR, &c1, &t);
+    t = f_mul(&FR, &k18, &p[1]); c1 = f_add(&FR, &c1, &t);
+    t = f_mul(&FR, &k9, &p[2]); c1 = f_sub(&FR, &c1, &t);
+    t = f_mul(&FR, &two, &p[3]); c1 = f_add(&FR, &c1, &t);
+    c1 = f_mul(&FR, &c1, &inv6);
+    c2 = f_mul(&FR, &two, &p[0]);
+    t = f_mul(&FR, &k5, &p[1]); c2 = f_sub(&FR, &c2, &t);
+    t = f_mul(&FR, &k4, &p[2]); c2 = f_add(&FR, &c2, &t);
+    c2 = f_sub(&FR, &c2, &p[3]);
+    c2 = f_mul(&FR, &c2, &inv2);
+    c3 = f_sub(&FR, &zero, &p[0]);
+    t = f_mul(&FR, &k3, &p[1]); c3 = f_add(&FR, &c3, &t);
+    t = f_mul(&FR, &k3, &p[2]); c3 = f_sub(&FR, &c3, &t);
+    c3 = f_add(&FR, &c3, &p[3]);
+    c3 = f_mul(&FR, &c3, &inv6);
+    fe out[4] = {p[0], c1, c2, c3};
+    memcpy(coeffs, out, 128);
+}
+/* ValEvaluationProver.computeRoundPolynomial — src/zkvm/ram/val_evaluation.zig:554-603 (n = effectiveLen; lt == NULL: the two-table
+ * form of ValFinalProver.computeRoundPolynomial, src/zkvm/ram/val_final.zig:149-185) */
+EXPORT void zo_val_evaluation_round(const uint64_t *inc, const uint64_t *wa, const uint64_t *lt, size_t n, uint64_t evals[16]) {
+    fe e[4] = {f_zero(), f_zero(), f_zero(), f_zero()};
+    const fe *I = (const fe *)inc, *W = (const fe *)wa, *L = (const fe *)lt;
+    size_t half = n / 2;
+    if (half == 0) {
+        if (n > 0) { e[0] = f_mul(&FR, &I[0], &W[0]); if (L) e[0] = f_mul(&FR, &e[0], &L[0]); }
+        memcpy(evals, e, 128);
+        return;
+    }
+    fe two = f_from_u64(&FR, 2), three = f_from_u64(&FR, 3);
+    for (size_t i = 0; i < half; i++) {
+        const fe *t[3] = {I, W, L};
+        fe v[4];
+        for (int k = 0; k < (L ? 3 : 2); k++) {
+            fe f0 = t[k][2 * i], f1 = t[k][2 * i + 1];
+            fe a = f_mul(&FR, &two, &f1), f2 = f_sub(&FR, &a, &f0);            /* two.mul(f_1).sub(f_0) */
+            fe b = f_mul(&FR, &three, &f1), c = f_mul(&FR, &two, &f0), f3 = f_sub(&FR, &b, &c);  /* three.mul(f_1).sub(two.mul(f_0)) */
+            fe f[4] = {f0, f1, f2, f3};
+            for (int x = 0; x < 4; x++) v[x] = k == 0 ? f[x] : f_mul(&FR, &v[x], &f[x]);
+        }
+        for (int x = 0; x < 4; x++) e[x] = f_add(&FR, &e[x], &v[x]);
+    }
+    memcpy(evals, e, 128);
+}
+/* OutputSumcheckProver.computeRoundPolynomial's s(0..3) — src/zkvm/ram/output_check.zig:375-430 */
+EXPORT void zo_output_check_round(const uint64_t *eq, const uint64_t *io, const uint64_t *vf, const uint64_t *vio, size_t current_size,
+                                  uint64_t evals[16]) {
+    fe s[4] = {f_zero(), f_zero(), f_zero(), f_zero()};
+    const fe *E = (const fe *)eq, *IO = (const fe *)io, *VF = (const fe *)vf, *VIO = (const fe *)vio;
+    for (size_t g = 0; g < current_size / 2; g++) {
+        size_t i0 = 2 * g, i1 = 2 * g + 1;
+        fe v0 = f_sub(&FR, &VF[i0], &VIO[i0]), v1 = f_sub(&FR, &VF[i1], &VIO[i1]);
+        fe deq = f_sub(&FR, &E[i1], &E[i0]), dio = f_sub(&FR, &IO[i1], &IO[i0]), dv = f_sub(&FR, &v1, &v0);
+        fe p0 = f_mul(&FR, &E[i0], &IO[i0]); p0 = f_mul(&FR, &p0, &v0);
+        fe p1 = f_mul(&FR, &E[i1], &IO[i1]); p1 = f_mul(&FR, &p1, &v1);
+        fe eq2 = f_add(&FR, &E[i0], &deq); eq2 = f_add(&FR, &eq2, &deq);
+        fe io2 = f_add(&FR, &IO[i0], &dio); io2 = f_add(&FR, &io2, &dio);
+        fe v2 = f_add(&FR, &v0, &dv); v2 = f_add(&FR, &v2, &dv);
+        fe p2 = f_mul(&FR, &eq2, &io2); p2 = f_mul(&FR, &p2, &v2);
+        fe eq3 = f_add(&FR, &eq2, &deq), io3 = f_add(&FR, &io2, &dio), v3 = f_add(&FR, &v2, &dv);
+        fe p3 = f_mul(&FR, &eq3, &io3); p3 = f_mul(&FR, &p3, &v3);
+        s[0] = f_add(&FR, &s[0], &p0); s[1] = f_add(&FR, &s[1], &p1); s[2] = f_add(&FR, &s[2], &p2); s[3] = f_add(&FR, &s[3], &p3);
+    }
+    memcpy(evals, s, 128);
+}
+/* OutputSumcheckProver.updateClaim — :482-499 with lagrangeC2 / lagrangeC3 (:523-548): c0 + c1 r + c2 r^2 + c3 r^3 */
+EXPORT void zo_output_check_update_claim(const uint64_t evals[16], const uint64_t challenge[4], uint64_t out[4]) {
+    const fe *e = (const fe *)evals;
+    fe r = *(const fe *)challenge, r2 = f_mul(&FR, &r, &r), r3 = f_mul(&FR, &r2, &r);
+    fe two = f_from_u64(&FR, 2), four = f_from_u64(&FR, 4), five = f_from_u64(&FR, 5), three = f_from_u64(&FR, 3), six = f_from_u64(&FR, 6);
+    fe half, sixth, zero = f_zero();
+    (void)f_inv(&FR, &two, &half); (void)f_inv(&FR, &six, &sixth);
+    fe t, c2 = f_mul(&FR, &e[0], &two);
+    t = f_mul(&FR, &e[1], &five); c2 = f_sub(&FR, &c2, &t);
+    t = f_mul(&FR, &e[2], &four); c2 = f_add(&FR, &c2, &t);
+    c2 = f_sub(&FR, &c2, &e[3]); c2 = f_mul(&FR, &c2, &half);
+    fe c3 = f_sub(&FR, &zero, &e[0]);                        /* (-s(0) + 3 s(1) - 3 s(2) + s(3)) / 6 */
+    t = f_mul(&FR, &e[1], &three); c3 = f_add(&FR, &c3, &t);
+    t = f_mul(&FR, &e[2], &three); c3 = f_sub(&FR, &c3, &t);
+    c3 = f_add(&FR, &c3, &e[3]); c3 = f_mul(&FR, &c3, &sixth);
+    fe c1 = f_sub(&FR, &e[1], &e[0]); c1 = f_sub(&FR, &c1, &c2); c1 = f_sub(&FR, &c1, &c3);
+    fe res = e[0];
+    t = f_mul(&FR, &c1, &r); res = f_add(&FR, &res, &t);
+    t = f_mul(&FR, &c2, &r2); res = f_add(&FR, &res, &t);
+    t = f_mul(&FR, &c3, &r3); res = f_add(&FR, &res, &t);
+    memcpy(out, &res, 32);
+}
+/* InstructionLookupsClaimReduction.computeRoundPolynomialCubic — src/zkvm/claim_reductions/instruction_lookups.zig:146-200 */
+EXPORT void zo_instruction_lookups_round(const uint64_t *eq, const uint64_t *lookup_outputs, const uint64_t *left, const uint64_t *right,
+                                         size_t current_len, const uint64_t gamma[4], const uint64_t current_claim[4], uint64_t evals[16]) {
+    const fe *E = (const fe *)eq, *O = (const fe *)lookup_outputs, *L = (const fe *)left, *R = (const fe *)right;
+    fe g = *(const fe *)gamma, g2 = f_mul(&FR, &g, &g), s0 = f_zero(), s2 = f_zero();
+    for (size_t idx = 0; idx < current_len / 2; idx++) {
+        size_t lo = 2 * idx, hi = 2 * idx + 1;
+        fe a = f_mul(&FR, &g, &L[lo]), b = f_mul(&FR, &g2, &R[lo]), clo = f_add(&FR, &O[lo], &a); clo = f_add(&FR, &clo, &b);
+        a = f_mul(&FR, &g, &L[hi]); b = f_mul(&FR, &g2, &R[hi]);
+        fe chi = f_add(&FR, &O[hi], &a); chi = f_add(&FR, &chi, &b);
+        fe prod0 = f_mul(&FR, &E[lo], &clo);
+        fe eq2 = f_add(&FR, &E[hi], &E[hi]); eq2 = f_sub(&FR, &eq2, &E[lo]);
+        fe c2 = f_add(&FR, &chi, &chi); c2 = f_sub(&FR, &c2, &clo);
+        fe prod2 = f_mul(&FR, &eq2, &c2);
+        s0 = f_add(&FR, &s0, &prod0); s2 = f_add(&FR, &s2, &prod2);
+    }
+    fe three = f_from_u64(&FR, 3), s1 = f_sub(&FR, (const fe *)current_claim, &s0);
+    fe a = f_mul(&FR, &s1, &three), b = f_mul(&FR, &s2, &three), s3 = f_sub(&FR, &s0, &a); s3 = f_add(&FR, &s3, &b);
+    fe out[4] = {s0, s1, s2, s3};
+    memcpy(evals, out, 128);
+}
+/* ProductVirtualRemainderProver.computeRoundPolynomial's t0 / t_inf — src/zkvm/spartan/product_remainder.zig:281-330 */
+EXPORT void zo_product_remainder_sums(const uint64_t *left, const uint64_t *right, size_t n, const uint64_t *e_out, size_t n_out,
+                                      const uint64_t *e_in, size_t n_in, uint64_t t0[4], uint64_t t_inf[4]) {
+    const fe *Lf = (const fe *)left, *Rt = (const fe *)right, *EO = (const fe *)e_out, *EI = (const fe *)e_in;
+    size_t num_groups = n / 2;
+    unsigned bits = 0;
+    if (n_in > 1) while (((size_t)1 << bits) < n_in) bits++;
+    fe t0s = f_zero(), tis = f_zero();
+    for (size_t xo = 0; xo < n_out; xo++) {
+        fe i0 = f_zero(), ii = f_zero();
+        for (size_t xi = 0; xi < n_in; xi++) {
+            size_t g = (xo << bits) | xi;
+            if (g < num_groups) {
+                fe p0 = f_mul(&FR, &Lf[2 * g], &Rt[2 * g]);
+                fe dl = f_sub(&FR, &Lf[2 * g + 1], &Lf[2 * g]), dr = f_sub(&FR, &Rt[2 * g + 1], &Rt[2 * g]), sl = f_mul(&FR, &dl, &dr);
+                fe a = f_mul(&FR, &p0, &EI[xi]), b = f_mul(&FR, &sl, &EI[xi]);
+                i0 = f_add(&FR, &i0, &a); ii = f_add(&FR, &ii, &b);
+            }
+        }
+        fe a = f_mul(&FR, &i0, &EO[xo]), b = f_mul(&FR, &ii, &EO[xo]);
+        t0s = f_add(&FR, &t0s, &a); tis = f_add(&FR, &tis, &b);
+    }
+    memcpy(t0, &t0s, 32); memcpy(t_inf, &tis, 32);
+}

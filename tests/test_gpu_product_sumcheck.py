@@ -1,0 +1,237 @@
+"""Product-form sumcheck sessions (zg_psc_*) and the prover loops that sit on them — ValEvaluationProver
+(src/zkvm/ram/val_evaluation.zig:545-700), ValFinalProver (ram/val_final.zig:144-230), OutputSumcheckProver (ram/output_check.zig:375-499),
+InstructionLookupsClaimReductionProver (claim_reductions/instruction_lookups.zig:146-284), ProductVirtualRemainderProver
+(spartan/product_remainder.zig:269-394) — device path against the oracle's restatement of each loop, bit for bit."""
+import numpy as np
+import pytest
+
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    from oracle import binding as ob
+    from zolt_amd import api, lib
+    lib.init()
+    return api, lib, ob
+
+
+def _rand(ob, seed, n, sparse=False):
+    a = ob.f_to_mont(ob.FR, U.random_raw256(seed, n))
+    if sparse and n:
+        a[U.splitmix64(seed + 7, n) % np.uint64(3) == 0] = 0
+    return a
+
+
+def _claim_of(api, tables_int):
+    acc = 0
+    for row in zip(*tables_int):
+        p = 1
+        for v in row:
+            p = p * v % api.R_MOD
+        acc = (acc + p) % api.R_MOD
+    return acc
+
+
+@pytest.mark.parametrize("p,q", [(1, 0), (2, 0), (3, 0), (4, 0), (0, 1), (0, 3), (1, 3), (2, 2), (3, 1), (4, 4)])
+def test_round_evals_against_big_int_model(env, p, q):
+    """zg_psc_round_evals at every (p, q) shape against plain Python integers, then a fold, then the evaluations again"""
+    api, lib, ob = env
+    P = api.R_MOD
+    k, n = 8, 64
+    tabs = [_rand(ob, 7000 + 10 * p + q + j, n, sparse=(j % 3 == 1)) for j in range(k)]
+    ints = [[api.fr_to_int(x) for x in t] for t in tabs]
+    prod_idx = [(3 * j + 1) % k for j in range(p)]
+    lin_idx = [(5 * m + 2) % k for m in range(q)]
+    coeff = _rand(ob, 7100 + p + q, max(q, 1))[:q]
+    cint = [api.fr_to_int(c) for c in coeff]
+    s = lib.ProductSumcheckSession.open(tabs)
+    assert len(s) == n and s.tables() == k
+    for rnd in range(3):
+        half = len(s) // 2
+        want = []
+        for t in range(4):
+            acc = 0
+            for g in range(half):
+                f = lambda T: (T[2 * g] + t * (T[2 * g + 1] - T[2 * g])) % P
+                v = 1
+                for j in prod_idx:
+                    v = v * f(ints[j]) % P
+                if q:
+                    v = v * (sum(c * f(ints[m]) for c, m in zip(cint, lin_idx)) % P) % P
+                acc = (acc + v) % P
+            want.append(acc)
+        got = s.round_evals(prod_idx, lin_idx, coeff if q else None)
+        assert [api.fr_to_int(x) for x in got] == want, (p, q, rnd)
+        r = _rand(ob, 7200 + rnd, 1)[0]
+        ri = api.fr_to_int(r)
+        s.bind(r)
+        ints = [[(T[2 * i] + ri * (T[2 * i + 1] - T[2 * i])) % P for i in range(half)] for T in ints]
+        for j in (0, k - 1):
+            assert [api.fr_to_int(x) for x in s.read(j)] == ints[j]
+    s.close()
+
+
+def test_session_edges_and_errors(env):
+    api, lib, ob = env
+    t = _rand(ob, 7300, 2)
+    s = lib.ProductSumcheckSession.open([t, t])
+    with pytest.raises(RuntimeError):
+        s.round_evals((0, 2))  # table index out of range
+    with pytest.raises(RuntimeError):
+        s.round_evals(())  # p + q == 0
+    with pytest.raises(RuntimeError):
+        s.final()  # two entries left
+    s.bind(t[0])
+    assert len(s) == 1
+    f = s.final()
+    assert np.array_equal(f[0], ob.fr_bind_low(t, t[0])[0]) and np.array_equal(f[0], f[1])
+    with pytest.raises(RuntimeError):
+        s.bind(t[0])
+    with pytest.raises(RuntimeError):
+        s.round_evals((0, 1))
+    s.close()
+    with pytest.raises(RuntimeError):
+        lib.ProductSumcheckSession.open([_rand(ob, 7301, 3)])  # not a power of two
+    with pytest.raises(RuntimeError):
+        lib.ProductSumcheckSession.open([t] * 9)
+    # device-pointer open: the same session contents
+    d = [lib.DeviceBuffer.from_host(x) for x in (_rand(ob, 7302, 32), _rand(ob, 7303, 32))]
+    s = lib.ProductSumcheckSession.open_dev([b.ptr for b in d], 32)
+    assert np.array_equal(s.read(1), d[1].to_host().reshape(-1, 4))
+    s.close()
+    for b in d:
+        b.free()
+
+
+@pytest.mark.parametrize("v", [0, 1, 2, 5, 10, 14])
+@pytest.mark.parametrize("three", [True, False])
+def test_val_evaluation_and_val_final_provers(env, v, three):
+    api, lib, ob = env
+    n = 1 << v
+    inc, wa = _rand(ob, 7400 + v, n, sparse=True), _rand(ob, 7410 + v, n)
+    lt = _rand(ob, 7420 + v, n) if three else None
+    claim = _rand(ob, 7430 + v, 1)[0]
+    g = api.ValEvaluationProver(inc, wa, lt, claim) if three else api.ValFinalProver(inc, wa, claim)
+    o = ob.ValEvaluationProver(inc, wa, lt, claim)
+    ch = _rand(ob, 7440 + v, v + 1)
+    for rnd in range(v + 1):  # one call past the last round: the single-entry branch (:559-565) and the no-op bind (:611-614)
+        rp, wrp = g.computeRoundPolynomial(), o.computeRoundPolynomial()
+        assert np.array_equal(rp, wrp), rnd
+        g.bindChallengeWithPoly(ch[rnd], rp)
+        o.bindChallengeWithPoly(ch[rnd], wrp)
+        assert np.array_equal(g.current_claim, o.current_claim) and g.effectiveLen() == o.n
+    for a, b in zip(g.getFinalClaims(), o.getFinalClaims()):
+        assert np.array_equal(a, b)
+    g.deinit()
+
+
+@pytest.mark.parametrize("v", [1, 2, 6, 12, 16])
+def test_output_sumcheck_prover(env, v):
+    api, lib, ob = env
+    n = 1 << v
+    tabs = [_rand(ob, 7500 + 10 * j + v, n, sparse=(j == 1)) for j in range(5)]
+    claim = _rand(ob, 7560 + v, 1)[0]
+    g, o = api.OutputSumcheckProver(*tabs, claim), ob.OutputSumcheckProver(*tabs, claim)
+    ch = _rand(ob, 7570 + v, v)
+    for rnd in range(v):
+        ev, wev = g.roundEvals(), o.roundEvals()
+        assert np.array_equal(ev, wev), rnd
+        assert np.array_equal(g.computeRoundPolynomial(), o.computeRoundPolynomial())
+        g.bindChallenge(ch[rnd]); o.bindChallenge(ch[rnd])
+        g.updateClaim(ev, ch[rnd]); o.updateClaim(wev, ch[rnd])
+        assert np.array_equal(g.current_claim, o.current_claim) and g.current_size == o.current_size
+    fg, fo = g.getFinalClaims(), o.getFinalClaims()
+    assert all(np.array_equal(fg[k], fo[k]) for k in fo)
+    g.deinit()
+
+
+@pytest.mark.parametrize("v", [1, 3, 8, 13, 16])
+def test_instruction_lookups_claim_reduction_prover(env, v):
+    """with a consistent initial claim the s(0) + s(1) = claim chain holds through every round, as in the reference's run"""
+    api, lib, ob = env
+    n = 1 << v
+    tabs = [_rand(ob, 7600 + 10 * j + v, n) for j in range(4)]
+    gamma = _rand(ob, 7650 + v, 1)[0]
+    gi = api.fr_to_int(gamma)
+    if v <= 8:
+        ints = [[api.fr_to_int(x) for x in t] for t in tabs]
+        comb = [(o + gi * l + gi * gi * r) % api.R_MOD for o, l, r in zip(ints[1], ints[2], ints[3])]
+        claim = api.fr_from_int(_claim_of(api, [ints[0], comb]))
+    else:
+        claim = _rand(ob, 7660 + v, 1)[0]
+    g = api.InstructionLookupsClaimReductionProver(*tabs, gamma, claim)
+    o = ob.InstructionLookupsClaimReduction(*tabs, gamma, claim)
+    ch = _rand(ob, 7670 + v, v)
+    for rnd in range(v):
+        ev, wev = g.computeRoundPolynomialCubic(), o.computeRoundPolynomialCubic()
+        assert np.array_equal(ev, wev), rnd
+        g.bindChallenge(ch[rnd]); o.bindChallenge(ch[rnd])
+        g.updateClaim(ev, ch[rnd]); o.updateClaim(wev, ch[rnd])
+        assert np.array_equal(g.current_claim, o.current_claim)
+    fg, fo = g.getOpeningClaims(), o.getOpeningClaims()
+    assert all(np.array_equal(fg[k], fo[k]) for k in fo)
+    if v <= 8:  # final claim = eq(r) * combined(r): the protocol was sound end to end
+        f = g._s.final()
+        fin = api.fr_to_int(f[0]) * (api.fr_to_int(f[1]) + gi * api.fr_to_int(f[2]) + gi * gi * api.fr_to_int(f[3])) % api.R_MOD
+        assert fin == api.fr_to_int(g.current_claim)
+    g.deinit()
+
+
+@pytest.mark.parametrize("v", [1, 2, 3, 7, 8, 13, 16])
+def test_product_virtual_remainder_prover(env, v):
+    """Gruen form: device (t0, t_inf) under device-resident split-eq prefix tables + host cubic, against the oracle's nested loops"""
+    api, lib, ob = env
+    n = 1 << v
+    left, right = _rand(ob, 7700 + v, n, sparse=True), _rand(ob, 7710 + v, n)
+    tau, kernel = _rand(ob, 7720 + v, v), _rand(ob, 7730 + v, 1)[0]
+    if v <= 8:  # consistent claim: sum_x eq(tau, x) * kernel * left * right
+        eq = ob.fr_eq_table(tau, kernel)
+        claim = api.fr_from_int(_claim_of(api, [[api.fr_to_int(x) for x in t] for t in (left, right, eq)]))
+    else:
+        claim = _rand(ob, 7740 + v, 1)[0]
+    g, o = api.ProductVirtualRemainderProver(left, right, tau, kernel, claim), ob.ProductRemainderProver(left, right, tau, kernel, claim)
+    ch = _rand(ob, 7750 + v, v)
+    for rnd in range(v):
+        ev, wev = g.roundEvals(), o.roundEvals()
+        assert np.array_equal(ev, wev), rnd
+        assert np.array_equal(g.computeRoundPolynomial(), o.computeRoundPolynomial())
+        if v <= 8:
+            assert (api.fr_to_int(ev[0]) + api.fr_to_int(ev[1])) % api.R_MOD == api.fr_to_int(g.current_claim)
+        g.bindChallenge(ch[rnd]); o.bindChallenge(ch[rnd])
+        g.updateClaim(ev, ch[rnd]); o.updateClaim(wev, ch[rnd])
+        assert np.array_equal(g.current_claim, o.current_claim)
+    assert np.array_equal(g.getFinalClaim(), o.getFinalClaim())
+    assert np.array_equal(g.computeRoundPolynomial(), o.computeRoundPolynomial())  # no groups left: [claim, 0, 0]
+    if v <= 8:
+        assert api.fr_to_int(g.getFinalClaim()) * api.fr_to_int(g.split_eq.current_scalar) % api.R_MOD == api.fr_to_int(g.current_claim)
+    g.deinit()
+
+
+def test_gruen_round_direct(env):
+    """zg_psc_round_gruen with p = 1, 3 and an E_out shorter than the pairs (the reference's g < num_groups / x_out < |E_out| guards)"""
+    api, lib, ob = env
+    P = api.R_MOD
+    n = 64
+    tabs = [_rand(ob, 7800 + j, n) for j in range(3)]
+    ints = [[api.fr_to_int(x) for x in t] for t in tabs]
+    e_out, e_in = _rand(ob, 7810, 4), _rand(ob, 7811, 4)  # 16 weights for 32 pairs: pairs 16..31 are outside
+    d_out, d_in = lib.DeviceBuffer.from_host(e_out), lib.DeviceBuffer.from_host(e_in)
+    s = lib.ProductSumcheckSession.open(tabs)
+    for idx in ((1,), (0, 1, 2)):
+        t0, ti = s.round_gruen(idx, d_out.ptr, 4, d_in.ptr, 4)
+        w0 = wi = 0
+        for g in range(16):
+            w = api.fr_to_int(e_out[g >> 2]) * api.fr_to_int(e_in[g & 3]) % P
+            a = b = w
+            for j in idx:
+                a = a * ints[j][2 * g] % P
+                b = b * (ints[j][2 * g + 1] - ints[j][2 * g]) % P
+            w0, wi = (w0 + a) % P, (wi + b) % P
+        assert api.fr_to_int(t0) == w0 and api.fr_to_int(ti) == wi
+    with pytest.raises(RuntimeError):
+        s.round_gruen((0,), d_out.ptr, 4, d_in.ptr, 3)  # |E_in| not a power of two
+    s.close()
+    d_out.free(); d_in.free()

@@ -442,3 +442,76 @@ def test_lasso_prover_oracle_reference_inline_tests_and_bigint_model():
     for ch in chal[:log_K]:
         fin = fin * (1 - ch) % P
     assert to_int(lp.getFinalEval()) == fin
+
+
+def test_product_form_prover_oracles_are_sound_sumchecks():
+    """The oracle's restatements of the product-form prover loops (ValEvaluation / ValFinal val_evaluation.zig:554-660, OutputCheck
+    output_check.zig:375-499, InstructionLookups claim reduction instruction_lookups.zig:146-270, ProductVirtualRemainder
+    product_remainder.zig:269-394) run as sumchecks with a consistent initial claim (a big-int sum over the hypercube): every round
+    satisfies s(0) + s(1) = claim, and the final claim equals the expression of the tables' final values — so the restated
+    formulas (extrapolations, Lagrange / Vandermonde steps, Gruen's cubic) are pinned by the protocol's own algebra."""
+    P = pm.R_MOD
+    rng = np.random.default_rng(11)
+    to_int = lambda a: pm.from_mont(pm.from_limbs(a), P)
+    to_mont = lambda v: ob.f_to_mont(FR, np.array([[(v >> (64 * i)) & (2**64 - 1) for i in range(4)]], dtype=np.uint64))[0]
+    rnd = lambda n: ob.f_to_mont(FR, rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64))
+    v, n = 5, 32
+    for three in (True, False):
+        inc, wa, lt = rnd(n), rnd(n), (rnd(n) if three else None)
+        cols = [[to_int(x) for x in t] for t in ((inc, wa, lt) if three else (inc, wa))]
+        claim = 0
+        for row in zip(*cols):
+            t = 1
+            for x in row:
+                t = t * x % P
+            claim = (claim + t) % P
+        p = ob.ValEvaluationProver(inc, wa, lt, to_mont(claim))
+        for _ in range(v):
+            ev = p.computeRoundPolynomial()
+            assert (to_int(ev[0]) + to_int(ev[1])) % P == to_int(p.current_claim)
+            p.bindChallengeWithPoly(rnd(1)[0], ev)
+        fin = 1
+        for x in p.getFinalClaims():
+            fin = fin * to_int(x) % P
+        assert fin == to_int(p.current_claim)
+    tabs = [rnd(n) for _ in range(5)]
+    I = [[to_int(x) for x in t] for t in tabs]
+    claim = sum(I[0][j] * I[1][j] * (I[2][j] - I[3][j]) for j in range(n)) % P
+    p = ob.OutputSumcheckProver(*tabs, to_mont(claim))
+    for _ in range(v):
+        ev = p.roundEvals()
+        assert (to_int(ev[0]) + to_int(ev[1])) % P == to_int(p.current_claim)
+        c = ob.interpolate_degree3(ev)  # the Vandermonde inverse reproduces the evaluations
+        ci = [to_int(x) for x in c]
+        assert [sum(ci[k] * t**k for k in range(4)) % P for t in range(4)] == [to_int(x) for x in ev]
+        assert np.array_equal(p.computeRoundPolynomial(), np.stack([c[0], c[2], c[3]]))
+        ch = rnd(1)[0]
+        p.bindChallenge(ch)
+        p.updateClaim(ev, ch)
+        assert np.array_equal(p.current_claim, ob.raf_update_claim(ev, ch))  # both claim-update forms agree
+    f = p.getFinalClaims()
+    assert to_int(f["eq_r_address"]) * to_int(f["io_mask"]) * (to_int(f["val_final"]) - to_int(f["val_io"])) % P == to_int(p.current_claim)
+    tabs = [rnd(n) for _ in range(4)]
+    I = [[to_int(x) for x in t] for t in tabs]
+    gamma = rnd(1)[0]
+    g = to_int(gamma)
+    claim = sum(I[0][j] * (I[1][j] + g * I[2][j] + g * g * I[3][j]) for j in range(n)) % P
+    p = ob.InstructionLookupsClaimReduction(*tabs, gamma, to_mont(claim))
+    for _ in range(v):
+        ev = p.computeRoundPolynomialCubic()
+        ch = rnd(1)[0]
+        p.bindChallenge(ch)
+        p.updateClaim(ev, ch)
+    f = p.getOpeningClaims()
+    assert to_int(p.t[0][0]) * (to_int(f["lookup_output"]) + g * to_int(f["left_operand"]) + g * g * to_int(f["right_operand"])) % P == to_int(p.current_claim)
+    left, right, tau, kernel = rnd(n), rnd(n), rnd(v), rnd(1)[0]
+    eq = ob.fr_eq_table(tau, kernel)
+    claim = sum(to_int(a) * to_int(b) * to_int(c) for a, b, c in zip(left, right, eq)) % P
+    p = ob.ProductRemainderProver(left, right, tau, kernel, to_mont(claim))
+    for _ in range(v):
+        ev = p.roundEvals()
+        assert (to_int(ev[0]) + to_int(ev[1])) % P == to_int(p.current_claim)
+        ch = rnd(1)[0]
+        p.bindChallenge(ch)
+        p.updateClaim(ev, ch)
+    assert to_int(p.getFinalClaim()) * to_int(p.split_eq.current_scalar) % P == to_int(p.current_claim)

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HDR = os.path.join(ROOT, "include", "zolt_gpu.h")
 OUT = os.path.join(ROOT, "zig", "gpu", "ffi.zig")
 
-HANDLES = {"zg_bases_t": "Bases", "zg_sc_t": "Session", "zg_sbases_t": "ShardedBases", "zg_ssc_t": "ShardedSession"}
+HANDLES = {"zg_bases_t": "Bases", "zg_sc_t": "Session", "zg_sbases_t": "ShardedBases", "zg_ssc_t": "ShardedSession", "zg_psc_t": "ProductSession"}
 SCALARS = {"int": "c_int", "unsigned": "c_uint", "size_t": "usize", "uint64_t": "u64", "uint8_t": "u8", "double": "f64"}
 
 
@@ -89,6 +89,7 @@ def generate():
         "pub const Session = ?*opaque {}; // zg_sc_t",
         "pub const ShardedBases = ?*opaque {}; // zg_sbases_t",
         "pub const ShardedSession = ?*opaque {}; // zg_ssc_t",
+        "pub const ProductSession = ?*opaque {}; // zg_psc_t",
         "",
         "pub const MsmConfig = extern struct { window_bits: c_int = 0, precompute_levels: c_int = 0, expected_uses: c_int = 0 };",
         "",

@@ -10,6 +10,7 @@ pub const Bases = ?*opaque {}; // zg_bases_t
 pub const Session = ?*opaque {}; // zg_sc_t
 pub const ShardedBases = ?*opaque {}; // zg_sbases_t
 pub const ShardedSession = ?*opaque {}; // zg_ssc_t
+pub const ProductSession = ?*opaque {}; // zg_psc_t
 
 pub const MsmConfig = extern struct { window_bits: c_int = 0, precompute_levels: c_int = 0, expected_uses: c_int = 0 };
 
@@ -94,6 +95,16 @@ pub extern fn zg_fr_bit_split_sums(vals: ?[*]const u64, idx128: ?[*]const u64, n
 pub extern fn zg_fr_bit_split_sums_dev(d_vals: ?[*]const u64, d_idx128: ?[*]const u64, n: usize, bit: c_uint, stream: ?*anyopaque, sum0: *[4]u64, sum1: *[4]u64) c_int;
 pub extern fn zg_run_sumcheck_dev(d_evals: ?[*]const u64, len: usize, stream: ?*anyopaque, claim: *[4]u64, rounds: ?[*]u64, challenges: ?[*]u64, final_eval: *[4]u64, result: ?[*]u8) c_int;
 pub extern fn zg_run_sumcheck(evals: ?[*]const u64, len: usize, claim: *[4]u64, rounds: ?[*]u64, challenges: ?[*]u64, final_eval: *[4]u64, result: ?[*]u8) c_int;
+pub extern fn zg_psc_open(tables: ?[*]const ?[*]const u64, k: usize, len: usize, s: *ProductSession) c_int;
+pub extern fn zg_psc_open_dev(d_tables: ?[*]const ?[*]const u64, k: usize, len: usize, stream: ?*anyopaque, s: *ProductSession) c_int;
+pub extern fn zg_psc_len(s: ProductSession) usize;
+pub extern fn zg_psc_tables(s: ProductSession) usize;
+pub extern fn zg_psc_round_evals(s: ProductSession, prod_idx: ?[*]const c_int, p: usize, lin_idx: ?[*]const c_int, lin_coeff: ?[*]const u64, q: usize, out: *[16]u64) c_int;
+pub extern fn zg_psc_round_gruen(s: ProductSession, prod_idx: ?[*]const c_int, p: usize, d_e_out: ?[*]const u64, n_out: usize, d_e_in: ?[*]const u64, n_in: usize, t0: *[4]u64, t_inf: *[4]u64) c_int;
+pub extern fn zg_psc_bind(s: ProductSession, r: *const [4]u64) c_int;
+pub extern fn zg_psc_read(s: ProductSession, table: usize, out: ?[*]u64) c_int;
+pub extern fn zg_psc_final(s: ProductSession, out: ?[*]u64) c_int;
+pub extern fn zg_psc_close(s: ProductSession) c_int;
 pub extern fn zg_shard_bounds(n: usize, shards: c_int, shard: c_int, start: ?*usize, len: ?*usize) c_int;
 pub extern fn zg_g1_bases_upload_sharded(xy: ?[*]const u64, inf: ?[*]const u8, n: usize, cfg: ?*const MsmConfig, out: *ShardedBases) c_int;
 pub extern fn zg_g1_sbases_free(sb: ShardedBases) c_int;

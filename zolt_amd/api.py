@@ -496,6 +496,7 @@ class GruenSplitEqPolynomial:
         self.num_x_in = min(n - 1 - m, n - 1) if n > 1 else 0
         self.E_out_vec = list(lib.fr_eq_prefix_tables(self.tau[:m]))
         self.E_in_vec = list(lib.fr_eq_prefix_tables(self.tau[m:m + self.num_x_in]))
+        self._d_out = self._d_in = None  # the same table sets in HBM, built on first use by getWindowEqTablesDev
 
     init = classmethod(lambda cls, tau: cls(tau))
     initWithScaling = classmethod(lambda cls, tau, scaling_factor: cls(tau, scaling_factor))
@@ -534,6 +535,29 @@ class GruenSplitEqPolynomial:
         e_out = self.E_out_vec[head_out_bits] if head_out_bits < len(self.E_out_vec) else self.E_out_vec[-1]
         e_in = self.E_in_vec[head_in_bits] if head_in_bits < len(self.E_in_vec) else self.E_in_vec[-1]
         return e_out, e_in, head_in_bits
+
+    def getWindowEqTablesDev(self, window_size):
+        """getWindowEqTables for device consumers (zg_psc_round_gruen): (d_E_out, |E_out|, d_E_in, |E_in|) — pointers into the two
+        prefix-table buffers zg_fr_eq_prefix_tables_dev filled (table k starts at element 2^k - 1); bind()'s pops only shorten the lists."""
+        if self._d_out is None:
+            m = self.tau.shape[0] // 2
+            self._d_out = lib.DeviceBuffer(((2 << m) - 1) * 32)
+            self._d_in = lib.DeviceBuffer(((2 << self.num_x_in) - 1) * 32)
+            lib.fr_eq_prefix_tables_dev(self.tau[:m], self._d_out.ptr)
+            lib.fr_eq_prefix_tables_dev(self.tau[m:m + self.num_x_in], self._d_in.ptr)
+        num_unbound = self.current_index
+        head_len = max(num_unbound - min(window_size, num_unbound), 0)
+        head_out_bits = min(head_len, self.tau.shape[0] // 2)
+        head_in_bits = max(head_len - head_out_bits, 0)
+        ko = min(head_out_bits, len(self.E_out_vec) - 1)
+        ki = min(head_in_bits, len(self.E_in_vec) - 1)
+        return self._d_out.ptr + ((1 << ko) - 1) * 32, 1 << ko, self._d_in.ptr + ((1 << ki) - 1) * 32, 1 << ki
+
+    def deinit(self):
+        for b in (self._d_out, self._d_in):
+            if b is not None:
+                b.free()
+        self._d_out = self._d_in = None
 
     def getCurrentEqFactors(self):
         """getCurrentEqFactors (:441-452) -> (eq_0, eq_1)"""
@@ -1076,6 +1100,200 @@ class LassoAddressRounds:
     def deinit(self):
         self._eq.free()
         self._idx.free()
+
+
+def cubicAtPoint(evals, challenge):
+    """Lagrange interpolation through evals at 0,1,2,3, evaluated at the challenge — the claim update every cubic prover repeats
+    (val_evaluation.zig:630-660, instruction_lookups.zig:250-270, product_remainder.zig:534-559)"""
+    c = fr_to_int(challenge)
+    e = [fr_to_int(x) for x in evals]
+    inv = lambda x: pow(x % R_MOD, -1, R_MOD)
+    L0 = (c - 1) * (c - 2) * (c - 3) * inv(-6)
+    L1 = c * (c - 2) * (c - 3) * inv(2)
+    L2 = c * (c - 1) * (c - 3) * inv(-2)
+    L3 = c * (c - 1) * (c - 2) * inv(6)
+    return fr_from_int((e[0] * L0 + e[1] * L1 + e[2] * L2 + e[3] * L3) % R_MOD)
+
+
+def interpolateDegree3(evals):
+    """UniPoly.interpolateDegree3 (src/poly/mod.zig:632-677): coefficients [c0, c1, c2, c3] from p(0), p(1), p(2), p(3)"""
+    p0, p1, p2, p3 = (fr_to_int(x) for x in evals)
+    inv6, inv2 = pow(6, -1, R_MOD), pow(2, -1, R_MOD)
+    c1 = (-11 * p0 + 18 * p1 - 9 * p2 + 2 * p3) * inv6 % R_MOD
+    c2 = (2 * p0 - 5 * p1 + 4 * p2 - p3) * inv2 % R_MOD
+    c3 = (-p0 + 3 * p1 - 3 * p2 + p3) * inv6 % R_MOD
+    return np.stack([fr_from_int(p0), fr_from_int(c1), fr_from_int(c2), fr_from_int(c3)])
+
+
+def evalsToCompressed(evals):
+    """UniPoly.evalsToCompressed (:682-685): [c0, c2, c3]"""
+    c = interpolateDegree3(evals)
+    return np.stack([c[0], c[2], c[3]])
+
+
+class ValEvaluationProver:
+    """ValEvaluationProver's sumcheck loop (src/zkvm/ram/val_evaluation.zig:545-700): inc * wa * lt over the cycles, LowToHigh.
+    The three tables stay in one device session (zg_psc_*); the claim update is the reference's host algebra."""
+    FACTORS = (0, 1, 2)
+
+    def __init__(self, inc_evals, wa_evals, lt_evals, claim):
+        tabs = [inc_evals, wa_evals] + ([] if lt_evals is None else [lt_evals])
+        self._s = lib.ProductSumcheckSession.open(tabs)
+        self.current_claim = np.ascontiguousarray(claim, dtype=np.uint64).copy()
+        self.round = 0
+
+    def computeInitialClaim(self):
+        return self.current_claim.copy()
+
+    def effectiveLen(self):
+        return len(self._s)
+
+    def computeRoundPolynomial(self):
+        """[p(0), p(1), p(2), p(3)] (:554-603)"""
+        if len(self._s) < 2:  # :559-565: a single entry: p(0) = the product, the rest zero
+            out = np.zeros((4, 4), dtype=np.uint64)
+            acc = 1
+            for v in self._s.final():
+                acc = acc * fr_to_int(v) % R_MOD
+            out[0] = fr_from_int(acc)
+            return out
+        return self._s.round_evals(self.FACTORS)
+
+    def bindChallengeWithPoly(self, r, round_poly):
+        """:609-660: fold every table, claim = p(r) by cubic Lagrange"""
+        if len(self._s) >= 2:
+            self._s.bind(r)
+            self.current_claim = cubicAtPoint(round_poly, r)
+        self.round += 1
+
+    def getFinalClaims(self):
+        return list(self._s.final())
+
+    def deinit(self):
+        self._s.close()
+
+
+class ValFinalProver(ValEvaluationProver):
+    """ValFinalProver's loop (src/zkvm/ram/val_final.zig:144-230): inc * wa, the same cubic message format"""
+    FACTORS = (0, 1)
+
+    def __init__(self, inc_evals, wa_evals, claim):
+        super().__init__(inc_evals, wa_evals, None, claim)
+
+
+class OutputSumcheckProver:
+    """OutputSumcheckProver's loop (src/zkvm/ram/output_check.zig:375-499): eq * io_mask * (val_final - val_io); val_init is folded
+    alongside for the final claims. Tables 0..4 = eq_r_address, io_mask, val_final, val_io, val_init."""
+
+    def __init__(self, eq_r_address, io_mask, val_final, val_io, val_init, claim):
+        self._s = lib.ProductSumcheckSession.open([eq_r_address, io_mask, val_final, val_io, val_init])
+        self.current_size = len(self._s)
+        self.current_claim = np.ascontiguousarray(claim, dtype=np.uint64).copy()
+        self._coeff = np.stack([fr_from_int(1), fr_from_int(R_MOD - 1)])  # vf - vio
+
+    def roundEvals(self):
+        """s(0), s(1), s(2), s(3) (:378-430)"""
+        return self._s.round_evals((0, 1), (2, 3), self._coeff)
+
+    def computeRoundPolynomial(self):
+        """compressed coefficients [c0, c2, c3] (:445)"""
+        return evalsToCompressed(self.roundEvals())
+
+    def bindChallenge(self, r):
+        self._s.bind(r)
+        self.current_size //= 2
+
+    def updateClaim(self, evals, challenge):
+        """:482-499: c0 + c1 r + c2 r^2 + c3 r^3 with c2, c3 from lagrangeC2 / lagrangeC3"""
+        c = interpolateDegree3(evals)
+        r = fr_to_int(challenge)
+        c0, c2, c3 = fr_to_int(c[0]), fr_to_int(c[2]), fr_to_int(c[3])
+        c1 = (fr_to_int(evals[1]) - c0 - c2 - c3) % R_MOD
+        self.current_claim = fr_from_int((c0 + c1 * r + c2 * r * r + c3 * r * r * r) % R_MOD)
+
+    def getFinalClaims(self):
+        f = self._s.final()
+        return {"val_final": f[2], "val_init": f[4], "val_io": f[3], "eq_r_address": f[0], "io_mask": f[1]}
+
+    def deinit(self):
+        self._s.close()
+
+
+class InstructionLookupsClaimReductionProver:
+    """InstructionLookupsClaimReductionProver's loop (src/zkvm/claim_reductions/instruction_lookups.zig:146-284):
+    eq * (lookup_output + gamma left + gamma^2 right). Tables 0..3 = eq_evals, lookup_outputs, left_operands, right_operands."""
+
+    def __init__(self, eq_evals, lookup_outputs, left_operands, right_operands, gamma, claim):
+        self._s = lib.ProductSumcheckSession.open([eq_evals, lookup_outputs, left_operands, right_operands])
+        g = fr_to_int(gamma)
+        self._coeff = np.stack([fr_from_int(1), fr_from_int(g), fr_from_int(g * g % R_MOD)])
+        self.current_claim = np.ascontiguousarray(claim, dtype=np.uint64).copy()
+        self.round = 0
+
+    def computeRoundPolynomialCubic(self):
+        """[s0, s1, s2, s3]: s0, s2 from the tables, s1 = claim - s0, s3 = s0 - 3 s1 + 3 s2 (:146-200)"""
+        ev = self._s.round_evals((0,), (1, 2, 3), self._coeff)
+        s0, s2 = fr_to_int(ev[0]), fr_to_int(ev[2])
+        s1 = (fr_to_int(self.current_claim) - s0) % R_MOD
+        s3 = (s0 - 3 * s1 + 3 * s2) % R_MOD
+        return np.stack([ev[0], fr_from_int(s1), ev[2], fr_from_int(s3)])
+
+    def bindChallenge(self, challenge):
+        self._s.bind(challenge)
+        self.round += 1
+
+    def updateClaim(self, evals, challenge):
+        self.current_claim = cubicAtPoint(evals, challenge)
+
+    def getOpeningClaims(self):
+        f = self._s.final()
+        return {"lookup_output": f[1], "left_operand": f[2], "right_operand": f[3]}
+
+    def deinit(self):
+        self._s.close()
+
+
+class ProductVirtualRemainderProver:
+    """ProductVirtualRemainderProver's loop (src/zkvm/spartan/product_remainder.zig:269-394) over the fused left / right tables:
+    Gruen's (t0, t_inf) on the device under the split-eq weights (prefix tables resident in HBM), the cubic from
+    GruenSplitEqPolynomial.computeCubicRoundPoly on the host."""
+
+    def __init__(self, left_evals, right_evals, tau_low, lagrange_kernel, uni_skip_claim):
+        self._s = lib.ProductSumcheckSession.open([left_evals, right_evals])
+        self.split_eq = GruenSplitEqPolynomial(tau_low, lagrange_kernel)
+        self.current_claim = np.ascontiguousarray(uni_skip_claim, dtype=np.uint64).copy()
+        self.current_round = 0
+
+    def roundEvals(self):
+        if len(self._s) < 2:
+            return None
+        d_out, n_out, d_in, n_in = self.split_eq.getWindowEqTablesDev(1)
+        t0, t_inf = self._s.round_gruen((0, 1), d_out, n_out, d_in, n_in)
+        return self.split_eq.computeCubicRoundPoly(t0, t_inf, self.current_claim)
+
+    def computeRoundPolynomial(self):
+        """compressed [c0, c2, c3]; [claim, 0, 0] without groups (:274-276)"""
+        ev = self.roundEvals()
+        if ev is None:
+            z = np.zeros(4, dtype=np.uint64)
+            return np.stack([self.current_claim, z, z])
+        return evalsToCompressed(ev)
+
+    def bindChallenge(self, challenge):
+        self._s.bind(challenge)
+        self.split_eq.bind(challenge)
+        self.current_round += 1
+
+    def updateClaim(self, round_evals, challenge):
+        self.current_claim = cubicAtPoint(round_evals, challenge)
+
+    def getFinalClaim(self):
+        f = self._s.final()
+        return fr_from_int(fr_to_int(f[0]) * fr_to_int(f[1]) % R_MOD)
+
+    def deinit(self):
+        self._s.close()
+        self.split_eq.deinit()
 
 
 class LassoProver:

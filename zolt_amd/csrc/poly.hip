@@ -17,15 +17,9 @@
 #include "common.hip.h"
 #include "field.hip.h"
 #include "fp29.hip.h"
+#include "sc_common.hip.h"
 
 namespace zg {
-
-ZG_DEV Fr fr_shfl_down(const Fr &v, int d) {
-    Fr r;
-#pragma unroll
-    for (int i = 0; i < 8; i++) r.l[i] = __shfl_down(v.l[i], d, 64);
-    return r;
-}
 
 // ------------------------------------------------------------------ eq table
 // Factor tables of eq(r, .) (r[0] <-> MSB of the index), one launch:
@@ -113,29 +107,6 @@ __global__ void __launch_bounds__(256) spartan_combine_kernel(const uint64_t *eq
 __global__ void __launch_bounds__(256) fr_dot_kernel(const uint64_t *a, const uint64_t *b, size_t n, uint64_t *partials);
 
 // ------------------------------------------------------------------ sums / folds
-// block-wide sum of (g0, g1) pairs (256 threads); result valid in thread 0. Wave-level shuffle tree first
-// (no barriers, no LDS round trips), then one LDS hop across the four waves: the latency of this reduction is
-// what a small sumcheck round mostly consists of.
-__device__ __forceinline__ void block_sum_pair(Fr &g0, Fr &g1, uint4 *sh) {
-    uint32_t tid = threadIdx.x;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        g0 = fe_add(g0, fr_shfl_down(g0, d));
-        g1 = fe_add(g1, fr_shfl_down(g1, d));
-    }
-    if ((tid & 63) == 0) {
-        fe_store(&sh[(tid >> 6) * 4], g0);
-        fe_store(&sh[(tid >> 6) * 4 + 2], g1);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        for (uint32_t w = 1; w < 4; w++) {
-            g0 = fe_add(g0, fe_load<FrParams>(&sh[w * 4]));
-            g1 = fe_add(g1, fe_load<FrParams>(&sh[w * 4 + 2]));
-        }
-    }
-}
-
 __global__ void __launch_bounds__(256) fr_dot_kernel(const uint64_t *a, const uint64_t *b, size_t n, uint64_t *partials) {
     __shared__ uint4 sh[256 * 4];
     Fr g0 = Fr::zero(), g1 = Fr::zero();
@@ -150,15 +121,7 @@ __global__ void __launch_bounds__(256) fr_dot_kernel(const uint64_t *a, const ui
 }
 
 // round sums of a table: HIGH: g0 = sum t[0..h), g1 = sum t[h..2h);  LOW: g0 = sum t[2i], g1 = sum t[2i+1]
-// A kernel that produces the final pair of a round publishes it to the pinned host mailbox: sums first, then
-// (after a system-scope fence) the round's sequence number, so the host can spin on the mailbox instead of
-// paying a stream synchronisation per round. flag == nullptr: this launch only writes block partials.
-ZG_DEV void publish_seq(uint64_t *flag, uint64_t seq) {
-    if (flag) {
-        __threadfence_system();
-        __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
+// (publication of a round's pair to the pinned host mailbox: publish_seq, sc_common.hip.h)
 
 // ---- runSumcheck resident on the device (src/subprotocols/mod.zig:302-354): the toy verifier (:165-243) runs as the
 // last step of the kernel that produced a round's sums, so no round needs the host. `res` (u64 words):
@@ -309,9 +272,6 @@ __global__ void __launch_bounds__(256) sc_sums_kernel(const uint64_t *t, size_t 
 // fold by r and produce the NEXT round's two sums from the values just written:
 //   HIGH: out[i] = (1-r)*t[i] + r*t[i+half]     next g0 over i < half/2, g1 over i >= half/2
 //   LOW : out[i] = t[2i] + r*(t[2i+1]-t[2i])    next g0 over even i,     g1 over odd i
-struct FrArg {  // a challenge travels as a kernel argument: no H2D copy, no staging buffer to recycle
-    uint32_t l[8];
-};
 
 // One level of HyperKZG.open (src/poly/commitment/mod.zig:296-310) in one pass over the table: the quotient
 // q[j] = t[j + half] - t[j] (the first q_count entries are kept: commit() uses min(half, srs_len) of them) and the fold

@@ -1,0 +1,495 @@
+// psc.hip — product-form sumcheck sessions on gfx950: k multilinear evaluation tables that are folded together (LowToHigh, adjacent
+// pairs) and whose round polynomial is a sum over the pairs g of
+//       prod_{j<p} A_j(t)  *  L(t),        A(t) = lo + t (hi - lo),   L(t) = sum_{m<q} c_m B_m(t)   (q = 0: L = 1)
+// evaluated at t = 0, 1, 2, 3, or — Gruen's form — as (t0, t_inf) = sum_g w(g) (prod lo, prod (hi - lo)) with w(g) the split-eq
+// weight E_out[g >> bits] * E_in[g & mask].
+//
+// Reference loops replaced (paths under /root/reference), all the same two shapes with different table counts:
+//   ValEvaluationProver.computeRoundPolynomial / bindChallengeWithPoly       src/zkvm/ram/val_evaluation.zig:554-628   (inc * wa * lt)
+//   ValFinalProver.computeRoundPolynomial / bindChallengeWithPoly            src/zkvm/ram/val_final.zig:149-200        (inc * wa)
+//   OutputSumcheckProver.computeRoundPolynomial / bind                       src/zkvm/ram/output_check.zig:375-470     (eq * io * (vf - vio))
+//   InstructionLookupsClaimReduction.computeRoundPolynomialCubic / bind      src/zkvm/claim_reductions/instruction_lookups.zig:146-240
+//                                                                            (eq * (out + gamma left + gamma^2 right))
+//   ProductVirtualRemainderProver.computeRoundPolynomial / bindChallenge     src/zkvm/spartan/product_remainder.zig:269-420 (Gruen, left * right)
+// Exact modular arithmetic with canonical outputs: 2*f1 - f0, f0 + 2 (f1 - f0) and f(1) + (f(1) - f(0)) are the same field value, sums
+// commute, so every evaluation order gives the reference's bytes.
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.hip.h"
+#include "field.hip.h"
+#include "fp29.hip.h"
+#include "sc_common.hip.h"
+
+#define ZG_PSC_MAX_TABLES 8
+#define ZG_PSC_MAX_FACTORS 4
+
+namespace zg {
+
+constexpr unsigned PSC_MAX_BLOCKS = 1024;
+constexpr size_t PSC_COUNTER_OFF = 16 * (size_t)PSC_MAX_BLOCKS;     // u64 words: block quadruples, then the arrival counter
+constexpr size_t PSC_MISC_BYTES = (PSC_COUNTER_OFF + 16) * 8;
+constexpr int PSC_FLAG = 24;                                        // h_pin: 16 words of values, sequence word at 24
+
+struct PscSpec {
+    uint32_t prod[ZG_PSC_MAX_FACTORS];  // table indices of the plain factors
+    uint32_t lin[ZG_PSC_MAX_FACTORS];   // table indices of the linear combination
+    FrArg coeff[ZG_PSC_MAX_FACTORS];    // its coefficients (Montgomery)
+};
+
+// End of a round inside the producing kernel: every block leaves NP pairs in `partials`; the block that arrives last adds them up,
+// writes the 2*NP values to the pinned mailbox and publishes the sequence word. v[]: the block's values, valid in thread 0.
+template <int NP>
+__device__ __forceinline__ void psc_finish(Fr (&v)[2 * NP], uint4 *sh, uint64_t *partials, uint64_t *sums, uint32_t *counter, uint64_t *flag,
+                                           uint64_t seq) {
+    uint32_t tid = threadIdx.x, nb = gridDim.x;
+    if (nb == 1) {
+        if (tid == 0) {
+#pragma unroll
+            for (int a = 0; a < 2 * NP; a++) fe_store(sums + 4 * a, v[a]);
+            publish_seq(flag, seq);
+        }
+        return;
+    }
+    __shared__ uint32_t last;
+    if (tid == 0) {
+        uint64_t *dst = partials + 16 * (size_t)blockIdx.x;
+#pragma unroll
+        for (int a = 0; a < 2 * NP; a++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                __hip_atomic_store(dst + 4 * a + i, (uint64_t)v[a].l[2 * i] | ((uint64_t)v[a].l[2 * i + 1] << 32), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t arrived = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last = arrived == nb - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!last) return;
+    Fr acc[2 * NP];
+#pragma unroll
+    for (int a = 0; a < 2 * NP; a++) acc[a] = Fr::zero();
+    for (uint32_t k = tid; k < nb; k += 256) {
+        const uint64_t *src = partials + 16 * (size_t)k;
+#pragma unroll
+        for (int a = 0; a < 2 * NP; a++) {
+            Fr p;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                uint64_t x = __hip_atomic_load(src + 4 * a + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                p.l[2 * i] = (uint32_t)x;
+                p.l[2 * i + 1] = (uint32_t)(x >> 32);
+            }
+            acc[a] = fe_add(acc[a], p);
+        }
+    }
+    __syncthreads();  // sh is reused
+    block_sum_pair(acc[0], acc[1], sh);
+    if constexpr (NP == 2) {
+        __syncthreads();
+        block_sum_pair(acc[2], acc[3], sh);
+    }
+    if (tid == 0) {
+        __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch (stream order)
+#pragma unroll
+        for (int a = 0; a < 2 * NP; a++) fe_store(sums + 4 * a, acc[a]);
+        publish_seq(flag, seq);
+    }
+}
+
+// round evaluations at t = 0..3; tables at base + table * stride (elements), pair g = entries 2g, 2g + 1
+template <int P, int Q>
+__global__ void __launch_bounds__(256) psc_evals_kernel(const uint64_t *base, size_t stride, size_t half, PscSpec spec, uint64_t *partials,
+                                                        uint64_t *sums, uint32_t *counter, uint64_t *flag, uint64_t seq) {
+    __shared__ uint4 sh[256 * 4];
+    F29 cp[Q > 0 ? Q : 1];
+    if constexpr (Q > 0) {
+#pragma unroll
+        for (int m = 0; m < Q; m++) {
+            Fr c;
+#pragma unroll
+            for (int i = 0; i < 8; i++) c.l[i] = spec.coeff[m].l[i];
+            cp[m] = fr29_prescale(c);
+        }
+    }
+    Fr e[4] = {Fr::zero(), Fr::zero(), Fr::zero(), Fr::zero()};
+    size_t step = (size_t)gridDim.x * 256;
+    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < half; g += step) {
+        Fr v0, v1, v2, v3;
+        bool have = false;
+        if constexpr (Q > 0) {  // L(0), L(1) from the tables, L(2), L(3) by linearity
+            Fr l0 = Fr::zero(), l1 = Fr::zero();
+#pragma unroll
+            for (int m = 0; m < Q; m++) {
+                const uint64_t *t = base + 4 * ((size_t)spec.lin[m] * stride + 2 * g);
+                l0 = fe_add(l0, fr_mul29(fe_load<FrParams>(t), cp[m]));
+                l1 = fe_add(l1, fr_mul29(fe_load<FrParams>(t + 4), cp[m]));
+            }
+            Fr d = fe_sub(l1, l0);
+            v0 = l0;
+            v1 = l1;
+            v2 = fe_add(l1, d);
+            v3 = fe_add(v2, d);
+            have = true;
+        }
+        if constexpr (P > 0) {
+        for (int j = 0; j < P; j++) {  // left to the compiler: four tables x four products do not unroll under its size limit
+            const uint64_t *t = base + 4 * ((size_t)spec.prod[j] * stride + 2 * g);
+            Fr lo = fe_load<FrParams>(t), hi = fe_load<FrParams>(t + 4);
+            Fr d = fe_sub(hi, lo), f2 = fe_add(hi, d), f3 = fe_add(f2, d);
+            if (!have) {
+                v0 = lo; v1 = hi; v2 = f2; v3 = f3;
+                have = true;
+            } else {
+                v0 = fr_mul29v(v0, lo);
+                v1 = fr_mul29v(v1, hi);
+                v2 = fr_mul29v(v2, f2);
+                v3 = fr_mul29v(v3, f3);
+            }
+        }
+        }
+        e[0] = fe_add(e[0], v0);
+        e[1] = fe_add(e[1], v1);
+        e[2] = fe_add(e[2], v2);
+        e[3] = fe_add(e[3], v3);
+    }
+    block_sum_pair(e[0], e[1], sh);
+    __syncthreads();
+    block_sum_pair(e[2], e[3], sh);
+    psc_finish<2>(e, sh, partials, sums, counter, flag, seq);
+}
+
+// Gruen's two sums with the split-eq weights (product_remainder.zig:281-330): E tables in device memory, 2^in_bits = |E_in|
+template <int P>
+__global__ void __launch_bounds__(256) psc_gruen_kernel(const uint64_t *base, size_t stride, size_t half, PscSpec spec, const uint64_t *e_out,
+                                                        size_t n_out, const uint64_t *e_in, uint32_t in_bits, uint64_t *partials, uint64_t *sums,
+                                                        uint32_t *counter, uint64_t *flag, uint64_t seq) {
+    __shared__ uint4 sh[256 * 4];
+    Fr e[2] = {Fr::zero(), Fr::zero()};
+    size_t step = (size_t)gridDim.x * 256;
+    const size_t mask = ((size_t)1 << in_bits) - 1;
+    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < half; g += step) {
+        size_t x_out = g >> in_bits;
+        if (x_out >= n_out) continue;  // the reference's loops only reach g = (x_out << bits) | x_in with x_out < |E_out|
+        Fr w = fr_mul29v(fe_load<FrParams>(e_out + 4 * x_out), fe_load<FrParams>(e_in + 4 * (g & mask)));
+        Fr t0 = w, ti = w;
+#pragma unroll
+        for (int j = 0; j < P; j++) {
+            const uint64_t *t = base + 4 * ((size_t)spec.prod[j] * stride + 2 * g);
+            Fr lo = fe_load<FrParams>(t), hi = fe_load<FrParams>(t + 4);
+            t0 = fr_mul29v(t0, lo);
+            ti = fr_mul29v(ti, fe_sub(hi, lo));
+        }
+        e[0] = fe_add(e[0], t0);
+        e[1] = fe_add(e[1], ti);
+    }
+    block_sum_pair(e[0], e[1], sh);
+    psc_finish<1>(e, sh, partials, sums, counter, flag, seq);
+}
+
+// every table folded by r in one launch: out[i] = (1 - r) t[2i] + r t[2i+1] = t[2i] + r (t[2i+1] - t[2i]); blockIdx.y = table
+__global__ void __launch_bounds__(256) psc_fold_kernel(const uint64_t *base, size_t stride, size_t half, FrArg r, uint64_t *out, size_t ostride) {
+    Fr rv;
+#pragma unroll
+    for (int i = 0; i < 8; i++) rv.l[i] = r.l[i];
+    F29 rp = fr29_prescale(rv);
+    const uint64_t *t = base + 4 * (size_t)blockIdx.y * stride;
+    uint64_t *o = out + 4 * (size_t)blockIdx.y * ostride;
+    size_t step = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < half; i += step) {
+        Fr lo = fe_load<FrParams>(t + 8 * i), hi = fe_load<FrParams>(t + 8 * i + 4);
+        fe_store(o + 4 * i, fe_add(lo, fr_mul29(fe_sub(hi, lo), rp)));
+    }
+}
+
+static unsigned psc_blocks(size_t half) {
+    size_t nb = (half + 255) / 256;
+    if (nb < 1) nb = 1;
+    return (unsigned)(nb > 512 ? 512 : nb);  // two blocks per CU: up to four tables' pairs in flight per thread
+}
+
+}  // namespace zg
+
+struct zg_psc_s {
+    int device = -1;
+    size_t k = 0, len = 0, cap = 0;
+    uint64_t *buf[2] = {nullptr, nullptr};  // buf[0]: k tables of cap entries; buf[1]: k tables of cap/2 (a fold cannot run in place)
+    int cur = 0;
+    uint64_t *d_misc = nullptr;
+    uint64_t *h_pin = nullptr;  // pinned, device-visible mailbox: up to 16 words of values, sequence word at PSC_FLAG
+    hipStream_t st = nullptr;
+    uint64_t seq = 0;
+    std::mutex mu;
+    size_t stride() const { return cur == 0 ? cap : (cap / 2 ? cap / 2 : 1); }
+};
+
+using namespace zg;
+
+static void psc_free(zg_psc_s *s) {
+    if (!s) return;
+    if (s->buf[0]) (void)hipFree(s->buf[0]);
+    if (s->buf[1]) (void)hipFree(s->buf[1]);
+    if (s->d_misc) (void)hipFree(s->d_misc);
+    if (s->h_pin) (void)hipHostFree(s->h_pin);
+    delete s;
+}
+
+static int psc_create(size_t k, size_t len, hipStream_t st, zg_psc_s **out) {
+    if (k == 0 || k > ZG_PSC_MAX_TABLES || len == 0 || (len & (len - 1))) {
+        set_error("zg_psc_open: 1..8 tables, len a power of two");
+        return ZG_ERR_INVALID;
+    }
+    zg_psc_s *s = new zg_psc_s();
+    s->device = current_device();
+    s->k = k;
+    s->len = s->cap = len;
+    s->st = st;
+    size_t half = len / 2 ? len / 2 : 1;
+    hipError_t e = hipMalloc((void **)&s->buf[0], k * len * 32);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->buf[1], k * half * 32);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_misc, PSC_MISC_BYTES);
+    if (e == hipSuccess) e = hipMemset(s->d_misc, 0, PSC_MISC_BYTES);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_pin, 256, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) s->h_pin[PSC_FLAG] = 0;
+    if (e != hipSuccess) {
+        set_error(std::string("zg_psc_open: ") + hipGetErrorString(e));
+        psc_free(s);
+        return e == hipErrorOutOfMemory ? ZG_ERR_NOMEM : ZG_ERR_HIP;
+    }
+    *out = s;
+    return ZG_OK;
+}
+
+// host side of a round that ended inside its kernel (same protocol as the single-table sessions of poly.hip)
+static int psc_wait(zg_psc_s *s, uint64_t *out, int words) {
+    ZG_HIP(hipGetLastError());
+    volatile uint64_t *flag = s->h_pin + PSC_FLAG;
+    bool got = false;
+    for (uint64_t spin = 0; spin < (1ull << 22); spin++) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == s->seq) { got = true; break; }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    if (!got) ZG_HIP(hipStreamSynchronize(s->st));
+    for (int i = 0; i < words; i++) out[i] = s->h_pin[i];
+    return ZG_OK;
+}
+
+static int psc_spec(zg_psc_s *s, const int *prod_idx, size_t p, const int *lin_idx, const uint64_t *lin_coeff, size_t q, PscSpec *spec,
+                    const char *who) {
+    bool bad = !s || p > ZG_PSC_MAX_FACTORS || q > ZG_PSC_MAX_FACTORS || (p + q) == 0 || (p && !prod_idx) || (q && (!lin_idx || !lin_coeff));
+    for (size_t j = 0; !bad && j < p; j++) bad = prod_idx[j] < 0 || (size_t)prod_idx[j] >= s->k;
+    for (size_t m = 0; !bad && m < q; m++) bad = lin_idx[m] < 0 || (size_t)lin_idx[m] >= s->k;
+    if (bad) {
+        set_error(std::string(who) + ": at most 4 product tables and 4 linear-combination tables, indices below the session's table count");
+        return ZG_ERR_INVALID;
+    }
+    for (size_t j = 0; j < ZG_PSC_MAX_FACTORS; j++) {
+        spec->prod[j] = j < p ? (uint32_t)prod_idx[j] : 0;
+        spec->lin[j] = j < q ? (uint32_t)lin_idx[j] : 0;
+        for (int i = 0; i < 4; i++) {
+            uint64_t w = j < q ? lin_coeff[4 * j + i] : 0;
+            spec->coeff[j].l[2 * i] = (uint32_t)w;
+            spec->coeff[j].l[2 * i + 1] = (uint32_t)(w >> 32);
+        }
+    }
+    return ZG_OK;
+}
+
+template <int P>
+static void psc_launch_evals_q(size_t q, unsigned nb, hipStream_t st, const uint64_t *base, size_t stride, size_t half, const PscSpec &spec,
+                               uint64_t *partials, uint64_t *sums, uint32_t *counter, uint64_t *flag, uint64_t seq) {
+    switch (q) {
+    case 0: hipLaunchKernelGGL((psc_evals_kernel<P, 0>), dim3(nb), dim3(256), 0, st, base, stride, half, spec, partials, sums, counter, flag, seq); break;
+    case 1: hipLaunchKernelGGL((psc_evals_kernel<P, 1>), dim3(nb), dim3(256), 0, st, base, stride, half, spec, partials, sums, counter, flag, seq); break;
+    case 2: hipLaunchKernelGGL((psc_evals_kernel<P, 2>), dim3(nb), dim3(256), 0, st, base, stride, half, spec, partials, sums, counter, flag, seq); break;
+    case 3: hipLaunchKernelGGL((psc_evals_kernel<P, 3>), dim3(nb), dim3(256), 0, st, base, stride, half, spec, partials, sums, counter, flag, seq); break;
+    default: hipLaunchKernelGGL((psc_evals_kernel<P, 4>), dim3(nb), dim3(256), 0, st, base, stride, half, spec, partials, sums, counter, flag, seq); break;
+    }
+}
+
+extern "C" {
+
+int zg_psc_open(const uint64_t *const *tables, size_t k, size_t len, zg_psc_t *out) {
+    ZG_INIT();
+    if (!tables || !out) {
+        set_error("zg_psc_open: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    for (size_t j = 0; j < k && j < ZG_PSC_MAX_TABLES; j++)
+        if (!tables[j]) {
+            set_error("zg_psc_open: null table");
+            return ZG_ERR_INVALID;
+        }
+    zg_psc_s *s = nullptr;
+    ZG_TRY(psc_create(k, len, lib_stream(), &s));
+    for (size_t j = 0; j < k; j++) {
+        hipError_t e = hipMemcpyAsync(s->buf[0] + 4 * j * len, tables[j], len * 32, hipMemcpyHostToDevice, s->st);
+        if (e != hipSuccess) {
+            (void)hipStreamSynchronize(s->st);
+            set_error(hipGetErrorString(e));
+            psc_free(s);
+            return ZG_ERR_HIP;
+        }
+    }
+    hipError_t e = hipStreamSynchronize(s->st);  // the host tables may be released on return
+    if (e != hipSuccess) {
+        set_error(hipGetErrorString(e));
+        psc_free(s);
+        return ZG_ERR_HIP;
+    }
+    *out = s;
+    return ZG_OK;
+}
+
+int zg_psc_open_dev(const uint64_t *const *d_tables, size_t k, size_t len, void *stream, zg_psc_t *out) {
+    ZG_INIT();
+    if (!d_tables || !out) {
+        set_error("zg_psc_open_dev: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    for (size_t j = 0; j < k && j < ZG_PSC_MAX_TABLES; j++)
+        if (!d_tables[j]) {
+            set_error("zg_psc_open_dev: null table");
+            return ZG_ERR_INVALID;
+        }
+    zg_psc_s *s = nullptr;
+    ZG_TRY(psc_create(k, len, pick_stream(stream), &s));
+    for (size_t j = 0; j < k; j++) {
+        hipError_t e = hipMemcpyAsync(s->buf[0] + 4 * j * len, d_tables[j], len * 32, hipMemcpyDeviceToDevice, s->st);
+        if (e != hipSuccess) {
+            (void)hipStreamSynchronize(s->st);
+            set_error(hipGetErrorString(e));
+            psc_free(s);
+            return ZG_ERR_HIP;
+        }
+    }
+    *out = s;
+    return ZG_OK;
+}
+
+size_t zg_psc_len(zg_psc_t s) { return s ? s->len : 0; }
+size_t zg_psc_tables(zg_psc_t s) { return s ? s->k : 0; }
+
+int zg_psc_round_evals(zg_psc_t s, const int *prod_idx, size_t p, const int *lin_idx, const uint64_t *lin_coeff, size_t q, uint64_t out[16]) {
+    ZG_INIT();
+    PscSpec spec;
+    ZG_TRY(psc_spec(s, prod_idx, p, lin_idx, lin_coeff, q, &spec, "zg_psc_round_evals"));
+    if (!out || s->len < 2) {
+        set_error("zg_psc_round_evals: invalid argument or a single entry left");
+        return ZG_ERR_INVALID;
+    }
+    DeviceGuard dg(s->device);
+    std::lock_guard<std::mutex> lk(s->mu);
+    const size_t half = s->len / 2;
+    unsigned nb = psc_blocks(half);
+    uint32_t *counter = reinterpret_cast<uint32_t *>(s->d_misc + PSC_COUNTER_OFF);
+    uint64_t *flag = s->h_pin + PSC_FLAG;
+    s->seq++;
+    const uint64_t *base = s->buf[s->cur];
+    switch (p) {
+    case 0: psc_launch_evals_q<0>(q, nb, s->st, base, s->stride(), half, spec, s->d_misc, s->h_pin, counter, flag, s->seq); break;
+    case 1: psc_launch_evals_q<1>(q, nb, s->st, base, s->stride(), half, spec, s->d_misc, s->h_pin, counter, flag, s->seq); break;
+    case 2: psc_launch_evals_q<2>(q, nb, s->st, base, s->stride(), half, spec, s->d_misc, s->h_pin, counter, flag, s->seq); break;
+    case 3: psc_launch_evals_q<3>(q, nb, s->st, base, s->stride(), half, spec, s->d_misc, s->h_pin, counter, flag, s->seq); break;
+    default: psc_launch_evals_q<4>(q, nb, s->st, base, s->stride(), half, spec, s->d_misc, s->h_pin, counter, flag, s->seq); break;
+    }
+    return psc_wait(s, out, 16);
+}
+
+int zg_psc_round_gruen(zg_psc_t s, const int *prod_idx, size_t p, const uint64_t *d_e_out, size_t n_out, const uint64_t *d_e_in, size_t n_in,
+                       uint64_t t0[4], uint64_t t_inf[4]) {
+    ZG_INIT();
+    PscSpec spec;
+    ZG_TRY(psc_spec(s, prod_idx, p, nullptr, nullptr, 0, &spec, "zg_psc_round_gruen"));
+    if (!t0 || !t_inf || !d_e_out || !d_e_in || n_out == 0 || n_in == 0 || (n_in & (n_in - 1)) || s->len < 2) {
+        set_error("zg_psc_round_gruen: invalid argument (|E_in| must be a power of two) or a single entry left");
+        return ZG_ERR_INVALID;
+    }
+    DeviceGuard dg(s->device);
+    std::lock_guard<std::mutex> lk(s->mu);
+    const size_t half = s->len / 2;
+    uint32_t in_bits = 0;
+    while (((size_t)1 << in_bits) < n_in) in_bits++;
+    unsigned nb = psc_blocks(half);
+    uint32_t *counter = reinterpret_cast<uint32_t *>(s->d_misc + PSC_COUNTER_OFF);
+    uint64_t *flag = s->h_pin + PSC_FLAG;
+    s->seq++;
+    const uint64_t *base = s->buf[s->cur];
+    switch (p) {
+    case 1: hipLaunchKernelGGL((psc_gruen_kernel<1>), dim3(nb), dim3(256), 0, s->st, base, s->stride(), half, spec, d_e_out, n_out, d_e_in, in_bits, s->d_misc, s->h_pin, counter, flag, s->seq); break;
+    case 2: hipLaunchKernelGGL((psc_gruen_kernel<2>), dim3(nb), dim3(256), 0, s->st, base, s->stride(), half, spec, d_e_out, n_out, d_e_in, in_bits, s->d_misc, s->h_pin, counter, flag, s->seq); break;
+    case 3: hipLaunchKernelGGL((psc_gruen_kernel<3>), dim3(nb), dim3(256), 0, s->st, base, s->stride(), half, spec, d_e_out, n_out, d_e_in, in_bits, s->d_misc, s->h_pin, counter, flag, s->seq); break;
+    default: hipLaunchKernelGGL((psc_gruen_kernel<4>), dim3(nb), dim3(256), 0, s->st, base, s->stride(), half, spec, d_e_out, n_out, d_e_in, in_bits, s->d_misc, s->h_pin, counter, flag, s->seq); break;
+    }
+    uint64_t h[8];
+    ZG_TRY(psc_wait(s, h, 8));
+    for (int i = 0; i < 4; i++) {
+        t0[i] = h[i];
+        t_inf[i] = h[4 + i];
+    }
+    return ZG_OK;
+}
+
+int zg_psc_bind(zg_psc_t s, const uint64_t r[4]) {
+    ZG_INIT();
+    if (!s || !r || s->len < 2) {
+        set_error("zg_psc_bind: invalid session or a single entry left");
+        return ZG_ERR_INVALID;
+    }
+    DeviceGuard dg(s->device);
+    std::lock_guard<std::mutex> lk(s->mu);
+    FrArg ra;
+    for (int i = 0; i < 4; i++) {
+        ra.l[2 * i] = (uint32_t)r[i];
+        ra.l[2 * i + 1] = (uint32_t)(r[i] >> 32);
+    }
+    const size_t half = s->len / 2;
+    const int nxt = s->cur ^ 1;
+    const size_t ostride = nxt == 0 ? s->cap : (s->cap / 2 ? s->cap / 2 : 1);
+    unsigned nbx = (unsigned)((half + 255) / 256);
+    if (nbx > 1024) nbx = 1024;
+    hipLaunchKernelGGL(psc_fold_kernel, dim3(nbx, (unsigned)s->k), dim3(256), 0, s->st, s->buf[s->cur], s->stride(), half, ra, s->buf[nxt], ostride);
+    ZG_HIP(hipGetLastError());  // asynchronous: the next round's kernel follows in stream order
+    s->cur = nxt;
+    s->len = half;
+    return ZG_OK;
+}
+
+int zg_psc_read(zg_psc_t s, size_t table, uint64_t *out) {
+    ZG_INIT();
+    if (!s || !out || table >= s->k) {
+        set_error("zg_psc_read: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    DeviceGuard dg(s->device);
+    std::lock_guard<std::mutex> lk(s->mu);
+    ZG_HIP(hipMemcpyAsync(out, s->buf[s->cur] + 4 * table * s->stride(), s->len * 32, hipMemcpyDeviceToHost, s->st));
+    ZG_HIP(hipStreamSynchronize(s->st));
+    return ZG_OK;
+}
+
+int zg_psc_final(zg_psc_t s, uint64_t *out) {
+    ZG_INIT();
+    if (!s || !out || s->len != 1) {
+        set_error("zg_psc_final: protocol not complete");
+        return ZG_ERR_INVALID;
+    }
+    DeviceGuard dg(s->device);
+    std::lock_guard<std::mutex> lk(s->mu);
+    ZG_HIP(hipMemcpy2DAsync(out, 32, s->buf[s->cur], s->stride() * 32, 32, s->k, hipMemcpyDeviceToHost, s->st));
+    ZG_HIP(hipStreamSynchronize(s->st));
+    return ZG_OK;
+}
+
+int zg_psc_close(zg_psc_t s) {
+    if (!s) return ZG_OK;
+    ZG_INIT();
+    DeviceGuard dg(s->device);
+    (void)hipStreamSynchronize(s->st);
+    psc_free(s);
+    return ZG_OK;
+}
+
+}  // extern "C"

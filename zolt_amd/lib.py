@@ -42,6 +42,8 @@ SYMBOLS = [
     "zg_sumcheck_len", "zg_sumcheck_final", "zg_sumcheck_read", "zg_sumcheck_close",
     "zg_sumcheck_round_sums_dev", "zg_sumcheck_read_dev", "zg_sumcheck_raf_round", "zg_sumcheck_bit_round", "zg_sumcheck_bit_bind", "zg_fr_bit_split_sums", "zg_fr_bit_split_sums_dev",
     "zg_run_sumcheck", "zg_run_sumcheck_dev", "zg_sumcheck_open_spartan_dev",
+    "zg_psc_open", "zg_psc_open_dev", "zg_psc_len", "zg_psc_tables", "zg_psc_round_evals", "zg_psc_round_gruen", "zg_psc_bind", "zg_psc_read",
+    "zg_psc_final", "zg_psc_close",
 ]
 # test / bench scaffolding of include/zolt_gpu_internal.h (not part of the drop-in boundary)
 INTERNAL_SYMBOLS = ["zg_profile_begin", "zg_profile_end"]
@@ -57,6 +59,8 @@ _lib.zg_g1_bases_len.restype = C.c_size_t
 _lib.zg_g1_sbases_len.restype = C.c_size_t
 _lib.zg_sumcheck_len_sharded.restype = C.c_size_t
 _lib.zg_sumcheck_len.restype = C.c_size_t
+_lib.zg_psc_len.restype = C.c_size_t
+_lib.zg_psc_tables.restype = C.c_size_t
 
 _u64p = C.POINTER(C.c_uint64)
 _u8p = C.POINTER(C.c_uint8)
@@ -630,6 +634,79 @@ class SumcheckSession:
     def close(self):
         if self._h:
             _chk(_lib.zg_sumcheck_close(self._h), "zg_sumcheck_close")
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ProductSumcheckSession:
+    """k multilinear tables folded together (LowToHigh) with product-form round evaluations (zg_psc_*): the loops of
+    ValEvaluationProver, ValFinalProver, OutputSumcheckProver, InstructionLookupsClaimReduction and ProductVirtualRemainderProver."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def open(cls, tables):
+        tabs = [_c(t).reshape(-1, 4) for t in tables]
+        n = tabs[0].shape[0]
+        assert all(t.shape[0] == n for t in tabs)
+        ptrs = (C.c_void_p * len(tabs))(*[t.ctypes.data for t in tabs])
+        h = C.c_void_p()
+        _chk(_lib.zg_psc_open(ptrs, C.c_size_t(len(tabs)), C.c_size_t(n), C.byref(h)), "zg_psc_open")
+        return cls(h)
+
+    @classmethod
+    def open_dev(cls, d_tables, n, stream=0):
+        ptrs = (C.c_void_p * len(d_tables))(*[int(p) for p in d_tables])
+        h = C.c_void_p()
+        _chk(_lib.zg_psc_open_dev(ptrs, C.c_size_t(len(d_tables)), C.c_size_t(n), _d(stream), C.byref(h)), "zg_psc_open_dev")
+        return cls(h)
+
+    def __len__(self):
+        return int(_lib.zg_psc_len(self._h))
+
+    def tables(self):
+        return int(_lib.zg_psc_tables(self._h))
+
+    def round_evals(self, prod_idx, lin_idx=(), lin_coeff=None):
+        """[p(0), p(1), p(2), p(3)] of sum_g prod_j T[prod_idx[j]](t) * sum_m lin_coeff[m] T[lin_idx[m]](t)"""
+        pi = (C.c_int * max(len(prod_idx), 1))(*prod_idx)
+        li = (C.c_int * max(len(lin_idx), 1))(*lin_idx)
+        co = _c(lin_coeff) if len(lin_idx) else None
+        out = np.empty((4, 4), dtype=np.uint64)
+        _chk(_lib.zg_psc_round_evals(self._h, pi, C.c_size_t(len(prod_idx)), li, _h(co), C.c_size_t(len(lin_idx)), _h(out)), "zg_psc_round_evals")
+        return out
+
+    def round_gruen(self, prod_idx, d_e_out, n_out, d_e_in, n_in):
+        """Gruen's (t0, t_inf) under the split-eq weights E_out x E_in (device pointers)"""
+        pi = (C.c_int * max(len(prod_idx), 1))(*prod_idx)
+        t0 = np.empty(4, dtype=np.uint64)
+        ti = np.empty(4, dtype=np.uint64)
+        _chk(_lib.zg_psc_round_gruen(self._h, pi, C.c_size_t(len(prod_idx)), _d(d_e_out), C.c_size_t(n_out), _d(d_e_in), C.c_size_t(n_in),
+                                     _h(t0), _h(ti)), "zg_psc_round_gruen")
+        return t0, ti
+
+    def bind(self, r):
+        _chk(_lib.zg_psc_bind(self._h, _h(_c(r))), "zg_psc_bind")
+
+    def read(self, table):
+        out = np.empty((len(self), 4), dtype=np.uint64)
+        _chk(_lib.zg_psc_read(self._h, C.c_size_t(table), _h(out)), "zg_psc_read")
+        return out
+
+    def final(self):
+        out = np.empty((self.tables(), 4), dtype=np.uint64)
+        _chk(_lib.zg_psc_final(self._h, _h(out)), "zg_psc_final")
+        return out
+
+    def close(self):
+        if self._h:
+            _chk(_lib.zg_psc_close(self._h), "zg_psc_close")
             self._h = None
 
     def __del__(self):
