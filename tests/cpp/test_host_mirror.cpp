@@ -312,6 +312,53 @@ TEST(lasso_prover_claim_tracking) {
     }
 }
 
+// ValEvaluationProver (src/zkvm/ram/val_evaluation.zig:545-700) and ProductVirtualRemainderProver (src/zkvm/spartan/product_remainder.zig:269-394)
+// as sumchecks: with the claim = sum over the hypercube every round has s(0) + s(1) = claim and the last claim is the product of the
+// tables' final values (times the split-eq scalar)
+TEST(product_form_provers_are_sound) {
+    const size_t v = 6, n = size_t(1) << v;
+    auto mk = [&](uint64_t seed) {
+        std::vector<Fr> t(n);
+        uint64_t x = seed;
+        for (auto &e : t) {
+            x = x * 6364136223846793005ULL + 1442695040888963407ULL;
+            e = Fr::fromU64(x >> 7).mul(Fr::fromU64(x | 1));
+        }
+        return t;
+    };
+    auto inc = mk(1), wa = mk(2), lt = mk(3);
+    Fr claim = Fr::zero();
+    for (size_t i = 0; i < n; i++) claim = claim.add(inc[i].mul(wa[i]).mul(lt[i]));
+    ValEvaluationProver p(inc, wa, &lt, claim);
+    for (size_t r = 0; r < v; r++) {
+        auto ev = p.computeRoundPolynomial();
+        EXPECT(ev[0].add(ev[1]).eql(p.current_claim));
+        p.bindChallengeWithPoly(Fr::fromU64(1000 + r).mul(inc[r]), ev);
+    }
+    auto f = p.getFinalClaims();
+    EXPECT(f.size() == 3 && f[0].mul(f[1]).mul(f[2]).eql(p.current_claim));
+
+    auto left = mk(4), right = mk(5);
+    std::vector<Fr> tau;
+    for (size_t i = 0; i < v; i++) tau.push_back(wa[i]);
+    Fr kernel = lt[0];
+    auto eq = EqPolynomial::evalsSliceWithScaling(tau, &kernel);
+    Fr c2 = Fr::zero();
+    for (size_t i = 0; i < n; i++) c2 = c2.add(eq[i].mul(left[i]).mul(right[i]));
+    ProductVirtualRemainderProver q(left, right, tau, kernel, c2);
+    for (size_t r = 0; r < v; r++) {
+        std::array<Fr, 4> ev;
+        EXPECT(q.roundEvals(ev));
+        EXPECT(ev[0].add(ev[1]).eql(q.current_claim));
+        auto comp = q.computeRoundPolynomial();
+        EXPECT(comp[0].eql(ev[0]));
+        Fr ch = Fr::fromU64(77 + r).mul(inc[r + 8]);
+        q.bindChallenge(ch);
+        q.updateClaim(ev, ch);
+    }
+    EXPECT(q.getFinalClaim().mul(q.split_eq.current_scalar).eql(q.current_claim));
+}
+
 int main() {
     if (zg_init(0) != ZG_OK) { std::printf("zg_init failed: %s\n", zg_last_error()); return 2; }
     for (auto &t : tests()) {

@@ -235,3 +235,67 @@ def test_gruen_round_direct(env):
         s.round_gruen((0,), d_out.ptr, 4, d_in.ptr, 3)  # |E_in| not a power of two
     s.close()
     d_out.free(); d_in.free()
+
+
+def test_fused_bind_keeps_every_table_and_every_spec_right(env):
+    """zg_psc_bind folds AND prepares the next round's evaluations for the spec of the last round_evals call: changing the spec
+    between rounds, Gruen rounds in between, binds without any evaluation before them, and tables outside the spec must all give
+    the values of an unfused run (big-int model of all six tables)."""
+    api, lib, ob = env
+    P = api.R_MOD
+    k, n = 6, 256
+    tabs = [_rand(ob, 7900 + j, n, sparse=(j == 4)) for j in range(k)]
+    ints = [[api.fr_to_int(x) for x in t] for t in tabs]
+    coeff = _rand(ob, 7910, 2)
+    cint = [api.fr_to_int(c) for c in coeff]
+    e_out, e_in = _rand(ob, 7911, 16), _rand(ob, 7912, 8)
+    d_out, d_in = lib.DeviceBuffer.from_host(e_out), lib.DeviceBuffer.from_host(e_in)
+
+    def model(prod, lin):
+        half = len(ints[0]) // 2
+        res = []
+        for t in range(4):
+            acc = 0
+            for g in range(half):
+                f = lambda T: (T[2 * g] + t * (T[2 * g + 1] - T[2 * g])) % P
+                v = 1
+                for j in prod:
+                    v = v * f(ints[j]) % P
+                if lin:
+                    v = v * (sum(c * f(ints[m]) for c, m in zip(cint, lin)) % P) % P
+                acc = (acc + v) % P
+            res.append(acc)
+        return res
+
+    s = lib.ProductSumcheckSession.open(tabs)
+    plan = [((0, 1, 2), ()), ((0, 1, 2), ()), ((3,), (4, 5)), ("gruen",), ((0, 1, 2), ()), None, ((0, 1), (2, 3)), ((0, 1), (2, 3))]
+    for rnd, step in enumerate(plan):
+        if step is None:
+            pass  # a bind with no evaluation since the last one (the cached spec is still the fourth step's)
+        elif step[0] == "gruen":
+            half = len(s) // 2
+            no, ni = 4, 8
+            t0, ti = s.round_gruen((1, 5), d_out.ptr, no, d_in.ptr, ni)
+            w0 = wi = 0
+            for g in range(min(half, no * ni)):
+                w = api.fr_to_int(e_out[g >> 3]) * api.fr_to_int(e_in[g & 7]) % P
+                w0 = (w0 + w * ints[1][2 * g] * ints[5][2 * g]) % P
+                wi = (wi + w * (ints[1][2 * g + 1] - ints[1][2 * g]) * (ints[5][2 * g + 1] - ints[5][2 * g])) % P
+            assert api.fr_to_int(t0) == w0 and api.fr_to_int(ti) == wi
+        else:
+            prod, lin = step
+            got = s.round_evals(prod, lin, coeff if lin else None)
+            assert [api.fr_to_int(x) for x in got] == model(prod, lin), rnd
+            if rnd % 2:  # asking twice gives the same answer (the second call finds the mailbox already filled)
+                assert np.array_equal(s.round_evals(prod, lin, coeff if lin else None), got)
+        r = _rand(ob, 7920 + rnd, 1)[0]
+        ri = api.fr_to_int(r)
+        s.bind(r)
+        half = len(ints[0]) // 2
+        ints = [[(T[2 * i] + ri * (T[2 * i + 1] - T[2 * i])) % P for i in range(half)] for T in ints]
+        for j in range(k):
+            assert [api.fr_to_int(x) for x in s.read(j)] == ints[j], (rnd, j)
+    assert len(s) == 1
+    assert [api.fr_to_int(x) for x in s.final()] == [T[0] for T in ints]
+    s.close()
+    d_out.free(); d_in.free()

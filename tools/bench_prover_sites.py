@@ -70,6 +70,17 @@ def main():
         t.append(time.perf_counter() - t0)
     lp.deinit()
     print(f"lasso 2^13 cycles: address round {1e6 * np.median(t[1:16]):.1f} us, cycle round {1e6 * np.median(t[16:]):.1f} us")
+    # product-form sessions at 2^22 entries: three-table cubic evaluations, two-table Gruen sums, the fold of all tables
+    ps = lib.ProductSumcheckSession.open([tab, tab[::-1].copy(), tab])
+    ps.round_evals((0, 1, 2))
+    ps.round_evals((0,), (1, 2), tab[:2])
+    g = api.GruenSplitEqPolynomial(tab[400:400 + v])
+    d_out, n_out, d_in, n_in = g.getWindowEqTablesDev(1)
+    ps.round_gruen((0, 1), d_out, n_out, d_in, n_in)
+    ps.bind(tab[9])
+    ps.round_evals((0, 1, 2))
+    ps.close()
+    g.deinit()
     # GruenSplitEqPolynomial init: both halves' prefix-table sets for a 24-variable tau (m = 12)
     t0 = time.perf_counter()
     for _ in range(20):

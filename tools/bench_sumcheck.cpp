@@ -171,7 +171,58 @@ int main(int argc, char **argv) {
             ok = ok && pr.round_polys.size() == (size_t)(16 + v);
         }
     }
-    std::printf("{\"lasso_log_K16_rounds_per_s\": %.1f, \"lasso_ms_whole_protocol_incl_setup\": %.4f, ", reps * (16 + v) / t_lasso, t_lasso / reps * 1e3);
+    // ValEvaluationProver (inc * wa * lt, val_evaluation.zig:554-660) and ProductVirtualRemainderProver (Gruen, product_remainder.zig:269-394):
+    // one product-form session each, Keccak transcript between rounds
+    double t_val = 0, t_prod = 0;
+    {
+        std::vector<Fr> a(n), b(n), c(n), tau;
+        uint64_t x = 0x50534321ULL;
+        for (size_t j = 0; j < n; j++) {
+            x = x * 6364136223846793005ULL + 1442695040888963407ULL;
+            a[j] = Fr::fromU64(x >> 3);
+            b[j] = Fr::fromU64(x ^ (x >> 29));
+            c[j] = a[j].add(b[j]);
+        }
+        for (int i = 0; i < v; i++) tau.push_back(Fr::fromU64(1000003ULL * i + 29));
+        for (int rep = -1; rep < reps; rep++) {
+            auto t0 = clk::now();
+            double dt_val = 0, dt_prod = 0;
+            {
+                ValEvaluationProver p(a, b, &c, Fr::fromU64(5));
+                t0 = clk::now();  // rounds only: the session set-up (three uploads, allocations) is a one-off per proof
+                Transcript tr("Jolt");
+                for (int k = 0; k < v; k++) {
+                    auto ev = p.computeRoundPolynomial();
+                    for (auto &e : ev) tr.appendScalar("val_eval", e);
+                    p.bindChallengeWithPoly(tr.challengeScalar("val_eval_r"), ev);
+                }
+                ok = ok && p.getFinalClaims().size() == 3;
+                dt_val = std::chrono::duration<double>(clk::now() - t0).count();
+            }
+            auto t1 = clk::now();
+            {
+                ProductVirtualRemainderProver q(a, b, tau, Fr::fromU64(3), Fr::fromU64(9));
+                t1 = clk::now();
+                Transcript tr("Jolt");
+                for (int k = 0; k < v; k++) {
+                    std::array<Fr, 4> ev;
+                    q.roundEvals(ev);
+                    for (auto &e : ev) tr.appendScalar("prod", e);
+                    Fr ch = tr.challengeScalar("prod_r");
+                    q.bindChallenge(ch);
+                    q.updateClaim(ev, ch);
+                }
+                dt_prod = std::chrono::duration<double>(clk::now() - t1).count();
+            }
+            if (rep >= 0) {
+                t_val += dt_val;
+                t_prod += dt_prod;
+            }
+        }
+    }
+    std::printf("{\"val_evaluation_rounds_per_s\": %.1f, \"val_evaluation_ms\": %.4f, \"product_remainder_rounds_per_s\": %.1f, "
+                "\"product_remainder_ms\": %.4f, ", reps * v / t_val, t_val / reps * 1e3, reps * v / t_prod, t_prod / reps * 1e3);
+    std::printf("\"lasso_log_K16_rounds_per_s\": %.1f, \"lasso_ms_whole_protocol_incl_setup\": %.4f, ", reps * (16 + v) / t_lasso, t_lasso / reps * 1e3);
     std::printf("\"v\": %d, \"reps\": %d, \"verified\": %s, \"stage1_keccak_rounds_per_s\": %.1f, \"stage1_ms\": %.4f, "
                 "\"raf_cubic_rounds_per_s\": %.1f, \"raf_ms\": %.4f, \"device_resident_rounds_per_s\": %.1f, "
                 "\"device_resident_ms_runSumcheck\": %.4f, ", v, reps, ok ? "true" : "false", reps * v / t_s1, t_s1 / reps * 1e3, reps * v / t_raf,

@@ -450,6 +450,90 @@ pub fn SumcheckSession(comptime F: type) type {
     };
 }
 
+/// k multilinear tables folded together (LowToHigh) with product-form round evaluations: the loops of ValEvaluationProver
+/// (src/zkvm/ram/val_evaluation.zig:554-628), ValFinalProver (ram/val_final.zig:149-200), OutputSumcheckProver (ram/output_check.zig:375-470),
+/// InstructionLookupsClaimReductionProver (claim_reductions/instruction_lookups.zig:146-240) and ProductVirtualRemainderProver
+/// (spartan/product_remainder.zig:269-340). The prover struct keeps one of these instead of its `[]F` tables; the claim update, the
+/// compressed-coefficient conversion and the transcript stay as they are.
+pub fn ProductSession(comptime F: type) type {
+    comptime std.debug.assert(isBn254Scalar(F));
+    return struct {
+        const Self = @This();
+        handle: ffi.ProductSession = null,
+
+        /// `tables`: up to 8 slices of the same power-of-two length (copied to the device)
+        pub fn open(tables: []const []const F) Error!Self {
+            std.debug.assert(tables.len >= 1 and tables.len <= 8);
+            var ptrs: [8]?[*]const u64 = .{null} ** 8;
+            for (tables, 0..) |t, j| ptrs[j] = limbsOf(F, t);
+            var self: Self = .{};
+            if (ffi.zg_psc_open(@ptrCast(&ptrs), tables.len, tables[0].len, &self.handle) != ffi.OK) return Error.GpuFailure;
+            return self;
+        }
+        pub fn len(self: *const Self) usize {
+            return ffi.zg_psc_len(self.handle);
+        }
+        /// [p(0), p(1), p(2), p(3)] of sum_g prod_j T[prod[j]](t) * sum_m coeff[m] * T[lin[m]](t)  (lin empty: the plain product)
+        pub fn roundEvals(self: *Self, prod: []const c_int, lin: []const c_int, coeff: []const F) Error![4]F {
+            std.debug.assert(lin.len == coeff.len);
+            var out: [4]F = undefined;
+            if (ffi.zg_psc_round_evals(self.handle, prod.ptr, prod.len, lin.ptr, limbsOf(F, coeff), lin.len, @ptrCast(&out)) != ffi.OK) return Error.GpuFailure;
+            return out;
+        }
+        /// Gruen's (t0, t_inf) under the split-eq weights; e_out / e_in: device tables (see `GruenDeviceTables`)
+        pub fn roundGruen(self: *Self, prod: []const c_int, e_out: DeviceTable, e_in: DeviceTable) Error![2]F {
+            var t0: F = undefined;
+            var t_inf: F = undefined;
+            if (ffi.zg_psc_round_gruen(self.handle, prod.ptr, prod.len, e_out.ptr, e_out.len, e_in.ptr, e_in.len, &t0.limbs, &t_inf.limbs) != ffi.OK) return Error.GpuFailure;
+            return .{ t0, t_inf };
+        }
+        /// folds every table by the challenge; the next roundEvals with the same arguments is prepared by the same launch
+        pub fn bind(self: *Self, challenge: F) Error!void {
+            if (ffi.zg_psc_bind(self.handle, &challenge.limbs) != ffi.OK) return Error.GpuFailure;
+        }
+        /// each table's single remaining entry (getFinalClaims / getOpeningClaims)
+        pub fn finalValues(self: *Self, out: []F) Error!void {
+            if (ffi.zg_psc_final(self.handle, @ptrCast(out.ptr)) != ffi.OK) return Error.GpuFailure;
+        }
+        pub fn close(self: *Self) void {
+            if (self.handle != null) _ = ffi.zg_psc_close(self.handle);
+            self.* = .{};
+        }
+    };
+}
+
+/// a table in device memory (element pointer + entry count)
+pub const DeviceTable = struct { ptr: ?[*]const u64 = null, len: usize = 0 };
+
+/// GruenSplitEqPolynomial's two prefix-table sets resident in HBM for `ProductSession.roundGruen`: built once next to
+/// initWithScaling; `window(k_out, k_in)` = the tables getWindowEqTables returns (E_out_vec[k_out], E_in_vec[k_in]).
+pub const GruenDeviceTables = struct {
+    d_out: ?*anyopaque = null,
+    d_in: ?*anyopaque = null,
+
+    pub fn init(comptime F: type, w_out: []const F, w_in: []const F) Error!GruenDeviceTables {
+        var self: GruenDeviceTables = .{};
+        errdefer self.deinit();
+        if (ffi.zg_dev_alloc(((@as(usize, 2) << @intCast(w_out.len)) - 1) * 32, &self.d_out) != ffi.OK) return Error.GpuFailure;
+        if (ffi.zg_dev_alloc(((@as(usize, 2) << @intCast(w_in.len)) - 1) * 32, &self.d_in) != ffi.OK) return Error.GpuFailure;
+        if (ffi.zg_fr_eq_prefix_tables_dev(limbsOf(F, w_out), w_out.len, @ptrCast(@alignCast(self.d_out)), null) != ffi.OK) return Error.GpuFailure;
+        if (ffi.zg_fr_eq_prefix_tables_dev(limbsOf(F, w_in), w_in.len, @ptrCast(@alignCast(self.d_in)), null) != ffi.OK) return Error.GpuFailure;
+        return self;
+    }
+    pub fn window(self: *const GruenDeviceTables, k_out: usize, k_in: usize) struct { e_out: DeviceTable, e_in: DeviceTable } {
+        const o: [*]const u64 = @ptrCast(@alignCast(self.d_out.?));
+        const i: [*]const u64 = @ptrCast(@alignCast(self.d_in.?));
+        const no = @as(usize, 1) << @intCast(k_out);
+        const ni = @as(usize, 1) << @intCast(k_in);
+        return .{ .e_out = .{ .ptr = o + 4 * (no - 1), .len = no }, .e_in = .{ .ptr = i + 4 * (ni - 1), .len = ni } };
+    }
+    pub fn deinit(self: *GruenDeviceTables) void {
+        if (self.d_out != null) _ = ffi.zg_dev_free(self.d_out);
+        if (self.d_in != null) _ = ffi.zg_dev_free(self.d_in);
+        self.* = .{};
+    }
+};
+
 /// runSumcheck (:302-354) with prover AND toy verifier on the device. rounds: v × [c0, c1]; challenges: v (= final_point).
 pub fn runSumcheck(comptime F: type, allocator: std.mem.Allocator, evaluations: []const F) !struct { claim: F, rounds: []F, challenges: []F, final_eval: F, result: bool } {
     const v: usize = std.math.log2_int(usize, evaluations.len);

@@ -13,8 +13,11 @@
 //   ProductVirtualRemainderProver.computeRoundPolynomial / bindChallenge     src/zkvm/spartan/product_remainder.zig:269-420 (Gruen, left * right)
 // Exact modular arithmetic with canonical outputs: 2*f1 - f0, f0 + 2 (f1 - f0) and f(1) + (f(1) - f(0)) are the same field value, sums
 // commute, so every evaluation order gives the reference's bytes.
+#include <stdlib.h>
+
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "common.hip.h"
@@ -27,10 +30,19 @@
 
 namespace zg {
 
-constexpr unsigned PSC_MAX_BLOCKS = 1024;
+constexpr unsigned PSC_MAX_BLOCKS = 4096;
 constexpr size_t PSC_COUNTER_OFF = 16 * (size_t)PSC_MAX_BLOCKS;     // u64 words: block quadruples, then the arrival counter
 constexpr size_t PSC_MISC_BYTES = (PSC_COUNTER_OFF + 16) * 8;
 constexpr int PSC_FLAG = 24;                                        // h_pin: 16 words of values, sequence word at 24
+
+// compile-time loop: the table loops carry register arrays (prescaled coefficients) and must not stay loops
+template <int I, int N, class F>
+ZG_DEV void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 
 struct PscSpec {
     uint32_t prod[ZG_PSC_MAX_FACTORS];  // table indices of the plain factors
@@ -104,49 +116,47 @@ __global__ void __launch_bounds__(256) psc_evals_kernel(const uint64_t *base, si
     __shared__ uint4 sh[256 * 4];
     F29 cp[Q > 0 ? Q : 1];
     if constexpr (Q > 0) {
-#pragma unroll
-        for (int m = 0; m < Q; m++) {
+        static_for<0, Q>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
             Fr c;
 #pragma unroll
             for (int i = 0; i < 8; i++) c.l[i] = spec.coeff[m].l[i];
             cp[m] = fr29_prescale(c);
-        }
+        });
     }
     Fr e[4] = {Fr::zero(), Fr::zero(), Fr::zero(), Fr::zero()};
     size_t step = (size_t)gridDim.x * 256;
     for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < half; g += step) {
         Fr v0, v1, v2, v3;
-        bool have = false;
         if constexpr (Q > 0) {  // L(0), L(1) from the tables, L(2), L(3) by linearity
             Fr l0 = Fr::zero(), l1 = Fr::zero();
-#pragma unroll
-            for (int m = 0; m < Q; m++) {
+            static_for<0, Q>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
                 const uint64_t *t = base + 4 * ((size_t)spec.lin[m] * stride + 2 * g);
                 l0 = fe_add(l0, fr_mul29(fe_load<FrParams>(t), cp[m]));
                 l1 = fe_add(l1, fr_mul29(fe_load<FrParams>(t + 4), cp[m]));
-            }
+            });
             Fr d = fe_sub(l1, l0);
             v0 = l0;
             v1 = l1;
             v2 = fe_add(l1, d);
             v3 = fe_add(v2, d);
-            have = true;
         }
         if constexpr (P > 0) {
-        for (int j = 0; j < P; j++) {  // left to the compiler: four tables x four products do not unroll under its size limit
+        static_for<0, P>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
             const uint64_t *t = base + 4 * ((size_t)spec.prod[j] * stride + 2 * g);
             Fr lo = fe_load<FrParams>(t), hi = fe_load<FrParams>(t + 4);
             Fr d = fe_sub(hi, lo), f2 = fe_add(hi, d), f3 = fe_add(f2, d);
-            if (!have) {
+            if (Q == 0 && j == 0) {
                 v0 = lo; v1 = hi; v2 = f2; v3 = f3;
-                have = true;
             } else {
                 v0 = fr_mul29v(v0, lo);
                 v1 = fr_mul29v(v1, hi);
                 v2 = fr_mul29v(v2, f2);
                 v3 = fr_mul29v(v3, f3);
             }
-        }
+        });
         }
         e[0] = fe_add(e[0], v0);
         e[1] = fe_add(e[1], v1);
@@ -187,14 +197,20 @@ __global__ void __launch_bounds__(256) psc_gruen_kernel(const uint64_t *base, si
     psc_finish<1>(e, sh, partials, sums, counter, flag, seq);
 }
 
-// every table folded by r in one launch: out[i] = (1 - r) t[2i] + r t[2i+1] = t[2i] + r (t[2i+1] - t[2i]); blockIdx.y = table
-__global__ void __launch_bounds__(256) psc_fold_kernel(const uint64_t *base, size_t stride, size_t half, FrArg r, uint64_t *out, size_t ostride) {
+struct PscTables {
+    uint32_t t[ZG_PSC_MAX_TABLES];
+};
+
+// tables which[0..gridDim.y) folded by r in one launch: out[i] = (1 - r) t[2i] + r t[2i+1] = t[2i] + r (t[2i+1] - t[2i])
+__global__ void __launch_bounds__(256) psc_fold_kernel(const uint64_t *base, size_t stride, size_t half, FrArg r, uint64_t *out, size_t ostride,
+                                                       PscTables which) {
     Fr rv;
 #pragma unroll
     for (int i = 0; i < 8; i++) rv.l[i] = r.l[i];
     F29 rp = fr29_prescale(rv);
-    const uint64_t *t = base + 4 * (size_t)blockIdx.y * stride;
-    uint64_t *o = out + 4 * (size_t)blockIdx.y * ostride;
+    const uint32_t table = which.t[blockIdx.y];
+    const uint64_t *t = base + 4 * (size_t)table * stride;
+    uint64_t *o = out + 4 * (size_t)table * ostride;
     size_t step = (size_t)gridDim.x * 256;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < half; i += step) {
         Fr lo = fe_load<FrParams>(t + 8 * i), hi = fe_load<FrParams>(t + 8 * i + 4);
@@ -202,10 +218,91 @@ __global__ void __launch_bounds__(256) psc_fold_kernel(const uint64_t *base, siz
     }
 }
 
+// The fold of a round and the NEXT round's evaluations in one pass (the spec of the previous psc_round_evals call): a thread folds
+// the two old pairs 4g..4g+3 of every table the spec names into the new pair (2g, 2g+1), writes it, and evaluates the product form
+// on the values it still holds — one launch per round, and the folded tables are not read back.
+template <int P, int Q>
+__global__ void __launch_bounds__(256) psc_fold_evals_kernel(const uint64_t *base, size_t stride, size_t quarter, FrArg r, uint64_t *out,
+                                                             size_t ostride, PscSpec spec, uint64_t *partials, uint64_t *sums, uint32_t *counter,
+                                                             uint64_t *flag, uint64_t seq) {
+    __shared__ uint4 sh[256 * 4];
+    Fr rv;
+#pragma unroll
+    for (int i = 0; i < 8; i++) rv.l[i] = r.l[i];
+    F29 rp = fr29_prescale(rv);
+    F29 cp[Q > 0 ? Q : 1];
+    if constexpr (Q > 0) {
+        static_for<0, Q>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            Fr c;
+#pragma unroll
+            for (int i = 0; i < 8; i++) c.l[i] = spec.coeff[m].l[i];
+            cp[m] = fr29_prescale(c);
+        });
+    }
+    Fr e[4] = {Fr::zero(), Fr::zero(), Fr::zero(), Fr::zero()};
+    size_t step = (size_t)gridDim.x * 256;
+    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < quarter; g += step) {
+        Fr v0, v1, v2, v3;
+        if constexpr (Q > 0) {
+            Fr l0 = Fr::zero(), l1 = Fr::zero();
+            static_for<0, Q>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                const uint64_t *t = base + 4 * ((size_t)spec.lin[m] * stride + 4 * g);
+                Fr a0 = fe_load<FrParams>(t), a1 = fe_load<FrParams>(t + 4), a2 = fe_load<FrParams>(t + 8), a3 = fe_load<FrParams>(t + 12);
+                Fr lo = fe_add(a0, fr_mul29(fe_sub(a1, a0), rp)), hi = fe_add(a2, fr_mul29(fe_sub(a3, a2), rp));
+                uint64_t *o = out + 4 * ((size_t)spec.lin[m] * ostride + 2 * g);
+                fe_store(o, lo);
+                fe_store(o + 4, hi);
+                l0 = fe_add(l0, fr_mul29(lo, cp[m]));
+                l1 = fe_add(l1, fr_mul29(hi, cp[m]));
+            });
+            Fr d = fe_sub(l1, l0);
+            v0 = l0;
+            v1 = l1;
+            v2 = fe_add(l1, d);
+            v3 = fe_add(v2, d);
+        }
+        if constexpr (P > 0) {
+        static_for<0, P>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const uint64_t *t = base + 4 * ((size_t)spec.prod[j] * stride + 4 * g);
+            Fr a0 = fe_load<FrParams>(t), a1 = fe_load<FrParams>(t + 4), a2 = fe_load<FrParams>(t + 8), a3 = fe_load<FrParams>(t + 12);
+            Fr lo = fe_add(a0, fr_mul29(fe_sub(a1, a0), rp)), hi = fe_add(a2, fr_mul29(fe_sub(a3, a2), rp));
+            uint64_t *o = out + 4 * ((size_t)spec.prod[j] * ostride + 2 * g);
+            fe_store(o, lo);
+            fe_store(o + 4, hi);
+            Fr d = fe_sub(hi, lo), f2 = fe_add(hi, d), f3 = fe_add(f2, d);
+            if (Q == 0 && j == 0) {
+                v0 = lo; v1 = hi; v2 = f2; v3 = f3;
+            } else {
+                v0 = fr_mul29v(v0, lo);
+                v1 = fr_mul29v(v1, hi);
+                v2 = fr_mul29v(v2, f2);
+                v3 = fr_mul29v(v3, f3);
+            }
+        });
+        }
+        e[0] = fe_add(e[0], v0);
+        e[1] = fe_add(e[1], v1);
+        e[2] = fe_add(e[2], v2);
+        e[3] = fe_add(e[3], v3);
+    }
+    block_sum_pair(e[0], e[1], sh);
+    __syncthreads();
+    block_sum_pair(e[2], e[3], sh);
+    psc_finish<2>(e, sh, partials, sums, counter, flag, seq);
+}
+
 static unsigned psc_blocks(size_t half) {
+    static const unsigned cap = [] {
+        const char *e = getenv("ZG_PSC_BLOCKS");
+        int v = e && *e ? atoi(e) : 512;
+        return (unsigned)(v < 1 ? 1 : (v > (int)PSC_MAX_BLOCKS ? (int)PSC_MAX_BLOCKS : v));
+    }();
     size_t nb = (half + 255) / 256;
     if (nb < 1) nb = 1;
-    return (unsigned)(nb > 512 ? 512 : nb);  // two blocks per CU: up to four tables' pairs in flight per thread
+    return (unsigned)(nb > cap ? cap : nb);
 }
 
 }  // namespace zg
@@ -219,6 +316,11 @@ struct zg_psc_s {
     uint64_t *h_pin = nullptr;  // pinned, device-visible mailbox: up to 16 words of values, sequence word at PSC_FLAG
     hipStream_t st = nullptr;
     uint64_t seq = 0;
+    // the spec of the last zg_psc_round_evals call: zg_psc_bind then folds AND evaluates in one launch, and the next
+    // zg_psc_round_evals with the same spec only collects the mailbox
+    bool have_spec = false, evals_pending = false;
+    zg::PscSpec spec;
+    size_t spec_p = 0, spec_q = 0;
     std::mutex mu;
     size_t stride() const { return cur == 0 ? cap : (cap / 2 ? cap / 2 : 1); }
 };
@@ -309,6 +411,31 @@ static void psc_launch_evals_q(size_t q, unsigned nb, hipStream_t st, const uint
     }
 }
 
+template <int P>
+static void psc_launch_fold_evals_q(size_t q, unsigned nb, hipStream_t st, const uint64_t *base, size_t stride, size_t quarter, const FrArg &r,
+                                    uint64_t *out, size_t ostride, const PscSpec &spec, uint64_t *partials, uint64_t *sums, uint32_t *counter,
+                                    uint64_t *flag, uint64_t seq) {
+    switch (q) {
+    case 0: hipLaunchKernelGGL((psc_fold_evals_kernel<P, 0>), dim3(nb), dim3(256), 0, st, base, stride, quarter, r, out, ostride, spec, partials, sums, counter, flag, seq); break;
+    case 1: hipLaunchKernelGGL((psc_fold_evals_kernel<P, 1>), dim3(nb), dim3(256), 0, st, base, stride, quarter, r, out, ostride, spec, partials, sums, counter, flag, seq); break;
+    case 2: hipLaunchKernelGGL((psc_fold_evals_kernel<P, 2>), dim3(nb), dim3(256), 0, st, base, stride, quarter, r, out, ostride, spec, partials, sums, counter, flag, seq); break;
+    case 3: hipLaunchKernelGGL((psc_fold_evals_kernel<P, 3>), dim3(nb), dim3(256), 0, st, base, stride, quarter, r, out, ostride, spec, partials, sums, counter, flag, seq); break;
+    default: hipLaunchKernelGGL((psc_fold_evals_kernel<P, 4>), dim3(nb), dim3(256), 0, st, base, stride, quarter, r, out, ostride, spec, partials, sums, counter, flag, seq); break;
+    }
+}
+
+static bool psc_same_spec(const zg_psc_s *s, const PscSpec &spec, size_t p, size_t q) {
+    if (!s->have_spec || s->spec_p != p || s->spec_q != q) return false;
+    for (size_t j = 0; j < p; j++)
+        if (s->spec.prod[j] != spec.prod[j]) return false;
+    for (size_t m = 0; m < q; m++) {
+        if (s->spec.lin[m] != spec.lin[m]) return false;
+        for (int i = 0; i < 8; i++)
+            if (s->spec.coeff[m].l[i] != spec.coeff[m].l[i]) return false;
+    }
+    return true;
+}
+
 extern "C" {
 
 int zg_psc_open(const uint64_t *const *tables, size_t k, size_t len, zg_psc_t *out) {
@@ -382,11 +509,17 @@ int zg_psc_round_evals(zg_psc_t s, const int *prod_idx, size_t p, const int *lin
     }
     DeviceGuard dg(s->device);
     std::lock_guard<std::mutex> lk(s->mu);
+    if (s->evals_pending && psc_same_spec(s, spec, p, q)) return psc_wait(s, out, 16);  // produced by the fold of the last bind
     const size_t half = s->len / 2;
     unsigned nb = psc_blocks(half);
     uint32_t *counter = reinterpret_cast<uint32_t *>(s->d_misc + PSC_COUNTER_OFF);
     uint64_t *flag = s->h_pin + PSC_FLAG;
     s->seq++;
+    s->spec = spec;
+    s->spec_p = p;
+    s->spec_q = q;
+    s->have_spec = true;
+    s->evals_pending = true;  // the mailbox holds this spec's evaluations of the current tables until the next bind / Gruen round
     const uint64_t *base = s->buf[s->cur];
     switch (p) {
     case 0: psc_launch_evals_q<0>(q, nb, s->st, base, s->stride(), half, spec, s->d_misc, s->h_pin, counter, flag, s->seq); break;
@@ -412,6 +545,7 @@ int zg_psc_round_gruen(zg_psc_t s, const int *prod_idx, size_t p, const uint64_t
     const size_t half = s->len / 2;
     uint32_t in_bits = 0;
     while (((size_t)1 << in_bits) < n_in) in_bits++;
+    s->have_spec = s->evals_pending = false;  // the E tables differ from round to round: nothing to prepare at the bind
     unsigned nb = psc_blocks(half);
     uint32_t *counter = reinterpret_cast<uint32_t *>(s->d_misc + PSC_COUNTER_OFF);
     uint64_t *flag = s->h_pin + PSC_FLAG;
@@ -450,7 +584,34 @@ int zg_psc_bind(zg_psc_t s, const uint64_t r[4]) {
     const size_t ostride = nxt == 0 ? s->cap : (s->cap / 2 ? s->cap / 2 : 1);
     unsigned nbx = (unsigned)((half + 255) / 256);
     if (nbx > 1024) nbx = 1024;
-    hipLaunchKernelGGL(psc_fold_kernel, dim3(nbx, (unsigned)s->k), dim3(256), 0, s->st, s->buf[s->cur], s->stride(), half, ra, s->buf[nxt], ostride);
+    PscTables rest;
+    unsigned n_rest = 0;
+    const bool fuse = s->have_spec && half >= 2;  // a next round exists and its product form is known
+    s->evals_pending = false;
+    if (fuse) {
+        bool in_spec[ZG_PSC_MAX_TABLES] = {false};
+        for (size_t j = 0; j < s->spec_p; j++) in_spec[s->spec.prod[j]] = true;
+        for (size_t m = 0; m < s->spec_q; m++) in_spec[s->spec.lin[m]] = true;
+        for (size_t t = 0; t < s->k; t++)
+            if (!in_spec[t]) rest.t[n_rest++] = (uint32_t)t;
+        const size_t quarter = half / 2;
+        unsigned nb = psc_blocks(quarter);
+        uint32_t *counter = reinterpret_cast<uint32_t *>(s->d_misc + PSC_COUNTER_OFF);
+        s->seq++;
+        const uint64_t *base = s->buf[s->cur];
+        switch (s->spec_p) {
+        case 0: psc_launch_fold_evals_q<0>(s->spec_q, nb, s->st, base, s->stride(), quarter, ra, s->buf[nxt], ostride, s->spec, s->d_misc, s->h_pin, counter, s->h_pin + PSC_FLAG, s->seq); break;
+        case 1: psc_launch_fold_evals_q<1>(s->spec_q, nb, s->st, base, s->stride(), quarter, ra, s->buf[nxt], ostride, s->spec, s->d_misc, s->h_pin, counter, s->h_pin + PSC_FLAG, s->seq); break;
+        case 2: psc_launch_fold_evals_q<2>(s->spec_q, nb, s->st, base, s->stride(), quarter, ra, s->buf[nxt], ostride, s->spec, s->d_misc, s->h_pin, counter, s->h_pin + PSC_FLAG, s->seq); break;
+        case 3: psc_launch_fold_evals_q<3>(s->spec_q, nb, s->st, base, s->stride(), quarter, ra, s->buf[nxt], ostride, s->spec, s->d_misc, s->h_pin, counter, s->h_pin + PSC_FLAG, s->seq); break;
+        default: psc_launch_fold_evals_q<4>(s->spec_q, nb, s->st, base, s->stride(), quarter, ra, s->buf[nxt], ostride, s->spec, s->d_misc, s->h_pin, counter, s->h_pin + PSC_FLAG, s->seq); break;
+        }
+        s->evals_pending = true;
+    } else {
+        for (size_t t = 0; t < s->k; t++) rest.t[n_rest++] = (uint32_t)t;
+    }
+    if (n_rest)  // the tables the product form does not name (or all of them), off the round's critical path
+        hipLaunchKernelGGL(psc_fold_kernel, dim3(nbx, n_rest), dim3(256), 0, s->st, s->buf[s->cur], s->stride(), half, ra, s->buf[nxt], ostride, rest);
     ZG_HIP(hipGetLastError());  // asynchronous: the next round's kernel follows in stream order
     s->cur = nxt;
     s->len = half;

@@ -784,6 +784,156 @@ inline SumcheckResult runSumcheck(const DensePolynomial &polynomial) {
     return out;
 }
 
+// ---------------------------------------------------------------- product-form provers (zg_psc_*)
+// Lagrange interpolation through evals at 0,1,2,3 evaluated at x — the claim update of every cubic prover
+// (val_evaluation.zig:630-660, instruction_lookups.zig:250-270, product_remainder.zig:534-559)
+inline Fr cubicAtPoint(const std::array<Fr, 4> &evals, const Fr &x) {
+    Fr x1 = x.sub(Fr::one()), x2 = x.sub(Fr::fromU64(2)), x3 = x.sub(Fr::fromU64(3));
+    // the four constant inverses are computed once (a Fermat inversion is ~380 products: four per call would dominate a round)
+    static const std::array<Fr, 4> inv = [] {
+        std::array<Fr, 4> r;
+        Fr::zero().sub(Fr::fromU64(6)).inverse(r[0]);
+        Fr::fromU64(2).inverse(r[1]);
+        Fr::zero().sub(Fr::fromU64(2)).inverse(r[2]);
+        Fr::fromU64(6).inverse(r[3]);
+        return r;
+    }();
+    const Fr &i6n = inv[0], &i2 = inv[1], &i2n = inv[2], &i6 = inv[3];
+    Fr L0 = x1.mul(x2).mul(x3).mul(i6n), L1 = x.mul(x2).mul(x3).mul(i2), L2 = x.mul(x1).mul(x3).mul(i2n), L3 = x.mul(x1).mul(x2).mul(i6);
+    return evals[0].mul(L0).add(evals[1].mul(L1)).add(evals[2].mul(L2)).add(evals[3].mul(L3));
+}
+// UniPoly.interpolateDegree3 / evalsToCompressed (src/poly/mod.zig:632-685)
+inline std::array<Fr, 4> interpolateDegree3(const std::array<Fr, 4> &p) {
+    static const std::array<Fr, 2> inv = [] {
+        std::array<Fr, 2> r;
+        Fr::fromU64(6).inverse(r[0]);
+        Fr::fromU64(2).inverse(r[1]);
+        return r;
+    }();
+    const Fr &inv6 = inv[0], &inv2 = inv[1];
+    Fr c1 = Fr::zero().sub(Fr::fromU64(11).mul(p[0])).add(Fr::fromU64(18).mul(p[1])).sub(Fr::fromU64(9).mul(p[2])).add(Fr::fromU64(2).mul(p[3])).mul(inv6);
+    Fr c2 = Fr::fromU64(2).mul(p[0]).sub(Fr::fromU64(5).mul(p[1])).add(Fr::fromU64(4).mul(p[2])).sub(p[3]).mul(inv2);
+    Fr c3 = Fr::zero().sub(p[0]).add(Fr::fromU64(3).mul(p[1])).sub(Fr::fromU64(3).mul(p[2])).add(p[3]).mul(inv6);
+    return {p[0], c1, c2, c3};
+}
+inline std::array<Fr, 3> evalsToCompressed(const std::array<Fr, 4> &evals) {
+    auto c = interpolateDegree3(evals);
+    return {c[0], c[2], c[3]};
+}
+
+// k tables folded together in one device session
+class ProductSumcheckSession {
+public:
+    explicit ProductSumcheckSession(const std::vector<const std::vector<Fr> *> &tables) {
+        std::vector<const uint64_t *> ptrs;
+        for (auto *t : tables) ptrs.push_back(reinterpret_cast<const uint64_t *>(t->data()));
+        check(zg_psc_open(ptrs.data(), ptrs.size(), tables.empty() ? 0 : tables[0]->size(), &s_), "zg_psc_open");
+    }
+    ~ProductSumcheckSession() { zg_psc_close(s_); }
+    ProductSumcheckSession(const ProductSumcheckSession &) = delete;
+    size_t len() const { return zg_psc_len(s_); }
+    std::array<Fr, 4> roundEvals(const std::vector<int> &prod, const std::vector<int> &lin = {}, const std::vector<Fr> &coeff = {}) {
+        std::array<Fr, 4> out;
+        check(zg_psc_round_evals(s_, prod.data(), prod.size(), lin.data(), reinterpret_cast<const uint64_t *>(coeff.data()), lin.size(),
+                                 reinterpret_cast<uint64_t *>(out.data())), "zg_psc_round_evals");
+        return out;
+    }
+    std::array<Fr, 2> roundGruen(const std::vector<int> &prod, const uint64_t *d_e_out, size_t n_out, const uint64_t *d_e_in, size_t n_in) {
+        std::array<Fr, 2> out;
+        check(zg_psc_round_gruen(s_, prod.data(), prod.size(), d_e_out, n_out, d_e_in, n_in, out[0].limbs, out[1].limbs), "zg_psc_round_gruen");
+        return out;
+    }
+    void bind(const Fr &r) { check(zg_psc_bind(s_, r.limbs), "zg_psc_bind"); }
+    std::vector<Fr> final() {
+        std::vector<Fr> out(zg_psc_tables(s_));
+        check(zg_psc_final(s_, reinterpret_cast<uint64_t *>(out.data())), "zg_psc_final");
+        return out;
+    }
+
+private:
+    zg_psc_t s_ = nullptr;
+};
+
+// ValEvaluationProver's loop (src/zkvm/ram/val_evaluation.zig:545-700); lt == nullptr: ValFinalProver (ram/val_final.zig:144-230)
+class ValEvaluationProver {
+public:
+    Fr current_claim;
+    size_t round = 0;
+    ValEvaluationProver(const std::vector<Fr> &inc, const std::vector<Fr> &wa, const std::vector<Fr> *lt, const Fr &claim)
+        : current_claim(claim), s_(lt ? std::vector<const std::vector<Fr> *>{&inc, &wa, lt} : std::vector<const std::vector<Fr> *>{&inc, &wa}),
+          factors_(lt ? std::vector<int>{0, 1, 2} : std::vector<int>{0, 1}) {}
+    std::array<Fr, 4> computeRoundPolynomial() {  // :554-603
+        if (s_.len() < 2) {
+            Fr acc = Fr::one();
+            for (const Fr &v : s_.final()) acc = acc.mul(v);
+            return {acc, Fr::zero(), Fr::zero(), Fr::zero()};
+        }
+        return s_.roundEvals(factors_);
+    }
+    void bindChallengeWithPoly(const Fr &r, const std::array<Fr, 4> &round_poly) {  // :609-660
+        if (s_.len() >= 2) {
+            s_.bind(r);
+            current_claim = cubicAtPoint(round_poly, r);
+        }
+        round++;
+    }
+    std::vector<Fr> getFinalClaims() { return s_.final(); }
+
+private:
+    ProductSumcheckSession s_;
+    std::vector<int> factors_;
+};
+
+// ProductVirtualRemainderProver's loop (src/zkvm/spartan/product_remainder.zig:269-394): Gruen's (t0, t_inf) on the device under
+// split-eq prefix tables resident in HBM, the cubic on the host
+class ProductVirtualRemainderProver {
+public:
+    Fr current_claim;
+    size_t current_round = 0;
+    GruenSplitEqPolynomial split_eq;
+    ProductVirtualRemainderProver(const std::vector<Fr> &left, const std::vector<Fr> &right, const std::vector<Fr> &tau_low, const Fr &lagrange_kernel,
+                                  const Fr &uni_skip_claim)
+        : current_claim(uni_skip_claim), split_eq(tau_low, &lagrange_kernel), s_({&left, &right}) {
+        size_t m = tau_low.size() / 2;
+        check(zg_dev_alloc(((size_t(2) << m) - 1) * 32, &d_out_), "zg_dev_alloc");
+        check(zg_dev_alloc(((size_t(2) << split_eq.num_x_in) - 1) * 32, &d_in_), "zg_dev_alloc");
+        check(zg_fr_eq_prefix_tables_dev(reinterpret_cast<const uint64_t *>(tau_low.data()), m, static_cast<uint64_t *>(d_out_), nullptr), "prefix");
+        check(zg_fr_eq_prefix_tables_dev(reinterpret_cast<const uint64_t *>(tau_low.data() + m), split_eq.num_x_in, static_cast<uint64_t *>(d_in_), nullptr),
+              "prefix");
+    }
+    ~ProductVirtualRemainderProver() {
+        zg_dev_free(d_out_);
+        zg_dev_free(d_in_);
+    }
+    bool roundEvals(std::array<Fr, 4> &evals) {
+        if (s_.len() < 2) return false;
+        auto w = split_eq.getWindowEqTables(current_round, 1);  // sizes; the same tables sit at element 2^k - 1 of the device buffers
+        size_t n_out = w.E_out->size(), n_in = w.E_in->size();
+        auto t = s_.roundGruen({0, 1}, static_cast<const uint64_t *>(d_out_) + 4 * (n_out - 1), n_out, static_cast<const uint64_t *>(d_in_) + 4 * (n_in - 1), n_in);
+        evals = split_eq.computeCubicRoundPoly(t[0], t[1], current_claim);
+        return true;
+    }
+    std::array<Fr, 3> computeRoundPolynomial() {  // compressed [c0, c2, c3]; [claim, 0, 0] without groups (:274-276)
+        std::array<Fr, 4> ev;
+        if (!roundEvals(ev)) return {current_claim, Fr::zero(), Fr::zero()};
+        return evalsToCompressed(ev);
+    }
+    void bindChallenge(const Fr &challenge) {
+        s_.bind(challenge);
+        split_eq.bind(challenge);
+        current_round++;
+    }
+    void updateClaim(const std::array<Fr, 4> &round_evals, const Fr &challenge) { current_claim = cubicAtPoint(round_evals, challenge); }
+    Fr getFinalClaim() {
+        auto f = s_.final();
+        return f[0].mul(f[1]);
+    }
+
+private:
+    ProductSumcheckSession s_;
+    void *d_out_ = nullptr, *d_in_ = nullptr;
+};
+
 // ---------------------------------------------------------------- LassoProver (src/zkvm/lasso/prover.zig:80-551)
 // The sumcheck over eq_evals on ONE device session: address rounds = zg_sumcheck_bit_round / bit_bind, cycle rounds = the session's
 // HIGH_HALF round_sums / bind. The prefix-suffix structures the reference binds alongside (:402-404) do not enter the round
