@@ -127,5 +127,54 @@ while time.time() - t0 < budget:
         cur = ob.fr_bind_high(cur, ch) if layout == 0 else ob.fr_bind_low(cur, ch)
     assert np.array_equal(ss.final(), cur[0])
     ss.close()
+    # product-form provers on one k-table session against the oracle's restatement of each loop
+    if v >= 1:
+        kind = int(rng.integers(0, 4))
+        chs = rand_fr(v)
+        claim = rand_fr(1)[0]
+        if kind <= 1:
+            tabs = [rand_fr(n, sparse), rand_fr(n), rand_fr(n) if kind == 0 else None]
+            g = api.ValEvaluationProver(*tabs, claim) if kind == 0 else api.ValFinalProver(tabs[0], tabs[1], claim)
+            o = ob.ValEvaluationProver(*tabs, claim)
+            for k in range(v):
+                rp, wrp = g.computeRoundPolynomial(), o.computeRoundPolynomial()
+                assert np.array_equal(rp, wrp), ("val", kind, v, k)
+                g.bindChallengeWithPoly(chs[k], rp)
+                o.bindChallengeWithPoly(chs[k], wrp)
+                assert np.array_equal(g.current_claim, o.current_claim)
+            assert all(np.array_equal(a, b) for a, b in zip(g.getFinalClaims(), o.getFinalClaims()))
+        elif kind == 2:
+            tabs = [rand_fr(n, sparse and j == 1) for j in range(5)]
+            g, o = api.OutputSumcheckProver(*tabs, claim), ob.OutputSumcheckProver(*tabs, claim)
+            for k in range(v):
+                ev, wev = g.roundEvals(), o.roundEvals()
+                assert np.array_equal(ev, wev), ("output", v, k)
+                g.bindChallenge(chs[k]); o.bindChallenge(chs[k])
+                g.updateClaim(ev, chs[k]); o.updateClaim(wev, chs[k])
+                assert np.array_equal(g.current_claim, o.current_claim)
+            fg, fo = g.getFinalClaims(), o.getFinalClaims()
+            assert all(np.array_equal(fg[key], fo[key]) for key in fo)
+        else:
+            left, right, tau, kern = rand_fr(n, sparse), rand_fr(n), rand_fr(v), rand_fr(1)[0]
+            g, o = api.ProductVirtualRemainderProver(left, right, tau, kern, claim), ob.ProductRemainderProver(left, right, tau, kern, claim)
+            for k in range(v):
+                ev, wev = g.roundEvals(), o.roundEvals()
+                assert np.array_equal(ev, wev), ("product", v, k)
+                g.bindChallenge(chs[k]); o.bindChallenge(chs[k])
+                g.updateClaim(ev, chs[k]); o.updateClaim(wev, chs[k])
+            assert np.array_equal(g.getFinalClaim(), o.getFinalClaim())
+        g.deinit()
+    # LassoProver with a ragged cycle count
+    if v <= 10:
+        log_K = int(rng.integers(1, 129))
+        ncyc = int(rng.integers(1, n + 1))
+        lidx = rng.integers(0, 1 << 63, size=(ncyc, 2), dtype=np.uint64)
+        if log_K < 128:
+            mask = (1 << log_K) - 1
+            lidx[:, 0] &= np.uint64(mask & (2**64 - 1))
+            lidx[:, 1] &= np.uint64(mask >> 64)
+        w = rand_fr(v)
+        got, want = api.runLassoProver(lidx, v, log_K, w), ob.run_lasso_prover(lidx, v, log_K, w)
+        assert all(np.array_equal(got[key], want[key]) for key in want), ("lasso", v, log_K, ncyc)
     cases += 1
 print(f"fuzz ok: {cases} random instances (all entry points) in {time.time() - t0:.1f} s")
