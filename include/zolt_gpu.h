@@ -272,7 +272,8 @@ ZG_API int zg_sumcheck_raf_round(zg_sc_t s, const uint64_t base[4], uint64_t cur
  * each; zg_dev_alloc + zg_memcpy_h2d), n_idx <= the session's length.
  *   bit_round = computeAddressRoundPoly's sum_0 / sum_1 (:283-293) over the first n_idx entries;
  *   bit_bind  = receiveChallenge's address branch (:375-399): entry j *= (bit of idx[j]) ? r : 1 - r, claim = sum of ALL entries.
- * bit_bind also leaves the next round's sums (bit + 1) behind, so the following bit_round costs no pass over the table. */
+ * bit_bind also leaves the next round's sums (bit + 1) behind, so the following bit_round costs no pass over the table (they are
+ * keyed by d_idx128, n_idx and the bit: the index buffer's CONTENTS must stay unchanged between the two calls, as a prover's do). */
 ZG_API int zg_sumcheck_bit_round(zg_sc_t s, const uint64_t *d_idx128, size_t n_idx, unsigned bit, uint64_t sum0[4], uint64_t sum1[4]);
 ZG_API int zg_sumcheck_bit_bind(zg_sc_t s, const uint64_t *d_idx128, size_t n_idx, unsigned bit, const uint64_t r[4], uint64_t claim[4]);
 /* LassoProver.computeAddressRoundPoly's two sums (src/zkvm/lasso/prover.zig:283-293): sum0 / sum1 = the sum of vals[j] over the
