@@ -728,3 +728,81 @@ class ProductRemainderProver:
 
     def getFinalClaim(self):
         return f_mul(FR, self.left[:1], self.right[:1])[0]
+
+
+# ---- batched sumcheck driver (src/zkvm/batched_sumcheck.zig) restated over the C oracle's field arithmetic
+def _fe(v):
+    return f_from_u64(FR, np.array([v], dtype=np.uint64))
+
+
+def _mul(a, b):
+    return f_mul(FR, _c(a).reshape(1, 4), _c(b).reshape(1, 4))[0]
+
+
+def _add(a, b):
+    return f_add(FR, _c(a).reshape(1, 4), _c(b).reshape(1, 4))[0]
+
+
+def _sub(a, b):
+    return f_sub(FR, _c(a).reshape(1, 4), _c(b).reshape(1, 4))[0]
+
+
+class BatchedSumcheck:
+    """BatchedSumcheckProver (batched_sumcheck.zig:77-262). Instances: objects with num_rounds, input_claim,
+    computeRoundPoly(round) -> (4,4), bindChallenge(challenge)."""
+
+    def __init__(self, instances, coeffs):
+        self.instances, self.coeffs = instances, [_c(c) for c in coeffs]
+        self.max_num_rounds = max(i.num_rounds for i in instances)
+        self.current_round = 0
+        self.challenges = []
+        acc = np.zeros(4, dtype=np.uint64)
+        for inst, c in zip(instances, self.coeffs):  # :161-173
+            scaled = _c(inst.input_claim)
+            for _ in range(self.max_num_rounds - inst.num_rounds):
+                scaled = _add(scaled, scaled)
+            acc = _add(acc, _mul(scaled, c))
+        self.current_claim = acc
+
+    def combinedEvals(self):  # :193-222
+        comb = np.zeros((4, 4), dtype=np.uint64)
+        for inst, c in zip(self.instances, self.coeffs):
+            start = self.max_num_rounds - inst.num_rounds
+            if self.current_round >= start:
+                ev = inst.computeRoundPoly(self.current_round - start)
+                for j in range(4):
+                    comb[j] = _add(comb[j], _mul(ev[j], c))
+            else:
+                scaled = _c(inst.input_claim)
+                for _ in range(start - self.current_round):
+                    scaled = _add(scaled, scaled)
+                w = _mul(scaled, c)
+                for j in range(4):
+                    comb[j] = _add(comb[j], w)
+        return comb
+
+    def computeRoundPolynomial(self):
+        return evals_to_compressed(self.combinedEvals())
+
+    def bindChallenge(self, challenge):  # :229-241
+        self.challenges.append(_c(challenge).copy())
+        for inst in self.instances:
+            if self.current_round >= self.max_num_rounds - inst.num_rounds:
+                inst.bindChallenge(challenge)
+        self.current_round += 1
+
+    def updateClaim(self, round_evals, challenge):
+        self.current_claim = raf_update_claim(round_evals, challenge)
+
+
+def decompress_round_poly(compressed, current_claim):
+    """batched_sumcheck.zig:380-400"""
+    c0, c2, c3 = (_c(x) for x in compressed)
+    c1 = _sub(_sub(_sub(_sub(current_claim, c0), c0), c2), c3)
+    out = []
+    for t in range(4):
+        v = _add(c0, _mul(c1, _fe(t)[0]))
+        v = _add(v, _mul(c2, _fe(t * t)[0]))
+        v = _add(v, _mul(c3, _fe(t * t * t)[0]))
+        out.append(v)
+    return np.stack(out)

@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Extracts the Stage-2 BATCHED sumcheck the reference captured in its own run log into tests/golden/stage2_batched_rounds.json
+(data only: inputs and expected outputs, no source text).
+
+Source: /root/reference/logs/zolt.log, printed by src/zkvm/batched_sumcheck.zig:127-186 (setupBatching) and :306-420
+(generateBatchedProof) with F.toBytes() — the canonical value as 32 little-endian bytes:
+  STAGE2_PRE      input_claim[i], num_rounds[i], degree[i] of the five instances, batching_coeff[i] (challengeScalarFull)
+  STAGE2_INITIAL  batched_claim = sum_i coeff_i * 2^(max_rounds - rounds_i) * claim_i                     (:161-173)
+  STAGE2_ROUND_k  current_claim, the compressed round polynomial c0, c2, c3, the challenge, next_claim     (:334-412)
+  STAGE2_FINAL    output_claim
+A challenge is a MontU128Challenge: its stored Montgomery limbs are [0, 0, lo, hi]; the bytes printed are the canonical value of
+that element.
+
+Run in the build container (needs /root/reference); the JSON it writes is committed.
+"""
+import json
+import os
+import re
+
+LOG = "/root/reference/logs/zolt.log"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "stage2_batched_rounds.json")
+
+
+def le_bytes(line):
+    nums = re.search(r"= \{ ([0-9, ]+)\}", line).group(1)
+    b = bytes(int(x) for x in nums.replace(" ", "").strip(",").split(","))
+    assert len(b) == 32
+    return b.hex()
+
+
+def main():
+    lines = open(LOG, errors="replace").read().splitlines()
+    claims, rounds_of, degrees, coeffs = {}, {}, {}, {}
+    initial = final = None
+    rounds = {}
+    for l in lines:
+        m = re.match(r"\[ZOLT\] STAGE2_PRE: input_claim\[(\d+)\] = ", l)
+        if m:
+            claims[int(m.group(1))] = le_bytes(l)
+            continue
+        m = re.match(r"\[ZOLT\] STAGE2_PRE: num_rounds\[(\d+)\] = (\d+)", l)
+        if m:
+            rounds_of[int(m.group(1))] = int(m.group(2))
+            continue
+        m = re.match(r"\[ZOLT\] STAGE2_PRE: degree\[(\d+)\] = (\d+)", l)
+        if m:
+            degrees[int(m.group(1))] = int(m.group(2))
+            continue
+        m = re.match(r"\[ZOLT\] STAGE2_PRE: batching_coeff\[(\d+)\] = ", l)
+        if m:
+            coeffs[int(m.group(1))] = le_bytes(l)
+            continue
+        if l.startswith("[ZOLT] STAGE2_INITIAL: batched_claim = "):
+            initial = le_bytes(l)
+            continue
+        if l.startswith("[ZOLT] STAGE2_FINAL: output_claim = "):
+            final = le_bytes(l)
+            continue
+        m = re.match(r"\[ZOLT\] STAGE2_ROUND_(\d+): (current_claim|c0|c2|c3|challenge|next_claim) = ", l)
+        if m:
+            rounds.setdefault(int(m.group(1)), {})[m.group(2)] = le_bytes(l)
+    n = len(claims)
+    assert n == 5 and sorted(rounds) == list(range(max(rounds_of.values())))
+    out = {
+        "source": "reference logs/zolt.log, STAGE2_* lines of src/zkvm/batched_sumcheck.zig (canonical little-endian hex)",
+        "input_claims": [claims[i] for i in range(n)],
+        "num_rounds": [rounds_of[i] for i in range(n)],
+        "degrees": [degrees[i] for i in range(n)],
+        "batching_coeffs": [coeffs[i] for i in range(n)],
+        "initial_batched_claim": initial,
+        "rounds": [rounds[k] for k in sorted(rounds)],
+        "output_claim": final,
+    }
+    for r in out["rounds"]:
+        assert set(r) == {"current_claim", "c0", "c2", "c3", "challenge", "next_claim"}
+    with open(OUT, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", OUT, len(out["rounds"]), "rounds")
+
+
+if __name__ == "__main__":
+    main()

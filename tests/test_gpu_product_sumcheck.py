@@ -299,3 +299,113 @@ def test_fused_bind_keeps_every_table_and_every_spec_right(env):
     assert [api.fr_to_int(x) for x in s.final()] == [T[0] for T in ints]
     s.close()
     d_out.free(); d_in.free()
+
+
+def _stage2_like_batch(api, ob, side, seed):
+    """five instances with different round counts, as Stage 2 batches them (src/zkvm/batched_sumcheck.zig:1-21): ProductVirtualRemainder
+    (6 rounds), RafEvaluation (9), ValEvaluation (11), OutputSumcheck (9), InstructionLookupsClaimReduction (6).
+    side = "gpu": device-backed mirrors, "oracle": the oracle's restatements. -> list of (num_rounds, claim, round_fn, bind_fn, finals_fn)"""
+    F = lambda s, n, sp=False: _rand(ob, seed + s, n, sparse=sp)
+    out = []
+    claims = F(90, 5)
+    left, right, tau, kern = F(1, 64, True), F(2, 64), F(3, 6), F(4, 1)[0]
+    ra = F(5, 512)
+    inc, wa, lt = F(6, 2048, True), F(7, 2048), F(8, 2048)
+    oc = [F(10 + j, 512, j == 1) for j in range(5)]
+    il = [F(20 + j, 64) for j in range(4)]
+    gamma = F(30, 1)[0]
+    if side == "gpu":
+        pv = api.ProductVirtualRemainderProver(left, right, tau, kern, claims[0])
+        raf = api.RafEvaluationProver(ra, 0x7FFF8000, 9, claims[1])
+        ve = api.ValEvaluationProver(inc, wa, lt, claims[2])
+        op = api.OutputSumcheckProver(*oc, claims[3])
+        ip = api.InstructionLookupsClaimReductionProver(*il, gamma, claims[4])
+        raf_round = raf.computeRoundPolynomialCubic
+    else:
+        pv = ob.ProductRemainderProver(left, right, tau, kern, claims[0])
+        ve = ob.ValEvaluationProver(inc, wa, lt, claims[2])
+        op = ob.OutputSumcheckProver(*oc, claims[3])
+        ip = ob.InstructionLookupsClaimReduction(*il, gamma, claims[4])
+
+        class Raf:  # the oracle's RAF loop: table, bound challenges, claim (raf_checking.zig:335-445)
+            def __init__(self):
+                self.ra, self.bound, self.current_claim = ra.copy(), np.zeros((0, 4), dtype=np.uint64), claims[1].copy()
+
+            def computeRoundPolynomialCubic(self):
+                return ob.raf_round_cubic(self.ra, 0x7FFF8000, self.bound, 9, self.current_claim)
+
+            def updateClaim(self, ev, ch):
+                self.current_claim = ob.raf_update_claim(ev, ch)
+
+            def bindChallenge(self, ch):
+                self.ra = ob.fr_bind_low(self.ra, ch)
+                self.bound = np.concatenate([self.bound, np.asarray(ch, dtype=np.uint64)[None, :]])
+
+        raf = Raf()
+        raf_round = raf.computeRoundPolynomialCubic
+    last = {}
+
+    def wrap(key, prover, round_fn, update=True):
+        def rnd(_round):
+            last[key] = round_fn()
+            return last[key]
+
+        def bind(ch):
+            if update:
+                prover.updateClaim(last[key], ch)
+            prover.bindChallenge(ch)
+        return rnd, bind
+
+    r, b = wrap("pv", pv, pv.roundEvals)
+    out.append((6, claims[0], r, b, lambda: pv.getFinalClaim()))
+    r, b = wrap("raf", raf, raf_round)
+    out.append((9, claims[1], r, b, lambda: raf.current_claim))
+    out.append((11, claims[2], lambda _r: last.__setitem__("ve", ve.computeRoundPolynomial()) or last["ve"],
+                lambda ch: ve.bindChallengeWithPoly(ch, last["ve"]), lambda: np.stack(ve.getFinalClaims())))
+    r, b = wrap("op", op, op.roundEvals)
+    out.append((9, claims[3], r, b, lambda: np.stack([v for v in op.getFinalClaims().values()])))
+    r, b = wrap("ip", ip, ip.computeRoundPolynomialCubic)
+    out.append((6, claims[4], r, b, lambda: np.stack([v for v in ip.getOpeningClaims().values()])))
+    return out
+
+
+def test_batched_sumcheck_stage2_shape(env):
+    """BatchedSumcheckProver + generateBatchedProof (src/zkvm/batched_sumcheck.zig:77-430) over five device-backed instances that
+    start at different rounds, with the Blake2b transcript: every compressed round polynomial, challenge, claim and every instance's
+    final values against the oracle's restatement of the driver over the oracle's restatement of each instance."""
+    api, lib, ob = env
+    gpu, ora = _stage2_like_batch(api, ob, "gpu", 8000), _stage2_like_batch(api, ob, "oracle", 8000)
+    p = api.BatchedSumcheckProver()
+    for nr, claim, rnd, bind, _ in gpu:
+        p.addInstance(api.SumcheckInstance(nr, 3, claim, rnd, bind))
+    t = api.Blake2bTranscript(b"Jolt")
+    p.setupBatching(t)
+
+    class Inst:
+        def __init__(self, nr, claim, rnd, bind):
+            self.num_rounds, self.input_claim, self.computeRoundPoly, self.bindChallenge = nr, claim, rnd, bind
+
+    o = ob.BatchedSumcheck([Inst(nr, claim, rnd, bind) for nr, claim, rnd, bind, _ in ora], p.batching_coeffs)
+    assert p.numRounds() == 11 and np.array_equal(p.current_claim, o.current_claim)
+    proof = api.generateBatchedProof(p, t)
+    # the oracle side replays the same transcript: absorb its own polynomials, the challenges must come out the same
+    t2 = api.Blake2bTranscript(b"Jolt")
+    for _, claim, _, _, _ in ora:
+        t2.appendScalar(claim)
+    for _ in ora:
+        t2.challengeScalarFull()
+    for k in range(11):
+        comp = o.computeRoundPolynomial()
+        assert np.array_equal(comp, proof["round_polys"][k]), k
+        t2.appendMessage(b"UniPoly_begin")
+        for c in comp:
+            t2.appendScalar(c)
+        t2.appendMessage(b"UniPoly_end")
+        ch = t2.challengeScalar()
+        assert np.array_equal(ch, proof["challenges"][k])
+        full = ob.decompress_round_poly(comp, o.current_claim)
+        o.updateClaim(full, ch)
+        o.bindChallenge(ch)
+    assert np.array_equal(o.current_claim, proof["final_claim"])
+    for (_, _, _, _, fg), (_, _, _, _, fo) in zip(gpu, ora):
+        assert np.array_equal(fg(), fo())

@@ -210,3 +210,46 @@ def test_keccak_transcript_inline_tests_of_the_reference():
     o1, o2 = a.challengeBytes(b"label", 64), b.challengeBytes(b"label", 64)
     assert o1 == o2 and len(o1) == 64
     assert len(a.challengeBytes(b"more", 300)) == 300  # three permutations: 136 + 136 + 28 bytes
+
+
+def test_stage2_batched_sumcheck_of_the_captured_run(golden_dir):
+    """The Stage-2 BATCHED sumcheck the reference ran and logged (logs/zolt.log STAGE2_* lines, src/zkvm/batched_sumcheck.zig:127-430;
+    fixture tests/golden/stage2_batched_rounds.json): five instances with 8/16/24/16/8 rounds. Pins, against reference-produced
+    numbers, the batched claim sum_i coeff_i 2^(24 - rounds_i) claim_i and — for all 24 rounds — the recovery of
+    [s(0..3)] from the compressed [c0, c2, c3] + claim, the cubic Lagrange step to next_claim, and evalsToCompressed as the inverse
+    of that recovery; both in the host mirror (zolt_amd.api) and in the oracle's restatement."""
+    import json
+    import os
+    from zolt_amd import api
+    d = json.load(open(os.path.join(golden_dir, "stage2_batched_rounds.json")))
+    M = lambda h: api.fr_from_int(int.from_bytes(bytes.fromhex(h), "little"))
+
+    class Inst:
+        def __init__(self, nr, claim):
+            self.num_rounds, self.input_claim = nr, claim
+
+    insts = [Inst(r, M(c)) for r, c in zip(d["num_rounds"], d["input_claims"])]
+    coeffs = [M(c) for c in d["batching_coeffs"]]
+    assert all(int.from_bytes(bytes.fromhex(c), "little") < 1 << 128 for c in d["batching_coeffs"])  # challengeScalarFull values
+    assert np.array_equal(ob.BatchedSumcheck(insts, coeffs).current_claim, M(d["initial_batched_claim"]))
+    p = api.BatchedSumcheckProver()
+    for i in insts:
+        p.addInstance(api.SumcheckInstance(i.num_rounds, 3, i.input_claim, None, None))
+    p.batching_coeffs = coeffs
+    assert p.numRounds() == 24 and np.array_equal(p.batchedClaim(), M(d["initial_batched_claim"]))
+    # before any instance has started the combined polynomial is the constant claim / 2 (:208-218): rounds 0..7 of the capture
+    # have only the 24-round instance active, so this branch is exercised by the real data through the claim chain below
+    prev = M(d["initial_batched_claim"])
+    for k, r in enumerate(d["rounds"]):
+        claim, ch = M(r["current_claim"]), M(r["challenge"])
+        assert np.array_equal(claim, prev), k
+        assert not ch[0] and not ch[1] and int(ch[3]) < 1 << 61  # MontU128Challenge: Montgomery limbs [0, 0, lo, hi], 125 bits
+        comp = np.stack([M(r["c0"]), M(r["c2"]), M(r["c3"])])
+        fa, fo = api.decompressRoundPoly(comp, claim), ob.decompress_round_poly(comp, claim)
+        assert np.array_equal(fa, fo)
+        assert (api.fr_to_int(fa[0]) + api.fr_to_int(fa[1])) % api.R_MOD == api.fr_to_int(claim)
+        assert np.array_equal(api.cubicAtPoint(fa, ch), M(r["next_claim"])), k
+        assert np.array_equal(ob.raf_update_claim(fo, ch), M(r["next_claim"])), k
+        assert np.array_equal(api.evalsToCompressed(fa), comp) and np.array_equal(ob.evals_to_compressed(fo), comp)
+        prev = M(r["next_claim"])
+    assert np.array_equal(prev, M(d["output_claim"]))

@@ -1296,6 +1296,114 @@ class ProductVirtualRemainderProver:
         self.split_eq.deinit()
 
 
+class SumcheckInstance:
+    """SumcheckInstance(F) (src/zkvm/batched_sumcheck.zig:34-74): num_rounds, degree, input_claim and the three callbacks.
+    compute_round_poly(round) -> [s(0), s(1), s(2), s(3)]; bind_challenge(challenge); cache_openings(r_sumcheck) optional."""
+
+    def __init__(self, num_rounds, degree, input_claim, compute_round_poly, bind_challenge, cache_openings=None):
+        self.num_rounds, self.degree = num_rounds, degree
+        self.input_claim = np.ascontiguousarray(input_claim, dtype=np.uint64).copy()
+        self.computeRoundPoly, self.bindChallenge = compute_round_poly, bind_challenge
+        self.cacheOpenings = cache_openings or (lambda r: None)
+
+
+class BatchedSumcheckProver:
+    """BatchedSumcheckProver(F) (src/zkvm/batched_sumcheck.zig:77-262): several instances, possibly with fewer rounds than the
+    longest, combined with transcript-sampled coefficients. The instances' round evaluations come from device sessions; the
+    combination below is the reference's host algebra."""
+
+    def __init__(self):
+        self.instances, self.batching_coeffs, self.challenges = [], [], []
+        self.max_num_rounds = 0
+        self.current_round = 0
+        self.current_claim = fr_from_int(0)
+
+    def addInstance(self, instance):  # :115-121
+        self.instances.append(instance)
+        self.max_num_rounds = max(self.max_num_rounds, instance.num_rounds)
+
+    def setupBatching(self, transcript):
+        """:127-186: absorb every input claim, sample one coefficient each (challengeScalarFull), claim = sum coeff * 2^k * claim"""
+        for inst in self.instances:
+            transcript.appendScalar(inst.input_claim)
+        self.batching_coeffs = [transcript.challengeScalarFull() for _ in self.instances]
+        self.current_claim = self.batchedClaim()
+
+    def batchedClaim(self):
+        acc = 0
+        for inst, c in zip(self.instances, self.batching_coeffs):
+            acc += fr_to_int(inst.input_claim) * pow(2, self.max_num_rounds - inst.num_rounds, R_MOD) * fr_to_int(c)
+        return fr_from_int(acc % R_MOD)
+
+    def combinedEvals(self):
+        """:193-222: active instances contribute coeff * evals, the others the constant coeff * 2^k * input_claim"""
+        comb = [0, 0, 0, 0]
+        for inst, c in zip(self.instances, self.batching_coeffs):
+            ci = fr_to_int(c)
+            start = self.max_num_rounds - inst.num_rounds
+            if self.current_round >= start:
+                ev = inst.computeRoundPoly(self.current_round - start)
+                for j in range(4):
+                    comb[j] = (comb[j] + fr_to_int(ev[j]) * ci) % R_MOD
+            else:
+                w = fr_to_int(inst.input_claim) * pow(2, start - self.current_round, R_MOD) * ci % R_MOD
+                for j in range(4):
+                    comb[j] = (comb[j] + w) % R_MOD
+        return np.stack([fr_from_int(v) for v in comb])
+
+    def computeRoundPolynomial(self):
+        """compressed [c0, c2, c3] (:224-226)"""
+        return evalsToCompressed(self.combinedEvals())
+
+    def bindChallenge(self, challenge):  # :229-241
+        self.challenges.append(np.array(challenge, dtype=np.uint64))
+        for inst in self.instances:
+            if self.current_round >= self.max_num_rounds - inst.num_rounds:
+                inst.bindChallenge(challenge)
+        self.current_round += 1
+
+    def updateClaim(self, round_evals, challenge):  # :244-247
+        self.current_claim = cubicAtPoint(round_evals, challenge)
+
+    def cacheOpenings(self):  # :250-258: each instance gets the suffix of challenges of its own rounds
+        for inst in self.instances:
+            inst.cacheOpenings(self.challenges[self.max_num_rounds - inst.num_rounds:])
+
+    def getFinalClaim(self):
+        return self.current_claim
+
+    def numRounds(self):
+        return self.max_num_rounds
+
+
+def decompressRoundPoly(compressed, current_claim):
+    """generateBatchedProof's recovery of [s(0), s(1), s(2), s(3)] from [c0, c2, c3] and the claim (:380-400):
+    c1 = claim - 2 c0 - c2 - c3, then s(t) = c0 + c1 t + c2 t^2 + c3 t^3"""
+    c0, c2, c3 = (fr_to_int(x) for x in compressed)
+    c1 = (fr_to_int(current_claim) - 2 * c0 - c2 - c3) % R_MOD
+    return np.stack([fr_from_int((c0 + c1 * t + c2 * t * t + c3 * t * t * t) % R_MOD) for t in range(4)])
+
+
+def generateBatchedProof(prover, transcript):
+    """generateBatchedProof (:306-430) with the Blake2b transcript: per round the compressed polynomial goes in between
+    "UniPoly_begin" / "UniPoly_end", challengeScalar comes out. -> {round_polys (rounds,3,4), challenges, final_claim}"""
+    polys, chals = [], []
+    for _ in range(prover.numRounds()):
+        comp = prover.computeRoundPolynomial()
+        polys.append(comp)
+        transcript.appendMessage(b"UniPoly_begin")
+        for c in comp:
+            transcript.appendScalar(c)
+        transcript.appendMessage(b"UniPoly_end")
+        challenge = transcript.challengeScalar()
+        chals.append(challenge)
+        full = decompressRoundPoly(comp, prover.current_claim)
+        prover.updateClaim(full, challenge)
+        prover.bindChallenge(challenge)
+    z3, z1 = np.zeros((0, 3, 4), dtype=np.uint64), np.zeros((0, 4), dtype=np.uint64)
+    return {"round_polys": np.stack(polys) if polys else z3, "challenges": np.stack(chals) if chals else z1, "final_claim": prover.getFinalClaim()}
+
+
 class LassoProver:
     """LassoProver's sumcheck over eq_evals (src/zkvm/lasso/prover.zig:80-467) on ONE device session: the padded eq_evals array is
     built on the device (SplitEqPolynomial.getEq, src/zkvm/lasso/split_eq.zig:113-168 = the eq table with each half's variables
