@@ -751,7 +751,10 @@ class BatchedSumcheck:
     """BatchedSumcheckProver (batched_sumcheck.zig:77-262). Instances: objects with num_rounds, input_claim,
     computeRoundPoly(round) -> (4,4), bindChallenge(challenge)."""
 
-    def __init__(self, instances, coeffs):
+    def __init__(self, instances, coeffs, inactive_scaling="proof_converter"):
+        """inactive_scaling "proof_converter": 2^(start - round - 1) (src/zkvm/proof_converter.zig:3330-3343, the loop the prover runs);
+        "batched_sumcheck_zig": 2^(start - round) (batched_sumcheck.zig:208-212 as written)"""
+        self.minus_one = inactive_scaling == "proof_converter"
         self.instances, self.coeffs = instances, [_c(c) for c in coeffs]
         self.max_num_rounds = max(i.num_rounds for i in instances)
         self.current_round = 0
@@ -774,7 +777,7 @@ class BatchedSumcheck:
                     comb[j] = _add(comb[j], _mul(ev[j], c))
             else:
                 scaled = _c(inst.input_claim)
-                for _ in range(start - self.current_round):
+                for _ in range(start - self.current_round - (1 if self.minus_one else 0)):
                     scaled = _add(scaled, scaled)
                 w = _mul(scaled, c)
                 for j in range(4):

@@ -359,6 +359,106 @@ TEST(product_form_provers_are_sound) {
     EXPECT(q.getFinalClaim().mul(q.split_eq.current_scalar).eql(q.current_claim));
 }
 
+// src/transcripts/blake2b.zig — the C++ Blake2b transcript against values of the Python mirror (api.Blake2bTranscript), which is held
+// against the states the reference printed (tests/golden/blake2b_transcript_preamble.json): init("Jolt"), appendU64, appendMessage,
+// appendScalar, a 200-byte appendBytes, then challengeScalarFull and challengeScalar
+TEST(blake2b_transcript_kat) {
+    auto hex = [](const uint8_t *b, size_t n) {
+        std::string s;
+        char t[3];
+        for (size_t i = 0; i < n; i++) { std::snprintf(t, 3, "%02x", b[i]); s += t; }
+        return s;
+    };
+    Blake2bTranscript t("Jolt");
+    EXPECT(hex(t.state, 32) == "06ce2c10d1d2801c48c859d7cb16510476b0d48667d9562ed021b20d9a05e547");
+    t.appendU64(0x1122334455667788ULL);
+    t.appendMessage("UniPoly_begin");
+    t.appendScalar(Fr::fromU64(123456789));
+    uint8_t data[200];
+    for (int i = 0; i < 200; i++) data[i] = (uint8_t)i;
+    t.appendBytes(data, 200);
+    EXPECT(hex(t.state, 32) == "99d58a4ad34a2480b75e52df4cd885908f0cd089674e56f5fdd656ee62450ce0" && t.n_rounds == 4);
+    Fr full = t.challengeScalarFull();
+    Fr want_full{{0xcd111d86aac77a34ULL, 0x84437048f6f30ccfULL, 0x3dd77a39079b4474ULL, 0x8e52df5bb84bdbULL}};
+    EXPECT(full.eql(want_full));
+    Fr ch = t.challengeScalar();
+    Fr want_ch{{0, 0, 0xcc31546f28f7fe6cULL, 0x5540a1100b32435ULL}};
+    EXPECT(ch.eql(want_ch));
+}
+
+// src/zkvm/batched_sumcheck.zig:77-430 — five device-backed instances of different length under one Blake2b transcript (the shape of
+// Stage 2): with consistent input claims every combined round satisfies s(0) + s(1) = claim, and the final claim is the
+// coefficient-weighted sum of the instances' own final claims
+TEST(batched_sumcheck_stage2_shape) {
+    auto mk = [&](size_t n, uint64_t seed) {
+        std::vector<Fr> t(n);
+        uint64_t x = seed;
+        for (auto &e : t) {
+            x = x * 6364136223846793005ULL + 1442695040888963407ULL;
+            e = Fr::fromU64(x >> 7).mul(Fr::fromU64(x | 1));
+        }
+        return t;
+    };
+    // ProductVirtualRemainder, 5 rounds
+    auto left = mk(32, 1), right = mk(32, 2);
+    std::vector<Fr> tau = mk(5, 3);
+    Fr kernel = Fr::fromU64(77);
+    auto eq = EqPolynomial::evalsSliceWithScaling(tau, &kernel);
+    Fr c_pv = Fr::zero();
+    for (size_t i = 0; i < 32; i++) c_pv = c_pv.add(eq[i].mul(left[i]).mul(right[i]));
+    ProductVirtualRemainderProver pv(left, right, tau, kernel, c_pv);
+    // ValEvaluation, 9 rounds
+    auto inc = mk(512, 4), wa = mk(512, 5), lt = mk(512, 6);
+    Fr c_ve = Fr::zero();
+    for (size_t i = 0; i < 512; i++) c_ve = c_ve.add(inc[i].mul(wa[i]).mul(lt[i]));
+    ValEvaluationProver ve(inc, wa, &lt, c_ve);
+    // OutputSumcheck, 7 rounds
+    auto e2 = mk(128, 7), io = mk(128, 8), vf = mk(128, 9), vio = mk(128, 10), vinit = mk(128, 11);
+    Fr c_op = Fr::zero();
+    for (size_t i = 0; i < 128; i++) c_op = c_op.add(e2[i].mul(io[i]).mul(vf[i].sub(vio[i])));
+    OutputSumcheckProver op(e2, io, vf, vio, vinit, c_op);
+    // InstructionLookups claim reduction, 5 rounds
+    auto e3 = mk(32, 12), lo = mk(32, 13), lf = mk(32, 14), rt = mk(32, 15);
+    Fr gamma = Fr::fromU64(991), c_il = Fr::zero();
+    for (size_t i = 0; i < 32; i++) c_il = c_il.add(e3[i].mul(lo[i].add(gamma.mul(lf[i])).add(gamma.mul(gamma).mul(rt[i]))));
+    InstructionLookupsClaimReductionProver il(e3, lo, lf, rt, gamma, c_il);
+
+    std::array<Fr, 4> last_pv, last_ve, last_op, last_il;
+    BatchedSumcheckProver p;
+    p.addInstance({5, 3, c_pv, [&](size_t) { pv.roundEvals(last_pv); return last_pv; }, [&](const Fr &c) { pv.updateClaim(last_pv, c); pv.bindChallenge(c); }});
+    p.addInstance({9, 3, c_ve, [&](size_t) { last_ve = ve.computeRoundPolynomial(); return last_ve; }, [&](const Fr &c) { ve.bindChallengeWithPoly(c, last_ve); }});
+    p.addInstance({7, 3, c_op, [&](size_t) { last_op = op.roundEvals(); return last_op; }, [&](const Fr &c) { op.updateClaim(last_op, c); op.bindChallenge(c); }});
+    p.addInstance({5, 2, c_il, [&](size_t) { last_il = il.computeRoundPolynomialCubic(); return last_il; }, [&](const Fr &c) { il.updateClaim(last_il, c); il.bindChallenge(c); }});
+    Blake2bTranscript tr("Jolt");
+    p.setupBatching(tr);
+    EXPECT(p.max_num_rounds == 9);
+    for (size_t k = 0; k < 9; k++) {
+        Fr claim = p.current_claim;
+        auto ev = p.combinedEvals();
+        EXPECT(ev[0].add(ev[1]).eql(claim));
+        auto comp = evalsToCompressed(ev);
+        auto back = decompressRoundPoly(comp, claim);
+        for (int j = 0; j < 4; j++) EXPECT(back[j].eql(ev[j]));
+        tr.appendMessage("UniPoly_begin");
+        for (const Fr &c : comp) tr.appendScalar(c);
+        tr.appendMessage("UniPoly_end");
+        Fr ch = tr.challengeScalar();
+        p.updateClaim(ev, ch);
+        p.bindChallenge(ch);
+    }
+    Fr want = pv.current_claim.mul(p.batching_coeffs[0]).add(ve.current_claim.mul(p.batching_coeffs[1]))
+                  .add(op.current_claim.mul(p.batching_coeffs[2])).add(il.current_claim.mul(p.batching_coeffs[3]));
+    EXPECT(p.current_claim.eql(want));
+    // and each instance ended on the product form of its tables' final values
+    auto f = ve.getFinalClaims();
+    EXPECT(f[0].mul(f[1]).mul(f[2]).eql(ve.current_claim));
+    auto g = op.finalValues();
+    EXPECT(g[0].mul(g[1]).mul(g[2].sub(g[3])).eql(op.current_claim));
+    auto h = il.finalValues();
+    EXPECT(h[0].mul(h[1].add(gamma.mul(h[2])).add(gamma.mul(gamma).mul(h[3]))).eql(il.current_claim));
+    EXPECT(pv.getFinalClaim().mul(pv.split_eq.current_scalar).eql(pv.current_claim));
+}
+
 int main() {
     if (zg_init(0) != ZG_OK) { std::printf("zg_init failed: %s\n", zg_last_error()); return 2; }
     for (auto &t : tests()) {

@@ -8,6 +8,8 @@ Source: /root/reference/logs/zolt.log, printed by src/zkvm/batched_sumcheck.zig:
   STAGE2_INITIAL  batched_claim = sum_i coeff_i * 2^(max_rounds - rounds_i) * claim_i                     (:161-173)
   STAGE2_ROUND_k  current_claim, the compressed round polynomial c0, c2, c3, the challenge, next_claim     (:334-412)
   STAGE2_FINAL    output_claim
+  [ZOLT DEBUG] instK individual_claims[K]: each instance's own claim after its last round (proof_converter.zig, big-endian bytes);
+                  the reference checks sum_i coeff_i * individual_i == output_claim ("expected_batched", logs/zolt.log:3583-3585)
 A challenge is a MontU128Challenge: its stored Montgomery limbs are [0, 0, lo, hi]; the bytes printed are the canonical value of
 that element.
 
@@ -33,6 +35,7 @@ def main():
     claims, rounds_of, degrees, coeffs = {}, {}, {}, {}
     initial = final = None
     rounds = {}
+    individual = {}
     for l in lines:
         m = re.match(r"\[ZOLT\] STAGE2_PRE: input_claim\[(\d+)\] = ", l)
         if m:
@@ -56,6 +59,12 @@ def main():
         if l.startswith("[ZOLT] STAGE2_FINAL: output_claim = "):
             final = le_bytes(l)
             continue
+        m = re.match(r"\[ZOLT DEBUG\] inst(\d+) individual_claims\[\d+\] = \{ ([0-9, ]+)\}", l)
+        if m:  # printed with toBytesBE (src/zkvm/proof_converter.zig): reversed here to the little-endian form of the rest
+            b = bytes(int(x) for x in m.group(2).replace(" ", "").strip(",").split(","))
+            assert len(b) == 32
+            individual[int(m.group(1))] = b[::-1].hex()
+            continue
         m = re.match(r"\[ZOLT\] STAGE2_ROUND_(\d+): (current_claim|c0|c2|c3|challenge|next_claim) = ", l)
         if m:
             rounds.setdefault(int(m.group(1)), {})[m.group(2)] = le_bytes(l)
@@ -70,6 +79,7 @@ def main():
         "initial_batched_claim": initial,
         "rounds": [rounds[k] for k in sorted(rounds)],
         "output_claim": final,
+        "instance_final_claims": [individual[i] for i in range(n)],
     }
     for r in out["rounds"]:
         assert set(r) == {"current_claim", "c0", "c2", "c3", "challenge", "next_claim"}

@@ -369,13 +369,14 @@ def _stage2_like_batch(api, ob, side, seed):
     return out
 
 
-def test_batched_sumcheck_stage2_shape(env):
+@pytest.mark.parametrize("mode", ["proof_converter", "batched_sumcheck_zig"])
+def test_batched_sumcheck_stage2_shape(env, mode):
     """BatchedSumcheckProver + generateBatchedProof (src/zkvm/batched_sumcheck.zig:77-430) over five device-backed instances that
     start at different rounds, with the Blake2b transcript: every compressed round polynomial, challenge, claim and every instance's
     final values against the oracle's restatement of the driver over the oracle's restatement of each instance."""
     api, lib, ob = env
     gpu, ora = _stage2_like_batch(api, ob, "gpu", 8000), _stage2_like_batch(api, ob, "oracle", 8000)
-    p = api.BatchedSumcheckProver()
+    p = api.BatchedSumcheckProver(mode)
     for nr, claim, rnd, bind, _ in gpu:
         p.addInstance(api.SumcheckInstance(nr, 3, claim, rnd, bind))
     t = api.Blake2bTranscript(b"Jolt")
@@ -385,7 +386,7 @@ def test_batched_sumcheck_stage2_shape(env):
         def __init__(self, nr, claim, rnd, bind):
             self.num_rounds, self.input_claim, self.computeRoundPoly, self.bindChallenge = nr, claim, rnd, bind
 
-    o = ob.BatchedSumcheck([Inst(nr, claim, rnd, bind) for nr, claim, rnd, bind, _ in ora], p.batching_coeffs)
+    o = ob.BatchedSumcheck([Inst(nr, claim, rnd, bind) for nr, claim, rnd, bind, _ in ora], p.batching_coeffs, mode)
     assert p.numRounds() == 11 and np.array_equal(p.current_claim, o.current_claim)
     proof = api.generateBatchedProof(p, t)
     # the oracle side replays the same transcript: absorb its own polynomials, the challenges must come out the same

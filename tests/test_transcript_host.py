@@ -253,3 +253,64 @@ def test_stage2_batched_sumcheck_of_the_captured_run(golden_dir):
         assert np.array_equal(api.evalsToCompressed(fa), comp) and np.array_equal(ob.evals_to_compressed(fo), comp)
         prev = M(r["next_claim"])
     assert np.array_equal(prev, M(d["output_claim"]))
+    # the reference's own end check (logs/zolt.log:3583-3585 "expected_batched == actual batched"): the final batched claim is the
+    # coefficient-weighted sum of the five instances' own final claims
+    acc = sum(api.fr_to_int(c) * int.from_bytes(bytes.fromhex(f), "little") for c, f in zip(coeffs, d["instance_final_claims"]))
+    assert acc % api.R_MOD == api.fr_to_int(M(d["output_claim"]))
+
+
+def test_batched_driver_inactive_instance_rule():
+    """Which constant does an instance contribute before its first round? The loop `zolt prove` runs (src/zkvm/proof_converter.zig:
+    3330-3343) uses coeff * claim * 2^(start - round - 1): twice that is the instance's share of the claim, so s(0) + s(1) = claim in
+    every round and the final claim is sum_i coeff_i * final_i — the identity the captured run ends on. batched_sumcheck.zig:208-212 as
+    written doubles the constant; with it the same batch is NOT a sumcheck (the recovered linear term silently absorbs the error and the
+    end check fails). The mirrors default to the first rule and keep the second as an option; this test holds both against the
+    protocol's algebra with the oracle's instances (CPU)."""
+    from zolt_amd import api
+    P = api.R_MOD
+    rng = np.random.default_rng(23)
+    rnd = lambda n: ob.f_to_mont(ob.FR, rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64))
+    to_int = api.fr_to_int
+
+    def batch():
+        inc, wa, lt = rnd(64), rnd(64), rnd(64)
+        c1 = sum(to_int(a) * to_int(b) * to_int(c) for a, b, c in zip(inc, wa, lt)) % P
+        ve = ob.ValEvaluationProver(inc, wa, lt, api.fr_from_int(c1))
+        i2, w2 = rnd(8), rnd(8)
+        c2 = sum(to_int(a) * to_int(b) for a, b in zip(i2, w2)) % P
+        vf = ob.ValEvaluationProver(i2, w2, None, api.fr_from_int(c2))
+        last = {}
+
+        class Inst:
+            def __init__(self, key, prover, nr):
+                self.key, self.p, self.num_rounds, self.input_claim = key, prover, nr, prover.current_claim.copy()
+
+            def computeRoundPoly(self, _r):
+                last[self.key] = self.p.computeRoundPolynomial()
+                return last[self.key]
+
+            def bindChallenge(self, ch):
+                self.p.bindChallengeWithPoly(ch, last[self.key])
+
+        return [Inst("ve", ve, 6), Inst("vf", vf, 3)], (ve, vf)
+
+    coeffs = rnd(2)
+    chals = rnd(6)
+    for mode, sound in (("proof_converter", True), ("batched_sumcheck_zig", False)):
+        rng = np.random.default_rng(23)  # the same tables for both modes
+        insts, (ve, vf) = batch()
+        b = ob.BatchedSumcheck(insts, coeffs, mode)
+        p = api.BatchedSumcheckProver(mode)
+        for i in insts:
+            p.addInstance(api.SumcheckInstance(i.num_rounds, 3, i.input_claim, None, None))
+        p.batching_coeffs = list(coeffs)
+        assert np.array_equal(p.batchedClaim(), b.current_claim)
+        holds = True
+        for k in range(6):
+            ev = b.combinedEvals()
+            holds &= (to_int(ev[0]) + to_int(ev[1])) % P == to_int(b.current_claim)
+            comp = ob.evals_to_compressed(ev)
+            b.updateClaim(ob.decompress_round_poly(comp, b.current_claim), chals[k])
+            b.bindChallenge(chals[k])
+        want = (to_int(coeffs[0]) * to_int(ve.current_claim) + to_int(coeffs[1]) * to_int(vf.current_claim)) % P
+        assert holds == sound and (to_int(b.current_claim) == want) == sound, mode

@@ -220,7 +220,52 @@ int main(int argc, char **argv) {
             }
         }
     }
-    std::printf("{\"val_evaluation_rounds_per_s\": %.1f, \"val_evaluation_ms\": %.4f, \"product_remainder_rounds_per_s\": %.1f, "
+    // A Stage-2-shaped batched sumcheck (src/zkvm/batched_sumcheck.zig:1-21, proof_converter.zig:3026-3400): ProductVirtualRemainder (v rounds),
+    // RamRafEvaluation (16), OutputSumcheck (16), InstructionLookupsClaimReduction (v) and a ValEvaluation of v + 8 rounds in the place of
+    // RamReadWriteChecking (log_K + v rounds in the reference), one Blake2b transcript, generateBatchedProof
+    double t_batch = 0;
+    size_t batch_rounds = 0;
+    if (v <= 16) {
+        auto mkt = [&](size_t len, uint64_t seed) {
+            std::vector<Fr> t(len);
+            uint64_t x = seed;
+            for (auto &e : t) {
+                x = x * 6364136223846793005ULL + 1442695040888963407ULL;
+                e = Fr::fromU64(x >> 5);
+            }
+            return t;
+        };
+        const size_t nk = size_t(1) << 16, nl = n << 8;
+        auto left = mkt(n, 1), right = mkt(n, 2), ra = mkt(nk, 3), e2 = mkt(nk, 4), io = mkt(nk, 5), vf = mkt(nk, 6), vio = mkt(nk, 7), vin = mkt(nk, 8);
+        auto e3 = mkt(n, 9), lo = mkt(n, 10), lf = mkt(n, 11), rt = mkt(n, 12), inc = mkt(nl, 13), wa = mkt(nl, 14), lt = mkt(nl, 15);
+        std::vector<Fr> tau;
+        for (int i = 0; i < v; i++) tau.push_back(Fr::fromU64(1000003ULL * i + 31));
+        for (int rep = -1; rep < reps; rep++) {
+            ProductVirtualRemainderProver pv(left, right, tau, Fr::fromU64(3), Fr::fromU64(11));
+            RafEvaluationProver raf(ra, 0x7fff8000ULL, Fr::fromU64(12));
+            ValEvaluationProver ve(inc, wa, &lt, Fr::fromU64(13));
+            OutputSumcheckProver op(e2, io, vf, vio, vin, Fr::fromU64(14));
+            InstructionLookupsClaimReductionProver il(e3, lo, lf, rt, Fr::fromU64(7), Fr::fromU64(15));
+            std::array<Fr, 4> l0, l1, l2, l3, l4;
+            BatchedSumcheckProver p;
+            p.addInstance({(size_t)v, 3, pv.current_claim, [&](size_t) { pv.roundEvals(l0); return l0; }, [&](const Fr &c) { pv.updateClaim(l0, c); pv.bindChallenge(c); }});
+            p.addInstance({16, 2, raf.current_claim, [&](size_t) { l1 = raf.computeRoundPolynomialCubic(); return l1; }, [&](const Fr &c) { raf.updateClaim(l1, c); raf.bindChallenge(c); }});
+            p.addInstance({(size_t)v + 8, 3, ve.current_claim, [&](size_t) { l2 = ve.computeRoundPolynomial(); return l2; }, [&](const Fr &c) { ve.bindChallengeWithPoly(c, l2); }});
+            p.addInstance({16, 3, op.current_claim, [&](size_t) { l3 = op.roundEvals(); return l3; }, [&](const Fr &c) { op.updateClaim(l3, c); op.bindChallenge(c); }});
+            p.addInstance({(size_t)v, 2, il.current_claim, [&](size_t) { l4 = il.computeRoundPolynomialCubic(); return l4; }, [&](const Fr &c) { il.updateClaim(l4, c); il.bindChallenge(c); }});
+            Blake2bTranscript tr("Jolt");
+            auto t0 = clk::now();
+            p.setupBatching(tr);
+            BatchedSumcheckProof proof = generateBatchedProof(p, tr);
+            if (rep >= 0) t_batch += std::chrono::duration<double>(clk::now() - t0).count();
+            batch_rounds = proof.round_polys.size();
+        }
+        std::printf("{\"stage2_shaped_batched_proof_ms\": %.4f, \"stage2_shaped_rounds\": %zu, \"stage2_shaped_instance_rounds_per_s\": %.1f, ", t_batch / reps * 1e3,
+                    batch_rounds, reps * (double)(2 * v + 32 + v + 8) / t_batch);
+    } else {
+        std::printf("{");
+    }
+    std::printf("\"val_evaluation_rounds_per_s\": %.1f, \"val_evaluation_ms\": %.4f, \"product_remainder_rounds_per_s\": %.1f, "
                 "\"product_remainder_ms\": %.4f, ", reps * v / t_val, t_val / reps * 1e3, reps * v / t_prod, t_prod / reps * 1e3);
     std::printf("\"lasso_log_K16_rounds_per_s\": %.1f, \"lasso_ms_whole_protocol_incl_setup\": %.4f, ", reps * (16 + v) / t_lasso, t_lasso / reps * 1e3);
     std::printf("\"v\": %d, \"reps\": %d, \"verified\": %s, \"stage1_keccak_rounds_per_s\": %.1f, \"stage1_ms\": %.4f, "

@@ -1312,7 +1312,14 @@ class BatchedSumcheckProver:
     longest, combined with transcript-sampled coefficients. The instances' round evaluations come from device sessions; the
     combination below is the reference's host algebra."""
 
-    def __init__(self):
+    def __init__(self, inactive_scaling="proof_converter"):
+        """inactive_scaling: the constant an instance contributes before its first round. "proof_converter" = coeff * claim *
+        2^(start - round - 1), the loop `zolt prove` actually runs (src/zkvm/proof_converter.zig:3330-3343, Jolt's rule: twice the
+        constant is the instance's share of the claim, so s(0) + s(1) = claim holds in every round — the captured Stage-2 run
+        ends with "expected_batched == actual batched", logs/zolt.log:3583-3585). "batched_sumcheck_zig" = 2^(start - round), the
+        formula of batched_sumcheck.zig:208-212 itself, which no caller in the reference reaches and which breaks that identity."""
+        assert inactive_scaling in ("proof_converter", "batched_sumcheck_zig")
+        self.inactive_scaling = inactive_scaling
         self.instances, self.batching_coeffs, self.challenges = [], [], []
         self.max_num_rounds = 0
         self.current_round = 0
@@ -1336,7 +1343,7 @@ class BatchedSumcheckProver:
         return fr_from_int(acc % R_MOD)
 
     def combinedEvals(self):
-        """:193-222: active instances contribute coeff * evals, the others the constant coeff * 2^k * input_claim"""
+        """:193-222 / proof_converter.zig:3026-3343: active instances contribute coeff * evals, the others a constant (see __init__)"""
         comb = [0, 0, 0, 0]
         for inst, c in zip(self.instances, self.batching_coeffs):
             ci = fr_to_int(c)
@@ -1346,7 +1353,8 @@ class BatchedSumcheckProver:
                 for j in range(4):
                     comb[j] = (comb[j] + fr_to_int(ev[j]) * ci) % R_MOD
             else:
-                w = fr_to_int(inst.input_claim) * pow(2, start - self.current_round, R_MOD) * ci % R_MOD
+                k = start - self.current_round - (1 if self.inactive_scaling == "proof_converter" else 0)
+                w = fr_to_int(inst.input_claim) * pow(2, k, R_MOD) * ci % R_MOD
                 for j in range(4):
                     comb[j] = (comb[j] + w) % R_MOD
         return np.stack([fr_from_int(v) for v in comb])

@@ -16,6 +16,7 @@
 #include <array>
 #include <cstdint>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -651,6 +652,127 @@ private:
     }
 };
 
+// Blake2b-256 (RFC 7693, unkeyed) for the Jolt-compatible transcript
+inline void blake2b256(const uint8_t *in, size_t inlen, uint8_t out[32]) {
+    static const uint64_t IV[8] = {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL,
+                                   0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
+    static const uint8_t SIGMA[12][16] = {
+        {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+        {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+        {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+        {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+        {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0},
+        {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3}};
+    uint64_t h[8];
+    for (int i = 0; i < 8; i++) h[i] = IV[i];
+    h[0] ^= 0x01010000ULL ^ 32ULL;
+    auto rotr = [](uint64_t x, unsigned n) { return (x >> n) | (x << (64 - n)); };
+    auto compress = [&](const uint8_t *block, uint64_t t, bool last) {
+        uint64_t m[16], v[16];
+        for (int i = 0; i < 16; i++) {
+            uint64_t w = 0;
+            for (int b = 7; b >= 0; b--) w = (w << 8) | block[8 * i + b];
+            m[i] = w;
+        }
+        for (int i = 0; i < 8; i++) {
+            v[i] = h[i];
+            v[i + 8] = IV[i];
+        }
+        v[12] ^= t;
+        if (last) v[14] = ~v[14];
+        auto G = [&](int a, int b, int c, int d, uint64_t x, uint64_t y) {
+            v[a] = v[a] + v[b] + x; v[d] = rotr(v[d] ^ v[a], 32);
+            v[c] = v[c] + v[d];     v[b] = rotr(v[b] ^ v[c], 24);
+            v[a] = v[a] + v[b] + y; v[d] = rotr(v[d] ^ v[a], 16);
+            v[c] = v[c] + v[d];     v[b] = rotr(v[b] ^ v[c], 63);
+        };
+        for (int r = 0; r < 12; r++) {
+            const uint8_t *sg = SIGMA[r];
+            G(0, 4, 8, 12, m[sg[0]], m[sg[1]]);   G(1, 5, 9, 13, m[sg[2]], m[sg[3]]);
+            G(2, 6, 10, 14, m[sg[4]], m[sg[5]]);  G(3, 7, 11, 15, m[sg[6]], m[sg[7]]);
+            G(0, 5, 10, 15, m[sg[8]], m[sg[9]]);  G(1, 6, 11, 12, m[sg[10]], m[sg[11]]);
+            G(2, 7, 8, 13, m[sg[12]], m[sg[13]]); G(3, 4, 9, 14, m[sg[14]], m[sg[15]]);
+        }
+        for (int i = 0; i < 8; i++) h[i] ^= v[i] ^ v[i + 8];
+    };
+    size_t off = 0;
+    while (inlen - off > 128) {
+        compress(in + off, off + 128, false);
+        off += 128;
+    }
+    uint8_t blk[128] = {0};
+    std::memcpy(blk, in + off, inlen - off);
+    compress(blk, inlen, true);
+    for (int i = 0; i < 4; i++)
+        for (int b = 0; b < 8; b++) out[8 * i + b] = (uint8_t)(h[i] >> (8 * b));
+}
+
+// Blake2bTranscript(F) — the Jolt-compatible transcript of the reference's proving path (src/transcripts/blake2b.zig:25-545): a 32-byte
+// state and a round counter; every operation hashes state || [0u8; 28] || n_rounds_be32 || payload, the digest is the new state.
+class Blake2bTranscript {
+public:
+    uint8_t state[32];
+    uint32_t n_rounds = 0;
+    explicit Blake2bTranscript(const std::string &label = "Jolt") {  // :39-69
+        uint8_t padded[32] = {0};
+        std::memcpy(padded, label.data(), label.size() < 32 ? label.size() : 32);
+        blake2b256(padded, 32, state);
+    }
+    void appendMessage(const std::string &msg) {  // :96-120: right-padded to 32 bytes
+        uint8_t padded[32] = {0};
+        std::memcpy(padded, msg.data(), msg.size() < 32 ? msg.size() : 32);
+        hashWith(padded, 32, nullptr);
+    }
+    void appendBytes(const uint8_t *data, size_t n) { hashWith(data, n, nullptr); }  // :123-156
+    void appendU64(uint64_t x) {  // :160-176: [0u8; 24] ++ x.to_be_bytes()
+        uint8_t buf[32] = {0};
+        for (int b = 0; b < 8; b++) buf[24 + b] = (uint8_t)(x >> (8 * (7 - b)));
+        hashWith(buf, 32, nullptr);
+    }
+    void appendScalar(const Fr &scalar) {  // :182-200: the canonical value, big-endian
+        Fr one_raw{{1, 0, 0, 0}};
+        Fr canon = scalar.mul(one_raw);  // fromMontgomery
+        uint8_t buf[32];
+        for (int i = 0; i < 4; i++)
+            for (int b = 0; b < 8; b++) buf[31 - (8 * i + b)] = (uint8_t)(canon.limbs[i] >> (8 * b));
+        hashWith(buf, 32, nullptr);
+    }
+    void challenge16(uint8_t out16[16]) {  // challengeBytes(16) (:215-240)
+        uint8_t d[32];
+        hashWith(nullptr, 0, d);
+        std::memcpy(out16, d, 16);
+    }
+    Fr challengeScalarFull() {  // :279-312: the 16 bytes reversed, read little-endian = the digest prefix as a big-endian u128, to Montgomery
+        uint8_t b[16];
+        challenge16(b);
+        uint64_t hi = 0, lo = 0;
+        for (int i = 0; i < 8; i++) hi = (hi << 8) | b[i];
+        for (int i = 8; i < 16; i++) lo = (lo << 8) | b[i];
+        Fr raw{{lo, hi, 0, 0}}, r2{{Fr::R2[0], Fr::R2[1], Fr::R2[2], Fr::R2[3]}};
+        return raw.mul(r2);
+    }
+    Fr challengeScalar() {  // :264-266,332-390: 125-bit mask, stored as RAW Montgomery limbs [0, 0, lo, hi] (MontU128Challenge)
+        uint8_t b[16];
+        challenge16(b);
+        uint64_t hi = 0, lo = 0;  // the reversed buffer read big-endian = the digest prefix as a LITTLE-endian u128 (unlike challengeScalarFull)
+        for (int i = 7; i >= 0; i--) lo = (lo << 8) | b[i];
+        for (int i = 15; i >= 8; i--) hi = (hi << 8) | b[i];
+        hi &= (1ULL << 61) - 1;
+        return Fr{{0, 0, lo, hi}};
+    }
+
+private:
+    void hashWith(const uint8_t *payload, size_t n, uint8_t *digest_out) {  // hasher() (:76-87) + payload, updateState (:90-93)
+        std::vector<uint8_t> buf(64 + n, 0);
+        std::memcpy(buf.data(), state, 32);
+        buf[60] = (uint8_t)(n_rounds >> 24); buf[61] = (uint8_t)(n_rounds >> 16); buf[62] = (uint8_t)(n_rounds >> 8); buf[63] = (uint8_t)n_rounds;
+        if (n) std::memcpy(buf.data() + 64, payload, n);
+        blake2b256(buf.data(), buf.size(), state);
+        n_rounds += 1;
+        if (digest_out) std::memcpy(digest_out, state, 32);
+    }
+};
+
 struct SumcheckVerificationFailed : std::runtime_error {
     SumcheckVerificationFailed() : std::runtime_error("SumcheckVerificationFailed") {}
 };
@@ -933,6 +1055,172 @@ private:
     ProductSumcheckSession s_;
     void *d_out_ = nullptr, *d_in_ = nullptr;
 };
+
+// OutputSumcheckProver's loop (src/zkvm/ram/output_check.zig:375-499): eq * io_mask * (val_final - val_io); val_init folded alongside
+class OutputSumcheckProver {
+public:
+    Fr current_claim;
+    OutputSumcheckProver(const std::vector<Fr> &eq_r_address, const std::vector<Fr> &io_mask, const std::vector<Fr> &val_final,
+                         const std::vector<Fr> &val_io, const std::vector<Fr> &val_init, const Fr &claim)
+        : current_claim(claim), s_({&eq_r_address, &io_mask, &val_final, &val_io, &val_init}), coeff_{Fr::one(), Fr::zero().sub(Fr::one())} {}
+    std::array<Fr, 4> roundEvals() { return s_.roundEvals({0, 1}, {2, 3}, coeff_); }               // s(0..3) (:378-430)
+    std::array<Fr, 3> computeRoundPolynomial() { return evalsToCompressed(roundEvals()); }           // :445
+    void bindChallenge(const Fr &r) { s_.bind(r); }                                                  // :449-480
+    void updateClaim(const std::array<Fr, 4> &evals, const Fr &r) {                                  // :482-499
+        auto c = interpolateDegree3(evals);
+        Fr c1 = evals[1].sub(c[0]).sub(c[2]).sub(c[3]);
+        Fr r2 = r.mul(r);
+        current_claim = c[0].add(c1.mul(r)).add(c[2].mul(r2)).add(c[3].mul(r2.mul(r)));
+    }
+    std::vector<Fr> finalValues() { return s_.final(); }  // eq_r_address, io_mask, val_final, val_io, val_init
+
+private:
+    ProductSumcheckSession s_;
+    std::vector<Fr> coeff_;
+};
+
+// InstructionLookupsClaimReductionProver's loop (src/zkvm/claim_reductions/instruction_lookups.zig:146-284)
+class InstructionLookupsClaimReductionProver {
+public:
+    Fr current_claim;
+    InstructionLookupsClaimReductionProver(const std::vector<Fr> &eq_evals, const std::vector<Fr> &lookup_outputs, const std::vector<Fr> &left_operands,
+                                           const std::vector<Fr> &right_operands, const Fr &gamma, const Fr &claim)
+        : current_claim(claim), s_({&eq_evals, &lookup_outputs, &left_operands, &right_operands}), coeff_{Fr::one(), gamma, gamma.mul(gamma)} {}
+    std::array<Fr, 4> computeRoundPolynomialCubic() {  // :146-200: s0, s2 from the tables; s1 = claim - s0; s3 = s0 - 3 s1 + 3 s2
+        auto ev = s_.roundEvals({0}, {1, 2, 3}, coeff_);
+        Fr s1 = current_claim.sub(ev[0]), three = Fr::fromU64(3);
+        return {ev[0], s1, ev[2], ev[0].sub(s1.mul(three)).add(ev[2].mul(three))};
+    }
+    void bindChallenge(const Fr &c) { s_.bind(c); }
+    void updateClaim(const std::array<Fr, 4> &evals, const Fr &c) { current_claim = cubicAtPoint(evals, c); }
+    std::vector<Fr> finalValues() { return s_.final(); }  // eq, lookup_output, left_operand, right_operand
+
+private:
+    ProductSumcheckSession s_;
+    std::vector<Fr> coeff_;
+};
+
+// RafEvaluationProver's loop (src/zkvm/ram/raf_checking.zig:262-470) over RaPolynomial's table in a LOW_PAIR session
+class RafEvaluationProver {
+public:
+    Fr current_claim;
+    RafEvaluationProver(const std::vector<Fr> &ra_evals, uint64_t start_address, const Fr &initial_claim)
+        : current_claim(initial_claim), base_(Fr::fromU64(start_address)) {
+        check(zg_sumcheck_open(reinterpret_cast<const uint64_t *>(ra_evals.data()), ra_evals.size(), ZG_SC_LOW_PAIR, &s_), "zg_sumcheck_open");
+    }
+    ~RafEvaluationProver() { zg_sumcheck_close(s_); }
+    RafEvaluationProver(const RafEvaluationProver &) = delete;
+    std::array<Fr, 4> computeRoundPolynomialCubic() {  // :335-410: s(0), s(2) in one pass on the device
+        Fr s0, s2;
+        check(zg_sumcheck_raf_round(s_, base_.limbs, power_, s0.limbs, s2.limbs), "zg_sumcheck_raf_round");
+        Fr s1 = current_claim.sub(s0), three = Fr::fromU64(3);
+        return {s0, s1, s2, s0.sub(s1.mul(three)).add(s2.mul(three))};
+    }
+    void updateClaim(const std::array<Fr, 4> &evals, const Fr &c) { current_claim = cubicAtPoint(evals, c); }  // :420-445
+    void bindChallenge(const Fr &c) {  // RaPolynomial.bind (:162-174) + the bound-address bookkeeping (:413-417)
+        check(zg_sumcheck_bind(s_, c.limbs), "zg_sumcheck_bind");
+        base_ = base_.add(c.mul(Fr::fromU64(power_)));
+        power_ *= 2;
+    }
+
+private:
+    zg_sc_t s_ = nullptr;
+    Fr base_;
+    uint64_t power_ = 8;
+};
+
+// SumcheckInstance / BatchedSumcheckProver / generateBatchedProof (src/zkvm/batched_sumcheck.zig:34-430)
+struct SumcheckInstance {
+    size_t num_rounds, degree;
+    Fr input_claim;
+    std::function<std::array<Fr, 4>(size_t)> computeRoundPoly;
+    std::function<void(const Fr &)> bindChallenge;
+};
+
+class BatchedSumcheckProver {
+public:
+    std::vector<SumcheckInstance> instances;
+    std::vector<Fr> batching_coeffs, challenges;
+    size_t max_num_rounds = 0, current_round = 0;
+    Fr current_claim = Fr::zero();
+    // The constant an instance contributes before its first round: coeff * claim * 2^(start - round - 1) is what the loop `zolt prove`
+    // runs uses (src/zkvm/proof_converter.zig:3330-3343, Jolt's rule — twice the constant is the instance's share of the claim, so
+    // s(0) + s(1) = claim in every round); batched_sumcheck.zig:208-212 itself writes 2^(start - round), which no caller in the
+    // reference reaches and which breaks that identity. false selects the file's own formula.
+    bool proof_converter_scaling = true;
+
+    void addInstance(SumcheckInstance inst) {  // :115-121
+        max_num_rounds = std::max(max_num_rounds, inst.num_rounds);
+        instances.push_back(std::move(inst));
+    }
+    void setupBatching(Blake2bTranscript &transcript) {  // :127-186
+        for (auto &inst : instances) transcript.appendScalar(inst.input_claim);
+        for (size_t i = 0; i < instances.size(); i++) batching_coeffs.push_back(transcript.challengeScalarFull());
+        Fr batched = Fr::zero();
+        for (size_t i = 0; i < instances.size(); i++)
+            batched = batched.add(scaled(instances[i].input_claim, max_num_rounds - instances[i].num_rounds).mul(batching_coeffs[i]));
+        current_claim = batched;
+    }
+    std::array<Fr, 4> combinedEvals() {  // :193-222
+        std::array<Fr, 4> comb = {Fr::zero(), Fr::zero(), Fr::zero(), Fr::zero()};
+        for (size_t i = 0; i < instances.size(); i++) {
+            size_t start = max_num_rounds - instances[i].num_rounds;
+            if (current_round >= start) {
+                auto ev = instances[i].computeRoundPoly(current_round - start);
+                for (int j = 0; j < 4; j++) comb[j] = comb[j].add(ev[j].mul(batching_coeffs[i]));
+            } else {
+                Fr w = scaled(instances[i].input_claim, start - current_round - (proof_converter_scaling ? 1 : 0)).mul(batching_coeffs[i]);
+                for (int j = 0; j < 4; j++) comb[j] = comb[j].add(w);
+            }
+        }
+        return comb;
+    }
+    std::array<Fr, 3> computeRoundPolynomial() { return evalsToCompressed(combinedEvals()); }
+    void bindChallenge(const Fr &challenge) {  // :229-241
+        challenges.push_back(challenge);
+        for (auto &inst : instances)
+            if (current_round >= max_num_rounds - inst.num_rounds) inst.bindChallenge(challenge);
+        current_round++;
+    }
+    void updateClaim(const std::array<Fr, 4> &round_evals, const Fr &challenge) { current_claim = cubicAtPoint(round_evals, challenge); }
+
+private:
+    static Fr scaled(Fr v, size_t doublings) {
+        for (size_t k = 0; k < doublings; k++) v = v.add(v);
+        return v;
+    }
+};
+
+struct BatchedSumcheckProof {
+    std::vector<std::array<Fr, 3>> round_polys;
+    std::vector<Fr> challenges;
+    Fr final_claim;
+};
+
+// [s(0), s(1), s(2), s(3)] from the compressed [c0, c2, c3] and the claim (:380-400)
+inline std::array<Fr, 4> decompressRoundPoly(const std::array<Fr, 3> &c, const Fr &claim) {
+    Fr c1 = claim.sub(c[0]).sub(c[0]).sub(c[1]).sub(c[2]);
+    return {c[0], c[0].add(c1).add(c[1]).add(c[2]),
+            c[0].add(c1.mul(Fr::fromU64(2))).add(c[1].mul(Fr::fromU64(4))).add(c[2].mul(Fr::fromU64(8))),
+            c[0].add(c1.mul(Fr::fromU64(3))).add(c[1].mul(Fr::fromU64(9))).add(c[2].mul(Fr::fromU64(27)))};
+}
+
+inline BatchedSumcheckProof generateBatchedProof(BatchedSumcheckProver &prover, Blake2bTranscript &transcript) {  // :306-430
+    BatchedSumcheckProof proof;
+    for (size_t k = 0; k < prover.max_num_rounds; k++) {
+        auto comp = prover.computeRoundPolynomial();
+        proof.round_polys.push_back(comp);
+        transcript.appendMessage("UniPoly_begin");
+        for (const Fr &c : comp) transcript.appendScalar(c);
+        transcript.appendMessage("UniPoly_end");
+        Fr challenge = transcript.challengeScalar();
+        proof.challenges.push_back(challenge);
+        prover.updateClaim(decompressRoundPoly(comp, prover.current_claim), challenge);
+        prover.bindChallenge(challenge);
+    }
+    proof.final_claim = prover.current_claim;
+    return proof;
+}
 
 // ---------------------------------------------------------------- LassoProver (src/zkvm/lasso/prover.zig:80-551)
 // The sumcheck over eq_evals on ONE device session: address rounds = zg_sumcheck_bit_round / bit_bind, cycle rounds = the session's
