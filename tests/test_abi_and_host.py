@@ -66,6 +66,46 @@ def test_zig_ffi_is_generated_from_the_header():
     assert "expected_uses" in zig  # zg_msm_config's third field
 
 
+def test_zig_backend_calls_match_the_generated_externs():
+    """No Zig toolchain here, so zig/gpu/backend.zig is at least held statically to zig/gpu/ffi.zig (itself generated from the header):
+    every `ffi.zg_*(...)` call names an existing extern and passes exactly as many arguments as the extern declares, every
+    `ffi.CONST` exists, and braces / parentheses / brackets balance once comments and string literals are removed."""
+    src = open(os.path.join(ROOT, "zig", "gpu", "backend.zig")).read()
+    ffi = open(os.path.join(ROOT, "zig", "gpu", "ffi.zig")).read()
+    ext = {m.group(1): m.group(2) for m in re.finditer(r"pub extern fn (zg_\w+)\((.*?)\) [\w\[\]:*?. ]+;", ffi)}
+    consts = set(re.findall(r"pub const (\w+)", ffi))
+
+    def split_top(text):
+        out, depth, cur = [], 0, ""
+        for ch in text:
+            depth += ch in "([{"
+            depth -= ch in ")]}"
+            if ch == "," and depth == 0:
+                out.append(cur)
+                cur = ""
+            else:
+                cur += ch
+        return out + ([cur] if cur.strip() else [])
+
+    calls = 0
+    for m in re.finditer(r"ffi\.(zg_\w+)\(", src):
+        name, i = m.group(1), m.end()
+        depth, j = 1, i
+        while depth:
+            depth += (src[j] == "(") - (src[j] == ")")
+            j += 1
+        assert name in ext, name
+        want = len(ext[name].split(",")) if ext[name].strip() else 0
+        assert len(split_top(src[i:j - 1])) == want, (name, src[i:j - 1][:100])
+        calls += 1
+    assert calls >= 50
+    for c in set(re.findall(r"ffi\.([A-Z]\w+)", src)):
+        assert c in consts, c
+    code = re.sub(r'"(?:\\.|[^"\\])*"', '""', re.sub(r"//[^\n]*", "", src))
+    for o, c in ("{}", "()", "[]"):
+        assert code.count(o) == code.count(c), o
+
+
 def test_zig_backend_rules_out_the_stale_table_and_wrong_field_hazards():
     """zig/gpu/backend.zig (compile-unverified) is at least held to the three rules INTEGRATION.md states: a comptime type gate in
     front of every MSM path (the reference instantiates MSM(Fr, Fr), src/msm/mod.zig:853-873,911-936), no (ptr, len)-keyed
