@@ -218,6 +218,13 @@ ZG_API int zg_fr_eq_prefix_tables_dev(const uint64_t *tau_host, size_t v, uint64
  * index bit j <-> point[j] (LSB first). The reference expands every term (O(n*v) multiplications); here the
  * weights are one eq table (point reversed) and the sum is a device dot product — same field value. */
 ZG_API int zg_fr_dense_evaluate(const uint64_t *evals, size_t num_vars, const uint64_t *point, uint64_t out[4]);
+/* R1CSInputEvaluator.computeClaimedInputs (src/zkvm/r1cs/evaluation.zig:55-122) and the factor claims of
+ * ProductVirtualRemainderProver.computeOpeningClaims (src/zkvm/spartan/product_remainder.zig:396-425): the MLE evaluation of k <= 64
+ * column polynomials at one point from a CYCLE-MAJOR matrix (rows[t*k + i] = column i at cycle t, the layout of R1CSCycleInputs.values):
+ * out[i] = sum_{t < min(n_rows, 2^v)} eq(r, t) * rows[t*k + i], eq = EqPolynomial(r).evals (r[0] <-> MSB of t). */
+ZG_API int zg_fr_rows_mle(const uint64_t *rows, size_t n_rows, size_t k, const uint64_t *r, size_t v, uint64_t *out /* k*4 */);
+ZG_API int zg_fr_rows_mle_dev(const uint64_t *d_rows, size_t n_rows, size_t k, const uint64_t *r_host, size_t v, void *stream,
+                       uint64_t *out /* host, k*4 */);
 /* DensePolynomial.bindLow, in place: t[i] = t[2i] + r*(t[2i+1]-t[2i]), len -> len/2 (src/poly/mod.zig:160-175) */
 ZG_API int zg_fr_bind_low(uint64_t *table, size_t len, const uint64_t r[4]);
 /* DensePolynomial.bindFirst: out[i] = (1-r)*t[i] + r*t[i+len/2] (src/poly/mod.zig:128-149) */

@@ -809,3 +809,14 @@ def decompress_round_poly(compressed, current_claim):
         v = _add(v, _mul(c3, _fe(t * t * t)[0]))
         out.append(v)
     return np.stack(out)
+
+
+def r1cs_claimed_inputs(cycle_witnesses, r_cycle):
+    """R1CSInputEvaluator.computeClaimedInputs (src/zkvm/r1cs/evaluation.zig:55-122); cycle_witnesses: (T, k, 4)"""
+    rows = _c(cycle_witnesses)
+    r = _c(np.asarray(r_cycle, dtype=np.uint64).reshape(-1, 4))
+    out = np.empty((rows.shape[1], 4), dtype=np.uint64)
+    rc = lib.zo_r1cs_claimed_inputs(_p(rows), C.c_size_t(rows.shape[0]), C.c_size_t(rows.shape[1]), _p(r), C.c_size_t(r.shape[0]), _p(out))
+    if rc != 0:
+        raise IndexError("eq_evals index out of bounds (r_cycle shorter than log2 of the cycle count)")
+    return out

@@ -1335,3 +1335,36 @@ EXPORT void zo_product_remainder_sums(const uint64_t *left, const uint64_t *righ
     }
     memcpy(t0, &t0s, 32); memcpy(t_inf, &tis, 32);
 }
+
+/* R1CSInputEvaluator.computeClaimedInputs — src/zkvm/r1cs/evaluation.zig:55-122: rows = cycle_witnesses[t].values (k per cycle);
+ * log_n = floor(log2(num_cycles)), padded_len = 2^log_n, effective_len = min(r_len, log_n); effective_len == 0 -> the first
+ * witness's values; else out[i] = sum_{t < min(num_cycles, padded_len)} eq(r[0..effective_len))[t] * rows[t][i] with the eq table of
+ * EqPolynomial.evals (r[0] <-> MSB). Returns 0, or -1 where the reference would index eq_evals out of bounds (effective_len < log_n). */
+EXPORT int zo_r1cs_claimed_inputs(const uint64_t *rows, size_t num_cycles, size_t k, const uint64_t *r, size_t r_len, uint64_t *out) {
+    fe *o = (fe *)out;
+    const fe *W = (const fe *)rows;
+    for (size_t i = 0; i < k; i++) o[i] = f_zero();
+    if (num_cycles == 0) return 0;
+    size_t log_n = 0;
+    while (((size_t)2 << log_n) <= num_cycles) log_n++;
+    size_t padded_len = (size_t)1 << log_n;
+    size_t effective_len = r_len < log_n ? r_len : log_n;
+    if (effective_len == 0) {
+        for (size_t i = 0; i < k; i++) o[i] = W[i];
+        return 0;
+    }
+    if (effective_len < log_n) return -1;
+    size_t n_eq = (size_t)1 << effective_len;
+    fe *eq = (fe *)malloc(n_eq * sizeof(fe));
+    zo_fr_eq_table(r, effective_len, NULL, (uint64_t *)eq);
+    size_t lim = num_cycles < padded_len ? num_cycles : padded_len;
+    for (size_t t = 0; t < lim; t++) {
+        if (f_is_zero(&eq[t])) continue;
+        for (size_t i = 0; i < k; i++) {
+            fe m = f_mul(&FR, &eq[t], &W[t * k + i]);
+            o[i] = f_add(&FR, &o[i], &m);
+        }
+    }
+    free(eq);
+    return 0;
+}

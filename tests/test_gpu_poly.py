@@ -138,6 +138,48 @@ def test_gruen_split_eq_mirror_vs_oracle_through_all_rounds(zl, ob, n):
         w.bind(rs[rnd])
 
 
+@pytest.mark.parametrize("T,k", [(1, 36), (2, 36), (3, 36), (256, 36), (1000, 36), (4096, 8), (1 << 16, 64), (1 << 14, 1)])
+def test_r1cs_claimed_inputs_vs_oracle(zl, ob, T, k):
+    """R1CSInputEvaluator.computeClaimedInputs (src/zkvm/r1cs/evaluation.zig:55-122): k column MLEs at r_cycle from the cycle-major
+    witness matrix; a cycle count that is not a power of two uses the floor power of two, as the reference's log2_int does"""
+    from zolt_amd import api
+    w = _rand(ob, 1300 + k, T * k).reshape(T, k, 4)
+    w[U.splitmix64(1301, T * k).reshape(T, k) % np.uint64(4) == 0] = 0
+    log_n = T.bit_length() - 1
+    r = _rand(ob, 1302 + T % 89, log_n)
+    got = api.R1CSInputEvaluator.computeClaimedInputs(w, r)
+    assert np.array_equal(got, ob.r1cs_claimed_inputs(w, r))
+    assert np.array_equal(api.R1CSInputEvaluator.computeClaimedInput(w, r, k - 1), got[k - 1])
+    if log_n:
+        longer = np.concatenate([r, _rand(ob, 1303, 2)])  # only the first log_n challenges are used (:71-73)
+        assert np.array_equal(api.R1CSInputEvaluator.computeClaimedInputs(w, longer), got)
+        assert np.array_equal(api.R1CSInputEvaluator.computeClaimedInputs(w, r[:0]), w[0])  # no cycle variables: the first witness (:75-83)
+        assert np.array_equal(ob.r1cs_claimed_inputs(w, r[:0]), w[0])
+    if log_n > 1:  # fewer challenges than variables: the reference would index eq_evals out of bounds
+        with pytest.raises(IndexError):
+            api.R1CSInputEvaluator.computeClaimedInputs(w, r[:-1])
+        with pytest.raises(IndexError):
+            ob.r1cs_claimed_inputs(w, r[:-1])
+
+
+def test_rows_mle_direct(zl, ob):
+    """zg_fr_rows_mle[_dev]: fewer rows than the hypercube (the missing rows count as zero), rows beyond it ignored, argument checks"""
+    T, k, v = 300, 5, 9
+    w = _rand(ob, 1310, T * k).reshape(T, k, 4)
+    r = _rand(ob, 1311, v)
+    eq = ob.fr_eq_table(r)
+    want = np.stack([ob.fr_sum_halves(np.concatenate([ob.f_mul(ob.FR, eq[:T], w[:, i]), np.zeros((2 * 512 - T, 4), dtype=np.uint64)]))[0] for i in range(k)])
+    assert np.array_equal(zl.fr_rows_mle(w, r), want)
+    d = zl.DeviceBuffer.from_host(w)
+    assert np.array_equal(zl.fr_rows_mle_dev(d.ptr, T, k, r), want)
+    assert np.array_equal(zl.fr_rows_mle_dev(d.ptr, T, k, r[:0]), w[0])  # v = 0: eq = [1], one row
+    big = _rand(ob, 1312, 20 * k).reshape(20, k, 4)
+    assert np.array_equal(zl.fr_rows_mle(big, r[:3]), zl.fr_rows_mle(big[:8], r[:3]))
+    d.free()
+    with pytest.raises(RuntimeError):
+        zl.fr_rows_mle(_rand(ob, 1313, 65 * 2).reshape(2, 65, 4), r[:1])
+
+
 def test_bind_kats_and_golden(zl, ob):
     """src/poly/mod.zig:816-888 and tests/golden folds."""
     got = zl.fr_bind_low(U.fr([1, 2, 3, 4]), U.fr([3])[0])

@@ -81,6 +81,17 @@ def main():
     ps.round_evals((0, 1, 2))
     ps.close()
     g.deinit()
+    # R1CSInputEvaluator.computeClaimedInputs: 36 column MLEs from a 2^20-cycle witness matrix (1.2 GB, resident)
+    T = 1 << 20
+    rows = np.tile(tab[:T // 4], (36 * 4, 1))[:T * 36].reshape(T, 36, 4)
+    d_rows = lib.DeviceBuffer.from_host(rows)
+    lib.fr_rows_mle_dev(d_rows.ptr, T, 36, tab[500:520])
+    t0 = time.perf_counter()
+    for _ in range(5):
+        lib.fr_rows_mle_dev(d_rows.ptr, T, 36, tab[500:520])
+    dt = (time.perf_counter() - t0) / 5
+    print(f"computeClaimedInputs 2^20 cycles x 36 inputs: {1e6 * dt:.0f} us ({T * 36 * 32 / dt / 1e9:.0f} GB/s of matrix)")
+    d_rows.free()
     # GruenSplitEqPolynomial init: both halves' prefix-table sets for a 24-variable tau (m = 12)
     t0 = time.perf_counter()
     for _ in range(20):

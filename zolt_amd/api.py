@@ -1296,6 +1296,34 @@ class ProductVirtualRemainderProver:
         self.split_eq.deinit()
 
 
+class R1CSInputEvaluator:
+    """R1CSInputEvaluator(F) (src/zkvm/r1cs/evaluation.zig:41-160): the MLE evaluations of all R1CS input columns at r_cycle from the
+    cycle-major witness matrix — one eq table and one pass over the matrix on the device (zg_fr_rows_mle)."""
+
+    @staticmethod
+    def computeClaimedInputs(cycle_witnesses, r_cycle):
+        """cycle_witnesses: (num_cycles, NUM_INPUTS, 4) = R1CSCycleInputs.values per cycle; -> (NUM_INPUTS, 4)   (:55-122)"""
+        w = np.ascontiguousarray(cycle_witnesses, dtype=np.uint64)
+        assert w.ndim == 3 and w.shape[2] == 4
+        r = np.ascontiguousarray(r_cycle, dtype=np.uint64).reshape(-1, 4)
+        num_cycles, k = w.shape[0], w.shape[1]
+        if num_cycles == 0:
+            return np.zeros((k, 4), dtype=np.uint64)
+        log_n = num_cycles.bit_length() - 1  # std.math.log2_int: floor
+        padded_len = 1 << log_n
+        effective_len = min(r.shape[0], log_n)
+        if effective_len == 0:  # :75-83: no cycle variables — the first witness
+            return w[0].copy()
+        if effective_len < log_n:  # the reference indexes eq_evals[t] for t < padded_len: out of bounds here (a safety-checked panic)
+            raise IndexError("computeClaimedInputs: r_cycle shorter than log2 of the cycle count")
+        return lib.fr_rows_mle(w[:min(num_cycles, padded_len)], r[:effective_len])
+
+    @staticmethod
+    def computeClaimedInput(cycle_witnesses, r_cycle, input_index):
+        """computeClaimedInput (:125-160): one column of the above"""
+        return R1CSInputEvaluator.computeClaimedInputs(np.ascontiguousarray(cycle_witnesses, dtype=np.uint64)[:, input_index:input_index + 1], r_cycle)[0]
+
+
 class SumcheckInstance:
     """SumcheckInstance(F) (src/zkvm/batched_sumcheck.zig:34-74): num_rounds, degree, input_claim and the three callbacks.
     compute_round_poly(round) -> [s(0), s(1), s(2), s(3)]; bind_challenge(challenge); cache_openings(r_sumcheck) optional."""

@@ -391,6 +391,36 @@ __global__ void __launch_bounds__(256) sc_tail_run_kernel(const uint64_t *t, uin
     }
 }
 
+// R1CSInputEvaluator.computeClaimedInputs (src/zkvm/r1cs/evaluation.zig:55-122): out[i] = sum_t eq[t] * rows[t][i] for the k columns of a
+// cycle-major matrix (k field elements per cycle, the layout of R1CSCycleInputs.values). One wave per cycle: lane i multiplies column i by
+// the cycle's eq value (prescaled once per wave), four waves of a block take consecutive cycles; partials[block][column].
+constexpr unsigned ROWS_MLE_MAX_K = 64;
+__global__ void __launch_bounds__(256) rows_mle_kernel(const uint64_t *rows, size_t n_rows, uint32_t k, const uint64_t *eq, uint64_t *partials) {
+    __shared__ uint4 sh[4 * ROWS_MLE_MAX_K * 2];
+    const uint32_t col = threadIdx.x & 63, w = threadIdx.x >> 6;
+    Fr acc = Fr::zero();
+    size_t step = (size_t)gridDim.x * 4;
+    for (size_t t = (size_t)blockIdx.x * 4 + w; t < n_rows; t += step) {
+        F29 ep = fr29_prescale(fe_load<FrParams>(eq + 4 * t));  // uniform across the wave
+        if (col < k) acc = fe_add(acc, fr_mul29(fe_load<FrParams>(rows + 4 * (t * k + col)), ep));
+    }
+    if (col < k) fe_store(&sh[(w * ROWS_MLE_MAX_K + col) * 2], acc);
+    __syncthreads();
+    if (w == 0 && col < k) {
+        for (uint32_t x = 1; x < 4; x++) acc = fe_add(acc, fe_load<FrParams>(&sh[(x * ROWS_MLE_MAX_K + col) * 2]));
+        fe_store(partials + 4 * ((size_t)blockIdx.x * k + col), acc);
+    }
+}
+
+// out[column] = sum over the blocks' partials; one block per column
+__global__ void __launch_bounds__(256) rows_mle_finish_kernel(const uint64_t *partials, uint32_t nblocks, uint32_t k, uint64_t *out) {
+    __shared__ uint4 sh[256 * 4];
+    Fr g0 = Fr::zero(), g1 = Fr::zero();
+    for (uint32_t b = threadIdx.x; b < nblocks; b += 256) g0 = fe_add(g0, fe_load<FrParams>(partials + 4 * ((size_t)b * k + blockIdx.x)));
+    block_sum_pair(g0, g1, sh);
+    if (threadIdx.x == 0) fe_store(out + 4 * (size_t)blockIdx.x, g0);
+}
+
 // reduce the per-block partial pairs to sums[0..8)
 __global__ void __launch_bounds__(256) sc_finish_kernel(const uint64_t *partials, uint32_t nblocks, uint64_t *sums, uint64_t *flag,
                                                         uint64_t seq) {
@@ -911,6 +941,47 @@ int zg_fr_dense_evaluate(const uint64_t *evals, size_t num_vars, const uint64_t 
     }
     if (rc != ZG_OK) (void)hipStreamSynchronize(st);
     return rc;
+}
+
+int zg_fr_rows_mle_dev(const uint64_t *d_rows, size_t n_rows, size_t k, const uint64_t *r_host, size_t v, void *stream, uint64_t *out) {
+    ZG_INIT();
+    if (!out || k == 0 || k > ROWS_MLE_MAX_K || v > 30 || (v && !r_host) || (n_rows && !d_rows)) {
+        set_error("zg_fr_rows_mle: 1..64 columns, at most 30 variables");
+        return ZG_ERR_INVALID;
+    }
+    const size_t full = (size_t)1 << v;
+    if (n_rows > full) n_rows = full;  // rows past the hypercube have no eq value
+    hipStream_t st = pick_stream(stream);
+    unsigned nb = (unsigned)((n_rows + 3) / 4);
+    if (nb < 1) nb = 1;
+    if (nb > 1024) nb = 1024;
+    Scratch s_eq(full * 32), s_part((size_t)nb * k * 32), s_out(k * 32);
+    if (!s_eq.p || !s_part.p || !s_out.p) return ZG_ERR_NOMEM;
+    SyncGuard sync(st);
+    ZG_TRY(eq_table_enqueue(r_host, v, nullptr, s_eq.as<uint64_t>(), st));
+    hipLaunchKernelGGL(rows_mle_kernel, dim3(nb), dim3(256), 0, st, d_rows, n_rows, (uint32_t)k, s_eq.as<uint64_t>(), s_part.as<uint64_t>());
+    hipLaunchKernelGGL(rows_mle_finish_kernel, dim3((unsigned)k), dim3(256), 0, st, s_part.as<uint64_t>(), nb, (uint32_t)k, s_out.as<uint64_t>());
+    ZG_HIP(hipGetLastError());
+    ZG_HIP(hipMemcpyAsync(out, s_out.p, k * 32, hipMemcpyDeviceToHost, st));
+    ZG_HIP(hipStreamSynchronize(st));
+    sync.dismiss();
+    return ZG_OK;
+}
+
+int zg_fr_rows_mle(const uint64_t *rows, size_t n_rows, size_t k, const uint64_t *r, size_t v, uint64_t *out) {
+    ZG_INIT();
+    if (!out || k == 0 || k > ROWS_MLE_MAX_K || v > 30 || (v && !r) || (n_rows && !rows)) {
+        set_error("zg_fr_rows_mle: 1..64 columns, at most 30 variables");
+        return ZG_ERR_INVALID;
+    }
+    const size_t full = (size_t)1 << v;
+    if (n_rows > full) n_rows = full;
+    hipStream_t st = lib_stream();
+    Scratch s_rows((n_rows ? n_rows : 1) * k * 32);
+    if (!s_rows.p) return ZG_ERR_NOMEM;
+    SyncGuard sync(st);
+    if (n_rows) ZG_HIP(hipMemcpyAsync(s_rows.p, rows, n_rows * k * 32, hipMemcpyHostToDevice, st));
+    return zg_fr_rows_mle_dev(s_rows.as<uint64_t>(), n_rows, k, r, v, st, out);
 }
 
 int zg_fr_spartan_combine_dev(const uint64_t *d_eq, const uint64_t *d_az, const uint64_t *d_bz, const uint64_t *d_cz, size_t n,
