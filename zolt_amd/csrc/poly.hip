@@ -729,6 +729,8 @@ struct zg_sc_s {
     uint64_t *h_pin = nullptr;  // pinned, device-visible: the kernels write the round sums (8 limbs) straight to the host
     bool sums_valid = false;
     hipStream_t st = nullptr;
+    hipStream_t own_st = nullptr;  // created with the session, kept across pooling: zg_sumcheck_open (host table) runs on it, so the
+                                   // independent provers of a batched sumcheck overlap instead of queueing on the library stream
     uint64_t seq = 0;  // number of (sums) publications requested so far; h_pin[12] holds the last one completed
     size_t cap = 0;  // elements buf[0] can hold (sessions are pooled: hipMalloc/hipFree cost more than a round)
     // address-phase state of a Lasso session (zg_sumcheck_bit_round / bit_bind)
@@ -751,6 +753,7 @@ static void sc_free(zg_sc_s *s) {
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (s->h_pin) (void)hipHostFree(s->h_pin);
+    if (s->own_st) (void)hipStreamDestroy(s->own_st);
     delete s;
 }
 
@@ -768,7 +771,7 @@ static int sc_create(size_t len, int layout, hipStream_t st, zg_sc_s **out) {
             if (g_pool[i]->device == current_device() && g_pool[i]->cap >= len && g_pool[i]->cap <= 4 * len) {
                 zg_sc_s *s = g_pool[i];
                 g_pool.erase(g_pool.begin() + i);
-                s->layout = layout; s->len = len; s->st = st; s->cur = 0; s->sums_valid = false;
+                s->layout = layout; s->len = len; s->st = st ? st : s->own_st; s->cur = 0; s->sums_valid = false;
                 s->seq = 0; s->h_pin[12] = 0;
                 s->bit_valid = false; s->pad_valid = false;
                 *out = s;
@@ -781,8 +784,9 @@ static int sc_create(size_t len, int layout, hipStream_t st, zg_sc_s **out) {
     s->cap = len;
     s->layout = layout;
     s->len = len;
-    s->st = st;
-    hipError_t e = hipMalloc((void **)&s->buf[0], len * 32);
+    hipError_t e = hipStreamCreateWithFlags(&s->own_st, hipStreamNonBlocking);
+    s->st = st ? st : s->own_st;
+    if (e == hipSuccess) e = hipMalloc((void **)&s->buf[0], len * 32);
     if (e == hipSuccess) e = hipMalloc((void **)&s->buf[1], (len / 2 ? len / 2 : 1) * 32);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_partials, SC_MISC_BYTES);
     if (e == hipSuccess) e = hipMemset(s->d_partials, 0, SC_MISC_BYTES);
@@ -1539,7 +1543,7 @@ int zg_sumcheck_open(const uint64_t *evals, size_t len, int layout, zg_sc_t *out
         return ZG_ERR_INVALID;
     }
     zg_sc_s *s = nullptr;
-    ZG_TRY(sc_create(len, layout, lib_stream(), &s));
+    ZG_TRY(sc_create(len, layout, nullptr, &s));  // the session's own stream
     hipError_t e = hipMemcpyAsync(s->buf[0], evals, len * 32, hipMemcpyHostToDevice, s->st);
     if (e == hipSuccess) e = hipStreamSynchronize(s->st);
     if (e != hipSuccess) {

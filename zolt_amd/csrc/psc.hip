@@ -315,6 +315,7 @@ struct zg_psc_s {
     uint64_t *d_misc = nullptr;
     uint64_t *h_pin = nullptr;  // pinned, device-visible mailbox: up to 16 words of values, sequence word at PSC_FLAG
     hipStream_t st = nullptr;
+    hipStream_t own_st = nullptr;  // sessions opened from host tables run on a stream of their own: independent provers of a batch overlap
     uint64_t seq = 0;
     // the spec of the last zg_psc_round_evals call: zg_psc_bind then folds AND evaluates in one launch, and the next
     // zg_psc_round_evals with the same spec only collects the mailbox
@@ -333,6 +334,7 @@ static void psc_free(zg_psc_s *s) {
     if (s->buf[1]) (void)hipFree(s->buf[1]);
     if (s->d_misc) (void)hipFree(s->d_misc);
     if (s->h_pin) (void)hipHostFree(s->h_pin);
+    if (s->own_st) (void)hipStreamDestroy(s->own_st);
     delete s;
 }
 
@@ -347,7 +349,12 @@ static int psc_create(size_t k, size_t len, hipStream_t st, zg_psc_s **out) {
     s->len = s->cap = len;
     s->st = st;
     size_t half = len / 2 ? len / 2 : 1;
-    hipError_t e = hipMalloc((void **)&s->buf[0], k * len * 32);
+    hipError_t e = hipSuccess;
+    if (!st) {  // no caller stream: the session's own
+        e = hipStreamCreateWithFlags(&s->own_st, hipStreamNonBlocking);
+        s->st = s->own_st;
+    }
+    if (e == hipSuccess) e = hipMalloc((void **)&s->buf[0], k * len * 32);
     if (e == hipSuccess) e = hipMalloc((void **)&s->buf[1], k * half * 32);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_misc, PSC_MISC_BYTES);
     if (e == hipSuccess) e = hipMemset(s->d_misc, 0, PSC_MISC_BYTES);
@@ -450,7 +457,7 @@ int zg_psc_open(const uint64_t *const *tables, size_t k, size_t len, zg_psc_t *o
             return ZG_ERR_INVALID;
         }
     zg_psc_s *s = nullptr;
-    ZG_TRY(psc_create(k, len, lib_stream(), &s));
+    ZG_TRY(psc_create(k, len, nullptr, &s));
     for (size_t j = 0; j < k; j++) {
         hipError_t e = hipMemcpyAsync(s->buf[0] + 4 * j * len, tables[j], len * 32, hipMemcpyHostToDevice, s->st);
         if (e != hipSuccess) {
