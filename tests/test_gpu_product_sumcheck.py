@@ -410,3 +410,26 @@ def test_batched_sumcheck_stage2_shape(env, mode):
     assert np.array_equal(o.current_claim, proof["final_claim"])
     for (_, _, _, _, fg), (_, _, _, _, fo) in zip(gpu, ora):
         assert np.array_equal(fg(), fo())
+
+
+def test_pooled_sessions_serve_smaller_shapes(env):
+    """a closed session is kept and reused for a later one with fewer tables / a shorter length (its buffers keep their stride): the
+    reused session must behave like a fresh one through evaluations, folds and finals"""
+    api, lib, ob = env
+    for k, n, seed in ((5, 256, 1), (3, 128, 2), (2, 64, 3), (5, 256, 4), (1, 64, 5)):
+        tabs = [_rand(ob, 8100 + 10 * seed + j, n) for j in range(k)]
+        s = lib.ProductSumcheckSession.open(tabs)
+        assert len(s) == n and s.tables() == k
+        cur = [t.copy() for t in tabs]
+        idx = tuple(range(min(k, 3)))
+        while len(s) > 1:
+            want = ob.ValEvaluationProver(cur[0], cur[1 % k], cur[2 % k] if len(idx) == 3 else None, cur[0][0]).computeRoundPolynomial() if len(idx) >= 2 else None
+            got = s.round_evals(idx)
+            if want is not None:
+                assert np.array_equal(got, want), (k, n, len(s))
+            r = _rand(ob, 8150 + len(s), 1)[0]
+            s.bind(r)
+            cur = [ob.fr_bind_low(t, r) for t in cur]
+            assert np.array_equal(s.read(k - 1), cur[k - 1])
+        assert np.array_equal(s.final(), np.stack([t[0] for t in cur]))
+        s.close()

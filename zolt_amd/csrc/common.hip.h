@@ -17,6 +17,8 @@ int ensure_init();          // ZG_OK or ZG_ERR_NO_DEVICE / ZG_ERR_HIP
 int primary_device();       // the device zg_init / zg_init_devices bound this process to (valid after ensure_init)
 int current_device();       // the calling thread's HIP device
 hipStream_t lib_stream();   // the library's own stream on the calling thread's CURRENT device (created on first use)
+hipStream_t stream_acquire();                     // an idle stream of the current device (created if none): sumcheck sessions
+void stream_release(hipStream_t st, int device);  // back to the free list (streams live until zg_shutdown)
 
 // HIP's current device is per host thread (a fresh std.Thread worker starts on device 0) and a handle's memory lives on
 // the device it was created on: every entry point pins the calling thread to the right device for its duration.
@@ -142,6 +144,8 @@ static inline void fr_add_host(uint64_t r[4], const uint64_t a[4], const uint64_
 
 int bound_devices();      // devices 0..n-1 bound by zg_init_devices (1 in the one-GPU-per-process model)
 void sharded_shutdown();  // sharded.hip: drop communicators / exchange buffers (called by zg_shutdown)
+void sc_shutdown();       // poly.hip / psc.hip: drop the pooled sumcheck sessions (called by zg_shutdown)
+void psc_shutdown();
 
 // msm.hip: zg_msm_g1_batch_dev that also fuses zero-padded rows on wide-window handles (HyperKZG.open's long levels)
 int msm_batch_dev_wide(zg_bases_t b, size_t n, const uint64_t *d_scalars, size_t k, hipStream_t st, uint64_t *d_out9);

@@ -729,8 +729,8 @@ struct zg_sc_s {
     uint64_t *h_pin = nullptr;  // pinned, device-visible: the kernels write the round sums (8 limbs) straight to the host
     bool sums_valid = false;
     hipStream_t st = nullptr;
-    hipStream_t own_st = nullptr;  // created with the session, kept across pooling: zg_sumcheck_open (host table) runs on it, so the
-                                   // independent provers of a batched sumcheck overlap instead of queueing on the library stream
+    hipStream_t own_st = nullptr;  // zg_sumcheck_open (host table) runs on it: created with the session and kept in the pool, so the
+                                   // independent provers of a batched sumcheck overlap (psc.hip: psc_open_stream has the measurements)
     uint64_t seq = 0;  // number of (sums) publications requested so far; h_pin[12] holds the last one completed
     size_t cap = 0;  // elements buf[0] can hold (sessions are pooled: hipMalloc/hipFree cost more than a round)
     // address-phase state of a Lasso session (zg_sumcheck_bit_round / bit_bind)
@@ -753,7 +753,7 @@ static void sc_free(zg_sc_s *s) {
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (s->h_pin) (void)hipHostFree(s->h_pin);
-    if (s->own_st) (void)hipStreamDestroy(s->own_st);
+    stream_release(s->own_st, s->device);
     delete s;
 }
 
@@ -771,9 +771,10 @@ static int sc_create(size_t len, int layout, hipStream_t st, zg_sc_s **out) {
             if (g_pool[i]->device == current_device() && g_pool[i]->cap >= len && g_pool[i]->cap <= 4 * len) {
                 zg_sc_s *s = g_pool[i];
                 g_pool.erase(g_pool.begin() + i);
-                s->layout = layout; s->len = len; s->st = st ? st : s->own_st; s->cur = 0; s->sums_valid = false;
+                s->layout = layout; s->len = len; s->st = st; s->cur = 0; s->sums_valid = false;
                 s->seq = 0; s->h_pin[12] = 0;
                 s->bit_valid = false; s->pad_valid = false;
+                if (!st) s->st = s->own_st;
                 *out = s;
                 return ZG_OK;
             }
@@ -784,8 +785,9 @@ static int sc_create(size_t len, int layout, hipStream_t st, zg_sc_s **out) {
     s->cap = len;
     s->layout = layout;
     s->len = len;
-    hipError_t e = hipStreamCreateWithFlags(&s->own_st, hipStreamNonBlocking);
+    s->own_st = stream_acquire();  // kept with the pooled session; from the runtime's free list (creating one costs ~3 ms)
     s->st = st ? st : s->own_st;
+    hipError_t e = s->own_st ? hipSuccess : hipErrorOutOfMemory;
     if (e == hipSuccess) e = hipMalloc((void **)&s->buf[0], len * 32);
     if (e == hipSuccess) e = hipMalloc((void **)&s->buf[1], (len / 2 ? len / 2 : 1) * 32);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_partials, SC_MISC_BYTES);
@@ -1543,7 +1545,7 @@ int zg_sumcheck_open(const uint64_t *evals, size_t len, int layout, zg_sc_t *out
         return ZG_ERR_INVALID;
     }
     zg_sc_s *s = nullptr;
-    ZG_TRY(sc_create(len, layout, nullptr, &s));  // the session's own stream
+    ZG_TRY(sc_create(len, layout, nullptr, &s));  // a stream of its own
     hipError_t e = hipMemcpyAsync(s->buf[0], evals, len * 32, hipMemcpyHostToDevice, s->st);
     if (e == hipSuccess) e = hipStreamSynchronize(s->st);
     if (e != hipSuccess) {
@@ -1872,3 +1874,14 @@ int zg_sumcheck_close(zg_sc_t s) {
 }
 
 }  // extern "C"
+
+namespace zg {
+void sc_shutdown() {  // zg_shutdown: drop the pooled sessions (buffers, pinned mailbox, stream)
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (zg_sc_s *s : g_pool) {
+        DeviceGuard dg(s->device);
+        sc_free(s);
+    }
+    g_pool.clear();
+}
+}  // namespace zg

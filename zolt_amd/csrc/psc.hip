@@ -310,12 +310,13 @@ static unsigned psc_blocks(size_t half) {
 struct zg_psc_s {
     int device = -1;
     size_t k = 0, len = 0, cap = 0;
+    size_t alloc_k = 0;  // tables the buffers were sized for (a pooled session serves any k <= alloc_k)
     uint64_t *buf[2] = {nullptr, nullptr};  // buf[0]: k tables of cap entries; buf[1]: k tables of cap/2 (a fold cannot run in place)
     int cur = 0;
     uint64_t *d_misc = nullptr;
     uint64_t *h_pin = nullptr;  // pinned, device-visible mailbox: up to 16 words of values, sequence word at PSC_FLAG
     hipStream_t st = nullptr;
-    hipStream_t own_st = nullptr;  // sessions opened from host tables run on a stream of their own: independent provers of a batch overlap
+    hipStream_t own_st = nullptr;  // created with the session, kept in the pool (see psc_open_stream)
     uint64_t seq = 0;
     // the spec of the last zg_psc_round_evals call: zg_psc_bind then folds AND evaluates in one launch, and the next
     // zg_psc_round_evals with the same spec only collects the mailbox
@@ -334,26 +335,55 @@ static void psc_free(zg_psc_s *s) {
     if (s->buf[1]) (void)hipFree(s->buf[1]);
     if (s->d_misc) (void)hipFree(s->d_misc);
     if (s->h_pin) (void)hipHostFree(s->h_pin);
-    if (s->own_st) (void)hipStreamDestroy(s->own_st);
+    stream_release(s->own_st, s->device);
     delete s;
 }
+
+// A session opened without a caller stream runs on a stream of its own, so the independent provers of a batched sumcheck overlap;
+// the stream is created with the session and STAYS with it in the pool. Measured (tools/bench_sumcheck, Stage-2-shaped proof: four of
+// these sessions + one single-table session, same box, A/B): rounds of the proof 1.42 ms with pooled streams, 1.15 ms with a stream
+// created per open (streams created together land on consecutive hardware queues; long-lived ones can share a queue with another busy
+// session), 1.40 / 1.55 ms with a per-device ring of eight / four shared streams, 2.2 ms with everything on the library stream —
+// but hipStreamCreate + hipStreamDestroy cost 2.9 ms per open, against 45 us for a pooled open: per proof the pooled stream wins by far.
+static hipError_t psc_open_stream(zg_psc_s *s, hipStream_t caller) {
+    if (!s->own_st) s->own_st = stream_acquire();  // from the runtime's free list: creating one costs ~3 ms
+    s->st = caller ? caller : s->own_st;
+    return s->own_st ? hipSuccess : hipErrorOutOfMemory;
+}
+
+// closed sessions kept for reuse (allocations and the pinned mailbox cost more than a proof's worth of rounds)
+static std::mutex g_psc_pool_mu;
+static std::vector<zg_psc_s *> g_psc_pool;
 
 static int psc_create(size_t k, size_t len, hipStream_t st, zg_psc_s **out) {
     if (k == 0 || k > ZG_PSC_MAX_TABLES || len == 0 || (len & (len - 1))) {
         set_error("zg_psc_open: 1..8 tables, len a power of two");
         return ZG_ERR_INVALID;
     }
+    {
+        std::lock_guard<std::mutex> lk(g_psc_pool_mu);
+        for (size_t i = 0; i < g_psc_pool.size(); i++) {
+            zg_psc_s *c = g_psc_pool[i];
+            if (c->device == current_device() && c->alloc_k >= k && c->cap >= len && c->cap <= 4 * len) {
+                g_psc_pool.erase(g_psc_pool.begin() + i);
+                c->k = k; c->len = len; c->cur = 0; c->seq = 0; c->h_pin[PSC_FLAG] = 0;
+                c->have_spec = c->evals_pending = false;
+                if (psc_open_stream(c, st) != hipSuccess) {
+                    set_error("zg_psc_open: hipStreamCreate failed");
+                    psc_free(c);
+                    return ZG_ERR_HIP;
+                }
+                *out = c;
+                return ZG_OK;
+            }
+        }
+    }
     zg_psc_s *s = new zg_psc_s();
     s->device = current_device();
-    s->k = k;
+    s->k = s->alloc_k = k;
     s->len = s->cap = len;
-    s->st = st;
     size_t half = len / 2 ? len / 2 : 1;
-    hipError_t e = hipSuccess;
-    if (!st) {  // no caller stream: the session's own
-        e = hipStreamCreateWithFlags(&s->own_st, hipStreamNonBlocking);
-        s->st = s->own_st;
-    }
+    hipError_t e = psc_open_stream(s, st);
     if (e == hipSuccess) e = hipMalloc((void **)&s->buf[0], k * len * 32);
     if (e == hipSuccess) e = hipMalloc((void **)&s->buf[1], k * half * 32);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_misc, PSC_MISC_BYTES);
@@ -459,7 +489,7 @@ int zg_psc_open(const uint64_t *const *tables, size_t k, size_t len, zg_psc_t *o
     zg_psc_s *s = nullptr;
     ZG_TRY(psc_create(k, len, nullptr, &s));
     for (size_t j = 0; j < k; j++) {
-        hipError_t e = hipMemcpyAsync(s->buf[0] + 4 * j * len, tables[j], len * 32, hipMemcpyHostToDevice, s->st);
+        hipError_t e = hipMemcpyAsync(s->buf[0] + 4 * j * s->cap, tables[j], len * 32, hipMemcpyHostToDevice, s->st);
         if (e != hipSuccess) {
             (void)hipStreamSynchronize(s->st);
             set_error(hipGetErrorString(e));
@@ -491,7 +521,7 @@ int zg_psc_open_dev(const uint64_t *const *d_tables, size_t k, size_t len, void 
     zg_psc_s *s = nullptr;
     ZG_TRY(psc_create(k, len, pick_stream(stream), &s));
     for (size_t j = 0; j < k; j++) {
-        hipError_t e = hipMemcpyAsync(s->buf[0] + 4 * j * len, d_tables[j], len * 32, hipMemcpyDeviceToDevice, s->st);
+        hipError_t e = hipMemcpyAsync(s->buf[0] + 4 * j * s->cap, d_tables[j], len * 32, hipMemcpyDeviceToDevice, s->st);
         if (e != hipSuccess) {
             (void)hipStreamSynchronize(s->st);
             set_error(hipGetErrorString(e));
@@ -656,8 +686,27 @@ int zg_psc_close(zg_psc_t s) {
     ZG_INIT();
     DeviceGuard dg(s->device);
     (void)hipStreamSynchronize(s->st);
+    static const bool pool_on = [] { const char *e = getenv("ZG_PSC_POOL"); return !(e && *e == '0'); }();
+    if (pool_on) {
+        std::lock_guard<std::mutex> lk(g_psc_pool_mu);
+        if (g_psc_pool.size() < 8) {
+            g_psc_pool.push_back(s);
+            return ZG_OK;
+        }
+    }
     psc_free(s);
     return ZG_OK;
 }
 
 }  // extern "C"
+
+namespace zg {
+void psc_shutdown() {  // zg_shutdown: drop the pooled sessions
+    std::lock_guard<std::mutex> lk(g_psc_pool_mu);
+    for (zg_psc_s *s : g_psc_pool) {
+        DeviceGuard dg(s->device);
+        psc_free(s);
+    }
+    g_psc_pool.clear();
+}
+}  // namespace zg

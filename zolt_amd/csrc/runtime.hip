@@ -37,6 +37,31 @@ hipStream_t lib_stream() {
     return g_streams[d];
 }
 
+// Streams for sumcheck sessions: hipStreamCreate + hipStreamDestroy cost ~3 ms on this stack, a session open must not pay that.
+// A session takes an idle stream from this per-device free list (or creates one) and hands it back when its buffers are freed;
+// the streams live until zg_shutdown.
+static std::vector<hipStream_t> g_idle_streams[ZG_MAX_DEVICES];
+hipStream_t stream_acquire() {
+    int d = current_device();
+    if (d < 0 || d >= ZG_MAX_DEVICES) return nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (!g_idle_streams[d].empty()) {
+            hipStream_t st = g_idle_streams[d].back();
+            g_idle_streams[d].pop_back();
+            return st;
+        }
+    }
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    return st;
+}
+void stream_release(hipStream_t st, int device) {
+    if (!st || device < 0 || device >= ZG_MAX_DEVICES) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_idle_streams[device].push_back(st);
+}
+
 // device >= 0: bind that device as the primary; -1: keep the calling thread's current device. ndev: devices 0..ndev-1 are bound
 // (zg_init_devices), 1 for the one-GPU-per-process model.
 static int do_init(int device, int ndev) {
@@ -245,6 +270,8 @@ int zg_n_devices(void) { return bound_devices(); }
 
 void zg_shutdown(void) {
     sharded_shutdown();  // communicators and per-device exchange buffers (sharded.hip)
+    sc_shutdown();       // pooled sumcheck sessions
+    psc_shutdown();
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_inited) return;
     int prev = current_device();
@@ -254,6 +281,13 @@ void zg_shutdown(void) {
         (void)hipStreamSynchronize(g_streams[d]);
         (void)hipStreamDestroy(g_streams[d]);
         g_streams[d] = nullptr;
+    }
+    for (int d = 0; d < ZG_MAX_DEVICES; d++) {
+        for (hipStream_t st : g_idle_streams[d]) {
+            (void)hipSetDevice(d);
+            (void)hipStreamDestroy(st);
+        }
+        g_idle_streams[d].clear();
     }
     if (prev >= 0) (void)hipSetDevice(prev);
     scratch_trim();
