@@ -204,3 +204,35 @@ def test_lasso_session_bit_ops_edge_cases(env):
         s.bit_bind(0, 10, 1, r)
     s.close()
     d_idx.free()
+
+
+@pytest.mark.parametrize("v", [0, 1, 2, 6, 13, 16])
+def test_jolt_outer_prover_rounds(env, v):
+    """JoltOuterProver's loop (src/zkvm/spartan/jolt_outer_prover.zig:148-262): [p(0), p(2)], the cubic form by linear extrapolation,
+    the fold and the claim (= sum of the folded table), against the oracle's LowToHigh sums / two-product fold"""
+    api, lib, ob = env
+    n = 1 << v
+    w = _rand(ob, 5600 + v, n)
+    g = api.JoltOuterProver(w)
+    cur = w.copy()
+    tot = lambda t: ob.f_add(ob.FR, *[x[None, :] for x in ob.fr_sum_even_odd(t)])[0] if len(t) >= 2 else t[0]
+    assert np.array_equal(g.current_claim, tot(cur))
+    chal = _rand(ob, 5610 + v, v + 1)
+    two, three = ob.f_from_u64(ob.FR, np.array([2], dtype=np.uint64)), ob.f_from_u64(ob.FR, np.array([3], dtype=np.uint64))
+    for rnd in range(v + 1):
+        if len(cur) >= 2:
+            p0, p1 = ob.fr_sum_even_odd(cur)
+            c1 = ob.f_sub(ob.FR, p1[None, :], p0[None, :])
+            want2 = ob.f_sub(ob.FR, ob.f_add(ob.FR, p1[None, :], p1[None, :]), p0[None, :])[0]
+            assert np.array_equal(g.computeRoundPoly(), np.stack([p0, want2]))
+            cub = g.computeCubicRoundPoly()
+            assert np.array_equal(cub[0], p0)
+            assert np.array_equal(cub[1], ob.f_add(ob.FR, p0[None, :], ob.f_mul(ob.FR, c1, two))[0])
+            assert np.array_equal(cub[2], ob.f_add(ob.FR, p0[None, :], ob.f_mul(ob.FR, c1, three))[0])
+            cur = ob.fr_bind_low_2mul(cur, chal[rnd])  # (1-r)*lo + r*hi (:240-243)
+        else:
+            assert np.array_equal(g.computeRoundPoly()[0], g.current_claim) and not g.computeCubicRoundPoly()[1:].any()
+        g.bindChallenge(chal[rnd])
+        assert g.current_len == len(cur) and np.array_equal(g.current_claim, tot(cur))
+    assert np.array_equal(g.getFinalEval(), cur[0])
+    g.deinit()

@@ -1296,6 +1296,59 @@ class ProductVirtualRemainderProver:
         self.split_eq.deinit()
 
 
+class JoltOuterProver:
+    """JoltOuterProver's round loop (src/zkvm/spartan/jolt_outer_prover.zig:148-262) over the table f(cycle) = eq(tau, cycle) * Az * Bz it
+    builds in init (:96-116, host work over the R1CS constraints): LowToHigh sums and folds on a LOW_PAIR device session."""
+
+    def __init__(self, working_evals):
+        w = np.ascontiguousarray(working_evals, dtype=np.uint64).reshape(-1, 4)
+        self.current_len = w.shape[0]
+        self._s = lib.SumcheckSession.open(w, lib.SC_LOW_PAIR)
+        self.challenges = []
+        self.current_claim = self._sum()  # :104-115: the sum of the table
+
+    def _sum(self):
+        if self.current_len >= 2:
+            g0, g1 = self._s.round_sums()
+            return _fr_add(g0, g1)
+        return self._s.final()
+
+    def computeRoundPoly(self):
+        """[p(0), p(2)] with p(2) = 2 p(1) - p(0) (:152-176)"""
+        if self.current_len <= 1:
+            return np.stack([self.current_claim, np.zeros(4, dtype=np.uint64)])
+        p0, p1 = self._s.round_sums()
+        return np.stack([p0, _fr_sub(_fr_add(p1, p1), p0)])
+
+    def computeCubicRoundPoly(self):
+        """[p(0), p(2), p(3)] by linear extrapolation from p(0), p(1) (:181-226)"""
+        if self.current_len <= 1:
+            z = np.zeros(4, dtype=np.uint64)
+            return np.stack([self.current_claim, z, z])
+        p0, p1 = self._s.round_sums()
+        a0, a1 = fr_to_int(p0), fr_to_int(p1)
+        c1 = (a1 - a0) % R_MOD
+        return np.stack([p0, fr_from_int((a0 + 2 * c1) % R_MOD), fr_from_int((a0 + 3 * c1) % R_MOD)])
+
+    def bindChallenge(self, challenge):
+        """:230-252: fold, the new claim is the sum of the folded table"""
+        self.challenges.append(np.array(challenge, dtype=np.uint64))
+        if self.current_len <= 1:
+            return
+        self._s.bind(challenge)
+        self.current_len //= 2
+        self.current_claim = self._sum()
+
+    def getFinalEval(self):
+        """:255-259"""
+        if self.current_len == 0:
+            return fr_from_int(0)
+        return self._s.final() if self.current_len == 1 else self.current_claim
+
+    def deinit(self):
+        self._s.close()
+
+
 class R1CSInputEvaluator:
     """R1CSInputEvaluator(F) (src/zkvm/r1cs/evaluation.zig:41-160): the MLE evaluations of all R1CS input columns at r_cycle from the
     cycle-major witness matrix — one eq table and one pass over the matrix on the device (zg_fr_rows_mle)."""
