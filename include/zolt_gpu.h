@@ -308,7 +308,7 @@ ZG_API int zg_run_sumcheck(const uint64_t *evals, size_t len, uint64_t claim[4],
  * (ram/val_final.zig:149-200: inc * wa), OutputSumcheckProver (ram/output_check.zig:375-470: eq * io * (vf - vio)),
  * InstructionLookupsClaimReduction (claim_reductions/instruction_lookups.zig:146-240: eq * (out + gamma left + gamma^2 right)) and the
  * Gruen-form ProductVirtualRemainderProver (spartan/product_remainder.zig:269-420: left * right under split-eq weights). A session keeps
- * k <= 8 tables of `len` entries (a power of two) resident in HBM; the transcript, the claim update and the Gruen scalar algebra stay
+ * k <= 12 tables of `len` entries (a power of two) resident in HBM; the transcript, the claim update and the Gruen scalar algebra stay
  * on the host. */
 typedef struct zg_psc_s *zg_psc_t;
 ZG_API int zg_psc_open(const uint64_t *const *tables /* k host pointers, len*4 words each */, size_t k, size_t len, zg_psc_t *s);
@@ -321,6 +321,18 @@ ZG_API size_t zg_psc_tables(zg_psc_t s);
  * [p(0), p(1), p(2), p(3)] (val_evaluation.zig:554-603); provers that send fewer values drop the rest. */
 ZG_API int zg_psc_round_evals(zg_psc_t s, const int *prod_idx, size_t p, const int *lin_idx, const uint64_t *lin_coeff /* q*4 */, size_t q,
                        uint64_t out[16]);
+/* A SUM of up to four such product terms in one pass — the round polynomials of stage3_prover.zig: ShiftSumcheck phase 1 (four P*Q
+ * pairs, :1351-1392) and phase 2 (:1399-1455), InstructionInput ((eq_out + g^2 eq_prod) * (is_rs2*rs2 + is_imm*imm + g (is_rs1*rs1 +
+ * is_pc*pc)), :2029-2100: four terms of two plain factors and a two-table combination). out as zg_psc_round_evals; provers that
+ * derive p(1) from the claim drop it. */
+typedef struct {
+    int n_prod;
+    int prod[4];
+    int n_lin;
+    int lin[4];
+    uint64_t lin_coeff[16]; /* n_lin x 4 words, Montgomery */
+} zg_psc_term;
+ZG_API int zg_psc_round_expr(zg_psc_t s, const zg_psc_term *terms, size_t n_terms /* 1..4 */, uint64_t out[16]);
 /* Gruen's pair (product_remainder.zig:281-330): t0 = sum_g w(g) prod_j T_j[2g], t_inf = sum_g w(g) prod_j (T_j[2g+1] - T_j[2g]),
  * w(g) = E_out[g >> log2|E_in|] * E_in[g & (|E_in| - 1)], pairs with g >> log2|E_in| >= |E_out| skipped. d_e_out / d_e_in: DEVICE
  * pointers (e.g. into the buffer zg_fr_eq_prefix_tables_dev filled: table k starts at element 2^k - 1). */

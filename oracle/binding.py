@@ -820,3 +820,43 @@ def r1cs_claimed_inputs(cycle_witnesses, r_cycle):
     if rc != 0:
         raise IndexError("eq_evals index out of bounds (r_cycle shorter than log2 of the cycle count)")
     return out
+
+
+# ---- Stage-3 prover rounds (src/zkvm/spartan/stage3_prover.zig): tables in, round evaluations out
+def _ptrs(tabs):
+    arrs = [_c(t).reshape(-1, 4) for t in tabs]
+    return arrs, (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+
+
+def shift_phase1_round(P, Q, current_prefix_size):
+    """ShiftSumcheckProver.computeRoundEvalsPhase1 (:1351-1392); P, Q: four tables each -> (3,4): p(0), p(1), p(2)"""
+    pa, pp = _ptrs(P)
+    qa, qp = _ptrs(Q)
+    out = np.empty((3, 4), dtype=np.uint64)
+    lib.zo_shift_phase1_round(pp, qp, C.c_size_t(current_prefix_size), _p(out))
+    return out
+
+
+def shift_phase2_round(tabs, gamma_powers, previous_claim):
+    """computeRoundEvalsPhase2 (:1399-1455); tabs = [eq_outer, eq_prod, upc, pc, virt, first, noop] -> (3,4)"""
+    arrs, ptrs = _ptrs(tabs)
+    out = np.empty((3, 4), dtype=np.uint64)
+    lib.zo_shift_phase2_round(ptrs, C.c_size_t(arrs[0].shape[0]), _p(_c(gamma_powers)), _p(_c(previous_claim)), _p(out))
+    return out
+
+
+def instruction_input_round(tabs, gamma, previous_claim):
+    """InstructionInputProver.computeRoundEvals (:2029-2100); tabs = [left_is_rs1, rs1_value, left_is_pc, unexpanded_pc, right_is_rs2,
+    rs2_value, right_is_imm, imm, eq_outer, eq_product] -> (4,4)"""
+    arrs, ptrs = _ptrs(tabs)
+    out = np.empty((4, 4), dtype=np.uint64)
+    lib.zo_instruction_input_round(ptrs, C.c_size_t(arrs[0].shape[0]), _p(_c(gamma)), _p(_c(previous_claim)), _p(out))
+    return out
+
+
+def registers_cr_round(phase2, tabs, gamma, previous_claim):
+    """RegistersClaimReductionProver.computeRoundEvalsPhase1 / Phase2 (:2334-2389) -> (3,4)"""
+    arrs, ptrs = _ptrs(tabs)
+    out = np.empty((3, 4), dtype=np.uint64)
+    lib.zo_registers_cr_round(C.c_int(1 if phase2 else 0), ptrs, C.c_size_t(arrs[0].shape[0]), _p(_c(gamma)), _p(_c(previous_claim)), _p(out))
+    return out

@@ -1368,3 +1368,105 @@ EXPORT int zo_r1cs_claimed_inputs(const uint64_t *rows, size_t num_cycles, size_
     free(eq);
     return 0;
 }
+
+/* ---------------------------------------------------------- Stage-3 prover rounds (src/zkvm/spartan/stage3_prover.zig) */
+/* ShiftSumcheckProver.computeRoundEvalsPhase1 — :1351-1392: four (P, Q) pairs, H(X) = sum_pairs sum_j P(X) Q(X) at X = 0, 1, 2 */
+EXPORT void zo_shift_phase1_round(const uint64_t *const *P, const uint64_t *const *Q, size_t current_prefix_size, uint64_t evals[12]) {
+    fe e[3] = {f_zero(), f_zero(), f_zero()};
+    size_t half = current_prefix_size / 2;
+    for (int k = 0; k < 4; k++) {
+        const fe *p = (const fe *)P[k], *q = (const fe *)Q[k];
+        for (size_t i = 0; i < half; i++) {
+            fe p0 = p[2 * i], p1 = p[2 * i + 1], q0 = q[2 * i], q1 = q[2 * i + 1];
+            fe p2 = f_add(&FR, &p1, &p1); p2 = f_sub(&FR, &p2, &p0);
+            fe q2 = f_add(&FR, &q1, &q1); q2 = f_sub(&FR, &q2, &q0);
+            fe a = f_mul(&FR, &p0, &q0), b = f_mul(&FR, &p1, &q1), c = f_mul(&FR, &p2, &q2);
+            e[0] = f_add(&FR, &e[0], &a); e[1] = f_add(&FR, &e[1], &b); e[2] = f_add(&FR, &e[2], &c);
+        }
+    }
+    memcpy(evals, e, 96);
+}
+static fe lin2(const fe *t, size_t j) {  /* X = 2 extrapolation of the pair (2j, 2j+1): f1 + f1 - f0 */
+    fe v = f_add(&FR, &t[2 * j + 1], &t[2 * j + 1]);
+    return f_sub(&FR, &v, &t[2 * j]);
+}
+/* ShiftSumcheckProver.computeRoundEvalsPhase2 — :1399-1455: tables eq_outer, eq_prod, upc, pc, virt, first, noop; gamma_powers[0..4];
+ * -> [p(0), previous_claim - p(0), p(2)] */
+EXPORT void zo_shift_phase2_round(const uint64_t *const *tabs, size_t n, const uint64_t *gamma_powers, const uint64_t previous_claim[4],
+                                  uint64_t evals[12]) {
+    const fe *eo = (const fe *)tabs[0], *ep = (const fe *)tabs[1], *upc = (const fe *)tabs[2], *pc = (const fe *)tabs[3],
+             *virt = (const fe *)tabs[4], *first = (const fe *)tabs[5], *noop = (const fe *)tabs[6];
+    const fe *g = (const fe *)gamma_powers;
+    fe one = f_one(&FR), e0 = f_zero(), e2 = f_zero();
+    for (size_t j = 0; j < n / 2; j++) {
+        for (int x = 0; x < 2; x++) {  /* X = 0, then X = 2 */
+            fe veo = x ? lin2(eo, j) : eo[2 * j], vep = x ? lin2(ep, j) : ep[2 * j], vu = x ? lin2(upc, j) : upc[2 * j];
+            fe vp = x ? lin2(pc, j) : pc[2 * j], vv = x ? lin2(virt, j) : virt[2 * j], vf = x ? lin2(first, j) : first[2 * j];
+            fe vn = x ? lin2(noop, j) : noop[2 * j];
+            fe a = f_mul(&FR, &g[1], &vp), b = f_mul(&FR, &g[2], &vv), c = f_mul(&FR, &g[3], &vf);
+            fe val = f_add(&FR, &vu, &a); val = f_add(&FR, &val, &b); val = f_add(&FR, &val, &c);
+            fe term1 = f_mul(&FR, &veo, &val);
+            fe omn = f_sub(&FR, &one, &vn), term2 = f_mul(&FR, &g[4], &omn); term2 = f_mul(&FR, &term2, &vep);
+            fe f = f_add(&FR, &term1, &term2);
+            if (x) e2 = f_add(&FR, &e2, &f); else e0 = f_add(&FR, &e0, &f);
+        }
+    }
+    fe p1 = f_sub(&FR, (const fe *)previous_claim, &e0);
+    fe out[3] = {e0, p1, e2};
+    memcpy(evals, out, 96);
+}
+/* InstructionInputProver.computeRoundEvals — :2029-2100: tables left_is_rs1, rs1_value, left_is_pc, unexpanded_pc, right_is_rs2, rs2_value,
+ * right_is_imm, imm, eq_outer, eq_product; -> [p(0), previous_claim - p(0), p(2), p(3)] */
+EXPORT void zo_instruction_input_round(const uint64_t *const *tabs, size_t n, const uint64_t gamma[4], const uint64_t previous_claim[4],
+                                       uint64_t evals[16]) {
+    const fe *T[10];
+    for (int k = 0; k < 10; k++) T[k] = (const fe *)tabs[k];
+    fe g = *(const fe *)gamma, g2 = f_mul(&FR, &g, &g), e[3] = {f_zero(), f_zero(), f_zero()};
+    for (size_t j = 0; j < n / 2; j++) {
+        fe v[10][3];  /* values at X = 0, 2, 3: f_2 = f_1 + f_1 - f_0, f_3 = f_2 + f_1 - f_0 */
+        for (int k = 0; k < 10; k++) {
+            fe f0 = T[k][2 * j], f1 = T[k][2 * j + 1];
+            fe f2 = f_add(&FR, &f1, &f1); f2 = f_sub(&FR, &f2, &f0);
+            fe f3 = f_add(&FR, &f2, &f1); f3 = f_sub(&FR, &f3, &f0);
+            v[k][0] = f0; v[k][1] = f2; v[k][2] = f3;
+        }
+        for (int x = 0; x < 3; x++) {
+            fe a = f_mul(&FR, &v[0][x], &v[1][x]), b = f_mul(&FR, &v[2][x], &v[3][x]), left = f_add(&FR, &a, &b);
+            a = f_mul(&FR, &v[4][x], &v[5][x]); b = f_mul(&FR, &v[6][x], &v[7][x]);
+            fe right = f_add(&FR, &a, &b);
+            fe w = f_mul(&FR, &g2, &v[9][x]), eqw = f_add(&FR, &v[8][x], &w);
+            fe gl = f_mul(&FR, &g, &left), sum = f_add(&FR, &right, &gl), f = f_mul(&FR, &eqw, &sum);
+            e[x] = f_add(&FR, &e[x], &f);
+        }
+    }
+    fe p1 = f_sub(&FR, (const fe *)previous_claim, &e[0]);
+    fe out[4] = {e[0], p1, e[1], e[2]};
+    memcpy(evals, out, 128);
+}
+/* RegistersClaimReductionProver.computeRoundEvalsPhase1 (:2334-2354: P * Q) and Phase2 (:2356-2389: eq * (rd + gamma rs1 + gamma^2 rs2));
+ * phase 1: tabs = {P, Q}; phase 2: tabs = {eq, rd_write_value, rs1_value, rs2_value}; -> [p(0), previous_claim - p(0), p(2)] */
+EXPORT void zo_registers_cr_round(int phase2, const uint64_t *const *tabs, size_t n, const uint64_t gamma[4], const uint64_t previous_claim[4],
+                                  uint64_t evals[12]) {
+    fe e0 = f_zero(), e2 = f_zero();
+    if (!phase2) {
+        const fe *P = (const fe *)tabs[0], *Q = (const fe *)tabs[1];
+        for (size_t i = 0; i < n / 2; i++) {
+            fe p2 = lin2(P, i), q2 = lin2(Q, i), a = f_mul(&FR, &P[2 * i], &Q[2 * i]), b = f_mul(&FR, &p2, &q2);
+            e0 = f_add(&FR, &e0, &a); e2 = f_add(&FR, &e2, &b);
+        }
+    } else {
+        const fe *eq = (const fe *)tabs[0], *rd = (const fe *)tabs[1], *rs1 = (const fe *)tabs[2], *rs2 = (const fe *)tabs[3];
+        fe g = *(const fe *)gamma, g2 = f_mul(&FR, &g, &g);
+        for (size_t j = 0; j < n / 2; j++) {
+            fe eq2 = lin2(eq, j), rd2 = lin2(rd, j), a2 = lin2(rs1, j), b2 = lin2(rs2, j);
+            fe x = f_mul(&FR, &g, &rs1[2 * j]), y = f_mul(&FR, &g2, &rs2[2 * j]), v0 = f_add(&FR, &rd[2 * j], &x); v0 = f_add(&FR, &v0, &y);
+            x = f_mul(&FR, &g, &a2); y = f_mul(&FR, &g2, &b2);
+            fe v2 = f_add(&FR, &rd2, &x); v2 = f_add(&FR, &v2, &y);
+            fe a = f_mul(&FR, &eq[2 * j], &v0), b = f_mul(&FR, &eq2, &v2);
+            e0 = f_add(&FR, &e0, &a); e2 = f_add(&FR, &e2, &b);
+        }
+    }
+    fe p1 = f_sub(&FR, (const fe *)previous_claim, &e0);
+    fe out[3] = {e0, p1, e2};
+    memcpy(evals, out, 96);
+}

@@ -96,7 +96,7 @@ def test_session_edges_and_errors(env):
     with pytest.raises(RuntimeError):
         lib.ProductSumcheckSession.open([_rand(ob, 7301, 3)])  # not a power of two
     with pytest.raises(RuntimeError):
-        lib.ProductSumcheckSession.open([t] * 9)
+        lib.ProductSumcheckSession.open([t] * 13)
     # device-pointer open: the same session contents
     d = [lib.DeviceBuffer.from_host(x) for x in (_rand(ob, 7302, 32), _rand(ob, 7303, 32))]
     s = lib.ProductSumcheckSession.open_dev([b.ptr for b in d], 32)
@@ -433,3 +433,126 @@ def test_pooled_sessions_serve_smaller_shapes(env):
             assert np.array_equal(s.read(k - 1), cur[k - 1])
         assert np.array_equal(s.final(), np.stack([t[0] for t in cur]))
         s.close()
+
+
+@pytest.mark.parametrize("shape", [[(2, 0)], [(2, 0), (2, 0), (2, 0), (2, 0)], [(1, 4), (0, 1), (1, 1)], [(2, 2), (2, 2), (2, 2), (2, 2)], [(4, 4), (3, 0), (0, 3)]])
+def test_round_expr_against_big_int_model(env, shape):
+    """zg_psc_round_expr: sums of product terms of every (p, q) shape the Stage-3 provers use, against plain Python integers, across
+    three rounds (the second and third come out of the fused bind)"""
+    api, lib, ob = env
+    P = api.R_MOD
+    k, n = 12, 64
+    tabs = [_rand(ob, 8300 + j, n, sparse=(j % 4 == 1)) for j in range(k)]
+    ints = [[api.fr_to_int(x) for x in t] for t in tabs]
+    terms, model = [], []
+    for ti, (p, q) in enumerate(shape):
+        prod_idx = tuple((5 * ti + 3 * j + 1) % k for j in range(p))
+        lin_idx = tuple((7 * ti + 2 * m) % k for m in range(q))
+        coeff = _rand(ob, 8350 + ti, max(q, 1))[:q]
+        terms.append((prod_idx, lin_idx, coeff if q else None))
+        model.append((prod_idx, lin_idx, [api.fr_to_int(c) for c in coeff]))
+    s = lib.ProductSumcheckSession.open(tabs)
+    for rnd in range(3):
+        half = len(s) // 2
+        want = []
+        for t in range(4):
+            acc = 0
+            for g in range(half):
+                f = lambda T: (T[2 * g] + t * (T[2 * g + 1] - T[2 * g])) % P
+                for prod_idx, lin_idx, cint in model:
+                    v = 1
+                    for j in prod_idx:
+                        v = v * f(ints[j]) % P
+                    if lin_idx:
+                        v = v * (sum(c * f(ints[m]) for c, m in zip(cint, lin_idx)) % P) % P
+                    acc = (acc + v) % P
+            want.append(acc)
+        assert [api.fr_to_int(x) for x in s.round_expr(terms)] == want, (shape, rnd)
+        r = _rand(ob, 8360 + rnd, 1)[0]
+        ri = api.fr_to_int(r)
+        s.bind(r)
+        ints = [[(T[2 * i] + ri * (T[2 * i + 1] - T[2 * i])) % P for i in range(half)] for T in ints]
+        for j in (0, 5, k - 1):
+            assert [api.fr_to_int(x) for x in s.read(j)] == ints[j]
+    with pytest.raises(RuntimeError):
+        s.round_expr([((0, 12), (), None)])
+    with pytest.raises(RuntimeError):
+        s.round_expr([])
+    with pytest.raises(RuntimeError):
+        s.round_expr([((), (), None)])
+    s.close()
+
+
+@pytest.mark.parametrize("v", [1, 2, 5, 10, 14])
+def test_instruction_input_prover(env, v):
+    """InstructionInputProver (src/zkvm/spartan/stage3_prover.zig:2029-2150): ten tables, four product terms in one pass per round"""
+    api, lib, ob = env
+    n = 1 << v
+    tabs = [_rand(ob, 8400 + 10 * j + v, n, sparse=(j in (0, 2, 4, 6))) for j in range(10)]
+    gamma = _rand(ob, 8490 + v, 1)[0]
+    g = api.InstructionInputProver(tabs, gamma)
+    cur = [t.copy() for t in tabs]
+    claim = _rand(ob, 8495 + v, 1)[0]
+    ch = _rand(ob, 8496 + v, v)
+    for rnd in range(v):
+        got, want = g.computeRoundEvals(claim), ob.instruction_input_round(cur, gamma, claim)
+        assert np.array_equal(got, want), rnd
+        g.bind(ch[rnd])
+        cur = [ob.fr_bind_low(t, ch[rnd]) for t in cur]
+        claim = ob.raf_update_claim(want, ch[rnd])
+    fc = g.finalClaims()
+    assert all(np.array_equal(fc[name], cur[j][0]) for j, name in enumerate(api.InstructionInputProver.NAMES))
+    g.deinit()
+
+
+@pytest.mark.parametrize("v", [1, 3, 8, 12])
+def test_shift_sumcheck_rounds_both_phases(env, v):
+    """ShiftSumcheckProver's phase-1 (four P*Q pairs) and phase-2 (eq_out * (...) + gamma^4 (1 - noop) eq_prod) loops
+    (stage3_prover.zig:1343-1500,1782-1817) over given tables"""
+    api, lib, ob = env
+    n = 1 << v
+    tabs = [_rand(ob, 8500 + 10 * j + v, n) for j in range(8)]
+    p1 = api.ShiftSumcheckRounds(tabs)
+    cur = [t.copy() for t in tabs]
+    ch = _rand(ob, 8590 + v, v)
+    for rnd in range(v):
+        want = ob.shift_phase1_round(cur[0::2], cur[1::2], len(cur[0]))
+        assert np.array_equal(p1.computeRoundEvals(None), want), rnd
+        p1.bind(ch[rnd])
+        cur = [ob.fr_bind_low(t, ch[rnd]) for t in cur]
+    assert all(np.array_equal(a, b) for a, b in zip(p1.tables(), cur))
+    p1.deinit()
+    tabs = [_rand(ob, 8600 + 10 * j + v, n, sparse=(j == 6)) for j in range(7)]
+    gp = _rand(ob, 8690 + v, 5)
+    p2 = api.ShiftSumcheckRounds(tabs, phase2=True, gamma_powers=gp)
+    cur = [t.copy() for t in tabs]
+    claim = _rand(ob, 8695 + v, 1)[0]
+    for rnd in range(v):
+        want = ob.shift_phase2_round(cur, gp, claim)
+        assert np.array_equal(p2.computeRoundEvals(claim), want), rnd
+        p2.bind(ch[rnd])
+        cur = [ob.fr_bind_low(t, ch[rnd]) for t in cur]
+        claim = want[2]  # any value: the claim only enters p(1) = claim - p(0)
+    p2.deinit()
+
+
+@pytest.mark.parametrize("v", [1, 4, 9])
+def test_registers_claim_reduction_rounds(env, v):
+    """RegistersClaimReductionProver's two loops (stage3_prover.zig:2326-2481)"""
+    api, lib, ob = env
+    n = 1 << v
+    gamma = _rand(ob, 8700 + v, 1)[0]
+    claim = _rand(ob, 8701 + v, 1)[0]
+    ch = _rand(ob, 8702 + v, v)
+    for phase2, k in ((False, 2), (True, 4)):
+        tabs = [_rand(ob, 8710 + 10 * j + v + (50 if phase2 else 0), n) for j in range(k)]
+        g = api.RegistersClaimReductionRounds(tabs, gamma, phase2=phase2)
+        cur = [t.copy() for t in tabs]
+        for rnd in range(v):
+            assert np.array_equal(g.computeRoundEvals(claim), ob.registers_cr_round(phase2, cur, gamma, claim)), (phase2, rnd)
+            g.bind(ch[rnd])
+            cur = [ob.fr_bind_low(t, ch[rnd]) for t in cur]
+        if phase2:
+            fc = g.finalClaims()
+            assert np.array_equal(fc["rd_write_value"], cur[1][0]) and np.array_equal(fc["rs2_value"], cur[3][0])
+        g.deinit()

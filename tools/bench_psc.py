@@ -35,7 +35,10 @@ def main():
            "evals_p4_us": med(lambda: ps.round_evals((0, 1, 2, 3))),
            "evals_p1q3_us": med(lambda: ps.round_evals((0,), (1, 2, 3), tab[:3])),
            "evals_p2q2_us": med(lambda: ps.round_evals((0, 1), (2, 3), tab[:2])),
-           "gruen_p2_us": med(lambda: ps.round_gruen((0, 1), d_out, n_out, d_in, n_in))}
+           "gruen_p2_us": med(lambda: ps.round_gruen((0, 1), d_out, n_out, d_in, n_in)),
+           "expr_4x_p2_us": med(lambda: ps.round_expr([((0, 1), (), None), ((2, 3), (), None), ((0, 2), (), None), ((1, 3), (), None)])),
+           "expr_instruction_input_shape_us": med(lambda: ps.round_expr([((0, 1), (2, 3), tab[:2]), ((1, 2), (2, 3), tab[:2]), ((0, 3), (2, 3), tab[2:4]),
+                                                                         ((1, 3), (2, 3), tab[2:4])]))}
     print(out)
     ps.close()
     g.deinit()

@@ -42,6 +42,8 @@ def zig_type(ctype, array):
         return HANDLES[base] if stars == 0 else "*" + HANDLES[base]
     if base == "zg_msm_config":
         return "?*const MsmConfig"
+    if base == "zg_psc_term":
+        return "?[*]const PscTerm"
     if base == "void":
         if stars == 2:
             return "*?*anyopaque"
@@ -92,6 +94,7 @@ def generate():
         "pub const ProductSession = ?*opaque {}; // zg_psc_t",
         "",
         "pub const MsmConfig = extern struct { window_bits: c_int = 0, precompute_levels: c_int = 0, expected_uses: c_int = 0 };",
+        "pub const PscTerm = extern struct { n_prod: c_int = 0, prod: [4]c_int = .{ 0, 0, 0, 0 }, n_lin: c_int = 0, lin: [4]c_int = .{ 0, 0, 0, 0 }, lin_coeff: [16]u64 = .{0} ** 16 }; // zg_psc_term",
         "",
     ]
     for name, val in consts:

@@ -461,10 +461,10 @@ pub fn ProductSession(comptime F: type) type {
         const Self = @This();
         handle: ffi.ProductSession = null,
 
-        /// `tables`: up to 8 slices of the same power-of-two length (copied to the device)
+        /// `tables`: up to 12 slices of the same power-of-two length (copied to the device)
         pub fn open(tables: []const []const F) Error!Self {
-            std.debug.assert(tables.len >= 1 and tables.len <= 8);
-            var ptrs: [8]?[*]const u64 = .{null} ** 8;
+            std.debug.assert(tables.len >= 1 and tables.len <= 12);
+            var ptrs: [12]?[*]const u64 = .{null} ** 12;
             for (tables, 0..) |t, j| ptrs[j] = limbsOf(F, t);
             var self: Self = .{};
             if (ffi.zg_psc_open(@ptrCast(&ptrs), tables.len, tables[0].len, &self.handle) != ffi.OK) return Error.GpuFailure;
@@ -478,6 +478,13 @@ pub fn ProductSession(comptime F: type) type {
             std.debug.assert(lin.len == coeff.len);
             var out: [4]F = undefined;
             if (ffi.zg_psc_round_evals(self.handle, prod.ptr, prod.len, lin.ptr, limbsOf(F, coeff), lin.len, @ptrCast(&out)) != ffi.OK) return Error.GpuFailure;
+            return out;
+        }
+        /// [p(0..3)] of a SUM of up to four product terms (ffi.PscTerm each) — ShiftSumcheckProver's two phases and InstructionInputProver
+        /// (src/zkvm/spartan/stage3_prover.zig:1351-1455,2029-2100)
+        pub fn roundExpr(self: *Self, terms: []const ffi.PscTerm) Error![4]F {
+            var out: [4]F = undefined;
+            if (ffi.zg_psc_round_expr(self.handle, terms.ptr, terms.len, @ptrCast(&out)) != ffi.OK) return Error.GpuFailure;
             return out;
         }
         /// Gruen's (t0, t_inf) under the split-eq weights; e_out / e_in: device tables (see `GruenDeviceTables`)

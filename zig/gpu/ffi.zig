@@ -13,6 +13,7 @@ pub const ShardedSession = ?*opaque {}; // zg_ssc_t
 pub const ProductSession = ?*opaque {}; // zg_psc_t
 
 pub const MsmConfig = extern struct { window_bits: c_int = 0, precompute_levels: c_int = 0, expected_uses: c_int = 0 };
+pub const PscTerm = extern struct { n_prod: c_int = 0, prod: [4]c_int = .{ 0, 0, 0, 0 }, n_lin: c_int = 0, lin: [4]c_int = .{ 0, 0, 0, 0 }, lin_coeff: [16]u64 = .{0} ** 16 }; // zg_psc_term
 
 pub const OK: c_int = 0;
 pub const ERR_INVALID: c_int = 1;
@@ -102,6 +103,7 @@ pub extern fn zg_psc_open_dev(d_tables: ?[*]const ?[*]const u64, k: usize, len: 
 pub extern fn zg_psc_len(s: ProductSession) usize;
 pub extern fn zg_psc_tables(s: ProductSession) usize;
 pub extern fn zg_psc_round_evals(s: ProductSession, prod_idx: ?[*]const c_int, p: usize, lin_idx: ?[*]const c_int, lin_coeff: ?[*]const u64, q: usize, out: *[16]u64) c_int;
+pub extern fn zg_psc_round_expr(s: ProductSession, terms: ?[*]const PscTerm, n_terms: usize, out: *[16]u64) c_int;
 pub extern fn zg_psc_round_gruen(s: ProductSession, prod_idx: ?[*]const c_int, p: usize, d_e_out: ?[*]const u64, n_out: usize, d_e_in: ?[*]const u64, n_in: usize, t0: *[4]u64, t_inf: *[4]u64) c_int;
 pub extern fn zg_psc_bind(s: ProductSession, r: *const [4]u64) c_int;
 pub extern fn zg_psc_read(s: ProductSession, table: usize, out: ?[*]u64) c_int;

@@ -1296,6 +1296,106 @@ class ProductVirtualRemainderProver:
         self.split_eq.deinit()
 
 
+class InstructionInputProver:
+    """InstructionInputProver's loop (src/zkvm/spartan/stage3_prover.zig:2029-2150): ten cycle-length tables,
+    f = (eq_outer + gamma^2 eq_product) * (right_is_rs2 * rs2 + right_is_imm * imm + gamma (left_is_rs1 * rs1 + left_is_pc * pc)) as four
+    product terms of one multi-term round (zg_psc_round_expr). Table order: left_is_rs1, rs1_value, left_is_pc, unexpanded_pc,
+    right_is_rs2, rs2_value, right_is_imm, imm, eq_outer, eq_product."""
+    NAMES = ("left_is_rs1", "rs1_value", "left_is_pc", "unexpanded_pc", "right_is_rs2", "rs2_value", "right_is_imm", "imm", "eq_outer", "eq_product")
+
+    def __init__(self, tables, gamma):
+        assert len(tables) == 10
+        self._s = lib.ProductSumcheckSession.open(tables)
+        g = fr_to_int(gamma)
+        w_right = np.stack([fr_from_int(1), fr_from_int(g * g % R_MOD)])  # eq_outer + gamma^2 eq_product
+        w_left = np.stack([fr_from_int(g), fr_from_int(g * g * g % R_MOD)])  # gamma times the same weight
+        self._terms = [((4, 5), (8, 9), w_right), ((6, 7), (8, 9), w_right), ((0, 1), (8, 9), w_left), ((2, 3), (8, 9), w_left)]
+        self.current_size = len(self._s)
+
+    def computeRoundEvals(self, previous_claim):
+        """[p(0), previous_claim - p(0), p(2), p(3)] (:2029-2100)"""
+        ev = self._s.round_expr(self._terms)
+        return np.stack([ev[0], _fr_sub(previous_claim, ev[0]), ev[2], ev[3]])
+
+    def bind(self, r_j):
+        self._s.bind(r_j)
+        self.current_size //= 2
+
+    def finalClaims(self):
+        return dict(zip(self.NAMES, self._s.final()))
+
+    def deinit(self):
+        self._s.close()
+
+
+class ShiftSumcheckRounds:
+    """The two round loops of ShiftSumcheckProver (src/zkvm/spartan/stage3_prover.zig:1343-1500,1782-1817) over given tables; the
+    prefix-suffix construction of P / Q and the phase transition (:1504-1780) stay the caller's.
+    phase 1: P_0_outer, Q_0_outer, P_1_outer, Q_1_outer, P_0_prod, Q_0_prod, P_1_prod, Q_1_prod (H = sum of the four P * Q);
+    phase 2: eq+1_outer, eq+1_prod, unexpanded_pc, pc, is_virtual, is_first_in_sequence, is_noop and gamma_powers[0..4]."""
+
+    def __init__(self, tables, phase2=False, gamma_powers=None):
+        self.phase2 = phase2
+        self._s = lib.ProductSumcheckSession.open(tables)
+        if not phase2:
+            assert len(tables) == 8
+            self._terms = [((0, 1), (), None), ((2, 3), (), None), ((4, 5), (), None), ((6, 7), (), None)]
+        else:
+            assert len(tables) == 7
+            g = [fr_to_int(x) for x in np.ascontiguousarray(gamma_powers, dtype=np.uint64).reshape(-1, 4)]
+            val = np.stack([fr_from_int(1), fr_from_int(g[1]), fr_from_int(g[2]), fr_from_int(g[3])])
+            # gamma^4 (1 - noop) eq_prod = gamma^4 eq_prod - gamma^4 noop eq_prod: the same field value at every t
+            self._terms = [((0,), (2, 3, 4, 5), val), ((), (1,), fr_from_int(g[4]).reshape(1, 4)), ((6,), (1,), fr_from_int((-g[4]) % R_MOD).reshape(1, 4))]
+
+    def computeRoundEvals(self, previous_claim):
+        """phase 1 (:1351-1392): [p(0), p(1), p(2)] all computed; phase 2 (:1399-1455): [p(0), previous_claim - p(0), p(2)]"""
+        ev = self._s.round_expr(self._terms)
+        if not self.phase2:
+            return np.stack([ev[0], ev[1], ev[2]])
+        return np.stack([ev[0], _fr_sub(previous_claim, ev[0]), ev[2]])
+
+    def bind(self, r_j):
+        """bindPhase1 (:1479-1503) / bindPhase2 (:1782-1817): every table by lo + r (hi - lo)"""
+        self._s.bind(r_j)
+
+    def tables(self):
+        return [self._s.read(j) for j in range(self._s.tables())]
+
+    def deinit(self):
+        self._s.close()
+
+
+class RegistersClaimReductionRounds:
+    """The two round loops of RegistersClaimReductionProver (stage3_prover.zig:2326-2481) over given tables.
+    phase 1: P, Q (prefix-sized; the witness tables rd_write_value / rs1_value / rs2_value the reference folds alongside, :2404-2416, have
+    the full cycle length and live in a second session that is only bound); phase 2: eq, rd_write_value, rs1_value, rs2_value."""
+
+    def __init__(self, tables, gamma, phase2=False):
+        self.phase2 = phase2
+        self._s = lib.ProductSumcheckSession.open(tables)
+        g = fr_to_int(gamma)
+        self._coeff = np.stack([fr_from_int(1), fr_from_int(g), fr_from_int(g * g % R_MOD)])
+
+    def computeRoundEvals(self, previous_claim):
+        """[p(0), previous_claim - p(0), p(2)] (:2334-2389)"""
+        ev = self._s.round_evals((0,), (1, 2, 3), self._coeff) if self.phase2 else self._s.round_evals((0, 1))
+        return np.stack([ev[0], _fr_sub(previous_claim, ev[0]), ev[2]])
+
+    def bind(self, r_j):
+        self._s.bind(r_j)
+
+    def finalClaims(self):
+        """:2483-2494 (phase 2)"""
+        f = self._s.final()
+        return {"rd_write_value": f[1], "rs1_value": f[2], "rs2_value": f[3]}
+
+    def tables(self):
+        return [self._s.read(j) for j in range(self._s.tables())]
+
+    def deinit(self):
+        self._s.close()
+
+
 class JoltOuterProver:
     """JoltOuterProver's round loop (src/zkvm/spartan/jolt_outer_prover.zig:148-262) over the table f(cycle) = eq(tau, cycle) * Az * Bz it
     builds in init (:96-116, host work over the R1CS constraints): LowToHigh sums and folds on a LOW_PAIR device session."""

@@ -14,6 +14,7 @@
 // Exact modular arithmetic with canonical outputs: 2*f1 - f0, f0 + 2 (f1 - f0) and f(1) + (f(1) - f(0)) are the same field value, sums
 // commute, so every evaluation order gives the reference's bytes.
 #include <stdlib.h>
+#include <string.h>
 
 #include <mutex>
 #include <string>
@@ -25,7 +26,8 @@
 #include "fp29.hip.h"
 #include "sc_common.hip.h"
 
-#define ZG_PSC_MAX_TABLES 8
+#define ZG_PSC_MAX_TABLES 12
+#define ZG_PSC_MAX_TERMS 4
 #define ZG_PSC_MAX_FACTORS 4
 
 namespace zg {
@@ -294,6 +296,97 @@ __global__ void __launch_bounds__(256) psc_fold_evals_kernel(const uint64_t *bas
     psc_finish<2>(e, sh, partials, sums, counter, flag, seq);
 }
 
+// A SUM of up to four product terms (each: up to four plain factors times an optional linear combination), evaluated at t = 0..3 —
+// the round polynomials of stage3_prover.zig (ShiftSumcheck phase 1: four P*Q pairs, :1351-1392; phase 2: eq_out * (upc + g pc + g^2 virt
+// + g^3 first) + g^4 (1 - noop) eq_prod, :1399-1455; InstructionInput: (eq_out + g^2 eq_prod) * (is_rs2 * rs2 + is_imm * imm +
+// g (is_rs1 * rs1 + is_pc * pc)), :2029-2100). Runtime loops over the description (uniform across the grid), no register arrays.
+struct PscExprTerm {
+    uint32_t np, nq;
+    uint32_t prod[ZG_PSC_MAX_FACTORS], lin[ZG_PSC_MAX_FACTORS];
+    FrArg coeff[ZG_PSC_MAX_FACTORS];
+};
+struct PscExpr {
+    uint32_t n_terms;
+    PscExprTerm t[ZG_PSC_MAX_TERMS];
+};
+
+// FOLD: fold the two old pairs 4g..4g+3 of every named table by r into the new pair first (and write it), as psc_fold_evals_kernel
+template <bool FOLD>
+__global__ void __launch_bounds__(256) psc_expr_kernel(const uint64_t *base, size_t stride, size_t n_pairs, FrArg r, uint64_t *out, size_t ostride,
+                                                       PscExpr ex, uint64_t *partials, uint64_t *sums, uint32_t *counter, uint64_t *flag, uint64_t seq) {
+    __shared__ uint4 sh[256 * 4];
+    F29 rp;
+    if (FOLD) {
+        Fr rv;
+#pragma unroll
+        for (int i = 0; i < 8; i++) rv.l[i] = r.l[i];
+        rp = fr29_prescale(rv);
+    }
+    Fr e[4] = {Fr::zero(), Fr::zero(), Fr::zero(), Fr::zero()};
+    size_t step = (size_t)gridDim.x * 256;
+    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < n_pairs; g += step) {
+        for (uint32_t ti = 0; ti < ex.n_terms; ti++) {
+            const PscExprTerm &tm = ex.t[ti];
+            Fr v0 = Fr::zero(), v1 = Fr::zero(), v2 = Fr::zero(), v3 = Fr::zero();
+            bool have = false;
+            auto pair_of = [&](uint32_t table, Fr &lo, Fr &hi) {
+                if (FOLD) {
+                    const uint64_t *t = base + 4 * ((size_t)table * stride + 4 * g);
+                    Fr a0 = fe_load<FrParams>(t), a1 = fe_load<FrParams>(t + 4), a2 = fe_load<FrParams>(t + 8), a3 = fe_load<FrParams>(t + 12);
+                    lo = fe_add(a0, fr_mul29(fe_sub(a1, a0), rp));
+                    hi = fe_add(a2, fr_mul29(fe_sub(a3, a2), rp));
+                    uint64_t *o = out + 4 * ((size_t)table * ostride + 2 * g);
+                    fe_store(o, lo);
+                    fe_store(o + 4, hi);
+                } else {
+                    const uint64_t *t = base + 4 * ((size_t)table * stride + 2 * g);
+                    lo = fe_load<FrParams>(t);
+                    hi = fe_load<FrParams>(t + 4);
+                }
+            };
+            if (tm.nq) {
+                Fr l0 = Fr::zero(), l1 = Fr::zero();
+                for (uint32_t m = 0; m < tm.nq; m++) {
+                    Fr lo, hi, c;
+                    pair_of(tm.lin[m], lo, hi);
+#pragma unroll
+                    for (int i = 0; i < 8; i++) c.l[i] = tm.coeff[m].l[i];
+                    l0 = fe_add(l0, fr_mul29v(lo, c));
+                    l1 = fe_add(l1, fr_mul29v(hi, c));
+                }
+                Fr d = fe_sub(l1, l0);
+                v0 = l0;
+                v1 = l1;
+                v2 = fe_add(l1, d);
+                v3 = fe_add(v2, d);
+                have = true;
+            }
+            for (uint32_t j = 0; j < tm.np; j++) {
+                Fr lo, hi;
+                pair_of(tm.prod[j], lo, hi);
+                Fr d = fe_sub(hi, lo), f2 = fe_add(hi, d), f3 = fe_add(f2, d);
+                if (!have) {
+                    v0 = lo; v1 = hi; v2 = f2; v3 = f3;
+                    have = true;
+                } else {
+                    v0 = fr_mul29v(v0, lo);
+                    v1 = fr_mul29v(v1, hi);
+                    v2 = fr_mul29v(v2, f2);
+                    v3 = fr_mul29v(v3, f3);
+                }
+            }
+            e[0] = fe_add(e[0], v0);
+            e[1] = fe_add(e[1], v1);
+            e[2] = fe_add(e[2], v2);
+            e[3] = fe_add(e[3], v3);
+        }
+    }
+    block_sum_pair(e[0], e[1], sh);
+    __syncthreads();
+    block_sum_pair(e[2], e[3], sh);
+    psc_finish<2>(e, sh, partials, sums, counter, flag, seq);
+}
+
 static unsigned psc_blocks(size_t half) {
     static const unsigned cap = [] {
         const char *e = getenv("ZG_PSC_BLOCKS");
@@ -323,6 +416,8 @@ struct zg_psc_s {
     bool have_spec = false, evals_pending = false;
     zg::PscSpec spec;
     size_t spec_p = 0, spec_q = 0;
+    bool spec_is_expr = false;  // the cached description is `expr` (zg_psc_round_expr) instead of spec / spec_p / spec_q
+    zg::PscExpr expr;
     std::mutex mu;
     size_t stride() const { return cur == 0 ? cap : (cap / 2 ? cap / 2 : 1); }
 };
@@ -357,7 +452,7 @@ static std::vector<zg_psc_s *> g_psc_pool;
 
 static int psc_create(size_t k, size_t len, hipStream_t st, zg_psc_s **out) {
     if (k == 0 || k > ZG_PSC_MAX_TABLES || len == 0 || (len & (len - 1))) {
-        set_error("zg_psc_open: 1..8 tables, len a power of two");
+        set_error("zg_psc_open: 1..12 tables, len a power of two");
         return ZG_ERR_INVALID;
     }
     {
@@ -462,7 +557,7 @@ static void psc_launch_fold_evals_q(size_t q, unsigned nb, hipStream_t st, const
 }
 
 static bool psc_same_spec(const zg_psc_s *s, const PscSpec &spec, size_t p, size_t q) {
-    if (!s->have_spec || s->spec_p != p || s->spec_q != q) return false;
+    if (!s->have_spec || s->spec_is_expr || s->spec_p != p || s->spec_q != q) return false;
     for (size_t j = 0; j < p; j++)
         if (s->spec.prod[j] != spec.prod[j]) return false;
     for (size_t m = 0; m < q; m++) {
@@ -555,6 +650,7 @@ int zg_psc_round_evals(zg_psc_t s, const int *prod_idx, size_t p, const int *lin
     s->spec = spec;
     s->spec_p = p;
     s->spec_q = q;
+    s->spec_is_expr = false;
     s->have_spec = true;
     s->evals_pending = true;  // the mailbox holds this spec's evaluations of the current tables until the next bind / Gruen round
     const uint64_t *base = s->buf[s->cur];
@@ -565,6 +661,53 @@ int zg_psc_round_evals(zg_psc_t s, const int *prod_idx, size_t p, const int *lin
     case 3: psc_launch_evals_q<3>(q, nb, s->st, base, s->stride(), half, spec, s->d_misc, s->h_pin, counter, flag, s->seq); break;
     default: psc_launch_evals_q<4>(q, nb, s->st, base, s->stride(), half, spec, s->d_misc, s->h_pin, counter, flag, s->seq); break;
     }
+    return psc_wait(s, out, 16);
+}
+
+int zg_psc_round_expr(zg_psc_t s, const zg_psc_term *terms, size_t n_terms, uint64_t out[16]) {
+    ZG_INIT();
+    if (!s || !terms || !out || n_terms == 0 || n_terms > ZG_PSC_MAX_TERMS || s->len < 2) {
+        set_error("zg_psc_round_expr: 1..4 terms, a session with at least two entries");
+        return ZG_ERR_INVALID;
+    }
+    PscExpr ex;
+    memset(&ex, 0, sizeof(ex));
+    ex.n_terms = (uint32_t)n_terms;
+    for (size_t ti = 0; ti < n_terms; ti++) {
+        const zg_psc_term &t = terms[ti];
+        bool bad = t.n_prod < 0 || t.n_prod > ZG_PSC_MAX_FACTORS || t.n_lin < 0 || t.n_lin > ZG_PSC_MAX_FACTORS || t.n_prod + t.n_lin == 0;
+        for (int j = 0; !bad && j < t.n_prod; j++) bad = t.prod[j] < 0 || (size_t)t.prod[j] >= s->k;
+        for (int m = 0; !bad && m < t.n_lin; m++) bad = t.lin[m] < 0 || (size_t)t.lin[m] >= s->k;
+        if (bad) {
+            set_error("zg_psc_round_expr: a term has at most 4 product tables and 4 linear-combination tables, indices below the table count");
+            return ZG_ERR_INVALID;
+        }
+        ex.t[ti].np = (uint32_t)t.n_prod;
+        ex.t[ti].nq = (uint32_t)t.n_lin;
+        for (int j = 0; j < t.n_prod; j++) ex.t[ti].prod[j] = (uint32_t)t.prod[j];
+        for (int m = 0; m < t.n_lin; m++) {
+            ex.t[ti].lin[m] = (uint32_t)t.lin[m];
+            for (int i = 0; i < 4; i++) {
+                ex.t[ti].coeff[m].l[2 * i] = (uint32_t)t.lin_coeff[4 * m + i];
+                ex.t[ti].coeff[m].l[2 * i + 1] = (uint32_t)(t.lin_coeff[4 * m + i] >> 32);
+            }
+        }
+    }
+    DeviceGuard dg(s->device);
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (s->evals_pending && s->have_spec && s->spec_is_expr && memcmp(&s->expr, &ex, sizeof(ex)) == 0) return psc_wait(s, out, 16);
+    const size_t half = s->len / 2;
+    unsigned nb = psc_blocks(half);
+    uint32_t *counter = reinterpret_cast<uint32_t *>(s->d_misc + PSC_COUNTER_OFF);
+    s->seq++;
+    s->expr = ex;
+    s->spec_is_expr = true;
+    s->have_spec = true;
+    s->evals_pending = true;
+    FrArg none;
+    memset(&none, 0, sizeof(none));
+    hipLaunchKernelGGL((psc_expr_kernel<false>), dim3(nb), dim3(256), 0, s->st, s->buf[s->cur], s->stride(), half, none, (uint64_t *)nullptr, (size_t)0, ex,
+                       s->d_misc, s->h_pin, counter, s->h_pin + PSC_FLAG, s->seq);
     return psc_wait(s, out, 16);
 }
 
@@ -627,8 +770,15 @@ int zg_psc_bind(zg_psc_t s, const uint64_t r[4]) {
     s->evals_pending = false;
     if (fuse) {
         bool in_spec[ZG_PSC_MAX_TABLES] = {false};
-        for (size_t j = 0; j < s->spec_p; j++) in_spec[s->spec.prod[j]] = true;
-        for (size_t m = 0; m < s->spec_q; m++) in_spec[s->spec.lin[m]] = true;
+        if (s->spec_is_expr) {
+            for (uint32_t ti = 0; ti < s->expr.n_terms; ti++) {
+                for (uint32_t j = 0; j < s->expr.t[ti].np; j++) in_spec[s->expr.t[ti].prod[j]] = true;
+                for (uint32_t m = 0; m < s->expr.t[ti].nq; m++) in_spec[s->expr.t[ti].lin[m]] = true;
+            }
+        } else {
+            for (size_t j = 0; j < s->spec_p; j++) in_spec[s->spec.prod[j]] = true;
+            for (size_t m = 0; m < s->spec_q; m++) in_spec[s->spec.lin[m]] = true;
+        }
         for (size_t t = 0; t < s->k; t++)
             if (!in_spec[t]) rest.t[n_rest++] = (uint32_t)t;
         const size_t quarter = half / 2;
@@ -636,6 +786,10 @@ int zg_psc_bind(zg_psc_t s, const uint64_t r[4]) {
         uint32_t *counter = reinterpret_cast<uint32_t *>(s->d_misc + PSC_COUNTER_OFF);
         s->seq++;
         const uint64_t *base = s->buf[s->cur];
+        if (s->spec_is_expr) {
+            hipLaunchKernelGGL((psc_expr_kernel<true>), dim3(nb), dim3(256), 0, s->st, base, s->stride(), quarter, ra, s->buf[nxt], ostride, s->expr,
+                               s->d_misc, s->h_pin, counter, s->h_pin + PSC_FLAG, s->seq);
+        } else
         switch (s->spec_p) {
         case 0: psc_launch_fold_evals_q<0>(s->spec_q, nb, s->st, base, s->stride(), quarter, ra, s->buf[nxt], ostride, s->spec, s->d_misc, s->h_pin, counter, s->h_pin + PSC_FLAG, s->seq); break;
         case 1: psc_launch_fold_evals_q<1>(s->spec_q, nb, s->st, base, s->stride(), quarter, ra, s->buf[nxt], ostride, s->spec, s->d_misc, s->h_pin, counter, s->h_pin + PSC_FLAG, s->seq); break;

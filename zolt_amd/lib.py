@@ -42,7 +42,7 @@ SYMBOLS = [
     "zg_sumcheck_len", "zg_sumcheck_final", "zg_sumcheck_read", "zg_sumcheck_close",
     "zg_sumcheck_round_sums_dev", "zg_sumcheck_read_dev", "zg_sumcheck_raf_round", "zg_sumcheck_bit_round", "zg_sumcheck_bit_bind", "zg_fr_bit_split_sums", "zg_fr_bit_split_sums_dev",
     "zg_run_sumcheck", "zg_run_sumcheck_dev", "zg_sumcheck_open_spartan_dev",
-    "zg_psc_open", "zg_psc_open_dev", "zg_psc_len", "zg_psc_tables", "zg_psc_round_evals", "zg_psc_round_gruen", "zg_psc_bind", "zg_psc_read",
+    "zg_psc_open", "zg_psc_open_dev", "zg_psc_len", "zg_psc_tables", "zg_psc_round_evals", "zg_psc_round_expr", "zg_psc_round_gruen", "zg_psc_bind", "zg_psc_read",
     "zg_psc_final", "zg_psc_close",
 ]
 # test / bench scaffolding of include/zolt_gpu_internal.h (not part of the drop-in boundary)
@@ -660,6 +660,11 @@ class SumcheckSession:
             pass
 
 
+class PscTerm(C.Structure):
+    """zg_psc_term: one product term of zg_psc_round_expr"""
+    _fields_ = [("n_prod", C.c_int), ("prod", C.c_int * 4), ("n_lin", C.c_int), ("lin", C.c_int * 4), ("lin_coeff", C.c_uint64 * 16)]
+
+
 class ProductSumcheckSession:
     """k multilinear tables folded together (LowToHigh) with product-form round evaluations (zg_psc_*): the loops of
     ValEvaluationProver, ValFinalProver, OutputSumcheckProver, InstructionLookupsClaimReduction and ProductVirtualRemainderProver."""
@@ -697,6 +702,23 @@ class ProductSumcheckSession:
         co = _c(lin_coeff) if len(lin_idx) else None
         out = np.empty((4, 4), dtype=np.uint64)
         _chk(_lib.zg_psc_round_evals(self._h, pi, C.c_size_t(len(prod_idx)), li, _h(co), C.c_size_t(len(lin_idx)), _h(out)), "zg_psc_round_evals")
+        return out
+
+    def round_expr(self, terms):
+        """[p(0..3)] of a SUM of product terms; terms: list of (prod_idx, lin_idx, lin_coeff) with lin_coeff (len(lin_idx), 4) or None"""
+        arr = (PscTerm * len(terms))()
+        for t, (prod_idx, lin_idx, coeff) in zip(arr, terms):
+            t.n_prod, t.n_lin = len(prod_idx), len(lin_idx)
+            for j, v in enumerate(prod_idx):
+                t.prod[j] = v
+            for m, v in enumerate(lin_idx):
+                t.lin[m] = v
+            if len(lin_idx):
+                flat = _c(coeff).reshape(-1)
+                for i in range(4 * len(lin_idx)):
+                    t.lin_coeff[i] = int(flat[i])
+        out = np.empty((4, 4), dtype=np.uint64)
+        _chk(_lib.zg_psc_round_expr(self._h, arr, C.c_size_t(len(terms)), _h(out)), "zg_psc_round_expr")
         return out
 
     def round_gruen(self, prod_idx, d_e_out, n_out, d_e_in, n_in):
