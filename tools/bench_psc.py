@@ -20,10 +20,12 @@ def main():
     g = api.GruenSplitEqPolynomial(tab[400:400 + v])
     d_out, n_out, d_in, n_in = g.getWindowEqTablesDev(1)
 
-    def med(f):
+    def med(f, reset=True):
         f()
         t = []
         for _ in range(7):
+            if reset:  # a repeated call with the same description only collects the mailbox: a Gruen round in between empties it
+                ps.round_gruen((0,), d_out, n_out, d_in, n_in)
             t0 = time.perf_counter()
             f()
             t.append(time.perf_counter() - t0)
@@ -35,7 +37,7 @@ def main():
            "evals_p4_us": med(lambda: ps.round_evals((0, 1, 2, 3))),
            "evals_p1q3_us": med(lambda: ps.round_evals((0,), (1, 2, 3), tab[:3])),
            "evals_p2q2_us": med(lambda: ps.round_evals((0, 1), (2, 3), tab[:2])),
-           "gruen_p2_us": med(lambda: ps.round_gruen((0, 1), d_out, n_out, d_in, n_in)),
+           "gruen_p2_us": med(lambda: ps.round_gruen((0, 1), d_out, n_out, d_in, n_in), reset=False),
            "expr_4x_p2_us": med(lambda: ps.round_expr([((0, 1), (), None), ((2, 3), (), None), ((0, 2), (), None), ((1, 3), (), None)])),
            "expr_instruction_input_shape_us": med(lambda: ps.round_expr([((0, 1), (2, 3), tab[:2]), ((1, 2), (2, 3), tab[:2]), ((0, 3), (2, 3), tab[2:4]),
                                                                          ((1, 3), (2, 3), tab[2:4])]))}
