@@ -164,6 +164,30 @@ while time.time() - t0 < budget:
                 g.updateClaim(ev, chs[k]); o.updateClaim(wev, chs[k])
             assert np.array_equal(g.getFinalClaim(), o.getFinalClaim())
         g.deinit()
+    # Stage-3 shapes: InstructionInput (four terms over ten tables) and Shift phase 2 (three terms over seven)
+    if 1 <= v <= 11:
+        gamma = rand_fr(1)[0]
+        tabs = [rand_fr(n, sparse and j % 2 == 0) for j in range(10)]
+        g = api.InstructionInputProver(tabs, gamma)
+        cur, claim = [t.copy() for t in tabs], rand_fr(1)[0]
+        for k in range(min(v, 5)):
+            want = ob.instruction_input_round(cur, gamma, claim)
+            assert np.array_equal(g.computeRoundEvals(claim), want), ("instruction input", v, k)
+            ch = rand_fr(1)[0]
+            g.bind(ch)
+            cur = [ob.fr_bind_low(t, ch) for t in cur]
+            claim = ob.raf_update_claim(want, ch)
+        g.deinit()
+        gp = rand_fr(5)
+        tabs = [rand_fr(n, sparse and j == 6) for j in range(7)]
+        g = api.ShiftSumcheckRounds(tabs, phase2=True, gamma_powers=gp)
+        cur = [t.copy() for t in tabs]
+        for k in range(min(v, 5)):
+            assert np.array_equal(g.computeRoundEvals(claim), ob.shift_phase2_round(cur, gp, claim)), ("shift phase 2", v, k)
+            ch = rand_fr(1)[0]
+            g.bind(ch)
+            cur = [ob.fr_bind_low(t, ch) for t in cur]
+        g.deinit()
     # LassoProver with a ragged cycle count
     if v <= 10:
         log_K = int(rng.integers(1, 129))
