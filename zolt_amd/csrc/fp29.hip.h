@@ -426,6 +426,71 @@ ZG_DEV Fr fr_mul29v(const Fr &x, const Fr &y) {
     return fr_mul29(x, ys);
 }
 
+// ---- product CHAINS of canonical scalars without leaving the 29-bit-limb form (the product-form sumcheck kernels, psc.hip).
+// fr_mul29v pays an unpack of both operands, a conditional subtraction and a repack per product; in a chain v = f0 * f1 * f2 ...
+// only the factors need unpacking (the later ones with the 5-bit shift that turns the 2^-261 of the lazy multiplier into the ABI's
+// 2^-256), the running product stays a lazy value (< 1.3 r, exact limbs), and a SUM of chain values is kept limb-wise in 64-bit
+// words — no carries, no reduction — until one multiplication by 2^261 mod r brings it back to the canonical element.
+ZG_DEV F29 fr29_in(const Fr &x) { return f29_unpack(x.l); }      // first factor of a chain (value < r)
+ZG_DEV F29 fr29_in_shift(const Fr &y) {                         // every later factor: 32 * y < 32 r, limbs < 2^29 (top < 2^27)
+    F29 yu = f29_unpack(y.l), ys;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        u32 lo = i ? (yu.l[i - 1] >> 24) : 0u;
+        ys.l[i] = (i < 8) ? (((yu.l[i] << 5) & Fr29::MASK) | lo) : ((yu.l[i] << 5) | lo);
+    }
+    return ys;
+}
+// a < A r (A <= 4), b = fr29_in_shift(y): a * y * 2^-256 mod r as a lazy value < (32 A / 168.9 + 1) r <= 1.76 r, exact limbs
+ZG_DEV F29 fr29_chain_mul(const F29 &a, const F29 &b_shifted) { return f29t_mul<Fr29>(a, b_shifted); }
+// a lazy chain value (< 2 r, exact limbs) -> canonical element
+ZG_DEV Fr fr29_out(const F29 &t) {
+    F29 d;
+    u32 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        u32 v = t.l[i] - Fr29::P[i] - borrow;
+        borrow = v >> 31;
+        d.l[i] = (i < 8) ? (v & Fr29::MASK) : v;
+    }
+    F29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = borrow ? t.l[i] : d.l[i];
+    Fr out;
+    f29_pack(r, out.l);
+    return out;
+}
+// limb-wise sum of lazy chain values in 64-bit words: at most FR29_ACC_MAX values (< 2 r each) between two reductions
+struct Acc29 {
+    u64 l[9];
+};
+constexpr unsigned FR29_ACC_MAX = 64;  // 64 * 2 r < 2^261: the sum still fits the nine limbs the multiplier accepts
+ZG_DEV Acc29 acc29_zero() {
+    Acc29 a;
+#pragma unroll
+    for (int i = 0; i < 9; i++) a.l[i] = 0;
+    return a;
+}
+ZG_DEV void acc29_add(Acc29 &a, const F29 &v) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) a.l[i] += v.l[i];
+}
+// the sum as a canonical element: carry into 29-bit limbs (top limb keeps the rest, < 2^30), one lazy product by 2^261 mod r
+// (X * 2^261 * 2^-261 = X mod r, < (128 / 168.9 + 1) r < 2 r), one conditional subtraction
+ZG_DEV Fr acc29_reduce(const Acc29 &a) {
+    constexpr u32 C261[9] = {0x0fffff57u, 0x1ea70ab4u, 0x052c068bu, 0x17504f49u, 0x0aa8075bu, 0x1d4240ceu, 0x11d54c07u, 0x052ac7a8u, 0x000dc836u};
+    F29 x, c;
+    u64 carry = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        u64 v = a.l[i] + carry;
+        x.l[i] = (i < 8) ? ((u32)v & Fr29::MASK) : (u32)v;
+        carry = v >> 29;
+        c.l[i] = C261[i];
+    }
+    return fr29_out(f29t_mul<Fr29>(x, c));
+}
+
 // Montgomery -> canonical integer of a scalar (fromMontgomery, src/field/mod.zig:642-645) = montgomeryMul(x, 1): the
 // prescaled 1 is the constant 32, so the product half of the multiplication folds to nine shifts and only the reduction
 // remains (~260 instructions instead of ~500 for the 32-bit-limb CIOS by one). Canonical output.

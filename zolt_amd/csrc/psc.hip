@@ -46,6 +46,39 @@ ZG_DEV void static_for(F &&f) {
     }
 }
 
+// Four chain values (t = 0..3) summed lazily over the pairs a thread owns (fp29.hip.h: Acc29), flushed into canonical accumulators
+// before the limb sums could outgrow the multiplier's input range.
+struct ChainAcc4 {
+    Acc29 a[4];
+    unsigned cnt;
+    ZG_DEV void init() {
+#pragma unroll
+        for (int t = 0; t < 4; t++) a[t] = acc29_zero();
+        cnt = 0;
+    }
+    ZG_DEV void add(const F29 (&w)[4], Fr (&e)[4]) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc29_add(a[t], w[t]);
+        if (++cnt == FR29_ACC_MAX) flush(e);
+    }
+    ZG_DEV void flush(Fr (&e)[4]) {
+        if (cnt == 0) return;
+        if (cnt == 1) {  // a single chain value: exact limbs, < 2 r — no product needed (the one-pair-per-thread regime of short tables)
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                F29 v;
+#pragma unroll
+                for (int i = 0; i < 9; i++) v.l[i] = (u32)a[t].l[i];
+                e[t] = fe_add(e[t], fr29_out(v));
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; t++) e[t] = fe_add(e[t], acc29_reduce(a[t]));
+        }
+        init();
+    }
+};
+
 struct PscSpec {
     uint32_t prod[ZG_PSC_MAX_FACTORS];  // table indices of the plain factors
     uint32_t lin[ZG_PSC_MAX_FACTORS];   // table indices of the linear combination
@@ -127,9 +160,11 @@ __global__ void __launch_bounds__(256) psc_evals_kernel(const uint64_t *base, si
         });
     }
     Fr e[4] = {Fr::zero(), Fr::zero(), Fr::zero(), Fr::zero()};
+    ChainAcc4 acc;
+    acc.init();
     size_t step = (size_t)gridDim.x * 256;
     for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < half; g += step) {
-        Fr v0, v1, v2, v3;
+        F29 w[4];  // the running products at t = 0..3, lazy 29-bit-limb values (fp29.hip.h: fr29_chain_mul)
         if constexpr (Q > 0) {  // L(0), L(1) from the tables, L(2), L(3) by linearity
             Fr l0 = Fr::zero(), l1 = Fr::zero();
             static_for<0, Q>([&](auto mc) {
@@ -138,11 +173,11 @@ __global__ void __launch_bounds__(256) psc_evals_kernel(const uint64_t *base, si
                 l0 = fe_add(l0, fr_mul29(fe_load<FrParams>(t), cp[m]));
                 l1 = fe_add(l1, fr_mul29(fe_load<FrParams>(t + 4), cp[m]));
             });
-            Fr d = fe_sub(l1, l0);
-            v0 = l0;
-            v1 = l1;
-            v2 = fe_add(l1, d);
-            v3 = fe_add(v2, d);
+            Fr d = fe_sub(l1, l0), l2 = fe_add(l1, d);
+            w[0] = fr29_in(l0);
+            w[1] = fr29_in(l1);
+            w[2] = fr29_in(l2);
+            w[3] = fr29_in(fe_add(l2, d));
         }
         if constexpr (P > 0) {
         static_for<0, P>([&](auto jc) {
@@ -151,20 +186,18 @@ __global__ void __launch_bounds__(256) psc_evals_kernel(const uint64_t *base, si
             Fr lo = fe_load<FrParams>(t), hi = fe_load<FrParams>(t + 4);
             Fr d = fe_sub(hi, lo), f2 = fe_add(hi, d), f3 = fe_add(f2, d);
             if (Q == 0 && j == 0) {
-                v0 = lo; v1 = hi; v2 = f2; v3 = f3;
+                w[0] = fr29_in(lo); w[1] = fr29_in(hi); w[2] = fr29_in(f2); w[3] = fr29_in(f3);
             } else {
-                v0 = fr_mul29v(v0, lo);
-                v1 = fr_mul29v(v1, hi);
-                v2 = fr_mul29v(v2, f2);
-                v3 = fr_mul29v(v3, f3);
+                w[0] = fr29_chain_mul(w[0], fr29_in_shift(lo));
+                w[1] = fr29_chain_mul(w[1], fr29_in_shift(hi));
+                w[2] = fr29_chain_mul(w[2], fr29_in_shift(f2));
+                w[3] = fr29_chain_mul(w[3], fr29_in_shift(f3));
             }
         });
         }
-        e[0] = fe_add(e[0], v0);
-        e[1] = fe_add(e[1], v1);
-        e[2] = fe_add(e[2], v2);
-        e[3] = fe_add(e[3], v3);
+        acc.add(w, e);
     }
+    acc.flush(e);
     block_sum_pair(e[0], e[1], sh);
     __syncthreads();
     block_sum_pair(e[2], e[3], sh);
@@ -243,9 +276,11 @@ __global__ void __launch_bounds__(256) psc_fold_evals_kernel(const uint64_t *bas
         });
     }
     Fr e[4] = {Fr::zero(), Fr::zero(), Fr::zero(), Fr::zero()};
+    ChainAcc4 acc;
+    acc.init();
     size_t step = (size_t)gridDim.x * 256;
     for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < quarter; g += step) {
-        Fr v0, v1, v2, v3;
+        F29 w[4];
         if constexpr (Q > 0) {
             Fr l0 = Fr::zero(), l1 = Fr::zero();
             static_for<0, Q>([&](auto mc) {
@@ -259,11 +294,11 @@ __global__ void __launch_bounds__(256) psc_fold_evals_kernel(const uint64_t *bas
                 l0 = fe_add(l0, fr_mul29(lo, cp[m]));
                 l1 = fe_add(l1, fr_mul29(hi, cp[m]));
             });
-            Fr d = fe_sub(l1, l0);
-            v0 = l0;
-            v1 = l1;
-            v2 = fe_add(l1, d);
-            v3 = fe_add(v2, d);
+            Fr d = fe_sub(l1, l0), l2 = fe_add(l1, d);
+            w[0] = fr29_in(l0);
+            w[1] = fr29_in(l1);
+            w[2] = fr29_in(l2);
+            w[3] = fr29_in(fe_add(l2, d));
         }
         if constexpr (P > 0) {
         static_for<0, P>([&](auto jc) {
@@ -276,20 +311,18 @@ __global__ void __launch_bounds__(256) psc_fold_evals_kernel(const uint64_t *bas
             fe_store(o + 4, hi);
             Fr d = fe_sub(hi, lo), f2 = fe_add(hi, d), f3 = fe_add(f2, d);
             if (Q == 0 && j == 0) {
-                v0 = lo; v1 = hi; v2 = f2; v3 = f3;
+                w[0] = fr29_in(lo); w[1] = fr29_in(hi); w[2] = fr29_in(f2); w[3] = fr29_in(f3);
             } else {
-                v0 = fr_mul29v(v0, lo);
-                v1 = fr_mul29v(v1, hi);
-                v2 = fr_mul29v(v2, f2);
-                v3 = fr_mul29v(v3, f3);
+                w[0] = fr29_chain_mul(w[0], fr29_in_shift(lo));
+                w[1] = fr29_chain_mul(w[1], fr29_in_shift(hi));
+                w[2] = fr29_chain_mul(w[2], fr29_in_shift(f2));
+                w[3] = fr29_chain_mul(w[3], fr29_in_shift(f3));
             }
         });
         }
-        e[0] = fe_add(e[0], v0);
-        e[1] = fe_add(e[1], v1);
-        e[2] = fe_add(e[2], v2);
-        e[3] = fe_add(e[3], v3);
+        acc.add(w, e);
     }
+    acc.flush(e);
     block_sum_pair(e[0], e[1], sh);
     __syncthreads();
     block_sum_pair(e[2], e[3], sh);
