@@ -392,33 +392,35 @@ __global__ void __launch_bounds__(256) sc_tail_run_kernel(const uint64_t *t, uin
 }
 
 // R1CSInputEvaluator.computeClaimedInputs (src/zkvm/r1cs/evaluation.zig:55-122): out[i] = sum_t eq[t] * rows[t][i] for the k columns of a
-// cycle-major matrix (k field elements per cycle, the layout of R1CSCycleInputs.values). One wave per cycle: lane i multiplies column i by
-// the cycle's eq value, four waves of a block take consecutive cycles; partials[block][column].
+// cycle-major matrix (k field elements per cycle, the layout of R1CSCycleInputs.values). The matrix is read as ONE flat stream of
+// n_rows * k elements with every lane busy: the grid has a multiple of k threads, so thread g always meets column g mod k and its
+// cycle advances by (threads / k) per iteration — no division in the loop, coalesced 32-byte loads, one general product per element
+// (the eq value of an element's cycle is a second, mostly shared, 32-byte load). partials[thread] = that thread's column sum.
 constexpr unsigned ROWS_MLE_MAX_K = 64;
 __global__ void __launch_bounds__(256) rows_mle_kernel(const uint64_t *rows, size_t n_rows, uint32_t k, const uint64_t *eq, uint64_t *partials) {
-    __shared__ uint4 sh[4 * ROWS_MLE_MAX_K * 2];
-    const uint32_t col = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x, threads = (size_t)gridDim.x * 256;
+    const size_t t_step = threads / k;  // threads is a multiple of k
     Fr acc = Fr::zero();
-    size_t step = (size_t)gridDim.x * 4;
-    for (size_t t = (size_t)blockIdx.x * 4 + w; t < n_rows; t += step) {
-        // the cycle's eq value is the second operand of the variable-by-variable product: its 5-bit limb shift (~40 instructions) is
-        // cheaper per cycle than a prescale by five doublings (~150), and the product is the same value
-        Fr ev = fe_load<FrParams>(eq + 4 * t);  // uniform across the wave
-        if (col < k) acc = fe_add(acc, fr_mul29v(fe_load<FrParams>(rows + 4 * (t * k + col)), ev));
+    Acc29 lazy = acc29_zero();  // products summed limb-wise in 64-bit words, reduced every FR29_ACC_MAX terms (fp29.hip.h)
+    unsigned cnt = 0;
+    size_t e = g;
+    for (size_t t = g / k; t < n_rows; t += t_step, e += threads) {
+        acc29_add(lazy, fr29_chain_mul(fr29_in(fe_load<FrParams>(rows + 4 * e)), fr29_in_shift(fe_load<FrParams>(eq + 4 * t))));
+        if (++cnt == FR29_ACC_MAX) {
+            acc = fe_add(acc, acc29_reduce(lazy));
+            lazy = acc29_zero();
+            cnt = 0;
+        }
     }
-    if (col < k) fe_store(&sh[(w * ROWS_MLE_MAX_K + col) * 2], acc);
-    __syncthreads();
-    if (w == 0 && col < k) {
-        for (uint32_t x = 1; x < 4; x++) acc = fe_add(acc, fe_load<FrParams>(&sh[(x * ROWS_MLE_MAX_K + col) * 2]));
-        fe_store(partials + 4 * ((size_t)blockIdx.x * k + col), acc);
-    }
+    if (cnt) acc = fe_add(acc, acc29_reduce(lazy));
+    fe_store(partials + 4 * g, acc);
 }
 
-// out[column] = sum over the blocks' partials; one block per column
-__global__ void __launch_bounds__(256) rows_mle_finish_kernel(const uint64_t *partials, uint32_t nblocks, uint32_t k, uint64_t *out) {
+// out[column] = sum of the partials of the threads g with g mod k == column; one block per column
+__global__ void __launch_bounds__(256) rows_mle_finish_kernel(const uint64_t *partials, size_t threads, uint32_t k, uint64_t *out) {
     __shared__ uint4 sh[256 * 4];
     Fr g0 = Fr::zero(), g1 = Fr::zero();
-    for (uint32_t b = threadIdx.x; b < nblocks; b += 256) g0 = fe_add(g0, fe_load<FrParams>(partials + 4 * ((size_t)b * k + blockIdx.x)));
+    for (size_t g = blockIdx.x + (size_t)threadIdx.x * k; g < threads; g += (size_t)256 * k) g0 = fe_add(g0, fe_load<FrParams>(partials + 4 * g));
     block_sum_pair(g0, g1, sh);
     if (threadIdx.x == 0) fe_store(out + 4 * (size_t)blockIdx.x, g0);
 }
@@ -960,15 +962,20 @@ int zg_fr_rows_mle_dev(const uint64_t *d_rows, size_t n_rows, size_t k, const ui
     const size_t full = (size_t)1 << v;
     if (n_rows > full) n_rows = full;  // rows past the hypercube have no eq value
     hipStream_t st = pick_stream(stream);
-    unsigned nb = (unsigned)((n_rows + 3) / 4);
-    if (nb < 1) nb = 1;
-    if (nb > 1024) nb = 1024;
-    Scratch s_eq(full * 32), s_part((size_t)nb * k * 32), s_out(k * 32);
+    // blocks: a multiple of k / gcd(k, 256) so that the thread count is a multiple of k; enough threads for one element each, at most ~1024 blocks
+    unsigned unit = (unsigned)k;
+    for (unsigned d = 2; d <= 256 && unit % 2 == 0; d *= 2) unit /= 2;  // k / gcd(k, 256)
+    size_t want = (n_rows * k + 255) / 256;
+    if (want > 1024) want = 1024;
+    unsigned nb = (unsigned)((want + unit - 1) / unit) * unit;
+    if (nb < unit) nb = unit;
+    const size_t threads = (size_t)nb * 256;
+    Scratch s_eq(full * 32), s_part(threads * 32), s_out(k * 32);
     if (!s_eq.p || !s_part.p || !s_out.p) return ZG_ERR_NOMEM;
     SyncGuard sync(st);
     ZG_TRY(eq_table_enqueue(r_host, v, nullptr, s_eq.as<uint64_t>(), st));
     hipLaunchKernelGGL(rows_mle_kernel, dim3(nb), dim3(256), 0, st, d_rows, n_rows, (uint32_t)k, s_eq.as<uint64_t>(), s_part.as<uint64_t>());
-    hipLaunchKernelGGL(rows_mle_finish_kernel, dim3((unsigned)k), dim3(256), 0, st, s_part.as<uint64_t>(), nb, (uint32_t)k, s_out.as<uint64_t>());
+    hipLaunchKernelGGL(rows_mle_finish_kernel, dim3((unsigned)k), dim3(256), 0, st, s_part.as<uint64_t>(), threads, (uint32_t)k, s_out.as<uint64_t>());
     ZG_HIP(hipGetLastError());
     ZG_HIP(hipMemcpyAsync(out, s_out.p, k * 32, hipMemcpyDeviceToHost, st));
     ZG_HIP(hipStreamSynchronize(st));
