@@ -211,22 +211,36 @@ __global__ void __launch_bounds__(256) psc_gruen_kernel(const uint64_t *base, si
                                                         uint32_t *counter, uint64_t *flag, uint64_t seq) {
     __shared__ uint4 sh[256 * 4];
     Fr e[2] = {Fr::zero(), Fr::zero()};
+    Acc29 a0 = acc29_zero(), a1 = acc29_zero();
+    unsigned cnt = 0;
     size_t step = (size_t)gridDim.x * 256;
     const size_t mask = ((size_t)1 << in_bits) - 1;
     for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < half; g += step) {
         size_t x_out = g >> in_bits;
         if (x_out >= n_out) continue;  // the reference's loops only reach g = (x_out << bits) | x_in with x_out < |E_out|
-        Fr w = fr_mul29v(fe_load<FrParams>(e_out + 4 * x_out), fe_load<FrParams>(e_in + 4 * (g & mask)));
-        Fr t0 = w, ti = w;
+        // weight and both products as one lazy chain each (fp29.hip.h): w = E_out * E_in, then the P table factors
+        F29 w = fr29_chain_mul(fr29_in(fe_load<FrParams>(e_out + 4 * x_out)), fr29_in_shift(fe_load<FrParams>(e_in + 4 * (g & mask))));
+        F29 t0 = w, ti = w;
 #pragma unroll
         for (int j = 0; j < P; j++) {
             const uint64_t *t = base + 4 * ((size_t)spec.prod[j] * stride + 2 * g);
             Fr lo = fe_load<FrParams>(t), hi = fe_load<FrParams>(t + 4);
-            t0 = fr_mul29v(t0, lo);
-            ti = fr_mul29v(ti, fe_sub(hi, lo));
+            t0 = fr29_chain_mul(t0, fr29_in_shift(lo));
+            ti = fr29_chain_mul(ti, fr29_in_shift(fe_sub(hi, lo)));
         }
-        e[0] = fe_add(e[0], t0);
-        e[1] = fe_add(e[1], ti);
+        acc29_add(a0, t0);
+        acc29_add(a1, ti);
+        if (++cnt == FR29_ACC_MAX) {
+            e[0] = fe_add(e[0], acc29_reduce(a0));
+            e[1] = fe_add(e[1], acc29_reduce(a1));
+            a0 = acc29_zero();
+            a1 = acc29_zero();
+            cnt = 0;
+        }
+    }
+    if (cnt) {
+        e[0] = fe_add(e[0], acc29_reduce(a0));
+        e[1] = fe_add(e[1], acc29_reduce(a1));
     }
     block_sum_pair(e[0], e[1], sh);
     psc_finish<1>(e, sh, partials, sums, counter, flag, seq);
@@ -356,11 +370,17 @@ __global__ void __launch_bounds__(256) psc_expr_kernel(const uint64_t *base, siz
         rp = fr29_prescale(rv);
     }
     Fr e[4] = {Fr::zero(), Fr::zero(), Fr::zero(), Fr::zero()};
+    ChainAcc4 acc;
+    acc.init();
     size_t step = (size_t)gridDim.x * 256;
     for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < n_pairs; g += step) {
         for (uint32_t ti = 0; ti < ex.n_terms; ti++) {
             const PscExprTerm &tm = ex.t[ti];
-            Fr v0 = Fr::zero(), v1 = Fr::zero(), v2 = Fr::zero(), v3 = Fr::zero();
+            F29 w[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int i = 0; i < 9; i++) w[t].l[i] = 0;
             bool have = false;
             auto pair_of = [&](uint32_t table, Fr &lo, Fr &hi) {
                 if (FOLD) {
@@ -387,11 +407,11 @@ __global__ void __launch_bounds__(256) psc_expr_kernel(const uint64_t *base, siz
                     l0 = fe_add(l0, fr_mul29v(lo, c));
                     l1 = fe_add(l1, fr_mul29v(hi, c));
                 }
-                Fr d = fe_sub(l1, l0);
-                v0 = l0;
-                v1 = l1;
-                v2 = fe_add(l1, d);
-                v3 = fe_add(v2, d);
+                Fr d = fe_sub(l1, l0), l2 = fe_add(l1, d);
+                w[0] = fr29_in(l0);
+                w[1] = fr29_in(l1);
+                w[2] = fr29_in(l2);
+                w[3] = fr29_in(fe_add(l2, d));
                 have = true;
             }
             for (uint32_t j = 0; j < tm.np; j++) {
@@ -399,21 +419,19 @@ __global__ void __launch_bounds__(256) psc_expr_kernel(const uint64_t *base, siz
                 pair_of(tm.prod[j], lo, hi);
                 Fr d = fe_sub(hi, lo), f2 = fe_add(hi, d), f3 = fe_add(f2, d);
                 if (!have) {
-                    v0 = lo; v1 = hi; v2 = f2; v3 = f3;
+                    w[0] = fr29_in(lo); w[1] = fr29_in(hi); w[2] = fr29_in(f2); w[3] = fr29_in(f3);
                     have = true;
-                } else {
-                    v0 = fr_mul29v(v0, lo);
-                    v1 = fr_mul29v(v1, hi);
-                    v2 = fr_mul29v(v2, f2);
-                    v3 = fr_mul29v(v3, f3);
+                } else {  // the running products stay lazy 29-bit-limb values (fp29.hip.h: fr29_chain_mul)
+                    w[0] = fr29_chain_mul(w[0], fr29_in_shift(lo));
+                    w[1] = fr29_chain_mul(w[1], fr29_in_shift(hi));
+                    w[2] = fr29_chain_mul(w[2], fr29_in_shift(f2));
+                    w[3] = fr29_chain_mul(w[3], fr29_in_shift(f3));
                 }
             }
-            e[0] = fe_add(e[0], v0);
-            e[1] = fe_add(e[1], v1);
-            e[2] = fe_add(e[2], v2);
-            e[3] = fe_add(e[3], v3);
+            acc.add(w, e);
         }
     }
+    acc.flush(e);
     block_sum_pair(e[0], e[1], sh);
     __syncthreads();
     block_sum_pair(e[2], e[3], sh);
