@@ -208,6 +208,12 @@ ZG_API int zg_hyperkzg_batch_open(zg_bases_t srs, const uint64_t *const *polys, 
  * (src/poly/split_eq.zig:122-171). */
 ZG_API int zg_fr_eq_table(const uint64_t *r, size_t v, const uint64_t *scale, uint64_t *out);
 ZG_API int zg_fr_eq_table_dev(const uint64_t *r_host, size_t v, const uint64_t *scale_host, uint64_t *d_out, void *stream);
+/* The eq+1 evaluation table of EqPlusOnePrefixSuffixPoly (src/poly/mod.zig:462-560, computeEqPlusOneEvals :530-548; the same helper in
+ * src/zkvm/spartan/stage3_prover.zig:1878-1894): out[j] = EqPlusOnePolynomial.mle(r, bits(j)), r[0] <-> MSB, 2^v entries. Over the
+ * boolean cube eq+1(r, j) = eq(r, j - 1) and out[0] = 0, so this is the eq table moved up by one entry (the reference evaluates the
+ * general formula, v^2 products per entry). */
+ZG_API int zg_fr_eq_plus_one_table(const uint64_t *r, size_t v, uint64_t *out);
+ZG_API int zg_fr_eq_plus_one_table_dev(const uint64_t *r_host, size_t v, uint64_t *d_out, void *stream);
 /* GruenSplitEqPolynomial.initWithScaling's prefix-table set in one launch (src/poly/split_eq.zig:122-171: E_out_vec / E_in_vec,
  * "append the new variable as LSB" and KEEP every level): out holds the v+1 tables eq(tau[0..k), .), k = 0..v, back to back —
  * table k has 2^k entries and starts at element 2^k - 1 (so out has 2^(v+1) - 1 elements; table 0 is [1]); within a table

@@ -860,3 +860,19 @@ def registers_cr_round(phase2, tabs, gamma, previous_claim):
     out = np.empty((3, 4), dtype=np.uint64)
     lib.zo_registers_cr_round(C.c_int(1 if phase2 else 0), ptrs, C.c_size_t(arrs[0].shape[0]), _p(_c(gamma)), _p(_c(previous_claim)), _p(out))
     return out
+
+
+def eq_plus_one_mle(x, y):
+    """EqPlusOnePolynomial.mle (src/poly/mod.zig:407-435)"""
+    x, y = _c(np.asarray(x, dtype=np.uint64).reshape(-1, 4)), _c(np.asarray(y, dtype=np.uint64).reshape(-1, 4))
+    out = np.empty(4, dtype=np.uint64)
+    lib.zo_eq_plus_one_mle(_p(x), _p(y), C.c_size_t(x.shape[0]), _p(out))
+    return out
+
+
+def eq_plus_one_table(r):
+    """computeEqPlusOneEvals (src/poly/mod.zig:530-548): the general formula at every cube point, as the reference does it"""
+    r = _c(np.asarray(r, dtype=np.uint64).reshape(-1, 4))
+    out = np.empty((1 << r.shape[0], 4), dtype=np.uint64)
+    lib.zo_eq_plus_one_table(_p(r), C.c_size_t(r.shape[0]), _p(out))
+    return out

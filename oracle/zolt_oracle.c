@@ -1470,3 +1470,39 @@ EXPORT void zo_registers_cr_round(int phase2, const uint64_t *const *tabs, size_
     fe out[3] = {e0, p1, e2};
     memcpy(evals, out, 96);
 }
+
+/* EqPlusOnePolynomial.mle — src/poly/mod.zig:407-435 (x, y big-endian: index 0 is the MSB) */
+EXPORT void zo_eq_plus_one_mle(const uint64_t *x, const uint64_t *y, size_t l, uint64_t out[4]) {
+    const fe *X = (const fe *)x, *Y = (const fe *)y;
+    fe one = f_one(&FR), result = f_zero();
+    for (size_t k = 0; k < l; k++) {
+        fe lower = one;
+        for (size_t i = 0; i < k; i++) {
+            size_t idx = l - 1 - i;
+            fe omy = f_sub(&FR, &one, &Y[idx]), t = f_mul(&FR, &X[idx], &omy);
+            lower = f_mul(&FR, &lower, &t);
+        }
+        size_t kth_idx = l - 1 - k;
+        fe omx = f_sub(&FR, &one, &X[kth_idx]), kth = f_mul(&FR, &omx, &Y[kth_idx]);
+        fe higher = one;
+        for (size_t i = k + 1; i < l; i++) {
+            size_t idx = l - 1 - i;
+            fe xy = f_mul(&FR, &X[idx], &Y[idx]), a = f_sub(&FR, &one, &X[idx]), b = f_sub(&FR, &one, &Y[idx]), ab = f_mul(&FR, &a, &b);
+            fe s = f_add(&FR, &xy, &ab);
+            higher = f_mul(&FR, &higher, &s);
+        }
+        fe t = f_mul(&FR, &lower, &kth); t = f_mul(&FR, &t, &higher);
+        result = f_add(&FR, &result, &t);
+    }
+    memcpy(out, &result, 32);
+}
+/* computeEqPlusOneEvals — src/poly/mod.zig:530-548: out[j] = mle(r, bits of j as field elements, MSB first), the reference's way */
+EXPORT void zo_eq_plus_one_table(const uint64_t *r, size_t n, uint64_t *out) {
+    size_t size = (size_t)1 << n;
+    fe *bits = (fe *)malloc((n ? n : 1) * sizeof(fe));
+    for (size_t j = 0; j < size; j++) {
+        for (size_t k = 0; k < n; k++) bits[k] = ((j >> (n - 1 - k)) & 1) ? f_one(&FR) : f_zero();
+        zo_eq_plus_one_mle(r, (const uint64_t *)bits, n, out + 4 * j);
+    }
+    free(bits);
+}

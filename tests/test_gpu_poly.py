@@ -180,6 +180,28 @@ def test_rows_mle_direct(zl, ob):
         zl.fr_rows_mle(_rand(ob, 1313, 65 * 2).reshape(2, 65, 4), r[:1])
 
 
+@pytest.mark.parametrize("v", [0, 1, 2, 5, 9, 11])
+def test_eq_plus_one_table_vs_oracle(zl, ob, v):
+    """zg_fr_eq_plus_one_table[_dev] against the oracle evaluating EqPlusOnePolynomial.mle at every cube point (src/poly/mod.zig:407-435,
+    530-548); EqPlusOnePrefixSuffixPoly's four tables (:462-528)"""
+    from zolt_amd import api
+    r = _rand(ob, 1400 + v, v)
+    want = ob.eq_plus_one_table(r)
+    assert np.array_equal(zl.fr_eq_plus_one_table(r), want)
+    assert np.array_equal(api.EqPlusOnePolynomial(r).evals(), want)
+    buf = zl.DeviceBuffer((1 << v) * 32)
+    zl.fr_eq_plus_one_table_dev(r, buf.ptr)
+    assert np.array_equal(buf.to_host().reshape(-1, 4), want)
+    buf.free()
+    if v >= 2:
+        ps = api.EqPlusOnePrefixSuffixPoly(r)
+        mid = v // 2
+        assert np.array_equal(ps.prefix_0, ob.eq_plus_one_table(r[mid:])) and np.array_equal(ps.suffix_0, ob.fr_eq_table(r[:mid]))
+        assert np.array_equal(ps.suffix_1, ob.eq_plus_one_table(r[:mid])) and ps.prefixSize() == 1 << (v - mid) and ps.suffixSize() == 1 << mid
+        ones = np.tile(ob.f_from_u64(ob.FR, np.array([1], dtype=np.uint64)), (v - mid, 1))
+        assert np.array_equal(ps.prefix_1[0], ob.fr_eq_mle(ones, r[mid:])) and not ps.prefix_1[1:].any()
+
+
 def test_bind_kats_and_golden(zl, ob):
     """src/poly/mod.zig:816-888 and tests/golden folds."""
     got = zl.fr_bind_low(U.fr([1, 2, 3, 4]), U.fr([3])[0])

@@ -515,3 +515,25 @@ def test_product_form_prover_oracles_are_sound_sumchecks():
         p.bindChallenge(ch)
         p.updateClaim(ev, ch)
     assert to_int(p.getFinalClaim()) * to_int(p.split_eq.current_scalar) % P == to_int(p.current_claim)
+
+
+def test_eq_plus_one_reference_inline_test_and_shift_identity():
+    """src/poly/mod.zig:890-943 "EqPlusOnePolynomial basic" restated against the oracle's mle AND the host mirror's; then the fact the
+    device table rests on: over the cube eq+1(r, j) = eq(r, j - 1), eq+1(r, 0) = 0 — checked with the oracle evaluating the general
+    formula at every cube point, the way computeEqPlusOneEvals does (:530-548)."""
+    from zolt_amd import api
+    F = lambda v: ob.f_from_u64(FR, np.array([v], dtype=np.uint64))[0]
+    zero, one = F(0), F(1)
+    cases = [((zero, zero), (zero, one), one), ((zero, one), (one, zero), one), ((one, zero), (one, one), one),
+             ((one, one), (zero, zero), zero), ((zero, zero), (one, zero), zero)]
+    for x, y, want in cases:
+        assert np.array_equal(ob.eq_plus_one_mle(np.stack(x), np.stack(y)), want)
+        assert np.array_equal(api.EqPlusOnePolynomial.mle(np.stack(x), np.stack(y)), want)
+    rng = np.random.default_rng(17)
+    for v in range(0, 8):
+        r = ob.f_to_mont(FR, rng.integers(0, 1 << 62, size=(v, 4), dtype=np.uint64))
+        t, eq = ob.eq_plus_one_table(r), ob.fr_eq_table(r)
+        assert not t[0].any() and np.array_equal(t[1:], eq[:-1]), v
+        if v:
+            y = ob.f_to_mont(FR, rng.integers(0, 1 << 62, size=(v, 4), dtype=np.uint64))  # a non-boolean point: the two mle restatements agree
+            assert np.array_equal(ob.eq_plus_one_mle(r, y), api.EqPlusOnePolynomial(r).evaluate(y))

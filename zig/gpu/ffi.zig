@@ -71,6 +71,8 @@ pub extern fn zg_hyperkzg_open_dev(srs: Bases, d_evals: ?[*]const u64, n_evals: 
 pub extern fn zg_hyperkzg_batch_open(srs: Bases, polys: ?[*]const ?[*]const u64, lens: ?[*]const usize, k: usize, point: ?[*]const u64, num_vars: usize, q_xy: ?[*]u64, q_inf: ?[*]u8, n_quot: ?*usize, evaluations: ?[*]u64, final_eval: *[4]u64, gamma: *[4]u64) c_int;
 pub extern fn zg_fr_eq_table(r: ?[*]const u64, v: usize, scale: ?[*]const u64, out: ?[*]u64) c_int;
 pub extern fn zg_fr_eq_table_dev(r_host: ?[*]const u64, v: usize, scale_host: ?[*]const u64, d_out: ?[*]u64, stream: ?*anyopaque) c_int;
+pub extern fn zg_fr_eq_plus_one_table(r: ?[*]const u64, v: usize, out: ?[*]u64) c_int;
+pub extern fn zg_fr_eq_plus_one_table_dev(r_host: ?[*]const u64, v: usize, d_out: ?[*]u64, stream: ?*anyopaque) c_int;
 pub extern fn zg_fr_eq_prefix_tables(tau: ?[*]const u64, v: usize, out: ?[*]u64) c_int;
 pub extern fn zg_fr_eq_prefix_tables_dev(tau_host: ?[*]const u64, v: usize, d_out: ?[*]u64, stream: ?*anyopaque) c_int;
 pub extern fn zg_fr_dense_evaluate(evals: ?[*]const u64, num_vars: usize, point: ?[*]const u64, out: *[4]u64) c_int;

@@ -477,6 +477,67 @@ class EqPolynomial:
         return lib.fr_eq_table(np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4), scaling_factor)
 
 
+class EqPlusOnePolynomial:
+    """EqPlusOnePolynomial(F) (src/poly/mod.zig:332-446): eq+1(x, y) = 1 iff y = x + 1 on the cube (x[0] is the MSB). evaluate / mle are
+    the reference's host scalar formula; the table over the cube comes from the device."""
+
+    def __init__(self, x):
+        self.x = np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, 4).copy()
+
+    def evaluate(self, y):
+        return EqPlusOnePolynomial.mle(self.x, y)
+
+    @staticmethod
+    def mle(x, y):
+        """:407-435: sum over the flip position k of prod_{i<k} x_i (1 - y_i) * (1 - x_k) y_k * prod_{i>k} eq(x_i, y_i), bits counted from the LSB"""
+        xs = [fr_to_int(v) for v in np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, 4)]
+        ys = [fr_to_int(v) for v in np.ascontiguousarray(y, dtype=np.uint64).reshape(-1, 4)]
+        l = len(xs)
+        assert len(ys) == l
+        result = 0
+        for k in range(l):
+            lower = 1
+            for i in range(k):
+                idx = l - 1 - i
+                lower = lower * (xs[idx] * (1 - ys[idx]) % R_MOD) % R_MOD
+            kth = (1 - xs[l - 1 - k]) * ys[l - 1 - k] % R_MOD
+            higher = 1
+            for i in range(k + 1, l):
+                idx = l - 1 - i
+                higher = higher * ((xs[idx] * ys[idx] + (1 - xs[idx]) * (1 - ys[idx])) % R_MOD) % R_MOD
+            result = (result + lower * kth % R_MOD * higher) % R_MOD
+        return fr_from_int(result)
+
+    def evals(self):
+        """the table over the cube (computeEqPlusOneEvals, :530-548)"""
+        return lib.fr_eq_plus_one_table(self.x)
+
+
+class EqPlusOnePrefixSuffixPoly:
+    """EqPlusOnePrefixSuffixPoly(F).init (src/poly/mod.zig:462-528): r = (r_hi || r_lo) split at len / 2; prefix_0 = eq+1(r_lo, .),
+    suffix_0 = eq(r_hi, .), prefix_1 = is_max(r_lo) at index 0, suffix_1 = eq+1(r_hi, .) — three table builds on the device."""
+
+    def __init__(self, r):
+        r = np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4)
+        assert r.shape[0] >= 2
+        mid = r.shape[0] // 2
+        r_hi, r_lo = r[:mid], r[mid:]
+        self.prefix_0 = lib.fr_eq_plus_one_table(r_lo)
+        self.suffix_0 = lib.fr_eq_table(r_hi)
+        self.suffix_1 = lib.fr_eq_plus_one_table(r_hi)
+        is_max = 1
+        for v in r_lo:
+            is_max = is_max * fr_to_int(v) % R_MOD
+        self.prefix_1 = np.zeros_like(self.prefix_0)
+        self.prefix_1[0] = fr_from_int(is_max)
+
+    def prefixSize(self):
+        return self.prefix_0.shape[0]
+
+    def suffixSize(self):
+        return self.suffix_0.shape[0]
+
+
 class GruenSplitEqPolynomial:
     """GruenSplitEqPolynomial (src/poly/split_eq.zig:22-514). The prefix-table set is built on the device in one launch per
     half (zg_fr_eq_prefix_tables); bind / computeCubicRoundPoly are the reference's host scalar algebra; getFullEqTable and

@@ -854,6 +854,50 @@ int zg_fr_eq_table(const uint64_t *r, size_t v, const uint64_t *scale, uint64_t 
     return rc;
 }
 
+// eq+1(r, j) = 1 iff j = x + 1: over the boolean cube the only non-zero term of EqPlusOnePolynomial.mle's sum (src/poly/mod.zig:407-435)
+// is the one whose flip position is the number of trailing zeros of j, and its factors are exactly those of eq(r, j - 1) (the low
+// bits 10..0 of j against 01..1 of j - 1) — the table is the eq table moved up by one entry, with a zero in front.
+static int eq_plus_one_enqueue(const uint64_t *r_host, size_t v, uint64_t *d_out, hipStream_t st) {
+    size_t n = (size_t)1 << v;
+    Scratch s_eq(n * 32);
+    if (!s_eq.p) return ZG_ERR_NOMEM;
+    SyncGuard sync(st);
+    ZG_TRY(eq_table_enqueue(r_host, v, nullptr, s_eq.as<uint64_t>(), st));
+    ZG_HIP(hipMemsetAsync(d_out, 0, 32, st));
+    if (n > 1) ZG_HIP(hipMemcpyAsync(d_out + 4, s_eq.p, (n - 1) * 32, hipMemcpyDeviceToDevice, st));
+    ZG_HIP(hipStreamSynchronize(st));
+    return ZG_OK;
+}
+
+int zg_fr_eq_plus_one_table_dev(const uint64_t *r_host, size_t v, uint64_t *d_out, void *stream) {
+    ZG_INIT();
+    if (!d_out || (v && !r_host) || v > 30) {
+        set_error("zg_fr_eq_plus_one_table_dev: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    return eq_plus_one_enqueue(r_host, v, d_out, pick_stream(stream));
+}
+
+int zg_fr_eq_plus_one_table(const uint64_t *r, size_t v, uint64_t *out) {
+    ZG_INIT();
+    if (!out || (v && !r) || v > 30) {
+        set_error("zg_fr_eq_plus_one_table: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    size_t bytes = ((size_t)1 << v) * 32;
+    Scratch s_out(bytes);
+    if (!s_out.p) return ZG_ERR_NOMEM;
+    int rc = eq_plus_one_enqueue(r, v, s_out.as<uint64_t>(), lib_stream());
+    if (rc == ZG_OK) {
+        hipError_t e = hipMemcpy(out, s_out.p, bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            set_error(hipGetErrorString(e));
+            rc = ZG_ERR_HIP;
+        }
+    }
+    return rc;
+}
+
 int zg_fr_eq_prefix_tables_dev(const uint64_t *tau_host, size_t v, uint64_t *d_out, void *stream) {
     ZG_INIT();
     if (!d_out || (v && !tau_host)) {

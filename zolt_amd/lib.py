@@ -36,7 +36,7 @@ SYMBOLS = [
     "zg_msm_g1", "zg_msm_g1_dev", "zg_msm_g1_dev_async", "zg_msm_g1_batch", "zg_msm_g1_batch_dev", "zg_msm_g1_partial_dev", "zg_msm_g1_partial_fast_dev",
     "zg_g1_combine_partials_dev", "zg_g1_combine_partials_dev_async", "zg_g1_is_on_curve_batch", "zg_g1_scalar_mul_batch", "zg_g1_fixed_base_mul_batch",
     "zg_hyperkzg_open", "zg_hyperkzg_open_dev", "zg_hyperkzg_batch_open",
-    "zg_fr_dense_evaluate", "zg_fr_eq_table", "zg_fr_eq_table_dev", "zg_fr_eq_prefix_tables", "zg_fr_eq_prefix_tables_dev", "zg_fr_rows_mle", "zg_fr_rows_mle_dev", "zg_fr_bind_low", "zg_fr_bind_high",
+    "zg_fr_dense_evaluate", "zg_fr_eq_table", "zg_fr_eq_table_dev", "zg_fr_eq_prefix_tables", "zg_fr_eq_prefix_tables_dev", "zg_fr_rows_mle", "zg_fr_rows_mle_dev", "zg_fr_eq_plus_one_table", "zg_fr_eq_plus_one_table_dev", "zg_fr_bind_low", "zg_fr_bind_high",
     "zg_fr_spartan_combine", "zg_fr_spartan_combine_dev",
     "zg_sumcheck_open", "zg_sumcheck_open_dev", "zg_sumcheck_round_sums", "zg_sumcheck_bind",
     "zg_sumcheck_len", "zg_sumcheck_final", "zg_sumcheck_read", "zg_sumcheck_close",
@@ -467,6 +467,19 @@ def fr_eq_table(r, scale=None):
 def fr_eq_table_dev(r, d_out, scale=None, stream=0):
     r = _c(r)
     _chk(_lib.zg_fr_eq_table_dev(_h(r), C.c_size_t(r.size // 4), _h(_c(scale)), _d(d_out), _d(stream)), "zg_fr_eq_table_dev")
+
+
+def fr_eq_plus_one_table(r):
+    """out[j] = EqPlusOnePolynomial.mle(r, bits(j)) (zg_fr_eq_plus_one_table)"""
+    r = _c(np.asarray(r, dtype=np.uint64).reshape(-1, 4))
+    out = np.empty((1 << r.shape[0], 4), dtype=np.uint64)
+    _chk(_lib.zg_fr_eq_plus_one_table(_h(r), C.c_size_t(r.shape[0]), _h(out)), "zg_fr_eq_plus_one_table")
+    return out
+
+
+def fr_eq_plus_one_table_dev(r, d_out, stream=0):
+    r = _c(np.asarray(r, dtype=np.uint64).reshape(-1, 4))
+    _chk(_lib.zg_fr_eq_plus_one_table_dev(_h(r), C.c_size_t(r.shape[0]), _d(d_out), _d(stream)), "zg_fr_eq_plus_one_table_dev")
 
 
 def fr_eq_prefix_tables(tau):
