@@ -459,6 +459,55 @@ TEST(batched_sumcheck_stage2_shape) {
     EXPECT(pv.getFinalClaim().mul(pv.split_eq.current_scalar).eql(pv.current_claim));
 }
 
+// InstructionInputProver (src/zkvm/spartan/stage3_prover.zig:2029-2150) as a sumcheck, computeClaimedInputs (src/zkvm/r1cs/evaluation.zig:55-122)
+// against the eq-table definition, and the eq+1 table (src/poly/mod.zig:530-548) as the eq table moved up one entry
+TEST(stage3_and_opening_claim_sites) {
+    const size_t v = 6, n = size_t(1) << v;
+    auto mk = [&](uint64_t seed, size_t len) {
+        std::vector<Fr> t(len);
+        uint64_t x = seed;
+        for (auto &e : t) {
+            x = x * 6364136223846793005ULL + 1442695040888963407ULL;
+            e = Fr::fromU64(x >> 9).mul(Fr::fromU64(x | 1));
+        }
+        return t;
+    };
+    std::vector<std::vector<Fr>> T;
+    for (int j = 0; j < 10; j++) T.push_back(mk(100 + j, n));
+    Fr gamma = Fr::fromU64(12345), g2 = gamma.mul(gamma);
+    Fr claim = Fr::zero();
+    for (size_t i = 0; i < n; i++) {
+        Fr left = T[0][i].mul(T[1][i]).add(T[2][i].mul(T[3][i])), right = T[4][i].mul(T[5][i]).add(T[6][i].mul(T[7][i]));
+        claim = claim.add(T[8][i].add(g2.mul(T[9][i])).mul(right.add(gamma.mul(left))));
+    }
+    std::vector<const std::vector<Fr> *> ptrs;
+    for (auto &t : T) ptrs.push_back(&t);
+    InstructionInputProver p(ptrs, gamma);
+    for (size_t r = 0; r < v; r++) {
+        auto ev = p.computeRoundEvals(claim);  // p(1) is derived, so check the cubic through p(0), p(2), p(3) against the next round instead
+        Fr ch = Fr::fromU64(900 + r).mul(T[0][r]);
+        claim = cubicAtPoint(ev, ch);
+        p.bind(ch);
+    }
+    auto f = p.finalClaims();
+    Fr left = f[0].mul(f[1]).add(f[2].mul(f[3])), right = f[4].mul(f[5]).add(f[6].mul(f[7]));
+    EXPECT(f[8].add(g2.mul(f[9])).mul(right.add(gamma.mul(left))).eql(claim));
+
+    const size_t k = 36, cycles = 64;
+    auto W = mk(7, cycles * k);
+    std::vector<Fr> rc = mk(8, 6);
+    auto eq = EqPolynomial(rc).evals();
+    auto got = computeClaimedInputs(W, k, rc);
+    for (size_t i : {size_t(0), size_t(17), k - 1}) {
+        Fr want = Fr::zero();
+        for (size_t t = 0; t < cycles; t++) want = want.add(eq[t].mul(W[t * k + i]));
+        EXPECT(got[i].eql(want));
+    }
+    auto e1 = eqPlusOneEvals(rc);
+    EXPECT(e1.size() == 64 && e1[0].isZero());
+    for (size_t j = 1; j < 64; j++) EXPECT(e1[j].eql(eq[j - 1]));
+}
+
 int main() {
     if (zg_init(0) != ZG_OK) { std::printf("zg_init failed: %s\n", zg_last_error()); return 2; }
     for (auto &t : tests()) {

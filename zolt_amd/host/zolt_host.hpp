@@ -965,6 +965,27 @@ public:
         check(zg_psc_round_gruen(s_, prod.data(), prod.size(), d_e_out, n_out, d_e_in, n_in, out[0].limbs, out[1].limbs), "zg_psc_round_gruen");
         return out;
     }
+    // a SUM of product terms in one pass (zg_psc_round_expr)
+    struct Term {
+        std::vector<int> prod, lin;
+        std::vector<Fr> coeff;
+    };
+    std::array<Fr, 4> roundExpr(const std::vector<Term> &terms) {
+        std::vector<zg_psc_term> t(terms.size());
+        for (size_t i = 0; i < terms.size(); i++) {
+            std::memset(&t[i], 0, sizeof(zg_psc_term));
+            t[i].n_prod = (int)terms[i].prod.size();
+            t[i].n_lin = (int)terms[i].lin.size();
+            for (size_t j = 0; j < terms[i].prod.size() && j < 4; j++) t[i].prod[j] = terms[i].prod[j];
+            for (size_t m = 0; m < terms[i].lin.size() && m < 4; m++) {
+                t[i].lin[m] = terms[i].lin[m];
+                std::memcpy(&t[i].lin_coeff[4 * m], terms[i].coeff[m].limbs, 32);
+            }
+        }
+        std::array<Fr, 4> out;
+        check(zg_psc_round_expr(s_, t.data(), t.size(), reinterpret_cast<uint64_t *>(out.data())), "zg_psc_round_expr");
+        return out;
+    }
     void bind(const Fr &r) { check(zg_psc_bind(s_, r.limbs), "zg_psc_bind"); }
     std::vector<Fr> final() {
         std::vector<Fr> out(zg_psc_tables(s_));
@@ -1055,6 +1076,53 @@ private:
     ProductSumcheckSession s_;
     void *d_out_ = nullptr, *d_in_ = nullptr;
 };
+
+// InstructionInputProver's loop (src/zkvm/spartan/stage3_prover.zig:2029-2150): tables left_is_rs1, rs1_value, left_is_pc, unexpanded_pc,
+// right_is_rs2, rs2_value, right_is_imm, imm, eq_outer, eq_product; f = (eq_outer + g^2 eq_product) * (is_rs2*rs2 + is_imm*imm +
+// g (is_rs1*rs1 + is_pc*pc)) as four product terms of one multi-term round
+class InstructionInputProver {
+public:
+    InstructionInputProver(const std::vector<const std::vector<Fr> *> &tables, const Fr &gamma) : s_(tables) {
+        Fr g2 = gamma.mul(gamma);
+        std::vector<Fr> w_right = {Fr::one(), g2}, w_left = {gamma, g2.mul(gamma)};
+        terms_ = {{{4, 5}, {8, 9}, w_right}, {{6, 7}, {8, 9}, w_right}, {{0, 1}, {8, 9}, w_left}, {{2, 3}, {8, 9}, w_left}};
+    }
+    std::array<Fr, 4> computeRoundEvals(const Fr &previous_claim) {  // [p(0), claim - p(0), p(2), p(3)] (:2029-2100)
+        auto ev = s_.roundExpr(terms_);
+        return {ev[0], previous_claim.sub(ev[0]), ev[2], ev[3]};
+    }
+    void bind(const Fr &r_j) { s_.bind(r_j); }
+    std::vector<Fr> finalClaims() { return s_.final(); }
+
+private:
+    ProductSumcheckSession s_;
+    std::vector<ProductSumcheckSession::Term> terms_;
+};
+
+// R1CSInputEvaluator.computeClaimedInputs (src/zkvm/r1cs/evaluation.zig:55-122): witness = cycle-major matrix, k values per cycle
+inline std::vector<Fr> computeClaimedInputs(const std::vector<Fr> &cycle_witnesses, size_t k, const std::vector<Fr> &r_cycle) {
+    size_t num_cycles = k ? cycle_witnesses.size() / k : 0;
+    std::vector<Fr> out(k, Fr::zero());
+    if (num_cycles == 0) return out;
+    size_t log_n = 0;
+    while ((size_t(2) << log_n) <= num_cycles) log_n++;
+    size_t padded_len = size_t(1) << log_n, effective_len = std::min(r_cycle.size(), log_n);
+    if (effective_len == 0) {  // :75-83
+        for (size_t i = 0; i < k; i++) out[i] = cycle_witnesses[i];
+        return out;
+    }
+    if (effective_len < log_n) throw std::out_of_range("computeClaimedInputs: r_cycle shorter than log2 of the cycle count");
+    check(zg_fr_rows_mle(reinterpret_cast<const uint64_t *>(cycle_witnesses.data()), std::min(num_cycles, padded_len), k,
+                         reinterpret_cast<const uint64_t *>(r_cycle.data()), effective_len, reinterpret_cast<uint64_t *>(out.data())), "zg_fr_rows_mle");
+    return out;
+}
+
+// computeEqPlusOneEvals (src/poly/mod.zig:530-548; src/zkvm/spartan/stage3_prover.zig:1878-1894): eq+1(r, j) over the cube
+inline std::vector<Fr> eqPlusOneEvals(const std::vector<Fr> &r) {
+    std::vector<Fr> out(size_t(1) << r.size());
+    check(zg_fr_eq_plus_one_table(reinterpret_cast<const uint64_t *>(r.data()), r.size(), reinterpret_cast<uint64_t *>(out.data())), "zg_fr_eq_plus_one_table");
+    return out;
+}
 
 // OutputSumcheckProver's loop (src/zkvm/ram/output_check.zig:375-499): eq * io_mask * (val_final - val_io); val_init folded alongside
 class OutputSumcheckProver {
