@@ -556,3 +556,35 @@ def test_registers_claim_reduction_rounds(env, v):
             fc = g.finalClaims()
             assert np.array_equal(fc["rd_write_value"], cur[1][0]) and np.array_equal(fc["rs2_value"], cur[3][0])
         g.deinit()
+
+
+def test_full_size_val_evaluation_and_instruction_input(env):
+    """BASELINE config 3's size (2^20 entries) on the product-form path: every round of a three-table ValEvaluation and five rounds of the
+    ten-table InstructionInput against the oracle (the per-thread lazy sums are flushed several times at this length), then the
+    protocol's own identity on the final values"""
+    api, lib, ob = env
+    v = 20
+    n = 1 << v
+    inc, wa, lt = _rand(ob, 9000, n, sparse=True), _rand(ob, 9001, n), _rand(ob, 9002, n)
+    claim = _rand(ob, 9003, 1)[0]
+    g, o = api.ValEvaluationProver(inc, wa, lt, claim), ob.ValEvaluationProver(inc, wa, lt, claim)
+    ch = _rand(ob, 9004, v)
+    for rnd in range(v):
+        rp, wrp = g.computeRoundPolynomial(), o.computeRoundPolynomial()
+        assert np.array_equal(rp, wrp), rnd
+        g.bindChallengeWithPoly(ch[rnd], rp)
+        o.bindChallengeWithPoly(ch[rnd], wrp)
+    assert all(np.array_equal(a, b) for a, b in zip(g.getFinalClaims(), o.getFinalClaims()))
+    g.deinit()
+    m = 1 << 18
+    tabs = [_rand(ob, 9010 + j, m, sparse=(j % 2 == 0)) for j in range(10)]
+    gamma = _rand(ob, 9030, 1)[0]
+    p = api.InstructionInputProver(tabs, gamma)
+    cur = tabs
+    for rnd in range(5):
+        want = ob.instruction_input_round(cur, gamma, claim)
+        assert np.array_equal(p.computeRoundEvals(claim), want), rnd
+        p.bind(ch[rnd])
+        cur = [ob.fr_bind_low(t, ch[rnd]) for t in cur]
+        claim = ob.raf_update_claim(want, ch[rnd])
+    p.deinit()

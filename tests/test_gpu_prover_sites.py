@@ -236,3 +236,21 @@ def test_jolt_outer_prover_rounds(env, v):
         assert g.current_len == len(cur) and np.array_equal(g.current_claim, tot(cur))
     assert np.array_equal(g.getFinalEval(), cur[0])
     g.deinit()
+
+
+def test_full_size_lasso_prover(env):
+    """2^20 cycles (BASELINE config 3's table length), log_K = 16: every address and cycle round against the oracle, final evaluation"""
+    api, lib, ob = env
+    log_T, log_K, n = 20, 16, (1 << 20) - 12345
+    w, idx = _lasso_case(ob, 9100, log_T, log_K, n)
+    g, o = api.LassoProver(idx, log_T, log_K, w), ob.LassoProver(idx, log_T, log_K, w)
+    assert np.array_equal(g.computeInitialClaim(), o.current_claim)
+    chal = _rand(ob, 9101, log_T + log_K)
+    for rnd in range(log_T + log_K):
+        assert np.array_equal(g.computeRoundPolynomial(), o.computeRoundPolynomial()), rnd
+        g.receiveChallenge(chal[rnd])
+        o.receiveChallenge(chal[rnd])
+        assert np.array_equal(g.current_claim, o.current_claim), rnd
+    assert np.array_equal(g.getFinalEval(), o.getFinalEval())
+    assert np.array_equal(g.eq_evals(), o.eq_evals[:1])
+    g.deinit()
