@@ -4,6 +4,7 @@
 // throughput of the Montgomery multiply as compiled.
 //   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/microbench.hip -o tools/microbench
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
@@ -238,7 +239,53 @@ static int run_mem(const char *mode) {
     return 0;
 }
 
+// ---- launch chains: nine dependent short kernels (the shape of zg_run_sumcheck's 8 folds + tail) launched one by one against the same
+// chain replayed as a hipGraph. usage: microbench launch
+__global__ void k_chain_step(unsigned *p, unsigned rounds) {
+    unsigned v = p[threadIdx.x];
+    for (unsigned i = 0; i < rounds; i++) v = v * 1664525u + 1013904223u;
+    p[threadIdx.x] = v;
+}
+static int run_launch() {
+    unsigned *d;
+    CHK(hipMalloc(&d, 256 * 4));
+    CHK(hipMemset(d, 1, 256 * 4));
+    hipStream_t st;
+    CHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    const int chain = 9, reps = 200;
+    for (unsigned work : {1u, 2000u}) {  // ~2 us and ~10 us kernels
+        auto t0 = std::chrono::steady_clock::now();
+        for (int r = 0; r < reps; r++) {
+            for (int k = 0; k < chain; k++) hipLaunchKernelGGL(k_chain_step, dim3(64), dim3(256), 0, st, d, work);
+            CHK(hipStreamSynchronize(st));
+        }
+        double direct = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / reps;
+        hipGraph_t graph;
+        hipGraphExec_t exec;
+        CHK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+        for (int k = 0; k < chain; k++) hipLaunchKernelGGL(k_chain_step, dim3(64), dim3(256), 0, st, d, work);
+        CHK(hipStreamEndCapture(st, &graph));
+        auto tc = std::chrono::steady_clock::now();
+        CHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        double inst = std::chrono::duration<double>(std::chrono::steady_clock::now() - tc).count();
+        CHK(hipGraphLaunch(exec, st));
+        CHK(hipStreamSynchronize(st));
+        t0 = std::chrono::steady_clock::now();
+        for (int r = 0; r < reps; r++) {
+            CHK(hipGraphLaunch(exec, st));
+            CHK(hipStreamSynchronize(st));
+        }
+        double replay = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / reps;
+        printf("chain of %d dependent kernels (%u iterations each): direct launches %.1f us, hipGraph replay %.1f us, instantiate %.1f us\n", chain, work,
+               direct * 1e6, replay * 1e6, inst * 1e6);
+        CHK(hipGraphExecDestroy(exec));
+        CHK(hipGraphDestroy(graph));
+    }
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc > 1 && argv[1][0] == 'l') return run_launch();
     if (argc > 1 && (argv[1][0] == 'g' || argv[1][0] == 's')) return run_mem(argv[1]);
     bool only_ec = argc > 1 && argv[1][0] == 'e';
     hipDeviceProp_t prop; CHK(hipGetDeviceProperties(&prop, 0));
