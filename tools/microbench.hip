@@ -216,6 +216,52 @@ __global__ void k_stream64(const uint4 *table, size_t n_rows_table, size_t rows_
     }
     sink[tid] = acc.x ^ acc.y;
 }
+// ---- XCD-aware block mapping for a pure stream: workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each XCD has its own
+// L2. `microbench xcd` streams the same 2 GiB three ways: (a) grid-stride (every wave-load of consecutive blocks is adjacent, all XCDs
+// touch every region), (b) one contiguous chunk per block, (c) chunks grouped so that the blocks of one XCD own one contiguous eighth.
+__global__ void k_stream_map(const uint4 *table, size_t n16, int mapping, unsigned *sink) {
+    const size_t nb = gridDim.x, per_block = n16 / nb;
+    size_t b = blockIdx.x;
+    if (mapping == 2) b = (b % 8) * (nb / 8) + b / 8;  // XCD x = blockIdx % 8 owns blocks' chunks [x * nb/8, (x+1) * nb/8)
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    if (mapping == 0) {
+        const size_t nthreads = nb * blockDim.x, tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+        for (size_t i = tid; i < n16; i += nthreads) {
+            uint4 a = table[i];
+            acc.x ^= a.x; acc.y += a.w;
+        }
+    } else {
+        const uint4 *p = table + b * per_block;
+        for (size_t i = threadIdx.x; i < per_block; i += blockDim.x) {
+            uint4 a = p[i];
+            acc.x ^= a.x; acc.y += a.w;
+        }
+    }
+    sink[blockIdx.x * (size_t)blockDim.x + threadIdx.x] = acc.x ^ acc.y;
+}
+static int run_xcd() {
+    const size_t table_bytes = (size_t)2 << 30, n16 = table_bytes / 16;
+    const int blocks = 256 * 8, threads = 256;
+    uint4 *table; unsigned *sink;
+    CHK(hipMalloc(&table, table_bytes));
+    CHK(hipMemset(table, 1, table_bytes));
+    CHK(hipMalloc(&sink, (size_t)blocks * threads * 4));
+    hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    const char *names[3] = {"grid-stride", "contiguous chunk per block", "contiguous eighth per XCD"};
+    for (int mapping = 0; mapping < 3; mapping++) {
+        float best = 1e9f;
+        for (int rep = 0; rep < 4; rep++) {
+            CHK(hipEventRecord(e0));
+            hipLaunchKernelGGL(k_stream_map, dim3(blocks), dim3(threads), 0, 0, table, n16, mapping, sink);
+            CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+            float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep && ms < best) best = ms;
+        }
+        printf("stream 2 GiB, %-28s: %.3f ms, %.2f TB/s\n", names[mapping], best, table_bytes / best / 1e9);
+    }
+    return 0;
+}
+
 static int run_mem(const char *mode) {
     const size_t table_bytes = (size_t)2 << 30, n_rows = table_bytes / 64;
     const int blocks = 256 * 8, threads = 256;
@@ -286,6 +332,7 @@ static int run_launch() {
 
 int main(int argc, char **argv) {
     if (argc > 1 && argv[1][0] == 'l') return run_launch();
+    if (argc > 1 && argv[1][0] == 'x') return run_xcd();
     if (argc > 1 && (argv[1][0] == 'g' || argv[1][0] == 's')) return run_mem(argv[1]);
     bool only_ec = argc > 1 && argv[1][0] == 'e';
     hipDeviceProp_t prop; CHK(hipGetDeviceProperties(&prop, 0));
