@@ -230,6 +230,15 @@ __global__ void k_stream_map(const uint4 *table, size_t n16, int mapping, unsign
             uint4 a = table[i];
             acc.x ^= a.x; acc.y += a.w;
         }
+    } else if (mapping == 3 || mapping == 4) {  // each lane owns 64 (or 32) contiguous bytes, neighbours 64 (32) bytes apart: the fold kernels' shape
+        const size_t per = mapping == 3 ? 4 : 2;
+        const size_t nthreads = nb * blockDim.x, tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+        for (size_t i = tid; i < n16 / per; i += nthreads) {
+            for (size_t q = 0; q < per; q++) {
+                uint4 a = table[per * i + q];
+                acc.x ^= a.x; acc.y += a.w;
+            }
+        }
     } else {
         const uint4 *p = table + b * per_block;
         for (size_t i = threadIdx.x; i < per_block; i += blockDim.x) {
@@ -239,6 +248,15 @@ __global__ void k_stream_map(const uint4 *table, size_t n16, int mapping, unsign
     }
     sink[blockIdx.x * (size_t)blockDim.x + threadIdx.x] = acc.x ^ acc.y;
 }
+// the LowToHigh fold's traffic without its arithmetic: 64 contiguous bytes read and 32 written per lane, grid-strided
+__global__ void k_fold_traffic(const uint4 *in, uint4 *out, size_t n_pairs) {
+    const size_t nthreads = (size_t)gridDim.x * blockDim.x, tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    for (size_t i = tid; i < n_pairs; i += nthreads) {
+        uint4 a = in[4 * i], b = in[4 * i + 1], c = in[4 * i + 2], d = in[4 * i + 3];
+        out[2 * i] = make_uint4(a.x ^ c.x, a.y + c.y, a.z ^ c.z, a.w + c.w);
+        out[2 * i + 1] = make_uint4(b.x ^ d.x, b.y + d.y, b.z ^ d.z, b.w + d.w);
+    }
+}
 static int run_xcd() {
     const size_t table_bytes = (size_t)2 << 30, n16 = table_bytes / 16;
     const int blocks = 256 * 8, threads = 256;
@@ -247,8 +265,8 @@ static int run_xcd() {
     CHK(hipMemset(table, 1, table_bytes));
     CHK(hipMalloc(&sink, (size_t)blocks * threads * 4));
     hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
-    const char *names[3] = {"grid-stride", "contiguous chunk per block", "contiguous eighth per XCD"};
-    for (int mapping = 0; mapping < 3; mapping++) {
+    const char *names[5] = {"grid-stride", "contiguous chunk per block", "contiguous eighth per XCD", "64 B per lane, grid-stride", "32 B per lane, grid-stride"};
+    for (int mapping = 0; mapping < 5; mapping++) {
         float best = 1e9f;
         for (int rep = 0; rep < 4; rep++) {
             CHK(hipEventRecord(e0));
@@ -258,6 +276,19 @@ static int run_xcd() {
             if (rep && ms < best) best = ms;
         }
         printf("stream 2 GiB, %-28s: %.3f ms, %.2f TB/s\n", names[mapping], best, table_bytes / best / 1e9);
+    }
+    uint4 *outb;
+    CHK(hipMalloc(&outb, table_bytes / 2));
+    for (int nb : {256, 512, 1024, 2048, 4096}) {
+        float best = 1e9f;
+        for (int rep = 0; rep < 4; rep++) {
+            CHK(hipEventRecord(e0));
+            hipLaunchKernelGGL(k_fold_traffic, dim3(nb), dim3(threads), 0, 0, table, outb, n16 / 4);
+            CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+            float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep && ms < best) best = ms;
+        }
+        printf("fold traffic (2 GiB read + 1 GiB written), %4d workgroups: %.3f ms, %.2f TB/s\n", nb, best, 1.5 * table_bytes / best / 1e9);
     }
     return 0;
 }

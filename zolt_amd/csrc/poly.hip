@@ -195,6 +195,30 @@ ZG_DEV Fr sc_verifier_step(const ScRunArg &a, const Fr &g0, const Fr &g1, F29 *c
     return ch;
 }
 
+// Arrival of a workgroup at the end of a round; returns true in the one that arrives last (after every other group's partials are
+// visible to it). Same-address atomics serialise at ~30 ns each: 2048 workgroups on one counter cost 60 us (measured: a 2^20-entry
+// fold 37 -> 100 us), which pinned the grids to one workgroup per CU and the long folds to 3-4 TB/s. Above SC_ARRIVE_FLAT groups the
+// arrival is two-level: 16 counters on separate 128-byte lines (blockIdx mod 16), the last arrival of each line moves on to the top
+// counter — at most nb / 16 + 16 serialised atomics. Every counter is left at zero for the next launch (stream order).
+constexpr uint32_t SC_ARRIVE_FLAT = 64, SC_ARRIVE_LINES = 16, SC_ARRIVE_STRIDE = 32;  // uint32 words between counters (128 bytes)
+constexpr size_t SC_COUNTER_BYTES = 128 * (1 + SC_ARRIVE_LINES);
+ZG_DEV bool sc_arrive(uint32_t *counter, uint32_t nb) {
+    if (nb <= SC_ARRIVE_FLAT) {
+        uint32_t arrived = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (arrived != nb - 1) return false;
+        __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return true;
+    }
+    const uint32_t line = blockIdx.x % SC_ARRIVE_LINES;
+    const uint32_t members = (nb - line + SC_ARRIVE_LINES - 1) / SC_ARRIVE_LINES;  // workgroups b < nb with b mod 16 == line
+    uint32_t *lc = counter + SC_ARRIVE_STRIDE * (1 + line);
+    if (__hip_atomic_fetch_add(lc, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) != members - 1) return false;
+    __hip_atomic_store(lc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) != SC_ARRIVE_LINES - 1) return false;
+    __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
+
 // End of a round inside the producing kernel (no second launch): every block leaves its pair in `partials`; the block
 // that arrives last at the device-scope counter adds all of them up, writes the round's pair to `sums` (the pinned
 // host mailbox), publishes the sequence word and re-arms the counter. g0/g1: the block's pair, valid in thread 0.
@@ -221,13 +245,12 @@ __device__ __forceinline__ void finish_round(Fr &g0, Fr &g1, uint4 *sh, uint64_t
             __hip_atomic_store(dst + i, (uint64_t)g0.l[2 * i] | ((uint64_t)g0.l[2 * i + 1] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(dst + 4 + i, (uint64_t)g1.l[2 * i] | ((uint64_t)g1.l[2 * i + 1] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        uint32_t arrived = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        last = arrived == nb - 1 ? 1u : 0u;
+        last = sc_arrive(counter, nb) ? 1u : 0u;
     }
     __syncthreads();
     if (!last) return;
     Fr a0 = Fr::zero(), a1 = Fr::zero();
-    for (uint32_t k = tid; k < nb; k += 256) {
+    for (uint32_t k = tid; k < nb; k += blockDim.x) {
         const uint64_t *src = partials + 8 * (size_t)k;
         Fr p0, p1;
 #pragma unroll
@@ -243,7 +266,6 @@ __device__ __forceinline__ void finish_round(Fr &g0, Fr &g1, uint4 *sh, uint64_t
     __syncthreads();  // sh is reused
     block_sum_pair(a0, a1, sh);
     if (tid == 0) {
-        __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch (stream order)
         if (run.res) {
             sc_verifier_step(run, a0, a1);
         } else {
@@ -294,8 +316,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(56))) hk_q
     }
 }
 
+// Launched with 256 threads per workgroup, or with 1024 for long tables: every arrival at the end of a round is an agent-scope
+// release (on this multi-XCD part: a write-back of the XCD's dirty L2 lines), so MORE workgroups make a round slower (2^20 entries:
+// 37 us with 256 workgroups, 100 us with 2048 — and identical with the arrivals spread over 16 counters, so it is not the counter),
+// while one wave per SIMD cannot keep enough loads in flight (3-4 TB/s against the 5.5 TB/s the same traffic reaches without the
+// arithmetic, tools/microbench xcd). More waves per workgroup give the loads without the arrivals.
 template <int LAYOUT>
-__global__ void __launch_bounds__(256) sc_fold_kernel(const uint64_t *t, size_t half, FrArg r, uint64_t *out,
+__global__ void __launch_bounds__(1024) sc_fold_kernel(const uint64_t *t, size_t half, FrArg r, uint64_t *out,
                                                       uint64_t *partials, uint64_t *sums, uint32_t *counter, uint64_t *flag,
                                                       uint64_t seq, ScRunArg run) {
     __shared__ uint4 sh[256 * 4];
@@ -308,11 +335,11 @@ __global__ void __launch_bounds__(256) sc_fold_kernel(const uint64_t *t, size_t 
     }
     F29 rp = fr29_prescale(rv);  // the challenge is the shared factor of every product of this launch
     Fr g0 = Fr::zero(), g1 = Fr::zero();
-    size_t stride = (size_t)gridDim.x * 256;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
     size_t quarter = half / 2;
     // the pair of the next iteration is requested before the current product is computed: with one block per CU (4 waves) the
     // loads in flight, not the arithmetic, bound a long table (Little's law: 64 B per thread x 65536 threads per ~2 us)
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     Fr lo = Fr::zero(), hi = Fr::zero();
     if (i < half) {
         lo = fe_load<FrParams>(LAYOUT == ZG_SC_HIGH_HALF ? t + 4 * i : t + 8 * i);
@@ -589,10 +616,10 @@ static unsigned env_uint(const char *name, unsigned dflt, unsigned lo, unsigned 
     return v < lo ? lo : (v > hi ? hi : v);
 }
 
-// scratch layout of a fold/sums launch (u64 words): [0, 8*SC_MAX_BLOCKS) block pairs | 16 words: arrival counter
+// scratch layout of a fold/sums launch (u64 words): [0, 8*SC_MAX_BLOCKS) block pairs | SC_COUNTER_BYTES: arrival counters (sc_arrive)
 // (must be 0 before a launch; the kernels re-arm it) | 8 words: the round's pair when it is not sent to a host mailbox
 constexpr unsigned SC_MAX_BLOCKS = 2048;
-constexpr size_t SC_SUMS_OFF = 8 * (size_t)SC_MAX_BLOCKS + 16;
+constexpr size_t SC_SUMS_OFF = 8 * (size_t)SC_MAX_BLOCKS + SC_COUNTER_BYTES / 8;
 constexpr size_t SC_MISC_BYTES = (SC_SUMS_OFF + 8) * 8;
 static unsigned sc_blocks(size_t half) {
     static const unsigned cap = [] {
@@ -631,10 +658,13 @@ static int launch_fold(int layout, const uint64_t *t, size_t len, const uint64_t
     }
     uint32_t *counter = reinterpret_cast<uint32_t *>(partials + 8 * (size_t)SC_MAX_BLOCKS);
     prof_begin(ZG_PROF_SC_FOLD, st);
+    // outputs from which a workgroup gets 1024 threads: measured 2^24 entries 219 -> 188 us, 2^23 124 -> 117, 2^22 77 -> 80, 2^20 39 -> 52
+    static const unsigned wide_min = env_uint("ZG_SC_WIDE_MIN_LOG2", 22, 0, 40);
+    const unsigned threads = (half >> wide_min) ? 1024u : 256u;
     if (layout == ZG_SC_HIGH_HALF)
-        hipLaunchKernelGGL(sc_fold_kernel<ZG_SC_HIGH_HALF>, dim3(nb), dim3(256), 0, st, t, half, ra, out, partials, sums, counter, flag, seq, run);
+        hipLaunchKernelGGL(sc_fold_kernel<ZG_SC_HIGH_HALF>, dim3(nb), dim3(threads), 0, st, t, half, ra, out, partials, sums, counter, flag, seq, run);
     else
-        hipLaunchKernelGGL(sc_fold_kernel<ZG_SC_LOW_PAIR>, dim3(nb), dim3(256), 0, st, t, half, ra, out, partials, sums, counter, flag, seq, run);
+        hipLaunchKernelGGL(sc_fold_kernel<ZG_SC_LOW_PAIR>, dim3(nb), dim3(threads), 0, st, t, half, ra, out, partials, sums, counter, flag, seq, run);
     prof_end(ZG_PROF_SC_FOLD, st);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
@@ -938,7 +968,7 @@ static int bind_host(int layout, const uint64_t *table, size_t len, const uint64
     if (!s_t.p || !s_o.p || !s_misc.p) return ZG_ERR_NOMEM;
     uint64_t *d_t = s_t.as<uint64_t>(), *d_o = s_o.as<uint64_t>(), *d_misc = s_misc.as<uint64_t>();
     uint64_t *d_sums = d_misc + SC_SUMS_OFF;
-    ZG_HIP(hipMemsetAsync(d_misc + 8 * (size_t)SC_MAX_BLOCKS, 0, 128, st));
+    ZG_HIP(hipMemsetAsync(d_misc + 8 * (size_t)SC_MAX_BLOCKS, 0, SC_COUNTER_BYTES, st));
     ZG_HIP(hipMemcpyAsync(d_t, table, len * 32, hipMemcpyHostToDevice, st));
     int rc = launch_fold(layout, d_t, len, r, d_o, d_misc, d_sums, st);
     if (rc == ZG_OK) {
@@ -1162,7 +1192,7 @@ static int hk_open_device(zg_bases_t srs, uint64_t *d_a, uint64_t *d_b, uint64_t
     uint64_t *d_res = s_res.as<uint64_t>(), *d_misc = s_misc.as<uint64_t>(), *d_small = s_small.as<uint64_t>();
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = hipMemsetAsync(d_res, 0, (9 * num_vars + 4) * 8, st);
-    if (e == hipSuccess) e = hipMemsetAsync(d_misc + 8 * (size_t)SC_MAX_BLOCKS, 0, 128, st);
+    if (e == hipSuccess) e = hipMemsetAsync(d_misc + 8 * (size_t)SC_MAX_BLOCKS, 0, SC_COUNTER_BYTES, st);
     if (e == hipSuccess && small_rows) e = hipMemsetAsync(d_small, 0, small_rows * small_len * 32, st);
     if (e == hipSuccess && fuse_long) e = hipMemsetAsync(d_qall + 4 * fl_off, 0, fl_rows * fl_len * 32, st);
     int rc = ZG_OK;
@@ -1527,7 +1557,7 @@ static int run_sumcheck_enqueue(const uint64_t *d_evals, size_t len, hipStream_t
     if (!s_a.p || !s_b.p || !s_res.p || !s_misc.p) return ZG_ERR_NOMEM;
     uint64_t *d_res = s_res.as<uint64_t>(), *d_misc = s_misc.as<uint64_t>();
     uint64_t *buf[2] = {s_a.as<uint64_t>(), s_b.as<uint64_t>()};
-    ZG_HIP(hipMemsetAsync(d_misc + 8 * (size_t)SC_MAX_BLOCKS, 0, 128, st));
+    ZG_HIP(hipMemsetAsync(d_misc + 8 * (size_t)SC_MAX_BLOCKS, 0, SC_COUNTER_BYTES, st));
     // round 0's sums: also fixes the claim; every later round's sums come out of the fold that precedes it
     ZG_TRY(launch_sums(ZG_SC_HIGH_HALF, d_evals, len, d_misc, d_misc + SC_SUMS_OFF, st, nullptr, 0, ScRunArg{d_res, v, 0, 1}));
     const uint64_t *cur = d_evals;

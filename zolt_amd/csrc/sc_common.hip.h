@@ -13,7 +13,7 @@ ZG_DEV Fr fr_shfl_down(const Fr &v, int d) {
     return r;
 }
 
-// block-wide sum of (g0, g1) pairs (256 threads); result valid in thread 0. Wave-level shuffle tree first
+// block-wide sum of (g0, g1) pairs (a multiple of 64 threads, at most 1024); result valid in thread 0. Wave-level shuffle tree first
 // (no barriers, no LDS round trips), then one LDS hop across the four waves: the latency of this reduction is
 // what a small sumcheck round mostly consists of.
 __device__ __forceinline__ void block_sum_pair(Fr &g0, Fr &g1, uint4 *sh) {
@@ -29,7 +29,8 @@ __device__ __forceinline__ void block_sum_pair(Fr &g0, Fr &g1, uint4 *sh) {
     }
     __syncthreads();
     if (tid == 0) {
-        for (uint32_t w = 1; w < 4; w++) {
+        const uint32_t nwaves = blockDim.x >> 6;  // 4 for the 256-thread launches, up to 16 (sh holds 4 * nwaves entries)
+        for (uint32_t w = 1; w < nwaves; w++) {
             g0 = fe_add(g0, fe_load<FrParams>(&sh[w * 4]));
             g1 = fe_add(g1, fe_load<FrParams>(&sh[w * 4 + 2]));
         }
