@@ -316,11 +316,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(56))) hk_q
     }
 }
 
-// Launched with 256 threads per workgroup, or with 1024 for long tables: every arrival at the end of a round is an agent-scope
-// release (on this multi-XCD part: a write-back of the XCD's dirty L2 lines), so MORE workgroups make a round slower (2^20 entries:
-// 37 us with 256 workgroups, 100 us with 2048 — and identical with the arrivals spread over 16 counters, so it is not the counter),
-// while one wave per SIMD cannot keep enough loads in flight (3-4 TB/s against the 5.5 TB/s the same traffic reaches without the
-// arithmetic, tools/microbench xcd). More waves per workgroup give the loads without the arrivals.
+// Launched with 256 threads per workgroup, or with 1024 for long tables. MORE workgroups make a round slower (2^20 entries: 37 us
+// with 256 workgroups, 100 us with 2048) — identically with the arrivals spread over 16 counters, so it is not the same-address atomic,
+// and identically with streaming stores for the output, so it is not dirty L2 lines waiting for the arrival's release; the cost sits in
+// the per-workgroup end of a round (block reduction, eight agent-scope stores, the acq_rel arrival) — while one wave per SIMD cannot
+// keep enough loads in flight (3-4 TB/s against the 5.5 TB/s the same traffic reaches without the arithmetic, tools/microbench xcd).
+// More waves per workgroup give the loads without more round ends.
 template <int LAYOUT>
 __global__ void __launch_bounds__(1024) sc_fold_kernel(const uint64_t *t, size_t half, FrArg r, uint64_t *out,
                                                       uint64_t *partials, uint64_t *sums, uint32_t *counter, uint64_t *flag,
