@@ -240,11 +240,8 @@ __device__ __forceinline__ void finish_round(Fr &g0, Fr &g1, uint4 *sh, uint64_t
     __shared__ uint32_t last;
     if (tid == 0) {
         uint64_t *dst = partials + 8 * (size_t)blockIdx.x;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            __hip_atomic_store(dst + i, (uint64_t)g0.l[2 * i] | ((uint64_t)g0.l[2 * i + 1] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(dst + 4 + i, (uint64_t)g1.l[2 * i] | ((uint64_t)g1.l[2 * i + 1] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        fe_store(dst, g0);  // plain stores: the arrival's release makes them visible to the workgroup whose acquire sees it last
+        fe_store(dst + 4, g1);
         last = sc_arrive(counter, nb) ? 1u : 0u;
     }
     __syncthreads();
@@ -252,16 +249,8 @@ __device__ __forceinline__ void finish_round(Fr &g0, Fr &g1, uint4 *sh, uint64_t
     Fr a0 = Fr::zero(), a1 = Fr::zero();
     for (uint32_t k = tid; k < nb; k += blockDim.x) {
         const uint64_t *src = partials + 8 * (size_t)k;
-        Fr p0, p1;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            uint64_t x = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            uint64_t y = __hip_atomic_load(src + 4 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            p0.l[2 * i] = (uint32_t)x; p0.l[2 * i + 1] = (uint32_t)(x >> 32);
-            p1.l[2 * i] = (uint32_t)y; p1.l[2 * i + 1] = (uint32_t)(y >> 32);
-        }
-        a0 = fe_add(a0, p0);
-        a1 = fe_add(a1, p1);
+        a0 = fe_add(a0, fe_load<FrParams>(src));
+        a1 = fe_add(a1, fe_load<FrParams>(src + 4));
     }
     __syncthreads();  // sh is reused
     block_sum_pair(a0, a1, sh);
@@ -319,7 +308,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(56))) hk_q
 // Launched with 256 threads per workgroup, or with 1024 for long tables. MORE workgroups make a round slower (2^20 entries: 37 us
 // with 256 workgroups, 100 us with 2048) — identically with the arrivals spread over 16 counters, so it is not the same-address atomic,
 // and identically with streaming stores for the output, so it is not dirty L2 lines waiting for the arrival's release; the cost sits in
-// the per-workgroup end of a round (block reduction, eight agent-scope stores, the acq_rel arrival) — while one wave per SIMD cannot
+// the per-workgroup end of a round (block reduction and the acq_rel arrival; plain instead of agent-scope atomic stores for the
+// partials change nothing either) — while one wave per SIMD cannot
 // keep enough loads in flight (3-4 TB/s against the 5.5 TB/s the same traffic reaches without the arithmetic, tools/microbench xcd).
 // More waves per workgroup give the loads without more round ends.
 template <int LAYOUT>
