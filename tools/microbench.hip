@@ -257,6 +257,51 @@ __global__ void k_fold_traffic(const uint4 *in, uint4 *out, size_t n_pairs) {
         out[2 * i + 1] = make_uint4(b.x ^ d.x, b.y + d.y, b.z ^ d.z, b.w + d.w);
     }
 }
+// ---- what does the END of a workgroup cost when thousands of them finish a round? `microbench arrive`: 2048 workgroups of 256
+// threads, each does a little work and then (0) nothing, (1) one plain store by thread 0, (2) + a relaxed agent-scope fetch_add,
+// (3) + an acq_rel agent-scope fetch_add, (4) acq_rel on one of 16 counters (128-byte lines apart), (5) a release fence + relaxed add
+__global__ void k_arrive(unsigned *cnt, unsigned *out, int mode) {
+    __shared__ unsigned sh[256];
+    unsigned v = threadIdx.x * 2654435761u + blockIdx.x;
+    for (int i = 0; i < 64; i++) v = v * 1664525u + 1013904223u;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned acc = 0;
+        for (int w = 0; w < 4; w++) acc += sh[64 * w];
+        if (mode >= 1) out[16 * blockIdx.x] = acc;
+        if (mode == 2) (void)__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (mode == 3) (void)__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (mode == 4) (void)__hip_atomic_fetch_add(cnt + 32 * (1 + blockIdx.x % 16), 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (mode == 5) {
+            __atomic_thread_fence(__ATOMIC_RELEASE);
+            (void)__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+}
+static int run_arrive() {
+    unsigned *cnt, *out;
+    CHK(hipMalloc(&cnt, 4096));
+    CHK(hipMemset(cnt, 0, 4096));
+    CHK(hipMalloc(&out, 4096 * 64));
+    hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    const char *names[6] = {"work only", "+ plain store", "+ relaxed agent fetch_add", "+ acq_rel agent fetch_add", "+ acq_rel, 16 counters", "+ release fence, wg-scope add"};
+    for (int nb : {256, 2048}) {
+        for (int mode = 0; mode < 6; mode++) {
+            float best = 1e9f;
+            for (int rep = 0; rep < 5; rep++) {
+                CHK(hipEventRecord(e0));
+                hipLaunchKernelGGL(k_arrive, dim3(nb), dim3(256), 0, 0, cnt, out, mode);
+                CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+                float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+                if (rep && ms < best) best = ms;
+            }
+            printf("%4d workgroups, %-32s: %.1f us\n", nb, names[mode], best * 1e3);
+        }
+    }
+    return 0;
+}
+
 static int run_xcd() {
     const size_t table_bytes = (size_t)2 << 30, n16 = table_bytes / 16;
     const int blocks = 256 * 8, threads = 256;
@@ -364,6 +409,7 @@ static int run_launch() {
 int main(int argc, char **argv) {
     if (argc > 1 && argv[1][0] == 'l') return run_launch();
     if (argc > 1 && argv[1][0] == 'x') return run_xcd();
+    if (argc > 1 && argv[1][0] == 'a') return run_arrive();
     if (argc > 1 && (argv[1][0] == 'g' || argv[1][0] == 's')) return run_mem(argv[1]);
     bool only_ec = argc > 1 && argv[1][0] == 'e';
     hipDeviceProp_t prop; CHK(hipGetDeviceProperties(&prop, 0));

@@ -305,13 +305,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(56))) hk_q
     }
 }
 
-// Launched with 256 threads per workgroup, or with 1024 for long tables. MORE workgroups make a round slower (2^20 entries: 37 us
-// with 256 workgroups, 100 us with 2048) — identically with the arrivals spread over 16 counters, so it is not the same-address atomic,
-// and identically with streaming stores for the output, so it is not dirty L2 lines waiting for the arrival's release; the cost sits in
-// the per-workgroup end of a round (block reduction and the acq_rel arrival; plain instead of agent-scope atomic stores for the
-// partials change nothing either) — while one wave per SIMD cannot
-// keep enough loads in flight (3-4 TB/s against the 5.5 TB/s the same traffic reaches without the arithmetic, tools/microbench xcd).
-// More waves per workgroup give the loads without more round ends.
+// Launched with 256 threads per workgroup, or with 1024 for tables of >= 2^23 entries (2^24: 219 -> 188 us). A long fold is bound by
+// instruction issue, not by HBM: ~400 instructions per output (unpack, 162 multiply-adds, conditional subtraction, repack, one modular
+// subtraction and addition) against 96 bytes of traffic put the ceiling at ~9 TB/s with every issue slot used; the kernel reaches
+// 4.2-4.6 TB/s, the same traffic without the arithmetic 5.5 (tools/microbench xcd). More workgroups do not help and cost more: an
+// arrival (acq_rel fetch_add, agent scope) takes ~20 ns of chip-wide throughput per workgroup whatever the counter layout
+// (tools/microbench arrive: 2048 workgroups 6 us without, 48 us with, 34 us on 16 counters) — 2^20 entries: 37 us with 256 workgroups,
+// 100 us with 2048; finishing the round in a second launch instead (no arrivals, 2048 workgroups) measured 187 vs 193 us at 2^24 and
+// 50 vs 40 us at 2^20, and was left out.
 template <int LAYOUT>
 __global__ void __launch_bounds__(1024) sc_fold_kernel(const uint64_t *t, size_t half, FrArg r, uint64_t *out,
                                                       uint64_t *partials, uint64_t *sums, uint32_t *counter, uint64_t *flag,
