@@ -361,6 +361,18 @@ def test_full_size_closed_form(zl, ob, n):
             assert cinf == ginf and np.array_equal(cxy, got), G
         zl._lib.zg_dev_free(d_sc)
         zl._lib.zg_dev_free(d_part)
+        # the same config through the ONE-process entry points (zg_g1_bases_upload_sharded / zg_msm_g1_sharded): eight logical shards
+        # resident at once on this device, worker threads, the partial exchange and the device combine
+        os.environ["ZG_SHARDS"] = "8"
+        try:
+            zl.init_devices(1)
+            sb = zl.ShardedBases.upload(gm)
+            assert len(sb.shards()) == 8
+            sxy, sinf = sb.msm(sc)
+            sb.free()
+        finally:
+            del os.environ["ZG_SHARDS"]
+        assert sinf == ginf and np.array_equal(sxy, got)
 
 
 @pytest.mark.parametrize("kind", ["boolean", "bytes", "all_equal", "one_hot_bucket", "mixed"])
