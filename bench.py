@@ -594,6 +594,11 @@ def extra_measurements(lib, api, torch, dev, stream, args, srs_xy=None):
             extra["sumcheck_v20_compiled_host"] = json.loads(out.stdout.strip().splitlines()[-1])
         except Exception as e:  # noqa: BLE001
             extra["sumcheck_v20_compiled_host"] = {"error": str(e)}
+        try:  # the sizes the reference's own runs have: prover fold sites and a Stage-2-shaped batched proof at 2^13 cycles
+            out = subprocess.run([exe, "13", "10"], capture_output=True, text=True, timeout=300)
+            extra["prover_sites_v13_compiled_host"] = json.loads(out.stdout.strip().splitlines()[-1])
+        except Exception as e:  # noqa: BLE001
+            extra["prover_sites_v13_compiled_host"] = {"error": str(e)}
     return extra
 
 
