@@ -34,6 +34,18 @@ inline void check(int rc, const char *where) {
     if (rc != ZG_OK) throw GpuError(rc, where);
 }
 
+// raw device memory through the C ABI, released when the owner goes away (also when a constructor throws half-way)
+struct DeviceMem {
+    void *p = nullptr;
+    DeviceMem() = default;
+    explicit DeviceMem(size_t bytes) { alloc(bytes); }
+    DeviceMem(const DeviceMem &) = delete;
+    DeviceMem &operator=(const DeviceMem &) = delete;
+    ~DeviceMem() { if (p) zg_dev_free(p); }
+    void alloc(size_t bytes) { check(zg_dev_alloc(bytes ? bytes : 1, &p), "zg_dev_alloc"); }
+    uint64_t *u64() const { return static_cast<uint64_t *>(p); }
+};
+
 // ---------------------------------------------------------------- host Fr (scalar use only)
 struct Fr {
     uint64_t limbs[4];
@@ -1038,21 +1050,16 @@ public:
                                   const Fr &uni_skip_claim)
         : current_claim(uni_skip_claim), split_eq(tau_low, &lagrange_kernel), s_({&left, &right}) {
         size_t m = tau_low.size() / 2;
-        check(zg_dev_alloc(((size_t(2) << m) - 1) * 32, &d_out_), "zg_dev_alloc");
-        check(zg_dev_alloc(((size_t(2) << split_eq.num_x_in) - 1) * 32, &d_in_), "zg_dev_alloc");
-        check(zg_fr_eq_prefix_tables_dev(reinterpret_cast<const uint64_t *>(tau_low.data()), m, static_cast<uint64_t *>(d_out_), nullptr), "prefix");
-        check(zg_fr_eq_prefix_tables_dev(reinterpret_cast<const uint64_t *>(tau_low.data() + m), split_eq.num_x_in, static_cast<uint64_t *>(d_in_), nullptr),
-              "prefix");
-    }
-    ~ProductVirtualRemainderProver() {
-        zg_dev_free(d_out_);
-        zg_dev_free(d_in_);
+        d_out_.alloc(((size_t(2) << m) - 1) * 32);
+        d_in_.alloc(((size_t(2) << split_eq.num_x_in) - 1) * 32);
+        check(zg_fr_eq_prefix_tables_dev(reinterpret_cast<const uint64_t *>(tau_low.data()), m, d_out_.u64(), nullptr), "prefix");
+        check(zg_fr_eq_prefix_tables_dev(reinterpret_cast<const uint64_t *>(tau_low.data() + m), split_eq.num_x_in, d_in_.u64(), nullptr), "prefix");
     }
     bool roundEvals(std::array<Fr, 4> &evals) {
         if (s_.len() < 2) return false;
         auto w = split_eq.getWindowEqTables(current_round, 1);  // sizes; the same tables sit at element 2^k - 1 of the device buffers
         size_t n_out = w.E_out->size(), n_in = w.E_in->size();
-        auto t = s_.roundGruen({0, 1}, static_cast<const uint64_t *>(d_out_) + 4 * (n_out - 1), n_out, static_cast<const uint64_t *>(d_in_) + 4 * (n_in - 1), n_in);
+        auto t = s_.roundGruen({0, 1}, d_out_.u64() + 4 * (n_out - 1), n_out, d_in_.u64() + 4 * (n_in - 1), n_in);
         evals = split_eq.computeCubicRoundPoly(t[0], t[1], current_claim);
         return true;
     }
@@ -1074,7 +1081,7 @@ public:
 
 private:
     ProductSumcheckSession s_;
-    void *d_out_ = nullptr, *d_in_ = nullptr;
+    DeviceMem d_out_, d_in_;
 };
 
 // InstructionInputProver's loop (src/zkvm/spartan/stage3_prover.zig:2029-2150): tables left_is_rs1, rs1_value, left_is_pc, unexpanded_pc,
@@ -1309,37 +1316,38 @@ public:
         std::vector<Fr> point;
         for (size_t i = outer; i-- > 0;) point.push_back(r_reduction[i]);
         for (size_t i = log_T; i-- > outer;) point.push_back(r_reduction[i]);
-        void *d_tab = nullptr;
-        check(zg_dev_alloc(eq_evals_len * 32, &d_tab), "zg_dev_alloc");
-        int rc = zg_fr_eq_table_dev(reinterpret_cast<const uint64_t *>(point.data()), log_T, nullptr, static_cast<uint64_t *>(d_tab), nullptr);
-        if (rc == ZG_OK && n_ < eq_evals_len) {
-            std::vector<uint64_t> zeros((eq_evals_len - n_) * 4, 0);
-            rc = zg_memcpy_h2d(static_cast<uint64_t *>(d_tab) + 4 * n_, zeros.data(), zeros.size() * 8);
+        {
+            DeviceMem d_tab(eq_evals_len * 32);
+            check(zg_fr_eq_table_dev(reinterpret_cast<const uint64_t *>(point.data()), log_T, nullptr, d_tab.u64(), nullptr), "zg_fr_eq_table_dev");
+            if (n_ < eq_evals_len) {
+                std::vector<uint64_t> zeros((eq_evals_len - n_) * 4, 0);
+                check(zg_memcpy_h2d(d_tab.u64() + 4 * n_, zeros.data(), zeros.size() * 8), "zg_memcpy_h2d");
+            }
+            check(zg_sumcheck_open_dev(d_tab.u64(), eq_evals_len, ZG_SC_HIGH_HALF, nullptr, &s_), "zg_sumcheck_open_dev");
+            check(zg_sync(), "zg_sync");  // the session copied the table: the staging buffer may go
         }
-        if (rc == ZG_OK) rc = zg_sumcheck_open_dev(static_cast<const uint64_t *>(d_tab), eq_evals_len, ZG_SC_HIGH_HALF, nullptr, &s_);
-        if (rc == ZG_OK) rc = zg_sync();
-        zg_dev_free(d_tab);
-        check(rc, "LassoProver: eq_evals");
         std::vector<uint64_t> words(2 * (n_ ? n_ : 1), 0);
         for (size_t j = 0; j < n_; j++) {
             words[2 * j] = (uint64_t)lookup_indices[j];
             words[2 * j + 1] = (uint64_t)(lookup_indices[j] >> 64);
         }
-        check(zg_dev_alloc(words.size() * 8, &d_idx_), "zg_dev_alloc");
-        check(zg_memcpy_h2d(d_idx_, words.data(), words.size() * 8), "zg_memcpy_h2d");
-        current_claim = total();  // :166-171
+        try {
+            d_idx_.alloc(words.size() * 8);
+            check(zg_memcpy_h2d(d_idx_.p, words.data(), words.size() * 8), "zg_memcpy_h2d");
+            current_claim = total();  // :166-171
+        } catch (...) {
+            zg_sumcheck_close(s_);
+            throw;
+        }
     }
-    ~LassoProver() {
-        zg_sumcheck_close(s_);
-        zg_dev_free(d_idx_);
-    }
+    ~LassoProver() { zg_sumcheck_close(s_); }
     LassoProver(const LassoProver &) = delete;
     bool isAddressPhase() const { return round < log_K; }
     bool isComplete() const { return round >= log_K + log_T; }
     UniPoly computeRoundPolynomial() {  // :262-345 -> [sum_0, sum_1 - sum_0, 0]
         Fr s0, s1;
         if (isAddressPhase()) {
-            check(zg_sumcheck_bit_round(s_, static_cast<const uint64_t *>(d_idx_), n_, (unsigned)round, s0.limbs, s1.limbs), "zg_sumcheck_bit_round");
+            check(zg_sumcheck_bit_round(s_, d_idx_.u64(), n_, (unsigned)round, s0.limbs, s1.limbs), "zg_sumcheck_bit_round");
         } else if (eq_evals_len <= 1) {
             check(zg_sumcheck_final(s_, s0.limbs), "zg_sumcheck_final");
             return UniPoly{{s0, Fr::zero(), Fr::zero()}};
@@ -1351,7 +1359,7 @@ public:
     void receiveChallenge(const Fr &challenge) {  // :352-453
         challenges.push_back(challenge);
         if (isAddressPhase()) {
-            check(zg_sumcheck_bit_bind(s_, static_cast<const uint64_t *>(d_idx_), n_, (unsigned)round, challenge.limbs, current_claim.limbs),
+            check(zg_sumcheck_bit_bind(s_, d_idx_.u64(), n_, (unsigned)round, challenge.limbs, current_claim.limbs),
                   "zg_sumcheck_bit_bind");
         } else if (eq_evals_len > 1) {
             check(zg_sumcheck_bind(s_, challenge.limbs), "zg_sumcheck_bind");
@@ -1390,7 +1398,7 @@ private:
     }
     size_t n_;
     zg_sc_t s_ = nullptr;
-    void *d_idx_ = nullptr;
+    DeviceMem d_idx_;
 };
 
 struct LassoProof {  // :470-492
