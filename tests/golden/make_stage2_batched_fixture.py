@@ -68,8 +68,30 @@ def main():
         m = re.match(r"\[ZOLT\] STAGE2_ROUND_(\d+): (current_claim|c0|c2|c3|challenge|next_claim) = ", l)
         if m:
             rounds.setdefault(int(m.group(1)), {})[m.group(2)] = le_bytes(l)
+    # ProductVirtualRemainderProver (instance 0, rounds 16.. of the batch): split_eq.current_scalar before its rounds 0, 1, 2 and the
+    # window-table sizes (src/zkvm/spartan/product_remainder.zig:345-356, toBytesBE), and the last Stage-1 r_cycle challenge = the
+    # tau the first bind uses (proof_converter.zig OPENING_CLAIMS, toBytes = little-endian)
+    product = {"current_scalar": {}, "E_out_len": {}, "E_in_len": {}}
+    for l in lines:
+        m = re.match(r"\[ZOLT PRODUCT round (\d+)\] split_eq.current_scalar = \{ ([0-9, ]+)\}", l)
+        if m:
+            b = bytes(int(x) for x in m.group(2).replace(" ", "").strip(",").split(","))
+            product["current_scalar"][int(m.group(1))] = b[::-1].hex()
+            continue
+        m = re.match(r"\[ZOLT PRODUCT round (\d+)\] E_out.len = (\d+), E_in.len = (\d+)", l)
+        if m:
+            product["E_out_len"][int(m.group(1))] = int(m.group(2))
+            product["E_in_len"][int(m.group(1))] = int(m.group(3))
+            continue
+        m = re.match(r"\[ZOLT\] OPENING_CLAIMS: r_cycle\[last\] = \{ ([0-9, ]+)\}", l)
+        if m and "tau_last" not in product:
+            product["tau_last"] = bytes(int(x) for x in m.group(1).replace(" ", "").strip(",").split(",")).hex()
+        m = re.match(r"\[ZOLT\] OPENING_CLAIMS: r_cycle.len = (\d+)", l)
+        if m and "tau_len" not in product:
+            product["tau_len"] = int(m.group(1))
     n = len(claims)
     assert n == 5 and sorted(rounds) == list(range(max(rounds_of.values())))
+    assert sorted(product["current_scalar"]) == [0, 1, 2]
     out = {
         "source": "reference logs/zolt.log, STAGE2_* lines of src/zkvm/batched_sumcheck.zig (canonical little-endian hex)",
         "input_claims": [claims[i] for i in range(n)],
@@ -80,6 +102,14 @@ def main():
         "rounds": [rounds[k] for k in sorted(rounds)],
         "output_claim": final,
         "instance_final_claims": [individual[i] for i in range(n)],
+        "product_remainder": {
+            "tau_len": product["tau_len"],
+            "tau_last": product["tau_last"],
+            "current_scalar_before_round": [product["current_scalar"][k] for k in range(3)],
+            "E_out_len": [product["E_out_len"][k] for k in range(3)],
+            "E_in_len": [product["E_in_len"][k] for k in range(3)],
+            "first_batch_round": max(rounds_of.values()) - rounds_of[0],
+        },
     }
     for r in out["rounds"]:
         assert set(r) == {"current_claim", "c0", "c2", "c3", "challenge", "next_claim"}

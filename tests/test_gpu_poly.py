@@ -105,6 +105,26 @@ def test_gruen_split_eq_mirror_reference_inline_tests(zl, ob):
     assert [api.fr_to_int(x) for x in p.getEActiveForWindow(5)] == [1]  # wider than the unbound variables (:476-481)
 
 
+def test_gruen_mirror_bind_of_the_captured_run(zl, ob):
+    """api.GruenSplitEqPolynomial against the split_eq scalars and window sizes the reference printed for its ProductVirtualRemainder
+    instance (fixture stage2_batched_rounds.json; see tests/test_transcript_host.py::test_gruen_split_eq_bind_of_the_captured_run)"""
+    from zolt_amd import api
+    d = json.load(open(os.path.join(U.GOLDEN, "stage2_batched_rounds.json")))
+    pr = d["product_remainder"]
+    M = lambda h: api.fr_from_int(int.from_bytes(bytes.fromhex(h), "little"))
+    tau = np.stack([api.fr_from_int(1000 + i) for i in range(pr["tau_len"] - 1)] + [M(pr["tau_last"])])
+    g = api.GruenSplitEqPolynomial.initWithScaling(tau, M(pr["current_scalar_before_round"][0]))
+    for k in range(3):
+        e_out, e_in, _ = g.getWindowEqTables(0, 1)
+        assert (len(e_out), len(e_in)) == (pr["E_out_len"][k], pr["E_in_len"][k])
+        d_out, n_out, d_in, n_in = g.getWindowEqTablesDev(1)
+        assert (n_out, n_in) == (pr["E_out_len"][k], pr["E_in_len"][k])
+        if k == 1:
+            assert np.array_equal(g.current_scalar, M(pr["current_scalar_before_round"][1]))
+        g.bind(M(d["rounds"][pr["first_batch_round"] + k]["challenge"]))
+    g.deinit()
+
+
 @pytest.mark.parametrize("n", [0, 1, 2, 7, 8, 13, 24])
 def test_gruen_split_eq_mirror_vs_oracle_through_all_rounds(zl, ob, n):
     """The mirror against the oracle's restatement of the struct across a whole LowToHigh binding: tables, window views,

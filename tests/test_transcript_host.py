@@ -259,6 +259,36 @@ def test_stage2_batched_sumcheck_of_the_captured_run(golden_dir):
     assert acc % api.R_MOD == api.fr_to_int(M(d["output_claim"]))
 
 
+def test_gruen_split_eq_bind_of_the_captured_run(golden_dir):
+    """GruenSplitEqPolynomial.bind and getWindowEqTables against the ProductVirtualRemainderProver of the captured run
+    (logs/zolt.log "[ZOLT PRODUCT round k]" lines, src/zkvm/spartan/product_remainder.zig:345-356; fixture
+    stage2_batched_rounds.json): its split_eq has 8 variables and a Lagrange-kernel scaling; the scalar it printed before round 1 is
+    the one before round 0 times eq(tau[7], challenge of batch round 16) — the LAST tau is bound first (src/poly/split_eq.zig:213-219)
+    — and the window tables shrink 16 x 8 -> 16 x 4 -> 16 x 2 (:312-343). tau[7] is the last Stage-1 r_cycle challenge the log holds."""
+    import json
+    import os
+    from zolt_amd import api
+    d = json.load(open(os.path.join(golden_dir, "stage2_batched_rounds.json")))
+    pr = d["product_remainder"]
+    M = lambda h: api.fr_from_int(int.from_bytes(bytes.fromhex(h), "little"))
+    n = pr["tau_len"]
+    tau = np.stack([api.fr_from_int(1000 + i) for i in range(n - 1)] + [M(pr["tau_last"])])  # only tau[7] enters the first bind
+    g = ob.GruenSplitEq(tau, M(pr["current_scalar_before_round"][0]))
+    e_out, e_in, _ = g.getWindowEqTables(1)
+    assert (len(e_out), len(e_in)) == (pr["E_out_len"][0], pr["E_in_len"][0])
+    g.bind(M(d["rounds"][pr["first_batch_round"]]["challenge"]))
+    assert np.array_equal(g.current_scalar, M(pr["current_scalar_before_round"][1]))
+    e_out, e_in, _ = g.getWindowEqTables(1)
+    assert (len(e_out), len(e_in)) == (pr["E_out_len"][1], pr["E_in_len"][1])
+    g.bind(M(d["rounds"][pr["first_batch_round"] + 1]["challenge"]))  # tau[6] is not in the log: only the table sizes are held here
+    e_out, e_in, _ = g.getWindowEqTables(1)
+    assert (len(e_out), len(e_in)) == (pr["E_out_len"][2], pr["E_in_len"][2])
+    # the host mirror's scalar step (api.GruenSplitEqPolynomial.bind is this arithmetic on Python integers)
+    t, r, s0 = (api.fr_to_int(M(pr["tau_last"])), api.fr_to_int(M(d["rounds"][pr["first_batch_round"]]["challenge"])),
+                api.fr_to_int(M(pr["current_scalar_before_round"][0])))
+    assert s0 * ((t * r + (1 - t) * (1 - r)) % api.R_MOD) % api.R_MOD == api.fr_to_int(M(pr["current_scalar_before_round"][1]))
+
+
 def test_batched_driver_inactive_instance_rule():
     """Which constant does an instance contribute before its first round? The loop `zolt prove` runs (src/zkvm/proof_converter.zig:
     3330-3343) uses coeff * claim * 2^(start - round - 1): twice that is the instance's share of the claim, so s(0) + s(1) = claim in
