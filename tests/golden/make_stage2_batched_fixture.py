@@ -89,9 +89,20 @@ def main():
         m = re.match(r"\[ZOLT\] OPENING_CLAIMS: r_cycle.len = (\d+)", l)
         if m and "tau_len" not in product:
             product["tau_len"] = int(m.group(1))
+    # R1CSInputEvaluator.computeClaimedInputs' debug lines (src/zkvm/r1cs/evaluation.zig:91-103, toBytesBE): the whole Stage-1 r_cycle
+    # (= tau_low of the Stage-2 split_eq) and the first three entries of EqPolynomial(r_cycle).evals (256 entries)
+    mle = {"r_cycle": {}, "eq_evals": {}}
+    for l in lines:
+        m = re.match(r"\[ZOLT MLE\] (r_cycle|eq_evals)\[(\d+)\] = \{ ([0-9, ]+)\}", l)
+        if m:
+            b = bytes(int(x) for x in m.group(3).replace(" ", "").strip(",").split(","))
+            assert len(b) == 32
+            mle[m.group(1)].setdefault(int(m.group(2)), b[::-1].hex())  # first occurrence; reversed to little-endian
     n = len(claims)
     assert n == 5 and sorted(rounds) == list(range(max(rounds_of.values())))
     assert sorted(product["current_scalar"]) == [0, 1, 2]
+    assert sorted(mle["r_cycle"]) == list(range(product["tau_len"])) and sorted(mle["eq_evals"]) == [0, 1, 2]
+    assert mle["r_cycle"][product["tau_len"] - 1] == product["tau_last"]
     out = {
         "source": "reference logs/zolt.log, STAGE2_* lines of src/zkvm/batched_sumcheck.zig (canonical little-endian hex)",
         "input_claims": [claims[i] for i in range(n)],
@@ -110,6 +121,8 @@ def main():
             "E_in_len": [product["E_in_len"][k] for k in range(3)],
             "first_batch_round": max(rounds_of.values()) - rounds_of[0],
         },
+        "stage1_r_cycle": [mle["r_cycle"][i] for i in range(product["tau_len"])],
+        "eq_evals_of_r_cycle_first3": [mle["eq_evals"][i] for i in range(3)],
     }
     for r in out["rounds"]:
         assert set(r) == {"current_claim", "c0", "c2", "c3", "challenge", "next_claim"}

@@ -112,17 +112,19 @@ def test_gruen_mirror_bind_of_the_captured_run(zl, ob):
     d = json.load(open(os.path.join(U.GOLDEN, "stage2_batched_rounds.json")))
     pr = d["product_remainder"]
     M = lambda h: api.fr_from_int(int.from_bytes(bytes.fromhex(h), "little"))
-    tau = np.stack([api.fr_from_int(1000 + i) for i in range(pr["tau_len"] - 1)] + [M(pr["tau_last"])])
+    tau = np.stack([M(h) for h in d["stage1_r_cycle"]])
     g = api.GruenSplitEqPolynomial.initWithScaling(tau, M(pr["current_scalar_before_round"][0]))
     for k in range(3):
         e_out, e_in, _ = g.getWindowEqTables(0, 1)
         assert (len(e_out), len(e_in)) == (pr["E_out_len"][k], pr["E_in_len"][k])
         d_out, n_out, d_in, n_in = g.getWindowEqTablesDev(1)
         assert (n_out, n_in) == (pr["E_out_len"][k], pr["E_in_len"][k])
-        if k == 1:
-            assert np.array_equal(g.current_scalar, M(pr["current_scalar_before_round"][1]))
+        assert np.array_equal(g.current_scalar, M(pr["current_scalar_before_round"][k]))
         g.bind(M(d["rounds"][pr["first_batch_round"] + k]["challenge"]))
     g.deinit()
+    # the eq table the same run built over these eight challenges for its opening claims: first three of 256 entries are in the log
+    eq = zl.fr_eq_table(tau)
+    assert len(eq) == 256 and all(np.array_equal(eq[i], M(h)) for i, h in enumerate(d["eq_evals_of_r_cycle_first3"]))
 
 
 @pytest.mark.parametrize("n", [0, 1, 2, 7, 8, 13, 24])

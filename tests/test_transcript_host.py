@@ -271,8 +271,8 @@ def test_gruen_split_eq_bind_of_the_captured_run(golden_dir):
     d = json.load(open(os.path.join(golden_dir, "stage2_batched_rounds.json")))
     pr = d["product_remainder"]
     M = lambda h: api.fr_from_int(int.from_bytes(bytes.fromhex(h), "little"))
-    n = pr["tau_len"]
-    tau = np.stack([api.fr_from_int(1000 + i) for i in range(n - 1)] + [M(pr["tau_last"])])  # only tau[7] enters the first bind
+    tau = np.stack([M(h) for h in d["stage1_r_cycle"]])  # tau_low of the Stage-2 split_eq = the Stage-1 r_cycle (evaluation.zig:100-103 prints it)
+    assert len(tau) == pr["tau_len"] and np.array_equal(tau[-1], M(pr["tau_last"]))
     g = ob.GruenSplitEq(tau, M(pr["current_scalar_before_round"][0]))
     e_out, e_in, _ = g.getWindowEqTables(1)
     assert (len(e_out), len(e_in)) == (pr["E_out_len"][0], pr["E_in_len"][0])
@@ -280,13 +280,33 @@ def test_gruen_split_eq_bind_of_the_captured_run(golden_dir):
     assert np.array_equal(g.current_scalar, M(pr["current_scalar_before_round"][1]))
     e_out, e_in, _ = g.getWindowEqTables(1)
     assert (len(e_out), len(e_in)) == (pr["E_out_len"][1], pr["E_in_len"][1])
-    g.bind(M(d["rounds"][pr["first_batch_round"] + 1]["challenge"]))  # tau[6] is not in the log: only the table sizes are held here
+    g.bind(M(d["rounds"][pr["first_batch_round"] + 1]["challenge"]))
+    assert np.array_equal(g.current_scalar, M(pr["current_scalar_before_round"][2]))
     e_out, e_in, _ = g.getWindowEqTables(1)
     assert (len(e_out), len(e_in)) == (pr["E_out_len"][2], pr["E_in_len"][2])
     # the host mirror's scalar step (api.GruenSplitEqPolynomial.bind is this arithmetic on Python integers)
     t, r, s0 = (api.fr_to_int(M(pr["tau_last"])), api.fr_to_int(M(d["rounds"][pr["first_batch_round"]]["challenge"])),
                 api.fr_to_int(M(pr["current_scalar_before_round"][0])))
     assert s0 * ((t * r + (1 - t) * (1 - r)) % api.R_MOD) % api.R_MOD == api.fr_to_int(M(pr["current_scalar_before_round"][1]))
+
+
+def test_eq_table_of_the_captured_opening_claims(golden_dir):
+    """EqPolynomial(r_cycle).evals as R1CSInputEvaluator.computeClaimedInputs built it in the captured run (logs/zolt.log "[ZOLT MLE]",
+    src/zkvm/r1cs/evaluation.zig:86-103): all eight r_cycle challenges and the first three of the 256 table entries are in the log —
+    a reference-produced eq table with every input known; held against the C oracle, the big-int model and (GPU suite) zg_fr_eq_table."""
+    import json
+    import os
+    from zolt_amd import api
+    d = json.load(open(os.path.join(golden_dir, "stage2_batched_rounds.json")))
+    M = lambda h: api.fr_from_int(int.from_bytes(bytes.fromhex(h), "little"))
+    r = np.stack([M(h) for h in d["stage1_r_cycle"]])
+    want = [M(h) for h in d["eq_evals_of_r_cycle_first3"]]
+    eq = ob.fr_eq_table(r)
+    assert len(eq) == 256 and all(np.array_equal(eq[i], want[i]) for i in range(3))
+    assert all(np.array_equal(ob.fr_eq_table_append_lsb(r)[i], want[i]) for i in range(3))
+    ri = [int.from_bytes(bytes.fromhex(h), "little") for h in d["stage1_r_cycle"]]
+    tp = pm.eq_table(ri)
+    assert [int(v) for v in tp[:3]] == [int.from_bytes(bytes.fromhex(h), "little") for h in d["eq_evals_of_r_cycle_first3"]]
 
 
 def test_batched_driver_inactive_instance_rule():
