@@ -98,9 +98,17 @@ def main():
             b = bytes(int(x) for x in m.group(3).replace(" ", "").strip(",").split(","))
             assert len(b) == 32
             mle[m.group(1)].setdefault(int(m.group(2)), b[::-1].hex())  # first occurrence; reversed to little-endian
+    # computeOpeningClaims' eq table (src/zkvm/spartan/product_remainder.zig:396-425, computeEqEvalsGeneric :496-531; printed big-endian):
+    # r_cycle there = the last n_cycle_vars batch challenges reversed; first three entries of its 256-entry table
+    factor_eq = {}
+    for l in lines:
+        m = re.match(r"\[ZOLT\] FACTOR_EVALS: eq_evals\[(\d+)\] = \{ ([0-9, ]+)\}", l)
+        if m:
+            b = bytes(int(x) for x in m.group(2).replace(" ", "").strip(",").split(","))
+            factor_eq.setdefault(int(m.group(1)), b[::-1].hex())
     n = len(claims)
     assert n == 5 and sorted(rounds) == list(range(max(rounds_of.values())))
-    assert sorted(product["current_scalar"]) == [0, 1, 2]
+    assert sorted(product["current_scalar"]) == [0, 1, 2] and sorted(factor_eq) == [0, 1, 2]
     assert sorted(mle["r_cycle"]) == list(range(product["tau_len"])) and sorted(mle["eq_evals"]) == [0, 1, 2]
     assert mle["r_cycle"][product["tau_len"] - 1] == product["tau_last"]
     out = {
@@ -123,6 +131,7 @@ def main():
         },
         "stage1_r_cycle": [mle["r_cycle"][i] for i in range(product["tau_len"])],
         "eq_evals_of_r_cycle_first3": [mle["eq_evals"][i] for i in range(3)],
+        "eq_evals_of_reversed_stage2_challenges_first3": [factor_eq[i] for i in range(3)],
     }
     for r in out["rounds"]:
         assert set(r) == {"current_claim", "c0", "c2", "c3", "challenge", "next_claim"}

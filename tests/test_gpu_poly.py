@@ -125,6 +125,11 @@ def test_gruen_mirror_bind_of_the_captured_run(zl, ob):
     # the eq table the same run built over these eight challenges for its opening claims: first three of 256 entries are in the log
     eq = zl.fr_eq_table(tau)
     assert len(eq) == 256 and all(np.array_equal(eq[i], M(h)) for i, h in enumerate(d["eq_evals_of_r_cycle_first3"]))
+    # and computeOpeningClaims' table over the reversed Stage-2 cycle challenges ("FACTOR_EVALS: eq_evals[k]")
+    first = pr["first_batch_round"]
+    r2 = np.stack([M(d["rounds"][k]["challenge"]) for k in range(len(d["rounds"]) - 1, first - 1, -1)])
+    eq2 = zl.fr_eq_table(r2)
+    assert all(np.array_equal(eq2[i], M(h)) for i, h in enumerate(d["eq_evals_of_reversed_stage2_challenges_first3"]))
 
 
 @pytest.mark.parametrize("n", [0, 1, 2, 7, 8, 13, 24])

@@ -307,6 +307,12 @@ def test_eq_table_of_the_captured_opening_claims(golden_dir):
     ri = [int.from_bytes(bytes.fromhex(h), "little") for h in d["stage1_r_cycle"]]
     tp = pm.eq_table(ri)
     assert [int(v) for v in tp[:3]] == [int.from_bytes(bytes.fromhex(h), "little") for h in d["eq_evals_of_r_cycle_first3"]]
+    # a second one: computeOpeningClaims' table over the Stage-2 cycle challenges (batch rounds 16..23, reversed to MSB-first order;
+    # logs/zolt.log "FACTOR_EVALS: eq_evals[k]", src/zkvm/spartan/product_remainder.zig:396-425,496-531)
+    first = d["product_remainder"]["first_batch_round"]
+    r2 = np.stack([M(d["rounds"][k]["challenge"]) for k in range(len(d["rounds"]) - 1, first - 1, -1)])
+    eq2 = ob.fr_eq_table(r2)
+    assert len(eq2) == 256 and all(np.array_equal(eq2[i], M(h)) for i, h in enumerate(d["eq_evals_of_reversed_stage2_challenges_first3"]))
 
 
 def test_batched_driver_inactive_instance_rule():
