@@ -106,6 +106,34 @@ def main():
         if m:
             b = bytes(int(x) for x in m.group(2).replace(" ", "").strip(",").split(","))
             factor_eq.setdefault(int(m.group(1)), b[::-1].hex())
+    # OutputSumcheckProver (instance 3, rounds 8.. of the batch; src/zkvm/ram/output_check.zig:100-365 init, :586-609 eq table, printed
+    # big-endian): its r_address, the region bounds it derived, and the five folded tables' final values after its 16 rounds
+    oc = {"r_address": {}, "final": {}}
+    for l in lines:
+        m = re.match(r"\[ZOLT OUTPUT_CHECK\]\s+r_address\[(\d+)\] = \{ ([0-9, ]+)\}", l)
+        if m:
+            oc["r_address"].setdefault(int(m.group(1)), bytes(int(x) for x in m.group(2).replace(" ", "").strip(",").split(","))[::-1].hex())
+            continue
+        m = re.match(r"\[ZOLT OUTPUT_CHECK\] (val_final|val_init|val_io|eq_r_address|io_mask)\[0\]: \{ ([0-9, ]+)\}", l)
+        if m:
+            oc["final"].setdefault(m.group(1), bytes(int(x) for x in m.group(2).replace(" ", "").strip(",").split(","))[::-1].hex())
+            continue
+        m = re.match(r"\[ZOLT\] OutputSumcheck: lowest=0x[0-9A-Fa-f]+, io_start=(\d+), io_end=(\d+)", l)
+        if m:
+            oc["io_start"], oc["io_end"] = int(m.group(1)), int(m.group(2))
+            continue
+        m = re.match(r"\[ZOLT\] OutputSumcheck: termination_index=(\d+)", l)
+        if m:
+            oc["termination_index"] = int(m.group(1))
+            continue
+        m = re.match(r"\[ZOLT\] OutputSumcheck: final_ram non_zero_count=(\d+), io_region_values=(\d+), K=(\d+)", l)
+        if m:
+            oc["ram_words"], oc["K"] = int(m.group(1)), int(m.group(3))
+            continue
+        m = re.match(r"\[ZOLT\] OutputSumcheck: initial_ram k=(\d+), addr=0x80000000,", l)
+        if m:
+            oc["first_ram_index"] = int(m.group(1))
+    assert sorted(oc["r_address"]) == list(range(16)) and len(oc["final"]) == 5 and oc["K"] == 1 << 16
     n = len(claims)
     assert n == 5 and sorted(rounds) == list(range(max(rounds_of.values())))
     assert sorted(product["current_scalar"]) == [0, 1, 2] and sorted(factor_eq) == [0, 1, 2]
@@ -132,6 +160,17 @@ def main():
         "stage1_r_cycle": [mle["r_cycle"][i] for i in range(product["tau_len"])],
         "eq_evals_of_r_cycle_first3": [mle["eq_evals"][i] for i in range(3)],
         "eq_evals_of_reversed_stage2_challenges_first3": [factor_eq[i] for i in range(3)],
+        "output_check": {
+            "K": oc["K"],
+            "io_start": oc["io_start"],
+            "io_end": oc["io_end"],
+            "termination_index": oc["termination_index"],
+            "first_ram_index": oc["first_ram_index"],
+            "ram_words": oc["ram_words"],
+            "r_address": [oc["r_address"][i] for i in range(16)],
+            "final": oc["final"],
+            "first_batch_round": max(rounds_of.values()) - rounds_of[3],
+        },
     }
     for r in out["rounds"]:
         assert set(r) == {"current_claim", "c0", "c2", "c3", "challenge", "next_claim"}

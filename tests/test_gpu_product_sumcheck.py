@@ -148,6 +148,34 @@ def test_output_sumcheck_prover(env, v):
     g.deinit()
 
 
+def test_output_sumcheck_of_the_captured_run(env, golden_dir):
+    """The reference's own OutputSumcheck instance (Stage-2 instance 3 of its captured fibonacci run, logs/zolt.log "[ZOLT OUTPUT_CHECK]" /
+    "OutputSumcheck:" lines of src/zkvm/ram/output_check.zig:100-365): every input is in the log or the ELF — r_address, the region
+    bounds, the 13 program words — so the five 2^16-entry tables are rebuilt, the eq table comes from zg_fr_eq_table, the prover
+    runs its 16 rounds on the device with the challenges the reference drew (batch rounds 8..23), and the five folded finals plus
+    the running claim are held against what the reference printed. No oracle in between."""
+    import json
+    import os
+    api, lib, ob = env
+    d = json.load(open(os.path.join(golden_dir, "stage2_batched_rounds.json")))
+    oc = d["output_check"]
+    M = lambda h: api.fr_from_int(int.from_bytes(bytes.fromhex(h), "little"))
+    elf = open(os.path.join(golden_dir, "fibonacci.elf"), "rb").read()
+    tabs = U.output_check_tables_of_the_captured_run(oc, elf, api.fr_from_int, lib.fr_eq_table)
+    assert int.from_bytes(bytes.fromhex(d["input_claims"][3]), "little") == 0
+    g = api.OutputSumcheckProver(*tabs, api.fr_from_int(0))
+    for k in range(d["num_rounds"][3]):
+        ev = g.roundEvals()
+        assert (api.fr_to_int(ev[0]) + api.fr_to_int(ev[1])) % api.R_MOD == api.fr_to_int(g.current_claim), k
+        c = M(d["rounds"][oc["first_batch_round"] + k]["challenge"])
+        g.updateClaim(ev, c)
+        g.bindChallenge(c)
+    f = g.getFinalClaims()
+    assert sorted(f) == sorted(oc["final"]) and all(np.array_equal(f[k], M(h)) for k, h in oc["final"].items())
+    assert np.array_equal(g.current_claim, M(d["instance_final_claims"][3]))
+    g.deinit()
+
+
 @pytest.mark.parametrize("v", [1, 3, 8, 13, 16])
 def test_instruction_lookups_claim_reduction_prover(env, v):
     """with a consistent initial claim the s(0) + s(1) = claim chain holds through every round, as in the reference's run"""

@@ -315,6 +315,36 @@ def test_eq_table_of_the_captured_opening_claims(golden_dir):
     assert len(eq2) == 256 and all(np.array_equal(eq2[i], M(h)) for i, h in enumerate(d["eq_evals_of_reversed_stage2_challenges_first3"]))
 
 
+def test_output_sumcheck_of_the_captured_run(golden_dir):
+    """OutputSumcheckProver as the reference ran it (Stage-2 instance 3 of the captured fibonacci run): the tables rebuilt from the
+    log's own statements and the ELF (tests/util.output_check_tables_of_the_captured_run), 16 rounds with the reference's
+    challenges; the oracle's five folded finals and its running claim must be the values the reference printed
+    (logs/zolt.log "[ZOLT OUTPUT_CHECK] val_final[0] ... io_mask[0]", "inst3 individual_claims"). Pins zo_output_check_round,
+    zo_output_check_update_claim, the LowToHigh fold and the eq table's variable order in one go; the GPU suite runs the same on
+    the device path."""
+    import json
+    import os
+    from zolt_amd import api
+    d = json.load(open(os.path.join(golden_dir, "stage2_batched_rounds.json")))
+    oc = d["output_check"]
+    M = lambda h: api.fr_from_int(int.from_bytes(bytes.fromhex(h), "little"))
+    elf = open(os.path.join(golden_dir, "fibonacci.elf"), "rb").read()
+    tabs = U.output_check_tables_of_the_captured_run(oc, elf, api.fr_from_int, ob.fr_eq_table)
+    p = ob.OutputSumcheckProver(*tabs, api.fr_from_int(0))
+    for k in range(d["num_rounds"][3]):
+        ev = p.roundEvals()
+        assert (api.fr_to_int(ev[0]) + api.fr_to_int(ev[1])) % api.R_MOD == api.fr_to_int(p.current_claim), k
+        c = M(d["rounds"][oc["first_batch_round"] + k]["challenge"])
+        p.updateClaim(ev, c)
+        p.bindChallenge(c)
+    f = p.getFinalClaims()
+    assert sorted(f) == sorted(oc["final"]) and all(np.array_equal(f[k], M(h)) for k, h in oc["final"].items())
+    assert np.array_equal(p.current_claim, M(d["instance_final_claims"][3]))
+    # eq * io_mask * (val_final - val_io) at the bound point = that claim (output_check.zig "expected (eq * io_mask * diff)")
+    I = lambda k: api.fr_to_int(f[k])
+    assert I("eq_r_address") * I("io_mask") % api.R_MOD * ((I("val_final") - I("val_io")) % api.R_MOD) % api.R_MOD == api.fr_to_int(p.current_claim)
+
+
 def test_batched_driver_inactive_instance_rule():
     """Which constant does an instance contribute before its first round? The loop `zolt prove` runs (src/zkvm/proof_converter.zig:
     3330-3343) uses coeff * claim * 2^(start - round - 1): twice that is the instance's share of the claim, so s(0) + s(1) = claim in

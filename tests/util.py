@@ -122,3 +122,26 @@ def fibonacci_rd_values(elf_bytes, steps=54):
         pc = npc
     assert pc == 0x80000010 and regs[10] == 55  # back in the `j .` loop with fib = 55 in a0
     return vals
+
+
+def output_check_tables_of_the_captured_run(oc, elf_bytes, fr_from_int, eq_table):
+    """The five tables OutputSumcheckProver.init (src/zkvm/ram/output_check.zig:100-365) built in the reference's captured fibonacci
+    run, from what logs/zolt.log states about it (tests/golden/stage2_batched_rounds.json "output_check"): K = 2^16 words; the 13
+    program words (the ELF's 104 code bytes as little-endian u64) at index 4096.. in both val_init and val_final; no inputs, no
+    outputs, panic bit 0; the termination bit 1 in val_final and val_io only; io_mask = 1 on [io_start, io_end); eq table of
+    r_address with r[0] the most significant variable (:586-609). Returns (eq, io_mask, val_final, val_io, val_init) as (K,4) limbs."""
+    import struct
+    K = oc["K"]
+    zero, one = fr_from_int(0), fr_from_int(1)
+    words = struct.unpack("<%dQ" % oc["ram_words"], elf_bytes[0x1000:0x1000 + 8 * oc["ram_words"]])
+    val_init = np.tile(zero, (K, 1))
+    for i, w in enumerate(words):
+        val_init[oc["first_ram_index"] + i] = fr_from_int(w)
+    val_final = val_init.copy()
+    val_final[oc["termination_index"]] = one
+    val_io = np.tile(zero, (K, 1))
+    val_io[oc["termination_index"]] = one
+    io_mask = np.tile(zero, (K, 1))
+    io_mask[oc["io_start"]:oc["io_end"]] = one
+    r = np.stack([fr_from_int(int.from_bytes(bytes.fromhex(h), "little")) for h in oc["r_address"]])
+    return eq_table(r), io_mask, val_final, val_io, val_init
