@@ -1,0 +1,152 @@
+"""The fold kernels' narrow-factor path (fp29.hip.h FrMul): the reference's sumcheck challenges are MontU128Challenge values whose stored
+Montgomery element is [0, 0, lo, hi] (tests/golden/stage2_batched_rounds.json holds 24 of them), and a fold by such a challenge takes a
+9 x 5-limb product with five reduction steps instead of 9 x 9 with nine. The result must not depend on which form ran: every fold site
+— the single-table session in both layouts, the product-form session's plain fold, its fused fold + evaluations and its fused
+fold + expression — is held against the oracle's bind with narrow challenges, including the extreme ones."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+
+R_TOP = 0x30644E72E131A029  # top u64 limb of r: [0, 0, lo, hi] is a canonical element for hi < R_TOP
+
+
+@pytest.fixture(scope="module")
+def env():
+    from oracle import binding as ob
+    from zolt_amd import api, lib
+    lib.init()
+    return api, lib, ob
+
+
+def _rand(ob, seed, n):
+    return ob.f_to_mont(ob.FR, U.random_raw256(seed, n))
+
+
+def narrow(seed, n):
+    """n stored elements [0, 0, lo, hi]: 125-bit ones like the transcript's (hi < 2^61), with the extremes in front"""
+    w = U.splitmix64(seed, 2 * n).reshape(n, 2)
+    out = np.zeros((n, 4), dtype=np.uint64)
+    out[:, 2] = w[:, 0]
+    out[:, 3] = w[:, 1] & np.uint64((1 << 61) - 1)
+    edge = [(0, 0), (1, 0), (0, 1), ((1 << 64) - 1, (1 << 61) - 1), ((1 << 64) - 1, R_TOP - 1), (0, 1 << 60)]
+    for i, (lo, hi) in enumerate(edge[:n]):
+        out[i, 2], out[i, 3] = lo, hi
+    return out
+
+
+def test_narrow_elements_are_canonical(env):
+    api, lib, ob = env
+    for row in narrow(1, 16):
+        assert int(row[0]) == 0 and int(row[1]) == 0 and sum(int(row[i]) << (64 * i) for i in range(4)) < api.R_MOD
+
+
+@pytest.mark.parametrize("v,layout", [(1, 0), (2, 1), (7, 0), (8, 1), (13, 0), (16, 1), (18, 0)])
+def test_session_folds_with_narrow_challenges(env, v, layout):
+    api, lib, ob = env
+    t = _rand(ob, 9100 + v, 1 << v)
+    s = lib.SumcheckSession.open(t, lib.SC_HIGH_HALF if layout == 0 else lib.SC_LOW_PAIR)
+    ch = narrow(9200 + v, v)
+    cur = t
+    for k in range(v):
+        g0, g1 = s.round_sums()
+        w0, w1 = ob.fr_sum_halves(cur) if layout == 0 else ob.fr_sum_even_odd(cur)
+        assert np.array_equal(g0, w0) and np.array_equal(g1, w1), k
+        s.bind(ch[k])
+        cur = ob.fr_bind_high(cur, ch[k]) if layout == 0 else ob.fr_bind_low(cur, ch[k])
+        assert hashlib.sha256(s.read().tobytes()).digest() == hashlib.sha256(cur.tobytes()).digest(), k
+    assert np.array_equal(s.final(), cur[0])
+    s.close()
+
+
+def test_long_fold_narrow_and_wide_agree_with_the_oracle(env):
+    """2^23 entries (the 1024-thread launch): one narrow and one full-width fold of the same table, both against the oracle"""
+    api, lib, ob = env
+    v = 23
+    t = _rand(ob, 9300, 1 << v)
+    for r in (narrow(9301, 8)[7], narrow(9301, 8)[4], _rand(ob, 9302, 1)[0]):
+        s = lib.SumcheckSession.open(t, lib.SC_LOW_PAIR)
+        s.bind(r)
+        want = ob.fr_bind_low(t, r)
+        assert hashlib.sha256(s.read().tobytes()).digest() == hashlib.sha256(want.tobytes()).digest()
+        g0, g1 = s.round_sums()
+        w0, w1 = ob.fr_sum_even_odd(want)
+        assert np.array_equal(g0, w0) and np.array_equal(g1, w1)
+        s.close()
+
+
+@pytest.mark.parametrize("v", [1, 2, 6, 11, 15])
+def test_product_session_plain_fold_with_narrow_challenges(env, v):
+    """zg_psc_bind with no cached evaluation spec: psc_fold_kernel over every table"""
+    api, lib, ob = env
+    tabs = [_rand(ob, 9400 + 10 * j + v, 1 << v) for j in range(5)]
+    s = lib.ProductSumcheckSession.open(tabs)
+    ch = narrow(9450 + v, v)
+    cur = tabs
+    for k in range(v):
+        s.bind(ch[k])
+        cur = [ob.fr_bind_low(t, ch[k]) for t in cur]
+        for j in range(5):
+            assert np.array_equal(s.read(j), cur[j]), (k, j)
+    s.close()
+
+
+@pytest.mark.parametrize("v", [1, 3, 9, 14])
+def test_prover_loops_with_narrow_challenges(env, v):
+    """the fused fold + evaluations (ValEvaluation, InstructionLookups, Output) and fold + expression (InstructionInput) kernels"""
+    api, lib, ob = env
+    n = 1 << v
+    ch = narrow(9500 + v, v)
+    inc, wa, lt = (_rand(ob, 9510 + j + 10 * v, n) for j in range(3))
+    claim = _rand(ob, 9520 + v, 1)[0]
+    g, o = api.ValEvaluationProver(inc, wa, lt, claim), ob.ValEvaluationProver(inc, wa, lt, claim)
+    for k in range(v):
+        rp, wrp = g.computeRoundPolynomial(), o.computeRoundPolynomial()
+        assert np.array_equal(rp, wrp), k
+        g.bindChallengeWithPoly(ch[k], rp)
+        o.bindChallengeWithPoly(ch[k], wrp)
+        assert np.array_equal(g.current_claim, o.current_claim)
+    assert all(np.array_equal(a, b) for a, b in zip(g.getFinalClaims(), o.getFinalClaims()))
+    g.deinit()
+
+    tabs = [_rand(ob, 9530 + j + 10 * v, n) for j in range(4)]
+    gamma = _rand(ob, 9540 + v, 1)[0]
+    g = api.InstructionLookupsClaimReductionProver(*tabs, gamma, claim)
+    o = ob.InstructionLookupsClaimReduction(*tabs, gamma, claim)
+    for k in range(v):
+        ev, wev = g.computeRoundPolynomialCubic(), o.computeRoundPolynomialCubic()
+        assert np.array_equal(ev, wev), k
+        g.bindChallenge(ch[k]); o.bindChallenge(ch[k])
+        g.updateClaim(ev, ch[k]); o.updateClaim(wev, ch[k])
+        assert np.array_equal(g.current_claim, o.current_claim)
+    fg, fo = g.getOpeningClaims(), o.getOpeningClaims()
+    assert all(np.array_equal(fg[name], fo[name]) for name in fo)
+    g.deinit()
+
+    tabs = [_rand(ob, 9550 + j + 10 * v, n) for j in range(5)]
+    g, o = api.OutputSumcheckProver(*tabs, claim), ob.OutputSumcheckProver(*tabs, claim)
+    for k in range(v):
+        ev, wev = g.roundEvals(), o.roundEvals()
+        assert np.array_equal(ev, wev), k
+        g.bindChallenge(ch[k]); o.bindChallenge(ch[k])
+    fg, fo = g.getFinalClaims(), o.getFinalClaims()
+    assert all(np.array_equal(fg[name], fo[name]) for name in fo)
+    g.deinit()
+
+    tabs = [_rand(ob, 9560 + j + 10 * v, n) for j in range(len(api.InstructionInputProver.NAMES))]
+    g = api.InstructionInputProver(tabs, gamma)
+    cur = [t.copy() for t in tabs]
+    c = claim
+    for k in range(v):
+        got, want = g.computeRoundEvals(c), ob.instruction_input_round(cur, gamma, c)
+        assert np.array_equal(got, want), k
+        g.bind(ch[k])
+        cur = [ob.fr_bind_low(t, ch[k]) for t in cur]
+        c = ob.raf_update_claim(want, ch[k])
+    fc = g.finalClaims()
+    assert all(np.array_equal(fc[name], cur[j][0]) for j, name in enumerate(api.InstructionInputProver.NAMES))
+    g.deinit()

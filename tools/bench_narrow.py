@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Full-width against narrow challenges ([0, 0, lo, hi], the reference's stored MontU128Challenge) at the fold sites, host-timed, median
+of 5 sessions: usage bench_narrow.py [v=22]. A fold by a narrow challenge takes the 9 x 5-limb product (fp29.hip.h FrMul)."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    from bench import raw_scalars
+    from zolt_amd import lib
+    lib.init(0)
+    v = int(sys.argv[1]) if len(sys.argv) > 1 else 22
+    n = 1 << v
+    tab = lib.field_op(lib.FR, lib.OP_TO_MONT, raw_scalars(0x4E415252, 0, n))
+    wide = tab[7].copy()
+    nar = tab[7].copy()
+    nar[:2] = 0
+    nar[3] &= np.uint64((1 << 61) - 1)
+    d = lib.DeviceBuffer.from_host(tab)
+    out = {"v": v}
+
+    def fold_once(ch):
+        s = lib.SumcheckSession.open_dev(d.ptr, n, lib.SC_LOW_PAIR)
+        s.round_sums()
+        t0 = time.perf_counter()
+        s.bind(ch)
+        s.round_sums()
+        dt = time.perf_counter() - t0
+        s.close()
+        return dt
+
+    def psc_once(ch, k, spec):
+        s = lib.ProductSumcheckSession.open_dev([d.ptr] * k, n)
+        spec(s)
+        t0 = time.perf_counter()
+        s.bind(ch)
+        spec(s)
+        dt = time.perf_counter() - t0
+        s.close()
+        return dt
+
+    def med(f):
+        f()
+        return round(1e6 * float(np.median([f() for _ in range(5)])), 1)
+
+    for name, ch in (("wide", wide), ("narrow", nar)):
+        out[f"session_fold_{name}_us"] = med(lambda: fold_once(ch))
+        out[f"psc_fold_evals_p3_{name}_us"] = med(lambda: psc_once(ch, 3, lambda s: s.round_evals((0, 1, 2))))
+        out[f"psc_fold_evals_p1q3_{name}_us"] = med(lambda: psc_once(ch, 4, lambda s: s.round_evals((0,), (1, 2, 3), tab[:3])))
+        out[f"psc_fold_expr_instruction_input_{name}_us"] = med(lambda: psc_once(ch, 10, lambda s: s.round_expr(
+            [((8, 0), (1, 2), tab[:2]), ((8, 3), (4, 5), tab[:2]), ((9, 0), (1, 2), tab[2:4]), ((9, 3), (4, 5), tab[2:4])])))
+        out[f"psc_plain_fold_5_tables_{name}_us"] = med(lambda: psc_once(ch, 5, lambda s: None))
+    print(out)
+
+
+if __name__ == "__main__":
+    main()

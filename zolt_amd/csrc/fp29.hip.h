@@ -460,6 +460,56 @@ ZG_DEV Fr fr29_out(const F29 &t) {
     f29_pack(r, out.l);
     return out;
 }
+// ---- narrow shared factors. The reference's sumcheck challenges are MontU128Challenge values: the stored Montgomery element is
+// [0, 0, lo, hi] (src/transcripts: challengeScalar; tests/golden/stage2_batched_rounds.json), i.e. y = H * 2^128 with H < 2^126.
+// Then x * y * 2^-256 = x * H * 2^-128 = x * (H * 2^17) * 2^-145: a 9 x 5-limb product and FIVE reduction steps instead of
+// 9 x 9 and nine — 90 multiply-adds instead of 162 (the reference takes the same shortcut in its own multiplier). The output is
+// < x * H / 2^128 + r < 2 r with exact limbs, as fr29_out expects. FrMul picks the form once per launch from the factor itself;
+// any other factor takes the full-width path, so the result never depends on the choice.
+template <class C29, int NB>
+ZG_DEV F29 f29t_mul_short(const F29 &a, const F29 &b) {  // b: NB limbs used
+    u32 m[NB];
+    F29 r;
+    u64 acc = 0;
+#pragma unroll
+    for (int k = 0; k < 9 + NB - 1; k++) {
+#pragma unroll
+        for (int i = (k > NB - 1 ? k - (NB - 1) : 0); i <= (k < 8 ? k : 8); i++) acc = mad64(a.l[i], b.l[k - i], acc);
+#pragma unroll
+        for (int i = (k > 8 ? k - 8 : 0); i <= (k < NB ? k - 1 : NB - 1); i++) acc = mad64k(m[i], C29::P[k - i], acc);
+        if (k < NB) {
+            m[k] = ((u32)acc * C29::NINV) & C29::MASK;
+            acc = mad64k(m[k], C29::P[0], acc);
+        } else {
+            r.l[k - NB] = (u32)acc & C29::MASK;
+        }
+        acc >>= 29;
+    }
+    r.l[8] = (u32)acc;
+    return r;
+}
+struct FrMul {
+    F29 p;
+    bool narrow;
+};
+ZG_DEV FrMul frmul_prepare(const Fr &y) {
+    FrMul m;
+    m.narrow = (y.l[0] | y.l[1] | y.l[2] | y.l[3]) == 0;
+    if (m.narrow) {  // H * 2^17 < 2^145: five limbs
+        u32 w[8] = {y.l[4] << 17, (y.l[5] << 17) | (y.l[4] >> 15), (y.l[6] << 17) | (y.l[5] >> 15), (y.l[7] << 17) | (y.l[6] >> 15),
+                    y.l[7] >> 15, 0u, 0u, 0u};
+        m.p = f29_unpack(w);
+    } else {
+        m.p = fr29_prescale(y);
+    }
+    return m;
+}
+ZG_DEV Fr frmul_apply(const Fr &x, const FrMul &m) {
+    F29 xu = f29_unpack(x.l);
+    F29 t = m.narrow ? f29t_mul_short<Fr29, 5>(xu, m.p) : f29t_mul<Fr29>(xu, m.p);
+    return fr29_out(t);
+}
+
 // limb-wise sum of lazy chain values in 64-bit words: at most FR29_ACC_MAX values (< 2 r each) between two reductions
 struct Acc29 {
     u64 l[9];

@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(1024) sc_fold_kernel(const uint64_t *t, size_t
 #pragma unroll
         for (int i = 0; i < 8; i++) rv.l[i] = r.l[i];
     }
-    F29 rp = fr29_prescale(rv);  // the challenge is the shared factor of every product of this launch
+    FrMul rp = frmul_prepare(rv);  // the challenge is the shared factor of every product of this launch (narrow form for a 128-bit one)
     Fr g0 = Fr::zero(), g1 = Fr::zero();
     size_t stride = (size_t)gridDim.x * blockDim.x;
     size_t quarter = half / 2;
@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(1024) sc_fold_kernel(const uint64_t *t, size_t
             nlo = fe_load<FrParams>(LAYOUT == ZG_SC_HIGH_HALF ? t + 4 * ni : t + 8 * ni);
             nhi = fe_load<FrParams>(LAYOUT == ZG_SC_HIGH_HALF ? t + 4 * (ni + half) : t + 8 * ni + 4);
         }
-        Fr v = fe_add(lo, fr_mul29(fe_sub(hi, lo), rp));  // (1-r)*lo + r*hi = lo + r*(hi - lo): one product, same value
+        Fr v = fe_add(lo, frmul_apply(fe_sub(hi, lo), rp));  // (1-r)*lo + r*hi = lo + r*(hi - lo): one product, same value
         fe_store(out + 4 * i, v);
         bool second = LAYOUT == ZG_SC_HIGH_HALF ? (i >= quarter) : (i & 1);
         if (second) g1 = fe_add(g1, v);

@@ -256,14 +256,14 @@ __global__ void __launch_bounds__(256) psc_fold_kernel(const uint64_t *base, siz
     Fr rv;
 #pragma unroll
     for (int i = 0; i < 8; i++) rv.l[i] = r.l[i];
-    F29 rp = fr29_prescale(rv);
+    FrMul rp = frmul_prepare(rv);
     const uint32_t table = which.t[blockIdx.y];
     const uint64_t *t = base + 4 * (size_t)table * stride;
     uint64_t *o = out + 4 * (size_t)table * ostride;
     size_t step = (size_t)gridDim.x * 256;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < half; i += step) {
         Fr lo = fe_load<FrParams>(t + 8 * i), hi = fe_load<FrParams>(t + 8 * i + 4);
-        fe_store(o + 4 * i, fe_add(lo, fr_mul29(fe_sub(hi, lo), rp)));
+        fe_store(o + 4 * i, fe_add(lo, frmul_apply(fe_sub(hi, lo), rp)));
     }
 }
 
@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(256) psc_fold_evals_kernel(const uint64_t *bas
     Fr rv;
 #pragma unroll
     for (int i = 0; i < 8; i++) rv.l[i] = r.l[i];
-    F29 rp = fr29_prescale(rv);
+    FrMul rp = frmul_prepare(rv);
     F29 cp[Q > 0 ? Q : 1];
     if constexpr (Q > 0) {
         static_for<0, Q>([&](auto mc) {
@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(256) psc_fold_evals_kernel(const uint64_t *bas
                 constexpr int m = decltype(mc)::value;
                 const uint64_t *t = base + 4 * ((size_t)spec.lin[m] * stride + 4 * g);
                 Fr a0 = fe_load<FrParams>(t), a1 = fe_load<FrParams>(t + 4), a2 = fe_load<FrParams>(t + 8), a3 = fe_load<FrParams>(t + 12);
-                Fr lo = fe_add(a0, fr_mul29(fe_sub(a1, a0), rp)), hi = fe_add(a2, fr_mul29(fe_sub(a3, a2), rp));
+                Fr lo = fe_add(a0, frmul_apply(fe_sub(a1, a0), rp)), hi = fe_add(a2, frmul_apply(fe_sub(a3, a2), rp));
                 uint64_t *o = out + 4 * ((size_t)spec.lin[m] * ostride + 2 * g);
                 fe_store(o, lo);
                 fe_store(o + 4, hi);
@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(256) psc_fold_evals_kernel(const uint64_t *bas
             constexpr int j = decltype(jc)::value;
             const uint64_t *t = base + 4 * ((size_t)spec.prod[j] * stride + 4 * g);
             Fr a0 = fe_load<FrParams>(t), a1 = fe_load<FrParams>(t + 4), a2 = fe_load<FrParams>(t + 8), a3 = fe_load<FrParams>(t + 12);
-            Fr lo = fe_add(a0, fr_mul29(fe_sub(a1, a0), rp)), hi = fe_add(a2, fr_mul29(fe_sub(a3, a2), rp));
+            Fr lo = fe_add(a0, frmul_apply(fe_sub(a1, a0), rp)), hi = fe_add(a2, frmul_apply(fe_sub(a3, a2), rp));
             uint64_t *o = out + 4 * ((size_t)spec.prod[j] * ostride + 2 * g);
             fe_store(o, lo);
             fe_store(o + 4, hi);
@@ -362,12 +362,13 @@ template <bool FOLD>
 __global__ void __launch_bounds__(256) psc_expr_kernel(const uint64_t *base, size_t stride, size_t n_pairs, FrArg r, uint64_t *out, size_t ostride,
                                                        PscExpr ex, uint64_t *partials, uint64_t *sums, uint32_t *counter, uint64_t *flag, uint64_t seq) {
     __shared__ uint4 sh[256 * 4];
-    F29 rp;
+    FrMul rp;
+    rp.narrow = false;
     if (FOLD) {
         Fr rv;
 #pragma unroll
         for (int i = 0; i < 8; i++) rv.l[i] = r.l[i];
-        rp = fr29_prescale(rv);
+        rp = frmul_prepare(rv);
     }
     Fr e[4] = {Fr::zero(), Fr::zero(), Fr::zero(), Fr::zero()};
     ChainAcc4 acc;
@@ -386,8 +387,8 @@ __global__ void __launch_bounds__(256) psc_expr_kernel(const uint64_t *base, siz
                 if (FOLD) {
                     const uint64_t *t = base + 4 * ((size_t)table * stride + 4 * g);
                     Fr a0 = fe_load<FrParams>(t), a1 = fe_load<FrParams>(t + 4), a2 = fe_load<FrParams>(t + 8), a3 = fe_load<FrParams>(t + 12);
-                    lo = fe_add(a0, fr_mul29(fe_sub(a1, a0), rp));
-                    hi = fe_add(a2, fr_mul29(fe_sub(a3, a2), rp));
+                    lo = fe_add(a0, frmul_apply(fe_sub(a1, a0), rp));
+                    hi = fe_add(a2, frmul_apply(fe_sub(a3, a2), rp));
                     uint64_t *o = out + 4 * ((size_t)table * ostride + 2 * g);
                     fe_store(o, lo);
                     fe_store(o + 4, hi);
