@@ -150,3 +150,42 @@ def test_prover_loops_with_narrow_challenges(env, v):
     fc = g.finalClaims()
     assert all(np.array_equal(fc[name], cur[j][0]) for j, name in enumerate(api.InstructionInputProver.NAMES))
     g.deinit()
+
+
+@pytest.mark.parametrize("log_T,log_K,n", [(2, 3, 4), (8, 16, 200), (14, 32, 16384)])
+def test_lasso_prover_with_narrow_challenges(env, log_T, log_K, n):
+    """bit_bind_kernel's narrow form (v * r by the short product, v * (1 - r) as v - v * r) and the cycle-phase folds"""
+    api, lib, ob = env
+    w = _rand(ob, 9600 + log_T, log_T)
+    idx = U.splitmix64(9601 + log_T, 2 * n).reshape(-1, 2).copy()
+    mask = (1 << log_K) - 1
+    idx[:, 0] &= np.uint64(mask & (2**64 - 1))
+    idx[:, 1] &= np.uint64(mask >> 64)
+    g, o = api.LassoProver(idx, log_T, log_K, w), ob.LassoProver(idx, log_T, log_K, w)
+    ch = narrow(9602 + log_T, log_T + log_K)
+    for rnd in range(log_T + log_K):
+        assert np.array_equal(g.computeRoundPolynomial(), o.computeRoundPolynomial()), rnd
+        g.receiveChallenge(ch[rnd])
+        o.receiveChallenge(ch[rnd])
+        assert np.array_equal(g.current_claim, o.current_claim), rnd
+        if rnd % 5 == 0 or rnd >= log_K:
+            assert np.array_equal(g.eq_evals(), o.eq_evals[:o.eq_evals_len]), rnd
+    assert np.array_equal(g.getFinalEval(), o.getFinalEval())
+    g.deinit()
+
+
+@pytest.mark.parametrize("v,srs_n", [(10, 1024), (14, 16384), (17, 1 << 17)])
+def test_hyperkzg_open_at_a_narrow_point(env, v, srs_n):
+    """HyperKZG.open folds by the opening point's coordinates (hk_quot_fold_kernel): sumcheck challenges in the reference's flow"""
+    api, lib, ob = env
+    gm = ob.g1_gen_multiples(srs_n)
+    inf = np.zeros(srs_n, dtype=np.uint8)
+    params = api.HyperKZG.SetupParams(gm, inf)
+    ev = _rand(ob, 9700 + v, 1 << v)
+    pt = narrow(9710 + v, v)
+    quotients, final = api.HyperKZG.open(params, ev, pt, np.zeros(4, dtype=np.uint64))
+    wq, wqi, wfin = ob.hyperkzg_open(gm, inf, ev, pt, np.zeros(4, dtype=np.uint64))
+    assert np.array_equal(final, wfin) and len(quotients) == v
+    for i, (q, qi) in enumerate(quotients):
+        assert qi == wqi[i] and np.array_equal(q, wq[i]), i
+    params.deinit()

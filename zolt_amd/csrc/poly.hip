@@ -295,13 +295,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(56))) hk_q
     Fr rv;
 #pragma unroll
     for (int i = 0; i < 8; i++) rv.l[i] = r.l[i];
-    F29 rp = fr29_prescale(rv);
+    FrMul rp = frmul_prepare(rv);
     size_t stride = (size_t)gridDim.x * 256;
     for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < half; j += stride) {
         Fr lo = fe_load<FrParams>(t + 4 * j), hi = fe_load<FrParams>(t + 4 * (j + half));
         Fr d = fe_sub(hi, lo);
         if (j < q_count) fe_store(q + 4 * j, d);
-        fe_store(out + 4 * j, fe_add(lo, fr_mul29(d, rp)));
+        fe_store(out + 4 * j, fe_add(lo, frmul_apply(d, rp)));
     }
 }
 
@@ -565,14 +565,21 @@ __global__ void __launch_bounds__(256) bit_bind_kernel(uint64_t *t, const uint64
     Fr rv;
 #pragma unroll
     for (int i = 0; i < 8; i++) rv.l[i] = r.l[i];
-    F29 rp = fr29_prescale(rv), omrp = fr29_prescale(fe_sub(Fr::one(), rv));
+    // a narrow challenge (FrMul): v * r by the short product and v * (1 - r) = v - v * r — the same canonical value, 90 multiply-adds
+    FrMul rm = frmul_prepare(rv);
+    F29 omrp = fr29_prescale(fe_sub(Fr::one(), rv));
     Fr g0 = Fr::zero(), g1 = Fr::zero();
     size_t stride = (size_t)gridDim.x * 256;
     const uint32_t w0 = bit >> 6, s0 = bit & 63u, w1 = next_bit >> 6, s1 = next_bit & 63u;
     for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < n; j += stride) {
         Fr v = fe_load<FrParams>(t + 4 * j);
         uint64_t a = idx[2 * j + w0], b = w1 == w0 ? a : idx[2 * j + w1];
-        v = ((a >> s0) & 1ull) ? fr_mul29(v, rp) : fr_mul29(v, omrp);
+        if (rm.narrow) {
+            Fr vr = frmul_apply(v, rm);
+            v = ((a >> s0) & 1ull) ? vr : fe_sub(v, vr);
+        } else {
+            v = ((a >> s0) & 1ull) ? fr_mul29(v, rm.p) : fr_mul29(v, omrp);
+        }
         fe_store(t + 4 * j, v);
         if ((b >> s1) & 1ull) g1 = fe_add(g1, v);
         else g0 = fe_add(g0, v);
