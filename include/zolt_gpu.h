@@ -339,6 +339,12 @@ typedef struct {
     uint64_t lin_coeff[16]; /* n_lin x 4 words, Montgomery */
 } zg_psc_term;
 ZG_API int zg_psc_round_expr(zg_psc_t s, const zg_psc_term *terms, size_t n_terms /* 1..4 */, uint64_t out[16]);
+/* The evaluation points the following zg_psc_round_evals / zg_psc_round_expr calls (and the evaluations fused into zg_psc_bind)
+ * compute: bit t of `points` = p(t) is wanted; the other slots of out[] come back as zero and their field products are not spent.
+ * Several reference provers read p(0) and p(2) only and derive p(1) = claim - p(0), p(3) = p(0) - 3 p(1) + 3 p(2)
+ * (claim_reductions/instruction_lookups.zig:146-200; stage3_prover.zig:1399-1455, 2334-2389) or all but p(1) (:2029-2100).
+ * Default 0xF (all four); a session handed out again by zg_psc_open starts at 0xF. */
+ZG_API int zg_psc_set_points(zg_psc_t s, unsigned points /* 1..15 */);
 /* Gruen's pair (product_remainder.zig:281-330): t0 = sum_g w(g) prod_j T_j[2g], t_inf = sum_g w(g) prod_j (T_j[2g+1] - T_j[2g]),
  * w(g) = E_out[g >> log2|E_in|] * E_in[g & (|E_in| - 1)], pairs with g >> log2|E_in| >= |E_out| skipped. d_e_out / d_e_in: DEVICE
  * pointers (e.g. into the buffer zg_fr_eq_prefix_tables_dev filled: table k starts at element 2^k - 1). */

@@ -616,3 +616,48 @@ def test_full_size_val_evaluation_and_instruction_input(env):
         cur = [ob.fr_bind_low(t, ch[rnd]) for t in cur]
         claim = ob.raf_update_claim(want, ch[rnd])
     p.deinit()
+
+
+@pytest.mark.parametrize("mask", [0b0101, 0b1101, 0b0111, 0b0001, 0b1000, 0b1010])
+def test_set_points_skips_only_what_was_not_asked_for(env, mask):
+    """zg_psc_set_points: the wanted evaluations are the ones an all-points session gives — for the plain product form, the
+    product-times-combination form and the multi-term form, straight and through the evaluations fused into the bind — and the
+    others come back as zero; changing the mask between two calls on the same tables recomputes."""
+    api, lib, ob = env
+    v = 9
+    tabs = [_rand(ob, 9800 + j, 1 << v) for j in range(6)]
+    co = _rand(ob, 9810, 3)
+    terms = [((0, 1), (2, 3), co[:2]), ((4,), (), None), ((), (5, 1), co[1:3])]
+    full, part = lib.ProductSumcheckSession.open(tabs), lib.ProductSumcheckSession.open(tabs)
+    part.set_points(mask)
+    zero = np.zeros(4, dtype=np.uint64)
+
+    def check(got, want):
+        for t in range(4):
+            assert np.array_equal(got[t], want[t] if (mask >> t) & 1 else zero), t
+
+    ch = _rand(ob, 9820, 4)
+    for rnd in range(4):
+        for call in (lambda s: s.round_evals((0, 1, 2)), lambda s: s.round_evals((3,), (0, 4, 5), co), lambda s: s.round_expr(terms)):
+            check(call(part), call(full))
+        # the last description is the one the bind fuses; ask for it again after the fold
+        full.bind(ch[rnd]); part.bind(ch[rnd])
+        check(part.round_expr(terms), full.round_expr(terms))
+        for j in range(6):
+            assert np.array_equal(part.read(j), full.read(j))
+    # same description, other mask: not served from the mailbox of the previous call
+    want = full.round_expr(terms)
+    part.set_points(0xF)
+    assert np.array_equal(part.round_expr(terms), want)
+    part.set_points(0b0010)
+    got = part.round_expr(terms)
+    assert np.array_equal(got[1], want[1]) and not got[0].any() and not got[2].any() and not got[3].any()
+    for bad in (0, 16, 255):
+        with pytest.raises(RuntimeError):
+            part.set_points(bad)
+    full.close(); part.close()
+    # a pooled handle starts at all four points again
+    again = lib.ProductSumcheckSession.open(tabs)
+    assert np.array_equal(again.round_expr(terms), lib.ProductSumcheckSession.open(tabs).round_expr(terms))
+    assert again.round_expr(terms)[3].any()
+    again.close()

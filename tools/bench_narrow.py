@@ -34,8 +34,9 @@ def main():
         s.close()
         return dt
 
-    def psc_once(ch, k, spec):
+    def psc_once(ch, k, spec, points=0xF):
         s = lib.ProductSumcheckSession.open_dev([d.ptr] * k, n)
+        s.set_points(points)
         spec(s)
         t0 = time.perf_counter()
         s.bind(ch)
@@ -54,6 +55,9 @@ def main():
         out[f"psc_fold_evals_p1q3_{name}_us"] = med(lambda: psc_once(ch, 4, lambda s: s.round_evals((0,), (1, 2, 3), tab[:3])))
         out[f"psc_fold_expr_instruction_input_{name}_us"] = med(lambda: psc_once(ch, 10, lambda s: s.round_expr(
             [((8, 0), (1, 2), tab[:2]), ((8, 3), (4, 5), tab[:2]), ((9, 0), (1, 2), tab[2:4]), ((9, 3), (4, 5), tab[2:4])])))
+        out[f"psc_fold_evals_p1q3_points_0_2_{name}_us"] = med(lambda: psc_once(ch, 4, lambda s: s.round_evals((0,), (1, 2, 3), tab[:3]), 0b0101))
+        out[f"psc_fold_expr_instruction_input_points_0_2_3_{name}_us"] = med(lambda: psc_once(ch, 10, lambda s: s.round_expr(
+            [((8, 0), (1, 2), tab[:2]), ((8, 3), (4, 5), tab[:2]), ((9, 0), (1, 2), tab[2:4]), ((9, 3), (4, 5), tab[2:4])]), 0b1101))
         out[f"psc_plain_fold_5_tables_{name}_us"] = med(lambda: psc_once(ch, 5, lambda s: None))
     print(out)
 

@@ -487,6 +487,11 @@ pub fn ProductSession(comptime F: type) type {
             if (ffi.zg_psc_round_expr(self.handle, terms.ptr, terms.len, @ptrCast(&out)) != ffi.OK) return Error.GpuFailure;
             return out;
         }
+        /// bit t of `points`: roundEvals / roundExpr compute p(t) only; the other slots come back as zero. The provers that derive
+        /// p(1) from the claim (stage3_prover.zig:1399-1455, 2029-2100, 2334-2389) save the products of the points they never read.
+        pub fn setPoints(self: *Self, points: c_uint) Error!void {
+            if (ffi.zg_psc_set_points(self.handle, points) != ffi.OK) return Error.GpuFailure;
+        }
         /// Gruen's (t0, t_inf) under the split-eq weights; e_out / e_in: device tables (see `GruenDeviceTables`)
         pub fn roundGruen(self: *Self, prod: []const c_int, e_out: DeviceTable, e_in: DeviceTable) Error![2]F {
             var t0: F = undefined;

@@ -106,6 +106,7 @@ pub extern fn zg_psc_len(s: ProductSession) usize;
 pub extern fn zg_psc_tables(s: ProductSession) usize;
 pub extern fn zg_psc_round_evals(s: ProductSession, prod_idx: ?[*]const c_int, p: usize, lin_idx: ?[*]const c_int, lin_coeff: ?[*]const u64, q: usize, out: *[16]u64) c_int;
 pub extern fn zg_psc_round_expr(s: ProductSession, terms: ?[*]const PscTerm, n_terms: usize, out: *[16]u64) c_int;
+pub extern fn zg_psc_set_points(s: ProductSession, points: c_uint) c_int;
 pub extern fn zg_psc_round_gruen(s: ProductSession, prod_idx: ?[*]const c_int, p: usize, d_e_out: ?[*]const u64, n_out: usize, d_e_in: ?[*]const u64, n_in: usize, t0: *[4]u64, t_inf: *[4]u64) c_int;
 pub extern fn zg_psc_bind(s: ProductSession, r: *const [4]u64) c_int;
 pub extern fn zg_psc_read(s: ProductSession, table: usize, out: ?[*]u64) c_int;

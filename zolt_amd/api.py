@@ -1288,6 +1288,7 @@ class InstructionLookupsClaimReductionProver:
         self._s = lib.ProductSumcheckSession.open([eq_evals, lookup_outputs, left_operands, right_operands])
         g = fr_to_int(gamma)
         self._coeff = np.stack([fr_from_int(1), fr_from_int(g), fr_from_int(g * g % R_MOD)])
+        self._s.set_points(0b0101)  # only s(0) and s(2) are read from the tables
         self.current_claim = np.ascontiguousarray(claim, dtype=np.uint64).copy()
         self.round = 0
 
@@ -1371,6 +1372,7 @@ class InstructionInputProver:
         w_right = np.stack([fr_from_int(1), fr_from_int(g * g % R_MOD)])  # eq_outer + gamma^2 eq_product
         w_left = np.stack([fr_from_int(g), fr_from_int(g * g * g % R_MOD)])  # gamma times the same weight
         self._terms = [((4, 5), (8, 9), w_right), ((6, 7), (8, 9), w_right), ((0, 1), (8, 9), w_left), ((2, 3), (8, 9), w_left)]
+        self._s.set_points(0b1101)  # p(1) comes from the claim
         self.current_size = len(self._s)
 
     def computeRoundEvals(self, previous_claim):
@@ -1401,12 +1403,14 @@ class ShiftSumcheckRounds:
         if not phase2:
             assert len(tables) == 8
             self._terms = [((0, 1), (), None), ((2, 3), (), None), ((4, 5), (), None), ((6, 7), (), None)]
+            self._s.set_points(0b0111)  # a quadratic: p(0), p(1), p(2)
         else:
             assert len(tables) == 7
             g = [fr_to_int(x) for x in np.ascontiguousarray(gamma_powers, dtype=np.uint64).reshape(-1, 4)]
             val = np.stack([fr_from_int(1), fr_from_int(g[1]), fr_from_int(g[2]), fr_from_int(g[3])])
             # gamma^4 (1 - noop) eq_prod = gamma^4 eq_prod - gamma^4 noop eq_prod: the same field value at every t
             self._terms = [((0,), (2, 3, 4, 5), val), ((), (1,), fr_from_int(g[4]).reshape(1, 4)), ((6,), (1,), fr_from_int((-g[4]) % R_MOD).reshape(1, 4))]
+            self._s.set_points(0b0101)  # p(0) and p(2); p(1) comes from the claim
 
     def computeRoundEvals(self, previous_claim):
         """phase 1 (:1351-1392): [p(0), p(1), p(2)] all computed; phase 2 (:1399-1455): [p(0), previous_claim - p(0), p(2)]"""
@@ -1436,6 +1440,7 @@ class RegistersClaimReductionRounds:
         self._s = lib.ProductSumcheckSession.open(tables)
         g = fr_to_int(gamma)
         self._coeff = np.stack([fr_from_int(1), fr_from_int(g), fr_from_int(g * g % R_MOD)])
+        self._s.set_points(0b0101)  # p(0) and p(2); p(1) comes from the claim
 
     def computeRoundEvals(self, previous_claim):
         """[p(0), previous_claim - p(0), p(2)] (:2334-2389)"""

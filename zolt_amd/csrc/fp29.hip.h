@@ -541,6 +541,17 @@ ZG_DEV Fr acc29_reduce(const Acc29 &a) {
     return fr29_out(f29t_mul<Fr29>(x, c));
 }
 
+// The same sum kept in 32-bit limbs (36 registers less for four running sums): limb-wise additions with a carry pass (f29_carry)
+// at least every FOUR additions — 2^29 + 8 + 4 * 2^29 < 2^32 — and the reduction below after at most FR29_ACC_MAX values.
+// x: near-normalised limbs (any f29_carry output), value < 128 r.
+ZG_DEV Fr fr29_sum_reduce(const F29 &x) {
+    constexpr u32 C261[9] = {0x0fffff57u, 0x1ea70ab4u, 0x052c068bu, 0x17504f49u, 0x0aa8075bu, 0x1d4240ceu, 0x11d54c07u, 0x052ac7a8u, 0x000dc836u};
+    F29 c;
+#pragma unroll
+    for (int i = 0; i < 9; i++) c.l[i] = C261[i];
+    return fr29_out(f29t_mul<Fr29>(x, c));
+}
+
 // Montgomery -> canonical integer of a scalar (fromMontgomery, src/field/mod.zig:642-645) = montgomeryMul(x, 1): the
 // prescaled 1 is the constant 32, so the product half of the multiplication folds to nine shifts and only the reduction
 // remains (~260 instructions instead of ~500 for the 32-bit-limb CIOS by one). Canonical output.

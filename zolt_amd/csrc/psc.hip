@@ -46,44 +46,75 @@ ZG_DEV void static_for(F &&f) {
     }
 }
 
-// Four chain values (t = 0..3) summed lazily over the pairs a thread owns (fp29.hip.h: Acc29), flushed into canonical accumulators
-// before the limb sums could outgrow the multiplier's input range.
+// Four chain values (t = 0..3) summed lazily over the pairs a thread owns, limb-wise in 32-bit words (fp29.hip.h: fr29_sum_reduce): a
+// carry pass every four additions, one reduction into the canonical accumulators every 64 — before the sum could outgrow the
+// multiplier's input range. 36 registers instead of 72 for the 64-bit limb sums: these kernels live on the 256-register line.
 struct ChainAcc4 {
-    Acc29 a[4];
+    F29 a[4];
     unsigned cnt;
     ZG_DEV void init() {
 #pragma unroll
-        for (int t = 0; t < 4; t++) a[t] = acc29_zero();
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int i = 0; i < 9; i++) a[t].l[i] = 0;
         cnt = 0;
     }
     ZG_DEV void add(const F29 (&w)[4], Fr (&e)[4]) {
 #pragma unroll
-        for (int t = 0; t < 4; t++) acc29_add(a[t], w[t]);
-        if (++cnt == FR29_ACC_MAX) flush(e);
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int i = 0; i < 9; i++) a[t].l[i] += w[t].l[i];
+        ++cnt;
+        if ((cnt & 3u) == 0) {
+#pragma unroll
+            for (int t = 0; t < 4; t++) a[t] = f29_carry(a[t]);
+            if (cnt == FR29_ACC_MAX) flush(e);
+        }
     }
     ZG_DEV void flush(Fr (&e)[4]) {
         if (cnt == 0) return;
         if (cnt == 1) {  // a single chain value: exact limbs, < 2 r — no product needed (the one-pair-per-thread regime of short tables)
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                F29 v;
-#pragma unroll
-                for (int i = 0; i < 9; i++) v.l[i] = (u32)a[t].l[i];
-                e[t] = fe_add(e[t], fr29_out(v));
-            }
+            for (int t = 0; t < 4; t++) e[t] = fe_add(e[t], fr29_out(a[t]));
         } else {
 #pragma unroll
-            for (int t = 0; t < 4; t++) e[t] = fe_add(e[t], acc29_reduce(a[t]));
+            for (int t = 0; t < 4; t++) e[t] = fe_add(e[t], fr29_sum_reduce(f29_carry(a[t])));
         }
         init();
     }
 };
 
+// two waves per SIMD (at most 256 registers): these kernels issue their loads right before the products that use them, and a second
+// resident wave is what overlaps one wave's HBM latency with the other's arithmetic
+#ifndef PSC_OCC
+#define PSC_OCC __attribute__((amdgpu_waves_per_eu(2, 2)))
+#endif
 struct PscSpec {
     uint32_t prod[ZG_PSC_MAX_FACTORS];  // table indices of the plain factors
     uint32_t lin[ZG_PSC_MAX_FACTORS];   // table indices of the linear combination
     FrArg coeff[ZG_PSC_MAX_FACTORS];    // its coefficients (Montgomery)
+    uint32_t points;                    // bit t: the evaluation at t is wanted (zg_psc_set_points; the others are not multiplied out)
 };
+
+// The running products at t = 0..3 times the next factor's values lo, hi, 2 hi - lo, 3 hi - 2 lo — only at the points the caller
+// reads: several of the reference's provers derive p(1) from the previous claim and p(3) from the others (stage3_prover.zig:2029-2100,
+// 2334-2389; claim_reductions/instruction_lookups.zig:146-200), and these kernels are bound by the field products.
+ZG_DEV void psc_chain4(F29 (&w)[4], uint32_t pm, const Fr &lo, const Fr &hi) {
+    if (pm & 1u) w[0] = fr29_chain_mul(w[0], fr29_in_shift(lo));
+    if (pm & 2u) w[1] = fr29_chain_mul(w[1], fr29_in_shift(hi));
+    if (pm & 12u) {
+        Fr d = fe_sub(hi, lo), f2 = fe_add(hi, d);
+        if (pm & 4u) w[2] = fr29_chain_mul(w[2], fr29_in_shift(f2));
+        if (pm & 8u) w[3] = fr29_chain_mul(w[3], fr29_in_shift(fe_add(f2, d)));
+    }
+}
+ZG_DEV void psc_first4(F29 (&w)[4], const Fr &lo, const Fr &hi) {
+    Fr d = fe_sub(hi, lo), f2 = fe_add(hi, d);
+    w[0] = fr29_in(lo);
+    w[1] = fr29_in(hi);
+    w[2] = fr29_in(f2);
+    w[3] = fr29_in(fe_add(f2, d));
+}
 
 // End of a round inside the producing kernel: every block leaves NP pairs in `partials`; the block that arrives last adds them up,
 // writes the 2*NP values to the pinned mailbox and publishes the sequence word. v[]: the block's values, valid in thread 0.
@@ -146,7 +177,7 @@ __device__ __forceinline__ void psc_finish(Fr (&v)[2 * NP], uint4 *sh, uint64_t 
 
 // round evaluations at t = 0..3; tables at base + table * stride (elements), pair g = entries 2g, 2g + 1
 template <int P, int Q>
-__global__ void __launch_bounds__(256) psc_evals_kernel(const uint64_t *base, size_t stride, size_t half, PscSpec spec, uint64_t *partials,
+__global__ void __launch_bounds__(256) PSC_OCC psc_evals_kernel(const uint64_t *base, size_t stride, size_t half, PscSpec spec, uint64_t *partials,
                                                         uint64_t *sums, uint32_t *counter, uint64_t *flag, uint64_t seq) {
     __shared__ uint4 sh[256 * 4];
     F29 cp[Q > 0 ? Q : 1];
@@ -184,15 +215,8 @@ __global__ void __launch_bounds__(256) psc_evals_kernel(const uint64_t *base, si
             constexpr int j = decltype(jc)::value;
             const uint64_t *t = base + 4 * ((size_t)spec.prod[j] * stride + 2 * g);
             Fr lo = fe_load<FrParams>(t), hi = fe_load<FrParams>(t + 4);
-            Fr d = fe_sub(hi, lo), f2 = fe_add(hi, d), f3 = fe_add(f2, d);
-            if (Q == 0 && j == 0) {
-                w[0] = fr29_in(lo); w[1] = fr29_in(hi); w[2] = fr29_in(f2); w[3] = fr29_in(f3);
-            } else {
-                w[0] = fr29_chain_mul(w[0], fr29_in_shift(lo));
-                w[1] = fr29_chain_mul(w[1], fr29_in_shift(hi));
-                w[2] = fr29_chain_mul(w[2], fr29_in_shift(f2));
-                w[3] = fr29_chain_mul(w[3], fr29_in_shift(f3));
-            }
+            if (Q == 0 && j == 0) psc_first4(w, lo, hi);
+            else psc_chain4(w, spec.points, lo, hi);
         });
         }
         acc.add(w, e);
@@ -271,7 +295,7 @@ __global__ void __launch_bounds__(256) psc_fold_kernel(const uint64_t *base, siz
 // the two old pairs 4g..4g+3 of every table the spec names into the new pair (2g, 2g+1), writes it, and evaluates the product form
 // on the values it still holds — one launch per round, and the folded tables are not read back.
 template <int P, int Q>
-__global__ void __launch_bounds__(256) psc_fold_evals_kernel(const uint64_t *base, size_t stride, size_t quarter, FrArg r, uint64_t *out,
+__global__ void __launch_bounds__(256) PSC_OCC psc_fold_evals_kernel(const uint64_t *base, size_t stride, size_t quarter, FrArg r, uint64_t *out,
                                                              size_t ostride, PscSpec spec, uint64_t *partials, uint64_t *sums, uint32_t *counter,
                                                              uint64_t *flag, uint64_t seq) {
     __shared__ uint4 sh[256 * 4];
@@ -323,15 +347,8 @@ __global__ void __launch_bounds__(256) psc_fold_evals_kernel(const uint64_t *bas
             uint64_t *o = out + 4 * ((size_t)spec.prod[j] * ostride + 2 * g);
             fe_store(o, lo);
             fe_store(o + 4, hi);
-            Fr d = fe_sub(hi, lo), f2 = fe_add(hi, d), f3 = fe_add(f2, d);
-            if (Q == 0 && j == 0) {
-                w[0] = fr29_in(lo); w[1] = fr29_in(hi); w[2] = fr29_in(f2); w[3] = fr29_in(f3);
-            } else {
-                w[0] = fr29_chain_mul(w[0], fr29_in_shift(lo));
-                w[1] = fr29_chain_mul(w[1], fr29_in_shift(hi));
-                w[2] = fr29_chain_mul(w[2], fr29_in_shift(f2));
-                w[3] = fr29_chain_mul(w[3], fr29_in_shift(f3));
-            }
+            if (Q == 0 && j == 0) psc_first4(w, lo, hi);
+            else psc_chain4(w, spec.points, lo, hi);
         });
         }
         acc.add(w, e);
@@ -354,12 +371,13 @@ struct PscExprTerm {
 };
 struct PscExpr {
     uint32_t n_terms;
+    uint32_t points;  // as PscSpec::points
     PscExprTerm t[ZG_PSC_MAX_TERMS];
 };
 
 // FOLD: fold the two old pairs 4g..4g+3 of every named table by r into the new pair first (and write it), as psc_fold_evals_kernel
 template <bool FOLD>
-__global__ void __launch_bounds__(256) psc_expr_kernel(const uint64_t *base, size_t stride, size_t n_pairs, FrArg r, uint64_t *out, size_t ostride,
+__global__ void __launch_bounds__(256) PSC_OCC psc_expr_kernel(const uint64_t *base, size_t stride, size_t n_pairs, FrArg r, uint64_t *out, size_t ostride,
                                                        PscExpr ex, uint64_t *partials, uint64_t *sums, uint32_t *counter, uint64_t *flag, uint64_t seq) {
     __shared__ uint4 sh[256 * 4];
     FrMul rp;
@@ -418,15 +436,11 @@ __global__ void __launch_bounds__(256) psc_expr_kernel(const uint64_t *base, siz
             for (uint32_t j = 0; j < tm.np; j++) {
                 Fr lo, hi;
                 pair_of(tm.prod[j], lo, hi);
-                Fr d = fe_sub(hi, lo), f2 = fe_add(hi, d), f3 = fe_add(f2, d);
                 if (!have) {
-                    w[0] = fr29_in(lo); w[1] = fr29_in(hi); w[2] = fr29_in(f2); w[3] = fr29_in(f3);
+                    psc_first4(w, lo, hi);
                     have = true;
                 } else {  // the running products stay lazy 29-bit-limb values (fp29.hip.h: fr29_chain_mul)
-                    w[0] = fr29_chain_mul(w[0], fr29_in_shift(lo));
-                    w[1] = fr29_chain_mul(w[1], fr29_in_shift(hi));
-                    w[2] = fr29_chain_mul(w[2], fr29_in_shift(f2));
-                    w[3] = fr29_chain_mul(w[3], fr29_in_shift(f3));
+                    psc_chain4(w, ex.points, lo, hi);
                 }
             }
             acc.add(w, e);
@@ -468,6 +482,7 @@ struct zg_psc_s {
     bool have_spec = false, evals_pending = false;
     zg::PscSpec spec;
     size_t spec_p = 0, spec_q = 0;
+    uint32_t points = 0xF;      // zg_psc_set_points: evaluation points the round calls compute
     bool spec_is_expr = false;  // the cached description is `expr` (zg_psc_round_expr) instead of spec / spec_p / spec_q
     zg::PscExpr expr;
     std::mutex mu;
@@ -515,6 +530,7 @@ static int psc_create(size_t k, size_t len, hipStream_t st, zg_psc_s **out) {
                 g_psc_pool.erase(g_psc_pool.begin() + i);
                 c->k = k; c->len = len; c->cur = 0; c->seq = 0; c->h_pin[PSC_FLAG] = 0;
                 c->have_spec = c->evals_pending = false;
+                c->points = 0xF;
                 if (psc_open_stream(c, st) != hipSuccess) {
                     set_error("zg_psc_open: hipStreamCreate failed");
                     psc_free(c);
@@ -562,6 +578,14 @@ static int psc_wait(zg_psc_s *s, uint64_t *out, int words) {
     return ZG_OK;
 }
 
+// the evaluations that were not asked for come back as zero
+static int psc_collect(zg_psc_s *s, uint32_t points, uint64_t *out) {
+    int rc = psc_wait(s, out, 16);
+    for (int t = 0; t < 4; t++)
+        if (!((points >> t) & 1u)) memset(out + 4 * t, 0, 32);
+    return rc;
+}
+
 static int psc_spec(zg_psc_s *s, const int *prod_idx, size_t p, const int *lin_idx, const uint64_t *lin_coeff, size_t q, PscSpec *spec,
                     const char *who) {
     bool bad = !s || p > ZG_PSC_MAX_FACTORS || q > ZG_PSC_MAX_FACTORS || (p + q) == 0 || (p && !prod_idx) || (q && (!lin_idx || !lin_coeff));
@@ -571,6 +595,7 @@ static int psc_spec(zg_psc_s *s, const int *prod_idx, size_t p, const int *lin_i
         set_error(std::string(who) + ": at most 4 product tables and 4 linear-combination tables, indices below the session's table count");
         return ZG_ERR_INVALID;
     }
+    spec->points = 0xF;
     for (size_t j = 0; j < ZG_PSC_MAX_FACTORS; j++) {
         spec->prod[j] = j < p ? (uint32_t)prod_idx[j] : 0;
         spec->lin[j] = j < q ? (uint32_t)lin_idx[j] : 0;
@@ -609,7 +634,7 @@ static void psc_launch_fold_evals_q(size_t q, unsigned nb, hipStream_t st, const
 }
 
 static bool psc_same_spec(const zg_psc_s *s, const PscSpec &spec, size_t p, size_t q) {
-    if (!s->have_spec || s->spec_is_expr || s->spec_p != p || s->spec_q != q) return false;
+    if (!s->have_spec || s->spec_is_expr || s->spec_p != p || s->spec_q != q || s->spec.points != spec.points) return false;
     for (size_t j = 0; j < p; j++)
         if (s->spec.prod[j] != spec.prod[j]) return false;
     for (size_t m = 0; m < q; m++) {
@@ -693,7 +718,8 @@ int zg_psc_round_evals(zg_psc_t s, const int *prod_idx, size_t p, const int *lin
     }
     DeviceGuard dg(s->device);
     std::lock_guard<std::mutex> lk(s->mu);
-    if (s->evals_pending && psc_same_spec(s, spec, p, q)) return psc_wait(s, out, 16);  // produced by the fold of the last bind
+    spec.points = s->points;
+    if (s->evals_pending && psc_same_spec(s, spec, p, q)) return psc_collect(s, spec.points, out);  // produced by the fold of the last bind
     const size_t half = s->len / 2;
     unsigned nb = psc_blocks(half);
     uint32_t *counter = reinterpret_cast<uint32_t *>(s->d_misc + PSC_COUNTER_OFF);
@@ -713,7 +739,18 @@ int zg_psc_round_evals(zg_psc_t s, const int *prod_idx, size_t p, const int *lin
     case 3: psc_launch_evals_q<3>(q, nb, s->st, base, s->stride(), half, spec, s->d_misc, s->h_pin, counter, flag, s->seq); break;
     default: psc_launch_evals_q<4>(q, nb, s->st, base, s->stride(), half, spec, s->d_misc, s->h_pin, counter, flag, s->seq); break;
     }
-    return psc_wait(s, out, 16);
+    return psc_collect(s, spec.points, out);
+}
+
+int zg_psc_set_points(zg_psc_t s, unsigned points) {
+    ZG_INIT();
+    if (!s || points == 0 || points > 0xFu) {
+        set_error("zg_psc_set_points: a non-empty subset of the points 0..3 as a bit mask");
+        return ZG_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->points = points;
+    return ZG_OK;
 }
 
 int zg_psc_round_expr(zg_psc_t s, const zg_psc_term *terms, size_t n_terms, uint64_t out[16]) {
@@ -747,7 +784,8 @@ int zg_psc_round_expr(zg_psc_t s, const zg_psc_term *terms, size_t n_terms, uint
     }
     DeviceGuard dg(s->device);
     std::lock_guard<std::mutex> lk(s->mu);
-    if (s->evals_pending && s->have_spec && s->spec_is_expr && memcmp(&s->expr, &ex, sizeof(ex)) == 0) return psc_wait(s, out, 16);
+    ex.points = s->points;
+    if (s->evals_pending && s->have_spec && s->spec_is_expr && memcmp(&s->expr, &ex, sizeof(ex)) == 0) return psc_collect(s, ex.points, out);
     const size_t half = s->len / 2;
     unsigned nb = psc_blocks(half);
     uint32_t *counter = reinterpret_cast<uint32_t *>(s->d_misc + PSC_COUNTER_OFF);
@@ -760,7 +798,7 @@ int zg_psc_round_expr(zg_psc_t s, const zg_psc_term *terms, size_t n_terms, uint
     memset(&none, 0, sizeof(none));
     hipLaunchKernelGGL((psc_expr_kernel<false>), dim3(nb), dim3(256), 0, s->st, s->buf[s->cur], s->stride(), half, none, (uint64_t *)nullptr, (size_t)0, ex,
                        s->d_misc, s->h_pin, counter, s->h_pin + PSC_FLAG, s->seq);
-    return psc_wait(s, out, 16);
+    return psc_collect(s, ex.points, out);
 }
 
 int zg_psc_round_gruen(zg_psc_t s, const int *prod_idx, size_t p, const uint64_t *d_e_out, size_t n_out, const uint64_t *d_e_in, size_t n_in,

@@ -998,6 +998,8 @@ public:
         check(zg_psc_round_expr(s_, t.data(), t.size(), reinterpret_cast<uint64_t *>(out.data())), "zg_psc_round_expr");
         return out;
     }
+    // bit t of `points`: the round calls compute p(t); the other slots come back as zero
+    void setPoints(unsigned points) { check(zg_psc_set_points(s_, points), "zg_psc_set_points"); }
     void bind(const Fr &r) { check(zg_psc_bind(s_, r.limbs), "zg_psc_bind"); }
     std::vector<Fr> final() {
         std::vector<Fr> out(zg_psc_tables(s_));
@@ -1093,6 +1095,7 @@ public:
         Fr g2 = gamma.mul(gamma);
         std::vector<Fr> w_right = {Fr::one(), g2}, w_left = {gamma, g2.mul(gamma)};
         terms_ = {{{4, 5}, {8, 9}, w_right}, {{6, 7}, {8, 9}, w_right}, {{0, 1}, {8, 9}, w_left}, {{2, 3}, {8, 9}, w_left}};
+        s_.setPoints(0b1101);  // p(1) comes from the claim
     }
     std::array<Fr, 4> computeRoundEvals(const Fr &previous_claim) {  // [p(0), claim - p(0), p(2), p(3)] (:2029-2100)
         auto ev = s_.roundExpr(terms_);
@@ -1160,7 +1163,9 @@ public:
     Fr current_claim;
     InstructionLookupsClaimReductionProver(const std::vector<Fr> &eq_evals, const std::vector<Fr> &lookup_outputs, const std::vector<Fr> &left_operands,
                                            const std::vector<Fr> &right_operands, const Fr &gamma, const Fr &claim)
-        : current_claim(claim), s_({&eq_evals, &lookup_outputs, &left_operands, &right_operands}), coeff_{Fr::one(), gamma, gamma.mul(gamma)} {}
+        : current_claim(claim), s_({&eq_evals, &lookup_outputs, &left_operands, &right_operands}), coeff_{Fr::one(), gamma, gamma.mul(gamma)} {
+        s_.setPoints(0b0101);  // only s(0) and s(2) are read
+    }
     std::array<Fr, 4> computeRoundPolynomialCubic() {  // :146-200: s0, s2 from the tables; s1 = claim - s0; s3 = s0 - 3 s1 + 3 s2
         auto ev = s_.roundEvals({0}, {1, 2, 3}, coeff_);
         Fr s1 = current_claim.sub(ev[0]), three = Fr::fromU64(3);

@@ -42,7 +42,7 @@ SYMBOLS = [
     "zg_sumcheck_len", "zg_sumcheck_final", "zg_sumcheck_read", "zg_sumcheck_close",
     "zg_sumcheck_round_sums_dev", "zg_sumcheck_read_dev", "zg_sumcheck_raf_round", "zg_sumcheck_bit_round", "zg_sumcheck_bit_bind", "zg_fr_bit_split_sums", "zg_fr_bit_split_sums_dev",
     "zg_run_sumcheck", "zg_run_sumcheck_dev", "zg_sumcheck_open_spartan_dev",
-    "zg_psc_open", "zg_psc_open_dev", "zg_psc_len", "zg_psc_tables", "zg_psc_round_evals", "zg_psc_round_expr", "zg_psc_round_gruen", "zg_psc_bind", "zg_psc_read",
+    "zg_psc_open", "zg_psc_open_dev", "zg_psc_len", "zg_psc_tables", "zg_psc_round_evals", "zg_psc_round_expr", "zg_psc_set_points", "zg_psc_round_gruen", "zg_psc_bind", "zg_psc_read",
     "zg_psc_final", "zg_psc_close",
 ]
 # test / bench scaffolding of include/zolt_gpu_internal.h (not part of the drop-in boundary)
@@ -733,6 +733,10 @@ class ProductSumcheckSession:
         out = np.empty((4, 4), dtype=np.uint64)
         _chk(_lib.zg_psc_round_expr(self._h, arr, C.c_size_t(len(terms)), _h(out)), "zg_psc_round_expr")
         return out
+
+    def set_points(self, points):
+        """bit t of `points`: the round calls compute p(t); the other slots come back as zero (zg_psc_set_points)"""
+        _chk(_lib.zg_psc_set_points(self._h, C.c_uint(points)), "zg_psc_set_points")
 
     def round_gruen(self, prod_idx, d_e_out, n_out, d_e_in, n_in):
         """Gruen's (t0, t_inf) under the split-eq weights E_out x E_in (device pointers)"""
