@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 # references (counted at half: +31 MB).
 MEASURED_TRAFFIC = {20: 1248779.2 * 1024.0 + 0.5 * 4.0 * 15.73e6 + 28522.3 * 1024.0}
 TRAFFIC_SOURCE = ("rocprofv3 PMC FETCH_SIZE (+x2 on the streamed 63 MB of sorted references, x1 on the gathered 64-byte rows: calibrated with "
-                  "tools/microbench gather|stream) + WRITE_SIZE, profiles/r2a_rocprofv3_summary.txt")
+                  "tools/microbench gather|stream) + WRITE_SIZE, profiles/r2a_rocprofv3_summary.txt (re-measured unchanged in profiles/r2e_rocprofv3_summary.txt: FETCH_SIZE 1,253,897 KB, WRITE_SIZE 28,523 KB)")
 # static instruction mix of one lazy-limb XYZZ mixed add (hipcc --save-temps of the accumulate fast path): 1467
 # v_mad_u64_u32 + 146 v_lshl_add_u64 + 144 v_lshrrev_b64 + 81 v_mul_lo_u32 at 4 issue cycles per wave, 382 32-bit
 # add/and/shift/sub at 2 (tools/microbench.hip rates)
