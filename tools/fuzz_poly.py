@@ -21,6 +21,16 @@ def rand_fr(n, sparse=False):
     return a
 
 
+def rand_ch(k=None):
+    """challenges: half of them in the reference's stored 128-bit form [0, 0, lo, hi] (the fold kernels' narrow product)"""
+    a = rand_fr(1 if k is None else k)
+    for row in a:
+        if rng.random() < 0.5:
+            row[:2] = 0
+            row[3] &= np.uint64((1 << 61) - 1)
+    return a[0] if k is None else a
+
+
 def dev(a):
     p = C.c_void_p()
     assert lib._lib.zg_dev_alloc(C.c_size_t(max(a.size, 1) * 8), C.byref(p)) == 0
@@ -49,7 +59,7 @@ while time.time() - t0 < budget:
             g0, g1 = s.round_sums()
             w0, w1 = ob.fr_sum_halves(cur) if layout == 0 else ob.fr_sum_even_odd(cur)
             assert np.array_equal(g0, w0) and np.array_equal(g1, w1)
-            ch = rand_fr(1)[0]
+            ch = rand_ch()
             s.bind(ch)
             cur = ob.fr_bind_high(cur, ch) if layout == 0 else ob.fr_bind_low(cur, ch)
         assert np.array_equal(s.final(), cur[0])
@@ -97,7 +107,7 @@ while time.time() - t0 < budget:
             s0, s2 = s.raf_round(api.fr_from_int(base), power)
             want = ob.raf_round_cubic(cur, start, bound, v, claim)
             assert np.array_equal(s0, want[0]) and np.array_equal(s2, want[2]), ("raf", v, k)
-            ch = rand_fr(1)[0]
+            ch = rand_ch()
             s.bind(ch)
             cur = ob.fr_bind_low(cur, ch)
             bound = np.concatenate([bound, ch[None, :]])
@@ -122,7 +132,7 @@ while time.time() - t0 < budget:
         g0, g1 = ss.round_sums()
         w0, w1 = ob.fr_sum_halves(cur) if layout == 0 else ob.fr_sum_even_odd(cur)
         assert np.array_equal(g0, w0) and np.array_equal(g1, w1), ("sharded session", v, k)
-        ch = rand_fr(1)[0]
+        ch = rand_ch()
         ss.bind(ch)
         cur = ob.fr_bind_high(cur, ch) if layout == 0 else ob.fr_bind_low(cur, ch)
     assert np.array_equal(ss.final(), cur[0])
@@ -130,7 +140,7 @@ while time.time() - t0 < budget:
     # product-form provers on one k-table session against the oracle's restatement of each loop
     if v >= 1:
         kind = int(rng.integers(0, 4))
-        chs = rand_fr(v)
+        chs = rand_ch(v)
         claim = rand_fr(1)[0]
         if kind <= 1:
             tabs = [rand_fr(n, sparse), rand_fr(n), rand_fr(n) if kind == 0 else None]
@@ -173,7 +183,7 @@ while time.time() - t0 < budget:
         for k in range(min(v, 5)):
             want = ob.instruction_input_round(cur, gamma, claim)
             assert np.array_equal(g.computeRoundEvals(claim), want), ("instruction input", v, k)
-            ch = rand_fr(1)[0]
+            ch = rand_ch()
             g.bind(ch)
             cur = [ob.fr_bind_low(t, ch) for t in cur]
             claim = ob.raf_update_claim(want, ch)
@@ -184,7 +194,7 @@ while time.time() - t0 < budget:
         cur = [t.copy() for t in tabs]
         for k in range(min(v, 5)):
             assert np.array_equal(g.computeRoundEvals(claim), ob.shift_phase2_round(cur, gp, claim)), ("shift phase 2", v, k)
-            ch = rand_fr(1)[0]
+            ch = rand_ch()
             g.bind(ch)
             cur = [ob.fr_bind_low(t, ch) for t in cur]
         g.deinit()
