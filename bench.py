@@ -532,6 +532,35 @@ def extra_measurements(lib, api, torch, dev, stream, args, srs_xy=None):
     el = time.perf_counter() - t0
     extra["sumcheck_v20_device_resident"] = {"rounds_per_s": 20 * v / el, "ms_per_runSumcheck": el / 20 * 1e3,
                                              "note": "prover + toy verifier on the device; transcript equals the host-verifier run"}
+    # the fold by one of the reference's 128-bit challenges (stored [0, 0, lo, hi]: 9 x 5-limb product, fp29.hip.h FrMul) against a
+    # full-width one, on a 2^24-entry table resident in HBM: kernel + fused next sums + mailbox, host-timed, best of 5
+    try:
+        n24 = 1 << 24
+        d_big = d_f.repeat(n24 // n, 1)
+        torch.cuda.synchronize()  # the session copies on the library's stream
+        wide = lib.field_op(lib.FR, lib.OP_TO_MONT, raw_scalars(0x464F4C44, 0, 1))[0]
+        nar = wide.copy()
+        nar[:2] = 0
+        nar[3] &= np.uint64((1 << 61) - 1)
+        res = {}
+        for name, c in (("full_width", wide), ("narrow", nar)):
+            best = None
+            for _ in range(5):
+                s = lib.SumcheckSession.open_dev(d_big.data_ptr(), n24, lib.SC_LOW_PAIR)
+                s.round_sums()
+                t0 = time.perf_counter()
+                s.bind(c)
+                s.round_sums()
+                dt = time.perf_counter() - t0
+                s.close()
+                best = dt if best is None else min(best, dt)
+            res[f"{name}_us"] = best * 1e6
+            res[f"{name}_TBps"] = n24 * 48 / best / 1e12
+        res["note"] = "48 bytes per entry (32 read, 16 written); the transcript's challenges are the narrow kind"
+        extra["fold_2^24_by_challenge_kind"] = res
+        del d_big
+    except Exception as exc:  # an extra: never take the headline line down with it
+        extra["fold_2^24_by_challenge_kind"] = {"error": repr(exc)}
     # HyperKZG.open over the same 2^20 bases as an SRS: host table in, v quotient commitments + final value out
     if srs_xy is not None:
         try:
