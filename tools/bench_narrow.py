@@ -58,6 +58,8 @@ def main():
         out[f"psc_fold_evals_p1q3_points_0_2_{name}_us"] = med(lambda: psc_once(ch, 4, lambda s: s.round_evals((0,), (1, 2, 3), tab[:3]), 0b0101))
         out[f"psc_fold_expr_instruction_input_points_0_2_3_{name}_us"] = med(lambda: psc_once(ch, 10, lambda s: s.round_expr(
             [((8, 0), (1, 2), tab[:2]), ((8, 3), (4, 5), tab[:2]), ((9, 0), (1, 2), tab[2:4]), ((9, 3), (4, 5), tab[2:4])]), 0b1101))
+        one_first = np.stack([lib.field_op(lib.FR, lib.OP_TO_MONT, np.array([[1, 0, 0, 0]], dtype=np.uint64))[0], tab[1], tab[2]])
+        out[f"psc_fold_evals_p1q3_coeff_1_g_g2_points_0_2_{name}_us"] = med(lambda: psc_once(ch, 4, lambda s: s.round_evals((0,), (1, 2, 3), one_first), 0b0101))
         out[f"psc_plain_fold_5_tables_{name}_us"] = med(lambda: psc_once(ch, 5, lambda s: None))
     print(out)
 

@@ -108,6 +108,36 @@ ZG_DEV void psc_chain4(F29 (&w)[4], uint32_t pm, const Fr &lo, const Fr &hi) {
         if (pm & 8u) w[3] = fr29_chain_mul(w[3], fr29_in_shift(fe_add(f2, d)));
     }
 }
+// A coefficient of the linear combination, prepared once per launch: 1 and -1 (OutputSumcheck's vf - vio, the leading 1 of every
+// gamma-power combination) cost an addition instead of a field product.
+struct LinCoeff {
+    F29 p;
+    uint32_t kind;  // 0: general, 1: one, 2: minus one
+};
+ZG_DEV uint32_t lin_kind(const FrArg &a) {  // scalar work: the coefficient is a kernel argument
+    Fr one = Fr::one(), mone = fe_neg(Fr::one());
+    uint32_t d1 = 0, d2 = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        d1 |= a.l[i] ^ one.l[i];
+        d2 |= a.l[i] ^ mone.l[i];
+    }
+    return d1 == 0 ? 1u : (d2 == 0 ? 2u : 0u);
+}
+ZG_DEV LinCoeff lin_prepare(const FrArg &a) {
+    Fr c;
+#pragma unroll
+    for (int i = 0; i < 8; i++) c.l[i] = a.l[i];
+    LinCoeff r;
+    r.kind = lin_kind(a);
+    r.p = fr29_prescale(c);
+    return r;
+}
+ZG_DEV Fr lin_add(const Fr &acc, const Fr &v, const LinCoeff &c) {
+    if (c.kind == 1u) return fe_add(acc, v);
+    if (c.kind == 2u) return fe_sub(acc, v);
+    return fe_add(acc, fr_mul29(v, c.p));
+}
 ZG_DEV void psc_first4(F29 (&w)[4], const Fr &lo, const Fr &hi) {
     Fr d = fe_sub(hi, lo), f2 = fe_add(hi, d);
     w[0] = fr29_in(lo);
@@ -180,14 +210,11 @@ template <int P, int Q>
 __global__ void __launch_bounds__(256) PSC_OCC psc_evals_kernel(const uint64_t *base, size_t stride, size_t half, PscSpec spec, uint64_t *partials,
                                                         uint64_t *sums, uint32_t *counter, uint64_t *flag, uint64_t seq) {
     __shared__ uint4 sh[256 * 4];
-    F29 cp[Q > 0 ? Q : 1];
+    LinCoeff cp[Q > 0 ? Q : 1];
     if constexpr (Q > 0) {
         static_for<0, Q>([&](auto mc) {
             constexpr int m = decltype(mc)::value;
-            Fr c;
-#pragma unroll
-            for (int i = 0; i < 8; i++) c.l[i] = spec.coeff[m].l[i];
-            cp[m] = fr29_prescale(c);
+            cp[m] = lin_prepare(spec.coeff[m]);
         });
     }
     Fr e[4] = {Fr::zero(), Fr::zero(), Fr::zero(), Fr::zero()};
@@ -201,8 +228,8 @@ __global__ void __launch_bounds__(256) PSC_OCC psc_evals_kernel(const uint64_t *
             static_for<0, Q>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
                 const uint64_t *t = base + 4 * ((size_t)spec.lin[m] * stride + 2 * g);
-                l0 = fe_add(l0, fr_mul29(fe_load<FrParams>(t), cp[m]));
-                l1 = fe_add(l1, fr_mul29(fe_load<FrParams>(t + 4), cp[m]));
+                l0 = lin_add(l0, fe_load<FrParams>(t), cp[m]);
+                l1 = lin_add(l1, fe_load<FrParams>(t + 4), cp[m]);
             });
             Fr d = fe_sub(l1, l0), l2 = fe_add(l1, d);
             w[0] = fr29_in(l0);
@@ -303,14 +330,11 @@ __global__ void __launch_bounds__(256) PSC_OCC psc_fold_evals_kernel(const uint6
 #pragma unroll
     for (int i = 0; i < 8; i++) rv.l[i] = r.l[i];
     FrMul rp = frmul_prepare(rv);
-    F29 cp[Q > 0 ? Q : 1];
+    LinCoeff cp[Q > 0 ? Q : 1];
     if constexpr (Q > 0) {
         static_for<0, Q>([&](auto mc) {
             constexpr int m = decltype(mc)::value;
-            Fr c;
-#pragma unroll
-            for (int i = 0; i < 8; i++) c.l[i] = spec.coeff[m].l[i];
-            cp[m] = fr29_prescale(c);
+            cp[m] = lin_prepare(spec.coeff[m]);
         });
     }
     Fr e[4] = {Fr::zero(), Fr::zero(), Fr::zero(), Fr::zero()};
@@ -329,8 +353,8 @@ __global__ void __launch_bounds__(256) PSC_OCC psc_fold_evals_kernel(const uint6
                 uint64_t *o = out + 4 * ((size_t)spec.lin[m] * ostride + 2 * g);
                 fe_store(o, lo);
                 fe_store(o + 4, hi);
-                l0 = fe_add(l0, fr_mul29(lo, cp[m]));
-                l1 = fe_add(l1, fr_mul29(hi, cp[m]));
+                l0 = lin_add(l0, lo, cp[m]);
+                l1 = lin_add(l1, hi, cp[m]);
             });
             Fr d = fe_sub(l1, l0), l2 = fe_add(l1, d);
             w[0] = fr29_in(l0);
@@ -419,12 +443,22 @@ __global__ void __launch_bounds__(256) PSC_OCC psc_expr_kernel(const uint64_t *b
             if (tm.nq) {
                 Fr l0 = Fr::zero(), l1 = Fr::zero();
                 for (uint32_t m = 0; m < tm.nq; m++) {
-                    Fr lo, hi, c;
+                    Fr lo, hi;
                     pair_of(tm.lin[m], lo, hi);
+                    const uint32_t kind = lin_kind(tm.coeff[m]);
+                    if (kind == 1u) {
+                        l0 = fe_add(l0, lo);
+                        l1 = fe_add(l1, hi);
+                    } else if (kind == 2u) {
+                        l0 = fe_sub(l0, lo);
+                        l1 = fe_sub(l1, hi);
+                    } else {
+                        Fr c;
 #pragma unroll
-                    for (int i = 0; i < 8; i++) c.l[i] = tm.coeff[m].l[i];
-                    l0 = fe_add(l0, fr_mul29v(lo, c));
-                    l1 = fe_add(l1, fr_mul29v(hi, c));
+                        for (int i = 0; i < 8; i++) c.l[i] = tm.coeff[m].l[i];
+                        l0 = fe_add(l0, fr_mul29v(lo, c));
+                        l1 = fe_add(l1, fr_mul29v(hi, c));
+                    }
                 }
                 Fr d = fe_sub(l1, l0), l2 = fe_add(l1, d);
                 w[0] = fr29_in(l0);
