@@ -661,3 +661,51 @@ def test_set_points_skips_only_what_was_not_asked_for(env, mask):
     assert np.array_equal(again.round_expr(terms), lib.ProductSumcheckSession.open(tabs).round_expr(terms))
     assert again.round_expr(terms)[3].any()
     again.close()
+
+
+def test_round_expr_terms_that_share_a_linear_combination(env):
+    """psc_expr_kernel reuses a term's linear combination (and, in the fused bind, the fold of its tables) when the NEXT term names the
+    same tables with the same coefficients: shared between neighbours, between all four, broken by a different coefficient or a
+    different table, and a term without a combination in between — against the big-int model over three rounds (2 fused)."""
+    api, lib, ob = env
+    P = api.R_MOD
+    k, n = 8, 128
+    tabs = [_rand(ob, 10100 + j, n) for j in range(k)]
+    co = _rand(ob, 10110, 4)
+    one = api.fr_from_int(1)
+    cases = [
+        [((0, 1), (6, 7), co[:2]), ((2, 3), (6, 7), co[:2]), ((0, 2), (6, 7), co[2:4]), ((1, 3), (6, 7), co[2:4])],      # InstructionInput's pattern
+        [((0,), (6, 7), co[:2]), ((1,), (6, 7), co[:2]), ((2,), (6, 7), co[:2]), ((3,), (6, 7), co[:2])],               # all four share
+        [((0,), (6, 7), co[:2]), ((1,), (7, 6), co[:2]), ((2,), (6, 7), np.stack([co[0], co[2]])), ((3,), (6,), co[:1])],  # never the same
+        [((0,), (5, 6), np.stack([one, co[1]])), ((1, 2), (), None), ((3,), (5, 6), np.stack([one, co[1]])), ((4,), (5, 6), np.stack([one, co[1]]))],
+        [((), (6, 7), co[:2]), ((), (6, 7), co[:2])],                                                                    # the combination alone, twice
+    ]
+    for ci, terms in enumerate(cases):
+        ints = [[api.fr_to_int(x) for x in t] for t in tabs]
+        s = lib.ProductSumcheckSession.open(tabs)
+        for rnd in range(3):
+            half = len(s) // 2
+            want = []
+            for t in range(4):
+                acc = 0
+                for g in range(half):
+                    f = lambda T: (T[2 * g] + t * (T[2 * g + 1] - T[2 * g])) % P
+                    for prod_idx, lin_idx, coeff in terms:
+                        v = 1
+                        for j in prod_idx:
+                            v = v * f(ints[j]) % P
+                        if lin_idx:
+                            v = v * (sum(api.fr_to_int(c) * f(ints[m]) for c, m in zip(coeff, lin_idx)) % P) % P
+                        acc = (acc + v) % P
+                want.append(acc)
+            assert [api.fr_to_int(x) for x in s.round_expr(terms)] == want, (ci, rnd)
+            r = _rand(ob, 10120 + rnd, 1)[0]
+            if rnd == 1:
+                r[:2] = 0
+                r[3] &= np.uint64((1 << 61) - 1)
+            ri = api.fr_to_int(r)
+            s.bind(r)
+            ints = [[(T[2 * i] + ri * (T[2 * i + 1] - T[2 * i])) % P for i in range(half)] for T in ints]
+            for j in range(k):
+                assert [api.fr_to_int(x) for x in s.read(j)] == ints[j], (ci, rnd, j)
+        s.close()

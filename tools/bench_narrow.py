@@ -23,6 +23,8 @@ def main():
     nar[3] &= np.uint64((1 << 61) - 1)
     d = lib.DeviceBuffer.from_host(tab)
     out = {"v": v}
+    # InstructionInputProver's four terms (api.InstructionInputProver): factors 0..7, the two eq tables 8, 9 under (1, g^2) and (g, g^3)
+    II_TERMS = [((4, 5), (8, 9), tab[:2]), ((6, 7), (8, 9), tab[:2]), ((0, 1), (8, 9), tab[2:4]), ((2, 3), (8, 9), tab[2:4])]
 
     def fold_once(ch):
         s = lib.SumcheckSession.open_dev(d.ptr, n, lib.SC_LOW_PAIR)
@@ -54,10 +56,10 @@ def main():
         out[f"psc_fold_evals_p3_{name}_us"] = med(lambda: psc_once(ch, 3, lambda s: s.round_evals((0, 1, 2))))
         out[f"psc_fold_evals_p1q3_{name}_us"] = med(lambda: psc_once(ch, 4, lambda s: s.round_evals((0,), (1, 2, 3), tab[:3])))
         out[f"psc_fold_expr_instruction_input_{name}_us"] = med(lambda: psc_once(ch, 10, lambda s: s.round_expr(
-            [((8, 0), (1, 2), tab[:2]), ((8, 3), (4, 5), tab[:2]), ((9, 0), (1, 2), tab[2:4]), ((9, 3), (4, 5), tab[2:4])])))
+            II_TERMS)))
         out[f"psc_fold_evals_p1q3_points_0_2_{name}_us"] = med(lambda: psc_once(ch, 4, lambda s: s.round_evals((0,), (1, 2, 3), tab[:3]), 0b0101))
         out[f"psc_fold_expr_instruction_input_points_0_2_3_{name}_us"] = med(lambda: psc_once(ch, 10, lambda s: s.round_expr(
-            [((8, 0), (1, 2), tab[:2]), ((8, 3), (4, 5), tab[:2]), ((9, 0), (1, 2), tab[2:4]), ((9, 3), (4, 5), tab[2:4])]), 0b1101))
+            II_TERMS), 0b1101))
         one_first = np.stack([lib.field_op(lib.FR, lib.OP_TO_MONT, np.array([[1, 0, 0, 0]], dtype=np.uint64))[0], tab[1], tab[2]])
         out[f"psc_fold_evals_p1q3_coeff_1_g_g2_points_0_2_{name}_us"] = med(lambda: psc_once(ch, 4, lambda s: s.round_evals((0,), (1, 2, 3), one_first), 0b0101))
         out[f"psc_plain_fold_5_tables_{name}_us"] = med(lambda: psc_once(ch, 5, lambda s: None))

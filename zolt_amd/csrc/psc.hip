@@ -417,8 +417,17 @@ __global__ void __launch_bounds__(256) PSC_OCC psc_expr_kernel(const uint64_t *b
     acc.init();
     size_t step = (size_t)gridDim.x * 256;
     for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < n_pairs; g += step) {
+        Fr l0 = Fr::zero(), l1 = Fr::zero();  // the linear combination of the current term; kept while the next terms name the same one
         for (uint32_t ti = 0; ti < ex.n_terms; ti++) {
             const PscExprTerm &tm = ex.t[ti];
+            // consecutive terms with the same combination (InstructionInput: two terms per weight) share its two values — and, when
+            // folding, the fold of its tables. Uniform: the description is a kernel argument.
+            bool same_lin = ti > 0 && tm.nq == ex.t[ti - 1].nq;
+            if (same_lin)
+                for (uint32_t m = 0; m < tm.nq; m++) {
+                    same_lin = same_lin && tm.lin[m] == ex.t[ti - 1].lin[m];
+                    for (int i = 0; i < 8; i++) same_lin = same_lin && tm.coeff[m].l[i] == ex.t[ti - 1].coeff[m].l[i];
+                }
             F29 w[4];
 #pragma unroll
             for (int t = 0; t < 4; t++)
@@ -441,7 +450,9 @@ __global__ void __launch_bounds__(256) PSC_OCC psc_expr_kernel(const uint64_t *b
                 }
             };
             if (tm.nq) {
-                Fr l0 = Fr::zero(), l1 = Fr::zero();
+                if (!same_lin) {
+                l0 = Fr::zero();
+                l1 = Fr::zero();
                 for (uint32_t m = 0; m < tm.nq; m++) {
                     Fr lo, hi;
                     pair_of(tm.lin[m], lo, hi);
@@ -459,6 +470,7 @@ __global__ void __launch_bounds__(256) PSC_OCC psc_expr_kernel(const uint64_t *b
                         l0 = fe_add(l0, fr_mul29v(lo, c));
                         l1 = fe_add(l1, fr_mul29v(hi, c));
                     }
+                }
                 }
                 Fr d = fe_sub(l1, l0), l2 = fe_add(l1, d);
                 w[0] = fr29_in(l0);
