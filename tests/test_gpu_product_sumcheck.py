@@ -709,3 +709,61 @@ def test_round_expr_terms_that_share_a_linear_combination(env):
             for j in range(k):
                 assert [api.fr_to_int(x) for x in s.read(j)] == ints[j], (ci, rnd, j)
         s.close()
+
+
+@pytest.mark.parametrize("mask", [0xF, 0b1101, 0b0101])
+def test_round_expr_pair_sum_terms(env, mask):
+    """ZG_PSC_PAIR_SUM: (T[p0] T[p1] + T[p2] T[p3]) * L as ONE term — alone, next to ordinary terms, two of them sharing the combination
+    (InstructionInput's form) — against the big-int model over three rounds (two out of the fused bind), under a point mask."""
+    api, lib, ob = env
+    P = api.R_MOD
+    k, n = 10, 128
+    tabs = [_rand(ob, 10200 + j, n, sparse=(j in (0, 4))) for j in range(k)]
+    co = _rand(ob, 10210, 4)
+    one = api.fr_from_int(1)
+    cases = [
+        [((4, 5, 6, 7), (8, 9), np.stack([one, co[0]]), True), ((0, 1, 2, 3), (8, 9), np.stack([co[1], co[2]]), True)],
+        [((0, 1, 2, 3), (8,), co[:1], True)],
+        [((0, 1), (), None), ((2, 3, 4, 5), (6, 7, 8), co[:3], True), ((9,), (6, 7, 8), co[:3])],
+        [((0, 1, 0, 1), (2, 3), co[:2], True), ((0, 1, 2, 3), (2, 3), co[:2], True)],  # tables named more than once
+    ]
+    zero = [0, 0, 0, 0]
+    for ci, terms in enumerate(cases):
+        ints = [[api.fr_to_int(x) for x in t] for t in tabs]
+        s = lib.ProductSumcheckSession.open(tabs)
+        s.set_points(mask)
+        for rnd in range(3):
+            half = len(s) // 2
+            want = []
+            for t in range(4):
+                acc = 0
+                for g in range(half):
+                    f = lambda T: (T[2 * g] + t * (T[2 * g + 1] - T[2 * g])) % P
+                    for term in terms:
+                        prod_idx, lin_idx, coeff = term[:3]
+                        if len(term) > 3:
+                            v = (f(ints[prod_idx[0]]) * f(ints[prod_idx[1]]) + f(ints[prod_idx[2]]) * f(ints[prod_idx[3]])) % P
+                        else:
+                            v = 1
+                            for j in prod_idx:
+                                v = v * f(ints[j]) % P
+                        if lin_idx:
+                            v = v * (sum(api.fr_to_int(c) * f(ints[m]) for c, m in zip(coeff, lin_idx)) % P) % P
+                        acc = (acc + v) % P
+                want.append(acc if (mask >> t) & 1 else 0)
+            assert [api.fr_to_int(x) for x in s.round_expr(terms)] == want, (ci, rnd)
+            r = _rand(ob, 10220 + rnd, 1)[0]
+            if rnd == 0:
+                r[:2] = 0
+                r[3] &= np.uint64((1 << 61) - 1)
+            ri = api.fr_to_int(r)
+            s.bind(r)
+            ints = [[(T[2 * i] + ri * (T[2 * i + 1] - T[2 * i])) % P for i in range(half)] for T in ints]
+            for j in range(k):
+                assert [api.fr_to_int(x) for x in s.read(j)] == ints[j], (ci, rnd, j)
+        s.close()
+    s = lib.ProductSumcheckSession.open(tabs)
+    for bad in ([((0, 1, 2), (8,), co[:1], True)], [((0, 1, 2, 3), (), None, True)], [((0, 1), (8,), co[:1], True)]):
+        with pytest.raises(RuntimeError):
+            s.round_expr(bad)  # a pair sum needs exactly four tables and a linear combination
+    s.close()

@@ -24,7 +24,7 @@ def main():
     d = lib.DeviceBuffer.from_host(tab)
     out = {"v": v}
     # InstructionInputProver's four terms (api.InstructionInputProver): factors 0..7, the two eq tables 8, 9 under (1, g^2) and (g, g^3)
-    II_TERMS = [((4, 5), (8, 9), tab[:2]), ((6, 7), (8, 9), tab[:2]), ((0, 1), (8, 9), tab[2:4]), ((2, 3), (8, 9), tab[2:4])]
+    II_TERMS = [((4, 5, 6, 7), (8, 9), tab[:2], True), ((0, 1, 2, 3), (8, 9), tab[2:4], True)]  # two ZG_PSC_PAIR_SUM terms
 
     def fold_once(ch):
         s = lib.SumcheckSession.open_dev(d.ptr, n, lib.SC_LOW_PAIR)

@@ -77,7 +77,7 @@ def parse_header(text):
 def generate():
     text = open(HDR).read()
     protos = parse_header(text)
-    consts = re.findall(r"#define (ZG_(?:OK|ERR_\w+|FIELD_\w+|OP_\w+|SC_\w+)) (\d+)", text)
+    consts = re.findall(r"#define (ZG_(?:OK|ERR_\w+|FIELD_\w+|OP_\w+|SC_\w+|PSC_\w+)) (\d+)", text)
     out = [
         "//! extern declarations of libzolt_gpu.so, for Zolt's src/gpu/ffi.zig.",
         "//! GENERATED from include/zolt_gpu.h by tools/gen_zig_ffi.py — do not edit; tests/test_abi_and_host.py holds the two together.",

@@ -33,6 +33,7 @@ pub const OP_FROM_MONT: c_int = 6;
 pub const OP_TO_MONT: c_int = 7;
 pub const SC_HIGH_HALF: c_int = 0;
 pub const SC_LOW_PAIR: c_int = 1;
+pub const PSC_PAIR_SUM: c_int = 256;
 
 pub extern fn zg_init(device: c_int) c_int;
 pub extern fn zg_init_devices(n_devices: c_int) c_int;

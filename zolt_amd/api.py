@@ -1371,7 +1371,8 @@ class InstructionInputProver:
         g = fr_to_int(gamma)
         w_right = np.stack([fr_from_int(1), fr_from_int(g * g % R_MOD)])  # eq_outer + gamma^2 eq_product
         w_left = np.stack([fr_from_int(g), fr_from_int(g * g * g % R_MOD)])  # gamma times the same weight
-        self._terms = [((4, 5), (8, 9), w_right), ((6, 7), (8, 9), w_right), ((0, 1), (8, 9), w_left), ((2, 3), (8, 9), w_left)]
+        # two pair-sum terms (ZG_PSC_PAIR_SUM): (is_rs2 rs2 + is_imm imm) under the right weight, (is_rs1 rs1 + is_pc pc) under gamma times it
+        self._terms = [((4, 5, 6, 7), (8, 9), w_right, True), ((0, 1, 2, 3), (8, 9), w_left, True)]
         self._s.set_points(0b1101)  # p(1) comes from the claim
         self.current_size = len(self._s)
 

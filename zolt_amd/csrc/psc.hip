@@ -390,6 +390,7 @@ __global__ void __launch_bounds__(256) PSC_OCC psc_fold_evals_kernel(const uint6
 // g (is_rs1 * rs1 + is_pc * pc)), :2029-2100). Runtime loops over the description (uniform across the grid), no register arrays.
 struct PscExprTerm {
     uint32_t np, nq;
+    uint32_t pair_sum;  // ZG_PSC_PAIR_SUM: (T[prod0] * T[prod1] + T[prod2] * T[prod3]) * L instead of the product of the four
     uint32_t prod[ZG_PSC_MAX_FACTORS], lin[ZG_PSC_MAX_FACTORS];
     FrArg coeff[ZG_PSC_MAX_FACTORS];
 };
@@ -472,13 +473,44 @@ __global__ void __launch_bounds__(256) PSC_OCC psc_expr_kernel(const uint64_t *b
                     }
                 }
                 }
-                Fr d = fe_sub(l1, l0), l2 = fe_add(l1, d);
-                w[0] = fr29_in(l0);
-                w[1] = fr29_in(l1);
-                w[2] = fr29_in(l2);
-                w[3] = fr29_in(fe_add(l2, d));
-                have = true;
+                if (!tm.pair_sum) {
+                    Fr d = fe_sub(l1, l0), l2 = fe_add(l1, d);
+                    w[0] = fr29_in(l0);
+                    w[1] = fr29_in(l1);
+                    w[2] = fr29_in(l2);
+                    w[3] = fr29_in(fe_add(l2, d));
+                    have = true;
+                }
             }
+            if (tm.pair_sum) {
+                // (a b + c d) L: the two pair products are added as lazy values (limbs < 2^30, value < 2.4 r: still a valid left operand of
+                // the multiplier, product < (2.4 * 32 / 168.9 + 1) r) and the sum takes ONE product by L — three per point instead of four
+                for (uint32_t q = 0; q < 2; q++) {
+                    Fr alo, ahi, blo, bhi;
+                    pair_of(tm.prod[2 * q], alo, ahi);
+                    pair_of(tm.prod[2 * q + 1], blo, bhi);
+                    Fr da = fe_sub(ahi, alo), db = fe_sub(bhi, blo);
+                    Fr at = alo, bt = blo;
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        if ((ex.points >> t) & 1u) {
+                            F29 v = fr29_chain_mul(fr29_in(at), fr29_in_shift(bt));
+#pragma unroll
+                            for (int i = 0; i < 9; i++) w[t].l[i] += v.l[i];
+                        }
+                        if (t < 3) {
+                            at = fe_add(at, da);
+                            bt = fe_add(bt, db);
+                        }
+                    }
+                }
+                Fr dl = fe_sub(l1, l0), lt = l0;
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    if ((ex.points >> t) & 1u) w[t] = fr29_chain_mul(w[t], fr29_in_shift(lt));
+                    if (t < 3) lt = fe_add(lt, dl);
+                }
+            } else
             for (uint32_t j = 0; j < tm.np; j++) {
                 Fr lo, hi;
                 pair_of(tm.prod[j], lo, hi);
@@ -810,16 +842,21 @@ int zg_psc_round_expr(zg_psc_t s, const zg_psc_term *terms, size_t n_terms, uint
     ex.n_terms = (uint32_t)n_terms;
     for (size_t ti = 0; ti < n_terms; ti++) {
         const zg_psc_term &t = terms[ti];
-        bool bad = t.n_prod < 0 || t.n_prod > ZG_PSC_MAX_FACTORS || t.n_lin < 0 || t.n_lin > ZG_PSC_MAX_FACTORS || t.n_prod + t.n_lin == 0;
-        for (int j = 0; !bad && j < t.n_prod; j++) bad = t.prod[j] < 0 || (size_t)t.prod[j] >= s->k;
+        const bool pair_sum = t.n_prod >= 0 && (t.n_prod & ZG_PSC_PAIR_SUM);
+        const int n_prod = pair_sum ? (t.n_prod & ~ZG_PSC_PAIR_SUM) : t.n_prod;
+        bool bad = n_prod < 0 || n_prod > ZG_PSC_MAX_FACTORS || t.n_lin < 0 || t.n_lin > ZG_PSC_MAX_FACTORS || n_prod + t.n_lin == 0 ||
+                   (pair_sum && (n_prod != 4 || t.n_lin == 0));
+        for (int j = 0; !bad && j < n_prod; j++) bad = t.prod[j] < 0 || (size_t)t.prod[j] >= s->k;
         for (int m = 0; !bad && m < t.n_lin; m++) bad = t.lin[m] < 0 || (size_t)t.lin[m] >= s->k;
         if (bad) {
-            set_error("zg_psc_round_expr: a term has at most 4 product tables and 4 linear-combination tables, indices below the table count");
+            set_error("zg_psc_round_expr: a term has at most 4 product tables and 4 linear-combination tables, indices below the table count; "
+                      "ZG_PSC_PAIR_SUM needs exactly 4 product tables and a linear combination");
             return ZG_ERR_INVALID;
         }
-        ex.t[ti].np = (uint32_t)t.n_prod;
+        ex.t[ti].np = (uint32_t)n_prod;
         ex.t[ti].nq = (uint32_t)t.n_lin;
-        for (int j = 0; j < t.n_prod; j++) ex.t[ti].prod[j] = (uint32_t)t.prod[j];
+        ex.t[ti].pair_sum = pair_sum ? 1u : 0u;
+        for (int j = 0; j < n_prod; j++) ex.t[ti].prod[j] = (uint32_t)t.prod[j];
         for (int m = 0; m < t.n_lin; m++) {
             ex.t[ti].lin[m] = (uint32_t)t.lin[m];
             for (int i = 0; i < 4; i++) {

@@ -981,12 +981,13 @@ public:
     struct Term {
         std::vector<int> prod, lin;
         std::vector<Fr> coeff;
+        bool pair_sum = false;  // ZG_PSC_PAIR_SUM: (T[prod0] T[prod1] + T[prod2] T[prod3]) * L
     };
     std::array<Fr, 4> roundExpr(const std::vector<Term> &terms) {
         std::vector<zg_psc_term> t(terms.size());
         for (size_t i = 0; i < terms.size(); i++) {
             std::memset(&t[i], 0, sizeof(zg_psc_term));
-            t[i].n_prod = (int)terms[i].prod.size();
+            t[i].n_prod = (int)terms[i].prod.size() | (terms[i].pair_sum ? ZG_PSC_PAIR_SUM : 0);
             t[i].n_lin = (int)terms[i].lin.size();
             for (size_t j = 0; j < terms[i].prod.size() && j < 4; j++) t[i].prod[j] = terms[i].prod[j];
             for (size_t m = 0; m < terms[i].lin.size() && m < 4; m++) {
@@ -1094,7 +1095,7 @@ public:
     InstructionInputProver(const std::vector<const std::vector<Fr> *> &tables, const Fr &gamma) : s_(tables) {
         Fr g2 = gamma.mul(gamma);
         std::vector<Fr> w_right = {Fr::one(), g2}, w_left = {gamma, g2.mul(gamma)};
-        terms_ = {{{4, 5}, {8, 9}, w_right}, {{6, 7}, {8, 9}, w_right}, {{0, 1}, {8, 9}, w_left}, {{2, 3}, {8, 9}, w_left}};
+        terms_ = {{{4, 5, 6, 7}, {8, 9}, w_right, true}, {{0, 1, 2, 3}, {8, 9}, w_left, true}};  // two pair-sum terms
         s_.setPoints(0b1101);  // p(1) comes from the claim
     }
     std::array<Fr, 4> computeRoundEvals(const Fr &previous_claim) {  // [p(0), claim - p(0), p(2), p(3)] (:2029-2100)

@@ -673,6 +673,9 @@ class SumcheckSession:
             pass
 
 
+PSC_PAIR_SUM = 256  # ZG_PSC_PAIR_SUM
+
+
 class PscTerm(C.Structure):
     """zg_psc_term: one product term of zg_psc_round_expr"""
     _fields_ = [("n_prod", C.c_int), ("prod", C.c_int * 4), ("n_lin", C.c_int), ("lin", C.c_int * 4), ("lin_coeff", C.c_uint64 * 16)]
@@ -718,10 +721,12 @@ class ProductSumcheckSession:
         return out
 
     def round_expr(self, terms):
-        """[p(0..3)] of a SUM of product terms; terms: list of (prod_idx, lin_idx, lin_coeff) with lin_coeff (len(lin_idx), 4) or None"""
+        """[p(0..3)] of a SUM of product terms; terms: list of (prod_idx, lin_idx, lin_coeff) with lin_coeff (len(lin_idx), 4) or None,
+        or (prod_idx, lin_idx, lin_coeff, True) for a ZG_PSC_PAIR_SUM term: (T[p0] T[p1] + T[p2] T[p3]) * L"""
         arr = (PscTerm * len(terms))()
-        for t, (prod_idx, lin_idx, coeff) in zip(arr, terms):
-            t.n_prod, t.n_lin = len(prod_idx), len(lin_idx)
+        for t, term in zip(arr, terms):
+            prod_idx, lin_idx, coeff = term[:3]
+            t.n_prod, t.n_lin = len(prod_idx) | (PSC_PAIR_SUM if len(term) > 3 and term[3] else 0), len(lin_idx)
             for j, v in enumerate(prod_idx):
                 t.prod[j] = v
             for m, v in enumerate(lin_idx):
