@@ -482,6 +482,7 @@ pub fn ProductSession(comptime F: type) type {
         }
         /// [p(0..3)] of a SUM of up to four product terms (ffi.PscTerm each) — ShiftSumcheckProver's two phases and InstructionInputProver
         /// (src/zkvm/spartan/stage3_prover.zig:1351-1455,2029-2100)
+        /// A term with `n_prod = 4 | ffi.PSC_PAIR_SUM` is (T[prod[0]]*T[prod[1]] + T[prod[2]]*T[prod[3]]) * L: InstructionInput's two sides.
         pub fn roundExpr(self: *Self, terms: []const ffi.PscTerm) Error![4]F {
             var out: [4]F = undefined;
             if (ffi.zg_psc_round_expr(self.handle, terms.ptr, terms.len, @ptrCast(&out)) != ffi.OK) return Error.GpuFailure;
