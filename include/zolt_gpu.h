@@ -331,9 +331,9 @@ ZG_API int zg_psc_round_evals(zg_psc_t s, const int *prod_idx, size_t p, const i
  * pairs, :1351-1392) and phase 2 (:1399-1455), InstructionInput ((eq_out + g^2 eq_prod) * (is_rs2*rs2 + is_imm*imm + g (is_rs1*rs1 +
  * is_pc*pc)), :2029-2100: four terms of two plain factors and a two-table combination). out as zg_psc_round_evals; provers that
  * derive p(1) from the claim drop it. */
-#define ZG_PSC_PAIR_SUM 256 /* n_prod = 4 | ZG_PSC_PAIR_SUM: the term is (T[prod[0]]*T[prod[1]] + T[prod[2]]*T[prod[3]]) * L, n_lin >= 1 —
-                             * two terms with the same weight L as one (InstructionInput: is_rs2*rs2 + is_imm*imm under one weight): three
-                             * field products per evaluation point instead of four */
+#define ZG_PSC_PAIR_SUM 256 /* n_prod = 4 | ZG_PSC_PAIR_SUM: the term is (T[prod[0]]*T[prod[1]] + T[prod[2]]*T[prod[3]]) * L (L = 1 when
+                             * n_lin = 0) — two terms with the same weight as one (InstructionInput: is_rs2*rs2 + is_imm*imm under one
+                             * weight; ShiftSumcheck phase 1: P_0*Q_0 + P_1*Q_1): three field products per evaluation point, not four */
 typedef struct {
     int n_prod;
     int prod[4];

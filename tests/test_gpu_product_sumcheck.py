@@ -726,6 +726,8 @@ def test_round_expr_pair_sum_terms(env, mask):
         [((0, 1, 2, 3), (8,), co[:1], True)],
         [((0, 1), (), None), ((2, 3, 4, 5), (6, 7, 8), co[:3], True), ((9,), (6, 7, 8), co[:3])],
         [((0, 1, 0, 1), (2, 3), co[:2], True), ((0, 1, 2, 3), (2, 3), co[:2], True)],  # tables named more than once
+        [((0, 1, 2, 3), (), None, True), ((4, 5, 6, 7), (), None, True)],               # no weight: ShiftSumcheck phase 1
+        [((0, 1, 2, 3), (), None, True)],
     ]
     zero = [0, 0, 0, 0]
     for ci, terms in enumerate(cases):
@@ -763,7 +765,7 @@ def test_round_expr_pair_sum_terms(env, mask):
                 assert [api.fr_to_int(x) for x in s.read(j)] == ints[j], (ci, rnd, j)
         s.close()
     s = lib.ProductSumcheckSession.open(tabs)
-    for bad in ([((0, 1, 2), (8,), co[:1], True)], [((0, 1, 2, 3), (), None, True)], [((0, 1), (8,), co[:1], True)]):
+    for bad in ([((0, 1, 2), (8,), co[:1], True)], [((0, 1), (), None, True)], [((0, 1), (8,), co[:1], True)]):
         with pytest.raises(RuntimeError):
-            s.round_expr(bad)  # a pair sum needs exactly four tables and a linear combination
+            s.round_expr(bad)  # a pair sum needs exactly four tables
     s.close()

@@ -1403,7 +1403,7 @@ class ShiftSumcheckRounds:
         self._s = lib.ProductSumcheckSession.open(tables)
         if not phase2:
             assert len(tables) == 8
-            self._terms = [((0, 1), (), None), ((2, 3), (), None), ((4, 5), (), None), ((6, 7), (), None)]
+            self._terms = [((0, 1, 2, 3), (), None, True), ((4, 5, 6, 7), (), None, True)]  # two pair sums: P0 Q0 + P1 Q1 per opening
             self._s.set_points(0b0111)  # a quadratic: p(0), p(1), p(2)
         else:
             assert len(tables) == 7

@@ -504,11 +504,18 @@ __global__ void __launch_bounds__(256) PSC_OCC psc_expr_kernel(const uint64_t *b
                         }
                     }
                 }
-                Fr dl = fe_sub(l1, l0), lt = l0;
+                if (tm.nq) {
+                    Fr dl = fe_sub(l1, l0), lt = l0;
 #pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    if ((ex.points >> t) & 1u) w[t] = fr29_chain_mul(w[t], fr29_in_shift(lt));
-                    if (t < 3) lt = fe_add(lt, dl);
+                    for (int t = 0; t < 4; t++) {
+                        if ((ex.points >> t) & 1u) w[t] = fr29_chain_mul(w[t], fr29_in_shift(lt));
+                        if (t < 3) lt = fe_add(lt, dl);
+                    }
+                } else {  // no weight: one product by 1 brings the sum of two lazy values back under 2 r with exact limbs (what the sums expect)
+                    const F29 one_s = fr29_in_shift(Fr::one());
+#pragma unroll
+                    for (int t = 0; t < 4; t++)
+                        if ((ex.points >> t) & 1u) w[t] = fr29_chain_mul(w[t], one_s);
                 }
             } else
             for (uint32_t j = 0; j < tm.np; j++) {
@@ -845,12 +852,12 @@ int zg_psc_round_expr(zg_psc_t s, const zg_psc_term *terms, size_t n_terms, uint
         const bool pair_sum = t.n_prod >= 0 && (t.n_prod & ZG_PSC_PAIR_SUM);
         const int n_prod = pair_sum ? (t.n_prod & ~ZG_PSC_PAIR_SUM) : t.n_prod;
         bool bad = n_prod < 0 || n_prod > ZG_PSC_MAX_FACTORS || t.n_lin < 0 || t.n_lin > ZG_PSC_MAX_FACTORS || n_prod + t.n_lin == 0 ||
-                   (pair_sum && (n_prod != 4 || t.n_lin == 0));
+                   (pair_sum && n_prod != 4);
         for (int j = 0; !bad && j < n_prod; j++) bad = t.prod[j] < 0 || (size_t)t.prod[j] >= s->k;
         for (int m = 0; !bad && m < t.n_lin; m++) bad = t.lin[m] < 0 || (size_t)t.lin[m] >= s->k;
         if (bad) {
             set_error("zg_psc_round_expr: a term has at most 4 product tables and 4 linear-combination tables, indices below the table count; "
-                      "ZG_PSC_PAIR_SUM needs exactly 4 product tables and a linear combination");
+                      "ZG_PSC_PAIR_SUM needs exactly 4 product tables");
             return ZG_ERR_INVALID;
         }
         ex.t[ti].np = (uint32_t)n_prod;
