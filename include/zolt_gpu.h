@@ -378,13 +378,32 @@ ZG_API int zg_g1_sbases_shard(zg_sbases_t sb, int shard, int *device, size_t *st
  * serial combine + the single toAffine (:647-652). Result bytes equal zg_msm_g1's. Scalars: n x 4 limbs on the host. */
 ZG_API int zg_msm_g1_sharded(zg_sbases_t sb, size_t n, const uint64_t *scalars_mont, uint64_t out_xy[8], uint8_t *out_inf);
 /* same with the scalars resident: d_scalars_per_shard[i] points into device memory of shard i's device and holds the scalars of
- * that shard's chunk (zg_g1_sbases_shard tells which) */
+ * that shard's chunk (zg_g1_sbases_shard tells which). The buffers are read on the handle's own streams, which are not ordered
+ * with the streams of the caller: their contents must be complete (synchronised) when the call is made. */
 ZG_API int zg_msm_g1_sharded_dev(zg_sbases_t sb, size_t n, const uint64_t *const *d_scalars_per_shard, uint64_t out_xy[8],
                           uint8_t *out_inf);
 /* ParallelBatchMSM.compute / HyperKZG.batchCommit (src/msm/mod.zig:683-748, src/poly/commitment/mod.zig:558-570) sharded: k scalar
  * vectors over bases[0..n) -> k partials per device, ONE all-gather of k x 96 B per device, k combines. */
 ZG_API int zg_msm_g1_batch_sharded(zg_sbases_t sb, size_t n, const uint64_t *const *scalar_batches, size_t k, uint64_t *out_xy /* k*8 */,
                             uint8_t *out_inf /* k */);
+/* Pipelined forms: the call returns a ticket as soon as every device's launch set, the exchange and the combine are ENQUEUED;
+ * zg_sharded_wait(ticket) blocks until that call's result records have reached the host and hands them out (out_xy: k*8 words,
+ * out_inf: k bytes or NULL; k = 1 for zg_msm_g1_sharded_dev_async). A handle keeps zg_g1_sbases_inflight() calls in flight (3 by
+ * default; ZG_SHARDED_INFLIGHT = 1..8 at upload), each on its own stream per device, so the latency-bound tail and the exchange of
+ * one MSM run under the accumulation of the next — HyperKZG.batchCommit over long vectors (src/poly/commitment/mod.zig:558-570)
+ * and `zolt prove`'s three commitments (src/zkvm/mod.zig:1538,1572,1607) overlap this way. One more call than that without a wait
+ * returns ZG_ERR_INVALID. Tickets may be waited for in any order, each exactly once. The synchronous entry points above are
+ * these + zg_sharded_wait.
+ * Scalars: the host vectors of zg_msm_g1_batch_sharded_async must stay valid until the ticket is waited for. The device buffers
+ * of zg_msm_g1_sharded_dev[_async] are read on the handle's own streams: they must be COMPLETE when the call is made, unless
+ * ready_streams (S stream handles, shard order; NULL or NULL entries = complete) names for every shard the stream whose enqueued
+ * work fills that shard's buffer — the shard's launch set is then ordered behind it with an event. */
+ZG_API int zg_msm_g1_sharded_dev_async(zg_sbases_t sb, size_t n, const uint64_t *const *d_scalars_per_shard, void *const *ready_streams,
+                                uint64_t *ticket);
+ZG_API int zg_msm_g1_batch_sharded_async(zg_sbases_t sb, size_t n, const uint64_t *const *scalar_batches, size_t k /* >= 1 */,
+                                  uint64_t *ticket);
+ZG_API int zg_sharded_wait(zg_sbases_t sb, uint64_t ticket, uint64_t *out_xy, uint8_t *out_inf);
+ZG_API int zg_g1_sbases_inflight(zg_sbases_t sb); /* calls the handle keeps in flight */
 
 /* Sumcheck(F).Prover over a table sharded across the bound devices (S = the largest power of two <= devices and <= len):
  * LOW_PAIR tables by contiguous chunks, HIGH_HALF tables by residue class i mod S, so that every fold of the first

@@ -35,6 +35,10 @@ extern "C" {
 ZG_API int zg_profile_begin(int max_records);
 ZG_API int zg_profile_end(double ms_out[ZG_PROF_NKERNELS], uint64_t count_out[ZG_PROF_NKERNELS]);
 
+/* RCCL communicator sets (ncclCommInitAll) created so far by the one-process / several-GPU path: a set is shared by the sharded
+ * handles made while the same number of devices is bound; tests check that re-binding creates a new set instead of failing. */
+ZG_API int zg_sharded_comm_sets_created(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,43 @@
+"""bench.py's N > 1 code on the one-GPU test box: two ranks over the gloo rendezvous share cuda:0 (RCCL refuses two ranks per
+device), so every branch the driver's `--gpus N` run takes — the self-launcher, run_size at 2^20 and 2^22 with sharded bases, the
+sharded sumcheck measurement, the one-process / several-GPU child, the host barrier, the max-over-ranks timing and the single JSON
+line of rank 0 — executes here before it ever meets an 8-GPU node. Numbers from this run are never reported."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(args, extra_env, timeout=900):
+    env = dict(os.environ, **extra_env)
+    env.pop("ZG_SHARDS", None)
+    env.pop("ZG_SHARD_EXCHANGE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, (out.returncode, out.stdout[-800:], out.stderr[-1500:])
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_over_gloo_takes_every_multi_rank_branch():
+    d = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--msms-per-step", "2", "--no-cpu-baseline"], {"ZOLT_BENCH_DIST_BACKEND": "gloo"})
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "strong"
+    assert d["metric"] == "BN254 G1 MSM/sec" and d["unit"] == "MSM/s" and d["value"] > 0
+    assert d["config"]["points"] == 1 << 20 and d["config"]["points_per_gpu"] == 1 << 19
+    ex = d["extra"]
+    assert ex["msm_2^22_sharded"]["points_per_gpu"] == 1 << 21 and ex["msm_2^22_sharded"]["value"] > 0
+    assert ex["sumcheck_v20_sharded"]["ranks"] == 2 and ex["sumcheck_v20_sharded"]["rounds_per_s"] > 0
+    sp = ex["single_process_c_abi"]
+    assert "error" not in sp, sp
+    assert sp["devices"] >= 1 and any(isinstance(v, dict) and v.get("msm_per_s", 0) > 0 for v in sp.values())
+
+
+def test_bench_single_rank_through_the_sharded_path():
+    """world size 1 with the whole sharded sequence forced (partial MSM, RCCL all-gather with its one rank, device combine)"""
+    env = {"ZOLT_BENCH_FORCE_SHARDED": "1", "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29731"}
+    d = _bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--msms-per-step", "2", "--no-cpu-baseline", "--no-extra"], env)
+    assert d["n_gpus"] == 1 and d["value"] > 0

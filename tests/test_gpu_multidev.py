@@ -100,6 +100,112 @@ def test_rccl_exchange_at_one_device(env, monkeypatch):
         sb.free()
 
 
+def test_communicator_sets_survive_rebinding_and_shutdown(env, monkeypatch):
+    """Round-2 review: a 1-rank communicator created earlier in the process must not make a later, differently bound handle fail,
+    and a handle that outlives zg_shutdown must keep a working communicator (csrc/sharded.hip: CommSet). On the one-GPU box the
+    bound set cannot widen, so the sequence is: handle A (1 rank) -> second handle shares A's set -> zg_shutdown + zg_init_devices(1)
+    -> handle B gets a NEW set while A still computes through its old one."""
+    api, lib, ob, gm = env
+    monkeypatch.setenv("ZG_SHARDS", "1")
+    monkeypatch.setenv("ZG_SHARD_EXCHANGE", "rccl")
+    sc = _rand(ob, 1250, N)
+    want = ob.msm_g1(gm, None, sc)
+    a = lib.ShardedBases.upload(gm)
+    made = lib.sharded_comm_sets_created()
+    assert made >= 1 and a.exchange() == "rccl"
+    a2 = lib.ShardedBases.upload(gm[:64])
+    assert lib.sharded_comm_sets_created() == made  # same number of bound devices: the set is shared
+    a2.free()
+    lib.shutdown()  # drops the library's reference to the set; A keeps its own
+    lib.init()
+    lib.init_devices(1)
+    got = a.msm(sc)  # the review's out-of-bounds read: a live handle after zg_shutdown
+    assert got[1] == want[1] and np.array_equal(got[0], want[0])
+    b = lib.ShardedBases.upload(gm)
+    assert lib.sharded_comm_sets_created() == made + 1  # re-created for the new binding, not an error
+    for h in (a, b):
+        got = h.msm(sc)
+        assert got[1] == want[1] and np.array_equal(got[0], want[0])
+    a.free()
+    got = b.msm(sc)
+    assert got[1] == want[1] and np.array_equal(got[0], want[0])
+    b.free()
+
+
+@pytest.mark.parametrize("shards,exchange", [(1, None), (1, "rccl"), (3, None)])
+def test_pipelined_sharded_calls(env, shards, exchange, monkeypatch):
+    """zg_msm_g1_sharded_dev_async / zg_msm_g1_batch_sharded_async + zg_sharded_wait: as many calls in flight as the handle has
+    slots, waited for out of order; one more is refused; every result equals the oracle's."""
+    api, lib, ob, gm = env
+    monkeypatch.setenv("ZG_SHARDS", str(shards))
+    if exchange:
+        monkeypatch.setenv("ZG_SHARD_EXCHANGE", exchange)
+    sb = lib.ShardedBases.upload(gm)
+    try:
+        R = sb.inflight()
+        assert R == 3
+        vecs = [_rand(ob, 1270 + j, N) for j in range(R)]
+        wants = [ob.msm_g1(gm, None, v) for v in vecs]
+        d = [[lib.DeviceBuffer.from_host(v[s:s + l]) for _, s, l in sb.shards()] for v in vecs]
+        for rep in range(3):
+            tickets = [sb.msm_dev_async([t.ptr for t in d[j]], N) for j in range(R)]
+            with pytest.raises(lib.ZgError) as e:
+                sb.msm_dev_async([t.ptr for t in d[0]], N)
+            assert e.value.code == lib.ERR_INVALID and "zg_sharded_wait" in str(e.value)
+            for j in ([1, 0, 2] if rep == 0 else reversed(range(R))):
+                out, inf = sb.wait(tickets[j])
+                assert inf[0] == wants[j][1] and np.array_equal(out[0], wants[j][0]), (rep, j)
+            with pytest.raises(lib.ZgError):
+                sb.wait(tickets[0])  # a ticket completes once
+        # batches in flight beside a single MSM; a prefix; the synchronous form between them
+        t0, k0, keep0 = sb.msm_batch_async(vecs)
+        t1, k1, keep1 = sb.msm_batch_async([v[:777] for v in vecs[:2]], 777)
+        t2 = sb.msm_dev_async([t.ptr for t in d[1]], N)
+        out, inf = sb.wait(t1, k1)
+        for j in range(2):
+            w = ob.msm_g1(gm[:777], None, vecs[j][:777])
+            assert inf[j] == w[1] and np.array_equal(out[j], w[0])
+        got = sb.msm(vecs[2])  # takes the slot t1 freed
+        assert got[1] == wants[2][1] and np.array_equal(got[0], wants[2][0])
+        out, inf = sb.wait(t0, k0)
+        for j in range(R):
+            assert inf[j] == wants[j][1] and np.array_equal(out[j], wants[j][0])
+        out, inf = sb.wait(t2)
+        assert inf[0] == wants[1][1] and np.array_equal(out[0], wants[1][0])
+    finally:
+        sb.free()
+
+
+def test_sharded_dev_call_ordered_behind_the_callers_stream(env, monkeypatch):
+    """ready_streams: the shard's launch set waits for the caller's stream (advisor finding: the handle's streams are not ordered
+    with whatever fills the device scalars). A long fill kernel chain on a torch stream, then the call without any synchronisation."""
+    import torch
+    api, lib, ob, gm = env
+    monkeypatch.setenv("ZG_SHARDS", "2")
+    sb = lib.ShardedBases.upload(gm)
+    try:
+        sc = _rand(ob, 1290, N)
+        want = ob.msm_g1(gm, None, sc)
+        dev = torch.device("cuda", 0)
+        src = torch.from_numpy(sc.view(np.int64).copy()).to(dev)
+        st = torch.cuda.Stream(device=dev)
+        torch.cuda.synchronize()
+        for rep in range(3):
+            parts = [torch.zeros((l, 4), dtype=torch.int64, device=dev) for _, s, l in sb.shards()]
+            torch.cuda.synchronize()
+            with torch.cuda.stream(st):
+                big = torch.empty(1 << 26, dtype=torch.int64, device=dev)
+                for _ in range(8):
+                    big.fill_(rep)  # ~0.5 GB per fill: the scalars below are written well after the call has returned
+                for p_, (_, s, l) in zip(parts, sb.shards()):
+                    p_.copy_(src[s:s + l])
+            t = sb.msm_dev_async([p_.data_ptr() for p_ in parts], N, ready_streams=[st.cuda_stream] * len(parts))
+            out, inf = sb.wait(t)
+            assert inf[0] == want[1] and np.array_equal(out[0], want[0]), rep
+    finally:
+        sb.free()
+
+
 def test_sharded_msm_resident_scalars(env, monkeypatch):
     api, lib, ob, gm = env
     monkeypatch.setenv("ZG_SHARDS", "4")

@@ -45,6 +45,8 @@ def zig_type(ctype, array):
     if base == "zg_psc_term":
         return "?[*]const PscTerm"
     if base == "void":
+        if stars == 2 and "*const*" in t.replace(" ", ""):
+            return "?[*]const ?*anyopaque"  # array of stream handles
         if stars == 2:
             return "*?*anyopaque"
         return "?*const anyopaque" if const else "?*anyopaque"

@@ -123,6 +123,10 @@ pub extern fn zg_g1_sbases_shard(sb: ShardedBases, shard: c_int, device: ?*c_int
 pub extern fn zg_msm_g1_sharded(sb: ShardedBases, n: usize, scalars_mont: ?[*]const u64, out_xy: *[8]u64, out_inf: ?[*]u8) c_int;
 pub extern fn zg_msm_g1_sharded_dev(sb: ShardedBases, n: usize, d_scalars_per_shard: ?[*]const ?[*]const u64, out_xy: *[8]u64, out_inf: ?[*]u8) c_int;
 pub extern fn zg_msm_g1_batch_sharded(sb: ShardedBases, n: usize, scalar_batches: ?[*]const ?[*]const u64, k: usize, out_xy: ?[*]u64, out_inf: ?[*]u8) c_int;
+pub extern fn zg_msm_g1_sharded_dev_async(sb: ShardedBases, n: usize, d_scalars_per_shard: ?[*]const ?[*]const u64, ready_streams: ?[*]const ?*anyopaque, ticket: ?[*]u64) c_int;
+pub extern fn zg_msm_g1_batch_sharded_async(sb: ShardedBases, n: usize, scalar_batches: ?[*]const ?[*]const u64, k: usize, ticket: ?[*]u64) c_int;
+pub extern fn zg_sharded_wait(sb: ShardedBases, ticket: u64, out_xy: ?[*]u64, out_inf: ?[*]u8) c_int;
+pub extern fn zg_g1_sbases_inflight(sb: ShardedBases) c_int;
 pub extern fn zg_sumcheck_open_sharded(evals: ?[*]const u64, len: usize, layout: c_int, s: *ShardedSession) c_int;
 pub extern fn zg_sumcheck_shards(s: ShardedSession) c_int;
 pub extern fn zg_sumcheck_len_sharded(s: ShardedSession) usize;

@@ -153,5 +153,7 @@ int msm_batch_dev_wide(zg_bases_t b, size_t n, const uint64_t *d_scalars, size_t
 int msm_batch_partials_dev(zg_bases_t b, size_t n, const uint64_t *d_scalars, size_t k, hipStream_t st, uint64_t *d_out12);
 int msm_combine_batch_enqueue(const uint64_t *d_partials, size_t ranks, size_t rank_stride, size_t k, hipStream_t st, uint64_t *d_out9);
 int bases_device(zg_bases_t b);
+// poly.hip, for sharded.hip: enqueue a session's round-sums pass without waiting for its mailbox
+int sc_round_sums_start(zg_sc_t s);
 
 }  // namespace zg

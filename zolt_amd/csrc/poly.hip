@@ -1697,6 +1697,29 @@ int zg_sumcheck_round_sums(zg_sc_t s, uint64_t g0[4], uint64_t g1[4]) {
     return ZG_OK;
 }
 
+}  // extern "C"
+
+namespace zg {
+// sharded.hip: start the pass that produces the session's round sums (if the last fold did not leave them behind) without
+// waiting for the mailbox; the following zg_sumcheck_round_sums only collects them
+int sc_round_sums_start(zg_sc_t s) {
+    if (!s || s->len < 2) {
+        set_error("zg_sumcheck_round_sums: invalid session or protocol already complete");
+        return ZG_ERR_INVALID;
+    }
+    DeviceGuard dg(s->device);
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (!s->sums_valid) {
+        s->seq++;
+        ZG_TRY(launch_sums(s->layout, s->buf[s->cur], s->len, s->d_partials, s->h_pin, s->st, s->h_pin + 12, s->seq));
+        s->sums_valid = true;
+    }
+    return ZG_OK;
+}
+}  // namespace zg
+
+extern "C" {
+
 int zg_sumcheck_bind(zg_sc_t s, const uint64_t r[4]) {
     ZG_INIT();
     if (!s || !r || s->len < 2) {

@@ -20,8 +20,10 @@
 #include <string.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -42,7 +44,6 @@ struct RcclApi {
 };
 static RcclApi g_rccl;
 static std::mutex g_comm_mu;
-static std::vector<ncclComm_t> g_comms;  // one per bound device, ncclCommInitAll order (rank i = device i)
 
 static int rccl_load() {
     if (g_rccl.handle) return ZG_OK;
@@ -78,28 +79,43 @@ static int rccl_load() {
         }                                                                                  \
     } while (0)
 
-// communicator over devices 0..ndev-1 (created once, on first need)
-static int comms_ensure(int ndev) {
+// One communicator per device over devices 0..ndev-1 (ncclCommInitAll order: rank i = device i). A set belongs to the sharded
+// handles that were created while that many devices were bound and lives until the last of them is freed. When the bound set
+// widens (zg_init_devices(n) after zg_init, or after a handle over fewer devices) the next handle gets a NEW set for the wider
+// range; zg_shutdown only drops the library's own reference, so a handle that outlives it keeps working communicators.
+struct CommSet {
+    int ndev = 0;
+    std::vector<ncclComm_t> comms;
+    ~CommSet() {
+        for (ncclComm_t c : comms)
+            if (c && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c);
+    }
+};
+static std::shared_ptr<CommSet> g_commset;  // the set the next handle will share (guarded by g_comm_mu)
+static std::atomic<int> g_commsets_created{0};
+
+static int comms_acquire(int ndev, std::shared_ptr<CommSet> &out) {
     std::lock_guard<std::mutex> lk(g_comm_mu);
-    if ((int)g_comms.size() == ndev) return ZG_OK;
-    if (!g_comms.empty()) {
-        set_error("sharded: the set of bound devices changed after the communicator was created");
-        return ZG_ERR_INVALID;
+    if (g_commset && g_commset->ndev == ndev) {
+        out = g_commset;
+        return ZG_OK;
     }
     ZG_TRY(rccl_load());
     std::vector<int> devs(ndev);
     for (int i = 0; i < ndev; i++) devs[i] = i;
-    std::vector<ncclComm_t> comms(ndev);
-    ZG_NCCL(g_rccl.CommInitAll(comms.data(), ndev, devs.data()));
-    g_comms = comms;
+    auto cs = std::make_shared<CommSet>();
+    cs->ndev = ndev;
+    cs->comms.assign(ndev, nullptr);
+    ZG_NCCL(g_rccl.CommInitAll(cs->comms.data(), ndev, devs.data()));
+    g_commsets_created.fetch_add(1);
+    g_commset = cs;  // an older set (other ndev) stays alive through the handles that hold it
+    out = cs;
     return ZG_OK;
 }
 
 void sharded_shutdown() {
     std::lock_guard<std::mutex> lk(g_comm_mu);
-    for (ncclComm_t c : g_comms)
-        if (c && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c);
-    g_comms.clear();
+    g_commset.reset();
 }
 
 // ------------------------------------------------------------------ one host worker per shard
@@ -207,26 +223,42 @@ static int pick_exchange(const std::vector<int> &devs, Exchange &ex) {
 
 using namespace zg;
 
+// A sharded call in flight occupies one SLOT of the handle: a stream, staging and exchange buffers per shard, a result record
+// and a completion event. The handle's slots rotate, so several MSMs overlap on every device — the latency-bound tail and the
+// exchange of one under the ALU-bound accumulation of the next (the per-device handles rotate their own workspaces the same way).
 struct zg_sbases_s {
     size_t n = 0;
     struct Shard {
         int device = 0;
         size_t start = 0, len = 0;
         zg_bases_t b = nullptr;
+        Worker *worker = nullptr;
+    };
+    struct SlotShard {
         hipStream_t st = nullptr;
         uint64_t *d_scal = nullptr;    // staging for host scalars (len * 32 * vectors), grown on demand
         size_t scal_cap = 0;           // bytes
         uint64_t *d_send = nullptr;    // this shard's partial records (k * 12 words)
         uint64_t *d_gather = nullptr;  // all shards' records, shard-major (S * k * 12 words)
-        size_t xcap = 0;               // k the exchange buffers hold
-        hipEvent_t ev = nullptr;       // partial ready (P2P exchange)
-        Worker *worker = nullptr;
+        hipEvent_t ev_part = nullptr;  // partial ready (P2P exchange)
+        hipEvent_t ev_in = nullptr;    // the caller's scalars ready (zg_msm_g1_sharded_dev_async with ready_streams)
+    };
+    struct Slot {
+        std::vector<SlotShard> ps;
+        size_t xcap = 0;             // records per shard the exchange buffers hold
+        uint64_t *d_out9 = nullptr;  // result records on shard 0's device (9 words each: xy[8], flag word)
+        uint64_t *h_out9 = nullptr;  // pinned
+        size_t out_cap = 0;
+        hipEvent_t done = nullptr;   // recorded on shard 0's stream behind the copy into h_out9
+        uint64_t ticket = 0;
+        size_t k = 0;
+        bool pending = false;
     };
     std::vector<Shard> shards;
+    std::vector<Slot> slots;
+    uint64_t next_ticket = 1;
     Exchange ex = EX_NONE;
-    uint64_t *d_out9 = nullptr;  // result records on shard 0's device
-    size_t out_cap = 0;
-    uint64_t *h_out9 = nullptr;  // pinned
+    std::shared_ptr<CommSet> comms;  // EX_RCCL: the communicator set this handle was created with
     std::mutex mu;
 };
 
@@ -234,52 +266,66 @@ namespace zg {
 
 static void sbases_destroy(zg_sbases_s *sb) {
     if (!sb) return;
-    for (auto &sh : sb->shards) {
+    for (auto &sh : sb->shards)
         if (sh.worker) {
             sh.worker->stop();
             delete sh.worker;
         }
+    for (auto &sl : sb->slots) {
+        for (size_t i = 0; i < sl.ps.size() && i < sb->shards.size(); i++) {
+            auto &p = sl.ps[i];
+            DeviceScope scope(sb->shards[i].device);
+            if (p.st) (void)hipStreamSynchronize(p.st);
+            void *ptrs[] = {p.d_scal, p.d_send, p.d_gather};
+            for (void *q : ptrs)
+                if (q) (void)hipFree(q);
+            if (p.ev_part) (void)hipEventDestroy(p.ev_part);
+            if (p.ev_in) (void)hipEventDestroy(p.ev_in);
+            if (p.st) stream_release(p.st, sb->shards[i].device);
+        }
+        if (!sb->shards.empty()) {
+            DeviceScope scope(sb->shards[0].device);
+            if (sl.d_out9) (void)hipFree(sl.d_out9);
+            if (sl.h_out9) (void)hipHostFree(sl.h_out9);
+            if (sl.done) (void)hipEventDestroy(sl.done);
+        }
+    }
+    for (auto &sh : sb->shards) {
         DeviceScope scope(sh.device);
-        if (sh.st) (void)hipStreamSynchronize(sh.st);
         if (sh.b) (void)zg_g1_bases_free(sh.b);
-        void *ptrs[] = {sh.d_scal, sh.d_send, sh.d_gather};
-        for (void *p : ptrs)
-            if (p) (void)hipFree(p);
-        if (sh.ev) (void)hipEventDestroy(sh.ev);
-        if (sh.st) (void)hipStreamDestroy(sh.st);
     }
-    if (!sb->shards.empty()) {
-        DeviceScope scope(sb->shards[0].device);
-        if (sb->d_out9) (void)hipFree(sb->d_out9);
-        if (sb->h_out9) (void)hipHostFree(sb->h_out9);
-    }
+    sb->comms.reset();
     delete sb;
 }
 
-// exchange buffers for k records per shard
-static int shard_reserve_exchange(zg_sbases_s *sb, size_t k) {
+// exchange buffers of one (idle) slot for k records per shard
+static int slot_reserve(zg_sbases_s *sb, zg_sbases_s::Slot &sl, size_t k) {
     const size_t S = sb->shards.size();
-    for (auto &sh : sb->shards) {
-        if (sh.xcap >= k) continue;
-        DeviceScope scope(sh.device);
-        if (sh.st) ZG_HIP(hipStreamSynchronize(sh.st));
-        if (sh.d_send) (void)hipFree(sh.d_send);
-        if (sh.d_gather) (void)hipFree(sh.d_gather);
-        sh.d_send = sh.d_gather = nullptr;
-        sh.xcap = 0;
-        ZG_HIP(hipMalloc((void **)&sh.d_send, k * 12 * 8));
-        ZG_HIP(hipMalloc((void **)&sh.d_gather, S * k * 12 * 8));
-        sh.xcap = k;
+    if (sl.xcap < k && S > 1) {
+        for (size_t i = 0; i < S; i++) {
+            auto &p = sl.ps[i];
+            DeviceScope scope(sb->shards[i].device);
+            ZG_HIP(hipStreamSynchronize(p.st));
+            if (p.d_send) (void)hipFree(p.d_send);
+            if (p.d_gather) (void)hipFree(p.d_gather);
+            p.d_send = p.d_gather = nullptr;
+            sl.xcap = 0;
+            ZG_HIP(hipMalloc((void **)&p.d_send, k * 12 * 8));
+            if (i == 0 || sb->ex == EX_RCCL) ZG_HIP(hipMalloc((void **)&p.d_gather, S * k * 12 * 8));  // peer copies land on shard 0 only
+        }
+        sl.xcap = k;
     }
-    if (sb->out_cap < k) {
+    if (sl.out_cap < k) {
         DeviceScope scope(sb->shards[0].device);
-        if (sb->d_out9) (void)hipFree(sb->d_out9);
-        if (sb->h_out9) (void)hipHostFree(sb->h_out9);
-        sb->d_out9 = sb->h_out9 = nullptr;
-        sb->out_cap = 0;
-        ZG_HIP(hipMalloc((void **)&sb->d_out9, k * 9 * 8));
-        ZG_HIP(hipHostMalloc((void **)&sb->h_out9, k * 9 * 8));
-        sb->out_cap = k;
+        ZG_HIP(hipStreamSynchronize(sl.ps[0].st));
+        if (sl.d_out9) (void)hipFree(sl.d_out9);
+        if (sl.h_out9) (void)hipHostFree(sl.h_out9);
+        sl.d_out9 = sl.h_out9 = nullptr;
+        sl.out_cap = 0;
+        ZG_HIP(hipMalloc((void **)&sl.d_out9, k * 9 * 8));
+        ZG_HIP(hipMemset(sl.d_out9, 0, k * 9 * 8));  // a record's flag is written as ONE byte of its ninth word
+        ZG_HIP(hipHostMalloc((void **)&sl.h_out9, k * 9 * 8));
+        sl.out_cap = k;
     }
     return ZG_OK;
 }
@@ -291,63 +337,172 @@ static size_t shard_count(const zg_sbases_s::Shard &sh, size_t n) {
     return c < sh.len ? c : sh.len;
 }
 
-// Run `per_shard(i)` on every shard's worker (each on its own device), then exchange k records per shard and combine them on
-// shard 0; the k result records land in sb->h_out9.
-static int sharded_finish(zg_sbases_s *sb, size_t k, const std::function<int(size_t)> &per_shard) {
-    const size_t S = sb->shards.size();
-    for (size_t i = 0; i < S; i++) sb->shards[i].worker->submit([&per_shard, i] { return per_shard(i); });
-    int rc = ZG_OK;
-    for (size_t i = 0; i < S; i++) {
-        int r = sb->shards[i].worker->wait();
-        if (r != ZG_OK && rc == ZG_OK) rc = r;
+// Enqueue one sharded call on a free slot: `per_shard(i, slot)` issues shard i's launch set on the slot's stream of that shard
+// (on the shard's worker thread, all shards concurrently) and leaves k records in the slot's send buffer — or, with a single
+// shard, the k finished result records; then the exchange, the combine on shard 0 and the copy of the k result records into the
+// slot's pinned buffer are enqueued behind them. Nothing is waited for: the ticket completes in sharded_wait. The caller holds
+// sb->mu.
+typedef std::function<int(size_t, zg_sbases_s::Slot &)> PerShard;
+static int sharded_submit(zg_sbases_s *sb, size_t k, const PerShard &per_shard, uint64_t *ticket) {
+    const size_t S = sb->shards.size(), R = sb->slots.size();
+    zg_sbases_s::Slot *slp = nullptr;
+    for (size_t t = 0; t < R && !slp; t++) {
+        zg_sbases_s::Slot &c = sb->slots[(sb->next_ticket + t) % R];
+        if (!c.pending) slp = &c;
     }
-    if (rc != ZG_OK) {
-        for (auto &sh : sb->shards) {
-            DeviceScope scope(sh.device);
-            (void)hipStreamSynchronize(sh.st);
+    if (!slp) {
+        set_error("sharded: every in-flight slot of the handle holds an unfinished call (ZG_SHARDED_INFLIGHT): zg_sharded_wait for a ticket first");
+        return ZG_ERR_INVALID;
+    }
+    zg_sbases_s::Slot &sl = *slp;
+    ZG_TRY(slot_reserve(sb, sl, k));
+    int rc = ZG_OK;
+    if (S == 1) {  // no thread hop for a single shard
+        DeviceScope scope(sb->shards[0].device);
+        rc = per_shard(0, sl);
+    } else {
+        for (size_t i = 0; i < S; i++) sb->shards[i].worker->submit([&per_shard, &sl, i] { return per_shard(i, sl); });
+        for (size_t i = 0; i < S; i++) {
+            int r = sb->shards[i].worker->wait();
+            if (r != ZG_OK && rc == ZG_OK) rc = r;
         }
+    }
+    auto drain = [&] {  // after an error: nothing of the slot may still be in flight when it is handed out again
+        for (size_t i = 0; i < S; i++) {
+            DeviceScope scope(sb->shards[i].device);
+            (void)hipStreamSynchronize(sl.ps[i].st);
+        }
+    };
+    if (rc != ZG_OK) {
+        std::string keep = zg_last_error();
+        drain();
+        set_error(keep);
         return rc;
     }
-    zg_sbases_s::Shard &root = sb->shards[0];
-    const uint64_t *d_all = root.d_send;
-    if (sb->ex == EX_RCCL) {
-        ZG_NCCL(g_rccl.GroupStart());
-        for (size_t i = 0; i < S; i++) {
-            zg_sbases_s::Shard &sh = sb->shards[i];
-            DeviceScope scope(sh.device);
-            ncclResult_t r = g_rccl.AllGather(sh.d_send, sh.d_gather, k * 12, ncclUint64, g_comms[sh.device], sh.st);
-            if (r != ncclSuccess) {
-                (void)g_rccl.GroupEnd();
-                set_error(std::string("ncclAllGather: ") + g_rccl.GetErrorString(r));
-                return ZG_ERR_HIP;
+    const int root_dev = sb->shards[0].device;
+    hipStream_t root_st = sl.ps[0].st;
+    const uint64_t *d_all = sl.ps[0].d_send;
+    rc = [&]() -> int {
+        if (sb->ex == EX_RCCL) {
+            CommSet *cs = sb->comms.get();
+            if (!cs || cs->comms.size() < S) {
+                set_error("sharded: the handle has no communicator set");
+                return ZG_ERR_INVALID;
             }
+            ZG_NCCL(g_rccl.GroupStart());
+            for (size_t i = 0; i < S; i++) {
+                DeviceScope scope(sb->shards[i].device);
+                ncclResult_t r = g_rccl.AllGather(sl.ps[i].d_send, sl.ps[i].d_gather, k * 12, ncclUint64, cs->comms[sb->shards[i].device], sl.ps[i].st);
+                if (r != ncclSuccess) {
+                    (void)g_rccl.GroupEnd();
+                    set_error(std::string("ncclAllGather: ") + g_rccl.GetErrorString(r));
+                    return ZG_ERR_HIP;
+                }
+            }
+            ZG_NCCL(g_rccl.GroupEnd());
+            d_all = sl.ps[0].d_gather;
+        } else if (sb->ex == EX_P2P) {
+            DeviceScope scope(root_dev);
+            for (size_t i = 0; i < S; i++) {
+                ZG_HIP(hipStreamWaitEvent(root_st, sl.ps[i].ev_part, 0));
+                if (sb->shards[i].device == root_dev)
+                    ZG_HIP(hipMemcpyAsync(sl.ps[0].d_gather + i * k * 12, sl.ps[i].d_send, k * 12 * 8, hipMemcpyDeviceToDevice, root_st));
+                else
+                    ZG_HIP(hipMemcpyPeerAsync(sl.ps[0].d_gather + i * k * 12, root_dev, sl.ps[i].d_send, sb->shards[i].device, k * 12 * 8, root_st));
+            }
+            d_all = sl.ps[0].d_gather;
         }
-        ZG_NCCL(g_rccl.GroupEnd());
-        d_all = root.d_gather;
-    } else if (sb->ex == EX_P2P) {
-        DeviceScope scope(root.device);
-        for (size_t i = 0; i < S; i++) {
-            zg_sbases_s::Shard &sh = sb->shards[i];
-            ZG_HIP(hipStreamWaitEvent(root.st, sh.ev, 0));
-            if (sh.device == root.device)
-                ZG_HIP(hipMemcpyAsync(root.d_gather + i * k * 12, sh.d_send, k * 12 * 8, hipMemcpyDeviceToDevice, root.st));
-            else
-                ZG_HIP(hipMemcpyPeerAsync(root.d_gather + i * k * 12, root.device, sh.d_send, sh.device, k * 12 * 8, root.st));
-        }
-        d_all = root.d_gather;
+        DeviceScope scope(root_dev);
+        if (S > 1) ZG_TRY(msm_combine_batch_enqueue(d_all, S, k * 12, k, root_st, sl.d_out9));
+        ZG_HIP(hipMemcpyAsync(sl.h_out9, sl.d_out9, k * 9 * 8, hipMemcpyDeviceToHost, root_st));
+        ZG_HIP(hipEventRecord(sl.done, root_st));
+        return ZG_OK;
+    }();
+    if (rc != ZG_OK) {
+        std::string keep = zg_last_error();
+        drain();
+        set_error(keep);
+        return rc;
     }
-    DeviceScope scope(root.device);
-    ZG_TRY(msm_combine_batch_enqueue(d_all, S, k * 12, k, root.st, sb->d_out9));
-    ZG_HIP(hipMemcpyAsync(sb->h_out9, sb->d_out9, k * 9 * 8, hipMemcpyDeviceToHost, root.st));
-    ZG_HIP(hipStreamSynchronize(root.st));
+    sl.pending = true;
+    sl.k = k;
+    sl.ticket = sb->next_ticket++;
+    *ticket = sl.ticket;
     return ZG_OK;
 }
 
-static void copy_records(const zg_sbases_s *sb, size_t k, uint64_t *out_xy, uint8_t *out_inf) {
-    for (size_t j = 0; j < k; j++) {
-        for (int l = 0; l < 8; l++) out_xy[8 * j + l] = sb->h_out9[9 * j + l];
-        if (out_inf) out_inf[j] = (uint8_t)(sb->h_out9[9 * j + 8] & 0xff);
+// complete a ticket: wait for its slot's event, hand out the k result records, free the slot
+static int sharded_wait(zg_sbases_s *sb, uint64_t ticket, uint64_t *out_xy, uint8_t *out_inf) {
+    zg_sbases_s::Slot *slp = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(sb->mu);
+        for (auto &c : sb->slots)
+            if (c.pending && c.ticket == ticket) slp = &c;
     }
+    if (!slp) {
+        set_error("zg_sharded_wait: unknown or already completed ticket");
+        return ZG_ERR_INVALID;
+    }
+    hipError_t e;
+    {
+        DeviceScope scope(sb->shards[0].device);
+        e = hipEventSynchronize(slp->done);  // the slot's buffers cannot change while it is pending
+    }
+    std::lock_guard<std::mutex> lk(sb->mu);
+    if (e == hipSuccess && out_xy)
+        for (size_t j = 0; j < slp->k; j++) {
+            for (int l = 0; l < 8; l++) out_xy[8 * j + l] = slp->h_out9[9 * j + l];
+            if (out_inf) out_inf[j] = (uint8_t)(slp->h_out9[9 * j + 8] & 0xff);
+        }
+    slp->pending = false;
+    if (e != hipSuccess) {
+        set_error(std::string("zg_sharded_wait: ") + hipGetErrorString(e));
+        return ZG_ERR_HIP;
+    }
+    return ZG_OK;
+}
+
+// shard i's launch set for k host scalar vectors (each n scalars; the shard's chunk is copied to the slot's staging buffer)
+static int shard_host_vectors(zg_sbases_s *sb, size_t i, zg_sbases_s::Slot &sl, size_t n, const uint64_t *const *batches, size_t k) {
+    zg_sbases_s::Shard &sh = sb->shards[i];
+    zg_sbases_s::SlotShard &p = sl.ps[i];
+    const size_t cnt = shard_count(sh, n);
+    if (cnt * 32 * k > p.scal_cap) {
+        ZG_HIP(hipStreamSynchronize(p.st));
+        if (p.d_scal) (void)hipFree(p.d_scal);
+        p.d_scal = nullptr;
+        p.scal_cap = 0;
+        size_t want = sh.len * 32 * k;
+        ZG_HIP(hipMalloc((void **)&p.d_scal, want));
+        p.scal_cap = want;
+    }
+    for (size_t j = 0; j < k && cnt; j++)
+        ZG_HIP(hipMemcpyAsync(p.d_scal + 4 * cnt * j, batches[j] + 4 * sh.start, cnt * 32, hipMemcpyHostToDevice, p.st));
+    if (sb->shards.size() == 1) {  // a single shard finishes its own records: no partial, no combine launch
+        if (k == 1) return zg_msm_g1_dev_async(sh.b, 0, cnt, p.d_scal, p.st, sl.d_out9, reinterpret_cast<uint8_t *>(sl.d_out9 + 8));
+        return zg_msm_g1_batch_dev(sh.b, cnt, p.d_scal, k, p.st, sl.d_out9);
+    }
+    if (k == 1) ZG_TRY(zg_msm_g1_partial_fast_dev(sh.b, 0, cnt, p.d_scal, p.st, p.d_send));
+    else ZG_TRY(msm_batch_partials_dev(sh.b, cnt, p.d_scal, k, p.st, p.d_send));
+    if (sb->ex == EX_P2P) ZG_HIP(hipEventRecord(p.ev_part, p.st));
+    return ZG_OK;
+}
+
+static int batch_args_ok(zg_sbases_t sb, size_t n, const uint64_t *const *batches, size_t k, const char *who) {
+    if (!sb || (k && !batches)) {
+        set_error(std::string(who) + ": invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    if (n > sb->n) {
+        set_error("msm: range exceeds uploaded bases");
+        return ZG_ERR_INVALID;
+    }
+    for (size_t j = 0; j < k; j++)
+        if (n && !batches[j]) {
+            set_error(std::string(who) + ": null scalar vector");
+            return ZG_ERR_INVALID;
+        }
+    return ZG_OK;
 }
 
 }  // namespace zg
@@ -377,32 +532,45 @@ int zg_g1_bases_upload_sharded(const uint64_t *xy, const uint8_t *inf, size_t n,
     ZG_TRY(shard_layout(devs));
     Exchange ex;
     ZG_TRY(pick_exchange(devs, ex));
-    if (ex == EX_RCCL) ZG_TRY(comms_ensure(bound_devices()));
+    std::shared_ptr<CommSet> comms;
+    if (ex == EX_RCCL) ZG_TRY(comms_acquire(bound_devices(), comms));
     const size_t S = devs.size();
     zg_sbases_s *sb = new zg_sbases_s();
     sb->n = n;
     sb->ex = ex;
+    sb->comms = comms;
     sb->shards.resize(S);
+    int R = env_int_s("ZG_SHARDED_INFLIGHT", 3);
+    sb->slots.resize(R < 1 ? 1 : (R > 8 ? 8 : R));
+    for (auto &sl : sb->slots) sl.ps.resize(S);
     int rc = ZG_OK;
     for (size_t i = 0; i < S && rc == ZG_OK; i++) {
         zg_sbases_s::Shard &sh = sb->shards[i];
         sh.device = devs[i];
         (void)zg_shard_bounds(n, (int)S, (int)i, &sh.start, &sh.len);
         DeviceScope scope(sh.device);
-        hipError_t e = hipStreamCreateWithFlags(&sh.st, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&sh.ev, hipEventDisableTiming);
+        hipError_t e = hipSuccess;
+        for (auto &sl : sb->slots) {
+            auto &p = sl.ps[i];
+            p.st = stream_acquire();  // from the runtime's free list: creating a stream costs ~3 ms on this stack
+            if (!p.st) e = hipErrorOutOfMemory;
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&p.ev_part, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&p.ev_in, hipEventDisableTiming);
+            if (e == hipSuccess && i == 0) e = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming);
+        }
         if (e != hipSuccess) {
             set_error(std::string("sharded upload: ") + hipGetErrorString(e));
             rc = ZG_ERR_HIP;
             break;
         }
         rc = zg_g1_bases_upload(xy + 8 * sh.start, inf ? inf + sh.start : nullptr, sh.len, cfg, &sh.b);
-        if (rc == ZG_OK) {
+        if (rc == ZG_OK && S > 1) {
             sh.worker = new Worker();
             sh.worker->start(sh.device);
         }
     }
-    if (rc == ZG_OK) rc = shard_reserve_exchange(sb, 1);
+    for (auto &sl : sb->slots)
+        if (rc == ZG_OK) rc = slot_reserve(sb, sl, 1);
     if (rc != ZG_OK) {
         std::string keep = zg_last_error();
         sbases_destroy(sb);
@@ -437,46 +605,75 @@ int zg_g1_sbases_shard(zg_sbases_t sb, int shard, int *device, size_t *start, si
 
 int zg_g1_sbases_exchange(zg_sbases_t sb) { return sb ? (int)sb->ex : -1; }
 
-int zg_msm_g1_batch_sharded(zg_sbases_t sb, size_t n, const uint64_t *const *batches, size_t k, uint64_t *out_xy, uint8_t *out_inf) {
+int zg_g1_sbases_inflight(zg_sbases_t sb) { return sb ? (int)sb->slots.size() : 0; }
+
+int zg_sharded_comm_sets_created(void) { return g_commsets_created.load(); }
+
+int zg_msm_g1_batch_sharded_async(zg_sbases_t sb, size_t n, const uint64_t *const *batches, size_t k, uint64_t *ticket) {
     ZG_INIT();
-    if (!sb || (k && (!batches || !out_xy))) {
-        set_error("zg_msm_g1_batch_sharded: invalid argument");
+    ZG_TRY(batch_args_ok(sb, n, batches, k, "zg_msm_g1_batch_sharded_async"));
+    if (!ticket || k == 0) {
+        set_error("zg_msm_g1_batch_sharded_async: invalid argument (k must be at least 1)");
+        return ZG_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(sb->mu);
+    PerShard per_shard = [&](size_t i, zg_sbases_s::Slot &sl) -> int { return shard_host_vectors(sb, i, sl, n, batches, k); };
+    return sharded_submit(sb, k, per_shard, ticket);
+}
+
+int zg_msm_g1_sharded_dev_async(zg_sbases_t sb, size_t n, const uint64_t *const *d_scalars_per_shard, void *const *ready_streams,
+                                uint64_t *ticket) {
+    ZG_INIT();
+    if (!sb || !ticket || (n && !d_scalars_per_shard)) {
+        set_error("zg_msm_g1_sharded_dev_async: invalid argument");
         return ZG_ERR_INVALID;
     }
     if (n > sb->n) {
         set_error("msm: range exceeds uploaded bases");
         return ZG_ERR_INVALID;
     }
-    if (k == 0) return ZG_OK;
-    for (size_t j = 0; j < k; j++)
-        if (n && !batches[j]) {
-            set_error("zg_msm_g1_batch_sharded: null scalar vector");
+    std::lock_guard<std::mutex> lk(sb->mu);
+    PerShard per_shard = [&](size_t i, zg_sbases_s::Slot &sl) -> int {
+        zg_sbases_s::Shard &sh = sb->shards[i];
+        zg_sbases_s::SlotShard &p = sl.ps[i];
+        size_t cnt = shard_count(sh, n);
+        if (cnt && !d_scalars_per_shard[i]) {
+            set_error("zg_msm_g1_sharded_dev: null shard pointer");
             return ZG_ERR_INVALID;
         }
-    std::lock_guard<std::mutex> lk(sb->mu);
-    ZG_TRY(shard_reserve_exchange(sb, k));
-    auto per_shard = [&](size_t i) -> int {
-        zg_sbases_s::Shard &sh = sb->shards[i];
-        size_t cnt = shard_count(sh, n);
-        if (cnt * 32 * k > sh.scal_cap) {
-            ZG_HIP(hipStreamSynchronize(sh.st));
-            if (sh.d_scal) (void)hipFree(sh.d_scal);
-            sh.d_scal = nullptr;
-            sh.scal_cap = 0;
-            size_t want = sh.len * 32 * k;
-            ZG_HIP(hipMalloc((void **)&sh.d_scal, want));
-            sh.scal_cap = want;
+        if (cnt && ready_streams && ready_streams[i]) {  // order the shard's work behind whatever fills its scalars
+            ZG_HIP(hipEventRecord(p.ev_in, reinterpret_cast<hipStream_t>(ready_streams[i])));
+            ZG_HIP(hipStreamWaitEvent(p.st, p.ev_in, 0));
         }
-        for (size_t j = 0; j < k && cnt; j++)
-            ZG_HIP(hipMemcpyAsync(sh.d_scal + 4 * cnt * j, batches[j] + 4 * sh.start, cnt * 32, hipMemcpyHostToDevice, sh.st));
-        if (k == 1) ZG_TRY(zg_msm_g1_partial_fast_dev(sh.b, 0, cnt, sh.d_scal, sh.st, sh.d_send));
-        else ZG_TRY(msm_batch_partials_dev(sh.b, cnt, sh.d_scal, k, sh.st, sh.d_send));
-        if (sb->ex == EX_P2P) ZG_HIP(hipEventRecord(sh.ev, sh.st));
+        if (sb->shards.size() == 1)
+            return zg_msm_g1_dev_async(sh.b, 0, cnt, d_scalars_per_shard[i], p.st, sl.d_out9, reinterpret_cast<uint8_t *>(sl.d_out9 + 8));
+        ZG_TRY(zg_msm_g1_partial_fast_dev(sh.b, 0, cnt, d_scalars_per_shard[i], p.st, p.d_send));
+        if (sb->ex == EX_P2P) ZG_HIP(hipEventRecord(p.ev_part, p.st));
         return ZG_OK;
     };
-    ZG_TRY(sharded_finish(sb, k, per_shard));
-    copy_records(sb, k, out_xy, out_inf);
-    return ZG_OK;
+    return sharded_submit(sb, 1, per_shard, ticket);
+}
+
+int zg_sharded_wait(zg_sbases_t sb, uint64_t ticket, uint64_t *out_xy, uint8_t *out_inf) {
+    ZG_INIT();
+    if (!sb) {
+        set_error("zg_sharded_wait: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    return sharded_wait(sb, ticket, out_xy, out_inf);
+}
+
+int zg_msm_g1_batch_sharded(zg_sbases_t sb, size_t n, const uint64_t *const *batches, size_t k, uint64_t *out_xy, uint8_t *out_inf) {
+    ZG_INIT();
+    ZG_TRY(batch_args_ok(sb, n, batches, k, "zg_msm_g1_batch_sharded"));
+    if (k && !out_xy) {
+        set_error("zg_msm_g1_batch_sharded: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    if (k == 0) return ZG_OK;
+    uint64_t ticket = 0;
+    ZG_TRY(zg_msm_g1_batch_sharded_async(sb, n, batches, k, &ticket));
+    return sharded_wait(sb, ticket, out_xy, out_inf);
 }
 
 int zg_msm_g1_sharded(zg_sbases_t sb, size_t n, const uint64_t *scalars, uint64_t out_xy[8], uint8_t *out_inf) {
@@ -494,26 +691,9 @@ int zg_msm_g1_sharded_dev(zg_sbases_t sb, size_t n, const uint64_t *const *d_sca
         set_error("zg_msm_g1_sharded_dev: invalid argument");
         return ZG_ERR_INVALID;
     }
-    if (n > sb->n) {
-        set_error("msm: range exceeds uploaded bases");
-        return ZG_ERR_INVALID;
-    }
-    std::lock_guard<std::mutex> lk(sb->mu);
-    ZG_TRY(shard_reserve_exchange(sb, 1));
-    auto per_shard = [&](size_t i) -> int {
-        zg_sbases_s::Shard &sh = sb->shards[i];
-        size_t cnt = shard_count(sh, n);
-        if (cnt && !d_scalars_per_shard[i]) {
-            set_error("zg_msm_g1_sharded_dev: null shard pointer");
-            return ZG_ERR_INVALID;
-        }
-        ZG_TRY(zg_msm_g1_partial_fast_dev(sh.b, 0, cnt, d_scalars_per_shard[i], sh.st, sh.d_send));
-        if (sb->ex == EX_P2P) ZG_HIP(hipEventRecord(sh.ev, sh.st));
-        return ZG_OK;
-    };
-    ZG_TRY(sharded_finish(sb, 1, per_shard));
-    copy_records(sb, 1, out_xy, out_inf);
-    return ZG_OK;
+    uint64_t ticket = 0;
+    ZG_TRY(zg_msm_g1_sharded_dev_async(sb, n, d_scalars_per_shard, nullptr, &ticket));
+    return sharded_wait(sb, ticket, out_xy, out_inf);
 }
 
 }  // extern "C"
@@ -548,16 +728,18 @@ static void ssc_destroy(zg_ssc_s *s) {
 // the S residual elements (one per shard, shard order = index order for both layouts) become the tail table on device 0
 static int ssc_enter_tail(zg_ssc_s *s) {
     std::vector<uint64_t> res(4 * s->S);
-    for (size_t i = 0; i < s->S; i++) {
+    int rc = ZG_OK;
+    for (size_t i = 0; i < s->S && rc == ZG_OK; i++) {
         DeviceScope scope(s->devs[i]);
-        ZG_TRY(zg_sumcheck_read(s->sess[i], res.data() + 4 * i));
+        rc = zg_sumcheck_read(s->sess[i], res.data() + 4 * i);
     }
-    for (size_t i = 0; i < s->S; i++) {
+    for (size_t i = 0; i < s->S; i++) {  // every shard session is closed, also when a read failed
         DeviceScope scope(s->devs[i]);
         (void)zg_sumcheck_close(s->sess[i]);
         s->sess[i] = nullptr;
     }
     s->sess.clear();
+    if (rc != ZG_OK) return rc;
     DeviceScope scope(s->devs[0]);
     return zg_sumcheck_open(res.data(), s->S, s->layout, &s->tail);
 }
@@ -620,6 +802,12 @@ int zg_sumcheck_round_sums_sharded(zg_ssc_t s, uint64_t g0[4], uint64_t g1[4]) {
     if (s->tail) {
         DeviceScope scope(s->devs[0]);
         return zg_sumcheck_round_sums(s->tail, g0, g1);
+    }
+    // rounds whose sums the preceding fold did not leave behind (round 0, the first round after open): every shard's pass is
+    // enqueued before the first mailbox is waited for, so the round costs one latency, not S
+    for (size_t i = 0; i < s->S; i++) {
+        DeviceScope scope(s->devs[i]);
+        ZG_TRY(sc_round_sums_start(s->sess[i]));
     }
     uint64_t a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
     for (size_t i = 0; i < s->S; i++) {

@@ -30,6 +30,7 @@ SYMBOLS = [
     "zg_field_op", "zg_fr_scale", "zg_g1_affine_add_batch",
     "zg_shard_bounds", "zg_g1_bases_upload_sharded", "zg_g1_sbases_free", "zg_g1_sbases_len", "zg_g1_sbases_shards", "zg_g1_sbases_exchange", "zg_g1_sbases_shard",
     "zg_msm_g1_sharded", "zg_msm_g1_sharded_dev", "zg_msm_g1_batch_sharded",
+    "zg_msm_g1_sharded_dev_async", "zg_msm_g1_batch_sharded_async", "zg_sharded_wait", "zg_g1_sbases_inflight",
     "zg_sumcheck_open_sharded", "zg_sumcheck_shards", "zg_sumcheck_len_sharded", "zg_sumcheck_round_sums_sharded",
     "zg_sumcheck_bind_sharded", "zg_sumcheck_final_sharded", "zg_sumcheck_close_sharded",
     "zg_g1_bases_upload", "zg_g1_bases_upload_dev", "zg_g1_bases_free", "zg_g1_bases_len", "zg_g1_bases_plan",
@@ -46,7 +47,7 @@ SYMBOLS = [
     "zg_psc_final", "zg_psc_close",
 ]
 # test / bench scaffolding of include/zolt_gpu_internal.h (not part of the drop-in boundary)
-INTERNAL_SYMBOLS = ["zg_profile_begin", "zg_profile_end"]
+INTERNAL_SYMBOLS = ["zg_profile_begin", "zg_profile_end", "zg_sharded_comm_sets_created"]
 
 
 class MsmConfig(C.Structure):
@@ -273,6 +274,11 @@ class Bases:
         return out, inf
 
 
+def sharded_comm_sets_created():
+    """test hook (include/zolt_gpu_internal.h): RCCL communicator sets created so far by the one-process multi-GPU path"""
+    return int(_lib.zg_sharded_comm_sets_created())
+
+
 def shard_bounds(n, shards, shard):
     """ParallelMSM's chunk `shard` of `shards` over n points -> (start, len); host arithmetic only (works without a GPU)"""
     st, ln = C.c_size_t(), C.c_size_t()
@@ -333,6 +339,36 @@ class ShardedBases:
         out = np.empty((k, 8), dtype=np.uint64)
         inf = np.zeros(k, dtype=np.uint8)
         _chk(_lib.zg_msm_g1_batch_sharded(self._h, C.c_size_t(n), arr, C.c_size_t(k), _h(out), _hb(inf)), "zg_msm_g1_batch_sharded")
+        return out, inf
+
+    def inflight(self):
+        """sharded calls the handle keeps in flight (its slots)"""
+        return int(_lib.zg_g1_sbases_inflight(self._h))
+
+    def msm_dev_async(self, d_scalars_per_shard, n, ready_streams=None):
+        """-> ticket; the result comes from wait(ticket). ready_streams: per shard the stream whose work fills its scalars (or None)"""
+        arr = (C.c_void_p * len(d_scalars_per_shard))(*[int(p) if p else None for p in d_scalars_per_shard])
+        rs = None
+        if ready_streams is not None:
+            rs = (C.c_void_p * len(ready_streams))(*[int(p) if p else None for p in ready_streams])
+        t = C.c_uint64(0)
+        _chk(_lib.zg_msm_g1_sharded_dev_async(self._h, C.c_size_t(n), arr, rs, C.byref(t)), "zg_msm_g1_sharded_dev_async")
+        return int(t.value)
+
+    def msm_batch_async(self, batches, n=None):
+        """-> (ticket, k, keepalive); the host vectors must stay alive until wait(ticket)"""
+        batches = [_c(b) for b in batches]
+        k = len(batches)
+        n = (batches[0].size // 4 if k else 0) if n is None else n
+        arr = (_u64p * max(k, 1))(*[_h(b) for b in batches])
+        t = C.c_uint64(0)
+        _chk(_lib.zg_msm_g1_batch_sharded_async(self._h, C.c_size_t(n), arr, C.c_size_t(k), C.byref(t)), "zg_msm_g1_batch_sharded_async")
+        return int(t.value), k, batches
+
+    def wait(self, ticket, k=1):
+        out = np.empty((k, 8), dtype=np.uint64)
+        inf = np.zeros(k, dtype=np.uint8)
+        _chk(_lib.zg_sharded_wait(self._h, C.c_uint64(ticket), _h(out), _hb(inf)), "zg_sharded_wait")
         return out, inf
 
     def free(self):
