@@ -207,6 +207,8 @@ ZG_API int zg_hyperkzg_batch_open(zg_bases_t srs, const uint64_t *const *polys, 
  * scale may be NULL (= one). Identical values to GruenSplitEqPolynomial's tables
  * (src/poly/split_eq.zig:122-171). */
 ZG_API int zg_fr_eq_table(const uint64_t *r, size_t v, const uint64_t *scale, uint64_t *out);
+/* device output; ASYNCHRONOUS: one launch on `stream`, r and scale travel as kernel arguments (nothing of the caller's is read
+ * after the call returns, no upload precedes the kernel). v <= 34. */
 ZG_API int zg_fr_eq_table_dev(const uint64_t *r_host, size_t v, const uint64_t *scale_host, uint64_t *d_out, void *stream);
 /* The eq+1 evaluation table of EqPlusOnePrefixSuffixPoly (src/poly/mod.zig:462-560, computeEqPlusOneEvals :530-548; the same helper in
  * src/zkvm/spartan/stage3_prover.zig:1878-1894): out[j] = EqPlusOnePolynomial.mle(r, bits(j)), r[0] <-> MSB, 2^v entries. Over the

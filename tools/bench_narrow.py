@@ -62,7 +62,8 @@ def main():
             II_TERMS), 0b1101))
         one_first = np.stack([lib.field_op(lib.FR, lib.OP_TO_MONT, np.array([[1, 0, 0, 0]], dtype=np.uint64))[0], tab[1], tab[2]])
         out[f"psc_fold_evals_p1q3_coeff_1_g_g2_points_0_2_{name}_us"] = med(lambda: psc_once(ch, 4, lambda s: s.round_evals((0,), (1, 2, 3), one_first), 0b0101))
-        out[f"psc_plain_fold_5_tables_{name}_us"] = med(lambda: psc_once(ch, 5, lambda s: None))
+        # (a plain fold without a following evaluation is asynchronous: it has no host-visible end to time here — its kernel time is
+        # in the rocprofv3 kernel stats, profiles/*_product_form_kernel_stats.csv: psc_fold_kernel)
     print(out)
 
 

@@ -225,11 +225,13 @@ __global__ void __launch_bounds__(1024) msm_scan_a_kernel(const uint32_t *__rest
 __global__ void __launch_bounds__(1024) msm_scan_b_kernel(const uint32_t *__restrict__ hist, uint32_t NK, const uint32_t *__restrict__ loc,
                                                           const uint32_t *__restrict__ locz, const uint32_t *__restrict__ tile_tot,
                                                           uint32_t *__restrict__ starts, uint32_t *__restrict__ nzrank,
-                                                          uint32_t *__restrict__ nzlist, uint32_t *__restrict__ state) {
+                                                          uint32_t *__restrict__ nzlist, uint32_t *__restrict__ state, uint32_t nstate) {
     ZG_HIPRIO();
     __shared__ uint32_t pre[2];
-    // the launch set's MsmState (heavy / huge bucket counters of the reduction) is cleared here: one launch less than a memset
-    if (state && blockIdx.x == 0 && threadIdx.x < 4) state[threadIdx.x] = 0;
+    // the launch set's MsmState (heavy / huge bucket counters of the reduction and the arrival counters of the huge buckets) is
+    // cleared here: one launch less than a memset
+    if (state && blockIdx.x == 0)
+        for (uint32_t w = threadIdx.x; w < nstate; w += 1024) state[w] = 0;
     uint32_t tid = threadIdx.x, k = blockIdx.x * 1024 + tid;
     if (tid < 64) {  // one wave sums the totals of the preceding tiles (at most 2048 tiles)
         uint32_t a = 0, az = 0;
@@ -465,6 +467,14 @@ __global__ void __launch_bounds__(1024) msm_partition_kernel(const uint32_t *dig
         if (tid == T - 1) lbase[NCB] = sums[T - 1];
     }
     __syncthreads();
+    // destinations of this block's bins (at most 3 per thread: NCB <= 3000), loaded now so that their latency hides under the placing pass
+    const uint32_t *row = blockoff + (size_t)blockIdx.x * NCB;
+    uint32_t dst_pre[3];
+#pragma unroll
+    for (int u = 0; u < 3; u++) {
+        uint32_t k = (uint32_t)u * T + tid;
+        dst_pre[u] = k < NCB ? tstarts[k] + row[k] : 0u;
+    }
     // a thread's entries belong to at most two scalars (rows 0 and 1 of every window): their point indices are found once
     // (several scalar vectors lie back to back over the same bases: index modulo n_pts)
     const uint32_t pt_row0 = PLAIN ? i0 + tid : (i0 + tid) % n_pts, pt_row1 = PLAIN ? i0 + T + tid : (i0 + T + tid) % n_pts;
@@ -479,12 +489,22 @@ __global__ void __launch_bounds__(1024) msm_partition_kernel(const uint32_t *dig
         }
     }
     __syncthreads();
-    // copy-out: wave v takes bins v, v + 16, ...; lanes walk the bin's run
-    const uint32_t *row = blockoff + (size_t)blockIdx.x * NCB;
-    for (uint32_t bin = tid >> 6; bin < NCB; bin += T >> 6) {
+    // every bin's destination goes to LDS first (the placing cursors are done with): read inside the copy loop, the two global
+    // loads per bin were a dependent ~2 us each, i.e. most of this kernel's time (NCB / 16 iterations per wave)
+#pragma unroll
+    for (int u = 0; u < 3; u++) {
+        uint32_t k = (uint32_t)u * T + tid;
+        if (k < NCB) cnt[k] = dst_pre[u];
+    }
+    __syncthreads();
+    // copy-out: a group of sg lanes (64, 32 or 16, by the average run length) walks one bin's run; wave v takes the bins
+    // v * (64 / sg) + group, stepping by 16 waves' worth
+    const uint32_t avg = STAGE_ENTRIES / NCB, sg = avg >= 48 ? 64u : (avg >= 24 ? 32u : 16u), per = 64u / sg;
+    const uint32_t lane = tid & 63, sub = lane / sg, sl = lane % sg;
+    for (uint32_t bin = (tid >> 6) * per + sub; bin < NCB; bin += (T >> 6) * per) {
         uint32_t a = lbase[bin], b = lbase[bin + 1];
-        uint32_t dst = tstarts[bin] + row[bin];
-        for (uint32_t j = a + (tid & 63); j < b; j += 64) tmp[dst + (j - a)] = buf[j];
+        uint32_t dst = cnt[bin];
+        for (uint32_t j = a + sl; j < b; j += sg) tmp[dst + (j - a)] = buf[j];
     }
 }
 
@@ -570,6 +590,9 @@ __global__ void __launch_bounds__(1024) msm_fine_place_kernel(const uint32_t *tm
     uint32_t count = total - q0 < FINE_SLICE ? total - q0 : FINE_SLICE;
     const uint4 *src = reinterpret_cast<const uint4 *>(tmp + tstarts[bin] + q0);
     const uint32_t T = 1024, quads = (count + 3) / 4;
+    // where every fine key's run goes: loaded now (latency under the counting pass), kept in LDS for the copy loop, which used
+    // to wait for two dependent global loads per key
+    uint32_t dst_pre = tid < nf ? cstarts[bin] + fbase[(size_t)bin * nf + tid] + slicecnt[(size_t)blockIdx.x * nf + tid] : 0u;
     uint4 v[FINE_SLICE / 4 / 1024];
 #pragma unroll
     for (int u = 0; u < (int)(FINE_SLICE / 4 / 1024); u++) {
@@ -605,10 +628,11 @@ __global__ void __launch_bounds__(1024) msm_fine_place_kernel(const uint32_t *tm
             }
     }
     __syncthreads();
-    uint32_t base = cstarts[bin];
+    if (tid < nf) cnt[tid] = dst_pre;  // the cursors are done with
+    __syncthreads();
     for (uint32_t f = tid >> 6; f < nf; f += T >> 6) {
         uint32_t a = lbase[f], b = lbase[f + 1];
-        uint32_t dst = base + fbase[(size_t)bin * nf + f] + slicecnt[(size_t)blockIdx.x * nf + f];
+        uint32_t dst = cnt[f];
         for (uint32_t j = a + (tid & 63); j < b; j += 64) sorted[dst + (j - a)] = buf[j];
     }
 }
@@ -728,11 +752,15 @@ __global__ void __launch_bounds__(256) msm_accumulate_kernel(const uint32_t *sor
 // bucket, contiguous. Buckets with few partials are finished by one thread each; "heavy" buckets
 // (more than 8 partials) go through two block-level tree stages.
 struct MsmState {
-    uint32_t nheavy;  // buckets with more than 8*GS partials (queued by msm_bucket_combine)
-    uint32_t nhuge;   // of those, buckets with more than HUGE_PARTIALS (queued by msm_heavy_wave)
+    uint32_t nheavy;  // buckets with more than 8*GS and at most HUGE_PARTIALS partials (queued by msm_bucket_combine)
+    uint32_t nhuge;   // buckets with more than HUGE_PARTIALS partials (queued by msm_bucket_combine)
     uint32_t pad[2];
+    // followed by one arrival counter per huge bucket (index = position in the huge list): see msm_heavy_kernel
 };
 static constexpr uint32_t HUGE_PARTIALS = 2048;
+static constexpr uint32_t HEAVY_BLOCK_ITEMS = 2048;
+// words of a launch set's state: the header and one arrival counter per possible huge bucket (each owns > 2048 partial slots)
+static uint32_t state_words(uint32_t NT, uint32_t NK) { return 4 + (NT + NK) / HUGE_PARTIALS + 1; }
 
 ZG_DEV uint32_t chunk_len(uint32_t total, uint32_t NT) {
     uint32_t C = (total + NT - 1) / NT;
@@ -808,12 +836,23 @@ __global__ void __launch_bounds__(64) msm_bucket_combine_kernel(const char *part
             light = true;  // empty bucket: identity
         } else {
             uint32_t q0 = s0 / C, q1 = (s1 - 1) / C, cnt = q1 - q0 + 1, base = q0 + nzrank[k];
-            if (cnt > 8u * (uint32_t)GS) {
-                if (g == 0 && q == 0) heavy_list[atomicAdd(&st->nheavy, 1u)] = k;
+            if (cnt > 8u * (uint32_t)GS) {  // heavy: a wave each; huge (a 0/1 witness column's bucket): block trees — msm_heavy_kernel
+                if (g == 0 && q == 0) {
+                    if (cnt > HUGE_PARTIALS) heavy_list[NK + atomicAdd(&st->nhuge, 1u)] = k;
+                    else heavy_list[atomicAdd(&st->nheavy, 1u)] = k;
+                }
             } else {
                 light = true;
                 if (g < cnt) acc = xyzz29_load(part + 144 * (size_t)(base + g));  // the first partial is taken as it is
-                for (uint32_t j = g + (uint32_t)GS; j < cnt; j += (uint32_t)GS) acc = xyzz29_add4(acc, xyzz29_load(part + 144 * (size_t)(base + j)), q);
+                // the next partial is loaded under the current addition (the chain used to pay a memory latency per partial)
+                uint32_t j = g + (uint32_t)GS;
+                XYZZ29 nxt = j < cnt ? xyzz29_load(part + 144 * (size_t)(base + j)) : xyzz29_identity();
+                while (j < cnt) {
+                    XYZZ29 cur = nxt;
+                    j += (uint32_t)GS;
+                    if (j < cnt) nxt = xyzz29_load(part + 144 * (size_t)(base + j));
+                    acc = xyzz29_add4(acc, cur, q);
+                }
             }
         }
     }
@@ -848,47 +887,43 @@ __device__ __forceinline__ XYZZ29 block_sum_xyzz29(const XYZZ29 &acc, uint4 *sh)
     return xyzz29_load(&sh[0]);
 }
 
-// heavy buckets, first stage: one wave per bucket — strided serial sums (<= 32 per lane) and a shuffle tree.
-// (Typical source: the top window of a c-bit decomposition covers only a few bits, so its digits pile into a
-// small set of buckets.) Only "huge" buckets (a 0/1 column: one bucket holds everything) go on to the block stages.
-__global__ void __launch_bounds__(64) msm_heavy_wave_kernel(const char *part, const uint32_t *starts, const uint32_t *nzrank, uint32_t NK,
-                                                            uint32_t NT, const uint32_t *heavy_list, uint32_t *huge_list, MsmState *st,
-                                                            char *buckets) {
-    ZG_HIPRIO();
-    uint32_t nheavy = st->nheavy;
-    uint32_t C = chunk_len(starts[NK], NT);
-    uint32_t lane = threadIdx.x;
-    for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
-        uint32_t k = heavy_list[h];
-        uint32_t s0 = starts[k], s1 = starts[k + 1];
-        uint32_t q0 = s0 / C, q1 = (s1 - 1) / C, cnt = q1 - q0 + 1, base = q0 + nzrank[k];
-        if (cnt > HUGE_PARTIALS) {
-            if (lane == 0) huge_list[atomicAdd(&st->nhuge, 1u)] = k;
-            continue;
-        }
-        XYZZ29 acc = xyzz29_identity();
-        for (uint32_t j = lane; j < cnt; j += 64) acc = xyzz29_add(acc, xyzz29_load(part + 144 * (size_t)(base + j)));
-        for (int d = 1; d < 64; d <<= 1) {
-            XYZZ29 o = xyzz29_shfl_down(acc, d);
-            if ((lane & (uint32_t)(2 * d - 1)) == 0) acc = xyzz29_add(acc, o);
-        }
-        if (lane == 0) xyzz29_store(buckets + 144 * (size_t)k, acc);
-    }
-}
-
-static constexpr uint32_t HEAVY_BLOCK_ITEMS = 2048;
-
-// heavy stage A: block b owns partial slots [2048 b, 2048 (b+1)); every run of a heavy bucket inside is
-// tree-summed by the whole block into part2[b + nzrank[k]]
-__global__ void __launch_bounds__(256) msm_heavy_a_kernel(const char *part, const uint32_t *starts, const uint32_t *nzrank,
-                                                         const uint32_t *nzlist, uint32_t NK, uint32_t NT, int GS, char *part2,
-                                                         const MsmState *st) {
+// Heavy buckets in ONE launch (uniform scalars have none: the kernel then returns at once — it used to be three launches of ~5 us
+// each). Part 1, one wave per heavy bucket (more than 8*GS, at most HUGE_PARTIALS partials; typical source: the top window of a
+// c-bit decomposition covers only a few bits, so its digits pile into a small set of buckets): strided serial sums (<= 32 per lane)
+// and a shuffle tree. Part 2, huge buckets (a 0/1 column: one bucket holds everything): block b owns the partial slots
+// [2048 b, 2048 (b+1)) and tree-sums every run of a huge bucket inside into part2[b + nzrank[k]] (stage A); the block that
+// arrives LAST at the bucket's counter (device-scope acq_rel, as the sumcheck rounds end) sums the bucket's stage-A partials
+// (stage B). The counters are cleared by msm_scan_b_kernel.
+__global__ void __launch_bounds__(256) msm_heavy_kernel(const char *part, const uint32_t *starts, const uint32_t *nzrank, const uint32_t *nzlist,
+                                                        uint32_t NK, uint32_t NT, const uint32_t *heavy_list, MsmState *st, char *part2,
+                                                        char *buckets) {
     ZG_HIPRIO();
     __shared__ uint4 sh[256 * 9];
-    if (st->nhuge == 0) return;
-    uint32_t C = chunk_len(starts[NK], NT);
+    __shared__ uint32_t sh_last;
+    const uint32_t nheavy = st->nheavy, nhuge = st->nhuge;
+    if (nheavy == 0 && nhuge == 0) return;
+    const uint32_t C = chunk_len(starts[NK], NT), tid = threadIdx.x;
+    {
+        const uint32_t lane = tid & 63;
+        for (uint32_t h = blockIdx.x * 4 + (tid >> 6); h < nheavy; h += gridDim.x * 4) {
+            uint32_t k = heavy_list[h];
+            uint32_t s0 = starts[k], s1 = starts[k + 1];
+            uint32_t q0 = s0 / C, q1 = (s1 - 1) / C, cnt = q1 - q0 + 1, base = q0 + nzrank[k];
+            XYZZ29 acc = xyzz29_identity();
+            for (uint32_t j = lane; j < cnt; j += 64) acc = xyzz29_add(acc, xyzz29_load(part + 144 * (size_t)(base + j)));
+            for (int d = 1; d < 64; d <<= 1) {
+                XYZZ29 o = xyzz29_shfl_down(acc, d);
+                if ((lane & (uint32_t)(2 * d - 1)) == 0) acc = xyzz29_add(acc, o);
+            }
+            if (lane == 0) xyzz29_store(buckets + 144 * (size_t)k, acc);
+        }
+    }
+    if (nhuge == 0) return;
+    const uint32_t *huge_list = heavy_list + NK;
+    uint32_t *arrive = reinterpret_cast<uint32_t *>(st) + 4;
     uint32_t NZ = nzrank[NK];  // non-empty buckets; the r-th one, k = nzlist[r], owns slots [starts[k]/C + r, ...)
     uint32_t lo_slot = blockIdx.x * HEAVY_BLOCK_ITEMS, hi_slot = lo_slot + HEAVY_BLOCK_ITEMS;
+    if (lo_slot >= NT + NK) return;
     uint32_t lo = 0, hi = NZ;  // last r whose first slot is <= lo_slot (first slots increase strictly with r)
     while (hi - lo > 1) {
         uint32_t mid = (lo + hi) >> 1;
@@ -902,29 +937,24 @@ __global__ void __launch_bounds__(256) msm_heavy_a_kernel(const char *part, cons
         if (cnt <= HUGE_PARTIALS || base + cnt <= lo_slot) continue;
         uint32_t r0 = base > lo_slot ? base : lo_slot, r1 = base + cnt < hi_slot ? base + cnt : hi_slot;
         XYZZ29 acc = xyzz29_identity();
-        for (uint32_t j = r0 + threadIdx.x; j < r1; j += 256) acc = xyzz29_add(acc, xyzz29_load(part + 144 * (size_t)j));
+        for (uint32_t j = r0 + tid; j < r1; j += 256) acc = xyzz29_add(acc, xyzz29_load(part + 144 * (size_t)j));
         XYZZ29 res = block_sum_xyzz29(acc, sh);
-        if (threadIdx.x == 0) xyzz29_store(part2 + 144 * (size_t)(blockIdx.x + r), res);
+        const uint32_t b0 = base / HEAVY_BLOCK_ITEMS, b1 = (base + cnt - 1) / HEAVY_BLOCK_ITEMS;
+        if (tid == 0) {
+            xyzz29_store(part2 + 144 * (size_t)(blockIdx.x + r), res);  // plain store: the arrival's release publishes it
+            uint32_t h = 0;
+            while (h < nhuge && huge_list[h] != k) h++;
+            uint32_t arrived = __hip_atomic_fetch_add(&arrive[h], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            sh_last = arrived == b1 - b0 ? 1u : 0u;
+        }
         __syncthreads();
-    }
-}
-
-// heavy stage B: one block per heavy bucket sums its stage-A partials (at most a few dozen)
-__global__ void __launch_bounds__(256) msm_heavy_b_kernel(const char *part2, const uint32_t *starts, const uint32_t *nzrank, uint32_t NK,
-                                                         uint32_t NT, const uint32_t *heavy_list, const MsmState *st, char *buckets) {
-    ZG_HIPRIO();
-    __shared__ uint4 sh[256 * 9];
-    uint32_t nheavy = st->nhuge;  // heavy_list is the huge list here
-    uint32_t C = chunk_len(starts[NK], NT);
-    for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
-        uint32_t k = heavy_list[h];
-        uint32_t s0 = starts[k], s1 = starts[k + 1];
-        uint32_t q0 = s0 / C, q1 = (s1 - 1) / C, cnt = q1 - q0 + 1, base = q0 + nzrank[k];
-        uint32_t b0 = base / HEAVY_BLOCK_ITEMS, b1 = (base + cnt - 1) / HEAVY_BLOCK_ITEMS;
-        XYZZ29 acc = xyzz29_identity();
-        for (uint32_t bb = b0 + threadIdx.x; bb <= b1; bb += 256) acc = xyzz29_add(acc, xyzz29_load(part2 + 144 * (size_t)(bb + nzrank[k])));
-        XYZZ29 r = block_sum_xyzz29(acc, sh);
-        if (threadIdx.x == 0) xyzz29_store(buckets + 144 * (size_t)k, r);
+        if (sh_last) {  // stage B: this block saw every other block of the bucket arrive
+            XYZZ29 a2 = xyzz29_identity();
+            for (uint32_t bb = b0 + tid; bb <= b1; bb += 256) a2 = xyzz29_add(a2, xyzz29_load(part2 + 144 * (size_t)(bb + r)));
+            __syncthreads();  // sh is reused
+            XYZZ29 tot = block_sum_xyzz29(a2, sh);
+            if (tid == 0) xyzz29_store(buckets + 144 * (size_t)k, tot);
+        }
         __syncthreads();
     }
 }
@@ -1309,13 +1339,19 @@ static uint32_t sort_span(uint32_t NK) {
 }
 
 // chunks (threads, or quads of lanes) of the chunk-scheduled accumulate for a launch set of `digits` entries
-static uint32_t chunk_threads(uint64_t digits) {
-    uint64_t want = digits / 16;
+// alone: no other MSM of the handle is in flight — nothing needs the spare registers, the kernel takes every slot (2^20 points:
+// 1.26 -> 1.18 ms)
+static uint32_t chunk_threads(uint64_t digits, bool alone = false) {
+    static const uint64_t per_chunk = [] {
+        int v = env_int("ZG_MSM_CHUNK_ENTRIES", 16);  // sorted entries per chunk a launch aims for (each chunk also emits >= 1 partial)
+        return (uint64_t)(v < 1 ? 1 : v);
+    }();
+    uint64_t want = digits / per_chunk;
     uint32_t nt = 1024;
     while (nt < want && nt < 131072u) nt <<= 1;
     // full size = 2 waves per SIMD on 256 CUs; 15/16 of it leaves a few CUs with spare registers so that
     // another stream's latency-bound kernels (bit sums, final) can run under this kernel (measured +4-6 % MSM/s)
-    return nt == 131072u ? 122880u : nt;
+    return nt == 131072u && !alone ? 122880u : nt;
 }
 
 static int make_plan(size_t n, const zg_msm_config *cfg, MsmPlan &p, size_t batch = 1) {
@@ -1371,11 +1407,12 @@ static int make_plan(size_t n, const zg_msm_config *cfg, MsmPlan &p, size_t batc
     }
     // chunk-scheduled accumulate: enough threads to fill 2 waves per SIMD on 256 CUs, fewer for small inputs
     p.NT = 0;
-    if (env_int("ZG_MSM_CHUNK_SCHED", 1)) p.NT = (uint32_t)env_int("ZG_MSM_CHUNK_THREADS", (int)chunk_threads((uint64_t)n * batch * p.W));
+    if (env_int("ZG_MSM_CHUNK_SCHED", 1)) p.NT = (uint32_t)env_int("ZG_MSM_CHUNK_THREADS", (int)chunk_threads((uint64_t)n * batch * p.W, true));  // the most a launch uses
     // combine lanes per bucket: a bucket expects about NT/NK + 1 partials; about 4 per quad (every tree level costs the whole
     // wave one more addition; ZG_MSM_COMBINE_PER_QUAD = 8 halves the quads, measured equal)
     p.GS = 1;
-    while (p.GS < 16 && (uint64_t)p.GS * (uint64_t)env_int("ZG_MSM_COMBINE_PER_QUAD", 4) < (uint64_t)p.NT / p.NK + 1) p.GS <<= 1;  // GS quads of lanes per bucket: 4 * GS <= 64
+    const uint64_t nt_usual = p.NT ? (getenv("ZG_MSM_CHUNK_THREADS") ? p.NT : chunk_threads((uint64_t)n * batch * p.W)) : 0;  // with other MSMs in flight
+    while (p.GS < 16 && (uint64_t)p.GS * (uint64_t)env_int("ZG_MSM_COMBINE_PER_QUAD", 4) < nt_usual / p.NK + 1) p.GS <<= 1;  // GS quads of lanes per bucket: 4 * GS <= 64
     // bit-sum partial blocks: ~4 buckets per thread, at most 16 (the final kernel reduces 16 lanes per bit)
     int pb = (int)(p.NB / 2 / (256 * 4));
     p.PB = pb < 1 ? 1 : (pb > 16 ? 16 : pb);
@@ -1464,7 +1501,7 @@ static hipError_t lane_alloc(zg_bases_s::Lane &ln, const MsmPlan &p, size_t n_to
         A(ln.d_part, slots * 144);
         A(ln.d_part2, (slots / HEAVY_BLOCK_ITEMS + 1 + p.NK) * 144);
         A(ln.d_heavy, (size_t)p.NK * 8);
-        A(ln.d_state, sizeof(MsmState));
+        A(ln.d_state, state_words(p.NT, p.NK) * 4);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ln.done, hipEventDisableTiming);
     return e;
@@ -1521,7 +1558,7 @@ static int bases_create(const uint64_t *d_xy, const uint8_t *d_inf_in, size_t n,
     }
     ZG_ALLOC(b->d_table, (size_t)p.L * n * 64);
     if (d_inf_in) ZG_ALLOC(b->d_inf, n);
-    int nlanes = env_int("ZG_MSM_LANES", 3);
+    int nlanes = env_int("ZG_MSM_LANES", 6);  // 2^17-point MSMs: 0.36 ms per MSM with 3 in flight, 0.25 with 6 (tools/bench_tail.py)
     if (nlanes < 1) nlanes = 1;
     if (nlanes > 8) nlanes = 8;
     bool lds_sort = (size_t)p.NK * 4 <= 128 * 1024 && env_int("ZG_MSM_LDS_SORT", 1);
@@ -1711,7 +1748,8 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
         hipLaunchKernelGGL(msm_scan_a_kernel, dim3(tiles), dim3(1024), 0, st, ln.d_hist, p.NK, ln.d_scan_tmp, ln.d_scan_tmp + p.NK,
                            ln.d_scan_tmp + 2 * (size_t)p.NK);
         hipLaunchKernelGGL(msm_scan_b_kernel, dim3(tiles), dim3(1024), 0, st, ln.d_hist, p.NK, ln.d_scan_tmp, ln.d_scan_tmp + p.NK,
-                           ln.d_scan_tmp + 2 * (size_t)p.NK, ln.d_starts, ln.d_nzrank, ln.d_nzlist, reinterpret_cast<uint32_t *>(ln.d_state));
+                           ln.d_scan_tmp + 2 * (size_t)p.NK, ln.d_starts, ln.d_nzrank, ln.d_nzlist, reinterpret_cast<uint32_t *>(ln.d_state),
+                           ln.d_state ? state_words(p.NT, p.NK) : 0u);
     } else if (ln.d_blockhist) {
         uint32_t nblk = nblk_cap;
         while (nblk > 1 && (size_t)(nblk - 1) * 1024 >= n) nblk--;  // no empty blocks for short sub-range MSMs
@@ -1727,7 +1765,8 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
             hipLaunchKernelGGL(msm_scan_a_kernel, dim3(tiles), dim3(1024), 0, st, ln.d_hist, p.NK, ln.d_scan_tmp, ln.d_scan_tmp + p.NK,
                                ln.d_scan_tmp + 2 * (size_t)p.NK);
             hipLaunchKernelGGL(msm_scan_b_kernel, dim3(tiles), dim3(1024), 0, st, ln.d_hist, p.NK, ln.d_scan_tmp, ln.d_scan_tmp + p.NK,
-                               ln.d_scan_tmp + 2 * (size_t)p.NK, ln.d_starts, ln.d_nzrank, ln.d_nzlist, reinterpret_cast<uint32_t *>(ln.d_state));
+                               ln.d_scan_tmp + 2 * (size_t)p.NK, ln.d_starts, ln.d_nzrank, ln.d_nzlist, reinterpret_cast<uint32_t *>(ln.d_state),
+                           ln.d_state ? state_words(p.NT, p.NK) : 0u);
         }
         static PerDeviceOnce scatter_once;
         ZG_HIP(scatter_once.run([] {
@@ -1746,7 +1785,8 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
             hipLaunchKernelGGL(msm_scan_a_kernel, dim3(tiles), dim3(1024), 0, st, ln.d_hist, p.NK, ln.d_scan_tmp, ln.d_scan_tmp + p.NK,
                                ln.d_scan_tmp + 2 * (size_t)p.NK);
             hipLaunchKernelGGL(msm_scan_b_kernel, dim3(tiles), dim3(1024), 0, st, ln.d_hist, p.NK, ln.d_scan_tmp, ln.d_scan_tmp + p.NK,
-                               ln.d_scan_tmp + 2 * (size_t)p.NK, ln.d_starts, ln.d_nzrank, ln.d_nzlist, reinterpret_cast<uint32_t *>(ln.d_state));
+                               ln.d_scan_tmp + 2 * (size_t)p.NK, ln.d_starts, ln.d_nzrank, ln.d_nzlist, reinterpret_cast<uint32_t *>(ln.d_state),
+                           ln.d_state ? state_words(p.NT, p.NK) : 0u);
         }
         ZG_HIP(hipMemsetAsync(ln.d_hist, 0, (size_t)p.NK * 4, st));
         hipLaunchKernelGGL(msm_scatter_kernel, dim3(div_up(n, 256), p.W), dim3(256), 0, st, ln.d_dig, (uint32_t)n, (uint32_t)n_pts, p.G,
@@ -1757,7 +1797,11 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
     if (p.NT) {
         // a launch over a sub-range of the handle (a short prefix, the last set of a batch) gets as many chunks as ITS digits
         // warrant, never more than the workspace was sized for
-        uint32_t NT = chunk_threads((uint64_t)n * p.W);
+        bool alone = env_int("ZG_MSM_ALONE_FULL", 1) != 0;
+        for (auto &o : b->lanes)
+            if (alone && &o != &ln && o.used && hipEventQuery(o.done) == hipErrorNotReady) alone = false;
+        (void)hipGetLastError();  // hipErrorNotReady is an answer, not a failure
+        uint32_t NT = chunk_threads((uint64_t)n * p.W, alone);
         if (NT > p.NT || getenv("ZG_MSM_CHUNK_THREADS")) NT = p.NT;
         if (NT <= (uint32_t)env_int("ZG_MSM_QUAD_ACC_MAX_CHUNKS", 32768))
             hipLaunchKernelGGL(msm_accumulate_chunk_kernel<true>, dim3(div_up((size_t)NT * 4, 256)), dim3(256), 0, st, ln.d_sorted, ln.d_starts,
@@ -1769,14 +1813,9 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
         prof_begin(ZG_PROF_MSM_REDUCE, st);
         hipLaunchKernelGGL(msm_bucket_combine_kernel, dim3(div_up((size_t)p.NK * p.GS * 4, 64)), dim3(64), 0, st, ln.d_part, ln.d_starts,
                            ln.d_nzrank, p.NK, NT, p.GS, ln.d_partial, ln.d_heavy, reinterpret_cast<MsmState *>(ln.d_state));
-        hipLaunchKernelGGL(msm_heavy_wave_kernel, dim3(1024), dim3(64), 0, st, ln.d_part, ln.d_starts, ln.d_nzrank, p.NK, NT, ln.d_heavy,
-                           ln.d_heavy + p.NK, reinterpret_cast<MsmState *>(ln.d_state), ln.d_partial);
-        uint32_t nblk_a = (NT + p.NK) / HEAVY_BLOCK_ITEMS + 1;
-        hipLaunchKernelGGL(msm_heavy_a_kernel, dim3(nblk_a), dim3(256), 0, st, ln.d_part, ln.d_starts, ln.d_nzrank, ln.d_nzlist, p.NK, NT,
-                           p.GS, ln.d_part2,
-                           reinterpret_cast<const MsmState *>(ln.d_state));
-        hipLaunchKernelGGL(msm_heavy_b_kernel, dim3(64), dim3(256), 0, st, ln.d_part2, ln.d_starts, ln.d_nzrank, p.NK, NT, ln.d_heavy + p.NK,
-                           reinterpret_cast<const MsmState *>(ln.d_state), ln.d_partial);
+        uint32_t nblk_a = (NT + p.NK) / HEAVY_BLOCK_ITEMS + 1;  // stage-A blocks of the huge buckets; at least 256 blocks = 1024 waves for the heavy ones
+        hipLaunchKernelGGL(msm_heavy_kernel, dim3(nblk_a < 256 ? 256 : nblk_a), dim3(256), 0, st, ln.d_part, ln.d_starts, ln.d_nzrank, ln.d_nzlist,
+                           p.NK, NT, ln.d_heavy, reinterpret_cast<MsmState *>(ln.d_state), ln.d_part2, ln.d_partial);
     } else {
         hipLaunchKernelGGL(msm_accumulate_kernel, dim3(div_up((size_t)p.NK * p.S, 256)), dim3(256), 0, st, ln.d_sorted, ln.d_starts,
                            b->d_table, p.NK, p.S, ln.d_partial);

@@ -22,12 +22,9 @@
 namespace zg {
 
 // ------------------------------------------------------------------ eq table
-// Factor tables of eq(r, .) (r[0] <-> MSB of the index), one launch:
-//   blocks [0, nb_hi):  hi[h]   = scale * prod_{j < v_hi} (bit_j(h) ? r[j] : 1 - r[j]),        bit_j = bit (v_hi-1-j) of h
-//   the other blocks:   lo[t]   =         prod_{j < v_lo} (bit_j(t) ? r[v_hi+j] : 1 - r[v_hi+j])   (256 entries at most)
-// The kernel is pure dependency latency (a few thousand outputs), so FOUR adjacent lanes share one output: lane q
-// multiplies the factors j = q (mod 4), then two shuffle steps combine the four partial products — a chain of
-// ceil(v/4) + 2 products instead of v.
+// A factor product of eq(r, .) for one index (r[0] <-> MSB of the index). Used where a launch is pure dependency latency (the
+// prefix-table set of GruenSplitEqPolynomial): FOUR adjacent lanes share one output — lane q multiplies the factors
+// j = q (mod 4), then two shuffle steps combine the four partial products: a chain of ceil(v/4) + 2 products instead of v.
 ZG_DEV Fr eq_factor_product4(const uint64_t *r, int v, uint32_t idx, uint32_t q, const Fr *init) {
     Fr one = Fr::one();
     Fr c = (q == 0 && init) ? *init : one;
@@ -45,23 +42,6 @@ ZG_DEV Fr eq_factor_product4(const uint64_t *r, int v, uint32_t idx, uint32_t q,
     return fr_mul29v(c, o);
 }
 
-__global__ void __launch_bounds__(256) eq_tables_kernel(const uint64_t *r, int v_hi, int v_lo, const uint64_t *scale, uint64_t *hi,
-                                                        uint32_t nb_hi, uint64_t *lo) {
-    uint32_t q = threadIdx.x & 3;
-    if (blockIdx.x < nb_hi) {
-        uint32_t h = blockIdx.x * 64 + (threadIdx.x >> 2);
-        bool live = h < (1u << v_hi);
-        Fr sc = scale ? fe_load<FrParams>(scale) : Fr::one();
-        Fr p = eq_factor_product4(r, v_hi, live ? h : 0, q, scale ? &sc : nullptr);
-        if (live && q == 0) fe_store(hi + 4 * (size_t)h, p);
-    } else {
-        uint32_t t = (blockIdx.x - nb_hi) * 64 + (threadIdx.x >> 2);
-        bool live = t < (1u << v_lo);
-        Fr p = eq_factor_product4(r + 4 * (size_t)v_hi, v_lo, live ? t : 0, q, nullptr);
-        if (live && q == 0) fe_store(lo + 4 * (size_t)t, p);
-    }
-}
-
 // GruenSplitEqPolynomial's prefix tables: entry idx of table k = prod_{j<k} (bit_j(idx) ? tau[j] : 1 - tau[j]) at element
 // 2^k - 1 + idx of out. Element p-1 (p = 1 .. 2^(v+1)-1) therefore has k = floor(log2 p), idx = p - 2^k: one launch, four
 // lanes per output as above (the chain is at most ceil(v/4) + 2 products; Montgomery products are exact, so the product
@@ -76,19 +56,86 @@ __global__ void __launch_bounds__(256) eq_prefix_kernel(const uint64_t *tau, int
     if (live && q == 0) fe_store(out + 4 * (size_t)(p - 1), e);
 }
 
+// ---- eq table, one launch. The challenge vector travels as a KERNEL ARGUMENT (<= 34 x 32 bytes): no H2D copy, no staging
+// buffer, no factor-table launch in front — building a 2^20-entry table was 8 us of factor tables + 17 us of stream behind a
+// pageable copy; now the call is one asynchronous launch.
+struct EqArgs {
+    uint32_t r[34][8];  // r[0] <-> MSB of the index
+    uint32_t scale[8];
+    int v, has_scale;
+};
+static constexpr int EQ_MAX_ROWS = 256;  // rows of 2^v_lo entries per workgroup
+struct EqShared {
+    uint4 small[9][16][2];        // factor tables of 4 variables each: groups 0, 1 = the low 8 index bits, 2.. = the row index h
+    uint4 hi_row[EQ_MAX_ROWS][2];  // hi[h0 + k], canonical
+};
+
+// Factor tables in LDS, then thread t's lo[t] (returned, canonical) and the block's hi[h0 .. h0 + rows) in sh.hi_row.
+//   lo[t]  = prod_{j < v_lo} (bit_j(t) ? r[v_hi + j] : 1 - r[v_hi + j]),  bit_j(t) = bit (v_lo - 1 - j) of t
+//   hi[h]  = scale * prod_{j < v_hi} (bit_j(h) ? r[j] : 1 - r[j]),          bit_j(h) = bit (v_hi - 1 - j) of h
+// Index bits are taken four at a time: 16-entry tables of <= 3 products each (144 threads at most), then lo[t] is one product
+// of two table entries and hi[h] at most ceil(v_hi / 4) products by one thread per row — a chain of ~10 products (~2 us)
+// in front of the stream instead of a launch of its own. Exact products: any grouping gives the reference's bytes.
+ZG_DEV Fr eq_block_factors(const EqArgs &a, int v_lo, int v_hi, uint32_t h0, uint32_t rows, EqShared &sh) {
+    const uint32_t tid = threadIdx.x;
+    const int ng_hi = (v_hi + 3) / 4, ng = 2 + ng_hi;
+    const Fr one = Fr::one();
+    if (tid < 16u * (uint32_t)ng) {
+        const int g = (int)(tid >> 4);
+        const uint32_t e = tid & 15u;
+        // group g covers index bits [b0, b0 + nb) of the low part (g < 2) or of h (g >= 2); bit b <-> variable var(b)
+        const int part_bits = g < 2 ? v_lo : v_hi, b0 = g < 2 ? 4 * g : 4 * (g - 2);
+        Fr acc = one;
+        bool used = false;
+        for (int b = 0; b < 4; b++) {
+            const int bit = b0 + b;
+            if (bit >= part_bits) break;
+            const int var = g < 2 ? v_hi + (v_lo - 1 - bit) : (v_hi - 1 - bit);
+            Fr rj;
+#pragma unroll
+            for (int i = 0; i < 8; i++) rj.l[i] = a.r[var][i];
+            Fr f = ((e >> b) & 1u) ? rj : fe_sub(one, rj);
+            acc = used ? fr_mul29v(acc, f) : f;
+            used = true;
+        }
+        fe_store(&sh.small[g][e][0], acc);
+    }
+    __syncthreads();
+    Fr lo = fe_load<FrParams>(&sh.small[0][tid & 15u][0]);
+    if (v_lo > 4) lo = fr_mul29v(lo, fe_load<FrParams>(&sh.small[1][(tid >> 4) & 15u][0]));
+    if (tid < rows) {
+        const uint32_t h = h0 + tid;
+        Fr hv = one;
+        bool used = false;
+        if (a.has_scale) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) hv.l[i] = a.scale[i];
+            used = true;
+        }
+        for (int g = 0; g < ng_hi; g++) {
+            Fr f = fe_load<FrParams>(&sh.small[2 + g][(h >> (4 * g)) & 15u][0]);
+            hv = used ? fr_mul29v(hv, f) : f;
+            used = true;
+        }
+        fe_store(&sh.hi_row[tid][0], hv);
+    }
+    __syncthreads();
+    return lo;
+}
+
 // out[(h << v_lo) | t] = hi[h] * lo[t]; one 32-byte store per thread and row, 8 KiB contiguous per (block, h): the
 // kernel is an HBM write stream with one mixed-format product (fr_mul29) per element.
-__global__ void __launch_bounds__(256) eq_main_kernel(const uint64_t *lo_tab, int v_lo, const uint64_t *hi, uint32_t n_hi,
-                                                      uint32_t hi_per_block, uint64_t *out) {
+__global__ void __launch_bounds__(256) eq_main_kernel(EqArgs a, int v_lo, int v_hi, uint32_t hi_per_block, uint64_t *out) {
+    __shared__ EqShared sh;
+    const uint32_t n_hi = 1u << v_hi, h0 = blockIdx.x * hi_per_block;
+    const uint32_t rows = n_hi - h0 < hi_per_block ? n_hi - h0 : hi_per_block;
+    Fr lov = eq_block_factors(a, v_lo, v_hi, h0, rows, sh);
     uint32_t lo = threadIdx.x;
     if (lo >= (1u << v_lo)) return;
-    F29 tp = fr29_prescale(fe_load<FrParams>(lo_tab + 4 * (size_t)lo));  // shared factor of this thread's products
-    uint32_t h0 = blockIdx.x * hi_per_block;
-    for (uint32_t k = 0; k < hi_per_block; k++) {
-        uint32_t h = h0 + k;
-        if (h >= n_hi) break;
-        Fr hv = fe_load<FrParams>(hi + 4 * (size_t)h);
-        fe_store(out + 4 * (((size_t)h << v_lo) | lo), fr_mul29(hv, tp));
+    F29 tp = fr29_prescale(lov);  // shared factor of this thread's products
+    for (uint32_t k = 0; k < rows; k++) {
+        Fr hv = fe_load<FrParams>(&sh.hi_row[k][0]);
+        fe_store(out + 4 * (((size_t)(h0 + k) << v_lo) | lo), fr_mul29(hv, tp));
     }
 }
 
@@ -467,21 +514,22 @@ __global__ void __launch_bounds__(256) sc_finish_kernel(const uint64_t *partials
 // block to arrive, like every other round): the eq table is never materialised, the 2^v-entry copy into the session and the
 // separate first sums pass disappear.
 template <int LAYOUT>
-__global__ void __launch_bounds__(256) eq_spartan_kernel(const uint64_t *lo_tab, int v_lo, const uint64_t *hi, uint32_t n_hi,
-                                                         uint32_t hi_per_block, const uint64_t *az, const uint64_t *bz, const uint64_t *cz,
-                                                         uint64_t *out, uint64_t *partials, uint64_t *sums, uint32_t *counter, uint64_t *flag,
-                                                         uint64_t seq) {
+__global__ void __launch_bounds__(256) eq_spartan_kernel(EqArgs ea, int v_lo, int v_hi, uint32_t hi_per_block, const uint64_t *az,
+                                                         const uint64_t *bz, const uint64_t *cz, uint64_t *out, uint64_t *partials,
+                                                         uint64_t *sums, uint32_t *counter, uint64_t *flag, uint64_t seq) {
     __shared__ uint4 sh[256 * 4];
+    __shared__ EqShared fs;
+    const uint32_t n_hi = 1u << v_hi, h0 = blockIdx.x * hi_per_block;
+    const uint32_t rows = n_hi - h0 < hi_per_block ? n_hi - h0 : hi_per_block;
+    Fr lov = eq_block_factors(ea, v_lo, v_hi, h0, rows, fs);
     uint32_t lo = threadIdx.x;
     Fr g0 = Fr::zero(), g1 = Fr::zero();
     if (lo < (1u << v_lo)) {
-        F29 tp = fr29_prescale(fe_load<FrParams>(lo_tab + 4 * (size_t)lo));
-        uint32_t h0 = blockIdx.x * hi_per_block;
-        for (uint32_t k = 0; k < hi_per_block; k++) {
+        F29 tp = fr29_prescale(lov);
+        for (uint32_t k = 0; k < rows; k++) {
             uint32_t h = h0 + k;
-            if (h >= n_hi) break;
             size_t i = ((size_t)h << v_lo) | lo;
-            Fr e = fr_mul29(fe_load<FrParams>(hi + 4 * (size_t)h), tp);
+            Fr e = fr_mul29(fe_load<FrParams>(&fs.hi_row[k][0]), tp);
             Fr a = fe_load<FrParams>(az + 4 * i), b = fe_load<FrParams>(bz + 4 * i), c = fe_load<FrParams>(cz + 4 * i);
             Fr f = fr_mul29v(e, fe_sub(fr_mul29v(a, b), c));
             fe_store(out + 4 * i, f);
@@ -669,28 +717,46 @@ static int launch_fold(int layout, const uint64_t *t, size_t len, const uint64_t
     return ZG_OK;
 }
 
-static int eq_table_enqueue(const uint64_t *r_host, size_t v, const uint64_t *scale_host, uint64_t *d_out, hipStream_t st) {
+static int eq_args_fill(EqArgs &a, const uint64_t *r_host, size_t v, const uint64_t *scale_host) {
     if (v > 34) {
         set_error("zg_fr_eq_table: v too large");
         return ZG_ERR_INVALID;
     }
+    a.v = (int)v;
+    a.has_scale = scale_host ? 1 : 0;
+    for (size_t j = 0; j < v; j++)
+        for (int i = 0; i < 4; i++) {
+            a.r[j][2 * i] = (uint32_t)r_host[4 * j + i];
+            a.r[j][2 * i + 1] = (uint32_t)(r_host[4 * j + i] >> 32);
+        }
+    for (int i = 0; i < 4; i++) {
+        a.scale[2 * i] = scale_host ? (uint32_t)scale_host[i] : 0;
+        a.scale[2 * i + 1] = scale_host ? (uint32_t)(scale_host[i] >> 32) : 0;
+    }
+    return ZG_OK;
+}
+
+// rows of 2^v_lo entries per workgroup: two workgroups per CU when the table is long enough (the factor prologue is per
+// workgroup), never more than EQ_MAX_ROWS
+static uint32_t eq_rows_per_block(uint32_t n_hi, uint32_t blocks_cap) {
+    uint32_t nb = n_hi < blocks_cap ? n_hi : blocks_cap;
+    uint32_t hpb = div_up(n_hi, nb);
+    return hpb > (uint32_t)EQ_MAX_ROWS ? (uint32_t)EQ_MAX_ROWS : hpb;
+}
+
+// ASYNCHRONOUS: one launch on `st`, nothing of the caller's is read after the call returns (r and scale travel as kernel arguments)
+static int eq_table_enqueue(const uint64_t *r_host, size_t v, const uint64_t *scale_host, uint64_t *d_out, hipStream_t st) {
+    static EqArgs zero_args;  // (value-initialised once; the fill below overwrites what the kernel reads)
+    EqArgs a = zero_args;
+    ZG_TRY(eq_args_fill(a, r_host, v, scale_host));
     int v_lo = v < 8 ? (int)v : 8, v_hi = (int)v - v_lo;
     uint32_t n_hi = 1u << v_hi;
-    Scratch s_r((v + 1) * 32 + 32), s_hi((size_t)n_hi * 32 + 256 * 32);
-    if (!s_r.p || !s_hi.p) return ZG_ERR_NOMEM;
-    SyncGuard sync(st);  // the temporaries go back to the shared cache on return, also on an error path
-    uint64_t *d_r = s_r.as<uint64_t>(), *d_hi = s_hi.as<uint64_t>(), *d_lo = d_hi + 4 * (size_t)n_hi;
-    if (v) ZG_HIP(hipMemcpyAsync(d_r + 4, r_host, v * 32, hipMemcpyHostToDevice, st));
-    if (scale_host) ZG_HIP(hipMemcpyAsync(d_r, scale_host, 32, hipMemcpyHostToDevice, st));
+    static const uint32_t nb_cap = env_uint("ZG_EQ_BLOCKS", 512, 1, 65536);
+    uint32_t hpb = eq_rows_per_block(n_hi, nb_cap);
     prof_begin(ZG_PROF_EQ_TABLE, st);
-    uint32_t nb_hi = div_up(n_hi, 64), nb_lo = div_up(1u << v_lo, 64);
-    hipLaunchKernelGGL(eq_tables_kernel, dim3(nb_hi + nb_lo), dim3(256), 0, st, d_r + 4, v_hi, v_lo, scale_host ? d_r : nullptr, d_hi, nb_hi,
-                       d_lo);
-    uint32_t hpb = n_hi / 1024 ? n_hi / 1024 : 1;  // rows per block: amortises the per-thread prescale, keeps >= 4 blocks per CU
-    hipLaunchKernelGGL(eq_main_kernel, dim3(div_up(n_hi, hpb)), dim3(256), 0, st, d_lo, v_lo, d_hi, n_hi, hpb, d_out);
+    hipLaunchKernelGGL(eq_main_kernel, dim3(div_up(n_hi, hpb)), dim3(256), 0, st, a, v_lo, v_hi, hpb, d_out);
     prof_end(ZG_PROF_EQ_TABLE, st);
     ZG_HIP(hipGetLastError());
-    ZG_HIP(hipStreamSynchronize(st));  // r_host / temporaries are released on return
     return ZG_OK;
 }
 
@@ -713,38 +779,33 @@ static int eq_prefix_enqueue(const uint64_t *tau_host, size_t v, uint64_t *d_out
     return ZG_OK;
 }
 
-// factor tables + fused table/sums kernel of zg_sumcheck_open_spartan_dev
+// fused table/sums kernel of zg_sumcheck_open_spartan_dev (asynchronous, like eq_table_enqueue)
 static int eq_spartan_enqueue(const uint64_t *r_host, size_t v, const uint64_t *scale_host, const uint64_t *d_az, const uint64_t *d_bz,
                               const uint64_t *d_cz, int layout, uint64_t *d_out, uint64_t *partials, uint64_t *sums, uint64_t *flag,
                               uint64_t seq, hipStream_t st) {
+    static EqArgs zero_args;
+    EqArgs a = zero_args;
+    ZG_TRY(eq_args_fill(a, r_host, v, scale_host));
     int v_lo = v < 8 ? (int)v : 8, v_hi = (int)v - v_lo;
     uint32_t n_hi = 1u << v_hi;
-    Scratch s_r((v + 1) * 32 + 32), s_hi((size_t)n_hi * 32 + 256 * 32);
-    if (!s_r.p || !s_hi.p) return ZG_ERR_NOMEM;
-    SyncGuard sync(st);  // the temporaries go back to the shared cache on return, also on an error path
-    uint64_t *d_r = s_r.as<uint64_t>(), *d_hi = s_hi.as<uint64_t>(), *d_lo = d_hi + 4 * (size_t)n_hi;
-    if (v) ZG_HIP(hipMemcpyAsync(d_r + 4, r_host, v * 32, hipMemcpyHostToDevice, st));
-    if (scale_host) ZG_HIP(hipMemcpyAsync(d_r, scale_host, 32, hipMemcpyHostToDevice, st));
-    prof_begin(ZG_PROF_EQ_TABLE, st);
-    uint32_t nb_hi = div_up(n_hi, 64), nb_lo = div_up(1u << v_lo, 64);
-    hipLaunchKernelGGL(eq_tables_kernel, dim3(nb_hi + nb_lo), dim3(256), 0, st, d_r + 4, v_hi, v_lo, scale_host ? d_r : nullptr, d_hi, nb_hi,
-                       d_lo);
-    prof_end(ZG_PROF_EQ_TABLE, st);
-    static const uint32_t nb_cap = env_uint("ZG_SC_SPARTAN_BLOCKS", 512, 1, SC_MAX_BLOCKS);
-    uint32_t nb = n_hi < nb_cap ? n_hi : nb_cap;  // enough waves per SIMD for three products per element; each block is one more atomic
-    uint32_t hpb = div_up(n_hi, nb);
-    nb = div_up(n_hi, hpb);
+    static const uint32_t nb_cap = env_uint("ZG_SC_SPARTAN_BLOCKS", 512, 1, SC_MAX_BLOCKS);  // enough waves per SIMD for three products per element; each block is one more atomic
+    uint32_t hpb = div_up(n_hi, n_hi < nb_cap ? n_hi : nb_cap);
+    if (hpb > (uint32_t)EQ_MAX_ROWS) hpb = EQ_MAX_ROWS;
+    uint32_t nb = div_up(n_hi, hpb);
+    if (nb > SC_MAX_BLOCKS) {
+        set_error("zg_sumcheck_open_spartan_dev: table too long");
+        return ZG_ERR_INVALID;
+    }
     uint32_t *counter = reinterpret_cast<uint32_t *>(partials + 8 * (size_t)SC_MAX_BLOCKS);
     prof_begin(ZG_PROF_COMBINE, st);
     if (layout == ZG_SC_HIGH_HALF)
-        hipLaunchKernelGGL(eq_spartan_kernel<ZG_SC_HIGH_HALF>, dim3(nb), dim3(256), 0, st, d_lo, v_lo, d_hi, n_hi, hpb, d_az, d_bz, d_cz, d_out,
+        hipLaunchKernelGGL(eq_spartan_kernel<ZG_SC_HIGH_HALF>, dim3(nb), dim3(256), 0, st, a, v_lo, v_hi, hpb, d_az, d_bz, d_cz, d_out,
                            partials, sums, counter, flag, seq);
     else
-        hipLaunchKernelGGL(eq_spartan_kernel<ZG_SC_LOW_PAIR>, dim3(nb), dim3(256), 0, st, d_lo, v_lo, d_hi, n_hi, hpb, d_az, d_bz, d_cz, d_out,
+        hipLaunchKernelGGL(eq_spartan_kernel<ZG_SC_LOW_PAIR>, dim3(nb), dim3(256), 0, st, a, v_lo, v_hi, hpb, d_az, d_bz, d_cz, d_out,
                            partials, sums, counter, flag, seq);
     prof_end(ZG_PROF_COMBINE, st);
     ZG_HIP(hipGetLastError());
-    ZG_HIP(hipStreamSynchronize(st));  // r_host / temporaries are released on return
     return ZG_OK;
 }
 
@@ -872,13 +933,14 @@ int zg_fr_eq_table(const uint64_t *r, size_t v, const uint64_t *scale, uint64_t 
     Scratch s_out(bytes);
     if (!s_out.p) return ZG_ERR_NOMEM;
     uint64_t *d_out = s_out.as<uint64_t>();
-    int rc = eq_table_enqueue(r, v, scale, d_out, lib_stream());
-    if (rc == ZG_OK) {
-        hipError_t e = hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) {
-            set_error(hipGetErrorString(e));
-            rc = ZG_ERR_HIP;
-        }
+    hipStream_t st = lib_stream();
+    int rc = eq_table_enqueue(r, v, scale, d_out, st);
+    hipError_t e = rc == ZG_OK ? hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, st) : hipSuccess;
+    hipError_t e2 = hipStreamSynchronize(st);  // also after a failure: the scratch buffer goes back to the cache on return
+    if (e == hipSuccess) e = e2;
+    if (rc == ZG_OK && e != hipSuccess) {
+        set_error(hipGetErrorString(e));
+        rc = ZG_ERR_HIP;
     }
     return rc;
 }
