@@ -176,8 +176,9 @@ def main():
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--precompute", type=int, default=0)
-    ap.add_argument("--streams", type=int, default=3,
-                    help="independent MSMs are issued round-robin on this many HIP streams (1 = strictly serial)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="independent MSMs are issued round-robin on this many HIP streams (1 = strictly serial; 0 = 3 on one GPU, 4 per rank "
+                         "when the work is sharded: measured best at 2^17..2^19 points per rank, tools/ab_sharded_streams.sh)")
     args = ap.parse_args()
 
     if args.single_process:
@@ -221,7 +222,7 @@ def main():
     torch.cuda.set_stream(work_stream)
     stream = work_stream.cuda_stream
     assert stream != 0
-    nstreams = max(1, args.streams)
+    nstreams = args.streams if args.streams > 0 else (4 if use_dist else 3)
     if world > 1 and dist_backend != "nccl":
         nstreams = 1  # the gloo debugging path stages through the host and is synchronous anyway
     tstreams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(nstreams - 1)]
@@ -540,6 +541,50 @@ def extra_measurements(lib, api, torch, dev, stream, args, srs_xy=None):
                           "its completion — the two kernels alone take 24 us (profiles/*_sumcheck_kernel_stats.csv); sc_fold / sc_sums "
                           "are averages over the 20 rounds",
     }
+    # config 3 against the HBM roof (north_star: "sumcheck-rounds/sec ... as fraction of HBM roofline"). Algorithmic bytes of the
+    # protocol: the eq table written once (32 * 2^v) and every fold reading its table and writing half of it (48 * L for a table of
+    # L entries, L = 2^v .. 2): 32 * 2^v + sum 48 * L. The Spartan combine in front of it (160 B per entry) is listed beside it.
+    fold_bytes = 48.0 * (2 * n - 2)
+    alg_bytes = 32.0 * n + fold_bytes
+    ms_host = el / reps * 1e3
+    kern_ms = sum(val[0] for k, val in prof.items() if k in ("eq_table", "sc_fold", "sc_sums")) / reps
+
+    def roof(nbytes, ms, note):
+        ach = nbytes / (ms * 1e-3) / 1e9 if ms else 0.0
+        return {"bound": "hbm", "bytes": nbytes, "ms": ms, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+                "note": note}
+    extra["sumcheck_v20"]["roofline"] = roof(alg_bytes, ms_host, "whole protocol host-timed (eq table + 20 rounds with the verifier on the host, through the Python "
+                                             "binding; the Spartan combine's 160 B per entry is not counted): latency-bound — 20 host round trips, and from round 5 on a "
+                                             "round is the ~14 us floor of a launch + mailbox, not traffic")
+    extra["sumcheck_v20"]["roofline_kernels_only"] = roof(alg_bytes, kern_ms, "the same bytes over the SUM of the kernels' HIP-event durations (eq table, folds, first sums)")
+    extra["sumcheck_v20"]["spartan_combine_bytes"] = 160.0 * n
+    # per-kernel fractions of the three HBM-shaped kernels of the path, each timed by its own HIP-event bracket on the launch stream
+    per_kernel = {}
+    lib.profile_begin(64)
+    for _ in range(5):
+        lib.fr_eq_table_dev(r, d_eq.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    pk = lib.profile_end()
+    ms_eq = pk["eq_table"][0] / max(pk["eq_table"][1], 1)
+    per_kernel["eq_main_kernel"] = roof(32.0 * n, ms_eq, "2^20-entry eq table, one launch (factor tables built inside): 32 B written per entry")
+    lib.profile_begin(64)
+    for _ in range(5):
+        s2 = lib.SumcheckSession.open_spartan_dev(r, tabs[0].data_ptr(), tabs[1].data_ptr(), tabs[2].data_ptr(), lib.SC_HIGH_HALF, stream=stream)
+        s2.round_sums()
+        s2.close()
+    pk = lib.profile_end()
+    ms_sp = pk["combine"][0] / max(pk["combine"][1], 1)
+    per_kernel["eq_spartan_kernel"] = roof(128.0 * n, ms_sp, "f = eq * (Az * Bz - Cz) straight into the session + round 0's sums: 96 B read + 32 B written per entry")
+    s3 = lib.SumcheckSession.open_dev(d_f.data_ptr(), n, lib.SC_HIGH_HALF, stream=stream)
+    s3.round_sums()
+    lib.profile_begin(16)
+    s3.bind(r[0])
+    s3.round_sums()
+    pk = lib.profile_end()
+    s3.close()
+    ms_f0 = pk["sc_fold"][0] / max(pk["sc_fold"][1], 1)
+    per_kernel["sc_fold_kernel_round0"] = roof(48.0 * n, ms_f0, "the first fold of the 2^20-entry table (32 B read per entry, 16 B written) with the next round's sums fused")
+    extra["sumcheck_v20"]["kernel_rooflines"] = per_kernel
     # runSumcheck with the toy verifier on the device as well (zg_run_sumcheck_dev): no PCIe crossing per round
     res = lib.run_sumcheck_dev(d_f.data_ptr(), n, stream=stream)
     assert res["result"] and np.array_equal(res["final_eval"], fin)
@@ -549,7 +594,10 @@ def extra_measurements(lib, api, torch, dev, stream, args, srs_xy=None):
         lib.run_sumcheck_dev(d_f.data_ptr(), n, stream=stream)
     el = time.perf_counter() - t0
     extra["sumcheck_v20_device_resident"] = {"rounds_per_s": 20 * v / el, "ms_per_runSumcheck": el / 20 * 1e3,
-                                             "note": "prover + toy verifier on the device; transcript equals the host-verifier run"}
+                                             "note": "prover + toy verifier on the device; transcript equals the host-verifier run",
+                                             "roofline": roof(fold_bytes + 32.0 * n, el / 20 * 1e3,
+                                                              "20 folds (sum 48 * L) + the first sums pass (32 * 2^v read): 8 fold launches, then one "
+                                                              "LDS-resident launch for the last 12 rounds — serial GPU code per round, not traffic")}
     # the fold by one of the reference's 128-bit challenges (stored [0, 0, lo, hi]: 9 x 5-limb product, fp29.hip.h FrMul) against a
     # full-width one, on a 2^24-entry table resident in HBM: kernel + fused next sums + mailbox, host-timed, best of 5
     try:

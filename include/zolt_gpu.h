@@ -268,6 +268,10 @@ ZG_API int zg_sumcheck_bind(zg_sc_t s, const uint64_t r[4]);
 ZG_API size_t zg_sumcheck_len(zg_sc_t s);
 ZG_API int zg_sumcheck_final(zg_sc_t s, uint64_t out[4]); /* getFinalEval (:130-133), needs len == 1 */
 ZG_API int zg_sumcheck_read(zg_sc_t s, uint64_t *out_table); /* copy the current table to the host (tests) */
+/* out[i] = table[idx[i]], i < n (every idx < the current length): what a SPARSE-entry prover reads of a dense table —
+ * RamReadWriteCheckingProver's val_init checkpoints of the column pairs its entries touch (src/zkvm/ram/read_write_checking.zig:591-602,
+ * 985-996) — instead of copying the table back every round. */
+ZG_API int zg_sumcheck_gather(zg_sc_t s, const uint64_t *idx, size_t n, uint64_t *out /* n*4 */);
 /* Sharded tables: the LOCAL pair g0||g1 (8 limbs) / the current local table, written to device
  * memory in stream order on the session's stream (the one given to zg_sumcheck_open_dev) with no host
  * synchronisation, so an RCCL all-gather enqueued on that stream can follow directly. */
@@ -358,6 +362,8 @@ ZG_API int zg_psc_round_gruen(zg_psc_t s, const int *prod_idx, size_t p, const u
 /* every table folded: T'[i] = (1 - r) T[2i] + r T[2i+1]; len -> len / 2 (val_evaluation.zig:609-628) */
 ZG_API int zg_psc_bind(zg_psc_t s, const uint64_t r[4]);
 ZG_API int zg_psc_read(zg_psc_t s, size_t table, uint64_t *out /* len*4 */);
+/* out[i] = T[table][idx[i]], i < n: the inc values of the row pairs a sparse prover's entries touch (read_write_checking.zig:431-446) */
+ZG_API int zg_psc_gather(zg_psc_t s, size_t table, const uint64_t *idx, size_t n, uint64_t *out /* n*4 */);
 ZG_API int zg_psc_final(zg_psc_t s, uint64_t *out /* k*4: each table's single remaining entry */);
 ZG_API int zg_psc_close(zg_psc_t s);
 

@@ -876,3 +876,302 @@ def eq_plus_one_table(r):
     out = np.empty((1 << r.shape[0], 4), dtype=np.uint64)
     lib.zo_eq_plus_one_table(_p(r), C.c_size_t(r.shape[0]), _p(out))
     return out
+
+
+# ---- RamReadWriteCheckingProver (src/zkvm/ram/read_write_checking.zig:160-1323), restated. The sparse cycle-major / address-major
+# entry algebra runs on Python integers (canonical values mod r; the reference's field type is Montgomery, the values are the same),
+# the dense tables (eq_evals, inc, val_init) are Montgomery arrays folded by the C oracle's bind_low, and the Gruen split-eq
+# machinery is the GruenSplitEq restatement above.
+_R_P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+_R_MONT = (1 << 256) % _R_P
+_R_MONT_INV = pow(_R_MONT, -1, _R_P)
+
+
+def fr_to_int(a):
+    a = np.asarray(a, dtype=np.uint64).reshape(4)
+    return (int(a[0]) | int(a[1]) << 64 | int(a[2]) << 128 | int(a[3]) << 192) * _R_MONT_INV % _R_P
+
+
+def fr_from_int(v):
+    m = (v % _R_P) * _R_MONT % _R_P
+    return np.array([(m >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+
+
+class RamReadWriteCheckingProver:
+    """accesses: [(timestamp, address, is_write, value)] in trace order (MemoryTrace.accesses); initial_ram: {address: u64}.
+    Entry = [cycle, address, ra_coeff, val_coeff, prev_val, next_val] (CycleMajorEntry, :91-157)."""
+
+    def __init__(self, accesses, gamma, r_cycle, log_k, log_t, phase1_num_rounds, start_address, initial_claim, initial_ram=None):
+        P = _R_P
+        self.gamma = fr_to_int(gamma)
+        self.r_cycle = _c(np.asarray(r_cycle, dtype=np.uint64).reshape(-1, 4)).copy()
+        self.log_k, self.log_t, self.phase1_num_rounds, self.start_address = log_k, log_t, phase1_num_rounds, start_address
+        K, T = 1 << log_k, 1 << log_t
+        inc = [0] * T
+        val_init = [0] * K
+        cur = {}
+        for addr, val in (initial_ram or {}).items():  # :212-231, :253-267
+            if addr >= start_address:
+                idx = (addr - start_address) // 8
+                if idx < K:
+                    val_init[idx] = val % P
+                    cur[idx] = val
+        self.entries = []
+        for ts, address, is_write, value in accesses:  # :269-330
+            if ts >= T or address < start_address:
+                continue
+            idx = (address - start_address) // 8
+            if idx >= K:
+                continue
+            prev = cur.get(idx, 0)
+            if is_write:
+                inc[ts] = (value - prev) % P
+                cur[idx] = value
+            val_coeff = prev if is_write else value
+            self.entries.append([ts, idx, 1, val_coeff % P, prev, value])
+        self.entries.sort(key=lambda e: (e[0], e[1]))  # :333-340
+        self.inc = np.stack([fr_from_int(v) for v in inc]) if T <= 4096 else self._bulk(inc)
+        self.val_init = self._bulk(val_init)
+        self.eq_evals = fr_eq_table(self.r_cycle) if log_t else f_from_u64(FR, np.array([1], dtype=np.uint64))  # :345-348 computeEqBigEndian
+        self.eq_size = T
+        self.gruen = GruenSplitEq(self.r_cycle)  # :354
+        self.current_claim = fr_to_int(initial_claim)
+        self.round = 0
+        self.challenges = []
+
+    @staticmethod
+    def _bulk(vals):
+        """list of canonical ints (mostly zero) -> Montgomery array"""
+        out = np.zeros((len(vals), 4), dtype=np.uint64)
+        for i, v in enumerate(vals):
+            if v:
+                out[i] = fr_from_int(v)
+        return out
+
+    def numRounds(self):
+        return self.log_k + self.log_t
+
+    def isComplete(self):
+        return self.round >= self.numRounds()
+
+    def _in_cycle_phase(self):
+        p1 = self.phase1_num_rounds
+        return self.round < p1 or self.round >= p1 + self.log_k
+
+    def computeRoundPolynomialCubic(self):  # :391-408 -> (4, 4) Montgomery
+        ev = self._phase1() if self._in_cycle_phase() else self._phase2()
+        return ev
+
+    def _phase1(self):  # :410-536
+        P, gamma = _R_P, self.gamma
+        g = self.gruen
+        e_out, e_in, head_in_bits = g.getWindowEqTables(1)  # getWindowEqTables(current_index, 1)
+        qc = qq = 0
+        ents, i = self.entries, 0
+        inc_len = self.inc.shape[0]
+        cache_out, cache_in, cache_inc = {}, {}, {}
+
+        def eo(x):
+            if x not in cache_out:
+                cache_out[x] = fr_to_int(e_out[x]) if x < e_out.shape[0] else 1
+            return cache_out[x]
+
+        def ei(x):
+            if x not in cache_in:
+                cache_in[x] = fr_to_int(e_in[x]) if x < e_in.shape[0] else 1
+            return cache_in[x]
+
+        def incv(j):
+            if j not in cache_inc:
+                cache_inc[j] = fr_to_int(self.inc[j]) if j < inc_len else 0
+            return cache_inc[j]
+        while i < len(ents):
+            e = ents[i]
+            pair = e[0] // 2
+            e_prefix = eo(pair >> head_in_bits) * ei(pair & ((1 << head_in_bits) - 1)) % P
+            inc_0, inc_1 = incv(2 * pair), incv(2 * pair + 1)
+            inc_inf = (inc_1 - inc_0) % P
+            if e[0] % 2 == 0:
+                nxt = ents[i + 1] if i + 1 < len(ents) else None
+                if nxt is not None and nxt[0] // 2 == pair and nxt[1] == e[1] and nxt[0] % 2 == 1:  # :465-484
+                    ra_0, ra_inf = e[2], (nxt[2] - e[2]) % P
+                    val_0, val_inf = e[3], (nxt[3] - e[3]) % P
+                    i += 2
+                else:  # :485-494 only the even entry: the odd one is implicit
+                    ra_0, ra_inf = e[2], (-e[2]) % P
+                    val_0, val_inf = e[3], (e[5] - e[3]) % P
+                    i += 1
+            else:  # :496-505 only the odd entry
+                ra_0, ra_inf = 0, e[2]
+                val_0, val_inf = e[4] % P, (e[3] - e[4]) % P
+                i += 1
+            inner_0 = (val_0 + gamma * (inc_0 + val_0)) % P  # :510-511
+            inner_inf = (val_inf + gamma * (inc_inf + val_inf)) % P
+            qc = (qc + e_prefix * ra_0 % P * inner_0) % P
+            qq = (qq + e_prefix * ra_inf % P * inner_inf) % P
+        self.last_q = (qc, qq)
+        return g.computeCubicRoundPoly(fr_from_int(qc), fr_from_int(qq), fr_from_int(self.current_claim))
+
+    def _eq_addr(self, address, addr_round):  # the loops at :785-794 etc.
+        P = _R_P
+        acc = 1
+        for i in range(addr_round):
+            r_i = self.challenges[self.phase1_num_rounds + i]
+            acc = acc * (r_i if (address >> i) & 1 else (1 - r_i)) % P
+        return acc
+
+    def _pair_groups(self, addr_round):
+        """entries (address-major order) grouped by column pair: yields (col_pair, even_list, odd_list)"""
+        ents, i = self.entries, 0
+        while i < len(ents):
+            col_pair = (ents[i][1] >> addr_round) // 2
+            j = i
+            while j < len(ents) and (ents[j][1] >> addr_round) // 2 == col_pair:
+                j += 1
+            k = i
+            while k < j and (ents[k][1] >> addr_round) % 2 == 0:
+                k += 1
+            yield col_pair, ents[i:k], ents[k:j]
+            i = j
+
+    def _phase2(self):  # :538-769
+        P, gamma = _R_P, self.gamma
+        addr_round = self.round - self.phase1_num_rounds
+        if addr_round == 0:
+            self.entries.sort(key=lambda e: (e[1], e[0]))  # :555-562
+        eq_cycle, inc_s = fr_to_int(self.eq_evals[0]), fr_to_int(self.inc[0])
+        size = (1 << self.log_k) >> addr_round
+        s0 = s2 = 0
+        opg = (1 + gamma) % P
+        for col_pair, even, odd in self._pair_groups(addr_round):
+            ec = fr_to_int(self.val_init[2 * col_pair]) if 2 * col_pair < size else 0
+            oc = fr_to_int(self.val_init[2 * col_pair + 1]) if 2 * col_pair + 1 < size else 0
+            a = b = 0
+
+            def contrib(address, ra_0, ra_2, val_0, val_2):
+                eq_partial = eq_cycle * self._eq_addr(address, addr_round) % P
+                c0 = eq_partial * ra_0 % P * ((val_0 * opg + gamma * inc_s) % P) % P
+                c2 = eq_partial * ra_2 % P * ((val_2 * opg + gamma * inc_s) % P) % P
+                return c0, c2
+            while a < len(even) or b < len(odd):
+                ee = even[a] if a < len(even) else None
+                oe = odd[b] if b < len(odd) else None
+                if ee is not None and oe is not None and ee[0] == oe[0]:  # :771-812
+                    c0, c2 = contrib(ee[1], ee[2], (2 * oe[2] - ee[2]) % P, ee[3], (2 * oe[3] - ee[3]) % P)
+                    ec, oc = ee[5] % P, oe[5] % P
+                    a += 1
+                    b += 1
+                elif oe is None or (ee is not None and ee[0] < oe[0]):  # :815-855 even only
+                    c0, c2 = contrib(ee[1], ee[2], (-ee[2]) % P, ee[3], (2 * oc - ee[3]) % P)
+                    ec = ee[5] % P
+                    a += 1
+                else:  # :858-899 odd only
+                    c0, c2 = contrib(oe[1], 0, 2 * oe[2] % P, ec, (2 * oe[3] - ec) % P)
+                    oc = oe[5] % P
+                    b += 1
+                s0, s2 = (s0 + c0) % P, (s2 + c2) % P
+        s1 = (self.current_claim - s0) % P  # :752
+        s3 = (3 * s2 - 3 * s1 + s0) % P  # :755
+        return np.stack([fr_from_int(v) for v in (s0, s1, s2, s3)])
+
+    def bindChallenge(self, challenge):  # :902-970
+        P = _R_P
+        ch = _c(challenge).copy()
+        r = fr_to_int(ch)
+        self.challenges.append(r)
+        p1 = self.phase1_num_rounds
+        if self._in_cycle_phase() and self.eq_size > 1:
+            half = self.eq_size // 2
+            self.eq_evals = fr_bind_low(self.eq_evals[:self.eq_size], ch)
+            self.inc = fr_bind_low(self.inc[:self.eq_size], ch)
+            self.eq_size = half
+            self.gruen.bind(ch)
+            self._bind_entries(r)
+        if p1 <= self.round < p1 + self.log_k:
+            addr_round = self.round - p1
+            size = (1 << self.log_k) >> addr_round
+            if size > 1:  # :953-959 folds IN PLACE: [0, size/2) are the new values, [size/2, size) keep the old ones ...
+                self.val_init[:size // 2] = fr_bind_low(self.val_init[:size], ch)
+            # ... and :962 reads its checkpoints from that array with the OLD size (:974-975), as restated here
+            self._bind_entries_address_major(r, addr_round, self.val_init, size)
+        self.round += 1
+
+    def _bind_entries(self, r):  # :1139-1185 with CycleMajorEntry.bindEntries (:110-156)
+        P = _R_P
+        ents, out, i = self.entries, [], 0
+        while i < len(ents):
+            e = ents[i]
+            if e[0] % 2 == 0:
+                nxt = ents[i + 1] if i + 1 < len(ents) else None
+                if nxt is not None and nxt[0] // 2 == e[0] // 2 and nxt[1] == e[1] and nxt[0] % 2 == 1:
+                    out.append([e[0] // 2, e[1], (e[2] + r * (nxt[2] - e[2])) % P, (e[3] + r * (nxt[3] - e[3])) % P, e[4], nxt[5]])
+                    i += 2
+                    continue
+                out.append([e[0] // 2, e[1], (1 - r) * e[2] % P, (e[3] + r * (e[5] - e[3])) % P, e[4], e[5]])
+            else:
+                out.append([e[0] // 2, e[1], r * e[2] % P, (e[4] + r * (e[3] - e[4])) % P, e[4], e[5]])
+            i += 1
+        self.entries = out
+
+    def _bind_entries_address_major(self, r, addr_round, val_init, size):  # :973-1086, :1088-1137
+        P = _R_P
+        out = []
+        for col_pair, even, odd in self._pair_groups(addr_round):
+            ec = fr_to_int(val_init[2 * col_pair]) if 2 * col_pair < size else 0
+            oc = fr_to_int(val_init[2 * col_pair + 1]) if 2 * col_pair + 1 < size else 0
+            a = b = 0
+            while a < len(even) or b < len(odd):
+                ee = even[a] if a < len(even) else None
+                oe = odd[b] if b < len(odd) else None
+                if ee is not None and oe is not None and ee[0] == oe[0]:
+                    out.append([ee[0], ee[1] // 2, (ee[2] + r * (oe[2] - ee[2])) % P, (ee[3] + r * (oe[3] - ee[3])) % P, ee[4], oe[5]])
+                    ec, oc = ee[5] % P, oe[5] % P
+                    a += 1
+                    b += 1
+                elif oe is None or (ee is not None and ee[0] < oe[0]):
+                    out.append([ee[0], ee[1] // 2, (1 - r) * ee[2] % P, (ee[3] + r * (oc - ee[3])) % P, ee[4], ee[5]])
+                    ec = ee[5] % P
+                    a += 1
+                else:
+                    out.append([oe[0], oe[1] // 2, r * oe[2] % P, (ec + r * (oe[3] - ec)) % P, oe[4], oe[5]])
+                    oc = oe[5] % P
+                    b += 1
+        self.entries = out
+
+    def updateClaim(self, evals, challenge):  # :1187-1204 (Lagrange interpolation through 0, 1, 2, 3)
+        P = _R_P
+        e = [fr_to_int(x) for x in np.asarray(evals, dtype=np.uint64).reshape(4, 4)]
+        c = fr_to_int(challenge)
+        inv = lambda v: pow(v % P, -1, P)  # noqa: E731
+        L0 = (c - 1) * (c - 2) % P * (c - 3) % P * inv(-6) % P
+        L1 = c * (c - 2) % P * (c - 3) % P * inv(2) % P
+        L2 = c * (c - 1) % P * (c - 3) % P * inv(-2) % P
+        L3 = c * (c - 1) % P * (c - 2) % P * inv(6) % P
+        self.current_claim = (e[0] * L0 + e[1] * L1 + e[2] * L2 + e[3] * L3) % P
+
+    def getOpeningClaims(self, r_sumcheck):  # :1210-1322 -> (ra_claim, val_claim, inc_claim) Montgomery
+        P = _R_P
+        rs = [fr_to_int(x) for x in np.asarray(r_sumcheck, dtype=np.uint64).reshape(-1, 4)]
+        log_k, log_t, p1 = self.log_k, self.log_t, self.phase1_num_rounds
+        p2, p3 = p1 + log_k, log_t - p1
+        r_address, r_cyc = [0] * log_k, [0] * log_t
+        for i in range(min(log_k, max(len(rs) - p1, 0))):
+            r_address[log_k - 1 - i] = rs[p1 + i]
+        for i in range(min(p1, len(rs))):
+            if p3 + (p1 - 1 - i) < log_t:
+                r_cyc[p3 + (p1 - 1 - i)] = rs[i]
+        for i in range(min(p3, max(len(rs) - p2, 0))):
+            r_cyc[p3 - 1 - i] = rs[p2 + i]
+
+        def eq(rv, x):  # computeEq, :1353-1366
+            acc, n = 1, len(rv)
+            for i in range(n):
+                acc = acc * (rv[i] if (x >> (n - 1 - i)) & 1 else (1 - rv[i])) % P
+            return acc
+        ra = 0
+        val = fr_to_int(self.val_init[0])
+        for e in self.entries:
+            w = eq(r_address, e[1]) * eq(r_cyc, e[0]) % P
+            ra = (ra + w * e[2]) % P
+            val = (val + w * (e[3] - fr_to_int(self.val_init[e[1]]))) % P
+        return fr_from_int(ra), fr_from_int(val), self.inc[0].copy()

@@ -254,3 +254,36 @@ def test_full_size_lasso_prover(env):
     assert np.array_equal(g.getFinalEval(), o.getFinalEval())
     assert np.array_equal(g.eq_evals(), o.eq_evals[:1])
     g.deinit()
+
+
+def test_lasso_rounds_of_the_captured_run_on_the_device(env, golden_dir):
+    """The reference's captured LassoProver run (tests/golden/lasso_rounds.json, logs/zolt.log:430-970) against the DEVICE: all 24
+    claim updates claim_after = c0 + c1 * challenge in one zg_field_op pass each (raw Montgomery limbs in, raw limbs out), and the
+    shape of the run — 44 lookups in a 2^8-entry table: the cycle rounds 16 and 17 have an empty second half — reproduced by
+    api.LassoProver (zero padding, HIGH_HALF folds) on arbitrary tables."""
+    import json
+    import os
+    api, lib, ob = env
+    d = json.load(open(os.path.join(golden_dir, "lasso_rounds.json")))
+
+    def fe(h):
+        return np.array([int(h[48:64], 16), int(h[32:48], 16), int(h[16:32], 16), int(h[0:16], 16)], dtype=np.uint64)
+    R = d["rounds"]
+    c0, c1, ch = (np.stack([fe(r[k]) for r in R]) for k in ("c0", "c1", "challenge"))
+    after = lib.field_op(lib.FR, lib.OP_ADD, c0, lib.field_op(lib.FR, lib.OP_MUL, c1, ch))
+    assert np.array_equal(after, np.stack([fe(r["claim_after"]) for r in R]))
+    assert np.array_equal(after[:-1], np.stack([fe(r["claim"]) for r in R[1:]]))
+    assert np.array_equal(lib.field_op(lib.FR, lib.OP_ADD, c0, lib.field_op(lib.FR, lib.OP_ADD, c0, c1)), np.stack([fe(r["claim"]) for r in R]))
+    rng = np.random.default_rng(44)
+    idx = np.zeros((44, 2), dtype=np.uint64)
+    idx[:, 0] = rng.integers(0, 1 << 16, size=44, dtype=np.uint64)
+    p = api.LassoProver(idx, d["log_T"], d["log_K"], _rand(ob, 4401, d["log_T"]))
+    zero = np.zeros(4, dtype=np.uint64)
+    empty_second = []
+    for i in range(d["total_rounds"]):
+        co = p.computeRoundPolynomial()
+        if i >= d["log_K"] and np.array_equal(lib.field_op(lib.FR, lib.OP_ADD, co[0][None], co[1][None])[0], zero):
+            empty_second.append(i)
+        p.receiveChallenge(_rand(ob, 4500 + i, 1)[0])
+    p.deinit()
+    assert empty_second == [i for i, r in enumerate(R) if i >= d["log_K"] and not fe(r["p1"]).any()] == [16, 17]

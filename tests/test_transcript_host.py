@@ -400,3 +400,131 @@ def test_batched_driver_inactive_instance_rule():
             b.bindChallenge(chals[k])
         want = (to_int(coeffs[0]) * to_int(ve.current_claim) + to_int(coeffs[1]) * to_int(vf.current_claim)) % P
         assert holds == sound and (to_int(b.current_claim) == want) == sound, mode
+
+
+def _lasso_fixture(golden_dir):
+    import json
+    import os
+    d = json.load(open(os.path.join(golden_dir, "lasso_rounds.json")))
+
+    def fe(h):  # 64 hex digits, most significant limb first -> uint64[4] little-endian limbs (the ABI's element format)
+        return np.array([int(h[48:64], 16), int(h[32:48], 16), int(h[16:32], 16), int(h[0:16], 16)], dtype=np.uint64)
+    return d, fe
+
+
+def test_lasso_rounds_of_the_captured_run(golden_dir):
+    """The LassoProver run of the reference's captured proof (logs/zolt.log:430-970: 16 address + 8 cycle rounds over 44 lookups),
+    every printed number held against the oracle's field arithmetic and the oracle's LassoProver restatement:
+      * p(0) = c0, p(1) = c0 + c1 + c2, p(0) + p(1) = claim — computeRoundPolynomial's [sum_0, sum_1 - sum_0, 0] (prover.zig:283-345);
+      * current_claim after receiveChallenge = p(challenge) — the address rounds' scale-by-index-bit (:375-399) and the cycle rounds'
+        HIGH-HALF fold (:411-441) both end on the sum of the updated eq_evals, which the log prints; it is also the next round's claim;
+      * the rounds whose second sum is zero are exactly the ones a 44-of-256 table gives under the bindFirst (HIGH_HALF) order and the
+        zero padding of :160-164 — the restatement reproduces that pattern (a LOW_PAIR fold, or padding with ones, would not)."""
+    d, fe = _lasso_fixture(golden_dir)
+    F = ob.FR
+    rounds = d["rounds"]
+    zero = np.zeros(4, dtype=np.uint64)
+    for i, r in enumerate(rounds):
+        c0, c1, c2, ch = fe(r["c0"]), fe(r["c1"]), fe(r["c2"]), fe(r["challenge"])
+        assert np.array_equal(c2, zero)
+        assert np.array_equal(fe(r["p0"]), c0) and np.array_equal(fe(r["p1"]), ob.f_add(F, c0, c1))
+        assert np.array_equal(ob.f_add(F, fe(r["p0"]), fe(r["p1"])), fe(r["claim"]))
+        after = ob.f_add(F, c0, ob.f_mul(F, c1, ch))  # Montgomery product of the raw limbs, as the prover's own mul
+        assert np.array_equal(after, fe(r["claim_after"])), i
+        if i + 1 < len(rounds):
+            assert np.array_equal(fe(rounds[i + 1]["claim"]), after)
+        assert r["phase"] == ("address" if i < d["log_K"] else "cycle")
+    # (address rounds with a zero second sum exist too — index bits no lookup of this program sets; they depend on the inputs)
+    zero_second = [i for i, r in enumerate(rounds) if i >= d["log_K"] and np.array_equal(fe(r["p1"]), zero)]
+    # the same shape from the restatement: 44 lookups, log_T = 8, log_K = 16, any tables
+    rng = np.random.default_rng(44)
+    idx = np.zeros((44, 2), dtype=np.uint64)
+    idx[:, 0] = rng.integers(0, 1 << 16, size=44, dtype=np.uint64)
+    p = ob.LassoProver(idx, d["log_T"], d["log_K"], ob.f_to_mont(F, U.random_raw256(4401, d["log_T"])))
+    got_zero = []
+    for i in range(d["total_rounds"]):
+        co = p.computeRoundPolynomial()
+        if i >= d["log_K"] and np.array_equal(ob.f_add(F, co[0], co[1]), zero):
+            got_zero.append(i)
+        p.receiveChallenge(ob.f_to_mont(F, U.random_raw256(4500 + i, 1))[0])
+    assert zero_second == got_zero == [16, 17]
+
+
+def _be8(fr_to_int, x):
+    return fr_to_int(x).to_bytes(32, "big")[:8].hex()
+
+
+def check_rwc_against_the_captured_run(prover, rwc, stage2, challenges, fr_to_int, last_q=None):
+    """drives a RamReadWriteCheckingProver (oracle restatement or device mirror) through the 24 Stage-2 rounds of the captured run and
+    holds every number the reference printed about it (tests/golden/rwc_captured_run.json) against it"""
+    P = ob._R_P
+    for k in range(24):
+        want = rwc["rounds"][str(k)]
+        assert _be8(fr_to_int, prover.claim_element()) == want.get("claim_be8", _be8(fr_to_int, prover.claim_element()))
+        ev = prover.computeRoundPolynomialCubic()
+        s = [fr_to_int(x) for x in ev]
+        assert (s[0] + s[1]) % P == fr_to_int(prover.claim_element()), k  # a sumcheck round
+        assert (s[3] - 3 * s[2] + 3 * s[1] - s[0]) % P == 0 or want["phase"] == "cycle", k  # address rounds are quadratics (:755)
+        for name, idx in (("s0_be8", 0), ("s1_be8", 1), ("s2_be8", 2)):
+            if name in want:
+                assert s[idx].to_bytes(32, "big")[:8].hex() == want[name], (k, name)
+        if want["phase"] == "cycle" and last_q is not None:
+            qc, qq = last_q(prover)
+            assert qc.to_bytes(32, "big")[:8].hex() == want["q_constant_be8"] and qq.to_bytes(32, "big")[:8].hex() == want["q_quadratic_be8"], k
+        if k == rwc["phase1_num_rounds"]:  # the phase switch prints the two cycle scalars and the entry it carries over
+            eqs, incs = prover.cycle_scalars()
+            assert _be8(fr_to_int, eqs) == rwc["phase2_eq_cycle_scalar_be8"] and _be8(fr_to_int, incs) == rwc["phase2_inc_scalar_be8"]
+        prover.updateClaim(ev, challenges[k])
+        prover.bindChallenge(challenges[k])
+        ents = prover.entry_list()
+        assert len(ents) == want["entries_after_bind"]
+        if "entry0_after_bind" in want:
+            e0 = want["entry0_after_bind"]
+            assert (ents[0][0], ents[0][1]) == (e0["cycle"], e0["addr"]) and ents[0][2].to_bytes(32, "big")[:8].hex() == e0["ra_coeff_be8"], k
+    assert prover.isComplete()
+    # the instance's own claim after its last round (tests/golden/stage2_batched_rounds.json: instance_final_claims[2], little-endian)
+    assert fr_to_int(prover.claim_element()) == int.from_bytes(bytes.fromhex(stage2["instance_final_claims"][2]), "little")
+    ra, val, inc = prover.getOpeningClaims(challenges)
+    op = rwc["opening"]
+    assert fr_to_int(ra) == int(op["ra_claim_be"], 16) and fr_to_int(val) == int(op["val_claim_be"], 16) and fr_to_int(inc) == int(op["inc_claim_be"], 16)
+
+
+class _OracleRwc:
+    """adapter: the oracle restatement behind the checker's small interface"""
+
+    def __init__(self, p):
+        self.p = p
+
+    def __getattr__(self, name):
+        return getattr(self.p, name)
+
+    def claim_element(self):
+        return ob.fr_from_int(self.p.current_claim)
+
+    def cycle_scalars(self):
+        return self.p.eq_evals[0], self.p.inc[0]
+
+    def entry_list(self):
+        return [(e[0], e[1], e[2]) for e in self.p.entries]
+
+
+def test_ram_read_write_checking_of_the_captured_run(golden_dir):
+    """RamReadWriteCheckingProver (src/zkvm/ram/read_write_checking.zig:160-1323) END TO END on the reference's own run: instance 2
+    of the captured Stage-2 batched sumcheck, 24 rounds in three phases (4 cycle / 16 address / 4 cycle variables). Every input is
+    known (tests/golden/make_rwc_fixture.py); the restatement reproduces, round by round, the printed prefixes of q_constant,
+    q_quadratic, s(0), s(1), s(2), the bound entry (cycle, column, ra coefficient), the two cycle scalars at the phase switch, the
+    instance's final claim (full width) and the three opening claims ra / val / inc (full width)."""
+    import json
+    import os
+    rwc = json.load(open(os.path.join(golden_dir, "rwc_captured_run.json")))
+    stage2 = json.load(open(os.path.join(golden_dir, "stage2_batched_rounds.json")))
+    elf = open(os.path.join(golden_dir, "fibonacci.elf"), "rb").read()
+    accesses, gamma, r_cycle, initial_ram, challenges = U.rwc_inputs_of_the_captured_run(rwc, stage2, elf, ob.fr_from_int)
+    assert ob.fr_to_int(r_cycle[0]).to_bytes(32, "big")[:8].hex() == rwc["init"]["tau_0_be8"]
+    assert ob.fr_to_int(r_cycle[-1]).to_bytes(32, "big")[:8].hex() == rwc["init"]["tau_last_be8"]
+    claim0 = np.array([int(x) for x in np.frombuffer(bytes.fromhex(stage2["input_claims"][2]), dtype="<u8")], dtype=np.uint64)
+    assert not claim0.any()
+    p = ob.RamReadWriteCheckingProver(accesses, gamma, r_cycle, rwc["log_k"], rwc["log_t"], rwc["phase1_num_rounds"], rwc["start_address"],
+                                      ob.fr_from_int(0), initial_ram)
+    assert ob.fr_to_int(p.inc[54]) == 1 and len(p.entries) == 1
+    check_rwc_against_the_captured_run(_OracleRwc(p), rwc, stage2, challenges, ob.fr_to_int, last_q=lambda a: a.p.last_q)

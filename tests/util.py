@@ -145,3 +145,20 @@ def output_check_tables_of_the_captured_run(oc, elf_bytes, fr_from_int, eq_table
     io_mask[oc["io_start"]:oc["io_end"]] = one
     r = np.stack([fr_from_int(int.from_bytes(bytes.fromhex(h), "little")) for h in oc["r_address"]])
     return eq_table(r), io_mask, val_final, val_io, val_init
+
+
+def rwc_inputs_of_the_captured_run(rwc, stage2, elf_bytes, fr_from_int):
+    """The inputs of the RamReadWriteCheckingProver of the reference's captured run (tests/golden/rwc_captured_run.json, with the
+    Stage-1 / Stage-2 challenges of tests/golden/stage2_batched_rounds.json): (accesses, gamma, r_cycle, initial_ram, challenges).
+    The 13 program words are the ELF's 104 code bytes at 0x80000000 (the file keeps them at offset 0x1000)."""
+    import struct
+    words = struct.unpack("<%dQ" % rwc["initial_ram_entries"], elf_bytes[0x1000:0x1000 + 8 * rwc["initial_ram_entries"]])
+    initial_ram = {0x80000000 + 8 * i: w for i, w in enumerate(words)}
+    for s in rwc["init"]["val_init_shown"]:  # the five the log shows
+        assert initial_ram[s["addr"]] == s["val"] and (s["addr"] - rwc["start_address"]) // 8 == s["idx"]
+    e = rwc["init"]["entries"][0]
+    accesses = [(e["cycle"], rwc["start_address"] + 8 * e["addr"], e["op"] == 1, e["next_val"])]
+    gamma = fr_from_int(int(rwc["gamma_be"], 16))
+    r_cycle = np.stack([fr_from_int(int.from_bytes(bytes.fromhex(h), "little")) for h in stage2["stage1_r_cycle"]])
+    challenges = np.stack([fr_from_int(int.from_bytes(bytes.fromhex(r["challenge"]), "little")) for r in stage2["rounds"]])
+    return accesses, gamma, r_cycle, initial_ram, challenges

@@ -8,7 +8,7 @@ for logn in 17 19; do
     for s in 3 4 6; do
       port=$((port+1))
       GPU_MAX_HW_QUEUES=$q MASTER_PORT=$port python3 bench.py --logn $logn --steps 10 --warmup 3 --msms-per-step 32 --no-cpu-baseline --no-extra --streams $s 2>/dev/null \
-        | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('logn=$logn hwq=$q streams=$s', round(d['value'],1), 'MSM/s', round(d['config']['ms_per_msm'],4), 'ms/MSM')"
+        | grep '^{' | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('logn=$logn hwq=$q streams=$s', round(d['value'],1), 'MSM/s', round(d['config']['ms_per_msm'],4), 'ms/MSM')"
     done
   done
 done

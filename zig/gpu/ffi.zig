@@ -91,6 +91,7 @@ pub extern fn zg_sumcheck_bind(s: Session, r: *const [4]u64) c_int;
 pub extern fn zg_sumcheck_len(s: Session) usize;
 pub extern fn zg_sumcheck_final(s: Session, out: *[4]u64) c_int;
 pub extern fn zg_sumcheck_read(s: Session, out_table: ?[*]u64) c_int;
+pub extern fn zg_sumcheck_gather(s: Session, idx: ?[*]const u64, n: usize, out: ?[*]u64) c_int;
 pub extern fn zg_sumcheck_round_sums_dev(s: Session, d_out8: ?[*]u64) c_int;
 pub extern fn zg_sumcheck_read_dev(s: Session, d_out_table: ?[*]u64) c_int;
 pub extern fn zg_sumcheck_close(s: Session) c_int;
@@ -111,6 +112,7 @@ pub extern fn zg_psc_set_points(s: ProductSession, points: c_uint) c_int;
 pub extern fn zg_psc_round_gruen(s: ProductSession, prod_idx: ?[*]const c_int, p: usize, d_e_out: ?[*]const u64, n_out: usize, d_e_in: ?[*]const u64, n_in: usize, t0: *[4]u64, t_inf: *[4]u64) c_int;
 pub extern fn zg_psc_bind(s: ProductSession, r: *const [4]u64) c_int;
 pub extern fn zg_psc_read(s: ProductSession, table: usize, out: ?[*]u64) c_int;
+pub extern fn zg_psc_gather(s: ProductSession, table: usize, idx: ?[*]const u64, n: usize, out: ?[*]u64) c_int;
 pub extern fn zg_psc_final(s: ProductSession, out: ?[*]u64) c_int;
 pub extern fn zg_psc_close(s: ProductSession) c_int;
 pub extern fn zg_shard_bounds(n: usize, shards: c_int, shard: c_int, start: ?*usize, len: ?*usize) c_int;

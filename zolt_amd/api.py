@@ -549,7 +549,8 @@ class GruenSplitEqPolynomial:
         n = self.tau.shape[0]
         self.current_index = n
         self.current_scalar = fr_from_int(1) if scaling_factor is None else np.ascontiguousarray(scaling_factor, dtype=np.uint64).copy()
-        if n == 0:  # :75-86
+        self._d_out = self._d_in = None  # the same table sets in HBM, built on first use by getWindowEqTablesDev
+        if n == 0:  # :75-86: a valid object without tables (deinit is a no-op)
             self.E_out_vec, self.E_in_vec, self.num_x_out, self.num_x_in = [], [], 0, 0
             return
         m = n // 2
@@ -557,7 +558,6 @@ class GruenSplitEqPolynomial:
         self.num_x_in = min(n - 1 - m, n - 1) if n > 1 else 0
         self.E_out_vec = list(lib.fr_eq_prefix_tables(self.tau[:m]))
         self.E_in_vec = list(lib.fr_eq_prefix_tables(self.tau[m:m + self.num_x_in]))
-        self._d_out = self._d_in = None  # the same table sets in HBM, built on first use by getWindowEqTablesDev
 
     init = classmethod(lambda cls, tau: cls(tau))
     initWithScaling = classmethod(lambda cls, tau, scaling_factor: cls(tau, scaling_factor))
@@ -593,8 +593,9 @@ class GruenSplitEqPolynomial:
         m = self.tau.shape[0] // 2
         head_out_bits = min(head_len, m)
         head_in_bits = max(head_len - head_out_bits, 0)
-        e_out = self.E_out_vec[head_out_bits] if head_out_bits < len(self.E_out_vec) else self.E_out_vec[-1]
-        e_in = self.E_in_vec[head_in_bits] if head_in_bits < len(self.E_in_vec) else self.E_in_vec[-1]
+        one = fr_from_int(1).reshape(1, 4)  # (an object over no variables has no tables: the empty product)
+        e_out = one if not self.E_out_vec else (self.E_out_vec[head_out_bits] if head_out_bits < len(self.E_out_vec) else self.E_out_vec[-1])
+        e_in = one if not self.E_in_vec else (self.E_in_vec[head_in_bits] if head_in_bits < len(self.E_in_vec) else self.E_in_vec[-1])
         return e_out, e_in, head_in_bits
 
     def getWindowEqTablesDev(self, window_size):
@@ -1658,6 +1659,303 @@ def generateBatchedProof(prover, transcript):
         prover.bindChallenge(challenge)
     z3, z1 = np.zeros((0, 3, 4), dtype=np.uint64), np.zeros((0, 4), dtype=np.uint64)
     return {"round_polys": np.stack(polys) if polys else z3, "challenges": np.stack(chals) if chals else z1, "final_claim": prover.getFinalClaim()}
+
+
+class RamReadWriteCheckingProver:
+    """RamReadWriteCheckingProver (src/zkvm/ram/read_write_checking.zig:160-1323): the three-phase sumcheck (phase1_num_rounds cycle
+    variables, log_k address variables, the remaining cycle variables) over a SPARSE access matrix with three DENSE side tables. The
+    dense tables live on the device and are folded there — eq_evals and inc (2^log_t entries, LowToHigh: one two-table product-form
+    session, zg_psc_bind) and val_init (2^log_k entries: a LOW_PAIR session, zg_sumcheck_bind) — and the host reads of them only the
+    rows / columns the entries touch (zg_psc_gather / zg_sumcheck_gather). The sparse entry algebra (pair merges, checkpoints, the
+    Gruen cubic) is host scalar code, as in the reference. accesses: [(timestamp, address, is_write, value)] in trace order;
+    initial_ram: {address: u64}. Entry = [cycle, address, ra_coeff, val_coeff, prev_val, next_val] (CycleMajorEntry, :91-157), integers mod r."""
+
+    def __init__(self, accesses, gamma, r_cycle, log_k, log_t, phase1_num_rounds, start_address, initial_claim, initial_ram=None):
+        self.gamma = fr_to_int(gamma)
+        self.r_cycle = np.ascontiguousarray(r_cycle, dtype=np.uint64).reshape(-1, 4).copy()
+        self.log_k, self.log_t, self.phase1_num_rounds, self.start_address = log_k, log_t, phase1_num_rounds, start_address
+        K, T = 1 << log_k, 1 << log_t
+        inc = np.zeros((T, 4), dtype=np.uint64)
+        val_init = np.zeros((K, 4), dtype=np.uint64)
+        cur = {}
+        for addr, val in (initial_ram or {}).items():  # :212-231, :253-267
+            if addr >= start_address and (addr - start_address) // 8 < K:
+                idx = (addr - start_address) // 8
+                val_init[idx] = fr_from_int(val)
+                cur[idx] = val
+        self.entries = []
+        for ts, address, is_write, value in accesses:  # :269-330
+            if ts >= T or address < start_address or (address - start_address) // 8 >= K:
+                continue
+            idx = (address - start_address) // 8
+            prev = cur.get(idx, 0)
+            if is_write:
+                inc[ts] = fr_from_int(value - prev)
+                cur[idx] = value
+            self.entries.append([ts, idx, 1, (prev if is_write else value) % R_MOD, prev, value])
+        self.entries.sort(key=lambda e: (e[0], e[1]))  # :333-340
+        # eq_evals = eq(r_cycle, .) (computeEqBigEndian, :345-348) built on the device; inc uploaded; both in ONE session
+        d_eq, d_inc = lib.DeviceBuffer(T * 32), lib.DeviceBuffer.from_host(inc)
+        lib.fr_eq_table_dev(self.r_cycle, d_eq.ptr)
+        lib.sync()
+        self._cyc = lib.ProductSumcheckSession.open_dev([d_eq.ptr, d_inc.ptr], T)
+        lib.sync()
+        d_eq.free()
+        d_inc.free()
+        self._val = lib.SumcheckSession.open(val_init, lib.SC_LOW_PAIR)
+        self._val_prev = None  # the table before the last address fold: the reference folds val_init IN PLACE (see bindChallenge)
+        self.eq_size = T
+        self.gruen_eq = GruenSplitEqPolynomial(self.r_cycle)  # :354
+        self.current_claim = fr_to_int(initial_claim)
+        self.round = 0
+        self.challenges = []
+
+    def numRounds(self):
+        return self.log_k + self.log_t
+
+    def isComplete(self):
+        return self.round >= self.numRounds()
+
+    def _in_cycle_phase(self):
+        p1 = self.phase1_num_rounds
+        return self.round < p1 or self.round >= p1 + self.log_k
+
+    def computeRoundPolynomialCubic(self):
+        """[s(0), s(1), s(2), s(3)] (:391-408)"""
+        return self._phase1() if self._in_cycle_phase() else self._phase2()
+
+    def _phase1(self):  # computePhase1Polynomial, :410-536
+        P, gamma, g = R_MOD, self.gamma, self.gruen_eq
+        e_out, e_in, head_in_bits = g.getWindowEqTables(g.current_index, 1)
+        ents = self.entries
+        pairs = sorted({e[0] // 2 for e in ents})
+        rows = [r for p_ in pairs for r in (2 * p_, 2 * p_ + 1) if r < len(self._cyc)]
+        got = self._cyc.gather(1, rows) if rows else np.zeros((0, 4), dtype=np.uint64)  # only the inc rows the entries touch
+        inc_at = {r: fr_to_int(v) for r, v in zip(rows, got)}
+        eo, ei = {}, {}
+        qc = qq = 0
+        i = 0
+        while i < len(ents):
+            e = ents[i]
+            pair = e[0] // 2
+            x_out, x_in = pair >> head_in_bits, pair & ((1 << head_in_bits) - 1)
+            if x_out not in eo:
+                eo[x_out] = fr_to_int(e_out[x_out]) if x_out < len(e_out) else 1
+            if x_in not in ei:
+                ei[x_in] = fr_to_int(e_in[x_in]) if x_in < len(e_in) else 1
+            e_prefix = eo[x_out] * ei[x_in] % P
+            inc_0, inc_1 = inc_at.get(2 * pair, 0), inc_at.get(2 * pair + 1, 0)
+            inc_inf = (inc_1 - inc_0) % P
+            if e[0] % 2 == 0:
+                nxt = ents[i + 1] if i + 1 < len(ents) else None
+                if nxt is not None and nxt[0] // 2 == pair and nxt[1] == e[1] and nxt[0] % 2 == 1:
+                    ra_0, ra_inf, val_0, val_inf = e[2], (nxt[2] - e[2]) % P, e[3], (nxt[3] - e[3]) % P
+                    i += 2
+                else:  # the odd entry is implicit: it would hold the value after this access
+                    ra_0, ra_inf, val_0, val_inf = e[2], (-e[2]) % P, e[3], (e[5] - e[3]) % P
+                    i += 1
+            else:  # the even entry is implicit: the value before this access
+                ra_0, ra_inf, val_0, val_inf = 0, e[2], e[4] % P, (e[3] - e[4]) % P
+                i += 1
+            qc = (qc + e_prefix * ra_0 % P * ((val_0 + gamma * (inc_0 + val_0)) % P)) % P
+            qq = (qq + e_prefix * ra_inf % P * ((val_inf + gamma * (inc_inf + val_inf)) % P)) % P
+        self.last_q = (qc, qq)
+        return g.computeCubicRoundPoly(fr_from_int(qc), fr_from_int(qq), fr_from_int(self.current_claim))
+
+    def _eq_addr(self, address, addr_round):
+        acc = 1
+        for i in range(addr_round):
+            r_i = self.challenges[self.phase1_num_rounds + i]
+            acc = acc * (r_i if (address >> i) & 1 else (1 - r_i)) % R_MOD
+        return acc
+
+    def _pair_groups(self, addr_round):
+        ents, i = self.entries, 0
+        while i < len(ents):
+            col_pair = (ents[i][1] >> addr_round) // 2
+            j = i
+            while j < len(ents) and (ents[j][1] >> addr_round) // 2 == col_pair:
+                j += 1
+            k = i
+            while k < j and (ents[k][1] >> addr_round) % 2 == 0:
+                k += 1
+            yield col_pair, ents[i:k], ents[k:j]
+            i = j
+
+    def _checkpoints(self, addr_round, after_fold):
+        """val_init at the columns 2c, 2c + 1 of every column pair c the entries touch (:591-602). after_fold: as bindEntriesAddressMajor
+        sees the array (:985-996) — the reference has just folded it IN PLACE (:953-959), so indices below size / 2 hold the new values
+        and the others still the old ones; the device fold is out of place, so the old table's values were gathered before it."""
+        size = (1 << self.log_k) >> addr_round
+        cols = sorted({c for cp, _, _ in self._pair_groups(addr_round) for c in (2 * cp, 2 * cp + 1) if c < size})
+        if not after_fold:
+            got = self._val.gather(cols) if cols else []
+            return {c: fr_to_int(v) for c, v in zip(cols, got)}, size
+        lo = [c for c in cols if c < size // 2]
+        got = self._val.gather(lo) if lo else []
+        out = {c: fr_to_int(v) for c, v in zip(lo, got)}
+        out.update({c: self._val_prev[c] for c in cols if c >= size // 2})
+        return out, size
+
+    def _phase2(self):  # computePhase2Polynomial, :538-769
+        P, gamma = R_MOD, self.gamma
+        addr_round = self.round - self.phase1_num_rounds
+        if addr_round == 0:
+            self.entries.sort(key=lambda e: (e[1], e[0]))  # AddressMajor (:555-562)
+            both = self._cyc.gather(0, [0]), self._cyc.gather(1, [0])
+            self._eq_cycle, self._inc_scalar = fr_to_int(both[0][0]), fr_to_int(both[1][0])
+        eq_cycle, inc_s = self._eq_cycle, self._inc_scalar
+        chk, size = self._checkpoints(addr_round, False)
+        opg = (1 + gamma) % P
+        s0 = s2 = 0
+
+        def contrib(address, ra_0, ra_2, val_0, val_2):
+            eq_partial = eq_cycle * self._eq_addr(address, addr_round) % P
+            return (eq_partial * ra_0 % P * ((val_0 * opg + gamma * inc_s) % P) % P,
+                    eq_partial * ra_2 % P * ((val_2 * opg + gamma * inc_s) % P) % P)
+        for col_pair, even, odd in self._pair_groups(addr_round):
+            ec, oc = chk.get(2 * col_pair, 0), chk.get(2 * col_pair + 1, 0)
+            a = b = 0
+            while a < len(even) or b < len(odd):
+                ee = even[a] if a < len(even) else None
+                oe = odd[b] if b < len(odd) else None
+                if ee is not None and oe is not None and ee[0] == oe[0]:
+                    c0, c2 = contrib(ee[1], ee[2], (2 * oe[2] - ee[2]) % P, ee[3], (2 * oe[3] - ee[3]) % P)
+                    ec, oc = ee[5] % P, oe[5] % P
+                    a += 1
+                    b += 1
+                elif oe is None or (ee is not None and ee[0] < oe[0]):
+                    c0, c2 = contrib(ee[1], ee[2], (-ee[2]) % P, ee[3], (2 * oc - ee[3]) % P)
+                    ec = ee[5] % P
+                    a += 1
+                else:
+                    c0, c2 = contrib(oe[1], 0, 2 * oe[2] % P, ec, (2 * oe[3] - ec) % P)
+                    oc = oe[5] % P
+                    b += 1
+                s0, s2 = (s0 + c0) % P, (s2 + c2) % P
+        s1 = (self.current_claim - s0) % P
+        s3 = (3 * s2 - 3 * s1 + s0) % P
+        return np.stack([fr_from_int(v) for v in (s0, s1, s2, s3)])
+
+    def bindChallenge(self, challenge):  # :902-970
+        P = R_MOD
+        ch = np.ascontiguousarray(challenge, dtype=np.uint64).copy()
+        r = fr_to_int(ch)
+        self.challenges.append(r)
+        p1 = self.phase1_num_rounds
+        if self._in_cycle_phase() and self.eq_size > 1:
+            self._cyc.bind(ch)  # eq_evals and inc, LowToHigh, one launch
+            self.eq_size //= 2
+            self.gruen_eq.bind(ch)
+            self._bind_entries(r)
+        if p1 <= self.round < p1 + self.log_k:
+            addr_round = self.round - p1
+            size = (1 << self.log_k) >> addr_round
+            cols = sorted({c for cp, _, _ in self._pair_groups(addr_round) for c in (2 * cp, 2 * cp + 1) if size // 2 <= c < size})
+            self._val_prev = {c: fr_to_int(v) for c, v in zip(cols, self._val.gather(cols))} if cols else {}
+            if size > 1:
+                self._val.bind(ch)
+            chk, _ = self._checkpoints(addr_round, True) if size > 1 else (self._checkpoints(addr_round, False)[0], size)
+            self._bind_entries_address_major(r, addr_round, chk)
+        self.round += 1
+
+    def _bind_entries(self, r):  # :1139-1185, CycleMajorEntry.bindEntries :110-156
+        P = R_MOD
+        ents, out, i = self.entries, [], 0
+        while i < len(ents):
+            e = ents[i]
+            if e[0] % 2 == 0:
+                nxt = ents[i + 1] if i + 1 < len(ents) else None
+                if nxt is not None and nxt[0] // 2 == e[0] // 2 and nxt[1] == e[1] and nxt[0] % 2 == 1:
+                    out.append([e[0] // 2, e[1], (e[2] + r * (nxt[2] - e[2])) % P, (e[3] + r * (nxt[3] - e[3])) % P, e[4], nxt[5]])
+                    i += 2
+                    continue
+                out.append([e[0] // 2, e[1], (1 - r) * e[2] % P, (e[3] + r * (e[5] - e[3])) % P, e[4], e[5]])
+            else:
+                out.append([e[0] // 2, e[1], r * e[2] % P, (e[4] + r * (e[3] - e[4])) % P, e[4], e[5]])
+            i += 1
+        self.entries = out
+
+    def _bind_entries_address_major(self, r, addr_round, chk):  # :973-1137
+        P = R_MOD
+        out = []
+        for col_pair, even, odd in self._pair_groups(addr_round):
+            ec, oc = chk.get(2 * col_pair, 0), chk.get(2 * col_pair + 1, 0)
+            a = b = 0
+            while a < len(even) or b < len(odd):
+                ee = even[a] if a < len(even) else None
+                oe = odd[b] if b < len(odd) else None
+                if ee is not None and oe is not None and ee[0] == oe[0]:
+                    out.append([ee[0], ee[1] // 2, (ee[2] + r * (oe[2] - ee[2])) % P, (ee[3] + r * (oe[3] - ee[3])) % P, ee[4], oe[5]])
+                    ec, oc = ee[5] % P, oe[5] % P
+                    a += 1
+                    b += 1
+                elif oe is None or (ee is not None and ee[0] < oe[0]):
+                    out.append([ee[0], ee[1] // 2, (1 - r) * ee[2] % P, (ee[3] + r * (oc - ee[3])) % P, ee[4], ee[5]])
+                    ec = ee[5] % P
+                    a += 1
+                else:
+                    out.append([oe[0], oe[1] // 2, r * oe[2] % P, (ec + r * (oe[3] - ec)) % P, oe[4], oe[5]])
+                    oc = oe[5] % P
+                    b += 1
+        self.entries = out
+
+    def updateClaim(self, evals, challenge):  # :1187-1204
+        P = R_MOD
+        e = [fr_to_int(x) for x in np.asarray(evals, dtype=np.uint64).reshape(4, 4)]
+        c = fr_to_int(challenge)
+        inv = lambda v: pow(v % P, P - 2, P)  # noqa: E731
+        L0 = (c - 1) * (c - 2) % P * (c - 3) % P * inv(-6) % P
+        L1 = c * (c - 2) % P * (c - 3) % P * inv(2) % P
+        L2 = c * (c - 1) % P * (c - 3) % P * inv(-2) % P
+        L3 = c * (c - 1) % P * (c - 2) % P * inv(6) % P
+        self.current_claim = (e[0] * L0 + e[1] * L1 + e[2] * L2 + e[3] * L3) % P
+
+    def getOpeningClaims(self, r_sumcheck):
+        """(ra_claim, val_claim, inc_claim) (:1210-1322); val_init[entry.address] is read as the reference reads it: from the array it
+        folded in place, where index 0 is the fully bound value"""
+        P = R_MOD
+        rs = [fr_to_int(x) for x in np.asarray(r_sumcheck, dtype=np.uint64).reshape(-1, 4)]
+        log_k, log_t, p1 = self.log_k, self.log_t, self.phase1_num_rounds
+        p2, p3 = p1 + log_k, log_t - p1
+        r_address, r_cyc = [0] * log_k, [0] * log_t
+        for i in range(min(log_k, max(len(rs) - p1, 0))):
+            r_address[log_k - 1 - i] = rs[p1 + i]
+        for i in range(min(p1, len(rs))):
+            if p3 + (p1 - 1 - i) < log_t:
+                r_cyc[p3 + (p1 - 1 - i)] = rs[i]
+        for i in range(min(p3, max(len(rs) - p2, 0))):
+            r_cyc[p3 - 1 - i] = rs[p2 + i]
+
+        def eq(rv, x):
+            acc, n = 1, len(rv)
+            for i in range(n):
+                acc = acc * (rv[i] if (x >> (n - 1 - i)) & 1 else (1 - rv[i])) % P
+            return acc
+        v0 = fr_to_int(self._val.gather([0])[0])
+        ra, val = 0, v0
+        for e in self.entries:
+            if e[1] != 0:
+                raise ValueError("getOpeningClaims before the address variables are bound")
+            w = eq(r_address, e[1]) * eq(r_cyc, e[0]) % P
+            ra = (ra + w * e[2]) % P
+            val = (val + w * (e[3] - v0)) % P
+        return fr_from_int(ra), fr_from_int(val), self._cyc.gather(1, [0])[0]
+
+    # small accessors shared with the tests' checker
+    def claim_element(self):
+        return fr_from_int(self.current_claim)
+
+    def cycle_scalars(self):
+        return fr_from_int(self._eq_cycle), fr_from_int(self._inc_scalar)
+
+    def entry_list(self):
+        return [(e[0], e[1], e[2]) for e in self.entries]
+
+    def deinit(self):
+        self._cyc.close()
+        self._val.close()
+        self.gruen_eq.deinit()
 
 
 class LassoProver:

@@ -155,5 +155,7 @@ int msm_combine_batch_enqueue(const uint64_t *d_partials, size_t ranks, size_t r
 int bases_device(zg_bases_t b);
 // poly.hip, for sharded.hip: enqueue a session's round-sums pass without waiting for its mailbox
 int sc_round_sums_start(zg_sc_t s);
+// poly.hip: out_host[i] = d_table[idx_host[i]] (32-byte elements; every index < len) through one gather launch on st, synchronous
+int gather_to_host(const uint64_t *d_table, size_t len, const uint64_t *idx_host, size_t n, uint64_t *out_host, hipStream_t st);
 
 }  // namespace zg

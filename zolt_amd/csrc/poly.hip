@@ -809,6 +809,32 @@ static int eq_spartan_enqueue(const uint64_t *r_host, size_t v, const uint64_t *
     return ZG_OK;
 }
 
+// out[i] = table[idx[i]]: the rows / columns a sparse-entry prover touches of a dense device table (RamReadWriteChecking's inc pairs
+// and val_init checkpoints, src/zkvm/ram/read_write_checking.zig:431-446,591-602) — one small gather + one copy instead of the table
+__global__ void __launch_bounds__(256) fr_gather_kernel(const uint64_t *table, const uint64_t *idx, size_t n, uint64_t *out) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) fe_store(out + 4 * i, fe_load<FrParams>(table + 4 * idx[i]));
+}
+
+int gather_to_host(const uint64_t *d_table, size_t len, const uint64_t *idx_host, size_t n, uint64_t *out_host, hipStream_t st) {
+    if (n == 0) return ZG_OK;
+    for (size_t i = 0; i < n; i++)
+        if (idx_host[i] >= len) {
+            set_error("gather: index beyond the table's current length");
+            return ZG_ERR_INVALID;
+        }
+    Scratch s_idx(n * 8), s_out(n * 32);
+    if (!s_idx.p || !s_out.p) return ZG_ERR_NOMEM;
+    SyncGuard sync(st);
+    ZG_HIP(hipMemcpyAsync(s_idx.p, idx_host, n * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(fr_gather_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, d_table, s_idx.as<uint64_t>(), n, s_out.as<uint64_t>());
+    ZG_HIP(hipGetLastError());
+    ZG_HIP(hipMemcpyAsync(out_host, s_out.p, n * 32, hipMemcpyDeviceToHost, st));
+    ZG_HIP(hipStreamSynchronize(st));
+    sync.dismiss();
+    return ZG_OK;
+}
+
 }  // namespace zg
 
 struct zg_sc_s {
@@ -1816,6 +1842,17 @@ int zg_sumcheck_final(zg_sc_t s, uint64_t out[4]) {
     ZG_HIP(hipStreamSynchronize(s->st));
     for (int i = 0; i < 4; i++) out[i] = s->h_pin[8 + i];
     return ZG_OK;
+}
+
+int zg_sumcheck_gather(zg_sc_t s, const uint64_t *idx, size_t n, uint64_t *out) {
+    ZG_INIT();
+    if (!s || (n && (!idx || !out))) {
+        set_error("zg_sumcheck_gather: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    DeviceGuard dg(s->device);
+    std::lock_guard<std::mutex> lk(s->mu);
+    return gather_to_host(s->buf[s->cur], s->len, idx, n, out, s->st);
 }
 
 int zg_sumcheck_read(zg_sc_t s, uint64_t *out_table) {

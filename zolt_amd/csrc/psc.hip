@@ -1002,6 +1002,17 @@ int zg_psc_read(zg_psc_t s, size_t table, uint64_t *out) {
     return ZG_OK;
 }
 
+int zg_psc_gather(zg_psc_t s, size_t table, const uint64_t *idx, size_t n, uint64_t *out) {
+    ZG_INIT();
+    if (!s || table >= s->k || (n && (!idx || !out))) {
+        set_error("zg_psc_gather: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    DeviceGuard dg(s->device);
+    std::lock_guard<std::mutex> lk(s->mu);
+    return gather_to_host(s->buf[s->cur] + 4 * table * s->stride(), s->len, idx, n, out, s->st);
+}
+
 int zg_psc_final(zg_psc_t s, uint64_t *out) {
     ZG_INIT();
     if (!s || !out || s->len != 1) {

@@ -40,10 +40,10 @@ SYMBOLS = [
     "zg_fr_dense_evaluate", "zg_fr_eq_table", "zg_fr_eq_table_dev", "zg_fr_eq_prefix_tables", "zg_fr_eq_prefix_tables_dev", "zg_fr_rows_mle", "zg_fr_rows_mle_dev", "zg_fr_eq_plus_one_table", "zg_fr_eq_plus_one_table_dev", "zg_fr_bind_low", "zg_fr_bind_high",
     "zg_fr_spartan_combine", "zg_fr_spartan_combine_dev",
     "zg_sumcheck_open", "zg_sumcheck_open_dev", "zg_sumcheck_round_sums", "zg_sumcheck_bind",
-    "zg_sumcheck_len", "zg_sumcheck_final", "zg_sumcheck_read", "zg_sumcheck_close",
+    "zg_sumcheck_len", "zg_sumcheck_final", "zg_sumcheck_read", "zg_sumcheck_gather", "zg_sumcheck_close",
     "zg_sumcheck_round_sums_dev", "zg_sumcheck_read_dev", "zg_sumcheck_raf_round", "zg_sumcheck_bit_round", "zg_sumcheck_bit_bind", "zg_fr_bit_split_sums", "zg_fr_bit_split_sums_dev",
     "zg_run_sumcheck", "zg_run_sumcheck_dev", "zg_sumcheck_open_spartan_dev",
-    "zg_psc_open", "zg_psc_open_dev", "zg_psc_len", "zg_psc_tables", "zg_psc_round_evals", "zg_psc_round_expr", "zg_psc_set_points", "zg_psc_round_gruen", "zg_psc_bind", "zg_psc_read",
+    "zg_psc_open", "zg_psc_open_dev", "zg_psc_len", "zg_psc_tables", "zg_psc_round_evals", "zg_psc_round_expr", "zg_psc_set_points", "zg_psc_round_gruen", "zg_psc_bind", "zg_psc_read", "zg_psc_gather",
     "zg_psc_final", "zg_psc_close",
 ]
 # test / bench scaffolding of include/zolt_gpu_internal.h (not part of the drop-in boundary)
@@ -671,6 +671,13 @@ class SumcheckSession:
         _chk(_lib.zg_sumcheck_read(self._h, _h(out)), "zg_sumcheck_read")
         return out
 
+    def gather(self, idx):
+        """table[idx[i]] of the current table -> (n, 4)"""
+        idx = np.ascontiguousarray(idx, dtype=np.uint64)
+        out = np.empty((idx.size, 4), dtype=np.uint64)
+        _chk(_lib.zg_sumcheck_gather(self._h, _h(idx), C.c_size_t(idx.size), _h(out)), "zg_sumcheck_gather")
+        return out
+
     def raf_round(self, base, current_power):
         """RAF cubic round sums s(0), s(2) over this LOW_PAIR session's table (zg_sumcheck_raf_round)"""
         s0 = np.empty(4, dtype=np.uint64)
@@ -794,6 +801,13 @@ class ProductSumcheckSession:
     def read(self, table):
         out = np.empty((len(self), 4), dtype=np.uint64)
         _chk(_lib.zg_psc_read(self._h, C.c_size_t(table), _h(out)), "zg_psc_read")
+        return out
+
+    def gather(self, table, idx):
+        """T[table][idx[i]] of the current tables -> (n, 4)"""
+        idx = np.ascontiguousarray(idx, dtype=np.uint64)
+        out = np.empty((idx.size, 4), dtype=np.uint64)
+        _chk(_lib.zg_psc_gather(self._h, C.c_size_t(table), _h(idx), C.c_size_t(idx.size), _h(out)), "zg_psc_gather")
         return out
 
     def final(self):
