@@ -133,6 +133,39 @@ def test_zig_backend_rules_out_the_stale_table_and_wrong_field_hazards():
     assert "defer _ = ffi.zg_g1_bases_free(h);" in body and ".expected_uses = 1" in body
 
 
+def test_zig_backend_size_gates_are_the_measured_crossovers():
+    """Every host-pointer forwarding wrapper of zig/gpu/backend.zig refuses sizes below the CPU / GPU crossover measured by
+    tools/crossover.py (profiles/r3_crossover.json), and its constant IS the measured gate: no wrapper forwards a size at which the
+    GPU call was slower than the CPU body."""
+    import json
+    be = open(os.path.join(ROOT, "zig", "gpu", "backend.zig")).read()
+    code = "\n".join(l for l in be.splitlines() if not l.lstrip().startswith("//"))
+    cross = json.load(open(os.path.join(ROOT, "profiles", "r3_crossover.json")))
+    consts = {m.group(1): int(m.group(2)) for m in re.finditer(r"pub const (\w+_min_\w+): usize = (\d+);", code)}
+    want = {"srs_commit_min_points": "srs_commit", "one_shot_min_points": "one_shot_msm", "eq_table_min_entries": "eq_table",
+            "bind_low_min_entries": "bind_low", "bind_high_min_entries": "bind_high", "run_sumcheck_min_entries": "run_sumcheck",
+            "open_min_entries": "hyperkzg_open"}
+    assert set(want) <= set(consts)
+    for const, key in want.items():
+        assert consts[const] == cross["gates"][key], (const, consts[const], cross["gates"][key])
+        pts = {p["n"]: p for p in cross["points"][key]}
+        for n, p in pts.items():  # at and above the gate the GPU was faster wherever the CPU was timed
+            if n >= consts[const] and p["cpu_us"] is not None:
+                assert p["gpu_us"] < p["cpu_us"], (key, n)
+
+    def body(name):
+        i = code.index("pub fn " + name + "(")
+        j = code.find("\n    pub fn ", i + 10) if code[i - 4:i] == "    " else code.find("\npub fn ", i + 10)
+        return code[i:j if j > 0 else len(code)]
+    gated = {"commit": "srs_commit_min_points", "batchCommit": "srs_commit_min_points", "open": "open_min_entries", "batchOpen": "open_min_entries", "msmComputeOneShot": "one_shot_min_points",
+             "parallelMsmOneShot": "one_shot_min_points", "eqTable": "eq_table_min_entries", "bindLow": "bind_low_min_entries",
+             "bindHigh": "bind_high_min_entries", "runSumcheck": "run_sumcheck_min_entries"}
+    for fn, const in gated.items():
+        b = body(fn)
+        assert const in b, (fn, const)
+        assert b.index(const) < b.index("ffi.zg_"), fn  # the gate comes before the first library call
+
+
 def test_header_compiles_as_c_and_cpp(tmp_path):
     src = tmp_path / "t.c"
     src.write_text('#include "zolt_gpu.h"\nint main(void){ zg_msm_config c = {0,0,0}; (void)c; return ZG_OK; }\n')

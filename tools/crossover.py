@@ -45,7 +45,7 @@ def best(fn, reps, budget_s=2.0):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r3_crossover.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "crossover.json"), help="copy the file to profiles/ afterwards")
     ap.add_argument("--max-log", type=int, default=20)
     ap.add_argument("--cpu-budget", type=float, default=1.5, help="seconds of CPU work per (entry point, size); larger sizes are not timed on the CPU")
     args = ap.parse_args()

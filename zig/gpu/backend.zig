@@ -111,6 +111,20 @@ const Packed = struct {
 };
 
 // ---------------------------------------------------------------------------------------------------------------
+// Size gates: the CPU / GPU crossover of every host-pointer wrapper, MEASURED on an MI355X box against the reference's CPU bodies
+// restated in C (tools/crossover.py -> profiles/r3_crossover.json; tests/test_abi_and_host.py holds these constants to that file).
+// Below its gate a wrapper returns null and the caller keeps its Zig body: a host-pointer call pays upload + launch + download
+// (>= 30-40 us), more than the CPU needs for the 2^8..2^13-entry tables of a small trace (logs/zolt.log: log_t = 8).
+// ---------------------------------------------------------------------------------------------------------------
+pub const srs_commit_min_points: usize = 16; // zg_msm_g1 on a resident handle: 0.18 ms against 0.66 ms at 16 points
+pub const one_shot_min_points: usize = 64; // upload + table-less MSM + free: 1.4-1.6 ms against 1.9 ms at 64 points
+pub const eq_table_min_entries: usize = 4096; // 2^12 entries: 42 us against 69 us (2^10: 36 against 19)
+pub const bind_low_min_entries: usize = 16384; // in place: the table crosses PCIe both ways (2^12: 71 us against 60)
+pub const bind_high_min_entries: usize = 4096; // 2^12: 70 us against 83
+pub const run_sumcheck_min_entries: usize = 4096; // whole protocol on the device: 0.17 ms against 0.21 ms
+pub const open_min_entries: usize = 16; // HyperKZG.open: 0.25 ms against 1.2 ms at 16 evaluations
+
+// ---------------------------------------------------------------------------------------------------------------
 // SrsHandle: the device image of SetupParams.powers_of_tau_g1 (src/poly/commitment/mod.zig:122-140). A FIELD of SetupParams
 // (`gpu: gpu.SrsHandle = .{}`): HyperKZG.setup / SRS loaders call init(), SetupParams.deinit calls deinit(). One table on one
 // GPU, or — when the process drives several (ZOLT_GPU_DEVICES) — one shard per GPU.
@@ -151,6 +165,7 @@ pub const SrsHandle = struct {
         if (!self.ready()) return null;
         const n = @min(evals.len, self.len);
         if (n == 0) return Affine.identity();
+        if (n < srs_commit_min_points) return null; // measured crossover: the CPU body is faster
         var xy: [8]u64 = undefined;
         var inf: u8 = 0;
         const rc = if (self.sharded != null)
@@ -167,6 +182,7 @@ pub const SrsHandle = struct {
         if (!self.ready() or polys.len == 0) return null;
         const n = @min(polys[0].len, self.len);
         for (polys) |p| if (@min(p.len, self.len) != n) return null; // ragged batch: keep the per-polynomial loop
+        if (n < srs_commit_min_points) return null; // measured crossover (per vector; a fused batch only lowers it)
         const k = polys.len;
         const results = try allocator.alloc(Affine, k);
         errdefer allocator.free(results);
@@ -193,6 +209,7 @@ pub const SrsHandle = struct {
     /// commitments (one per variable the fold reaches) and the final evaluation; null = run the Zig body.
     pub fn open(self: *const SrsHandle, comptime F: type, comptime Affine: type, evals: []const F, point: []const F, value: F, allocator: std.mem.Allocator) !?struct { quotients: []Affine, final_eval: F } {
         if (self.bases == null) return null; // single-device handle only (the sharded form commits level by level: not offered)
+        if (evals.len < open_min_entries) return null; // measured crossover
         const v = point.len;
         const q = try allocator.alloc(Affine, v);
         errdefer allocator.free(q);
@@ -212,6 +229,7 @@ pub const SrsHandle = struct {
     /// HyperKZG.batchOpen (:607-732): gamma, the combined polynomial, per-polynomial evaluations and the same loop, one call.
     pub fn batchOpen(self: *const SrsHandle, comptime F: type, comptime Affine: type, polys: []const []const F, point: []const F, allocator: std.mem.Allocator) !?struct { quotients: []Affine, evaluations: []F, final_eval: F, gamma: F } {
         if (self.bases == null) return null;
+        if (polys.len == 0 or polys[0].len < open_min_entries) return null; // measured crossover (the combined polynomial has polys[0]'s length)
         const k = polys.len;
         const v = point.len;
         const ptrs = try allocator.alloc(?[*]const u64, @max(k, 1));
@@ -263,7 +281,6 @@ pub fn setupPowers(comptime F: type, comptime Affine: type, g1: Affine, scalars:
 // MSM(F, G).compute on an arbitrary slice (src/msm/mod.zig:355-372): ONE-SHOT. No table outlives the call.
 // ---------------------------------------------------------------------------------------------------------------
 /// below this many points the upload + launch latency (~0.5 ms) loses to the CPU body
-pub const one_shot_min_points: usize = 4096;
 
 /// null = not handled here (wrong field types, GPU disabled, too small, or a device failure): run the original body.
 pub fn msmComputeOneShot(comptime F: type, comptime G: type, comptime Affine: type, bases: []const Affine, scalars: []const F) ?Affine {
@@ -306,7 +323,9 @@ pub fn parallelMsmOneShot(comptime F: type, comptime G: type, comptime Affine: t
 // poly: EqPolynomial.evalsSliceWithScaling, DensePolynomial.bindLow / bindFirst / evaluate (src/poly/mod.zig). Fr only:
 // callers gate with `comptime gpu.isBn254Scalar(F)`.
 // ---------------------------------------------------------------------------------------------------------------
-pub fn eqTable(comptime F: type, allocator: std.mem.Allocator, r: []const F, scaling_factor: ?F) ![]F {
+/// null = below the measured crossover (eq_table_min_entries): the caller runs its Zig loop
+pub fn eqTable(comptime F: type, allocator: std.mem.Allocator, r: []const F, scaling_factor: ?F) !?[]F {
+    if ((@as(usize, 1) << @intCast(r.len)) < eq_table_min_entries) return null;
     const result = try allocator.alloc(F, @as(usize, 1) << @intCast(r.len));
     errdefer allocator.free(result);
     const sc: ?[*]const u64 = if (scaling_factor) |*s| &s.limbs else null;
@@ -332,13 +351,17 @@ pub fn gruenPrefixTables(comptime F: type, allocator: std.mem.Allocator, w: []co
     }
 }
 
-/// in place; the caller then halves its live length / decrements num_vars as the original does (:160-175)
-pub fn bindLow(comptime F: type, evaluations: []F, value: F) Error!void {
+/// in place; the caller then halves its live length / decrements num_vars as the original does (:160-175).
+/// false = below the measured crossover (bind_low_min_entries): nothing was done, the caller runs its Zig loop
+pub fn bindLow(comptime F: type, evaluations: []F, value: F) Error!bool {
+    if (evaluations.len < bind_low_min_entries) return false;
     if (ffi.zg_fr_bind_low(@ptrCast(evaluations.ptr), evaluations.len, &value.limbs) != ffi.OK) return Error.GpuFailure;
+    return true;
 }
 
-/// new allocation of len / 2 entries, like bindFirst (:128-149)
-pub fn bindHigh(comptime F: type, allocator: std.mem.Allocator, evaluations: []const F, value: F) ![]F {
+/// new allocation of len / 2 entries, like bindFirst (:128-149); null = below the measured crossover (bind_high_min_entries)
+pub fn bindHigh(comptime F: type, allocator: std.mem.Allocator, evaluations: []const F, value: F) !?[]F {
+    if (evaluations.len < bind_high_min_entries) return null;
     const out = try allocator.alloc(F, evaluations.len / 2);
     errdefer allocator.free(out);
     if (ffi.zg_fr_bind_high(limbsOf(F, evaluations), evaluations.len, &value.limbs, @ptrCast(out.ptr)) != ffi.OK) return Error.GpuFailure;
@@ -548,7 +571,8 @@ pub const GruenDeviceTables = struct {
 };
 
 /// runSumcheck (:302-354) with prover AND toy verifier on the device. rounds: v × [c0, c1]; challenges: v (= final_point).
-pub fn runSumcheck(comptime F: type, allocator: std.mem.Allocator, evaluations: []const F) !struct { claim: F, rounds: []F, challenges: []F, final_eval: F, result: bool } {
+pub fn runSumcheck(comptime F: type, allocator: std.mem.Allocator, evaluations: []const F) !?struct { claim: F, rounds: []F, challenges: []F, final_eval: F, result: bool } {
+    if (evaluations.len < run_sumcheck_min_entries) return null; // measured crossover: the Zig loop is faster on short tables
     const v: usize = std.math.log2_int(usize, evaluations.len);
     const rounds = try allocator.alloc(F, 2 * v);
     errdefer allocator.free(rounds);
