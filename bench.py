@@ -29,14 +29,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # HBM traffic of one msm_accumulate launch at 2^20 points (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, serial bench,
-# profiles/r2a_rocprofv3_summary.txt; 17-bit windows, 15.7M table rows): FETCH_SIZE 1,248,779 KB, WRITE_SIZE 28,522 KB per launch.
+# profiles/r3a_rocprofv3_summary.txt; 17-bit windows, 15.7M table rows): FETCH_SIZE 1,314,038 KB, WRITE_SIZE 28,689 KB per launch.
 # Calibration on this access pattern (tools/microbench gather|stream under --pmc FETCH_SIZE, same file): random 64-byte rows read
 # with the kernel's load shape report 1.04x their bytes (no correction), a sequential 16 B/lane stream reports 0.50x (the gfx950
 # x2 of MI355X_MICROARCH.md). The launch gathers 15.7M rows (1.007 GB, taken as counted) and streams 63 MB of sorted
 # references (counted at half: +31 MB).
-MEASURED_TRAFFIC = {20: 1248779.2 * 1024.0 + 0.5 * 4.0 * 15.73e6 + 28522.3 * 1024.0}
+MEASURED_TRAFFIC = {20: 1314038.4 * 1024.0 + 0.5 * 4.0 * 15.73e6 + 28688.8 * 1024.0}
 TRAFFIC_SOURCE = ("rocprofv3 PMC FETCH_SIZE (+x2 on the streamed 63 MB of sorted references, x1 on the gathered 64-byte rows: calibrated with "
-                  "tools/microbench gather|stream) + WRITE_SIZE, profiles/r2a_rocprofv3_summary.txt (re-measured unchanged in profiles/r2e_rocprofv3_summary.txt: FETCH_SIZE 1,253,897 KB, WRITE_SIZE 28,523 KB)")
+                  "tools/microbench gather|stream) + WRITE_SIZE, profiles/r3a_rocprofv3_summary.txt (round 2: profiles/r2a_/r2e_rocprofv3_summary.txt, "
+                  "FETCH_SIZE 1,248,779 / 1,253,897 KB)")
 # static instruction mix of one lazy-limb XYZZ mixed add (hipcc --save-temps of the accumulate fast path): 1467
 # v_mad_u64_u32 + 146 v_lshl_add_u64 + 144 v_lshrrev_b64 + 81 v_mul_lo_u32 at 4 issue cycles per wave, 382 32-bit
 # add/and/shift/sub at 2 (tools/microbench.hip rates)

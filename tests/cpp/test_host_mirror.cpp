@@ -508,8 +508,73 @@ TEST(stage3_and_opening_claim_sites) {
     for (size_t j = 1; j < 64; j++) EXPECT(e1[j].eql(eq[j - 1]));
 }
 
-int main() {
+// `test_host_mirror rwc <file>`: runs zolt::RamReadWriteCheckingProver on the instance the file describes (written by
+// tests/test_gpu_cpp_host.py: the reference's captured run and random traces) and prints every round polynomial, claim, entry count and
+// the opening claims as hex limbs; the Python test compares the lines with the oracle's.
+static Fr read_fr(std::FILE *f) {
+    Fr x;
+    for (int i = 0; i < 4; i++) {
+        unsigned long long v = 0;
+        if (std::fscanf(f, "%llx", &v) != 1) throw std::runtime_error("rwc input: field element expected");
+        x.limbs[i] = v;
+    }
+    return x;
+}
+static void print_fr(const Fr &x) { std::printf(" %016llx %016llx %016llx %016llx", (unsigned long long)x.limbs[0], (unsigned long long)x.limbs[1], (unsigned long long)x.limbs[2], (unsigned long long)x.limbs[3]); }
+static int rwc_main(const char *path) {
+    std::FILE *f = std::fopen(path, "r");
+    if (!f) { std::printf("cannot open %s\n", path); return 2; }
+    unsigned long long log_k, log_t, p1, start, n;
+    if (std::fscanf(f, "%llu %llu %llu %llu", &log_k, &log_t, &p1, &start) != 4) return 2;
+    Fr gamma = read_fr(f), claim = read_fr(f);
+    std::vector<Fr> r_cycle;
+    for (size_t i = 0; i < log_t; i++) r_cycle.push_back(read_fr(f));
+    std::vector<std::pair<uint64_t, uint64_t>> init;
+    if (std::fscanf(f, "%llu", &n) != 1) return 2;
+    for (size_t i = 0; i < n; i++) {
+        unsigned long long a, v;
+        if (std::fscanf(f, "%llu %llu", &a, &v) != 2) return 2;
+        init.emplace_back(a, v);
+    }
+    std::vector<MemoryAccess> acc;
+    if (std::fscanf(f, "%llu", &n) != 1) return 2;
+    for (size_t i = 0; i < n; i++) {
+        unsigned long long ts, a, w, v;
+        if (std::fscanf(f, "%llu %llu %llu %llu", &ts, &a, &w, &v) != 4) return 2;
+        acc.push_back(MemoryAccess{ts, a, w != 0, v});
+    }
+    std::vector<Fr> ch;
+    for (size_t i = 0; i < log_k + log_t; i++) ch.push_back(read_fr(f));
+    std::fclose(f);
+    RamReadWriteCheckingProver p(acc, gamma, r_cycle, log_k, log_t, p1, start, claim, init);
+    for (size_t rd = 0; rd < log_k + log_t; rd++) {
+        auto ev = p.computeRoundPolynomialCubic();
+        std::printf("E");
+        for (const Fr &x : ev) print_fr(x);
+        std::printf("\n");
+        p.updateClaim(ev, ch[rd]);
+        p.bindChallenge(ch[rd]);
+        std::printf("C");
+        print_fr(p.current_claim);
+        std::printf(" %zu\n", p.entries.size());
+    }
+    auto oc = p.getOpeningClaims(ch);
+    std::printf("O");
+    print_fr(oc.ra_claim);
+    print_fr(oc.val_claim);
+    print_fr(oc.inc_claim);
+    std::printf("\n%d\n", p.isComplete() ? 1 : 0);
+    return 0;
+}
+
+int main(int argc, char **argv) {
     if (zg_init(0) != ZG_OK) { std::printf("zg_init failed: %s\n", zg_last_error()); return 2; }
+    if (argc >= 3 && !std::strcmp(argv[1], "rwc")) {
+        int rc;
+        try { rc = rwc_main(argv[2]); } catch (const std::exception &e) { std::printf("EXCEPTION: %s\n", e.what()); rc = 3; }
+        zg_shutdown();
+        return rc;
+    }
     for (auto &t : tests()) {
         int before = g_failed;
         try { t.f(); } catch (const std::exception &e) { std::printf("  EXCEPTION in %s: %s\n", t.n, e.what()); g_failed++; }

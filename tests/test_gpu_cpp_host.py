@@ -16,3 +16,83 @@ def test_cpp_host_mirror():
     print(res.stdout)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "0 failures" in res.stdout
+
+
+def _hexfr(x):
+    return " ".join("%x" % int(v) for v in x)
+
+
+def _write_rwc_case(path, log_k, log_t, p1, start, gamma, claim, r_cycle, initial_ram, accesses, challenges):
+    with open(path, "w") as f:
+        f.write(f"{log_k} {log_t} {p1} {start}\n{_hexfr(gamma)}\n{_hexfr(claim)}\n")
+        for r in r_cycle:
+            f.write(_hexfr(r) + "\n")
+        f.write(f"{len(initial_ram)}\n" + "".join(f"{a} {v}\n" for a, v in initial_ram.items()))
+        f.write(f"{len(accesses)}\n" + "".join(f"{ts} {a} {int(w)} {v}\n" for ts, a, w, v in accesses))
+        for c in challenges:
+            f.write(_hexfr(c) + "\n")
+
+
+def _parse_rwc_output(text):
+    import numpy as np
+    rounds, claims, opening = [], [], None
+    for line in text.splitlines():
+        w = line.split()
+        if not w:
+            continue
+        if w[0] == "E":
+            rounds.append(np.array([int(x, 16) for x in w[1:17]], dtype=np.uint64).reshape(4, 4))
+        elif w[0] == "C":
+            claims.append((np.array([int(x, 16) for x in w[1:5]], dtype=np.uint64), int(w[5])))
+        elif w[0] == "O":
+            opening = np.array([int(x, 16) for x in w[1:13]], dtype=np.uint64).reshape(3, 4)
+    return rounds, claims, opening
+
+
+@pytest.mark.gpu
+def test_cpp_ram_read_write_checking_mirror(tmp_path, golden_dir):
+    """zolt::RamReadWriteCheckingProver (zolt_amd/host/zolt_host.hpp) — compiled host code over the C ABI — against the oracle's
+    restatement of src/zkvm/ram/read_write_checking.zig on the reference's captured run and on random traces: every round polynomial,
+    claim, entry count and the three opening claims."""
+    import json
+    import numpy as np
+    from oracle import binding as ob
+    from tests import util as U
+    from tests.test_gpu_rwc import _trace
+    exe = os.path.join(ROOT, "tests", "cpp", "test_host_mirror")
+    subprocess.check_call(["make", "-C", os.path.dirname(exe), "test_host_mirror"])
+    rwc = json.load(open(os.path.join(golden_dir, "rwc_captured_run.json")))
+    stage2 = json.load(open(os.path.join(golden_dir, "stage2_batched_rounds.json")))
+    elf = open(os.path.join(golden_dir, "fibonacci.elf"), "rb").read()
+    acc, gamma, r_cycle, initial_ram, challenges = U.rwc_inputs_of_the_captured_run(rwc, stage2, elf, ob.fr_from_int)
+    cases = [(rwc["log_k"], rwc["log_t"], rwc["phase1_num_rounds"], rwc["start_address"], gamma, 0, r_cycle, initial_ram, acc, challenges)]
+    for log_k, log_t, p1, n_acc in ((4, 8, 4, 200), (10, 13, 6, 3000), (3, 6, 0, 64)):
+        start = 0x80000000
+        a2, i2 = _trace(7000 + log_t, log_k, log_t, n_acc, start)
+        g2 = ob.f_to_mont(ob.FR, U.random_raw256(70, 1))[0]
+        rc2 = ob.f_to_mont(ob.FR, U.random_raw256(71 + log_t, log_t))
+        ch2 = ob.f_to_mont(ob.FR, U.random_raw256(72 + log_t, log_k + log_t))
+        cases.append((log_k, log_t, p1, start, g2, None, rc2, i2, a2, ch2))
+    for k, (log_k, log_t, p1, start, g, claim, rc, init, accs, chal) in enumerate(cases):
+        o = ob.RamReadWriteCheckingProver(accs, g, rc, log_k, log_t, p1, start, np.zeros(4, dtype=np.uint64), init)
+        if claim is None:  # the true sum, so that every round is a sumcheck round
+            P, gi = ob._R_P, ob.fr_to_int(g)
+            claim = sum(ob.fr_to_int(o.eq_evals[e[0]]) * e[2] * (e[3] + gi * (e[3] + ob.fr_to_int(o.inc[e[0]]))) for e in o.entries) % P
+        o.current_claim = claim
+        path = str(tmp_path / f"rwc_{k}.txt")
+        _write_rwc_case(path, log_k, log_t, p1, start, g, ob.fr_from_int(claim), rc, init, accs, chal)
+        res = subprocess.run([exe, "rwc", path], capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+        rounds, claims, opening = _parse_rwc_output(res.stdout)
+        assert len(rounds) == len(claims) == log_k + log_t
+        for rd in range(log_k + log_t):
+            we = o.computeRoundPolynomialCubic()
+            assert np.array_equal(rounds[rd], we), (k, rd)
+            o.updateClaim(we, chal[rd])
+            o.bindChallenge(chal[rd])
+            assert ob.fr_to_int(claims[rd][0]) == o.current_claim and claims[rd][1] == len(o.entries), (k, rd)
+        wo = o.getOpeningClaims(chal)
+        assert all(np.array_equal(opening[i], wo[i]) for i in range(3)), k
+        if k == 0:  # the captured run: the reference's own final claim and opening claims, full width
+            assert o.current_claim == int.from_bytes(bytes.fromhex(stage2["instance_final_claims"][2]), "little")
+            assert ob.fr_to_int(opening[0]) == int(rwc["opening"]["ra_claim_be"], 16) and ob.fr_to_int(opening[1]) == int(rwc["opening"]["val_claim_be"], 16)

@@ -265,6 +265,43 @@ int main(int argc, char **argv) {
     } else {
         std::printf("{");
     }
+    // RamReadWriteCheckingProver (src/zkvm/ram/read_write_checking.zig): 2^v cycles, 2^16 words, a memory access in one cycle of four
+    // over 64 hot addresses, three phases (v / 2 cycle, 16 address, v / 2 cycle variables), Keccak transcript between rounds. The dense
+    // tables (eq_evals, inc, val_init) fold on the device, the sparse entries on the host.
+    double t_rwc = 0;
+    size_t rwc_rounds = 0;
+    {
+        const size_t log_k = 16, T = n;
+        std::vector<MemoryAccess> acc;
+        std::vector<std::pair<uint64_t, uint64_t>> init;
+        std::map<uint64_t, uint64_t> mem;
+        const uint64_t start = 0x80000000ULL;
+        for (size_t i = 0; i < 13; i++) { init.emplace_back(start + 8 * (4096 + i), splitmix() >> 8); mem[init.back().first] = init.back().second; }
+        for (size_t ts = 0; ts < T; ts++) {
+            uint64_t z = splitmix();
+            if (z & 3) continue;
+            uint64_t a = start + 8 * (4096 + ((z >> 8) & 63));
+            if ((z >> 4) & 1) { uint64_t val = splitmix(); acc.push_back(MemoryAccess{ts, a, true, val}); mem[a] = val; }
+            else acc.push_back(MemoryAccess{ts, a, false, mem.count(a) ? mem[a] : 0});
+        }
+        std::vector<Fr> rc(r.begin(), r.begin() + v);
+        Fr gamma = Fr::fromU64(splitmix());
+        for (int rep = -1; rep < (reps > 5 ? 5 : reps); rep++) {
+            auto t0 = clk::now();
+            RamReadWriteCheckingProver p(acc, gamma, rc, log_k, (size_t)v, (size_t)v / 2, start, Fr::zero());
+            Transcript tr("Jolt");
+            while (!p.isComplete()) {
+                auto ev = p.computeRoundPolynomialCubic();
+                for (auto &e : ev) tr.appendScalar("rwc", e);
+                Fr ch = tr.challengeScalar("rwc_r");
+                p.updateClaim(ev, ch);
+                p.bindChallenge(ch);
+            }
+            if (rep >= 0) { t_rwc += std::chrono::duration<double>(clk::now() - t0).count(); rwc_rounds += p.numRounds(); }
+        }
+        std::printf("\"ram_read_write_checking_rounds_per_s\": %.1f, \"ram_read_write_checking_ms_incl_setup\": %.4f, \"ram_read_write_checking_accesses\": %zu, ",
+                    rwc_rounds / t_rwc, t_rwc / (reps > 5 ? 5 : reps) * 1e3, acc.size());
+    }
     std::printf("\"val_evaluation_rounds_per_s\": %.1f, \"val_evaluation_ms\": %.4f, \"product_remainder_rounds_per_s\": %.1f, "
                 "\"product_remainder_ms\": %.4f, ", reps * v / t_val, t_val / reps * 1e3, reps * v / t_prod, t_prod / reps * 1e3);
     std::printf("\"lasso_log_K16_rounds_per_s\": %.1f, \"lasso_ms_whole_protocol_incl_setup\": %.4f, ", reps * (16 + v) / t_lasso, t_lasso / reps * 1e3);

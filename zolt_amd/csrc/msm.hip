@@ -664,29 +664,30 @@ __global__ void __launch_bounds__(128) msm_fine_offsets_kernel(const uint32_t *i
     }
 }
 
-// per coarse bin (one block each): exclusive prefix over the blocks' counts, in place, and the bin's total. The layout is
-// chist[blk][bin]; a thread owns a contiguous run of blocks.
-__global__ void __launch_bounds__(256) msm_colscan_bins_kernel(uint32_t *chist, uint32_t nblk, uint32_t NCB, uint32_t *total) {
+// per coarse bin: exclusive prefix over the blocks' counts, in place, and the bin's total. The layout is chist[blk][bin]: a
+// 1024-thread workgroup takes 16 CONSECUTIVE bins (16 lanes along the bin index: every access is a 64-byte row segment) and
+// splits the blocks into 64 contiguous slices; the slices' sums meet in LDS. (One workgroup per bin walking a column with an
+// 8 KiB stride cost 100 us at 2^22 points — 4 M uncoalesced 4-byte accesses; 64 bins per workgroup left only 32 workgroups.)
+__global__ void __launch_bounds__(1024) msm_colscan_bins_kernel(uint32_t *chist, uint32_t nblk, uint32_t NCB, uint32_t *total) {
     ZG_HIPRIO();
-    __shared__ uint32_t sh[256];
-    uint32_t bin = blockIdx.x, tid = threadIdx.x, per = (nblk + 255) / 256, a = tid * per, b = a + per < nblk ? a + per : nblk;
+    __shared__ uint32_t sh[64][16];
+    const uint32_t lane = threadIdx.x & 15, slice = threadIdx.x >> 4, bin = blockIdx.x * 16 + lane;
+    const uint32_t per = (nblk + 63) / 64, a = slice * per < nblk ? slice * per : nblk, b = a + per < nblk ? a + per : nblk;
     uint32_t s = 0;
-    for (uint32_t k = a; k < b; k++) s += chist[(size_t)k * NCB + bin];
-    sh[tid] = s;
+    if (bin < NCB)
+        for (uint32_t k = a; k < b; k++) s += chist[(size_t)k * NCB + bin];
+    sh[slice][lane] = s;
     __syncthreads();
-    for (uint32_t o = 1; o < 256; o <<= 1) {
-        uint32_t v = tid >= o ? sh[tid - o] : 0;
-        __syncthreads();
-        sh[tid] += v;
-        __syncthreads();
+    uint32_t run = 0;
+    for (uint32_t q = 0; q < slice; q++) run += sh[q][lane];
+    if (bin < NCB) {
+        for (uint32_t k = a; k < b; k++) {
+            uint32_t v = chist[(size_t)k * NCB + bin];
+            chist[(size_t)k * NCB + bin] = run;
+            run += v;
+        }
+        if (slice == 63) total[bin] = run;
     }
-    uint32_t run = sh[tid] - s;
-    for (uint32_t k = a; k < b; k++) {
-        uint32_t v = chist[(size_t)k * NCB + bin];
-        chist[(size_t)k * NCB + bin] = run;
-        run += v;
-    }
-    if (tid == 255) total[bin] = sh[255];
 }
 
 ZG_DEV XYZZ xyzz_shfl_down(const XYZZ &v, int delta) {
@@ -1724,7 +1725,7 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
         prof_end(ZG_PROF_MSM_DIGITS, st);
         prof_begin(ZG_PROF_MSM_SORT, st);
         uint32_t *d_tot = ln.d_cstarts + p.NCB + 1, *d_tst = ln.d_cstarts + 2 * (size_t)p.NCB + 2, *d_ist = ln.d_cstarts + 3 * (size_t)p.NCB + 3;
-        hipLaunchKernelGGL(msm_colscan_bins_kernel, dim3(p.NCB), dim3(256), 0, st, ln.d_blockhist, nblk, p.NCB, d_tot);
+        hipLaunchKernelGGL(msm_colscan_bins_kernel, dim3(div_up(p.NCB, 16)), dim3(1024), 0, st, ln.d_blockhist, nblk, p.NCB, d_tot);
         hipLaunchKernelGGL(msm_coarse_base_kernel, dim3(1), dim3(1024), 0, st, d_tot, p.NCB, ln.d_cstarts, d_tst, d_ist);
         ZG_TRY(two_pass_attrs());
         if (p.G == 1 && n == n_pts)

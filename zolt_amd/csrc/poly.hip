@@ -242,30 +242,6 @@ ZG_DEV Fr sc_verifier_step(const ScRunArg &a, const Fr &g0, const Fr &g1, F29 *c
     return ch;
 }
 
-// Arrival of a workgroup at the end of a round; returns true in the one that arrives last (after every other group's partials are
-// visible to it). Same-address atomics serialise at ~30 ns each: 2048 workgroups on one counter cost 60 us (measured: a 2^20-entry
-// fold 37 -> 100 us), which pinned the grids to one workgroup per CU and the long folds to 3-4 TB/s. Above SC_ARRIVE_FLAT groups the
-// arrival is two-level: 16 counters on separate 128-byte lines (blockIdx mod 16), the last arrival of each line moves on to the top
-// counter — at most nb / 16 + 16 serialised atomics. Every counter is left at zero for the next launch (stream order).
-constexpr uint32_t SC_ARRIVE_FLAT = 64, SC_ARRIVE_LINES = 16, SC_ARRIVE_STRIDE = 32;  // uint32 words between counters (128 bytes)
-constexpr size_t SC_COUNTER_BYTES = 128 * (1 + SC_ARRIVE_LINES);
-ZG_DEV bool sc_arrive(uint32_t *counter, uint32_t nb) {
-    if (nb <= SC_ARRIVE_FLAT) {
-        uint32_t arrived = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (arrived != nb - 1) return false;
-        __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return true;
-    }
-    const uint32_t line = blockIdx.x % SC_ARRIVE_LINES;
-    const uint32_t members = (nb - line + SC_ARRIVE_LINES - 1) / SC_ARRIVE_LINES;  // workgroups b < nb with b mod 16 == line
-    uint32_t *lc = counter + SC_ARRIVE_STRIDE * (1 + line);
-    if (__hip_atomic_fetch_add(lc, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) != members - 1) return false;
-    __hip_atomic_store(lc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (__hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) != SC_ARRIVE_LINES - 1) return false;
-    __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return true;
-}
-
 // End of a round inside the producing kernel (no second launch): every block leaves its pair in `partials`; the block
 // that arrives last at the device-scope counter adds all of them up, writes the round's pair to `sums` (the pinned
 // host mailbox), publishes the sequence word and re-arms the counter. g0/g1: the block's pair, valid in thread 0.

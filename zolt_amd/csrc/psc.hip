@@ -33,8 +33,8 @@
 namespace zg {
 
 constexpr unsigned PSC_MAX_BLOCKS = 4096;
-constexpr size_t PSC_COUNTER_OFF = 16 * (size_t)PSC_MAX_BLOCKS;     // u64 words: block quadruples, then the arrival counter
-constexpr size_t PSC_MISC_BYTES = (PSC_COUNTER_OFF + 16) * 8;
+constexpr size_t PSC_COUNTER_OFF = 16 * (size_t)PSC_MAX_BLOCKS;     // u64 words: block quadruples, then the arrival counters (sc_arrive)
+constexpr size_t PSC_MISC_BYTES = PSC_COUNTER_OFF * 8 + SC_COUNTER_BYTES;
 constexpr int PSC_FLAG = 24;                                        // h_pin: 16 words of values, sequence word at 24
 
 // compile-time loop: the table loops carry register arrays (prescaled coefficients) and must not stay loops
@@ -164,13 +164,8 @@ __device__ __forceinline__ void psc_finish(Fr (&v)[2 * NP], uint4 *sh, uint64_t 
     if (tid == 0) {
         uint64_t *dst = partials + 16 * (size_t)blockIdx.x;
 #pragma unroll
-        for (int a = 0; a < 2 * NP; a++)
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-                __hip_atomic_store(dst + 4 * a + i, (uint64_t)v[a].l[2 * i] | ((uint64_t)v[a].l[2 * i + 1] << 32), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t arrived = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        last = arrived == nb - 1 ? 1u : 0u;
+        for (int a = 0; a < 2 * NP; a++) fe_store(dst + 4 * a, v[a]);  // plain stores: the arrival's release publishes them
+        last = sc_arrive(counter, nb) ? 1u : 0u;  // two-level above 64 workgroups (sc_common.hip.h): ~20-30 ns per same-address arrival
     }
     __syncthreads();
     if (!last) return;
@@ -181,14 +176,7 @@ __device__ __forceinline__ void psc_finish(Fr (&v)[2 * NP], uint4 *sh, uint64_t 
         const uint64_t *src = partials + 16 * (size_t)k;
 #pragma unroll
         for (int a = 0; a < 2 * NP; a++) {
-            Fr p;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                uint64_t x = __hip_atomic_load(src + 4 * a + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                p.l[2 * i] = (uint32_t)x;
-                p.l[2 * i + 1] = (uint32_t)(x >> 32);
-            }
-            acc[a] = fe_add(acc[a], p);
+            acc[a] = fe_add(acc[a], fe_load<FrParams>(src + 4 * a));
         }
     }
     __syncthreads();  // sh is reused
@@ -197,8 +185,7 @@ __device__ __forceinline__ void psc_finish(Fr (&v)[2 * NP], uint4 *sh, uint64_t 
         __syncthreads();
         block_sum_pair(acc[2], acc[3], sh);
     }
-    if (tid == 0) {
-        __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch (stream order)
+    if (tid == 0) {  // (sc_arrive re-armed its counters)
 #pragma unroll
         for (int a = 0; a < 2 * NP; a++) fe_store(sums + 4 * a, acc[a]);
         publish_seq(flag, seq);
