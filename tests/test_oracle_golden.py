@@ -537,3 +537,113 @@ def test_eq_plus_one_reference_inline_test_and_shift_identity():
         if v:
             y = ob.f_to_mont(FR, rng.integers(0, 1 << 62, size=(v, 4), dtype=np.uint64))  # a non-boolean point: the two mle restatements agree
             assert np.array_equal(ob.eq_plus_one_mle(r, y), api.EqPlusOnePolynomial(r).evaluate(y))
+
+
+def test_round_polynomials_from_the_unfolded_tables():
+    """Round-2 review, "strengthen the algebra-only pins": s(0) + s(1) = claim cannot see a restatement that folds the wrong pair
+    order consistently on both sides. Here every round polynomial of the product-form restatements is computed a second time from the
+    ORIGINAL tables by the definition of the sumcheck it belongs to — no folded state, no shared code:
+
+        s_k(t) = sum over x in {0,1}^(v-k-1) of  F( T_j~(r_0, ..., r_(k-1), t, x) for the tables j ),
+        T~(z_0, ..., z_k, x) = sum over b in {0,1}^(k+1) of  prod_i (b_i ? z_i : 1 - z_i) * T[b_0 + 2 b_1 + ... + 2^k b_k + 2^(k+1) x]
+
+    — variable i of the protocol IS bit i of the table index (LowToHigh: the pair (2i, 2i + 1) is bound first, val_evaluation.zig:609-628,
+    output_check.zig:449-480, instruction_lookups.zig:240-270, product_remainder.zig:357-394) — with exact integers, at t = 0..3, for
+    ValEvaluation / ValFinal (product of the tables), OutputCheck (eq * io * (vf - vio)), the InstructionLookups claim reduction
+    (eq * (out + g left + g^2 right)) and ProductVirtualRemainder (left * right * eq(tau, .), the eq table big-endian in tau, so the LAST
+    tau is bound first). The final claim is the product form at the multilinear extensions' values at (r_0, ..., r_(v-1))."""
+    P = pm.R_MOD
+    rng = np.random.default_rng(23)
+    to_int = lambda a: pm.from_mont(pm.from_limbs(a), P)
+    to_mont = lambda v: ob.f_to_mont(FR, np.array([[(v >> (64 * i)) & (2**64 - 1) for i in range(4)]], dtype=np.uint64))[0]
+    rnd = lambda n: ob.f_to_mont(FR, rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64))
+    v, n = 5, 32
+
+    def mle_partial(T, prefix, t, x):
+        k = len(prefix)
+        acc = 0
+        for b in range(1 << (k + 1)):
+            w = t if (b >> k) & 1 else (1 - t)
+            for i in range(k):
+                w = w * (prefix[i] if (b >> i) & 1 else (1 - prefix[i])) % P
+            acc += w * T[b + (x << (k + 1))]
+        return acc % P
+
+    def round_from_definition(tables, F, prefix):
+        k = len(prefix)
+        return [sum(F([mle_partial(T, prefix, t, x) for T in tables]) for x in range(1 << (v - k - 1))) % P for t in range(4)]
+
+    def prod(vals):
+        out = 1
+        for x in vals:
+            out = out * x % P
+        return out
+
+    def drive(tables, F, make, round_evals, bind):
+        ints = [[to_int(x) for x in t] for t in tables]
+        claim = sum(F([T[j] for T in ints]) for j in range(n)) % P
+        p = make(to_mont(claim))
+        prefix = []
+        for k in range(v):
+            ev = [to_int(x) for x in round_evals(p)]
+            assert ev == round_from_definition(ints, F, prefix), k
+            ch = rnd(1)[0]
+            bind(p, ch, ev)
+            prefix.append(to_int(ch))
+        return p, ints, prefix
+
+    for three in (True, False):
+        tabs = [rnd(n) for _ in range(3 if three else 2)]
+        drive(tabs, prod, lambda c: ob.ValEvaluationProver(tabs[0], tabs[1], tabs[2] if three else None, c),
+              lambda p: p.computeRoundPolynomial(), lambda p, ch, ev: p.bindChallengeWithPoly(ch, np.stack([to_mont(e) for e in ev])))
+    tabs = [rnd(n) for _ in range(5)]
+    drive(tabs, lambda a: a[0] * a[1] * (a[2] - a[3]) % P, lambda c: ob.OutputSumcheckProver(*tabs, c), lambda p: p.roundEvals(),
+          lambda p, ch, ev: (p.bindChallenge(ch), p.updateClaim(np.stack([to_mont(e) for e in ev]), ch)))
+    tabs = [rnd(n) for _ in range(4)]
+    gamma = rnd(1)[0]
+    g = to_int(gamma)
+
+    def il_bind(p, ch, ev):
+        p.bindChallenge(ch)
+        p.updateClaim(np.stack([to_mont(e) for e in ev]), ch)
+    drive(tabs, lambda a: a[0] * (a[1] + g * a[2] + g * g * a[3]) % P, lambda c: ob.InstructionLookupsClaimReduction(*tabs, gamma, c),
+          lambda p: p.computeRoundPolynomialCubic(), il_bind)
+    left, right, tau, kernel = rnd(n), rnd(n), rnd(v), rnd(1)[0]
+    eq = ob.fr_eq_table(tau, kernel)  # index MSB <-> tau[0]: binding index bit 0 first binds tau[v-1] first
+
+    def pr_bind(p, ch, ev):
+        p.bindChallenge(ch)
+        p.updateClaim(np.stack([to_mont(e) for e in ev]), ch)
+    p, ints, prefix = drive([left, right, eq], prod, lambda c: ob.ProductRemainderProver(left, right, tau, kernel, c), lambda p: p.roundEvals(), pr_bind)
+    # and the end of the protocol: the claim is the product of the three multilinear extensions at (r_0, ..., r_(v-1))
+    full = [sum(prod([(prefix[i] if (idx >> i) & 1 else (1 - prefix[i])) for i in range(v)]) * T[idx] for idx in range(n)) % P for T in ints]
+    assert prod(full) == to_int(p.current_claim)
+    # the Lasso cycle phase folds the OTHER way (bindFirst order, prover.zig:411-441): variable k is index bit (v - 1 - k)
+    lv = 4
+    idx = np.zeros((1 << lv, 2), dtype=np.uint64)
+    idx[:, 0] = rng.integers(0, 4, size=1 << lv, dtype=np.uint64)
+    rr = rnd(lv)
+    lp = ob.LassoProver(idx, lv, 2, rr)
+    for k in range(2):
+        lp.computeRoundPolynomial()
+        lp.receiveChallenge(rnd(1)[0])
+    table = [to_int(x) for x in lp.eq_evals[:1 << lv]]
+    pre = []
+    for k in range(lv):
+        co = [to_int(x) for x in lp.computeRoundPolynomial()]
+        half = 1 << (lv - k - 1)
+
+        def at(t, x):  # eq_evals~ at (pre_0, ..., pre_(k-1), t, bits of x): variable m is index bit (lv - 1 - m), i.e. bit (k - m) of b
+            acc = 0
+            for b in range(1 << (k + 1)):
+                w = t if b & 1 else 1 - t
+                for m in range(k):
+                    w = w * (pre[m] if (b >> (k - m)) & 1 else (1 - pre[m])) % P
+                acc += w * table[(b << (lv - k - 1)) | x]
+            return acc % P
+        s0 = sum(at(0, x) for x in range(half)) % P
+        s1 = sum(at(1, x) for x in range(half)) % P
+        assert co[0] == s0 and (co[0] + co[1]) % P == s1, k
+        ch = rnd(1)[0]
+        lp.receiveChallenge(ch)
+        pre.append(to_int(ch))

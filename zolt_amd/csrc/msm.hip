@@ -112,9 +112,10 @@ struct zg_bases_s {
     zg::MsmPlan batch_plan;
     size_t batch_n = 0;
     uint32_t batch_nblk = 0;
-    // long vectors are not fused: they rotate over the caller's stream and two forked helper streams instead
-    hipStream_t aux[2] = {nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    // long vectors are not fused: they rotate over the caller's stream and three forked helper streams instead
+    static constexpr int NAUX = 3;  // four streams with the caller's: fewer can land two of them on one of HIP's four hardware queues
+    hipStream_t aux[NAUX] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[NAUX] = {nullptr, nullptr, nullptr};
     // Wide-window handles (2^15 buckets) also keep a narrow-window table of their first SIDE_TABLE_POINTS bases: MSMs over a
     // short prefix (HyperKZG.commit of a short polynomial on a long SRS, HyperKZG.open's last levels) then sort into 2^7
     // buckets instead of 2^15, and batches of them can be fused into one launch set. Same results, by construction.
@@ -1516,7 +1517,7 @@ static void free_bases(zg_bases_s *b) {
         if (p) (void)hipFree(p);
     for (auto &ln : b->lanes) lane_free(ln);
     lane_free(b->batch_lane);
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < zg_bases_s::NAUX; i++) {
         if (b->aux[i]) (void)hipStreamDestroy(b->aux[i]);
         if (b->ev_join[i]) (void)hipEventDestroy(b->ev_join[i]);
     }
@@ -1562,6 +1563,9 @@ static int bases_create(const uint64_t *d_xy, const uint8_t *d_inf_in, size_t n,
     int nlanes = env_int("ZG_MSM_LANES", 6);  // 2^17-point MSMs: 0.36 ms per MSM with 3 in flight, 0.25 with 6 (tools/bench_tail.py)
     if (nlanes < 1) nlanes = 1;
     if (nlanes > 8) nlanes = 8;
+    // a one-shot handle (MSM.compute on a temporary slice) serves one MSM: one workspace — a workspace is ~18 allocations, and the
+    // upload + free of such a handle is most of what its caller pays (tools/crossover.py: one_shot_msm)
+    if (cfg && cfg->expected_uses > 0 && cfg->expected_uses < 16 && !getenv("ZG_MSM_LANES")) nlanes = 1;
     bool lds_sort = (size_t)p.NK * 4 <= 128 * 1024 && env_int("ZG_MSM_LDS_SORT", 1);
     plan_two_pass(b->plan, (size_t)p.L * n, n);
     if (p.fb) {
@@ -1939,19 +1943,19 @@ static int msm_host_sliced(zg_bases_s *b, size_t off, size_t n, const uint64_t *
     hipStream_t st = lib_stream();
     ZG_TRY(ensure_aux_streams(b));
     if (!b->d_slice_parts) ZG_HIP(hipMalloc((void **)&b->d_slice_parts, HOST_SLICES_MAX * 12 * 8));
-    hipStream_t ss[3] = {st, b->aux[0], b->aux[1]};
+    hipStream_t ss[zg_bases_s::NAUX + 1] = {st, b->aux[0], b->aux[1], b->aux[2]};
     ZG_HIP(hipEventRecord(b->ev_fork, st));
-    for (int i = 0; i < 2; i++) ZG_HIP(hipStreamWaitEvent(b->aux[i], b->ev_fork, 0));
+    for (int i = 0; i < zg_bases_s::NAUX; i++) ZG_HIP(hipStreamWaitEvent(b->aux[i], b->ev_fork, 0));
     const size_t per = (n + (size_t)slices - 1) / (size_t)slices;
     int rc = ZG_OK;
     hipError_t e = hipSuccess;
     for (int i = 0; i < slices && rc == ZG_OK && e == hipSuccess; i++) {
         size_t a = (size_t)i * per, cnt = a >= n ? 0 : (n - a < per ? n - a : per);
-        hipStream_t si = ss[i % 3];
+        hipStream_t si = ss[i % (zg_bases_s::NAUX + 1)];
         if (cnt) e = hipMemcpyAsync(b->d_scal + 4 * a, scalars + 4 * a, cnt * 32, hipMemcpyHostToDevice, si);
         if (e == hipSuccess) rc = msm_enqueue(b, off + a, cnt, b->d_scal + 4 * a, si, 2, b->d_slice_parts + 12 * (size_t)i, nullptr);
     }
-    for (int i = 0; i < 2; i++) {  // join even after an error so the helpers never run ahead of the caller's next work
+    for (int i = 0; i < zg_bases_s::NAUX; i++) {  // join even after an error so the helpers never run ahead of the caller's next work
         hipError_t e1 = hipEventRecord(b->ev_join[i], b->aux[i]);
         if (e1 == hipSuccess) e1 = hipStreamWaitEvent(st, b->ev_join[i], 0);
         if (e == hipSuccess) e = e1;
@@ -2055,7 +2059,7 @@ static size_t batch_fuse_limit(const zg_bases_s *b, size_t n, bool wide_ok = fal
 static int ensure_aux_streams(zg_bases_s *b) {
     if (b->aux[0]) return ZG_OK;
     hipError_t e = hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming);
-    for (int i = 0; i < 2 && e == hipSuccess; i++) {
+    for (int i = 0; i < zg_bases_s::NAUX && e == hipSuccess; i++) {
         e = hipStreamCreateWithFlags(&b->aux[i], hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_join[i], hipEventDisableTiming);
     }
@@ -2085,15 +2089,15 @@ static int msm_batch_enqueue(zg_bases_s *b, size_t n, const uint64_t *d_scalars,
         if (fork) ZG_TRY(ensure_aux_streams(b));
         if (fork) {
             ZG_HIP(hipEventRecord(b->ev_fork, st));
-            for (int i = 0; i < 2; i++) ZG_HIP(hipStreamWaitEvent(b->aux[i], b->ev_fork, 0));
+            for (int i = 0; i < zg_bases_s::NAUX; i++) ZG_HIP(hipStreamWaitEvent(b->aux[i], b->ev_fork, 0));
         }
         int rc = ZG_OK;
         for (size_t i = 0; i < k && rc == ZG_OK; i++) {
-            hipStream_t si = !fork || i % 3 == 0 ? st : b->aux[i % 3 - 1];
+            hipStream_t si = !fork || i % (zg_bases_s::NAUX + 1) == 0 ? st : b->aux[i % (zg_bases_s::NAUX + 1) - 1];
             rc = msm_enqueue(b, 0, n, d_scalars + 4 * n * i, si, mode, d_out9 + RS * i, inf_of(i));
         }
         if (fork) {  // join even after an error so the helpers never run ahead of the caller's next work
-            for (int i = 0; i < 2; i++) {
+            for (int i = 0; i < zg_bases_s::NAUX; i++) {
                 ZG_HIP(hipEventRecord(b->ev_join[i], b->aux[i]));
                 ZG_HIP(hipStreamWaitEvent(st, b->ev_join[i], 0));
             }
@@ -2210,15 +2214,15 @@ int zg_msm_g1_batch(zg_bases_t b, size_t n, const uint64_t *const *batches, size
         // 32n-byte copy of the next vector runs under the MSM of the previous one instead of all k copies preceding all k MSMs
         rc = ensure_aux_streams(b);
         if (rc == ZG_OK) {
-            hipStream_t ss[3] = {st, b->aux[0], b->aux[1]};
+            hipStream_t ss[zg_bases_s::NAUX + 1] = {st, b->aux[0], b->aux[1], b->aux[2]};
             hipError_t e = hipEventRecord(b->ev_fork, st);
-            for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipStreamWaitEvent(b->aux[i], b->ev_fork, 0);
+            for (int i = 0; i < zg_bases_s::NAUX && e == hipSuccess; i++) e = hipStreamWaitEvent(b->aux[i], b->ev_fork, 0);
             for (size_t i = 0; i < k && rc == ZG_OK && e == hipSuccess; i++) {
-                hipStream_t si = ss[i % 3];
+                hipStream_t si = ss[i % (zg_bases_s::NAUX + 1)];
                 e = hipMemcpyAsync(d_sc + 4 * n * i, batches[i], n * 32, hipMemcpyHostToDevice, si);
                 if (e == hipSuccess) rc = msm_enqueue(b, 0, n, d_sc + 4 * n * i, si, 0, d_res + 9 * i, reinterpret_cast<uint8_t *>(d_res + 9 * i + 8));
             }
-            for (int i = 0; i < 2; i++) {  // join even after an error
+            for (int i = 0; i < zg_bases_s::NAUX; i++) {  // join even after an error
                 hipError_t e1 = hipEventRecord(b->ev_join[i], b->aux[i]);
                 if (e1 == hipSuccess) e1 = hipStreamWaitEvent(st, b->ev_join[i], 0);
                 if (e == hipSuccess) e = e1;

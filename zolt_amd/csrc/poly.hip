@@ -1224,15 +1224,20 @@ static int hk_open_device(zg_bases_t srs, uint64_t *d_a, uint64_t *d_b, uint64_t
     // issued on one of three helper streams in turn (forked / joined by events), never on the caller's stream, so the
     // latency-bound tail of one commit runs under the accumulation of the next.
     constexpr int NAUX = 3;
-    static hipStream_t aux_all[ZG_MAX_DEVICES][NAUX] = {};  // helper streams belong to a device (created on its first open, kept)
-    static PerDeviceOnce aux_once;
-    const int aux_dev = current_device();
-    (void)aux_once.run([aux_dev] {
-        for (int i = 0; i < NAUX; i++)
-            if (hipStreamCreateWithFlags(&aux_all[aux_dev][i], hipStreamNonBlocking) != hipSuccess) aux_all[aux_dev][i] = nullptr;
-        return hipSuccess;
-    });
-    hipStream_t *aux = aux_all[aux_dev];
+    // the helper streams belong to THIS call: taken from the runtime's per-device free list (creating a stream costs ~3 ms) and handed
+    // back on return, so concurrent opens from different caller threads do not serialise through a shared set (round-2 review)
+    struct AuxStreams {
+        hipStream_t s[NAUX];
+        int dev;
+        AuxStreams() : dev(current_device()) {
+            for (int i = 0; i < NAUX; i++) s[i] = stream_acquire();
+        }
+        ~AuxStreams() {
+            for (int i = 0; i < NAUX; i++)
+                if (s[i]) stream_release(s[i], dev);
+        }
+    } aux_streams;
+    hipStream_t *aux = aux_streams.s;
     const bool fork = aux[0] && aux[1] && aux[2];
     const bool fuse_long = fork && fuse_long_env && long_rows >= 2;
     const bool split_first = fuse_long && fuse_long_env == 2 && long_rows >= 3;
