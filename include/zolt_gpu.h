@@ -367,6 +367,38 @@ ZG_API int zg_psc_gather(zg_psc_t s, size_t table, const uint64_t *idx, size_t n
 ZG_API int zg_psc_final(zg_psc_t s, uint64_t *out /* k*4: each table's single remaining entry */);
 ZG_API int zg_psc_close(zg_psc_t s);
 
+/* ------------------------------------------------------------------ registers read/write checking (Stage 4) */
+/* Stage4GruenProver (src/zkvm/spartan/stage4_gruen_prover.zig:65-1240), the RegistersReadWriteChecking sumcheck: five DENSE tables of
+ * K = 128 registers x T = 2^log_t cycles — val, rd_wa, ra = gamma rs1_ra + gamma^2 rs2_ra, rs1_ra, rs2_ra, indexed [k * T + j] — plus
+ * inc[T], LOG_K + log_t rounds in three phases (cycle variables in Gruen form, the seven register variables, the remaining cycle
+ * variables under the merged dense eq table). The session builds the tables on the device from the per-cycle trace columns and keeps
+ * them in HBM; every round is one pass (sums) + one pass (folds). The eq structure, Gruen's cubic, the claim and the transcript stay on
+ * the host. Values are the reference's, exactly.
+ *   rs1 / rs2 / rd [T]: the register a cycle reads / writes, 0xFF = none — decided as initWithPhaseConfig does (:199-246: by opcode; rd
+ *                        only when it is used and non-zero); padding cycles are 0xFF;
+ *   reg_vals [32 * T] : value of register k before cycle j at [k * T + j] (:186-192, 249-258);  inc [T * 4]: F.fromU64(post) - F.fromU64(pre)
+ *                        of the written register, zero elsewhere (:240-243);  gamma: the batching challenge. */
+typedef struct zg_rrw_s *zg_rrw_t;
+ZG_API int zg_rrw_open(size_t log_t, const uint8_t *rs1, const uint8_t *rs2, const uint8_t *rd, const uint64_t *reg_vals, const uint64_t *inc,
+                const uint64_t gamma[4], zg_rrw_t *s);
+ZG_API size_t zg_rrw_cycles(zg_rrw_t s);    /* current_T */
+ZG_API size_t zg_rrw_registers(zg_rrw_t s); /* current_K */
+/* phase1ComputeMessage's pair (:561-741): q0 = sum_i E_out[i >> log2|E_in|] E_in[i & (|E_in| - 1)] sum_k C_0(k, i), qX2 likewise with the
+ * slopes; C = ra val + wa (val + inc) over the cycle pair (2i, 2i + 1). d_e_out / d_e_in: DEVICE tables (zg_fr_eq_prefix_tables_dev). */
+ZG_API int zg_rrw_round_cycle_gruen(zg_rrw_t s, const uint64_t *d_e_out, size_t n_out, const uint64_t *d_e_in, size_t n_in, uint64_t q0[4], uint64_t qx2[4]);
+/* the merged eq table of gruen_eq.merge (gruen_eq.zig:119-146) after the last phase-1 bind: n = zg_rrw_cycles(s) entries (host) */
+ZG_API int zg_rrw_set_eq(zg_rrw_t s, const uint64_t *eq, size_t n);
+/* phase2ComputeMessage's (eval_0, eval_2) (:764-852; also the register rounds once a single cycle is left, :955-1013) */
+ZG_API int zg_rrw_round_address(zg_rrw_t s, uint64_t e0[4], uint64_t e2[4]);
+/* phase3ComputeMessage's (eval_0, eval_2, eval_3) (:854-953) */
+ZG_API int zg_rrw_round_cycle(zg_rrw_t s, uint64_t e0[4], uint64_t e2[4], uint64_t e3[4]);
+/* bindPolynomials (:1047-1163): fold the cycle variable (five tables, inc, and the merged eq table once it is set) / the register variable */
+ZG_API int zg_rrw_bind_cycle(zg_rrw_t s, const uint64_t r[4]);
+ZG_API int zg_rrw_bind_address(zg_rrw_t s, const uint64_t r[4]);
+/* entry [0][0] of val, rd_wa, ra, rs1_ra, rs2_ra, then inc[0] and merged_eq[0] (7 x 4 words): getFinalClaims (:1219-1236) */
+ZG_API int zg_rrw_final(zg_rrw_t s, uint64_t *out /* 28 */);
+ZG_API int zg_rrw_close(zg_rrw_t s);
+
 /* ------------------------------------------------------------------ several GPUs in one process */
 /* The bases (SRS) sharded over the bound devices in ParallelMSM's contiguous chunks of ceil(n / S) points
  * (src/msm/mod.zig:609,619-639), one resident table per device. */

@@ -1175,3 +1175,207 @@ class RamReadWriteCheckingProver:
             ra = (ra + w * e[2]) % P
             val = (val + w * (e[3] - fr_to_int(self.val_init[e[1]]))) % P
         return fr_from_int(ra), fr_from_int(val), self.inc[0].copy()
+
+
+# ---- Stage4GruenProver — RegistersReadWriteChecking (src/zkvm/spartan/stage4_gruen_prover.zig:65-1240, with src/zkvm/spartan/gruen_eq.zig:
+# the same prefix-table split-eq structure as src/poly/split_eq.zig; E_in_current / E_out_current = getWindowEqTables(1), gruenPolyDeg3's
+# four evaluations = computeCubicRoundPoly). Dense K x T tables (K = 128 registers), restated with the C oracle's vector field ops.
+def _fmul(a, b):
+    sh = np.broadcast(a[..., 0], b[..., 0]).shape
+    a2 = np.ascontiguousarray(np.broadcast_to(a, sh + (4,))).reshape(-1, 4)
+    b2 = np.ascontiguousarray(np.broadcast_to(b, sh + (4,))).reshape(-1, 4)
+    return f_mul(FR, a2, b2).reshape(sh + (4,))
+
+
+def _fadd(a, b):
+    sh = np.broadcast(a[..., 0], b[..., 0]).shape
+    a2 = np.ascontiguousarray(np.broadcast_to(a, sh + (4,))).reshape(-1, 4)
+    b2 = np.ascontiguousarray(np.broadcast_to(b, sh + (4,))).reshape(-1, 4)
+    return f_add(FR, a2, b2).reshape(sh + (4,))
+
+
+def _fsub(a, b):
+    sh = np.broadcast(a[..., 0], b[..., 0]).shape
+    a2 = np.ascontiguousarray(np.broadcast_to(a, sh + (4,))).reshape(-1, 4)
+    b2 = np.ascontiguousarray(np.broadcast_to(b, sh + (4,))).reshape(-1, 4)
+    return f_sub(FR, a2, b2).reshape(sh + (4,))
+
+
+def _fsum(a):
+    """sum of all elements of an (..., 4) array -> (4,)"""
+    v = np.ascontiguousarray(a).reshape(-1, 4)
+    if v.shape[0] == 0:
+        return np.zeros(4, dtype=np.uint64)
+    while v.shape[0] > 1:
+        if v.shape[0] % 2:
+            v = np.concatenate([v, np.zeros((1, 4), dtype=np.uint64)])
+        v = f_add(FR, np.ascontiguousarray(v[0::2]), np.ascontiguousarray(v[1::2]))
+    return v[0]
+
+
+def _fsum_axis0(a):
+    """(K, n, 4) -> (n, 4): sum over the first axis"""
+    v = np.ascontiguousarray(a)
+    while v.shape[0] > 1:
+        if v.shape[0] % 2:
+            v = np.concatenate([v, np.zeros((1,) + v.shape[1:], dtype=np.uint64)])
+        v = _fadd(v[0::2], v[1::2])
+    return v[0]
+
+
+class Stage4GruenProver:
+    """steps: [(instruction u32, rd_value u64, is_noop)] (ExecutionTrace.steps); r_cycle in ROUND order (r_cycle[0] bound first, :283-288).
+    Tables are (K, T, 4) Montgomery arrays with the reference's [k * T + j] indexing; the live region is [:current_K, :current_T]."""
+    LOG_K, K = 7, 128
+
+    def __init__(self, steps, gamma, r_cycle, phase1_num_rounds, phase2_num_rounds):
+        n = len(steps)
+        T = 1
+        while T < n:
+            T *= 2
+        self.T, self.log_T = T, T.bit_length() - 1
+        r_cycle = _c(np.asarray(r_cycle, dtype=np.uint64).reshape(-1, 4))
+        assert r_cycle.shape[0] == self.log_T
+        self.num_rounds = self.LOG_K + self.log_T
+        self.gamma = _c(gamma).copy()
+        self.gamma_sq = f_mul(FR, self.gamma.reshape(1, 4), self.gamma.reshape(1, 4))[0]
+        K = self.K
+        one = f_from_u64(FR, np.array([1], dtype=np.uint64))[0]
+        val_u = np.zeros((K, T), dtype=np.uint64)
+        wa = np.zeros((K, T, 4), dtype=np.uint64)
+        ra = np.zeros((K, T, 4), dtype=np.uint64)
+        r1 = np.zeros((K, T, 4), dtype=np.uint64)
+        r2 = np.zeros((K, T, 4), dtype=np.uint64)
+        inc_pre, inc_post, inc_set = np.zeros(T, dtype=np.uint64), np.zeros(T, dtype=np.uint64), np.zeros(T, dtype=bool)
+        regs = [0] * 32
+        for cycle, (instr, rd_value, is_noop) in enumerate(steps):  # :183-246
+            val_u[:32, cycle] = regs
+            if is_noop:
+                continue
+            rd, rs1, rs2, opcode = (instr >> 7) & 31, (instr >> 15) & 31, (instr >> 20) & 31, instr & 0x7F
+            if opcode in (0x13, 0x03, 0x67, 0x1B, 0x33, 0x3B, 0x23, 0x63):
+                r1[rs1, cycle] = one
+                ra[rs1, cycle] = f_add(FR, ra[rs1, cycle].reshape(1, 4), self.gamma.reshape(1, 4))[0]
+            if opcode in (0x33, 0x3B, 0x23, 0x63):
+                r2[rs2, cycle] = one
+                ra[rs2, cycle] = f_add(FR, ra[rs2, cycle].reshape(1, 4), self.gamma_sq.reshape(1, 4))[0]
+            if opcode not in (0x23, 0x63) and rd != 0:
+                wa[rd, cycle] = one
+                inc_pre[cycle], inc_post[cycle], inc_set[cycle] = regs[rd], rd_value, True
+                regs[rd] = rd_value
+        for cycle in range(n, T):  # :249-258 padding cycles keep the final register file
+            val_u[:32, cycle] = regs
+        self.val = f_from_u64(FR, val_u.reshape(-1)).reshape(K, T, 4)
+        self.inc = f_sub(FR, f_from_u64(FR, inc_post), f_from_u64(FR, inc_pre))  # F.fromU64(post) - F.fromU64(pre), zero where unset
+        self.wa, self.ra, self.rs1_ra, self.rs2_ra = wa, ra, r1, r2
+        self.gruen = GruenSplitEq(r_cycle[::-1].copy())  # big-endian for the split-eq structure (:283-288)
+        self.current_T, self.current_K = T, K
+        self.phase1_num_rounds, self.phase2_num_rounds = phase1_num_rounds, phase2_num_rounds
+        self.merged_eq = None
+
+    def computeInputClaim(self):  # :385-431 without Stage-3 claims: sum over (k, j) of eq(r_cycle, j) * combined
+        eq = self.gruen.getFullEqTable()
+        comb = _fadd(_fmul(self.ra, self.val), _fmul(self.wa, _fadd(self.val, self.inc[None, :, :])))
+        return _fsum(_fmul(_fsum_axis0(comb), eq))
+
+    def _live(self):
+        K, T = self.current_K, self.current_T
+        return self.ra[:K, :T], self.wa[:K, :T], self.val[:K, :T], self.inc[:T]
+
+    def computeRoundEvals(self, rnd, current_claim):  # :1165-1190 -> (4, 4): p(0..3)
+        p1, p2 = self.phase1_num_rounds, self.phase2_num_rounds
+        claim = _c(current_claim)
+        ra, wa, val, inc = self._live()
+        two = f_from_u64(FR, np.array([2], dtype=np.uint64))[0]
+        three = f_from_u64(FR, np.array([3], dtype=np.uint64))[0]
+        if rnd < p1:  # phase1ComputeMessage :561-741
+            e_out, e_in, head_in_bits = self.gruen.getWindowEqTables(1)
+            half = self.current_T // 2
+            i = np.arange(half)
+            x_in, x_out = i & ((1 << head_in_bits) - 1), i >> head_in_bits
+            one = f_from_u64(FR, np.array([1], dtype=np.uint64))
+            eo = np.where((x_out < len(e_out))[:, None], _c(e_out)[np.minimum(x_out, len(e_out) - 1)], one)
+            ei = np.where((x_in < len(e_in))[:, None], _c(e_in)[np.minimum(x_in, len(e_in) - 1)], one)
+            E = _fmul(eo, ei)
+            inc0, incs = inc[0::2], _fsub(inc[1::2], inc[0::2])
+            rae, was, vae = ra[:, 0::2], wa[:, 0::2], val[:, 0::2]
+            ras, wss, vas = _fsub(ra[:, 1::2], rae), _fsub(wa[:, 1::2], was), _fsub(val[:, 1::2], vae)
+            c0 = _fadd(_fmul(rae, vae), _fmul(was, _fadd(vae, inc0[None])))
+            cx = _fadd(_fmul(ras, vas), _fmul(wss, _fadd(vas, incs[None])))
+            q0 = _fsum(_fmul(_fsum_axis0(c0), E))
+            qx = _fsum(_fmul(_fsum_axis0(cx), E))
+            self.last_q = (q0, qx)
+            return self.gruen.computeCubicRoundPoly(q0, qx, claim)
+        if rnd < p1 + p2 or self.current_T == 1:  # phase2ComputeMessage :764-852; phase 3 with no cycle left :955-1013
+            eq = self.merged_eq[:self.current_T]
+            rae, rao = ra[0::2], ra[1::2]
+            wae, wao = wa[0::2], wa[1::2]
+            vae, vao = val[0::2], val[1::2]
+            c0 = _fadd(_fmul(rae, vae), _fmul(wae, _fadd(vae, inc[None])))
+            ra2 = _fadd(rae, _fmul(two, _fsub(rao, rae)))
+            wa2 = _fadd(wae, _fmul(two, _fsub(wao, wae)))
+            va2 = _fadd(vae, _fmul(two, _fsub(vao, vae)))
+            c2 = _fadd(_fmul(ra2, va2), _fmul(wa2, _fadd(va2, inc[None])))
+            e0 = _fsum(_fmul(_fsum_axis0(c0), eq))
+            e2 = _fsum(_fmul(_fsum_axis0(c2), eq))
+            e1 = f_sub(FR, claim.reshape(1, 4), e0.reshape(1, 4))[0]
+            # quadratic through (0, e0), (1, e1), (2, e2): p(3) = e0 - 3 e1 + 3 e2 (c3 = 0, :841-850)
+            e3 = _fadd(_fsub(e0, _fmul(three, e1)), _fmul(three, e2))
+            return np.stack([e0, e1, e2, e3])
+        # phase3ComputeMessage with cycles remaining :854-953
+        eq = self.merged_eq[:self.current_T]
+        eqe, eqs = eq[0::2], _fsub(eq[1::2], eq[0::2])
+        ince, incs = inc[0::2], _fsub(inc[1::2], inc[0::2])
+        rae, was, vae = ra[:, 0::2], wa[:, 0::2], val[:, 0::2]
+        ras, wss, vas = _fsub(ra[:, 1::2], rae), _fsub(wa[:, 1::2], was), _fsub(val[:, 1::2], vae)
+        out = []
+        for t, tf in ((0, None), (2, two), (3, three)):
+            if tf is None:
+                r_, w_, v_, i_, q_ = rae, was, vae, ince, eqe
+            else:
+                r_, w_, v_ = _fadd(rae, _fmul(tf, ras)), _fadd(was, _fmul(tf, wss)), _fadd(vae, _fmul(tf, vas))
+                i_, q_ = _fadd(ince, _fmul(tf, incs)), _fadd(eqe, _fmul(tf, eqs))
+            inner = _fsum_axis0(_fadd(_fmul(r_, v_), _fmul(w_, _fadd(v_, i_[None]))))
+            out.append(_fsum(_fmul(q_, inner)))
+        e0, e2, e3 = out
+        e1 = f_sub(FR, claim.reshape(1, 4), e0.reshape(1, 4))[0]
+        return np.stack([e0, e1, e2, e3])
+
+    def bindChallenge(self, rnd, challenge):  # bindPolynomials :1047-1163
+        ch = _c(challenge).reshape(1, 4)
+        p1, p2 = self.phase1_num_rounds, self.phase2_num_rounds
+        K, T = self.current_K, self.current_T
+
+        def fold_cycle(t):
+            lo, hi = t[:K, 0:T:2], t[:K, 1:T:2]
+            t[:K, :T // 2] = _fadd(lo, _fmul(ch, _fsub(hi, lo)))  # lo (1 - c) + hi c
+
+        def fold_vec(v):
+            lo, hi = v[0:T:2], v[1:T:2]
+            v[:T // 2] = _fadd(lo, _fmul(ch, _fsub(hi, lo)))
+        if rnd < p1 or rnd >= p1 + p2:
+            for t in (self.val, self.wa, self.ra, self.rs1_ra, self.rs2_ra):
+                fold_cycle(t)
+            fold_vec(self.inc)
+            if rnd >= p1 + p2 and self.merged_eq is not None:
+                fold_vec(self.merged_eq)
+            self.current_T = T // 2
+            if rnd < p1:
+                self.gruen.bind(ch[0])
+                if rnd == p1 - 1:  # gruen_eq.merge (:119-146)
+                    self.merged_eq = self.gruen.getFullEqTable().copy()
+        else:
+            for t in (self.val, self.wa, self.ra, self.rs1_ra, self.rs2_ra):
+                lo, hi = t[0:K:2, :T], t[1:K:2, :T]
+                t[:K // 2, :T] = _fadd(lo, _fmul(ch, _fsub(hi, lo)))
+            self.current_K = K // 2
+
+    def getFinalClaims(self):  # :1219-1236
+        return {"val_claim": self.val[0, 0].copy(), "rs1_ra_claim": self.rs1_ra[0, 0].copy(), "rs2_ra_claim": self.rs2_ra[0, 0].copy(),
+                "rd_wa_claim": self.wa[0, 0].copy(), "inc_claim": self.inc[0].copy()}
+
+    def finalCheck(self):
+        """(eq_scalar, combined, expected) as bindChallenge prints them after the last round (:1196-1210)"""
+        eq = self.merged_eq[0]
+        comb = _fadd(_fmul(self.ra[0, 0], self.val[0, 0]), _fmul(self.wa[0, 0], _fadd(self.val[0, 0], self.inc[0])))
+        return eq, comb, _fmul(eq, comb)

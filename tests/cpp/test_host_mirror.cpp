@@ -567,8 +567,51 @@ static int rwc_main(const char *path) {
     return 0;
 }
 
+// `test_host_mirror stage4 <file>`: zolt::Stage4GruenProver on the instance the file describes (written by tests/test_gpu_cpp_host.py):
+// log_t, phase-1 rounds, gamma, the claim, r_cycle, the steps, the challenges -> every round's four evaluations and the final values.
+static int stage4_main(const char *path) {
+    std::FILE *f = std::fopen(path, "r");
+    if (!f) { std::printf("cannot open %s\n", path); return 2; }
+    unsigned long long log_t, p1, n;
+    if (std::fscanf(f, "%llu %llu", &log_t, &p1) != 2) return 2;
+    Fr gamma = read_fr(f), claim = read_fr(f);
+    std::vector<Fr> r_cycle;
+    for (size_t i = 0; i < log_t; i++) r_cycle.push_back(read_fr(f));
+    if (std::fscanf(f, "%llu", &n) != 1) return 2;
+    std::vector<TraceStep> steps;
+    for (size_t i = 0; i < n; i++) {
+        unsigned long long w, v, z;
+        if (std::fscanf(f, "%llu %llu %llu", &w, &v, &z) != 3) return 2;
+        steps.push_back(TraceStep{(uint32_t)w, v, z != 0});
+    }
+    std::vector<Fr> ch;
+    for (size_t i = 0; i < 7 + log_t; i++) ch.push_back(read_fr(f));
+    std::fclose(f);
+    Stage4GruenProver p(steps, gamma, r_cycle, p1, 7);
+    for (size_t rd = 0; rd < p.num_rounds; rd++) {
+        auto ev = p.computeRoundEvals(rd, claim);
+        std::printf("E");
+        for (const Fr &x : ev) print_fr(x);
+        std::printf("\n");
+        claim = cubicAtPoint(ev, ch[rd]);
+        p.bindChallenge(rd, ch[rd]);
+    }
+    auto fc = p.getFinalClaims();
+    auto chk = p.finalCheck();
+    std::printf("O");
+    for (const Fr &x : {fc.val_claim, fc.rs1_ra_claim, fc.rs2_ra_claim, fc.rd_wa_claim, fc.inc_claim, chk[0], chk[1], chk[2], claim}) print_fr(x);
+    std::printf("\n");
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (zg_init(0) != ZG_OK) { std::printf("zg_init failed: %s\n", zg_last_error()); return 2; }
+    if (argc >= 3 && !std::strcmp(argv[1], "stage4")) {
+        int rc;
+        try { rc = stage4_main(argv[2]); } catch (const std::exception &e) { std::printf("EXCEPTION: %s\n", e.what()); rc = 3; }
+        zg_shutdown();
+        return rc;
+    }
     if (argc >= 3 && !std::strcmp(argv[1], "rwc")) {
         int rc;
         try { rc = rwc_main(argv[2]); } catch (const std::exception &e) { std::printf("EXCEPTION: %s\n", e.what()); rc = 3; }

@@ -96,3 +96,52 @@ def test_cpp_ram_read_write_checking_mirror(tmp_path, golden_dir):
         if k == 0:  # the captured run: the reference's own final claim and opening claims, full width
             assert o.current_claim == int.from_bytes(bytes.fromhex(stage2["instance_final_claims"][2]), "little")
             assert ob.fr_to_int(opening[0]) == int(rwc["opening"]["ra_claim_be"], 16) and ob.fr_to_int(opening[1]) == int(rwc["opening"]["val_claim_be"], 16)
+
+
+@pytest.mark.gpu
+def test_cpp_stage4_registers_mirror(tmp_path, golden_dir):
+    """zolt::Stage4GruenProver (compiled host code over zg_rrw_*) against the restatement of src/zkvm/spartan/stage4_gruen_prover.zig:
+    the reference's captured run (its printed round-0 evaluations and final values, full width) and seeded traces, every round's four
+    evaluations and the final claims bit for bit."""
+    import json
+    import numpy as np
+    from oracle import binding as ob
+    from tests import util as U
+    from tests.test_gpu_stage4 import seeded_steps
+    from tests.test_transcript_host import stage4_inputs_of_the_captured_run
+    exe = os.path.join(ROOT, "tests", "cpp", "test_host_mirror")
+    subprocess.check_call(["make", "-C", os.path.dirname(exe), "test_host_mirror"])
+    fx, gr, steps, gamma, r_cycle = stage4_inputs_of_the_captured_run(golden_dir, ob.fr_from_int)
+    le = lambda h: int.from_bytes(bytes.fromhex(h), "little")
+    chal = np.stack([ob.fr_from_int(le(h)) for h in fx["challenges_le"][:15]])
+    cases = [(8, fx["phase1_num_rounds"], gamma, ob.fr_from_int(le(fx["round0"]["claim_le"])), r_cycle, steps, chal)]
+    for log_t, n_steps, p1 in ((3, 7, 2), (9, 400, 9), (11, 2048, 5)):
+        r = ob.f_to_mont(ob.FR, U.random_raw256(900 + log_t, 2 * log_t + 8))
+        cases.append((log_t, p1, r[0], None, r[1:1 + log_t], seeded_steps(40 + log_t, n_steps), r[1 + log_t:]))
+    for k, (log_t, p1, g, claim, rc, st, ch) in enumerate(cases):
+        o = ob.Stage4GruenProver(st, g, rc, p1, 7)
+        if claim is None:
+            claim = o.computeInputClaim()
+        path = str(tmp_path / f"stage4_{k}.txt")
+        with open(path, "w") as f:
+            f.write(f"{log_t} {p1}\n{_hexfr(g)}\n{_hexfr(claim)}\n" + "".join(_hexfr(x) + "\n" for x in rc))
+            f.write(f"{len(st)}\n" + "".join(f"{w} {v} {int(z)}\n" for w, v, z in st) + "".join(_hexfr(x) + "\n" for x in ch))
+        res = subprocess.run([exe, "stage4", path], capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+        lines = [l.split() for l in res.stdout.splitlines() if l[:1] in ("E", "O")]
+        rounds = [np.array([int(x, 16) for x in l[1:17]], dtype=np.uint64).reshape(4, 4) for l in lines if l[0] == "E"]
+        final = np.array([int(x, 16) for x in [l for l in lines if l[0] == "O"][0][1:37]], dtype=np.uint64).reshape(9, 4)
+        assert len(rounds) == 7 + log_t
+        for rd in range(7 + log_t):
+            we = o.computeRoundEvals(rd, claim)
+            assert np.array_equal(rounds[rd], we), (k, rd)
+            claim = ob.raf_update_claim(we, ch[rd])
+            o.bindChallenge(rd, ch[rd])
+        fc, chk = o.getFinalClaims(), o.finalCheck()
+        want = [fc["val_claim"], fc["rs1_ra_claim"], fc["rs2_ra_claim"], fc["rd_wa_claim"], fc["inc_claim"], chk[0], chk[1], chk[2], claim]
+        for i, w in enumerate(want):
+            assert np.array_equal(final[i], w), (k, i)
+        if k == 0:  # what the reference printed
+            assert [ob.fr_to_int(x) for x in rounds[0]] == [le(fx["round0"]["p%d_le" % t]) for t in range(4)]
+            assert ob.fr_to_int(final[8]) == le(fx["final"]["claim_le"]) == le(fx["final"]["expected_le"])
+            assert ob.fr_to_int(final[5]) == le(fx["final"]["eq_scalar_le"]) and ob.fr_to_int(final[6]) == le(fx["final"]["combined_le"])

@@ -528,3 +528,48 @@ def test_ram_read_write_checking_of_the_captured_run(golden_dir):
                                       ob.fr_from_int(0), initial_ram)
     assert ob.fr_to_int(p.inc[54]) == 1 and len(p.entries) == 1
     check_rwc_against_the_captured_run(_OracleRwc(p), rwc, stage2, challenges, ob.fr_to_int, last_q=lambda a: a.p.last_q)
+
+
+def check_stage4_against_the_captured_run(prover, fx, gr, fr_from_int, fr_to_int, claim_after=None):
+    """drives a Stage4GruenProver (oracle restatement or device mirror) through the 15 rounds of the captured run with the reference's
+    challenges and holds what the reference printed against it (tests/golden/stage4_registers_run.json)"""
+    le = lambda h: int.from_bytes(bytes.fromhex(h), "little")
+    claim = fr_from_int(le(fx["round0"]["claim_le"]))
+    for k in range(15):
+        ev = prover.computeRoundEvals(k, claim)
+        s = [fr_to_int(x) for x in ev]
+        assert (s[0] + s[1]) % ob._R_P == fr_to_int(claim), k
+        if k == 0:  # the registers instance's own round-0 evaluations, full width
+            assert s == [le(fx["round0"]["p%d_le" % t]) for t in range(4)]
+        ch = fr_from_int(le(fx["challenges_le"][k]))
+        claim = ob.raf_update_claim(ev, ch)  # the cubic through the four evaluations at the challenge
+        prover.bindChallenge(k, ch)
+    eq, comb, exp = prover.finalCheck()
+    f = fx["final"]
+    assert fr_to_int(eq) == le(f["eq_scalar_le"]) and fr_to_int(comb) == le(f["combined_le"]) and fr_to_int(exp) == le(f["expected_le"])
+    assert fr_to_int(claim) == le(f["claim_le"]) == le(f["expected_le"])  # the sumcheck's last claim IS eq * combined
+
+
+def stage4_inputs_of_the_captured_run(golden_dir, fr_from_int):
+    import json
+    import os
+    fx = json.load(open(os.path.join(golden_dir, "stage4_registers_run.json")))
+    gr = json.load(open(os.path.join(golden_dir, "stage4_gruen_eq.json")))
+    elf = open(os.path.join(golden_dir, "fibonacci.elf"), "rb").read()
+    steps = U.fibonacci_trace_steps(elf, 54, fx["T"])
+    gamma = fr_from_int(int(fx["gamma_be"], 16))
+    r_cycle_be = np.array(gr["r_cycle_be_mont_limbs"], dtype=np.uint64)  # raw Montgomery limbs [0, 0, lo, hi]
+    return fx, gr, steps, gamma, r_cycle_be[::-1].copy()  # round order: the prover reverses it again (:283-288)
+
+
+def test_stage4_registers_read_write_checking_of_the_captured_run(golden_dir):
+    """Stage4GruenProver (src/zkvm/spartan/stage4_gruen_prover.zig) END TO END on the reference's own run: K = 128 x T = 256 dense
+    tables built from the fibonacci trace (regenerated from the ELF), gamma and the eight r_cycle challenges as logged, phases 4 / 7 /
+    4, the reference's 15 challenges. The restatement reproduces the registers instance's round-0 evaluations p(0..3) (full width), the
+    first inc values, and — after 15 folds — merged_eq[0], ra*val + wa*(val + inc), their product and the final claim (full width)."""
+    fx, gr, steps, gamma, r_cycle = stage4_inputs_of_the_captured_run(golden_dir, ob.fr_from_int)
+    p = ob.Stage4GruenProver(steps, gamma, r_cycle, fx["phase1_num_rounds"], fx["phase2_num_rounds"])
+    assert (p.T, p.K) == (fx["T"], fx["K"])
+    for j, h in enumerate(fx["inc_first4_le8"]):
+        assert ob.fr_to_int(p.inc[j]).to_bytes(32, "little")[:8].hex() == h
+    check_stage4_against_the_captured_run(p, fx, gr, ob.fr_from_int, ob.fr_to_int)

@@ -75,7 +75,7 @@ def random_raw256(seed, n):
     return splitmix64(seed, 4 * n).reshape(n, 4)
 
 
-def fibonacci_rd_values(elf_bytes, steps=54):
+def fibonacci_rd_values(elf_bytes, steps=54, records=None):
     """rd_value of every step of the reference's captured fibonacci run (logs/zolt.log:23-27: 54 cycles, terminated by the
     `j .` at 0x80000010), from a minimal RV64 interpreter of the ten instruction forms the 104-byte program uses — the semantics
     of the reference's tracer (src/tracer/mod.zig:429-816: rd_value = the value computed for rd, 0 for branches; JAL / JALR
@@ -119,9 +119,19 @@ def fibonacci_rd_values(elf_bytes, steps=54):
         if rd:
             regs[rd] = rv
         vals.append(rv)
+        if records is not None:
+            records.append((w, rv, a, b))
         pc = npc
     assert pc == 0x80000010 and regs[10] == 55  # back in the `j .` loop with fib = 55 in a0
     return vals
+
+
+def fibonacci_trace_steps(elf_bytes, steps=54, padded=256):
+    """ExecutionTrace.steps of the captured run as Stage4GruenProver reads them (src/zkvm/spartan/stage4_gruen_prover.zig:183-246):
+    (instruction word, rd_value, is_noop) per cycle — the 54 executed instructions, then no-op padding up to the trace length."""
+    recs = []
+    fibonacci_rd_values(elf_bytes, steps, recs)
+    return [(w, rv, False) for w, rv, _, _ in recs] + [(0, 0, True)] * (padded - len(recs))
 
 
 def output_check_tables_of_the_captured_run(oc, elf_bytes, fr_from_int, eq_table):

@@ -115,6 +115,17 @@ pub extern fn zg_psc_read(s: ProductSession, table: usize, out: ?[*]u64) c_int;
 pub extern fn zg_psc_gather(s: ProductSession, table: usize, idx: ?[*]const u64, n: usize, out: ?[*]u64) c_int;
 pub extern fn zg_psc_final(s: ProductSession, out: ?[*]u64) c_int;
 pub extern fn zg_psc_close(s: ProductSession) c_int;
+pub extern fn zg_rrw_open(log_t: usize, rs1: ?[*]const u8, rs2: ?[*]const u8, rd: ?[*]const u8, reg_vals: ?[*]const u64, inc: ?[*]const u64, gamma: *const [4]u64, s: *RegistersSession) c_int;
+pub extern fn zg_rrw_cycles(s: RegistersSession) usize;
+pub extern fn zg_rrw_registers(s: RegistersSession) usize;
+pub extern fn zg_rrw_round_cycle_gruen(s: RegistersSession, d_e_out: ?[*]const u64, n_out: usize, d_e_in: ?[*]const u64, n_in: usize, q0: *[4]u64, qx2: *[4]u64) c_int;
+pub extern fn zg_rrw_set_eq(s: RegistersSession, eq: ?[*]const u64, n: usize) c_int;
+pub extern fn zg_rrw_round_address(s: RegistersSession, e0: *[4]u64, e2: *[4]u64) c_int;
+pub extern fn zg_rrw_round_cycle(s: RegistersSession, e0: *[4]u64, e2: *[4]u64, e3: *[4]u64) c_int;
+pub extern fn zg_rrw_bind_cycle(s: RegistersSession, r: *const [4]u64) c_int;
+pub extern fn zg_rrw_bind_address(s: RegistersSession, r: *const [4]u64) c_int;
+pub extern fn zg_rrw_final(s: RegistersSession, out: ?[*]u64) c_int;
+pub extern fn zg_rrw_close(s: RegistersSession) c_int;
 pub extern fn zg_shard_bounds(n: usize, shards: c_int, shard: c_int, start: ?*usize, len: ?*usize) c_int;
 pub extern fn zg_g1_bases_upload_sharded(xy: ?[*]const u64, inf: ?[*]const u8, n: usize, cfg: ?*const MsmConfig, out: *ShardedBases) c_int;
 pub extern fn zg_g1_sbases_free(sb: ShardedBases) c_int;

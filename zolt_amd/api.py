@@ -607,6 +607,7 @@ class GruenSplitEqPolynomial:
             self._d_in = lib.DeviceBuffer(((2 << self.num_x_in) - 1) * 32)
             lib.fr_eq_prefix_tables_dev(self.tau[:m], self._d_out.ptr)
             lib.fr_eq_prefix_tables_dev(self.tau[m:m + self.num_x_in], self._d_in.ptr)
+            lib.sync()  # the consumers read the tables on their sessions' own streams
         num_unbound = self.current_index
         head_len = max(num_unbound - min(window_size, num_unbound), 0)
         head_out_bits = min(head_len, self.tau.shape[0] // 2)
@@ -1956,6 +1957,126 @@ class RamReadWriteCheckingProver:
         self._cyc.close()
         self._val.close()
         self.gruen_eq.deinit()
+
+
+class Stage4GruenProver:
+    """Stage4GruenProver (src/zkvm/spartan/stage4_gruen_prover.zig:65-1240), the RegistersReadWriteChecking sumcheck: five dense
+    K = 128 x T tables (val, rd_wa, ra = gamma rs1_ra + gamma^2 rs2_ra, rs1_ra, rs2_ra), inc[T] and the eq structure over the cycles;
+    LOG_K + log T rounds — phase1_num_rounds cycle variables in Gruen form, the seven register variables, the remaining cycle
+    variables under the merged dense eq table. The tables are built ON THE DEVICE from the per-cycle trace columns and stay in HBM
+    (zg_rrw_*): a round is one pass for the sums and one for the folds. The host keeps what the reference's host keeps: the
+    GruenSplitEqPolynomial (its prefix tables are device buffers too), Gruen's cubic and the claim algebra.
+    steps: [(instruction u32, rd_value u64, is_noop)] or the three columns as arrays; r_cycle in ROUND order (:283-288)."""
+    LOG_K, K = 7, 128
+    _RS1_OPS = (0x13, 0x03, 0x67, 0x1B, 0x33, 0x3B, 0x23, 0x63)  # opcodes that read rs1 (:205-218)
+    _RS2_OPS = (0x33, 0x3B, 0x23, 0x63)  # ... rs2 (:220-231)
+    _NO_RD_OPS = (0x23, 0x63)  # stores and branches write no register (:233-236)
+
+    def __init__(self, steps, gamma, r_cycle, phase1_num_rounds, phase2_num_rounds):
+        if isinstance(steps, tuple) and len(steps) == 3 and hasattr(steps[0], "__len__"):
+            instr, rd_value, noop = (np.asarray(c) for c in steps)
+        else:
+            instr = np.array([s[0] for s in steps], dtype=np.uint32)
+            rd_value = np.array([s[1] for s in steps], dtype=np.uint64)
+            noop = np.array([bool(s[2]) for s in steps], dtype=bool)
+        n = len(instr)
+        T = 1
+        while T < n:
+            T *= 2
+        self.T, self.log_T = T, T.bit_length() - 1
+        r_cycle = np.ascontiguousarray(r_cycle, dtype=np.uint64).reshape(-1, 4)
+        assert r_cycle.shape[0] == self.log_T and self.log_T >= 1
+        assert 1 <= phase1_num_rounds <= self.log_T and phase2_num_rounds == self.LOG_K  # (the reference's configurations)
+        self.num_rounds = self.LOG_K + self.log_T
+        self.gamma = np.ascontiguousarray(gamma, dtype=np.uint64).copy()
+        self.phase1_num_rounds, self.phase2_num_rounds = phase1_num_rounds, phase2_num_rounds
+        rs1, rs2, rd, reg_vals, inc = self.traceColumns(instr.astype(np.uint32), rd_value.astype(np.uint64), noop.astype(bool), T)
+        self._s = lib.RegistersRwSession.open(self.log_T, rs1, rs2, rd, reg_vals, inc, self.gamma)
+        self.gruen = GruenSplitEqPolynomial(r_cycle[::-1].copy())  # big-endian for the split-eq structure (:283-288)
+        self.current_T, self.current_K = T, self.K
+        self.last_q = None
+
+    @classmethod
+    def traceColumns(cls, instr, rd_value, noop, T):
+        """what initWithPhaseConfig reads of the trace (:183-258), as columns: the register each cycle reads / writes (0xFF = none), the
+        register file BEFORE every cycle (32 x T, padding cycles keep the last one) and inc = F.fromU64(post) - F.fromU64(pre)."""
+        n = len(instr)
+        opcode, live = instr & 0x7F, ~noop
+        f_rd, f_rs1, f_rs2 = ((instr >> 7) & 31).astype(np.uint8), ((instr >> 15) & 31).astype(np.uint8), ((instr >> 20) & 31).astype(np.uint8)
+        rs1 = np.full(T, 0xFF, dtype=np.uint8)
+        rs2 = np.full(T, 0xFF, dtype=np.uint8)
+        rd = np.full(T, 0xFF, dtype=np.uint8)
+        rs1[:n] = np.where(live & np.isin(opcode, cls._RS1_OPS), f_rs1, 0xFF)
+        rs2[:n] = np.where(live & np.isin(opcode, cls._RS2_OPS), f_rs2, 0xFF)
+        writes = live & ~np.isin(opcode, cls._NO_RD_OPS) & (f_rd != 0)
+        rd[:n] = np.where(writes, f_rd, 0xFF)
+        reg_vals = np.zeros((32, T), dtype=np.uint64)
+        idx = np.arange(n)
+        for k in range(1, 32):  # value of register k before cycle j = rd_value of its last write at a cycle < j
+            last = np.maximum.accumulate(np.where(writes & (f_rd == k), idx, -1))
+            prev = np.full(T, last[-1] if n else -1, dtype=np.int64)  # padding cycles: the final register file (:249-258)
+            if n:
+                prev[0] = -1
+                prev[1:n] = last[:-1]
+            reg_vals[k] = np.where(prev >= 0, rd_value[np.maximum(prev, 0)], 0)
+        pre = np.zeros(T, dtype=np.uint64)
+        post = np.zeros(T, dtype=np.uint64)
+        w = np.nonzero(writes)[0]
+        pre[w] = reg_vals[f_rd[w], w]
+        post[w] = rd_value[w]
+        def from_u64(u):  # F.fromU64
+            l = np.zeros((T, 4), dtype=np.uint64)
+            l[:, 0] = u
+            return lib.field_op(lib.FR, lib.OP_TO_MONT, l)
+        inc = lib.field_op(lib.FR, lib.OP_SUB, from_u64(post), from_u64(pre))
+        return rs1, rs2, rd, reg_vals, inc
+
+    def computeRoundEvals(self, rnd, current_claim):
+        """computeRoundEvals (:1165-1190) -> (4, 4): p(0), p(1), p(2), p(3)"""
+        p1, p2 = self.phase1_num_rounds, self.phase2_num_rounds
+        claim = np.ascontiguousarray(current_claim, dtype=np.uint64)
+        if rnd < p1:  # phase1ComputeMessage (:561-741)
+            d_out, n_out, d_in, n_in = self.gruen.getWindowEqTablesDev(1)
+            q0, qx = self._s.round_cycle_gruen(d_out, n_out, d_in, n_in)
+            self.last_q = (q0, qx)
+            return self.gruen.computeCubicRoundPoly(q0, qx, claim)
+        if rnd < p1 + p2 or self.current_T == 1:  # phase2ComputeMessage (:764-852); phase 3 with a single cycle left (:955-1013)
+            e0, e2 = self._s.round_address()
+            a, b, c = fr_to_int(e0), fr_to_int(claim), fr_to_int(e2)
+            e1 = (b - a) % R_MOD
+            return np.stack([e0, fr_from_int(e1), e2, fr_from_int((a - 3 * e1 + 3 * c) % R_MOD)])  # the quadratic's p(3) (:841-850)
+        e0, e2, e3 = self._s.round_cycle()  # phase3ComputeMessage (:854-953)
+        return np.stack([e0, fr_from_int((fr_to_int(claim) - fr_to_int(e0)) % R_MOD), e2, e3])
+
+    def bindChallenge(self, rnd, challenge):
+        """bindChallenge / bindPolynomials (:1047-1163, 1192-1216)"""
+        p1, p2 = self.phase1_num_rounds, self.phase2_num_rounds
+        ch = np.ascontiguousarray(challenge, dtype=np.uint64)
+        if rnd < p1 or rnd >= p1 + p2:
+            self._s.bind_cycle(ch)
+            self.current_T //= 2
+            if rnd < p1:
+                self.gruen.bind(ch)
+                if rnd == p1 - 1:  # gruen_eq.merge (gruen_eq.zig:119-146): the dense table over the cycle variables still unbound
+                    self._s.set_eq(self.gruen.getFullEqTable())
+        else:
+            self._s.bind_address(ch)
+            self.current_K //= 2
+
+    def getFinalClaims(self):
+        """getFinalClaims (:1219-1236)"""
+        f = self._s.final()
+        return {"val_claim": f["val"], "rs1_ra_claim": f["rs1_ra"], "rs2_ra_claim": f["rs2_ra"], "rd_wa_claim": f["rd_wa"], "inc_claim": f["inc"]}
+
+    def finalCheck(self):
+        """(eq_scalar, combined, expected) as bindChallenge prints them after the last round (:1196-1210)"""
+        f = {k: fr_to_int(v) for k, v in self._s.final().items()}
+        comb = (f["ra"] * f["val"] + f["rd_wa"] * (f["val"] + f["inc"])) % R_MOD
+        return fr_from_int(f["eq"]), fr_from_int(comb), fr_from_int(f["eq"] * comb % R_MOD)
+
+    def deinit(self):
+        self._s.close()
+        self.gruen.deinit()
 
 
 class LassoProver:

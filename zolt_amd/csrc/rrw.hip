@@ -1,0 +1,565 @@
+// rrw.hip — RegistersReadWriteChecking (Stage 4) on gfx950: the dense K x T tables of Stage4GruenProver
+// (/root/reference/src/zkvm/spartan/stage4_gruen_prover.zig:65-1240) resident in HBM for the whole sumcheck.
+//
+// The reference keeps five tables indexed [k * T + j] (k < K = 128 registers, j < T cycles) — val, rd_wa, ra = gamma rs1_ra +
+// gamma^2 rs2_ra, rs1_ra, rs2_ra — plus inc[T] and an eq structure over the cycles, and runs LOG_K + log T rounds in three phases:
+//   phase 1  cycle variables, Gruen form:  (q0, qX2) = sum_i E_out[x_out(i)] E_in[x_in(i)] sum_k C(k, i)        (:561-741)
+//   phase 2  register variables:           (e0, e2)  = sum_j eq[j] sum_i C(2i, 2i+1; j) at t = 0, 2            (:764-852)
+//   phase 3  remaining cycle variables:    (e0, e2, e3) with the dense merged eq table                          (:854-953)
+// with C = ra val + wa (val + inc), and folds every table by the challenge after each round (:1047-1163). At T = 2^20 that is
+// 4 GiB per table and 128 M products per round for a CPU loop; here a round is one pass over ra / wa (and val where they are not
+// zero) + a fold pass, all five tables moved between two device buffers (compact rows of the live length).
+//
+// Sparsity. ra and wa start one-hot per cycle (at most two reads, one write among 128 registers) and a fold at most doubles the
+// share of non-zero entries, so in the large early rounds almost every (k, i) pair contributes nothing: the round kernels test
+// ra / wa first and skip val and the products where all four are zero, the fold kernels skip the product where hi == lo. The sums
+// and the folded tables are the reference's values exactly (zero terms, zero differences).
+#include <mutex>
+#include <vector>
+
+#include "common.hip.h"
+#include "field.hip.h"
+#include "fp29.hip.h"
+#include "sc_common.hip.h"
+
+namespace zg {
+
+static constexpr int RRW_K = 128, RRW_TABLES = 5;  // val, wa, ra, rs1_ra, rs2_ra
+enum { RT_VAL = 0, RT_WA = 1, RT_RA = 2, RT_RS1 = 3, RT_RS2 = 4 };
+static constexpr unsigned RRW_MAX_BLOCKS = 65536;
+
+struct RrwTabs {
+    const uint64_t *t[RRW_TABLES];
+};
+struct RrwTabsOut {
+    uint64_t *t[RRW_TABLES];
+};
+
+ZG_DEV Fr fr_from_arg(const FrArg &a) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = a.l[i];
+    return r;
+}
+
+// tables from the per-cycle trace columns: val[k][j] = F.fromU64(register k before cycle j) (k < 32, else 0), wa / rs1_ra / rs2_ra one-hot
+// in the register index, ra = gamma rs1_ra + gamma^2 rs2_ra (:183-246)
+__global__ void __launch_bounds__(256) rrw_build_kernel(const uint8_t *rs1, const uint8_t *rs2, const uint8_t *rd, const uint64_t *reg_vals,
+                                                        size_t T, FrArg gamma, RrwTabsOut out) {
+    size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)RRW_K * T) return;
+    size_t k = idx / T, j = idx - k * T;
+    F29 r2p;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r2p.l[i] = Fr29::R2PRE[i];
+    Fr v = Fr::zero();
+    if (k < 32) {
+        uint64_t u = reg_vals[k * T + j];
+        if (u) {
+            v.l[0] = (uint32_t)u;
+            v.l[1] = (uint32_t)(u >> 32);
+            v = fr_mul29(v, r2p);  // F.fromU64
+        }
+    }
+    const Fr one = Fr::one(), zero = Fr::zero();
+    const bool a1 = rs1[j] == k, a2 = rs2[j] == k, w = rd[j] == k;
+    Fr ra = zero;
+    if (a1) ra = fr_from_arg(gamma);
+    if (a2) {
+        Fr g = fr_from_arg(gamma);
+        ra = fe_add(ra, fr_mul29v(g, g));
+    }
+    fe_store(out.t[RT_VAL] + 4 * idx, v);
+    fe_store(out.t[RT_WA] + 4 * idx, w ? one : zero);
+    fe_store(out.t[RT_RA] + 4 * idx, ra);
+    fe_store(out.t[RT_RS1] + 4 * idx, a1 ? one : zero);
+    fe_store(out.t[RT_RS2] + 4 * idx, a2 ? one : zero);
+}
+
+// block partial sums of NV accumulators -> partials[block][NV] (finished by rrw_finish_kernel)
+template <int NV>
+__device__ __forceinline__ void rrw_block_out(Fr (&acc)[NV], uint4 *sh, uint64_t *partials) {
+    Fr z = Fr::zero();
+    block_sum_pair(acc[0], acc[1], sh);
+    if constexpr (NV > 2) {
+        __syncthreads();
+        block_sum_pair(acc[2], z, sh);
+    }
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int a = 0; a < NV; a++) fe_store(partials + 4 * ((size_t)blockIdx.x * NV + a), acc[a]);
+}
+
+__global__ void __launch_bounds__(256) rrw_finish_kernel(const uint64_t *partials, uint32_t nblocks, int nv, uint64_t *out) {
+    __shared__ uint4 sh[256 * 4];
+    for (int a = 0; a < nv; a++) {
+        Fr g0 = Fr::zero(), g1 = Fr::zero();
+        for (uint32_t b = threadIdx.x; b < nblocks; b += 256) g0 = fe_add(g0, fe_load<FrParams>(partials + 4 * ((size_t)b * nv + a)));
+        block_sum_pair(g0, g1, sh);
+        if (threadIdx.x == 0) fe_store(out + 4 * a, g0);
+        __syncthreads();
+    }
+}
+
+ZG_DEV bool fr_is_zero(const Fr &a) { return a.is_zero(); }
+
+// phase 1 (:561-741): thread t -> cycle pair i = t % half_T, register chunk t / half_T; (q0, qX2) += E(i) * sum_k C_0 / C_X2
+__global__ void __launch_bounds__(256) rrw_cycle_gruen_kernel(RrwTabs tb, size_t stride, const uint64_t *inc, const uint64_t *e_out, uint32_t n_out,
+                                                              const uint64_t *e_in, uint32_t n_in, uint32_t in_bits, size_t half_T, uint32_t cur_K,
+                                                              uint32_t kc_n, uint64_t *partials) {
+    __shared__ uint4 sh[256 * 4];
+    Fr acc[2] = {Fr::zero(), Fr::zero()};
+    size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < half_T * kc_n) {
+        size_t i = t % half_T;
+        uint32_t kc = (uint32_t)(t / half_T);
+        Fr inc0 = fe_load<FrParams>(inc + 8 * i), incs = fe_sub(fe_load<FrParams>(inc + 8 * i + 4), inc0);
+        Fr c0 = Fr::zero(), cx = Fr::zero();
+        bool any = false;
+        for (uint32_t k = kc; k < cur_K; k += kc_n) {
+            size_t o = 4 * ((size_t)k * stride + 2 * i);
+            Fr rae = fe_load<FrParams>(tb.t[RT_RA] + o), rao = fe_load<FrParams>(tb.t[RT_RA] + o + 4);
+            Fr wae = fe_load<FrParams>(tb.t[RT_WA] + o), wao = fe_load<FrParams>(tb.t[RT_WA] + o + 4);
+            if (fr_is_zero(rae) && fr_is_zero(rao) && fr_is_zero(wae) && fr_is_zero(wao)) continue;  // C_0 = C_X2 = 0
+            any = true;
+            Fr vae = fe_load<FrParams>(tb.t[RT_VAL] + o), vao = fe_load<FrParams>(tb.t[RT_VAL] + o + 4);
+            Fr ras = fe_sub(rao, rae), was = fe_sub(wao, wae), vas = fe_sub(vao, vae);
+            c0 = fe_add(c0, fe_add(fr_mul29v(rae, vae), fr_mul29v(wae, fe_add(vae, inc0))));
+            cx = fe_add(cx, fe_add(fr_mul29v(ras, vas), fr_mul29v(was, fe_add(vas, incs))));
+        }
+        if (any) {
+            size_t x_in = i & (((size_t)1 << in_bits) - 1), x_out = i >> in_bits;
+            Fr eo = x_out < n_out ? fe_load<FrParams>(e_out + 4 * x_out) : Fr::one();
+            Fr ei = x_in < n_in ? fe_load<FrParams>(e_in + 4 * x_in) : Fr::one();
+            F29 ep = fr29_prescale(fr_mul29v(eo, ei));
+            acc[0] = fr_mul29(c0, ep);
+            acc[1] = fr_mul29(cx, ep);
+        }
+    }
+    rrw_block_out<2>(acc, sh, partials);
+}
+
+// phase 2 (:764-852) and the register rounds once no cycle is left (:955-1013): thread t -> cycle j = t % cur_T, pair chunk t / cur_T;
+// (e0, e2) += eq[j] * sum_i C at t = 0 / 2 of the row pair (2i, 2i + 1)
+__global__ void __launch_bounds__(256) rrw_address_kernel(RrwTabs tb, size_t stride, const uint64_t *inc, const uint64_t *eq, size_t cur_T,
+                                                          uint32_t half_K, uint32_t ic_n, uint64_t *partials) {
+    __shared__ uint4 sh[256 * 4];
+    Fr acc[2] = {Fr::zero(), Fr::zero()};
+    size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < cur_T * ic_n) {
+        size_t j = t % cur_T;
+        uint32_t ic = (uint32_t)(t / cur_T);
+        Fr incj = fe_load<FrParams>(inc + 4 * j);
+        Fr c0 = Fr::zero(), c2 = Fr::zero();
+        bool any = false;
+        for (uint32_t i = ic; i < half_K; i += ic_n) {
+            size_t oe = 4 * ((size_t)(2 * i) * stride + j), oo = oe + 4 * stride;
+            Fr rae = fe_load<FrParams>(tb.t[RT_RA] + oe), rao = fe_load<FrParams>(tb.t[RT_RA] + oo);
+            Fr wae = fe_load<FrParams>(tb.t[RT_WA] + oe), wao = fe_load<FrParams>(tb.t[RT_WA] + oo);
+            if (fr_is_zero(rae) && fr_is_zero(rao) && fr_is_zero(wae) && fr_is_zero(wao)) continue;
+            any = true;
+            Fr vae = fe_load<FrParams>(tb.t[RT_VAL] + oe), vao = fe_load<FrParams>(tb.t[RT_VAL] + oo);
+            c0 = fe_add(c0, fe_add(fr_mul29v(rae, vae), fr_mul29v(wae, fe_add(vae, incj))));
+            Fr ra2 = fe_sub(fe_add(rao, rao), rae), wa2 = fe_sub(fe_add(wao, wao), wae), va2 = fe_sub(fe_add(vao, vao), vae);  // f(0) + 2 (f(1) - f(0))
+            c2 = fe_add(c2, fe_add(fr_mul29v(ra2, va2), fr_mul29v(wa2, fe_add(va2, incj))));
+        }
+        if (any) {
+            F29 ep = fr29_prescale(fe_load<FrParams>(eq + 4 * j));
+            acc[0] = fr_mul29(c0, ep);
+            acc[1] = fr_mul29(c2, ep);
+        }
+    }
+    rrw_block_out<2>(acc, sh, partials);
+}
+
+// phase 3 with cycles left (:854-953): thread t -> cycle pair i, register chunk; (e0, e2, e3) += eq(t) * sum_k C(t), t = 0, 2, 3
+__global__ void __launch_bounds__(256) rrw_cycle_dense_kernel(RrwTabs tb, size_t stride, const uint64_t *inc, const uint64_t *eq, size_t half_T,
+                                                              uint32_t cur_K, uint32_t kc_n, uint64_t *partials) {
+    __shared__ uint4 sh[256 * 4];
+    Fr acc[3] = {Fr::zero(), Fr::zero(), Fr::zero()};
+    size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < half_T * kc_n) {
+        size_t i = t % half_T;
+        uint32_t kc = (uint32_t)(t / half_T);
+        Fr inc0 = fe_load<FrParams>(inc + 8 * i), incs = fe_sub(fe_load<FrParams>(inc + 8 * i + 4), inc0);
+        Fr inc2 = fe_add(fe_add(inc0, incs), incs), inc3 = fe_add(inc2, incs);
+        Fr c0 = Fr::zero(), c2 = Fr::zero(), c3 = Fr::zero();
+        bool any = false;
+        for (uint32_t k = kc; k < cur_K; k += kc_n) {
+            size_t o = 4 * ((size_t)k * stride + 2 * i);
+            Fr rae = fe_load<FrParams>(tb.t[RT_RA] + o), rao = fe_load<FrParams>(tb.t[RT_RA] + o + 4);
+            Fr wae = fe_load<FrParams>(tb.t[RT_WA] + o), wao = fe_load<FrParams>(tb.t[RT_WA] + o + 4);
+            if (fr_is_zero(rae) && fr_is_zero(rao) && fr_is_zero(wae) && fr_is_zero(wao)) continue;
+            any = true;
+            Fr vae = fe_load<FrParams>(tb.t[RT_VAL] + o), vao = fe_load<FrParams>(tb.t[RT_VAL] + o + 4);
+            Fr ras = fe_sub(rao, rae), was = fe_sub(wao, wae), vas = fe_sub(vao, vae);
+            c0 = fe_add(c0, fe_add(fr_mul29v(rae, vae), fr_mul29v(wae, fe_add(vae, inc0))));
+            Fr ra2 = fe_add(rao, ras), wa2 = fe_add(wao, was), va2 = fe_add(vao, vas);
+            c2 = fe_add(c2, fe_add(fr_mul29v(ra2, va2), fr_mul29v(wa2, fe_add(va2, inc2))));
+            Fr ra3 = fe_add(ra2, ras), wa3 = fe_add(wa2, was), va3 = fe_add(va2, vas);
+            c3 = fe_add(c3, fe_add(fr_mul29v(ra3, va3), fr_mul29v(wa3, fe_add(va3, inc3))));
+        }
+        if (any) {
+            Fr eqe = fe_load<FrParams>(eq + 8 * i), eqs = fe_sub(fe_load<FrParams>(eq + 8 * i + 4), eqe);
+            Fr eq2 = fe_add(fe_add(eqe, eqs), eqs), eq3 = fe_add(eq2, eqs);
+            acc[0] = fr_mul29v(c0, eqe);
+            acc[1] = fr_mul29v(c2, eq2);
+            acc[2] = fr_mul29v(c3, eq3);
+        }
+    }
+    rrw_block_out<3>(acc, sh, partials);
+}
+
+ZG_DEV Fr rrw_fold1(const Fr &lo, const Fr &hi, const FrMul &rm) {
+    Fr d = fe_sub(hi, lo);
+    if (fr_is_zero(d)) return lo;  // (also every pair of zeros of the one-hot tables)
+    return fe_add(lo, rm.narrow ? frmul_apply(d, rm) : fr_mul29(d, rm.p));
+}
+
+// cycle fold (:1053-1090, 1124-1162): out[k][i] = lo (1 - c) + hi c for the five tables; rows compacted to half_T. blockIdx.y = table.
+__global__ void __launch_bounds__(256) rrw_fold_cycle_kernel(RrwTabs in, size_t stride, RrwTabsOut out, size_t half_T, uint32_t cur_K, FrArg r) {
+    const FrMul rm = frmul_prepare(fr_from_arg(r));
+    const uint64_t *src = in.t[blockIdx.y];
+    uint64_t *dst = out.t[blockIdx.y];
+    size_t n = (size_t)cur_K * half_T, step = (size_t)gridDim.x * 256;
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < n; t += step) {
+        size_t k = t / half_T, i = t - k * half_T;
+        const uint64_t *p = src + 4 * (k * stride + 2 * i);
+        fe_store(dst + 4 * (k * half_T + i), rrw_fold1(fe_load<FrParams>(p), fe_load<FrParams>(p + 4), rm));
+    }
+}
+
+// the vectors over the cycles (inc, and the merged eq table in phase 3), same fold
+__global__ void __launch_bounds__(256) rrw_fold_vec_kernel(const uint64_t *a, uint64_t *a_out, const uint64_t *b, uint64_t *b_out, size_t half, FrArg r) {
+    const FrMul rm = frmul_prepare(fr_from_arg(r));
+    size_t step = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < half; i += step) {
+        fe_store(a_out + 4 * i, rrw_fold1(fe_load<FrParams>(a + 8 * i), fe_load<FrParams>(a + 8 * i + 4), rm));
+        if (b) fe_store(b_out + 4 * i, rrw_fold1(fe_load<FrParams>(b + 8 * i), fe_load<FrParams>(b + 8 * i + 4), rm));
+    }
+}
+
+// register fold (:1092-1122): out[i][j] = row 2i (1 - c) + row 2i+1 c
+__global__ void __launch_bounds__(256) rrw_fold_address_kernel(RrwTabs in, size_t stride, RrwTabsOut out, size_t cur_T, uint32_t half_K, FrArg r) {
+    const FrMul rm = frmul_prepare(fr_from_arg(r));
+    const uint64_t *src = in.t[blockIdx.y];
+    uint64_t *dst = out.t[blockIdx.y];
+    size_t n = (size_t)half_K * cur_T, step = (size_t)gridDim.x * 256;
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < n; t += step) {
+        size_t i = t / cur_T, j = t - i * cur_T;
+        const uint64_t *p = src + 4 * ((2 * i) * stride + j);
+        fe_store(dst + 4 * (i * cur_T + j), rrw_fold1(fe_load<FrParams>(p), fe_load<FrParams>(p + 4 * stride), rm));
+    }
+}
+
+}  // namespace zg
+
+struct zg_rrw_s {
+    int device = -1;
+    size_t T = 0, cur_T = 0, stride = 0;
+    uint32_t cur_K = zg::RRW_K;
+    uint64_t *tab[zg::RRW_TABLES][2] = {};  // [table][buffer]: buffer 0 holds K x T elements, buffer 1 K x T / 2
+    uint64_t *inc[2] = {nullptr, nullptr}, *eq[2] = {nullptr, nullptr};
+    int cur = 0, vcur = 0;  // live buffer of the tables / of the two cycle vectors
+    bool have_eq = false;
+    uint64_t *d_part = nullptr, *d_out = nullptr, *h_out = nullptr;
+    hipStream_t st = nullptr;
+    std::mutex mu;
+};
+
+using namespace zg;
+
+static void rrw_free(zg_rrw_s *s) {
+    if (!s) return;
+    for (int t = 0; t < RRW_TABLES; t++)
+        for (int b = 0; b < 2; b++)
+            if (s->tab[t][b]) (void)hipFree(s->tab[t][b]);
+    for (int b = 0; b < 2; b++) {
+        if (s->inc[b]) (void)hipFree(s->inc[b]);
+        if (s->eq[b]) (void)hipFree(s->eq[b]);
+    }
+    if (s->d_part) (void)hipFree(s->d_part);
+    if (s->d_out) (void)hipFree(s->d_out);
+    if (s->h_out) (void)hipHostFree(s->h_out);
+    if (s->st) stream_release(s->st, s->device);
+    delete s;
+}
+
+static FrArg fr_arg(const uint64_t r[4]) {
+    FrArg a;
+    for (int i = 0; i < 4; i++) {
+        a.l[2 * i] = (uint32_t)r[i];
+        a.l[2 * i + 1] = (uint32_t)(r[i] >> 32);
+    }
+    return a;
+}
+
+static RrwTabs rrw_tabs(const zg_rrw_s *s) {
+    RrwTabs t;
+    for (int i = 0; i < RRW_TABLES; i++) t.t[i] = s->tab[i][s->cur];
+    return t;
+}
+static RrwTabsOut rrw_tabs_out(const zg_rrw_s *s, int buf) {
+    RrwTabsOut t;
+    for (int i = 0; i < RRW_TABLES; i++) t.t[i] = s->tab[i][buf];
+    return t;
+}
+
+// threads per round launch: one per (pair / cycle, chunk); chunks spread the register loop when the cycle dimension alone is short
+static uint32_t rrw_chunks(size_t inner, uint32_t outer) {
+    uint32_t c = 1;
+    while (c < outer && inner * c < 65536) c <<= 1;
+    return c > outer ? outer : c;
+}
+
+// sum the block partials and bring nv values to the host
+static int rrw_collect(zg_rrw_s *s, uint32_t nblocks, int nv, uint64_t *out) {
+    hipLaunchKernelGGL(rrw_finish_kernel, dim3(1), dim3(256), 0, s->st, s->d_part, nblocks, nv, s->d_out);
+    ZG_HIP(hipGetLastError());
+    ZG_HIP(hipMemcpyAsync(s->h_out, s->d_out, (size_t)nv * 32, hipMemcpyDeviceToHost, s->st));
+    ZG_HIP(hipStreamSynchronize(s->st));
+    for (int i = 0; i < 4 * nv; i++) out[i] = s->h_out[i];
+    return ZG_OK;
+}
+
+extern "C" {
+
+int zg_rrw_open(size_t log_t, const uint8_t *rs1, const uint8_t *rs2, const uint8_t *rd, const uint64_t *reg_vals, const uint64_t *inc,
+                const uint64_t gamma[4], zg_rrw_t *out) {
+    ZG_INIT();
+    if (!out || !rs1 || !rs2 || !rd || !reg_vals || !inc || !gamma || log_t < 1 || log_t > 22) {
+        set_error("zg_rrw_open: invalid argument (1 <= log_t <= 22: five 128 x 2^log_t tables and their half-size partners)");
+        return ZG_ERR_INVALID;
+    }
+    const size_t T = (size_t)1 << log_t;
+    zg_rrw_s *s = new zg_rrw_s();
+    s->device = current_device();
+    s->T = s->cur_T = s->stride = T;
+    s->st = stream_acquire();
+    hipError_t e = s->st ? hipSuccess : hipErrorOutOfMemory;
+    for (int t = 0; t < RRW_TABLES && e == hipSuccess; t++) {
+        e = hipMalloc((void **)&s->tab[t][0], (size_t)RRW_K * T * 32);
+        if (e == hipSuccess) e = hipMalloc((void **)&s->tab[t][1], (size_t)RRW_K * (T / 2) * 32);
+    }
+    for (int b = 0; b < 2 && e == hipSuccess; b++) {
+        e = hipMalloc((void **)&s->inc[b], (T >> b) * 32);
+        if (e == hipSuccess) e = hipMalloc((void **)&s->eq[b], (T >> b) * 32);
+    }
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_part, (size_t)RRW_MAX_BLOCKS * 3 * 32);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_out, 8 * 32);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_out, 8 * 32);
+    if (e != hipSuccess) {
+        set_error(std::string("zg_rrw_open: ") + hipGetErrorString(e));
+        rrw_free(s);
+        return e == hipErrorOutOfMemory ? ZG_ERR_NOMEM : ZG_ERR_HIP;
+    }
+    // the trace columns travel in one scratch buffer: rs1 | rs2 | rd (T bytes each, padded) then the 32 x T register values
+    const size_t pad = (T + 255) & ~(size_t)255;
+    Scratch s_cols(3 * pad), s_vals(32 * T * 8);
+    if (!s_cols.p || !s_vals.p) {
+        rrw_free(s);
+        return ZG_ERR_NOMEM;
+    }
+    int rc = [&]() -> int {
+        SyncGuard sync(s->st);
+        uint8_t *d_cols = s_cols.as<uint8_t>();
+        ZG_HIP(hipMemcpyAsync(d_cols, rs1, T, hipMemcpyHostToDevice, s->st));
+        ZG_HIP(hipMemcpyAsync(d_cols + pad, rs2, T, hipMemcpyHostToDevice, s->st));
+        ZG_HIP(hipMemcpyAsync(d_cols + 2 * pad, rd, T, hipMemcpyHostToDevice, s->st));
+        ZG_HIP(hipMemcpyAsync(s_vals.p, reg_vals, 32 * T * 8, hipMemcpyHostToDevice, s->st));
+        ZG_HIP(hipMemcpyAsync(s->inc[0], inc, T * 32, hipMemcpyHostToDevice, s->st));
+        size_t n = (size_t)RRW_K * T;
+        hipLaunchKernelGGL(rrw_build_kernel, dim3(div_up(n, 256)), dim3(256), 0, s->st, d_cols, d_cols + pad, d_cols + 2 * pad, s_vals.as<uint64_t>(), T,
+                           fr_arg(gamma), rrw_tabs_out(s, 0));
+        ZG_HIP(hipGetLastError());
+        ZG_HIP(hipStreamSynchronize(s->st));
+        sync.dismiss();
+        return ZG_OK;
+    }();
+    if (rc != ZG_OK) {
+        std::string keep = zg_last_error();
+        (void)hipStreamSynchronize(s->st);
+        rrw_free(s);
+        set_error(keep);
+        return rc;
+    }
+    *out = s;
+    return ZG_OK;
+}
+
+size_t zg_rrw_cycles(zg_rrw_t s) { return s ? s->cur_T : 0; }
+size_t zg_rrw_registers(zg_rrw_t s) { return s ? s->cur_K : 0; }
+
+int zg_rrw_round_cycle_gruen(zg_rrw_t s, const uint64_t *d_e_out, size_t n_out, const uint64_t *d_e_in, size_t n_in, uint64_t q0[4], uint64_t qx2[4]) {
+    ZG_INIT();
+    if (!s || !q0 || !qx2 || s->cur_T < 2 || !d_e_out || !d_e_in || n_in == 0 || (n_in & (n_in - 1))) {
+        set_error("zg_rrw_round_cycle_gruen: invalid argument (|E_in| a power of two, at least two cycles left)");
+        return ZG_ERR_INVALID;
+    }
+    DeviceGuard dg(s->device);
+    std::lock_guard<std::mutex> lk(s->mu);
+    const size_t half = s->cur_T / 2;
+    uint32_t in_bits = 0;
+    while (((size_t)1 << in_bits) < n_in) in_bits++;
+    uint32_t kc = rrw_chunks(half, s->cur_K);
+    uint32_t nb = div_up(half * kc, 256);
+    if (nb > RRW_MAX_BLOCKS) {
+        set_error("zg_rrw_round_cycle_gruen: table too long");
+        return ZG_ERR_INVALID;
+    }
+    hipLaunchKernelGGL(rrw_cycle_gruen_kernel, dim3(nb), dim3(256), 0, s->st, rrw_tabs(s), s->stride, s->inc[s->vcur], d_e_out, (uint32_t)n_out, d_e_in,
+                       (uint32_t)n_in, in_bits, half, s->cur_K, kc, s->d_part);
+    ZG_HIP(hipGetLastError());
+    uint64_t o[8];
+    ZG_TRY(rrw_collect(s, nb, 2, o));
+    for (int i = 0; i < 4; i++) {
+        q0[i] = o[i];
+        qx2[i] = o[4 + i];
+    }
+    return ZG_OK;
+}
+
+int zg_rrw_set_eq(zg_rrw_t s, const uint64_t *eq, size_t n) {
+    ZG_INIT();
+    if (!s || !eq || n != s->cur_T) {
+        set_error("zg_rrw_set_eq: the merged eq table must have one entry per live cycle");
+        return ZG_ERR_INVALID;
+    }
+    DeviceGuard dg(s->device);
+    std::lock_guard<std::mutex> lk(s->mu);
+    ZG_HIP(hipMemcpyAsync(s->eq[s->vcur], eq, n * 32, hipMemcpyHostToDevice, s->st));
+    ZG_HIP(hipStreamSynchronize(s->st));
+    s->have_eq = true;
+    return ZG_OK;
+}
+
+int zg_rrw_round_address(zg_rrw_t s, uint64_t e0[4], uint64_t e2[4]) {
+    ZG_INIT();
+    if (!s || !e0 || !e2 || s->cur_K < 2 || !s->have_eq) {
+        set_error("zg_rrw_round_address: needs the merged eq table (zg_rrw_set_eq) and at least two registers left");
+        return ZG_ERR_INVALID;
+    }
+    DeviceGuard dg(s->device);
+    std::lock_guard<std::mutex> lk(s->mu);
+    const uint32_t half_K = s->cur_K / 2;
+    uint32_t ic = rrw_chunks(s->cur_T, half_K);
+    uint32_t nb = div_up(s->cur_T * ic, 256);
+    if (nb > RRW_MAX_BLOCKS) {
+        set_error("zg_rrw_round_address: table too long");
+        return ZG_ERR_INVALID;
+    }
+    hipLaunchKernelGGL(rrw_address_kernel, dim3(nb), dim3(256), 0, s->st, rrw_tabs(s), s->stride, s->inc[s->vcur], s->eq[s->vcur], s->cur_T, half_K, ic,
+                       s->d_part);
+    ZG_HIP(hipGetLastError());
+    uint64_t o[8];
+    ZG_TRY(rrw_collect(s, nb, 2, o));
+    for (int i = 0; i < 4; i++) {
+        e0[i] = o[i];
+        e2[i] = o[4 + i];
+    }
+    return ZG_OK;
+}
+
+int zg_rrw_round_cycle(zg_rrw_t s, uint64_t e0[4], uint64_t e2[4], uint64_t e3[4]) {
+    ZG_INIT();
+    if (!s || !e0 || !e2 || !e3 || s->cur_T < 2 || !s->have_eq) {
+        set_error("zg_rrw_round_cycle: needs the merged eq table (zg_rrw_set_eq) and at least two cycles left");
+        return ZG_ERR_INVALID;
+    }
+    DeviceGuard dg(s->device);
+    std::lock_guard<std::mutex> lk(s->mu);
+    const size_t half = s->cur_T / 2;
+    uint32_t kc = rrw_chunks(half, s->cur_K);
+    uint32_t nb = div_up(half * kc, 256);
+    if (nb > RRW_MAX_BLOCKS) {
+        set_error("zg_rrw_round_cycle: table too long");
+        return ZG_ERR_INVALID;
+    }
+    hipLaunchKernelGGL(rrw_cycle_dense_kernel, dim3(nb), dim3(256), 0, s->st, rrw_tabs(s), s->stride, s->inc[s->vcur], s->eq[s->vcur], half, s->cur_K, kc,
+                       s->d_part);
+    ZG_HIP(hipGetLastError());
+    uint64_t o[12];
+    ZG_TRY(rrw_collect(s, nb, 3, o));
+    for (int i = 0; i < 4; i++) {
+        e0[i] = o[i];
+        e2[i] = o[4 + i];
+        e3[i] = o[8 + i];
+    }
+    return ZG_OK;
+}
+
+int zg_rrw_bind_cycle(zg_rrw_t s, const uint64_t r[4]) {
+    ZG_INIT();
+    if (!s || !r || s->cur_T < 2) {
+        set_error("zg_rrw_bind_cycle: no cycle variable left");
+        return ZG_ERR_INVALID;
+    }
+    DeviceGuard dg(s->device);
+    std::lock_guard<std::mutex> lk(s->mu);
+    const size_t half = s->cur_T / 2;
+    const int nxt = s->cur ^ 1, vn = s->vcur ^ 1;
+    size_t n = (size_t)s->cur_K * half;
+    unsigned nb = div_up(n, 256);
+    if (nb > 16384) nb = 16384;
+    hipLaunchKernelGGL(rrw_fold_cycle_kernel, dim3(nb, RRW_TABLES), dim3(256), 0, s->st, rrw_tabs(s), s->stride, rrw_tabs_out(s, nxt), half, s->cur_K, fr_arg(r));
+    unsigned nv = div_up(half, 256);
+    if (nv > 4096) nv = 4096;
+    hipLaunchKernelGGL(rrw_fold_vec_kernel, dim3(nv), dim3(256), 0, s->st, s->inc[s->vcur], s->inc[vn], s->have_eq ? s->eq[s->vcur] : (const uint64_t *)nullptr,
+                       s->eq[vn], half, fr_arg(r));
+    ZG_HIP(hipGetLastError());
+    s->cur = nxt;
+    s->vcur = vn;
+    s->cur_T = half;
+    s->stride = half;
+    return ZG_OK;
+}
+
+int zg_rrw_bind_address(zg_rrw_t s, const uint64_t r[4]) {
+    ZG_INIT();
+    if (!s || !r || s->cur_K < 2) {
+        set_error("zg_rrw_bind_address: no register variable left");
+        return ZG_ERR_INVALID;
+    }
+    DeviceGuard dg(s->device);
+    std::lock_guard<std::mutex> lk(s->mu);
+    const uint32_t half_K = s->cur_K / 2;
+    const int nxt = s->cur ^ 1;
+    size_t n = (size_t)half_K * s->cur_T;
+    unsigned nb = div_up(n, 256);
+    if (nb > 16384) nb = 16384;
+    hipLaunchKernelGGL(rrw_fold_address_kernel, dim3(nb, RRW_TABLES), dim3(256), 0, s->st, rrw_tabs(s), s->stride, rrw_tabs_out(s, nxt), s->cur_T, half_K,
+                       fr_arg(r));
+    ZG_HIP(hipGetLastError());
+    s->cur = nxt;
+    s->cur_K = half_K;
+    s->stride = s->cur_T;
+    return ZG_OK;
+}
+
+int zg_rrw_final(zg_rrw_t s, uint64_t *out) {
+    ZG_INIT();
+    if (!s || !out) {
+        set_error("zg_rrw_final: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    DeviceGuard dg(s->device);
+    std::lock_guard<std::mutex> lk(s->mu);
+    // entry [0][0] of val, wa, ra, rs1_ra, rs2_ra, then inc[0] and eq[0] (zero when no eq table was set)
+    for (int t = 0; t < RRW_TABLES; t++) ZG_HIP(hipMemcpyAsync(out + 4 * t, s->tab[t][s->cur], 32, hipMemcpyDeviceToHost, s->st));
+    ZG_HIP(hipMemcpyAsync(out + 20, s->inc[s->vcur], 32, hipMemcpyDeviceToHost, s->st));
+    if (s->have_eq) ZG_HIP(hipMemcpyAsync(out + 24, s->eq[s->vcur], 32, hipMemcpyDeviceToHost, s->st));
+    else for (int i = 0; i < 4; i++) out[24 + i] = 0;
+    ZG_HIP(hipStreamSynchronize(s->st));
+    return ZG_OK;
+}
+
+int zg_rrw_close(zg_rrw_t s) {
+    if (!s) return ZG_OK;
+    ZG_INIT();
+    DeviceGuard dg(s->device);
+    (void)hipStreamSynchronize(s->st);
+    rrw_free(s);
+    return ZG_OK;
+}
+
+}  // extern "C"

@@ -1450,6 +1450,117 @@ private:
 };
 
 // InstructionLookupsClaimReductionProver's loop (src/zkvm/claim_reductions/instruction_lookups.zig:146-284)
+// Stage4GruenProver (src/zkvm/spartan/stage4_gruen_prover.zig:65-1240), RegistersReadWriteChecking: the five dense K = 128 x T tables
+// and inc[T] are built on the device from the per-cycle trace columns and stay in HBM (zg_rrw_*); the eq structure (its prefix tables in
+// device buffers as well), Gruen's cubic and the claim algebra stay on the host, as in the reference.
+struct TraceStep {  // what the prover reads of ExecutionTrace.steps (:196-246)
+    uint32_t instruction;
+    uint64_t rd_value;
+    bool is_noop;
+};
+class Stage4GruenProver {
+public:
+    static constexpr size_t LOG_K = 7, K = 128;
+    size_t T = 1, log_T = 0, current_T = 0, current_K = K, num_rounds = 0;
+    Fr last_q_constant = Fr::zero(), last_q_quadratic = Fr::zero();
+
+    // r_cycle in ROUND order (r_cycle[0] is bound first); the split-eq structure takes it big-endian (:283-288)
+    Stage4GruenProver(const std::vector<TraceStep> &steps, const Fr &gamma, const std::vector<Fr> &r_cycle, size_t phase1_num_rounds, size_t phase2_num_rounds)
+        : p1_(phase1_num_rounds), p2_(phase2_num_rounds), gruen_(std::vector<Fr>(r_cycle.rbegin(), r_cycle.rend())) {
+        while (T < steps.size()) T <<= 1, log_T++;
+        if (r_cycle.size() != log_T || log_T < 1 || p1_ < 1 || p1_ > log_T || p2_ != LOG_K) throw std::invalid_argument("Stage4GruenProver: configuration");
+        current_T = T;
+        num_rounds = LOG_K + log_T;
+        std::vector<uint8_t> rs1(T, 0xFF), rs2(T, 0xFF), rd(T, 0xFF);
+        std::vector<uint64_t> reg_vals(32 * T, 0);
+        std::vector<Fr> inc(T, Fr::zero());
+        uint64_t regs[32] = {};
+        for (size_t j = 0; j < T; j++) {  // :183-258
+            for (size_t k = 0; k < 32; k++) reg_vals[k * T + j] = regs[k];
+            if (j >= steps.size() || steps[j].is_noop) continue;
+            const uint32_t w = steps[j].instruction, op = w & 0x7F, f_rd = (w >> 7) & 31, f_rs1 = (w >> 15) & 31, f_rs2 = (w >> 20) & 31;
+            const bool two = op == 0x33 || op == 0x3B || op == 0x23 || op == 0x63;
+            if (two || op == 0x13 || op == 0x03 || op == 0x67 || op == 0x1B) rs1[j] = (uint8_t)f_rs1;
+            if (two) rs2[j] = (uint8_t)f_rs2;
+            if (op != 0x23 && op != 0x63 && f_rd != 0) {
+                rd[j] = (uint8_t)f_rd;
+                inc[j] = Fr::fromU64(steps[j].rd_value).sub(Fr::fromU64(regs[f_rd]));
+                regs[f_rd] = steps[j].rd_value;
+            }
+        }
+        check(zg_rrw_open(log_T, rs1.data(), rs2.data(), rd.data(), reg_vals.data(), reinterpret_cast<const uint64_t *>(inc.data()), gamma.limbs, &s_), "zg_rrw_open");
+        // the two prefix-table sets of the split-eq structure, in HBM for the phase-1 rounds (table k starts at element 2^k - 1)
+        const size_t m = log_T / 2;
+        try {
+            d_out_.alloc(((size_t(2) << m) - 1) * 32);
+            d_in_.alloc(((size_t(2) << gruen_.num_x_in) - 1) * 32);
+            check(zg_fr_eq_prefix_tables_dev(reinterpret_cast<const uint64_t *>(gruen_.tau.data()), m, d_out_.u64(), nullptr), "zg_fr_eq_prefix_tables_dev");
+            check(zg_fr_eq_prefix_tables_dev(reinterpret_cast<const uint64_t *>(gruen_.tau.data() + m), gruen_.num_x_in, d_in_.u64(), nullptr), "zg_fr_eq_prefix_tables_dev");
+            check(zg_sync(), "zg_sync");  // the session reads the tables on its own stream
+        } catch (...) {
+            zg_rrw_close(s_);
+            throw;
+        }
+    }
+    Stage4GruenProver(const Stage4GruenProver &) = delete;
+    Stage4GruenProver &operator=(const Stage4GruenProver &) = delete;
+    ~Stage4GruenProver() { zg_rrw_close(s_); }
+
+    std::array<Fr, 4> computeRoundEvals(size_t round, const Fr &current_claim) {  // :1165-1190
+        if (round < p1_) {  // phase1ComputeMessage (:561-741)
+            size_t head_len = gruen_.current_index - std::min<size_t>(1, gruen_.current_index), m = gruen_.tau.size() / 2;
+            size_t ho = std::min(head_len, m), hi = head_len - ho;
+            size_t ko = std::min(ho, gruen_.E_out_vec.size() - 1), ki = std::min(hi, gruen_.E_in_vec.size() - 1);
+            check(zg_rrw_round_cycle_gruen(s_, d_out_.u64() + 4 * ((size_t(1) << ko) - 1), size_t(1) << ko, d_in_.u64() + 4 * ((size_t(1) << ki) - 1), size_t(1) << ki,
+                                           last_q_constant.limbs, last_q_quadratic.limbs), "zg_rrw_round_cycle_gruen");
+            return gruen_.computeCubicRoundPoly(last_q_constant, last_q_quadratic, current_claim);
+        }
+        if (round < p1_ + p2_ || current_T == 1) {  // phase2ComputeMessage (:764-852); phase 3 with a single cycle left (:955-1013)
+            Fr e0, e2;
+            check(zg_rrw_round_address(s_, e0.limbs, e2.limbs), "zg_rrw_round_address");
+            Fr e1 = current_claim.sub(e0), three = Fr::fromU64(3);
+            return {e0, e1, e2, e0.sub(three.mul(e1)).add(three.mul(e2))};  // the quadratic's p(3) (:841-850)
+        }
+        Fr e0, e2, e3;  // phase3ComputeMessage (:854-953)
+        check(zg_rrw_round_cycle(s_, e0.limbs, e2.limbs, e3.limbs), "zg_rrw_round_cycle");
+        return {e0, current_claim.sub(e0), e2, e3};
+    }
+    void bindChallenge(size_t round, const Fr &challenge) {  // :1047-1163, 1192-1216
+        if (round < p1_ || round >= p1_ + p2_) {
+            check(zg_rrw_bind_cycle(s_, challenge.limbs), "zg_rrw_bind_cycle");
+            current_T /= 2;
+            if (round < p1_) {
+                gruen_.bind(challenge);
+                if (round == p1_ - 1) {  // gruen_eq.merge (gruen_eq.zig:119-146)
+                    std::vector<Fr> eq = gruen_.getFullEqTable();
+                    check(zg_rrw_set_eq(s_, reinterpret_cast<const uint64_t *>(eq.data()), eq.size()), "zg_rrw_set_eq");
+                }
+            }
+        } else {
+            check(zg_rrw_bind_address(s_, challenge.limbs), "zg_rrw_bind_address");
+            current_K /= 2;
+        }
+    }
+    struct FinalClaims { Fr val_claim, rs1_ra_claim, rs2_ra_claim, rd_wa_claim, inc_claim; };
+    FinalClaims getFinalClaims() {  // :1219-1236
+        Fr f[7];
+        check(zg_rrw_final(s_, reinterpret_cast<uint64_t *>(f)), "zg_rrw_final");
+        return FinalClaims{f[0], f[3], f[4], f[1], f[5]};
+    }
+    std::array<Fr, 3> finalCheck() {  // (eq_scalar, combined, expected) as printed after the last round (:1196-1210)
+        Fr f[7];
+        check(zg_rrw_final(s_, reinterpret_cast<uint64_t *>(f)), "zg_rrw_final");
+        Fr comb = f[2].mul(f[0]).add(f[1].mul(f[0].add(f[5])));
+        return {f[6], comb, f[6].mul(comb)};
+    }
+
+private:
+    size_t p1_, p2_;
+    GruenSplitEqPolynomial gruen_;
+    zg_rrw_t s_ = nullptr;
+    DeviceMem d_out_, d_in_;
+};
+
 class InstructionLookupsClaimReductionProver {
 public:
     Fr current_claim;

@@ -45,6 +45,8 @@ SYMBOLS = [
     "zg_run_sumcheck", "zg_run_sumcheck_dev", "zg_sumcheck_open_spartan_dev",
     "zg_psc_open", "zg_psc_open_dev", "zg_psc_len", "zg_psc_tables", "zg_psc_round_evals", "zg_psc_round_expr", "zg_psc_set_points", "zg_psc_round_gruen", "zg_psc_bind", "zg_psc_read", "zg_psc_gather",
     "zg_psc_final", "zg_psc_close",
+    "zg_rrw_open", "zg_rrw_cycles", "zg_rrw_registers", "zg_rrw_round_cycle_gruen", "zg_rrw_set_eq", "zg_rrw_round_address", "zg_rrw_round_cycle",
+    "zg_rrw_bind_cycle", "zg_rrw_bind_address", "zg_rrw_final", "zg_rrw_close",
 ]
 # test / bench scaffolding of include/zolt_gpu_internal.h (not part of the drop-in boundary)
 INTERNAL_SYMBOLS = ["zg_profile_begin", "zg_profile_end", "zg_sharded_comm_sets_created"]
@@ -62,6 +64,8 @@ _lib.zg_sumcheck_len_sharded.restype = C.c_size_t
 _lib.zg_sumcheck_len.restype = C.c_size_t
 _lib.zg_psc_len.restype = C.c_size_t
 _lib.zg_psc_tables.restype = C.c_size_t
+_lib.zg_rrw_cycles.restype = C.c_size_t
+_lib.zg_rrw_registers.restype = C.c_size_t
 
 _u64p = C.POINTER(C.c_uint64)
 _u8p = C.POINTER(C.c_uint8)
@@ -818,6 +822,71 @@ class ProductSumcheckSession:
     def close(self):
         if self._h:
             _chk(_lib.zg_psc_close(self._h), "zg_psc_close")
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class RegistersRwSession:
+    """Stage4GruenProver's dense tables on the device (zg_rrw_*)"""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def open(cls, log_t, rs1, rs2, rd, reg_vals, inc, gamma):
+        rs1, rs2, rd = _c(rs1, np.uint8), _c(rs2, np.uint8), _c(rd, np.uint8)
+        reg_vals, inc, gamma = _c(reg_vals), _c(inc), _c(gamma)
+        T = 1 << log_t
+        assert rs1.size == rs2.size == rd.size == T and reg_vals.size == 32 * T and inc.size == 4 * T
+        h = C.c_void_p()
+        _chk(_lib.zg_rrw_open(C.c_size_t(log_t), _hb(rs1), _hb(rs2), _hb(rd), _h(reg_vals), _h(inc), _h(gamma), C.byref(h)), "zg_rrw_open")
+        return cls(h)
+
+    def cycles(self):
+        return int(_lib.zg_rrw_cycles(self._h))
+
+    def registers(self):
+        return int(_lib.zg_rrw_registers(self._h))
+
+    def round_cycle_gruen(self, d_e_out, n_out, d_e_in, n_in):
+        a, b = np.empty(4, dtype=np.uint64), np.empty(4, dtype=np.uint64)
+        _chk(_lib.zg_rrw_round_cycle_gruen(self._h, _d(d_e_out), C.c_size_t(n_out), _d(d_e_in), C.c_size_t(n_in), _h(a), _h(b)), "zg_rrw_round_cycle_gruen")
+        return a, b
+
+    def set_eq(self, eq):
+        eq = _c(eq)
+        _chk(_lib.zg_rrw_set_eq(self._h, _h(eq), C.c_size_t(eq.size // 4)), "zg_rrw_set_eq")
+
+    def round_address(self):
+        a, b = np.empty(4, dtype=np.uint64), np.empty(4, dtype=np.uint64)
+        _chk(_lib.zg_rrw_round_address(self._h, _h(a), _h(b)), "zg_rrw_round_address")
+        return a, b
+
+    def round_cycle(self):
+        a, b, c = (np.empty(4, dtype=np.uint64) for _ in range(3))
+        _chk(_lib.zg_rrw_round_cycle(self._h, _h(a), _h(b), _h(c)), "zg_rrw_round_cycle")
+        return a, b, c
+
+    def bind_cycle(self, r):
+        _chk(_lib.zg_rrw_bind_cycle(self._h, _h(_c(r))), "zg_rrw_bind_cycle")
+
+    def bind_address(self, r):
+        _chk(_lib.zg_rrw_bind_address(self._h, _h(_c(r))), "zg_rrw_bind_address")
+
+    def final(self):
+        """{val, rd_wa, ra, rs1_ra, rs2_ra, inc, eq}: entry [0][0] of every table"""
+        out = np.empty((7, 4), dtype=np.uint64)
+        _chk(_lib.zg_rrw_final(self._h, _h(out)), "zg_rrw_final")
+        return dict(zip(("val", "rd_wa", "ra", "rs1_ra", "rs2_ra", "inc", "eq"), out))
+
+    def close(self):
+        if self._h:
+            _chk(_lib.zg_rrw_close(self._h), "zg_rrw_close")
             self._h = None
 
     def __del__(self):
