@@ -233,6 +233,17 @@ ZG_API int zg_fr_dense_evaluate(const uint64_t *evals, size_t num_vars, const ui
 ZG_API int zg_fr_rows_mle(const uint64_t *rows, size_t n_rows, size_t k, const uint64_t *r, size_t v, uint64_t *out /* k*4 */);
 ZG_API int zg_fr_rows_mle_dev(const uint64_t *d_rows, size_t n_rows, size_t k, const uint64_t *r_host, size_t v, void *stream,
                        uint64_t *out /* host, k*4 */);
+/* StreamingOuterProver.materializeLinearPhasePolynomials (src/zkvm/spartan/streaming_outer.zig:258-372): per cycle, Az and Bz of the two
+ * constraint groups are Lagrange-weighted sums of the 19 uniform constraints' linear combinations (src/zkvm/r1cs/constraints.zig:248-531)
+ * — AFFINE maps of the cycle's R1CS inputs. Generic form, over the same cycle-major matrix zg_fr_rows_mle reads (k <= 64 columns):
+ *     table t, element i * g + j  =  C[t*g + j][k] + sum_{col < k} C[t*g + j][col] * rows[i*k + col]      i < n_rows
+ *                                 =  0                                                                     n_rows <= i < n_pad
+ * coeffs: (ntab * g) rows of k + 1 elements (the last one the constant), host memory; ntab * g <= 16. For the outer prover ntab = 2
+ * (Az, Bz), g = 2 (the group selector is the lowest variable), coefficient rows (az0, az1, bz0, bz1), n_pad = the padded trace length. */
+ZG_API int zg_fr_rows_affine(const uint64_t *rows, size_t n_rows, size_t k, const uint64_t *coeffs, size_t ntab, size_t g, size_t n_pad,
+                      uint64_t *const *tables /* ntab host pointers, n_pad * g elements each */);
+ZG_API int zg_fr_rows_affine_dev(const uint64_t *d_rows, size_t n_rows, size_t k, const uint64_t *coeffs_host, size_t ntab, size_t g, size_t n_pad,
+                          uint64_t *const *d_tables /* host array of ntab DEVICE pointers */, void *stream);
 /* DensePolynomial.bindLow, in place: t[i] = t[2i] + r*(t[2i+1]-t[2i]), len -> len/2 (src/poly/mod.zig:160-175) */
 ZG_API int zg_fr_bind_low(uint64_t *table, size_t len, const uint64_t r[4]);
 /* DensePolynomial.bindFirst: out[i] = (1-r)*t[i] + r*t[i+len/2] (src/poly/mod.zig:128-149) */

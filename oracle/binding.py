@@ -1379,3 +1379,162 @@ class Stage4GruenProver:
         eq = self.merged_eq[0]
         comb = _fadd(_fmul(self.ra[0, 0], self.val[0, 0]), _fmul(self.wa[0, 0], _fadd(self.val[0, 0], self.inc[0])))
         return eq, comb, _fmul(eq, comb)
+
+
+# ---------------------------------------------------------------- Spartan outer sumcheck, remaining rounds (linear phase)
+# StreamingOuterProver (src/zkvm/spartan/streaming_outer.zig) after the UniSkip first round: Az / Bz of the two constraint groups are
+# materialised per cycle, then every round is Gruen's (t'(0), t'(inf)) over adjacent pairs under the split-eq weights and a low-to-high
+# fold. The 19 uniform constraints are the published Jolt R1CS (src/zkvm/r1cs/constraints.zig:248-531), restated here as data:
+# condition * (left - right) = 0, each side a linear combination of the 43 per-cycle inputs (:39-92) plus a constant.
+R1CS_INPUT_NAMES = [  # R1CSInputIndex (:39-92)
+    "LeftInstructionInput", "RightInstructionInput", "Product", "WriteLookupOutputToRD", "WritePCtoRD", "ShouldBranch", "PC", "UnexpandedPC",
+    "Imm", "RamAddress", "Rs1Value", "Rs2Value", "RdWriteValue", "RamReadValue", "RamWriteValue", "LeftLookupOperand", "RightLookupOperand",
+    "NextUnexpandedPC", "NextPC", "NextIsVirtual", "NextIsFirstInSequence", "LookupOutput", "ShouldJump", "FlagAddOperands",
+    "FlagSubtractOperands", "FlagMultiplyOperands", "FlagLoad", "FlagStore", "FlagJump", "FlagWriteLookupOutputToRD", "FlagVirtualInstruction",
+    "FlagAssert", "FlagDoNotUpdateUnexpandedPC", "FlagAdvice", "FlagIsCompressed", "FlagIsFirstInSequence", "FlagIsRdNotZero", "FlagBranch",
+    "FlagIsNoop", "FlagLeftOperandIsRs1", "FlagLeftOperandIsPC", "FlagRightOperandIsRs2", "FlagRightOperandIsImm"]
+NUM_R1CS_INPUTS = len(R1CS_INPUT_NAMES)  # 43
+_R1 = {n: i for i, n in enumerate(R1CS_INPUT_NAMES)}
+
+
+def _lc(const=0, **terms):
+    return ([(_R1[k], v) for k, v in terms.items()], const)
+
+
+UNIFORM_CONSTRAINTS = [  # (condition, left, right), constraints.zig:248-531 in order
+    (_lc(FlagLoad=1, FlagStore=1), _lc(RamAddress=1), _lc(Rs1Value=1, Imm=1)),                                           # 0
+    (_lc(1, FlagLoad=-1, FlagStore=-1), _lc(RamAddress=1), _lc()),                                                      # 1
+    (_lc(FlagLoad=1), _lc(RamReadValue=1), _lc(RamWriteValue=1)),                                                       # 2
+    (_lc(FlagLoad=1), _lc(RamReadValue=1), _lc(RdWriteValue=1)),                                                        # 3
+    (_lc(FlagStore=1), _lc(Rs2Value=1), _lc(RamWriteValue=1)),                                                          # 4
+    (_lc(FlagAddOperands=1, FlagSubtractOperands=1, FlagMultiplyOperands=1), _lc(LeftLookupOperand=1), _lc()),          # 5
+    (_lc(1, FlagAddOperands=-1, FlagSubtractOperands=-1, FlagMultiplyOperands=-1), _lc(LeftLookupOperand=1), _lc(LeftInstructionInput=1)),  # 6
+    (_lc(FlagAddOperands=1), _lc(RightLookupOperand=1), _lc(LeftInstructionInput=1, RightInstructionInput=1)),          # 7
+    (_lc(FlagSubtractOperands=1), _lc(RightLookupOperand=1), _lc(1 << 64, LeftInstructionInput=1, RightInstructionInput=-1)),  # 8
+    (_lc(FlagMultiplyOperands=1), _lc(RightLookupOperand=1), _lc(Product=1)),                                           # 9
+    (_lc(1, FlagAddOperands=-1, FlagSubtractOperands=-1, FlagMultiplyOperands=-1, FlagAdvice=-1), _lc(RightLookupOperand=1), _lc(RightInstructionInput=1)),  # 10
+    (_lc(FlagAssert=1), _lc(LookupOutput=1), _lc(1)),                                                                   # 11
+    (_lc(WriteLookupOutputToRD=1), _lc(RdWriteValue=1), _lc(LookupOutput=1)),                                           # 12
+    (_lc(WritePCtoRD=1), _lc(RdWriteValue=1), _lc(4, UnexpandedPC=1, FlagIsCompressed=-2)),                             # 13
+    (_lc(ShouldJump=1), _lc(NextUnexpandedPC=1), _lc(LookupOutput=1)),                                                  # 14
+    (_lc(ShouldBranch=1), _lc(NextUnexpandedPC=1), _lc(UnexpandedPC=1, Imm=1)),                                         # 15
+    (_lc(1, ShouldBranch=-1, FlagJump=-1), _lc(NextUnexpandedPC=1), _lc(4, UnexpandedPC=1, FlagDoNotUpdateUnexpandedPC=-4, FlagIsCompressed=-2)),  # 16
+    (_lc(FlagVirtualInstruction=1), _lc(NextPC=1), _lc(1, PC=1)),                                                       # 17
+    (_lc(NextIsVirtual=1, NextIsFirstInSequence=-1), _lc(1), _lc(FlagDoNotUpdateUnexpandedPC=1)),                       # 18
+]
+FIRST_GROUP_INDICES = [1, 2, 3, 4, 5, 6, 11, 14, 17, 18]  # :537-548
+SECOND_GROUP_INDICES = [0, 7, 8, 9, 10, 12, 13, 15, 16]  # :553-563
+
+
+def lagrange_evals_symmetric(r, size=10):
+    """L_i(r), i < size, over the symmetric domain {-(size-1)/2, ...} = {-4..5} for size 10 (computeLagrangeEvalsAtR0,
+    streaming_outer.zig:1157-1213; LagrangePoly.evals of r1cs/univariate_skip.zig) -> (size, 4) Montgomery"""
+    rv, start = fr_to_int(r), -((size - 1) // 2)
+    out = []
+    for i in range(size):
+        num = den = 1
+        for j in range(size):
+            if j != i:
+                num = num * (rv - (start + j)) % _R_P
+                den = den * (i - j) % _R_P
+        out.append(fr_from_int(num * pow(den, _R_P - 2, _R_P) % _R_P))
+    return np.stack(out)
+
+
+def lagrange_kernel(x, y, size=10):
+    """K(x, y) = sum_i L_i(x) L_i(y) (LagrangePoly.lagrangeKernel, r1cs/univariate_skip.zig:296-312)"""
+    a, b = lagrange_evals_symmetric(x, size), lagrange_evals_symmetric(y, size)
+    return fr_from_int(sum(fr_to_int(u) * fr_to_int(v) for u, v in zip(a, b)) % _R_P)
+
+
+def _lc_eval(lc, w):
+    """LinearCombination.evaluate (constraints.zig:183-198) over all cycles at once: w (n, 43, 4) -> (n, 4)"""
+    terms, const = lc
+    n = w.shape[0]
+    acc = np.repeat(fr_from_int(const % _R_P).reshape(1, 4), n, axis=0)
+    for idx, coeff in terms:
+        scaled = _fmul(w[:, idx], fr_from_int(abs(coeff)))
+        acc = _fadd(acc, scaled) if coeff >= 0 else _fsub(acc, scaled)
+    return acc
+
+
+class StreamingOuterProver:
+    """the remaining rounds of StreamingOuterProver (streaming_outer.zig:120-212 init, 1135-1155 bindFirstRoundChallenge, 258-372
+    materializeLinearPhasePolynomials, 381-465 buildTPrimePoly, 481-491 computeTEvals, 1215-1281 computeRemainingRoundPoly, 1681-1717
+    bindRemainingRoundChallenge, 1723-1737 updateClaim). cycle_witnesses: (n, 43, 4); tau: num_cycle_vars + 2 challenges."""
+
+    def __init__(self, cycle_witnesses, tau, lagrange_tau_r0=None):
+        self.cycle_witnesses = _c(np.asarray(cycle_witnesses, dtype=np.uint64).reshape(-1, NUM_R1CS_INPUTS, 4))
+        n = self.cycle_witnesses.shape[0]
+        assert n > 0
+        self.padded_trace_len = 1
+        while self.padded_trace_len < n:
+            self.padded_trace_len *= 2
+        self.num_cycle_vars = self.padded_trace_len.bit_length() - 1
+        tau = _c(np.asarray(tau, dtype=np.uint64).reshape(-1, 4))
+        self.tau_high = tau[-1].copy()
+        self.split_eq = GruenSplitEq(tau[:-1], lagrange_tau_r0)  # tau_low (:165-167)
+        self.current_claim = fr_from_int(0)
+        self.current_round = 0
+        self.challenges = []
+        self.lagrange_evals_r0 = None
+        self.az = self.bz = None
+
+    def numRounds(self):  # :236-238
+        return 1 + self.num_cycle_vars
+
+    def bindFirstRoundChallenge(self, r0, uni_skip_claim):  # :1135-1155 (r0 is NOT bound in split_eq)
+        self.current_round = 1
+        self.current_claim = _c(uni_skip_claim).copy()
+        self.lagrange_evals_r0 = lagrange_evals_symmetric(r0, 10)
+
+    def materializeLinearPhasePolynomials(self):  # :258-372
+        e_out, e_in, _ = self.split_eq.getWindowEqTables(1)
+        poly_size = len(e_out) * len(e_in) * 2
+        w = self.cycle_witnesses
+        n = min(w.shape[0], poly_size // 2)
+        zero = np.zeros((poly_size, 4), dtype=np.uint64)
+        az, bz = zero.copy(), zero.copy()
+        for g, group in enumerate((FIRST_GROUP_INDICES, SECOND_GROUP_INDICES[:10])):
+            a = np.zeros((n, 4), dtype=np.uint64)
+            b = np.zeros((n, 4), dtype=np.uint64)
+            for t, ci in enumerate(group):
+                cond, left, right = UNIFORM_CONSTRAINTS[ci]
+                wt = self.lagrange_evals_r0[t]
+                a = _fadd(a, _fmul(_lc_eval(cond, w[:n]), wt))
+                b = _fadd(b, _fmul(_fsub(_lc_eval(left, w[:n]), _lc_eval(right, w[:n])), wt))
+            az[g:2 * n:2], bz[g:2 * n:2] = a, b
+        self.az, self.bz = az, bz
+
+    def _t_evals(self):  # buildTPrimePoly with window 1 (:381-465) projected by E_active = [1] (:481-491)
+        e_out, e_in, _ = self.split_eq.getWindowEqTables(1)
+        e_out, e_in = _c(e_out), _c(e_in)
+        bits = (len(e_in).bit_length() - 1) if len(e_in) > 1 else 0
+        n_i = len(e_out) * len(e_in)
+        i = np.arange(n_i)
+        live = self.az.shape[0]
+        pad = lambda t: np.concatenate([t, np.zeros((max(2 * n_i - live, 0), 4), dtype=np.uint64)])[:2 * n_i]
+        az, bz = pad(self.az), pad(self.bz)
+        weight = _fmul(e_out[i >> bits], e_in[i & ((1 << bits) - 1)])
+        t0 = _fsum(_fmul(_fmul(az[0::2], bz[0::2]), weight))
+        tinf = _fsum(_fmul(_fmul(_fsub(az[1::2], az[0::2]), _fsub(bz[1::2], bz[0::2])), weight))
+        return t0, tinf
+
+    def computeRemainingRoundPoly(self):  # :1215-1281
+        if self.current_round == 1 and self.az is None:
+            self.materializeLinearPhasePolynomials()
+        t0, tinf = self._t_evals()
+        self.last_t = (t0, tinf)
+        return self.split_eq.computeCubicRoundPoly(t0, tinf, self.current_claim)
+
+    def bindRemainingRoundChallenge(self, r):  # :1681-1717: split_eq first, then Az / Bz low-to-high
+        self.challenges.append(_c(r).copy())
+        self.split_eq.bind(r)
+        self.az, self.bz = fr_bind_low(self.az, r), fr_bind_low(self.bz, r)
+        self.current_round += 1
+
+    def updateClaim(self, round_poly, challenge):  # :1723-1737: the cubic through the four evaluations at the challenge
+        self.current_claim = raf_update_claim(round_poly, challenge)
+
+    def getFinalEval(self):  # :1740-1742
+        return self.current_claim

@@ -604,8 +604,50 @@ static int stage4_main(const char *path) {
     return 0;
 }
 
+// `test_host_mirror outer <file>`: zolt::StreamingOuterProver's remaining rounds on the instance the file describes (cycles, scaling, r0,
+// claim, tau, the 43 inputs of every cycle, the challenges) -> per round (t'(0), t'(inf)) and the four evaluations, then the final values.
+static int outer_main(const char *path) {
+    std::FILE *f = std::fopen(path, "r");
+    if (!f) { std::printf("cannot open %s\n", path); return 2; }
+    unsigned long long n, nv;
+    if (std::fscanf(f, "%llu %llu", &n, &nv) != 2) return 2;
+    Fr scale = read_fr(f), r0 = read_fr(f), claim = read_fr(f);
+    std::vector<Fr> tau;
+    for (size_t i = 0; i < nv + 2; i++) tau.push_back(read_fr(f));
+    std::vector<StreamingOuterProver::CycleInputs> w(n);
+    for (size_t i = 0; i < n; i++)
+        for (size_t k = 0; k < r1cs::NUM_INPUTS; k++) w[i][k] = read_fr(f);
+    std::vector<Fr> ch;
+    for (size_t i = 0; i < nv + 1; i++) ch.push_back(read_fr(f));
+    std::fclose(f);
+    StreamingOuterProver p(w, tau, &scale);
+    p.bindFirstRoundChallenge(r0, claim);
+    for (size_t rd = 0; rd < p.numRounds(); rd++) {
+        auto ev = p.computeRemainingRoundPoly();
+        std::printf("T");
+        print_fr(p.last_t_zero);
+        print_fr(p.last_t_infinity);
+        std::printf("\nE");
+        for (const Fr &x : ev) print_fr(x);
+        std::printf("\n");
+        p.updateClaim(ev, ch[rd]);
+        p.bindRemainingRoundChallenge(ch[rd]);
+    }
+    auto fin = p.finalAzBz();
+    std::printf("O");
+    for (const Fr &x : {fin[0], fin[1], p.getFinalEval(), p.split_eq.current_scalar}) print_fr(x);
+    std::printf("\n");
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (zg_init(0) != ZG_OK) { std::printf("zg_init failed: %s\n", zg_last_error()); return 2; }
+    if (argc >= 3 && !std::strcmp(argv[1], "outer")) {
+        int rc;
+        try { rc = outer_main(argv[2]); } catch (const std::exception &e) { std::printf("EXCEPTION: %s\n", e.what()); rc = 3; }
+        zg_shutdown();
+        return rc;
+    }
     if (argc >= 3 && !std::strcmp(argv[1], "stage4")) {
         int rc;
         try { rc = stage4_main(argv[2]); } catch (const std::exception &e) { std::printf("EXCEPTION: %s\n", e.what()); rc = 3; }

@@ -145,3 +145,43 @@ def test_cpp_stage4_registers_mirror(tmp_path, golden_dir):
             assert [ob.fr_to_int(x) for x in rounds[0]] == [le(fx["round0"]["p%d_le" % t]) for t in range(4)]
             assert ob.fr_to_int(final[8]) == le(fx["final"]["claim_le"]) == le(fx["final"]["expected_le"])
             assert ob.fr_to_int(final[5]) == le(fx["final"]["eq_scalar_le"]) and ob.fr_to_int(final[6]) == le(fx["final"]["combined_le"])
+
+
+@pytest.mark.gpu
+def test_cpp_streaming_outer_mirror(tmp_path, golden_dir):
+    """zolt::StreamingOuterProver (compiled host code: constraint table, Lagrange weights, zg_fr_rows_affine_dev + a product session)
+    against the restatement of src/zkvm/spartan/streaming_outer.zig's remaining rounds on random cycle inputs: (t'(0), t'(inf)), the four
+    evaluations of every round, and the final Az, Bz, claim and split-eq scalar, bit for bit."""
+    import numpy as np
+    from oracle import binding as ob
+    from tests import util as U
+    from tests.test_transcript_host import outer_true_claim, random_cycle_witnesses
+    exe = os.path.join(ROOT, "tests", "cpp", "test_host_mirror")
+    subprocess.check_call(["make", "-C", os.path.dirname(exe), "test_host_mirror"])
+    for k, n in enumerate((1, 37, 512)):
+        w = random_cycle_witnesses(300 + n, n)
+        nv = max(n - 1, 0).bit_length()
+        r = ob.f_to_mont(ob.FR, U.random_raw256(400 + n, 3 * nv + 8))
+        tau, r0, scale, chals = r[:nv + 2], r[nv + 2], r[nv + 3], r[nv + 4:nv + 4 + nv + 1]
+        o = ob.StreamingOuterProver(w, tau, scale)
+        o.bindFirstRoundChallenge(r0, ob.fr_from_int(0))
+        o.materializeLinearPhasePolynomials()
+        o.current_claim = outer_true_claim(o)
+        path = str(tmp_path / f"outer_{k}.txt")
+        with open(path, "w") as f:
+            f.write(f"{n} {nv}\n{_hexfr(scale)}\n{_hexfr(r0)}\n{_hexfr(o.current_claim)}\n")
+            f.write("".join(_hexfr(x) + "\n" for x in tau) + "".join(_hexfr(x) + "\n" for x in w.reshape(-1, 4)) + "".join(_hexfr(x) + "\n" for x in chals))
+        res = subprocess.run([exe, "outer", path], capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+        parse = lambda tag, cnt: [np.array([int(x, 16) for x in l.split()[1:1 + 4 * cnt]], dtype=np.uint64).reshape(cnt, 4)
+                                  for l in res.stdout.splitlines() if l.startswith(tag + " ")]
+        ts, evs, fin = parse("T", 2), parse("E", 4), parse("O", 4)[0]
+        assert len(ts) == len(evs) == nv + 1
+        for rd in range(nv + 1):
+            we = o.computeRemainingRoundPoly()
+            assert np.array_equal(ts[rd][0], o.last_t[0]) and np.array_equal(ts[rd][1], o.last_t[1]), (k, rd)
+            assert np.array_equal(evs[rd], we), (k, rd)
+            o.updateClaim(we, chals[rd])
+            o.bindRemainingRoundChallenge(chals[rd])
+        assert np.array_equal(fin[0], o.az[0]) and np.array_equal(fin[1], o.bz[0]) and np.array_equal(fin[2], o.current_claim)
+        assert np.array_equal(fin[3], o.split_eq.current_scalar)

@@ -1,0 +1,142 @@
+"""StreamingOuterProver's remaining rounds (src/zkvm/spartan/streaming_outer.zig) on the device: Az / Bz materialised by one affine-map
+launch over the cycle witnesses (zg_fr_rows_affine), Gruen rounds and folds in a product session — against the restatement (oracle/)
+and the reference's captured Stage-1 run."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+from tests import util as U
+from tests.test_transcript_host import check_stage1_outer_chain_of_the_captured_run, outer_true_claim, random_cycle_witnesses
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api():
+    from zolt_amd import api, lib
+    lib.init(0)
+    return api
+
+
+def test_captured_stage1_chain_with_the_mirrors_host_algebra(api, golden_dir):
+    """the mirror's Lagrange weights / kernel, split-eq scalar (prefix tables from the device) and cubic on the reference's printed run"""
+    fx = json.load(open(os.path.join(golden_dir, "stage1_outer_rounds.json")))
+    check_stage1_outer_chain_of_the_captured_run(fx, api.GruenSplitEqPolynomial, api.lagrangeEvals, api.lagrangeKernel, api.fr_from_int, api.fr_to_int,
+                                                 api.cubicAtPoint)
+
+
+def test_constraint_table_matches_the_restatement(api):
+    assert api.UNIFORM_CONSTRAINTS == ob.UNIFORM_CONSTRAINTS and list(api.FIRST_GROUP_INDICES) == ob.FIRST_GROUP_INDICES
+    assert list(api.SECOND_GROUP_INDICES) == ob.SECOND_GROUP_INDICES and api.NUM_R1CS_INPUTS == ob.NUM_R1CS_INPUTS
+
+
+@pytest.mark.parametrize("k,ntab,g,n_rows,n_pad", [(43, 2, 2, 100, 128), (1, 1, 1, 1, 1), (64, 4, 4, 65, 65), (7, 3, 1, 0, 4), (43, 2, 2, 5000, 8192)])
+def test_rows_affine_against_integers(api, k, ntab, g, n_rows, n_pad):
+    """zg_fr_rows_affine (host pointers) on random matrices with sparse coefficient rows, a zero row and a constant-only row"""
+    from zolt_amd import lib
+    rng = np.random.default_rng(k * 1000 + n_rows)
+    rows = ob.f_to_mont(ob.FR, rng.integers(0, 1 << 63, size=(max(n_rows, 1) * k, 4), dtype=np.uint64)).reshape(-1, k, 4)[:n_rows]
+    nout = ntab * g
+    coeff_int = [[int(rng.integers(0, 1 << 62)) ** 4 % ob._R_P if rng.random() < 0.4 else 0 for _ in range(k + 1)] for _ in range(nout)]
+    coeff_int[0] = [0] * (k + 1)
+    if nout > 1:
+        coeff_int[1] = [0] * k + [12345]
+    coeffs = np.stack([np.stack([ob.fr_from_int(v) for v in row]) for row in coeff_int])
+    outs = lib.fr_rows_affine(rows, coeffs, ntab, g, n_pad)
+    assert len(outs) == ntab and all(o.shape == (n_pad * g, 4) for o in outs)
+    check = sorted(set([0, n_rows // 2, max(n_rows - 1, 0)])) if n_rows else []
+    for i in check:
+        vals = [ob.fr_to_int(x) for x in rows[i]]
+        for c in range(nout):
+            want = (coeff_int[c][k] + sum(a * b for a, b in zip(coeff_int[c][:k], vals))) % ob._R_P
+            assert ob.fr_to_int(outs[c // g][i * g + c % g]) == want, (i, c)
+    for o in outs:
+        assert not o[n_rows * g:].any()
+    # the whole result against the vectorised oracle arithmetic
+    if n_rows:
+        for c in range(nout):
+            acc = np.repeat(coeffs[c, k].reshape(1, 4), n_rows, axis=0)
+            for col in range(k):
+                if coeff_int[c][col]:
+                    acc = ob._fadd(acc, ob._fmul(rows[:, col], coeffs[c, col]))
+            assert np.array_equal(outs[c // g][c % g:n_rows * g:g], acc), c
+
+
+@pytest.mark.parametrize("n_cycles", [1, 3, 256, 5000])
+def test_rounds_against_the_restatement(api, n_cycles):
+    """materialised Az / Bz, every round's (t'(0), t'(inf)) and four evaluations, the claim chain and the final point, bit for bit; trace
+    lengths that are not powers of two, a single cycle"""
+    w = random_cycle_witnesses(n_cycles + 7, n_cycles)
+    T = 1
+    while T < n_cycles:
+        T *= 2
+    nv = T.bit_length() - 1
+    r = ob.f_to_mont(ob.FR, U.random_raw256(90 + n_cycles, 3 * nv + 8))
+    tau, r0, scale, chals = r[:nv + 2], r[nv + 2], r[nv + 3], r[nv + 4:]
+    o = ob.StreamingOuterProver(w, tau, scale)
+    d = api.StreamingOuterProver(w, tau, scale)
+    o.bindFirstRoundChallenge(r0, ob.fr_from_int(0))
+    d.bindFirstRoundChallenge(r0, ob.fr_from_int(0))
+    o.materializeLinearPhasePolynomials()
+    d.materializeLinearPhasePolynomials()
+    assert np.array_equal(d._s.read(0), o.az) and np.array_equal(d._s.read(1), o.bz)
+    o.current_claim = outer_true_claim(o)
+    d.current_claim = o.current_claim.copy()
+    assert d.numRounds() == o.numRounds() == nv + 1
+    for k in range(o.numRounds()):
+        eo, ed = o.computeRemainingRoundPoly(), d.computeRemainingRoundPoly()
+        assert np.array_equal(o.last_t[0], d.last_t[0]) and np.array_equal(o.last_t[1], d.last_t[1]), k
+        assert np.array_equal(eo, ed), k
+        assert np.array_equal(ob.f_add(ob.FR, eo[0:1], eo[1:2])[0], o.current_claim), k
+        for p in (o, d):
+            p.updateClaim(eo, chals[k])
+            p.bindRemainingRoundChallenge(chals[k])
+        assert np.array_equal(o.current_claim, d.current_claim)
+    az, bz = d.finalAzBz()
+    assert np.array_equal(az, o.az[0]) and np.array_equal(bz, o.bz[0])
+    assert np.array_equal(ob._fmul(ob._fmul(az, bz), d.split_eq.current_scalar).reshape(4), d.getFinalEval())
+    d.deinit()
+
+
+def test_full_size_claim_chain(api):
+    """2^20 cycles (1.4 GB of witnesses): the materialised tables against the restatement on a sample of cycles, then the size-independent
+    property — from the true sum (a device dot product of eq, Az, Bz) every round's s(0) + s(1) is the claim and the last claim is
+    scalar * Az * Bz at the bound point."""
+    from zolt_amd import lib
+    nv = 20
+    n = (1 << nv) - 12345
+    rng = np.random.default_rng(2)
+    u = rng.integers(0, 1 << 63, size=(n, ob.NUM_R1CS_INPUTS), dtype=np.uint64)
+    flags = [i for i, name in enumerate(ob.R1CS_INPUT_NAMES) if name.startswith(("Flag", "Should", "Write", "NextIs"))]
+    u[:, flags] &= np.uint64(1)
+    l = np.zeros((n * ob.NUM_R1CS_INPUTS, 4), dtype=np.uint64)
+    l[:, 0] = u.reshape(-1)
+    w = lib.field_op(lib.FR, lib.OP_TO_MONT, l).reshape(n, ob.NUM_R1CS_INPUTS, 4)
+    del l, u
+    r = ob.f_to_mont(ob.FR, U.random_raw256(77, 3 * nv + 8))
+    tau, r0, scale, chals = r[:nv + 2], r[nv + 2], r[nv + 3], r[nv + 4:]
+    d = api.StreamingOuterProver(w, tau, scale)
+    d.bindFirstRoundChallenge(r0, api.fr_from_int(0))
+    d.materializeLinearPhasePolynomials()
+    az, bz = d._s.read(0), d._s.read(1)
+    sample = np.concatenate([np.arange(0, 64), rng.integers(0, n, size=128), np.arange(n - 64, n)])
+    o = ob.StreamingOuterProver(w[sample], tau[:10], scale)  # (only its per-cycle map is used: 256 cycles)
+    o.bindFirstRoundChallenge(r0, ob.fr_from_int(0))
+    o.materializeLinearPhasePolynomials()
+    idx = np.stack([2 * sample, 2 * sample + 1], axis=1).reshape(-1)
+    assert np.array_equal(az[idx], o.az) and np.array_equal(bz[idx], o.bz)
+    assert not az[2 * n:].any() and not bz[2 * n:].any()
+    eq = lib.fr_eq_table(tau[:-1], scale)
+    d.current_claim = ob._fsum(ob._fmul(ob._fmul(az, bz), eq))
+    del az, bz, eq
+    for k in range(d.numRounds()):
+        ev = d.computeRemainingRoundPoly()
+        assert np.array_equal(ob.f_add(ob.FR, ev[0:1], ev[1:2])[0], d.current_claim), k
+        d.updateClaim(ev, chals[k])
+        d.bindRemainingRoundChallenge(chals[k])
+    fa, fb = d.finalAzBz()
+    assert np.array_equal(ob._fmul(ob._fmul(fa, fb), d.split_eq.current_scalar).reshape(4), d.getFinalEval())
+    d.deinit()

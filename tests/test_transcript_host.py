@@ -5,6 +5,7 @@ squeeze sequence, including the rate boundary at 136 bytes."""
 import hashlib
 
 import numpy as np
+import pytest
 
 from oracle import binding as ob
 from oracle import pymodel as pm
@@ -573,3 +574,104 @@ def test_stage4_registers_read_write_checking_of_the_captured_run(golden_dir):
     for j, h in enumerate(fx["inc_first4_le8"]):
         assert ob.fr_to_int(p.inc[j]).to_bytes(32, "little")[:8].hex() == h
     check_stage4_against_the_captured_run(p, fx, gr, ob.fr_from_int, ob.fr_to_int)
+
+
+def check_stage1_outer_chain_of_the_captured_run(fx, gruen_cls, lagrange_evals, lagrange_kernel, fr_from_int, fr_to_int, update_claim):
+    """what the reference printed about the nine remaining rounds of its StreamingOuterProver (tests/golden/stage1_outer_rounds.json)
+    against a split-eq implementation (oracle restatement or a mirror's host algebra): Lagrange weights and kernel, every round's
+    s(0) = l(0) q(0), s(1) = l(1) q(1), their sum, the batched coefficient c0, Gruen's cubic rebuilt from (q(0), t_inf, claim) against
+    the logged coefficients — t_inf recovered from s(2), so s(3) is a genuine check of the cubic's form —, the next claim, and the
+    scalar after nine binds."""
+    P = ob._R_P
+    be, le = (lambda h: int(h, 16)), (lambda h: int.from_bytes(bytes.fromhex(h), "little"))
+    tau = np.array(fx["tau_limbs"], dtype=np.uint64)  # raw Montgomery limbs [0, 0, lo, hi]
+    r0 = fr_from_int(be(fx["r0_be"]))
+    assert [fr_to_int(x) for x in lagrange_evals(r0)] == [be(h) for h in fx["w_be"]]
+    k0 = lagrange_kernel(r0, tau[-1])
+    assert [int(x) for x in k0] == fx["lagrange_tau_r0_limbs"]
+    g = gruen_cls(tau[:-1], k0)
+    b = be(fx["batching_coeff_be"])
+    assert be(fx["uni_skip_claim_be"]) * b % P == le(fx["initial_claim_le"]) and be(fx["rounds"][0]["previous_claim_be"]) == be(fx["uni_skip_claim_be"])
+    inv = lambda x: pow(x, P - 2, P)
+    for k, r in enumerate(fx["rounds"]):
+        assert g.current_index == r["index"]
+        q0, q1, prev = be(r["q0_be"]), be(r["q1_be"]), be(r["previous_claim_be"])
+        cs, t = fr_to_int(g.current_scalar), fr_to_int(tau[g.current_index - 1])
+        l0, l1 = cs * (1 - t) % P, cs * t % P
+        s0, s1 = l0 * q0 % P, l1 * q1 % P
+        assert (s0 + s1) % P == prev, k
+        c0, c2, c3 = (le(r[n]) * inv(b) % P for n in ("c0_le", "c2_le", "c3_le"))
+        assert c0 == s0, k
+        c1 = (prev - 2 * c0 - c2 - c3) % P
+        assert (c0 + c1 + c2 + c3) % P == s1, k
+        s2, s3 = (c0 + 2 * c1 + 4 * c2 + 8 * c3) % P, (c0 + 3 * c1 + 9 * c2 + 27 * c3) % P
+        l2 = (l0 + 2 * (l1 - l0)) % P
+        e = (s2 * inv(l2) - 2 * q1 + q0) * inv(2) % P  # q(2) = 2 q(1) - q(0) + 2 e
+        ev = g.computeCubicRoundPoly(fr_from_int(q0), fr_from_int(e), fr_from_int(prev))
+        assert [fr_to_int(x) for x in ev] == [s0, s1, s2, s3], k
+        ch = fr_from_int(le(r["challenge_le"]))
+        nxt = fr_to_int(update_claim(np.stack(ev), ch))
+        if k + 1 < len(fx["rounds"]):
+            assert nxt == be(fx["rounds"][k + 1]["previous_claim_be"]), k
+        g.bind(ch)
+    assert fr_to_int(g.current_scalar) == le(fx["final_eq_factor_le"]) and [int(x) for x in g.current_scalar] == fx["final_eq_factor_limbs"]
+
+
+def test_stage1_outer_claim_chain_of_the_captured_run(golden_dir):
+    """StreamingOuterProver's remaining rounds on the reference's own Stage-1 run (9 rounds, 256 cycles): everything the log prints around
+    the two sums of a round, held against the restatement's Lagrange weights, split-eq scalar and cubic (oracle/binding.py)."""
+    import json
+    import os
+    fx = json.load(open(os.path.join(golden_dir, "stage1_outer_rounds.json")))
+    check_stage1_outer_chain_of_the_captured_run(fx, ob.GruenSplitEq, ob.lagrange_evals_symmetric, ob.lagrange_kernel, ob.fr_from_int, ob.fr_to_int,
+                                                 ob.raf_update_claim)
+
+
+def random_cycle_witnesses(seed, n):
+    """(n, 43, 4) R1CS inputs: 0/1 flags, 64-bit values — not a satisfying assignment (the prover's algebra does not need one)"""
+    rng = np.random.default_rng(seed)
+    u = rng.integers(0, 1 << 63, size=(n, ob.NUM_R1CS_INPUTS), dtype=np.uint64)
+    flags = [i for i, name in enumerate(ob.R1CS_INPUT_NAMES) if name.startswith(("Flag", "Should", "Write", "NextIs"))]
+    u[:, flags] = rng.integers(0, 2, size=(n, len(flags)), dtype=np.uint64)
+    return ob.f_from_u64(ob.FR, u.reshape(-1)).reshape(n, ob.NUM_R1CS_INPUTS, 4)
+
+
+def outer_true_claim(p):
+    """sum over (cycle, group) of eq(tau_low, .) * scaling * Az * Bz for a prover whose Az / Bz are materialised — the claim under which
+    every remaining round is a sumcheck round"""
+    eq = p.split_eq.getFullEqTable()
+    return ob._fsum(ob._fmul(ob._fmul(p.az, p.bz), eq[:p.az.shape[0]]))
+
+
+@pytest.mark.parametrize("n_cycles", [1, 5, 64, 200])
+def test_streaming_outer_restatement_is_a_sumcheck(n_cycles):
+    """the restatement on random inputs: materialised Az / Bz against a direct evaluation of the constraint table, every round
+    s(0) + s(1) = claim from the true sum, and the last claim = scalar * Az * Bz at the bound point"""
+    w = random_cycle_witnesses(n_cycles, n_cycles)
+    T = 1
+    while T < n_cycles:
+        T *= 2
+    nv = T.bit_length() - 1
+    r = ob.f_to_mont(ob.FR, U.random_raw256(50 + n_cycles, 3 * nv + 8))
+    tau, r0, scale, chals = r[:nv + 2], r[nv + 2], r[nv + 3], r[nv + 4:]
+    p = ob.StreamingOuterProver(w, tau, scale)
+    p.bindFirstRoundChallenge(r0, ob.fr_from_int(0))
+    p.materializeLinearPhasePolynomials()
+    # one cycle, one group, evaluated term by term with Python integers
+    wts = [ob.fr_to_int(x) for x in p.lagrange_evals_r0]
+    cyc = n_cycles - 1
+    vals = [ob.fr_to_int(x) for x in w[cyc]]
+    ev = lambda lc: (lc[1] + sum(c * vals[i] for i, c in lc[0])) % ob._R_P
+    for g, group in enumerate((ob.FIRST_GROUP_INDICES, ob.SECOND_GROUP_INDICES)):
+        az = sum(wts[t] * ev(ob.UNIFORM_CONSTRAINTS[ci][0]) for t, ci in enumerate(group)) % ob._R_P
+        bz = sum(wts[t] * (ev(ob.UNIFORM_CONSTRAINTS[ci][1]) - ev(ob.UNIFORM_CONSTRAINTS[ci][2])) for t, ci in enumerate(group)) % ob._R_P
+        assert ob.fr_to_int(p.az[2 * cyc + g]) == az and ob.fr_to_int(p.bz[2 * cyc + g]) == bz
+    assert not p.az[2 * n_cycles:].any() and p.az.shape[0] == 2 * T
+    p.current_claim = outer_true_claim(p)
+    for k in range(p.numRounds()):
+        ev4 = p.computeRemainingRoundPoly()
+        assert np.array_equal(ob.f_add(ob.FR, ev4[0:1], ev4[1:2])[0], p.current_claim), k
+        p.updateClaim(ev4, chals[k])
+        p.bindRemainingRoundChallenge(chals[k])
+    fin = ob._fmul(ob._fmul(p.az[0], p.bz[0]), p.split_eq.current_scalar)
+    assert np.array_equal(fin.reshape(4), p.getFinalEval())

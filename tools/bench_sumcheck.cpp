@@ -302,6 +302,79 @@ int main(int argc, char **argv) {
         std::printf("\"ram_read_write_checking_rounds_per_s\": %.1f, \"ram_read_write_checking_ms_incl_setup\": %.4f, \"ram_read_write_checking_accesses\": %zu, ",
                     rwc_rounds / t_rwc, t_rwc / (reps > 5 ? 5 : reps) * 1e3, acc.size());
     }
+    // Stage4GruenProver (src/zkvm/spartan/stage4_gruen_prover.zig), RegistersReadWriteChecking: 128 registers x 2^min(v, 18) cycles (five dense
+    // tables of 128 * T elements built and folded on the device), phases T/2 cycle, 7 register, T/2 cycle variables, Keccak transcript
+    {
+        const size_t lt = v > 18 ? 18 : (size_t)v, T4 = size_t(1) << lt;
+        std::vector<TraceStep> steps(T4);
+        static const uint32_t ops[11] = {0x13, 0x03, 0x67, 0x1B, 0x33, 0x3B, 0x23, 0x63, 0x37, 0x6F, 0x17};
+        for (auto &st : steps) {
+            uint64_t z = splitmix();
+            st.instruction = ops[z % 11] | (uint32_t)(((z >> 8) & 31) << 7) | (uint32_t)(((z >> 16) & 31) << 15) | (uint32_t)(((z >> 24) & 31) << 20);
+            st.rd_value = splitmix();
+            st.is_noop = false;
+        }
+        std::vector<Fr> rc(r.begin(), r.begin() + lt);
+        Fr gamma = Fr::fromU64(splitmix());
+        double t_s4 = 0, t_s4_rounds = 0;
+        const int n4 = reps > 3 ? 3 : reps;
+        for (int rep = -1; rep < n4; rep++) {
+            auto t0 = clk::now();
+            Stage4GruenProver p(steps, gamma, rc, lt / 2 ? lt / 2 : 1, 7);
+            auto t1 = clk::now();
+            Transcript tr("Jolt");
+            Fr claim = Fr::zero();
+            for (size_t rd = 0; rd < p.num_rounds; rd++) {
+                auto ev = p.computeRoundEvals(rd, claim);
+                for (auto &e : ev) tr.appendScalar("s4", e);
+                Fr ch = tr.challengeScalar("s4_r");
+                claim = cubicAtPoint(ev, ch);
+                p.bindChallenge(rd, ch);
+            }
+            (void)p.getFinalClaims();
+            if (rep >= 0) { t_s4 += std::chrono::duration<double>(clk::now() - t0).count(); t_s4_rounds += std::chrono::duration<double>(clk::now() - t1).count(); }
+        }
+        std::printf("\"stage4_registers_log_t\": %zu, \"stage4_registers_ms_incl_setup\": %.4f, \"stage4_registers_rounds_ms\": %.4f, \"stage4_registers_rounds_per_s\": %.1f, ",
+                    lt, t_s4 / n4 * 1e3, t_s4_rounds / n4 * 1e3, n4 * (double)(7 + lt) / t_s4_rounds);
+    }
+    // StreamingOuterProver's remaining rounds (src/zkvm/spartan/streaming_outer.zig): 2^min(v, 20) cycles x 43 inputs, Az / Bz materialised
+    // by one launch, 1 + log T Gruen rounds with a Keccak transcript
+    {
+        const size_t lt = v > 20 ? 20 : (size_t)v, To = size_t(1) << lt;
+        std::vector<StreamingOuterProver::CycleInputs> w(To);
+        for (auto &row : w)
+            for (size_t k = 0; k < r1cs::NUM_INPUTS; k++) row[k] = k >= 23 ? Fr::fromU64(splitmix() & 1) : Fr::fromU64(splitmix());
+        std::vector<Fr> tau(lt + 2);
+        for (auto &x : tau) x = Fr::fromU64(splitmix());
+        Fr r0 = Fr::fromU64(splitmix()), scale = Fr::fromU64(splitmix());
+        double t_up = 0, t_mat = 0, t_rounds = 0;
+        const int no = reps > 3 ? 3 : reps;
+        for (int rep = -1; rep < no; rep++) {
+            auto t0 = clk::now();
+            StreamingOuterProver p(w, tau, &scale);
+            p.bindFirstRoundChallenge(r0, Fr::zero());
+            auto t1 = clk::now();
+            p.materializeLinearPhasePolynomials();
+            auto t2 = clk::now();
+            Transcript tr("Jolt");
+            for (size_t rd = 0; rd < p.numRounds(); rd++) {
+                auto ev = p.computeRemainingRoundPoly();
+                for (auto &e : ev) tr.appendScalar("so", e);
+                Fr ch = tr.challengeScalar("so_r");
+                p.updateClaim(ev, ch);
+                p.bindRemainingRoundChallenge(ch);
+            }
+            (void)p.finalAzBz();
+            auto t3 = clk::now();
+            if (rep >= 0) {
+                t_up += std::chrono::duration<double>(t1 - t0).count();
+                t_mat += std::chrono::duration<double>(t2 - t1).count();
+                t_rounds += std::chrono::duration<double>(t3 - t2).count();
+            }
+        }
+        std::printf("\"outer_log_t\": %zu, \"outer_upload_ms\": %.4f, \"outer_materialize_ms\": %.4f, \"outer_rounds_ms\": %.4f, \"outer_rounds_per_s\": %.1f, ", lt,
+                    t_up / no * 1e3, t_mat / no * 1e3, t_rounds / no * 1e3, no * (double)(lt + 1) / t_rounds);
+    }
     std::printf("\"val_evaluation_rounds_per_s\": %.1f, \"val_evaluation_ms\": %.4f, \"product_remainder_rounds_per_s\": %.1f, "
                 "\"product_remainder_ms\": %.4f, ", reps * v / t_val, t_val / reps * 1e3, reps * v / t_prod, t_prod / reps * 1e3);
     std::printf("\"lasso_log_K16_rounds_per_s\": %.1f, \"lasso_ms_whole_protocol_incl_setup\": %.4f, ", reps * (16 + v) / t_lasso, t_lasso / reps * 1e3);

@@ -55,8 +55,8 @@ def zig_type(ctype, array):
     el = SCALARS[base]
     if stars == 0:
         return el
-    if stars == 2:  # array of pointers to arrays (scalar batches)
-        return f"?[*]const ?[*]const {el}"
+    if stars == 2:  # array of pointers to arrays (scalar batches; output tables when the pointed-to elements are not const)
+        return f"?[*]const ?[*]const {el}" if const else f"?[*]const ?[*]{el}"
     if base in ("int", "size_t") and not const:
         return f"?*{el}"  # single out-parameter
     return f"?[*]const {el}" if const else f"?[*]{el}"

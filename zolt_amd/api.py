@@ -1959,6 +1959,162 @@ class RamReadWriteCheckingProver:
         self.gruen_eq.deinit()
 
 
+# the 19 uniform R1CS constraints (src/zkvm/r1cs/constraints.zig:248-531; the published Jolt R1CS): condition * (left - right) = 0, each side
+# [(input index, coefficient)...] + constant over the 43 per-cycle inputs (R1CSInputIndex, :39-92)
+NUM_R1CS_INPUTS = 43
+_I = {n: i for i, n in enumerate((
+    "LeftInstructionInput RightInstructionInput Product WriteLookupOutputToRD WritePCtoRD ShouldBranch PC UnexpandedPC Imm RamAddress Rs1Value "
+    "Rs2Value RdWriteValue RamReadValue RamWriteValue LeftLookupOperand RightLookupOperand NextUnexpandedPC NextPC NextIsVirtual "
+    "NextIsFirstInSequence LookupOutput ShouldJump FlagAddOperands FlagSubtractOperands FlagMultiplyOperands FlagLoad FlagStore FlagJump "
+    "FlagWriteLookupOutputToRD FlagVirtualInstruction FlagAssert FlagDoNotUpdateUnexpandedPC FlagAdvice FlagIsCompressed FlagIsFirstInSequence "
+    "FlagIsRdNotZero FlagBranch FlagIsNoop FlagLeftOperandIsRs1 FlagLeftOperandIsPC FlagRightOperandIsRs2 FlagRightOperandIsImm").split())}
+
+
+def _lc(const=0, **terms):
+    return ([(_I[k], v) for k, v in terms.items()], const)
+
+
+UNIFORM_CONSTRAINTS = [
+    (_lc(FlagLoad=1, FlagStore=1), _lc(RamAddress=1), _lc(Rs1Value=1, Imm=1)),
+    (_lc(1, FlagLoad=-1, FlagStore=-1), _lc(RamAddress=1), _lc()),
+    (_lc(FlagLoad=1), _lc(RamReadValue=1), _lc(RamWriteValue=1)),
+    (_lc(FlagLoad=1), _lc(RamReadValue=1), _lc(RdWriteValue=1)),
+    (_lc(FlagStore=1), _lc(Rs2Value=1), _lc(RamWriteValue=1)),
+    (_lc(FlagAddOperands=1, FlagSubtractOperands=1, FlagMultiplyOperands=1), _lc(LeftLookupOperand=1), _lc()),
+    (_lc(1, FlagAddOperands=-1, FlagSubtractOperands=-1, FlagMultiplyOperands=-1), _lc(LeftLookupOperand=1), _lc(LeftInstructionInput=1)),
+    (_lc(FlagAddOperands=1), _lc(RightLookupOperand=1), _lc(LeftInstructionInput=1, RightInstructionInput=1)),
+    (_lc(FlagSubtractOperands=1), _lc(RightLookupOperand=1), _lc(1 << 64, LeftInstructionInput=1, RightInstructionInput=-1)),
+    (_lc(FlagMultiplyOperands=1), _lc(RightLookupOperand=1), _lc(Product=1)),
+    (_lc(1, FlagAddOperands=-1, FlagSubtractOperands=-1, FlagMultiplyOperands=-1, FlagAdvice=-1), _lc(RightLookupOperand=1), _lc(RightInstructionInput=1)),
+    (_lc(FlagAssert=1), _lc(LookupOutput=1), _lc(1)),
+    (_lc(WriteLookupOutputToRD=1), _lc(RdWriteValue=1), _lc(LookupOutput=1)),
+    (_lc(WritePCtoRD=1), _lc(RdWriteValue=1), _lc(4, UnexpandedPC=1, FlagIsCompressed=-2)),
+    (_lc(ShouldJump=1), _lc(NextUnexpandedPC=1), _lc(LookupOutput=1)),
+    (_lc(ShouldBranch=1), _lc(NextUnexpandedPC=1), _lc(UnexpandedPC=1, Imm=1)),
+    (_lc(1, ShouldBranch=-1, FlagJump=-1), _lc(NextUnexpandedPC=1), _lc(4, UnexpandedPC=1, FlagDoNotUpdateUnexpandedPC=-4, FlagIsCompressed=-2)),
+    (_lc(FlagVirtualInstruction=1), _lc(NextPC=1), _lc(1, PC=1)),
+    (_lc(NextIsVirtual=1, NextIsFirstInSequence=-1), _lc(1), _lc(FlagDoNotUpdateUnexpandedPC=1)),
+]
+FIRST_GROUP_INDICES = (1, 2, 3, 4, 5, 6, 11, 14, 17, 18)  # constraints.zig:537-548
+SECOND_GROUP_INDICES = (0, 7, 8, 9, 10, 12, 13, 15, 16)  # :553-563
+
+
+def lagrangeEvals(r, size=10):
+    """L_i(r) over the symmetric domain {-(size-1)/2 ..} (LagrangePoly.evals; computeLagrangeEvalsAtR0, streaming_outer.zig:1157-1213)"""
+    rv, start = fr_to_int(r), -((size - 1) // 2)
+    out = []
+    for i in range(size):
+        num = den = 1
+        for j in range(size):
+            if j != i:
+                num = num * (rv - (start + j)) % R_MOD
+                den = den * (i - j) % R_MOD
+        out.append(fr_from_int(num * pow(den, R_MOD - 2, R_MOD) % R_MOD))
+    return np.stack(out)
+
+
+def lagrangeKernel(x, y, size=10):
+    """LagrangePoly.lagrangeKernel (src/zkvm/r1cs/univariate_skip.zig:296-312): sum_i L_i(x) L_i(y)"""
+    return fr_from_int(sum(fr_to_int(a) * fr_to_int(b) for a, b in zip(lagrangeEvals(x, size), lagrangeEvals(y, size))) % R_MOD)
+
+
+class StreamingOuterProver:
+    """StreamingOuterProver's remaining rounds (src/zkvm/spartan/streaming_outer.zig: init :120-212, bindFirstRoundChallenge :1135-1155,
+    materializeLinearPhasePolynomials :258-372, computeRemainingRoundPoly :1215-1281, bindRemainingRoundChallenge :1681-1717, updateClaim
+    :1723-1737). The cycle witnesses go to the device once; Az / Bz of both constraint groups are ONE launch over them (the Lagrange-weighted
+    constraint sums are an affine map of a cycle's 43 inputs: zg_fr_rows_affine_dev), and live on as a two-table product session: a round
+    is Gruen's (t'(0), t'(inf)) under the split-eq prefix tables (zg_psc_round_gruen) and a fold of both tables (zg_psc_bind). The
+    split-eq scalar, the cubic and the claim are host algebra, as in the reference."""
+
+    def __init__(self, cycle_witnesses, tau, lagrange_tau_r0=None):
+        w = np.ascontiguousarray(cycle_witnesses, dtype=np.uint64).reshape(-1, NUM_R1CS_INPUTS, 4)
+        self.num_cycles = w.shape[0]
+        assert self.num_cycles > 0  # error.EmptyTrace (:147-149)
+        self.padded_trace_len = 1
+        while self.padded_trace_len < self.num_cycles:
+            self.padded_trace_len *= 2
+        self.num_cycle_vars = self.padded_trace_len.bit_length() - 1
+        tau = np.ascontiguousarray(tau, dtype=np.uint64).reshape(-1, 4)
+        assert tau.shape[0] == self.num_cycle_vars + 2
+        self.tau_high = tau[-1].copy()
+        self.split_eq = GruenSplitEqPolynomial(tau[:-1], lagrange_tau_r0)
+        self._d_rows = lib.DeviceBuffer.from_host(w)
+        self.current_claim = fr_from_int(0)
+        self.current_round = 0
+        self.challenges = []
+        self.lagrange_evals_r0 = None
+        self._s = None
+        self.last_t = None
+
+    def numRounds(self):
+        return 1 + self.num_cycle_vars
+
+    def bindFirstRoundChallenge(self, r0, uni_skip_claim):
+        """r0 is not bound in split_eq: its weight is the initial scalar (:1135-1155)"""
+        self.current_round = 1
+        self.current_claim = np.ascontiguousarray(uni_skip_claim, dtype=np.uint64).copy()
+        self.lagrange_evals_r0 = lagrangeEvals(r0, 10)
+
+    def constraintMatrix(self):
+        """(4, 44, 4): rows az(group 0), az(group 1), bz(group 0), bz(group 1) as affine maps of a cycle's inputs — sum_t L_t(r0) *
+        condition_t and sum_t L_t(r0) * (left_t - right_t) over the group's constraints (:300-345), the constant in the last column"""
+        wts = [fr_to_int(x) for x in self.lagrange_evals_r0]
+        m = [[0] * (NUM_R1CS_INPUTS + 1) for _ in range(4)]
+        for g, group in enumerate((FIRST_GROUP_INDICES, SECOND_GROUP_INDICES)):
+            for t, ci in enumerate(group):
+                cond, left, right = UNIFORM_CONSTRAINTS[ci]
+                for row, lc, sign in ((g, cond, 1), (2 + g, left, 1), (2 + g, right, -1)):
+                    for idx, c in lc[0]:
+                        m[row][idx] = (m[row][idx] + sign * wts[t] * c) % R_MOD
+                    m[row][NUM_R1CS_INPUTS] = (m[row][NUM_R1CS_INPUTS] + sign * wts[t] * lc[1]) % R_MOD
+        return np.stack([np.stack([fr_from_int(v) for v in row]) for row in m])
+
+    def materializeLinearPhasePolynomials(self):
+        """Az[2 i + group], Bz[2 i + group] for every cycle i (zero past the trace), straight into a device session (:258-372)"""
+        n2 = 2 * self.padded_trace_len
+        d_az, d_bz = lib.DeviceBuffer(n2 * 32), lib.DeviceBuffer(n2 * 32)
+        lib.fr_rows_affine_dev(self._d_rows.ptr, min(self.num_cycles, self.padded_trace_len), NUM_R1CS_INPUTS, self.constraintMatrix(), 2, 2,
+                               self.padded_trace_len, [d_az.ptr, d_bz.ptr])
+        self._s = lib.ProductSumcheckSession.open_dev([d_az.ptr, d_bz.ptr], n2)
+        lib.sync()
+        d_az.free()
+        d_bz.free()
+
+    def computeRemainingRoundPoly(self):
+        """[s(0), s(1), s(2), s(3)] (:1215-1281): t'(0), t'(inf) of buildTPrimePoly / computeTEvals with window 1, then Gruen's cubic"""
+        if self.current_round == 1 and self._s is None:
+            self.materializeLinearPhasePolynomials()
+        d_out, n_out, d_in, n_in = self.split_eq.getWindowEqTablesDev(1)
+        t0, t_inf = self._s.round_gruen((0, 1), d_out, n_out, d_in, n_in)
+        self.last_t = (t0, t_inf)
+        return self.split_eq.computeCubicRoundPoly(t0, t_inf, self.current_claim)
+
+    def bindRemainingRoundChallenge(self, r):
+        """split_eq first, then Az / Bz low-to-high (:1681-1717)"""
+        r = np.ascontiguousarray(r, dtype=np.uint64)
+        self.challenges.append(r.copy())
+        self.split_eq.bind(r)
+        self._s.bind(r)
+        self.current_round += 1
+
+    def updateClaim(self, round_poly, challenge):
+        self.current_claim = cubicAtPoint(round_poly, challenge)
+
+    def getFinalEval(self):
+        return self.current_claim
+
+    def finalAzBz(self):
+        """(Az, Bz) at the bound point once every variable is bound"""
+        f = self._s.final()
+        return f[0], f[1]
+
+    def deinit(self):
+        if self._s is not None:
+            self._s.close()
+        self._d_rows.free()
+        self.split_eq.deinit()
+
+
 class Stage4GruenProver:
     """Stage4GruenProver (src/zkvm/spartan/stage4_gruen_prover.zig:65-1240), the RegistersReadWriteChecking sumcheck: five dense
     K = 128 x T tables (val, rd_wa, ra = gamma rs1_ra + gamma^2 rs2_ra, rs1_ra, rs2_ra), inc[T] and the eq structure over the cycles;

@@ -467,6 +467,51 @@ __global__ void __launch_bounds__(256) rows_mle_finish_kernel(const uint64_t *pa
     if (threadIdx.x == 0) fe_store(out + 4 * (size_t)blockIdx.x, g0);
 }
 
+// Affine maps of a cycle-major matrix: out[c][i] = coeff[c][k] + sum_{col < k} coeff[c][col] * rows[i][col] for nout <= 16 outputs —
+// what StreamingOuterProver.materializeLinearPhasePolynomials computes per cycle for (Az, Bz) x (first, second constraint group)
+// (src/zkvm/spartan/streaming_outer.zig:258-372): the Lagrange-weighted sums of the constraints' condition / left - right linear
+// combinations ARE one affine map of the cycle's R1CS inputs each. Wave w of a block <-> output w, lane <-> cycle: the column list of
+// an output (its non-zero coefficients only) and the prescaled coefficients are wave-uniform, a lane reads just the elements of its
+// row that the output uses; the terms are summed limb-wise and reduced once. Output c goes to table c / g, element i * g + c % g
+// (g interleaved outputs per table: Az[2 i + group]); rows i in [n_rows, n_pad) are written as zero.
+constexpr unsigned ROWS_AFFINE_MAX_OUT = 16, ROWS_AFFINE_MAX_K = 64;
+struct RowsAffineArgs {
+    uint64_t *tab[ROWS_AFFINE_MAX_OUT];  // per OUTPUT: its table's base
+    uint8_t nnz[ROWS_AFFINE_MAX_OUT];
+};
+// coeff: nout x (k + 1) canonical elements -> pre: the same entries as prescaled 29-bit limbs (9 words each)
+__global__ void __launch_bounds__(256) rows_affine_prep_kernel(const uint64_t *coeff, uint32_t n, uint32_t *pre) {
+    uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    F29 f = fr29_prescale(fe_load<FrParams>(coeff + 4 * (size_t)e));
+#pragma unroll
+    for (int i = 0; i < 9; i++) pre[9 * (size_t)e + i] = f.l[i];
+}
+__global__ void __launch_bounds__(1024) rows_affine_kernel(const uint64_t *rows, size_t n_rows, uint32_t k, const uint64_t *coeff, const uint32_t *pre,
+                                                           const uint8_t *cols /* nout x 64 */, RowsAffineArgs a, uint32_t g, size_t n_pad) {
+    const uint32_t c = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t i = (size_t)blockIdx.x * 64 + lane;
+    if (i >= n_pad) return;
+    Fr val = Fr::zero();
+    if (i < n_rows) {
+        const uint64_t *row = rows + 4 * i * k;
+        const uint32_t *pc = pre + 9 * (size_t)c * (k + 1);
+        const uint8_t *cl = cols + 64 * c;
+        Acc29 lazy = acc29_zero();
+        const uint32_t nnz = a.nnz[c];  // <= 64 = FR29_ACC_MAX: one reduction
+        for (uint32_t j = 0; j < nnz; j++) {
+            const uint32_t col = cl[j];
+            F29 y;
+#pragma unroll
+            for (int w = 0; w < 9; w++) y.l[w] = pc[9 * col + w];
+            acc29_add(lazy, fr29_chain_mul(fr29_in(fe_load<FrParams>(row + 4 * col)), y));
+        }
+        val = fe_load<FrParams>(coeff + 4 * ((size_t)c * (k + 1) + k));  // the constant
+        if (nnz) val = fe_add(val, acc29_reduce(lazy));
+    }
+    fe_store(a.tab[c] + 4 * (i * g + c % g), val);
+}
+
 // reduce the per-block partial pairs to sums[0..8)
 __global__ void __launch_bounds__(256) sc_finish_kernel(const uint64_t *partials, uint32_t nblocks, uint64_t *sums, uint64_t *flag,
                                                         uint64_t seq) {
@@ -1134,6 +1179,74 @@ int zg_fr_rows_mle(const uint64_t *rows, size_t n_rows, size_t k, const uint64_t
     SyncGuard sync(st);
     if (n_rows) ZG_HIP(hipMemcpyAsync(s_rows.p, rows, n_rows * k * 32, hipMemcpyHostToDevice, st));
     return zg_fr_rows_mle_dev(s_rows.as<uint64_t>(), n_rows, k, r, v, st, out);
+}
+
+int zg_fr_rows_affine_dev(const uint64_t *d_rows, size_t n_rows, size_t k, const uint64_t *coeffs, size_t ntab, size_t g, size_t n_pad,
+                          uint64_t *const *d_tables, void *stream) {
+    ZG_INIT();
+    const size_t nout = ntab * g;
+    if (!coeffs || !d_tables || k == 0 || k > ROWS_AFFINE_MAX_K || ntab == 0 || g == 0 || nout > ROWS_AFFINE_MAX_OUT || n_pad < n_rows || (n_rows && !d_rows)) {
+        set_error("zg_fr_rows_affine: 1..64 columns, 1..16 outputs (tables x interleave), n_pad >= n_rows");
+        return ZG_ERR_INVALID;
+    }
+    if (n_pad == 0) return ZG_OK;
+    hipStream_t st = pick_stream(stream);
+    // per output: the columns with a non-zero coefficient
+    std::vector<uint8_t> cols(64 * nout, 0);
+    RowsAffineArgs a{};
+    for (size_t c = 0; c < nout; c++) {
+        if (!d_tables[c / g]) {
+            set_error("zg_fr_rows_affine: null table");
+            return ZG_ERR_INVALID;
+        }
+        a.tab[c] = d_tables[c / g];
+        unsigned nnz = 0;
+        for (size_t col = 0; col < k; col++) {
+            const uint64_t *e = coeffs + 4 * (c * (k + 1) + col);
+            if (e[0] | e[1] | e[2] | e[3]) cols[64 * c + nnz++] = (uint8_t)col;
+        }
+        a.nnz[c] = (uint8_t)nnz;
+    }
+    const size_t n_coeff = nout * (k + 1);
+    Scratch s_coeff(n_coeff * 32), s_pre(n_coeff * 36), s_cols(64 * nout);
+    if (!s_coeff.p || !s_pre.p || !s_cols.p) return ZG_ERR_NOMEM;
+    SyncGuard sync(st);
+    ZG_HIP(hipMemcpyAsync(s_coeff.p, coeffs, n_coeff * 32, hipMemcpyHostToDevice, st));
+    ZG_HIP(hipMemcpyAsync(s_cols.p, cols.data(), cols.size(), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(rows_affine_prep_kernel, dim3(div_up(n_coeff, 256)), dim3(256), 0, st, s_coeff.as<uint64_t>(), (uint32_t)n_coeff, s_pre.as<uint32_t>());
+    hipLaunchKernelGGL(rows_affine_kernel, dim3(div_up(n_pad, 64)), dim3((unsigned)(64 * nout)), 0, st, d_rows, n_rows, (uint32_t)k, s_coeff.as<uint64_t>(),
+                       s_pre.as<uint32_t>(), s_cols.as<uint8_t>(), a, (uint32_t)g, n_pad);
+    ZG_HIP(hipGetLastError());
+    ZG_HIP(hipStreamSynchronize(st));  // the coefficient buffers go back to the cache; `cols` is a local
+    sync.dismiss();
+    return ZG_OK;
+}
+
+int zg_fr_rows_affine(const uint64_t *rows, size_t n_rows, size_t k, const uint64_t *coeffs, size_t ntab, size_t g, size_t n_pad, uint64_t *const *tables) {
+    ZG_INIT();
+    if (!tables || ntab == 0 || ntab > ROWS_AFFINE_MAX_OUT || g == 0 || k == 0 || k > ROWS_AFFINE_MAX_K || n_pad < n_rows || (n_rows && !rows)) {
+        set_error("zg_fr_rows_affine: 1..64 columns, 1..16 outputs (tables x interleave), n_pad >= n_rows");
+        return ZG_ERR_INVALID;
+    }
+    if (n_pad == 0) return ZG_OK;
+    hipStream_t st = lib_stream();
+    Scratch s_rows((n_rows ? n_rows : 1) * k * 32), s_out(ntab * n_pad * g * 32);
+    if (!s_rows.p || !s_out.p) return ZG_ERR_NOMEM;
+    SyncGuard sync(st);
+    if (n_rows) ZG_HIP(hipMemcpyAsync(s_rows.p, rows, n_rows * k * 32, hipMemcpyHostToDevice, st));
+    uint64_t *d_tab[ROWS_AFFINE_MAX_OUT];
+    for (size_t t = 0; t < ntab; t++) d_tab[t] = s_out.as<uint64_t>() + 4 * t * n_pad * g;
+    ZG_TRY(zg_fr_rows_affine_dev(s_rows.as<uint64_t>(), n_rows, k, coeffs, ntab, g, n_pad, d_tab, st));
+    for (size_t t = 0; t < ntab; t++) {
+        if (!tables[t]) {
+            set_error("zg_fr_rows_affine: null table");
+            return ZG_ERR_INVALID;
+        }
+        ZG_HIP(hipMemcpyAsync(tables[t], d_tab[t], n_pad * g * 32, hipMemcpyDeviceToHost, st));
+    }
+    ZG_HIP(hipStreamSynchronize(st));
+    sync.dismiss();
+    return ZG_OK;
 }
 
 int zg_fr_spartan_combine_dev(const uint64_t *d_eq, const uint64_t *d_az, const uint64_t *d_bz, const uint64_t *d_cz, size_t n,

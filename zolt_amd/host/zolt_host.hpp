@@ -964,6 +964,10 @@ public:
         for (auto *t : tables) ptrs.push_back(reinterpret_cast<const uint64_t *>(t->data()));
         check(zg_psc_open(ptrs.data(), ptrs.size(), tables.empty() ? 0 : tables[0]->size(), &s_), "zg_psc_open");
     }
+    struct OnDevice {};  // tables already in HBM (the session copies them): zg_psc_open_dev
+    ProductSumcheckSession(OnDevice, const std::vector<const uint64_t *> &d_tables, size_t n) {
+        check(zg_psc_open_dev(d_tables.data(), d_tables.size(), n, nullptr, &s_), "zg_psc_open_dev");
+    }
     ~ProductSumcheckSession() { zg_psc_close(s_); }
     ProductSumcheckSession(const ProductSumcheckSession &) = delete;
     size_t len() const { return zg_psc_len(s_); }
@@ -1063,6 +1067,7 @@ public:
         d_in_.alloc(((size_t(2) << split_eq.num_x_in) - 1) * 32);
         check(zg_fr_eq_prefix_tables_dev(reinterpret_cast<const uint64_t *>(tau_low.data()), m, d_out_.u64(), nullptr), "prefix");
         check(zg_fr_eq_prefix_tables_dev(reinterpret_cast<const uint64_t *>(tau_low.data() + m), split_eq.num_x_in, d_in_.u64(), nullptr), "prefix");
+        check(zg_sync(), "zg_sync");  // the session reads the tables on its own stream
     }
     bool roundEvals(std::array<Fr, 4> &evals) {
         if (s_.len() < 2) return false;
@@ -1450,6 +1455,182 @@ private:
 };
 
 // InstructionLookupsClaimReductionProver's loop (src/zkvm/claim_reductions/instruction_lookups.zig:146-284)
+// ---------------------------------------------------------------- Spartan outer sumcheck, remaining rounds
+// The 19 uniform R1CS constraints (src/zkvm/r1cs/constraints.zig:248-531, the published Jolt R1CS): condition * (left - right) = 0 with
+// each side a linear combination of the 43 per-cycle inputs (R1CSInputIndex, :39-92) plus a constant.
+namespace r1cs {
+constexpr size_t NUM_INPUTS = 43;
+enum In : int {
+    LeftInstructionInput, RightInstructionInput, Product, WriteLookupOutputToRD, WritePCtoRD, ShouldBranch, PC, UnexpandedPC, Imm, RamAddress,
+    Rs1Value, Rs2Value, RdWriteValue, RamReadValue, RamWriteValue, LeftLookupOperand, RightLookupOperand, NextUnexpandedPC, NextPC, NextIsVirtual,
+    NextIsFirstInSequence, LookupOutput, ShouldJump, FlagAddOperands, FlagSubtractOperands, FlagMultiplyOperands, FlagLoad, FlagStore, FlagJump,
+    FlagWriteLookupOutputToRD, FlagVirtualInstruction, FlagAssert, FlagDoNotUpdateUnexpandedPC, FlagAdvice, FlagIsCompressed, FlagIsFirstInSequence
+};
+struct Term { int input; int coeff; };
+struct LC {
+    std::vector<Term> terms;
+    bool two_pow_64 = false;  // the one constant that does not fit an int (constraint 8)
+    int constant = 0;
+};
+struct Constraint { LC condition, left, right; };
+inline LC lc(std::vector<Term> t, int c = 0) { return LC{std::move(t), false, c}; }
+inline const std::vector<Constraint> &uniformConstraints() {
+    static const std::vector<Constraint> k = [] {
+        LC sub_rhs = lc({{LeftInstructionInput, 1}, {RightInstructionInput, -1}});
+        sub_rhs.two_pow_64 = true;
+        return std::vector<Constraint>{
+            {lc({{FlagLoad, 1}, {FlagStore, 1}}), lc({{RamAddress, 1}}), lc({{Rs1Value, 1}, {Imm, 1}})},
+            {lc({{FlagLoad, -1}, {FlagStore, -1}}, 1), lc({{RamAddress, 1}}), lc({})},
+            {lc({{FlagLoad, 1}}), lc({{RamReadValue, 1}}), lc({{RamWriteValue, 1}})},
+            {lc({{FlagLoad, 1}}), lc({{RamReadValue, 1}}), lc({{RdWriteValue, 1}})},
+            {lc({{FlagStore, 1}}), lc({{Rs2Value, 1}}), lc({{RamWriteValue, 1}})},
+            {lc({{FlagAddOperands, 1}, {FlagSubtractOperands, 1}, {FlagMultiplyOperands, 1}}), lc({{LeftLookupOperand, 1}}), lc({})},
+            {lc({{FlagAddOperands, -1}, {FlagSubtractOperands, -1}, {FlagMultiplyOperands, -1}}, 1), lc({{LeftLookupOperand, 1}}), lc({{LeftInstructionInput, 1}})},
+            {lc({{FlagAddOperands, 1}}), lc({{RightLookupOperand, 1}}), lc({{LeftInstructionInput, 1}, {RightInstructionInput, 1}})},
+            {lc({{FlagSubtractOperands, 1}}), lc({{RightLookupOperand, 1}}), sub_rhs},
+            {lc({{FlagMultiplyOperands, 1}}), lc({{RightLookupOperand, 1}}), lc({{Product, 1}})},
+            {lc({{FlagAddOperands, -1}, {FlagSubtractOperands, -1}, {FlagMultiplyOperands, -1}, {FlagAdvice, -1}}, 1), lc({{RightLookupOperand, 1}}),
+             lc({{RightInstructionInput, 1}})},
+            {lc({{FlagAssert, 1}}), lc({{LookupOutput, 1}}), lc({}, 1)},
+            {lc({{WriteLookupOutputToRD, 1}}), lc({{RdWriteValue, 1}}), lc({{LookupOutput, 1}})},
+            {lc({{WritePCtoRD, 1}}), lc({{RdWriteValue, 1}}), lc({{UnexpandedPC, 1}, {FlagIsCompressed, -2}}, 4)},
+            {lc({{ShouldJump, 1}}), lc({{NextUnexpandedPC, 1}}), lc({{LookupOutput, 1}})},
+            {lc({{ShouldBranch, 1}}), lc({{NextUnexpandedPC, 1}}), lc({{UnexpandedPC, 1}, {Imm, 1}})},
+            {lc({{ShouldBranch, -1}, {FlagJump, -1}}, 1), lc({{NextUnexpandedPC, 1}}),
+             lc({{UnexpandedPC, 1}, {FlagDoNotUpdateUnexpandedPC, -4}, {FlagIsCompressed, -2}}, 4)},
+            {lc({{FlagVirtualInstruction, 1}}), lc({{NextPC, 1}}), lc({{PC, 1}}, 1)},
+            {lc({{NextIsVirtual, 1}, {NextIsFirstInSequence, -1}}), lc({}, 1), lc({{FlagDoNotUpdateUnexpandedPC, 1}})},
+        };
+    }();
+    return k;
+}
+constexpr int FIRST_GROUP[10] = {1, 2, 3, 4, 5, 6, 11, 14, 17, 18};  // :537-548
+constexpr int SECOND_GROUP[9] = {0, 7, 8, 9, 10, 12, 13, 15, 16};    // :553-563
+inline Fr fromInt(int v) { return v >= 0 ? Fr::fromU64((uint64_t)v) : Fr::zero().sub(Fr::fromU64((uint64_t)(-(int64_t)v))); }
+}  // namespace r1cs
+
+// L_i(r) over the symmetric domain {-(size-1)/2, ...} (LagrangePoly.evals; computeLagrangeEvalsAtR0, streaming_outer.zig:1157-1213)
+inline std::vector<Fr> lagrangeEvals(const Fr &r, size_t size = 10) {
+    const int start = -(int)((size - 1) / 2);
+    std::vector<Fr> out(size);
+    for (size_t i = 0; i < size; i++) {
+        Fr num = Fr::one(), den = Fr::one(), inv;
+        for (size_t j = 0; j < size; j++) {
+            if (j == i) continue;
+            num = num.mul(r.sub(r1cs::fromInt(start + (int)j)));
+            den = den.mul(r1cs::fromInt((int)i - (int)j));
+        }
+        out[i] = den.inverse(inv) ? num.mul(inv) : Fr::zero();
+    }
+    return out;
+}
+// LagrangePoly.lagrangeKernel (src/zkvm/r1cs/univariate_skip.zig:296-312)
+inline Fr lagrangeKernel(const Fr &x, const Fr &y, size_t size = 10) {
+    auto a = lagrangeEvals(x, size), b = lagrangeEvals(y, size);
+    Fr acc = Fr::zero();
+    for (size_t i = 0; i < size; i++) acc = acc.add(a[i].mul(b[i]));
+    return acc;
+}
+
+// StreamingOuterProver's remaining rounds (src/zkvm/spartan/streaming_outer.zig: :120-212, 1135-1155, 258-372, 1215-1281, 1681-1737): the
+// cycle witnesses are uploaded once, Az / Bz of both constraint groups are ONE affine-map launch over them (zg_fr_rows_affine_dev) into a
+// two-table product session; a round is zg_psc_round_gruen + zg_psc_bind, the split-eq scalar / cubic / claim are host algebra.
+class StreamingOuterProver {
+public:
+    using CycleInputs = std::array<Fr, r1cs::NUM_INPUTS>;  // R1CSCycleInputs.values
+    Fr current_claim = Fr::zero(), last_t_zero = Fr::zero(), last_t_infinity = Fr::zero();
+    size_t current_round = 0, num_cycle_vars = 0, padded_trace_len = 1;
+    GruenSplitEqPolynomial split_eq;
+    std::vector<Fr> challenges, lagrange_evals_r0;
+
+    StreamingOuterProver(const std::vector<CycleInputs> &cycle_witnesses, const std::vector<Fr> &tau, const Fr *lagrange_tau_r0 = nullptr)
+        : split_eq(std::vector<Fr>(tau.begin(), tau.end() - (tau.empty() ? 0 : 1)), lagrange_tau_r0), num_cycles_(cycle_witnesses.size()) {
+        if (cycle_witnesses.empty()) throw std::invalid_argument("StreamingOuterProver: empty trace");  // error.EmptyTrace
+        while (padded_trace_len < num_cycles_) padded_trace_len <<= 1, num_cycle_vars++;
+        if (tau.size() != num_cycle_vars + 2) throw std::invalid_argument("StreamingOuterProver: tau has num_cycle_vars + 2 challenges");
+        d_rows_.alloc(num_cycles_ * r1cs::NUM_INPUTS * 32);
+        check(zg_memcpy_h2d(d_rows_.p, cycle_witnesses.data(), num_cycles_ * r1cs::NUM_INPUTS * 32), "zg_memcpy_h2d");
+        const size_t m = split_eq.tau.size() / 2;
+        d_out_.alloc(((size_t(2) << m) - 1) * 32);
+        d_in_.alloc(((size_t(2) << split_eq.num_x_in) - 1) * 32);
+        check(zg_fr_eq_prefix_tables_dev(reinterpret_cast<const uint64_t *>(split_eq.tau.data()), m, d_out_.u64(), nullptr), "zg_fr_eq_prefix_tables_dev");
+        check(zg_fr_eq_prefix_tables_dev(reinterpret_cast<const uint64_t *>(split_eq.tau.data() + m), split_eq.num_x_in, d_in_.u64(), nullptr), "zg_fr_eq_prefix_tables_dev");
+        check(zg_sync(), "zg_sync");
+    }
+    size_t numRounds() const { return 1 + num_cycle_vars; }
+    void bindFirstRoundChallenge(const Fr &r0, const Fr &uni_skip_claim) {  // r0 is not bound in split_eq (:1135-1155)
+        current_round = 1;
+        current_claim = uni_skip_claim;
+        lagrange_evals_r0 = lagrangeEvals(r0, 10);
+    }
+    // rows az(group 0), az(group 1), bz(group 0), bz(group 1) as affine maps of a cycle's inputs, the constant last (:300-345)
+    std::vector<Fr> constraintMatrix() const {
+        const size_t W = r1cs::NUM_INPUTS + 1;
+        std::vector<Fr> m(4 * W, Fr::zero());
+        const Fr two64 = Fr::fromU64(uint64_t(1) << 32).mul(Fr::fromU64(uint64_t(1) << 32));
+        auto add = [&](size_t row, const r1cs::LC &l, const Fr &w, bool negate) {
+            for (const auto &t : l.terms) {
+                Fr v = w.mul(r1cs::fromInt(negate ? -t.coeff : t.coeff));
+                m[row * W + t.input] = m[row * W + t.input].add(v);
+            }
+            Fr c = r1cs::fromInt(l.constant);
+            if (l.two_pow_64) c = c.add(two64);
+            c = w.mul(c);
+            m[row * W + r1cs::NUM_INPUTS] = negate ? m[row * W + r1cs::NUM_INPUTS].sub(c) : m[row * W + r1cs::NUM_INPUTS].add(c);
+        };
+        const auto &cs = r1cs::uniformConstraints();
+        for (size_t t = 0; t < 10; t++) {
+            const auto &c0 = cs[r1cs::FIRST_GROUP[t]];
+            add(0, c0.condition, lagrange_evals_r0[t], false);
+            add(2, c0.left, lagrange_evals_r0[t], false);
+            add(2, c0.right, lagrange_evals_r0[t], true);
+            if (t < 9) {
+                const auto &c1 = cs[r1cs::SECOND_GROUP[t]];
+                add(1, c1.condition, lagrange_evals_r0[t], false);
+                add(3, c1.left, lagrange_evals_r0[t], false);
+                add(3, c1.right, lagrange_evals_r0[t], true);
+            }
+        }
+        return m;
+    }
+    void materializeLinearPhasePolynomials() {  // Az[2 i + group], Bz[2 i + group], zero past the trace (:258-372)
+        const size_t n2 = 2 * padded_trace_len;
+        DeviceMem d_az(n2 * 32), d_bz(n2 * 32);
+        std::vector<Fr> m = constraintMatrix();
+        uint64_t *tabs[2] = {d_az.u64(), d_bz.u64()};
+        check(zg_fr_rows_affine_dev(d_rows_.u64(), std::min(num_cycles_, padded_trace_len), r1cs::NUM_INPUTS, reinterpret_cast<const uint64_t *>(m.data()), 2, 2,
+                                    padded_trace_len, tabs, nullptr), "zg_fr_rows_affine_dev");
+        s_.reset(new ProductSumcheckSession(ProductSumcheckSession::OnDevice{}, {d_az.u64(), d_bz.u64()}, n2));
+        check(zg_sync(), "zg_sync");  // the session holds its own copies before the two buffers are released
+    }
+    std::array<Fr, 4> computeRemainingRoundPoly() {  // :1215-1281
+        if (current_round == 1 && !s_) materializeLinearPhasePolynomials();
+        auto w = split_eq.getWindowEqTables(0, 1);
+        size_t n_out = w.E_out->size(), n_in = w.E_in->size();
+        auto t = s_->roundGruen({0, 1}, d_out_.u64() + 4 * (n_out - 1), n_out, d_in_.u64() + 4 * (n_in - 1), n_in);
+        last_t_zero = t[0];
+        last_t_infinity = t[1];
+        return split_eq.computeCubicRoundPoly(t[0], t[1], current_claim);
+    }
+    void bindRemainingRoundChallenge(const Fr &r) {  // split_eq first, then Az / Bz low-to-high (:1681-1717)
+        challenges.push_back(r);
+        split_eq.bind(r);
+        s_->bind(r);
+        current_round++;
+    }
+    void updateClaim(const std::array<Fr, 4> &round_poly, const Fr &challenge) { current_claim = cubicAtPoint(round_poly, challenge); }
+    Fr getFinalEval() const { return current_claim; }
+    std::array<Fr, 2> finalAzBz() {
+        auto f = s_->final();
+        return {f[0], f[1]};
+    }
+
+private:
+    size_t num_cycles_;
+    DeviceMem d_rows_, d_out_, d_in_;
+    std::unique_ptr<ProductSumcheckSession> s_;
+};
+
 // Stage4GruenProver (src/zkvm/spartan/stage4_gruen_prover.zig:65-1240), RegistersReadWriteChecking: the five dense K = 128 x T tables
 // and inc[T] are built on the device from the per-cycle trace columns and stay in HBM (zg_rrw_*); the eq structure (its prefix tables in
 // device buffers as well), Gruen's cubic and the claim algebra stay on the host, as in the reference.

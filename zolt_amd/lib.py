@@ -37,7 +37,7 @@ SYMBOLS = [
     "zg_msm_g1", "zg_msm_g1_dev", "zg_msm_g1_dev_async", "zg_msm_g1_batch", "zg_msm_g1_batch_dev", "zg_msm_g1_partial_dev", "zg_msm_g1_partial_fast_dev",
     "zg_g1_combine_partials_dev", "zg_g1_combine_partials_dev_async", "zg_g1_is_on_curve_batch", "zg_g1_scalar_mul_batch", "zg_g1_fixed_base_mul_batch",
     "zg_hyperkzg_open", "zg_hyperkzg_open_dev", "zg_hyperkzg_batch_open",
-    "zg_fr_dense_evaluate", "zg_fr_eq_table", "zg_fr_eq_table_dev", "zg_fr_eq_prefix_tables", "zg_fr_eq_prefix_tables_dev", "zg_fr_rows_mle", "zg_fr_rows_mle_dev", "zg_fr_eq_plus_one_table", "zg_fr_eq_plus_one_table_dev", "zg_fr_bind_low", "zg_fr_bind_high",
+    "zg_fr_dense_evaluate", "zg_fr_eq_table", "zg_fr_eq_table_dev", "zg_fr_eq_prefix_tables", "zg_fr_eq_prefix_tables_dev", "zg_fr_rows_mle", "zg_fr_rows_mle_dev", "zg_fr_rows_affine", "zg_fr_rows_affine_dev", "zg_fr_eq_plus_one_table", "zg_fr_eq_plus_one_table_dev", "zg_fr_bind_low", "zg_fr_bind_high",
     "zg_fr_spartan_combine", "zg_fr_spartan_combine_dev",
     "zg_sumcheck_open", "zg_sumcheck_open_dev", "zg_sumcheck_round_sums", "zg_sumcheck_bind",
     "zg_sumcheck_len", "zg_sumcheck_final", "zg_sumcheck_read", "zg_sumcheck_gather", "zg_sumcheck_close",
@@ -551,6 +551,27 @@ def fr_rows_mle_dev(d_rows, n_rows, k, r, stream=0):
     out = np.empty((k, 4), dtype=np.uint64)
     _chk(_lib.zg_fr_rows_mle_dev(_d(d_rows), C.c_size_t(n_rows), C.c_size_t(k), _h(r), C.c_size_t(r.shape[0]), _d(stream), _h(out)), "zg_fr_rows_mle_dev")
     return out
+
+
+def fr_rows_affine(rows, coeffs, ntab, g, n_pad=None):
+    """tables[t][i * g + j] = C[t*g + j][k] + sum_col C[t*g + j][col] * rows[i][col] (zg_fr_rows_affine): rows (T, k, 4) cycle-major,
+    coeffs (ntab * g, k + 1, 4) with the constant last -> ntab arrays of (n_pad * g, 4)"""
+    rows, coeffs = _c(rows), _c(coeffs)
+    assert rows.ndim == 3 and rows.shape[2] == 4 and coeffs.shape == (ntab * g, rows.shape[1] + 1, 4)
+    n_pad = rows.shape[0] if n_pad is None else n_pad
+    outs = [np.empty((n_pad * g, 4), dtype=np.uint64) for _ in range(ntab)]
+    ptrs = (C.c_void_p * ntab)(*[o.ctypes.data for o in outs])
+    _chk(_lib.zg_fr_rows_affine(_h(rows), C.c_size_t(rows.shape[0]), C.c_size_t(rows.shape[1]), _h(coeffs), C.c_size_t(ntab), C.c_size_t(g),
+                                C.c_size_t(n_pad), ptrs), "zg_fr_rows_affine")
+    return outs
+
+
+def fr_rows_affine_dev(d_rows, n_rows, k, coeffs, ntab, g, n_pad, d_tables, stream=0):
+    coeffs = _c(coeffs)
+    assert coeffs.size == ntab * g * (k + 1) * 4 and len(d_tables) == ntab
+    ptrs = (C.c_void_p * ntab)(*[int(p) for p in d_tables])
+    _chk(_lib.zg_fr_rows_affine_dev(_d(d_rows), C.c_size_t(n_rows), C.c_size_t(k), _h(coeffs), C.c_size_t(ntab), C.c_size_t(g), C.c_size_t(n_pad),
+                                    ptrs, _d(stream)), "zg_fr_rows_affine_dev")
 
 
 def fr_bind_low(table, r):
