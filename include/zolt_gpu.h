@@ -79,7 +79,8 @@ ZG_API const char *zg_last_error(void);
 ZG_API const char *zg_version(void);
 ZG_API int zg_device_count(void);
 
-/* raw device memory, for hosts without their own HIP binding (the Zig shim) */
+/* raw device memory, for hosts without their own HIP binding (the Zig shim). The two copies run on the library's stream and return when
+ * they are done: ordered after every earlier call that was given stream = NULL (e.g. the asynchronous zg_fr_eq_table_dev). */
 ZG_API int zg_dev_alloc(size_t bytes, void **dptr);
 ZG_API int zg_dev_free(void *dptr);
 ZG_API int zg_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);

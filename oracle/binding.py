@@ -1538,3 +1538,65 @@ class StreamingOuterProver:
 
     def getFinalEval(self):  # :1740-1742
         return self.current_claim
+
+
+# ---------------------------------------------------------------- MultiStageProver stages 5 and 6 (src/zkvm/prover.zig:818-1112)
+def compute_reg_eq(r, reg):
+    """computeRegEq (prover.zig:961-972): prod_i (bit_i(reg) ? r[i] : 1 - r[i]), bit i <-> r[i]"""
+    one = fr_from_int(1)
+    acc = one
+    for i, ri in enumerate(_c(r).reshape(-1, 4)):
+        acc = _fmul(acc, ri if (reg >> i) & 1 else _fsub(one, ri))
+    return acc.reshape(4)
+
+
+def _high_half_rounds(evals, num_rounds, transcript, label):
+    """the round loop stages 5 and 6 share (:902-944, 1055-1097): p(0), p(1) = sums of the two halves, the proof keeps [p(0), p(2) = 2 p(1) -
+    p(0)], challengeScalar(label), f[j] = (1 - r) f[j] + r f[j + half], claim = (1 - r) p(0) + r p(1)"""
+    cur = _c(evals).reshape(-1, 4).copy()
+    one = fr_from_int(1)
+    polys, chals, claims = [], [], []
+    for _ in range(num_rounds):
+        p0, p1 = fr_sum_halves(cur)
+        polys.append(np.stack([p0, _fsub(_fadd(p1, p1), p0)]))
+        ch = transcript.challenge_scalar(label)
+        chals.append(ch)
+        omr = _fsub(one, ch)
+        half = cur.shape[0] // 2
+        cur = _fadd(_fmul(cur[:half], omr), _fmul(cur[half:], ch))
+        claims.append(_fadd(_fmul(omr, p0), _fmul(ch, p1)).reshape(4))
+    z2, z1 = np.zeros((0, 2, 4), dtype=np.uint64), np.zeros((0, 4), dtype=np.uint64)
+    return (np.stack(polys) if polys else z2, np.stack(chals) if chals else z1, np.stack(claims) if claims else z1,
+            cur[0].copy() if cur.shape[0] else np.zeros(4, dtype=np.uint64))
+
+
+def stage5_prove(instructions, log_t, transcript):
+    """proveStage5 (prover.zig:829-958): r_register (5) and r_cycle_reg (log_t) challenges, eq_evals[j] = eq(r_register, rd(j)) over the
+    trace steps (zero past them), initial claim = their sum, log2_ceil(trace_len) rounds. -> dict; None rounds for an empty trace"""
+    r_register = np.stack([transcript.challenge_scalar(b"r_register") for _ in range(5)])
+    r_cycle_reg = [transcript.challenge_scalar(b"r_cycle_reg") for _ in range(log_t)]
+    instr = np.asarray(instructions, dtype=np.uint32)
+    n_steps = len(instr)
+    if n_steps == 0:
+        return {"r_register": r_register, "r_cycle_reg": r_cycle_reg, "initial_claim": None}
+    num_rounds = 0 if n_steps <= 1 else (n_steps - 1).bit_length()
+    n = 1 << num_rounds
+    table = np.stack([compute_reg_eq(r_register, reg) for reg in range(32)])
+    eq_evals = np.zeros((n, 4), dtype=np.uint64)
+    eq_evals[:n_steps] = table[(instr >> 7) & 31]
+    polys, chals, claims, fin = _high_half_rounds(eq_evals, num_rounds, transcript, b"reg_eval_round")
+    return {"r_register": r_register, "r_cycle_reg": r_cycle_reg, "initial_claim": _fsum(eq_evals), "round_polys": polys, "challenges": chals,
+            "claims": claims, "final_claim": fin}
+
+
+def stage6_prove(trace_len, transcript):
+    """proveStage6 (prover.zig:990-1112): the booleanity batching challenge, violation_evals = 0 for every step (a valid trace is assumed,
+    :1024-1033), the same round loop under "bool_round" """
+    bool_challenge = transcript.challenge_scalar(b"booleanity")
+    if trace_len == 0:
+        return {"bool_challenge": bool_challenge, "initial_claim": None}
+    num_rounds = 0 if trace_len <= 1 else (trace_len - 1).bit_length()
+    viol = np.zeros((1 << num_rounds, 4), dtype=np.uint64)
+    polys, chals, claims, fin = _high_half_rounds(viol, num_rounds, transcript, b"bool_round")
+    return {"bool_challenge": bool_challenge, "initial_claim": np.zeros(4, dtype=np.uint64), "round_polys": polys, "challenges": chals,
+            "claims": claims, "final_claim": fin}

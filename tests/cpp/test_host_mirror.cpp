@@ -508,6 +508,48 @@ TEST(stage3_and_opening_claim_sites) {
     for (size_t j = 1; j < 64; j++) EXPECT(e1[j].eql(eq[j - 1]));
 }
 
+// proveStage5 / proveStage6 (src/zkvm/prover.zig:829-1112) on the device against the same loops written out with host scalars
+TEST(stages_5_and_6) {
+    for (size_t n_steps : {size_t(1), size_t(2), size_t(200), size_t(4096)}) {
+        std::vector<uint32_t> instr(n_steps);
+        uint64_t z = 0x5eed + n_steps;
+        for (auto &w : instr) { z = z * 6364136223846793005ULL + 1442695040888963407ULL; w = (uint32_t)(z >> 29); }
+        Transcript ta("Jolt"), tb("Jolt");
+        ta.appendBytes("stages 1-4"); tb.appendBytes("stages 1-4");
+        std::vector<Fr> r_reg;
+        auto got = proveStage5(instr, 4, ta, &r_reg);
+        // host restatement
+        std::vector<Fr> rr(5);
+        for (auto &x : rr) x = tb.challengeScalar("r_register");
+        for (int i = 0; i < 4; i++) (void)tb.challengeScalar("r_cycle_reg");
+        for (int i = 0; i < 5; i++) EXPECT(rr[i].eql(r_reg[i]));
+        size_t rounds = n_steps <= 1 ? 0 : log2Ceil(n_steps), n = size_t(1) << rounds;
+        std::vector<Fr> ev(n, Fr::zero());
+        Fr claim = Fr::zero();
+        for (size_t j = 0; j < n_steps; j++) { ev[j] = computeRegEq(rr, (instr[j] >> 7) & 31); claim = claim.add(ev[j]); }
+        EXPECT(got.initial_claim.eql(claim) && got.round_polys.size() == rounds);
+        for (size_t rd = 0; rd < rounds; rd++) {
+            size_t half = n >> (rd + 1);
+            Fr s0 = Fr::zero(), s1 = Fr::zero();
+            for (size_t j = 0; j < half; j++) { s0 = s0.add(ev[j]); s1 = s1.add(ev[j + half]); }
+            EXPECT(got.round_polys[rd][0].eql(s0) && got.round_polys[rd][1].eql(s1.add(s1).sub(s0)));
+            Fr ch = tb.challengeScalar("reg_eval_round");
+            EXPECT(ch.eql(got.challenges[rd]));
+            Fr omr = Fr::one().sub(ch);
+            for (size_t j = 0; j < half; j++) ev[j] = omr.mul(ev[j]).add(ch.mul(ev[j + half]));
+            claim = omr.mul(s0).add(ch.mul(s1));
+            EXPECT(claim.eql(got.claims[rd]));
+        }
+        EXPECT(got.final_claim.eql(ev[0]) && (rounds == 0 || claim.eql(ev[0])));
+        Fr bc;
+        auto g6 = proveStage6(n_steps, ta, &bc);
+        EXPECT(bc.eql(tb.challengeScalar("booleanity")) && g6.round_polys.size() == rounds && g6.final_claim.isZero() && g6.initial_claim.isZero());
+        for (size_t rd = 0; rd < rounds; rd++) EXPECT(g6.round_polys[rd][0].isZero() && g6.round_polys[rd][1].isZero() && g6.challenges[rd].eql(tb.challengeScalar("bool_round")));
+    }
+    Transcript te("Jolt");
+    EXPECT(proveStage5({}, 3, te).skipped && proveStage6(0, te).skipped);
+}
+
 // `test_host_mirror rwc <file>`: runs zolt::RamReadWriteCheckingProver on the instance the file describes (written by
 // tests/test_gpu_cpp_host.py: the reference's captured run and random traces) and prints every round polynomial, claim, entry count and
 // the opening claims as hex limbs; the Python test compares the lines with the oracle's.

@@ -287,3 +287,41 @@ def test_lasso_rounds_of_the_captured_run_on_the_device(env, golden_dir):
         p.receiveChallenge(_rand(ob, 4500 + i, 1)[0])
     p.deinit()
     assert empty_second == [i for i, r in enumerate(R) if i >= d["log_K"] and not fe(r["p1"]).any()] == [16, 17]
+
+
+@pytest.mark.parametrize("n_steps", [1, 2, 200, 256, 1 << 13, (1 << 20) - 3])
+def test_stages_5_and_6_with_keccak_transcript(env, n_steps):
+    """MultiStageProver.proveStage5 / proveStage6 (src/zkvm/prover.zig:829-1112): the register-eq table and the booleanity table through a
+    HIGH_HALF device session against the restatement — challenges, [p(0), p(2)] of every round, the claim chain, the final claims and the
+    transcripts' end state; 256 steps is the captured run's length (logs/zolt.log:1064)."""
+    api, lib, ob = env
+    rng = np.random.default_rng(n_steps)
+    instr = rng.integers(0, 1 << 32, size=n_steps, dtype=np.uint64).astype(np.uint32)
+    log_t = max((n_steps - 1).bit_length(), 1)
+    ta, tb = api.Transcript(b"Jolt"), ob.Transcript(b"Jolt")
+    ta.appendBytes(b"stages 1-4"); tb.append_bytes(b"stages 1-4")
+    g5, w5 = api.proveStage5(instr, log_t, ta), ob.stage5_prove(instr, log_t, tb)
+    g6, w6 = api.proveStage6(n_steps, ta), ob.stage6_prove(n_steps, tb)
+    for g, w in ((g5, w5), (g6, w6)):
+        assert g.keys() == w.keys()
+        for k in w:
+            assert np.array_equal(np.asarray(g[k]), np.asarray(w[k])), k
+    assert len(g5["round_polys"]) == (0 if n_steps <= 1 else (n_steps - 1).bit_length())
+    if n_steps > 1:  # the sumcheck relations the verifier uses: p(1) = (p(0) + p(2)) / 2, p(0) + p(1) = claim
+        claim = ob.fr_to_int(g5["initial_claim"])
+        for rp, nxt in zip(g5["round_polys"], g5["claims"]):
+            p0, p2 = ob.fr_to_int(rp[0]), ob.fr_to_int(rp[1])
+            assert (p0 + (p0 + p2) * pow(2, -1, ob._R_P)) % ob._R_P == claim
+            claim = ob.fr_to_int(nxt)
+        assert claim == ob.fr_to_int(g5["final_claim"])
+    assert not g6["final_claim"].any() and not g6["round_polys"].any()
+    assert bytes(ta.state) == tb.state_bytes()[0]
+
+
+def test_stage5_empty_trace(env):
+    api, lib, ob = env
+    ta, tb = api.Transcript(b"Jolt"), ob.Transcript(b"Jolt")
+    g, w = api.proveStage5(np.zeros(0, dtype=np.uint32), 3, ta), ob.stage5_prove(np.zeros(0, dtype=np.uint32), 3, tb)
+    assert g["initial_claim"] is None and w["initial_claim"] is None and np.array_equal(g["r_register"], w["r_register"])
+    assert api.proveStage6(0, ta)["initial_claim"] is None and ob.stage6_prove(0, tb)["initial_claim"] is None
+    assert bytes(ta.state) == tb.state_bytes()[0]

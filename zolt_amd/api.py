@@ -1073,6 +1073,71 @@ def proveStage1(combined_poly, num_rounds, transcript):
             sess.close()
 
 
+def computeRegEq(r, reg):
+    """computeRegEq (src/zkvm/prover.zig:961-972): prod_i (bit_i(reg) ? r[i] : 1 - r[i])"""
+    acc = 1
+    for i, ri in enumerate(np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4)):
+        v = fr_to_int(ri)
+        acc = acc * (v if (reg >> i) & 1 else 1 - v) % R_MOD
+    return fr_from_int(acc)
+
+
+def _highHalfRounds(evals, num_rounds, transcript, label):
+    """the round loop of stages 5 and 6 (src/zkvm/prover.zig:902-944, 1055-1097) over a HIGH_HALF device session: p(0), p(1) = the sums
+    of the two halves (64 bytes back per round), the proof keeps [p(0), 2 p(1) - p(0)], the challenge folds f[j] = (1 - r) f[j] + r f[j + half]
+    on the device, claim = (1 - r) p(0) + r p(1) on the host"""
+    ev = np.ascontiguousarray(evals, dtype=np.uint64).reshape(-1, 4)
+    sess = lib.SumcheckSession.open(ev, lib.SC_HIGH_HALF)
+    polys, chals, claims, initial = [], [], [], None
+    try:
+        for _ in range(num_rounds):
+            p0, p1 = sess.round_sums()
+            if initial is None:
+                initial = _fr_add(p0, p1)  # the sum of the whole table: the stage's initial claim
+            polys.append(np.stack([p0, _fr_sub(_fr_add(p1, p1), p0)]))
+            ch = transcript.challengeScalar(label)
+            chals.append(ch)
+            sess.bind(ch)
+            a, b, c = fr_to_int(p0), fr_to_int(p1), fr_to_int(ch)
+            claims.append(fr_from_int(((1 - c) * a + c * b) % R_MOD))
+        final = sess.final() if len(sess) == 1 else sess.read()[0]
+    finally:
+        sess.close()
+    z = np.zeros((0, 4), dtype=np.uint64)
+    return (np.stack(polys) if polys else np.zeros((0, 2, 4), dtype=np.uint64), np.stack(chals) if chals else z,
+            np.stack(claims) if claims else z, final, final.copy() if initial is None else initial)
+
+
+def proveStage5(instructions, log_t, transcript):
+    """MultiStageProver.proveStage5 (src/zkvm/prover.zig:829-958), register value evaluation: five r_register and log_t r_cycle_reg
+    challenges, eq_evals[j] = eq(r_register, rd(j)) for the trace steps (a 32-entry table indexed by the rd field, zero past the trace),
+    initial claim = the table's sum (the session's first pair of sums), then log2_ceil(trace_len) rounds on the device."""
+    r_register = np.stack([transcript.challengeScalar(b"r_register") for _ in range(5)])
+    r_cycle_reg = [transcript.challengeScalar(b"r_cycle_reg") for _ in range(log_t)]
+    instr = np.asarray(instructions, dtype=np.uint32)
+    if len(instr) == 0:  # :859-863
+        return {"r_register": r_register, "r_cycle_reg": r_cycle_reg, "initial_claim": None}
+    num_rounds = 0 if len(instr) <= 1 else (len(instr) - 1).bit_length()
+    table = np.stack([computeRegEq(r_register, reg) for reg in range(32)])
+    eq_evals = np.zeros((1 << num_rounds, 4), dtype=np.uint64)
+    eq_evals[:len(instr)] = table[(instr >> 7) & 31]
+    polys, chals, claims, fin, initial = _highHalfRounds(eq_evals, num_rounds, transcript, b"reg_eval_round")
+    return {"r_register": r_register, "r_cycle_reg": r_cycle_reg, "initial_claim": initial, "round_polys": polys, "challenges": chals,
+            "claims": claims, "final_claim": fin}
+
+
+def proveStage6(trace_len, transcript):
+    """MultiStageProver.proveStage6 (src/zkvm/prover.zig:990-1112), booleanity: the batching challenge, violation_evals = 0 for every step
+    (the reference assumes a valid trace, :1024-1033) through the same round loop under "bool_round" """
+    bool_challenge = transcript.challengeScalar(b"booleanity")
+    if trace_len == 0:
+        return {"bool_challenge": bool_challenge, "initial_claim": None}
+    num_rounds = 0 if trace_len <= 1 else (trace_len - 1).bit_length()
+    polys, chals, claims, fin, initial = _highHalfRounds(np.zeros((1 << num_rounds, 4), dtype=np.uint64), num_rounds, transcript, b"bool_round")
+    return {"bool_challenge": bool_challenge, "initial_claim": initial, "round_polys": polys, "challenges": chals,
+            "claims": claims, "final_claim": fin}
+
+
 class RafEvaluationProver:
     """RafEvaluationProver (src/zkvm/ram/raf_checking.zig:262-470) with RaPolynomial's table in a LOW_PAIR device session: the
     cubic round polynomial's two sums are one kernel pass (zg_sumcheck_raf_round), the bind is the session's fold; the handful of

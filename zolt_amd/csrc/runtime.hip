@@ -321,14 +321,19 @@ int zg_dev_free(void *dptr) {
     ZG_HIP(hipFree(dptr));
     return ZG_OK;
 }
+// Both copies run ON the library stream and wait for it: they are ordered after every call that was given stream = NULL (the
+// asynchronous zg_fr_eq_table_dev in particular — a plain hipMemcpy is not ordered with a non-blocking stream, and a zero tail written
+// "after" a table build could land before it).
 int zg_memcpy_h2d(void *dst, const void *src, size_t bytes) {
     ZG_INIT();
-    ZG_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    ZG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, lib_stream()));
+    ZG_HIP(hipStreamSynchronize(lib_stream()));
     return ZG_OK;
 }
 int zg_memcpy_d2h(void *dst, const void *src, size_t bytes) {
     ZG_INIT();
-    ZG_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    ZG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, lib_stream()));
+    ZG_HIP(hipStreamSynchronize(lib_stream()));
     return ZG_OK;
 }
 int zg_sync(void) {

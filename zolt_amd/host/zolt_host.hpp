@@ -1455,6 +1455,74 @@ private:
 };
 
 // InstructionLookupsClaimReductionProver's loop (src/zkvm/claim_reductions/instruction_lookups.zig:146-284)
+// ---------------------------------------------------------------- MultiStageProver stages 5 and 6 (src/zkvm/prover.zig:818-1112)
+struct StageRoundsResult {
+    Fr initial_claim = Fr::zero(), final_claim = Fr::zero();
+    std::vector<std::array<Fr, 2>> round_polys;  // [p(0), p(2)] (:925-927)
+    std::vector<Fr> challenges, claims;
+    bool skipped = false;  // empty trace (:859-863, 1003-1007)
+};
+inline Fr computeRegEq(const std::vector<Fr> &r, unsigned reg) {  // :961-972
+    Fr acc = Fr::one();
+    for (size_t i = 0; i < r.size(); i++) acc = acc.mul(((reg >> i) & 1) ? r[i] : Fr::one().sub(r[i]));
+    return acc;
+}
+// the round loop the two stages share (:902-944, 1055-1097) over a HIGH_HALF device session
+inline void highHalfRounds(const std::vector<Fr> &evals, size_t num_rounds, Transcript &transcript, const std::string &label, StageRoundsResult &out) {
+    zg_sc_t s = nullptr;
+    check(zg_sumcheck_open(reinterpret_cast<const uint64_t *>(evals.data()), evals.size(), ZG_SC_HIGH_HALF, &s), "zg_sumcheck_open");
+    try {
+        for (size_t rd = 0; rd < num_rounds; rd++) {
+            Fr p0, p1;
+            check(zg_sumcheck_round_sums(s, p0.limbs, p1.limbs), "zg_sumcheck_round_sums");
+            if (rd == 0) out.initial_claim = p0.add(p1);
+            out.round_polys.push_back({p0, p1.add(p1).sub(p0)});
+            Fr ch = transcript.challengeScalar(label);
+            out.challenges.push_back(ch);
+            check(zg_sumcheck_bind(s, ch.limbs), "zg_sumcheck_bind");
+            out.claims.push_back(Fr::one().sub(ch).mul(p0).add(ch.mul(p1)));
+        }
+        check(zg_sumcheck_final(s, out.final_claim.limbs), "zg_sumcheck_final");
+        if (num_rounds == 0) out.initial_claim = out.final_claim;
+    } catch (...) {
+        zg_sumcheck_close(s);
+        throw;
+    }
+    check(zg_sumcheck_close(s), "zg_sumcheck_close");
+}
+inline size_t log2Ceil(size_t n) {
+    size_t k = 0;
+    while ((size_t(1) << k) < n) k++;
+    return k;
+}
+// proveStage5 (:829-958): register value evaluation — eq(r_register, rd(j)) over the trace steps
+inline StageRoundsResult proveStage5(const std::vector<uint32_t> &instructions, size_t log_t, Transcript &transcript, std::vector<Fr> *r_register_out = nullptr) {
+    std::vector<Fr> r_register(5);
+    for (auto &x : r_register) x = transcript.challengeScalar("r_register");
+    for (size_t i = 0; i < log_t; i++) (void)transcript.challengeScalar("r_cycle_reg");
+    if (r_register_out) *r_register_out = r_register;
+    StageRoundsResult out;
+    if (instructions.empty()) { out.skipped = true; return out; }
+    const size_t num_rounds = instructions.size() <= 1 ? 0 : log2Ceil(instructions.size());
+    Fr table[32];
+    for (unsigned reg = 0; reg < 32; reg++) table[reg] = computeRegEq(r_register, reg);
+    std::vector<Fr> eq_evals(size_t(1) << num_rounds, Fr::zero());
+    for (size_t j = 0; j < instructions.size(); j++) eq_evals[j] = table[(instructions[j] >> 7) & 31];
+    highHalfRounds(eq_evals, num_rounds, transcript, "reg_eval_round", out);
+    return out;
+}
+// proveStage6 (:990-1112): booleanity — violation_evals = 0 for every step of a valid trace (:1024-1033)
+inline StageRoundsResult proveStage6(size_t trace_len, Transcript &transcript, Fr *bool_challenge_out = nullptr) {
+    Fr bc = transcript.challengeScalar("booleanity");
+    if (bool_challenge_out) *bool_challenge_out = bc;
+    StageRoundsResult out;
+    if (trace_len == 0) { out.skipped = true; return out; }
+    const size_t num_rounds = trace_len <= 1 ? 0 : log2Ceil(trace_len);
+    std::vector<Fr> viol(size_t(1) << num_rounds, Fr::zero());
+    highHalfRounds(viol, num_rounds, transcript, "bool_round", out);
+    return out;
+}
+
 // ---------------------------------------------------------------- Spartan outer sumcheck, remaining rounds
 // The 19 uniform R1CS constraints (src/zkvm/r1cs/constraints.zig:248-531, the published Jolt R1CS): condition * (left - right) = 0 with
 // each side a linear combination of the 43 per-cycle inputs (R1CSInputIndex, :39-92) plus a constant.
