@@ -380,7 +380,9 @@ ZG_API int zg_psc_final(zg_psc_t s, uint64_t *out /* k*4: each table's single re
 ZG_API int zg_psc_close(zg_psc_t s);
 
 /* ------------------------------------------------------------------ registers read/write checking (Stage 4) */
-/* Stage4GruenProver (src/zkvm/spartan/stage4_gruen_prover.zig:65-1240), the RegistersReadWriteChecking sumcheck: five DENSE tables of
+/* Stage4GruenProver (src/zkvm/spartan/stage4_gruen_prover.zig:65-1240) and the original Stage4Prover (stage4_prover.zig:74-865: the same
+ * tables, every cycle variable first under a dense eq table set at the start, all four evaluations computed directly), the
+ * RegistersReadWriteChecking sumcheck: five DENSE tables of
  * K = 128 registers x T = 2^log_t cycles — val, rd_wa, ra = gamma rs1_ra + gamma^2 rs2_ra, rs1_ra, rs2_ra, indexed [k * T + j] — plus
  * inc[T], LOG_K + log_t rounds in three phases (cycle variables in Gruen form, the seven register variables, the remaining cycle
  * variables under the merged dense eq table). The session builds the tables on the device from the per-cycle trace columns and keeps
@@ -400,10 +402,13 @@ ZG_API size_t zg_rrw_registers(zg_rrw_t s); /* current_K */
 ZG_API int zg_rrw_round_cycle_gruen(zg_rrw_t s, const uint64_t *d_e_out, size_t n_out, const uint64_t *d_e_in, size_t n_in, uint64_t q0[4], uint64_t qx2[4]);
 /* the merged eq table of gruen_eq.merge (gruen_eq.zig:119-146) after the last phase-1 bind: n = zg_rrw_cycles(s) entries (host) */
 ZG_API int zg_rrw_set_eq(zg_rrw_t s, const uint64_t *eq, size_t n);
-/* phase2ComputeMessage's (eval_0, eval_2) (:764-852; also the register rounds once a single cycle is left, :955-1013) */
-ZG_API int zg_rrw_round_address(zg_rrw_t s, uint64_t e0[4], uint64_t e2[4]);
-/* phase3ComputeMessage's (eval_0, eval_2, eval_3) (:854-953) */
-ZG_API int zg_rrw_round_cycle(zg_rrw_t s, uint64_t e0[4], uint64_t e2[4], uint64_t e3[4]);
+/* phase2ComputeMessage's (eval_0, eval_2) (:764-852; also the register rounds once a single cycle is left, :955-1013). e1 != NULL: the value
+ * at t = 1 as well, computed from the odd rows — Stage4Prover.computeRoundEvalsInternal's register rounds evaluate it directly
+ * (src/zkvm/spartan/stage4_prover.zig:666-706) instead of taking it from the claim. */
+ZG_API int zg_rrw_round_address(zg_rrw_t s, uint64_t e0[4], uint64_t *e1 /* 4 words, or NULL */, uint64_t e2[4]);
+/* phase3ComputeMessage's (eval_0, eval_2, eval_3) (:854-953); e1 != NULL: p(1) too, as Stage4Prover's cycle rounds compute all four
+ * (stage4_prover.zig:617-664) */
+ZG_API int zg_rrw_round_cycle(zg_rrw_t s, uint64_t e0[4], uint64_t *e1 /* 4 words, or NULL */, uint64_t e2[4], uint64_t e3[4]);
 /* bindPolynomials (:1047-1163): fold the cycle variable (five tables, inc, and the merged eq table once it is set) / the register variable */
 ZG_API int zg_rrw_bind_cycle(zg_rrw_t s, const uint64_t r[4]);
 ZG_API int zg_rrw_bind_address(zg_rrw_t s, const uint64_t r[4]);

@@ -1600,3 +1600,96 @@ def stage6_prove(trace_len, transcript):
     polys, chals, claims, fin = _high_half_rounds(viol, num_rounds, transcript, b"bool_round")
     return {"bool_challenge": bool_challenge, "initial_claim": np.zeros(4, dtype=np.uint64), "round_polys": polys, "challenges": chals,
             "claims": claims, "final_claim": fin}
+
+
+class Stage4Prover(Stage4GruenProver):
+    """the original Stage4Prover (src/zkvm/spartan/stage4_prover.zig:74-865): the same tables from the same trace rules (:183-277), a DENSE
+    eq table over the cycles from the start (computeEqEvalsBE of the reversed r_cycle, :279-292), all log_T cycle rounds first and then the
+    seven register rounds, every round's four evaluations computed directly from the tables (:601-723) — p(1) is not taken from the claim —
+    and the full-coefficient round polynomial (:731-758)."""
+
+    def __init__(self, steps, gamma, r_cycle, stage3_claims=None, batching_coeff=None):
+        log_t = max(len(steps) - 1, 0).bit_length()
+        super().__init__(steps, gamma, r_cycle, max(log_t, 1), self.LOG_K)
+        self.eq_cycle_evals = self.gruen.getFullEqTable().copy()  # eq(r_cycle_be, .), r_cycle_be[0] <-> MSB
+        self.stage3_claims = stage3_claims  # (rd_write_value, rs1_value, rs2_value) or None
+        self.batching_coeff = fr_from_int(1) if batching_coeff is None else _c(batching_coeff).copy()
+
+    def computeInputClaim(self):  # :569-599
+        comb = _fadd(_fmul(self.ra, self.val), _fmul(self.wa, _fadd(self.val, self.inc[None, :, :])))
+        return _fsum(_fmul(_fsum_axis0(comb), self.eq_cycle_evals))
+
+    def computeRoundEvals(self, rnd, current_claim=None):  # :601-723 -> p(0..3)
+        ra, wa, val, inc = self._live()
+        eq = self.eq_cycle_evals[:self.current_T]
+        ts = [fr_from_int(t) for t in range(4)]
+        lerp = lambda a, b, t: _fadd(a, _fmul(t, _fsub(b, a)))  # (1 - t) a + t b
+        out = []
+        if rnd < self.log_T:
+            for t in ts:
+                r_, w_, v_ = lerp(ra[:, 0::2], ra[:, 1::2], t), lerp(wa[:, 0::2], wa[:, 1::2], t), lerp(val[:, 0::2], val[:, 1::2], t)
+                i_, q_ = lerp(inc[0::2], inc[1::2], t), lerp(eq[0::2], eq[1::2], t)
+                out.append(_fsum(_fmul(q_, _fsum_axis0(_fadd(_fmul(r_, v_), _fmul(w_, _fadd(v_, i_[None])))))))
+        else:
+            for t in ts:
+                r_, w_, v_ = lerp(ra[0::2], ra[1::2], t), lerp(wa[0::2], wa[1::2], t), lerp(val[0::2], val[1::2], t)
+                out.append(_fsum(_fmul(eq, _fsum_axis0(_fadd(_fmul(r_, v_), _fmul(w_, _fadd(v_, inc[None])))))))
+        return np.stack(out)
+
+    def computeRoundPolynomial(self, rnd, current_claim=None):  # :731-758 -> coefficients c0..c3
+        P = _R_P
+        e = [fr_to_int(x) for x in self.computeRoundEvals(rnd, current_claim)]
+        c3 = (-e[0] + 3 * e[1] - 3 * e[2] + e[3]) * pow(6, P - 2, P) % P
+        c2 = (2 * e[0] - 5 * e[1] + 4 * e[2] - e[3]) * pow(2, P - 2, P) % P
+        c1 = (e[1] - e[0] - c2 - c3) % P
+        return np.stack([fr_from_int(v) for v in (e[0], c1, c2, c3)])
+
+    def bindChallenge(self, rnd, challenge):  # bindPolynomials :779-839
+        ch = _c(challenge).reshape(1, 4)
+        K, T = self.current_K, self.current_T
+        if rnd < self.log_T:
+            for t in (self.val, self.wa, self.ra, self.rs1_ra, self.rs2_ra):
+                lo, hi = t[:K, 0:T:2], t[:K, 1:T:2]
+                t[:K, :T // 2] = _fadd(lo, _fmul(ch, _fsub(hi, lo)))
+            for v in (self.inc, self.eq_cycle_evals):
+                lo, hi = v[0:T:2], v[1:T:2]
+                v[:T // 2] = _fadd(lo, _fmul(ch, _fsub(hi, lo)))
+            self.current_T = T // 2
+        else:
+            for t in (self.val, self.wa, self.ra, self.rs1_ra, self.rs2_ra):
+                lo, hi = t[0:K:2, :T], t[1:K:2, :T]
+                t[:K // 2, :T] = _fadd(lo, _fmul(ch, _fsub(hi, lo)))
+            self.current_K = K // 2
+
+    def finalCheck(self):  # the values prove() prints at the end (:533-553)
+        eq = self.eq_cycle_evals[0]
+        comb = _fadd(_fmul(self.ra[0, 0], self.val[0, 0]), _fmul(self.wa[0, 0], _fadd(self.val[0, 0], self.inc[0])))
+        return eq, comb, _fmul(eq, comb)
+
+    def prove(self, transcript):
+        """prove (:395-567) with a Blake2bTranscript (any object with appendScalar / challengeScalar: the transcript is host logic with its own
+        fixture, tests/golden/blake2b_transcript_preamble.json): batched compressed coefficients appended, challenges squeezed, batched claims tracked
+        -> dict(round_polys (rounds, 4, 4) batched coefficients, challenges, final claims)"""
+        P = _R_P
+        b = fr_to_int(self.batching_coeff)
+        if self.stage3_claims is not None:  # :404-437
+            g = fr_to_int(self.gamma)
+            rd, r1, r2 = (fr_to_int(x) for x in self.stage3_claims)
+            unbatched = (rd + g * r1 + g * g * r2) % P
+        else:
+            unbatched = fr_to_int(self.computeInputClaim())
+        claim = unbatched * b % P
+        polys, chals = [], []
+        for rnd in range(self.num_rounds):
+            c = [fr_to_int(x) for x in self.computeRoundPolynomial(rnd, fr_from_int(claim))]
+            for i in (0, 2, 3):
+                transcript.appendScalar(fr_from_int(c[i] * b % P))
+            ch = transcript.challengeScalar()
+            chals.append(ch)
+            x = fr_to_int(ch)
+            claim = (c[0] + x * (c[1] + x * (c[2] + x * c[3]))) % P * b % P
+            self.bindChallenge(rnd, ch)
+            polys.append(np.stack([fr_from_int(v * b % P) for v in c]))
+        out = self.getFinalClaims()
+        out.update({"round_polys": np.stack(polys), "challenges": np.stack(chals), "final_claim": fr_from_int(claim)})
+        return out

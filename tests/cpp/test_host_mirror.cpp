@@ -629,6 +629,25 @@ static int stage4_main(const char *path) {
     std::vector<Fr> ch;
     for (size_t i = 0; i < 7 + log_t; i++) ch.push_back(read_fr(f));
     std::fclose(f);
+    if (p1 == 0) {  // phase-1 length 0 in the file: the ORIGINAL Stage4Prover (cycle variables first, four evaluations from the tables)
+        Stage4Prover q(steps, gamma, r_cycle);
+        for (size_t rd = 0; rd < q.num_rounds; rd++) {
+            auto ev = q.computeRoundEvals(rd, claim);
+            auto co = q.computeRoundPolynomial(rd, claim);
+            std::printf("E");
+            for (const Fr &x : ev) print_fr(x);
+            std::printf("\nP");
+            for (const Fr &x : co) print_fr(x);
+            std::printf("\n");
+            claim = cubicAtPoint(ev, ch[rd]);
+            q.bindChallenge(rd, ch[rd]);
+        }
+        auto fc = q.getFinalClaims();
+        std::printf("O");
+        for (const Fr &x : {fc.val_claim, fc.rs1_ra_claim, fc.rs2_ra_claim, fc.rd_wa_claim, fc.inc_claim, claim}) print_fr(x);
+        std::printf("\n");
+        return 0;
+    }
     Stage4GruenProver p(steps, gamma, r_cycle, p1, 7);
     for (size_t rd = 0; rd < p.num_rounds; rd++) {
         auto ev = p.computeRoundEvals(rd, claim);

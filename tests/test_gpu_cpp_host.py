@@ -185,3 +185,40 @@ def test_cpp_streaming_outer_mirror(tmp_path, golden_dir):
             o.bindRemainingRoundChallenge(chals[rd])
         assert np.array_equal(fin[0], o.az[0]) and np.array_equal(fin[1], o.bz[0]) and np.array_equal(fin[2], o.current_claim)
         assert np.array_equal(fin[3], o.split_eq.current_scalar)
+
+
+@pytest.mark.gpu
+def test_cpp_original_stage4_prover_mirror(tmp_path):
+    """zolt::Stage4Prover (the original, non-Gruen prover of src/zkvm/spartan/stage4_prover.zig) against the restatement: four evaluations
+    and the coefficient form of every round, the final claims"""
+    import numpy as np
+    from oracle import binding as ob
+    from tests import util as U
+    from tests.test_gpu_stage4 import seeded_steps
+    exe = os.path.join(ROOT, "tests", "cpp", "test_host_mirror")
+    subprocess.check_call(["make", "-C", os.path.dirname(exe), "test_host_mirror"])
+    for k, (log_t, n_steps) in enumerate(((2, 3), (7, 100), (10, 1024))):
+        r = ob.f_to_mont(ob.FR, U.random_raw256(950 + log_t, 2 * log_t + 8))
+        g, rc, ch, st = r[0], r[1:1 + log_t], r[1 + log_t:], seeded_steps(60 + log_t, n_steps)
+        o = ob.Stage4Prover(st, g, rc)
+        claim = o.computeInputClaim()
+        path = str(tmp_path / f"stage4orig_{k}.txt")
+        with open(path, "w") as f:
+            f.write(f"{log_t} 0\n{_hexfr(g)}\n{_hexfr(claim)}\n" + "".join(_hexfr(x) + "\n" for x in rc))
+            f.write(f"{len(st)}\n" + "".join(f"{w} {v} {int(z)}\n" for w, v, z in st) + "".join(_hexfr(x) + "\n" for x in ch))
+        res = subprocess.run([exe, "stage4", path], capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+        rows = lambda tag, cnt: [np.array([int(x, 16) for x in l.split()[1:1 + 4 * cnt]], dtype=np.uint64).reshape(cnt, 4)
+                                 for l in res.stdout.splitlines() if l.startswith(tag + " ")]
+        evs, cos, fin = rows("E", 4), rows("P", 4), rows("O", 6)[0]
+        assert len(evs) == len(cos) == 7 + log_t
+        for rd in range(7 + log_t):
+            we = o.computeRoundEvals(rd)
+            assert np.array_equal(evs[rd], we), (k, rd)
+            assert np.array_equal(cos[rd], o.computeRoundPolynomial(rd)), (k, rd)
+            claim = ob.raf_update_claim(we, ch[rd])
+            o.bindChallenge(rd, ch[rd])
+        fc = o.getFinalClaims()
+        want = [fc["val_claim"], fc["rs1_ra_claim"], fc["rs2_ra_claim"], fc["rd_wa_claim"], fc["inc_claim"], claim]
+        assert all(np.array_equal(fin[i], w) for i, w in enumerate(want)), k
+        assert np.array_equal(o.finalCheck()[2], claim)

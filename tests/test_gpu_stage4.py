@@ -127,3 +127,48 @@ def test_full_size_claim_chain(api, log_t):
         p.bindChallenge(k, chals[k])
     assert np.array_equal(p.finalCheck()[2], claim)
     p.deinit()
+
+
+@pytest.mark.parametrize("log_t,n_steps", [(1, 2), (4, 11), (8, 256), (10, 1000)])
+def test_original_stage4_prover_against_the_restatement(api, log_t, n_steps):
+    """Stage4Prover (stage4_prover.zig): cycle variables first under the dense eq table, all four evaluations from the tables — every
+    round's evaluations and coefficient form, the final claims, and prove() through two Blake2b transcripts"""
+    steps = seeded_steps(500 + log_t, n_steps)
+    rng = np.random.default_rng(40 + log_t)
+    r = ob.f_to_mont(ob.FR, rng.integers(0, 1 << 63, size=(2 * log_t + 12, 4), dtype=np.uint64))
+    gamma, r_cycle, chals, coeff = r[0], r[1:1 + log_t], r[1 + log_t:8 + 2 * log_t], r[8 + 2 * log_t]
+    o, d = ob.Stage4Prover(steps, gamma, r_cycle), api.Stage4Prover(steps, gamma, r_cycle)
+    claim = o.computeInputClaim()
+    for k in range(7 + log_t):
+        eo, ed = o.computeRoundEvals(k, claim), d.computeRoundEvals(k, claim)
+        assert np.array_equal(eo, ed), k
+        assert np.array_equal(ob.f_add(ob.FR, eo[0:1], eo[1:2])[0], claim), k
+        assert np.array_equal(o.computeRoundPolynomial(k), d.computeRoundPolynomial(k)), k
+        claim = ob.raf_update_claim(eo, chals[k])
+        o.bindChallenge(k, chals[k])
+        d.bindChallenge(k, chals[k])
+    fo, fd = o.getFinalClaims(), d.getFinalClaims()
+    assert all(np.array_equal(fo[n], fd[n]) for n in fo)
+    assert all(np.array_equal(a, b) for a, b in zip(o.finalCheck(), d.finalCheck())) and np.array_equal(d.finalCheck()[2], claim)
+    d.deinit()
+    # prove(): batching coefficient, Stage-3 claims absent -> the computed input claim
+    o, d = ob.Stage4Prover(steps, gamma, r_cycle, None, coeff), api.Stage4Prover(steps, gamma, r_cycle, None, coeff)
+    ta, tb = api.Blake2bTranscript(b"Jolt"), api.Blake2bTranscript(b"Jolt")
+    want = o.prove(ta)
+    got = d.prove(tb, input_claim=ob.Stage4Prover(steps, gamma, r_cycle).computeInputClaim())
+    assert want.keys() == got.keys()
+    for name in want:
+        assert np.array_equal(want[name], got[name]), name
+    assert ta.state == tb.state
+    d.deinit()
+
+
+def test_original_stage4_prover_rejects_nothing_it_should_not(api):
+    """an inconsistent claim: the original prover's evaluations do not depend on it (p(1) comes from the tables)"""
+    steps = seeded_steps(9, 40)
+    r = ob.f_to_mont(ob.FR, np.random.default_rng(1).integers(0, 1 << 63, size=(8, 4), dtype=np.uint64))
+    d = api.Stage4Prover(steps, r[0], r[1:7])
+    a = d.computeRoundEvals(0, r[7])
+    b = d.computeRoundEvals(0, api.fr_from_int(0))
+    assert np.array_equal(a, b)
+    d.deinit()

@@ -675,3 +675,22 @@ def test_streaming_outer_restatement_is_a_sumcheck(n_cycles):
         p.bindRemainingRoundChallenge(chals[k])
     fin = ob._fmul(ob._fmul(p.az[0], p.bz[0]), p.split_eq.current_scalar)
     assert np.array_equal(fin.reshape(4), p.getFinalEval())
+
+
+def test_original_stage4_prover_shares_the_pinned_input_claim(golden_dir):
+    """Stage4Prover (the original, stage4_prover.zig) was not run in the captured log; its restatement is tied to the pinned one through what
+    they share: the same tables from the same trace, so its input claim over the dense eq table is the registers instance's logged round-0
+    claim, and its rounds — different order, all four evaluations from the tables — are a sumcheck from that claim to eq * combined."""
+    fx, gr, steps, gamma, r_cycle = stage4_inputs_of_the_captured_run(golden_dir, ob.fr_from_int)
+    p = ob.Stage4Prover(steps, gamma, r_cycle)
+    claim = p.computeInputClaim()
+    assert ob.fr_to_int(claim) == int.from_bytes(bytes.fromhex(fx["round0"]["claim_le"]), "little")
+    chals = ob.f_to_mont(ob.FR, U.random_raw256(4, 15))
+    for k in range(15):
+        ev = p.computeRoundEvals(k)
+        assert np.array_equal(ob.f_add(ob.FR, ev[0:1], ev[1:2])[0], claim), k
+        c = [ob.fr_to_int(x) for x in p.computeRoundPolynomial(k)]
+        assert [sum(ci * t ** i for i, ci in enumerate(c)) % ob._R_P for t in range(4)] == [ob.fr_to_int(x) for x in ev]
+        claim = ob.raf_update_claim(ev, chals[k])
+        p.bindChallenge(k, chals[k])
+    assert np.array_equal(p.finalCheck()[2], claim)

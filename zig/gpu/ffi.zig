@@ -122,8 +122,8 @@ pub extern fn zg_rrw_cycles(s: RegistersSession) usize;
 pub extern fn zg_rrw_registers(s: RegistersSession) usize;
 pub extern fn zg_rrw_round_cycle_gruen(s: RegistersSession, d_e_out: ?[*]const u64, n_out: usize, d_e_in: ?[*]const u64, n_in: usize, q0: *[4]u64, qx2: *[4]u64) c_int;
 pub extern fn zg_rrw_set_eq(s: RegistersSession, eq: ?[*]const u64, n: usize) c_int;
-pub extern fn zg_rrw_round_address(s: RegistersSession, e0: *[4]u64, e2: *[4]u64) c_int;
-pub extern fn zg_rrw_round_cycle(s: RegistersSession, e0: *[4]u64, e2: *[4]u64, e3: *[4]u64) c_int;
+pub extern fn zg_rrw_round_address(s: RegistersSession, e0: *[4]u64, e1: ?[*]u64, e2: *[4]u64) c_int;
+pub extern fn zg_rrw_round_cycle(s: RegistersSession, e0: *[4]u64, e1: ?[*]u64, e2: *[4]u64, e3: *[4]u64) c_int;
 pub extern fn zg_rrw_bind_cycle(s: RegistersSession, r: *const [4]u64) c_int;
 pub extern fn zg_rrw_bind_address(s: RegistersSession, r: *const [4]u64) c_int;
 pub extern fn zg_rrw_final(s: RegistersSession, out: ?[*]u64) c_int;

@@ -2300,6 +2300,74 @@ class Stage4GruenProver:
         self.gruen.deinit()
 
 
+class Stage4Prover(Stage4GruenProver):
+    """the original Stage4Prover (src/zkvm/spartan/stage4_prover.zig:74-865) on the same device session: the dense eq table over the cycles
+    is set at the start (computeEqEvalsBE of the reversed r_cycle, :279-292), every cycle variable is bound first, then the seven register
+    variables; all four evaluations of a round come from the tables (zg_rrw_round_cycle / zg_rrw_round_address with e1; the register rounds'
+    p(3) = p(0) - 3 p(1) + 3 p(2), the polynomial being quadratic there), the full-coefficient round polynomial and prove()'s batched
+    transcript loop are host code."""
+
+    def __init__(self, steps, gamma, r_cycle, stage3_claims=None, batching_coeff=None):
+        n = len(steps[0]) if isinstance(steps, tuple) and len(steps) == 3 and hasattr(steps[0], "__len__") else len(steps)
+        log_t = max(n - 1, 0).bit_length()
+        super().__init__(steps, gamma, r_cycle, max(log_t, 1), self.LOG_K)
+        self._s.set_eq(self.gruen.getFullEqTable())  # eq(r_cycle_be, .) with r_cycle_be[0] <-> MSB
+        self.stage3_claims = stage3_claims
+        self.batching_coeff = fr_from_int(1) if batching_coeff is None else np.ascontiguousarray(batching_coeff, dtype=np.uint64).copy()
+
+    def computeRoundEvals(self, rnd, current_claim=None):
+        """computeRoundEvalsInternal (:601-723): p(0), p(1), p(2), p(3) from the tables"""
+        if rnd < self.log_T:
+            return np.stack(self._s.round_cycle(with_e1=True))
+        e0, e1, e2 = self._s.round_address(with_e1=True)
+        a, b, c = fr_to_int(e0), fr_to_int(e1), fr_to_int(e2)
+        return np.stack([e0, e1, e2, fr_from_int((a - 3 * b + 3 * c) % R_MOD)])
+
+    def computeRoundPolynomial(self, rnd, current_claim=None):
+        """computeRoundPolynomial (:731-758) -> coefficients [c0, c1, c2, c3]"""
+        e = [fr_to_int(x) for x in self.computeRoundEvals(rnd, current_claim)]
+        c3 = (-e[0] + 3 * e[1] - 3 * e[2] + e[3]) * pow(6, R_MOD - 2, R_MOD) % R_MOD
+        c2 = (2 * e[0] - 5 * e[1] + 4 * e[2] - e[3]) * pow(2, R_MOD - 2, R_MOD) % R_MOD
+        return np.stack([fr_from_int(v) for v in (e[0], (e[1] - e[0] - c2 - c3) % R_MOD, c2, c3)])
+
+    def bindChallenge(self, rnd, challenge):
+        """bindPolynomials (:779-839)"""
+        ch = np.ascontiguousarray(challenge, dtype=np.uint64)
+        if rnd < self.log_T:
+            self._s.bind_cycle(ch)
+            self.current_T //= 2
+        else:
+            self._s.bind_address(ch)
+            self.current_K //= 2
+
+    def prove(self, transcript, input_claim=None):
+        """prove (:395-567): the input claim from the Stage-3 claims when given (else input_claim, which the caller computed — the
+        reference sums the full tables on the CPU, :569-599), batched compressed coefficients into the Blake2b transcript, the challenge,
+        the batched claim"""
+        b = fr_to_int(self.batching_coeff)
+        if self.stage3_claims is not None:
+            g = fr_to_int(self.gamma)
+            rd, r1, r2 = (fr_to_int(x) for x in self.stage3_claims)
+            unbatched = (rd + g * r1 + g * g * r2) % R_MOD
+        else:
+            unbatched = fr_to_int(input_claim)
+        claim = unbatched * b % R_MOD
+        polys, chals = [], []
+        for rnd in range(self.num_rounds):
+            c = [fr_to_int(x) for x in self.computeRoundPolynomial(rnd, fr_from_int(claim))]
+            for i in (0, 2, 3):
+                transcript.appendScalar(fr_from_int(c[i] * b % R_MOD))
+            ch = transcript.challengeScalar()
+            chals.append(ch)
+            x = fr_to_int(ch)
+            claim = (c[0] + x * (c[1] + x * (c[2] + x * c[3]))) % R_MOD * b % R_MOD
+            self.bindChallenge(rnd, ch)
+            polys.append(np.stack([fr_from_int(v * b % R_MOD) for v in c]))
+        out = self.getFinalClaims()
+        out.update({"round_polys": np.stack(polys), "challenges": np.stack(chals), "final_claim": fr_from_int(claim)})
+        return out
+
+
 class LassoProver:
     """LassoProver's sumcheck over eq_evals (src/zkvm/lasso/prover.zig:80-467) on ONE device session: the padded eq_evals array is
     built on the device (SplitEqPolynomial.getEq, src/zkvm/lasso/split_eq.zig:113-168 = the eq table with each half's variables

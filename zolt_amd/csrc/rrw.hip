@@ -81,9 +81,13 @@ template <int NV>
 __device__ __forceinline__ void rrw_block_out(Fr (&acc)[NV], uint4 *sh, uint64_t *partials) {
     Fr z = Fr::zero();
     block_sum_pair(acc[0], acc[1], sh);
-    if constexpr (NV > 2) {
+    if constexpr (NV == 3) {
         __syncthreads();
         block_sum_pair(acc[2], z, sh);
+    }
+    if constexpr (NV == 4) {
+        __syncthreads();
+        block_sum_pair(acc[2], acc[3], sh);
     }
     if (threadIdx.x == 0)
 #pragma unroll
@@ -141,16 +145,21 @@ __global__ void __launch_bounds__(256) rrw_cycle_gruen_kernel(RrwTabs tb, size_t
 
 // phase 2 (:764-852) and the register rounds once no cycle is left (:955-1013): thread t -> cycle j = t % cur_T, pair chunk t / cur_T;
 // (e0, e2) += eq[j] * sum_i C at t = 0 / 2 of the row pair (2i, 2i + 1)
+// E1: also the value at t = 1 (the odd rows), which Stage4Prover evaluates directly (stage4_prover.zig:666-706) instead of taking it from the claim
+template <bool E1>
 __global__ void __launch_bounds__(256) rrw_address_kernel(RrwTabs tb, size_t stride, const uint64_t *inc, const uint64_t *eq, size_t cur_T,
                                                           uint32_t half_K, uint32_t ic_n, uint64_t *partials) {
     __shared__ uint4 sh[256 * 4];
-    Fr acc[2] = {Fr::zero(), Fr::zero()};
+    constexpr int NV = E1 ? 3 : 2;
+    Fr acc[NV];
+#pragma unroll
+    for (int a = 0; a < NV; a++) acc[a] = Fr::zero();
     size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (t < cur_T * ic_n) {
         size_t j = t % cur_T;
         uint32_t ic = (uint32_t)(t / cur_T);
         Fr incj = fe_load<FrParams>(inc + 4 * j);
-        Fr c0 = Fr::zero(), c2 = Fr::zero();
+        Fr c0 = Fr::zero(), c2 = Fr::zero(), c1 = Fr::zero();
         bool any = false;
         for (uint32_t i = ic; i < half_K; i += ic_n) {
             size_t oe = 4 * ((size_t)(2 * i) * stride + j), oo = oe + 4 * stride;
@@ -162,28 +171,34 @@ __global__ void __launch_bounds__(256) rrw_address_kernel(RrwTabs tb, size_t str
             c0 = fe_add(c0, fe_add(fr_mul29v(rae, vae), fr_mul29v(wae, fe_add(vae, incj))));
             Fr ra2 = fe_sub(fe_add(rao, rao), rae), wa2 = fe_sub(fe_add(wao, wao), wae), va2 = fe_sub(fe_add(vao, vao), vae);  // f(0) + 2 (f(1) - f(0))
             c2 = fe_add(c2, fe_add(fr_mul29v(ra2, va2), fr_mul29v(wa2, fe_add(va2, incj))));
+            if constexpr (E1) c1 = fe_add(c1, fe_add(fr_mul29v(rao, vao), fr_mul29v(wao, fe_add(vao, incj))));
         }
         if (any) {
             F29 ep = fr29_prescale(fe_load<FrParams>(eq + 4 * j));
             acc[0] = fr_mul29(c0, ep);
             acc[1] = fr_mul29(c2, ep);
+            if constexpr (E1) acc[2] = fr_mul29(c1, ep);
         }
     }
-    rrw_block_out<2>(acc, sh, partials);
+    rrw_block_out<NV>(acc, sh, partials);
 }
 
 // phase 3 with cycles left (:854-953): thread t -> cycle pair i, register chunk; (e0, e2, e3) += eq(t) * sum_k C(t), t = 0, 2, 3
+template <bool E1>
 __global__ void __launch_bounds__(256) rrw_cycle_dense_kernel(RrwTabs tb, size_t stride, const uint64_t *inc, const uint64_t *eq, size_t half_T,
                                                               uint32_t cur_K, uint32_t kc_n, uint64_t *partials) {
     __shared__ uint4 sh[256 * 4];
-    Fr acc[3] = {Fr::zero(), Fr::zero(), Fr::zero()};
+    constexpr int NV = E1 ? 4 : 3;
+    Fr acc[NV];
+#pragma unroll
+    for (int a = 0; a < NV; a++) acc[a] = Fr::zero();
     size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (t < half_T * kc_n) {
         size_t i = t % half_T;
         uint32_t kc = (uint32_t)(t / half_T);
         Fr inc0 = fe_load<FrParams>(inc + 8 * i), incs = fe_sub(fe_load<FrParams>(inc + 8 * i + 4), inc0);
         Fr inc2 = fe_add(fe_add(inc0, incs), incs), inc3 = fe_add(inc2, incs);
-        Fr c0 = Fr::zero(), c2 = Fr::zero(), c3 = Fr::zero();
+        Fr c0 = Fr::zero(), c2 = Fr::zero(), c3 = Fr::zero(), c1 = Fr::zero();
         bool any = false;
         for (uint32_t k = kc; k < cur_K; k += kc_n) {
             size_t o = 4 * ((size_t)k * stride + 2 * i);
@@ -194,6 +209,7 @@ __global__ void __launch_bounds__(256) rrw_cycle_dense_kernel(RrwTabs tb, size_t
             Fr vae = fe_load<FrParams>(tb.t[RT_VAL] + o), vao = fe_load<FrParams>(tb.t[RT_VAL] + o + 4);
             Fr ras = fe_sub(rao, rae), was = fe_sub(wao, wae), vas = fe_sub(vao, vae);
             c0 = fe_add(c0, fe_add(fr_mul29v(rae, vae), fr_mul29v(wae, fe_add(vae, inc0))));
+            if constexpr (E1) c1 = fe_add(c1, fe_add(fr_mul29v(rao, vao), fr_mul29v(wao, fe_add(vao, fe_add(inc0, incs)))));
             Fr ra2 = fe_add(rao, ras), wa2 = fe_add(wao, was), va2 = fe_add(vao, vas);
             c2 = fe_add(c2, fe_add(fr_mul29v(ra2, va2), fr_mul29v(wa2, fe_add(va2, inc2))));
             Fr ra3 = fe_add(ra2, ras), wa3 = fe_add(wa2, was), va3 = fe_add(va2, vas);
@@ -205,9 +221,10 @@ __global__ void __launch_bounds__(256) rrw_cycle_dense_kernel(RrwTabs tb, size_t
             acc[0] = fr_mul29v(c0, eqe);
             acc[1] = fr_mul29v(c2, eq2);
             acc[2] = fr_mul29v(c3, eq3);
+            if constexpr (E1) acc[3] = fr_mul29v(c1, fe_add(eqe, eqs));
         }
     }
-    rrw_block_out<3>(acc, sh, partials);
+    rrw_block_out<NV>(acc, sh, partials);
 }
 
 ZG_DEV Fr rrw_fold1(const Fr &lo, const Fr &hi, const FrMul &rm) {
@@ -345,7 +362,7 @@ int zg_rrw_open(size_t log_t, const uint8_t *rs1, const uint8_t *rs2, const uint
         e = hipMalloc((void **)&s->inc[b], (T >> b) * 32);
         if (e == hipSuccess) e = hipMalloc((void **)&s->eq[b], (T >> b) * 32);
     }
-    if (e == hipSuccess) e = hipMalloc((void **)&s->d_part, (size_t)RRW_MAX_BLOCKS * 3 * 32);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_part, (size_t)RRW_MAX_BLOCKS * 4 * 32);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_out, 8 * 32);
     if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_out, 8 * 32);
     if (e != hipSuccess) {
@@ -433,10 +450,10 @@ int zg_rrw_set_eq(zg_rrw_t s, const uint64_t *eq, size_t n) {
     return ZG_OK;
 }
 
-int zg_rrw_round_address(zg_rrw_t s, uint64_t e0[4], uint64_t e2[4]) {
+int zg_rrw_round_address(zg_rrw_t s, uint64_t e0[4], uint64_t *e1, uint64_t e2[4]) {
     ZG_INIT();
     if (!s || !e0 || !e2 || s->cur_K < 2 || !s->have_eq) {
-        set_error("zg_rrw_round_address: needs the merged eq table (zg_rrw_set_eq) and at least two registers left");
+        set_error("zg_rrw_round_address: needs the eq table (zg_rrw_set_eq) and at least two registers left");
         return ZG_ERR_INVALID;
     }
     DeviceGuard dg(s->device);
@@ -448,22 +465,27 @@ int zg_rrw_round_address(zg_rrw_t s, uint64_t e0[4], uint64_t e2[4]) {
         set_error("zg_rrw_round_address: table too long");
         return ZG_ERR_INVALID;
     }
-    hipLaunchKernelGGL(rrw_address_kernel, dim3(nb), dim3(256), 0, s->st, rrw_tabs(s), s->stride, s->inc[s->vcur], s->eq[s->vcur], s->cur_T, half_K, ic,
-                       s->d_part);
+    if (e1)
+        hipLaunchKernelGGL(rrw_address_kernel<true>, dim3(nb), dim3(256), 0, s->st, rrw_tabs(s), s->stride, s->inc[s->vcur], s->eq[s->vcur], s->cur_T, half_K, ic,
+                           s->d_part);
+    else
+        hipLaunchKernelGGL(rrw_address_kernel<false>, dim3(nb), dim3(256), 0, s->st, rrw_tabs(s), s->stride, s->inc[s->vcur], s->eq[s->vcur], s->cur_T, half_K, ic,
+                           s->d_part);
     ZG_HIP(hipGetLastError());
-    uint64_t o[8];
-    ZG_TRY(rrw_collect(s, nb, 2, o));
+    uint64_t o[12];
+    ZG_TRY(rrw_collect(s, nb, e1 ? 3 : 2, o));
     for (int i = 0; i < 4; i++) {
         e0[i] = o[i];
         e2[i] = o[4 + i];
+        if (e1) e1[i] = o[8 + i];
     }
     return ZG_OK;
 }
 
-int zg_rrw_round_cycle(zg_rrw_t s, uint64_t e0[4], uint64_t e2[4], uint64_t e3[4]) {
+int zg_rrw_round_cycle(zg_rrw_t s, uint64_t e0[4], uint64_t *e1, uint64_t e2[4], uint64_t e3[4]) {
     ZG_INIT();
     if (!s || !e0 || !e2 || !e3 || s->cur_T < 2 || !s->have_eq) {
-        set_error("zg_rrw_round_cycle: needs the merged eq table (zg_rrw_set_eq) and at least two cycles left");
+        set_error("zg_rrw_round_cycle: needs the eq table (zg_rrw_set_eq) and at least two cycles left");
         return ZG_ERR_INVALID;
     }
     DeviceGuard dg(s->device);
@@ -475,15 +497,20 @@ int zg_rrw_round_cycle(zg_rrw_t s, uint64_t e0[4], uint64_t e2[4], uint64_t e3[4
         set_error("zg_rrw_round_cycle: table too long");
         return ZG_ERR_INVALID;
     }
-    hipLaunchKernelGGL(rrw_cycle_dense_kernel, dim3(nb), dim3(256), 0, s->st, rrw_tabs(s), s->stride, s->inc[s->vcur], s->eq[s->vcur], half, s->cur_K, kc,
-                       s->d_part);
+    if (e1)
+        hipLaunchKernelGGL(rrw_cycle_dense_kernel<true>, dim3(nb), dim3(256), 0, s->st, rrw_tabs(s), s->stride, s->inc[s->vcur], s->eq[s->vcur], half, s->cur_K, kc,
+                           s->d_part);
+    else
+        hipLaunchKernelGGL(rrw_cycle_dense_kernel<false>, dim3(nb), dim3(256), 0, s->st, rrw_tabs(s), s->stride, s->inc[s->vcur], s->eq[s->vcur], half, s->cur_K, kc,
+                           s->d_part);
     ZG_HIP(hipGetLastError());
-    uint64_t o[12];
-    ZG_TRY(rrw_collect(s, nb, 3, o));
+    uint64_t o[16];
+    ZG_TRY(rrw_collect(s, nb, e1 ? 4 : 3, o));
     for (int i = 0; i < 4; i++) {
         e0[i] = o[i];
         e2[i] = o[4 + i];
         e3[i] = o[8 + i];
+        if (e1) e1[i] = o[12 + i];
     }
     return ZG_OK;
 }

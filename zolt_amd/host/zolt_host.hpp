@@ -1707,6 +1707,31 @@ struct TraceStep {  // what the prover reads of ExecutionTrace.steps (:196-246)
     uint64_t rd_value;
     bool is_noop;
 };
+// what initWithPhaseConfig / initWithClaims read of the trace (stage4_gruen_prover.zig:183-258 = stage4_prover.zig:183-277), as the columns
+// zg_rrw_open takes: the register a cycle reads / writes (0xFF: none), the register file before every cycle, inc of the written register
+inline zg_rrw_t openRegistersSession(const std::vector<TraceStep> &steps, size_t log_T, const Fr &gamma) {
+    const size_t T = size_t(1) << log_T;
+    std::vector<uint8_t> rs1(T, 0xFF), rs2(T, 0xFF), rd(T, 0xFF);
+    std::vector<uint64_t> reg_vals(32 * T, 0);
+    std::vector<Fr> inc(T, Fr::zero());
+    uint64_t regs[32] = {};
+    for (size_t j = 0; j < T; j++) {
+        for (size_t k = 0; k < 32; k++) reg_vals[k * T + j] = regs[k];
+        if (j >= steps.size() || steps[j].is_noop) continue;
+        const uint32_t w = steps[j].instruction, op = w & 0x7F, f_rd = (w >> 7) & 31, f_rs1 = (w >> 15) & 31, f_rs2 = (w >> 20) & 31;
+        const bool two = op == 0x33 || op == 0x3B || op == 0x23 || op == 0x63;
+        if (two || op == 0x13 || op == 0x03 || op == 0x67 || op == 0x1B) rs1[j] = (uint8_t)f_rs1;
+        if (two) rs2[j] = (uint8_t)f_rs2;
+        if (op != 0x23 && op != 0x63 && f_rd != 0) {
+            rd[j] = (uint8_t)f_rd;
+            inc[j] = Fr::fromU64(steps[j].rd_value).sub(Fr::fromU64(regs[f_rd]));
+            regs[f_rd] = steps[j].rd_value;
+        }
+    }
+    zg_rrw_t s = nullptr;
+    check(zg_rrw_open(log_T, rs1.data(), rs2.data(), rd.data(), reg_vals.data(), reinterpret_cast<const uint64_t *>(inc.data()), gamma.limbs, &s), "zg_rrw_open");
+    return s;
+}
 class Stage4GruenProver {
 public:
     static constexpr size_t LOG_K = 7, K = 128;
@@ -1720,24 +1745,7 @@ public:
         if (r_cycle.size() != log_T || log_T < 1 || p1_ < 1 || p1_ > log_T || p2_ != LOG_K) throw std::invalid_argument("Stage4GruenProver: configuration");
         current_T = T;
         num_rounds = LOG_K + log_T;
-        std::vector<uint8_t> rs1(T, 0xFF), rs2(T, 0xFF), rd(T, 0xFF);
-        std::vector<uint64_t> reg_vals(32 * T, 0);
-        std::vector<Fr> inc(T, Fr::zero());
-        uint64_t regs[32] = {};
-        for (size_t j = 0; j < T; j++) {  // :183-258
-            for (size_t k = 0; k < 32; k++) reg_vals[k * T + j] = regs[k];
-            if (j >= steps.size() || steps[j].is_noop) continue;
-            const uint32_t w = steps[j].instruction, op = w & 0x7F, f_rd = (w >> 7) & 31, f_rs1 = (w >> 15) & 31, f_rs2 = (w >> 20) & 31;
-            const bool two = op == 0x33 || op == 0x3B || op == 0x23 || op == 0x63;
-            if (two || op == 0x13 || op == 0x03 || op == 0x67 || op == 0x1B) rs1[j] = (uint8_t)f_rs1;
-            if (two) rs2[j] = (uint8_t)f_rs2;
-            if (op != 0x23 && op != 0x63 && f_rd != 0) {
-                rd[j] = (uint8_t)f_rd;
-                inc[j] = Fr::fromU64(steps[j].rd_value).sub(Fr::fromU64(regs[f_rd]));
-                regs[f_rd] = steps[j].rd_value;
-            }
-        }
-        check(zg_rrw_open(log_T, rs1.data(), rs2.data(), rd.data(), reg_vals.data(), reinterpret_cast<const uint64_t *>(inc.data()), gamma.limbs, &s_), "zg_rrw_open");
+        s_ = openRegistersSession(steps, log_T, gamma);
         // the two prefix-table sets of the split-eq structure, in HBM for the phase-1 rounds (table k starts at element 2^k - 1)
         const size_t m = log_T / 2;
         try {
@@ -1766,12 +1774,12 @@ public:
         }
         if (round < p1_ + p2_ || current_T == 1) {  // phase2ComputeMessage (:764-852); phase 3 with a single cycle left (:955-1013)
             Fr e0, e2;
-            check(zg_rrw_round_address(s_, e0.limbs, e2.limbs), "zg_rrw_round_address");
+            check(zg_rrw_round_address(s_, e0.limbs, nullptr, e2.limbs), "zg_rrw_round_address");
             Fr e1 = current_claim.sub(e0), three = Fr::fromU64(3);
             return {e0, e1, e2, e0.sub(three.mul(e1)).add(three.mul(e2))};  // the quadratic's p(3) (:841-850)
         }
         Fr e0, e2, e3;  // phase3ComputeMessage (:854-953)
-        check(zg_rrw_round_cycle(s_, e0.limbs, e2.limbs, e3.limbs), "zg_rrw_round_cycle");
+        check(zg_rrw_round_cycle(s_, e0.limbs, nullptr, e2.limbs, e3.limbs), "zg_rrw_round_cycle");
         return {e0, current_claim.sub(e0), e2, e3};
     }
     void bindChallenge(size_t round, const Fr &challenge) {  // :1047-1163, 1192-1216
@@ -1808,6 +1816,68 @@ private:
     GruenSplitEqPolynomial gruen_;
     zg_rrw_t s_ = nullptr;
     DeviceMem d_out_, d_in_;
+};
+
+// the original Stage4Prover (src/zkvm/spartan/stage4_prover.zig:74-865) on the same device session: dense eq table from the start, every
+// cycle variable first, all four evaluations from the tables (:601-723), full-coefficient round polynomial (:731-758)
+class Stage4Prover {
+public:
+    static constexpr size_t LOG_K = 7, K = 128;
+    size_t T = 1, log_T = 0, current_T = 0, current_K = K, num_rounds = 0;
+    Stage4Prover(const std::vector<TraceStep> &steps, const Fr &gamma, const std::vector<Fr> &r_cycle) {
+        if (steps.empty()) throw std::invalid_argument("Stage4Prover: empty trace");  // error.EmptyTrace
+        while (T < steps.size()) T <<= 1, log_T++;
+        if (log_T < 1) throw std::invalid_argument("Stage4Prover: at least two cycles");  // (the device session holds cycle pairs)
+        if (r_cycle.size() != log_T) throw std::invalid_argument("Stage4Prover: r_cycle length");  // error.InvalidRCycleLength
+        current_T = T;
+        num_rounds = LOG_K + log_T;
+        s_ = openRegistersSession(steps, log_T, gamma);
+        std::vector<Fr> be(r_cycle.rbegin(), r_cycle.rend());  // :279-292: computeEqEvalsBE of the reversed point
+        std::vector<Fr> eq = EqPolynomial::evalsSliceWithScaling(be, nullptr);
+        int rc = zg_rrw_set_eq(s_, reinterpret_cast<const uint64_t *>(eq.data()), eq.size());
+        if (rc != ZG_OK) { zg_rrw_close(s_); check(rc, "zg_rrw_set_eq"); }
+    }
+    Stage4Prover(const Stage4Prover &) = delete;
+    Stage4Prover &operator=(const Stage4Prover &) = delete;
+    ~Stage4Prover() { zg_rrw_close(s_); }
+    std::array<Fr, 4> computeRoundEvals(size_t round, const Fr & /* current_claim: not read, p(1) comes from the tables */) {
+        std::array<Fr, 4> e;
+        if (round < log_T) {
+            check(zg_rrw_round_cycle(s_, e[0].limbs, e[1].limbs, e[2].limbs, e[3].limbs), "zg_rrw_round_cycle");
+        } else {
+            check(zg_rrw_round_address(s_, e[0].limbs, e[1].limbs, e[2].limbs), "zg_rrw_round_address");
+            Fr three = Fr::fromU64(3);
+            e[3] = e[0].sub(three.mul(e[1])).add(three.mul(e[2]));  // quadratic in the register variable
+        }
+        return e;
+    }
+    std::array<Fr, 4> computeRoundPolynomial(size_t round, const Fr &current_claim) {  // :731-758 -> c0..c3
+        auto e = computeRoundEvals(round, current_claim);
+        Fr six_inv, two_inv;
+        Fr::fromU64(6).inverse(six_inv);
+        Fr::fromU64(2).inverse(two_inv);
+        Fr three = Fr::fromU64(3);
+        Fr c3 = Fr::zero().sub(e[0]).add(e[1].mul(three)).sub(e[2].mul(three)).add(e[3]).mul(six_inv);
+        Fr c2 = e[0].mul(Fr::fromU64(2)).sub(e[1].mul(Fr::fromU64(5))).add(e[2].mul(Fr::fromU64(4))).sub(e[3]).mul(two_inv);
+        return {e[0], e[1].sub(e[0]).sub(c2).sub(c3), c2, c3};
+    }
+    void bindChallenge(size_t round, const Fr &challenge) {  // :779-839
+        if (round < log_T) {
+            check(zg_rrw_bind_cycle(s_, challenge.limbs), "zg_rrw_bind_cycle");
+            current_T /= 2;
+        } else {
+            check(zg_rrw_bind_address(s_, challenge.limbs), "zg_rrw_bind_address");
+            current_K /= 2;
+        }
+    }
+    Stage4GruenProver::FinalClaims getFinalClaims() {  // :845-863
+        Fr f[7];
+        check(zg_rrw_final(s_, reinterpret_cast<uint64_t *>(f)), "zg_rrw_final");
+        return Stage4GruenProver::FinalClaims{f[0], f[3], f[4], f[1], f[5]};
+    }
+
+private:
+    zg_rrw_t s_ = nullptr;
 };
 
 class InstructionLookupsClaimReductionProver {

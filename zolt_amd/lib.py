@@ -883,15 +883,17 @@ class RegistersRwSession:
         eq = _c(eq)
         _chk(_lib.zg_rrw_set_eq(self._h, _h(eq), C.c_size_t(eq.size // 4)), "zg_rrw_set_eq")
 
-    def round_address(self):
-        a, b = np.empty(4, dtype=np.uint64), np.empty(4, dtype=np.uint64)
-        _chk(_lib.zg_rrw_round_address(self._h, _h(a), _h(b)), "zg_rrw_round_address")
-        return a, b
-
-    def round_cycle(self):
+    def round_address(self, with_e1=False):
+        """(e0, e2), or (e0, e1, e2) with the t = 1 value computed from the tables"""
         a, b, c = (np.empty(4, dtype=np.uint64) for _ in range(3))
-        _chk(_lib.zg_rrw_round_cycle(self._h, _h(a), _h(b), _h(c)), "zg_rrw_round_cycle")
-        return a, b, c
+        _chk(_lib.zg_rrw_round_address(self._h, _h(a), _h(c) if with_e1 else None, _h(b)), "zg_rrw_round_address")
+        return (a, c, b) if with_e1 else (a, b)
+
+    def round_cycle(self, with_e1=False):
+        """(e0, e2, e3), or (e0, e1, e2, e3)"""
+        a, b, c, d = (np.empty(4, dtype=np.uint64) for _ in range(4))
+        _chk(_lib.zg_rrw_round_cycle(self._h, _h(a), _h(d) if with_e1 else None, _h(b), _h(c)), "zg_rrw_round_cycle")
+        return (a, d, b, c) if with_e1 else (a, b, c)
 
     def bind_cycle(self, r):
         _chk(_lib.zg_rrw_bind_cycle(self._h, _h(_c(r))), "zg_rrw_bind_cycle")
