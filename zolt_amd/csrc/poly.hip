@@ -85,8 +85,9 @@ ZG_DEV Fr eq_block_factors(const EqArgs &a, int v_lo, int v_hi, uint32_t h0, uin
         const uint32_t e = tid & 15u;
         // group g covers index bits [b0, b0 + nb) of the low part (g < 2) or of h (g >= 2); bit b <-> variable var(b)
         const int part_bits = g < 2 ? v_lo : v_hi, b0 = g < 2 ? 4 * g : 4 * (g - 2);
-        Fr acc = one;
-        bool used = false;
+        // the group's <= 4 factors as a balanced tree, (f0 f1)(f2 f3): two independent products, then one — a chain of two instead of three
+        Fr f[4];
+        int nf = 0;
         for (int b = 0; b < 4; b++) {
             const int bit = b0 + b;
             if (bit >= part_bits) break;
@@ -94,9 +95,15 @@ ZG_DEV Fr eq_block_factors(const EqArgs &a, int v_lo, int v_hi, uint32_t h0, uin
             Fr rj;
 #pragma unroll
             for (int i = 0; i < 8; i++) rj.l[i] = a.r[var][i];
-            Fr f = ((e >> b) & 1u) ? rj : fe_sub(one, rj);
-            acc = used ? fr_mul29v(acc, f) : f;
-            used = true;
+            f[nf++] = ((e >> b) & 1u) ? rj : fe_sub(one, rj);
+        }
+        Fr acc = one;
+        if (nf == 1) acc = f[0];
+        else if (nf == 2) acc = fr_mul29v(f[0], f[1]);
+        else if (nf == 3) acc = fr_mul29v(fr_mul29v(f[0], f[1]), f[2]);
+        else if (nf == 4) {
+            Fr p01 = fr_mul29v(f[0], f[1]), p23 = fr_mul29v(f[2], f[3]);
+            acc = fr_mul29v(p01, p23);
         }
         fe_store(&sh.small[g][e][0], acc);
     }
@@ -125,15 +132,18 @@ ZG_DEV Fr eq_block_factors(const EqArgs &a, int v_lo, int v_hi, uint32_t h0, uin
 
 // out[(h << v_lo) | t] = hi[h] * lo[t]; one 32-byte store per thread and row, 8 KiB contiguous per (block, h): the
 // kernel is an HBM write stream with one mixed-format product (fr_mul29) per element.
-__global__ void __launch_bounds__(256) eq_main_kernel(EqArgs a, int v_lo, int v_hi, uint32_t hi_per_block, uint64_t *out) {
+// WG groups of 256 threads per block: thread (grp, lo) writes rows grp, grp + WG, ... — the factor prologue (a latency chain of ~5
+// products) is paid once per block, and a block of 1024 threads keeps four waves per SIMD in the product stream behind it.
+template <int WG>
+__global__ void __launch_bounds__(256 * WG) eq_main_kernel(EqArgs a, int v_lo, int v_hi, uint32_t hi_per_block, uint64_t *out) {
     __shared__ EqShared sh;
     const uint32_t n_hi = 1u << v_hi, h0 = blockIdx.x * hi_per_block;
     const uint32_t rows = n_hi - h0 < hi_per_block ? n_hi - h0 : hi_per_block;
     Fr lov = eq_block_factors(a, v_lo, v_hi, h0, rows, sh);
-    uint32_t lo = threadIdx.x;
+    const uint32_t lo = threadIdx.x & 255u, grp = threadIdx.x >> 8;
     if (lo >= (1u << v_lo)) return;
     F29 tp = fr29_prescale(lov);  // shared factor of this thread's products
-    for (uint32_t k = 0; k < rows; k++) {
+    for (uint32_t k = grp; k < rows; k += WG) {
         Fr hv = fe_load<FrParams>(&sh.hi_row[k][0]);
         fe_store(out + 4 * (((size_t)(h0 + k) << v_lo) | lo), fr_mul29(hv, tp));
     }
@@ -772,10 +782,19 @@ static int eq_table_enqueue(const uint64_t *r_host, size_t v, const uint64_t *sc
     ZG_TRY(eq_args_fill(a, r_host, v, scale_host));
     int v_lo = v < 8 ? (int)v : 8, v_hi = (int)v - v_lo;
     uint32_t n_hi = 1u << v_hi;
-    static const uint32_t nb_cap = env_uint("ZG_EQ_BLOCKS", 512, 1, 65536);
+    // one block per CU up to 2^20 entries (the factor prologue is per block), two above; 512 threads: measured, profiles/r3f_eq_ab.txt
+    static const uint32_t nb_env = env_uint("ZG_EQ_BLOCKS", 0, 0, 65536);
+    const uint32_t nb_cap = nb_env ? nb_env : (n_hi <= 4096 ? 256u : 512u);
     uint32_t hpb = eq_rows_per_block(n_hi, nb_cap);
     prof_begin(ZG_PROF_EQ_TABLE, st);
-    hipLaunchKernelGGL(eq_main_kernel, dim3(div_up(n_hi, hpb)), dim3(256), 0, st, a, v_lo, v_hi, hpb, d_out);
+    static const uint32_t wg_env = env_uint("ZG_EQ_WG", 0, 0, 4);
+    const uint32_t wg = wg_env ? wg_env : (n_hi <= 4096 ? 2u : 1u);
+    if (wg >= 4 && hpb >= 4)
+        hipLaunchKernelGGL(eq_main_kernel<4>, dim3(div_up(n_hi, hpb)), dim3(1024), 0, st, a, v_lo, v_hi, hpb, d_out);
+    else if (wg >= 2 && hpb >= 2)
+        hipLaunchKernelGGL(eq_main_kernel<2>, dim3(div_up(n_hi, hpb)), dim3(512), 0, st, a, v_lo, v_hi, hpb, d_out);
+    else
+        hipLaunchKernelGGL(eq_main_kernel<1>, dim3(div_up(n_hi, hpb)), dim3(256), 0, st, a, v_lo, v_hi, hpb, d_out);
     prof_end(ZG_PROF_EQ_TABLE, st);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
