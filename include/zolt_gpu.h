@@ -416,6 +416,42 @@ ZG_API int zg_rrw_bind_address(zg_rrw_t s, const uint64_t r[4]);
 ZG_API int zg_rrw_final(zg_rrw_t s, uint64_t *out /* 28 */);
 ZG_API int zg_rrw_close(zg_rrw_t s);
 
+/* ------------------------------------------------------------------ RAM read/write checking (Stage 2, the sparse instance) */
+/* RamReadWriteCheckingProver (src/zkvm/ram/read_write_checking.zig:160-1323): a list of access entries {cycle, address, ra_coeff, val_coeff,
+ * prev_val, next_val} (:91-157) beside three dense tables — eq_evals = eq(r_cycle, .) and inc over 2^log_t cycles, val_init over 2^log_k
+ * words — and log_t + log_k rounds in three phases: phase1_num_rounds cycle variables, the address variables, the remaining cycle
+ * variables. The session owns everything: the integer fields of the list live on the host inside the library, where the reference's
+ * sequential walks (who pairs with whom, which checkpoint a lone entry meets) run once per round; ra_coeff, val_coeff and the dense
+ * tables live in HBM, where one kernel turns a round's walk into its two sums and one into the bound list. The caller keeps what the
+ * reference's struct keeps besides: the GruenSplitEqPolynomial (its prefix tables as device buffers), the cubic, the claim.
+ *   entries: sorted by (cycle, address) as init leaves them (:333-340); val_coeff as u64 (F.fromU64 of prev_val for a write, of the value
+ *   for a read, :300-330), ra_coeff = 1; inc / val_init: field elements (:253-330); r_cycle: the eq point, r_cycle[0] <-> MSB (:345-348). */
+typedef struct zg_rwc_s *zg_rwc_t;
+ZG_API int zg_rwc_open(size_t log_k, size_t log_t, size_t n, const uint32_t *cycle, const uint32_t *address, const uint64_t *val_coeff,
+                const uint64_t *prev_val, const uint64_t *next_val, const uint64_t *inc /* 2^log_t * 4 */, const uint64_t *val_init /* 2^log_k * 4 */,
+                const uint64_t *r_cycle /* log_t * 4 */, zg_rwc_t *s);
+ZG_API size_t zg_rwc_entries(zg_rwc_t s); /* current length of the list */
+ZG_API size_t zg_rwc_cycles(zg_rwc_t s);  /* current length of eq_evals / inc */
+/* computePhase1Polynomial's (q_constant, q_quadratic) (:410-536) under the split-eq weights E_out x E_in (DEVICE tables, as
+ * zg_psc_round_gruen takes them); cycle phases 1 and 3 */
+ZG_API int zg_rwc_round_cycle(zg_rwc_t s, const uint64_t *d_e_out, size_t n_out, const uint64_t *d_e_in, size_t n_in, const uint64_t gamma[4],
+                       uint64_t q_constant[4], uint64_t q_quadratic[4]);
+/* bindChallenge in a cycle phase (:919-938, 1139-1185): eq_evals and inc LowToHigh, the entry list pairwise. Needs zg_rwc_cycles(s) >= 2
+ * (the reference skips the whole bind otherwise, :915). */
+ZG_API int zg_rwc_bind_cycle(zg_rwc_t s, const uint64_t r[4]);
+/* computePhase2Polynomial's (s(0), s(2)) (:538-769) in address round addr_round = round - phase1_num_rounds; challenges: the address
+ * challenges bound so far (addr_round elements, host). The first call sorts the list address-major (:553-558). */
+ZG_API int zg_rwc_round_address(zg_rwc_t s, size_t addr_round, const uint64_t *challenges, const uint64_t gamma[4], uint64_t s0[4], uint64_t s2[4]);
+/* bindChallenge in the address phase (:953-970, 973-1137): val_init LowToHigh, then the entry list by column pairs */
+ZG_API int zg_rwc_bind_address(zg_rwc_t s, size_t addr_round, const uint64_t r[4]);
+/* getOpeningClaims (:1210-1322): ra_claim, val_claim, inc_claim (3 x 4 words) at r_address (log_k, [0] <-> MSB) and r_cycle (log_t) */
+ZG_API int zg_rwc_opening(zg_rwc_t s, const uint64_t *r_address, const uint64_t *r_cycle, uint64_t out[12]);
+/* eq_evals[0] and inc[0] as they stand (the two scalars the address phase works with, :543-552) */
+ZG_API int zg_rwc_cycle_scalars(zg_rwc_t s, uint64_t eq0[4], uint64_t inc0[4]);
+/* the current list (any pointer may be NULL); the coefficient columns come from the device */
+ZG_API int zg_rwc_read_entries(zg_rwc_t s, uint32_t *cycle, uint32_t *address, uint64_t *ra_coeff, uint64_t *val_coeff, uint64_t *prev_val, uint64_t *next_val);
+ZG_API int zg_rwc_close(zg_rwc_t s);
+
 /* ------------------------------------------------------------------ several GPUs in one process */
 /* The bases (SRS) sharded over the bound devices in ParallelMSM's contiguous chunks of ceil(n / S) points
  * (src/msm/mod.zig:609,619-639), one resident table per device. */

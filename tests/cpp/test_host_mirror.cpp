@@ -598,7 +598,7 @@ static int rwc_main(const char *path) {
         p.bindChallenge(ch[rd]);
         std::printf("C");
         print_fr(p.current_claim);
-        std::printf(" %zu\n", p.entries.size());
+        std::printf(" %zu\n", p.numEntries());
     }
     auto oc = p.getOpeningClaims(ch);
     std::printf("O");

@@ -58,7 +58,7 @@ def test_zig_ffi_is_generated_from_the_header():
         zargs, cargs = _split_params(args), protos[name]
         assert len(zargs) == len(cargs), (name, zargs, cargs)
         for za, ca in zip(zargs, cargs):
-            c_ptr = "*" in ca or "[" in ca or any(h in ca for h in ("zg_bases_t", "zg_sc_t", "zg_sbases_t", "zg_ssc_t", "zg_psc_t", "zg_rrw_t"))
+            c_ptr = "*" in ca or "[" in ca or any(h in ca for h in ("zg_bases_t", "zg_sc_t", "zg_sbases_t", "zg_ssc_t", "zg_psc_t", "zg_rrw_t", "zg_rwc_t"))
             z_ptr = "*" in za or any(h in za for h in ("Bases", "Session"))
             assert c_ptr == z_ptr, (name, za, ca)
     for cname, cval in re.findall(r"#define (ZG_(?:OK|ERR_\w+|SC_\w+|FIELD_\w+)) (\d+)", hdr):

@@ -1,6 +1,6 @@
-"""RamReadWriteCheckingProver (src/zkvm/ram/read_write_checking.zig:160-1323) on the device mirror — SURVEY 8(f)3: the three-phase
-sumcheck whose dense tables (eq_evals, inc: one two-table LowToHigh session; val_init: a LOW_PAIR session) are folded on the GPU while
-the sparse access entries stay host scalar code, as in the reference. Held against (1) the reference's own captured run, end to end
+"""RamReadWriteCheckingProver (src/zkvm/ram/read_write_checking.zig:160-1323) on the device session (zg_rwc_*) — SURVEY 8(f)3: the
+three-phase sumcheck whose entry list is walked on the host (integers only) and evaluated / bound on the GPU next to its dense tables
+(eq_evals, inc, val_init). Held against (1) the reference's own captured run, end to end
 (tests/golden/rwc_captured_run.json: every printed prefix, the final claim and the three opening claims in full), and (2) the oracle's
 restatement on random traces at 2^8, 2^13 and 2^20 cycles — every round polynomial, every bound entry, every claim, bit for bit."""
 import json
@@ -61,7 +61,7 @@ def _trace(seed, log_k, log_t, n_acc, start):
 
 
 @pytest.mark.parametrize("log_k,log_t,p1,n_acc", [(4, 8, 4, 200), (3, 8, 0, 256), (6, 8, 8, 90), (10, 13, 6, 3000), (16, 20, 10, 2500), (1, 1, 0, 2),
-                                                  (5, 4, 2, 0)])
+                                                  (5, 4, 2, 0), (12, 15, 7, 12000)])
 def test_ram_read_write_checking_vs_oracle(env, log_k, log_t, p1, n_acc):
     api, lib, ob = env
     start = 0x80000000
@@ -94,6 +94,8 @@ def test_ram_read_write_checking_vs_oracle(env, log_k, log_t, p1, n_acc):
                 x.updateClaim(we, ch)
                 x.bindChallenge(ch)
             assert d.current_claim == o.current_claim and d.entry_list() == [(e[0], e[1], e[2]) for e in o.entries], rd
+            if rd % 5 == 0 or rd >= log_k + log_t - 2:  # every field of every entry
+                assert d.entries_full() == [[e[0], e[1], e[2] % P, e[3] % P, e[4], e[5]] for e in o.entries], rd
         assert d.isComplete() and o.isComplete()
         wo, go = o.getOpeningClaims(np.stack(chal)), d.getOpeningClaims(np.stack(chal))
         assert all(np.array_equal(a, b) for a, b in zip(go, wo))

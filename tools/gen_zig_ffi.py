@@ -14,8 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HDR = os.path.join(ROOT, "include", "zolt_gpu.h")
 OUT = os.path.join(ROOT, "zig", "gpu", "ffi.zig")
 
-HANDLES = {"zg_bases_t": "Bases", "zg_sc_t": "Session", "zg_sbases_t": "ShardedBases", "zg_ssc_t": "ShardedSession", "zg_psc_t": "ProductSession", "zg_rrw_t": "RegistersSession"}
-SCALARS = {"int": "c_int", "unsigned": "c_uint", "size_t": "usize", "uint64_t": "u64", "uint8_t": "u8", "double": "f64"}
+HANDLES = {"zg_bases_t": "Bases", "zg_sc_t": "Session", "zg_sbases_t": "ShardedBases", "zg_ssc_t": "ShardedSession", "zg_psc_t": "ProductSession", "zg_rrw_t": "RegistersSession", "zg_rwc_t": "RamRwSession"}
+SCALARS = {"int": "c_int", "unsigned": "c_uint", "size_t": "usize", "uint64_t": "u64", "uint32_t": "u32", "uint8_t": "u8", "double": "f64"}
 
 
 def split_params(arglist):

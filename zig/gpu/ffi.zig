@@ -128,6 +128,17 @@ pub extern fn zg_rrw_bind_cycle(s: RegistersSession, r: *const [4]u64) c_int;
 pub extern fn zg_rrw_bind_address(s: RegistersSession, r: *const [4]u64) c_int;
 pub extern fn zg_rrw_final(s: RegistersSession, out: ?[*]u64) c_int;
 pub extern fn zg_rrw_close(s: RegistersSession) c_int;
+pub extern fn zg_rwc_open(log_k: usize, log_t: usize, n: usize, cycle: ?[*]const u32, address: ?[*]const u32, val_coeff: ?[*]const u64, prev_val: ?[*]const u64, next_val: ?[*]const u64, inc: ?[*]const u64, val_init: ?[*]const u64, r_cycle: ?[*]const u64, s: *RamRwSession) c_int;
+pub extern fn zg_rwc_entries(s: RamRwSession) usize;
+pub extern fn zg_rwc_cycles(s: RamRwSession) usize;
+pub extern fn zg_rwc_round_cycle(s: RamRwSession, d_e_out: ?[*]const u64, n_out: usize, d_e_in: ?[*]const u64, n_in: usize, gamma: *const [4]u64, q_constant: *[4]u64, q_quadratic: *[4]u64) c_int;
+pub extern fn zg_rwc_bind_cycle(s: RamRwSession, r: *const [4]u64) c_int;
+pub extern fn zg_rwc_round_address(s: RamRwSession, addr_round: usize, challenges: ?[*]const u64, gamma: *const [4]u64, s0: *[4]u64, s2: *[4]u64) c_int;
+pub extern fn zg_rwc_bind_address(s: RamRwSession, addr_round: usize, r: *const [4]u64) c_int;
+pub extern fn zg_rwc_opening(s: RamRwSession, r_address: ?[*]const u64, r_cycle: ?[*]const u64, out: *[12]u64) c_int;
+pub extern fn zg_rwc_cycle_scalars(s: RamRwSession, eq0: *[4]u64, inc0: *[4]u64) c_int;
+pub extern fn zg_rwc_read_entries(s: RamRwSession, cycle: ?[*]u32, address: ?[*]u32, ra_coeff: ?[*]u64, val_coeff: ?[*]u64, prev_val: ?[*]u64, next_val: ?[*]u64) c_int;
+pub extern fn zg_rwc_close(s: RamRwSession) c_int;
 pub extern fn zg_shard_bounds(n: usize, shards: c_int, shard: c_int, start: ?*usize, len: ?*usize) c_int;
 pub extern fn zg_g1_bases_upload_sharded(xy: ?[*]const u64, inf: ?[*]const u8, n: usize, cfg: ?*const MsmConfig, out: *ShardedBases) c_int;
 pub extern fn zg_g1_sbases_free(sb: ShardedBases) c_int;

@@ -1729,15 +1729,15 @@ def generateBatchedProof(prover, transcript):
 
 class RamReadWriteCheckingProver:
     """RamReadWriteCheckingProver (src/zkvm/ram/read_write_checking.zig:160-1323): the three-phase sumcheck (phase1_num_rounds cycle
-    variables, log_k address variables, the remaining cycle variables) over a SPARSE access matrix with three DENSE side tables. The
-    dense tables live on the device and are folded there — eq_evals and inc (2^log_t entries, LowToHigh: one two-table product-form
-    session, zg_psc_bind) and val_init (2^log_k entries: a LOW_PAIR session, zg_sumcheck_bind) — and the host reads of them only the
-    rows / columns the entries touch (zg_psc_gather / zg_sumcheck_gather). The sparse entry algebra (pair merges, checkpoints, the
-    Gruen cubic) is host scalar code, as in the reference. accesses: [(timestamp, address, is_write, value)] in trace order;
-    initial_ram: {address: u64}. Entry = [cycle, address, ra_coeff, val_coeff, prev_val, next_val] (CycleMajorEntry, :91-157), integers mod r."""
+    variables, log_k address variables, the remaining cycle variables) over a SPARSE access list with three DENSE side tables, all of it
+    behind one device session (zg_rwc_*): the library walks the list's integer fields on the host once per round (who pairs with whom,
+    which checkpoint a lone entry meets — the reference's sequential loops), the coefficients and the tables live in HBM and every round
+    is one kernel for the two sums and one for the bound list. What stays here is what the reference's struct keeps besides: the trace
+    decoding of init, the GruenSplitEqPolynomial, the cubic, the claim. accesses: [(timestamp, address, is_write, value)] in trace order;
+    initial_ram: {address: u64}."""
 
     def __init__(self, accesses, gamma, r_cycle, log_k, log_t, phase1_num_rounds, start_address, initial_claim, initial_ram=None):
-        self.gamma = fr_to_int(gamma)
+        self.gamma = np.ascontiguousarray(gamma, dtype=np.uint64).copy()
         self.r_cycle = np.ascontiguousarray(r_cycle, dtype=np.uint64).reshape(-1, 4).copy()
         self.log_k, self.log_t, self.phase1_num_rounds, self.start_address = log_k, log_t, phase1_num_rounds, start_address
         K, T = 1 << log_k, 1 << log_t
@@ -1749,7 +1749,7 @@ class RamReadWriteCheckingProver:
                 idx = (addr - start_address) // 8
                 val_init[idx] = fr_from_int(val)
                 cur[idx] = val
-        self.entries = []
+        ents = []
         for ts, address, is_write, value in accesses:  # :269-330
             if ts >= T or address < start_address or (address - start_address) // 8 >= K:
                 continue
@@ -1758,23 +1758,17 @@ class RamReadWriteCheckingProver:
             if is_write:
                 inc[ts] = fr_from_int(value - prev)
                 cur[idx] = value
-            self.entries.append([ts, idx, 1, (prev if is_write else value) % R_MOD, prev, value])
-        self.entries.sort(key=lambda e: (e[0], e[1]))  # :333-340
-        # eq_evals = eq(r_cycle, .) (computeEqBigEndian, :345-348) built on the device; inc uploaded; both in ONE session
-        d_eq, d_inc = lib.DeviceBuffer(T * 32), lib.DeviceBuffer.from_host(inc)
-        lib.fr_eq_table_dev(self.r_cycle, d_eq.ptr)
-        lib.sync()
-        self._cyc = lib.ProductSumcheckSession.open_dev([d_eq.ptr, d_inc.ptr], T)
-        lib.sync()
-        d_eq.free()
-        d_inc.free()
-        self._val = lib.SumcheckSession.open(val_init, lib.SC_LOW_PAIR)
-        self._val_prev = None  # the table before the last address fold: the reference folds val_init IN PLACE (see bindChallenge)
+            ents.append((ts, idx, prev if is_write else value, prev, value))
+        ents.sort(key=lambda e: (e[0], e[1]))  # :333-340 (stable)
+        col = lambda k, dt: np.array([e[k] for e in ents], dtype=dt)
+        self._s = lib.RamRwSession.open(log_k, log_t, col(0, np.uint32), col(1, np.uint32), col(2, np.uint64), col(3, np.uint64), col(4, np.uint64),
+                                        inc, val_init, self.r_cycle)
         self.eq_size = T
         self.gruen_eq = GruenSplitEqPolynomial(self.r_cycle)  # :354
         self.current_claim = fr_to_int(initial_claim)
         self.round = 0
         self.challenges = []
+        self.last_q = None
 
     def numRounds(self):
         return self.log_k + self.log_t
@@ -1788,203 +1782,39 @@ class RamReadWriteCheckingProver:
 
     def computeRoundPolynomialCubic(self):
         """[s(0), s(1), s(2), s(3)] (:391-408)"""
-        return self._phase1() if self._in_cycle_phase() else self._phase2()
+        if self._in_cycle_phase():  # computePhase1Polynomial (:410-536) + Gruen's cubic
+            d_out, n_out, d_in, n_in = self.gruen_eq.getWindowEqTablesDev(1)
+            qc, qq = self._s.round_cycle(d_out, n_out, d_in, n_in, self.gamma)
+            self.last_q = (fr_to_int(qc), fr_to_int(qq))
+            return self.gruen_eq.computeCubicRoundPoly(qc, qq, fr_from_int(self.current_claim))
+        addr_round = self.round - self.phase1_num_rounds  # computePhase2Polynomial (:538-769)
+        s0, s2 = self._s.round_address(addr_round, self.challenges[self.phase1_num_rounds:self.phase1_num_rounds + addr_round], self.gamma)
+        a, c = fr_to_int(s0), fr_to_int(s2)
+        s1 = (self.current_claim - a) % R_MOD
+        return np.stack([s0, fr_from_int(s1), s2, fr_from_int((3 * c - 3 * s1 + a) % R_MOD)])
 
-    def _phase1(self):  # computePhase1Polynomial, :410-536
-        P, gamma, g = R_MOD, self.gamma, self.gruen_eq
-        e_out, e_in, head_in_bits = g.getWindowEqTables(g.current_index, 1)
-        ents = self.entries
-        pairs = sorted({e[0] // 2 for e in ents})
-        rows = [r for p_ in pairs for r in (2 * p_, 2 * p_ + 1) if r < len(self._cyc)]
-        got = self._cyc.gather(1, rows) if rows else np.zeros((0, 4), dtype=np.uint64)  # only the inc rows the entries touch
-        inc_at = {r: fr_to_int(v) for r, v in zip(rows, got)}
-        eo, ei = {}, {}
-        qc = qq = 0
-        i = 0
-        while i < len(ents):
-            e = ents[i]
-            pair = e[0] // 2
-            x_out, x_in = pair >> head_in_bits, pair & ((1 << head_in_bits) - 1)
-            if x_out not in eo:
-                eo[x_out] = fr_to_int(e_out[x_out]) if x_out < len(e_out) else 1
-            if x_in not in ei:
-                ei[x_in] = fr_to_int(e_in[x_in]) if x_in < len(e_in) else 1
-            e_prefix = eo[x_out] * ei[x_in] % P
-            inc_0, inc_1 = inc_at.get(2 * pair, 0), inc_at.get(2 * pair + 1, 0)
-            inc_inf = (inc_1 - inc_0) % P
-            if e[0] % 2 == 0:
-                nxt = ents[i + 1] if i + 1 < len(ents) else None
-                if nxt is not None and nxt[0] // 2 == pair and nxt[1] == e[1] and nxt[0] % 2 == 1:
-                    ra_0, ra_inf, val_0, val_inf = e[2], (nxt[2] - e[2]) % P, e[3], (nxt[3] - e[3]) % P
-                    i += 2
-                else:  # the odd entry is implicit: it would hold the value after this access
-                    ra_0, ra_inf, val_0, val_inf = e[2], (-e[2]) % P, e[3], (e[5] - e[3]) % P
-                    i += 1
-            else:  # the even entry is implicit: the value before this access
-                ra_0, ra_inf, val_0, val_inf = 0, e[2], e[4] % P, (e[3] - e[4]) % P
-                i += 1
-            qc = (qc + e_prefix * ra_0 % P * ((val_0 + gamma * (inc_0 + val_0)) % P)) % P
-            qq = (qq + e_prefix * ra_inf % P * ((val_inf + gamma * (inc_inf + val_inf)) % P)) % P
-        self.last_q = (qc, qq)
-        return g.computeCubicRoundPoly(fr_from_int(qc), fr_from_int(qq), fr_from_int(self.current_claim))
-
-    def _eq_addr(self, address, addr_round):
-        acc = 1
-        for i in range(addr_round):
-            r_i = self.challenges[self.phase1_num_rounds + i]
-            acc = acc * (r_i if (address >> i) & 1 else (1 - r_i)) % R_MOD
-        return acc
-
-    def _pair_groups(self, addr_round):
-        ents, i = self.entries, 0
-        while i < len(ents):
-            col_pair = (ents[i][1] >> addr_round) // 2
-            j = i
-            while j < len(ents) and (ents[j][1] >> addr_round) // 2 == col_pair:
-                j += 1
-            k = i
-            while k < j and (ents[k][1] >> addr_round) % 2 == 0:
-                k += 1
-            yield col_pair, ents[i:k], ents[k:j]
-            i = j
-
-    def _checkpoints(self, addr_round, after_fold):
-        """val_init at the columns 2c, 2c + 1 of every column pair c the entries touch (:591-602). after_fold: as bindEntriesAddressMajor
-        sees the array (:985-996) — the reference has just folded it IN PLACE (:953-959), so indices below size / 2 hold the new values
-        and the others still the old ones; the device fold is out of place, so the old table's values were gathered before it."""
-        size = (1 << self.log_k) >> addr_round
-        cols = sorted({c for cp, _, _ in self._pair_groups(addr_round) for c in (2 * cp, 2 * cp + 1) if c < size})
-        if not after_fold:
-            got = self._val.gather(cols) if cols else []
-            return {c: fr_to_int(v) for c, v in zip(cols, got)}, size
-        lo = [c for c in cols if c < size // 2]
-        got = self._val.gather(lo) if lo else []
-        out = {c: fr_to_int(v) for c, v in zip(lo, got)}
-        out.update({c: self._val_prev[c] for c in cols if c >= size // 2})
-        return out, size
-
-    def _phase2(self):  # computePhase2Polynomial, :538-769
-        P, gamma = R_MOD, self.gamma
-        addr_round = self.round - self.phase1_num_rounds
-        if addr_round == 0:
-            self.entries.sort(key=lambda e: (e[1], e[0]))  # AddressMajor (:555-562)
-            both = self._cyc.gather(0, [0]), self._cyc.gather(1, [0])
-            self._eq_cycle, self._inc_scalar = fr_to_int(both[0][0]), fr_to_int(both[1][0])
-        eq_cycle, inc_s = self._eq_cycle, self._inc_scalar
-        chk, size = self._checkpoints(addr_round, False)
-        opg = (1 + gamma) % P
-        s0 = s2 = 0
-
-        def contrib(address, ra_0, ra_2, val_0, val_2):
-            eq_partial = eq_cycle * self._eq_addr(address, addr_round) % P
-            return (eq_partial * ra_0 % P * ((val_0 * opg + gamma * inc_s) % P) % P,
-                    eq_partial * ra_2 % P * ((val_2 * opg + gamma * inc_s) % P) % P)
-        for col_pair, even, odd in self._pair_groups(addr_round):
-            ec, oc = chk.get(2 * col_pair, 0), chk.get(2 * col_pair + 1, 0)
-            a = b = 0
-            while a < len(even) or b < len(odd):
-                ee = even[a] if a < len(even) else None
-                oe = odd[b] if b < len(odd) else None
-                if ee is not None and oe is not None and ee[0] == oe[0]:
-                    c0, c2 = contrib(ee[1], ee[2], (2 * oe[2] - ee[2]) % P, ee[3], (2 * oe[3] - ee[3]) % P)
-                    ec, oc = ee[5] % P, oe[5] % P
-                    a += 1
-                    b += 1
-                elif oe is None or (ee is not None and ee[0] < oe[0]):
-                    c0, c2 = contrib(ee[1], ee[2], (-ee[2]) % P, ee[3], (2 * oc - ee[3]) % P)
-                    ec = ee[5] % P
-                    a += 1
-                else:
-                    c0, c2 = contrib(oe[1], 0, 2 * oe[2] % P, ec, (2 * oe[3] - ec) % P)
-                    oc = oe[5] % P
-                    b += 1
-                s0, s2 = (s0 + c0) % P, (s2 + c2) % P
-        s1 = (self.current_claim - s0) % P
-        s3 = (3 * s2 - 3 * s1 + s0) % P
-        return np.stack([fr_from_int(v) for v in (s0, s1, s2, s3)])
-
-    def bindChallenge(self, challenge):  # :902-970
-        P = R_MOD
+    def bindChallenge(self, challenge):
+        """bindChallenge (:902-970)"""
         ch = np.ascontiguousarray(challenge, dtype=np.uint64).copy()
-        r = fr_to_int(ch)
-        self.challenges.append(r)
+        self.challenges.append(ch)
         p1 = self.phase1_num_rounds
         if self._in_cycle_phase() and self.eq_size > 1:
-            self._cyc.bind(ch)  # eq_evals and inc, LowToHigh, one launch
+            self._s.bind_cycle(ch)  # eq_evals, inc and the entry list
             self.eq_size //= 2
             self.gruen_eq.bind(ch)
-            self._bind_entries(r)
         if p1 <= self.round < p1 + self.log_k:
-            addr_round = self.round - p1
-            size = (1 << self.log_k) >> addr_round
-            cols = sorted({c for cp, _, _ in self._pair_groups(addr_round) for c in (2 * cp, 2 * cp + 1) if size // 2 <= c < size})
-            self._val_prev = {c: fr_to_int(v) for c, v in zip(cols, self._val.gather(cols))} if cols else {}
-            if size > 1:
-                self._val.bind(ch)
-            chk, _ = self._checkpoints(addr_round, True) if size > 1 else (self._checkpoints(addr_round, False)[0], size)
-            self._bind_entries_address_major(r, addr_round, chk)
+            self._s.bind_address(self.round - p1, ch)  # val_init and the entry list
         self.round += 1
 
-    def _bind_entries(self, r):  # :1139-1185, CycleMajorEntry.bindEntries :110-156
-        P = R_MOD
-        ents, out, i = self.entries, [], 0
-        while i < len(ents):
-            e = ents[i]
-            if e[0] % 2 == 0:
-                nxt = ents[i + 1] if i + 1 < len(ents) else None
-                if nxt is not None and nxt[0] // 2 == e[0] // 2 and nxt[1] == e[1] and nxt[0] % 2 == 1:
-                    out.append([e[0] // 2, e[1], (e[2] + r * (nxt[2] - e[2])) % P, (e[3] + r * (nxt[3] - e[3])) % P, e[4], nxt[5]])
-                    i += 2
-                    continue
-                out.append([e[0] // 2, e[1], (1 - r) * e[2] % P, (e[3] + r * (e[5] - e[3])) % P, e[4], e[5]])
-            else:
-                out.append([e[0] // 2, e[1], r * e[2] % P, (e[4] + r * (e[3] - e[4])) % P, e[4], e[5]])
-            i += 1
-        self.entries = out
-
-    def _bind_entries_address_major(self, r, addr_round, chk):  # :973-1137
-        P = R_MOD
-        out = []
-        for col_pair, even, odd in self._pair_groups(addr_round):
-            ec, oc = chk.get(2 * col_pair, 0), chk.get(2 * col_pair + 1, 0)
-            a = b = 0
-            while a < len(even) or b < len(odd):
-                ee = even[a] if a < len(even) else None
-                oe = odd[b] if b < len(odd) else None
-                if ee is not None and oe is not None and ee[0] == oe[0]:
-                    out.append([ee[0], ee[1] // 2, (ee[2] + r * (oe[2] - ee[2])) % P, (ee[3] + r * (oe[3] - ee[3])) % P, ee[4], oe[5]])
-                    ec, oc = ee[5] % P, oe[5] % P
-                    a += 1
-                    b += 1
-                elif oe is None or (ee is not None and ee[0] < oe[0]):
-                    out.append([ee[0], ee[1] // 2, (1 - r) * ee[2] % P, (ee[3] + r * (oc - ee[3])) % P, ee[4], ee[5]])
-                    ec = ee[5] % P
-                    a += 1
-                else:
-                    out.append([oe[0], oe[1] // 2, r * oe[2] % P, (ec + r * (oe[3] - ec)) % P, oe[4], oe[5]])
-                    oc = oe[5] % P
-                    b += 1
-        self.entries = out
-
     def updateClaim(self, evals, challenge):  # :1187-1204
-        P = R_MOD
-        e = [fr_to_int(x) for x in np.asarray(evals, dtype=np.uint64).reshape(4, 4)]
-        c = fr_to_int(challenge)
-        inv = lambda v: pow(v % P, P - 2, P)  # noqa: E731
-        L0 = (c - 1) * (c - 2) % P * (c - 3) % P * inv(-6) % P
-        L1 = c * (c - 2) % P * (c - 3) % P * inv(2) % P
-        L2 = c * (c - 1) % P * (c - 3) % P * inv(-2) % P
-        L3 = c * (c - 1) % P * (c - 2) % P * inv(6) % P
-        self.current_claim = (e[0] * L0 + e[1] * L1 + e[2] * L2 + e[3] * L3) % P
+        self.current_claim = fr_to_int(cubicAtPoint(np.asarray(evals, dtype=np.uint64).reshape(4, 4), challenge))
 
     def getOpeningClaims(self, r_sumcheck):
-        """(ra_claim, val_claim, inc_claim) (:1210-1322); val_init[entry.address] is read as the reference reads it: from the array it
-        folded in place, where index 0 is the fully bound value"""
-        P = R_MOD
-        rs = [fr_to_int(x) for x in np.asarray(r_sumcheck, dtype=np.uint64).reshape(-1, 4)]
+        """(ra_claim, val_claim, inc_claim) (:1210-1322)"""
+        rs = np.asarray(r_sumcheck, dtype=np.uint64).reshape(-1, 4)
         log_k, log_t, p1 = self.log_k, self.log_t, self.phase1_num_rounds
         p2, p3 = p1 + log_k, log_t - p1
-        r_address, r_cyc = [0] * log_k, [0] * log_t
+        r_address, r_cyc = np.zeros((log_k, 4), dtype=np.uint64), np.zeros((log_t, 4), dtype=np.uint64)
         for i in range(min(log_k, max(len(rs) - p1, 0))):
             r_address[log_k - 1 - i] = rs[p1 + i]
         for i in range(min(p1, len(rs))):
@@ -1992,35 +1822,26 @@ class RamReadWriteCheckingProver:
                 r_cyc[p3 + (p1 - 1 - i)] = rs[i]
         for i in range(min(p3, max(len(rs) - p2, 0))):
             r_cyc[p3 - 1 - i] = rs[p2 + i]
-
-        def eq(rv, x):
-            acc, n = 1, len(rv)
-            for i in range(n):
-                acc = acc * (rv[i] if (x >> (n - 1 - i)) & 1 else (1 - rv[i])) % P
-            return acc
-        v0 = fr_to_int(self._val.gather([0])[0])
-        ra, val = 0, v0
-        for e in self.entries:
-            if e[1] != 0:
-                raise ValueError("getOpeningClaims before the address variables are bound")
-            w = eq(r_address, e[1]) * eq(r_cyc, e[0]) % P
-            ra = (ra + w * e[2]) % P
-            val = (val + w * (e[3] - v0)) % P
-        return fr_from_int(ra), fr_from_int(val), self._cyc.gather(1, [0])[0]
+        return self._s.opening(r_address, r_cyc)
 
     # small accessors shared with the tests' checker
     def claim_element(self):
         return fr_from_int(self.current_claim)
 
     def cycle_scalars(self):
-        return fr_from_int(self._eq_cycle), fr_from_int(self._inc_scalar)
+        return self._s.cycle_scalars()
 
     def entry_list(self):
-        return [(e[0], e[1], e[2]) for e in self.entries]
+        cyc, adr, ra, _, _, _ = self._s.read_entries()
+        return [(int(c), int(a), fr_to_int(r)) for c, a, r in zip(cyc, adr, ra)]
+
+    def entries_full(self):
+        """[cycle, address, ra_coeff, val_coeff, prev_val, next_val] as integers, like the restatement's list"""
+        cyc, adr, ra, val, prev, nxt = self._s.read_entries()
+        return [[int(c), int(a), fr_to_int(r), fr_to_int(v), int(p), int(n)] for c, a, r, v, p, n in zip(cyc, adr, ra, val, prev, nxt)]
 
     def deinit(self):
-        self._cyc.close()
-        self._val.close()
+        self._s.close()
         self.gruen_eq.deinit()
 
 

@@ -1180,14 +1180,16 @@ struct MemoryAccess {  // one element of MemoryTrace.accesses
 };
 class RamReadWriteCheckingProver {
 public:
-    struct Entry {  // CycleMajorEntry (:91-157)
+    // RamReadWriteCheckingProver (src/zkvm/ram/read_write_checking.zig:160-1323) over one device session (zg_rwc_*): the library walks the
+    // entry list's integer fields on the host once per round, the coefficients and the dense tables (eq_evals, inc, val_init) live in
+    // HBM; here: the trace decoding of init, the split-eq structure, the cubic, the claim.
+    struct Entry {  // CycleMajorEntry (:91-157), as read back from the session
         size_t cycle, address;
         Fr ra_coeff, val_coeff;
         uint64_t prev_val, next_val;
     };
     Fr current_claim;
     size_t round = 0;
-    std::vector<Entry> entries;
     std::vector<Fr> challenges;
     Fr last_q_constant = Fr::zero(), last_q_quadratic = Fr::zero();
 
@@ -1204,49 +1206,68 @@ public:
                 val_init[idx] = Fr::fromU64(kv.second);
                 cur[idx] = kv.second;
             }
+        struct Raw { uint32_t cycle, address; uint64_t val, prev, next; };
+        std::vector<Raw> raw;
         for (auto &a : accesses) {  // :269-330
             if (a.timestamp >= T || a.address < start_address || (a.address - start_address) / 8 >= K) continue;
             size_t idx = (a.address - start_address) / 8;
-            uint64_t prev = cur.count(idx) ? cur[idx] : 0;
+            auto it = cur.find(idx);
+            uint64_t prev = it == cur.end() ? 0 : it->second;
             if (a.is_write) {
                 inc[a.timestamp] = a.value >= prev ? Fr::fromU64(a.value - prev) : Fr::zero().sub(Fr::fromU64(prev - a.value));
                 cur[idx] = a.value;
             }
-            entries.push_back(Entry{(size_t)a.timestamp, idx, Fr::one(), Fr::fromU64(a.is_write ? prev : a.value), prev, a.value});
+            raw.push_back(Raw{(uint32_t)a.timestamp, (uint32_t)idx, a.is_write ? prev : a.value, prev, a.value});
         }
-        std::stable_sort(entries.begin(), entries.end(), [](const Entry &x, const Entry &y) { return x.cycle != y.cycle ? x.cycle < y.cycle : x.address < y.address; });
-        std::vector<Fr> eq = EqPolynomial::evalsSliceWithScaling(r_cycle, nullptr);  // computeEqBigEndian (:345-348)
-        cyc_ = std::make_unique<ProductSumcheckSession>(std::vector<const std::vector<Fr> *>{&eq, &inc});
-        check(zg_sumcheck_open(reinterpret_cast<const uint64_t *>(val_init.data()), K, ZG_SC_LOW_PAIR, &val_), "zg_sumcheck_open");
+        std::stable_sort(raw.begin(), raw.end(), [](const Raw &x, const Raw &y) { return x.cycle != y.cycle ? x.cycle < y.cycle : x.address < y.address; });
+        std::vector<uint32_t> cyc(raw.size()), adr(raw.size());
+        std::vector<uint64_t> val(raw.size()), prev(raw.size()), next(raw.size());
+        for (size_t i = 0; i < raw.size(); i++) { cyc[i] = raw[i].cycle; adr[i] = raw[i].address; val[i] = raw[i].val; prev[i] = raw[i].prev; next[i] = raw[i].next; }
+        check(zg_rwc_open(log_k, log_t, raw.size(), cyc.data(), adr.data(), val.data(), prev.data(), next.data(), reinterpret_cast<const uint64_t *>(inc.data()),
+                          reinterpret_cast<const uint64_t *>(val_init.data()), reinterpret_cast<const uint64_t *>(r_cycle.data()), &s_), "zg_rwc_open");
         eq_size_ = T;
+        const size_t m = r_cycle.size() / 2;
+        try {  // the two prefix-table sets of the split-eq structure in HBM (table k starts at element 2^k - 1)
+            d_out_.alloc(((size_t(2) << m) - 1) * 32);
+            d_in_.alloc(((size_t(2) << gruen_.num_x_in) - 1) * 32);
+            check(zg_fr_eq_prefix_tables_dev(reinterpret_cast<const uint64_t *>(gruen_.tau.data()), m, d_out_.u64(), nullptr), "zg_fr_eq_prefix_tables_dev");
+            check(zg_fr_eq_prefix_tables_dev(reinterpret_cast<const uint64_t *>(gruen_.tau.data() + m), gruen_.num_x_in, d_in_.u64(), nullptr), "zg_fr_eq_prefix_tables_dev");
+        } catch (...) {
+            zg_rwc_close(s_);
+            throw;
+        }
     }
-    ~RamReadWriteCheckingProver() { zg_sumcheck_close(val_); }
+    ~RamReadWriteCheckingProver() { zg_rwc_close(s_); }
     RamReadWriteCheckingProver(const RamReadWriteCheckingProver &) = delete;
+    RamReadWriteCheckingProver &operator=(const RamReadWriteCheckingProver &) = delete;
     size_t numRounds() const { return log_k_ + log_t_; }
     bool isComplete() const { return round >= numRounds(); }
+    size_t numEntries() const { return zg_rwc_entries(s_); }
 
-    std::array<Fr, 4> computeRoundPolynomialCubic() { return inCyclePhase() ? phase1() : phase2(); }  // :391-408
-
+    std::array<Fr, 4> computeRoundPolynomialCubic() {  // :391-408
+        if (inCyclePhase()) {  // computePhase1Polynomial (:410-536) + Gruen's cubic
+            size_t head_len = gruen_.current_index - std::min<size_t>(1, gruen_.current_index), m = gruen_.tau.size() / 2;
+            size_t ho = std::min(head_len, m), hi = head_len - ho;
+            size_t ko = gruen_.E_out_vec.empty() ? 0 : std::min(ho, gruen_.E_out_vec.size() - 1), ki = gruen_.E_in_vec.empty() ? 0 : std::min(hi, gruen_.E_in_vec.size() - 1);
+            check(zg_rwc_round_cycle(s_, d_out_.u64() + 4 * ((size_t(1) << ko) - 1), size_t(1) << ko, d_in_.u64() + 4 * ((size_t(1) << ki) - 1), size_t(1) << ki,
+                                     gamma_.limbs, last_q_constant.limbs, last_q_quadratic.limbs), "zg_rwc_round_cycle");
+            return gruen_.computeCubicRoundPoly(last_q_constant, last_q_quadratic, current_claim);
+        }
+        const size_t addr_round = round - p1_;  // computePhase2Polynomial (:538-769)
+        Fr s0, s2;
+        check(zg_rwc_round_address(s_, addr_round, addr_round ? reinterpret_cast<const uint64_t *>(challenges.data() + p1_) : nullptr, gamma_.limbs, s0.limbs, s2.limbs),
+              "zg_rwc_round_address");
+        Fr s1 = current_claim.sub(s0), three = Fr::fromU64(3);
+        return {s0, s1, s2, s2.mul(three).sub(s1.mul(three)).add(s0)};
+    }
     void bindChallenge(const Fr &r) {  // :902-970
         challenges.push_back(r);
         if (inCyclePhase() && eq_size_ > 1) {
-            cyc_->bind(r);  // eq_evals and inc, LowToHigh, one launch
+            check(zg_rwc_bind_cycle(s_, r.limbs), "zg_rwc_bind_cycle");  // eq_evals, inc and the entry list
             eq_size_ /= 2;
             gruen_.bind(r);
-            bindEntries(r);
         }
-        if (round >= p1_ && round < p1_ + log_k_) {
-            const size_t addr_round = round - p1_, size = (size_t(1) << log_k_) >> addr_round;
-            // the reference folds val_init IN PLACE and then reads its checkpoints with the old size (:953-962,:974-996): indices below
-            // size / 2 hold the new values, the others still the old ones — the old ones are gathered before the (out-of-place) device fold
-            std::vector<uint64_t> cols = touchedColumns(addr_round, size), hi_cols, lo_cols;
-            for (uint64_t c : cols) (c >= size / 2 ? hi_cols : lo_cols).push_back(c);
-            std::map<uint64_t, Fr> chk;
-            gatherVal(hi_cols, chk);
-            if (size > 1) check(zg_sumcheck_bind(val_, r.limbs), "zg_sumcheck_bind");
-            gatherVal(lo_cols, chk);
-            bindEntriesAddressMajor(r, addr_round, chk);
-        }
+        if (round >= p1_ && round < p1_ + log_k_) check(zg_rwc_bind_address(s_, round - p1_, r.limbs), "zg_rwc_bind_address");  // val_init and the list
         round++;
     }
     void updateClaim(const std::array<Fr, 4> &evals, const Fr &challenge) { current_claim = cubicAtPoint(evals, challenge); }  // :1187-1204
@@ -1258,200 +1279,30 @@ public:
         for (size_t i = 0; i < p1_ && i < r_sumcheck.size(); i++)
             if (p3 + (p1_ - 1 - i) < log_t_) r_cyc[p3 + (p1_ - 1 - i)] = r_sumcheck[i];
         for (size_t i = 0; i < p3 && p2 + i < r_sumcheck.size(); i++) r_cyc[p3 - 1 - i] = r_sumcheck[p2 + i];
-        auto eq = [](const std::vector<Fr> &rv, size_t x) {  // computeEq (:1353-1366)
-            Fr acc = Fr::one();
-            for (size_t i = 0; i < rv.size(); i++) acc = acc.mul(((x >> (rv.size() - 1 - i)) & 1) ? rv[i] : Fr::one().sub(rv[i]));
-            return acc;
-        };
-        std::map<uint64_t, Fr> v0m;
-        gatherVal({0}, v0m);
-        const Fr v0 = v0m[0];  // every entry's column is 0 once the address variables are bound: val_init[entry.address] is the bound value
-        Fr ra = Fr::zero(), val = v0;
-        for (const Entry &e : entries) {
-            Fr w = eq(r_address, e.address).mul(eq(r_cyc, e.cycle));
-            ra = ra.add(w.mul(e.ra_coeff));
-            val = val.add(w.mul(e.val_coeff.sub(v0)));
-        }
-        return OpeningClaims{ra, val, cyc_->gather(1, {0})[0]};
+        Fr out[3];
+        check(zg_rwc_opening(s_, reinterpret_cast<const uint64_t *>(r_address.data()), reinterpret_cast<const uint64_t *>(r_cyc.data()), reinterpret_cast<uint64_t *>(out)),
+              "zg_rwc_opening");
+        return OpeningClaims{out[0], out[1], out[2]};
+    }
+    std::vector<Entry> entries() {  // the current list, coefficients from the device
+        const size_t n = numEntries();
+        std::vector<uint32_t> cyc(n), adr(n);
+        std::vector<Fr> ra(n), val(n);
+        std::vector<uint64_t> prev(n), next(n);
+        check(zg_rwc_read_entries(s_, cyc.data(), adr.data(), reinterpret_cast<uint64_t *>(ra.data()), reinterpret_cast<uint64_t *>(val.data()), prev.data(), next.data()),
+              "zg_rwc_read_entries");
+        std::vector<Entry> out(n);
+        for (size_t i = 0; i < n; i++) out[i] = Entry{cyc[i], adr[i], ra[i], val[i], prev[i], next[i]};
+        return out;
     }
 
 private:
     Fr gamma_;
     size_t log_k_, log_t_, p1_, eq_size_ = 0;
     GruenSplitEqPolynomial gruen_;
-    std::unique_ptr<ProductSumcheckSession> cyc_;
-    zg_sc_t val_ = nullptr;
-    Fr eq_cycle_ = Fr::zero(), inc_scalar_ = Fr::zero();
-
+    zg_rwc_t s_ = nullptr;
+    DeviceMem d_out_, d_in_;
     bool inCyclePhase() const { return round < p1_ || round >= p1_ + log_k_; }
-    void gatherVal(const std::vector<uint64_t> &cols, std::map<uint64_t, Fr> &out) {
-        if (cols.empty()) return;
-        std::vector<Fr> got(cols.size());
-        check(zg_sumcheck_gather(val_, cols.data(), cols.size(), reinterpret_cast<uint64_t *>(got.data())), "zg_sumcheck_gather");
-        for (size_t i = 0; i < cols.size(); i++) out[cols[i]] = got[i];
-    }
-    std::vector<uint64_t> touchedColumns(size_t addr_round, size_t size) const {
-        std::vector<uint64_t> cols;
-        for (const Entry &e : entries) {
-            uint64_t cp = (e.address >> addr_round) / 2;
-            for (uint64_t c : {2 * cp, 2 * cp + 1})
-                if (c < size) cols.push_back(c);
-        }
-        std::sort(cols.begin(), cols.end());
-        cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
-        return cols;
-    }
-    std::array<Fr, 4> phase1() {  // computePhase1Polynomial (:410-536)
-        auto win = gruen_.getWindowEqTables(gruen_.current_index, 1);
-        const std::vector<Fr> &E_out = *win.E_out, &E_in = *win.E_in;
-        const size_t hib = win.head_in_bits, live = cyc_->len();
-        std::vector<uint64_t> rows;
-        for (const Entry &e : entries)
-            for (uint64_t r : {uint64_t(2 * (e.cycle / 2)), uint64_t(2 * (e.cycle / 2) + 1)})
-                if (r < live) rows.push_back(r);
-        std::sort(rows.begin(), rows.end());
-        rows.erase(std::unique(rows.begin(), rows.end()), rows.end());
-        std::map<uint64_t, Fr> inc_at;
-        if (!rows.empty()) {
-            std::vector<Fr> got = cyc_->gather(1, rows);  // only the inc rows the entries touch
-            for (size_t i = 0; i < rows.size(); i++) inc_at[rows[i]] = got[i];
-        }
-        auto inc = [&](uint64_t r) { auto it = inc_at.find(r); return it == inc_at.end() ? Fr::zero() : it->second; };
-        Fr qc = Fr::zero(), qq = Fr::zero();
-        for (size_t i = 0; i < entries.size();) {
-            const Entry &e = entries[i];
-            const size_t pair = e.cycle / 2, x_out = pair >> hib, x_in = pair & ((size_t(1) << hib) - 1);
-            Fr e_prefix = (x_out < E_out.size() ? E_out[x_out] : Fr::one()).mul(x_in < E_in.size() ? E_in[x_in] : Fr::one());
-            Fr inc_0 = inc(2 * pair), inc_inf = inc(2 * pair + 1).sub(inc_0);
-            Fr ra_0, ra_inf, val_0, val_inf;
-            if (e.cycle % 2 == 0) {
-                const Entry *nx = i + 1 < entries.size() ? &entries[i + 1] : nullptr;
-                if (nx && nx->cycle / 2 == pair && nx->address == e.address && nx->cycle % 2 == 1) {
-                    ra_0 = e.ra_coeff; ra_inf = nx->ra_coeff.sub(e.ra_coeff); val_0 = e.val_coeff; val_inf = nx->val_coeff.sub(e.val_coeff);
-                    i += 2;
-                } else {  // the odd entry is implicit: it would hold the value after this access
-                    ra_0 = e.ra_coeff; ra_inf = Fr::zero().sub(e.ra_coeff); val_0 = e.val_coeff; val_inf = Fr::fromU64(e.next_val).sub(e.val_coeff);
-                    i += 1;
-                }
-            } else {  // the even entry is implicit: the value before this access
-                Fr even_val = Fr::fromU64(e.prev_val);
-                ra_0 = Fr::zero(); ra_inf = e.ra_coeff; val_0 = even_val; val_inf = e.val_coeff.sub(even_val);
-                i += 1;
-            }
-            qc = qc.add(e_prefix.mul(ra_0).mul(val_0.add(gamma_.mul(inc_0.add(val_0)))));
-            qq = qq.add(e_prefix.mul(ra_inf).mul(val_inf.add(gamma_.mul(inc_inf.add(val_inf)))));
-        }
-        last_q_constant = qc;
-        last_q_quadratic = qq;
-        return gruen_.computeCubicRoundPoly(qc, qq, current_claim);
-    }
-    Fr eqAddr(size_t address, size_t addr_round) const {
-        Fr acc = Fr::one();
-        for (size_t i = 0; i < addr_round; i++) {
-            const Fr &r_i = challenges[p1_ + i];
-            acc = acc.mul(((address >> i) & 1) ? r_i : Fr::one().sub(r_i));
-        }
-        return acc;
-    }
-    // column-pair groups of the address-major entry list: [begin, mid) even column, [mid, end) odd column
-    template <class Fn> void forEachPairGroup(size_t addr_round, Fn fn) const {
-        for (size_t i = 0; i < entries.size();) {
-            const size_t cp = (entries[i].address >> addr_round) / 2;
-            size_t j = i;
-            while (j < entries.size() && (entries[j].address >> addr_round) / 2 == cp) j++;
-            size_t k = i;
-            while (k < j && (entries[k].address >> addr_round) % 2 == 0) k++;
-            fn(cp, i, k, j);
-            i = j;
-        }
-    }
-    std::array<Fr, 4> phase2() {  // computePhase2Polynomial (:538-769)
-        const size_t addr_round = round - p1_, size = (size_t(1) << log_k_) >> addr_round;
-        if (addr_round == 0) {
-            std::stable_sort(entries.begin(), entries.end(), [](const Entry &x, const Entry &y) { return x.address != y.address ? x.address < y.address : x.cycle < y.cycle; });
-            eq_cycle_ = cyc_->gather(0, {0})[0];
-            inc_scalar_ = cyc_->gather(1, {0})[0];
-        }
-        std::map<uint64_t, Fr> chk;
-        gatherVal(touchedColumns(addr_round, size), chk);
-        auto ck = [&](uint64_t c) { auto it = chk.find(c); return it == chk.end() ? Fr::zero() : it->second; };
-        const Fr opg = Fr::one().add(gamma_), g_inc = gamma_.mul(inc_scalar_);
-        Fr s0 = Fr::zero(), s2 = Fr::zero();
-        auto contrib = [&](size_t address, const Fr &ra_0, const Fr &ra_2, const Fr &val_0, const Fr &val_2) {
-            Fr eq_partial = eq_cycle_.mul(eqAddr(address, addr_round));
-            s0 = s0.add(eq_partial.mul(ra_0).mul(val_0.mul(opg).add(g_inc)));
-            s2 = s2.add(eq_partial.mul(ra_2).mul(val_2.mul(opg).add(g_inc)));
-        };
-        forEachPairGroup(addr_round, [&](size_t cp, size_t b, size_t m, size_t en) {
-            Fr ec = ck(2 * cp), oc = ck(2 * cp + 1);
-            size_t a = b, o = m;
-            while (a < m || o < en) {
-                const Entry *ee = a < m ? &entries[a] : nullptr, *oe = o < en ? &entries[o] : nullptr;
-                if (ee && oe && ee->cycle == oe->cycle) {
-                    contrib(ee->address, ee->ra_coeff, oe->ra_coeff.add(oe->ra_coeff).sub(ee->ra_coeff), ee->val_coeff, oe->val_coeff.add(oe->val_coeff).sub(ee->val_coeff));
-                    ec = Fr::fromU64(ee->next_val); oc = Fr::fromU64(oe->next_val);
-                    a++; o++;
-                } else if (!oe || (ee && ee->cycle < oe->cycle)) {
-                    contrib(ee->address, ee->ra_coeff, Fr::zero().sub(ee->ra_coeff), ee->val_coeff, oc.add(oc).sub(ee->val_coeff));
-                    ec = Fr::fromU64(ee->next_val);
-                    a++;
-                } else {
-                    contrib(oe->address, Fr::zero(), oe->ra_coeff.add(oe->ra_coeff), ec, oe->val_coeff.add(oe->val_coeff).sub(ec));
-                    oc = Fr::fromU64(oe->next_val);
-                    o++;
-                }
-            }
-        });
-        Fr s1 = current_claim.sub(s0), three = Fr::fromU64(3);
-        return {s0, s1, s2, s2.mul(three).sub(s1.mul(three)).add(s0)};
-    }
-    void bindEntries(const Fr &r) {  // :1139-1185, CycleMajorEntry.bindEntries :110-156
-        std::vector<Entry> out;
-        const Fr omr = Fr::one().sub(r);
-        for (size_t i = 0; i < entries.size();) {
-            const Entry &e = entries[i];
-            if (e.cycle % 2 == 0) {
-                const Entry *nx = i + 1 < entries.size() ? &entries[i + 1] : nullptr;
-                if (nx && nx->cycle / 2 == e.cycle / 2 && nx->address == e.address && nx->cycle % 2 == 1) {
-                    out.push_back(Entry{e.cycle / 2, e.address, e.ra_coeff.add(r.mul(nx->ra_coeff.sub(e.ra_coeff))), e.val_coeff.add(r.mul(nx->val_coeff.sub(e.val_coeff))), e.prev_val, nx->next_val});
-                    i += 2;
-                    continue;
-                }
-                out.push_back(Entry{e.cycle / 2, e.address, omr.mul(e.ra_coeff), e.val_coeff.add(r.mul(Fr::fromU64(e.next_val).sub(e.val_coeff))), e.prev_val, e.next_val});
-            } else {
-                Fr ev = Fr::fromU64(e.prev_val);
-                out.push_back(Entry{e.cycle / 2, e.address, r.mul(e.ra_coeff), ev.add(r.mul(e.val_coeff.sub(ev))), e.prev_val, e.next_val});
-            }
-            i += 1;
-        }
-        entries.swap(out);
-    }
-    void bindEntriesAddressMajor(const Fr &r, size_t addr_round, const std::map<uint64_t, Fr> &chk) {  // :973-1137
-        auto ck = [&](uint64_t c) { auto it = chk.find(c); return it == chk.end() ? Fr::zero() : it->second; };
-        std::vector<Entry> out;
-        const Fr omr = Fr::one().sub(r);
-        forEachPairGroup(addr_round, [&](size_t cp, size_t b, size_t m, size_t en) {
-            Fr ec = ck(2 * cp), oc = ck(2 * cp + 1);
-            size_t a = b, o = m;
-            while (a < m || o < en) {
-                const Entry *ee = a < m ? &entries[a] : nullptr, *oe = o < en ? &entries[o] : nullptr;
-                if (ee && oe && ee->cycle == oe->cycle) {
-                    out.push_back(Entry{ee->cycle, ee->address / 2, ee->ra_coeff.add(r.mul(oe->ra_coeff.sub(ee->ra_coeff))), ee->val_coeff.add(r.mul(oe->val_coeff.sub(ee->val_coeff))), ee->prev_val, oe->next_val});
-                    ec = Fr::fromU64(ee->next_val); oc = Fr::fromU64(oe->next_val);
-                    a++; o++;
-                } else if (!oe || (ee && ee->cycle < oe->cycle)) {
-                    out.push_back(Entry{ee->cycle, ee->address / 2, omr.mul(ee->ra_coeff), ee->val_coeff.add(r.mul(oc.sub(ee->val_coeff))), ee->prev_val, ee->next_val});
-                    ec = Fr::fromU64(ee->next_val);
-                    a++;
-                } else {
-                    out.push_back(Entry{oe->cycle, oe->address / 2, r.mul(oe->ra_coeff), ec.add(r.mul(oe->val_coeff.sub(ec))), oe->prev_val, oe->next_val});
-                    oc = Fr::fromU64(oe->next_val);
-                    o++;
-                }
-            }
-        });
-        entries.swap(out);
-    }
 };
 
 // InstructionLookupsClaimReductionProver's loop (src/zkvm/claim_reductions/instruction_lookups.zig:146-284)

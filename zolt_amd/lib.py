@@ -47,6 +47,8 @@ SYMBOLS = [
     "zg_psc_final", "zg_psc_close",
     "zg_rrw_open", "zg_rrw_cycles", "zg_rrw_registers", "zg_rrw_round_cycle_gruen", "zg_rrw_set_eq", "zg_rrw_round_address", "zg_rrw_round_cycle",
     "zg_rrw_bind_cycle", "zg_rrw_bind_address", "zg_rrw_final", "zg_rrw_close",
+    "zg_rwc_open", "zg_rwc_entries", "zg_rwc_cycles", "zg_rwc_round_cycle", "zg_rwc_bind_cycle", "zg_rwc_round_address", "zg_rwc_bind_address",
+    "zg_rwc_opening", "zg_rwc_cycle_scalars", "zg_rwc_read_entries", "zg_rwc_close",
 ]
 # test / bench scaffolding of include/zolt_gpu_internal.h (not part of the drop-in boundary)
 INTERNAL_SYMBOLS = ["zg_profile_begin", "zg_profile_end", "zg_sharded_comm_sets_created"]
@@ -65,6 +67,8 @@ _lib.zg_sumcheck_len.restype = C.c_size_t
 _lib.zg_psc_len.restype = C.c_size_t
 _lib.zg_psc_tables.restype = C.c_size_t
 _lib.zg_rrw_cycles.restype = C.c_size_t
+_lib.zg_rwc_entries.restype = C.c_size_t
+_lib.zg_rwc_cycles.restype = C.c_size_t
 _lib.zg_rrw_registers.restype = C.c_size_t
 
 _u64p = C.POINTER(C.c_uint64)
@@ -910,6 +914,83 @@ class RegistersRwSession:
     def close(self):
         if self._h:
             _chk(_lib.zg_rrw_close(self._h), "zg_rrw_close")
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class RamRwSession:
+    """RamReadWriteCheckingProver's entry list and dense tables behind zg_rwc_*: the integer walks on the host inside the library, the
+    field arithmetic on the device"""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def open(cls, log_k, log_t, cycle, address, val_coeff, prev_val, next_val, inc, val_init, r_cycle):
+        cycle, address = _c(cycle, np.uint32), _c(address, np.uint32)
+        val_coeff, prev_val, next_val = _c(val_coeff), _c(prev_val), _c(next_val)
+        inc, val_init, r_cycle = _c(inc), _c(val_init), _c(r_cycle)
+        n = cycle.size
+        assert address.size == val_coeff.size == prev_val.size == next_val.size == n
+        assert inc.size == 4 << log_t and val_init.size == 4 << log_k and r_cycle.size == 4 * log_t
+        h = C.c_void_p()
+        _chk(_lib.zg_rwc_open(C.c_size_t(log_k), C.c_size_t(log_t), C.c_size_t(n), _hb(cycle), _hb(address), _h(val_coeff), _h(prev_val), _h(next_val),
+                              _h(inc), _h(val_init), _h(r_cycle), C.byref(h)), "zg_rwc_open")
+        return cls(h)
+
+    def entries(self):
+        return int(_lib.zg_rwc_entries(self._h))
+
+    def cycles(self):
+        return int(_lib.zg_rwc_cycles(self._h))
+
+    def round_cycle(self, d_e_out, n_out, d_e_in, n_in, gamma):
+        a, b = np.empty(4, dtype=np.uint64), np.empty(4, dtype=np.uint64)
+        _chk(_lib.zg_rwc_round_cycle(self._h, _d(d_e_out), C.c_size_t(n_out), _d(d_e_in), C.c_size_t(n_in), _h(_c(gamma)), _h(a), _h(b)), "zg_rwc_round_cycle")
+        return a, b
+
+    def bind_cycle(self, r):
+        _chk(_lib.zg_rwc_bind_cycle(self._h, _h(_c(r))), "zg_rwc_bind_cycle")
+
+    def round_address(self, addr_round, challenges, gamma):
+        ch = _c(np.asarray(challenges, dtype=np.uint64).reshape(-1, 4))
+        assert ch.shape[0] == addr_round
+        a, b = np.empty(4, dtype=np.uint64), np.empty(4, dtype=np.uint64)
+        _chk(_lib.zg_rwc_round_address(self._h, C.c_size_t(addr_round), _h(ch) if addr_round else None, _h(_c(gamma)), _h(a), _h(b)), "zg_rwc_round_address")
+        return a, b
+
+    def bind_address(self, addr_round, r):
+        _chk(_lib.zg_rwc_bind_address(self._h, C.c_size_t(addr_round), _h(_c(r))), "zg_rwc_bind_address")
+
+    def opening(self, r_address, r_cycle):
+        out = np.empty((3, 4), dtype=np.uint64)
+        ra, rc = _c(np.asarray(r_address, dtype=np.uint64).reshape(-1, 4)), _c(np.asarray(r_cycle, dtype=np.uint64).reshape(-1, 4))
+        _chk(_lib.zg_rwc_opening(self._h, _h(ra) if ra.size else None, _h(rc) if rc.size else None, _h(out)), "zg_rwc_opening")
+        return out[0], out[1], out[2]
+
+    def cycle_scalars(self):
+        a, b = np.empty(4, dtype=np.uint64), np.empty(4, dtype=np.uint64)
+        _chk(_lib.zg_rwc_cycle_scalars(self._h, _h(a), _h(b)), "zg_rwc_cycle_scalars")
+        return a, b
+
+    def read_entries(self, coefficients=True):
+        """-> (cycle, address, ra_coeff, val_coeff, prev_val, next_val) arrays of the current list"""
+        n = self.entries()
+        cyc, adr = np.empty(n, dtype=np.uint32), np.empty(n, dtype=np.uint32)
+        ra, val = np.empty((n, 4), dtype=np.uint64), np.empty((n, 4), dtype=np.uint64)
+        prev, nxt = np.empty(n, dtype=np.uint64), np.empty(n, dtype=np.uint64)
+        _chk(_lib.zg_rwc_read_entries(self._h, _hb(cyc), _hb(adr), _h(ra) if coefficients else None, _h(val) if coefficients else None, _h(prev), _h(nxt)),
+             "zg_rwc_read_entries")
+        return cyc, adr, ra, val, prev, nxt
+
+    def close(self):
+        if self._h:
+            _chk(_lib.zg_rwc_close(self._h), "zg_rwc_close")
             self._h = None
 
     def __del__(self):
