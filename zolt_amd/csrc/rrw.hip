@@ -14,6 +14,7 @@
 // share of non-zero entries, so in the large early rounds almost every (k, i) pair contributes nothing: the round kernels test
 // ra / wa first and skip val and the products where all four are zero, the fold kernels skip the product where hi == lo. The sums
 // and the folded tables are the reference's values exactly (zero terms, zero differences).
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -25,6 +26,11 @@
 namespace zg {
 
 static constexpr int RRW_K = 128, RRW_TABLES = 5;  // val, wa, ra, rs1_ra, rs2_ra
+// Register indices are 5-bit instruction fields and the register file has 32 entries (:186-192, 199-246), so rows 32..127 of all five
+// tables are zero — and stay zero under every fold of the cycle variables. Only the ACTIVE rows are stored and visited (32 until the
+// register rounds, halved — rounded up — by each of them); a row at or past the active count reads as zero. A quarter of the memory
+// and of the traffic of the full 128 x T tables, the same values.
+static constexpr int RRW_ACTIVE = 32;
 enum { RT_VAL = 0, RT_WA = 1, RT_RA = 2, RT_RS1 = 3, RT_RS2 = 4 };
 static constexpr unsigned RRW_MAX_BLOCKS = 65536;
 
@@ -47,7 +53,7 @@ ZG_DEV Fr fr_from_arg(const FrArg &a) {
 __global__ void __launch_bounds__(256) rrw_build_kernel(const uint8_t *rs1, const uint8_t *rs2, const uint8_t *rd, const uint64_t *reg_vals,
                                                         size_t T, FrArg gamma, RrwTabsOut out) {
     size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (size_t)RRW_K * T) return;
+    if (idx >= (size_t)RRW_ACTIVE * T) return;
     size_t k = idx / T, j = idx - k * T;
     F29 r2p;
 #pragma unroll
@@ -74,6 +80,34 @@ __global__ void __launch_bounds__(256) rrw_build_kernel(const uint8_t *rs1, cons
     fe_store(out.t[RT_RA] + 4 * idx, ra);
     fe_store(out.t[RT_RS1] + 4 * idx, a1 ? one : zero);
     fe_store(out.t[RT_RS2] + 4 * idx, a2 ? one : zero);
+}
+
+// Which rows of a cycle can be non-zero in ra / rd_wa / rs1_ra / rs2_ra: bit k of mask[j]. The four tables start one-hot (at most three
+// registers per cycle), and a cycle fold can only produce a non-zero where one of its two inputs had one: mask'[i] = mask[2i] | mask[2i+1].
+// While the cycle variables are being folded, the round kernels visit and the fold kernel WRITES only the masked entries of the four
+// tables — at round 0 three rows of 32, doubling per round at worst — instead of streaming a table of zeros; entries outside the mask
+// are not written at all, rrw_materialize_kernel zeroes them once before the first reader that ignores the mask (the register rounds,
+// when the tables are 2^-phase1 of their size). val is dense (a register holds its value whether or not a cycle touches it) and is
+// folded densely.
+__global__ void __launch_bounds__(256) rrw_mask_build_kernel(const uint8_t *rs1, const uint8_t *rs2, const uint8_t *rd, size_t T, uint32_t *mask) {
+    size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= T) return;
+    uint32_t m = 0;
+    if (rs1[j] < RRW_ACTIVE) m |= 1u << rs1[j];
+    if (rs2[j] < RRW_ACTIVE) m |= 1u << rs2[j];
+    if (rd[j] < RRW_ACTIVE) m |= 1u << rd[j];
+    mask[j] = m;
+}
+__global__ void __launch_bounds__(256) rrw_materialize_kernel(RrwTabsOut tb, size_t stride, const uint32_t *mask, size_t cur_T, uint32_t act_K) {
+    size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= cur_T * act_K) return;
+    size_t k = t / cur_T, j = t - k * cur_T;
+    if ((mask[j] >> k) & 1u) return;
+    const Fr z = Fr::zero();
+    fe_store(tb.t[RT_WA] + 4 * (k * stride + j), z);
+    fe_store(tb.t[RT_RA] + 4 * (k * stride + j), z);
+    fe_store(tb.t[RT_RS1] + 4 * (k * stride + j), z);
+    fe_store(tb.t[RT_RS2] + 4 * (k * stride + j), z);
 }
 
 // block partial sums of NV accumulators -> partials[block][NV] (finished by rrw_finish_kernel)
@@ -110,7 +144,7 @@ ZG_DEV bool fr_is_zero(const Fr &a) { return a.is_zero(); }
 // phase 1 (:561-741): thread t -> cycle pair i = t % half_T, register chunk t / half_T; (q0, qX2) += E(i) * sum_k C_0 / C_X2
 __global__ void __launch_bounds__(256) rrw_cycle_gruen_kernel(RrwTabs tb, size_t stride, const uint64_t *inc, const uint64_t *e_out, uint32_t n_out,
                                                               const uint64_t *e_in, uint32_t n_in, uint32_t in_bits, size_t half_T, uint32_t cur_K,
-                                                              uint32_t kc_n, uint64_t *partials) {
+                                                              uint32_t kc_n, const uint32_t *mask, uint64_t *partials) {
     __shared__ uint4 sh[256 * 4];
     Fr acc[2] = {Fr::zero(), Fr::zero()};
     size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -120,10 +154,20 @@ __global__ void __launch_bounds__(256) rrw_cycle_gruen_kernel(RrwTabs tb, size_t
         Fr inc0 = fe_load<FrParams>(inc + 8 * i), incs = fe_sub(fe_load<FrParams>(inc + 8 * i + 4), inc0);
         Fr c0 = Fr::zero(), cx = Fr::zero();
         bool any = false;
-        for (uint32_t k = kc; k < cur_K; k += kc_n) {
+        // rows of this thread: k = kc (mod kc_n), k < cur_K; with masks each LANE walks its own set bits (a wave-uniform row loop would
+        // run all 32 rows for every wave: some lane always has the bit), without them every row
+        uint32_t rows = 0;
+        for (uint32_t k = kc; k < cur_K; k += kc_n) rows |= 1u << k;
+        const uint32_t me = mask ? mask[2 * i] : ~0u, mo = mask ? mask[2 * i + 1] : ~0u;
+        uint32_t m = (me | mo) & rows;
+        while (m) {
+            const uint32_t k = (uint32_t)__builtin_ctz(m);
+            m &= m - 1;
+            const bool he = (me >> k) & 1u, ho = (mo >> k) & 1u;
             size_t o = 4 * ((size_t)k * stride + 2 * i);
-            Fr rae = fe_load<FrParams>(tb.t[RT_RA] + o), rao = fe_load<FrParams>(tb.t[RT_RA] + o + 4);
-            Fr wae = fe_load<FrParams>(tb.t[RT_WA] + o), wao = fe_load<FrParams>(tb.t[RT_WA] + o + 4);
+            const Fr z = Fr::zero();
+            Fr rae = he ? fe_load<FrParams>(tb.t[RT_RA] + o) : z, rao = ho ? fe_load<FrParams>(tb.t[RT_RA] + o + 4) : z;
+            Fr wae = he ? fe_load<FrParams>(tb.t[RT_WA] + o) : z, wao = ho ? fe_load<FrParams>(tb.t[RT_WA] + o + 4) : z;
             if (fr_is_zero(rae) && fr_is_zero(rao) && fr_is_zero(wae) && fr_is_zero(wao)) continue;  // C_0 = C_X2 = 0
             any = true;
             Fr vae = fe_load<FrParams>(tb.t[RT_VAL] + o), vao = fe_load<FrParams>(tb.t[RT_VAL] + o + 4);
@@ -148,7 +192,7 @@ __global__ void __launch_bounds__(256) rrw_cycle_gruen_kernel(RrwTabs tb, size_t
 // E1: also the value at t = 1 (the odd rows), which Stage4Prover evaluates directly (stage4_prover.zig:666-706) instead of taking it from the claim
 template <bool E1>
 __global__ void __launch_bounds__(256) rrw_address_kernel(RrwTabs tb, size_t stride, const uint64_t *inc, const uint64_t *eq, size_t cur_T,
-                                                          uint32_t half_K, uint32_t ic_n, uint64_t *partials) {
+                                                          uint32_t half_K, uint32_t act_K, uint32_t ic_n, uint64_t *partials) {
     __shared__ uint4 sh[256 * 4];
     constexpr int NV = E1 ? 3 : 2;
     Fr acc[NV];
@@ -163,11 +207,12 @@ __global__ void __launch_bounds__(256) rrw_address_kernel(RrwTabs tb, size_t str
         bool any = false;
         for (uint32_t i = ic; i < half_K; i += ic_n) {
             size_t oe = 4 * ((size_t)(2 * i) * stride + j), oo = oe + 4 * stride;
-            Fr rae = fe_load<FrParams>(tb.t[RT_RA] + oe), rao = fe_load<FrParams>(tb.t[RT_RA] + oo);
-            Fr wae = fe_load<FrParams>(tb.t[RT_WA] + oe), wao = fe_load<FrParams>(tb.t[RT_WA] + oo);
+            const bool odd_row = 2 * i + 1 < act_K;  // past the active rows: zero
+            Fr rae = fe_load<FrParams>(tb.t[RT_RA] + oe), rao = odd_row ? fe_load<FrParams>(tb.t[RT_RA] + oo) : Fr::zero();
+            Fr wae = fe_load<FrParams>(tb.t[RT_WA] + oe), wao = odd_row ? fe_load<FrParams>(tb.t[RT_WA] + oo) : Fr::zero();
             if (fr_is_zero(rae) && fr_is_zero(rao) && fr_is_zero(wae) && fr_is_zero(wao)) continue;
             any = true;
-            Fr vae = fe_load<FrParams>(tb.t[RT_VAL] + oe), vao = fe_load<FrParams>(tb.t[RT_VAL] + oo);
+            Fr vae = fe_load<FrParams>(tb.t[RT_VAL] + oe), vao = odd_row ? fe_load<FrParams>(tb.t[RT_VAL] + oo) : Fr::zero();
             c0 = fe_add(c0, fe_add(fr_mul29v(rae, vae), fr_mul29v(wae, fe_add(vae, incj))));
             Fr ra2 = fe_sub(fe_add(rao, rao), rae), wa2 = fe_sub(fe_add(wao, wao), wae), va2 = fe_sub(fe_add(vao, vao), vae);  // f(0) + 2 (f(1) - f(0))
             c2 = fe_add(c2, fe_add(fr_mul29v(ra2, va2), fr_mul29v(wa2, fe_add(va2, incj))));
@@ -186,7 +231,7 @@ __global__ void __launch_bounds__(256) rrw_address_kernel(RrwTabs tb, size_t str
 // phase 3 with cycles left (:854-953): thread t -> cycle pair i, register chunk; (e0, e2, e3) += eq(t) * sum_k C(t), t = 0, 2, 3
 template <bool E1>
 __global__ void __launch_bounds__(256) rrw_cycle_dense_kernel(RrwTabs tb, size_t stride, const uint64_t *inc, const uint64_t *eq, size_t half_T,
-                                                              uint32_t cur_K, uint32_t kc_n, uint64_t *partials) {
+                                                              uint32_t cur_K, uint32_t kc_n, const uint32_t *mask, uint64_t *partials) {
     __shared__ uint4 sh[256 * 4];
     constexpr int NV = E1 ? 4 : 3;
     Fr acc[NV];
@@ -200,10 +245,18 @@ __global__ void __launch_bounds__(256) rrw_cycle_dense_kernel(RrwTabs tb, size_t
         Fr inc2 = fe_add(fe_add(inc0, incs), incs), inc3 = fe_add(inc2, incs);
         Fr c0 = Fr::zero(), c2 = Fr::zero(), c3 = Fr::zero(), c1 = Fr::zero();
         bool any = false;
-        for (uint32_t k = kc; k < cur_K; k += kc_n) {
+        uint32_t rows = 0;
+        for (uint32_t k = kc; k < cur_K; k += kc_n) rows |= 1u << k;
+        const uint32_t me = mask ? mask[2 * i] : ~0u, mo = mask ? mask[2 * i + 1] : ~0u;
+        uint32_t m = (me | mo) & rows;
+        while (m) {
+            const uint32_t k = (uint32_t)__builtin_ctz(m);
+            m &= m - 1;
+            const bool he = (me >> k) & 1u, ho = (mo >> k) & 1u;
             size_t o = 4 * ((size_t)k * stride + 2 * i);
-            Fr rae = fe_load<FrParams>(tb.t[RT_RA] + o), rao = fe_load<FrParams>(tb.t[RT_RA] + o + 4);
-            Fr wae = fe_load<FrParams>(tb.t[RT_WA] + o), wao = fe_load<FrParams>(tb.t[RT_WA] + o + 4);
+            const Fr z = Fr::zero();
+            Fr rae = he ? fe_load<FrParams>(tb.t[RT_RA] + o) : z, rao = ho ? fe_load<FrParams>(tb.t[RT_RA] + o + 4) : z;
+            Fr wae = he ? fe_load<FrParams>(tb.t[RT_WA] + o) : z, wao = ho ? fe_load<FrParams>(tb.t[RT_WA] + o + 4) : z;
             if (fr_is_zero(rae) && fr_is_zero(rao) && fr_is_zero(wae) && fr_is_zero(wao)) continue;
             any = true;
             Fr vae = fe_load<FrParams>(tb.t[RT_VAL] + o), vao = fe_load<FrParams>(tb.t[RT_VAL] + o + 4);
@@ -233,11 +286,36 @@ ZG_DEV Fr rrw_fold1(const Fr &lo, const Fr &hi, const FrMul &rm) {
     return fe_add(lo, rm.narrow ? frmul_apply(d, rm) : fr_mul29(d, rm.p));
 }
 
-// cycle fold (:1053-1090, 1124-1162): out[k][i] = lo (1 - c) + hi c for the five tables; rows compacted to half_T. blockIdx.y = table.
-__global__ void __launch_bounds__(256) rrw_fold_cycle_kernel(RrwTabs in, size_t stride, RrwTabsOut out, size_t half_T, uint32_t cur_K, FrArg r) {
+// the same fold of the four one-hot-born tables under the row masks: thread i folds the masked rows of cycle pair i and writes mask'[i]
+__global__ void __launch_bounds__(256) rrw_fold_cycle_masked_kernel(RrwTabs in, size_t stride, RrwTabsOut out, size_t half_T, const uint32_t *mask,
+                                                                    uint32_t *mask_out, FrArg r) {
     const FrMul rm = frmul_prepare(fr_from_arg(r));
-    const uint64_t *src = in.t[blockIdx.y];
-    uint64_t *dst = out.t[blockIdx.y];
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= 4 * half_T) return;
+    const size_t i = t % half_T;
+    const uint32_t g = (uint32_t)(t / half_T);  // row group: rows 8 g .. 8 g + 7
+    const uint32_t me = mask[2 * i], mo = mask[2 * i + 1];
+    if (g == 0) mask_out[i] = me | mo;
+    uint32_t m = (me | mo) & (0xFFu << (8 * g));
+    const Fr z = Fr::zero();
+    while (m) {
+        const uint32_t k = (uint32_t)__builtin_ctz(m);
+        m &= m - 1;
+        const bool he = (me >> k) & 1u, ho = (mo >> k) & 1u;
+        const size_t o = 4 * ((size_t)k * stride + 2 * i), d = 4 * ((size_t)k * half_T + i);
+#pragma unroll
+        for (int tt = RT_WA; tt <= RT_RS2; tt++) {
+            Fr lo = he ? fe_load<FrParams>(in.t[tt] + o) : z, hi = ho ? fe_load<FrParams>(in.t[tt] + o + 4) : z;
+            fe_store(out.t[tt] + d, rrw_fold1(lo, hi, rm));
+        }
+    }
+}
+
+// cycle fold (:1053-1090, 1124-1162): out[k][i] = lo (1 - c) + hi c; rows compacted to half_T. blockIdx.y + t0 = table.
+__global__ void __launch_bounds__(256) rrw_fold_cycle_kernel(RrwTabs in, size_t stride, RrwTabsOut out, size_t half_T, uint32_t cur_K, FrArg r, int t0) {
+    const FrMul rm = frmul_prepare(fr_from_arg(r));
+    const uint64_t *src = in.t[blockIdx.y + t0];
+    uint64_t *dst = out.t[blockIdx.y + t0];
     size_t n = (size_t)cur_K * half_T, step = (size_t)gridDim.x * 256;
     for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < n; t += step) {
         size_t k = t / half_T, i = t - k * half_T;
@@ -257,7 +335,8 @@ __global__ void __launch_bounds__(256) rrw_fold_vec_kernel(const uint64_t *a, ui
 }
 
 // register fold (:1092-1122): out[i][j] = row 2i (1 - c) + row 2i+1 c
-__global__ void __launch_bounds__(256) rrw_fold_address_kernel(RrwTabs in, size_t stride, RrwTabsOut out, size_t cur_T, uint32_t half_K, FrArg r) {
+__global__ void __launch_bounds__(256) rrw_fold_address_kernel(RrwTabs in, size_t stride, RrwTabsOut out, size_t cur_T, uint32_t half_K, uint32_t act_K,
+                                                               FrArg r) {
     const FrMul rm = frmul_prepare(fr_from_arg(r));
     const uint64_t *src = in.t[blockIdx.y];
     uint64_t *dst = out.t[blockIdx.y];
@@ -265,7 +344,7 @@ __global__ void __launch_bounds__(256) rrw_fold_address_kernel(RrwTabs in, size_
     for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < n; t += step) {
         size_t i = t / cur_T, j = t - i * cur_T;
         const uint64_t *p = src + 4 * ((2 * i) * stride + j);
-        fe_store(dst + 4 * (i * cur_T + j), rrw_fold1(fe_load<FrParams>(p), fe_load<FrParams>(p + 4 * stride), rm));
+        fe_store(dst + 4 * (i * cur_T + j), rrw_fold1(fe_load<FrParams>(p), 2 * i + 1 < act_K ? fe_load<FrParams>(p + 4 * stride) : Fr::zero(), rm));
     }
 }
 
@@ -274,11 +353,15 @@ __global__ void __launch_bounds__(256) rrw_fold_address_kernel(RrwTabs in, size_
 struct zg_rrw_s {
     int device = -1;
     size_t T = 0, cur_T = 0, stride = 0;
-    uint32_t cur_K = zg::RRW_K;
+    uint32_t cur_K = zg::RRW_K, act_K = zg::RRW_ACTIVE;  // current_K of the reference / rows that can be non-zero (stored)
     uint64_t *tab[zg::RRW_TABLES][2] = {};  // [table][buffer]: buffer 0 holds K x T elements, buffer 1 K x T / 2
     uint64_t *inc[2] = {nullptr, nullptr}, *eq[2] = {nullptr, nullptr};
     int cur = 0, vcur = 0;  // live buffer of the tables / of the two cycle vectors
     bool have_eq = false;
+    uint32_t *mask[2] = {nullptr, nullptr};  // row masks of the live cycles (see rrw_mask_build_kernel); mcur = live buffer
+    int mcur = 0;
+    bool mask_ok = true, garbage = false;    // masks describe the four tables / entries outside them have not been written
+    int masked_folds = 0;
     uint64_t *d_part = nullptr, *d_out = nullptr, *h_out = nullptr;
     hipStream_t st = nullptr;
     std::mutex mu;
@@ -295,6 +378,8 @@ static void rrw_free(zg_rrw_s *s) {
         if (s->inc[b]) (void)hipFree(s->inc[b]);
         if (s->eq[b]) (void)hipFree(s->eq[b]);
     }
+    for (int b = 0; b < 2; b++)
+        if (s->mask[b]) (void)hipFree(s->mask[b]);
     if (s->d_part) (void)hipFree(s->d_part);
     if (s->d_out) (void)hipFree(s->d_out);
     if (s->h_out) (void)hipHostFree(s->h_out);
@@ -324,8 +409,13 @@ static RrwTabsOut rrw_tabs_out(const zg_rrw_s *s, int buf) {
 
 // threads per round launch: one per (pair / cycle, chunk); chunks spread the register loop when the cycle dimension alone is short
 static uint32_t rrw_chunks(size_t inner, uint32_t outer) {
+    static const size_t want = [] {
+        const char *e = getenv("ZG_RRW_THREADS");
+        long v = e ? atol(e) : 0;
+        return (size_t)(v >= 1024 && v <= (1l << 26) ? v : 65536);
+    }();
     uint32_t c = 1;
-    while (c < outer && inner * c < 65536) c <<= 1;
+    while (c < outer && inner * c < want) c <<= 1;
     return c > outer ? outer : c;
 }
 
@@ -339,13 +429,31 @@ static int rrw_collect(zg_rrw_s *s, uint32_t nblocks, int nv, uint64_t *out) {
     return ZG_OK;
 }
 
+static int masked_folds_max() {
+    static const int v = [] {
+        const char *e = getenv("ZG_RRW_MASKED_FOLDS");
+        int x = e ? atoi(e) : 3;
+        return x < 0 ? 0 : (x > 30 ? 30 : x);
+    }();
+    return v;
+}
+// before the first reader that ignores the row masks: zero what the masked folds did not write
+static int rrw_materialize(zg_rrw_s *s) {
+    if (!s->garbage) return ZG_OK;
+    size_t n = (size_t)s->act_K * s->cur_T;
+    hipLaunchKernelGGL(rrw_materialize_kernel, dim3(div_up(n, 256)), dim3(256), 0, s->st, rrw_tabs_out(s, s->cur), s->stride, s->mask[s->mcur], s->cur_T, s->act_K);
+    ZG_HIP(hipGetLastError());
+    s->garbage = false;
+    return ZG_OK;
+}
+
 extern "C" {
 
 int zg_rrw_open(size_t log_t, const uint8_t *rs1, const uint8_t *rs2, const uint8_t *rd, const uint64_t *reg_vals, const uint64_t *inc,
                 const uint64_t gamma[4], zg_rrw_t *out) {
     ZG_INIT();
-    if (!out || !rs1 || !rs2 || !rd || !reg_vals || !inc || !gamma || log_t < 1 || log_t > 22) {
-        set_error("zg_rrw_open: invalid argument (1 <= log_t <= 22: five 128 x 2^log_t tables and their half-size partners)");
+    if (!out || !rs1 || !rs2 || !rd || !reg_vals || !inc || !gamma || log_t < 1 || log_t > 24) {
+        set_error("zg_rrw_open: invalid argument (1 <= log_t <= 24: five 32 x 2^log_t tables of active rows and their half-size partners)");
         return ZG_ERR_INVALID;
     }
     const size_t T = (size_t)1 << log_t;
@@ -355,13 +463,14 @@ int zg_rrw_open(size_t log_t, const uint8_t *rs1, const uint8_t *rs2, const uint
     s->st = stream_acquire();
     hipError_t e = s->st ? hipSuccess : hipErrorOutOfMemory;
     for (int t = 0; t < RRW_TABLES && e == hipSuccess; t++) {
-        e = hipMalloc((void **)&s->tab[t][0], (size_t)RRW_K * T * 32);
-        if (e == hipSuccess) e = hipMalloc((void **)&s->tab[t][1], (size_t)RRW_K * (T / 2) * 32);
+        e = hipMalloc((void **)&s->tab[t][0], (size_t)RRW_ACTIVE * T * 32);
+        if (e == hipSuccess) e = hipMalloc((void **)&s->tab[t][1], (size_t)RRW_ACTIVE * (T / 2) * 32);
     }
     for (int b = 0; b < 2 && e == hipSuccess; b++) {
         e = hipMalloc((void **)&s->inc[b], (T >> b) * 32);
         if (e == hipSuccess) e = hipMalloc((void **)&s->eq[b], (T >> b) * 32);
     }
+    for (int b = 0; b < 2 && e == hipSuccess; b++) e = hipMalloc((void **)&s->mask[b], (T >> b) * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_part, (size_t)RRW_MAX_BLOCKS * 4 * 32);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_out, 8 * 32);
     if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_out, 8 * 32);
@@ -385,9 +494,10 @@ int zg_rrw_open(size_t log_t, const uint8_t *rs1, const uint8_t *rs2, const uint
         ZG_HIP(hipMemcpyAsync(d_cols + 2 * pad, rd, T, hipMemcpyHostToDevice, s->st));
         ZG_HIP(hipMemcpyAsync(s_vals.p, reg_vals, 32 * T * 8, hipMemcpyHostToDevice, s->st));
         ZG_HIP(hipMemcpyAsync(s->inc[0], inc, T * 32, hipMemcpyHostToDevice, s->st));
-        size_t n = (size_t)RRW_K * T;
+        size_t n = (size_t)RRW_ACTIVE * T;
         hipLaunchKernelGGL(rrw_build_kernel, dim3(div_up(n, 256)), dim3(256), 0, s->st, d_cols, d_cols + pad, d_cols + 2 * pad, s_vals.as<uint64_t>(), T,
                            fr_arg(gamma), rrw_tabs_out(s, 0));
+        hipLaunchKernelGGL(rrw_mask_build_kernel, dim3(div_up(T, 256)), dim3(256), 0, s->st, d_cols, d_cols + pad, d_cols + 2 * pad, T, s->mask[0]);
         ZG_HIP(hipGetLastError());
         ZG_HIP(hipStreamSynchronize(s->st));
         sync.dismiss();
@@ -418,14 +528,14 @@ int zg_rrw_round_cycle_gruen(zg_rrw_t s, const uint64_t *d_e_out, size_t n_out, 
     const size_t half = s->cur_T / 2;
     uint32_t in_bits = 0;
     while (((size_t)1 << in_bits) < n_in) in_bits++;
-    uint32_t kc = rrw_chunks(half, s->cur_K);
+    uint32_t kc = rrw_chunks(half, s->act_K);
     uint32_t nb = div_up(half * kc, 256);
     if (nb > RRW_MAX_BLOCKS) {
         set_error("zg_rrw_round_cycle_gruen: table too long");
         return ZG_ERR_INVALID;
     }
     hipLaunchKernelGGL(rrw_cycle_gruen_kernel, dim3(nb), dim3(256), 0, s->st, rrw_tabs(s), s->stride, s->inc[s->vcur], d_e_out, (uint32_t)n_out, d_e_in,
-                       (uint32_t)n_in, in_bits, half, s->cur_K, kc, s->d_part);
+                       (uint32_t)n_in, in_bits, half, s->act_K, kc, s->mask_ok ? s->mask[s->mcur] : (const uint32_t *)nullptr, s->d_part);
     ZG_HIP(hipGetLastError());
     uint64_t o[8];
     ZG_TRY(rrw_collect(s, nb, 2, o));
@@ -458,7 +568,8 @@ int zg_rrw_round_address(zg_rrw_t s, uint64_t e0[4], uint64_t *e1, uint64_t e2[4
     }
     DeviceGuard dg(s->device);
     std::lock_guard<std::mutex> lk(s->mu);
-    const uint32_t half_K = s->cur_K / 2;
+    ZG_TRY(rrw_materialize(s));
+    const uint32_t half_K = (s->act_K + 1) / 2;  // row pairs with an active member; the pairs past them are zero
     uint32_t ic = rrw_chunks(s->cur_T, half_K);
     uint32_t nb = div_up(s->cur_T * ic, 256);
     if (nb > RRW_MAX_BLOCKS) {
@@ -466,11 +577,11 @@ int zg_rrw_round_address(zg_rrw_t s, uint64_t e0[4], uint64_t *e1, uint64_t e2[4
         return ZG_ERR_INVALID;
     }
     if (e1)
-        hipLaunchKernelGGL(rrw_address_kernel<true>, dim3(nb), dim3(256), 0, s->st, rrw_tabs(s), s->stride, s->inc[s->vcur], s->eq[s->vcur], s->cur_T, half_K, ic,
-                           s->d_part);
+        hipLaunchKernelGGL(rrw_address_kernel<true>, dim3(nb), dim3(256), 0, s->st, rrw_tabs(s), s->stride, s->inc[s->vcur], s->eq[s->vcur], s->cur_T, half_K,
+                           s->act_K, ic, s->d_part);
     else
-        hipLaunchKernelGGL(rrw_address_kernel<false>, dim3(nb), dim3(256), 0, s->st, rrw_tabs(s), s->stride, s->inc[s->vcur], s->eq[s->vcur], s->cur_T, half_K, ic,
-                           s->d_part);
+        hipLaunchKernelGGL(rrw_address_kernel<false>, dim3(nb), dim3(256), 0, s->st, rrw_tabs(s), s->stride, s->inc[s->vcur], s->eq[s->vcur], s->cur_T, half_K,
+                           s->act_K, ic, s->d_part);
     ZG_HIP(hipGetLastError());
     uint64_t o[12];
     ZG_TRY(rrw_collect(s, nb, e1 ? 3 : 2, o));
@@ -491,18 +602,18 @@ int zg_rrw_round_cycle(zg_rrw_t s, uint64_t e0[4], uint64_t *e1, uint64_t e2[4],
     DeviceGuard dg(s->device);
     std::lock_guard<std::mutex> lk(s->mu);
     const size_t half = s->cur_T / 2;
-    uint32_t kc = rrw_chunks(half, s->cur_K);
+    uint32_t kc = rrw_chunks(half, s->act_K);
     uint32_t nb = div_up(half * kc, 256);
     if (nb > RRW_MAX_BLOCKS) {
         set_error("zg_rrw_round_cycle: table too long");
         return ZG_ERR_INVALID;
     }
     if (e1)
-        hipLaunchKernelGGL(rrw_cycle_dense_kernel<true>, dim3(nb), dim3(256), 0, s->st, rrw_tabs(s), s->stride, s->inc[s->vcur], s->eq[s->vcur], half, s->cur_K, kc,
-                           s->d_part);
+        hipLaunchKernelGGL(rrw_cycle_dense_kernel<true>, dim3(nb), dim3(256), 0, s->st, rrw_tabs(s), s->stride, s->inc[s->vcur], s->eq[s->vcur], half, s->act_K, kc,
+                           s->mask_ok ? s->mask[s->mcur] : (const uint32_t *)nullptr, s->d_part);
     else
-        hipLaunchKernelGGL(rrw_cycle_dense_kernel<false>, dim3(nb), dim3(256), 0, s->st, rrw_tabs(s), s->stride, s->inc[s->vcur], s->eq[s->vcur], half, s->cur_K, kc,
-                           s->d_part);
+        hipLaunchKernelGGL(rrw_cycle_dense_kernel<false>, dim3(nb), dim3(256), 0, s->st, rrw_tabs(s), s->stride, s->inc[s->vcur], s->eq[s->vcur], half, s->act_K, kc,
+                           s->mask_ok ? s->mask[s->mcur] : (const uint32_t *)nullptr, s->d_part);
     ZG_HIP(hipGetLastError());
     uint64_t o[16];
     ZG_TRY(rrw_collect(s, nb, e1 ? 4 : 3, o));
@@ -525,10 +636,25 @@ int zg_rrw_bind_cycle(zg_rrw_t s, const uint64_t r[4]) {
     std::lock_guard<std::mutex> lk(s->mu);
     const size_t half = s->cur_T / 2;
     const int nxt = s->cur ^ 1, vn = s->vcur ^ 1;
-    size_t n = (size_t)s->cur_K * half;
+    size_t n = (size_t)s->act_K * half;
     unsigned nb = div_up(n, 256);
     if (nb > 16384) nb = 16384;
-    hipLaunchKernelGGL(rrw_fold_cycle_kernel, dim3(nb, RRW_TABLES), dim3(256), 0, s->st, rrw_tabs(s), s->stride, rrw_tabs_out(s, nxt), half, s->cur_K, fr_arg(r));
+    // the masks pay while they are sparse: <= 3 rows of 32 per cycle at the start, doubling per fold at worst. After RRW_MASKED_FOLDS folds
+    // (or when the table is short) the unwritten entries are zeroed once and everything is dense again.
+    if (s->mask_ok && (s->masked_folds >= masked_folds_max() || half < 4096)) {
+        ZG_TRY(rrw_materialize(s));
+        s->mask_ok = false;
+    }
+    if (s->mask_ok) {  // val densely, the four one-hot-born tables under the row masks
+        s->masked_folds++;
+        hipLaunchKernelGGL(rrw_fold_cycle_kernel, dim3(nb, 1), dim3(256), 0, s->st, rrw_tabs(s), s->stride, rrw_tabs_out(s, nxt), half, s->act_K, fr_arg(r), RT_VAL);
+        hipLaunchKernelGGL(rrw_fold_cycle_masked_kernel, dim3(div_up(4 * half, 256)), dim3(256), 0, s->st, rrw_tabs(s), s->stride, rrw_tabs_out(s, nxt), half,
+                           s->mask[s->mcur], s->mask[s->mcur ^ 1], fr_arg(r));
+        s->mcur ^= 1;
+        s->garbage = true;
+    } else {
+        hipLaunchKernelGGL(rrw_fold_cycle_kernel, dim3(nb, RRW_TABLES), dim3(256), 0, s->st, rrw_tabs(s), s->stride, rrw_tabs_out(s, nxt), half, s->act_K, fr_arg(r), 0);
+    }
     unsigned nv = div_up(half, 256);
     if (nv > 4096) nv = 4096;
     hipLaunchKernelGGL(rrw_fold_vec_kernel, dim3(nv), dim3(256), 0, s->st, s->inc[s->vcur], s->inc[vn], s->have_eq ? s->eq[s->vcur] : (const uint64_t *)nullptr,
@@ -549,16 +675,19 @@ int zg_rrw_bind_address(zg_rrw_t s, const uint64_t r[4]) {
     }
     DeviceGuard dg(s->device);
     std::lock_guard<std::mutex> lk(s->mu);
-    const uint32_t half_K = s->cur_K / 2;
+    ZG_TRY(rrw_materialize(s));
+    s->mask_ok = false;  // rows merge: the cycle masks no longer describe the tables (which are small by now)
+    const uint32_t half_act = (s->act_K + 1) / 2;
     const int nxt = s->cur ^ 1;
-    size_t n = (size_t)half_K * s->cur_T;
+    size_t n = (size_t)half_act * s->cur_T;
     unsigned nb = div_up(n, 256);
     if (nb > 16384) nb = 16384;
-    hipLaunchKernelGGL(rrw_fold_address_kernel, dim3(nb, RRW_TABLES), dim3(256), 0, s->st, rrw_tabs(s), s->stride, rrw_tabs_out(s, nxt), s->cur_T, half_K,
-                       fr_arg(r));
+    hipLaunchKernelGGL(rrw_fold_address_kernel, dim3(nb, RRW_TABLES), dim3(256), 0, s->st, rrw_tabs(s), s->stride, rrw_tabs_out(s, nxt), s->cur_T, half_act,
+                       s->act_K, fr_arg(r));
     ZG_HIP(hipGetLastError());
     s->cur = nxt;
-    s->cur_K = half_K;
+    s->cur_K /= 2;
+    s->act_K = half_act;
     s->stride = s->cur_T;
     return ZG_OK;
 }
@@ -573,10 +702,14 @@ int zg_rrw_final(zg_rrw_t s, uint64_t *out) {
     std::lock_guard<std::mutex> lk(s->mu);
     // entry [0][0] of val, wa, ra, rs1_ra, rs2_ra, then inc[0] and eq[0] (zero when no eq table was set)
     for (int t = 0; t < RRW_TABLES; t++) ZG_HIP(hipMemcpyAsync(out + 4 * t, s->tab[t][s->cur], 32, hipMemcpyDeviceToHost, s->st));
+    uint32_t m0 = ~0u;  // while the row masks are in force an entry outside them has not been written: it is zero
+    if (s->garbage) ZG_HIP(hipMemcpyAsync(&m0, s->mask[s->mcur], 4, hipMemcpyDeviceToHost, s->st));
     ZG_HIP(hipMemcpyAsync(out + 20, s->inc[s->vcur], 32, hipMemcpyDeviceToHost, s->st));
     if (s->have_eq) ZG_HIP(hipMemcpyAsync(out + 24, s->eq[s->vcur], 32, hipMemcpyDeviceToHost, s->st));
     else for (int i = 0; i < 4; i++) out[24 + i] = 0;
     ZG_HIP(hipStreamSynchronize(s->st));
+    if (!(m0 & 1u))
+        for (int i = 4; i < 20; i++) out[i] = 0;
     return ZG_OK;
 }
 
