@@ -245,6 +245,15 @@ ZG_API int zg_fr_rows_affine(const uint64_t *rows, size_t n_rows, size_t k, cons
                       uint64_t *const *tables /* ntab host pointers, n_pad * g elements each */);
 ZG_API int zg_fr_rows_affine_dev(const uint64_t *d_rows, size_t n_rows, size_t k, const uint64_t *coeffs_host, size_t ntab, size_t g, size_t n_pad,
                           uint64_t *const *d_tables /* host array of ntab DEVICE pointers */, void *stream);
+/* StreamingOuterProver.computeFirstRoundPoly's extended evaluations (src/zkvm/spartan/streaming_outer.zig:523-597, evaluateAzBzAtTargetY
+ * :599-671): for each UniSkip target Y_j and constraint group, Az(x, Y_j) and Bz(x, Y_j) are Lagrange extrapolations (COEFFS_PER_J,
+ * src/zkvm/r1cs/univariate_skip.zig:469-476) of the group's constraint values — affine maps of the cycle's inputs — and
+ * t1(Y_j) = sum_{cycle, group} eq(tau_low, (cycle, group)) * Az * Bz. Generic form over the cycle-major matrix:
+ *     out[p] = sum_{i < n_rows} W[i * g + p % g] * A_p(rows[i]) * B_p(rows[i]),     p < npairs <= 32,
+ * A_p / B_p = coefficient rows 2p / 2p + 1 (k + 1 elements each, the constant last; host memory); W: DEVICE table of n_rows * g weights
+ * (for the outer prover g = 2 and W = zg_fr_eq_table_dev(tau_low): index = cycle * 2 + group; pairs ordered (target, group)). */
+ZG_API int zg_fr_rows_affine_prodsum_dev(const uint64_t *d_rows, size_t n_rows, size_t k, const uint64_t *coeffs_host, size_t npairs,
+                                  const uint64_t *d_weights, size_t g, uint64_t *out /* host, npairs * 4 */, void *stream);
 /* DensePolynomial.bindLow, in place: t[i] = t[2i] + r*(t[2i+1]-t[2i]), len -> len/2 (src/poly/mod.zig:160-175) */
 ZG_API int zg_fr_bind_low(uint64_t *table, size_t len, const uint64_t r[4]);
 /* DensePolynomial.bindFirst: out[i] = (1-r)*t[i] + r*t[i+len/2] (src/poly/mod.zig:128-149) */
@@ -386,7 +395,8 @@ ZG_API int zg_psc_close(zg_psc_t s);
  * K = 128 registers x T = 2^log_t cycles — val, rd_wa, ra = gamma rs1_ra + gamma^2 rs2_ra, rs1_ra, rs2_ra, indexed [k * T + j] — plus
  * inc[T], LOG_K + log_t rounds in three phases (cycle variables in Gruen form, the seven register variables, the remaining cycle
  * variables under the merged dense eq table). The session builds the tables on the device from the per-cycle trace columns and keeps
- * them in HBM; every round is one pass (sums) + one pass (folds). The eq structure, Gruen's cubic, the claim and the transcript stay on
+ * them in HBM — the 32 rows that can be non-zero (register indices are 5-bit fields; rows 32..127 are zero in the reference's tables
+ * and are neither stored nor visited here); every round is one pass (sums) + one pass (folds). The eq structure, Gruen's cubic, the claim and the transcript stay on
  * the host. Values are the reference's, exactly.
  *   rs1 / rs2 / rd [T]: the register a cycle reads / writes, 0xFF = none — decided as initWithPhaseConfig does (:199-246: by opcode; rd
  *                        only when it is used and non-zero); padding cycles are 0xFF;

@@ -1473,6 +1473,7 @@ class StreamingOuterProver:
         self.num_cycle_vars = self.padded_trace_len.bit_length() - 1
         tau = _c(np.asarray(tau, dtype=np.uint64).reshape(-1, 4))
         self.tau_high = tau[-1].copy()
+        self.full_tau = tau.copy()
         self.split_eq = GruenSplitEq(tau[:-1], lagrange_tau_r0)  # tau_low (:165-167)
         self.current_claim = fr_from_int(0)
         self.current_round = 0
@@ -1693,3 +1694,129 @@ class Stage4Prover(Stage4GruenProver):
         out = self.getFinalClaims()
         out.update({"round_polys": np.stack(polys), "challenges": np.stack(chals), "final_claim": fr_from_int(claim)})
         return out
+
+
+# ---- the UniSkip first round of the outer prover (streaming_outer.zig:523-597, r1cs/univariate_skip.zig)
+def uniskip_targets(domain_size=10, degree=9):
+    """uniskipTargets (univariate_skip.zig:188-225): the extended points outside the base window, interleaved -5, 6, -6, 7, ..."""
+    base_left = -((domain_size - 1) // 2)
+    base_right = base_left + domain_size - 1
+    out, n, p = [], base_left - 1, base_right + 1
+    while n >= -degree and p <= degree and len(out) < degree:
+        out.append(n)
+        if len(out) >= degree:
+            break
+        out.append(p)
+        n -= 1
+        p += 1
+    while len(out) < degree and n >= -degree:
+        out.append(n)
+        n -= 1
+    while len(out) < degree and p <= degree:
+        out.append(p)
+        p += 1
+    return out
+
+
+def _generalized_binomial(t, k):  # LagrangeHelper.generalizedBinomial (:398-428)
+    if k == 0:
+        return 1
+    if t >= 0:
+        if k > t:
+            return 0
+        num = den = 1
+        for j in range(k):
+            num *= t - j
+            den *= j + 1
+        return num // den
+    sign = -1 if k & 1 else 1
+    tt = -t + k - 1
+    num = den = 1
+    for j in range(k):
+        num *= tt - j
+        den *= j + 1
+    return sign * (num // den)
+
+
+def shift_coeffs(n, shift):
+    """shiftCoeffsI32 (:435-448): alpha with p(shift) = sum_i alpha[i] p(i) for a polynomial of degree < n given on 0..n-1"""
+    out = []
+    for i in range(n):
+        s1 = _generalized_binomial(shift, i)
+        s2 = _generalized_binomial(shift - i - 1, (n - 1) - i)
+        sign = -1 if ((n - 1 - i) & 1) else 1
+        out.append(sign * s1 * s2)
+    return out
+
+
+UNISKIP_TARGETS = uniskip_targets()
+COEFFS_PER_J = [shift_coeffs(10, t + 4) for t in UNISKIP_TARGETS]  # :469-476 (TARGET_SHIFTS = target - BASE_LEFT)
+
+
+def _interpolate_int_domain(vals, left):
+    """coefficients (ascending) of the polynomial through (left + i, vals[i]) — lagrangeInterpolate (streaming_outer.zig:728-799);
+    exact arithmetic mod r, so any construction gives the same field elements"""
+    P, n = _R_P, len(vals)
+    coeffs = [0] * n
+    for i, y in enumerate(vals):
+        if y % P == 0:
+            continue
+        den, basis = 1, [1] + [0] * (n - 1)
+        deg = 0
+        for j in range(n):
+            if j == i:
+                continue
+            den = den * (i - j) % P
+            xj = left + j
+            for k in range(deg + 1, 0, -1):  # multiply by (Y - x_j)
+                basis[k] = (basis[k - 1] - xj * basis[k]) % P if k <= deg else basis[k - 1]
+            basis[0] = (-xj * basis[0]) % P
+            deg += 1
+        scale = y * pow(den, P - 2, P) % P
+        for k in range(n):
+            coeffs[k] = (coeffs[k] + basis[k] * scale) % P
+    return coeffs
+
+
+def _outer_first_round(self):
+    """computeFirstRoundPoly (:523-597) -> 28 coefficients (ascending) of s1(Y) = L(tau_high, Y) t1(Y); self.full_tau = the whole tau"""
+    P = _R_P
+    tau_low = self.full_tau[:-1]
+    T2 = 1 << len(tau_low)
+    weights = fr_eq_table(tau_low) if len(tau_low) else fr_from_int(1).reshape(1, 4)  # E_out[x_out] E_in[x_in], index = cycle * 2 + group
+    w = self.cycle_witnesses
+    n = min(w.shape[0], T2 // 2)
+    base = []
+    for group in (FIRST_GROUP_INDICES, SECOND_GROUP_INDICES):
+        az = [_lc_eval(UNIFORM_CONSTRAINTS[ci][0], w[:n]) for ci in group]
+        bz = [_fsub(_lc_eval(UNIFORM_CONSTRAINTS[ci][1], w[:n]), _lc_eval(UNIFORM_CONSTRAINTS[ci][2], w[:n])) for ci in group]
+        base.append((az, bz))
+    ext = []
+    for j in range(len(UNISKIP_TARGETS)):
+        total = np.zeros(4, dtype=np.uint64)
+        for g, (az, bz) in enumerate(base):
+            a = np.zeros((n, 4), dtype=np.uint64)
+            b = np.zeros((n, 4), dtype=np.uint64)
+            for i in range(len(az)):  # the second group uses the first nine of the ten coefficients (:631-657)
+                c = COEFFS_PER_J[j][i]
+                if c:
+                    cf = fr_from_int(abs(c))
+                    a = _fadd(a, _fmul(az[i], cf)) if c > 0 else _fsub(a, _fmul(az[i], cf))
+                    b = _fadd(b, _fmul(bz[i], cf)) if c > 0 else _fsub(b, _fmul(bz[i], cf))
+            total = _fadd(total, _fsum(_fmul(_fmul(a, b), weights[g:2 * n:2]))).reshape(4)
+        ext.append(fr_to_int(total))
+    self.last_extended_evals = ext
+    t1 = [0] * 19
+    for z, v in zip(UNISKIP_TARGETS, ext):
+        t1[z + 9] = v
+    t1_coeffs = _interpolate_int_domain(t1, -9)
+    lag = [fr_to_int(x) for x in lagrange_evals_symmetric(self.tau_high, 10)]
+    lag_coeffs = _interpolate_int_domain(lag, -4)
+    s1 = [0] * 28
+    for i in range(10):
+        for j in range(19):
+            s1[i + j] = (s1[i + j] + lag_coeffs[i] * t1_coeffs[j]) % P
+    return np.stack([fr_from_int(v) for v in s1])
+
+
+StreamingOuterProver.computeFirstRoundPoly = _outer_first_round

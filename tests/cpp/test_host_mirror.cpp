@@ -682,6 +682,14 @@ static int outer_main(const char *path) {
     for (size_t i = 0; i < nv + 1; i++) ch.push_back(read_fr(f));
     std::fclose(f);
     StreamingOuterProver p(w, tau, &scale);
+    {  // the UniSkip first round: t1 at the nine targets and the 28 coefficients of s1
+        auto s1 = p.computeFirstRoundPoly();
+        std::printf("X");
+        for (const Fr &x : p.last_extended_evals) print_fr(x);
+        std::printf("\nS");
+        for (const Fr &x : s1) print_fr(x);
+        std::printf("\n");
+    }
     p.bindFirstRoundChallenge(r0, claim);
     for (size_t rd = 0; rd < p.numRounds(); rd++) {
         auto ev = p.computeRemainingRoundPoly();

@@ -177,6 +177,10 @@ def test_cpp_streaming_outer_mirror(tmp_path, golden_dir):
                                   for l in res.stdout.splitlines() if l.startswith(tag + " ")]
         ts, evs, fin = parse("T", 2), parse("E", 4), parse("O", 4)[0]
         assert len(ts) == len(evs) == nv + 1
+        first = ob.StreamingOuterProver(w, tau, scale)  # the UniSkip first round of the same instance
+        want_s1 = first.computeFirstRoundPoly()
+        assert [ob.fr_to_int(x) for x in parse("X", 9)[0]] == first.last_extended_evals, k
+        assert np.array_equal(parse("S", 28)[0], want_s1), k
         for rd in range(nv + 1):
             we = o.computeRemainingRoundPoly()
             assert np.array_equal(ts[rd][0], o.last_t[0]) and np.array_equal(ts[rd][1], o.last_t[1]), (k, rd)

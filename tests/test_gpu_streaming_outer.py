@@ -140,3 +140,35 @@ def test_full_size_claim_chain(api):
     fa, fb = d.finalAzBz()
     assert np.array_equal(ob._fmul(ob._fmul(fa, fb), d.split_eq.current_scalar).reshape(4), d.getFinalEval())
     d.deinit()
+
+
+@pytest.mark.parametrize("n_cycles", [1, 6, 256, 3000])
+def test_uniskip_first_round_against_the_restatement(api, n_cycles):
+    """computeFirstRoundPoly: t1 at the nine targets (one prodsum launch) and the 28 coefficients of s1 = L(tau_high, .) t1, bit for bit;
+    s1 vanishes on the base window {-4..5} where t1 does (constraint products of a SATISFYING assignment would — random inputs only give
+    t1's zeros by construction of t1_vals), so s1(0) = 0: coefficient 0 is zero, as the captured run prints (logs/zolt.log:1661)"""
+    w = random_cycle_witnesses(n_cycles + 11, n_cycles)
+    nv = max(n_cycles - 1, 0).bit_length()
+    r = ob.f_to_mont(ob.FR, U.random_raw256(190 + n_cycles, nv + 3))
+    tau, scale = r[:nv + 2], r[nv + 2]
+    o = ob.StreamingOuterProver(w, tau, scale)
+    d = api.StreamingOuterProver(w, tau, scale)
+    want, got = o.computeFirstRoundPoly(), d.computeFirstRoundPoly()
+    assert o.last_extended_evals == d.last_extended_evals
+    assert np.array_equal(want, got) and got.shape == (28, 4)
+    assert not got[0].any()
+    # s1 at a target equals L(tau_high, target) * t1(target), t1(target) the device sum
+    P = ob._R_P
+    co = [ob.fr_to_int(x) for x in got]
+    for z, t1z in zip(api.UNISKIP_TARGETS, d.last_extended_evals):
+        lag = [ob.fr_to_int(x) for x in ob.lagrange_evals_symmetric(tau[-1], 10)]
+        basis_at_z = [ob.fr_to_int(x) for x in ob.lagrange_evals_symmetric(ob.fr_from_int(z % P), 10)]
+        kernel = sum(a * b for a, b in zip(lag, basis_at_z)) % P
+        assert sum(c * pow(z, k, P) for k, c in enumerate(co)) % P == kernel * t1z % P
+    d.deinit()
+
+
+def test_uniskip_constants(api):
+    assert api.UNISKIP_TARGETS == ob.UNISKIP_TARGETS == [-5, 6, -6, 7, -7, 8, -8, 9, -9] and api.COEFFS_PER_J == ob.COEFFS_PER_J
+    for j, t in enumerate(api.UNISKIP_TARGETS):  # the shift coefficients ARE the Lagrange basis of {-4..5} at the target
+        assert [c % ob._R_P for c in api.COEFFS_PER_J[j]] == [ob.fr_to_int(x) for x in api.lagrangeEvals(api.fr_from_int(t % ob._R_P), 10)]

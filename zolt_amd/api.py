@@ -1904,6 +1904,67 @@ def lagrangeKernel(x, y, size=10):
     return fr_from_int(sum(fr_to_int(a) * fr_to_int(b) for a, b in zip(lagrangeEvals(x, size), lagrangeEvals(y, size))) % R_MOD)
 
 
+def uniskipTargets(domain_size=10, degree=9):
+    """uniskipTargets (src/zkvm/r1cs/univariate_skip.zig:188-225): -5, 6, -6, 7, ... for the outer sumcheck"""
+    base_left = -((domain_size - 1) // 2)
+    out, n, p = [], base_left - 1, base_left + domain_size
+    while n >= -degree and p <= degree and len(out) < degree:
+        out.append(n)
+        if len(out) >= degree:
+            break
+        out.append(p)
+        n, p = n - 1, p + 1
+    while len(out) < degree and n >= -degree:
+        out.append(n)
+        n -= 1
+    while len(out) < degree and p <= degree:
+        out.append(p)
+        p += 1
+    return out
+
+
+def shiftCoeffs(n, shift):
+    """LagrangeHelper.shiftCoeffsI32 (univariate_skip.zig:398-448): p(shift) = sum_i alpha[i] p(i) for deg p < n"""
+    def gb(t, k):
+        if k == 0:
+            return 1
+        if t >= 0 and k > t:
+            return 0
+        tt, sign = (t, 1) if t >= 0 else (-t + k - 1, -1 if k & 1 else 1)
+        num = den = 1
+        for j in range(k):
+            num, den = num * (tt - j), den * (j + 1)
+        return sign * (num // den)
+    return [(-1 if ((n - 1 - i) & 1) else 1) * gb(shift, i) * gb(shift - i - 1, n - 1 - i) for i in range(n)]
+
+
+UNISKIP_TARGETS = uniskipTargets()
+COEFFS_PER_J = [shiftCoeffs(10, t + 4) for t in UNISKIP_TARGETS]  # :469-476
+
+
+def interpolateIntDomain(vals, left):
+    """coefficients (ascending) of the polynomial through (left + i, vals[i]) (lagrangeInterpolate, streaming_outer.zig:728-799)"""
+    n = len(vals)
+    coeffs = [0] * n
+    for i, y in enumerate(vals):
+        if y % R_MOD == 0:
+            continue
+        den, basis, deg = 1, [1] + [0] * (n - 1), 0
+        for j in range(n):
+            if j == i:
+                continue
+            den = den * (i - j) % R_MOD
+            xj = left + j
+            for k in range(deg + 1, 0, -1):
+                basis[k] = (basis[k - 1] - xj * basis[k]) % R_MOD if k <= deg else basis[k - 1]
+            basis[0] = (-xj * basis[0]) % R_MOD
+            deg += 1
+        scale = y * pow(den, R_MOD - 2, R_MOD) % R_MOD
+        for k in range(n):
+            coeffs[k] = (coeffs[k] + basis[k] * scale) % R_MOD
+    return coeffs
+
+
 class StreamingOuterProver:
     """StreamingOuterProver's remaining rounds (src/zkvm/spartan/streaming_outer.zig: init :120-212, bindFirstRoundChallenge :1135-1155,
     materializeLinearPhasePolynomials :258-372, computeRemainingRoundPoly :1215-1281, bindRemainingRoundChallenge :1681-1717, updateClaim
@@ -1923,6 +1984,7 @@ class StreamingOuterProver:
         tau = np.ascontiguousarray(tau, dtype=np.uint64).reshape(-1, 4)
         assert tau.shape[0] == self.num_cycle_vars + 2
         self.tau_high = tau[-1].copy()
+        self.full_tau = tau.copy()
         self.split_eq = GruenSplitEqPolynomial(tau[:-1], lagrange_tau_r0)
         self._d_rows = lib.DeviceBuffer.from_host(w)
         self.current_claim = fr_from_int(0)
@@ -1934,6 +1996,43 @@ class StreamingOuterProver:
 
     def numRounds(self):
         return 1 + self.num_cycle_vars
+
+    def computeFirstRoundPoly(self):
+        """computeFirstRoundPoly (:523-597): the 28 coefficients of s1(Y) = L(tau_high, Y) t1(Y). t1 at the nine UniSkip targets is ONE
+        launch over the resident witnesses: for target j and group g, Az(., Y_j) and Bz(., Y_j) are the COEFFS_PER_J[j]-weighted sums of the
+        group's condition / left - right combinations — two affine maps of a cycle's inputs — and the launch sums their product under
+        eq(tau_low, (cycle, group)) (zg_fr_rows_affine_prodsum_dev); the two interpolations and the product of the polynomials are host
+        integer arithmetic (19 + 10 points)."""
+        W = NUM_R1CS_INPUTS + 1
+        m = [[0] * W for _ in range(36)]  # rows 2 p, 2 p + 1 = A_p, B_p for pair p = 2 j + g
+        for j in range(9):
+            for g, group in enumerate((FIRST_GROUP_INDICES, SECOND_GROUP_INDICES)):
+                p = 2 * j + g
+                for i, ci in enumerate(group):  # the second group uses the first nine of the ten coefficients (:631-657)
+                    a = COEFFS_PER_J[j][i]
+                    cond, left, right = UNIFORM_CONSTRAINTS[ci]
+                    for row, lc, sign in ((2 * p, cond, 1), (2 * p + 1, left, 1), (2 * p + 1, right, -1)):
+                        for idx, c in lc[0]:
+                            m[row][idx] = (m[row][idx] + sign * a * c) % R_MOD
+                        m[row][NUM_R1CS_INPUTS] = (m[row][NUM_R1CS_INPUTS] + sign * a * lc[1]) % R_MOD
+        coeffs = np.stack([np.stack([fr_from_int(v) for v in row]) for row in m])
+        tau_low = self.full_tau[:-1]
+        d_w = lib.DeviceBuffer((1 << tau_low.shape[0]) * 32)
+        lib.fr_eq_table_dev(tau_low, d_w.ptr)  # E_out[x_out] E_in[x_in] at index (x_out, x_in) = cycle * 2 + group (:541-566)
+        out = lib.fr_rows_affine_prodsum_dev(self._d_rows.ptr, min(self.num_cycles, self.padded_trace_len), NUM_R1CS_INPUTS, coeffs, 18, d_w.ptr, 2)
+        d_w.free()
+        ext = [(fr_to_int(out[2 * j]) + fr_to_int(out[2 * j + 1])) % R_MOD for j in range(9)]
+        self.last_extended_evals = ext
+        t1 = [0] * 19
+        for z, v in zip(UNISKIP_TARGETS, ext):
+            t1[z + 9] = v
+        t1_coeffs = interpolateIntDomain(t1, -9)
+        lag_coeffs = interpolateIntDomain([fr_to_int(x) for x in lagrangeEvals(self.tau_high, 10)], -4)
+        s1 = [0] * 28
+        for i in range(10):
+            for j in range(19):
+                s1[i + j] = (s1[i + j] + lag_coeffs[i] * t1_coeffs[j]) % R_MOD
+        return np.stack([fr_from_int(v) for v in s1])
 
     def bindFirstRoundChallenge(self, r0, uni_skip_claim):
         """r0 is not bound in split_eq: its weight is the initial scalar (:1135-1155)"""

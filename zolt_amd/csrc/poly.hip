@@ -522,6 +522,58 @@ __global__ void __launch_bounds__(1024) rows_affine_kernel(const uint64_t *rows,
     fe_store(a.tab[c] + 4 * (i * g + c % g), val);
 }
 
+// Weighted sums of PRODUCTS of two affine maps of the rows: out[p] = sum_i W[i * G + p % G] * A_p(row_i) * B_p(row_i) — the extended
+// evaluations of StreamingOuterProver.computeFirstRoundPoly (src/zkvm/spartan/streaming_outer.zig:523-597): for each of the nine UniSkip
+// targets and each constraint group, Az and Bz at the target are Lagrange extrapolations of the group's constraint values, i.e. affine
+// maps of the cycle's inputs; their product is summed under eq(tau_low, (cycle, group)). Wave w of a block <-> pair (blockIdx.y * waves
+// + w), lane <-> cycle (grid-stride over the cycles): the two affine maps as in rows_affine_kernel (wave-uniform column lists, lazy
+// limb-wise sums), one product, one product by the weight, a lane-wise running sum; a shuffle tree per wave at the end.
+constexpr unsigned ROWS_PS_MAX_PAIRS = 32, ROWS_PS_WAVES = 8;
+struct RowsProdSumArgs {
+    uint8_t nnz[2 * ROWS_PS_MAX_PAIRS];
+};
+__global__ void __launch_bounds__(64 * ROWS_PS_WAVES) rows_affine_prodsum_kernel(const uint64_t *rows, size_t n_rows, uint32_t k, const uint64_t *coeff,
+                                                                                 const uint32_t *pre, const uint8_t *cols, RowsProdSumArgs a,
+                                                                                 const uint64_t *w, uint32_t G, uint32_t npairs, uint64_t *partials) {
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, p = blockIdx.y * ROWS_PS_WAVES + wave;
+    if (p >= npairs) return;
+    Fr acc = Fr::zero();
+    for (size_t i = (size_t)blockIdx.x * 64 + lane; i < n_rows; i += (size_t)gridDim.x * 64) {
+        const uint64_t *row = rows + 4 * i * k;
+        Fr ab[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t c = 2 * p + h;
+            const uint32_t *pc = pre + 9 * (size_t)c * (k + 1);
+            const uint8_t *cl = cols + 64 * c;
+            Acc29 lazy = acc29_zero();
+            const uint32_t nnz = a.nnz[c];
+            for (uint32_t j = 0; j < nnz; j++) {
+                const uint32_t col = cl[j];
+                F29 y;
+#pragma unroll
+                for (int t = 0; t < 9; t++) y.l[t] = pc[9 * col + t];
+                acc29_add(lazy, fr29_chain_mul(fr29_in(fe_load<FrParams>(row + 4 * col)), y));
+            }
+            ab[h] = fe_load<FrParams>(coeff + 4 * ((size_t)c * (k + 1) + k));
+            if (nnz) ab[h] = fe_add(ab[h], acc29_reduce(lazy));
+        }
+        if (ab[0].is_zero() || ab[1].is_zero()) continue;
+        acc = fe_add(acc, fr_mul29v(fr_mul29v(ab[0], ab[1]), fe_load<FrParams>(w + 4 * (i * G + p % G))));
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) acc = fe_add(acc, fr_shfl_down(acc, d));
+    if (lane == 0) fe_store(partials + 4 * ((size_t)blockIdx.x * npairs + p), acc);
+}
+// out[p] = sum over the blocks' partials; one block per pair
+__global__ void __launch_bounds__(256) rows_prodsum_finish_kernel(const uint64_t *partials, uint32_t nblocks, uint32_t npairs, uint64_t *out) {
+    __shared__ uint4 sh[256 * 4];
+    Fr g0 = Fr::zero(), g1 = Fr::zero();
+    for (uint32_t b = threadIdx.x; b < nblocks; b += 256) g0 = fe_add(g0, fe_load<FrParams>(partials + 4 * ((size_t)b * npairs + blockIdx.x)));
+    block_sum_pair(g0, g1, sh);
+    if (threadIdx.x == 0) fe_store(out + 4 * (size_t)blockIdx.x, g0);
+}
+
 // reduce the per-block partial pairs to sums[0..8)
 __global__ void __launch_bounds__(256) sc_finish_kernel(const uint64_t *partials, uint32_t nblocks, uint64_t *sums, uint64_t *flag,
                                                         uint64_t seq) {
@@ -1237,6 +1289,48 @@ int zg_fr_rows_affine_dev(const uint64_t *d_rows, size_t n_rows, size_t k, const
                        s_pre.as<uint32_t>(), s_cols.as<uint8_t>(), a, (uint32_t)g, n_pad);
     ZG_HIP(hipGetLastError());
     ZG_HIP(hipStreamSynchronize(st));  // the coefficient buffers go back to the cache; `cols` is a local
+    sync.dismiss();
+    return ZG_OK;
+}
+
+int zg_fr_rows_affine_prodsum_dev(const uint64_t *d_rows, size_t n_rows, size_t k, const uint64_t *coeffs, size_t npairs, const uint64_t *d_weights, size_t g,
+                                  uint64_t *out, void *stream) {
+    ZG_INIT();
+    if (!coeffs || !out || k == 0 || k > ROWS_AFFINE_MAX_K || npairs == 0 || npairs > ROWS_PS_MAX_PAIRS || g == 0 || (n_rows && (!d_rows || !d_weights))) {
+        set_error("zg_fr_rows_affine_prodsum: 1..64 columns, 1..32 pairs, a weight interleave >= 1");
+        return ZG_ERR_INVALID;
+    }
+    if (n_rows == 0) {
+        for (size_t i = 0; i < 4 * npairs; i++) out[i] = 0;
+        return ZG_OK;
+    }
+    hipStream_t st = pick_stream(stream);
+    const size_t nout = 2 * npairs;
+    std::vector<uint8_t> cols(64 * nout, 0);
+    RowsProdSumArgs a{};
+    for (size_t c = 0; c < nout; c++) {
+        unsigned nnz = 0;
+        for (size_t col = 0; col < k; col++) {
+            const uint64_t *e = coeffs + 4 * (c * (k + 1) + col);
+            if (e[0] | e[1] | e[2] | e[3]) cols[64 * c + nnz++] = (uint8_t)col;
+        }
+        a.nnz[c] = (uint8_t)nnz;
+    }
+    const size_t n_coeff = nout * (k + 1);
+    unsigned nb = div_up(n_rows, 64);
+    if (nb > 1024) nb = 1024;
+    Scratch s_coeff(n_coeff * 32), s_pre(n_coeff * 36), s_cols(64 * nout), s_part((size_t)nb * npairs * 32), s_out(npairs * 32);
+    if (!s_coeff.p || !s_pre.p || !s_cols.p || !s_part.p || !s_out.p) return ZG_ERR_NOMEM;
+    SyncGuard sync(st);
+    ZG_HIP(hipMemcpyAsync(s_coeff.p, coeffs, n_coeff * 32, hipMemcpyHostToDevice, st));
+    ZG_HIP(hipMemcpyAsync(s_cols.p, cols.data(), cols.size(), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(rows_affine_prep_kernel, dim3(div_up(n_coeff, 256)), dim3(256), 0, st, s_coeff.as<uint64_t>(), (uint32_t)n_coeff, s_pre.as<uint32_t>());
+    hipLaunchKernelGGL(rows_affine_prodsum_kernel, dim3(nb, div_up(npairs, ROWS_PS_WAVES)), dim3(64 * ROWS_PS_WAVES), 0, st, d_rows, n_rows, (uint32_t)k,
+                       s_coeff.as<uint64_t>(), s_pre.as<uint32_t>(), s_cols.as<uint8_t>(), a, d_weights, (uint32_t)g, (uint32_t)npairs, s_part.as<uint64_t>());
+    hipLaunchKernelGGL(rows_prodsum_finish_kernel, dim3((unsigned)npairs), dim3(256), 0, st, s_part.as<uint64_t>(), nb, (uint32_t)npairs, s_out.as<uint64_t>());
+    ZG_HIP(hipGetLastError());
+    ZG_HIP(hipMemcpyAsync(out, s_out.p, npairs * 32, hipMemcpyDeviceToHost, st));
+    ZG_HIP(hipStreamSynchronize(st));
     sync.dismiss();
     return ZG_OK;
 }

@@ -1463,7 +1463,8 @@ public:
     std::vector<Fr> challenges, lagrange_evals_r0;
 
     StreamingOuterProver(const std::vector<CycleInputs> &cycle_witnesses, const std::vector<Fr> &tau, const Fr *lagrange_tau_r0 = nullptr)
-        : split_eq(std::vector<Fr>(tau.begin(), tau.end() - (tau.empty() ? 0 : 1)), lagrange_tau_r0), num_cycles_(cycle_witnesses.size()) {
+        : split_eq(std::vector<Fr>(tau.begin(), tau.end() - (tau.empty() ? 0 : 1)), lagrange_tau_r0), num_cycles_(cycle_witnesses.size()),
+          tau_high_(tau.empty() ? Fr::zero() : tau.back()) {
         if (cycle_witnesses.empty()) throw std::invalid_argument("StreamingOuterProver: empty trace");  // error.EmptyTrace
         while (padded_trace_len < num_cycles_) padded_trace_len <<= 1, num_cycle_vars++;
         if (tau.size() != num_cycle_vars + 2) throw std::invalid_argument("StreamingOuterProver: tau has num_cycle_vars + 2 challenges");
@@ -1477,6 +1478,89 @@ public:
         check(zg_sync(), "zg_sync");
     }
     size_t numRounds() const { return 1 + num_cycle_vars; }
+    // uniskipTargets / COEFFS_PER_J of the outer sumcheck (src/zkvm/r1cs/univariate_skip.zig:188-225, 398-476): -5, 6, -6, ... and, per target,
+    // the Lagrange basis of the base window {-4..5} at it (integers)
+    static std::array<int, 9> uniskipTargets() { return {-5, 6, -6, 7, -7, 8, -8, 9, -9}; }
+    static std::array<long long, 10> shiftCoeffs(int target) {
+        std::array<long long, 10> out;
+        for (int i = 0; i < 10; i++) {  // L_i(target) = prod_{j != i} (target - x_j) / (x_i - x_j), x_k = -4 + k: exact integer division
+            long long num = 1, den = 1;
+            for (int j = 0; j < 10; j++)
+                if (j != i) { num *= target - (-4 + j); den *= i - j; }
+            out[i] = num / den;
+        }
+        return out;
+    }
+    // coefficients (ascending) of the polynomial through (left + i, vals[i]) (lagrangeInterpolate, streaming_outer.zig:728-799)
+    static std::vector<Fr> interpolateIntDomain(const std::vector<Fr> &vals, int left) {
+        const size_t n = vals.size();
+        std::vector<Fr> coeffs(n, Fr::zero());
+        for (size_t i = 0; i < n; i++) {
+            if (vals[i].isZero()) continue;
+            Fr den = Fr::one(), inv;
+            std::vector<Fr> basis(n, Fr::zero());
+            basis[0] = Fr::one();
+            size_t deg = 0;
+            for (size_t j = 0; j < n; j++) {
+                if (j == i) continue;
+                den = den.mul(r1cs::fromInt((int)i - (int)j));
+                const Fr neg_xj = r1cs::fromInt(-(left + (int)j));
+                for (size_t k = deg + 1; k > 0; k--) basis[k] = k <= deg ? basis[k - 1].add(neg_xj.mul(basis[k])) : basis[k - 1];
+                basis[0] = neg_xj.mul(basis[0]);
+                deg++;
+            }
+            den.inverse(inv);
+            const Fr scale = vals[i].mul(inv);
+            for (size_t k = 0; k < n; k++) coeffs[k] = coeffs[k].add(basis[k].mul(scale));
+        }
+        return coeffs;
+    }
+    // computeFirstRoundPoly (:523-597): t1 at the nine targets by ONE launch over the resident witnesses (zg_fr_rows_affine_prodsum_dev), then
+    // s1 = L(tau_high, .) * t1 as 28 coefficients on the host
+    std::vector<Fr> last_extended_evals;
+    std::array<Fr, 28> computeFirstRoundPoly() {
+        const size_t W = r1cs::NUM_INPUTS + 1;
+        std::vector<Fr> m(36 * W, Fr::zero());  // rows 2 p, 2 p + 1 = A_p, B_p for pair p = 2 j + group
+        const auto &cs = r1cs::uniformConstraints();
+        const auto targets = uniskipTargets();
+        auto add = [&](size_t row, const r1cs::LC &l, const Fr &w, bool negate) {
+            for (const auto &t : l.terms) m[row * W + t.input] = m[row * W + t.input].add(w.mul(r1cs::fromInt(negate ? -t.coeff : t.coeff)));
+            Fr c = r1cs::fromInt(l.constant);
+            if (l.two_pow_64) c = c.add(Fr::fromU64(uint64_t(1) << 32).mul(Fr::fromU64(uint64_t(1) << 32)));
+            c = w.mul(c);
+            m[row * W + r1cs::NUM_INPUTS] = negate ? m[row * W + r1cs::NUM_INPUTS].sub(c) : m[row * W + r1cs::NUM_INPUTS].add(c);
+        };
+        for (size_t j = 0; j < 9; j++) {
+            const auto alpha = shiftCoeffs(targets[j]);
+            for (size_t g = 0; g < 2; g++) {
+                const size_t p = 2 * j + g, gs = g == 0 ? 10 : 9;  // the second group uses the first nine of the ten coefficients (:631-657)
+                for (size_t i = 0; i < gs; i++) {
+                    const Fr a = alpha[i] >= 0 ? Fr::fromU64((uint64_t)alpha[i]) : Fr::zero().sub(Fr::fromU64((uint64_t)(-alpha[i])));
+                    const auto &c = cs[g == 0 ? r1cs::FIRST_GROUP[i] : r1cs::SECOND_GROUP[i]];
+                    add(2 * p, c.condition, a, false);
+                    add(2 * p + 1, c.left, a, false);
+                    add(2 * p + 1, c.right, a, true);
+                }
+            }
+        }
+        DeviceMem d_w((size_t(1) << split_eq.tau.size()) * 32);  // eq(tau_low, .): index = cycle * 2 + group (:541-566)
+        check(zg_fr_eq_table_dev(reinterpret_cast<const uint64_t *>(split_eq.tau.data()), split_eq.tau.size(), nullptr, d_w.u64(), nullptr), "zg_fr_eq_table_dev");
+        Fr out[18];
+        check(zg_fr_rows_affine_prodsum_dev(d_rows_.u64(), std::min(num_cycles_, padded_trace_len), r1cs::NUM_INPUTS, reinterpret_cast<const uint64_t *>(m.data()), 18,
+                                            d_w.u64(), 2, reinterpret_cast<uint64_t *>(out), nullptr), "zg_fr_rows_affine_prodsum_dev");
+        std::vector<Fr> t1(19, Fr::zero());
+        last_extended_evals.assign(9, Fr::zero());
+        for (size_t j = 0; j < 9; j++) {
+            last_extended_evals[j] = out[2 * j].add(out[2 * j + 1]);
+            t1[(size_t)(targets[j] + 9)] = last_extended_evals[j];
+        }
+        const std::vector<Fr> t1c = interpolateIntDomain(t1, -9), lc = interpolateIntDomain(lagrangeEvals(tau_high_, 10), -4);
+        std::array<Fr, 28> s1;
+        for (auto &x : s1) x = Fr::zero();
+        for (size_t i = 0; i < 10; i++)
+            for (size_t j = 0; j < 19; j++) s1[i + j] = s1[i + j].add(lc[i].mul(t1c[j]));
+        return s1;
+    }
     void bindFirstRoundChallenge(const Fr &r0, const Fr &uni_skip_claim) {  // r0 is not bound in split_eq (:1135-1155)
         current_round = 1;
         current_claim = uni_skip_claim;
@@ -1546,6 +1630,7 @@ public:
 
 private:
     size_t num_cycles_;
+    Fr tau_high_;
     DeviceMem d_rows_, d_out_, d_in_;
     std::unique_ptr<ProductSumcheckSession> s_;
 };

@@ -37,7 +37,7 @@ SYMBOLS = [
     "zg_msm_g1", "zg_msm_g1_dev", "zg_msm_g1_dev_async", "zg_msm_g1_batch", "zg_msm_g1_batch_dev", "zg_msm_g1_partial_dev", "zg_msm_g1_partial_fast_dev",
     "zg_g1_combine_partials_dev", "zg_g1_combine_partials_dev_async", "zg_g1_is_on_curve_batch", "zg_g1_scalar_mul_batch", "zg_g1_fixed_base_mul_batch",
     "zg_hyperkzg_open", "zg_hyperkzg_open_dev", "zg_hyperkzg_batch_open",
-    "zg_fr_dense_evaluate", "zg_fr_eq_table", "zg_fr_eq_table_dev", "zg_fr_eq_prefix_tables", "zg_fr_eq_prefix_tables_dev", "zg_fr_rows_mle", "zg_fr_rows_mle_dev", "zg_fr_rows_affine", "zg_fr_rows_affine_dev", "zg_fr_eq_plus_one_table", "zg_fr_eq_plus_one_table_dev", "zg_fr_bind_low", "zg_fr_bind_high",
+    "zg_fr_dense_evaluate", "zg_fr_eq_table", "zg_fr_eq_table_dev", "zg_fr_eq_prefix_tables", "zg_fr_eq_prefix_tables_dev", "zg_fr_rows_mle", "zg_fr_rows_mle_dev", "zg_fr_rows_affine", "zg_fr_rows_affine_dev", "zg_fr_rows_affine_prodsum_dev", "zg_fr_eq_plus_one_table", "zg_fr_eq_plus_one_table_dev", "zg_fr_bind_low", "zg_fr_bind_high",
     "zg_fr_spartan_combine", "zg_fr_spartan_combine_dev",
     "zg_sumcheck_open", "zg_sumcheck_open_dev", "zg_sumcheck_round_sums", "zg_sumcheck_bind",
     "zg_sumcheck_len", "zg_sumcheck_final", "zg_sumcheck_read", "zg_sumcheck_gather", "zg_sumcheck_close",
@@ -576,6 +576,16 @@ def fr_rows_affine_dev(d_rows, n_rows, k, coeffs, ntab, g, n_pad, d_tables, stre
     ptrs = (C.c_void_p * ntab)(*[int(p) for p in d_tables])
     _chk(_lib.zg_fr_rows_affine_dev(_d(d_rows), C.c_size_t(n_rows), C.c_size_t(k), _h(coeffs), C.c_size_t(ntab), C.c_size_t(g), C.c_size_t(n_pad),
                                     ptrs, _d(stream)), "zg_fr_rows_affine_dev")
+
+
+def fr_rows_affine_prodsum_dev(d_rows, n_rows, k, coeffs, npairs, d_weights, g, stream=0):
+    """out[p] = sum_i W[i * g + p % g] * A_p(row_i) * B_p(row_i) (zg_fr_rows_affine_prodsum_dev) -> (npairs, 4)"""
+    coeffs = _c(coeffs)
+    assert coeffs.size == 2 * npairs * (k + 1) * 4
+    out = np.empty((npairs, 4), dtype=np.uint64)
+    _chk(_lib.zg_fr_rows_affine_prodsum_dev(_d(d_rows), C.c_size_t(n_rows), C.c_size_t(k), _h(coeffs), C.c_size_t(npairs), _d(d_weights), C.c_size_t(g),
+                                            _h(out), _d(stream)), "zg_fr_rows_affine_prodsum_dev")
+    return out
 
 
 def fr_bind_low(table, r):
