@@ -1820,3 +1820,138 @@ def _outer_first_round(self):
 
 
 StreamingOuterProver.computeFirstRoundPoly = _outer_first_round
+
+
+# ---------------------------------------------------------------- R1CS cycle inputs from the trace
+def _sx(v, bits):
+    return v - (1 << bits) if v >> (bits - 1) else v
+
+
+def _imm_i(w):
+    return _sx(w >> 20, 12)
+
+
+def _imm_s(w):
+    return _sx(((w >> 25) << 5) | ((w >> 7) & 0x1F), 12)
+
+
+def _imm_b(w):
+    return _sx(((w >> 31) << 12) | (((w >> 7) & 1) << 11) | (((w >> 25) & 0x3F) << 5) | (((w >> 8) & 0xF) << 1), 13)
+
+
+def _imm_j(w):
+    return _sx(((w >> 31) << 20) | (((w >> 12) & 0xFF) << 12) | (((w >> 20) & 1) << 11) | (((w >> 21) & 0x3FF) << 1), 21)
+
+
+def _is_noop_instruction(step):  # isNoopInstruction (constraints.zig:569-595)
+    if step is None:
+        return False
+    if step["is_noop"]:
+        return True
+    w = step["instruction"]
+    return (w & 0x7F) == 0x13 and ((w >> 7) & 31) == 0 and ((w >> 15) & 31) == 0 and ((w >> 12) & 7) == 0 and (w >> 20) == 0
+
+
+def r1cs_cycle_inputs(step, next_step):
+    """R1CSCycleInputs.fromTraceStep (src/zkvm/r1cs/constraints.zig:930-1223) with deriveImmediate (:1226-1274), setFlagsFromInstruction
+    (:1288-1398) and computeLookupOutput (:600-640) -> the 43 inputs of a cycle as integers mod r. step: tracer.TraceStep as a dict."""
+    P, M64 = _R_P, (1 << 64) - 1
+    v = [0] * NUM_R1CS_INPUTS
+    I = _R1
+    w = step["instruction"]
+    op, f3, f7, rd = w & 0x7F, (w >> 12) & 7, (w >> 25) & 0x7F, (w >> 7) & 31
+    is_load, is_store = op == 0x03, op == 0x23
+    v[I["FlagLoad"]], v[I["FlagStore"]] = int(is_load), int(is_store)
+    v[I["FlagIsCompressed"]] = int(step["is_compressed"])
+    # deriveImmediate: I / S / B / J sign-extended, U as the unsigned upper bits, everything else (incl. the 32-bit ops) zero
+    if op in (0x13, 0x03, 0x67):
+        imm = _imm_i(w)
+    elif op == 0x23:
+        imm = _imm_s(w)
+    elif op == 0x63:
+        imm = _imm_b(w)
+    elif op == 0x6F:
+        imm = _imm_j(w)
+    elif op in (0x37, 0x17):
+        imm = w & 0xFFFFF000
+    else:
+        imm = 0
+    v[I["Imm"]] = imm % P
+    if op in (0x13, 0x03, 0x67, 0x1B, 0x33, 0x3B, 0x23, 0x63):  # :957-977
+        v[I["Rs1Value"]] = step["rs1_value"]
+    if op in (0x33, 0x3B, 0x23, 0x63):  # :986-993
+        v[I["Rs2Value"]] = step["rs2_value"]
+    v[I["RamAddress"]] = (step["rs1_value"] + imm) % P if (is_load or is_store) else 0  # :1001-1009
+    mem = step["memory_value"] or 0
+    writes_rd = not is_store and op != 0x63 and rd != 0
+    if is_load:  # :1023-1047
+        v[I["RamReadValue"]] = v[I["RamWriteValue"]] = v[I["RdWriteValue"]] = mem
+    elif is_store:
+        v[I["RamReadValue"]], v[I["RamWriteValue"]] = mem, step["rs2_value"]
+    else:
+        v[I["RdWriteValue"]] = step["rd_value"] if writes_rd else 0
+    left_is_rs1 = int(op in (0x33, 0x13, 0x03, 0x67, 0x23, 0x63, 0x1B, 0x3B))  # :1059-1098
+    left_is_pc = int(op in (0x17, 0x6F))
+    right_is_rs2 = int(op in (0x33, 0x63, 0x3B))
+    right_is_imm = int(op in (0x13, 0x03, 0x67, 0x23, 0x37, 0x17, 0x6F, 0x1B))
+    v[I["FlagLeftOperandIsRs1"]], v[I["FlagLeftOperandIsPC"]] = left_is_rs1, left_is_pc
+    v[I["FlagRightOperandIsRs2"]], v[I["FlagRightOperandIsImm"]] = right_is_rs2, right_is_imm
+    left = (left_is_rs1 * v[I["Rs1Value"]] + left_is_pc * step["unexpanded_pc"]) % P  # :1106-1118
+    right = (right_is_rs2 * v[I["Rs2Value"]] + right_is_imm * v[I["Imm"]]) % P
+    v[I["LeftInstructionInput"]], v[I["RightInstructionInput"]], v[I["Product"]] = left, right, left * right % P
+    # computeLookupOutput (:600-640)
+    if op == 0x6F:
+        lookup = (step["pc"] + _imm_j(w)) & M64
+    elif op == 0x67:
+        lookup = ((step["rs1_value"] + _imm_i(w)) & M64) & ~1
+    elif op == 0x63:
+        a, b = step["rs1_value"], step["rs2_value"]
+        sa, sb = _sx(a, 64), _sx(b, 64)
+        lookup = int({0: a == b, 1: a != b, 4: sa < sb, 5: sa >= sb, 6: a < b, 7: a >= b}.get(f3, False))
+    else:
+        lookup = step["rd_value"]
+    v[I["LookupOutput"]] = lookup
+    v[I["PC"]], v[I["UnexpandedPC"]] = step["pc"], step["unexpanded_pc"]
+    if next_step is not None and not next_step["is_noop"]:  # :1150-1172 (a NoOp successor reads as zero)
+        v[I["NextPC"]], v[I["NextUnexpandedPC"]] = next_step["pc"], next_step["unexpanded_pc"]
+    # setFlagsFromInstruction (:1288-1398): circuit flags and the two lookup operands
+    add = sub = mul = wl = jump = 0
+    lo_l, lo_r = left, right  # "NOT Add + Sub + Mul": the operands pass through
+    if op == 0x33:
+        if f7 == 0x01:
+            if f3 == 0:
+                mul, lo_l, lo_r = 1, 0, left * right % P
+        elif f7 == 0x20 and f3 == 0:
+            sub, lo_l, lo_r = 1, 0, (left - right + (1 << 64)) % P
+        else:
+            add, lo_l, lo_r = 1, 0, (left + right) % P
+        wl = 1
+    elif op == 0x13:
+        add, wl, lo_l, lo_r = 1, 1, 0, (left + right) % P
+    elif op in (0x6F, 0x67):
+        jump, add, lo_l, lo_r = 1, 1, 0, (left + right) % P
+    elif op in (0x37, 0x17):
+        add, wl, lo_l, lo_r = 1, 1, 0, (left + right) % P
+    v[I["FlagAddOperands"]], v[I["FlagSubtractOperands"]], v[I["FlagMultiplyOperands"]] = add, sub, mul
+    v[I["FlagWriteLookupOutputToRD"]], v[I["FlagJump"]] = wl, jump
+    v[I["LeftLookupOperand"]], v[I["RightLookupOperand"]] = lo_l, lo_r
+    v[I["ShouldJump"]] = jump * (0 if _is_noop_instruction(next_step) else 1)  # :1181-1185
+    nz = int(rd != 0)
+    v[I["WriteLookupOutputToRD"]], v[I["WritePCtoRD"]] = nz * wl, nz * jump  # :1199-1203
+    v[I["ShouldBranch"]] = lookup * int(op == 0x63) % P
+    v[I["FlagIsRdNotZero"]], v[I["FlagBranch"]] = nz, int(op == 0x63)
+    return [x % P for x in v]
+
+
+def r1cs_witness_from_trace(steps):
+    """R1CSWitnessGenerator.generateWitness (:1469-1494) -> (n, 43, 4): a NoOp padding cycle is createNoopWitness (:1418-1438: only
+    DoNotUpdateUnexpandedPC and IsNoop set), a real cycle fromTraceStep(step, the step after it)"""
+    rows = []
+    for i, st in enumerate(steps):
+        if st["is_noop"]:
+            row = [0] * NUM_R1CS_INPUTS
+            row[_R1["FlagDoNotUpdateUnexpandedPC"]] = row[_R1["FlagIsNoop"]] = 1
+        else:
+            row = r1cs_cycle_inputs(st, steps[i + 1] if i + 1 < len(steps) else None)
+        rows.append(row)
+    return np.stack([np.stack([fr_from_int(x) for x in row]) for row in rows])

@@ -5,6 +5,7 @@ StreamingOuterProver (Spartan outer sumcheck, 256 cycles) — into tests/golden/
 Source: /root/reference/logs/zolt.log:1572-2091, printed by src/zkvm/proof_converter.zig:380-540, src/zkvm/spartan/streaming_outer.zig
 and src/poly/split_eq.zig:429-431:
   tau[0..10)             the ten 125-bit challenges as stored limbs [0, 0, lo, hi] (raw Montgomery form, as the C ABI takes them)
+  uni_poly_coeffs[0..2)  the two coefficients of the UniSkip polynomial the log prints (canonical, big-endian)
   r0, w[0..10)           the first-round challenge and the Lagrange basis values L_i(r0) over {-4..5} (canonical, big-endian)
   lagrange_tau_r0        L(r0, tau_high) as raw limbs — the split-eq structure's initial scalar
   uni_skip_claim, batching_coeff (big-endian), the initial batched claim (little-endian)
@@ -33,12 +34,15 @@ def limbs(line):
 
 def main():
     lines = open(LOG, errors="replace").read().splitlines()
-    out = {"source": "logs/zolt.log:1572-2091", "tau_limbs": [], "w_be": [], "rounds": []}
+    out = {"source": "logs/zolt.log:1572-2091", "tau_limbs": [], "uni_poly_coeffs_be": [], "w_be": [], "rounds": []}
     cur = None
     for i, l in enumerate(lines[:2100]):
         if re.match(r"\[ZOLT PROVE\] tau\[\d+\] = challengeScalar", l):
             j = next(k for k in range(i, i + 10) if "result_limbs" in lines[k])
             out["tau_limbs"].append(limbs(lines[j]))
+        m = re.match(r"\[ZOLT UNISKIP_PROOF\] uni_poly_coeffs\[(\d+)\] = ", l)
+        if m and len(out["uni_poly_coeffs_be"]) == int(m.group(1)):
+            out["uni_poly_coeffs_be"].append(braces(l)[0])
         if l.startswith("[STREAMING_OUTER] lagrange_tau_r0 (limbs)"):
             out["lagrange_tau_r0_limbs"] = limbs(l)
         if l.startswith("[ZOLT] STAGE1: uni_skip_claim@SpartanOuter"):
@@ -66,7 +70,7 @@ def main():
             out["final_eq_factor_le"] = braces(l)[0]
         if l.startswith("[ZOLT] STAGE1_FINAL: prover eq_factor limbs = "):
             out["final_eq_factor_limbs"] = limbs(l)
-    assert len(out["tau_limbs"]) == 10 and len(out["w_be"]) == 10
+    assert len(out["tau_limbs"]) == 10 and len(out["w_be"]) == 10 and len(out["uni_poly_coeffs_be"]) == 2
     assert len(out["rounds"]) == 9 and all(len(r) == 8 for r in out["rounds"]), out["rounds"]
     assert [r["index"] for r in out["rounds"]] == list(range(9, 0, -1))
     with open(OUT, "w") as f:

@@ -150,7 +150,7 @@ def test_cpp_stage4_registers_mirror(tmp_path, golden_dir):
 @pytest.mark.gpu
 def test_cpp_streaming_outer_mirror(tmp_path, golden_dir):
     """zolt::StreamingOuterProver (compiled host code: constraint table, Lagrange weights, zg_fr_rows_affine_dev + a product session)
-    against the restatement of src/zkvm/spartan/streaming_outer.zig's remaining rounds on random cycle inputs: (t'(0), t'(inf)), the four
+    against the restatement of src/zkvm/spartan/streaming_outer.zig on random cycle inputs and on the captured Stage-1 run: (t'(0), t'(inf)), the four
     evaluations of every round, and the final Az, Bz, claim and split-eq scalar, bit for bit."""
     import numpy as np
     from oracle import binding as ob
@@ -158,15 +158,27 @@ def test_cpp_streaming_outer_mirror(tmp_path, golden_dir):
     from tests.test_transcript_host import outer_true_claim, random_cycle_witnesses
     exe = os.path.join(ROOT, "tests", "cpp", "test_host_mirror")
     subprocess.check_call(["make", "-C", os.path.dirname(exe), "test_host_mirror"])
-    for k, n in enumerate((1, 37, 512)):
-        w = random_cycle_witnesses(300 + n, n)
-        nv = max(n - 1, 0).bit_length()
-        r = ob.f_to_mont(ob.FR, U.random_raw256(400 + n, 3 * nv + 8))
-        tau, r0, scale, chals = r[:nv + 2], r[nv + 2], r[nv + 3], r[nv + 4:nv + 4 + nv + 1]
+    import json
+    from tests.test_transcript_host import stage1_witness_of_the_captured_run
+    fx = json.load(open(os.path.join(golden_dir, "stage1_outer_rounds.json")))
+    le = lambda h: int.from_bytes(bytes.fromhex(h), "little")
+    for k, n in enumerate((1, 37, 512, 256)):
+        if k == 3:  # the reference's captured Stage-1 run: witnesses regenerated from the ELF, its tau, r0, kernel and challenges
+            w = stage1_witness_of_the_captured_run(golden_dir)
+            nv = 8
+            tau = np.array(fx["tau_limbs"], dtype=np.uint64)
+            r0 = ob.fr_from_int(int(fx["r0_be"], 16))
+            scale = ob.lagrange_kernel(r0, tau[-1])
+            chals = np.stack([ob.fr_from_int(le(r["challenge_le"])) for r in fx["rounds"]])
+        else:
+            w = random_cycle_witnesses(300 + n, n)
+            nv = max(n - 1, 0).bit_length()
+            r = ob.f_to_mont(ob.FR, U.random_raw256(400 + n, 3 * nv + 8))
+            tau, r0, scale, chals = r[:nv + 2], r[nv + 2], r[nv + 3], r[nv + 4:nv + 4 + nv + 1]
         o = ob.StreamingOuterProver(w, tau, scale)
         o.bindFirstRoundChallenge(r0, ob.fr_from_int(0))
         o.materializeLinearPhasePolynomials()
-        o.current_claim = outer_true_claim(o)
+        o.current_claim = ob.fr_from_int(int(fx["uni_skip_claim_be"], 16)) if k == 3 else outer_true_claim(o)
         path = str(tmp_path / f"outer_{k}.txt")
         with open(path, "w") as f:
             f.write(f"{n} {nv}\n{_hexfr(scale)}\n{_hexfr(r0)}\n{_hexfr(o.current_claim)}\n")
@@ -189,6 +201,10 @@ def test_cpp_streaming_outer_mirror(tmp_path, golden_dir):
             o.bindRemainingRoundChallenge(chals[rd])
         assert np.array_equal(fin[0], o.az[0]) and np.array_equal(fin[1], o.bz[0]) and np.array_equal(fin[2], o.current_claim)
         assert np.array_equal(fin[3], o.split_eq.current_scalar)
+        if k == 3:  # what the reference printed: q(0) of every round, the claim chain, the final scalar (the first-round polynomial of the
+            # compiled mirror is built with the kernel scaling here, so only the rounds are held against the log)
+            assert [ob.fr_to_int(t[0]) for t in ts] == [int(r["q0_be"], 16) for r in fx["rounds"]]
+            assert ob.fr_to_int(fin[3]) == le(fx["final_eq_factor_le"])
 
 
 @pytest.mark.gpu

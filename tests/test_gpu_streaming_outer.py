@@ -172,3 +172,24 @@ def test_uniskip_constants(api):
     assert api.UNISKIP_TARGETS == ob.UNISKIP_TARGETS == [-5, 6, -6, 7, -7, 8, -8, 9, -9] and api.COEFFS_PER_J == ob.COEFFS_PER_J
     for j, t in enumerate(api.UNISKIP_TARGETS):  # the shift coefficients ARE the Lagrange basis of {-4..5} at the target
         assert [c % ob._R_P for c in api.COEFFS_PER_J[j]] == [ob.fr_to_int(x) for x in api.lagrangeEvals(api.fr_from_int(t % ob._R_P), 10)]
+
+
+def test_stage1_of_the_captured_run_on_the_device(api, golden_dir):
+    """Stage 1 of the reference's captured run through the DEVICE path, from the witnesses regenerated out of the ELF: the 36 R1CS input
+    claims (zg_fr_rows_mle over the cycle-major matrix), the UniSkip first-round polynomial (zg_fr_rows_affine_prodsum_dev) and the nine
+    rounds (zg_fr_rows_affine_dev + the product session) — every printed value, full width."""
+    from zolt_amd import lib
+    from tests.test_transcript_host import (check_r1cs_claims_of_the_captured_run, check_stage1_outer_against_the_captured_run,
+                                            stage1_witness_of_the_captured_run)
+    w = stage1_witness_of_the_captured_run(golden_dir)
+    cl = json.load(open(os.path.join(golden_dir, "stage1_r1cs_claims.json")))
+    check_r1cs_claims_of_the_captured_run(lambda r: lib.fr_rows_mle(w, r), cl)
+    fx = json.load(open(os.path.join(golden_dir, "stage1_outer_rounds.json")))
+    provers = []
+
+    def make(tau, scale):
+        provers.append(api.StreamingOuterProver(w, tau, scale))
+        return provers[-1]
+    check_stage1_outer_against_the_captured_run(make, fx, api.fr_from_int, api.fr_to_int, api.lagrangeKernel)
+    for p in provers:
+        p.deinit()

@@ -694,3 +694,82 @@ def test_original_stage4_prover_shares_the_pinned_input_claim(golden_dir):
         claim = ob.raf_update_claim(ev, chals[k])
         p.bindChallenge(k, chals[k])
     assert np.array_equal(p.finalCheck()[2], claim)
+
+
+def stage1_witness_of_the_captured_run(golden_dir):
+    """the 256 x 43 R1CS inputs of the captured run: the fibonacci trace regenerated from the ELF (tests/util.fibonacci_full_trace) through
+    the restatement of R1CSCycleInputs.fromTraceStep / createNoopWitness (oracle/binding.py)"""
+    import os
+    elf = open(os.path.join(golden_dir, "fibonacci.elf"), "rb").read()
+    return ob.r1cs_witness_from_trace(U.fibonacci_full_trace(elf))
+
+
+def check_r1cs_claims_of_the_captured_run(claims_of, cl):
+    """the 36 R1CS input claims the reference appended after Stage 1 (tests/golden/stage1_r1cs_claims.json: 13 in full, 23 by their first
+    and last eight bytes) against claims_of(r_cycle) -> (>= 36, 4): a witness / evaluator error shows up column by column"""
+    r = np.stack([ob.fr_from_int(int(h, 16)) for h in cl["r_cycle_be"]])
+    got = claims_of(r)
+    for i, c in enumerate(cl["claims"]):
+        b = ob.fr_to_int(got[i]).to_bytes(32, "big").hex()
+        assert b[:16] == c["first8_be"] and b[-16:] == c["last8_be"], (i, ob.R1CS_INPUT_NAMES[i])
+        assert c.get("full_be", b) == b, (i, ob.R1CS_INPUT_NAMES[i])
+
+
+def check_stage1_outer_against_the_captured_run(make_prover, fx, fr_from_int, fr_to_int, lagrange_kernel):
+    """Stage 1 of the captured run END TO END from the witnesses: make_prover(tau, scaling) -> a StreamingOuterProver over the regenerated
+    witness matrix. The UniSkip polynomial (coefficients 0 and 1 as printed, and all 28 through uni_skip_claim = s1(r0)), then the nine
+    remaining rounds: t'(0) = q(0), the claim before every round, s(0..3) through the batched compressed coefficients c0, c2, c3, and
+    the split-eq scalar at the end — every value full width (tests/golden/stage1_outer_rounds.json)."""
+    P = ob._R_P
+    be, le = (lambda h: int(h, 16)), (lambda h: int.from_bytes(bytes.fromhex(h), "little"))
+    tau = np.array(fx["tau_limbs"], dtype=np.uint64)
+    r0 = fr_from_int(be(fx["r0_be"]))
+    first = make_prover(tau, None)  # the UniSkip polynomial is built before r0 exists: no scaling (logs/zolt.log:1658)
+    co = [fr_to_int(x) for x in first.computeFirstRoundPoly()]
+    assert len(co) == 28 and [co[0], co[1]] == [be(h) for h in fx["uni_poly_coeffs_be"]]
+    x = fr_to_int(r0)
+    claim = sum(c * pow(x, k, P) for k, c in enumerate(co)) % P
+    assert claim == be(fx["uni_skip_claim_be"])
+    p = make_prover(tau, lagrange_kernel(r0, tau[-1]))
+    p.bindFirstRoundChallenge(r0, fr_from_int(claim))
+    b = be(fx["batching_coeff_be"])
+    for k, r in enumerate(fx["rounds"]):
+        assert fr_to_int(p.current_claim) == be(r["previous_claim_be"]), k
+        ev = [fr_to_int(v) for v in p.computeRemainingRoundPoly()]
+        assert fr_to_int(p.last_t[0]) == be(r["q0_be"]), k
+        # compressed coefficients of the batched polynomial (:493-504): c0 = s(0), c2, c3 from the four evaluations
+        c3 = (-ev[0] + 3 * ev[1] - 3 * ev[2] + ev[3]) * pow(6, P - 2, P) % P
+        c2 = (2 * ev[0] - 5 * ev[1] + 4 * ev[2] - ev[3]) * pow(2, P - 2, P) % P
+        assert [ev[0] * b % P, c2 * b % P, c3 * b % P] == [le(r["c0_le"]), le(r["c2_le"]), le(r["c3_le"])], k
+        ch = fr_from_int(le(r["challenge_le"]))
+        p.updateClaim(np.stack([fr_from_int(v) for v in ev]), ch)
+        p.bindRemainingRoundChallenge(ch)
+    assert fr_to_int(p.split_eq.current_scalar) == le(fx["final_eq_factor_le"])
+    return first, p
+
+
+def test_stage1_of_the_captured_run_from_the_elf(golden_dir):
+    """The whole of Stage 1 reproduced from the committed ELF: trace (54 cycles + NoOp padding) -> R1CS inputs (fromTraceStep restated) ->
+    the 36 input claims at r_cycle, the UniSkip first-round polynomial, the nine rounds of the streaming outer prover. Everything the
+    reference printed about them matches, full width."""
+    import json
+    import os
+    w = stage1_witness_of_the_captured_run(golden_dir)
+    assert w.shape == (256, ob.NUM_R1CS_INPUTS, 4)
+    cl = json.load(open(os.path.join(golden_dir, "stage1_r1cs_claims.json")))
+    le = lambda h: int.from_bytes(bytes.fromhex(h), "little")
+    for key, h in cl["witness_samples_le"].items():
+        cyc, name = key.split(".")
+        assert ob.fr_to_int(w[int(cyc)][ob.R1CS_INPUT_NAMES.index(name)]) == le(h), key
+
+    def claims_of(r):
+        eq = ob.fr_eq_table(r)
+        assert [ob.fr_to_int(eq[i]) for i in range(3)] == [int(h, 16) for h in cl["eq_evals_be"]]
+        return [ob._fsum(ob._fmul(w[:, i], eq)) for i in range(36)]
+    check_r1cs_claims_of_the_captured_run(claims_of, cl)
+    fx = json.load(open(os.path.join(golden_dir, "stage1_outer_rounds.json")))
+    check_stage1_outer_against_the_captured_run(lambda tau, scale: ob.StreamingOuterProver(w, tau, scale), fx, ob.fr_from_int, ob.fr_to_int, ob.lagrange_kernel)
+    # and the witness satisfies the 19 constraints in every cycle (Az * Bz = 0): what makes t1 vanish on the base window
+    for cond, left, right in ob.UNIFORM_CONSTRAINTS:
+        az, bz = ob._lc_eval(cond, w), ob._fsub(ob._lc_eval(left, w), ob._lc_eval(right, w))
+        assert not ob._fmul(az, bz).any()

@@ -120,7 +120,7 @@ def fibonacci_rd_values(elf_bytes, steps=54, records=None):
             regs[rd] = rv
         vals.append(rv)
         if records is not None:
-            records.append((w, rv, a, b))
+            records.append((w, rv, a, b, pc))
         pc = npc
     assert pc == 0x80000010 and regs[10] == 55  # back in the `j .` loop with fib = 55 in a0
     return vals
@@ -131,7 +131,19 @@ def fibonacci_trace_steps(elf_bytes, steps=54, padded=256):
     (instruction word, rd_value, is_noop) per cycle — the 54 executed instructions, then no-op padding up to the trace length."""
     recs = []
     fibonacci_rd_values(elf_bytes, steps, recs)
-    return [(w, rv, False) for w, rv, _, _ in recs] + [(0, 0, True)] * (padded - len(recs))
+    return [(w, rv, False) for w, rv, _, _, _ in recs] + [(0, 0, True)] * (padded - len(recs))
+
+
+def fibonacci_full_trace(elf_bytes, steps=54, padded=256):
+    """the same run as tracer.TraceStep records (src/tracer/mod.zig:14-45, 300-318): what R1CSCycleInputs.fromTraceStep reads of a step —
+    instruction, pc (= unexpanded_pc: no virtual sequences), rs1_value / rs2_value (the registers named by the instruction's fields, read
+    before it executes), rd_value, no memory access, not compressed — then NoOp padding (padWithNoop)."""
+    recs = []
+    fibonacci_rd_values(elf_bytes, steps, recs)
+    out = [{"instruction": w, "pc": pc, "unexpanded_pc": pc, "rs1_value": a, "rs2_value": b, "rd_value": rv, "memory_value": None, "is_compressed": False,
+            "is_noop": False} for w, rv, a, b, pc in recs]
+    noop = {"instruction": 0, "pc": 0, "unexpanded_pc": 0, "rs1_value": 0, "rs2_value": 0, "rd_value": 0, "memory_value": None, "is_compressed": False, "is_noop": True}
+    return out + [dict(noop) for _ in range(padded - len(out))]
 
 
 def output_check_tables_of_the_captured_run(oc, elf_bytes, fr_from_int, eq_table):
