@@ -237,14 +237,17 @@ ZG_API int zg_fr_rows_mle_dev(const uint64_t *d_rows, size_t n_rows, size_t k, c
 /* StreamingOuterProver.materializeLinearPhasePolynomials (src/zkvm/spartan/streaming_outer.zig:258-372): per cycle, Az and Bz of the two
  * constraint groups are Lagrange-weighted sums of the 19 uniform constraints' linear combinations (src/zkvm/r1cs/constraints.zig:248-531)
  * — AFFINE maps of the cycle's R1CS inputs. Generic form, over the same cycle-major matrix zg_fr_rows_mle reads (k <= 64 columns):
- *     table t, element i * g + j  =  C[t*g + j][k] + sum_{col < k} C[t*g + j][col] * rows[i*k + col]      i < n_rows
+ *     table t, element i * g + j  =  C[t*g + j][k] + sum_{col < k} C[t*g + j][col] * rows[i*stride + col] i < n_rows
  *                                 =  0                                                                     n_rows <= i < n_pad
  * coeffs: (ntab * g) rows of k + 1 elements (the last one the constant), host memory; ntab * g <= 16. For the outer prover ntab = 2
- * (Az, Bz), g = 2 (the group selector is the lowest variable), coefficient rows (az0, az1, bz0, bz1), n_pad = the padded trace length. */
-ZG_API int zg_fr_rows_affine(const uint64_t *rows, size_t n_rows, size_t k, const uint64_t *coeffs, size_t ntab, size_t g, size_t n_pad,
+ * (Az, Bz), g = 2 (the group selector is the lowest variable), coefficient rows (az0, az1, bz0, bz1), n_pad = the padded trace length.
+ * stride: elements between the starts of consecutive rows, 0 = k. With stride < k a map is a SLIDING WINDOW over the matrix — row i's
+ * columns stride .. k-1 are the first columns of the rows after it, the matrix must hold (n_rows - 1) * stride + k elements — which is how
+ * ProductVirtualRemainderProver's fused right factor reads the NEXT cycle's IsNoop flag (src/zkvm/spartan/product_remainder.zig:436-476). */
+ZG_API int zg_fr_rows_affine(const uint64_t *rows, size_t n_rows, size_t k, size_t stride, const uint64_t *coeffs, size_t ntab, size_t g, size_t n_pad,
                       uint64_t *const *tables /* ntab host pointers, n_pad * g elements each */);
-ZG_API int zg_fr_rows_affine_dev(const uint64_t *d_rows, size_t n_rows, size_t k, const uint64_t *coeffs_host, size_t ntab, size_t g, size_t n_pad,
-                          uint64_t *const *d_tables /* host array of ntab DEVICE pointers */, void *stream);
+ZG_API int zg_fr_rows_affine_dev(const uint64_t *d_rows, size_t n_rows, size_t k, size_t stride, const uint64_t *coeffs_host, size_t ntab, size_t g,
+                          size_t n_pad, uint64_t *const *d_tables /* host array of ntab DEVICE pointers */, void *stream);
 /* StreamingOuterProver.computeFirstRoundPoly's extended evaluations (src/zkvm/spartan/streaming_outer.zig:523-597, evaluateAzBzAtTargetY
  * :599-671): for each UniSkip target Y_j and constraint group, Az(x, Y_j) and Bz(x, Y_j) are Lagrange extrapolations (COEFFS_PER_J,
  * src/zkvm/r1cs/univariate_skip.zig:469-476) of the group's constraint values — affine maps of the cycle's inputs — and
@@ -252,7 +255,7 @@ ZG_API int zg_fr_rows_affine_dev(const uint64_t *d_rows, size_t n_rows, size_t k
  *     out[p] = sum_{i < n_rows} W[i * g + p % g] * A_p(rows[i]) * B_p(rows[i]),     p < npairs <= 32,
  * A_p / B_p = coefficient rows 2p / 2p + 1 (k + 1 elements each, the constant last; host memory); W: DEVICE table of n_rows * g weights
  * (for the outer prover g = 2 and W = zg_fr_eq_table_dev(tau_low): index = cycle * 2 + group; pairs ordered (target, group)). */
-ZG_API int zg_fr_rows_affine_prodsum_dev(const uint64_t *d_rows, size_t n_rows, size_t k, const uint64_t *coeffs_host, size_t npairs,
+ZG_API int zg_fr_rows_affine_prodsum_dev(const uint64_t *d_rows, size_t n_rows, size_t k, size_t stride, const uint64_t *coeffs_host, size_t npairs,
                                   const uint64_t *d_weights, size_t g, uint64_t *out /* host, npairs * 4 */, void *stream);
 /* DensePolynomial.bindLow, in place: t[i] = t[2i] + r*(t[2i+1]-t[2i]), len -> len/2 (src/poly/mod.zig:160-175) */
 ZG_API int zg_fr_bind_low(uint64_t *table, size_t len, const uint64_t r[4]);

@@ -1955,3 +1955,81 @@ def r1cs_witness_from_trace(steps):
             row = r1cs_cycle_inputs(st, steps[i + 1] if i + 1 < len(steps) else None)
         rows.append(row)
     return np.stack([np.stack([fr_from_int(x) for x in row]) for row in rows])
+
+
+# ---------------------------------------------------------------- Stage 2: product virtualisation (UniSkip first round and the fused tables)
+PRODUCT_VIRTUAL_TARGETS = uniskip_targets(5, 4)  # -3, 3, -4, 4 (univariate_skip.zig:56-59)
+PRODUCT_VIRTUAL_COEFFS_PER_J = [shift_coeffs(5, t + 2) for t in PRODUCT_VIRTUAL_TARGETS]  # :78-84
+
+
+def product_factors(w):
+    """extractProductInputs (src/zkvm/spartan/product_remainder.zig:436-476) over all cycles: (n, 43, 4) -> eight (n, 4) columns —
+    LeftInstructionInput, RightInstructionInput, IsRdNotZero, WriteLookupOutputToRDFlag, JumpFlag, LookupOutput, BranchFlag, NextIsNoop
+    (the NEXT cycle's IsNoop flag; the last cycle reads 1)"""
+    w = _c(w)
+    n = w.shape[0]
+    nxt = np.concatenate([w[1:, _R1["FlagIsNoop"]], fr_from_int(1).reshape(1, 4)]) if n else np.zeros((0, 4), dtype=np.uint64)
+    return [w[:, _R1["LeftInstructionInput"]], w[:, _R1["RightInstructionInput"]], w[:, _R1["FlagIsRdNotZero"]], w[:, _R1["FlagWriteLookupOutputToRD"]],
+            w[:, _R1["FlagJump"]], w[:, _R1["LookupOutput"]], w[:, _R1["FlagBranch"]], nxt]
+
+
+def product_fused(f, weights):
+    """fusedLeft / fusedRight (product_remainder.zig:113-134; computeProductVirtualExtendedEvals, univariate_skip.zig:648-665) under five
+    weights (field elements): left = w0 LeftInput + (w1 + w2) IsRdNotZero + w3 LookupOutput + w4 Jump; right = w0 RightInput + w1 WLFlag +
+    w2 Jump + w3 Branch + w4 (1 - NextIsNoop)"""
+    one = fr_from_int(1).reshape(1, 4)
+    wt = [_c(x).reshape(1, 4) for x in weights]
+    left = _fadd(_fadd(_fadd(_fadd(_fmul(f[0], wt[0]), _fmul(f[2], wt[1])), _fmul(f[2], wt[2])), _fmul(f[5], wt[3])), _fmul(f[4], wt[4]))
+    right = _fadd(_fadd(_fadd(_fadd(_fmul(f[1], wt[0]), _fmul(f[3], wt[1])), _fmul(f[4], wt[2])), _fmul(f[6], wt[3])), _fmul(_fsub(one, f[7]), wt[4]))
+    return left, right
+
+
+def product_virtual_extended_evals(w, tau):
+    """computeProductVirtualExtendedEvals (univariate_skip.zig:607-678): t1 at -3, 3, -4, 4 = sum_x eq(tau[0..log n), x) fused_left fused_right"""
+    w = _c(w)
+    n = w.shape[0]
+    log_n = max(n - 1, 0).bit_length()
+    eq = fr_eq_table(_c(tau)[:log_n])[:n]
+    f = product_factors(w)
+    out = []
+    for coeffs in PRODUCT_VIRTUAL_COEFFS_PER_J:
+        left, right = product_fused(f, [fr_from_int(c % _R_P) for c in coeffs])
+        out.append(_fsum(_fmul(_fmul(left, right), eq)))
+    return np.stack(out)
+
+
+def build_uniskip_first_round_poly(domain_size, degree, base_evals, extended_evals, tau_high):
+    """buildUniskipFirstRoundPoly (univariate_skip.zig:486-546): t1 from its values on the base window (given, or zero) and at the
+    targets, times the Lagrange kernel L(tau_high, .) over the base window -> 3 * degree + 1 coefficients"""
+    P = _R_P
+    targets = uniskip_targets(domain_size, degree)
+    t1 = [0] * (2 * degree + 1)
+    base_left = -((domain_size - 1) // 2)
+    if base_evals is not None:
+        for i, v in enumerate(base_evals):
+            t1[base_left + i + degree] = fr_to_int(v)
+    for z, v in zip(targets, extended_evals):
+        t1[z + degree] = fr_to_int(v)
+    t1c = _interpolate_int_domain(t1, -degree)
+    lagc = _interpolate_int_domain([fr_to_int(x) for x in lagrange_evals_symmetric(tau_high, domain_size)], base_left)
+    s1 = [0] * (3 * degree + 1)
+    for i, a in enumerate(lagc):
+        for j, b in enumerate(t1c):
+            if i + j < len(s1):
+                s1[i + j] = (s1[i + j] + a * b) % P
+    return np.stack([fr_from_int(v) for v in s1])
+
+
+def product_remainder_prover_from_witness(w, r0, tau, uni_skip_claim):
+    """ProductVirtualRemainderProver.init (product_remainder.zig:166-243): Lagrange weights at r0 over {-2..2}, the fused left / right tables
+    (zero past the trace), the split-eq structure over tau_low scaled by L(tau_high, r0)"""
+    w = _c(w)
+    n = w.shape[0]
+    padded = 1
+    while padded < n:
+        padded *= 2
+    weights = lagrange_evals_symmetric(r0, 5)
+    left, right = product_fused(product_factors(w), weights)
+    z = np.zeros((padded - n, 4), dtype=np.uint64)
+    tau = _c(tau)
+    return ProductRemainderProver(np.concatenate([left, z]), np.concatenate([right, z]), tau[:-1], lagrange_kernel(r0, tau[-1], 5), uni_skip_claim)

@@ -769,3 +769,39 @@ def test_round_expr_pair_sum_terms(env, mask):
         with pytest.raises(RuntimeError):
             s.round_expr(bad)  # a pair sum needs exactly four tables
     s.close()
+
+
+def test_stage2_product_virtualisation_of_the_captured_run_on_the_device(golden_dir):
+    """the product-virtualisation instance of the reference's captured Stage 2 on the DEVICE, from the witnesses regenerated out of the ELF:
+    t1 at the four targets (a product-sum launch over two-cycle windows), the fused tables built on the device (sliding-window affine maps)
+    into the prover's session, eight Gruen rounds — the printed extended evaluations, 13 coefficients, input and final claim, full width"""
+    from zolt_amd import api, lib
+    from tests.test_transcript_host import check_stage2_product_virtual_against_the_captured_run
+    lib.init(0)
+    p = check_stage2_product_virtual_against_the_captured_run(api.productVirtualExtendedEvals, api.buildUniskipFirstRoundPoly,
+                                                              api.productVirtualRemainderProverFromWitnesses, golden_dir, api.fr_from_int, api.fr_to_int)
+    p.deinit()
+
+
+@pytest.mark.parametrize("n", [1, 2, 77, 1024])
+def test_product_virtual_from_witnesses_against_the_restatement(n):
+    """random witnesses (not a satisfying assignment): extended evaluations and the fused tables / rounds, device against restatement"""
+    from oracle import binding as ob
+    from zolt_amd import api, lib
+    from tests.test_transcript_host import random_cycle_witnesses
+    lib.init(0)
+    w = random_cycle_witnesses(900 + n, n)
+    nv = max(n - 1, 0).bit_length()
+    r = ob.f_to_mont(ob.FR, U.random_raw256(990 + n, 2 * nv + 4))
+    tau, r0, claim, chals = r[:nv + 1], r[nv + 1], r[nv + 2], r[nv + 3:]
+    assert np.array_equal(api.productVirtualExtendedEvals(w, tau), ob.product_virtual_extended_evals(w, tau))
+    g, o = api.productVirtualRemainderProverFromWitnesses(w, r0, tau, claim), ob.product_remainder_prover_from_witness(w, r0, tau, claim)
+    assert np.array_equal(g._s.read(0), o.left) and np.array_equal(g._s.read(1), o.right)
+    for k in range(nv):
+        eg, eo = g.roundEvals(), o.roundEvals()
+        assert np.array_equal(eg, eo), k
+        for p in (g, o):
+            p.updateClaim(eo, chals[k])
+            p.bindChallenge(chals[k])
+    assert np.array_equal(g.getFinalClaim(), o.getFinalClaim())
+    g.deinit()

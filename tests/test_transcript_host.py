@@ -773,3 +773,51 @@ def test_stage1_of_the_captured_run_from_the_elf(golden_dir):
     for cond, left, right in ob.UNIFORM_CONSTRAINTS:
         az, bz = ob._lc_eval(cond, w), ob._fsub(ob._lc_eval(left, w), ob._lc_eval(right, w))
         assert not ob._fmul(az, bz).any()
+
+
+def check_stage2_product_virtual_against_the_captured_run(extended_evals_of, first_round_poly, make_prover, golden_dir, fr_from_int, fr_to_int):
+    """Stage 2's product-virtualisation instance of the captured run END TO END from the regenerated witnesses
+    (tests/golden/stage2_uniskip.json, stage2_batched_rounds.json): t1 at the four targets, the 13 coefficients of the UniSkip polynomial,
+    s1(r0) = the instance's input claim, and — through its eight rounds under the batch's challenges — its final claim, all full width."""
+    import json
+    import os
+    P = ob._R_P
+    be, le = (lambda h: int(h, 16)), (lambda h: int.from_bytes(bytes.fromhex(h), "little"))
+    fx = json.load(open(os.path.join(golden_dir, "stage2_uniskip.json")))
+    s1 = json.load(open(os.path.join(golden_dir, "stage1_outer_rounds.json")))
+    s2 = json.load(open(os.path.join(golden_dir, "stage2_batched_rounds.json")))
+    w = stage1_witness_of_the_captured_run(golden_dir)
+    r_cycle = [fr_from_int(le(r["challenge_le"])) for r in s1["rounds"]][1:]  # Stage 1's challenges without r_stream (:1117-1121)
+    tau = np.stack(r_cycle[::-1] + [fr_from_int(be(fx["tau_high_be"]))])  # [r_cycle reversed, tau_high] (:1112-1137)
+    ext = extended_evals_of(w, tau)
+    assert [fr_to_int(x) for x in ext] == [be(h) for h in fx["extended_evals_be"]]
+    base = [fr_from_int(be(h)) for h in fx["base_evals_be"]]
+    co = [fr_to_int(x) for x in first_round_poly(5, 4, base, ext, tau[-1])]
+    assert co == [le(h) for h in fx["coeffs_le"]]
+    x = be(fx["r0_be"])
+    claim = sum(c * pow(x, k, P) for k, c in enumerate(co)) % P
+    assert claim == be(fx["uni_skip_claim_be"]) == le(s2["input_claims"][0])
+    p = make_prover(w, fr_from_int(x), tau, fr_from_int(claim))
+    first = s2["product_remainder"]["first_batch_round"]
+    for k in range(8):
+        ev = p.roundEvals()
+        ch = fr_from_int(le(s2["rounds"][first + k]["challenge"]))
+        p.updateClaim(ev, ch)
+        p.bindChallenge(ch)
+    assert fr_to_int(p.current_claim) == le(s2["instance_final_claims"][0])
+    assert fr_to_int(p.getFinalClaim()) * fr_to_int(p.split_eq.current_scalar) % P == fr_to_int(p.current_claim)
+    return p
+
+
+def test_stage2_product_virtualisation_of_the_captured_run_from_the_elf(golden_dir):
+    import json
+    import os
+    check_stage2_product_virtual_against_the_captured_run(ob.product_virtual_extended_evals, ob.build_uniskip_first_round_poly,
+                                                          ob.product_remainder_prover_from_witness, golden_dir, ob.fr_from_int, ob.fr_to_int)
+    # the five base evaluations are Stage 1's claims of the product columns
+    fx = json.load(open(os.path.join(golden_dir, "stage2_uniskip.json")))
+    cl = json.load(open(os.path.join(golden_dir, "stage1_r1cs_claims.json")))
+    w = stage1_witness_of_the_captured_run(golden_dir)
+    eq = ob.fr_eq_table(np.stack([ob.fr_from_int(int(h, 16)) for h in cl["r_cycle_be"]]))
+    for name, h in zip(("Product", "WriteLookupOutputToRD", "WritePCtoRD", "ShouldBranch", "ShouldJump"), fx["base_evals_be"]):
+        assert ob.fr_to_int(ob._fsum(ob._fmul(w[:, ob.R1CS_INPUT_NAMES.index(name)], eq))) == int(h, 16), name

@@ -1425,6 +1425,101 @@ class ProductVirtualRemainderProver:
         self.split_eq.deinit()
 
 
+PRODUCT_VIRTUAL_TARGETS = None  # filled below (uniskipTargets is defined later in this module)
+PRODUCT_VIRTUAL_COEFFS_PER_J = None
+
+
+def _product_fused_rows(weights):
+    """fusedLeft / fusedRight (src/zkvm/spartan/product_remainder.zig:113-134, extractProductInputs :436-476) as two affine maps of a WINDOW of
+    two consecutive cycles' inputs (86 columns + the constant): left = w0 LeftInput + (w1 + w2) IsRdNotZero + w3 LookupOutput + w4 Jump,
+    right = w0 RightInput + w1 WLFlag + w2 Jump + w3 Branch + w4 (1 - IsNoop of the NEXT cycle). weights: five integers mod r."""
+    W = 2 * NUM_R1CS_INPUTS + 1
+    left, right = [0] * W, [0] * W
+    w0, w1, w2, w3, w4 = [int(x) % R_MOD for x in weights]
+    left[_I["LeftInstructionInput"]] = w0
+    left[_I["FlagIsRdNotZero"]] = (w1 + w2) % R_MOD
+    left[_I["LookupOutput"]] = w3
+    left[_I["FlagJump"]] = w4
+    right[_I["RightInstructionInput"]] = w0
+    right[_I["FlagWriteLookupOutputToRD"]] = w1
+    right[_I["FlagJump"]] = w2
+    right[_I["FlagBranch"]] = w3
+    right[NUM_R1CS_INPUTS + _I["FlagIsNoop"]] = (-w4) % R_MOD
+    right[W - 1] = w4
+    return left, right
+
+
+def _witnesses_with_sentinel(cycle_witnesses):
+    """the cycle-major matrix on the device with one more row after the last cycle whose IsNoop flag is set: the window of the last cycle
+    reads NextIsNoop = 1 there (product_remainder.zig:468-474)"""
+    w = np.ascontiguousarray(cycle_witnesses, dtype=np.uint64).reshape(-1, NUM_R1CS_INPUTS, 4)
+    ext = np.zeros((w.shape[0] + 1, NUM_R1CS_INPUTS, 4), dtype=np.uint64)
+    ext[:-1] = w
+    ext[-1, _I["FlagIsNoop"]] = fr_from_int(1)
+    return lib.DeviceBuffer.from_host(ext), w.shape[0]
+
+
+def productVirtualExtendedEvals(cycle_witnesses, tau):
+    """computeProductVirtualExtendedEvals (src/zkvm/r1cs/univariate_skip.zig:607-678): t1 at -3, 3, -4, 4 = sum_x eq(tau[0..log n), x) *
+    fused_left(x) * fused_right(x) — one product-sum launch over the resident witnesses (two-cycle windows)"""
+    d_rows, n = _witnesses_with_sentinel(cycle_witnesses)
+    log_n = max(n - 1, 0).bit_length()
+    tau = np.ascontiguousarray(tau, dtype=np.uint64).reshape(-1, 4)
+    rows = []
+    for coeffs in PRODUCT_VIRTUAL_COEFFS_PER_J:
+        rows.extend(_product_fused_rows(coeffs))
+    m = np.stack([np.stack([fr_from_int(v) for v in row]) for row in rows])
+    d_w = lib.DeviceBuffer((1 << log_n) * 32)
+    lib.fr_eq_table_dev(tau[:log_n], d_w.ptr)
+    out = lib.fr_rows_affine_prodsum_dev(d_rows.ptr, n, 2 * NUM_R1CS_INPUTS, m, 4, d_w.ptr, 1, stride=NUM_R1CS_INPUTS)
+    d_w.free()
+    d_rows.free()
+    return out
+
+
+def buildUniskipFirstRoundPoly(domain_size, degree, base_evals, extended_evals, tau_high):
+    """buildUniskipFirstRoundPoly (univariate_skip.zig:486-546) -> 3 * degree + 1 coefficients of s1 = L(tau_high, .) * t1 (host integers)"""
+    targets = uniskipTargets(domain_size, degree)
+    t1 = [0] * (2 * degree + 1)
+    base_left = -((domain_size - 1) // 2)
+    if base_evals is not None:
+        for i, v in enumerate(base_evals):
+            t1[base_left + i + degree] = fr_to_int(v)
+    for z, v in zip(targets, extended_evals):
+        t1[z + degree] = fr_to_int(v)
+    t1c = interpolateIntDomain(t1, -degree)
+    lagc = interpolateIntDomain([fr_to_int(x) for x in lagrangeEvals(tau_high, domain_size)], base_left)
+    s1 = [0] * (3 * degree + 1)
+    for i, a in enumerate(lagc):
+        for j, b in enumerate(t1c):
+            if i + j < len(s1):
+                s1[i + j] = (s1[i + j] + a * b) % R_MOD
+    return np.stack([fr_from_int(v) for v in s1])
+
+
+def productVirtualRemainderProverFromWitnesses(cycle_witnesses, r0, tau, uni_skip_claim):
+    """ProductVirtualRemainderProver.init (product_remainder.zig:166-243): the fused left / right tables built ON THE DEVICE from the resident
+    witnesses (two affine maps of a two-cycle window, zg_fr_rows_affine_dev) straight into the prover's product session"""
+    d_rows, n = _witnesses_with_sentinel(cycle_witnesses)
+    padded = 1
+    while padded < n:
+        padded *= 2
+    tau = np.ascontiguousarray(tau, dtype=np.uint64).reshape(-1, 4)
+    left, right = _product_fused_rows([fr_to_int(x) for x in lagrangeEvals(r0, 5)])
+    m = np.stack([np.stack([fr_from_int(v) for v in row]) for row in (left, right)])
+    d_l, d_r = lib.DeviceBuffer(padded * 32), lib.DeviceBuffer(padded * 32)
+    lib.fr_rows_affine_dev(d_rows.ptr, n, 2 * NUM_R1CS_INPUTS, m, 2, 1, padded, [d_l.ptr, d_r.ptr], stride=NUM_R1CS_INPUTS)
+    p = ProductVirtualRemainderProver.__new__(ProductVirtualRemainderProver)
+    p._s = lib.ProductSumcheckSession.open_dev([d_l.ptr, d_r.ptr], padded)
+    lib.sync()
+    for b in (d_l, d_r, d_rows):
+        b.free()
+    p.split_eq = GruenSplitEqPolynomial(tau[:-1], lagrangeKernel(r0, tau[-1], 5))
+    p.current_claim = np.ascontiguousarray(uni_skip_claim, dtype=np.uint64).copy()
+    p.current_round = 0
+    return p
+
+
 class InstructionInputProver:
     """InstructionInputProver's loop (src/zkvm/spartan/stage3_prover.zig:2029-2150): ten cycle-length tables,
     f = (eq_outer + gamma^2 eq_product) * (right_is_rs2 * rs2 + right_is_imm * imm + gamma (left_is_rs1 * rs1 + left_is_pc * pc)) as four
@@ -1940,6 +2035,8 @@ def shiftCoeffs(n, shift):
 
 UNISKIP_TARGETS = uniskipTargets()
 COEFFS_PER_J = [shiftCoeffs(10, t + 4) for t in UNISKIP_TARGETS]  # :469-476
+PRODUCT_VIRTUAL_TARGETS = uniskipTargets(5, 4)  # -3, 3, -4, 4 (:56-59)
+PRODUCT_VIRTUAL_COEFFS_PER_J = [shiftCoeffs(5, t + 2) for t in PRODUCT_VIRTUAL_TARGETS]  # :78-84
 
 
 def interpolateIntDomain(vals, left):

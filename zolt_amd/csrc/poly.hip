@@ -484,7 +484,7 @@ __global__ void __launch_bounds__(256) rows_mle_finish_kernel(const uint64_t *pa
 // an output (its non-zero coefficients only) and the prescaled coefficients are wave-uniform, a lane reads just the elements of its
 // row that the output uses; the terms are summed limb-wise and reduced once. Output c goes to table c / g, element i * g + c % g
 // (g interleaved outputs per table: Az[2 i + group]); rows i in [n_rows, n_pad) are written as zero.
-constexpr unsigned ROWS_AFFINE_MAX_OUT = 16, ROWS_AFFINE_MAX_K = 64;
+constexpr unsigned ROWS_AFFINE_MAX_OUT = 16, ROWS_AFFINE_MAX_K = 128, ROWS_AFFINE_MAX_NNZ = 64;
 struct RowsAffineArgs {
     uint64_t *tab[ROWS_AFFINE_MAX_OUT];  // per OUTPUT: its table's base
     uint8_t nnz[ROWS_AFFINE_MAX_OUT];
@@ -497,14 +497,14 @@ __global__ void __launch_bounds__(256) rows_affine_prep_kernel(const uint64_t *c
 #pragma unroll
     for (int i = 0; i < 9; i++) pre[9 * (size_t)e + i] = f.l[i];
 }
-__global__ void __launch_bounds__(1024) rows_affine_kernel(const uint64_t *rows, size_t n_rows, uint32_t k, const uint64_t *coeff, const uint32_t *pre,
+__global__ void __launch_bounds__(1024) rows_affine_kernel(const uint64_t *rows, size_t n_rows, uint32_t k, uint32_t stride, const uint64_t *coeff, const uint32_t *pre,
                                                            const uint8_t *cols /* nout x 64 */, RowsAffineArgs a, uint32_t g, size_t n_pad) {
     const uint32_t c = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const size_t i = (size_t)blockIdx.x * 64 + lane;
     if (i >= n_pad) return;
     Fr val = Fr::zero();
     if (i < n_rows) {
-        const uint64_t *row = rows + 4 * i * k;
+        const uint64_t *row = rows + 4 * i * stride;  // k >= stride: a map may read into the following rows (a sliding window)
         const uint32_t *pc = pre + 9 * (size_t)c * (k + 1);
         const uint8_t *cl = cols + 64 * c;
         Acc29 lazy = acc29_zero();
@@ -532,14 +532,14 @@ constexpr unsigned ROWS_PS_MAX_PAIRS = 32, ROWS_PS_WAVES = 8;
 struct RowsProdSumArgs {
     uint8_t nnz[2 * ROWS_PS_MAX_PAIRS];
 };
-__global__ void __launch_bounds__(64 * ROWS_PS_WAVES) rows_affine_prodsum_kernel(const uint64_t *rows, size_t n_rows, uint32_t k, const uint64_t *coeff,
+__global__ void __launch_bounds__(64 * ROWS_PS_WAVES) rows_affine_prodsum_kernel(const uint64_t *rows, size_t n_rows, uint32_t k, uint32_t stride, const uint64_t *coeff,
                                                                                  const uint32_t *pre, const uint8_t *cols, RowsProdSumArgs a,
                                                                                  const uint64_t *w, uint32_t G, uint32_t npairs, uint64_t *partials) {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, p = blockIdx.y * ROWS_PS_WAVES + wave;
     if (p >= npairs) return;
     Fr acc = Fr::zero();
     for (size_t i = (size_t)blockIdx.x * 64 + lane; i < n_rows; i += (size_t)gridDim.x * 64) {
-        const uint64_t *row = rows + 4 * i * k;
+        const uint64_t *row = rows + 4 * i * stride;
         Fr ab[2];
 #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -1252,12 +1252,14 @@ int zg_fr_rows_mle(const uint64_t *rows, size_t n_rows, size_t k, const uint64_t
     return zg_fr_rows_mle_dev(s_rows.as<uint64_t>(), n_rows, k, r, v, st, out);
 }
 
-int zg_fr_rows_affine_dev(const uint64_t *d_rows, size_t n_rows, size_t k, const uint64_t *coeffs, size_t ntab, size_t g, size_t n_pad,
+int zg_fr_rows_affine_dev(const uint64_t *d_rows, size_t n_rows, size_t k, size_t stride, const uint64_t *coeffs, size_t ntab, size_t g, size_t n_pad,
                           uint64_t *const *d_tables, void *stream) {
     ZG_INIT();
     const size_t nout = ntab * g;
-    if (!coeffs || !d_tables || k == 0 || k > ROWS_AFFINE_MAX_K || ntab == 0 || g == 0 || nout > ROWS_AFFINE_MAX_OUT || n_pad < n_rows || (n_rows && !d_rows)) {
-        set_error("zg_fr_rows_affine: 1..64 columns, 1..16 outputs (tables x interleave), n_pad >= n_rows");
+    if (stride == 0) stride = k;
+    if (!coeffs || !d_tables || k == 0 || k > ROWS_AFFINE_MAX_K || stride > k || ntab == 0 || g == 0 || nout > ROWS_AFFINE_MAX_OUT || n_pad < n_rows ||
+        (n_rows && !d_rows)) {
+        set_error("zg_fr_rows_affine: 1..128 columns, stride <= columns, 1..16 outputs (tables x interleave), n_pad >= n_rows");
         return ZG_ERR_INVALID;
     }
     if (n_pad == 0) return ZG_OK;
@@ -1274,7 +1276,13 @@ int zg_fr_rows_affine_dev(const uint64_t *d_rows, size_t n_rows, size_t k, const
         unsigned nnz = 0;
         for (size_t col = 0; col < k; col++) {
             const uint64_t *e = coeffs + 4 * (c * (k + 1) + col);
-            if (e[0] | e[1] | e[2] | e[3]) cols[64 * c + nnz++] = (uint8_t)col;
+            if (e[0] | e[1] | e[2] | e[3]) {
+                if (nnz == ROWS_AFFINE_MAX_NNZ) {
+                    set_error("zg_fr_rows_affine: at most 64 non-zero coefficients per map");
+                    return ZG_ERR_INVALID;
+                }
+                cols[64 * c + nnz++] = (uint8_t)col;
+            }
         }
         a.nnz[c] = (uint8_t)nnz;
     }
@@ -1285,7 +1293,7 @@ int zg_fr_rows_affine_dev(const uint64_t *d_rows, size_t n_rows, size_t k, const
     ZG_HIP(hipMemcpyAsync(s_coeff.p, coeffs, n_coeff * 32, hipMemcpyHostToDevice, st));
     ZG_HIP(hipMemcpyAsync(s_cols.p, cols.data(), cols.size(), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(rows_affine_prep_kernel, dim3(div_up(n_coeff, 256)), dim3(256), 0, st, s_coeff.as<uint64_t>(), (uint32_t)n_coeff, s_pre.as<uint32_t>());
-    hipLaunchKernelGGL(rows_affine_kernel, dim3(div_up(n_pad, 64)), dim3((unsigned)(64 * nout)), 0, st, d_rows, n_rows, (uint32_t)k, s_coeff.as<uint64_t>(),
+    hipLaunchKernelGGL(rows_affine_kernel, dim3(div_up(n_pad, 64)), dim3((unsigned)(64 * nout)), 0, st, d_rows, n_rows, (uint32_t)k, (uint32_t)stride, s_coeff.as<uint64_t>(),
                        s_pre.as<uint32_t>(), s_cols.as<uint8_t>(), a, (uint32_t)g, n_pad);
     ZG_HIP(hipGetLastError());
     ZG_HIP(hipStreamSynchronize(st));  // the coefficient buffers go back to the cache; `cols` is a local
@@ -1293,11 +1301,13 @@ int zg_fr_rows_affine_dev(const uint64_t *d_rows, size_t n_rows, size_t k, const
     return ZG_OK;
 }
 
-int zg_fr_rows_affine_prodsum_dev(const uint64_t *d_rows, size_t n_rows, size_t k, const uint64_t *coeffs, size_t npairs, const uint64_t *d_weights, size_t g,
-                                  uint64_t *out, void *stream) {
+int zg_fr_rows_affine_prodsum_dev(const uint64_t *d_rows, size_t n_rows, size_t k, size_t stride, const uint64_t *coeffs, size_t npairs,
+                                  const uint64_t *d_weights, size_t g, uint64_t *out, void *stream) {
     ZG_INIT();
-    if (!coeffs || !out || k == 0 || k > ROWS_AFFINE_MAX_K || npairs == 0 || npairs > ROWS_PS_MAX_PAIRS || g == 0 || (n_rows && (!d_rows || !d_weights))) {
-        set_error("zg_fr_rows_affine_prodsum: 1..64 columns, 1..32 pairs, a weight interleave >= 1");
+    if (stride == 0) stride = k;
+    if (!coeffs || !out || k == 0 || k > ROWS_AFFINE_MAX_K || stride > k || npairs == 0 || npairs > ROWS_PS_MAX_PAIRS || g == 0 ||
+        (n_rows && (!d_rows || !d_weights))) {
+        set_error("zg_fr_rows_affine_prodsum: 1..128 columns, stride <= columns, 1..32 pairs, a weight interleave >= 1");
         return ZG_ERR_INVALID;
     }
     if (n_rows == 0) {
@@ -1312,7 +1322,13 @@ int zg_fr_rows_affine_prodsum_dev(const uint64_t *d_rows, size_t n_rows, size_t 
         unsigned nnz = 0;
         for (size_t col = 0; col < k; col++) {
             const uint64_t *e = coeffs + 4 * (c * (k + 1) + col);
-            if (e[0] | e[1] | e[2] | e[3]) cols[64 * c + nnz++] = (uint8_t)col;
+            if (e[0] | e[1] | e[2] | e[3]) {
+                if (nnz == ROWS_AFFINE_MAX_NNZ) {
+                    set_error("zg_fr_rows_affine_prodsum: at most 64 non-zero coefficients per map");
+                    return ZG_ERR_INVALID;
+                }
+                cols[64 * c + nnz++] = (uint8_t)col;
+            }
         }
         a.nnz[c] = (uint8_t)nnz;
     }
@@ -1326,7 +1342,7 @@ int zg_fr_rows_affine_prodsum_dev(const uint64_t *d_rows, size_t n_rows, size_t 
     ZG_HIP(hipMemcpyAsync(s_cols.p, cols.data(), cols.size(), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(rows_affine_prep_kernel, dim3(div_up(n_coeff, 256)), dim3(256), 0, st, s_coeff.as<uint64_t>(), (uint32_t)n_coeff, s_pre.as<uint32_t>());
     hipLaunchKernelGGL(rows_affine_prodsum_kernel, dim3(nb, div_up(npairs, ROWS_PS_WAVES)), dim3(64 * ROWS_PS_WAVES), 0, st, d_rows, n_rows, (uint32_t)k,
-                       s_coeff.as<uint64_t>(), s_pre.as<uint32_t>(), s_cols.as<uint8_t>(), a, d_weights, (uint32_t)g, (uint32_t)npairs, s_part.as<uint64_t>());
+                       (uint32_t)stride, s_coeff.as<uint64_t>(), s_pre.as<uint32_t>(), s_cols.as<uint8_t>(), a, d_weights, (uint32_t)g, (uint32_t)npairs, s_part.as<uint64_t>());
     hipLaunchKernelGGL(rows_prodsum_finish_kernel, dim3((unsigned)npairs), dim3(256), 0, st, s_part.as<uint64_t>(), nb, (uint32_t)npairs, s_out.as<uint64_t>());
     ZG_HIP(hipGetLastError());
     ZG_HIP(hipMemcpyAsync(out, s_out.p, npairs * 32, hipMemcpyDeviceToHost, st));
@@ -1335,21 +1351,25 @@ int zg_fr_rows_affine_prodsum_dev(const uint64_t *d_rows, size_t n_rows, size_t 
     return ZG_OK;
 }
 
-int zg_fr_rows_affine(const uint64_t *rows, size_t n_rows, size_t k, const uint64_t *coeffs, size_t ntab, size_t g, size_t n_pad, uint64_t *const *tables) {
+int zg_fr_rows_affine(const uint64_t *rows, size_t n_rows, size_t k, size_t stride, const uint64_t *coeffs, size_t ntab, size_t g, size_t n_pad,
+                      uint64_t *const *tables) {
     ZG_INIT();
-    if (!tables || ntab == 0 || ntab > ROWS_AFFINE_MAX_OUT || g == 0 || k == 0 || k > ROWS_AFFINE_MAX_K || n_pad < n_rows || (n_rows && !rows)) {
-        set_error("zg_fr_rows_affine: 1..64 columns, 1..16 outputs (tables x interleave), n_pad >= n_rows");
+    if (stride == 0) stride = k;
+    if (!tables || ntab == 0 || ntab > ROWS_AFFINE_MAX_OUT || g == 0 || k == 0 || k > ROWS_AFFINE_MAX_K || stride > k || n_pad < n_rows || (n_rows && !rows)) {
+        set_error("zg_fr_rows_affine: 1..128 columns, stride <= columns, 1..16 outputs (tables x interleave), n_pad >= n_rows");
         return ZG_ERR_INVALID;
     }
     if (n_pad == 0) return ZG_OK;
     hipStream_t st = lib_stream();
-    Scratch s_rows((n_rows ? n_rows : 1) * k * 32), s_out(ntab * n_pad * g * 32);
+    // the matrix holds (n_rows - 1) * stride + k elements: the last row's window ends there
+    const size_t n_elems = n_rows ? (n_rows - 1) * stride + k : 1;
+    Scratch s_rows(n_elems * 32), s_out(ntab * n_pad * g * 32);
     if (!s_rows.p || !s_out.p) return ZG_ERR_NOMEM;
     SyncGuard sync(st);
-    if (n_rows) ZG_HIP(hipMemcpyAsync(s_rows.p, rows, n_rows * k * 32, hipMemcpyHostToDevice, st));
+    if (n_rows) ZG_HIP(hipMemcpyAsync(s_rows.p, rows, n_elems * 32, hipMemcpyHostToDevice, st));
     uint64_t *d_tab[ROWS_AFFINE_MAX_OUT];
     for (size_t t = 0; t < ntab; t++) d_tab[t] = s_out.as<uint64_t>() + 4 * t * n_pad * g;
-    ZG_TRY(zg_fr_rows_affine_dev(s_rows.as<uint64_t>(), n_rows, k, coeffs, ntab, g, n_pad, d_tab, st));
+    ZG_TRY(zg_fr_rows_affine_dev(s_rows.as<uint64_t>(), n_rows, k, stride, coeffs, ntab, g, n_pad, d_tab, st));
     for (size_t t = 0; t < ntab; t++) {
         if (!tables[t]) {
             set_error("zg_fr_rows_affine: null table");

@@ -1546,7 +1546,7 @@ public:
         DeviceMem d_w((size_t(1) << split_eq.tau.size()) * 32);  // eq(tau_low, .): index = cycle * 2 + group (:541-566)
         check(zg_fr_eq_table_dev(reinterpret_cast<const uint64_t *>(split_eq.tau.data()), split_eq.tau.size(), nullptr, d_w.u64(), nullptr), "zg_fr_eq_table_dev");
         Fr out[18];
-        check(zg_fr_rows_affine_prodsum_dev(d_rows_.u64(), std::min(num_cycles_, padded_trace_len), r1cs::NUM_INPUTS, reinterpret_cast<const uint64_t *>(m.data()), 18,
+        check(zg_fr_rows_affine_prodsum_dev(d_rows_.u64(), std::min(num_cycles_, padded_trace_len), r1cs::NUM_INPUTS, 0, reinterpret_cast<const uint64_t *>(m.data()), 18,
                                             d_w.u64(), 2, reinterpret_cast<uint64_t *>(out), nullptr), "zg_fr_rows_affine_prodsum_dev");
         std::vector<Fr> t1(19, Fr::zero());
         last_extended_evals.assign(9, Fr::zero());
@@ -1601,7 +1601,7 @@ public:
         DeviceMem d_az(n2 * 32), d_bz(n2 * 32);
         std::vector<Fr> m = constraintMatrix();
         uint64_t *tabs[2] = {d_az.u64(), d_bz.u64()};
-        check(zg_fr_rows_affine_dev(d_rows_.u64(), std::min(num_cycles_, padded_trace_len), r1cs::NUM_INPUTS, reinterpret_cast<const uint64_t *>(m.data()), 2, 2,
+        check(zg_fr_rows_affine_dev(d_rows_.u64(), std::min(num_cycles_, padded_trace_len), r1cs::NUM_INPUTS, 0, reinterpret_cast<const uint64_t *>(m.data()), 2, 2,
                                     padded_trace_len, tabs, nullptr), "zg_fr_rows_affine_dev");
         s_.reset(new ProductSumcheckSession(ProductSumcheckSession::OnDevice{}, {d_az.u64(), d_bz.u64()}, n2));
         check(zg_sync(), "zg_sync");  // the session holds its own copies before the two buffers are released

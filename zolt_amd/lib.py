@@ -557,34 +557,39 @@ def fr_rows_mle_dev(d_rows, n_rows, k, r, stream=0):
     return out
 
 
-def fr_rows_affine(rows, coeffs, ntab, g, n_pad=None):
-    """tables[t][i * g + j] = C[t*g + j][k] + sum_col C[t*g + j][col] * rows[i][col] (zg_fr_rows_affine): rows (T, k, 4) cycle-major,
-    coeffs (ntab * g, k + 1, 4) with the constant last -> ntab arrays of (n_pad * g, 4)"""
+def fr_rows_affine(rows, coeffs, ntab, g, n_pad=None, k=None):
+    """tables[t][i * g + j] = C[t*g + j][k] + sum_col C[t*g + j][col] * rows[i][col] (zg_fr_rows_affine): rows (T, stride, 4) cycle-major,
+    coeffs (ntab * g, k + 1, 4) with the constant last -> ntab arrays of (n_pad * g, 4). k > stride: a sliding window — the maps of row i
+    read into the rows after it, and the last k - stride elements of `rows` are only ever read as such a tail (n_rows = (T * stride - k) //
+    stride + 1)."""
     rows, coeffs = _c(rows), _c(coeffs)
-    assert rows.ndim == 3 and rows.shape[2] == 4 and coeffs.shape == (ntab * g, rows.shape[1] + 1, 4)
-    n_pad = rows.shape[0] if n_pad is None else n_pad
+    stride = rows.shape[1]
+    k = stride if k is None else k
+    assert rows.ndim == 3 and rows.shape[2] == 4 and coeffs.shape == (ntab * g, k + 1, 4) and k >= stride
+    n_rows = rows.shape[0] if k == stride else (rows.shape[0] * stride - k) // stride + 1
+    n_pad = n_rows if n_pad is None else n_pad
     outs = [np.empty((n_pad * g, 4), dtype=np.uint64) for _ in range(ntab)]
     ptrs = (C.c_void_p * ntab)(*[o.ctypes.data for o in outs])
-    _chk(_lib.zg_fr_rows_affine(_h(rows), C.c_size_t(rows.shape[0]), C.c_size_t(rows.shape[1]), _h(coeffs), C.c_size_t(ntab), C.c_size_t(g),
+    _chk(_lib.zg_fr_rows_affine(_h(rows), C.c_size_t(n_rows), C.c_size_t(k), C.c_size_t(stride), _h(coeffs), C.c_size_t(ntab), C.c_size_t(g),
                                 C.c_size_t(n_pad), ptrs), "zg_fr_rows_affine")
     return outs
 
 
-def fr_rows_affine_dev(d_rows, n_rows, k, coeffs, ntab, g, n_pad, d_tables, stream=0):
+def fr_rows_affine_dev(d_rows, n_rows, k, coeffs, ntab, g, n_pad, d_tables, stream=0, stride=0):
     coeffs = _c(coeffs)
     assert coeffs.size == ntab * g * (k + 1) * 4 and len(d_tables) == ntab
     ptrs = (C.c_void_p * ntab)(*[int(p) for p in d_tables])
-    _chk(_lib.zg_fr_rows_affine_dev(_d(d_rows), C.c_size_t(n_rows), C.c_size_t(k), _h(coeffs), C.c_size_t(ntab), C.c_size_t(g), C.c_size_t(n_pad),
-                                    ptrs, _d(stream)), "zg_fr_rows_affine_dev")
+    _chk(_lib.zg_fr_rows_affine_dev(_d(d_rows), C.c_size_t(n_rows), C.c_size_t(k), C.c_size_t(stride), _h(coeffs), C.c_size_t(ntab), C.c_size_t(g),
+                                    C.c_size_t(n_pad), ptrs, _d(stream)), "zg_fr_rows_affine_dev")
 
 
-def fr_rows_affine_prodsum_dev(d_rows, n_rows, k, coeffs, npairs, d_weights, g, stream=0):
+def fr_rows_affine_prodsum_dev(d_rows, n_rows, k, coeffs, npairs, d_weights, g, stream=0, stride=0):
     """out[p] = sum_i W[i * g + p % g] * A_p(row_i) * B_p(row_i) (zg_fr_rows_affine_prodsum_dev) -> (npairs, 4)"""
     coeffs = _c(coeffs)
     assert coeffs.size == 2 * npairs * (k + 1) * 4
     out = np.empty((npairs, 4), dtype=np.uint64)
-    _chk(_lib.zg_fr_rows_affine_prodsum_dev(_d(d_rows), C.c_size_t(n_rows), C.c_size_t(k), _h(coeffs), C.c_size_t(npairs), _d(d_weights), C.c_size_t(g),
-                                            _h(out), _d(stream)), "zg_fr_rows_affine_prodsum_dev")
+    _chk(_lib.zg_fr_rows_affine_prodsum_dev(_d(d_rows), C.c_size_t(n_rows), C.c_size_t(k), C.c_size_t(stride), _h(coeffs), C.c_size_t(npairs), _d(d_weights),
+                                            C.c_size_t(g), _h(out), _d(stream)), "zg_fr_rows_affine_prodsum_dev")
     return out
 
 
