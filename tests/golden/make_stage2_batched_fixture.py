@@ -139,6 +139,8 @@ def main():
     assert sorted(product["current_scalar"]) == [0, 1, 2] and sorted(factor_eq) == [0, 1, 2]
     assert sorted(mle["r_cycle"]) == list(range(product["tau_len"])) and sorted(mle["eq_evals"]) == [0, 1, 2]
     assert mle["r_cycle"][product["tau_len"] - 1] == product["tau_last"]
+    gl = next(l for l in lines if l.startswith("[ZOLT] STAGE2_BATCHED: gamma_instr = "))
+    gamma_instr = bytes(int(x) for x in re.search(r"= \{ ([0-9, ]+)\}", gl).group(1).replace(" ", "").strip(",").split(",")).hex()
     out = {
         "source": "reference logs/zolt.log, STAGE2_* lines of src/zkvm/batched_sumcheck.zig (canonical little-endian hex)",
         "input_claims": [claims[i] for i in range(n)],
@@ -149,6 +151,7 @@ def main():
         "rounds": [rounds[k] for k in sorted(rounds)],
         "output_claim": final,
         "instance_final_claims": [individual[i] for i in range(n)],
+        "gamma_instr_be": gamma_instr,  # [ZOLT] STAGE2_BATCHED: gamma_instr (canonical, big-endian), proof_converter.zig:2790
         "product_remainder": {
             "tau_len": product["tau_len"],
             "tau_last": product["tau_last"],

@@ -805,3 +805,23 @@ def test_product_virtual_from_witnesses_against_the_restatement(n):
             p.bindChallenge(chals[k])
     assert np.array_equal(g.getFinalClaim(), o.getFinalClaim())
     g.deinit()
+
+
+def test_stage2_batched_proof_of_the_captured_run_on_the_device(golden_dir):
+    """The reference's captured Stage-2 batched sumcheck with all five instances on the DEVICE, built from inputs (witnesses and memory
+    access regenerated from the ELF): product virtualisation (fused tables by sliding-window affine maps), RAF (cubic round kernel),
+    RAM read/write checking (the rwc session), output check and instruction-lookups claim reduction (product sessions), combined by
+    api.BatchedSumcheckProver under the logged coefficients — all 24 compressed round polynomials, the claims between them and the output
+    claim, full width."""
+    from zolt_amd import api, lib
+    from tests.test_transcript_host import check_stage2_batch_of_the_captured_run_from_inputs
+    lib.init(0)
+
+    def driver(insts, coeffs):
+        p = api.BatchedSumcheckProver("proof_converter")
+        for nr, claim, rnd, bind, _ in insts:
+            p.addInstance(api.SumcheckInstance(nr, 3, claim, rnd, bind))
+        p.batching_coeffs = list(coeffs)
+        p.current_claim = p.batchedClaim()
+        return p
+    check_stage2_batch_of_the_captured_run_from_inputs("gpu", golden_dir, driver, api.decompressRoundPoly, api.fr_to_int)

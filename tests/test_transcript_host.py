@@ -821,3 +821,126 @@ def test_stage2_product_virtualisation_of_the_captured_run_from_the_elf(golden_d
     eq = ob.fr_eq_table(np.stack([ob.fr_from_int(int(h, 16)) for h in cl["r_cycle_be"]]))
     for name, h in zip(("Product", "WriteLookupOutputToRD", "WritePCtoRD", "ShouldBranch", "ShouldJump"), fx["base_evals_be"]):
         assert ob.fr_to_int(ob._fsum(ob._fmul(w[:, ob.R1CS_INPUT_NAMES.index(name)], eq))) == int(h, 16), name
+
+
+def stage2_instances_of_the_captured_run(side, golden_dir):
+    """the five instances of the captured Stage-2 batch built FROM INPUTS — the witnesses and the one memory access regenerated from the
+    ELF, the challenges / gammas the log states — as (num_rounds, input_claim, round_fn, bind_fn, close_fn): side "oracle" = the
+    restatements, "gpu" = the device mirrors (zolt_amd.api). Instance order as proof_converter.zig:2754-2760."""
+    import json
+    import os
+    if side == "gpu":
+        from zolt_amd import api as m
+        fi = m.fr_from_int
+    else:
+        m, fi = None, ob.fr_from_int
+    be, le = (lambda h: int(h, 16)), (lambda h: int.from_bytes(bytes.fromhex(h), "little"))
+    J = lambda name: json.load(open(os.path.join(golden_dir, name)))
+    s1, s2, u, rwc, cl = J("stage1_outer_rounds.json"), J("stage2_batched_rounds.json"), J("stage2_uniskip.json"), J("rwc_captured_run.json"), J("stage1_r1cs_claims.json")
+    elf = open(os.path.join(golden_dir, "fibonacci.elf"), "rb").read()
+    w = stage1_witness_of_the_captured_run(golden_dir)
+    claims = [fi(le(h)) for h in s2["input_claims"]]
+    col = lambda name: w[:, ob.R1CS_INPUT_NAMES.index(name)]
+    last, out = {}, []
+
+    def wrap(key, nr, claim, prover, round_fn, update=True, close=None):
+        def rnd(_round):
+            last[key] = round_fn()
+            return last[key]
+
+        def bind(ch):
+            if update:
+                prover.updateClaim(last[key], ch)
+            prover.bindChallenge(ch)
+        out.append((nr, claim, rnd, bind, close or (lambda: None)))
+    # 0: ProductVirtualRemainder over tau = [Stage 1's r_cycle reversed, tau_high], r0, claim = s1(r0)
+    r_cycle = [fi(le(r["challenge_le"])) for r in s1["rounds"]][1:]
+    tau = np.stack(r_cycle[::-1] + [fi(be(u["tau_high_be"]))])
+    pv = (m.productVirtualRemainderProverFromWitnesses if m else ob.product_remainder_prover_from_witness)(w, fi(be(u["r0_be"])), tau, claims[0])
+    wrap("pv", 8, claims[0], pv, pv.roundEvals, close=getattr(pv, "deinit", None))
+    # 1: RamRafEvaluation: RaPolynomial.fromTrace indexes eq by the ACCESS index over log2_ceil(#accesses) variables (raf_checking.zig:101-117):
+    # one access -> ra[2049] = 1
+    ra = np.zeros((1 << rwc["log_k"], 4), dtype=np.uint64)
+    e = rwc["init"]["entries"][0]
+    ra[e["addr"]] = fi(1)
+    if m:
+        raf = m.RafEvaluationProver(ra, rwc["start_address"], rwc["log_k"], claims[1])
+        wrap("raf", 16, claims[1], raf, raf.computeRoundPolynomialCubic, close=raf.deinit)
+    else:
+        class Raf:
+            def __init__(self):
+                self.ra, self.bound, self.current_claim = ra.copy(), np.zeros((0, 4), dtype=np.uint64), claims[1].copy()
+
+            def computeRoundPolynomialCubic(self):
+                return ob.raf_round_cubic(self.ra, rwc["start_address"], self.bound, rwc["log_k"], self.current_claim)
+
+            def updateClaim(self, ev, ch):
+                self.current_claim = ob.raf_update_claim(ev, ch)
+
+            def bindChallenge(self, ch):
+                self.ra = ob.fr_bind_low(self.ra, ch)
+                self.bound = np.concatenate([self.bound, np.asarray(ch, dtype=np.uint64)[None, :]])
+        raf = Raf()
+        wrap("raf", 16, claims[1], raf, raf.computeRoundPolynomialCubic)
+    # 2: RamReadWriteChecking
+    acc, gamma, rc, iram, _ = U.rwc_inputs_of_the_captured_run(rwc, s2, elf, fi)
+    cls = m.RamReadWriteCheckingProver if m else ob.RamReadWriteCheckingProver
+    rw = cls(acc, gamma, rc, rwc["log_k"], rwc["log_t"], rwc["phase1_num_rounds"], rwc["start_address"], claims[2], iram)
+    wrap("rwc", 24, claims[2], rw, rw.computeRoundPolynomialCubic, close=getattr(rw, "deinit", None))
+    # 3: OutputSumcheck
+    tabs = U.output_check_tables_of_the_captured_run(s2["output_check"], elf, fi, ob.fr_eq_table)
+    oc = (m.OutputSumcheckProver if m else ob.OutputSumcheckProver)(*tabs, claims[3])
+    wrap("oc", 16, claims[3], oc, oc.roundEvals, close=getattr(oc, "deinit", None))
+    # 4: InstructionLookupsClaimReduction over eq(r_spartan, .) with r_spartan = Stage 1's r_cycle, big-endian (proof_converter.zig:3238-3272)
+    r_sp = np.stack([fi(be(h)) for h in cl["r_cycle_be"]])
+    gi = fi(be(s2["gamma_instr_be"]))
+    cls = m.InstructionLookupsClaimReductionProver if m else ob.InstructionLookupsClaimReduction
+    il = cls(ob.fr_eq_table(r_sp), col("LookupOutput"), col("LeftLookupOperand"), col("RightLookupOperand"), gi, claims[4])
+    wrap("il", 8, claims[4], il, il.computeRoundPolynomialCubic, close=getattr(il, "deinit", None))
+    return out, s2, w
+
+
+def check_stage2_batch_of_the_captured_run_from_inputs(side, golden_dir, driver, evals_from_compressed, fr_to_int):
+    """the captured Stage-2 BATCHED sumcheck reproduced from inputs: the driver combines the five instances' round evaluations under the
+    logged batching coefficients; every one of the 24 compressed round polynomials (c0, c2, c3), the initial claim and the output claim
+    must be the printed values, full width (tests/golden/stage2_batched_rounds.json)"""
+    le = lambda h: int.from_bytes(bytes.fromhex(h), "little")
+    insts, s2, _ = stage2_instances_of_the_captured_run(side, golden_dir)
+    fi = ob.fr_from_int
+    b = driver(insts, [fi(le(h)) for h in s2["batching_coeffs"]])
+    try:
+        assert fr_to_int(b.current_claim) == le(s2["initial_batched_claim"])
+        for k, r in enumerate(s2["rounds"]):
+            comp = b.computeRoundPolynomial()
+            assert [fr_to_int(comp[i]) for i in range(3)] == [le(r["c0"]), le(r["c2"]), le(r["c3"])], k
+            ch = fi(le(r["challenge"]))
+            b.updateClaim(evals_from_compressed(comp, b.current_claim), ch)
+            b.bindChallenge(ch)
+            assert fr_to_int(b.current_claim) == le(r["next_claim"]), k
+        assert fr_to_int(b.current_claim) == le(s2["output_claim"])
+    finally:
+        for inst in insts:
+            inst[4]()
+
+
+def test_stage2_batched_proof_of_the_captured_run_from_the_elf(golden_dir):
+    """All of Stage 2 from the committed ELF: ProductVirtualRemainder, RamRafEvaluation, RamReadWriteChecking, OutputSumcheck and
+    InstructionLookupsClaimReduction built from the regenerated witnesses / memory access and the logged challenges, combined by the
+    batched driver — the reference's 24 round polynomials come out bit for bit."""
+    class Inst:
+        def __init__(self, t):
+            self.num_rounds, self.input_claim, self.computeRoundPoly, self.bindChallenge = t[0], t[1], t[2], t[3]
+    check_stage2_batch_of_the_captured_run_from_inputs("oracle", golden_dir, lambda insts, coeffs: ob.BatchedSumcheck([Inst(t) for t in insts], coeffs),
+                                                       ob.decompress_round_poly, ob.fr_to_int)
+    # the input claims themselves follow from the witness: RamAddress; LookupOutput + g Left + g^2 Right at Stage 1's r_cycle
+    import json
+    import os
+    s2 = json.load(open(os.path.join(golden_dir, "stage2_batched_rounds.json")))
+    cl = json.load(open(os.path.join(golden_dir, "stage1_r1cs_claims.json")))
+    w = stage1_witness_of_the_captured_run(golden_dir)
+    eq = ob.fr_eq_table(np.stack([ob.fr_from_int(int(h, 16)) for h in cl["r_cycle_be"]]))
+    mle = lambda name: ob.fr_to_int(ob._fsum(ob._fmul(w[:, ob.R1CS_INPUT_NAMES.index(name)], eq)))
+    g, P = int(s2["gamma_instr_be"], 16), ob._R_P
+    le = lambda h: int.from_bytes(bytes.fromhex(h), "little")
+    assert mle("RamAddress") == le(s2["input_claims"][1])
+    assert (mle("LookupOutput") + g * mle("LeftLookupOperand") + g * g * mle("RightLookupOperand")) % P == le(s2["input_claims"][4])
