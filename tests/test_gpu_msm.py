@@ -591,6 +591,57 @@ def test_host_scalar_path_sliced(zl, ob, gm, slices, monkeypatch):
         b.free()
 
 
+@pytest.mark.parametrize("span_pts", [700, 1300, 2600])
+def test_device_scalar_path_in_point_slices(zl, ob, gm, span_pts, monkeypatch):
+    """A launch set whose table rows would span more than ZG_MSM_TABLE_SPAN_MB is cut into slices of consecutive points
+    (msm_enqueue_lane: every slice sorted and accumulated into its own set of bucket sums, the sets added up by
+    msm_bucket_fold_kernel, ONE reduction). Same bytes as the oracle through every entry point that reaches it: synchronous,
+    asynchronous (more calls in flight on two streams than the handle has workspaces), the ParallelMSM record mode, a
+    sub-range, host scalars, infinity bases; 8, 4 and 2 slices (the last one shorter)."""
+    import torch
+    monkeypatch.setenv("ZG_MSM_TABLE_SPAN_MB", "1")
+    monkeypatch.setenv("ZG_MSM_TABLE_SPAN_MIN_POINTS", str(span_pts))
+    monkeypatch.setenv("ZG_MSM_HOST_SLICE_MIN", "1000")
+    n = 5003
+    inf = np.zeros(n, dtype=np.uint8)
+    inf[7::40] = 1
+    b = zl.Bases.upload(gm[:n], inf)
+    dev = torch.device("cuda", 0)
+    try:
+        vecs = [ob.f_to_mont(ob.FR, U.random_raw256(4300 + j, n)) for j in range(5)]
+        want = [ob.msm_g1(gm[:n], inf, v) for v in vecs]
+        d = [torch.from_numpy(v.view(np.int64)).to(dev) for v in vecs]
+        torch.cuda.synchronize()
+        for j in range(2):
+            got = b.msm_dev(d[j].data_ptr(), n)
+            assert got[1] == want[j][1] and np.array_equal(got[0], want[j][0]), j
+        streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        outs = torch.zeros((20, 9), dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        for rep in range(20):  # more calls in flight than workspaces
+            j = rep % 5
+            b.msm_dev_async(d[j].data_ptr(), n, outs[rep].data_ptr(), outs[rep, 8:].data_ptr(), stream=streams[rep % 2].cuda_stream)
+        torch.cuda.synchronize()
+        o = outs.cpu().numpy().view(np.uint64)
+        for rep in range(20):
+            j = rep % 5
+            assert (o[rep, 8] & 0xFF) == want[j][1] and np.array_equal(o[rep, :8], want[j][0]), rep
+        w2 = ob.msm_g1(gm[100:4100], inf[100:4100], vecs[0][:4000])
+        g2 = b.msm_dev(d[0].data_ptr(), 4000, off=100)
+        assert g2[1] == w2[1] and np.array_equal(g2[0], w2[0])
+        jac = torch.zeros(12, dtype=torch.int64, device=dev)
+        b.msm_partial_dev(d[1].data_ptr(), n, jac.data_ptr())
+        torch.cuda.synchronize()
+        rec = jac.cpu().numpy().view(np.uint64)
+        assert np.array_equal(rec[:8], want[1][0]) and rec[8:].any()  # (x, y, 1): ParallelMSM's fromAffine record
+        got = b.msm(vecs[2])  # host scalars
+        assert got[1] == want[2][1] and np.array_equal(got[0], want[2][0])
+        z = b.msm_dev(torch.zeros((n, 4), dtype=torch.int64, device=dev).data_ptr(), n)
+        assert z[1] == 1
+    finally:
+        b.free()
+
+
 def test_fixed_base_batch_equals_scalar_mul(zl, ob):
     """zg_g1_fixed_base_mul_batch (HyperKZG.setup's primitive) against the generic per-pair scalarMul kernel and the oracle:
     random scalars, 0, 1, r - 1, small values, single-window values, a base other than the generator, an infinity base."""

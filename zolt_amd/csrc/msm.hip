@@ -91,6 +91,9 @@ struct zg_bases_s {
         uint32_t *d_cstarts = nullptr;    // two-pass sort: cstarts | totals | tstarts | istarts, NCB + 1 each
         uint32_t *d_fine = nullptr;       // two-pass sort: slicecnt[max items][2^fb] then fbase[NCB][2^fb]
         char *d_partial = nullptr;        // NK * 144 B: bucket sums (lazy 29-bit-limb XYZZ records)
+        char *d_slice_buckets = nullptr;  // point slices (msm_enqueue_sliced): the bucket sums of slices 1 .. S-1, built on first use
+        size_t slice_buckets = 0;         // ... how many sets it holds
+        uint32_t *d_slice_meta = nullptr; // ... and per slice: starts | nzrank | nzlist | MsmState (every slice is sorted before the first is accumulated)
         char *d_bits = nullptr;           // G * c * PB * 144 B: per-bit partial sums
         char *d_rg = nullptr;             // G * 128 B: per-group results
         uint32_t *d_nzrank = nullptr;     // NK + 1: non-empty buckets before k
@@ -771,6 +774,11 @@ ZG_DEV uint32_t chunk_len(uint32_t total, uint32_t NT) {
 
 // QUAD = true: one chunk per quad of lanes, every mixed add by xyzz29_madd4 — for launch sets too short to fill the GPU, where
 // the kernel is a latency chain of a few adds per chunk rather than a throughput problem (4 * NT lanes are launched).
+#ifdef ZG_EXP_TABLE_MASK  // timing experiment only (tools/build_variant.sh): folds the gathers into a smaller table footprint — wrong sums
+#define ZG_ROW_MASK (0x7FFFFFFFu & (uint32_t)(ZG_EXP_TABLE_MASK))
+#else
+#define ZG_ROW_MASK 0x7FFFFFFFu
+#endif
 template <bool QUAD>
 __global__ void __launch_bounds__(256) msm_accumulate_chunk_kernel(const uint32_t *sorted, const uint32_t *starts, const uint32_t *nzrank,
                                                                    const uint32_t *nzlist, const char *table, uint32_t NK, uint32_t NT,
@@ -794,15 +802,22 @@ __global__ void __launch_bounds__(256) msm_accumulate_chunk_kernel(const uint32_
     uint32_t r = nzrank[lo], kend = starts[lo + 1];  // r-th non-empty bucket; nzlist[r] == lo
     XYZZ29 acc;
     bool acc_inf = true;
+    // Two loads feed an addition: the reference sorted[p] and the table row it names. Both run ahead of the arithmetic — the row
+    // of entry p+1 is in flight during addition p (one row of 16 registers), and the reference of entry p+2 is loaded then too, so
+    // the row gather of the next iteration never waits for its index (measured: accumulate 1.18 -> 1.13-1.14 ms at 2^20 points,
+    // 784 -> 791-794 MSM/s; the sorted list is read at a stride of one chunk per lane, i.e. every lane pulls its own cache line).
+    // TWO rows in flight (214 registers instead of 200) were measured slower: 759 MSM/s.
     uint32_t e = sorted[a];
-    Affine cur = affine_load(table + 64 * (size_t)(e & 0x7FFFFFFFu));  // packed lazy-form row
+    Affine cur = affine_load(table + 64 * (size_t)(e & ZG_ROW_MASK));  // packed lazy-form row
     uint32_t cneg = e >> 31;
+    uint32_t e1 = a + 1 < b ? sorted[a + 1] : 0u;
     for (uint32_t p = a; p < b; p++) {
         Affine nxt = cur;
         uint32_t nneg = 0;
         if (p + 1 < b) {  // prefetch the next row under the current add
-            uint32_t e2 = sorted[p + 1];
-            nxt = affine_load(table + 64 * (size_t)(e2 & 0x7FFFFFFFu));
+            uint32_t e2 = e1;
+            if (p + 2 < b) e1 = sorted[p + 2];
+            nxt = affine_load(table + 64 * (size_t)(e2 & ZG_ROW_MASK));
             nneg = e2 >> 31;
         }
         if (p == kend) {  // the run of bucket k ended inside this chunk: emit its partial, move on
@@ -1139,7 +1154,7 @@ __global__ void msm_identity_kernel(int mode, uint64_t *out_rec, uint8_t *out_in
 // a sharded batch: rank i's record for it sits at partials + i * rank_stride + 12 * j (u64 units); its result record goes to
 // out_xy + j * rec_stride / out_inf + j * inf_stride.
 __global__ void __launch_bounds__(64) msm_combine_kernel(const uint64_t *partials, uint32_t k, uint32_t rank_stride, uint64_t *out_xy,
-                                                         uint8_t *out_inf, uint32_t rec_stride, uint32_t inf_stride) {
+                                                         uint8_t *out_inf, uint32_t rec_stride, uint32_t inf_stride, int mode = 0) {
     // one wave = 16 quads of lanes: quad i folds partials i, i+16, ... (Jacobian -> lazy XYZZ), then a shuffle tree over the
     // quads, every addition by a quad (g1_29x4.hip.h); the group sum does not depend on the association order, and the
     // affine result is canonical
@@ -1165,10 +1180,9 @@ __global__ void __launch_bounds__(64) msm_combine_kernel(const uint64_t *partial
         if ((quad & (uint32_t)(2 * d - 1)) == 0 && (uint32_t)d < k) acc = xyzz29_add4(acc, o, q);
     }
     if (lane != 0) return;
-    Affine r;
-    bool inf = xyzz_to_affine(xyzz29_to_std_val(acc), r);
-    affine_store(out_xy, r);
-    *out_inf = inf ? 1 : 0;
+    XYZZ tot = xyzz29_to_std_val(acc);
+    if (mode == 2) write_partial_unnormalised(tot, out_xy);  // the record modes of msm_final_kernel (a sliced MSM ends here instead)
+    else write_result(tot, mode, out_xy, out_inf);
 }
 
 // MSM.scalarMul(base, scalar).toAffine() (msm/mod.zig:503-540), one pair per thread
@@ -1462,7 +1476,7 @@ static void plan_two_pass(MsmPlan &p, size_t table_rows, size_t n_total) {
 static size_t fine_max_items(const MsmPlan &p, size_t n_total) { return (size_t)p.NCB + (size_t)p.W * n_total / FINE_SLICE + 1; }
 
 static void lane_free(zg_bases_s::Lane &ln) {
-    void *lp[] = {ln.d_dig, ln.d_sorted, ln.d_hist, ln.d_starts, ln.d_blockhist, ln.d_tmp, ln.d_cstarts, ln.d_fine, ln.d_partial, ln.d_bits, ln.d_rg,
+    void *lp[] = {ln.d_dig, ln.d_sorted, ln.d_hist, ln.d_starts, ln.d_blockhist, ln.d_tmp, ln.d_cstarts, ln.d_fine, ln.d_partial, ln.d_slice_buckets, ln.d_slice_meta, ln.d_bits, ln.d_rg,
                   ln.d_nzrank, ln.d_nzlist, ln.d_scan_tmp, ln.d_part, ln.d_part2, ln.d_heavy, ln.d_state};
     for (void *p : lp)
         if (p) (void)hipFree(p);
@@ -1688,6 +1702,56 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
                             const uint64_t *d_scalars, hipStream_t st, int mode, uint64_t *d_rec, uint8_t *d_inf_out,
                             uint32_t rec_stride, uint32_t inf_stride);
 
+static int ensure_aux_streams(zg_bases_s *b) {
+    if (b->aux[0]) return ZG_OK;
+    hipError_t e = hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming);
+    for (int i = 0; i < zg_bases_s::NAUX && e == hipSuccess; i++) {
+        e = hipStreamCreateWithFlags(&b->aux[i], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_join[i], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) {
+        set_error(std::string("msm helper streams: ") + hipGetErrorString(e));
+        return ZG_ERR_HIP;
+    }
+    return ZG_OK;
+}
+
+// ---- point slices. The accumulate kernel gathers one random 64-byte table row per addition; the rows of one launch set span
+// L * n * 64 bytes, and random rows over more than ~1-2 GiB run at half the rate of rows inside 1 GiB on this part (translation
+// reach: tools/microbench_tlb — 56 G rows/s inside 1 GiB, 25 G over 4 GiB, however the 4 GiB are allocated). At 2^22 points
+// (4 GiB table) that cost the kernel +10 % per addition, at 2^24 (16 GiB) +45 %. A long MSM is therefore cut into slices of
+// consecutive points whose L table segments together stay within ZG_MSM_TABLE_SPAN_MB (default 1024): slice j is sorted and
+// accumulated by itself (same workspace, same stream, one after the other) into its own set of bucket sums, one launch adds
+// the sets up bucket by bucket, and the reduction runs ONCE — the fixed tail is not multiplied (slices as separate MSMs with
+// a Jacobian combine were measured first: 4 x 0.45 ms of sorts and tails ate the whole gain). The sums are the same group
+// elements, so the result bytes are those of the unsliced launch set.
+static size_t table_span_points(const zg_bases_s *b) {
+    const size_t span_mb = (size_t)env_int("ZG_MSM_TABLE_SPAN_MB", 1024);  // 0 = never slice
+    if (!span_mb) return 0;
+    const size_t pts = (span_mb << 20) / (64 * (size_t)b->plan.L), least = (size_t)env_int("ZG_MSM_TABLE_SPAN_MIN_POINTS", 65536);  // tests lower it
+    return pts < least ? least : pts;
+}
+struct SliceView {  // what the sort of a point slice hands to its accumulation
+    uint32_t *sorted, *starts, *nzrank, *nzlist;
+    void *state;
+};
+static constexpr size_t DEV_SLICES_MAX = 128;  // 2^27 bases (the most a handle takes) / 2^20
+
+// bucket set 0 += sets 1 .. S-1 (set j at sets + (j-1) * NK * 144), one quad of lanes per bucket
+__global__ void __launch_bounds__(256) msm_bucket_fold_kernel(char *buckets, const char *sets, uint32_t NK, uint32_t S) {
+    ZG_HIPRIO();
+    uint32_t k = (blockIdx.x * 256 + threadIdx.x) >> 2, q = threadIdx.x & 3;
+    if (k >= NK) return;
+    XYZZ29 acc = xyzz29_load(buckets + 144 * (size_t)k);
+    XYZZ29 nxt = xyzz29_load(sets + 144 * (size_t)k);
+    for (uint32_t j = 1; j < S; j++) {
+        XYZZ29 cur = nxt;
+        if (j + 1 < S) nxt = xyzz29_load(sets + 144 * ((size_t)j * NK + k));
+        acc = xyzz29_add4(acc, cur, q);
+    }
+    if (q == 0) xyzz29_store(buckets + 144 * (size_t)k, acc);
+}
+
 // Enqueue one MSM over bases[off, off+n) on `st`; result record lands in d_rec / d_inf_out.
 static int msm_enqueue(zg_bases_s *b, size_t off, size_t n, const uint64_t *d_scalars, hipStream_t st, int mode, uint64_t *d_rec,
                        uint8_t *d_inf_out) {
@@ -1711,10 +1775,35 @@ static int msm_enqueue(zg_bases_s *b, size_t off, size_t n, const uint64_t *d_sc
 static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &ln, uint32_t nblk_cap, size_t off, size_t n_pts,
                             const uint64_t *d_scalars, hipStream_t st, int mode, uint64_t *d_rec, uint8_t *d_inf_out,
                             uint32_t rec_stride, uint32_t inf_stride) {
-    const size_t n = n_pts * (size_t)p.K;  // scalars in this launch set
-    const uint8_t *infp = b->d_inf ? b->d_inf + off : nullptr;
     if (ln.used) ZG_HIP(hipStreamWaitEvent(st, ln.done, 0));  // the lane's previous MSM may be on another stream
     ln.used = true;
+    // point slices (see table_span_points): S > 1 only for one scalar vector over a table wider than the span
+    size_t S = 1, per = n_pts;
+    if (p.K == 1) {
+        const size_t sp = table_span_points(b);
+        if (sp && n_pts >= 2 * sp) {  // slices only pay when there are at least two full ones
+            S = (n_pts + sp - 1) / sp;
+            if (S > DEV_SLICES_MAX) S = DEV_SLICES_MAX;
+            per = (n_pts + S - 1) / S;
+            S = (n_pts + per - 1) / per;  // no empty slice
+        }
+    }
+    // per slice: bucket starts, non-empty ranks, non-empty list, reduction state (what a sort hands to its accumulation), 16-byte aligned
+    const size_t meta_stride = (3 * ((size_t)p.NK + 1) + state_words(p.NT, p.NK) + 3) & ~(size_t)3;
+    if (S > 1 && ln.slice_buckets < S - 1) {
+        if (ln.d_slice_buckets) ZG_HIP(hipFree(ln.d_slice_buckets));  // (synchronises the device: once per lane and slice count)
+        ln.d_slice_buckets = nullptr;
+        ln.slice_buckets = 0;
+        ZG_HIP(hipMalloc((void **)&ln.d_slice_buckets, (S - 1) * (size_t)p.NK * 144));
+        if (ln.d_slice_meta) ZG_HIP(hipFree(ln.d_slice_meta));
+        ln.d_slice_meta = nullptr;
+        ZG_HIP(hipMalloc((void **)&ln.d_slice_meta, S * meta_stride * 4));
+        ln.slice_buckets = S - 1;
+    }
+    // digits and sort of bases[off, off + n_pts) x p.K scalar vectors at d_scalars -> sv (sorted references, bucket starts, ...)
+    auto sort_range = [&](size_t off, size_t n_pts, const uint64_t *d_scalars, const SliceView &sv) -> int {
+    const size_t n = n_pts * (size_t)p.K;  // scalars in this launch set
+    const uint8_t *infp = b->d_inf ? b->d_inf + off : nullptr;
     if (p.fb) {
         // two-pass sort: blocks of 256 threads over TWO_PASS_SPAN scalars each (coarse counters are a few KiB of LDS)
         uint32_t nblk = (uint32_t)div_up(n, two_pass_span(p.W));  // per_block * W <= STAGE_ENTRIES
@@ -1747,14 +1836,14 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
                                ln.d_fine);
             hipLaunchKernelGGL(msm_fine_offsets_kernel, dim3(p.NCB), dim3(128), 0, st, d_ist, p.fb, p.NK, ln.d_fine, d_fbase, ln.d_hist);
             hipLaunchKernelGGL(msm_fine_place_kernel, dim3(items), dim3(1024), (STAGE_ENTRIES + 128 + 132) * 4, st, ln.d_tmp, ln.d_cstarts, d_tst,
-                               d_ist, p.NCB, p.fb, p.rb, ln.d_fine, d_fbase, ln.d_sorted);
+                               d_ist, p.NCB, p.fb, p.rb, ln.d_fine, d_fbase, sv.sorted);
         }
         uint32_t tiles = div_up(p.NK, 1024);
         hipLaunchKernelGGL(msm_scan_a_kernel, dim3(tiles), dim3(1024), 0, st, ln.d_hist, p.NK, ln.d_scan_tmp, ln.d_scan_tmp + p.NK,
                            ln.d_scan_tmp + 2 * (size_t)p.NK);
         hipLaunchKernelGGL(msm_scan_b_kernel, dim3(tiles), dim3(1024), 0, st, ln.d_hist, p.NK, ln.d_scan_tmp, ln.d_scan_tmp + p.NK,
-                           ln.d_scan_tmp + 2 * (size_t)p.NK, ln.d_starts, ln.d_nzrank, ln.d_nzlist, reinterpret_cast<uint32_t *>(ln.d_state),
-                           ln.d_state ? state_words(p.NT, p.NK) : 0u);
+                           ln.d_scan_tmp + 2 * (size_t)p.NK, sv.starts, sv.nzrank, sv.nzlist, reinterpret_cast<uint32_t *>(sv.state),
+                           sv.state ? state_words(p.NT, p.NK) : 0u);
     } else if (ln.d_blockhist) {
         uint32_t nblk = nblk_cap;
         while (nblk > 1 && (size_t)(nblk - 1) * 1024 >= n) nblk--;  // no empty blocks for short sub-range MSMs
@@ -1770,15 +1859,15 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
             hipLaunchKernelGGL(msm_scan_a_kernel, dim3(tiles), dim3(1024), 0, st, ln.d_hist, p.NK, ln.d_scan_tmp, ln.d_scan_tmp + p.NK,
                                ln.d_scan_tmp + 2 * (size_t)p.NK);
             hipLaunchKernelGGL(msm_scan_b_kernel, dim3(tiles), dim3(1024), 0, st, ln.d_hist, p.NK, ln.d_scan_tmp, ln.d_scan_tmp + p.NK,
-                               ln.d_scan_tmp + 2 * (size_t)p.NK, ln.d_starts, ln.d_nzrank, ln.d_nzlist, reinterpret_cast<uint32_t *>(ln.d_state),
-                           ln.d_state ? state_words(p.NT, p.NK) : 0u);
+                               ln.d_scan_tmp + 2 * (size_t)p.NK, sv.starts, sv.nzrank, sv.nzlist, reinterpret_cast<uint32_t *>(sv.state),
+                           sv.state ? state_words(p.NT, p.NK) : 0u);
         }
         static PerDeviceOnce scatter_once;
         ZG_HIP(scatter_once.run([] {
             return hipFuncSetAttribute(reinterpret_cast<const void *>(msm_scatter_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         }));
         hipLaunchKernelGGL(msm_scatter_lds_kernel, dim3(nblk), dim3(sort_threads()), p.NK * 4, st, ln.d_dig, (uint32_t)n, (uint32_t)n_pts, p.W, p.G,
-                           b->n, (uint32_t)off, per_block, p.NK, ln.d_starts, ln.d_blockhist, ln.d_sorted);
+                           b->n, (uint32_t)off, per_block, p.NK, sv.starts, ln.d_blockhist, sv.sorted);
     } else {
         prof_begin(ZG_PROF_MSM_DIGITS, st);
         ZG_HIP(hipMemsetAsync(ln.d_hist, 0, (size_t)p.NK * 4, st));
@@ -1790,14 +1879,19 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
             hipLaunchKernelGGL(msm_scan_a_kernel, dim3(tiles), dim3(1024), 0, st, ln.d_hist, p.NK, ln.d_scan_tmp, ln.d_scan_tmp + p.NK,
                                ln.d_scan_tmp + 2 * (size_t)p.NK);
             hipLaunchKernelGGL(msm_scan_b_kernel, dim3(tiles), dim3(1024), 0, st, ln.d_hist, p.NK, ln.d_scan_tmp, ln.d_scan_tmp + p.NK,
-                               ln.d_scan_tmp + 2 * (size_t)p.NK, ln.d_starts, ln.d_nzrank, ln.d_nzlist, reinterpret_cast<uint32_t *>(ln.d_state),
-                           ln.d_state ? state_words(p.NT, p.NK) : 0u);
+                               ln.d_scan_tmp + 2 * (size_t)p.NK, sv.starts, sv.nzrank, sv.nzlist, reinterpret_cast<uint32_t *>(sv.state),
+                           sv.state ? state_words(p.NT, p.NK) : 0u);
         }
         ZG_HIP(hipMemsetAsync(ln.d_hist, 0, (size_t)p.NK * 4, st));
         hipLaunchKernelGGL(msm_scatter_kernel, dim3(div_up(n, 256), p.W), dim3(256), 0, st, ln.d_dig, (uint32_t)n, (uint32_t)n_pts, p.G,
-                           b->n, (uint32_t)off, ln.d_starts, ln.d_hist, ln.d_sorted);
+                           b->n, (uint32_t)off, sv.starts, ln.d_hist, sv.sorted);
     }
     prof_end(ZG_PROF_MSM_SORT, st);
+    return ZG_OK;
+    };
+    // accumulation and bucket sums of a sorted range -> bucket_out
+    auto accumulate_range = [&](size_t n_pts, const SliceView &sv, char *bucket_out) -> int {
+    const size_t n = n_pts * (size_t)p.K;
     prof_begin(ZG_PROF_MSM_ACCUMULATE, st);
     if (p.NT) {
         // a launch over a sub-range of the handle (a short prefix, the last set of a batch) gets as many chunks as ITS digits
@@ -1809,24 +1903,52 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
         uint32_t NT = chunk_threads((uint64_t)n * p.W, alone);
         if (NT > p.NT || getenv("ZG_MSM_CHUNK_THREADS")) NT = p.NT;
         if (NT <= (uint32_t)env_int("ZG_MSM_QUAD_ACC_MAX_CHUNKS", 32768))
-            hipLaunchKernelGGL(msm_accumulate_chunk_kernel<true>, dim3(div_up((size_t)NT * 4, 256)), dim3(256), 0, st, ln.d_sorted, ln.d_starts,
-                               ln.d_nzrank, ln.d_nzlist, b->d_table, p.NK, NT, ln.d_part);
+            hipLaunchKernelGGL(msm_accumulate_chunk_kernel<true>, dim3(div_up((size_t)NT * 4, 256)), dim3(256), 0, st, sv.sorted, sv.starts,
+                               sv.nzrank, sv.nzlist, b->d_table, p.NK, NT, ln.d_part);
         else
-            hipLaunchKernelGGL(msm_accumulate_chunk_kernel<false>, dim3(div_up(NT, 256)), dim3(256), 0, st, ln.d_sorted, ln.d_starts,
-                               ln.d_nzrank, ln.d_nzlist, b->d_table, p.NK, NT, ln.d_part);
+            hipLaunchKernelGGL(msm_accumulate_chunk_kernel<false>, dim3(div_up(NT, 256)), dim3(256), 0, st, sv.sorted, sv.starts,
+                               sv.nzrank, sv.nzlist, b->d_table, p.NK, NT, ln.d_part);
         prof_end(ZG_PROF_MSM_ACCUMULATE, st);  // the dominant kernel alone; combine/heavy stages count as reduction
         prof_begin(ZG_PROF_MSM_REDUCE, st);
-        hipLaunchKernelGGL(msm_bucket_combine_kernel, dim3(div_up((size_t)p.NK * p.GS * 4, 64)), dim3(64), 0, st, ln.d_part, ln.d_starts,
-                           ln.d_nzrank, p.NK, NT, p.GS, ln.d_partial, ln.d_heavy, reinterpret_cast<MsmState *>(ln.d_state));
+        hipLaunchKernelGGL(msm_bucket_combine_kernel, dim3(div_up((size_t)p.NK * p.GS * 4, 64)), dim3(64), 0, st, ln.d_part, sv.starts,
+                           sv.nzrank, p.NK, NT, p.GS, bucket_out, ln.d_heavy, reinterpret_cast<MsmState *>(sv.state));
         uint32_t nblk_a = (NT + p.NK) / HEAVY_BLOCK_ITEMS + 1;  // stage-A blocks of the huge buckets; at least 256 blocks = 1024 waves for the heavy ones
-        hipLaunchKernelGGL(msm_heavy_kernel, dim3(nblk_a < 256 ? 256 : nblk_a), dim3(256), 0, st, ln.d_part, ln.d_starts, ln.d_nzrank, ln.d_nzlist,
-                           p.NK, NT, ln.d_heavy, reinterpret_cast<MsmState *>(ln.d_state), ln.d_part2, ln.d_partial);
+        hipLaunchKernelGGL(msm_heavy_kernel, dim3(nblk_a < 256 ? 256 : nblk_a), dim3(256), 0, st, ln.d_part, sv.starts, sv.nzrank, sv.nzlist,
+                           p.NK, NT, ln.d_heavy, reinterpret_cast<MsmState *>(sv.state), ln.d_part2, bucket_out);
     } else {
-        hipLaunchKernelGGL(msm_accumulate_kernel, dim3(div_up((size_t)p.NK * p.S, 256)), dim3(256), 0, st, ln.d_sorted, ln.d_starts,
-                           b->d_table, p.NK, p.S, ln.d_partial);
+        hipLaunchKernelGGL(msm_accumulate_kernel, dim3(div_up((size_t)p.NK * p.S, 256)), dim3(256), 0, st, sv.sorted, sv.starts,
+                           b->d_table, p.NK, p.S, bucket_out);
         prof_end(ZG_PROF_MSM_ACCUMULATE, st);
         prof_begin(ZG_PROF_MSM_REDUCE, st);
     }
+    return ZG_OK;
+    };
+    // every slice is sorted before the first one is accumulated: with other MSMs in flight on other streams, the sorts then run
+    // under THEIR accumulations (a long stretch with 1/16 of the CUs free) instead of between this MSM's own (measured at 2^22:
+    // sort - accumulate - sort - ... left 0.7 ms per MSM outside the accumulations, this order ...)
+    auto view = [&](size_t j) {
+        SliceView sv{ln.d_sorted, ln.d_starts, ln.d_nzrank, ln.d_nzlist, ln.d_state};
+        if (S > 1) {
+            uint32_t *m = ln.d_slice_meta + j * meta_stride;
+            sv = SliceView{ln.d_sorted + j * (size_t)p.W * per, m, m + ((size_t)p.NK + 1), m + 2 * ((size_t)p.NK + 1),
+                           ln.d_state ? (void *)(m + 3 * ((size_t)p.NK + 1)) : nullptr};
+        }
+        return sv;
+    };
+    const bool sort_first = S > 1 && env_int("ZG_MSM_SLICE_SORT_FIRST", 0) != 0;
+    for (size_t j = 0; j < S && sort_first; j++) {
+        const size_t a = j * per, cnt = n_pts - a < per ? n_pts - a : per;
+        ZG_TRY(sort_range(off + a, cnt, d_scalars + 4 * a, view(j)));
+    }
+    for (size_t j = 0; j < S; j++) {
+        const size_t a = j * per, cnt = n_pts - a < per ? n_pts - a : per;
+        if (j) prof_end(ZG_PROF_MSM_REDUCE, st);  // the bucket sums of a slice count as reduction
+        if (!sort_first) ZG_TRY(sort_range(off + a, cnt, d_scalars + 4 * a, view(j)));
+        ZG_TRY(accumulate_range(cnt, view(j), j == 0 ? ln.d_partial : ln.d_slice_buckets + (j - 1) * (size_t)p.NK * 144));
+    }
+    if (S > 1)
+        hipLaunchKernelGGL(msm_bucket_fold_kernel, dim3(div_up((size_t)p.NK * 4, 256)), dim3(256), 0, st, ln.d_partial, ln.d_slice_buckets, p.NK,
+                           (uint32_t)S);
     if (p.lb) {
         char *d_rc = ln.d_bits + 144 * (size_t)p.G * p.K * p.c;  // rows and columns behind the c bit sums of every group
         hipLaunchKernelGGL(msm_rowcol_kernel, dim3((1u << p.hb) + (1u << p.lb), p.G * p.K), dim3(256), 0, st, ln.d_partial, p.NB, p.lb, p.hb, d_rc);
@@ -1844,13 +1966,100 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
     return ZG_OK;
 }
 
+// ---- toAffine on the host for the entry points that hand the result to the host anyway. On the device the inversion is a
+// single-lane safegcd of ~41 us at the very end of a latency chain (a third of msm_final_kernel); the host does it in a few
+// microseconds. The device hands over the un-normalised Jacobian record of mode 2, (X*ZZ, Y*ZZZ, ZZ): x = X'/Z^2, y = Y'/Z^3 —
+// canonical Montgomery residues, so the bytes are those of the device's own toAffine (msm/mod.zig:178-189).
+namespace hostfp {
+typedef unsigned __int128 u128;
+static const uint64_t P[4] = {0x3c208c16d87cfd47ull, 0x97816a916871ca8dull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
+static uint64_t n0inv() {  // -P^-1 mod 2^64
+    uint64_t inv = 1;
+    for (int i = 0; i < 6; i++) inv *= 2 - P[0] * inv;
+    return 0 - inv;
+}
+static void mul(uint64_t r[4], const uint64_t a[4], const uint64_t b[4]) {  // Montgomery product, CIOS, result < P
+    static const uint64_t N0 = n0inv();
+    uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) {
+        u128 c = 0;
+        for (int j = 0; j < 4; j++) {
+            c += (u128)a[j] * b[i] + t[j];
+            t[j] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[4];
+        t[4] = (uint64_t)c;
+        t[5] = (uint64_t)(c >> 64);
+        const uint64_t m = t[0] * N0;
+        c = ((u128)m * P[0] + t[0]) >> 64;
+        for (int j = 1; j < 4; j++) {
+            c += (u128)m * P[j] + t[j];
+            t[j - 1] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[4];
+        t[3] = (uint64_t)c;
+        t[4] = t[5] + (uint64_t)(c >> 64);
+    }
+    uint64_t d[4];
+    u128 br = 0;
+    for (int j = 0; j < 4; j++) {
+        u128 v = (u128)t[j] - P[j] - (uint64_t)br;
+        d[j] = (uint64_t)v;
+        br = (v >> 64) & 1;
+    }
+    const bool ge = t[4] != 0 || br == 0;
+    for (int j = 0; j < 4; j++) r[j] = ge ? d[j] : t[j];
+}
+static void inv(uint64_t r[4], const uint64_t a[4]) {  // a^(P-2), Montgomery domain in and out; a != 0
+    uint64_t e[4] = {P[0] - 2, P[1], P[2], P[3]}, acc[4], base[4];
+    bool started = false;
+    for (int j = 0; j < 4; j++) base[j] = a[j];
+    for (int bit = 253; bit >= 0; bit--) {
+        if (started) mul(acc, acc, acc);
+        if ((e[bit >> 6] >> (bit & 63)) & 1) {
+            if (started) mul(acc, acc, base);
+            else {
+                for (int j = 0; j < 4; j++) acc[j] = base[j];
+                started = true;
+            }
+        }
+    }
+    for (int j = 0; j < 4; j++) r[j] = acc[j];
+}
+// (X, Y, Z) Jacobian record -> affine xy[8] + infinity flag
+static void jacobian_to_affine(const uint64_t rec[12], uint64_t out_xy[8], uint8_t *out_inf) {
+    const uint64_t *X = rec, *Y = rec + 4, *Z = rec + 8;
+    if ((Z[0] | Z[1] | Z[2] | Z[3]) == 0) {
+        for (int i = 0; i < 8; i++) out_xy[i] = 0;
+        if (out_inf) *out_inf = 1;
+        return;
+    }
+    uint64_t iz[4], iz2[4], iz3[4];
+    inv(iz, Z);
+    mul(iz2, iz, iz);
+    mul(iz3, iz2, iz);
+    mul(out_xy, X, iz2);
+    mul(out_xy + 4, Y, iz3);
+    if (out_inf) *out_inf = 0;
+}
+}  // namespace hostfp
+
 static int msm_to_host(zg_bases_s *b, size_t off, size_t n, const uint64_t *d_scalars, hipStream_t st, uint64_t out_xy[8],
                        uint8_t *out_inf) {
-    ZG_TRY(msm_enqueue(b, off, n, d_scalars, st, 0, b->d_out, reinterpret_cast<uint8_t *>(b->d_out + 8)));
-    ZG_HIP(hipMemcpyAsync(b->h_out, b->d_out, 9 * 8, hipMemcpyDeviceToHost, st));
+    if (!env_int("ZG_MSM_HOST_AFFINE", 1)) {  // A/B: toAffine inside msm_final_kernel
+        ZG_TRY(msm_enqueue(b, off, n, d_scalars, st, 0, b->d_out, reinterpret_cast<uint8_t *>(b->d_out + 8)));
+        ZG_HIP(hipMemcpyAsync(b->h_out, b->d_out, 9 * 8, hipMemcpyDeviceToHost, st));
+        ZG_HIP(hipStreamSynchronize(st));
+        for (int i = 0; i < 8; i++) out_xy[i] = b->h_out[i];
+        if (out_inf) *out_inf = (uint8_t)(b->h_out[8] & 0xff);
+        return ZG_OK;
+    }
+    ZG_TRY(msm_enqueue(b, off, n, d_scalars, st, 2, b->d_out, nullptr));
+    ZG_HIP(hipMemcpyAsync(b->h_out, b->d_out, 12 * 8, hipMemcpyDeviceToHost, st));
     ZG_HIP(hipStreamSynchronize(st));
-    for (int i = 0; i < 8; i++) out_xy[i] = b->h_out[i];
-    if (out_inf) *out_inf = (uint8_t)(b->h_out[8] & 0xff);
+    hostfp::jacobian_to_affine(b->h_out, out_xy, out_inf);
     return ZG_OK;
 }
 
@@ -1934,7 +2143,6 @@ int zg_msm_g1_dev(zg_bases_t b, size_t off, size_t n, const uint64_t *d_scalars,
 // while slice i-1's launch set computes (three streams, the handle's workspaces rotate), every slice ends in an un-normalised
 // Jacobian partial, and one combine launch adds them up (the group sum does not depend on how the points were grouped, so
 // the bytes are those of the unsliced MSM).
-static int ensure_aux_streams(zg_bases_s *b);
 static constexpr size_t HOST_SLICE_MIN_POINTS = (size_t)1 << 18;
 static size_t host_slice_min() { return (size_t)env_int("ZG_MSM_HOST_SLICE_MIN", (int)HOST_SLICE_MIN_POINTS); }  // tests lower it
 static constexpr int HOST_SLICES_MAX = 8;
@@ -1962,9 +2170,9 @@ static int msm_host_sliced(zg_bases_s *b, size_t off, size_t n, const uint64_t *
     }
     if (rc == ZG_OK && e == hipSuccess) {
         hipLaunchKernelGGL(msm_combine_kernel, dim3(1), dim3(64), 0, st, b->d_slice_parts, (uint32_t)slices, 12u, b->d_out,
-                           reinterpret_cast<uint8_t *>(b->d_out + 8), 0u, 0u);
+                           reinterpret_cast<uint8_t *>(b->d_out + 12), 0u, 0u, 2);  // Jacobian record: toAffine on the host (msm_to_host)
         e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(b->h_out, b->d_out, 9 * 8, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(b->h_out, b->d_out, 12 * 8, hipMemcpyDeviceToHost, st);
     }
     hipError_t e2 = hipStreamSynchronize(st);
     if (e == hipSuccess) e = e2;
@@ -1973,8 +2181,7 @@ static int msm_host_sliced(zg_bases_s *b, size_t off, size_t n, const uint64_t *
         set_error(std::string("zg_msm_g1 (sliced): ") + hipGetErrorString(e));
         return ZG_ERR_HIP;
     }
-    for (int i = 0; i < 8; i++) out_xy[i] = b->h_out[i];
-    if (out_inf) *out_inf = (uint8_t)(b->h_out[8] & 0xff);
+    hostfp::jacobian_to_affine(b->h_out, out_xy, out_inf);
     return ZG_OK;
 }
 
@@ -2056,19 +2263,6 @@ static size_t batch_fuse_limit(const zg_bases_s *b, size_t n, bool wide_ok = fal
 }
 
 // the handle's two helper streams (+ fork / join events): independent launch sets rotate over the caller's stream and these
-static int ensure_aux_streams(zg_bases_s *b) {
-    if (b->aux[0]) return ZG_OK;
-    hipError_t e = hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming);
-    for (int i = 0; i < zg_bases_s::NAUX && e == hipSuccess; i++) {
-        e = hipStreamCreateWithFlags(&b->aux[i], hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_join[i], hipEventDisableTiming);
-    }
-    if (e != hipSuccess) {
-        set_error(std::string("msm helper streams: ") + hipGetErrorString(e));
-        return ZG_ERR_HIP;
-    }
-    return ZG_OK;
-}
 
 // enqueue k scalar vectors (device, back to back) over bases[0, n) on st. mode 0: record i = d_out9[9*i .. 9*i+8] (xy[8], flag
 // word); mode 1 / 2: record i = 12 limbs at d_out9 + 12*i (Jacobian partial, normalised / any representative — see write_result)
