@@ -2033,3 +2033,259 @@ def product_remainder_prover_from_witness(w, r0, tau, uni_skip_claim):
     z = np.zeros((padded - n, 4), dtype=np.uint64)
     tau = _c(tau)
     return ProductRemainderProver(np.concatenate([left, z]), np.concatenate([right, z]), tau[:-1], lagrange_kernel(r0, tau[-1], 5), uni_skip_claim)
+
+
+# ---------------------------------------------------------------- Stage 3 as a whole (src/zkvm/spartan/stage3_prover.zig:113-760)
+# The three instances are BUILT here as the reference builds them — the prefix / suffix tables of ShiftPrefixSuffixProver.init
+# (:979-1112), its transition to the second phase (:1506-1700), RegistersPrefixSuffixProver (:2189-2467), InstructionInputProver.init
+# (:1945-2013) — from the cycle witnesses, Stage 1's r_cycle and Stage 2's product r_cycle; the round evaluations are the C
+# restatements above. Tables are lists of canonical integers (mod r); challenges come from the caller (the reference's transcript is
+# not restated: the captured run's challenges are fixture data).
+def _s3_tab(ints):
+    return np.stack([fr_from_int(v) for v in ints]) if len(ints) else np.zeros((0, 4), dtype=np.uint64)
+
+
+def _s3_ints(tab):
+    return [fr_to_int(x) for x in _c(tab).reshape(-1, 4)]
+
+
+def _s3_eq(r):  # EqPolynomial.evals: r[0] is the most significant index bit
+    return _s3_ints(fr_eq_table(_s3_tab(r))) if len(r) else [1]
+
+
+def _s3_eqp1(r):  # computeEqPlusOneEvals (:1878-1895)
+    return _s3_ints(eq_plus_one_table(_s3_tab(r))) if len(r) else [0]
+
+
+def _s3_bind(t, r):  # new[i] = old[2i] + r (old[2i+1] - old[2i])
+    return [(t[2 * i] + r * (t[2 * i + 1] - t[2 * i])) % _R_P for i in range(len(t) // 2)]
+
+
+def _s3_eval_mle(t, point):  # evaluateMle (:1820-1838): the point's first entry binds the LOW index bit
+    t = list(t)
+    for r in point:
+        if len(t) == 1:
+            break
+        t = _s3_bind(t, r)
+    return t[0]
+
+
+def _s3_prod(xs):
+    r = 1
+    for x in xs:
+        r = r * x % _R_P
+    return r
+
+
+class Stage3ShiftProver:
+    """ShiftPrefixSuffixProver (:928-1919)"""
+    COLS = ("UnexpandedPC", "PC", "FlagVirtualInstruction", "FlagIsFirstInSequence", "FlagIsNoop")
+
+    def __init__(self, w, r_outer, r_product, gamma_powers):
+        """w: (T, 43) canonical integers; r_outer, r_product big-endian; gamma_powers[0..4]"""
+        n, P = len(r_outer), _R_P
+        split = n // 2
+        self.w, self.T, self.g = w, len(w), list(gamma_powers)
+        self.r_outer, self.r_product, self.suffix_n = list(r_outer), list(r_product), split
+        self.prefix_n = n - split
+        ps, ss = 1 << self.prefix_n, 1 << split
+        o_hi, o_lo, p_hi, p_lo = r_outer[:split], r_outer[split:], r_product[:split], r_product[split:]
+        # P_0 = eq+1(r_lo, .), P_1 = is_max(r_lo) at index 0 (:1013-1037); order: P_0_outer, P_1_outer, P_0_prod, P_1_prod
+        self.P = [_s3_eqp1(o_lo), [_s3_prod(o_lo)] + [0] * (ps - 1), _s3_eqp1(p_lo), [_s3_prod(p_lo)] + [0] * (ps - 1)]
+        s0o, s1o, s0p, s1p = _s3_eq(o_hi), _s3_eqp1(o_hi), _s3_eq(p_hi), _s3_eqp1(p_hi)
+        iu, ip, iv, if_, inp = (_R1[c] for c in self.COLS)
+        Q = [[0] * ps for _ in range(4)]
+        for lo in range(ps):
+            for hi in range(ss):
+                x = lo + (hi << self.prefix_n)
+                if x >= self.T:
+                    continue
+                row = w[x]
+                v = (row[iu] + self.g[1] * row[ip] + self.g[2] * row[iv] + self.g[3] * row[if_]) % P
+                omn = (1 - row[inp]) % P
+                Q[0][lo] = (Q[0][lo] + v * s0o[hi]) % P
+                Q[1][lo] = (Q[1][lo] + v * s1o[hi]) % P
+                Q[2][lo] = (Q[2][lo] + omn * s0p[hi]) % P
+                Q[3][lo] = (Q[3][lo] + omn * s1p[hi]) % P
+        Q[2] = [q * self.g[4] % P for q in Q[2]]
+        Q[3] = [q * self.g[4] % P for q in Q[3]]
+        self.Q, self.size, self.challenges, self.phase2 = Q, ps, [], False
+        self.tabs2 = None
+
+    def phase1_tables(self):
+        """P_0_outer, Q_0_outer, P_1_outer, Q_1_outer, P_0_prod, Q_0_prod, P_1_prod, Q_1_prod"""
+        return [_s3_tab(t) for k in range(4) for t in (self.P[k], self.Q[k])]
+
+    def phase2_tables(self):
+        return [_s3_tab(t) for t in self.tabs2]
+
+    def computeRoundEvals(self, previous_claim):
+        if not self.phase2:  # :1351-1392
+            return shift_phase1_round([_s3_tab(t) for t in self.P], [_s3_tab(t) for t in self.Q], self.size)
+        return shift_phase2_round(self.phase2_tables(), _s3_tab(self.g), previous_claim)  # :1399-1455
+
+    def bind(self, r):
+        P = _R_P
+        if self.phase2:  # :1782-1817
+            self.tabs2 = [_s3_bind(t, r) for t in self.tabs2]
+            return
+        transition = self.size == 2  # :1474-1477
+        self.P = [_s3_bind(t, r) for t in self.P]
+        self.Q = [_s3_bind(t, r) for t in self.Q]
+        self.size //= 2
+        self.challenges.append(r)
+        if not transition:
+            return
+        # transitionToPhase2 (:1506-1700)
+        self.phase2 = True
+        le = self.challenges
+        be = le[::-1]
+        ss = 1 << self.suffix_n
+        tabs = []
+        for rr in (self.r_outer, self.r_product):
+            hi, lo = rr[:self.suffix_n], rr[self.suffix_n:]
+            p0 = _s3_eqp1(lo)
+            p1 = [_s3_prod(lo)] + [0] * (len(p0) - 1)
+            e0, e1 = _s3_eval_mle(p0, le), _s3_eval_mle(p1, le)
+            s0, s1 = _s3_eq(hi), _s3_eqp1(hi)
+            tabs.append([(e0 * s0[j] + e1 * s1[j]) % P for j in range(ss)])
+        eq = _s3_eq(be)
+        pd = len(eq)
+        cols = [_R1[c] for c in self.COLS]
+        for c in cols:
+            t = []
+            for j in range(ss):
+                acc = 0
+                for i in range(pd):
+                    x = j * pd + i
+                    if x < self.T:
+                        acc += eq[i] * self.w[x][c]
+                t.append(acc % P)
+            tabs.append(t)
+        self.tabs2 = tabs  # eq+1_outer, eq+1_prod, unexpanded_pc, pc, is_virtual, is_first_in_sequence, is_noop
+
+    def finalClaims(self):
+        return dict(zip(("unexpanded_pc", "pc", "is_virtual", "is_first_in_sequence", "is_noop"), (t[0] for t in self.tabs2[2:])))
+
+
+class Stage3RegistersProver:
+    """RegistersPrefixSuffixProver (:2156-2495)"""
+
+    def __init__(self, w, r_spartan, gamma):
+        n, P = len(r_spartan), _R_P
+        split = n // 2
+        self.r_hi, self.r_lo, self.g = list(r_spartan[:split]), list(r_spartan[split:]), gamma
+        pn = n - split
+        ps, ss = 1 << pn, 1 << split
+        self.P = _s3_eq(self.r_lo)
+        suf = _s3_eq(self.r_hi)
+        ird, i1, i2 = _R1["RdWriteValue"], _R1["Rs1Value"], _R1["Rs2Value"]
+        T = len(w)
+        self.wit = [[row[c] for row in w] for c in (ird, i1, i2)]
+        g2 = gamma * gamma % P
+        self.Q = [0] * ps
+        for lo in range(ps):
+            for hi in range(ss):
+                x = lo + (hi << pn)
+                if x < T:
+                    self.Q[lo] = (self.Q[lo] + (w[x][ird] + gamma * w[x][i1] + g2 * w[x][i2]) * suf[hi]) % P
+        self.size, self.phase2, self.challenges, self.eq2 = ps, False, [], None
+
+    def computeRoundEvals(self, previous_claim):
+        g = fr_from_int(self.g)
+        if not self.phase2:  # :2334-2354
+            return registers_cr_round(False, [_s3_tab(self.P), _s3_tab(self.Q)], g, previous_claim)
+        return registers_cr_round(True, [_s3_tab(self.eq2)] + [_s3_tab(t) for t in self.wit], g, previous_claim)  # :2356-2386
+
+    def bind(self, r):
+        self.wit = [_s3_bind(t, r) for t in self.wit]
+        if self.phase2:  # :2467-2481
+            self.eq2 = _s3_bind(self.eq2, r)
+            return
+        transition = self.size == 2
+        self.P, self.Q = _s3_bind(self.P, r), _s3_bind(self.Q, r)  # :2404-2426 (the witness tables are folded alongside)
+        self.size //= 2
+        self.challenges.append(r)
+        if transition:  # :2427-2466: eq(r_lo, reversed prefix challenges) * eq(r_hi, .)
+            self.phase2 = True
+            e = fr_to_int(fr_eq_mle(_s3_tab(self.r_lo), _s3_tab(self.challenges[::-1])))
+            self.eq2 = [x * e % _R_P for x in _s3_eq(self.r_hi)]
+
+    def finalClaims(self):
+        return dict(zip(("rd_write_value", "rs1_value", "rs2_value"), (t[0] for t in self.wit)))
+
+
+class Stage3InstructionInputProver:
+    """InstructionInputProver (:1921-2150): ten cycle-length tables folded low to high"""
+    COLS = ("FlagLeftOperandIsRs1", "Rs1Value", "FlagLeftOperandIsPC", "UnexpandedPC", "FlagRightOperandIsRs2", "Rs2Value", "FlagRightOperandIsImm", "Imm")
+
+    def __init__(self, w, r_outer, r_product, gamma):
+        self.tabs = [[row[_R1[c]] for row in w] for c in self.COLS] + [_s3_eq(r_outer), _s3_eq(r_product)]
+        self.g = gamma
+
+    def tables(self):
+        return [_s3_tab(t) for t in self.tabs]
+
+    def computeRoundEvals(self, previous_claim):
+        return instruction_input_round(self.tables(), fr_from_int(self.g), previous_claim)
+
+    def bind(self, r):
+        self.tabs = [_s3_bind(t, r) for t in self.tabs]
+
+    def finalClaims(self):
+        return [t[0] for t in self.tabs]
+
+
+def stage3_evals_to_coeffs(ev):
+    """evalsToCoeffs (:846-901), degree 2 or 3, canonical integers"""
+    P = _R_P
+    if len(ev) == 3:
+        p0, p1, p2 = ev
+        c2 = (p2 - 2 * p1 + p0) * pow(2, -1, P) % P
+        return [p0, (p1 - p0 - c2) % P, c2]
+    p0, p1, p2, p3 = ev
+    d1, d2, d3 = p1 - p0, p2 - p1, p3 - p2
+    dd1, dd2 = d2 - d1, d3 - d2
+    c3 = (dd2 - dd1) * pow(6, -1, P) % P
+    c2 = (dd1 * pow(2, -1, P) - 3 * c3) % P
+    return [p0 % P, (d1 - c2 - c3) % P, c2, c3]
+
+
+def stage3_input_claims(outer, product, shift_gammas, instr_gamma, reg_gamma):
+    """computeShiftInputClaim / computeInstructionInputClaim / computeRegistersInputClaim (:775-844); outer / product: opening claims
+    by polynomial name at Stage 1's and at the product sumcheck's r_cycle (canonical integers)"""
+    P, g = _R_P, shift_gammas
+    shift = (outer["NextUnexpandedPC"] + g[1] * outer["NextPC"] + g[2] * outer["NextIsVirtual"] + g[3] * outer["NextIsFirstInSequence"]
+             + g[4] * (1 - product["NextIsNoop"])) % P
+    instr = (outer["RightInstructionInput"] + instr_gamma * outer["LeftInstructionInput"]
+             + instr_gamma * instr_gamma % P * (product["RightInstructionInput"] + instr_gamma * product["LeftInstructionInput"])) % P
+    reg = (outer["RdWriteValue"] + reg_gamma * outer["Rs1Value"] + reg_gamma * reg_gamma % P * outer["Rs2Value"]) % P
+    return shift, instr, reg
+
+
+class Stage3Batch:
+    """the round loop of generateStage3Proof (:327-560): three instances under three batching coefficients; a round's message is
+    (c0, c2, c3) of the combined cubic; every instance's claim follows its own polynomial"""
+
+    def __init__(self, shift, instr, reg, input_claims, coeffs):
+        self.inst, self.claims, self.coeffs = (shift, instr, reg), list(input_claims), list(coeffs)
+        self.combined = sum(c * k for c, k in zip(self.claims, self.coeffs)) % _R_P
+
+    def computeRoundPolynomial(self):
+        P = _R_P
+        ev = [[fr_to_int(x) for x in p.computeRoundEvals(fr_from_int(c))] for p, c in zip(self.inst, self.claims)]
+        self.evals = ev
+        full = []
+        for e in ev:  # a quadratic's value at 3: 3 p(2) - 3 p(1) + p(0)  (:415-417)
+            full.append(e if len(e) == 4 else e + [(3 * e[2] - 3 * e[1] + e[0]) % P])
+        comb = [sum(full[k][i] * self.coeffs[k] for k in range(3)) % P for i in range(4)]
+        self.coeffs_poly = stage3_evals_to_coeffs(comb)
+        return [self.coeffs_poly[0], self.coeffs_poly[2], self.coeffs_poly[3]]
+
+    def bindChallenge(self, r):
+        P = _R_P
+        at = lambda cs: sum(c * pow(r, i, P) for i, c in enumerate(cs)) % P
+        self.combined = at(self.coeffs_poly)
+        self.claims = [at(stage3_evals_to_coeffs(e)) for e in self.evals]
+        for p in self.inst:
+            p.bind(r)

@@ -944,3 +944,69 @@ def test_stage2_batched_proof_of_the_captured_run_from_the_elf(golden_dir):
     le = lambda h: int.from_bytes(bytes.fromhex(h), "little")
     assert mle("RamAddress") == le(s2["input_claims"][1])
     assert (mle("LookupOutput") + g * mle("LeftLookupOperand") + g * g * mle("RightLookupOperand")) % P == le(s2["input_claims"][4])
+
+
+def stage3_inputs_of_the_captured_run(golden_dir):
+    """what Stage 3 of the captured run starts from, regenerated: the 256 x 43 witness (from the ELF), Stage 1's r_cycle (big-endian, as
+    printed), the product sumcheck's r_cycle = the reversed challenges of Stage 2's last eight rounds, the logged gammas / batching
+    coefficients / round challenges; the two opening points are checked against the eight bytes each the reference printed"""
+    import json
+    import os
+    le = lambda h: int.from_bytes(bytes.fromhex(h), "little")
+    s3 = json.load(open(os.path.join(golden_dir, "stage3_batched_rounds.json")))
+    s2 = json.load(open(os.path.join(golden_dir, "stage2_batched_rounds.json")))
+    cl = json.load(open(os.path.join(golden_dir, "stage1_r1cs_claims.json")))
+    r_outer = [int(h, 16) for h in cl["r_cycle_be"]]
+    r_product = [le(r["challenge"]) for r in s2["rounds"][-8:]][::-1]
+    assert [r_outer[i].to_bytes(32, "little")[:8].hex() for i in (0, -1)] == [s3["prefix8"]["r_outer_0"], s3["prefix8"]["r_outer_last"]]
+    assert r_product[0].to_bytes(32, "big")[:8].hex() == s3["prefix8"]["r_product_0"]  # printed with toBytesBE (proof_converter.zig:1476)
+    wm = stage1_witness_of_the_captured_run(golden_dir)
+    w = [[ob.fr_to_int(x) for x in row] for row in wm]
+    return s3, w, wm, r_outer, r_product
+
+
+def check_stage3_of_the_captured_run(make_instances, golden_dir):
+    """Stage 3 of the captured run END TO END from the ELF: the three input claims from the witness columns at the two opening points,
+    then eight rounds — ShiftSumcheck's own p(0), p(1), the combined compressed polynomial (c0, c2, c3), the claim after the challenge —
+    and the final claims of the three instances, every value full width (tests/golden/stage3_batched_rounds.json).
+    make_instances(w, wm, r_outer, r_product, shift_gammas, instr_gamma, reg_gamma) -> (shift, instr, reg) with computeRoundEvals / bind /
+    finalClaims"""
+    P = ob._R_P
+    le = lambda h: int.from_bytes(bytes.fromhex(h), "little")
+    s3, w, wm, r_outer, r_product = stage3_inputs_of_the_captured_run(golden_dir)
+    g = int(s3["shift_gamma_be"], 16)
+    shift_g = [pow(g, i, P) for i in range(5)]
+    instr_g, reg_g = int(s3["instr_gamma_be"], 16), int(s3["reg_gamma_be"], 16)
+    # opening claims = MLEs of witness columns (and of NextIsNoop, the product sumcheck's shifted factor) at the two points
+    col = lambda name: wm[:, ob.R1CS_INPUT_NAMES.index(name)]
+    eq_o, eq_p = ob.fr_eq_table(ob._s3_tab(r_outer)), ob.fr_eq_table(ob._s3_tab(r_product))
+    mle = lambda tab, eq: ob.fr_to_int(ob._fsum(ob._fmul(tab, eq)))
+    outer = {n: mle(col(n), eq_o) for n in ("NextUnexpandedPC", "NextPC", "NextIsVirtual", "NextIsFirstInSequence", "LeftInstructionInput",
+                                             "RightInstructionInput", "RdWriteValue", "Rs1Value", "Rs2Value")}
+    noop = [row[ob.R1CS_INPUT_NAMES.index("FlagIsNoop")] for row in w]
+    next_noop = ob._s3_tab(noop[1:] + [1])  # NextIsNoop: the next cycle's flag, 1 past the end (product_factors, constraints.zig)
+    product = {"NextIsNoop": mle(next_noop, eq_p), "LeftInstructionInput": mle(col("LeftInstructionInput"), eq_p),
+               "RightInstructionInput": mle(col("RightInstructionInput"), eq_p)}
+    claims = ob.stage3_input_claims(outer, product, shift_g, instr_g, reg_g)
+    assert list(claims) == [le(h) for h in s3["input_claims"]]
+    insts = make_instances(w, wm, r_outer, r_product, shift_g, instr_g, reg_g)
+    b = ob.Stage3Batch(*insts, claims, [int(h, 16) for h in s3["batching_coeffs_be"]])
+    for k, r in enumerate(s3["rounds"]):
+        comp = b.computeRoundPolynomial()
+        assert b.evals[0][:2] == [le(r["shift_p0"]), le(r["shift_p1"])], k
+        assert comp == [le(r["c0"]), le(r["c2"]), le(r["c3"])], k
+        b.bindChallenge(le(r["challenge"]))
+        assert b.combined == le(r["next_claim"]), k
+    f = s3["final"]
+    assert b.combined == le(f["combined_claim"]) and b.claims[1] == le(f["current_instr_claim"]) and b.claims[2] == le(f["current_reg_claim"])
+    sh, rg = insts[0].finalClaims(), insts[2].finalClaims()
+    as_int = lambda v: v if isinstance(v, int) else ob.fr_to_int(v)
+    assert [as_int(sh[k]) for k in ("unexpanded_pc", "pc", "is_noop")] == [le(f["shift_unexpanded_pc"]), le(f["shift_pc"]), le(f["shift_is_noop"])]
+    assert [as_int(rg[k]) for k in ("rd_write_value", "rs1_value", "rs2_value")] == [le(f["reg_rd_write_value"]), le(f["reg_rs1_value"]), le(f["reg_rs2_value"])]
+
+
+def test_stage3_of_the_captured_run_from_the_elf(golden_dir):
+    """ShiftSumcheck (prefix / suffix tables, the phase transition), InstructionInput and RegistersClaimReduction as the reference builds
+    them (oracle restatement of stage3_prover.zig), from the committed ELF: all eight round polynomials and the final claims bit for bit"""
+    check_stage3_of_the_captured_run(lambda w, wm, ro, rp, sg, ig, rg: (ob.Stage3ShiftProver(w, ro, rp, sg), ob.Stage3InstructionInputProver(w, ro, rp, ig),
+                                                                          ob.Stage3RegistersProver(w, ro, rg)), golden_dir)
