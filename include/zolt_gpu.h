@@ -248,6 +248,13 @@ ZG_API int zg_fr_rows_affine(const uint64_t *rows, size_t n_rows, size_t k, size
                       uint64_t *const *tables /* ntab host pointers, n_pad * g elements each */);
 ZG_API int zg_fr_rows_affine_dev(const uint64_t *d_rows, size_t n_rows, size_t k, size_t stride, const uint64_t *coeffs_host, size_t ntab, size_t g,
                           size_t n_pad, uint64_t *const *d_tables /* host array of ntab DEVICE pointers */, void *stream);
+/* The Q tables of Stage 3's prefix / suffix provers (ShiftPrefixSuffixProver.init, src/zkvm/spartan/stage3_prover.zig:1066-1112;
+ * RegistersPrefixSuffixProver.init, :2232-2290): Q[x_lo] = sum over x_hi of witness(x_lo + x_hi * 2^prefix_vars) * suffix[x_hi] — column
+ * sums of the cycle-length table read as a (rows = 2^suffix_vars) x (cols = 2^prefix_vars) matrix, under up to four weight vectors at
+ * once (eq and eq+1 suffixes share the pass):   out[k * cols + c] = sum_r weights[k * rows + r] * table[r * cols + c],  k < m <= 4. */
+ZG_API int zg_fr_weighted_colsum(const uint64_t *table, size_t rows, size_t cols, const uint64_t *weights, size_t m, uint64_t *out);
+ZG_API int zg_fr_weighted_colsum_dev(const uint64_t *d_table, size_t rows, size_t cols, const uint64_t *d_weights, size_t m, uint64_t *d_out,
+                              void *stream);
 /* StreamingOuterProver.computeFirstRoundPoly's extended evaluations (src/zkvm/spartan/streaming_outer.zig:523-597, evaluateAzBzAtTargetY
  * :599-671): for each UniSkip target Y_j and constraint group, Az(x, Y_j) and Bz(x, Y_j) are Lagrange extrapolations (COEFFS_PER_J,
  * src/zkvm/r1cs/univariate_skip.zig:469-476) of the group's constraint values — affine maps of the cycle's inputs — and

@@ -1625,6 +1625,224 @@ class RegistersClaimReductionRounds:
         self._s.close()
 
 
+def _evaluate_mle_low(table, point):
+    """evaluateMle of the Stage-3 provers (src/zkvm/spartan/stage3_prover.zig:1820-1838): the point's first entry binds the LOW index bit"""
+    t = np.ascontiguousarray(table, dtype=np.uint64).reshape(-1, 4)
+    for r in point:
+        if t.shape[0] == 1:
+            break
+        t = lib.fr_bind_low(t, r)
+    return t[0]
+
+
+def _pad_pow2(col, n):
+    out = np.zeros((n, 4), dtype=np.uint64)
+    out[:col.shape[0]] = col
+    return out
+
+
+class ShiftPrefixSuffixProver:
+    """ShiftPrefixSuffixProver (src/zkvm/spartan/stage3_prover.zig:928-1919) as a whole, over the cycle witnesses.
+    init (:979-1112): P_0 = eq+1(r_lo, .), P_1 = is_max(r_lo) at 0, suffixes eq(r_hi, .) / eq+1(r_hi, .) are sqrt(T)-sized device table builds
+    (EqPlusOnePrefixSuffixPoly); the batched witness value v = upc + g pc + g^2 virt + g^3 first and g^4 (1 - noop) are AFFINE maps of a
+    cycle's R1CS inputs (one zg_fr_rows_affine launch over the witness matrix), and the four Q tables are their column sums under the
+    suffixes (zg_fr_weighted_colsum: the table read as 2^suffix_vars rows of 2^prefix_vars columns). Rounds: ShiftSumcheckRounds. The five
+    witness columns are folded on the device from round 0 — low-to-high binds by the prefix challenges give exactly the
+    sum_i eq(r_prefix, i) * witness[j * 2^prefix + i] the reference rebuilds at the transition (:1628-1664) — and the two eq+1 tables of the
+    second phase are prefix evaluations times the suffix tables (:1560-1610), sqrt(T) entries."""
+    COLS = ("UnexpandedPC", "PC", "FlagVirtualInstruction", "FlagIsFirstInSequence", "FlagIsNoop")
+
+    def __init__(self, cycle_witnesses, r_outer, r_product, gamma_powers):
+        w = np.ascontiguousarray(cycle_witnesses, dtype=np.uint64).reshape(-1, NUM_R1CS_INPUTS, 4)
+        r_outer = np.ascontiguousarray(r_outer, dtype=np.uint64).reshape(-1, 4)
+        r_product = np.ascontiguousarray(r_product, dtype=np.uint64).reshape(-1, 4)
+        n = r_outer.shape[0]
+        assert n >= 2 and r_product.shape[0] == n and w.shape[0] == (1 << n)  # the padded trace, as generateStage3Proof receives it
+        self.gamma_powers = np.ascontiguousarray(gamma_powers, dtype=np.uint64).reshape(5, 4).copy()
+        g = [fr_to_int(x) for x in self.gamma_powers]
+        self.suffix_n_vars = n // 2
+        self.prefix_n_vars = n - self.suffix_n_vars
+        ps, ss = 1 << self.prefix_n_vars, 1 << self.suffix_n_vars
+        self._eq = (EqPlusOnePrefixSuffixPoly(r_outer), EqPlusOnePrefixSuffixPoly(r_product))
+        m = [[0] * (NUM_R1CS_INPUTS + 1) for _ in range(2)]
+        for c, k in zip(self.COLS[:4], (1, g[1], g[2], g[3])):
+            m[0][_I[c]] = k
+        m[1][_I["FlagIsNoop"]], m[1][NUM_R1CS_INPUTS] = (-g[4]) % R_MOD, g[4]  # g^4 (1 - noop): the reference scales the sum, the same value
+        coeffs = np.stack([np.stack([fr_from_int(x) for x in row]) for row in m])
+        v, omn = lib.fr_rows_affine(w, coeffs, 2, 1, n_pad=1 << n)
+        # cycles past the trace contribute nothing (:1075): zg_fr_rows_affine writes zeros there, the map's constant included
+        q_o = lib.fr_weighted_colsum(v, ss, ps, np.stack([self._eq[0].suffix_0, self._eq[0].suffix_1]))
+        q_p = lib.fr_weighted_colsum(omn, ss, ps, np.stack([self._eq[1].suffix_0, self._eq[1].suffix_1]))
+        self._rounds = ShiftSumcheckRounds([self._eq[0].prefix_0, q_o[0], self._eq[0].prefix_1, q_o[1], self._eq[1].prefix_0, q_p[0], self._eq[1].prefix_1, q_p[1]])
+        self._wit = lib.ProductSumcheckSession.open([_pad_pow2(np.ascontiguousarray(w[:, _I[c]]), 1 << n) for c in self.COLS])
+        self.current_prefix_size, self.in_phase2, self.sumcheck_challenges = ps, False, []
+
+    def computeRoundEvals(self, previous_claim):
+        return self._rounds.computeRoundEvals(previous_claim)
+
+    def bind(self, r_j):
+        """:1458-1472"""
+        r_j = np.ascontiguousarray(r_j, dtype=np.uint64).reshape(4)
+        self._rounds.bind(r_j)
+        if self.in_phase2:
+            return
+        transition = self.current_prefix_size == 2  # shouldTransitionToPhase2 (:1474-1477)
+        self._wit.bind(r_j)
+        self.sumcheck_challenges.append(r_j.copy())
+        self.current_prefix_size //= 2
+        if transition:
+            self._transition()
+
+    def _transition(self):
+        """transitionToPhase2 (:1506-1700)"""
+        tabs = []
+        for e in self._eq:
+            e0, e1 = fr_to_int(_evaluate_mle_low(e.prefix_0, self.sumcheck_challenges)), fr_to_int(_evaluate_mle_low(e.prefix_1, self.sumcheck_challenges))
+            tabs.append(np.stack([fr_from_int((e0 * fr_to_int(a) + e1 * fr_to_int(b)) % R_MOD) for a, b in zip(e.suffix_0, e.suffix_1)]))
+        wit = [self._wit.read(j) for j in range(5)]
+        self._wit.close()
+        self._wit = None
+        self._rounds.deinit()
+        self._rounds = ShiftSumcheckRounds(tabs + wit, phase2=True, gamma_powers=self.gamma_powers)
+        self.in_phase2 = True
+
+    def finalClaims(self):
+        """:1860-1876"""
+        t = self._rounds.tables()
+        return dict(zip(("unexpanded_pc", "pc", "is_virtual", "is_first_in_sequence", "is_noop"), (x[0] for x in t[2:])))
+
+    def deinit(self):
+        if self._wit is not None:
+            self._wit.close()
+        self._rounds.deinit()
+
+
+class RegistersPrefixSuffixProver:
+    """RegistersPrefixSuffixProver (src/zkvm/spartan/stage3_prover.zig:2156-2495) as a whole: P = eq(r_lo, .), Q = column sums of
+    rd + g rs1 + g^2 rs2 (an affine map of the witness rows) under eq(r_hi, .); the three witness tables are folded on the device from
+    round 0, as the reference folds them (:2404-2416); the second phase's eq table is eq(r_lo, reversed prefix challenges) * eq(r_hi, .)
+    (:2427-2466)."""
+
+    def __init__(self, cycle_witnesses, r_spartan, gamma):
+        w = np.ascontiguousarray(cycle_witnesses, dtype=np.uint64).reshape(-1, NUM_R1CS_INPUTS, 4)
+        r = np.ascontiguousarray(r_spartan, dtype=np.uint64).reshape(-1, 4)
+        n = r.shape[0]
+        assert n >= 2 and w.shape[0] == (1 << n)  # the padded trace (the reference's own fold of an unpadded witness table drops odd tails)
+        split = n // 2
+        self.r_hi, self.r_lo = r[:split].copy(), r[split:].copy()
+        ps, ss = 1 << (n - split), 1 << split
+        self.gamma = np.ascontiguousarray(gamma, dtype=np.uint64).reshape(4).copy()
+        g = fr_to_int(self.gamma)
+        m = [0] * (NUM_R1CS_INPUTS + 1)
+        m[_I["RdWriteValue"]], m[_I["Rs1Value"]], m[_I["Rs2Value"]] = 1, g, g * g % R_MOD
+        (v,) = lib.fr_rows_affine(w, np.stack([fr_from_int(x) for x in m]).reshape(1, NUM_R1CS_INPUTS + 1, 4), 1, 1, n_pad=1 << n)
+        q = lib.fr_weighted_colsum(v, ss, ps, lib.fr_eq_table(self.r_hi).reshape(1, ss, 4))[0]
+        self._rounds = RegistersClaimReductionRounds([lib.fr_eq_table(self.r_lo), q], self.gamma)
+        self._wit = lib.ProductSumcheckSession.open([_pad_pow2(np.ascontiguousarray(w[:, _I[c]]), 1 << n) for c in ("RdWriteValue", "Rs1Value", "Rs2Value")])
+        self.current_prefix_size, self.in_phase2, self.prefix_challenges = ps, False, []
+
+    def computeRoundEvals(self, previous_claim):
+        return self._rounds.computeRoundEvals(previous_claim)
+
+    def bind(self, r_j):
+        """:2388-2398"""
+        r_j = np.ascontiguousarray(r_j, dtype=np.uint64).reshape(4)
+        self._rounds.bind(r_j)
+        if self.in_phase2:
+            return
+        transition = self.current_prefix_size == 2
+        self._wit.bind(r_j)
+        self.prefix_challenges.append(r_j.copy())
+        self.current_prefix_size //= 2
+        if transition:
+            e = 1  # EqPolynomial(r_lo).evaluate(reversed prefix challenges)
+            for a, b in zip((fr_to_int(x) for x in self.r_lo), (fr_to_int(x) for x in self.prefix_challenges[::-1])):
+                e = e * ((a * b + (1 - a) * (1 - b)) % R_MOD) % R_MOD
+            eq2 = np.stack([fr_from_int(fr_to_int(x) * e % R_MOD) for x in lib.fr_eq_table(self.r_hi)])
+            wit = [self._wit.read(j) for j in range(3)]
+            self._wit.close()
+            self._wit = None
+            self._rounds.deinit()
+            self._rounds = RegistersClaimReductionRounds([eq2] + wit, self.gamma, phase2=True)
+            self.in_phase2 = True
+
+    def finalClaims(self):
+        return self._rounds.finalClaims()
+
+    def deinit(self):
+        if self._wit is not None:
+            self._wit.close()
+        self._rounds.deinit()
+
+
+class Stage3Prover:
+    """The round loop of Stage3Prover.generateStage3Proof (src/zkvm/spartan/stage3_prover.zig:113-760) over the three instances: input
+    claims (:775-844), the combined cubic under the three batching coefficients, its compressed form (c0, c2, c3), and after a challenge
+    every instance's claim from its own polynomial (evalsToCoeffs / evaluatePolyAtPoint, :846-926). The transcript stays the caller's:
+    computeRoundPolynomial() -> compressed, bindChallenge(r_j)."""
+
+    def __init__(self, cycle_witnesses, r_outer, r_product, shift_gamma_powers, instr_gamma, reg_gamma, input_claims, batching_coeffs):
+        w = np.ascontiguousarray(cycle_witnesses, dtype=np.uint64).reshape(-1, NUM_R1CS_INPUTS, 4)
+        n = np.ascontiguousarray(r_outer, dtype=np.uint64).reshape(-1, 4).shape[0]
+        self.shift = ShiftPrefixSuffixProver(w, r_outer, r_product, shift_gamma_powers)
+        self.reg = RegistersPrefixSuffixProver(w, r_outer, reg_gamma)
+        cols = [_pad_pow2(np.ascontiguousarray(w[:, _I[c]]), 1 << n) for c in ("FlagLeftOperandIsRs1", "Rs1Value", "FlagLeftOperandIsPC", "UnexpandedPC",
+                                                                                "FlagRightOperandIsRs2", "Rs2Value", "FlagRightOperandIsImm", "Imm")]
+        self.instr = InstructionInputProver(cols + [lib.fr_eq_table(r_outer), lib.fr_eq_table(r_product)], instr_gamma)
+        self.claims = [fr_to_int(c) for c in np.ascontiguousarray(input_claims, dtype=np.uint64).reshape(3, 4)]  # shift, instruction input, registers
+        self.coeffs = [fr_to_int(c) for c in np.ascontiguousarray(batching_coeffs, dtype=np.uint64).reshape(3, 4)]
+        self.combined_claim = sum(c * k for c, k in zip(self.claims, self.coeffs)) % R_MOD
+
+    @staticmethod
+    def inputClaims(outer, product, shift_gamma_powers, instr_gamma, reg_gamma):
+        """computeShiftInputClaim / computeInstructionInputClaim / computeRegistersInputClaim (:775-844); outer / product: opening claims by
+        polynomial name (Montgomery limbs) at Stage 1's r_cycle and at the product sumcheck's -> (3, 4)"""
+        o = {k: fr_to_int(v) for k, v in outer.items()}
+        p = {k: fr_to_int(v) for k, v in product.items()}
+        g = [fr_to_int(x) for x in np.ascontiguousarray(shift_gamma_powers, dtype=np.uint64).reshape(5, 4)]
+        gi, gr = fr_to_int(instr_gamma), fr_to_int(reg_gamma)
+        shift = o["NextUnexpandedPC"] + g[1] * o["NextPC"] + g[2] * o["NextIsVirtual"] + g[3] * o["NextIsFirstInSequence"] + g[4] * (1 - p["NextIsNoop"])
+        instr = o["RightInstructionInput"] + gi * o["LeftInstructionInput"] + gi * gi * (p["RightInstructionInput"] + gi * p["LeftInstructionInput"])
+        reg = o["RdWriteValue"] + gr * o["Rs1Value"] + gr * gr * o["Rs2Value"]
+        return np.stack([fr_from_int(x % R_MOD) for x in (shift, instr, reg)])
+
+    @staticmethod
+    def evalsToCoeffs(ev):
+        """:846-901 (degree 2 or 3), canonical integers"""
+        if len(ev) == 3:
+            p0, p1, p2 = ev
+            c2 = (p2 - 2 * p1 + p0) * pow(2, -1, R_MOD) % R_MOD
+            return [p0 % R_MOD, (p1 - p0 - c2) % R_MOD, c2]
+        p0, p1, p2, p3 = ev
+        d1, d2, d3 = p1 - p0, p2 - p1, p3 - p2
+        c3 = ((d3 - d2) - (d2 - d1)) * pow(6, -1, R_MOD) % R_MOD
+        c2 = ((d2 - d1) * pow(2, -1, R_MOD) - 3 * c3) % R_MOD
+        return [p0 % R_MOD, (d1 - c2 - c3) % R_MOD, c2, c3]
+
+    def computeRoundPolynomial(self):
+        """:333-445 -> (3, 4): c0, c2, c3 of the combined cubic"""
+        insts = (self.shift, self.instr, self.reg)
+        self.round_evals = [[fr_to_int(x) for x in p.computeRoundEvals(fr_from_int(c))] for p, c in zip(insts, self.claims)]
+        full = [e if len(e) == 4 else e + [(3 * e[2] - 3 * e[1] + e[0]) % R_MOD] for e in self.round_evals]  # a quadratic at 3 (:415-417)
+        comb = [sum(full[k][i] * self.coeffs[k] for k in range(3)) % R_MOD for i in range(4)]
+        self.combined_coeffs = self.evalsToCoeffs(comb)
+        return np.stack([fr_from_int(self.combined_coeffs[i]) for i in (0, 2, 3)])
+
+    def bindChallenge(self, r_j):
+        """:458-490"""
+        r = fr_to_int(r_j)
+        at = lambda cs: sum(c * pow(r, i, R_MOD) for i, c in enumerate(cs)) % R_MOD
+        self.combined_claim = at(self.combined_coeffs)
+        self.claims = [at(self.evalsToCoeffs(e)) for e in self.round_evals]
+        for p in (self.shift, self.instr, self.reg):
+            p.bind(r_j)
+
+    def deinit(self):
+        self.shift.deinit()
+        self.reg.deinit()
+        self.instr.deinit()
+
+
 class JoltOuterProver:
     """JoltOuterProver's round loop (src/zkvm/spartan/jolt_outer_prover.zig:148-262) over the table f(cycle) = eq(tau, cycle) * Az * Bz it
     builds in init (:96-116, host work over the R1CS constraints): LowToHigh sums and folds on a LOW_PAIR device session."""

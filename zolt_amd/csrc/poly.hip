@@ -1382,6 +1382,85 @@ int zg_fr_rows_affine(const uint64_t *rows, size_t n_rows, size_t k, size_t stri
     return ZG_OK;
 }
 
+// ---- weighted column sums: out[m][c] = sum_r W[m][r] * T[r * cols + c]  (m <= 4 weight vectors share one pass over T).
+// The prefix / suffix provers of Stage 3 build their Q tables this way (src/zkvm/spartan/stage3_prover.zig:1066-1112, :2232-2290):
+// Q[x_lo] = sum over x_hi of witness(x_lo + x_hi * 2^prefix_vars) * suffix[x_hi]. Consecutive lanes take consecutive columns (every
+// row is read coalesced); the rows are cut into gridDim.y slabs whose partial sums a second launch adds up.
+static constexpr int COLSUM_MAX_W = 4;
+__global__ void __launch_bounds__(256) weighted_colsum_kernel(const uint64_t *tab, size_t rows, size_t cols, const uint64_t *w, int m,
+                                                              size_t rows_per_slab, uint64_t *partials /* [slab][m][cols] */) {
+    const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    const size_t r0 = (size_t)blockIdx.y * rows_per_slab, r1 = r0 + rows_per_slab < rows ? r0 + rows_per_slab : rows;
+    Fr acc[COLSUM_MAX_W];
+#pragma unroll
+    for (int k = 0; k < COLSUM_MAX_W; k++) acc[k] = Fr::zero();
+    for (size_t r = r0; r < r1; r++) {
+        Fr t = fe_load<FrParams>(tab + 4 * (r * cols + c));
+#pragma unroll
+        for (int k = 0; k < COLSUM_MAX_W; k++)
+            if (k < m) acc[k] = fe_add(acc[k], fr_mul29v(t, fe_load<FrParams>(w + 4 * ((size_t)k * rows + r))));
+    }
+#pragma unroll
+    for (int k = 0; k < COLSUM_MAX_W; k++)
+        if (k < m) fe_store(partials + 4 * (((size_t)blockIdx.y * m + k) * cols + c), acc[k]);
+}
+__global__ void __launch_bounds__(256) colsum_finish_kernel(const uint64_t *partials, size_t slabs, size_t n /* m * cols */, uint64_t *out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    Fr acc = fe_load<FrParams>(partials + 4 * i);
+    for (size_t s = 1; s < slabs; s++) acc = fe_add(acc, fe_load<FrParams>(partials + 4 * (s * n + i)));
+    fe_store(out + 4 * i, acc);
+}
+
+int zg_fr_weighted_colsum_dev(const uint64_t *d_table, size_t rows, size_t cols, const uint64_t *d_weights, size_t m, uint64_t *d_out, void *stream) {
+    ZG_INIT();
+    if (m == 0 || m > (size_t)COLSUM_MAX_W || rows == 0 || cols == 0 || !d_table || !d_weights || !d_out) {
+        set_error("zg_fr_weighted_colsum_dev: 1..4 weight vectors, a non-empty table");
+        return ZG_ERR_INVALID;
+    }
+    hipStream_t st = pick_stream(stream);
+    // enough workgroups to fill the chip: columns / 256 blocks times row slabs
+    const size_t col_blocks = div_up(cols, 256);
+    size_t slabs = col_blocks >= 1024 ? 1 : 1024 / col_blocks;
+    if (slabs > rows) slabs = rows;
+    if (slabs > 256) slabs = 256;
+    const size_t per = div_up(rows, slabs);
+    slabs = div_up(rows, per);
+    if (slabs == 1) {
+        hipLaunchKernelGGL(weighted_colsum_kernel, dim3((unsigned)col_blocks, 1), dim3(256), 0, st, d_table, rows, cols, d_weights, (int)m, per, d_out);
+        ZG_HIP(hipGetLastError());
+        return ZG_OK;
+    }
+    Scratch part(slabs * m * cols * 32);
+    if (!part.p) return ZG_ERR_NOMEM;
+    hipLaunchKernelGGL(weighted_colsum_kernel, dim3((unsigned)col_blocks, (unsigned)slabs), dim3(256), 0, st, d_table, rows, cols, d_weights, (int)m, per,
+                       part.as<uint64_t>());
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)div_up(m * cols, 256)), dim3(256), 0, st, part.as<uint64_t>(), slabs, m * cols, d_out);
+    ZG_HIP(hipGetLastError());
+    ZG_HIP(hipStreamSynchronize(st));  // the scratch partials go back to the cache with this call
+    return ZG_OK;
+}
+
+int zg_fr_weighted_colsum(const uint64_t *table, size_t rows, size_t cols, const uint64_t *weights, size_t m, uint64_t *out) {
+    ZG_INIT();
+    if (m == 0 || m > (size_t)COLSUM_MAX_W || rows == 0 || cols == 0 || !table || !weights || !out) {
+        set_error("zg_fr_weighted_colsum: 1..4 weight vectors, a non-empty table");
+        return ZG_ERR_INVALID;
+    }
+    hipStream_t st = lib_stream();
+    Scratch s_t(rows * cols * 32), s_w(m * rows * 32), s_o(m * cols * 32);
+    if (!s_t.p || !s_w.p || !s_o.p) return ZG_ERR_NOMEM;
+    SyncGuard sync(st);
+    ZG_HIP(hipMemcpyAsync(s_t.p, table, rows * cols * 32, hipMemcpyHostToDevice, st));
+    ZG_HIP(hipMemcpyAsync(s_w.p, weights, m * rows * 32, hipMemcpyHostToDevice, st));
+    ZG_TRY(zg_fr_weighted_colsum_dev(s_t.as<uint64_t>(), rows, cols, s_w.as<uint64_t>(), m, s_o.as<uint64_t>(), st));
+    ZG_HIP(hipMemcpyAsync(out, s_o.p, m * cols * 32, hipMemcpyDeviceToHost, st));
+    ZG_HIP(hipStreamSynchronize(st));
+    sync.dismiss();
+    return ZG_OK;
+}
+
 int zg_fr_spartan_combine_dev(const uint64_t *d_eq, const uint64_t *d_az, const uint64_t *d_bz, const uint64_t *d_cz, size_t n,
                               uint64_t *d_out, void *stream) {
     ZG_INIT();
