@@ -193,3 +193,68 @@ def test_weighted_colsum(env, rows, cols, m):
         for k in range(m):
             for c in range(cols):
                 assert np.array_equal(got[k, c], ob._fsum(ob._fmul(np.ascontiguousarray(t3[:, c]), np.ascontiguousarray(wts[k]))))
+
+
+def test_stage3_provers_at_full_size(env):
+    """2^20 padded cycles (1.4 GB of witnesses): the restatement's Python loops do not reach this size, so the check is the protocol's own
+    identities. Phase 1 of ShiftSumcheck computes p(0) AND p(1) from the tables: p(0) + p(1) must be the running claim in every one of its
+    ten rounds, starting from the total sum. In the second phase p(1) is derived, so the proof of the pudding is the end: the last claim
+    must equal  eq+1(r_outer, r) * v(r) + gamma^4 * eq+1(r_product, r) * (1 - noop(r))  resp.  eq(r_spartan, r) * (rd + g rs1 + g^2 rs2)(r)
+    with the openings v(r), noop(r), rd(r) ... taken from an INDEPENDENT evaluator of the witness columns (zg_fr_rows_mle) at the
+    challenge point — which also pins the provers' final claims."""
+    api, lib, ob = env
+    from tests import util as U
+    n, P = 20, ob._R_P
+    T = 1 << n
+    rng = np.random.default_rng(20)
+    wm = np.zeros((T, 43, 4), dtype=np.uint64)
+    wm[:, :, 0] = rng.integers(0, 1 << 62, size=(T, 43), dtype=np.uint64)  # small canonical values, written as Montgomery limbs below
+    cols = [api._I[c] for c in ("UnexpandedPC", "PC", "FlagVirtualInstruction", "FlagIsFirstInSequence", "FlagIsNoop", "RdWriteValue", "Rs1Value", "Rs2Value")]
+    for c in cols:  # only the columns Stage 3 reads need to be field elements in Montgomery form
+        wm[:, c] = lib.field_op(lib.FR, lib.OP_TO_MONT, np.ascontiguousarray(wm[:, c]))
+    rnd = lambda seed, k: ob.f_to_mont(ob.FR, U.random_raw256(seed, k))
+    ro, rp, ch, g = rnd(1, n), rnd(2, n), rnd(3, n), rnd(4, 2)
+    gi = ob.fr_to_int(g[0])
+    shift_g = np.stack([ob.fr_from_int(pow(gi, i, P)) for i in range(5)])
+    sh = api.ShiftPrefixSuffixProver(wm, ro, rp, shift_g)
+    rg = api.RegistersPrefixSuffixProver(wm, ro, g[1])
+    to_int = ob.fr_to_int
+    at = lambda cs, r: sum(c * pow(r, i, P) for i, c in enumerate(cs)) % P
+    try:
+        ev = [to_int(x) for x in sh.computeRoundEvals(ob.fr_from_int(0))]
+        claim_s = (ev[0] + ev[1]) % P  # the total sum
+        # registers: the total is the inner product of the two prefix tables
+        claim_r = None
+        for k in range(n):
+            ev = [to_int(x) for x in sh.computeRoundEvals(ob.fr_from_int(claim_s))]
+            assert (ev[0] + ev[1]) % P == claim_s, k
+            er = [to_int(x) for x in rg.computeRoundEvals(ob.fr_from_int(claim_r if claim_r is not None else 0))]
+            if claim_r is None:  # round 0: take the claim that makes p(1) = the true p(1): P . Q summed over the cube
+                t = rg._rounds.tables()
+                claim_r = to_int(ob._fsum(ob._fmul(t[0], t[1])))
+                er = [to_int(x) for x in rg.computeRoundEvals(ob.fr_from_int(claim_r))]
+            r = to_int(ch[k])
+            claim_s = at(api.Stage3Prover.evalsToCoeffs(ev), r)
+            claim_r = at(api.Stage3Prover.evalsToCoeffs(er), r)
+            sh.bind(ch[k])
+            rg.bind(ch[k])
+        r_be = ch[::-1]  # the challenges as an MLE point (the first one bound the lowest index bit)
+        opened = lib.fr_rows_mle(wm, r_be)
+        fs, fr_ = sh.finalClaims(), rg.finalClaims()
+        names = dict(unexpanded_pc="UnexpandedPC", pc="PC", is_virtual="FlagVirtualInstruction", is_first_in_sequence="FlagIsFirstInSequence",
+                     is_noop="FlagIsNoop", rd_write_value="RdWriteValue", rs1_value="Rs1Value", rs2_value="Rs2Value")
+        for k, v in list(fs.items()) + list(fr_.items()):
+            assert np.array_equal(v, opened[api._I[names[k]]]), k
+        o = {k: to_int(opened[api._I[v]]) for k, v in names.items()}
+        gp = [pow(gi, i, P) for i in range(5)]
+        v_r = (o["unexpanded_pc"] + gp[1] * o["pc"] + gp[2] * o["is_virtual"] + gp[3] * o["is_first_in_sequence"]) % P
+        e1o, e1p = to_int(api.EqPlusOnePolynomial.mle(ro, r_be)), to_int(api.EqPlusOnePolynomial.mle(rp, r_be))
+        assert claim_s == (e1o * v_r + gp[4] * e1p % P * (1 - o["is_noop"])) % P
+        eq = 1
+        for a, b in zip((to_int(x) for x in ro), (to_int(x) for x in r_be)):
+            eq = eq * ((a * b + (1 - a) * (1 - b)) % P) % P
+        g2 = to_int(g[1])
+        assert claim_r == eq * (o["rd_write_value"] + g2 * o["rs1_value"] + g2 * g2 * o["rs2_value"]) % P
+    finally:
+        sh.deinit()
+        rg.deinit()

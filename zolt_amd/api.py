@@ -1527,9 +1527,14 @@ class InstructionInputProver:
     right_is_rs2, rs2_value, right_is_imm, imm, eq_outer, eq_product."""
     NAMES = ("left_is_rs1", "rs1_value", "left_is_pc", "unexpanded_pc", "right_is_rs2", "rs2_value", "right_is_imm", "imm", "eq_outer", "eq_product")
 
-    def __init__(self, tables, gamma):
-        assert len(tables) == 10
-        self._s = lib.ProductSumcheckSession.open(tables)
+    def __init__(self, tables, gamma, d_tables=None, n=None):
+        """tables: ten host arrays, or None with d_tables = ten device pointers of n entries each (copied into the session)"""
+        if d_tables is None:
+            assert len(tables) == 10
+            self._s = lib.ProductSumcheckSession.open(tables)
+        else:
+            assert len(d_tables) == 10
+            self._s = lib.ProductSumcheckSession.open_dev(d_tables, n)
         g = fr_to_int(gamma)
         w_right = np.stack([fr_from_int(1), fr_from_int(g * g % R_MOD)])  # eq_outer + gamma^2 eq_product
         w_left = np.stack([fr_from_int(g), fr_from_int(g * g * g % R_MOD)])  # gamma times the same weight
@@ -1635,9 +1640,35 @@ def _evaluate_mle_low(table, point):
     return t[0]
 
 
-def _pad_pow2(col, n):
-    out = np.zeros((n, 4), dtype=np.uint64)
-    out[:col.shape[0]] = col
+def _witness_maps_dev(d_rows, n_rows, n_pad, maps):
+    """cycle-length tables that are affine maps of the witness rows, built in HBM: maps = rows of NUM_R1CS_INPUTS + 1 canonical integers
+    (the constant last; a plain column is a single 1) -> (DeviceBuffer holding len(maps) tables of n_pad entries, their device pointers).
+    zg_fr_rows_affine_dev takes at most 16 maps per launch."""
+    buf = lib.DeviceBuffer(len(maps) * n_pad * 32)
+    ptrs = [buf.ptr + i * n_pad * 32 for i in range(len(maps))]
+    for a in range(0, len(maps), 16):
+        part = maps[a:a + 16]
+        coeffs = np.stack([np.stack([fr_from_int(x) for x in row]) for row in part])
+        lib.fr_rows_affine_dev(d_rows, n_rows, NUM_R1CS_INPUTS, coeffs, len(part), 1, n_pad, ptrs[a:a + 16])
+    return buf, ptrs
+
+
+def _column_map(name):
+    m = [0] * (NUM_R1CS_INPUTS + 1)
+    m[_I[name]] = 1
+    return m
+
+
+def _colsum_dev(d_table, rows, cols, weights):
+    """zg_fr_weighted_colsum_dev with host weights in and the (m, cols, 4) sums out (sqrt(T)-sized both)"""
+    weights = np.ascontiguousarray(weights, dtype=np.uint64)
+    m = weights.size // (4 * rows)
+    d_w, d_o = lib.DeviceBuffer.from_host(weights), lib.DeviceBuffer(m * cols * 32)
+    lib.fr_weighted_colsum_dev(d_table, rows, cols, d_w.ptr, m, d_o.ptr)
+    lib.sync()
+    out = d_o.to_host().reshape(m, cols, 4)
+    d_w.free()
+    d_o.free()
     return out
 
 
@@ -1652,12 +1683,19 @@ class ShiftPrefixSuffixProver:
     second phase are prefix evaluations times the suffix tables (:1560-1610), sqrt(T) entries."""
     COLS = ("UnexpandedPC", "PC", "FlagVirtualInstruction", "FlagIsFirstInSequence", "FlagIsNoop")
 
-    def __init__(self, cycle_witnesses, r_outer, r_product, gamma_powers):
-        w = np.ascontiguousarray(cycle_witnesses, dtype=np.uint64).reshape(-1, NUM_R1CS_INPUTS, 4)
+    def __init__(self, cycle_witnesses, r_outer, r_product, gamma_powers, d_rows=None):
+        """cycle_witnesses: the padded trace's (2^n, 43, 4) R1CS inputs in host memory, or None with d_rows = the same matrix already in
+        HBM (Stage 1's upload: StreamingOuterProver keeps it)"""
         r_outer = np.ascontiguousarray(r_outer, dtype=np.uint64).reshape(-1, 4)
         r_product = np.ascontiguousarray(r_product, dtype=np.uint64).reshape(-1, 4)
         n = r_outer.shape[0]
-        assert n >= 2 and r_product.shape[0] == n and w.shape[0] == (1 << n)  # the padded trace, as generateStage3Proof receives it
+        assert n >= 2 and r_product.shape[0] == n
+        own = None
+        if d_rows is None:
+            w = np.ascontiguousarray(cycle_witnesses, dtype=np.uint64).reshape(-1, NUM_R1CS_INPUTS, 4)
+            assert w.shape[0] == (1 << n)  # the padded trace, as generateStage3Proof receives it
+            own = lib.DeviceBuffer.from_host(w)
+            d_rows = own.ptr
         self.gamma_powers = np.ascontiguousarray(gamma_powers, dtype=np.uint64).reshape(5, 4).copy()
         g = [fr_to_int(x) for x in self.gamma_powers]
         self.suffix_n_vars = n // 2
@@ -1668,13 +1706,16 @@ class ShiftPrefixSuffixProver:
         for c, k in zip(self.COLS[:4], (1, g[1], g[2], g[3])):
             m[0][_I[c]] = k
         m[1][_I["FlagIsNoop"]], m[1][NUM_R1CS_INPUTS] = (-g[4]) % R_MOD, g[4]  # g^4 (1 - noop): the reference scales the sum, the same value
-        coeffs = np.stack([np.stack([fr_from_int(x) for x in row]) for row in m])
-        v, omn = lib.fr_rows_affine(w, coeffs, 2, 1, n_pad=1 << n)
-        # cycles past the trace contribute nothing (:1075): zg_fr_rows_affine writes zeros there, the map's constant included
-        q_o = lib.fr_weighted_colsum(v, ss, ps, np.stack([self._eq[0].suffix_0, self._eq[0].suffix_1]))
-        q_p = lib.fr_weighted_colsum(omn, ss, ps, np.stack([self._eq[1].suffix_0, self._eq[1].suffix_1]))
+        N = 1 << n
+        buf, ptrs = _witness_maps_dev(d_rows, N, N, m + [_column_map(c) for c in self.COLS])  # v, g^4 (1 - noop), the five columns
+        q_o = _colsum_dev(ptrs[0], ss, ps, np.stack([self._eq[0].suffix_0, self._eq[0].suffix_1]))
+        q_p = _colsum_dev(ptrs[1], ss, ps, np.stack([self._eq[1].suffix_0, self._eq[1].suffix_1]))
         self._rounds = ShiftSumcheckRounds([self._eq[0].prefix_0, q_o[0], self._eq[0].prefix_1, q_o[1], self._eq[1].prefix_0, q_p[0], self._eq[1].prefix_1, q_p[1]])
-        self._wit = lib.ProductSumcheckSession.open([_pad_pow2(np.ascontiguousarray(w[:, _I[c]]), 1 << n) for c in self.COLS])
+        self._wit = lib.ProductSumcheckSession.open_dev(ptrs[2:], N)
+        lib.sync()
+        buf.free()
+        if own is not None:
+            own.free()
         self.current_prefix_size, self.in_phase2, self.sumcheck_challenges = ps, False, []
 
     def computeRoundEvals(self, previous_claim):
@@ -1697,8 +1738,10 @@ class ShiftPrefixSuffixProver:
         """transitionToPhase2 (:1506-1700)"""
         tabs = []
         for e in self._eq:
-            e0, e1 = fr_to_int(_evaluate_mle_low(e.prefix_0, self.sumcheck_challenges)), fr_to_int(_evaluate_mle_low(e.prefix_1, self.sumcheck_challenges))
-            tabs.append(np.stack([fr_from_int((e0 * fr_to_int(a) + e1 * fr_to_int(b)) % R_MOD) for a, b in zip(e.suffix_0, e.suffix_1)]))
+            e0, e1 = _evaluate_mle_low(e.prefix_0, self.sumcheck_challenges), _evaluate_mle_low(e.prefix_1, self.sumcheck_challenges)
+            ss = e.suffix_0.shape[0]
+            tabs.append(lib.field_op(lib.FR, lib.OP_ADD, lib.field_op(lib.FR, lib.OP_MUL, np.tile(e0, (ss, 1)), e.suffix_0),
+                                     lib.field_op(lib.FR, lib.OP_MUL, np.tile(e1, (ss, 1)), e.suffix_1)))
         wit = [self._wit.read(j) for j in range(5)]
         self._wit.close()
         self._wit = None
@@ -1723,11 +1766,16 @@ class RegistersPrefixSuffixProver:
     round 0, as the reference folds them (:2404-2416); the second phase's eq table is eq(r_lo, reversed prefix challenges) * eq(r_hi, .)
     (:2427-2466)."""
 
-    def __init__(self, cycle_witnesses, r_spartan, gamma):
-        w = np.ascontiguousarray(cycle_witnesses, dtype=np.uint64).reshape(-1, NUM_R1CS_INPUTS, 4)
+    def __init__(self, cycle_witnesses, r_spartan, gamma, d_rows=None):
         r = np.ascontiguousarray(r_spartan, dtype=np.uint64).reshape(-1, 4)
         n = r.shape[0]
-        assert n >= 2 and w.shape[0] == (1 << n)  # the padded trace (the reference's own fold of an unpadded witness table drops odd tails)
+        assert n >= 2
+        own = None
+        if d_rows is None:
+            w = np.ascontiguousarray(cycle_witnesses, dtype=np.uint64).reshape(-1, NUM_R1CS_INPUTS, 4)
+            assert w.shape[0] == (1 << n)  # the padded trace (the reference's own fold of an unpadded witness table drops odd tails)
+            own = lib.DeviceBuffer.from_host(w)
+            d_rows = own.ptr
         split = n // 2
         self.r_hi, self.r_lo = r[:split].copy(), r[split:].copy()
         ps, ss = 1 << (n - split), 1 << split
@@ -1735,10 +1783,15 @@ class RegistersPrefixSuffixProver:
         g = fr_to_int(self.gamma)
         m = [0] * (NUM_R1CS_INPUTS + 1)
         m[_I["RdWriteValue"]], m[_I["Rs1Value"]], m[_I["Rs2Value"]] = 1, g, g * g % R_MOD
-        (v,) = lib.fr_rows_affine(w, np.stack([fr_from_int(x) for x in m]).reshape(1, NUM_R1CS_INPUTS + 1, 4), 1, 1, n_pad=1 << n)
-        q = lib.fr_weighted_colsum(v, ss, ps, lib.fr_eq_table(self.r_hi).reshape(1, ss, 4))[0]
+        N = 1 << n
+        buf, ptrs = _witness_maps_dev(d_rows, N, N, [m] + [_column_map(c) for c in ("RdWriteValue", "Rs1Value", "Rs2Value")])
+        q = _colsum_dev(ptrs[0], ss, ps, lib.fr_eq_table(self.r_hi).reshape(1, ss, 4))[0]
         self._rounds = RegistersClaimReductionRounds([lib.fr_eq_table(self.r_lo), q], self.gamma)
-        self._wit = lib.ProductSumcheckSession.open([_pad_pow2(np.ascontiguousarray(w[:, _I[c]]), 1 << n) for c in ("RdWriteValue", "Rs1Value", "Rs2Value")])
+        self._wit = lib.ProductSumcheckSession.open_dev(ptrs[1:], N)
+        lib.sync()
+        buf.free()
+        if own is not None:
+            own.free()
         self.current_prefix_size, self.in_phase2, self.prefix_challenges = ps, False, []
 
     def computeRoundEvals(self, previous_claim):
@@ -1758,7 +1811,8 @@ class RegistersPrefixSuffixProver:
             e = 1  # EqPolynomial(r_lo).evaluate(reversed prefix challenges)
             for a, b in zip((fr_to_int(x) for x in self.r_lo), (fr_to_int(x) for x in self.prefix_challenges[::-1])):
                 e = e * ((a * b + (1 - a) * (1 - b)) % R_MOD) % R_MOD
-            eq2 = np.stack([fr_from_int(fr_to_int(x) * e % R_MOD) for x in lib.fr_eq_table(self.r_hi)])
+            suffix = lib.fr_eq_table(self.r_hi)
+            eq2 = lib.field_op(lib.FR, lib.OP_MUL, np.tile(fr_from_int(e), (suffix.shape[0], 1)), suffix)
             wit = [self._wit.read(j) for j in range(3)]
             self._wit.close()
             self._wit = None
@@ -1781,14 +1835,31 @@ class Stage3Prover:
     every instance's claim from its own polynomial (evalsToCoeffs / evaluatePolyAtPoint, :846-926). The transcript stays the caller's:
     computeRoundPolynomial() -> compressed, bindChallenge(r_j)."""
 
-    def __init__(self, cycle_witnesses, r_outer, r_product, shift_gamma_powers, instr_gamma, reg_gamma, input_claims, batching_coeffs):
-        w = np.ascontiguousarray(cycle_witnesses, dtype=np.uint64).reshape(-1, NUM_R1CS_INPUTS, 4)
-        n = np.ascontiguousarray(r_outer, dtype=np.uint64).reshape(-1, 4).shape[0]
-        self.shift = ShiftPrefixSuffixProver(w, r_outer, r_product, shift_gamma_powers)
-        self.reg = RegistersPrefixSuffixProver(w, r_outer, reg_gamma)
-        cols = [_pad_pow2(np.ascontiguousarray(w[:, _I[c]]), 1 << n) for c in ("FlagLeftOperandIsRs1", "Rs1Value", "FlagLeftOperandIsPC", "UnexpandedPC",
-                                                                                "FlagRightOperandIsRs2", "Rs2Value", "FlagRightOperandIsImm", "Imm")]
-        self.instr = InstructionInputProver(cols + [lib.fr_eq_table(r_outer), lib.fr_eq_table(r_product)], instr_gamma)
+    def __init__(self, cycle_witnesses, r_outer, r_product, shift_gamma_powers, instr_gamma, reg_gamma, input_claims, batching_coeffs, d_rows=None):
+        """the witness matrix is uploaded once (or taken from HBM: d_rows) and read by all three instances"""
+        r_outer = np.ascontiguousarray(r_outer, dtype=np.uint64).reshape(-1, 4)
+        r_product = np.ascontiguousarray(r_product, dtype=np.uint64).reshape(-1, 4)
+        n = r_outer.shape[0]
+        N = 1 << n
+        own = None
+        if d_rows is None:
+            w = np.ascontiguousarray(cycle_witnesses, dtype=np.uint64).reshape(-1, NUM_R1CS_INPUTS, 4)
+            assert w.shape[0] == N
+            own = lib.DeviceBuffer.from_host(w)
+            d_rows = own.ptr
+        self.shift = ShiftPrefixSuffixProver(None, r_outer, r_product, shift_gamma_powers, d_rows=d_rows)
+        self.reg = RegistersPrefixSuffixProver(None, r_outer, reg_gamma, d_rows=d_rows)
+        buf, ptrs = _witness_maps_dev(d_rows, N, N, [_column_map(c) for c in ("FlagLeftOperandIsRs1", "Rs1Value", "FlagLeftOperandIsPC", "UnexpandedPC",
+                                                                                "FlagRightOperandIsRs2", "Rs2Value", "FlagRightOperandIsImm", "Imm")])
+        d_eq = lib.DeviceBuffer(2 * N * 32)
+        lib.fr_eq_table_dev(r_outer, d_eq.ptr)
+        lib.fr_eq_table_dev(r_product, d_eq.ptr + N * 32)
+        lib.sync()
+        self.instr = InstructionInputProver(None, instr_gamma, d_tables=ptrs + [d_eq.ptr, d_eq.ptr + N * 32], n=N)
+        lib.sync()
+        for b in (buf, d_eq, own):
+            if b is not None:
+                b.free()
         self.claims = [fr_to_int(c) for c in np.ascontiguousarray(input_claims, dtype=np.uint64).reshape(3, 4)]  # shift, instruction input, registers
         self.coeffs = [fr_to_int(c) for c in np.ascontiguousarray(batching_coeffs, dtype=np.uint64).reshape(3, 4)]
         self.combined_claim = sum(c * k for c, k in zip(self.claims, self.coeffs)) % R_MOD
