@@ -709,11 +709,63 @@ static int outer_main(const char *path) {
     return 0;
 }
 
+// `test_host_mirror stage3 <file>`: zolt::Stage3Prover on the instance the file describes (written by tests/test_gpu_cpp_host.py): n, the
+// five shift gamma powers, the two other gammas, three input claims, three batching coefficients, r_outer, r_product, the 2^n x 43 witness
+// matrix, n challenges -> per round ShiftSumcheck's three evaluations (S), the compressed combined polynomial (P), the claims after the
+// challenge (C: shift, instruction input, registers, combined); then the final claims of ShiftSumcheck (F) and RegistersClaimReduction (G)
+static int stage3_main(const char *path) {
+    std::FILE *f = std::fopen(path, "r");
+    if (!f) { std::printf("cannot open %s\n", path); return 2; }
+    unsigned long long n;
+    if (std::fscanf(f, "%llu", &n) != 1) return 2;
+    std::vector<Fr> sg;
+    for (int i = 0; i < 5; i++) sg.push_back(read_fr(f));
+    Fr ig = read_fr(f), rg = read_fr(f);
+    std::array<Fr, 3> claims, coeffs;
+    for (auto &x : claims) x = read_fr(f);
+    for (auto &x : coeffs) x = read_fr(f);
+    std::vector<Fr> ro, rp, w, ch;
+    for (size_t i = 0; i < n; i++) ro.push_back(read_fr(f));
+    for (size_t i = 0; i < n; i++) rp.push_back(read_fr(f));
+    const size_t N = size_t(1) << n;
+    w.reserve(N * 43);
+    for (size_t i = 0; i < N * 43; i++) w.push_back(read_fr(f));
+    for (size_t i = 0; i < n; i++) ch.push_back(read_fr(f));
+    std::fclose(f);
+    DeviceMem d_rows(N * 43 * 32);
+    check(zg_memcpy_h2d(d_rows.p, w.data(), N * 43 * 32), "zg_memcpy_h2d");
+    Stage3Prover p(d_rows.u64(), ro, rp, sg, ig, rg, claims, coeffs);
+    for (size_t rd = 0; rd < n; rd++) {
+        auto comp = p.computeRoundPolynomial();
+        std::printf("S");
+        for (const Fr &x : p.roundEvals(0)) print_fr(x);
+        std::printf("\nP");
+        for (const Fr &x : comp) print_fr(x);
+        p.bindChallenge(ch[rd]);
+        std::printf("\nC");
+        for (const Fr &x : p.claims) print_fr(x);
+        print_fr(p.combined_claim);
+        std::printf("\n");
+    }
+    std::printf("F");
+    for (const Fr &x : p.shift.finalClaims()) print_fr(x);
+    std::printf("\nG");
+    for (const Fr &x : p.reg.finalClaims()) print_fr(x);
+    std::printf("\n");
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (zg_init(0) != ZG_OK) { std::printf("zg_init failed: %s\n", zg_last_error()); return 2; }
     if (argc >= 3 && !std::strcmp(argv[1], "outer")) {
         int rc;
         try { rc = outer_main(argv[2]); } catch (const std::exception &e) { std::printf("EXCEPTION: %s\n", e.what()); rc = 3; }
+        zg_shutdown();
+        return rc;
+    }
+    if (argc >= 3 && !std::strcmp(argv[1], "stage3")) {
+        int rc;
+        try { rc = stage3_main(argv[2]); } catch (const std::exception &e) { std::printf("EXCEPTION: %s\n", e.what()); rc = 3; }
         zg_shutdown();
         return rc;
     }

@@ -242,3 +242,61 @@ def test_cpp_original_stage4_prover_mirror(tmp_path):
         want = [fc["val_claim"], fc["rs1_ra_claim"], fc["rs2_ra_claim"], fc["rd_wa_claim"], fc["inc_claim"], claim]
         assert all(np.array_equal(fin[i], w) for i, w in enumerate(want)), k
         assert np.array_equal(o.finalCheck()[2], claim)
+
+
+@pytest.mark.gpu
+def test_cpp_stage3_mirror(tmp_path, golden_dir):
+    """zolt::Stage3Prover (compiled host code: ShiftPrefixSuffixProver / RegistersPrefixSuffixProver built from the witness matrix in HBM by
+    zg_fr_rows_affine_dev + zg_fr_weighted_colsum_dev, the InstructionInput session, the stage's batching loop) against the restatement of
+    src/zkvm/spartan/stage3_prover.zig: the captured run from the ELF (whose logged round polynomials the restatement reproduces) and
+    random witnesses with odd and even variable counts — ShiftSumcheck's evaluations, the compressed polynomial, the four claims of every
+    round and the final claims, bit for bit."""
+    import json
+    import numpy as np
+    from oracle import binding as ob
+    from tests import util as U
+    from tests import test_transcript_host as H
+    exe = os.path.join(ROOT, "tests", "cpp", "test_host_mirror")
+    subprocess.check_call(["make", "-C", os.path.dirname(exe), "test_host_mirror"])
+    P = ob._R_P
+    le = lambda h: int.from_bytes(bytes.fromhex(h), "little")
+    rnd = lambda seed, k: [ob.fr_to_int(x) for x in ob.f_to_mont(ob.FR, U.random_raw256(seed, k))]
+    for case, n in enumerate((8, 5, 6, 2)):
+        if case == 0:
+            s3, w, wm, ro, rp = H.stage3_inputs_of_the_captured_run(golden_dir)
+            g = int(s3["shift_gamma_be"], 16)
+            ig, rg = int(s3["instr_gamma_be"], 16), int(s3["reg_gamma_be"], 16)
+            claims = [le(h) for h in s3["input_claims"]]
+            coeffs = [int(h, 16) for h in s3["batching_coeffs_be"]]
+            ch = [le(r["challenge"]) for r in s3["rounds"]]
+        else:
+            T = 1 << n
+            wm = ob.f_to_mont(ob.FR, U.random_raw256(7000 + n, T * 43)).reshape(T, 43, 4)
+            w = [[ob.fr_to_int(x) for x in row] for row in wm]
+            ro, rp, ch = rnd(7100 + n, n), rnd(7200 + n, n), rnd(7300 + n, n)
+            g, ig, rg, *rest = rnd(7400 + n, 9)
+            claims, coeffs = rest[:3], rest[3:]
+        sg = [pow(g, i, P) for i in range(5)]
+        path = str(tmp_path / f"stage3_{case}.txt")
+        fi = ob.fr_from_int
+        with open(path, "w") as f:
+            f.write(f"{n}\n" + "".join(_hexfr(fi(x)) + "\n" for x in sg + [ig, rg] + claims + coeffs + ro + rp))
+            f.write("".join(_hexfr(x) + "\n" for x in wm.reshape(-1, 4)) + "".join(_hexfr(fi(x)) + "\n" for x in ch))
+        res = subprocess.run([exe, "stage3", path], capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+        parse = lambda tag, cnt: [[ob.fr_to_int(x) for x in np.array([int(v, 16) for v in l.split()[1:1 + 4 * cnt]], dtype=np.uint64).reshape(cnt, 4)]
+                                  for l in res.stdout.splitlines() if l.startswith(tag + " ")]
+        S, Pl, Cl = parse("S", 3), parse("P", 3), parse("C", 4)
+        b = ob.Stage3Batch(ob.Stage3ShiftProver(w, ro, rp, sg), ob.Stage3InstructionInputProver(w, ro, rp, ig), ob.Stage3RegistersProver(w, ro, rg), claims, coeffs)
+        assert len(S) == len(Pl) == len(Cl) == n
+        for k in range(n):
+            comp = b.computeRoundPolynomial()
+            assert S[k] == b.evals[0] and Pl[k] == comp, (case, k)
+            b.bindChallenge(ch[k])
+            assert Cl[k] == b.claims + [b.combined], (case, k)
+        sh, rgc = b.inst[0].finalClaims(), b.inst[2].finalClaims()
+        assert parse("F", 5)[0] == [sh[k] for k in ("unexpanded_pc", "pc", "is_virtual", "is_first_in_sequence", "is_noop")], case
+        assert parse("G", 3)[0] == [rgc[k] for k in ("rd_write_value", "rs1_value", "rs2_value")], case
+        if case == 0:  # and the reference's own printed values
+            assert Pl == [[le(r[c]) for c in ("c0", "c2", "c3")] for r in s3["rounds"]]
+            assert [c[3] for c in Cl] == [le(r["next_claim"]) for r in s3["rounds"]]

@@ -379,6 +379,44 @@ int main(int argc, char **argv) {
         std::printf("\"outer_log_t\": %zu, \"outer_upload_ms\": %.4f, \"outer_uniskip_first_round_ms\": %.4f, \"outer_materialize_ms\": %.4f, \"outer_rounds_ms\": %.4f, "
                     "\"outer_rounds_per_s\": %.1f, ", lt, t_up / no * 1e3, t_first / no * 1e3, t_mat / no * 1e3, t_rounds / no * 1e3, no * (double)(lt + 1) / t_rounds);
     }
+    // Stage 3 (src/zkvm/spartan/stage3_prover.zig): ShiftSumcheck + InstructionInput + RegistersClaimReduction over 2^min(v, 20) padded cycles,
+    // the witness matrix resident in HBM (Stage 1's upload): build of the three instances, then log T batched rounds with a Keccak transcript
+    {
+        const size_t lt = v > 20 ? 20 : (v < 2 ? 2 : (size_t)v), T3 = size_t(1) << lt;
+        std::vector<Fr> w(T3 * 43);
+        for (auto &x : w) x = Fr::fromU64(splitmix());
+        DeviceMem d_rows(T3 * 43 * 32);
+        check(zg_memcpy_h2d(d_rows.p, w.data(), T3 * 43 * 32), "h2d");
+        std::vector<Fr> ro(lt), rp(lt), sg(5);
+        for (auto &x : ro) x = Fr::fromU64(splitmix());
+        for (auto &x : rp) x = Fr::fromU64(splitmix());
+        Fr g = Fr::fromU64(splitmix());
+        sg[0] = Fr::one();
+        for (int i = 1; i < 5; i++) sg[i] = sg[i - 1].mul(g);
+        std::array<Fr, 3> cl = {Fr::fromU64(splitmix()), Fr::fromU64(splitmix()), Fr::fromU64(splitmix())}, co = cl;
+        double t_build = 0, t_rounds = 0;
+        const int n3 = reps > 3 ? 3 : reps;
+        for (int rep = -1; rep < n3; rep++) {
+            auto t0 = clk::now();
+            Stage3Prover p(d_rows.u64(), ro, rp, sg, g, sg[2], cl, co);
+            auto t1 = clk::now();
+            Transcript tr("Jolt");
+            for (size_t rd = 0; rd < lt; rd++) {
+                auto c = p.computeRoundPolynomial();
+                for (auto &e : c) tr.appendScalar("s3", e);
+                p.bindChallenge(tr.challengeScalar("s3_r"));
+            }
+            (void)p.shift.finalClaims();
+            (void)p.reg.finalClaims();
+            auto t2 = clk::now();
+            if (rep >= 0) {
+                t_build += std::chrono::duration<double>(t1 - t0).count();
+                t_rounds += std::chrono::duration<double>(t2 - t1).count();
+            }
+        }
+        std::printf("\"stage3_log_t\": %zu, \"stage3_build_ms\": %.4f, \"stage3_rounds_ms\": %.4f, \"stage3_rounds_per_s\": %.1f, ", lt, t_build / n3 * 1e3,
+                    t_rounds / n3 * 1e3, n3 * (double)lt / t_rounds);
+    }
     std::printf("\"val_evaluation_rounds_per_s\": %.1f, \"val_evaluation_ms\": %.4f, \"product_remainder_rounds_per_s\": %.1f, "
                 "\"product_remainder_ms\": %.4f, ", reps * v / t_val, t_val / reps * 1e3, reps * v / t_prod, t_prod / reps * 1e3);
     std::printf("\"lasso_log_K16_rounds_per_s\": %.1f, \"lasso_ms_whole_protocol_incl_setup\": %.4f, ", reps * (16 + v) / t_lasso, t_lasso / reps * 1e3);

@@ -29,5 +29,19 @@ cd $OUT
   echo "== HBM access-pattern calibration (tools/microbench gather|stream under --pmc FETCH_SIZE) =="
   grep -h "rows of 64 B" $OUT/cal_gather.log $OUT/cal_stream.log
 } > $OUT/summary.txt 2>&1
+# the metric's second size: kernel stats and HBM counters of the serial 2^22 bench (point slices: four accumulate launches per MSM)
+O22=$ROOT/gpurun_out/prof_${TAG}_2e22
+mkdir -p $O22
+cd /tmp
+B22="python3 $ROOT/bench.py --logn 22 --steps 3 --warmup 1 --msms-per-step 2 --streams 1 --no-cpu-baseline --no-extra"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O22/trace1 -- $B22 </dev/null > $O22/trace1.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O22/pmc_fetch -- $B22 </dev/null > $O22/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O22/pmc_write -- $B22 </dev/null > $O22/pmc_write.log 2>&1
+{
+  echo "# serial 2^22 bench command: $B22"; grep -h '^{' $O22/trace1.log | tail -1
+  python3 $ROOT/tools/summarize_prof.py $O22
+} > $O22/summary.txt 2>&1
+find $O22 -name "*.csv" -size +2M -delete
+cd $OUT
 find $OUT -name "*.csv" -size +2M -delete
 tail -c 600 $OUT/trace1.log

@@ -1146,6 +1146,281 @@ inline std::vector<Fr> eqPlusOneEvals(const std::vector<Fr> &r) {
     return out;
 }
 
+// ---- Stage 3 as a whole (src/zkvm/spartan/stage3_prover.zig). The witness matrix (cycle-major, 43 elements per padded cycle) is read
+// in HBM; cycle-length tables are affine maps of its rows (zg_fr_rows_affine_dev), the Q tables weighted column sums
+// (zg_fr_weighted_colsum_dev); prefix / suffix tables have sqrt(T) entries.
+namespace stage3 {
+constexpr size_t NUM_INPUTS = 43;
+// R1CSInputIndex (src/zkvm/r1cs/constraints.zig:39-92), the columns Stage 3 reads
+enum Input : size_t { PC = 6, UnexpandedPC = 7, Imm = 8, Rs1Value = 10, Rs2Value = 11, RdWriteValue = 12, FlagVirtualInstruction = 30,
+                      FlagIsFirstInSequence = 35, FlagIsNoop = 38, FlagLeftOperandIsRs1 = 39, FlagLeftOperandIsPC = 40,
+                      FlagRightOperandIsRs2 = 41, FlagRightOperandIsImm = 42 };
+using Map = std::vector<std::pair<size_t, Fr>>;  // (column, coefficient) terms; the constant rides at column NUM_INPUTS
+
+// tables (n entries each, back to back in `out`) = the maps applied to every row; at most 16 per launch
+inline void witnessMaps(const uint64_t *d_rows, size_t n, const std::vector<Map> &maps, DeviceMem &out, std::vector<const uint64_t *> &ptrs) {
+    out.alloc(maps.size() * n * 32);
+    ptrs.clear();
+    for (size_t i = 0; i < maps.size(); i++) ptrs.push_back(out.u64() + 4 * i * n);
+    for (size_t a = 0; a < maps.size(); a += 16) {
+        size_t cnt = std::min<size_t>(16, maps.size() - a);
+        std::vector<Fr> coeffs(cnt * (NUM_INPUTS + 1), Fr::zero());
+        for (size_t i = 0; i < cnt; i++)
+            for (auto &t : maps[a + i]) coeffs[i * (NUM_INPUTS + 1) + t.first] = t.second;
+        std::vector<uint64_t *> tabs;
+        for (size_t i = 0; i < cnt; i++) tabs.push_back(const_cast<uint64_t *>(ptrs[a + i]));
+        check(zg_fr_rows_affine_dev(d_rows, n, NUM_INPUTS, 0, reinterpret_cast<const uint64_t *>(coeffs.data()), cnt, 1, n, tabs.data(), nullptr),
+              "zg_fr_rows_affine_dev");
+    }
+}
+// out[k][c] = sum_r weights[k][r] * table[r * cols + c]; weights and sums travel through the host (sqrt(T) entries)
+inline std::vector<std::vector<Fr>> colsum(const uint64_t *d_table, size_t rows, size_t cols, const std::vector<const std::vector<Fr> *> &weights) {
+    const size_t m = weights.size();
+    std::vector<Fr> w(m * rows);
+    for (size_t k = 0; k < m; k++) std::copy(weights[k]->begin(), weights[k]->end(), w.begin() + k * rows);
+    DeviceMem d_w(m * rows * 32), d_o(m * cols * 32);
+    check(zg_memcpy_h2d(d_w.p, w.data(), m * rows * 32), "zg_memcpy_h2d");
+    check(zg_fr_weighted_colsum_dev(d_table, rows, cols, d_w.u64(), m, d_o.u64(), nullptr), "zg_fr_weighted_colsum_dev");
+    check(zg_sync(), "zg_sync");
+    std::vector<Fr> flat(m * cols);
+    check(zg_memcpy_d2h(flat.data(), d_o.p, m * cols * 32), "zg_memcpy_d2h");
+    std::vector<std::vector<Fr>> out(m);
+    for (size_t k = 0; k < m; k++) out[k].assign(flat.begin() + k * cols, flat.begin() + (k + 1) * cols);
+    return out;
+}
+inline Fr evaluateMle(std::vector<Fr> t, const std::vector<Fr> &point) {  // :1820-1838: the point's first entry binds the LOW index bit
+    for (const Fr &r : point) {
+        if (t.size() == 1) break;
+        std::vector<Fr> n(t.size() / 2);
+        for (size_t i = 0; i < n.size(); i++) n[i] = t[2 * i].add(r.mul(t[2 * i + 1].sub(t[2 * i])));
+        t.swap(n);
+    }
+    return t[0];
+}
+inline std::vector<Fr> readTable(ProductSumcheckSession &s, size_t table) {
+    std::vector<uint64_t> idx(s.len());
+    for (size_t i = 0; i < idx.size(); i++) idx[i] = i;
+    return s.gather(table, idx);
+}
+inline std::array<Fr, 4> evalsToCoeffs(const std::vector<Fr> &ev) {  // :846-901, degree 2 (three evaluations) or 3 (four)
+    Fr two_inv, six_inv;
+    Fr::fromU64(2).inverse(two_inv);
+    Fr::fromU64(6).inverse(six_inv);
+    if (ev.size() == 3) {
+        Fr c2 = ev[2].sub(ev[1].add(ev[1])).add(ev[0]).mul(two_inv);
+        return {ev[0], ev[1].sub(ev[0]).sub(c2), c2, Fr::zero()};
+    }
+    Fr d1 = ev[1].sub(ev[0]), d2 = ev[2].sub(ev[1]), d3 = ev[3].sub(ev[2]);
+    Fr dd1 = d2.sub(d1), dd2 = d3.sub(d2), c3 = dd2.sub(dd1).mul(six_inv);
+    Fr c2 = dd1.mul(two_inv).sub(c3.mul(Fr::fromU64(3)));
+    return {ev[0], d1.sub(c2).sub(c3), c2, c3};
+}
+inline Fr polyAt(const std::array<Fr, 4> &c, const Fr &x) { return c[0].add(x.mul(c[1].add(x.mul(c[2].add(x.mul(c[3])))))); }
+}  // namespace stage3
+
+class ShiftPrefixSuffixProver {  // :928-1919
+public:
+    ShiftPrefixSuffixProver(const uint64_t *d_rows, const std::vector<Fr> &r_outer, const std::vector<Fr> &r_product, const std::vector<Fr> &gamma_powers)
+        : g_(gamma_powers) {
+        using namespace stage3;
+        const size_t n = r_outer.size(), split = n / 2, N = size_t(1) << n;
+        if (n < 2 || r_product.size() != n || g_.size() != 5) throw std::invalid_argument("ShiftPrefixSuffixProver: n >= 2, five gamma powers");
+        prefix_size_ = size_t(1) << (n - split);
+        const size_t ss = size_t(1) << split;
+        for (const auto *r : {&r_outer, &r_product}) {  // EqPlusOnePrefixSuffixPoly: PREFIX uses r_lo, SUFFIX uses r_hi
+            std::vector<Fr> hi(r->begin(), r->begin() + split), lo(r->begin() + split, r->end());
+            Fr is_max = Fr::one();
+            for (const Fr &x : lo) is_max = is_max.mul(x);
+            std::vector<Fr> p1(prefix_size_, Fr::zero());
+            p1[0] = is_max;
+            prefix_0_.push_back(eqPlusOneEvals(lo));
+            prefix_1_.push_back(p1);
+            suffix_0_.push_back(EqPolynomial(hi).evals());
+            suffix_1_.push_back(eqPlusOneEvals(hi));
+        }
+        std::vector<Map> maps = {{{UnexpandedPC, Fr::one()}, {PC, g_[1]}, {FlagVirtualInstruction, g_[2]}, {FlagIsFirstInSequence, g_[3]}},
+                                 {{FlagIsNoop, Fr::zero().sub(g_[4])}, {NUM_INPUTS, g_[4]}}};
+        for (size_t c : {UnexpandedPC, PC, FlagVirtualInstruction, FlagIsFirstInSequence, FlagIsNoop}) maps.push_back({{c, Fr::one()}});
+        DeviceMem buf;
+        std::vector<const uint64_t *> ptrs;
+        witnessMaps(d_rows, N, maps, buf, ptrs);
+        auto qo = colsum(ptrs[0], ss, prefix_size_, {&suffix_0_[0], &suffix_1_[0]});
+        auto qp = colsum(ptrs[1], ss, prefix_size_, {&suffix_0_[1], &suffix_1_[1]});
+        rounds_.reset(new ProductSumcheckSession({&prefix_0_[0], &qo[0], &prefix_1_[0], &qo[1], &prefix_0_[1], &qp[0], &prefix_1_[1], &qp[1]}));
+        rounds_->setPoints(0b0111);
+        wit_.reset(new ProductSumcheckSession(ProductSumcheckSession::OnDevice{}, std::vector<const uint64_t *>(ptrs.begin() + 2, ptrs.end()), N));
+        check(zg_sync(), "zg_sync");
+    }
+    std::array<Fr, 3> computeRoundEvals(const Fr &previous_claim) {
+        if (!in_phase2_) {  // :1351-1392: p(0), p(1), p(2) all from the tables
+            auto ev = rounds_->roundExpr({{{0, 1, 2, 3}, {}, {}, true}, {{4, 5, 6, 7}, {}, {}, true}});
+            return {ev[0], ev[1], ev[2]};
+        }
+        Fr neg_g4 = Fr::zero().sub(g_[4]);  // :1399-1455: eq_outer * val + gamma^4 eq_prod - gamma^4 noop eq_prod
+        auto ev = rounds_->roundExpr({{{0}, {2, 3, 4, 5}, {Fr::one(), g_[1], g_[2], g_[3]}, false}, {{}, {1}, {g_[4]}, false}, {{6}, {1}, {neg_g4}, false}});
+        return {ev[0], previous_claim.sub(ev[0]), ev[2]};
+    }
+    void bind(const Fr &r_j) {  // :1458-1472
+        rounds_->bind(r_j);
+        if (in_phase2_) return;
+        const bool transition = prefix_size_ == 2;
+        wit_->bind(r_j);
+        challenges_.push_back(r_j);
+        prefix_size_ /= 2;
+        if (!transition) return;
+        std::vector<std::vector<Fr>> tabs;  // transitionToPhase2 (:1506-1700)
+        for (size_t k = 0; k < 2; k++) {
+            Fr e0 = stage3::evaluateMle(prefix_0_[k], challenges_), e1 = stage3::evaluateMle(prefix_1_[k], challenges_);
+            std::vector<Fr> t(suffix_0_[k].size());
+            for (size_t j = 0; j < t.size(); j++) t[j] = e0.mul(suffix_0_[k][j]).add(e1.mul(suffix_1_[k][j]));
+            tabs.push_back(std::move(t));
+        }
+        for (size_t c = 0; c < 5; c++) tabs.push_back(stage3::readTable(*wit_, c));  // folded on the device since round 0
+        wit_.reset();
+        std::vector<const std::vector<Fr> *> tp;
+        for (auto &t : tabs) tp.push_back(&t);
+        rounds_.reset(new ProductSumcheckSession(tp));
+        rounds_->setPoints(0b0101);
+        in_phase2_ = true;
+    }
+    std::vector<Fr> finalClaims() {  // unexpanded_pc, pc, is_virtual, is_first_in_sequence, is_noop (:1860-1876)
+        auto f = rounds_->final();
+        return std::vector<Fr>(f.begin() + 2, f.end());
+    }
+
+private:
+    std::vector<Fr> g_, challenges_;
+    std::vector<std::vector<Fr>> prefix_0_, prefix_1_, suffix_0_, suffix_1_;
+    std::unique_ptr<ProductSumcheckSession> rounds_, wit_;
+    size_t prefix_size_ = 0;
+    bool in_phase2_ = false;
+};
+
+class RegistersPrefixSuffixProver {  // :2156-2495
+public:
+    RegistersPrefixSuffixProver(const uint64_t *d_rows, const std::vector<Fr> &r_spartan, const Fr &gamma) : gamma_(gamma) {
+        using namespace stage3;
+        const size_t n = r_spartan.size(), split = n / 2, N = size_t(1) << n;
+        if (n < 2) throw std::invalid_argument("RegistersPrefixSuffixProver: n >= 2");
+        r_hi_.assign(r_spartan.begin(), r_spartan.begin() + split);
+        r_lo_.assign(r_spartan.begin() + split, r_spartan.end());
+        prefix_size_ = size_t(1) << (n - split);
+        std::vector<Map> maps = {{{RdWriteValue, Fr::one()}, {Rs1Value, gamma}, {Rs2Value, gamma.mul(gamma)}}};
+        for (size_t c : {RdWriteValue, Rs1Value, Rs2Value}) maps.push_back({{c, Fr::one()}});
+        DeviceMem buf;
+        std::vector<const uint64_t *> ptrs;
+        witnessMaps(d_rows, N, maps, buf, ptrs);
+        std::vector<Fr> suffix = EqPolynomial(r_hi_).evals(), P = EqPolynomial(r_lo_).evals();
+        auto q = colsum(ptrs[0], suffix.size(), prefix_size_, {&suffix});
+        rounds_.reset(new ProductSumcheckSession({&P, &q[0]}));
+        rounds_->setPoints(0b0101);
+        wit_.reset(new ProductSumcheckSession(ProductSumcheckSession::OnDevice{}, std::vector<const uint64_t *>(ptrs.begin() + 1, ptrs.end()), N));
+        check(zg_sync(), "zg_sync");
+    }
+    std::array<Fr, 3> computeRoundEvals(const Fr &previous_claim) {  // [p(0), claim - p(0), p(2)] (:2334-2389)
+        auto ev = in_phase2_ ? rounds_->roundEvals({0}, {1, 2, 3}, {Fr::one(), gamma_, gamma_.mul(gamma_)}) : rounds_->roundEvals({0, 1});
+        return {ev[0], previous_claim.sub(ev[0]), ev[2]};
+    }
+    void bind(const Fr &r_j) {  // :2388-2398
+        rounds_->bind(r_j);
+        if (in_phase2_) return;
+        const bool transition = prefix_size_ == 2;
+        wit_->bind(r_j);
+        challenges_.push_back(r_j);
+        prefix_size_ /= 2;
+        if (!transition) return;
+        std::vector<Fr> rev(challenges_.rbegin(), challenges_.rend());  // :2427-2466
+        Fr e = EqPolynomial::mle(r_lo_, rev);
+        std::vector<std::vector<Fr>> tabs = {EqPolynomial(r_hi_).evals()};
+        for (Fr &x : tabs[0]) x = x.mul(e);
+        for (size_t c = 0; c < 3; c++) tabs.push_back(stage3::readTable(*wit_, c));
+        wit_.reset();
+        std::vector<const std::vector<Fr> *> tp;
+        for (auto &t : tabs) tp.push_back(&t);
+        rounds_.reset(new ProductSumcheckSession(tp));
+        rounds_->setPoints(0b0101);
+        in_phase2_ = true;
+    }
+    std::vector<Fr> finalClaims() {  // rd_write_value, rs1_value, rs2_value (:2483-2494)
+        auto f = rounds_->final();
+        return std::vector<Fr>(f.begin() + 1, f.end());
+    }
+
+private:
+    Fr gamma_;
+    std::vector<Fr> r_hi_, r_lo_, challenges_;
+    std::unique_ptr<ProductSumcheckSession> rounds_, wit_;
+    size_t prefix_size_ = 0;
+    bool in_phase2_ = false;
+};
+
+// the round loop of Stage3Prover.generateStage3Proof (:327-560) over the three instances; the transcript stays the caller's
+class Stage3Prover {
+public:
+    Stage3Prover(const uint64_t *d_rows, const std::vector<Fr> &r_outer, const std::vector<Fr> &r_product, const std::vector<Fr> &shift_gamma_powers,
+                 const Fr &instr_gamma, const Fr &reg_gamma, const std::array<Fr, 3> &input_claims, const std::array<Fr, 3> &batching_coeffs)
+        : shift(d_rows, r_outer, r_product, shift_gamma_powers), reg(d_rows, r_outer, reg_gamma), claims(input_claims), coeffs_(batching_coeffs) {
+        using namespace stage3;
+        const size_t N = size_t(1) << r_outer.size();
+        std::vector<Map> maps;
+        for (size_t c : {FlagLeftOperandIsRs1, Rs1Value, FlagLeftOperandIsPC, UnexpandedPC, FlagRightOperandIsRs2, Rs2Value, FlagRightOperandIsImm, Imm})
+            maps.push_back({{c, Fr::one()}});
+        DeviceMem buf, d_eq(2 * N * 32);
+        std::vector<const uint64_t *> ptrs;
+        witnessMaps(d_rows, N, maps, buf, ptrs);
+        check(zg_fr_eq_table_dev(reinterpret_cast<const uint64_t *>(r_outer.data()), r_outer.size(), nullptr, d_eq.u64(), nullptr), "zg_fr_eq_table_dev");
+        check(zg_fr_eq_table_dev(reinterpret_cast<const uint64_t *>(r_product.data()), r_product.size(), nullptr, d_eq.u64() + 4 * N, nullptr), "zg_fr_eq_table_dev");
+        check(zg_sync(), "zg_sync");
+        ptrs.push_back(d_eq.u64());
+        ptrs.push_back(d_eq.u64() + 4 * N);
+        instr_.reset(new ProductSumcheckSession(ProductSumcheckSession::OnDevice{}, ptrs, N));
+        check(zg_sync(), "zg_sync");
+        Fr g2 = instr_gamma.mul(instr_gamma);
+        instr_terms_ = {{{4, 5, 6, 7}, {8, 9}, {Fr::one(), g2}, true}, {{0, 1, 2, 3}, {8, 9}, {instr_gamma, g2.mul(instr_gamma)}, true}};
+        instr_->setPoints(0b1101);
+        combined_claim = claims[0].mul(coeffs_[0]).add(claims[1].mul(coeffs_[1])).add(claims[2].mul(coeffs_[2]));
+    }
+    std::array<Fr, 3> computeRoundPolynomial() {  // (c0, c2, c3) of the combined cubic (:333-445)
+        auto s = shift.computeRoundEvals(claims[0]);
+        auto iv = instr_->roundExpr(instr_terms_);
+        auto r = reg.computeRoundEvals(claims[2]);
+        evals_[0] = {s[0], s[1], s[2]};
+        evals_[1] = {iv[0], claims[1].sub(iv[0]), iv[2], iv[3]};
+        evals_[2] = {r[0], r[1], r[2]};
+        std::array<Fr, 4> comb;
+        Fr three = Fr::fromU64(3);
+        for (size_t i = 0; i < 4; i++) {
+            comb[i] = Fr::zero();
+            for (size_t k = 0; k < 3; k++) {
+                const auto &e = evals_[k];
+                Fr v = i < e.size() ? e[i] : e[2].mul(three).sub(e[1].mul(three)).add(e[0]);  // a quadratic at 3 (:415-417)
+                comb[i] = comb[i].add(v.mul(coeffs_[k]));
+            }
+        }
+        combined_coeffs_ = stage3::evalsToCoeffs(std::vector<Fr>(comb.begin(), comb.end()));
+        return {combined_coeffs_[0], combined_coeffs_[2], combined_coeffs_[3]};
+    }
+    void bindChallenge(const Fr &r_j) {  // :458-490
+        combined_claim = stage3::polyAt(combined_coeffs_, r_j);
+        for (size_t k = 0; k < 3; k++) claims[k] = stage3::polyAt(stage3::evalsToCoeffs(evals_[k]), r_j);
+        shift.bind(r_j);
+        instr_->bind(r_j);
+        reg.bind(r_j);
+    }
+    const std::vector<Fr> &roundEvals(size_t k) const { return evals_[k]; }
+    ShiftPrefixSuffixProver shift;
+    RegistersPrefixSuffixProver reg;
+    std::array<Fr, 3> claims;  // shift, instruction input, registers
+    Fr combined_claim;
+
+private:
+    std::array<Fr, 3> coeffs_;
+    std::unique_ptr<ProductSumcheckSession> instr_;
+    std::vector<ProductSumcheckSession::Term> instr_terms_;
+    std::array<std::vector<Fr>, 3> evals_;
+    std::array<Fr, 4> combined_coeffs_;
+};
+
 // OutputSumcheckProver's loop (src/zkvm/ram/output_check.zig:375-499): eq * io_mask * (val_final - val_io); val_init folded alongside
 class OutputSumcheckProver {
 public:
