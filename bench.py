@@ -34,10 +34,11 @@ sys.path.insert(0, ROOT)
 # with the kernel's load shape report 1.04x their bytes (no correction), a sequential 16 B/lane stream reports 0.50x (the gfx950
 # x2 of MI355X_MICROARCH.md). The launch gathers 15.7M rows (1.007 GB, taken as counted) and streams 63 MB of sorted
 # references (counted at half: +31 MB).
-MEASURED_TRAFFIC = {20: 1256199.3 * 1024.0 + 0.5 * 4.0 * 15.73e6 + 28690.0 * 1024.0}
+MEASURED_TRAFFIC = {20: 1222851.1 * 1024.0 + 0.5 * 4.0 * 15.73e6 + 28689.5 * 1024.0}
 TRAFFIC_SOURCE = ("rocprofv3 PMC FETCH_SIZE (+x2 on the streamed 63 MB of sorted references, x1 on the gathered 64-byte rows: calibrated with "
-                  "tools/microbench gather|stream) + WRITE_SIZE, profiles/r3z_rocprofv3_summary.txt: FETCH_SIZE 1,256,199 KB, WRITE_SIZE 28,690 KB per launch "
-                  "(r3a: 1,314,038 KB; round 2 r2a/r2e: 1,248,779 / 1,253,897 KB)")
+                  "tools/microbench gather|stream) + WRITE_SIZE, profiles/r3final_rocprofv3_summary.txt: FETCH_SIZE 1,222,851 KB, WRITE_SIZE 28,690 KB per launch "
+                  "(r3z: 1,256,199 KB, r3a: 1,314,038 KB; round 2 r2a/r2e: 1,248,779 / 1,253,897 KB; 2^22 as four point slices: 1,181,588 KB per launch, "
+                  "profiles/r3final_rocprofv3_summary_2^22.txt)")
 # static instruction mix of one lazy-limb XYZZ mixed add (hipcc --save-temps of the accumulate fast path): 1467
 # v_mad_u64_u32 + 146 v_lshl_add_u64 + 144 v_lshrrev_b64 + 81 v_mul_lo_u32 at 4 issue cycles per wave, 382 32-bit
 # add/and/shift/sub at 2 (tools/microbench.hip rates)
