@@ -105,6 +105,9 @@ struct zg_bases_s {
         void *d_state = nullptr;          // MsmState
         hipEvent_t done = nullptr;        // recorded after the lane's last MSM; the next user waits on it
         bool used = false;
+#ifdef ZG_EXP_SKIP_SORT
+        bool exp_sorted_once = false;
+#endif
     };
     std::vector<Lane> lanes;
     size_t next_lane = 0;
@@ -1802,6 +1805,10 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
     }
     // digits and sort of bases[off, off + n_pts) x p.K scalar vectors at d_scalars -> sv (sorted references, bucket starts, ...)
     auto sort_range = [&](size_t off, size_t n_pts, const uint64_t *d_scalars, const SliceView &sv) -> int {
+#ifdef ZG_EXP_SKIP_SORT  // timing experiment only (tools/build_variant.sh): a workspace's second and later MSMs reuse its sorted list
+    if (ln.exp_sorted_once) return ZG_OK;
+    ln.exp_sorted_once = true;
+#endif
     const size_t n = n_pts * (size_t)p.K;  // scalars in this launch set
     const uint8_t *infp = b->d_inf ? b->d_inf + off : nullptr;
     if (p.fb) {
