@@ -591,6 +591,26 @@ def test_host_scalar_path_sliced(zl, ob, gm, slices, monkeypatch):
         b.free()
 
 
+@pytest.mark.parametrize("kind", ["boolean", "bytes", "one_hot_bucket"])
+def test_skewed_scalars_in_point_slices(zl, ob, gm, kind, monkeypatch):
+    """skewed columns (a 0/1 flag puts half of all points into one bucket: the heavy / huge bucket stages) with the launch set cut into
+    eight point slices: every slice runs the heavy stages on its own bucket set and reduction state, the sets are added up — the
+    oracle's bytes"""
+    monkeypatch.setenv("ZG_MSM_TABLE_SPAN_MB", "1")
+    monkeypatch.setenv("ZG_MSM_TABLE_SPAN_MIN_POINTS", "8192")
+    n = 1 << 16
+    rng = np.random.default_rng(78)
+    if kind == "boolean":
+        vals = rng.integers(0, 2, size=n)
+    elif kind == "bytes":
+        vals = rng.integers(0, 256, size=n)
+    else:
+        vals = np.where(rng.integers(0, 10, size=n) == 0, rng.integers(0, 1 << 30, size=n), 7)
+    sc = ob.f_from_u64(ob.FR, vals.astype(np.uint64))
+    _check(zl, ob, gm[:n], None, sc)
+    _check(zl, ob, gm[:n], None, sc, window_bits=13, precompute_levels=1)
+
+
 @pytest.mark.parametrize("span_pts", [700, 1300, 2600])
 def test_device_scalar_path_in_point_slices(zl, ob, gm, span_pts, monkeypatch):
     """A launch set whose table rows would span more than ZG_MSM_TABLE_SPAN_MB is cut into slices of consecutive points
