@@ -280,7 +280,24 @@ struct zg_rwc_s {
     // the integer skeleton of the entry list (host) and the plan of the current round
     std::vector<uint32_t> cycle, addr;
     std::vector<uint64_t> prev, next;
-    std::vector<zg::RwcStep> plan;
+    // the plan is written into PINNED memory (two buffers in turn: the upload of one round's plan is asynchronous, the next round's walk
+    // must not overwrite it before the copy engine has read it) — a pageable 5 MB plan per round was staged synchronously
+    struct Plan {
+        zg::RwcStep *p = nullptr;
+        size_t n = 0;
+        void clear() { n = 0; }
+        void reserve(size_t) {}
+        void push_back(const zg::RwcStep &s) { p[n++] = s; }
+        size_t size() const { return n; }
+        bool empty() const { return n == 0; }
+        const zg::RwcStep &operator[](size_t i) const { return p[i]; }
+        const zg::RwcStep *data() const { return p; }
+    } plan;
+    zg::RwcStep *h_plan[2] = {nullptr, nullptr};
+    hipEvent_t plan_uploaded[2] = {nullptr, nullptr};
+    int plan_buf = 0;
+    std::vector<uint32_t> c2, a2;  // rwc_apply_plan's output buffers, kept between rounds
+    std::vector<uint64_t> p2, n2;
     bool plan_valid = false, plan_is_address = false;
     size_t plan_addr_round = 0;
     // device: coefficient columns (double-buffered), the plan, the dense tables
@@ -309,6 +326,10 @@ static void rwc_free(zg_rwc_s *s) {
     for (void *p : {(void *)s->d_plan, (void *)s->d_idx, (void *)s->d_part, (void *)s->d_out})
         if (p) (void)hipFree(p);
     if (s->h_out) (void)hipHostFree(s->h_out);
+    for (int b = 0; b < 2; b++) {
+        if (s->h_plan[b]) (void)hipHostFree(s->h_plan[b]);
+        if (s->plan_uploaded[b]) (void)hipEventDestroy(s->plan_uploaded[b]);
+    }
     if (s->st) stream_release(s->st, s->device);
     delete s;
 }
@@ -332,10 +353,18 @@ static int rwc_collect(zg_rwc_s *s, uint32_t nblocks, uint64_t *a, uint64_t *b) 
     return ZG_OK;
 }
 
+// the other pinned plan buffer, once its last upload has left the host
+static void rwc_next_plan_buffer(zg_rwc_s *s) {
+    s->plan_buf ^= 1;
+    (void)hipEventSynchronize(s->plan_uploaded[s->plan_buf]);
+    s->plan.p = s->h_plan[s->plan_buf];
+    s->plan.n = 0;
+}
 // ---- the walks (host, integers only)
 // cycle phases: the pairing of computePhase1Polynomial / bindEntries (:431-470, 1146-1160)
 static void rwc_plan_cycle(zg_rwc_s *s) {
     const size_t n = s->cycle.size();
+    rwc_next_plan_buffer(s);
     s->plan.clear();
     s->plan.reserve(n);
     for (size_t i = 0; i < n;) {
@@ -358,6 +387,7 @@ static void rwc_plan_cycle(zg_rwc_s *s) {
 // address phase: column pairs by (address >> addr_round) / 2 and the two-pointer walk with carried checkpoints (:585-700, 1000-1075)
 static void rwc_plan_address(zg_rwc_s *s, size_t addr_round) {
     const size_t n = s->cycle.size();
+    rwc_next_plan_buffer(s);
     const uint32_t sh = (uint32_t)addr_round;
     s->plan.clear();
     s->plan.reserve(n);
@@ -406,8 +436,9 @@ static void rwc_plan_address(zg_rwc_s *s, size_t addr_round) {
 // the skeleton of the bound list: step k -> entry k (CycleMajorEntry.bindEntries :110-156; bindAddressMajor* :1077-1137)
 static void rwc_apply_plan(zg_rwc_s *s, bool address) {
     const size_t m = s->plan.size();
-    std::vector<uint32_t> c2(m), a2(m);
-    std::vector<uint64_t> p2(m), n2(m);
+    std::vector<uint32_t> &c2 = s->c2, &a2 = s->a2;
+    std::vector<uint64_t> &p2 = s->p2, &n2 = s->n2;
+    c2.resize(m); a2.resize(m); p2.resize(m); n2.resize(m);
     for (size_t k = 0; k < m; k++) {
         const RwcStep &st = s->plan[k];
         c2[k] = address ? s->cycle[st.a] : s->cycle[st.a] >> 1;
@@ -423,6 +454,7 @@ static void rwc_apply_plan(zg_rwc_s *s, bool address) {
 }
 static int rwc_upload_plan(zg_rwc_s *s) {
     if (!s->plan.empty()) ZG_HIP(hipMemcpyAsync(s->d_plan, s->plan.data(), s->plan.size() * sizeof(RwcStep), hipMemcpyHostToDevice, s->st));
+    ZG_HIP(hipEventRecord(s->plan_uploaded[s->plan_buf], s->st));
     return ZG_OK;
 }
 
@@ -463,6 +495,11 @@ int zg_rwc_open(size_t log_k, size_t log_t, size_t n, const uint32_t *cycle, con
         if (e == hipSuccess) e = hipMalloc((void **)&s->val[b], K * 32);  // both full size: the previous level stays readable
     }
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_plan, (size_t)s->cap * sizeof(RwcStep));
+    for (int b = 0; b < 2 && e == hipSuccess; b++) {
+        e = hipHostMalloc((void **)&s->h_plan[b], (size_t)s->cap * sizeof(RwcStep));
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s->plan_uploaded[b], hipEventDisableTiming);
+    }
+    s->plan.p = s->h_plan[0];
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_idx, (size_t)s->cap * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_part, (size_t)RWC_MAX_BLOCKS * 2 * 32);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_out, 8 * 32);
