@@ -782,8 +782,13 @@ ZG_DEV uint32_t chunk_len(uint32_t total, uint32_t NT) {
 #else
 #define ZG_ROW_MASK 0x7FFFFFFFu
 #endif
+#ifdef ZG_EXP_ACC_WAVES  // experiment: force the register budget of N waves per SIMD (tools/build_variant.sh)
+#define ZG_ACC_ATTR __attribute__((amdgpu_waves_per_eu(ZG_EXP_ACC_WAVES, ZG_EXP_ACC_WAVES)))
+#else
+#define ZG_ACC_ATTR
+#endif
 template <bool QUAD>
-__global__ void __launch_bounds__(256) msm_accumulate_chunk_kernel(const uint32_t *sorted, const uint32_t *starts, const uint32_t *nzrank,
+__global__ void __launch_bounds__(256) ZG_ACC_ATTR msm_accumulate_chunk_kernel(const uint32_t *sorted, const uint32_t *starts, const uint32_t *nzrank,
                                                                    const uint32_t *nzlist, const char *table, uint32_t NK, uint32_t NT,
                                                                    char *part) {
     uint32_t i = blockIdx.x * 256 + threadIdx.x, q = 0;
