@@ -251,7 +251,9 @@ ZG_API int zg_fr_rows_affine_dev(const uint64_t *d_rows, size_t n_rows, size_t k
 /* The Q tables of Stage 3's prefix / suffix provers (ShiftPrefixSuffixProver.init, src/zkvm/spartan/stage3_prover.zig:1066-1112;
  * RegistersPrefixSuffixProver.init, :2232-2290): Q[x_lo] = sum over x_hi of witness(x_lo + x_hi * 2^prefix_vars) * suffix[x_hi] — column
  * sums of the cycle-length table read as a (rows = 2^suffix_vars) x (cols = 2^prefix_vars) matrix, under up to four weight vectors at
- * once (eq and eq+1 suffixes share the pass):   out[k * cols + c] = sum_r weights[k * rows + r] * table[r * cols + c],  k < m <= 4. */
+ * once (eq and eq+1 suffixes share the pass):   out[k * cols + c] = sum_r weights[k * rows + r] * table[r * cols + c],  k < m <= 4.
+ * The _dev form is enqueued on `stream`; when the rows are cut into slabs (more than one) it also waits for the stream, because the
+ * slab partials live in the library's scratch cache. */
 ZG_API int zg_fr_weighted_colsum(const uint64_t *table, size_t rows, size_t cols, const uint64_t *weights, size_t m, uint64_t *out);
 ZG_API int zg_fr_weighted_colsum_dev(const uint64_t *d_table, size_t rows, size_t cols, const uint64_t *d_weights, size_t m, uint64_t *d_out,
                               void *stream);
