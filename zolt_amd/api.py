@@ -1633,6 +1633,9 @@ class RegistersClaimReductionRounds:
 def _evaluate_mle_low(table, point):
     """evaluateMle of the Stage-3 provers (src/zkvm/spartan/stage3_prover.zig:1820-1838): the point's first entry binds the LOW index bit"""
     t = np.ascontiguousarray(table, dtype=np.uint64).reshape(-1, 4)
+    point = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1, 4)
+    if t.shape[0] == (1 << point.shape[0]):  # the whole cube: one device call (zg_fr_dense_evaluate has the same bit order)
+        return lib.fr_dense_evaluate(t, point)
     for r in point:
         if t.shape[0] == 1:
             break
