@@ -755,11 +755,81 @@ static int stage3_main(const char *path) {
     return 0;
 }
 
+// `test_host_mirror wire <kind> <in> <out>`: the wire / disk formats of zolt::wire on a file written by tests/test_gpu_cpp_host.py.
+//   raw    : raw SRS file  -> prints n, then re-serialises it (out must equal in); the Montgomery limbs of every point as hex lines
+//   ptau   : ptau container -> power, ceremony power, counts; limbs of the three G1 sections
+//   proof  : ZOLT proof     -> the eleven 64-byte commitments as hex, and the re-serialised 744-byte header to <out>
+static std::vector<uint8_t> read_file(const char *path) {
+    std::FILE *f = std::fopen(path, "rb");
+    if (!f) throw std::runtime_error("cannot open input");
+    std::vector<uint8_t> d;
+    uint8_t buf[65536];
+    size_t k;
+    while ((k = std::fread(buf, 1, sizeof buf, f)) > 0) d.insert(d.end(), buf, buf + k);
+    std::fclose(f);
+    return d;
+}
+static void write_file(const char *path, const std::vector<uint8_t> &d) {
+    std::FILE *f = std::fopen(path, "wb");
+    if (!f) throw std::runtime_error("cannot open output");
+    std::fwrite(d.data(), 1, d.size(), f);
+    std::fclose(f);
+}
+static void print_points(const char *tag, const wire::G1Points &p) {
+    for (size_t i = 0; i < p.size(); i++) {
+        std::printf("%s %d", tag, (int)p.inf[i]);
+        for (size_t l = 0; l < 8; l++) std::printf(" %016llx", (unsigned long long)p.xy[8 * i + l]);
+        std::printf("\n");
+    }
+}
+static int wire_main(const char *kind, const char *in, const char *out) {
+    auto data = read_file(in);
+    try {
+        if (!std::strcmp(kind, "raw")) {
+            std::vector<uint8_t> trailer;
+            auto pts = wire::srsG1FromRaw(data, &trailer);
+            std::printf("N %zu\n", pts.size());
+            print_points("P", pts);
+            write_file(out, wire::srsG1ToRaw(pts, trailer));
+        } else if (!std::strcmp(kind, "ptau")) {
+            auto pt = wire::srsG1FromPtau(data);
+            std::printf("H %u %u %zu %zu %zu %zu %zu\n", pt.power, pt.ceremony_power, pt.powers_of_tau_g1.size(), pt.has_alpha ? pt.alpha_tau_g1.size() : 0,
+                        pt.has_beta ? pt.beta_tau_g1.size() : 0, pt.tau_g2_raw.size(), pt.beta_g2_raw.size());
+            print_points("T", pt.powers_of_tau_g1);
+            print_points("A", pt.alpha_tau_g1);
+            print_points("B", pt.beta_tau_g1);
+        } else {
+            auto cs = wire::parseZoltProofCommitments(data);
+            for (size_t i = 0; i < 11; i++) {
+                std::printf("C %s ", wire::PROOF_COMMITMENT_NAMES[i]);
+                for (uint8_t b : cs[i]) std::printf("%02x", b);
+                std::printf("\n");
+            }
+            write_file(out, wire::serializeZoltProofHeader(cs));
+            // a commitment produced here: the generator, as PolyCommitment.toBytes writes it
+            auto g = wire::commitmentToBytes(AffinePoint::generator());
+            std::printf("G ");
+            for (uint8_t b : g) std::printf("%02x", b);
+            std::printf("\n");
+        }
+    } catch (const wire::SRSError &e) {
+        std::printf("SRSError %s\n", e.what());
+        return 0;
+    }
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (zg_init(0) != ZG_OK) { std::printf("zg_init failed: %s\n", zg_last_error()); return 2; }
     if (argc >= 3 && !std::strcmp(argv[1], "outer")) {
         int rc;
         try { rc = outer_main(argv[2]); } catch (const std::exception &e) { std::printf("EXCEPTION: %s\n", e.what()); rc = 3; }
+        zg_shutdown();
+        return rc;
+    }
+    if (argc >= 5 && !std::strcmp(argv[1], "wire")) {
+        int rc;
+        try { rc = wire_main(argv[2], argv[3], argv[4]); } catch (const std::exception &e) { std::printf("EXCEPTION: %s\n", e.what()); rc = 3; }
         zg_shutdown();
         return rc;
     }

@@ -300,3 +300,82 @@ def test_cpp_stage3_mirror(tmp_path, golden_dir):
         if case == 0:  # and the reference's own printed values
             assert Pl == [[le(r[c]) for c in ("c0", "c2", "c3")] for r in s3["rounds"]]
             assert [c[3] for c in Cl] == [le(r["next_claim"]) for r in s3["rounds"]]
+
+
+@pytest.mark.gpu
+def test_cpp_wire_formats(tmp_path, golden_dir):
+    """zolt::wire (compiled host code) on the formats around the path (SURVEY 8(f)4), against the Python mirror / the oracle / the
+    reference's own captured proof file: the raw SRS file (parse -> the oracle's Montgomery limbs, re-serialised byte for byte, an
+    infinity record, truncation and a point off the curve), the ptau container (header, TauG1 capped by the power, AlphaTauG1, an
+    infinity record, raw G2 sections, bad magic), and the ZOLT-v1 proof header (the eleven 64-byte commitments of
+    logs/zolt_proof_regular.bin, re-serialised to its first 744 bytes)."""
+    import numpy as np
+    from oracle import binding as ob
+    from oracle import pymodel as pm
+    from zolt_amd import api
+    exe = os.path.join(ROOT, "tests", "cpp", "test_host_mirror")
+    subprocess.check_call(["make", "-C", os.path.dirname(exe), "test_host_mirror"])
+
+    def run(kind, blob):
+        src, dst = str(tmp_path / f"{kind}.in"), str(tmp_path / f"{kind}.out")
+        open(src, "wb").write(blob)
+        if os.path.exists(dst):
+            os.remove(dst)
+        res = subprocess.run([exe, "wire", kind, src, dst], capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+        return res.stdout.splitlines(), (open(dst, "rb").read() if os.path.exists(dst) else None)
+
+    def points(lines, tag):
+        rows = [l.split()[1:] for l in lines if l.startswith(tag + " ")]
+        inf = [int(r[0]) for r in rows]
+        xy = np.array([[int(v, 16) for v in r[1:9]] for r in rows], dtype=np.uint64).reshape(-1, 8)
+        return xy, inf
+
+    # raw SRS
+    n = 33
+    srs, inf = ob.hyperkzg_setup(n)
+    blob = bytearray(n.to_bytes(4, "little") + b"".join(pm.commitment_bytes(p) for p in pm.mock_srs(n)) + bytes(range(64)) * 5)
+    blob[4 + 64 * 5: 4 + 64 * 6] = bytes(64)  # point 5 := infinity
+    lines, back = run("raw", bytes(blob))
+    xy, pinf = points(lines, "P")
+    want = srs.copy()
+    want[5] = 0
+    assert lines[0] == f"N {n}" and np.array_equal(xy, want) and pinf == [1 if i == 5 else 0 for i in range(n)]
+    assert back == bytes(blob)  # trailer included
+    assert run("raw", bytes(blob[:100]))[0] == ["SRSError TruncatedData"]
+    bad = bytearray(blob)
+    bad[4 + 64 * 3 + 63] ^= 1
+    assert run("raw", bytes(bad))[0] == ["SRSError PointNotOnCurve"]
+    # ptau
+    hdr = (32).to_bytes(4, "little") + bytes(32) + (2).to_bytes(4, "little") + (3).to_bytes(4, "little")
+    gm = ob.g1_gen_multiples(9)
+    canon = ob.f_from_mont(ob.FP, gm.reshape(-1, 4)).reshape(9, 8)
+    recs = [canon[i].tobytes() for i in range(9)]
+    recs[3] = bytes(64)
+
+    def ptau(sections):
+        out = b"ptau" + (1).to_bytes(4, "little") + len(sections).to_bytes(4, "little")
+        for typ, payload in sections:
+            out += typ.to_bytes(4, "little") + len(payload).to_bytes(8, "little") + payload
+        return out
+    file = ptau([(1, hdr), (2, b"".join(recs)), (4, b"".join(recs[:4])), (3, bytes(128 * 5)), (6, bytes(128))])
+    lines, _ = run("ptau", file)
+    assert lines[0] == "H 2 3 7 4 0 640 128"
+    txy, tinf = points(lines, "T")
+    w7 = gm[:7].copy()
+    w7[3] = 0
+    assert np.array_equal(txy, w7) and tinf == [0, 0, 0, 1, 0, 0, 0]
+    axy, ainf = points(lines, "A")
+    assert np.array_equal(axy[:3], gm[:3]) and ainf == [0, 0, 0, 1]
+    got = api.srs_g1_from_ptau(file)  # the Python mirror reads the same file the same way
+    assert np.array_equal(got["powers_of_tau_g1"][0], txy) and got["power"] == 2 and got["ceremony_power"] == 3
+    assert run("ptau", bytes(24))[0] == ["SRSError InvalidFileFormat"]
+    assert run("ptau", b"ptau")[0] == ["SRSError TruncatedData"]
+    # the reference's captured proof
+    proof = open(os.path.join(golden_dir, "zolt_proof_regular.bin"), "rb").read()
+    lines, header = run("proof", proof)
+    want_c = api.parse_zolt_proof_commitments(proof)
+    got_c = {l.split()[1]: bytes.fromhex(l.split()[2]) for l in lines if l.startswith("C ")}
+    assert got_c == want_c and header == proof[:744]
+    g = ob.g1_gen_multiples(1)[0]
+    assert bytes.fromhex([l for l in lines if l.startswith("G ")][0].split()[1]) == api.commitment_to_bytes(g, 0)
