@@ -2289,3 +2289,34 @@ class Stage3Batch:
         self.claims = [at(stage3_evals_to_coeffs(e)) for e in self.evals]
         for p in self.inst:
             p.bind(r)
+
+
+# ---------------------------------------------------------------- Dory's data-parallel G1 / Fr pieces (src/poly/commitment/dory.zig)
+def dory_row_commitments(g1_xy, g1_inf, evals, num_columns):
+    """computeRowCommitments (dory.zig:646-670): row r = MSM(g1_vec[0..len(row)], evals[r * cols .. min((r + 1) * cols, len)]);
+    the last row may be shorter -> (rows, 8), (rows,)"""
+    ev = _c(evals).reshape(-1, 4)
+    rows = (ev.shape[0] + num_columns - 1) // num_columns
+    out, inf = np.zeros((rows, 8), dtype=np.uint64), np.zeros(rows, dtype=np.uint8)
+    for r in range(rows):
+        row = ev[r * num_columns:(r + 1) * num_columns]
+        k = row.shape[0]
+        xy, i = msm_g1(_c(g1_xy)[:k], None if g1_inf is None else _c(g1_inf, np.uint8)[:k], row)
+        out[r], inf[r] = xy, i
+    return out, inf
+
+
+def dory_vector_matrix_product(evals, left_vec, nu, sigma):
+    """computeVectorMatrixProduct (dory.zig:622-642): v[col] = sum_row left_vec[row] * evals[row * 2^sigma + col] over 2^nu rows; rows
+    past left_vec and entries past evals contribute nothing -> (2^sigma, 4)"""
+    ev, lv = _c(evals).reshape(-1, 4), _c(left_vec).reshape(-1, 4)
+    cols, rows = 1 << sigma, 1 << nu
+    acc = [0] * cols
+    e = [fr_to_int(x) for x in ev]
+    l = [fr_to_int(x) for x in lv]
+    for r in range(min(rows, len(l))):
+        for c in range(cols):
+            idx = r * cols + c
+            if idx < len(e):
+                acc[c] = (acc[c] + l[r] * e[idx]) % _R_P
+    return np.stack([fr_from_int(v) for v in acc])

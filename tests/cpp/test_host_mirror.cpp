@@ -819,6 +819,41 @@ static int wire_main(const char *kind, const char *in, const char *out) {
     return 0;
 }
 
+// `test_host_mirror dory <file>`: zolt::Dory on the instance the file describes (written by tests/test_gpu_cpp_host.py): n bases (packed
+// xy limbs + infinity flags), num_columns, the evaluations, nu, sigma, left_vec -> the row commitments (R) and the vector-matrix product (V)
+static int dory_main(const char *path) {
+    std::FILE *f = std::fopen(path, "r");
+    if (!f) { std::printf("cannot open %s\n", path); return 2; }
+    unsigned long long n, cols, ne, nu, sigma, nl;
+    if (std::fscanf(f, "%llu", &n) != 1) return 2;
+    std::vector<AffinePoint> bases(n);
+    for (auto &b : bases) {
+        for (int i = 0; i < 4; i++) { unsigned long long v; if (std::fscanf(f, "%llx", &v) != 1) return 2; b.x.limbs[i] = v; }
+        for (int i = 0; i < 4; i++) { unsigned long long v; if (std::fscanf(f, "%llx", &v) != 1) return 2; b.y.limbs[i] = v; }
+        unsigned long long inf;
+        if (std::fscanf(f, "%llu", &inf) != 1) return 2;
+        b.infinity = inf != 0;
+    }
+    if (std::fscanf(f, "%llu %llu", &cols, &ne) != 2) return 2;
+    std::vector<Fr> evals;
+    for (size_t i = 0; i < ne; i++) evals.push_back(read_fr(f));
+    if (std::fscanf(f, "%llu %llu %llu", &nu, &sigma, &nl) != 3) return 2;
+    std::vector<Fr> left;
+    for (size_t i = 0; i < nl; i++) left.push_back(read_fr(f));
+    std::fclose(f);
+    DeviceBases g1(bases);
+    for (const AffinePoint &p : Dory::computeRowCommitments(g1, evals, cols)) {
+        std::printf("R %d", p.infinity ? 1 : 0);
+        for (int i = 0; i < 4; i++) std::printf(" %016llx", (unsigned long long)p.x.limbs[i]);
+        for (int i = 0; i < 4; i++) std::printf(" %016llx", (unsigned long long)p.y.limbs[i]);
+        std::printf("\n");
+    }
+    std::printf("V");
+    for (const Fr &x : Dory::computeVectorMatrixProduct(evals, left, (unsigned)nu, (unsigned)sigma)) print_fr(x);
+    std::printf("\n");
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (zg_init(0) != ZG_OK) { std::printf("zg_init failed: %s\n", zg_last_error()); return 2; }
     if (argc >= 3 && !std::strcmp(argv[1], "outer")) {
@@ -830,6 +865,12 @@ int main(int argc, char **argv) {
     if (argc >= 5 && !std::strcmp(argv[1], "wire")) {
         int rc;
         try { rc = wire_main(argv[2], argv[3], argv[4]); } catch (const std::exception &e) { std::printf("EXCEPTION: %s\n", e.what()); rc = 3; }
+        zg_shutdown();
+        return rc;
+    }
+    if (argc >= 3 && !std::strcmp(argv[1], "dory")) {
+        int rc;
+        try { rc = dory_main(argv[2]); } catch (const std::exception &e) { std::printf("EXCEPTION: %s\n", e.what()); rc = 3; }
         zg_shutdown();
         return rc;
     }

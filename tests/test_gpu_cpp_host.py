@@ -379,3 +379,47 @@ def test_cpp_wire_formats(tmp_path, golden_dir):
     assert got_c == want_c and header == proof[:744]
     g = ob.g1_gen_multiples(1)[0]
     assert bytes.fromhex([l for l in lines if l.startswith("G ")][0].split()[1]) == api.commitment_to_bytes(g, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_evals,sigma,nu", [(64, 3, 3), (61, 3, 3), (1000, 5, 5), (5, 4, 2)])
+def test_dory_row_commitments_and_vector_matrix_product(tmp_path, n_evals, sigma, nu):
+    """Dory's two data-parallel pieces (src/poly/commitment/dory.zig:622-670) — row commitments = a batch of MSMs over a prefix of g1_vec
+    (ragged last row, fewer evaluations than one row), vector-matrix product = a weighted column sum (left_vec shorter than the row count,
+    evaluations shorter than the matrix) — through the Python mirror and the compiled mirror, against the restatement, bit for bit."""
+    import numpy as np
+    from oracle import binding as ob
+    from tests import util as U
+    from zolt_amd import api, lib
+    lib.init()
+    cols = 1 << sigma
+    g1 = ob.g1_gen_multiples(cols)
+    g1_inf = np.zeros(cols, dtype=np.uint8)
+    g1_inf[2] = 1  # an identity element inside g1_vec
+    ev = ob.f_to_mont(ob.FR, U.random_raw256(6000 + n_evals, n_evals))
+    ev[3] = 0
+    left = ob.f_to_mont(ob.FR, U.random_raw256(6100 + n_evals, max(1, (1 << nu) - 1)))  # one short of the row count
+    want_rc, want_inf = ob.dory_row_commitments(g1, g1_inf, ev, cols)
+    want_v = ob.dory_vector_matrix_product(ev, left, nu, sigma)
+    b = lib.Bases.upload(g1, g1_inf)
+    try:
+        rc, inf = api.Dory.computeRowCommitments(b, ev, cols)
+    finally:
+        b.free()
+    assert np.array_equal(inf, want_inf) and np.array_equal(rc, want_rc)
+    assert np.array_equal(api.Dory.computeVectorMatrixProduct(ev, left, nu, sigma), want_v)
+    exe = os.path.join(ROOT, "tests", "cpp", "test_host_mirror")
+    subprocess.check_call(["make", "-C", os.path.dirname(exe), "test_host_mirror"])
+    path = str(tmp_path / "dory.txt")
+    with open(path, "w") as f:
+        f.write(f"{cols}\n" + "".join(" ".join("%x" % int(v) for v in g1[i]) + f" {int(g1_inf[i])}\n" for i in range(cols)))
+        f.write(f"{cols} {n_evals}\n" + "".join(_hexfr(x) + "\n" for x in ev))
+        f.write(f"{nu} {sigma} {left.shape[0]}\n" + "".join(_hexfr(x) + "\n" for x in left))
+    res = subprocess.run([exe, "dory", path], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    rows = [l.split()[1:] for l in res.stdout.splitlines() if l.startswith("R ")]
+    assert [int(r[0]) for r in rows] == list(want_inf)
+    got = np.array([[int(v, 16) for v in r[1:9]] for r in rows], dtype=np.uint64).reshape(-1, 8)
+    assert np.array_equal(got[want_inf == 0], want_rc[want_inf == 0])
+    v = [l for l in res.stdout.splitlines() if l.startswith("V")][0].split()[1:]
+    assert np.array_equal(np.array([int(x, 16) for x in v], dtype=np.uint64).reshape(-1, 4), want_v)

@@ -306,6 +306,41 @@ class HyperKZG:
                 "batching_challenge": gam}
 
 
+class Dory:
+    """The data-parallel G1 / Fr pieces of Dory's commit and open (src/poly/commitment/dory.zig; pairings and GT arithmetic stay the
+    reference's): the row commitments are a batch of MSMs over one prefix of g1_vec, the vector-matrix product a weighted column sum."""
+
+    @staticmethod
+    def computeRowCommitments(g1_bases, evals, num_columns):
+        """computeRowCommitments (:646-670): g1_bases = a lib.Bases handle over params.g1_vec (resident, like the HyperKZG SRS);
+        row r = MSM(g1_vec[0..len(row)], row r of evals). Full rows go through ONE fused launch set (zg_msm_g1_batch), a shorter last
+        row is one more MSM over the prefix -> (xy (rows, 8), inf (rows,))"""
+        ev = np.ascontiguousarray(evals, dtype=np.uint64).reshape(-1, 4)
+        full, rest = divmod(ev.shape[0], num_columns)
+        assert num_columns <= g1_bases.n
+        out = np.zeros((full + (1 if rest else 0), 8), dtype=np.uint64)
+        inf = np.zeros(out.shape[0], dtype=np.uint8)
+        if full:
+            out[:full], inf[:full] = g1_bases.msm_batch([ev[r * num_columns:(r + 1) * num_columns] for r in range(full)], n=num_columns)
+        if rest:
+            xy, i = g1_bases.msm(ev[full * num_columns:], n=rest)
+            out[full], inf[full] = xy, i
+        return out, inf
+
+    @staticmethod
+    def computeVectorMatrixProduct(evals, left_vec, nu, sigma):
+        """computeVectorMatrixProduct (:622-642): v = L^T M over the 2^nu x 2^sigma matrix of evaluations (zg_fr_weighted_colsum); rows
+        past left_vec and entries past evals are zero -> (2^sigma, 4)"""
+        rows, cols = 1 << nu, 1 << sigma
+        ev = np.ascontiguousarray(evals, dtype=np.uint64).reshape(-1, 4)
+        lv = np.ascontiguousarray(left_vec, dtype=np.uint64).reshape(-1, 4)
+        m = np.zeros((rows * cols, 4), dtype=np.uint64)
+        m[:min(ev.shape[0], rows * cols)] = ev[:rows * cols]
+        w = np.zeros((rows, 4), dtype=np.uint64)
+        w[:min(lv.shape[0], rows)] = lv[:rows]
+        return lib.fr_weighted_colsum(m, rows, cols, w.reshape(1, rows, 4))[0]
+
+
 # ---- ZOLT v1 proof container: the commitments this backend produces
 def parse_zolt_proof_commitments(data):
     """Header of serializeProof (src/zkvm/serialization.zig:283-306): "ZOLT" | u32 version | bytecode proof

@@ -269,6 +269,35 @@ struct BatchMSM {  // :545-565 (ParallelBatchMSM :683-748 returns the same value
     }
 };
 
+// Dory's data-parallel G1 / Fr pieces (src/poly/commitment/dory.zig; pairings and GT arithmetic stay the reference's)
+struct Dory {
+    // computeRowCommitments (:646-670): row r = MSM(g1_vec[0..len(row)], row r); full rows in one fused launch set, a shorter last row after
+    static std::vector<AffinePoint> computeRowCommitments(const DeviceBases &g1_vec, const std::vector<Fr> &evals, size_t num_columns) {
+        const size_t full = evals.size() / num_columns, rest = evals.size() % num_columns;
+        std::vector<AffinePoint> out;
+        if (full) {
+            std::vector<const uint64_t *> ptrs;
+            for (size_t r = 0; r < full; r++) ptrs.push_back(reinterpret_cast<const uint64_t *>(evals.data() + r * num_columns));
+            std::vector<uint64_t> xy(8 * full);
+            std::vector<uint8_t> inf(full);
+            check(zg_msm_g1_batch(g1_vec.handle(), num_columns, ptrs.data(), full, xy.data(), inf.data()), "zg_msm_g1_batch");
+            for (size_t r = 0; r < full; r++) out.push_back(unpack_point(xy.data() + 8 * r, inf[r]));
+        }
+        if (rest) out.push_back(g1_vec.msm(evals.data() + full * num_columns, rest));
+        return out;
+    }
+    // computeVectorMatrixProduct (:622-642): v[col] = sum_row left_vec[row] * evals[row * 2^sigma + col]
+    static std::vector<Fr> computeVectorMatrixProduct(const std::vector<Fr> &evals, const std::vector<Fr> &left_vec, unsigned nu, unsigned sigma) {
+        const size_t rows = size_t(1) << nu, cols = size_t(1) << sigma;
+        std::vector<Fr> m(rows * cols, Fr::zero()), w(rows, Fr::zero()), out(cols);
+        std::copy(evals.begin(), evals.begin() + std::min(evals.size(), rows * cols), m.begin());
+        std::copy(left_vec.begin(), left_vec.begin() + std::min(left_vec.size(), rows), w.begin());
+        check(zg_fr_weighted_colsum(reinterpret_cast<const uint64_t *>(m.data()), rows, cols, reinterpret_cast<const uint64_t *>(w.data()), 1,
+                                    reinterpret_cast<uint64_t *>(out.data())), "zg_fr_weighted_colsum");
+        return out;
+    }
+};
+
 // the SRS sharded over the devices bound by zg_init_devices (one resident table per GPU)
 class ShardedDeviceBases {
 public:
