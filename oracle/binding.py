@@ -2320,3 +2320,37 @@ def dory_vector_matrix_product(evals, left_vec, nu, sigma):
             if idx < len(e):
                 acc[c] = (acc[c] + l[r] * e[idx]) % _R_P
     return np.stack([fr_from_int(v) for v in acc])
+
+
+def dory_multilinear_lagrange_basis(point, out_len=None):
+    """multilinearLagrangeBasis (dory.zig:544-588): output[i] = prod_level (bit_level(i) ? point[level] : 1 - point[level]), the index's
+    LOW bit belongs to point[0]; an output shorter than 2^len(point) holds the first entries of the full table -> (out_len, 4)"""
+    pt = [fr_to_int(x) for x in _c(np.asarray(point, dtype=np.uint64).reshape(-1, 4))]
+    n = (1 << len(pt)) if out_len is None else out_len
+    out = []
+    for i in range(n):
+        v = 1
+        for lvl, p in enumerate(pt):
+            v = v * (p if (i >> lvl) & 1 else (1 - p)) % _R_P
+        out.append(v)
+    return np.stack([fr_from_int(v) for v in out]) if out else np.zeros((0, 4), dtype=np.uint64)
+
+
+def dory_evaluation_vectors(point, nu, sigma):
+    """computeEvaluationVectors (dory.zig:590-620) -> (left_vec (2^nu, 4), right_vec (2^sigma, 4)); entries the reference does not write stay zero"""
+    pt = _c(np.asarray(point, dtype=np.uint64).reshape(-1, 4))
+    d = pt.shape[0]
+    left, right = np.zeros((1 << nu, 4), dtype=np.uint64), np.zeros((1 << sigma, 4), dtype=np.uint64)
+    one = fr_from_int(1)
+    if d == 0:
+        left[0], right[0] = one, one
+    elif d <= sigma:
+        right[:1 << d] = dory_multilinear_lagrange_basis(pt)
+        left[0] = one
+    elif d <= nu + sigma:
+        right[:] = dory_multilinear_lagrange_basis(pt[:sigma])
+        left[:1 << (d - sigma)] = dory_multilinear_lagrange_basis(pt[sigma:])
+    else:
+        right[:] = dory_multilinear_lagrange_basis(pt[:sigma])
+        left[:] = dory_multilinear_lagrange_basis(pt[sigma:], 1 << nu)
+    return left, right

@@ -423,3 +423,19 @@ def test_dory_row_commitments_and_vector_matrix_product(tmp_path, n_evals, sigma
     assert np.array_equal(got[want_inf == 0], want_rc[want_inf == 0])
     v = [l for l in res.stdout.splitlines() if l.startswith("V")][0].split()[1:]
     assert np.array_equal(np.array([int(x, 16) for x in v], dtype=np.uint64).reshape(-1, 4), want_v)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,nu,sigma", [(0, 2, 2), (2, 3, 3), (3, 3, 3), (6, 3, 3), (8, 3, 3), (5, 2, 4)])
+def test_dory_evaluation_vectors(d, nu, sigma):
+    """multilinearLagrangeBasis / computeEvaluationVectors (dory.zig:544-620) on the device's eq-table kernel (reversed point) against the
+    restatement's product formula: fewer variables than columns, an exact split, more variables than the matrix holds"""
+    import numpy as np
+    from oracle import binding as ob
+    from tests import util as U
+    from zolt_amd import api, lib
+    lib.init()
+    pt = ob.f_to_mont(ob.FR, U.random_raw256(6200 + d, max(d, 1)))[:d]
+    wl, wr = ob.dory_evaluation_vectors(pt, nu, sigma)
+    gl, gr = api.Dory.computeEvaluationVectors(pt, nu, sigma)
+    assert np.array_equal(gl, wl) and np.array_equal(gr, wr)

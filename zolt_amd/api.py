@@ -328,6 +328,31 @@ class Dory:
         return out, inf
 
     @staticmethod
+    def multilinearLagrangeBasis(point, out_len=None):
+        """multilinearLagrangeBasis (:544-588): the eq table of the point with the index's LOW bit on point[0] — the device's eq table of
+        the reversed point; a shorter output is its first entries -> (out_len, 4)"""
+        pt = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1, 4)
+        full = lib.fr_eq_table(np.ascontiguousarray(pt[::-1])) if pt.shape[0] else fr_from_int(1).reshape(1, 4)
+        return full if out_len is None else np.ascontiguousarray(full[:out_len])
+
+    @staticmethod
+    def computeEvaluationVectors(point, nu, sigma):
+        """computeEvaluationVectors (:590-620) -> (left_vec (2^nu, 4), right_vec (2^sigma, 4))"""
+        pt = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1, 4)
+        d = pt.shape[0]
+        left, right = np.zeros((1 << nu, 4), dtype=np.uint64), np.zeros((1 << sigma, 4), dtype=np.uint64)
+        if d <= sigma:
+            right[:1 << d] = Dory.multilinearLagrangeBasis(pt)
+            left[0] = fr_from_int(1)
+        elif d <= nu + sigma:
+            right[:] = Dory.multilinearLagrangeBasis(pt[:sigma])
+            left[:1 << (d - sigma)] = Dory.multilinearLagrangeBasis(pt[sigma:])
+        else:  # more variables than the matrix has: the row basis is cut at 2^nu entries
+            right[:] = Dory.multilinearLagrangeBasis(pt[:sigma])
+            left[:] = Dory.multilinearLagrangeBasis(pt[sigma:], 1 << nu)
+        return left, right
+
+    @staticmethod
     def computeVectorMatrixProduct(evals, left_vec, nu, sigma):
         """computeVectorMatrixProduct (:622-642): v = L^T M over the 2^nu x 2^sigma matrix of evaluations (zg_fr_weighted_colsum); rows
         past left_vec and entries past evals are zero -> (2^sigma, 4)"""
