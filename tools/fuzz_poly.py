@@ -5,7 +5,7 @@ import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import binding as ob  # checker
-from zolt_amd import lib
+from zolt_amd import api, lib
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -210,5 +210,43 @@ while time.time() - t0 < budget:
         w = rand_fr(v)
         got, want = api.runLassoProver(lidx, v, log_K, w), ob.run_lasso_prover(lidx, v, log_K, w)
         assert all(np.array_equal(got[key], want[key]) for key in want), ("lasso", v, log_K, ncyc)
+    # weighted column sums and Dory's vector-matrix product / evaluation vectors
+    if v >= 1:
+        rows, m = 1 << int(rng.integers(0, v + 1)), int(rng.integers(1, 5))
+        cols = n // rows
+        tab, wts = rand_fr(n, sparse), rand_fr(m * rows).reshape(m, rows, 4)
+        got = lib.fr_weighted_colsum(tab, rows, cols, wts)
+        t3 = tab.reshape(rows, cols, 4)
+        for c in {0, cols - 1, int(rng.integers(0, cols))}:
+            for k in range(m):
+                assert np.array_equal(got[k, c], ob._fsum(ob._fmul(np.ascontiguousarray(t3[:, c]), np.ascontiguousarray(wts[k])))), ("colsum", rows, cols, k, c)
+    if v <= 8:
+        nu, sigma = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+        ne, nl = int(rng.integers(1, (1 << (nu + sigma)) + 3)), int(rng.integers(1, (1 << nu) + 2))
+        ev, lv = rand_fr(ne, sparse), rand_fr(nl)
+        assert np.array_equal(api.Dory.computeVectorMatrixProduct(ev, lv, nu, sigma), ob.dory_vector_matrix_product(ev, lv, nu, sigma)), ("dory vmp", nu, sigma, ne, nl)
+        pt = rand_fr(int(rng.integers(0, nu + sigma + 3)))
+        gl, gr = api.Dory.computeEvaluationVectors(pt, nu, sigma)
+        wl, wr = ob.dory_evaluation_vectors(pt, nu, sigma)
+        assert np.array_equal(gl, wl) and np.array_equal(gr, wr), ("dory vectors", nu, sigma, pt.shape[0])
+    # Stage 3's prefix / suffix provers as a whole, over random padded witnesses
+    if 2 <= v <= 7:
+        wm = rand_fr(n * 43, sparse).reshape(n, 43, 4)
+        wi = [[ob.fr_to_int(x) for x in row] for row in wm]
+        ro, rp, g3 = rand_fr(v), rand_fr(v), rand_fr(2)
+        gi = ob.fr_to_int(g3[0])
+        sgi = [pow(gi, i, ob._R_P) for i in range(5)]
+        want = (ob.Stage3ShiftProver(wi, [ob.fr_to_int(x) for x in ro], [ob.fr_to_int(x) for x in rp], sgi),
+                ob.Stage3RegistersProver(wi, [ob.fr_to_int(x) for x in ro], ob.fr_to_int(g3[1])))
+        gotp = (api.ShiftPrefixSuffixProver(wm, ro, rp, np.stack([ob.fr_from_int(x) for x in sgi])), api.RegistersPrefixSuffixProver(wm, ro, g3[1]))
+        claim = rand_fr(1)[0]
+        for k in range(v):
+            ch = rand_ch()
+            for a, b in zip(gotp, want):
+                assert np.array_equal(a.computeRoundEvals(claim), b.computeRoundEvals(claim)), ("stage3", v, k, type(a).__name__)
+                a.bind(ch)
+                b.bind(ob.fr_to_int(ch))
+        for a in gotp:
+            a.deinit()
     cases += 1
 print(f"fuzz ok: {cases} random instances (all entry points) in {time.time() - t0:.1f} s")
