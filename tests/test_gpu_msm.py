@@ -611,6 +611,50 @@ def test_skewed_scalars_in_point_slices(zl, ob, gm, kind, monkeypatch):
     _check(zl, ob, gm[:n], None, sc, window_bits=13, precompute_levels=1)
 
 
+def test_point_slices_with_slice_local_references(zl, ob, monkeypatch):
+    """2^21 + 12345 points (a 2 GiB table) cut into five slices of ~420 k points: a slice's sorted references are level << 19 | point
+    instead of table rows, so the slice sorts with 7 fine bits where the handle's own plan has 5 (slice_sort_plan), and the accumulate
+    kernel decodes them. Checked by the closed form: bases (i+1)*G, so the MSM is (sum s_i (i+1))*G — one scalar multiplication on an
+    independent kernel path; also with the slice plan switched off, a sub-range that is not sliced, and 0/1 scalars."""
+    import torch
+    from zolt_amd import api
+    monkeypatch.setenv("ZG_MSM_TABLE_SPAN_MB", "512")
+    n = (1 << 21) + 12345
+    g = api.generator()
+    ks = np.zeros((n, 4), dtype=np.uint64)
+    ks[:, 0] = np.arange(1, n + 1, dtype=np.uint64)
+    bases, _ = zl.g1_scalar_mul_batch(np.repeat(g[None, :], n, axis=0), np.zeros(n, dtype=np.uint8), zl.field_op(zl.FR, zl.OP_TO_MONT, ks))
+    rng = np.random.default_rng(2121)
+    small = rng.integers(0, 1 << 40, size=n, dtype=np.uint64).astype(object)
+    big = [int(x) for x in rng.integers(0, 1 << 62, size=n, dtype=np.uint64)]
+    vals = [(int(a) << 180) + c for a, c in zip(small, big)]  # 220-bit scalars: every window is used
+    raw = np.array([[(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)] for v in vals], dtype=np.uint64)
+    sc = zl.field_op(zl.FR, zl.OP_TO_MONT, raw)
+    want_k = sum(v * (i + 1) for i, v in enumerate(vals)) % api.R_MOD
+    want = api.MSM.scalarMul(g, api.fr_from_int(want_k))
+    b = zl.Bases.upload(bases)
+    try:
+        assert b.plan()[0] >= 16
+        got = b.msm(sc)
+        assert got[1] == want[1] and np.array_equal(got[0], want[0])
+        monkeypatch.setenv("ZG_MSM_SLICE_LOCAL_REFS", "0")
+        got = b.msm(sc)
+        assert got[1] == want[1] and np.array_equal(got[0], want[0])
+        monkeypatch.delenv("ZG_MSM_SLICE_LOCAL_REFS")
+        m = 700001  # a sub-range below two slices: one launch set with table-row references on the same workspaces
+        sub_k = sum(v * (i + 1 + 1000) for i, v in enumerate(vals[:m])) % api.R_MOD
+        wsub = api.MSM.scalarMul(g, api.fr_from_int(sub_k))
+        gsub = b.msm(sc[:m], off=1000, n=m)
+        assert gsub[1] == wsub[1] and np.array_equal(gsub[0], wsub[0])
+        flags = rng.integers(0, 2, size=n)
+        fsc = ob.f_from_u64(ob.FR, flags.astype(np.uint64))
+        wf = api.MSM.scalarMul(g, api.fr_from_int(int(sum(int(i + 1) for i in np.nonzero(flags)[0])) % api.R_MOD))
+        gf = b.msm(fsc)
+        assert gf[1] == wf[1] and np.array_equal(gf[0], wf[0])
+    finally:
+        b.free()
+
+
 @pytest.mark.parametrize("span_pts", [700, 1300, 2600])
 def test_device_scalar_path_in_point_slices(zl, ob, gm, span_pts, monkeypatch):
     """A launch set whose table rows would span more than ZG_MSM_TABLE_SPAN_MB is cut into slices of consecutive points

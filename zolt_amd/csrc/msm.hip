@@ -90,6 +90,7 @@ struct zg_bases_s {
         uint32_t *d_tmp = nullptr;        // two-pass sort: entries partitioned by coarse bin, W * n
         uint32_t *d_cstarts = nullptr;    // two-pass sort: cstarts | totals | tstarts | istarts, NCB + 1 each
         uint32_t *d_fine = nullptr;       // two-pass sort: slicecnt[max items][2^fb] then fbase[NCB][2^fb]
+        size_t fine_words = 0;            // ... its size (a point slice may sort under its own plan: slice_sort_plan)
         char *d_partial = nullptr;        // NK * 144 B: bucket sums (lazy 29-bit-limb XYZZ records)
         char *d_slice_buckets = nullptr;  // point slices (msm_enqueue_sliced): the bucket sums of slices 1 .. S-1, built on first use
         size_t slice_buckets = 0;         // ... how many sets it holds
@@ -429,7 +430,7 @@ static constexpr uint32_t STAGE_ENTRIES = 32768;  // 128 KiB of LDS
 template <bool PLAIN>
 __global__ void __launch_bounds__(1024) msm_partition_kernel(const uint32_t *dig, uint32_t n, uint32_t n_pts, int W, int G, size_t table_n,
                                                              uint32_t off, uint32_t per_block, uint32_t NCB, int fb, int rb,
-                                                             const uint32_t *tstarts, const uint32_t *blockoff, uint32_t *tmp) {
+                                                             const uint32_t *tstarts, const uint32_t *blockoff, uint32_t *tmp, int local_shift) {
     ZG_HIPRIO();
     extern __shared__ uint32_t lds[];
     uint32_t *buf = lds, *cnt = lds + STAGE_ENTRIES, *lbase = cnt + NCB, *sums = lbase + NCB + 1;  // sums: 1024 scan partials
@@ -491,7 +492,10 @@ __global__ void __launch_bounds__(1024) msm_partition_kernel(const uint32_t *dig
             uint32_t w = (uint32_t)r >> jw2;
             uint32_t key = e[r] & 0x7FFFFFFFu, bin = key >> fb, lvl = (PLAIN || G == 1) ? w : w / (uint32_t)G;
             uint32_t pt = ((uint32_t)r & jw2) ? pt_row1 : pt_row0;
-            uint32_t packed = (e[r] & 0x80000000u) | ((key & fmask) << rb) | (uint32_t)((size_t)lvl * table_n + off + pt);
+            // a point slice keeps slice-local references level << local_shift | point in the INTERMEDIATE entries (fewer bits than a table
+            // row index: more fine bits, fewer coarse bins); msm_fine_place_kernel writes table rows into the final list
+            const uint32_t ref = local_shift ? (lvl << local_shift) | pt : (uint32_t)((size_t)lvl * table_n + off + pt);
+            uint32_t packed = (e[r] & 0x80000000u) | ((key & fmask) << rb) | ref;
             buf[lbase[bin] + atomicAdd(&cnt[bin], 1u)] = packed;
         }
     }
@@ -577,7 +581,8 @@ __global__ void __launch_bounds__(1024) msm_fine_count_kernel(const uint32_t *tm
 // fine key's run is copied to  cstarts[bin] + fbase[bin][f] + (prefix over the earlier slices)  with coalesced stores.
 __global__ void __launch_bounds__(1024) msm_fine_place_kernel(const uint32_t *tmp, const uint32_t *cstarts, const uint32_t *tstarts,
                                                               const uint32_t *istarts, uint32_t NCB, int fb, int rb, const uint32_t *slicecnt,
-                                                              const uint32_t *fbase, uint32_t *sorted) {
+                                                              const uint32_t *fbase, uint32_t *sorted, int local_shift, uint32_t table_n,
+                                                              uint32_t off) {
     ZG_HIPRIO();
     extern __shared__ uint32_t lds[];
     uint32_t *buf = lds, *cnt = lds + STAGE_ENTRIES, *lbase = cnt + 128;  // lbase: 129 entries
@@ -631,7 +636,11 @@ __global__ void __launch_bounds__(1024) msm_fine_place_kernel(const uint32_t *tm
         for (int j = 0; j < 4; j++)
             if (4 * q + j < count) {
                 uint32_t f = (e[j] >> rb) & fmask;
-                buf[lbase[f] + atomicAdd(&cnt[f], 1u)] = (e[j] & 0x80000000u) | (e[j] & rmask);
+                uint32_t ref = e[j] & rmask;
+                // a point slice sorted on slice-local references (level << shift | point): the final list holds table rows again,
+                // so the accumulate kernel is the same for every launch (decoding there cost it 3 %)
+                if (local_shift) ref = (ref >> local_shift) * table_n + off + (ref & ((1u << local_shift) - 1u));
+                buf[lbase[f] + atomicAdd(&cnt[f], 1u)] = (e[j] & 0x80000000u) | ref;
             }
     }
     __syncthreads();
@@ -1481,6 +1490,45 @@ static void plan_two_pass(MsmPlan &p, size_t table_rows, size_t n_total) {
     p.NCB = ncb;
 }
 
+// ---- point slices (see msm_enqueue_lane): how a launch set of n_pts points under plan p is cut, and the sort plan of one slice
+static size_t table_span_points(int L) {
+    const size_t span_mb = (size_t)env_int("ZG_MSM_TABLE_SPAN_MB", 1024);  // 0 = never slice
+    if (!span_mb) return 0;
+    const size_t pts = (span_mb << 20) / (64 * (size_t)L), least = (size_t)env_int("ZG_MSM_TABLE_SPAN_MIN_POINTS", 65536);  // tests lower it
+    return pts < least ? least : pts;
+}
+static constexpr size_t DEV_SLICES_MAX = 128;  // 2^27 bases (the most a handle takes) / 2^20
+static void slice_counts(const MsmPlan &p, size_t n_pts, size_t &S, size_t &per) {
+    S = 1;
+    per = n_pts;
+    if (p.K != 1) return;
+    const size_t sp = table_span_points(p.L);
+    if (!sp || n_pts < 2 * sp) return;  // slices only pay when there are at least two full ones
+    S = (n_pts + sp - 1) / sp;
+    if (S > DEV_SLICES_MAX) S = DEV_SLICES_MAX;
+    per = (n_pts + S - 1) / S;
+    S = (n_pts + per - 1) / per;  // no empty slice
+}
+// A slice's sorted references need not be table rows (L * n of them): level << shift | point-of-the-slice takes fewer bits, which
+// leaves more fine-key bits in a 32-bit intermediate entry and therefore fewer coarse bins — at 2^22 points the slices then sort under
+// the 2^20 plan (7 fine bits, 512 bins: 130 us) instead of the handle's (5 bits, 2048 bins: 181 us). The second pass writes table rows
+// into the final list (msm_fine_place_kernel). Returns false when the slice plan is no finer than the handle's.
+static void plan_two_pass(MsmPlan &p, size_t table_rows, size_t n_total);
+static bool slice_sort_plan(const MsmPlan &p, size_t per, MsmPlan &ps, int &shift) {
+    shift = 0;
+    ps = p;
+    if (!p.fb || !p.NT || !env_int("ZG_MSM_SLICE_LOCAL_REFS", 1)) return false;
+    int k = 1;
+    while (((size_t)1 << k) < per) k++;
+    plan_two_pass(ps, (size_t)p.L << k, per);
+    if (ps.fb <= p.fb) {
+        ps = p;
+        return false;
+    }
+    shift = k;
+    return true;
+}
+
 static size_t fine_max_items(const MsmPlan &p, size_t n_total) { return (size_t)p.NCB + (size_t)p.W * n_total / FINE_SLICE + 1; }
 
 static void lane_free(zg_bases_s::Lane &ln) {
@@ -1506,7 +1554,18 @@ static hipError_t lane_alloc(zg_bases_s::Lane &ln, const MsmPlan &p, size_t n_to
         A(ln.d_blockhist, (size_t)nblk_lds * p.NCB * 4);
         A(ln.d_tmp, ((size_t)p.W * n_total + 4 * (size_t)p.NCB + 4) * 4);
         A(ln.d_cstarts, (4 * (size_t)p.NCB + 8) * 4);
-        A(ln.d_fine, (fine_max_items(p, n_total) + (size_t)p.NCB) * ((size_t)1 << p.fb) * 4);
+        ln.fine_words = (fine_max_items(p, n_total) + (size_t)p.NCB) * ((size_t)1 << p.fb);
+        {
+            size_t S, per;
+            MsmPlan ps;
+            int shift;
+            slice_counts(p, n_total, S, per);
+            if (S > 1 && slice_sort_plan(p, per, ps, shift)) {
+                const size_t w = (fine_max_items(ps, per) + (size_t)ps.NCB) * ((size_t)1 << ps.fb);
+                if (w > ln.fine_words) ln.fine_words = w;
+            }
+        }
+        A(ln.d_fine, ln.fine_words * 4);
     } else if (nblk_lds) {
         A(ln.d_blockhist, (size_t)nblk_lds * p.NK * 4);
     }
@@ -1733,17 +1792,11 @@ static int ensure_aux_streams(zg_bases_s *b) {
 // the sets up bucket by bucket, and the reduction runs ONCE — the fixed tail is not multiplied (slices as separate MSMs with
 // a Jacobian combine were measured first: 4 x 0.45 ms of sorts and tails ate the whole gain). The sums are the same group
 // elements, so the result bytes are those of the unsliced launch set.
-static size_t table_span_points(const zg_bases_s *b) {
-    const size_t span_mb = (size_t)env_int("ZG_MSM_TABLE_SPAN_MB", 1024);  // 0 = never slice
-    if (!span_mb) return 0;
-    const size_t pts = (span_mb << 20) / (64 * (size_t)b->plan.L), least = (size_t)env_int("ZG_MSM_TABLE_SPAN_MIN_POINTS", 65536);  // tests lower it
-    return pts < least ? least : pts;
-}
+static size_t table_span_points(const zg_bases_s *b) { return table_span_points(b->plan.L); }
 struct SliceView {  // what the sort of a point slice hands to its accumulation
     uint32_t *sorted, *starts, *nzrank, *nzlist;
     void *state;
 };
-static constexpr size_t DEV_SLICES_MAX = 128;  // 2^27 bases (the most a handle takes) / 2^20
 
 // bucket set 0 += sets 1 .. S-1 (set j at sets + (j-1) * NK * 144), one quad of lanes per bucket
 __global__ void __launch_bounds__(256) msm_bucket_fold_kernel(char *buckets, const char *sets, uint32_t NK, uint32_t S) {
@@ -1786,14 +1839,15 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
     if (ln.used) ZG_HIP(hipStreamWaitEvent(st, ln.done, 0));  // the lane's previous MSM may be on another stream
     ln.used = true;
     // point slices (see table_span_points): S > 1 only for one scalar vector over a table wider than the span
-    size_t S = 1, per = n_pts;
-    if (p.K == 1) {
-        const size_t sp = table_span_points(b);
-        if (sp && n_pts >= 2 * sp) {  // slices only pay when there are at least two full ones
-            S = (n_pts + sp - 1) / sp;
-            if (S > DEV_SLICES_MAX) S = DEV_SLICES_MAX;
-            per = (n_pts + S - 1) / S;
-            S = (n_pts + per - 1) / per;  // no empty slice
+    size_t S, per;
+    slice_counts(p, n_pts, S, per);
+    MsmPlan ps = p;  // the sort plan of a slice (slice_sort_plan)
+    int local_shift = 0;
+    if (S > 1 && slice_sort_plan(p, per, ps, local_shift)) {
+        const size_t need = (fine_max_items(ps, per) + (size_t)ps.NCB) * ((size_t)1 << ps.fb);
+        if (need > ln.fine_words || ps.NCB > p.NCB) {  // the workspace was sized under another slice setting: keep table-row references
+            ps = p;
+            local_shift = 0;
         }
     }
     // per slice: bucket starts, non-empty ranks, non-empty list, reduction state (what a sort hands to its accumulation), 16-byte aligned
@@ -1816,6 +1870,7 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
 #endif
     const size_t n = n_pts * (size_t)p.K;  // scalars in this launch set
     const uint8_t *infp = b->d_inf ? b->d_inf + off : nullptr;
+    const MsmPlan &q = local_shift ? ps : p;  // fine bits / coarse bins of this launch
     if (p.fb) {
         // two-pass sort: blocks of 256 threads over TWO_PASS_SPAN scalars each (coarse counters are a few KiB of LDS)
         uint32_t nblk = (uint32_t)div_up(n, two_pass_span(p.W));  // per_block * W <= STAGE_ENTRIES
@@ -1825,30 +1880,30 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
         }
         uint32_t per_block = (uint32_t)((n + nblk - 1) / nblk);
         prof_begin(ZG_PROF_MSM_DIGITS, st);
-        ZG_TRY(launch_digits_lds_c(p.c, st, d_scalars, infp, (uint32_t)n, (uint32_t)n_pts, p.G, per_block, p.NCB, nblk, ln.d_dig,
-                                   ln.d_blockhist, p.fb, 256));
+        ZG_TRY(launch_digits_lds_c(p.c, st, d_scalars, infp, (uint32_t)n, (uint32_t)n_pts, p.G, per_block, q.NCB, nblk, ln.d_dig,
+                                   ln.d_blockhist, q.fb, 256));
         prof_end(ZG_PROF_MSM_DIGITS, st);
         prof_begin(ZG_PROF_MSM_SORT, st);
-        uint32_t *d_tot = ln.d_cstarts + p.NCB + 1, *d_tst = ln.d_cstarts + 2 * (size_t)p.NCB + 2, *d_ist = ln.d_cstarts + 3 * (size_t)p.NCB + 3;
-        hipLaunchKernelGGL(msm_colscan_bins_kernel, dim3(div_up(p.NCB, 16)), dim3(1024), 0, st, ln.d_blockhist, nblk, p.NCB, d_tot);
-        hipLaunchKernelGGL(msm_coarse_base_kernel, dim3(1), dim3(1024), 0, st, d_tot, p.NCB, ln.d_cstarts, d_tst, d_ist);
+        uint32_t *d_tot = ln.d_cstarts + q.NCB + 1, *d_tst = ln.d_cstarts + 2 * (size_t)q.NCB + 2, *d_ist = ln.d_cstarts + 3 * (size_t)q.NCB + 3;
+        hipLaunchKernelGGL(msm_colscan_bins_kernel, dim3(div_up(q.NCB, 16)), dim3(1024), 0, st, ln.d_blockhist, nblk, q.NCB, d_tot);
+        hipLaunchKernelGGL(msm_coarse_base_kernel, dim3(1), dim3(1024), 0, st, d_tot, q.NCB, ln.d_cstarts, d_tst, d_ist);
         ZG_TRY(two_pass_attrs());
         if (p.G == 1 && n == n_pts)
-            hipLaunchKernelGGL(msm_partition_kernel<true>, dim3(nblk), dim3(1024), (STAGE_ENTRIES + 2 * (size_t)p.NCB + 1 + 1024) * 4, st, ln.d_dig,
-                               (uint32_t)n, (uint32_t)n_pts, p.W, p.G, b->n, (uint32_t)off, per_block, p.NCB, p.fb, p.rb, d_tst, ln.d_blockhist,
-                               ln.d_tmp);
+            hipLaunchKernelGGL(msm_partition_kernel<true>, dim3(nblk), dim3(1024), (STAGE_ENTRIES + 2 * (size_t)q.NCB + 1 + 1024) * 4, st, ln.d_dig,
+                               (uint32_t)n, (uint32_t)n_pts, p.W, p.G, b->n, (uint32_t)off, per_block, q.NCB, q.fb, q.rb, d_tst, ln.d_blockhist,
+                               ln.d_tmp, local_shift);
         else
-            hipLaunchKernelGGL(msm_partition_kernel<false>, dim3(nblk), dim3(1024), (STAGE_ENTRIES + 2 * (size_t)p.NCB + 1 + 1024) * 4, st, ln.d_dig,
-                               (uint32_t)n, (uint32_t)n_pts, p.W, p.G, b->n, (uint32_t)off, per_block, p.NCB, p.fb, p.rb, d_tst, ln.d_blockhist,
-                               ln.d_tmp);
+            hipLaunchKernelGGL(msm_partition_kernel<false>, dim3(nblk), dim3(1024), (STAGE_ENTRIES + 2 * (size_t)q.NCB + 1 + 1024) * 4, st, ln.d_dig,
+                               (uint32_t)n, (uint32_t)n_pts, p.W, p.G, b->n, (uint32_t)off, per_block, q.NCB, q.fb, q.rb, d_tst, ln.d_blockhist,
+                               ln.d_tmp, local_shift);
         {
-            uint32_t items = (uint32_t)fine_max_items(p, n);
-            uint32_t *d_fbase = ln.d_fine + (size_t)items * ((size_t)1 << p.fb);
-            hipLaunchKernelGGL(msm_fine_count_kernel, dim3(items), dim3(1024), 0, st, ln.d_tmp, ln.d_cstarts, d_tst, d_ist, p.NCB, p.fb, p.rb,
+            uint32_t items = (uint32_t)fine_max_items(q, n);
+            uint32_t *d_fbase = ln.d_fine + (size_t)items * ((size_t)1 << q.fb);
+            hipLaunchKernelGGL(msm_fine_count_kernel, dim3(items), dim3(1024), 0, st, ln.d_tmp, ln.d_cstarts, d_tst, d_ist, q.NCB, q.fb, q.rb,
                                ln.d_fine);
-            hipLaunchKernelGGL(msm_fine_offsets_kernel, dim3(p.NCB), dim3(128), 0, st, d_ist, p.fb, p.NK, ln.d_fine, d_fbase, ln.d_hist);
+            hipLaunchKernelGGL(msm_fine_offsets_kernel, dim3(q.NCB), dim3(128), 0, st, d_ist, q.fb, p.NK, ln.d_fine, d_fbase, ln.d_hist);
             hipLaunchKernelGGL(msm_fine_place_kernel, dim3(items), dim3(1024), (STAGE_ENTRIES + 128 + 132) * 4, st, ln.d_tmp, ln.d_cstarts, d_tst,
-                               d_ist, p.NCB, p.fb, p.rb, ln.d_fine, d_fbase, sv.sorted);
+                               d_ist, q.NCB, q.fb, q.rb, ln.d_fine, d_fbase, sv.sorted, local_shift, (uint32_t)b->n, (uint32_t)off);
         }
         uint32_t tiles = div_up(p.NK, 1024);
         hipLaunchKernelGGL(msm_scan_a_kernel, dim3(tiles), dim3(1024), 0, st, ln.d_hist, p.NK, ln.d_scan_tmp, ln.d_scan_tmp + p.NK,
