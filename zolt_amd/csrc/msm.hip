@@ -91,6 +91,7 @@ struct zg_bases_s {
         uint32_t *d_cstarts = nullptr;    // two-pass sort: cstarts | totals | tstarts | istarts, NCB + 1 each
         uint32_t *d_fine = nullptr;       // two-pass sort: slicecnt[max items][2^fb] then fbase[NCB][2^fb]
         size_t fine_words = 0;            // ... its size (a point slice may sort under its own plan: slice_sort_plan)
+        size_t blockhist_words = 0, tmp_words = 0, cstarts_words = 0;  // sizes of the two-pass buffers (0 = not there)
         char *d_partial = nullptr;        // NK * 144 B: bucket sums (lazy 29-bit-limb XYZZ records)
         char *d_slice_buckets = nullptr;  // point slices (msm_enqueue_sliced): the bucket sums of slices 1 .. S-1, built on first use
         size_t slice_buckets = 0;         // ... how many sets it holds
@@ -1517,7 +1518,7 @@ static void plan_two_pass(MsmPlan &p, size_t table_rows, size_t n_total);
 static bool slice_sort_plan(const MsmPlan &p, size_t per, MsmPlan &ps, int &shift) {
     shift = 0;
     ps = p;
-    if (!p.fb || !p.NT || !env_int("ZG_MSM_SLICE_LOCAL_REFS", 1)) return false;
+    if (!p.NT || !env_int("ZG_MSM_SLICE_LOCAL_REFS", 1)) return false;  // (p.fb == 0: the handle's own launch sets sort in one pass)
     int k = 1;
     while (((size_t)1 << k) < per) k++;
     plan_two_pass(ps, (size_t)p.L << k, per);
@@ -1550,24 +1551,36 @@ static hipError_t lane_alloc(zg_bases_s::Lane &ln, const MsmPlan &p, size_t n_to
     A(ln.d_sorted, (size_t)p.W * n_total * 4);
     A(ln.d_hist, (size_t)p.NK * 4);
     A(ln.d_starts, ((size_t)p.NK + 1) * 4);
-    if (p.fb) {
-        A(ln.d_blockhist, (size_t)nblk_lds * p.NCB * 4);
-        A(ln.d_tmp, ((size_t)p.W * n_total + 4 * (size_t)p.NCB + 4) * 4);
-        A(ln.d_cstarts, (4 * (size_t)p.NCB + 8) * 4);
-        ln.fine_words = (fine_max_items(p, n_total) + (size_t)p.NCB) * ((size_t)1 << p.fb);
-        {
-            size_t S, per;
-            MsmPlan ps;
-            int shift;
-            slice_counts(p, n_total, S, per);
-            if (S > 1 && slice_sort_plan(p, per, ps, shift)) {
-                const size_t w = (fine_max_items(ps, per) + (size_t)ps.NCB) * ((size_t)1 << ps.fb);
-                if (w > ln.fine_words) ln.fine_words = w;
-            }
+    {
+        // two-pass sort buffers: for the handle's own plan (p.fb), for the plan of a point slice (slice_sort_plan: a handle whose own
+        // launch sets sort in one pass — 2^23 points and up, where a table row index leaves fewer than 5 fine bits — still sorts its
+        // slices in two), or both; every buffer takes the larger of the two needs
+        size_t S, per;
+        MsmPlan ps;
+        int shift;
+        slice_counts(p, n_total, S, per);
+        const bool slice_two_pass = S > 1 && slice_sort_plan(p, per, ps, shift);
+        size_t bh = 0, tmp = 0, cst = 0, fine = 0;
+        if (p.fb) {
+            bh = (size_t)nblk_lds * p.NCB;
+            tmp = (size_t)p.W * n_total + 4 * (size_t)p.NCB + 4;
+            cst = 4 * (size_t)p.NCB + 8;
+            fine = (fine_max_items(p, n_total) + (size_t)p.NCB) * ((size_t)1 << p.fb);
+        } else if (nblk_lds) {
+            bh = (size_t)nblk_lds * p.NK;
         }
-        A(ln.d_fine, ln.fine_words * 4);
-    } else if (nblk_lds) {
-        A(ln.d_blockhist, (size_t)nblk_lds * p.NK * 4);
+        if (slice_two_pass) {
+            const size_t nblk_s = div_up(per, two_pass_span(p.W));
+            bh = std::max(bh, nblk_s * ps.NCB);
+            tmp = std::max(tmp, (size_t)p.W * per + 4 * (size_t)ps.NCB + 4);
+            cst = std::max(cst, 4 * (size_t)ps.NCB + 8);
+            fine = std::max(fine, (fine_max_items(ps, per) + (size_t)ps.NCB) * ((size_t)1 << ps.fb));
+        }
+        if (bh) A(ln.d_blockhist, bh * 4);
+        if (tmp) A(ln.d_tmp, tmp * 4);
+        if (cst) A(ln.d_cstarts, cst * 4);
+        if (fine) A(ln.d_fine, fine * 4);
+        ln.blockhist_words = bh; ln.tmp_words = tmp; ln.cstarts_words = cst; ln.fine_words = fine;
     }
     A(ln.d_partial, (size_t)p.NK * 144);
     {
@@ -1844,9 +1857,10 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
     MsmPlan ps = p;  // the sort plan of a slice (slice_sort_plan)
     int local_shift = 0;
     if (S > 1 && slice_sort_plan(p, per, ps, local_shift)) {
-        const size_t need = (fine_max_items(ps, per) + (size_t)ps.NCB) * ((size_t)1 << ps.fb);
-        if (need > ln.fine_words || ps.NCB > p.NCB) {  // the workspace was sized under another slice setting: keep table-row references
-            ps = p;
+        const size_t nblk_s = div_up(per, two_pass_span(p.W));
+        if ((fine_max_items(ps, per) + (size_t)ps.NCB) * ((size_t)1 << ps.fb) > ln.fine_words || nblk_s * ps.NCB > ln.blockhist_words ||
+            (size_t)p.W * per + 4 * (size_t)ps.NCB + 4 > ln.tmp_words || 4 * (size_t)ps.NCB + 8 > ln.cstarts_words) {
+            ps = p;  // the workspace was sized under another slice setting: keep table-row references and the handle's plan
             local_shift = 0;
         }
     }
@@ -1871,10 +1885,10 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
     const size_t n = n_pts * (size_t)p.K;  // scalars in this launch set
     const uint8_t *infp = b->d_inf ? b->d_inf + off : nullptr;
     const MsmPlan &q = local_shift ? ps : p;  // fine bits / coarse bins of this launch
-    if (p.fb) {
+    if (q.fb) {
         // two-pass sort: blocks of 256 threads over TWO_PASS_SPAN scalars each (coarse counters are a few KiB of LDS)
         uint32_t nblk = (uint32_t)div_up(n, two_pass_span(p.W));  // per_block * W <= STAGE_ENTRIES
-        if (nblk > nblk_cap) {
+        if ((size_t)nblk * q.NCB > ln.blockhist_words) {
             set_error("msm: two-pass workspace too small for this launch");
             return ZG_ERR_INVALID;
         }
