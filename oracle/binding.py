@@ -2354,3 +2354,108 @@ def dory_evaluation_vectors(point, nu, sigma):
         right[:] = dory_multilinear_lagrange_basis(pt[:sigma])
         left[:] = dory_multilinear_lagrange_basis(pt[sigma:], 1 << nu)
     return left, right
+
+
+# ---------------------------------------------------------------- the remaining fold sites (canonical integers; small restatements)
+class SpartanOuterRounds:
+    """SpartanOuterProver.computeStandardRoundPoly / bindChallenge (src/zkvm/spartan/outer.zig:364-407) over working_vals"""
+
+    def __init__(self, working_vals):
+        self.vals = [fr_to_int(x) for x in _c(working_vals).reshape(-1, 4)]
+        self.challenges = []
+
+    def computeStandardRoundPoly(self):
+        P = _R_P
+        if len(self.vals) <= 1:
+            return [self.vals[0] if self.vals else 0, 0, 0]
+        p0, p1 = sum(self.vals[0::2]) % P, sum(self.vals[1::2]) % P
+        return [p0, p1, (2 * p1 - p0) % P]
+
+    def bindChallenge(self, r):
+        self.challenges.append(r)
+        if len(self.vals) > 1:
+            self.vals = [((1 - r) * self.vals[2 * i] + r * self.vals[2 * i + 1]) % _R_P for i in range(len(self.vals) // 2)]
+
+
+class Phase1Prover:
+    """Phase1Prover (src/zkvm/spartan/prefix_suffix.zig:35-147): P / Q pairs, g(0) = sum P[2i] Q[2i], g(1) = sum P[2i+1] Q[2i+1] (:95-112),
+    bind every buffer low to high (:114-132)"""
+
+    def __init__(self):
+        self.pairs, self.challenges, self.current_size = [], [], 0
+
+    def addPair(self, P, Q):
+        P, Q = [fr_to_int(x) for x in _c(P).reshape(-1, 4)], [fr_to_int(x) for x in _c(Q).reshape(-1, 4)]
+        assert len(P) == len(Q) and (self.current_size in (0, len(P)))
+        self.current_size = len(P)
+        self.pairs.append([P, Q])
+
+    def shouldTransition(self):
+        return self.current_size <= 2
+
+    def computeRoundEvals(self):
+        g0 = g1 = 0
+        for P, Q in self.pairs:
+            for i in range(self.current_size // 2):
+                g0 += P[2 * i] * Q[2 * i]
+                g1 += P[2 * i + 1] * Q[2 * i + 1]
+        return [g0 % _R_P, g1 % _R_P]
+
+    def bind(self, r):
+        self.challenges.append(r)
+        half = self.current_size // 2
+        for pq in self.pairs:
+            for t in range(2):
+                v = pq[t]
+                pq[t] = [(v[2 * i] + r * (v[2 * i + 1] - v[2 * i])) % _R_P for i in range(half)]
+        self.current_size = half
+
+
+def init_shift_q_buffers(unexpanded_pc, pc, is_virtual, is_first_in_sequence, is_noop, suffix_0_outer, suffix_1_outer, suffix_0_product,
+                         suffix_1_product, gamma_powers, prefix_size):
+    """initShiftQBuffers (src/zkvm/spartan/prefix_suffix.zig:149-232) -> (Q_0_outer, Q_1_outer, Q_0_product, Q_1_product), (prefix_size, 4) each"""
+    P = _R_P
+    cols = [[fr_to_int(x) for x in _c(t).reshape(-1, 4)] for t in (unexpanded_pc, pc, is_virtual, is_first_in_sequence, is_noop)]
+    suf = [[fr_to_int(x) for x in _c(t).reshape(-1, 4)] for t in (suffix_0_outer, suffix_1_outer, suffix_0_product, suffix_1_product)]
+    g = [fr_to_int(x) for x in _c(gamma_powers).reshape(-1, 4)]
+    ss = len(suf[0])
+    assert len(cols[0]) == prefix_size * ss and len(g) >= 5
+    Q = [[0] * prefix_size for _ in range(4)]
+    for hi in range(ss):
+        for lo in range(prefix_size):
+            x = lo + hi * prefix_size
+            v = (cols[0][x] + g[1] * cols[1][x] + g[2] * cols[2][x] + g[3] * cols[3][x]) % P
+            Q[0][lo] = (Q[0][lo] + v * suf[0][hi]) % P
+            Q[1][lo] = (Q[1][lo] + v * suf[1][hi]) % P
+            nf = (1 - cols[4][x]) % P
+            Q[2][lo] = (Q[2][lo] + nf * suf[2][hi]) % P
+            Q[3][lo] = (Q[3][lo] + nf * suf[3][hi]) % P
+    Q[2] = [q * g[4] % P for q in Q[2]]
+    Q[3] = [q * g[4] % P for q in Q[3]]
+    return tuple(np.stack([fr_from_int(v) for v in q]) for q in Q)
+
+
+class LassoPrefixPolynomial:
+    """PrefixPolynomial (src/zkvm/lasso/prefix_suffix.zig:133-231): bind = the high-half fold new[i] = old[i] (1 - c) + old[i + half] c
+    (:175-196); evaluate = sum_i evals[i] prod_j (bit_j(i) ? point[j] : 1 - point[j]) (:198-216)"""
+
+    def __init__(self, evaluations):
+        self.evaluations = [fr_to_int(x) for x in _c(evaluations).reshape(-1, 4)]
+        self.num_vars = len(self.evaluations).bit_length() - 1
+
+    def bind(self, c):
+        h = len(self.evaluations) // 2
+        out = LassoPrefixPolynomial.__new__(LassoPrefixPolynomial)
+        out.evaluations = [(self.evaluations[i] * (1 - c) + self.evaluations[i + h] * c) % _R_P for i in range(h)]
+        out.num_vars = self.num_vars - 1
+        return out
+
+    def evaluate(self, point):
+        assert len(point) == self.num_vars
+        r = 0
+        for i, e in enumerate(self.evaluations):
+            t = e
+            for j, pj in enumerate(point):
+                t = t * (pj if (i >> j) & 1 else (1 - pj)) % _R_P
+            r += t
+        return r % _R_P

@@ -550,6 +550,39 @@ TEST(stages_5_and_6) {
     EXPECT(proveStage5({}, 3, te).skipped && proveStage6(0, te).skipped);
 }
 
+// the reference's own vectors for the last fold sites: src/zkvm/spartan/prefix_suffix.zig "Phase1Prover basic" (P = [1,2,3,4], Q = [5,6,7,8]:
+// evaluations (26, 44), bind 2 -> P = [3, 5]) and src/zkvm/lasso/prefix_suffix.zig "prefix polynomial bind" ([1,2,3,4] at 2 -> [5, 6])
+TEST(remaining_fold_sites_on_the_references_vectors) {
+    auto f = [](std::initializer_list<uint64_t> v) { std::vector<Fr> o; for (uint64_t x : v) o.push_back(Fr::fromU64(x)); return o; };
+    Phase1Prover p;
+    p.addPair(f({1, 2, 3, 4}), f({5, 6, 7, 8}));
+    auto ev = p.computeRoundEvals();
+    EXPECT(ev[0].eql(Fr::fromU64(26)) && ev[1].eql(Fr::fromU64(44)) && !p.shouldTransition());
+    p.bind(Fr::fromU64(2));
+    auto P = p.buffer(0, false);
+    EXPECT(p.current_size == 2 && P.size() == 2 && P[0].eql(Fr::fromU64(3)) && P[1].eql(Fr::fromU64(5)) && p.shouldTransition());
+    // three pairs: two in one pair-sum term, one as a plain product
+    Phase1Prover p3;
+    p3.addPair(f({1, 2, 3, 4}), f({5, 6, 7, 8}));
+    p3.addPair(f({2, 0, 1, 3}), f({1, 1, 2, 2}));
+    p3.addPair(f({7, 1, 0, 9}), f({3, 4, 5, 6}));
+    auto e3 = p3.computeRoundEvals();  // g0 = 26 + (2 + 2) + (21 + 0), g1 = 44 + (0 + 6) + (4 + 54)
+    EXPECT(e3[0].eql(Fr::fromU64(51)) && e3[1].eql(Fr::fromU64(108)));
+    LassoPrefixPolynomial lp(f({1, 2, 3, 4}));
+    auto b = lp.bind(Fr::fromU64(2));
+    EXPECT(b.num_vars == 1 && b.evaluations[0].eql(Fr::fromU64(5)) && b.evaluations[1].eql(Fr::fromU64(6)));
+    EXPECT(lp.evaluate({Fr::one(), Fr::zero()}).eql(Fr::fromU64(2)) && lp.evaluate({Fr::zero(), Fr::one()}).eql(Fr::fromU64(3)));
+    SpartanOuterProver o(f({1, 2, 3, 4}));
+    auto r0 = o.computeStandardRoundPoly();
+    EXPECT(r0[0].eql(Fr::fromU64(4)) && r0[1].eql(Fr::fromU64(6)) && r0[2].eql(Fr::fromU64(8)));
+    o.bindChallenge(Fr::fromU64(3));  // [(1 - 3) * 1 + 3 * 2, (1 - 3) * 3 + 3 * 4] = [4, 6]
+    auto r1 = o.computeStandardRoundPoly();
+    EXPECT(r1[0].eql(Fr::fromU64(4)) && r1[1].eql(Fr::fromU64(6)));
+    o.bindChallenge(Fr::fromU64(2));  // 4 * (1 - 2) + 6 * 2 = 8
+    auto r2 = o.computeStandardRoundPoly();
+    EXPECT(r2[0].eql(Fr::fromU64(8)) && r2[1].isZero() && r2[2].isZero());
+}
+
 // `test_host_mirror rwc <file>`: runs zolt::RamReadWriteCheckingProver on the instance the file describes (written by
 // tests/test_gpu_cpp_host.py: the reference's captured run and random traces) and prints every round polynomial, claim, entry count and
 // the opening claims as hex limbs; the Python test compares the lines with the oracle's.

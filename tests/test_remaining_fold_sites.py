@@ -1,0 +1,117 @@
+"""SURVEY 8(f)3, the last fold sites the review listed: SpartanOuterProver's standard rounds (src/zkvm/spartan/outer.zig:364-407),
+Phase1Prover / initShiftQBuffers (src/zkvm/spartan/prefix_suffix.zig:35-232) and the Lasso PrefixPolynomial (src/zkvm/lasso/
+prefix_suffix.zig:133-231). The restatements are pinned on the reference's OWN test vectors (prefix_suffix.zig "Phase1Prover basic":
+P = [1,2,3,4], Q = [5,6,7,8] -> (26, 44), bind 2 -> P = [3, 5]; lasso "prefix polynomial bind": [1,2,3,4] bound at 2 -> [5, 6]); the device
+mirrors against the restatements on random tables."""
+import numpy as np
+import pytest
+
+from tests import util as U
+
+
+def _ob():
+    from oracle import binding as ob
+    return ob
+
+
+def test_restatements_on_the_references_own_vectors():
+    ob = _ob()
+    f = lambda vals: np.stack([ob.fr_from_int(v) for v in vals])
+    p = ob.Phase1Prover()
+    p.addPair(f([1, 2, 3, 4]), f([5, 6, 7, 8]))
+    assert p.computeRoundEvals() == [26, 44] and not p.shouldTransition()
+    p.bind(2)
+    assert p.current_size == 2 and p.pairs[0][0] == [3, 5] and p.shouldTransition()
+    lp = ob.LassoPrefixPolynomial(f([1, 2, 3, 4])).bind(2)
+    assert lp.num_vars == 1 and lp.evaluations == [5, 6]
+    # evaluate: the index's low bit belongs to point[0] (prefix_suffix.zig:198-216)
+    q = ob.LassoPrefixPolynomial(f([1, 2, 3, 4]))
+    P = ob._R_P
+    assert q.evaluate([0, 0]) == 1 and q.evaluate([1, 0]) == 2 and q.evaluate([0, 1]) == 3 and q.evaluate([1, 1]) == 4
+    assert q.evaluate([5, 7]) == (1 * (1 - 5) * (1 - 7) + 2 * 5 * (1 - 7) + 3 * (1 - 5) * 7 + 4 * 35) % P
+    # SpartanOuterProver rounds: p(2) = 2 p(1) - p(0); the fold (1 - r) even + r odd
+    o = ob.SpartanOuterRounds(f([1, 2, 3, 4]))
+    assert o.computeStandardRoundPoly() == [4, 6, 8]
+    o.bindChallenge(3)
+    assert o.vals == [(1 - 3) * 1 + 3 * 2, (1 - 3) * 3 + 3 * 4]
+    o.bindChallenge(2)
+    assert o.computeStandardRoundPoly() == [o.vals[0], 0, 0]
+    # initShiftQBuffers against the whole-prover restatement's own Q tables (two routes to the same sums)
+    n = 4
+    T = 1 << n
+    w = [[int(v) for v in row] for row in np.random.default_rng(5).integers(0, 1 << 40, size=(T, 43))]
+    ro, rp = [3, 5, 7, 11], [13, 17, 19, 23]
+    g = [pow(29, i, P) for i in range(5)]
+    sh = ob.Stage3ShiftProver(w, ro, rp, g)
+    col = lambda name: f([row[ob.R1CS_INPUT_NAMES.index(name)] for row in w])
+    q = ob.init_shift_q_buffers(col("UnexpandedPC"), col("PC"), col("FlagVirtualInstruction"), col("FlagIsFirstInSequence"), col("FlagIsNoop"),
+                                f(ob._s3_eq(ro[:2])), f(ob._s3_eqp1(ro[:2])), f(ob._s3_eq(rp[:2])), f(ob._s3_eqp1(rp[:2])), f(g), 4)
+    assert [[ob.fr_to_int(x) for x in t] for t in q] == sh.Q
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("v", [1, 2, 5, 10, 14])
+def test_device_mirrors_of_the_remaining_fold_sites(v):
+    ob = _ob()
+    from zolt_amd import api, lib
+    lib.init()
+    n = 1 << v
+    rnd = lambda seed, k: ob.f_to_mont(ob.FR, U.random_raw256(seed, k))
+    ch = rnd(8100 + v, v + 1)
+    # SpartanOuterProver
+    tab = rnd(8000 + v, n)
+    a, b = api.SpartanOuterProver(tab), ob.SpartanOuterRounds(tab)
+    for k in range(v + 1):
+        assert [ob.fr_to_int(x) for x in a.computeStandardRoundPoly()] == b.computeStandardRoundPoly(), k
+        a.bindChallenge(ch[k])
+        b.bindChallenge(ob.fr_to_int(ch[k]))
+    a.deinit()
+    # Phase1Prover with 1, 2, 3 and 5 pairs
+    for npairs in (1, 2, 3, 5):
+        a, b = api.Phase1Prover(), ob.Phase1Prover()
+        for j in range(npairs):
+            P, Q = rnd(8200 + 10 * v + j, n), rnd(8300 + 10 * v + j, n)
+            a.addPair(P, Q)
+            b.addPair(P, Q)
+        for k in range(v):
+            assert [ob.fr_to_int(x) for x in a.computeRoundEvals()] == b.computeRoundEvals(), (npairs, k)
+            assert a.shouldTransition() == b.shouldTransition()
+            a.bind(ch[k])
+            b.bind(ob.fr_to_int(ch[k]))
+        assert [[ob.fr_to_int(x[0]) for x in pq] for pq in a.pairs()] == [[pq[0][0], pq[1][0]] for pq in b.pairs]
+        a.deinit()
+    # Lasso PrefixPolynomial
+    a, b = api.LassoPrefixPolynomial(tab), ob.LassoPrefixPolynomial(tab)
+    if v <= 10:
+        pt = rnd(8400 + v, v)
+        assert ob.fr_to_int(a.evaluate(pt)) == b.evaluate([ob.fr_to_int(x) for x in pt])
+    for k in range(v):
+        a, b = a.bind(ch[k]), b.bind(ob.fr_to_int(ch[k]))
+        assert [ob.fr_to_int(x) for x in a.evaluations] == b.evaluations, k
+    # initShiftQBuffers
+    if 2 <= v <= 12:
+        ps = 1 << (v - v // 2)
+        ss = n // ps
+        cols = [rnd(8500 + 10 * v + j, n) for j in range(5)]
+        suf = [rnd(8600 + 10 * v + j, ss) for j in range(4)]
+        g = rnd(8700 + v, 5)
+        got = api.initShiftQBuffers(*cols, *suf, g, ps)
+        want = ob.init_shift_q_buffers(*cols, *suf, g, ps)
+        for x, y in zip(got, want):
+            assert np.array_equal(x, y)
+
+
+@pytest.mark.gpu
+def test_device_mirrors_on_the_references_own_vectors():
+    ob = _ob()
+    from zolt_amd import api, lib
+    lib.init()
+    f = lambda vals: np.stack([ob.fr_from_int(v) for v in vals])
+    p = api.Phase1Prover()
+    p.addPair(f([1, 2, 3, 4]), f([5, 6, 7, 8]))
+    assert [ob.fr_to_int(x) for x in p.computeRoundEvals()] == [26, 44]
+    p.bind(ob.fr_from_int(2))
+    assert p.current_size == 2 and [ob.fr_to_int(x) for x in p.pairs()[0][0]] == [3, 5]
+    p.deinit()
+    lp = api.LassoPrefixPolynomial(f([1, 2, 3, 4])).bind(ob.fr_from_int(2))
+    assert lp.num_vars == 1 and [ob.fr_to_int(x) for x in lp.evaluations] == [5, 6]

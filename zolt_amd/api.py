@@ -1977,6 +1977,133 @@ class Stage3Prover:
         self.instr.deinit()
 
 
+class SpartanOuterProver:
+    """The standard rounds of SpartanOuterProver (src/zkvm/spartan/outer.zig:364-407) over its working_vals table: LowToHigh sums and
+    folds on a LOW_PAIR device session (the UniSkip first round of this prover is StreamingOuterProver.computeFirstRoundPoly's)."""
+
+    def __init__(self, working_vals):
+        w = np.ascontiguousarray(working_vals, dtype=np.uint64).reshape(-1, 4)
+        self.current_len = w.shape[0]
+        self._s = lib.SumcheckSession.open(w, lib.SC_LOW_PAIR) if self.current_len else None
+        self.challenges = []
+
+    def computeStandardRoundPoly(self):
+        """[p(0), p(1), 2 p(1) - p(0)] (:364-388); a single entry left: [it, 0, 0]"""
+        z = np.zeros(4, dtype=np.uint64)
+        if self.current_len <= 1:
+            return np.stack([self._s.final() if self.current_len == 1 else z, z, z])
+        p0, p1 = self._s.round_sums()
+        return np.stack([p0, p1, _fr_sub(_fr_add(p1, p1), p0)])
+
+    def bindChallenge(self, challenge):
+        """:391-407"""
+        self.challenges.append(np.ascontiguousarray(challenge, dtype=np.uint64).copy())
+        if self.current_len <= 1:
+            return
+        self._s.bind(challenge)
+        self.current_len //= 2
+
+    def deinit(self):
+        if self._s is not None:
+            self._s.close()
+
+
+class Phase1Prover:
+    """Phase1Prover (src/zkvm/spartan/prefix_suffix.zig:35-147): up to six P / Q pairs in one product session; a round is one pass of pair-sum
+    terms (two pairs per term), a bind folds every buffer."""
+
+    def __init__(self):
+        self._pending, self._s, self.challenges, self.current_size = [], None, [], 0
+
+    def addPair(self, P, Q):
+        P = np.ascontiguousarray(P, dtype=np.uint64).reshape(-1, 4)
+        Q = np.ascontiguousarray(Q, dtype=np.uint64).reshape(-1, 4)
+        assert P.shape == Q.shape and self.current_size in (0, P.shape[0]) and self._s is None and len(self._pending) < 12
+        self.current_size = P.shape[0]
+        self._pending += [P, Q]
+
+    def shouldTransition(self):
+        return self.current_size <= 2
+
+    def _open(self):
+        if self._s is None:
+            self._s = lib.ProductSumcheckSession.open(self._pending)
+            k = len(self._pending) // 2
+            self._terms = [((4 * t, 4 * t + 1, 4 * t + 2, 4 * t + 3), (), None, True) for t in range(k // 2)]
+            if k % 2:
+                self._terms.append(((2 * k - 2, 2 * k - 1), (), None))
+            self._s.set_points(0b0011)
+            self._pending = None
+
+    def computeRoundEvals(self):
+        """[g(0), g(1)] (:95-112)"""
+        self._open()
+        ev = self._s.round_expr(self._terms)
+        return np.stack([ev[0], ev[1]])
+
+    def bind(self, r):
+        """:114-132"""
+        self._open()
+        self.challenges.append(np.ascontiguousarray(r, dtype=np.uint64).copy())
+        self._s.bind(r)
+        self.current_size //= 2
+
+    def pairs(self):
+        self._open()
+        t = [self._s.read(j) for j in range(self._s.tables())]
+        return [(t[2 * i], t[2 * i + 1]) for i in range(len(t) // 2)]
+
+    def deinit(self):
+        if self._s is not None:
+            self._s.close()
+
+
+def initShiftQBuffers(unexpanded_pc, pc, is_virtual, is_first_in_sequence, is_noop, suffix_0_outer, suffix_1_outer, suffix_0_product,
+                      suffix_1_product, gamma_powers, prefix_size):
+    """initShiftQBuffers (src/zkvm/spartan/prefix_suffix.zig:149-232): the double loop over x_hi / x_lo is a weighted column sum of every input
+    table (zg_fr_weighted_colsum, two suffixes per pass); the gamma combination and the (1 - noop) form are applied to the sqrt(T)-sized
+    sums -> (Q_0_outer, Q_1_outer, Q_0_product, Q_1_product)"""
+    g = [fr_to_int(x) for x in np.ascontiguousarray(gamma_powers, dtype=np.uint64).reshape(-1, 4)]
+    so = np.stack([np.ascontiguousarray(suffix_0_outer, dtype=np.uint64).reshape(-1, 4), np.ascontiguousarray(suffix_1_outer, dtype=np.uint64).reshape(-1, 4)])
+    sp = np.stack([np.ascontiguousarray(suffix_0_product, dtype=np.uint64).reshape(-1, 4), np.ascontiguousarray(suffix_1_product, dtype=np.uint64).reshape(-1, 4)])
+    ss = so.shape[1]
+    sums = [lib.fr_weighted_colsum(np.ascontiguousarray(t, dtype=np.uint64).reshape(-1, 4), ss, prefix_size, so) for t in (unexpanded_pc, pc, is_virtual, is_first_in_sequence)]
+    noop = lib.fr_weighted_colsum(np.ascontiguousarray(is_noop, dtype=np.uint64).reshape(-1, 4), ss, prefix_size, sp)
+    out = []
+    for k in range(2):
+        q = [[fr_to_int(x) for x in s_[k]] for s_ in sums]
+        out.append(np.stack([fr_from_int((a + g[1] * b + g[2] * c + g[3] * d) % R_MOD) for a, b, c, d in zip(*q)]))
+    for k in range(2):
+        total = sum(fr_to_int(x) for x in sp[k]) % R_MOD  # sum over x_hi of the suffix: the "1" of (1 - noop)
+        out.append(np.stack([fr_from_int(g[4] * (total - fr_to_int(x)) % R_MOD) for x in noop[k]]))
+    return tuple(out)
+
+
+class LassoPrefixPolynomial:
+    """PrefixPolynomial (src/zkvm/lasso/prefix_suffix.zig:133-231): bind = the high-half fold (:175-196, zg_fr_bind_high), evaluate = the
+    dense evaluation with the index's low bit on point[0] (:198-216, zg_fr_dense_evaluate)"""
+
+    def __init__(self, evaluations, prefix_type=None):
+        self.evaluations = np.ascontiguousarray(evaluations, dtype=np.uint64).reshape(-1, 4).copy()
+        self.num_vars = self.evaluations.shape[0].bit_length() - 1
+        self.prefix_type = prefix_type
+
+    def get(self, index):
+        return self.evaluations[index]
+
+    def set(self, index, value):
+        self.evaluations[index] = value
+
+    def bind(self, challenge):
+        assert self.num_vars > 0
+        return LassoPrefixPolynomial(lib.fr_bind_high(self.evaluations, challenge), self.prefix_type)
+
+    def evaluate(self, point):
+        point = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1, 4)
+        assert point.shape[0] == self.num_vars
+        return lib.fr_dense_evaluate(self.evaluations, point) if self.num_vars else self.evaluations[0].copy()
+
+
 class JoltOuterProver:
     """JoltOuterProver's round loop (src/zkvm/spartan/jolt_outer_prover.zig:148-262) over the table f(cycle) = eq(tau, cycle) * Az * Bz it
     builds in init (:96-116, host work over the R1CS constraints): LowToHigh sums and folds on a LOW_PAIR device session."""

@@ -1334,6 +1334,111 @@ inline std::vector<uint8_t> serializeZoltProofHeader(const std::array<std::array
 }
 }  // namespace wire
 
+// ---- the remaining fold sites: SpartanOuterProver's standard rounds (src/zkvm/spartan/outer.zig:364-407), Phase1Prover
+// (src/zkvm/spartan/prefix_suffix.zig:35-147), the Lasso PrefixPolynomial (src/zkvm/lasso/prefix_suffix.zig:133-231)
+class SpartanOuterProver {
+public:
+    explicit SpartanOuterProver(const std::vector<Fr> &working_vals) : current_len(working_vals.size()) {
+        if (current_len) check(zg_sumcheck_open(reinterpret_cast<const uint64_t *>(working_vals.data()), current_len, ZG_SC_LOW_PAIR, &s_), "zg_sumcheck_open");
+    }
+    ~SpartanOuterProver() { if (s_) zg_sumcheck_close(s_); }
+    SpartanOuterProver(const SpartanOuterProver &) = delete;
+    std::array<Fr, 3> computeStandardRoundPoly() {  // [p(0), p(1), 2 p(1) - p(0)]; a single entry left: [it, 0, 0] (:364-388)
+        if (current_len <= 1) {
+            Fr v = Fr::zero();
+            if (current_len == 1) check(zg_sumcheck_final(s_, v.limbs), "zg_sumcheck_final");
+            return {v, Fr::zero(), Fr::zero()};
+        }
+        Fr p0, p1;
+        check(zg_sumcheck_round_sums(s_, p0.limbs, p1.limbs), "zg_sumcheck_round_sums");
+        return {p0, p1, p1.add(p1).sub(p0)};
+    }
+    void bindChallenge(const Fr &challenge) {  // :391-407
+        challenges.push_back(challenge);
+        if (current_len <= 1) return;
+        check(zg_sumcheck_bind(s_, challenge.limbs), "zg_sumcheck_bind");
+        current_len /= 2;
+    }
+    size_t current_len;
+    std::vector<Fr> challenges;
+
+private:
+    zg_sc_t s_ = nullptr;
+};
+
+class Phase1Prover {
+public:
+    void addPair(const std::vector<Fr> &P, const std::vector<Fr> &Q) {
+        if (P.size() != Q.size() || (current_size && P.size() != current_size) || s_ || tabs_.size() >= 12)
+            throw std::invalid_argument("Phase1Prover.addPair: equal lengths, at most six pairs, before the first round");
+        current_size = P.size();
+        tabs_.push_back(P);
+        tabs_.push_back(Q);
+    }
+    bool shouldTransition() const { return current_size <= 2; }
+    std::array<Fr, 2> computeRoundEvals() {  // g(0), g(1) (:95-112)
+        open();
+        auto ev = s_->roundExpr(terms_);
+        return {ev[0], ev[1]};
+    }
+    void bind(const Fr &r) {  // :114-132
+        open();
+        challenges.push_back(r);
+        s_->bind(r);
+        current_size /= 2;
+    }
+    std::vector<Fr> buffer(size_t pair, bool q) {  // P (q = false) or Q of a pair, as folded so far
+        open();
+        return stage3_readTable(*s_, 2 * pair + (q ? 1 : 0));
+    }
+    size_t current_size = 0;
+    std::vector<Fr> challenges;
+
+private:
+    static std::vector<Fr> stage3_readTable(ProductSumcheckSession &s, size_t table) {
+        std::vector<uint64_t> idx(s.len());
+        for (size_t i = 0; i < idx.size(); i++) idx[i] = i;
+        return s.gather(table, idx);
+    }
+    void open() {
+        if (s_) return;
+        std::vector<const std::vector<Fr> *> tp;
+        for (auto &t : tabs_) tp.push_back(&t);
+        s_.reset(new ProductSumcheckSession(tp));
+        const int k = (int)tabs_.size() / 2;
+        for (int t = 0; t < k / 2; t++) terms_.push_back({{4 * t, 4 * t + 1, 4 * t + 2, 4 * t + 3}, {}, {}, true});
+        if (k % 2) terms_.push_back({{2 * k - 2, 2 * k - 1}, {}, {}, false});
+        s_->setPoints(0b0011);
+        tabs_.clear();
+    }
+    std::vector<std::vector<Fr>> tabs_;
+    std::unique_ptr<ProductSumcheckSession> s_;
+    std::vector<ProductSumcheckSession::Term> terms_;
+};
+
+struct LassoPrefixPolynomial {
+    std::vector<Fr> evaluations;
+    size_t num_vars;
+    explicit LassoPrefixPolynomial(std::vector<Fr> evals) : evaluations(std::move(evals)), num_vars(0) {
+        while ((size_t(2) << num_vars) <= evaluations.size()) num_vars++;
+    }
+    LassoPrefixPolynomial bind(const Fr &challenge) const {  // new[i] = old[i] (1 - c) + old[i + half] c (:175-196)
+        if (num_vars == 0) throw std::invalid_argument("PrefixPolynomial.bind: no variable left");
+        std::vector<Fr> out(evaluations.size() / 2);
+        check(zg_fr_bind_high(reinterpret_cast<const uint64_t *>(evaluations.data()), evaluations.size(), challenge.limbs,
+                              reinterpret_cast<uint64_t *>(out.data())), "zg_fr_bind_high");
+        return LassoPrefixPolynomial(std::move(out));
+    }
+    Fr evaluate(const std::vector<Fr> &point) const {  // the index's low bit on point[0] (:198-216)
+        if (point.size() != num_vars) throw std::invalid_argument("PrefixPolynomial.evaluate: point.len != num_vars");
+        if (num_vars == 0) return evaluations[0];
+        Fr out;
+        check(zg_fr_dense_evaluate(reinterpret_cast<const uint64_t *>(evaluations.data()), num_vars, reinterpret_cast<const uint64_t *>(point.data()), out.limbs),
+              "zg_fr_dense_evaluate");
+        return out;
+    }
+};
+
 // ---- Stage 3 as a whole (src/zkvm/spartan/stage3_prover.zig). The witness matrix (cycle-major, 43 elements per padded cycle) is read
 // in HBM; cycle-length tables are affine maps of its rows (zg_fr_rows_affine_dev), the Q tables weighted column sums
 // (zg_fr_weighted_colsum_dev); prefix / suffix tables have sqrt(T) entries.
