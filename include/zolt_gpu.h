@@ -248,6 +248,10 @@ ZG_API int zg_fr_rows_affine(const uint64_t *rows, size_t n_rows, size_t k, size
                       uint64_t *const *tables /* ntab host pointers, n_pad * g elements each */);
 ZG_API int zg_fr_rows_affine_dev(const uint64_t *d_rows, size_t n_rows, size_t k, size_t stride, const uint64_t *coeffs_host, size_t ntab, size_t g,
                           size_t n_pad, uint64_t *const *d_tables /* host array of ntab DEVICE pointers */, void *stream);
+/* LtPolynomial over the cube (src/zkvm/ram/val_evaluation.zig:289-330), the third factor of ValEvaluationProver's inc * wa * lt:
+ * out[j] = sum over the ZERO bits i of j of r[i] * prod_{k > i} (bit_k(j) ? r[k] : 1 - r[k]); index bit i <-> r[i]. v <= 30. */
+ZG_API int zg_fr_lt_table(const uint64_t *r, size_t v, uint64_t *out /* 2^v * 4 */);
+ZG_API int zg_fr_lt_table_dev(const uint64_t *r_host, size_t v, uint64_t *d_out, void *stream);
 /* The Q tables of Stage 3's prefix / suffix provers (ShiftPrefixSuffixProver.init, src/zkvm/spartan/stage3_prover.zig:1066-1112;
  * RegistersPrefixSuffixProver.init, :2232-2290): Q[x_lo] = sum over x_hi of witness(x_lo + x_hi * 2^prefix_vars) * suffix[x_hi] — column
  * sums of the cycle-length table read as a (rows = 2^suffix_vars) x (cols = 2^prefix_vars) matrix, under up to four weight vectors at

@@ -2459,3 +2459,76 @@ class LassoPrefixPolynomial:
                 t = t * (pj if (i >> j) & 1 else (1 - pj)) % _R_P
             r += t
         return r % _R_P
+
+
+# ---------------------------------------------------------------- Stage 4 of the standard path (src/zkvm/prover.zig:713-828)
+def lt_table_int(r_cycle):
+    """LtPolynomial.evaluateAtIndex over the cube (src/zkvm/ram/val_evaluation.zig:309-330), canonical integers; index bit i <-> r_cycle[i]"""
+    P, v = _R_P, len(r_cycle)
+    out = []
+    for j in range(1 << v):
+        res = 0
+        for i in range(v):
+            if not (j >> i) & 1:
+                c = r_cycle[i]
+                for k in range(i + 1, v):
+                    c = c * (r_cycle[k] if (j >> k) & 1 else (1 - r_cycle[k])) % P
+                res += c
+        out.append(res % P)
+    return out
+
+
+def val_evaluation_tables(accesses, initial_ram, trace_len, k, r_address, r_cycle, start_address):
+    """IncPolynomial.fromTrace (:92-165), WaPolynomial.fromTrace / evaluateAtCycle (:208-262), LtPolynomial (:289-330) as ValEvaluationProver.init
+    tabulates them (:423-470): n = ceilPow2(max(trace_len, 1)) entries each. accesses: [(timestamp, address, is_write, value)];
+    r_address / r_cycle: canonical integers -> (inc, wa, lt) lists of integers"""
+    P = _R_P
+    n = 1
+    while n < max(trace_len, 1):
+        n <<= 1
+    inc, wa_addr = [0] * n, [None] * n
+    last = {}
+    for addr, val in (initial_ram or {}).items():
+        if addr >= start_address and (addr - start_address) // 8 < k:
+            last[addr] = val
+    for ts, addr, is_write, value in accesses:
+        if not is_write or addr < start_address or (addr - start_address) // 8 >= k or ts >= trace_len:
+            continue
+        old = last.get(addr, 0)
+        inc[ts] = (value - old) % P
+        last[addr] = value
+        wa_addr[ts] = (addr - start_address) // 8
+    def eq_at(r, idx):  # computeEqAtPoint (:790-802): index bit i <-> r[i]
+        v = 1
+        for i, ri in enumerate(r):
+            v = v * (ri if (idx >> i) & 1 else (1 - ri)) % P
+        return v
+    wa = [0 if a is None else eq_at(r_address, a) for a in wa_addr]
+    full = lt_table_int(r_cycle)
+    lt = [full[j % len(full)] for j in range(n)]  # evaluateAtIndex reads len(r_cycle) index bits
+    return inc, wa, lt
+
+
+def stage4_prove(accesses, initial_ram, trace_len, log_k, log_t, start_address, transcript):
+    """proveStage4 (prover.zig:713-828): log_k "r_address" and log_t "r_cycle_val" challenges, ValEvaluationProver over the memory trace
+    (init_eval = 0), the initial claim, log2_ceil(trace_len) rounds of [p(0..3)] under "val_eval_round", the final claim"""
+    r_address = [transcript.challenge_scalar(b"r_address") for _ in range(log_k)]
+    r_cycle = [transcript.challenge_scalar(b"r_cycle_val") for _ in range(log_t)]
+    out = {"r_address": r_address, "r_cycle": r_cycle}
+    if trace_len == 0:
+        return out
+    inc, wa, lt = val_evaluation_tables(accesses, initial_ram, trace_len, 1 << log_k, [fr_to_int(x) for x in r_address], [fr_to_int(x) for x in r_cycle], start_address)
+    claim = sum(a * b % _R_P * c for a, b, c in zip(inc, wa, lt)) % _R_P
+    pr = ValEvaluationProver(_s3_tab(inc), _s3_tab(wa), _s3_tab(lt), fr_from_int(claim))
+    out["initial_claim"] = fr_from_int(claim)
+    num_rounds = 0 if trace_len <= 1 else (trace_len - 1).bit_length()
+    polys, chals = [], []
+    for _ in range(num_rounds):
+        rp = pr.computeRoundPolynomial()
+        polys.append(rp)
+        ch = transcript.challenge_scalar(b"val_eval_round")
+        chals.append(ch)
+        pr.bindChallengeWithPoly(ch, rp)
+    f = pr.getFinalClaims()
+    out.update(round_polys=polys, challenges=chals, final_claim=_mul(_mul(f[0], f[1]), f[2]), final_openings=f)
+    return out

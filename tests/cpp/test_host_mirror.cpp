@@ -509,6 +509,77 @@ TEST(stage3_and_opening_claim_sites) {
 }
 
 // proveStage5 / proveStage6 (src/zkvm/prover.zig:829-1112) on the device against the same loops written out with host scalars
+TEST(stage_4_val_evaluation) {
+    // LtPolynomial at a boolean point is the indicator j < r (the reference's "lt polynomial basic", all points of three variables)
+    for (unsigned r = 0; r < 8; r++) {
+        std::vector<Fr> bits = {Fr::fromU64(r & 1), Fr::fromU64((r >> 1) & 1), Fr::fromU64((r >> 2) & 1)}, tab(8);
+        check(zg_fr_lt_table(reinterpret_cast<const uint64_t *>(bits.data()), 3, reinterpret_cast<uint64_t *>(tab.data())), "zg_fr_lt_table");
+        for (unsigned j = 0; j < 8; j++) EXPECT(tab[j].eql(j < r ? Fr::one() : Fr::zero()));
+    }
+    for (size_t trace_len : {size_t(1), size_t(37), size_t(1000)}) {
+        const size_t log_k = 5, log_t = 10, K = size_t(1) << log_k;
+        const uint64_t start = 0x80000000ULL;
+        std::vector<MemoryAccess> acc;
+        uint64_t z = 0xabc + trace_len;
+        auto next = [&]() { z = z * 6364136223846793005ULL + 1442695040888963407ULL; return z >> 20; };
+        for (size_t ts = 0; ts < trace_len; ts++)
+            if (next() % 3) acc.push_back(MemoryAccess{ts, start + 8 * (next() % (K + 2)), (next() & 1) != 0, next()});
+        std::vector<std::pair<uint64_t, uint64_t>> init = {{start + 8, 77}, {start + 8 * 3, 1234567}};
+        Transcript ta("Jolt"), tb("Jolt");
+        ta.appendBytes("stages 1-3"); tb.appendBytes("stages 1-3");
+        auto got = proveStage4(acc, init, trace_len, log_k, log_t, start, ta);
+        // host restatement: tables by the reference's formulas, rounds by plain loops
+        std::vector<Fr> ra, rc;
+        for (size_t i = 0; i < log_k; i++) ra.push_back(tb.challengeScalar("r_address"));
+        for (size_t i = 0; i < log_t; i++) rc.push_back(tb.challengeScalar("r_cycle_val"));
+        size_t n = 1;
+        while (n < trace_len) n <<= 1;
+        std::vector<Fr> inc(n, Fr::zero()), wa(n, Fr::zero()), lt(n, Fr::zero());
+        std::map<uint64_t, uint64_t> last;
+        for (auto &kv : init) last[kv.first] = kv.second;
+        for (auto &a : acc) {
+            if (!a.is_write || (a.address - start) / 8 >= K || a.timestamp >= trace_len) continue;
+            uint64_t old = last.count(a.address) ? last[a.address] : 0;
+            inc[a.timestamp] = a.value >= old ? Fr::fromU64(a.value - old) : Fr::zero().sub(Fr::fromU64(old - a.value));
+            last[a.address] = a.value;
+            Fr e = Fr::one();
+            for (size_t i = 0; i < log_k; i++) e = e.mul((((a.address - start) / 8) >> i) & 1 ? ra[i] : Fr::one().sub(ra[i]));
+            wa[a.timestamp] = e;
+        }
+        for (size_t j = 0; j < n; j++)
+            for (size_t i = 0; i < log_t; i++)
+                if (!((j >> i) & 1)) {
+                    Fr c = rc[i];
+                    for (size_t k2 = i + 1; k2 < log_t; k2++) c = c.mul((j >> k2) & 1 ? rc[k2] : Fr::one().sub(rc[k2]));
+                    lt[j] = lt[j].add(c);
+                }
+        Fr claim = Fr::zero();
+        for (size_t j = 0; j < n; j++) claim = claim.add(inc[j].mul(wa[j]).mul(lt[j]));
+        EXPECT(got.initial_claim.eql(claim));
+        const size_t rounds = trace_len <= 1 ? 0 : log2Ceil(trace_len);
+        EXPECT(got.round_polys.size() == rounds);
+        for (size_t rd = 0; rd < rounds; rd++) {
+            const size_t half = n >> (rd + 1);
+            std::array<Fr, 4> ev = {Fr::zero(), Fr::zero(), Fr::zero(), Fr::zero()};
+            for (size_t j = 0; j < half; j++)
+                for (uint64_t x = 0; x < 4; x++) {
+                    auto at = [&](const std::vector<Fr> &t) { return t[2 * j].add(Fr::fromU64(x).mul(t[2 * j + 1].sub(t[2 * j]))); };
+                    ev[x] = ev[x].add(at(inc).mul(at(wa)).mul(at(lt)));
+                }
+            for (int x = 0; x < 4; x++) EXPECT(got.round_polys[rd][x].eql(ev[x]));
+            EXPECT(ev[0].add(ev[1]).eql(claim));
+            Fr ch = tb.challengeScalar("val_eval_round");
+            EXPECT(ch.eql(got.challenges[rd]));
+            for (auto *t : {&inc, &wa, &lt})
+                for (size_t j = 0; j < half; j++) (*t)[j] = (*t)[2 * j].add(ch.mul((*t)[2 * j + 1].sub((*t)[2 * j])));
+            claim = cubicAtPoint(ev, ch);
+        }
+        EXPECT(got.final_claim.eql(inc[0].mul(wa[0]).mul(lt[0])) && (rounds == 0 || claim.eql(got.final_claim)));
+    }
+    Transcript te("Jolt");
+    EXPECT(proveStage4({}, {}, 0, 2, 2, 0, te).skipped);
+}
+
 TEST(stages_5_and_6) {
     for (size_t n_steps : {size_t(1), size_t(2), size_t(200), size_t(4096)}) {
         std::vector<uint32_t> instr(n_steps);

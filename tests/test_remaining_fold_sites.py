@@ -115,3 +115,58 @@ def test_device_mirrors_on_the_references_own_vectors():
     p.deinit()
     lp = api.LassoPrefixPolynomial(f([1, 2, 3, 4])).bind(ob.fr_from_int(2))
     assert lp.num_vars == 1 and [ob.fr_to_int(x) for x in lp.evaluations] == [5, 6]
+
+
+def _trace(seed, trace_len, k, start):
+    rng = np.random.default_rng(seed)
+    acc, init = [], {start + 8 * int(a): int(v) for a, v in zip(rng.integers(0, k, size=3), rng.integers(0, 1 << 40, size=3))}
+    for ts in range(trace_len):
+        if rng.random() < 0.6:
+            addr = start + 8 * int(rng.integers(0, k + 2))  # a few addresses past the table: skipped by the reference
+            acc.append((ts, addr, bool(rng.random() < 0.5), int(rng.integers(0, 1 << 62))))
+    acc.append((trace_len + 3, start, True, 5))  # a timestamp past the trace: skipped
+    acc.append((0, start - 8, True, 7))  # an address below the RAM region: skipped
+    return acc, init
+
+
+def test_lt_polynomial_is_the_less_than_indicator_on_the_cube():
+    """the reference's own LtPolynomial test (val_evaluation.zig "lt polynomial basic"), extended: at a boolean point r the table is
+    [j < r] for every index j (bit i of the integers <-> r[i])"""
+    ob = _ob()
+    for v in range(1, 5):
+        for r in range(1 << v):
+            bits = [(r >> i) & 1 for i in range(v)]
+            assert ob.lt_table_int(bits) == [1 if j < r else 0 for j in range(1 << v)], (v, r)
+    assert ob.lt_table_int([1, 0])[:3] == [1, 0, 0]  # the reference's vector: r_cycle = [1, 0] is cycle 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("trace_len,log_k,log_t", [(1, 3, 1), (37, 4, 6), (256, 6, 8), (1000, 8, 10), (5000, 10, 13)])
+def test_standard_stage4_val_evaluation(trace_len, log_k, log_t):
+    """MultiStageProver.proveStage4 (prover.zig:713-828) through api.proveStage4 (tables: eq gather, zg_fr_lt_table; rounds: one product
+    session) against the restatement, both on Keccak transcripts seeded alike: challenges, initial claim, every round polynomial, the final
+    openings and claim; the transcripts end in the same state"""
+    ob = _ob()
+    from zolt_amd import api, lib
+    lib.init()
+    start = 0x80000000
+    acc, init = _trace(9000 + trace_len, trace_len, 1 << log_k, start)
+    ta, tb = api.Transcript(b"Jolt"), ob.Transcript(b"Jolt")
+    ta.appendBytes(b"stage4" * 5)
+    tb.append_bytes(b"stage4" * 5)
+    got = api.proveStage4(acc, init, trace_len, log_k, log_t, start, ta)
+    want = ob.stage4_prove(acc, init, trace_len, log_k, log_t, start, tb)
+    assert np.array_equal(np.array(got["r_address"]), np.array(want["r_address"])) and np.array_equal(np.array(got["r_cycle"]), np.array(want["r_cycle"]))
+    assert np.array_equal(got["initial_claim"], want["initial_claim"])
+    assert len(got["round_polys"]) == len(want["round_polys"])
+    for k, (a, b) in enumerate(zip(got["round_polys"], want["round_polys"])):
+        assert np.array_equal(a, b), k
+    assert np.array_equal(np.array(got["challenges"]).reshape(-1, 4), np.array(want["challenges"]).reshape(-1, 4))
+    assert np.array_equal(got["final_claim"], want["final_claim"])
+    assert bytes(ta.state) == tb.state_bytes()[0]
+    # the tables themselves, and the device's lt table against the restatement's formula
+    ra, rc = [ob.fr_to_int(x) for x in want["r_address"]], [ob.fr_to_int(x) for x in want["r_cycle"]]
+    inc, wa, lt = api.valEvaluationTables(acc, init, trace_len, 1 << log_k, np.array(want["r_address"]), np.array(want["r_cycle"]), start)
+    winc, wwa, wlt = ob.val_evaluation_tables(acc, init, trace_len, 1 << log_k, ra, rc, start)
+    for x, y in ((inc, winc), (wa, wwa), (lt, wlt)):
+        assert [ob.fr_to_int(v) for v in x] == y

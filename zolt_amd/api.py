@@ -1168,6 +1168,69 @@ def _highHalfRounds(evals, num_rounds, transcript, label):
             np.stack(claims) if claims else z, final, final.copy() if initial is None else initial)
 
 
+def valEvaluationTables(accesses, initial_ram, trace_len, k, r_address, r_cycle, start_address):
+    """What ValEvaluationProver.init tabulates (src/zkvm/ram/val_evaluation.zig:423-470) -> (inc, wa, lt), (n, 4) each with
+    n = ceilPow2(max(trace_len, 1)): inc from the writes of the trace (IncPolynomial.fromTrace, :92-165: host integers, one field element per
+    write); wa[j] = eq(r_address, address written in cycle j) (WaPolynomial, :208-262) = a gather from the device's eq table of the
+    reversed point; lt = LtPolynomial over the cube (:289-330, zg_fr_lt_table). accesses: [(timestamp, address, is_write, value)]."""
+    r_address = np.ascontiguousarray(r_address, dtype=np.uint64).reshape(-1, 4)
+    r_cycle = np.ascontiguousarray(r_cycle, dtype=np.uint64).reshape(-1, 4)
+    n = 1
+    while n < max(trace_len, 1):
+        n <<= 1
+    inc = np.zeros((n, 4), dtype=np.uint64)
+    wa = np.zeros((n, 4), dtype=np.uint64)
+    last = {}
+    for addr, val in (initial_ram or {}).items():
+        if addr >= start_address and (addr - start_address) // 8 < k:
+            last[addr] = val
+    eq = lib.fr_eq_table(np.ascontiguousarray(r_address[::-1])) if r_address.shape[0] else fr_from_int(1).reshape(1, 4)  # index bit i <-> r_address[i]
+    for ts, addr, is_write, value in accesses:
+        if not is_write or addr < start_address or (addr - start_address) // 8 >= k or ts >= trace_len:
+            continue
+        inc[ts] = fr_from_int((value - last.get(addr, 0)) % R_MOD)
+        last[addr] = value
+        wa[ts] = eq[((addr - start_address) // 8) % eq.shape[0]]
+    full = lib.fr_lt_table(r_cycle)
+    lt = full[:n] if full.shape[0] >= n else np.tile(full, (n // full.shape[0], 1))
+    return inc, wa, np.ascontiguousarray(lt)
+
+
+def proveStage4(accesses, initial_ram, trace_len, log_k, log_t, start_address, transcript):
+    """MultiStageProver.proveStage4 (src/zkvm/prover.zig:713-828), Val evaluation: log_k "r_address" and log_t "r_cycle_val" challenges, the
+    ValEvaluationProver over the memory trace (init_eval = 0), its initial claim, log2_ceil(trace_len) cubic rounds under "val_eval_round"
+    on one device session, the final claim."""
+    r_address = [transcript.challengeScalar(b"r_address") for _ in range(log_k)]
+    r_cycle = [transcript.challengeScalar(b"r_cycle_val") for _ in range(log_t)]
+    out = {"r_address": r_address, "r_cycle": r_cycle}
+    if trace_len == 0:  # :764-768
+        return out
+    inc, wa, lt = valEvaluationTables(accesses, initial_ram, trace_len, 1 << log_k, np.array(r_address).reshape(-1, 4), np.array(r_cycle).reshape(-1, 4), start_address)
+    sess = lib.ProductSumcheckSession.open([inc, wa, lt])
+    if inc.shape[0] >= 2:  # the initial claim = p(0) + p(1) of the first round
+        ev = sess.round_evals((0, 1, 2))
+        claim = _fr_add(ev[0], ev[1])
+    else:
+        f = sess.final()
+        claim = fr_from_int(fr_to_int(f[0]) * fr_to_int(f[1]) % R_MOD * fr_to_int(f[2]) % R_MOD)
+    sess.close()
+    pr = ValEvaluationProver(inc, wa, lt, claim)
+    out["initial_claim"] = pr.computeInitialClaim()
+    num_rounds = 0 if trace_len <= 1 else (trace_len - 1).bit_length()
+    polys, chals = [], []
+    for _ in range(num_rounds):
+        rp = pr.computeRoundPolynomial()
+        polys.append(rp)
+        ch = transcript.challengeScalar(b"val_eval_round")
+        chals.append(ch)
+        pr.bindChallengeWithPoly(ch, rp)
+    f = pr.getFinalClaims()
+    out.update(round_polys=polys, challenges=chals, final_openings=f,
+               final_claim=fr_from_int(fr_to_int(f[0]) * fr_to_int(f[1]) % R_MOD * fr_to_int(f[2]) % R_MOD))
+    pr.deinit()
+    return out
+
+
 def proveStage5(instructions, log_t, transcript):
     """MultiStageProver.proveStage5 (src/zkvm/prover.zig:829-958), register value evaluation: five r_register and log_t r_cycle_reg
     challenges, eq_evals[j] = eq(r_register, rd(j)) for the trace steps (a 32-entry table indexed by the rd field, zero past the trace),

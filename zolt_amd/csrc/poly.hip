@@ -1107,6 +1107,75 @@ int zg_fr_eq_plus_one_table(const uint64_t *r, size_t v, uint64_t *out) {
     return rc;
 }
 
+// LtPolynomial.evaluateAtIndex over the whole cube (src/zkvm/ram/val_evaluation.zig:309-330): lt(j) = sum over the zero bits i of j of
+// r[i] * prod_{k > i} (j_k ? r[k] : 1 - r[k]) — the index's bit i belongs to r[i]. One thread per index walks the bits from the top with
+// the running suffix product: 2 v products.
+struct LtArgs {
+    FrArg r[30];
+};
+__global__ void __launch_bounds__(256) lt_table_kernel(LtArgs a, int v, size_t n, uint64_t *out) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        Fr suffix = Fr::one(), result = Fr::zero();
+        for (int i = v - 1; i >= 0; i--) {
+            Fr ri;
+#pragma unroll
+            for (int l = 0; l < 8; l++) ri.l[l] = a.r[i].l[l];
+            if ((j >> i) & 1) {
+                suffix = fr_mul29v(suffix, ri);
+            } else {
+                result = fe_add(result, fr_mul29v(ri, suffix));
+                suffix = fr_mul29v(suffix, fe_sub(Fr::one(), ri));
+            }
+        }
+        fe_store(out + 4 * j, result);
+    }
+}
+static int lt_table_enqueue(const uint64_t *r_host, size_t v, uint64_t *d_out, hipStream_t st) {
+    LtArgs a = {};
+    for (size_t i = 0; i < v; i++)
+        for (int l = 0; l < 4; l++) {
+            a.r[i].l[2 * l] = (uint32_t)r_host[4 * i + l];
+            a.r[i].l[2 * l + 1] = (uint32_t)(r_host[4 * i + l] >> 32);
+        }
+    const size_t n = (size_t)1 << v;
+    unsigned nb = (unsigned)div_up(n, 256);
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(lt_table_kernel, dim3(nb), dim3(256), 0, st, a, (int)v, n, d_out);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
+int zg_fr_lt_table_dev(const uint64_t *r_host, size_t v, uint64_t *d_out, void *stream) {
+    ZG_INIT();
+    if (!d_out || (v && !r_host) || v > 30) {
+        set_error("zg_fr_lt_table_dev: invalid argument (at most 30 variables)");
+        return ZG_ERR_INVALID;
+    }
+    return lt_table_enqueue(r_host, v, d_out, pick_stream(stream));
+}
+
+int zg_fr_lt_table(const uint64_t *r, size_t v, uint64_t *out) {
+    ZG_INIT();
+    if (!out || (v && !r) || v > 30) {
+        set_error("zg_fr_lt_table: invalid argument (at most 30 variables)");
+        return ZG_ERR_INVALID;
+    }
+    const size_t bytes = ((size_t)1 << v) * 32;
+    Scratch s_out(bytes);
+    if (!s_out.p) return ZG_ERR_NOMEM;
+    hipStream_t st = lib_stream();
+    int rc = lt_table_enqueue(r, v, s_out.as<uint64_t>(), st);
+    hipError_t e = rc == ZG_OK ? hipMemcpyAsync(out, s_out.p, bytes, hipMemcpyDeviceToHost, st) : hipSuccess;
+    hipError_t e2 = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = e2;
+    if (rc == ZG_OK && e != hipSuccess) {
+        set_error(hipGetErrorString(e));
+        rc = ZG_ERR_HIP;
+    }
+    return rc;
+}
+
 int zg_fr_eq_prefix_tables_dev(const uint64_t *tau_host, size_t v, uint64_t *d_out, void *stream) {
     ZG_INIT();
     if (!d_out || (v && !tau_host)) {

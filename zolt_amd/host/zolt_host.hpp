@@ -1914,6 +1914,66 @@ inline size_t log2Ceil(size_t n) {
     while ((size_t(1) << k) < n) k++;
     return k;
 }
+// What ValEvaluationProver.init tabulates (src/zkvm/ram/val_evaluation.zig:423-470): inc from the writes of the trace (IncPolynomial.fromTrace,
+// :92-165), wa[j] = eq(r_address, address written in cycle j) (WaPolynomial, :208-262: a gather from the device's eq table of the reversed
+// point — index bit i belongs to r_address[i]), lt = LtPolynomial over the cube (:289-330, zg_fr_lt_table); n = ceilPow2(max(trace_len, 1))
+struct ValEvaluationTables { std::vector<Fr> inc, wa, lt; };
+inline ValEvaluationTables valEvaluationTables(const std::vector<MemoryAccess> &accesses, const std::vector<std::pair<uint64_t, uint64_t>> &initial_ram,
+                                               size_t trace_len, size_t k, const std::vector<Fr> &r_address, const std::vector<Fr> &r_cycle, uint64_t start_address) {
+    size_t n = 1;
+    while (n < std::max<size_t>(trace_len, 1)) n <<= 1;
+    ValEvaluationTables t{std::vector<Fr>(n, Fr::zero()), std::vector<Fr>(n, Fr::zero()), std::vector<Fr>(n)};
+    std::map<uint64_t, uint64_t> last;
+    for (auto &kv : initial_ram)
+        if (kv.first >= start_address && (kv.first - start_address) / 8 < k) last[kv.first] = kv.second;
+    std::vector<Fr> eq = EqPolynomial(std::vector<Fr>(r_address.rbegin(), r_address.rend())).evals();
+    for (const MemoryAccess &a : accesses) {
+        if (!a.is_write || a.address < start_address || (a.address - start_address) / 8 >= k || a.timestamp >= trace_len) continue;
+        auto it = last.find(a.address);
+        const uint64_t old = it == last.end() ? 0 : it->second;
+        t.inc[a.timestamp] = a.value >= old ? Fr::fromU64(a.value - old) : Fr::zero().sub(Fr::fromU64(old - a.value));
+        last[a.address] = a.value;
+        t.wa[a.timestamp] = eq[((a.address - start_address) / 8) % eq.size()];
+    }
+    std::vector<Fr> full(size_t(1) << r_cycle.size());
+    check(zg_fr_lt_table(reinterpret_cast<const uint64_t *>(r_cycle.data()), r_cycle.size(), reinterpret_cast<uint64_t *>(full.data())), "zg_fr_lt_table");
+    for (size_t j = 0; j < n; j++) t.lt[j] = full[j % full.size()];  // evaluateAtIndex reads len(r_cycle) index bits
+    return t;
+}
+// proveStage4 (:713-828): Val evaluation — challenges, the prover over the memory trace (init_eval = 0), cubic rounds under "val_eval_round"
+struct Stage4Result {
+    std::vector<Fr> r_address, r_cycle, challenges;
+    std::vector<std::array<Fr, 4>> round_polys;
+    Fr initial_claim = Fr::zero(), final_claim = Fr::zero();
+    bool skipped = false;
+};
+inline Stage4Result proveStage4(const std::vector<MemoryAccess> &accesses, const std::vector<std::pair<uint64_t, uint64_t>> &initial_ram, size_t trace_len,
+                                size_t log_k, size_t log_t, uint64_t start_address, Transcript &transcript) {
+    Stage4Result out;
+    for (size_t i = 0; i < log_k; i++) out.r_address.push_back(transcript.challengeScalar("r_address"));
+    for (size_t i = 0; i < log_t; i++) out.r_cycle.push_back(transcript.challengeScalar("r_cycle_val"));
+    if (trace_len == 0) { out.skipped = true; return out; }
+    auto t = valEvaluationTables(accesses, initial_ram, trace_len, size_t(1) << log_k, out.r_address, out.r_cycle, start_address);
+    Fr claim = Fr::zero();
+    {
+        ProductSumcheckSession s({&t.inc, &t.wa, &t.lt});  // the initial claim = p(0) + p(1) of the first round (one entry: the product)
+        if (t.inc.size() >= 2) { auto ev = s.roundEvals({0, 1, 2}); claim = ev[0].add(ev[1]); }
+        else { auto f = s.final(); claim = f[0].mul(f[1]).mul(f[2]); }
+    }
+    ValEvaluationProver pr(t.inc, t.wa, &t.lt, claim);
+    out.initial_claim = claim;
+    const size_t num_rounds = trace_len <= 1 ? 0 : log2Ceil(trace_len);
+    for (size_t rd = 0; rd < num_rounds; rd++) {
+        auto rp = pr.computeRoundPolynomial();
+        out.round_polys.push_back(rp);
+        Fr ch = transcript.challengeScalar("val_eval_round");
+        out.challenges.push_back(ch);
+        pr.bindChallengeWithPoly(ch, rp);
+    }
+    auto f = pr.getFinalClaims();
+    out.final_claim = f[0].mul(f[1]).mul(f[2]);
+    return out;
+}
 // proveStage5 (:829-958): register value evaluation — eq(r_register, rd(j)) over the trace steps
 inline StageRoundsResult proveStage5(const std::vector<uint32_t> &instructions, size_t log_t, Transcript &transcript, std::vector<Fr> *r_register_out = nullptr) {
     std::vector<Fr> r_register(5);

@@ -37,7 +37,7 @@ SYMBOLS = [
     "zg_msm_g1", "zg_msm_g1_dev", "zg_msm_g1_dev_async", "zg_msm_g1_batch", "zg_msm_g1_batch_dev", "zg_msm_g1_partial_dev", "zg_msm_g1_partial_fast_dev",
     "zg_g1_combine_partials_dev", "zg_g1_combine_partials_dev_async", "zg_g1_is_on_curve_batch", "zg_g1_scalar_mul_batch", "zg_g1_fixed_base_mul_batch",
     "zg_hyperkzg_open", "zg_hyperkzg_open_dev", "zg_hyperkzg_batch_open",
-    "zg_fr_dense_evaluate", "zg_fr_eq_table", "zg_fr_eq_table_dev", "zg_fr_eq_prefix_tables", "zg_fr_eq_prefix_tables_dev", "zg_fr_rows_mle", "zg_fr_rows_mle_dev", "zg_fr_rows_affine", "zg_fr_rows_affine_dev", "zg_fr_rows_affine_prodsum_dev", "zg_fr_weighted_colsum", "zg_fr_weighted_colsum_dev", "zg_fr_eq_plus_one_table", "zg_fr_eq_plus_one_table_dev", "zg_fr_bind_low", "zg_fr_bind_high",
+    "zg_fr_dense_evaluate", "zg_fr_eq_table", "zg_fr_eq_table_dev", "zg_fr_eq_prefix_tables", "zg_fr_eq_prefix_tables_dev", "zg_fr_rows_mle", "zg_fr_rows_mle_dev", "zg_fr_rows_affine", "zg_fr_rows_affine_dev", "zg_fr_rows_affine_prodsum_dev", "zg_fr_weighted_colsum", "zg_fr_weighted_colsum_dev", "zg_fr_lt_table", "zg_fr_lt_table_dev", "zg_fr_eq_plus_one_table", "zg_fr_eq_plus_one_table_dev", "zg_fr_bind_low", "zg_fr_bind_high",
     "zg_fr_spartan_combine", "zg_fr_spartan_combine_dev",
     "zg_sumcheck_open", "zg_sumcheck_open_dev", "zg_sumcheck_round_sums", "zg_sumcheck_bind",
     "zg_sumcheck_len", "zg_sumcheck_final", "zg_sumcheck_read", "zg_sumcheck_gather", "zg_sumcheck_close",
@@ -573,6 +573,19 @@ def fr_rows_affine(rows, coeffs, ntab, g, n_pad=None, k=None):
     _chk(_lib.zg_fr_rows_affine(_h(rows), C.c_size_t(n_rows), C.c_size_t(k), C.c_size_t(stride), _h(coeffs), C.c_size_t(ntab), C.c_size_t(g),
                                 C.c_size_t(n_pad), ptrs), "zg_fr_rows_affine")
     return outs
+
+
+def fr_lt_table(r):
+    """out[j] = LtPolynomial(r).evaluateAtIndex(j) over the cube (zg_fr_lt_table); index bit i <-> r[i]"""
+    r = _c(np.asarray(r, dtype=np.uint64).reshape(-1, 4))
+    out = np.empty((1 << r.shape[0], 4), dtype=np.uint64)
+    _chk(_lib.zg_fr_lt_table(_h(r), C.c_size_t(r.shape[0]), _h(out)), "zg_fr_lt_table")
+    return out
+
+
+def fr_lt_table_dev(r, d_out, stream=0):
+    r = _c(np.asarray(r, dtype=np.uint64).reshape(-1, 4))
+    _chk(_lib.zg_fr_lt_table_dev(_h(r), C.c_size_t(r.shape[0]), _d(d_out), _d(stream)), "zg_fr_lt_table_dev")
 
 
 def fr_weighted_colsum(table, rows, cols, weights):
