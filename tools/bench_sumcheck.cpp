@@ -304,6 +304,28 @@ int main(int argc, char **argv) {
                     "\"ram_read_write_checking_accesses\": %zu, ", rwc_rounds / t_rwc, t_rwc / (reps > 5 ? 5 : reps) * 1e3,
                     t_rwc_setup / (reps > 5 ? 5 : reps) * 1e3, acc.size());
     }
+    // proveStage4 of the standard path (src/zkvm/prover.zig:713-828): Val evaluation over a memory trace of 2^v cycles, 2^16 words, a write in
+    // one cycle of eight; tables (inc from the trace, wa = eq gather, lt = zg_fr_lt_table) + log T cubic rounds with a Keccak transcript
+    {
+        const size_t log_k = 16, T = n;
+        const uint64_t start = 0x80000000ULL;
+        std::vector<MemoryAccess> acc;
+        for (size_t ts = 0; ts < T; ts++) {
+            uint64_t z = splitmix();
+            if (z & 7) continue;
+            acc.push_back(MemoryAccess{ts, start + 8 * ((z >> 8) & 0xFFFF), true, splitmix() >> 2});
+        }
+        double t_s4 = 0;
+        const int n4 = reps > 3 ? 3 : reps;
+        for (int rep = -1; rep < n4; rep++) {
+            Transcript tr("Jolt");
+            auto t0 = clk::now();
+            auto res = proveStage4(acc, {}, T, log_k, (size_t)v, start, tr);
+            if (rep >= 0) t_s4 += std::chrono::duration<double>(clk::now() - t0).count();
+            ok = ok && res.round_polys.size() == (size_t)v;
+        }
+        std::printf("\"stage4_val_evaluation_ms_incl_tables\": %.4f, \"stage4_val_evaluation_writes\": %zu, ", t_s4 / n4 * 1e3, acc.size());
+    }
     // Stage4GruenProver (src/zkvm/spartan/stage4_gruen_prover.zig), RegistersReadWriteChecking: 128 registers x 2^min(v, 18) cycles (five dense
     // tables of 128 * T elements built and folded on the device), phases T/2 cycle, 7 register, T/2 cycle variables, Keccak transcript
     {

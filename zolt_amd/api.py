@@ -1206,20 +1206,14 @@ def proveStage4(accesses, initial_ram, trace_len, log_k, log_t, start_address, t
     if trace_len == 0:  # :764-768
         return out
     inc, wa, lt = valEvaluationTables(accesses, initial_ram, trace_len, 1 << log_k, np.array(r_address).reshape(-1, 4), np.array(r_cycle).reshape(-1, 4), start_address)
-    sess = lib.ProductSumcheckSession.open([inc, wa, lt])
-    if inc.shape[0] >= 2:  # the initial claim = p(0) + p(1) of the first round
-        ev = sess.round_evals((0, 1, 2))
-        claim = _fr_add(ev[0], ev[1])
-    else:
-        f = sess.final()
-        claim = fr_from_int(fr_to_int(f[0]) * fr_to_int(f[1]) % R_MOD * fr_to_int(f[2]) % R_MOD)
-    sess.close()
-    pr = ValEvaluationProver(inc, wa, lt, claim)
+    pr = ValEvaluationProver(inc, wa, lt, np.zeros(4, dtype=np.uint64))
+    first = pr.computeRoundPolynomial()  # the initial claim = p(0) + p(1) of the first round (a single entry: the product); kept for round 0
+    pr.current_claim = _fr_add(first[0], first[1]) if inc.shape[0] >= 2 else first[0].copy()
     out["initial_claim"] = pr.computeInitialClaim()
     num_rounds = 0 if trace_len <= 1 else (trace_len - 1).bit_length()
     polys, chals = [], []
-    for _ in range(num_rounds):
-        rp = pr.computeRoundPolynomial()
+    for rd in range(num_rounds):
+        rp = first if rd == 0 else pr.computeRoundPolynomial()
         polys.append(rp)
         ch = transcript.challengeScalar(b"val_eval_round")
         chals.append(ch)

@@ -1059,6 +1059,9 @@ public:
     ValEvaluationProver(const std::vector<Fr> &inc, const std::vector<Fr> &wa, const std::vector<Fr> *lt, const Fr &claim)
         : current_claim(claim), s_(lt ? std::vector<const std::vector<Fr> *>{&inc, &wa, lt} : std::vector<const std::vector<Fr> *>{&inc, &wa}),
           factors_(lt ? std::vector<int>{0, 1, 2} : std::vector<int>{0, 1}) {}
+    // three tables already in HBM (n entries each; the session copies them)
+    ValEvaluationProver(ProductSumcheckSession::OnDevice, const uint64_t *d_inc, const uint64_t *d_wa, const uint64_t *d_lt, size_t n, const Fr &claim)
+        : current_claim(claim), s_(ProductSumcheckSession::OnDevice{}, {d_inc, d_wa, d_lt}, n), factors_{0, 1, 2} {}
     std::array<Fr, 4> computeRoundPolynomial() {  // :554-603
         if (s_.len() < 2) {
             Fr acc = Fr::one();
@@ -1918,11 +1921,13 @@ inline size_t log2Ceil(size_t n) {
 // :92-165), wa[j] = eq(r_address, address written in cycle j) (WaPolynomial, :208-262: a gather from the device's eq table of the reversed
 // point — index bit i belongs to r_address[i]), lt = LtPolynomial over the cube (:289-330, zg_fr_lt_table); n = ceilPow2(max(trace_len, 1))
 struct ValEvaluationTables { std::vector<Fr> inc, wa, lt; };
-inline ValEvaluationTables valEvaluationTables(const std::vector<MemoryAccess> &accesses, const std::vector<std::pair<uint64_t, uint64_t>> &initial_ram,
-                                               size_t trace_len, size_t k, const std::vector<Fr> &r_address, const std::vector<Fr> &r_cycle, uint64_t start_address) {
+// inc and wa on the host (one element per write of the trace), n = ceilPow2(max(trace_len, 1)); lt stays out (valEvaluationTables adds it)
+inline void valEvaluationIncWa(const std::vector<MemoryAccess> &accesses, const std::vector<std::pair<uint64_t, uint64_t>> &initial_ram, size_t trace_len,
+                               size_t k, const std::vector<Fr> &r_address, uint64_t start_address, std::vector<Fr> &inc, std::vector<Fr> &wa) {
     size_t n = 1;
     while (n < std::max<size_t>(trace_len, 1)) n <<= 1;
-    ValEvaluationTables t{std::vector<Fr>(n, Fr::zero()), std::vector<Fr>(n, Fr::zero()), std::vector<Fr>(n)};
+    inc.assign(n, Fr::zero());
+    wa.assign(n, Fr::zero());
     std::map<uint64_t, uint64_t> last;
     for (auto &kv : initial_ram)
         if (kv.first >= start_address && (kv.first - start_address) / 8 < k) last[kv.first] = kv.second;
@@ -1931,10 +1936,17 @@ inline ValEvaluationTables valEvaluationTables(const std::vector<MemoryAccess> &
         if (!a.is_write || a.address < start_address || (a.address - start_address) / 8 >= k || a.timestamp >= trace_len) continue;
         auto it = last.find(a.address);
         const uint64_t old = it == last.end() ? 0 : it->second;
-        t.inc[a.timestamp] = a.value >= old ? Fr::fromU64(a.value - old) : Fr::zero().sub(Fr::fromU64(old - a.value));
+        inc[a.timestamp] = a.value >= old ? Fr::fromU64(a.value - old) : Fr::zero().sub(Fr::fromU64(old - a.value));
         last[a.address] = a.value;
-        t.wa[a.timestamp] = eq[((a.address - start_address) / 8) % eq.size()];
+        wa[a.timestamp] = eq[((a.address - start_address) / 8) % eq.size()];
     }
+}
+inline ValEvaluationTables valEvaluationTables(const std::vector<MemoryAccess> &accesses, const std::vector<std::pair<uint64_t, uint64_t>> &initial_ram,
+                                               size_t trace_len, size_t k, const std::vector<Fr> &r_address, const std::vector<Fr> &r_cycle, uint64_t start_address) {
+    ValEvaluationTables t;
+    valEvaluationIncWa(accesses, initial_ram, trace_len, k, r_address, start_address, t.inc, t.wa);
+    const size_t n = t.inc.size();
+    t.lt.resize(n);
     std::vector<Fr> full(size_t(1) << r_cycle.size());
     check(zg_fr_lt_table(reinterpret_cast<const uint64_t *>(r_cycle.data()), r_cycle.size(), reinterpret_cast<uint64_t *>(full.data())), "zg_fr_lt_table");
     for (size_t j = 0; j < n; j++) t.lt[j] = full[j % full.size()];  // evaluateAtIndex reads len(r_cycle) index bits
@@ -1953,18 +1965,31 @@ inline Stage4Result proveStage4(const std::vector<MemoryAccess> &accesses, const
     for (size_t i = 0; i < log_k; i++) out.r_address.push_back(transcript.challengeScalar("r_address"));
     for (size_t i = 0; i < log_t; i++) out.r_cycle.push_back(transcript.challengeScalar("r_cycle_val"));
     if (trace_len == 0) { out.skipped = true; return out; }
-    auto t = valEvaluationTables(accesses, initial_ram, trace_len, size_t(1) << log_k, out.r_address, out.r_cycle, start_address);
-    Fr claim = Fr::zero();
-    {
-        ProductSumcheckSession s({&t.inc, &t.wa, &t.lt});  // the initial claim = p(0) + p(1) of the first round (one entry: the product)
-        if (t.inc.size() >= 2) { auto ev = s.roundEvals({0, 1, 2}); claim = ev[0].add(ev[1]); }
-        else { auto f = s.final(); claim = f[0].mul(f[1]).mul(f[2]); }
+    std::vector<Fr> inc, wa;
+    valEvaluationIncWa(accesses, initial_ram, trace_len, size_t(1) << log_k, out.r_address, start_address, inc, wa);
+    const size_t n = inc.size();
+    // the three tables go to HBM once: inc and wa uploaded, lt built there (when the cube of r_cycle is at least n entries; else tiled on the host)
+    DeviceMem d(3 * n * 32);
+    check(zg_memcpy_h2d(d.p, inc.data(), n * 32), "zg_memcpy_h2d");
+    check(zg_memcpy_h2d(d.u64() + 4 * n, wa.data(), n * 32), "zg_memcpy_h2d");
+    if ((size_t(1) << log_t) == n) {
+        check(zg_fr_lt_table_dev(reinterpret_cast<const uint64_t *>(out.r_cycle.data()), log_t, d.u64() + 8 * n, nullptr), "zg_fr_lt_table_dev");
+        check(zg_sync(), "zg_sync");
+    } else {
+        std::vector<Fr> full(size_t(1) << log_t), lt(n);
+        check(zg_fr_lt_table(reinterpret_cast<const uint64_t *>(out.r_cycle.data()), log_t, reinterpret_cast<uint64_t *>(full.data())), "zg_fr_lt_table");
+        for (size_t j = 0; j < n; j++) lt[j] = full[j % full.size()];
+        check(zg_memcpy_h2d(d.u64() + 8 * n, lt.data(), n * 32), "zg_memcpy_h2d");
     }
-    ValEvaluationProver pr(t.inc, t.wa, &t.lt, claim);
-    out.initial_claim = claim;
+    ValEvaluationProver pr(ProductSumcheckSession::OnDevice{}, d.u64(), d.u64() + 4 * n, d.u64() + 8 * n, n, Fr::zero());
+    check(zg_sync(), "zg_sync");
+    // the initial claim is p(0) + p(1) of the first round (a single entry: the product); that round's evaluations are kept
+    std::array<Fr, 4> first = pr.computeRoundPolynomial();
+    pr.current_claim = n >= 2 ? first[0].add(first[1]) : first[0];
+    out.initial_claim = pr.current_claim;
     const size_t num_rounds = trace_len <= 1 ? 0 : log2Ceil(trace_len);
     for (size_t rd = 0; rd < num_rounds; rd++) {
-        auto rp = pr.computeRoundPolynomial();
+        auto rp = rd == 0 ? first : pr.computeRoundPolynomial();
         out.round_polys.push_back(rp);
         Fr ch = transcript.challengeScalar("val_eval_round");
         out.challenges.push_back(ch);
