@@ -2532,3 +2532,28 @@ def stage4_prove(accesses, initial_ram, trace_len, log_k, log_t, start_address, 
     f = pr.getFinalClaims()
     out.update(round_polys=polys, challenges=chals, final_claim=_mul(_mul(f[0], f[1]), f[2]), final_openings=f)
     return out
+
+
+class ExpandingTable:
+    """ExpandingTable (src/zkvm/lasso/expanding_table.zig:27-190), canonical integers: bind doubles the table, new[2i] = v (1 - r),
+    new[2i+1] = v r (:83-99) — after k binds the eq table of the challenges with the FIRST challenge on the index's top bit"""
+
+    def __init__(self, max_rounds, initial=1):
+        self.values, self.round, self.max_rounds = [initial % _R_P], 0, max_rounds
+
+    def bind(self, r):
+        assert self.round < self.max_rounds
+        self.values = [x for v in self.values for x in (v * (1 - r) % _R_P, v * r % _R_P)]
+        self.round += 1
+
+    def sum(self):
+        return sum(self.values) % _R_P
+
+    def condense(self, weights, out_bits):
+        """:144-161: out[i / chunk] += values[i] * weights[i], chunk = 2^(round - out_bits)"""
+        assert len(weights) == len(self.values) and out_bits <= self.round
+        chunk = 1 << (self.round - out_bits)
+        out = [0] * (1 << out_bits)
+        for i, (v, w) in enumerate(zip(self.values, weights)):
+            out[i // chunk] = (out[i // chunk] + v * w) % _R_P
+        return out

@@ -170,3 +170,43 @@ def test_standard_stage4_val_evaluation(trace_len, log_k, log_t):
     winc, wwa, wlt = ob.val_evaluation_tables(acc, init, trace_len, 1 << log_k, ra, rc, start)
     for x, y in ((inc, winc), (wa, wwa), (lt, wlt)):
         assert [ob.fr_to_int(v) for v in x] == y
+
+
+def test_expanding_table_restatement_on_the_references_vectors():
+    """src/zkvm/lasso/expanding_table.zig tests: bind 3 -> [1 - 3, 3], sum 1; binds 2, 3, 5 -> 8 entries, sum 1, entry 0 = -8, entry 7 = 30;
+    condense after binds 2, 3 under weights [1, 2, 3, 4] to one bit. (The reference's own expectation for entry 1 of the second test,
+    r0 (1 - r1)(1 - r2) = 16, disagrees with its bind, which puts the LAST challenge on the low bit: entry 1 = (1 - r0)(1 - r1) r2 = 10 —
+    the restatement follows the code.)"""
+    ob = _ob()
+    P = ob._R_P
+    t = ob.ExpandingTable(3)
+    assert t.values == [1]
+    t.bind(3)
+    assert t.values == [(1 - 3) % P, 3] and t.sum() == 1
+    t = ob.ExpandingTable(4)
+    for r in (2, 3, 5):
+        t.bind(r)
+    assert len(t.values) == 8 and t.sum() == 1 and t.values[0] == (-8) % P and t.values[7] == 30 and t.values[1] == 10
+    t = ob.ExpandingTable(4)
+    t.bind(2)
+    t.bind(3)
+    v = t.values
+    assert t.condense([1, 2, 3, 4], 1) == [(v[0] * 1 + v[1] * 2) % P, (v[2] * 3 + v[3] * 4) % P]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rounds", [1, 3, 8, 13])
+def test_expanding_table_on_the_device(rounds):
+    ob = _ob()
+    from zolt_amd import api, lib
+    lib.init()
+    ch = ob.f_to_mont(ob.FR, U.random_raw256(8800 + rounds, rounds + 1))
+    a, b = api.ExpandingTable(rounds, ch[rounds]), ob.ExpandingTable(rounds, ob.fr_to_int(ch[rounds]))
+    for k in range(rounds):
+        a.bind(ch[k])
+        b.bind(ob.fr_to_int(ch[k]))
+        assert [ob.fr_to_int(x) for x in a.getAll()] == b.values, k
+    assert ob.fr_to_int(a.sum()) == b.sum()
+    w = ob.f_to_mont(ob.FR, U.random_raw256(8900 + rounds, 1 << rounds))
+    for out_bits in {0, rounds // 2, rounds}:
+        assert [ob.fr_to_int(x) for x in a.condense(w, out_bits)] == b.condense([ob.fr_to_int(x) for x in w], out_bits), out_bits

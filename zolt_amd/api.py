@@ -2034,6 +2034,46 @@ class Stage3Prover:
         self.instr.deinit()
 
 
+class ExpandingTable:
+    """ExpandingTable (src/zkvm/lasso/expanding_table.zig:27-190): after k binds the table IS the eq table of the k challenges, first
+    challenge on the index's top bit, times the initial value — rebuilt by the device's eq-table kernel at every bind (:83-99 doubles it on
+    the host); condense (:144-161) = an element-wise product and sums over runs of 2^(round - out_bits) entries (weighted column sums of
+    the transposed products)."""
+
+    def __init__(self, max_rounds, initial=None):
+        self.max_rounds, self.round = max_rounds, 0
+        self._initial = fr_from_int(1) if initial is None else np.ascontiguousarray(initial, dtype=np.uint64).reshape(4).copy()
+        self._r = []
+        self.values = self._initial.reshape(1, 4).copy()
+
+    def size(self):
+        return self.values.shape[0]
+
+    def bind(self, r):
+        assert self.round < self.max_rounds
+        self._r.append(np.ascontiguousarray(r, dtype=np.uint64).reshape(4).copy())
+        self.values = lib.fr_eq_table(np.stack(self._r), self._initial)
+        self.round += 1
+
+    def get(self, index):
+        return self.values[index]
+
+    def getAll(self):
+        return self.values
+
+    def sum(self):
+        return fr_from_int(sum(fr_to_int(x) for x in self.values) % R_MOD) if self.values.shape[0] <= 4096 else \
+            lib.fr_weighted_colsum(self.values, self.values.shape[0], 1, np.tile(fr_from_int(1), (1, self.values.shape[0], 1)))[0, 0]
+
+    def condense(self, weights, out_bits):
+        w = np.ascontiguousarray(weights, dtype=np.uint64).reshape(-1, 4)
+        assert w.shape[0] == self.values.shape[0] and out_bits <= self.round
+        out_size, chunk = 1 << out_bits, 1 << (self.round - out_bits)
+        prod = lib.field_op(lib.FR, lib.OP_MUL, self.values, w).reshape(out_size, chunk, 4)
+        t = np.ascontiguousarray(prod.transpose(1, 0, 2)).reshape(-1, 4)  # chunk rows of out_size columns: a column sum per output
+        return lib.fr_weighted_colsum(t, chunk, out_size, np.tile(fr_from_int(1), (1, chunk, 1)))[0]
+
+
 class SpartanOuterProver:
     """The standard rounds of SpartanOuterProver (src/zkvm/spartan/outer.zig:364-407) over its working_vals table: LowToHigh sums and
     folds on a LOW_PAIR device session (the UniSkip first round of this prover is StreamingOuterProver.computeFirstRoundPoly's)."""
