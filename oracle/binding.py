@@ -2557,3 +2557,20 @@ class ExpandingTable:
         for i, (v, w) in enumerate(zip(self.values, weights)):
             out[i // chunk] = (out[i // chunk] + v * w) % _R_P
         return out
+
+
+def lt_table(r_cycle):
+    """the C restatement of LtPolynomial over the cube (zo_lt_table) -> (2^v, 4)"""
+    r = _c(np.asarray(r_cycle, dtype=np.uint64).reshape(-1, 4))
+    out = np.empty((1 << r.shape[0], 4), dtype=np.uint64)
+    lib.zo_lt_table(_p(r), C.c_size_t(r.shape[0]), _p(out))
+    return out
+
+
+def weighted_colsum(table, rows, cols, weights):
+    """the C restatement of the x_hi / x_lo double loop (zo_weighted_colsum) -> (m, cols, 4)"""
+    t, w = _c(table), _c(weights)
+    m = w.size // (4 * rows)
+    out = np.empty((m, cols, 4), dtype=np.uint64)
+    lib.zo_weighted_colsum(_p(t), C.c_size_t(rows), C.c_size_t(cols), _p(w), C.c_size_t(m), _p(out))
+    return out

@@ -1506,3 +1506,36 @@ EXPORT void zo_eq_plus_one_table(const uint64_t *r, size_t n, uint64_t *out) {
     }
     free(bits);
 }
+
+
+/* LtPolynomial.evaluateAtIndex over the cube — src/zkvm/ram/val_evaluation.zig:309-330, the reference's double loop (index bit i <-> r[i]) */
+EXPORT void zo_lt_table(const uint64_t *r, size_t v, uint64_t *out) {
+    const fe *R = (const fe *)r;
+    fe one = f_one(&FR);
+    for (size_t j = 0; j < ((size_t)1 << v); j++) {
+        fe result = f_zero();
+        for (size_t i = 0; i < v; i++) {
+            if ((j >> i) & 1) continue;
+            fe contrib = R[i];
+            for (size_t k = i + 1; k < v; k++) {
+                fe omr = f_sub(&FR, &one, &R[k]);
+                contrib = f_mul(&FR, &contrib, ((j >> k) & 1) ? &R[k] : &omr);
+            }
+            result = f_add(&FR, &result, &contrib);
+        }
+        memcpy(out + 4 * j, &result, 32);
+    }
+}
+/* the x_hi / x_lo double loop of the Stage-3 Q tables and Dory's vector-matrix product — src/zkvm/spartan/stage3_prover.zig:1066-1112,
+ * src/poly/commitment/dory.zig:622-642: out[k][c] = sum_r weights[k][r] * table[r * cols + c] */
+EXPORT void zo_weighted_colsum(const uint64_t *table, size_t rows, size_t cols, const uint64_t *weights, size_t m, uint64_t *out) {
+    const fe *T = (const fe *)table, *W = (const fe *)weights;
+    fe *O = (fe *)out;
+    for (size_t i = 0; i < m * cols; i++) O[i] = f_zero();
+    for (size_t r = 0; r < rows; r++)
+        for (size_t c = 0; c < cols; c++)
+            for (size_t k = 0; k < m; k++) {
+                fe p = f_mul(&FR, &T[r * cols + c], &W[k * rows + r]);
+                O[k * cols + c] = f_add(&FR, &O[k * cols + c], &p);
+            }
+}

@@ -146,6 +146,11 @@ def test_zig_backend_size_gates_are_the_measured_crossovers():
             "bind_low_min_entries": "bind_low", "bind_high_min_entries": "bind_high", "run_sumcheck_min_entries": "run_sumcheck",
             "open_min_entries": "hyperkzg_open"}
     assert set(want) <= set(consts)
+    # the round-3 additions were measured into their own file (tools/crossover.py --only lt_table,weighted_colsum)
+    cross3 = json.load(open(os.path.join(ROOT, "profiles", "r3_crossover_stage3.json")))
+    want.update({"lt_table_min_entries": "lt_table", "weighted_colsum_min_entries": "weighted_colsum"})
+    for key in ("lt_table", "weighted_colsum"):
+        cross["gates"][key], cross["points"][key] = cross3["gates"][key], cross3["points"][key]
     for const, key in want.items():
         assert consts[const] == cross["gates"][key], (const, consts[const], cross["gates"][key])
         pts = {p["n"]: p for p in cross["points"][key]}
@@ -159,7 +164,8 @@ def test_zig_backend_size_gates_are_the_measured_crossovers():
         return code[i:j if j > 0 else len(code)]
     gated = {"commit": "srs_commit_min_points", "batchCommit": "srs_commit_min_points", "open": "open_min_entries", "batchOpen": "open_min_entries", "msmComputeOneShot": "one_shot_min_points",
              "parallelMsmOneShot": "one_shot_min_points", "eqTable": "eq_table_min_entries", "bindLow": "bind_low_min_entries",
-             "bindHigh": "bind_high_min_entries", "runSumcheck": "run_sumcheck_min_entries"}
+             "bindHigh": "bind_high_min_entries", "runSumcheck": "run_sumcheck_min_entries", "ltTable": "lt_table_min_entries",
+             "weightedColsum": "weighted_colsum_min_entries"}
     for fn, const in gated.items():
         b = body(fn)
         assert const in b, (fn, const)

@@ -13,6 +13,8 @@ For n = 2^4 .. 2^max-log it times, on THIS box (GPU and host cores side by side)
     bind_high      zg_fr_bind_high                               vs  oracle fr_bind_high
     run_sumcheck   zg_run_sumcheck (whole protocol on the device) vs  oracle run_sumcheck
     hyperkzg_open  zg_hyperkzg_open on the resident SRS          vs  oracle hyperkzg_open
+    lt_table       zg_fr_lt_table (v = log2 n)                   vs  oracle lt_table (LtPolynomial.evaluateAtIndex per index)
+    weighted_colsum zg_fr_weighted_colsum (sqrt n rows, two weight vectors) vs oracle weighted_colsum (the x_hi / x_lo double loop)
 and reports per entry point the smallest power of two from which the GPU is faster at every larger measured size (`gate`). The
 gates are the constants of zig/gpu/backend.zig (tests/test_abi_and_host.py holds the two against each other). The oracle is the
 checker of the test suite; here it is only the CPU side of a timing comparison (tools/, never the product path)."""
@@ -48,6 +50,8 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "crossover.json"), help="copy the file to profiles/ afterwards")
     ap.add_argument("--max-log", type=int, default=20)
     ap.add_argument("--cpu-budget", type=float, default=1.5, help="seconds of CPU work per (entry point, size); larger sizes are not timed on the CPU")
+    ap.add_argument("--only", default="", help="comma-separated entry points to measure (default: all); the round-3 additions lt_table,weighted_colsum "
+                    "were measured into profiles/r3_crossover_stage3.json this way")
     args = ap.parse_args()
     lib.init(0)
     nmax = 1 << args.max_log
@@ -79,9 +83,23 @@ def main():
         res["points"].setdefault(name, []).append({"n": n, "gpu_us": g * 1e6, "cpu_us": None if c is None else c * 1e6})
         print(f"{name:14s} n=2^{n.bit_length() - 1:<2d} gpu {g * 1e6:10.1f} us   cpu {'-' if c is None else format(c * 1e6, '10.1f')} us", flush=True)
 
+    only = set(x for x in args.only.split(",") if x)
+    _measure = measure
+
+    def measure(name, *a, **kw):  # noqa: F811
+        if not only or name in only:
+            _measure(name, *a, **kw)
+
     for lg in logs:
         n = 1 << lg
         s_n, b_n = sc[:n], gm[:n]
+        # round 3: LtPolynomial over the cube (ValEvaluationProver.init) and the Q-table / vector-matrix double loop (a square matrix, two suffixes)
+        measure("lt_table", n, lambda: lib.fr_lt_table(sc[:lg]), lambda: ob.lt_table(sc[:lg]))
+        rows = 1 << (lg // 2)
+        measure("weighted_colsum", n, lambda: lib.fr_weighted_colsum(s_n, rows, n // rows, sc[:2 * rows].reshape(2, rows, 4)),
+                lambda: ob.weighted_colsum(s_n, rows, n // rows, sc[:2 * rows].reshape(2, rows, 4)))
+        if only and not (only - {"lt_table", "weighted_colsum"}):
+            continue
         measure("srs_commit", n, lambda: srs.msm(s_n, 0, n), lambda: ob.msm_g1(b_n, None, s_n))
 
         def one_shot():

@@ -123,6 +123,9 @@ pub const bind_low_min_entries: usize = 16384; // in place: the table crosses PC
 pub const bind_high_min_entries: usize = 4096; // 2^12: 70 us against 83
 pub const run_sumcheck_min_entries: usize = 4096; // whole protocol on the device: 0.17 ms against 0.21 ms
 pub const open_min_entries: usize = 16; // HyperKZG.open: 0.25 ms against 1.2 ms at 16 evaluations
+// round-3 additions (tools/crossover.py --only lt_table,weighted_colsum -> profiles/r3_crossover_stage3.json)
+pub const lt_table_min_entries: usize = 256; // LtPolynomial over the cube (ValEvaluationProver.init): 44 us against 71 us at 2^8 (2^6: 41 against 13)
+pub const weighted_colsum_min_entries: usize = 4096; // 86 us against 149 us at 2^12 (2^10: 70 against 41): the Q tables of Stage 3's prefix / suffix provers, Dory's vector-matrix product
 
 // ---------------------------------------------------------------------------------------------------------------
 // SrsHandle: the device image of SetupParams.powers_of_tau_g1 (src/poly/commitment/mod.zig:122-140). A FIELD of SetupParams
@@ -349,6 +352,28 @@ pub fn gruenPrefixTables(comptime F: type, allocator: std.mem.Allocator, w: []co
         @memcpy(table, flat[size - 1 .. 2 * size - 1]);
         try vec.append(allocator, table);
     }
+}
+
+/// LtPolynomial.evaluateAtIndex for every index (src/zkvm/ram/val_evaluation.zig:309-330): what ValEvaluationProver.init loops over.
+/// null = below the measured crossover (lt_table_min_entries): the caller keeps its loop
+pub fn ltTable(comptime F: type, allocator: std.mem.Allocator, r_cycle: []const F) !?[]F {
+    if ((@as(usize, 1) << @intCast(r_cycle.len)) < lt_table_min_entries) return null;
+    const out = try allocator.alloc(F, @as(usize, 1) << @intCast(r_cycle.len));
+    errdefer allocator.free(out);
+    if (ffi.zg_fr_lt_table(limbsOf(F, r_cycle), r_cycle.len, @ptrCast(out.ptr)) != ffi.OK) return Error.GpuFailure;
+    return out;
+}
+
+/// out[k * cols + c] = sum_r weights[k * rows + r] * table[r * cols + c]: the x_hi / x_lo double loop of ShiftPrefixSuffixProver.init /
+/// RegistersPrefixSuffixProver.init (src/zkvm/spartan/stage3_prover.zig:1066-1112, 2232-2290) and Dory's computeVectorMatrixProduct
+/// (src/poly/commitment/dory.zig:622-642). null = below the measured crossover (weighted_colsum_min_entries)
+pub fn weightedColsum(comptime F: type, allocator: std.mem.Allocator, table: []const F, rows: usize, cols: usize, weights: []const F) !?[]F {
+    if (table.len < weighted_colsum_min_entries) return null;
+    const m = weights.len / rows;
+    const out = try allocator.alloc(F, m * cols);
+    errdefer allocator.free(out);
+    if (ffi.zg_fr_weighted_colsum(limbsOf(F, table), rows, cols, limbsOf(F, weights), m, @ptrCast(out.ptr)) != ffi.OK) return Error.GpuFailure;
+    return out;
 }
 
 /// in place; the caller then halves its live length / decrements num_vars as the original does (:160-175).
