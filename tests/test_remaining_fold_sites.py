@@ -210,3 +210,32 @@ def test_expanding_table_on_the_device(rounds):
     w = ob.f_to_mont(ob.FR, U.random_raw256(8900 + rounds, 1 << rounds))
     for out_bits in {0, rounds // 2, rounds}:
         assert [ob.fr_to_int(x) for x in a.condense(w, out_bits)] == b.condense([ob.fr_to_int(x) for x in w], out_bits), out_bits
+
+
+def test_c_restatements_of_the_lt_table_and_the_column_sums():
+    """oracle/zolt_oracle.c's zo_lt_table / zo_weighted_colsum (the CPU side of tools/crossover.py) against the Python restatements"""
+    ob = _ob()
+    r = [ob.fr_to_int(x) for x in ob.f_to_mont(ob.FR, U.random_raw256(9901, 7))]
+    assert [ob.fr_to_int(x) for x in ob.lt_table(np.stack([ob.fr_from_int(v) for v in r]))] == ob.lt_table_int(r)
+    tab = ob.f_to_mont(ob.FR, U.random_raw256(9902, 6 * 10))
+    w = ob.f_to_mont(ob.FR, U.random_raw256(9903, 3 * 6)).reshape(3, 6, 4)
+    got = ob.weighted_colsum(tab, 6, 10, w)
+    t3 = tab.reshape(6, 10, 4)
+    for k in range(3):
+        for c in range(10):
+            assert np.array_equal(got[k, c], ob._fsum(ob._fmul(np.ascontiguousarray(t3[:, c]), np.ascontiguousarray(w[k]))))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("v", [0, 1, 5, 12, 16])
+def test_lt_table_and_column_sums_against_the_c_restatement(v):
+    ob = _ob()
+    from zolt_amd import lib
+    lib.init()
+    r = ob.f_to_mont(ob.FR, U.random_raw256(9910 + v, max(v, 1)))[:v]
+    assert np.array_equal(lib.fr_lt_table(r), ob.lt_table(r))
+    n = 1 << v
+    rows = 1 << (v // 2)
+    tab = ob.f_to_mont(ob.FR, U.random_raw256(9920 + v, n))
+    w = ob.f_to_mont(ob.FR, U.random_raw256(9930 + v, 4 * rows)).reshape(4, rows, 4)
+    assert np.array_equal(lib.fr_weighted_colsum(tab, rows, n // rows, w), ob.weighted_colsum(tab, rows, n // rows, w))
