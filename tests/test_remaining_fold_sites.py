@@ -141,7 +141,7 @@ def test_lt_polynomial_is_the_less_than_indicator_on_the_cube():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("trace_len,log_k,log_t", [(1, 3, 1), (37, 4, 6), (256, 6, 8), (1000, 8, 10), (5000, 10, 13)])
+@pytest.mark.parametrize("trace_len,log_k,log_t", [(1, 3, 1), (37, 4, 6), (256, 6, 8), (1000, 8, 10), (5000, 10, 13), (300, 5, 12), (300, 5, 7)])
 def test_standard_stage4_val_evaluation(trace_len, log_k, log_t):
     """MultiStageProver.proveStage4 (prover.zig:713-828) through api.proveStage4 (tables: eq gather, zg_fr_lt_table; rounds: one product
     session) against the restatement, both on Keccak transcripts seeded alike: challenges, initial claim, every round polynomial, the final
