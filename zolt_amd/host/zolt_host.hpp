@@ -1036,6 +1036,11 @@ public:
     // bit t of `points`: the round calls compute p(t); the other slots come back as zero
     void setPoints(unsigned points) { check(zg_psc_set_points(s_, points), "zg_psc_set_points"); }
     void bind(const Fr &r) { check(zg_psc_bind(s_, r.limbs), "zg_psc_bind"); }
+    std::vector<Fr> read(size_t table) {  // the whole current table
+        std::vector<Fr> out(len());
+        check(zg_psc_read(s_, table, reinterpret_cast<uint64_t *>(out.data())), "zg_psc_read");
+        return out;
+    }
     std::vector<Fr> gather(size_t table, const std::vector<uint64_t> &idx) {  // T[table][idx[i]] of the current tables
         std::vector<Fr> out(idx.size());
         check(zg_psc_gather(s_, table, idx.data(), idx.size(), reinterpret_cast<uint64_t *>(out.data())), "zg_psc_gather");
@@ -1398,11 +1403,7 @@ public:
     std::vector<Fr> challenges;
 
 private:
-    static std::vector<Fr> stage3_readTable(ProductSumcheckSession &s, size_t table) {
-        std::vector<uint64_t> idx(s.len());
-        for (size_t i = 0; i < idx.size(); i++) idx[i] = i;
-        return s.gather(table, idx);
-    }
+    static std::vector<Fr> stage3_readTable(ProductSumcheckSession &s, size_t table) { return s.read(table); }
     void open() {
         if (s_) return;
         std::vector<const std::vector<Fr> *> tp;
@@ -1493,11 +1494,7 @@ inline Fr evaluateMle(std::vector<Fr> t, const std::vector<Fr> &point) {  // :18
     }
     return t[0];
 }
-inline std::vector<Fr> readTable(ProductSumcheckSession &s, size_t table) {
-    std::vector<uint64_t> idx(s.len());
-    for (size_t i = 0; i < idx.size(); i++) idx[i] = i;
-    return s.gather(table, idx);
-}
+inline std::vector<Fr> readTable(ProductSumcheckSession &s, size_t table) { return s.read(table); }
 inline std::array<Fr, 4> evalsToCoeffs(const std::vector<Fr> &ev) {  // :846-901, degree 2 (three evaluations) or 3 (four)
     Fr two_inv, six_inv;
     Fr::fromU64(2).inverse(two_inv);
