@@ -643,6 +643,17 @@ TEST(remaining_fold_sites_on_the_references_vectors) {
     auto b = lp.bind(Fr::fromU64(2));
     EXPECT(b.num_vars == 1 && b.evaluations[0].eql(Fr::fromU64(5)) && b.evaluations[1].eql(Fr::fromU64(6)));
     EXPECT(lp.evaluate({Fr::one(), Fr::zero()}).eql(Fr::fromU64(2)) && lp.evaluate({Fr::zero(), Fr::one()}).eql(Fr::fromU64(3)));
+    // src/zkvm/lasso/expanding_table.zig tests: bind 3 -> [1 - 3, 3]; binds 2, 3, 5 -> sum 1, entry 0 = -8, entry 7 = 30; condense
+    ExpandingTable et(4);
+    for (uint64_t c : {2, 3, 5}) et.bind(Fr::fromU64(c));
+    EXPECT(et.size() == 8 && et.sum().eql(Fr::one()) && et.get(0).eql(Fr::zero().sub(Fr::fromU64(8))) && et.get(7).eql(Fr::fromU64(30)) &&
+           et.get(1).eql(Fr::fromU64(10)));
+    ExpandingTable e2(4);
+    e2.bind(Fr::fromU64(2));
+    e2.bind(Fr::fromU64(3));
+    auto cd = e2.condense(f({1, 2, 3, 4}), 1);
+    EXPECT(cd.size() == 2 && cd[0].eql(e2.get(0).add(e2.get(1).mul(Fr::fromU64(2)))) &&
+           cd[1].eql(e2.get(2).mul(Fr::fromU64(3)).add(e2.get(3).mul(Fr::fromU64(4)))));
     SpartanOuterProver o(f({1, 2, 3, 4}));
     auto r0 = o.computeStandardRoundPoly();
     EXPECT(r0[0].eql(Fr::fromU64(4)) && r0[1].eql(Fr::fromU64(6)) && r0[2].eql(Fr::fromU64(8)));

@@ -1420,6 +1420,44 @@ private:
     std::vector<ProductSumcheckSession::Term> terms_;
 };
 
+// ExpandingTable (src/zkvm/lasso/expanding_table.zig:27-190): after k binds the table IS the eq table of the challenges (first challenge on
+// the index's top bit) times the initial value — rebuilt by the device's eq-table kernel; condense (:144-161) = products and sums over runs
+class ExpandingTable {
+public:
+    explicit ExpandingTable(size_t max_rounds, const Fr &initial = Fr::one()) : max_rounds_(max_rounds), initial_(initial), values_{initial} {}
+    size_t size() const { return values_.size(); }
+    size_t round() const { return r_.size(); }
+    void bind(const Fr &r) {  // :83-99
+        if (r_.size() >= max_rounds_) throw std::invalid_argument("ExpandingTable.bind: past max_rounds");
+        r_.push_back(r);
+        values_ = EqPolynomial::evalsSliceWithScaling(r_, &initial_);
+    }
+    const Fr &get(size_t i) const { return values_.at(i); }
+    const std::vector<Fr> &getAll() const { return values_; }
+    Fr sum() const {
+        Fr s = Fr::zero();
+        for (const Fr &v : values_) s = s.add(v);
+        return s;
+    }
+    std::vector<Fr> condense(const std::vector<Fr> &weights, size_t out_bits) const {  // out[i / chunk] += values[i] * weights[i]
+        if (weights.size() != values_.size() || out_bits > r_.size()) throw std::invalid_argument("ExpandingTable.condense: weights.len == size, out_bits <= round");
+        const size_t out_size = size_t(1) << out_bits, chunk = size_t(1) << (r_.size() - out_bits), n = values_.size();
+        std::vector<Fr> prod(n), t(n), ones(chunk, Fr::one()), out(out_size);
+        check(zg_field_op(ZG_FIELD_FR, ZG_OP_MUL, reinterpret_cast<const uint64_t *>(values_.data()), reinterpret_cast<const uint64_t *>(weights.data()),
+                          reinterpret_cast<uint64_t *>(prod.data()), n), "zg_field_op");
+        for (size_t g = 0; g < out_size; g++)  // chunk rows of out_size columns: a column sum per output
+            for (size_t c = 0; c < chunk; c++) t[c * out_size + g] = prod[g * chunk + c];
+        check(zg_fr_weighted_colsum(reinterpret_cast<const uint64_t *>(t.data()), chunk, out_size, reinterpret_cast<const uint64_t *>(ones.data()), 1,
+                                    reinterpret_cast<uint64_t *>(out.data())), "zg_fr_weighted_colsum");
+        return out;
+    }
+
+private:
+    size_t max_rounds_;
+    Fr initial_;
+    std::vector<Fr> r_, values_;
+};
+
 struct LassoPrefixPolynomial {
     std::vector<Fr> evaluations;
     size_t num_vars;
