@@ -654,6 +654,13 @@ TEST(remaining_fold_sites_on_the_references_vectors) {
     auto cd = e2.condense(f({1, 2, 3, 4}), 1);
     EXPECT(cd.size() == 2 && cd[0].eql(e2.get(0).add(e2.get(1).mul(Fr::fromU64(2)))) &&
            cd[1].eql(e2.get(2).mul(Fr::fromU64(3)).add(e2.get(3).mul(Fr::fromU64(4)))));
+    // Dory's evaluation vectors (src/poly/commitment/dory.zig:544-620): the basis at (3, 5) is [(1-3)(1-5), 3 (1-5), (1-3) 5, 15]
+    auto lb = Dory::multilinearLagrangeBasis(f({3, 5}));
+    EXPECT(lb.size() == 4 && lb[0].eql(Fr::fromU64(8)) && lb[1].eql(Fr::zero().sub(Fr::fromU64(12))) && lb[2].eql(Fr::zero().sub(Fr::fromU64(10))) &&
+           lb[3].eql(Fr::fromU64(15)));
+    auto lr = Dory::computeEvaluationVectors(f({3, 5, 7}), 2, 2);  // two column variables, one row variable: left = [1 - 7, 7, 0, 0]
+    EXPECT(lr.second.size() == 4 && lr.second[3].eql(Fr::fromU64(15)) && lr.first[0].eql(Fr::zero().sub(Fr::fromU64(6))) && lr.first[1].eql(Fr::fromU64(7)) &&
+           lr.first[2].isZero() && lr.first[3].isZero());
     SpartanOuterProver o(f({1, 2, 3, 4}));
     auto r0 = o.computeStandardRoundPoly();
     EXPECT(r0[0].eql(Fr::fromU64(4)) && r0[1].eql(Fr::fromU64(6)) && r0[2].eql(Fr::fromU64(8)));

@@ -286,6 +286,31 @@ struct Dory {
         if (rest) out.push_back(g1_vec.msm(evals.data() + full * num_columns, rest));
         return out;
     }
+    // multilinearLagrangeBasis (:544-588): the eq table with the index's LOW bit on point[0] = the device's eq table of the reversed point;
+    // a shorter output is its first entries
+    static std::vector<Fr> multilinearLagrangeBasis(const std::vector<Fr> &point, size_t out_len = 0) {
+        std::vector<Fr> full(size_t(1) << point.size(), Fr::one());
+        if (!point.empty()) {
+            std::vector<Fr> rev(point.rbegin(), point.rend());
+            check(zg_fr_eq_table(reinterpret_cast<const uint64_t *>(rev.data()), rev.size(), nullptr, reinterpret_cast<uint64_t *>(full.data())), "zg_fr_eq_table");
+        }
+        if (out_len && out_len < full.size()) full.resize(out_len);
+        return full;
+    }
+    // computeEvaluationVectors (:590-620) -> (left_vec of 2^nu, right_vec of 2^sigma entries)
+    static std::pair<std::vector<Fr>, std::vector<Fr>> computeEvaluationVectors(const std::vector<Fr> &point, unsigned nu, unsigned sigma) {
+        std::vector<Fr> left(size_t(1) << nu, Fr::zero()), right(size_t(1) << sigma, Fr::zero());
+        const size_t d = point.size();
+        auto put = [](std::vector<Fr> &dst, const std::vector<Fr> &src) { std::copy(src.begin(), src.end(), dst.begin()); };
+        if (d <= sigma) {
+            put(right, multilinearLagrangeBasis(point));
+            left[0] = Fr::one();
+        } else {
+            put(right, multilinearLagrangeBasis(std::vector<Fr>(point.begin(), point.begin() + sigma)));
+            put(left, multilinearLagrangeBasis(std::vector<Fr>(point.begin() + sigma, point.end()), d <= nu + sigma ? 0 : left.size()));
+        }
+        return {left, right};
+    }
     // computeVectorMatrixProduct (:622-642): v[col] = sum_row left_vec[row] * evals[row * 2^sigma + col]
     static std::vector<Fr> computeVectorMatrixProduct(const std::vector<Fr> &evals, const std::vector<Fr> &left_vec, unsigned nu, unsigned sigma) {
         const size_t rows = size_t(1) << nu, cols = size_t(1) << sigma;
