@@ -421,6 +421,11 @@ ZG_API int zg_psc_close(zg_psc_t s);
 typedef struct zg_rrw_s *zg_rrw_t;
 ZG_API int zg_rrw_open(size_t log_t, const uint8_t *rs1, const uint8_t *rs2, const uint8_t *rd, const uint64_t *reg_vals, const uint64_t *inc,
                 const uint64_t gamma[4], zg_rrw_t *s);
+/* the same session from the write column alone: rd_value [T] = what cycle j writes to register rd[j] (ignored where rd[j] = 0xFF). The
+ * register file before every cycle (the last write to each register at an earlier cycle, zero before the first) and inc are rebuilt on
+ * the device — 11 bytes per cycle cross the boundary instead of 291, and the host keeps no 32 x T table (stage4_gruen_prover.zig:183-258). */
+ZG_API int zg_rrw_open_trace(size_t log_t, const uint8_t *rs1, const uint8_t *rs2, const uint8_t *rd, const uint64_t *rd_value,
+                      const uint64_t gamma[4], zg_rrw_t *s);
 ZG_API size_t zg_rrw_cycles(zg_rrw_t s);    /* current_T */
 ZG_API size_t zg_rrw_registers(zg_rrw_t s); /* current_K */
 /* phase1ComputeMessage's pair (:561-741): q0 = sum_i E_out[i >> log2|E_in|] E_in[i & (|E_in| - 1)] sum_k C_0(k, i), qX2 likewise with the

@@ -68,6 +68,32 @@ def test_rounds_against_the_restatement(api, log_t, n_steps, p1):
     d.deinit()
 
 
+@pytest.mark.parametrize("log_t,n_steps,noop_share", [(1, 2, 0.0), (5, 31, 0.1), (6, 64, 0.0), (7, 100, 0.5), (12, 4000, 0.1), (13, 8192, 0.985), (14, 9000, 0.0)])
+def test_register_file_rebuilt_on_the_device(api, log_t, n_steps, noop_share):
+    """zg_rrw_open_trace (write column only; register file and inc rebuilt by the device's last-write scan) against zg_rrw_open (both
+    built on the host by traceColumns): every round identical — traces shorter than a 64-cycle chunk, padded ones, and one with so few
+    writes that a register's value is carried over dozens of chunks"""
+    steps = seeded_steps(900 + log_t, n_steps, noop_share)
+    rng = np.random.default_rng(50 + log_t)
+    r = ob.f_to_mont(ob.FR, rng.integers(0, 1 << 63, size=(log_t + 1 + 7 + log_t, 4), dtype=np.uint64))
+    gamma, r_cycle, chals = r[0], r[1:1 + log_t], r[1 + log_t:]
+    p1 = max(1, log_t // 2)
+    h = api.Stage4GruenProver(steps, gamma, r_cycle, p1, 7, host_register_file=True)
+    d = api.Stage4GruenProver(steps, gamma, r_cycle, p1, 7)
+    claim = api.fr_from_int(0)
+    for k in range(7 + log_t):
+        eh, ed = h.computeRoundEvals(k, claim), d.computeRoundEvals(k, claim)
+        assert np.array_equal(eh, ed), k
+        claim = ob.raf_update_claim(eh, chals[k])
+        h.bindChallenge(k, chals[k])
+        d.bindChallenge(k, chals[k])
+    fh, fd = h.getFinalClaims(), d.getFinalClaims()
+    for name in fh:
+        assert np.array_equal(fh[name], fd[name]), name
+    h.deinit()
+    d.deinit()
+
+
 def test_trace_columns_match_the_sequential_register_file(api):
     """traceColumns' vectorised register file against the reference's sequential loop (restated here): value before every cycle"""
     steps = seeded_steps(7, 300)

@@ -123,6 +123,7 @@ pub extern fn zg_psc_gather(s: ProductSession, table: usize, idx: ?[*]const u64,
 pub extern fn zg_psc_final(s: ProductSession, out: ?[*]u64) c_int;
 pub extern fn zg_psc_close(s: ProductSession) c_int;
 pub extern fn zg_rrw_open(log_t: usize, rs1: ?[*]const u8, rs2: ?[*]const u8, rd: ?[*]const u8, reg_vals: ?[*]const u64, inc: ?[*]const u64, gamma: *const [4]u64, s: *RegistersSession) c_int;
+pub extern fn zg_rrw_open_trace(log_t: usize, rs1: ?[*]const u8, rs2: ?[*]const u8, rd: ?[*]const u8, rd_value: ?[*]const u64, gamma: *const [4]u64, s: *RegistersSession) c_int;
 pub extern fn zg_rrw_cycles(s: RegistersSession) usize;
 pub extern fn zg_rrw_registers(s: RegistersSession) usize;
 pub extern fn zg_rrw_round_cycle_gruen(s: RegistersSession, d_e_out: ?[*]const u64, n_out: usize, d_e_in: ?[*]const u64, n_in: usize, q0: *[4]u64, qx2: *[4]u64) c_int;

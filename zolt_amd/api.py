@@ -2786,7 +2786,7 @@ class Stage4GruenProver:
     _RS2_OPS = (0x33, 0x3B, 0x23, 0x63)  # ... rs2 (:220-231)
     _NO_RD_OPS = (0x23, 0x63)  # stores and branches write no register (:233-236)
 
-    def __init__(self, steps, gamma, r_cycle, phase1_num_rounds, phase2_num_rounds):
+    def __init__(self, steps, gamma, r_cycle, phase1_num_rounds, phase2_num_rounds, host_register_file=False):
         if isinstance(steps, tuple) and len(steps) == 3 and hasattr(steps[0], "__len__"):
             instr, rd_value, noop = (np.asarray(c) for c in steps)
         else:
@@ -2804,26 +2804,44 @@ class Stage4GruenProver:
         self.num_rounds = self.LOG_K + self.log_T
         self.gamma = np.ascontiguousarray(gamma, dtype=np.uint64).copy()
         self.phase1_num_rounds, self.phase2_num_rounds = phase1_num_rounds, phase2_num_rounds
-        rs1, rs2, rd, reg_vals, inc = self.traceColumns(instr.astype(np.uint32), rd_value.astype(np.uint64), noop.astype(bool), T)
-        self._s = lib.RegistersRwSession.open(self.log_T, rs1, rs2, rd, reg_vals, inc, self.gamma)
+        if host_register_file:  # zg_rrw_open: the 32 x T register file and inc built here
+            rs1, rs2, rd, reg_vals, inc = self.traceColumns(instr.astype(np.uint32), rd_value.astype(np.uint64), noop.astype(bool), T)
+            self._s = lib.RegistersRwSession.open(self.log_T, rs1, rs2, rd, reg_vals, inc, self.gamma)
+        else:  # zg_rrw_open_trace: both rebuilt on the device from the write column
+            rs1, rs2, rd, written = self.traceWriteColumns(instr.astype(np.uint32), rd_value.astype(np.uint64), noop.astype(bool), T)
+            self._s = lib.RegistersRwSession.open_trace(self.log_T, rs1, rs2, rd, written, self.gamma)
         self.gruen = GruenSplitEqPolynomial(r_cycle[::-1].copy())  # big-endian for the split-eq structure (:283-288)
         self.current_T, self.current_K = T, self.K
         self.last_q = None
 
     @classmethod
-    def traceColumns(cls, instr, rd_value, noop, T):
-        """what initWithPhaseConfig reads of the trace (:183-258), as columns: the register each cycle reads / writes (0xFF = none), the
-        register file BEFORE every cycle (32 x T, padding cycles keep the last one) and inc = F.fromU64(post) - F.fromU64(pre)."""
+    def traceWriteColumns(cls, instr, rd_value, noop, T):
+        """the columns zg_rrw_open_trace takes (:199-246): the register each cycle reads / writes (0xFF = none; rd only when it is used
+        and non-zero) and the value written"""
         n = len(instr)
         opcode, live = instr & 0x7F, ~noop
         f_rd, f_rs1, f_rs2 = ((instr >> 7) & 31).astype(np.uint8), ((instr >> 15) & 31).astype(np.uint8), ((instr >> 20) & 31).astype(np.uint8)
         rs1 = np.full(T, 0xFF, dtype=np.uint8)
         rs2 = np.full(T, 0xFF, dtype=np.uint8)
         rd = np.full(T, 0xFF, dtype=np.uint8)
+        written = np.zeros(T, dtype=np.uint64)
         rs1[:n] = np.where(live & np.isin(opcode, cls._RS1_OPS), f_rs1, 0xFF)
         rs2[:n] = np.where(live & np.isin(opcode, cls._RS2_OPS), f_rs2, 0xFF)
         writes = live & ~np.isin(opcode, cls._NO_RD_OPS) & (f_rd != 0)
         rd[:n] = np.where(writes, f_rd, 0xFF)
+        written[:n] = np.where(writes, rd_value, 0)
+        return rs1, rs2, rd, written
+
+    @classmethod
+    def traceColumns(cls, instr, rd_value, noop, T):
+        """what initWithPhaseConfig reads of the trace (:183-258), as columns for zg_rrw_open: the register each cycle reads / writes
+        (0xFF = none), the register file BEFORE every cycle (32 x T, padding cycles keep the last one) and
+        inc = F.fromU64(post) - F.fromU64(pre) — the host-side form of what zg_rrw_open_trace rebuilds on the device."""
+        n = len(instr)
+        opcode, live = instr & 0x7F, ~noop
+        f_rd = ((instr >> 7) & 31).astype(np.uint8)
+        writes = live & ~np.isin(opcode, cls._NO_RD_OPS) & (f_rd != 0)
+        rs1, rs2, rd, _ = cls.traceWriteColumns(instr, rd_value, noop, T)
         reg_vals = np.zeros((32, T), dtype=np.uint64)
         idx = np.arange(n)
         for k in range(1, 32):  # value of register k before cycle j = rd_value of its last write at a cycle < j

@@ -82,6 +82,71 @@ __global__ void __launch_bounds__(256) rrw_build_kernel(const uint8_t *rs1, cons
     fe_store(out.t[RT_RS2] + 4 * idx, a2 ? one : zero);
 }
 
+// The register file before every cycle, rebuilt on the device from the write column alone (zg_rrw_open_trace): the value of register k
+// before cycle j is rd_value of the last cycle < j that wrote k (:186-192, 249-258 walk the trace with a running register file). Three
+// launches: the last write per register inside every 64-cycle chunk (one wave = one chunk: a ballot per register), an exclusive running
+// maximum over the chunks per register, and the per-cycle lookup (ballot again, the lanes below mine that wrote k) which also forms inc.
+__global__ void __launch_bounds__(256) rrw_last_write_kernel(const uint8_t *rd, size_t T, int32_t *last, size_t nch) {
+    size_t j = (size_t)blockIdx.x * 256 + threadIdx.x, chunk = j >> 6;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t r = j < T ? rd[j] : 0xFFu;
+    int32_t mine = -1;
+    for (uint32_t k = 0; k < 32; k++) {
+        uint64_t m = __ballot(r == k);
+        if (lane == k && m) mine = (int32_t)((chunk << 6) + 63 - __clzll((long long)m));
+    }
+    if (lane < 32 && chunk < nch) last[lane * nch + chunk] = mine;
+}
+// one workgroup per register: last[k][c] := the last write to k in the chunks before c (-1: none yet)
+__global__ void __launch_bounds__(256) rrw_carry_scan_kernel(int32_t *last, size_t nch) {
+    __shared__ int32_t top[256];
+    int32_t *row = last + (size_t)blockIdx.x * nch;
+    const size_t per = (nch + 255) / 256, c0 = threadIdx.x * per, c1 = c0 + per < nch ? c0 + per : nch;
+    int32_t m = -1;
+    for (size_t c = c0; c < c1; c++) m = row[c] > m ? row[c] : m;
+    top[threadIdx.x] = m;
+    __syncthreads();
+    int32_t run = -1;
+    for (uint32_t t = 0; t < threadIdx.x; t++) run = top[t] > run ? top[t] : run;
+    for (size_t c = c0; c < c1; c++) {
+        int32_t t = row[c];
+        row[c] = run;
+        run = t > run ? t : run;
+    }
+}
+__global__ void __launch_bounds__(256) rrw_regfile_kernel(const uint8_t *rd, const uint64_t *rd_value, size_t T, const int32_t *carry, size_t nch,
+                                                          uint64_t *reg_vals, uint64_t *inc) {
+    size_t j = (size_t)blockIdx.x * 256 + threadIdx.x, chunk = j >> 6;
+    const uint32_t lane = threadIdx.x & 63;
+    const bool live = j < T;
+    const uint32_t r = live ? rd[j] : 0xFFu;
+    const int32_t c_in = lane < 32 && chunk < nch ? carry[lane * nch + chunk] : -1;
+    uint64_t old = 0;
+    for (uint32_t k = 0; k < 32; k++) {
+        const uint64_t below = __ballot(r == k) & (((uint64_t)1 << lane) - 1);
+        const int32_t carried = __shfl(c_in, (int)k);  // by every lane: a shuffle under the branch below would read idle lanes
+        int32_t idx = below ? (int32_t)((chunk << 6) + 63 - __clzll((long long)below)) : carried;
+        uint64_t v = idx >= 0 ? rd_value[idx] : 0;
+        if (live) reg_vals[k * T + j] = v;
+        if (r == k) old = v;
+    }
+    if (!live) return;
+    Fr d = Fr::zero();
+    if (r < 32) {  // inc = F.fromU64(post) - F.fromU64(pre) (:240-243)
+        F29 r2p;
+#pragma unroll
+        for (int i = 0; i < 9; i++) r2p.l[i] = Fr29::R2PRE[i];
+        const uint64_t post = rd_value[j];
+        Fr a = Fr::zero(), b = Fr::zero();
+        a.l[0] = (uint32_t)post;
+        a.l[1] = (uint32_t)(post >> 32);
+        b.l[0] = (uint32_t)old;
+        b.l[1] = (uint32_t)(old >> 32);
+        d = fe_sub(fr_mul29(a, r2p), fr_mul29(b, r2p));
+    }
+    fe_store(inc + 4 * j, d);
+}
+
 // Which rows of a cycle can be non-zero in ra / rd_wa / rs1_ra / rs2_ra: bit k of mask[j]. The four tables start one-hot (at most three
 // registers per cycle), and a cycle fold can only produce a non-zero where one of its two inputs had one: mask'[i] = mask[2i] | mask[2i+1].
 // While the cycle variables are being folded, the round kernels visit and the fold kernel WRITES only the masked entries of the four
@@ -449,10 +514,11 @@ static int rrw_materialize(zg_rrw_s *s) {
 
 extern "C" {
 
-int zg_rrw_open(size_t log_t, const uint8_t *rs1, const uint8_t *rs2, const uint8_t *rd, const uint64_t *reg_vals, const uint64_t *inc,
-                const uint64_t gamma[4], zg_rrw_t *out) {
+// reg_vals + inc from the host (zg_rrw_open), or rd_value alone and both rebuilt on the device (zg_rrw_open_trace)
+static int rrw_open_impl(size_t log_t, const uint8_t *rs1, const uint8_t *rs2, const uint8_t *rd, const uint64_t *reg_vals, const uint64_t *inc,
+                         const uint64_t *rd_value, const uint64_t gamma[4], zg_rrw_t *out) {
     ZG_INIT();
-    if (!out || !rs1 || !rs2 || !rd || !reg_vals || !inc || !gamma || log_t < 1 || log_t > 24) {
+    if (!out || !rs1 || !rs2 || !rd || (rd_value ? false : !reg_vals || !inc) || !gamma || log_t < 1 || log_t > 24) {
         set_error("zg_rrw_open: invalid argument (1 <= log_t <= 24: five 32 x 2^log_t tables of active rows and their half-size partners)");
         return ZG_ERR_INVALID;
     }
@@ -481,8 +547,9 @@ int zg_rrw_open(size_t log_t, const uint8_t *rs1, const uint8_t *rs2, const uint
     }
     // the trace columns travel in one scratch buffer: rs1 | rs2 | rd (T bytes each, padded) then the 32 x T register values
     const size_t pad = (T + 255) & ~(size_t)255;
-    Scratch s_cols(3 * pad), s_vals(32 * T * 8);
-    if (!s_cols.p || !s_vals.p) {
+    const size_t nch = (T + 63) / 64;
+    Scratch s_cols(3 * pad), s_vals(32 * T * 8), s_trace(rd_value ? T * 8 + 32 * nch * 4 : 8);
+    if (!s_cols.p || !s_vals.p || !s_trace.p) {
         rrw_free(s);
         return ZG_ERR_NOMEM;
     }
@@ -492,8 +559,18 @@ int zg_rrw_open(size_t log_t, const uint8_t *rs1, const uint8_t *rs2, const uint
         ZG_HIP(hipMemcpyAsync(d_cols, rs1, T, hipMemcpyHostToDevice, s->st));
         ZG_HIP(hipMemcpyAsync(d_cols + pad, rs2, T, hipMemcpyHostToDevice, s->st));
         ZG_HIP(hipMemcpyAsync(d_cols + 2 * pad, rd, T, hipMemcpyHostToDevice, s->st));
-        ZG_HIP(hipMemcpyAsync(s_vals.p, reg_vals, 32 * T * 8, hipMemcpyHostToDevice, s->st));
-        ZG_HIP(hipMemcpyAsync(s->inc[0], inc, T * 32, hipMemcpyHostToDevice, s->st));
+        if (rd_value) {
+            uint64_t *d_rdv = s_trace.as<uint64_t>();
+            int32_t *d_last = reinterpret_cast<int32_t *>(d_rdv + T);
+            ZG_HIP(hipMemcpyAsync(d_rdv, rd_value, T * 8, hipMemcpyHostToDevice, s->st));
+            hipLaunchKernelGGL(rrw_last_write_kernel, dim3(div_up(nch * 64, 256)), dim3(256), 0, s->st, d_cols + 2 * pad, T, d_last, nch);
+            hipLaunchKernelGGL(rrw_carry_scan_kernel, dim3(32), dim3(256), 0, s->st, d_last, nch);
+            hipLaunchKernelGGL(rrw_regfile_kernel, dim3(div_up(nch * 64, 256)), dim3(256), 0, s->st, d_cols + 2 * pad, d_rdv, T, d_last, nch,
+                               s_vals.as<uint64_t>(), s->inc[0]);
+        } else {
+            ZG_HIP(hipMemcpyAsync(s_vals.p, reg_vals, 32 * T * 8, hipMemcpyHostToDevice, s->st));
+            ZG_HIP(hipMemcpyAsync(s->inc[0], inc, T * 32, hipMemcpyHostToDevice, s->st));
+        }
         size_t n = (size_t)RRW_ACTIVE * T;
         hipLaunchKernelGGL(rrw_build_kernel, dim3(div_up(n, 256)), dim3(256), 0, s->st, d_cols, d_cols + pad, d_cols + 2 * pad, s_vals.as<uint64_t>(), T,
                            fr_arg(gamma), rrw_tabs_out(s, 0));
@@ -512,6 +589,18 @@ int zg_rrw_open(size_t log_t, const uint8_t *rs1, const uint8_t *rs2, const uint
     }
     *out = s;
     return ZG_OK;
+}
+int zg_rrw_open(size_t log_t, const uint8_t *rs1, const uint8_t *rs2, const uint8_t *rd, const uint64_t *reg_vals, const uint64_t *inc,
+                const uint64_t gamma[4], zg_rrw_t *out) {
+    return rrw_open_impl(log_t, rs1, rs2, rd, reg_vals, inc, nullptr, gamma, out);
+}
+int zg_rrw_open_trace(size_t log_t, const uint8_t *rs1, const uint8_t *rs2, const uint8_t *rd, const uint64_t *rd_value, const uint64_t gamma[4],
+                      zg_rrw_t *out) {
+    if (!rd_value) {
+        set_error("zg_rrw_open_trace: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    return rrw_open_impl(log_t, rs1, rs2, rd, nullptr, nullptr, rd_value, gamma, out);
 }
 
 size_t zg_rrw_cycles(zg_rrw_t s) { return s ? s->cur_T : 0; }

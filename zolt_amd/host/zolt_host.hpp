@@ -2357,28 +2357,25 @@ struct TraceStep {  // what the prover reads of ExecutionTrace.steps (:196-246)
     bool is_noop;
 };
 // what initWithPhaseConfig / initWithClaims read of the trace (stage4_gruen_prover.zig:183-258 = stage4_prover.zig:183-277), as the columns
-// zg_rrw_open takes: the register a cycle reads / writes (0xFF: none), the register file before every cycle, inc of the written register
+// zg_rrw_open_trace takes: the register a cycle reads / writes (0xFF: none) and the value it writes; the register file before every cycle
+// and inc of the written register are rebuilt from them on the device
 inline zg_rrw_t openRegistersSession(const std::vector<TraceStep> &steps, size_t log_T, const Fr &gamma) {
     const size_t T = size_t(1) << log_T;
     std::vector<uint8_t> rs1(T, 0xFF), rs2(T, 0xFF), rd(T, 0xFF);
-    std::vector<uint64_t> reg_vals(32 * T, 0);
-    std::vector<Fr> inc(T, Fr::zero());
-    uint64_t regs[32] = {};
-    for (size_t j = 0; j < T; j++) {
-        for (size_t k = 0; k < 32; k++) reg_vals[k * T + j] = regs[k];
-        if (j >= steps.size() || steps[j].is_noop) continue;
+    std::vector<uint64_t> rd_value(T, 0);
+    for (size_t j = 0; j < T && j < steps.size(); j++) {
+        if (steps[j].is_noop) continue;
         const uint32_t w = steps[j].instruction, op = w & 0x7F, f_rd = (w >> 7) & 31, f_rs1 = (w >> 15) & 31, f_rs2 = (w >> 20) & 31;
         const bool two = op == 0x33 || op == 0x3B || op == 0x23 || op == 0x63;
         if (two || op == 0x13 || op == 0x03 || op == 0x67 || op == 0x1B) rs1[j] = (uint8_t)f_rs1;
         if (two) rs2[j] = (uint8_t)f_rs2;
         if (op != 0x23 && op != 0x63 && f_rd != 0) {
             rd[j] = (uint8_t)f_rd;
-            inc[j] = Fr::fromU64(steps[j].rd_value).sub(Fr::fromU64(regs[f_rd]));
-            regs[f_rd] = steps[j].rd_value;
+            rd_value[j] = steps[j].rd_value;
         }
     }
     zg_rrw_t s = nullptr;
-    check(zg_rrw_open(log_T, rs1.data(), rs2.data(), rd.data(), reg_vals.data(), reinterpret_cast<const uint64_t *>(inc.data()), gamma.limbs, &s), "zg_rrw_open");
+    check(zg_rrw_open_trace(log_T, rs1.data(), rs2.data(), rd.data(), rd_value.data(), gamma.limbs, &s), "zg_rrw_open_trace");
     return s;
 }
 class Stage4GruenProver {

@@ -45,7 +45,7 @@ SYMBOLS = [
     "zg_run_sumcheck", "zg_run_sumcheck_dev", "zg_sumcheck_open_spartan_dev",
     "zg_psc_open", "zg_psc_open_dev", "zg_psc_len", "zg_psc_tables", "zg_psc_round_evals", "zg_psc_round_expr", "zg_psc_set_points", "zg_psc_round_gruen", "zg_psc_bind", "zg_psc_read", "zg_psc_gather",
     "zg_psc_final", "zg_psc_close",
-    "zg_rrw_open", "zg_rrw_cycles", "zg_rrw_registers", "zg_rrw_round_cycle_gruen", "zg_rrw_set_eq", "zg_rrw_round_address", "zg_rrw_round_cycle",
+    "zg_rrw_open", "zg_rrw_open_trace", "zg_rrw_cycles", "zg_rrw_registers", "zg_rrw_round_cycle_gruen", "zg_rrw_set_eq", "zg_rrw_round_address", "zg_rrw_round_cycle",
     "zg_rrw_bind_cycle", "zg_rrw_bind_address", "zg_rrw_final", "zg_rrw_close",
     "zg_rwc_open", "zg_rwc_entries", "zg_rwc_cycles", "zg_rwc_round_cycle", "zg_rwc_bind_cycle", "zg_rwc_round_address", "zg_rwc_bind_address",
     "zg_rwc_opening", "zg_rwc_cycle_scalars", "zg_rwc_read_entries", "zg_rwc_close",
@@ -914,6 +914,17 @@ class RegistersRwSession:
         assert rs1.size == rs2.size == rd.size == T and reg_vals.size == 32 * T and inc.size == 4 * T
         h = C.c_void_p()
         _chk(_lib.zg_rrw_open(C.c_size_t(log_t), _hb(rs1), _hb(rs2), _hb(rd), _h(reg_vals), _h(inc), _h(gamma), C.byref(h)), "zg_rrw_open")
+        return cls(h)
+
+    @classmethod
+    def open_trace(cls, log_t, rs1, rs2, rd, rd_value, gamma):
+        """the same session from the write column alone (zg_rrw_open_trace): the register file and inc are rebuilt on the device"""
+        rs1, rs2, rd = _c(rs1, np.uint8), _c(rs2, np.uint8), _c(rd, np.uint8)
+        rd_value, gamma = _c(rd_value), _c(gamma)
+        T = 1 << log_t
+        assert rs1.size == rs2.size == rd.size == rd_value.size == T
+        h = C.c_void_p()
+        _chk(_lib.zg_rrw_open_trace(C.c_size_t(log_t), _hb(rs1), _hb(rs2), _hb(rd), _h(rd_value), _h(gamma), C.byref(h)), "zg_rrw_open_trace")
         return cls(h)
 
     def cycles(self):
