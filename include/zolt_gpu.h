@@ -461,6 +461,12 @@ typedef struct zg_rwc_s *zg_rwc_t;
 ZG_API int zg_rwc_open(size_t log_k, size_t log_t, size_t n, const uint32_t *cycle, const uint32_t *address, const uint64_t *val_coeff,
                 const uint64_t *prev_val, const uint64_t *next_val, const uint64_t *inc /* 2^log_t * 4 */, const uint64_t *val_init /* 2^log_k * 4 */,
                 const uint64_t *r_cycle /* log_t * 4 */, zg_rwc_t *s);
+/* the same session without the dense inc table crossing the boundary: is_write [n] marks the entries that are writes, and the device
+ * forms inc[cycle] = F.fromU64(next_val) - F.fromU64(prev_val) for them (zero elsewhere) — what init's loop assigns (:283-291). A list
+ * with two writes in one cycle is refused (ZG_ERR_INVALID): the reference keeps the later one in ACCESS order; use zg_rwc_open then. */
+ZG_API int zg_rwc_open_writes(size_t log_k, size_t log_t, size_t n, const uint32_t *cycle, const uint32_t *address, const uint64_t *val_coeff,
+                       const uint64_t *prev_val, const uint64_t *next_val, const uint8_t *is_write, const uint64_t *val_init /* 2^log_k * 4 */,
+                       const uint64_t *r_cycle /* log_t * 4 */, zg_rwc_t *s);
 ZG_API size_t zg_rwc_entries(zg_rwc_t s); /* current length of the list */
 ZG_API size_t zg_rwc_cycles(zg_rwc_t s);  /* current length of eq_evals / inc */
 /* computePhase1Polynomial's (q_constant, q_quadratic) (:410-536) under the split-eq weights E_out x E_in (DEVICE tables, as

@@ -62,7 +62,8 @@ def _trace(seed, log_k, log_t, n_acc, start):
 
 @pytest.mark.parametrize("log_k,log_t,p1,n_acc", [(4, 8, 4, 200), (3, 8, 0, 256), (6, 8, 8, 90), (10, 13, 6, 3000), (16, 20, 10, 2500), (1, 1, 0, 2),
                                                   (5, 4, 2, 0), (12, 15, 7, 12000)])
-def test_ram_read_write_checking_vs_oracle(env, log_k, log_t, p1, n_acc):
+@pytest.mark.parametrize("device_inc", [False, True])  # inc handed over (zg_rwc_open) / formed on the device from the write entries (zg_rwc_open_writes)
+def test_ram_read_write_checking_vs_oracle(env, log_k, log_t, p1, n_acc, device_inc):
     api, lib, ob = env
     start = 0x80000000
     acc, initial = _trace(1000 * log_t + log_k, log_k, log_t, n_acc, start)
@@ -77,7 +78,7 @@ def test_ram_read_write_checking_vs_oracle(env, log_k, log_t, p1, n_acc):
     incv = {r: ob.fr_to_int(o.inc[r]) for r in rows}
     claim = sum(eqv[e[0]] * e[2] * (e[3] + g * (e[3] + incv[e[0]])) for e in o.entries) % P
     o.current_claim = claim
-    d = api.RamReadWriteCheckingProver(acc, gamma, r_cycle, log_k, log_t, p1, start, ob.fr_from_int(claim), initial)
+    d = api.RamReadWriteCheckingProver(acc, gamma, r_cycle, log_k, log_t, p1, start, ob.fr_from_int(claim), initial, device_inc=device_inc)
     try:
         assert d.entry_list() == [(e[0], e[1], e[2]) for e in o.entries]
         chal = []
@@ -99,6 +100,24 @@ def test_ram_read_write_checking_vs_oracle(env, log_k, log_t, p1, n_acc):
         assert d.isComplete() and o.isComplete()
         wo, go = o.getOpeningClaims(np.stack(chal)), d.getOpeningClaims(np.stack(chal))
         assert all(np.array_equal(a, b) for a, b in zip(go, wo))
+    finally:
+        d.deinit()
+
+
+def test_two_writes_in_one_cycle_are_refused_by_the_write_list_form(env):
+    """the reference keeps the LATER write of a cycle in access order, which the (cycle, address)-sorted list cannot tell:
+    zg_rwc_open_writes refuses such a list and the dense form (zg_rwc_open) serves it"""
+    api, lib, ob = env
+    start = 0x80000000
+    acc = [(3, start + 8, True, 5), (3, start, True, 9), (4, start, False, 9)]
+    g = ob.fr_from_int(7)
+    r_cycle = ob.f_to_mont(ob.FR, U.random_raw256(3, 3))
+    with pytest.raises(RuntimeError, match="two writes in one cycle"):
+        api.RamReadWriteCheckingProver(acc, g, r_cycle, 2, 3, 1, start, ob.fr_from_int(0), device_inc=True)
+    d = api.RamReadWriteCheckingProver(acc, g, r_cycle, 2, 3, 1, start, ob.fr_from_int(0))
+    o = ob.RamReadWriteCheckingProver(acc, g, r_cycle, 2, 3, 1, start, np.zeros(4, dtype=np.uint64))
+    try:
+        assert np.array_equal(d.computeRoundPolynomialCubic(), o.computeRoundPolynomialCubic())
     finally:
         d.deinit()
 

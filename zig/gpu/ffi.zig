@@ -135,6 +135,7 @@ pub extern fn zg_rrw_bind_address(s: RegistersSession, r: *const [4]u64) c_int;
 pub extern fn zg_rrw_final(s: RegistersSession, out: ?[*]u64) c_int;
 pub extern fn zg_rrw_close(s: RegistersSession) c_int;
 pub extern fn zg_rwc_open(log_k: usize, log_t: usize, n: usize, cycle: ?[*]const u32, address: ?[*]const u32, val_coeff: ?[*]const u64, prev_val: ?[*]const u64, next_val: ?[*]const u64, inc: ?[*]const u64, val_init: ?[*]const u64, r_cycle: ?[*]const u64, s: *RamRwSession) c_int;
+pub extern fn zg_rwc_open_writes(log_k: usize, log_t: usize, n: usize, cycle: ?[*]const u32, address: ?[*]const u32, val_coeff: ?[*]const u64, prev_val: ?[*]const u64, next_val: ?[*]const u64, is_write: ?[*]const u8, val_init: ?[*]const u64, r_cycle: ?[*]const u64, s: *RamRwSession) c_int;
 pub extern fn zg_rwc_entries(s: RamRwSession) usize;
 pub extern fn zg_rwc_cycles(s: RamRwSession) usize;
 pub extern fn zg_rwc_round_cycle(s: RamRwSession, d_e_out: ?[*]const u64, n_out: usize, d_e_in: ?[*]const u64, n_in: usize, gamma: *const [4]u64, q_constant: *[4]u64, q_quadratic: *[4]u64) c_int;

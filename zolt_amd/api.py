@@ -2407,7 +2407,7 @@ class RamReadWriteCheckingProver:
     decoding of init, the GruenSplitEqPolynomial, the cubic, the claim. accesses: [(timestamp, address, is_write, value)] in trace order;
     initial_ram: {address: u64}."""
 
-    def __init__(self, accesses, gamma, r_cycle, log_k, log_t, phase1_num_rounds, start_address, initial_claim, initial_ram=None):
+    def __init__(self, accesses, gamma, r_cycle, log_k, log_t, phase1_num_rounds, start_address, initial_claim, initial_ram=None, device_inc=False):
         self.gamma = np.ascontiguousarray(gamma, dtype=np.uint64).copy()
         self.r_cycle = np.ascontiguousarray(r_cycle, dtype=np.uint64).reshape(-1, 4).copy()
         self.log_k, self.log_t, self.phase1_num_rounds, self.start_address = log_k, log_t, phase1_num_rounds, start_address
@@ -2429,11 +2429,15 @@ class RamReadWriteCheckingProver:
             if is_write:
                 inc[ts] = fr_from_int(value - prev)
                 cur[idx] = value
-            ents.append((ts, idx, prev if is_write else value, prev, value))
+            ents.append((ts, idx, prev if is_write else value, prev, value, bool(is_write)))
         ents.sort(key=lambda e: (e[0], e[1]))  # :333-340 (stable)
         col = lambda k, dt: np.array([e[k] for e in ents], dtype=dt)
-        self._s = lib.RamRwSession.open(log_k, log_t, col(0, np.uint32), col(1, np.uint32), col(2, np.uint64), col(3, np.uint64), col(4, np.uint64),
-                                        inc, val_init, self.r_cycle)
+        if device_inc:  # zg_rwc_open_writes: inc formed on the device from the write entries (refused when a cycle holds two writes)
+            self._s = lib.RamRwSession.open_writes(log_k, log_t, col(0, np.uint32), col(1, np.uint32), col(2, np.uint64), col(3, np.uint64), col(4, np.uint64),
+                                                   col(5, np.uint8), val_init, self.r_cycle)
+        else:
+            self._s = lib.RamRwSession.open(log_k, log_t, col(0, np.uint32), col(1, np.uint32), col(2, np.uint64), col(3, np.uint64), col(4, np.uint64),
+                                            inc, val_init, self.r_cycle)
         self.eq_size = T
         self.gruen_eq = GruenSplitEqPolynomial(self.r_cycle)  # :354
         self.current_claim = fr_to_int(initial_claim)

@@ -62,6 +62,15 @@ __global__ void __launch_bounds__(256) rwc_init_kernel(const uint64_t *val_u64, 
     fe_store(val + 4 * (size_t)i, fr_from_u64_dev(val_u64[i]));
 }
 
+// inc of the written cycles from the entries themselves (zg_rwc_open_writes): F.fromU64(next) - F.fromU64(prev) where an entry is a write
+// (:283-291 forms the same difference from the larger of the two), the rest of the table zeroed beforehand
+__global__ void __launch_bounds__(256) rwc_inc_scatter_kernel(const uint32_t *cycle, const uint64_t *prev, const uint64_t *next, const uint8_t *is_write,
+                                                              uint32_t n, uint64_t *inc) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !is_write[i]) return;
+    fe_store(inc + 4 * (size_t)cycle[i], fe_sub(fr_from_u64_dev(next[i]), fr_from_u64_dev(prev[i])));
+}
+
 __device__ __forceinline__ void rwc_block_out(Fr (&acc)[2], uint4 *sh, uint64_t *partials) {
     block_sum_pair(acc[0], acc[1], sh);
     if (threadIdx.x == 0) {
@@ -460,10 +469,11 @@ static int rwc_upload_plan(zg_rwc_s *s) {
 
 extern "C" {
 
-int zg_rwc_open(size_t log_k, size_t log_t, size_t n, const uint32_t *cycle, const uint32_t *address, const uint64_t *val_coeff, const uint64_t *prev_val,
-                const uint64_t *next_val, const uint64_t *inc, const uint64_t *val_init, const uint64_t *r_cycle, zg_rwc_t *out) {
+// inc from the host (zg_rwc_open) or, with is_write, scattered on the device from the entries (zg_rwc_open_writes)
+static int rwc_open_impl(size_t log_k, size_t log_t, size_t n, const uint32_t *cycle, const uint32_t *address, const uint64_t *val_coeff, const uint64_t *prev_val,
+                         const uint64_t *next_val, const uint64_t *inc, const uint8_t *is_write, const uint64_t *val_init, const uint64_t *r_cycle, zg_rwc_t *out) {
     ZG_INIT();
-    if (!out || log_k > 24 || log_t > 26 || n > ((size_t)1 << 24) || !inc || !val_init || (log_t && !r_cycle) ||
+    if (!out || log_k > 24 || log_t > 26 || n > ((size_t)1 << 24) || (!inc && !is_write && n) || !val_init || (log_t && !r_cycle) ||
         (n && (!cycle || !address || !val_coeff || !prev_val || !next_val))) {
         set_error("zg_rwc_open: invalid argument (log_k <= 24, log_t <= 26, at most 2^24 entries)");
         return ZG_ERR_INVALID;
@@ -474,6 +484,16 @@ int zg_rwc_open(size_t log_k, size_t log_t, size_t n, const uint32_t *cycle, con
             set_error("zg_rwc_open: entries must lie inside the tables and be sorted by (cycle, address)");
             return ZG_ERR_INVALID;
         }
+    if (!inc) {  // the reference keeps the LAST write of a cycle in access order, which the sorted list no longer knows
+        uint32_t writes_in_cycle = 0;
+        for (size_t i = 0; i < n; i++) {
+            writes_in_cycle = (i && cycle[i] == cycle[i - 1] ? writes_in_cycle : 0) + (is_write[i] ? 1 : 0);
+            if (writes_in_cycle > 1) {
+                set_error("zg_rwc_open_writes: two writes in one cycle (pass inc with zg_rwc_open)");
+                return ZG_ERR_INVALID;
+            }
+        }
+    }
     zg_rwc_s *s = new zg_rwc_s();
     s->device = current_device();
     s->log_k = log_k;
@@ -509,8 +529,9 @@ int zg_rwc_open(size_t log_k, size_t log_t, size_t n, const uint32_t *cycle, con
         rwc_free(s);
         return e == hipErrorOutOfMemory ? ZG_ERR_NOMEM : ZG_ERR_HIP;
     }
-    Scratch s_val((size_t)s->cap * 8);
-    if (!s_val.p) {
+    const size_t n8 = (n + 7) & ~(size_t)7;
+    Scratch s_val((size_t)s->cap * 8), s_wr(inc ? 8 : n8 * 21 + 8);  // prev | next | cycle | is_write of the entries, for the scatter
+    if (!s_val.p || !s_wr.p) {
         rwc_free(s);
         return ZG_ERR_NOMEM;
     }
@@ -521,7 +542,22 @@ int zg_rwc_open(size_t log_k, size_t log_t, size_t n, const uint32_t *cycle, con
             hipLaunchKernelGGL(rwc_init_kernel, dim3(div_up(n, 256)), dim3(256), 0, s->st, s_val.as<uint64_t>(), (uint32_t)n, s->ra[0], s->val_c[0]);
             ZG_HIP(hipGetLastError());
         }
-        ZG_HIP(hipMemcpyAsync(s->inc[0], inc, T * 32, hipMemcpyHostToDevice, s->st));
+        if (inc) {
+            ZG_HIP(hipMemcpyAsync(s->inc[0], inc, T * 32, hipMemcpyHostToDevice, s->st));
+        } else {
+            ZG_HIP(hipMemsetAsync(s->inc[0], 0, T * 32, s->st));
+            if (n) {
+                uint64_t *d_prev = s_wr.as<uint64_t>(), *d_next = d_prev + n8;
+                uint32_t *d_cyc = reinterpret_cast<uint32_t *>(d_next + n8);
+                uint8_t *d_w = reinterpret_cast<uint8_t *>(d_cyc + n8);
+                ZG_HIP(hipMemcpyAsync(d_prev, prev_val, n * 8, hipMemcpyHostToDevice, s->st));
+                ZG_HIP(hipMemcpyAsync(d_next, next_val, n * 8, hipMemcpyHostToDevice, s->st));
+                ZG_HIP(hipMemcpyAsync(d_cyc, cycle, n * 4, hipMemcpyHostToDevice, s->st));
+                ZG_HIP(hipMemcpyAsync(d_w, is_write, n, hipMemcpyHostToDevice, s->st));
+                hipLaunchKernelGGL(rwc_inc_scatter_kernel, dim3(div_up(n, 256)), dim3(256), 0, s->st, d_cyc, d_prev, d_next, d_w, (uint32_t)n, s->inc[0]);
+                ZG_HIP(hipGetLastError());
+            }
+        }
         ZG_HIP(hipMemcpyAsync(s->val[0], val_init, K * 32, hipMemcpyHostToDevice, s->st));
         ZG_TRY(zg_fr_eq_table_dev(r_cycle, log_t, nullptr, s->eq[0], s->st));  // computeEqBigEndian (:345-348)
         ZG_HIP(hipStreamSynchronize(s->st));
@@ -537,6 +573,22 @@ int zg_rwc_open(size_t log_k, size_t log_t, size_t n, const uint32_t *cycle, con
     }
     *out = s;
     return ZG_OK;
+}
+int zg_rwc_open(size_t log_k, size_t log_t, size_t n, const uint32_t *cycle, const uint32_t *address, const uint64_t *val_coeff, const uint64_t *prev_val,
+                const uint64_t *next_val, const uint64_t *inc, const uint64_t *val_init, const uint64_t *r_cycle, zg_rwc_t *out) {
+    if (!inc) {
+        set_error("zg_rwc_open: invalid argument (inc)");
+        return ZG_ERR_INVALID;
+    }
+    return rwc_open_impl(log_k, log_t, n, cycle, address, val_coeff, prev_val, next_val, inc, nullptr, val_init, r_cycle, out);
+}
+int zg_rwc_open_writes(size_t log_k, size_t log_t, size_t n, const uint32_t *cycle, const uint32_t *address, const uint64_t *val_coeff, const uint64_t *prev_val,
+                       const uint64_t *next_val, const uint8_t *is_write, const uint64_t *val_init, const uint64_t *r_cycle, zg_rwc_t *out) {
+    if (n && !is_write) {
+        set_error("zg_rwc_open_writes: invalid argument (is_write)");
+        return ZG_ERR_INVALID;
+    }
+    return rwc_open_impl(log_k, log_t, n, cycle, address, val_coeff, prev_val, next_val, nullptr, is_write, val_init, r_cycle, out);
 }
 
 size_t zg_rwc_entries(zg_rwc_t s) { return s ? s->cycle.size() : 0; }

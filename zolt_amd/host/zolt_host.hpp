@@ -1829,33 +1829,48 @@ public:
                                const std::vector<std::pair<uint64_t, uint64_t>> &initial_ram = {})
         : current_claim(initial_claim), gamma_(gamma), log_k_(log_k), log_t_(log_t), p1_(phase1_num_rounds), gruen_(r_cycle) {
         const size_t K = size_t(1) << log_k, T = size_t(1) << log_t;
-        std::vector<Fr> inc(T, Fr::zero()), val_init(K, Fr::zero());
-        std::map<size_t, uint64_t> cur;
+        std::vector<Fr> val_init(K, Fr::zero());
+        std::vector<uint64_t> cur(K, 0);  // the reference's address -> value map (an absent address reads 0), flat: val_init is K elements already
         for (auto &kv : initial_ram)  // :212-231, :253-267
             if (kv.first >= start_address && (kv.first - start_address) / 8 < K) {
                 size_t idx = (kv.first - start_address) / 8;
                 val_init[idx] = Fr::fromU64(kv.second);
                 cur[idx] = kv.second;
             }
-        struct Raw { uint32_t cycle, address; uint64_t val, prev, next; };
+        struct Raw { uint32_t cycle, address; uint64_t val, prev, next; bool is_write; };
         std::vector<Raw> raw;
-        for (auto &a : accesses) {  // :269-330
+        raw.reserve(accesses.size());
+        for (auto &a : accesses) {  // :269-330; inc[timestamp] of a write = F(value) - F(prev) is formed on the device from these entries
             if (a.timestamp >= T || a.address < start_address || (a.address - start_address) / 8 >= K) continue;
             size_t idx = (a.address - start_address) / 8;
-            auto it = cur.find(idx);
-            uint64_t prev = it == cur.end() ? 0 : it->second;
-            if (a.is_write) {
-                inc[a.timestamp] = a.value >= prev ? Fr::fromU64(a.value - prev) : Fr::zero().sub(Fr::fromU64(prev - a.value));
-                cur[idx] = a.value;
-            }
-            raw.push_back(Raw{(uint32_t)a.timestamp, (uint32_t)idx, a.is_write ? prev : a.value, prev, a.value});
+            uint64_t prev = cur[idx];
+            if (a.is_write) cur[idx] = a.value;
+            raw.push_back(Raw{(uint32_t)a.timestamp, (uint32_t)idx, a.is_write ? prev : a.value, prev, a.value, a.is_write});
         }
-        std::stable_sort(raw.begin(), raw.end(), [](const Raw &x, const Raw &y) { return x.cycle != y.cycle ? x.cycle < y.cycle : x.address < y.address; });
+        // two writes in one cycle: the reference keeps the later one in ACCESS order, so inc is built here (before the sort) and handed over
+        std::vector<Fr> inc;
+        {
+            std::vector<uint32_t> wc;
+            for (auto &e : raw) if (e.is_write) wc.push_back(e.cycle);
+            if (!std::is_sorted(wc.begin(), wc.end())) std::sort(wc.begin(), wc.end());
+            if (std::adjacent_find(wc.begin(), wc.end()) != wc.end()) {
+                inc.assign(T, Fr::zero());
+                for (auto &e : raw)
+                    if (e.is_write) inc[e.cycle] = e.next >= e.prev ? Fr::fromU64(e.next - e.prev) : Fr::zero().sub(Fr::fromU64(e.prev - e.next));
+            }
+        }
+        auto by_cycle_then_address = [](const Raw &x, const Raw &y) { return x.cycle != y.cycle ? x.cycle < y.cycle : x.address < y.address; };
+        if (!std::is_sorted(raw.begin(), raw.end(), by_cycle_then_address)) std::stable_sort(raw.begin(), raw.end(), by_cycle_then_address);  // a trace arrives in order
         std::vector<uint32_t> cyc(raw.size()), adr(raw.size());
         std::vector<uint64_t> val(raw.size()), prev(raw.size()), next(raw.size());
-        for (size_t i = 0; i < raw.size(); i++) { cyc[i] = raw[i].cycle; adr[i] = raw[i].address; val[i] = raw[i].val; prev[i] = raw[i].prev; next[i] = raw[i].next; }
-        check(zg_rwc_open(log_k, log_t, raw.size(), cyc.data(), adr.data(), val.data(), prev.data(), next.data(), reinterpret_cast<const uint64_t *>(inc.data()),
-                          reinterpret_cast<const uint64_t *>(val_init.data()), reinterpret_cast<const uint64_t *>(r_cycle.data()), &s_), "zg_rwc_open");
+        std::vector<uint8_t> wr(raw.size());
+        for (size_t i = 0; i < raw.size(); i++) { cyc[i] = raw[i].cycle; adr[i] = raw[i].address; val[i] = raw[i].val; prev[i] = raw[i].prev; next[i] = raw[i].next; wr[i] = raw[i].is_write; }
+        if (inc.empty())
+            check(zg_rwc_open_writes(log_k, log_t, raw.size(), cyc.data(), adr.data(), val.data(), prev.data(), next.data(), wr.data(),
+                                     reinterpret_cast<const uint64_t *>(val_init.data()), reinterpret_cast<const uint64_t *>(r_cycle.data()), &s_), "zg_rwc_open_writes");
+        else
+            check(zg_rwc_open(log_k, log_t, raw.size(), cyc.data(), adr.data(), val.data(), prev.data(), next.data(), reinterpret_cast<const uint64_t *>(inc.data()),
+                              reinterpret_cast<const uint64_t *>(val_init.data()), reinterpret_cast<const uint64_t *>(r_cycle.data()), &s_), "zg_rwc_open");
         eq_size_ = T;
         const size_t m = r_cycle.size() / 2;
         try {  // the two prefix-table sets of the split-eq structure in HBM (table k starts at element 2^k - 1)

@@ -47,7 +47,7 @@ SYMBOLS = [
     "zg_psc_final", "zg_psc_close",
     "zg_rrw_open", "zg_rrw_open_trace", "zg_rrw_cycles", "zg_rrw_registers", "zg_rrw_round_cycle_gruen", "zg_rrw_set_eq", "zg_rrw_round_address", "zg_rrw_round_cycle",
     "zg_rrw_bind_cycle", "zg_rrw_bind_address", "zg_rrw_final", "zg_rrw_close",
-    "zg_rwc_open", "zg_rwc_entries", "zg_rwc_cycles", "zg_rwc_round_cycle", "zg_rwc_bind_cycle", "zg_rwc_round_address", "zg_rwc_bind_address",
+    "zg_rwc_open", "zg_rwc_open_writes", "zg_rwc_entries", "zg_rwc_cycles", "zg_rwc_round_cycle", "zg_rwc_bind_cycle", "zg_rwc_round_address", "zg_rwc_bind_address",
     "zg_rwc_opening", "zg_rwc_cycle_scalars", "zg_rwc_read_entries", "zg_rwc_close",
 ]
 # test / bench scaffolding of include/zolt_gpu_internal.h (not part of the drop-in boundary)
@@ -996,6 +996,20 @@ class RamRwSession:
         h = C.c_void_p()
         _chk(_lib.zg_rwc_open(C.c_size_t(log_k), C.c_size_t(log_t), C.c_size_t(n), _hb(cycle), _hb(address), _h(val_coeff), _h(prev_val), _h(next_val),
                               _h(inc), _h(val_init), _h(r_cycle), C.byref(h)), "zg_rwc_open")
+        return cls(h)
+
+    @classmethod
+    def open_writes(cls, log_k, log_t, cycle, address, val_coeff, prev_val, next_val, is_write, val_init, r_cycle):
+        """zg_rwc_open_writes: inc is formed on the device from the entries marked as writes"""
+        cycle, address, is_write = _c(cycle, np.uint32), _c(address, np.uint32), _c(is_write, np.uint8)
+        val_coeff, prev_val, next_val = _c(val_coeff), _c(prev_val), _c(next_val)
+        val_init, r_cycle = _c(val_init), _c(r_cycle)
+        n = cycle.size
+        assert address.size == val_coeff.size == prev_val.size == next_val.size == is_write.size == n
+        assert val_init.size == 4 << log_k and r_cycle.size == 4 * log_t
+        h = C.c_void_p()
+        _chk(_lib.zg_rwc_open_writes(C.c_size_t(log_k), C.c_size_t(log_t), C.c_size_t(n), _hb(cycle), _hb(address), _h(val_coeff), _h(prev_val),
+                                     _h(next_val), _hb(is_write), _h(val_init), _h(r_cycle), C.byref(h)), "zg_rwc_open_writes")
         return cls(h)
 
     def entries(self):
