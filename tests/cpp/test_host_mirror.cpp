@@ -523,7 +523,10 @@ TEST(stage_4_val_evaluation) {
         uint64_t z = 0xabc + trace_len;
         auto next = [&]() { z = z * 6364136223846793005ULL + 1442695040888963407ULL; return z >> 20; };
         for (size_t ts = 0; ts < trace_len; ts++)
-            if (next() % 3) acc.push_back(MemoryAccess{ts, start + 8 * (next() % (K + 2)), (next() & 1) != 0, next()});
+            if (next() % 3) {
+                acc.push_back(MemoryAccess{ts, start + 8 * (next() % (K + 2)), (next() & 1) != 0, next()});
+                if (next() % 5 == 0) acc.push_back(MemoryAccess{ts, start + 8 * (next() % K) + (next() % 3), true, next()});  // a second, unaligned write in the cycle: the later one stays
+            }
         std::vector<std::pair<uint64_t, uint64_t>> init = {{start + 8, 77}, {start + 8 * 3, 1234567}};
         Transcript ta("Jolt"), tb("Jolt");
         ta.appendBytes("stages 1-3"); tb.appendBytes("stages 1-3");

@@ -170,6 +170,33 @@ def test_standard_stage4_val_evaluation(trace_len, log_k, log_t):
     winc, wwa, wlt = ob.val_evaluation_tables(acc, init, trace_len, 1 << log_k, ra, rc, start)
     for x, y in ((inc, winc), (wa, wwa), (lt, wlt)):
         assert [ob.fr_to_int(v) for v in x] == y
+    # inc and wa scattered on the device from the list of writes (zg_fr_write_tables_dev, what the compiled host's proveStage4 calls): the
+    # list keeps the last write of a cycle; a second, unaligned write per few cycles is added to exercise exactly that
+    acc2 = []
+    for e in acc:
+        acc2.append(e)
+        if e[2] and e[0] % 3 == 0 and e[0] < trace_len:
+            acc2.append((e[0], start + 8 * (e[0] % (1 << log_k)) + 1, True, e[3] ^ 0x5A5A))
+    winc2, wwa2, _ = ob.val_evaluation_tables(acc2, init, trace_len, 1 << log_k, ra, rc, start)
+    n, k = len(winc2), 1 << log_k
+    last = {a: v for a, v in (init or {}).items() if a >= start and (a - start) // 8 < k}
+    slot, rows = {}, []
+    for ts, addr, is_write, value in acc2:
+        if not is_write or addr < start or (addr - start) // 8 >= k or ts >= trace_len:
+            continue
+        row = [ts, (addr - start) // 8, last.get(addr, 0), value]
+        if ts in slot:
+            rows[slot[ts]] = row
+        else:
+            slot[ts] = len(rows)
+            rows.append(row)
+        last[addr] = value
+    col = lambda i, dt: np.array([r[i] for r in rows], dtype=dt)
+    d = lib.DeviceBuffer(2 * n * 32)
+    lib.fr_write_tables_dev(n, col(0, np.uint32), col(1, np.uint32), col(2, np.uint64), col(3, np.uint64), np.array(want["r_address"])[::-1].copy(),
+                            d.ptr, d.ptr + n * 32)
+    both = d.to_host().view(np.uint64).reshape(2, n, 4)
+    assert [ob.fr_to_int(v) for v in both[0]] == winc2 and [ob.fr_to_int(v) for v in both[1]] == wwa2
 
 
 def test_expanding_table_restatement_on_the_references_vectors():

@@ -83,6 +83,7 @@ pub extern fn zg_fr_rows_affine(rows: ?[*]const u64, n_rows: usize, k: usize, st
 pub extern fn zg_fr_rows_affine_dev(d_rows: ?[*]const u64, n_rows: usize, k: usize, stride: usize, coeffs_host: ?[*]const u64, ntab: usize, g: usize, n_pad: usize, d_tables: ?[*]const ?[*]u64, stream: ?*anyopaque) c_int;
 pub extern fn zg_fr_lt_table(r: ?[*]const u64, v: usize, out: ?[*]u64) c_int;
 pub extern fn zg_fr_lt_table_dev(r_host: ?[*]const u64, v: usize, d_out: ?[*]u64, stream: ?*anyopaque) c_int;
+pub extern fn zg_fr_write_tables_dev(n: usize, m: usize, cycle: ?[*]const u32, word: ?[*]const u32, pre: ?[*]const u64, post: ?[*]const u64, r_eq: ?[*]const u64, log_k: usize, d_inc: ?[*]u64, d_wa: ?[*]u64, stream: ?*anyopaque) c_int;
 pub extern fn zg_fr_weighted_colsum(table: ?[*]const u64, rows: usize, cols: usize, weights: ?[*]const u64, m: usize, out: ?[*]u64) c_int;
 pub extern fn zg_fr_weighted_colsum_dev(d_table: ?[*]const u64, rows: usize, cols: usize, d_weights: ?[*]const u64, m: usize, d_out: ?[*]u64, stream: ?*anyopaque) c_int;
 pub extern fn zg_fr_rows_affine_prodsum_dev(d_rows: ?[*]const u64, n_rows: usize, k: usize, stride: usize, coeffs_host: ?[*]const u64, npairs: usize, d_weights: ?[*]const u64, g: usize, out: ?[*]u64, stream: ?*anyopaque) c_int;

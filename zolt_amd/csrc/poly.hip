@@ -1176,6 +1176,64 @@ int zg_fr_lt_table(const uint64_t *r, size_t v, uint64_t *out) {
     return rc;
 }
 
+// ValEvaluation's inc and wa from the list of writes (src/zkvm/ram/val_evaluation.zig:298-345 as the prover's stage 4 builds them,
+// prover.zig:760-800): inc[cycle] = F.fromU64(post) - F.fromU64(pre), wa[cycle] = eq(r_address, word), zero elsewhere
+__global__ void __launch_bounds__(256) write_tables_kernel(const uint32_t *cycle, const uint32_t *word, const uint64_t *pre, const uint64_t *post, uint32_t m,
+                                                           const uint64_t *eq, uint32_t eq_mask, uint64_t *inc, uint64_t *wa) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    F29 r2p;
+#pragma unroll
+    for (int k = 0; k < 9; k++) r2p.l[k] = Fr29::R2PRE[k];
+    Fr a = Fr::zero(), b = Fr::zero();
+    const uint64_t hi = post[i], lo = pre[i];
+    a.l[0] = (uint32_t)hi;
+    a.l[1] = (uint32_t)(hi >> 32);
+    b.l[0] = (uint32_t)lo;
+    b.l[1] = (uint32_t)(lo >> 32);
+    if (hi) a = fr_mul29(a, r2p);  // F.fromU64
+    if (lo) b = fr_mul29(b, r2p);
+    const size_t c = cycle[i];
+    fe_store(inc + 4 * c, fe_sub(a, b));
+    fe_store(wa + 4 * c, fe_load<FrParams>(eq + 4 * (size_t)(word[i] & eq_mask)));
+}
+
+int zg_fr_write_tables_dev(size_t n, size_t m, const uint32_t *cycle, const uint32_t *word, const uint64_t *pre, const uint64_t *post, const uint64_t *r_eq,
+                           size_t log_k, uint64_t *d_inc, uint64_t *d_wa, void *stream) {
+    ZG_INIT();
+    if (!d_inc || !d_wa || n == 0 || log_k > 26 || (log_k && !r_eq) || m > ((size_t)1 << 30) || (m && (!cycle || !word || !pre || !post))) {
+        set_error("zg_fr_write_tables_dev: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    for (size_t i = 0; i < m; i++)
+        if (cycle[i] >= n) {
+            set_error("zg_fr_write_tables_dev: a write beyond the tables");
+            return ZG_ERR_INVALID;
+        }
+    hipStream_t st = pick_stream(stream);
+    const size_t m8 = (m + 7) & ~(size_t)7, K = (size_t)1 << log_k;
+    Scratch s_eq(K * 32), s_w(m8 * 24 + 8);
+    if (!s_eq.p || !s_w.p) return ZG_ERR_NOMEM;
+    SyncGuard sync(st);
+    ZG_TRY(eq_table_enqueue(r_eq, log_k, nullptr, s_eq.as<uint64_t>(), st));
+    ZG_HIP(hipMemsetAsync(d_inc, 0, n * 32, st));
+    ZG_HIP(hipMemsetAsync(d_wa, 0, n * 32, st));
+    if (m) {
+        uint64_t *d_pre = s_w.as<uint64_t>(), *d_post = d_pre + m8;
+        uint32_t *d_cyc = reinterpret_cast<uint32_t *>(d_post + m8), *d_word = d_cyc + m8;
+        ZG_HIP(hipMemcpyAsync(d_pre, pre, m * 8, hipMemcpyHostToDevice, st));
+        ZG_HIP(hipMemcpyAsync(d_post, post, m * 8, hipMemcpyHostToDevice, st));
+        ZG_HIP(hipMemcpyAsync(d_cyc, cycle, m * 4, hipMemcpyHostToDevice, st));
+        ZG_HIP(hipMemcpyAsync(d_word, word, m * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(write_tables_kernel, dim3(div_up(m, 256)), dim3(256), 0, st, d_cyc, d_word, d_pre, d_post, (uint32_t)m, s_eq.as<uint64_t>(),
+                           (uint32_t)(K - 1), d_inc, d_wa);
+        ZG_HIP(hipGetLastError());
+    }
+    ZG_HIP(hipStreamSynchronize(st));  // the write list and the eq table are the caller's / scratch
+    sync.dismiss();
+    return ZG_OK;
+}
+
 int zg_fr_eq_prefix_tables_dev(const uint64_t *tau_host, size_t v, uint64_t *d_out, void *stream) {
     ZG_INIT();
     if (!d_out || (v && !tau_host)) {

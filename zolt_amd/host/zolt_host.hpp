@@ -18,6 +18,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <unordered_map>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -2016,6 +2017,40 @@ inline void valEvaluationIncWa(const std::vector<MemoryAccess> &accesses, const 
         wa[a.timestamp] = eq[((a.address - start_address) / 8) % eq.size()];
     }
 }
+// the same two tables as the list of their non-zero entries, for zg_fr_write_tables_dev: (cycle, word, old value, new value) per write; a
+// cycle written twice keeps its later write, as the loop above does by overwriting
+struct ValEvaluationWrites {
+    size_t n = 1;
+    std::vector<uint32_t> cycle, word;
+    std::vector<uint64_t> pre, post;
+};
+inline ValEvaluationWrites valEvaluationWrites(const std::vector<MemoryAccess> &accesses, const std::vector<std::pair<uint64_t, uint64_t>> &initial_ram,
+                                               size_t trace_len, size_t k, uint64_t start_address) {
+    ValEvaluationWrites w;
+    while (w.n < std::max<size_t>(trace_len, 1)) w.n <<= 1;
+    std::unordered_map<uint64_t, uint64_t> last;
+    last.reserve(initial_ram.size() + 1024);
+    for (auto &kv : initial_ram)
+        if (kv.first >= start_address && (kv.first - start_address) / 8 < k) last[kv.first] = kv.second;
+    std::vector<uint32_t> slot(w.n, ~0u);
+    for (const MemoryAccess &a : accesses) {
+        if (!a.is_write || a.address < start_address || (a.address - start_address) / 8 >= k || a.timestamp >= trace_len) continue;
+        uint64_t &cur = last[a.address];  // an address not seen before reads 0
+        uint32_t &sl = slot[a.timestamp];
+        if (sl == ~0u) {
+            sl = (uint32_t)w.cycle.size();
+            w.cycle.push_back((uint32_t)a.timestamp);
+            w.word.push_back(0);
+            w.pre.push_back(0);
+            w.post.push_back(0);
+        }
+        w.word[sl] = (uint32_t)((a.address - start_address) / 8);
+        w.pre[sl] = cur;
+        w.post[sl] = a.value;
+        cur = a.value;
+    }
+    return w;
+}
 inline ValEvaluationTables valEvaluationTables(const std::vector<MemoryAccess> &accesses, const std::vector<std::pair<uint64_t, uint64_t>> &initial_ram,
                                                size_t trace_len, size_t k, const std::vector<Fr> &r_address, const std::vector<Fr> &r_cycle, uint64_t start_address) {
     ValEvaluationTables t;
@@ -2040,13 +2075,16 @@ inline Stage4Result proveStage4(const std::vector<MemoryAccess> &accesses, const
     for (size_t i = 0; i < log_k; i++) out.r_address.push_back(transcript.challengeScalar("r_address"));
     for (size_t i = 0; i < log_t; i++) out.r_cycle.push_back(transcript.challengeScalar("r_cycle_val"));
     if (trace_len == 0) { out.skipped = true; return out; }
-    std::vector<Fr> inc, wa;
-    valEvaluationIncWa(accesses, initial_ram, trace_len, size_t(1) << log_k, out.r_address, start_address, inc, wa);
-    const size_t n = inc.size();
-    // the three tables go to HBM once: inc and wa uploaded, lt built there (when the cube of r_cycle is at least n entries; else tiled on the host)
+    // the three tables are built in HBM: inc and wa scattered from the list of writes (24 bytes per write cross the boundary), lt by its
+    // table kernel (when the cube of r_cycle is at least n entries; else tiled on the host)
+    ValEvaluationWrites w = valEvaluationWrites(accesses, initial_ram, trace_len, size_t(1) << log_k, start_address);
+    const size_t n = w.n;
     DeviceMem d(3 * n * 32);
-    check(zg_memcpy_h2d(d.p, inc.data(), n * 32), "zg_memcpy_h2d");
-    check(zg_memcpy_h2d(d.u64() + 4 * n, wa.data(), n * 32), "zg_memcpy_h2d");
+    {
+        std::vector<Fr> r_eq(out.r_address.rbegin(), out.r_address.rend());
+        check(zg_fr_write_tables_dev(n, w.cycle.size(), w.cycle.data(), w.word.data(), w.pre.data(), w.post.data(), reinterpret_cast<const uint64_t *>(r_eq.data()),
+                                     log_k, d.u64(), d.u64() + 4 * n, nullptr), "zg_fr_write_tables_dev");
+    }
     if ((size_t(1) << log_t) == n) {
         check(zg_fr_lt_table_dev(reinterpret_cast<const uint64_t *>(out.r_cycle.data()), log_t, d.u64() + 8 * n, nullptr), "zg_fr_lt_table_dev");
         check(zg_sync(), "zg_sync");

@@ -37,7 +37,7 @@ SYMBOLS = [
     "zg_msm_g1", "zg_msm_g1_dev", "zg_msm_g1_dev_async", "zg_msm_g1_batch", "zg_msm_g1_batch_dev", "zg_msm_g1_partial_dev", "zg_msm_g1_partial_fast_dev",
     "zg_g1_combine_partials_dev", "zg_g1_combine_partials_dev_async", "zg_g1_is_on_curve_batch", "zg_g1_scalar_mul_batch", "zg_g1_fixed_base_mul_batch",
     "zg_hyperkzg_open", "zg_hyperkzg_open_dev", "zg_hyperkzg_batch_open",
-    "zg_fr_dense_evaluate", "zg_fr_eq_table", "zg_fr_eq_table_dev", "zg_fr_eq_prefix_tables", "zg_fr_eq_prefix_tables_dev", "zg_fr_rows_mle", "zg_fr_rows_mle_dev", "zg_fr_rows_affine", "zg_fr_rows_affine_dev", "zg_fr_rows_affine_prodsum_dev", "zg_fr_weighted_colsum", "zg_fr_weighted_colsum_dev", "zg_fr_lt_table", "zg_fr_lt_table_dev", "zg_fr_eq_plus_one_table", "zg_fr_eq_plus_one_table_dev", "zg_fr_bind_low", "zg_fr_bind_high",
+    "zg_fr_dense_evaluate", "zg_fr_eq_table", "zg_fr_eq_table_dev", "zg_fr_eq_prefix_tables", "zg_fr_eq_prefix_tables_dev", "zg_fr_rows_mle", "zg_fr_rows_mle_dev", "zg_fr_rows_affine", "zg_fr_rows_affine_dev", "zg_fr_rows_affine_prodsum_dev", "zg_fr_weighted_colsum", "zg_fr_weighted_colsum_dev", "zg_fr_lt_table", "zg_fr_lt_table_dev", "zg_fr_write_tables_dev", "zg_fr_eq_plus_one_table", "zg_fr_eq_plus_one_table_dev", "zg_fr_bind_low", "zg_fr_bind_high",
     "zg_fr_spartan_combine", "zg_fr_spartan_combine_dev",
     "zg_sumcheck_open", "zg_sumcheck_open_dev", "zg_sumcheck_round_sums", "zg_sumcheck_bind",
     "zg_sumcheck_len", "zg_sumcheck_final", "zg_sumcheck_read", "zg_sumcheck_gather", "zg_sumcheck_close",
@@ -586,6 +586,17 @@ def fr_lt_table(r):
 def fr_lt_table_dev(r, d_out, stream=0):
     r = _c(np.asarray(r, dtype=np.uint64).reshape(-1, 4))
     _chk(_lib.zg_fr_lt_table_dev(_h(r), C.c_size_t(r.shape[0]), _d(d_out), _d(stream)), "zg_fr_lt_table_dev")
+
+
+def fr_write_tables_dev(n, cycle, word, pre, post, r_eq, d_inc, d_wa, stream=0):
+    """ValEvaluation's inc / wa (n entries each, device) from the list of writes (zg_fr_write_tables_dev): inc[cycle] = F(post) - F(pre),
+    wa[cycle] = eq(r_eq, word); r_eq (log_k, 4) in EqPolynomial order"""
+    cycle, word, pre, post = _c(cycle, np.uint32), _c(word, np.uint32), _c(pre), _c(post)
+    r_eq = _c(np.asarray(r_eq, dtype=np.uint64).reshape(-1, 4))
+    m = cycle.size
+    assert word.size == pre.size == post.size == m
+    _chk(_lib.zg_fr_write_tables_dev(C.c_size_t(n), C.c_size_t(m), _hb(cycle), _hb(word), _h(pre), _h(post), _h(r_eq) if r_eq.size else None,
+                                     C.c_size_t(r_eq.shape[0]), _d(d_inc), _d(d_wa), _d(stream)), "zg_fr_write_tables_dev")
 
 
 def fr_weighted_colsum(table, rows, cols, weights):
