@@ -369,7 +369,9 @@ ZG_API int zg_run_sumcheck(const uint64_t *evals, size_t len, uint64_t claim[4],
 typedef struct zg_psc_s *zg_psc_t;
 ZG_API int zg_psc_open(const uint64_t *const *tables /* k host pointers, len*4 words each */, size_t k, size_t len, zg_psc_t *s);
 ZG_API int zg_psc_open_dev(const uint64_t *const *d_tables /* host array of k device pointers */, size_t k, size_t len, void *stream,
-                    zg_psc_t *s); /* copies */
+                    zg_psc_t *s); /* copies. stream = NULL: the session runs on its own stream; the copies follow the work already on the
+                                   * library stream (the *_dev builders' default) and are complete on return. Otherwise the session
+                                   * lives on `stream` and the copies are only enqueued there. */
 ZG_API size_t zg_psc_len(zg_psc_t s);
 ZG_API size_t zg_psc_tables(zg_psc_t s);
 /* out[t] (t = 0..3, 4 words each) = sum over the pairs g of  prod_{j<p} T[prod_idx[j]](t) * L(t), where T(t) = T[2g] + t (T[2g+1] - T[2g])

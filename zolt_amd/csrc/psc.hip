@@ -763,15 +763,27 @@ int zg_psc_open_dev(const uint64_t *const *d_tables, size_t k, size_t len, void 
             return ZG_ERR_INVALID;
         }
     zg_psc_s *s = nullptr;
-    ZG_TRY(psc_create(k, len, pick_stream(stream), &s));
-    for (size_t j = 0; j < k; j++) {
-        hipError_t e = hipMemcpyAsync(s->buf[0] + 4 * j * s->cap, d_tables[j], len * 32, hipMemcpyDeviceToDevice, s->st);
-        if (e != hipSuccess) {
-            (void)hipStreamSynchronize(s->st);
-            set_error(hipGetErrorString(e));
-            psc_free(s);
-            return ZG_ERR_HIP;
-        }
+    // stream == NULL: the session works on its OWN pooled stream (sessions of one prover overlap instead of queueing on the library
+    // stream); the copies are ordered after what the library stream holds — where the *_dev table builders put their work by default —
+    // and have completed on return, so the caller may release or overwrite the sources at once
+    hipStream_t caller = reinterpret_cast<hipStream_t>(stream);
+    ZG_TRY(psc_create(k, len, caller, &s));
+    hipError_t e = hipSuccess;
+    if (!caller) {
+        hipEvent_t ev = nullptr;
+        e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventRecord(ev, lib_stream());
+        if (e == hipSuccess) e = hipStreamWaitEvent(s->st, ev, 0);
+        if (ev) (void)hipEventDestroy(ev);
+    }
+    for (size_t j = 0; j < k && e == hipSuccess; j++)
+        e = hipMemcpyAsync(s->buf[0] + 4 * j * s->cap, d_tables[j], len * 32, hipMemcpyDeviceToDevice, s->st);
+    if (e == hipSuccess && !caller) e = hipStreamSynchronize(s->st);
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(s->st);
+        set_error(hipGetErrorString(e));
+        psc_free(s);
+        return ZG_ERR_HIP;
     }
     *out = s;
     return ZG_OK;

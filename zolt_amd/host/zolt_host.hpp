@@ -1560,9 +1560,13 @@ inline Fr evaluateMle(std::vector<Fr> t, const std::vector<Fr> &point) {  // :18
 }
 inline std::vector<Fr> readTable(ProductSumcheckSession &s, size_t table) { return s.read(table); }
 inline std::array<Fr, 4> evalsToCoeffs(const std::vector<Fr> &ev) {  // :846-901, degree 2 (three evaluations) or 3 (four)
-    Fr two_inv, six_inv;
-    Fr::fromU64(2).inverse(two_inv);
-    Fr::fromU64(6).inverse(six_inv);
+    static const std::array<Fr, 2> inv = [] {  // 1/2 and 1/6, once: an inversion costs more than the rest of a round's host algebra
+        std::array<Fr, 2> r;
+        Fr::fromU64(2).inverse(r[0]);
+        Fr::fromU64(6).inverse(r[1]);
+        return r;
+    }();
+    const Fr &two_inv = inv[0], &six_inv = inv[1];
     if (ev.size() == 3) {
         Fr c2 = ev[2].sub(ev[1].add(ev[1])).add(ev[0]).mul(two_inv);
         return {ev[0], ev[1].sub(ev[0]).sub(c2), c2, Fr::zero()};
@@ -2552,9 +2556,13 @@ public:
     }
     std::array<Fr, 4> computeRoundPolynomial(size_t round, const Fr &current_claim) {  // :731-758 -> c0..c3
         auto e = computeRoundEvals(round, current_claim);
-        Fr six_inv, two_inv;
-        Fr::fromU64(6).inverse(six_inv);
-        Fr::fromU64(2).inverse(two_inv);
+        static const std::array<Fr, 2> inv = [] {  // 1/6 and 1/2, once
+            std::array<Fr, 2> r;
+            Fr::fromU64(6).inverse(r[0]);
+            Fr::fromU64(2).inverse(r[1]);
+            return r;
+        }();
+        const Fr &six_inv = inv[0], &two_inv = inv[1];
         Fr three = Fr::fromU64(3);
         Fr c3 = Fr::zero().sub(e[0]).add(e[1].mul(three)).sub(e[2].mul(three)).add(e[3]).mul(six_inv);
         Fr c2 = e[0].mul(Fr::fromU64(2)).sub(e[1].mul(Fr::fromU64(5))).add(e[2].mul(Fr::fromU64(4))).sub(e[3]).mul(two_inv);
