@@ -408,6 +408,10 @@ ZG_API int zg_psc_round_gruen(zg_psc_t s, const int *prod_idx, size_t p, const u
 /* every table folded: T'[i] = (1 - r) T[2i] + r T[2i+1]; len -> len / 2 (val_evaluation.zig:609-628) */
 ZG_API int zg_psc_bind(zg_psc_t s, const uint64_t r[4]);
 ZG_API int zg_psc_read(zg_psc_t s, size_t table, uint64_t *out /* len*4 */);
+/* the table where it lies in HBM (zg_psc_len(s) * 4 words), after the session's pending folds have completed: valid until the next
+ * bind / close of this session. For handing folded tables to another session or kernel without a host round trip (Stage 3's phase
+ * transitions, src/zkvm/spartan/stage3_prover.zig:1506-1700, 2427-2466, re-open their provers over the folded witness columns). */
+ZG_API int zg_psc_table_dev(zg_psc_t s, size_t table, const uint64_t **d_ptr);
 /* out[i] = T[table][idx[i]], i < n: the inc values of the row pairs a sparse prover's entries touch (read_write_checking.zig:431-446) */
 ZG_API int zg_psc_gather(zg_psc_t s, size_t table, const uint64_t *idx, size_t n, uint64_t *out /* n*4 */);
 ZG_API int zg_psc_final(zg_psc_t s, uint64_t *out /* k*4: each table's single remaining entry */);

@@ -440,6 +440,39 @@ def test_batched_sumcheck_stage2_shape(env, mode):
         assert np.array_equal(fg(), fo())
 
 
+def test_folded_tables_handed_to_another_session_inside_hbm(env):
+    """zg_psc_table_dev + zg_psc_open_dev (stream NULL: own stream, copies complete on return) — how Stage 3's phase transitions re-open
+    their provers over the folded witness columns: after a few binds the tables of one session become (in another order, beside a
+    fresh one) the tables of a second, which then folds on by itself; the first may be closed at once"""
+    api, lib, ob = env
+    n, k = 512, 4
+    tabs = [_rand(ob, 8700 + j, n) for j in range(k)]
+    a = lib.ProductSumcheckSession.open(tabs)
+    cur = [t.copy() for t in tabs]
+    a.round_evals((0, 1))  # with a spec cached, the binds below are the fused fold + next-sums launches
+    for i in range(3):
+        r = _rand(ob, 8720 + i, 1)[0]
+        a.bind(r)
+        cur = [ob.fr_bind_low(t, r) for t in cur]
+    m = len(a)
+    fresh = _rand(ob, 8730, m)
+    d_fresh = lib.DeviceBuffer.from_host(fresh)
+    b = lib.ProductSumcheckSession.open_dev([d_fresh.ptr, a.table_dev(3), a.table_dev(1), a.table_dev(0)], m)
+    a.close()
+    d_fresh.free()
+    now = [fresh, cur[3], cur[1], cur[0]]
+    for j in range(4):
+        assert np.array_equal(b.read(j), now[j]), j
+    while len(b) > 1:
+        want = ob.ValEvaluationProver(now[0], now[1], now[2], now[0][0]).computeRoundPolynomial()
+        assert np.array_equal(b.round_evals((0, 1, 2)), want), len(b)
+        r = _rand(ob, 8740 + len(b), 1)[0]
+        b.bind(r)
+        now = [ob.fr_bind_low(t, r) for t in now]
+    assert np.array_equal(b.final(), np.stack([t[0] for t in now]))
+    b.close()
+
+
 def test_pooled_sessions_serve_smaller_shapes(env):
     """a closed session is kept and reused for a later one with fewer tables / a shorter length (its buffers keep their stride): the
     reused session must behave like a fresh one through evaluations, folds and finals"""

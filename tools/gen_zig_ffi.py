@@ -55,6 +55,8 @@ def zig_type(ctype, array):
     el = SCALARS[base]
     if stars == 0:
         return el
+    if stars == 2 and const and "*const*" not in t.replace(" ", ""):
+        return f"*?[*]const {el}"  # out-parameter receiving a device address (const T **)
     if stars == 2:  # array of pointers to arrays (scalar batches; output tables when the pointed-to elements are not const)
         return f"?[*]const ?[*]const {el}" if const else f"?[*]const ?[*]{el}"
     if base in ("int", "size_t") and not const:

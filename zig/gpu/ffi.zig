@@ -120,6 +120,7 @@ pub extern fn zg_psc_set_points(s: ProductSession, points: c_uint) c_int;
 pub extern fn zg_psc_round_gruen(s: ProductSession, prod_idx: ?[*]const c_int, p: usize, d_e_out: ?[*]const u64, n_out: usize, d_e_in: ?[*]const u64, n_in: usize, t0: *[4]u64, t_inf: *[4]u64) c_int;
 pub extern fn zg_psc_bind(s: ProductSession, r: *const [4]u64) c_int;
 pub extern fn zg_psc_read(s: ProductSession, table: usize, out: ?[*]u64) c_int;
+pub extern fn zg_psc_table_dev(s: ProductSession, table: usize, d_ptr: *?[*]const u64) c_int;
 pub extern fn zg_psc_gather(s: ProductSession, table: usize, idx: ?[*]const u64, n: usize, out: ?[*]u64) c_int;
 pub extern fn zg_psc_final(s: ProductSession, out: ?[*]u64) c_int;
 pub extern fn zg_psc_close(s: ProductSession) c_int;

@@ -1001,6 +1001,19 @@ int zg_psc_read(zg_psc_t s, size_t table, uint64_t *out) {
     return ZG_OK;
 }
 
+int zg_psc_table_dev(zg_psc_t s, size_t table, const uint64_t **d_ptr) {
+    ZG_INIT();
+    if (!s || !d_ptr || table >= s->k) {
+        set_error("zg_psc_table_dev: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    DeviceGuard dg(s->device);
+    std::lock_guard<std::mutex> lk(s->mu);
+    ZG_HIP(hipStreamSynchronize(s->st));  // the folds enqueued so far have landed: any stream may read the table now
+    *d_ptr = s->buf[s->cur] + 4 * table * s->stride();
+    return ZG_OK;
+}
+
 int zg_psc_gather(zg_psc_t s, size_t table, const uint64_t *idx, size_t n, uint64_t *out) {
     ZG_INIT();
     if (!s || table >= s->k || (n && (!idx || !out))) {

@@ -1072,6 +1072,11 @@ public:
         check(zg_psc_gather(s_, table, idx.data(), idx.size(), reinterpret_cast<uint64_t *>(out.data())), "zg_psc_gather");
         return out;
     }
+    const uint64_t *tableDev(size_t table) {  // where the folded table lies in HBM, pending folds completed (zg_psc_table_dev)
+        const uint64_t *p = nullptr;
+        check(zg_psc_table_dev(s_, table, &p), "zg_psc_table_dev");
+        return p;
+    }
     std::vector<Fr> final() {
         std::vector<Fr> out(zg_psc_tables(s_));
         check(zg_psc_final(s_, reinterpret_cast<uint64_t *>(out.data())), "zg_psc_final");
@@ -1629,18 +1634,22 @@ public:
         challenges_.push_back(r_j);
         prefix_size_ /= 2;
         if (!transition) return;
-        std::vector<std::vector<Fr>> tabs;  // transitionToPhase2 (:1506-1700)
+        // transitionToPhase2 (:1506-1700). The prefix tables evaluated at the phase-1 challenges are what the round session's P tables
+        // have been folded down to (the same LowToHigh steps as stage3::evaluateMle), so they are read from it; the witness columns,
+        // folded on the device since round 0, go to the new session inside HBM
+        const std::vector<Fr> f = rounds_->final();
+        const size_t S = suffix_0_[0].size();
+        std::vector<Fr> t(2 * S);
         for (size_t k = 0; k < 2; k++) {
-            Fr e0 = stage3::evaluateMle(prefix_0_[k], challenges_), e1 = stage3::evaluateMle(prefix_1_[k], challenges_);
-            std::vector<Fr> t(suffix_0_[k].size());
-            for (size_t j = 0; j < t.size(); j++) t[j] = e0.mul(suffix_0_[k][j]).add(e1.mul(suffix_1_[k][j]));
-            tabs.push_back(std::move(t));
+            const Fr &e0 = f[4 * k], &e1 = f[4 * k + 2];
+            for (size_t j = 0; j < S; j++) t[k * S + j] = e0.mul(suffix_0_[k][j]).add(e1.mul(suffix_1_[k][j]));
         }
-        for (size_t c = 0; c < 5; c++) tabs.push_back(stage3::readTable(*wit_, c));  // folded on the device since round 0
+        DeviceMem d_t(2 * S * 32);
+        check(zg_memcpy_h2d(d_t.p, t.data(), 2 * S * 32), "zg_memcpy_h2d");
+        std::vector<const uint64_t *> ptrs = {d_t.u64(), d_t.u64() + 4 * S};
+        for (size_t c = 0; c < 5; c++) ptrs.push_back(wit_->tableDev(c));
+        rounds_.reset(new ProductSumcheckSession(ProductSumcheckSession::OnDevice{}, ptrs, S));  // the copies are complete on return
         wit_.reset();
-        std::vector<const std::vector<Fr> *> tp;
-        for (auto &t : tabs) tp.push_back(&t);
-        rounds_.reset(new ProductSumcheckSession(tp));
         rounds_->setPoints(0b0101);
         in_phase2_ = true;
     }
@@ -1692,13 +1701,14 @@ public:
         if (!transition) return;
         std::vector<Fr> rev(challenges_.rbegin(), challenges_.rend());  // :2427-2466
         Fr e = EqPolynomial::mle(r_lo_, rev);
-        std::vector<std::vector<Fr>> tabs = {EqPolynomial(r_hi_).evals()};
-        for (Fr &x : tabs[0]) x = x.mul(e);
-        for (size_t c = 0; c < 3; c++) tabs.push_back(stage3::readTable(*wit_, c));
+        std::vector<Fr> eq_hi = EqPolynomial(r_hi_).evals();
+        for (Fr &x : eq_hi) x = x.mul(e);
+        DeviceMem d_eq(eq_hi.size() * 32);
+        check(zg_memcpy_h2d(d_eq.p, eq_hi.data(), eq_hi.size() * 32), "zg_memcpy_h2d");
+        std::vector<const uint64_t *> ptrs = {d_eq.u64()};
+        for (size_t c = 0; c < 3; c++) ptrs.push_back(wit_->tableDev(c));  // folded on the device since round 0: handed over inside HBM
+        rounds_.reset(new ProductSumcheckSession(ProductSumcheckSession::OnDevice{}, ptrs, eq_hi.size()));  // the copies are complete on return
         wit_.reset();
-        std::vector<const std::vector<Fr> *> tp;
-        for (auto &t : tabs) tp.push_back(&t);
-        rounds_.reset(new ProductSumcheckSession(tp));
         rounds_->setPoints(0b0101);
         in_phase2_ = true;
     }

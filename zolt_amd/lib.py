@@ -43,7 +43,7 @@ SYMBOLS = [
     "zg_sumcheck_len", "zg_sumcheck_final", "zg_sumcheck_read", "zg_sumcheck_gather", "zg_sumcheck_close",
     "zg_sumcheck_round_sums_dev", "zg_sumcheck_read_dev", "zg_sumcheck_raf_round", "zg_sumcheck_bit_round", "zg_sumcheck_bit_bind", "zg_fr_bit_split_sums", "zg_fr_bit_split_sums_dev",
     "zg_run_sumcheck", "zg_run_sumcheck_dev", "zg_sumcheck_open_spartan_dev",
-    "zg_psc_open", "zg_psc_open_dev", "zg_psc_len", "zg_psc_tables", "zg_psc_round_evals", "zg_psc_round_expr", "zg_psc_set_points", "zg_psc_round_gruen", "zg_psc_bind", "zg_psc_read", "zg_psc_gather",
+    "zg_psc_open", "zg_psc_open_dev", "zg_psc_len", "zg_psc_tables", "zg_psc_round_evals", "zg_psc_round_expr", "zg_psc_set_points", "zg_psc_round_gruen", "zg_psc_bind", "zg_psc_read", "zg_psc_table_dev", "zg_psc_gather",
     "zg_psc_final", "zg_psc_close",
     "zg_rrw_open", "zg_rrw_open_trace", "zg_rrw_cycles", "zg_rrw_registers", "zg_rrw_round_cycle_gruen", "zg_rrw_set_eq", "zg_rrw_round_address", "zg_rrw_round_cycle",
     "zg_rrw_bind_cycle", "zg_rrw_bind_address", "zg_rrw_final", "zg_rrw_close",
@@ -824,6 +824,12 @@ class ProductSumcheckSession:
         h = C.c_void_p()
         _chk(_lib.zg_psc_open(ptrs, C.c_size_t(len(tabs)), C.c_size_t(n), C.byref(h)), "zg_psc_open")
         return cls(h)
+
+    def table_dev(self, table):
+        """device address of a table's current entries (zg_psc_table_dev): valid until the next bind / close"""
+        p = C.c_void_p()
+        _chk(_lib.zg_psc_table_dev(self._h, C.c_size_t(table), C.byref(p)), "zg_psc_table_dev")
+        return p.value
 
     @classmethod
     def open_dev(cls, d_tables, n, stream=0):
