@@ -255,7 +255,8 @@ ZG_API int zg_fr_lt_table_dev(const uint64_t *r_host, size_t v, uint64_t *d_out,
 /* ValEvaluation's other two tables from the LIST OF WRITES (the prover's stage 4, src/zkvm/prover.zig:760-800 over
  * ram/val_evaluation.zig:298-345): d_inc[cycle[i]] = F.fromU64(post[i]) - F.fromU64(pre[i]) and d_wa[cycle[i]] = eq(r_eq, word[i] mod 2^log_k)
  * for the m writes, zero elsewhere (n entries each, DEVICE). r_eq is the point in EqPolynomial order (the reference passes r_address
- * reversed). The cycles must be distinct (the caller keeps the last write of a cycle, as the reference's loop does by overwriting).
+ * reversed). The cycles must be distinct — a repeated or out-of-range cycle is refused (ZG_ERR_INVALID); the caller keeps the last write of a
+ * cycle, as the reference's loop does by overwriting.
  * Returns after the work has completed: 24 bytes per write cross the boundary instead of two n-element tables. */
 ZG_API int zg_fr_write_tables_dev(size_t n, size_t m, const uint32_t *cycle, const uint32_t *word, const uint64_t *pre, const uint64_t *post,
                            const uint64_t *r_eq, size_t log_k, uint64_t *d_inc, uint64_t *d_wa, void *stream);

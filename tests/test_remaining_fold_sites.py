@@ -197,6 +197,12 @@ def test_standard_stage4_val_evaluation(trace_len, log_k, log_t):
                             d.ptr, d.ptr + n * 32)
     both = d.to_host().view(np.uint64).reshape(2, n, 4)
     assert [ob.fr_to_int(v) for v in both[0]] == winc2 and [ob.fr_to_int(v) for v in both[1]] == wwa2
+    if len(rows) >= 1:  # a list that names a cycle twice, or a cycle beyond the tables, is refused (the scatter would race / overrun)
+        for bad in (np.array([rows[0][0], rows[0][0]], dtype=np.uint32), np.array([n], dtype=np.uint32)):
+            z32, z64 = np.zeros(len(bad), dtype=np.uint32), np.zeros(len(bad), dtype=np.uint64)
+            with pytest.raises(lib.ZgError):
+                lib.fr_write_tables_dev(n, bad, z32, z64, z64, np.array(want["r_address"])[::-1].copy(), d.ptr, d.ptr + n * 32)
+    d.free()
 
 
 def test_expanding_table_restatement_on_the_references_vectors():

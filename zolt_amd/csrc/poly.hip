@@ -1205,11 +1205,16 @@ int zg_fr_write_tables_dev(size_t n, size_t m, const uint32_t *cycle, const uint
         set_error("zg_fr_write_tables_dev: invalid argument");
         return ZG_ERR_INVALID;
     }
-    for (size_t i = 0; i < m; i++)
-        if (cycle[i] >= n) {
-            set_error("zg_fr_write_tables_dev: a write beyond the tables");
-            return ZG_ERR_INVALID;
+    {
+        std::vector<bool> seen(n, false);  // two writes to one cycle would race in the scatter: the caller keeps the later one
+        for (size_t i = 0; i < m; i++) {
+            if (cycle[i] >= n || seen[cycle[i]]) {
+                set_error(cycle[i] >= n ? "zg_fr_write_tables_dev: a write beyond the tables" : "zg_fr_write_tables_dev: two writes in one cycle");
+                return ZG_ERR_INVALID;
+            }
+            seen[cycle[i]] = true;
         }
+    }
     hipStream_t st = pick_stream(stream);
     const size_t m8 = (m + 7) & ~(size_t)7, K = (size_t)1 << log_k;
     Scratch s_eq(K * 32), s_w(m8 * 24 + 8);
