@@ -1537,12 +1537,30 @@ __global__ void __launch_bounds__(256) weighted_colsum_kernel(const uint64_t *ta
     for (int k = 0; k < COLSUM_MAX_W; k++)
         if (k < m) fe_store(partials + 4 * (((size_t)blockIdx.y * m + k) * cols + c), acc[k]);
 }
+// sixteen outputs per workgroup, sixteen lanes per output (each takes every sixteenth slab), a tree over the sixteen in LDS: one thread
+// per output walking all <= 256 slabs was a 97 us chain of dependent loads for a 2048-entry result (rocprofv3, Stage 3's Q tables)
+constexpr int COLSUM_FIN_OUT = 16;
 __global__ void __launch_bounds__(256) colsum_finish_kernel(const uint64_t *partials, size_t slabs, size_t n /* m * cols */, uint64_t *out) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    Fr acc = fe_load<FrParams>(partials + 4 * i);
-    for (size_t s = 1; s < slabs; s++) acc = fe_add(acc, fe_load<FrParams>(partials + 4 * (s * n + i)));
-    fe_store(out + 4 * i, acc);
+    __shared__ uint32_t sh[256][8];
+    const uint32_t li = threadIdx.x % COLSUM_FIN_OUT, q = threadIdx.x / COLSUM_FIN_OUT;
+    const size_t i = (size_t)blockIdx.x * COLSUM_FIN_OUT + li;
+    Fr acc = Fr::zero();
+    if (i < n)
+        for (size_t s = q; s < slabs; s += 256 / COLSUM_FIN_OUT) acc = fe_add(acc, fe_load<FrParams>(partials + 4 * (s * n + i)));
+    for (uint32_t half = 256 / COLSUM_FIN_OUT / 2; half >= 1; half >>= 1) {
+        if (q >= half && q < 2 * half)
+#pragma unroll
+            for (int w = 0; w < 8; w++) sh[threadIdx.x][w] = acc.l[w];
+        __syncthreads();
+        if (q < half) {
+            Fr other;
+#pragma unroll
+            for (int w = 0; w < 8; w++) other.l[w] = sh[threadIdx.x + half * COLSUM_FIN_OUT][w];
+            acc = fe_add(acc, other);
+        }
+        __syncthreads();
+    }
+    if (q == 0 && i < n) fe_store(out + 4 * i, acc);
 }
 
 int zg_fr_weighted_colsum_dev(const uint64_t *d_table, size_t rows, size_t cols, const uint64_t *d_weights, size_t m, uint64_t *d_out, void *stream) {
@@ -1568,7 +1586,7 @@ int zg_fr_weighted_colsum_dev(const uint64_t *d_table, size_t rows, size_t cols,
     if (!part.p) return ZG_ERR_NOMEM;
     hipLaunchKernelGGL(weighted_colsum_kernel, dim3((unsigned)col_blocks, (unsigned)slabs), dim3(256), 0, st, d_table, rows, cols, d_weights, (int)m, per,
                        part.as<uint64_t>());
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)div_up(m * cols, 256)), dim3(256), 0, st, part.as<uint64_t>(), slabs, m * cols, d_out);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)div_up(m * cols, COLSUM_FIN_OUT)), dim3(256), 0, st, part.as<uint64_t>(), slabs, m * cols, d_out);
     ZG_HIP(hipGetLastError());
     ZG_HIP(hipStreamSynchronize(st));  // the scratch partials go back to the cache with this call
     return ZG_OK;
