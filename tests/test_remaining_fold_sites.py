@@ -260,7 +260,7 @@ def test_c_restatements_of_the_lt_table_and_the_column_sums():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("v", [0, 1, 5, 12, 16])
+@pytest.mark.parametrize("v", [0, 1, 5, 11, 12, 13, 16, 17])  # 12 and above: the factored form (hi / lo factor tables, one product per entry)
 def test_lt_table_and_column_sums_against_the_c_restatement(v):
     ob = _ob()
     from zolt_amd import lib

@@ -1113,24 +1113,39 @@ int zg_fr_eq_plus_one_table(const uint64_t *r, size_t v, uint64_t *out) {
 struct LtArgs {
     FrArg r[30];
 };
-__global__ void __launch_bounds__(256) lt_table_kernel(LtArgs a, int v, size_t n, uint64_t *out) {
+// variables [lo, hi) of the point, index bit (i - lo) <-> r[i]: lt_out[j] = sum over the zero bits i of j of r_i * prod_{k > i} eq(r_k, j_k),
+// eq_out[j] (optional) = prod over all the range's bits of eq(r_k, j_k)
+__global__ void __launch_bounds__(256) lt_table_kernel(LtArgs a, int lo, int hi, size_t n, uint64_t *lt_out, uint64_t *eq_out) {
     size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
         Fr suffix = Fr::one(), result = Fr::zero();
-        for (int i = v - 1; i >= 0; i--) {
+        for (int i = hi - 1; i >= lo; i--) {
             Fr ri;
 #pragma unroll
             for (int l = 0; l < 8; l++) ri.l[l] = a.r[i].l[l];
-            if ((j >> i) & 1) {
+            if ((j >> (i - lo)) & 1) {
                 suffix = fr_mul29v(suffix, ri);
             } else {
                 result = fe_add(result, fr_mul29v(ri, suffix));
                 suffix = fr_mul29v(suffix, fe_sub(Fr::one(), ri));
             }
         }
-        fe_store(out + 4 * j, result);
+        fe_store(lt_out + 4 * j, result);
+        if (eq_out) fe_store(eq_out + 4 * j, suffix);
     }
 }
+// lt(j) = lt_hi(j_hi) + eq_hi(j_hi) * lt_lo(j_lo): one product per entry over three 2^(v/2)-entry factor tables (the direct form above
+// is ~2v products per entry: 0.42 ms for 2^20 entries in the trace of the standard Stage 4)
+__global__ void __launch_bounds__(256) lt_combine_kernel(const uint64_t *lt_hi, const uint64_t *eq_hi, const uint64_t *lt_lo, int h, size_t n, uint64_t *out) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t mask = ((size_t)1 << h) - 1;
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        const size_t jh = j >> h, jl = j & mask;
+        Fr t = fr_mul29v(fe_load<FrParams>(eq_hi + 4 * jh), fe_load<FrParams>(lt_lo + 4 * jl));
+        fe_store(out + 4 * j, fe_add(fe_load<FrParams>(lt_hi + 4 * jh), t));
+    }
+}
+constexpr size_t LT_FACTORED_MIN_VARS = 12;
 static int lt_table_enqueue(const uint64_t *r_host, size_t v, uint64_t *d_out, hipStream_t st) {
     LtArgs a = {};
     for (size_t i = 0; i < v; i++)
@@ -1141,8 +1156,22 @@ static int lt_table_enqueue(const uint64_t *r_host, size_t v, uint64_t *d_out, h
     const size_t n = (size_t)1 << v;
     unsigned nb = (unsigned)div_up(n, 256);
     if (nb > 8192) nb = 8192;
-    hipLaunchKernelGGL(lt_table_kernel, dim3(nb), dim3(256), 0, st, a, (int)v, n, d_out);
+    if (v < LT_FACTORED_MIN_VARS) {
+        hipLaunchKernelGGL(lt_table_kernel, dim3(nb), dim3(256), 0, st, a, 0, (int)v, n, d_out, (uint64_t *)nullptr);
+        ZG_HIP(hipGetLastError());
+        return ZG_OK;
+    }
+    const size_t h = v / 2, n_lo = (size_t)1 << h, n_hi = (size_t)1 << (v - h);
+    Scratch s_f((2 * n_hi + n_lo) * 32);
+    if (!s_f.p) return ZG_ERR_NOMEM;
+    SyncGuard sync(st);
+    uint64_t *lt_hi = s_f.as<uint64_t>(), *eq_hi = lt_hi + 4 * n_hi, *lt_lo = eq_hi + 4 * n_hi;
+    hipLaunchKernelGGL(lt_table_kernel, dim3(div_up(n_hi, 256)), dim3(256), 0, st, a, (int)h, (int)v, n_hi, lt_hi, eq_hi);
+    hipLaunchKernelGGL(lt_table_kernel, dim3(div_up(n_lo, 256)), dim3(256), 0, st, a, 0, (int)h, n_lo, lt_lo, (uint64_t *)nullptr);
+    hipLaunchKernelGGL(lt_combine_kernel, dim3(nb), dim3(256), 0, st, lt_hi, eq_hi, lt_lo, (int)h, n, d_out);
     ZG_HIP(hipGetLastError());
+    ZG_HIP(hipStreamSynchronize(st));  // the factor tables go back to the scratch cache with this call
+    sync.dismiss();
     return ZG_OK;
 }
 
