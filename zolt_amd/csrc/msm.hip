@@ -980,6 +980,7 @@ __global__ void __launch_bounds__(256) msm_heavy_kernel(const char *part, const 
             uint32_t h = 0;
             while (h < nhuge && huge_list[h] != k) h++;
             uint32_t arrived = __hip_atomic_fetch_add(&arrive[h], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the acquire's invalidate has completed before the barrier releases the other waves' loads
             sh_last = arrived == b1 - b0 ? 1u : 0u;
         }
         __syncthreads();

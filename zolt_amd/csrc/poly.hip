@@ -203,7 +203,8 @@ ZG_DEV bool fr_eq(const Fr &a, const Fr &b) {
 
 // Verifier.verifyRound for the round polynomial [g0, g1 - g0]: check, derive the challenge, update the claim.
 // One thread. With `init` the claim is first set to g0 + g1 (runSumcheck's initial sum over the hypercube).
-ZG_DEV Fr sc_verifier_step(const ScRunArg &a, const Fr &g0, const Fr &g1, F29 *ch_pre = nullptr) {
+// `claim_reg` (the LDS tail): the running claim is taken from and left in the caller's registers instead of a dependent global load.
+ZG_DEV Fr sc_verifier_step(const ScRunArg &a, const Fr &g0, const Fr &g1, F29 *ch_pre = nullptr, Fr *claim_reg = nullptr) {
     uint64_t *res = a.res;
     Fr sum = fe_add(g0, g1);
     Fr claim;
@@ -212,7 +213,7 @@ ZG_DEV Fr sc_verifier_step(const ScRunArg &a, const Fr &g0, const Fr &g1, F29 *c
         fe_store(res, claim);
         res[run_off_status(a.v)] = 0;
     } else {
-        claim = fe_load<FrParams>(res + run_off_claim(a.v));
+        claim = claim_reg ? *claim_reg : fe_load<FrParams>(res + run_off_claim(a.v));
     }
     Fr c1 = fe_sub(g1, g0);
     if (!fr_eq(sum, claim) && (res[run_off_status(a.v)] >> 8) == 0) res[run_off_status(a.v)] = ((uint64_t)(a.round + 1)) << 8;
@@ -249,67 +250,85 @@ ZG_DEV Fr sc_verifier_step(const ScRunArg &a, const Fr &g0, const Fr &g1, F29 *c
     fe_store(res + run_off_chal(a.v) + 4 * (size_t)a.round, ch);
     fe_store(res + run_off_claim(a.v), next);
     fe_store(res + run_off_cur(a.v), ch);
+    if (claim_reg) *claim_reg = next;
     return ch;
 }
 
-// End of a round inside the producing kernel (no second launch): every block leaves its pair in `partials`; the block
-// that arrives last at the device-scope counter adds all of them up, writes the round's pair to `sums` (the pinned
-// host mailbox), publishes the sequence word and re-arms the counter. g0/g1: the block's pair, valid in thread 0.
-__device__ __forceinline__ void finish_round(Fr &g0, Fr &g1, uint4 *sh, uint64_t *partials, uint64_t *sums, uint32_t *counter,
+// End of a round inside the producing kernel (no second launch): every thread hands in its lazy sums; the block's canonical
+// pair goes to `partials` (write-through stores by the two lanes of wave 0 that hold the totals, drained, then one relaxed arrival:
+// sc_common.hip.h), and the block that arrives last adds all pairs up (sc1 loads), writes the round's pair to `sums` (the pinned
+// host mailbox) and publishes the sequence word — or runs the device-resident protocol's verifier step. `sh`: SC_RED_WORDS u32.
+__device__ __forceinline__ void finish_round(const Acc9 &g0, const Acc9 &g1, u32 *sh, uint64_t *partials, uint64_t *sums, uint32_t *counter,
                                              uint64_t *flag, uint64_t seq, const ScRunArg &run) {
-    uint32_t tid = threadIdx.x, nb = gridDim.x;
-    if (nb == 1) {
-        if (tid == 0) {
+    const uint32_t tid = threadIdx.x, nb = gridDim.x, lane = tid & 63u;
+    Fr tot = block_sum_pair9(g0, g1, sh);  // wave 0: lane SC_LANE_G0 / SC_LANE_G1
+    if (nb > 1) {
+        __shared__ uint32_t last;
+        if (tid < 64) {
+            if (lane == SC_LANE_G0 || lane == SC_LANE_G1) sc1_store_fr(partials + 8 * (size_t)blockIdx.x + (lane == SC_LANE_G1 ? 4 : 0), tot);
+            sc_drain_stores();  // the one storing wave, before its lane signals
+            if (lane == SC_LANE_G0) last = sc_arrive(counter, nb) ? 1u : 0u;
+        }
+        __syncthreads();  // (also orders the reduction's LDS reads before its reuse below)
+        if (!last) return;
+        Acc9 a0 = acc9_zero(), a1 = acc9_zero();
+        for (uint32_t k = tid; k < nb; k += blockDim.x) {
+            const uint64_t *src = partials + 8 * (size_t)k;
+            acc9_add(a0, sc1_load_fr(src));
+            acc9_add(a1, sc1_load_fr(src + 4));
+        }
+        tot = block_sum_pair9(a0, a1, sh);
+    }
+    if (tid < 64) {
+        Fr second = pair_second_to_first(tot);
+        if (lane == SC_LANE_G0) {
             if (run.res) {
-                sc_verifier_step(run, g0, g1);
+                sc_verifier_step(run, tot, second);
             } else {
-                fe_store(sums, g0);
-                fe_store(sums + 4, g1);
+                mailbox_store_fr(sums, tot, flag);
+                mailbox_store_fr(sums + 4, second, flag);
                 publish_seq(flag, seq);
             }
-        }
-        return;
-    }
-    __shared__ uint32_t last;
-    if (tid == 0) {
-        uint64_t *dst = partials + 8 * (size_t)blockIdx.x;
-        fe_store(dst, g0);  // plain stores: the arrival's release makes them visible to the workgroup whose acquire sees it last
-        fe_store(dst + 4, g1);
-        last = sc_arrive(counter, nb) ? 1u : 0u;
-    }
-    __syncthreads();
-    if (!last) return;
-    Fr a0 = Fr::zero(), a1 = Fr::zero();
-    for (uint32_t k = tid; k < nb; k += blockDim.x) {
-        const uint64_t *src = partials + 8 * (size_t)k;
-        a0 = fe_add(a0, fe_load<FrParams>(src));
-        a1 = fe_add(a1, fe_load<FrParams>(src + 4));
-    }
-    __syncthreads();  // sh is reused
-    block_sum_pair(a0, a1, sh);
-    if (tid == 0) {
-        if (run.res) {
-            sc_verifier_step(run, a0, a1);
-        } else {
-            fe_store(sums, a0);
-            fe_store(sums + 4, a1);
-            publish_seq(flag, seq);
         }
     }
 }
 
+// the block's canonical pair to partials[blockIdx] with plain stores (finished by a later launch: sc_finish_kernel)
+__device__ __forceinline__ void store_block_pair(const Acc9 &g0, const Acc9 &g1, u32 *sh, uint64_t *partials) {
+    Fr tot = block_sum_pair9(g0, g1, sh);
+    const uint32_t lane = threadIdx.x & 63u;
+    if (threadIdx.x < 64 && (lane == SC_LANE_G0 || lane == SC_LANE_G1))
+        fe_store(partials + 8 * (size_t)blockIdx.x + (lane == SC_LANE_G1 ? 4 : 0), tot);
+}
+
+// Sums of a table (a session's first round). SC_SUMS_U pairs per thread are requested before the first addition; 1024-thread
+// workgroups, at most one per CU: 2^20 entries 25 -> 9 us, 2^24 202 -> 90 us (6 TB/s) against round 3's one-pair-per-trip loop of
+// modular additions (tools/exp/fold_ab.hip, profiles/r4_fold_ab_*).
+constexpr int SC_SUMS_U = 2;
 template <int LAYOUT>
-__global__ void __launch_bounds__(256) sc_sums_kernel(const uint64_t *t, size_t half, uint64_t *partials, uint64_t *sums,
-                                                      uint32_t *counter, uint64_t *flag, uint64_t seq, ScRunArg run) {
-    __shared__ uint4 sh[256 * 4];
-    Fr g0 = Fr::zero(), g1 = Fr::zero();
-    size_t stride = (size_t)gridDim.x * 256;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < half; i += stride) {
-        size_t i0 = LAYOUT == ZG_SC_HIGH_HALF ? i : 2 * i, i1 = LAYOUT == ZG_SC_HIGH_HALF ? i + half : 2 * i + 1;
-        g0 = fe_add(g0, fe_load<FrParams>(t + 4 * i0));
-        g1 = fe_add(g1, fe_load<FrParams>(t + 4 * i1));
+__global__ void __launch_bounds__(1024) sc_sums_kernel(const uint64_t *t, size_t half, uint64_t *partials, uint64_t *sums,
+                                                       uint32_t *counter, uint64_t *flag, uint64_t seq, ScRunArg run) {
+    __shared__ u32 sh[SC_RED_WORDS];
+    Acc9 g0 = acc9_zero(), g1 = acc9_zero();
+    const size_t tile = (size_t)blockDim.x * SC_SUMS_U, stride = (size_t)gridDim.x * tile;
+    for (size_t b = (size_t)blockIdx.x * tile + threadIdx.x; b < half; b += stride) {
+        Fr lo[SC_SUMS_U], hi[SC_SUMS_U];
+#pragma unroll
+        for (int k = 0; k < SC_SUMS_U; k++) {
+            const size_t i = b + (size_t)k * blockDim.x;
+            lo[k] = Fr::zero();
+            hi[k] = Fr::zero();
+            if (i < half) {
+                lo[k] = fe_load<FrParams>(t + 4 * (LAYOUT == ZG_SC_HIGH_HALF ? i : 2 * i));
+                hi[k] = fe_load<FrParams>(t + 4 * (LAYOUT == ZG_SC_HIGH_HALF ? i + half : 2 * i + 1));
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < SC_SUMS_U; k++) {
+            acc9_add(g0, lo[k]);
+            acc9_add(g1, hi[k]);
+        }
     }
-    block_sum_pair(g0, g1, sh);
     finish_round(g0, g1, sh, partials, sums, counter, flag, seq, run);
 }
 
@@ -338,40 +357,34 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(56))) hk_q
     }
 }
 
-// Launched with 256 threads per workgroup, or with 1024 for tables of >= 2^23 entries (2^24: 219 -> 188 us). A long fold is bound by
-// instruction issue, not by HBM: ~400 instructions per output (unpack, 162 multiply-adds, conditional subtraction, repack, one modular
-// subtraction and addition) against 96 bytes of traffic put the ceiling at ~9 TB/s with every issue slot used; the kernel reaches
-// 4.2-4.6 TB/s, the same traffic without the arithmetic 5.5 (tools/microbench xcd). More workgroups do not help and cost more: an
-// arrival (acq_rel fetch_add, agent scope) takes ~20 ns of chip-wide throughput per workgroup whatever the counter layout
-// (tools/microbench arrive: 2048 workgroups 6 us without, 48 us with, 34 us on 16 counters) — 2^20 entries: 37 us with 256 workgroups,
-// 100 us with 2048; finishing the round in a second launch instead (no arrivals, 2048 workgroups) measured 187 vs 193 us at 2^24 and
-// 50 vs 40 us at 2^20, and was left out.
+// 512-thread workgroups, at most 512 of them (two per CU = four waves per SIMD), grid-stride with the next pair requested before the
+// current product. Round 3 ran one wave per SIMD (every trip a full memory latency) and ended each block with a shuffle tree of modular
+// additions plus an ACQ_REL arrival: 2^16 entries 15.7 -> 8.4 us, 2^20 30.0 -> 19 us, 2^24 245 -> 170 us (4.8 TB/s) with the lazy sums,
+// the DPP reduction and the relaxed hand-off (tools/exp/fold_ab.hip; profiles/r4_fold_ab_*). What is left at 2^20: ~2 us launch ramp,
+// ~7 us for the 50 MB, the last batch of products (not overlapped with loads), ~4 us of hand-off (three dependent memory round trips).
 template <int LAYOUT>
-__global__ void __launch_bounds__(1024) sc_fold_kernel(const uint64_t *t, size_t half, FrArg r, uint64_t *out,
-                                                      uint64_t *partials, uint64_t *sums, uint32_t *counter, uint64_t *flag,
-                                                      uint64_t seq, ScRunArg run) {
-    __shared__ uint4 sh[256 * 4];
+__global__ void __launch_bounds__(512) sc_fold_kernel(const uint64_t *t, size_t half, FrArg r, uint64_t *out,
+                                                     uint64_t *partials, uint64_t *sums, uint32_t *counter, uint64_t *flag,
+                                                     uint64_t seq, ScRunArg run) {
+    __shared__ u32 sh[SC_RED_WORDS];
+    const size_t stride = (size_t)gridDim.x * blockDim.x, quarter = half / 2;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    Fr lo = Fr::zero(), hi = Fr::zero();
+    if (i < half) {  // requested before the challenge is prepared
+        lo = fe_load<FrParams>(LAYOUT == ZG_SC_HIGH_HALF ? t + 4 * i : t + 8 * i);
+        hi = fe_load<FrParams>(LAYOUT == ZG_SC_HIGH_HALF ? t + 4 * (i + half) : t + 8 * i + 4);
+    }
     Fr rv;
     if (run.res) {  // device-resident protocol: the challenge was left in device memory by the previous kernel's verifier step
         rv = fe_load<FrParams>(run.res + run_off_cur(run.v));
     } else {
 #pragma unroll
-        for (int i = 0; i < 8; i++) rv.l[i] = r.l[i];
+        for (int k = 0; k < 8; k++) rv.l[k] = r.l[k];
     }
     FrMul rp = frmul_prepare(rv);  // the challenge is the shared factor of every product of this launch (narrow form for a 128-bit one)
-    Fr g0 = Fr::zero(), g1 = Fr::zero();
-    size_t stride = (size_t)gridDim.x * blockDim.x;
-    size_t quarter = half / 2;
-    // the pair of the next iteration is requested before the current product is computed: with one block per CU (4 waves) the
-    // loads in flight, not the arithmetic, bound a long table (Little's law: 64 B per thread x 65536 threads per ~2 us)
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    Fr lo = Fr::zero(), hi = Fr::zero();
-    if (i < half) {
-        lo = fe_load<FrParams>(LAYOUT == ZG_SC_HIGH_HALF ? t + 4 * i : t + 8 * i);
-        hi = fe_load<FrParams>(LAYOUT == ZG_SC_HIGH_HALF ? t + 4 * (i + half) : t + 8 * i + 4);
-    }
+    Acc9 g0 = acc9_zero(), g1 = acc9_zero();
     while (i < half) {
-        size_t ni = i + stride;
+        const size_t ni = i + stride;
         Fr nlo = lo, nhi = hi;
         if (ni < half) {
             nlo = fe_load<FrParams>(LAYOUT == ZG_SC_HIGH_HALF ? t + 4 * ni : t + 8 * ni);
@@ -379,14 +392,13 @@ __global__ void __launch_bounds__(1024) sc_fold_kernel(const uint64_t *t, size_t
         }
         Fr v = fe_add(lo, frmul_apply(fe_sub(hi, lo), rp));  // (1-r)*lo + r*hi = lo + r*(hi - lo): one product, same value
         fe_store(out + 4 * i, v);
-        bool second = LAYOUT == ZG_SC_HIGH_HALF ? (i >= quarter) : (i & 1);
-        if (second) g1 = fe_add(g1, v);
-        else g0 = fe_add(g0, v);
+        const bool second = LAYOUT == ZG_SC_HIGH_HALF ? (i >= quarter) : (i & 1);
+        acc9_add_if(g0, v, !second);
+        acc9_add_if(g1, v, second);
         lo = nlo;
         hi = nhi;
         i = ni;
     }
-    block_sum_pair(g0, g1, sh);
     if (run.res && half == 1) {  // the table is down to one element: getFinalEval + the verifier's last comparison
         if (threadIdx.x == 0 && blockIdx.x == 0) {
             Fr fin = fe_load<FrParams>(out);
@@ -402,44 +414,49 @@ __global__ void __launch_bounds__(1024) sc_fold_kernel(const uint64_t *t, size_t
 // entries = 128 KiB) every remaining round — fold by the challenge the previous verifier step left, sums of the folded
 // table, verifier step, next challenge — stays inside the workgroup; a round costs a block reduction and two
 // dependent field products instead of a kernel launch. run.round = index of the next verifier step.
-constexpr uint32_t SC_TAIL_MAX = 4096;
-__global__ void __launch_bounds__(256) sc_tail_run_kernel(const uint64_t *t, uint32_t len, ScRunArg run) {
-    extern __shared__ uint4 lds_tab[];          // len entries of 2 x uint4, then 16 uint4 of reduction scratch + 2 for the challenge
-    uint4 *sh = lds_tab + 2 * (size_t)len;
-    uint32_t *sh_rp = reinterpret_cast<uint32_t *>(sh + 16);  // the prescaled challenge (9 limbs), written by lane 0
-    uint32_t tid = threadIdx.x;
-    for (uint32_t i = tid; i < len; i += 256) fe_store(&lds_tab[2 * i], fe_load<FrParams>(t + 4 * (size_t)i));
+constexpr uint32_t SC_TAIL_MAX = 4096, SC_TAIL_THREADS = 1024;
+constexpr size_t SC_TAIL_LDS_EXTRA = (SC_RED_WORDS + 12) * 4;  // reduction scratch + the prescaled challenge, after the table
+__global__ void __launch_bounds__(SC_TAIL_THREADS) sc_tail_run_kernel(const uint64_t *t, uint32_t len, ScRunArg run) {
+    extern __shared__ uint4 lds_tab[];  // len entries of 2 x uint4, then SC_RED_WORDS u32 of reduction scratch + 9 for the challenge
+    u32 *sh = reinterpret_cast<u32 *>(lds_tab + 2 * (size_t)len);
+    u32 *sh_rp = sh + SC_RED_WORDS;  // the prescaled challenge (9 limbs), written by the lane that ran the verifier step
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    for (uint32_t i = tid; i < len; i += SC_TAIL_THREADS) fe_store(&lds_tab[2 * i], fe_load<FrParams>(t + 4 * (size_t)i));
     F29 rp = fr29_prescale(fe_load<FrParams>(run.res + run_off_cur(run.v)));
+    Fr claim = fe_load<FrParams>(run.res + run_off_claim(run.v));  // stays in the verifier lane's registers from here on
     __syncthreads();
     while (len > 1) {
-        uint32_t half = len / 2, quarter = half / 2;
-        Fr g0 = Fr::zero(), g1 = Fr::zero();
-        for (uint32_t i = tid; i < half; i += 256) {
+        const uint32_t half = len / 2, quarter = half / 2;
+        Acc9 g0 = acc9_zero(), g1 = acc9_zero();
+        for (uint32_t i = tid; i < half; i += SC_TAIL_THREADS) {
             Fr lo = fe_load<FrParams>(&lds_tab[2 * i]), hi = fe_load<FrParams>(&lds_tab[2 * (i + half)]);
             Fr v = fe_add(lo, fr_mul29(fe_sub(hi, lo), rp));
             fe_store(&lds_tab[2 * i], v);  // in place: entry i is read and written by this thread only
-            if (i >= quarter) g1 = fe_add(g1, v);
-            else g0 = fe_add(g0, v);
+            acc9_add_if(g0, v, i < quarter);
+            acc9_add_if(g1, v, i >= quarter);
         }
         len = half;
         if (len == 1) break;
-        block_sum_pair(g0, g1, sh);
-        if (tid == 0) {
-            F29 cp;
-            (void)sc_verifier_step(run, g0, g1, &cp);
+        Fr tot = block_sum_pair9(g0, g1, sh);
+        if (tid < 64) {
+            Fr second = pair_second_to_first(tot);
+            if (lane == SC_LANE_G0) {
+                F29 cp;
+                (void)sc_verifier_step(run, tot, second, &cp, &claim);
 #pragma unroll
-            for (int i = 0; i < 9; i++) sh_rp[i] = cp.l[i];
+                for (int i = 0; i < 9; i++) sh_rp[i] = cp.l[i];
+            }
         }
         run.round++;
-        __syncthreads();
+        __syncthreads();  // the folded table and the challenge are visible; the reduction scratch is free again
 #pragma unroll
         for (int i = 0; i < 9; i++) rp.l[i] = sh_rp[i];
-        __syncthreads();  // sh is rewritten by the next round's reduction
     }
-    if (tid == 0) {
+    __syncthreads();
+    if (tid == SC_LANE_G0) {
         Fr fin = fe_load<FrParams>(&lds_tab[0]);
         fe_store(run.res + run_off_final(run.v), fin);
-        if (fr_eq(fin, fe_load<FrParams>(run.res + run_off_claim(run.v)))) run.res[run_off_status(run.v)] |= 1;
+        if (fr_eq(fin, claim)) run.res[run_off_status(run.v)] |= 1;
     }
 }
 
@@ -585,8 +602,8 @@ __global__ void __launch_bounds__(256) sc_finish_kernel(const uint64_t *partials
     }
     block_sum_pair(g0, g1, sh);
     if (threadIdx.x == 0) {
-        fe_store(sums, g0);
-        fe_store(sums + 4, g1);
+        mailbox_store_fr(sums, g0, flag);
+        mailbox_store_fr(sums + 4, g1, flag);
         publish_seq(flag, seq);
     }
 }
@@ -596,32 +613,53 @@ __global__ void __launch_bounds__(256) sc_finish_kernel(const uint64_t *partials
 // is written straight into the session's buffer and round 0's pair of sums is accumulated on the way (finished by the last
 // block to arrive, like every other round): the eq table is never materialised, the 2^v-entry copy into the session and the
 // separate first sums pass disappear.
-template <int LAYOUT>
-__global__ void __launch_bounds__(256) eq_spartan_kernel(EqArgs ea, int v_lo, int v_hi, uint32_t hi_per_block, const uint64_t *az,
-                                                         const uint64_t *bz, const uint64_t *cz, uint64_t *out, uint64_t *partials,
-                                                         uint64_t *sums, uint32_t *counter, uint64_t *flag, uint64_t seq) {
-    __shared__ uint4 sh[256 * 4];
+// WG groups of 256 threads per block (thread (grp, lo) takes rows grp, grp + WG, ...), the next row's three operands requested before
+// the current row's three products: round 3 ran 512 x 256 threads with the loads inside the trip (two waves per SIMD, each trip a
+// memory latency plus three dependent products) — 78 us at 2^20 for 134 MB and 3 x 2^20 products (~20 us of multiplier throughput).
+template <int LAYOUT, int WG>
+__global__ void __launch_bounds__(256 * WG) eq_spartan_kernel(EqArgs ea, int v_lo, int v_hi, uint32_t hi_per_block, const uint64_t *az,
+                                                              const uint64_t *bz, const uint64_t *cz, uint64_t *out, uint64_t *partials,
+                                                              uint64_t *sums, uint32_t *counter, uint64_t *flag, uint64_t seq) {
+    __shared__ u32 sh[SC_RED_WORDS];
     __shared__ EqShared fs;
     const uint32_t n_hi = 1u << v_hi, h0 = blockIdx.x * hi_per_block;
     const uint32_t rows = n_hi - h0 < hi_per_block ? n_hi - h0 : hi_per_block;
+    const uint32_t lo = threadIdx.x & 255u, grp = threadIdx.x >> 8;
+    const bool live = lo < (1u << v_lo);
+    uint32_t k = grp;
+    Fr a = Fr::zero(), b = Fr::zero(), c = Fr::zero();
+    if (live && k < rows) {  // requested before the factor prologue
+        const size_t i = ((size_t)(h0 + k) << v_lo) | lo;
+        a = fe_load<FrParams>(az + 4 * i);
+        b = fe_load<FrParams>(bz + 4 * i);
+        c = fe_load<FrParams>(cz + 4 * i);
+    }
     Fr lov = eq_block_factors(ea, v_lo, v_hi, h0, rows, fs);
-    uint32_t lo = threadIdx.x;
-    Fr g0 = Fr::zero(), g1 = Fr::zero();
-    if (lo < (1u << v_lo)) {
+    Acc9 g0 = acc9_zero(), g1 = acc9_zero();
+    if (live) {
         F29 tp = fr29_prescale(lov);
-        for (uint32_t k = 0; k < rows; k++) {
-            uint32_t h = h0 + k;
-            size_t i = ((size_t)h << v_lo) | lo;
+        while (k < rows) {
+            const uint32_t nk = k + WG, h = h0 + k;
+            const size_t i = ((size_t)h << v_lo) | lo;
+            Fr na = a, nb = b, nc = c;
+            if (nk < rows) {
+                const size_t ni = ((size_t)(h0 + nk) << v_lo) | lo;
+                na = fe_load<FrParams>(az + 4 * ni);
+                nb = fe_load<FrParams>(bz + 4 * ni);
+                nc = fe_load<FrParams>(cz + 4 * ni);
+            }
             Fr e = fr_mul29(fe_load<FrParams>(&fs.hi_row[k][0]), tp);
-            Fr a = fe_load<FrParams>(az + 4 * i), b = fe_load<FrParams>(bz + 4 * i), c = fe_load<FrParams>(cz + 4 * i);
             Fr f = fr_mul29v(e, fe_sub(fr_mul29v(a, b), c));
             fe_store(out + 4 * i, f);
-            bool second = LAYOUT == ZG_SC_HIGH_HALF ? (n_hi > 1 ? h >= n_hi / 2 : lo >= (1u << v_lo) / 2) : (lo & 1u);
-            if (second) g1 = fe_add(g1, f);
-            else g0 = fe_add(g0, f);
+            const bool second = LAYOUT == ZG_SC_HIGH_HALF ? (n_hi > 1 ? h >= n_hi / 2 : lo >= (1u << v_lo) / 2) : (lo & 1u);
+            acc9_add_if(g0, f, !second);
+            acc9_add_if(g1, f, second);
+            a = na;
+            b = nb;
+            c = nc;
+            k = nk;
         }
     }
-    block_sum_pair(g0, g1, sh);
     finish_round(g0, g1, sh, partials, sums, counter, flag, seq, ScRunArg{nullptr, 0, 0, 0});
 }
 
@@ -632,7 +670,7 @@ __global__ void __launch_bounds__(256) eq_spartan_kernel(EqArgs ea, int v_lo, in
 // checked that step * half fits 64 bits, so F.fromU64 of the sum equals the reference's sum of F.fromU64 terms).
 __global__ void __launch_bounds__(256) raf_round_kernel(const uint64_t *t, size_t half, FrArg base, uint64_t step, uint64_t *partials,
                                                         uint64_t *sums, uint32_t *counter, uint64_t *flag, uint64_t seq) {
-    __shared__ uint4 sh[256 * 4];
+    __shared__ u32 sh[SC_RED_WORDS];
     Fr bv;
 #pragma unroll
     for (int i = 0; i < 8; i++) bv.l[i] = base.l[i];
@@ -643,7 +681,7 @@ __global__ void __launch_bounds__(256) raf_round_kernel(const uint64_t *t, size_
     cp2.l[0] = (uint32_t)step;
     cp2.l[1] = (uint32_t)(step >> 32);
     cp2 = fr_mul29(cp2, r2p);
-    Fr g0 = Fr::zero(), g1 = Fr::zero();
+    Acc9 g0 = acc9_zero(), g1 = acc9_zero();
     size_t stride = (size_t)gridDim.x * 256;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < half; i += stride) {
         Fr lo = fe_load<FrParams>(t + 8 * i), hi = fe_load<FrParams>(t + 8 * i + 4);
@@ -654,10 +692,9 @@ __global__ void __launch_bounds__(256) raf_round_kernel(const uint64_t *t, size_
         Fr u0 = fe_add(bv, fr_mul29(rv, r2p));  // F.fromU64(rem) = rem * R^2 * R^-1
         Fr u2 = fe_add(u0, cp2);
         Fr ra2 = fe_sub(fe_add(hi, hi), lo);
-        g0 = fe_add(g0, fr_mul29v(lo, u0));
-        g1 = fe_add(g1, fr_mul29v(ra2, u2));
+        acc9_add(g0, fr_mul29v(lo, u0));
+        acc9_add(g1, fr_mul29v(ra2, u2));
     }
-    block_sum_pair(g0, g1, sh);
     finish_round(g0, g1, sh, partials, sums, counter, flag, seq, ScRunArg{nullptr, 0, 0, 0});  // the round ends inside this launch
 }
 
@@ -668,21 +705,20 @@ __global__ void __launch_bounds__(256) raf_round_kernel(const uint64_t *t, size_
 __global__ void __launch_bounds__(256) bit_split_sums_kernel(const uint64_t *vals, const uint64_t *idx, size_t n, uint32_t bit,
                                                              uint64_t *partials, uint64_t *sums, uint32_t *counter, uint64_t *flag,
                                                              uint64_t seq) {
-    __shared__ uint4 sh[256 * 4];
-    Fr g0 = Fr::zero(), g1 = Fr::zero();
+    __shared__ u32 sh[SC_RED_WORDS];
+    Acc9 g0 = acc9_zero(), g1 = acc9_zero();
     size_t stride = (size_t)gridDim.x * 256;
     const uint32_t word = bit >> 6, sh_bits = bit & 63u;
     for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < n; j += stride) {
         Fr v = fe_load<FrParams>(vals + 4 * j);
-        if ((idx[2 * j + word] >> sh_bits) & 1ull) g1 = fe_add(g1, v);
-        else g0 = fe_add(g0, v);
+        const bool one = (idx[2 * j + word] >> sh_bits) & 1ull;
+        acc9_add_if(g0, v, !one);
+        acc9_add_if(g1, v, one);
     }
-    block_sum_pair(g0, g1, sh);
     if (sums) {
         finish_round(g0, g1, sh, partials, sums, counter, flag, seq, ScRunArg{nullptr, 0, 0, 0});
-    } else if (threadIdx.x == 0) {
-        fe_store(partials + 8 * (size_t)blockIdx.x, g0);
-        fe_store(partials + 8 * (size_t)blockIdx.x + 4, g1);
+    } else {
+        store_block_pair(g0, g1, sh, partials);
     }
 }
 
@@ -692,14 +728,14 @@ __global__ void __launch_bounds__(256) bit_split_sums_kernel(const uint64_t *val
 __global__ void __launch_bounds__(256) bit_bind_kernel(uint64_t *t, const uint64_t *idx, size_t n, uint32_t bit, uint32_t next_bit,
                                                        FrArg r, uint64_t *partials, uint64_t *sums, uint32_t *counter, uint64_t *flag,
                                                        uint64_t seq) {
-    __shared__ uint4 sh[256 * 4];
+    __shared__ u32 sh[SC_RED_WORDS];
     Fr rv;
 #pragma unroll
     for (int i = 0; i < 8; i++) rv.l[i] = r.l[i];
     // a narrow challenge (FrMul): v * r by the short product and v * (1 - r) = v - v * r — the same canonical value, 90 multiply-adds
     FrMul rm = frmul_prepare(rv);
     F29 omrp = fr29_prescale(fe_sub(Fr::one(), rv));
-    Fr g0 = Fr::zero(), g1 = Fr::zero();
+    Acc9 g0 = acc9_zero(), g1 = acc9_zero();
     size_t stride = (size_t)gridDim.x * 256;
     const uint32_t w0 = bit >> 6, s0 = bit & 63u, w1 = next_bit >> 6, s1 = next_bit & 63u;
     for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < n; j += stride) {
@@ -712,31 +748,28 @@ __global__ void __launch_bounds__(256) bit_bind_kernel(uint64_t *t, const uint64
             v = ((a >> s0) & 1ull) ? fr_mul29(v, rm.p) : fr_mul29(v, omrp);
         }
         fe_store(t + 4 * j, v);
-        if ((b >> s1) & 1ull) g1 = fe_add(g1, v);
-        else g0 = fe_add(g0, v);
+        const bool one = (b >> s1) & 1ull;
+        acc9_add_if(g0, v, !one);
+        acc9_add_if(g1, v, one);
     }
-    block_sum_pair(g0, g1, sh);
     if (sums) {
         finish_round(g0, g1, sh, partials, sums, counter, flag, seq, ScRunArg{nullptr, 0, 0, 0});
-    } else if (threadIdx.x == 0) {
-        fe_store(partials + 8 * (size_t)blockIdx.x, g0);
-        fe_store(partials + 8 * (size_t)blockIdx.x + 4, g1);
+    } else {
+        store_block_pair(g0, g1, sh, partials);
     }
 }
 
 // sum of t[from, to) as the pair (sum, 0): the padding entries of LassoProver.eq_evals (:164-171) that `current_claim` includes
 __global__ void __launch_bounds__(256) range_sum_kernel(const uint64_t *t, size_t from, size_t to, uint64_t *partials, uint64_t *sums,
                                                         uint32_t *counter, uint64_t *flag, uint64_t seq) {
-    __shared__ uint4 sh[256 * 4];
-    Fr g0 = Fr::zero(), g1 = Fr::zero();
+    __shared__ u32 sh[SC_RED_WORDS];
+    Acc9 g0 = acc9_zero(), g1 = acc9_zero();
     size_t stride = (size_t)gridDim.x * 256;
-    for (size_t j = from + (size_t)blockIdx.x * 256 + threadIdx.x; j < to; j += stride) g0 = fe_add(g0, fe_load<FrParams>(t + 4 * j));
-    block_sum_pair(g0, g1, sh);
+    for (size_t j = from + (size_t)blockIdx.x * 256 + threadIdx.x; j < to; j += stride) acc9_add(g0, fe_load<FrParams>(t + 4 * j));
     if (sums) {
         finish_round(g0, g1, sh, partials, sums, counter, flag, seq, ScRunArg{nullptr, 0, 0, 0});
-    } else if (threadIdx.x == 0) {
-        fe_store(partials + 8 * (size_t)blockIdx.x, g0);
-        fe_store(partials + 8 * (size_t)blockIdx.x + 4, g1);
+    } else {
+        store_block_pair(g0, g1, sh, partials);
     }
 }
 
@@ -751,26 +784,35 @@ static unsigned env_uint(const char *name, unsigned dflt, unsigned lo, unsigned 
 constexpr unsigned SC_MAX_BLOCKS = 2048;
 constexpr size_t SC_SUMS_OFF = 8 * (size_t)SC_MAX_BLOCKS + SC_COUNTER_BYTES / 8;
 constexpr size_t SC_MISC_BYTES = (SC_SUMS_OFF + 8) * 8;
-static unsigned sc_blocks(size_t half) {
-    static const unsigned cap = [] {
+// Grid of a 256-thread pair-sum kernel (raf / bit-split / range sums, dot products): one element per thread up to `cap` workgroups
+// (default two per CU), grid-stride beyond. ZG_SC_MAX_BLOCKS overrides the cap of every sumcheck-family grid (tests: 1 = single block).
+static unsigned sc_block_cap(unsigned dflt) {
+    static const unsigned env = [] {
         const char *e = getenv("ZG_SC_MAX_BLOCKS");
-        unsigned v = e && *e ? (unsigned)atoi(e) : 256u;  // one block per CU: every extra block is one more same-address atomic
-        return v < 1 ? 1u : (v > SC_MAX_BLOCKS ? SC_MAX_BLOCKS : v);
+        unsigned v = e && *e ? (unsigned)atoi(e) : 0u;
+        return v > SC_MAX_BLOCKS ? SC_MAX_BLOCKS : v;
     }();
-    unsigned b = div_up(half ? half : 1, 256);
-    return b > cap ? cap : b;  // grid-stride beyond that (fewer, fatter blocks were measured: 2 pairs per thread equal, 4+ slower)
+    return env ? env : dflt;
+}
+static unsigned sc_blocks(size_t half) {
+    const unsigned cap = sc_block_cap(512u), b = div_up(half ? half : 1, 256);
+    return b > cap ? cap : b;
 }
 
 static int launch_sums(int layout, const uint64_t *t, size_t len, uint64_t *partials, uint64_t *sums, hipStream_t st,
                        uint64_t *flag = nullptr, uint64_t seq = 0, ScRunArg run = ScRunArg{nullptr, 0, 0, 0}) {
     size_t half = len / 2;
-    unsigned nb = sc_blocks(half);
+    // 1024-thread workgroups of SC_SUMS_U pairs per thread, at most one per CU (measured: tools/exp/fold_ab.hip)
+    static const unsigned threads = env_uint("ZG_SC_SUMS_THREADS", 1024, 64, 1024) & ~63u;
+    const unsigned cap = sc_block_cap(256u);
+    unsigned nb = div_up(half ? half : 1, (size_t)threads * SC_SUMS_U);
+    if (nb > cap) nb = cap;
     uint32_t *counter = reinterpret_cast<uint32_t *>(partials + 8 * (size_t)SC_MAX_BLOCKS);  // zeroed at session creation
     prof_begin(ZG_PROF_SC_SUMS, st);
     if (layout == ZG_SC_HIGH_HALF)
-        hipLaunchKernelGGL(sc_sums_kernel<ZG_SC_HIGH_HALF>, dim3(nb), dim3(256), 0, st, t, half, partials, sums, counter, flag, seq, run);
+        hipLaunchKernelGGL(sc_sums_kernel<ZG_SC_HIGH_HALF>, dim3(nb), dim3(threads), 0, st, t, half, partials, sums, counter, flag, seq, run);
     else
-        hipLaunchKernelGGL(sc_sums_kernel<ZG_SC_LOW_PAIR>, dim3(nb), dim3(256), 0, st, t, half, partials, sums, counter, flag, seq, run);
+        hipLaunchKernelGGL(sc_sums_kernel<ZG_SC_LOW_PAIR>, dim3(nb), dim3(threads), 0, st, t, half, partials, sums, counter, flag, seq, run);
     prof_end(ZG_PROF_SC_SUMS, st);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
@@ -780,17 +822,18 @@ static int launch_fold(int layout, const uint64_t *t, size_t len, const uint64_t
                        uint64_t *sums, hipStream_t st, uint64_t *flag = nullptr, uint64_t seq = 0,
                        ScRunArg run = ScRunArg{nullptr, 0, 0, 0}) {
     size_t half = len / 2;
-    unsigned nb = sc_blocks(half);
     FrArg ra;
     for (int i = 0; i < 4; i++) {
         ra.l[2 * i] = r ? (uint32_t)r[i] : 0;
         ra.l[2 * i + 1] = r ? (uint32_t)(r[i] >> 32) : 0;
     }
     uint32_t *counter = reinterpret_cast<uint32_t *>(partials + 8 * (size_t)SC_MAX_BLOCKS);
+    // 512-thread workgroups, at most two per CU (four waves per SIMD): measured at 2^16 .. 2^24 entries, tools/exp/fold_ab.hip
+    static const unsigned threads = env_uint("ZG_SC_FOLD_THREADS", 512, 64, 512) & ~63u;
+    const unsigned cap = sc_block_cap(512u);
+    unsigned nb = div_up(half ? half : 1, threads);
+    if (nb > cap) nb = cap;
     prof_begin(ZG_PROF_SC_FOLD, st);
-    // outputs from which a workgroup gets 1024 threads: measured 2^24 entries 219 -> 188 us, 2^23 124 -> 117, 2^22 77 -> 80, 2^20 39 -> 52
-    static const unsigned wide_min = env_uint("ZG_SC_WIDE_MIN_LOG2", 22, 0, 40);
-    const unsigned threads = (half >> wide_min) ? 1024u : 256u;
     if (layout == ZG_SC_HIGH_HALF)
         hipLaunchKernelGGL(sc_fold_kernel<ZG_SC_HIGH_HALF>, dim3(nb), dim3(threads), 0, st, t, half, ra, out, partials, sums, counter, flag, seq, run);
     else
@@ -880,7 +923,7 @@ static int eq_spartan_enqueue(const uint64_t *r_host, size_t v, const uint64_t *
     ZG_TRY(eq_args_fill(a, r_host, v, scale_host));
     int v_lo = v < 8 ? (int)v : 8, v_hi = (int)v - v_lo;
     uint32_t n_hi = 1u << v_hi;
-    static const uint32_t nb_cap = env_uint("ZG_SC_SPARTAN_BLOCKS", 512, 1, SC_MAX_BLOCKS);  // enough waves per SIMD for three products per element; each block is one more atomic
+    static const uint32_t nb_cap = env_uint("ZG_SC_SPARTAN_BLOCKS", 512, 1, SC_MAX_BLOCKS);  // two 512-thread workgroups per CU: four waves per SIMD
     uint32_t hpb = div_up(n_hi, n_hi < nb_cap ? n_hi : nb_cap);
     if (hpb > (uint32_t)EQ_MAX_ROWS) hpb = EQ_MAX_ROWS;
     uint32_t nb = div_up(n_hi, hpb);
@@ -889,13 +932,24 @@ static int eq_spartan_enqueue(const uint64_t *r_host, size_t v, const uint64_t *
         return ZG_ERR_INVALID;
     }
     uint32_t *counter = reinterpret_cast<uint32_t *>(partials + 8 * (size_t)SC_MAX_BLOCKS);
+    static const uint32_t wg_env = env_uint("ZG_SC_SPARTAN_WG", 2, 1, 2);
+    const bool wide = wg_env >= 2 && hpb >= 2;
     prof_begin(ZG_PROF_COMBINE, st);
-    if (layout == ZG_SC_HIGH_HALF)
-        hipLaunchKernelGGL(eq_spartan_kernel<ZG_SC_HIGH_HALF>, dim3(nb), dim3(256), 0, st, a, v_lo, v_hi, hpb, d_az, d_bz, d_cz, d_out,
-                           partials, sums, counter, flag, seq);
-    else
-        hipLaunchKernelGGL(eq_spartan_kernel<ZG_SC_LOW_PAIR>, dim3(nb), dim3(256), 0, st, a, v_lo, v_hi, hpb, d_az, d_bz, d_cz, d_out,
-                           partials, sums, counter, flag, seq);
+    if (layout == ZG_SC_HIGH_HALF) {
+        if (wide)
+            hipLaunchKernelGGL((eq_spartan_kernel<ZG_SC_HIGH_HALF, 2>), dim3(nb), dim3(512), 0, st, a, v_lo, v_hi, hpb, d_az, d_bz, d_cz, d_out,
+                               partials, sums, counter, flag, seq);
+        else
+            hipLaunchKernelGGL((eq_spartan_kernel<ZG_SC_HIGH_HALF, 1>), dim3(nb), dim3(256), 0, st, a, v_lo, v_hi, hpb, d_az, d_bz, d_cz, d_out,
+                               partials, sums, counter, flag, seq);
+    } else {
+        if (wide)
+            hipLaunchKernelGGL((eq_spartan_kernel<ZG_SC_LOW_PAIR, 2>), dim3(nb), dim3(512), 0, st, a, v_lo, v_hi, hpb, d_az, d_bz, d_cz, d_out,
+                               partials, sums, counter, flag, seq);
+        else
+            hipLaunchKernelGGL((eq_spartan_kernel<ZG_SC_LOW_PAIR, 1>), dim3(nb), dim3(256), 0, st, a, v_lo, v_hi, hpb, d_az, d_bz, d_cz, d_out,
+                               partials, sums, counter, flag, seq);
+    }
     prof_end(ZG_PROF_COMBINE, st);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
@@ -2147,9 +2201,9 @@ static int run_sumcheck_enqueue(const uint64_t *d_evals, size_t len, hipStream_t
         static PerDeviceOnce once;
         ZG_HIP(once.run([] {
             return hipFuncSetAttribute(reinterpret_cast<const void *>(sc_tail_run_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)(SC_TAIL_MAX * 32 + 20 * 16));
+                                       (int)(SC_TAIL_MAX * 32 + SC_TAIL_LDS_EXTRA));
         }));
-        hipLaunchKernelGGL(sc_tail_run_kernel, dim3(1), dim3(256), cl * 32 + 20 * 16, st, cur, (uint32_t)cl, ScRunArg{d_res, v, k + 1, 0});
+        hipLaunchKernelGGL(sc_tail_run_kernel, dim3(1), dim3(SC_TAIL_THREADS), cl * 32 + SC_TAIL_LDS_EXTRA, st, cur, (uint32_t)cl, ScRunArg{d_res, v, k + 1, 0});
         ZG_HIP(hipGetLastError());
     }
     std::vector<uint64_t> h(res_words);

@@ -146,16 +146,18 @@ ZG_DEV void psc_first4(F29 (&w)[4], const Fr &lo, const Fr &hi) {
     w[3] = fr29_in(fe_add(f2, d));
 }
 
-// End of a round inside the producing kernel: every block leaves NP pairs in `partials`; the block that arrives last adds them up,
-// writes the 2*NP values to the pinned mailbox and publishes the sequence word. v[]: the block's values, valid in thread 0.
+// End of a round inside the producing kernel: every block leaves NP pairs in `partials` (write-through stores, drained, one relaxed
+// arrival: the hand-off of sc_common.hip.h); the block that arrives last adds them up (sc1 loads, lazy sums), writes the 2*NP values
+// to the pinned mailbox and publishes the sequence word. v[]: the block's values, valid in thread 0.
 template <int NP>
-__device__ __forceinline__ void psc_finish(Fr (&v)[2 * NP], uint4 *sh, uint64_t *partials, uint64_t *sums, uint32_t *counter, uint64_t *flag,
+__device__ __forceinline__ void psc_finish(Fr (&v)[2 * NP], uint4 *sh4, uint64_t *partials, uint64_t *sums, uint32_t *counter, uint64_t *flag,
                                            uint64_t seq) {
-    uint32_t tid = threadIdx.x, nb = gridDim.x;
+    const uint32_t tid = threadIdx.x, nb = gridDim.x, lane = tid & 63u;
+    u32 *sh = reinterpret_cast<u32 *>(sh4);
     if (nb == 1) {
         if (tid == 0) {
 #pragma unroll
-            for (int a = 0; a < 2 * NP; a++) fe_store(sums + 4 * a, v[a]);
+            for (int a = 0; a < 2 * NP; a++) mailbox_store_fr(sums + 4 * a, v[a], flag);
             publish_seq(flag, seq);
         }
         return;
@@ -164,31 +166,32 @@ __device__ __forceinline__ void psc_finish(Fr (&v)[2 * NP], uint4 *sh, uint64_t 
     if (tid == 0) {
         uint64_t *dst = partials + 16 * (size_t)blockIdx.x;
 #pragma unroll
-        for (int a = 0; a < 2 * NP; a++) fe_store(dst + 4 * a, v[a]);  // plain stores: the arrival's release publishes them
-        last = sc_arrive(counter, nb) ? 1u : 0u;  // two-level above 64 workgroups (sc_common.hip.h): ~20-30 ns per same-address arrival
+        for (int a = 0; a < 2 * NP; a++) sc1_store_fr(dst + 4 * a, v[a]);
+        sc_drain_stores();
+        last = sc_arrive(counter, nb) ? 1u : 0u;
     }
     __syncthreads();
     if (!last) return;
-    Fr acc[2 * NP];
+    Acc9 acc[2 * NP];
 #pragma unroll
-    for (int a = 0; a < 2 * NP; a++) acc[a] = Fr::zero();
-    for (uint32_t k = tid; k < nb; k += 256) {
+    for (int a = 0; a < 2 * NP; a++) acc[a] = acc9_zero();
+    for (uint32_t k = tid; k < nb; k += blockDim.x) {
         const uint64_t *src = partials + 16 * (size_t)k;
 #pragma unroll
-        for (int a = 0; a < 2 * NP; a++) {
-            acc[a] = fe_add(acc[a], fe_load<FrParams>(src + 4 * a));
-        }
+        for (int a = 0; a < 2 * NP; a++) acc9_add(acc[a], sc1_load_fr(src + 4 * a));
     }
-    __syncthreads();  // sh is reused
-    block_sum_pair(acc[0], acc[1], sh);
+    Fr t01 = block_sum_pair9(acc[0], acc[1], sh), t23 = Fr::zero();
     if constexpr (NP == 2) {
         __syncthreads();
-        block_sum_pair(acc[2], acc[3], sh);
+        t23 = block_sum_pair9(acc[2], acc[3], sh);
     }
-    if (tid == 0) {  // (sc_arrive re-armed its counters)
-#pragma unroll
-        for (int a = 0; a < 2 * NP; a++) fe_store(sums + 4 * a, acc[a]);
-        publish_seq(flag, seq);
+    if (tid < 64) {  // wave 0: lane SC_LANE_G0 holds values 0 and 2, lane SC_LANE_G1 values 1 and 3
+        if (lane == SC_LANE_G0 || lane == SC_LANE_G1) {
+            const int odd = lane == SC_LANE_G1 ? 1 : 0;
+            mailbox_store_fr(sums + 4 * odd, t01, flag);
+            if constexpr (NP == 2) mailbox_store_fr(sums + 4 * (2 + odd), t23, flag);
+        }
+        if (lane == SC_LANE_G0) publish_seq(flag, seq);  // its s_waitcnt covers the wave's stores, the other lane's included
     }
 }
 
