@@ -347,6 +347,14 @@ ZG_API int zg_fr_bit_split_sums(const uint64_t *vals, const uint64_t *idx128, si
 ZG_API int zg_fr_bit_split_sums_dev(const uint64_t *d_vals, const uint64_t *d_idx128, size_t n, unsigned bit, void *stream, uint64_t sum0[4],
                              uint64_t sum1[4]);
 
+/* Self-test of the round-ending hand-off every sumcheck-family kernel uses (block partials -> the workgroup that arrives last; the
+ * reference's serial sums of src/subprotocols/mod.zig:79-93 have no counterpart): `iters` launches of `blocks` workgroups of `threads`
+ * threads on the library's stream. Each workgroup first reads every partial line with PLAIN loads (its L1 then holds the previous
+ * launch's bytes), waits an uneven, launch-dependent time, and hands in a pattern unique to (launch, workgroup); the last arriver
+ * checks EVERY word it reads against the pattern. With busy != 0 a second stream streams through a 256 MiB buffer meanwhile.
+ * Outputs: words that differed (must be 0) and launches that elected exactly one last arriver (must be iters). */
+ZG_API int zg_selftest_handoff(unsigned blocks, unsigned threads, unsigned iters, int busy, uint64_t *mismatches, uint64_t *completed);
+
 /* runSumcheck (src/subprotocols/mod.zig:302-354) with the WHOLE protocol on the device: the prover's sums and folds
  * (bindFirst order) and the reference's toy verifier (verifyRound / deriveChallenge, :165-243: the deterministic
  * 64-bit mixer, F.fromU64, claim <- p(challenge)) — the verifier step runs at the end of the kernel that produced the

@@ -388,6 +388,52 @@ __global__ void __launch_bounds__(THREADS) sums2_up(const uint64_t *t, size_t ha
     finish2<ARR>(g0, g1, sh, partials, sums, counter);
 }
 
+// diagnostic variants of fold2_gs: MODE 1 = no stores, 2 = nontemporal stores, 3 = no product (v = lo + d), 4 = stores only (no loads: lo = hi = i)
+template <int ARR, int THREADS, int MODE>
+__global__ void __launch_bounds__(THREADS) fold3_gs(const uint64_t *t, size_t half, FrArg r, uint64_t *out, uint64_t *partials, uint64_t *sums,
+                                                    uint32_t *counter) {
+    __shared__ u32 sh[SC_RED_WORDS];
+    Fr rv;
+#pragma unroll
+    for (int i = 0; i < 8; i++) rv.l[i] = r.l[i];
+    const size_t stride = (size_t)gridDim.x * THREADS, quarter = half / 2;
+    size_t i = (size_t)blockIdx.x * THREADS + threadIdx.x;
+    Fr lo = Fr::zero(), hi = Fr::zero();
+    if (i < half && MODE != 4) {
+        lo = fe_load<FrParams>(t + 4 * i);
+        hi = fe_load<FrParams>(t + 4 * (i + half));
+    }
+    FrMul rp = frmul_prepare(rv);
+    Acc9 g0 = acc9_zero(), g1 = acc9_zero();
+    while (i < half) {
+        size_t ni = i + stride;
+        Fr nlo = lo, nhi = hi;
+        if (ni < half && MODE != 4) {
+            nlo = fe_load<FrParams>(t + 4 * ni);
+            nhi = fe_load<FrParams>(t + 4 * (ni + half));
+        }
+        if (MODE == 4) { lo.l[0] = (u32)i; hi.l[1] = (u32)i; }
+        Fr d = fe_sub(hi, lo);
+        Fr v = fe_add(lo, MODE == 3 ? d : frmul_apply(d, rp));
+        if (MODE == 2) {
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 *q = reinterpret_cast<u32x4 *>(out + 4 * i);
+            u32x4 w0 = {v.l[0], v.l[1], v.l[2], v.l[3]}, w1 = {v.l[4], v.l[5], v.l[6], v.l[7]};
+            __builtin_nontemporal_store(w0, q);
+            __builtin_nontemporal_store(w1, q + 1);
+        } else if (MODE != 1) {
+            fe_store(out + 4 * i, v);
+        }
+        const bool second = i >= quarter;
+        acc9_add_if(g0, v, !second);
+        acc9_add_if(g1, v, second);
+        lo = nlo;
+        hi = nhi;
+        i = ni;
+    }
+    finish2<ARR>(g0, g1, sh, partials, sums, counter);
+}
+
 __global__ void finish_only(const uint64_t *partials, uint32_t nb, uint64_t *sums) {
     __shared__ uint4 sh[256 * 4];
     Fr a0 = Fr::zero(), a1 = Fr::zero();
@@ -557,6 +603,26 @@ int main(int argc, char **argv) {
         FOLD2_UP(ARR_SC1_2LVL_ACQ, 1024, 1)
         FOLD2_UP(ARR_SC1_FLAT, 1024, 2)
         FOLD2_UP(ARR_SC1_FLAT, 1024, 4)
+
+#define FOLD3_GS(ARR, TH, MODE, NB)                                                                                              \
+    {                                                                                                                            \
+        unsigned nb = (unsigned)((half + (TH)-1) / (TH));                                                                        \
+        if (nb > (NB)) nb = (NB);                                                                                                \
+        bool keep = c.have_ref; std::vector<uint64_t> keep_sums = c.ref_sums; if (MODE == 3 || MODE == 4) c.have_ref = false;     \
+        run_variant(c, "fold3_gs<" #ARR "," #TH ",mode " #MODE "> cap " #NB, nb, ARR == ARR_NONE,                                \
+                    [&] { hipLaunchKernelGGL((fold3_gs<ARR, TH, MODE>), dim3(nb), dim3(TH), 0, c.st, c.t, half, c.r, c.out, c.partials, c.sums, c.counter); }); \
+        c.have_ref = keep; c.ref_sums = keep_sums;                                                                               \
+    }
+        FOLD3_GS(ARR_SC1_FLAT, 512, 0, 256)
+        FOLD3_GS(ARR_SC1_FLAT, 512, 1, 256)
+        FOLD3_GS(ARR_SC1_FLAT, 512, 2, 256)
+        FOLD3_GS(ARR_SC1_FLAT, 512, 3, 256)
+        FOLD3_GS(ARR_SC1_FLAT, 512, 4, 256)
+        FOLD3_GS(ARR_NONE, 512, 0, 256)
+        FOLD3_GS(ARR_NONE, 512, 1, 256)
+        FOLD3_GS(ARR_NONE, 512, 2, 256)
+        FOLD3_GS(ARR_NONE, 512, 3, 256)
+        FOLD3_GS(ARR_NONE, 512, 4, 256)
         printf("== sums, 2^%d entries, %.1f MB\n", lg, c.n * 32 / 1e6);
         c.have_ref = false;
 #define SUMS_GS(ARR, TH, NB)                                                                                                     \

@@ -108,6 +108,7 @@ pub extern fn zg_sumcheck_bit_round(s: Session, d_idx128: ?[*]const u64, n_idx: 
 pub extern fn zg_sumcheck_bit_bind(s: Session, d_idx128: ?[*]const u64, n_idx: usize, bit: c_uint, r: *const [4]u64, claim: *[4]u64) c_int;
 pub extern fn zg_fr_bit_split_sums(vals: ?[*]const u64, idx128: ?[*]const u64, n: usize, bit: c_uint, sum0: *[4]u64, sum1: *[4]u64) c_int;
 pub extern fn zg_fr_bit_split_sums_dev(d_vals: ?[*]const u64, d_idx128: ?[*]const u64, n: usize, bit: c_uint, stream: ?*anyopaque, sum0: *[4]u64, sum1: *[4]u64) c_int;
+pub extern fn zg_selftest_handoff(blocks: c_uint, threads: c_uint, iters: c_uint, busy: c_int, mismatches: ?[*]u64, completed: ?[*]u64) c_int;
 pub extern fn zg_run_sumcheck_dev(d_evals: ?[*]const u64, len: usize, stream: ?*anyopaque, claim: *[4]u64, rounds: ?[*]u64, challenges: ?[*]u64, final_eval: *[4]u64, result: ?[*]u8) c_int;
 pub extern fn zg_run_sumcheck(evals: ?[*]const u64, len: usize, claim: *[4]u64, rounds: ?[*]u64, challenges: ?[*]u64, final_eval: *[4]u64, result: ?[*]u8) c_int;
 pub extern fn zg_psc_open(tables: ?[*]const ?[*]const u64, k: usize, len: usize, s: *ProductSession) c_int;

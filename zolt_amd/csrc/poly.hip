@@ -204,7 +204,8 @@ ZG_DEV bool fr_eq(const Fr &a, const Fr &b) {
 // Verifier.verifyRound for the round polynomial [g0, g1 - g0]: check, derive the challenge, update the claim.
 // One thread. With `init` the claim is first set to g0 + g1 (runSumcheck's initial sum over the hypercube).
 // `claim_reg` (the LDS tail): the running claim is taken from and left in the caller's registers instead of a dependent global load.
-ZG_DEV Fr sc_verifier_step(const ScRunArg &a, const Fr &g0, const Fr &g1, F29 *ch_pre = nullptr, Fr *claim_reg = nullptr) {
+// `defer_claim`: the claim update g0 + c1 * ch is left to the caller (the single-wave tail folds it with the table: same formula).
+ZG_DEV Fr sc_verifier_step(const ScRunArg &a, const Fr &g0, const Fr &g1, F29 *ch_pre = nullptr, Fr *claim_reg = nullptr, bool defer_claim = false) {
     uint64_t *res = a.res;
     Fr sum = fe_add(g0, g1);
     Fr claim;
@@ -234,23 +235,18 @@ ZG_DEV Fr sc_verifier_step(const ScRunArg &a, const Fr &g0, const Fr &g1, F29 *c
     h ^= h >> 33;
     h *= 0xff51afd7ed558ccdull;
     h ^= h >> 33;
-    Fr hv = Fr::zero();
-    hv.l[0] = (uint32_t)h;
-    hv.l[1] = (uint32_t)(h >> 32);
-    // both products through the carry-free 29-bit-limb multiplier (this single-lane chain is the floor of a small round)
-    F29 r2p;
-#pragma unroll
-    for (int i = 0; i < 9; i++) r2p.l[i] = Fr29::R2PRE[i];
-    Fr ch = fr_mul29(hv, r2p);                   // F.fromU64: h * R^2 * R^-1
+    Fr ch = fr_from_u64_29(h);                   // F.fromU64
     F29 chp = fr29_prescale(ch);                 // also the shared factor of the fold that follows
-    Fr next = fe_add(fr_mul29(c1, chp), g0);     // UniPoly.evaluate by Horner: c1 * x + c0
     if (ch_pre) *ch_pre = chp;
     fe_store(res + 4 + 8 * (size_t)a.round, g0);
     fe_store(res + 8 + 8 * (size_t)a.round, c1);
     fe_store(res + run_off_chal(a.v) + 4 * (size_t)a.round, ch);
-    fe_store(res + run_off_claim(a.v), next);
     fe_store(res + run_off_cur(a.v), ch);
-    if (claim_reg) *claim_reg = next;
+    if (!defer_claim) {
+        Fr next = fe_add(fr_mul29(c1, chp), g0);  // UniPoly.evaluate by Horner: c1 * x + c0
+        fe_store(res + run_off_claim(a.v), next);
+        if (claim_reg) *claim_reg = next;
+    }
     return ch;
 }
 
@@ -299,6 +295,53 @@ __device__ __forceinline__ void store_block_pair(const Acc9 &g0, const Acc9 &g1,
     const uint32_t lane = threadIdx.x & 63u;
     if (threadIdx.x < 64 && (lane == SC_LANE_G0 || lane == SC_LANE_G1))
         fe_store(partials + 8 * (size_t)blockIdx.x + (lane == SC_LANE_G1 ? 4 : 0), tot);
+}
+
+// ---- zg_selftest_handoff: the hand-off of finish_round under the conditions that expose a wrong one (MI355X_MICROARCH.md: "test every
+// hand-off under UNEVEN load, consumer L1-warm, checking every word"). Same primitives, same lanes, same order as finish_round.
+ZG_DEV uint32_t handoff_word(uint32_t epoch, uint32_t block, uint32_t w) { return (epoch * 0x9e3779b1u) ^ (block * 0x85ebca6bu) ^ (w * 0xc2b2ae35u) ^ 0x27d4eb2fu; }
+__global__ void __launch_bounds__(1024) handoff_stress_kernel(uint64_t *partials, uint32_t *counter, uint32_t epoch, uint64_t *res) {
+    const uint32_t tid = threadIdx.x, nb = gridDim.x, lane = tid & 63u;
+    // 1. warm this CU's L1 with the previous launch's partials: plain loads of every line
+    uint64_t warm = 0;
+    for (uint32_t k = tid; k < nb * 8; k += blockDim.x) warm ^= partials[k];
+    if (warm == 0x0123456789abcdefull) res[7] = warm;  // keeps the loads
+    // 2. uneven arrival: a block- and launch-dependent wait of 0 .. ~8 us
+    const uint32_t spins = ((blockIdx.x * 2654435761u + epoch * 40503u) >> 7) % 37u;
+    for (uint32_t k = 0; k < spins * 8; k++) __builtin_amdgcn_s_sleep(32);
+    __syncthreads();
+    // 3. the hand-off, exactly as in finish_round
+    __shared__ uint32_t last;
+    if (tid < 64) {
+        if (lane == SC_LANE_G0 || lane == SC_LANE_G1) {
+            const uint32_t half = lane == SC_LANE_G1 ? 1u : 0u;
+            Fr v;
+#pragma unroll
+            for (int i = 0; i < 8; i++) v.l[i] = handoff_word(epoch, blockIdx.x, 8 * half + i);
+            sc1_store_fr(partials + 8 * (size_t)blockIdx.x + 4 * half, v);
+        }
+        sc_drain_stores();
+        if (lane == SC_LANE_G0) last = sc_arrive(counter, nb) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!last) return;
+    // 4. the last arriver checks every word of every partial
+    uint32_t bad = 0;
+    for (uint32_t k = tid; k < nb; k += blockDim.x) {
+        Fr a = sc1_load_fr(partials + 8 * (size_t)k), b = sc1_load_fr(partials + 8 * (size_t)k + 4);
+#pragma unroll
+        for (int i = 0; i < 8; i++) bad += (a.l[i] != handoff_word(epoch, k, i)) + (b.l[i] != handoff_word(epoch, k, 8 + i));
+    }
+    if (bad) atomicAdd((unsigned long long *)res, (unsigned long long)bad);
+    if (tid == 0) atomicAdd((unsigned long long *)(res + 1), 1ull);
+}
+__global__ void __launch_bounds__(256) handoff_busy_kernel(uint4 *buf, size_t n) {  // read-modify-write stream beside the test
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        uint4 v = buf[i];
+        v.x += 1;
+        buf[i] = v;
+    }
 }
 
 // Sums of a table (a session's first round). SC_SUMS_U pairs per thread are requested before the first addition; 1024-thread
@@ -414,18 +457,39 @@ __global__ void __launch_bounds__(512) sc_fold_kernel(const uint64_t *t, size_t 
 // entries = 128 KiB) every remaining round — fold by the challenge the previous verifier step left, sums of the folded
 // table, verifier step, next challenge — stays inside the workgroup; a round costs a block reduction and two
 // dependent field products instead of a kernel launch. run.round = index of the next verifier step.
+// End of the device-resident protocol: the result block goes to a pinned host buffer straight from the last kernel (write-through
+// system-scope stores, drained, then the flag word) — the host spins on the flag instead of paying a device-to-host copy and a stream
+// synchronisation (~15 us of a 0.24 ms protocol). Called by every thread of ONE block, behind a barrier that follows the block's own
+// stores to `res` (sc1 loads: the verifier lane's stores are then read from L2 whatever this CU's L1 holds).
+__device__ __forceinline__ void run_publish(const uint64_t *res, uint32_t words, uint64_t *host, uint64_t *hflag) {
+    if (!host) return;
+    for (uint32_t k = threadIdx.x; k < words; k += blockDim.x) {
+        uint64_t w = __hip_atomic_load((const sc_gu64 *)res + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store((sc_gu64 *)host + k, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave, before the barrier behind which one lane signals
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store((sc_gu64 *)hflag, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void __launch_bounds__(256) sc_run_publish_kernel(const uint64_t *res, uint32_t words, uint64_t *host, uint64_t *hflag) {
+    run_publish(res, words, host, hflag);
+}
+
 constexpr uint32_t SC_TAIL_MAX = 4096, SC_TAIL_THREADS = 1024;
 constexpr size_t SC_TAIL_LDS_EXTRA = (SC_RED_WORDS + 12) * 4;  // reduction scratch + the prescaled challenge, after the table
-__global__ void __launch_bounds__(SC_TAIL_THREADS) sc_tail_run_kernel(const uint64_t *t, uint32_t len, ScRunArg run) {
+__global__ void __launch_bounds__(SC_TAIL_THREADS) sc_tail_run_kernel(const uint64_t *t, uint32_t len, ScRunArg run, uint32_t res_words,
+                                                                       uint64_t *host, uint64_t *hflag) {
     extern __shared__ uint4 lds_tab[];  // len entries of 2 x uint4, then SC_RED_WORDS u32 of reduction scratch + 9 for the challenge
     u32 *sh = reinterpret_cast<u32 *>(lds_tab + 2 * (size_t)len);
     u32 *sh_rp = sh + SC_RED_WORDS;  // the prescaled challenge (9 limbs), written by the lane that ran the verifier step
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     for (uint32_t i = tid; i < len; i += SC_TAIL_THREADS) fe_store(&lds_tab[2 * i], fe_load<FrParams>(t + 4 * (size_t)i));
     F29 rp = fr29_prescale(fe_load<FrParams>(run.res + run_off_cur(run.v)));
-    Fr claim = fe_load<FrParams>(run.res + run_off_claim(run.v));  // stays in the verifier lane's registers from here on
+    Fr claim = fe_load<FrParams>(run.res + run_off_claim(run.v));  // stays in registers from here on
     __syncthreads();
-    while (len > 1) {
+    // ---- phase A: rounds with at least 64 pairs, all waves. A round = fold in LDS, block reduction, verifier step in lane
+    // SC_LANE_G0 of wave 0 (which keeps the claim), challenge through LDS.
+    while (len > 64) {
         const uint32_t half = len / 2, quarter = half / 2;
         Acc9 g0 = acc9_zero(), g1 = acc9_zero();
         for (uint32_t i = tid; i < half; i += SC_TAIL_THREADS) {
@@ -436,7 +500,6 @@ __global__ void __launch_bounds__(SC_TAIL_THREADS) sc_tail_run_kernel(const uint
             acc9_add_if(g1, v, i >= quarter);
         }
         len = half;
-        if (len == 1) break;
         Fr tot = block_sum_pair9(g0, g1, sh);
         if (tid < 64) {
             Fr second = pair_second_to_first(tot);
@@ -452,12 +515,61 @@ __global__ void __launch_bounds__(SC_TAIL_THREADS) sc_tail_run_kernel(const uint
 #pragma unroll
         for (int i = 0; i < 9; i++) rp.l[i] = sh_rp[i];
     }
-    __syncthreads();
-    if (tid == SC_LANE_G0) {
-        Fr fin = fe_load<FrParams>(&lds_tab[0]);
-        fe_store(run.res + run_off_final(run.v), fin);
-        if (fr_eq(fin, claim)) run.res[run_off_status(run.v)] |= 1;
+    // ---- phase B: at most 32 pairs — wave 0 alone, no barriers, no LDS hops for the sums or the challenge. The claim update
+    // g0 + (g1 - g0) * ch is the fold formula applied to the previous round's pair: lane 63 (never a folding lane here) carries it
+    // through the same instruction stream as the table's pairs, so the verifier lane's serial work is the check, the hash and the
+    // conversion of the challenge only.
+    if (tid < 64) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) claim.l[i] = __shfl(claim.l[i], (int)SC_LANE_G0, 64);  // phase A's verifier lane (every lane holds the loaded one if it never ran)
+        Fr pg0 = Fr::zero(), pg1 = Fr::zero();
+        bool have_pg = false;
+        while (len > 1) {
+            const uint32_t half = len / 2, quarter = half / 2;
+            Fr lo = Fr::zero(), hi = Fr::zero();
+            if (lane < half) {
+                lo = fe_load<FrParams>(&lds_tab[2 * lane]);
+                hi = fe_load<FrParams>(&lds_tab[2 * (lane + half)]);
+            } else if (lane == 63 && have_pg) {
+                lo = pg0;
+                hi = pg1;
+            }
+            Fr v = fe_add(lo, fr_mul29(fe_sub(hi, lo), rp));
+            if (lane < half) fe_store(&lds_tab[2 * lane], v);
+            if (lane == 63 && have_pg) claim = v;
+            len = half;
+            if (len == 1) break;
+            Acc9 g0 = acc9_zero(), g1 = acc9_zero();
+            acc9_add_if(g0, v, lane < quarter);
+            acc9_add_if(g1, v, lane >= quarter && lane < half);
+            wave_sum_pair9(g0, g1);          // lane 31: the g0 total, lane 63: the g1 total
+            const Fr tot = acc9_reduce(g0);
+            Fr G0, G1, cl;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                G0.l[i] = __shfl(tot.l[i], 31, 64);
+                G1.l[i] = __shfl(tot.l[i], 63, 64);
+                cl.l[i] = __shfl(claim.l[i], 63, 64);
+            }
+            F29 cp;
+#pragma unroll
+            for (int i = 0; i < 9; i++) cp.l[i] = 0;
+            if (lane == 31) (void)sc_verifier_step(run, G0, G1, &cp, &cl, true);
+#pragma unroll
+            for (int i = 0; i < 9; i++) rp.l[i] = __shfl(cp.l[i], 31, 64);
+            pg0 = G0;
+            pg1 = G1;
+            have_pg = true;
+            run.round++;
+        }
+        if (lane == 63) {
+            Fr fin = fe_load<FrParams>(&lds_tab[0]);
+            fe_store(run.res + run_off_final(run.v), fin);
+            if (fr_eq(fin, claim)) run.res[run_off_status(run.v)] |= 1;
+        }
     }
+    __syncthreads();  // (waits for the stores above: the workgroup-scope release of the barrier)
+    run_publish(run.res, res_words, host, hflag);
 }
 
 // R1CSInputEvaluator.computeClaimedInputs (src/zkvm/r1cs/evaluation.zig:55-122): out[i] = sum_t eq[t] * rows[t][i] for the k columns of a
@@ -674,22 +786,12 @@ __global__ void __launch_bounds__(256) raf_round_kernel(const uint64_t *t, size_
     Fr bv;
 #pragma unroll
     for (int i = 0; i < 8; i++) bv.l[i] = base.l[i];
-    F29 r2p;
-#pragma unroll
-    for (int i = 0; i < 9; i++) r2p.l[i] = Fr29::R2PRE[i];
-    Fr cp2 = Fr::zero();  // F.fromU64(2 * current_power)
-    cp2.l[0] = (uint32_t)step;
-    cp2.l[1] = (uint32_t)(step >> 32);
-    cp2 = fr_mul29(cp2, r2p);
+    const Fr cp2 = fr_from_u64_29(step);  // F.fromU64(2 * current_power)
     Acc9 g0 = acc9_zero(), g1 = acc9_zero();
     size_t stride = (size_t)gridDim.x * 256;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < half; i += stride) {
         Fr lo = fe_load<FrParams>(t + 8 * i), hi = fe_load<FrParams>(t + 8 * i + 4);
-        uint64_t rem = step * (uint64_t)i;
-        Fr rv = Fr::zero();
-        rv.l[0] = (uint32_t)rem;
-        rv.l[1] = (uint32_t)(rem >> 32);
-        Fr u0 = fe_add(bv, fr_mul29(rv, r2p));  // F.fromU64(rem) = rem * R^2 * R^-1
+        Fr u0 = fe_add(bv, fr_from_u64_29(step * (uint64_t)i));  // base + F.fromU64(rem)
         Fr u2 = fe_add(u0, cp2);
         Fr ra2 = fe_sub(fe_add(hi, hi), lo);
         acc9_add(g0, fr_mul29v(lo, u0));
@@ -923,7 +1025,7 @@ static int eq_spartan_enqueue(const uint64_t *r_host, size_t v, const uint64_t *
     ZG_TRY(eq_args_fill(a, r_host, v, scale_host));
     int v_lo = v < 8 ? (int)v : 8, v_hi = (int)v - v_lo;
     uint32_t n_hi = 1u << v_hi;
-    static const uint32_t nb_cap = env_uint("ZG_SC_SPARTAN_BLOCKS", 512, 1, SC_MAX_BLOCKS);  // two 512-thread workgroups per CU: four waves per SIMD
+    static const uint32_t nb_cap = env_uint("ZG_SC_SPARTAN_BLOCKS", 256, 1, SC_MAX_BLOCKS);  // one 512-thread workgroup per CU: the kernel is bound by its 3 products per entry, and the factor prologue is per workgroup (2^20: 256 -> 51.5 us, 512 -> 55, 1024 -> 67)
     uint32_t hpb = div_up(n_hi, n_hi < nb_cap ? n_hi : nb_cap);
     if (hpb > (uint32_t)EQ_MAX_ROWS) hpb = EQ_MAX_ROWS;
     uint32_t nb = div_up(n_hi, hpb);
@@ -2159,6 +2261,67 @@ static uint32_t ilog2_sz(size_t x) {
     return r;
 }
 
+// pinned result blocks of zg_run_sumcheck (one per call in flight; hipHostMalloc costs more than the protocol, so they are pooled)
+constexpr size_t RUN_PIN_WORDS = 1024;  // result words (17 + 12 v <= 425 for v <= 34), the flag in the last word
+static std::mutex g_runpin_mu;
+static std::vector<uint64_t *> g_runpin_free;
+static uint64_t *runpin_get() {
+    {
+        std::lock_guard<std::mutex> lk(g_runpin_mu);
+        if (!g_runpin_free.empty()) {
+            uint64_t *p = g_runpin_free.back();
+            g_runpin_free.pop_back();
+            return p;
+        }
+    }
+    uint64_t *p = nullptr;
+    if (hipHostMalloc((void **)&p, RUN_PIN_WORDS * 8, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return nullptr;
+    return p;
+}
+static void runpin_put(uint64_t *p) {
+    std::lock_guard<std::mutex> lk(g_runpin_mu);
+    g_runpin_free.push_back(p);
+}
+struct RunPin {
+    uint64_t *p;
+    RunPin() : p(runpin_get()) {}
+    ~RunPin() { if (p) runpin_put(p); }
+};
+// partials + arrival counters of zg_run_sumcheck, pooled per device: zeroed when created, and every kernel leaves its counters at zero
+// (sc_arrive), so a call needs no memset launch in front of its first kernel (2.4 us + a 4 us gap of a 0.19 ms protocol). A block that
+// may hold a half-finished arrival (an error return) is zeroed again before it goes back.
+static std::mutex g_runmisc_mu;
+static std::vector<uint64_t *> g_runmisc_free[ZG_MAX_DEVICES];
+struct RunMisc {
+    uint64_t *p = nullptr;
+    int dev;
+    bool clean = false;
+    RunMisc() : dev(current_device()) {
+        if (dev < 0 || dev >= ZG_MAX_DEVICES) return;
+        {
+            std::lock_guard<std::mutex> lk(g_runmisc_mu);
+            if (!g_runmisc_free[dev].empty()) {
+                p = g_runmisc_free[dev].back();
+                g_runmisc_free[dev].pop_back();
+                return;
+            }
+        }
+        if (hipMalloc((void **)&p, SC_MISC_BYTES) != hipSuccess || hipMemset(p, 0, SC_MISC_BYTES) != hipSuccess) {
+            if (p) (void)hipFree(p);
+            p = nullptr;
+        }
+    }
+    ~RunMisc() {
+        if (!p) return;
+        if (!clean && hipMemset(p, 0, SC_MISC_BYTES) != hipSuccess) {  // (synchronous: the stream has been drained by the SyncGuard)
+            (void)hipFree(p);
+            return;
+        }
+        std::lock_guard<std::mutex> lk(g_runmisc_mu);
+        g_runmisc_free[dev].push_back(p);
+    }
+};
+
 static int run_sumcheck_enqueue(const uint64_t *d_evals, size_t len, hipStream_t st, uint64_t claim[4], uint64_t *rounds,
                                 uint64_t *challenges, uint64_t final_eval[4], uint8_t *result) {
     if (!d_evals || len == 0 || (len & (len - 1)) || !claim || !final_eval || !result) {
@@ -2179,11 +2342,19 @@ static int run_sumcheck_enqueue(const uint64_t *d_evals, size_t len, hipStream_t
         *result = 1;
         return ZG_OK;
     }
-    Scratch s_a(len / 2 * 32), s_b((len / 4 ? len / 4 : 1) * 32), s_res(res_words * 8), s_misc(SC_MISC_BYTES);
+    Scratch s_a(len / 2 * 32), s_b((len / 4 ? len / 4 : 1) * 32), s_res(res_words * 8);
+    RunMisc s_misc;  // (declared before the SyncGuard: destroyed after it has drained the stream)
+    RunPin pin;
     if (!s_a.p || !s_b.p || !s_res.p || !s_misc.p) return ZG_ERR_NOMEM;
-    uint64_t *d_res = s_res.as<uint64_t>(), *d_misc = s_misc.as<uint64_t>();
+    if (!pin.p || res_words >= RUN_PIN_WORDS) {
+        set_error("zg_run_sumcheck: no pinned result block");
+        return ZG_ERR_NOMEM;
+    }
+    SyncGuard sync(st);  // the scratch buffers and the pinned block go back to their pools only after the work on st has drained
+    uint64_t *d_res = s_res.as<uint64_t>(), *d_misc = s_misc.p;
     uint64_t *buf[2] = {s_a.as<uint64_t>(), s_b.as<uint64_t>()};
-    ZG_HIP(hipMemsetAsync(d_misc + 8 * (size_t)SC_MAX_BLOCKS, 0, SC_COUNTER_BYTES, st));
+    uint64_t *h = pin.p, *hflag = pin.p + RUN_PIN_WORDS - 1;
+    __atomic_store_n(hflag, 0ull, __ATOMIC_RELEASE);
     // round 0's sums: also fixes the claim; every later round's sums come out of the fold that precedes it
     ZG_TRY(launch_sums(ZG_SC_HIGH_HALF, d_evals, len, d_misc, d_misc + SC_SUMS_OFF, st, nullptr, 0, ScRunArg{d_res, v, 0, 1}));
     const uint64_t *cur = d_evals;
@@ -2197,18 +2368,36 @@ static int run_sumcheck_enqueue(const uint64_t *d_evals, size_t len, hipStream_t
         cur = nxt;
         cl /= 2;
     }
-    if (cl > 1) {  // the remaining rounds in one launch, table in LDS
+    if (cl > 1) {  // the remaining rounds in one launch, table in LDS; it also hands the result block to the host
         static PerDeviceOnce once;
         ZG_HIP(once.run([] {
             return hipFuncSetAttribute(reinterpret_cast<const void *>(sc_tail_run_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)(SC_TAIL_MAX * 32 + SC_TAIL_LDS_EXTRA));
         }));
-        hipLaunchKernelGGL(sc_tail_run_kernel, dim3(1), dim3(SC_TAIL_THREADS), cl * 32 + SC_TAIL_LDS_EXTRA, st, cur, (uint32_t)cl, ScRunArg{d_res, v, k + 1, 0});
-        ZG_HIP(hipGetLastError());
+        hipLaunchKernelGGL(sc_tail_run_kernel, dim3(1), dim3(SC_TAIL_THREADS), cl * 32 + SC_TAIL_LDS_EXTRA, st, cur, (uint32_t)cl,
+                           ScRunArg{d_res, v, k + 1, 0}, (uint32_t)res_words, h, hflag);
+    } else {
+        hipLaunchKernelGGL(sc_run_publish_kernel, dim3(1), dim3(256), 0, st, d_res, (uint32_t)res_words, h, hflag);
     }
-    std::vector<uint64_t> h(res_words);
-    ZG_HIP(hipMemcpyAsync(h.data(), d_res, res_words * 8, hipMemcpyDeviceToHost, st));
-    ZG_HIP(hipStreamSynchronize(st));
+    ZG_HIP(hipGetLastError());
+    {  // spin on the flag; a stream synchronisation if it does not arrive promptly (or an error stopped the stream)
+        bool got = false;
+        for (uint64_t spin = 0; spin < (1ull << 22); spin++) {
+            if (__atomic_load_n(hflag, __ATOMIC_ACQUIRE) == 1) { got = true; break; }
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        if (!got) {
+            ZG_HIP(hipStreamSynchronize(st));
+            if (__atomic_load_n(hflag, __ATOMIC_ACQUIRE) != 1) {
+                set_error("zg_run_sumcheck: the result block was not published");
+                return ZG_ERR_HIP;
+            }
+        }
+        sync.dismiss();  // the flag is the last thing the last kernel writes: nothing enqueued here touches the scratch buffers any more
+        s_misc.clean = true;  // every launch ran to its end: all counters are back at zero
+    }
     for (int i = 0; i < 4; i++) {
         claim[i] = h[i];
         final_eval[i] = h[4 + 12 * (size_t)v + i];
@@ -2221,6 +2410,40 @@ static int run_sumcheck_enqueue(const uint64_t *d_evals, size_t len, hipStream_t
         set_error("zg_run_sumcheck: SumcheckVerificationFailed in round " + std::to_string((status >> 8) - 1));
         return ZG_ERR_VERIFY;
     }
+    return ZG_OK;
+}
+
+int zg_selftest_handoff(unsigned blocks, unsigned threads, unsigned iters, int busy, uint64_t *mismatches, uint64_t *completed) {
+    ZG_INIT();
+    if (!mismatches || !completed || blocks < 2 || blocks > SC_MAX_BLOCKS || threads < 64 || threads > 1024 || (threads & 63u)) {
+        set_error("zg_selftest_handoff: blocks in [2, 2048], threads a multiple of 64 in [64, 1024]");
+        return ZG_ERR_INVALID;
+    }
+    hipStream_t st = lib_stream();
+    Scratch s_misc(SC_MISC_BYTES), s_res(64), s_busy(busy ? (size_t)256 << 20 : 64);
+    if (!s_misc.p || !s_res.p || !s_busy.p) return ZG_ERR_NOMEM;
+    SyncGuard sync(st);
+    uint64_t *d_misc = s_misc.as<uint64_t>(), *d_res = s_res.as<uint64_t>();
+    ZG_HIP(hipMemsetAsync(d_misc, 0, SC_MISC_BYTES, st));
+    ZG_HIP(hipMemsetAsync(d_res, 0, 64, st));
+    hipStream_t st2 = nullptr;
+    if (busy) ZG_HIP(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
+    uint32_t *counter = reinterpret_cast<uint32_t *>(d_misc + 8 * (size_t)SC_MAX_BLOCKS);
+    for (unsigned it = 0; it < iters; it++) {
+        if (busy && (it % 4) == 0) hipLaunchKernelGGL(handoff_busy_kernel, dim3(1024), dim3(256), 0, st2, s_busy.as<uint4>(), ((size_t)256 << 20) / 16);
+        hipLaunchKernelGGL(handoff_stress_kernel, dim3(blocks), dim3(threads), 0, st, d_misc, counter, it + 1, d_res);
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (st2) {
+        (void)hipStreamSynchronize(st2);
+        (void)hipStreamDestroy(st2);
+    }
+    ZG_HIP(e);
+    uint64_t h[2];
+    ZG_HIP(hipMemcpy(h, d_res, 16, hipMemcpyDeviceToHost));
+    *mismatches = h[0];
+    *completed = h[1];
     return ZG_OK;
 }
 
@@ -2624,5 +2847,15 @@ void sc_shutdown() {  // zg_shutdown: drop the pooled sessions (buffers, pinned 
         sc_free(s);
     }
     g_pool.clear();
+    std::lock_guard<std::mutex> lk2(g_runpin_mu);
+    for (uint64_t *p : g_runpin_free) (void)hipHostFree(p);
+    g_runpin_free.clear();
+    std::lock_guard<std::mutex> lk3(g_runmisc_mu);
+    for (int d = 0; d < ZG_MAX_DEVICES; d++) {
+        if (g_runmisc_free[d].empty()) continue;
+        DeviceGuard dg(d);
+        for (uint64_t *p : g_runmisc_free[d]) (void)hipFree(p);
+        g_runmisc_free[d].clear();
+    }
 }
 }  // namespace zg

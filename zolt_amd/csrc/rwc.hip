@@ -43,16 +43,7 @@ ZG_DEV Fr rwc_arg(const FrArg &a) {
     for (int i = 0; i < 8; i++) r.l[i] = a.l[i];
     return r;
 }
-ZG_DEV Fr fr_from_u64_dev(uint64_t u) {  // F.fromU64
-    if (u == 0) return Fr::zero();
-    Fr v = Fr::zero();
-    v.l[0] = (uint32_t)u;
-    v.l[1] = (uint32_t)(u >> 32);
-    F29 r2p;
-#pragma unroll
-    for (int i = 0; i < 9; i++) r2p.l[i] = Fr29::R2PRE[i];
-    return fr_mul29(v, r2p);
-}
+ZG_DEV Fr fr_from_u64_dev(uint64_t u) { return fr_from_u64_29(u); }  // F.fromU64 (short product, fp29.hip.h)
 
 // ra_coeff = 1, val_coeff = F.fromU64(.) of the initial entries (:300-330)
 __global__ void __launch_bounds__(256) rwc_init_kernel(const uint64_t *val_u64, uint32_t n, uint64_t *ra, uint64_t *val) {

@@ -41,7 +41,7 @@ SYMBOLS = [
     "zg_fr_spartan_combine", "zg_fr_spartan_combine_dev",
     "zg_sumcheck_open", "zg_sumcheck_open_dev", "zg_sumcheck_round_sums", "zg_sumcheck_bind",
     "zg_sumcheck_len", "zg_sumcheck_final", "zg_sumcheck_read", "zg_sumcheck_gather", "zg_sumcheck_close",
-    "zg_sumcheck_round_sums_dev", "zg_sumcheck_read_dev", "zg_sumcheck_raf_round", "zg_sumcheck_bit_round", "zg_sumcheck_bit_bind", "zg_fr_bit_split_sums", "zg_fr_bit_split_sums_dev",
+    "zg_sumcheck_round_sums_dev", "zg_sumcheck_read_dev", "zg_sumcheck_raf_round", "zg_sumcheck_bit_round", "zg_sumcheck_bit_bind", "zg_fr_bit_split_sums", "zg_fr_bit_split_sums_dev", "zg_selftest_handoff",
     "zg_run_sumcheck", "zg_run_sumcheck_dev", "zg_sumcheck_open_spartan_dev",
     "zg_psc_open", "zg_psc_open_dev", "zg_psc_len", "zg_psc_tables", "zg_psc_round_evals", "zg_psc_round_expr", "zg_psc_set_points", "zg_psc_round_gruen", "zg_psc_bind", "zg_psc_read", "zg_psc_table_dev", "zg_psc_gather",
     "zg_psc_final", "zg_psc_close",
@@ -675,6 +675,15 @@ def fr_bit_split_sums_dev(d_vals, d_idx128, n, bit, stream=0):
     _chk(_lib.zg_fr_bit_split_sums_dev(_d(d_vals), _d(d_idx128), C.c_size_t(n), C.c_uint(bit), _d(stream), _h(s0), _h(s1)),
          "zg_fr_bit_split_sums_dev")
     return s0, s1
+
+
+def selftest_handoff(blocks, threads=512, iters=200, busy=True):
+    """zg_selftest_handoff: (words that differed, launches that elected exactly one last arriver)"""
+    bad = C.c_uint64(0)
+    done = C.c_uint64(0)
+    _chk(_lib.zg_selftest_handoff(C.c_uint(blocks), C.c_uint(threads), C.c_uint(iters), C.c_int(1 if busy else 0), C.byref(bad), C.byref(done)),
+         "zg_selftest_handoff")
+    return int(bad.value), int(done.value)
 
 
 class SumcheckVerificationFailed(RuntimeError):
