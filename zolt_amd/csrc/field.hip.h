@@ -95,17 +95,17 @@ ZG_DEV void fe_store(void *p, const Fe<P> &v) {
     q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
 }
 
+// The carry chains below are written with __builtin_addc / __builtin_subc: they compile to one v_addc_co_u32 / v_subb_co_u32 per limb.
+// The round-3 form ((u64)a + b + carry, carry = t >> 32) was compiled as 64-bit arithmetic — a v_sub_co, a v_subb_co of the high half,
+// a sign extension, a v_lshl_add_u64 and a register copy per limb: ~80 instructions for fe_sub instead of 24 (sc_fold's inner loop,
+// tools/exp, round 4).
 // r = a - MOD if a >= MOD else a   (a < 2*MOD)
 template <class P>
 ZG_DEV Fe<P> fe_reduce_once(const Fe<P> &a) {
     Fe<P> d;
     u32 borrow = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        u64 s = (u64)a.l[i] - P::MOD[i] - borrow;
-        d.l[i] = (u32)s;
-        borrow = (u32)(s >> 32) & 1u;
-    }
+    for (int i = 0; i < 8; i++) d.l[i] = __builtin_subc(a.l[i], P::MOD[i], borrow, &borrow);
     Fe<P> r;
 #pragma unroll
     for (int i = 0; i < 8; i++) r.l[i] = borrow ? a.l[i] : d.l[i];
@@ -118,11 +118,7 @@ ZG_DEV Fe<P> fe_add(const Fe<P> &a, const Fe<P> &b) {
     Fe<P> s;
     u32 carry = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        u64 t = (u64)a.l[i] + b.l[i] + carry;
-        s.l[i] = (u32)t;
-        carry = (u32)(t >> 32);
-    }
+    for (int i = 0; i < 8; i++) s.l[i] = __builtin_addc(a.l[i], b.l[i], carry, &carry);
     return fe_reduce_once(s);
 }
 
@@ -132,19 +128,11 @@ ZG_DEV Fe<P> fe_sub(const Fe<P> &a, const Fe<P> &b) {
     Fe<P> d;
     u32 borrow = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        u64 s = (u64)a.l[i] - b.l[i] - borrow;
-        d.l[i] = (u32)s;
-        borrow = (u32)(s >> 32) & 1u;
-    }
-    u32 mask = 0u - borrow;
+    for (int i = 0; i < 8; i++) d.l[i] = __builtin_subc(a.l[i], b.l[i], borrow, &borrow);
+    const u32 mask = 0u - borrow;
     u32 carry = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        u64 t = (u64)d.l[i] + (P::MOD[i] & mask) + carry;
-        d.l[i] = (u32)t;
-        carry = (u32)(t >> 32);
-    }
+    for (int i = 0; i < 8; i++) d.l[i] = __builtin_addc(d.l[i], P::MOD[i] & mask, carry, &carry);
     return d;
 }
 
