@@ -161,6 +161,12 @@ ZG_API int zg_g1_combine_partials_dev(const uint64_t *d_partials_jac /* k*12 */,
 /* asynchronous form: result (8 limbs) and flag land in DEVICE memory, ordered on `stream` */
 ZG_API int zg_g1_combine_partials_dev_async(const uint64_t *d_partials_jac /* k*12 */, size_t k, void *stream, uint64_t *d_out_xy,
                                      uint8_t *d_out_inf);
+/* The same combine for a BATCH of m MSMs behind ONE exchange (ParallelBatchMSM's per-thread partial lists, src/msm/mod.zig:683-748): the
+ * gathered buffer holds, for every rank r, that rank's m records back to back at d_partials_jac + r * rank_stride (u64 words,
+ * rank_stride >= 12 * m — the layout of one all-gather of m * 96 bytes per rank); result j (xy[8] + flag word, 9 words) goes to
+ * d_out9 + 9 * j. One launch of m workgroups, stream-ordered. */
+ZG_API int zg_g1_combine_partials_batch_dev_async(const uint64_t *d_partials_jac, size_t ranks, size_t rank_stride, size_t m, void *stream,
+                                           uint64_t *d_out9);
 /* AffinePoint.isOnCurve (src/msm/mod.zig:106-115) for n points: out[i] = 1 iff infinity or y^2 == x^3 + 3
  * (what parseG1Uncompressed checks per SRS point, src/poly/commitment/srs.zig:93-96). */
 ZG_API int zg_g1_is_on_curve_batch(const uint64_t *xy, const uint8_t *inf, size_t n, uint8_t *out);

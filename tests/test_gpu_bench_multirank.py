@@ -28,6 +28,7 @@ def test_bench_two_ranks_over_gloo_takes_every_multi_rank_branch():
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "strong"
     assert d["metric"] == "BN254 G1 MSM/sec" and d["unit"] == "MSM/s" and d["value"] > 0
     assert d["config"]["points"] == 1 << 20 and d["config"]["points_per_gpu"] == 1 << 19
+    assert d["config"]["collective_ranks"] == {"backend": "gloo", "ranks": 2}  # the all-reduce census of the group the partials travel on
     ex = d["extra"]
     assert ex["msm_2^22_sharded"]["points_per_gpu"] == 1 << 21 and ex["msm_2^22_sharded"]["value"] > 0
     assert ex["sumcheck_v20_sharded"]["ranks"] == 2 and ex["sumcheck_v20_sharded"]["rounds_per_s"] > 0

@@ -655,6 +655,47 @@ def test_point_slices_with_slice_local_references(zl, ob, monkeypatch):
         b.free()
 
 
+def test_sub_range_on_a_handle_whose_slices_alone_sort_in_two_passes(zl, ob):
+    """2^23 points with 17-bit windows: a table row index (15 * 2^23 rows) leaves the handle's own plan no room for the two-pass sort's
+    fine key bits and 2^16 buckets do not fit the LDS sort, so unsliced launch sets sort through global atomics — while the point
+    slices of a full-size MSM sort in two passes on slice-local references and own the per-block histogram buffer. A short sub-range
+    (HyperKZG.open's prefixes, MSM.compute on a slice of the SRS) must take the global path, not mistake that buffer for the LDS sort's
+    (round-3 advisor finding: a division by zero in the launch geometry). Closed form: bases (i+1) G, so MSM = (sum s_i (i+1)) G."""
+    from zolt_amd import api
+    n = 1 << 23
+    g = api.generator()
+    ks = np.zeros((n, 4), dtype=np.uint64)
+    ks[:, 0] = np.arange(1, n + 1, dtype=np.uint64)
+    bases, _ = zl.g1_scalar_mul_batch(np.repeat(g[None, :], n, axis=0), np.zeros(n, dtype=np.uint8), zl.field_op(zl.FR, zl.OP_TO_MONT, ks))
+    rng = np.random.default_rng(2323)
+    lo = rng.integers(0, 1 << 30, size=n, dtype=np.uint64)
+    hi = rng.integers(0, 1 << 30, size=n, dtype=np.uint64)
+    raw = np.zeros((n, 4), dtype=np.uint64)
+    raw[:, 0] = lo
+    raw[:, 2] = hi  # s_i = lo_i + 2^128 hi_i: low and high windows both in use
+    sc = zl.field_op(zl.FR, zl.OP_TO_MONT, raw)
+    idx = np.arange(1, n + 1, dtype=np.uint64)
+
+    def closed(a, b, first):  # (sum (lo_i + 2^128 hi_i) * (first + i)) mod r over the given rows, exact in Python integers
+        w = idx[:a.shape[0]] + np.uint64(first - 1)
+        s_lo = sum(int(x) for x in (a * w).reshape(-1, 512).sum(axis=1)) if a.shape[0] % 512 == 0 else sum(int(x) * int(y) for x, y in zip(a, w))
+        s_hi = sum(int(x) for x in (b * w).reshape(-1, 512).sum(axis=1)) if b.shape[0] % 512 == 0 else sum(int(x) * int(y) for x, y in zip(b, w))
+        return (s_lo + (s_hi << 128)) % api.R_MOD
+
+    b = zl.Bases.upload(bases, window_bits=17)
+    try:
+        assert b.plan()[0] == 17
+        want = api.MSM.scalarMul(g, api.fr_from_int(closed(lo, hi, 1)))
+        got = b.msm(sc)
+        assert got[1] == want[1] and np.array_equal(got[0], want[0])
+        m, off = 100352, 1000  # 196 * 512 points, far below two slices
+        wsub = api.MSM.scalarMul(g, api.fr_from_int(closed(lo[:m], hi[:m], off + 1)))
+        gsub = b.msm(sc[:m], off=off, n=m)
+        assert gsub[1] == wsub[1] and np.array_equal(gsub[0], wsub[0])
+    finally:
+        b.free()
+
+
 @pytest.mark.parametrize("span_pts", [700, 1300, 2600])
 def test_device_scalar_path_in_point_slices(zl, ob, gm, span_pts, monkeypatch):
     """A launch set whose table rows would span more than ZG_MSM_TABLE_SPAN_MB is cut into slices of consecutive points

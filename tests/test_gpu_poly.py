@@ -409,6 +409,43 @@ def test_low_pair_session_every_table(zl, ob):
     s.close()
 
 
+def test_full_size_low_pair_session_from_spartan_inputs(zl, ob):
+    """BASELINE config 3 mode (ii) at FULL size (v = 20): the fused eq x (Az*Bz - Cz) open (zg_sumcheck_open_spartan_dev:
+    src/zkvm/spartan/mod.zig:182-206 + Sumcheck.Prover.init), then 20 LowToHigh rounds with given challenges (the reference's 128-bit
+    challenge shape on odd rounds, full-width elements on even ones: both multiplier forms). Every round's (even, odd) pair equals the
+    oracle's; SHA-256 of the whole table equals the oracle's after rounds 0, 1, 2, 10 and at the end (the oracle folds on one core:
+    ~1 s for the first fold)."""
+    import ctypes as C
+    v = 20
+    n = 1 << v
+    r = _rand(ob, 0x4C4F5750, v)
+    az, bz, cz = (_rand(ob, 0x4C4F5751 + k, n) for k in range(3))
+    cur = ob.fr_spartan_combine(ob.fr_eq_table(r), az, bz, cz)
+    d = []
+    for t in (az, bz, cz):
+        p = C.c_void_p()
+        assert zl._lib.zg_dev_alloc(C.c_size_t(n * 32), C.byref(p)) == 0
+        assert zl._lib.zg_memcpy_h2d(p, np.ascontiguousarray(t).ctypes.data_as(C.c_void_p), C.c_size_t(n * 32)) == 0
+        d.append(p)
+    s = zl.SumcheckSession.open_spartan_dev(r, d[0].value, d[1].value, d[2].value, layout=zl.SC_LOW_PAIR)
+    assert len(s) == n
+    assert hashlib.sha256(s.read().tobytes()).digest() == hashlib.sha256(cur.tobytes()).digest(), "table after the fused open"
+    chals = _rand(ob, 0x4C4F5760, v)
+    chals[1::2, :2] = 0  # MontU128Challenge: the stored Montgomery element is [0, 0, lo, hi]
+    for k in range(v):
+        g0, g1 = s.round_sums()
+        w0, w1 = ob.fr_sum_even_odd(cur)
+        assert np.array_equal(g0, w0) and np.array_equal(g1, w1), k
+        s.bind(chals[k])
+        cur = ob.fr_bind_low(cur, chals[k])
+        if k in (0, 1, 2, 10, v - 1):
+            assert hashlib.sha256(s.read().tobytes()).digest() == hashlib.sha256(cur.tobytes()).digest(), k
+    assert np.array_equal(s.final(), cur[0])
+    s.close()
+    for p in d:
+        zl._lib.zg_dev_free(p)
+
+
 def test_full_size_sumcheck_properties(zl, ob):
     """BASELINE config 3 at full size (v = 20): size-independent checks — every round satisfies
     g0 + g1 == previous claim evaluated at the challenge, and the final evaluation equals the

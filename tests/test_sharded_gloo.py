@@ -38,6 +38,12 @@ class OracleShardBackend:
             acc = ob.g1_jac_add(acc, r)
         return ob.g1_jac_to_affine(acc)
 
+    def partial_batch(self, scalar_sets):
+        return torch.stack([self.partial(sc) for sc in scalar_sets])
+
+    def combine_batch(self, gathered):  # [world, m, 12]
+        return [self.combine(gathered[:, j, :].contiguous()) for j in range(gathered.shape[1])]
+
 
 def _worker(rank, world, port, n, q):
     sys.path.insert(0, ROOT)
@@ -54,22 +60,29 @@ def _worker(rank, world, port, n, q):
     want, winf = ob.msm_g1_parallel(gm, None, sc, world)   # the reference's ParallelMSM with T = world
     full, finf = ob.msm_g1(gm, None, sc)
     ok = inf == winf == finf and np.array_equal(xy, want) and np.array_equal(xy, full)
+    # the batched form: m scalar vectors, ONE all-gather of m * 96 bytes per rank, m combines
+    vecs = [ob.f_to_mont(ob.FR, U.random_raw256(4300 + j, n)) for j in range(3)]
+    res = sharded.compute_batch([torch.from_numpy(v[s:e].view(np.int64).copy()) for v in vecs])
+    for v, (bxy, binf) in zip(vecs, res):
+        wxy, winf2 = ob.msm_g1(gm, None, v)
+        ok = ok and binf == winf2 and np.array_equal(bxy, wxy)
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n", [5000, 3])
-def test_sharded_msm_two_ranks_gloo(n):
+@pytest.mark.parametrize("n,world", [(5000, 2), (3, 2), (2000, 4)])
+def test_sharded_msm_gloo(n, world):
+    """single and batched (one exchange for m MSMs) sharded MSM over world-size 2 and 4"""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in procs)
+    res = sorted(q.get(timeout=180) for _ in procs)
     for p in procs:
         p.join(timeout=60)
-    assert res == [(0, True), (1, True)]
+    assert res == [(r, True) for r in range(world)]

@@ -63,6 +63,7 @@ pub extern fn zg_msm_g1_partial_dev(b: Bases, off: usize, n: usize, d_scalars_mo
 pub extern fn zg_msm_g1_partial_fast_dev(b: Bases, off: usize, n: usize, d_scalars_mont: ?[*]const u64, stream: ?*anyopaque, d_out_jac: ?[*]u64) c_int;
 pub extern fn zg_g1_combine_partials_dev(d_partials_jac: ?[*]const u64, k: usize, stream: ?*anyopaque, out_xy: *[8]u64, out_inf: ?[*]u8) c_int;
 pub extern fn zg_g1_combine_partials_dev_async(d_partials_jac: ?[*]const u64, k: usize, stream: ?*anyopaque, d_out_xy: ?[*]u64, d_out_inf: ?[*]u8) c_int;
+pub extern fn zg_g1_combine_partials_batch_dev_async(d_partials_jac: ?[*]const u64, ranks: usize, rank_stride: usize, m: usize, stream: ?*anyopaque, d_out9: ?[*]u64) c_int;
 pub extern fn zg_g1_is_on_curve_batch(xy: ?[*]const u64, inf: ?[*]const u8, n: usize, out: ?[*]u8) c_int;
 pub extern fn zg_g1_affine_add_batch(a_xy: ?[*]const u64, a_inf: ?[*]const u8, b_xy: ?[*]const u64, b_inf: ?[*]const u8, n: usize, out_xy: ?[*]u64, out_inf: ?[*]u8) c_int;
 pub extern fn zg_g1_scalar_mul_batch(xy: ?[*]const u64, inf: ?[*]const u8, scalars_mont: ?[*]const u64, n: usize, out_xy: ?[*]u64, out_inf: ?[*]u8) c_int;

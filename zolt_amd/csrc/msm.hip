@@ -1395,6 +1395,20 @@ static int make_plan(size_t n, const zg_msm_config *cfg, MsmPlan &p, size_t batc
     p.NCB = 0;
     int c = cfg ? cfg->window_bits : 0;
     if (c == 0) c = env_int("ZG_MSM_WINDOW_BITS", 0);
+    int L = cfg ? cfg->precompute_levels : 0;
+    if (L == 0) L = env_int("ZG_MSM_PRECOMPUTE", 0);
+    // a handle that will serve only a few MSMs (MSM.compute on a temporary slice) skips the table: its build costs about as
+    // much as twenty MSMs save (2^20 points: 41 ms against 2 ms per MSM)
+    if (L == 0 && cfg && cfg->expected_uses > 0 && cfg->expected_uses < 16) L = 1;
+    if (c == 0 && L == 1) {
+        // table-less plan (one bucket set per window): the windows cost buckets, not table rows, so the choice differs from the table
+        // plan's. Measured (tools/exp/run_noprecomp_sweep.sh, profiles/r4_noprecomp_sweep.txt): at 2^20 points c = 15 runs 559 MSM/s
+        // pipelined / 3.0 ms alone, c = 13 553 / 3.3, and the table plan's c = 16 347 / 4.4 (2^19 buckets overflow the LDS sort:
+        // digits 0.03 -> 0.64 ms, sort 0.26 -> 0.93); at 2^16 points c = 13 is 0.55 / 1.42 ms against 0.90 / 1.63 for c = 16.
+        // What remains alone is the window combine: (W - 1) c = 240 dependent doublings (msm_groups_kernel, 0.86 ms) that a table
+        // would have removed and nothing else can.
+        c = n >= ((size_t)1 << 19) ? 15 : (n >= 8192 ? 13 : (n >= 2048 ? 8 : (n >= 64 ? 7 : 5)));
+    }
     if (c == 0) {
         // measured on MI355X (tools/bench_window.py): window sizes whose last window covers only a couple of the 254
         // scalar bits (c = 9, 12, 14) waste a window and pile its digits into a handful of buckets; 16 wins from
@@ -1411,11 +1425,6 @@ static int make_plan(size_t n, const zg_msm_config *cfg, MsmPlan &p, size_t batc
     }
     p.c = c;
     p.W = (255 + c - 1) / c;
-    int L = cfg ? cfg->precompute_levels : 0;
-    if (L == 0) L = env_int("ZG_MSM_PRECOMPUTE", 0);
-    // a handle that will serve only a few MSMs (MSM.compute on a temporary slice) skips the table: its build costs about as
-    // much as twenty MSMs save (2^20 points: 41 ms against 2 ms per MSM)
-    if (L == 0 && cfg && cfg->expected_uses > 0 && cfg->expected_uses < 16) L = 1;
     if (L == 0) L = p.W;  // 288 GB of HBM: full precompute is 64*W bytes per base
     if (L < 1) L = 1;
     if (L > p.W) L = p.W;
@@ -1926,7 +1935,7 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
         hipLaunchKernelGGL(msm_scan_b_kernel, dim3(tiles), dim3(1024), 0, st, ln.d_hist, p.NK, ln.d_scan_tmp, ln.d_scan_tmp + p.NK,
                            ln.d_scan_tmp + 2 * (size_t)p.NK, sv.starts, sv.nzrank, sv.nzlist, reinterpret_cast<uint32_t *>(sv.state),
                            sv.state ? state_words(p.NT, p.NK) : 0u);
-    } else if (ln.d_blockhist) {
+    } else if (nblk_cap && ln.d_blockhist) {  // the handle's own plan sorts in LDS (a non-null d_blockhist alone may belong to a point slice's two-pass plan)
         uint32_t nblk = nblk_cap;
         while (nblk > 1 && (size_t)(nblk - 1) * 1024 >= n) nblk--;  // no empty blocks for short sub-range MSMs
         uint32_t per_block = (uint32_t)((n + nblk - 1) / nblk);
@@ -2564,6 +2573,15 @@ int zg_g1_combine_partials_dev_async(const uint64_t *d_partials, size_t k, void 
     hipLaunchKernelGGL(msm_combine_kernel, dim3(1), dim3(64), 0, pick_stream(stream), d_partials, (uint32_t)k, 12u, d_out_xy, d_out_inf, 0u, 0u);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
+}
+
+int zg_g1_combine_partials_batch_dev_async(const uint64_t *d_partials, size_t ranks, size_t rank_stride, size_t m, void *stream, uint64_t *d_out9) {
+    ZG_INIT();
+    if ((m && (!d_partials || !d_out9)) || ranks == 0 || rank_stride < 12 * m || ranks > 0xffffffffu || rank_stride > 0xffffffffu) {
+        set_error("zg_g1_combine_partials_batch_dev_async: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    return msm_combine_batch_enqueue(d_partials, ranks, rank_stride, m, pick_stream(stream), d_out9);
 }
 
 int zg_g1_is_on_curve_batch(const uint64_t *xy, const uint8_t *inf, size_t n, uint8_t *out) {

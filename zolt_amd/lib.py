@@ -35,7 +35,7 @@ SYMBOLS = [
     "zg_sumcheck_bind_sharded", "zg_sumcheck_final_sharded", "zg_sumcheck_close_sharded",
     "zg_g1_bases_upload", "zg_g1_bases_upload_dev", "zg_g1_bases_free", "zg_g1_bases_len", "zg_g1_bases_plan",
     "zg_msm_g1", "zg_msm_g1_dev", "zg_msm_g1_dev_async", "zg_msm_g1_batch", "zg_msm_g1_batch_dev", "zg_msm_g1_partial_dev", "zg_msm_g1_partial_fast_dev",
-    "zg_g1_combine_partials_dev", "zg_g1_combine_partials_dev_async", "zg_g1_is_on_curve_batch", "zg_g1_scalar_mul_batch", "zg_g1_fixed_base_mul_batch",
+    "zg_g1_combine_partials_dev", "zg_g1_combine_partials_dev_async", "zg_g1_combine_partials_batch_dev_async", "zg_g1_is_on_curve_batch", "zg_g1_scalar_mul_batch", "zg_g1_fixed_base_mul_batch",
     "zg_hyperkzg_open", "zg_hyperkzg_open_dev", "zg_hyperkzg_batch_open",
     "zg_fr_dense_evaluate", "zg_fr_eq_table", "zg_fr_eq_table_dev", "zg_fr_eq_prefix_tables", "zg_fr_eq_prefix_tables_dev", "zg_fr_rows_mle", "zg_fr_rows_mle_dev", "zg_fr_rows_affine", "zg_fr_rows_affine_dev", "zg_fr_rows_affine_prodsum_dev", "zg_fr_weighted_colsum", "zg_fr_weighted_colsum_dev", "zg_fr_lt_table", "zg_fr_lt_table_dev", "zg_fr_write_tables_dev", "zg_fr_eq_plus_one_table", "zg_fr_eq_plus_one_table_dev", "zg_fr_bind_low", "zg_fr_bind_high",
     "zg_fr_spartan_combine", "zg_fr_spartan_combine_dev",
@@ -420,6 +420,12 @@ def combine_partials_dev(d_partials, k, stream=0):
 def combine_partials_dev_async(d_partials, k, d_out_xy, d_out_inf, stream=0):
     _chk(_lib.zg_g1_combine_partials_dev_async(_d(d_partials), C.c_size_t(k), _d(stream), _d(d_out_xy), _d(d_out_inf)),
          "zg_g1_combine_partials_dev_async")
+
+
+def combine_partials_batch_dev_async(d_partials, ranks, rank_stride, m, d_out9, stream=0):
+    """m results behind one exchange: rank r's m records at d_partials + r * rank_stride words; result j at d_out9 + 9 j"""
+    _chk(_lib.zg_g1_combine_partials_batch_dev_async(_d(d_partials), C.c_size_t(ranks), C.c_size_t(rank_stride), C.c_size_t(m), _d(stream),
+                                                     _d(d_out9)), "zg_g1_combine_partials_batch_dev_async")
 
 
 def g1_scalar_mul_batch(xy, inf, scalars):
