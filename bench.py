@@ -48,6 +48,13 @@ VALU_PEAK_GCYC = 1024 * 2.4  # 256 CUs x 4 SIMDs x 2.4 GHz
 # ns per wave-instruction per SIMD under load: v_mad_u64_u32 2.034, v_lshl_add_u64 2.181 (v_lshrrev_b64 taken equal), v_mul_lo_u32
 # 2.113, 32-bit add 1.183): the least time one SIMD needs for one wave-wide mixed add, clocks as they really are under this load
 MADD_MIN_NS_PER_SIMD = 1467 * 2.034 + (146 + 144) * 2.181 + 81 * 2.113 + 382 * 1.183
+# The executed instruction count from the counters instead of the static mix (round-3 review): SQ_INSTS_VALU per msm_accumulate launch at
+# 2^20 points, rocprofv3 --pmc in a pass of its own (profiles/r4f_rocprofv3_summary.txt: 585,452,780; r3final: 585.4e6): 2382 wave
+# instructions per wave-wide mixed add (15.73 M adds / 64) against the 2220 of the static fast path — the 162 on top are the loop around
+# the add (sorted-reference decode, row address, conditional negation of y, chunk bookkeeping), 32-bit work priced at the simple-op rate.
+PMC_INSTS_VALU_PER_LAUNCH = {20: 585452779.9}
+MADD_STATIC_INSTRS = 1467 + 146 + 144 + 81 + 382
+SIMPLE_OP_NS = 1.183
 SEED = 0x5A4F4C54
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 N_SCALAR_SETS = 3
@@ -442,6 +449,20 @@ def main():
         "floor_ms": floor_ms, "frac": floor_ms / alone_ms if floor_ms and alone_ms else None,
         "model": "adds / (64 lanes x 1024 SIMDs) x least ns per wave-wide mixed add at the issue times measured by tools/microbench.hip "
                  "(profiles/r1_microbench_instruction_rates.txt); frac = floor / avg_launch_ms_alone"}
+    pmc = PMC_INSTS_VALU_PER_LAUNCH.get(args.logn) if world == 1 and args.window_bits == 0 and args.precompute == 0 else None
+    if pmc and alone_ms:
+        wave_adds = adds / 64.0
+        per_add = pmc / wave_adds
+        ns_per_add = MADD_MIN_NS_PER_SIMD + max(per_add - MADD_STATIC_INSTRS, 0.0) * SIMPLE_OP_NS
+        floor_pmc = wave_adds / 1024.0 * ns_per_add * 1e-6
+        out["roofline"]["valu_issue_measured_rates"].update({
+            "pmc_wave_instructions_per_add": per_add, "static_wave_instructions_per_add": MADD_STATIC_INSTRS,
+            "floor_ms_from_pmc_count": floor_pmc, "frac_from_pmc_count": floor_pmc / alone_ms,
+            "residual": 1.0 - floor_pmc / alone_ms,
+            "residual_is": "time the SIMDs do not spend issuing: the launch runs 15/16 of the chip's chunk slots when other MSMs are in flight (full "
+                           "when alone), the random 64-byte table rows (DESIGN 4a: a wave waits on its gathers when the other wave of its SIMD "
+                           "does too), and the chunk-length spread at the end of the launch",
+            "pmc_source": "SQ_INSTS_VALU, rocprofv3 --pmc (own pass), profiles/r4f_rocprofv3_summary.txt"})
     if single_proc is not None:
         out["extra"]["single_process_c_abi"] = single_proc
     if sharded_sc is not None:

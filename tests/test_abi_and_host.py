@@ -135,22 +135,17 @@ def test_zig_backend_rules_out_the_stale_table_and_wrong_field_hazards():
 
 def test_zig_backend_size_gates_are_the_measured_crossovers():
     """Every host-pointer forwarding wrapper of zig/gpu/backend.zig refuses sizes below the CPU / GPU crossover measured by
-    tools/crossover.py (profiles/r3_crossover.json), and its constant IS the measured gate: no wrapper forwards a size at which the
+    tools/crossover.py (profiles/r4_crossover.json), and its constant IS the measured gate: no wrapper forwards a size at which the
     GPU call was slower than the CPU body."""
     import json
     be = open(os.path.join(ROOT, "zig", "gpu", "backend.zig")).read()
     code = "\n".join(l for l in be.splitlines() if not l.lstrip().startswith("//"))
-    cross = json.load(open(os.path.join(ROOT, "profiles", "r3_crossover.json")))
+    cross = json.load(open(os.path.join(ROOT, "profiles", "r4_crossover.json")))  # re-measured in round 4 (new table-less MSM plan, new fold kernels)
     consts = {m.group(1): int(m.group(2)) for m in re.finditer(r"pub const (\w+_min_\w+): usize = (\d+);", code)}
     want = {"srs_commit_min_points": "srs_commit", "one_shot_min_points": "one_shot_msm", "eq_table_min_entries": "eq_table",
             "bind_low_min_entries": "bind_low", "bind_high_min_entries": "bind_high", "run_sumcheck_min_entries": "run_sumcheck",
-            "open_min_entries": "hyperkzg_open"}
+            "open_min_entries": "hyperkzg_open", "lt_table_min_entries": "lt_table", "weighted_colsum_min_entries": "weighted_colsum"}
     assert set(want) <= set(consts)
-    # the round-3 additions were measured into their own file (tools/crossover.py --only lt_table,weighted_colsum)
-    cross3 = json.load(open(os.path.join(ROOT, "profiles", "r3_crossover_stage3.json")))
-    want.update({"lt_table_min_entries": "lt_table", "weighted_colsum_min_entries": "weighted_colsum"})
-    for key in ("lt_table", "weighted_colsum"):
-        cross["gates"][key], cross["points"][key] = cross3["gates"][key], cross3["points"][key]
     for const, key in want.items():
         assert consts[const] == cross["gates"][key], (const, consts[const], cross["gates"][key])
         pts = {p["n"]: p for p in cross["points"][key]}

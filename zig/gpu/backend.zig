@@ -112,16 +112,16 @@ const Packed = struct {
 
 // ---------------------------------------------------------------------------------------------------------------
 // Size gates: the CPU / GPU crossover of every host-pointer wrapper, MEASURED on an MI355X box against the reference's CPU bodies
-// restated in C (tools/crossover.py -> profiles/r3_crossover.json; tests/test_abi_and_host.py holds these constants to that file).
+// restated in C (tools/crossover.py -> profiles/r4_crossover.json, re-measured in round 4; tests/test_abi_and_host.py holds these constants to that file).
 // Below its gate a wrapper returns null and the caller keeps its Zig body: a host-pointer call pays upload + launch + download
 // (>= 30-40 us), more than the CPU needs for the 2^8..2^13-entry tables of a small trace (logs/zolt.log: log_t = 8).
 // ---------------------------------------------------------------------------------------------------------------
 pub const srs_commit_min_points: usize = 16; // zg_msm_g1 on a resident handle: 0.18 ms against 0.66 ms at 16 points
-pub const one_shot_min_points: usize = 64; // upload + table-less MSM + free: 1.4-1.6 ms against 1.9 ms at 64 points
+pub const one_shot_min_points: usize = 64; // upload + table-less MSM + free: 1.36 ms against 1.85 ms at 64 points (16 points: 1.26 against 0.65); round 4's table-less plan did not move the gate
 pub const eq_table_min_entries: usize = 4096; // 2^12 entries: 42 us against 69 us (2^10: 36 against 19)
 pub const bind_low_min_entries: usize = 16384; // in place: the table crosses PCIe both ways (2^12: 71 us against 60)
 pub const bind_high_min_entries: usize = 4096; // 2^12: 70 us against 83
-pub const run_sumcheck_min_entries: usize = 4096; // whole protocol on the device: 0.17 ms against 0.21 ms
+pub const run_sumcheck_min_entries: usize = 4096; // whole protocol on the device: 0.086 ms against 0.21 ms (2^10: 0.067 against 0.057)
 pub const open_min_entries: usize = 16; // HyperKZG.open: 0.25 ms against 1.2 ms at 16 evaluations
 // round-3 additions (tools/crossover.py --only lt_table,weighted_colsum -> profiles/r3_crossover_stage3.json)
 pub const lt_table_min_entries: usize = 256; // LtPolynomial over the cube (ValEvaluationProver.init): 44 us against 71 us at 2^8 (2^6: 41 against 13)
@@ -357,6 +357,7 @@ pub fn gruenPrefixTables(comptime F: type, allocator: std.mem.Allocator, w: []co
 /// LtPolynomial.evaluateAtIndex for every index (src/zkvm/ram/val_evaluation.zig:309-330): what ValEvaluationProver.init loops over.
 /// null = below the measured crossover (lt_table_min_entries): the caller keeps its loop
 pub fn ltTable(comptime F: type, allocator: std.mem.Allocator, r_cycle: []const F) !?[]F {
+    if (r_cycle.len > 30) return null; // beyond what the device entry point accepts: the caller keeps its Zig body
     if ((@as(usize, 1) << @intCast(r_cycle.len)) < lt_table_min_entries) return null;
     const out = try allocator.alloc(F, @as(usize, 1) << @intCast(r_cycle.len));
     errdefer allocator.free(out);
@@ -369,7 +370,10 @@ pub fn ltTable(comptime F: type, allocator: std.mem.Allocator, r_cycle: []const 
 /// (src/poly/commitment/dory.zig:622-642). null = below the measured crossover (weighted_colsum_min_entries)
 pub fn weightedColsum(comptime F: type, allocator: std.mem.Allocator, table: []const F, rows: usize, cols: usize, weights: []const F) !?[]F {
     if (table.len < weighted_colsum_min_entries) return null;
+    // shapes the device entry point does not take (or that would read past a slice): the caller keeps its Zig body
+    if (rows == 0 or cols == 0 or table.len != rows * cols or weights.len % rows != 0) return null;
     const m = weights.len / rows;
+    if (m == 0 or m > 4) return null;
     const out = try allocator.alloc(F, m * cols);
     errdefer allocator.free(out);
     if (ffi.zg_fr_weighted_colsum(limbsOf(F, table), rows, cols, limbsOf(F, weights), m, @ptrCast(out.ptr)) != ffi.OK) return Error.GpuFailure;

@@ -1397,6 +1397,10 @@ int zg_fr_write_tables_dev(size_t n, size_t m, const uint32_t *cycle, const uint
                 set_error(cycle[i] >= n ? "zg_fr_write_tables_dev: a write beyond the tables" : "zg_fr_write_tables_dev: two writes in one cycle");
                 return ZG_ERR_INVALID;
             }
+            if (word[i] >= ((size_t)1 << log_k)) {  // the reference skips such a write; the kernel would fold it onto word mod K: refuse, the caller keeps its loop
+                set_error("zg_fr_write_tables_dev: a word index beyond 2^log_k");
+                return ZG_ERR_INVALID;
+            }
             seen[cycle[i]] = true;
         }
     }

@@ -81,13 +81,41 @@ template <int CTRL, int ROW_MASK>
 ZG_DEV u32 dpp_take(u32 v) {  // lanes without a source (or outside ROW_MASK) read 0
     return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
 }
+// x += (x moved across lanes by a DPP control), nine limbs with the carry chain, the lane movement folded INTO the additions
+// (v_add_co_u32_dpp / v_addc_co_u32_dpp): nine instructions. Left to the compiler the same step was a v_mov_b32_dpp, a hazard s_nop
+// and a v_addc per limb (27). Lanes without a source add 0 (bound_ctrl), lanes of rows outside the row mask are not written.
+// Hazards: a DPP read needs two wait states after a VALU write of the same register — inside the sequence every source limb was
+// written nine instructions earlier; the leading s_nop 1 covers whatever the compiler scheduled in front.
+#define ZG_ACC9_DPP_ADD(NAME, CTRL_TEXT)                                                                                              \
+    ZG_DEV void NAME(Acc9 &x) {                                                                                                       \
+        asm volatile("s_nop 1\n\t"                                                                                                    \
+                     "v_add_co_u32_dpp %0, vcc, %0, %0 " CTRL_TEXT "\n\t"                                                             \
+                     "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc " CTRL_TEXT "\n\t"                                                       \
+                     "v_addc_co_u32_dpp %2, vcc, %2, %2, vcc " CTRL_TEXT "\n\t"                                                       \
+                     "v_addc_co_u32_dpp %3, vcc, %3, %3, vcc " CTRL_TEXT "\n\t"                                                       \
+                     "v_addc_co_u32_dpp %4, vcc, %4, %4, vcc " CTRL_TEXT "\n\t"                                                       \
+                     "v_addc_co_u32_dpp %5, vcc, %5, %5, vcc " CTRL_TEXT "\n\t"                                                       \
+                     "v_addc_co_u32_dpp %6, vcc, %6, %6, vcc " CTRL_TEXT "\n\t"                                                       \
+                     "v_addc_co_u32_dpp %7, vcc, %7, %7, vcc " CTRL_TEXT "\n\t"                                                       \
+                     "v_addc_co_u32_dpp %8, vcc, %8, %8, vcc " CTRL_TEXT "\n\t"                                                       \
+                     : "+v"(x.l[0]), "+v"(x.l[1]), "+v"(x.l[2]), "+v"(x.l[3]), "+v"(x.l[4]), "+v"(x.l[5]), "+v"(x.l[6]), "+v"(x.l[7]),  \
+                       "+v"(x.l[8])                                                                                                   \
+                     :                                                                                                                \
+                     : "vcc");                                                                                                        \
+    }
+ZG_ACC9_DPP_ADD(acc9_row_shr1_add, "row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+ZG_ACC9_DPP_ADD(acc9_row_shr2_add, "row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+ZG_ACC9_DPP_ADD(acc9_row_shr4_add, "row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+ZG_ACC9_DPP_ADD(acc9_row_shr8_add, "row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+ZG_ACC9_DPP_ADD(acc9_row_bcast15_add, "row_bcast:15 row_mask:0xa bank_mask:0xf")  // rows 1 and 3 += lane 15 of the row before
+#undef ZG_ACC9_DPP_ADD
 // x += x shifted right by N lanes inside each row of 16 (lanes without a source add 0)
 template <int N>
 ZG_DEV void acc9_row_shr_add(Acc9 &x) {
-    Acc9 t;
-#pragma unroll
-    for (int i = 0; i < 9; i++) t.l[i] = dpp_take<0x110 + N, 0xf>(x.l[i]);
-    acc9_add_acc(x, t);
+    if (N == 1) acc9_row_shr1_add(x);
+    else if (N == 2) acc9_row_shr2_add(x);
+    else if (N == 4) acc9_row_shr4_add(x);
+    else acc9_row_shr8_add(x);
 }
 
 // Sum of (g0, g1) over a wavefront without LDS traffic: one v_permlane32_swap per limb puts the g0 halves on lanes 0-31 and the g1
@@ -105,10 +133,7 @@ ZG_DEV void wave_sum_pair9(Acc9 &g0, Acc9 &g1) {
     acc9_row_shr_add<2>(g0);
     acc9_row_shr_add<4>(g0);
     acc9_row_shr_add<8>(g0);
-    Acc9 t;
-#pragma unroll
-    for (int i = 0; i < 9; i++) t.l[i] = dpp_take<0x142, 0xa>(g0.l[i]);  // row_bcast:15 into rows 1 and 3
-    acc9_add_acc(g0, t);
+    acc9_row_bcast15_add(g0);  // rows 1 and 3 += lane 15 of rows 0 and 2
 }
 
 // Block-wide sum of (g0, g1) (a multiple of 64 threads, at most 1024). `sh`: SC_RED_WORDS u32 of LDS. On return, in wave 0, lane

@@ -83,10 +83,16 @@ static int rccl_load() {
 // handles that were created while that many devices were bound and lives until the last of them is freed. When the bound set
 // widens (zg_init_devices(n) after zg_init, or after a handle over fewer devices) the next handle gets a NEW set for the wider
 // range; zg_shutdown only drops the library's own reference, so a handle that outlives it keeps working communicators.
+// Communicators are destroyed only while the library is alive (the last handle freed, or zg_shutdown): at process exit, static
+// destruction may run after librccl (dlopen'ed later than this library) and HIP have torn their own state down, so a set that is
+// still referenced then is LEAKED on purpose (g_exiting, set by an atexit hook registered when the first set is created).
+static std::atomic<bool> g_exiting{false};
 struct CommSet {
     int ndev = 0;
     std::vector<ncclComm_t> comms;
+    std::mutex mu;  // RCCL communicators are not thread-safe: every GroupStart .. GroupEnd section over this set holds it
     ~CommSet() {
+        if (g_exiting.load()) return;
         for (ncclComm_t c : comms)
             if (c && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c);
     }
@@ -107,7 +113,7 @@ static int comms_acquire(int ndev, std::shared_ptr<CommSet> &out) {
     cs->ndev = ndev;
     cs->comms.assign(ndev, nullptr);
     ZG_NCCL(g_rccl.CommInitAll(cs->comms.data(), ndev, devs.data()));
-    g_commsets_created.fetch_add(1);
+    if (g_commsets_created.fetch_add(1) == 0) (void)atexit([] { g_exiting.store(true); });  // runs before this library's static destructors
     g_commset = cs;  // an older set (other ndev) stays alive through the handles that hold it
     out = cs;
     return ZG_OK;
@@ -389,6 +395,7 @@ static int sharded_submit(zg_sbases_s *sb, size_t k, const PerShard &per_shard, 
                 set_error("sharded: the handle has no communicator set");
                 return ZG_ERR_INVALID;
             }
+            std::lock_guard<std::mutex> comm_lk(cs->mu);  // two handles (two threads) share the set: one group section at a time
             ZG_NCCL(g_rccl.GroupStart());
             for (size_t i = 0; i < S; i++) {
                 DeviceScope scope(sb->shards[i].device);

@@ -130,6 +130,11 @@ def shutdown():
     _lib.zg_shutdown()
 
 
+import atexit as _atexit  # noqa: E402
+
+_atexit.register(lambda: _lib.zg_shutdown())  # communicators / pooled sessions are released while HIP and RCCL are still alive
+
+
 def sync():
     _chk(_lib.zg_sync(), "zg_sync")
 
