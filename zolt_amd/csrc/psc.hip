@@ -528,6 +528,135 @@ __global__ void __launch_bounds__(256) PSC_OCC psc_expr_kernel(const uint64_t *b
     psc_finish<2>(e, sh, partials, sums, counter, flag, seq);
 }
 
+// ---- the same round evaluations for SHORT tables: one lane per (pair, term, point). In psc_expr_kernel a thread walks every term and
+// every point of its pair — with a few pairs left that is ONE chain of up to ~60 dependent field products per round (35-65 us at
+// 2.2 ns per instruction of a lone wave, whatever the table length: the floor of Stage 3's last dozen rounds). Here lane
+// u = 16 g + 4 term + point evaluates its term at its point only: the folds of the term's tables, its linear combination at that point
+// (one product per weighted table instead of two) and the chain of its factors — a quarter to a sixth of the dependent products.
+// Values: the same field elements (a term's value at a point is one product of canonical factors however it is scheduled), summed
+// by the same canonical reduction, so every round's evaluations are the reference's bytes as before.
+ZG_DEV Fr psc_at_point(const Fr &lo, const Fr &hi, uint32_t t) {  // lo + t (hi - lo), t = 0..3, without lane divergence
+    const Fr d = fe_sub(hi, lo);
+    Fr v, a1, a2;
+    const u32 m0 = t == 0 ? ~0u : 0u, m2 = t >= 2 ? ~0u : 0u, m3 = t == 3 ? ~0u : 0u;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        v.l[i] = (lo.l[i] & m0) | (hi.l[i] & ~m0);
+        a1.l[i] = d.l[i] & m2;
+        a2.l[i] = d.l[i] & m3;
+    }
+    return fe_add(fe_add(v, a1), a2);
+}
+constexpr size_t PSC_SPREAD_MAX_PAIRS = 1024;
+template <bool FOLD>
+__global__ void __launch_bounds__(256) psc_expr_spread_kernel(const uint64_t *base, size_t stride, size_t n_pairs, FrArg r, uint64_t *out, size_t ostride,
+                                                              PscExpr ex, uint64_t *partials, uint64_t *sums, uint32_t *counter, uint64_t *flag, uint64_t seq) {
+    __shared__ uint4 sh[256 * 4];
+    FrMul rp;
+    rp.narrow = false;
+    if (FOLD) {
+        Fr rv;
+#pragma unroll
+        for (int i = 0; i < 8; i++) rv.l[i] = r.l[i];
+        rp = frmul_prepare(rv);
+    }
+    const size_t u = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t t = (uint32_t)u & 3u, ti = ((uint32_t)u >> 2) & 3u;
+    const size_t g = u >> 4;
+    const bool live = g < n_pairs && ti < ex.n_terms && ((ex.points >> t) & 1u);
+    const bool writer = g < n_pairs && ti < ex.n_terms && t == 0;  // the lane that stores a folded pair (a table named by several terms is stored by each: same bytes)
+    Fr val = Fr::zero();
+    if (g < n_pairs && ti < ex.n_terms) {
+        const PscExprTerm &tm = ex.t[ti];
+        auto pair_of = [&](uint32_t table, Fr &lo, Fr &hi) {
+            if (FOLD) {
+                const uint64_t *p4 = base + 4 * ((size_t)table * stride + 4 * g);
+                Fr a0 = fe_load<FrParams>(p4), a1 = fe_load<FrParams>(p4 + 4), a2 = fe_load<FrParams>(p4 + 8), a3 = fe_load<FrParams>(p4 + 12);
+                lo = fe_add(a0, frmul_apply(fe_sub(a1, a0), rp));
+                hi = fe_add(a2, frmul_apply(fe_sub(a3, a2), rp));
+                if (writer) {
+                    uint64_t *o = out + 4 * ((size_t)table * ostride + 2 * g);
+                    fe_store(o, lo);
+                    fe_store(o + 4, hi);
+                }
+            } else {
+                const uint64_t *p2 = base + 4 * ((size_t)table * stride + 2 * g);
+                lo = fe_load<FrParams>(p2);
+                hi = fe_load<FrParams>(p2 + 4);
+            }
+        };
+        Fr L = Fr::zero();  // the term's linear combination at this lane's point
+        for (uint32_t m = 0; m < tm.nq; m++) {
+            Fr lo, hi;
+            pair_of(tm.lin[m], lo, hi);
+            const Fr x = psc_at_point(lo, hi, t);
+            const uint32_t kind = lin_kind(tm.coeff[m]);
+            if (kind == 1u) {
+                L = fe_add(L, x);
+            } else if (kind == 2u) {
+                L = fe_sub(L, x);
+            } else {
+                Fr c;
+#pragma unroll
+                for (int i = 0; i < 8; i++) c.l[i] = tm.coeff[m].l[i];
+                L = fe_add(L, fr_mul29v(x, c));
+            }
+        }
+        F29 w;
+#pragma unroll
+        for (int i = 0; i < 9; i++) w.l[i] = 0;
+        bool have = false;
+        if (tm.pair_sum) {
+            for (uint32_t q = 0; q < 2; q++) {
+                Fr alo, ahi, blo, bhi;
+                pair_of(tm.prod[2 * q], alo, ahi);
+                pair_of(tm.prod[2 * q + 1], blo, bhi);
+                F29 v = fr29_chain_mul(fr29_in(psc_at_point(alo, ahi, t)), fr29_in_shift(psc_at_point(blo, bhi, t)));
+#pragma unroll
+                for (int i = 0; i < 9; i++) w.l[i] += v.l[i];
+            }
+            w = fr29_chain_mul(w, fr29_in_shift(tm.nq ? L : Fr::one()));  // (a b + c d) L; without a weight the product by 1 restores exact limbs
+        } else {
+            if (tm.nq) {
+                w = fr29_in(L);
+                have = true;
+            }
+            for (uint32_t j = 0; j < tm.np; j++) {
+                Fr lo, hi;
+                pair_of(tm.prod[j], lo, hi);
+                const Fr f = psc_at_point(lo, hi, t);
+                if (!have) {
+                    w = fr29_in(f);
+                    have = true;
+                } else {
+                    w = fr29_chain_mul(w, fr29_in_shift(f));
+                }
+            }
+        }
+        if (live) val = fr29_out(w);
+    }
+    Fr e[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const u32 mk = (t == (uint32_t)k) ? ~0u : 0u;
+#pragma unroll
+        for (int i = 0; i < 8; i++) e[k].l[i] = val.l[i] & mk;
+    }
+    block_sum_pair(e[0], e[1], sh);
+    __syncthreads();
+    block_sum_pair(e[2], e[3], sh);
+    psc_finish<2>(e, sh, partials, sums, counter, flag, seq);
+}
+
+// one lane per (pair, term, point) from this many pairs down (ZG_PSC_SPREAD_MAX_PAIRS; 0 = never): measured, tools/bench_sumcheck Stage 3
+static bool psc_spread(size_t pairs) {
+    static const size_t lim = [] {
+        const char *e = getenv("ZG_PSC_SPREAD_MAX_PAIRS");
+        long v = e && *e ? atol(e) : (long)PSC_SPREAD_MAX_PAIRS;
+        return (size_t)(v < 0 ? 0 : v);
+    }();
+    return pairs >= 1 && pairs <= lim && pairs * 16 <= (size_t)PSC_MAX_BLOCKS * 256;
+}
 static unsigned psc_blocks(size_t half) {
     static const unsigned cap = [] {
         const char *e = getenv("ZG_PSC_BLOCKS");
@@ -888,6 +1017,10 @@ int zg_psc_round_expr(zg_psc_t s, const zg_psc_term *terms, size_t n_terms, uint
     s->evals_pending = true;
     FrArg none;
     memset(&none, 0, sizeof(none));
+    if (psc_spread(half))
+        hipLaunchKernelGGL((psc_expr_spread_kernel<false>), dim3(div_up(half * 16, 256)), dim3(256), 0, s->st, s->buf[s->cur], s->stride(), half, none,
+                           (uint64_t *)nullptr, (size_t)0, ex, s->d_misc, s->h_pin, counter, s->h_pin + PSC_FLAG, s->seq);
+    else
     hipLaunchKernelGGL((psc_expr_kernel<false>), dim3(nb), dim3(256), 0, s->st, s->buf[s->cur], s->stride(), half, none, (uint64_t *)nullptr, (size_t)0, ex,
                        s->d_misc, s->h_pin, counter, s->h_pin + PSC_FLAG, s->seq);
     return psc_collect(s, ex.points, out);
@@ -969,6 +1102,10 @@ int zg_psc_bind(zg_psc_t s, const uint64_t r[4]) {
         s->seq++;
         const uint64_t *base = s->buf[s->cur];
         if (s->spec_is_expr) {
+            if (psc_spread(quarter))
+                hipLaunchKernelGGL((psc_expr_spread_kernel<true>), dim3(div_up(quarter * 16, 256)), dim3(256), 0, s->st, base, s->stride(), quarter, ra,
+                                   s->buf[nxt], ostride, s->expr, s->d_misc, s->h_pin, counter, s->h_pin + PSC_FLAG, s->seq);
+            else
             hipLaunchKernelGGL((psc_expr_kernel<true>), dim3(nb), dim3(256), 0, s->st, base, s->stride(), quarter, ra, s->buf[nxt], ostride, s->expr,
                                s->d_misc, s->h_pin, counter, s->h_pin + PSC_FLAG, s->seq);
         } else

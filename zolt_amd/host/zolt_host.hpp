@@ -1615,6 +1615,14 @@ public:
         rounds_.reset(new ProductSumcheckSession({&prefix_0_[0], &qo[0], &prefix_1_[0], &qo[1], &prefix_0_[1], &qp[0], &prefix_1_[1], &qp[1]}));
         rounds_->setPoints(0b0111);
         wit_.reset(new ProductSumcheckSession(ProductSumcheckSession::OnDevice{}, std::vector<const uint64_t *>(ptrs.begin() + 2, ptrs.end()), N));
+        // the suffix tables stay resident for the transition: [suffix_0[k]; suffix_1[k]] as a 2 x S matrix per k
+        d_suffix_.alloc(4 * ss * 32);
+        d_t_.alloc(2 * ss * 32);  // the transition's buffers are allocated here: a hipMalloc / hipFree pair inside the round loop costs more than the round
+        d_w_.alloc(4 * 32);
+        for (size_t k = 0; k < 2; k++) {
+            check(zg_memcpy_h2d(d_suffix_.u64() + 4 * (2 * k) * ss, suffix_0_[k].data(), ss * 32), "zg_memcpy_h2d");
+            check(zg_memcpy_h2d(d_suffix_.u64() + 4 * (2 * k + 1) * ss, suffix_1_[k].data(), ss * 32), "zg_memcpy_h2d");
+        }
         check(zg_sync(), "zg_sync");
     }
     std::array<Fr, 3> computeRoundEvals(const Fr &previous_claim) {
@@ -1639,14 +1647,14 @@ public:
         // folded on the device since round 0, go to the new session inside HBM
         const std::vector<Fr> f = rounds_->final();
         const size_t S = suffix_0_[0].size();
-        std::vector<Fr> t(2 * S);
-        for (size_t k = 0; k < 2; k++) {
-            const Fr &e0 = f[4 * k], &e1 = f[4 * k + 2];
-            for (size_t j = 0; j < S; j++) t[k * S + j] = e0.mul(suffix_0_[k][j]).add(e1.mul(suffix_1_[k][j]));
-        }
-        DeviceMem d_t(2 * S * 32);
-        check(zg_memcpy_h2d(d_t.p, t.data(), 2 * S * 32), "zg_memcpy_h2d");
-        std::vector<const uint64_t *> ptrs = {d_t.u64(), d_t.u64() + 4 * S};
+        // t_k[j] = e0 suffix_0[k][j] + e1 suffix_1[k][j]: a 2-row weighted column sum of the resident suffix matrix on the device
+        // (round 3 formed the 2 S products on the host: 0.46 ms of a 2.9 ms stage at 2^20 cycles)
+        const Fr w[4] = {f[0], f[2], f[4], f[6]};
+        check(zg_memcpy_h2d(d_w_.p, w, sizeof(w)), "zg_memcpy_h2d");
+        for (size_t k = 0; k < 2; k++)
+            check(zg_fr_weighted_colsum_dev(d_suffix_.u64() + 4 * (2 * k) * S, 2, S, d_w_.u64() + 8 * k, 1, d_t_.u64() + 4 * k * S, nullptr), "zg_fr_weighted_colsum_dev");
+        check(zg_sync(), "zg_sync");
+        std::vector<const uint64_t *> ptrs = {d_t_.u64(), d_t_.u64() + 4 * S};
         for (size_t c = 0; c < 5; c++) ptrs.push_back(wit_->tableDev(c));
         rounds_.reset(new ProductSumcheckSession(ProductSumcheckSession::OnDevice{}, ptrs, S));  // the copies are complete on return
         wit_.reset();
@@ -1661,6 +1669,7 @@ public:
 private:
     std::vector<Fr> g_, challenges_;
     std::vector<std::vector<Fr>> prefix_0_, prefix_1_, suffix_0_, suffix_1_;
+    DeviceMem d_suffix_, d_t_, d_w_;
     std::unique_ptr<ProductSumcheckSession> rounds_, wit_;
     size_t prefix_size_ = 0;
     bool in_phase2_ = false;
@@ -1685,6 +1694,7 @@ public:
         rounds_.reset(new ProductSumcheckSession({&P, &q[0]}));
         rounds_->setPoints(0b0101);
         wit_.reset(new ProductSumcheckSession(ProductSumcheckSession::OnDevice{}, std::vector<const uint64_t *>(ptrs.begin() + 1, ptrs.end()), N));
+        d_eq_.alloc((size_t(1) << r_hi_.size()) * 32);
         check(zg_sync(), "zg_sync");
     }
     std::array<Fr, 3> computeRoundEvals(const Fr &previous_claim) {  // [p(0), claim - p(0), p(2)] (:2334-2389)
@@ -1701,13 +1711,13 @@ public:
         if (!transition) return;
         std::vector<Fr> rev(challenges_.rbegin(), challenges_.rend());  // :2427-2466
         Fr e = EqPolynomial::mle(r_lo_, rev);
-        std::vector<Fr> eq_hi = EqPolynomial(r_hi_).evals();
-        for (Fr &x : eq_hi) x = x.mul(e);
-        DeviceMem d_eq(eq_hi.size() * 32);
-        check(zg_memcpy_h2d(d_eq.p, eq_hi.data(), eq_hi.size() * 32), "zg_memcpy_h2d");
-        std::vector<const uint64_t *> ptrs = {d_eq.u64()};
+        const size_t n_hi = size_t(1) << r_hi_.size();
+        // e * eq(r_hi, .) straight from the eq-table kernel (its scale argument): no host table, no upload; buffer allocated at construction
+        check(zg_fr_eq_table_dev(r_hi_.empty() ? nullptr : r_hi_[0].limbs, r_hi_.size(), e.limbs, d_eq_.u64(), nullptr), "zg_fr_eq_table_dev");
+        check(zg_sync(), "zg_sync");
+        std::vector<const uint64_t *> ptrs = {d_eq_.u64()};
         for (size_t c = 0; c < 3; c++) ptrs.push_back(wit_->tableDev(c));  // folded on the device since round 0: handed over inside HBM
-        rounds_.reset(new ProductSumcheckSession(ProductSumcheckSession::OnDevice{}, ptrs, eq_hi.size()));  // the copies are complete on return
+        rounds_.reset(new ProductSumcheckSession(ProductSumcheckSession::OnDevice{}, ptrs, n_hi));  // the copies are complete on return
         wit_.reset();
         rounds_->setPoints(0b0101);
         in_phase2_ = true;
@@ -1720,6 +1730,7 @@ public:
 private:
     Fr gamma_;
     std::vector<Fr> r_hi_, r_lo_, challenges_;
+    DeviceMem d_eq_;
     std::unique_ptr<ProductSumcheckSession> rounds_, wit_;
     size_t prefix_size_ = 0;
     bool in_phase2_ = false;
