@@ -290,7 +290,7 @@ def test_shard_bounds_is_parallel_msm_partition():
 
 def test_eq_mle_host_mirror_matches_oracle_and_bigint():
     """EqPolynomial.mle / evaluate (src/poly/mod.zig:214-227,311-321) is host scalar code in the reference and in the mirror
-    (zolt_amd/api.py): checked here, without a GPU, against the C oracle and the big-int model."""
+    (zolt_amd/api/): checked here, without a GPU, against the C oracle and the big-int model."""
     from oracle import binding as ob
     from oracle import pymodel as pm
     from tests import util as U

@@ -1,4 +1,4 @@
-"""The Python host mirror (zolt_amd/api.py) against the oracle: HyperKZG setup/commit/batchCommit/open, the
+"""The Python host mirror (zolt_amd/api/) against the oracle: HyperKZG setup/commit/batchCommit/open, the
 polynomial classes, runSumcheck; plus re-entrancy of the C ABI from several host threads."""
 import threading
 

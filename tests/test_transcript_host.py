@@ -1,6 +1,6 @@
 """The host Keccak transcript (src/transcripts/mod.zig:49-221) — CPU only. Keccak-f[1600] of the C oracle and of the big-int
 model is pinned against an INDEPENDENT implementation (hashlib's SHA3-256 uses the same permutation); the transcript wrappers
-(oracle C, oracle/pymodel.py, zolt_amd/api.py — the product's host mirror) must then agree byte for byte on every absorb /
+(oracle C, oracle/pymodel.py, zolt_amd/api/ — the product's host mirror) must then agree byte for byte on every absorb /
 squeeze sequence, including the rate boundary at 136 bytes."""
 import hashlib
 

@@ -1,1145 +1,17 @@
-"""Host-side mirror of the reference's module API for the hot path, over libzolt_gpu.so.
+"""provers.py — the prover fold sites of stages 1-6 driven by the host transcript.
 
-Names, argument meaning and error behaviour follow the Zig modules so the parity tests
-read like the reference's own tests (paths under /root/reference):
-
-  MSM.compute / BatchMSM / ParallelMSM        src/msm/mod.zig:345-748
-  HyperKZG.setup / commit / batchCommit / open src/poly/commitment/mod.zig:174-324,558-570
-  EqPolynomial.evals, DensePolynomial          src/poly/mod.zig:23-323
-  Sumcheck.Prover / Verifier, runSumcheck      src/subprotocols/mod.zig:18-354
-
-All heavy arithmetic runs in the HIP kernels. What stays on the host is exactly what
-stays on the host in the reference integration: the toy verifier's 64-bit challenge mixer
-and a handful of scalar field operations per round (Python ints below), i.e. the role the
-unchanged Zig `field` module plays above the FFI seam.
-
-Field elements are numpy uint64[4] Montgomery limbs; points numpy uint64[8] + inf flag.
-"""
+Part of the zolt_amd.api package (the host mirror of the reference's module API over libzolt_gpu.so); import zolt_amd.api,
+which re-exports every name of every part."""
 import numpy as np
 
-from . import lib
-
-R_MOD = 21888242871839275222246405745257275088548364400416034343698204186575808495617
-P_MOD = 21888242871839275222246405745257275088696311157297823662689037894645226208583
-_M64 = (1 << 64) - 1
-_MONT_R = 1 << 256
-_RINV_R = pow(_MONT_R, -1, R_MOD)
-_RINV_P = pow(_MONT_R, -1, P_MOD)
-
-
-# ---- host scalar helpers (representation only)
-def _limbs(v):
-    return np.array([(v >> (64 * i)) & _M64 for i in range(4)], dtype=np.uint64)
-
-
-def _int(l):
-    return sum(int(x) << (64 * i) for i, x in enumerate(l))
-
-
-def fr_from_int(v):
-    """F.fromU64 / canonical integer -> Montgomery limbs (src/field/mod.zig:617-622)."""
-    return _limbs((v % R_MOD) * _MONT_R % R_MOD)
-
-
-def fr_to_int(l):
-    return _int(l) * _RINV_R % R_MOD
-
-
-def fp_from_int(v):
-    return _limbs((v % P_MOD) * _MONT_R % P_MOD)
-
-
-def fp_to_int(l):
-    return _int(l) * _RINV_P % P_MOD
-
-
-def generator():
-    """AffinePoint.generator() = (1, 2) (src/msm/mod.zig:43-49)."""
-    return np.concatenate([fp_from_int(1), fp_from_int(2)])
-
-
-def commitment_to_bytes(xy, inf):
-    """PolyCommitment.toBytes: x || y big-endian canonical (src/zkvm/commitment_types.zig:49-54)."""
-    if inf:
-        return bytes(64)
-    return fp_to_int(xy[:4]).to_bytes(32, "big") + fp_to_int(xy[4:]).to_bytes(32, "big")
-
-
-# ---- MSM
-class MSM:
-    """MSM(F, G) with F = Fr, G = Fp."""
-
-    @staticmethod
-    def compute(bases_xy, scalars, bases_inf=None):
-        """MSM.compute(bases, scalars) -> (xy, inf)   (src/msm/mod.zig:355-372)."""
-        bases_xy = np.ascontiguousarray(bases_xy, dtype=np.uint64).reshape(-1, 8)
-        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
-        assert bases_xy.shape[0] == scalars.shape[0]  # std.debug.assert(bases.len == scalars.len), :359
-        b = lib.Bases.upload(bases_xy, bases_inf, expected_uses=1)  # a one-shot slice: no precompute table
-        try:
-            return b.msm(scalars)
-        finally:
-            b.free()
-
-    @staticmethod
-    def scalarMul(base_xy, scalar, base_inf=0):
-        """MSM.scalarMul(base, scalar).toAffine() (src/msm/mod.zig:503-540)."""
-        out, inf = lib.g1_scalar_mul_batch(np.asarray(base_xy).reshape(1, 8), np.array([base_inf], dtype=np.uint8),
-                                           np.asarray(scalar).reshape(1, 4))
-        return out[0], int(inf[0])
-
-
-class AffinePoint:
-    """AffinePoint(G) group law (src/msm/mod.zig:15-140) on (xy[8], inf) pairs."""
-
-    @staticmethod
-    def add(a_xy, a_inf, b_xy, b_inf):
-        """AffinePoint.add (:74-103) -> (xy, inf)"""
-        out, inf = lib.g1_affine_add_batch(np.asarray(a_xy).reshape(1, 8), np.array([a_inf], dtype=np.uint8),
-                                           np.asarray(b_xy).reshape(1, 8), np.array([b_inf], dtype=np.uint8))
-        return out[0], int(inf[0])
-
-    @staticmethod
-    def double(xy, inf=0):
-        """AffinePoint.double (:118-138) = add(p, p)"""
-        return AffinePoint.add(xy, inf, xy, inf)
-
-    @staticmethod
-    def isOnCurve(xy, inf=0):
-        return bool(lib.g1_is_on_curve_batch(np.asarray(xy).reshape(1, 8), np.array([inf], dtype=np.uint8))[0])
-
-
-class ParallelMSM:
-    """ParallelMSM.compute (src/msm/mod.zig:588-653) in the reference's process model: ONE process, its workers = the GPUs bound
-    by lib.init_devices (contiguous chunks of ceil(n / S), one partial per GPU, RCCL all-gather, serial combine on device 0)."""
-
-    @staticmethod
-    def compute(bases_xy, scalars, bases_inf=None, num_threads=None):
-        bases_xy = np.ascontiguousarray(bases_xy, dtype=np.uint64).reshape(-1, 8)
-        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
-        assert bases_xy.shape[0] == scalars.shape[0]
-        sb = lib.ShardedBases.upload(bases_xy, bases_inf, precompute_levels=1)
-        try:
-            return sb.msm(scalars)
-        finally:
-            sb.free()
-
-
-class ParallelBatchMSM:
-    """ParallelBatchMSM.compute (src/msm/mod.zig:683-748) / HyperKZG.batchCommit sharded: k partials per GPU, one exchange."""
-
-    @staticmethod
-    def compute(bases_xy, scalar_batches, bases_inf=None):
-        sb = lib.ShardedBases.upload(bases_xy, bases_inf, precompute_levels=1)
-        try:
-            return sb.msm_batch(scalar_batches)
-        finally:
-            sb.free()
-
-
-class BatchMSM:
-    @staticmethod
-    def compute(bases_xy, scalar_batches, bases_inf=None):
-        """BatchMSM.compute / ParallelBatchMSM.compute (src/msm/mod.zig:545-565,683-748)."""
-        b = lib.Bases.upload(bases_xy, bases_inf)
-        try:
-            return b.msm_batch(scalar_batches)
-        finally:
-            b.free()
-
-
-def shard_bounds(n, parts):
-    """ParallelMSM's partition: contiguous chunks of ceil(n/T) (src/msm/mod.zig:609,619-639).
-    Returns [(start, end)] of length `parts`; trailing shards may be empty."""
-    chunk = (n + parts - 1) // parts if parts else 0
-    out = []
-    for i in range(parts):
-        s = min(i * chunk, n)
-        out.append((s, min(s + chunk, n)))
-    return out
-
-
-class ShardedMSM:
-    """ParallelMSM across GPUs: rank r owns bases/scalars [start_r, end_r), computes its
-    Jacobian partial on its GPU, the partials are all-gathered (RCCL via torch.distributed: one
-    96-byte record per rank), and the serial combine + toAffine runs on the device.
-
-    `backend` supplies the two device operations so the orchestration can be exercised on CPU
-    with gloo in the tests:
-        backend.partial(rank_scalars_tensor) -> torch int64[12] tensor (device of the backend)
-        backend.combine(gathered int64[world,12]) -> (xy, inf)
-    """
-
-    def __init__(self, backend, world_size, rank, group=None):
-        self.backend, self.world, self.rank, self.group = backend, world_size, rank, group
-
-    def compute(self, local_scalars, out=None):
-        """-> (xy, inf) on the host, or, with `out` (a device int64[9] slot: xy[8] + flag word), fully
-        asynchronous: partial MSM, all-gather and combine are only stream-ordered."""
-        import torch
-        import torch.distributed as dist
-        part = self.backend.partial(local_scalars)
-        if self.world == 1 and not dist.is_initialized():
-            gathered = part.reshape(1, 12)
-        elif dist.get_backend(self.group) == "gloo" and part.is_cuda:
-            # debugging aid (several ranks on one GPU): stage the 96-byte records through the host
-            parts = [torch.empty(12, dtype=torch.int64) for _ in range(self.world)]
-            dist.all_gather(parts, part.cpu(), group=self.group)
-            gathered = torch.stack(parts).to(part.device)
-        else:
-            gathered = torch.empty((self.world, 12), dtype=torch.int64, device=part.device)
-            dist.all_gather_into_tensor(gathered, part.reshape(1, 12), group=self.group)
-        if out is not None:
-            return self.backend.combine_async(gathered, out)
-        return self.backend.combine(gathered)
-
-    def compute_batch(self, local_scalar_sets, out=None):
-        """m MSMs over the same bases behind ONE exchange (ParallelBatchMSM, src/msm/mod.zig:683-748): this rank's m partials go into
-        one [m, 12] block, one all-gather of m * 96 bytes per rank replaces m collectives of 96 bytes (at 2^17 points per rank a
-        partial takes 0.23 ms: 32 MSMs per step were 32 tiny collectives serialised on the communicator's stream), one launch combines
-        the m results. -> list of (xy, inf), or with `out` (device int64[m, 9]) fully stream-ordered."""
-        import torch
-        import torch.distributed as dist
-        m = len(local_scalar_sets)
-        parts = self.backend.partial_batch(local_scalar_sets)  # [m, 12]
-        if self.world == 1 and not dist.is_initialized():
-            gathered = parts.reshape(1, m, 12)
-        elif dist.get_backend(self.group) == "gloo" and parts.is_cuda:
-            lst = [torch.empty((m, 12), dtype=torch.int64) for _ in range(self.world)]
-            dist.all_gather(lst, parts.cpu(), group=self.group)
-            gathered = torch.stack(lst).to(parts.device)
-        else:
-            gathered = torch.empty((self.world, m, 12), dtype=torch.int64, device=parts.device)
-            dist.all_gather_into_tensor(gathered, parts.reshape(1, m, 12), group=self.group)
-        if out is not None:
-            return self.backend.combine_batch_async(gathered, out)
-        return self.backend.combine_batch(gathered)
-
-
-class GpuShardBackend:
-    """ShardedMSM backend over libzolt_gpu.so; tensors are torch CUDA tensors (device memory plumbing). All work is
-    enqueued on torch's CURRENT stream, so the caller can rotate streams (`with torch.cuda.stream(s)`) to overlap
-    consecutive sharded MSMs; the collective is ordered against that stream by torch.distributed."""
-
-    def __init__(self, bases, n_local):
-        self.bases, self.n = bases, n_local
-
-    @staticmethod
-    def _stream():
-        import torch
-        s = torch.cuda.current_stream().cuda_stream
-        assert s != 0, "run under an explicit torch stream: a NULL stream means the library's own stream"
-        return s
-
-    def partial(self, d_scalars):
-        import torch
-        out = torch.empty(12, dtype=torch.int64, device=d_scalars.device)
-        # un-normalised Jacobian partial: the combine result is identical and the rank skips an inversion
-        self.bases.msm_partial_fast_dev(d_scalars.data_ptr(), self.n, out.data_ptr(), stream=self._stream())
-        return out
-
-    def partial_batch(self, d_scalar_sets):
-        import torch
-        out = torch.empty((len(d_scalar_sets), 12), dtype=torch.int64, device=d_scalar_sets[0].device)
-        for j, sc in enumerate(d_scalar_sets):
-            self.bases.msm_partial_fast_dev(sc.data_ptr(), self.n, out[j].data_ptr(), stream=self._stream())
-        return out
-
-    def combine(self, gathered):
-        return lib.combine_partials_dev(gathered.data_ptr(), gathered.shape[0], stream=self._stream())
-
-    def combine_batch_async(self, gathered, out):
-        """gathered: device int64[world, m, 12]; out: device int64[m, 9]"""
-        gathered.record_stream(__import__("torch").cuda.current_stream())
-        world, m = gathered.shape[0], gathered.shape[1]
-        lib.combine_partials_batch_dev_async(gathered.data_ptr(), world, 12 * m, m, out.data_ptr(), stream=self._stream())
-        return None
-
-    def combine_batch(self, gathered):
-        import torch
-        m = gathered.shape[1]
-        out = torch.empty((m, 9), dtype=torch.int64, device=gathered.device)
-        self.combine_batch_async(gathered, out)
-        torch.cuda.current_stream().synchronize()
-        h = out.cpu().numpy().view(np.uint64)
-        return [(h[j, :8].copy(), int(h[j, 8] & 0xFF)) for j in range(m)]
-
-    def combine_async(self, gathered, out):
-        gathered.record_stream(__import__("torch").cuda.current_stream())
-        lib.combine_partials_dev_async(gathered.data_ptr(), gathered.shape[0], out.data_ptr(), out[8:].data_ptr(), stream=self._stream())
-        return None
-
-
-# ---- HyperKZG (commit side)
-class HyperKZG:
-    TAU = 0x12345678  # src/poly/commitment/mod.zig:189 (mock SRS, INSECURE by design)
-
-    class SetupParams:
-        def __init__(self, xy, inf, sharded=False):
-            self.powers_of_tau_g1 = xy
-            self.infinity = inf
-            self.max_degree = xy.shape[0]
-            # device-resident for the whole run (:122-140); sharded=True: one shard per GPU bound by lib.init_devices — commit and
-            # batchCommit then go through the one-process multi-GPU entry points (zg_msm_g1_sharded / zg_msm_g1_batch_sharded)
-            self.sharded = bool(sharded)
-            self._dev = lib.ShardedBases.upload(xy, inf) if sharded else lib.Bases.upload(xy, inf)
-
-        def deinit(self):
-            self._dev.free()
-
-    @staticmethod
-    def setup(max_degree):
-        """powers[i] = scalarMul(G1, tau^i).toAffine() (src/poly/commitment/mod.zig:174-213)."""
-        g = generator()
-        taus = np.zeros((max_degree, 4), dtype=np.uint64)
-        t = 1
-        for i in range(max_degree):  # tau_power = tau_power.mul(tau) (:196-198)
-            taus[i] = fr_from_int(t)
-            t = t * HyperKZG.TAU % R_MOD
-        # every product has the same base: the fixed-base batch kernel (32 table additions per point instead of double-and-add)
-        xy, inf = lib.g1_fixed_base_mul_batch(g, taus)
-        return HyperKZG.SetupParams(xy, inf)
-
-    @staticmethod
-    def commit(params, evals):
-        """commit(params, evals) (src/poly/commitment/mod.zig:239-255): empty -> identity; n = min(len, srs)."""
-        evals = np.ascontiguousarray(evals, dtype=np.uint64).reshape(-1, 4)
-        if evals.shape[0] == 0:
-            return np.zeros(8, dtype=np.uint64), 1
-        n = min(evals.shape[0], params.max_degree)
-        if params.sharded:
-            return params._dev.msm(evals[:n], n=n)
-        return params._dev.msm(evals[:n], off=0, n=n)
-
-    @staticmethod
-    def batchCommit(params, polys):
-        """batchCommit (src/poly/commitment/mod.zig:558-570): out[i] = commit(poly_i). Polynomials of equal (clamped)
-        length share one zg_msm_g1_batch call, which fuses short vectors into a single launch set."""
-        polys = [np.ascontiguousarray(p, dtype=np.uint64).reshape(-1, 4) for p in polys]
-        out = [None] * len(polys)
-        groups = {}
-        for i, p in enumerate(polys):
-            groups.setdefault(min(p.shape[0], params.max_degree), []).append(i)
-        for n, idx in groups.items():
-            if n == 0 or len(idx) == 1:
-                for i in idx:
-                    out[i] = HyperKZG.commit(params, polys[i])
-            else:
-                xy, inf = params._dev.msm_batch([polys[i][:n] for i in idx], n=n)
-                for j, i in enumerate(idx):
-                    out[i] = (xy[j], int(inf[j]))
-        return out
-
-    @staticmethod
-    def open(params, evals, point, value):
-        """open (src/poly/commitment/mod.zig:261-324): per variable commit(q = hi - lo), fold high half.
-        Returns (quotient commitments [(xy, inf)], final_eval)."""
-        point = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1, 4)
-        if point.shape[0] == 0:
-            return [], np.asarray(value, dtype=np.uint64)
-        q, qinf, final = lib.hyperkzg_open(params._dev, evals, point, value)  # whole loop resident on the device
-        return [(q[i], int(qinf[i])) for i in range(point.shape[0])], final
-
-
-    @staticmethod
-    def batchOpen(params, polys, point):
-        """batchOpen (src/poly/commitment/mod.zig:607-732) -> dict(quotient_commitments [(xy, inf)], evaluations,
-        final_eval, batching_challenge); the combination, the evaluations and the fold/commit loop run on the device."""
-        point = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1, 4)
-        q, qinf, ev, fin, gam = lib.hyperkzg_batch_open(params._dev, polys, point)
-        return {"quotient_commitments": [(q[i], int(qinf[i])) for i in range(q.shape[0])], "evaluations": ev, "final_eval": fin,
-                "batching_challenge": gam}
-
-
-class Dory:
-    """The data-parallel G1 / Fr pieces of Dory's commit and open (src/poly/commitment/dory.zig; pairings and GT arithmetic stay the
-    reference's): the row commitments are a batch of MSMs over one prefix of g1_vec, the vector-matrix product a weighted column sum."""
-
-    @staticmethod
-    def computeRowCommitments(g1_bases, evals, num_columns):
-        """computeRowCommitments (:646-670): g1_bases = a lib.Bases handle over params.g1_vec (resident, like the HyperKZG SRS);
-        row r = MSM(g1_vec[0..len(row)], row r of evals). Full rows go through ONE fused launch set (zg_msm_g1_batch), a shorter last
-        row is one more MSM over the prefix -> (xy (rows, 8), inf (rows,))"""
-        ev = np.ascontiguousarray(evals, dtype=np.uint64).reshape(-1, 4)
-        full, rest = divmod(ev.shape[0], num_columns)
-        assert num_columns <= g1_bases.n
-        out = np.zeros((full + (1 if rest else 0), 8), dtype=np.uint64)
-        inf = np.zeros(out.shape[0], dtype=np.uint8)
-        if full:
-            out[:full], inf[:full] = g1_bases.msm_batch([ev[r * num_columns:(r + 1) * num_columns] for r in range(full)], n=num_columns)
-        if rest:
-            xy, i = g1_bases.msm(ev[full * num_columns:], n=rest)
-            out[full], inf[full] = xy, i
-        return out, inf
-
-    @staticmethod
-    def multilinearLagrangeBasis(point, out_len=None):
-        """multilinearLagrangeBasis (:544-588): the eq table of the point with the index's LOW bit on point[0] — the device's eq table of
-        the reversed point; a shorter output is its first entries -> (out_len, 4)"""
-        pt = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1, 4)
-        full = lib.fr_eq_table(np.ascontiguousarray(pt[::-1])) if pt.shape[0] else fr_from_int(1).reshape(1, 4)
-        return full if out_len is None else np.ascontiguousarray(full[:out_len])
-
-    @staticmethod
-    def computeEvaluationVectors(point, nu, sigma):
-        """computeEvaluationVectors (:590-620) -> (left_vec (2^nu, 4), right_vec (2^sigma, 4))"""
-        pt = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1, 4)
-        d = pt.shape[0]
-        left, right = np.zeros((1 << nu, 4), dtype=np.uint64), np.zeros((1 << sigma, 4), dtype=np.uint64)
-        if d <= sigma:
-            right[:1 << d] = Dory.multilinearLagrangeBasis(pt)
-            left[0] = fr_from_int(1)
-        elif d <= nu + sigma:
-            right[:] = Dory.multilinearLagrangeBasis(pt[:sigma])
-            left[:1 << (d - sigma)] = Dory.multilinearLagrangeBasis(pt[sigma:])
-        else:  # more variables than the matrix has: the row basis is cut at 2^nu entries
-            right[:] = Dory.multilinearLagrangeBasis(pt[:sigma])
-            left[:] = Dory.multilinearLagrangeBasis(pt[sigma:], 1 << nu)
-        return left, right
-
-    @staticmethod
-    def computeVectorMatrixProduct(evals, left_vec, nu, sigma):
-        """computeVectorMatrixProduct (:622-642): v = L^T M over the 2^nu x 2^sigma matrix of evaluations (zg_fr_weighted_colsum); rows
-        past left_vec and entries past evals are zero -> (2^sigma, 4)"""
-        rows, cols = 1 << nu, 1 << sigma
-        ev = np.ascontiguousarray(evals, dtype=np.uint64).reshape(-1, 4)
-        lv = np.ascontiguousarray(left_vec, dtype=np.uint64).reshape(-1, 4)
-        m = np.zeros((rows * cols, 4), dtype=np.uint64)
-        m[:min(ev.shape[0], rows * cols)] = ev[:rows * cols]
-        w = np.zeros((rows, 4), dtype=np.uint64)
-        w[:min(lv.shape[0], rows)] = lv[:rows]
-        return lib.fr_weighted_colsum(m, rows, cols, w.reshape(1, rows, 4))[0]
-
-
-# ---- ZOLT v1 proof container: the commitments this backend produces
-def parse_zolt_proof_commitments(data):
-    """Header of serializeProof (src/zkvm/serialization.zig:283-306): "ZOLT" | u32 version | bytecode proof
-    {commitment, read_ts, write_ts (64 B each, x||y big-endian, identity = 64 zero bytes,
-    src/zkvm/commitment_types.zig:49-54), legacy field element 32 B} | memory proof {4 x 64 B} | register proof
-    {4 x 64 B}. Returns {name: 64 raw bytes}; the rest of the proof (R1CS / stage proofs) is not parsed."""
-    if len(data) < 8 + 3 * 64 + 32 + 8 * 64 or data[:4] != b"ZOLT":
-        raise ValueError("not a ZOLT proof")
-    version = int.from_bytes(data[4:8], "little")
-    if version != 1:
-        raise ValueError(f"unsupported ZOLT proof version {version}")
-    out, off = {}, 8
-    for name in ("bytecode.commitment", "bytecode.read_ts_commitment", "bytecode.write_ts_commitment"):
-        out[name] = bytes(data[off:off + 64])
-        off += 64
-    off += 32  # bytecode._legacy_commitment
-    for group in ("memory", "register"):
-        for name in ("commitment", "final_state_commitment", "read_ts_commitment", "write_ts_commitment"):
-            out[f"{group}.{name}"] = bytes(data[off:off + 64])
-            off += 64
-    return out
-
-
-def serialize_zolt_proof_header(commitments):
-    """The part of serializeProof (src/zkvm/serialization.zig:283-306) this backend produces: "ZOLT" | u32 version 1 | bytecode
-    proof {commitment, read_ts, write_ts, 32-byte legacy field element} | memory proof {commitment, final_state, read_ts, write_ts}
-    | register proof {same four}. `commitments`: {name: (xy, inf)} with the names of parse_zolt_proof_commitments; missing names are
-    the identity (64 zero bytes, PolyCommitment.zero()) — what commitBytecode / commitMemory / commitRegisters leave in the
-    timestamp and final-state slots (src/zkvm/mod.zig:1540-1546,1574-1581,1609-1616). Returns the first 744 bytes of the proof."""
-    def enc(name):
-        c = commitments.get(name)
-        return bytes(64) if c is None else commitment_to_bytes(c[0], c[1])
-    out = b"ZOLT" + (1).to_bytes(4, "little")
-    for name in ("bytecode.commitment", "bytecode.read_ts_commitment", "bytecode.write_ts_commitment"):
-        out += enc(name)
-    out += bytes(32)  # bytecode._legacy_commitment = F.zero()
-    for group in ("memory", "register"):
-        for name in ("commitment", "final_state_commitment", "read_ts_commitment", "write_ts_commitment"):
-            out += enc(f"{group}.{name}")
-    return out
-
-
-# ---- SRS wire format (G1 section)
-class SRSError(Exception):
-    pass
-
-
-def srs_g1_from_raw(data):
-    """G1 part of loadFromRawBinary (src/poly/commitment/srs.zig:256-306): u32 n (LE) | n x (x BE 32 B | y BE 32 B).
-    All-zero 64 bytes = point at infinity (parseG1Uncompressed, :65-99). Coordinates are reduced and converted to
-    Montgomery form on the GPU (Fp.fromBytesBE -> fromBytes, src/field/mod.zig:171-210). The G2 / generator trailer
-    (pairing side, out of scope) is returned untouched. -> (xy (n,8) uint64, inf (n,) uint8, trailer bytes)"""
-    if len(data) < 4:
-        raise SRSError("TruncatedData")
-    n = int.from_bytes(data[:4], "little")
-    if len(data) < 4 + 64 * n + 128 + 64 + 128:
-        raise SRSError("TruncatedData")
-    body = np.frombuffer(data, dtype=np.uint8, count=64 * n, offset=4).reshape(n, 2, 32)
-    inf = (~body.reshape(n, 64).any(axis=1)).astype(np.uint8)
-    raw = np.ascontiguousarray(body[:, :, ::-1]).view(np.uint64).reshape(n, 8)  # BE bytes -> LE limbs
-    xy = lib.field_op(lib.FP, lib.OP_TO_MONT, raw.reshape(2 * n, 4)).reshape(n, 8) if n else np.zeros((0, 8), dtype=np.uint64)
-    xy[inf == 1] = 0
-    if n and not lib.g1_is_on_curve_batch(xy, inf).all():  # parseG1Uncompressed, :93-96
-        raise SRSError("PointNotOnCurve")
-    return xy, inf, bytes(data[4 + 64 * n:])
-
-
-PTAU_MAGIC = b"ptau"
-_PTAU_HEADER, _PTAU_TAU_G1, _PTAU_TAU_G2, _PTAU_ALPHA_G1, _PTAU_BETA_G1, _PTAU_BETA_G2 = 1, 2, 3, 4, 5, 6
-
-
-def _g1_from_le(sec, count):
-    """parseG1LE (src/poly/commitment/srs.zig:616-660) over `count` 64-byte records: x | y as little-endian integers
-    (reduced like Fp.fromBytesBE of the reversed bytes), all-zero = infinity, every other point checked on the curve.
-    Conversion to Montgomery form and the curve check run on the GPU."""
-    body = np.frombuffer(sec, dtype=np.uint8, count=64 * count).reshape(count, 64)
-    inf = (~body.any(axis=1)).astype(np.uint8)
-    raw = np.ascontiguousarray(body).view(np.uint64).reshape(count, 8)  # LE bytes are already LE limbs
-    xy = lib.field_op(lib.FP, lib.OP_TO_MONT, raw.reshape(2 * count, 4)).reshape(count, 8) if count else np.zeros((0, 8), dtype=np.uint64)
-    xy[inf == 1] = 0
-    if count and not lib.g1_is_on_curve_batch(xy, inf).all():
-        raise SRSError("PointNotOnCurve")
-    return xy, inf
-
-
-def srs_g1_from_ptau(data):
-    """G1 side of loadFromPtau (src/poly/commitment/srs.zig:733-900, snarkjs powers-of-tau container): "ptau" | u32 version
-    (= 1) | u32 sections | sections (u32 type, u64 size, payload). Header payload: u32 field size (= 32) | 32-byte prime |
-    u32 power | u32 ceremony power. TauG1 holds min(2*2^power - 1, size/64) points, AlphaTauG1 / BetaTauG1 min(2^power,
-    size/64). The G2 sections (pairing side, out of scope) are returned as raw bytes.
-    -> dict(power, ceremony_power, powers_of_tau_g1=(xy, inf), alpha_tau_g1, beta_tau_g1 (or None), tau_g2_raw, beta_g2_raw)"""
-    if len(data) < 12:
-        raise SRSError("TruncatedData")
-    if data[:4] != PTAU_MAGIC:
-        raise SRSError("InvalidFileFormat")
-    if int.from_bytes(data[4:8], "little") != 1:
-        raise SRSError("UnsupportedFormat")
-    nsec = int.from_bytes(data[8:12], "little")
-    off, secs = 12, {}
-    for _ in range(nsec):
-        if off + 12 > len(data):
-            raise SRSError("TruncatedData")
-        typ = int.from_bytes(data[off:off + 4], "little")
-        size = int.from_bytes(data[off + 4:off + 12], "little")
-        off += 12
-        if off + size > len(data):
-            raise SRSError("TruncatedData")
-        secs[typ] = data[off:off + size]  # a later section of the same type wins, as in the reference's scan
-        off += size
-    if _PTAU_HEADER not in secs:
-        raise SRSError("InvalidFileFormat")
-    hdr = secs[_PTAU_HEADER]
-    if len(hdr) < 8:
-        raise SRSError("TruncatedData")
-    if int.from_bytes(hdr[:4], "little") != 32:
-        raise SRSError("UnsupportedFormat")
-    if len(hdr) < 44:
-        raise SRSError("TruncatedData")
-    power = int.from_bytes(hdr[36:40], "little")
-    out = {"power": power, "ceremony_power": int.from_bytes(hdr[40:44], "little"),
-           "powers_of_tau_g1": (np.zeros((0, 8), dtype=np.uint64), np.zeros(0, dtype=np.uint8)),
-           "alpha_tau_g1": None, "beta_tau_g1": None,
-           "tau_g2_raw": bytes(secs.get(_PTAU_TAU_G2, b"")), "beta_g2_raw": bytes(secs.get(_PTAU_BETA_G2, b""))}
-    if _PTAU_TAU_G1 in secs:
-        sec = secs[_PTAU_TAU_G1]
-        out["powers_of_tau_g1"] = _g1_from_le(sec, min((1 << power) * 2 - 1, len(sec) // 64))
-    for key, typ in (("alpha_tau_g1", _PTAU_ALPHA_G1), ("beta_tau_g1", _PTAU_BETA_G1)):
-        if typ in secs:
-            out[key] = _g1_from_le(secs[typ], min(1 << power, len(secs[typ]) // 64))
-    return out
-
-
-def srs_g1_to_raw(xy, inf, trailer=bytes(128 + 64 + 128)):
-    """serializeToRawBinary's G1 section (src/poly/commitment/srs.zig:358-408): toBytesBE of x and y."""
-    xy = np.ascontiguousarray(xy, dtype=np.uint64).reshape(-1, 8)
-    n = xy.shape[0]
-    canon = lib.field_op(lib.FP, lib.OP_FROM_MONT, xy.reshape(2 * n, 4)) if n else np.zeros((0, 4), dtype=np.uint64)
-    be = np.ascontiguousarray(canon).view(np.uint8).reshape(n, 2, 32)[:, :, ::-1]
-    return n.to_bytes(4, "little") + np.ascontiguousarray(be).tobytes() + bytes(trailer)
-
-
-# ---- polynomials
-class EqPolynomial:
-    def __init__(self, r):
-        self.r = np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4).copy()
-
-    def evals(self):
-        """EqPolynomial.evals (src/poly/mod.zig:240-242): 2^n table, index MSB <-> r[0]."""
-        return lib.fr_eq_table(self.r)
-
-    def evaluate(self, x):
-        """EqPolynomial.evaluate (src/poly/mod.zig:214-227): eq(x, r) — host scalar code, like the reference's."""
-        return EqPolynomial.mle(self.r, x)
-
-    @staticmethod
-    def mle(r, x):
-        """EqPolynomial.mle (src/poly/mod.zig:311-321): prod_i (r_i x_i + (1 - r_i)(1 - x_i))."""
-        r = np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4)
-        x = np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, 4)
-        assert r.shape[0] == x.shape[0]  # std.debug.assert(r.len == x.len)
-        acc = 1
-        for ri, xi in zip(r, x):
-            a, b = fr_to_int(ri), fr_to_int(xi)
-            acc = acc * ((a * b + (1 - a) * (1 - b)) % R_MOD) % R_MOD
-        return fr_from_int(acc)
-
-    @staticmethod
-    def evalsSliceWithScaling(r, scaling_factor=None):
-        return lib.fr_eq_table(np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4), scaling_factor)
-
-
-class EqPlusOnePolynomial:
-    """EqPlusOnePolynomial(F) (src/poly/mod.zig:332-446): eq+1(x, y) = 1 iff y = x + 1 on the cube (x[0] is the MSB). evaluate / mle are
-    the reference's host scalar formula; the table over the cube comes from the device."""
-
-    def __init__(self, x):
-        self.x = np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, 4).copy()
-
-    def evaluate(self, y):
-        return EqPlusOnePolynomial.mle(self.x, y)
-
-    @staticmethod
-    def mle(x, y):
-        """:407-435: sum over the flip position k of prod_{i<k} x_i (1 - y_i) * (1 - x_k) y_k * prod_{i>k} eq(x_i, y_i), bits counted from the LSB"""
-        xs = [fr_to_int(v) for v in np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, 4)]
-        ys = [fr_to_int(v) for v in np.ascontiguousarray(y, dtype=np.uint64).reshape(-1, 4)]
-        l = len(xs)
-        assert len(ys) == l
-        result = 0
-        for k in range(l):
-            lower = 1
-            for i in range(k):
-                idx = l - 1 - i
-                lower = lower * (xs[idx] * (1 - ys[idx]) % R_MOD) % R_MOD
-            kth = (1 - xs[l - 1 - k]) * ys[l - 1 - k] % R_MOD
-            higher = 1
-            for i in range(k + 1, l):
-                idx = l - 1 - i
-                higher = higher * ((xs[idx] * ys[idx] + (1 - xs[idx]) * (1 - ys[idx])) % R_MOD) % R_MOD
-            result = (result + lower * kth % R_MOD * higher) % R_MOD
-        return fr_from_int(result)
-
-    def evals(self):
-        """the table over the cube (computeEqPlusOneEvals, :530-548)"""
-        return lib.fr_eq_plus_one_table(self.x)
-
-
-class EqPlusOnePrefixSuffixPoly:
-    """EqPlusOnePrefixSuffixPoly(F).init (src/poly/mod.zig:462-528): r = (r_hi || r_lo) split at len / 2; prefix_0 = eq+1(r_lo, .),
-    suffix_0 = eq(r_hi, .), prefix_1 = is_max(r_lo) at index 0, suffix_1 = eq+1(r_hi, .) — three table builds on the device."""
-
-    def __init__(self, r):
-        r = np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4)
-        assert r.shape[0] >= 2
-        mid = r.shape[0] // 2
-        r_hi, r_lo = r[:mid], r[mid:]
-        self.prefix_0 = lib.fr_eq_plus_one_table(r_lo)
-        self.suffix_0 = lib.fr_eq_table(r_hi)
-        self.suffix_1 = lib.fr_eq_plus_one_table(r_hi)
-        is_max = 1
-        for v in r_lo:
-            is_max = is_max * fr_to_int(v) % R_MOD
-        self.prefix_1 = np.zeros_like(self.prefix_0)
-        self.prefix_1[0] = fr_from_int(is_max)
-
-    def prefixSize(self):
-        return self.prefix_0.shape[0]
-
-    def suffixSize(self):
-        return self.suffix_0.shape[0]
-
-
-class GruenSplitEqPolynomial:
-    """GruenSplitEqPolynomial (src/poly/split_eq.zig:22-514). The prefix-table set is built on the device in one launch per
-    half (zg_fr_eq_prefix_tables); bind / computeCubicRoundPoly are the reference's host scalar algebra; getFullEqTable and
-    getEActiveForWindow are eq-table builds on the device."""
-
-    def __init__(self, tau, scaling_factor=None):
-        """init / initWithScaling (:51-183): m = len/2, w_out = tau[0..m), w_in = tau[m..len-1), tau[len-1] stays out of the tables"""
-        self.tau = np.ascontiguousarray(tau, dtype=np.uint64).reshape(-1, 4).copy()
-        n = self.tau.shape[0]
-        self.current_index = n
-        self.current_scalar = fr_from_int(1) if scaling_factor is None else np.ascontiguousarray(scaling_factor, dtype=np.uint64).copy()
-        self._d_out = self._d_in = None  # the same table sets in HBM, built on first use by getWindowEqTablesDev
-        if n == 0:  # :75-86: a valid object without tables (deinit is a no-op)
-            self.E_out_vec, self.E_in_vec, self.num_x_out, self.num_x_in = [], [], 0, 0
-            return
-        m = n // 2
-        self.num_x_out = m
-        self.num_x_in = min(n - 1 - m, n - 1) if n > 1 else 0
-        self.E_out_vec = list(lib.fr_eq_prefix_tables(self.tau[:m]))
-        self.E_in_vec = list(lib.fr_eq_prefix_tables(self.tau[m:m + self.num_x_in]))
-
-    init = classmethod(lambda cls, tau: cls(tau))
-    initWithScaling = classmethod(lambda cls, tau, scaling_factor: cls(tau, scaling_factor))
-
-    def bind(self, r):
-        """bind (:213-248): current_scalar *= eq(tau[current_index-1], r); pops the largest E_in (then E_out) table, never table 0"""
-        if self.current_index == 0:
-            return
-        t, rv = fr_to_int(self.tau[self.current_index - 1]), fr_to_int(r)
-        eq_val = (t * rv + (1 - t) * (1 - rv)) % R_MOD
-        self.current_scalar = fr_from_int(fr_to_int(self.current_scalar) * eq_val % R_MOD)
-        self.current_index -= 1
-        m = self.tau.shape[0] // 2
-        if m < self.current_index:
-            if len(self.E_in_vec) > 1:
-                self.E_in_vec.pop()
-        elif self.current_index > 0:
-            if len(self.E_out_vec) > 1:
-                self.E_out_vec.pop()
-
-    def getFullEqTable(self):
-        """getFullEqTable (:254-285): eq(tau[0..current_index), .) scaled by current_scalar, tau[0] <-> MSB"""
-        return lib.fr_eq_table(self.tau[:self.current_index], self.current_scalar)
-
-    def getTauHigh(self):
-        """getTauHigh (:291-294)"""
-        return self.tau[-1].copy() if self.tau.shape[0] else fr_from_int(0)
-
-    def getWindowEqTables(self, num_unbound_vars, window_size):
-        """getWindowEqTables (:312-343); the first argument is ignored, as in the reference. -> (E_out, E_in, head_in_bits)"""
-        num_unbound = self.current_index
-        head_len = max(num_unbound - min(window_size, num_unbound), 0)
-        m = self.tau.shape[0] // 2
-        head_out_bits = min(head_len, m)
-        head_in_bits = max(head_len - head_out_bits, 0)
-        one = fr_from_int(1).reshape(1, 4)  # (an object over no variables has no tables: the empty product)
-        e_out = one if not self.E_out_vec else (self.E_out_vec[head_out_bits] if head_out_bits < len(self.E_out_vec) else self.E_out_vec[-1])
-        e_in = one if not self.E_in_vec else (self.E_in_vec[head_in_bits] if head_in_bits < len(self.E_in_vec) else self.E_in_vec[-1])
-        return e_out, e_in, head_in_bits
-
-    def getWindowEqTablesDev(self, window_size):
-        """getWindowEqTables for device consumers (zg_psc_round_gruen): (d_E_out, |E_out|, d_E_in, |E_in|) — pointers into the two
-        prefix-table buffers zg_fr_eq_prefix_tables_dev filled (table k starts at element 2^k - 1); bind()'s pops only shorten the lists."""
-        if self._d_out is None:
-            m = self.tau.shape[0] // 2
-            self._d_out = lib.DeviceBuffer(((2 << m) - 1) * 32)
-            self._d_in = lib.DeviceBuffer(((2 << self.num_x_in) - 1) * 32)
-            lib.fr_eq_prefix_tables_dev(self.tau[:m], self._d_out.ptr)
-            lib.fr_eq_prefix_tables_dev(self.tau[m:m + self.num_x_in], self._d_in.ptr)
-            lib.sync()  # the consumers read the tables on their sessions' own streams
-        num_unbound = self.current_index
-        head_len = max(num_unbound - min(window_size, num_unbound), 0)
-        head_out_bits = min(head_len, self.tau.shape[0] // 2)
-        head_in_bits = max(head_len - head_out_bits, 0)
-        ko = min(head_out_bits, len(self.E_out_vec) - 1)
-        ki = min(head_in_bits, len(self.E_in_vec) - 1)
-        return self._d_out.ptr + ((1 << ko) - 1) * 32, 1 << ko, self._d_in.ptr + ((1 << ki) - 1) * 32, 1 << ki
-
-    def deinit(self):
-        for b in (self._d_out, self._d_in):
-            if b is not None:
-                b.free()
-        self._d_out = self._d_in = None
-
-    def getCurrentEqFactors(self):
-        """getCurrentEqFactors (:441-452) -> (eq_0, eq_1)"""
-        if self.current_index == 0:
-            return self.current_scalar.copy(), self.current_scalar.copy()
-        cs, t = fr_to_int(self.current_scalar), fr_to_int(self.tau[self.current_index - 1])
-        return fr_from_int(cs * (1 - t) % R_MOD), fr_from_int(cs * t % R_MOD)
-
-    def computeCubicRoundPoly(self, q_constant, q_quadratic_coeff, previous_claim):
-        """computeCubicRoundPoly (:353-434): [s(0), s(1), s(2), s(3)] with s = l*q, q(1) recovered from the claim"""
-        claim = fr_to_int(previous_claim)
-        if self.current_index == 0:
-            return np.stack([fr_from_int(claim), fr_from_int(0), fr_from_int(0), fr_from_int(0)])
-        cs, t = fr_to_int(self.current_scalar), fr_to_int(self.tau[self.current_index - 1])
-        c, e = fr_to_int(q_constant), fr_to_int(q_quadratic_coeff)
-        l0, l1 = cs * (1 - t) % R_MOD, cs * t % R_MOD
-        slope = (l1 - l0) % R_MOD
-        l2, l3 = (l0 + 2 * slope) % R_MOD, (l0 + 3 * slope) % R_MOD
-        q1 = 0 if l1 == 0 else (claim - l0 * c) * pow(l1, R_MOD - 2, R_MOD) % R_MOD
-        q2 = (2 * q1 - c + 2 * e) % R_MOD
-        q3 = (q2 + q1 - c + 4 * e) % R_MOD
-        return np.stack([fr_from_int(l0 * c % R_MOD), fr_from_int(l1 * q1 % R_MOD), fr_from_int(l2 * q2 % R_MOD), fr_from_int(l3 * q3 % R_MOD)])
-
-    def getEActiveForWindow(self, window_size):
-        """getEActiveForWindow (:466-514): eq over the window's bits except the current one; [1] for windows of 0/1 or too wide"""
-        if window_size <= 1 or window_size > self.current_index:
-            return fr_from_int(1).reshape(1, 4)
-        ws = self.current_index - window_size
-        return lib.fr_eq_table(self.tau[ws:ws + window_size - 1])
-
-
-class DensePolynomial:
-    def __init__(self, evaluations):
-        ev = np.ascontiguousarray(evaluations, dtype=np.uint64).reshape(-1, 4)
-        n = ev.shape[0]
-        assert n and n & (n - 1) == 0  # src/poly/mod.zig:36-37
-        self.evaluations = ev.copy()
-        self.num_vars = n.bit_length() - 1
-
-    def len(self):
-        return self.evaluations.shape[0]
-
-    def evaluate(self, point):
-        """DensePolynomial.evaluate (src/poly/mod.zig:73-92), index bit j <-> point[j]."""
-        point = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1, 4)
-        assert point.shape[0] == self.num_vars
-        return lib.fr_dense_evaluate(self.evaluations, point)
-
-    def add(self, other):
-        """DensePolynomial.add (src/poly/mod.zig:94-110) -> new polynomial"""
-        assert self.num_vars == other.num_vars
-        return DensePolynomial(lib.field_op(lib.FR, lib.OP_ADD, self.evaluations, other.evaluations))
-
-    def scale(self, scalar):
-        """DensePolynomial.scale (src/poly/mod.zig:112-126) -> new polynomial"""
-        return DensePolynomial(lib.fr_scale(self.evaluations, scalar))
-
-    def bindFirst(self, value):
-        """high-half fold into a NEW polynomial (src/poly/mod.zig:128-149)."""
-        assert self.num_vars > 0
-        return DensePolynomial(lib.fr_bind_high(self.evaluations, value))
-
-    def bindLow(self, value):
-        """adjacent-pair fold IN PLACE (src/poly/mod.zig:160-175)."""
-        assert self.num_vars > 0
-        self.evaluations = lib.fr_bind_low(self.evaluations, value)
-        self.num_vars -= 1
-
-
-# ---- sumcheck
-class SumcheckVerificationFailed(Exception):
-    pass
-
-
-class Sumcheck:
-    class Prover:
-        """Sumcheck(F).Prover with the polynomial resident on the GPU (src/subprotocols/mod.zig:50-134)."""
-
-        def __init__(self, polynomial):
-            self._s = lib.SumcheckSession.open(polynomial.evaluations, lib.SC_HIGH_HALF)
-            self.round = 0
-
-        def nextRound(self):
-            """-> coeffs [g(0), g(1) - g(0)] (src/subprotocols/mod.zig:69-109)."""
-            g0, g1 = self._s.round_sums()
-            c1 = _limbs((_int(g1) - _int(g0)) % R_MOD)  # Montgomery form is linear: sub on limbs mod r
-            return np.stack([g0, c1])
-
-        def receiveChallenge(self, challenge):
-            self._s.bind(challenge)
-            self.round += 1
-
-        def isComplete(self):
-            return len(self._s) == 1
-
-        def getFinalEval(self):
-            assert self.isComplete()
-            return self._s.final()
-
-        def deinit(self):
-            self._s.close()
-
-    class Verifier:
-        """Toy verifier with the deterministic 64-bit mixer (src/subprotocols/mod.zig:137-244)."""
-
-        def __init__(self, claim):
-            self.claim = np.asarray(claim, dtype=np.uint64)
-            self.round = 0
-            self.challenges = []
-
-        @staticmethod
-        def _eval(coeffs, x_int):
-            """UniPoly.evaluate by Horner (src/poly/mod.zig:608-618) on canonical ints."""
-            res = 0
-            for c in reversed(coeffs):
-                res = (res * x_int + c) % R_MOD
-            return res
-
-        def deriveChallenge(self, coeffs):
-            h = 0x9E3779B97F4A7C15
-            h ^= self.round
-            h = (h * 0xFF51AFD7ED558CCD) & _M64
-            for limb in self.claim:
-                h ^= int(limb)
-                h = (h * 0xC4CEB9FE1A85EC53) & _M64
-            for c in coeffs:
-                for limb in c:
-                    h ^= int(limb)
-                    h = (h * 0xFF51AFD7ED558CCD) & _M64
-                    h ^= h >> 33
-            h ^= h >> 33
-            h = (h * 0xFF51AFD7ED558CCD) & _M64
-            h ^= h >> 33
-            return h
-
-        def verifyRound(self, coeffs):
-            ci = [fr_to_int(c) for c in coeffs]
-            p0, p1 = self._eval(ci, 0), self._eval(ci, 1)
-            if (p0 + p1) % R_MOD != fr_to_int(self.claim):
-                raise SumcheckVerificationFailed()
-            h = self.deriveChallenge(coeffs)
-            challenge = fr_from_int(h)
-            self.challenges.append(challenge)
-            self.claim = fr_from_int(self._eval(ci, h))
-            self.round += 1
-            return challenge
-
-
-def sumcheck_shard_slice(length, world, rank, layout):
-    """Index set of rank `rank` for a table sharded over `world` (a power of two) ranks such that every fold of
-    the first log2(length/world) rounds is local:
-      LOW_PAIR  (pairs 2i,2i+1 — DensePolynomial.bindLow, src/poly/mod.zig:160-175): contiguous chunk (high bits);
-      HIGH_HALF (pairs i,i+half — bindFirst, :128-149): the residue class i ≡ rank (mod world) (low bits).
-    Returns a slice usable on the full table."""
-    assert world & (world - 1) == 0 and length % world == 0
-    if layout == lib.SC_LOW_PAIR:
-        c = length // world
-        return slice(rank * c, (rank + 1) * c)
-    return slice(rank, length, world)
-
-
-def sharded_eq_args(r, world, rank, layout, scaling_factor=None):
-    """Arguments (r_local, scale_local) with which a rank builds ITS shard of EqPolynomial.evals(r) (big-endian:
-    r[0] <-> MSB, src/poly/mod.zig:252-290) with one ordinary eq-table build: the shard is the eq table of the
-    remaining variables scaled by eq(shared variables, rank bits) — the "shared prefix scalar" of SURVEY §8(e).
-    Host arithmetic on log2(world) challenges only."""
-    g = world.bit_length() - 1
-    v = len(r)
-    assert g <= v
-    ri = [fr_to_int(x) for x in r]
-    # LOW_PAIR shards by the high index bits = r[0..g); HIGH_HALF shards by the low index bits = r[v-g..v)
-    shared, rest = (ri[:g], r[g:]) if layout == lib.SC_LOW_PAIR else (ri[v - g:], r[:v - g])
-    sc = fr_to_int(scaling_factor) if scaling_factor is not None else 1
-    for j, rv in enumerate(shared):
-        bit = (rank >> (g - 1 - j)) & 1
-        sc = sc * (rv if bit else (1 - rv)) % R_MOD
-    return np.asarray(rest, dtype=np.uint64).reshape(-1, 4), fr_from_int(sc)
-
-
-class ShardedSumcheck:
-    """Sumcheck(F).Prover (src/subprotocols/mod.zig:50-134) over a table sharded across GPUs.
-
-    Every rank holds `sumcheck_shard_slice` of the table in an ordinary device session; a round is: local pair of
-    sums -> ONE all-gather of 64 B per rank -> modular sum on the host (field addition is exact, so the order of the
-    ranks does not matter) -> the caller's transcript derives the challenge -> local fold. After
-    log2(len/world) rounds each rank is left with one element; those `world` elements are all-gathered once and
-    the last log2(world) rounds run redundantly on every rank in a tiny session. Outputs are the reference's.
-
-    `backend` supplies the device operations (GpuSumcheckShardBackend; the gloo CPU test plugs in a CPU-side one):
-        round_sums() -> torch int64[8] (local g0||g1)      bind(challenge)      local_len()
-        residual()   -> torch int64[4]                     open_tail(table u64[world,4]) -> session-like
-    """
-
-    def __init__(self, backend, world_size, rank, group=None):
-        assert world_size & (world_size - 1) == 0, "world size must be a power of two"
-        self.backend, self.world, self.rank, self.group = backend, world_size, rank, group
-        self._tail = None
-        self.round = 0
-        if self.backend.local_len() == 1:
-            self._enter_tail()
-
-    def _all_gather(self, t):
-        import torch
-        import torch.distributed as dist
-        if self.world == 1 and not dist.is_initialized():
-            return t.reshape(1, -1)
-        if dist.get_backend(self.group) == "gloo" and t.is_cuda:  # several ranks sharing one GPU (debugging / tests)
-            parts = [torch.empty(t.numel(), dtype=torch.int64) for _ in range(self.world)]
-            dist.all_gather(parts, t.cpu(), group=self.group)
-            return torch.stack(parts)
-        out = torch.empty((self.world, t.numel()), dtype=torch.int64, device=t.device)
-        dist.all_gather_into_tensor(out, t.reshape(1, -1), group=self.group)
-        return out
-
-    def _enter_tail(self):
-        res = self._all_gather(self.backend.residual()).cpu().numpy().view(np.uint64).reshape(self.world, 4)
-        self._tail = self.backend.open_tail(res) if self.world > 1 else None
-        self._final = res[0].copy() if self.world == 1 else None
-
-    def nextRound(self):
-        """-> coeffs [g(0), g(1) - g(0)] of the WHOLE table."""
-        if self._tail is not None:
-            g0, g1 = self._tail.round_sums()
-            a, b = _int(g0), _int(g1)
-        else:
-            rec = self._all_gather(self.backend.round_sums()).cpu().numpy().view(np.uint64).reshape(self.world, 8)
-            a = sum(_int(x[:4]) for x in rec) % R_MOD
-            b = sum(_int(x[4:]) for x in rec) % R_MOD
-        return np.stack([_limbs(a), _limbs((b - a) % R_MOD)])
-
-    def receiveChallenge(self, challenge):
-        if self._tail is not None:
-            self._tail.bind(challenge)
-        else:
-            self.backend.bind(challenge)
-            if self.backend.local_len() == 1:
-                self._enter_tail()
-        self.round += 1
-
-    def isComplete(self):
-        if self._tail is not None:
-            return len(self._tail) == 1
-        return self.backend.local_len() == 1 and self.world == 1
-
-    def getFinalEval(self):
-        assert self.isComplete()
-        return self._tail.final() if self._tail is not None else self._final
-
-    def deinit(self):
-        if self._tail is not None:
-            self._tail.close()
-        self.backend.close()
-
-
-class GpuSumcheckShardBackend:
-    """ShardedSumcheck backend over libzolt_gpu.so. `d_local` is this rank's shard (torch CUDA int64[len,4], Montgomery
-    limbs); the session runs on torch's CURRENT stream so that the RCCL all-gather (torch.distributed orders it
-    against that stream) follows the sums kernel without a host synchronisation."""
-
-    def __init__(self, d_local, layout):
-        import torch
-        self.layout = layout
-        self.dev = d_local.device
-        self._st = GpuShardBackend._stream()
-        self._s = lib.SumcheckSession.open_dev(d_local.data_ptr(), d_local.shape[0], layout, stream=self._st)
-
-    def local_len(self):
-        return len(self._s)
-
-    def round_sums(self):
-        import torch
-        out = torch.empty(8, dtype=torch.int64, device=self.dev)
-        self._s.round_sums_dev(out.data_ptr())
-        return out
-
-    def bind(self, challenge):
-        self._s.bind(challenge)
-
-    def residual(self):
-        import torch
-        out = torch.empty(4, dtype=torch.int64, device=self.dev)
-        self._s.read_dev(out.data_ptr())
-        return out
-
-    def open_tail(self, table):
-        return lib.SumcheckSession.open(table, self.layout)
-
-    def close(self):
-        self._s.close()
-
-
-def runSumcheck(polynomial):
-    """runSumcheck (src/subprotocols/mod.zig:302-354) -> dict(claim, rounds, final_point, final_eval, result), with the
-    prover AND the toy verifier on the device (zg_run_sumcheck): no PCIe crossing between rounds. Raises
-    SumcheckVerificationFailed where the reference returns that error."""
-    try:
-        out = lib.run_sumcheck(polynomial.evaluations)
-    except lib.SumcheckVerificationFailed as e:
-        raise SumcheckVerificationFailed(str(e)) from None
-    out["rounds"] = list(out["rounds"])
-    out["final_point"] = list(out["final_point"])
-    return out
-
-
-def runSumcheckInteractive(polynomial):
-    """The same protocol with the verifier on the host and one device round trip per round — the shape a prover with
-    a real (Keccak/Blake2b) transcript has. Same outputs as runSumcheck."""
-    s = lib.SumcheckSession.open(polynomial.evaluations, lib.SC_HIGH_HALF)
-    g0, g1 = s.round_sums() if polynomial.num_vars else (polynomial.evaluations[0], np.zeros(4, dtype=np.uint64))
-    s.close()
-    claim = _limbs((_int(g0) + _int(g1)) % R_MOD)
-    prover = Sumcheck.Prover(polynomial)
-    verifier = Sumcheck.Verifier(claim)
-    rounds = []
-    for _ in range(polynomial.num_vars):
-        coeffs = prover.nextRound()
-        ch = verifier.verifyRound(coeffs)
-        prover.receiveChallenge(ch)
-        rounds.append(coeffs)
-    final_eval = prover.getFinalEval()
-    prover.deinit()
-    return {"claim": claim, "rounds": rounds, "final_point": list(verifier.challenges), "final_eval": final_eval,
-            "result": bool(np.array_equal(verifier.claim, final_eval))}
-
-
-# ---- host Fiat-Shamir transcript + the prover fold sites driven by it
-_KECCAK_RC = [0x0000000000000001, 0x0000000000008082, 0x800000000000808a, 0x8000000080008000, 0x000000000000808b, 0x0000000080000001,
-              0x8000000080008081, 0x8000000000008009, 0x000000000000008a, 0x0000000000000088, 0x0000000080008009, 0x000000008000000a,
-              0x000000008000808b, 0x800000000000008b, 0x8000000000008089, 0x8000000000008003, 0x8000000000008002, 0x8000000000000080,
-              0x000000000000800a, 0x800000008000000a, 0x8000000080008081, 0x8000000000008080, 0x0000000080000001, 0x8000000080008008]
-_KECCAK_ROTC = [1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44]
-_KECCAK_PILN = [10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1]
-
-
-class Transcript:
-    """Transcript(F) — the reference's Keccak Fiat-Shamir transcript (src/transcripts/mod.zig:49-221), on the host, where it stays
-    in the reference integration too: a sequential hash between rounds. Field elements go in as their raw Montgomery limbs
-    (appendScalar, :100-110) and challenges come out through F.fromBytes (:116-130), so it plugs straight onto the C ABI's limbs."""
-    KECCAK_RATE = 136
-
-    def __init__(self, domain=b"Jolt"):
-        self.state = bytearray(200)
-        self.position = 0
-        self.appendBytes(domain)
-
-    def _keccakF(self):
-        st = [int.from_bytes(self.state[8 * i:8 * i + 8], "little") for i in range(25)]
-        for rc in _KECCAK_RC:
-            bc = [st[i] ^ st[i + 5] ^ st[i + 10] ^ st[i + 15] ^ st[i + 20] for i in range(5)]
-            for i in range(5):
-                b1 = bc[(i + 1) % 5]
-                t = bc[(i + 4) % 5] ^ (((b1 << 1) | (b1 >> 63)) & _M64)
-                for j in range(i, 25, 5):
-                    st[j] ^= t
-            t = st[1]
-            for i in range(24):
-                j, n = _KECCAK_PILN[i], _KECCAK_ROTC[i]
-                st[j], t = ((t << n) | (t >> (64 - n))) & _M64, st[j]
-            for row in range(0, 25, 5):
-                b = st[row:row + 5]
-                for i in range(5):
-                    st[row + i] = b[i] ^ ((~b[(i + 1) % 5]) & _M64 & b[(i + 2) % 5])
-            st[0] ^= rc
-        for i, v in enumerate(st):
-            self.state[8 * i:8 * i + 8] = v.to_bytes(8, "little")
-
-    def appendBytes(self, data):
-        for byte in bytes(data):
-            self.state[self.position] ^= byte
-            self.position += 1
-            if self.position >= self.KECCAK_RATE:
-                self._keccakF()
-                self.position = 0
-
-    def appendMessage(self, label, message):
-        self.appendBytes(label)
-        self.appendBytes(message)
-
-    def appendScalar(self, label, scalar):
-        self.appendBytes(label)
-        self.appendBytes(np.ascontiguousarray(scalar, dtype="<u8").tobytes())
-
-    def appendScalars(self, label, scalars):
-        self.appendBytes(label)
-        for s in np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4):
-            self.appendScalar(b"", s)
-
-    def challengeScalar(self, label):
-        self.appendBytes(label)
-        self._keccakF()
-        raw = np.frombuffer(bytes(self.state[:32]), dtype="<u8").astype(np.uint64)
-        return _limbs((_int(raw) % R_MOD) * _MONT_R % R_MOD)  # F.fromBytes: the 256-bit little-endian integer, reduced, Montgomery
-
-    def challengeScalars(self, label, count):
-        self.appendBytes(label)
-        return np.stack([self.challengeScalar(b"") for _ in range(count)]) if count else np.zeros((0, 4), dtype=np.uint64)
-
-    def challengeBytes(self, label, n):
-        """challengeBytes (:143-160): one Keccak-f per 136 output bytes, each block read from the start of the state"""
-        self.appendBytes(label)
-        out = b""
-        while len(out) < n:
-            self._keccakF()
-            out += bytes(self.state[:min(n - len(out), self.KECCAK_RATE)])
-        return out
-
-
-def _fr_add(a, b):
-    return _limbs((_int(a) + _int(b)) % R_MOD)
-
-
-def _fr_sub(a, b):
-    return _limbs((_int(a) - _int(b)) % R_MOD)
-
+from .. import lib
+from ._base import *  # noqa: F401,F403
+from .msm import *  # noqa: F401,F403
+from .commitment import *  # noqa: F401,F403
+from .wire import *  # noqa: F401,F403
+from .poly import *  # noqa: F401,F403
+from .sumcheck import *  # noqa: F401,F403
+from .transcript import *  # noqa: F401,F403
 
 def proveStage1(combined_poly, num_rounds, transcript):
     """The Stage-1 (outer Spartan) round loop of MultiStageProver.proveStage1 (src/zkvm/prover.zig:397-432) over
@@ -3145,62 +2017,4 @@ def runLassoProver(lookup_indices_u128, log_T, log_K, r_reduction):
     return out
 
 
-class Blake2bTranscript:
-    """Blake2bTranscript(F) — the Jolt-compatible transcript the reference's proving path uses (src/transcripts/blake2b.zig:25-545):
-    a 32-byte running state and a round counter; every operation hashes state || [0u8; 28] || n_rounds_be32 || payload with
-    Blake2b-256 and the digest becomes the new state. Host code (hashlib), like the Keccak one above."""
-
-    def __init__(self, label=b"Jolt"):
-        import hashlib
-        label = bytes(label)
-        assert len(label) < 33
-        self._blake = lambda data: hashlib.blake2b(data, digest_size=32).digest()
-        self.state = self._blake(label.ljust(32, b"\0"))  # :39-69
-        self.n_rounds = 0
-
-    def _hash_with(self, payload):
-        """hasher() (:76-87) + payload, then updateState (:90-93)"""
-        out = self._blake(self.state + bytes(28) + self.n_rounds.to_bytes(4, "big") + bytes(payload))
-        self.state = out
-        self.n_rounds += 1
-        return out
-
-    def appendMessage(self, msg):  # :96-120: right-padded to 32 bytes
-        msg = bytes(msg)
-        assert len(msg) < 33
-        self._hash_with(msg.ljust(32, b"\0"))
-
-    def appendBytes(self, data):  # :123-156
-        self._hash_with(bytes(data))
-
-    def appendU64(self, x):  # :160-176: [0u8; 24] ++ x.to_be_bytes()
-        self._hash_with(bytes(24) + int(x).to_bytes(8, "big"))
-
-    def appendScalar(self, scalar):  # :182-200: canonical value, little-endian bytes reversed to big-endian
-        self.appendBytes(fr_to_int(scalar).to_bytes(32, "big"))
-
-    def appendScalars(self, scalars):  # :205-211
-        self.appendMessage(b"begin_append_vector")
-        for s in np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4):
-            self.appendScalar(s)
-        self.appendMessage(b"end_append_vector")
-
-    def challengeBytes(self, n):  # :215-240
-        out = b""
-        while n - len(out) > 32:
-            out += self._hash_with(b"")
-        return out + self._hash_with(b"")[:n - len(out)]
-
-    def challengeU128(self):  # :243-254
-        return int.from_bytes(self.challengeBytes(16)[::-1], "big")
-
-    def challengeScalarFull(self):  # :279-312: the 128-bit value as a proper Montgomery element
-        buf = self.challengeBytes(16)[::-1]
-        return fr_from_int(int.from_bytes(buf, "little"))
-
-    def challengeScalar(self):  # :264-266,332-390: 125-bit mask, stored as RAW limbs [0, 0, low, high] (MontU128Challenge)
-        v = int.from_bytes(self.challengeBytes(16)[::-1], "big") & ((1 << 125) - 1)
-        return np.array([0, 0, v & _M64, v >> 64], dtype=np.uint64)
-
-    def challengeVector(self, n):  # :392-399 (challengeScalar each)
-        return np.stack([self.challengeScalar() for _ in range(n)]) if n else np.zeros((0, 4), dtype=np.uint64)
+__all__ = [_k for _k in dir() if not _k.startswith("__")]  # underscore helpers are shared between the parts too
