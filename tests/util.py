@@ -146,6 +146,77 @@ def fibonacci_full_trace(elf_bytes, steps=54, padded=256):
     return out + [dict(noop) for _ in range(padded - len(out))]
 
 
+def fibonacci_lookup_indices(elf_bytes, steps=54):
+    """LookupTraceCollector.recordInstruction's entries for the captured fibonacci run (src/zkvm/instruction/lookup_trace.zig:843-1015, the
+    tracer records one per instruction BEFORE it executes, src/tracer/mod.zig:269-277), as the u128 lookup indices LassoProver reads
+    (src/zkvm/prover.zig:609-612) — 44 entries for the 54 cycles: ADDIW (opcode OP_IMM_32) is not recorded. Per form
+    (src/zkvm/instruction/lookups.zig): ADDI -> the wrapped sum rs1 + imm (AddLookup.toLookupIndex :49-54); SLLI -> interleaveBits(rs1,
+    shamt) (:982); BNE -> interleaveBits(rs1, rs2) (:406-408); ADDW -> the sign-extended 32-bit sum (:1706), SUBW -> the interleaved low
+    words (:1757); JAL / JALR -> pc + 4 (:720, :777); LUI -> the sign-extended immediate (:622-630). interleaveBits (lookup_table/mod.zig:52-73)
+    puts x on the odd and y on the even bit positions. Test infrastructure for the proof-file fixture: -> (n, 2) uint64 (low, high)."""
+    import numpy as np
+    recs = []
+    fibonacci_rd_values(elf_bytes, steps, recs)
+    mask = (1 << 64) - 1
+
+    def sx(v, b):
+        return v - (1 << b) if v >> (b - 1) else v
+
+    def interleave(x, y):
+        r = 0
+        for i in range(64):
+            r |= ((x >> i) & 1) << (2 * i + 1)
+            r |= ((y >> i) & 1) << (2 * i)
+        return r
+
+    idx = []
+    for w, _, a, b, pc in recs:
+        op, f3, f7, imm_i = w & 0x7F, (w >> 12) & 7, w >> 25, sx(w >> 20, 12)
+        if op == 0x13 and f3 == 0:
+            idx.append((a + imm_i) & mask)
+        elif op == 0x13 and f3 == 1:
+            idx.append(interleave(a, (w >> 20) & 0x3F))
+        elif op == 0x3B and f3 == 0:
+            idx.append(interleave(a & 0xFFFFFFFF, b & 0xFFFFFFFF) if f7 & 0x20 else sx((a + b) & 0xFFFFFFFF, 32) & mask)
+        elif op == 0x63:
+            idx.append(interleave(a, b))
+        elif op in (0x6F, 0x67):
+            idx.append((pc + 4) & mask)
+        elif op == 0x37:
+            idx.append(sx(w & 0xFFFFF000, 32) & mask)
+        elif op != 0x1B:
+            raise ValueError(f"unexpected instruction {w:08x}")
+    return np.array([[v & mask, v >> 64] for v in idx], dtype=np.uint64)
+
+
+def proof_file_sections():
+    """tests/golden/proof_stage_sections.json (make_proof_sections_fixture.py): the stage records of the reference's captured proof file"""
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "proof_stage_sections.json")) as fh:
+        return json.load(fh)
+
+
+def serialize_stage_sections(log_t, log_k, stages):
+    """the bytes serializeProof writes after the 744-byte header (src/zkvm/serialization.zig:308-343, stage records :186-227) for the
+    R1CS placeholder the standard prover emits (R1CSProof.placeholder: one zero tau, three zero claims, one zero eval point, zero claim /
+    final_eval, no rounds, empty final point) and six stage records; stages: [(round_polys, challenges, final_claims)] of canonical ints"""
+    import struct
+
+    def fe(v):
+        return int(v).to_bytes(32, "little")
+
+    out = bytearray()
+    out += struct.pack("<Q", 1) + fe(0) + fe(0) * 3 + struct.pack("<Q", 1) + fe(0) + fe(0) + fe(0) + struct.pack("<Q", 0) + struct.pack("<Q", 0)
+    out += b"\x01" + struct.pack("<QQ", log_t, log_k)
+    for polys, chals, claims in stages:
+        out += struct.pack("<Q", len(polys))
+        for p in polys:
+            out += struct.pack("<Q", len(p)) + b"".join(fe(c) for c in p)
+        out += struct.pack("<Q", len(chals)) + b"".join(fe(c) for c in chals)
+        out += struct.pack("<Q", len(claims)) + b"".join(fe(c) for c in claims)
+    return bytes(out)
+
+
 def output_check_tables_of_the_captured_run(oc, elf_bytes, fr_from_int, eq_table):
     """The five tables OutputSumcheckProver.init (src/zkvm/ram/output_check.zig:100-365) built in the reference's captured fibonacci
     run, from what logs/zolt.log states about it (tests/golden/stage2_batched_rounds.json "output_check"): K = 2^16 words; the 13
