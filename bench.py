@@ -34,11 +34,11 @@ sys.path.insert(0, ROOT)
 # with the kernel's load shape report 1.04x their bytes (no correction), a sequential 16 B/lane stream reports 0.50x (the gfx950
 # x2 of MI355X_MICROARCH.md). The launch gathers 15.7M rows (1.007 GB, taken as counted) and streams 63 MB of sorted
 # references (counted at half: +31 MB).
-MEASURED_TRAFFIC = {20: 1222851.1 * 1024.0 + 0.5 * 4.0 * 15.73e6 + 28689.5 * 1024.0}
+MEASURED_TRAFFIC = {20: 1218561.0 * 1024.0 + 0.5 * 4.0 * 15.73e6 + 28685.2 * 1024.0}
 TRAFFIC_SOURCE = ("rocprofv3 PMC FETCH_SIZE (+x2 on the streamed 63 MB of sorted references, x1 on the gathered 64-byte rows: calibrated with "
-                  "tools/microbench gather|stream) + WRITE_SIZE, profiles/r3final_rocprofv3_summary.txt: FETCH_SIZE 1,222,851 KB, WRITE_SIZE 28,690 KB per launch "
-                  "(r3z: 1,256,199 KB, r3a: 1,314,038 KB; round 2 r2a/r2e: 1,248,779 / 1,253,897 KB; 2^22 as four point slices: 1,181,588 KB per launch, "
-                  "profiles/r3final_rocprofv3_summary_2^22.txt)")
+                  "tools/microbench gather|stream) + WRITE_SIZE, profiles/r4final_rocprofv3_summary.txt: FETCH_SIZE 1,218,561 KB, WRITE_SIZE 28,685 KB per launch "
+                  "(r3final: 1,222,851 KB, r3z: 1,256,199 KB, r3a: 1,314,038 KB; round 2 r2a/r2e: 1,248,779 / 1,253,897 KB; 2^22 as four point slices: 1,195,017 KB "
+                  "per launch, profiles/r4final_rocprofv3_summary_2^22.txt)")
 # static instruction mix of one lazy-limb XYZZ mixed add (hipcc --save-temps of the accumulate fast path): 1467
 # v_mad_u64_u32 + 146 v_lshl_add_u64 + 144 v_lshrrev_b64 + 81 v_mul_lo_u32 at 4 issue cycles per wave, 382 32-bit
 # add/and/shift/sub at 2 (tools/microbench.hip rates)
@@ -49,10 +49,10 @@ VALU_PEAK_GCYC = 1024 * 2.4  # 256 CUs x 4 SIMDs x 2.4 GHz
 # 2.113, 32-bit add 1.183): the least time one SIMD needs for one wave-wide mixed add, clocks as they really are under this load
 MADD_MIN_NS_PER_SIMD = 1467 * 2.034 + (146 + 144) * 2.181 + 81 * 2.113 + 382 * 1.183
 # The executed instruction count from the counters instead of the static mix (round-3 review): SQ_INSTS_VALU per msm_accumulate launch at
-# 2^20 points, rocprofv3 --pmc in a pass of its own (profiles/r4f_rocprofv3_summary.txt: 585,452,780; r3final: 585.4e6): 2382 wave
+# 2^20 points, rocprofv3 --pmc in a pass of its own (profiles/r4final_rocprofv3_summary.txt: 585,452,785; r3final: 585.4e6): 2382 wave
 # instructions per wave-wide mixed add (15.73 M adds / 64) against the 2220 of the static fast path — the 162 on top are the loop around
 # the add (sorted-reference decode, row address, conditional negation of y, chunk bookkeeping), 32-bit work priced at the simple-op rate.
-PMC_INSTS_VALU_PER_LAUNCH = {20: 585452779.9}
+PMC_INSTS_VALU_PER_LAUNCH = {20: 585452784.8}
 MADD_STATIC_INSTRS = 1467 + 146 + 144 + 81 + 382
 SIMPLE_OP_NS = 1.183
 SEED = 0x5A4F4C54
@@ -462,7 +462,7 @@ def main():
             "residual_is": "time the SIMDs do not spend issuing: the launch runs 15/16 of the chip's chunk slots when other MSMs are in flight (full "
                            "when alone), the random 64-byte table rows (DESIGN 4a: a wave waits on its gathers when the other wave of its SIMD "
                            "does too), and the chunk-length spread at the end of the launch",
-            "pmc_source": "SQ_INSTS_VALU, rocprofv3 --pmc (own pass), profiles/r4f_rocprofv3_summary.txt"})
+            "pmc_source": "SQ_INSTS_VALU, rocprofv3 --pmc (own pass), profiles/r4final_rocprofv3_summary.txt"})
     if single_proc is not None:
         out["extra"]["single_process_c_abi"] = single_proc
     if sharded_sc is not None:
