@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(256) handoff_busy_kernel(uint4 *buf, size_t n)
 
 // Sums of a table (a session's first round). SC_SUMS_U pairs per thread are requested before the first addition; 1024-thread
 // workgroups, at most one per CU: 2^20 entries 25 -> 9 us, 2^24 202 -> 90 us (6 TB/s) against round 3's one-pair-per-trip loop of
-// modular additions (tools/exp/fold_ab.hip, profiles/r4_fold_ab_*).
+// modular additions (tools/exp/fold_ab.hip, profiles/r4a_fold_ab_*_first_pass.txt, r4final_fold_ab_*).
 constexpr int SC_SUMS_U = 2;
 template <int LAYOUT>
 __global__ void __launch_bounds__(1024) sc_sums_kernel(const uint64_t *t, size_t half, uint64_t *partials, uint64_t *sums,
@@ -402,9 +402,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(56))) hk_q
 
 // 512-thread workgroups, at most 512 of them (two per CU = four waves per SIMD), grid-stride with the next pair requested before the
 // current product. Round 3 ran one wave per SIMD (every trip a full memory latency) and ended each block with a shuffle tree of modular
-// additions plus an ACQ_REL arrival: 2^16 entries 15.7 -> 8.4 us, 2^20 30.0 -> 19 us, 2^24 245 -> 170 us (4.8 TB/s) with the lazy sums,
-// the DPP reduction and the relaxed hand-off (tools/exp/fold_ab.hip; profiles/r4_fold_ab_*). What is left at 2^20: ~2 us launch ramp,
-// ~7 us for the 50 MB, the last batch of products (not overlapped with loads), ~4 us of hand-off (three dependent memory round trips).
+// additions plus an ACQ_REL arrival. Steady state (tools/exp/fold_ab.hip; profiles/r4a_fold_ab_*_first_pass.txt, r4final_fold_ab_*):
+// 2^16 entries 15.7 -> 7.8 us, 2^20 30.0 -> 15.7 us, 2^24 245 -> 168 us (4.8 TB/s). What is left at 2^20 is issue, not traffic: ~2 us
+// launch boundary, ~2 us until the first loads land, ~8 us of VALU issue (532 executed instructions per pair: SQ_INSTS_VALU 4.1 M wave
+// instructions per launch, profiles/r4final_kernel_table.md), then ~4 us of hand-off for the last workgroup (three dependent round trips).
 template <int LAYOUT>
 __global__ void __launch_bounds__(512) sc_fold_kernel(const uint64_t *t, size_t half, FrArg r, uint64_t *out,
                                                      uint64_t *partials, uint64_t *sums, uint32_t *counter, uint64_t *flag,
