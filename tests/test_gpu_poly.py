@@ -446,6 +446,31 @@ def test_full_size_low_pair_session_from_spartan_inputs(zl, ob):
         zl._lib.zg_dev_free(p)
 
 
+@pytest.mark.parametrize("logn", [6, 12, 20, 22])
+def test_lazy_sums_at_the_largest_stored_values(zl, ob, logn):
+    """The round sums are kept as plain 288-bit integers and reduced once per workgroup (csrc/sc_common.hip.h: Acc9, acc9_reduce's
+    quotient estimate from the top 64 bits). Worst case for the estimate and the carries: every stored element is r - 1 (the
+    largest canonical limb pattern), so a half-table of 2^(logn-1) entries sums to 2^(logn-1) (r - 1) — top limb and quotient as
+    large as that length allows. Closed form in Python integers; both layouts; then a fold by r - 1 and the next sums."""
+    R = U.pm.R_MOD if hasattr(U, "pm") else 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    n = 1 << logn
+    top = np.array([(R - 1) >> (64 * i) & ((1 << 64) - 1) for i in range(4)], dtype=np.uint64)
+    tab = np.repeat(top[None, :], n, axis=0)
+    want = (n // 2) * (R - 1) % R
+    limbs = lambda v: np.array([(v >> (64 * i)) & ((1 << 64) - 1) for i in range(4)], dtype=np.uint64)
+    for layout in (zl.SC_HIGH_HALF, zl.SC_LOW_PAIR):
+        s = zl.SumcheckSession.open(tab, layout)
+        g0, g1 = s.round_sums()
+        assert np.array_equal(g0, limbs(want)) and np.array_equal(g1, limbs(want)), (logn, layout)
+        if logn <= 12:  # the oracle folds on one core: keep the fold check to the short tables
+            s.bind(top)
+            cur = ob.fr_bind_high(tab, top) if layout == zl.SC_HIGH_HALF else ob.fr_bind_low(tab, top)
+            w0, w1 = ob.fr_sum_halves(cur) if layout == zl.SC_HIGH_HALF else ob.fr_sum_even_odd(cur)
+            g0, g1 = s.round_sums()
+            assert np.array_equal(g0, w0) and np.array_equal(g1, w1)
+        s.close()
+
+
 def test_full_size_sumcheck_properties(zl, ob):
     """BASELINE config 3 at full size (v = 20): size-independent checks — every round satisfies
     g0 + g1 == previous claim evaluated at the challenge, and the final evaluation equals the

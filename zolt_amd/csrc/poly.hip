@@ -761,8 +761,23 @@ __global__ void __launch_bounds__(256 * WG) eq_spartan_kernel(EqArgs ea, int v_l
                 nb = fe_load<FrParams>(bz + 4 * ni);
                 nc = fe_load<FrParams>(cz + 4 * ni);
             }
-            Fr e = fr_mul29(fe_load<FrParams>(&fs.hi_row[k][0]), tp);
-            Fr f = fr_mul29v(e, fe_sub(fr_mul29v(a, b), c));
+            // f = e (a b - c) with e = hi lo, as ONE lazy chain (no canonical value between the three products): with every
+            // 2^-261 of the lazy multiplier paid for by a 5-bit shift of one operand,
+            //   E  = hi * (32 lo)          * 2^-261 = e                      (< 1.2 r)
+            //   AB = (32 a) * (32 b)       * 2^-261 = 32 a b R^-1            (< 7.1 r)
+            //   W  = AB - 32 c + 64 r                = 32 (a b R^-1 - c) mod r  (limb-wise with a pre-biased 64 r, < 71.1 r < 2^261)
+            //   f  = E * W                 * 2^-261 = e (a b R^-1 - c) R^-1   (< (1.2 * 71.1 / 168.9 + 1) r = 1.5 r: one conditional subtraction)
+            // — the reference's montgomeryMul(e, sub(montgomeryMul(a, b), c)), since Montgomery products are exact. Saves two
+            // canonicalisations, a modular subtraction and two unpacks per entry of a kernel that is bound by its instruction count.
+            constexpr u32 BIAS64R[9] = {0x40000040u, 0x43eb27deu, 0x5709143cu, 0x54243cdau, 0x4174a0cdu, 0x56d03029u, 0x49b85043u, 0x57098cffu, 0x0c19139au};
+            const Fr hv = fe_load<FrParams>(&fs.hi_row[k][0]);
+            const F29 E = f29t_mul<Fr29>(f29_unpack(hv.l), tp);
+            const F29 AB = f29t_mul<Fr29>(fr29_in_shift(a), fr29_in_shift(b));
+            const F29 cs = fr29_in_shift(c);
+            F29 W;
+#pragma unroll
+            for (int q = 0; q < 9; q++) W.l[q] = AB.l[q] + BIAS64R[q] - cs.l[q];
+            Fr f = fr29_out(f29t_mul<Fr29>(E, f29_carry(W)));
             fe_store(out + 4 * i, f);
             const bool second = LAYOUT == ZG_SC_HIGH_HALF ? (n_hi > 1 ? h >= n_hi / 2 : lo >= (1u << v_lo) / 2) : (lo & 1u);
             acc9_add_if(g0, f, !second);
