@@ -439,3 +439,56 @@ def test_dory_evaluation_vectors(d, nu, sigma):
     wl, wr = ob.dory_evaluation_vectors(pt, nu, sigma)
     gl, gr = api.Dory.computeEvaluationVectors(pt, nu, sigma)
     assert np.array_equal(gl, wl) and np.array_equal(gr, wr)
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_produces_the_captured_proof_file(golden_dir, tmp_path):
+    """BASELINE config 5 from COMPILED host code (the stand-in for the patched Zig modules): zolt::Transcript, zolt::LassoProver,
+    zolt::proveStage4 / 5 / 6 and the device folds produce the stage records of the reference's captured proof file; re-serialised
+    (src/zkvm/serialization.zig:186-343) they are bytes 744 .. 11345 of tests/golden/zolt_proof_regular.bin. Inputs regenerated from the
+    ELF by tests/util.py (trace, lookup indices) and the oracle's R1CS restatement (Az, Bz), as in tests/test_transcript_host.py."""
+    import numpy as np
+    from oracle import binding as ob  # fixture regeneration (the R1CS witness of the captured run) and representation conversions
+    from tests import util as U
+    exe = os.path.join(ROOT, "tests", "cpp", "test_host_mirror")
+    subprocess.check_call(["make", "-C", os.path.dirname(exe), "test_host_mirror"])
+    P = U.proof_file_sections()
+    data = open(os.path.join(golden_dir, "zolt_proof_regular.bin"), "rb").read()
+    elf = open(os.path.join(golden_dir, "fibonacci.elf"), "rb").read()
+    w = ob.r1cs_witness_from_trace(U.fibonacci_full_trace(elf))
+    n = w.shape[0]
+    az = np.zeros((1 << 13, 4), dtype=np.uint64)
+    bz = np.zeros((1 << 13, 4), dtype=np.uint64)
+    for i, (cond, left, right) in enumerate(ob.UNIFORM_CONSTRAINTS):
+        az[np.arange(n) * 19 + i] = ob._lc_eval(cond, w)
+        bz[np.arange(n) * 19 + i] = ob._fsub(ob._lc_eval(left, w), ob._lc_eval(right, w))
+    idx = U.fibonacci_lookup_indices(elf)
+    steps = U.fibonacci_trace_steps(elf)
+    path = tmp_path / "proof_case.txt"
+    with open(path, "w") as f:
+        for off in P["absorbed_commitment_offsets"].values():
+            f.write(data[off:off + 64].hex() + "\n")
+        f.write(f"{P['log_t']} {P['log_k']} {len(steps)}\n" + " ".join(str(wd) for wd, _, _ in steps) + "\n")
+        f.write(f"{idx.shape[0]}\n" + "".join(f"{int(lo)} {int(hi)}\n" for lo, hi in idx))
+        f.write(f"{az.shape[0]}\n")
+        for t in (az, bz):
+            f.write("".join(_hexfr(x) + "\n" for x in t))
+    res = subprocess.run([exe, "proof", str(path)], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    stages, cur = [], None
+    to_int = lambda words: ob.fr_to_int(np.array([int(x, 16) for x in words], dtype=np.uint64))
+    for line in res.stdout.splitlines():
+        t = line.split()
+        if not t:
+            continue
+        if t[0] == "S":
+            cur = ([], [], [])
+            stages.append(cur)
+        elif t[0] == "P":
+            cur[0].append([to_int(t[1 + 4 * k:5 + 4 * k]) for k in range((len(t) - 1) // 4)])
+        elif t[0] == "H":
+            cur[1].extend(to_int(t[1 + 4 * k:5 + 4 * k]) for k in range((len(t) - 1) // 4))
+        elif t[0] == "C":
+            cur[2].extend(to_int(t[1 + 4 * k:5 + 4 * k]) for k in range((len(t) - 1) // 4))
+    assert len(stages) == 6
+    assert U.serialize_stage_sections(P["log_t"], P["log_k"], stages) == data[744:]
