@@ -399,13 +399,14 @@ def test_skewed_scalar_distributions(zl, ob, gm, kind):
     _check(zl, ob, gm[:n], None, sc, window_bits=13, precompute_levels=1)
 
 
-@pytest.mark.parametrize("c", list(range(2, 18)))
+@pytest.mark.parametrize("c", list(range(2, 20)))
 def test_every_window_size(zl, ob, gm, c):
-    """every digit-kernel instantiation (window_bits 2..17), full precompute and none"""
+    """every digit-kernel instantiation (window_bits 2..19), full precompute and none"""
     n = 2000
     sc = _scalars(ob, 4000 + c, n)
     _check(zl, ob, gm[:n], None, sc, window_bits=c, precompute_levels=0)
-    if (255 + c - 1) // c <= 64:
+    W = (255 + c - 1) // c
+    if W <= 64 and (1 << (c - 1)) * W <= 1 << 21:  # table-less: one bucket set per window, at most 2^21 buckets in all (c <= 18)
         _check(zl, ob, gm[:n], None, sc, window_bits=c, precompute_levels=1)
 
 

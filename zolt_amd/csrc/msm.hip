@@ -1025,13 +1025,15 @@ __global__ void __launch_bounds__(256) msm_rowcol_kernel(const char *buckets, ui
     __shared__ uint4 sh[256 * 9];
     const uint32_t x = blockIdx.x, g = blockIdx.y, nrow = 1u << hb, ncol = 1u << lb, t = threadIdx.x;
     XYZZ29 acc = xyzz29_identity();
-    uint32_t k = 0;  // digit magnitude of this thread's element; 0 = none
-    if (x < nrow) {
-        if (t < ncol) k = (x << lb) | t;
-    } else {
-        if (t < nrow) k = (t << lb) | (x - nrow);
+    // (rows / columns of more than 256 elements — windows of 18 bits and more — take several elements per thread)
+    const uint32_t len = x < nrow ? ncol : nrow;
+    for (uint32_t e = t; e < len; e += 256) {
+        const uint32_t k = x < nrow ? ((x << lb) | e) : ((e << lb) | (x - nrow));  // digit magnitude of the element; 0 = none
+        if (k != 0) {
+            XYZZ29 v = xyzz29_load(buckets + 144 * ((size_t)g * NB + (k - 1)));
+            acc = e < 256 ? v : xyzz29_add(acc, v);
+        }
     }
-    if (k != 0) acc = xyzz29_load(buckets + 144 * ((size_t)g * NB + (k - 1)));
     XYZZ29 r = block_sum_xyzz29(acc, sh);
     if (t == 0) xyzz29_store(rc + 144 * ((size_t)g * (nrow + ncol) + x), r);
 }
@@ -1045,9 +1047,11 @@ __global__ void __launch_bounds__(256) msm_bits2d_kernel(const char *buckets, co
     if (b == (uint32_t)(c - 1)) {
         if (t == 0) acc = xyzz29_load(buckets + 144 * ((size_t)g * NB + (NB - 1)));
     } else if (b < (uint32_t)lb) {
-        if (t < ncol && ((t >> b) & 1u)) acc = xyzz29_load(rcg + 144 * (size_t)(nrow + t));
+        for (uint32_t e = t; e < ncol; e += 256)
+            if ((e >> b) & 1u) acc = xyzz29_add(acc, xyzz29_load(rcg + 144 * (size_t)(nrow + e)));
     } else {
-        if (t < nrow && ((t >> (b - (uint32_t)lb)) & 1u)) acc = xyzz29_load(rcg + 144 * (size_t)t);
+        for (uint32_t e = t; e < nrow; e += 256)
+            if ((e >> (b - (uint32_t)lb)) & 1u) acc = xyzz29_add(acc, xyzz29_load(rcg + 144 * (size_t)e));
     }
     XYZZ29 r = block_sum_xyzz29(acc, sh);
     if (t == 0) xyzz29_store(out + 144 * ((size_t)g * c + b), r);
@@ -1418,9 +1422,12 @@ static int make_plan(size_t n, const zg_msm_config *cfg, MsmPlan &p, size_t batc
         // as long as the 15 n table rows leave the two-pass sort at least 5 fine key bits beside the 26-bit reference of an
         // intermediate entry (n <= 4.4 M: 2^22 points run 177 instead of 172 MSM/s, accumulate 5.98 -> 5.61 ms)
         if (batch == 1 && n >= (size_t)env_int("ZG_MSM_C17_MIN", 900000) && (uint64_t)n * 15 <= (1u << 26)) c = 17;
+        // 18 / 19 bits exist (window_bits, ZG_MSM_WINDOW_BITS) and are NOT chosen: 19 bits = 14 windows take 8 % off the accumulate kernel
+        // (1.18 -> 1.09 ms at 2^20) and put more than that back into the per-bucket work of 2^18 buckets (sort 0.13 -> 0.22 ms, combine +
+        // row / column sums 0.27 -> 0.49 ms): 781 -> 735 MSM/s pipelined, 1.65 -> 1.95 ms alone (round 4, tools/exp/run_c19.sh)
     }
-    if (c < 2 || c > 17) {
-        set_error("msm: window_bits must be in [2,17]");
+    if (c < 2 || c > 19) {
+        set_error("msm: window_bits must be in [2,19]");
         return ZG_ERR_INVALID;
     }
     p.c = c;
@@ -1757,7 +1764,7 @@ static int launch_digits_lds_c(int c, hipStream_t st, const uint64_t *sc, const 
     switch (c) {
 #define ZG_CASE(C) case C: return launch_digits_lds<C>(st, sc, inf, n, n_pts, G, per_block, NK, nblk, dig, blockhist, shift, threads);
         ZG_CASE(2) ZG_CASE(3) ZG_CASE(4) ZG_CASE(5) ZG_CASE(6) ZG_CASE(7) ZG_CASE(8) ZG_CASE(9) ZG_CASE(10)
-        ZG_CASE(11) ZG_CASE(12) ZG_CASE(13) ZG_CASE(14) ZG_CASE(15) ZG_CASE(16) ZG_CASE(17)
+        ZG_CASE(11) ZG_CASE(12) ZG_CASE(13) ZG_CASE(14) ZG_CASE(15) ZG_CASE(16) ZG_CASE(17) ZG_CASE(18) ZG_CASE(19)
 #undef ZG_CASE
         default: set_error("msm: unsupported window size"); return ZG_ERR_INVALID;
     }
@@ -1768,7 +1775,7 @@ static int launch_digits_c(int c, hipStream_t st, const uint64_t *sc, const uint
     switch (c) {
 #define ZG_CASE(C) case C: launch_digits<C>(st, sc, inf, n, n_pts, G, dig, hist); break;
         ZG_CASE(2) ZG_CASE(3) ZG_CASE(4) ZG_CASE(5) ZG_CASE(6) ZG_CASE(7) ZG_CASE(8) ZG_CASE(9) ZG_CASE(10)
-        ZG_CASE(11) ZG_CASE(12) ZG_CASE(13) ZG_CASE(14) ZG_CASE(15) ZG_CASE(16) ZG_CASE(17)
+        ZG_CASE(11) ZG_CASE(12) ZG_CASE(13) ZG_CASE(14) ZG_CASE(15) ZG_CASE(16) ZG_CASE(17) ZG_CASE(18) ZG_CASE(19)
 #undef ZG_CASE
         default: set_error("msm: unsupported window size"); return ZG_ERR_INVALID;
     }
