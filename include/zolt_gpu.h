@@ -479,9 +479,10 @@ ZG_API int zg_rrw_close(zg_rrw_t s);
 /* RamReadWriteCheckingProver (src/zkvm/ram/read_write_checking.zig:160-1323): a list of access entries {cycle, address, ra_coeff, val_coeff,
  * prev_val, next_val} (:91-157) beside three dense tables — eq_evals = eq(r_cycle, .) and inc over 2^log_t cycles, val_init over 2^log_k
  * words — and log_t + log_k rounds in three phases: phase1_num_rounds cycle variables, the address variables, the remaining cycle
- * variables. The session owns everything: the integer fields of the list live on the host inside the library, where the reference's
- * sequential walks (who pairs with whom, which checkpoint a lone entry meets) run once per round; ra_coeff, val_coeff and the dense
- * tables live in HBM, where one kernel turns a round's walk into its two sums and one into the bound list. The caller keeps what the
+ * variables. The session owns everything: the reference's walks over the integer fields of the list (who pairs with whom, which
+ * checkpoint a lone entry meets) run once per round inside the library — the cycle phases' neighbour rule on the device, the address
+ * phase's sequential column walk on the host; ra_coeff, val_coeff and the dense tables live in HBM, where one kernel turns a round's
+ * walk into its two sums and one into the bound list. The caller keeps what the
  * reference's struct keeps besides: the GruenSplitEqPolynomial (its prefix tables as device buffers), the cubic, the claim.
  *   entries: sorted by (cycle, address) as init leaves them (:333-340); val_coeff as u64 (F.fromU64 of prev_val for a write, of the value
  *   for a read, :300-330), ra_coeff = 1; inc / val_init: field elements (:253-330); r_cycle: the eq point, r_cycle[0] <-> MSB (:345-348). */

@@ -291,12 +291,21 @@ int main(int argc, char **argv) {
             RamReadWriteCheckingProver p(acc, gamma, rc, log_k, (size_t)v, (size_t)v / 2, start, Fr::zero());
             if (rep >= 0) t_rwc_setup += std::chrono::duration<double>(clk::now() - t0).count();
             Transcript tr("Jolt");
+            const bool split = rep == 0 && std::getenv("ZOLT_RWC_SPLIT");  // per-round times of one run, to stderr
+            if (split) std::fprintf(stderr, "rwc setup %.1f us\n", std::chrono::duration<double>(clk::now() - t0).count() * 1e6);
+            size_t rd = 0;
             while (!p.isComplete()) {
+                auto ta = clk::now();
                 auto ev = p.computeRoundPolynomialCubic();
+                auto tb = clk::now();
                 for (auto &e : ev) tr.appendScalar("rwc", e);
                 Fr ch = tr.challengeScalar("rwc_r");
                 p.updateClaim(ev, ch);
                 p.bindChallenge(ch);
+                if (split)
+                    std::fprintf(stderr, "rwc round %2zu: poly %8.1f us, bind %8.1f us\n", rd, std::chrono::duration<double>(tb - ta).count() * 1e6,
+                                 std::chrono::duration<double>(clk::now() - tb).count() * 1e6);
+                rd++;
             }
             if (rep >= 0) { t_rwc += std::chrono::duration<double>(clk::now() - t0).count(); rwc_rounds += p.numRounds(); }
         }

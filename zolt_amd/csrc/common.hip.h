@@ -146,6 +146,7 @@ int bound_devices();      // devices 0..n-1 bound by zg_init_devices (1 in the o
 void sharded_shutdown();  // sharded.hip: drop communicators / exchange buffers (called by zg_shutdown)
 void sc_shutdown();       // poly.hip / psc.hip: drop the pooled sumcheck sessions (called by zg_shutdown)
 void psc_shutdown();
+void rwc_shutdown();      // rwc.hip: free the pinned-buffer pool (called by zg_shutdown)
 
 // msm.hip: zg_msm_g1_batch_dev that also fuses zero-padded rows on wide-window handles (HyperKZG.open's long levels)
 int msm_batch_dev_wide(zg_bases_t b, size_t n, const uint64_t *d_scalars, size_t k, hipStream_t st, uint64_t *d_out9);

@@ -272,6 +272,7 @@ void zg_shutdown(void) {
     sharded_shutdown();  // communicators and per-device exchange buffers (sharded.hip)
     sc_shutdown();       // pooled sumcheck sessions
     psc_shutdown();
+    rwc_shutdown();
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_inited) return;
     int prev = current_device();

@@ -9,8 +9,12 @@
 // and then spend a dozen field products per step. The address walk cannot be turned into rank queries: the reference groups by
 // (address >> addr_round) although it already halves every address at each bind, so from the second address round on a "column" holds
 // several addresses and is not cycle-sorted; what its two-pointer loop does on such lists is defined only by running it. So the split is:
-//   host, inside this library: the integer skeleton of the list (cycle, address, prev_val, next_val) and, once per round, the walk over
-//         it — a PLAN of steps {entry a, entry b or none, kind, key, implicit value or checkpoint column}, O(entries) integer work;
+//   the integer skeleton of the list (cycle, address, prev_val, next_val) and, once per round, the walk over it — a PLAN of steps
+//         {entry a, entry b or none, kind, key, implicit value or checkpoint column}, O(entries) integer work. The CYCLE-phase walk is a local
+//         rule (an entry is the odd member of a pair exactly when its predecessor is the even entry of the same cycle pair and address; an
+//         even entry always opens a step), so it runs on the device: head flags, a scan, one kernel that writes the plan and the bound
+//         skeleton (round 4: the host walk plus the upload of a 24-byte step per entry cost ~2.5 ms per round at 2^18 entries). The
+//         ADDRESS-phase walk stays on the host inside this library (see above); the skeleton moves between the two sides at the phase switches;
 //   device: ra_coeff / val_coeff of every entry and the three dense tables; per round one kernel turns the plan into the two sums
 //         (thread per step), one kernel into the bound entries (step k writes entry k: the plan order IS the reference's output order),
 //         one folds the dense tables.
@@ -83,6 +87,81 @@ __global__ void __launch_bounds__(256) rwc_finish_kernel(const uint64_t *partial
     }
 }
 
+// ---- the cycle-phase walk (computePhase1Polynomial's pairing :431-470, bindEntries :1146-1160) as a local rule. The reference scans the
+// list once: an even-cycle entry pairs with its SUCCESSOR when that one holds the odd cycle of the same pair at the same address, every
+// other entry stands alone. An odd entry can only be consumed by its predecessor and an even entry never is, so "entry i opens a step" needs
+// entries i - 1 and i only.
+static constexpr uint32_t RWC_WALK_BLOCK = 1024;
+ZG_DEV bool rwc_is_odd_member(const uint32_t *cycle, const uint32_t *addr, uint32_t i) {
+    if (i == 0) return false;
+    const uint32_t c = cycle[i], cp = cycle[i - 1];
+    return (c & 1u) && !(cp & 1u) && (cp >> 1) == (c >> 1) && addr[i - 1] == addr[i];
+}
+// steps opened inside each block of RWC_WALK_BLOCK entries
+__global__ void __launch_bounds__(RWC_WALK_BLOCK) rwc_walk_count_kernel(const uint32_t *cycle, const uint32_t *addr, uint32_t n, uint32_t *blk) {
+    const uint32_t i = blockIdx.x * RWC_WALK_BLOCK + threadIdx.x;
+    const int heads = __syncthreads_count(i < n && !rwc_is_odd_member(cycle, addr, i));
+    if (threadIdx.x == 0) blk[blockIdx.x] = (uint32_t)heads;
+}
+// exclusive scan of the block counts in place (one workgroup; <= 2^14 blocks for 2^24 entries), the total behind them
+__global__ void __launch_bounds__(1024) rwc_walk_scan_kernel(uint32_t *blk, uint32_t nblk) {
+    __shared__ uint32_t sh[1024];
+    const uint32_t t = threadIdx.x, per = (nblk + 1023) / 1024;
+    const uint32_t a = t * per < nblk ? t * per : nblk, b = a + per < nblk ? a + per : nblk;
+    uint32_t sum = 0;
+    for (uint32_t j = a; j < b; j++) sum += blk[j];
+    sh[t] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        const uint32_t v = t >= d ? sh[t - d] : 0u;
+        __syncthreads();
+        sh[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = sh[t] - sum;
+    for (uint32_t j = a; j < b; j++) {
+        const uint32_t v = blk[j];
+        blk[j] = run;
+        run += v;
+    }
+    if (t == 1023) blk[nblk] = sh[1023];
+}
+// step k of the plan and entry k of the bound skeleton (cycle halved, the address kept, prev_val of the first member, next_val of the last:
+// CycleMajorEntry.bindEntries :110-156)
+__global__ void __launch_bounds__(RWC_WALK_BLOCK) rwc_walk_plan_kernel(const uint32_t *cycle, const uint32_t *addr, const uint64_t *prev, const uint64_t *next,
+                                                                       uint32_t n, const uint32_t *blk, RwcStep *plan, uint32_t *cycle2, uint32_t *addr2,
+                                                                       uint64_t *prev2, uint64_t *next2) {
+    __shared__ uint32_t wsum[RWC_WALK_BLOCK / 64];
+    const uint32_t i = blockIdx.x * RWC_WALK_BLOCK + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool head = i < n && !rwc_is_odd_member(cycle, addr, i);
+    const uint64_t bal = __ballot(head);
+    uint32_t pre = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    for (uint32_t w = 0; w < wave; w++) pre += wsum[w];
+    if (!head) return;
+    const uint32_t k = blk[blockIdx.x] + pre, c = cycle[i];
+    RwcStep st{i, ~0u, c >> 1, RWC_ODD_ALONE, 0};
+    uint64_t nxt = next[i];
+    if (!(c & 1u)) {
+        if (i + 1 < n && rwc_is_odd_member(cycle, addr, i + 1)) {
+            st.b = i + 1;
+            st.kind = RWC_PAIR;
+            nxt = next[i + 1];
+        } else {
+            st.kind = RWC_EVEN_ALONE;
+            st.imp = nxt;  // the odd member is implicit: the value after this access
+        }
+    } else {
+        st.imp = prev[i];  // the even member is implicit: the value before it
+    }
+    plan[k] = st;
+    cycle2[k] = c >> 1;
+    addr2[k] = addr[i];
+    prev2[k] = prev[i];
+    next2[k] = nxt;
+}
+
 // the members of a cycle-phase step at t = 0 and their slopes (:431-470): an even entry alone meets the value AFTER its access, an odd
 // one the value BEFORE it
 ZG_DEV void rwc_cycle_members(const RwcStep &s, const uint64_t *ra, const uint64_t *val, Fr &ra_e, Fr &ra_o, Fr &val_e, Fr &val_o) {
@@ -105,13 +184,13 @@ ZG_DEV void rwc_cycle_members(const RwcStep &s, const uint64_t *ra, const uint64
 
 // computePhase1Polynomial (:410-536): (q_constant, q_quadratic) = sum over the steps of E(pair) ra (val + gamma (inc + val)) at t = 0 and
 // at infinity (the slopes)
-__global__ void __launch_bounds__(256) rwc_cycle_round_kernel(const RwcStep *plan, uint32_t n_steps, const uint64_t *ra, const uint64_t *val, const uint64_t *inc,
+__global__ void __launch_bounds__(256) rwc_cycle_round_kernel(const RwcStep *plan, const uint32_t *n_steps, const uint64_t *ra, const uint64_t *val, const uint64_t *inc,
                                                               uint32_t live, const uint64_t *e_out, uint32_t n_out, const uint64_t *e_in, uint32_t n_in,
                                                               uint32_t in_bits, FrArg gamma_a, uint64_t *partials) {
     __shared__ uint4 sh[256 * 4];
     Fr acc[2] = {Fr::zero(), Fr::zero()};
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
-    if (k < n_steps) {
+    if (k < *n_steps) {  // the grid covers the entries; the plan kernel's step count is not on the host yet
         const RwcStep s = plan[k];
         Fr ra_0, ra_1, val_0, val_1;
         rwc_cycle_members(s, ra, val, ra_0, ra_1, val_0, val_1);
@@ -300,6 +379,15 @@ struct zg_rwc_s {
     std::vector<uint64_t> p2, n2;
     bool plan_valid = false, plan_is_address = false;
     size_t plan_addr_round = 0;
+    size_t plan_m = 0;  // steps of the current plan (a cycle-phase plan is written on the device: its length arrives with the round's sums)
+    // the skeleton on the device, authoritative in the cycle phases: cycle | address (u32) and prev_val | next_val (u64), cap words each, two
+    // sets in turn (the walk writes the bound skeleton into the other set); host_skel / dev_skel say which side holds the current list
+    uint32_t *d_sk32[2] = {nullptr, nullptr};
+    uint64_t *d_sk64[2] = {nullptr, nullptr};
+    int sk = 0;
+    size_t n_entries = 0;
+    bool dev_skel = false, host_skel = true;
+    uint32_t *d_blk = nullptr;  // the walk's per-block step counts, then its step count
     // device: coefficient columns (double-buffered), the plan, the dense tables
     uint32_t cap = 0;
     uint64_t *ra[2] = {nullptr, nullptr}, *val_c[2] = {nullptr, nullptr};
@@ -318,16 +406,51 @@ struct zg_rwc_s {
 
 using namespace zg;
 
+// pinned host buffers (the address phase's plans, the result words) are pooled per process: hipHostMalloc of a 6 MB plan buffer costs about
+// as much as a whole cycle phase. A buffer is reused for requests of at least a quarter of its size; rwc_shutdown (zg_shutdown) frees the pool.
+static std::mutex g_rwc_pin_mu;
+struct RwcPin { void *p; size_t bytes; };
+static std::vector<RwcPin> g_rwc_pins;
+static void *rwc_pin_get(size_t bytes) {
+    {
+        std::lock_guard<std::mutex> lk(g_rwc_pin_mu);
+        for (size_t i = 0; i < g_rwc_pins.size(); i++)
+            if (g_rwc_pins[i].bytes >= bytes && g_rwc_pins[i].bytes <= 4 * bytes + 4096) {
+                void *p = g_rwc_pins[i].p;
+                g_rwc_pins.erase(g_rwc_pins.begin() + i);
+                return p;
+            }
+    }
+    void *p = nullptr;
+    return hipHostMalloc(&p, bytes ? bytes : 16) == hipSuccess ? p : nullptr;
+}
+static void rwc_pin_put(void *p, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_rwc_pin_mu);
+    if (g_rwc_pins.size() >= 16) {
+        (void)hipHostFree(p);
+        return;
+    }
+    g_rwc_pins.push_back(RwcPin{p, bytes ? bytes : 16});
+}
+namespace zg {
+void rwc_shutdown() {
+    std::lock_guard<std::mutex> lk(g_rwc_pin_mu);
+    for (auto &b : g_rwc_pins) (void)hipHostFree(b.p);
+    g_rwc_pins.clear();
+}
+}  // namespace zg
+
 static void rwc_free(zg_rwc_s *s) {
     if (!s) return;
     for (int b = 0; b < 2; b++)
         for (void *p : {(void *)s->ra[b], (void *)s->val_c[b], (void *)s->eq[b], (void *)s->inc[b], (void *)s->val[b]})
-            if (p) (void)hipFree(p);
-    for (void *p : {(void *)s->d_plan, (void *)s->d_idx, (void *)s->d_part, (void *)s->d_out})
-        if (p) (void)hipFree(p);
-    if (s->h_out) (void)hipHostFree(s->h_out);
+            if (p) scratch_put(p);
+    for (void *p : {(void *)s->d_plan, (void *)s->d_idx, (void *)s->d_part, (void *)s->d_out, (void *)s->d_blk, (void *)s->d_sk32[0], (void *)s->d_sk32[1],
+                    (void *)s->d_sk64[0], (void *)s->d_sk64[1]})
+        if (p) scratch_put(p);
+    if (s->h_out) rwc_pin_put(s->h_out, 16 * 32);
     for (int b = 0; b < 2; b++) {
-        if (s->h_plan[b]) (void)hipHostFree(s->h_plan[b]);
+        if (s->h_plan[b]) rwc_pin_put(s->h_plan[b], (size_t)s->cap * sizeof(RwcStep));
         if (s->plan_uploaded[b]) (void)hipEventDestroy(s->plan_uploaded[b]);
     }
     if (s->st) stream_release(s->st, s->device);
@@ -341,11 +464,14 @@ static FrArg rwc_fr_arg(const uint64_t r[4]) {
     }
     return a;
 }
-static int rwc_collect(zg_rwc_s *s, uint32_t nblocks, uint64_t *a, uint64_t *b) {
+// the two sums of a round; with d_m, the step count of the device walk comes back under the same synchronisation
+static int rwc_collect(zg_rwc_s *s, uint32_t nblocks, uint64_t *a, uint64_t *b, const uint32_t *d_m = nullptr) {
     hipLaunchKernelGGL(rwc_finish_kernel, dim3(1), dim3(256), 0, s->st, s->d_part, nblocks, s->d_out);
     ZG_HIP(hipGetLastError());
     ZG_HIP(hipMemcpyAsync(s->h_out, s->d_out, 64, hipMemcpyDeviceToHost, s->st));
+    if (d_m) ZG_HIP(hipMemcpyAsync(s->h_out + 8, d_m, 4, hipMemcpyDeviceToHost, s->st));
     ZG_HIP(hipStreamSynchronize(s->st));
+    if (d_m) s->plan_m = (uint32_t)s->h_out[8];
     for (int i = 0; i < 4; i++) {
         a[i] = s->h_out[i];
         b[i] = s->h_out[4 + i];
@@ -354,40 +480,72 @@ static int rwc_collect(zg_rwc_s *s, uint32_t nblocks, uint64_t *a, uint64_t *b) 
 }
 
 // the other pinned plan buffer, once its last upload has left the host
-static void rwc_next_plan_buffer(zg_rwc_s *s) {
+static int rwc_next_plan_buffer(zg_rwc_s *s) {
     s->plan_buf ^= 1;
+    if (!s->h_plan[s->plan_buf]) {
+        s->h_plan[s->plan_buf] = reinterpret_cast<RwcStep *>(rwc_pin_get((size_t)s->cap * sizeof(RwcStep)));
+        if (!s->h_plan[s->plan_buf]) {
+            set_error("zg_rwc: pinned plan buffer");
+            return ZG_ERR_NOMEM;
+        }
+    }
     (void)hipEventSynchronize(s->plan_uploaded[s->plan_buf]);
     s->plan.p = s->h_plan[s->plan_buf];
     s->plan.n = 0;
+    return ZG_OK;
 }
-// ---- the walks (host, integers only)
-// cycle phases: the pairing of computePhase1Polynomial / bindEntries (:431-470, 1146-1160)
-static void rwc_plan_cycle(zg_rwc_s *s) {
-    const size_t n = s->cycle.size();
-    rwc_next_plan_buffer(s);
-    s->plan.clear();
-    s->plan.reserve(n);
-    for (size_t i = 0; i < n;) {
-        const uint32_t c = s->cycle[i], pair = c >> 1;
-        if (!(c & 1u)) {
-            if (i + 1 < n && (s->cycle[i + 1] >> 1) == pair && s->addr[i + 1] == s->addr[i] && (s->cycle[i + 1] & 1u)) {
-                s->plan.push_back(RwcStep{(uint32_t)i, (uint32_t)(i + 1), pair, RWC_PAIR, 0});
-                i += 2;
-                continue;
-            }
-            s->plan.push_back(RwcStep{(uint32_t)i, ~0u, pair, RWC_EVEN_ALONE, s->next[i]});  // the odd member is implicit: the value after this access
-        } else {
-            s->plan.push_back(RwcStep{(uint32_t)i, ~0u, pair, RWC_ODD_ALONE, s->prev[i]});  // the even member is implicit: the value before it
-        }
-        i += 1;
+// ---- where the skeleton lives. The cycle phases keep it on the device (rwc_walk_*), the address phase on the host.
+static int rwc_host_skeleton(zg_rwc_s *s) {
+    if (s->host_skel) return ZG_OK;
+    const size_t n = s->n_entries, cap = s->cap;
+    s->cycle.resize(n); s->addr.resize(n); s->prev.resize(n); s->next.resize(n);
+    if (n) {
+        ZG_HIP(hipMemcpyAsync(s->cycle.data(), s->d_sk32[s->sk], n * 4, hipMemcpyDeviceToHost, s->st));
+        ZG_HIP(hipMemcpyAsync(s->addr.data(), s->d_sk32[s->sk] + cap, n * 4, hipMemcpyDeviceToHost, s->st));
+        ZG_HIP(hipMemcpyAsync(s->prev.data(), s->d_sk64[s->sk], n * 8, hipMemcpyDeviceToHost, s->st));
+        ZG_HIP(hipMemcpyAsync(s->next.data(), s->d_sk64[s->sk] + cap, n * 8, hipMemcpyDeviceToHost, s->st));
+        ZG_HIP(hipStreamSynchronize(s->st));
     }
+    s->host_skel = true;
+    return ZG_OK;
+}
+static int rwc_dev_skeleton(zg_rwc_s *s) {
+    if (s->dev_skel) return ZG_OK;
+    const size_t n = s->n_entries, cap = s->cap;  // host_skel holds: one side always does
+    if (n) {
+        ZG_HIP(hipMemcpyAsync(s->d_sk32[s->sk], s->cycle.data(), n * 4, hipMemcpyHostToDevice, s->st));
+        ZG_HIP(hipMemcpyAsync(s->d_sk32[s->sk] + cap, s->addr.data(), n * 4, hipMemcpyHostToDevice, s->st));
+        ZG_HIP(hipMemcpyAsync(s->d_sk64[s->sk], s->prev.data(), n * 8, hipMemcpyHostToDevice, s->st));
+        ZG_HIP(hipMemcpyAsync(s->d_sk64[s->sk] + cap, s->next.data(), n * 8, hipMemcpyHostToDevice, s->st));
+        ZG_HIP(hipStreamSynchronize(s->st));  // pageable sources
+    }
+    s->dev_skel = true;
+    return ZG_OK;
+}
+// ---- the walks
+// cycle phases, on the device (rwc_walk_*): the plan into d_plan, the bound skeleton into the other set, the step count behind the block counts
+static uint32_t *rwc_walk_total(zg_rwc_s *s) { return s->d_blk + div_up(s->n_entries, RWC_WALK_BLOCK); }
+static int rwc_plan_cycle(zg_rwc_s *s) {
+    ZG_TRY(rwc_dev_skeleton(s));
+    const uint32_t n = (uint32_t)s->n_entries, nblk = (uint32_t)div_up(s->n_entries, RWC_WALK_BLOCK), cap = s->cap;
+    if (n) {
+        const uint32_t *cyc = s->d_sk32[s->sk], *adr = cyc + cap;
+        const uint64_t *prv = s->d_sk64[s->sk], *nxt = prv + cap;
+        hipLaunchKernelGGL(rwc_walk_count_kernel, dim3(nblk), dim3(RWC_WALK_BLOCK), 0, s->st, cyc, adr, n, s->d_blk);
+        hipLaunchKernelGGL(rwc_walk_scan_kernel, dim3(1), dim3(1024), 0, s->st, s->d_blk, nblk);
+        hipLaunchKernelGGL(rwc_walk_plan_kernel, dim3(nblk), dim3(RWC_WALK_BLOCK), 0, s->st, cyc, adr, prv, nxt, n, s->d_blk, s->d_plan, s->d_sk32[s->sk ^ 1],
+                           s->d_sk32[s->sk ^ 1] + cap, s->d_sk64[s->sk ^ 1], s->d_sk64[s->sk ^ 1] + cap);
+        ZG_HIP(hipGetLastError());
+    }
+    s->plan_m = 0;  // known once rwc_collect / zg_rwc_bind_cycle has read it
     s->plan_valid = true;
     s->plan_is_address = false;
+    return ZG_OK;
 }
 // address phase: column pairs by (address >> addr_round) / 2 and the two-pointer walk with carried checkpoints (:585-700, 1000-1075)
-static void rwc_plan_address(zg_rwc_s *s, size_t addr_round) {
+static int rwc_plan_address(zg_rwc_s *s, size_t addr_round) {
     const size_t n = s->cycle.size();
-    rwc_next_plan_buffer(s);
+    ZG_TRY(rwc_next_plan_buffer(s));
     const uint32_t sh = (uint32_t)addr_round;
     s->plan.clear();
     s->plan.reserve(n);
@@ -429,12 +587,15 @@ static void rwc_plan_address(zg_rwc_s *s, size_t addr_round) {
         while (o < j) odd_alone(o++);
         i = j;
     }
+    s->plan_m = s->plan.size();
     s->plan_valid = true;
     s->plan_is_address = true;
     s->plan_addr_round = addr_round;
+    return ZG_OK;
 }
-// the skeleton of the bound list: step k -> entry k (CycleMajorEntry.bindEntries :110-156; bindAddressMajor* :1077-1137)
-static void rwc_apply_plan(zg_rwc_s *s, bool address) {
+// the skeleton of the bound list, address phase: step k -> entry k (bindAddressMajor* :1077-1137)
+static void rwc_apply_plan(zg_rwc_s *s) {
+    const bool address = true;
     const size_t m = s->plan.size();
     std::vector<uint32_t> &c2 = s->c2, &a2 = s->a2;
     std::vector<uint64_t> &p2 = s->p2, &n2 = s->n2;
@@ -450,6 +611,8 @@ static void rwc_apply_plan(zg_rwc_s *s, bool address) {
     s->addr.swap(a2);
     s->prev.swap(p2);
     s->next.swap(n2);
+    s->n_entries = m;
+    s->dev_skel = false;
     s->plan_valid = false;
 }
 static int rwc_upload_plan(zg_rwc_s *s) {
@@ -498,37 +661,47 @@ static int rwc_open_impl(size_t log_k, size_t log_t, size_t n, const uint32_t *c
     s->next.assign(next_val, next_val + n);
     s->st = stream_acquire();
     hipError_t e = s->st ? hipSuccess : hipErrorOutOfMemory;
-    for (int b = 0; b < 2 && e == hipSuccess; b++) {
-        e = hipMalloc((void **)&s->ra[b], (size_t)s->cap * 32);
-        if (e == hipSuccess) e = hipMalloc((void **)&s->val_c[b], (size_t)s->cap * 32);
-        if (e == hipSuccess) e = hipMalloc((void **)&s->eq[b], (b ? (T / 2 ? T / 2 : 1) : T) * 32);
-        if (e == hipSuccess) e = hipMalloc((void **)&s->inc[b], (b ? (T / 2 ? T / 2 : 1) : T) * 32);
-        if (e == hipSuccess) e = hipMalloc((void **)&s->val[b], K * 32);  // both full size: the previous level stays readable
-    }
-    if (e == hipSuccess) e = hipMalloc((void **)&s->d_plan, (size_t)s->cap * sizeof(RwcStep));
-    for (int b = 0; b < 2 && e == hipSuccess; b++) {
-        e = hipHostMalloc((void **)&s->h_plan[b], (size_t)s->cap * sizeof(RwcStep));
+    // session buffers come from the library's scratch cache and a pinned pool: nineteen hipMalloc + three hipHostMalloc calls per prover
+    // were most of a 6 ms set-up. The pinned plan buffers of the address phase are taken when that phase starts (rwc_next_plan_buffer).
+    auto dev = [&](auto **pp, size_t bytes) {
+        if (e != hipSuccess) return;
+        *pp = reinterpret_cast<std::remove_reference_t<decltype(*pp)>>(scratch_get(bytes));
+        if (!*pp) e = hipErrorOutOfMemory;
+    };
+    for (int b = 0; b < 2; b++) {
+        dev(&s->ra[b], (size_t)s->cap * 32);
+        dev(&s->val_c[b], (size_t)s->cap * 32);
+        dev(&s->eq[b], (b ? (T / 2 ? T / 2 : 1) : T) * 32);
+        dev(&s->inc[b], (b ? (T / 2 ? T / 2 : 1) : T) * 32);
+        dev(&s->val[b], K * 32);  // both full size: the previous level stays readable
+        dev(&s->d_sk32[b], (size_t)s->cap * 2 * 4);
+        dev(&s->d_sk64[b], (size_t)s->cap * 2 * 8);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&s->plan_uploaded[b], hipEventDisableTiming);
     }
-    s->plan.p = s->h_plan[0];
-    if (e == hipSuccess) e = hipMalloc((void **)&s->d_idx, (size_t)s->cap * 8);
-    if (e == hipSuccess) e = hipMalloc((void **)&s->d_part, (size_t)RWC_MAX_BLOCKS * 2 * 32);
-    if (e == hipSuccess) e = hipMalloc((void **)&s->d_out, 8 * 32);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_out, 16 * 32);
+    dev(&s->d_plan, (size_t)s->cap * sizeof(RwcStep));
+    dev(&s->d_idx, (size_t)s->cap * 4);
+    dev(&s->d_blk, (div_up(s->cap, RWC_WALK_BLOCK) + 2) * 4);
+    s->n_entries = n;
+    dev(&s->d_part, (size_t)RWC_MAX_BLOCKS * 2 * 32);
+    dev(&s->d_out, 8 * 32);
+    if (e == hipSuccess && !(s->h_out = reinterpret_cast<uint64_t *>(rwc_pin_get(16 * 32)))) e = hipErrorOutOfMemory;
     if (e != hipSuccess) {
         set_error(std::string("zg_rwc_open: ") + hipGetErrorString(e));
         rwc_free(s);
         return e == hipErrorOutOfMemory ? ZG_ERR_NOMEM : ZG_ERR_HIP;
     }
-    const size_t n8 = (n + 7) & ~(size_t)7;
-    Scratch s_val((size_t)s->cap * 8), s_wr(inc ? 8 : n8 * 21 + 8);  // prev | next | cycle | is_write of the entries, for the scatter
+    Scratch s_val((size_t)s->cap * 8), s_wr(inc ? 8 : n + 8);  // val_coeff as u64; is_write of the entries, for the scatter
     if (!s_val.p || !s_wr.p) {
         rwc_free(s);
         return ZG_ERR_NOMEM;
     }
     int rc = [&]() -> int {
         SyncGuard sync(s->st);
-        if (n) {
+        if (n) {  // the skeleton, set 0
+            ZG_HIP(hipMemcpyAsync(s->d_sk32[0], cycle, n * 4, hipMemcpyHostToDevice, s->st));
+            ZG_HIP(hipMemcpyAsync(s->d_sk32[0] + s->cap, address, n * 4, hipMemcpyHostToDevice, s->st));
+            ZG_HIP(hipMemcpyAsync(s->d_sk64[0], prev_val, n * 8, hipMemcpyHostToDevice, s->st));
+            ZG_HIP(hipMemcpyAsync(s->d_sk64[0] + s->cap, next_val, n * 8, hipMemcpyHostToDevice, s->st));
             ZG_HIP(hipMemcpyAsync(s_val.p, val_coeff, n * 8, hipMemcpyHostToDevice, s->st));
             hipLaunchKernelGGL(rwc_init_kernel, dim3(div_up(n, 256)), dim3(256), 0, s->st, s_val.as<uint64_t>(), (uint32_t)n, s->ra[0], s->val_c[0]);
             ZG_HIP(hipGetLastError());
@@ -538,14 +711,10 @@ static int rwc_open_impl(size_t log_k, size_t log_t, size_t n, const uint32_t *c
         } else {
             ZG_HIP(hipMemsetAsync(s->inc[0], 0, T * 32, s->st));
             if (n) {
-                uint64_t *d_prev = s_wr.as<uint64_t>(), *d_next = d_prev + n8;
-                uint32_t *d_cyc = reinterpret_cast<uint32_t *>(d_next + n8);
-                uint8_t *d_w = reinterpret_cast<uint8_t *>(d_cyc + n8);
-                ZG_HIP(hipMemcpyAsync(d_prev, prev_val, n * 8, hipMemcpyHostToDevice, s->st));
-                ZG_HIP(hipMemcpyAsync(d_next, next_val, n * 8, hipMemcpyHostToDevice, s->st));
-                ZG_HIP(hipMemcpyAsync(d_cyc, cycle, n * 4, hipMemcpyHostToDevice, s->st));
+                uint8_t *d_w = s_wr.as<uint8_t>();
                 ZG_HIP(hipMemcpyAsync(d_w, is_write, n, hipMemcpyHostToDevice, s->st));
-                hipLaunchKernelGGL(rwc_inc_scatter_kernel, dim3(div_up(n, 256)), dim3(256), 0, s->st, d_cyc, d_prev, d_next, d_w, (uint32_t)n, s->inc[0]);
+                hipLaunchKernelGGL(rwc_inc_scatter_kernel, dim3(div_up(n, 256)), dim3(256), 0, s->st, s->d_sk32[0], s->d_sk64[0], s->d_sk64[0] + s->cap, d_w,
+                                   (uint32_t)n, s->inc[0]);
                 ZG_HIP(hipGetLastError());
             }
         }
@@ -553,6 +722,7 @@ static int rwc_open_impl(size_t log_k, size_t log_t, size_t n, const uint32_t *c
         ZG_TRY(zg_fr_eq_table_dev(r_cycle, log_t, nullptr, s->eq[0], s->st));  // computeEqBigEndian (:345-348)
         ZG_HIP(hipStreamSynchronize(s->st));
         sync.dismiss();
+        s->dev_skel = true;
         return ZG_OK;
     }();
     if (rc != ZG_OK) {
@@ -582,7 +752,7 @@ int zg_rwc_open_writes(size_t log_k, size_t log_t, size_t n, const uint32_t *cyc
     return rwc_open_impl(log_k, log_t, n, cycle, address, val_coeff, prev_val, next_val, nullptr, is_write, val_init, r_cycle, out);
 }
 
-size_t zg_rwc_entries(zg_rwc_t s) { return s ? s->cycle.size() : 0; }
+size_t zg_rwc_entries(zg_rwc_t s) { return s ? s->n_entries : 0; }
 size_t zg_rwc_cycles(zg_rwc_t s) { return s ? s->eq_size : 0; }
 
 int zg_rwc_round_cycle(zg_rwc_t s, const uint64_t *d_e_out, size_t n_out, const uint64_t *d_e_in, size_t n_in, const uint64_t gamma[4], uint64_t q_constant[4],
@@ -594,20 +764,18 @@ int zg_rwc_round_cycle(zg_rwc_t s, const uint64_t *d_e_out, size_t n_out, const 
     }
     DeviceGuard dg(s->device);
     std::lock_guard<std::mutex> lk(s->mu);
-    rwc_plan_cycle(s);
-    const uint32_t m = (uint32_t)s->plan.size();
-    if (m == 0) {
+    ZG_TRY(rwc_plan_cycle(s));
+    if (s->n_entries == 0) {
         for (int i = 0; i < 4; i++) q_constant[i] = q_quadratic[i] = 0;
         return ZG_OK;
     }
-    ZG_TRY(rwc_upload_plan(s));
     uint32_t in_bits = 0;
     while (((size_t)1 << in_bits) < n_in) in_bits++;
-    const uint32_t nb = div_up(m, 256);
-    hipLaunchKernelGGL(rwc_cycle_round_kernel, dim3(nb), dim3(256), 0, s->st, s->d_plan, m, s->ra[s->cur], s->val_c[s->cur], s->inc[s->vcur], (uint32_t)s->eq_size,
-                       d_e_out, (uint32_t)n_out, d_e_in, (uint32_t)n_in, in_bits, rwc_fr_arg(gamma), s->d_part);
+    const uint32_t nb = div_up(s->n_entries, 256);  // one thread per ENTRY: the steps are at most as many, their count is still on the device
+    hipLaunchKernelGGL(rwc_cycle_round_kernel, dim3(nb), dim3(256), 0, s->st, s->d_plan, rwc_walk_total(s), s->ra[s->cur], s->val_c[s->cur], s->inc[s->vcur],
+                       (uint32_t)s->eq_size, d_e_out, (uint32_t)n_out, d_e_in, (uint32_t)n_in, in_bits, rwc_fr_arg(gamma), s->d_part);
     ZG_HIP(hipGetLastError());
-    return rwc_collect(s, nb, q_constant, q_quadratic);
+    return rwc_collect(s, nb, q_constant, q_quadratic, rwc_walk_total(s));
 }
 
 int zg_rwc_bind_cycle(zg_rwc_t s, const uint64_t r[4]) {
@@ -627,23 +795,32 @@ int zg_rwc_bind_cycle(zg_rwc_t s, const uint64_t r[4]) {
     s->vcur = vn;
     s->eq_size = half;
     if (!s->plan_valid || s->plan_is_address) {  // a bind without the round call before it: walk now
-        rwc_plan_cycle(s);
-        ZG_TRY(rwc_upload_plan(s));
+        ZG_TRY(rwc_plan_cycle(s));
+        if (s->n_entries) {
+            ZG_HIP(hipMemcpyAsync(s->h_out + 8, rwc_walk_total(s), 4, hipMemcpyDeviceToHost, s->st));
+            ZG_HIP(hipStreamSynchronize(s->st));
+            s->plan_m = (uint32_t)s->h_out[8];
+        }
     }
-    const uint32_t m = (uint32_t)s->plan.size();
+    const uint32_t m = (uint32_t)s->plan_m;
     if (m) {
         hipLaunchKernelGGL(rwc_cycle_bind_kernel, dim3(div_up(m, 256)), dim3(256), 0, s->st, s->d_plan, m, s->ra[s->cur], s->val_c[s->cur], rwc_fr_arg(r),
                            s->ra[s->cur ^ 1], s->val_c[s->cur ^ 1]);
         ZG_HIP(hipGetLastError());
         s->cur ^= 1;
     }
-    rwc_apply_plan(s, false);
+    // the bound skeleton is what the walk wrote into the other set
+    s->sk ^= 1;
+    s->n_entries = m;
+    s->host_skel = false;
+    s->plan_valid = false;
     return ZG_OK;
 }
 
 // the stable sort by (address, cycle) at the phase switch (:553-558), and eq_evals[0] / inc[0] as they stand then (:543-552)
 static int rwc_to_address_major(zg_rwc_s *s) {
     if (s->address_major) return ZG_OK;
+    ZG_TRY(rwc_host_skeleton(s));
     ZG_HIP(hipMemcpyAsync(s->h_out, s->eq[s->vcur], 32, hipMemcpyDeviceToHost, s->st));
     ZG_HIP(hipMemcpyAsync(s->h_out + 4, s->inc[s->vcur], 32, hipMemcpyDeviceToHost, s->st));
     ZG_HIP(hipStreamSynchronize(s->st));
@@ -654,9 +831,25 @@ static int rwc_to_address_major(zg_rwc_s *s) {
     const size_t n = s->cycle.size();
     if (n > 1) {
         std::vector<uint32_t> perm(n);
-        for (size_t i = 0; i < n; i++) perm[i] = (uint32_t)i;
-        std::stable_sort(perm.begin(), perm.end(),
-                         [&](uint32_t x, uint32_t y) { return s->addr[x] != s->addr[y] ? s->addr[x] < s->addr[y] : s->cycle[x] < s->cycle[y]; });
+        // The list the cycle phase leaves is still in cycle order (a bind halves every cycle and keeps the steps in list order), so a STABLE
+        // counting sort by address alone is the stable sort by (address, cycle): O(n + addresses) instead of 11 ms of comparisons at 2^18
+        // entries. A list that is not in cycle order (entry points called out of the prover's order) takes the comparison sort.
+        bool by_cycle = true;
+        uint32_t amax = 0;
+        for (size_t i = 0; i < n; i++) {
+            by_cycle = by_cycle && (i == 0 || s->cycle[i - 1] <= s->cycle[i]);
+            amax = s->addr[i] > amax ? s->addr[i] : amax;
+        }
+        if (by_cycle && (size_t)amax <= 8 * n + 65536) {
+            std::vector<uint32_t> first((size_t)amax + 2, 0u);
+            for (size_t i = 0; i < n; i++) first[(size_t)s->addr[i] + 1]++;
+            for (size_t a = 1; a < first.size(); a++) first[a] += first[a - 1];
+            for (size_t i = 0; i < n; i++) perm[first[s->addr[i]]++] = (uint32_t)i;
+        } else {
+            for (size_t i = 0; i < n; i++) perm[i] = (uint32_t)i;
+            std::stable_sort(perm.begin(), perm.end(),
+                             [&](uint32_t x, uint32_t y) { return s->addr[x] != s->addr[y] ? s->addr[x] < s->addr[y] : s->cycle[x] < s->cycle[y]; });
+        }
         std::vector<uint32_t> c2(n), a2(n);
         std::vector<uint64_t> p2(n), n2(n);
         for (size_t i = 0; i < n; i++) {
@@ -675,6 +868,7 @@ static int rwc_to_address_major(zg_rwc_s *s) {
         ZG_HIP(hipGetLastError());
         ZG_HIP(hipStreamSynchronize(s->st));  // perm is a local
         s->cur ^= 1;
+        s->dev_skel = false;
     }
     s->address_major = true;
     s->plan_valid = false;
@@ -707,8 +901,9 @@ int zg_rwc_round_address(zg_rwc_t s, size_t addr_round, const uint64_t *challeng
         set_error("zg_rwc_round_address: addr_round does not match the address binds so far");
         return ZG_ERR_INVALID;
     }
+    ZG_TRY(rwc_host_skeleton(s));
     ZG_TRY(rwc_to_address_major(s));
-    rwc_plan_address(s, addr_round);
+    ZG_TRY(rwc_plan_address(s, addr_round));
     const uint32_t m = (uint32_t)s->plan.size();
     if (m == 0) {
         for (int i = 0; i < 4; i++) s0[i] = s2[i] = 0;
@@ -733,6 +928,7 @@ int zg_rwc_bind_address(zg_rwc_t s, size_t addr_round, const uint64_t r[4]) {
     }
     DeviceGuard dg(s->device);
     std::lock_guard<std::mutex> lk(s->mu);
+    ZG_TRY(rwc_host_skeleton(s));
     ZG_TRY(rwc_to_address_major(s));
     const size_t size = s->k_size;  // >= 2 here
     const int kn = s->kcur ^ 1;
@@ -743,7 +939,7 @@ int zg_rwc_bind_address(zg_rwc_t s, size_t addr_round, const uint64_t r[4]) {
                        rwc_fr_arg(r));
     ZG_HIP(hipGetLastError());
     if (!s->plan_valid || !s->plan_is_address || s->plan_addr_round != addr_round) {
-        rwc_plan_address(s, addr_round);
+        ZG_TRY(rwc_plan_address(s, addr_round));
         ZG_TRY(rwc_upload_plan(s));
     }
     const uint32_t m = (uint32_t)s->plan.size();
@@ -753,7 +949,7 @@ int zg_rwc_bind_address(zg_rwc_t s, size_t addr_round, const uint64_t r[4]) {
         ZG_HIP(hipGetLastError());
         s->cur ^= 1;
     }
-    rwc_apply_plan(s, true);
+    rwc_apply_plan(s);
     s->kcur = kn;
     s->k_size = size / 2;
     return ZG_OK;
@@ -777,7 +973,7 @@ int zg_rwc_opening(zg_rwc_t s, const uint64_t *r_address, const uint64_t *r_cycl
         inc0[i] = s->h_out[4 + i];
     }
     uint64_t ra[4] = {0, 0, 0, 0}, dv[4] = {0, 0, 0, 0};
-    const size_t n = s->cycle.size();
+    const size_t n = s->n_entries;
     if (n) {
         static RwcPoint zero_pt;
         RwcPoint pt = zero_pt;
@@ -790,11 +986,10 @@ int zg_rwc_opening(zg_rwc_t s, const uint64_t *r_address, const uint64_t *r_cycl
                 pt.r[j][2 * w + 1] = (uint32_t)(src[w] >> 32);
             }
         }
-        ZG_HIP(hipMemcpyAsync(s->d_idx, s->cycle.data(), n * 4, hipMemcpyHostToDevice, s->st));
-        ZG_HIP(hipMemcpyAsync(s->d_idx + s->cap, s->addr.data(), n * 4, hipMemcpyHostToDevice, s->st));
+        ZG_TRY(rwc_dev_skeleton(s));
         const uint32_t nb = div_up(n, 256);
-        hipLaunchKernelGGL(rwc_opening_kernel, dim3(nb), dim3(256), 0, s->st, s->d_idx, s->d_idx + s->cap, s->ra[s->cur], s->val_c[s->cur], (uint32_t)n, pt,
-                           rwc_fr_arg(v0), s->d_part);
+        hipLaunchKernelGGL(rwc_opening_kernel, dim3(nb), dim3(256), 0, s->st, s->d_sk32[s->sk], s->d_sk32[s->sk] + s->cap, s->ra[s->cur], s->val_c[s->cur],
+                           (uint32_t)n, pt, rwc_fr_arg(v0), s->d_part);
         ZG_HIP(hipGetLastError());
         ZG_TRY(rwc_collect(s, nb, ra, dv));
     }
@@ -834,7 +1029,8 @@ int zg_rwc_read_entries(zg_rwc_t s, uint32_t *cycle, uint32_t *address, uint64_t
     }
     DeviceGuard dg(s->device);
     std::lock_guard<std::mutex> lk(s->mu);
-    const size_t n = s->cycle.size();
+    ZG_TRY(rwc_host_skeleton(s));
+    const size_t n = s->n_entries;
     for (size_t i = 0; i < n; i++) {
         if (cycle) cycle[i] = s->cycle[i];
         if (address) address[i] = s->addr[i];

@@ -1016,8 +1016,8 @@ class RegistersRwSession:
 
 
 class RamRwSession:
-    """RamReadWriteCheckingProver's entry list and dense tables behind zg_rwc_*: the integer walks on the host inside the library, the
-    field arithmetic on the device"""
+    """RamReadWriteCheckingProver's entry list and dense tables behind zg_rwc_*: the cycle-phase walk and the field arithmetic on the
+    device, the address-phase walk on the host inside the library"""
 
     def __init__(self, handle):
         self._h = handle
