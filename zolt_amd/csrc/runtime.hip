@@ -1,7 +1,10 @@
 // runtime.hip — lifecycle, error reporting, raw device memory and the elementwise field
 // kernels of libzolt_gpu.so (C ABI: include/zolt_gpu.h).
 #include <atomic>
+#include <cstdlib>
+#include <map>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "common.hip.h"
@@ -170,6 +173,43 @@ static void scratch_trim() {
     g_scratch_total = 0;
 }
 
+// ------------------------------------------------------------------ zg_dev_alloc / zg_dev_free
+// A host that drives a prover through the C ABI allocates and frees its tables per proof (the C++ / Python mirrors: a few 32 MB tables per
+// stage): hipMalloc + hipFree of those cost more than the rounds they serve. Freed blocks are kept per device in size classes (the request
+// rounded up to an eighth of its leading power of two: at most 12.5 % slack) and handed out again. zg_dev_free keeps hipFree's guarantee —
+// it returns after all device work has finished (hipDeviceSynchronize), so a block that comes back from the cache is idle. Blocks above
+// 512 MiB bypass the cache; at most 2 GiB stay cached (ZG_DEV_ALLOC_CACHE_MB, 0 = off); an allocation that fails empties the cache and
+// tries again.
+struct DevBlock { size_t bytes; int dev; };
+static std::mutex g_da_mu;
+static std::unordered_map<void *, DevBlock> g_da_live;             // blocks handed out by zg_dev_alloc (class size, device)
+static std::multimap<std::pair<int, size_t>, void *> g_da_free;    // (device, class size) -> idle block
+static size_t g_da_cached = 0;
+static constexpr size_t DA_MAX_BLOCK = (size_t)512 << 20;
+static size_t da_cache_cap() {
+    static const size_t cap = [] {
+        const char *v = getenv("ZG_DEV_ALLOC_CACHE_MB");
+        long mb = v && *v ? atol(v) : 2048;
+        return (size_t)(mb < 0 ? 0 : mb) << 20;
+    }();
+    return cap;
+}
+static size_t da_class(size_t bytes) {
+    if (bytes <= 4096) return 4096;
+    int lg = 63 - __builtin_clzll((unsigned long long)bytes);  // 2^lg <= bytes
+    const size_t step = (size_t)1 << (lg - 3);
+    return (bytes + step - 1) / step * step;
+}
+static void da_trim_locked() {
+    for (auto &kv : g_da_free) (void)hipFree(kv.second);
+    g_da_free.clear();
+    g_da_cached = 0;
+}
+static void da_trim() {
+    std::lock_guard<std::mutex> lk(g_da_mu);
+    da_trim_locked();
+}
+
 // ------------------------------------------------------------------ profiling
 struct ProfRec { int id; hipEvent_t e0, e1; };
 static std::vector<ProfRec> g_prof;
@@ -292,6 +332,7 @@ void zg_shutdown(void) {
     }
     if (prev >= 0) (void)hipSetDevice(prev);
     scratch_trim();
+    da_trim();
     g_primary = -1;
     g_ndev = 0;
     g_inited = false;
@@ -309,17 +350,61 @@ int zg_device_count(void) {
 int zg_dev_alloc(size_t bytes, void **dptr) {
     ZG_INIT();
     if (!dptr) return ZG_ERR_INVALID;
-    hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
+    const int dev = current_device();
+    const size_t cls = da_class(bytes ? bytes : 1);
+    const bool cached = cls <= DA_MAX_BLOCK && da_cache_cap() > 0;
+    if (cached) {
+        std::lock_guard<std::mutex> lk(g_da_mu);
+        auto it = g_da_free.find({dev, cls});
+        if (it != g_da_free.end()) {
+            *dptr = it->second;
+            g_da_free.erase(it);
+            g_da_cached -= cls;
+            g_da_live[*dptr] = DevBlock{cls, dev};
+            return ZG_OK;
+        }
+    }
+    hipError_t e = hipMalloc(dptr, cached ? cls : (bytes ? bytes : 1));
+    if (e == hipErrorOutOfMemory) {  // give the cached blocks (this cache and the scratch cache) back and try once more
+        (void)hipGetLastError();
+        da_trim();
+        e = hipMalloc(dptr, cached ? cls : (bytes ? bytes : 1));
+    }
     if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
         set_error("hipMalloc: out of memory");
         return ZG_ERR_NOMEM;
     }
     ZG_HIP(e);
+    if (cached) {
+        std::lock_guard<std::mutex> lk(g_da_mu);
+        g_da_live[*dptr] = DevBlock{cls, dev};
+    }
     return ZG_OK;
 }
 int zg_dev_free(void *dptr) {
     ZG_INIT();
-    ZG_HIP(hipFree(dptr));
+    if (!dptr) return ZG_OK;
+    DevBlock b{0, -1};
+    {
+        std::lock_guard<std::mutex> lk(g_da_mu);
+        auto it = g_da_live.find(dptr);
+        if (it != g_da_live.end()) {
+            b = it->second;
+            g_da_live.erase(it);
+        }
+    }
+    if (b.dev < 0 || g_da_cached + b.bytes > da_cache_cap()) {  // not from the cache's classes, or the cache is full
+        ZG_HIP(hipFree(dptr));
+        return ZG_OK;
+    }
+    {  // hipFree's guarantee: nothing on the block's device still uses it when it is handed out again
+        DeviceGuard dg(b.dev);
+        ZG_HIP(hipDeviceSynchronize());
+    }
+    std::lock_guard<std::mutex> lk(g_da_mu);
+    g_da_free.insert({{b.dev, b.bytes}, dptr});
+    g_da_cached += b.bytes;
     return ZG_OK;
 }
 // Both copies run ON the library stream and wait for it: they are ordered after every call that was given stream = NULL (the
