@@ -108,13 +108,13 @@ def test_hyperkzg_open_mid_sizes(env, v, srs_n):
     params.deinit()
 
 
-@pytest.mark.parametrize("v,srs_n,fuse", [(17, 1 << 17, "2"), (18, 1 << 17, "2"), (18, 1 << 18, "2"), (18, 1 << 17, "1"), (17, 1 << 17, "0")])
+@pytest.mark.parametrize("v,srs_n,fuse", [(17, 1 << 17, "2"), (18, 1 << 17, "2"), (18, 1 << 18, "2"), (18, 1 << 17, "1"), (17, 1 << 17, "1"), (18, 1 << 18, "1"), (17, 1 << 17, "0")])
 def test_hyperkzg_open_long_levels(env, v, srs_n, fuse, monkeypatch):
     """open() with several long levels (quotients of more than 16384 entries) on a wide-window SRS handle: they are committed as
     the rows of one zero-padded matrix by ONE fused launch set (two-pass sort over several vectors' bucket sets), the short
-    levels by another; v = 18 on a 2^17-point SRS clamps the first commit to the SRS length. ZG_HK_FUSE_LONG=2 (default): the first
-    long level keeps its own launch set and the matrix holds the rest at the second level's length (needs three long levels);
-    1: all long levels in the matrix; 0: one launch set per long level on the helper streams. Same quotient commitments and final evaluation as the oracle either way."""
+    levels by another; v = 18 on a 2^17-point SRS clamps the first commit to the SRS length. ZG_HK_FUSE_LONG=1 (default): all long
+    levels in the matrix; 2: the first long level keeps its own launch set and the matrix holds the rest at the second level's length
+    (needs three long levels); 0: one launch set per long level on the helper streams. Same quotient commitments and final evaluation as the oracle either way."""
     api, lib, ob = env
     monkeypatch.setenv("ZG_HK_FUSE_LONG", fuse)
     gm = ob.g1_gen_multiples(srs_n)

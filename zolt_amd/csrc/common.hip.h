@@ -19,6 +19,9 @@ int current_device();       // the calling thread's HIP device
 hipStream_t lib_stream();   // the library's own stream on the calling thread's CURRENT device (created on first use)
 hipStream_t stream_acquire();                     // an idle stream of the current device (created if none): sumcheck sessions
 void stream_release(hipStream_t st, int device);  // back to the free list (streams live until zg_shutdown)
+// three streams created back to back (= on three different hardware queues), as a unit: launch sets that are meant to overlap
+bool stream_group_acquire(hipStream_t out[3]);
+void stream_group_release(const hipStream_t s[3], int device);
 
 // HIP's current device is per host thread (a fresh std.Thread worker starts on device 0) and a handle's memory lives on
 // the device it was created on: every entry point pins the calling thread to the right device for its duration.
@@ -149,7 +152,8 @@ void psc_shutdown();
 void rwc_shutdown();      // rwc.hip: free the pinned-buffer pool (called by zg_shutdown)
 
 // msm.hip: zg_msm_g1_batch_dev that also fuses zero-padded rows on wide-window handles (HyperKZG.open's long levels)
-int msm_batch_dev_wide(zg_bases_t b, size_t n, const uint64_t *d_scalars, size_t k, hipStream_t st, uint64_t *d_out9);
+// row_len (optional, k entries): row j holds zeros from row_len[j] on — the digit and sort kernels then walk the live entries only
+int msm_batch_dev_wide(zg_bases_t b, size_t n, const uint64_t *d_scalars, size_t k, hipStream_t st, uint64_t *d_out9, const size_t *row_len = nullptr);
 // msm.hip, for sharded.hip: k un-normalised Jacobian partials of this device's shard; the combine of gathered partials
 int msm_batch_partials_dev(zg_bases_t b, size_t n, const uint64_t *d_scalars, size_t k, hipStream_t st, uint64_t *d_out12);
 int msm_combine_batch_enqueue(const uint64_t *d_partials, size_t ranks, size_t rank_stride, size_t k, hipStream_t st, uint64_t *d_out9);

@@ -286,6 +286,25 @@ __global__ void __launch_bounds__(256) msm_scatter_kernel(const uint32_t *dig, u
     sorted[pos] = (e & 0x80000000u) | ref;
 }
 
+// Rows of a zero-padded matrix of scalar vectors by their LIVE lengths (HyperKZG.open's long levels: 2^19, 2^18, ... entries in rows of
+// 2^19): the digit and sort kernels walk the compact index space [0, off[k]) — row j holds [off[j], off[j + 1]), its scalars sit at
+// j * n_pts + (i - off[j]) — instead of k * n_pts scalars of which four in five are padding. k = 0: uniform rows of n_pts scalars.
+struct RowOffs {
+    uint32_t k;
+    uint32_t off[33];
+};
+ZG_DEV void row_split(const RowOffs &r, uint32_t n_pts, uint32_t i, uint32_t &batch, uint32_t &pt) {
+    if (r.k == 0) {
+        batch = i / n_pts;
+        pt = i - batch * n_pts;
+        return;
+    }
+    uint32_t b = 0;
+    while (b + 1 < r.k && i >= r.off[b + 1]) b++;
+    batch = b;
+    pt = i - r.off[b];
+}
+
 // ---- LDS-staged counting sort (used when the whole bucket histogram fits in LDS: NK*4 <= 128 KiB).
 // One 1024-thread block per CU owns a contiguous slice of the scalars; its histogram and, later, its
 // scatter cursors live in LDS (ds_add_rtn_u32), so the sort issues no global atomics at all. The global
@@ -293,7 +312,7 @@ __global__ void __launch_bounds__(256) msm_scatter_kernel(const uint32_t *dig, u
 template <int C>
 __global__ void __launch_bounds__(1024) msm_digits_lds_kernel(const uint64_t *scalars, const uint8_t *inf, uint32_t n, uint32_t n_pts,
                                                               int G, uint32_t per_block, uint32_t NK, int shift, uint32_t *dig,
-                                                              uint32_t *blockhist) {
+                                                              uint32_t *blockhist, RowOffs rows) {
     ZG_HIPRIO();
     extern __shared__ uint32_t lds_hist[];
     constexpr int W = (255 + C - 1) / C;
@@ -302,8 +321,9 @@ __global__ void __launch_bounds__(1024) msm_digits_lds_kernel(const uint64_t *sc
     __syncthreads();
     uint32_t i0 = blockIdx.x * per_block, i1 = i0 + per_block < n ? i0 + per_block : n;
     for (uint32_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-        Fr s = fr_from_mont29(fe_load<FrParams>(scalars + 4 * (size_t)i));
-        uint32_t batch = i / n_pts, pt = i - batch * n_pts;
+        uint32_t batch, pt;
+        row_split(rows, n_pts, i, batch, pt);
+        Fr s = fr_from_mont29(fe_load<FrParams>(scalars + 4 * (rows.k ? (size_t)batch * n_pts + pt : (size_t)i)));
         bool skip = inf && inf[pt];
         uint32_t carry = 0;
 #pragma unroll
@@ -350,7 +370,7 @@ __global__ void __launch_bounds__(256) msm_colscan_kernel(uint32_t *blockhist, u
 
 __global__ void __launch_bounds__(1024) msm_scatter_lds_kernel(const uint32_t *dig, uint32_t n, uint32_t n_pts, int W, int G,
                                                                size_t table_n, uint32_t off, uint32_t per_block, uint32_t NK,
-                                                               const uint32_t *starts, const uint32_t *blockhist, uint32_t *sorted) {
+                                                               const uint32_t *starts, const uint32_t *blockhist, uint32_t *sorted, RowOffs rows) {
     ZG_HIPRIO();
     extern __shared__ uint32_t lds_cur[];
     const uint32_t *row = blockhist + (size_t)blockIdx.x * NK;
@@ -363,7 +383,9 @@ __global__ void __launch_bounds__(1024) msm_scatter_lds_kernel(const uint32_t *d
             uint32_t e = dig[(size_t)w * n + i];
             if (e == 0xFFFFFFFFu) continue;
             uint32_t pos = atomicAdd(&lds_cur[e & 0x7FFFFFFFu], 1u);
-            sorted[pos] = (e & 0x80000000u) | (uint32_t)((size_t)lvl * table_n + off + i % n_pts);
+            uint32_t batch, pt;
+            row_split(rows, n_pts, i, batch, pt);
+            sorted[pos] = (e & 0x80000000u) | (uint32_t)((size_t)lvl * table_n + off + pt);
         }
     }
 }
@@ -431,7 +453,8 @@ static constexpr uint32_t STAGE_ENTRIES = 32768;  // 128 KiB of LDS
 template <bool PLAIN>
 __global__ void __launch_bounds__(1024) msm_partition_kernel(const uint32_t *dig, uint32_t n, uint32_t n_pts, int W, int G, size_t table_n,
                                                              uint32_t off, uint32_t per_block, uint32_t NCB, int fb, int rb,
-                                                             const uint32_t *tstarts, const uint32_t *blockoff, uint32_t *tmp, int local_shift) {
+                                                             const uint32_t *tstarts, const uint32_t *blockoff, uint32_t *tmp, int local_shift,
+                                                             RowOffs rows) {
     ZG_HIPRIO();
     extern __shared__ uint32_t lds[];
     uint32_t *buf = lds, *cnt = lds + STAGE_ENTRIES, *lbase = cnt + NCB, *sums = lbase + NCB + 1;  // sums: 1024 scan partials
@@ -486,7 +509,11 @@ __global__ void __launch_bounds__(1024) msm_partition_kernel(const uint32_t *dig
     }
     // a thread's entries belong to at most two scalars (rows 0 and 1 of every window): their point indices are found once
     // (several scalar vectors lie back to back over the same bases: index modulo n_pts)
-    const uint32_t pt_row0 = PLAIN ? i0 + tid : (i0 + tid) % n_pts, pt_row1 = PLAIN ? i0 + T + tid : (i0 + T + tid) % n_pts;
+    uint32_t pt_row0 = i0 + tid, pt_row1 = i0 + T + tid, row_unused;
+    if (!PLAIN) {
+        row_split(rows, n_pts, i0 + tid, row_unused, pt_row0);
+        row_split(rows, n_pts, i0 + T + tid, row_unused, pt_row1);
+    }
 #pragma unroll
     for (int r = 0; r < (int)(STAGE_ENTRIES / 1024); r++) {
         if (e[r] != 0xFFFFFFFFu) {
@@ -1748,21 +1775,23 @@ static unsigned sort_threads() {
 
 template <int C>
 static int launch_digits_lds(hipStream_t st, const uint64_t *sc, const uint8_t *inf, uint32_t n, uint32_t n_pts, int G, uint32_t per_block,
-                             uint32_t NK, uint32_t nblk, uint32_t *dig, uint32_t *blockhist, int shift, unsigned threads) {
+                             uint32_t NK, uint32_t nblk, uint32_t *dig, uint32_t *blockhist, int shift, unsigned threads, const RowOffs &rows) {
     static PerDeviceOnce once;  // per instantiation and device; MSM entry points are re-entrant (std.Thread workers call MSM.compute)
     ZG_HIP(once.run([] {
         return hipFuncSetAttribute(reinterpret_cast<const void *>(msm_digits_lds_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     }));
-    hipLaunchKernelGGL(msm_digits_lds_kernel<C>, dim3(nblk), dim3(threads), NK * 4, st, sc, inf, n, n_pts, G, per_block, NK, shift, dig, blockhist);
+    hipLaunchKernelGGL(msm_digits_lds_kernel<C>, dim3(nblk), dim3(threads), NK * 4, st, sc, inf, n, n_pts, G, per_block, NK, shift, dig, blockhist, rows);
     return ZG_OK;
 }
 
 static int launch_digits_lds_c(int c, hipStream_t st, const uint64_t *sc, const uint8_t *inf, uint32_t n, uint32_t n_pts, int G,
                                uint32_t per_block, uint32_t NK, uint32_t nblk, uint32_t *dig, uint32_t *blockhist, int shift = 0,
-                               unsigned threads = 0) {
+                               unsigned threads = 0, const RowOffs *rows_in = nullptr) {
+    static const RowOffs uniform{};
+    const RowOffs &rows = rows_in ? *rows_in : uniform;
     if (!threads) threads = sort_threads();
     switch (c) {
-#define ZG_CASE(C) case C: return launch_digits_lds<C>(st, sc, inf, n, n_pts, G, per_block, NK, nblk, dig, blockhist, shift, threads);
+#define ZG_CASE(C) case C: return launch_digits_lds<C>(st, sc, inf, n, n_pts, G, per_block, NK, nblk, dig, blockhist, shift, threads, rows);
         ZG_CASE(2) ZG_CASE(3) ZG_CASE(4) ZG_CASE(5) ZG_CASE(6) ZG_CASE(7) ZG_CASE(8) ZG_CASE(9) ZG_CASE(10)
         ZG_CASE(11) ZG_CASE(12) ZG_CASE(13) ZG_CASE(14) ZG_CASE(15) ZG_CASE(16) ZG_CASE(17) ZG_CASE(18) ZG_CASE(19)
 #undef ZG_CASE
@@ -1861,6 +1890,10 @@ static int msm_enqueue(zg_bases_s *b, size_t off, size_t n, const uint64_t *d_sc
     return msm_enqueue_lane(b, b->plan, ln, b->nblk, off, n, d_scalars, st, mode, d_rec, d_inf_out, 0, 0);
 }
 
+// Live row lengths of the zero-padded matrix the next launch set sorts (msm_batch_dev_wide_rows sets it around its call; the sort reads
+// it when the set is the whole matrix): see RowOffs.
+static thread_local const RowOffs *t_row_offs = nullptr;
+
 // One launch set on workspace `ln` under plan `p`: p.K scalar vectors of n_pts scalars each, stored back to back at
 // d_scalars, all over bases[off, off+n_pts); vector i's record lands at d_rec + i*rec_stride / d_inf_out + i*inf_stride.
 static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &ln, uint32_t nblk_cap, size_t off, size_t n_pts,
@@ -1899,9 +1932,13 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
     if (ln.exp_sorted_once) return ZG_OK;
     ln.exp_sorted_once = true;
 #endif
-    const size_t n = n_pts * (size_t)p.K;  // scalars in this launch set
-    const uint8_t *infp = b->d_inf ? b->d_inf + off : nullptr;
     const MsmPlan &q = local_shift ? ps : p;  // fine bits / coarse bins of this launch
+    // rows by their live lengths: the LDS-histogram sorts only (the global-atomic sort of very small sets walks the padded matrix)
+    const RowOffs *rows = t_row_offs && S == 1 && t_row_offs->k == (uint32_t)p.K && (q.fb || (nblk_cap && ln.d_blockhist)) ? t_row_offs : nullptr;
+    static const RowOffs uniform_rows{};
+    const RowOffs &rowv = rows ? *rows : uniform_rows;
+    const size_t n = rows ? rows->off[rows->k] : n_pts * (size_t)p.K;  // scalars in this launch set
+    const uint8_t *infp = b->d_inf ? b->d_inf + off : nullptr;
     if (q.fb) {
         // two-pass sort: blocks of 256 threads over TWO_PASS_SPAN scalars each (coarse counters are a few KiB of LDS)
         uint32_t nblk = (uint32_t)div_up(n, two_pass_span(p.W));  // per_block * W <= STAGE_ENTRIES
@@ -1912,7 +1949,7 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
         uint32_t per_block = (uint32_t)((n + nblk - 1) / nblk);
         prof_begin(ZG_PROF_MSM_DIGITS, st);
         ZG_TRY(launch_digits_lds_c(p.c, st, d_scalars, infp, (uint32_t)n, (uint32_t)n_pts, p.G, per_block, q.NCB, nblk, ln.d_dig,
-                                   ln.d_blockhist, q.fb, 256));
+                                   ln.d_blockhist, q.fb, 256, rows));
         prof_end(ZG_PROF_MSM_DIGITS, st);
         prof_begin(ZG_PROF_MSM_SORT, st);
         uint32_t *d_tot = ln.d_cstarts + q.NCB + 1, *d_tst = ln.d_cstarts + 2 * (size_t)q.NCB + 2, *d_ist = ln.d_cstarts + 3 * (size_t)q.NCB + 3;
@@ -1922,11 +1959,11 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
         if (p.G == 1 && n == n_pts)
             hipLaunchKernelGGL(msm_partition_kernel<true>, dim3(nblk), dim3(1024), (STAGE_ENTRIES + 2 * (size_t)q.NCB + 1 + 1024) * 4, st, ln.d_dig,
                                (uint32_t)n, (uint32_t)n_pts, p.W, p.G, b->n, (uint32_t)off, per_block, q.NCB, q.fb, q.rb, d_tst, ln.d_blockhist,
-                               ln.d_tmp, local_shift);
+                               ln.d_tmp, local_shift, rowv);
         else
             hipLaunchKernelGGL(msm_partition_kernel<false>, dim3(nblk), dim3(1024), (STAGE_ENTRIES + 2 * (size_t)q.NCB + 1 + 1024) * 4, st, ln.d_dig,
                                (uint32_t)n, (uint32_t)n_pts, p.W, p.G, b->n, (uint32_t)off, per_block, q.NCB, q.fb, q.rb, d_tst, ln.d_blockhist,
-                               ln.d_tmp, local_shift);
+                               ln.d_tmp, local_shift, rowv);
         {
             uint32_t items = (uint32_t)fine_max_items(q, n);
             uint32_t *d_fbase = ln.d_fine + (size_t)items * ((size_t)1 << q.fb);
@@ -1948,7 +1985,7 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
         uint32_t per_block = (uint32_t)((n + nblk - 1) / nblk);
         prof_begin(ZG_PROF_MSM_DIGITS, st);
         ZG_TRY(launch_digits_lds_c(p.c, st, d_scalars, infp, (uint32_t)n, (uint32_t)n_pts, p.G, per_block, p.NK, nblk, ln.d_dig,
-                                   ln.d_blockhist));
+                                   ln.d_blockhist, 0, 0, rows));
         prof_end(ZG_PROF_MSM_DIGITS, st);
         prof_begin(ZG_PROF_MSM_SORT, st);
         hipLaunchKernelGGL(msm_colscan_kernel, dim3(div_up(p.NK, 256)), dim3(256), 0, st, ln.d_blockhist, nblk, p.NK, ln.d_hist);
@@ -1965,7 +2002,7 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
             return hipFuncSetAttribute(reinterpret_cast<const void *>(msm_scatter_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         }));
         hipLaunchKernelGGL(msm_scatter_lds_kernel, dim3(nblk), dim3(sort_threads()), p.NK * 4, st, ln.d_dig, (uint32_t)n, (uint32_t)n_pts, p.W, p.G,
-                           b->n, (uint32_t)off, per_block, p.NK, sv.starts, ln.d_blockhist, sv.sorted);
+                           b->n, (uint32_t)off, per_block, p.NK, sv.starts, ln.d_blockhist, sv.sorted, rowv);
     } else {
         prof_begin(ZG_PROF_MSM_DIGITS, st);
         ZG_HIP(hipMemsetAsync(ln.d_hist, 0, (size_t)p.NK * 4, st));
@@ -2440,10 +2477,18 @@ static int msm_batch_enqueue(zg_bases_s *b, size_t n, const uint64_t *d_scalars,
 namespace zg {
 // zg_msm_g1_batch_dev for zero-padded rows of different live lengths (HyperKZG.open's long levels): also fuses on wide-window
 // handles. Not exported: a general batch of full-length vectors on such a handle is better served by the stream rotation.
-int msm_batch_dev_wide(zg_bases_t b, size_t n, const uint64_t *d_scalars, size_t k, hipStream_t st, uint64_t *d_out9) {
+int msm_batch_dev_wide(zg_bases_t b, size_t n, const uint64_t *d_scalars, size_t k, hipStream_t st, uint64_t *d_out9, const size_t *row_len) {
     DeviceGuard dg(b->device);
     std::lock_guard<std::mutex> lk(b->mu);
-    return msm_batch_enqueue(b, n, d_scalars, k, st, d_out9, true);
+    RowOffs rows{};
+    if (row_len && k >= 2 && k <= 32) {  // row j is zero beyond row_len[j] <= n: the sort walks the live entries only
+        rows.k = (uint32_t)k;
+        for (size_t j = 0; j < k; j++) rows.off[j + 1] = rows.off[j] + (uint32_t)(row_len[j] < n ? row_len[j] : n);
+        t_row_offs = &rows;
+    }
+    int rc = msm_batch_enqueue(b, n, d_scalars, k, st, d_out9, true);
+    t_row_offs = nullptr;
+    return rc;
 }
 
 // sharded.hip: this device's k partial sums of a sharded batch (BatchMSM over one shard of the bases), as un-normalised

@@ -1895,26 +1895,29 @@ static int hk_open_device(zg_bases_t srs, uint64_t *d_a, uint64_t *d_b, uint64_t
     // by ONE fused launch set on a helper stream (msm_batch_dev_wide) — one sort, one accumulation over all levels' digits (as many
     // as a single MSM of twice the first level's size has) and one reduction, instead of five or six launch sets that overlap
     // badly. ZG_HK_FUSE_LONG=0 keeps one launch set per long level.
-    // Mode 2 (default): the first long level — half of all live scalars — keeps a launch set of its own on another helper stream,
-    // and the matrix holds the remaining long levels at the SECOND level's row length: the padding that the digit and sort kernels
-    // walk shrinks from 2.6 M to 1.5 M scalars at 2^20 evaluations, and the two sets run side by side. Mode 1: all long levels in
-    // one matrix.
-    const unsigned fuse_long_env = env_uint("ZG_HK_FUSE_LONG", 2, 0, 2);  // read per call: tests switch it
+    // Mode 1 (default): all long levels in one matrix. Mode 2: the first long level — half of all live scalars — keeps a launch set of
+    // its own on another helper stream, and the matrix holds the remaining long levels at the SECOND level's row length (the padding
+    // that the digit and sort kernels walk shrinks from 2.6 M to 1.5 M scalars at 2^20 evaluations). Mode 2 was the default until a
+    // kernel trace of round 4 showed what "side by side" means on the device: the second set's sort kernels (whole-CU workgroups) crawl
+    // while the first set's accumulation owns the register files (colscan 12 -> 360 us, fine_place 77 -> 290 us), so its accumulation
+    // starts when the first one ends and two reduction chains are exposed instead of one — 2^20 evaluations from a host table:
+    // mode 2 3.30-3.41 ms, mode 1 3.08-3.13 ms, mode 0 3.72 ms (tools/ab_open.py, profiles/r4h_open_modes.txt).
+    const unsigned fuse_long_env = env_uint("ZG_HK_FUSE_LONG", 1, 0, 2);  // read per call: tests switch it
     // The long levels' commits are independent of the folds that follow them: each gets its own quotient buffer and its MSM is
     // issued on one of three helper streams in turn (forked / joined by events), never on the caller's stream, so the
     // latency-bound tail of one commit runs under the accumulation of the next.
     constexpr int NAUX = 3;
-    // the helper streams belong to THIS call: taken from the runtime's per-device free list (creating a stream costs ~3 ms) and handed
-    // back on return, so concurrent opens from different caller threads do not serialise through a shared set (round-2 review)
+    // the helper streams belong to THIS call: a GROUP taken from the runtime's per-device free list (creating a stream costs ~3 ms) and
+    // handed back on return, so concurrent opens from different caller threads do not serialise through a shared set (round-2 review).
+    // A group's streams were created back to back and therefore sit on different hardware queues (HIP hands its four queues out in
+    // creation order): three streams taken one by one from the common free list put the first long level and the fused long levels
+    // on ONE queue in a trace of round 4 — the two launch sets that are meant to overlap ran one after the other (2.69 ms per open).
     struct AuxStreams {
-        hipStream_t s[NAUX];
+        hipStream_t s[NAUX] = {nullptr, nullptr, nullptr};
         int dev;
-        AuxStreams() : dev(current_device()) {
-            for (int i = 0; i < NAUX; i++) s[i] = stream_acquire();
-        }
+        AuxStreams() : dev(current_device()) { (void)stream_group_acquire(s); }
         ~AuxStreams() {
-            for (int i = 0; i < NAUX; i++)
-                if (s[i]) stream_release(s[i], dev);
+            if (s[0]) stream_group_release(s, dev);
         }
     } aux_streams;
     hipStream_t *aux = aux_streams.s;
@@ -1934,6 +1937,7 @@ static int hk_open_device(zg_bases_t srs, uint64_t *d_a, uint64_t *d_b, uint64_t
     uint64_t *d_qall = s_qall.as<uint64_t>();
     size_t q_used = 0, long_used = 0, first_long = num_vars;
     bool first_split_done = false;
+    std::vector<size_t> long_row_len;  // live entries of the matrix rows: the fused commit's sort skips the padding behind them
     struct PendingCommit { size_t level, nc; const uint64_t *q; };
     std::vector<PendingCommit> pending;
     bool aux_used[NAUX] = {false, false, false};
@@ -1976,6 +1980,7 @@ static int hk_open_device(zg_bases_t srs, uint64_t *d_a, uint64_t *d_b, uint64_t
                     if (first_long == num_vars) first_long = i;
                     hipLaunchKernelGGL(hk_quot_fold_kernel, dim3(nb), dim3(256), 0, st, cur, half, ra, d_qall + 4 * (fl_off + fl_len * long_used), nc,
                                        nxt);
+                    long_row_len.push_back(nc);
                     long_used++;
                 }
                 computed++;
@@ -1996,6 +2001,27 @@ static int hk_open_device(zg_bases_t srs, uint64_t *d_a, uint64_t *d_b, uint64_t
         computed++;
         uint64_t *t = cur; cur = nxt; nxt = t;
         len = half;
+    }
+    // The short levels' fused commit depends on the chain only: it runs beside the long commits, on the group's third stream (the
+    // caller's stream may share a hardware queue with one of the helpers; it only carries the chain, the joins and the result copy),
+    // and it is enqueued FIRST: its short kernels start right behind the chain and are done before the long levels' accumulation needs
+    // the chip (enqueued last, they ran under that accumulation's sort and stretched it: 616 -> 531 us in the trace of 2^20 evaluations).
+    if (e == hipSuccess && rc == ZG_OK && row) {  // rows are consecutive levels first_small, first_small + 1, ...
+        hipStream_t ss = st;
+        if (fork) {
+            hipEvent_t ev = nullptr;
+            e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e == hipSuccess) {
+                events.push_back(ev);
+                e = hipEventRecord(ev, st);
+            }
+            if (e == hipSuccess) e = hipStreamWaitEvent(aux[NAUX - 1], ev, 0);
+            if (e == hipSuccess) {
+                aux_used[NAUX - 1] = true;
+                ss = aux[NAUX - 1];
+            }
+        }
+        if (e == hipSuccess) rc = zg_msm_g1_batch_dev(srs, small_len, d_small, row, ss, d_res + 9 * first_small);
     }
     // The whole chain is enqueued (and, being a few short kernels, finished) before the first commit starts: kernels of different
     // streams share the dispatch pipes, and a commit's sort kernels (whole-CU workgroups that launch as accumulate workgroups
@@ -2030,13 +2056,9 @@ static int hk_open_device(zg_bases_t srs, uint64_t *d_a, uint64_t *d_b, uint64_t
         if (e == hipSuccess && !aux_used[fa]) e = hipStreamWaitEvent(aux[fa], ev, 0);
         if (e == hipSuccess) {
             aux_used[fa] = true;
-            rc = msm_batch_dev_wide(srs, fl_len, d_qall + 4 * fl_off, long_used, aux[fa], d_res + 9 * first_long);
+            rc = msm_batch_dev_wide(srs, fl_len, d_qall + 4 * fl_off, long_used, aux[fa], d_res + 9 * first_long, long_row_len.data());
         }
     }
-    // the short levels' fused commit depends on the chain only: it goes on the caller's stream before the joins and runs beside
-    // the long commits
-    if (e == hipSuccess && rc == ZG_OK && row)  // rows are consecutive levels first_small, first_small + 1, ...
-        rc = zg_msm_g1_batch_dev(srs, small_len, d_small, row, st, d_res + 9 * first_small);
     for (int a = 0; a < NAUX; a++)  // join the helper streams (also after an error, so that they never run ahead of later work)
         if (aux_used[a]) {
             hipEvent_t ev = nullptr;

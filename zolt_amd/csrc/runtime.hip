@@ -65,6 +65,36 @@ void stream_release(hipStream_t st, int device) {
     g_idle_streams[device].push_back(st);
 }
 
+// Groups of three streams created back to back. HIP gives a new stream the next of its hardware queues in turn (four by default), so the
+// members of a group sit on different queues and their kernels can overlap; two streams taken one by one from the free list above may
+// share a queue, and then what was enqueued to overlap runs one after the other. Created under the lock, so that no other creation of
+// this library falls in between.
+struct StreamGroup { hipStream_t s[3]; };
+static std::vector<StreamGroup> g_idle_groups[ZG_MAX_DEVICES];
+bool stream_group_acquire(hipStream_t out[3]) {
+    int d = current_device();
+    out[0] = out[1] = out[2] = nullptr;
+    if (d < 0 || d >= ZG_MAX_DEVICES) return false;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_idle_groups[d].empty()) {
+        for (int i = 0; i < 3; i++) out[i] = g_idle_groups[d].back().s[i];
+        g_idle_groups[d].pop_back();
+        return true;
+    }
+    for (int i = 0; i < 3; i++)
+        if (hipStreamCreateWithFlags(&out[i], hipStreamNonBlocking) != hipSuccess) {
+            for (int j = 0; j < i; j++) (void)hipStreamDestroy(out[j]);
+            out[0] = out[1] = out[2] = nullptr;
+            return false;
+        }
+    return true;
+}
+void stream_group_release(const hipStream_t s[3], int device) {
+    if (!s[0] || device < 0 || device >= ZG_MAX_DEVICES) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_idle_groups[device].push_back(StreamGroup{{s[0], s[1], s[2]}});
+}
+
 // device >= 0: bind that device as the primary; -1: keep the calling thread's current device. ndev: devices 0..ndev-1 are bound
 // (zg_init_devices), 1 for the one-GPU-per-process model.
 static int do_init(int device, int ndev) {
@@ -329,6 +359,12 @@ void zg_shutdown(void) {
             (void)hipStreamDestroy(st);
         }
         g_idle_streams[d].clear();
+        for (const StreamGroup &g : g_idle_groups[d])
+            for (int i = 0; i < 3; i++) {
+                (void)hipSetDevice(d);
+                (void)hipStreamDestroy(g.s[i]);
+            }
+        g_idle_groups[d].clear();
     }
     if (prev >= 0) (void)hipSetDevice(prev);
     scratch_trim();
