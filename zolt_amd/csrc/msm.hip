@@ -1415,9 +1415,15 @@ static uint32_t chunk_threads(uint64_t digits, bool alone = false) {
     uint64_t want = digits / per_chunk;
     uint32_t nt = 1024;
     while (nt < want && nt < 131072u) nt <<= 1;
-    // full size = 2 waves per SIMD on 256 CUs; 15/16 of it leaves a few CUs with spare registers so that
-    // another stream's latency-bound kernels (bit sums, final) can run under this kernel (measured +4-6 % MSM/s)
-    return nt == 131072u && !alone ? 122880u : nt;
+    // full size = 2 waves per SIMD on 256 CUs (512 workgroups). With other MSMs in flight a launch takes 7/8 of it (448 workgroups: a
+    // quarter of the CUs hold one workgroup instead of two): the spare registers let another stream's latency-bound kernels (bit sums,
+    // final) run under this kernel, and the NEXT accumulation's first workgroups start at once on the half-filled CUs, so that the
+    // equal-length chunks of consecutive launches stop draining and refilling the chip in step. Round 2 measured 15/16 against the
+    // full grid (+4-6 % MSM/s); round 4 swept the count (tools/exp/run_nt_sweep.sh, profiles/r4h_accumulate_slots_sweep.txt, three
+    // streams at 2^20): 512 / 496 / 480 / 464 / 448 / 440 / 432 / 416 / 384 workgroups = 793 / 790 / 800 / 790 / 816 / 810 / 800 /
+    // 809 / 792 MSM/s — 448 held +2 % over 480 in three separate runs.
+    static const uint32_t inflight = (uint32_t)env_int("ZG_MSM_INFLIGHT_CHUNKS", 114688);
+    return nt == 131072u && !alone ? inflight : nt;
 }
 
 static int make_plan(size_t n, const zg_msm_config *cfg, MsmPlan &p, size_t batch = 1) {
