@@ -828,7 +828,7 @@ template <bool QUAD>
 __global__ void __launch_bounds__(256) ZG_ACC_ATTR msm_accumulate_chunk_kernel(const uint32_t *sorted, const uint32_t *starts, const uint32_t *nzrank,
                                                                    const uint32_t *nzlist, const char *table, uint32_t NK, uint32_t NT,
                                                                    char *part) {
-    uint32_t i = blockIdx.x * 256 + threadIdx.x, q = 0;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, q = 0;
     if (QUAD) {
         q = i & 3;
         i >>= 2;
@@ -2043,11 +2043,18 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
         (void)hipGetLastError();  // hipErrorNotReady is an answer, not a failure
         uint32_t NT = chunk_threads((uint64_t)n * p.W, alone);
         if (NT > p.NT || getenv("ZG_MSM_CHUNK_THREADS")) NT = p.NT;
+        // threads per accumulate workgroup (64 / 128 / 256). Smaller workgroups spread evenly over the CUs and lose what the 7/8 launch
+        // gains (profiles/r4h_accumulate_slots_sweep.txt: 64 threads 771 / 745 / 696 MSM/s at 512 / 480 / 448 workgroups' worth of
+        // chunks against 761 / 780 / 791 with 256; 512-thread workgroups 776 / 754 / 777)
+        static const unsigned acc_block = [] {
+            int v = env_int("ZG_MSM_ACC_BLOCK", 256);
+            return (unsigned)(v == 64 || v == 128 ? v : 256);
+        }();
         if (NT <= (uint32_t)env_int("ZG_MSM_QUAD_ACC_MAX_CHUNKS", 32768))
             hipLaunchKernelGGL(msm_accumulate_chunk_kernel<true>, dim3(div_up((size_t)NT * 4, 256)), dim3(256), 0, st, sv.sorted, sv.starts,
                                sv.nzrank, sv.nzlist, b->d_table, p.NK, NT, ln.d_part);
         else
-            hipLaunchKernelGGL(msm_accumulate_chunk_kernel<false>, dim3(div_up(NT, 256)), dim3(256), 0, st, sv.sorted, sv.starts,
+            hipLaunchKernelGGL(msm_accumulate_chunk_kernel<false>, dim3(div_up(NT, acc_block)), dim3(acc_block), 0, st, sv.sorted, sv.starts,
                                sv.nzrank, sv.nzlist, b->d_table, p.NK, NT, ln.d_part);
         prof_end(ZG_PROF_MSM_ACCUMULATE, st);  // the dominant kernel alone; combine/heavy stages count as reduction
         prof_begin(ZG_PROF_MSM_REDUCE, st);
