@@ -459,7 +459,7 @@ def main():
             "pmc_wave_instructions_per_add": per_add, "static_wave_instructions_per_add": MADD_STATIC_INSTRS,
             "floor_ms_from_pmc_count": floor_pmc, "frac_from_pmc_count": floor_pmc / alone_ms,
             "residual": 1.0 - floor_pmc / alone_ms,
-            "residual_is": "time the SIMDs do not spend issuing: the launch runs 15/16 of the chip's chunk slots when other MSMs are in flight (full "
+            "residual_is": "time the SIMDs do not spend issuing: the launch runs 7/8 of the chip's chunk slots when other MSMs are in flight (full "
                            "when alone), the random 64-byte table rows (DESIGN 4a: a wave waits on its gathers when the other wave of its SIMD "
                            "does too), and the chunk-length spread at the end of the launch",
             "pmc_source": "SQ_INSTS_VALU, rocprofv3 --pmc (own pass), profiles/r4final_rocprofv3_summary.txt"})
