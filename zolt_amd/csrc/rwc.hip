@@ -595,15 +595,14 @@ static int rwc_plan_address(zg_rwc_s *s, size_t addr_round) {
 }
 // the skeleton of the bound list, address phase: step k -> entry k (bindAddressMajor* :1077-1137)
 static void rwc_apply_plan(zg_rwc_s *s) {
-    const bool address = true;
     const size_t m = s->plan.size();
     std::vector<uint32_t> &c2 = s->c2, &a2 = s->a2;
     std::vector<uint64_t> &p2 = s->p2, &n2 = s->n2;
     c2.resize(m); a2.resize(m); p2.resize(m); n2.resize(m);
     for (size_t k = 0; k < m; k++) {
         const RwcStep &st = s->plan[k];
-        c2[k] = address ? s->cycle[st.a] : s->cycle[st.a] >> 1;
-        a2[k] = address ? s->addr[st.a] >> 1 : s->addr[st.a];
+        c2[k] = s->cycle[st.a];
+        a2[k] = s->addr[st.a] >> 1;  // the bound address variable leaves the column index
         p2[k] = s->prev[st.a];
         n2[k] = (st.kind & RWC_KIND_MASK) == RWC_PAIR ? s->next[st.b] : s->next[st.a];
     }
