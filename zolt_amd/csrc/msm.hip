@@ -2041,6 +2041,9 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
         for (auto &o : b->lanes)
             if (alone && &o != &ln && o.used && hipEventQuery(o.done) == hipErrorNotReady) alone = false;
         (void)hipGetLastError();  // hipErrorNotReady is an answer, not a failure
+        // a table-less launch set (one bucket set per window: its reduction is a few hundred short workgroups, not a latency chain under
+        // someone else's accumulation) takes every slot either way: 612 MSM/s against 587 / 596 / 603 at 15/16, 7/8, 13/16 of them
+        if (p.G > 1) alone = true;
         uint32_t NT = chunk_threads((uint64_t)n * p.W, alone);
         if (NT > p.NT || getenv("ZG_MSM_CHUNK_THREADS")) NT = p.NT;
         // threads per accumulate workgroup (64 / 128 / 256). Smaller workgroups spread evenly over the CUs and lose what the 7/8 launch
