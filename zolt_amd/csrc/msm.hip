@@ -2312,7 +2312,8 @@ static int msm_host_sliced(zg_bases_s *b, size_t off, size_t n, const uint64_t *
         size_t a = (size_t)i * per, cnt = a >= n ? 0 : (n - a < per ? n - a : per);
         hipStream_t si = ss[i % (zg_bases_s::NAUX + 1)];
         if (cnt) e = hipMemcpyAsync(b->d_scal + 4 * a, scalars + 4 * a, cnt * 32, hipMemcpyHostToDevice, si);
-        if (e == hipSuccess) rc = msm_enqueue(b, off + a, cnt, b->d_scal + 4 * a, si, 2, b->d_slice_parts + 12 * (size_t)i, nullptr);
+        // (an empty trailing slice — more slices than scalars, a test setting — still writes its identity record; its range is [off, off))
+        if (e == hipSuccess) rc = msm_enqueue(b, cnt ? off + a : off, cnt, b->d_scal + 4 * (cnt ? a : 0), si, 2, b->d_slice_parts + 12 * (size_t)i, nullptr);
     }
     for (int i = 0; i < zg_bases_s::NAUX; i++) {  // join even after an error so the helpers never run ahead of the caller's next work
         hipError_t e1 = hipEventRecord(b->ev_join[i], b->aux[i]);
