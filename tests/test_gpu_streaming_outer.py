@@ -193,3 +193,53 @@ def test_stage1_of_the_captured_run_on_the_device(api, golden_dir):
     check_stage1_outer_against_the_captured_run(make, fx, api.fr_from_int, api.fr_to_int, api.lagrangeKernel)
     for p in provers:
         p.deinit()
+
+
+@pytest.mark.parametrize("small_path", ["1", "0"])
+def test_affine_product_sums_with_small_and_general_coefficients(api, small_path, monkeypatch):
+    """zg_fr_rows_affine_prodsum_dev term by term against Python integers: coefficients that are small integers (+-m, m < 2^24: an
+    8 x 1-limb product summed as a 288-bit integer, one reduction per map), the values on either side of that bound, full-width ones
+    (the general product), all in one map; 64 terms of the largest small magnitude on rows of r - 1 (the bound of the integer sum); a
+    zero constant and a full-width constant. ZG_ROWS_SMALL_COEFF=0 sends every term through the general product: same bytes."""
+    from zolt_amd import lib
+    monkeypatch.setenv("ZG_ROWS_SMALL_COEFF", small_path)
+    P = ob._R_P
+    rng = np.random.default_rng(5)
+    k, n_rows, npairs, g = 70, 300, 7, 2  # seven pairs: a full group of four and a short one
+    rows_int = [[int(x) for x in rng.integers(0, 1 << 62, size=k)] for _ in range(n_rows)]
+    for i in range(0, n_rows, 7):
+        rows_int[i] = [P - 1] * k  # the largest stored element in every column
+    rows_int[3] = [0] * k
+    big = [int.from_bytes(rng.bytes(32), "little") % P for _ in range(40)]
+    kinds = [1, P - 1, 5, P - 7, (1 << 24) - 1, P - ((1 << 24) - 1), 1 << 24, P - (1 << 24), (1 << 24) + 1, 12345, P - 99999] + big
+    coeff_int = []
+    for c in range(2 * npairs):
+        row = [0] * (k + 1)
+        if c == 0:  # 64 terms, every one the largest small magnitude, alternating sign
+            for col in range(64):
+                row[col] = (1 << 24) - 1 if col % 2 == 0 else P - ((1 << 24) - 1)
+        elif c == 1:  # 64 small positive terms of the largest magnitude: the bound of the positive sum
+            for col in range(64):
+                row[col] = (1 << 24) - 1
+        else:
+            cols = rng.choice(k, size=int(rng.integers(1, 50)), replace=False)
+            for col in cols:
+                row[int(col)] = kinds[int(rng.integers(0, len(kinds)))]
+        row[k] = 0 if c % 3 == 0 else big[c]
+        coeff_int.append(row)
+    w_int = [int.from_bytes(rng.bytes(32), "little") % P for _ in range(n_rows * g)]
+
+    def mont(vals):
+        raw = np.array([[(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)] for v in vals], dtype=np.uint64)
+        return ob.f_to_mont(ob.FR, raw)
+    d_rows = lib.DeviceBuffer.from_host(mont([x for r in rows_int for x in r]))
+    d_w = lib.DeviceBuffer.from_host(mont(w_int))
+    got = lib.fr_rows_affine_prodsum_dev(d_rows.ptr, n_rows, k, mont([x for r in coeff_int for x in r]), npairs, d_w.ptr, g)
+    for p in range(npairs):
+        a, b = coeff_int[2 * p], coeff_int[2 * p + 1]
+        tot = 0
+        for i in range(n_rows):
+            av = (a[k] + sum(a[c] * rows_int[i][c] for c in range(k))) % P
+            bv = (b[k] + sum(b[c] * rows_int[i][c] for c in range(k))) % P
+            tot += w_int[i * g + p % g] * av * bv
+        assert ob.fr_to_int(got[p]) == tot % P, (p, small_path)

@@ -619,13 +619,30 @@ struct RowsAffineArgs {
     uint64_t *tab[ROWS_AFFINE_MAX_OUT];  // per OUTPUT: its table's base
     uint8_t nnz[ROWS_AFFINE_MAX_OUT];
 };
-// coeff: nout x (k + 1) canonical elements -> pre: the same entries as prescaled 29-bit limbs (9 words each)
-__global__ void __launch_bounds__(256) rows_affine_prep_kernel(const uint64_t *coeff, uint32_t n, uint32_t *pre) {
+// coeff: nout x (k + 1) canonical elements -> pre: the same entries as prescaled 29-bit limbs (9 words each); small (optional): per entry
+// ROWS_SMALL | sign << 31 | magnitude when the coefficient is +-m with 0 < m < 2^24 as an INTEGER (its Montgomery form says nothing about
+// that: the entry is taken out of it first), else 0
+constexpr uint32_t ROWS_SMALL = 0x40000000u, ROWS_SMALL_MAG = 0x00FFFFFFu;
+__global__ void __launch_bounds__(256) rows_affine_prep_kernel(const uint64_t *coeff, uint32_t n, uint32_t *pre, uint32_t *small = nullptr) {
     uint32_t e = blockIdx.x * 256 + threadIdx.x;
     if (e >= n) return;
-    F29 f = fr29_prescale(fe_load<FrParams>(coeff + 4 * (size_t)e));
+    const Fr cm = fe_load<FrParams>(coeff + 4 * (size_t)e);
+    F29 f = fr29_prescale(cm);
 #pragma unroll
     for (int i = 0; i < 9; i++) pre[9 * (size_t)e + i] = f.l[i];
+    if (small) {
+        const Fr c = fr_from_mont29(cm), nc = fe_sub(Fr::zero(), c);
+        uint32_t hi_c = 0, hi_n = 0;
+#pragma unroll
+        for (int i = 1; i < 8; i++) {
+            hi_c |= c.l[i];
+            hi_n |= nc.l[i];
+        }
+        uint32_t w = 0;
+        if (hi_c == 0 && c.l[0] != 0 && c.l[0] <= ROWS_SMALL_MAG) w = ROWS_SMALL | c.l[0];
+        else if (hi_n == 0 && nc.l[0] != 0 && nc.l[0] <= ROWS_SMALL_MAG) w = ROWS_SMALL | 0x80000000u | nc.l[0];
+        small[e] = w;
+    }
 }
 __global__ void __launch_bounds__(1024) rows_affine_kernel(const uint64_t *rows, size_t n_rows, uint32_t k, uint32_t stride, const uint64_t *coeff, const uint32_t *pre,
                                                            const uint8_t *cols /* nout x 64 */, RowsAffineArgs a, uint32_t g, size_t n_pad) {
@@ -662,9 +679,15 @@ constexpr unsigned ROWS_PS_MAX_PAIRS = 32, ROWS_PS_WAVES = 8;
 struct RowsProdSumArgs {
     uint8_t nnz[2 * ROWS_PS_MAX_PAIRS];
 };
+// Small coefficients (round 4): the nine targets' maps are Lagrange-weighted sums of constraint rows, i.e. their coefficients are small
+// INTEGERS (a few thousand at most) — a term is then an 8 x 1-limb product of the stored element, summed as a 288-bit integer with
+// carries (an integer combination of Montgomery forms is the Montgomery form of the combination) and reduced once per map by
+// acc9_reduce: ~25 instructions per term instead of ~200 for the general product. +-m with m < 2^24 and <= 64 terms keep a sum below
+// 2^30 r; anything else takes the general path into the lazy limb sum, as before.
 __global__ void __launch_bounds__(64 * ROWS_PS_WAVES) rows_affine_prodsum_kernel(const uint64_t *rows, size_t n_rows, uint32_t k, uint32_t stride, const uint64_t *coeff,
-                                                                                 const uint32_t *pre, const uint8_t *cols, RowsProdSumArgs a,
-                                                                                 const uint64_t *w, uint32_t G, uint32_t npairs, uint64_t *partials) {
+                                                                                 const uint32_t *pre, const uint32_t *small, const uint8_t *cols,
+                                                                                 RowsProdSumArgs a, const uint64_t *w, uint32_t G, uint32_t npairs,
+                                                                                 uint64_t *partials) {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, p = blockIdx.y * ROWS_PS_WAVES + wave;
     if (p >= npairs) return;
     Fr acc = Fr::zero();
@@ -675,18 +698,45 @@ __global__ void __launch_bounds__(64 * ROWS_PS_WAVES) rows_affine_prodsum_kernel
         for (int h = 0; h < 2; h++) {
             const uint32_t c = 2 * p + h;
             const uint32_t *pc = pre + 9 * (size_t)c * (k + 1);
+            const uint32_t *sm = small + (size_t)c * (k + 1);
             const uint8_t *cl = cols + 64 * c;
             Acc29 lazy = acc29_zero();
+            Acc9 pos = acc9_zero(), neg = acc9_zero();
+            bool any_gen = false, any_pos = false, any_neg = false;  // wave-uniform: every lane walks the same map
             const uint32_t nnz = a.nnz[c];
             for (uint32_t j = 0; j < nnz; j++) {
-                const uint32_t col = cl[j];
-                F29 y;
+                const uint32_t col = cl[j], sw = sm[col];
+                const Fr x = fe_load<FrParams>(row + 4 * col);
+                if (sw) {
+                    const uint32_t mag = sw & ROWS_SMALL_MAG;
+                    Acc9 prod;
+                    uint64_t carry = 0;
 #pragma unroll
-                for (int t = 0; t < 9; t++) y.l[t] = pc[9 * col + t];
-                acc29_add(lazy, fr29_chain_mul(fr29_in(fe_load<FrParams>(row + 4 * col)), y));
+                    for (int t = 0; t < 8; t++) {
+                        carry += (uint64_t)x.l[t] * mag;
+                        prod.l[t] = (uint32_t)carry;
+                        carry >>= 32;
+                    }
+                    prod.l[8] = (uint32_t)carry;
+                    if (sw >> 31) {
+                        acc9_add_acc(neg, prod);
+                        any_neg = true;
+                    } else {
+                        acc9_add_acc(pos, prod);
+                        any_pos = true;
+                    }
+                } else {
+                    F29 y;
+#pragma unroll
+                    for (int t = 0; t < 9; t++) y.l[t] = pc[9 * col + t];
+                    acc29_add(lazy, fr29_chain_mul(fr29_in(x), y));
+                    any_gen = true;
+                }
             }
             ab[h] = fe_load<FrParams>(coeff + 4 * ((size_t)c * (k + 1) + k));
-            if (nnz) ab[h] = fe_add(ab[h], acc29_reduce(lazy));
+            if (any_gen) ab[h] = fe_add(ab[h], acc29_reduce(lazy));
+            if (any_pos) ab[h] = fe_add(ab[h], acc9_reduce(pos));
+            if (any_neg) ab[h] = fe_sub(ab[h], acc9_reduce(neg));
         }
         if (ab[0].is_zero() || ab[1].is_zero()) continue;
         acc = fe_add(acc, fr_mul29v(fr_mul29v(ab[0], ab[1]), fe_load<FrParams>(w + 4 * (i * G + p % G))));
@@ -695,6 +745,10 @@ __global__ void __launch_bounds__(64 * ROWS_PS_WAVES) rows_affine_prodsum_kernel
     for (int d = 32; d > 0; d >>= 1) acc = fe_add(acc, fr_shfl_down(acc, d));
     if (lane == 0) fe_store(partials + 4 * ((size_t)blockIdx.x * npairs + p), acc);
 }
+// (Round 4 also tried the ROW as the outer loop — a wave owning two or four pairs walks the columns, one load per element per wave, the
+// small-coefficient sums of its four or eight maps in registers: 5.9 / 7.8 ms against 4.1 ms for the kernel above at 2^20 cycles. The
+// column loop is a chain of dependent scalar loads, a row load and up to eight carry chains per column at one or two waves per SIMD;
+// the kernel above re-reads the row through L1 / L2 but keeps eight independent waves per workgroup busy. Taken out again.)
 // out[p] = sum over the blocks' partials; one block per pair
 __global__ void __launch_bounds__(256) rows_prodsum_finish_kernel(const uint64_t *partials, uint32_t nblocks, uint32_t npairs, uint64_t *out) {
     __shared__ uint4 sh[256 * 4];
@@ -1672,14 +1726,18 @@ int zg_fr_rows_affine_prodsum_dev(const uint64_t *d_rows, size_t n_rows, size_t 
     const size_t n_coeff = nout * (k + 1);
     unsigned nb = div_up(n_rows, 64);
     if (nb > 1024) nb = 1024;
-    Scratch s_coeff(n_coeff * 32), s_pre(n_coeff * 36), s_cols(64 * nout), s_part((size_t)nb * npairs * 32), s_out(npairs * 32);
-    if (!s_coeff.p || !s_pre.p || !s_cols.p || !s_part.p || !s_out.p) return ZG_ERR_NOMEM;
+    Scratch s_coeff(n_coeff * 32), s_pre(n_coeff * 36), s_small(n_coeff * 4), s_cols(64 * nout), s_part((size_t)nb * npairs * 32), s_out(npairs * 32);
+    if (!s_coeff.p || !s_pre.p || !s_small.p || !s_cols.p || !s_part.p || !s_out.p) return ZG_ERR_NOMEM;
     SyncGuard sync(st);
     ZG_HIP(hipMemcpyAsync(s_coeff.p, coeffs, n_coeff * 32, hipMemcpyHostToDevice, st));
     ZG_HIP(hipMemcpyAsync(s_cols.p, cols.data(), cols.size(), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(rows_affine_prep_kernel, dim3(div_up(n_coeff, 256)), dim3(256), 0, st, s_coeff.as<uint64_t>(), (uint32_t)n_coeff, s_pre.as<uint32_t>());
+    const bool small_ok = env_uint("ZG_ROWS_SMALL_COEFF", 1, 0, 1) != 0;  // 0: every term through the general product (A/B, tests); read per call
+    hipLaunchKernelGGL(rows_affine_prep_kernel, dim3(div_up(n_coeff, 256)), dim3(256), 0, st, s_coeff.as<uint64_t>(), (uint32_t)n_coeff, s_pre.as<uint32_t>(),
+                       s_small.as<uint32_t>());
+    if (!small_ok) ZG_HIP(hipMemsetAsync(s_small.p, 0, n_coeff * 4, st));
     hipLaunchKernelGGL(rows_affine_prodsum_kernel, dim3(nb, div_up(npairs, ROWS_PS_WAVES)), dim3(64 * ROWS_PS_WAVES), 0, st, d_rows, n_rows, (uint32_t)k,
-                       (uint32_t)stride, s_coeff.as<uint64_t>(), s_pre.as<uint32_t>(), s_cols.as<uint8_t>(), a, d_weights, (uint32_t)g, (uint32_t)npairs, s_part.as<uint64_t>());
+                       (uint32_t)stride, s_coeff.as<uint64_t>(), s_pre.as<uint32_t>(), s_small.as<uint32_t>(), s_cols.as<uint8_t>(), a, d_weights, (uint32_t)g,
+                       (uint32_t)npairs, s_part.as<uint64_t>());
     hipLaunchKernelGGL(rows_prodsum_finish_kernel, dim3((unsigned)npairs), dim3(256), 0, st, s_part.as<uint64_t>(), nb, (uint32_t)npairs, s_out.as<uint64_t>());
     ZG_HIP(hipGetLastError());
     ZG_HIP(hipMemcpyAsync(out, s_out.p, npairs * 32, hipMemcpyDeviceToHost, st));
