@@ -195,14 +195,16 @@ def test_stage1_of_the_captured_run_on_the_device(api, golden_dir):
         p.deinit()
 
 
-@pytest.mark.parametrize("small_path", ["1", "0"])
-def test_affine_product_sums_with_small_and_general_coefficients(api, small_path, monkeypatch):
+@pytest.mark.parametrize("small_path,stage", [("1", "1"), ("1", "0"), ("0", "1")])
+def test_affine_product_sums_with_small_and_general_coefficients(api, small_path, stage, monkeypatch):
     """zg_fr_rows_affine_prodsum_dev term by term against Python integers: coefficients that are small integers (+-m, m < 2^24: an
     8 x 1-limb product summed as a 288-bit integer, one reduction per map), the values on either side of that bound, full-width ones
     (the general product), all in one map; 64 terms of the largest small magnitude on rows of r - 1 (the bound of the integer sum); a
-    zero constant and a full-width constant. ZG_ROWS_SMALL_COEFF=0 sends every term through the general product: same bytes."""
+    zero constant and a full-width constant. ZG_ROWS_SMALL_COEFF=0 sends every term through the general product, ZG_ROWS_STAGE=0 reads
+    the rows from memory per term instead of from the workgroup's tile in LDS: same bytes."""
     from zolt_amd import lib
     monkeypatch.setenv("ZG_ROWS_SMALL_COEFF", small_path)
+    monkeypatch.setenv("ZG_ROWS_STAGE", stage)
     P = ob._R_P
     rng = np.random.default_rng(5)
     k, n_rows, npairs, g = 70, 300, 7, 2  # seven pairs: a full group of four and a short one
@@ -242,4 +244,4 @@ def test_affine_product_sums_with_small_and_general_coefficients(api, small_path
             av = (a[k] + sum(a[c] * rows_int[i][c] for c in range(k))) % P
             bv = (b[k] + sum(b[c] * rows_int[i][c] for c in range(k))) % P
             tot += w_int[i * g + p % g] * av * bv
-        assert ob.fr_to_int(got[p]) == tot % P, (p, small_path)
+        assert ob.fr_to_int(got[p]) == tot % P, (p, small_path, stage)

@@ -684,14 +684,33 @@ struct RowsProdSumArgs {
 // carries (an integer combination of Montgomery forms is the Montgomery form of the combination) and reduced once per map by
 // acc9_reduce: ~25 instructions per term instead of ~200 for the general product. +-m with m < 2^24 and <= 64 terms keep a sum below
 // 2^30 r; anything else takes the general path into the lazy limb sum, as before.
+// STAGED: the workgroup's tile of 64 rows is copied to LDS once (column-major, a column every 65 elements: the transposing writes of
+// consecutive lanes fall on different banks) and all its waves' maps read the elements from there — without it every map re-reads its
+// ~25 elements of a row through L1 / L2, 40 GB at 2^20 cycles for 1.4 GB of witness, which bound the kernel once the terms were cheap.
+constexpr uint32_t ROWS_TILE_COL = 65 * 2;  // uint4 units per staged column (64 rows x 32 bytes + one element of padding)
+template <bool STAGED>
 __global__ void __launch_bounds__(64 * ROWS_PS_WAVES) rows_affine_prodsum_kernel(const uint64_t *rows, size_t n_rows, uint32_t k, uint32_t stride, const uint64_t *coeff,
                                                                                  const uint32_t *pre, const uint32_t *small, const uint8_t *cols,
                                                                                  RowsProdSumArgs a, const uint64_t *w, uint32_t G, uint32_t npairs,
                                                                                  uint64_t *partials) {
+    extern __shared__ uint4 tile[];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, p = blockIdx.y * ROWS_PS_WAVES + wave;
-    if (p >= npairs) return;
+    if (!STAGED && p >= npairs) return;  // (a staged workgroup keeps every wave for the copy and the barriers)
     Fr acc = Fr::zero();
-    for (size_t i = (size_t)blockIdx.x * 64 + lane; i < n_rows; i += (size_t)gridDim.x * 64) {
+    for (size_t i0 = (size_t)blockIdx.x * 64; i0 < n_rows; i0 += (size_t)gridDim.x * 64) {
+        const size_t i = i0 + lane;
+        if (STAGED) {
+            __syncthreads();  // the previous tile has been read
+            const uint32_t live = n_rows - i0 < 64 ? (uint32_t)(n_rows - i0) : 64u;
+            for (uint32_t e = threadIdx.x; e < live * k; e += 64 * ROWS_PS_WAVES) {
+                const uint32_t r = e / k, c = e - r * k;
+                const uint4 *src = reinterpret_cast<const uint4 *>(rows + 4 * ((i0 + r) * stride + c));
+                tile[c * ROWS_TILE_COL + 2 * r] = src[0];
+                tile[c * ROWS_TILE_COL + 2 * r + 1] = src[1];
+            }
+            __syncthreads();
+        }
+        if (p >= npairs || i >= n_rows) continue;
         const uint64_t *row = rows + 4 * i * stride;
         Fr ab[2];
 #pragma unroll
@@ -706,7 +725,14 @@ __global__ void __launch_bounds__(64 * ROWS_PS_WAVES) rows_affine_prodsum_kernel
             const uint32_t nnz = a.nnz[c];
             for (uint32_t j = 0; j < nnz; j++) {
                 const uint32_t col = cl[j], sw = sm[col];
-                const Fr x = fe_load<FrParams>(row + 4 * col);
+                Fr x;
+                if (STAGED) {
+                    const uint4 lo = tile[col * ROWS_TILE_COL + 2 * lane], hi = tile[col * ROWS_TILE_COL + 2 * lane + 1];
+                    x.l[0] = lo.x; x.l[1] = lo.y; x.l[2] = lo.z; x.l[3] = lo.w;
+                    x.l[4] = hi.x; x.l[5] = hi.y; x.l[6] = hi.z; x.l[7] = hi.w;
+                } else {
+                    x = fe_load<FrParams>(row + 4 * col);
+                }
                 if (sw) {
                     const uint32_t mag = sw & ROWS_SMALL_MAG;
                     Acc9 prod;
@@ -741,6 +767,7 @@ __global__ void __launch_bounds__(64 * ROWS_PS_WAVES) rows_affine_prodsum_kernel
         if (ab[0].is_zero() || ab[1].is_zero()) continue;
         acc = fe_add(acc, fr_mul29v(fr_mul29v(ab[0], ab[1]), fe_load<FrParams>(w + 4 * (i * G + p % G))));
     }
+    if (p >= npairs) return;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) acc = fe_add(acc, fr_shfl_down(acc, d));
     if (lane == 0) fe_store(partials + 4 * ((size_t)blockIdx.x * npairs + p), acc);
@@ -1735,9 +1762,21 @@ int zg_fr_rows_affine_prodsum_dev(const uint64_t *d_rows, size_t n_rows, size_t 
     hipLaunchKernelGGL(rows_affine_prep_kernel, dim3(div_up(n_coeff, 256)), dim3(256), 0, st, s_coeff.as<uint64_t>(), (uint32_t)n_coeff, s_pre.as<uint32_t>(),
                        s_small.as<uint32_t>());
     if (!small_ok) ZG_HIP(hipMemsetAsync(s_small.p, 0, n_coeff * 4, st));
-    hipLaunchKernelGGL(rows_affine_prodsum_kernel, dim3(nb, div_up(npairs, ROWS_PS_WAVES)), dim3(64 * ROWS_PS_WAVES), 0, st, d_rows, n_rows, (uint32_t)k,
-                       (uint32_t)stride, s_coeff.as<uint64_t>(), s_pre.as<uint32_t>(), s_small.as<uint32_t>(), s_cols.as<uint8_t>(), a, d_weights, (uint32_t)g,
-                       (uint32_t)npairs, s_part.as<uint64_t>());
+    // the row tile in LDS when it fits (k <= 73 columns: the R1CS witness has 43); ZG_ROWS_STAGE=0 reads the rows from memory per term
+    const size_t tile_bytes = (size_t)k * ROWS_TILE_COL * 16;
+    if (tile_bytes <= 150 * 1024 && env_uint("ZG_ROWS_STAGE", 1, 0, 1)) {
+        static PerDeviceOnce once;
+        ZG_HIP(once.run([] {
+            return hipFuncSetAttribute(reinterpret_cast<const void *>(rows_affine_prodsum_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        }));
+        hipLaunchKernelGGL(rows_affine_prodsum_kernel<true>, dim3(nb, div_up(npairs, ROWS_PS_WAVES)), dim3(64 * ROWS_PS_WAVES), tile_bytes, st, d_rows, n_rows,
+                           (uint32_t)k, (uint32_t)stride, s_coeff.as<uint64_t>(), s_pre.as<uint32_t>(), s_small.as<uint32_t>(), s_cols.as<uint8_t>(), a, d_weights,
+                           (uint32_t)g, (uint32_t)npairs, s_part.as<uint64_t>());
+    } else {
+        hipLaunchKernelGGL(rows_affine_prodsum_kernel<false>, dim3(nb, div_up(npairs, ROWS_PS_WAVES)), dim3(64 * ROWS_PS_WAVES), 0, st, d_rows, n_rows,
+                           (uint32_t)k, (uint32_t)stride, s_coeff.as<uint64_t>(), s_pre.as<uint32_t>(), s_small.as<uint32_t>(), s_cols.as<uint8_t>(), a, d_weights,
+                           (uint32_t)g, (uint32_t)npairs, s_part.as<uint64_t>());
+    }
     hipLaunchKernelGGL(rows_prodsum_finish_kernel, dim3((unsigned)npairs), dim3(256), 0, st, s_part.as<uint64_t>(), nb, (uint32_t)npairs, s_out.as<uint64_t>());
     ZG_HIP(hipGetLastError());
     ZG_HIP(hipMemcpyAsync(out, s_out.p, npairs * 32, hipMemcpyDeviceToHost, st));
