@@ -688,21 +688,26 @@ struct RowsProdSumArgs {
 // consecutive lanes fall on different banks) and all its waves' maps read the elements from there — without it every map re-reads its
 // ~25 elements of a row through L1 / L2, 40 GB at 2^20 cycles for 1.4 GB of witness, which bound the kernel once the terms were cheap.
 constexpr uint32_t ROWS_TILE_COL = 65 * 2;  // uint4 units per staged column (64 rows x 32 bytes + one element of padding)
+// A staged workgroup serves ALL pairs of its tile — wave w takes pairs w, w + waves, ... (gridDim.y = 1, up to ROWS_PS_STAGED_WAVES
+// waves): the tile is copied once per 64 rows instead of once per eight pairs, and no wave idles beside a copy made for two pairs.
+constexpr unsigned ROWS_PS_STAGED_WAVES = 10;
 template <bool STAGED>
-__global__ void __launch_bounds__(64 * ROWS_PS_WAVES) rows_affine_prodsum_kernel(const uint64_t *rows, size_t n_rows, uint32_t k, uint32_t stride, const uint64_t *coeff,
+__global__ void __launch_bounds__(64 * (STAGED ? ROWS_PS_STAGED_WAVES : ROWS_PS_WAVES)) rows_affine_prodsum_kernel(const uint64_t *rows, size_t n_rows, uint32_t k, uint32_t stride, const uint64_t *coeff,
                                                                                  const uint32_t *pre, const uint32_t *small, const uint8_t *cols,
                                                                                  RowsProdSumArgs a, const uint64_t *w, uint32_t G, uint32_t npairs,
                                                                                  uint64_t *partials) {
     extern __shared__ uint4 tile[];
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, p = blockIdx.y * ROWS_PS_WAVES + wave;
-    if (!STAGED && p >= npairs) return;  // (a staged workgroup keeps every wave for the copy and the barriers)
-    Fr acc = Fr::zero();
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6, p_first = STAGED ? wave : blockIdx.y * ROWS_PS_WAVES + wave;
+    if (!STAGED && p_first >= npairs) return;  // (a staged workgroup keeps every wave for the copy and the barriers)
+    Fr accs[4];  // a wave's pairs: at most four (32 pairs over eight waves)
+#pragma unroll
+    for (int q = 0; q < 4; q++) accs[q] = Fr::zero();
     for (size_t i0 = (size_t)blockIdx.x * 64; i0 < n_rows; i0 += (size_t)gridDim.x * 64) {
         const size_t i = i0 + lane;
         if (STAGED) {
             __syncthreads();  // the previous tile has been read
             const uint32_t live = n_rows - i0 < 64 ? (uint32_t)(n_rows - i0) : 64u;
-            for (uint32_t e = threadIdx.x; e < live * k; e += 64 * ROWS_PS_WAVES) {
+            for (uint32_t e = threadIdx.x; e < live * k; e += blockDim.x) {
                 const uint32_t r = e / k, c = e - r * k;
                 const uint4 *src = reinterpret_cast<const uint4 *>(rows + 4 * ((i0 + r) * stride + c));
                 tile[c * ROWS_TILE_COL + 2 * r] = src[0];
@@ -710,8 +715,11 @@ __global__ void __launch_bounds__(64 * ROWS_PS_WAVES) rows_affine_prodsum_kernel
             }
             __syncthreads();
         }
-        if (p >= npairs || i >= n_rows) continue;
+        if (i >= n_rows) continue;
         const uint64_t *row = rows + 4 * i * stride;
+        for (int q = 0; q < 4; q++) {  // (rolled: the four running sums live in scratch, two accesses per pair and row)
+        const uint32_t p = p_first + (uint32_t)q * (STAGED ? nw : 0u);
+        if ((q && !STAGED) || p >= npairs) continue;
         Fr ab[2];
 #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -765,12 +773,17 @@ __global__ void __launch_bounds__(64 * ROWS_PS_WAVES) rows_affine_prodsum_kernel
             if (any_neg) ab[h] = fe_sub(ab[h], acc9_reduce(neg));
         }
         if (ab[0].is_zero() || ab[1].is_zero()) continue;
-        acc = fe_add(acc, fr_mul29v(fr_mul29v(ab[0], ab[1]), fe_load<FrParams>(w + 4 * (i * G + p % G))));
+        accs[q] = fe_add(accs[q], fr_mul29v(fr_mul29v(ab[0], ab[1]), fe_load<FrParams>(w + 4 * (i * G + p % G))));
+        }
     }
-    if (p >= npairs) return;
+    for (int q = 0; q < 4; q++) {
+        const uint32_t p = p_first + (uint32_t)q * (STAGED ? nw : 0u);
+        if ((q && !STAGED) || p >= npairs) continue;
+        Fr acc = accs[q];
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) acc = fe_add(acc, fr_shfl_down(acc, d));
-    if (lane == 0) fe_store(partials + 4 * ((size_t)blockIdx.x * npairs + p), acc);
+        for (int d = 32; d > 0; d >>= 1) acc = fe_add(acc, fr_shfl_down(acc, d));
+        if (lane == 0) fe_store(partials + 4 * ((size_t)blockIdx.x * npairs + p), acc);
+    }
 }
 // (Round 4 also tried the ROW as the outer loop — a wave owning two or four pairs walks the columns, one load per element per wave, the
 // small-coefficient sums of its four or eight maps in registers: 5.9 / 7.8 ms against 4.1 ms for the kernel above at 2^20 cycles. The
@@ -1769,7 +1782,8 @@ int zg_fr_rows_affine_prodsum_dev(const uint64_t *d_rows, size_t n_rows, size_t 
         ZG_HIP(once.run([] {
             return hipFuncSetAttribute(reinterpret_cast<const void *>(rows_affine_prodsum_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         }));
-        hipLaunchKernelGGL(rows_affine_prodsum_kernel<true>, dim3(nb, div_up(npairs, ROWS_PS_WAVES)), dim3(64 * ROWS_PS_WAVES), tile_bytes, st, d_rows, n_rows,
+        const unsigned per_wave = div_up(npairs, ROWS_PS_STAGED_WAVES), waves = div_up(npairs, per_wave);  // 18 pairs: nine waves of two
+        hipLaunchKernelGGL(rows_affine_prodsum_kernel<true>, dim3(nb), dim3(64 * waves), tile_bytes, st, d_rows, n_rows,
                            (uint32_t)k, (uint32_t)stride, s_coeff.as<uint64_t>(), s_pre.as<uint32_t>(), s_small.as<uint32_t>(), s_cols.as<uint8_t>(), a, d_weights,
                            (uint32_t)g, (uint32_t)npairs, s_part.as<uint64_t>());
     } else {
