@@ -80,7 +80,10 @@ ZG_API const char *zg_version(void);
 ZG_API int zg_device_count(void);
 
 /* raw device memory, for hosts without their own HIP binding (the Zig shim). The two copies run on the library's stream and return when
- * they are done: ordered after every earlier call that was given stream = NULL (e.g. the asynchronous zg_fr_eq_table_dev). */
+ * they are done: ordered after every earlier call that was given stream = NULL (e.g. the asynchronous zg_fr_eq_table_dev).
+ * zg_dev_free returns when the device is idle (hipFree's own guarantee) and keeps blocks of up to 512 MiB for the next zg_dev_alloc of
+ * their size class (at most 2 GiB in all, ZG_DEV_ALLOC_CACHE_MB; zg_shutdown releases them): a prover that allocates its tables per
+ * proof does not pay hipMalloc / hipFree each time. */
 ZG_API int zg_dev_alloc(size_t bytes, void **dptr);
 ZG_API int zg_dev_free(void *dptr);
 ZG_API int zg_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
