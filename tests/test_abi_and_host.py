@@ -318,3 +318,15 @@ def test_bench_self_launch_without_gpu_fails_fast_and_loudly():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True, timeout=300)
     assert res.returncode != 0
     assert res.stderr.count("bench.py needs a GPU") == 2 and "{" not in res.stdout
+
+
+def test_design_kernel_table_is_the_generated_one():
+    """DESIGN.md section 4.0 carries the table tools/kernel_table.py generates from the committed rocprofv3 summaries: regenerated here and
+    compared, so the figures in the document are the ones under profiles/ (and nobody edits the table by hand)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_table.py"), "r4final"], capture_output=True, text=True, check=True).stdout.strip()
+    assert out == open(os.path.join(root, "profiles", "r4final_kernel_table.md")).read().strip()
+    design = open(os.path.join(root, "DESIGN.md")).read()
+    assert out in design
