@@ -1443,7 +1443,10 @@ static uint32_t chunk_threads(uint64_t digits, bool alone = false) {
     // full grid (+4-6 % MSM/s); round 4 swept the count (tools/exp/run_nt_sweep.sh, profiles/r4h_accumulate_slots_sweep.txt, three
     // streams at 2^20): 512 / 496 / 480 / 464 / 448 / 440 / 432 / 416 / 384 workgroups = 793 / 790 / 800 / 790 / 816 / 810 / 800 /
     // 809 / 792 MSM/s — 448 held +2 % over 480 in three separate runs.
-    static const uint32_t inflight = (uint32_t)env_int("ZG_MSM_INFLIGHT_CHUNKS", 114688);
+    static const uint32_t inflight = [] {
+        int v = env_int("ZG_MSM_INFLIGHT_CHUNKS", 114688);
+        return (uint32_t)(v < 1024 ? 1024 : (v > 131072 ? 131072 : v));
+    }();
     return nt == 131072u && !alone ? inflight : nt;
 }
 
