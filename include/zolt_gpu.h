@@ -64,6 +64,25 @@ extern "C" {
 #define ZG_OP_TO_MONT 7    /* fromBytes' reduction :171-184 / :625-639: raw 256-bit LE -> Montgomery (b ignored) */
 /* op codes 9..13 are self-test hooks for the device arithmetic: include/zolt_gpu_internal.h */
 
+/* ------------------------------------------------------------------ ABI version and sections
+ * MAJOR changes when an existing signature or layout changes, MINOR when entry points are added. A host binds against the header it was
+ * built with and checks zg_abi_version() >> 16 == ZG_ABI_MAJOR (and the minor it needs) after loading the library.
+ *
+ * Sections of this header:
+ *   CORE      lifecycle, device memory, field vectors, G1 bases / MSM / HyperKZG, poly tables, sumcheck sessions, product-form
+ *             sessions, several GPUs in one process — the path BASELINE.json's north_star names.
+ *   OPTIONAL  protocol-specific device sessions for two of the reference's stage provers (zg_rrw_*: RegistersReadWriteChecking,
+ *             zg_rwc_*: RamReadWriteChecking). A host that only re-points MSM / poly / sumcheck call sites never touches them:
+ *             compile with -DZG_NO_PROTOCOL_SESSIONS to leave them out of the binding; zg_abi_features() reports whether the loaded
+ *             library carries them. */
+#define ZG_ABI_MAJOR 1
+#define ZG_ABI_MINOR 5
+#define ZG_FEATURE_PROTOCOL_SESSIONS 1u /* zg_rrw_* and zg_rwc_* are exported */
+#define ZG_FEATURE_RCCL 2u              /* the several-GPU entry points can exchange partials over RCCL */
+#define ZG_FEATURE_COLUMN_INGEST 4u     /* zg_fr_rows_from_columns[_dev] */
+ZG_API uint32_t zg_abi_version(void);  /* (ZG_ABI_MAJOR << 16) | ZG_ABI_MINOR of the library that was loaded */
+ZG_API uint32_t zg_abi_features(void); /* ZG_FEATURE_* bits */
+
 /* ------------------------------------------------------------------ lifecycle */
 /* Binds the calling process to one GPU (device < 0: keep the current HIP device) and
  * creates the library stream. Idempotent. */
@@ -81,11 +100,14 @@ ZG_API int zg_device_count(void);
 
 /* raw device memory, for hosts without their own HIP binding (the Zig shim). The two copies run on the library's stream and return when
  * they are done: ordered after every earlier call that was given stream = NULL (e.g. the asynchronous zg_fr_eq_table_dev).
- * zg_dev_free returns when the device is idle (hipFree's own guarantee) and keeps blocks of up to 512 MiB for the next zg_dev_alloc of
- * their size class (at most 2 GiB in all, ZG_DEV_ALLOC_CACHE_MB; zg_shutdown releases them): a prover that allocates its tables per
- * proof does not pay hipMalloc / hipFree each time. */
+ * zg_dev_free returns when the device is idle (hipFree's own guarantee) and keeps the block in the library's device pool for the next
+ * allocation of its size class — by zg_dev_alloc or by the library itself (scratch buffers, session tables): a prover that allocates
+ * its tables per proof does not pay hipMalloc / hipFree each time, whatever their size. The pool keeps up to a quarter of the device's
+ * memory (ZG_DEV_ALLOC_CACHE_MB overrides; 0 = no caching); an allocation that fails returns the idle blocks to the driver and tries
+ * again; zg_dev_trim does so on request, zg_shutdown at the end. */
 ZG_API int zg_dev_alloc(size_t bytes, void **dptr);
 ZG_API int zg_dev_free(void *dptr);
+ZG_API int zg_dev_trim(void);
 ZG_API int zg_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
 ZG_API int zg_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
 ZG_API int zg_sync(void);
@@ -104,8 +126,10 @@ typedef struct zg_bases_s *zg_bases_t;
 /* MSM tuning. window_bits 0 = auto from n; precompute_levels: 1 = none, 0 = auto,
  * k>1 = store 2^(c*G*l)*P for l<k at upload so k windows share one bucket set
  * (HBM cost k*64 B per base). expected_uses: how many MSMs the handle is expected to serve — 0 = many (an SRS that lives for
- * the whole run: the full table, 64*W bytes per base and a one-time build, pays back after ~20 MSMs); 1..15 = an ad-hoc
- * bases slice (MSM.compute on a temporary): auto picks precompute_levels = 1, no table build. Results do not depend on these. */
+ * the whole run: the full table, 64*W bytes per base and a one-time build — 1 GB and ~20 ms at 2^20 bases, 4 GB and ~74 ms at 2^22 —
+ * which pays back after ~15 MSMs issued one at a time, ~45 when several are kept in flight: bench.py reports table_build_ms,
+ * table_bytes and breakeven_msms in its config); 1..15 = an ad-hoc bases slice (MSM.compute on a temporary): auto picks
+ * precompute_levels = 1, no table build. Results do not depend on these. */
 typedef struct {
     int window_bits;
     int precompute_levels;
@@ -125,6 +149,8 @@ ZG_API size_t zg_g1_bases_len(zg_bases_t b);
 /* the plan the handle was built with: window bits c (optimalWindowSize's role, src/msm/mod.zig:475-484, chosen for the GPU),
  * windows per scalar ceil(255 / c), table levels stored per base. Any pointer may be NULL. */
 ZG_API int zg_g1_bases_plan(zg_bases_t b, int *window_bits, int *windows, int *precompute_levels);
+/* bytes of HBM the handle holds for its bases: the table of precomputed multiples (levels * 64 B per base) or the plain bases */
+ZG_API size_t zg_g1_bases_table_bytes(zg_bases_t b);
 
 /* ------------------------------------------------------------------ MSM */
 /* MSM(F,G).compute(bases[off..off+n], scalars) -> Affine   (src/msm/mod.zig:355-438)
@@ -435,6 +461,8 @@ ZG_API int zg_psc_gather(zg_psc_t s, size_t table, const uint64_t *idx, size_t n
 ZG_API int zg_psc_final(zg_psc_t s, uint64_t *out /* k*4: each table's single remaining entry */);
 ZG_API int zg_psc_close(zg_psc_t s);
 
+/* ================================================================== OPTIONAL section: protocol-specific sessions */
+#ifndef ZG_NO_PROTOCOL_SESSIONS
 /* ------------------------------------------------------------------ registers read/write checking (Stage 4) */
 /* Stage4GruenProver (src/zkvm/spartan/stage4_gruen_prover.zig:65-1240) and the original Stage4Prover (stage4_prover.zig:74-865: the same
  * tables, every cycle variable first under a dense eq table set at the start, all four evaluations computed directly), the
@@ -520,6 +548,9 @@ ZG_API int zg_rwc_cycle_scalars(zg_rwc_t s, uint64_t eq0[4], uint64_t inc0[4]);
 /* the current list (any pointer may be NULL); the coefficient columns come from the device */
 ZG_API int zg_rwc_read_entries(zg_rwc_t s, uint32_t *cycle, uint32_t *address, uint64_t *ra_coeff, uint64_t *val_coeff, uint64_t *prev_val, uint64_t *next_val);
 ZG_API int zg_rwc_close(zg_rwc_t s);
+
+#endif /* ZG_NO_PROTOCOL_SESSIONS */
+/* ================================================================== end of the OPTIONAL section */
 
 /* ------------------------------------------------------------------ several GPUs in one process */
 /* The bases (SRS) sharded over the bound devices in ParallelMSM's contiguous chunks of ceil(n / S) points

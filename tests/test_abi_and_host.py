@@ -34,6 +34,40 @@ def test_header_symbols_all_exported():
         assert name not in pub, name
 
 
+def test_bindings_are_generated_from_the_header():
+    """zolt_amd/_abi.py (ctypes signatures of every entry point) and zig/gpu/ffi.zig are both written by tools/gen_bindings.py from the
+    header; neither is maintained by hand. The loaded library reports the ABI version of the header the binding was generated from."""
+    assert subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_bindings.py"), "--check"]).returncode == 0
+    from zolt_amd import _abi, lib
+    hdr = open(os.path.join(ROOT, "include", "zolt_gpu.h")).read()
+    protos = {m.group(1): _split_params(m.group(2)) for m in re.finditer(r"ZG_API[^;(]*?\b(zg_\w+)\s*\(([^;]*?)\)\s*;", hdr, flags=re.S)}
+    assert sorted(_abi.PROTOS) == sorted(protos)
+    for name, (ret, args) in _abi.PROTOS.items():
+        assert len(args) == len(protos[name]), name
+        fn = getattr(lib._lib, name)
+        assert fn.argtypes == args and fn.restype == ret, name
+    assert lib.abi_version() == (_abi.ZG_ABI_MAJOR, _abi.ZG_ABI_MINOR)
+    assert lib.abi_features() & _abi.ZG_FEATURE_PROTOCOL_SESSIONS
+    # the optional section really is optional: the header parses without it and loses exactly the two protocol-specific families
+    core = subprocess.run(["gcc", "-E", "-DZG_NO_PROTOCOL_SESSIONS", os.path.join(ROOT, "include", "zolt_gpu.h")], capture_output=True, text=True, check=True).stdout
+    core_syms = set(re.findall(r"\b(zg_\w+)\s*\(", core))
+    dropped = set(protos) - core_syms
+    assert dropped and all(n.startswith(("zg_rrw_", "zg_rwc_")) for n in dropped)
+    assert not any(n.startswith(("zg_rrw_", "zg_rwc_")) for n in core_syms)
+
+
+def test_zig_ffi_declares_every_type_it_names():
+    """A static stand-in for the compiler this image lacks: every type name an extern of zig/gpu/ffi.zig uses is declared in the file
+    (round 5 found `RegistersSession` / `RamRwSession` used by 24 externs and declared nowhere)."""
+    zig = open(os.path.join(ROOT, "zig", "gpu", "ffi.zig")).read()
+    declared = set(re.findall(r"^pub const (\w+) =", zig, flags=re.M))
+    builtin = {"c_int", "c_uint", "usize", "u64", "u32", "u8", "f64", "anyopaque", "void", "const"}
+    for name, args, ret in re.findall(r"pub extern fn (zg_\w+)\((.*?)\) ([\w\[\]:*?. ]+);", zig):
+        for ty in re.findall(r":\s*([^,]+)", args) + [ret]:
+            for ident in re.findall(r"[A-Za-z_]\w*", ty):
+                assert ident in builtin or ident in declared, (name, ident)
+
+
 def _split_params(arglist):
     """top-level comma split of a C / Zig parameter list (no nested parentheses in either header)"""
     arglist = re.sub(r"/\*.*?\*/", "", arglist, flags=re.S).strip()

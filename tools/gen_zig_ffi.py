@@ -73,7 +73,7 @@ def parse_header(text):
             am = re.match(r"^(.*?)(\w+)\s*((?:\[\w*\])?)$", a)
             ctype, pname, arr = am.group(1).strip(), am.group(2), am.group(3)
             params.append((pname, zig_type(ctype, arr)))
-        zret = {"int": "c_int", "void": "void", "size_t": "usize", "const char *": "[*:0]const u8"}[ret]
+        zret = {"int": "c_int", "void": "void", "size_t": "usize", "uint32_t": "u32", "const char *": "[*:0]const u8"}[ret]
         protos.append((name, params, zret))
     return protos
 
@@ -81,7 +81,7 @@ def parse_header(text):
 def generate():
     text = open(HDR).read()
     protos = parse_header(text)
-    consts = re.findall(r"#define (ZG_(?:OK|ERR_\w+|FIELD_\w+|OP_\w+|SC_\w+|PSC_\w+)) (\d+)", text)
+    consts = re.findall(r"#define (ZG_(?:OK|ERR_\w+|FIELD_\w+|OP_\w+|SC_\w+|PSC_\w+|ABI_\w+|FEATURE_\w+|COL_\w+)) (\d+)u?\b", text)
     out = [
         "//! extern declarations of libzolt_gpu.so, for Zolt's src/gpu/ffi.zig.",
         "//! GENERATED from include/zolt_gpu.h by tools/gen_zig_ffi.py — do not edit; tests/test_abi_and_host.py holds the two together.",
@@ -91,18 +91,14 @@ def generate():
         "//! Field elements cross the boundary as they are: BN254Scalar / BN254BaseField are `struct { limbs: [4]u64 }`",
         "//! (src/field/mod.zig:131,583-584), Montgomery form, so `[]const F` is passed as `[*]const u64` via @ptrCast.",
         "",
-        "pub const Bases = ?*opaque {}; // zg_bases_t",
-        "pub const Session = ?*opaque {}; // zg_sc_t",
-        "pub const ShardedBases = ?*opaque {}; // zg_sbases_t",
-        "pub const ShardedSession = ?*opaque {}; // zg_ssc_t",
-        "pub const ProductSession = ?*opaque {}; // zg_psc_t",
+    ] + [f"pub const {zname} = ?*opaque {{}}; // {cname}" for cname, zname in HANDLES.items()] + [  # every handle type the externs below name
         "",
         "pub const MsmConfig = extern struct { window_bits: c_int = 0, precompute_levels: c_int = 0, expected_uses: c_int = 0 };",
         "pub const PscTerm = extern struct { n_prod: c_int = 0, prod: [4]c_int = .{ 0, 0, 0, 0 }, n_lin: c_int = 0, lin: [4]c_int = .{ 0, 0, 0, 0 }, lin_coeff: [16]u64 = .{0} ** 16 }; // zg_psc_term",
         "",
     ]
     for name, val in consts:
-        out.append(f"pub const {name[3:]}: c_int = {val};")
+        out.append(f"pub const {name[3:]}: {'u32' if name.startswith(('ZG_ABI_', 'ZG_FEATURE_', 'ZG_COL_')) else 'c_int'} = {val};")
     out.append("")
     for name, params, zret in protos:
         ps = ", ".join(f"{p}: {t}" for p, t in params)

@@ -54,6 +54,8 @@ fn initDevice() void {
     if (std.posix.getenv("ZOLT_GPU")) |v| {
         if (v.len > 0 and v[0] == '0') return;
     }
+    // a library built from another major version of the header is not this binding's library: keep the Zig bodies
+    if ((ffi.zg_abi_version() >> 16) != ffi.ABI_MAJOR) return;
     if (std.posix.getenv("ZOLT_GPU_DEVICES")) |v| {
         const n: c_int = if (std.mem.eql(u8, v, "all")) 0 else (std.fmt.parseInt(c_int, v, 10) catch 1);
         available = ffi.zg_init_devices(n) == ffi.OK;

@@ -11,6 +11,8 @@ pub const Session = ?*opaque {}; // zg_sc_t
 pub const ShardedBases = ?*opaque {}; // zg_sbases_t
 pub const ShardedSession = ?*opaque {}; // zg_ssc_t
 pub const ProductSession = ?*opaque {}; // zg_psc_t
+pub const RegistersSession = ?*opaque {}; // zg_rrw_t
+pub const RamRwSession = ?*opaque {}; // zg_rwc_t
 
 pub const MsmConfig = extern struct { window_bits: c_int = 0, precompute_levels: c_int = 0, expected_uses: c_int = 0 };
 pub const PscTerm = extern struct { n_prod: c_int = 0, prod: [4]c_int = .{ 0, 0, 0, 0 }, n_lin: c_int = 0, lin: [4]c_int = .{ 0, 0, 0, 0 }, lin_coeff: [16]u64 = .{0} ** 16 }; // zg_psc_term
@@ -31,10 +33,17 @@ pub const OP_SQR: c_int = 4;
 pub const OP_INV: c_int = 5;
 pub const OP_FROM_MONT: c_int = 6;
 pub const OP_TO_MONT: c_int = 7;
+pub const ABI_MAJOR: u32 = 1;
+pub const ABI_MINOR: u32 = 5;
+pub const FEATURE_PROTOCOL_SESSIONS: u32 = 1;
+pub const FEATURE_RCCL: u32 = 2;
+pub const FEATURE_COLUMN_INGEST: u32 = 4;
 pub const SC_HIGH_HALF: c_int = 0;
 pub const SC_LOW_PAIR: c_int = 1;
 pub const PSC_PAIR_SUM: c_int = 256;
 
+pub extern fn zg_abi_version() u32;
+pub extern fn zg_abi_features() u32;
 pub extern fn zg_init(device: c_int) c_int;
 pub extern fn zg_init_devices(n_devices: c_int) c_int;
 pub extern fn zg_n_devices() c_int;
@@ -44,6 +53,7 @@ pub extern fn zg_version() [*:0]const u8;
 pub extern fn zg_device_count() c_int;
 pub extern fn zg_dev_alloc(bytes: usize, dptr: *?*anyopaque) c_int;
 pub extern fn zg_dev_free(dptr: ?*anyopaque) c_int;
+pub extern fn zg_dev_trim() c_int;
 pub extern fn zg_memcpy_h2d(dst_dev: ?*anyopaque, src_host: ?*const anyopaque, bytes: usize) c_int;
 pub extern fn zg_memcpy_d2h(dst_host: ?*anyopaque, src_dev: ?*const anyopaque, bytes: usize) c_int;
 pub extern fn zg_sync() c_int;
@@ -54,6 +64,7 @@ pub extern fn zg_g1_bases_upload_dev(d_xy: ?[*]const u64, d_inf: ?[*]const u8, n
 pub extern fn zg_g1_bases_free(b: Bases) c_int;
 pub extern fn zg_g1_bases_len(b: Bases) usize;
 pub extern fn zg_g1_bases_plan(b: Bases, window_bits: ?*c_int, windows: ?*c_int, precompute_levels: ?*c_int) c_int;
+pub extern fn zg_g1_bases_table_bytes(b: Bases) usize;
 pub extern fn zg_msm_g1(b: Bases, off: usize, n: usize, scalars_mont: ?[*]const u64, out_xy: *[8]u64, out_inf: ?[*]u8) c_int;
 pub extern fn zg_msm_g1_dev(b: Bases, off: usize, n: usize, d_scalars_mont: ?[*]const u64, stream: ?*anyopaque, out_xy: *[8]u64, out_inf: ?[*]u8) c_int;
 pub extern fn zg_msm_g1_dev_async(b: Bases, off: usize, n: usize, d_scalars_mont: ?[*]const u64, stream: ?*anyopaque, d_out_xy: ?[*]u64, d_out_inf: ?[*]u8) c_int;

@@ -99,6 +99,16 @@ struct ProfScope {
 // A buffer is returned to the cache only after the work using it has been synchronised.
 void *scratch_get(size_t bytes);  // nullptr on allocation failure (error set)
 void scratch_put(void *p);
+// the pool underneath (runtime.hip): size-classed blocks of device memory kept for reuse, for session tables as well as scratch.
+// pool_free: the caller has synchronised the work that used the block. dev_malloc: hipMalloc for handle-lifetime allocations, with
+// the pool trimmed and one retry when the device is out of memory.
+void *pool_alloc(size_t bytes);
+void pool_free(void *p);
+void pool_trim();
+hipError_t dev_malloc(void **p, size_t bytes);
+// pinned host staging buffers, kept until zg_shutdown (nullptr + error on failure)
+void *pinned_get(size_t bytes);
+void pinned_put(void *p);
 struct Scratch {
     void *p = nullptr;
     Scratch() = default;

@@ -1619,7 +1619,7 @@ static void lane_free(zg_bases_s::Lane &ln) {
 static hipError_t lane_alloc(zg_bases_s::Lane &ln, const MsmPlan &p, size_t n_total, uint32_t nblk_lds) {
     hipError_t e = hipSuccess;
     auto A = [&](auto &ptr, size_t bytes) {
-        if (e == hipSuccess) e = hipMalloc((void **)&ptr, bytes ? bytes : 16);
+        if (e == hipSuccess) e = dev_malloc((void **)&ptr, bytes);
     };
     A(ln.d_dig, (size_t)p.W * n_total * 4);
     A(ln.d_sorted, (size_t)p.W * n_total * 4);
@@ -1696,7 +1696,7 @@ static void free_bases(zg_bases_s *b) {
 
 #define ZG_ALLOC(ptr, bytes)                                                         \
     do {                                                                             \
-        hipError_t _e = hipMalloc((void **)&(ptr), (bytes) ? (bytes) : 16);          \
+        hipError_t _e = dev_malloc((void **)&(ptr), (bytes));                         \
         if (_e != hipSuccess) {                                                      \
             set_error(std::string("hipMalloc(" #ptr "): ") + hipGetErrorString(_e)); \
             free_bases(b);                                                           \
@@ -1986,7 +1986,7 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
         hipLaunchKernelGGL(msm_colscan_bins_kernel, dim3(div_up(q.NCB, 16)), dim3(1024), 0, st, ln.d_blockhist, nblk, q.NCB, d_tot);
         hipLaunchKernelGGL(msm_coarse_base_kernel, dim3(1), dim3(1024), 0, st, d_tot, q.NCB, ln.d_cstarts, d_tst, d_ist);
         ZG_TRY(two_pass_attrs());
-        if (p.G == 1 && n == n_pts)
+        if (!rows && p.G == 1 && n == n_pts)  // PLAIN uses i as the point index: never with live row lengths (their total may equal n_pts)
             hipLaunchKernelGGL(msm_partition_kernel<true>, dim3(nblk), dim3(1024), (STAGE_ENTRIES + 2 * (size_t)q.NCB + 1 + 1024) * 4, st, ln.d_dig,
                                (uint32_t)n, (uint32_t)n_pts, p.W, p.G, b->n, (uint32_t)off, per_block, q.NCB, q.fb, q.rb, d_tst, ln.d_blockhist,
                                ln.d_tmp, local_shift, rowv);
@@ -2301,6 +2301,8 @@ int zg_g1_bases_plan(zg_bases_t b, int *window_bits, int *windows, int *precompu
     if (precompute_levels) *precompute_levels = b->plan.L;
     return ZG_OK;
 }
+
+size_t zg_g1_bases_table_bytes(zg_bases_t b) { return b ? (size_t)(b->plan.L > 1 ? b->plan.L : 1) * b->n * 64 : 0; }
 
 int zg_msm_g1_dev(zg_bases_t b, size_t off, size_t n, const uint64_t *d_scalars, void *stream, uint64_t out_xy[8], uint8_t *out_inf) {
     ZG_INIT();
@@ -2644,14 +2646,15 @@ int zg_g1_combine_partials_dev(const uint64_t *d_partials, size_t k, void *strea
         return ZG_ERR_INVALID;
     }
     hipStream_t st = pick_stream(stream);
-    uint64_t *d_out = nullptr;
-    ZG_HIP(hipMalloc((void **)&d_out, 16 * 8));
+    Scratch s_out(16 * 8);
+    if (!s_out.p) return ZG_ERR_NOMEM;
+    SyncGuard sync(st);
+    uint64_t *d_out = s_out.as<uint64_t>();
     hipLaunchKernelGGL(msm_combine_kernel, dim3(1), dim3(64), 0, st, d_partials, (uint32_t)k, 12u, d_out, reinterpret_cast<uint8_t *>(d_out + 8), 0u, 0u);
     uint64_t h[9];
-    hipError_t e = hipMemcpyAsync(h, d_out, 9 * 8, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)hipFree(d_out);
-    ZG_HIP(e);
+    ZG_HIP(hipMemcpyAsync(h, d_out, 9 * 8, hipMemcpyDeviceToHost, st));
+    ZG_HIP(hipStreamSynchronize(st));
+    sync.dismiss();
     for (int i = 0; i < 8; i++) out_xy[i] = h[i];
     if (out_inf) *out_inf = (uint8_t)(h[8] & 0xff);
     return ZG_OK;
@@ -2685,21 +2688,21 @@ int zg_g1_is_on_curve_batch(const uint64_t *xy, const uint8_t *inf, size_t n, ui
     }
     if (n == 0) return ZG_OK;
     hipStream_t st = lib_stream();
-    uint64_t *dxy = nullptr;
-    uint8_t *dinf = nullptr, *dout = nullptr;
-    ZG_HIP(hipMalloc((void **)&dxy, n * 64));
-    ZG_HIP(hipMalloc((void **)&dout, n));
+    Scratch s_xy(n * 64), s_f(2 * n);
+    if (!s_xy.p || !s_f.p) return ZG_ERR_NOMEM;
+    SyncGuard sync(st);
+    uint64_t *dxy = s_xy.as<uint64_t>();
+    uint8_t *dout = s_f.as<uint8_t>(), *dinf = nullptr;
     ZG_HIP(hipMemcpyAsync(dxy, xy, n * 64, hipMemcpyHostToDevice, st));
     if (inf) {
-        ZG_HIP(hipMalloc((void **)&dinf, n));
+        dinf = dout + n;
         ZG_HIP(hipMemcpyAsync(dinf, inf, n, hipMemcpyHostToDevice, st));
     }
     hipLaunchKernelGGL(g1_on_curve_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, dxy, dinf, n, dout);
     ZG_HIP(hipGetLastError());
     ZG_HIP(hipMemcpyAsync(out, dout, n, hipMemcpyDeviceToHost, st));
     ZG_HIP(hipStreamSynchronize(st));
-    (void)hipFree(dxy); (void)hipFree(dout);
-    if (dinf) (void)hipFree(dinf);
+    sync.dismiss();
     return ZG_OK;
 }
 
@@ -2771,16 +2774,15 @@ int zg_g1_scalar_mul_batch(const uint64_t *xy, const uint8_t *inf, const uint64_
     }
     if (n == 0) return ZG_OK;
     hipStream_t st = lib_stream();
-    uint64_t *dxy = nullptr, *dsc = nullptr, *dout = nullptr;
-    uint8_t *dinf = nullptr, *doinf = nullptr;
-    ZG_HIP(hipMalloc((void **)&dxy, n * 64));
-    ZG_HIP(hipMalloc((void **)&dsc, n * 32));
-    ZG_HIP(hipMalloc((void **)&dout, n * 64));
-    ZG_HIP(hipMalloc((void **)&doinf, n));
+    Scratch s_xy(n * 64), s_sc(n * 32), s_o(n * 64), s_f(2 * n);
+    if (!s_xy.p || !s_sc.p || !s_o.p || !s_f.p) return ZG_ERR_NOMEM;
+    SyncGuard sync(st);
+    uint64_t *dxy = s_xy.as<uint64_t>(), *dsc = s_sc.as<uint64_t>(), *dout = s_o.as<uint64_t>();
+    uint8_t *doinf = s_f.as<uint8_t>(), *dinf = nullptr;
     ZG_HIP(hipMemcpyAsync(dxy, xy, n * 64, hipMemcpyHostToDevice, st));
     ZG_HIP(hipMemcpyAsync(dsc, scalars, n * 32, hipMemcpyHostToDevice, st));
     if (inf) {
-        ZG_HIP(hipMalloc((void **)&dinf, n));
+        dinf = doinf + n;
         ZG_HIP(hipMemcpyAsync(dinf, inf, n, hipMemcpyHostToDevice, st));
     }
     hipLaunchKernelGGL(g1_scalar_mul_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, dxy, dinf, dsc, n, dout, doinf);
@@ -2788,8 +2790,7 @@ int zg_g1_scalar_mul_batch(const uint64_t *xy, const uint8_t *inf, const uint64_
     ZG_HIP(hipMemcpyAsync(out_xy, dout, n * 64, hipMemcpyDeviceToHost, st));
     ZG_HIP(hipMemcpyAsync(out_inf, doinf, n, hipMemcpyDeviceToHost, st));
     ZG_HIP(hipStreamSynchronize(st));
-    (void)hipFree(dxy); (void)hipFree(dsc); (void)hipFree(dout); (void)hipFree(doinf);
-    if (dinf) (void)hipFree(dinf);
+    sync.dismiss();
     return ZG_OK;
 }
 

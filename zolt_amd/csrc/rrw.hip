@@ -434,20 +434,20 @@ struct zg_rrw_s {
 
 using namespace zg;
 
+// session buffers come from the library's device pool and the pinned pool (runtime.hip): the ten tables of a 2^18-cycle session are 2 GB,
+// and hipMalloc + hipFree of those cost 2-40 ms per open depending on the box (BENCH_r04: 45 ms of set-up against 4.8 ms)
 static void rrw_free(zg_rrw_s *s) {
     if (!s) return;
     for (int t = 0; t < RRW_TABLES; t++)
-        for (int b = 0; b < 2; b++)
-            if (s->tab[t][b]) (void)hipFree(s->tab[t][b]);
+        for (int b = 0; b < 2; b++) pool_free(s->tab[t][b]);
     for (int b = 0; b < 2; b++) {
-        if (s->inc[b]) (void)hipFree(s->inc[b]);
-        if (s->eq[b]) (void)hipFree(s->eq[b]);
+        pool_free(s->inc[b]);
+        pool_free(s->eq[b]);
     }
-    for (int b = 0; b < 2; b++)
-        if (s->mask[b]) (void)hipFree(s->mask[b]);
-    if (s->d_part) (void)hipFree(s->d_part);
-    if (s->d_out) (void)hipFree(s->d_out);
-    if (s->h_out) (void)hipHostFree(s->h_out);
+    for (int b = 0; b < 2; b++) pool_free(s->mask[b]);
+    pool_free(s->d_part);
+    pool_free(s->d_out);
+    pinned_put(s->h_out);
     if (s->st) stream_release(s->st, s->device);
     delete s;
 }
@@ -527,23 +527,28 @@ static int rrw_open_impl(size_t log_t, const uint8_t *rs1, const uint8_t *rs2, c
     s->device = current_device();
     s->T = s->cur_T = s->stride = T;
     s->st = stream_acquire();
-    hipError_t e = s->st ? hipSuccess : hipErrorOutOfMemory;
-    for (int t = 0; t < RRW_TABLES && e == hipSuccess; t++) {
-        e = hipMalloc((void **)&s->tab[t][0], (size_t)RRW_ACTIVE * T * 32);
-        if (e == hipSuccess) e = hipMalloc((void **)&s->tab[t][1], (size_t)RRW_ACTIVE * (T / 2) * 32);
+    bool ok = s->st != nullptr;
+    auto grab = [&](auto *&ptr, size_t bytes) {
+        if (ok) ok = (ptr = reinterpret_cast<std::remove_reference_t<decltype(ptr)>>(pool_alloc(bytes))) != nullptr;
+    };
+    for (int t = 0; t < RRW_TABLES; t++) {
+        grab(s->tab[t][0], (size_t)RRW_ACTIVE * T * 32);
+        grab(s->tab[t][1], (size_t)RRW_ACTIVE * (T / 2) * 32);
     }
-    for (int b = 0; b < 2 && e == hipSuccess; b++) {
-        e = hipMalloc((void **)&s->inc[b], (T >> b) * 32);
-        if (e == hipSuccess) e = hipMalloc((void **)&s->eq[b], (T >> b) * 32);
+    for (int b = 0; b < 2; b++) {
+        grab(s->inc[b], (T >> b) * 32);
+        grab(s->eq[b], (T >> b) * 32);
     }
-    for (int b = 0; b < 2 && e == hipSuccess; b++) e = hipMalloc((void **)&s->mask[b], (T >> b) * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&s->d_part, (size_t)RRW_MAX_BLOCKS * 4 * 32);
-    if (e == hipSuccess) e = hipMalloc((void **)&s->d_out, 8 * 32);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_out, 8 * 32);
-    if (e != hipSuccess) {
-        set_error(std::string("zg_rrw_open: ") + hipGetErrorString(e));
+    for (int b = 0; b < 2; b++) grab(s->mask[b], (T >> b) * 4);
+    grab(s->d_part, (size_t)RRW_MAX_BLOCKS * 4 * 32);
+    grab(s->d_out, 8 * 32);
+    if (ok) ok = (s->h_out = reinterpret_cast<uint64_t *>(pinned_get(8 * 32))) != nullptr;
+    if (!ok) {
+        if (!s->st) set_error("zg_rrw_open: no stream");
+        std::string keep = zg_last_error();
         rrw_free(s);
-        return e == hipErrorOutOfMemory ? ZG_ERR_NOMEM : ZG_ERR_HIP;
+        set_error("zg_rrw_open: " + keep);
+        return ZG_ERR_NOMEM;
     }
     // the trace columns travel in one scratch buffer: rs1 | rs2 | rd (T bytes each, padded) then the 32 x T register values
     const size_t pad = (T + 255) & ~(size_t)255;

@@ -144,100 +144,152 @@ int ensure_init() {
     return do_init(-1, 1);
 }
 
-// ------------------------------------------------------------------ scratch cache
-struct ScratchBuf { void *p; size_t bytes; bool used; int dev; };
-static std::mutex g_scratch_mu;
-static std::vector<ScratchBuf> g_scratch;
-static size_t g_scratch_total = 0;
-static constexpr size_t SCRATCH_CAP = (size_t)4 << 30;  // cached bytes kept at most
-
-void *scratch_get(size_t bytes) {
-    if (bytes == 0) bytes = 16;
-    const int dev = current_device();
-    {
-        std::lock_guard<std::mutex> lk(g_scratch_mu);
-        size_t best = (size_t)-1;
-        for (size_t i = 0; i < g_scratch.size(); i++)
-            if (!g_scratch[i].used && g_scratch[i].dev == dev && g_scratch[i].bytes >= bytes && g_scratch[i].bytes <= 4 * bytes + 4096 &&
-                (best == (size_t)-1 || g_scratch[i].bytes < g_scratch[best].bytes))
-                best = i;
-        if (best != (size_t)-1) {
-            g_scratch[best].used = true;
-            return g_scratch[best].p;
-        }
-    }
-    void *p = nullptr;
-    hipError_t e = hipMalloc(&p, bytes);
-    if (e != hipSuccess) {
-        set_error(std::string("hipMalloc(scratch): ") + hipGetErrorString(e));
-        return nullptr;
-    }
-    std::lock_guard<std::mutex> lk(g_scratch_mu);
-    g_scratch.push_back({p, bytes, true, dev});
-    g_scratch_total += bytes;
-    return p;
-}
-
-void scratch_put(void *p) {
-    if (!p) return;
-    std::lock_guard<std::mutex> lk(g_scratch_mu);
-    for (size_t i = 0; i < g_scratch.size(); i++) {
-        if (g_scratch[i].p == p) {
-            if (g_scratch_total > SCRATCH_CAP) {  // over the cap: really free it
-                g_scratch_total -= g_scratch[i].bytes;
-                (void)hipFree(p);
-                g_scratch.erase(g_scratch.begin() + i);
-            } else {
-                g_scratch[i].used = false;
-            }
-            return;
-        }
-    }
-    (void)hipFree(p);
-}
-
-static void scratch_trim() {
-    std::lock_guard<std::mutex> lk(g_scratch_mu);
-    for (auto &b : g_scratch) (void)hipFree(b.p);
-    g_scratch.clear();
-    g_scratch_total = 0;
-}
-
-// ------------------------------------------------------------------ zg_dev_alloc / zg_dev_free
-// A host that drives a prover through the C ABI allocates and frees its tables per proof (the C++ / Python mirrors: a few 32 MB tables per
-// stage): hipMalloc + hipFree of those cost more than the rounds they serve. Freed blocks are kept per device in size classes (the request
-// rounded up to an eighth of its leading power of two: at most 12.5 % slack) and handed out again. zg_dev_free keeps hipFree's guarantee —
-// it returns after all device work has finished (hipDeviceSynchronize), so a block that comes back from the cache is idle. Blocks above
-// 512 MiB bypass the cache; at most 2 GiB stay cached (ZG_DEV_ALLOC_CACHE_MB, 0 = off); an allocation that fails empties the cache and
-// tries again.
-struct DevBlock { size_t bytes; int dev; };
-static std::mutex g_da_mu;
-static std::unordered_map<void *, DevBlock> g_da_live;             // blocks handed out by zg_dev_alloc (class size, device)
-static std::multimap<std::pair<int, size_t>, void *> g_da_free;    // (device, class size) -> idle block
-static size_t g_da_cached = 0;
-static constexpr size_t DA_MAX_BLOCK = (size_t)512 << 20;
-static size_t da_cache_cap() {
+// ------------------------------------------------------------------ the device-memory pool
+// ONE pool of device memory per process behind every transient allocation of the library: the scratch buffers of the host-pointer entry
+// points (Scratch), the session tables of zg_rrw_* / zg_rwc_*, and the caller's own tables (zg_dev_alloc / zg_dev_free). hipMalloc + hipFree
+// of the hundreds of MB a prover stage holds cost 1-40 ms DEPENDING ON THE BOX (round 4: the same binary set a Stage-4 session up in 4.8 ms
+// on one machine and 45 ms on the driver's; its ten tables were raw hipMalloc calls per open), so freed blocks are kept in size classes
+// (the request rounded up to an eighth of its leading power of two: at most 12.5 % slack) and handed out again, whatever their size. The
+// pool is sized for the part: by default it keeps up to a quarter of the device's memory (72 GB of the MI355X's 288 GB; ZG_DEV_ALLOC_CACHE_MB
+// overrides, 0 = no caching). An allocation that fails anywhere in the library (pool_alloc, dev_malloc: handle tables, MSM workspaces)
+// gives every idle block back to the driver and tries once more. A block is idle by contract when it is freed: the caller has synchronised
+// the work that used it (Scratch / SyncGuard, session close; zg_dev_free synchronises the device itself).
+struct PoolBlock { size_t bytes; int dev; };
+static std::mutex g_pool_mu;
+static std::unordered_map<void *, PoolBlock> g_pool_live;            // handed out (class size, device)
+static std::multimap<std::pair<int, size_t>, void *> g_pool_idle;    // (device, class size) -> idle block
+static size_t g_pool_cached = 0;                                     // bytes in g_pool_idle
+static size_t pool_cap() {
     static const size_t cap = [] {
         const char *v = getenv("ZG_DEV_ALLOC_CACHE_MB");
-        long mb = v && *v ? atol(v) : 2048;
-        return (size_t)(mb < 0 ? 0 : mb) << 20;
+        if (v && *v) {
+            long mb = atol(v);
+            return (size_t)(mb < 0 ? 0 : mb) << 20;
+        }
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) return (size_t)8 << 30;
+        return total_b / 4;
     }();
     return cap;
 }
-static size_t da_class(size_t bytes) {
+static size_t pool_class(size_t bytes) {
     if (bytes <= 4096) return 4096;
     int lg = 63 - __builtin_clzll((unsigned long long)bytes);  // 2^lg <= bytes
     const size_t step = (size_t)1 << (lg - 3);
     return (bytes + step - 1) / step * step;
 }
-static void da_trim_locked() {
-    for (auto &kv : g_da_free) (void)hipFree(kv.second);
-    g_da_free.clear();
-    g_da_cached = 0;
+void pool_trim() {  // every idle block back to the driver (blocks in use stay with their owners)
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (auto &kv : g_pool_idle) (void)hipFree(kv.second);
+    g_pool_idle.clear();
+    g_pool_cached = 0;
 }
-static void da_trim() {
-    std::lock_guard<std::mutex> lk(g_da_mu);
-    da_trim_locked();
+hipError_t dev_malloc(void **p, size_t bytes) {  // hipMalloc for allocations that live with a handle; out of memory: trim the pool, retry once
+    hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        pool_trim();
+        e = hipMalloc(p, bytes ? bytes : 16);
+    }
+    return e;
+}
+void *pool_alloc(size_t bytes) {
+    const int dev = current_device();
+    const size_t cls = pool_class(bytes ? bytes : 1);
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        auto it = g_pool_idle.find({dev, cls});
+        if (it != g_pool_idle.end()) {
+            void *p = it->second;
+            g_pool_idle.erase(it);
+            g_pool_cached -= cls;
+            g_pool_live[p] = PoolBlock{cls, dev};
+            return p;
+        }
+    }
+    void *p = nullptr;
+    hipError_t e = dev_malloc(&p, cls);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        set_error(std::string("hipMalloc: ") + hipGetErrorString(e));
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pool_live[p] = PoolBlock{cls, dev};
+    return p;
+}
+void pool_free(void *p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto it = g_pool_live.find(p);
+    if (it == g_pool_live.end()) {  // not ours (or the pool was shut down under its owner): plain free
+        (void)hipFree(p);
+        return;
+    }
+    const PoolBlock b = it->second;
+    g_pool_live.erase(it);
+    if (g_pool_cached + b.bytes > pool_cap()) {
+        (void)hipFree(p);
+        return;
+    }
+    g_pool_idle.insert({{b.dev, b.bytes}, p});
+    g_pool_cached += b.bytes;
+}
+// zg_shutdown: idle blocks are freed; blocks still held by a live session or Scratch are forgotten, so that their owner's later
+// pool_free takes the plain hipFree path (round-4 advisor finding: the old scratch_trim freed buffers under their owners)
+static void pool_shutdown() {
+    pool_trim();
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pool_live.clear();
+}
+void *scratch_get(size_t bytes) { return pool_alloc(bytes); }
+void scratch_put(void *p) { pool_free(p); }
+
+// Pinned staging buffers for the host-pointer entry points that move hundreds of MB (zg_fr_rows_from_columns): hipHostMalloc of 32 MB costs
+// milliseconds, so the few buffers ever asked for are kept until zg_shutdown. Best fit among the idle ones, otherwise a new one.
+struct PinBuf { void *p; size_t bytes; bool used; };
+static std::mutex g_pin_mu;
+static std::vector<PinBuf> g_pin;
+void *pinned_get(size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        size_t best = (size_t)-1;
+        for (size_t i = 0; i < g_pin.size(); i++)
+            if (!g_pin[i].used && g_pin[i].bytes >= bytes && g_pin[i].bytes <= 4 * bytes + 4096 && (best == (size_t)-1 || g_pin[i].bytes < g_pin[best].bytes)) best = i;
+        if (best != (size_t)-1) {
+            g_pin[best].used = true;
+            return g_pin[best].p;
+        }
+    }
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("hipHostMalloc(staging): out of memory");
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    g_pin.push_back({p, bytes, true});
+    return p;
+}
+void pinned_put(void *p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    for (auto &b : g_pin)
+        if (b.p == p) {
+            b.used = false;
+            return;
+        }
+    (void)hipHostFree(p);
+}
+static void pinned_shutdown() {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    size_t keep = 0;
+    for (size_t i = 0; i < g_pin.size(); i++) {
+        if (g_pin[i].used) g_pin[keep++] = g_pin[i];  // still held: its owner's pinned_put finds it
+        else (void)hipHostFree(g_pin[i].p);
+    }
+    g_pin.resize(keep);
 }
 
 // ------------------------------------------------------------------ profiling
@@ -367,13 +419,15 @@ void zg_shutdown(void) {
         g_idle_groups[d].clear();
     }
     if (prev >= 0) (void)hipSetDevice(prev);
-    scratch_trim();
-    da_trim();
+    pool_shutdown();
+    pinned_shutdown();
     g_primary = -1;
     g_ndev = 0;
     g_inited = false;
 }
 
+uint32_t zg_abi_version(void) { return ((uint32_t)ZG_ABI_MAJOR << 16) | (uint32_t)ZG_ABI_MINOR; }
+uint32_t zg_abi_features(void) { return ZG_FEATURE_PROTOCOL_SESSIONS | ZG_FEATURE_RCCL | ZG_FEATURE_COLUMN_INGEST; }
 const char *zg_last_error(void) { return t_err.c_str(); }
 const char *zg_version(void) { return "zolt-gfx950 0.1 (BN254 G1 MSM / eq-table / sumcheck fold; gfx950 HIP)"; }
 
@@ -386,61 +440,32 @@ int zg_device_count(void) {
 int zg_dev_alloc(size_t bytes, void **dptr) {
     ZG_INIT();
     if (!dptr) return ZG_ERR_INVALID;
-    const int dev = current_device();
-    const size_t cls = da_class(bytes ? bytes : 1);
-    const bool cached = cls <= DA_MAX_BLOCK && da_cache_cap() > 0;
-    if (cached) {
-        std::lock_guard<std::mutex> lk(g_da_mu);
-        auto it = g_da_free.find({dev, cls});
-        if (it != g_da_free.end()) {
-            *dptr = it->second;
-            g_da_free.erase(it);
-            g_da_cached -= cls;
-            g_da_live[*dptr] = DevBlock{cls, dev};
-            return ZG_OK;
-        }
-    }
-    hipError_t e = hipMalloc(dptr, cached ? cls : (bytes ? bytes : 1));
-    if (e == hipErrorOutOfMemory) {  // give the cached blocks (this cache and the scratch cache) back and try once more
-        (void)hipGetLastError();
-        da_trim();
-        e = hipMalloc(dptr, cached ? cls : (bytes ? bytes : 1));
-    }
-    if (e == hipErrorOutOfMemory) {
-        (void)hipGetLastError();
-        set_error("hipMalloc: out of memory");
-        return ZG_ERR_NOMEM;
-    }
-    ZG_HIP(e);
-    if (cached) {
-        std::lock_guard<std::mutex> lk(g_da_mu);
-        g_da_live[*dptr] = DevBlock{cls, dev};
-    }
-    return ZG_OK;
+    *dptr = pool_alloc(bytes);
+    return *dptr ? ZG_OK : ZG_ERR_NOMEM;
 }
 int zg_dev_free(void *dptr) {
     ZG_INIT();
     if (!dptr) return ZG_OK;
-    DevBlock b{0, -1};
+    int dev = -1;
     {
-        std::lock_guard<std::mutex> lk(g_da_mu);
-        auto it = g_da_live.find(dptr);
-        if (it != g_da_live.end()) {
-            b = it->second;
-            g_da_live.erase(it);
-        }
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        auto it = g_pool_live.find(dptr);
+        if (it != g_pool_live.end()) dev = it->second.dev;
     }
-    if (b.dev < 0 || g_da_cached + b.bytes > da_cache_cap()) {  // not from the cache's classes, or the cache is full
+    if (dev < 0) {  // not from zg_dev_alloc
         ZG_HIP(hipFree(dptr));
         return ZG_OK;
     }
     {  // hipFree's guarantee: nothing on the block's device still uses it when it is handed out again
-        DeviceGuard dg(b.dev);
+        DeviceGuard dg(dev);
         ZG_HIP(hipDeviceSynchronize());
     }
-    std::lock_guard<std::mutex> lk(g_da_mu);
-    g_da_free.insert({{b.dev, b.bytes}, dptr});
-    g_da_cached += b.bytes;
+    pool_free(dptr);
+    return ZG_OK;
+}
+int zg_dev_trim(void) {
+    ZG_INIT();
+    pool_trim();
     return ZG_OK;
 }
 // Both copies run ON the library stream and wait for it: they are ordered after every call that was given stream = NULL (the

@@ -378,6 +378,7 @@ struct zg_rwc_s {
     std::vector<uint32_t> c2, a2;  // rwc_apply_plan's output buffers, kept between rounds
     std::vector<uint64_t> p2, n2;
     bool plan_valid = false, plan_is_address = false;
+    bool plan_m_known = false;  // a cycle-phase plan's step count has been read back (plan_m means nothing before that)
     size_t plan_addr_round = 0;
     size_t plan_m = 0;  // steps of the current plan (a cycle-phase plan is written on the device: its length arrives with the round's sums)
     // the skeleton on the device, authoritative in the cycle phases: cycle | address (u32) and prev_val | next_val (u64), cap words each, two
@@ -471,7 +472,10 @@ static int rwc_collect(zg_rwc_s *s, uint32_t nblocks, uint64_t *a, uint64_t *b, 
     ZG_HIP(hipMemcpyAsync(s->h_out, s->d_out, 64, hipMemcpyDeviceToHost, s->st));
     if (d_m) ZG_HIP(hipMemcpyAsync(s->h_out + 8, d_m, 4, hipMemcpyDeviceToHost, s->st));
     ZG_HIP(hipStreamSynchronize(s->st));
-    if (d_m) s->plan_m = (uint32_t)s->h_out[8];
+    if (d_m) {
+        s->plan_m = (uint32_t)s->h_out[8];
+        s->plan_m_known = true;
+    }
     for (int i = 0; i < 4; i++) {
         a[i] = s->h_out[i];
         b[i] = s->h_out[4 + i];
@@ -538,6 +542,7 @@ static int rwc_plan_cycle(zg_rwc_s *s) {
         ZG_HIP(hipGetLastError());
     }
     s->plan_m = 0;  // known once rwc_collect / zg_rwc_bind_cycle has read it
+    s->plan_m_known = s->n_entries == 0;
     s->plan_valid = true;
     s->plan_is_address = false;
     return ZG_OK;
@@ -588,6 +593,7 @@ static int rwc_plan_address(zg_rwc_s *s, size_t addr_round) {
         i = j;
     }
     s->plan_m = s->plan.size();
+    s->plan_m_known = true;
     s->plan_valid = true;
     s->plan_is_address = true;
     s->plan_addr_round = addr_round;
@@ -793,13 +799,12 @@ int zg_rwc_bind_cycle(zg_rwc_t s, const uint64_t r[4]) {
     ZG_HIP(hipGetLastError());
     s->vcur = vn;
     s->eq_size = half;
-    if (!s->plan_valid || s->plan_is_address) {  // a bind without the round call before it: walk now
-        ZG_TRY(rwc_plan_cycle(s));
-        if (s->n_entries) {
-            ZG_HIP(hipMemcpyAsync(s->h_out + 8, rwc_walk_total(s), 4, hipMemcpyDeviceToHost, s->st));
-            ZG_HIP(hipStreamSynchronize(s->st));
-            s->plan_m = (uint32_t)s->h_out[8];
-        }
+    if (!s->plan_valid || s->plan_is_address) ZG_TRY(rwc_plan_cycle(s));  // a bind without the round call before it: walk now
+    if (!s->plan_m_known) {  // also after a round call whose collect failed between the walk and the read: never trust plan_m = 0
+        ZG_HIP(hipMemcpyAsync(s->h_out + 8, rwc_walk_total(s), 4, hipMemcpyDeviceToHost, s->st));
+        ZG_HIP(hipStreamSynchronize(s->st));
+        s->plan_m = (uint32_t)s->h_out[8];
+        s->plan_m_known = true;
     }
     const uint32_t m = (uint32_t)s->plan_m;
     if (m) {

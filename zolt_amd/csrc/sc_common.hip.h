@@ -225,8 +225,9 @@ __device__ __forceinline__ void block_sum_pair(Fr &g0, Fr &g1, void *sh) {
 // visibility, "hand-offs measured with sc1 loads", first row): the partials are written with write-through (sc1) stores by ONE wave,
 // that wave drains them (s_waitcnt vmcnt(0)), then ONE of its lanes adds to the arrival counter with a RELAXED agent-scope atomic;
 // the workgroup whose add returns the last ticket reads the partials with sc1 loads (they bypass its L1; no line of the partials
-// buffer is ever loaded any other way inside a launch). No release / acquire fence: round 3's ACQ_REL arrival wrote back and
-// invalidated the XCD's L2 behind a freshly written table once per workgroup.
+// buffer is ever loaded any other way inside a launch). No release fence and no per-workgroup acquire: round 3's ACQ_REL arrival wrote
+// back and invalidated the XCD's L2 behind a freshly written table once per workgroup. The LAST arriver alone runs one agent-scope
+// acquire per launch (sc_arrive), on both arrival paths.
 ZG_DEV void sc1_store_fr(uint64_t *dst, const Fr &v) {
     sc_gu64 *d = (sc_gu64 *)dst;
 #pragma unroll
@@ -259,6 +260,10 @@ ZG_DEV bool sc_arrive(uint32_t *counter, uint32_t nb) {
     if (nb <= SC_ARRIVE_FLAT) {
         if (__hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != nb - 1) return false;
         __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ONE agent-scope acquire per launch, in the last arriver only (round-4 advisor finding: the flat path relied on the measured
+        // table row alone, the two-level path fenced). The fence is `s_waitcnt vmcnt(0); buffer_inv sc1`: the invalidate is queued in
+        // front of every later vector-memory instruction of this wave, the other waves load after the caller's barrier.
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         return true;
     }
     const uint32_t line = blockIdx.x % SC_ARRIVE_LINES;

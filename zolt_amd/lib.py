@@ -23,53 +23,22 @@ OP_MUL, OP_ADD, OP_SUB, OP_NEG, OP_SQR, OP_INV, OP_FROM_MONT, OP_TO_MONT = range
 OP_MUL29, OP_SQR29, OP_X3_29, OP_INV_XGCD, OP_INV_SAFEGCD = 9, 10, 11, 12, 13
 SC_HIGH_HALF, SC_LOW_PAIR = 0, 1
 
-# every symbol include/zolt_gpu.h declares (tests check that the .so exports all of them, and that the header declares no more)
-SYMBOLS = [
-    "zg_init", "zg_init_devices", "zg_n_devices", "zg_shutdown", "zg_last_error", "zg_version", "zg_device_count",
-    "zg_dev_alloc", "zg_dev_free", "zg_memcpy_h2d", "zg_memcpy_d2h", "zg_sync",
-    "zg_field_op", "zg_fr_scale", "zg_g1_affine_add_batch",
-    "zg_shard_bounds", "zg_g1_bases_upload_sharded", "zg_g1_sbases_free", "zg_g1_sbases_len", "zg_g1_sbases_shards", "zg_g1_sbases_exchange", "zg_g1_sbases_shard",
-    "zg_msm_g1_sharded", "zg_msm_g1_sharded_dev", "zg_msm_g1_batch_sharded",
-    "zg_msm_g1_sharded_dev_async", "zg_msm_g1_batch_sharded_async", "zg_sharded_wait", "zg_g1_sbases_inflight",
-    "zg_sumcheck_open_sharded", "zg_sumcheck_shards", "zg_sumcheck_len_sharded", "zg_sumcheck_round_sums_sharded",
-    "zg_sumcheck_bind_sharded", "zg_sumcheck_final_sharded", "zg_sumcheck_close_sharded",
-    "zg_g1_bases_upload", "zg_g1_bases_upload_dev", "zg_g1_bases_free", "zg_g1_bases_len", "zg_g1_bases_plan",
-    "zg_msm_g1", "zg_msm_g1_dev", "zg_msm_g1_dev_async", "zg_msm_g1_batch", "zg_msm_g1_batch_dev", "zg_msm_g1_partial_dev", "zg_msm_g1_partial_fast_dev",
-    "zg_g1_combine_partials_dev", "zg_g1_combine_partials_dev_async", "zg_g1_combine_partials_batch_dev_async", "zg_g1_is_on_curve_batch", "zg_g1_scalar_mul_batch", "zg_g1_fixed_base_mul_batch",
-    "zg_hyperkzg_open", "zg_hyperkzg_open_dev", "zg_hyperkzg_batch_open",
-    "zg_fr_dense_evaluate", "zg_fr_eq_table", "zg_fr_eq_table_dev", "zg_fr_eq_prefix_tables", "zg_fr_eq_prefix_tables_dev", "zg_fr_rows_mle", "zg_fr_rows_mle_dev", "zg_fr_rows_affine", "zg_fr_rows_affine_dev", "zg_fr_rows_affine_prodsum_dev", "zg_fr_weighted_colsum", "zg_fr_weighted_colsum_dev", "zg_fr_lt_table", "zg_fr_lt_table_dev", "zg_fr_write_tables_dev", "zg_fr_eq_plus_one_table", "zg_fr_eq_plus_one_table_dev", "zg_fr_bind_low", "zg_fr_bind_high",
-    "zg_fr_spartan_combine", "zg_fr_spartan_combine_dev",
-    "zg_sumcheck_open", "zg_sumcheck_open_dev", "zg_sumcheck_round_sums", "zg_sumcheck_bind",
-    "zg_sumcheck_len", "zg_sumcheck_final", "zg_sumcheck_read", "zg_sumcheck_gather", "zg_sumcheck_close",
-    "zg_sumcheck_round_sums_dev", "zg_sumcheck_read_dev", "zg_sumcheck_raf_round", "zg_sumcheck_bit_round", "zg_sumcheck_bit_bind", "zg_fr_bit_split_sums", "zg_fr_bit_split_sums_dev", "zg_selftest_handoff",
-    "zg_run_sumcheck", "zg_run_sumcheck_dev", "zg_sumcheck_open_spartan_dev",
-    "zg_psc_open", "zg_psc_open_dev", "zg_psc_len", "zg_psc_tables", "zg_psc_round_evals", "zg_psc_round_expr", "zg_psc_set_points", "zg_psc_round_gruen", "zg_psc_bind", "zg_psc_read", "zg_psc_table_dev", "zg_psc_gather",
-    "zg_psc_final", "zg_psc_close",
-    "zg_rrw_open", "zg_rrw_open_trace", "zg_rrw_cycles", "zg_rrw_registers", "zg_rrw_round_cycle_gruen", "zg_rrw_set_eq", "zg_rrw_round_address", "zg_rrw_round_cycle",
-    "zg_rrw_bind_cycle", "zg_rrw_bind_address", "zg_rrw_final", "zg_rrw_close",
-    "zg_rwc_open", "zg_rwc_open_writes", "zg_rwc_entries", "zg_rwc_cycles", "zg_rwc_round_cycle", "zg_rwc_bind_cycle", "zg_rwc_round_address", "zg_rwc_bind_address",
-    "zg_rwc_opening", "zg_rwc_cycle_scalars", "zg_rwc_read_entries", "zg_rwc_close",
-]
+# every symbol include/zolt_gpu.h declares, with its ctypes signature: GENERATED from the header (tools/gen_bindings.py -> _abi.py), so the
+# binding cannot drift from the C ABI; apply() fails with AttributeError if the loaded library lacks one of them
+from . import _abi  # noqa: E402
+
+SYMBOLS = _abi.SYMBOLS
 # test / bench scaffolding of include/zolt_gpu_internal.h (not part of the drop-in boundary)
-INTERNAL_SYMBOLS = ["zg_profile_begin", "zg_profile_end", "zg_sharded_comm_sets_created"]
+INTERNAL_SYMBOLS = _abi.INTERNAL_SYMBOLS
+_abi.apply(_lib)
+if _lib.zg_abi_version() >> 16 != _abi.ZG_ABI_MAJOR:
+    raise ImportError(f"{LIB_PATH}: ABI major {_lib.zg_abi_version() >> 16}, this binding was generated for {_abi.ZG_ABI_MAJOR}")
 
 
 class MsmConfig(C.Structure):
     _fields_ = [("window_bits", C.c_int), ("precompute_levels", C.c_int), ("expected_uses", C.c_int)]
 
 
-_lib.zg_last_error.restype = C.c_char_p
-_lib.zg_version.restype = C.c_char_p
-_lib.zg_g1_bases_len.restype = C.c_size_t
-_lib.zg_g1_sbases_len.restype = C.c_size_t
-_lib.zg_sumcheck_len_sharded.restype = C.c_size_t
-_lib.zg_sumcheck_len.restype = C.c_size_t
-_lib.zg_psc_len.restype = C.c_size_t
-_lib.zg_psc_tables.restype = C.c_size_t
-_lib.zg_rrw_cycles.restype = C.c_size_t
-_lib.zg_rwc_entries.restype = C.c_size_t
-_lib.zg_rwc_cycles.restype = C.c_size_t
-_lib.zg_rrw_registers.restype = C.c_size_t
 
 _u64p = C.POINTER(C.c_uint64)
 _u8p = C.POINTER(C.c_uint8)
@@ -133,6 +102,21 @@ def shutdown():
 import atexit as _atexit  # noqa: E402
 
 _atexit.register(lambda: _lib.zg_shutdown())  # communicators / pooled sessions are released while HIP and RCCL are still alive
+
+
+def abi_version():
+    """(major, minor) of the loaded library's C ABI"""
+    v = int(_lib.zg_abi_version())
+    return v >> 16, v & 0xFFFF
+
+
+def abi_features():
+    return int(_lib.zg_abi_features())
+
+
+def dev_trim():
+    """return the device pool's idle blocks to the driver"""
+    _chk(_lib.zg_dev_trim(), "zg_dev_trim")
 
 
 def sync():
@@ -227,6 +211,10 @@ class Bases:
         _chk(_lib.zg_g1_bases_upload_dev(_d(d_xy), _d(d_inf), C.c_size_t(n), C.byref(cfg), _d(stream), C.byref(h)),
              "zg_g1_bases_upload_dev")
         return cls(h, n)
+
+    def table_bytes(self):
+        """bytes of HBM held for the bases: the table of precomputed multiples (levels x 64 B per base), or the plain bases"""
+        return int(_lib.zg_g1_bases_table_bytes(self._h))
 
     def plan(self):
         """(window bits c, windows per scalar, table levels per base) the handle was built with"""
