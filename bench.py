@@ -28,17 +28,38 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# HBM traffic of one msm_accumulate launch at 2^20 points (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, serial bench,
-# profiles/r3a_rocprofv3_summary.txt; 17-bit windows, 15.7M table rows): FETCH_SIZE 1,314,038 KB, WRITE_SIZE 28,689 KB per launch.
-# Calibration on this access pattern (tools/microbench gather|stream under --pmc FETCH_SIZE, same file): random 64-byte rows read
-# with the kernel's load shape report 1.04x their bytes (no correction), a sequential 16 B/lane stream reports 0.50x (the gfx950
-# x2 of MI355X_MICROARCH.md). The launch gathers 15.7M rows (1.007 GB, taken as counted) and streams 63 MB of sorted
-# references (counted at half: +31 MB).
-MEASURED_TRAFFIC = {20: 1218561.0 * 1024.0 + 0.5 * 4.0 * 15.73e6 + 28685.2 * 1024.0}
-TRAFFIC_SOURCE = ("rocprofv3 PMC FETCH_SIZE (+x2 on the streamed 63 MB of sorted references, x1 on the gathered 64-byte rows: calibrated with "
-                  "tools/microbench gather|stream) + WRITE_SIZE, profiles/r4final_rocprofv3_summary.txt: FETCH_SIZE 1,218,561 KB, WRITE_SIZE 28,685 KB per launch "
-                  "(r3final: 1,222,851 KB, r3z: 1,256,199 KB, r3a: 1,314,038 KB; round 2 r2a/r2e: 1,248,779 / 1,253,897 KB; 2^22 as four point slices: 1,195,017 KB "
-                  "per launch, profiles/r4final_rocprofv3_summary_2^22.txt)")
+# HBM traffic and executed VALU instructions of one msm_accumulate launch come from a COMMITTED counter file that
+# tools/collect_profiles.sh writes on the GPU box (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU in passes of their own, serial
+# bench): nothing is typed in by hand here, and tests/test_abi_and_host.py checks that what this file reports is what the JSON holds.
+# Calibration on this access pattern (tools/microbench gather|stream under --pmc FETCH_SIZE, the file's "calibration" object): random
+# 64-byte rows read with the kernel's load shape are reported at 1.04x their bytes (taken as counted), a sequential 16 B/lane stream at
+# 0.50x (the gfx950 x2 of MI355X_MICROARCH.md). A launch gathers one 64-byte table row per addition and streams 4 bytes of sorted
+# reference per addition (counted at half: + 0.5 * 4 * additions).
+PMC_FILE = os.path.join(ROOT, "profiles", "r5_pmc.json")
+
+
+def load_pmc(path=PMC_FILE):
+    """{'2^20': {'FETCH_SIZE': KB, 'WRITE_SIZE': KB, 'SQ_INSTS_VALU': n, ...}, '2^22': {...}} per launch of msm_accumulate, or {}"""
+    try:
+        with open(path) as fh:
+            d = json.load(fh)
+        return {size: {k: v["avg"] for k, v in blk.get("counters", {}).items()} for size, blk in d.get("sizes", {}).items()}
+    except (OSError, ValueError, KeyError):
+        return {}
+
+
+def measured_traffic(pmc, logn, adds_per_launch):
+    """HBM bytes of one msm_accumulate launch from the committed counters (None when the file has no entry for this size)"""
+    c = pmc.get(f"2^{logn}", {})
+    if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+        return None
+    return c["FETCH_SIZE"] * 1024.0 + 0.5 * 4.0 * adds_per_launch + c["WRITE_SIZE"] * 1024.0
+
+
+TRAFFIC_SOURCE = ("rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes, serial bench) per msm_accumulate launch, read from profiles/r5_pmc.json "
+                  "(written by tools/collect_profiles.sh; the text summaries of the same run are profiles/r5_rocprofv3_summary*.txt): FETCH_SIZE taken as "
+                  "counted for the gathered 64-byte rows, + 0.5 x 4 B x additions for the streamed sorted references (gfx950 tallies a wide stream at "
+                  "half its bytes; calibrated with tools/microbench gather|stream, same file), + WRITE_SIZE")
 # static instruction mix of one lazy-limb XYZZ mixed add (hipcc --save-temps of the accumulate fast path): 1467
 # v_mad_u64_u32 + 146 v_lshl_add_u64 + 144 v_lshrrev_b64 + 81 v_mul_lo_u32 at 4 issue cycles per wave, 382 32-bit
 # add/and/shift/sub at 2 (tools/microbench.hip rates)
@@ -48,11 +69,10 @@ VALU_PEAK_GCYC = 1024 * 2.4  # 256 CUs x 4 SIMDs x 2.4 GHz
 # ns per wave-instruction per SIMD under load: v_mad_u64_u32 2.034, v_lshl_add_u64 2.181 (v_lshrrev_b64 taken equal), v_mul_lo_u32
 # 2.113, 32-bit add 1.183): the least time one SIMD needs for one wave-wide mixed add, clocks as they really are under this load
 MADD_MIN_NS_PER_SIMD = 1467 * 2.034 + (146 + 144) * 2.181 + 81 * 2.113 + 382 * 1.183
-# The executed instruction count from the counters instead of the static mix (round-3 review): SQ_INSTS_VALU per msm_accumulate launch at
-# 2^20 points, rocprofv3 --pmc in a pass of its own (profiles/r4final_rocprofv3_summary.txt: 585,452,785; r3final: 585.4e6): 2382 wave
-# instructions per wave-wide mixed add (15.73 M adds / 64) against the 2220 of the static fast path — the 162 on top are the loop around
-# the add (sorted-reference decode, row address, conditional negation of y, chunk bookkeeping), 32-bit work priced at the simple-op rate.
-PMC_INSTS_VALU_PER_LAUNCH = {20: 585452784.8}
+# The executed instruction count comes from the counters instead of the static mix (round-3 review): SQ_INSTS_VALU per msm_accumulate
+# launch, rocprofv3 --pmc in a pass of its own, read from PMC_FILE — about 2382 wave instructions per wave-wide mixed add against the
+# 2220 of the static fast path; the 162 on top are the loop around the add (sorted-reference decode, row address, conditional negation of
+# y, chunk bookkeeping), 32-bit work priced at the simple-op rate.
 MADD_STATIC_INSTRS = 1467 + 146 + 144 + 81 + 382
 SIMPLE_OP_NS = 1.183
 SEED = 0x5A4F4C54
@@ -261,8 +281,12 @@ def main():
         bases_xy, bases_inf = lib.g1_scalar_mul_batch(np.repeat(g[None, :], n_loc, axis=0), np.zeros(n_loc, dtype=np.uint8), ks_m)
         assert not bases_inf.any()
         d_bases = torch.from_numpy(bases_xy.view(np.int64)).to(dev)
-        bases = lib.Bases.upload_dev(d_bases.data_ptr(), 0, n_loc, stream=stream, window_bits=args.window_bits,
+        torch.cuda.synchronize()
+        tb0 = time.perf_counter()  # the handle's one-time cost (untimed in the metric, priced in config.table_build_ms): plan, workspaces,
+        bases = lib.Bases.upload_dev(d_bases.data_ptr(), 0, n_loc, stream=stream, window_bits=args.window_bits,  # the table of multiples
                                      precompute_levels=args.precompute)
+        torch.cuda.synchronize()
+        table_build_ms = (time.perf_counter() - tb0) * 1e3
         raws, d_scalars, expect_k = [], [], []
         for s in range(N_SCALAR_SETS):
             raw = raw_scalars(SEED + s, start, n_loc)
@@ -340,6 +364,7 @@ def main():
             assert int(res[j, 8] & 0xFF) == winf and np.array_equal(res[j, :8], wxy), f"MSM result mismatch at MSM {j}"
 
         return {"n": n, "n_loc": n_loc, "elapsed": elapsed, "prof": prof, "prof_alone": prof_alone, "setup_s": setup_s, "bases_xy": bases_xy,
+                "table_build_ms": table_build_ms, "table_bytes": bases.table_bytes(),
                 "d_scalars": d_scalars, "want": want, "bases": bases}
 
     # ranks the collective really spans (an all-reduce of ones over the process group the partials travel on: RCCL when backend = nccl)
@@ -351,6 +376,7 @@ def main():
     per_step = max(1, args.msms_per_step)
     m = run_size(args.logn, args.steps, args.warmup, per_step)
     n, n_loc, elapsed, prof, setup_s = m["n"], m["n_loc"], m["elapsed"], m["prof"], m["setup_s"]
+    table_build_ms, table_bytes = m["table_build_ms"], m["table_bytes"]
     prof_alone = m["prof_alone"]
     bases_xy, d_scalars, want, bases = m["bases_xy"], m["d_scalars"], m["want"], m["bases"]
     m_plan = bases.plan()
@@ -420,8 +446,7 @@ def main():
                    "bit_exact_check": "closed form (sum s_i*(i+1))*G via scalarMul kernel, every timed MSM"},
         "roofline": {"bound": "hbm", "kernel": "msm_accumulate_chunk_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": MEASURED_TRAFFIC.get(args.logn) if world == 1 and args.window_bits == 0 and args.precompute == 0 else None,
-                     "traffic_source": TRAFFIC_SOURCE,
+                     "traffic": None, "traffic_source": TRAFFIC_SOURCE,
                      "algorithmic_bytes_per_launch": alg_bytes, "launches_per_msm": acc_launches, "avg_launch_ms": alone_ms,
                      "avg_launch_ms_source": "HIP events around the kernel, one stream in flight (6 serial MSMs right after the timed region)",
                      "avg_launch_ms_overlapped": acc_overlapped_ms,
@@ -439,6 +464,11 @@ def main():
     adds = float(n_loc) * plan_w * (1.0 - 2.0 ** -plan_c) / acc_launches  # one table row per non-zero signed c-bit digit, per launch
     issue = adds / 64.0 * MADD_ISSUE_CYCLES / (alone_ms * 1e-3) / 1e9 if alone_ms and args.logn >= 15 else None
     out["config"]["window_bits"], out["config"]["windows"], out["config"]["table_levels"] = plan_c, plan_w, plan_l
+    # what the headline mode costs before its first MSM: the table of precomputed multiples (review item: "the line does not price the table")
+    out["config"]["table_build_ms"], out["config"]["table_bytes"] = table_build_ms, table_bytes
+    out["config"]["table_build_note"] = ("zg_g1_bases_upload_dev to completion, host-timed on this rank: plan + workspaces + msm_precompute_kernel (levels x 64 B per "
+                                         "base); breakeven_msms is filled in from extra.msm_no_precompute (the same MSM with expected_uses = 1: no table)")
+    out["config"]["breakeven_msms"] = None
     out["roofline"]["avg_launch_ms_alone"] = alone_ms  # same number as avg_launch_ms (kept under its round-1 name)
     out["roofline"]["valu_issue"] = {"achieved": issue, "peak": VALU_PEAK_GCYC, "unit": "G issue-cycles/s",
                                      "frac": issue / VALU_PEAK_GCYC if issue else None,
@@ -449,7 +479,13 @@ def main():
         "floor_ms": floor_ms, "frac": floor_ms / alone_ms if floor_ms and alone_ms else None,
         "model": "adds / (64 lanes x 1024 SIMDs) x least ns per wave-wide mixed add at the issue times measured by tools/microbench.hip "
                  "(profiles/r1_microbench_instruction_rates.txt); frac = floor / avg_launch_ms_alone"}
-    pmc = PMC_INSTS_VALU_PER_LAUNCH.get(args.logn) if world == 1 and args.window_bits == 0 and args.precompute == 0 else None
+    default_plan = world == 1 and args.window_bits == 0 and args.precompute == 0
+    pmc_all = load_pmc() if default_plan else {}
+    out["roofline"]["traffic"] = measured_traffic(pmc_all, args.logn, adds)
+    if out["roofline"]["traffic"] is None:
+        out["roofline"]["traffic_source"] = ("null: " + ("profiles/r5_pmc.json has no counters for this size" if default_plan else
+                                                        "counters were collected for the default plan on one GPU only"))
+    pmc = pmc_all.get(f"2^{args.logn}", {}).get("SQ_INSTS_VALU")
     if pmc and alone_ms:
         wave_adds = adds / 64.0
         per_add = pmc / wave_adds
@@ -462,7 +498,7 @@ def main():
             "residual_is": "time the SIMDs do not spend issuing: the launch runs 7/8 of the chip's chunk slots when other MSMs are in flight (full "
                            "when alone), the random 64-byte table rows (DESIGN 4a: a wave waits on its gathers when the other wave of its SIMD "
                            "does too), and the chunk-length spread at the end of the launch",
-            "pmc_source": "SQ_INSTS_VALU, rocprofv3 --pmc (own pass), profiles/r4final_rocprofv3_summary.txt"})
+            "pmc_source": "SQ_INSTS_VALU, rocprofv3 --pmc (own pass), profiles/r5_pmc.json"})
     if single_proc is not None:
         out["extra"]["single_process_c_abi"] = single_proc
     if sharded_sc is not None:
@@ -479,6 +515,17 @@ def main():
         out["extra"]["msm_host_scalars_ms"] = (time.perf_counter() - t0) / 3 * 1e3
         assert hinf == want[0][1] and np.array_equal(hxy, want[0][0])
         out["extra"].update(extra_measurements(lib, api, torch, dev, stream, args, bases_xy if args.logn == 20 else None))
+        npc = out["extra"].get("msm_no_precompute", {})
+        if "ms_per_msm" in npc:
+            serial_table = sum(out["extra"]["kernel_ms_per_msm_alone"].values())
+            serial_plain = sum(npc.get("kernel_ms_per_msm_alone", {}).values())
+            gain_p, gain_s = npc["ms_per_msm"] - ms_per_msm, serial_plain - serial_table
+            out["config"]["breakeven_msms"] = {
+                "pipelined": table_build_ms / gain_p if gain_p > 0 else None, "one_at_a_time": table_build_ms / gain_s if gain_s > 0 else None,
+                "table_less_ms_per_msm": {"pipelined": npc["ms_per_msm"], "one_at_a_time_kernels": serial_plain},
+                "table_ms_per_msm": {"pipelined": ms_per_msm, "one_at_a_time_kernels": serial_table},
+                "note": "table_build_ms / (table-less ms per MSM - table ms per MSM); below this many MSMs over one SRS the table-less plan "
+                        "(zg_msm_config.expected_uses = 1) is the faster choice"}
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(bases_xy, d_scalars[0].cpu().numpy().view(np.uint64), want[0], args.logn)
     print(json.dumps(out))

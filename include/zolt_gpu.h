@@ -108,6 +108,10 @@ ZG_API int zg_device_count(void);
 ZG_API int zg_dev_alloc(size_t bytes, void **dptr);
 ZG_API int zg_dev_free(void *dptr);
 ZG_API int zg_dev_trim(void);
+/* pinned host memory (hipHostMalloc) for callers that fill large inputs in place — trace columns, scalar vectors: copies from it run by
+ * DMA at link rate whatever the page state of the process. Not pooled: the caller owns the lifetime. */
+ZG_API int zg_host_alloc(size_t bytes, void **ptr);
+ZG_API int zg_host_free(void *ptr);
 ZG_API int zg_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
 ZG_API int zg_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
 ZG_API int zg_sync(void);
@@ -285,6 +289,38 @@ ZG_API int zg_fr_rows_affine_dev(const uint64_t *d_rows, size_t n_rows, size_t k
                           size_t n_pad, uint64_t *const *d_tables /* host array of ntab DEVICE pointers */, void *stream);
 /* LtPolynomial over the cube (src/zkvm/ram/val_evaluation.zig:289-330), the third factor of ValEvaluationProver's inc * wa * lt:
  * out[j] = sum over the ZERO bits i of j of r[i] * prod_{k > i} (bit_k(j) ? r[k] : 1 - r[k]); index bit i <-> r[i]. v <= 30. */
+/* The witness matrix of a stage built ON THE DEVICE from integer columns. The reference derives every R1CS input of a cycle from machine
+ * integers — F.fromU64 of a register / memory / pc value, signedI64ToField of an immediate, a 0/1 flag, the field product of two inputs
+ * (R1CSCycleInputs.fromTraceStep, src/zkvm/r1cs/constraints.zig:929-1223, signedI64ToField :868-876) — and the provers then read the
+ * 32-byte elements (R1CSInputEvaluator.computeClaimedInputs, src/zkvm/r1cs/evaluation.zig:55-122; StreamingOuterProver,
+ * src/zkvm/spartan/streaming_outer.zig:258-372). A host hands the columns over as they are (~180 instead of 1376 bytes per cycle
+ * across PCIe) and d_rows[row * n_cols + c] = the column's value at `row` as a canonical Montgomery Fr element, bit for bit what the
+ * reference's conversions produce. One array per column, n_rows values each:
+ *   ZG_COL_ZERO  no data: the column is zero              ZG_COL_U8 / U32 / U64  unsigned integers -> F.fromU64
+ *   ZG_COL_I64   int64_t: v < 0 -> r - |v|                ZG_COL_I128 / U128     16 bytes per row (lo, hi), two's complement / unsigned
+ *   ZG_COL_FR    a Montgomery element per row, copied     ZG_COL_BIT             bit `a` of a packed flag word of `b` = 1, 4 or 8 bytes
+ *   ZG_COL_MUL   no data: the product of columns a and b of the same row (neither a ZG_COL_MUL itself)   per row -> 0 or F.one()
+ * Several ZG_COL_BIT columns may name the same word array (it crosses once). n_cols <= 64. */
+#define ZG_COL_ZERO 0
+#define ZG_COL_U8 1
+#define ZG_COL_U32 2
+#define ZG_COL_U64 3
+#define ZG_COL_I64 4
+#define ZG_COL_I128 5
+#define ZG_COL_U128 6
+#define ZG_COL_FR 7
+#define ZG_COL_BIT 8
+#define ZG_COL_MUL 9
+typedef struct {
+    uint32_t kind; /* ZG_COL_* */
+    uint32_t a, b; /* ZG_COL_BIT: bit index, bytes per word; ZG_COL_MUL: the two factor columns */
+    const void *data;
+} zg_col_t;
+/* host columns (pageable, or pinned from zg_host_alloc); returns when the matrix is complete */
+ZG_API int zg_fr_rows_from_columns(const zg_col_t *cols, size_t n_cols, size_t n_rows, uint64_t *d_rows /* device, n_rows*n_cols*4 */);
+/* columns already in HBM (data = device addresses); one asynchronous launch */
+ZG_API int zg_fr_rows_from_columns_dev(const zg_col_t *cols, size_t n_cols, size_t n_rows, uint64_t *d_rows, void *stream);
+
 ZG_API int zg_fr_lt_table(const uint64_t *r, size_t v, uint64_t *out /* 2^v * 4 */);
 ZG_API int zg_fr_lt_table_dev(const uint64_t *r_host, size_t v, uint64_t *d_out, void *stream);
 /* ValEvaluation's other two tables from the LIST OF WRITES (the prover's stage 4, src/zkvm/prover.zig:760-800 over

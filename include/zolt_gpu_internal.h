@@ -35,6 +35,13 @@ extern "C" {
 ZG_API int zg_profile_begin(int max_records);
 ZG_API int zg_profile_end(double ms_out[ZG_PROF_NKERNELS], uint64_t count_out[ZG_PROF_NKERNELS]);
 
+/* Set-up phase split (tools/bench_sumcheck: "time set-up phases separately"). With ZG_SETUP_TIMES=1 in the environment the two entry points
+ * that build large device state from host inputs — zg_fr_rows_from_columns and zg_rrw_open / zg_rrw_open_trace — synchronise between
+ * their phases and record, for the calling thread's last call: out[0] = device allocation (pool), out[1] = host-to-device copies,
+ * out[2] = kernels, out[3] = everything else inside the call, in milliseconds. Without the variable the calls run unsplit and this
+ * returns zeros. */
+ZG_API int zg_last_setup_times(double out[4]);
+
 /* RCCL communicator sets (ncclCommInitAll) created so far by the one-process / several-GPU path: a set is shared by the sharded
  * handles made while the same number of devices is bound; tests check that re-binding creates a new set instead of failing. */
 ZG_API int zg_sharded_comm_sets_created(void);

@@ -834,6 +834,48 @@ static int outer_main(const char *path) {
     return 0;
 }
 
+// `test_host_mirror witness <file>`: zolt::CycleColumns::fromTrace + CycleWitnessMatrix on the trace the file describes (n, then per step:
+// instruction pc unexpanded_pc rs1 rs2 rd has_memory memory is_compressed is_noop) -> per cycle "W" and its 43 inputs as the device widened
+// them, then "B" bytes per cycle; StreamingOuterProver's first round from the shared matrix and from ready rows must agree ("S" lines)
+static int witness_main(const char *path) {
+    std::FILE *f = std::fopen(path, "r");
+    if (!f) { std::printf("cannot open %s\n", path); return 2; }
+    unsigned long long n;
+    if (std::fscanf(f, "%llu", &n) != 1) return 2;
+    std::vector<R1CSTraceStep> steps(n);
+    for (auto &st : steps) {
+        unsigned long long w, pc, upc, a, b, rd, hm, mem, comp, noop;
+        if (std::fscanf(f, "%llx %llx %llx %llx %llx %llx %llu %llx %llu %llu", &w, &pc, &upc, &a, &b, &rd, &hm, &mem, &comp, &noop) != 10) return 2;
+        st.instruction = (uint32_t)w; st.pc = pc; st.unexpanded_pc = upc; st.rs1_value = a; st.rs2_value = b; st.rd_value = rd;
+        st.has_memory_value = hm != 0; st.memory_value = mem; st.is_compressed = comp != 0; st.is_noop = noop != 0;
+    }
+    std::fclose(f);
+    CycleColumns cols = CycleColumns::fromTrace(steps);
+    auto m = CycleWitnessMatrix::fromColumns(cols);
+    std::vector<Fr> rows = m->toHost();
+    for (size_t i = 0; i < n; i++) {
+        std::printf("W");
+        for (size_t k = 0; k < CycleColumns::NUM_INPUTS; k++) print_fr(rows[i * CycleColumns::NUM_INPUTS + k]);
+        std::printf("\n");
+    }
+    std::printf("B %zu\n", cols.bytesPerCycle());
+    size_t nv = 0;
+    while ((size_t(1) << nv) < n) nv++;
+    std::vector<Fr> tau(nv + 2);
+    for (size_t i = 0; i < tau.size(); i++) tau[i] = Fr::fromU64(0x9E3779B97F4A7C15ULL * (i + 1));
+    std::vector<StreamingOuterProver::CycleInputs> w(n);
+    for (size_t i = 0; i < n; i++)
+        for (size_t k = 0; k < r1cs::NUM_INPUTS; k++) w[i][k] = rows[i * r1cs::NUM_INPUTS + k];
+    StreamingOuterProver from_matrix(m, tau), from_rows(w, tau);
+    for (auto *p : {&from_matrix, &from_rows}) {
+        auto s1 = p->computeFirstRoundPoly();
+        std::printf("S");
+        for (const Fr &x : s1) print_fr(x);
+        std::printf("\n");
+    }
+    return 0;
+}
+
 // `test_host_mirror stage3 <file>`: zolt::Stage3Prover on the instance the file describes (written by tests/test_gpu_cpp_host.py): n, the
 // five shift gamma powers, the two other gammas, three input claims, three batching coefficients, r_outer, r_product, the 2^n x 43 witness
 // matrix, n challenges -> per round ShiftSumcheck's three evaluations (S), the compressed combined polynomial (P), the claims after the
@@ -1081,6 +1123,12 @@ int main(int argc, char **argv) {
     if (argc >= 3 && !std::strcmp(argv[1], "outer")) {
         int rc;
         try { rc = outer_main(argv[2]); } catch (const std::exception &e) { std::printf("EXCEPTION: %s\n", e.what()); rc = 3; }
+        zg_shutdown();
+        return rc;
+    }
+    if (argc >= 3 && !std::strcmp(argv[1], "witness")) {
+        int rc;
+        try { rc = witness_main(argv[2]); } catch (const std::exception &e) { std::printf("EXCEPTION: %s\n", e.what()); rc = 3; }
         zg_shutdown();
         return rc;
     }

@@ -492,3 +492,33 @@ def test_cpp_mirror_produces_the_captured_proof_file(golden_dir, tmp_path):
             cur[2].extend(to_int(t[1 + 4 * k:5 + 4 * k]) for k in range((len(t) - 1) // 4))
     assert len(stages) == 6
     assert U.serialize_stage_sections(P["log_t"], P["log_k"], stages) == data[744:]
+
+
+@pytest.mark.gpu
+def test_cpp_witness_matrix_from_trace_columns(tmp_path, golden_dir):
+    """zolt::CycleColumns::fromTrace (compiled host code: the integer-domain restatement of R1CSWitnessGenerator.generateWitness) +
+    zg_fr_rows_from_columns against the oracle's restatement of the same generator: every element of the device-widened matrix, on the
+    captured fibonacci run and on random traces that reach every opcode branch; StreamingOuterProver reads the shared matrix and ready
+    rows alike."""
+    import numpy as np
+    from oracle import binding as ob
+    from tests import util as U
+    from tests.test_witness_columns import random_trace
+    exe = os.path.join(ROOT, "tests", "cpp", "test_host_mirror")
+    subprocess.check_call(["make", "-C", os.path.dirname(exe), "test_host_mirror"])
+    elf = open(os.path.join(golden_dir, "fibonacci.elf"), "rb").read()
+    for k, steps in enumerate((U.fibonacci_full_trace(elf), random_trace(21, 600, 40), random_trace(22, 33, 0))):
+        path = str(tmp_path / f"trace_{k}.txt")
+        with open(path, "w") as f:
+            f.write(f"{len(steps)}\n")
+            for st in steps:
+                f.write("%x %x %x %x %x %x %d %x %d %d\n" % (st["instruction"], st["pc"], st["unexpanded_pc"], st["rs1_value"], st["rs2_value"], st["rd_value"],
+                                                            st["memory_value"] is not None, st["memory_value"] or 0, st["is_compressed"], st["is_noop"]))
+        res = subprocess.run([exe, "witness", path], capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+        rows = [np.array([int(x, 16) for x in l.split()[1:]], dtype=np.uint64).reshape(43, 4) for l in res.stdout.splitlines() if l.startswith("W ")]
+        assert np.array_equal(np.stack(rows), ob.r1cs_witness_from_trace(steps)), k
+        s1 = [l for l in res.stdout.splitlines() if l.startswith("S ")]
+        assert len(s1) == 2 and s1[0] == s1[1]
+        bpc = int([l for l in res.stdout.splitlines() if l.startswith("B ")][0].split()[1])
+        assert bpc in (156, 172)

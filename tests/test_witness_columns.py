@@ -1,0 +1,101 @@
+"""The R1CS cycle inputs as integer columns (zolt_amd/api/witness.py: what crosses PCIe instead of 1376-byte rows of field elements).
+
+CPU: cycleColumnsFromTrace — the product's integer-domain restatement of R1CSWitnessGenerator.generateWitness
+(src/zkvm/r1cs/constraints.zig:929-1223, 1418-1438, 1469-1494) — widened by a big-integer model of zg_fr_rows_from_columns must equal
+the oracle's restatement of the same generator, on the captured fibonacci run and on random traces that reach every opcode branch,
+negative immediates, 128-bit products and the wrap cases. GPU (tests/test_gpu_ingest.py): the device kernel against the same model."""
+import numpy as np
+import pytest
+
+from oracle import binding as ob  # checker
+from tests import util as U
+from zolt_amd import api, lib
+
+R = ob.FR_MOD if hasattr(ob, "FR_MOD") else api.R_MOD
+
+
+def widen_columns_model(cols, n):
+    """big-integer model of zg_fr_rows_from_columns (include/zolt_gpu.h): -> n x len(cols) integers mod r"""
+    out = [[0] * len(cols) for _ in range(n)]
+    for c, spec in enumerate(cols):
+        kind, data = spec[0], spec[1] if len(spec) > 1 else None
+        a, b = (spec[2] if len(spec) > 2 else 0), (spec[3] if len(spec) > 3 else 0)
+        for i in range(n):
+            if kind in (lib.COL_U8, lib.COL_U32, lib.COL_U64, lib.COL_I64):
+                v = int(data[i])
+            elif kind in (lib.COL_I128, lib.COL_U128):
+                v = int(data[i][0]) | (int(data[i][1]) << 64)
+                if kind == lib.COL_I128 and v >> 127:
+                    v -= 1 << 128
+            elif kind == lib.COL_FR:
+                v = api.fr_to_int(data[i])
+            elif kind == lib.COL_BIT:
+                v = (int(data[i]) >> a) & 1
+            else:
+                continue
+            out[i][c] = v % R
+    for c, spec in enumerate(cols):
+        if spec[0] == lib.COL_MUL:
+            for i in range(n):
+                out[i][c] = out[i][spec[2]] * out[i][spec[3]] % R
+    return out
+
+
+def random_trace(seed, n, pad):
+    """n real steps over every opcode class fromTraceStep distinguishes (+ unknown ones), operands at the edges, then NoOp padding"""
+    rng = np.random.default_rng(seed)
+    edge = [0, 1, 2, (1 << 63) - 1, 1 << 63, (1 << 64) - 1, (1 << 64) - 2, 0x80000000, 0xFFFFFFFF]
+    ops = [0x33, 0x13, 0x03, 0x23, 0x63, 0x37, 0x17, 0x6F, 0x67, 0x1B, 0x3B, 0x73, 0x0F]
+
+    def val():
+        return int(edge[rng.integers(len(edge))]) if rng.random() < 0.4 else int(rng.integers(0, 1 << 63)) * 2 + int(rng.integers(0, 2))
+
+    steps = []
+    for _ in range(n):
+        op = ops[rng.integers(len(ops))]
+        w = int(rng.integers(0, 1 << 32)) & ~0x7F | op
+        if op == 0x33:  # make MUL / SUB / ADD all likely
+            f7 = [0x01, 0x20, 0x00, int(rng.integers(0, 128))][rng.integers(4)]
+            f3 = [0, 0, int(rng.integers(0, 8))][rng.integers(3)]
+            w = (w & ~((0x7F << 25) | (7 << 12))) | (f7 << 25) | (f3 << 12)
+        if rng.random() < 0.2:
+            w &= ~(31 << 7)  # rd = x0
+        if rng.random() < 0.05:
+            w = 0x13  # the canonical NOP (isNoopInstruction)
+        pc = int(rng.integers(0, 1 << 20)) * 4 + 0x80000000
+        steps.append({"instruction": w, "pc": pc, "unexpanded_pc": pc if rng.random() < 0.7 else val(), "rs1_value": val(), "rs2_value": val(), "rd_value": val(),
+                      "memory_value": None if rng.random() < 0.3 else val(), "is_compressed": bool(rng.random() < 0.2), "is_noop": False})
+    noop = {"instruction": 0, "pc": 0, "unexpanded_pc": 0, "rs1_value": 0, "rs2_value": 0, "rd_value": 0, "memory_value": None, "is_compressed": False, "is_noop": True}
+    return steps + [dict(noop) for _ in range(pad)]
+
+
+def oracle_rows_int(steps):
+    return [[api.fr_to_int(x) for x in row] for row in ob.r1cs_witness_from_trace(steps)]
+
+
+def test_columns_of_the_captured_fibonacci_run_widen_to_the_reference_witness(golden_dir):
+    import os
+    elf = open(os.path.join(golden_dir, "fibonacci.elf"), "rb").read()
+    steps = U.fibonacci_full_trace(elf)
+    cols = api.cycleColumnsFromTrace(steps)
+    assert len(cols) == 43 and api.columnBytesPerCycle(cols) == 156  # against 43 * 32 = 1376 bytes of field elements per cycle
+    assert widen_columns_model(cols, len(steps)) == oracle_rows_int(steps)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_columns_of_random_traces_widen_to_the_reference_witness(seed):
+    steps = random_trace(seed, 400, 7)
+    cols = api.cycleColumnsFromTrace(steps)
+    got, want = widen_columns_model(cols, len(steps)), oracle_rows_int(steps)
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g == w, (i, hex(steps[i]["instruction"]), [api.R1CS_INPUT_NAMES[k] for k in range(43) if g[k] != w[k]])
+    # the wide columns use 128-bit two's complement whenever every row fits, ready field elements otherwise (a full-width MUL beside a
+    # negative row): both encodings must have been exercised by the three seeds together
+    kinds = {api.R1CS_INPUT_NAMES[k]: cols[k][0] for k in range(43)}
+    assert kinds["RightInstructionInput"] == lib.COL_I128 and kinds["RamAddress"] == lib.COL_I128
+    assert kinds["RightLookupOperand"] in (lib.COL_I128, lib.COL_FR)
+
+
+def test_a_trace_that_ends_on_a_real_step_has_no_successor():
+    steps = random_trace(9, 17, 0)
+    assert widen_columns_model(api.cycleColumnsFromTrace(steps), 17) == oracle_rows_int(steps)

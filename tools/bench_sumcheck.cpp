@@ -7,6 +7,7 @@
 #include <cstdlib>
 
 #include "../zolt_amd/host/zolt_host.hpp"
+#include "../include/zolt_gpu_internal.h"
 
 using namespace zolt;
 using clk = std::chrono::steady_clock;
@@ -349,12 +350,18 @@ int main(int argc, char **argv) {
         }
         std::vector<Fr> rc(r.begin(), r.begin() + lt);
         Fr gamma = Fr::fromU64(splitmix());
-        double t_s4 = 0, t_s4_rounds = 0;
+        setenv("ZG_SETUP_TIMES", "1", 1);
+        double t_s4 = 0, t_s4_rounds = 0, ph4[4] = {0, 0, 0, 0};
         const int n4 = reps > 3 ? 3 : reps;
         for (int rep = -1; rep < n4; rep++) {
             auto t0 = clk::now();
             Stage4GruenProver p(steps, gamma, rc, lt / 2 ? lt / 2 : 1, 7);
             auto t1 = clk::now();
+            if (rep >= 0) {
+                double p4[4];
+                zg_last_setup_times(p4);
+                for (int k = 0; k < 4; k++) ph4[k] += p4[k];
+            }
             Transcript tr("Jolt");
             Fr claim = Fr::zero();
             for (size_t rd = 0; rd < p.num_rounds; rd++) {
@@ -367,28 +374,52 @@ int main(int argc, char **argv) {
             (void)p.getFinalClaims();
             if (rep >= 0) { t_s4 += std::chrono::duration<double>(clk::now() - t0).count(); t_s4_rounds += std::chrono::duration<double>(clk::now() - t1).count(); }
         }
-        std::printf("\"stage4_registers_log_t\": %zu, \"stage4_registers_ms_incl_setup\": %.4f, \"stage4_registers_rounds_ms\": %.4f, \"stage4_registers_rounds_per_s\": %.1f, ",
-                    lt, t_s4 / n4 * 1e3, t_s4_rounds / n4 * 1e3, n4 * (double)(7 + lt) / t_s4_rounds);
+        std::printf("\"stage4_registers_log_t\": %zu, \"stage4_registers_ms_incl_setup\": %.4f, \"stage4_registers_setup_ms\": %.4f, "
+                    "\"stage4_registers_setup_split_ms\": {\"alloc\": %.4f, \"h2d\": %.4f, \"kernels\": %.4f}, \"stage4_registers_rounds_ms\": %.4f, "
+                    "\"stage4_registers_rounds_per_s\": %.1f, ",
+                    lt, t_s4 / n4 * 1e3, (t_s4 - t_s4_rounds) / n4 * 1e3, ph4[0] / n4, ph4[1] / n4, ph4[2] / n4, t_s4_rounds / n4 * 1e3, n4 * (double)(7 + lt) / t_s4_rounds);
     }
-    // StreamingOuterProver's remaining rounds (src/zkvm/spartan/streaming_outer.zig): 2^min(v, 20) cycles x 43 inputs, Az / Bz materialised
-    // by one launch, 1 + log T Gruen rounds with a Keccak transcript
+    // StreamingOuterProver (src/zkvm/spartan/streaming_outer.zig) over 2^min(v, 20) cycles. The witness matrix is built ON THE DEVICE from the
+    // integer columns of a synthetic trace (zolt::CycleColumns::fromTrace + zg_fr_rows_from_columns: 156 bytes per cycle cross PCIe instead
+    // of 43 field elements = 1376); Az / Bz are materialised by one launch, then 1 + log T Gruen rounds with a Keccak transcript. The set-up
+    // is reported phase by phase: the host's column decode (the reference spends this loop building field-element rows), the device allocation,
+    // the copies, the widening kernel (ZG_SETUP_TIMES=1 separates the last three with synchronisations), the prover's own tables.
+    std::shared_ptr<CycleWitnessMatrix> shared_matrix;  // Stage 1's matrix stays resident: Stage 3 below reads the same one
     {
         const size_t lt = v > 20 ? 20 : (size_t)v, To = size_t(1) << lt;
-        std::vector<StreamingOuterProver::CycleInputs> w(To);
-        for (auto &row : w)
-            for (size_t k = 0; k < r1cs::NUM_INPUTS; k++) row[k] = k >= 23 ? Fr::fromU64(splitmix() & 1) : Fr::fromU64(splitmix());
+        static const uint32_t ops[13] = {0x33, 0x13, 0x03, 0x23, 0x63, 0x37, 0x17, 0x6F, 0x67, 0x1B, 0x3B, 0x73, 0x0F};
+        std::vector<R1CSTraceStep> trace(To);
+        for (size_t i = 0; i < To; i++) {
+            auto &st = trace[i];
+            if (i >= To - To / 16) { st.is_noop = true; continue; }  // NoOp padding at the end, as padWithNoop leaves it
+            uint64_t z = splitmix();
+            st.instruction = ((uint32_t)(z >> 32) & ~0x7Fu) | ops[z % 13];
+            st.pc = st.unexpanded_pc = 0x80000000ULL + 4 * (splitmix() & 0xFFFFF);
+            st.rs1_value = splitmix();
+            st.rs2_value = splitmix();
+            st.rd_value = splitmix();
+            st.has_memory_value = (z >> 8) & 1;
+            st.memory_value = splitmix();
+        }
         std::vector<Fr> tau(lt + 2);
         for (auto &x : tau) x = Fr::fromU64(splitmix());
         Fr r0 = Fr::fromU64(splitmix()), scale = Fr::fromU64(splitmix());
-        double t_up = 0, t_mat = 0, t_rounds = 0, t_first = 0;
+        setenv("ZG_SETUP_TIMES", "1", 1);  // read once by the library: set before the first call that looks at it
+        double t_cols = 0, t_matrix = 0, t_ctor = 0, t_mat = 0, t_rounds = 0, t_first = 0, ph[4] = {0, 0, 0, 0};
+        size_t bytes_per_cycle = 0;
         const int no = reps > 3 ? 3 : reps;
         for (int rep = -1; rep < no; rep++) {
             auto t0 = clk::now();
-            StreamingOuterProver p(w, tau, &scale);
+            CycleColumns cols = CycleColumns::fromTrace(trace);
+            auto ta = clk::now();
+            auto matrix = CycleWitnessMatrix::fromColumns(cols);
+            auto tb = clk::now();
+            double p4[4];
+            zg_last_setup_times(p4);
+            StreamingOuterProver p(matrix, tau, &scale);
             auto tf = clk::now();
             (void)p.computeFirstRoundPoly();  // the UniSkip first round: t1 at nine targets, 28 coefficients
-            if (rep >= 0) t_first += std::chrono::duration<double>(clk::now() - tf).count();
-            t0 += clk::now() - tf;
+            auto tg = clk::now();
             p.bindFirstRoundChallenge(r0, Fr::zero());
             auto t1 = clk::now();
             p.materializeLinearPhasePolynomials();
@@ -403,23 +434,46 @@ int main(int argc, char **argv) {
             }
             (void)p.finalAzBz();
             auto t3 = clk::now();
+            bytes_per_cycle = cols.bytesPerCycle();
+            shared_matrix = matrix;
             if (rep >= 0) {
-                t_up += std::chrono::duration<double>(t1 - t0).count();
-                t_mat += std::chrono::duration<double>(t2 - t1).count();
-                t_rounds += std::chrono::duration<double>(t3 - t2).count();
+                auto d = [](clk::time_point x, clk::time_point y) { return std::chrono::duration<double>(y - x).count(); };
+                t_cols += d(t0, ta); t_matrix += d(ta, tb); t_ctor += d(tb, tf); t_first += d(tf, tg); t_mat += d(t1, t2); t_rounds += d(t2, t3);
+                for (int k = 0; k < 4; k++) ph[k] += p4[k];
             }
         }
-        std::printf("\"outer_log_t\": %zu, \"outer_upload_ms\": %.4f, \"outer_uniskip_first_round_ms\": %.4f, \"outer_materialize_ms\": %.4f, \"outer_rounds_ms\": %.4f, "
-                    "\"outer_rounds_per_s\": %.1f, ", lt, t_up / no * 1e3, t_first / no * 1e3, t_mat / no * 1e3, t_rounds / no * 1e3, no * (double)(lt + 1) / t_rounds);
+        // the rows-of-field-elements upload of rounds 3 / 4 beside it, once (1376 bytes per cycle through zg_memcpy_h2d)
+        double t_fr_rows = 0;
+        {
+            auto m0 = CycleWitnessMatrix::fromColumns(CycleColumns::fromTrace(trace));
+            std::vector<Fr> rows = m0->toHost();
+            m0.reset();
+            for (int rep = -1; rep < 2; rep++) {
+                auto t0 = clk::now();
+                auto m1 = CycleWitnessMatrix::fromWitnesses(rows.data(), To);
+                if (rep >= 0) t_fr_rows += std::chrono::duration<double>(clk::now() - t0).count() / 2;
+            }
+        }
+        std::printf("\"outer_log_t\": %zu, \"outer_column_bytes_per_cycle\": %zu, \"outer_host_columns_ms\": %.4f, \"outer_upload_ms\": %.4f, "
+                    "\"outer_upload_split_ms\": {\"alloc\": %.4f, \"h2d\": %.4f, \"widen_kernel\": %.4f}, \"outer_prover_tables_ms\": %.4f, "
+                    "\"outer_uniskip_first_round_ms\": %.4f, \"outer_materialize_ms\": %.4f, \"outer_upload_plus_first_round_plus_materialize_ms\": %.4f, "
+                    "\"outer_upload_fr_rows_ms\": %.4f, \"outer_rounds_ms\": %.4f, \"outer_rounds_per_s\": %.1f, ",
+                    lt, bytes_per_cycle, t_cols / no * 1e3, t_matrix / no * 1e3, ph[0] / no, ph[1] / no, ph[2] / no, t_ctor / no * 1e3, t_first / no * 1e3, t_mat / no * 1e3,
+                    (t_matrix + t_ctor + t_first + t_mat) / no * 1e3, t_fr_rows * 1e3, t_rounds / no * 1e3, no * (double)(lt + 1) / t_rounds);
     }
     // Stage 3 (src/zkvm/spartan/stage3_prover.zig): ShiftSumcheck + InstructionInput + RegistersClaimReduction over 2^min(v, 20) padded cycles,
     // the witness matrix resident in HBM (Stage 1's upload): build of the three instances, then log T batched rounds with a Keccak transcript
     {
         const size_t lt = v > 20 ? 20 : (v < 2 ? 2 : (size_t)v), T3 = size_t(1) << lt;
-        std::vector<Fr> w(T3 * 43);
-        for (auto &x : w) x = Fr::fromU64(splitmix());
-        DeviceMem d_rows(T3 * 43 * 32);
-        check(zg_memcpy_h2d(d_rows.p, w.data(), T3 * 43 * 32), "h2d");
+        const bool shared = shared_matrix && shared_matrix->num_cycles == T3;
+        DeviceMem d_own;
+        if (!shared) {  // sizes where no Stage-1 matrix of this length exists: a matrix of its own
+            std::vector<Fr> w(T3 * 43);
+            for (auto &x : w) x = Fr::fromU64(splitmix());
+            d_own.alloc(T3 * 43 * 32);
+            check(zg_memcpy_h2d(d_own.p, w.data(), T3 * 43 * 32), "h2d");
+        }
+        const uint64_t *d_rows_ptr = shared ? shared_matrix->u64() : d_own.u64();
         std::vector<Fr> ro(lt), rp(lt), sg(5);
         for (auto &x : ro) x = Fr::fromU64(splitmix());
         for (auto &x : rp) x = Fr::fromU64(splitmix());
@@ -431,7 +485,7 @@ int main(int argc, char **argv) {
         const int n3 = reps > 3 ? 3 : reps;
         for (int rep = -1; rep < n3; rep++) {
             auto t0 = clk::now();
-            Stage3Prover p(d_rows.u64(), ro, rp, sg, g, sg[2], cl, co);
+            Stage3Prover p(d_rows_ptr, ro, rp, sg, g, sg[2], cl, co);
             auto t1 = clk::now();
             Transcript tr("Jolt");
             for (size_t rd = 0; rd < lt; rd++) {
@@ -447,8 +501,9 @@ int main(int argc, char **argv) {
                 t_rounds += std::chrono::duration<double>(t2 - t1).count();
             }
         }
-        std::printf("\"stage3_log_t\": %zu, \"stage3_build_ms\": %.4f, \"stage3_rounds_ms\": %.4f, \"stage3_rounds_per_s\": %.1f, ", lt, t_build / n3 * 1e3,
-                    t_rounds / n3 * 1e3, n3 * (double)lt / t_rounds);
+        std::printf("\"stage3_log_t\": %zu, \"stage3_reads_stage1_matrix\": %s, \"stage3_build_ms\": %.4f, \"stage3_rounds_ms\": %.4f, \"stage3_rounds_per_s\": %.1f, ", lt,
+                    shared ? "true" : "false", t_build / n3 * 1e3, t_rounds / n3 * 1e3, n3 * (double)lt / t_rounds);
+        shared_matrix.reset();
     }
     std::printf("\"val_evaluation_rounds_per_s\": %.1f, \"val_evaluation_ms\": %.4f, \"product_remainder_rounds_per_s\": %.1f, "
                 "\"product_remainder_ms\": %.4f, ", reps * v / t_val, t_val / reps * 1e3, reps * v / t_prod, t_prod / reps * 1e3);

@@ -44,6 +44,8 @@ def zig_type(ctype, array):
         return "?*const MsmConfig"
     if base == "zg_psc_term":
         return "?[*]const PscTerm"
+    if base == "zg_col_t":
+        return "?[*]const Column"
     if base == "void":
         if stars == 2 and "*const*" in t.replace(" ", ""):
             return "?[*]const ?*anyopaque"  # array of stream handles
@@ -94,6 +96,7 @@ def generate():
     ] + [f"pub const {zname} = ?*opaque {{}}; // {cname}" for cname, zname in HANDLES.items()] + [  # every handle type the externs below name
         "",
         "pub const MsmConfig = extern struct { window_bits: c_int = 0, precompute_levels: c_int = 0, expected_uses: c_int = 0 };",
+        "pub const Column = extern struct { kind: u32 = 0, a: u32 = 0, b: u32 = 0, data: ?*const anyopaque = null }; // zg_col_t",
         "pub const PscTerm = extern struct { n_prod: c_int = 0, prod: [4]c_int = .{ 0, 0, 0, 0 }, n_lin: c_int = 0, lin: [4]c_int = .{ 0, 0, 0, 0 }, lin_coeff: [16]u64 = .{0} ** 16 }; // zg_psc_term",
         "",
     ]

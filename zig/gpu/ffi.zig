@@ -15,6 +15,7 @@ pub const RegistersSession = ?*opaque {}; // zg_rrw_t
 pub const RamRwSession = ?*opaque {}; // zg_rwc_t
 
 pub const MsmConfig = extern struct { window_bits: c_int = 0, precompute_levels: c_int = 0, expected_uses: c_int = 0 };
+pub const Column = extern struct { kind: u32 = 0, a: u32 = 0, b: u32 = 0, data: ?*const anyopaque = null }; // zg_col_t
 pub const PscTerm = extern struct { n_prod: c_int = 0, prod: [4]c_int = .{ 0, 0, 0, 0 }, n_lin: c_int = 0, lin: [4]c_int = .{ 0, 0, 0, 0 }, lin_coeff: [16]u64 = .{0} ** 16 }; // zg_psc_term
 
 pub const OK: c_int = 0;
@@ -38,6 +39,16 @@ pub const ABI_MINOR: u32 = 5;
 pub const FEATURE_PROTOCOL_SESSIONS: u32 = 1;
 pub const FEATURE_RCCL: u32 = 2;
 pub const FEATURE_COLUMN_INGEST: u32 = 4;
+pub const COL_ZERO: u32 = 0;
+pub const COL_U8: u32 = 1;
+pub const COL_U32: u32 = 2;
+pub const COL_U64: u32 = 3;
+pub const COL_I64: u32 = 4;
+pub const COL_I128: u32 = 5;
+pub const COL_U128: u32 = 6;
+pub const COL_FR: u32 = 7;
+pub const COL_BIT: u32 = 8;
+pub const COL_MUL: u32 = 9;
 pub const SC_HIGH_HALF: c_int = 0;
 pub const SC_LOW_PAIR: c_int = 1;
 pub const PSC_PAIR_SUM: c_int = 256;
@@ -54,6 +65,8 @@ pub extern fn zg_device_count() c_int;
 pub extern fn zg_dev_alloc(bytes: usize, dptr: *?*anyopaque) c_int;
 pub extern fn zg_dev_free(dptr: ?*anyopaque) c_int;
 pub extern fn zg_dev_trim() c_int;
+pub extern fn zg_host_alloc(bytes: usize, ptr: *?*anyopaque) c_int;
+pub extern fn zg_host_free(ptr: ?*anyopaque) c_int;
 pub extern fn zg_memcpy_h2d(dst_dev: ?*anyopaque, src_host: ?*const anyopaque, bytes: usize) c_int;
 pub extern fn zg_memcpy_d2h(dst_host: ?*anyopaque, src_dev: ?*const anyopaque, bytes: usize) c_int;
 pub extern fn zg_sync() c_int;
@@ -93,6 +106,8 @@ pub extern fn zg_fr_rows_mle(rows: ?[*]const u64, n_rows: usize, k: usize, r: ?[
 pub extern fn zg_fr_rows_mle_dev(d_rows: ?[*]const u64, n_rows: usize, k: usize, r_host: ?[*]const u64, v: usize, stream: ?*anyopaque, out: ?[*]u64) c_int;
 pub extern fn zg_fr_rows_affine(rows: ?[*]const u64, n_rows: usize, k: usize, stride: usize, coeffs: ?[*]const u64, ntab: usize, g: usize, n_pad: usize, tables: ?[*]const ?[*]u64) c_int;
 pub extern fn zg_fr_rows_affine_dev(d_rows: ?[*]const u64, n_rows: usize, k: usize, stride: usize, coeffs_host: ?[*]const u64, ntab: usize, g: usize, n_pad: usize, d_tables: ?[*]const ?[*]u64, stream: ?*anyopaque) c_int;
+pub extern fn zg_fr_rows_from_columns(cols: ?[*]const Column, n_cols: usize, n_rows: usize, d_rows: ?[*]u64) c_int;
+pub extern fn zg_fr_rows_from_columns_dev(cols: ?[*]const Column, n_cols: usize, n_rows: usize, d_rows: ?[*]u64, stream: ?*anyopaque) c_int;
 pub extern fn zg_fr_lt_table(r: ?[*]const u64, v: usize, out: ?[*]u64) c_int;
 pub extern fn zg_fr_lt_table_dev(r_host: ?[*]const u64, v: usize, d_out: ?[*]u64, stream: ?*anyopaque) c_int;
 pub extern fn zg_fr_write_tables_dev(n: usize, m: usize, cycle: ?[*]const u32, word: ?[*]const u32, pre: ?[*]const u64, post: ?[*]const u64, r_eq: ?[*]const u64, log_k: usize, d_inc: ?[*]u64, d_wa: ?[*]u64, stream: ?*anyopaque) c_int;

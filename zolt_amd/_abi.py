@@ -23,6 +23,16 @@ ZG_ABI_MINOR = 5
 ZG_FEATURE_PROTOCOL_SESSIONS = 1
 ZG_FEATURE_RCCL = 2
 ZG_FEATURE_COLUMN_INGEST = 4
+ZG_COL_ZERO = 0
+ZG_COL_U8 = 1
+ZG_COL_U32 = 2
+ZG_COL_U64 = 3
+ZG_COL_I64 = 4
+ZG_COL_I128 = 5
+ZG_COL_U128 = 6
+ZG_COL_FR = 7
+ZG_COL_BIT = 8
+ZG_COL_MUL = 9
 ZG_SC_HIGH_HALF = 0
 ZG_SC_LOW_PAIR = 1
 ZG_PSC_PAIR_SUM = 256
@@ -54,6 +64,8 @@ PROTOS = {
     "zg_dev_alloc": (c_int, [c_size_t, c_void_p]),  # bytes, dptr
     "zg_dev_free": (c_int, [c_void_p]),  # dptr
     "zg_dev_trim": (c_int, []),  # 
+    "zg_host_alloc": (c_int, [c_size_t, c_void_p]),  # bytes, ptr
+    "zg_host_free": (c_int, [c_void_p]),  # ptr
     "zg_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_size_t]),  # dst_dev, src_host, bytes
     "zg_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_size_t]),  # dst_host, src_dev, bytes
     "zg_sync": (c_int, []),  # 
@@ -93,6 +105,8 @@ PROTOS = {
     "zg_fr_rows_mle_dev": (c_int, [c_void_p, c_size_t, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p]),  # d_rows, n_rows, k, r_host, v, stream, out
     "zg_fr_rows_affine": (c_int, [c_void_p, c_size_t, c_size_t, c_size_t, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p]),  # rows, n_rows, k, stride, coeffs, ntab, g, n_pad, tables
     "zg_fr_rows_affine_dev": (c_int, [c_void_p, c_size_t, c_size_t, c_size_t, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p, c_void_p]),  # d_rows, n_rows, k, stride, coeffs_host, ntab, g, n_pad, d_tables, stream
+    "zg_fr_rows_from_columns": (c_int, [c_void_p, c_size_t, c_size_t, c_void_p]),  # cols, n_cols, n_rows, d_rows
+    "zg_fr_rows_from_columns_dev": (c_int, [c_void_p, c_size_t, c_size_t, c_void_p, c_void_p]),  # cols, n_cols, n_rows, d_rows, stream
     "zg_fr_lt_table": (c_int, [c_void_p, c_size_t, c_void_p]),  # r, v, out
     "zg_fr_lt_table_dev": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),  # r_host, v, d_out, stream
     "zg_fr_write_tables_dev": (c_int, [c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),  # n, m, cycle, word, pre, post, r_eq, log_k, d_inc, d_wa, stream
@@ -187,6 +201,7 @@ PROTOS = {
 INTERNAL_PROTOS = {
     "zg_profile_begin": (c_int, [c_int]),  # max_records
     "zg_profile_end": (c_int, [c_void_p, c_void_p]),  # ms_out, count_out
+    "zg_last_setup_times": (c_int, [c_void_p]),  # out
     "zg_sharded_comm_sets_created": (c_int, []),  # 
 }
 

@@ -16,7 +16,7 @@ unchanged Zig `field` module plays above the FFI seam.
 Field elements are numpy uint64[4] Montgomery limbs; points numpy uint64[8] + inf flag.
 
 The package is split per family (round-3 review): _base (scalars), msm, commitment, wire, poly, sumcheck, transcript,
-provers, blake2b. Every name of every part — the underscore helpers that bench.py and the tests use included — is re-exported
+witness (integer trace columns -> the device-resident witness matrix), provers, blake2b. Every name of every part — the underscore helpers that bench.py and the tests use included — is re-exported
 here, so `from zolt_amd import api; api.X` is unchanged.
 """
 from ._base import *  # noqa: F401,F403
@@ -26,5 +26,6 @@ from .wire import *  # noqa: F401,F403
 from .poly import *  # noqa: F401,F403
 from .sumcheck import *  # noqa: F401,F403
 from .transcript import *  # noqa: F401,F403
+from .witness import *  # noqa: F401,F403
 from .provers import *  # noqa: F401,F403
 from .blake2b import *  # noqa: F401,F403

@@ -12,6 +12,7 @@ from .wire import *  # noqa: F401,F403
 from .poly import *  # noqa: F401,F403
 from .sumcheck import *  # noqa: F401,F403
 from .transcript import *  # noqa: F401,F403
+from .witness import *  # noqa: F401,F403
 
 def proveStage1(combined_poly, num_rounds, transcript):
     """The Stage-1 (outer Spartan) round loop of MultiStageProver.proveStage1 (src/zkvm/prover.zig:397-432) over
@@ -1177,7 +1178,20 @@ class R1CSInputEvaluator:
 
     @staticmethod
     def computeClaimedInputs(cycle_witnesses, r_cycle):
-        """cycle_witnesses: (num_cycles, NUM_INPUTS, 4) = R1CSCycleInputs.values per cycle; -> (NUM_INPUTS, 4)   (:55-122)"""
+        """cycle_witnesses: (num_cycles, NUM_INPUTS, 4) = R1CSCycleInputs.values per cycle, or the shared device-resident
+        CycleWitnessMatrix (no upload: zg_fr_rows_mle_dev over it); -> (NUM_INPUTS, 4)   (:55-122)"""
+        if isinstance(cycle_witnesses, CycleWitnessMatrix):
+            m = cycle_witnesses
+            r = np.ascontiguousarray(r_cycle, dtype=np.uint64).reshape(-1, 4)
+            if m.num_cycles == 0:
+                return np.zeros((NUM_R1CS_INPUTS, 4), dtype=np.uint64)
+            log_n = m.num_cycles.bit_length() - 1
+            effective_len = min(r.shape[0], log_n)
+            if effective_len == 0:
+                return m.to_host()[0].copy()
+            if effective_len < log_n:
+                raise IndexError("computeClaimedInputs: r_cycle shorter than log2 of the cycle count")
+            return lib.fr_rows_mle_dev(m.ptr, min(m.num_cycles, 1 << log_n), NUM_R1CS_INPUTS, r[:effective_len])
         w = np.ascontiguousarray(cycle_witnesses, dtype=np.uint64)
         assert w.ndim == 3 and w.shape[2] == 4
         r = np.ascontiguousarray(r_cycle, dtype=np.uint64).reshape(-1, 4)
@@ -1568,8 +1582,10 @@ class StreamingOuterProver:
     split-eq scalar, the cubic and the claim are host algebra, as in the reference."""
 
     def __init__(self, cycle_witnesses, tau, lagrange_tau_r0=None):
-        w = np.ascontiguousarray(cycle_witnesses, dtype=np.uint64).reshape(-1, NUM_R1CS_INPUTS, 4)
-        self.num_cycles = w.shape[0]
+        # a CycleWitnessMatrix (api.witness: built on the device from integer trace columns, shared with the other stages) or host rows
+        self._owns_rows = not isinstance(cycle_witnesses, CycleWitnessMatrix)
+        self._d_rows = CycleWitnessMatrix.from_witnesses(cycle_witnesses) if self._owns_rows else cycle_witnesses
+        self.num_cycles = self._d_rows.num_cycles
         assert self.num_cycles > 0  # error.EmptyTrace (:147-149)
         self.padded_trace_len = 1
         while self.padded_trace_len < self.num_cycles:
@@ -1580,7 +1596,6 @@ class StreamingOuterProver:
         self.tau_high = tau[-1].copy()
         self.full_tau = tau.copy()
         self.split_eq = GruenSplitEqPolynomial(tau[:-1], lagrange_tau_r0)
-        self._d_rows = lib.DeviceBuffer.from_host(w)
         self.current_claim = fr_from_int(0)
         self.current_round = 0
         self.challenges = []
@@ -1690,7 +1705,8 @@ class StreamingOuterProver:
     def deinit(self):
         if self._s is not None:
             self._s.close()
-        self._d_rows.free()
+        if self._owns_rows:
+            self._d_rows.free()
         self.split_eq.deinit()
 
 

@@ -132,6 +132,13 @@ struct SyncGuard {
     void dismiss() { armed = false; }
 };
 
+// set-up phase split for the bench (include/zolt_gpu_internal.h: zg_last_setup_times); phases are only separated by synchronisations
+// when ZG_SETUP_TIMES is set
+struct SetupTimes { double alloc_ms = 0, h2d_ms = 0, kernel_ms = 0, other_ms = 0; };
+SetupTimes &setup_times();   // the calling thread's record
+bool setup_times_enabled();
+double now_ms();
+
 static inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
 // r = a + b mod the BN254 scalar modulus on the host, canonical inputs (src/field/mod.zig:782-798)

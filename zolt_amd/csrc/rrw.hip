@@ -527,6 +527,8 @@ static int rrw_open_impl(size_t log_t, const uint8_t *rs1, const uint8_t *rs2, c
     s->device = current_device();
     s->T = s->cur_T = s->stride = T;
     s->st = stream_acquire();
+    const bool split = setup_times_enabled();
+    const double ts0 = split ? now_ms() : 0;
     bool ok = s->st != nullptr;
     auto grab = [&](auto *&ptr, size_t bytes) {
         if (ok) ok = (ptr = reinterpret_cast<std::remove_reference_t<decltype(ptr)>>(pool_alloc(bytes))) != nullptr;
@@ -558,6 +560,8 @@ static int rrw_open_impl(size_t log_t, const uint8_t *rs1, const uint8_t *rs2, c
         rrw_free(s);
         return ZG_ERR_NOMEM;
     }
+    const double ts1 = split ? now_ms() : 0;
+    double ts2 = ts1;
     int rc = [&]() -> int {
         SyncGuard sync(s->st);
         uint8_t *d_cols = s_cols.as<uint8_t>();
@@ -568,6 +572,10 @@ static int rrw_open_impl(size_t log_t, const uint8_t *rs1, const uint8_t *rs2, c
             uint64_t *d_rdv = s_trace.as<uint64_t>();
             int32_t *d_last = reinterpret_cast<int32_t *>(d_rdv + T);
             ZG_HIP(hipMemcpyAsync(d_rdv, rd_value, T * 8, hipMemcpyHostToDevice, s->st));
+            if (split) {
+                ZG_HIP(hipStreamSynchronize(s->st));
+                ts2 = now_ms();
+            }
             hipLaunchKernelGGL(rrw_last_write_kernel, dim3(div_up(nch * 64, 256)), dim3(256), 0, s->st, d_cols + 2 * pad, T, d_last, nch);
             hipLaunchKernelGGL(rrw_carry_scan_kernel, dim3(32), dim3(256), 0, s->st, d_last, nch);
             hipLaunchKernelGGL(rrw_regfile_kernel, dim3(div_up(nch * 64, 256)), dim3(256), 0, s->st, d_cols + 2 * pad, d_rdv, T, d_last, nch,
@@ -591,6 +599,13 @@ static int rrw_open_impl(size_t log_t, const uint8_t *rs1, const uint8_t *rs2, c
         rrw_free(s);
         set_error(keep);
         return rc;
+    }
+    if (split) {
+        SetupTimes &tm = setup_times();
+        tm = SetupTimes{};
+        tm.alloc_ms = ts1 - ts0;
+        tm.h2d_ms = ts2 - ts1;
+        tm.kernel_ms = now_ms() - ts2;
     }
     *out = s;
     return ZG_OK;

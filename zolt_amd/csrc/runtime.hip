@@ -2,6 +2,7 @@
 // kernels of libzolt_gpu.so (C ABI: include/zolt_gpu.h).
 #include <atomic>
 #include <cstdlib>
+#include <ctime>
 #include <map>
 #include <mutex>
 #include <unordered_map>
@@ -292,6 +293,19 @@ static void pinned_shutdown() {
     g_pin.resize(keep);
 }
 
+// ------------------------------------------------------------------ set-up phase split
+static thread_local SetupTimes t_setup;
+SetupTimes &setup_times() { return t_setup; }
+bool setup_times_enabled() {
+    static const bool on = [] { const char *v = getenv("ZG_SETUP_TIMES"); return v && *v && *v != '0'; }();
+    return on;
+}
+double now_ms() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
 // ------------------------------------------------------------------ profiling
 struct ProfRec { int id; hipEvent_t e0, e1; };
 static std::vector<ProfRec> g_prof;
@@ -486,6 +500,13 @@ int zg_memcpy_d2h(void *dst, const void *src, size_t bytes) {
 int zg_sync(void) {
     ZG_INIT();
     ZG_HIP(hipStreamSynchronize(lib_stream()));
+    return ZG_OK;
+}
+
+int zg_last_setup_times(double out[4]) {
+    if (!out) return ZG_ERR_INVALID;
+    const SetupTimes &t = setup_times();
+    out[0] = t.alloc_ms; out[1] = t.h2d_ms; out[2] = t.kernel_ms; out[3] = t.other_ms;
     return ZG_OK;
 }
 

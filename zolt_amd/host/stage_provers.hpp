@@ -886,14 +886,17 @@ public:
     GruenSplitEqPolynomial split_eq;
     std::vector<Fr> challenges, lagrange_evals_r0;
 
+    // ready rows of field elements (1376 bytes per cycle cross PCIe) ...
     StreamingOuterProver(const std::vector<CycleInputs> &cycle_witnesses, const std::vector<Fr> &tau, const Fr *lagrange_tau_r0 = nullptr)
-        : split_eq(std::vector<Fr>(tau.begin(), tau.end() - (tau.empty() ? 0 : 1)), lagrange_tau_r0), num_cycles_(cycle_witnesses.size()),
-          tau_high_(tau.empty() ? Fr::zero() : tau.back()) {
-        if (cycle_witnesses.empty()) throw std::invalid_argument("StreamingOuterProver: empty trace");  // error.EmptyTrace
+        : StreamingOuterProver(cycle_witnesses.empty() ? std::shared_ptr<CycleWitnessMatrix>() : CycleWitnessMatrix::fromWitnesses(cycle_witnesses.data(), cycle_witnesses.size()),
+                               tau, lagrange_tau_r0) {}
+    // ... or the shared device-resident matrix (witness.hpp: widened on the device from integer trace columns, 156 bytes per cycle)
+    StreamingOuterProver(std::shared_ptr<CycleWitnessMatrix> rows, const std::vector<Fr> &tau, const Fr *lagrange_tau_r0 = nullptr)
+        : split_eq(std::vector<Fr>(tau.begin(), tau.end() - (tau.empty() ? 0 : 1)), lagrange_tau_r0), num_cycles_(rows ? rows->num_cycles : 0),
+          tau_high_(tau.empty() ? Fr::zero() : tau.back()), d_rows_(std::move(rows)) {
+        if (num_cycles_ == 0) throw std::invalid_argument("StreamingOuterProver: empty trace");  // error.EmptyTrace
         while (padded_trace_len < num_cycles_) padded_trace_len <<= 1, num_cycle_vars++;
         if (tau.size() != num_cycle_vars + 2) throw std::invalid_argument("StreamingOuterProver: tau has num_cycle_vars + 2 challenges");
-        d_rows_.alloc(num_cycles_ * r1cs::NUM_INPUTS * 32);
-        check(zg_memcpy_h2d(d_rows_.p, cycle_witnesses.data(), num_cycles_ * r1cs::NUM_INPUTS * 32), "zg_memcpy_h2d");
         const size_t m = split_eq.tau.size() / 2;
         d_out_.alloc(((size_t(2) << m) - 1) * 32);
         d_in_.alloc(((size_t(2) << split_eq.num_x_in) - 1) * 32);
@@ -970,7 +973,7 @@ public:
         DeviceMem d_w((size_t(1) << split_eq.tau.size()) * 32);  // eq(tau_low, .): index = cycle * 2 + group (:541-566)
         check(zg_fr_eq_table_dev(reinterpret_cast<const uint64_t *>(split_eq.tau.data()), split_eq.tau.size(), nullptr, d_w.u64(), nullptr), "zg_fr_eq_table_dev");
         Fr out[18];
-        check(zg_fr_rows_affine_prodsum_dev(d_rows_.u64(), std::min(num_cycles_, padded_trace_len), r1cs::NUM_INPUTS, 0, reinterpret_cast<const uint64_t *>(m.data()), 18,
+        check(zg_fr_rows_affine_prodsum_dev(d_rows_->u64(), std::min(num_cycles_, padded_trace_len), r1cs::NUM_INPUTS, 0, reinterpret_cast<const uint64_t *>(m.data()), 18,
                                             d_w.u64(), 2, reinterpret_cast<uint64_t *>(out), nullptr), "zg_fr_rows_affine_prodsum_dev");
         std::vector<Fr> t1(19, Fr::zero());
         last_extended_evals.assign(9, Fr::zero());
@@ -1025,7 +1028,7 @@ public:
         DeviceMem d_az(n2 * 32), d_bz(n2 * 32);
         std::vector<Fr> m = constraintMatrix();
         uint64_t *tabs[2] = {d_az.u64(), d_bz.u64()};
-        check(zg_fr_rows_affine_dev(d_rows_.u64(), std::min(num_cycles_, padded_trace_len), r1cs::NUM_INPUTS, 0, reinterpret_cast<const uint64_t *>(m.data()), 2, 2,
+        check(zg_fr_rows_affine_dev(d_rows_->u64(), std::min(num_cycles_, padded_trace_len), r1cs::NUM_INPUTS, 0, reinterpret_cast<const uint64_t *>(m.data()), 2, 2,
                                     padded_trace_len, tabs, nullptr), "zg_fr_rows_affine_dev");
         s_.reset(new ProductSumcheckSession(ProductSumcheckSession::OnDevice{}, {d_az.u64(), d_bz.u64()}, n2));
         check(zg_sync(), "zg_sync");  // the session holds its own copies before the two buffers are released
@@ -1055,7 +1058,8 @@ public:
 private:
     size_t num_cycles_;
     Fr tau_high_;
-    DeviceMem d_rows_, d_out_, d_in_;
+    std::shared_ptr<CycleWitnessMatrix> d_rows_;  // shared with the other stages that read the witness matrix
+    DeviceMem d_out_, d_in_;
     std::unique_ptr<ProductSumcheckSession> s_;
 };
 

@@ -1,0 +1,245 @@
+// witness.hpp — the R1CS cycle inputs as INTEGER COLUMNS and the device-resident witness matrix built from them.
+// Part of zolt_host.hpp (the C++ host mirror over include/zolt_gpu.h); included by it, after the parts it depends on.
+//
+// The reference widens every input of every cycle to a field element on the CPU (R1CSWitnessGenerator.generateWitness,
+// src/zkvm/r1cs/constraints.zig:1469-1494: createNoopWitness :1418-1438, fromTraceStep :929-1223) and the stage provers read that
+// 43-column matrix. Every one of those values is F.fromU64 of a machine word, signedI64ToField of an immediate (:868-876), a 0/1 flag,
+// or a sum / product of two such values, so the row also exists as 156 bytes of integers; zg_fr_rows_from_columns widens them in HBM to
+// the identical 1376-byte row. CycleColumns::fromTrace is the integer-domain restatement of the generator (what a Zig shim computes in
+// place of the field-element rows); CycleWitnessMatrix is the ONE resident matrix the stages share.
+#pragma once
+#ifndef ZOLT_HOST_UMBRELLA
+#error "include zolt_host.hpp"
+#endif
+namespace zolt {
+
+// tracer.TraceStep as fromTraceStep reads it (src/tracer/mod.zig:14-45)
+struct R1CSTraceStep {
+    uint32_t instruction = 0;
+    uint64_t pc = 0, unexpanded_pc = 0, rs1_value = 0, rs2_value = 0, rd_value = 0;
+    bool has_memory_value = false;
+    uint64_t memory_value = 0;
+    bool is_compressed = false, is_noop = false;
+};
+
+struct CycleColumns {
+    static constexpr size_t NUM_INPUTS = 43;
+    // R1CSInputIndex (:38-86) of the columns by storage class
+    static constexpr int U64_INPUTS[12] = {0, 6, 7, 10, 11, 12, 13, 14, 15, 17, 18, 21};  // Left, PC, UnexpandedPC, Rs1, Rs2, RdWrite, RamRead, RamWrite, LeftLookup, NextUnexpandedPC, NextPC, LookupOutput
+    static constexpr int WIDE_INPUTS[3] = {1, 9, 16};                                      // RightInstructionInput, RamAddress, RightLookupOperand
+    static constexpr int BIT_INPUTS[24] = {3, 4, 5, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42};
+    enum Bit : uint32_t { WriteLookupOutputToRD, WritePCtoRD, ShouldBranch, ShouldJump, AddOperands, SubtractOperands, MultiplyOperands, Load, Store, Jump,
+                          WriteLookupOutputToRDFlag, VirtualInstruction, Assert, DoNotUpdateUnexpandedPC, Advice, IsCompressed, IsFirstInSequence, IsRdNotZero,
+                          Branch, IsNoop, LeftOperandIsRs1, LeftOperandIsPC, RightOperandIsRs2, RightOperandIsImm };
+
+    size_t n = 0;
+    std::vector<uint64_t> u64[12];
+    std::vector<int64_t> imm;
+    std::vector<uint64_t> wide[3];  // 2 words per row: 128-bit two's complement
+    std::vector<Fr> wide_fr;        // RightLookupOperand as ready elements when a row does not fit 128-bit two's complement
+    std::vector<uint32_t> word;     // the 24 single-bit inputs of a cycle
+
+    explicit CycleColumns(size_t cycles = 0) { resize(cycles); }
+    void resize(size_t cycles) {
+        n = cycles;
+        for (auto &c : u64) c.assign(n, 0);
+        for (auto &c : wide) c.assign(2 * n, 0);
+        imm.assign(n, 0);
+        word.assign(n, 0);
+        wide_fr.clear();
+    }
+    static int64_t sx(uint64_t v, int bits) { return (int64_t)(v << (64 - bits)) >> (64 - bits); }
+    static int64_t immOf(uint32_t w) {  // deriveImmediate (:1226-1274) as a signed integer
+        const uint32_t op = w & 0x7F;
+        if (op == 0x13 || op == 0x03 || op == 0x67) return sx(w >> 20, 12);
+        if (op == 0x23) return sx((((w >> 25) & 0x7F) << 5) | ((w >> 7) & 0x1F), 12);
+        if (op == 0x63) return sx((((w >> 31) & 1) << 12) | (((w >> 7) & 1) << 11) | (((w >> 25) & 0x3F) << 5) | (((w >> 8) & 0xF) << 1), 13);
+        if (op == 0x6F) return sx((((w >> 31) & 1) << 20) | (((w >> 12) & 0xFF) << 12) | (((w >> 20) & 1) << 11) | (((w >> 21) & 0x3FF) << 1), 21);
+        if (op == 0x37 || op == 0x17) return (int64_t)(w & 0xFFFFF000u);
+        return 0;
+    }
+    static bool nextIsNoop(const R1CSTraceStep *s) {  // isNoopInstruction (:569-595)
+        if (!s) return false;
+        if (s->is_noop) return true;
+        const uint32_t w = s->instruction;
+        return (w & 0x7F) == 0x13 && ((w >> 7) & 31) == 0 && ((w >> 15) & 31) == 0 && ((w >> 12) & 7) == 0 && (w >> 20) == 0;
+    }
+    void setWide(int k, size_t i, __int128 v) {
+        wide[k][2 * i] = (uint64_t)(unsigned __int128)v;
+        wide[k][2 * i + 1] = (uint64_t)((unsigned __int128)v >> 64);
+    }
+    static Fr fromU128(unsigned __int128 m) {
+        const Fr two64 = Fr::fromU64(uint64_t(1) << 32).mul(Fr::fromU64(uint64_t(1) << 32));
+        return Fr::fromU64((uint64_t)(m >> 64)).mul(two64).add(Fr::fromU64((uint64_t)m));
+    }
+
+    // the integer-domain restatement of generateWitness over a NoOp-padded trace
+    static CycleColumns fromTrace(const std::vector<R1CSTraceStep> &steps) {
+        CycleColumns c(steps.size());
+        // RightLookupOperand per row as (negative?, magnitude): a full-width MUL does not fit 128-bit two's complement
+        std::vector<uint8_t> lo_neg(c.n, 0);
+        std::vector<unsigned __int128> lo_mag(c.n, 0);
+        bool lo_fits = true;
+        auto &Left = c.u64[0], &PC = c.u64[1], &UPC = c.u64[2], &Rs1 = c.u64[3], &Rs2 = c.u64[4], &RdW = c.u64[5], &RamR = c.u64[6], &RamW = c.u64[7], &LeftLookup = c.u64[8],
+             &NextUPC = c.u64[9], &NextPC = c.u64[10], &Lookup = c.u64[11];
+        for (size_t i = 0; i < c.n; i++) {
+            const R1CSTraceStep &st = steps[i];
+            uint32_t bits = 0;
+            auto set = [&](Bit b) { bits |= 1u << b; };
+            if (st.is_noop) {  // createNoopWitness (:1418-1438)
+                set(DoNotUpdateUnexpandedPC);
+                set(IsNoop);
+                c.word[i] = bits;
+                continue;
+            }
+            const R1CSTraceStep *nx = i + 1 < c.n ? &steps[i + 1] : nullptr;
+            const uint32_t w = st.instruction, op = w & 0x7F, f3 = (w >> 12) & 7, f7 = (w >> 25) & 0x7F, rd = (w >> 7) & 31;
+            const bool load = op == 0x03, store = op == 0x23, branch = op == 0x63;
+            if (load) set(Load);
+            if (store) set(Store);
+            if (st.is_compressed) set(IsCompressed);
+            const int64_t im = immOf(w);
+            c.imm[i] = im;
+            const bool reads1 = op == 0x13 || op == 0x03 || op == 0x67 || op == 0x1B || op == 0x33 || op == 0x3B || op == 0x23 || op == 0x63;  // :957-977
+            const bool reads2 = op == 0x33 || op == 0x3B || op == 0x23 || op == 0x63;                                                           // :986-993
+            const uint64_t rs1 = reads1 ? st.rs1_value : 0, rs2 = reads2 ? st.rs2_value : 0;
+            Rs1[i] = rs1;
+            Rs2[i] = rs2;
+            if (load || store) c.setWide(1, i, (__int128)st.rs1_value + im);  // RamAddress = rs1 + imm in the field (:1001-1009)
+            const uint64_t mem = st.has_memory_value ? st.memory_value : 0;
+            if (load) RamR[i] = RamW[i] = RdW[i] = mem;                        // :1023-1047
+            else if (store) { RamR[i] = mem; RamW[i] = st.rs2_value; }
+            else if (!branch && rd != 0) RdW[i] = st.rd_value;
+            const bool l_rs1 = op == 0x33 || op == 0x13 || op == 0x03 || op == 0x67 || op == 0x23 || op == 0x63 || op == 0x1B || op == 0x3B;  // :1059-1098
+            const bool l_pc = op == 0x17 || op == 0x6F, r_rs2 = op == 0x33 || op == 0x63 || op == 0x3B;
+            const bool r_imm = op == 0x13 || op == 0x03 || op == 0x67 || op == 0x23 || op == 0x37 || op == 0x17 || op == 0x6F || op == 0x1B;
+            if (l_rs1) set(LeftOperandIsRs1);
+            if (l_pc) set(LeftOperandIsPC);
+            if (r_rs2) set(RightOperandIsRs2);
+            if (r_imm) set(RightOperandIsImm);
+            const uint64_t left = l_rs1 ? rs1 : (l_pc ? st.unexpanded_pc : 0);                                  // :1106-1118
+            const __int128 right = r_rs2 ? (__int128)rs2 : (r_imm ? (__int128)im : (__int128)0);
+            Left[i] = left;
+            c.setWide(0, i, right);
+            uint64_t lookup;  // computeLookupOutput (:600-640)
+            if (op == 0x6F) lookup = st.pc + (uint64_t)im;
+            else if (op == 0x67) lookup = (st.rs1_value + (uint64_t)sx(w >> 20, 12)) & ~uint64_t(1);
+            else if (branch) {
+                const uint64_t a = st.rs1_value, b = st.rs2_value;
+                const int64_t sa = (int64_t)a, sb = (int64_t)b;
+                lookup = f3 == 0 ? a == b : f3 == 1 ? a != b : f3 == 4 ? sa < sb : f3 == 5 ? sa >= sb : f3 == 6 ? a < b : f3 == 7 ? a >= b : 0;
+            } else lookup = st.rd_value;
+            Lookup[i] = lookup;
+            PC[i] = st.pc;
+            UPC[i] = st.unexpanded_pc;
+            if (nx && !nx->is_noop) { NextPC[i] = nx->pc; NextUPC[i] = nx->unexpanded_pc; }  // :1150-1172
+            // setFlagsFromInstruction (:1288-1398): circuit flags and the two lookup operands
+            bool wl = false, jump = false, zero_left = false, neg = right < 0;
+            unsigned __int128 mag = neg ? (unsigned __int128)(-right) : (unsigned __int128)right;  // default: the operands pass through
+            auto sum = [&](__int128 v) { neg = v < 0; mag = neg ? (unsigned __int128)(-v) : (unsigned __int128)v; };
+            if (op == 0x33) {
+                if (f7 == 0x01) {
+                    if (f3 == 0) {
+                        set(MultiplyOperands);
+                        zero_left = true;
+                        neg = right < 0 && left != 0;
+                        mag = (unsigned __int128)left * (uint64_t)(right < 0 ? -right : right);  // |right| < 2^64: the product is < 2^128
+                    }
+                } else if (f7 == 0x20 && f3 == 0) {
+                    set(SubtractOperands);
+                    zero_left = true;
+                    sum((__int128)left - right + ((__int128)1 << 64));
+                } else {
+                    set(AddOperands);
+                    zero_left = true;
+                    sum((__int128)left + right);
+                }
+                wl = true;
+            } else if (op == 0x13 || op == 0x37 || op == 0x17) {
+                set(AddOperands);
+                zero_left = true;
+                sum((__int128)left + right);
+                wl = true;
+            } else if (op == 0x6F || op == 0x67) {
+                set(AddOperands);
+                zero_left = true;
+                sum((__int128)left + right);
+                jump = true;
+            }
+            LeftLookup[i] = zero_left ? 0 : left;
+            lo_neg[i] = neg;
+            lo_mag[i] = mag;
+            if (neg ? mag > ((unsigned __int128)1 << 127) : mag >= ((unsigned __int128)1 << 127)) lo_fits = false;
+            if (wl) set(WriteLookupOutputToRDFlag);
+            if (jump) {
+                set(Jump);
+                if (!nextIsNoop(nx)) set(ShouldJump);  // :1181-1185
+            }
+            if (rd != 0) {  // :1190-1215
+                set(IsRdNotZero);
+                if (wl) set(WriteLookupOutputToRD);
+                if (jump) set(WritePCtoRD);
+            }
+            if (branch) {
+                set(Branch);
+                if (lookup) set(ShouldBranch);
+            }
+            c.word[i] = bits;
+        }
+        if (lo_fits) {
+            for (size_t i = 0; i < c.n; i++) c.setWide(2, i, lo_neg[i] ? -(__int128)lo_mag[i] : (__int128)lo_mag[i]);
+        } else {  // the column crosses as ready field elements (32 instead of 16 bytes per cycle for this one input)
+            c.wide_fr.resize(c.n);
+            for (size_t i = 0; i < c.n; i++) c.wide_fr[i] = lo_neg[i] ? Fr::zero().sub(fromU128(lo_mag[i])) : fromU128(lo_mag[i]);
+        }
+        return c;
+    }
+
+    // the 43 descriptors of zg_fr_rows_from_columns, in R1CSInputIndex order
+    std::vector<zg_col_t> descriptors() const {
+        std::vector<zg_col_t> d(NUM_INPUTS, zg_col_t{ZG_COL_ZERO, 0, 0, nullptr});  // NextIsVirtual, NextIsFirstInSequence stay zero (:1160-1171)
+        for (int k = 0; k < 12; k++) d[U64_INPUTS[k]] = zg_col_t{ZG_COL_U64, 0, 0, u64[k].data()};
+        d[8] = zg_col_t{ZG_COL_I64, 0, 0, imm.data()};
+        for (int k = 0; k < 3; k++) d[WIDE_INPUTS[k]] = zg_col_t{ZG_COL_I128, 0, 0, wide[k].data()};
+        if (!wide_fr.empty()) d[16] = zg_col_t{ZG_COL_FR, 0, 0, wide_fr.data()};
+        d[2] = zg_col_t{ZG_COL_MUL, 0, 1, nullptr};  // Product = LeftInstructionInput * RightInstructionInput (:1120-1122)
+        for (uint32_t b = 0; b < 24; b++) d[BIT_INPUTS[b]] = zg_col_t{ZG_COL_BIT, b, 4, word.data()};
+        return d;
+    }
+    size_t bytesPerCycle() const { return 12 * 8 + 8 + 2 * 16 + (wide_fr.empty() ? 16 : 32) + 4; }
+};
+
+// The cycle-major witness matrix (num_cycles x 43 elements, src/zkvm/r1cs/evaluation.zig:55-122) resident in HBM: built once, shared by
+// the stages that read it (StreamingOuterProver, R1CSInputEvaluator, the product-virtualisation first round, Stage3Prover).
+class CycleWitnessMatrix {
+public:
+    size_t num_cycles = 0;
+    static std::shared_ptr<CycleWitnessMatrix> fromColumns(const CycleColumns &c) {
+        auto m = std::make_shared<CycleWitnessMatrix>();
+        m->num_cycles = c.n;
+        m->d_.alloc(c.n * CycleColumns::NUM_INPUTS * 32);
+        const auto d = c.descriptors();
+        check(zg_fr_rows_from_columns(d.data(), d.size(), c.n, m->d_.u64()), "zg_fr_rows_from_columns");
+        return m;
+    }
+    static std::shared_ptr<CycleWitnessMatrix> fromTrace(const std::vector<R1CSTraceStep> &steps) { return fromColumns(CycleColumns::fromTrace(steps)); }
+    // ready rows of field elements (R1CSCycleInputs.values per cycle): the 1376-bytes-per-cycle upload of rounds 3 and 4
+    static std::shared_ptr<CycleWitnessMatrix> fromWitnesses(const void *rows, size_t cycles) {
+        auto m = std::make_shared<CycleWitnessMatrix>();
+        m->num_cycles = cycles;
+        m->d_.alloc(cycles * CycleColumns::NUM_INPUTS * 32);
+        check(zg_memcpy_h2d(m->d_.p, rows, cycles * CycleColumns::NUM_INPUTS * 32), "zg_memcpy_h2d");
+        return m;
+    }
+    const uint64_t *u64() const { return d_.u64(); }
+    std::vector<Fr> toHost() const {
+        std::vector<Fr> out(num_cycles * CycleColumns::NUM_INPUTS);
+        if (!out.empty()) check(zg_memcpy_d2h(out.data(), d_.p, out.size() * 32), "zg_memcpy_d2h");
+        return out;
+    }
+
+private:
+    DeviceMem d_;
+};
+
+}  // namespace zolt

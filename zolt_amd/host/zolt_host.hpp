@@ -60,5 +60,6 @@ struct DeviceMem {
 #include "sumcheck.hpp"
 #include "product_provers.hpp"
 #include "wire.hpp"
+#include "witness.hpp"
 #include "stage_provers.hpp"
 #include "lasso.hpp"

@@ -574,6 +574,60 @@ def fr_rows_affine(rows, coeffs, ntab, g, n_pad=None, k=None):
     return outs
 
 
+COL_ZERO, COL_U8, COL_U32, COL_U64, COL_I64, COL_I128, COL_U128, COL_FR, COL_BIT, COL_MUL = range(10)
+_COL_DTYPE = {COL_U8: np.uint8, COL_U32: np.uint32, COL_U64: np.uint64, COL_I64: np.int64, COL_I128: np.uint64, COL_U128: np.uint64, COL_FR: np.uint64}
+
+
+class Column(C.Structure):
+    """zg_col_t: one typed integer column of zg_fr_rows_from_columns"""
+    _fields_ = [("kind", C.c_uint32), ("a", C.c_uint32), ("b", C.c_uint32), ("data", C.c_void_p)]
+
+
+def _columns(cols, n_rows, device):
+    """cols: list of (kind, data, a, b) — data a numpy array (host) or a device address (device=True), None for COL_ZERO / COL_MUL"""
+    arr = (Column * len(cols))()
+    keep = []
+    for i, spec in enumerate(cols):
+        kind, data = spec[0], spec[1] if len(spec) > 1 else None
+        a, b = (spec[2] if len(spec) > 2 else 0), (spec[3] if len(spec) > 3 else 0)
+        ptr = None
+        if data is not None:
+            if device:
+                ptr = int(data)
+            else:
+                dt = _COL_DTYPE.get(kind) or {1: np.uint8, 4: np.uint32, 8: np.uint64}[b]
+                h = np.ascontiguousarray(data, dtype=dt)
+                per = {COL_I128: 2, COL_U128: 2, COL_FR: 4}.get(kind, 1)
+                assert h.size == n_rows * per, (i, kind, h.shape, n_rows)
+                keep.append(h)
+                ptr = h.ctypes.data
+        arr[i] = Column(kind, a, b, ptr)
+    return arr, keep
+
+
+def fr_rows_from_columns(cols, n_rows, d_rows=None):
+    """The witness matrix built on the device from integer columns (zg_fr_rows_from_columns): rows[row][c] = column c's value at `row`
+    as a Montgomery element. d_rows: a device address to fill (returns None); None: the (n_rows, n_cols, 4) matrix comes back to the host."""
+    arr, keep = _columns(cols, n_rows, device=False)
+    buf = None
+    if d_rows is None:
+        buf = DeviceBuffer(max(n_rows * len(cols) * 32, 32))
+        d_rows = buf.ptr
+    _chk(_lib.zg_fr_rows_from_columns(arr, C.c_size_t(len(cols)), C.c_size_t(n_rows), _d(d_rows)), "zg_fr_rows_from_columns")
+    del keep
+    if buf is None:
+        return None
+    out = buf.to_host()[:n_rows * len(cols) * 4].reshape(n_rows, len(cols), 4)
+    buf.free()
+    return out
+
+
+def fr_rows_from_columns_dev(cols, n_rows, d_rows, stream=0):
+    """the same with the columns resident in HBM (data = device addresses); asynchronous"""
+    arr, _ = _columns(cols, n_rows, device=True)
+    _chk(_lib.zg_fr_rows_from_columns_dev(arr, C.c_size_t(len(cols)), C.c_size_t(n_rows), _d(d_rows), _d(stream)), "zg_fr_rows_from_columns_dev")
+
+
 def fr_lt_table(r):
     """out[j] = LtPolynomial(r).evaluateAtIndex(j) over the cube (zg_fr_lt_table); index bit i <-> r[i]"""
     r = _c(np.asarray(r, dtype=np.uint64).reshape(-1, 4))
