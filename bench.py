@@ -111,24 +111,130 @@ def closed_form_scalar(raw, start):
     return tot % R_MOD
 
 
+RANK_LOG_DIR = os.environ.get("ZOLT_BENCH_LOG_DIR") or os.path.join(ROOT, "gpurun_out", "bench_ranks")
+STALL_LIMIT_S = float(os.environ.get("ZOLT_BENCH_STALL_S", "120"))
+
+
+class Watchdog:
+    """A rank that makes no progress for STALL_LIMIT_S seconds must not hang the job (an RCCL collective that never completes waits for
+    ever): a daemon thread in every rank watches a heartbeat the main thread advances at every phase and step; on a stall it writes where
+    the rank stood (phase, all thread tracebacks) to RANK_LOG_DIR/rank<r>.log and to stderr and ends THIS process with exit code 3 —
+    torch.distributed.run (or self_launch below) then takes the other ranks down. Nothing is re-executed; the heartbeat file
+    rank<r>.beat is also what the self-launcher polls."""
+
+    def __init__(self, rank, world):
+        import threading
+        self.rank, self.world, self.phase, self.limit = rank, world, "start", STALL_LIMIT_S
+        self.last = time.monotonic()
+        self.log = self.beat_path = None
+        try:
+            os.makedirs(RANK_LOG_DIR, exist_ok=True)
+            self.log = open(os.path.join(RANK_LOG_DIR, f"rank{rank}.log"), "w")
+            self.beat_path = os.path.join(RANK_LOG_DIR, f"rank{rank}.beat")
+        except OSError:
+            pass
+        self.note(f"rank {rank} of {world}, pid {os.getpid()}, argv {sys.argv[1:]}")
+        threading.Thread(target=self._watch, daemon=True).start()
+
+    def note(self, msg):
+        if self.log:
+            self.log.write(f"[{time.strftime('%H:%M:%S')}] {msg}\n")
+            self.log.flush()
+
+    def beat(self, phase=None, limit=None):
+        """progress: the stall clock restarts; `limit` widens it for one known-long phase (a child process, the CPU baseline)"""
+        if phase is not None and phase != self.phase:
+            self.phase = phase
+            self.note(phase)
+        self.limit = limit if limit is not None else STALL_LIMIT_S
+        self.last = time.monotonic()
+        if self.beat_path:
+            try:
+                with open(self.beat_path, "w") as fh:
+                    fh.write(f"{time.time():.3f} {self.limit:.0f} {self.phase}\n")
+            except OSError:
+                pass
+
+    def _watch(self):
+        import faulthandler
+        while True:
+            time.sleep(2.0)
+            idle = time.monotonic() - self.last
+            if idle > self.limit:
+                msg = f"bench.py rank {self.rank}: no progress for {idle:.0f} s in phase '{self.phase}' (limit {self.limit:.0f} s): giving up"
+                for fh in (self.log, sys.stderr):
+                    if fh:
+                        try:
+                            fh.write(msg + "\n")
+                            faulthandler.dump_traceback(file=fh, all_threads=True)
+                            fh.flush()
+                        except (OSError, ValueError):
+                            pass
+                os._exit(3)
+
+
 def self_launch(n):
-    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU, the env torch.distributed.run would
-    set, rendezvous on 127.0.0.1) and relay rank 0's output. Nothing in this parent process has touched a GPU."""
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one FRESH process per GPU, the env torch.distributed.run would
+    set, rendezvous on 127.0.0.1), relay rank 0's output, keep every rank's stderr (and the other ranks' stdout) in RANK_LOG_DIR, and
+    watch them: when a rank exits non-zero, or its heartbeat (Watchdog) goes stale, the launcher kills exactly the children it
+    started and exits non-zero with a JSON line that names the rank. Nothing in this parent process ever touches a GPU."""
     import socket
     import subprocess
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    procs = []
+    os.makedirs(RANK_LOG_DIR, exist_ok=True)
+    for r in range(n):
+        try:
+            os.remove(os.path.join(RANK_LOG_DIR, f"rank{r}.beat"))
+        except OSError:
+            pass
+    procs, files = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port))
+                   MASTER_PORT=str(port), ZOLT_BENCH_LOG_DIR=RANK_LOG_DIR)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
+        err = open(os.path.join(RANK_LOG_DIR, f"rank{r}.stderr"), "w")
+        out = None if r == 0 else open(os.path.join(RANK_LOG_DIR, f"rank{r}.stdout"), "w")
+        files += [f for f in (err, out) if f]
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out, stderr=err))
+    t_start, failed = time.time(), None
+    while failed is None and any(pr.poll() is None for pr in procs):
+        time.sleep(1.0)
+        for r, pr in enumerate(procs):
+            rc = pr.poll()
+            if rc not in (None, 0):
+                failed = (r, f"exit code {rc}")
+                break
+            if rc is None:
+                try:
+                    with open(os.path.join(RANK_LOG_DIR, f"rank{r}.beat")) as fh:
+                        stamp, limit, phase = fh.read().split(None, 2)
+                    if time.time() - float(stamp) > float(limit) + 15.0:  # the rank's own watchdog should have fired: it is wedged below Python
+                        failed = (r, f"heartbeat stale for {time.time() - float(stamp):.0f} s in phase '{phase.strip()}'")
+                        break
+                except (OSError, ValueError):
+                    if time.time() - t_start > STALL_LIMIT_S + 60.0:  # never got as far as its first heartbeat
+                        failed = (r, "no heartbeat since launch")
+                        break
+    for pr in procs:
+        if failed is not None and pr.poll() is None:
+            pr.kill()  # exactly the processes started above
     rc = 0
     for pr in procs:
-        rc = max(rc, pr.wait())
+        rc = max(rc, abs(pr.wait()))
+    for f in files:
+        f.close()
+    if failed is not None:
+        r, why = failed
+        tail = ""
+        try:
+            with open(os.path.join(RANK_LOG_DIR, f"rank{r}.stderr")) as fh:
+                tail = fh.read()[-1500:]
+        except OSError:
+            pass
+        print(json.dumps({"error": f"bench.py --gpus {n}: rank {r} failed ({why}); all ranks stopped", "rank": r, "logs": RANK_LOG_DIR, "stderr_tail": tail}))
+        return rc or 3
     return rc
 
 
@@ -225,10 +331,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    fault = os.environ.get("ZOLT_BENCH_FAULT", "")  # supervision self-test (tests/test_bench_supervision.py, CPU): "stall:<rank>" / "exit:<rank>"
+    if fault and int(fault.split(":")[1]) == rank:
+        if fault.startswith("exit"):
+            raise SystemExit(7)
+        Watchdog(rank, world).beat("injected stall")
+        time.sleep(3600)
+    elif fault:
+        Watchdog(rank, world).beat("healthy rank waiting on a peer that never arrives", limit=3600)
+        time.sleep(3600)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or without a launcher)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libzolt_gpu has no CPU fallback)")
+    wd = Watchdog(rank, world)  # a stalled rank ends itself after STALL_LIMIT_S: a hung collective must not hang the driver
     # one process per GPU; ZOLT_BENCH_DIST_BACKEND=gloo lets several ranks share one GPU to exercise the
     # sharded path on a 1-GPU box (RCCL refuses two ranks on one device) — never used for reported numbers
     dist_backend = os.environ.get("ZOLT_BENCH_DIST_BACKEND", "nccl")
@@ -246,8 +362,10 @@ def main():
         else:
             dist.init_process_group(dist_backend)
 
+    wd.beat("process group up")
     from zolt_amd import api, lib
     lib.init(local_rank)
+    wd.beat("library initialised")
 
     # all work runs on an explicit (non-default) torch stream: the C ABI treats a NULL stream as "the library's own
     # stream", which is not ordered with torch's legacy default stream (handle 0)
@@ -274,6 +392,7 @@ def main():
         n_loc = end - start
 
         # ---- synthetic inputs, generated with the product's own kernels (untimed)
+        wd.beat(f"2^{logn}: generating inputs")
         t0 = time.time()
         ks = np.zeros((n_loc, 4), dtype=np.uint64)
         ks[:, 0] = np.arange(start + 1, end + 1, dtype=np.uint64)
@@ -295,6 +414,7 @@ def main():
             d_scalars.append(torch.from_numpy(sm.view(np.int64)).to(dev))
             expect_k.append(closed_form_scalar(raw, start))
         setup_s = time.time() - t0
+        wd.beat(f"2^{logn}: inputs resident, table built")
 
         backend = api.GpuShardBackend(bases, n_loc)
         sharded = api.ShardedMSM(backend, world, rank)
@@ -321,13 +441,16 @@ def main():
 
         for i in range(warmup):
             step(i)
+            wd.beat(f"2^{logn}: warmup")
         barrier()
+        wd.beat(f"2^{logn}: timed region")
 
         t0 = time.perf_counter()
         for i in range(steps):
             step(i)
         barrier()
         elapsed = time.perf_counter() - t0
+        wd.beat(f"2^{logn}: timed region done")  # (no heartbeat inside the timed region: a file write per step would be in it)
 
         # outside the timed region (no instrumentation inside it): the same issue pattern once more with HIP-event brackets around
         # every kernel group — the durations of kernels that SHARE the GPU with the other streams' work ("overlapped", transparency only)
@@ -336,6 +459,7 @@ def main():
             step(i)
         barrier()
         prof = lib.profile_end()
+        wd.beat(f"2^{logn}: profiled legs")
 
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist_backend == "nccl" else "cpu")
         if world > 1:
@@ -362,6 +486,7 @@ def main():
         for j in range(steps * per_step):
             wxy, winf = want[j % N_SCALAR_SETS]
             assert int(res[j, 8] & 0xFF) == winf and np.array_equal(res[j, :8], wxy), f"MSM result mismatch at MSM {j}"
+        wd.beat(f"2^{logn}: every timed result checked")
 
         return {"n": n, "n_loc": n_loc, "elapsed": elapsed, "prof": prof, "prof_alone": prof_alone, "setup_s": setup_s, "bases_xy": bases_xy,
                 "table_build_ms": table_build_ms, "table_bytes": bases.table_bytes(),
@@ -396,6 +521,7 @@ def main():
 
     sharded_sc = None
     if use_dist and not args.no_extra and world & (world - 1) == 0:
+        wd.beat("sharded sumcheck")
         sharded_sc = sharded_sumcheck_measurement(lib, api, torch, dist, dev, stream, world, rank, dist_backend)
 
     # the one-process / several-GPU C ABI on the same devices (extra, never the headline): rank 0 runs it as a child process while
@@ -407,11 +533,13 @@ def main():
             bases = None
         torch.cuda.empty_cache()
         host_pg = dist.new_group(backend="gloo") if use_dist and world > 1 else None
+        wd.beat("single-process child (rank 0 runs it, the others wait on a host barrier)", limit=400)
         if rank == 0:
             single_proc = single_process_child(min(world, torch.cuda.device_count()))  # (the gloo debugging mode shares one GPU)
         if host_pg is not None:
             dist.barrier(group=host_pg)
 
+    wd.beat("results")
     if rank != 0:
         dist.destroy_process_group()
         return
@@ -507,6 +635,7 @@ def main():
         out["extra"]["msm_2^22_sharded"] = sharded_22
     if not args.no_extra and world == 1:
         # the host-buffer entry point (what an unmodified MSM.compute call site pays): scalars cross PCIe every call
+        wd.beat("extras (child processes for 2^22, the table-less plan and the compiled host loops)", limit=1500)
         h_sc = d_scalars[0].cpu().numpy().view(np.uint64)
         bases.msm(h_sc)
         t0 = time.perf_counter()
@@ -527,6 +656,7 @@ def main():
                 "note": "table_build_ms / (table-less ms per MSM - table ms per MSM); below this many MSMs over one SRS the table-less plan "
                         "(zg_msm_config.expected_uses = 1) is the faster choice"}
     if not args.no_cpu_baseline and world == 1:
+        wd.beat("cpu baseline", limit=600)
         out["cpu_baseline"] = cpu_baseline(bases_xy, d_scalars[0].cpu().numpy().view(np.uint64), want[0], args.logn)
     print(json.dumps(out))
     if use_dist:
