@@ -290,20 +290,13 @@ def _n_gpus():
     return lib.device_count()
 
 
-@pytest.mark.skipif(_n_gpus() < 2, reason="needs at least two GPUs in this box (the real RCCL all-gather over xGMI)")
-def test_real_devices_rccl_all_gather(env, monkeypatch):
-    """On a multi-GPU box: one shard per physical device, partials exchanged by the grouped ncclAllGather, combined on device 0 —
-    single MSM, prefix, batch, and the sharded sumcheck session across the devices. Skipped on the one-GPU test box."""
-    api, lib, ob, gm = env
-    monkeypatch.delenv("ZG_SHARDS", raising=False)
-    monkeypatch.delenv("ZG_SHARD_EXCHANGE", raising=False)
-    nd = min(_n_gpus(), 8)
-    lib.init_devices(nd)
-    assert lib.n_devices() >= nd
+def _several_shards_body(lib, ob, gm, n_shards, exchange, devices):
+    """the body of the >= 2-GPU test, parametrised by where the shards live: single MSM, prefixes, a batch, the pipelined entry points,
+    and the sharded sumcheck session in both layouts"""
     sb = lib.ShardedBases.upload(gm)
     try:
-        assert len(sb.shards()) == lib.n_devices() and sb.exchange() == "rccl"
-        assert sorted(d for d, _, _ in sb.shards()) == list(range(lib.n_devices()))
+        assert len(sb.shards()) == n_shards and sb.exchange() == exchange
+        assert sorted(d for d, _, _ in sb.shards()) == devices
         sc = _rand(ob, 1700, N)
         for n in (N, N // 2 + 1, 3):
             want = ob.msm_g1(gm[:n], None, sc[:n])
@@ -314,6 +307,12 @@ def test_real_devices_rccl_all_gather(env, monkeypatch):
         for j in range(5):
             w, wi = ob.msm_g1(gm, None, batches[j])
             assert inf[j] == wi and np.array_equal(out[j], w)
+        # several calls in flight on the handle's slots (several slots' exchanges on one communicator)
+        tickets = [sb.msm_batch_async([batches[j]]) for j in range(min(sb.inflight(), 5))]
+        for j, (t, k, keep) in enumerate(tickets):
+            o, fl = sb.wait(t, k)
+            w, wi = ob.msm_g1(gm, None, batches[j])
+            assert fl[0] == wi and np.array_equal(o[0], w), j
     finally:
         sb.free()
     for layout in (lib.SC_HIGH_HALF, lib.SC_LOW_PAIR):
@@ -332,6 +331,33 @@ def test_real_devices_rccl_all_gather(env, monkeypatch):
             assert np.array_equal(s.final(), cur[0])
         finally:
             s.close()
+
+
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs at least two GPUs in this box (the real RCCL all-gather over xGMI)")
+def test_real_devices_rccl_all_gather(env, monkeypatch):
+    """On a multi-GPU box: one shard per physical device, partials exchanged by the grouped ncclAllGather, combined on device 0 —
+    single MSM, prefix, batch, pipelined calls, and the sharded sumcheck session across the devices. Skipped on the one-GPU test box;
+    test_two_logical_shards_same_body below runs the same body there."""
+    api, lib, ob, gm = env
+    monkeypatch.delenv("ZG_SHARDS", raising=False)
+    monkeypatch.delenv("ZG_SHARD_EXCHANGE", raising=False)
+    nd = min(_n_gpus(), 8)
+    lib.init_devices(nd)
+    assert lib.n_devices() >= nd
+    _several_shards_body(lib, ob, gm, lib.n_devices(), "rccl", list(range(lib.n_devices())))
+
+
+def test_two_logical_shards_same_body(env, monkeypatch):
+    """The body of the >= 2-GPU test with ZG_SHARDS = 2 on ONE device: every branch of csrc/sharded.hip that does not need a second
+    physical GPU runs — partition, per-shard worker threads and launch sets, slot pipeline, gather order, combine, the sharded session's
+    local rounds and its residual rounds — with the partials exchanged by peer copies. What remains unexecuted on a one-GPU box is
+    exactly the collective among SEVERAL communicator ranks: `ncclGroupStart .. ncclAllGather x S .. ncclGroupEnd` with S > 1 in
+    the EX_RCCL branch of csrc/sharded.hip's exchange step (its S = 1 form runs in test_rccl_exchange_at_one_device) and ncclCommInitAll over
+    more than one device (comms_acquire)."""
+    api, lib, ob, gm = env
+    monkeypatch.setenv("ZG_SHARDS", "2")
+    monkeypatch.delenv("ZG_SHARD_EXCHANGE", raising=False)
+    _several_shards_body(lib, ob, gm, 2, "p2p", [0, 0])
 
 
 def test_sharded_entry_points_reject_bad_arguments(env, monkeypatch):

@@ -59,7 +59,7 @@ def calibration(root):
             c = [0.0, 0]
             for f in glob.glob(os.path.join(root, f"cal_{mode}", "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if row.get("Counter_Name") == "FETCH_SIZE":
+                    if row.get("Counter_Name") == "FETCH_SIZE" and f"k_{mode}64" in row.get("Kernel_Name", ""):  # not the buffer fills in front
                         c[0] += float(row["Counter_Value"]); c[1] += 1
             out[mode] = {"bytes_per_launch_MB": mb, "FETCH_SIZE_KB_avg": c[0] / c[1] if c[1] else None,
                          "reported_over_actual": (c[0] / c[1] * 1024 / (mb * 1e6)) if c[1] else None}
