@@ -76,7 +76,7 @@ extern "C" {
  *             compile with -DZG_NO_PROTOCOL_SESSIONS to leave them out of the binding; zg_abi_features() reports whether the loaded
  *             library carries them. */
 #define ZG_ABI_MAJOR 1
-#define ZG_ABI_MINOR 5
+#define ZG_ABI_MINOR 6
 #define ZG_FEATURE_PROTOCOL_SESSIONS 1u /* zg_rrw_* and zg_rwc_* are exported */
 #define ZG_FEATURE_RCCL 2u              /* the several-GPU entry points can exchange partials over RCCL */
 #define ZG_FEATURE_COLUMN_INGEST 4u     /* zg_fr_rows_from_columns[_dev] */
@@ -161,6 +161,11 @@ ZG_API size_t zg_g1_bases_table_bytes(zg_bases_t b);
  * = HyperKZG.commit when bases is the SRS (src/poly/commitment/mod.zig:239-255).
  * n = 0 -> identity (:361-363). Scalars: n x 4 Montgomery Fr limbs on the host. */
 ZG_API int zg_msm_g1(zg_bases_t b, size_t off, size_t n, const uint64_t *scalars_mont, uint64_t out_xy[8], uint8_t *out_inf);
+/* The same MSM for scalars that are F.fromU64 of machine words, handed over as the words: what `zolt prove` commits to — program bytes,
+ * memory values, rd_value per cycle (commitBytecode / commitMemory / commitRegisters, src/zkvm/mod.zig:1518-1617) — is such a vector.
+ * 8 instead of 32 bytes per scalar cross PCIe, the conversion runs on the device, and a 64-bit scalar has digits in 4 of the 15 windows
+ * only. out = MSM.compute(bases[off..off+n], values.map(F.fromU64)), bit for bit. */
+ZG_API int zg_msm_g1_u64(zg_bases_t b, size_t off, size_t n, const uint64_t *values_u64, uint64_t out_xy[8], uint8_t *out_inf);
 /* same, scalars already resident in HBM */
 ZG_API int zg_msm_g1_dev(zg_bases_t b, size_t off, size_t n, const uint64_t *d_scalars_mont, void *stream, uint64_t out_xy[8],
                   uint8_t *out_inf);
@@ -287,6 +292,12 @@ ZG_API int zg_fr_rows_affine(const uint64_t *rows, size_t n_rows, size_t k, size
                       uint64_t *const *tables /* ntab host pointers, n_pad * g elements each */);
 ZG_API int zg_fr_rows_affine_dev(const uint64_t *d_rows, size_t n_rows, size_t k, size_t stride, const uint64_t *coeffs_host, size_t ntab, size_t g,
                           size_t n_pad, uint64_t *const *d_tables /* host array of ntab DEVICE pointers */, void *stream);
+/* The same affine maps written as RECORDS: d_out[(i * record + first + c) * 4 ..] = map_c(row_i) for c < nout <= 16 consecutive positions of a
+ * record of `record` elements per row. JoltR1CS.computeAz / computeBz (src/zkvm/r1cs/jolt_r1cs.zig:143-190) lay the 19 uniform constraints
+ * of a cycle out this way (constraint_idx = cycle * 19 + i): two calls per vector (constraints 0..15, 16..18) fill it in place; the zero
+ * padding up to the power of two is the caller's (a cleared buffer). coeffs_host: nout x (k + 1) elements, the constant last. */
+ZG_API int zg_fr_rows_affine_records_dev(const uint64_t *d_rows, size_t n_rows, size_t k, size_t stride, const uint64_t *coeffs_host, size_t nout,
+                                         size_t record, size_t first, uint64_t *d_out, void *stream);
 /* LtPolynomial over the cube (src/zkvm/ram/val_evaluation.zig:289-330), the third factor of ValEvaluationProver's inc * wa * lt:
  * out[j] = sum over the ZERO bits i of j of r[i] * prod_{k > i} (bit_k(j) ? r[k] : 1 - r[k]); index bit i <-> r[i]. v <= 30. */
 /* The witness matrix of a stage built ON THE DEVICE from integer columns. The reference derives every R1CS input of a cycle from machine
@@ -299,7 +310,9 @@ ZG_API int zg_fr_rows_affine_dev(const uint64_t *d_rows, size_t n_rows, size_t k
  *   ZG_COL_ZERO  no data: the column is zero              ZG_COL_U8 / U32 / U64  unsigned integers -> F.fromU64
  *   ZG_COL_I64   int64_t: v < 0 -> r - |v|                ZG_COL_I128 / U128     16 bytes per row (lo, hi), two's complement / unsigned
  *   ZG_COL_FR    a Montgomery element per row, copied     ZG_COL_BIT             bit `a` of a packed flag word of `b` = 1, 4 or 8 bytes
- *   ZG_COL_MUL   no data: the product of columns a and b of the same row (neither a ZG_COL_MUL itself)   per row -> 0 or F.one()
+ *   ZG_COL_MUL   the product of columns a and b of the same row, plus — when data is given — a           per row -> 0 or F.one()
+ *                128-bit two's-complement addend per row. A factor may itself be a ZG_COL_MUL column whose factors are plain columns
+ *                (RightLookupOperand = Product * FlagMultiplyOperands + the sum / difference of the other rows), no deeper.
  * Several ZG_COL_BIT columns may name the same word array (it crosses once). n_cols <= 64. */
 #define ZG_COL_ZERO 0
 #define ZG_COL_U8 1
@@ -313,7 +326,7 @@ ZG_API int zg_fr_rows_affine_dev(const uint64_t *d_rows, size_t n_rows, size_t k
 #define ZG_COL_MUL 9
 typedef struct {
     uint32_t kind; /* ZG_COL_* */
-    uint32_t a, b; /* ZG_COL_BIT: bit index, bytes per word; ZG_COL_MUL: the two factor columns */
+    uint32_t a, b; /* ZG_COL_BIT: bit index, bytes per word; ZG_COL_MUL: the two factor columns (data: optional addend) */
     const void *data;
 } zg_col_t;
 /* host columns (pageable, or pinned from zg_host_alloc); returns when the matrix is complete */

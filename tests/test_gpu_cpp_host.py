@@ -521,4 +521,4 @@ def test_cpp_witness_matrix_from_trace_columns(tmp_path, golden_dir):
         s1 = [l for l in res.stdout.splitlines() if l.startswith("S ")]
         assert len(s1) == 2 and s1[0] == s1[1]
         bpc = int([l for l in res.stdout.splitlines() if l.startswith("B ")][0].split()[1])
-        assert bpc in (156, 172)
+        assert bpc == 156

@@ -37,7 +37,8 @@ def test_every_column_kind_at_the_edges(n):
     word8 = rng.integers(0, 256, size=n, dtype=np.uint8)
     cols = [(lib.COL_U64, u64), (lib.COL_I64, i64), (lib.COL_MUL, None, 0, 1), (lib.COL_U8, word8), (lib.COL_U32, word32), (lib.COL_I128, wide),
             (lib.COL_U128, wide), (lib.COL_FR, frs), (lib.COL_ZERO, None), (lib.COL_BIT, word32, 0, 4), (lib.COL_BIT, word32, 31, 4),
-            (lib.COL_BIT, word64, 62, 8), (lib.COL_BIT, word8, 7, 1), (lib.COL_MUL, None, 5, 7), (lib.COL_MUL, None, 6, 6)]
+            (lib.COL_BIT, word64, 62, 8), (lib.COL_BIT, word8, 7, 1), (lib.COL_MUL, None, 5, 7), (lib.COL_MUL, None, 6, 6),
+            (lib.COL_MUL, wide, 2, 9), (lib.COL_MUL, wide[::-1].copy(), 0, 12)]  # product of a product + an addend; product + an addend
     got = lib.fr_rows_from_columns(cols, n)
     assert got.shape == (n, len(cols), 4)
     assert rows_int(got) == widen_columns_model(cols, n)
@@ -65,7 +66,7 @@ def test_invalid_column_descriptions_are_refused():
     p = a.ctypes.data
     bad = [[(lib.COL_MUL, 0, 0, None)],                                   # a product of itself
            [(lib.COL_U64, 0, 0, p), (lib.COL_MUL, 0, 5, None)],           # a factor outside the matrix
-           [(lib.COL_U64, 0, 0, p), (lib.COL_MUL, 0, 0, None), (lib.COL_MUL, 1, 0, None)],  # a product of a product
+           [(lib.COL_U64, 0, 0, p), (lib.COL_MUL, 0, 0, None), (lib.COL_MUL, 1, 0, None), (lib.COL_MUL, 2, 0, None)],  # nested three deep
            [(lib.COL_BIT, 64, 8, p)], [(lib.COL_BIT, 3, 2, p)],           # a bit outside its word, a word width that does not exist
            [(lib.COL_BIT, 3, 4, None)], [(lib.COL_U64, 0, 0, None)],      # no data
            [(17, 0, 0, p)]]

@@ -311,6 +311,10 @@ def test_all_commitments_of_the_reference_proof_header(zl, ob, golden_dir):
         assert hdr["register.commitment"] == proof[488:552] and hdr["register.commitment"] != bytes(64)
         one = api.HyperKZG.commit(params, polys[2])
         assert api.commitment_to_bytes(*one) == proof[488:552]
+        # the same commitments from the MACHINE WORDS (zg_msm_g1_u64: 8 bytes per evaluation across PCIe, fromU64 on the device)
+        assert api.commitment_to_bytes(*api.HyperKZG.commitU64(params, bc)) == hdr["bytecode.commitment"]
+        assert api.commitment_to_bytes(*api.HyperKZG.commitU64(params, reg)) == proof[488:552]
+        assert api.commitment_to_bytes(*api.HyperKZG.commitU64(params, np.zeros(0, dtype=np.uint64))) == bytes(64)
         # the proof header a `zolt prove` run would write from these commitments: byte-identical to the captured file's first 744 bytes
         header = api.serialize_zolt_proof_header({"bytecode.commitment": got[0], "memory.commitment": got[1], "register.commitment": got[2]})
         assert len(header) == 744 and header == proof[:744]
@@ -794,5 +798,29 @@ def test_host_batch_of_long_vectors_interleaves_copies(zl, ob, gm, monkeypatch):
         for j in range(k):
             w, wi = ob.msm_g1(gm[:n], None, batches[j])
             assert inf[j] == wi and np.array_equal(out[j], w), j
+    finally:
+        b.free()
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 1000, 4097, 1 << 16])
+def test_msm_over_machine_words_equals_msm_over_their_field_elements(zl, ob, n):
+    """zg_msm_g1_u64 (the commit path of `zolt prove`: every committed polynomial is F.fromU64 of machine words, src/zkvm/mod.zig:
+    1518-1617) == MSM.compute over the converted scalars, on the oracle and on the Montgomery entry point; edge words included"""
+    gm = ob.g1_gen_multiples(n)
+    rng = np.random.default_rng(n)
+    v = rng.integers(0, 1 << 63, size=n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=n, dtype=np.uint64)
+    v[:min(n, 5)] = np.array([0, 1, (1 << 64) - 1, 1 << 63, 255], dtype=np.uint64)[:min(n, 5)]
+    sc = ob.f_to_mont(ob.FR, np.stack([v, np.zeros(n, np.uint64), np.zeros(n, np.uint64), np.zeros(n, np.uint64)], axis=1))
+    b = zl.Bases.upload(gm)
+    try:
+        want = ob.msm_g1(gm, None, sc)
+        got = b.msm_u64(v)
+        assert got[1] == want[1] and np.array_equal(got[0], want[0])
+        again = b.msm(sc)
+        assert again[1] == want[1] and np.array_equal(again[0], want[0])
+        if n > 2:  # a range of the bases, as HyperKZG.commit of a shorter polynomial takes it
+            w2 = ob.msm_g1(gm[1:n - 1], None, sc[:n - 2])
+            g2 = b.msm_u64(v[:n - 2], n=n - 2, off=1)
+            assert g2[1] == w2[1] and np.array_equal(g2[0], w2[0])
     finally:
         b.free()

@@ -34,10 +34,18 @@ def widen_columns_model(cols, n):
             else:
                 continue
             out[i][c] = v % R
-    for c, spec in enumerate(cols):
-        if spec[0] == lib.COL_MUL:
+    def is_mul(k):
+        return cols[k][0] == lib.COL_MUL
+    for depth in (1, 2):  # a factor may be a depth-1 product; the optional data is a 128-bit two's-complement addend
+        for c, spec in enumerate(cols):
+            if spec[0] != lib.COL_MUL or (2 if (is_mul(spec[2]) or is_mul(spec[3])) else 1) != depth:
+                continue
             for i in range(n):
-                out[i][c] = out[i][spec[2]] * out[i][spec[3]] % R
+                v = out[i][spec[2]] * out[i][spec[3]]
+                if spec[1] is not None:
+                    a = int(spec[1][i][0]) | (int(spec[1][i][1]) << 64)
+                    v += a - (1 << 128) if a >> 127 else a
+                out[i][c] = v % R
     return out
 
 
@@ -89,13 +97,26 @@ def test_columns_of_random_traces_widen_to_the_reference_witness(seed):
     got, want = widen_columns_model(cols, len(steps)), oracle_rows_int(steps)
     for i, (g, w) in enumerate(zip(got, want)):
         assert g == w, (i, hex(steps[i]["instruction"]), [api.R1CS_INPUT_NAMES[k] for k in range(43) if g[k] != w[k]])
-    # the wide columns use 128-bit two's complement whenever every row fits, ready field elements otherwise (a full-width MUL beside a
-    # negative row): both encodings must have been exercised by the three seeds together
+    # the wide columns are 128-bit two's complement; RightLookupOperand is Product * FlagMultiplyOperands + a 128-bit addend
     kinds = {api.R1CS_INPUT_NAMES[k]: cols[k][0] for k in range(43)}
-    assert kinds["RightInstructionInput"] == lib.COL_I128 and kinds["RamAddress"] == lib.COL_I128
-    assert kinds["RightLookupOperand"] in (lib.COL_I128, lib.COL_FR)
+    assert kinds["RightInstructionInput"] == lib.COL_I128 and kinds["RamAddress"] == lib.COL_I128 and kinds["RightLookupOperand"] == lib.COL_MUL
+    assert api.columnBytesPerCycle(cols) == 156  # whatever the trace holds (a full-width MUL takes no wider encoding)
+
 
 
 def test_a_trace_that_ends_on_a_real_step_has_no_successor():
     steps = random_trace(9, 17, 0)
     assert widen_columns_model(api.cycleColumnsFromTrace(steps), 17) == oracle_rows_int(steps)
+
+
+def test_a_full_width_mul_beside_a_negative_row_keeps_the_narrow_encoding():
+    """MUL x1, x2, x3 with rs1 = rs2 = 2^64 - 1: Product = RightLookupOperand = (2^64 - 1)^2 >= 2^127 fits no signed 128-bit word, and
+    an ADDI with a negative immediate beside it needs the sign — the MUL rows ride on the device-side Product instead of a wider column"""
+    base = {"pc": 0x80000000, "unexpanded_pc": 0x80000000, "rd_value": 1, "memory_value": None, "is_compressed": False, "is_noop": False}
+    mul = dict(base, instruction=(1 << 25) | (3 << 20) | (2 << 15) | (1 << 7) | 0x33, rs1_value=(1 << 64) - 1, rs2_value=(1 << 64) - 1)
+    addi = dict(base, instruction=(0xFFF << 20) | (2 << 15) | (1 << 7) | 0x13, rs1_value=0, rs2_value=0)  # ADDI x1, x2, -1 with rs1 = 0: -1
+    steps = [mul, addi, mul]
+    cols = api.cycleColumnsFromTrace(steps)
+    assert api.columnBytesPerCycle(cols) == 156
+    got, want = widen_columns_model(cols, 3), oracle_rows_int(steps)
+    assert got == want and want[0][16] == ((1 << 64) - 1) ** 2 % R and want[1][16] == R - 1 and want[0][2] == want[0][16]

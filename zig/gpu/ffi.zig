@@ -35,7 +35,7 @@ pub const OP_INV: c_int = 5;
 pub const OP_FROM_MONT: c_int = 6;
 pub const OP_TO_MONT: c_int = 7;
 pub const ABI_MAJOR: u32 = 1;
-pub const ABI_MINOR: u32 = 5;
+pub const ABI_MINOR: u32 = 6;
 pub const FEATURE_PROTOCOL_SESSIONS: u32 = 1;
 pub const FEATURE_RCCL: u32 = 2;
 pub const FEATURE_COLUMN_INGEST: u32 = 4;
@@ -79,6 +79,7 @@ pub extern fn zg_g1_bases_len(b: Bases) usize;
 pub extern fn zg_g1_bases_plan(b: Bases, window_bits: ?*c_int, windows: ?*c_int, precompute_levels: ?*c_int) c_int;
 pub extern fn zg_g1_bases_table_bytes(b: Bases) usize;
 pub extern fn zg_msm_g1(b: Bases, off: usize, n: usize, scalars_mont: ?[*]const u64, out_xy: *[8]u64, out_inf: ?[*]u8) c_int;
+pub extern fn zg_msm_g1_u64(b: Bases, off: usize, n: usize, values_u64: ?[*]const u64, out_xy: *[8]u64, out_inf: ?[*]u8) c_int;
 pub extern fn zg_msm_g1_dev(b: Bases, off: usize, n: usize, d_scalars_mont: ?[*]const u64, stream: ?*anyopaque, out_xy: *[8]u64, out_inf: ?[*]u8) c_int;
 pub extern fn zg_msm_g1_dev_async(b: Bases, off: usize, n: usize, d_scalars_mont: ?[*]const u64, stream: ?*anyopaque, d_out_xy: ?[*]u64, d_out_inf: ?[*]u8) c_int;
 pub extern fn zg_msm_g1_batch(b: Bases, n: usize, scalar_batches: ?[*]const ?[*]const u64, k: usize, out_xy: ?[*]u64, out_inf: ?[*]u8) c_int;
@@ -106,6 +107,7 @@ pub extern fn zg_fr_rows_mle(rows: ?[*]const u64, n_rows: usize, k: usize, r: ?[
 pub extern fn zg_fr_rows_mle_dev(d_rows: ?[*]const u64, n_rows: usize, k: usize, r_host: ?[*]const u64, v: usize, stream: ?*anyopaque, out: ?[*]u64) c_int;
 pub extern fn zg_fr_rows_affine(rows: ?[*]const u64, n_rows: usize, k: usize, stride: usize, coeffs: ?[*]const u64, ntab: usize, g: usize, n_pad: usize, tables: ?[*]const ?[*]u64) c_int;
 pub extern fn zg_fr_rows_affine_dev(d_rows: ?[*]const u64, n_rows: usize, k: usize, stride: usize, coeffs_host: ?[*]const u64, ntab: usize, g: usize, n_pad: usize, d_tables: ?[*]const ?[*]u64, stream: ?*anyopaque) c_int;
+pub extern fn zg_fr_rows_affine_records_dev(d_rows: ?[*]const u64, n_rows: usize, k: usize, stride: usize, coeffs_host: ?[*]const u64, nout: usize, record: usize, first: usize, d_out: ?[*]u64, stream: ?*anyopaque) c_int;
 pub extern fn zg_fr_rows_from_columns(cols: ?[*]const Column, n_cols: usize, n_rows: usize, d_rows: ?[*]u64) c_int;
 pub extern fn zg_fr_rows_from_columns_dev(cols: ?[*]const Column, n_cols: usize, n_rows: usize, d_rows: ?[*]u64, stream: ?*anyopaque) c_int;
 pub extern fn zg_fr_lt_table(r: ?[*]const u64, v: usize, out: ?[*]u64) c_int;

@@ -19,7 +19,7 @@ ZG_OP_INV = 5
 ZG_OP_FROM_MONT = 6
 ZG_OP_TO_MONT = 7
 ZG_ABI_MAJOR = 1
-ZG_ABI_MINOR = 5
+ZG_ABI_MINOR = 6
 ZG_FEATURE_PROTOCOL_SESSIONS = 1
 ZG_FEATURE_RCCL = 2
 ZG_FEATURE_COLUMN_INGEST = 4
@@ -78,6 +78,7 @@ PROTOS = {
     "zg_g1_bases_plan": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),  # b, window_bits, windows, precompute_levels
     "zg_g1_bases_table_bytes": (c_size_t, [c_void_p]),  # b
     "zg_msm_g1": (c_int, [c_void_p, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p]),  # b, off, n, scalars_mont, out_xy, out_inf
+    "zg_msm_g1_u64": (c_int, [c_void_p, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p]),  # b, off, n, values_u64, out_xy, out_inf
     "zg_msm_g1_dev": (c_int, [c_void_p, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),  # b, off, n, d_scalars_mont, stream, out_xy, out_inf
     "zg_msm_g1_dev_async": (c_int, [c_void_p, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),  # b, off, n, d_scalars_mont, stream, d_out_xy, d_out_inf
     "zg_msm_g1_batch": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p]),  # b, n, scalar_batches, k, out_xy, out_inf
@@ -105,6 +106,7 @@ PROTOS = {
     "zg_fr_rows_mle_dev": (c_int, [c_void_p, c_size_t, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p]),  # d_rows, n_rows, k, r_host, v, stream, out
     "zg_fr_rows_affine": (c_int, [c_void_p, c_size_t, c_size_t, c_size_t, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p]),  # rows, n_rows, k, stride, coeffs, ntab, g, n_pad, tables
     "zg_fr_rows_affine_dev": (c_int, [c_void_p, c_size_t, c_size_t, c_size_t, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p, c_void_p]),  # d_rows, n_rows, k, stride, coeffs_host, ntab, g, n_pad, d_tables, stream
+    "zg_fr_rows_affine_records_dev": (c_int, [c_void_p, c_size_t, c_size_t, c_size_t, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p, c_void_p]),  # d_rows, n_rows, k, stride, coeffs_host, nout, record, first, d_out, stream
     "zg_fr_rows_from_columns": (c_int, [c_void_p, c_size_t, c_size_t, c_void_p]),  # cols, n_cols, n_rows, d_rows
     "zg_fr_rows_from_columns_dev": (c_int, [c_void_p, c_size_t, c_size_t, c_void_p, c_void_p]),  # cols, n_cols, n_rows, d_rows, stream
     "zg_fr_lt_table": (c_int, [c_void_p, c_size_t, c_void_p]),  # r, v, out

@@ -50,6 +50,18 @@ class HyperKZG:
         return params._dev.msm(evals[:n], off=0, n=n)
 
     @staticmethod
+    def commitU64(params, values):
+        """commit to the polynomial whose evaluations are F.fromU64 of `values` (machine words) — what commitBytecode / commitMemory /
+        commitRegisters build (src/zkvm/mod.zig:1518-1617): the words cross as they are (zg_msm_g1_u64), same commitment bytes"""
+        v = np.ascontiguousarray(values, dtype=np.uint64).reshape(-1)
+        if v.size == 0:
+            return np.zeros(8, dtype=np.uint64), 1
+        n = min(v.size, params.max_degree)
+        if params.sharded:  # the sharded handle takes field elements
+            return HyperKZG.commit(params, lib.field_op(lib.FR, lib.OP_TO_MONT, np.stack([v[:n], np.zeros(n, np.uint64), np.zeros(n, np.uint64), np.zeros(n, np.uint64)], axis=1)))
+        return params._dev.msm_u64(v[:n], n=n)
+
+    @staticmethod
     def batchCommit(params, polys):
         """batchCommit (src/poly/commitment/mod.zig:558-570): out[i] = commit(poly_i). Polynomials of equal (clamped)
         length share one zg_msm_g1_batch call, which fuses short vectors into a single launch set."""

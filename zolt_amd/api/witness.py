@@ -110,7 +110,7 @@ def _cycle_integers(step, nxt):
         if f7 == 0x01:
             if f3 == 0:
                 bits.add("FlagMultiplyOperands")
-                lo_l, lo_r = 0, left * right
+                lo_l, lo_r = 0, 0  # = Product: added on the device (cycleColumnsFromTrace)
         elif f7 == 0x20 and f3 == 0:
             bits.add("FlagSubtractOperands")
             lo_l, lo_r = 0, left - right + (1 << 64)
@@ -148,9 +148,9 @@ def cycleColumnsFromTrace(steps):
     """ExecutionTrace.steps (dicts with tracer.TraceStep's fields, NoOp-padded) -> the 43 typed columns of zg_fr_rows_from_columns, in
     R1CSInputIndex order: a list of (kind, data, a, b). Unsigned machine words travel as u64, the immediate as i64, the three values that
     can leave 64 bits (RightInstructionInput = rs2 or a signed immediate, RamAddress = rs1 + imm, RightLookupOperand = a sum, a
-    difference + 2^64 or a 128-bit product) as 128-bit two's complement — or, should a row not fit that either, as ready field elements
-    for that one column — every single-bit input as a bit of one u32 word, Product as the device-side product of columns 0 and 1, and
-    the two always-zero inputs as no data at all."""
+    difference + 2^64 or a pass-through) as 128-bit two's complement, every single-bit input as a bit of one u32 word, Product as the
+    device-side product of columns 0 and 1, RightLookupOperand's MUL rows as Product * FlagMultiplyOperands on the device (a full-width
+    product fits no 128-bit signed word) added to its column, and the two always-zero inputs as no data at all: 156 bytes per cycle."""
     n = len(steps)
     u64_names = ("LeftInstructionInput", "PC", "UnexpandedPC", "Rs1Value", "Rs2Value", "RdWriteValue", "RamReadValue", "RamWriteValue", "LeftLookupOperand",
                  "NextUnexpandedPC", "NextPC", "LookupOutput")
@@ -182,14 +182,14 @@ def cycleColumnsFromTrace(steps):
     cols[_W["Imm"]] = (lib.COL_I64, imm)
     for name in wide_names:
         vals = wide[name]
-        if all(-(1 << 127) <= x < (1 << 127) for x in vals):
-            a = np.zeros((n, 2), dtype=np.uint64)
-            for i, x in enumerate(vals):
-                x &= (1 << 128) - 1
-                a[i, 0], a[i, 1] = x & _M64, x >> 64
-            cols[_W[name]] = (lib.COL_I128, a)
-        else:  # a 128-bit product with its top bit set beside a negative row: the column crosses as field elements
-            cols[_W[name]] = (lib.COL_FR, np.stack([fr_from_int(x % R_MOD) for x in vals]))
+        assert all(-(1 << 127) <= x < (1 << 127) for x in vals), name
+        a = np.zeros((n, 2), dtype=np.uint64)
+        for i, x in enumerate(vals):
+            x &= (1 << 128) - 1
+            a[i, 0], a[i, 1] = x & _M64, x >> 64
+        # RightLookupOperand: the rows of a MUL instruction take Product (constraint 9; a full-width product does not fit 128-bit two's
+        # complement) — Product * FlagMultiplyOperands on the device — and every other row its sum / difference / pass-through as the addend
+        cols[_W[name]] = (lib.COL_MUL, a, _W["Product"], _W["FlagMultiplyOperands"]) if name == "RightLookupOperand" else (lib.COL_I128, a)
     cols[_W["Product"]] = (lib.COL_MUL, None, _W["LeftInstructionInput"], _W["RightInstructionInput"])
     for name in ("NextIsVirtual", "NextIsFirstInSequence"):  # no virtual sequences in a RISC-V trace (:1160-1171)
         cols[_W[name]] = (lib.COL_ZERO, None)
@@ -202,7 +202,7 @@ def cycleColumnsFromTrace(steps):
 def columnBytesPerCycle(cols):
     """bytes of column data that cross PCIe per cycle (a shared flag word counted once)"""
     seen, total = set(), 0
-    width = {lib.COL_U8: 1, lib.COL_U32: 4, lib.COL_U64: 8, lib.COL_I64: 8, lib.COL_I128: 16, lib.COL_U128: 16, lib.COL_FR: 32}
+    width = {lib.COL_U8: 1, lib.COL_U32: 4, lib.COL_U64: 8, lib.COL_I64: 8, lib.COL_I128: 16, lib.COL_U128: 16, lib.COL_FR: 32, lib.COL_MUL: 16}
     for c in cols:
         if len(c) < 2 or c[1] is None or id(c[1]) in seen:
             continue

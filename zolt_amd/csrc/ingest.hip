@@ -105,17 +105,31 @@ __global__ void __launch_bounds__(512) rows_from_columns_kernel(IngArgs args, ui
         tile_store(tile + ((size_t)lane * n_cols + c) * 2, v);
     }
     __syncthreads();
-    bool any_mul = false;
-    for (uint32_t c = wave; c < n_cols; c += nw) {
-        const IngCol d = args.c[c];
-        if (d.kind != ZG_COL_MUL) continue;
-        any_mul = true;
-        Fr v = Fr::zero();
-        if (live) v = fr_mul29v(tile_load(tile + ((size_t)lane * n_cols + d.a) * 2), tile_load(tile + ((size_t)lane * n_cols + d.b) * 2));
-        tile_store(tile + ((size_t)lane * n_cols + c) * 2, v);
+    // derived columns: col[a] * col[b] (+ a 128-bit two's-complement addend when the column has data). Depth 1 = both factors are plain
+    // columns, depth 2 = a factor is itself a depth-1 product (IngCol.pad holds the depth): one pass and one barrier per depth.
+    for (uint32_t depth = 1; depth <= 2; depth++) {
+        for (uint32_t c = wave; c < n_cols; c += nw) {
+            const IngCol d = args.c[c];
+            if (d.kind != ZG_COL_MUL || d.pad != depth) continue;
+            Fr v = Fr::zero();
+            if (live) {
+                v = fr_mul29v(tile_load(tile + ((size_t)lane * n_cols + d.a) * 2), tile_load(tile + ((size_t)lane * n_cols + d.b) * 2));
+                if (d.data) {
+                    const uint64_t *p = reinterpret_cast<const uint64_t *>(d.data) + 2 * row;
+                    uint64_t lo = p[0], hi = p[1];
+                    const bool neg = hi >> 63;
+                    if (neg) {
+                        lo = ~lo + 1;
+                        hi = ~hi + (lo == 0 ? 1 : 0);
+                    }
+                    const Fr add = fr_from_u128_29(lo, hi);
+                    v = neg ? fe_sub(v, add) : fe_add(v, add);
+                }
+            }
+            tile_store(tile + ((size_t)lane * n_cols + c) * 2, v);
+        }
+        __syncthreads();
     }
-    (void)any_mul;
-    __syncthreads();
     const size_t rows_here = n_rows - row0 < ING_TILE_ROWS ? n_rows - row0 : ING_TILE_ROWS;
     const size_t n16 = rows_here * n_cols * 2;
     uint4 *dst = reinterpret_cast<uint4 *>(out) + row0 * n_cols * 2;
@@ -130,8 +144,21 @@ static size_t col_width(uint32_t kind, uint32_t b) {
         case ZG_COL_I128: case ZG_COL_U128: return 16;
         case ZG_COL_FR: return 32;
         case ZG_COL_BIT: return b;
+        case ZG_COL_MUL: return 16;  // the optional addend (no data: nothing crosses)
         default: return 0;
     }
+}
+// 1: both factors are plain columns; 2: a factor is a depth-1 product; 0: anything else (out of range, itself, a deeper chain)
+static uint32_t mul_depth(const zg_col_t *cols, size_t n_cols, size_t c) {
+    uint32_t depth = 1;
+    for (uint32_t f : {cols[c].a, cols[c].b}) {
+        if (f >= n_cols || f == c) return 0;
+        if (cols[f].kind != ZG_COL_MUL) continue;
+        for (uint32_t g : {cols[f].a, cols[f].b})
+            if (g >= n_cols || cols[g].kind == ZG_COL_MUL) return 0;
+        depth = 2;
+    }
+    return depth;
 }
 static int validate_cols(const zg_col_t *cols, size_t n_cols, size_t n_rows, uint64_t *d_rows) {
     if (!cols || n_cols == 0 || n_cols > ING_MAX_COLS || (n_rows && !d_rows)) {
@@ -141,11 +168,11 @@ static int validate_cols(const zg_col_t *cols, size_t n_cols, size_t n_rows, uin
     for (size_t c = 0; c < n_cols; c++) {
         const zg_col_t &d = cols[c];
         bool ok = d.kind <= ZG_COL_MUL;
-        if (ok && d.kind == ZG_COL_MUL) ok = d.a < n_cols && d.b < n_cols && cols[d.a].kind != ZG_COL_MUL && cols[d.b].kind != ZG_COL_MUL;
+        if (ok && d.kind == ZG_COL_MUL) ok = mul_depth(cols, n_cols, c) != 0;
         else if (ok && d.kind == ZG_COL_BIT) ok = (d.b == 1 || d.b == 4 || d.b == 8) && d.a < 8 * d.b && d.data;
         else if (ok && d.kind != ZG_COL_ZERO) ok = d.data != nullptr || n_rows == 0;
         if (!ok) {
-            set_error("zg_fr_rows_from_columns: column " + std::to_string(c) + ": unknown kind, missing data, a bit outside its word, or a product of products");
+            set_error("zg_fr_rows_from_columns: column " + std::to_string(c) + ": unknown kind, missing data, a bit outside its word, or a product nested deeper than two");
             return ZG_ERR_INVALID;
         }
     }
@@ -161,6 +188,12 @@ static int launch_rows_from_columns(const IngArgs &args, size_t n_cols, size_t n
     return ZG_OK;
 }
 
+int ingest_u64_to_fr(const uint64_t *d_vals, size_t n, uint64_t *d_out, hipStream_t st) {
+    IngArgs args{};
+    args.c[0] = IngCol{ZG_COL_U64, 0, 0, 0, d_vals};
+    return launch_rows_from_columns(args, 1, n, d_out, st);
+}
+
 }  // namespace zg
 
 using namespace zg;
@@ -171,7 +204,8 @@ int zg_fr_rows_from_columns_dev(const zg_col_t *cols, size_t n_cols, size_t n_ro
     ZG_INIT();
     ZG_TRY(validate_cols(cols, n_cols, n_rows, d_rows));
     IngArgs args{};
-    for (size_t c = 0; c < n_cols; c++) args.c[c] = IngCol{cols[c].kind, cols[c].a, cols[c].b, 0, cols[c].data};
+    for (size_t c = 0; c < n_cols; c++)
+        args.c[c] = IngCol{cols[c].kind, cols[c].a, cols[c].b, cols[c].kind == ZG_COL_MUL ? mul_depth(cols, n_cols, c) : 0u, cols[c].data};
     return launch_rows_from_columns(args, n_cols, n_rows, d_rows, pick_stream(stream));
 }
 
@@ -191,7 +225,7 @@ int zg_fr_rows_from_columns(const zg_col_t *cols, size_t n_cols, size_t n_rows, 
     for (size_t c = 0; c < n_cols; c++) {
         src_of[c] = (size_t)-1;
         const size_t w = col_width(cols[c].kind, cols[c].b);
-        if (w == 0) continue;
+        if (w == 0 || !cols[c].data) continue;
         for (size_t s = 0; s < srcs.size(); s++)
             if (srcs[s].host == cols[c].data && srcs[s].bytes == w * n_rows) src_of[c] = s;
         if (src_of[c] == (size_t)-1) {
@@ -211,7 +245,8 @@ int zg_fr_rows_from_columns(const zg_col_t *cols, size_t n_cols, size_t n_rows, 
     const double t2 = split ? now_ms() : 0;
     IngArgs args{};
     for (size_t c = 0; c < n_cols; c++)
-        args.c[c] = IngCol{cols[c].kind, cols[c].a, cols[c].b, 0, src_of[c] == (size_t)-1 ? nullptr : (const void *)(stage.as<char>() + srcs[src_of[c]].off)};
+        args.c[c] = IngCol{cols[c].kind, cols[c].a, cols[c].b, cols[c].kind == ZG_COL_MUL ? mul_depth(cols, n_cols, c) : 0u,
+                           src_of[c] == (size_t)-1 ? nullptr : (const void *)(stage.as<char>() + srcs[src_of[c]].off)};
     ZG_TRY(launch_rows_from_columns(args, n_cols, n_rows, d_rows, st));
     ZG_HIP(hipStreamSynchronize(st));
     sync.dismiss();

@@ -1683,27 +1683,21 @@ int zg_fr_rows_mle(const uint64_t *rows, size_t n_rows, size_t k, const uint64_t
     return zg_fr_rows_mle_dev(s_rows.as<uint64_t>(), n_rows, k, r, v, st, out);
 }
 
-int zg_fr_rows_affine_dev(const uint64_t *d_rows, size_t n_rows, size_t k, size_t stride, const uint64_t *coeffs, size_t ntab, size_t g, size_t n_pad,
-                          uint64_t *const *d_tables, void *stream) {
-    ZG_INIT();
-    const size_t nout = ntab * g;
-    if (stride == 0) stride = k;
-    if (!coeffs || !d_tables || k == 0 || k > ROWS_AFFINE_MAX_K || stride > k || ntab == 0 || g == 0 || nout > ROWS_AFFINE_MAX_OUT || n_pad < n_rows ||
-        (n_rows && !d_rows)) {
-        set_error("zg_fr_rows_affine: 1..128 columns, stride <= columns, 1..16 outputs (tables x interleave), n_pad >= n_rows");
-        return ZG_ERR_INVALID;
+// nout <= 16 affine maps of the rows; output c goes to tab[c] + 4 * (i * g + c % g) for row i
+static int rows_affine_launch(const uint64_t *d_rows, size_t n_rows, size_t k, size_t stride, const uint64_t *coeffs, size_t nout, uint64_t *const *tab_of_output,
+                              size_t g, size_t n_pad, hipStream_t st) {
+    {
+        if (n_pad == 0) return ZG_OK;
     }
-    if (n_pad == 0) return ZG_OK;
-    hipStream_t st = pick_stream(stream);
     // per output: the columns with a non-zero coefficient
     std::vector<uint8_t> cols(64 * nout, 0);
     RowsAffineArgs a{};
     for (size_t c = 0; c < nout; c++) {
-        if (!d_tables[c / g]) {
+        if (!tab_of_output[c]) {
             set_error("zg_fr_rows_affine: null table");
             return ZG_ERR_INVALID;
         }
-        a.tab[c] = d_tables[c / g];
+        a.tab[c] = tab_of_output[c];
         unsigned nnz = 0;
         for (size_t col = 0; col < k; col++) {
             const uint64_t *e = coeffs + 4 * (c * (k + 1) + col);
@@ -1730,6 +1724,37 @@ int zg_fr_rows_affine_dev(const uint64_t *d_rows, size_t n_rows, size_t k, size_
     ZG_HIP(hipStreamSynchronize(st));  // the coefficient buffers go back to the cache; `cols` is a local
     sync.dismiss();
     return ZG_OK;
+}
+
+int zg_fr_rows_affine_dev(const uint64_t *d_rows, size_t n_rows, size_t k, size_t stride, const uint64_t *coeffs, size_t ntab, size_t g, size_t n_pad,
+                          uint64_t *const *d_tables, void *stream) {
+    ZG_INIT();
+    const size_t nout = ntab * g;
+    if (stride == 0) stride = k;
+    if (!coeffs || !d_tables || k == 0 || k > ROWS_AFFINE_MAX_K || stride > k || ntab == 0 || g == 0 || nout > ROWS_AFFINE_MAX_OUT || n_pad < n_rows ||
+        (n_rows && !d_rows)) {
+        set_error("zg_fr_rows_affine: 1..128 columns, stride <= columns, 1..16 outputs (tables x interleave), n_pad >= n_rows");
+        return ZG_ERR_INVALID;
+    }
+    uint64_t *tabs[ROWS_AFFINE_MAX_OUT];
+    for (size_t c = 0; c < nout; c++) tabs[c] = d_tables[c / g];
+    return rows_affine_launch(d_rows, n_rows, k, stride, coeffs, nout, tabs, g, n_pad, pick_stream(stream));
+}
+
+// Records of `record` elements per row: out[i * record + first + c] = map_c(row_i) for c < nout <= 16 consecutive positions of the record.
+// JoltR1CS.computeAz / computeBz (src/zkvm/r1cs/jolt_r1cs.zig:143-190) lay the 19 uniform constraints of a cycle out this way
+// (constraint_idx = cycle * 19 + i): two calls per vector (constraints 0..15, then 16..18) write it in place, cycle by cycle.
+int zg_fr_rows_affine_records_dev(const uint64_t *d_rows, size_t n_rows, size_t k, size_t stride, const uint64_t *coeffs, size_t nout, size_t record,
+                                  size_t first, uint64_t *d_out, void *stream) {
+    ZG_INIT();
+    if (stride == 0) stride = k;
+    if (!coeffs || !d_out || k == 0 || k > ROWS_AFFINE_MAX_K || stride > k || nout == 0 || nout > ROWS_AFFINE_MAX_OUT || first + nout > record || (n_rows && !d_rows)) {
+        set_error("zg_fr_rows_affine_records: 1..128 columns, stride <= columns, 1..16 outputs inside the record");
+        return ZG_ERR_INVALID;
+    }
+    uint64_t *tabs[ROWS_AFFINE_MAX_OUT];
+    for (size_t c = 0; c < nout; c++) tabs[c] = d_out + 4 * first;  // the kernel adds i * record + c (c % record = c: nout <= record)
+    return rows_affine_launch(d_rows, n_rows, k, stride, coeffs, nout, tabs, record, n_rows, pick_stream(stream));
 }
 
 int zg_fr_rows_affine_prodsum_dev(const uint64_t *d_rows, size_t n_rows, size_t k, size_t stride, const uint64_t *coeffs, size_t npairs,

@@ -43,6 +43,13 @@ struct HyperKZG {
         size_t n = evals.size() < params.powers_of_tau_g1.size() ? evals.size() : params.powers_of_tau_g1.size();
         return Commitment{params.device->msm(evals.data(), n)};
     }
+    // commit to a polynomial whose evaluations are F.fromU64 of machine words (commitBytecode / commitMemory / commitRegisters,
+    // src/zkvm/mod.zig:1518-1617 build exactly such vectors): the words cross as they are
+    static Commitment commitU64(const SetupParams &params, const std::vector<uint64_t> &values) {
+        if (values.empty()) return Commitment{AffinePoint::identity()};
+        size_t n = values.size() < params.powers_of_tau_g1.size() ? values.size() : params.powers_of_tau_g1.size();
+        return Commitment{params.device->msmU64(values.data(), n)};
+    }
     struct Proof {  // :155-167
         std::vector<Commitment> quotient_commitments;
         Fr final_eval;

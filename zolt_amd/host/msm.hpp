@@ -75,6 +75,13 @@ public:
         check(zg_msm_g1(h_, off, n, reinterpret_cast<const uint64_t *>(scalars), out, &inf), "zg_msm_g1");
         return unpack_point(out, inf);
     }
+    // scalars given as u64 machine words: = msm(F.fromU64 of every word), 8 bytes per scalar across PCIe (zg_msm_g1_u64)
+    AffinePoint msmU64(const uint64_t *values, size_t n, size_t off = 0) const {
+        uint64_t out[8];
+        uint8_t inf = 0;
+        check(zg_msm_g1_u64(h_, off, n, values, out, &inf), "zg_msm_g1_u64");
+        return unpack_point(out, inf);
+    }
     zg_bases_t handle() const { return h_; }
 
 private:

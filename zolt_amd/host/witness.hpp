@@ -32,21 +32,49 @@ struct CycleColumns {
                           WriteLookupOutputToRDFlag, VirtualInstruction, Assert, DoNotUpdateUnexpandedPC, Advice, IsCompressed, IsFirstInSequence, IsRdNotZero,
                           Branch, IsNoop, LeftOperandIsRs1, LeftOperandIsPC, RightOperandIsRs2, RightOperandIsImm };
 
+    // The columns live in ONE slab of pinned host memory (zg_host_alloc): the copies to the device then run by DMA at link rate and do not
+    // depend on the page state of the process (BENCH_r04: the same pageable upload took 26 ms on one box and 55 ms on another). The slab is
+    // kept per thread and reused by the next trace (hipHostMalloc of 160 MB costs more than the upload it speeds up).
     size_t n = 0;
-    std::vector<uint64_t> u64[12];
-    std::vector<int64_t> imm;
-    std::vector<uint64_t> wide[3];  // 2 words per row: 128-bit two's complement
-    std::vector<Fr> wide_fr;        // RightLookupOperand as ready elements when a row does not fit 128-bit two's complement
-    std::vector<uint32_t> word;     // the 24 single-bit inputs of a cycle
+    uint64_t *u64[12] = {};
+    int64_t *imm = nullptr;
+    uint64_t *wide[3] = {};    // 2 words per row: 128-bit two's complement
+    uint32_t *word = nullptr;  // the 24 single-bit inputs of a cycle
 
     explicit CycleColumns(size_t cycles = 0) { resize(cycles); }
+    CycleColumns(const CycleColumns &) = delete;
+    CycleColumns &operator=(const CycleColumns &) = delete;
+    CycleColumns(CycleColumns &&o) noexcept { *this = std::move(o); }
+    CycleColumns &operator=(CycleColumns &&o) noexcept {
+        release();
+        std::memcpy(static_cast<void *>(this), &o, sizeof(*this));
+        o.slab_ = nullptr;
+        o.n = 0;
+        return *this;
+    }
+    ~CycleColumns() { release(); }
+    static constexpr size_t BYTES_PER_CYCLE = 12 * 8 + 8 + 3 * 16 + 4;  // 156
     void resize(size_t cycles) {
+        release();
         n = cycles;
-        for (auto &c : u64) c.assign(n, 0);
-        for (auto &c : wide) c.assign(2 * n, 0);
-        imm.assign(n, 0);
-        word.assign(n, 0);
-        wide_fr.clear();
+        const size_t pad = (n + 31) & ~size_t(31);  // every column starts on a 256-byte boundary
+        bytes_ = pad * BYTES_PER_CYCLE + 256;
+        Slab &keep = spare();
+        if (keep.p && keep.bytes >= bytes_) {
+            slab_ = keep.p;
+            cap_ = keep.bytes;
+            keep.p = nullptr;
+        } else {
+            if (keep.p) { zg_host_free(keep.p); keep.p = nullptr; }
+            check(zg_host_alloc(bytes_, &slab_), "zg_host_alloc");
+            cap_ = bytes_;
+        }
+        std::memset(slab_, 0, bytes_);
+        char *p = static_cast<char *>(slab_);
+        for (auto &c : u64) { c = reinterpret_cast<uint64_t *>(p); p += pad * 8; }
+        imm = reinterpret_cast<int64_t *>(p); p += pad * 8;
+        for (auto &c : wide) { c = reinterpret_cast<uint64_t *>(p); p += pad * 16; }
+        word = reinterpret_cast<uint32_t *>(p);
     }
     static int64_t sx(uint64_t v, int bits) { return (int64_t)(v << (64 - bits)) >> (64 - bits); }
     static int64_t immOf(uint32_t w) {  // deriveImmediate (:1226-1274) as a signed integer
@@ -68,20 +96,12 @@ struct CycleColumns {
         wide[k][2 * i] = (uint64_t)(unsigned __int128)v;
         wide[k][2 * i + 1] = (uint64_t)((unsigned __int128)v >> 64);
     }
-    static Fr fromU128(unsigned __int128 m) {
-        const Fr two64 = Fr::fromU64(uint64_t(1) << 32).mul(Fr::fromU64(uint64_t(1) << 32));
-        return Fr::fromU64((uint64_t)(m >> 64)).mul(two64).add(Fr::fromU64((uint64_t)m));
-    }
 
     // the integer-domain restatement of generateWitness over a NoOp-padded trace
     static CycleColumns fromTrace(const std::vector<R1CSTraceStep> &steps) {
         CycleColumns c(steps.size());
-        // RightLookupOperand per row as (negative?, magnitude): a full-width MUL does not fit 128-bit two's complement
-        std::vector<uint8_t> lo_neg(c.n, 0);
-        std::vector<unsigned __int128> lo_mag(c.n, 0);
-        bool lo_fits = true;
-        auto &Left = c.u64[0], &PC = c.u64[1], &UPC = c.u64[2], &Rs1 = c.u64[3], &Rs2 = c.u64[4], &RdW = c.u64[5], &RamR = c.u64[6], &RamW = c.u64[7], &LeftLookup = c.u64[8],
-             &NextUPC = c.u64[9], &NextPC = c.u64[10], &Lookup = c.u64[11];
+        uint64_t *Left = c.u64[0], *PC = c.u64[1], *UPC = c.u64[2], *Rs1 = c.u64[3], *Rs2 = c.u64[4], *RdW = c.u64[5], *RamR = c.u64[6], *RamW = c.u64[7],
+                 *LeftLookup = c.u64[8], *NextUPC = c.u64[9], *NextPC = c.u64[10], *Lookup = c.u64[11];
         for (size_t i = 0; i < c.n; i++) {
             const R1CSTraceStep &st = steps[i];
             uint32_t bits = 0;
@@ -134,42 +154,40 @@ struct CycleColumns {
             UPC[i] = st.unexpanded_pc;
             if (nx && !nx->is_noop) { NextPC[i] = nx->pc; NextUPC[i] = nx->unexpanded_pc; }  // :1150-1172
             // setFlagsFromInstruction (:1288-1398): circuit flags and the two lookup operands
-            bool wl = false, jump = false, zero_left = false, neg = right < 0;
-            unsigned __int128 mag = neg ? (unsigned __int128)(-right) : (unsigned __int128)right;  // default: the operands pass through
-            auto sum = [&](__int128 v) { neg = v < 0; mag = neg ? (unsigned __int128)(-v) : (unsigned __int128)v; };
+            // RightLookupOperand: the rows of a MUL take Product (constraint 9) — a full-width product fits no signed 128-bit word, so the
+            // device adds Product * FlagMultiplyOperands to this column (descriptors()) — every other row its sum / difference / pass-through
+            bool wl = false, jump = false, zero_left = false;
+            __int128 lookup_right = right;
             if (op == 0x33) {
                 if (f7 == 0x01) {
                     if (f3 == 0) {
                         set(MultiplyOperands);
                         zero_left = true;
-                        neg = right < 0 && left != 0;
-                        mag = (unsigned __int128)left * (uint64_t)(right < 0 ? -right : right);  // |right| < 2^64: the product is < 2^128
+                        lookup_right = 0;
                     }
                 } else if (f7 == 0x20 && f3 == 0) {
                     set(SubtractOperands);
                     zero_left = true;
-                    sum((__int128)left - right + ((__int128)1 << 64));
+                    lookup_right = (__int128)left - right + ((__int128)1 << 64);
                 } else {
                     set(AddOperands);
                     zero_left = true;
-                    sum((__int128)left + right);
+                    lookup_right = (__int128)left + right;
                 }
                 wl = true;
             } else if (op == 0x13 || op == 0x37 || op == 0x17) {
                 set(AddOperands);
                 zero_left = true;
-                sum((__int128)left + right);
+                lookup_right = (__int128)left + right;
                 wl = true;
             } else if (op == 0x6F || op == 0x67) {
                 set(AddOperands);
                 zero_left = true;
-                sum((__int128)left + right);
+                lookup_right = (__int128)left + right;
                 jump = true;
             }
             LeftLookup[i] = zero_left ? 0 : left;
-            lo_neg[i] = neg;
-            lo_mag[i] = mag;
-            if (neg ? mag > ((unsigned __int128)1 << 127) : mag >= ((unsigned __int128)1 << 127)) lo_fits = false;
+            c.setWide(2, i, lookup_right);
             if (wl) set(WriteLookupOutputToRDFlag);
             if (jump) {
                 set(Jump);
@@ -186,27 +204,34 @@ struct CycleColumns {
             }
             c.word[i] = bits;
         }
-        if (lo_fits) {
-            for (size_t i = 0; i < c.n; i++) c.setWide(2, i, lo_neg[i] ? -(__int128)lo_mag[i] : (__int128)lo_mag[i]);
-        } else {  // the column crosses as ready field elements (32 instead of 16 bytes per cycle for this one input)
-            c.wide_fr.resize(c.n);
-            for (size_t i = 0; i < c.n; i++) c.wide_fr[i] = lo_neg[i] ? Fr::zero().sub(fromU128(lo_mag[i])) : fromU128(lo_mag[i]);
-        }
         return c;
     }
 
     // the 43 descriptors of zg_fr_rows_from_columns, in R1CSInputIndex order
     std::vector<zg_col_t> descriptors() const {
         std::vector<zg_col_t> d(NUM_INPUTS, zg_col_t{ZG_COL_ZERO, 0, 0, nullptr});  // NextIsVirtual, NextIsFirstInSequence stay zero (:1160-1171)
-        for (int k = 0; k < 12; k++) d[U64_INPUTS[k]] = zg_col_t{ZG_COL_U64, 0, 0, u64[k].data()};
-        d[8] = zg_col_t{ZG_COL_I64, 0, 0, imm.data()};
-        for (int k = 0; k < 3; k++) d[WIDE_INPUTS[k]] = zg_col_t{ZG_COL_I128, 0, 0, wide[k].data()};
-        if (!wide_fr.empty()) d[16] = zg_col_t{ZG_COL_FR, 0, 0, wide_fr.data()};
+        for (int k = 0; k < 12; k++) d[U64_INPUTS[k]] = zg_col_t{ZG_COL_U64, 0, 0, u64[k]};
+        d[8] = zg_col_t{ZG_COL_I64, 0, 0, imm};
+        for (int k = 0; k < 2; k++) d[WIDE_INPUTS[k]] = zg_col_t{ZG_COL_I128, 0, 0, wide[k]};
         d[2] = zg_col_t{ZG_COL_MUL, 0, 1, nullptr};  // Product = LeftInstructionInput * RightInstructionInput (:1120-1122)
-        for (uint32_t b = 0; b < 24; b++) d[BIT_INPUTS[b]] = zg_col_t{ZG_COL_BIT, b, 4, word.data()};
+        d[16] = zg_col_t{ZG_COL_MUL, 2, 25, wide[2]};  // RightLookupOperand = Product * FlagMultiplyOperands + the other rows' value
+        for (uint32_t b = 0; b < 24; b++) d[BIT_INPUTS[b]] = zg_col_t{ZG_COL_BIT, b, 4, word};
         return d;
     }
-    size_t bytesPerCycle() const { return 12 * 8 + 8 + 2 * 16 + (wide_fr.empty() ? 16 : 32) + 4; }
+    size_t bytesPerCycle() const { return BYTES_PER_CYCLE; }
+
+private:
+    struct Slab { void *p = nullptr; size_t bytes = 0; ~Slab() { if (p) zg_host_free(p); } };
+    static Slab &spare() { static thread_local Slab s; return s; }
+    void release() {  // the slab goes back to the thread's spare slot (one is kept; a second one is freed)
+        if (!slab_) return;
+        Slab &keep = spare();
+        if (!keep.p) { keep.p = slab_; keep.bytes = cap_; }
+        else zg_host_free(slab_);
+        slab_ = nullptr;
+    }
+    void *slab_ = nullptr;
+    size_t bytes_ = 0, cap_ = 0;
 };
 
 // The cycle-major witness matrix (num_cycles x 43 elements, src/zkvm/r1cs/evaluation.zig:55-122) resident in HBM: built once, shared by

@@ -212,6 +212,15 @@ class Bases:
              "zg_g1_bases_upload_dev")
         return cls(h, n)
 
+    def msm_u64(self, values, n=None, off=0):
+        """MSM over scalars given as u64 machine words (zg_msm_g1_u64): = msm(F.fromU64 of every word)"""
+        v = np.ascontiguousarray(values, dtype=np.uint64).reshape(-1)
+        n = v.size if n is None else n
+        out = np.empty(8, dtype=np.uint64)
+        inf = C.c_uint8(0)
+        _chk(_lib.zg_msm_g1_u64(self._h, C.c_size_t(off), C.c_size_t(n), _h(v), _h(out), C.byref(inf)), "zg_msm_g1_u64")
+        return out, int(inf.value)
+
     def table_bytes(self):
         """bytes of HBM held for the bases: the table of precomputed multiples (levels x 64 B per base), or the plain bases"""
         return int(_lib.zg_g1_bases_table_bytes(self._h))
@@ -575,7 +584,8 @@ def fr_rows_affine(rows, coeffs, ntab, g, n_pad=None, k=None):
 
 
 COL_ZERO, COL_U8, COL_U32, COL_U64, COL_I64, COL_I128, COL_U128, COL_FR, COL_BIT, COL_MUL = range(10)
-_COL_DTYPE = {COL_U8: np.uint8, COL_U32: np.uint32, COL_U64: np.uint64, COL_I64: np.int64, COL_I128: np.uint64, COL_U128: np.uint64, COL_FR: np.uint64}
+_COL_DTYPE = {COL_U8: np.uint8, COL_U32: np.uint32, COL_U64: np.uint64, COL_I64: np.int64, COL_I128: np.uint64, COL_U128: np.uint64, COL_FR: np.uint64,
+              COL_MUL: np.uint64}  # (COL_MUL's optional addend is a 128-bit two's-complement column)
 
 
 class Column(C.Structure):
@@ -597,7 +607,7 @@ def _columns(cols, n_rows, device):
             else:
                 dt = _COL_DTYPE.get(kind) or {1: np.uint8, 4: np.uint32, 8: np.uint64}[b]
                 h = np.ascontiguousarray(data, dtype=dt)
-                per = {COL_I128: 2, COL_U128: 2, COL_FR: 4}.get(kind, 1)
+                per = {COL_I128: 2, COL_U128: 2, COL_FR: 4, COL_MUL: 2}.get(kind, 1)
                 assert h.size == n_rows * per, (i, kind, h.shape, n_rows)
                 keep.append(h)
                 ptr = h.ctypes.data
@@ -674,6 +684,15 @@ def fr_rows_affine_dev(d_rows, n_rows, k, coeffs, ntab, g, n_pad, d_tables, stre
     ptrs = (C.c_void_p * ntab)(*[int(p) for p in d_tables])
     _chk(_lib.zg_fr_rows_affine_dev(_d(d_rows), C.c_size_t(n_rows), C.c_size_t(k), C.c_size_t(stride), _h(coeffs), C.c_size_t(ntab), C.c_size_t(g),
                                     C.c_size_t(n_pad), ptrs, _d(stream)), "zg_fr_rows_affine_dev")
+
+
+def fr_rows_affine_records_dev(d_rows, n_rows, k, coeffs, record, first, d_out, stream=0, stride=0):
+    """d_out[i * record + first + c] = map_c(row_i) for the nout <= 16 maps of coeffs (nout, k + 1, 4) (zg_fr_rows_affine_records_dev)"""
+    coeffs = _c(coeffs)
+    nout = coeffs.shape[0]
+    assert coeffs.shape == (nout, k + 1, 4)
+    _chk(_lib.zg_fr_rows_affine_records_dev(_d(d_rows), C.c_size_t(n_rows), C.c_size_t(k), C.c_size_t(stride), _h(coeffs), C.c_size_t(nout), C.c_size_t(record),
+                                            C.c_size_t(first), _d(d_out), _d(stream)), "zg_fr_rows_affine_records_dev")
 
 
 def fr_rows_affine_prodsum_dev(d_rows, n_rows, k, coeffs, npairs, d_weights, g, stream=0, stride=0):
