@@ -112,6 +112,7 @@ ZG_API int zg_dev_trim(void);
  * DMA at link rate whatever the page state of the process. Not pooled: the caller owns the lifetime. */
 ZG_API int zg_host_alloc(size_t bytes, void **ptr);
 ZG_API int zg_host_free(void *ptr);
+ZG_API int zg_dev_memset(void *dst_dev, int byte_value, size_t bytes); /* on the library's stream, returns when done (as the copies do) */
 ZG_API int zg_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
 ZG_API int zg_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
 ZG_API int zg_sync(void);
@@ -384,7 +385,8 @@ ZG_API int zg_sumcheck_open(const uint64_t *evals, size_t len, int layout, zg_sc
 ZG_API int zg_sumcheck_open_dev(const uint64_t *d_evals, size_t len, int layout, void *stream, zg_sc_t *s); /* copies */
 /* Spartan's first sumcheck instance in ONE pass (src/zkvm/spartan/mod.zig:182-206, then Sumcheck.Prover.init): opens a session
  * whose table is f[i] = eq(r, i) * (Az[i]*Bz[i] - Cz[i]) (eq as zg_fr_eq_table: r[0] <-> MSB, optional scale; Az, Bz, Cz: 2^v
- * device-resident elements) with round 0's sums already computed; the eq table is never materialised, nothing is copied. */
+ * device-resident elements; d_cz = NULL: Cz is identically zero, as JoltR1CS.computeCz leaves it, src/zkvm/r1cs/jolt_r1cs.zig:193-200)
+ * with round 0's sums already computed; the eq table is never materialised, nothing is copied. */
 ZG_API int zg_sumcheck_open_spartan_dev(const uint64_t *r /* host, v*4 */, size_t v, const uint64_t *scale /* host 4 or NULL */,
                                  const uint64_t *d_az, const uint64_t *d_bz, const uint64_t *d_cz, int layout, void *stream,
                                  zg_sc_t *s);

@@ -67,6 +67,7 @@ pub extern fn zg_dev_free(dptr: ?*anyopaque) c_int;
 pub extern fn zg_dev_trim() c_int;
 pub extern fn zg_host_alloc(bytes: usize, ptr: *?*anyopaque) c_int;
 pub extern fn zg_host_free(ptr: ?*anyopaque) c_int;
+pub extern fn zg_dev_memset(dst_dev: ?*anyopaque, byte_value: c_int, bytes: usize) c_int;
 pub extern fn zg_memcpy_h2d(dst_dev: ?*anyopaque, src_host: ?*const anyopaque, bytes: usize) c_int;
 pub extern fn zg_memcpy_d2h(dst_host: ?*anyopaque, src_dev: ?*const anyopaque, bytes: usize) c_int;
 pub extern fn zg_sync() c_int;

@@ -66,6 +66,7 @@ PROTOS = {
     "zg_dev_trim": (c_int, []),  # 
     "zg_host_alloc": (c_int, [c_size_t, c_void_p]),  # bytes, ptr
     "zg_host_free": (c_int, [c_void_p]),  # ptr
+    "zg_dev_memset": (c_int, [c_void_p, c_int, c_size_t]),  # dst_dev, byte_value, bytes
     "zg_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_size_t]),  # dst_dev, src_host, bytes
     "zg_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_size_t]),  # dst_host, src_dev, bytes
     "zg_sync": (c_int, []),  # 

@@ -839,7 +839,7 @@ __global__ void __launch_bounds__(256 * WG) eq_spartan_kernel(EqArgs ea, int v_l
         const size_t i = ((size_t)(h0 + k) << v_lo) | lo;
         a = fe_load<FrParams>(az + 4 * i);
         b = fe_load<FrParams>(bz + 4 * i);
-        c = fe_load<FrParams>(cz + 4 * i);
+        if (cz) c = fe_load<FrParams>(cz + 4 * i);  // cz == nullptr: Cz is identically zero (the uniform R1CS: condition * (left - right) = 0)
     }
     Fr lov = eq_block_factors(ea, v_lo, v_hi, h0, rows, fs);
     Acc9 g0 = acc9_zero(), g1 = acc9_zero();
@@ -853,7 +853,7 @@ __global__ void __launch_bounds__(256 * WG) eq_spartan_kernel(EqArgs ea, int v_l
                 const size_t ni = ((size_t)(h0 + nk) << v_lo) | lo;
                 na = fe_load<FrParams>(az + 4 * ni);
                 nb = fe_load<FrParams>(bz + 4 * ni);
-                nc = fe_load<FrParams>(cz + 4 * ni);
+                if (cz) nc = fe_load<FrParams>(cz + 4 * ni);
             }
             // f = e (a b - c) with e = hi lo, as ONE lazy chain (no canonical value between the three products): with every
             // 2^-261 of the lazy multiplier paid for by a 5-bit shift of one operand,
@@ -2686,7 +2686,7 @@ int zg_sumcheck_open_dev(const uint64_t *d_evals, size_t len, int layout, void *
 int zg_sumcheck_open_spartan_dev(const uint64_t *r, size_t v, const uint64_t *scale, const uint64_t *d_az, const uint64_t *d_bz,
                                  const uint64_t *d_cz, int layout, void *stream, zg_sc_t *out) {
     ZG_INIT();
-    if (!out || (v && !r) || !d_az || !d_bz || !d_cz || v > 30) {
+    if (!out || (v && !r) || !d_az || !d_bz || v > 30) {  // d_cz may be NULL: Cz = 0
         set_error("zg_sumcheck_open_spartan_dev: invalid argument");
         return ZG_ERR_INVALID;
     }

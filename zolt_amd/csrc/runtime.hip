@@ -491,6 +491,13 @@ int zg_memcpy_h2d(void *dst, const void *src, size_t bytes) {
     ZG_HIP(hipStreamSynchronize(lib_stream()));
     return ZG_OK;
 }
+int zg_dev_memset(void *dst, int byte_value, size_t bytes) {
+    ZG_INIT();
+    if (bytes == 0) return ZG_OK;
+    ZG_HIP(hipMemsetAsync(dst, byte_value, bytes, lib_stream()));
+    ZG_HIP(hipStreamSynchronize(lib_stream()));
+    return ZG_OK;
+}
 int zg_memcpy_d2h(void *dst, const void *src, size_t bytes) {
     ZG_INIT();
     ZG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, lib_stream()));
