@@ -251,26 +251,27 @@ static Timeline prove_once(const ProveCase &pc, bool emit) {
     const size_t K = size_t(1) << pc.log_k;
     std::vector<Fr> ra(K, Fr::zero());
     if (!pc.accesses.empty()) {
-        DeviceMem d_eq(T * 32);
-        check(zg_fr_eq_table_dev(reinterpret_cast<const uint64_t *>(r_cycle.data()), pc.log_t, nullptr, d_eq.u64(), nullptr), "zg_fr_eq_table_dev");
-        zg_sc_t se = nullptr;
-        check(zg_sumcheck_open_dev(d_eq.u64(), T, ZG_SC_LOW_PAIR, nullptr, &se), "zg_sumcheck_open_dev");
-        std::vector<uint64_t> idx(pc.accesses.size());
-        for (size_t i = 0; i < idx.size(); i++) idx[i] = pc.accesses[i].timestamp;
-        std::vector<Fr> w(idx.size());
-        check(zg_sumcheck_gather(se, idx.data(), idx.size(), reinterpret_cast<uint64_t *>(w.data())), "zg_sumcheck_gather");
-        zg_sumcheck_close(se);
-        for (size_t i = 0; i < idx.size(); i++) {
-            const uint64_t a = pc.accesses[i].address;
+        // RaPolynomial.fromTrace (src/zkvm/ram/raf_checking.zig:88-132): ra(k) += eq(r_cycle, j) for ACCESS j of slot k, the eq table over
+        // ceil(log2(#accesses)) variables, little-endian (computeEqEvals :535-567: index bit i <-> r[i]) = the device's big-endian table of
+        // the reversed point; missing challenges read as zero
+        size_t log_a = 0;
+        while ((size_t(1) << log_a) < pc.accesses.size()) log_a++;
+        std::vector<Fr> r_rev(log_a, Fr::zero());
+        for (size_t i = 0; i < log_a; i++)
+            if (i < r_cycle.size()) r_rev[log_a - 1 - i] = r_cycle[i];
+        std::vector<Fr> eq(size_t(1) << log_a);
+        check(zg_fr_eq_table(reinterpret_cast<const uint64_t *>(r_rev.data()), log_a, nullptr, reinterpret_cast<uint64_t *>(eq.data())), "zg_fr_eq_table");
+        for (size_t j = 0; j < pc.accesses.size(); j++) {
+            const uint64_t a = pc.accesses[j].address;
             if (a < pc.start_address) continue;
             const size_t k = (a - pc.start_address) / 8;
-            if (k < K) ra[k] = ra[k].add(w[i]);
+            if (k < K) ra[k] = ra[k].add(eq[j]);
         }
     }
     Fr claim2 = Fr::zero();
     for (size_t k = 0; k < K; k++)
         if (!ra[k].isZero()) claim2 = claim2.add(ra[k].mul(Fr::fromU64(pc.start_address + 8 * k)));
-    tl.lap("stage 2: RaPolynomial.fromTrace (eq table on the device, gather at the access times, per-slot sums on the host)", "kernels+d2h+host");
+    tl.lap("stage 2: RaPolynomial.fromTrace (eq table on the device, per-slot sums on the host)", "kernels+d2h+host");
     {
         RafEvaluationProver raf(ra, pc.start_address, claim2);
         std::vector<Fr> ch2;
@@ -284,7 +285,7 @@ static Timeline prove_once(const ProveCase &pc, bool emit) {
             raf.bindChallenge(c);
         }
         line(emit, "H", ch2);
-        line(emit, "C", {claim2, raf.current_claim});
+        line(emit, "C", {claim2, raf.getFinalClaim()});
     }
     tl.lap("stage 2: RAF cubic rounds (log K)", "h2d+kernels+host");
     // ---- stage 3: Lasso (prover.zig:562-700)

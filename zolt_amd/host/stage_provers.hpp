@@ -1284,6 +1284,11 @@ public:
         return {s0, s1, s2, s0.sub(s1.mul(three)).add(s2.mul(three))};
     }
     void updateClaim(const std::array<Fr, 4> &evals, const Fr &c) { current_claim = cubicAtPoint(evals, c); }  // :420-445
+    Fr getFinalClaim() {  // :448-450 -> RaPolynomial.finalClaim (:179-185): evals[0] once every address variable is bound
+        Fr v = Fr::zero();
+        if (zg_sumcheck_len(s_) == 1) check(zg_sumcheck_final(s_, v.limbs), "zg_sumcheck_final");
+        return v;
+    }
     void bindChallenge(const Fr &c) {  // RaPolynomial.bind (:162-174) + the bound-address bookkeeping (:413-417)
         check(zg_sumcheck_bind(s_, c.limbs), "zg_sumcheck_bind");
         base_ = base_.add(c.mul(Fr::fromU64(power_)));
