@@ -522,3 +522,68 @@ def test_cpp_witness_matrix_from_trace_columns(tmp_path, golden_dir):
         assert len(s1) == 2 and s1[0] == s1[1]
         bpc = int([l for l in res.stdout.splitlines() if l.startswith("B ")][0].split()[1])
         assert bpc == 156
+
+
+@pytest.mark.gpu
+def test_prove_path_composite_regenerates_the_captured_proof_file(golden_dir, tmp_path):
+    """tools/bench_prove_path — ONE sequence from compiled host code: HyperKZG.setup at the reference's srs_size, the three commitments from
+    machine words, the witness matrix widened on the device from integer trace columns, Az / Bz materialised on the device in JoltR1CS's
+    layout, the fused eq * Az * Bz open and its thirteen LowToHigh rounds, RAF, Lasso, stages 4-6 — fed with nothing but what the ELF
+    yields (trace steps, lookup indices, program bytes). Its header commitments and stage records re-serialised ARE the reference's
+    captured proof file: all 11 345 bytes (BASELINE config 5), and the same run prints the per-call cost breakdown of the sequence."""
+    import hashlib
+    import json
+    import numpy as np
+    from oracle import binding as ob  # representation conversions only
+    from tests import util as U
+    from zolt_amd import api
+    exe = os.path.join(ROOT, "tools", "bench_prove_path")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "../../tools/bench_prove_path"])
+    P = U.proof_file_sections()
+    data = open(os.path.join(golden_dir, "zolt_proof_regular.bin"), "rb").read()
+    elf = open(os.path.join(golden_dir, "fibonacci.elf"), "rb").read()
+    steps = U.fibonacci_full_trace(elf)
+    idx = U.fibonacci_lookup_indices(elf)
+    code = elf[0x1000:0x1000 + 104]
+    path = tmp_path / "prove_case.txt"
+    with open(path, "w") as f:
+        f.write(f"{P['log_t']} {P['log_k']} 1280 80000000\n{len(steps)}\n")
+        for st in steps:
+            f.write("%x %x %x %x %x %x %d %x %d %d\n" % (st["instruction"], st["pc"], st["unexpanded_pc"], st["rs1_value"], st["rs2_value"], st["rd_value"],
+                                                        st["memory_value"] is not None, st["memory_value"] or 0, st["is_compressed"], st["is_noop"]))
+        f.write("0\n")  # the fibonacci run touches no RAM
+        f.write(f"{idx.shape[0]}\n" + "".join(f"{int(lo)} {int(hi)}\n" for lo, hi in idx))
+        f.write(f"{len(code)}\n" + code.hex() + "\n")
+    res = subprocess.run([exe, "file", str(path), "1"], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    stages, cur, comm = [], None, {}
+    to_int = lambda words: ob.fr_to_int(np.array([int(x, 16) for x in words], dtype=np.uint64))
+    for line in res.stdout.splitlines():
+        t = line.split()
+        if not t:
+            continue
+        if t[0] == "K":
+            comm[t[1]] = bytes.fromhex(t[2])
+        elif t[0] == "S":
+            cur = ([], [], [])
+            stages.append(cur)
+        elif t[0] == "P":
+            cur[0].append([to_int(t[1 + 4 * k:5 + 4 * k]) for k in range((len(t) - 1) // 4)])
+        elif t[0] == "H":
+            cur[1].extend(to_int(t[1 + 4 * k:5 + 4 * k]) for k in range((len(t) - 1) // 4))
+        elif t[0] == "C":
+            cur[2].extend(to_int(t[1 + 4 * k:5 + 4 * k]) for k in range((len(t) - 1) // 4))
+    assert len(stages) == 6 and set(comm) == {"bytecode", "memory", "register"}
+    want = api.parse_zolt_proof_commitments(data)
+    assert comm["bytecode"] == want["bytecode.commitment"] and comm["memory"] == want["memory.commitment"] == bytes(64) and comm["register"] == want["register.commitment"]
+    # the header a `zolt prove` run writes from these three commitments (every other commitment slot of this run is the identity)
+    offs = P["absorbed_commitment_offsets"]
+    composed = bytearray(data[:744])
+    for name, key in (("bytecode", "bytecode"), ("memory", "memory"), ("register", "registers")):
+        composed[offs[key]:offs[key] + 64] = bytes(64)
+        composed[offs[key]:offs[key] + 64] = comm[name]
+    tail = U.serialize_stage_sections(P["log_t"], P["log_k"], stages)
+    assert tail == data[744:]
+    assert hashlib.sha256(bytes(composed) + tail).digest() == hashlib.sha256(data).digest() and len(composed) + len(tail) == 11345
+    line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])["prove_path"]
+    assert line["log_t"] == 8 and len(line["steps"]) >= 15 and len(line["top3"]) == 3 and line["total_ms"] > 0

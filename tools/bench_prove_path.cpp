@@ -23,6 +23,7 @@
 #include "../include/zolt_gpu_internal.h"
 
 using namespace zolt;
+using zolt::wire::commitmentToBytes;
 using clk = std::chrono::steady_clock;
 
 static uint64_t sm_state = 0x50524F5645ULL;
