@@ -933,6 +933,17 @@ def extra_measurements(lib, api, torch, dev, stream, args, srs_xy=None):
             extra["prover_sites_v13_compiled_host"] = json.loads(out.stdout.strip().splitlines()[-1])
         except Exception as e:  # noqa: BLE001
             extra["prover_sites_v13_compiled_host"] = {"error": str(e)}
+    # ONE proof as one sequence (review item 3): proving key, three commitments from machine words, stages 1-6 with their uploads, the
+    # opening — per-call costs and the top three, from compiled host code (tools/bench_prove_path.cpp); bytes at log_t = 8 are held
+    # against the reference's captured proof file by tests/test_gpu_cpp_host.py
+    exe = os.path.join(ROOT, "tools", "bench_prove_path")
+    if os.path.exists(exe):
+        import subprocess
+        try:
+            out = subprocess.run([exe, "synth", "20", "2"], capture_output=True, text=True, timeout=600)
+            extra["prove_path"] = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])["prove_path"]
+        except Exception as e:  # noqa: BLE001
+            extra["prove_path"] = {"error": str(e)}
     return extra
 
 

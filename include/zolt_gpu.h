@@ -76,7 +76,7 @@ extern "C" {
  *             compile with -DZG_NO_PROTOCOL_SESSIONS to leave them out of the binding; zg_abi_features() reports whether the loaded
  *             library carries them. */
 #define ZG_ABI_MAJOR 1
-#define ZG_ABI_MINOR 6
+#define ZG_ABI_MINOR 7
 #define ZG_FEATURE_PROTOCOL_SESSIONS 1u /* zg_rrw_* and zg_rwc_* are exported */
 #define ZG_FEATURE_RCCL 2u              /* the several-GPU entry points can exchange partials over RCCL */
 #define ZG_FEATURE_COLUMN_INGEST 4u     /* zg_fr_rows_from_columns[_dev] */
@@ -314,6 +314,8 @@ ZG_API int zg_fr_rows_affine_records_dev(const uint64_t *d_rows, size_t n_rows, 
  *   ZG_COL_MUL   the product of columns a and b of the same row, plus — when data is given — a           per row -> 0 or F.one()
  *                128-bit two's-complement addend per row. A factor may itself be a ZG_COL_MUL column whose factors are plain columns
  *                (RightLookupOperand = Product * FlagMultiplyOperands + the sum / difference of the other rows), no deeper.
+ *   ZG_COL_LUT   data = an index per row (a = 1, 2 or 4 bytes each), aux = a table of b Montgomery elements: the value is table[index]
+ *                (an index >= b reads as zero) — eq_evals[j] = table[rd(j)] of proveStage5, src/zkvm/prover.zig:880-900
  * Several ZG_COL_BIT columns may name the same word array (it crosses once). n_cols <= 64. */
 #define ZG_COL_ZERO 0
 #define ZG_COL_U8 1
@@ -325,10 +327,12 @@ ZG_API int zg_fr_rows_affine_records_dev(const uint64_t *d_rows, size_t n_rows, 
 #define ZG_COL_FR 7
 #define ZG_COL_BIT 8
 #define ZG_COL_MUL 9
+#define ZG_COL_LUT 10
 typedef struct {
     uint32_t kind; /* ZG_COL_* */
-    uint32_t a, b; /* ZG_COL_BIT: bit index, bytes per word; ZG_COL_MUL: the two factor columns (data: optional addend) */
+    uint32_t a, b; /* ZG_COL_BIT: bit index, bytes per word; ZG_COL_MUL: the two factor columns (data: optional addend); ZG_COL_LUT: bytes per index, table length */
     const void *data;
+    const void *aux; /* ZG_COL_LUT: the table (b elements); NULL otherwise */
 } zg_col_t;
 /* host columns (pageable, or pinned from zg_host_alloc); returns when the matrix is complete */
 ZG_API int zg_fr_rows_from_columns(const zg_col_t *cols, size_t n_cols, size_t n_rows, uint64_t *d_rows /* device, n_rows*n_cols*4 */);
@@ -383,6 +387,10 @@ ZG_API int zg_fr_spartan_combine_dev(const uint64_t *d_eq, const uint64_t *d_az,
 typedef struct zg_sc_s *zg_sc_t;
 ZG_API int zg_sumcheck_open(const uint64_t *evals, size_t len, int layout, zg_sc_t *s);
 ZG_API int zg_sumcheck_open_dev(const uint64_t *d_evals, size_t len, int layout, void *stream, zg_sc_t *s); /* copies */
+/* A session whose table is ONE integer column widened on the device (zg_fr_rows_from_columns' kinds; host data): entries [0, n_rows) from
+ * the column, [n_rows, len) zero. The tables of proveStage5 (eq_evals[j] = table[rd of cycle j]: a ZG_COL_LUT over one byte per cycle) and
+ * proveStage6 (all zero: ZG_COL_ZERO) are built this way without a 32-byte-per-cycle upload (src/zkvm/prover.zig:880-944, 1024-1097). */
+ZG_API int zg_sumcheck_open_column(const zg_col_t *col, size_t n_rows, size_t len, int layout, zg_sc_t *s);
 /* Spartan's first sumcheck instance in ONE pass (src/zkvm/spartan/mod.zig:182-206, then Sumcheck.Prover.init): opens a session
  * whose table is f[i] = eq(r, i) * (Az[i]*Bz[i] - Cz[i]) (eq as zg_fr_eq_table: r[0] <-> MSB, optional scale; Az, Bz, Cz: 2^v
  * device-resident elements; d_cz = NULL: Cz is identically zero, as JoltR1CS.computeCz leaves it, src/zkvm/r1cs/jolt_r1cs.zig:193-200)

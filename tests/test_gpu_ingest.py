@@ -38,7 +38,10 @@ def test_every_column_kind_at_the_edges(n):
     cols = [(lib.COL_U64, u64), (lib.COL_I64, i64), (lib.COL_MUL, None, 0, 1), (lib.COL_U8, word8), (lib.COL_U32, word32), (lib.COL_I128, wide),
             (lib.COL_U128, wide), (lib.COL_FR, frs), (lib.COL_ZERO, None), (lib.COL_BIT, word32, 0, 4), (lib.COL_BIT, word32, 31, 4),
             (lib.COL_BIT, word64, 62, 8), (lib.COL_BIT, word8, 7, 1), (lib.COL_MUL, None, 5, 7), (lib.COL_MUL, None, 6, 6),
-            (lib.COL_MUL, wide, 2, 9), (lib.COL_MUL, wide[::-1].copy(), 0, 12)]  # product of a product + an addend; product + an addend
+            (lib.COL_MUL, wide, 2, 9), (lib.COL_MUL, wide[::-1].copy(), 0, 12),  # product of a product + an addend; product + an addend
+            (lib.COL_LUT, word8, 1, 200, frs[:200] if n >= 200 else np.concatenate([frs] * (200 // n + 1))[:200]),  # indices >= 200 read as zero
+            (lib.COL_LUT, (word32 & 0x3FF).astype(np.uint16), 2, 1000, np.concatenate([frs] * (1000 // n + 1))[:1000]),
+            (lib.COL_LUT, word32 & np.uint32(31), 4, 32, np.concatenate([frs] * (32 // n + 1))[:32])]
     got = lib.fr_rows_from_columns(cols, n)
     assert got.shape == (n, len(cols), 4)
     assert rows_int(got) == widen_columns_model(cols, n)
@@ -48,7 +51,11 @@ def test_every_column_kind_at_the_edges(n):
     for spec in cols:
         if len(spec) > 1 and spec[1] is not None:
             bufs.append(lib.DeviceBuffer.from_host(spec[1]))
-            dcols.append((spec[0], bufs[-1].ptr) + tuple(spec[2:]))
+            d = (spec[0], bufs[-1].ptr) + tuple(spec[2:4])
+            if len(spec) > 4:
+                bufs.append(lib.DeviceBuffer.from_host(spec[4]))
+                d += (bufs[-1].ptr,)
+            dcols.append(d)
         else:
             dcols.append(spec)
     out = lib.DeviceBuffer(n * len(cols) * 32)
@@ -116,3 +123,30 @@ def test_witness_matrix_of_random_traces(seed, n):
         assert rows_int(got[::997]) == model
         again = lib.fr_rows_from_columns(cols, len(steps))
         assert np.array_equal(again, got)
+
+
+def test_session_from_one_column():
+    """zg_sumcheck_open_column: a session whose table is one widened column, zero past n_rows — the tables of proveStage5 (a 32-entry lookup
+    by the rd byte of every cycle) and proveStage6 (all zero) without a 32-byte-per-entry upload; rounds equal a session opened on the
+    host-built table"""
+    lib.init(0)
+    rng = np.random.default_rng(3)
+    table = lib.field_op(lib.FR, lib.OP_TO_MONT, rng.integers(0, 1 << 62, size=(32, 4), dtype=np.uint64))
+    for n_rows, n in ((1000, 1024), (1, 2), (4096, 4096), (0, 64)):
+        rd = rng.integers(0, 32, size=n_rows, dtype=np.uint8)
+        want = np.zeros((n, 4), dtype=np.uint64)
+        want[:n_rows] = table[rd]
+        col = (lib.COL_LUT, rd, 1, 32, table) if n_rows else (lib.COL_ZERO, None)
+        s1, s2 = lib.SumcheckSession.open_column(col, n_rows, n, lib.SC_HIGH_HALF), lib.SumcheckSession.open(want, lib.SC_HIGH_HALF)
+        assert np.array_equal(s1.read(), want)
+        while len(s1) > 1:
+            a, b = s1.round_sums(), s2.round_sums()
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+            r = table[len(s1) % 32]
+            s1.bind(r)
+            s2.bind(r)
+        assert np.array_equal(s1.final(), s2.final())
+        s1.close()
+        s2.close()
+    with pytest.raises(lib.ZgError):
+        lib.SumcheckSession.open_column((lib.COL_ZERO, None), 5, 4)

@@ -31,6 +31,9 @@ def widen_columns_model(cols, n):
                 v = api.fr_to_int(data[i])
             elif kind == lib.COL_BIT:
                 v = (int(data[i]) >> a) & 1
+            elif kind == lib.COL_LUT:
+                ix = int(data[i])
+                v = api.fr_to_int(spec[4][ix]) if ix < b else 0
             else:
                 continue
             out[i][c] = v % R

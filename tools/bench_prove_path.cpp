@@ -339,7 +339,7 @@ static Timeline prove_once(const ProveCase &pc, bool emit) {
     std::vector<Fr> point;
     for (size_t i = 0; i < reg_vars; i++) point.push_back(tr.challengeScalar("opening_point"));
     DeviceMem d_reg(reg.size() * 32);
-    const zg_col_t reg_col{ZG_COL_U64, 0, 0, reg.data()};
+    const zg_col_t reg_col{ZG_COL_U64, 0, 0, reg.data(), nullptr};
     check(zg_fr_rows_from_columns(&reg_col, 1, reg.size(), d_reg.u64()), "zg_fr_rows_from_columns");
     std::vector<uint64_t> q(8 * (reg_vars ? reg_vars : 1));
     std::vector<uint8_t> qi(reg_vars ? reg_vars : 1);

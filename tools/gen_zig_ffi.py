@@ -96,7 +96,7 @@ def generate():
     ] + [f"pub const {zname} = ?*opaque {{}}; // {cname}" for cname, zname in HANDLES.items()] + [  # every handle type the externs below name
         "",
         "pub const MsmConfig = extern struct { window_bits: c_int = 0, precompute_levels: c_int = 0, expected_uses: c_int = 0 };",
-        "pub const Column = extern struct { kind: u32 = 0, a: u32 = 0, b: u32 = 0, data: ?*const anyopaque = null }; // zg_col_t",
+        "pub const Column = extern struct { kind: u32 = 0, a: u32 = 0, b: u32 = 0, data: ?*const anyopaque = null, aux: ?*const anyopaque = null }; // zg_col_t",
         "pub const PscTerm = extern struct { n_prod: c_int = 0, prod: [4]c_int = .{ 0, 0, 0, 0 }, n_lin: c_int = 0, lin: [4]c_int = .{ 0, 0, 0, 0 }, lin_coeff: [16]u64 = .{0} ** 16 }; // zg_psc_term",
         "",
     ]

@@ -15,7 +15,7 @@ pub const RegistersSession = ?*opaque {}; // zg_rrw_t
 pub const RamRwSession = ?*opaque {}; // zg_rwc_t
 
 pub const MsmConfig = extern struct { window_bits: c_int = 0, precompute_levels: c_int = 0, expected_uses: c_int = 0 };
-pub const Column = extern struct { kind: u32 = 0, a: u32 = 0, b: u32 = 0, data: ?*const anyopaque = null }; // zg_col_t
+pub const Column = extern struct { kind: u32 = 0, a: u32 = 0, b: u32 = 0, data: ?*const anyopaque = null, aux: ?*const anyopaque = null }; // zg_col_t
 pub const PscTerm = extern struct { n_prod: c_int = 0, prod: [4]c_int = .{ 0, 0, 0, 0 }, n_lin: c_int = 0, lin: [4]c_int = .{ 0, 0, 0, 0 }, lin_coeff: [16]u64 = .{0} ** 16 }; // zg_psc_term
 
 pub const OK: c_int = 0;
@@ -35,7 +35,7 @@ pub const OP_INV: c_int = 5;
 pub const OP_FROM_MONT: c_int = 6;
 pub const OP_TO_MONT: c_int = 7;
 pub const ABI_MAJOR: u32 = 1;
-pub const ABI_MINOR: u32 = 6;
+pub const ABI_MINOR: u32 = 7;
 pub const FEATURE_PROTOCOL_SESSIONS: u32 = 1;
 pub const FEATURE_RCCL: u32 = 2;
 pub const FEATURE_COLUMN_INGEST: u32 = 4;
@@ -49,6 +49,7 @@ pub const COL_U128: u32 = 6;
 pub const COL_FR: u32 = 7;
 pub const COL_BIT: u32 = 8;
 pub const COL_MUL: u32 = 9;
+pub const COL_LUT: u32 = 10;
 pub const SC_HIGH_HALF: c_int = 0;
 pub const SC_LOW_PAIR: c_int = 1;
 pub const PSC_PAIR_SUM: c_int = 256;
@@ -123,6 +124,7 @@ pub extern fn zg_fr_spartan_combine(eq: ?[*]const u64, az: ?[*]const u64, bz: ?[
 pub extern fn zg_fr_spartan_combine_dev(d_eq: ?[*]const u64, d_az: ?[*]const u64, d_bz: ?[*]const u64, d_cz: ?[*]const u64, n: usize, d_out: ?[*]u64, stream: ?*anyopaque) c_int;
 pub extern fn zg_sumcheck_open(evals: ?[*]const u64, len: usize, layout: c_int, s: *Session) c_int;
 pub extern fn zg_sumcheck_open_dev(d_evals: ?[*]const u64, len: usize, layout: c_int, stream: ?*anyopaque, s: *Session) c_int;
+pub extern fn zg_sumcheck_open_column(col: ?[*]const Column, n_rows: usize, len: usize, layout: c_int, s: *Session) c_int;
 pub extern fn zg_sumcheck_open_spartan_dev(r: ?[*]const u64, v: usize, scale: ?[*]const u64, d_az: ?[*]const u64, d_bz: ?[*]const u64, d_cz: ?[*]const u64, layout: c_int, stream: ?*anyopaque, s: *Session) c_int;
 pub extern fn zg_sumcheck_round_sums(s: Session, g0: *[4]u64, g1: *[4]u64) c_int;
 pub extern fn zg_sumcheck_bind(s: Session, r: *const [4]u64) c_int;

@@ -64,8 +64,11 @@ def _highHalfRounds(evals, num_rounds, transcript, label):
     """the round loop of stages 5 and 6 (src/zkvm/prover.zig:902-944, 1055-1097) over a HIGH_HALF device session: p(0), p(1) = the sums
     of the two halves (64 bytes back per round), the proof keeps [p(0), 2 p(1) - p(0)], the challenge folds f[j] = (1 - r) f[j] + r f[j + half]
     on the device, claim = (1 - r) p(0) + r p(1) on the host"""
-    ev = np.ascontiguousarray(evals, dtype=np.uint64).reshape(-1, 4)
-    sess = lib.SumcheckSession.open(ev, lib.SC_HIGH_HALF)
+    if isinstance(evals, lib.SumcheckSession):  # a session built on the device (open_column)
+        sess = evals
+    else:
+        ev = np.ascontiguousarray(evals, dtype=np.uint64).reshape(-1, 4)
+        sess = lib.SumcheckSession.open(ev, lib.SC_HIGH_HALF)
     polys, chals, claims, initial = [], [], [], None
     try:
         for _ in range(num_rounds):
@@ -154,9 +157,10 @@ def proveStage5(instructions, log_t, transcript):
         return {"r_register": r_register, "r_cycle_reg": r_cycle_reg, "initial_claim": None}
     num_rounds = 0 if len(instr) <= 1 else (len(instr) - 1).bit_length()
     table = np.stack([computeRegEq(r_register, reg) for reg in range(32)])
-    eq_evals = np.zeros((1 << num_rounds, 4), dtype=np.uint64)
-    eq_evals[:len(instr)] = table[(instr >> 7) & 31]
-    polys, chals, claims, fin, initial = _highHalfRounds(eq_evals, num_rounds, transcript, b"reg_eval_round")
+    # eq_evals[j] = table[rd(j)], zero past the trace: one byte per cycle crosses, the lookup runs on the device (ZG_COL_LUT)
+    rd = ((instr >> 7) & 31).astype(np.uint8)
+    sess = lib.SumcheckSession.open_column((lib.COL_LUT, rd, 1, 32, table), len(rd), 1 << num_rounds, lib.SC_HIGH_HALF)
+    polys, chals, claims, fin, initial = _highHalfRounds(sess, num_rounds, transcript, b"reg_eval_round")
     return {"r_register": r_register, "r_cycle_reg": r_cycle_reg, "initial_claim": initial, "round_polys": polys, "challenges": chals,
             "claims": claims, "final_claim": fin}
 
@@ -168,7 +172,8 @@ def proveStage6(trace_len, transcript):
     if trace_len == 0:
         return {"bool_challenge": bool_challenge, "initial_claim": None}
     num_rounds = 0 if trace_len <= 1 else (trace_len - 1).bit_length()
-    polys, chals, claims, fin, initial = _highHalfRounds(np.zeros((1 << num_rounds, 4), dtype=np.uint64), num_rounds, transcript, b"bool_round")
+    sess = lib.SumcheckSession.open_column((lib.COL_ZERO, None), 0, 1 << num_rounds, lib.SC_HIGH_HALF)  # cleared on the device, nothing uploaded
+    polys, chals, claims, fin, initial = _highHalfRounds(sess, num_rounds, transcript, b"bool_round")
     return {"bool_challenge": bool_challenge, "initial_claim": initial, "round_polys": polys, "challenges": chals,
             "claims": claims, "final_claim": fin}
 

@@ -175,6 +175,8 @@ int msm_batch_dev_wide(zg_bases_t b, size_t n, const uint64_t *d_scalars, size_t
 int msm_batch_partials_dev(zg_bases_t b, size_t n, const uint64_t *d_scalars, size_t k, hipStream_t st, uint64_t *d_out12);
 int msm_combine_batch_enqueue(const uint64_t *d_partials, size_t ranks, size_t rank_stride, size_t k, hipStream_t st, uint64_t *d_out9);
 int bases_device(zg_bases_t b);
+// ingest.hip: host columns widened into the cycle-major matrix at d_rows on st (synchronous: zg_fr_rows_from_columns, zg_sumcheck_open_column)
+int rows_from_host_columns(const zg_col_t *cols, size_t n_cols, size_t n_rows, uint64_t *d_rows, hipStream_t st);
 // ingest.hip: d_out[i] = F.fromU64(d_vals[i]) as canonical Montgomery elements, one launch on st (zg_msm_g1_u64's widening step)
 int ingest_u64_to_fr(const uint64_t *d_vals, size_t n, uint64_t *d_out, hipStream_t st);
 // poly.hip, for sharded.hip: enqueue a session's round-sums pass without waiting for its mailbox

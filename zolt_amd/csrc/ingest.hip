@@ -15,12 +15,13 @@
 
 namespace zg {
 
-static constexpr uint32_t ING_MAX_COLS = 64;   // 64 rows x 64 columns x 32 B = 128 KiB of LDS per workgroup
+static constexpr uint32_t ING_MAX_COLS = 64;   // 64 rows x 64 columns x 32 B = 128 KiB of LDS per workgroup (kernel arguments: 64 x 32 B)
 static constexpr uint32_t ING_TILE_ROWS = 64;  // one lane per row of a tile: column reads are 64 consecutive values
 
 struct IngCol {
     uint32_t kind, a, b, pad;
     const void *data;  // device address of the column's n_rows values (nullptr for derived kinds)
+    const void *aux;   // ZG_COL_LUT: device address of the table
 };
 struct IngArgs {
     IngCol c[ING_MAX_COLS];
@@ -99,6 +100,13 @@ __global__ void __launch_bounds__(512) rows_from_columns_kernel(IngArgs args, ui
                     if ((w >> d.a) & 1) v = Fr::one();
                     break;
                 }
+                case ZG_COL_LUT: {  // table[index], an index past the table reads as zero
+                    const uint32_t ix = d.a == 4 ? reinterpret_cast<const uint32_t *>(d.data)[row]
+                                      : d.a == 2 ? (uint32_t) reinterpret_cast<const uint16_t *>(d.data)[row]
+                                                 : (uint32_t) reinterpret_cast<const uint8_t *>(d.data)[row];
+                    if (ix < d.b) v = fe_load<FrParams>(reinterpret_cast<const uint64_t *>(d.aux) + 4 * (size_t)ix);
+                    break;
+                }
                 default: break;  // ZG_COL_ZERO
             }
         }
@@ -136,7 +144,7 @@ __global__ void __launch_bounds__(512) rows_from_columns_kernel(IngArgs args, ui
     for (size_t i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = tile[i];
 }
 
-static size_t col_width(uint32_t kind, uint32_t b) {
+static size_t col_width(uint32_t kind, uint32_t b, uint32_t a_of_lut = 0) {
     switch (kind) {
         case ZG_COL_U8: return 1;
         case ZG_COL_U32: return 4;
@@ -145,6 +153,7 @@ static size_t col_width(uint32_t kind, uint32_t b) {
         case ZG_COL_FR: return 32;
         case ZG_COL_BIT: return b;
         case ZG_COL_MUL: return 16;  // the optional addend (no data: nothing crosses)
+        case ZG_COL_LUT: return a_of_lut;
         default: return 0;
     }
 }
@@ -167,12 +176,14 @@ static int validate_cols(const zg_col_t *cols, size_t n_cols, size_t n_rows, uin
     }
     for (size_t c = 0; c < n_cols; c++) {
         const zg_col_t &d = cols[c];
-        bool ok = d.kind <= ZG_COL_MUL;
+        bool ok = d.kind <= ZG_COL_LUT;
+        if (ok && d.kind == ZG_COL_LUT) ok = (d.a == 1 || d.a == 2 || d.a == 4) && (d.b == 0 || d.aux) && (d.data || n_rows == 0);
+        else
         if (ok && d.kind == ZG_COL_MUL) ok = mul_depth(cols, n_cols, c) != 0;
         else if (ok && d.kind == ZG_COL_BIT) ok = (d.b == 1 || d.b == 4 || d.b == 8) && d.a < 8 * d.b && d.data;
         else if (ok && d.kind != ZG_COL_ZERO) ok = d.data != nullptr || n_rows == 0;
         if (!ok) {
-            set_error("zg_fr_rows_from_columns: column " + std::to_string(c) + ": unknown kind, missing data, a bit outside its word, or a product nested deeper than two");
+            set_error("zg_fr_rows_from_columns: column " + std::to_string(c) + ": unknown kind, missing data or table, a bit outside its word, an index width other than 1 / 2 / 4, or a product nested deeper than two");
             return ZG_ERR_INVALID;
         }
     }
@@ -188,9 +199,58 @@ static int launch_rows_from_columns(const IngArgs &args, size_t n_cols, size_t n
     return ZG_OK;
 }
 
+// host columns -> the matrix at d_rows, on st; returns after the stream is synchronised (the staging buffer goes back to the pool)
+int rows_from_host_columns(const zg_col_t *cols, size_t n_cols, size_t n_rows, uint64_t *d_rows, hipStream_t st) {
+    ZG_TRY(validate_cols(cols, n_cols, n_rows, d_rows));
+    if (n_rows == 0) return ZG_OK;
+    // several ZG_COL_BIT columns usually share one packed word array: upload each distinct (pointer, size) once
+    struct Src { const void *host; size_t bytes, off; };
+    std::vector<Src> srcs;
+    size_t total = 0;
+    auto source = [&](const void *host, size_t bytes) -> size_t {
+        for (size_t s = 0; s < srcs.size(); s++)
+            if (srcs[s].host == host && srcs[s].bytes == bytes) return s;
+        srcs.push_back(Src{host, bytes, total});
+        total += (bytes + 255) & ~(size_t)255;
+        return srcs.size() - 1;
+    };
+    size_t src_of[ING_MAX_COLS], aux_of[ING_MAX_COLS];
+    for (size_t c = 0; c < n_cols; c++) {
+        src_of[c] = aux_of[c] = (size_t)-1;
+        const size_t w = col_width(cols[c].kind, cols[c].b, cols[c].a);
+        if (w && cols[c].data) src_of[c] = source(cols[c].data, w * n_rows);
+        if (cols[c].kind == ZG_COL_LUT && cols[c].b) aux_of[c] = source(cols[c].aux, (size_t)cols[c].b * 32);
+    }
+    const bool split = setup_times_enabled();
+    const double t0 = split ? now_ms() : 0;
+    Scratch stage(total ? total : 16);
+    if (!stage.p) return ZG_ERR_NOMEM;
+    const double t1 = split ? now_ms() : 0;
+    SyncGuard sync(st);
+    for (const Src &s : srcs) ZG_HIP(hipMemcpyAsync(stage.as<char>() + s.off, s.host, s.bytes, hipMemcpyHostToDevice, st));
+    if (split) ZG_HIP(hipStreamSynchronize(st));
+    const double t2 = split ? now_ms() : 0;
+    IngArgs args{};
+    for (size_t c = 0; c < n_cols; c++)
+        args.c[c] = IngCol{cols[c].kind, cols[c].a, cols[c].b, cols[c].kind == ZG_COL_MUL ? mul_depth(cols, n_cols, c) : 0u,
+                           src_of[c] == (size_t)-1 ? nullptr : (const void *)(stage.as<char>() + srcs[src_of[c]].off),
+                           aux_of[c] == (size_t)-1 ? nullptr : (const void *)(stage.as<char>() + srcs[aux_of[c]].off)};
+    ZG_TRY(launch_rows_from_columns(args, n_cols, n_rows, d_rows, st));
+    ZG_HIP(hipStreamSynchronize(st));
+    sync.dismiss();
+    if (split) {
+        SetupTimes &tm = setup_times();
+        tm = SetupTimes{};
+        tm.alloc_ms = t1 - t0;
+        tm.h2d_ms = t2 - t1;
+        tm.kernel_ms = now_ms() - t2;
+    }
+    return ZG_OK;
+}
+
 int ingest_u64_to_fr(const uint64_t *d_vals, size_t n, uint64_t *d_out, hipStream_t st) {
     IngArgs args{};
-    args.c[0] = IngCol{ZG_COL_U64, 0, 0, 0, d_vals};
+    args.c[0] = IngCol{ZG_COL_U64, 0, 0, 0, d_vals, nullptr};
     return launch_rows_from_columns(args, 1, n, d_out, st);
 }
 
@@ -205,7 +265,7 @@ int zg_fr_rows_from_columns_dev(const zg_col_t *cols, size_t n_cols, size_t n_ro
     ZG_TRY(validate_cols(cols, n_cols, n_rows, d_rows));
     IngArgs args{};
     for (size_t c = 0; c < n_cols; c++)
-        args.c[c] = IngCol{cols[c].kind, cols[c].a, cols[c].b, cols[c].kind == ZG_COL_MUL ? mul_depth(cols, n_cols, c) : 0u, cols[c].data};
+        args.c[c] = IngCol{cols[c].kind, cols[c].a, cols[c].b, cols[c].kind == ZG_COL_MUL ? mul_depth(cols, n_cols, c) : 0u, cols[c].data, cols[c].aux};
     return launch_rows_from_columns(args, n_cols, n_rows, d_rows, pick_stream(stream));
 }
 
@@ -214,50 +274,7 @@ int zg_fr_rows_from_columns_dev(const zg_col_t *cols, size_t n_cols, size_t n_ro
 // on the same stream and the call returns when the matrix is complete.
 int zg_fr_rows_from_columns(const zg_col_t *cols, size_t n_cols, size_t n_rows, uint64_t *d_rows) {
     ZG_INIT();
-    ZG_TRY(validate_cols(cols, n_cols, n_rows, d_rows));
-    if (n_rows == 0) return ZG_OK;
-    hipStream_t st = lib_stream();
-    // several ZG_COL_BIT columns usually share one packed word array: upload each distinct (pointer, width) once
-    struct Src { const void *host; size_t bytes, off; };
-    std::vector<Src> srcs;
-    size_t total = 0;
-    size_t src_of[ING_MAX_COLS];
-    for (size_t c = 0; c < n_cols; c++) {
-        src_of[c] = (size_t)-1;
-        const size_t w = col_width(cols[c].kind, cols[c].b);
-        if (w == 0 || !cols[c].data) continue;
-        for (size_t s = 0; s < srcs.size(); s++)
-            if (srcs[s].host == cols[c].data && srcs[s].bytes == w * n_rows) src_of[c] = s;
-        if (src_of[c] == (size_t)-1) {
-            src_of[c] = srcs.size();
-            srcs.push_back(Src{cols[c].data, w * n_rows, total});
-            total += (w * n_rows + 255) & ~(size_t)255;
-        }
-    }
-    const bool split = setup_times_enabled();
-    const double t0 = split ? now_ms() : 0;
-    Scratch stage(total ? total : 16);
-    if (!stage.p) return ZG_ERR_NOMEM;
-    const double t1 = split ? now_ms() : 0;
-    SyncGuard sync(st);
-    for (const Src &s : srcs) ZG_HIP(hipMemcpyAsync(stage.as<char>() + s.off, s.host, s.bytes, hipMemcpyHostToDevice, st));
-    if (split) ZG_HIP(hipStreamSynchronize(st));
-    const double t2 = split ? now_ms() : 0;
-    IngArgs args{};
-    for (size_t c = 0; c < n_cols; c++)
-        args.c[c] = IngCol{cols[c].kind, cols[c].a, cols[c].b, cols[c].kind == ZG_COL_MUL ? mul_depth(cols, n_cols, c) : 0u,
-                           src_of[c] == (size_t)-1 ? nullptr : (const void *)(stage.as<char>() + srcs[src_of[c]].off)};
-    ZG_TRY(launch_rows_from_columns(args, n_cols, n_rows, d_rows, st));
-    ZG_HIP(hipStreamSynchronize(st));
-    sync.dismiss();
-    if (split) {
-        SetupTimes &tm = setup_times();
-        tm = SetupTimes{};
-        tm.alloc_ms = t1 - t0;
-        tm.h2d_ms = t2 - t1;
-        tm.kernel_ms = now_ms() - t2;
-    }
-    return ZG_OK;
+    return rows_from_host_columns(cols, n_cols, n_rows, d_rows, lib_stream());
 }
 
 // Pinned host memory for callers that fill large inputs in place (trace columns, scalar vectors): copies from it run by DMA at link rate

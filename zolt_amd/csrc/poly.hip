@@ -2683,6 +2683,34 @@ int zg_sumcheck_open_dev(const uint64_t *d_evals, size_t len, int layout, void *
     return ZG_OK;
 }
 
+int zg_sumcheck_open_column(const zg_col_t *col, size_t n_rows, size_t len, int layout, zg_sc_t *out) {
+    ZG_INIT();
+    if (!col || !out || n_rows > len) {
+        set_error("zg_sumcheck_open_column: invalid argument (n_rows <= len)");
+        return ZG_ERR_INVALID;
+    }
+    zg_sc_s *s = nullptr;
+    ZG_TRY(sc_create(len, layout, nullptr, &s));  // a stream of its own
+    int rc = ZG_OK;
+    if (len > n_rows) {
+        hipError_t e = hipMemsetAsync(s->buf[0] + 4 * n_rows, 0, (len - n_rows) * 32, s->st);
+        if (e != hipSuccess) {
+            set_error(hipGetErrorString(e));
+            rc = ZG_ERR_HIP;
+        }
+    }
+    if (rc == ZG_OK) rc = rows_from_host_columns(col, 1, n_rows, s->buf[0], s->st);  // synchronises the session's stream
+    if (rc == ZG_OK && n_rows == 0 && hipStreamSynchronize(s->st) != hipSuccess) rc = ZG_ERR_HIP;
+    if (rc != ZG_OK) {
+        std::string keep = zg_last_error();
+        sc_free(s);
+        set_error(keep);
+        return rc;
+    }
+    *out = s;
+    return ZG_OK;
+}
+
 int zg_sumcheck_open_spartan_dev(const uint64_t *r, size_t v, const uint64_t *scale, const uint64_t *d_az, const uint64_t *d_bz,
                                  const uint64_t *d_cz, int layout, void *stream, zg_sc_t *out) {
     ZG_INIT();

@@ -624,9 +624,7 @@ inline Fr computeRegEq(const std::vector<Fr> &r, unsigned reg) {  // :961-972
     return acc;
 }
 // the round loop the two stages share (:902-944, 1055-1097) over a HIGH_HALF device session
-inline void highHalfRounds(const std::vector<Fr> &evals, size_t num_rounds, Transcript &transcript, const std::string &label, StageRoundsResult &out) {
-    zg_sc_t s = nullptr;
-    check(zg_sumcheck_open(reinterpret_cast<const uint64_t *>(evals.data()), evals.size(), ZG_SC_HIGH_HALF, &s), "zg_sumcheck_open");
+inline void highHalfRounds(zg_sc_t s, size_t num_rounds, Transcript &transcript, const std::string &label, StageRoundsResult &out) {
     try {
         for (size_t rd = 0; rd < num_rounds; rd++) {
             Fr p0, p1;
@@ -645,6 +643,11 @@ inline void highHalfRounds(const std::vector<Fr> &evals, size_t num_rounds, Tran
         throw;
     }
     check(zg_sumcheck_close(s), "zg_sumcheck_close");
+}
+inline void highHalfRounds(const std::vector<Fr> &evals, size_t num_rounds, Transcript &transcript, const std::string &label, StageRoundsResult &out) {
+    zg_sc_t s = nullptr;
+    check(zg_sumcheck_open(reinterpret_cast<const uint64_t *>(evals.data()), evals.size(), ZG_SC_HIGH_HALF, &s), "zg_sumcheck_open");
+    highHalfRounds(s, num_rounds, transcript, label, out);
 }
 inline size_t log2Ceil(size_t n) {
     size_t k = 0;
@@ -781,9 +784,14 @@ inline StageRoundsResult proveStage5(const std::vector<uint32_t> &instructions, 
     const size_t num_rounds = instructions.size() <= 1 ? 0 : log2Ceil(instructions.size());
     Fr table[32];
     for (unsigned reg = 0; reg < 32; reg++) table[reg] = computeRegEq(r_register, reg);
-    std::vector<Fr> eq_evals(size_t(1) << num_rounds, Fr::zero());
-    for (size_t j = 0; j < instructions.size(); j++) eq_evals[j] = table[(instructions[j] >> 7) & 31];
-    highHalfRounds(eq_evals, num_rounds, transcript, "reg_eval_round", out);
+    // eq_evals[j] = table[rd of cycle j] (:880-900), zero past the trace: one byte per cycle crosses, the 32-entry table is looked up on the
+    // device (ZG_COL_LUT) — the 2^log_t-element table of field elements is never built on the host
+    std::vector<uint8_t> rd(instructions.size());
+    for (size_t j = 0; j < instructions.size(); j++) rd[j] = (uint8_t)((instructions[j] >> 7) & 31);
+    const zg_col_t col{ZG_COL_LUT, 1, 32, rd.data(), table};
+    zg_sc_t s = nullptr;
+    check(zg_sumcheck_open_column(&col, rd.size(), size_t(1) << num_rounds, ZG_SC_HIGH_HALF, &s), "zg_sumcheck_open_column");
+    highHalfRounds(s, num_rounds, transcript, "reg_eval_round", out);
     return out;
 }
 // proveStage6 (:990-1112): booleanity — violation_evals = 0 for every step of a valid trace (:1024-1033)
@@ -793,8 +801,11 @@ inline StageRoundsResult proveStage6(size_t trace_len, Transcript &transcript, F
     StageRoundsResult out;
     if (trace_len == 0) { out.skipped = true; return out; }
     const size_t num_rounds = trace_len <= 1 ? 0 : log2Ceil(trace_len);
-    std::vector<Fr> viol(size_t(1) << num_rounds, Fr::zero());
-    highHalfRounds(viol, num_rounds, transcript, "bool_round", out);
+    // violation_evals = 0 for every step of a valid trace (:1024-1033): the session's table is cleared on the device, nothing is uploaded
+    const zg_col_t col{ZG_COL_ZERO, 0, 0, nullptr, nullptr};
+    zg_sc_t s = nullptr;
+    check(zg_sumcheck_open_column(&col, 0, size_t(1) << num_rounds, ZG_SC_HIGH_HALF, &s), "zg_sumcheck_open_column");
+    highHalfRounds(s, num_rounds, transcript, "bool_round", out);
     return out;
 }
 

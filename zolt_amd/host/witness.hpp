@@ -209,13 +209,13 @@ struct CycleColumns {
 
     // the 43 descriptors of zg_fr_rows_from_columns, in R1CSInputIndex order
     std::vector<zg_col_t> descriptors() const {
-        std::vector<zg_col_t> d(NUM_INPUTS, zg_col_t{ZG_COL_ZERO, 0, 0, nullptr});  // NextIsVirtual, NextIsFirstInSequence stay zero (:1160-1171)
-        for (int k = 0; k < 12; k++) d[U64_INPUTS[k]] = zg_col_t{ZG_COL_U64, 0, 0, u64[k]};
-        d[8] = zg_col_t{ZG_COL_I64, 0, 0, imm};
-        for (int k = 0; k < 2; k++) d[WIDE_INPUTS[k]] = zg_col_t{ZG_COL_I128, 0, 0, wide[k]};
-        d[2] = zg_col_t{ZG_COL_MUL, 0, 1, nullptr};  // Product = LeftInstructionInput * RightInstructionInput (:1120-1122)
-        d[16] = zg_col_t{ZG_COL_MUL, 2, 25, wide[2]};  // RightLookupOperand = Product * FlagMultiplyOperands + the other rows' value
-        for (uint32_t b = 0; b < 24; b++) d[BIT_INPUTS[b]] = zg_col_t{ZG_COL_BIT, b, 4, word};
+        std::vector<zg_col_t> d(NUM_INPUTS, zg_col_t{ZG_COL_ZERO, 0, 0, nullptr, nullptr});  // NextIsVirtual, NextIsFirstInSequence stay zero (:1160-1171)
+        for (int k = 0; k < 12; k++) d[U64_INPUTS[k]] = zg_col_t{ZG_COL_U64, 0, 0, u64[k], nullptr};
+        d[8] = zg_col_t{ZG_COL_I64, 0, 0, imm, nullptr};
+        for (int k = 0; k < 2; k++) d[WIDE_INPUTS[k]] = zg_col_t{ZG_COL_I128, 0, 0, wide[k], nullptr};
+        d[2] = zg_col_t{ZG_COL_MUL, 0, 1, nullptr, nullptr};  // Product = LeftInstructionInput * RightInstructionInput (:1120-1122)
+        d[16] = zg_col_t{ZG_COL_MUL, 2, 25, wide[2], nullptr};  // RightLookupOperand = Product * FlagMultiplyOperands + the other rows' value
+        for (uint32_t b = 0; b < 24; b++) d[BIT_INPUTS[b]] = zg_col_t{ZG_COL_BIT, b, 4, word, nullptr};
         return d;
     }
     size_t bytesPerCycle() const { return BYTES_PER_CYCLE; }

@@ -583,35 +583,45 @@ def fr_rows_affine(rows, coeffs, ntab, g, n_pad=None, k=None):
     return outs
 
 
-COL_ZERO, COL_U8, COL_U32, COL_U64, COL_I64, COL_I128, COL_U128, COL_FR, COL_BIT, COL_MUL = range(10)
+COL_ZERO, COL_U8, COL_U32, COL_U64, COL_I64, COL_I128, COL_U128, COL_FR, COL_BIT, COL_MUL, COL_LUT = range(11)
 _COL_DTYPE = {COL_U8: np.uint8, COL_U32: np.uint32, COL_U64: np.uint64, COL_I64: np.int64, COL_I128: np.uint64, COL_U128: np.uint64, COL_FR: np.uint64,
               COL_MUL: np.uint64}  # (COL_MUL's optional addend is a 128-bit two's-complement column)
 
 
 class Column(C.Structure):
     """zg_col_t: one typed integer column of zg_fr_rows_from_columns"""
-    _fields_ = [("kind", C.c_uint32), ("a", C.c_uint32), ("b", C.c_uint32), ("data", C.c_void_p)]
+    _fields_ = [("kind", C.c_uint32), ("a", C.c_uint32), ("b", C.c_uint32), ("data", C.c_void_p), ("aux", C.c_void_p)]
 
 
 def _columns(cols, n_rows, device):
-    """cols: list of (kind, data, a, b) — data a numpy array (host) or a device address (device=True), None for COL_ZERO / COL_MUL"""
+    """cols: list of (kind, data, a, b[, aux]) — data a numpy array (host) or a device address (device=True), None for COL_ZERO / COL_MUL;
+    COL_LUT: data = the index per row (a bytes each), aux = the table of b elements"""
     arr = (Column * len(cols))()
     keep = []
     for i, spec in enumerate(cols):
         kind, data = spec[0], spec[1] if len(spec) > 1 else None
         a, b = (spec[2] if len(spec) > 2 else 0), (spec[3] if len(spec) > 3 else 0)
-        ptr = None
+        aux = spec[4] if len(spec) > 4 else None
+        ptr = aptr = None
+        if aux is not None:
+            if device:
+                aptr = int(aux)
+            else:
+                t = np.ascontiguousarray(aux, dtype=np.uint64)
+                assert t.size == 4 * b, (i, t.shape, b)
+                keep.append(t)
+                aptr = t.ctypes.data
         if data is not None:
             if device:
                 ptr = int(data)
             else:
-                dt = _COL_DTYPE.get(kind) or {1: np.uint8, 4: np.uint32, 8: np.uint64}[b]
+                dt = {1: np.uint8, 2: np.uint16, 4: np.uint32}[a] if kind == COL_LUT else (_COL_DTYPE.get(kind) or {1: np.uint8, 4: np.uint32, 8: np.uint64}[b])
                 h = np.ascontiguousarray(data, dtype=dt)
                 per = {COL_I128: 2, COL_U128: 2, COL_FR: 4, COL_MUL: 2}.get(kind, 1)
                 assert h.size == n_rows * per, (i, kind, h.shape, n_rows)
                 keep.append(h)
                 ptr = h.ctypes.data
-        arr[i] = Column(kind, a, b, ptr)
+        arr[i] = Column(kind, a, b, ptr, aptr)
     return arr, keep
 
 
@@ -803,6 +813,16 @@ class SumcheckSession:
     def open_dev(cls, d_evals, n, layout=SC_HIGH_HALF, stream=0):
         h = C.c_void_p()
         _chk(_lib.zg_sumcheck_open_dev(_d(d_evals), C.c_size_t(n), C.c_int(layout), _d(stream), C.byref(h)), "zg_sumcheck_open_dev")
+        return cls(h)
+
+    @classmethod
+    def open_column(cls, col, n_rows, n, layout=SC_HIGH_HALF):
+        """a session whose table is ONE integer column widened on the device: entries [0, n_rows) from `col` (a fr_rows_from_columns
+        column spec, host data), [n_rows, n) zero (zg_sumcheck_open_column)"""
+        arr, keep = _columns([col], n_rows, device=False)
+        h = C.c_void_p()
+        _chk(_lib.zg_sumcheck_open_column(arr, C.c_size_t(n_rows), C.c_size_t(n), C.c_int(layout), C.byref(h)), "zg_sumcheck_open_column")
+        del keep
         return cls(h)
 
     @classmethod
