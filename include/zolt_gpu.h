@@ -225,6 +225,12 @@ ZG_API int zg_g1_scalar_mul_batch(const uint64_t *xy, const uint8_t *inf, const 
 ZG_API int zg_g1_fixed_base_mul_batch(const uint64_t base_xy[8], uint8_t base_inf, const uint64_t *scalars_mont, size_t n, uint64_t *out_xy,
                                uint8_t *out_inf);
 
+/* HyperKZG.setup's G1 side with nothing leaving the device (generateMockSRS, src/poly/commitment/mod.zig:174-213: powers[i] =
+ * scalarMul(g1, tau^i), i < n <= 2^24): powers of tau, fixed-base batch and the handle (with its table of multiples) are built in HBM.
+ * out_xy / out_inf (n*8 words / n bytes, host) may be NULL when the caller does not need the points themselves. The handle equals
+ * zg_g1_bases_upload of zg_g1_fixed_base_mul_batch's output for the scalars tau^i. */
+ZG_API int zg_hyperkzg_setup(const uint64_t base_xy[8], const uint64_t tau[4], size_t n, const zg_msm_config *cfg, uint64_t *out_xy, uint8_t *out_inf,
+                             zg_bases_t *out);
 /* HyperKZG.open (src/poly/commitment/mod.zig:261-324), resident on the device: per variable i the quotient
  * q[j] = cur[j+half] - cur[j] is committed (MSM over srs[0..min(half, srs_len))), then cur is folded by point[i]
  * (high half). Writes num_vars quotient commitments (rounds that the reference skips when the table runs out are

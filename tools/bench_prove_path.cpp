@@ -165,8 +165,8 @@ static Timeline prove_once(const ProveCase &pc, bool emit) {
     const size_t T = size_t(1) << pc.log_t;
     tl.start();
     // ---- proving key: HyperKZG.setup (mock SRS: tau^i * G by the fixed-base kernel), uploaded with its table of multiples
-    HyperKZG::SetupParams pk = HyperKZG::setup(pc.srs_size);
-    tl.lap("proving key: HyperKZG.setup (fixed-base batch, SRS upload, table of multiples)", "once per key");
+    HyperKZG::SetupParams pk = HyperKZG::setup(pc.srs_size, false);  // the prover commits and opens: the points never come back to the host
+    tl.lap("proving key: HyperKZG.setup on the device (powers of tau, fixed-base batch, table of multiples)", "once per key");
     // ---- the three commitments, from machine words (zg_msm_g1_u64)
     std::vector<uint64_t> bc(pc.bytecode.size() < 2 ? 2 : ceil_pow2(pc.bytecode.size()), 0), mem(pc.accesses.size() < 2 ? 2 : ceil_pow2(pc.accesses.size()), 0),
         reg(pc.trace.size() < 2 ? 2 : ceil_pow2(pc.trace.size()), 0);
@@ -344,7 +344,7 @@ static Timeline prove_once(const ProveCase &pc, bool emit) {
     std::vector<uint64_t> q(8 * (reg_vars ? reg_vars : 1));
     std::vector<uint8_t> qi(reg_vars ? reg_vars : 1);
     Fr value = Fr::zero(), final_eval;
-    const size_t n_open = reg.size() < pk.powers_of_tau_g1.size() ? reg.size() : pk.powers_of_tau_g1.size();
+    const size_t n_open = reg.size() < HyperKZG::srsLen(pk) ? reg.size() : HyperKZG::srsLen(pk);
     check(zg_hyperkzg_open_dev(pk.device->handle(), d_reg.u64(), n_open, reinterpret_cast<const uint64_t *>(point.data()), reg_vars, value.limbs, nullptr, q.data(),
                                qi.data(), final_eval.limbs), "zg_hyperkzg_open_dev");
     if (emit) {

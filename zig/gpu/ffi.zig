@@ -95,6 +95,7 @@ pub extern fn zg_g1_is_on_curve_batch(xy: ?[*]const u64, inf: ?[*]const u8, n: u
 pub extern fn zg_g1_affine_add_batch(a_xy: ?[*]const u64, a_inf: ?[*]const u8, b_xy: ?[*]const u64, b_inf: ?[*]const u8, n: usize, out_xy: ?[*]u64, out_inf: ?[*]u8) c_int;
 pub extern fn zg_g1_scalar_mul_batch(xy: ?[*]const u64, inf: ?[*]const u8, scalars_mont: ?[*]const u64, n: usize, out_xy: ?[*]u64, out_inf: ?[*]u8) c_int;
 pub extern fn zg_g1_fixed_base_mul_batch(base_xy: *const [8]u64, base_inf: u8, scalars_mont: ?[*]const u64, n: usize, out_xy: ?[*]u64, out_inf: ?[*]u8) c_int;
+pub extern fn zg_hyperkzg_setup(base_xy: *const [8]u64, tau: *const [4]u64, n: usize, cfg: ?*const MsmConfig, out_xy: ?[*]u64, out_inf: ?[*]u8, out: *Bases) c_int;
 pub extern fn zg_hyperkzg_open(srs: Bases, evals: ?[*]const u64, n_evals: usize, point: ?[*]const u64, num_vars: usize, value: *const [4]u64, q_xy: ?[*]u64, q_inf: ?[*]u8, final_eval: *[4]u64) c_int;
 pub extern fn zg_hyperkzg_open_dev(srs: Bases, d_evals: ?[*]const u64, n_evals: usize, point: ?[*]const u64, num_vars: usize, value: *const [4]u64, stream: ?*anyopaque, q_xy: ?[*]u64, q_inf: ?[*]u8, final_eval: *[4]u64) c_int;
 pub extern fn zg_hyperkzg_batch_open(srs: Bases, polys: ?[*]const ?[*]const u64, lens: ?[*]const usize, k: usize, point: ?[*]const u64, num_vars: usize, q_xy: ?[*]u64, q_inf: ?[*]u8, n_quot: ?*usize, evaluations: ?[*]u64, final_eval: *[4]u64, gamma: *[4]u64) c_int;

@@ -94,6 +94,7 @@ PROTOS = {
     "zg_g1_affine_add_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),  # a_xy, a_inf, b_xy, b_inf, n, out_xy, out_inf
     "zg_g1_scalar_mul_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),  # xy, inf, scalars_mont, n, out_xy, out_inf
     "zg_g1_fixed_base_mul_batch": (c_int, [c_void_p, c_uint8, c_void_p, c_size_t, c_void_p, c_void_p]),  # base_xy, base_inf, scalars_mont, n, out_xy, out_inf
+    "zg_hyperkzg_setup": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),  # base_xy, tau, n, cfg, out_xy, out_inf, out
     "zg_hyperkzg_open": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),  # srs, evals, n_evals, point, num_vars, value, q_xy, q_inf, final_eval
     "zg_hyperkzg_open_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),  # srs, d_evals, n_evals, point, num_vars, value, stream, q_xy, q_inf, final_eval
     "zg_hyperkzg_batch_open": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),  # srs, polys, lens, k, point, num_vars, q_xy, q_inf, n_quot, evaluations, final_eval, gamma

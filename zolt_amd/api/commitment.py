@@ -13,14 +13,14 @@ class HyperKZG:
     TAU = 0x12345678  # src/poly/commitment/mod.zig:189 (mock SRS, INSECURE by design)
 
     class SetupParams:
-        def __init__(self, xy, inf, sharded=False):
+        def __init__(self, xy, inf, sharded=False, dev=None):
             self.powers_of_tau_g1 = xy
             self.infinity = inf
             self.max_degree = xy.shape[0]
             # device-resident for the whole run (:122-140); sharded=True: one shard per GPU bound by lib.init_devices — commit and
             # batchCommit then go through the one-process multi-GPU entry points (zg_msm_g1_sharded / zg_msm_g1_batch_sharded)
             self.sharded = bool(sharded)
-            self._dev = lib.ShardedBases.upload(xy, inf) if sharded else lib.Bases.upload(xy, inf)
+            self._dev = dev if dev is not None else (lib.ShardedBases.upload(xy, inf) if sharded else lib.Bases.upload(xy, inf))
 
         def deinit(self):
             self._dev.free()
@@ -28,15 +28,11 @@ class HyperKZG:
     @staticmethod
     def setup(max_degree):
         """powers[i] = scalarMul(G1, tau^i).toAffine() (src/poly/commitment/mod.zig:174-213)."""
-        g = generator()
-        taus = np.zeros((max_degree, 4), dtype=np.uint64)
-        t = 1
-        for i in range(max_degree):  # tau_power = tau_power.mul(tau) (:196-198)
-            taus[i] = fr_from_int(t)
-            t = t * HyperKZG.TAU % R_MOD
-        # every product has the same base: the fixed-base batch kernel (32 table additions per point instead of double-and-add)
-        xy, inf = lib.g1_fixed_base_mul_batch(g, taus)
-        return HyperKZG.SetupParams(xy, inf)
+        # the powers tau^i (:196-198), the fixed-base batch (every product has the same base: 32 table additions per point instead of
+        # double-and-add) and the MSM handle with its table of multiples are built on the device (zg_hyperkzg_setup); the points come back
+        # once, for SetupParams.powers_of_tau_g1
+        dev, xy, inf = lib.Bases.hyperkzg_setup(generator(), fr_from_int(HyperKZG.TAU), max_degree)
+        return HyperKZG.SetupParams(xy, inf, dev=dev)
 
     @staticmethod
     def commit(params, evals):

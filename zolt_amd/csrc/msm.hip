@@ -1343,6 +1343,34 @@ __global__ void __launch_bounds__(256) fb_mul_kernel(const char *table, const ui
     out_inf[i] = isinf ? 1 : 0;
 }
 
+// tau^i for i < n as canonical Montgomery elements, for HyperKZG.setup on the device (zg_hyperkzg_setup): three 256-entry tables of
+// powers — tau^a, (tau^256)^b, (tau^65536)^c, one thread each walks its chain of 255 products — then every i = a + 256 b + 65536 c is two
+// products. Exact products: the bytes are those of the reference's running product tau_power = tau_power * tau
+// (src/poly/commitment/mod.zig:190-199).
+struct TauArg { uint32_t l[8]; };  // a field element as a kernel argument
+__global__ void __launch_bounds__(64) tau_tables_kernel(TauArg tau, uint64_t *tabs /* 3 x 256 x 4 */) {
+    if (threadIdx.x >= 3) return;
+    Fr t;
+#pragma unroll
+    for (int i = 0; i < 8; i++) t.l[i] = tau.l[i];
+    for (uint32_t k = 0; k < threadIdx.x; k++)  // t = tau^(256^table)
+        for (int j = 0; j < 8; j++) t = fr_mul29v(t, t);
+    Fr acc = Fr::one();
+    uint64_t *out = tabs + (size_t)threadIdx.x * 256 * 4;
+    for (int j = 0; j < 256; j++) {
+        fe_store(out + 4 * j, acc);
+        acc = fr_mul29v(acc, t);
+    }
+}
+__global__ void __launch_bounds__(256) tau_powers_kernel(const uint64_t *tabs, size_t n, uint64_t *out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    Fr v = fe_load<FrParams>(tabs + 4 * (i & 255));
+    if (i >> 8) v = fr_mul29v(v, fe_load<FrParams>(tabs + 4 * (256 + ((i >> 8) & 255))));
+    if (i >> 16) v = fr_mul29v(v, fe_load<FrParams>(tabs + 4 * (512 + (i >> 16))));
+    fe_store(out + 4 * i, v);
+}
+
 // AffinePoint.add (msm/mod.zig:74-103) and, through add(p, p), AffinePoint.double (:118-138): the lambda formulas on canonical
 // Montgomery values, one inversion per pair (safegcd, the value of the reference's Fermat inverse)
 __global__ void __launch_bounds__(256) g1_affine_add_kernel(const uint64_t *a_xy, const uint8_t *a_inf, const uint64_t *b_xy,
@@ -2792,6 +2820,49 @@ int zg_g1_fixed_base_mul_batch(const uint64_t base_xy[8], uint8_t base_inf, cons
     ZG_HIP(hipMemcpyAsync(out_inf, s_inf.p, n, hipMemcpyDeviceToHost, st));
     ZG_HIP(hipStreamSynchronize(st));
     sync.dismiss();
+    return ZG_OK;
+}
+
+// HyperKZG.setup's G1 side on the device (generateMockSRS, src/poly/commitment/mod.zig:174-213: powers[i] = scalarMul(g1, tau^i)): the
+// powers of tau, the fixed-base batch and the handle's table of multiples are built in HBM and stay there — the points cross PCIe only if
+// the caller asks for them (out_xy). The compiled mirror spent 131 ms of a 2^20-cycle proof here (131 of 210 ms, tools/bench_prove_path):
+// 2^20 host field products for the powers, 64 MB down, struct conversions, 64 MB up again.
+int zg_hyperkzg_setup(const uint64_t base_xy[8], const uint64_t tau[4], size_t n, const zg_msm_config *cfg, uint64_t *out_xy, uint8_t *out_inf,
+                      zg_bases_t *out) {
+    ZG_INIT();
+    if (!base_xy || !tau || !out || n > ((size_t)1 << 24)) {
+        set_error("zg_hyperkzg_setup: invalid argument (at most 2^24 powers)");
+        return ZG_ERR_INVALID;
+    }
+    hipStream_t st = lib_stream();
+    const uint32_t n_rows = FB_W * FB_ROWS;
+    const size_t nn = n ? n : 1;
+    Scratch s_base(64), s_rows((size_t)FB_W * 144), s_tab((size_t)n_rows * 64), s_pw(3 * 256 * 32), s_sc(nn * 32), s_out(nn * 64), s_inf(nn);
+    if (!s_base.p || !s_rows.p || !s_tab.p || !s_pw.p || !s_sc.p || !s_out.p || !s_inf.p) return ZG_ERR_NOMEM;
+    SyncGuard sync(st);
+    if (n) {
+        TauArg ta;
+        for (int i = 0; i < 4; i++) {
+            ta.l[2 * i] = (uint32_t)tau[i];
+            ta.l[2 * i + 1] = (uint32_t)(tau[i] >> 32);
+        }
+        ZG_HIP(hipMemcpyAsync(s_base.p, base_xy, 64, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(tau_tables_kernel, dim3(1), dim3(64), 0, st, ta, s_pw.as<uint64_t>());
+        hipLaunchKernelGGL(tau_powers_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, s_pw.as<uint64_t>(), n, s_sc.as<uint64_t>());
+        hipLaunchKernelGGL(fb_window_bases_kernel, dim3(1), dim3(4 * FB_W), 0, st, s_base.as<uint64_t>(), s_rows.as<char>());
+        hipLaunchKernelGGL(fb_table_rows_kernel, dim3(div_up(n_rows, 256)), dim3(256), 0, st, s_rows.as<char>(), n_rows, s_tab.as<char>());
+        hipLaunchKernelGGL(fb_mul_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, s_tab.as<char>(), s_sc.as<uint64_t>(), n, s_out.as<uint64_t>(),
+                           s_inf.as<uint8_t>());
+        ZG_HIP(hipGetLastError());
+        if (out_xy) ZG_HIP(hipMemcpyAsync(out_xy, s_out.p, n * 64, hipMemcpyDeviceToHost, st));
+        if (out_inf) ZG_HIP(hipMemcpyAsync(out_inf, s_inf.p, n, hipMemcpyDeviceToHost, st));
+    }
+    // tau^i is never 0 mod r and the base has prime order: no power is the identity, so the handle carries no infinity flags
+    int rc = bases_create(s_out.as<uint64_t>(), nullptr, n, cfg, st, out);  // copies the points into the handle's table
+    hipError_t e = hipStreamSynchronize(st);
+    sync.dismiss();
+    if (rc != ZG_OK) return rc;
+    ZG_HIP(e);
     return ZG_OK;
 }
 

