@@ -824,3 +824,31 @@ def test_msm_over_machine_words_equals_msm_over_their_field_elements(zl, ob, n):
             assert g2[1] == w2[1] and np.array_equal(g2[0], w2[0])
     finally:
         b.free()
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 257, 70000])
+def test_hyperkzg_setup_on_the_device(zl, ob, n):
+    """zg_hyperkzg_setup: tau^i * G for i < n with the powers of tau, the fixed-base batch and the MSM handle all built in HBM == the
+    oracle's generateMockSRS restatement (src/poly/commitment/mod.zig:174-213), across the three power tables (i < 256, < 65536, above);
+    the handle it returns commits like an uploaded copy of the points, and works without the points ever coming back"""
+    from zolt_amd import api
+    g, tau = api.generator(), api.fr_from_int(api.HyperKZG.TAU)
+    h, xy, inf = zl.Bases.hyperkzg_setup(g, tau, n)
+    try:
+        if n <= 300:
+            want, winf = ob.hyperkzg_setup(n) if n else (np.zeros((0, 8), dtype=np.uint64), np.zeros(0, dtype=np.uint8))
+            assert np.array_equal(xy, want) and not inf.any() and not np.asarray(winf).any()
+        else:  # the oracle's double-and-add is slow: spot-check powers on both sides of the table boundaries with scalarMul
+            for i in (0, 1, 255, 256, 257, 65535, 65536, 65537, n - 1):
+                wxy, wi = api.MSM.scalarMul(g, api.fr_from_int(pow(api.HyperKZG.TAU, i, api.R_MOD)))
+                assert wi == 0 and np.array_equal(xy[i], wxy), i
+        if n:
+            sc = ob.f_to_mont(ob.FR, U.random_raw256(77 + n, n))
+            h2, _, _ = zl.Bases.hyperkzg_setup(g, tau, n, want_points=False)
+            up = zl.Bases.upload(xy)
+            a, b, c = h.msm(sc), h2.msm(sc), up.msm(sc)
+            assert a[1] == b[1] == c[1] and np.array_equal(a[0], b[0]) and np.array_equal(a[0], c[0])
+            h2.free()
+            up.free()
+    finally:
+        h.free()

@@ -181,6 +181,46 @@ pub const SrsHandle = struct {
         return affineFrom(Affine, &xy, inf);
     }
 
+    /// commitBytecode / commitMemory / commitRegisters (src/zkvm/mod.zig:1518-1617) build `poly[i] = F.fromU64(word_i)` and commit to it:
+    /// here the machine words cross as they are (8 bytes each, no host fromU64 per evaluation) and the conversion runs on the device.
+    /// The result equals commit(evals) for evals[i] = F.fromU64(words[i]). null = run the Zig body.
+    pub fn commitWords(self: *const SrsHandle, comptime Affine: type, words: []const u64) ?Affine {
+        if (self.bases == null) return null; // (the sharded handle takes field elements: keep the Zig body there)
+        const n = @min(words.len, self.len);
+        if (n == 0) return Affine.identity();
+        if (n < srs_commit_min_points) return null;
+        var xy: [8]u64 = undefined;
+        var inf: u8 = 0;
+        if (ffi.zg_msm_g1_u64(self.bases, 0, n, words.ptr, &xy, @ptrCast(&inf)) != ffi.OK) return null;
+        return affineFrom(Affine, &xy, inf);
+    }
+
+    /// HyperKZG.setup's G1 side with nothing leaving the device (src/poly/commitment/mod.zig:174-213): powers of tau, the fixed-base batch
+    /// and the resident handle are built in HBM. `out` (may be empty) receives the points when the caller keeps them on the host
+    /// (SetupParams.powers_of_tau_g1); a prover that only commits and opens passes an empty slice and n = the SRS size.
+    pub fn initFromTau(comptime F: type, comptime Affine: type, g1: Affine, tau: F, n: usize, out: []Affine, allocator: std.mem.Allocator) !SrsHandle {
+        var h: SrsHandle = .{};
+        if (!enabled() or n == 0 or n_devices > 1 or g1.infinity) return h;
+        var g: [8]u64 = undefined;
+        @memcpy(g[0..4], &g1.x.limbs);
+        @memcpy(g[4..8], &g1.y.limbs);
+        if (out.len == 0) {
+            if (ffi.zg_hyperkzg_setup(&g, &tau.limbs, n, null, null, null, &h.bases) != ffi.OK) h.bases = null;
+        } else {
+            const oxy = try allocator.alloc(u64, 8 * n);
+            defer allocator.free(oxy);
+            const oinf = try allocator.alloc(u8, n);
+            defer allocator.free(oinf);
+            if (ffi.zg_hyperkzg_setup(&g, &tau.limbs, n, null, oxy.ptr, oinf.ptr, &h.bases) != ffi.OK) {
+                h.bases = null;
+            } else {
+                for (out, 0..) |*r, i| r.* = affineFrom(Affine, oxy[8 * i ..][0..8], oinf[i]);
+            }
+        }
+        if (h.ready()) h.len = n;
+        return h;
+    }
+
     /// HyperKZG.batchCommit (:558-570) / BatchMSM / ParallelBatchMSM (src/msm/mod.zig:545-565,683-748): k vectors of one length n
     /// over powers[0..n); short vectors run as ONE fused launch set, several GPUs exchange k partials in one all-gather.
     pub fn batchCommit(self: *const SrsHandle, comptime F: type, comptime Affine: type, polys: []const []const F, allocator: std.mem.Allocator) !?[]Affine {
@@ -281,6 +321,36 @@ pub fn setupPowers(comptime F: type, comptime Affine: type, g1: Affine, scalars:
     for (out, 0..) |*r, i| r.* = affineFrom(Affine, oxy[8 * i ..][0..8], oinf[i]);
     return true;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// The R1CS witness matrix, widened on the device from integer trace columns (zg_fr_rows_from_columns). R1CSWitnessGenerator.generateWitness
+// (src/zkvm/r1cs/constraints.zig:1469-1494) builds 43 field elements per cycle on the CPU; every one of them is F.fromU64 of a machine
+// word, signedI64ToField of an immediate, a flag, or a sum / product of two inputs, so the shim fills COLUMNS of integers instead
+// (zolt_amd/host/witness.hpp CycleColumns::fromTrace is the compiled reference for the column layout: 156 bytes per cycle) and the
+// matrix the stage provers read appears in HBM. The returned table is released with ffi.zg_dev_free.
+// ---------------------------------------------------------------------------------------------------------------
+pub const WitnessMatrix = struct {
+    ptr: ?[*]u64 = null, // device address: rows * cols elements of 4 words, cycle-major
+    rows: usize = 0,
+    cols: usize = 0,
+
+    pub fn fromColumns(cols: []const ffi.Column, n_rows: usize) Error!WitnessMatrix {
+        if (!enabled() or cols.len == 0 or cols.len > 64) return Error.GpuFailure;
+        var raw: ?*anyopaque = null;
+        if (ffi.zg_dev_alloc(@max(n_rows * cols.len * 32, 32), &raw) != ffi.OK) return Error.OutOfMemory;
+        const d: [*]u64 = @ptrCast(@alignCast(raw.?));
+        if (ffi.zg_fr_rows_from_columns(cols.ptr, cols.len, n_rows, d) != ffi.OK) {
+            _ = ffi.zg_dev_free(raw);
+            return Error.GpuFailure;
+        }
+        return .{ .ptr = d, .rows = n_rows, .cols = cols.len };
+    }
+
+    pub fn deinit(self: *WitnessMatrix) void {
+        if (self.ptr) |p| _ = ffi.zg_dev_free(@ptrCast(p));
+        self.* = .{};
+    }
+};
 
 // ---------------------------------------------------------------------------------------------------------------
 // MSM(F, G).compute on an arbitrary slice (src/msm/mod.zig:355-372): ONE-SHOT. No table outlives the call.
