@@ -67,7 +67,7 @@ struct EqArgs {
 static constexpr int EQ_MAX_ROWS = 256;  // rows of 2^v_lo entries per workgroup
 struct EqShared {
     uint4 small[9][16][2];        // factor tables of 4 variables each: groups 0, 1 = the low 8 index bits, 2.. = the row index h
-    uint4 hi_row[EQ_MAX_ROWS][2];  // hi[h0 + k], canonical
+    uint4 hi_row[EQ_MAX_ROWS][3];  // hi[h0 + k] as nine 29-bit limbs (the form every product of the main loop needs: unpacked once per row, not per entry)
 };
 
 // Factor tables in LDS, then thread t's lo[t] (returned, canonical) and the block's hi[h0 .. h0 + rows) in sh.hi_row.
@@ -85,26 +85,29 @@ ZG_DEV Fr eq_block_factors(const EqArgs &a, int v_lo, int v_hi, uint32_t h0, uin
         const uint32_t e = tid & 15u;
         // group g covers index bits [b0, b0 + nb) of the low part (g < 2) or of h (g >= 2); bit b <-> variable var(b)
         const int part_bits = g < 2 ? v_lo : v_hi, b0 = g < 2 ? 4 * g : 4 * (g - 2);
-        // the group's <= 4 factors as a balanced tree, (f0 f1)(f2 f3): two independent products, then one — a chain of two instead of three
-        Fr f[4];
-        int nf = 0;
+        // the group's <= 4 factors as a balanced tree, (f0 f1)(f2 f3): two independent products, then one — a chain of two instead of three.
+        // A group with fewer than four variables takes the Montgomery one for the missing factors (x * 1 is x, exactly): every index below
+        // is a compile-time constant, so the four factors live in registers. (Round 4 filled `f[nf++]` in a loop with a break: a dynamically
+        // indexed local array, 144 bytes of SCRATCH per lane — for 144 threads of a prologue, but a kernel that uses scratch at all pays
+        // for its set-up in every wave of every launch.)
+        Fr f0 = one, f1 = one, f2 = one, f3 = one;
+#pragma unroll
         for (int b = 0; b < 4; b++) {
             const int bit = b0 + b;
-            if (bit >= part_bits) break;
-            const int var = g < 2 ? v_hi + (v_lo - 1 - bit) : (v_hi - 1 - bit);
-            Fr rj;
+            Fr fb = one;
+            if (bit < part_bits) {
+                const int var = g < 2 ? v_hi + (v_lo - 1 - bit) : (v_hi - 1 - bit);
+                Fr rj;
 #pragma unroll
-            for (int i = 0; i < 8; i++) rj.l[i] = a.r[var][i];
-            f[nf++] = ((e >> b) & 1u) ? rj : fe_sub(one, rj);
+                for (int i = 0; i < 8; i++) rj.l[i] = a.r[var][i];
+                fb = ((e >> b) & 1u) ? rj : fe_sub(one, rj);
+            }
+            if (b == 0) f0 = fb;
+            else if (b == 1) f1 = fb;
+            else if (b == 2) f2 = fb;
+            else f3 = fb;
         }
-        Fr acc = one;
-        if (nf == 1) acc = f[0];
-        else if (nf == 2) acc = fr_mul29v(f[0], f[1]);
-        else if (nf == 3) acc = fr_mul29v(fr_mul29v(f[0], f[1]), f[2]);
-        else if (nf == 4) {
-            Fr p01 = fr_mul29v(f[0], f[1]), p23 = fr_mul29v(f[2], f[3]);
-            acc = fr_mul29v(p01, p23);
-        }
+        const Fr acc = fr_mul29v(fr_mul29v(f0, f1), fr_mul29v(f2, f3));
         fe_store(&sh.small[g][e][0], acc);
     }
     __syncthreads();
@@ -124,12 +127,25 @@ ZG_DEV Fr eq_block_factors(const EqArgs &a, int v_lo, int v_hi, uint32_t h0, uin
             hv = used ? fr_mul29v(hv, f) : f;
             used = true;
         }
-        fe_store(&sh.hi_row[tid][0], hv);
+        {
+            const F29 hu = f29_unpack(hv.l);
+            sh.hi_row[tid][0] = make_uint4(hu.l[0], hu.l[1], hu.l[2], hu.l[3]);
+            sh.hi_row[tid][1] = make_uint4(hu.l[4], hu.l[5], hu.l[6], hu.l[7]);
+            sh.hi_row[tid][2] = make_uint4(hu.l[8], 0u, 0u, 0u);
+        }
     }
     __syncthreads();
     return lo;
 }
 
+ZG_DEV F29 eq_hi_row(const EqShared &sh, uint32_t k) {
+    const uint4 a = sh.hi_row[k][0], b = sh.hi_row[k][1];
+    F29 r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    r.l[8] = sh.hi_row[k][2].x;
+    return r;
+}
 // out[(h << v_lo) | t] = hi[h] * lo[t]; one 32-byte store per thread and row, 8 KiB contiguous per (block, h): the
 // kernel is an HBM write stream with one mixed-format product (fr_mul29) per element.
 // WG groups of 256 threads per block: thread (grp, lo) writes rows grp, grp + WG, ... — the factor prologue (a latency chain of ~5
@@ -143,10 +159,15 @@ __global__ void __launch_bounds__(256 * WG) eq_main_kernel(EqArgs a, int v_lo, i
     const uint32_t lo = threadIdx.x & 255u, grp = threadIdx.x >> 8;
     if (lo >= (1u << v_lo)) return;
     F29 tp = fr29_prescale(lov);  // shared factor of this thread's products
-    for (uint32_t k = grp; k < rows; k += WG) {
-        Fr hv = fe_load<FrParams>(&sh.hi_row[k][0]);
-        fe_store(out + 4 * (((size_t)(h0 + k) << v_lo) | lo), fr_mul29(hv, tp));
+    // two rows per trip: the two products are independent chains of 162 multiply-adds each, so a wave has an instruction to issue while
+    // the other chain's accumulator is in flight (two waves per SIMD alone do not cover the multiplier's latency)
+    uint32_t k = grp;
+    for (; k + WG < rows; k += 2 * WG) {
+        const F29 t0 = f29t_mul<Fr29>(eq_hi_row(sh, k), tp), t1 = f29t_mul<Fr29>(eq_hi_row(sh, k + WG), tp);
+        fe_store(out + 4 * (((size_t)(h0 + k) << v_lo) | lo), fr29_out(t0));
+        fe_store(out + 4 * (((size_t)(h0 + k + WG) << v_lo) | lo), fr29_out(t1));
     }
+    if (k < rows) fe_store(out + 4 * (((size_t)(h0 + k) << v_lo) | lo), fr29_out(f29t_mul<Fr29>(eq_hi_row(sh, k), tp)));
 }
 
 // f[i] = eq[i] * (Az[i]*Bz[i] - Cz[i])
@@ -864,8 +885,7 @@ __global__ void __launch_bounds__(256 * WG) eq_spartan_kernel(EqArgs ea, int v_l
             // — the reference's montgomeryMul(e, sub(montgomeryMul(a, b), c)), since Montgomery products are exact. Saves two
             // canonicalisations, a modular subtraction and two unpacks per entry of a kernel that is bound by its instruction count.
             constexpr u32 BIAS64R[9] = {0x40000040u, 0x43eb27deu, 0x5709143cu, 0x54243cdau, 0x4174a0cdu, 0x56d03029u, 0x49b85043u, 0x57098cffu, 0x0c19139au};
-            const Fr hv = fe_load<FrParams>(&fs.hi_row[k][0]);
-            const F29 E = f29t_mul<Fr29>(f29_unpack(hv.l), tp);
+            const F29 E = f29t_mul<Fr29>(eq_hi_row(fs, k), tp);
             const F29 AB = f29t_mul<Fr29>(fr29_in_shift(a), fr29_in_shift(b));
             const F29 cs = fr29_in_shift(c);
             F29 W;
