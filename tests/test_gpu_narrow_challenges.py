@@ -189,3 +189,48 @@ def test_hyperkzg_open_at_a_narrow_point(env, v, srs_n):
     for i, (q, qi) in enumerate(quotients):
         assert qi == wqi[i] and np.array_equal(q, wq[i]), i
     params.deinit()
+
+
+@pytest.mark.parametrize("v", [13, 14, 15, 17, 20])
+def test_eq_table_with_narrow_challenges(env, v, monkeypatch):
+    """The expanding eq-table kernel (csrc/poly.hip eq_expand_kernel: from 2^14 entries on, when the three variables in the middle of the
+    index are 128-bit challenges, a thread forms one full product and expands it as the reference's own doubling build does — seven 9 x 5-limb
+    products and seven subtractions for eight entries) against the oracle's evalsSliceWithScaling, with every challenge narrow (extremes
+    included: 0, 1, the largest canonical [0, 0, lo, hi]), with only the middle three narrow, with one of them wide (the one-product-per-
+    entry kernel must take over), with a scaling factor, and with the kernel switched off: identical bytes every time."""
+    api, lib, ob = env
+    wide = _rand(ob, 4400 + v, v)
+    nar = narrow(4500 + v, v)
+    xh = v - 11
+    mid = wide.copy()
+    if v >= 14:
+        mid[xh:xh + 3] = nar[:3]  # the three extremes 0, 1 * 2^128, 2^192 sit exactly on the expansion variables
+    one_wide = nar.copy()
+    if v >= 14:
+        one_wide[xh + 1] = wide[0]
+    scale = _rand(ob, 4600 + v, 1)[0]
+    for r, sc in ((nar, None), (mid, None), (one_wide, scale), (nar[::-1].copy(), scale), (wide, None)):
+        want = ob.fr_eq_table(r, sc)
+        got = lib.fr_eq_table(r, sc)
+        assert hashlib.sha256(got.tobytes()).digest() == hashlib.sha256(want.tobytes()).digest()
+
+
+def test_eq_table_expanding_kernel_at_every_size_in_a_child_process(tmp_path):
+    """the expanding kernel is the default from 2^20 entries on; ZG_EQ_EXPAND = 14 (read once per process) forces it from 2^14 on, so that its
+    row / workgroup geometry is exercised at every size between: v = 14 .. 19 against the oracle, in a fresh process"""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import hashlib, numpy as np\n"
+        "from oracle import binding as ob\n"
+        "from zolt_amd import lib\n"
+        "from tests.test_gpu_narrow_challenges import narrow\n"
+        "lib.init(0)\n"
+        "for v in range(14, 20):\n"
+        "    r = narrow(9000 + v, v)[::-1].copy()\n"
+        "    assert hashlib.sha256(lib.fr_eq_table(r).tobytes()).digest() == hashlib.sha256(ob.fr_eq_table(r).tobytes()).digest(), v\n"
+        "print('ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZG_EQ_EXPAND="14", PYTHONPATH=root), cwd=root, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "ok" in res.stdout, res.stdout[-1000:] + res.stderr[-2000:]

@@ -76,7 +76,9 @@ struct EqShared {
 // Index bits are taken four at a time: 16-entry tables of <= 3 products each (144 threads at most), then lo[t] is one product
 // of two table entries and hi[h] at most ceil(v_hi / 4) products by one thread per row — a chain of ~10 products (~2 us)
 // in front of the stream instead of a launch of its own. Exact products: any grouping gives the reference's bytes.
-ZG_DEV Fr eq_block_factors(const EqArgs &a, int v_lo, int v_hi, uint32_t h0, uint32_t rows, EqShared &sh) {
+// lo_var0: the variable the MOST significant of the v_lo low index bits belongs to (v_hi when the two parts are adjacent)
+ZG_DEV Fr eq_block_factors(const EqArgs &a, int v_lo, int v_hi, uint32_t h0, uint32_t rows, EqShared &sh, int lo_var0 = -1) {
+    if (lo_var0 < 0) lo_var0 = v_hi;
     const uint32_t tid = threadIdx.x;
     const int ng_hi = (v_hi + 3) / 4, ng = 2 + ng_hi;
     const Fr one = Fr::one();
@@ -96,7 +98,7 @@ ZG_DEV Fr eq_block_factors(const EqArgs &a, int v_lo, int v_hi, uint32_t h0, uin
             const int bit = b0 + b;
             Fr fb = one;
             if (bit < part_bits) {
-                const int var = g < 2 ? v_hi + (v_lo - 1 - bit) : (v_hi - 1 - bit);
+                const int var = g < 2 ? lo_var0 + (v_lo - 1 - bit) : (v_hi - 1 - bit);
                 Fr rj;
 #pragma unroll
                 for (int i = 0; i < 8; i++) rj.l[i] = a.r[var][i];
@@ -168,6 +170,50 @@ __global__ void __launch_bounds__(256 * WG) eq_main_kernel(EqArgs a, int v_lo, i
         fe_store(out + 4 * (((size_t)(h0 + k + WG) << v_lo) | lo), fr29_out(t1));
     }
     if (k < rows) fe_store(out + 4 * (((size_t)(h0 + k) << v_lo) | lo), fr29_out(f29t_mul<Fr29>(eq_hi_row(sh, k), tp)));
+}
+
+// The same table when the three variables in the MIDDLE of the index are 128-bit challenges (the reference's transcript challenges are:
+// MontU128Challenge, stored [0, 0, lo, hi] — fp29.hip.h FrMul): index = (h << 11) | (e << 8) | t with h <-> r[0 .. v_hi), e <-> the three
+// variables r[v_hi .. v_hi + 3), t <-> the last eight. A thread forms B = hi[h] * lo[t] (one full product) and EXPANDS it over the three
+// variables exactly as the reference builds its table (evalsSliceWithScaling, src/poly/mod.zig:252-290: y = x * r_j, x = x - y): seven
+// products by a 128-bit factor (9 x 5 limbs, 90 multiply-adds instead of 162) and seven subtractions for eight entries. 2^20 entries:
+// 5.4 M -> 3.8 M wave instructions (the kernel is bound by its instruction count, profiles/r4final_kernel_table.md). For a fixed e the
+// lanes of a wave write consecutive t: every store instruction is a contiguous 2 KiB.
+constexpr int EQ_XL = 3;
+template <int WG>
+__global__ void __launch_bounds__(256 * WG) eq_expand_kernel(EqArgs a, int v_hi, uint32_t hi_per_block, uint64_t *out) {
+    __shared__ EqShared sh;
+    const uint32_t n_hi = 1u << v_hi, h0 = blockIdx.x * hi_per_block;
+    const uint32_t rows = n_hi - h0 < hi_per_block ? n_hi - h0 : hi_per_block;
+    const Fr lov = eq_block_factors(a, 8, v_hi, h0, rows, sh, v_hi + EQ_XL);
+    const uint32_t t = threadIdx.x & 255u, grp = threadIdx.x >> 8;
+    F29 rp[EQ_XL];  // H * 2^17 of the three expansion challenges (frmul_prepare's narrow form), opaque to the optimiser
+#pragma unroll
+    for (int j = 0; j < EQ_XL; j++) {
+        const uint32_t *y = a.r[v_hi + j];
+        u32 w[8] = {y[4] << 17, (y[5] << 17) | (y[4] >> 15), (y[6] << 17) | (y[5] >> 15), (y[7] << 17) | (y[6] >> 15), y[7] >> 15, 0u, 0u, 0u};
+        rp[j] = f29_unpack(w);
+#pragma unroll
+        for (int i = 0; i < 9; i++) asm volatile("" : "+v"(rp[j].l[i]));
+    }
+    const F29 tp = fr29_prescale(lov);
+    for (uint32_t k = grp; k < rows; k += WG) {
+        Fr v[8];
+        v[0] = fr29_out(f29t_mul<Fr29>(eq_hi_row(sh, k), tp));
+#pragma unroll
+        for (int j = 0; j < EQ_XL; j++) {
+            const int stride = 4 >> j;  // variable v_hi + j <-> bit (2 - j) of e
+#pragma unroll
+            for (int base = 0; base < 8; base += 2 * stride) {
+                const Fr y = fr29_out(f29t_mul_short<Fr29, 5>(f29_unpack(v[base].l), rp[j]));
+                v[base + stride] = y;
+                v[base] = fe_sub(v[base], y);
+            }
+        }
+        uint64_t *row = out + 4 * (((size_t)(h0 + k) << (8 + EQ_XL)) | t);
+#pragma unroll
+        for (int e = 0; e < 8; e++) fe_store(row + 4 * ((size_t)e << 8), v[e]);
+    }
 }
 
 // f[i] = eq[i] * (Az[i]*Bz[i] - Cz[i])
@@ -1113,6 +1159,26 @@ static int eq_table_enqueue(const uint64_t *r_host, size_t v, const uint64_t *sc
     static const uint32_t nb_env = env_uint("ZG_EQ_BLOCKS", 0, 0, 65536);
     const uint32_t nb_cap = nb_env ? nb_env : (n_hi <= 4096 ? 256u : 512u);
     uint32_t hpb = eq_rows_per_block(n_hi, nb_cap);
+    // tables of >= 2^20 entries whose three middle variables are 128-bit challenges take the expanding kernel. Measured, narrow challenges,
+    // back-to-back launches (tools/exp/run_eq_expand_ab.sh, profiles/r5e_eq_expand_ab.txt): 2^24 entries 165 -> 139 us, 2^20 18.6 -> 17.6 us;
+    // 2^16 7.6 -> 10.7 and 2^14 7.3 -> 9.8 us — a short table is a latency chain, and the expansion adds three dependent products to it.
+    // ZG_EQ_EXPAND = 0: never; k >= 14: from 2^k entries on (the tests use 14 to run the kernel at small sizes).
+    static const uint32_t expand_min = env_uint("ZG_EQ_EXPAND", 20, 0, 34);
+    if (expand_min >= 14 && v >= expand_min) {
+        const int xh = (int)v - 8 - EQ_XL;
+        bool narrow = true;
+        for (int j = 0; j < EQ_XL; j++) narrow = narrow && r_host[4 * (xh + j)] == 0 && r_host[4 * (xh + j) + 1] == 0;
+        if (narrow) {
+            const uint32_t xn = 1u << xh, xcap = nb_env ? nb_env : (xn <= 512 ? 256u : 512u);
+            const uint32_t xhpb = eq_rows_per_block(xn, xcap), xwg = xhpb >= 2 ? 2u : 1u;
+            prof_begin(ZG_PROF_EQ_TABLE, st);
+            if (xwg == 2) hipLaunchKernelGGL(eq_expand_kernel<2>, dim3(div_up(xn, xhpb)), dim3(512), 0, st, a, xh, xhpb, d_out);
+            else hipLaunchKernelGGL(eq_expand_kernel<1>, dim3(div_up(xn, xhpb)), dim3(256), 0, st, a, xh, xhpb, d_out);
+            prof_end(ZG_PROF_EQ_TABLE, st);
+            ZG_HIP(hipGetLastError());
+            return ZG_OK;
+        }
+    }
     prof_begin(ZG_PROF_EQ_TABLE, st);
     static const uint32_t wg_env = env_uint("ZG_EQ_WG", 0, 0, 4);
     const uint32_t wg = wg_env ? wg_env : (n_hi <= 4096 ? 2u : 1u);
