@@ -51,7 +51,23 @@ pass $O22/pmc_sq "$B22" --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAV
   echo "# serial 2^22 bench command: $B22"; grep -h '^{' $O22/trace1.log | tail -1
   python3 $ROOT/tools/summarize_prof.py $O22
 } > $O22/summary.txt 2>&1
+# the sumcheck-family kernels at ONE size (2^20 entries): durations, then counters in passes of their own
+OSC=$ROOT/gpurun_out/prof_sc_$TAG
+mkdir -p $OSC
+SC="python3 $ROOT/tools/prof_sc_kernels.py 20 8"
+pass $OSC/trace "$SC" --kernel-trace --stats
+pass $OSC/pmc_fetch "$SC" --pmc FETCH_SIZE
+pass $OSC/pmc_write "$SC" --pmc WRITE_SIZE
+pass $OSC/pmc_sq "$SC" --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES
+{
+  echo "# command: $SC   (every kernel below ran on 2^20-entry tables only; FETCH_SIZE / WRITE_SIZE in KB as rocprofv3 reports them:"
+  echo "#  FETCH_SIZE counts a wide coalesced streaming read at half its bytes on gfx950 — MI355X_MICROARCH.md — double it before comparing)"
+  python3 $ROOT/tools/summarize_prof.py $OSC
+} > $OSC/summary.txt 2>&1
+cp $OSC/summary.txt "$ROOT/profiles/${TAG}_sumcheck_kernels_2^20_durations_and_pmc.txt"
+find $OSC -name "*.csv" -size +2M -delete
 python3 $ROOT/tools/pmc_json.py $TAG $OUT $O22 > $OUT/pmc.json
+python3 $ROOT/tools/kernel_table.py $TAG > $ROOT/profiles/${TAG}_kernel_table.md 2>/dev/null
 cp $OUT/summary.txt $ROOT/profiles/${TAG}_rocprofv3_summary.txt
 cp $O22/summary.txt "$ROOT/profiles/${TAG}_rocprofv3_summary_2^22.txt"
 cp $OUT/pmc.json $ROOT/profiles/${TAG}_pmc.json

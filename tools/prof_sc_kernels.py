@@ -33,6 +33,8 @@ r = rand_fr(v)
 ch = rand_fr(1)[0]
 ch128 = ch.copy()
 ch128[:2] = 0  # the reference's MontU128Challenge shape: [0, 0, lo, hi]
+r128 = r.copy()
+r128[:, :2] = 0
 for _ in range(reps):
     for layout in (lib.SC_HIGH_HALF, lib.SC_LOW_PAIR):
         s = lib.SumcheckSession.open_dev(tab.ptr, n, layout)  # copy + sc_sums at 2^v
@@ -40,7 +42,8 @@ for _ in range(reps):
         s.bind(ch if layout == lib.SC_HIGH_HALF else ch128)  # sc_fold at 2^v (full-width / 128-bit challenge)
         s.round_sums()
         s.close()
-    lib.fr_eq_table_dev(r, out.ptr)  # eq_main at 2^v
+    lib.fr_eq_table_dev(r, out.ptr)  # eq_main at 2^v (full-width challenges)
+    lib.fr_eq_table_dev(r128, out.ptr)  # eq_expand at 2^v (the transcript's 128-bit challenges; from 2^20 entries)
     s = lib.SumcheckSession.open_spartan_dev(r, az.ptr, bz.ptr, cz.ptr)  # eq_spartan at 2^v
     s.round_sums()
     s.close()
