@@ -367,8 +367,8 @@ def test_design_kernel_table_is_the_generated_one():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_table.py"), "r4final"], capture_output=True, text=True, check=True).stdout.strip()
-    assert out == open(os.path.join(root, "profiles", "r4final_kernel_table.md")).read().strip()
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_table.py"), "r5"], capture_output=True, text=True, check=True).stdout.strip()
+    assert out == open(os.path.join(root, "profiles", "r5_kernel_table.md")).read().strip()
     design = open(os.path.join(root, "DESIGN.md")).read()
     assert out in design
 

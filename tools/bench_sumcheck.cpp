@@ -409,6 +409,7 @@ int main(int argc, char **argv) {
         size_t bytes_per_cycle = 0;
         const int no = reps > 3 ? 3 : reps;
         for (int rep = -1; rep < no; rep++) {
+            shared_matrix.reset();  // (the previous repetition's matrix goes back to the pool before the next one is built)
             auto t0 = clk::now();
             CycleColumns cols = CycleColumns::fromTrace(trace);
             auto ta = clk::now();

@@ -1637,17 +1637,20 @@ static size_t fine_max_items(const MsmPlan &p, size_t n_total) { return (size_t)
 static void lane_free(zg_bases_s::Lane &ln) {
     void *lp[] = {ln.d_dig, ln.d_sorted, ln.d_hist, ln.d_starts, ln.d_blockhist, ln.d_tmp, ln.d_cstarts, ln.d_fine, ln.d_partial, ln.d_slice_buckets, ln.d_slice_meta, ln.d_bits, ln.d_rg,
                   ln.d_nzrank, ln.d_nzlist, ln.d_scan_tmp, ln.d_part, ln.d_part2, ln.d_heavy, ln.d_state};
-    for (void *p : lp)
-        if (p) (void)hipFree(p);
+    for (void *p : lp) pool_free(p);
     if (ln.done) (void)hipEventDestroy(ln.done);
     ln = zg_bases_s::Lane();
 }
 
+static hipError_t lane_malloc(void **p, size_t bytes) {  // from the device pool, like the handle's table (free_bases)
+    *p = pool_alloc(bytes ? bytes : 16);
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
 // workspace of one MSM launch set: n_total scalars (all scalar vectors of a batched launch together) under plan p
 static hipError_t lane_alloc(zg_bases_s::Lane &ln, const MsmPlan &p, size_t n_total, uint32_t nblk_lds) {
     hipError_t e = hipSuccess;
     auto A = [&](auto &ptr, size_t bytes) {
-        if (e == hipSuccess) e = dev_malloc((void **)&ptr, bytes);
+        if (e == hipSuccess) e = lane_malloc((void **)&ptr, bytes);
     };
     A(ln.d_dig, (size_t)p.W * n_total * 4);
     A(ln.d_sorted, (size_t)p.W * n_total * 4);
@@ -1705,12 +1708,20 @@ static hipError_t lane_alloc(zg_bases_s::Lane &ln, const MsmPlan &p, size_t n_to
     return e;
 }
 
+// A handle's table and workspaces come from the device pool (runtime.hip) like every transient allocation: a prover that rebuilds its key
+// per proof (or a test that uploads bases per case) reuses the blocks instead of paying hipMalloc / hipFree of gigabytes — 26 ms against
+// 113 ms for HyperKZG.setup at 2^20 powers when another process holds a context on the same GPU (bench.py's child runs, round 5). The blocks
+// go back only after the device is idle (hipFree used to imply that).
+static hipError_t handle_malloc(void **p, size_t bytes) {
+    *p = pool_alloc(bytes ? bytes : 16);
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
 static void free_bases(zg_bases_s *b) {
     if (!b) return;
+    (void)hipDeviceSynchronize();
     free_bases(b->small);
     void *ptrs[] = {b->d_table, b->d_inf, b->d_scal, b->d_out, b->d_slice_parts};
-    for (void *p : ptrs)
-        if (p) (void)hipFree(p);
+    for (void *p : ptrs) pool_free(p);
     for (auto &ln : b->lanes) lane_free(ln);
     lane_free(b->batch_lane);
     for (int i = 0; i < zg_bases_s::NAUX; i++) {
@@ -1724,7 +1735,7 @@ static void free_bases(zg_bases_s *b) {
 
 #define ZG_ALLOC(ptr, bytes)                                                         \
     do {                                                                             \
-        hipError_t _e = dev_malloc((void **)&(ptr), (bytes));                         \
+        hipError_t _e = handle_malloc((void **)&(ptr), (bytes));                      \
         if (_e != hipSuccess) {                                                      \
             set_error(std::string("hipMalloc(" #ptr "): ") + hipGetErrorString(_e)); \
             free_bases(b);                                                           \
@@ -1975,13 +1986,14 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
     // per slice: bucket starts, non-empty ranks, non-empty list, reduction state (what a sort hands to its accumulation), 16-byte aligned
     const size_t meta_stride = (3 * ((size_t)p.NK + 1) + state_words(p.NT, p.NK) + 3) & ~(size_t)3;
     if (S > 1 && ln.slice_buckets < S - 1) {
-        if (ln.d_slice_buckets) ZG_HIP(hipFree(ln.d_slice_buckets));  // (synchronises the device: once per lane and slice count)
+        if (ln.d_slice_buckets || ln.d_slice_meta) ZG_HIP(hipDeviceSynchronize());  // once per lane and slice count: the old buffers may be in use
+        pool_free(ln.d_slice_buckets);
         ln.d_slice_buckets = nullptr;
         ln.slice_buckets = 0;
-        ZG_HIP(hipMalloc((void **)&ln.d_slice_buckets, (S - 1) * (size_t)p.NK * 144));
-        if (ln.d_slice_meta) ZG_HIP(hipFree(ln.d_slice_meta));
+        ZG_HIP(lane_malloc((void **)&ln.d_slice_buckets, (S - 1) * (size_t)p.NK * 144));
+        pool_free(ln.d_slice_meta);
         ln.d_slice_meta = nullptr;
-        ZG_HIP(hipMalloc((void **)&ln.d_slice_meta, S * meta_stride * 4));
+        ZG_HIP(lane_malloc((void **)&ln.d_slice_meta, S * meta_stride * 4));
         ln.slice_buckets = S - 1;
     }
     // digits and sort of bases[off, off + n_pts) x p.K scalar vectors at d_scalars -> sv (sorted references, bucket starts, ...)
@@ -2288,24 +2300,20 @@ int zg_g1_bases_upload(const uint64_t *xy, const uint8_t *inf, size_t n, const z
         set_error("zg_g1_bases_upload: invalid argument");
         return ZG_ERR_INVALID;
     }
-    uint64_t *dxy = nullptr;
-    uint8_t *dinf = nullptr;
-    hipError_t e = hipMalloc((void **)&dxy, n ? n * 64 : 16);
-    if (e == hipSuccess && n) e = hipMemcpy(dxy, xy, n * 64, hipMemcpyHostToDevice);
-    if (e == hipSuccess && inf) {
-        e = hipMalloc((void **)&dinf, n ? n : 16);
-        if (e == hipSuccess && n) e = hipMemcpy(dinf, inf, n, hipMemcpyHostToDevice);
-    }
-    int rc;
-    if (e != hipSuccess) {
-        set_error(std::string("zg_g1_bases_upload: ") + hipGetErrorString(e));
-        rc = e == hipErrorOutOfMemory ? ZG_ERR_NOMEM : ZG_ERR_HIP;
-    } else {
-        rc = bases_create(dxy, dinf, n, cfg, lib_stream(), out);
-    }
-    if (dxy) (void)hipFree(dxy);
-    if (dinf) (void)hipFree(dinf);
-    return rc;
+    hipStream_t st = lib_stream();
+    Scratch s_xy(n ? n * 64 : 16), s_inf(inf && n ? n : 16);
+    if (!s_xy.p || !s_inf.p) return ZG_ERR_NOMEM;
+    SyncGuard sync(st);  // the staging copies go back to the pool only after the table build that reads them has finished
+    uint64_t *dxy = s_xy.as<uint64_t>();
+    uint8_t *dinf = inf ? s_inf.as<uint8_t>() : nullptr;
+    if (n) ZG_HIP(hipMemcpyAsync(dxy, xy, n * 64, hipMemcpyHostToDevice, st));
+    if (inf && n) ZG_HIP(hipMemcpyAsync(dinf, inf, n, hipMemcpyHostToDevice, st));
+    int rc = bases_create(dxy, dinf, n, cfg, st, out);
+    hipError_t e = hipStreamSynchronize(st);
+    sync.dismiss();
+    if (rc != ZG_OK) return rc;
+    ZG_HIP(e);
+    return ZG_OK;
 }
 
 int zg_g1_bases_free(zg_bases_t b) {
@@ -2355,7 +2363,7 @@ static constexpr int HOST_SLICES_MAX = 8;
 static int msm_host_sliced(zg_bases_s *b, size_t off, size_t n, const uint64_t *scalars, int slices, uint64_t out_xy[8], uint8_t *out_inf) {
     hipStream_t st = lib_stream();
     ZG_TRY(ensure_aux_streams(b));
-    if (!b->d_slice_parts) ZG_HIP(hipMalloc((void **)&b->d_slice_parts, HOST_SLICES_MAX * 12 * 8));
+    if (!b->d_slice_parts) ZG_HIP(lane_malloc((void **)&b->d_slice_parts, HOST_SLICES_MAX * 12 * 8));
     hipStream_t ss[zg_bases_s::NAUX + 1] = {st, b->aux[0], b->aux[1], b->aux[2]};
     ZG_HIP(hipEventRecord(b->ev_fork, st));
     for (int i = 0; i < zg_bases_s::NAUX; i++) ZG_HIP(hipStreamWaitEvent(b->aux[i], b->ev_fork, 0));
@@ -2404,7 +2412,7 @@ int zg_msm_g1(zg_bases_t b, size_t off, size_t n, const uint64_t *scalars, uint6
     DeviceGuard dg(b->device);
     std::lock_guard<std::mutex> lk(b->mu);
     hipStream_t st = lib_stream();
-    if (n && !b->d_scal) ZG_HIP(dev_malloc((void **)&b->d_scal, b->n * 32));
+    if (n && !b->d_scal) ZG_HIP(lane_malloc((void **)&b->d_scal, b->n * 32));
     int slices = env_int("ZG_MSM_HOST_SLICES", 4);
     if (slices > HOST_SLICES_MAX) slices = HOST_SLICES_MAX;
     if (slices >= 2 && n >= host_slice_min() && b->lanes.size() >= 2) return msm_host_sliced(b, off, n, scalars, slices, out_xy, out_inf);
@@ -2429,7 +2437,7 @@ int zg_msm_g1_u64(zg_bases_t b, size_t off, size_t n, const uint64_t *values, ui
     DeviceGuard dg(b->device);
     std::lock_guard<std::mutex> lk(b->mu);
     hipStream_t st = lib_stream();
-    if (n && !b->d_scal) ZG_HIP(dev_malloc((void **)&b->d_scal, b->n * 32));
+    if (n && !b->d_scal) ZG_HIP(lane_malloc((void **)&b->d_scal, b->n * 32));
     Scratch s_vals(n ? n * 8 : 16);
     if (!s_vals.p) return ZG_ERR_NOMEM;
     SyncGuard sync(st);

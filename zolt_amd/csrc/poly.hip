@@ -1311,9 +1311,10 @@ using namespace zg;
 
 static void sc_free(zg_sc_s *s) {
     if (!s) return;
+    if (s->own_st) (void)hipStreamSynchronize(s->own_st);  // the tables go back to the device pool: nothing of this session may still run
+    if (s->st && s->st != s->own_st) (void)hipDeviceSynchronize();  // (a caller's stream may be gone by now: wait for the device instead)
     void *ptrs[] = {s->buf[0], s->buf[1], s->d_partials};
-    for (void *p : ptrs)
-        if (p) (void)hipFree(p);
+    for (void *p : ptrs) pool_free(p);
     if (s->h_pin) (void)hipHostFree(s->h_pin);
     stream_release(s->own_st, s->device);
     delete s;
@@ -1350,9 +1351,13 @@ static int sc_create(size_t len, int layout, hipStream_t st, zg_sc_s **out) {
     s->own_st = stream_acquire();  // kept with the pooled session; from the runtime's free list (creating one costs ~3 ms)
     s->st = st ? st : s->own_st;
     hipError_t e = s->own_st ? hipSuccess : hipErrorOutOfMemory;
-    if (e == hipSuccess) e = hipMalloc((void **)&s->buf[0], len * 32);
-    if (e == hipSuccess) e = hipMalloc((void **)&s->buf[1], (len / 2 ? len / 2 : 1) * 32);
-    if (e == hipSuccess) e = hipMalloc((void **)&s->d_partials, SC_MISC_BYTES);
+    // tables from the device pool (runtime.hip): a session of a size the session pool does not hold still reuses freed blocks
+    auto grab = [&](uint64_t *&ptr, size_t bytes) {
+        if (e == hipSuccess && !(ptr = reinterpret_cast<uint64_t *>(pool_alloc(bytes)))) e = hipErrorOutOfMemory;
+    };
+    grab(s->buf[0], len * 32);
+    grab(s->buf[1], (len / 2 ? len / 2 : 1) * 32);
+    grab(s->d_partials, SC_MISC_BYTES);
     if (e == hipSuccess) e = hipMemset(s->d_partials, 0, SC_MISC_BYTES);
     if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_pin, 128, hipHostMallocMapped | hipHostMallocCoherent);
     if (e == hipSuccess) s->h_pin[12] = 0;

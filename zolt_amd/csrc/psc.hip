@@ -697,9 +697,11 @@ using namespace zg;
 
 static void psc_free(zg_psc_s *s) {
     if (!s) return;
-    if (s->buf[0]) (void)hipFree(s->buf[0]);
-    if (s->buf[1]) (void)hipFree(s->buf[1]);
-    if (s->d_misc) (void)hipFree(s->d_misc);
+    if (s->own_st) (void)hipStreamSynchronize(s->own_st);  // the tables go back to the device pool: nothing of this session may still run
+    if (s->st && s->st != s->own_st) (void)hipDeviceSynchronize();  // (a caller's stream may be gone by now: wait for the device instead)
+    pool_free(s->buf[0]);
+    pool_free(s->buf[1]);
+    pool_free(s->d_misc);
     if (s->h_pin) (void)hipHostFree(s->h_pin);
     stream_release(s->own_st, s->device);
     delete s;
@@ -751,9 +753,12 @@ static int psc_create(size_t k, size_t len, hipStream_t st, zg_psc_s **out) {
     s->len = s->cap = len;
     size_t half = len / 2 ? len / 2 : 1;
     hipError_t e = psc_open_stream(s, st);
-    if (e == hipSuccess) e = hipMalloc((void **)&s->buf[0], k * len * 32);
-    if (e == hipSuccess) e = hipMalloc((void **)&s->buf[1], k * half * 32);
-    if (e == hipSuccess) e = hipMalloc((void **)&s->d_misc, PSC_MISC_BYTES);
+    auto grab = [&](uint64_t *&ptr, size_t bytes) {  // from the device pool (runtime.hip)
+        if (e == hipSuccess && !(ptr = reinterpret_cast<uint64_t *>(pool_alloc(bytes)))) e = hipErrorOutOfMemory;
+    };
+    grab(s->buf[0], k * len * 32);
+    grab(s->buf[1], k * half * 32);
+    grab(s->d_misc, PSC_MISC_BYTES);
     if (e == hipSuccess) e = hipMemset(s->d_misc, 0, PSC_MISC_BYTES);
     if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_pin, 256, hipHostMallocMapped | hipHostMallocCoherent);
     if (e == hipSuccess) s->h_pin[PSC_FLAG] = 0;
