@@ -48,6 +48,16 @@ def load_pmc(path=PMC_FILE):
         return {}
 
 
+def profiled_duration_ms(logn, path=PMC_FILE):
+    """the kernel's average duration in the committed rocprofv3 --kernel-trace --stats run of the serial bench (ms), or None"""
+    try:
+        with open(path) as fh:
+            d = json.load(fh)
+        return d["sizes"][f"2^{logn}"]["duration"]["avg_us"] / 1e3
+    except (OSError, ValueError, KeyError, TypeError):
+        return None
+
+
 def measured_traffic(pmc, logn, adds_per_launch):
     """HBM bytes of one msm_accumulate launch from the committed counters (None when the file has no entry for this size)"""
     c = pmc.get(f"2^{logn}", {})
@@ -613,6 +623,12 @@ def main():
     if out["roofline"]["traffic"] is None:
         out["roofline"]["traffic_source"] = ("null: " + ("profiles/r5_pmc.json has no counters for this size" if default_plan else
                                                         "counters were collected for the default plan on one GPU only"))
+    prof_ms = profiled_duration_ms(args.logn) if default_plan else None
+    if prof_ms:
+        # the same kernel in the committed rocprofv3 run (profiles/r5_kernel_stats_trace1.csv: the serial bench issues its MSMs back to
+        # back, so a launch takes 7/8 of the chunk slots; the HIP-event figure above is a lone launch with every slot): both fractions
+        out["roofline"]["rocprofv3_avg_launch_ms"] = prof_ms
+        out["roofline"]["frac_at_rocprofv3_duration"] = alg_bytes / (prof_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
     pmc = pmc_all.get(f"2^{args.logn}", {}).get("SQ_INSTS_VALU")
     if pmc and alone_ms:
         wave_adds = adds / 64.0
