@@ -290,8 +290,7 @@ int zg_host_alloc(size_t bytes, void **ptr) {
     }
     return ZG_OK;
 }
-int zg_host_free(void *ptr) {
-    ZG_INIT();
+int zg_host_free(void *ptr) {  // no ZG_INIT(): a holder's destructor may run after zg_shutdown, and must not bring the library up again
     if (ptr) ZG_HIP(hipHostFree(ptr));
     return ZG_OK;
 }
