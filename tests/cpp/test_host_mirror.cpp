@@ -859,6 +859,13 @@ static int witness_main(const char *path) {
         std::printf("\n");
     }
     std::printf("B %zu\n", cols.bytesPerCycle());
+    {  // the streamed construction (slices of cycles decoded while the previous slice uploads) must give the same matrix
+        setenv("ZOLT_WITNESS_SLICES", "3", 1);
+        auto m2 = CycleWitnessMatrix::fromTrace(steps);
+        unsetenv("ZOLT_WITNESS_SLICES");
+        std::vector<Fr> rows2 = m2->toHost();
+        std::printf("T %d\n", rows2.size() == rows.size() && std::memcmp(rows2.data(), rows.data(), rows.size() * sizeof(Fr)) == 0);
+    }
     size_t nv = 0;
     while ((size_t(1) << nv) < n) nv++;
     std::vector<Fr> tau(nv + 2);

@@ -522,6 +522,7 @@ def test_cpp_witness_matrix_from_trace_columns(tmp_path, golden_dir):
         assert len(s1) == 2 and s1[0] == s1[1]
         bpc = int([l for l in res.stdout.splitlines() if l.startswith("B ")][0].split()[1])
         assert bpc == 156
+        assert "T 1" in res.stdout.splitlines(), "CycleWitnessMatrix::fromTrace in slices differs from the one-call matrix"
 
 
 @pytest.mark.gpu

@@ -192,10 +192,8 @@ static Timeline prove_once(const ProveCase &pc, bool emit) {
     }
     tl.lap("transcript absorbs the commitments", "host");
     // ---- stage 1 (prover.zig:344-450): witness, Az / Bz, eq(tau) * Az * Bz, LowToHigh rounds, Az(r) / Bz(r)
-    CycleColumns cols = CycleColumns::fromTrace(pc.trace);
-    tl.lap("stage 1: host decodes the trace into 156-byte integer columns", "host");
-    auto matrix = CycleWitnessMatrix::fromColumns(cols);
-    tl.lap("stage 1: columns -> witness matrix in HBM (zg_fr_rows_from_columns)", "h2d+kernels");
+    auto matrix = CycleWitnessMatrix::fromTrace(pc.trace);
+    tl.lap("stage 1: trace -> 156-byte integer columns -> witness matrix in HBM (slices of cycles: decode on host threads beside the upload + widening of the previous slice)", "host+h2d+kernels");
     const size_t n_constraints = pc.trace.size() * 19, padded = n_constraints ? ceil_pow2(n_constraints) : 1;
     size_t rounds1 = 0;
     while ((size_t(1) << rounds1) < padded) rounds1++;

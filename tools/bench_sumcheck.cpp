@@ -455,6 +455,26 @@ int main(int argc, char **argv) {
                 if (rep >= 0) t_fr_rows += std::chrono::duration<double>(clk::now() - t0).count() / 2;
             }
         }
+        // the same matrix through CycleWitnessMatrix::fromTrace: slices of cycles, the decode of one beside the upload of the previous
+        // (what the prove path calls); the slice count is swept once so the default can be read against its neighbours
+        {
+            std::printf("\"outer_trace_to_matrix_streamed_ms\": {");
+            bool first = true;
+            for (const char *sl : {"", "1", "2", "4", "8", "16"}) {
+                if (*sl) setenv("ZOLT_WITNESS_SLICES", sl, 1);
+                double t = 0;
+                for (int rep = -1; rep < 3; rep++) {
+                    shared_matrix.reset();
+                    auto t0 = clk::now();
+                    shared_matrix = CycleWitnessMatrix::fromTrace(trace);
+                    if (rep >= 0) t += std::chrono::duration<double>(clk::now() - t0).count() / 3;
+                }
+                std::printf("%s\"%s\": %.4f", first ? "" : ", ", *sl ? sl : "default", t * 1e3);
+                first = false;
+            }
+            unsetenv("ZOLT_WITNESS_SLICES");
+            std::printf("}, ");
+        }
         std::printf("\"outer_log_t\": %zu, \"outer_column_bytes_per_cycle\": %zu, \"outer_host_columns_ms\": %.4f, \"outer_upload_ms\": %.4f, "
                     "\"outer_upload_split_ms\": {\"alloc\": %.4f, \"h2d\": %.4f, \"widen_kernel\": %.4f}, \"outer_prover_tables_ms\": %.4f, "
                     "\"outer_uniskip_first_round_ms\": %.4f, \"outer_materialize_ms\": %.4f, \"outer_upload_plus_first_round_plus_materialize_ms\": %.4f, "

@@ -100,10 +100,14 @@ struct CycleColumns {
     // the integer-domain restatement of generateWitness over a NoOp-padded trace
     static CycleColumns fromTrace(const std::vector<R1CSTraceStep> &steps) {
         CycleColumns c(steps.size(), false);  // every decoding thread clears its own rows (164 MB of memset on one thread cost more than the decode)
+        c.decodeParallel(steps, 0, c.n);
+        return c;
+    }
+    // rows [i0, i1) of the columns from the same rows of the trace (row i reads step i + 1 as its successor, nothing else)
+    void decodeRange(const std::vector<R1CSTraceStep> &steps, size_t i0, size_t i1) {
+        CycleColumns &c = *this;
         uint64_t *Left = c.u64[0], *PC = c.u64[1], *UPC = c.u64[2], *Rs1 = c.u64[3], *Rs2 = c.u64[4], *RdW = c.u64[5], *RamR = c.u64[6], *RamW = c.u64[7],
                  *LeftLookup = c.u64[8], *NextUPC = c.u64[9], *NextPC = c.u64[10], *Lookup = c.u64[11];
-        // every cycle is independent (it reads its successor only): long traces are decoded by several host threads
-        auto decode = [&](size_t i0, size_t i1) {
         for (auto *col : c.u64) std::memset(col + i0, 0, (i1 - i0) * 8);
         for (auto *col : c.wide) std::memset(col + 2 * i0, 0, (i1 - i0) * 16);
         std::memset(c.imm + i0, 0, (i1 - i0) * 8);
@@ -209,32 +213,39 @@ struct CycleColumns {
             }
             c.word[i] = bits;
         }
-        };
-        size_t nthreads = c.n >= (size_t(1) << 16) ? std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 8) : 1;
-        if (const char *e = std::getenv("ZOLT_HOST_THREADS")) nthreads = std::max(1, atoi(e));
+    }
+    // every cycle is independent: long ranges are decoded by several host threads (ZOLT_HOST_THREADS, default up to 16 — the loop is
+    // bound by its 17 output streams, 8 -> 16 threads took 4.7 -> 2.5 ms at 2^20 cycles, more gained nothing)
+    static size_t hostThreads(size_t rows) {
+        size_t t = rows >= (size_t(1) << 16) ? std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 16) : 1;
+        if (const char *e = std::getenv("ZOLT_HOST_THREADS")) t = std::max(1, atoi(e));
+        return t;
+    }
+    void decodeParallel(const std::vector<R1CSTraceStep> &steps, size_t i0, size_t i1) {
+        const size_t rows = i1 - i0, nthreads = hostThreads(rows);
         if (nthreads <= 1) {
-            decode(0, c.n);
-        } else {
-            std::vector<std::thread> pool;
-            const size_t per = (c.n + nthreads - 1) / nthreads;
-            for (size_t t = 0; t < nthreads; t++) {
-                const size_t a = t * per, b = std::min(c.n, a + per);
-                if (a < b) pool.emplace_back(decode, a, b);
-            }
-            for (auto &th : pool) th.join();
+            decodeRange(steps, i0, i1);
+            return;
         }
-        return c;
+        std::vector<std::thread> pool;
+        const size_t per = (rows + nthreads - 1) / nthreads;
+        for (size_t t = 0; t < nthreads; t++) {
+            const size_t a = i0 + t * per, b = std::min(i1, a + per);
+            if (a < b) pool.emplace_back([this, &steps, a, b] { decodeRange(steps, a, b); });
+        }
+        for (auto &th : pool) th.join();
     }
 
-    // the 43 descriptors of zg_fr_rows_from_columns, in R1CSInputIndex order
-    std::vector<zg_col_t> descriptors() const {
+    // the 43 descriptors of zg_fr_rows_from_columns, in R1CSInputIndex order; `first`: the descriptors of rows [first, ...) — a slice of
+    // the cycles is a matrix of its own (every column is a row-indexed array and a ZG_COL_MUL column names columns of the same row)
+    std::vector<zg_col_t> descriptors(size_t first = 0) const {
         std::vector<zg_col_t> d(NUM_INPUTS, zg_col_t{ZG_COL_ZERO, 0, 0, nullptr, nullptr});  // NextIsVirtual, NextIsFirstInSequence stay zero (:1160-1171)
-        for (int k = 0; k < 12; k++) d[U64_INPUTS[k]] = zg_col_t{ZG_COL_U64, 0, 0, u64[k], nullptr};
-        d[8] = zg_col_t{ZG_COL_I64, 0, 0, imm, nullptr};
-        for (int k = 0; k < 2; k++) d[WIDE_INPUTS[k]] = zg_col_t{ZG_COL_I128, 0, 0, wide[k], nullptr};
+        for (int k = 0; k < 12; k++) d[U64_INPUTS[k]] = zg_col_t{ZG_COL_U64, 0, 0, u64[k] + first, nullptr};
+        d[8] = zg_col_t{ZG_COL_I64, 0, 0, imm + first, nullptr};
+        for (int k = 0; k < 2; k++) d[WIDE_INPUTS[k]] = zg_col_t{ZG_COL_I128, 0, 0, wide[k] + 2 * first, nullptr};
         d[2] = zg_col_t{ZG_COL_MUL, 0, 1, nullptr, nullptr};  // Product = LeftInstructionInput * RightInstructionInput (:1120-1122)
-        d[16] = zg_col_t{ZG_COL_MUL, 2, 25, wide[2], nullptr};  // RightLookupOperand = Product * FlagMultiplyOperands + the other rows' value
-        for (uint32_t b = 0; b < 24; b++) d[BIT_INPUTS[b]] = zg_col_t{ZG_COL_BIT, b, 4, word, nullptr};
+        d[16] = zg_col_t{ZG_COL_MUL, 2, 25, wide[2] + 2 * first, nullptr};  // RightLookupOperand = Product * FlagMultiplyOperands + the other rows' value
+        for (uint32_t b = 0; b < 24; b++) d[BIT_INPUTS[b]] = zg_col_t{ZG_COL_BIT, b, 4, word + first, nullptr};
         return d;
     }
     size_t bytesPerCycle() const { return BYTES_PER_CYCLE; }
@@ -266,7 +277,52 @@ public:
         check(zg_fr_rows_from_columns(d.data(), d.size(), c.n, m->d_.u64()), "zg_fr_rows_from_columns");
         return m;
     }
-    static std::shared_ptr<CycleWitnessMatrix> fromTrace(const std::vector<R1CSTraceStep> &steps) { return fromColumns(CycleColumns::fromTrace(steps)); }
+    // trace -> matrix. A long trace is cut into slices of cycles: while slice s crosses PCIe and is widened (this thread, inside
+    // zg_fr_rows_from_columns), the host threads decode slice s + 1 — the decode (3.8 ms at 2^20 cycles on 8 threads) hides behind the
+    // 164 MB copy (3.3 ms) instead of preceding it. ZOLT_WITNESS_SLICES overrides the count (1: decode everything, then one call).
+    static std::shared_ptr<CycleWitnessMatrix> fromTrace(const std::vector<R1CSTraceStep> &steps) {
+        const size_t n = steps.size();
+        size_t slices = n >= (size_t(1) << 18) ? 4 : 1;
+        if (const char *e = std::getenv("ZOLT_WITNESS_SLICES")) slices = std::max(1, atoi(e));
+        const size_t per = ((n + slices - 1) / slices + 63) & ~size_t(63);  // slices start on 64-row boundaries: 512-byte aligned in every column
+        if (slices <= 1 || per >= n) return fromColumns(CycleColumns::fromTrace(steps));
+        CycleColumns c(n, false);
+        auto m = std::make_shared<CycleWitnessMatrix>();
+        m->num_cycles = n;
+        m->d_.alloc(n * CycleColumns::NUM_INPUTS * 32);
+        // the decoding threads live for the whole call: thread t decodes its share of slice 0, of slice 1, ...; a slice is final when
+        // every thread has counted itself off on it
+        const size_t n_slices = (n + per - 1) / per, T = CycleColumns::hostThreads(n);
+        std::mutex mu;
+        std::condition_variable cv;
+        std::vector<size_t> done(n_slices, 0);  // threads finished with slice s (under mu)
+        bool failed = false;
+        std::vector<std::thread> pool;
+        struct Join { std::vector<std::thread> &p; ~Join() { for (auto &t : p) if (t.joinable()) t.join(); } } join{pool};  // also on an exception below: the threads read c and steps
+        for (size_t t = 0; t < T; t++)
+            pool.emplace_back([&, t] {
+                for (size_t sl = 0; sl < n_slices; sl++) {
+                    const size_t a = sl * per, b = std::min(n, a + per), share = (b - a + T - 1) / T, i0 = std::min(b, a + t * share), i1 = std::min(b, i0 + share);
+                    bool ok = true;
+                    try { if (i0 < i1) c.decodeRange(steps, i0, i1); } catch (...) { ok = false; }
+                    bool last;
+                    { std::lock_guard<std::mutex> lk(mu); if (!ok) failed = true; last = ++done[sl] == T || !ok; }
+                    if (last) cv.notify_one();
+                    if (!ok) return;
+                }
+            });
+        for (size_t sl = 0; sl < n_slices; sl++) {
+            const size_t a = sl * per, b = std::min(n, a + per);
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return done[sl] == T || failed; });
+                if (failed) throw std::runtime_error("CycleWitnessMatrix::fromTrace: a decoding thread failed");
+            }
+            const auto d = c.descriptors(a);
+            check(zg_fr_rows_from_columns(d.data(), d.size(), b - a, m->d_.u64() + a * CycleColumns::NUM_INPUTS * 4), "zg_fr_rows_from_columns");
+        }
+        return m;
+    }
     // ready rows of field elements (R1CSCycleInputs.values per cycle): the 1376-bytes-per-cycle upload of rounds 3 and 4
     static std::shared_ptr<CycleWitnessMatrix> fromWitnesses(const void *rows, size_t cycles) {
         auto m = std::make_shared<CycleWitnessMatrix>();

@@ -19,7 +19,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <condition_variable>
 #include <map>
+#include <mutex>
 #include <unordered_map>
 #include <memory>
 #include <stdexcept>
