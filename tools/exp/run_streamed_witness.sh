@@ -1,20 +1,20 @@
-# A/B: host threads and slice counts of CycleWitnessMatrix::fromTrace at 2^20 cycles (prove-path composite, stage-1 line)
+# streamed witness build at 2^20 cycles: tests, the slice sweep of bench_sumcheck, the prove-path stage-1 line
 mkdir -p gpurun_out
-for th in 8 16 32; do for sl in 2 4 8; do
-  ZOLT_HOST_THREADS=$th ZOLT_WITNESS_SLICES=$sl timeout 600 ./tools/bench_prove_path synth 20 3 > gpurun_out/pp.json
-  python3 - "$th" "$sl" <<'PY'
-import json,sys
-d=json.load(open('gpurun_out/pp.json'))['prove_path']
-for s in d['steps']:
-    if s['call'].startswith('stage 1: trace') or s['call'].startswith('commit: host builds'): print('threads',sys.argv[1],'slices',sys.argv[2], round(s['ms'],3), s['call'][:40])
+timeout 900 python3 -m pytest tests/test_gpu_ingest.py tests/test_gpu_cpp_host.py -x -q -m gpu 2>&1 | tail -3
+timeout 600 ./tools/bench_sumcheck 20 3 > gpurun_out/r5i_bench_sumcheck.json 2> gpurun_out/r5i_bench_sumcheck.err
+python3 - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r5i_bench_sumcheck.json').read())
+for k in d:
+    if k.startswith('outer'): print(k, d[k])
 PY
-done; done 2>&1 | tee gpurun_out/r5h_streamed_witness_ab.txt
-timeout 600 ./tools/bench_prove_path synth 20 3 > gpurun_out/pp.json
-python3 - default default <<'PY'
-import json,sys
-d=json.load(open('gpurun_out/pp.json'))['prove_path']
+for i in 1 2; do
+timeout 600 ./tools/bench_prove_path synth 20 3 > gpurun_out/r5i_prove_path.json
+python3 - <<'PY'
+import json
+d=json.load(open('gpurun_out/r5i_prove_path.json'))['prove_path']
 print(d['total_ms'], d['total_ms_without_proving_key'])
 for s in d['steps']:
-    if s['call'].startswith('stage 1: trace'): print('default', round(s['ms'],3))
+    if s['call'].startswith('stage 1: trace'): print('stage-1 witness', round(s['ms'],3))
 PY
-timeout 300 python3 -m pytest tests/test_gpu_cpp_host.py -x -q -m gpu -k "witness or composite" 2>&1 | tail -2
+done

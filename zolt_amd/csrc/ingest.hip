@@ -5,7 +5,9 @@
 // R1CSCycleInputs.fromTraceStep is F.fromU64 / signedI64ToField / a flag / a product of two inputs) — and only then widens every one of
 // the 43 inputs of a cycle to a 32-byte Montgomery element (src/zkvm/r1cs/evaluation.zig:55-122 reads that matrix). A host that uploaded
 // the widened matrix moved 1376 bytes per cycle across PCIe (round 4: 1.44 GB, 26-55 ms at 2^20 cycles, against 4.6 ms of device work on
-// it). Here the columns cross as they are (~180 bytes per cycle) and one launch writes the matrix in HBM.
+// it). Here the columns cross as they are (156 bytes per cycle) and one launch writes the matrix in HBM.
+#include <algorithm>
+#include <cstdint>
 #include <cstdlib>
 #include <vector>
 
@@ -221,13 +223,40 @@ int rows_from_host_columns(const zg_col_t *cols, size_t n_cols, size_t n_rows, u
         if (w && cols[c].data) src_of[c] = source(cols[c].data, w * n_rows);
         if (cols[c].kind == ZG_COL_LUT && cols[c].b) aux_of[c] = source(cols[c].aux, (size_t)cols[c].b * 32);
     }
+    // Columns carved out of one host slab (zolt::CycleColumns; any caller that fills one allocation) cross as ONE copy: issuing a copy costs
+    // the host ~15 us, a 2 MB column slice takes 40 us on the link — sixteen small copies per slice of a streamed build left the DMA engine
+    // waiting for the host. When the sources span little more than their own bytes, the span is copied and every source keeps its offset.
+    // (a gap shorter than a page lies in pages its two neighbours already occupy: reading it cannot fault, whoever allocated the sources)
+    if (srcs.size() > 1) {
+        std::vector<size_t> order(srcs.size());
+        for (size_t k = 0; k < order.size(); k++) order[k] = k;
+        std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return srcs[x].host < srcs[y].host; });
+        const uintptr_t lo = reinterpret_cast<uintptr_t>(srcs[order[0]].host);
+        uintptr_t hi = lo + srcs[order[0]].bytes;
+        bool dense = true;
+        for (size_t k = 1; k < order.size() && dense; k++) {
+            const uintptr_t a = reinterpret_cast<uintptr_t>(srcs[order[k]].host);
+            if (a > hi && a - hi >= 4096) dense = false;
+            hi = std::max(hi, a + srcs[order[k]].bytes);
+        }
+        if (dense) {
+            const size_t head = lo & 255;  // the span sits at the same offset from a 256-byte boundary on both sides: every source keeps its alignment
+            for (Src &s : srcs) {
+                s.off = head + (reinterpret_cast<uintptr_t>(s.host) - lo);
+                s.bytes = 0;  // carries its offset only
+            }
+            total = head + (hi - lo);
+            srcs.push_back(Src{reinterpret_cast<const void *>(lo), hi - lo, head});  // the one copy
+        }
+    }
     const bool split = setup_times_enabled();
     const double t0 = split ? now_ms() : 0;
     Scratch stage(total ? total : 16);
     if (!stage.p) return ZG_ERR_NOMEM;
     const double t1 = split ? now_ms() : 0;
     SyncGuard sync(st);
-    for (const Src &s : srcs) ZG_HIP(hipMemcpyAsync(stage.as<char>() + s.off, s.host, s.bytes, hipMemcpyHostToDevice, st));
+    for (const Src &s : srcs)
+        if (s.bytes) ZG_HIP(hipMemcpyAsync(stage.as<char>() + s.off, s.host, s.bytes, hipMemcpyHostToDevice, st));
     if (split) ZG_HIP(hipStreamSynchronize(st));
     const double t2 = split ? now_ms() : 0;
     IngArgs args{};

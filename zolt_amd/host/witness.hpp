@@ -54,27 +54,35 @@ struct CycleColumns {
     }
     ~CycleColumns() { release(); }
     static constexpr size_t BYTES_PER_CYCLE = 12 * 8 + 8 + 3 * 16 + 4;  // 156
+    // bytes of the columns of `rows` cycles laid out back to back, every column on a 256-byte boundary
+    static size_t regionBytes(size_t rows) { return (((rows + 31) & ~size_t(31)) * BYTES_PER_CYCLE + 255) & ~size_t(255); }
     void resize(size_t cycles, bool zeroed = true) {
-        release();
-        n = cycles;
-        const size_t pad = (n + 31) & ~size_t(31);  // every column starts on a 256-byte boundary
-        bytes_ = pad * BYTES_PER_CYCLE + 256;
-        Slab &keep = spare();
-        if (keep.p && keep.bytes >= bytes_) {
-            slab_ = keep.p;
-            cap_ = keep.bytes;
-            keep.p = nullptr;
-        } else {
-            if (keep.p) { zg_host_free(keep.p); keep.p = nullptr; }
-            check(zg_host_alloc(bytes_, &slab_), "zg_host_alloc");
-            cap_ = bytes_;
+        if (cycles == 0) {  // nothing to hold: no slab
+            release();
+            layout(nullptr, 0);
+            return;
         }
+        allocate(regionBytes(cycles) + 256);
         if (zeroed) std::memset(slab_, 0, bytes_);
-        char *p = static_cast<char *>(slab_);
-        for (auto &c : u64) { c = reinterpret_cast<uint64_t *>(p); p += pad * 8; }
-        imm = reinterpret_cast<int64_t *>(p); p += pad * 8;
-        for (auto &c : wide) { c = reinterpret_cast<uint64_t *>(p); p += pad * 16; }
-        word = reinterpret_cast<uint32_t *>(p);
+        layout(static_cast<char *>(slab_), cycles);
+    }
+    // `owner` takes ONE slab for n cycles cut into slices of `per` cycles; the result holds one non-owning CycleColumns per slice, each
+    // with its columns back to back in its own region of the slab — a slice then crosses PCIe as one contiguous copy
+    // (zg_fr_rows_from_columns merges sources that sit side by side), while another slice is still being decoded
+    static std::vector<CycleColumns> sliced(CycleColumns &owner, size_t n, size_t per) {
+        size_t bytes = 256;
+        for (size_t a = 0; a < n; a += per) bytes += regionBytes(std::min(per, n - a));
+        owner.allocate(bytes);
+        owner.layout(static_cast<char *>(owner.slab_), 0);
+        std::vector<CycleColumns> part;
+        char *p = static_cast<char *>(owner.slab_);
+        for (size_t a = 0; a < n; a += per) {
+            const size_t rows = std::min(per, n - a);
+            part.emplace_back();  // (zero cycles: no slab of its own; the view owns nothing)
+            part.back().layout(p, rows);
+            p += regionBytes(rows);
+        }
+        return part;
     }
     static int64_t sx(uint64_t v, int bits) { return (int64_t)(v << (64 - bits)) >> (64 - bits); }
     static int64_t immOf(uint32_t w) {  // deriveImmediate (:1226-1274) as a signed integer
@@ -103,8 +111,8 @@ struct CycleColumns {
         c.decodeParallel(steps, 0, c.n);
         return c;
     }
-    // rows [i0, i1) of the columns from the same rows of the trace (row i reads step i + 1 as its successor, nothing else)
-    void decodeRange(const std::vector<R1CSTraceStep> &steps, size_t i0, size_t i1) {
+    // rows [i0, i1) of the columns from steps [step0 + i0, step0 + i1) of the trace (a row reads its step and the step after it, nothing else)
+    void decodeRange(const std::vector<R1CSTraceStep> &steps, size_t i0, size_t i1, size_t step0 = 0) {
         CycleColumns &c = *this;
         uint64_t *Left = c.u64[0], *PC = c.u64[1], *UPC = c.u64[2], *Rs1 = c.u64[3], *Rs2 = c.u64[4], *RdW = c.u64[5], *RamR = c.u64[6], *RamW = c.u64[7],
                  *LeftLookup = c.u64[8], *NextUPC = c.u64[9], *NextPC = c.u64[10], *Lookup = c.u64[11];
@@ -112,7 +120,7 @@ struct CycleColumns {
         for (auto *col : c.wide) std::memset(col + 2 * i0, 0, (i1 - i0) * 16);
         std::memset(c.imm + i0, 0, (i1 - i0) * 8);
         for (size_t i = i0; i < i1; i++) {
-            const R1CSTraceStep &st = steps[i];
+            const R1CSTraceStep &st = steps[step0 + i];
             uint32_t bits = 0;
             auto set = [&](Bit b) { bits |= 1u << b; };
             if (st.is_noop) {  // createNoopWitness (:1418-1438)
@@ -121,7 +129,7 @@ struct CycleColumns {
                 c.word[i] = bits;
                 continue;
             }
-            const R1CSTraceStep *nx = i + 1 < c.n ? &steps[i + 1] : nullptr;
+            const R1CSTraceStep *nx = step0 + i + 1 < steps.size() ? &steps[step0 + i + 1] : nullptr;
             const uint32_t w = st.instruction, op = w & 0x7F, f3 = (w >> 12) & 7, f7 = (w >> 25) & 0x7F, rd = (w >> 7) & 31;
             const bool load = op == 0x03, store = op == 0x23, branch = op == 0x63;
             if (load) set(Load);
@@ -236,16 +244,15 @@ struct CycleColumns {
         for (auto &th : pool) th.join();
     }
 
-    // the 43 descriptors of zg_fr_rows_from_columns, in R1CSInputIndex order; `first`: the descriptors of rows [first, ...) — a slice of
-    // the cycles is a matrix of its own (every column is a row-indexed array and a ZG_COL_MUL column names columns of the same row)
-    std::vector<zg_col_t> descriptors(size_t first = 0) const {
+    // the 43 descriptors of zg_fr_rows_from_columns, in R1CSInputIndex order
+    std::vector<zg_col_t> descriptors() const {
         std::vector<zg_col_t> d(NUM_INPUTS, zg_col_t{ZG_COL_ZERO, 0, 0, nullptr, nullptr});  // NextIsVirtual, NextIsFirstInSequence stay zero (:1160-1171)
-        for (int k = 0; k < 12; k++) d[U64_INPUTS[k]] = zg_col_t{ZG_COL_U64, 0, 0, u64[k] + first, nullptr};
-        d[8] = zg_col_t{ZG_COL_I64, 0, 0, imm + first, nullptr};
-        for (int k = 0; k < 2; k++) d[WIDE_INPUTS[k]] = zg_col_t{ZG_COL_I128, 0, 0, wide[k] + 2 * first, nullptr};
+        for (int k = 0; k < 12; k++) d[U64_INPUTS[k]] = zg_col_t{ZG_COL_U64, 0, 0, u64[k], nullptr};
+        d[8] = zg_col_t{ZG_COL_I64, 0, 0, imm, nullptr};
+        for (int k = 0; k < 2; k++) d[WIDE_INPUTS[k]] = zg_col_t{ZG_COL_I128, 0, 0, wide[k], nullptr};
         d[2] = zg_col_t{ZG_COL_MUL, 0, 1, nullptr, nullptr};  // Product = LeftInstructionInput * RightInstructionInput (:1120-1122)
-        d[16] = zg_col_t{ZG_COL_MUL, 2, 25, wide[2] + 2 * first, nullptr};  // RightLookupOperand = Product * FlagMultiplyOperands + the other rows' value
-        for (uint32_t b = 0; b < 24; b++) d[BIT_INPUTS[b]] = zg_col_t{ZG_COL_BIT, b, 4, word + first, nullptr};
+        d[16] = zg_col_t{ZG_COL_MUL, 2, 25, wide[2], nullptr};  // RightLookupOperand = Product * FlagMultiplyOperands + the other rows' value
+        for (uint32_t b = 0; b < 24; b++) d[BIT_INPUTS[b]] = zg_col_t{ZG_COL_BIT, b, 4, word, nullptr};
         return d;
     }
     size_t bytesPerCycle() const { return BYTES_PER_CYCLE; }
@@ -259,6 +266,28 @@ private:
         if (!keep.p) { keep.p = slab_; keep.bytes = cap_; }
         else zg_host_free(slab_);
         slab_ = nullptr;
+    }
+    void allocate(size_t bytes) {  // the thread's spare slab when it is large enough, a new pinned one otherwise
+        release();
+        bytes_ = bytes;
+        Slab &keep = spare();
+        if (keep.p && keep.bytes >= bytes_) {
+            slab_ = keep.p;
+            cap_ = keep.bytes;
+            keep.p = nullptr;
+        } else {
+            if (keep.p) { zg_host_free(keep.p); keep.p = nullptr; }
+            check(zg_host_alloc(bytes_, &slab_), "zg_host_alloc");
+            cap_ = bytes_;
+        }
+    }
+    void layout(char *p, size_t cycles) {  // the column pointers of `cycles` rows inside the region at p
+        n = cycles;
+        const size_t pad = (n + 31) & ~size_t(31);
+        for (auto &c : u64) { c = reinterpret_cast<uint64_t *>(p); p += pad * 8; }
+        imm = reinterpret_cast<int64_t *>(p); p += pad * 8;
+        for (auto &c : wide) { c = reinterpret_cast<uint64_t *>(p); p += pad * 16; }
+        word = reinterpret_cast<uint32_t *>(p);
     }
     void *slab_ = nullptr;
     size_t bytes_ = 0, cap_ = 0;
@@ -278,15 +307,17 @@ public:
         return m;
     }
     // trace -> matrix. A long trace is cut into slices of cycles: while slice s crosses PCIe and is widened (this thread, inside
-    // zg_fr_rows_from_columns), the host threads decode slice s + 1 — the decode (3.8 ms at 2^20 cycles on 8 threads) hides behind the
-    // 164 MB copy (3.3 ms) instead of preceding it. ZOLT_WITNESS_SLICES overrides the count (1: decode everything, then one call).
+    // zg_fr_rows_from_columns), the host threads decode slice s + 1 — the decode (2.3 ms at 2^20 cycles on 16 threads) hides behind the
+    // 164 MB of copies (3.0 ms) instead of preceding them; every slice has its columns side by side in the slab and crosses as one copy.
+    // 2^20 cycles: 7.7 ms decode-then-upload -> 4.8 ms (profiles/r5i_*). ZOLT_WITNESS_SLICES overrides the count (1: one call).
     static std::shared_ptr<CycleWitnessMatrix> fromTrace(const std::vector<R1CSTraceStep> &steps) {
         const size_t n = steps.size();
-        size_t slices = n >= (size_t(1) << 18) ? 4 : 1;
+        size_t slices = n >= (size_t(1) << 18) ? 8 : 1;
         if (const char *e = std::getenv("ZOLT_WITNESS_SLICES")) slices = std::max(1, atoi(e));
         const size_t per = ((n + slices - 1) / slices + 63) & ~size_t(63);  // slices start on 64-row boundaries: 512-byte aligned in every column
         if (slices <= 1 || per >= n) return fromColumns(CycleColumns::fromTrace(steps));
-        CycleColumns c(n, false);
+        CycleColumns slab(0, false);
+        std::vector<CycleColumns> part = CycleColumns::sliced(slab, n, per);
         auto m = std::make_shared<CycleWitnessMatrix>();
         m->num_cycles = n;
         m->d_.alloc(n * CycleColumns::NUM_INPUTS * 32);
@@ -298,13 +329,13 @@ public:
         std::vector<size_t> done(n_slices, 0);  // threads finished with slice s (under mu)
         bool failed = false;
         std::vector<std::thread> pool;
-        struct Join { std::vector<std::thread> &p; ~Join() { for (auto &t : p) if (t.joinable()) t.join(); } } join{pool};  // also on an exception below: the threads read c and steps
+        struct Join { std::vector<std::thread> &p; ~Join() { for (auto &t : p) if (t.joinable()) t.join(); } } join{pool};  // also on an exception below: the threads write the slab and read steps
         for (size_t t = 0; t < T; t++)
             pool.emplace_back([&, t] {
                 for (size_t sl = 0; sl < n_slices; sl++) {
                     const size_t a = sl * per, b = std::min(n, a + per), share = (b - a + T - 1) / T, i0 = std::min(b, a + t * share), i1 = std::min(b, i0 + share);
                     bool ok = true;
-                    try { if (i0 < i1) c.decodeRange(steps, i0, i1); } catch (...) { ok = false; }
+                    try { if (i0 < i1) part[sl].decodeRange(steps, i0 - a, i1 - a, a); } catch (...) { ok = false; }
                     bool last;
                     { std::lock_guard<std::mutex> lk(mu); if (!ok) failed = true; last = ++done[sl] == T || !ok; }
                     if (last) cv.notify_one();
@@ -318,7 +349,7 @@ public:
                 cv.wait(lk, [&] { return done[sl] == T || failed; });
                 if (failed) throw std::runtime_error("CycleWitnessMatrix::fromTrace: a decoding thread failed");
             }
-            const auto d = c.descriptors(a);
+            const auto d = part[sl].descriptors();
             check(zg_fr_rows_from_columns(d.data(), d.size(), b - a, m->d_.u64() + a * CycleColumns::NUM_INPUTS * 4), "zg_fr_rows_from_columns");
         }
         return m;
