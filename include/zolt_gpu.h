@@ -76,7 +76,7 @@ extern "C" {
  *             compile with -DZG_NO_PROTOCOL_SESSIONS to leave them out of the binding; zg_abi_features() reports whether the loaded
  *             library carries them. */
 #define ZG_ABI_MAJOR 1
-#define ZG_ABI_MINOR 7
+#define ZG_ABI_MINOR 8
 #define ZG_FEATURE_PROTOCOL_SESSIONS 1u /* zg_rrw_* and zg_rwc_* are exported */
 #define ZG_FEATURE_RCCL 2u              /* the several-GPU entry points can exchange partials over RCCL */
 #define ZG_FEATURE_COLUMN_INGEST 4u     /* zg_fr_rows_from_columns[_dev] */
@@ -430,6 +430,9 @@ ZG_API int zg_sumcheck_close(zg_sc_t s);
  * in one pass over the table; s(1) = claim - s(0) and s(3) = s(0) - 3 s(1) + 3 s(2) are host scalar code, the fold of the round
  * (RaPolynomial.bind, :162-174) is zg_sumcheck_bind. */
 ZG_API int zg_sumcheck_raf_round(zg_sc_t s, const uint64_t base[4], uint64_t current_power, uint64_t s0[4], uint64_t s2[4]);
+/* RafEvaluationProver.computeInitialClaim (src/zkvm/ram/raf_checking.zig:312-321): claim = sum_k t[k] * F.fromU64(base + step * k) over the
+ * session's current table (base = start_address, step = 8 for UnmapPolynomial :207-209); base + step * (len - 1) must fit 64 bits. */
+ZG_API int zg_sumcheck_raf_claim(zg_sc_t s, uint64_t base, uint64_t step, uint64_t claim[4]);
 /* LassoProver's eq_evals path on ONE session (src/zkvm/lasso/prover.zig:262-453): open the session with layout ZG_SC_HIGH_HALF over
  * the padded eq_evals (:153-171); the log_K address rounds use the two calls below, the log_T cycle rounds are the session's
  * ordinary round_sums / bind (:313-340,411-441). d_idx128: the u128 lookup indices in DEVICE memory (two little-endian u64 words

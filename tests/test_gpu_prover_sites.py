@@ -75,6 +75,30 @@ def test_raf_cubic_rounds(env, log_k):
     prover.deinit()
 
 
+@pytest.mark.parametrize("log_k", [0, 1, 7, 13, 16])
+def test_raf_initial_claim_on_the_device(env, log_k):
+    """RafEvaluationProver.computeInitialClaim (src/zkvm/ram/raf_checking.zig:312-321): sum_k ra(k) * F.fromU64(start + 8 k), one pass over
+    the resident table, against exact integers; the prover built without a claim starts from it, and its first round polynomial satisfies
+    s(0) + s(1) = claim with s(0) from the oracle."""
+    api, lib, ob = env
+    K = 1 << log_k
+    ra = _rand(ob, 3150 + log_k, K)
+    for start in (0x7FFF8000, 0, (1 << 64) - 8 * K):
+        want = sum(U.fr_to_int(ra[k]) * (start + 8 * k) for k in range(K)) % api.R_MOD
+        prover = api.RafEvaluationProver(ra, start, log_k)
+        assert U.fr_to_int(prover.current_claim) == want, (log_k, start)
+        assert np.array_equal(prover.computeInitialClaim(), api.fr_from_int(want))
+        if log_k >= 1 and start < (1 << 63):
+            got = prover.computeRoundPolynomialCubic()
+            assert np.array_equal(got, ob.raf_round_cubic(ra, start, np.zeros((0, 4), dtype=np.uint64), log_k, api.fr_from_int(want)))
+        prover.deinit()
+    if K > 1:  # start + 8 (K - 1) = 2^64: the reference's u64 sum (UnmapPolynomial.evaluateAtIndex) would overflow
+        s = lib.SumcheckSession.open(ra, lib.SC_LOW_PAIR)
+        with pytest.raises(lib.ZgError):
+            s.raf_claim((1 << 64) - 8 * K + 8, 8)
+        s.close()
+
+
 def test_raf_round_rejects_overflow_and_wrong_layout(env):
     api, lib, ob = env
     s = lib.SumcheckSession.open(_rand(ob, 1, 16), lib.SC_HIGH_HALF)

@@ -267,12 +267,10 @@ static Timeline prove_once(const ProveCase &pc, bool emit) {
             if (k < K) ra[k] = ra[k].add(eq[j]);
         }
     }
-    Fr claim2 = Fr::zero();
-    for (size_t k = 0; k < K; k++)
-        if (!ra[k].isZero()) claim2 = claim2.add(ra[k].mul(Fr::fromU64(pc.start_address + 8 * k)));
     tl.lap("stage 2: RaPolynomial.fromTrace (eq table on the device, per-slot sums on the host)", "kernels+d2h+host");
     {
-        RafEvaluationProver raf(ra, pc.start_address, claim2);
+        RafEvaluationProver raf(ra, pc.start_address);  // the claim = computeInitialClaim(): sum_k ra(k) * unmap(k) over the resident table
+        const Fr claim2 = raf.current_claim;
         std::vector<Fr> ch2;
         if (emit) std::printf("S 2\n");
         for (size_t k = 0; k < pc.log_k; k++) {
@@ -286,7 +284,7 @@ static Timeline prove_once(const ProveCase &pc, bool emit) {
         line(emit, "H", ch2);
         line(emit, "C", {claim2, raf.getFinalClaim()});
     }
-    tl.lap("stage 2: RAF cubic rounds (log K)", "h2d+kernels+host");
+    tl.lap("stage 2: RAF initial claim + cubic rounds (log K)", "h2d+kernels+host");
     // ---- stage 3: Lasso (prover.zig:562-700)
     (void)tr.challengeScalar("lasso_gamma");
     std::vector<Fr> r_red(pc.log_t);

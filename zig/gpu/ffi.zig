@@ -35,7 +35,7 @@ pub const OP_INV: c_int = 5;
 pub const OP_FROM_MONT: c_int = 6;
 pub const OP_TO_MONT: c_int = 7;
 pub const ABI_MAJOR: u32 = 1;
-pub const ABI_MINOR: u32 = 7;
+pub const ABI_MINOR: u32 = 8;
 pub const FEATURE_PROTOCOL_SESSIONS: u32 = 1;
 pub const FEATURE_RCCL: u32 = 2;
 pub const FEATURE_COLUMN_INGEST: u32 = 4;
@@ -137,6 +137,7 @@ pub extern fn zg_sumcheck_round_sums_dev(s: Session, d_out8: ?[*]u64) c_int;
 pub extern fn zg_sumcheck_read_dev(s: Session, d_out_table: ?[*]u64) c_int;
 pub extern fn zg_sumcheck_close(s: Session) c_int;
 pub extern fn zg_sumcheck_raf_round(s: Session, base: *const [4]u64, current_power: u64, s0: *[4]u64, s2: *[4]u64) c_int;
+pub extern fn zg_sumcheck_raf_claim(s: Session, base: u64, step: u64, claim: *[4]u64) c_int;
 pub extern fn zg_sumcheck_bit_round(s: Session, d_idx128: ?[*]const u64, n_idx: usize, bit: c_uint, sum0: *[4]u64, sum1: *[4]u64) c_int;
 pub extern fn zg_sumcheck_bit_bind(s: Session, d_idx128: ?[*]const u64, n_idx: usize, bit: c_uint, r: *const [4]u64, claim: *[4]u64) c_int;
 pub extern fn zg_fr_bit_split_sums(vals: ?[*]const u64, idx128: ?[*]const u64, n: usize, bit: c_uint, sum0: *[4]u64, sum1: *[4]u64) c_int;

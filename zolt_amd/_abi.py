@@ -19,7 +19,7 @@ ZG_OP_INV = 5
 ZG_OP_FROM_MONT = 6
 ZG_OP_TO_MONT = 7
 ZG_ABI_MAJOR = 1
-ZG_ABI_MINOR = 7
+ZG_ABI_MINOR = 8
 ZG_FEATURE_PROTOCOL_SESSIONS = 1
 ZG_FEATURE_RCCL = 2
 ZG_FEATURE_COLUMN_INGEST = 4
@@ -136,6 +136,7 @@ PROTOS = {
     "zg_sumcheck_read_dev": (c_int, [c_void_p, c_void_p]),  # s, d_out_table
     "zg_sumcheck_close": (c_int, [c_void_p]),  # s
     "zg_sumcheck_raf_round": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_void_p]),  # s, base, current_power, s0, s2
+    "zg_sumcheck_raf_claim": (c_int, [c_void_p, c_uint64, c_uint64, c_void_p]),  # s, base, step, claim
     "zg_sumcheck_bit_round": (c_int, [c_void_p, c_void_p, c_size_t, c_uint, c_void_p, c_void_p]),  # s, d_idx128, n_idx, bit, sum0, sum1
     "zg_sumcheck_bit_bind": (c_int, [c_void_p, c_void_p, c_size_t, c_uint, c_void_p, c_void_p]),  # s, d_idx128, n_idx, bit, r, claim
     "zg_fr_bit_split_sums": (c_int, [c_void_p, c_void_p, c_size_t, c_uint, c_void_p, c_void_p]),  # vals, idx128, n, bit, sum0, sum1

@@ -183,15 +183,20 @@ class RafEvaluationProver:
     cubic round polynomial's two sums are one kernel pass (zg_sumcheck_raf_round), the bind is the session's fold; the handful of
     scalar operations around them (base contribution, s(1), s(3), the Lagrange update of the claim) are host code as in the reference."""
 
-    def __init__(self, ra_evals, start_address, log_k, initial_claim):
+    def __init__(self, ra_evals, start_address, log_k, initial_claim=None):
+        """initial_claim None: the claim is computeInitialClaim() of the table (what prover.zig's Stage 2 passes in)"""
         ra = np.ascontiguousarray(ra_evals, dtype=np.uint64).reshape(-1, 4)
         assert ra.shape[0] == 1 << log_k
         self.sess = lib.SumcheckSession.open(ra, lib.SC_LOW_PAIR)
         self.start_address, self.log_k = int(start_address), log_k
-        self.current_claim = np.array(initial_claim, dtype=np.uint64)
+        self.current_claim = self.computeInitialClaim() if initial_claim is None else np.array(initial_claim, dtype=np.uint64)
         self.bound_values = []
         self.round = 0
         self._final = ra[0].copy() if log_k == 0 else None
+
+    def computeInitialClaim(self):
+        """sum_k ra(k) * unmap(k) (:312-321), one pass over the resident table; only meaningful before the first bind"""
+        return self.sess.raf_claim(self.start_address, 8)
 
     def computeRoundPolynomialCubic(self):
         """-> (4,4): s(0), s(1), s(2), s(3)   (:335-410)"""

@@ -976,6 +976,18 @@ __global__ void __launch_bounds__(256) raf_round_kernel(const uint64_t *t, size_
     finish_round(g0, g1, sh, partials, sums, counter, flag, seq, ScRunArg{nullptr, 0, 0, 0});  // the round ends inside this launch
 }
 
+// RafEvaluationProver.computeInitialClaim (src/zkvm/ram/raf_checking.zig:312-321): sum_k ra(k) * F.fromU64(start_address + 8 k) over the
+// table the session holds (base + step * k < 2^64 for every k: checked by the host) — the pair is (claim, 0)
+__global__ void __launch_bounds__(256) raf_claim_kernel(const uint64_t *t, size_t n, uint64_t base, uint64_t step, uint64_t *partials, uint64_t *sums,
+                                                        uint32_t *counter, uint64_t *flag, uint64_t seq) {
+    __shared__ u32 sh[SC_RED_WORDS];
+    Acc9 g0 = acc9_zero(), g1 = acc9_zero();
+    size_t stride = (size_t)gridDim.x * 256;
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += stride)
+        acc9_add(g0, fr_mul29v(fe_load<FrParams>(t + 4 * k), fr_from_u64_29(base + step * (uint64_t)k)));
+    finish_round(g0, g1, sh, partials, sums, counter, flag, seq, ScRunArg{nullptr, 0, 0, 0});
+}
+
 // LassoProver.computeAddressRoundPoly's two sums (src/zkvm/lasso/prover.zig:283-293): the eq values split by bit `bit` of the
 // u128 lookup index (two little-endian u64 words per entry)
 // `sums` == nullptr: the block pairs stay in `partials` (finished by sc_finish_kernel); otherwise the round ends inside this launch
@@ -2994,6 +3006,33 @@ int zg_sumcheck_raf_round(zg_sc_t s, const uint64_t base[4], uint64_t current_po
         s0[i] = h[i];
         s2[i] = h[4 + i];
     }
+    return ZG_OK;
+}
+
+int zg_sumcheck_raf_claim(zg_sc_t s, uint64_t base, uint64_t step, uint64_t claim[4]) {
+    ZG_INIT();
+    if (!s || !claim) {
+        set_error("zg_sumcheck_raf_claim: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    DeviceGuard dg(s->device);
+    std::lock_guard<std::mutex> lk(s->mu);
+    // base + step * k is a u64 in the reference (UnmapPolynomial.evaluateAtIndex, :207-209): it must not wrap for any k < len
+    const unsigned __int128 top = (unsigned __int128)base + (unsigned __int128)step * (s->len ? s->len - 1 : 0);
+    if ((top >> 64) != 0) {
+        set_error("zg_sumcheck_raf_claim: base + step * (len - 1) overflows 64 bits");
+        return ZG_ERR_INVALID;
+    }
+    unsigned nb = sc_blocks(s->len);
+    uint32_t *counter = reinterpret_cast<uint32_t *>(s->d_partials + 8 * (size_t)SC_MAX_BLOCKS);
+    s->sums_valid = false;  // the mailbox now carries (claim, 0)
+    s->bit_valid = false;
+    s->seq++;
+    hipLaunchKernelGGL(raf_claim_kernel, dim3(nb), dim3(256), 0, s->st, s->buf[s->cur], s->len, base, step, s->d_partials, s->h_pin, counter, s->h_pin + 12,
+                       s->seq);
+    uint64_t h[8];
+    ZG_TRY(sc_wait_mailbox(s, h));
+    for (int i = 0; i < 4; i++) claim[i] = h[i];
     return ZG_OK;
 }
 

@@ -1283,11 +1283,21 @@ class RafEvaluationProver {
 public:
     Fr current_claim;
     RafEvaluationProver(const std::vector<Fr> &ra_evals, uint64_t start_address, const Fr &initial_claim)
-        : current_claim(initial_claim), base_(Fr::fromU64(start_address)) {
+        : current_claim(initial_claim), base_(Fr::fromU64(start_address)), start_(start_address) {
         check(zg_sumcheck_open(reinterpret_cast<const uint64_t *>(ra_evals.data()), ra_evals.size(), ZG_SC_LOW_PAIR, &s_), "zg_sumcheck_open");
+    }
+    // the claim is computeInitialClaim() of the table (what prover.zig's Stage 2 passes in, :312-321)
+    RafEvaluationProver(const std::vector<Fr> &ra_evals, uint64_t start_address) : current_claim(Fr::zero()), base_(Fr::fromU64(start_address)), start_(start_address) {
+        check(zg_sumcheck_open(reinterpret_cast<const uint64_t *>(ra_evals.data()), ra_evals.size(), ZG_SC_LOW_PAIR, &s_), "zg_sumcheck_open");
+        current_claim = computeInitialClaim();
     }
     ~RafEvaluationProver() { zg_sumcheck_close(s_); }
     RafEvaluationProver(const RafEvaluationProver &) = delete;
+    Fr computeInitialClaim() {  // sum_k ra(k) * F.fromU64(start + 8 k), one pass over the resident table (before the first bind)
+        Fr c;
+        check(zg_sumcheck_raf_claim(s_, start_, 8, c.limbs), "zg_sumcheck_raf_claim");
+        return c;
+    }
     std::array<Fr, 4> computeRoundPolynomialCubic() {  // :335-410: s(0), s(2) in one pass on the device
         Fr s0, s2;
         check(zg_sumcheck_raf_round(s_, base_.limbs, power_, s0.limbs, s2.limbs), "zg_sumcheck_raf_round");
@@ -1309,7 +1319,7 @@ public:
 private:
     zg_sc_t s_ = nullptr;
     Fr base_;
-    uint64_t power_ = 8;
+    uint64_t start_ = 0, power_ = 8;
 };
 
 // SumcheckInstance / BatchedSumcheckProver / generateBatchedProof (src/zkvm/batched_sumcheck.zig:34-430)

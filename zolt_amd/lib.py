@@ -880,6 +880,12 @@ class SumcheckSession:
         _chk(_lib.zg_sumcheck_raf_round(self._h, _h(_c(base)), C.c_uint64(current_power), _h(s0), _h(s2)), "zg_sumcheck_raf_round")
         return s0, s2
 
+    def raf_claim(self, base, step=8):
+        """sum_k t[k] * F.fromU64(base + step * k) over the current table: RafEvaluationProver.computeInitialClaim (zg_sumcheck_raf_claim)"""
+        out = np.empty(4, dtype=np.uint64)
+        _chk(_lib.zg_sumcheck_raf_claim(self._h, C.c_uint64(base), C.c_uint64(step), _h(out)), "zg_sumcheck_raf_claim")
+        return out
+
     def bit_round(self, d_idx128, n_idx, bit):
         """LassoProver.computeAddressRoundPoly's sum_0 / sum_1 over the session's first n_idx entries (zg_sumcheck_bit_round)"""
         s0 = np.empty(4, dtype=np.uint64)
