@@ -960,6 +960,15 @@ def extra_measurements(lib, api, torch, dev, stream, args, srs_xy=None):
             extra["prove_path"] = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])["prove_path"]
         except Exception as e:  # noqa: BLE001
             extra["prove_path"] = {"error": str(e)}
+        try:  # the same proof with a key planned for ONE use (zg_msm_config.expected_uses = 1: no table of multiples) — what a single
+            # `zolt prove` run, which builds its mock SRS in-process, should ask for: three commits and an open are below the break-even
+            out = subprocess.run([exe, "synth", "20", "2", "1"], capture_output=True, text=True, timeout=600)
+            one = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])["prove_path"]
+            extra["prove_path_single_use_key"] = {k: one[k] for k in ("key_expected_uses", "total_ms", "total_ms_without_proving_key", "top3")}
+            extra["prove_path_single_use_key"]["steps_ms"] = {st["call"].split(":")[0].split(" (")[0]: st["ms"] for st in one["steps"]
+                                                              if any(w in st["call"] for w in ("proving key", "commitB", "commitM", "commitR", "HyperKZG.open"))}
+        except Exception as e:  # noqa: BLE001
+            extra["prove_path_single_use_key"] = {"error": str(e)}
     return extra
 
 

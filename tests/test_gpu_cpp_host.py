@@ -557,6 +557,11 @@ def test_prove_path_composite_regenerates_the_captured_proof_file(golden_dir, tm
         f.write(f"{len(code)}\n" + code.hex() + "\n")
     res = subprocess.run([exe, "file", str(path), "1"], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    # a key planned for one use (no table of multiples: zg_msm_config.expected_uses = 1) proves the same bytes
+    res1 = subprocess.run([exe, "file", str(path), "1", "1"], capture_output=True, text=True, timeout=600)
+    assert res1.returncode == 0, res1.stdout[-2000:] + res1.stderr[-2000:]
+    records = lambda out: [l for l in out.splitlines() if l[:2] in ("K ", "S ", "P ", "H ", "C ")]
+    assert records(res1.stdout) == records(res.stdout) and len(records(res.stdout)) > 50
     stages, cur, comm = [], None, {}
     to_int = lambda words: ob.fr_to_int(np.array([int(x, 16) for x in words], dtype=np.uint64))
     for line in res.stdout.splitlines():

@@ -159,13 +159,20 @@ static std::vector<Fr> constraint_maps() {
     return m;
 }
 
+// 0: the key's handle is planned as an SRS that lives on (table of multiples built with the key); k > 0: planned for k MSMs — a key that
+// serves one proof (`zolt prove` builds its mock SRS in-process, src/main.zig:271-696) does three commits and an open, fewer MSMs than the
+// table's break-even (bench.py config.breakeven_msms), so the table-less plan is the faster whole
+static int key_uses = 0, key_levels = 0;  // key_levels: zg_msm_config.precompute_levels (0 = the plan picks)
+
 // one proof; `emit`: print the stage records (file mode)
 static Timeline prove_once(const ProveCase &pc, bool emit) {
     Timeline tl;
     const size_t T = size_t(1) << pc.log_t;
     tl.start();
     // ---- proving key: HyperKZG.setup (mock SRS: tau^i * G by the fixed-base kernel), uploaded with its table of multiples
-    HyperKZG::SetupParams pk = HyperKZG::setup(pc.srs_size, false);  // the prover commits and opens: the points never come back to the host
+    // the prover commits and opens: the points never come back to the host. key_uses > 0: the key is planned for that many MSMs (no table)
+    const zg_msm_config key_cfg{0, key_levels, key_uses};
+    HyperKZG::SetupParams pk = HyperKZG::setup(pc.srs_size, false, key_uses > 0 || key_levels > 0 ? &key_cfg : nullptr);
     tl.lap("proving key: HyperKZG.setup on the device (powers of tau, fixed-base batch, table of multiples)", "once per key");
     // ---- the three commitments, from machine words (zg_msm_g1_u64)
     std::vector<uint64_t> bc(pc.bytecode.size() < 2 ? 2 : ceil_pow2(pc.bytecode.size()), 0), mem(pc.accesses.size() < 2 ? 2 : ceil_pow2(pc.accesses.size()), 0),
@@ -353,9 +360,11 @@ static Timeline prove_once(const ProveCase &pc, bool emit) {
 }
 
 int main(int argc, char **argv) {
-    if (argc < 3) { std::fprintf(stderr, "usage: bench_prove_path synth <log_t> [reps] | file <case> [reps]\n"); return 2; }
+    if (argc < 3) { std::fprintf(stderr, "usage: bench_prove_path synth <log_t> [reps [key_uses [key_table_levels]]] | file <case> [reps [key_uses [key_table_levels]]]\n"); return 2; }
     const bool from_file = !std::strcmp(argv[1], "file");
     const int reps = argc > 3 ? atoi(argv[3]) : 3;
+    key_uses = argc > 4 ? atoi(argv[4]) : 0;
+    key_levels = argc > 5 ? atoi(argv[5]) : 0;
     int rc = 0;
     try {
         auto t_init = clk::now();
@@ -386,9 +395,9 @@ int main(int argc, char **argv) {
         std::vector<size_t> order(ns);
         for (size_t i = 0; i < ns; i++) order[i] = i;
         std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return avg[a] > avg[b]; });
-        std::printf("{\"prove_path\": {\"log_t\": %zu, \"cycles\": %zu, \"memory_accesses\": %zu, \"lookups\": %zu, \"srs_size\": %zu, \"reps\": %d, "
+        std::printf("{\"prove_path\": {\"log_t\": %zu, \"cycles\": %zu, \"memory_accesses\": %zu, \"lookups\": %zu, \"srs_size\": %zu, \"reps\": %d, \"key_expected_uses\": %d, \"key_table_levels\": %d, "
                     "\"library_init_ms\": %.3f, \"total_ms\": %.3f, \"total_ms_without_proving_key\": %.3f, \"first_proof_ms_cold_pools\": %.3f, \"steps\": [",
-                    pc.log_t, pc.trace.size(), pc.accesses.size(), pc.lookup_indices.size(), pc.srs_size, reps, init_ms, total, total_wo_key, total_cold);
+                    pc.log_t, pc.trace.size(), pc.accesses.size(), pc.lookup_indices.size(), pc.srs_size, reps, key_uses, key_levels, init_ms, total, total_wo_key, total_cold);
         for (size_t i = 0; i < ns; i++)
             std::printf("%s{\"call\": \"%s\", \"what\": \"%s\", \"ms\": %.4f, \"ms_cold\": %.4f, \"share\": %.4f}", i ? ", " : "", cold.steps[i].name.c_str(),
                         cold.steps[i].kind.c_str(), avg[i], cold.steps[i].ms, total > 0 ? avg[i] / total : 0.0);

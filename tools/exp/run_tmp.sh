@@ -1,9 +1,12 @@
 mkdir -p gpurun_out
-timeout 900 python3 -m pytest tests/test_gpu_prover_sites.py tests/test_gpu_cpp_host.py -x -q -m gpu 2>&1 | tail -3
-timeout 600 ./tools/bench_prove_path synth 20 3 > gpurun_out/r5j_prove_path.json
-python3 - <<'PY'
-import json
-d=json.load(open('gpurun_out/r5j_prove_path.json'))['prove_path']
-print(d['total_ms'], d['total_ms_without_proving_key'])
-for s in d['steps']: print(round(s['ms'],3), s['call'][:100])
+for lv in 1 2 3 4 5 8 15; do
+timeout 600 ./tools/bench_prove_path synth 20 3 0 $lv > gpurun_out/pp_$lv.json
+python3 - $lv <<'PY'
+import json,sys
+d=json.load(open('gpurun_out/pp_%s.json'%sys.argv[1]))
+if 'error' in d: print(sys.argv[1], d); sys.exit()
+d=d['prove_path']
+st={s['call'][:12]:s['ms'] for s in d['steps']}
+print('levels',sys.argv[1], 'total',d['total_ms'], 'key',round(d['steps'][0]['ms'],2), 'commits',round(sum(s['ms'] for s in d['steps'][2:5]),2), 'open',round(d['steps'][-1]['ms'],2))
 PY
+done

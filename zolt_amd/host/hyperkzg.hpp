@@ -22,13 +22,15 @@ struct HyperKZG {
     // and the MSM handle with its table of multiples are built ON THE DEVICE (zg_hyperkzg_setup); host_points = false leaves
     // powers_of_tau_g1 empty for a prover that only commits and opens (the points are never read on the host then: 64 bytes per power
     // stay off PCIe and out of the struct conversions, 131 -> ~35 ms at 2^20 powers)
-    static SetupParams setup(size_t max_degree, bool host_points = true) {
+    // cfg: the MSM plan of the key's handle — expected_uses = 1..15 skips the table of multiples (a key that serves ONE proof: three
+    // commits and an open are fewer MSMs than the table's break-even, bench.py config.breakeven_msms); nullptr = an SRS that lives on
+    static SetupParams setup(size_t max_degree, bool host_points = true, const zg_msm_config *cfg = nullptr) {
         SetupParams p;
         p.g1 = AffinePoint::generator();
         p.max_degree = max_degree;
         std::vector<uint64_t> xy;
         std::vector<uint8_t> inf;
-        p.device.reset(new DeviceBases(p.g1, Fr::fromU64(0x12345678), max_degree, host_points ? &xy : nullptr, host_points ? &inf : nullptr));
+        p.device.reset(new DeviceBases(p.g1, Fr::fromU64(0x12345678), max_degree, host_points ? &xy : nullptr, host_points ? &inf : nullptr, cfg));
         if (host_points) {
             p.powers_of_tau_g1.reserve(max_degree);
             for (size_t i = 0; i < max_degree; i++) p.powers_of_tau_g1.push_back(unpack_point(&xy[8 * i], inf[i]));

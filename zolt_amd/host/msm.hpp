@@ -66,13 +66,14 @@ public:
         check(zg_g1_bases_upload(xy.data(), inf.data(), n_, cfg, &h_), "zg_g1_bases_upload");
     }
     // HyperKZG.setup's G1 side built on the device (zg_hyperkzg_setup): tau^i * base for i < n; the points come back only when asked for
-    DeviceBases(const AffinePoint &base, const Fr &tau, size_t n, std::vector<uint64_t> *xy_out = nullptr, std::vector<uint8_t> *inf_out = nullptr) : n_(n) {
+    DeviceBases(const AffinePoint &base, const Fr &tau, size_t n, std::vector<uint64_t> *xy_out = nullptr, std::vector<uint8_t> *inf_out = nullptr,
+                const zg_msm_config *cfg = nullptr) : n_(n) {
         uint64_t b[8];
         std::memcpy(b, base.x.limbs, 32);
         std::memcpy(b + 4, base.y.limbs, 32);
         if (xy_out) xy_out->resize(8 * n);
         if (inf_out) inf_out->resize(n);
-        check(zg_hyperkzg_setup(b, tau.limbs, n, nullptr, xy_out ? xy_out->data() : nullptr, inf_out ? inf_out->data() : nullptr, &h_), "zg_hyperkzg_setup");
+        check(zg_hyperkzg_setup(b, tau.limbs, n, cfg, xy_out ? xy_out->data() : nullptr, inf_out ? inf_out->data() : nullptr, &h_), "zg_hyperkzg_setup");
     }
     ~DeviceBases() { zg_g1_bases_free(h_); }
     DeviceBases(const DeviceBases &) = delete;
