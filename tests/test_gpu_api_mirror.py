@@ -139,6 +139,32 @@ def test_hyperkzg_open_long_levels(env, v, srs_n, fuse, monkeypatch):
     params.deinit()
 
 
+@pytest.mark.parametrize("v,srs_n,uses,shared", [(18, 1 << 18, 1, "1"), (18, 1 << 18, 3, "1"), (18, 1 << 17, 1, "1"), (17, 1 << 17, 1, "0"), (19, 1 << 19, 2, "1")])
+def test_hyperkzg_open_on_a_key_without_a_table(env, v, srs_n, uses, shared, monkeypatch):
+    """open() on a handle planned for a few MSMs (zg_msm_config.expected_uses = 1..15: no table of multiples, one bucket set per window):
+    the long levels are sorted and accumulated one by one and reduced TOGETHER (msm_rows_shared_tail: one row / column pass, one msm_final,
+    one window-combine launch for all of them; ZG_MSM_ROWS_SHARED_TAIL=0: a reduction per level) — same quotient commitments and final
+    evaluation as the oracle, and as the batch entry point gives for the same rows."""
+    api, lib, ob = env
+    monkeypatch.setenv("ZG_MSM_ROWS_SHARED_TAIL", shared)
+    gm = ob.g1_gen_multiples(srs_n)
+    inf = np.zeros(srs_n, dtype=np.uint8)
+    inf[5::777] = 1
+    dev = lib.Bases.upload(gm, inf, expected_uses=uses)
+    c, w, levels = dev.plan()
+    assert levels == 1 and w > 1
+    params = api.HyperKZG.SetupParams(gm, inf, dev=dev)
+    ev = _rand(ob, 900 + v, 1 << v)
+    pt = _rand(ob, 950 + v, v)
+    for _ in range(2):  # the second call reuses the rows' buffers
+        quotients, final = api.HyperKZG.open(params, ev, pt, np.zeros(4, dtype=np.uint64))
+        wq, wqi, wfin = ob.hyperkzg_open(gm, inf, ev, pt, np.zeros(4, dtype=np.uint64))
+        assert np.array_equal(final, wfin) and len(quotients) == v
+        for i, (q, qi) in enumerate(quotients):
+            assert qi == wqi[i] and np.array_equal(q, wq[i]), i
+    params.deinit()
+
+
 def test_hyperkzg_open_at_the_bench_size(env):
     """open() of 2^20 evaluations on a 2^20-point SRS — the size bench.py times — quotient by quotient against the oracle
     (the CPU side is ~2^20 points of Pippenger: tens of seconds)."""

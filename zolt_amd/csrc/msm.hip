@@ -131,6 +131,11 @@ struct zg_bases_s {
     uint64_t *d_out = nullptr;  // 16 x u64: result record + flag
     uint64_t *h_out = nullptr;  // pinned mirror
     uint64_t *d_slice_parts = nullptr;  // zg_msm_g1 (host scalars, sliced): one Jacobian partial per slice
+    // rows of a batch on a handle without a table (msm_rows_shared_tail): the bucket sums of every row side by side, the reduction's
+    // bit sums / rows / columns and group results for all of them, sized for rows_cap rows; rows_done: the last set that used them
+    char *d_rows_buckets = nullptr, *d_rows_bits = nullptr, *d_rows_rg = nullptr;
+    size_t rows_cap = 0;
+    hipEvent_t rows_done = nullptr;
     std::mutex mu;
 };
 
@@ -1720,8 +1725,9 @@ static void free_bases(zg_bases_s *b) {
     if (!b) return;
     (void)hipDeviceSynchronize();
     free_bases(b->small);
-    void *ptrs[] = {b->d_table, b->d_inf, b->d_scal, b->d_out, b->d_slice_parts};
+    void *ptrs[] = {b->d_table, b->d_inf, b->d_scal, b->d_out, b->d_slice_parts, b->d_rows_buckets, b->d_rows_bits, b->d_rows_rg};
     for (void *p : ptrs) pool_free(p);
+    if (b->rows_done) (void)hipEventDestroy(b->rows_done);
     for (auto &ln : b->lanes) lane_free(ln);
     lane_free(b->batch_lane);
     for (int i = 0; i < zg_bases_s::NAUX; i++) {
@@ -1962,6 +1968,9 @@ static int msm_enqueue(zg_bases_s *b, size_t off, size_t n, const uint64_t *d_sc
 // Live row lengths of the zero-padded matrix the next launch set sorts (msm_batch_dev_wide_rows sets it around its call; the sort reads
 // it when the set is the whole matrix): see RowOffs.
 static thread_local const RowOffs *t_row_offs = nullptr;
+// Where the next launch set leaves its bucket sums INSTEAD of reducing them (msm_rows_shared_tail sets it around each row): the set ends
+// after its accumulation, the caller reduces the rows' buckets together.
+static thread_local char *t_bucket_sink = nullptr;
 
 // One launch set on workspace `ln` under plan `p`: p.K scalar vectors of n_pts scalars each, stored back to back at
 // d_scalars, all over bases[off, off+n_pts); vector i's record lands at d_rec + i*rec_stride / d_inf_out + i*inf_stride.
@@ -2159,7 +2168,13 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
         const size_t a = j * per, cnt = n_pts - a < per ? n_pts - a : per;
         if (j) prof_end(ZG_PROF_MSM_REDUCE, st);  // the bucket sums of a slice count as reduction
         if (!sort_first) ZG_TRY(sort_range(off + a, cnt, d_scalars + 4 * a, view(j)));
-        ZG_TRY(accumulate_range(cnt, view(j), j == 0 ? ln.d_partial : ln.d_slice_buckets + (j - 1) * (size_t)p.NK * 144));
+        ZG_TRY(accumulate_range(cnt, view(j), j == 0 ? (t_bucket_sink && S == 1 ? t_bucket_sink : ln.d_partial) : ln.d_slice_buckets + (j - 1) * (size_t)p.NK * 144));
+    }
+    if (t_bucket_sink && S == 1) {  // bucket sums only: the reduction belongs to the caller
+        prof_end(ZG_PROF_MSM_REDUCE, st);
+        ZG_HIP(hipGetLastError());
+        ZG_HIP(hipEventRecord(ln.done, st));
+        return ZG_OK;
     }
     if (S > 1)
         hipLaunchKernelGGL(msm_bucket_fold_kernel, dim3(div_up((size_t)p.NK * 4, 256)), dim3(256), 0, st, ln.d_partial, ln.d_slice_buckets, p.NK,
@@ -2506,6 +2521,60 @@ static size_t batch_fuse_limit(const zg_bases_s *b, size_t n, bool wide_ok = fal
     return lim >= 2 ? lim : 0;
 }
 
+// Rows of a batch on a handle WITHOUT a table (G > 1: one bucket set per window) cannot share a sort (K * G * NB buckets leave the coarse
+// counters' LDS), and as launch sets of their own each ends in its own reduction: row / column sums (0.24 ms), bit sums, msm_final and the
+// window combine msm_groups_kernel — (G - 1) * c dependent doublings on one quad of lanes, 0.85 ms — all latency chains. HyperKZG.open's five
+// long levels paid that five times, one after the other (9.1 ms per opening of 2^20 evaluations, 4.3 ms of it in msm_groups_kernel). Here
+// every row is sorted and accumulated as a set of its own, its bucket sums land side by side in ONE array, and the reduction kernels run
+// once over K * G groups (their grids already take a batch): the chains of all rows run beside each other.
+static constexpr size_t ROWS_SHARED_TAIL_MAX = 16;
+static bool rows_shared_tail_ok(const zg_bases_s *b, size_t n) {
+    const MsmPlan &p = b->plan;
+    if (p.G <= 1 || !p.lb || !env_int("ZG_MSM_ROWS_SHARED_TAIL", 1)) return false;
+    size_t S, per;
+    slice_counts(p, n, S, per);
+    return S == 1;
+}
+static int msm_rows_shared_tail(zg_bases_s *b, size_t n, const uint64_t *d_scalars, size_t k, hipStream_t st, uint64_t *d_out9) {
+    const MsmPlan &p = b->plan;
+    const size_t row_bytes = (size_t)p.NK * 144;  // p.K == 1: NK = G * NB
+    size_t per_group = (size_t)p.c * p.PB;
+    if (((size_t)1 << p.lb) + ((size_t)1 << p.hb) + p.c > per_group) per_group = ((size_t)1 << p.lb) + ((size_t)1 << p.hb) + p.c;
+    if (!b->rows_done) ZG_HIP(hipEventCreateWithFlags(&b->rows_done, hipEventDisableTiming));
+    if (b->rows_cap < k) {
+        if (b->rows_cap) ZG_HIP(hipEventSynchronize(b->rows_done));
+        for (char **q : {&b->d_rows_buckets, &b->d_rows_bits, &b->d_rows_rg}) {
+            pool_free(*q);
+            *q = nullptr;
+        }
+        b->rows_cap = 0;
+        ZG_HIP(lane_malloc((void **)&b->d_rows_buckets, k * row_bytes));
+        ZG_HIP(lane_malloc((void **)&b->d_rows_bits, (size_t)p.G * k * per_group * 144));
+        ZG_HIP(lane_malloc((void **)&b->d_rows_rg, (size_t)p.G * k * 128));
+        b->rows_cap = k;
+    } else {
+        ZG_HIP(hipStreamWaitEvent(st, b->rows_done, 0));  // the previous batch may have run on another stream
+    }
+    int rc = ZG_OK;
+    for (size_t i = 0; i < k && rc == ZG_OK; i++) {
+        t_bucket_sink = b->d_rows_buckets + i * row_bytes;
+        rc = msm_enqueue(b, 0, n, d_scalars + 4 * n * i, st, 0, d_out9 + 9 * i, reinterpret_cast<uint8_t *>(d_out9 + 9 * i + 8));
+        t_bucket_sink = nullptr;
+    }
+    if (rc != ZG_OK) return rc;
+    const int GK = p.G * (int)k;
+    char *d_rc = b->d_rows_bits + 144 * (size_t)GK * p.c;  // rows and columns behind the c bit sums of every group (as in msm_enqueue_lane)
+    prof_begin(ZG_PROF_MSM_REDUCE, st);
+    hipLaunchKernelGGL(msm_rowcol_kernel, dim3((1u << p.hb) + (1u << p.lb), GK), dim3(256), 0, st, b->d_rows_buckets, p.NB, p.lb, p.hb, d_rc);
+    hipLaunchKernelGGL(msm_bits2d_kernel, dim3(p.c, GK), dim3(256), 0, st, b->d_rows_buckets, d_rc, p.NB, p.c, p.lb, p.hb, b->d_rows_bits);
+    hipLaunchKernelGGL(msm_final_kernel, dim3(GK), dim3(512), 0, st, b->d_rows_bits, p.c, 1, p.G, b->d_rows_rg, 0, d_out9, reinterpret_cast<uint8_t *>(d_out9 + 8), 9u, 72u);
+    hipLaunchKernelGGL(msm_groups_kernel, dim3((unsigned)k), dim3(4), 0, st, b->d_rows_rg, p.G, p.c, 0, d_out9, reinterpret_cast<uint8_t *>(d_out9 + 8), 9u, 72u);
+    prof_end(ZG_PROF_MSM_REDUCE, st);
+    ZG_HIP(hipGetLastError());
+    ZG_HIP(hipEventRecord(b->rows_done, st));
+    return ZG_OK;
+}
+
 // the handle's two helper streams (+ fork / join events): independent launch sets rotate over the caller's stream and these
 
 // enqueue k scalar vectors (device, back to back) over bases[0, n) on st. mode 0: record i = d_out9[9*i .. 9*i+8] (xy[8], flag
@@ -2520,6 +2589,7 @@ static int msm_batch_enqueue(zg_bases_s *b, size_t n, const uint64_t *d_scalars,
     }
     if (b->small && n <= b->small->n) return msm_batch_enqueue(b->small, n, d_scalars, k, st, d_out9, false, mode);  // narrow-window side table
     size_t lim = batch_fuse_limit(b, n, wide_ok);
+    if (lim == 0 && wide_ok && k >= 2 && k <= ROWS_SHARED_TAIL_MAX && mode == 0 && rows_shared_tail_ok(b, n)) return msm_rows_shared_tail(b, n, d_scalars, k, st, d_out9);
     if (lim == 0 || k < 2) {
         // one launch set per vector, rotating through the handle's workspaces AND through three streams (the caller's
         // plus two forked helpers), so the latency-bound tail of one MSM runs under the accumulation of the next

@@ -222,9 +222,9 @@ class Bases:
         return out, int(inf.value)
 
     @classmethod
-    def hyperkzg_setup(cls, base_xy, tau, n, want_points=True, window_bits=0, precompute_levels=0):
+    def hyperkzg_setup(cls, base_xy, tau, n, want_points=True, window_bits=0, precompute_levels=0, expected_uses=0):
         """HyperKZG.setup's G1 side on the device (zg_hyperkzg_setup): -> (handle, points xy (n, 8) or None, inf (n,) or None)"""
-        cfg = MsmConfig(window_bits, precompute_levels, 0)
+        cfg = MsmConfig(window_bits, precompute_levels, expected_uses)
         xy = np.empty((n, 8), dtype=np.uint64) if want_points else None
         inf = np.zeros(n, dtype=np.uint8) if want_points else None
         h = C.c_void_p()
