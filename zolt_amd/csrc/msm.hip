@@ -1751,24 +1751,28 @@ static void free_bases(zg_bases_s *b) {
 
 static constexpr size_t SIDE_TABLE_POINTS = 16384;
 
+// prebuilt_small: a side-table handle over the first SIDE_TABLE_POINTS bases that the caller built already (zg_hyperkzg_setup builds it
+// while the remaining powers are still being computed); taken over when this handle wants one, freed otherwise.
 static int bases_create(const uint64_t *d_xy, const uint8_t *d_inf_in, size_t n, const zg_msm_config *cfg, hipStream_t st,
-                        zg_bases_t *out) {
+                        zg_bases_t *out, zg_bases_s *prebuilt_small = nullptr) {
     if (n >= (1ull << 27)) {
         set_error("msm: at most 2^27 bases per handle");
+        free_bases(prebuilt_small);
         return ZG_ERR_INVALID;
     }
     zg_bases_s *b = new zg_bases_s();
     b->n = n;
     b->device = current_device();
+    b->small = prebuilt_small;  // from here on free_bases(b) releases it too
     int rc = make_plan(n ? n : 1, cfg, b->plan);
     if (rc != ZG_OK) {
-        delete b;
+        free_bases(b);
         return rc;
     }
     const MsmPlan &p = b->plan;
     if ((uint64_t)p.L * n >= (1ull << 31)) {
         set_error("msm: precompute table too large for 31-bit point references");
-        delete b;
+        free_bases(b);
         return ZG_ERR_INVALID;
     }
     ZG_ALLOC(b->d_table, (size_t)p.L * n * 64);
@@ -1803,6 +1807,22 @@ static int bases_create(const uint64_t *d_xy, const uint8_t *d_inf_in, size_t n,
         free_bases(b);
         return ZG_ERR_NOMEM;
     }
+    // The side table (narrow windows over the first SIDE_TABLE_POINTS bases, for short MSMs) is a handle of its own whose table build is a
+    // latency chain on 64 workgroups (2.5 ms): it is built on a helper stream WHILE the main table's kernel fills the chip, not after it.
+    const bool want_small = (size_t)p.NB * p.G > 4096 && n > SIDE_TABLE_POINTS && env_int("ZG_MSM_SIDE_TABLE", 1);
+    if (b->small && !want_small) {
+        free_bases(b->small);
+        b->small = nullptr;
+    }
+    const bool side_is_lib = st == lib_stream() && lib_side_stream();
+    hipStream_t side = want_small && !b->small ? (side_is_lib ? lib_side_stream() : stream_acquire()) : nullptr;
+    hipEvent_t inputs_ready = nullptr;
+    if (side && (hipEventCreateWithFlags(&inputs_ready, hipEventDisableTiming) != hipSuccess || hipEventRecord(inputs_ready, st) != hipSuccess ||
+                 hipStreamWaitEvent(side, inputs_ready, 0) != hipSuccess)) {  // d_xy / d_inf_in may be the product of work queued on st
+        (void)hipGetLastError();
+        if (!side_is_lib) stream_release(side, b->device);
+        side = nullptr;
+    }
     {
         hipError_t e = hipSuccess;
         if (n) {
@@ -1813,17 +1833,20 @@ static int bases_create(const uint64_t *d_xy, const uint8_t *d_inf_in, size_t n,
                 e = hipGetLastError();
             }
         }
+        int src = ZG_OK;
+        if (want_small && !b->small) {
+            zg_msm_config small_cfg{8, 0, 0};
+            src = bases_create(d_xy, d_inf_in, SIDE_TABLE_POINTS, &small_cfg, side ? side : st, &b->small);  // returns when ITS stream is drained
+        }
         hipError_t e2 = hipStreamSynchronize(st);  // also on failure: nothing of this handle may still be in flight when it is freed
+        if (side && !side_is_lib) stream_release(side, b->device);
+        if (inputs_ready) (void)hipEventDestroy(inputs_ready);
         if (e == hipSuccess) e = e2;
         if (e != hipSuccess) {
             set_error(std::string("msm table build: ") + hipGetErrorString(e));
             free_bases(b);
             return ZG_ERR_HIP;
         }
-    }
-    if ((size_t)p.NB * p.G > 4096 && n > SIDE_TABLE_POINTS && env_int("ZG_MSM_SIDE_TABLE", 1)) {
-        zg_msm_config small_cfg{8, 0, 0};
-        int src = bases_create(d_xy, d_inf_in, SIDE_TABLE_POINTS, &small_cfg, st, &b->small);
         if (src != ZG_OK) {
             free_bases(b);
             return src;
@@ -2918,6 +2941,17 @@ int zg_hyperkzg_setup(const uint64_t base_xy[8], const uint64_t tau[4], size_t n
     Scratch s_base(64), s_rows((size_t)FB_W * 144), s_tab((size_t)n_rows * 64), s_pw(3 * 256 * 32), s_sc(nn * 32), s_out(nn * 64), s_inf(nn);
     if (!s_base.p || !s_rows.p || !s_tab.p || !s_pw.p || !s_sc.p || !s_out.p || !s_inf.p) return ZG_ERR_NOMEM;
     SyncGuard sync(st);
+    hipStream_t side = nullptr;
+    hipEvent_t head_ready = nullptr;
+    zg_bases_s *small = nullptr;
+    struct Cleanup {  // what an early return would leave behind
+        hipEvent_t &ev;
+        zg_bases_s *&small;
+        ~Cleanup() {
+            if (ev) (void)hipEventDestroy(ev);
+            if (small) free_bases(small);
+        }
+    } cleanup{head_ready, small};
     if (n) {
         TauArg ta;
         for (int i = 0; i < 4; i++) {
@@ -2929,14 +2963,35 @@ int zg_hyperkzg_setup(const uint64_t base_xy[8], const uint64_t tau[4], size_t n
         hipLaunchKernelGGL(tau_powers_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, s_pw.as<uint64_t>(), n, s_sc.as<uint64_t>());
         hipLaunchKernelGGL(fb_window_bases_kernel, dim3(1), dim3(4 * FB_W), 0, st, s_base.as<uint64_t>(), s_rows.as<char>());
         hipLaunchKernelGGL(fb_table_rows_kernel, dim3(div_up(n_rows, 256)), dim3(256), 0, st, s_rows.as<char>(), n_rows, s_tab.as<char>());
-        hipLaunchKernelGGL(fb_mul_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, s_tab.as<char>(), s_sc.as<uint64_t>(), n, s_out.as<uint64_t>(),
-                           s_inf.as<uint8_t>());
+        // The handle's side table covers the first SIDE_TABLE_POINTS powers and its build is a 2.5 ms latency chain on 64 workgroups: those
+        // powers are computed first, and the side handle is built on a helper stream while the remaining powers (2.9 ms at 2^20, the whole
+        // chip) are still being multiplied out.
+        const size_t head = n > SIDE_TABLE_POINTS && env_int("ZG_MSM_SIDE_TABLE", 1) ? SIDE_TABLE_POINTS : 0;
+        if (head) {
+            hipLaunchKernelGGL(fb_mul_kernel, dim3(div_up(head, 256)), dim3(256), 0, st, s_tab.as<char>(), s_sc.as<uint64_t>(), head, s_out.as<uint64_t>(),
+                               s_inf.as<uint8_t>());
+            side = lib_side_stream();  // on another hardware queue than st (the library stream) by construction
+            if (side && (hipEventCreateWithFlags(&head_ready, hipEventDisableTiming) != hipSuccess || hipEventRecord(head_ready, st) != hipSuccess ||
+                         hipStreamWaitEvent(side, head_ready, 0) != hipSuccess)) {
+                (void)hipGetLastError();
+                side = nullptr;
+            }
+        }
+        hipLaunchKernelGGL(fb_mul_kernel, dim3(div_up(n - head, 256)), dim3(256), 0, st, s_tab.as<char>(), s_sc.as<uint64_t>() + 4 * head, n - head,
+                           s_out.as<uint64_t>() + 8 * head, s_inf.as<uint8_t>() + head);
         ZG_HIP(hipGetLastError());
+        if (side) {
+            zg_msm_config small_cfg{8, 0, 0};
+            int src = bases_create(s_out.as<uint64_t>(), nullptr, SIDE_TABLE_POINTS, &small_cfg, side, &small);  // returns when the side stream is drained
+            if (src != ZG_OK) return src;
+        }
         if (out_xy) ZG_HIP(hipMemcpyAsync(out_xy, s_out.p, n * 64, hipMemcpyDeviceToHost, st));
         if (out_inf) ZG_HIP(hipMemcpyAsync(out_inf, s_inf.p, n, hipMemcpyDeviceToHost, st));
     }
     // tau^i is never 0 mod r and the base has prime order: no power is the identity, so the handle carries no infinity flags
-    int rc = bases_create(s_out.as<uint64_t>(), nullptr, n, cfg, st, out);  // copies the points into the handle's table
+    zg_bases_s *prebuilt = small;
+    small = nullptr;  // bases_create owns it from the call on, whatever it returns
+    int rc = bases_create(s_out.as<uint64_t>(), nullptr, n, cfg, st, out, prebuilt);  // copies the points into the handle's table
     hipError_t e = hipStreamSynchronize(st);
     sync.dismiss();
     if (rc != ZG_OK) return rc;
