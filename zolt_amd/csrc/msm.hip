@@ -1814,13 +1814,12 @@ static int bases_create(const uint64_t *d_xy, const uint8_t *d_inf_in, size_t n,
         free_bases(b->small);
         b->small = nullptr;
     }
-    const bool side_is_lib = st == lib_stream() && lib_side_stream();
-    hipStream_t side = want_small && !b->small ? (side_is_lib ? lib_side_stream() : stream_acquire()) : nullptr;
+    hipStream_t side = want_small && !b->small ? stream_try_acquire() : nullptr;  // an idle stream or none: never a new one
     hipEvent_t inputs_ready = nullptr;
     if (side && (hipEventCreateWithFlags(&inputs_ready, hipEventDisableTiming) != hipSuccess || hipEventRecord(inputs_ready, st) != hipSuccess ||
                  hipStreamWaitEvent(side, inputs_ready, 0) != hipSuccess)) {  // d_xy / d_inf_in may be the product of work queued on st
         (void)hipGetLastError();
-        if (!side_is_lib) stream_release(side, b->device);
+        stream_release(side, b->device);
         side = nullptr;
     }
     {
@@ -1839,7 +1838,7 @@ static int bases_create(const uint64_t *d_xy, const uint8_t *d_inf_in, size_t n,
             src = bases_create(d_xy, d_inf_in, SIDE_TABLE_POINTS, &small_cfg, side ? side : st, &b->small);  // returns when ITS stream is drained
         }
         hipError_t e2 = hipStreamSynchronize(st);  // also on failure: nothing of this handle may still be in flight when it is freed
-        if (side && !side_is_lib) stream_release(side, b->device);
+        if (side) stream_release(side, b->device);
         if (inputs_ready) (void)hipEventDestroy(inputs_ready);
         if (e == hipSuccess) e = e2;
         if (e != hipSuccess) {
@@ -2970,10 +2969,11 @@ int zg_hyperkzg_setup(const uint64_t base_xy[8], const uint64_t tau[4], size_t n
         if (head) {
             hipLaunchKernelGGL(fb_mul_kernel, dim3(div_up(head, 256)), dim3(256), 0, st, s_tab.as<char>(), s_sc.as<uint64_t>(), head, s_out.as<uint64_t>(),
                                s_inf.as<uint8_t>());
-            side = lib_side_stream();  // on another hardware queue than st (the library stream) by construction
+            side = stream_try_acquire();  // an idle stream or none (never a new one); on the library stream's own hardware queue it runs behind it
             if (side && (hipEventCreateWithFlags(&head_ready, hipEventDisableTiming) != hipSuccess || hipEventRecord(head_ready, st) != hipSuccess ||
                          hipStreamWaitEvent(side, head_ready, 0) != hipSuccess)) {
                 (void)hipGetLastError();
+                stream_release(side, current_device());
                 side = nullptr;
             }
         }
@@ -2983,6 +2983,7 @@ int zg_hyperkzg_setup(const uint64_t base_xy[8], const uint64_t tau[4], size_t n
         if (side) {
             zg_msm_config small_cfg{8, 0, 0};
             int src = bases_create(s_out.as<uint64_t>(), nullptr, SIDE_TABLE_POINTS, &small_cfg, side, &small);  // returns when the side stream is drained
+            stream_release(side, current_device());
             if (src != ZG_OK) return src;
         }
         if (out_xy) ZG_HIP(hipMemcpyAsync(out_xy, s_out.p, n * 64, hipMemcpyDeviceToHost, st));

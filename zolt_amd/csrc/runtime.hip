@@ -20,15 +20,6 @@ static std::atomic<bool> g_inited{false};  // read without the mutex on every en
 static std::atomic<int> g_primary{-1};     // device bound by zg_init / zg_init_devices
 static std::atomic<int> g_ndev{0};         // devices bound (1 after zg_init, n after zg_init_devices(n)); they are 0..n-1 then
 static hipStream_t g_streams[ZG_MAX_DEVICES] = {};  // the library's own stream per device, created on first use
-// ... and its companion, created right behind it: HIP hands its hardware queues out in creation order, so the two sit on DIFFERENT queues
-// and work meant to run beside the library stream's (a handle's side table beside its main table) really does — a stream taken from the
-// free list may share the library stream's queue, and then runs behind it
-static hipStream_t g_side_streams[ZG_MAX_DEVICES] = {};
-static void create_lib_streams(int d) {  // g_mu held (or single-threaded init)
-    if (!g_streams[d] && hipStreamCreateWithFlags(&g_streams[d], hipStreamNonBlocking) != hipSuccess) g_streams[d] = nullptr;
-    if (g_streams[d] && !g_side_streams[d] && hipStreamCreateWithFlags(&g_side_streams[d], hipStreamNonBlocking) != hipSuccess) g_side_streams[d] = nullptr;
-    (void)hipGetLastError();
-}
 
 void set_error(const std::string &msg) { t_err = msg; }
 static thread_local int t_dev_override = -1;
@@ -46,15 +37,8 @@ hipStream_t lib_stream() {
     int d = current_device();
     if (d < 0 || d >= ZG_MAX_DEVICES) return nullptr;
     std::lock_guard<std::mutex> lk(g_mu);
-    if (!g_streams[d]) create_lib_streams(d);
+    if (!g_streams[d] && hipStreamCreateWithFlags(&g_streams[d], hipStreamNonBlocking) != hipSuccess) g_streams[d] = nullptr;
     return g_streams[d];
-}
-hipStream_t lib_side_stream() {
-    int d = current_device();
-    if (d < 0 || d >= ZG_MAX_DEVICES) return nullptr;
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (!g_streams[d]) create_lib_streams(d);
-    return g_side_streams[d];
 }
 
 // Streams for sumcheck sessions: hipStreamCreate + hipStreamDestroy cost ~3 ms on this stack, a session open must not pay that.
@@ -74,6 +58,18 @@ hipStream_t stream_acquire() {
     }
     hipStream_t st = nullptr;
     if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    return st;
+}
+// An idle stream if the free list holds one, nullptr otherwise — for work that MAY run beside the caller's but must not create a stream:
+// HIP hands its hardware queues out in creation order, and a stream created here would move every stream the caller creates afterwards
+// to another queue (bench.py's three MSM streams lost 12 % when the library created one more stream ahead of them).
+hipStream_t stream_try_acquire() {
+    int d = current_device();
+    if (d < 0 || d >= ZG_MAX_DEVICES) return nullptr;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_idle_streams[d].empty()) return nullptr;
+    hipStream_t st = g_idle_streams[d].back();
+    g_idle_streams[d].pop_back();
     return st;
 }
 void stream_release(hipStream_t st, int device) {
@@ -149,11 +145,7 @@ static int do_init(int device, int ndev) {
         set_error("zg_init: device ordinal beyond ZG_MAX_DEVICES");
         return ZG_ERR_INVALID;
     }
-    create_lib_streams(cur);
-    if (!g_streams[cur]) {
-        set_error("zg_init: hipStreamCreate failed");
-        return ZG_ERR_HIP;
-    }
+    ZG_HIP(hipStreamCreateWithFlags(&g_streams[cur], hipStreamNonBlocking));
     g_primary = cur;
     g_ndev = ndev;
     g_inited = true;
@@ -438,11 +430,6 @@ void zg_shutdown(void) {
         (void)hipStreamSynchronize(g_streams[d]);
         (void)hipStreamDestroy(g_streams[d]);
         g_streams[d] = nullptr;
-        if (g_side_streams[d]) {
-            (void)hipStreamSynchronize(g_side_streams[d]);
-            (void)hipStreamDestroy(g_side_streams[d]);
-            g_side_streams[d] = nullptr;
-        }
     }
     for (int d = 0; d < ZG_MAX_DEVICES; d++) {
         for (hipStream_t st : g_idle_streams[d]) {
