@@ -1,10 +1,12 @@
 mkdir -p gpurun_out
-timeout 1200 python3 bench.py > gpurun_out/r5l_bench.json 2> gpurun_out/r5l_bench.err
-python3 - <<'PY'
-import json
-d=json.loads(open('gpurun_out/r5l_bench.json').read().strip().splitlines()[-1])
-e=d['extra']
-print(d['value'], d['ms_per_step'], e['single_process_c_abi']['none']['pipelined']['msm_per_s'], e['msm_2^22_single_gpu']['value'], d['config']['table_build_ms'])
-print('prove_path', e['prove_path'].get('total_ms'), e['prove_path'].get('total_ms_without_proving_key'), e['prove_path']['steps'][0]['ms'])
-print('single use', e['prove_path_single_use_key']['total_ms'], e['prove_path_single_use_key']['steps_ms'])
+timeout 1500 python3 -m pytest tests/test_gpu_msm.py -x -q -m gpu 2>&1 | tail -3
+for v1 in 1 0; do
+ZG_MSM_PRECOMPUTE_V1=$v1 timeout 600 ./tools/bench_prove_path synth 20 3 0 > gpurun_out/pp_$v1.json
+python3 - $v1 <<'PY'
+import json,sys
+d=json.load(open('gpurun_out/pp_%s.json'%sys.argv[1]))
+if 'error' in d: print(d); sys.exit()
+d=d['prove_path']
+print('v1',sys.argv[1], d['total_ms'], d['total_ms_without_proving_key'], 'key',round(d['steps'][0]['ms'],2), 'cold key', round(d['steps'][0]['ms_cold'],2))
 PY
+done
