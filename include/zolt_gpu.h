@@ -131,8 +131,8 @@ typedef struct zg_bases_s *zg_bases_t;
 /* MSM tuning. window_bits 0 = auto from n; precompute_levels: 1 = none, 0 = auto,
  * k>1 = store 2^(c*G*l)*P for l<k at upload so k windows share one bucket set
  * (HBM cost k*64 B per base). expected_uses: how many MSMs the handle is expected to serve — 0 = many (an SRS that lives for
- * the whole run: the full table, 64*W bytes per base and a one-time build — 1 GB and ~20 ms at 2^20 bases, 4 GB and ~74 ms at 2^22 —
- * which pays back after ~15 MSMs issued one at a time, ~45 when several are kept in flight: bench.py reports table_build_ms,
+ * the whole run: the full table, 64*W bytes per base and a one-time build — 1 GB and ~13 ms at 2^20 bases, 4 GB and ~47 ms at 2^22 —
+ * which pays back after ~12 MSMs issued one at a time, ~35 when several are kept in flight: bench.py reports table_build_ms,
  * table_bytes and breakeven_msms in its config); 1..15 = an ad-hoc bases slice (MSM.compute on a temporary): auto picks
  * precompute_levels = 1, no table build. Results do not depend on these. */
 typedef struct {
