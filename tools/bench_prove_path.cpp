@@ -316,9 +316,9 @@ static Timeline prove_once(const ProveCase &pc, bool emit) {
     // ---- stages 4, 5, 6
     Stage4Result r4 = proveStage4(pc.accesses, {}, T, pc.log_k, pc.log_t, pc.start_address, tr);
     tl.lap("stage 4: Val evaluation (inc / wa / lt tables on the device, log T cubic rounds)", "h2d+kernels+host");
-    std::vector<uint32_t> instr(pc.trace.size());
-    for (size_t i = 0; i < instr.size(); i++) instr[i] = pc.trace[i].instruction;
-    StageRoundsResult r5 = proveStage5(instr, pc.log_t, tr);
+    std::vector<uint8_t> rd(pc.trace.size());  // the destination register of every cycle: all the stage reads of the trace
+    for (size_t i = 0; i < rd.size(); i++) rd[i] = (uint8_t)((pc.trace[i].instruction >> 7) & 31);
+    StageRoundsResult r5 = proveStage5(rd.data(), rd.size(), pc.log_t, tr);
     tl.lap("stage 5: register evaluation", "h2d+kernels+host");
     StageRoundsResult r6 = proveStage6(T, tr);
     tl.lap("stage 6: booleanity", "h2d+kernels+host");

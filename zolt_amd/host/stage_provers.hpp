@@ -689,14 +689,19 @@ inline ValEvaluationWrites valEvaluationWrites(const std::vector<MemoryAccess> &
                                                size_t trace_len, size_t k, uint64_t start_address) {
     ValEvaluationWrites w;
     while (w.n < std::max<size_t>(trace_len, 1)) w.n <<= 1;
-    std::unordered_map<uint64_t, uint64_t> last;
-    last.reserve(initial_ram.size() + 1024);
+    // last value per ADDRESS (the reference keys its map by address, not by word): every address that passes the range filter lies in
+    // [start, start + 8k), so the map is a flat array over byte offsets — a hash map cost 2 ms per 10^5 accesses here
+    const bool flat = k <= (size_t(1) << 22);  // (a larger address space keeps the hash map)
+    std::vector<uint64_t> last_flat(flat ? 8 * k : 0, 0);
+    std::unordered_map<uint64_t, uint64_t> last_map;
+    auto last = [&](uint64_t address) -> uint64_t & { return flat ? last_flat[address - start_address] : last_map[address]; };
     for (auto &kv : initial_ram)
-        if (kv.first >= start_address && (kv.first - start_address) / 8 < k) last[kv.first] = kv.second;
+        if (kv.first >= start_address && (kv.first - start_address) / 8 < k) last(kv.first) = kv.second;
     std::vector<uint32_t> slot(w.n, ~0u);
+    w.cycle.reserve(accesses.size()); w.word.reserve(accesses.size()); w.pre.reserve(accesses.size()); w.post.reserve(accesses.size());
     for (const MemoryAccess &a : accesses) {
         if (!a.is_write || a.address < start_address || (a.address - start_address) / 8 >= k || a.timestamp >= trace_len) continue;
-        uint64_t &cur = last[a.address];  // an address not seen before reads 0
+        uint64_t &cur = last(a.address);  // an address not seen before reads 0
         uint32_t &sl = slot[a.timestamp];
         if (sl == ~0u) {
             sl = (uint32_t)w.cycle.size();
@@ -774,25 +779,29 @@ inline Stage4Result proveStage4(const std::vector<MemoryAccess> &accesses, const
     return out;
 }
 // proveStage5 (:829-958): register value evaluation — eq(r_register, rd(j)) over the trace steps
-inline StageRoundsResult proveStage5(const std::vector<uint32_t> &instructions, size_t log_t, Transcript &transcript, std::vector<Fr> *r_register_out = nullptr) {
+// rd: the destination register of every cycle, (instruction >> 7) & 31 — what the stage reads of the trace
+inline StageRoundsResult proveStage5(const uint8_t *rd, size_t cycles, size_t log_t, Transcript &transcript, std::vector<Fr> *r_register_out = nullptr) {
     std::vector<Fr> r_register(5);
     for (auto &x : r_register) x = transcript.challengeScalar("r_register");
     for (size_t i = 0; i < log_t; i++) (void)transcript.challengeScalar("r_cycle_reg");
     if (r_register_out) *r_register_out = r_register;
     StageRoundsResult out;
-    if (instructions.empty()) { out.skipped = true; return out; }
-    const size_t num_rounds = instructions.size() <= 1 ? 0 : log2Ceil(instructions.size());
+    if (cycles == 0) { out.skipped = true; return out; }
+    const size_t num_rounds = cycles <= 1 ? 0 : log2Ceil(cycles);
     Fr table[32];
     for (unsigned reg = 0; reg < 32; reg++) table[reg] = computeRegEq(r_register, reg);
     // eq_evals[j] = table[rd of cycle j] (:880-900), zero past the trace: one byte per cycle crosses, the 32-entry table is looked up on the
     // device (ZG_COL_LUT) — the 2^log_t-element table of field elements is never built on the host
-    std::vector<uint8_t> rd(instructions.size());
-    for (size_t j = 0; j < instructions.size(); j++) rd[j] = (uint8_t)((instructions[j] >> 7) & 31);
-    const zg_col_t col{ZG_COL_LUT, 1, 32, rd.data(), table};
+    const zg_col_t col{ZG_COL_LUT, 1, 32, rd, table};
     zg_sc_t s = nullptr;
-    check(zg_sumcheck_open_column(&col, rd.size(), size_t(1) << num_rounds, ZG_SC_HIGH_HALF, &s), "zg_sumcheck_open_column");
+    check(zg_sumcheck_open_column(&col, cycles, size_t(1) << num_rounds, ZG_SC_HIGH_HALF, &s), "zg_sumcheck_open_column");
     highHalfRounds(s, num_rounds, transcript, "reg_eval_round", out);
     return out;
+}
+inline StageRoundsResult proveStage5(const std::vector<uint32_t> &instructions, size_t log_t, Transcript &transcript, std::vector<Fr> *r_register_out = nullptr) {
+    std::vector<uint8_t> rd(instructions.size());
+    for (size_t j = 0; j < instructions.size(); j++) rd[j] = (uint8_t)((instructions[j] >> 7) & 31);
+    return proveStage5(rd.data(), rd.size(), log_t, transcript, r_register_out);
 }
 // proveStage6 (:990-1112): booleanity — violation_evals = 0 for every step of a valid trace (:1024-1033)
 inline StageRoundsResult proveStage6(size_t trace_len, Transcript &transcript, Fr *bool_challenge_out = nullptr) {
