@@ -198,20 +198,24 @@ pub const SrsHandle = struct {
     /// HyperKZG.setup's G1 side with nothing leaving the device (src/poly/commitment/mod.zig:174-213): powers of tau, the fixed-base batch
     /// and the resident handle are built in HBM. `out` (may be empty) receives the points when the caller keeps them on the host
     /// (SetupParams.powers_of_tau_g1); a prover that only commits and opens passes an empty slice and n = the SRS size.
-    pub fn initFromTau(comptime F: type, comptime Affine: type, g1: Affine, tau: F, n: usize, out: []Affine, allocator: std.mem.Allocator) !SrsHandle {
+    /// `expected_uses`: 0 = an SRS that lives on (the table of multiples is built with it: 13 ms and 1 GB at 2^20 powers, repaid after ~12
+    /// MSMs); 1..15 = a key that serves ONE proof, as `zolt prove` builds it in-process (src/main.zig:271-696) — three commits and an
+    /// opening are fewer MSMs than the break-even, and the table-less plan proves the same bytes sooner (49.7 against 38.9 ms at 2^20 cycles).
+    pub fn initFromTau(comptime F: type, comptime Affine: type, g1: Affine, tau: F, n: usize, out: []Affine, allocator: std.mem.Allocator, expected_uses: c_int) !SrsHandle {
         var h: SrsHandle = .{};
         if (!enabled() or n == 0 or n_devices > 1 or g1.infinity) return h;
         var g: [8]u64 = undefined;
         @memcpy(g[0..4], &g1.x.limbs);
         @memcpy(g[4..8], &g1.y.limbs);
+        const cfg = ffi.MsmConfig{ .expected_uses = expected_uses };
         if (out.len == 0) {
-            if (ffi.zg_hyperkzg_setup(&g, &tau.limbs, n, null, null, null, &h.bases) != ffi.OK) h.bases = null;
+            if (ffi.zg_hyperkzg_setup(&g, &tau.limbs, n, &cfg, null, null, &h.bases) != ffi.OK) h.bases = null;
         } else {
             const oxy = try allocator.alloc(u64, 8 * n);
             defer allocator.free(oxy);
             const oinf = try allocator.alloc(u8, n);
             defer allocator.free(oinf);
-            if (ffi.zg_hyperkzg_setup(&g, &tau.limbs, n, null, oxy.ptr, oinf.ptr, &h.bases) != ffi.OK) {
+            if (ffi.zg_hyperkzg_setup(&g, &tau.limbs, n, &cfg, oxy.ptr, oinf.ptr, &h.bases) != ffi.OK) {
                 h.bases = null;
             } else {
                 for (out, 0..) |*r, i| r.* = affineFrom(Affine, oxy[8 * i ..][0..8], oinf[i]);
@@ -539,6 +543,13 @@ pub fn SumcheckSession(comptime F: type) type {
         /// RafEvaluationProver.computeRoundPolynomialCubic's two sums s(0), s(2) over this LOW_PAIR session's table
         /// (src/zkvm/ram/raf_checking.zig:335-410); `base` = start_address + 8 * sum_j bound_j 2^j, `current_power` = 8 * 2^round.
         /// s(1) = claim - s(0) and s(3) = s(0) - 3 s(1) + 3 s(2) stay host code; the bind of the round is `bind`.
+        /// RafEvaluationProver.computeInitialClaim (src/zkvm/ram/raf_checking.zig:312-321): sum_k ra(k) * F.fromU64(start_address + 8 k)
+        /// over this session's resident table, before the first bind — one pass on the device instead of 2^log_k host products.
+        pub fn rafInitialClaim(self: *Self, start_address: u64) Error!F {
+            var claim: F = undefined;
+            if (self.handle == null or ffi.zg_sumcheck_raf_claim(self.handle, start_address, 8, &claim.limbs) != ffi.OK) return Error.GpuFailure;
+            return claim;
+        }
         pub fn rafRoundSums(self: *Self, base: F, current_power: u64) Error![2]F {
             var s0: F = undefined;
             var s2: F = undefined;

@@ -26,12 +26,13 @@ class HyperKZG:
             self._dev.free()
 
     @staticmethod
-    def setup(max_degree):
-        """powers[i] = scalarMul(G1, tau^i).toAffine() (src/poly/commitment/mod.zig:174-213)."""
+    def setup(max_degree, expected_uses=0):
+        """powers[i] = scalarMul(G1, tau^i).toAffine() (src/poly/commitment/mod.zig:174-213). expected_uses 1..15: a key that serves one
+        proof — no table of multiples (three commits and an opening are fewer MSMs than its break-even); 0: an SRS that lives on."""
         # the powers tau^i (:196-198), the fixed-base batch (every product has the same base: 32 table additions per point instead of
         # double-and-add) and the MSM handle with its table of multiples are built on the device (zg_hyperkzg_setup); the points come back
         # once, for SetupParams.powers_of_tau_g1
-        dev, xy, inf = lib.Bases.hyperkzg_setup(generator(), fr_from_int(HyperKZG.TAU), max_degree)
+        dev, xy, inf = lib.Bases.hyperkzg_setup(generator(), fr_from_int(HyperKZG.TAU), max_degree, expected_uses=expected_uses)
         return HyperKZG.SetupParams(xy, inf, dev=dev)
 
     @staticmethod
