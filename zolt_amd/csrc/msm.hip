@@ -1337,11 +1337,19 @@ __global__ void __launch_bounds__(256) g1_scalar_mul_kernel(const uint64_t *xy, 
 // scalarMul is double-and-add (254 doublings + ~127 additions per output, msm/mod.zig:503-540); with one shared table
 // T[w][d-1] = d * 2^(8w) * G (32 windows x 255 multiples, 510 KiB, L2-resident) an output is at most 32 mixed additions
 // and one toAffine, no doubling at all.
-static constexpr int FB_C = 8, FB_W = 32, FB_ROWS = 255;
+// Window width by batch size: 8 bits (32 windows, 510 KiB of table, 8160 rows to build) up to 2^15 outputs, 10 bits (26 windows, 1.7 MB)
+// up to 2^18, 11 bits (24 windows, 3.1 MB — still inside one XCD's L2) beyond: an output then costs 24 additions instead of 32.
+// HyperKZG.setup of 2^20 powers, key without a table: 5.25 ms at 8 bits, 4.87 / 4.69 / 4.74 / 4.83 at 10 / 11 / 12 / 13.
+// ZG_FB_WINDOW_BITS overrides.
+struct FbPlan {
+    int c, W;
+    uint32_t rows;  // 2^c - 1 multiples per window
+};
+static constexpr int FB_W_MAX = 64;  // c >= 4
 
 // step 1 (one block, quad w of lanes per window): B_w = 2^(8w) * G by 8w doublings, every doubling by a quad (g1_29x4.hip.h) —
 // the only serial chain of the build (248 doublings for the top window)
-__global__ void __launch_bounds__(128) fb_window_bases_kernel(const uint64_t *base_xy, char *bw /* FB_W * 144 */) {
+__global__ void __launch_bounds__(4 * FB_W_MAX) fb_window_bases_kernel(const uint64_t *base_xy, int FB_C, char *bw /* W * 144 */) {
     uint32_t w = threadIdx.x >> 2, q = threadIdx.x & 3;
     Affine g = affine_load(base_xy);
     F29 one29;
@@ -1355,7 +1363,7 @@ __global__ void __launch_bounds__(128) fb_window_bases_kernel(const uint64_t *ba
 
 // step 2 (one thread per table row): d * B_w by double-and-add over the 8 bits of d, then to affine — the packed 64-byte row
 // format of the accumulate kernel (x, y as lazy Montgomery-2^261 values)
-__global__ void __launch_bounds__(256) fb_table_rows_kernel(const char *bw, uint32_t n_rows, char *table) {
+__global__ void __launch_bounds__(256) fb_table_rows_kernel(const char *bw, uint32_t n_rows, int FB_C, uint32_t FB_ROWS, char *table) {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_rows) return;
     uint32_t w = i / FB_ROWS, d = i % FB_ROWS + 1;
@@ -1370,15 +1378,19 @@ __global__ void __launch_bounds__(256) fb_table_rows_kernel(const char *bw, uint
     f29_store_packed(table + 64 * (size_t)i + 32, f29_mul(a.y, izzz));
 }
 
-__global__ void __launch_bounds__(256) fb_mul_kernel(const char *table, const uint64_t *scalars, size_t n, uint64_t *out_xy, uint8_t *out_inf) {
+__global__ void __launch_bounds__(256) fb_mul_kernel(const char *table, const uint64_t *scalars, size_t n, int FB_C, int FB_W, uint32_t FB_ROWS,
+                                                     uint64_t *out_xy, uint8_t *out_inf) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Fr s = fr_from_mont29(fe_load<FrParams>(scalars + 4 * i));  // canonical integer, 8 x 32-bit words
     XYZZ29 acc;
     bool acc_inf = true;
+    const uint32_t mask = (1u << FB_C) - 1u;
 #pragma unroll 1
     for (int w = 0; w < FB_W; w++) {
-        uint32_t d = (s.l[w >> 2] >> (8 * (w & 3))) & 0xffu;
+        const uint32_t d = s.l[0] & mask;  // the next FB_C bits; the scalar is shifted down behind it (static register indices)
+#pragma unroll
+        for (int k = 0; k < 8; k++) s.l[k] = (s.l[k] >> FB_C) | (k < 7 ? s.l[k + 1] << (32 - FB_C) : 0u);
         if (d == 0) continue;
         Affine row = affine_load(table + 64 * ((size_t)w * FB_ROWS + (d - 1)));
         xyzz29_madd(acc, acc_inf, f29_unpack(row.x.l), f29_unpack(row.y.l));
@@ -2946,6 +2958,13 @@ int zg_g1_affine_add_batch(const uint64_t *a_xy, const uint8_t *a_inf, const uin
     return ZG_OK;
 }
 
+static FbPlan fb_plan(size_t n) {
+    int c = n <= ((size_t)1 << 15) ? 8 : (n <= ((size_t)1 << 18) ? 10 : 11);
+    int e = env_int("ZG_FB_WINDOW_BITS", 0);
+    if (e >= 4 && e <= 14) c = e;
+    return FbPlan{c, (254 + c - 1) / c, (1u << c) - 1u};
+}
+
 int zg_g1_fixed_base_mul_batch(const uint64_t base_xy[8], uint8_t base_inf, const uint64_t *scalars, size_t n, uint64_t *out_xy,
                                uint8_t *out_inf) {
     ZG_INIT();
@@ -2960,16 +2979,17 @@ int zg_g1_fixed_base_mul_batch(const uint64_t base_xy[8], uint8_t base_inf, cons
         return ZG_OK;
     }
     hipStream_t st = lib_stream();
-    const uint32_t n_rows = FB_W * FB_ROWS;
-    Scratch s_base(64), s_rows((size_t)FB_W * 144), s_tab((size_t)n_rows * 64), s_sc(n * 32), s_out(n * 64), s_inf(n);
+    const FbPlan fb = fb_plan(n);
+    const uint32_t n_rows = (uint32_t)fb.W * fb.rows;
+    Scratch s_base(64), s_rows((size_t)fb.W * 144), s_tab((size_t)n_rows * 64), s_sc(n * 32), s_out(n * 64), s_inf(n);
     if (!s_base.p || !s_rows.p || !s_tab.p || !s_sc.p || !s_out.p || !s_inf.p) return ZG_ERR_NOMEM;
     SyncGuard sync(st);
     ZG_HIP(hipMemcpyAsync(s_base.p, base_xy, 64, hipMemcpyHostToDevice, st));
     ZG_HIP(hipMemcpyAsync(s_sc.p, scalars, n * 32, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(fb_window_bases_kernel, dim3(1), dim3(4 * FB_W), 0, st, s_base.as<uint64_t>(), s_rows.as<char>());
-    hipLaunchKernelGGL(fb_table_rows_kernel, dim3(div_up(n_rows, 256)), dim3(256), 0, st, s_rows.as<char>(), n_rows, s_tab.as<char>());
-    hipLaunchKernelGGL(fb_mul_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, s_tab.as<char>(), s_sc.as<uint64_t>(), n, s_out.as<uint64_t>(),
-                       s_inf.as<uint8_t>());
+    hipLaunchKernelGGL(fb_window_bases_kernel, dim3(1), dim3(4 * fb.W), 0, st, s_base.as<uint64_t>(), fb.c, s_rows.as<char>());
+    hipLaunchKernelGGL(fb_table_rows_kernel, dim3(div_up(n_rows, 256)), dim3(256), 0, st, s_rows.as<char>(), n_rows, fb.c, fb.rows, s_tab.as<char>());
+    hipLaunchKernelGGL(fb_mul_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, s_tab.as<char>(), s_sc.as<uint64_t>(), n, fb.c, fb.W, fb.rows,
+                       s_out.as<uint64_t>(), s_inf.as<uint8_t>());
     ZG_HIP(hipGetLastError());
     ZG_HIP(hipMemcpyAsync(out_xy, s_out.p, n * 64, hipMemcpyDeviceToHost, st));
     ZG_HIP(hipMemcpyAsync(out_inf, s_inf.p, n, hipMemcpyDeviceToHost, st));
@@ -2990,9 +3010,10 @@ int zg_hyperkzg_setup(const uint64_t base_xy[8], const uint64_t tau[4], size_t n
         return ZG_ERR_INVALID;
     }
     hipStream_t st = lib_stream();
-    const uint32_t n_rows = FB_W * FB_ROWS;
+    const FbPlan fb = fb_plan(n);
+    const uint32_t n_rows = (uint32_t)fb.W * fb.rows;
     const size_t nn = n ? n : 1;
-    Scratch s_base(64), s_rows((size_t)FB_W * 144), s_tab((size_t)n_rows * 64), s_pw(3 * 256 * 32), s_sc(nn * 32), s_out(nn * 64), s_inf(nn);
+    Scratch s_base(64), s_rows((size_t)fb.W * 144), s_tab((size_t)n_rows * 64), s_pw(3 * 256 * 32), s_sc(nn * 32), s_out(nn * 64), s_inf(nn);
     if (!s_base.p || !s_rows.p || !s_tab.p || !s_pw.p || !s_sc.p || !s_out.p || !s_inf.p) return ZG_ERR_NOMEM;
     SyncGuard sync(st);
     hipStream_t side = nullptr;
@@ -3015,15 +3036,15 @@ int zg_hyperkzg_setup(const uint64_t base_xy[8], const uint64_t tau[4], size_t n
         ZG_HIP(hipMemcpyAsync(s_base.p, base_xy, 64, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(tau_tables_kernel, dim3(1), dim3(64), 0, st, ta, s_pw.as<uint64_t>());
         hipLaunchKernelGGL(tau_powers_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, s_pw.as<uint64_t>(), n, s_sc.as<uint64_t>());
-        hipLaunchKernelGGL(fb_window_bases_kernel, dim3(1), dim3(4 * FB_W), 0, st, s_base.as<uint64_t>(), s_rows.as<char>());
-        hipLaunchKernelGGL(fb_table_rows_kernel, dim3(div_up(n_rows, 256)), dim3(256), 0, st, s_rows.as<char>(), n_rows, s_tab.as<char>());
+        hipLaunchKernelGGL(fb_window_bases_kernel, dim3(1), dim3(4 * fb.W), 0, st, s_base.as<uint64_t>(), fb.c, s_rows.as<char>());
+        hipLaunchKernelGGL(fb_table_rows_kernel, dim3(div_up(n_rows, 256)), dim3(256), 0, st, s_rows.as<char>(), n_rows, fb.c, fb.rows, s_tab.as<char>());
         // The handle's side table covers the first SIDE_TABLE_POINTS powers and its build is a 2.5 ms latency chain on 64 workgroups: those
         // powers are computed first, and the side handle is built on a helper stream while the remaining powers (2.9 ms at 2^20, the whole
         // chip) are still being multiplied out.
         const size_t head = n > SIDE_TABLE_POINTS && env_int("ZG_MSM_SIDE_TABLE", 1) ? SIDE_TABLE_POINTS : 0;
         if (head) {
-            hipLaunchKernelGGL(fb_mul_kernel, dim3(div_up(head, 256)), dim3(256), 0, st, s_tab.as<char>(), s_sc.as<uint64_t>(), head, s_out.as<uint64_t>(),
-                               s_inf.as<uint8_t>());
+            hipLaunchKernelGGL(fb_mul_kernel, dim3(div_up(head, 256)), dim3(256), 0, st, s_tab.as<char>(), s_sc.as<uint64_t>(), head, fb.c, fb.W, fb.rows,
+                               s_out.as<uint64_t>(), s_inf.as<uint8_t>());
             side = stream_try_acquire();  // an idle stream or none (never a new one); on the library stream's own hardware queue it runs behind it
             if (side && (hipEventCreateWithFlags(&head_ready, hipEventDisableTiming) != hipSuccess || hipEventRecord(head_ready, st) != hipSuccess ||
                          hipStreamWaitEvent(side, head_ready, 0) != hipSuccess)) {
@@ -3033,7 +3054,7 @@ int zg_hyperkzg_setup(const uint64_t base_xy[8], const uint64_t tau[4], size_t n
             }
         }
         hipLaunchKernelGGL(fb_mul_kernel, dim3(div_up(n - head, 256)), dim3(256), 0, st, s_tab.as<char>(), s_sc.as<uint64_t>() + 4 * head, n - head,
-                           s_out.as<uint64_t>() + 8 * head, s_inf.as<uint8_t>() + head);
+                           fb.c, fb.W, fb.rows, s_out.as<uint64_t>() + 8 * head, s_inf.as<uint8_t>() + head);
         ZG_HIP(hipGetLastError());
         if (side) {
             zg_msm_config small_cfg{8, 0, 0};
