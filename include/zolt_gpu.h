@@ -76,7 +76,7 @@ extern "C" {
  *             compile with -DZG_NO_PROTOCOL_SESSIONS to leave them out of the binding; zg_abi_features() reports whether the loaded
  *             library carries them. */
 #define ZG_ABI_MAJOR 1
-#define ZG_ABI_MINOR 8
+#define ZG_ABI_MINOR 9
 #define ZG_FEATURE_PROTOCOL_SESSIONS 1u /* zg_rrw_* and zg_rwc_* are exported */
 #define ZG_FEATURE_RCCL 2u              /* the several-GPU entry points can exchange partials over RCCL */
 #define ZG_FEATURE_COLUMN_INGEST 4u     /* zg_fr_rows_from_columns[_dev] */
@@ -393,6 +393,11 @@ ZG_API int zg_fr_spartan_combine_dev(const uint64_t *d_eq, const uint64_t *d_az,
 typedef struct zg_sc_s *zg_sc_t;
 ZG_API int zg_sumcheck_open(const uint64_t *evals, size_t len, int layout, zg_sc_t *s);
 ZG_API int zg_sumcheck_open_dev(const uint64_t *d_evals, size_t len, int layout, void *stream, zg_sc_t *s); /* copies */
+/* The same session WITHOUT the copy: the session reads the caller's table (never writes it) until its first bind has run — the caller
+ * keeps d_evals alive and unchanged until a later call on the session has returned round sums or a final value (or zg_sync). Its own
+ * buffers hold the folds only (len/2 + len/4 entries instead of len + len/2): Az and Bz of an outer sumcheck, 1 GB each at 2^20 cycles,
+ * are bound alongside without a second copy in HBM. zg_sumcheck_bit_bind (an in-place bind) is refused before the first zg_sumcheck_bind. */
+ZG_API int zg_sumcheck_open_dev_borrowed(const uint64_t *d_evals, size_t len, int layout, void *stream, zg_sc_t *out);
 /* A session whose table is ONE integer column widened on the device (zg_fr_rows_from_columns' kinds; host data): entries [0, n_rows) from
  * the column, [n_rows, len) zero. The tables of proveStage5 (eq_evals[j] = table[rd of cycle j]: a ZG_COL_LUT over one byte per cycle) and
  * proveStage6 (all zero: ZG_COL_ZERO) are built this way without a 32-byte-per-cycle upload (src/zkvm/prover.zig:880-944, 1024-1097). */

@@ -409,6 +409,45 @@ def test_low_pair_session_every_table(zl, ob):
     s.close()
 
 
+@pytest.mark.parametrize("layout_name", ["SC_LOW_PAIR", "SC_HIGH_HALF"])
+@pytest.mark.parametrize("v", [0, 1, 2, 9, 14])
+def test_session_on_a_borrowed_table(zl, ob, v, layout_name):
+    """zg_sumcheck_open_dev_borrowed: the session reads the caller's device table in place (no copy) until its first bind, then folds in
+    buffers of its own — every round's sums, every table after a bind and the final value equal the copying session's and the oracle's;
+    the caller's table is left as it was; an in-place bit-bind before the first bind is refused; a closed borrowed session goes back to the
+    pool and serves an ordinary one."""
+    layout = getattr(zl, layout_name)
+    n = 1 << v
+    tab = _rand(ob, 1700 + v, n)
+    chals = _rand(ob, 1750 + v, max(v, 1))
+    d = zl.DeviceBuffer.from_host(tab)
+    for rep in range(2):  # the second pass takes the first one's session from the pool
+        s = zl.SumcheckSession.open_dev(d.ptr, n, layout, borrow=True)
+        c = zl.SumcheckSession.open(tab, layout)
+        cur = tab
+        assert np.array_equal(s.read(), tab)
+        for k in range(v):
+            assert all(np.array_equal(a, b) for a, b in zip(s.round_sums(), c.round_sums())), k
+            want = ob.fr_sum_even_odd(cur) if layout == zl.SC_LOW_PAIR else ob.fr_sum_halves(cur)
+            assert all(np.array_equal(a, b) for a, b in zip(s.round_sums(), want)), k
+            s.bind(chals[k])
+            c.bind(chals[k])
+            cur = ob.fr_bind_low(cur, chals[k]) if layout == zl.SC_LOW_PAIR else ob.fr_bind_high(cur, chals[k])
+            assert np.array_equal(s.read().reshape(-1, 4), cur), k
+        assert np.array_equal(s.final(), cur[0]) and np.array_equal(c.final(), cur[0])
+        s.close()
+        c.close()
+        assert np.array_equal(d.to_host().reshape(-1, 4), tab)
+    if v >= 2:
+        s = zl.SumcheckSession.open_dev(d.ptr, n, zl.SC_HIGH_HALF, borrow=True)
+        idx = zl.DeviceBuffer.from_host(np.zeros((n, 2), dtype=np.uint64))
+        with pytest.raises(zl.ZgError):
+            s.bit_bind(idx.ptr, n, 0, chals[0])
+        s.close()
+        idx.free()
+    d.free()
+
+
 def test_full_size_low_pair_session_from_spartan_inputs(zl, ob):
     """BASELINE config 3 mode (ii) at FULL size (v = 20): the fused eq x (Az*Bz - Cz) open (zg_sumcheck_open_spartan_dev:
     src/zkvm/spartan/mod.zig:182-206 + Sumcheck.Prover.init), then 20 LowToHigh rounds with given challenges (the reference's 128-bit

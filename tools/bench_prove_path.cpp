@@ -222,8 +222,9 @@ static Timeline prove_once(const ProveCase &pc, bool emit) {
     zg_sc_t s1 = nullptr, sa = nullptr, sb = nullptr;
     check(zg_sumcheck_open_spartan_dev(reinterpret_cast<const uint64_t *>(tau.data()), rounds1, nullptr, d_az.u64(), d_bz.u64(), nullptr, ZG_SC_LOW_PAIR, nullptr, &s1),
           "zg_sumcheck_open_spartan_dev");
-    check(zg_sumcheck_open_dev(d_az.u64(), padded, ZG_SC_LOW_PAIR, nullptr, &sa), "zg_sumcheck_open_dev");
-    check(zg_sumcheck_open_dev(d_bz.u64(), padded, ZG_SC_LOW_PAIR, nullptr, &sb), "zg_sumcheck_open_dev");
+    // Az and Bz are bound alongside for Az(r), Bz(r): their sessions read the materialised tables in place (no second copy of 1 GB each)
+    check(zg_sumcheck_open_dev_borrowed(d_az.u64(), padded, ZG_SC_LOW_PAIR, nullptr, &sa), "zg_sumcheck_open_dev_borrowed");
+    check(zg_sumcheck_open_dev_borrowed(d_bz.u64(), padded, ZG_SC_LOW_PAIR, nullptr, &sb), "zg_sumcheck_open_dev_borrowed");
     if (emit) std::printf("S 1\n");
     Fr initial1 = Fr::zero();
     for (size_t k = 0; k < rounds1; k++) {

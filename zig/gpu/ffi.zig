@@ -35,7 +35,7 @@ pub const OP_INV: c_int = 5;
 pub const OP_FROM_MONT: c_int = 6;
 pub const OP_TO_MONT: c_int = 7;
 pub const ABI_MAJOR: u32 = 1;
-pub const ABI_MINOR: u32 = 8;
+pub const ABI_MINOR: u32 = 9;
 pub const FEATURE_PROTOCOL_SESSIONS: u32 = 1;
 pub const FEATURE_RCCL: u32 = 2;
 pub const FEATURE_COLUMN_INGEST: u32 = 4;
@@ -125,6 +125,7 @@ pub extern fn zg_fr_spartan_combine(eq: ?[*]const u64, az: ?[*]const u64, bz: ?[
 pub extern fn zg_fr_spartan_combine_dev(d_eq: ?[*]const u64, d_az: ?[*]const u64, d_bz: ?[*]const u64, d_cz: ?[*]const u64, n: usize, d_out: ?[*]u64, stream: ?*anyopaque) c_int;
 pub extern fn zg_sumcheck_open(evals: ?[*]const u64, len: usize, layout: c_int, s: *Session) c_int;
 pub extern fn zg_sumcheck_open_dev(d_evals: ?[*]const u64, len: usize, layout: c_int, stream: ?*anyopaque, s: *Session) c_int;
+pub extern fn zg_sumcheck_open_dev_borrowed(d_evals: ?[*]const u64, len: usize, layout: c_int, stream: ?*anyopaque, out: *Session) c_int;
 pub extern fn zg_sumcheck_open_column(col: ?[*]const Column, n_rows: usize, len: usize, layout: c_int, s: *Session) c_int;
 pub extern fn zg_sumcheck_open_spartan_dev(r: ?[*]const u64, v: usize, scale: ?[*]const u64, d_az: ?[*]const u64, d_bz: ?[*]const u64, d_cz: ?[*]const u64, layout: c_int, stream: ?*anyopaque, s: *Session) c_int;
 pub extern fn zg_sumcheck_round_sums(s: Session, g0: *[4]u64, g1: *[4]u64) c_int;

@@ -19,7 +19,7 @@ ZG_OP_INV = 5
 ZG_OP_FROM_MONT = 6
 ZG_OP_TO_MONT = 7
 ZG_ABI_MAJOR = 1
-ZG_ABI_MINOR = 8
+ZG_ABI_MINOR = 9
 ZG_FEATURE_PROTOCOL_SESSIONS = 1
 ZG_FEATURE_RCCL = 2
 ZG_FEATURE_COLUMN_INGEST = 4
@@ -124,6 +124,7 @@ PROTOS = {
     "zg_fr_spartan_combine_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),  # d_eq, d_az, d_bz, d_cz, n, d_out, stream
     "zg_sumcheck_open": (c_int, [c_void_p, c_size_t, c_int, c_void_p]),  # evals, len, layout, s
     "zg_sumcheck_open_dev": (c_int, [c_void_p, c_size_t, c_int, c_void_p, c_void_p]),  # d_evals, len, layout, stream, s
+    "zg_sumcheck_open_dev_borrowed": (c_int, [c_void_p, c_size_t, c_int, c_void_p, c_void_p]),  # d_evals, len, layout, stream, out
     "zg_sumcheck_open_column": (c_int, [c_void_p, c_size_t, c_size_t, c_int, c_void_p]),  # col, n_rows, len, layout, s
     "zg_sumcheck_open_spartan_dev": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),  # r, v, scale, d_az, d_bz, d_cz, layout, stream, s
     "zg_sumcheck_round_sums": (c_int, [c_void_p, c_void_p, c_void_p]),  # s, g0, g1

@@ -1298,6 +1298,9 @@ struct zg_sc_s {
     int layout = 0;
     size_t len = 0;
     uint64_t *buf[2] = {nullptr, nullptr};  // ping-pong tables (a fold cannot run in place across threads)
+    uint64_t *own[2] = {nullptr, nullptr};  // ... as allocated. buf[i] == own[i] except while a session opened with
+                                            // zg_sumcheck_open_dev_borrowed still reads the caller's table (buf[0]) — until its first bind
+    bool borrowing = false;
     int cur = 0;
     uint64_t *d_partials = nullptr;
     uint64_t *h_pin = nullptr;  // pinned, device-visible: the kernels write the round sums (8 limbs) straight to the host
@@ -1306,7 +1309,7 @@ struct zg_sc_s {
     hipStream_t own_st = nullptr;  // zg_sumcheck_open (host table) runs on it: created with the session and kept in the pool, so the
                                    // independent provers of a batched sumcheck overlap (psc.hip: psc_open_stream has the measurements)
     uint64_t seq = 0;  // number of (sums) publications requested so far; h_pin[12] holds the last one completed
-    size_t cap = 0;  // elements buf[0] can hold (sessions are pooled: hipMalloc/hipFree cost more than a round)
+    size_t cap = 0, cap1 = 0;  // elements own[0] / own[1] can hold (sessions are pooled: hipMalloc / hipHostMalloc cost more than a round)
     // address-phase state of a Lasso session (zg_sumcheck_bit_round / bit_bind)
     bool bit_valid = false;     // bit_sums = the split of the first bit_n entries by bit bit_cached (left by the last bit_bind)
     unsigned bit_cached = 0;
@@ -1325,7 +1328,7 @@ static void sc_free(zg_sc_s *s) {
     if (!s) return;
     if (s->own_st) (void)hipStreamSynchronize(s->own_st);  // the tables go back to the device pool: nothing of this session may still run
     if (s->st && s->st != s->own_st) (void)hipDeviceSynchronize();  // (a caller's stream may be gone by now: wait for the device instead)
-    void *ptrs[] = {s->buf[0], s->buf[1], s->d_partials};
+    void *ptrs[] = {s->own[0], s->own[1], s->d_partials};
     for (void *p : ptrs) pool_free(p);
     if (s->h_pin) (void)hipHostFree(s->h_pin);
     stream_release(s->own_st, s->device);
@@ -1335,7 +1338,9 @@ static void sc_free(zg_sc_s *s) {
 static std::mutex g_pool_mu;
 static std::vector<zg_sc_s *> g_pool;  // closed sessions kept for reuse (at most 4)
 
-static int sc_create(size_t len, int layout, hipStream_t st, zg_sc_s **out) {
+// borrowed: the session will read its first table from the caller (zg_sumcheck_open_dev_borrowed): its own buffers hold the folds only
+// (len / 2 and len / 4 entries)
+static int sc_create(size_t len, int layout, hipStream_t st, zg_sc_s **out, bool borrowed = false) {
     if (len == 0 || (len & (len - 1)) || (layout != ZG_SC_HIGH_HALF && layout != ZG_SC_LOW_PAIR)) {
         set_error("zg_sumcheck_open: len must be a power of two and layout valid");
         return ZG_ERR_INVALID;
@@ -1343,10 +1348,13 @@ static int sc_create(size_t len, int layout, hipStream_t st, zg_sc_s **out) {
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
         for (size_t i = 0; i < g_pool.size(); i++) {
-            if (g_pool[i]->device == current_device() && g_pool[i]->cap >= len && g_pool[i]->cap <= 4 * len) {
+            // an ordinary session folds len -> own[0] ... a borrowed one only len / 2 -> own[1], len / 4 -> own[0]
+            const size_t need0 = borrowed ? len / 4 : len, need1 = len / 2;
+            if (g_pool[i]->device == current_device() && g_pool[i]->cap >= need0 && g_pool[i]->cap1 >= need1 && g_pool[i]->cap <= 4 * len) {
                 zg_sc_s *s = g_pool[i];
                 g_pool.erase(g_pool.begin() + i);
                 s->layout = layout; s->len = len; s->st = st; s->cur = 0; s->sums_valid = false;
+                s->buf[0] = s->own[0]; s->buf[1] = s->own[1]; s->borrowing = false;
                 s->seq = 0; s->h_pin[12] = 0;
                 s->bit_valid = false; s->pad_valid = false;
                 if (!st) s->st = s->own_st;
@@ -1357,7 +1365,8 @@ static int sc_create(size_t len, int layout, hipStream_t st, zg_sc_s **out) {
     }
     zg_sc_s *s = new zg_sc_s();
     s->device = current_device();
-    s->cap = len;
+    s->cap = borrowed ? (len / 4 ? len / 4 : 1) : len;
+    s->cap1 = len / 2 ? len / 2 : 1;
     s->layout = layout;
     s->len = len;
     s->own_st = stream_acquire();  // kept with the pooled session; from the runtime's free list (creating one costs ~3 ms)
@@ -1367,8 +1376,10 @@ static int sc_create(size_t len, int layout, hipStream_t st, zg_sc_s **out) {
     auto grab = [&](uint64_t *&ptr, size_t bytes) {
         if (e == hipSuccess && !(ptr = reinterpret_cast<uint64_t *>(pool_alloc(bytes)))) e = hipErrorOutOfMemory;
     };
-    grab(s->buf[0], len * 32);
-    grab(s->buf[1], (len / 2 ? len / 2 : 1) * 32);
+    grab(s->own[0], (borrowed ? (len / 4 ? len / 4 : 1) : len) * 32);
+    grab(s->own[1], (len / 2 ? len / 2 : 1) * 32);
+    s->buf[0] = s->own[0];
+    s->buf[1] = s->own[1];
     grab(s->d_partials, SC_MISC_BYTES);
     if (e == hipSuccess) e = hipMemset(s->d_partials, 0, SC_MISC_BYTES);
     if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_pin, 128, hipHostMallocMapped | hipHostMallocCoherent);
@@ -2786,6 +2797,20 @@ int zg_sumcheck_open_dev(const uint64_t *d_evals, size_t len, int layout, void *
     return ZG_OK;
 }
 
+int zg_sumcheck_open_dev_borrowed(const uint64_t *d_evals, size_t len, int layout, void *stream, zg_sc_t *out) {
+    ZG_INIT();
+    if (!d_evals || !out) {
+        set_error("zg_sumcheck_open_dev_borrowed: invalid argument");
+        return ZG_ERR_INVALID;
+    }
+    zg_sc_s *s = nullptr;
+    ZG_TRY(sc_create(len, layout, pick_stream(stream), &s, true));
+    s->buf[0] = const_cast<uint64_t *>(d_evals);  // read only: every kernel that takes buf[cur] while `borrowing` has a const table argument
+    s->borrowing = true;
+    *out = s;
+    return ZG_OK;
+}
+
 int zg_sumcheck_open_column(const zg_col_t *col, size_t n_rows, size_t len, int layout, zg_sc_t *out) {
     ZG_INIT();
     if (!col || !out || n_rows > len) {
@@ -2896,6 +2921,10 @@ int zg_sumcheck_bind(zg_sc_t s, const uint64_t r[4]) {
     s->len /= 2;
     s->sums_valid = s->len >= 2;
     s->bit_valid = s->pad_valid = false;
+    if (s->borrowing) {  // the fold just enqueued was the last reader of the caller's table (nxt == 1: it wrote own[1])
+        s->buf[0] = s->own[0];
+        s->borrowing = false;
+    }
     return ZG_OK;
 }
 
@@ -3095,6 +3124,10 @@ int zg_sumcheck_bit_bind(zg_sc_t s, const uint64_t *d_idx128, size_t n_idx, unsi
     }
     const unsigned next_bit = bit < 127 ? bit + 1 : bit;
     unsigned nb = sc_blocks(n_idx ? n_idx : 1);
+    if (s->borrowing) {
+        set_error("zg_sumcheck_bit_bind: binds in place — not on a session that still reads a borrowed table (zg_sumcheck_open_dev_borrowed)");
+        return ZG_ERR_INVALID;
+    }
     s->bit_valid = false;
     s->seq++;
     hipLaunchKernelGGL(bit_bind_kernel, dim3(nb), dim3(256), 0, s->st, s->buf[s->cur], d_idx128, n_idx, (uint32_t)bit, (uint32_t)next_bit, ra,

@@ -820,9 +820,14 @@ class SumcheckSession:
         return cls(h)
 
     @classmethod
-    def open_dev(cls, d_evals, n, layout=SC_HIGH_HALF, stream=0):
+    def open_dev(cls, d_evals, n, layout=SC_HIGH_HALF, stream=0, borrow=False):
+        """borrow: no copy — the session reads the caller's device table until its first bind has run (zg_sumcheck_open_dev_borrowed);
+        the caller keeps it alive and unchanged until then"""
         h = C.c_void_p()
-        _chk(_lib.zg_sumcheck_open_dev(_d(d_evals), C.c_size_t(n), C.c_int(layout), _d(stream), C.byref(h)), "zg_sumcheck_open_dev")
+        if borrow:
+            _chk(_lib.zg_sumcheck_open_dev_borrowed(_d(d_evals), C.c_size_t(n), C.c_int(layout), _d(stream), C.byref(h)), "zg_sumcheck_open_dev_borrowed")
+        else:
+            _chk(_lib.zg_sumcheck_open_dev(_d(d_evals), C.c_size_t(n), C.c_int(layout), _d(stream), C.byref(h)), "zg_sumcheck_open_dev")
         return cls(h)
 
     @classmethod
