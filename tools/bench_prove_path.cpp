@@ -205,8 +205,9 @@ static Timeline prove_once(const ProveCase &pc, bool emit) {
     size_t rounds1 = 0;
     while ((size_t(1) << rounds1) < padded) rounds1++;
     DeviceMem d_az(padded * 32), d_bz(padded * 32);
-    check(zg_dev_memset(d_az.p, 0, padded * 32), "zg_dev_memset");
-    check(zg_dev_memset(d_bz.p, 0, padded * 32), "zg_dev_memset");
+    // (the constraint rows of every cycle are written below: only the padding behind them is cleared)
+    check(zg_dev_memset(d_az.u64() + 4 * n_constraints, 0, (padded - n_constraints) * 32), "zg_dev_memset");
+    check(zg_dev_memset(d_bz.u64() + 4 * n_constraints, 0, (padded - n_constraints) * 32), "zg_dev_memset");
     const std::vector<Fr> maps = constraint_maps();
     const size_t W = r1cs::NUM_INPUTS + 1;
     for (int t = 0; t < 2; t++) {
