@@ -200,7 +200,7 @@ pub const SrsHandle = struct {
     /// (SetupParams.powers_of_tau_g1); a prover that only commits and opens passes an empty slice and n = the SRS size.
     /// `expected_uses`: 0 = an SRS that lives on (the table of multiples is built with it: 13 ms and 1 GB at 2^20 powers, repaid after ~12
     /// MSMs); 1..15 = a key that serves ONE proof, as `zolt prove` builds it in-process (src/main.zig:271-696) — three commits and an
-    /// opening are fewer MSMs than the break-even, and the table-less plan proves the same bytes sooner (46 against 37 ms at 2^20 cycles).
+    /// opening are fewer MSMs than the break-even, and the table-less plan proves the same bytes sooner (37 against 46 ms at 2^20 cycles).
     pub fn initFromTau(comptime F: type, comptime Affine: type, g1: Affine, tau: F, n: usize, out: []Affine, allocator: std.mem.Allocator, expected_uses: c_int) !SrsHandle {
         var h: SrsHandle = .{};
         if (!enabled() or n == 0 or n_devices > 1 or g1.infinity) return h;
