@@ -150,10 +150,12 @@ namespace zg {
 // 7 products per level instead of an inversion (~80 products' worth), and Jacobian doublings (945 multiply-adds) instead of XYZZ ones
 // (1269): 2^20 bases x 15 levels 20.2 -> 13 ms. Rows are lazy representatives (< 1.1p) of the same affine coordinates as before.
 constexpr int PRE_GROUP = 7;
+constexpr size_t PRE_CHUNK = (size_t)1 << 21;  // bases per launch of the table kernel (bounds its records)
 __global__ void __launch_bounds__(256) msm_precompute_kernel(const uint64_t *xy, const uint8_t *inf, size_t n, int levels,
-                                                             int dbl_per_level, char *table, char *scratch) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+                                                             int dbl_per_level, char *table, char *scratch, size_t first, size_t count) {
+    // this launch: bases [first, first + count) of the n; the records of base i sit at local index i - first (stride count)
+    const size_t li = (size_t)blockIdx.x * blockDim.x + threadIdx.x, i = first + li;
+    if (li >= count) return;
     Affine p = affine_load(xy + 8 * i);
     Jac29 a;
     a.x = f29_from_fp(p.x);
@@ -172,12 +174,12 @@ __global__ void __launch_bounds__(256) msm_precompute_kernel(const uint64_t *xy,
             for (int k = 0; k < dbl_per_level; k++) a = jac29_dbl(a);
             XYZZ29 rec;
             rec.x = a.x; rec.y = a.y; rec.zz = a.z; rec.zzz = pref;
-            xyzz29_store(scratch + 144 * ((size_t)j * n + i), rec);
+            xyzz29_store(scratch + 144 * ((size_t)j * count + li), rec);
             pref = f29_mul(pref, a.z);
         }
         F29 t = f29_from_fp(fe_inv_safegcd(f29_to_fp(pref)));  // 1 / (Z_0 ... Z_(g-1))
         for (int j = g - 1; j >= 0; j--) {
-            const XYZZ29 rec = xyzz29_load(scratch + 144 * ((size_t)j * n + i));  // this thread's own record
+            const XYZZ29 rec = xyzz29_load(scratch + 144 * ((size_t)j * count + li));  // this thread's own record
             const F29 iz = f29_mul(t, rec.zzz);  // 1 / Z_j
             t = f29_mul(t, rec.zz);              // ... and Z_j leaves the running inverse
             const F29 iz2 = f29_sqr(iz);
@@ -1883,16 +1885,22 @@ static int bases_create(const uint64_t *d_xy, const uint8_t *d_inf_in, size_t n,
     // the table kernel's per-level records (see msm_precompute_kernel); without them (allocation refused, ZG_MSM_PRECOMPUTE_V1) the
     // round-4 kernel builds the same table with an inversion per level. Released after the synchronisation below.
     const size_t pre_levels = p.L > 1 ? (size_t)(p.L - 1 < PRE_GROUP ? p.L - 1 : PRE_GROUP) : 0;
+    // ... for at most PRE_CHUNK bases at a time (2^21: 2.1 GB of records whatever the handle's size — a 2^24-base handle would ask for 17 GB
+    // beside its 16 GiB table, and a fresh allocation of that size costs more than the kernel it serves)
+    const size_t pre_chunk = n < PRE_CHUNK ? (n ? n : 1) : PRE_CHUNK;
     Scratch pre_scratch;
-    if (n && pre_levels && !env_int("ZG_MSM_PRECOMPUTE_V1", 0) && !pre_scratch.alloc(pre_levels * n * 144)) (void)hipGetLastError();
+    if (n && pre_levels && !env_int("ZG_MSM_PRECOMPUTE_V1", 0) && !pre_scratch.alloc(pre_levels * pre_chunk * 144)) (void)hipGetLastError();
     {
         hipError_t e = hipSuccess;
         if (n) {
             if (d_inf_in) e = hipMemcpyAsync(b->d_inf, d_inf_in, n, hipMemcpyDeviceToDevice, st);
             if (e == hipSuccess) {
                 if (pre_scratch.p)
-                    hipLaunchKernelGGL(msm_precompute_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, d_xy, b->d_inf, n, p.L, p.c * p.G,
-                                       b->d_table, pre_scratch.as<char>());
+                    for (size_t first = 0; first < n; first += pre_chunk) {  // the launches reuse the records one after the other (stream order)
+                        const size_t count = n - first < pre_chunk ? n - first : pre_chunk;
+                        hipLaunchKernelGGL(msm_precompute_kernel, dim3(div_up(count, 256)), dim3(256), 0, st, d_xy, b->d_inf, n, p.L, p.c * p.G,
+                                           b->d_table, pre_scratch.as<char>(), first, count);
+                    }
                 else
                     hipLaunchKernelGGL(msm_precompute_v1_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, d_xy, b->d_inf, n, p.L, p.c * p.G,
                                        b->d_table);
