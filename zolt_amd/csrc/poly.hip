@@ -251,15 +251,27 @@ __global__ void __launch_bounds__(256) fr_dot_kernel(const uint64_t *a, const ui
 // last step of the kernel that produced a round's sums, so no round needs the host. `res` (u64 words):
 //   [0,4) claim | [4, 4+8v) rounds: c0 || c1 | [.., +4v) challenges | +4 final_eval | +1 status | +4 running claim |
 //   +4 running challenge.   status: bit 0 = result (verifier.claim == final_eval), bits 8.. = 1 + first failed round
+// Round 5: the verifier step of round k no longer closes the kernel that produced round k's sums (block pairs -> arrival counter ->
+// the last block adds them up -> verifier step: three dependent round trips, ~4 us at the end of every launch) — it OPENS the next
+// kernel: a producer leaves its block pairs in `partials` with plain stores and ends; every block of the consumer adds the nb_prev pairs
+// up for itself (32 KiB from L2, under the latency of its own first table loads), runs the same verifier step and gets the same
+// challenge; block 0 alone records it in `res`. The pairs alternate between two halves of the array and the running claim between two
+// slots (a consumer's early blocks write while its late blocks still read).
 struct ScRunArg {
     uint64_t *res;  // nullptr: an ordinary session launch (sums go to `sums`, sequence word published)
     uint32_t v, round, init;
+    uint32_t nb_prev = 0;  // device-resident protocol: workgroups of the launch that produced the sums this launch's verifier step reads
+                           // (0: this launch starts the protocol — it only produces); `round` = the round of THOSE sums
 };
+constexpr uint32_t SC_RUN_PAIRS = 1024;  // block pairs per half of the partials array in the device-resident protocol
 ZG_DEV size_t run_off_chal(uint32_t v) { return 4 + 8 * (size_t)v; }
 ZG_DEV size_t run_off_final(uint32_t v) { return 4 + 12 * (size_t)v; }
 ZG_DEV size_t run_off_status(uint32_t v) { return 8 + 12 * (size_t)v; }
 ZG_DEV size_t run_off_claim(uint32_t v) { return 9 + 12 * (size_t)v; }
 ZG_DEV size_t run_off_cur(uint32_t v) { return 13 + 12 * (size_t)v; }
+// the running claim BEFORE round `round`'s verifier step: two slots in turn (the second one is the word block that held the running
+// challenge until round 5 — every consumer now derives the challenge itself)
+ZG_DEV size_t run_off_claim_of(uint32_t v, uint32_t round) { return (round & 1u) ? run_off_cur(v) : run_off_claim(v); }
 ZG_DEV uint64_t fr_limb64(const Fr &a, int i) { return (uint64_t)a.l[2 * i] | ((uint64_t)a.l[2 * i + 1] << 32); }
 ZG_DEV bool fr_eq(const Fr &a, const Fr &b) {
     uint32_t d = 0;
@@ -272,19 +284,23 @@ ZG_DEV bool fr_eq(const Fr &a, const Fr &b) {
 // One thread. With `init` the claim is first set to g0 + g1 (runSumcheck's initial sum over the hypercube).
 // `claim_reg` (the LDS tail): the running claim is taken from and left in the caller's registers instead of a dependent global load.
 // `defer_claim`: the claim update g0 + c1 * ch is left to the caller (the single-wave tail folds it with the table: same formula).
-ZG_DEV Fr sc_verifier_step(const ScRunArg &a, const Fr &g0, const Fr &g1, F29 *ch_pre = nullptr, Fr *claim_reg = nullptr, bool defer_claim = false) {
+// `record`: this caller writes the round into `res` (one workgroup per launch does; the others only need the challenge and the claim).
+ZG_DEV Fr sc_verifier_step(const ScRunArg &a, const Fr &g0, const Fr &g1, F29 *ch_pre = nullptr, Fr *claim_reg = nullptr, bool defer_claim = false,
+                           bool record = true) {
     uint64_t *res = a.res;
     Fr sum = fe_add(g0, g1);
     Fr claim;
     if (a.init) {
         claim = sum;
-        fe_store(res, claim);
-        res[run_off_status(a.v)] = 0;
+        if (record) {
+            fe_store(res, claim);
+            res[run_off_status(a.v)] = 0;
+        }
     } else {
-        claim = claim_reg ? *claim_reg : fe_load<FrParams>(res + run_off_claim(a.v));
+        claim = claim_reg ? *claim_reg : fe_load<FrParams>(res + run_off_claim_of(a.v, a.round));
     }
     Fr c1 = fe_sub(g1, g0);
-    if (!fr_eq(sum, claim) && (res[run_off_status(a.v)] >> 8) == 0) res[run_off_status(a.v)] = ((uint64_t)(a.round + 1)) << 8;
+    if (record && !fr_eq(sum, claim) && (a.init || (res[run_off_status(a.v)] >> 8) == 0)) res[run_off_status(a.v)] = ((uint64_t)(a.round + 1)) << 8;
     uint64_t h = 0x9e3779b97f4a7c15ull;
     h ^= (uint64_t)a.round;
     h *= 0xff51afd7ed558ccdull;
@@ -305,16 +321,60 @@ ZG_DEV Fr sc_verifier_step(const ScRunArg &a, const Fr &g0, const Fr &g1, F29 *c
     Fr ch = fr_from_u64_29(h);                   // F.fromU64
     F29 chp = fr29_prescale(ch);                 // also the shared factor of the fold that follows
     if (ch_pre) *ch_pre = chp;
-    fe_store(res + 4 + 8 * (size_t)a.round, g0);
-    fe_store(res + 8 + 8 * (size_t)a.round, c1);
-    fe_store(res + run_off_chal(a.v) + 4 * (size_t)a.round, ch);
-    fe_store(res + run_off_cur(a.v), ch);
+    if (record) {
+        fe_store(res + 4 + 8 * (size_t)a.round, g0);
+        fe_store(res + 8 + 8 * (size_t)a.round, c1);
+        fe_store(res + run_off_chal(a.v) + 4 * (size_t)a.round, ch);
+    }
     if (!defer_claim) {
         Fr next = fe_add(fr_mul29(c1, chp), g0);  // UniPoly.evaluate by Horner: c1 * x + c0
-        fe_store(res + run_off_claim(a.v), next);
+        if (record) fe_store(res + run_off_claim_of(a.v, a.round + 1), next);
         if (claim_reg) *claim_reg = next;
     }
     return ch;
+}
+
+// The opening of a consumer launch of the device-resident protocol (see ScRunArg): every thread of every workgroup calls it. Adds the
+// producer's nb_prev block pairs up, runs round run.round's verifier step in one lane and returns the prescaled challenge to every thread
+// (through `sh`, which is free again on return); *claim_out (if given) receives the claim after the step in EVERY thread.
+ZG_DEV F29 sc_run_open(const ScRunArg &run, const uint64_t *partials, u32 *sh, Fr *claim_out = nullptr) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint64_t *src = partials + 8 * (size_t)SC_RUN_PAIRS * (run.round & 1u);
+    Acc9 a0 = acc9_zero(), a1 = acc9_zero();
+    for (uint32_t k = tid; k < run.nb_prev; k += blockDim.x) {
+        acc9_add(a0, fe_load<FrParams>(src + 8 * (size_t)k));
+        acc9_add(a1, fe_load<FrParams>(src + 8 * (size_t)k + 4));
+    }
+    const Fr tot = block_sum_pair9(a0, a1, sh);  // wave 0: lane SC_LANE_G0 / SC_LANE_G1
+    __syncthreads();                             // the reduction's reads of `sh` are done: it now carries the challenge and the claim
+    if (tid < 64) {
+        const Fr second = pair_second_to_first(tot);
+        if (lane == SC_LANE_G0) {
+            F29 cp;
+            Fr claim = Fr::zero();
+            Fr *creg = nullptr;
+            if (!run.init) {
+                claim = fe_load<FrParams>(run.res + run_off_claim_of(run.v, run.round));
+                creg = &claim;
+            }
+            ScRunArg a = run;
+            (void)sc_verifier_step(a, tot, second, &cp, run.init ? &claim : creg, false, blockIdx.x == 0);
+#pragma unroll
+            for (int i = 0; i < 9; i++) sh[i] = cp.l[i];
+#pragma unroll
+            for (int i = 0; i < 8; i++) sh[9 + i] = claim.l[i];
+        }
+    }
+    __syncthreads();
+    F29 rp;
+#pragma unroll
+    for (int i = 0; i < 9; i++) rp.l[i] = sh[i];
+    if (claim_out) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) claim_out->l[i] = sh[9 + i];
+    }
+    __syncthreads();  // `sh` may be reused by the caller's own reduction
+    return rp;
 }
 
 // End of a round inside the producing kernel (no second launch): every thread hands in its lazy sums; the block's canonical
@@ -325,6 +385,13 @@ __device__ __forceinline__ void finish_round(const Acc9 &g0, const Acc9 &g1, u32
                                              uint64_t *flag, uint64_t seq, const ScRunArg &run) {
     const uint32_t tid = threadIdx.x, nb = gridDim.x, lane = tid & 63u;
     Fr tot = block_sum_pair9(g0, g1, sh);  // wave 0: lane SC_LANE_G0 / SC_LANE_G1
+    if (run.res) {  // device-resident protocol: the block pair stays in `partials` (plain stores, complete when the launch is); the
+                    // next launch's workgroups add the pairs up and run the verifier step (sc_run_open)
+        const uint32_t out_round = run.nb_prev ? run.round + 1 : run.round;  // the round these sums belong to
+        if (tid < 64 && (lane == SC_LANE_G0 || lane == SC_LANE_G1))
+            fe_store(partials + 8 * ((size_t)SC_RUN_PAIRS * (out_round & 1u) + blockIdx.x) + (lane == SC_LANE_G1 ? 4 : 0), tot);
+        return;
+    }
     if (nb > 1) {
         __shared__ uint32_t last;
         if (tid < 64) {
@@ -345,13 +412,9 @@ __device__ __forceinline__ void finish_round(const Acc9 &g0, const Acc9 &g1, u32
     if (tid < 64) {
         Fr second = pair_second_to_first(tot);
         if (lane == SC_LANE_G0) {
-            if (run.res) {
-                sc_verifier_step(run, tot, second);
-            } else {
-                mailbox_store_fr(sums, tot, flag);
-                mailbox_store_fr(sums + 4, second, flag);
-                publish_seq(flag, seq);
-            }
+            mailbox_store_fr(sums, tot, flag);
+            mailbox_store_fr(sums + 4, second, flag);
+            publish_seq(flag, seq);
         }
     }
 }
@@ -485,14 +548,17 @@ __global__ void __launch_bounds__(512) sc_fold_kernel(const uint64_t *t, size_t 
         lo = fe_load<FrParams>(LAYOUT == ZG_SC_HIGH_HALF ? t + 4 * i : t + 8 * i);
         hi = fe_load<FrParams>(LAYOUT == ZG_SC_HIGH_HALF ? t + 4 * (i + half) : t + 8 * i + 4);
     }
-    Fr rv;
-    if (run.res) {  // device-resident protocol: the challenge was left in device memory by the previous kernel's verifier step
-        rv = fe_load<FrParams>(run.res + run_off_cur(run.v));
+    FrMul rp;  // the challenge is the shared factor of every product of this launch (narrow form for a 128-bit one)
+    Fr run_claim = Fr::zero();
+    if (run.res) {  // device-resident protocol: this launch opens with the verifier step of the round whose sums the previous launch left
+        rp.p = sc_run_open(run, partials, sh, &run_claim);
+        rp.narrow = false;
     } else {
+        Fr rv;
 #pragma unroll
         for (int k = 0; k < 8; k++) rv.l[k] = r.l[k];
+        rp = frmul_prepare(rv);
     }
-    FrMul rp = frmul_prepare(rv);  // the challenge is the shared factor of every product of this launch (narrow form for a 128-bit one)
     Acc9 g0 = acc9_zero(), g1 = acc9_zero();
     while (i < half) {
         const size_t ni = i + stride;
@@ -511,10 +577,10 @@ __global__ void __launch_bounds__(512) sc_fold_kernel(const uint64_t *t, size_t 
         i = ni;
     }
     if (run.res && half == 1) {  // the table is down to one element: getFinalEval + the verifier's last comparison
-        if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (threadIdx.x == 0 && blockIdx.x == 0) {  // (a one-pair fold is one workgroup; its store above is this thread's own)
             Fr fin = fe_load<FrParams>(out);
             fe_store(run.res + run_off_final(run.v), fin);
-            if (fr_eq(fin, fe_load<FrParams>(run.res + run_off_claim(run.v)))) run.res[run_off_status(run.v)] |= 1;
+            if (fr_eq(fin, run_claim)) run.res[run_off_status(run.v)] |= 1;
         }
         return;
     }
@@ -545,15 +611,17 @@ __global__ void __launch_bounds__(256) sc_run_publish_kernel(const uint64_t *res
 
 constexpr uint32_t SC_TAIL_MAX = 4096, SC_TAIL_THREADS = 1024;
 constexpr size_t SC_TAIL_LDS_EXTRA = (SC_RED_WORDS + 12) * 4;  // reduction scratch + the prescaled challenge, after the table
-__global__ void __launch_bounds__(SC_TAIL_THREADS) sc_tail_run_kernel(const uint64_t *t, uint32_t len, ScRunArg run, uint32_t res_words,
-                                                                       uint64_t *host, uint64_t *hflag) {
+__global__ void __launch_bounds__(SC_TAIL_THREADS) sc_tail_run_kernel(const uint64_t *t, uint32_t len, ScRunArg run, const uint64_t *partials,
+                                                                       uint32_t res_words, uint64_t *host, uint64_t *hflag) {
     extern __shared__ uint4 lds_tab[];  // len entries of 2 x uint4, then SC_RED_WORDS u32 of reduction scratch + 9 for the challenge
     u32 *sh = reinterpret_cast<u32 *>(lds_tab + 2 * (size_t)len);
     u32 *sh_rp = sh + SC_RED_WORDS;  // the prescaled challenge (9 limbs), written by the lane that ran the verifier step
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     for (uint32_t i = tid; i < len; i += SC_TAIL_THREADS) fe_store(&lds_tab[2 * i], fe_load<FrParams>(t + 4 * (size_t)i));
-    F29 rp = fr29_prescale(fe_load<FrParams>(run.res + run_off_cur(run.v)));
-    Fr claim = fe_load<FrParams>(run.res + run_off_claim(run.v));  // stays in registers from here on
+    Fr claim;  // stays in registers from here on
+    F29 rp = sc_run_open(run, partials, sh, &claim);  // the verifier step of the round whose sums the last fold (or the sums launch) left
+    run.round++;
+    run.init = 0;
     __syncthreads();
     // ---- phase A: rounds with at least 64 pairs, all waves. A round = fold in LDS, block reduction, verifier step in lane
     // SC_LANE_G0 of wave 0 (which keeps the claim), challenge through LDS.
@@ -1089,14 +1157,33 @@ static unsigned sc_blocks(size_t half) {
     return b > cap ? cap : b;
 }
 
+// workgroups of a sums / fold launch over `half` pairs (the device-resident protocol's next launch is told: ScRunArg.nb_prev)
+static unsigned sums_threads() {
+    static const unsigned threads = env_uint("ZG_SC_SUMS_THREADS", 1024, 64, 1024) & ~63u;
+    return threads;
+}
+static unsigned fold_threads() {
+    static const unsigned threads = env_uint("ZG_SC_FOLD_THREADS", 512, 64, 512) & ~63u;
+    return threads;
+}
+static unsigned sums_grid(size_t half, bool run) {
+    const unsigned cap = sc_block_cap(256u);
+    unsigned nb = div_up(half ? half : 1, (size_t)sums_threads() * SC_SUMS_U);
+    if (nb > cap) nb = cap;
+    return run && nb > SC_RUN_PAIRS ? SC_RUN_PAIRS : nb;
+}
+static unsigned fold_grid(size_t half, bool run) {
+    const unsigned cap = sc_block_cap(512u);
+    unsigned nb = div_up(half ? half : 1, fold_threads());
+    if (nb > cap) nb = cap;
+    return run && nb > SC_RUN_PAIRS ? SC_RUN_PAIRS : nb;
+}
+
 static int launch_sums(int layout, const uint64_t *t, size_t len, uint64_t *partials, uint64_t *sums, hipStream_t st,
                        uint64_t *flag = nullptr, uint64_t seq = 0, ScRunArg run = ScRunArg{nullptr, 0, 0, 0}) {
     size_t half = len / 2;
     // 1024-thread workgroups of SC_SUMS_U pairs per thread, at most one per CU (measured: tools/exp/fold_ab.hip)
-    static const unsigned threads = env_uint("ZG_SC_SUMS_THREADS", 1024, 64, 1024) & ~63u;
-    const unsigned cap = sc_block_cap(256u);
-    unsigned nb = div_up(half ? half : 1, (size_t)threads * SC_SUMS_U);
-    if (nb > cap) nb = cap;
+    const unsigned threads = sums_threads(), nb = sums_grid(half, run.res != nullptr);
     uint32_t *counter = reinterpret_cast<uint32_t *>(partials + 8 * (size_t)SC_MAX_BLOCKS);  // zeroed at session creation
     prof_begin(ZG_PROF_SC_SUMS, st);
     if (layout == ZG_SC_HIGH_HALF)
@@ -1119,10 +1206,7 @@ static int launch_fold(int layout, const uint64_t *t, size_t len, const uint64_t
     }
     uint32_t *counter = reinterpret_cast<uint32_t *>(partials + 8 * (size_t)SC_MAX_BLOCKS);
     // 512-thread workgroups, at most two per CU (four waves per SIMD): measured at 2^16 .. 2^24 entries, tools/exp/fold_ab.hip
-    static const unsigned threads = env_uint("ZG_SC_FOLD_THREADS", 512, 64, 512) & ~63u;
-    const unsigned cap = sc_block_cap(512u);
-    unsigned nb = div_up(half ? half : 1, threads);
-    if (nb > cap) nb = cap;
+    const unsigned threads = fold_threads(), nb = fold_grid(half, run.res != nullptr);
     prof_begin(ZG_PROF_SC_FOLD, st);
     if (layout == ZG_SC_HIGH_HALF)
         hipLaunchKernelGGL(sc_fold_kernel<ZG_SC_HIGH_HALF>, dim3(nb), dim3(threads), 0, st, t, half, ra, out, partials, sums, counter, flag, seq, run);
@@ -2648,7 +2732,10 @@ static int run_sumcheck_enqueue(const uint64_t *d_evals, size_t len, hipStream_t
     uint64_t *h = pin.p, *hflag = pin.p + RUN_PIN_WORDS - 1;
     __atomic_store_n(hflag, 0ull, __ATOMIC_RELEASE);
     // round 0's sums: also fixes the claim; every later round's sums come out of the fold that precedes it
-    ZG_TRY(launch_sums(ZG_SC_HIGH_HALF, d_evals, len, d_misc, d_misc + SC_SUMS_OFF, st, nullptr, 0, ScRunArg{d_res, v, 0, 1}));
+    // The launch that produces round k's sums only leaves block pairs; the NEXT launch opens with round k's verifier step (ScRunArg):
+    // launch 0 = the sums of round 0, then fold k (verifier step k, fold by its challenge, sums of round k + 1) for k = 0, 1, ...
+    ZG_TRY(launch_sums(ZG_SC_HIGH_HALF, d_evals, len, d_misc, d_misc + SC_SUMS_OFF, st, nullptr, 0, ScRunArg{d_res, v, 0, 1, 0}));
+    uint32_t nb_prev = sums_grid(len / 2, true);
     const uint64_t *cur = d_evals;
     size_t cl = len;
     const uint32_t tail_max = (uint32_t)env_uint("ZG_SC_TAIL_MAX", SC_TAIL_MAX, 1, SC_TAIL_MAX);  // 1: every round as its own launch
@@ -2656,7 +2743,8 @@ static int run_sumcheck_enqueue(const uint64_t *d_evals, size_t len, hipStream_t
     for (; k < v && cl > tail_max; k++) {
         uint64_t *nxt = buf[k & 1];
         ZG_TRY(launch_fold(ZG_SC_HIGH_HALF, cur, cl, nullptr, nxt, d_misc, d_misc + SC_SUMS_OFF, st, nullptr, 0,
-                           ScRunArg{d_res, v, k + 1, 0}));
+                           ScRunArg{d_res, v, k, k == 0 ? 1u : 0u, nb_prev}));
+        nb_prev = fold_grid(cl / 2, true);
         cur = nxt;
         cl /= 2;
     }
@@ -2667,7 +2755,7 @@ static int run_sumcheck_enqueue(const uint64_t *d_evals, size_t len, hipStream_t
                                        (int)(SC_TAIL_MAX * 32 + SC_TAIL_LDS_EXTRA));
         }));
         hipLaunchKernelGGL(sc_tail_run_kernel, dim3(1), dim3(SC_TAIL_THREADS), cl * 32 + SC_TAIL_LDS_EXTRA, st, cur, (uint32_t)cl,
-                           ScRunArg{d_res, v, k + 1, 0}, (uint32_t)res_words, h, hflag);
+                           ScRunArg{d_res, v, k, k == 0 ? 1u : 0u, nb_prev}, d_misc, (uint32_t)res_words, h, hflag);
     } else {
         hipLaunchKernelGGL(sc_run_publish_kernel, dim3(1), dim3(256), 0, st, d_res, (uint32_t)res_words, h, hflag);
     }
