@@ -127,4 +127,43 @@ while time.time() - t0 < budget:
             w, wi = ob.g1_add_affine(pa[j], int(ia[j]), pb[j], int(ib[j]))
             assert oi[j] == wi and (wi or np.array_equal(ox[j], w)), ("affine add", j)
         cases += 2
+    # round-5 entry points: handles planned for a few uses (no table; batches of rows share one reduction), MSMs over machine words,
+    # the proving key built on the device with a random fixed-base window width
+    if n and rng.random() < 0.4:
+        os.environ["ZG_MSM_ROWS_SHARED_TAIL"] = str(int(rng.integers(0, 2)))
+        bt = lib.Bases.upload(xy, inf, expected_uses=int(rng.integers(1, 16)))
+        k = int(rng.integers(2, 9))
+        nb = int(rng.integers(1, n + 1))
+        batches = [scalars(nb, int(rng.integers(0, 5))) for _ in range(k)]
+        outs, infs = bt.msm_batch(batches, n=nb)
+        for j in range(k):
+            want, winf = ob.msm_g1(xy[:nb], None if inf is None else inf[:nb], batches[j])
+            assert infs[j] == winf and np.array_equal(outs[j], want), ("table-less batch", n, nb, k, j, os.environ["ZG_MSM_ROWS_SHARED_TAIL"])
+        words = rng.integers(0, 1 << 63, size=nb, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=nb, dtype=np.uint64)
+        if rng.random() < 0.5:
+            words[rng.random(nb) < 0.5] = 0
+        got, ginf = bt.msm_u64(words, n=nb)
+        want, winf = ob.msm_g1(xy[:nb], None if inf is None else inf[:nb], ob.f_from_u64(ob.FR, words))
+        assert ginf == winf and np.array_equal(got, want), ("u64 msm", n, nb)
+        bt.free()
+        cases += k + 1
+    if rng.random() < 0.15:
+        from zolt_amd import api
+        m = int(rng.choice([1, 2, 33, 1000, 20000, 40000]))
+        os.environ["ZG_FB_WINDOW_BITS"] = str(int(rng.choice([0, 4, 7, 8, 10, 11, 12, 13])))
+        tau = scalars(1, 0)[0]
+        h, pxy, pinf = lib.Bases.hyperkzg_setup(gm[0], tau, m, expected_uses=int(rng.integers(0, 3)))
+        pw = [1]
+        for _ in range(m - 1):
+            pw.append(pw[-1] * api.fr_to_int(tau) % R)
+        for j in (0, m // 2, m - 1):
+            o, oi = ob.g1_scalar_mul(gm[0], 0, api.fr_from_int(pw[j]))
+            assert pinf[j] == oi and (oi or np.array_equal(pxy[j], o)), ("setup power", m, j)
+        sc = scalars(m, int(rng.integers(0, 5)))
+        got, ginf = h.msm(sc)
+        want, winf = ob.msm_g1(pxy, pinf, sc)
+        assert ginf == winf and np.array_equal(got, want), ("msm over the device-built key", m)
+        h.free()
+        os.environ.pop("ZG_FB_WINDOW_BITS")
+        cases += 1
 print(f"fuzz ok: {cases} MSMs checked in {time.time() - t0:.1f} s")
