@@ -1,5 +1,7 @@
 mkdir -p gpurun_out
-R=$GRAFT_REPO_ROOT
-cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/prof_pp; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_pp -- $R/tools/bench_prove_path synth 20 3 </dev/null > /tmp/prof_pp.log 2>&1
-f=$(find /tmp/prof_pp -name "*kernel_stats.csv" | head -1); cp "$f" $R/gpurun_out/r5t_prove_path_kernel_stats.csv; head -25 "$f" | cut -c1-150
+timeout 1500 python3 -m pytest tests/test_gpu_msm.py tests/test_gpu_api_mirror.py -x -q -m gpu 2>&1 | tail -2
+for wf in 0 3; do
+echo "ZG_MSM_ROWCOL_WAVE_FROM=$wf"
+ZG_MSM_ROWCOL_WAVE_FROM=$wf python3 tools/exp/open_tableless.py 20 1 | tail -6
+ZG_MSM_ROWCOL_WAVE_FROM=$wf python3 tools/exp/open_tableless.py 20 0 | tail -6
+done

@@ -1023,6 +1023,29 @@ __device__ __forceinline__ XYZZ29 block_sum_xyzz29(const XYZZ29 &acc, uint4 *sh)
     return xyzz29_load(&sh[0]);
 }
 
+// The same sum over ONE wave (64 partial sums, 9 KiB of LDS): one single-lane addition, then five levels of quad additions. For launches
+// with many rows (several bucket sets: a batch, a handle without a table) — see msm_rowcol_wave_kernel.
+__device__ __forceinline__ XYZZ29 wave_sum_xyzz29(const XYZZ29 &acc, uint4 *sh) {
+    const uint32_t tid = threadIdx.x;  // 64 threads
+    xyzz29_store(&sh[tid * 9], acc);
+    __syncthreads();
+    if (tid < 32) {
+        XYZZ29 x = xyzz29_load(&sh[tid * 9]), y = xyzz29_load(&sh[(tid + 32) * 9]);
+        xyzz29_store(&sh[tid * 9], xyzz29_add(x, y));
+    }
+    __syncthreads();
+    const uint32_t g = tid >> 2, q = tid & 3;
+    for (uint32_t o = 16; o > 0; o >>= 1) {
+        if (g < o) {
+            XYZZ29 x = xyzz29_load(&sh[g * 9]), y = xyzz29_load(&sh[(g + o) * 9]);
+            XYZZ29 r = xyzz29_add4(x, y, q);
+            if (q == 0) xyzz29_store(&sh[g * 9], r);
+        }
+        __syncthreads();
+    }
+    return xyzz29_load(&sh[0]);
+}
+
 // Heavy buckets in ONE launch (uniform scalars have none: the kernel then returns at once — it used to be three launches of ~5 us
 // each). Part 1, one wave per heavy bucket (more than 8*GS, at most HUGE_PARTIALS partials; typical source: the top window of a
 // c-bit decomposition covers only a few bits, so its digits pile into a small set of buckets): strided serial sums (<= 32 per lane)
@@ -1137,6 +1160,37 @@ __global__ void __launch_bounds__(256) msm_rowcol_kernel(const char *buckets, ui
     }
     XYZZ29 r = block_sum_xyzz29(acc, sh);
     if (t == 0) xyzz29_store(rc + 144 * ((size_t)g * (nrow + ncol) + x), r);
+}
+// The same sums by ONE wave per row / column: a lane adds up to four of the 256 elements itself, then the wave's tree. A 256-thread
+// workgroup per row keeps three quarters of its lanes idle from the second tree level on and needs 36 KiB of LDS: with several bucket
+// sets in one launch (K rows of a batch, the G window groups of a handle without a table: 2560 ... 8704 workgroups) the launch ran in
+// waves of workgroups — 230 us for the five long levels of HyperKZG.open, 240 us for ONE table-less MSM. One wave per row is a few
+// additions longer alone (57 -> ~70 us) and several times shorter there, so it is taken from three bucket sets on.
+__global__ void __launch_bounds__(64) msm_rowcol_wave_kernel(const char *buckets, uint32_t NB, int lb, int hb, char *rc) {
+    ZG_HIPRIO();
+    __shared__ uint4 sh[64 * 9];
+    const uint32_t x = blockIdx.x, g = blockIdx.y, nrow = 1u << hb, ncol = 1u << lb, t = threadIdx.x;
+    XYZZ29 acc = xyzz29_identity();
+    const uint32_t len = x < nrow ? ncol : nrow;
+    bool first = true;
+    for (uint32_t e = t; e < len; e += 64) {
+        const uint32_t k = x < nrow ? ((x << lb) | e) : ((e << lb) | (x - nrow));  // digit magnitude of the element; 0 = none
+        if (k != 0) {
+            XYZZ29 v = xyzz29_load(buckets + 144 * ((size_t)g * NB + (k - 1)));
+            acc = first ? v : xyzz29_add(acc, v);
+            first = false;
+        }
+    }
+    XYZZ29 r = wave_sum_xyzz29(acc, sh);
+    if (t == 0) xyzz29_store(rc + 144 * ((size_t)g * (nrow + ncol) + x), r);
+}
+static int env_int(const char *name, int dflt);
+static void launch_rowcol(hipStream_t st, const char *buckets, uint32_t NB, int lb, int hb, int sets, char *rc) {
+    const int wave_from = env_int("ZG_MSM_ROWCOL_WAVE_FROM", 3);  // bucket sets from which one wave sums a row (0: never)
+    if (wave_from > 0 && sets >= wave_from)
+        hipLaunchKernelGGL(msm_rowcol_wave_kernel, dim3((1u << hb) + (1u << lb), sets), dim3(64), 0, st, buckets, NB, lb, hb, rc);
+    else
+        hipLaunchKernelGGL(msm_rowcol_kernel, dim3((1u << hb) + (1u << lb), sets), dim3(256), 0, st, buckets, NB, lb, hb, rc);
 }
 
 __global__ void __launch_bounds__(256) msm_bits2d_kernel(const char *buckets, const char *rc, uint32_t NB, int c, int lb, int hb, char *out) {
@@ -2278,7 +2332,7 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
                            (uint32_t)S);
     if (p.lb) {
         char *d_rc = ln.d_bits + 144 * (size_t)p.G * p.K * p.c;  // rows and columns behind the c bit sums of every group
-        hipLaunchKernelGGL(msm_rowcol_kernel, dim3((1u << p.hb) + (1u << p.lb), p.G * p.K), dim3(256), 0, st, ln.d_partial, p.NB, p.lb, p.hb, d_rc);
+        launch_rowcol(st, ln.d_partial, p.NB, p.lb, p.hb, p.G * p.K, d_rc);
         hipLaunchKernelGGL(msm_bits2d_kernel, dim3(p.c, p.G * p.K), dim3(256), 0, st, ln.d_partial, d_rc, p.NB, p.c, p.lb, p.hb, ln.d_bits);
     } else {
         hipLaunchKernelGGL(msm_bitsum_kernel, dim3(p.PB, p.c, p.G * p.K), dim3(256), 0, st, ln.d_partial, p.NB, p.c, ln.d_bits);
@@ -2662,7 +2716,7 @@ static int msm_rows_shared_tail(zg_bases_s *b, size_t n, const uint64_t *d_scala
     const int GK = p.G * (int)k;
     char *d_rc = b->d_rows_bits + 144 * (size_t)GK * p.c;  // rows and columns behind the c bit sums of every group (as in msm_enqueue_lane)
     prof_begin(ZG_PROF_MSM_REDUCE, st);
-    hipLaunchKernelGGL(msm_rowcol_kernel, dim3((1u << p.hb) + (1u << p.lb), GK), dim3(256), 0, st, b->d_rows_buckets, p.NB, p.lb, p.hb, d_rc);
+    launch_rowcol(st, b->d_rows_buckets, p.NB, p.lb, p.hb, GK, d_rc);
     hipLaunchKernelGGL(msm_bits2d_kernel, dim3(p.c, GK), dim3(256), 0, st, b->d_rows_buckets, d_rc, p.NB, p.c, p.lb, p.hb, b->d_rows_bits);
     hipLaunchKernelGGL(msm_final_kernel, dim3(GK), dim3(512), 0, st, b->d_rows_bits, p.c, 1, p.G, b->d_rows_rg, 0, d_out9, reinterpret_cast<uint8_t *>(d_out9 + 8), 9u, 72u);
     hipLaunchKernelGGL(msm_groups_kernel, dim3((unsigned)k), dim3(4), 0, st, b->d_rows_rg, p.G, p.c, 0, d_out9, reinterpret_cast<uint8_t *>(d_out9 + 8), 9u, 72u);
