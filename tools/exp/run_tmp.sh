@@ -1,7 +1,9 @@
 mkdir -p gpurun_out
-timeout 1500 python3 -m pytest tests/test_gpu_msm.py tests/test_gpu_api_mirror.py -x -q -m gpu 2>&1 | tail -2
-for wf in 0 3; do
-echo "ZG_MSM_ROWCOL_WAVE_FROM=$wf"
-ZG_MSM_ROWCOL_WAVE_FROM=$wf python3 tools/exp/open_tableless.py 20 1 | tail -6
-ZG_MSM_ROWCOL_WAVE_FROM=$wf python3 tools/exp/open_tableless.py 20 0 | tail -6
+for uses in 0 1; do
+timeout 600 ./tools/bench_prove_path synth 20 3 $uses > gpurun_out/r5w_prove_path_uses$uses.json
+python3 - $uses <<'PY'
+import json,sys
+d=json.load(open('gpurun_out/r5w_prove_path_uses%s.json'%sys.argv[1]))['prove_path']
+print('uses',sys.argv[1], d['total_ms'], d['total_ms_without_proving_key'], 'key', round(d['steps'][0]['ms'],2), 'commits',round(sum(s['ms'] for s in d['steps'][2:5]),2), 'open', round(d['steps'][-1]['ms'],2))
+PY
 done
