@@ -1,9 +1,4 @@
-mkdir -p gpurun_out
-for uses in 0 1; do
-timeout 600 ./tools/bench_prove_path synth 20 3 $uses > gpurun_out/r5w_prove_path_uses$uses.json
-python3 - $uses <<'PY'
-import json,sys
-d=json.load(open('gpurun_out/r5w_prove_path_uses%s.json'%sys.argv[1]))['prove_path']
-print('uses',sys.argv[1], d['total_ms'], d['total_ms_without_proving_key'], 'key', round(d['steps'][0]['ms'],2), 'commits',round(sum(s['ms'] for s in d['steps'][2:5]),2), 'open', round(d['steps'][-1]['ms'],2))
-PY
+for early in 0 1 0 1; do
+echo "ZG_HK_LONG_EARLY=$early"; ZG_HK_LONG_EARLY=$early python3 tools/exp/open_tableless.py 20 0 | grep open | tail -3
 done
+ZG_HK_LONG_EARLY=1 timeout 900 python3 -m pytest tests/test_gpu_api_mirror.py -x -q -m gpu -k "open" 2>&1 | tail -1
