@@ -175,8 +175,10 @@ static Timeline prove_once(const ProveCase &pc, bool emit) {
     HyperKZG::SetupParams pk = HyperKZG::setup(pc.srs_size, false, key_uses > 0 || key_levels > 0 ? &key_cfg : nullptr);
     tl.lap("proving key: HyperKZG.setup on the device (powers of tau, fixed-base batch, table of multiples)", "once per key");
     // ---- the three commitments, from machine words (zg_msm_g1_u64)
-    std::vector<uint64_t> bc(pc.bytecode.size() < 2 ? 2 : ceil_pow2(pc.bytecode.size()), 0), mem(pc.accesses.size() < 2 ? 2 : ceil_pow2(pc.accesses.size()), 0),
-        reg(pc.trace.size() < 2 ? 2 : ceil_pow2(pc.trace.size()), 0);
+    // (in pinned memory, as a shim would hold them: PinnedWords — a pageable vector per proof is pinned on the fly and unpinned again by
+    // the HIP runtime, usually cheaply, by 10-15 ms when the process's address reuse changes)
+    PinnedWords bc(pc.bytecode.size() < 2 ? 2 : ceil_pow2(pc.bytecode.size())), mem(pc.accesses.size() < 2 ? 2 : ceil_pow2(pc.accesses.size())),
+        reg(pc.trace.size() < 2 ? 2 : ceil_pow2(pc.trace.size()));
     for (size_t i = 0; i < pc.bytecode.size(); i++) bc[i] = pc.bytecode[i];
     for (size_t i = 0; i < pc.accesses.size(); i++) mem[i] = pc.accesses[i].value;
     for (size_t i = 0; i < pc.trace.size(); i++) reg[i] = pc.trace[i].rd_value;

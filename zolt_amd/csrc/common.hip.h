@@ -18,7 +18,6 @@ int primary_device();       // the device zg_init / zg_init_devices bound this p
 int current_device();       // the calling thread's HIP device
 hipStream_t lib_stream();   // the library's own stream on the calling thread's CURRENT device (created on first use)
 hipStream_t stream_acquire();                     // an idle stream of the current device (created if none): sumcheck sessions
-hipStream_t stream_try_acquire();                  // an idle stream if there is one, nullptr otherwise (never creates one)
 void stream_release(hipStream_t st, int device);  // back to the free list (streams live until zg_shutdown)
 // three streams created back to back (= on three different hardware queues), as a unit: launch sets that are meant to overlap
 bool stream_group_acquire(hipStream_t out[3]);

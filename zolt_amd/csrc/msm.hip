@@ -151,10 +151,28 @@ namespace zg {
 // (1269): 2^20 bases x 15 levels 20.2 -> 13 ms. Rows are lazy representatives (< 1.1p) of the same affine coordinates as before.
 constexpr int PRE_GROUP = 7;
 constexpr size_t PRE_CHUNK = (size_t)1 << 21;  // bases per launch of the table kernel (bounds its records)
-__global__ void __launch_bounds__(256) msm_precompute_kernel(const uint64_t *xy, const uint8_t *inf, size_t n, int levels,
-                                                             int dbl_per_level, char *table, char *scratch, size_t first, size_t count) {
-    // this launch: bases [first, first + count) of the n; the records of base i sit at local index i - first (stride count)
-    const size_t li = (size_t)blockIdx.x * blockDim.x + threadIdx.x, i = first + li;
+// A launch carries up to TWO tables: job `side` (the handle's side table: 2^14 bases, 32 narrow levels — a 2.4 ms latency chain on 64
+// workgroups) takes the first side.blocks workgroups, the main table's the rest. Workgroups are dispatched in index order, so the side
+// table's chain starts first and runs UNDER the main table's thousands of workgroups: no second stream, no dependence on which hardware
+// queue an idle stream happens to sit on (the companion-stream version of this overlap took 4 ms or 23 ms depending on that).
+struct PreJob {
+    const uint64_t *xy;
+    const uint8_t *inf;
+    size_t n;          // bases of the handle (row stride of its table)
+    int levels, dbl_per_level;
+    char *table, *scratch;
+    size_t first, count;  // this launch: bases [first, first + count); the records of base i sit at local index i - first (stride count)
+    unsigned blocks;      // workgroups of this job in the launch
+};
+__global__ void __launch_bounds__(256) msm_precompute_kernel(PreJob side, PreJob main_job) {
+    const bool is_side = blockIdx.x < side.blocks;
+    const PreJob &jb = is_side ? side : main_job;
+    const uint64_t *xy = jb.xy;
+    const uint8_t *inf = jb.inf;
+    const size_t n = jb.n, first = jb.first, count = jb.count;
+    const int levels = jb.levels, dbl_per_level = jb.dbl_per_level;
+    char *table = jb.table, *scratch = jb.scratch;
+    const size_t li = (size_t)(blockIdx.x - (is_side ? 0u : side.blocks)) * blockDim.x + threadIdx.x, i = first + li;
     if (li >= count) return;
     Affine p = affine_load(xy + 8 * i);
     Jac29 a;
@@ -1865,19 +1883,17 @@ static void free_bases(zg_bases_s *b) {
 
 static constexpr size_t SIDE_TABLE_POINTS = 16384;
 
-// prebuilt_small: a side-table handle over the first SIDE_TABLE_POINTS bases that the caller built already (zg_hyperkzg_setup builds it
-// while the remaining powers are still being computed); taken over when this handle wants one, freed otherwise.
+// defer_table: everything but the table (plan, allocations, workspaces) — the caller builds it (a handle's side table is built by the
+// launch that builds its main table: PreJob).
 static int bases_create(const uint64_t *d_xy, const uint8_t *d_inf_in, size_t n, const zg_msm_config *cfg, hipStream_t st,
-                        zg_bases_t *out, zg_bases_s *prebuilt_small = nullptr) {
+                        zg_bases_t *out, bool defer_table = false) {
     if (n >= (1ull << 27)) {
         set_error("msm: at most 2^27 bases per handle");
-        free_bases(prebuilt_small);
         return ZG_ERR_INVALID;
     }
     zg_bases_s *b = new zg_bases_s();
     b->n = n;
     b->device = current_device();
-    b->small = prebuilt_small;  // from here on free_bases(b) releases it too
     int rc = make_plan(n ? n : 1, cfg, b->plan);
     if (rc != ZG_OK) {
         free_bases(b);
@@ -1921,20 +1937,21 @@ static int bases_create(const uint64_t *d_xy, const uint8_t *d_inf_in, size_t n,
         free_bases(b);
         return ZG_ERR_NOMEM;
     }
-    // The side table (narrow windows over the first SIDE_TABLE_POINTS bases, for short MSMs) is a handle of its own whose table build is a
-    // latency chain on 64 workgroups (2.5 ms): it is built on a helper stream WHILE the main table's kernel fills the chip, not after it.
-    const bool want_small = (size_t)p.NB * p.G > 4096 && n > SIDE_TABLE_POINTS && env_int("ZG_MSM_SIDE_TABLE", 1);
-    if (b->small && !want_small) {
-        free_bases(b->small);
-        b->small = nullptr;
+    // The side table (narrow windows over the first SIDE_TABLE_POINTS bases, for short MSMs) is a handle of its own; its table is built by
+    // the first launch of THIS handle's table kernel (PreJob): created here without a table.
+    const bool want_small = !defer_table && (size_t)p.NB * p.G > 4096 && n > SIDE_TABLE_POINTS && env_int("ZG_MSM_SIDE_TABLE", 1);
+    if (want_small) {
+        zg_msm_config small_cfg{8, 0, 0};
+        int src = bases_create(d_xy, d_inf_in, SIDE_TABLE_POINTS, &small_cfg, st, &b->small, true);
+        if (src != ZG_OK) {
+            b->small = nullptr;
+            free_bases(b);
+            return src;
+        }
     }
-    hipStream_t side = want_small && !b->small ? stream_try_acquire() : nullptr;  // an idle stream or none: never a new one
-    hipEvent_t inputs_ready = nullptr;
-    if (side && (hipEventCreateWithFlags(&inputs_ready, hipEventDisableTiming) != hipSuccess || hipEventRecord(inputs_ready, st) != hipSuccess ||
-                 hipStreamWaitEvent(side, inputs_ready, 0) != hipSuccess)) {  // d_xy / d_inf_in may be the product of work queued on st
-        (void)hipGetLastError();
-        stream_release(side, b->device);
-        side = nullptr;
+    if (defer_table) {  // (the inf flags are copied by the caller's launch sequence, on the same stream)
+        *out = b;
+        return ZG_OK;
     }
     // the table kernel's per-level records (see msm_precompute_kernel); without them (allocation refused, ZG_MSM_PRECOMPUTE_V1) the
     // round-4 kernel builds the same table with an inversion per level. Released after the synchronisation below.
@@ -1942,42 +1959,46 @@ static int bases_create(const uint64_t *d_xy, const uint8_t *d_inf_in, size_t n,
     // ... for at most PRE_CHUNK bases at a time (2^21: 2.1 GB of records whatever the handle's size — a 2^24-base handle would ask for 17 GB
     // beside its 16 GiB table, and a fresh allocation of that size costs more than the kernel it serves)
     const size_t pre_chunk = n < PRE_CHUNK ? (n ? n : 1) : PRE_CHUNK;
-    Scratch pre_scratch;
-    if (n && pre_levels && !env_int("ZG_MSM_PRECOMPUTE_V1", 0) && !pre_scratch.alloc(pre_levels * pre_chunk * 144)) (void)hipGetLastError();
+    const bool v1 = env_int("ZG_MSM_PRECOMPUTE_V1", 0) != 0;
+    Scratch pre_scratch, side_scratch;
+    if (n && pre_levels && !v1 && !pre_scratch.alloc(pre_levels * pre_chunk * 144)) (void)hipGetLastError();
+    const zg_bases_s *sm = b->small;
+    if (sm && !v1 && !side_scratch.alloc((size_t)PRE_GROUP * sm->n * 144)) (void)hipGetLastError();
     {
         hipError_t e = hipSuccess;
         if (n) {
             if (d_inf_in) e = hipMemcpyAsync(b->d_inf, d_inf_in, n, hipMemcpyDeviceToDevice, st);
+            if (e == hipSuccess && sm && d_inf_in) e = hipMemcpyAsync(sm->d_inf, d_inf_in, sm->n, hipMemcpyDeviceToDevice, st);
             if (e == hipSuccess) {
-                if (pre_scratch.p)
+                PreJob side{};  // no workgroups unless the side table rides along
+                bool side_pending = sm != nullptr;
+                if (side_pending && side_scratch.p)
+                    side = PreJob{d_xy, sm->d_inf, sm->n, sm->plan.L, sm->plan.c * sm->plan.G, sm->d_table, side_scratch.as<char>(), 0, sm->n, (unsigned)div_up(sm->n, 256)};
+                if (pre_scratch.p || p.L == 1) {
+                    // (a handle without a table, L == 1, needs no records: its job only converts the bases; the side table still rides along)
                     for (size_t first = 0; first < n; first += pre_chunk) {  // the launches reuse the records one after the other (stream order)
                         const size_t count = n - first < pre_chunk ? n - first : pre_chunk;
-                        hipLaunchKernelGGL(msm_precompute_kernel, dim3(div_up(count, 256)), dim3(256), 0, st, d_xy, b->d_inf, n, p.L, p.c * p.G,
-                                           b->d_table, pre_scratch.as<char>(), first, count);
+                        const PreJob mj{d_xy, b->d_inf, n, p.L, p.c * p.G, b->d_table, pre_scratch.as<char>(), first, count, (unsigned)div_up(count, 256)};
+                        hipLaunchKernelGGL(msm_precompute_kernel, dim3(side.blocks + mj.blocks), dim3(256), 0, st, side, mj);
+                        if (side.blocks) side_pending = false;
+                        side = PreJob{};
                     }
-                else
+                } else {
                     hipLaunchKernelGGL(msm_precompute_v1_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, d_xy, b->d_inf, n, p.L, p.c * p.G,
                                        b->d_table);
+                }
+                if (side_pending)  // no records for it (allocation refused / ZG_MSM_PRECOMPUTE_V1): the round-4 kernel, on its own
+                    hipLaunchKernelGGL(msm_precompute_v1_kernel, dim3(div_up(sm->n, 256)), dim3(256), 0, st, d_xy, sm->d_inf, sm->n, sm->plan.L,
+                                       sm->plan.c * sm->plan.G, sm->d_table);
                 e = hipGetLastError();
             }
         }
-        int src = ZG_OK;
-        if (want_small && !b->small) {
-            zg_msm_config small_cfg{8, 0, 0};
-            src = bases_create(d_xy, d_inf_in, SIDE_TABLE_POINTS, &small_cfg, side ? side : st, &b->small);  // returns when ITS stream is drained
-        }
         hipError_t e2 = hipStreamSynchronize(st);  // also on failure: nothing of this handle may still be in flight when it is freed
-        if (side) stream_release(side, b->device);
-        if (inputs_ready) (void)hipEventDestroy(inputs_ready);
         if (e == hipSuccess) e = e2;
         if (e != hipSuccess) {
             set_error(std::string("msm table build: ") + hipGetErrorString(e));
             free_bases(b);
             return ZG_ERR_HIP;
-        }
-        if (src != ZG_OK) {
-            free_bases(b);
-            return src;
         }
     }
     *out = b;
@@ -3078,17 +3099,6 @@ int zg_hyperkzg_setup(const uint64_t base_xy[8], const uint64_t tau[4], size_t n
     Scratch s_base(64), s_rows((size_t)fb.W * 144), s_tab((size_t)n_rows * 64), s_pw(3 * 256 * 32), s_sc(nn * 32), s_out(nn * 64), s_inf(nn);
     if (!s_base.p || !s_rows.p || !s_tab.p || !s_pw.p || !s_sc.p || !s_out.p || !s_inf.p) return ZG_ERR_NOMEM;
     SyncGuard sync(st);
-    hipStream_t side = nullptr;
-    hipEvent_t head_ready = nullptr;
-    zg_bases_s *small = nullptr;
-    struct Cleanup {  // what an early return would leave behind
-        hipEvent_t &ev;
-        zg_bases_s *&small;
-        ~Cleanup() {
-            if (ev) (void)hipEventDestroy(ev);
-            if (small) free_bases(small);
-        }
-    } cleanup{head_ready, small};
     if (n) {
         TauArg ta;
         for (int i = 0; i < 4; i++) {
@@ -3098,39 +3108,16 @@ int zg_hyperkzg_setup(const uint64_t base_xy[8], const uint64_t tau[4], size_t n
         ZG_HIP(hipMemcpyAsync(s_base.p, base_xy, 64, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(tau_tables_kernel, dim3(1), dim3(64), 0, st, ta, s_pw.as<uint64_t>());
         hipLaunchKernelGGL(tau_powers_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, s_pw.as<uint64_t>(), n, s_sc.as<uint64_t>());
-        hipLaunchKernelGGL(fb_window_bases_kernel, dim3(1), dim3(4 * fb.W), 0, st, s_base.as<uint64_t>(), fb.c, s_rows.as<char>());
+            hipLaunchKernelGGL(fb_window_bases_kernel, dim3(1), dim3(4 * fb.W), 0, st, s_base.as<uint64_t>(), fb.c, s_rows.as<char>());
         hipLaunchKernelGGL(fb_table_rows_kernel, dim3(div_up(n_rows, 256)), dim3(256), 0, st, s_rows.as<char>(), n_rows, fb.c, fb.rows, s_tab.as<char>());
-        // The handle's side table covers the first SIDE_TABLE_POINTS powers and its build is a 2.5 ms latency chain on 64 workgroups: those
-        // powers are computed first, and the side handle is built on a helper stream while the remaining powers (2.9 ms at 2^20, the whole
-        // chip) are still being multiplied out.
-        const size_t head = n > SIDE_TABLE_POINTS && env_int("ZG_MSM_SIDE_TABLE", 1) ? SIDE_TABLE_POINTS : 0;
-        if (head) {
-            hipLaunchKernelGGL(fb_mul_kernel, dim3(div_up(head, 256)), dim3(256), 0, st, s_tab.as<char>(), s_sc.as<uint64_t>(), head, fb.c, fb.W, fb.rows,
-                               s_out.as<uint64_t>(), s_inf.as<uint8_t>());
-            side = stream_try_acquire();  // an idle stream or none (never a new one); on the library stream's own hardware queue it runs behind it
-            if (side && (hipEventCreateWithFlags(&head_ready, hipEventDisableTiming) != hipSuccess || hipEventRecord(head_ready, st) != hipSuccess ||
-                         hipStreamWaitEvent(side, head_ready, 0) != hipSuccess)) {
-                (void)hipGetLastError();
-                stream_release(side, current_device());
-                side = nullptr;
-            }
-        }
-        hipLaunchKernelGGL(fb_mul_kernel, dim3(div_up(n - head, 256)), dim3(256), 0, st, s_tab.as<char>(), s_sc.as<uint64_t>() + 4 * head, n - head,
-                           fb.c, fb.W, fb.rows, s_out.as<uint64_t>() + 8 * head, s_inf.as<uint8_t>() + head);
+        hipLaunchKernelGGL(fb_mul_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, s_tab.as<char>(), s_sc.as<uint64_t>(), n, fb.c, fb.W, fb.rows,
+                           s_out.as<uint64_t>(), s_inf.as<uint8_t>());
         ZG_HIP(hipGetLastError());
-        if (side) {
-            zg_msm_config small_cfg{8, 0, 0};
-            int src = bases_create(s_out.as<uint64_t>(), nullptr, SIDE_TABLE_POINTS, &small_cfg, side, &small);  // returns when the side stream is drained
-            stream_release(side, current_device());
-            if (src != ZG_OK) return src;
-        }
-        if (out_xy) ZG_HIP(hipMemcpyAsync(out_xy, s_out.p, n * 64, hipMemcpyDeviceToHost, st));
+            if (out_xy) ZG_HIP(hipMemcpyAsync(out_xy, s_out.p, n * 64, hipMemcpyDeviceToHost, st));
         if (out_inf) ZG_HIP(hipMemcpyAsync(out_inf, s_inf.p, n, hipMemcpyDeviceToHost, st));
     }
     // tau^i is never 0 mod r and the base has prime order: no power is the identity, so the handle carries no infinity flags
-    zg_bases_s *prebuilt = small;
-    small = nullptr;  // bases_create owns it from the call on, whatever it returns
-    int rc = bases_create(s_out.as<uint64_t>(), nullptr, n, cfg, st, out, prebuilt);  // copies the points into the handle's table
+    int rc = bases_create(s_out.as<uint64_t>(), nullptr, n, cfg, st, out);  // copies the points into the handle's table (and builds the side table beside it)
     hipError_t e = hipStreamSynchronize(st);
     sync.dismiss();
     if (rc != ZG_OK) return rc;

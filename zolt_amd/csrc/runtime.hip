@@ -60,18 +60,6 @@ hipStream_t stream_acquire() {
     if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
     return st;
 }
-// An idle stream if the free list holds one, nullptr otherwise — for work that MAY run beside the caller's but must not create a stream:
-// HIP hands its hardware queues out in creation order, and a stream created here would move every stream the caller creates afterwards
-// to another queue (bench.py's three MSM streams lost 12 % when the library created one more stream ahead of them).
-hipStream_t stream_try_acquire() {
-    int d = current_device();
-    if (d < 0 || d >= ZG_MAX_DEVICES) return nullptr;
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (g_idle_streams[d].empty()) return nullptr;
-    hipStream_t st = g_idle_streams[d].back();
-    g_idle_streams[d].pop_back();
-    return st;
-}
 void stream_release(hipStream_t st, int device) {
     if (!st || device < 0 || device >= ZG_MAX_DEVICES) return;
     std::lock_guard<std::mutex> lk(g_mu);

@@ -45,11 +45,13 @@ struct HyperKZG {
     }
     // commit to a polynomial whose evaluations are F.fromU64 of machine words (commitBytecode / commitMemory / commitRegisters,
     // src/zkvm/mod.zig:1518-1617 build exactly such vectors): the words cross as they are
-    static Commitment commitU64(const SetupParams &params, const std::vector<uint64_t> &values) {
-        if (values.empty()) return Commitment{AffinePoint::identity()};
-        size_t n = values.size() < srsLen(params) ? values.size() : srsLen(params);
-        return Commitment{params.device->msmU64(values.data(), n)};
+    static Commitment commitU64(const SetupParams &params, const uint64_t *values, size_t count) {
+        if (count == 0) return Commitment{AffinePoint::identity()};
+        size_t n = count < srsLen(params) ? count : srsLen(params);
+        return Commitment{params.device->msmU64(values, n)};
     }
+    static Commitment commitU64(const SetupParams &params, const std::vector<uint64_t> &values) { return commitU64(params, values.data(), values.size()); }
+    static Commitment commitU64(const SetupParams &params, const PinnedWords &values) { return commitU64(params, values.data(), values.size()); }
     struct Proof {  // :155-167
         std::vector<Commitment> quotient_commitments;
         Fr final_eval;

@@ -35,14 +35,17 @@ public:
             check(zg_sumcheck_open_dev(d_tab.u64(), eq_evals_len, ZG_SC_HIGH_HALF, nullptr, &s_), "zg_sumcheck_open_dev");
             check(zg_sync(), "zg_sync");  // the session copied the table: the staging buffer may go
         }
-        std::vector<uint64_t> words(2 * (n_ ? n_ : 1), 0);
+        // (low word, high word) per index, assembled in the thread's pinned staging buffer: no 16 MB vector to zero-fill and page in
+        const size_t n_words = 2 * (n_ ? n_ : 1);
+        uint64_t *words = static_cast<uint64_t *>(PinnedStage::get(n_words * 8));
+        words[0] = words[1] = 0;
         for (size_t j = 0; j < n_; j++) {
             words[2 * j] = (uint64_t)lookup_indices[j];
             words[2 * j + 1] = (uint64_t)(lookup_indices[j] >> 64);
         }
         try {
-            d_idx_.alloc(words.size() * 8);
-            check(zg_memcpy_h2d(d_idx_.p, words.data(), words.size() * 8), "zg_memcpy_h2d");
+            d_idx_.alloc(n_words * 8);
+            check(zg_memcpy_h2d(d_idx_.p, words, n_words * 8), "zg_memcpy_h2d");
             current_claim = total();  // :166-171
         } catch (...) {
             zg_sumcheck_close(s_);
