@@ -134,6 +134,26 @@ pub const weighted_colsum_min_entries: usize = 4096; // 86 us against 149 us at 
 // (`gpu: gpu.SrsHandle = .{}`): HyperKZG.setup / SRS loaders call init(), SetupParams.deinit calls deinit(). One table on one
 // GPU, or — when the process drives several (ZOLT_GPU_DEVICES) — one shard per GPU.
 // ---------------------------------------------------------------------------------------------------------------
+/// Machine words in pinned host memory (zg_host_alloc): where a prover keeps the word vectors it commits to (commitWords) and any other
+/// large per-proof input. Copies from it run at link rate whatever the page state of the process; allocate once, refill per proof.
+pub const PinnedWords = struct {
+    ptr: ?[*]u64 = null,
+    len: usize = 0,
+
+    pub fn init(n: usize) PinnedWords {
+        var p: ?*anyopaque = null;
+        if (!enabled() or n == 0 or ffi.zg_host_alloc(n * 8, &p) != ffi.OK or p == null) return .{};
+        return .{ .ptr = @ptrCast(@alignCast(p.?)), .len = n };
+    }
+    pub fn slice(self: PinnedWords) []u64 {
+        return if (self.ptr) |p| p[0..self.len] else &[_]u64{};
+    }
+    pub fn deinit(self: *PinnedWords) void {
+        if (self.ptr) |p| _ = ffi.zg_host_free(@ptrCast(p));
+        self.* = .{};
+    }
+};
+
 pub const SrsHandle = struct {
     bases: ffi.Bases = null,
     sharded: ffi.ShardedBases = null,
@@ -181,6 +201,8 @@ pub const SrsHandle = struct {
         return affineFrom(Affine, &xy, inf);
     }
 
+    /// `words` should live in pinned memory that is kept across proofs (`PinnedWords` below): a fresh pageable slice per call is pinned on
+    /// the fly and unpinned again by the HIP runtime — usually cheap, 10-15 ms per proof when the allocator's address reuse is unlucky.
     /// commitBytecode / commitMemory / commitRegisters (src/zkvm/mod.zig:1518-1617) build `poly[i] = F.fromU64(word_i)` and commit to it:
     /// here the machine words cross as they are (8 bytes each, no host fromU64 per evaluation) and the conversion runs on the device.
     /// The result equals commit(evals) for evals[i] = F.fromU64(words[i]). null = run the Zig body.
