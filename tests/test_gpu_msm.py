@@ -525,6 +525,33 @@ def test_alternate_code_paths(zl, ob, gm, env, monkeypatch):
     _check(zl, ob, gm[:n], None, sc, window_bits=16, precompute_levels=2)
 
 
+@pytest.mark.parametrize("env", [{"ZG_MSM_PRECOMPUTE_V1": "1"}, {"ZG_MSM_ROWCOL_WAVE_FROM": "1"}, {"ZG_MSM_ROWCOL_WAVE_FROM": "0"},
+                                 {"ZG_MSM_ROWS_SHARED_TAIL": "0"}, {"ZG_MSM_SIDE_TABLE": "0"}])
+def test_round5_alternate_code_paths(zl, ob, gm, env, monkeypatch):
+    """the round-4 table kernel (an inversion per level, no records), row / column sums by one wave per row for a single bucket set and
+    never, a reduction per row of a table-less batch, no side table: every one of them the same bytes — on a handle with its table
+    (20 000 bases: the side table rides in the table kernel's launch), on one planned for a few uses, for single MSMs and batches."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    n = 20000
+    sc = _scalars(ob, 779, n)
+    want, winf = ob.msm_g1(gm[:n], None, sc)
+    for uses in (0, 2):
+        b = zl.Bases.upload(gm[:n], None, expected_uses=uses)
+        got, ginf = b.msm(sc)
+        assert ginf == winf and np.array_equal(got, want), (env, uses)
+        short = 3000  # a prefix the side table serves (when there is one)
+        g2, i2 = b.msm(sc[:short], n=short)
+        w2, wi2 = ob.msm_g1(gm[:short], None, sc[:short])
+        assert i2 == wi2 and np.array_equal(g2, w2), (env, uses, "short")
+        rows = [_scalars(ob, 780 + j, n) for j in range(3)]
+        outs, infs = b.msm_batch(rows, n=n)
+        for j in range(3):
+            wj, wij = ob.msm_g1(gm[:n], None, rows[j])
+            assert infs[j] == wij and np.array_equal(outs[j], wj), (env, uses, "batch", j)
+        b.free()
+
+
 def test_affine_point_add_and_double(zl, ob, gm):
     """AffinePoint.add / double (src/msm/mod.zig:74-138) as zg_g1_affine_add_batch: generic pairs, P + P (the doubling branch),
     P + (-P) (identity), identity operands, and the reference's KAT 'generator affine-double == Jacobian-double'
