@@ -17,11 +17,11 @@ for _ in range(8):
     t0 = time.perf_counter(); h.msm(sc); t.append((time.perf_counter() - t0) * 1e3)
 print("long-lived vector      ms", [round(x, 2) for x in t])
 keep, t = [], []
-for _ in range(8):
+for _ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 8):
     a = sc.copy()  # a new allocation at a new address (the old ones are kept)
     keep.append(a)
     t0 = time.perf_counter(); h.msm(a); t.append((time.perf_counter() - t0) * 1e3)
-print("fresh vector per call  ms", [round(x, 2) for x in t])
+print("fresh vector per call  ms", [round(x, 2) for x in t], "mean", round(float(np.mean(t)), 2), "median", round(float(np.median(t)), 2))
 t = []
 for a in keep:
     t0 = time.perf_counter(); h.msm(a); t.append((time.perf_counter() - t0) * 1e3)
