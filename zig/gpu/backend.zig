@@ -530,6 +530,20 @@ pub fn SumcheckSession(comptime F: type) type {
             }
             return self;
         }
+        /// A session over a table that already sits in device memory (`d_table`: `len` elements, e.g. Az / Bz materialised by
+        /// zg_fr_rows_affine_records_dev). `borrow`: no copy — the session reads the caller's table in place until its first bind has run
+        /// (zg_sumcheck_open_dev_borrowed: the caller keeps it alive and unchanged until a later call on the session has returned), its
+        /// own buffers hold the folds only. One device only.
+        pub fn openDevice(d_table: [*]const u64, len: usize, layout: c_int, borrow: bool) Error!Self {
+            var self: Self = .{};
+            if (!enabled() or n_devices > 1) return Error.GpuFailure;
+            const rc = if (borrow)
+                ffi.zg_sumcheck_open_dev_borrowed(d_table, len, layout, null, &self.handle)
+            else
+                ffi.zg_sumcheck_open_dev(d_table, len, layout, null, &self.handle);
+            if (rc != ffi.OK) return Error.GpuFailure;
+            return self;
+        }
         /// nextRound (:69-109): coefficients [g(0), g(1) - g(0)]
         pub fn roundCoeffs(self: *Self) Error![2]F {
             var g0: F = undefined;
