@@ -177,11 +177,23 @@ static Timeline prove_once(const ProveCase &pc, bool emit) {
     // ---- the three commitments, from machine words (zg_msm_g1_u64)
     // (in pinned memory, as a shim would hold them: PinnedWords — a pageable vector per proof is pinned on the fly and unpinned again by
     // the HIP runtime, usually cheaply, by 10-15 ms when the process's address reuse changes)
-    PinnedWords bc(pc.bytecode.size() < 2 ? 2 : ceil_pow2(pc.bytecode.size())), mem(pc.accesses.size() < 2 ? 2 : ceil_pow2(pc.accesses.size())),
-        reg(pc.trace.size() < 2 ? 2 : ceil_pow2(pc.trace.size()));
-    for (size_t i = 0; i < pc.bytecode.size(); i++) bc[i] = pc.bytecode[i];
-    for (size_t i = 0; i < pc.accesses.size(); i++) mem[i] = pc.accesses[i].value;
-    for (size_t i = 0; i < pc.trace.size(); i++) reg[i] = pc.trace[i].rd_value;
+    PinnedWords bc(pc.bytecode.size() < 2 ? 2 : ceil_pow2(pc.bytecode.size()), false), mem(pc.accesses.size() < 2 ? 2 : ceil_pow2(pc.accesses.size()), false),
+        reg(pc.trace.size() < 2 ? 2 : ceil_pow2(pc.trace.size()), false);
+    {  // every word is written exactly once (value or zero padding), long vectors by several host threads
+        auto fill = [](uint64_t *dst, size_t total, size_t live, auto value) {
+            const size_t T = total >= (size_t(1) << 16) ? std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 8) : 1;
+            std::vector<std::thread> pool;
+            for (size_t t = 0; t < T; t++) {
+                const size_t a = total * t / T, b = total * (t + 1) / T;
+                auto work = [=] { for (size_t i = a; i < b; i++) dst[i] = i < live ? value(i) : 0; };
+                if (T == 1) work(); else pool.emplace_back(work);
+            }
+            for (auto &th : pool) th.join();
+        };
+        fill(bc.data(), bc.size(), pc.bytecode.size(), [&](size_t i) { return (uint64_t)pc.bytecode[i]; });
+        fill(mem.data(), mem.size(), pc.accesses.size(), [&](size_t i) { return pc.accesses[i].value; });
+        fill(reg.data(), reg.size(), pc.trace.size(), [&](size_t i) { return pc.trace[i].rd_value; });
+    }
     tl.lap("commit: host builds the three u64 polynomials", "host");
     HyperKZG::Commitment c_bc = HyperKZG::commitU64(pk, bc);
     tl.lap("commitBytecode (MSM over machine words)", "h2d+kernels");
