@@ -3285,7 +3285,10 @@ int zg_sumcheck_close(zg_sc_t s) {
     (void)hipStreamSynchronize(s->st);
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
-        if (g_pool.size() < 4) {
+        // (twelve: a proof opens sessions of very different lengths — three of 2^25 entries in Stage 1, then 2^16 ... 2^20 — and a pooled
+        // session only serves lengths within a factor of four of its own; with four slots the large ones held the pool and every other
+        // session of a proof was created and destroyed again, a pinned mailbox allocation each time)
+        if (g_pool.size() < 12) {
             g_pool.push_back(s);
             return ZG_OK;
         }
