@@ -69,6 +69,36 @@ def test_hyperkzg_setup_commit_open(env):
     params.deinit()
 
 
+def test_hyperkzg_key_planned_for_one_proof(env):
+    """HyperKZG.setup(n, expected_uses = 1): the key of a prover that proves once (no table of multiples) — the same powers of tau, and
+    the same commitments (field elements and machine words), batch commitments and opening as the key that lives on, at a size where
+    the two handles take different plans (20 000 powers: 17-bit windows with a table against table-less windows + the side table)."""
+    api, lib, ob = env
+    n = 20000
+    once, keeps = api.HyperKZG.setup(n, expected_uses=1), api.HyperKZG.setup(n)
+    assert np.array_equal(once.powers_of_tau_g1, keeps.powers_of_tau_g1) and np.array_equal(once.infinity, keeps.infinity)
+    assert once._dev.plan()[2] == 1 and keeps._dev.plan()[2] > 1
+    ev = _rand(ob, 1201, n)
+    want = ob.hyperkzg_commit(keeps.powers_of_tau_g1, keeps.infinity, ev)
+    for params in (once, keeps):
+        c, ci = api.HyperKZG.commit(params, ev)
+        assert ci == want[1] and np.array_equal(c, want[0])
+    words = U.splitmix64(1202, n)
+    a, b = api.HyperKZG.commitU64(once, words), api.HyperKZG.commitU64(keeps, words)
+    assert a[1] == b[1] and np.array_equal(a[0], b[0])
+    polys = [_rand(ob, 1210 + k, n) for k in range(3)]
+    for (x, xi), (y, yi) in zip(api.HyperKZG.batchCommit(once, polys), api.HyperKZG.batchCommit(keeps, polys)):
+        assert xi == yi and np.array_equal(x, y)
+    v = 14
+    ev = _rand(ob, 1203, 1 << v)
+    pt = _rand(ob, 1204, v)
+    q1, f1 = api.HyperKZG.open(once, ev, pt, np.zeros(4, dtype=np.uint64))
+    q2, f2 = api.HyperKZG.open(keeps, ev, pt, np.zeros(4, dtype=np.uint64))
+    assert np.array_equal(f1, f2) and all(i1 == i2 and np.array_equal(x1, x2) for (x1, i1), (x2, i2) in zip(q1, q2))
+    once.deinit()
+    keeps.deinit()
+
+
 @pytest.mark.parametrize("srs_n,lens,v", [(64, [64, 64, 64], 6), (64, [32, 16, 40, 0], 5), (16, [8], 3), (64, [64, 64], 0),
                                           (2048, [2048, 2048, 1000], 11), (64, [4, 4], 5), (64, [], 3), (2048, [1024, 1024], 10)])
 def test_hyperkzg_batch_open(env, srs_n, lens, v):
