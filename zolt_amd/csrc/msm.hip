@@ -153,8 +153,8 @@ constexpr int PRE_GROUP = 7;
 constexpr size_t PRE_CHUNK = (size_t)1 << 21;  // bases per launch of the table kernel (bounds its records)
 // A launch carries up to TWO tables: job `side` (the handle's side table: 2^14 bases, 32 narrow levels — a 2.4 ms latency chain on 64
 // workgroups) takes the first side.blocks workgroups, the main table's the rest. Workgroups are dispatched in index order, so the side
-// table's chain starts first and runs UNDER the main table's thousands of workgroups: no second stream, no dependence on which hardware
-// queue an idle stream happens to sit on (the companion-stream version of this overlap took 4 ms or 23 ms depending on that).
+// table's chain starts first and runs UNDER the main table's thousands of workgroups: no second stream (a stream created for it would
+// move the caller's later streams onto other hardware queues, an idle one may share the launch stream's queue and run behind it).
 struct PreJob {
     const uint64_t *xy;
     const uint8_t *inf;
