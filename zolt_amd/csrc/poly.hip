@@ -247,10 +247,11 @@ __global__ void __launch_bounds__(256) fr_dot_kernel(const uint64_t *a, const ui
 // round sums of a table: HIGH: g0 = sum t[0..h), g1 = sum t[h..2h);  LOW: g0 = sum t[2i], g1 = sum t[2i+1]
 // (publication of a round's pair to the pinned host mailbox: publish_seq, sc_common.hip.h)
 
-// ---- runSumcheck resident on the device (src/subprotocols/mod.zig:302-354): the toy verifier (:165-243) runs as the
-// last step of the kernel that produced a round's sums, so no round needs the host. `res` (u64 words):
-//   [0,4) claim | [4, 4+8v) rounds: c0 || c1 | [.., +4v) challenges | +4 final_eval | +1 status | +4 running claim |
-//   +4 running challenge.   status: bit 0 = result (verifier.claim == final_eval), bits 8.. = 1 + first failed round
+// ---- runSumcheck resident on the device (src/subprotocols/mod.zig:302-354): the toy verifier (:165-243) runs on the device (until
+// round 5 as the last step of the kernel that produced a round's sums, since then as the first step of the next one), so no round needs
+// the host. `res` (u64 words):
+//   [0,4) claim | [4, 4+8v) rounds: c0 || c1 | [.., +4v) challenges | +4 final_eval | +1 status | +4 running claim before an even round |
+//   +4 running claim before an odd round.   status: bit 0 = result (verifier.claim == final_eval), bits 8.. = 1 + first failed round
 // Round 5: the verifier step of round k no longer closes the kernel that produced round k's sums (block pairs -> arrival counter ->
 // the last block adds them up -> verifier step: three dependent round trips, ~4 us at the end of every launch) — it OPENS the next
 // kernel: a producer leaves its block pairs in `partials` with plain stores and ends; every block of the consumer adds the nb_prev pairs
