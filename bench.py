@@ -12,10 +12,13 @@ point family, src/bench.zig:261-268) and device-resident uniform scalars (splitm
 sharded in ParallelMSM's contiguous chunks (src/msm/mod.zig:609), each rank computes its Jacobian
 partial, the partials are all-gathered over RCCL and combined on the device (strong scaling).
 
-Prints ONE JSON line on rank 0 with the driver contract fields plus
+Rank 0 prints ONE compact JSON line (< 4 KB, the LAST line of stdout: compact_line below) with the driver contract fields plus
   roofline     — dominant kernel (msm_accumulate): algorithmic bytes / HIP-event kernel time vs 8 TB/s
   cpu_baseline — the C restatement of the reference's pippengerMSM timed on this box's host cores
-  extra        — per-kernel times, 2^22 single-GPU figure, sumcheck rounds/s (config 3)
+  also         — scalars only: the 2^22 figure, the table-less figure, sumcheck rounds/s (config 3) with their roofline fractions
+Everything else (per-kernel times, notes, the prove path, the sharded legs: the old `extra` object) goes to the side file
+bench_extra.json in the cwd (copy: profiles/bench_extra_last.json), like the reference's harness, which prints one short result per size
+(src/bench.zig:243-287). `--full-line` (internal: the child processes of the extras) prints the full object instead.
 """
 import argparse
 import json
@@ -121,6 +124,102 @@ def closed_form_scalar(raw, start):
     return tot % R_MOD
 
 
+COMPACT_LIMIT = 4096  # bytes: the driver's parser reads the last stdout line; round 5's 22 KB line outgrew its capture window
+
+
+def _r(x, digits=6):
+    """floats at 6 significant digits (the line is a summary; the side file keeps full precision)"""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}")
+    return x
+
+
+def _get(d, *path):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d
+
+
+def compact_line(out, extra_file="bench_extra.json"):
+    """The line the driver parses: the contract's keys, `config` / `roofline` / `cpu_baseline` reduced to numbers and short names, and the
+    north_star's other figures as scalars under `also`. Built from the full object `out` (which goes to `extra_file` unshortened)."""
+    cfg, roof, cpu, ex = out.get("config", {}), out.get("roofline", {}), out.get("cpu_baseline"), out.get("extra", {})
+    be = cfg.get("breakeven_msms") or {}
+    line = {k: _r(out.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                        "vs_baseline", "dtype", "data")}
+    line["config"] = {k: _r(cfg.get(k)) for k in ("workload", "points", "points_per_gpu", "msms_per_step", "ms_per_msm", "streams", "window_bits",
+                                                   "windows", "table_levels", "table_build_ms", "table_bytes")}
+    line["config"]["mode"] = cfg.get("mode")
+    line["config"]["breakeven_msms"] = [_r(be.get("pipelined")), _r(be.get("one_at_a_time"))]  # [pipelined, one at a time]
+    line["config"]["collective_ranks"] = cfg.get("collective_ranks")
+    line["config"]["sharding"] = "single GPU" if out.get("n_gpus", 1) == 1 else "contiguous chunks, all-gather of 96 B partials, device combine"
+    line["config"]["bit_exact_check"] = "closed form via scalarMul, every timed MSM"
+    line["roofline"] = {k: _r(roof.get(k)) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch",
+                                                      "launches_per_msm", "avg_launch_ms", "rocprofv3_avg_launch_ms", "frac_at_rocprofv3_duration")}
+    line["roofline"]["valu_issue_frac"] = _r(_get(roof, "valu_issue_measured_rates", "frac_from_pmc_count") or _get(roof, "valu_issue", "frac"))
+    line["roofline"]["counters"] = os.path.relpath(PMC_FILE, ROOT) if roof.get("traffic") is not None else None
+    line["roofline"]["binds"] = "VALU issue (integer Fp products), not HBM"
+    if cpu is not None:
+        line["cpu_baseline"] = {k: _r(cpu.get(k)) for k in ("value", "unit", "cores", "kind", "sample", "seconds_per_msm", "result_checked",
+                                                             "host_cores_available")}
+        line["cpu_baseline"]["seconds_per_msm_2e22"] = _r(_get(cpu, "sizes", "2^22", "seconds_per_msm"))
+        line["cpu_baseline"]["parallel_msm_per_s"] = _r(_get(cpu, "parallel_msm", "value"))
+        line["cpu_baseline"]["parallel_threads"] = _get(cpu, "parallel_msm", "threads")
+        line["cpu_baseline"]["sumcheck_v20_rounds_per_s"] = _r(_get(cpu, "sumcheck_v20", "rounds_per_s"))
+    sc = ex.get("sumcheck_v20", {})
+    also = {
+        "msm_2e22_per_s": _r(_get(ex, "msm_2^22_single_gpu", "value")), "msm_2e22_ms": _r(_get(ex, "msm_2^22_single_gpu", "ms_per_msm")),
+        "msm_2e22_roofline_frac": _r(_get(ex, "msm_2^22_single_gpu", "roofline", "frac")),
+        "msm_table_less_per_s": _r(_get(ex, "msm_no_precompute", "value")), "msm_table_less_ms": _r(_get(ex, "msm_no_precompute", "ms_per_msm")),
+        "msm_host_scalars_ms": _r(ex.get("msm_host_scalars_ms")),
+        "sumcheck_rounds_per_s": _r(sc.get("rounds_per_s")), "sumcheck_ms": _r(sc.get("ms_per_sumcheck")),
+        "sumcheck_roofline_frac": _r(_get(sc, "roofline", "frac")),
+        "sumcheck_device_resident_rounds_per_s": _r(_get(ex, "sumcheck_v20_device_resident", "rounds_per_s")),
+        "sumcheck_device_resident_roofline_frac": _r(_get(ex, "sumcheck_v20_device_resident", "roofline", "frac")),
+        "sumcheck_host": "compiled C++ loop over the C ABI" if "python_binding" in sc else "python binding",
+        "eq_table_roofline_frac": _r(_get(sc, "kernel_rooflines", "eq_main_kernel", "frac")),
+        "fold_round0_roofline_frac": _r(_get(sc, "kernel_rooflines", "sc_fold_kernel_round0", "frac")),
+        "fold_2e24_TBps": _r(_get(ex, "fold_2^24_by_challenge_kind", "narrow_TBps")),
+        "hyperkzg_open_v20_resident_ms": _r(_get(ex, "hyperkzg_open", "v20_resident_ms")),
+        "prove_path_ms": _r(_get(ex, "prove_path", "total_ms")), "prove_path_single_use_key_ms": _r(_get(ex, "prove_path_single_use_key", "total_ms")),
+        "msm_2e22_sharded_per_s": _r(_get(ex, "msm_2^22_sharded", "value")),
+        "sumcheck_sharded_rounds_per_s": _r(_get(ex, "sumcheck_v20_sharded", "rounds_per_s")),
+    }
+    line["also"] = {k: v for k, v in also.items() if v is not None}
+    line["extra_file"] = extra_file
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) >= COMPACT_LIMIT:  # cannot happen with the fixed key set above; never let a long string take the line down
+        line.pop("also")
+        text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < COMPACT_LIMIT, len(text)
+    return text
+
+
+def write_side_file(out, name="bench_extra.json"):
+    """the full object, unshortened: cwd/bench_extra.json and profiles/bench_extra_last.json (rank 0 only). Returns the paths written."""
+    paths = []
+    for path in (os.path.join(os.getcwd(), name), os.path.join(ROOT, "profiles", "bench_extra_last.json")):
+        try:
+            with open(path, "w") as fh:
+                json.dump(out, fh, indent=1)
+            paths.append(path)
+        except OSError:
+            pass
+    return paths
+
+
+def emit(out, full_line=False):
+    """rank 0's last act: side file, then the one line (flushed; nothing is printed after it)"""
+    if full_line:
+        print(json.dumps(out), flush=True)
+        return
+    write_side_file(out)
+    sys.stdout.flush()
+    print(compact_line(out), flush=True)
+
+
 RANK_LOG_DIR = os.environ.get("ZOLT_BENCH_LOG_DIR") or os.path.join(ROOT, "gpurun_out", "bench_ranks")
 STALL_LIMIT_S = float(os.environ.get("ZOLT_BENCH_STALL_S", "120"))
 
@@ -135,6 +234,7 @@ class Watchdog:
     def __init__(self, rank, world):
         import threading
         self.rank, self.world, self.phase, self.limit = rank, world, "start", STALL_LIMIT_S
+        self.child = None  # the extras' running child process (run_child), ended before this process is
         self.last = time.monotonic()
         self.log = self.beat_path = None
         try:
@@ -180,6 +280,9 @@ class Watchdog:
                             fh.flush()
                         except (OSError, ValueError):
                             pass
+                ch = self.child
+                if ch is not None and ch.poll() is None:
+                    ch.kill()  # exactly the child this process started
                 os._exit(3)
 
 
@@ -321,6 +424,8 @@ def main():
     ap.add_argument("--cpu-baseline-2e22", action="store_true",
                     help="measure the single-thread CPU baseline at 2^22 points IN FULL (~45 s) and write profiles/cpu_baseline_2e22_full.json")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--full-line", action="store_true",
+                    help="internal (child processes of the extras): print the full object on one line instead of the compact line + side file")
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--precompute", type=int, default=0)
     ap.add_argument("--streams", type=int, default=0,
@@ -508,6 +613,11 @@ def main():
         ones = torch.ones(1, dtype=torch.int64, device=dev if dist_backend == "nccl" else "cpu")
         dist.all_reduce(ones)
         collective_ranks = {"backend": "rccl" if dist_backend == "nccl" else dist_backend, "ranks": int(ones.item())}
+        if collective_ranks["ranks"] != world:  # before any timed region: a group that does not span the N ranks would time something else
+            msg = f"bench.py --gpus {world}: rank {rank} sees a {collective_ranks['backend']} group of {collective_ranks['ranks']} ranks, expected {world}"
+            if rank == 0:
+                print(json.dumps({"error": msg, "rank": rank}), flush=True)
+            raise SystemExit(msg)
     per_step = max(1, args.msms_per_step)
     m = run_size(args.logn, args.steps, args.warmup, per_step)
     n, n_loc, elapsed, prof, setup_s = m["n"], m["n_loc"], m["elapsed"], m["prof"], m["setup_s"]
@@ -545,7 +655,7 @@ def main():
         host_pg = dist.new_group(backend="gloo") if use_dist and world > 1 else None
         wd.beat("single-process child (rank 0 runs it, the others wait on a host barrier)", limit=400)
         if rank == 0:
-            single_proc = single_process_child(min(world, torch.cuda.device_count()))  # (the gloo debugging mode shares one GPU)
+            single_proc = single_process_child(min(world, torch.cuda.device_count()), wd=wd)  # (the gloo debugging mode shares one GPU)
         if host_pg is not None:
             dist.barrier(group=host_pg)
 
@@ -576,6 +686,7 @@ def main():
         "vs_baseline": None, "dtype": "u32", "data": "synthetic",
         "config": {"workload": f"msm_g1_2^{args.logn}", "points": n, "points_per_gpu": n_loc, "msms_per_step": per_step,
                    "ms_per_msm": ms_per_msm,
+                   "mode": "table-less (expected_uses = 1)" if args.precompute == 1 else "precomputed table of multiples",
                    "arithmetic": "256-bit Montgomery field elements as 32-bit limbs (9x29-bit lazy limbs in the MSM), integer only",
                    "bases": "(i+1)*G resident in HBM (table of 2^(c*l)*P_i built once at upload, like an SRS)", "scalars": "uniform mod r, splitmix64 seed 0x5A4F4C54, resident in HBM",
                    "sharding": f"contiguous chunks + {dist_backend} all-gather of the step's Jacobian partials (96 bytes per MSM, one exchange per stream and step)" if world > 1 else "single GPU",
@@ -651,7 +762,7 @@ def main():
         out["extra"]["msm_2^22_sharded"] = sharded_22
     if not args.no_extra and world == 1:
         # the host-buffer entry point (what an unmodified MSM.compute call site pays): scalars cross PCIe every call
-        wd.beat("extras (child processes for 2^22, the table-less plan and the compiled host loops)", limit=1500)
+        wd.beat("extras (child processes for 2^22, the table-less plan and the compiled host loops: each restarts the clock with its own limit)", limit=300)
         h_sc = d_scalars[0].cpu().numpy().view(np.uint64)
         bases.msm(h_sc)
         t0 = time.perf_counter()
@@ -659,7 +770,7 @@ def main():
             hxy, hinf = bases.msm(h_sc)
         out["extra"]["msm_host_scalars_ms"] = (time.perf_counter() - t0) / 3 * 1e3
         assert hinf == want[0][1] and np.array_equal(hxy, want[0][0])
-        out["extra"].update(extra_measurements(lib, api, torch, dev, stream, args, bases_xy if args.logn == 20 else None))
+        out["extra"].update(extra_measurements(lib, api, torch, dev, stream, args, bases_xy if args.logn == 20 else None, wd=wd))
         npc = out["extra"].get("msm_no_precompute", {})
         if "ms_per_msm" in npc:
             serial_table = sum(out["extra"]["kernel_ms_per_msm_alone"].values())
@@ -674,18 +785,45 @@ def main():
     if not args.no_cpu_baseline and world == 1:
         wd.beat("cpu baseline", limit=600)
         out["cpu_baseline"] = cpu_baseline(bases_xy, d_scalars[0].cpu().numpy().view(np.uint64), want[0], args.logn)
-    print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
+    emit(out, full_line=args.full_line)  # the LAST thing this process prints
 
 
-def single_process_child(n_devices):
+class _Done:
+    def __init__(self, rc, out, err):
+        self.returncode, self.stdout, self.stderr = rc, out, err
+
+
+def run_child(cmd, timeout, wd=None, env=None):
+    """One child process of the extras: the watchdog's stall clock is restarted with the child's own limit (+30 s) before it starts, and the
+    watchdog knows the child so that it can end it before it ends this process (a child left behind would still hold the GPU)."""
+    import subprocess
+    prev = wd.limit if wd is not None else None
+    if wd is not None:
+        wd.beat(limit=timeout + 30)
+    pr = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    if wd is not None:
+        wd.child = pr
+    try:
+        so, se = pr.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        pr.kill()
+        pr.communicate()
+        raise
+    finally:
+        if wd is not None:
+            wd.child = None
+            wd.beat(limit=prev)
+    return _Done(pr.returncode, so, se)
+
+
+def single_process_child(n_devices, wd=None):
     import subprocess
     try:
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
                                                                  "ZG_SHARDS", "ZG_SHARD_EXCHANGE")}
-        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--single-process", str(n_devices), "--logn", "20"],
-                             capture_output=True, text=True, timeout=240, env=env)
+        out = run_child([sys.executable, os.path.abspath(__file__), "--single-process", str(n_devices), "--logn", "20"], 240, wd=wd, env=env)
         lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
         if out.returncode != 0 or not lines:
             return {"error": (out.stderr or out.stdout)[-600:], "returncode": out.returncode}
@@ -739,7 +877,7 @@ def sharded_sumcheck_measurement(lib, api, torch, dist, dev, stream, world, rank
             "layout": "LOW_PAIR, contiguous shards"}
 
 
-def extra_measurements(lib, api, torch, dev, stream, args, srs_xy=None):
+def extra_measurements(lib, api, torch, dev, stream, args, srs_xy=None, wd=None):
     """sumcheck rounds/s at v = 20 (BASELINE config 3): eq-table build + Spartan combine + 20 x (round sums,
     host toy challenge, fold) with the table resident in HBM."""
     extra = {}
@@ -898,9 +1036,8 @@ def extra_measurements(lib, api, torch, dev, stream, args, srs_xy=None):
     # the metric's second size, 2^22 points on this one GPU (same code path, fresh process)
     try:
         import subprocess
-        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--logn", "22", "--steps", "4", "--warmup", "1", "--msms-per-step", "4",
-                              "--no-cpu-baseline", "--no-extra", "--streams", str(args.streams)],
-                             capture_output=True, text=True, timeout=600)
+        out = run_child([sys.executable, os.path.abspath(__file__), "--logn", "22", "--steps", "4", "--warmup", "1", "--msms-per-step", "4",
+                         "--no-cpu-baseline", "--no-extra", "--full-line", "--streams", str(args.streams)], 600, wd=wd)
         d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
         extra["msm_2^22_single_gpu"] = {"value": d["value"], "unit": "MSM/s", "ms_per_msm": d["config"]["ms_per_msm"],
                                         "kernel_ms_per_msm_alone": d["extra"]["kernel_ms_per_msm_alone"], "roofline": d["roofline"]}
@@ -910,9 +1047,8 @@ def extra_measurements(lib, api, torch, dev, stream, args, srs_xy=None):
     # per-window bucket sets, window combine by doublings on the device) — what a one-shot caller would see
     try:
         import subprocess
-        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--logn", str(args.logn), "--steps", "4", "--warmup", "1", "--msms-per-step", "8",
-                              "--precompute", "1", "--no-cpu-baseline", "--no-extra", "--streams", str(args.streams)],
-                             capture_output=True, text=True, timeout=600)
+        out = run_child([sys.executable, os.path.abspath(__file__), "--logn", str(args.logn), "--steps", "4", "--warmup", "1", "--msms-per-step", "8",
+                         "--precompute", "1", "--no-cpu-baseline", "--no-extra", "--full-line", "--streams", str(args.streams)], 600, wd=wd)
         d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
         extra["msm_no_precompute"] = {"value": d["value"], "unit": "MSM/s", "ms_per_msm": d["config"]["ms_per_msm"],
                                       "kernel_ms_per_msm_alone": d["extra"]["kernel_ms_per_msm_alone"]}
@@ -924,7 +1060,7 @@ def extra_measurements(lib, api, torch, dev, stream, args, srs_xy=None):
     if os.path.exists(exe):
         import subprocess
         try:
-            out = subprocess.run([exe, "20", "20"], capture_output=True, text=True, timeout=300)
+            out = run_child([exe, "20", "20"], 300, wd=wd)
             extra["sumcheck_v20_compiled_host"] = json.loads(out.stdout.strip().splitlines()[-1])
         except Exception as e:  # noqa: BLE001
             extra["sumcheck_v20_compiled_host"] = {"error": str(e)}
@@ -945,7 +1081,7 @@ def extra_measurements(lib, api, torch, dev, stream, args, srs_xy=None):
                     "python_binding": py}
             extra["sumcheck_v20"] = lead
         try:  # the sizes the reference's own runs have: prover fold sites and a Stage-2-shaped batched proof at 2^13 cycles
-            out = subprocess.run([exe, "13", "10"], capture_output=True, text=True, timeout=300)
+            out = run_child([exe, "13", "10"], 300, wd=wd)
             extra["prover_sites_v13_compiled_host"] = json.loads(out.stdout.strip().splitlines()[-1])
         except Exception as e:  # noqa: BLE001
             extra["prover_sites_v13_compiled_host"] = {"error": str(e)}
@@ -956,13 +1092,13 @@ def extra_measurements(lib, api, torch, dev, stream, args, srs_xy=None):
     if os.path.exists(exe):
         import subprocess
         try:
-            out = subprocess.run([exe, "synth", "20", "2"], capture_output=True, text=True, timeout=600)
+            out = run_child([exe, "synth", "20", "2"], 600, wd=wd)
             extra["prove_path"] = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])["prove_path"]
         except Exception as e:  # noqa: BLE001
             extra["prove_path"] = {"error": str(e)}
         try:  # the same proof with a key planned for ONE use (zg_msm_config.expected_uses = 1: no table of multiples) — what a single
             # `zolt prove` run, which builds its mock SRS in-process, should ask for: three commits and an open are below the break-even
-            out = subprocess.run([exe, "synth", "20", "2", "1"], capture_output=True, text=True, timeout=600)
+            out = run_child([exe, "synth", "20", "2", "1"], 600, wd=wd)
             one = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])["prove_path"]
             extra["prove_path_single_use_key"] = {k: one[k] for k in ("key_expected_uses", "total_ms", "total_ms_without_proving_key", "top3")}
             extra["prove_path_single_use_key"]["steps_ms"] = {st["call"].split(":")[0].split(" (")[0]: st["ms"] for st in one["steps"]
