@@ -217,6 +217,11 @@ def emit(out, full_line=False):
         return
     write_side_file(out)
     sys.stdout.flush()
+    try:  # RCCL prints its version banner through C stdio; on a pipe that buffer would reach stdout at exit, AFTER the line: flush it first
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
     print(compact_line(out), flush=True)
 
 

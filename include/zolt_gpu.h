@@ -226,9 +226,11 @@ ZG_API int zg_g1_fixed_base_mul_batch(const uint64_t base_xy[8], uint8_t base_in
                                uint8_t *out_inf);
 
 /* HyperKZG.setup's G1 side with nothing leaving the device (generateMockSRS, src/poly/commitment/mod.zig:174-213: powers[i] =
- * scalarMul(g1, tau^i), i < n <= 2^24): powers of tau, fixed-base batch and the handle (with its table of multiples) are built in HBM.
+ * scalarMul(g1, tau^i), i < n < 2^27 — the reference's largest key is 2^24 + 256 powers, src/host/mod.zig:384-387): powers of tau,
+ * fixed-base batch and the handle (with its table of multiples) are built in HBM.
  * out_xy / out_inf (n*8 words / n bytes, host) may be NULL when the caller does not need the points themselves. The handle equals
- * zg_g1_bases_upload of zg_g1_fixed_base_mul_batch's output for the scalars tau^i. */
+ * zg_g1_bases_upload of zg_g1_fixed_base_mul_batch's output for the scalars tau^i, infinity flags included (tau = 0: every power
+ * but the first is the identity). */
 ZG_API int zg_hyperkzg_setup(const uint64_t base_xy[8], const uint64_t tau[4], size_t n, const zg_msm_config *cfg, uint64_t *out_xy, uint8_t *out_inf,
                              zg_bases_t *out);
 /* HyperKZG.open (src/poly/commitment/mod.zig:261-324), resident on the device: per variable i the quotient

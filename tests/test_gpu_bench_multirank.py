@@ -22,7 +22,7 @@ def _bench(args, extra_env, cwd, timeout=900):
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert out.returncode == 0 and len(lines) == 1, (out.returncode, out.stdout[-800:], out.stderr[-1500:])
     last = out.stdout.rstrip("\n").splitlines()[-1]
-    assert last == lines[0] and len(last) < 4096, len(last)  # the compact line is the LAST line of stdout and fits the driver's window
+    assert last == lines[0] and len(last) < 4096, (len(last), out.stdout[-600:])  # the compact line is the LAST line of stdout and fits the driver's window
     side = os.path.join(str(cwd), "bench_extra.json")
     assert os.path.exists(side), "rank 0 writes the side file into the cwd"
     assert sorted(os.listdir(str(cwd))) == ["bench_extra.json"], "one side file, written by rank 0 only"

@@ -879,3 +879,21 @@ def test_hyperkzg_setup_on_the_device(zl, ob, n):
             up.free()
     finally:
         h.free()
+
+
+def test_hyperkzg_setup_with_tau_zero_keeps_the_identity_flags(zl, ob):
+    """tau = 0 (the ABI accepts any field element): powers[0] = G, every later power is scalarMul(g1, 0) = the identity, as in the
+    reference's loop (src/poly/commitment/mod.zig:194-199). The handle must carry those flags — a commitment over it is evals[0] * G and
+    nothing else (round-5 advisor: the flags were dropped and (0, 0) entered the MSM as a point)."""
+    from zolt_amd import api
+    g, n = api.generator(), 300
+    h, xy, inf = zl.Bases.hyperkzg_setup(g, np.zeros(4, dtype=np.uint64), n)
+    try:
+        assert inf[0] == 0 and np.array_equal(xy[0], g) and inf[1:].all() and not xy[1:].any()
+        sc = ob.f_to_mont(ob.FR, U.random_raw256(4040, n))
+        got = h.msm(sc)
+        want = ob.msm_g1(xy, inf, sc)
+        w1 = api.MSM.scalarMul(g, sc[0])
+        assert got[1] == want[1] == w1[1] == 0 and np.array_equal(got[0], want[0]) and np.array_equal(got[0], w1[0])
+    finally:
+        h.free()

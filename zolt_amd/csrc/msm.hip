@@ -1485,8 +1485,8 @@ __global__ void __launch_bounds__(256) fb_mul_kernel(const char *table, const ui
 // products. Exact products: the bytes are those of the reference's running product tau_power = tau_power * tau
 // (src/poly/commitment/mod.zig:190-199).
 struct TauArg { uint32_t l[8]; };  // a field element as a kernel argument
-__global__ void __launch_bounds__(64) tau_tables_kernel(TauArg tau, uint64_t *tabs /* 3 x 256 x 4 */) {
-    if (threadIdx.x >= 3) return;
+__global__ void __launch_bounds__(64) tau_tables_kernel(TauArg tau, uint64_t *tabs /* 4 x 256 x 4 */) {
+    if (threadIdx.x >= 4) return;
     Fr t;
 #pragma unroll
     for (int i = 0; i < 8; i++) t.l[i] = tau.l[i];
@@ -1504,7 +1504,8 @@ __global__ void __launch_bounds__(256) tau_powers_kernel(const uint64_t *tabs, s
     if (i >= n) return;
     Fr v = fe_load<FrParams>(tabs + 4 * (i & 255));
     if (i >> 8) v = fr_mul29v(v, fe_load<FrParams>(tabs + 4 * (256 + ((i >> 8) & 255))));
-    if (i >> 16) v = fr_mul29v(v, fe_load<FrParams>(tabs + 4 * (512 + (i >> 16))));
+    if (i >> 16) v = fr_mul29v(v, fe_load<FrParams>(tabs + 4 * (512 + ((i >> 16) & 255))));
+    if (i >> 24) v = fr_mul29v(v, fe_load<FrParams>(tabs + 4 * (768 + (i >> 24))));  // the reference's largest key is 2^24 + 256 powers (src/host/mod.zig:384-387)
     fe_store(out + 4 * i, v);
 }
 
@@ -3088,15 +3089,15 @@ int zg_g1_fixed_base_mul_batch(const uint64_t base_xy[8], uint8_t base_inf, cons
 int zg_hyperkzg_setup(const uint64_t base_xy[8], const uint64_t tau[4], size_t n, const zg_msm_config *cfg, uint64_t *out_xy, uint8_t *out_inf,
                       zg_bases_t *out) {
     ZG_INIT();
-    if (!base_xy || !tau || !out || n > ((size_t)1 << 24)) {
-        set_error("zg_hyperkzg_setup: invalid argument (at most 2^24 powers)");
+    if (!base_xy || !tau || !out || n >= ((size_t)1 << 27)) {
+        set_error("zg_hyperkzg_setup: invalid argument (fewer than 2^27 powers, the most a handle holds)");
         return ZG_ERR_INVALID;
     }
     hipStream_t st = lib_stream();
     const FbPlan fb = fb_plan(n);
     const uint32_t n_rows = (uint32_t)fb.W * fb.rows;
     const size_t nn = n ? n : 1;
-    Scratch s_base(64), s_rows((size_t)fb.W * 144), s_tab((size_t)n_rows * 64), s_pw(3 * 256 * 32), s_sc(nn * 32), s_out(nn * 64), s_inf(nn);
+    Scratch s_base(64), s_rows((size_t)fb.W * 144), s_tab((size_t)n_rows * 64), s_pw(4 * 256 * 32), s_sc(nn * 32), s_out(nn * 64), s_inf(nn);
     if (!s_base.p || !s_rows.p || !s_tab.p || !s_pw.p || !s_sc.p || !s_out.p || !s_inf.p) return ZG_ERR_NOMEM;
     SyncGuard sync(st);
     if (n) {
@@ -3116,8 +3117,11 @@ int zg_hyperkzg_setup(const uint64_t base_xy[8], const uint64_t tau[4], size_t n
             if (out_xy) ZG_HIP(hipMemcpyAsync(out_xy, s_out.p, n * 64, hipMemcpyDeviceToHost, st));
         if (out_inf) ZG_HIP(hipMemcpyAsync(out_inf, s_inf.p, n, hipMemcpyDeviceToHost, st));
     }
-    // tau^i is never 0 mod r and the base has prime order: no power is the identity, so the handle carries no infinity flags
-    int rc = bases_create(s_out.as<uint64_t>(), nullptr, n, cfg, st, out);  // copies the points into the handle's table (and builds the side table beside it)
+    // tau != 0: tau^i is never 0 mod r and the base has prime order, no power is the identity and the handle carries no infinity flags.
+    // tau == 0 (canonical zero; the ABI accepts any field element): powers[i] = scalarMul(g1, 0) = identity for every i >= 1, as in the
+    // reference — the flags fb_mul_kernel wrote travel into the handle, or its MSMs would take (0, 0) for a point (round-5 advisor)
+    const bool tau_zero = !(tau[0] | tau[1] | tau[2] | tau[3]);
+    int rc = bases_create(s_out.as<uint64_t>(), tau_zero && n ? s_inf.as<uint8_t>() : nullptr, n, cfg, st, out);  // copies the points into the handle's table (and builds the side table beside it)
     hipError_t e = hipStreamSynchronize(st);
     sync.dismiss();
     if (rc != ZG_OK) return rc;
