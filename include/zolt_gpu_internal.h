@@ -46,6 +46,14 @@ ZG_API int zg_last_setup_times(double out[4]);
  * handles made while the same number of devices is bound; tests check that re-binding creates a new set instead of failing. */
 ZG_API int zg_sharded_comm_sets_created(void);
 
+/* ZG_POOL_DEBUG (csrc/runtime.hip): the device pool's "a freed block is idle" contract, checked. With ZG_POOL_DEBUG=1 in the environment
+ * freed (and fresh) blocks are filled with 0xDBDBDBDB and verified before they are handed out again; a block written after its free is
+ * refused and counted (=2: the process aborts). zg_pool_debug_stats: out[0] = hits, out[1] = frees made while the device's library stream
+ * was busy (information only), out[2] = blocks verified, out[3] = bytes poisoned; returns the mode (0 = off).
+ * zg_pool_debug_selftest breaks the contract on purpose: 1 = the mode caught it, 0 = mode off (nothing checked), < 0 = error. */
+ZG_API int zg_pool_debug_stats(uint64_t out[4]);
+ZG_API int zg_pool_debug_selftest(void);
+
 #ifdef __cplusplus
 }
 #endif

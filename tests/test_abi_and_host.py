@@ -20,7 +20,8 @@ def test_header_symbols_all_exported():
     from zolt_amd import lib
     declared = _declared_symbols()
     internal = _declared_symbols("zolt_gpu_internal.h")
-    assert len(declared) >= 70 and internal == ["zg_last_setup_times", "zg_profile_begin", "zg_profile_end", "zg_sharded_comm_sets_created"]
+    assert len(declared) >= 70 and internal == ["zg_last_setup_times", "zg_pool_debug_selftest", "zg_pool_debug_stats", "zg_profile_begin", "zg_profile_end",
+                                              "zg_sharded_comm_sets_created"]
     nm = subprocess.check_output(["nm", "-D", "--defined-only", lib.LIB_PATH], text=True)
     exported = set(re.findall(r" T (zg_\w+)", nm))
     assert exported == set(declared) | set(internal)  # the library exports exactly the two headers, nothing more, nothing less

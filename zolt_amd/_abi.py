@@ -211,6 +211,8 @@ INTERNAL_PROTOS = {
     "zg_profile_end": (c_int, [c_void_p, c_void_p]),  # ms_out, count_out
     "zg_last_setup_times": (c_int, [c_void_p]),  # out
     "zg_sharded_comm_sets_created": (c_int, []),  # 
+    "zg_pool_debug_stats": (c_int, [c_void_p]),  # out
+    "zg_pool_debug_selftest": (c_int, []),  # 
 }
 
 SYMBOLS = list(PROTOS)

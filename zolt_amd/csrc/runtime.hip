@@ -194,6 +194,75 @@ hipError_t dev_malloc(void **p, size_t bytes) {  // hipMalloc for allocations th
     }
     return e;
 }
+
+// ---- ZG_POOL_DEBUG: the check behind "a block is idle by contract when it is freed" (round-5 review: nothing checked it; a block freed
+// with work in flight and handed to another stream is a silent wrong answer). MSM.compute is called from concurrent host threads
+// (src/msm/mod.zig:355-372,637,732), so the pool is where two calls' memory can meet.
+//   ZG_POOL_DEBUG=1  pool_free fills the block with a poison pattern (on a stream of the pool's own, ordered with nothing: work still in
+//                    flight on the block reads poison and its parity test fails loudly instead of rarely); pool_alloc, before it hands an
+//                    idle block out again, waits for the device and verifies that every word is still poison — a word that is not was
+//                    WRITTEN AFTER THE FREE. Such a block is refused (nullptr, error text names it) and counted. Fresh blocks from the
+//                    driver are poisoned too (a kernel that relied on zeroed scratch reads 0xDB...). Frees made while a library stream of
+//                    the device still had work queued are counted as "suspect" (information: other calls' work is on those streams too).
+//   ZG_POOL_DEBUG=2  the same, and a hit aborts the process on the spot.
+// zg_pool_debug_stats (include/zolt_gpu_internal.h) reads the counters; zg_pool_debug_selftest breaks the contract on purpose.
+static const uint32_t POOL_POISON = 0xDBDBDBDBu;
+static int pool_debug() {
+    static const int on = [] { const char *v = getenv("ZG_POOL_DEBUG"); return v && *v ? atoi(v) : 0; }();
+    return on;
+}
+static std::atomic<uint64_t> g_pd_hits{0}, g_pd_suspect{0}, g_pd_checked{0}, g_pd_poisoned_bytes{0};
+static hipStream_t g_pd_stream[ZG_MAX_DEVICES] = {};
+static uint32_t *g_pd_count[ZG_MAX_DEVICES] = {};  // pinned: [0] words that are not poison, [1] index of the first one
+static hipStream_t pd_stream(int dev) {            // under g_pool_mu
+    if (dev < 0 || dev >= ZG_MAX_DEVICES) return nullptr;
+    if (!g_pd_stream[dev]) {
+        if (hipStreamCreateWithFlags(&g_pd_stream[dev], hipStreamNonBlocking) != hipSuccess) g_pd_stream[dev] = nullptr;
+        if (hipHostMalloc((void **)&g_pd_count[dev], 16) != hipSuccess) g_pd_count[dev] = nullptr;
+    }
+    return g_pd_stream[dev];
+}
+__global__ void __launch_bounds__(256) pool_poison_check_kernel(const uint32_t *p, size_t words, uint32_t poison, uint32_t *count) {
+    uint32_t bad = 0, first = 0xFFFFFFFFu;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256)
+        if (p[i] != poison) {
+            bad++;
+            if (first == 0xFFFFFFFFu) first = (uint32_t)(i > 0xFFFFFFFEull ? 0xFFFFFFFEu : i);
+        }
+    if (bad) {
+        atomicAdd(&count[0], bad);
+        atomicMin(&count[1], first);
+    }
+}
+static void pd_poison(void *p, size_t bytes, int dev) {  // under g_pool_mu; complete on return
+    hipStream_t st = pd_stream(dev);
+    if (!st) return;
+    (void)hipMemsetD32Async((hipDeviceptr_t)p, (int)POOL_POISON, bytes / 4, st);
+    (void)hipStreamSynchronize(st);
+    g_pd_poisoned_bytes += bytes;
+}
+static bool pd_verify(void *p, size_t bytes, int dev) {  // under g_pool_mu; true = every word is still poison
+    hipStream_t st = pd_stream(dev);
+    if (!st || !g_pd_count[dev]) return true;
+    (void)hipDeviceSynchronize();  // whatever was in flight when the block was freed has landed now
+    g_pd_count[dev][0] = 0;
+    g_pd_count[dev][1] = 0xFFFFFFFFu;
+    const size_t words = bytes / 4;
+    const unsigned grid = (unsigned)(words / 256 / 16 < 1 ? 1 : (words / 256 / 16 > 4096 ? 4096 : words / 256 / 16));
+    hipLaunchKernelGGL(pool_poison_check_kernel, dim3(grid), dim3(256), 0, st, (const uint32_t *)p, words, POOL_POISON, g_pd_count[dev]);
+    (void)hipStreamSynchronize(st);
+    g_pd_checked++;
+    if (g_pd_count[dev][0] == 0) return true;
+    g_pd_hits++;
+    char msg[256];
+    snprintf(msg, sizeof msg, "ZG_POOL_DEBUG: block %p (class %zu bytes, device %d) was written after it was freed: %u words are not poison, first at word %u",
+             p, bytes, dev, g_pd_count[dev][0], g_pd_count[dev][1]);
+    fprintf(stderr, "%s\n", msg);
+    set_error(msg);
+    if (pool_debug() >= 2) abort();
+    return false;
+}
+
 void *pool_alloc(size_t bytes) {
     const int dev = current_device();
     const size_t cls = pool_class(bytes ? bytes : 1);
@@ -204,6 +273,12 @@ void *pool_alloc(size_t bytes) {
             void *p = it->second;
             g_pool_idle.erase(it);
             g_pool_cached -= cls;
+            if (pool_debug() && !pd_verify(p, cls, dev)) {
+                pd_poison(p, cls, dev);  // refused: back among the idle blocks, clean again; the caller sees an allocation failure
+                g_pool_idle.insert({{dev, cls}, p});
+                g_pool_cached += cls;
+                return nullptr;
+            }
             g_pool_live[p] = PoolBlock{cls, dev};
             return p;
         }
@@ -216,6 +291,7 @@ void *pool_alloc(size_t bytes) {
         return nullptr;
     }
     std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (pool_debug()) pd_poison(p, cls, dev);
     g_pool_live[p] = PoolBlock{cls, dev};
     return p;
 }
@@ -232,6 +308,16 @@ void pool_free(void *p) {
     if (g_pool_cached + b.bytes > pool_cap()) {
         (void)hipFree(p);
         return;
+    }
+    if (pool_debug()) {
+        // (read without g_mu: zg_shutdown takes g_mu before the pool's mutex; a stale pointer only costs this counter)
+        hipStream_t ls = b.dev >= 0 && b.dev < ZG_MAX_DEVICES ? g_streams[b.dev] : nullptr;
+        if (ls && hipStreamQuery(ls) == hipErrorNotReady) g_pd_suspect++;
+        (void)hipGetLastError();
+        int cur = current_device();
+        if (cur != b.dev) (void)hipSetDevice(b.dev);
+        pd_poison(p, b.bytes, b.dev);
+        if (cur != b.dev && cur >= 0) (void)hipSetDevice(cur);
     }
     g_pool_idle.insert({{b.dev, b.bytes}, p});
     g_pool_cached += b.bytes;
@@ -508,6 +594,47 @@ int zg_sync(void) {
     ZG_INIT();
     ZG_HIP(hipStreamSynchronize(lib_stream()));
     return ZG_OK;
+}
+
+int zg_pool_debug_stats(uint64_t out[4]) {
+    if (!out) return ZG_ERR_INVALID;
+    out[0] = g_pd_hits.load();
+    out[1] = g_pd_suspect.load();
+    out[2] = g_pd_checked.load();
+    out[3] = g_pd_poisoned_bytes.load();
+    return pool_debug();
+}
+
+// Breaks the pool's contract on purpose: a block is freed while a kernel that will still write it is queued behind a slow one on the
+// library's stream, and the same size class is asked for again. Returns 1 when the debug mode caught the write (the allocation was refused
+// and counted), 0 when the block came back unchecked (ZG_POOL_DEBUG unset), a negative error code otherwise.
+__global__ void pool_selftest_late_writer(uint32_t *p, size_t words, long long spin_cycles) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < spin_cycles) {}
+    for (size_t i = threadIdx.x; i < words; i += blockDim.x) p[i] = 0x600DF00Du;
+}
+int zg_pool_debug_selftest(void) {
+    ZG_INIT();
+    if (pool_debug() >= 2) return ZG_ERR_INVALID;  // would abort by design
+    const size_t bytes = 3 * 4096 + 512;            // a class of its own in practice
+    hipStream_t st = lib_stream();
+    void *p = pool_alloc(bytes);
+    if (!p) return -ZG_ERR_NOMEM;
+    hipLaunchKernelGGL(pool_selftest_late_writer, dim3(1), dim3(64), 0, st, (uint32_t *)p, bytes / 4, (long long)2000000);  // ~20 ms at 100 MHz
+    pool_free(p);  // the violation: the writer is still running
+    const uint64_t before = g_pd_hits.load();
+    void *q = pool_alloc(bytes);
+    (void)hipStreamSynchronize(st);
+    const bool caught = q == nullptr && g_pd_hits.load() == before + 1;
+    if (q) pool_free(q);
+    if (!caught && pool_debug()) return -ZG_ERR_HIP;
+    if (pool_debug()) {  // the refused block sits clean among the idle ones: the pool stays usable after a hit
+        void *r = pool_alloc(bytes);
+        if (!r) return -ZG_ERR_NOMEM;
+        pool_free(r);
+        g_pd_hits--;  // the hit was the self-test's own
+    }
+    return caught ? 1 : 0;
 }
 
 int zg_last_setup_times(double out[4]) {

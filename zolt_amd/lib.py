@@ -294,6 +294,21 @@ class Bases:
         return out, inf
 
 
+def pool_debug_stats():
+    """ZG_POOL_DEBUG counters (include/zolt_gpu_internal.h): {'mode', 'hits', 'suspect_frees', 'blocks_verified', 'bytes_poisoned'}"""
+    out = np.zeros(4, dtype=np.uint64)
+    mode = int(_lib.zg_pool_debug_stats(_h(out)))
+    return {"mode": mode, "hits": int(out[0]), "suspect_frees": int(out[1]), "blocks_verified": int(out[2]), "bytes_poisoned": int(out[3])}
+
+
+def pool_debug_selftest():
+    """breaks the pool's contract on purpose: 1 = ZG_POOL_DEBUG caught it, 0 = mode off; raises on an error"""
+    rc = int(_lib.zg_pool_debug_selftest())
+    if rc < 0:
+        raise ZgError(-rc, "zg_pool_debug_selftest")
+    return rc
+
+
 def sharded_comm_sets_created():
     """test hook (include/zolt_gpu_internal.h): RCCL communicator sets created so far by the one-process multi-GPU path"""
     return int(_lib.zg_sharded_comm_sets_created())
