@@ -74,9 +74,11 @@ extern "C" {
  *   OPTIONAL  protocol-specific device sessions for two of the reference's stage provers (zg_rrw_*: RegistersReadWriteChecking,
  *             zg_rwc_*: RamReadWriteChecking). A host that only re-points MSM / poly / sumcheck call sites never touches them:
  *             compile with -DZG_NO_PROTOCOL_SESSIONS to leave them out of the binding; zg_abi_features() reports whether the loaded
- *             library carries them. */
+ *             library carries them.
+ * 1.10 (round 6): NO entry point added — the boundary is frozen; zg_hyperkzg_setup accepts the reference's largest key (2^24 + 256 powers,
+ * formerly at most 2^24) and keeps the identity flags of tau = 0. */
 #define ZG_ABI_MAJOR 1
-#define ZG_ABI_MINOR 9
+#define ZG_ABI_MINOR 10
 #define ZG_FEATURE_PROTOCOL_SESSIONS 1u /* zg_rrw_* and zg_rwc_* are exported */
 #define ZG_FEATURE_RCCL 2u              /* the several-GPU entry points can exchange partials over RCCL */
 #define ZG_FEATURE_COLUMN_INGEST 4u     /* zg_fr_rows_from_columns[_dev] */

@@ -239,6 +239,24 @@ TEST(keccak_transcript_kat) {
     EXPECT(c2.eql(want2));
 }
 
+// RaPolynomial.finalClaim (src/zkvm/ram/raf_checking.zig:179-185) returns evals[0] at ANY point of the protocol; the mirror used to answer
+// zero until the table had one entry (round-5 advisor)
+TEST(raf_final_claim_before_the_last_bind) {
+    std::vector<Fr> ra;
+    for (uint64_t i = 0; i < 8; i++) ra.push_back(Fr::fromU64(5 + 3 * i));
+    RafEvaluationProver p(ra, 0x7fff8000ULL);
+    EXPECT(p.getFinalClaim().eql(ra[0]));
+    Fr c = Fr::fromU64(11);
+    p.bindChallenge(c);  // LowToHigh: new[0] = ra[0] + c (ra[1] - ra[0])
+    EXPECT(p.getFinalClaim().eql(ra[0].add(c.mul(ra[1].sub(ra[0])))));
+    p.bindChallenge(c);
+    p.bindChallenge(c);  // one entry left: the session's final value
+    Fr a = ra[0].add(c.mul(ra[1].sub(ra[0]))), b = ra[2].add(c.mul(ra[3].sub(ra[2])));
+    Fr e = ra[4].add(c.mul(ra[5].sub(ra[4]))), f = ra[6].add(c.mul(ra[7].sub(ra[6])));
+    Fr ab = a.add(c.mul(b.sub(a))), ef = e.add(c.mul(f.sub(e)));
+    EXPECT(p.getFinalClaim().eql(ab.add(c.mul(ef.sub(ab)))));
+}
+
 // src/poly/split_eq.zig:525-733 — the reference's six GruenSplitEqPolynomial tests, restated
 TEST(gruen_split_eq_polynomial) {
     auto F = [](uint64_t v) { return Fr::fromU64(v); };

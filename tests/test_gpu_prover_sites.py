@@ -68,6 +68,8 @@ def test_raf_cubic_rounds(env, log_k):
         prover.bindChallenge(ch)
         cur = ob.fr_bind_low(cur, ch)
         bound = np.concatenate([bound, ch[None, :]])
+        if rd in (0, log_k // 2):  # RaPolynomial.finalClaim is evals[0] at any point, not only after the last bind (raf_checking.zig:179-185)
+            assert np.array_equal(prover.getFinalClaim(), cur[0]), rd
     assert prover.isComplete() and np.array_equal(prover.getFinalClaim(), cur[0])
     if log_k <= 10:  # a true claim stays consistent: the final claim equals ra(r) * unmap(r)
         unmap_r = (start + 8 * sum(U.fr_to_int(b) << j for j, b in enumerate(bound))) % api.R_MOD

@@ -35,7 +35,7 @@ pub const OP_INV: c_int = 5;
 pub const OP_FROM_MONT: c_int = 6;
 pub const OP_TO_MONT: c_int = 7;
 pub const ABI_MAJOR: u32 = 1;
-pub const ABI_MINOR: u32 = 9;
+pub const ABI_MINOR: u32 = 10;
 pub const FEATURE_PROTOCOL_SESSIONS: u32 = 1;
 pub const FEATURE_RCCL: u32 = 2;
 pub const FEATURE_COLUMN_INGEST: u32 = 4;

@@ -19,7 +19,7 @@ ZG_OP_INV = 5
 ZG_OP_FROM_MONT = 6
 ZG_OP_TO_MONT = 7
 ZG_ABI_MAJOR = 1
-ZG_ABI_MINOR = 9
+ZG_ABI_MINOR = 10
 ZG_FEATURE_PROTOCOL_SESSIONS = 1
 ZG_FEATURE_RCCL = 2
 ZG_FEATURE_COLUMN_INGEST = 4

@@ -691,7 +691,9 @@ inline ValEvaluationWrites valEvaluationWrites(const std::vector<MemoryAccess> &
     while (w.n < std::max<size_t>(trace_len, 1)) w.n <<= 1;
     // last value per ADDRESS (the reference keys its map by address, not by word): every address that passes the range filter lies in
     // [start, start + 8k), so the map is a flat array over byte offsets — a hash map cost 2 ms per 10^5 accesses here
-    const bool flat = k <= (size_t(1) << 22);  // (a larger address space keeps the hash map)
+    // 64 * k bytes, value-initialised on every call: 4 MB at log_k = 16 (the captured run) but 256 MB of memset and page faults at 2^22,
+    // far more than the map costs a sparse trace — flat only while the array stays within 16 MB or the trace really fills it
+    const bool flat = k <= (size_t(1) << 18) || (k <= (size_t(1) << 22) && accesses.size() >= k);
     std::vector<uint64_t> last_flat(flat ? 8 * k : 0, 0);
     std::unordered_map<uint64_t, uint64_t> last_map;
     auto last = [&](uint64_t address) -> uint64_t & { return flat ? last_flat[address - start_address] : last_map[address]; };
@@ -1314,9 +1316,14 @@ public:
         return {s0, s1, s2, s0.sub(s1.mul(three)).add(s2.mul(three))};
     }
     void updateClaim(const std::array<Fr, 4> &evals, const Fr &c) { current_claim = cubicAtPoint(evals, c); }  // :420-445
-    Fr getFinalClaim() {  // :448-450 -> RaPolynomial.finalClaim (:179-185): evals[0] once every address variable is bound
+    Fr getFinalClaim() {  // :448-450 -> RaPolynomial.finalClaim (:179-185): evals[0] at ANY point of the protocol, zero only for an empty table
         Fr v = Fr::zero();
-        if (zg_sumcheck_len(s_) == 1) check(zg_sumcheck_final(s_, v.limbs), "zg_sumcheck_final");
+        const size_t len = zg_sumcheck_len(s_);
+        if (len == 1) check(zg_sumcheck_final(s_, v.limbs), "zg_sumcheck_final");
+        else if (len > 1) {  // read before the last bind: entry 0 of the current table (32 bytes over PCIe)
+            const uint64_t zero = 0;
+            check(zg_sumcheck_gather(s_, &zero, 1, v.limbs), "zg_sumcheck_gather");
+        }
         return v;
     }
     void bindChallenge(const Fr &c) {  // RaPolynomial.bind (:162-174) + the bound-address bookkeeping (:413-417)
