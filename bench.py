@@ -38,7 +38,7 @@ sys.path.insert(0, ROOT)
 # 64-byte rows read with the kernel's load shape are reported at 1.04x their bytes (taken as counted), a sequential 16 B/lane stream at
 # 0.50x (the gfx950 x2 of MI355X_MICROARCH.md). A launch gathers one 64-byte table row per addition and streams 4 bytes of sorted
 # reference per addition (counted at half: + 0.5 * 4 * additions).
-PMC_FILE = os.path.join(ROOT, "profiles", "r5_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r6_pmc.json")
 
 
 def load_pmc(path=PMC_FILE):
@@ -69,8 +69,8 @@ def measured_traffic(pmc, logn, adds_per_launch):
     return c["FETCH_SIZE"] * 1024.0 + 0.5 * 4.0 * adds_per_launch + c["WRITE_SIZE"] * 1024.0
 
 
-TRAFFIC_SOURCE = ("rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes, serial bench) per msm_accumulate launch, read from profiles/r5_pmc.json "
-                  "(written by tools/collect_profiles.sh; the text summaries of the same run are profiles/r5_rocprofv3_summary*.txt): FETCH_SIZE taken as "
+TRAFFIC_SOURCE = ("rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes, serial bench) per msm_accumulate launch, read from profiles/r6_pmc.json "
+                  "(written by tools/collect_profiles.sh; the text summaries of the same run are profiles/r6_rocprofv3_summary*.txt): FETCH_SIZE taken as "
                   "counted for the gathered 64-byte rows, + 0.5 x 4 B x additions for the streamed sorted references (gfx950 tallies a wide stream at "
                   "half its bytes; calibrated with tools/microbench gather|stream, same file), + WRITE_SIZE")
 # static instruction mix of one lazy-limb XYZZ mixed add (hipcc --save-temps of the accumulate fast path): 1467
@@ -737,11 +737,11 @@ def main():
     pmc_all = load_pmc() if default_plan else {}
     out["roofline"]["traffic"] = measured_traffic(pmc_all, args.logn, adds)
     if out["roofline"]["traffic"] is None:
-        out["roofline"]["traffic_source"] = ("null: " + ("profiles/r5_pmc.json has no counters for this size" if default_plan else
+        out["roofline"]["traffic_source"] = ("null: " + ("profiles/r6_pmc.json has no counters for this size" if default_plan else
                                                         "counters were collected for the default plan on one GPU only"))
     prof_ms = profiled_duration_ms(args.logn) if default_plan else None
     if prof_ms:
-        # the same kernel in the committed rocprofv3 run (profiles/r5_kernel_stats_trace1.csv: the serial bench issues its MSMs back to
+        # the same kernel in the committed rocprofv3 run (profiles/r6_kernel_stats_trace1.csv: the serial bench issues its MSMs back to
         # back, so a launch takes 7/8 of the chunk slots; the HIP-event figure above is a lone launch with every slot): both fractions
         out["roofline"]["rocprofv3_avg_launch_ms"] = prof_ms
         out["roofline"]["frac_at_rocprofv3_duration"] = alg_bytes / (prof_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
@@ -758,7 +758,7 @@ def main():
             "residual_is": "time the SIMDs do not spend issuing: the launch runs 7/8 of the chip's chunk slots when other MSMs are in flight (full "
                            "when alone), the random 64-byte table rows (DESIGN 4a: a wave waits on its gathers when the other wave of its SIMD "
                            "does too), and the chunk-length spread at the end of the launch",
-            "pmc_source": "SQ_INSTS_VALU, rocprofv3 --pmc (own pass), profiles/r5_pmc.json"})
+            "pmc_source": "SQ_INSTS_VALU, rocprofv3 --pmc (own pass), profiles/r6_pmc.json"})
     if single_proc is not None:
         out["extra"]["single_process_c_abi"] = single_proc
     if sharded_sc is not None:

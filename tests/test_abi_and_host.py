@@ -368,15 +368,15 @@ def test_design_kernel_table_is_the_generated_one():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_table.py"), "r5"], capture_output=True, text=True, check=True).stdout.strip()
-    assert out == open(os.path.join(root, "profiles", "r5_kernel_table.md")).read().strip()
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_table.py"), "r6"], capture_output=True, text=True, check=True).stdout.strip()
+    assert out == open(os.path.join(root, "profiles", "r6_kernel_table.md")).read().strip()
     design = open(os.path.join(root, "DESIGN.md")).read()
     assert out in design
 
 
 def test_bench_roofline_counters_come_from_the_committed_pmc_file():
     """Round-4 review: bench.py's roofline.traffic quoted numbers the file it cited no longer held. Now bench.py holds no counter values at
-    all — it reads profiles/r5_pmc.json, which tools/collect_profiles.sh writes on the GPU box from rocprofv3 --pmc passes — and this test
+    all — it reads profiles/r6_pmc.json, which tools/collect_profiles.sh writes on the GPU box from rocprofv3 --pmc passes — and this test
     holds the two together: what bench.py would report for 2^20 and 2^22 points is exactly what the committed file contains."""
     import importlib.util
     import json
@@ -399,7 +399,7 @@ def test_bench_roofline_counters_come_from_the_committed_pmc_file():
         assert pmc[size]["SQ_INSTS_VALU"] == c["SQ_INSTS_VALU"]["avg"]
         assert 2300 < c["SQ_INSTS_VALU"]["avg"] / (adds / 64.0) < 2450  # wave instructions per wave-wide mixed addition
         # the committed text summary of the same run holds the same averages (one decimal)
-        summary = open(os.path.join(root, "profiles", "r5_rocprofv3_summary.txt" if logn == 20 else "r5_rocprofv3_summary_2^22.txt")).read()
+        summary = open(os.path.join(root, "profiles", "r6_rocprofv3_summary.txt" if logn == 20 else "r6_rocprofv3_summary_2^22.txt")).read()
         block = summary[summary.index("void zg::msm_accumulate_chunk_kernel<false>\n"):]
         assert "FETCH_SIZE               avg %16.1f" % c["FETCH_SIZE"]["avg"] in block[:2500]
         assert "WRITE_SIZE               avg %16.1f" % c["WRITE_SIZE"]["avg"] in block[:2500]

@@ -67,9 +67,9 @@ pass $OSC/pmc_sq "$SC" --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INS
 cp $OSC/summary.txt "$ROOT/profiles/${TAG}_sumcheck_kernels_2^20_durations_and_pmc.txt"
 find $OSC -name "*.csv" -size +2M -delete
 python3 $ROOT/tools/pmc_json.py $TAG $OUT $O22 > $OUT/pmc.json
-python3 $ROOT/tools/kernel_table.py $TAG > $ROOT/profiles/${TAG}_kernel_table.md 2>/dev/null
 cp $OUT/summary.txt $ROOT/profiles/${TAG}_rocprofv3_summary.txt
 cp $O22/summary.txt "$ROOT/profiles/${TAG}_rocprofv3_summary_2^22.txt"
+python3 $ROOT/tools/kernel_table.py $TAG > $ROOT/profiles/${TAG}_kernel_table.md 2>/dev/null  # (reads the two summaries copied above)
 cp $OUT/pmc.json $ROOT/profiles/${TAG}_pmc.json
 for t in trace1 trace3; do
   f=$(find $OUT/$t -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $ROOT/profiles/${TAG}_kernel_stats_$t.csv

@@ -1,7 +1,7 @@
 // microbench_tlb.hip — does the cost of a random 64-byte row gather depend on the SIZE OF THE ALLOCATION it falls in, or only on the
 // footprint touched? (The 2^22-point MSM's accumulate kernel pays +10 % per addition over the 2^20 one; folding its gathers into
 // the first 64 MB of the same 4 GiB table removes all of it, folding them into the first 1 GiB removes almost nothing, while the
-// 2^20 MSM's own 1 GiB table costs nothing: tools/exp/exp_mask.sh.)
+// 2^20 MSM's own 1 GiB table costs nothing: tools/exp/archive/exp_mask.sh.)
 //
 //   hipcc -O3 --offload-arch=gfx950 tools/microbench_tlb.hip -o tools/microbench_tlb && tools/microbench_tlb
 //

@@ -1606,7 +1606,7 @@ static uint32_t chunk_threads(uint64_t digits, bool alone = false) {
     // quarter of the CUs hold one workgroup instead of two): the spare registers let another stream's latency-bound kernels (bit sums,
     // final) run under this kernel, and the NEXT accumulation's first workgroups start at once on the half-filled CUs, so that the
     // equal-length chunks of consecutive launches stop draining and refilling the chip in step. Round 2 measured 15/16 against the
-    // full grid (+4-6 % MSM/s); round 4 swept the count (tools/exp/run_nt_sweep.sh, profiles/r4h_accumulate_slots_sweep.txt, three
+    // full grid (+4-6 % MSM/s); round 4 swept the count (tools/exp/archive/run_nt_sweep.sh, profiles/r4h_accumulate_slots_sweep.txt, three
     // streams at 2^20): 512 / 496 / 480 / 464 / 448 / 440 / 432 / 416 / 384 workgroups = 793 / 790 / 800 / 790 / 816 / 810 / 800 /
     // 809 / 792 MSM/s — 448 held +2 % over 480 in three separate runs.
     static const uint32_t inflight = [] {
@@ -1629,7 +1629,7 @@ static int make_plan(size_t n, const zg_msm_config *cfg, MsmPlan &p, size_t batc
     if (L == 0 && cfg && cfg->expected_uses > 0 && cfg->expected_uses < 16) L = 1;
     if (c == 0 && L == 1) {
         // table-less plan (one bucket set per window): the windows cost buckets, not table rows, so the choice differs from the table
-        // plan's. Measured (tools/exp/run_noprecomp_sweep.sh, profiles/r4_noprecomp_sweep.txt): at 2^20 points c = 15 runs 559 MSM/s
+        // plan's. Measured (tools/exp/archive/run_noprecomp_sweep.sh, profiles/r4_noprecomp_sweep.txt): at 2^20 points c = 15 runs 559 MSM/s
         // pipelined / 3.0 ms alone, c = 13 553 / 3.3, and the table plan's c = 16 347 / 4.4 (2^19 buckets overflow the LDS sort:
         // digits 0.03 -> 0.64 ms, sort 0.26 -> 0.93); at 2^16 points c = 13 is 0.55 / 1.42 ms against 0.90 / 1.63 for c = 16.
         // What remains alone is the window combine: (W - 1) c = 240 dependent doublings (msm_groups_kernel, 0.86 ms) that a table
@@ -1647,7 +1647,7 @@ static int make_plan(size_t n, const zg_msm_config *cfg, MsmPlan &p, size_t batc
         if (batch == 1 && n >= (size_t)env_int("ZG_MSM_C17_MIN", 900000) && (uint64_t)n * 15 <= (1u << 26)) c = 17;
         // 18 / 19 bits exist (window_bits, ZG_MSM_WINDOW_BITS) and are NOT chosen: 19 bits = 14 windows take 8 % off the accumulate kernel
         // (1.18 -> 1.09 ms at 2^20) and put more than that back into the per-bucket work of 2^18 buckets (sort 0.13 -> 0.22 ms, combine +
-        // row / column sums 0.27 -> 0.49 ms): 781 -> 735 MSM/s pipelined, 1.65 -> 1.95 ms alone (round 4, tools/exp/run_c19.sh)
+        // row / column sums 0.27 -> 0.49 ms): 781 -> 735 MSM/s pipelined, 1.65 -> 1.95 ms alone (round 4, tools/exp/archive/run_c19.sh)
     }
     if (c < 2 || c > 19) {
         set_error("msm: window_bits must be in [2,19]");

@@ -1257,7 +1257,7 @@ static int eq_table_enqueue(const uint64_t *r_host, size_t v, const uint64_t *sc
     const uint32_t nb_cap = nb_env ? nb_env : (n_hi <= 4096 ? 256u : 512u);
     uint32_t hpb = eq_rows_per_block(n_hi, nb_cap);
     // tables of >= 2^20 entries whose three middle variables are 128-bit challenges take the expanding kernel. Measured, narrow challenges,
-    // back-to-back launches (tools/exp/run_eq_expand_ab.sh, profiles/r5e_eq_expand_ab.txt): 2^24 entries 165 -> 139 us, 2^20 18.6 -> 17.6 us;
+    // back-to-back launches (tools/exp/archive/run_eq_expand_ab.sh, profiles/r5e_eq_expand_ab.txt): 2^24 entries 165 -> 139 us, 2^20 18.6 -> 17.6 us;
     // 2^16 7.6 -> 10.7 and 2^14 7.3 -> 9.8 us — a short table is a latency chain, and the expansion adds three dependent products to it.
     // ZG_EQ_EXPAND = 0: never; k >= 14: from 2^k entries on (the tests use 14 to run the kernel at small sizes).
     static const uint32_t expand_min = env_uint("ZG_EQ_EXPAND", 20, 0, 34);
