@@ -184,6 +184,9 @@ def compact_line(out, extra_file="bench_extra.json"):
         "fold_2e24_TBps": _r(_get(ex, "fold_2^24_by_challenge_kind", "narrow_TBps")),
         "hyperkzg_open_v20_resident_ms": _r(_get(ex, "hyperkzg_open", "v20_resident_ms")),
         "prove_path_ms": _r(_get(ex, "prove_path", "total_ms")), "prove_path_single_use_key_ms": _r(_get(ex, "prove_path_single_use_key", "total_ms")),
+        "key_2e24_setup_ms": _r(_get(ex, "largest_key_2^24+256", "table", "setup_ms")), "key_2e24_table_bytes": _get(ex, "largest_key_2^24+256", "table", "table_bytes"),
+        "key_2e24_commit_ms": _r(_get(ex, "largest_key_2^24+256", "table", "commit_ms")),
+        "key_2e24_table_less_commit_ms": _r(_get(ex, "largest_key_2^24+256", "table_less", "commit_ms")),
         "msm_2e22_sharded_per_s": _r(_get(ex, "msm_2^22_sharded", "value")),
         "sumcheck_sharded_rounds_per_s": _r(_get(ex, "sumcheck_v20_sharded", "rounds_per_s")),
     }
@@ -1038,6 +1041,34 @@ def extra_measurements(lib, api, torch, dev, stream, args, srs_xy=None, wd=None)
             params.deinit()
         except Exception as exc:  # an extra: never take the headline line down with it
             extra["hyperkzg_open"] = {"error": repr(exc)}
+    # the reference's largest proving key (srs_size = 256 + 2^24, src/host/mod.zig:384-387): HyperKZG.setup on the device, the table's bytes and
+    # one commitment with the table and without it. Parity at this size is tests/test_gpu_largest_key.py; here only the costs.
+    try:
+        if wd is not None:
+            wd.beat(limit=300)
+        nk = (1 << 24) + 256
+        res = {"points": nk}
+        torch.cuda.synchronize()
+        d_sc = torch.from_numpy(lib.field_op(lib.FR, lib.OP_TO_MONT, raw_scalars(0x4B455924, 0, 1 << 20)).view(np.int64)).to(dev).repeat(17, 1)[:nk].contiguous()
+        for uses, name in ((0, "table"), (1, "table_less")):
+            t0 = time.perf_counter()
+            h, _, _ = lib.Bases.hyperkzg_setup(api.generator(), api.fr_from_int(api.HyperKZG.TAU), nk, want_points=False, expected_uses=uses)
+            t_setup = (time.perf_counter() - t0) * 1e3
+            h.msm_dev(d_sc.data_ptr(), nk, stream=stream)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                got = h.msm_dev(d_sc.data_ptr(), nk, stream=stream)
+            res[name] = {"setup_ms": t_setup, "table_bytes": h.table_bytes(), "plan": list(h.plan()), "commit_ms": (time.perf_counter() - t0) / 3 * 1e3}
+            res[name + "_result"] = got
+            h.free()
+        a, b = res.pop("table_result"), res.pop("table_less_result")
+        res["both_handles_agree"] = bool(a[1] == b[1] and np.array_equal(a[0], b[0]))
+        res["note"] = "zg_hyperkzg_setup(2^24 + 256) to completion (host-timed, nothing leaves the device), then zg_msm_g1_dev over the whole key, scalars resident"
+        extra["largest_key_2^24+256"] = res
+        del d_sc
+        torch.cuda.empty_cache()
+    except Exception as exc:  # an extra: never take the headline line down with it
+        extra["largest_key_2^24+256"] = {"error": repr(exc)}
     # the metric's second size, 2^22 points on this one GPU (same code path, fresh process)
     try:
         import subprocess
