@@ -744,8 +744,8 @@ def main():
                                                         "counters were collected for the default plan on one GPU only"))
     prof_ms = profiled_duration_ms(args.logn) if default_plan else None
     if prof_ms:
-        # the same kernel in the committed rocprofv3 run (profiles/r6_kernel_stats_trace1.csv: the serial bench issues its MSMs back to
-        # back, so a launch takes 7/8 of the chunk slots; the HIP-event figure above is a lone launch with every slot): both fractions
+        # the same kernel in the committed rocprofv3 run (profiles/r6_kernel_stats_trace1.csv: the one-stream serial bench; since round 6 a
+        # launch there takes every chunk slot, like the lone launch the HIP events above bracket — msm.hip, "not company"): both fractions
         out["roofline"]["rocprofv3_avg_launch_ms"] = prof_ms
         out["roofline"]["frac_at_rocprofv3_duration"] = alg_bytes / (prof_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
     pmc = pmc_all.get(f"2^{args.logn}", {}).get("SQ_INSTS_VALU")
@@ -758,7 +758,7 @@ def main():
             "pmc_wave_instructions_per_add": per_add, "static_wave_instructions_per_add": MADD_STATIC_INSTRS,
             "floor_ms_from_pmc_count": floor_pmc, "frac_from_pmc_count": floor_pmc / alone_ms,
             "residual": 1.0 - floor_pmc / alone_ms,
-            "residual_is": "time the SIMDs do not spend issuing: the launch runs 7/8 of the chip's chunk slots when other MSMs are in flight (full "
+            "residual_is": "time the SIMDs do not spend issuing: the launch runs 7/8 of the chip's chunk slots when MSMs on other streams are in flight (full "
                            "when alone), the random 64-byte table rows (DESIGN 4a: a wave waits on its gathers when the other wave of its SIMD "
                            "does too), and the chunk-length spread at the end of the launch",
             "pmc_source": "SQ_INSTS_VALU, rocprofv3 --pmc (own pass), profiles/r6_pmc.json"})

@@ -106,6 +106,7 @@ struct zg_bases_s {
         uint32_t *d_heavy = nullptr;      // 2*NK: heavy bucket list, then huge bucket list
         void *d_state = nullptr;          // MsmState
         hipEvent_t done = nullptr;        // recorded after the lane's last MSM; the next user waits on it
+        hipStream_t last_st = nullptr;    // ... and the stream it was recorded on
         bool used = false;
 #ifdef ZG_EXP_SKIP_SORT
         bool exp_sorted_once = false;
@@ -2152,6 +2153,7 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
                             uint32_t rec_stride, uint32_t inf_stride) {
     if (ln.used) ZG_HIP(hipStreamWaitEvent(st, ln.done, 0));  // the lane's previous MSM may be on another stream
     ln.used = true;
+    ln.last_st = st;
     // point slices (see table_span_points): S > 1 only for one scalar vector over a table wider than the span
     size_t S, per;
     slice_counts(p, n_pts, S, per);
@@ -2284,8 +2286,11 @@ static int msm_enqueue_lane(zg_bases_s *b, const MsmPlan &p, zg_bases_s::Lane &l
         // a launch over a sub-range of the handle (a short prefix, the last set of a batch) gets as many chunks as ITS digits
         // warrant, never more than the workspace was sized for
         bool alone = env_int("ZG_MSM_ALONE_FULL", 1) != 0;
+        // (round 6) an MSM still in flight ON THIS STREAM is not company: its kernels finish before this launch starts (stream order), so
+        // there is nothing the spare registers could run under. Only work on OTHER streams makes the 7/8 launch pay; a caller that
+        // pipelines on one stream gets the full grid (serial bench at 2^20: accumulate 1.30 -> 1.18 ms per launch).
         for (auto &o : b->lanes)
-            if (alone && &o != &ln && o.used && hipEventQuery(o.done) == hipErrorNotReady) alone = false;
+            if (alone && &o != &ln && o.used && o.last_st != st && hipEventQuery(o.done) == hipErrorNotReady) alone = false;
         (void)hipGetLastError();  // hipErrorNotReady is an answer, not a failure
         // a table-less launch set (one bucket set per window: its reduction is a few hundred short workgroups, not a latency chain under
         // someone else's accumulation) takes every slot either way: 612 MSM/s against 587 / 596 / 603 at 15/16, 7/8, 13/16 of them
