@@ -293,7 +293,7 @@ def test_run_sumcheck_vs_oracle(zl, ob, logn):
     assert np.array_equal(fin, wfin) and ok == wok == 1
 
 
-@pytest.mark.parametrize("logn", [0, 1, 2, 3, 6, 9, 10, 12, 13, 16, 18])
+@pytest.mark.parametrize("logn", [0, 1, 2, 3, 6, 9, 10, 12, 13, 16, 17, 18])
 def test_device_resident_run_sumcheck_vs_oracle(zl, ob, logn):
     """zg_run_sumcheck: prover and toy verifier both on the device (src/subprotocols/mod.zig:302-354, :165-243) —
     claim, every round polynomial, every challenge, the final evaluation and the result flag equal the oracle's."""

@@ -5,8 +5,8 @@
 # (zolt_amd/csrc/*.o: run make there first).
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-NAME=$1; FLAGS=$2; FILES=${3:-"runtime msm poly psc sharded rrw rwc"}
-ALL="runtime msm poly psc sharded rrw rwc"
+NAME=$1; FLAGS=$2; FILES=${3:-"runtime msm poly psc sharded rrw rwc ingest"}
+ALL="runtime msm poly psc sharded rrw rwc ingest"
 D=$ROOT/build_ab/$NAME
 mkdir -p $D
 for f in $FILES; do
