@@ -192,6 +192,8 @@ def compact_line(out, extra_file="bench_extra.json"):
     }
     line["also"] = {k: v for k, v in also.items() if v is not None}
     line["extra_file"] = extra_file
+    if out.get("provisional"):
+        line["provisional"] = True  # N > 1 only: printed right after the timed region; the last line of a complete run supersedes it
     text = json.dumps(line, separators=(",", ":"))
     if len(text) >= COMPACT_LIMIT:  # cannot happen with the fixed key set above; never let a long string take the line down
         line.pop("also")
@@ -634,6 +636,108 @@ def main():
     bases_xy, d_scalars, want, bases = m["bases_xy"], m["d_scalars"], m["want"], m["bases"]
     m_plan = bases.plan()
 
+    def core_object():
+        """the line's contract keys, config, roofline (and the per-kernel times under extra) from the timed region alone — built twice when
+        N > 1: right after the timed region (a provisional line, so that the first run on a multi-GPU node leaves its headline on stdout
+        even if one of the extras behind it fails) and at the end"""
+        ms_per_step = elapsed / args.steps * 1e3
+        value = args.steps * per_step / elapsed
+        ms_per_msm = ms_per_step / per_step
+        # roofline of the dominant kernel from its duration running BY ITSELF (one stream, outside the timed region): this is the
+        # figure rocprofv3 --kernel-trace --stats reports for the serial run (profiles/r2*_kernel_stats_streams1.csv). Inside the timed
+        # region kernels of three streams share the GPU and a HIP-event bracket stretches beyond the per-MSM step time; that
+        # overlapped figure is kept beside it for transparency only.
+        acc_ms, acc_cnt = prof["msm_accumulate"]
+        acc_overlapped_ms = acc_ms / max(acc_cnt, 1)
+        alone_ms = prof_alone["msm_accumulate"][0] / max(prof_alone["msm_accumulate"][1], 1)
+        # a long MSM runs as point slices (DESIGN.md 5.10): several accumulate launches per MSM, each over its share of the points
+        SERIAL_MSMS = 6  # the serial leg above
+        launches = {k: v[1] / SERIAL_MSMS for k, v in prof_alone.items()}
+        acc_launches = max(launches.get("msm_accumulate", 1.0), 1.0)
+        alg_bytes = 96.0 * n_loc / acc_launches  # 64 B affine point + 32 B scalar per point (SURVEY §8(d)) on this rank, per launch
+        achieved = alg_bytes / (alone_ms * 1e-3) / 1e9 if alone_ms else 0.0
+        out = {
+            "metric": "BN254 G1 MSM/sec", "value": value, "unit": "MSM/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"msm_g1_2^{args.logn}", "points": n, "points_per_gpu": n_loc, "msms_per_step": per_step,
+                       "ms_per_msm": ms_per_msm,
+                       "mode": "table-less (expected_uses = 1)" if args.precompute == 1 else "precomputed table of multiples",
+                       "arithmetic": "256-bit Montgomery field elements as 32-bit limbs (9x29-bit lazy limbs in the MSM), integer only",
+                       "bases": "(i+1)*G resident in HBM (table of 2^(c*l)*P_i built once at upload, like an SRS)", "scalars": "uniform mod r, splitmix64 seed 0x5A4F4C54, resident in HBM",
+                       "sharding": f"contiguous chunks + {dist_backend} all-gather of the step's Jacobian partials (96 bytes per MSM, one exchange per stream and step)" if world > 1 else "single GPU",
+                       "collective_ranks": collective_ranks,
+                       "streams": nstreams,
+                       "bit_exact_check": "closed form (sum s_i*(i+1))*G via scalarMul kernel, every timed MSM"},
+            "roofline": {"bound": "hbm", "kernel": "msm_accumulate_chunk_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": None, "traffic_source": TRAFFIC_SOURCE,
+                         "algorithmic_bytes_per_launch": alg_bytes, "launches_per_msm": acc_launches, "avg_launch_ms": alone_ms,
+                         "avg_launch_ms_source": "HIP events around the kernel, one stream in flight (6 serial MSMs right after the timed region)",
+                         "avg_launch_ms_overlapped": acc_overlapped_ms,
+                         "note": "MSM is integer-ALU-bound (Fp products per bucket addition x windows per point); see DESIGN.md"},
+            "extra": {"kernel_ms_per_msm_overlapped": {k: (v[0] / max(v[1], 1)) * launches.get(k, 1.0) for k, v in prof.items() if v[1]},
+                      "kernel_ms_per_msm_alone": {k: v[0] / SERIAL_MSMS for k, v in prof_alone.items() if v[1]},
+                      "kernel_launch_sets_per_msm": acc_launches,
+                      "setup_seconds": setup_s},
+        }
+        assert alone_ms <= ms_per_msm * 1.5 or world > 1 or nstreams == 1, "kernel-alone duration inconsistent with the step time"
+
+        # the ceiling that actually binds msm_accumulate: VALU issue. One mixed add compiles to MADD_ISSUE_CYCLES issue cycles
+        # per wave (static instruction mix of the kernel's fast path, DESIGN.md 4a); peak = 1024 SIMDs x 2.4 GHz.
+        plan_c, plan_w, plan_l = m_plan
+        adds = float(n_loc) * plan_w * (1.0 - 2.0 ** -plan_c) / acc_launches  # one table row per non-zero signed c-bit digit, per launch
+        issue = adds / 64.0 * MADD_ISSUE_CYCLES / (alone_ms * 1e-3) / 1e9 if alone_ms and args.logn >= 15 else None
+        out["config"]["window_bits"], out["config"]["windows"], out["config"]["table_levels"] = plan_c, plan_w, plan_l
+        # what the headline mode costs before its first MSM: the table of precomputed multiples (review item: "the line does not price the table")
+        out["config"]["table_build_ms"], out["config"]["table_bytes"] = table_build_ms, table_bytes
+        out["config"]["table_build_note"] = ("zg_g1_bases_upload_dev to completion, host-timed on this rank: plan + workspaces + msm_precompute_kernel (levels x 64 B per "
+                                             "base); breakeven_msms is filled in from extra.msm_no_precompute (the same MSM with expected_uses = 1: no table)")
+        out["config"]["breakeven_msms"] = None
+        out["roofline"]["avg_launch_ms_alone"] = alone_ms  # same number as avg_launch_ms (kept under its round-1 name)
+        out["roofline"]["valu_issue"] = {"achieved": issue, "peak": VALU_PEAK_GCYC, "unit": "G issue-cycles/s",
+                                         "frac": issue / VALU_PEAK_GCYC if issue else None,
+                                         "duration": "avg_launch_ms_alone (the kernel running by itself, outside the timed region)",
+                                         "model": "1467 v_mad_u64_u32 + 371 other quarter-rate + 382 half-rate VALU instructions per mixed add"}
+        floor_ms = adds / 64.0 / 1024.0 * MADD_MIN_NS_PER_SIMD * 1e-6 if args.logn >= 15 else None
+        out["roofline"]["valu_issue_measured_rates"] = {
+            "floor_ms": floor_ms, "frac": floor_ms / alone_ms if floor_ms and alone_ms else None,
+            "model": "adds / (64 lanes x 1024 SIMDs) x least ns per wave-wide mixed add at the issue times measured by tools/microbench.hip "
+                     "(profiles/r1_microbench_instruction_rates.txt); frac = floor / avg_launch_ms_alone"}
+        default_plan = world == 1 and args.window_bits == 0 and args.precompute == 0
+        pmc_all = load_pmc() if default_plan else {}
+        out["roofline"]["traffic"] = measured_traffic(pmc_all, args.logn, adds)
+        if out["roofline"]["traffic"] is None:
+            out["roofline"]["traffic_source"] = ("null: " + ("profiles/r6_pmc.json has no counters for this size" if default_plan else
+                                                            "counters were collected for the default plan on one GPU only"))
+        prof_ms = profiled_duration_ms(args.logn) if default_plan else None
+        if prof_ms:
+            # the same kernel in the committed rocprofv3 run (profiles/r6_kernel_stats_trace1.csv: the one-stream serial bench; since round 6 a
+            # launch there takes every chunk slot, like the lone launch the HIP events above bracket — msm.hip, "not company"): both fractions
+            out["roofline"]["rocprofv3_avg_launch_ms"] = prof_ms
+            out["roofline"]["frac_at_rocprofv3_duration"] = alg_bytes / (prof_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
+        pmc = pmc_all.get(f"2^{args.logn}", {}).get("SQ_INSTS_VALU")
+        if pmc and alone_ms:
+            wave_adds = adds / 64.0
+            per_add = pmc / wave_adds
+            ns_per_add = MADD_MIN_NS_PER_SIMD + max(per_add - MADD_STATIC_INSTRS, 0.0) * SIMPLE_OP_NS
+            floor_pmc = wave_adds / 1024.0 * ns_per_add * 1e-6
+            out["roofline"]["valu_issue_measured_rates"].update({
+                "pmc_wave_instructions_per_add": per_add, "static_wave_instructions_per_add": MADD_STATIC_INSTRS,
+                "floor_ms_from_pmc_count": floor_pmc, "frac_from_pmc_count": floor_pmc / alone_ms,
+                "residual": 1.0 - floor_pmc / alone_ms,
+                "residual_is": "time the SIMDs do not spend issuing: the launch runs 7/8 of the chip's chunk slots when MSMs on other streams are in flight (full "
+                               "when alone), the random 64-byte table rows (DESIGN 4a: a wave waits on its gathers when the other wave of its SIMD "
+                               "does too), and the chunk-length spread at the end of the launch",
+                "pmc_source": "SQ_INSTS_VALU, rocprofv3 --pmc (own pass), profiles/r6_pmc.json"})
+        return out, ms_per_msm
+
+    if world > 1 and rank == 0:
+        prov, _ = core_object()
+        prov["provisional"] = True
+        sys.stdout.flush()
+        print(compact_line(prov, extra_file=None), flush=True)  # an EARLIER stdout line; the last line of a complete run supersedes it
+
     # BASELINE config 4: the 2^22-point MSM sharded over the ranks (same code path, untimed setup), reported beside the
     # headline workload so that the strong-scaling curve exists at both sizes of the metric
     sharded_22 = None
@@ -672,96 +776,7 @@ def main():
         dist.destroy_process_group()
         return
 
-    ms_per_step = elapsed / args.steps * 1e3
-    value = args.steps * per_step / elapsed
-    ms_per_msm = ms_per_step / per_step
-    # roofline of the dominant kernel from its duration running BY ITSELF (one stream, outside the timed region): this is the
-    # figure rocprofv3 --kernel-trace --stats reports for the serial run (profiles/r2*_kernel_stats_streams1.csv). Inside the timed
-    # region kernels of three streams share the GPU and a HIP-event bracket stretches beyond the per-MSM step time; that
-    # overlapped figure is kept beside it for transparency only.
-    acc_ms, acc_cnt = prof["msm_accumulate"]
-    acc_overlapped_ms = acc_ms / max(acc_cnt, 1)
-    alone_ms = prof_alone["msm_accumulate"][0] / max(prof_alone["msm_accumulate"][1], 1)
-    # a long MSM runs as point slices: several accumulate launches per MSM, each over its share of the points
-    SERIAL_MSMS = 6  # the serial leg above
-    launches = {k: v[1] / SERIAL_MSMS for k, v in prof_alone.items()}
-    acc_launches = max(launches.get("msm_accumulate", 1.0), 1.0)
-    alg_bytes = 96.0 * n_loc / acc_launches  # 64 B affine point + 32 B scalar per point on this rank, per launch
-    achieved = alg_bytes / (alone_ms * 1e-3) / 1e9 if alone_ms else 0.0
-    out = {
-        "metric": "BN254 G1 MSM/sec", "value": value, "unit": "MSM/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-        "config": {"workload": f"msm_g1_2^{args.logn}", "points": n, "points_per_gpu": n_loc, "msms_per_step": per_step,
-                   "ms_per_msm": ms_per_msm,
-                   "mode": "table-less (expected_uses = 1)" if args.precompute == 1 else "precomputed table of multiples",
-                   "arithmetic": "256-bit Montgomery field elements as 32-bit limbs (9x29-bit lazy limbs in the MSM), integer only",
-                   "bases": "(i+1)*G resident in HBM (table of 2^(c*l)*P_i built once at upload, like an SRS)", "scalars": "uniform mod r, splitmix64 seed 0x5A4F4C54, resident in HBM",
-                   "sharding": f"contiguous chunks + {dist_backend} all-gather of the step's Jacobian partials (96 bytes per MSM, one exchange per stream and step)" if world > 1 else "single GPU",
-                   "collective_ranks": collective_ranks,
-                   "streams": nstreams,
-                   "bit_exact_check": "closed form (sum s_i*(i+1))*G via scalarMul kernel, every timed MSM"},
-        "roofline": {"bound": "hbm", "kernel": "msm_accumulate_chunk_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": None, "traffic_source": TRAFFIC_SOURCE,
-                     "algorithmic_bytes_per_launch": alg_bytes, "launches_per_msm": acc_launches, "avg_launch_ms": alone_ms,
-                     "avg_launch_ms_source": "HIP events around the kernel, one stream in flight (6 serial MSMs right after the timed region)",
-                     "avg_launch_ms_overlapped": acc_overlapped_ms,
-                     "note": "MSM is integer-ALU-bound (Fp products per bucket addition x windows per point); see DESIGN.md"},
-        "extra": {"kernel_ms_per_msm_overlapped": {k: (v[0] / max(v[1], 1)) * launches.get(k, 1.0) for k, v in prof.items() if v[1]},
-                  "kernel_ms_per_msm_alone": {k: v[0] / SERIAL_MSMS for k, v in prof_alone.items() if v[1]},
-                  "kernel_launch_sets_per_msm": acc_launches,
-                  "setup_seconds": setup_s},
-    }
-    assert alone_ms <= ms_per_msm * 1.5 or world > 1 or nstreams == 1, "kernel-alone duration inconsistent with the step time"
-
-    # the ceiling that actually binds msm_accumulate: VALU issue. One mixed add compiles to MADD_ISSUE_CYCLES issue cycles
-    # per wave (static instruction mix of the kernel's fast path); peak = 1024 SIMDs x 2.4 GHz.
-    plan_c, plan_w, plan_l = m_plan
-    adds = float(n_loc) * plan_w * (1.0 - 2.0 ** -plan_c) / acc_launches  # one table row per non-zero signed c-bit digit, per launch
-    issue = adds / 64.0 * MADD_ISSUE_CYCLES / (alone_ms * 1e-3) / 1e9 if alone_ms and args.logn >= 15 else None
-    out["config"]["window_bits"], out["config"]["windows"], out["config"]["table_levels"] = plan_c, plan_w, plan_l
-    # what the headline mode costs before its first MSM: the table of precomputed multiples (review item: "the line does not price the table")
-    out["config"]["table_build_ms"], out["config"]["table_bytes"] = table_build_ms, table_bytes
-    out["config"]["table_build_note"] = ("zg_g1_bases_upload_dev to completion, host-timed on this rank: plan + workspaces + msm_precompute_kernel (levels x 64 B per "
-                                         "base); breakeven_msms is filled in from extra.msm_no_precompute (the same MSM with expected_uses = 1: no table)")
-    out["config"]["breakeven_msms"] = None
-    out["roofline"]["avg_launch_ms_alone"] = alone_ms  # same number as avg_launch_ms (kept under its round-1 name)
-    out["roofline"]["valu_issue"] = {"achieved": issue, "peak": VALU_PEAK_GCYC, "unit": "G issue-cycles/s",
-                                     "frac": issue / VALU_PEAK_GCYC if issue else None,
-                                     "duration": "avg_launch_ms_alone (the kernel running by itself, outside the timed region)",
-                                     "model": "1467 v_mad_u64_u32 + 371 other quarter-rate + 382 half-rate VALU instructions per mixed add"}
-    floor_ms = adds / 64.0 / 1024.0 * MADD_MIN_NS_PER_SIMD * 1e-6 if args.logn >= 15 else None
-    out["roofline"]["valu_issue_measured_rates"] = {
-        "floor_ms": floor_ms, "frac": floor_ms / alone_ms if floor_ms and alone_ms else None,
-        "model": "adds / (64 lanes x 1024 SIMDs) x least ns per wave-wide mixed add at the issue times measured by tools/microbench.hip "
-                 "(profiles/r1_microbench_instruction_rates.txt); frac = floor / avg_launch_ms_alone"}
-    default_plan = world == 1 and args.window_bits == 0 and args.precompute == 0
-    pmc_all = load_pmc() if default_plan else {}
-    out["roofline"]["traffic"] = measured_traffic(pmc_all, args.logn, adds)
-    if out["roofline"]["traffic"] is None:
-        out["roofline"]["traffic_source"] = ("null: " + ("profiles/r6_pmc.json has no counters for this size" if default_plan else
-                                                        "counters were collected for the default plan on one GPU only"))
-    prof_ms = profiled_duration_ms(args.logn) if default_plan else None
-    if prof_ms:
-        # the same kernel in the committed rocprofv3 run (profiles/r6_kernel_stats_trace1.csv: the one-stream serial bench; since round 6 a
-        # launch there takes every chunk slot, like the lone launch the HIP events above bracket — msm.hip, "not company"): both fractions
-        out["roofline"]["rocprofv3_avg_launch_ms"] = prof_ms
-        out["roofline"]["frac_at_rocprofv3_duration"] = alg_bytes / (prof_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
-    pmc = pmc_all.get(f"2^{args.logn}", {}).get("SQ_INSTS_VALU")
-    if pmc and alone_ms:
-        wave_adds = adds / 64.0
-        per_add = pmc / wave_adds
-        ns_per_add = MADD_MIN_NS_PER_SIMD + max(per_add - MADD_STATIC_INSTRS, 0.0) * SIMPLE_OP_NS
-        floor_pmc = wave_adds / 1024.0 * ns_per_add * 1e-6
-        out["roofline"]["valu_issue_measured_rates"].update({
-            "pmc_wave_instructions_per_add": per_add, "static_wave_instructions_per_add": MADD_STATIC_INSTRS,
-            "floor_ms_from_pmc_count": floor_pmc, "frac_from_pmc_count": floor_pmc / alone_ms,
-            "residual": 1.0 - floor_pmc / alone_ms,
-            "residual_is": "time the SIMDs do not spend issuing: the launch runs 7/8 of the chip's chunk slots when MSMs on other streams are in flight (full "
-                           "when alone), the random 64-byte table rows (DESIGN 4a: a wave waits on its gathers when the other wave of its SIMD "
-                           "does too), and the chunk-length spread at the end of the launch",
-            "pmc_source": "SQ_INSTS_VALU, rocprofv3 --pmc (own pass), profiles/r6_pmc.json"})
+    out, ms_per_msm = core_object()
     if single_proc is not None:
         out["extra"]["single_process_c_abi"] = single_proc
     if sharded_sc is not None:

@@ -80,6 +80,10 @@ def test_compact_line_two_ranks_and_missing_legs():
     assert line["config"]["collective_ranks"] == {"backend": "rccl", "ranks": 2} and line["config"]["points_per_gpu"] == 1 << 19
     assert line["roofline"]["traffic"] is None and line["roofline"]["counters"] is None
     assert line["also"] == {"msm_2e22_sharded_per_s": 321.5, "sumcheck_sharded_rounds_per_s": 12345.6, "sumcheck_host": "python binding"}
+    assert "provisional" not in line
+    full["provisional"] = True  # what rank 0 prints right after the timed region when N > 1 (an earlier stdout line)
+    prov = json.loads(bench.compact_line(full, extra_file=None))
+    assert prov["provisional"] is True and prov["extra_file"] is None and prov["value"] == line["value"]
 
 
 def test_emit_prints_the_compact_line_last_and_writes_the_side_file(tmp_path, monkeypatch, capsys):

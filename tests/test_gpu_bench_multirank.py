@@ -20,9 +20,14 @@ def _bench(args, extra_env, cwd, timeout=900):
     env.pop("ZG_SHARD_EXCHANGE", None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env, cwd=str(cwd))
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert out.returncode == 0 and len(lines) == 1, (out.returncode, out.stdout[-800:], out.stderr[-1500:])
+    n_ranks = int(args[args.index("--gpus") + 1]) if extra_env.get("ZOLT_BENCH_DIST_BACKEND") else 1
+    # N > 1: a provisional line right after the timed region (the headline survives a failing extra on a first multi-GPU run), then the line
+    assert out.returncode == 0 and len(lines) == (2 if n_ranks > 1 else 1), (out.returncode, out.stdout[-800:], out.stderr[-1500:])
+    if n_ranks > 1:
+        prov = json.loads(lines[0])
+        assert prov["provisional"] is True and prov["n_gpus"] == n_ranks and prov["value"] > 0 and "roofline" in prov and len(lines[0]) < 4096
     last = out.stdout.rstrip("\n").splitlines()[-1]
-    assert last == lines[0] and len(last) < 4096, (len(last), out.stdout[-600:])  # the compact line is the LAST line of stdout and fits the driver's window
+    assert last == lines[-1] and len(last) < 4096 and "provisional" not in json.loads(last), (len(last), out.stdout[-600:])  # the compact line is the LAST line of stdout
     side = os.path.join(str(cwd), "bench_extra.json")
     assert os.path.exists(side), "rank 0 writes the side file into the cwd"
     assert sorted(os.listdir(str(cwd))) == ["bench_extra.json"], "one side file, written by rank 0 only"
