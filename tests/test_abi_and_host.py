@@ -141,6 +141,36 @@ def test_zig_backend_calls_match_the_generated_externs():
         assert code.count(o) == code.count(c), o
 
 
+def test_zig_sources_use_no_undeclared_identifier(tmp_path):
+    """One notch above counting brackets (no Zig toolchain in this image): tools/zig_lint.py holds every identifier USED in
+    zig/gpu/backend.zig and the generated ffi.zig to a declaration (file / container level const, var, fn; parameter, local or capture of
+    the enclosing function; keyword, primitive, builtin) and every direct call of one of the shim's free functions to its parameter count.
+    The lint has to earn its keep: five one-token mutations of the shim — a misspelt
+    local, a wrong parameter name, a missing helper, a wrong capture, a dropped file-level name — must each be reported."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import zig_lint
+    for name in ("backend.zig", "ffi.zig"):
+        found, n = zig_lint.lint(os.path.join(ROOT, "zig", "gpu", name))
+        assert not found and n > 2000, found[:5]
+    src = open(os.path.join(ROOT, "zig", "gpu", "backend.zig")).read()
+    mutations = [("&f1.limbs, &FR_ONE) and", "&f_1.limbs, &FR_ONE) and", "f_1"),
+                 ("available = ffi.zg_init(dev) == ffi.OK;", "available = ffi.zg_init(device) == ffi.OK;", "device"),
+                 ("init_once.call();", "initOnce.call();", "initOnce"),
+                 ("if (v.len > 0 and v[0] == '0') return;", "if (w.len > 0 and v[0] == '0') return;", "w"),
+                 ("return @intCast(n_devices);", "return @intCast(n_device);", "n_device")]
+    for k, (a, b, bad) in enumerate(mutations):
+        assert src.count(a) == 1, a
+        path = tmp_path / f"mutant{k}.zig"
+        path.write_text(src.replace(a, b))
+        found, _ = zig_lint.lint(str(path))
+        assert len(found) == 1 and f"'{bad}' is used but never declared" in found[0], (k, found)
+    # ... and the arity of direct calls to the shim's own free functions
+    path = tmp_path / "mutant_arity.zig"
+    path.write_text(src.replace("limbsOf(F, scalars)", "limbsOf(scalars)", 1))
+    found, _ = zig_lint.lint(str(path))
+    assert found == [f for f in found if "'limbsOf' takes 2 arguments, called with 1" in f] and len(found) == 1, found
+
+
 def test_zig_backend_rules_out_the_stale_table_and_wrong_field_hazards():
     """zig/gpu/backend.zig (compile-unverified) is at least held to the three rules INTEGRATION.md states: a comptime type gate in
     front of every MSM path (the reference instantiates MSM(Fr, Fr), src/msm/mod.zig:853-873,911-936), no (ptr, len)-keyed
