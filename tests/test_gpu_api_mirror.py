@@ -138,7 +138,8 @@ def test_hyperkzg_open_mid_sizes(env, v, srs_n):
     params.deinit()
 
 
-@pytest.mark.parametrize("v,srs_n,fuse", [(17, 1 << 17, "2"), (18, 1 << 17, "2"), (18, 1 << 18, "2"), (18, 1 << 17, "1"), (17, 1 << 17, "1"), (18, 1 << 18, "1"), (17, 1 << 17, "0")])
+@pytest.mark.parametrize("v,srs_n,fuse", [(17, 1 << 17, "2"), (18, 1 << 17, "2"), (18, 1 << 18, "2"), (18, 1 << 17, "1"), (17, 1 << 17, "1"), (18, 1 << 18, "1"), (17, 1 << 17, "0"),
+                                          (18, 1 << 17, "1:single_pass_sort"), (17, 1 << 17, "2:single_pass_sort"), (18, 1 << 18, "1:fine_bits_min_8")])
 def test_hyperkzg_open_long_levels(env, v, srs_n, fuse, monkeypatch):
     """open() with several long levels (quotients of more than 16384 entries) on a wide-window SRS handle: they are committed as
     the rows of one zero-padded matrix by ONE fused launch set (two-pass sort over several vectors' bucket sets), the short
@@ -146,6 +147,14 @@ def test_hyperkzg_open_long_levels(env, v, srs_n, fuse, monkeypatch):
     levels in the matrix; 2: the first long level keeps its own launch set and the matrix holds the rest at the second level's length
     (needs three long levels); 0: one launch set per long level on the helper streams. Same quotient commitments and final evaluation as the oracle either way."""
     api, lib, ob = env
+    # (round 6) "...:single_pass_sort" / "...:fine_bits_min_8": the fused set of long levels is priced by the two-pass sort's coarse bins; with
+    # that sort switched off (or refused for lack of fine key bits) the set must NOT be fused — it ran the single-pass LDS scatter over 160 k
+    # counters and faulted. Found by running the whole suite under the alternate switches.
+    fuse, _, alt = fuse.partition(":")
+    if alt == "single_pass_sort":
+        monkeypatch.setenv("ZG_MSM_TWO_PASS_SORT", "0")
+    elif alt == "fine_bits_min_8":
+        monkeypatch.setenv("ZG_MSM_FINE_BITS_MIN", "8")
     monkeypatch.setenv("ZG_HK_FUSE_LONG", fuse)
     gm = ob.g1_gen_multiples(srs_n)
     inf = np.zeros(srs_n, dtype=np.uint8)

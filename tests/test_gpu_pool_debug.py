@@ -51,6 +51,7 @@ print(json.dumps(out))
 def _run(mode):
     env = dict(os.environ)
     env.pop("ZG_POOL_DEBUG", None)
+    env.pop("ZG_DEV_ALLOC_CACHE_MB", None)  # (0 = the pool keeps nothing: there is no reuse to check)
     if mode:
         env["ZG_POOL_DEBUG"] = str(mode)
     res = subprocess.run([sys.executable, "-c", SCRIPT % ROOT], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)

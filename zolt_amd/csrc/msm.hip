@@ -2767,6 +2767,21 @@ static int msm_batch_enqueue(zg_bases_s *b, size_t n, const uint64_t *d_scalars,
     }
     if (b->small && n <= b->small->n) return msm_batch_enqueue(b->small, n, d_scalars, k, st, d_out9, false, mode);  // narrow-window side table
     size_t lim = batch_fuse_limit(b, n, wide_ok);
+    if (lim >= 2 && k >= 2) {
+        // batch_fuse_limit prices a wide set by the two-pass sort's coarse bins; whether that sort really applies is plan_two_pass's
+        // decision (ZG_MSM_TWO_PASS_SORT, ZG_MSM_FINE_BITS*, the set's size). A set that would sort in ONE pass needs all its K * G * NB
+        // counters in 128 KiB of LDS: if it has neither, it is not fused (round 6: with ZG_MSM_TWO_PASS_SORT=0 HyperKZG.open's long
+        // levels ran the LDS scatter over 160 k counters — a memory fault; found by running the suite under the alternate switches)
+        zg_msm_config cfg_t{b->plan.c, b->plan.L, 0};
+        MsmPlan trial;
+        const size_t kc_t = k < lim ? k : lim;
+        if (make_plan(n, &cfg_t, trial, kc_t) != ZG_OK) {
+            lim = 0;
+        } else {
+            plan_two_pass(trial, (size_t)b->plan.L * b->n, n * kc_t);
+            if (!trial.fb && (size_t)trial.NK * 4 > 128 * 1024) lim = 0;
+        }
+    }
     if (lim == 0 && wide_ok && k >= 2 && k <= ROWS_SHARED_TAIL_MAX && mode == 0 && rows_shared_tail_ok(b, n)) return msm_rows_shared_tail(b, n, d_scalars, k, st, d_out9);
     if (lim == 0 || k < 2) {
         // one launch set per vector, rotating through the handle's workspaces AND through three streams (the caller's

@@ -616,6 +616,7 @@ __global__ void pool_selftest_late_writer(uint32_t *p, size_t words, long long s
 int zg_pool_debug_selftest(void) {
     ZG_INIT();
     if (pool_debug() >= 2) return ZG_ERR_INVALID;  // would abort by design
+    if (pool_cap() == 0) return 0;                  // ZG_DEV_ALLOC_CACHE_MB=0: freed blocks go straight back to the driver, nothing is ever reused
     const size_t bytes = 3 * 4096 + 512;            // a class of its own in practice
     hipStream_t st = lib_stream();
     void *p = pool_alloc(bytes);
