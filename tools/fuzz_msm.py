@@ -38,9 +38,28 @@ def scalars(n, kind):
     return sc
 
 
+# ambient code-path switches, drawn per iteration before the handle is made (see tools/fuzz_open_rwc.py: round 6)
+AMBIENT = {"ZG_MSM_TWO_PASS_SORT": ["0"], "ZG_MSM_LDS_SORT": ["0"], "ZG_MSM_REDUCE_2D": ["0"], "ZG_MSM_ALONE_FULL": ["0"], "ZG_MSM_BATCH_FUSE": ["0"],
+           "ZG_MSM_SIDE_TABLE": ["0"], "ZG_MSM_FINE_BITS": ["5", "6"], "ZG_MSM_FINE_BITS_MIN": ["7", "8"], "ZG_MSM_HOST_AFFINE": ["0"],
+           "ZG_MSM_ROWCOL_WAVE_FROM": ["0", "1"], "ZG_MSM_LANES": ["1", "2"], "ZG_MSM_CHUNK_SCHED": ["0"], "ZG_MSM_COMBINE_PER_QUAD": ["8"],
+           "ZG_MSM_SLICE_LOCAL_REFS": ["0"]}
+
+
+def draw_ambient():
+    for k in AMBIENT:
+        os.environ.pop(k, None)
+    picked = {}
+    if rng.random() < 0.4:
+        for k in rng.choice(sorted(AMBIENT), size=int(rng.choice([1, 1, 2, 3])), replace=False):
+            picked[str(k)] = str(rng.choice(AMBIENT[str(k)]))
+            os.environ[str(k)] = picked[str(k)]
+    return picked
+
+
 t0 = time.time()
 cases = 0
 while time.time() - t0 < budget:
+    ambient = draw_ambient()
     big = rng.random() < 0.25
     n = int(rng.integers(32768, NMAX)) if big else int(rng.choice([0, 1, 2, 7, 8, 9, 31, 33, 100, 511, 1000, 2048, 4097, 9000, 20000]))
     perm_dup = rng.random() < 0.3
@@ -67,7 +86,7 @@ while time.time() - t0 < budget:
         m = int(rng.integers(0, n - off + 1)) if off or rng.random() < 0.3 else n
         got, ginf = b.msm(sc[:m], off=off, n=m)
         want, winf = ob.msm_g1(xy[off:off + m], None if inf is None else inf[off:off + m], sc[:m])
-        assert ginf == winf and np.array_equal(got, want), ("msm", n, cfg, off, m)
+        assert ginf == winf and np.array_equal(got, want), ("msm", n, cfg, off, m, ambient)
         cases += 1
     if n and rng.random() < 0.5:
         k = int(rng.integers(2, 12))
@@ -76,7 +95,7 @@ while time.time() - t0 < budget:
         outs, infs = b.msm_batch(batches, n=nb)
         for j in range(k):
             want, winf = ob.msm_g1(xy[:nb], None if inf is None else inf[:nb], batches[j])
-            assert infs[j] == winf and np.array_equal(outs[j], want), ("batch", n, cfg, nb, k, j)
+            assert infs[j] == winf and np.array_equal(outs[j], want), ("batch", n, cfg, nb, k, j, ambient)
         cases += k
     b.free()
     # round-2 entry points: the one-process multi-GPU path with a random number of logical shards (peer-copy exchange on this box),

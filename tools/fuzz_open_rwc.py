@@ -30,7 +30,27 @@ def rand_fr(s, n):
     return ob.f_to_mont(ob.FR, U.random_raw256(s, n))
 
 
+# Ambient code-path switches (docs/design/08_switches.md), drawn per iteration BEFORE the handle is made and kept for its lifetime (some are
+# read when the handle is planned, some at every launch). Round 6: a whole-suite run under ZG_MSM_TWO_PASS_SORT=0 found a fused launch set
+# that could not sort; the fuzzers now walk these switches too. Most iterations keep the defaults.
+AMBIENT = {"ZG_MSM_TWO_PASS_SORT": ["0"], "ZG_MSM_LDS_SORT": ["0"], "ZG_MSM_REDUCE_2D": ["0"], "ZG_MSM_ALONE_FULL": ["0"], "ZG_MSM_BATCH_FUSE": ["0"],
+           "ZG_MSM_SIDE_TABLE": ["0"], "ZG_MSM_FINE_BITS": ["5", "6"], "ZG_MSM_FINE_BITS_MIN": ["7", "8"], "ZG_MSM_HOST_AFFINE": ["0"],
+           "ZG_MSM_ROWCOL_WAVE_FROM": ["0", "1"], "ZG_MSM_TABLE_SPAN_MB": ["8", "32"], "ZG_MSM_LANES": ["1", "2"], "ZG_MSM_ROWS_SHARED_TAIL": ["0"]}
+
+
+def draw_ambient():
+    for k in AMBIENT:
+        os.environ.pop(k, None)
+    picked = {}
+    if rnd.random() < 0.4:
+        for k in rnd.sample(sorted(AMBIENT), rnd.choice([1, 1, 2, 3])):
+            picked[k] = rnd.choice(AMBIENT[k])
+            os.environ[k] = picked[k]
+    return picked
+
+
 def one_open(it):
+    ambient = draw_ambient()
     v = rnd.choice([8, 10, 12, 14, 15, 16, 16, 17, 17, 18])
     srs_n = rnd.choice([1 << v, 1 << (v - 1), (1 << (v - 1)) + rnd.randrange(1, 1000), 1 << max(v - 2, 4), min(1 << 18, 1 << (v + 1))])
     srs_n = min(srs_n, 1 << 18)
@@ -55,8 +75,8 @@ def one_open(it):
         else:
             d_ev = lib.DeviceBuffer.from_host(ev)
             q, qi, final = lib.hyperkzg_open_dev(params._dev, d_ev.ptr, 1 << v, pt, zero)
-        assert np.array_equal(final, wfin), ("open final", v, srs_n, nv, os.environ["ZG_HK_FUSE_LONG"])
-        assert np.array_equal(np.asarray(qi, dtype=np.uint8), wqi) and np.array_equal(q, wq), ("open quotients", v, srs_n, nv, os.environ["ZG_HK_FUSE_LONG"])
+        assert np.array_equal(final, wfin), ("open final", v, srs_n, nv, os.environ["ZG_HK_FUSE_LONG"], ambient)
+        assert np.array_equal(np.asarray(qi, dtype=np.uint8), wqi) and np.array_equal(q, wq), ("open quotients", v, srs_n, nv, os.environ["ZG_HK_FUSE_LONG"], ambient)
     finally:
         params.deinit()
 
