@@ -67,3 +67,26 @@ def test_sizes_without_data_are_refused_not_dereferenced():
         has_size = any(a in (ctypes.c_size_t, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint) for a in args)
         if has_ptr and has_size:
             assert out[name] != 0, f"{name}: sizes of 16 with NULL pointers returned ZG_OK"
+
+
+def test_an_allocation_the_device_cannot_hold_is_an_error_code_and_the_library_stays_usable():
+    """400 GB on a 288 GB part: ZG_ERR_NOMEM (after the pool was trimmed and the driver asked once more), promptly, and the next call works"""
+    import time
+
+    import numpy as np
+    from oracle import binding as ob
+    from zolt_amd import lib
+    lib.init(0)
+    keep = [lib.DeviceBuffer(64 << 20) for _ in range(3)]  # something idle in the pool for the trim to return
+    for b in keep:
+        b.free()
+    t0 = time.perf_counter()
+    with pytest.raises(lib.ZgError) as err:
+        lib.DeviceBuffer(400 << 30)
+    assert err.value.code == lib.ERR_NOMEM and time.perf_counter() - t0 < 5.0, (err.value, time.perf_counter() - t0)
+    gm = ob.g1_gen_multiples(2000)
+    sc = ob.f_to_mont(ob.FR, np.random.default_rng(3).integers(0, 1 << 63, size=(2000, 4), dtype=np.uint64))
+    h = lib.Bases.upload(gm)
+    got, want = h.msm(sc), ob.msm_g1(gm, None, sc)
+    h.free()
+    assert got[1] == want[1] and np.array_equal(got[0], want[0])
