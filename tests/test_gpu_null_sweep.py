@@ -90,3 +90,51 @@ def test_an_allocation_the_device_cannot_hold_is_an_error_code_and_the_library_s
     got, want = h.msm(sc), ob.msm_g1(gm, None, sc)
     h.free()
     assert got[1] == want[1] and np.array_equal(got[0], want[0])
+
+
+LIFECYCLE = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+from oracle import binding as ob
+from zolt_amd import api, lib
+n = 3000
+gm = ob.g1_gen_multiples(n)
+sc = ob.f_to_mont(ob.FR, np.random.default_rng(4).integers(0, 1 << 63, size=(n, 4), dtype=np.uint64))
+want = ob.msm_g1(gm, None, sc)
+ev = sc[:1024]
+wrun = ob.run_sumcheck(ev)
+held = None
+for cycle in range(4):
+    lib.init(0)
+    h = lib.Bases.upload(gm)
+    got = h.msm(sc)
+    assert got[1] == want[1] and np.array_equal(got[0], want[0]), cycle
+    r = lib.run_sumcheck(ev)
+    assert r["result"] and np.array_equal(r["final_eval"], wrun[3]), cycle
+    s = lib.SumcheckSession.open(ev)
+    g0, g1 = s.round_sums()
+    w0, w1 = ob.fr_sum_halves(ev)
+    assert np.array_equal(g0, w0) and np.array_equal(g1, w1), cycle
+    if held is not None:  # a handle and a session that outlived a zg_shutdown: still usable, freed by their owners later
+        hg = held[0].msm(sc)
+        assert hg[1] == want[1] and np.array_equal(hg[0], want[0]), ("held handle", cycle)
+        held[1].bind(ev[0])
+        held[1].close()
+        held[0].free()
+        held = None
+    if cycle %% 2 == 0:
+        held = (h, s)  # keep them across the shutdown below
+    else:
+        s.close()
+        h.free()
+    lib.shutdown()
+print("LIFECYCLE OK")
+"""
+
+
+def test_shutdown_and_init_again_with_handles_that_outlive_it():
+    """zg_shutdown / zg_init cycles in one process: the pool's idle blocks, the streams and the pinned buffers go back, what a live handle or
+    session still holds is forgotten (freed by its owner later), and the next cycle computes the same bytes."""
+    res = subprocess.run([sys.executable, "-c", LIFECYCLE % ROOT], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0 and "LIFECYCLE OK" in res.stdout, (res.returncode, res.stdout[-300:], res.stderr[-1200:])
