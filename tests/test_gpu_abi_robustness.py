@@ -1,4 +1,5 @@
-"""The C ABI "returns an error code, never throws" (MSM.compute has no error channel, src/msm/mod.zig:355-372: a shim must be
+"""Robustness of the boundary itself (argument sweeps over every export, an allocation the device cannot hold, shutdown / init cycles).
+The C ABI "returns an error code, never throws" (MSM.compute has no error channel, src/msm/mod.zig:355-372: a shim must be
 able to trust a return code): EVERY exported entry point is called with (a) all-zero arguments — NULL handles and pointers, sizes 0 — and
 (b) NULL handles and pointers with every size / count argument = 16. Neither may crash the process; (b) must be refused (a size says there
 is data, the pointer says there is none) unless the function has no pointer to refuse. Each sweep runs in a child process: a signal there
