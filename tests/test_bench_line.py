@@ -86,6 +86,18 @@ def test_compact_line_two_ranks_and_missing_legs():
     assert prov["provisional"] is True and prov["extra_file"] is None and prov["value"] == line["value"]
 
 
+def test_compact_line_never_outgrows_the_limit_whatever_the_strings():
+    """the last line of defence: long strings in the very keys the line carries are dropped, the numbers stay"""
+    bench, full = _bench_module(), _round5_object()
+    full["config"]["workload"] = "w" * 5000
+    full["cpu_baseline"]["sample"] = "s" * 5000
+    full["roofline"]["kernel"] = "k" * 5000
+    text = bench.compact_line(full)
+    line = json.loads(text)
+    assert len(text) < 4096 and line["value"] > 0 and line["roofline"]["frac"] > 0 and line["cpu_baseline"]["value"] > 0
+    assert "workload" not in line["config"] and line["config"]["points"] == 1 << 20
+
+
 def test_emit_prints_the_compact_line_last_and_writes_the_side_file(tmp_path, monkeypatch, capsys):
     bench, full = _bench_module(), _round5_object()
     monkeypatch.chdir(tmp_path)
