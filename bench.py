@@ -142,6 +142,13 @@ def _get(d, *path):
     return d
 
 
+def _json_default(o):
+    """numpy scalars / arrays that found their way into an object: their Python value (never a TypeError at the very end of a run)"""
+    if hasattr(o, "tolist"):
+        return o.tolist()
+    return str(o)
+
+
 def compact_line(out, extra_file="bench_extra.json"):
     """The line the driver parses: the contract's keys, `config` / `roofline` / `cpu_baseline` reduced to numbers and short names, and the
     north_star's other figures as scalars under `also`. Built from the full object `out` (which goes to `extra_file` unshortened)."""
@@ -194,16 +201,16 @@ def compact_line(out, extra_file="bench_extra.json"):
     line["extra_file"] = extra_file
     if out.get("provisional"):
         line["provisional"] = True  # N > 1 only: printed right after the timed region; the last line of a complete run supersedes it
-    text = json.dumps(line, separators=(",", ":"))
+    text = json.dumps(line, separators=(",", ":"), default=_json_default)
     if len(text) >= COMPACT_LIMIT:  # cannot happen with the fixed key set above; never let a long string take the line down
         line.pop("also")
-        text = json.dumps(line, separators=(",", ":"))
+        text = json.dumps(line, separators=(",", ":"), default=_json_default)
     if len(text) >= COMPACT_LIMIT:  # still too long (a pathological string somewhere): the contract's keys and the two objects' numbers only
         line["config"] = {k: v for k, v in line["config"].items() if not isinstance(v, str) or len(v) <= 40}
         line["roofline"] = {k: v for k, v in line["roofline"].items() if not isinstance(v, str) or len(v) <= 40}
         if "cpu_baseline" in line:
             line["cpu_baseline"] = {k: v for k, v in line["cpu_baseline"].items() if not isinstance(v, str) or len(v) <= 40}
-        text = json.dumps(line, separators=(",", ":"))
+        text = json.dumps(line, separators=(",", ":"), default=_json_default)
     return text
 
 
@@ -213,9 +220,9 @@ def write_side_file(out, name="bench_extra.json"):
     for path in (os.path.join(os.getcwd(), name), os.path.join(ROOT, "profiles", "bench_extra_last.json")):
         try:
             with open(path, "w") as fh:
-                json.dump(out, fh, indent=1)
+                json.dump(out, fh, indent=1, default=_json_default)
             paths.append(path)
-        except OSError:
+        except (OSError, TypeError, ValueError):  # the side file is a convenience: it must never stand between a finished run and its line
             pass
     return paths
 
@@ -223,7 +230,7 @@ def write_side_file(out, name="bench_extra.json"):
 def emit(out, full_line=False):
     """rank 0's last act: side file, then the one line (flushed; nothing is printed after it)"""
     if full_line:
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out, default=_json_default), flush=True)
         return
     write_side_file(out)
     sys.stdout.flush()
