@@ -199,6 +199,9 @@ def compact_line(out, extra_file="bench_extra.json"):
     }
     line["also"] = {k: v for k, v in also.items() if v is not None}
     line["extra_file"] = extra_file
+    errs = {k: str(v)[:120] for k, v in (("extras", ex.get("extras_error")), ("cpu_baseline", out.get("cpu_baseline_error"))) if v}
+    if errs:  # a leg behind the headline failed: the line says so instead of silently lacking a key
+        line["errors"] = errs
     if out.get("provisional"):
         line["provisional"] = True  # N > 1 only: printed right after the timed region; the last line of a complete run supersedes it
     text = json.dumps(line, separators=(",", ":"), default=_json_default)
@@ -796,30 +799,36 @@ def main():
     if sharded_22 is not None:
         out["extra"]["msm_2^22_sharded"] = sharded_22
     if not args.no_extra and world == 1:
-        # the host-buffer entry point (what an unmodified MSM.compute call site pays): scalars cross PCIe every call
-        wd.beat("extras (child processes for 2^22, the table-less plan and the compiled host loops: each restarts the clock with its own limit)", limit=300)
-        h_sc = d_scalars[0].cpu().numpy().view(np.uint64)
-        bases.msm(h_sc)
-        t0 = time.perf_counter()
-        for _ in range(3):
-            hxy, hinf = bases.msm(h_sc)
-        out["extra"]["msm_host_scalars_ms"] = (time.perf_counter() - t0) / 3 * 1e3
-        assert hinf == want[0][1] and np.array_equal(hxy, want[0][0])
-        out["extra"].update(extra_measurements(lib, api, torch, dev, stream, args, bases_xy if args.logn == 20 else None, wd=wd))
-        npc = out["extra"].get("msm_no_precompute", {})
-        if "ms_per_msm" in npc:
-            serial_table = sum(out["extra"]["kernel_ms_per_msm_alone"].values())
-            serial_plain = sum(npc.get("kernel_ms_per_msm_alone", {}).values())
-            gain_p, gain_s = npc["ms_per_msm"] - ms_per_msm, serial_plain - serial_table
-            out["config"]["breakeven_msms"] = {
-                "pipelined": table_build_ms / gain_p if gain_p > 0 else None, "one_at_a_time": table_build_ms / gain_s if gain_s > 0 else None,
-                "table_less_ms_per_msm": {"pipelined": npc["ms_per_msm"], "one_at_a_time_kernels": serial_plain},
-                "table_ms_per_msm": {"pipelined": ms_per_msm, "one_at_a_time_kernels": serial_table},
-                "note": "table_build_ms / (table-less ms per MSM - table ms per MSM); below this many MSMs over one SRS the table-less plan "
-                        "(zg_msm_config.expected_uses = 1) is the faster choice"}
+        try:  # the headline above is measured and checked: nothing behind it may take the line down
+            # the host-buffer entry point (what an unmodified MSM.compute call site pays): scalars cross PCIe every call
+            wd.beat("extras (child processes for 2^22, the table-less plan and the compiled host loops: each restarts the clock with its own limit)", limit=300)
+            h_sc = d_scalars[0].cpu().numpy().view(np.uint64)
+            bases.msm(h_sc)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                hxy, hinf = bases.msm(h_sc)
+            out["extra"]["msm_host_scalars_ms"] = (time.perf_counter() - t0) / 3 * 1e3
+            assert hinf == want[0][1] and np.array_equal(hxy, want[0][0])
+            out["extra"].update(extra_measurements(lib, api, torch, dev, stream, args, bases_xy if args.logn == 20 else None, wd=wd))
+            npc = out["extra"].get("msm_no_precompute", {})
+            if "ms_per_msm" in npc:
+                serial_table = sum(out["extra"]["kernel_ms_per_msm_alone"].values())
+                serial_plain = sum(npc.get("kernel_ms_per_msm_alone", {}).values())
+                gain_p, gain_s = npc["ms_per_msm"] - ms_per_msm, serial_plain - serial_table
+                out["config"]["breakeven_msms"] = {
+                    "pipelined": table_build_ms / gain_p if gain_p > 0 else None, "one_at_a_time": table_build_ms / gain_s if gain_s > 0 else None,
+                    "table_less_ms_per_msm": {"pipelined": npc["ms_per_msm"], "one_at_a_time_kernels": serial_plain},
+                    "table_ms_per_msm": {"pipelined": ms_per_msm, "one_at_a_time_kernels": serial_table},
+                    "note": "table_build_ms / (table-less ms per MSM - table ms per MSM); below this many MSMs over one SRS the table-less plan "
+                            "(zg_msm_config.expected_uses = 1) is the faster choice"}
+        except Exception as exc:  # noqa: BLE001
+            out["extra"]["extras_error"] = repr(exc)[:300]
     if not args.no_cpu_baseline and world == 1:
         wd.beat("cpu baseline", limit=600)
-        out["cpu_baseline"] = cpu_baseline(bases_xy, d_scalars[0].cpu().numpy().view(np.uint64), want[0], args.logn)
+        try:
+            out["cpu_baseline"] = cpu_baseline(bases_xy, d_scalars[0].cpu().numpy().view(np.uint64), want[0], args.logn)
+        except Exception as exc:  # noqa: BLE001  (a line without cpu_baseline is still a measured headline; the error says why it is missing)
+            out["cpu_baseline_error"] = repr(exc)[:300]
     if use_dist:
         dist.destroy_process_group()
     emit(out, full_line=args.full_line)  # the LAST thing this process prints
